@@ -1,0 +1,121 @@
+/* raven_hip.h — C ABI of the MI355X-native overlap engine for Raven (libraven_hip.so).
+ *
+ * Drop-in boundary: the entry points below are what a binding for Raven's overlap hot
+ * path would bind instead of the un-vendored ram::MinimizerEngine; each cites the reference interface
+ * it replaces (paths relative to the lbcb-sci/raven tree).  Plain pointers and sizes only.
+ *
+ * Conventions
+ *   - every function returning int returns RVN_OK (0) or a negative RVN_E* code; rvn_last_error()
+ *     gives the thread-local message.  The C++ facade (include/ram/minimizer_engine.hpp) rethrows
+ *     RVN_EINVAL as std::invalid_argument, matching ram/biosoup behaviour.
+ *   - reads are handed over in biosoup::NucleicAcid layout: 2 bits per base, 32 bases per uint64_t,
+ *     base i at bits (2i mod 64) of word i/32, A=0 C=1 G=2 T=3; every read starts on a word boundary
+ *     (i.e. the concatenation of each read's `deflated_data`); `word_offsets` has n+1 entries.
+ *   - rvn_overlap == biosoup::Overlap without the alignment string (8 x uint32_t).
+ *   - the library fails loudly (RVN_ENODEVICE) when no HIP device is present; there is no CPU path.
+ */
+#ifndef RAVEN_HIP_H_
+#define RAVEN_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RVN_OK 0
+#define RVN_EINVAL (-1)    /* invalid argument (ram: std::invalid_argument) */
+#define RVN_ENODEVICE (-2) /* no usable HIP device */
+#define RVN_EHIP (-3)      /* HIP runtime / kernel failure */
+#define RVN_ENOMEM (-4)
+
+typedef struct rvn_engine rvn_engine; /* one per (device, k, w): replaces ram::MinimizerEngine */
+typedef struct rvn_reads rvn_reads;   /* device-resident packed read set */
+typedef struct rvn_pass1 rvn_pass1;   /* result of FindOverlapsAndCreatePiles, resident in HBM */
+
+typedef struct rvn_overlap {
+  uint32_t lhs_id, lhs_begin, lhs_end;
+  uint32_t rhs_id, rhs_begin, rhs_end;
+  uint32_t score;
+  uint32_t strand;
+} rvn_overlap;
+
+const char* rvn_last_error(void);
+int rvn_device_count(void);
+
+/* ram::MinimizerEngine{thread_pool, k, w[, bandwidth=500, chain=4, matches=100, gap=10000]}
+ * (RavenLib/src/construct.cc:661-662, RavenLib/src/assemble.cc:753).  k is clamped to [1,31] as in ram. */
+int rvn_engine_create(rvn_engine** out, uint32_t k, uint32_t w, uint32_t bandwidth, uint32_t chain,
+                      uint32_t matches, uint32_t gap, int device);
+void rvn_engine_destroy(rvn_engine* e);
+
+/* Copies the packed reads to HBM once; they stay resident for any number of calls
+ * (the reference keeps std::vector<std::unique_ptr<biosoup::NucleicAcid>> in RAM, RavenExe/src/main.cc:258-299). */
+int rvn_reads_upload(rvn_engine* e, const uint64_t* packed, uint64_t n_words, const uint64_t* word_offsets,
+                     const uint32_t* lengths, const uint32_t* ids, uint32_t n_reads, rvn_reads** out);
+void rvn_reads_destroy(rvn_reads* r);
+
+/* ram::MinimizerEngine::Minimize(first, last, minhash) — builds the index (construct.cc:42-43, :363). */
+int rvn_engine_minimize(rvn_engine* e, const rvn_reads* r, uint32_t first, uint32_t last, int minhash);
+/* ram::MinimizerEngine::Filter(frequency) (construct.cc:44, :372); RVN_EINVAL unless 0 <= f <= 1. */
+int rvn_engine_filter(rvn_engine* e, double frequency);
+uint32_t rvn_engine_occurrence(const rvn_engine* e);
+
+/* Batched ram::MinimizerEngine::Map(sequence, avoid_equal, avoid_symmetric, minhash[, filtered])
+ * for reads [first, last) (construct.cc:59-64 / :377-381).  Results stay on the device until fetched;
+ * overlaps come back in (read, Map-output) order with per-read offsets (last-first+1 entries). */
+int rvn_engine_map_batch(rvn_engine* e, const rvn_reads* r, uint32_t first, uint32_t last, int avoid_equal,
+                         int avoid_symmetric, int minhash, int want_filtered, uint64_t* n_overlaps);
+int rvn_engine_map_fetch(rvn_engine* e, rvn_overlap* overlaps, uint32_t* read_offsets);
+/* positions of query minimizers skipped by the occurrence filter (`filtered` argument of Map),
+ * per read: offsets (last-first+1) into `positions`.  Pass positions == NULL to query the total. */
+int rvn_engine_map_fetch_filtered(rvn_engine* e, uint32_t* positions, uint32_t* read_offsets, uint64_t* total);
+
+/* raven::FindOverlapsAndCreatePiles (RavenLib/src/construct.cc:14-121; decl construct.h:22-29):
+ * index batches of `index_batch_bases` (reference: 1<<32), query flushes of `flush_bases` (reference:
+ * 1<<30), merge, Pile::AddLayers (pile.cc:33-62) and the top-kMax truncation, all on the device.
+ * Requires ids[i] == i (the reference's own invariant, construct.cc:25,74-75). */
+int rvn_find_overlaps_and_create_piles(rvn_engine* e, const rvn_reads* r, double freq, uint32_t k_max_overlaps,
+                                       int use_minhash, uint64_t index_batch_bases, uint64_t flush_bases,
+                                       rvn_pass1** out);
+uint64_t rvn_pass1_pile_words(const rvn_pass1* p);   /* sum over reads of (len >> 4) */
+uint64_t rvn_pass1_num_overlaps(const rvn_pass1* p); /* sum of per-pile list sizes */
+/* pile coverage: uint16 data of all piles concatenated + offsets[n+1] (Pile::data_, pile.h:133) */
+int rvn_pass1_fetch_piles(const rvn_pass1* p, uint16_t* data, uint64_t* offsets);
+/* overlaps[i] of construct.cc:666, concatenated + offsets[n+1] */
+int rvn_pass1_fetch_overlaps(const rvn_pass1* p, rvn_overlap* overlaps, uint32_t* offsets);
+void rvn_pass1_destroy(rvn_pass1* p);
+
+/* raven::Pile::AddLayers on one pile (RavenLib/src/pile.cc:33-62): `data` (cells = len >> 4) is updated
+ * in place with the coverage of `n` overlaps touching pile `id`. */
+int rvn_pile_add_layers(rvn_engine* e, uint16_t* data, uint32_t cells, uint32_t id, const rvn_overlap* overlaps,
+                        uint64_t n);
+
+/* ---- introspection used by the parity tests and bench.py ------------------------------------- */
+/* sketch of reads [first,last) == ram Minimize(sequence, minhash) per read; values widened to u64 */
+int rvn_engine_sketch(rvn_engine* e, const rvn_reads* r, uint32_t first, uint32_t last, int minhash,
+                      uint64_t* count);
+int rvn_engine_sketch_fetch(rvn_engine* e, uint64_t* values, uint64_t* origins, uint32_t* read_offsets);
+/* sorted index content: (value, origin) pairs in index order; count = minimizers in the index */
+int rvn_engine_index_size(const rvn_engine* e, uint64_t* n_minimizers, uint64_t* n_keys);
+int rvn_engine_index_fetch(rvn_engine* e, uint64_t* values, uint64_t* origins);
+/* counters since the last reset: {index_bases, index_minimizers, index_keys, query_bases,
+ * query_minimizers, matches, overlaps(Map outputs), intervals} */
+int rvn_engine_counters(const rvn_engine* e, uint64_t out[8]);
+/* accumulated device milliseconds per stage (HIP events on the engine's stream) and launch counts */
+int rvn_engine_num_stages(void);
+const char* rvn_engine_stage_name(int stage);
+int rvn_engine_stage_ms(const rvn_engine* e, double* ms, uint64_t* launches, int n);
+void rvn_engine_reset_stats(rvn_engine* e);
+void rvn_engine_set_timing(rvn_engine* e, int enabled);
+
+/* host-side test hooks for the __host__ __device__ building blocks (no GPU needed) */
+uint64_t rvn_test_hash(uint64_t key, uint32_t k, int use32);
+int rvn_test_canonical(const uint64_t* words, uint32_t pos, uint32_t k, int use32, uint64_t* value, uint32_t* strand);
+void rvn_test_std_sort_lendesc(uint64_t* data, uint64_t n);
+void rvn_test_heap_sort_lendesc(uint64_t* data, uint64_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RAVEN_HIP_H_ */

@@ -1,0 +1,196 @@
+"""ctypes binding of the CPU oracle (oracle/raven_oracle.cpp).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg.  The product package `raven_amd` never imports it.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libraven_oracle.so")
+
+OVERLAP_DTYPE = np.dtype([
+    ("lhs_id", "<u4"), ("lhs_begin", "<u4"), ("lhs_end", "<u4"),
+    ("rhs_id", "<u4"), ("rhs_begin", "<u4"), ("rhs_end", "<u4"),
+    ("score", "<u4"), ("strand", "<u4")])
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(_HERE, "raven_oracle.cpp")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        L = C.CDLL(_LIB_PATH)
+        vp, u32, u64, i32, dbl = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int, C.c_double
+        L.orc_engine_create.restype = vp
+        L.orc_engine_create.argtypes = [u32] * 6
+        L.orc_engine_destroy.argtypes = [vp]
+        L.orc_sketch.restype = u64
+        L.orc_sketch.argtypes = [vp, vp, u32, u32, i32, vp, vp, u64]
+        L.orc_engine_minimize.argtypes = [vp, vp, vp, vp, vp, u32, u32, i32, C.c_uint]
+        L.orc_engine_filter.restype = i32
+        L.orc_engine_filter.argtypes = [vp, dbl]
+        L.orc_engine_occurrence.restype = u32
+        L.orc_engine_occurrence.argtypes = [vp]
+        L.orc_engine_find.restype = u32
+        L.orc_engine_find.argtypes = [vp, u64, vp, u32]
+        L.orc_engine_map.restype = u64
+        L.orc_engine_map.argtypes = [vp, vp, u32, u32, i32, i32, i32, vp, u64, vp, u64, vp, vp, vp, u64, vp]
+        L.orc_engine_counters.argtypes = [vp, vp]
+        L.orc_chain.restype = u64
+        L.orc_chain.argtypes = [vp, u32, vp, vp, u64, vp, u64]
+        L.orc_pile_add_layers.argtypes = [vp, u32, vp, u64]
+        L.orc_truncate.restype = u64
+        L.orc_truncate.argtypes = [vp, u64, u64]
+        L.orc_find_overlaps_and_create_piles.restype = vp
+        L.orc_find_overlaps_and_create_piles.argtypes = [vp, vp, vp, vp, vp, u32, dbl, u64, i32, u64, u64, C.c_uint]
+        L.orc_pass1_destroy.argtypes = [vp]
+        for name, rt in (("pile_words", u64), ("pile_data", vp), ("pile_offsets", vp), ("num_overlaps", u64),
+                         ("overlaps", vp), ("overlap_offsets", vp), ("occurrence", u32), ("t_minimize", dbl),
+                         ("t_map", dbl)):
+            fn = getattr(L, "orc_pass1_" + name)
+            fn.restype = rt
+            fn.argtypes = [vp]
+        L.orc_edit_distance.restype = u32
+        L.orc_edit_distance.argtypes = [C.c_char_p, u32, C.c_char_p, u32]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _copy(ptr, n, dtype):
+    if n == 0:
+        return np.zeros(0, dtype=dtype)
+    buf = (C.c_char * (n * np.dtype(dtype).itemsize)).from_address(ptr)
+    return np.frombuffer(buf, dtype=dtype).copy()
+
+
+class Engine:
+    """ram::MinimizerEngine restatement (defaults as in ram: bandwidth 500, chain 4, matches 100, gap 10000)."""
+
+    def __init__(self, k=15, w=5, bandwidth=500, chain=4, matches=100, gap=10000):
+        self.k, self.w = k, w
+        self._h = lib().orc_engine_create(k, w, bandwidth, chain, matches, gap)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_engine_destroy(self._h)
+            self._h = None
+
+    def sketch(self, rs, i, minhash=False):
+        L = int(rs.lengths[i])
+        cap = L + 1
+        v = np.zeros(cap, dtype=np.uint64)
+        o = np.zeros(cap, dtype=np.uint64)
+        words = rs.packed[int(rs.word_offsets[i]):]
+        n = lib().orc_sketch(self._h, _p(words), L, int(rs.ids[i]), int(minhash), _p(v), _p(o), cap)
+        return v[:n].copy(), o[:n].copy()
+
+    def minimize(self, rs, first=0, last=None, minhash=False, threads=1):
+        last = rs.n if last is None else last
+        lib().orc_engine_minimize(self._h, _p(rs.packed), _p(rs.word_offsets), _p(rs.lengths), _p(rs.ids),
+                                  first, last, int(minhash), threads)
+
+    def filter(self, f):
+        if lib().orc_engine_filter(self._h, float(f)) != 0:
+            raise ValueError("[ram::MinimizerEngine::Filter] error: invalid frequency")
+
+    @property
+    def occurrence(self):
+        return int(lib().orc_engine_occurrence(self._h))
+
+    def find(self, value, cap=1 << 16):
+        o = np.zeros(cap, dtype=np.uint64)
+        n = lib().orc_engine_find(self._h, int(value), _p(o), cap)
+        return o[:min(n, cap)].copy(), n
+
+    def map(self, rs, i, avoid_equal=True, avoid_symmetric=True, minhash=False, want_matches=False):
+        L = int(rs.lengths[i])
+        cap = 4096
+        out = np.zeros(cap, dtype=OVERLAP_DTYPE)
+        filt = np.zeros(L + 1, dtype=np.uint32)
+        nf = C.c_uint64(0)
+        nm = C.c_uint64(0)
+        mcap = 1 << 22 if want_matches else 0
+        mg = np.zeros(max(mcap, 1), dtype=np.uint64)
+        mp = np.zeros(max(mcap, 1), dtype=np.uint64)
+        words = rs.packed[int(rs.word_offsets[i]):]
+        n = lib().orc_engine_map(self._h, _p(words), L, int(rs.ids[i]), int(avoid_equal), int(avoid_symmetric),
+                                 int(minhash), _p(out), cap, _p(filt), L + 1, C.byref(nf),
+                                 _p(mg) if want_matches else None, _p(mp) if want_matches else None, mcap,
+                                 C.byref(nm))
+        assert n <= cap
+        res = dict(overlaps=out[:n].copy(), filtered=filt[:nf.value].copy(), n_matches=nm.value)
+        if want_matches:
+            assert nm.value <= mcap
+            res["match_groups"] = mg[:nm.value].copy()
+            res["match_positions"] = mp[:nm.value].copy()
+        return res
+
+    def counters(self):
+        c = np.zeros(7, dtype=np.uint64)
+        lib().orc_engine_counters(self._h, _p(c))
+        return dict(zip(("index_bases", "index_minimizers", "index_keys", "query_bases", "query_minimizers",
+                         "matches", "overlaps"), (int(x) for x in c)))
+
+    def chain(self, lhs_id, groups, positions):
+        groups = np.ascontiguousarray(groups, dtype=np.uint64)
+        positions = np.ascontiguousarray(positions, dtype=np.uint64)
+        cap = max(16, groups.shape[0])
+        out = np.zeros(cap, dtype=OVERLAP_DTYPE)
+        n = lib().orc_chain(self._h, lhs_id, _p(groups), _p(positions), groups.shape[0], _p(out), cap)
+        return out[:n].copy()
+
+    def find_overlaps_and_create_piles(self, rs, freq=0.001, kmax=32, use_minhash=False,
+                                       index_batch_bases=1 << 32, flush_bases=1 << 30, threads=1):
+        h = lib().orc_find_overlaps_and_create_piles(self._h, _p(rs.packed), _p(rs.word_offsets), _p(rs.lengths),
+                                                     _p(rs.ids), rs.n, float(freq), kmax, int(use_minhash),
+                                                     index_batch_bases, flush_bases, threads)
+        L = lib()
+        try:
+            res = dict(
+                pile_offsets=_copy(L.orc_pass1_pile_offsets(h), rs.n + 1, np.uint64),
+                pile_data=_copy(L.orc_pass1_pile_data(h), L.orc_pass1_pile_words(h), np.uint16),
+                overlap_offsets=_copy(L.orc_pass1_overlap_offsets(h), rs.n + 1, np.uint64),
+                overlaps=_copy(L.orc_pass1_overlaps(h), L.orc_pass1_num_overlaps(h), OVERLAP_DTYPE),
+                occurrence=int(L.orc_pass1_occurrence(h)),
+                t_minimize=float(L.orc_pass1_t_minimize(h)),
+                t_map=float(L.orc_pass1_t_map(h)),
+                counters=self.counters())
+        finally:
+            L.orc_pass1_destroy(h)
+        return res
+
+
+def pile_add_layers(data: np.ndarray, pile_id: int, overlaps: np.ndarray) -> None:
+    assert data.dtype == np.uint16 and overlaps.dtype == OVERLAP_DTYPE
+    overlaps = np.ascontiguousarray(overlaps)
+    lib().orc_pile_add_layers(_p(data), pile_id, _p(overlaps), overlaps.shape[0])
+
+
+def truncate(overlaps: np.ndarray, kmax: int) -> np.ndarray:
+    o = np.ascontiguousarray(overlaps).copy()
+    n = lib().orc_truncate(_p(o), o.shape[0], kmax)
+    return o[:n]
+
+
+def edit_distance(a: bytes, b: bytes) -> int:
+    return int(lib().orc_edit_distance(a, len(a), b, len(b)))

@@ -1,0 +1,86 @@
+// common.h — host-side plumbing shared by the HIP translation units.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <stdexcept>
+#include <string>
+
+namespace rvn {
+
+using u8 = std::uint8_t;
+using u16 = std::uint16_t;
+using u32 = std::uint32_t;
+using u64 = std::uint64_t;
+using i32 = std::int32_t;
+
+struct HipError : std::runtime_error {
+  using std::runtime_error::runtime_error;
+};
+
+#define RVN_HIP(expr)                                                                            \
+  do {                                                                                           \
+    hipError_t _e = (expr);                                                                      \
+    if (_e != hipSuccess) {                                                                      \
+      throw ::rvn::HipError(std::string("[raven_hip] HIP error: ") + hipGetErrorString(_e) +    \
+                            " at " __FILE__ ":" + std::to_string(__LINE__) + " (" #expr ")");    \
+    }                                                                                            \
+  } while (0)
+
+#define RVN_LAUNCH_CHECK() RVN_HIP(hipGetLastError())
+
+// Growable device buffer; capacity only grows, so steady-state iterations do
+// not touch the allocator.
+struct DevBuf {
+  void* ptr = nullptr;
+  size_t cap = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  ~DevBuf() {
+    if (ptr) (void)hipFree(ptr);
+  }
+  void reserve(size_t bytes) {
+    if (bytes <= cap) return;
+    if (ptr) RVN_HIP(hipFree(ptr));
+    ptr = nullptr;
+    cap = 0;
+    size_t want = bytes + bytes / 8 + 256;
+    RVN_HIP(hipMalloc(&ptr, want));
+    cap = want;
+  }
+  template <typename T>
+  T* as() const {
+    return reinterpret_cast<T*>(ptr);
+  }
+  template <typename T>
+  T* get(size_t count) {
+    reserve(count * sizeof(T));
+    return reinterpret_cast<T*>(ptr);
+  }
+};
+
+// 8 x u32 overlap record == biosoup::Overlap minus the alignment string.
+struct Overlap {
+  u32 lhs_id, lhs_begin, lhs_end, rhs_id, rhs_begin, rhs_end, score, strand;
+};
+
+static inline u32 div_up(u64 a, u64 b) { return static_cast<u32>((a + b - 1) / b); }
+
+// ---- device-wide primitives (scan.hip / radix_sort.hip) ----------------------
+
+// out[0..n] = exclusive prefix sums of in[0..n-1] (out[n] = total). `tmp` is scratch.
+void exclusive_scan_u32_u64(const u32* in, u64* out, u64 n, DevBuf& tmp, hipStream_t s);
+void exclusive_scan_u32_u32(const u32* in, u32* out, u64 n, DevBuf& tmp, hipStream_t s);
+void exclusive_scan_u8_u32(const u8* in, u32* out, u64 n, DevBuf& tmp, hipStream_t s);
+
+// Stable LSD radix sort of (key, value) pairs on key bits [0, key_bits).
+// Ping-pongs between (k0,v0) and (k1,v1); returns 0 if the sorted data ends in
+// (k0,v0), 1 if in (k1,v1).
+int radix_sort_pairs_u32_u64(u32* k0, u32* k1, u64* v0, u64* v1, u64 n, int key_bits, DevBuf& tmp, DevBuf& tmp2, hipStream_t s);
+int radix_sort_pairs_u64_u64(u64* k0, u64* k1, u64* v0, u64* v1, u64 n, int key_bits, DevBuf& tmp, DevBuf& tmp2, hipStream_t s);
+int radix_sort_pairs_u32_u32(u32* k0, u32* k1, u32* v0, u32* v1, u64 n, int key_bits, DevBuf& tmp, DevBuf& tmp2, hipStream_t s);
+
+}  // namespace rvn

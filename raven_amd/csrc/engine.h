@@ -1,0 +1,142 @@
+// engine.h — internal structures of the MI355X overlap engine (not part of the public C ABI).
+#pragma once
+
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+namespace rvn {
+
+constexpr int kSketchTile = 1024;  // k-mer positions per sketch workgroup
+constexpr int kMaxWindow = 256;    // largest supported winnowing window w
+
+// Device-resident read set: concatenated 2-bit packed words (every read starts on a word
+// boundary, one pad word at the end), per-read word offsets / lengths / ids.
+struct ReadsDev {
+  u32 n = 0;
+  u64 total_bases = 0;
+  u64 n_words = 0;
+  DevBuf packed;    // u64[n_words + 1]
+  DevBuf word_off;  // u64[n + 1]
+  DevBuf len;       // u32[n]
+  DevBuf id;        // u32[n]
+  std::vector<u64> h_word_off;
+  std::vector<u32> h_len, h_id;
+  // sketch tiles for the owning engine's (k, w)
+  u32 n_tiles = 0;
+  DevBuf tile_read;      // u32[n_tiles]  read index of the tile
+  DevBuf tile_start;     // u32[n_tiles]  first k-mer position of the tile
+  DevBuf read_tile_off;  // u32[n + 1]
+  std::vector<u32> h_read_tile_off;
+};
+
+// Sketch of a read range: minimizers in (read, position) order.
+struct Sketch {
+  u32 first = 0, last = 0;
+  u64 count = 0;
+  DevBuf val;       // V[count]   (u32 when 2k < 32, else u64)
+  DevBuf org;       // u64[count] id << 32 | pos << 1 | strand
+  DevBuf read_off;  // u32[last - first + 1]
+};
+
+struct Index {
+  u64 m = 0;  // minimizers in the index
+  u64 u = 0;  // distinct keys
+  int table_bits = 0;
+  int shift = 0;
+  DevBuf s_val[2];  // sorted values (ping-pong)
+  DevBuf s_org[2];  // sorted origins
+  int cur = 0;
+  DevBuf u_val;    // V[u]
+  DevBuf u_start;  // u32[u + 1]
+  DevBuf table;    // u32[2^table_bits + 1]
+  u32 occurrence = 0xFFFFFFFFu;
+};
+
+struct MapOut {
+  u32 first = 0, last = 0;
+  u64 n_query = 0;    // M_q
+  u64 n_matches = 0;  // H
+  u64 n_intervals = 0;
+  u64 n_overlaps = 0;  // O
+  DevBuf ovl;          // Overlap[n_overlaps] in (query read, emission) order
+  DevBuf ovl_read_off; // u32[last - first + 1]
+  DevBuf filtered;     // u8[n_query] (1 = skipped by the occurrence filter); valid when requested
+};
+
+struct StageTimes {
+  // accumulated device milliseconds per stage (HIP events on the engine stream)
+  enum { kSketch, kSort, kIndex, kFilter, kQuery, kMatch, kSegSort, kIntervals, kChain, kCompact, kMerge, kPile,
+         kTruncate, kNum };
+  double ms[kNum] = {};
+  u64 launches[kNum] = {};
+};
+
+struct Engine {
+  u32 k, w, bandwidth, chain, matches, gap;
+  int device = 0;
+  bool val64 = false;  // true when minimizer values need 64 bits
+  hipStream_t stream = nullptr;
+  Index index;
+  Sketch index_sketch, query_sketch;
+  MapOut map_out;
+  // scratch
+  DevBuf tmp_a, tmp_b, tmp_c, tmp_d, tmp_e, tmp_f, scan_tmp, sort_tmp;
+  DevBuf raw_val, raw_org, raw_read_off;
+  DevBuf q_start, q_cnt, m_off;
+  DevBuf m_grp[2], m_pos[2];
+  DevBuf seg_off, iv_slot_begin, iv_slot_end, iv_cnt, iv_off, iv_begin, iv_end;
+  DevBuf lis_min, lis_pred, ovl_slots, ovl_flags, ovl_scan;
+  StageTimes times;
+  // counters for algorithmic bytes
+  u64 c_index_bases = 0, c_index_min = 0, c_index_keys = 0, c_query_bases = 0, c_query_min = 0, c_matches = 0,
+      c_overlaps = 0;
+  u64 c_intervals = 0;
+  bool timing = true;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+// Stage timing helper: records HIP events on the engine stream around a stage.
+struct StageTimer {
+  Engine& e;
+  int stage;
+  StageTimer(Engine& eng, int st) : e(eng), stage(st) {
+    if (e.timing) RVN_HIP(hipEventRecord(e.ev0, e.stream));
+  }
+  void stop() {
+    if (!e.timing) return;
+    RVN_HIP(hipEventRecord(e.ev1, e.stream));
+    RVN_HIP(hipEventSynchronize(e.ev1));
+    float ms = 0;
+    RVN_HIP(hipEventElapsedTime(&ms, e.ev0, e.ev1));
+    e.times.ms[stage] += ms;
+    e.times.launches[stage] += 1;
+  }
+};
+
+// ---- stages (one translation unit each) -------------------------------------
+void reads_build_tiles(Engine& e, ReadsDev& r);
+void sketch_range(Engine& e, const ReadsDev& r, u32 first, u32 last, bool minhash, Sketch& out);
+void index_build(Engine& e, Sketch& sk);                 // consumes sk.val/sk.org
+void index_filter(Engine& e, double freq);               // sets e.index.occurrence
+void map_batch(Engine& e, const ReadsDev& r, u32 first, u32 last, bool avoid_equal, bool avoid_symmetric,
+               bool minhash, bool want_filtered, MapOut& out);
+
+// Pass-1 state: per-pile kept overlaps + coverage (pile.hip)
+struct PileState {
+  u32 n = 0;
+  DevBuf pile_off;   // u64[n + 1] in u16 units
+  DevBuf pile_data;  // u16[total]
+  u64 pile_words = 0;
+  DevBuf kept_off;   // u32[n + 1]
+  DevBuf kept;       // Overlap[kept_total]
+  u64 kept_total = 0;
+  DevBuf new_off, new_list, tmp1, tmp2, tmp3, tmp4, tmp5, tmp6;
+};
+void piles_init(Engine& e, const ReadsDev& r, PileState& ps);
+void piles_merge(Engine& e, const ReadsDev& r, const MapOut& mo, u32 kmax, PileState& ps);
+// Pile::AddLayers on a single pile (ps initialised for one read); h_ovl is a host array
+void pile_add_layers_single(Engine& e, PileState& ps, const u32* d_ids, const Overlap* h_ovl, u32 n);
+
+}  // namespace rvn

@@ -1,0 +1,463 @@
+// engine.hip — host orchestration + the C ABI declared in include/raven_hip.h.
+#include "engine.h"
+
+#include <cstring>
+#include <memory>
+#include <new>
+
+#include "../../include/raven_hip.h"
+#include "introsort.h"
+#include "kmer.h"
+
+using namespace rvn;
+
+static_assert(sizeof(rvn_overlap) == sizeof(rvn::Overlap), "overlap layout");
+
+struct rvn_engine {
+  Engine e;
+};
+struct rvn_reads {
+  ReadsDev r;
+};
+struct rvn_pass1 {
+  Engine* e = nullptr;
+  PileState ps;
+};
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+
+template <typename F>
+int guarded(F f) {
+  try {
+    return f();
+  } catch (const HipError& ex) {
+    return fail(RVN_EHIP, ex.what());
+  } catch (const std::bad_alloc&) {
+    return fail(RVN_ENOMEM, "[raven_hip] out of host memory");
+  } catch (const std::invalid_argument& ex) {
+    return fail(RVN_EINVAL, ex.what());
+  } catch (const std::exception& ex) {
+    return fail(RVN_EHIP, ex.what());
+  }
+}
+
+const char* kStageNames[StageTimes::kNum] = {"sketch", "sort", "index", "filter", "query_sketch", "match",
+                                             "seg_sort", "intervals", "chain", "compact", "merge", "pile",
+                                             "truncate"};
+
+void do_minimize(Engine& e, const ReadsDev& r, u32 first, u32 last, bool minhash) {
+  {
+    StageTimer t(e, StageTimes::kSketch);
+    sketch_range(e, r, first, last, minhash, e.index_sketch);
+    t.stop();
+  }
+  for (u32 i = first; i < last; ++i) e.c_index_bases += r.h_len[i];
+  e.c_index_min += e.index_sketch.count;
+  index_build(e, e.index_sketch);
+  e.c_index_keys += e.index.u;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* rvn_last_error(void) { return g_err.c_str(); }
+
+int rvn_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int rvn_engine_create(rvn_engine** out, uint32_t k, uint32_t w, uint32_t bandwidth, uint32_t chain, uint32_t matches,
+                      uint32_t gap, int device) {
+  return guarded([&]() -> int {
+    if (!out) return fail(RVN_EINVAL, "[raven_hip] rvn_engine_create: out == NULL");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n == 0)
+      return fail(RVN_ENODEVICE, "[raven_hip] no HIP device available (this library has no CPU path)");
+    if (device < 0 || device >= n) return fail(RVN_EINVAL, "[raven_hip] invalid device ordinal");
+    if (w == 0 || w > static_cast<uint32_t>(kMaxWindow))
+      return fail(RVN_EINVAL, "[raven_hip] window length must be in [1, 256]");
+    if (chain == 0) return fail(RVN_EINVAL, "[raven_hip] chain must be >= 1");
+    RVN_HIP(hipSetDevice(device));
+    std::unique_ptr<rvn_engine> h(new rvn_engine());
+    Engine& e = h->e;
+    e.k = std::min(std::max(k, 1u), 31u);  // as ram's constructor
+    e.w = w;
+    e.bandwidth = bandwidth;
+    e.chain = chain;
+    e.matches = matches;
+    e.gap = gap;
+    e.device = device;
+    e.val64 = 2 * e.k >= 32;
+    RVN_HIP(hipStreamCreateWithFlags(&e.stream, hipStreamNonBlocking));
+    RVN_HIP(hipEventCreate(&e.ev0));
+    RVN_HIP(hipEventCreate(&e.ev1));
+    *out = h.release();
+    return RVN_OK;
+  });
+}
+
+void rvn_engine_destroy(rvn_engine* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->e.device);
+  if (h->e.stream) (void)hipStreamSynchronize(h->e.stream);
+  if (h->e.ev0) (void)hipEventDestroy(h->e.ev0);
+  if (h->e.ev1) (void)hipEventDestroy(h->e.ev1);
+  if (h->e.stream) (void)hipStreamDestroy(h->e.stream);
+  delete h;
+}
+
+int rvn_reads_upload(rvn_engine* h, const uint64_t* packed, uint64_t n_words, const uint64_t* word_offsets,
+                     const uint32_t* lengths, const uint32_t* ids, uint32_t n, rvn_reads** out) {
+  return guarded([&]() -> int {
+    if (!h || !out || (n && (!packed || !word_offsets || !lengths)))
+      return fail(RVN_EINVAL, "[raven_hip] rvn_reads_upload: NULL argument");
+    Engine& e = h->e;
+    RVN_HIP(hipSetDevice(e.device));
+    std::unique_ptr<rvn_reads> rr(new rvn_reads());
+    ReadsDev& r = rr->r;
+    r.n = n;
+    r.h_word_off.assign(word_offsets, word_offsets + n + 1);
+    r.h_len.assign(lengths, lengths + n);
+    r.h_id.resize(n);
+    for (u32 i = 0; i < n; ++i) r.h_id[i] = ids ? ids[i] : i;
+    r.total_bases = 0;
+    for (u32 i = 0; i < n; ++i) {
+      r.total_bases += lengths[i];
+      const u64 need = (static_cast<u64>(lengths[i]) + 31) / 32;
+      if (word_offsets[i + 1] < word_offsets[i] || word_offsets[i + 1] - word_offsets[i] < need ||
+          word_offsets[i + 1] > n_words)
+        return fail(RVN_EINVAL, "[raven_hip] rvn_reads_upload: word_offsets inconsistent with lengths");
+    }
+    r.n_words = n_words;
+    u64* d_packed = r.packed.get<u64>(n_words + 2);
+    if (n_words) RVN_HIP(hipMemcpy(d_packed, packed, n_words * 8, hipMemcpyHostToDevice));
+    RVN_HIP(hipMemset(d_packed + n_words, 0, 16));  // pad words: kernels may read one word past a read
+    u64* d_wo = r.word_off.get<u64>(static_cast<size_t>(n) + 1);
+    RVN_HIP(hipMemcpy(d_wo, r.h_word_off.data(), (static_cast<size_t>(n) + 1) * 8, hipMemcpyHostToDevice));
+    u32* d_len = r.len.get<u32>(static_cast<size_t>(n) + 1);
+    u32* d_id = r.id.get<u32>(static_cast<size_t>(n) + 1);
+    if (n) {
+      RVN_HIP(hipMemcpy(d_len, r.h_len.data(), static_cast<size_t>(n) * 4, hipMemcpyHostToDevice));
+      RVN_HIP(hipMemcpy(d_id, r.h_id.data(), static_cast<size_t>(n) * 4, hipMemcpyHostToDevice));
+    }
+    reads_build_tiles(e, r);
+    *out = rr.release();
+    return RVN_OK;
+  });
+}
+
+void rvn_reads_destroy(rvn_reads* r) { delete r; }
+
+int rvn_engine_minimize(rvn_engine* h, const rvn_reads* r, uint32_t first, uint32_t last, int minhash) {
+  return guarded([&]() -> int {
+    if (!h || !r || first > last || last > r->r.n) return fail(RVN_EINVAL, "[raven_hip] rvn_engine_minimize: bad range");
+    RVN_HIP(hipSetDevice(h->e.device));
+    do_minimize(h->e, r->r, first, last, minhash != 0);
+    RVN_HIP(hipStreamSynchronize(h->e.stream));
+    return RVN_OK;
+  });
+}
+
+int rvn_engine_filter(rvn_engine* h, double f) {
+  return guarded([&]() -> int {
+    if (!h) return fail(RVN_EINVAL, "[raven_hip] NULL engine");
+    if (!(0 <= f && f <= 1)) return fail(RVN_EINVAL, "[ram::MinimizerEngine::Filter] error: invalid frequency");
+    RVN_HIP(hipSetDevice(h->e.device));
+    index_filter(h->e, f);
+    return RVN_OK;
+  });
+}
+
+uint32_t rvn_engine_occurrence(const rvn_engine* h) { return h ? h->e.index.occurrence : 0; }
+
+int rvn_engine_map_batch(rvn_engine* h, const rvn_reads* r, uint32_t first, uint32_t last, int avoid_equal,
+                         int avoid_symmetric, int minhash, int want_filtered, uint64_t* n_overlaps) {
+  return guarded([&]() -> int {
+    if (!h || !r || first > last || last > r->r.n) return fail(RVN_EINVAL, "[raven_hip] rvn_engine_map_batch: bad range");
+    RVN_HIP(hipSetDevice(h->e.device));
+    map_batch(h->e, r->r, first, last, avoid_equal != 0, avoid_symmetric != 0, minhash != 0, want_filtered != 0,
+              h->e.map_out);
+    h->e.c_intervals += h->e.map_out.n_intervals;
+    RVN_HIP(hipStreamSynchronize(h->e.stream));
+    if (n_overlaps) *n_overlaps = h->e.map_out.n_overlaps;
+    return RVN_OK;
+  });
+}
+
+int rvn_engine_map_fetch(rvn_engine* h, rvn_overlap* overlaps, uint32_t* read_offsets) {
+  return guarded([&]() -> int {
+    if (!h) return fail(RVN_EINVAL, "[raven_hip] NULL engine");
+    MapOut& m = h->e.map_out;
+    RVN_HIP(hipSetDevice(h->e.device));
+    if (overlaps && m.n_overlaps)
+      RVN_HIP(hipMemcpy(overlaps, m.ovl.ptr, m.n_overlaps * sizeof(Overlap), hipMemcpyDeviceToHost));
+    if (read_offsets)
+      RVN_HIP(hipMemcpy(read_offsets, m.ovl_read_off.ptr, (static_cast<size_t>(m.last - m.first) + 1) * 4,
+                        hipMemcpyDeviceToHost));
+    return RVN_OK;
+  });
+}
+
+int rvn_engine_map_fetch_filtered(rvn_engine* h, uint32_t* positions, uint32_t* read_offsets, uint64_t* total) {
+  return guarded([&]() -> int {
+    if (!h) return fail(RVN_EINVAL, "[raven_hip] NULL engine");
+    Engine& e = h->e;
+    MapOut& m = e.map_out;
+    RVN_HIP(hipSetDevice(e.device));
+    const u64 nq = m.n_query;
+    const u32 nr = m.last - m.first;
+    std::vector<u8> flags(nq);
+    std::vector<u64> org(nq);
+    std::vector<u32> roff(static_cast<size_t>(nr) + 1, 0);
+    if (nq) {
+      RVN_HIP(hipMemcpy(flags.data(), m.filtered.ptr, nq, hipMemcpyDeviceToHost));
+      RVN_HIP(hipMemcpy(org.data(), e.query_sketch.org.ptr, nq * 8, hipMemcpyDeviceToHost));
+    }
+    RVN_HIP(hipMemcpy(roff.data(), e.query_sketch.read_off.ptr, roff.size() * 4, hipMemcpyDeviceToHost));
+    u64 tot = 0;
+    for (u32 i = 0; i < nr; ++i) {
+      if (read_offsets) read_offsets[i] = static_cast<u32>(tot);
+      for (u32 q = roff[i]; q < roff[i + 1]; ++q) {
+        if (flags[q]) {
+          if (positions) positions[tot] = static_cast<u32>(org[q]) >> 1;
+          ++tot;
+        }
+      }
+    }
+    if (read_offsets) read_offsets[nr] = static_cast<u32>(tot);
+    if (total) *total = tot;
+    return RVN_OK;
+  });
+}
+
+int rvn_find_overlaps_and_create_piles(rvn_engine* h, const rvn_reads* rr, double freq, uint32_t kmax,
+                                       int use_minhash, uint64_t index_batch_bases, uint64_t flush_bases,
+                                       rvn_pass1** out) {
+  return guarded([&]() -> int {
+    if (!h || !rr || !out) return fail(RVN_EINVAL, "[raven_hip] NULL argument");
+    if (!(0 <= freq && freq <= 1)) return fail(RVN_EINVAL, "[ram::MinimizerEngine::Filter] error: invalid frequency");
+    Engine& e = h->e;
+    const ReadsDev& r = rr->r;
+    for (u32 i = 0; i < r.n; ++i)
+      if (r.h_id[i] != i) return fail(RVN_EINVAL, "[raven_hip] FindOverlapsAndCreatePiles requires ids[i] == i");
+    RVN_HIP(hipSetDevice(e.device));
+    std::unique_ptr<rvn_pass1> p(new rvn_pass1());
+    p->e = &e;
+    piles_init(e, r, p->ps);
+    const u32 n = r.n;
+    // construct.cc:32-120
+    u64 bytes = 0;
+    for (u32 i = 0, j = 0; i < n; ++i) {
+      bytes += r.h_len[i];
+      if (i != n - 1 && bytes < index_batch_bases) continue;
+      bytes = 0;
+      do_minimize(e, r, j, i + 1, use_minhash != 0);
+      index_filter(e, freq);
+      u32 flush_first = 0;
+      for (u32 k = 0; k < i + 1; ++k) {
+        bytes += r.h_len[k];
+        if (k != i && bytes < flush_bases) continue;
+        bytes = 0;
+        map_batch(e, r, flush_first, k + 1, true, true, true, false, e.map_out);
+        e.c_intervals += e.map_out.n_intervals;
+        piles_merge(e, r, e.map_out, kmax, p->ps);
+        flush_first = k + 1;
+      }
+      j = i + 1;
+    }
+    RVN_HIP(hipStreamSynchronize(e.stream));
+    *out = p.release();
+    return RVN_OK;
+  });
+}
+
+uint64_t rvn_pass1_pile_words(const rvn_pass1* p) { return p ? p->ps.pile_words : 0; }
+uint64_t rvn_pass1_num_overlaps(const rvn_pass1* p) { return p ? p->ps.kept_total : 0; }
+
+int rvn_pass1_fetch_piles(const rvn_pass1* p, uint16_t* data, uint64_t* offsets) {
+  return guarded([&]() -> int {
+    if (!p) return fail(RVN_EINVAL, "[raven_hip] NULL pass1");
+    RVN_HIP(hipSetDevice(p->e->device));
+    if (data && p->ps.pile_words)
+      RVN_HIP(hipMemcpy(data, p->ps.pile_data.ptr, p->ps.pile_words * 2, hipMemcpyDeviceToHost));
+    if (offsets)
+      RVN_HIP(hipMemcpy(offsets, p->ps.pile_off.ptr, (static_cast<size_t>(p->ps.n) + 1) * 8, hipMemcpyDeviceToHost));
+    return RVN_OK;
+  });
+}
+
+int rvn_pass1_fetch_overlaps(const rvn_pass1* p, rvn_overlap* overlaps, uint32_t* offsets) {
+  return guarded([&]() -> int {
+    if (!p) return fail(RVN_EINVAL, "[raven_hip] NULL pass1");
+    RVN_HIP(hipSetDevice(p->e->device));
+    if (overlaps && p->ps.kept_total)
+      RVN_HIP(hipMemcpy(overlaps, p->ps.kept.ptr, p->ps.kept_total * sizeof(Overlap), hipMemcpyDeviceToHost));
+    if (offsets)
+      RVN_HIP(hipMemcpy(offsets, p->ps.kept_off.ptr, (static_cast<size_t>(p->ps.n) + 1) * 4, hipMemcpyDeviceToHost));
+    return RVN_OK;
+  });
+}
+
+void rvn_pass1_destroy(rvn_pass1* p) { delete p; }
+
+int rvn_pile_add_layers(rvn_engine* h, uint16_t* data, uint32_t cells, uint32_t id, const rvn_overlap* overlaps,
+                        uint64_t n) {
+  return guarded([&]() -> int {
+    if (!h || (cells && !data) || (n && !overlaps)) return fail(RVN_EINVAL, "[raven_hip] NULL argument");
+    if (n == 0 || cells == 0) return RVN_OK;
+    if (n >= (1ULL << 31)) return fail(RVN_EINVAL, "[raven_hip] too many overlaps");
+    Engine& e = h->e;
+    RVN_HIP(hipSetDevice(e.device));
+    // a one-pile PileState whose "new list" is the caller's overlaps
+    ReadsDev r;
+    r.n = 1;
+    r.h_len = {cells << 4};
+    r.h_id = {id};
+    u32* d_id = r.id.get<u32>(1);
+    RVN_HIP(hipMemcpy(d_id, &id, 4, hipMemcpyHostToDevice));
+    PileState ps;
+    piles_init(e, r, ps);
+    RVN_HIP(hipMemcpy(ps.pile_data.ptr, data, static_cast<size_t>(cells) * 2, hipMemcpyHostToDevice));
+    pile_add_layers_single(e, ps, d_id, reinterpret_cast<const Overlap*>(overlaps), static_cast<u32>(n));
+    RVN_HIP(hipMemcpy(data, ps.pile_data.ptr, static_cast<size_t>(cells) * 2, hipMemcpyDeviceToHost));
+    return RVN_OK;
+  });
+}
+
+int rvn_engine_sketch(rvn_engine* h, const rvn_reads* r, uint32_t first, uint32_t last, int minhash, uint64_t* count) {
+  return guarded([&]() -> int {
+    if (!h || !r || first > last || last > r->r.n) return fail(RVN_EINVAL, "[raven_hip] rvn_engine_sketch: bad range");
+    RVN_HIP(hipSetDevice(h->e.device));
+    sketch_range(h->e, r->r, first, last, minhash != 0, h->e.query_sketch);
+    RVN_HIP(hipStreamSynchronize(h->e.stream));
+    if (count) *count = h->e.query_sketch.count;
+    return RVN_OK;
+  });
+}
+
+static int fetch_values(Engine& e, const DevBuf& val, u64 n, uint64_t* values) {
+  if (!values || n == 0) return RVN_OK;
+  if (e.val64) {
+    RVN_HIP(hipMemcpy(values, val.ptr, n * 8, hipMemcpyDeviceToHost));
+  } else {
+    std::vector<u32> tmp(n);
+    RVN_HIP(hipMemcpy(tmp.data(), val.ptr, n * 4, hipMemcpyDeviceToHost));
+    for (u64 i = 0; i < n; ++i) values[i] = tmp[i];
+  }
+  return RVN_OK;
+}
+
+int rvn_engine_sketch_fetch(rvn_engine* h, uint64_t* values, uint64_t* origins, uint32_t* read_offsets) {
+  return guarded([&]() -> int {
+    if (!h) return fail(RVN_EINVAL, "[raven_hip] NULL engine");
+    Engine& e = h->e;
+    Sketch& s = e.query_sketch;
+    RVN_HIP(hipSetDevice(e.device));
+    fetch_values(e, s.val, s.count, values);
+    if (origins && s.count) RVN_HIP(hipMemcpy(origins, s.org.ptr, s.count * 8, hipMemcpyDeviceToHost));
+    if (read_offsets)
+      RVN_HIP(hipMemcpy(read_offsets, s.read_off.ptr, (static_cast<size_t>(s.last - s.first) + 1) * 4,
+                        hipMemcpyDeviceToHost));
+    return RVN_OK;
+  });
+}
+
+int rvn_engine_index_size(const rvn_engine* h, uint64_t* n_minimizers, uint64_t* n_keys) {
+  if (!h) return fail(RVN_EINVAL, "[raven_hip] NULL engine");
+  if (n_minimizers) *n_minimizers = h->e.index.m;
+  if (n_keys) *n_keys = h->e.index.u;
+  return RVN_OK;
+}
+
+int rvn_engine_index_fetch(rvn_engine* h, uint64_t* values, uint64_t* origins) {
+  return guarded([&]() -> int {
+    if (!h) return fail(RVN_EINVAL, "[raven_hip] NULL engine");
+    Engine& e = h->e;
+    Index& ix = e.index;
+    RVN_HIP(hipSetDevice(e.device));
+    fetch_values(e, ix.s_val[ix.cur], ix.m, values);
+    if (origins && ix.m) RVN_HIP(hipMemcpy(origins, ix.s_org[ix.cur].ptr, ix.m * 8, hipMemcpyDeviceToHost));
+    return RVN_OK;
+  });
+}
+
+int rvn_engine_counters(const rvn_engine* h, uint64_t out[8]) {
+  if (!h || !out) return fail(RVN_EINVAL, "[raven_hip] NULL argument");
+  const Engine& e = h->e;
+  out[0] = e.c_index_bases;
+  out[1] = e.c_index_min;
+  out[2] = e.c_index_keys;
+  out[3] = e.c_query_bases;
+  out[4] = e.c_query_min;
+  out[5] = e.c_matches;
+  out[6] = e.c_overlaps;
+  out[7] = e.c_intervals;
+  return RVN_OK;
+}
+
+int rvn_engine_num_stages(void) { return StageTimes::kNum; }
+const char* rvn_engine_stage_name(int s) { return (s >= 0 && s < StageTimes::kNum) ? kStageNames[s] : ""; }
+
+int rvn_engine_stage_ms(const rvn_engine* h, double* ms, uint64_t* launches, int n) {
+  if (!h) return fail(RVN_EINVAL, "[raven_hip] NULL engine");
+  for (int i = 0; i < n && i < StageTimes::kNum; ++i) {
+    if (ms) ms[i] = h->e.times.ms[i];
+    if (launches) launches[i] = h->e.times.launches[i];
+  }
+  return RVN_OK;
+}
+
+void rvn_engine_reset_stats(rvn_engine* h) {
+  if (!h) return;
+  Engine& e = h->e;
+  e.times = StageTimes();
+  e.c_index_bases = e.c_index_min = e.c_index_keys = e.c_query_bases = e.c_query_min = e.c_matches = e.c_overlaps =
+      e.c_intervals = 0;
+}
+
+void rvn_engine_set_timing(rvn_engine* h, int enabled) {
+  if (h) h->e.timing = enabled != 0;
+}
+
+// ---- host test hooks ---------------------------------------------------------------------------
+uint64_t rvn_test_hash(uint64_t key, uint32_t k, int use32) {
+  const u64 mask = (1ULL << (2 * k)) - 1;
+  if (use32) return hash32(static_cast<u32>(key), static_cast<u32>(mask));
+  return hash64(key, mask);
+}
+
+int rvn_test_canonical(const uint64_t* words, uint32_t pos, uint32_t k, int use32, uint64_t* value,
+                       uint32_t* strand) {
+  const u64 mask = (1ULL << (2 * k)) - 1;
+  const u32 bit = 2 * pos;
+  const u64 x = extract_bits(words[bit >> 6], words[(bit >> 6) + 1], bit & 63, mask);
+  unsigned st = 0;
+  bool ok;
+  if (use32) {
+    u32 v = 0;
+    ok = canonical_hash<u32>(x, k, mask, &v, &st);
+    *value = v;
+  } else {
+    u64 v = 0;
+    ok = canonical_hash<u64>(x, k, mask, &v, &st);
+    *value = v;
+  }
+  *strand = st;
+  return ok ? 1 : 0;
+}
+
+void rvn_test_std_sort_lendesc(uint64_t* data, uint64_t n) { std_sort(data, data + n, LenDesc()); }
+void rvn_test_heap_sort_lendesc(uint64_t* data, uint64_t n) { intro::heap_sort(data, data + n, LenDesc()); }
+
+}  // extern "C"

@@ -1,0 +1,199 @@
+// index.hip — minimizer index: stable sort by value, distinct-key table, direct-address bucket table,
+// occurrence filter (replaces ram::MinimizerEngine::Minimize(first,last,minhash) index build and
+// ::Filter(f); call sites RavenLib/src/construct.cc:42-44).
+//
+// ram buckets by the low 14 bits, stable-sorts each bucket by value and keeps an unordered_map
+// value -> (offset,count) into an origins array ordered by (read iteration order, position).  The same
+// mapping is obtained here from ONE stable device radix sort of the (value, origin) stream (already in
+// iteration/position order), a run-head compaction (distinct keys + start offsets) and a direct-address
+// table over the top bits of the (uniformly distributed) hash: lookup = 2 table loads + a <=few-entry scan.
+#include <algorithm>
+#include <vector>
+
+#include "engine.h"
+#include "wave.h"
+
+namespace rvn {
+
+namespace {
+
+template <typename V>
+__global__ void heads_kernel(const V* __restrict__ val, u64 n, u8* __restrict__ flags) {
+  u64 i = static_cast<u64>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n) flags[i] = (i == 0 || val[i] != val[i - 1]) ? 1 : 0;
+}
+
+template <typename V>
+__global__ void unique_kernel(const V* __restrict__ val, const u8* __restrict__ flags, const u32* __restrict__ scan,
+                              u64 n, V* __restrict__ u_val, u32* __restrict__ u_start, u32 u) {
+  u64 i = static_cast<u64>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n && flags[i]) {
+    u32 j = scan[i];
+    u_val[j] = val[i];
+    u_start[j] = static_cast<u32>(i);
+  }
+  if (i == 0) u_start[u] = static_cast<u32>(n);
+}
+
+// table[b] = first distinct-key index j with (u_val[j] >> shift) >= b, for b in [0, B]; B = 1 << bits.
+template <typename V>
+__global__ void table_kernel(const V* __restrict__ u_val, u32 u, int shift, u32 B, u32* __restrict__ table) {
+  u32 j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= u) return;
+  const long long bj = static_cast<long long>(static_cast<u64>(u_val[j]) >> shift);
+  const long long bp = j ? static_cast<long long>(static_cast<u64>(u_val[j - 1]) >> shift) : -1;
+  for (long long b = bp + 1; b <= bj; ++b) table[b] = j;
+  if (j == u - 1)
+    for (long long b = bj + 1; b <= static_cast<long long>(B); ++b) table[b] = u;
+}
+
+__global__ void table_empty_kernel(u32* table, u32 B) {
+  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i <= B) table[i] = 0;
+}
+
+constexpr u32 kHistBins = 65536;
+
+// count-of-counts histogram of run lengths (bin kHistBins-1 = overflow ">= 65535")
+__global__ __launch_bounds__(256) void occ_hist_kernel(const u32* __restrict__ u_start, u32 u,
+                                                      u32* __restrict__ hist, u32* __restrict__ overflow_list,
+                                                      u32* __restrict__ overflow_n, u32 overflow_cap) {
+  __shared__ u32 lh[256];
+  lh[threadIdx.x] = 0;
+  __syncthreads();
+  for (u32 j = blockIdx.x * 256 + threadIdx.x; j < u; j += gridDim.x * 256) {
+    const u32 c = u_start[j + 1] - u_start[j];
+    if (c < 256) {
+      atomicAdd(&lh[c], 1u);
+    } else if (c < kHistBins - 1) {
+      atomicAdd(&hist[c], 1u);
+    } else {
+      atomicAdd(&hist[kHistBins - 1], 1u);
+      u32 slot = atomicAdd(overflow_n, 1u);
+      if (slot < overflow_cap) overflow_list[slot] = c;
+    }
+  }
+  __syncthreads();
+  if (lh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], lh[threadIdx.x]);
+}
+
+template <typename V>
+void index_build_impl(Engine& e, Sketch& sk) {
+  hipStream_t s = e.stream;
+  Index& ix = e.index;
+  const u64 m = sk.count;
+  ix.m = m;
+  ix.u = 0;
+  ix.occurrence = 0xFFFFFFFFu;
+  if (m >= (1ULL << 32)) throw HipError("[raven_hip] index batch with >= 2^32 minimizers is not supported");
+
+  // adopt the sketch buffers as ping side 0 (swap ownership, no copy)
+  std::swap(ix.s_val[0].ptr, sk.val.ptr);
+  std::swap(ix.s_val[0].cap, sk.val.cap);
+  std::swap(ix.s_org[0].ptr, sk.org.ptr);
+  std::swap(ix.s_org[0].cap, sk.org.cap);
+  ix.cur = 0;
+  if (m == 0) {
+    ix.table_bits = 1;
+    ix.shift = 2 * e.k > 1 ? 2 * e.k - 1 : 0;
+    u32* table = ix.table.get<u32>(3);
+    table_empty_kernel<<<1, 64, 0, s>>>(table, 2);
+    RVN_LAUNCH_CHECK();
+    ix.u_val.reserve(16);
+    ix.u_start.reserve(16);
+    RVN_HIP(hipMemsetAsync(ix.u_start.ptr, 0, 8, s));
+    return;
+  }
+  V* v0 = ix.s_val[0].as<V>();
+  u64* o0 = ix.s_org[0].as<u64>();
+  V* v1 = ix.s_val[1].get<V>(m + 1);
+  u64* o1 = ix.s_org[1].get<u64>(m + 1);
+  {
+    StageTimer t(e, StageTimes::kSort);
+    if (sizeof(V) == 4)
+      ix.cur = radix_sort_pairs_u32_u64(reinterpret_cast<u32*>(v0), reinterpret_cast<u32*>(v1), o0, o1, m, 2 * e.k,
+                                        e.sort_tmp, e.scan_tmp, s);
+    else
+      ix.cur = radix_sort_pairs_u64_u64(reinterpret_cast<u64*>(v0), reinterpret_cast<u64*>(v1), o0, o1, m, 2 * e.k,
+                                        e.sort_tmp, e.scan_tmp, s);
+    t.stop();
+  }
+  StageTimer t(e, StageTimes::kIndex);
+  const V* sv = ix.s_val[ix.cur].as<V>();
+  u8* flags = e.tmp_c.get<u8>(m + 1);
+  u32* fscan = e.tmp_d.get<u32>(m + 1);
+  heads_kernel<V><<<div_up(m, 256), 256, 0, s>>>(sv, m, flags);
+  RVN_LAUNCH_CHECK();
+  exclusive_scan_u8_u32(flags, fscan, m, e.scan_tmp, s);
+  u32 u = 0;
+  RVN_HIP(hipMemcpyAsync(&u, fscan + m, 4, hipMemcpyDeviceToHost, s));
+  RVN_HIP(hipStreamSynchronize(s));
+  ix.u = u;
+  V* u_val = ix.u_val.get<V>(static_cast<size_t>(u) + 1);
+  u32* u_start = ix.u_start.get<u32>(static_cast<size_t>(u) + 2);
+  unique_kernel<V><<<div_up(m, 256), 256, 0, s>>>(sv, flags, fscan, m, u_val, u_start, u);
+  RVN_LAUNCH_CHECK();
+
+  int bits = 1;
+  while ((1ULL << bits) < 2ULL * u) ++bits;
+  bits = std::max(8, bits);
+  bits = std::min(bits, std::min<int>(2 * e.k, 26));
+  ix.table_bits = bits;
+  ix.shift = 2 * e.k - bits;
+  const u32 B = 1u << bits;
+  u32* table = ix.table.get<u32>(static_cast<size_t>(B) + 2);
+  table_kernel<V><<<div_up(u, 256), 256, 0, s>>>(u_val, u, ix.shift, B, table);
+  RVN_LAUNCH_CHECK();
+  t.stop();
+}
+
+}  // namespace
+
+void index_build(Engine& e, Sketch& sk) {
+  if (e.val64) index_build_impl<u64>(e, sk);
+  else index_build_impl<u32>(e, sk);
+}
+
+// ram Filter: occurrence_ = (value at index (1-f)*U of the sorted per-key counts) + 1; f == 0 -> no filter.
+void index_filter(Engine& e, double freq) {
+  Index& ix = e.index;
+  if (freq == 0 || ix.u == 0) {
+    ix.occurrence = 0xFFFFFFFFu;
+    return;
+  }
+  StageTimer t(e, StageTimes::kFilter);
+  hipStream_t s = e.stream;
+  const u32 overflow_cap = 1u << 20;
+  u32* hist = e.tmp_a.get<u32>(kHistBins + 1);
+  u32* ovl = e.tmp_b.get<u32>(overflow_cap + 1);
+  RVN_HIP(hipMemsetAsync(hist, 0, (kHistBins + 1) * 4, s));
+  const u32 u = static_cast<u32>(ix.u);
+  const u32 grid = std::min<u32>(div_up(u, 256), 2048);
+  occ_hist_kernel<<<grid, 256, 0, s>>>(ix.u_start.as<u32>(), u, hist, ovl, hist + kHistBins, overflow_cap);
+  RVN_LAUNCH_CHECK();
+  std::vector<u32> h(kHistBins + 1);
+  RVN_HIP(hipMemcpyAsync(h.data(), hist, (kHistBins + 1) * 4, hipMemcpyDeviceToHost, s));
+  RVN_HIP(hipStreamSynchronize(s));
+  size_t nth = static_cast<size_t>((1 - freq) * u);
+  if (nth >= u) nth = u - 1;
+  u64 cum = 0;
+  u32 c = 0;
+  for (c = 0; c < kHistBins; ++c) {
+    cum += h[c];
+    if (cum > nth) break;
+  }
+  if (c >= kHistBins - 1) {
+    // quantile lands among run lengths >= 65535: resolve exactly from the overflow list
+    const u32 n_over = h[kHistBins];
+    if (n_over > overflow_cap) throw HipError("[raven_hip] Filter: overflow list too small");
+    std::vector<u32> over(n_over);
+    RVN_HIP(hipMemcpy(over.data(), ovl, static_cast<size_t>(n_over) * 4, hipMemcpyDeviceToHost));
+    std::sort(over.begin(), over.end());
+    const u64 below = cum - h[kHistBins - 1];
+    c = over[nth - below];
+  }
+  ix.occurrence = c + 1;
+  t.stop();
+}
+
+}  // namespace rvn

@@ -1,0 +1,545 @@
+// map.hip — batched ram::MinimizerEngine::Map (call site RavenLib/src/construct.cc:59-64, :377-381):
+// query sketch -> index probe -> match emit -> sort by group -> diagonal-band intervals ->
+// per-interval sort by positions -> LIS chain -> overlaps, for a whole batch of query reads at once.
+// Output order equals the reference's "for each query read in order, Map() output order".
+//
+// Kernels (all integer, HBM/L2-bound; no MFMA):
+//   match_count / match_emit   one lane per query minimizer, direct-address table probe
+//   seg_sort                   one wave per segment, LSD radix on 64-bit keys, LDS histogram,
+//                              stable rank by wave ballots (used for both sorts)
+//   intervals                  one wave per read segment; ram's sequential (i, j) sweep restated as
+//                              a per-element binary search + wave max-scan
+//   chain                      one lane per interval: ram's exact patience/binary-search LIS, gap split,
+//                              covered-bases score
+#include <algorithm>
+
+#include "engine.h"
+#include "wave.h"
+
+namespace rvn {
+
+namespace {
+
+template <typename V>
+__device__ __forceinline__ bool index_find(const V* __restrict__ u_val, const u32* __restrict__ u_start,
+                                           const u32* __restrict__ table, int shift, V v, u32* start, u32* count) {
+  const u32 b = static_cast<u32>(static_cast<u64>(v) >> shift);
+  u32 lo = table[b], hi = table[b + 1];
+  const u32 end = hi;
+  while (lo < hi) {
+    const u32 mid = lo + ((hi - lo) >> 1);
+    if (u_val[mid] < v) lo = mid + 1;
+    else hi = mid;
+  }
+  if (lo < end && u_val[lo] == v) {
+    *start = u_start[lo];
+    *count = u_start[lo + 1] - *start;
+    return true;
+  }
+  return false;
+}
+
+template <typename V>
+__global__ void match_count_kernel(const V* __restrict__ q_val, const u64* __restrict__ q_org, u64 nq,
+                                   const V* __restrict__ u_val, const u32* __restrict__ u_start,
+                                   const u32* __restrict__ table, int shift, u32 n_keys,
+                                   const u64* __restrict__ s_org, u32 occurrence, int avoid_equal,
+                                   int avoid_symmetric, u32* __restrict__ q_start, u32* __restrict__ q_n,
+                                   u32* __restrict__ q_cnt, u8* __restrict__ filtered) {
+  u64 q = static_cast<u64>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (q >= nq) return;
+  const V v = q_val[q];
+  const u32 qid = static_cast<u32>(q_org[q] >> 32);
+  u32 start = 0, count = 0, cnt = 0;
+  u8 filt = 0;
+  if (n_keys && index_find<V>(u_val, u_start, table, shift, v, &start, &count)) {
+    if (count > occurrence) {
+      filt = 1;
+      count = 0;
+    } else {
+      for (u32 j = 0; j < count; ++j) {
+        const u32 rid = static_cast<u32>(s_org[start + j] >> 32);
+        if (avoid_equal && qid == rid) continue;
+        if (avoid_symmetric && qid > rid) continue;
+        ++cnt;
+      }
+    }
+  }
+  q_start[q] = start;
+  q_n[q] = count;
+  q_cnt[q] = cnt;
+  if (filtered) filtered[q] = filt;
+}
+
+__global__ void match_emit_kernel(const u64* __restrict__ q_org, u64 nq, const u64* __restrict__ s_org,
+                                  const u32* __restrict__ q_start, const u32* __restrict__ q_n,
+                                  const u64* __restrict__ m_off, int avoid_equal, int avoid_symmetric,
+                                  u64* __restrict__ m_grp, u64* __restrict__ m_pos) {
+  u64 q = static_cast<u64>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (q >= nq) return;
+  const u32 count = q_n[q];
+  if (count == 0) return;
+  const u64 qo = q_org[q];
+  const u32 qid = static_cast<u32>(qo >> 32);
+  const u64 lhs_pos = static_cast<u32>(qo) >> 1;
+  const u32 qstrand = static_cast<u32>(qo) & 1u;
+  const u32 start = q_start[q];
+  u64 o = m_off[q];
+  for (u32 j = 0; j < count; ++j) {
+    const u64 ro = s_org[start + j];
+    const u32 rid = static_cast<u32>(ro >> 32);
+    if (avoid_equal && qid == rid) continue;
+    if (avoid_symmetric && qid > rid) continue;
+    const u64 rhs_pos = static_cast<u32>(ro) >> 1;
+    const u64 strand = (qstrand == (static_cast<u32>(ro) & 1u)) ? 1 : 0;
+    const u64 diagonal = !strand ? rhs_pos + lhs_pos : rhs_pos - lhs_pos + (3ULL << 30);
+    m_grp[o] = (((static_cast<u64>(rid) << 1) | strand) << 32) | diagonal;
+    m_pos[o] = (lhs_pos << 32) | rhs_pos;
+    ++o;
+  }
+}
+
+__global__ void gather_u64_by_u32_kernel(const u64* __restrict__ src, const u32* __restrict__ idx,
+                                         u64* __restrict__ dst, u32 n) {
+  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[idx[i]];
+}
+
+// ---- wave-level segmented LSD radix sort ---------------------------------------------------------
+// Sorts keys k0[b, b+n) (payload p0) stably by the full 64-bit key; result always ends in k0/p0.
+__device__ void wave_sort_segment(u64* __restrict__ k0, u64* __restrict__ k1, u64* __restrict__ p0,
+                                  u64* __restrict__ p1, u64 b, u64 n, u32* hist) {
+  const int lane = lane_id();
+  const unsigned long long lt = lanemask_lt();
+  u64 o = 0, a = ~0ULL;
+  for (u64 i = lane; i < n; i += 64) {
+    const u64 key = k0[b + i];
+    o |= key;
+    a &= key;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    o |= __shfl_xor(o, off, 64);
+    a &= __shfl_xor(a, off, 64);
+  }
+  const u64 varying = o ^ a;
+  int cur = 0;
+  for (int shift = 0; shift < 64; shift += 8) {
+    if (((varying >> shift) & 0xFF) == 0) continue;
+    const u64* kin = cur ? k1 : k0;
+    const u64* pin = cur ? p1 : p0;
+    u64* kout = cur ? k0 : k1;
+    u64* pout = cur ? p0 : p1;
+    for (int i = lane; i < 256; i += 64) hist[i] = 0;
+    __builtin_amdgcn_wave_barrier();
+    for (u64 base = 0; base < n; base += 64) {
+      const u64 i = base + lane;
+      if (i < n) atomicAdd(&hist[(kin[b + i] >> shift) & 0xFF], 1u);
+    }
+    __builtin_amdgcn_wave_barrier();
+    {
+      const u32 h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
+      const u32 s = h0 + h1 + h2 + h3;
+      const u32 ex = wave_inclusive_sum(s) - s;
+      __builtin_amdgcn_wave_barrier();
+      hist[4 * lane] = ex;
+      hist[4 * lane + 1] = ex + h0;
+      hist[4 * lane + 2] = ex + h0 + h1;
+      hist[4 * lane + 3] = ex + h0 + h1 + h2;
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (u64 base = 0; base < n; base += 64) {
+      const u64 i = base + lane;
+      const bool valid = i < n;
+      u64 key = 0, pay = 0;
+      if (valid) {
+        key = kin[b + i];
+        pay = pin[b + i];
+      }
+      const unsigned d = static_cast<unsigned>((key >> shift) & 0xFF);
+      const unsigned long long peers = match_digit8(d, valid);
+      u32 before = 0;
+      if (valid) before = hist[d];
+      __builtin_amdgcn_wave_barrier();
+      const u32 rank = before + __popcll(peers & lt);
+      if (valid && (peers & lt) == 0) hist[d] = before + __popcll(peers);
+      __builtin_amdgcn_wave_barrier();
+      if (valid) {
+        kout[b + rank] = key;
+        pout[b + rank] = pay;
+      }
+    }
+    __threadfence_block();  // this wave's stores must be visible to its other lanes' loads next pass
+    cur ^= 1;
+  }
+  if (cur) {
+    for (u64 i = lane; i < n; i += 64) {
+      k0[b + i] = k1[b + i];
+      p0[b + i] = p1[b + i];
+    }
+    __threadfence_block();
+  }
+}
+
+// segments given by off[seg], off[seg+1]
+__global__ __launch_bounds__(256) void seg_sort_off_kernel(u64* k0, u64* k1, u64* p0, u64* p1,
+                                                          const u64* __restrict__ off, u32 n_seg) {
+  __shared__ u32 hist[4][256];
+  const u32 seg = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (seg >= n_seg) return;
+  const u64 b = off[seg], e = off[seg + 1];
+  if (e - b < 2) return;
+  wave_sort_segment(k0, k1, p0, p1, b, e - b, hist[threadIdx.x >> 6]);
+}
+
+// segments given by begin[seg], end[seg]; segments shorter than min_n are skipped
+__global__ __launch_bounds__(256) void seg_sort_be_kernel(u64* k0, u64* k1, u64* p0, u64* p1,
+                                                         const u64* __restrict__ begin,
+                                                         const u64* __restrict__ end, u32 n_seg, u32 min_n) {
+  __shared__ u32 hist[4][256];
+  const u32 seg = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (seg >= n_seg) return;
+  const u64 b = begin[seg], e = end[seg];
+  if (e - b < 2 || e - b < min_n) return;
+  wave_sort_segment(k0, k1, p0, p1, b, e - b, hist[threadIdx.x >> 6]);
+}
+
+// ---- diagonal-band intervals (ram Chain, first loop) ------------------------------------------
+// One wave per read segment. Slots: segment [b, e) may hold at most (e-b)/4 intervals, stored at
+// slot ceil(b/4)+id (disjoint across segments).
+__global__ __launch_bounds__(256) void intervals_kernel(const u64* __restrict__ grp, const u64* __restrict__ seg_off,
+                                                       u32 n_seg, u64 bandwidth, u64* __restrict__ slot_begin,
+                                                       u64* __restrict__ slot_end, u32* __restrict__ iv_cnt) {
+  const u32 seg = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (seg >= n_seg) return;
+  const int lane = lane_id();
+  const u64 b = seg_off[seg], e = seg_off[seg + 1];
+  const long long n = static_cast<long long>(e - b);
+  if (n < 4) {
+    if (lane == 0) iv_cnt[seg] = 0;
+    return;
+  }
+  const u64 slot_base = (b + 3) >> 2;
+  const u64* g = grp + b;
+  long long carry_prev = -1;  // local index (end) of the last valid candidate so far
+  u32 n_iv = 0;
+  const unsigned long long lt = lanemask_lt();
+  for (long long base = 1; base <= n; base += 64) {
+    const long long il = base + lane;
+    const bool in = il <= n;
+    long long lprev = 0;
+    bool cand = false;
+    if (in) {
+      const u64 g_prev = g[il - 1];
+      long long lo = 0, hi = il - 1;
+      while (lo < hi) {
+        const long long mid = (lo + hi) >> 1;
+        if (g_prev - g[mid] <= bandwidth) hi = mid;
+        else lo = mid + 1;
+      }
+      lprev = lo;
+      const u64 gi = il == n ? ~0ULL : g[il];
+      cand = (gi - g[lprev] > bandwidth) && (il - lprev >= 4);
+    }
+    const long long mine = cand ? il : -1;
+    const long long incl = wave_inclusive_max(mine);
+    long long excl = __shfl_up(incl, 1, 64);
+    if (lane == 0) excl = -1;
+    excl = excl > carry_prev ? excl : carry_prev;
+    const bool is_new = cand && !(excl > lprev);
+    const unsigned long long newmask = __ballot(is_new);
+    if (is_new) {
+      const u32 id = n_iv + __popcll(newmask & lt);
+      slot_begin[slot_base + id] = b + static_cast<u64>(lprev);
+      if (excl >= 0) slot_end[slot_base + id - 1] = b + static_cast<u64>(excl);
+    }
+    const long long wmax = __shfl(incl, 63, 64);
+    carry_prev = wmax > carry_prev ? wmax : carry_prev;
+    n_iv += __popcll(newmask);
+  }
+  if (lane == 0) {
+    if (n_iv) slot_end[slot_base + n_iv - 1] = b + static_cast<u64>(carry_prev);
+    iv_cnt[seg] = n_iv;
+  }
+}
+
+__global__ __launch_bounds__(256) void intervals_gather_kernel(const u64* __restrict__ slot_begin,
+                                                              const u64* __restrict__ slot_end,
+                                                              const u64* __restrict__ seg_off,
+                                                              const u32* __restrict__ iv_off, u32 n_seg,
+                                                              u64* __restrict__ iv_begin, u64* __restrict__ iv_end,
+                                                              u32* __restrict__ iv_read) {
+  const u32 seg = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (seg >= n_seg) return;
+  const u32 o0 = iv_off[seg], o1 = iv_off[seg + 1];
+  const u64 slot_base = (seg_off[seg] + 3) >> 2;
+  for (u32 i = lane_id(); i < o1 - o0; i += 64) {
+    iv_begin[o0 + i] = slot_begin[slot_base + i];
+    iv_end[o0 + i] = slot_end[slot_base + i];
+    iv_read[o0 + i] = seg;
+  }
+}
+
+// ---- LIS chain + overlap emission (ram Chain second loop + LongestSubsequence) ----------------
+__global__ __launch_bounds__(64) void chain_kernel(const u64* __restrict__ grp, const u64* __restrict__ pos,
+                                                  const u64* __restrict__ iv_begin, const u64* __restrict__ iv_end,
+                                                  const u32* __restrict__ iv_read, u32 n_iv,
+                                                  const u32* __restrict__ ids, u32 first, u32 k, u32 chain,
+                                                  u32 min_matches, u32 gap, u32 slot_div,
+                                                  u32* __restrict__ lis_min, u32* __restrict__ lis_pred,
+                                                  Overlap* __restrict__ slots, u8* __restrict__ slot_flags) {
+  const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_iv) return;
+  const u64 b = iv_begin[t], e = iv_end[t];
+  const u32 n = static_cast<u32>(e - b);
+  if (n < chain) return;
+  u32* minimal = lis_min + b + t;  // n + 1 entries
+  u32* pred = lis_pred + b;        // n entries
+  const u64* p = pos + b;
+  const u64 g0 = grp[b];
+  const bool strand = (g0 >> 32) & 1;
+  u32 longest = 0;
+  minimal[0] = 0;
+  for (u32 it = 0; it < n; ++it) {
+    const u64 cur = p[it];
+    const u32 lhs = static_cast<u32>(cur >> 32), rhs = static_cast<u32>(cur);
+    u32 lo = 1, hi = longest;
+    while (lo <= hi) {
+      const u32 mid = lo + (hi - lo) / 2;
+      const u64 q = p[minimal[mid]];
+      const u32 ql = static_cast<u32>(q >> 32), qr = static_cast<u32>(q);
+      const bool ok = ql < lhs && (strand ? qr < rhs : qr > rhs);
+      if (ok) lo = mid + 1;
+      else hi = mid - 1;
+    }
+    pred[it] = minimal[lo - 1];
+    minimal[lo] = it;
+    longest = longest > lo ? longest : lo;
+  }
+  if (longest < chain) return;
+  {
+    u32 j = minimal[longest];
+    for (u32 i = 0; i < longest; ++i) {
+      const u32 nj = pred[j];
+      minimal[longest - 1 - i] = j;  // chain indices ascending in minimal[0 .. longest)
+      j = nj;
+    }
+  }
+  const u64 slot_base = (b + slot_div - 1) / slot_div;
+  u32 emitted = 0;
+  u32 l = 0;
+  for (u32 kk = 1; kk <= longest; ++kk) {
+    const u32 lhs_k = kk < longest ? static_cast<u32>(p[minimal[kk]] >> 32) : 0xFFFFFFFFu;
+    const u32 lhs_km1 = static_cast<u32>(p[minimal[kk - 1]] >> 32);
+    if (lhs_k - lhs_km1 > gap) {
+      if (kk - l < chain) {
+        l = kk;
+        continue;
+      }
+      u32 lhs_matches = 0, lhs_begin = 0, lhs_end = 0;
+      u32 rhs_matches = 0, rhs_begin = 0, rhs_end = 0;
+      for (u32 m = l; m < kk; ++m) {
+        const u64 mm = p[minimal[m]];
+        const u32 lhs_pos = static_cast<u32>(mm >> 32);
+        if (lhs_pos > lhs_end) {
+          lhs_matches += lhs_end - lhs_begin;
+          lhs_begin = lhs_pos;
+        }
+        lhs_end = lhs_pos + k;
+        u32 rhs_pos = static_cast<u32>(mm);
+        rhs_pos = strand ? rhs_pos : (1U << 31) - (rhs_pos + k - 1);
+        if (rhs_pos > rhs_end) {
+          rhs_matches += rhs_end - rhs_begin;
+          rhs_begin = rhs_pos;
+        }
+        rhs_end = rhs_pos + k;
+      }
+      lhs_matches += lhs_end - lhs_begin;
+      rhs_matches += rhs_end - rhs_begin;
+      const u32 score = lhs_matches < rhs_matches ? lhs_matches : rhs_matches;
+      if (score < min_matches) {
+        l = kk;
+        continue;
+      }
+      const u64 ml = p[minimal[l]], mr = p[minimal[kk - 1]];
+      Overlap o;
+      o.lhs_id = ids[first + iv_read[t]];
+      o.lhs_begin = static_cast<u32>(ml >> 32);
+      o.lhs_end = k + static_cast<u32>(mr >> 32);
+      o.rhs_id = static_cast<u32>(g0 >> 33);
+      o.rhs_begin = strand ? static_cast<u32>(ml) : static_cast<u32>(mr);
+      o.rhs_end = k + (strand ? static_cast<u32>(mr) : static_cast<u32>(ml));
+      o.score = score;
+      o.strand = strand ? 1u : 0u;
+      slots[slot_base + emitted] = o;
+      slot_flags[slot_base + emitted] = 1;
+      ++emitted;
+      l = kk;
+    }
+  }
+}
+
+__global__ void compact_overlaps_kernel(const Overlap* __restrict__ slots, const u8* __restrict__ flags,
+                                        const u32* __restrict__ scan, u64 n_slots, Overlap* __restrict__ out) {
+  u64 i = static_cast<u64>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n_slots && flags[i]) out[scan[i]] = slots[i];
+}
+
+__global__ void read_ovl_off_kernel(const u64* __restrict__ seg_off, const u32* __restrict__ scan, u32 slot_div,
+                                    u32 n, u32* __restrict__ out) {
+  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = scan[(seg_off[i] + slot_div - 1) / slot_div];
+}
+
+template <typename V>
+void map_batch_impl(Engine& e, const ReadsDev& r, u32 first, u32 last, bool avoid_equal, bool avoid_symmetric,
+                    bool minhash, bool want_filtered, MapOut& out) {
+  hipStream_t s = e.stream;
+  Index& ix = e.index;
+  const u32 nr = last - first;
+  out.first = first;
+  out.last = last;
+  out.n_query = out.n_matches = out.n_intervals = out.n_overlaps = 0;
+  u32* ovl_read_off = out.ovl_read_off.get<u32>(static_cast<size_t>(nr) + 1);
+
+  Sketch& qs = e.query_sketch;
+  {
+    StageTimer t(e, StageTimes::kQuery);
+    sketch_range(e, r, first, last, minhash, qs);
+    t.stop();
+  }
+  const u64 nq = qs.count;
+  out.n_query = nq;
+  for (u32 i = first; i < last; ++i) e.c_query_bases += r.h_len[i];
+  e.c_query_min += nq;
+  if (nq == 0 || ix.m == 0) {
+    RVN_HIP(hipMemsetAsync(ovl_read_off, 0, (static_cast<size_t>(nr) + 1) * 4, s));
+    if (want_filtered) {
+      u8* f = out.filtered.get<u8>(nq + 1);
+      RVN_HIP(hipMemsetAsync(f, 0, nq + 1, s));
+    }
+    return;
+  }
+  u64 H = 0;
+  {
+    StageTimer t(e, StageTimes::kMatch);
+    u32* q_start = e.q_start.get<u32>(nq + 1);
+    u32* q_n = e.tmp_a.get<u32>(nq + 1);
+    u32* q_cnt = e.q_cnt.get<u32>(nq + 1);
+    u8* filt = want_filtered ? out.filtered.get<u8>(nq + 1) : nullptr;
+    u64* m_off = e.m_off.get<u64>(nq + 2);
+    match_count_kernel<V><<<div_up(nq, 256), 256, 0, s>>>(
+        qs.val.as<V>(), qs.org.as<u64>(), nq, ix.u_val.as<V>(), ix.u_start.as<u32>(), ix.table.as<u32>(), ix.shift,
+        static_cast<u32>(ix.u), ix.s_org[ix.cur].as<u64>(), ix.occurrence, avoid_equal, avoid_symmetric, q_start, q_n,
+        q_cnt, filt);
+    RVN_LAUNCH_CHECK();
+    exclusive_scan_u32_u64(q_cnt, m_off, nq, e.scan_tmp, s);
+    RVN_HIP(hipMemcpyAsync(&H, m_off + nq, 8, hipMemcpyDeviceToHost, s));
+    RVN_HIP(hipStreamSynchronize(s));
+    out.n_matches = H;
+    e.c_matches += H;
+    if (H) {
+      u64* g0 = e.m_grp[0].get<u64>(H + 1);
+      u64* p0 = e.m_pos[0].get<u64>(H + 1);
+      e.m_grp[1].reserve((H + 1) * 8);
+      e.m_pos[1].reserve((H + 1) * 8);
+      match_emit_kernel<<<div_up(nq, 256), 256, 0, s>>>(qs.org.as<u64>(), nq, ix.s_org[ix.cur].as<u64>(), q_start,
+                                                        q_n, m_off, avoid_equal, avoid_symmetric, g0, p0);
+      RVN_LAUNCH_CHECK();
+    }
+    t.stop();
+  }
+  if (H == 0) {
+    RVN_HIP(hipMemsetAsync(ovl_read_off, 0, (static_cast<size_t>(nr) + 1) * 4, s));
+    return;
+  }
+  u64* g0 = e.m_grp[0].as<u64>();
+  u64* g1 = e.m_grp[1].as<u64>();
+  u64* p0 = e.m_pos[0].as<u64>();
+  u64* p1 = e.m_pos[1].as<u64>();
+  u64* seg_off = e.seg_off.get<u64>(static_cast<size_t>(nr) + 1);
+  {
+    StageTimer t(e, StageTimes::kSegSort);
+    gather_u64_by_u32_kernel<<<div_up(nr + 1, 256), 256, 0, s>>>(e.m_off.as<u64>(), qs.read_off.as<u32>(), seg_off,
+                                                                 nr + 1);
+    RVN_LAUNCH_CHECK();
+    seg_sort_off_kernel<<<div_up(nr, 4), 256, 0, s>>>(g0, g1, p0, p1, seg_off, nr);
+    RVN_LAUNCH_CHECK();
+    t.stop();
+  }
+  u32 NI = 0;
+  const u64 n_slots4 = (H + 3) / 4 + 1;
+  {
+    StageTimer t(e, StageTimes::kIntervals);
+    u64* slot_begin = e.iv_slot_begin.get<u64>(n_slots4 + 1);
+    u64* slot_end = e.iv_slot_end.get<u64>(n_slots4 + 1);
+    u32* iv_cnt = e.iv_cnt.get<u32>(static_cast<size_t>(nr) + 1);
+    u32* iv_off = e.iv_off.get<u32>(static_cast<size_t>(nr) + 2);
+    intervals_kernel<<<div_up(nr, 4), 256, 0, s>>>(g0, seg_off, nr, e.bandwidth, slot_begin, slot_end, iv_cnt);
+    RVN_LAUNCH_CHECK();
+    exclusive_scan_u32_u32(iv_cnt, iv_off, nr, e.scan_tmp, s);
+    RVN_HIP(hipMemcpyAsync(&NI, iv_off + nr, 4, hipMemcpyDeviceToHost, s));
+    RVN_HIP(hipStreamSynchronize(s));
+    out.n_intervals = NI;
+    if (NI) {
+      u64* iv_begin = e.iv_begin.get<u64>(static_cast<size_t>(NI) + 1);
+      u64* iv_end = e.iv_end.get<u64>(static_cast<size_t>(NI) + 1);
+      u32* iv_read = e.tmp_b.get<u32>(static_cast<size_t>(NI) + 1);
+      intervals_gather_kernel<<<div_up(nr, 4), 256, 0, s>>>(slot_begin, slot_end, seg_off, iv_off, nr, iv_begin,
+                                                            iv_end, iv_read);
+      RVN_LAUNCH_CHECK();
+    }
+    t.stop();
+  }
+  if (NI == 0) {
+    RVN_HIP(hipMemsetAsync(ovl_read_off, 0, (static_cast<size_t>(nr) + 1) * 4, s));
+    return;
+  }
+  const u32 slot_div = std::max(1u, std::min(4u, e.chain));
+  const u64 n_slots = (H + slot_div - 1) / slot_div + 1;
+  Overlap* slots = e.ovl_slots.get<Overlap>(n_slots + 1);
+  u8* slot_flags = e.ovl_flags.get<u8>(n_slots + 1);
+  {
+    StageTimer t(e, StageTimes::kChain);
+    u64* iv_begin = e.iv_begin.as<u64>();
+    u64* iv_end = e.iv_end.as<u64>();
+    u32* iv_read = e.tmp_b.as<u32>();
+    // sort every interval by positions (payload = group)
+    seg_sort_be_kernel<<<div_up(NI, 4), 256, 0, s>>>(p0, p1, g0, g1, iv_begin, iv_end, NI, e.chain);
+    RVN_LAUNCH_CHECK();
+    u32* lis_min = e.lis_min.get<u32>(H + NI + 1);
+    u32* lis_pred = e.lis_pred.get<u32>(H + 1);
+    RVN_HIP(hipMemsetAsync(slot_flags, 0, n_slots + 1, s));
+    chain_kernel<<<div_up(NI, 64), 64, 0, s>>>(g0, p0, iv_begin, iv_end, iv_read, NI, r.id.as<u32>(), first, e.k,
+                                               e.chain, e.matches, e.gap, slot_div, lis_min, lis_pred, slots,
+                                               slot_flags);
+    RVN_LAUNCH_CHECK();
+    t.stop();
+  }
+  {
+    StageTimer t(e, StageTimes::kCompact);
+    u32* scan = e.ovl_scan.get<u32>(n_slots + 2);
+    exclusive_scan_u8_u32(slot_flags, scan, n_slots, e.scan_tmp, s);
+    u32 O = 0;
+    RVN_HIP(hipMemcpyAsync(&O, scan + n_slots, 4, hipMemcpyDeviceToHost, s));
+    RVN_HIP(hipStreamSynchronize(s));
+    out.n_overlaps = O;
+    e.c_overlaps += O;
+    Overlap* ovl = out.ovl.get<Overlap>(static_cast<size_t>(O) + 1);
+    compact_overlaps_kernel<<<div_up(n_slots, 256), 256, 0, s>>>(slots, slot_flags, scan, n_slots, ovl);
+    RVN_LAUNCH_CHECK();
+    read_ovl_off_kernel<<<div_up(nr + 1, 256), 256, 0, s>>>(seg_off, scan, slot_div, nr + 1, ovl_read_off);
+    RVN_LAUNCH_CHECK();
+    t.stop();
+  }
+}
+
+}  // namespace
+
+void map_batch(Engine& e, const ReadsDev& r, u32 first, u32 last, bool avoid_equal, bool avoid_symmetric,
+               bool minhash, bool want_filtered, MapOut& out) {
+  if (e.val64) map_batch_impl<u64>(e, r, first, last, avoid_equal, avoid_symmetric, minhash, want_filtered, out);
+  else map_batch_impl<u32>(e, r, first, last, avoid_equal, avoid_symmetric, minhash, want_filtered, out);
+}
+
+}  // namespace rvn

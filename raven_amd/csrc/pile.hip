@@ -1,0 +1,263 @@
+// pile.hip — the serial merge, Pile::AddLayers and the top-kMax truncation of
+// FindOverlapsAndCreatePiles (RavenLib/src/construct.cc:72-113, RavenLib/src/pile.cc:12-62),
+// for one flush of Map results, entirely on the device.
+//
+// Reference order of pile p's list after the merge (construct.cc:72-77, serial, submission order):
+//   kept overlaps (previous flushes, <= kMax, sorted) ++ reverse(o) for every new o with rhs_id == p in
+//   global (query, emission) order ++ new overlaps with lhs_id == p in emission order
+// (avoid_symmetric => lhs_id < rhs_id, so the reversed ones always come from earlier queries).
+// AddLayers then adds coverage of the NEW overlaps only (construct.cc:89-90), and lists that reached
+// kMax are std::sort'ed by length (unstable -> introsort.h) and cut to kMax (construct.cc:92-107).
+//
+// Pile ids must equal read indices (the reference's own invariant, construct.cc:25,74-75).
+#include <algorithm>
+
+#include "engine.h"
+#include "introsort.h"
+#include "wave.h"
+
+namespace rvn {
+
+namespace {
+
+constexpr u32 kPSS = 4;  // pile.h:21
+
+__global__ void rhs_keys_kernel(const Overlap* __restrict__ ovl, u32 n, u32* __restrict__ keys,
+                                u32* __restrict__ idx, u32* __restrict__ in_cnt) {
+  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const u32 r = ovl[i].rhs_id;
+  keys[i] = r;
+  idx[i] = i;
+  atomicAdd(&in_cnt[r], 1u);
+}
+
+// tot[p] = kept + new when the pile has new overlaps, else 0 (list untouched)
+__global__ void pile_counts_kernel(const u32* __restrict__ in_cnt, const u32* __restrict__ ovl_read_off, u32 first,
+                                   u32 last, const u32* __restrict__ kept_off, u32 n, u32 kmax,
+                                   u32* __restrict__ tot, u32* __restrict__ new_kept_cnt) {
+  u32 p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  u32 out = 0;
+  if (p >= first && p < last) out = ovl_read_off[p - first + 1] - ovl_read_off[p - first];
+  const u32 nn = in_cnt[p] + out;
+  const u32 kept = kept_off[p + 1] - kept_off[p];
+  const u32 t = nn ? kept + nn : 0;
+  tot[p] = t;
+  new_kept_cnt[p] = nn ? (t < kmax ? t : kmax) : kept;
+}
+
+__device__ __forceinline__ Overlap reverse_overlap(const Overlap& o) {  // overlap_utils.cc:5-8
+  return Overlap{o.rhs_id, o.rhs_begin, o.rhs_end, o.lhs_id, o.lhs_begin, o.lhs_end, o.score, o.strand};
+}
+__device__ __forceinline__ u32 overlap_length(const Overlap& o) {  // overlap_utils.cc:10-12
+  const u32 a = o.rhs_end - o.rhs_begin, b = o.lhs_end - o.lhs_begin;
+  return a > b ? a : b;
+}
+
+// one wave per pile: build the merged list
+__global__ __launch_bounds__(256) void pile_build_kernel(const Overlap* __restrict__ ovl,
+                                                        const u32* __restrict__ ovl_read_off, u32 first, u32 last,
+                                                        const u32* __restrict__ in_idx_sorted,
+                                                        const u32* __restrict__ in_off,
+                                                        const Overlap* __restrict__ kept,
+                                                        const u32* __restrict__ kept_off,
+                                                        const u32* __restrict__ list_off, u32 n,
+                                                        Overlap* __restrict__ list) {
+  const u32 p = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (p >= n) return;
+  const u32 lb = list_off[p], le = list_off[p + 1];
+  if (le == lb) return;
+  const int lane = lane_id();
+  const u32 kb = kept_off[p], kn = kept_off[p + 1] - kb;
+  const u32 ib = in_off[p], in = in_off[p + 1] - ib;
+  for (u32 i = lane; i < kn; i += 64) list[lb + i] = kept[kb + i];
+  for (u32 i = lane; i < in; i += 64) list[lb + kn + i] = reverse_overlap(ovl[in_idx_sorted[ib + i]]);
+  if (p >= first && p < last) {
+    const u32 ob = ovl_read_off[p - first], on = ovl_read_off[p - first + 1] - ob;
+    for (u32 i = lane; i < on; i += 64) list[lb + kn + in + i] = ovl[ob + i];
+  }
+}
+
+// Pile::AddLayers (pile.cc:33-62) as an order-free per-cell sum: coverage(cell) = #{begin events <= cell}
+// - #{end events <= cell} in uint32 wrap-around arithmetic, data = clamp(data + coverage).
+// One workgroup per pile; events staged in LDS in chunks.
+constexpr int kEvChunk = 1024;
+__global__ __launch_bounds__(256) void add_layers_kernel(const Overlap* __restrict__ list,
+                                                        const u32* __restrict__ list_off,
+                                                        const u32* __restrict__ kept_off,
+                                                        const u64* __restrict__ pile_off,
+                                                        const u32* __restrict__ ids, u16* __restrict__ data) {
+  __shared__ u32 ev_b[kEvChunk];
+  __shared__ u32 ev_e[kEvChunk];
+  const u32 p = blockIdx.x;
+  const u32 lb = list_off[p], le = list_off[p + 1];
+  if (le == lb) return;
+  const u32 kn = kept_off[p + 1] - kept_off[p];
+  const u32 nb = lb + kn;  // first new overlap
+  const u32 nn = le - nb;
+  const u32 id = ids[p];
+  const u64 d0 = pile_off[p];
+  const u32 cells = static_cast<u32>(pile_off[p + 1] - d0);
+  for (u32 c0 = 0; c0 < nn; c0 += kEvChunk) {
+    const u32 cn = min(static_cast<u32>(kEvChunk), nn - c0);
+    __syncthreads();
+    for (u32 i = threadIdx.x; i < cn; i += 256) {
+      const Overlap o = list[nb + c0 + i];
+      u32 b = 0xFFFFFFFFu, e = 0xFFFFFFFFu;  // "never reached" for overlaps touching neither side
+      if (o.lhs_id == id) {
+        b = (o.lhs_begin >> kPSS) + 1;
+        e = (o.lhs_end >> kPSS) - 1;
+      } else if (o.rhs_id == id) {
+        b = (o.rhs_begin >> kPSS) + 1;
+        e = (o.rhs_end >> kPSS) - 1;
+      }
+      // the reference stores events as (x << 1 | flag) in 32 bits and compares x = event >> 1
+      ev_b[i] = (b << 1) >> 1;
+      ev_e[i] = ((e << 1) | 1u) >> 1;
+      if (o.lhs_id != id && o.rhs_id != id) ev_b[i] = ev_e[i] = 0xFFFFFFFFu;
+    }
+    __syncthreads();
+    for (u32 cell = threadIdx.x; cell < cells; cell += 256) {
+      u32 cov = 0;
+      for (u32 i = 0; i < cn; ++i) {
+        cov += (ev_b[i] <= cell) ? 1u : 0u;
+        cov -= (ev_e[i] <= cell) ? 1u : 0u;
+      }
+      if (cov) {
+        const u32 v = static_cast<u32>(data[d0 + cell]) + cov;
+        data[d0 + cell] = static_cast<u16>(v < 65535u ? v : 65535u);
+      }
+    }
+  }
+}
+
+// one lane per pile: exact std::sort on (length << 32 | local index), top-kMax
+__global__ void truncate_sort_kernel(const Overlap* __restrict__ list, const u32* __restrict__ list_off, u32 n,
+                                     u32 kmax, u64* __restrict__ keys) {
+  u32 p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const u32 lb = list_off[p], t = list_off[p + 1] - lb;
+  if (t == 0) return;
+  u64* kk = keys + lb;
+  for (u32 i = 0; i < t; ++i) kk[i] = (static_cast<u64>(overlap_length(list[lb + i])) << 32) | i;
+  if (t >= kmax) std_sort(kk, kk + t, LenDesc());
+}
+
+// one wave per pile: write the new kept list
+__global__ __launch_bounds__(256) void kept_write_kernel(const Overlap* __restrict__ list,
+                                                        const u32* __restrict__ list_off,
+                                                        const u64* __restrict__ keys,
+                                                        const Overlap* __restrict__ kept_old,
+                                                        const u32* __restrict__ kept_off_old,
+                                                        const u32* __restrict__ kept_off_new, u32 n,
+                                                        Overlap* __restrict__ kept_new) {
+  const u32 p = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (p >= n) return;
+  const int lane = lane_id();
+  const u32 nb = kept_off_new[p], nn = kept_off_new[p + 1] - nb;
+  const u32 lb = list_off[p], t = list_off[p + 1] - lb;
+  if (t == 0) {
+    const u32 ob = kept_off_old[p];
+    for (u32 i = lane; i < nn; i += 64) kept_new[nb + i] = kept_old[ob + i];
+  } else {
+    for (u32 i = lane; i < nn; i += 64) kept_new[nb + i] = list[lb + static_cast<u32>(keys[lb + i])];
+  }
+}
+
+}  // namespace
+
+void piles_init(Engine& e, const ReadsDev& r, PileState& ps) {
+  ps.n = r.n;
+  std::vector<u64> off(static_cast<size_t>(r.n) + 1, 0);
+  for (u32 i = 0; i < r.n; ++i) off[i + 1] = off[i] + (r.h_len[i] >> kPSS);
+  ps.pile_words = off[r.n];
+  u64* d_off = ps.pile_off.get<u64>(off.size());
+  RVN_HIP(hipMemcpyAsync(d_off, off.data(), off.size() * 8, hipMemcpyHostToDevice, e.stream));
+  u16* d = ps.pile_data.get<u16>(ps.pile_words + 1);
+  RVN_HIP(hipMemsetAsync(d, 0, (ps.pile_words + 1) * 2, e.stream));
+  u32* ko = ps.kept_off.get<u32>(static_cast<size_t>(r.n) + 1);
+  RVN_HIP(hipMemsetAsync(ko, 0, (static_cast<size_t>(r.n) + 1) * 4, e.stream));
+  ps.kept.reserve(64);
+  ps.kept_total = 0;
+  RVN_HIP(hipStreamSynchronize(e.stream));  // `off` is a stack-owned host buffer
+}
+
+void pile_add_layers_single(Engine& e, PileState& ps, const u32* d_ids, const Overlap* h_ovl, u32 n) {
+  hipStream_t s = e.stream;
+  Overlap* list = ps.new_list.get<Overlap>(static_cast<size_t>(n) + 1);
+  RVN_HIP(hipMemcpyAsync(list, h_ovl, static_cast<size_t>(n) * sizeof(Overlap), hipMemcpyHostToDevice, s));
+  u32* offs = ps.tmp3.get<u32>(4);
+  const u32 h_offs[4] = {0, n, 0, 0};  // list_off = {0, n}; kept_off = {0, 0}
+  RVN_HIP(hipMemcpyAsync(offs, h_offs, sizeof(h_offs), hipMemcpyHostToDevice, s));
+  add_layers_kernel<<<1, 256, 0, s>>>(list, offs, offs + 2, ps.pile_off.as<u64>(), d_ids, ps.pile_data.as<u16>());
+  RVN_LAUNCH_CHECK();
+  RVN_HIP(hipStreamSynchronize(s));
+}
+
+void piles_merge(Engine& e, const ReadsDev& r, const MapOut& mo, u32 kmax, PileState& ps) {
+  const u32 O = static_cast<u32>(mo.n_overlaps);
+  if (O == 0) return;
+  hipStream_t s = e.stream;
+  const u32 n = ps.n;
+  const Overlap* ovl = mo.ovl.as<Overlap>();
+  const u32* ovl_read_off = mo.ovl_read_off.as<u32>();
+
+  StageTimer tm(e, StageTimes::kMerge);
+  u32* keys0 = ps.tmp1.get<u32>(static_cast<size_t>(O) * 2 + 2);
+  u32* keys1 = keys0 + O + 1;
+  u32* idx0 = ps.tmp2.get<u32>(static_cast<size_t>(O) * 2 + 2);
+  u32* idx1 = idx0 + O + 1;
+  // tmp3: in_cnt[n+1], in_off[n+1], tot[n+1], list_off[n+1], new_kept_cnt[n+1], new_kept_off[n+1]
+  const size_t stride = static_cast<size_t>(n) + 2;
+  u32* base = ps.tmp3.get<u32>(stride * 6);
+  u32 *in_cnt = base, *in_off = base + stride, *tot = base + 2 * stride, *list_off = base + 3 * stride,
+      *new_kept_cnt = base + 4 * stride, *new_kept_off = base + 5 * stride;
+  RVN_HIP(hipMemsetAsync(in_cnt, 0, stride * 4, s));
+  rhs_keys_kernel<<<div_up(O, 256), 256, 0, s>>>(ovl, O, keys0, idx0, in_cnt);
+  RVN_LAUNCH_CHECK();
+  const int cur = radix_sort_pairs_u32_u32(keys0, keys1, idx0, idx1, O, 32, e.sort_tmp, e.scan_tmp, s);
+  const u32* in_idx_sorted = cur ? idx1 : idx0;
+  exclusive_scan_u32_u32(in_cnt, in_off, n, e.scan_tmp, s);
+  pile_counts_kernel<<<div_up(n, 256), 256, 0, s>>>(in_cnt, ovl_read_off, mo.first, mo.last, ps.kept_off.as<u32>(), n,
+                                                    kmax, tot, new_kept_cnt);
+  RVN_LAUNCH_CHECK();
+  exclusive_scan_u32_u32(tot, list_off, n, e.scan_tmp, s);
+  exclusive_scan_u32_u32(new_kept_cnt, new_kept_off, n, e.scan_tmp, s);
+  u32 totals[2] = {0, 0};
+  RVN_HIP(hipMemcpyAsync(&totals[0], list_off + n, 4, hipMemcpyDeviceToHost, s));
+  RVN_HIP(hipMemcpyAsync(&totals[1], new_kept_off + n, 4, hipMemcpyDeviceToHost, s));
+  RVN_HIP(hipStreamSynchronize(s));
+  const u32 L = totals[0], K = totals[1];
+  Overlap* list = ps.new_list.get<Overlap>(static_cast<size_t>(L) + 1);
+  pile_build_kernel<<<div_up(n, 4), 256, 0, s>>>(ovl, ovl_read_off, mo.first, mo.last, in_idx_sorted, in_off,
+                                                 ps.kept.as<Overlap>(), ps.kept_off.as<u32>(), list_off, n, list);
+  RVN_LAUNCH_CHECK();
+  tm.stop();
+  {
+    StageTimer t(e, StageTimes::kPile);
+    add_layers_kernel<<<n, 256, 0, s>>>(list, list_off, ps.kept_off.as<u32>(), ps.pile_off.as<u64>(),
+                                        r.id.as<u32>(), ps.pile_data.as<u16>());
+    RVN_LAUNCH_CHECK();
+    t.stop();
+  }
+  {
+    StageTimer t(e, StageTimes::kTruncate);
+    u64* skeys = ps.tmp4.get<u64>(static_cast<size_t>(L) + 1);
+    truncate_sort_kernel<<<div_up(n, 64), 64, 0, s>>>(list, list_off, n, kmax, skeys);
+    RVN_LAUNCH_CHECK();
+    Overlap* kept_new = ps.tmp5.get<Overlap>(static_cast<size_t>(K) + 1);
+    kept_write_kernel<<<div_up(n, 4), 256, 0, s>>>(list, list_off, skeys, ps.kept.as<Overlap>(),
+                                                   ps.kept_off.as<u32>(), new_kept_off, n, kept_new);
+    RVN_LAUNCH_CHECK();
+    // adopt: kept <- kept_new, kept_off <- new_kept_off
+    std::swap(ps.kept.ptr, ps.tmp5.ptr);
+    std::swap(ps.kept.cap, ps.tmp5.cap);
+    u32* ko = ps.kept_off.get<u32>(static_cast<size_t>(n) + 1);
+    RVN_HIP(hipMemcpyAsync(ko, new_kept_off, (static_cast<size_t>(n) + 1) * 4, hipMemcpyDeviceToDevice, s));
+    ps.kept_total = K;
+    t.stop();
+  }
+}
+
+}  // namespace rvn

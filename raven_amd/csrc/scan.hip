@@ -1,0 +1,110 @@
+// scan.hip — device-wide exclusive prefix sums (three-kernel reduce / scan / downsweep).
+// HBM-bound: reads the input twice, writes the output once.
+#include "common.h"
+#include "wave.h"
+
+namespace rvn {
+
+namespace {
+
+constexpr int kScanThreads = 256;
+constexpr int kScanItems = 16;  // per thread
+constexpr int kScanTile = kScanThreads * kScanItems;
+
+template <typename In>
+__global__ __launch_bounds__(kScanThreads) void scan_reduce_kernel(const In* __restrict__ in, u64 n,
+                                                                  u64* __restrict__ block_sums) {
+  __shared__ u64 smem[4];
+  const u64 base = static_cast<u64>(blockIdx.x) * kScanTile;
+  u64 sum = 0;
+#pragma unroll
+  for (int i = 0; i < kScanItems; ++i) {
+    u64 idx = base + static_cast<u64>(i) * kScanThreads + threadIdx.x;
+    if (idx < n) sum += in[idx];
+  }
+  sum = wave_sum(sum);
+  if (lane_id() == 0) smem[threadIdx.x >> 6] = sum;
+  __syncthreads();
+  if (threadIdx.x == 0) block_sums[blockIdx.x] = smem[0] + smem[1] + smem[2] + smem[3];
+}
+
+// Single block: in-place exclusive scan of block sums; total written to sums[nb].
+__global__ __launch_bounds__(kScanThreads) void scan_block_sums_kernel(u64* __restrict__ sums, u32 nb) {
+  __shared__ u64 smem[4];
+  __shared__ u64 carry_s;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  for (u32 start = 0; start < nb; start += kScanThreads) {
+    u32 idx = start + threadIdx.x;
+    u64 v = idx < nb ? sums[idx] : 0;
+    u64 total;
+    u64 ex = block_exclusive_sum_256<u64>(v, smem, &total);
+    u64 carry = carry_s;
+    if (idx < nb) sums[idx] = carry + ex;
+    __syncthreads();
+    if (threadIdx.x == 0) carry_s = carry + total;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) sums[nb] = carry_s;
+}
+
+template <typename In, typename Out>
+__global__ __launch_bounds__(kScanThreads) void scan_downsweep_kernel(const In* __restrict__ in, Out* __restrict__ out,
+                                                                     u64 n, const u64* __restrict__ block_sums,
+                                                                     u32 nb) {
+  __shared__ u64 smem[4];
+  // blocked arrangement: thread t owns items [t*16, t*16+16) of the tile
+  const u64 base = static_cast<u64>(blockIdx.x) * kScanTile + static_cast<u64>(threadIdx.x) * kScanItems;
+  u64 vals[kScanItems];
+  u64 sum = 0;
+#pragma unroll
+  for (int i = 0; i < kScanItems; ++i) {
+    u64 idx = base + i;
+    vals[i] = idx < n ? static_cast<u64>(in[idx]) : 0;
+    sum += vals[i];
+  }
+  u64 total;
+  u64 ex = block_exclusive_sum_256<u64>(sum, smem, &total);
+  u64 run = block_sums[blockIdx.x] + ex;
+#pragma unroll
+  for (int i = 0; i < kScanItems; ++i) {
+    u64 idx = base + i;
+    if (idx < n) out[idx] = static_cast<Out>(run);
+    run += vals[i];
+  }
+  if (blockIdx.x == nb - 1 && threadIdx.x == 0) out[n] = static_cast<Out>(block_sums[nb]);
+}
+
+template <typename Out>
+__global__ void scan_empty_kernel(Out* out) { out[0] = 0; }
+
+template <typename In, typename Out>
+void exclusive_scan_impl(const In* in, Out* out, u64 n, DevBuf& tmp, hipStream_t s) {
+  if (n == 0) {
+    scan_empty_kernel<Out><<<1, 1, 0, s>>>(out);
+    RVN_LAUNCH_CHECK();
+    return;
+  }
+  u32 nb = div_up(n, kScanTile);
+  u64* sums = tmp.get<u64>(static_cast<size_t>(nb) + 1);
+  scan_reduce_kernel<In><<<nb, kScanThreads, 0, s>>>(in, n, sums);
+  RVN_LAUNCH_CHECK();
+  scan_block_sums_kernel<<<1, kScanThreads, 0, s>>>(sums, nb);
+  RVN_LAUNCH_CHECK();
+  scan_downsweep_kernel<In, Out><<<nb, kScanThreads, 0, s>>>(in, out, n, sums, nb);
+  RVN_LAUNCH_CHECK();
+}
+
+}  // namespace
+
+void exclusive_scan_u32_u64(const u32* in, u64* out, u64 n, DevBuf& tmp, hipStream_t s) {
+  exclusive_scan_impl<u32, u64>(in, out, n, tmp, s);
+}
+void exclusive_scan_u32_u32(const u32* in, u32* out, u64 n, DevBuf& tmp, hipStream_t s) {
+  exclusive_scan_impl<u32, u32>(in, out, n, tmp, s);
+}
+void exclusive_scan_u8_u32(const u8* in, u32* out, u64 n, DevBuf& tmp, hipStream_t s) {
+  exclusive_scan_impl<u8, u32>(in, out, n, tmp, s);
+}
+
+}  // namespace rvn

@@ -1,0 +1,275 @@
+"""ctypes binding of libraven_hip.so (the C ABI in include/raven_hip.h).
+
+This is the product path: it fails loudly when the HIP extension is missing or
+no GPU is present — there is no CPU fallback (the CPU oracle lives in oracle/
+and is test infrastructure only).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libraven_hip.so")
+
+OVERLAP_DTYPE = np.dtype([
+    ("lhs_id", "<u4"), ("lhs_begin", "<u4"), ("lhs_end", "<u4"),
+    ("rhs_id", "<u4"), ("rhs_begin", "<u4"), ("rhs_end", "<u4"),
+    ("score", "<u4"), ("strand", "<u4")])
+
+RVN_OK, RVN_EINVAL, RVN_ENODEVICE, RVN_EHIP, RVN_ENOMEM = 0, -1, -2, -3, -4
+
+# every symbol include/raven_hip.h declares (checked by tests/test_abi.py)
+SYMBOLS = [
+    "rvn_last_error", "rvn_device_count", "rvn_engine_create", "rvn_engine_destroy", "rvn_reads_upload",
+    "rvn_reads_destroy", "rvn_engine_minimize", "rvn_engine_filter", "rvn_engine_occurrence",
+    "rvn_engine_map_batch", "rvn_engine_map_fetch", "rvn_engine_map_fetch_filtered",
+    "rvn_find_overlaps_and_create_piles", "rvn_pass1_pile_words", "rvn_pass1_num_overlaps",
+    "rvn_pass1_fetch_piles", "rvn_pass1_fetch_overlaps", "rvn_pass1_destroy", "rvn_pile_add_layers",
+    "rvn_engine_sketch", "rvn_engine_sketch_fetch", "rvn_engine_index_size", "rvn_engine_index_fetch",
+    "rvn_engine_counters", "rvn_engine_num_stages", "rvn_engine_stage_name", "rvn_engine_stage_ms",
+    "rvn_engine_reset_stats", "rvn_engine_set_timing", "rvn_test_hash", "rvn_test_canonical",
+    "rvn_test_std_sort_lendesc", "rvn_test_heap_sort_lendesc",
+]
+
+
+class RavenHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Load libraven_hip.so; raises (never falls back) when it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RavenHipError(
+            "libraven_hip.so not built (%s): run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or raven_amd/csrc/build.sh" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, u32, u64, i32, dbl = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int, C.c_double
+    pp = C.POINTER(C.c_void_p)
+    L.rvn_last_error.restype = C.c_char_p
+    L.rvn_device_count.restype = i32
+    L.rvn_engine_create.argtypes = [pp, u32, u32, u32, u32, u32, u32, i32]
+    L.rvn_engine_destroy.argtypes = [vp]
+    L.rvn_reads_upload.argtypes = [vp, vp, u64, vp, vp, vp, u32, pp]
+    L.rvn_reads_destroy.argtypes = [vp]
+    L.rvn_engine_minimize.argtypes = [vp, vp, u32, u32, i32]
+    L.rvn_engine_filter.argtypes = [vp, dbl]
+    L.rvn_engine_occurrence.restype = u32
+    L.rvn_engine_occurrence.argtypes = [vp]
+    L.rvn_engine_map_batch.argtypes = [vp, vp, u32, u32, i32, i32, i32, i32, C.POINTER(u64)]
+    L.rvn_engine_map_fetch.argtypes = [vp, vp, vp]
+    L.rvn_engine_map_fetch_filtered.argtypes = [vp, vp, vp, C.POINTER(u64)]
+    L.rvn_find_overlaps_and_create_piles.argtypes = [vp, vp, dbl, u32, i32, u64, u64, pp]
+    L.rvn_pass1_pile_words.restype = u64
+    L.rvn_pass1_pile_words.argtypes = [vp]
+    L.rvn_pass1_num_overlaps.restype = u64
+    L.rvn_pass1_num_overlaps.argtypes = [vp]
+    L.rvn_pass1_fetch_piles.argtypes = [vp, vp, vp]
+    L.rvn_pass1_fetch_overlaps.argtypes = [vp, vp, vp]
+    L.rvn_pass1_destroy.argtypes = [vp]
+    L.rvn_pile_add_layers.argtypes = [vp, vp, u32, u32, vp, u64]
+    L.rvn_engine_sketch.argtypes = [vp, vp, u32, u32, i32, C.POINTER(u64)]
+    L.rvn_engine_sketch_fetch.argtypes = [vp, vp, vp, vp]
+    L.rvn_engine_index_size.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
+    L.rvn_engine_index_fetch.argtypes = [vp, vp, vp]
+    L.rvn_engine_counters.argtypes = [vp, vp]
+    L.rvn_engine_num_stages.restype = i32
+    L.rvn_engine_stage_name.restype = C.c_char_p
+    L.rvn_engine_stage_name.argtypes = [i32]
+    L.rvn_engine_stage_ms.argtypes = [vp, vp, vp, i32]
+    L.rvn_engine_reset_stats.argtypes = [vp]
+    L.rvn_engine_set_timing.argtypes = [vp, i32]
+    L.rvn_test_hash.restype = u64
+    L.rvn_test_hash.argtypes = [u64, u32, i32]
+    L.rvn_test_canonical.restype = i32
+    L.rvn_test_canonical.argtypes = [vp, u32, u32, i32, C.POINTER(u64), C.POINTER(u32)]
+    L.rvn_test_std_sort_lendesc.argtypes = [vp, u64]
+    L.rvn_test_heap_sort_lendesc.argtypes = [vp, u64]
+    _lib = L
+    return L
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _check(rc):
+    if rc != RVN_OK:
+        msg = lib().rvn_last_error().decode(errors="replace")
+        if rc == RVN_EINVAL:
+            raise ValueError(msg)
+        raise RavenHipError("rc=%d: %s" % (rc, msg))
+
+
+def device_count() -> int:
+    return int(lib().rvn_device_count())
+
+
+class Reads:
+    def __init__(self, engine: "Engine", rs):
+        self.rs = rs
+        self.engine = engine
+        h = C.c_void_p()
+        packed = np.ascontiguousarray(rs.packed, dtype=np.uint64)
+        n_words = int(rs.word_offsets[-1])
+        _check(lib().rvn_reads_upload(engine._h, _p(packed), n_words,
+                                      _p(np.ascontiguousarray(rs.word_offsets, dtype=np.uint64)),
+                                      _p(np.ascontiguousarray(rs.lengths, dtype=np.uint32)),
+                                      _p(np.ascontiguousarray(rs.ids, dtype=np.uint32)), rs.n, C.byref(h)))
+        self._h = h
+
+    @property
+    def n(self):
+        return self.rs.n
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().rvn_reads_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+
+class Pass1:
+    def __init__(self, h, n):
+        self._h = h
+        self.n = n
+
+    def piles(self):
+        L = lib()
+        words = int(L.rvn_pass1_pile_words(self._h))
+        data = np.zeros(words, dtype=np.uint16)
+        off = np.zeros(self.n + 1, dtype=np.uint64)
+        _check(L.rvn_pass1_fetch_piles(self._h, _p(data), _p(off)))
+        return data, off
+
+    def overlaps(self):
+        L = lib()
+        n = int(L.rvn_pass1_num_overlaps(self._h))
+        ovl = np.zeros(n, dtype=OVERLAP_DTYPE)
+        off = np.zeros(self.n + 1, dtype=np.uint32)
+        _check(L.rvn_pass1_fetch_overlaps(self._h, _p(ovl), _p(off)))
+        return ovl, off
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().rvn_pass1_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+
+class Engine:
+    """Mirror of ram::MinimizerEngine over the C ABI (defaults as in ram)."""
+
+    def __init__(self, k=15, w=5, bandwidth=500, chain=4, matches=100, gap=10000, device=0):
+        self.k, self.w = min(max(k, 1), 31), w
+        h = C.c_void_p()
+        _check(lib().rvn_engine_create(C.byref(h), k, w, bandwidth, chain, matches, gap, device))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().rvn_engine_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def upload(self, rs) -> Reads:
+        return Reads(self, rs)
+
+    # -- ram::MinimizerEngine interface -----------------------------------------------------
+    def minimize(self, reads: Reads, first=0, last=None, minhash=False):
+        last = reads.n if last is None else last
+        _check(lib().rvn_engine_minimize(self._h, reads._h, first, last, int(minhash)))
+
+    def filter(self, f):
+        _check(lib().rvn_engine_filter(self._h, float(f)))
+
+    @property
+    def occurrence(self):
+        return int(lib().rvn_engine_occurrence(self._h))
+
+    def map_batch(self, reads: Reads, first=0, last=None, avoid_equal=True, avoid_symmetric=True, minhash=False,
+                  want_filtered=False):
+        last = reads.n if last is None else last
+        n = C.c_uint64(0)
+        _check(lib().rvn_engine_map_batch(self._h, reads._h, first, last, int(avoid_equal), int(avoid_symmetric),
+                                          int(minhash), int(want_filtered), C.byref(n)))
+        ovl = np.zeros(n.value, dtype=OVERLAP_DTYPE)
+        off = np.zeros(last - first + 1, dtype=np.uint32)
+        _check(lib().rvn_engine_map_fetch(self._h, _p(ovl), _p(off)))
+        res = dict(overlaps=ovl, read_offsets=off)
+        if want_filtered:
+            tot = C.c_uint64(0)
+            _check(lib().rvn_engine_map_fetch_filtered(self._h, None, None, C.byref(tot)))
+            pos = np.zeros(tot.value, dtype=np.uint32)
+            foff = np.zeros(last - first + 1, dtype=np.uint32)
+            _check(lib().rvn_engine_map_fetch_filtered(self._h, _p(pos), _p(foff), C.byref(tot)))
+            res["filtered"] = pos
+            res["filtered_offsets"] = foff
+        return res
+
+    # -- raven::FindOverlapsAndCreatePiles ---------------------------------------------------
+    def find_overlaps_and_create_piles(self, reads: Reads, freq=0.001, kmax=32, use_minhash=False,
+                                       index_batch_bases=1 << 32, flush_bases=1 << 30) -> Pass1:
+        h = C.c_void_p()
+        _check(lib().rvn_find_overlaps_and_create_piles(self._h, reads._h, float(freq), kmax, int(use_minhash),
+                                                        index_batch_bases, flush_bases, C.byref(h)))
+        return Pass1(h, reads.n)
+
+    def pile_add_layers(self, data: np.ndarray, pile_id: int, overlaps: np.ndarray):
+        assert data.dtype == np.uint16 and overlaps.dtype == OVERLAP_DTYPE
+        overlaps = np.ascontiguousarray(overlaps)
+        _check(lib().rvn_pile_add_layers(self._h, _p(data), data.shape[0], pile_id, _p(overlaps),
+                                         overlaps.shape[0]))
+
+    # -- introspection ---------------------------------------------------------------------
+    def sketch(self, reads: Reads, first=0, last=None, minhash=False):
+        last = reads.n if last is None else last
+        cnt = C.c_uint64(0)
+        _check(lib().rvn_engine_sketch(self._h, reads._h, first, last, int(minhash), C.byref(cnt)))
+        v = np.zeros(cnt.value, dtype=np.uint64)
+        o = np.zeros(cnt.value, dtype=np.uint64)
+        off = np.zeros(last - first + 1, dtype=np.uint32)
+        _check(lib().rvn_engine_sketch_fetch(self._h, _p(v), _p(o), _p(off)))
+        return v, o, off
+
+    def index_content(self):
+        m, u = C.c_uint64(0), C.c_uint64(0)
+        _check(lib().rvn_engine_index_size(self._h, C.byref(m), C.byref(u)))
+        v = np.zeros(m.value, dtype=np.uint64)
+        o = np.zeros(m.value, dtype=np.uint64)
+        _check(lib().rvn_engine_index_fetch(self._h, _p(v), _p(o)))
+        return v, o, int(u.value)
+
+    def counters(self):
+        c = np.zeros(8, dtype=np.uint64)
+        _check(lib().rvn_engine_counters(self._h, _p(c)))
+        return dict(zip(("index_bases", "index_minimizers", "index_keys", "query_bases", "query_minimizers",
+                         "matches", "overlaps", "intervals"), (int(x) for x in c)))
+
+    def stage_ms(self):
+        L = lib()
+        n = L.rvn_engine_num_stages()
+        ms = np.zeros(n, dtype=np.float64)
+        la = np.zeros(n, dtype=np.uint64)
+        _check(L.rvn_engine_stage_ms(self._h, _p(ms), _p(la), n))
+        return {L.rvn_engine_stage_name(i).decode(): (float(ms[i]), int(la[i])) for i in range(n)}
+
+    def reset_stats(self):
+        lib().rvn_engine_reset_stats(self._h)
+
+    def set_timing(self, enabled: bool):
+        lib().rvn_engine_set_timing(self._h, int(enabled))

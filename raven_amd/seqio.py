@@ -1,0 +1,143 @@
+"""Host-side sequence plumbing: FASTA/FASTQ(.gz) parsing and biosoup-style 2-bit packing.
+
+Mirrors what the reference gets from bioparser + biosoup::NucleicAcid (io.cc:7-41,
+SURVEY §8 a6): 32 bases per uint64, base i at bits (2i mod 64) LSB-first,
+A=0 C=1 G=2 T=3, IUPAC folded to 0..3, anything else -> ValueError
+(biosoup throws std::invalid_argument).  Every read starts on a word boundary.
+"""
+from __future__ import annotations
+
+import gzip
+from dataclasses import dataclass
+
+import numpy as np
+
+# biosoup coder table
+_CODER = np.full(256, 255, dtype=np.uint8)
+for _chars, _code in (("AaDdNnRrWw-", 0), ("CcBbMmSs", 1), ("GgKkVv", 2), ("TtUuHhYy", 3)):
+    for _c in _chars:
+        _CODER[ord(_c)] = _code
+
+_DECODER = np.frombuffer(b"ACGT", dtype=np.uint8)
+
+
+@dataclass
+class ReadSet:
+    """Concatenated 2-bit packed reads (host memory)."""
+
+    packed: np.ndarray  # uint64 words, all reads concatenated
+    word_offsets: np.ndarray  # uint64[n+1], word index where read i starts
+    lengths: np.ndarray  # uint32[n]
+    ids: np.ndarray  # uint32[n]
+    names: list | None = None
+    qualities: list | None = None  # optional list of uint8 arrays (Phred+33 removed)
+
+    @property
+    def n(self) -> int:
+        return int(self.lengths.shape[0])
+
+    @property
+    def total_bases(self) -> int:
+        return int(self.lengths.astype(np.uint64).sum())
+
+    def codes(self, i: int) -> np.ndarray:
+        """2-bit codes of read i as uint8 array."""
+        w = self.packed[int(self.word_offsets[i]): int(self.word_offsets[i + 1])]
+        n = int(self.lengths[i])
+        shifts = (np.arange(32, dtype=np.uint64) * np.uint64(2))
+        c = ((w[:, None] >> shifts[None, :]) & np.uint64(3)).astype(np.uint8).reshape(-1)
+        return c[:n]
+
+    def inflate(self, i: int) -> bytes:
+        return _DECODER[self.codes(i)].tobytes()
+
+
+def encode(seq: bytes | str) -> np.ndarray:
+    if isinstance(seq, str):
+        seq = seq.encode()
+    codes = _CODER[np.frombuffer(seq, dtype=np.uint8)]
+    if codes.size and codes.max() == 255:
+        raise ValueError("[raven_amd::seqio] error: invalid character in sequence")
+    return codes
+
+
+def pack_codes(codes: np.ndarray) -> np.ndarray:
+    """uint8 codes (0..3) -> uint64 words, LSB-first."""
+    n = codes.shape[0]
+    nw = (n + 31) // 32
+    buf = np.zeros(nw * 32, dtype=np.uint64)
+    buf[:n] = codes
+    buf = buf.reshape(nw, 32)
+    shifts = (np.arange(32, dtype=np.uint64) * np.uint64(2))
+    return np.bitwise_or.reduce(buf << shifts[None, :], axis=1)
+
+
+def pack_reads(code_arrays, ids=None, names=None, qualities=None) -> ReadSet:
+    lengths = np.array([c.shape[0] for c in code_arrays], dtype=np.uint32)
+    nwords = (lengths.astype(np.uint64) + np.uint64(31)) // np.uint64(32)
+    word_offsets = np.zeros(len(code_arrays) + 1, dtype=np.uint64)
+    np.cumsum(nwords, out=word_offsets[1:])
+    packed = np.zeros(int(word_offsets[-1]) + 1, dtype=np.uint64)  # +1 pad word for device over-read
+    for i, c in enumerate(code_arrays):
+        packed[int(word_offsets[i]): int(word_offsets[i + 1])] = pack_codes(c)
+    if ids is None:
+        ids = np.arange(len(code_arrays), dtype=np.uint32)
+    return ReadSet(packed, word_offsets, lengths, np.asarray(ids, dtype=np.uint32), names, qualities)
+
+
+def _open(path):
+    return gzip.open(path, "rb") if str(path).endswith(".gz") else open(path, "rb")
+
+
+def parse_fastq(path, limit: int | None = None):
+    names, seqs, quals = [], [], []
+    with _open(path) as f:
+        while True:
+            h = f.readline()
+            if not h:
+                break
+            s = f.readline().rstrip(b"\r\n")
+            f.readline()
+            q = f.readline().rstrip(b"\r\n")
+            names.append(h[1:].split()[0].decode())
+            seqs.append(s)
+            quals.append(np.frombuffer(q, dtype=np.uint8) - 33)
+            if limit is not None and len(seqs) >= limit:
+                break
+    return names, seqs, quals
+
+
+def parse_fasta(path, limit: int | None = None):
+    names, seqs = [], []
+    cur = []
+    with _open(path) as f:
+        for line in f:
+            if line.startswith(b">"):
+                if cur or names:
+                    seqs.append(b"".join(cur))
+                    cur = []
+                    if limit is not None and len(seqs) >= limit:
+                        names = names[:limit]
+                        return names, seqs
+                names.append(line[1:].split()[0].decode())
+            else:
+                cur.append(line.strip())
+    if names:
+        seqs.append(b"".join(cur))
+    return names, seqs
+
+
+def load_reads(path, limit: int | None = None) -> ReadSet:
+    """Extension sniffing as in io.cc:7-41."""
+    p = str(path)
+    base = p[:-3] if p.endswith(".gz") else p
+    if base.endswith((".fastq", ".fq")):
+        names, seqs, quals = parse_fastq(p, limit)
+    elif base.endswith((".fasta", ".fa")):
+        names, seqs = parse_fasta(p, limit)
+        quals = None
+    else:
+        raise ValueError(
+            "[raven_amd::seqio] error: file %s has unsupported format extension "
+            "(valid extensions: .fasta, .fasta.gz, .fa, .fa.gz, .fastq, .fastq.gz, .fq, .fq.gz)" % p)
+    return pack_reads([encode(s) for s in seqs], names=names, qualities=quals)

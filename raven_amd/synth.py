@@ -1,0 +1,108 @@
+"""Seeded synthetic genomes and long reads (BASELINE.json configs).
+
+Genome: iid uniform ACGT.  ONT-like reads: source segment sampled uniformly,
+strand Bernoulli(1/2), iid per-base errors (default 4 % sub, 3 % ins, 3 % del).
+Everything is numpy-vectorised in chunks of reads so the 1.5e8-base C2 set is
+generated in seconds.  Returns a packed `ReadSet` plus the truth table
+(start, source length, strand) used by sanity tests.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .seqio import ReadSet
+
+
+def make_genome(n_bases: int, seed: int = 0x5EED0001) -> np.ndarray:
+    rng = np.random.Generator(np.random.PCG64(seed))
+    return rng.integers(0, 4, size=n_bases, dtype=np.uint8)
+
+
+def _pack_many(codes: np.ndarray, lengths: np.ndarray):
+    """Pack concatenated codes of many reads, each read word-aligned."""
+    n = lengths.shape[0]
+    nwords = (lengths.astype(np.int64) + 31) // 32
+    word_off = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(nwords, out=word_off[1:])
+    base_off = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(lengths.astype(np.int64), out=base_off[1:])
+    # destination slot (in bases, word-aligned per read) of every base
+    read_of = np.repeat(np.arange(n, dtype=np.int64), lengths.astype(np.int64))
+    within = np.arange(codes.shape[0], dtype=np.int64) - base_off[read_of]
+    slot = word_off[read_of] * 32 + within
+    buf = np.zeros(int(word_off[-1]) * 32, dtype=np.uint64)
+    buf[slot] = codes
+    buf = buf.reshape(-1, 32)
+    shifts = np.arange(32, dtype=np.uint64) * np.uint64(2)
+    words = np.bitwise_or.reduce(buf << shifts[None, :], axis=1)
+    return words, word_off
+
+
+def make_reads(genome: np.ndarray, coverage: float, read_len: int = 10000, *, length_model: str = "fixed",
+               sub: float = 0.04, ins: float = 0.03, dele: float = 0.03, seed: int = 0x5EED0002,
+               chunk_reads: int = 512, min_len: int = 1000, max_len: int = 60000, sigma: float = 0.5):
+    """Returns (ReadSet, truth) with truth = dict(start, src_len, strand)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    G = genome.shape[0]
+    target = int(coverage * G)
+    if length_model == "fixed":
+        n_reads = max(1, target // read_len)
+        src_len = np.full(n_reads, min(read_len, G), dtype=np.int64)
+    elif length_model == "lognormal":
+        lens = []
+        tot = 0
+        while tot < target:
+            L = rng.lognormal(np.log(read_len), sigma, size=4096)
+            L = np.clip(L, min_len, min(max_len, G)).astype(np.int64)
+            lens.append(L)
+            tot += int(L.sum())
+        src_len = np.concatenate(lens)
+        n_reads = int(np.searchsorted(np.cumsum(src_len), target) + 1)
+        src_len = src_len[:n_reads]
+    else:
+        raise ValueError(length_model)
+    start = (rng.random(n_reads) * (G - src_len + 1)).astype(np.int64)
+    strand = rng.integers(0, 2, size=n_reads, dtype=np.uint8)
+
+    packed_chunks, lengths_all = [], []
+    word_total = 0
+    word_offsets = [np.zeros(1, dtype=np.int64)]
+    for c0 in range(0, n_reads, chunk_reads):
+        c1 = min(n_reads, c0 + chunk_reads)
+        sl = src_len[c0:c1]
+        m = c1 - c0
+        off = np.zeros(m + 1, dtype=np.int64)
+        np.cumsum(sl, out=off[1:])
+        tot = int(off[-1])
+        read_of = np.repeat(np.arange(m, dtype=np.int64), sl)
+        within = np.arange(tot, dtype=np.int64) - off[read_of]
+        fwd = strand[c0:c1][read_of] == 0
+        gpos = np.where(fwd, start[c0:c1][read_of] + within, start[c0:c1][read_of] + sl[read_of] - 1 - within)
+        base = genome[gpos]
+        base = np.where(fwd, base, 3 - base).astype(np.uint8)
+        u = rng.random(tot)
+        is_del = u < dele
+        is_sub = (~is_del) & (u < dele + sub)
+        base = np.where(is_sub, (base + rng.integers(1, 4, size=tot, dtype=np.uint8)) & 3, base).astype(np.uint8)
+        n_ins = (rng.random(tot) < ins).astype(np.int64)
+        emit = (~is_del).astype(np.int64) + n_ins  # bases emitted per source base
+        out_read = np.repeat(read_of, emit)
+        out_codes = np.repeat(base, emit)
+        # the inserted base is the second copy whenever a kept base also inserts, or the only copy when deleted
+        out_off = np.zeros(tot + 1, dtype=np.int64)
+        np.cumsum(emit, out=out_off[1:])
+        ins_slot = out_off[1:][n_ins > 0] - 1
+        out_codes[ins_slot] = rng.integers(0, 4, size=ins_slot.shape[0], dtype=np.uint8)
+        lengths = np.bincount(out_read, minlength=m).astype(np.uint32)
+        words, woff = _pack_many(out_codes, lengths)
+        packed_chunks.append(words)
+        lengths_all.append(lengths)
+        word_offsets.append(woff[1:] + word_total)
+        word_total += int(woff[-1])
+
+    packed = np.concatenate(packed_chunks + [np.zeros(1, dtype=np.uint64)])  # +1 pad word
+    lengths = np.concatenate(lengths_all)
+    woffs = np.concatenate(word_offsets).astype(np.uint64)
+    rs = ReadSet(packed, woffs, lengths, np.arange(n_reads, dtype=np.uint32))
+    truth = dict(start=start, src_len=src_len, strand=strand)
+    return rs, truth

@@ -1,0 +1,35 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def lambda_reads():
+    from raven_amd import seqio
+    return seqio.load_reads(os.path.join(GOLDEN, "ERA476754.fastq.gz"))
+
+
+@pytest.fixture(scope="session")
+def lambda_genome():
+    from raven_amd import seqio
+    return seqio.load_reads(os.path.join(GOLDEN, "NC_001416.fasta.gz"))
+
+
+@pytest.fixture(scope="session")
+def synth_small():
+    """200 kb genome, 20x, 8 kb ONT-like reads (seeded) + truth."""
+    from raven_amd import synth
+    g = synth.make_genome(200_000, seed=11)
+    rs, truth = synth.make_reads(g, 20, 8000, seed=12)
+    return g, rs, truth
