@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""bench.py — read Gbase/s through raven's overlap hot path (FindOverlapsAndCreatePiles) on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+Workload (BASELINE.json configs[1]): synthetic 5 Mb genome, 30x ONT-like 10 kb reads (10 % error),
+k=15 w=5, -p 0 (no polishing rounds): one "step" = one full raven::FindOverlapsAndCreatePiles pass over the
+whole read set — sketch, index (sort), filter, map/chain of every read, merge, Pile::AddLayers, top-kMax
+truncation — with the packed reads already resident in HBM and results left in HBM.
+Multi-GPU: every rank owns an independent shard (its own genome + reads), no data-path collective ->
+"scaling": "weak"; value = bases processed by all ranks / max-over-ranks time.
+
+Prints ONE JSON line on rank 0 (metric contract + "roofline" + "cpu_baseline").
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from raven_amd import hip, synth  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured copy)
+
+
+def algorithmic_bytes(site, c, val_bytes):
+    """ALGORITHMIC bytes of ONE launch of kernel `site`, from the exact engine counters of
+    one step: N index bases, Mi index minimizers, U keys, Mq query minimizers, H matches, O overlaps."""
+    N, Mi, U, Mq, H, O = (c["index_bases"], c["index_minimizers"], c["index_keys"], c["query_minimizers"],
+                          c["matches"], c["overlaps"])
+    rec = val_bytes + 8  # one (value, origin) record
+    table = {
+        "sketch_count": N / 4.0,
+        "sketch_write": N / 4.0 + rec * Mi,
+        "rs_upsweep": val_bytes * Mi,
+        "rs_downsweep": 2.0 * rec * Mi,          # read + write every (value, origin) once
+        "heads": (val_bytes + 1) * Mi,
+        "unique": (val_bytes + 1 + 4) * Mi + (val_bytes + 4) * U,
+        "scan": None,
+        "table": val_bytes * U + 4.0 * (1 << 26),
+        "match_count": rec * Mq + 8.0 * H + 12.0 * Mq,
+        "match_emit": 8.0 * Mq + 8.0 * H + 16.0 * H,
+        "seg_sort_group": 2.0 * 16.0 * H,
+        "seg_sort_pos": 2.0 * 16.0 * H,
+        "chain": 16.0 * H + 32.0 * O,
+        "minhash_select": val_bytes * Mi + Mi,
+    }
+    return table.get(site)
+
+
+def cpu_baseline(args, cores):
+    """Oracle (CPU restatement, 'port') timed on a bounded sample of the same workload."""
+    from oracle import oracle
+    g = synth.make_genome(args.cpu_sample_genome, seed=0xC0FFEE)
+    rs, _ = synth.make_reads(g, args.coverage, args.read_len, seed=0xC0FFEF)
+    t = time.time()
+    r1 = oracle.Engine(args.k, args.w).find_overlaps_and_create_piles(rs, threads=1) if args.cpu_single else None
+    t1 = time.time() - t
+    t = time.time()
+    oracle.Engine(args.k, args.w).find_overlaps_and_create_piles(rs, threads=cores)
+    tc = time.time() - t
+    sample = "%d reads / %d bases of the same generator (%.2f Mb genome, %gx), oracle FindOverlapsAndCreatePiles, %d threads: %.2f s" % (
+        rs.n, rs.total_bases, args.cpu_sample_genome / 1e6, args.coverage, cores, tc)
+    if r1 is not None:
+        sample += "; 1 thread: %.2f s = %.4f Gbase/s" % (t1, rs.total_bases / t1 / 1e9)
+    return {"value": rs.total_bases / tc / 1e9, "unit": "Gbase/s", "cores": cores, "kind": "port", "sample": sample}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--genome", type=int, default=5_000_000)
+    ap.add_argument("--coverage", type=float, default=30.0)
+    ap.add_argument("--read-len", type=int, default=10000)
+    ap.add_argument("--k", type=int, default=15)
+    ap.add_argument("--w", type=int, default=5)
+    ap.add_argument("--freq", type=float, default=0.001)
+    ap.add_argument("--kmax", type=int, default=32)
+    ap.add_argument("--cpu-sample-genome", type=int, default=1_000_000)
+    ap.add_argument("--cpu-single", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+
+    import torch  # plumbing only: device selection, barrier, max-over-ranks
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (torch.cuda.is_available() is False)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist_mod.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
+        dist = dist_mod
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- synthetic shard of this rank (seeded; rank-dependent so shards are independent) ----
+    t0 = time.time()
+    genome = synth.make_genome(args.genome, seed=0x5EED0001 + 1000 * rank)
+    rs, _ = synth.make_reads(genome, args.coverage, args.read_len, seed=0x5EED0002 + 1000 * rank)
+    t_gen = time.time() - t0
+
+    eng = hip.Engine(args.k, args.w, device=local_rank)
+    t0 = time.time()
+    reads = eng.upload(rs)  # H2D once; resident for every step
+    t_h2d = time.time() - t0
+    eng.set_timing(False)  # no per-stage host syncs inside the timed region
+    eng.set_kernel_timing(not args.no_kernel_timing)
+
+    def step():
+        p = eng.find_overlaps_and_create_piles(reads, freq=args.freq, kmax=args.kmax)  # synchronous: returns when done
+        p.close()
+
+    for _ in range(args.warmup):
+        step()
+    eng.reset_stats()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+        tb = torch.tensor([float(rs.total_bases)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tb, op=dist.ReduceOp.SUM)
+        total_bases = float(tb.item())
+    else:
+        total_bases = float(rs.total_bases)
+
+    if rank == 0:
+        steps = max(args.steps, 1)
+        counters = {k: v // steps for k, v in eng.counters().items()}
+        kms = eng.kernel_ms() if not args.no_kernel_timing else {}
+        val_bytes = 4 if 2 * eng.k < 32 else 8
+        roofline = None
+        kernels = {}
+        if kms:
+            tot = sum(v[0] for v in kms.values())
+            for name, (ms, la) in sorted(kms.items(), key=lambda x: -x[1][0]):
+                if la:
+                    kernels[name] = {"ms_per_step": round(ms / steps, 4), "launches_per_step": la / steps,
+                                     "avg_launch_ms": round(ms / la, 5)}
+            dom = None
+            for name in kernels:  # dominant kernel with a defined algorithmic byte count
+                if algorithmic_bytes(name, counters, val_bytes):
+                    dom = name
+                    break
+            if dom:
+                b = algorithmic_bytes(dom, counters, val_bytes)
+                avg_s = kms[dom][0] / kms[dom][1] / 1e3
+                achieved = b / avg_s / 1e9
+                roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                            "algorithmic_bytes_per_launch": int(b), "avg_launch_ms": round(avg_s * 1e3, 5),
+                            "kernel_ms_share": round(kms[dom][0] / tot, 3) if tot else None}
+        out = {
+            "metric": "read Gbase/s through overlap+polish",
+            "value": round(total_bases * args.steps / dt / 1e9, 4),
+            "unit": "Gbase/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(dt / steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32" if val_bytes == 4 else "u64",
+            "data": "synthetic",
+            "config": {
+                "workload": "BASELINE.json configs[1]: synthetic %.1f Mb genome, %gx ONT-like %d bp reads "
+                            "(4%% sub, 3%% ins, 3%% del), k=%d w=%d, -p 0 (FindOverlapsAndCreatePiles only, "
+                            "no polishing rounds), 1 shard per GPU" % (args.genome / 1e6, args.coverage,
+                                                                       args.read_len, args.k, args.w),
+                "reads_per_gpu": rs.n, "bases_per_gpu": rs.total_bases, "freq": args.freq, "kmax": args.kmax,
+                "parallelism": "independent shard per GPU (no data-path collective)",
+            },
+            "overlaps_per_s": round(counters["overlaps"] * world * args.steps / dt, 1),
+            "counters_per_step": counters,
+            "roofline": roofline,
+            "kernels": kernels,
+            "host": {"gen_s": round(t_gen, 2), "h2d_s": round(t_h2d, 3),
+                     "h2d_inclusive_gbase_s": round(rs.total_bases / (dt / steps + t_h2d) / 1e9, 4)},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            cores = os.cpu_count() or 1
+            out["cpu_baseline"] = cpu_baseline(args, cores)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -108,6 +108,12 @@ const char* rvn_engine_stage_name(int stage);
 int rvn_engine_stage_ms(const rvn_engine* e, double* ms, uint64_t* launches, int n);
 void rvn_engine_reset_stats(rvn_engine* e);
 void rvn_engine_set_timing(rvn_engine* e, int enabled);
+/* per-kernel-site device time: HIP events recorded on the engine's stream around every launch of the
+ * site (no host synchronisation while recording); rvn_engine_kernel_ms synchronises and accumulates. */
+void rvn_engine_set_kernel_timing(rvn_engine* e, int enabled);
+int rvn_engine_num_kernel_sites(void);
+const char* rvn_engine_kernel_site_name(int site);
+int rvn_engine_kernel_ms(rvn_engine* e, double* ms, uint64_t* launches, int n);
 
 /* host-side test hooks for the __host__ __device__ building blocks (no GPU needed) */
 uint64_t rvn_test_hash(uint64_t key, uint32_t k, int use32);

@@ -66,6 +66,7 @@ def lib():
             fn = getattr(L, "orc_pass1_" + name)
             fn.restype = rt
             fn.argtypes = [vp]
+        L.orc_antiqsort.argtypes = [vp, u32]
         L.orc_edit_distance.restype = u32
         L.orc_edit_distance.argtypes = [C.c_char_p, u32, C.c_char_p, u32]
         _lib = L
@@ -190,6 +191,13 @@ def truncate(overlaps: np.ndarray, kmax: int) -> np.ndarray:
     o = np.ascontiguousarray(overlaps).copy()
     n = lib().orc_truncate(_p(o), o.shape[0], kmax)
     return o[:n]
+
+
+def antiqsort(n: int) -> np.ndarray:
+    """Values (ascending-sort killer) that drive libstdc++'s introsort into its heapsort fallback."""
+    out = np.zeros(n, dtype=np.uint32)
+    lib().orc_antiqsort(_p(out), n)
+    return out
 
 
 def edit_distance(a: bytes, b: bytes) -> int:

@@ -762,6 +762,26 @@ std::uint32_t orc_pass1_occurrence(orc_pass1* p) { return p->r.last_occurrence; 
 double orc_pass1_t_minimize(orc_pass1* p) { return p->r.t_minimize; }
 double orc_pass1_t_map(orc_pass1* p) { return p->r.t_map; }
 
+// McIlroy's "killer adversary for quicksort" run against std::sort itself: produces values on which
+// libstdc++'s introsort exhausts its depth limit and falls back to heapsort (used to test that the device
+// restatement of std::sort follows the same path).
+void orc_antiqsort(std::uint32_t* out_vals, std::uint32_t n) {
+  const std::uint32_t gas = n;
+  std::vector<std::uint32_t> val(n, gas), ptr(n);
+  for (std::uint32_t i = 0; i < n; ++i) ptr[i] = i;
+  std::uint32_t nsolid = 0, candidate = 0;
+  std::sort(ptr.begin(), ptr.end(), [&](std::uint32_t x, std::uint32_t y) {
+    if (val[x] == gas && val[y] == gas) {
+      if (x == candidate) val[x] = nsolid++;
+      else val[y] = nsolid++;
+    }
+    if (val[x] == gas) candidate = x;
+    else if (val[y] == gas) candidate = y;
+    return val[x] < val[y];
+  });
+  for (std::uint32_t i = 0; i < n; ++i) out_vals[i] = val[i];
+}
+
 std::uint32_t orc_edit_distance(const char* a, std::uint32_t n, const char* b, std::uint32_t m) {
   return orc::EditDistance(a, n, b, m);
 }

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <stdexcept>
 #include <string>
+#include <vector>
 
 namespace rvn {
 
@@ -62,6 +63,61 @@ struct DevBuf {
   }
 };
 
+// ---- per-kernel-site timing (HIP events on the engine stream, no host sync while recording) ----
+enum KernelSite {
+  kKSketchCount, kKSketchWrite, kKMinhashSelect, kKCompactSketch, kKScan, kKRsBits, kKRsUpsweep, kKRsDownsweep,
+  kKHeads, kKUnique, kKTable, kKOccHist, kKMatchCount, kKMatchEmit, kKSegSortGroup, kKIntervals,
+  kKIntervalsGather, kKSegSortPos, kKChain, kKCompactOverlaps, kKPileKeys, kKPileCounts, kKPileBuild,
+  kKAddLayers, kKTruncateSort, kKKeptWrite, kKGather, kKPileSortUp, kKPileSortDown, kKNumSites
+};
+extern const char* const kKernelSiteNames[kKNumSites];
+
+struct KernelTimers {
+  bool enabled = false;
+  hipStream_t stream = nullptr;
+  std::vector<hipEvent_t> pool;
+  size_t used = 0;
+  struct Rec {
+    int site;
+    size_t e0, e1;
+  };
+  std::vector<Rec> recs;
+  double ms[kKNumSites] = {};
+  u64 launches[kKNumSites] = {};
+  ~KernelTimers();
+  size_t next_event();
+  void resolve();  // call after the stream is synchronised
+  void reset();
+};
+// timers of the engine currently executing on this host thread (nullptr = no timing)
+extern thread_local KernelTimers* g_kernel_timers;
+
+struct KernelScope {
+  KernelTimers* kt;
+  size_t e1 = 0;
+  explicit KernelScope(int site) : kt(g_kernel_timers) {
+    if (kt && kt->enabled) {
+      size_t e0 = kt->next_event();
+      e1 = kt->next_event();
+      kt->recs.push_back({site, e0, e1});
+      RVN_HIP(hipEventRecord(kt->pool[e0], kt->stream));
+    } else {
+      kt = nullptr;
+    }
+  }
+  ~KernelScope() {
+    if (kt) (void)hipEventRecord(kt->pool[e1], kt->stream);
+  }
+};
+
+// launch a kernel (or a few) attributed to `site`
+#define RVN_KLAUNCH(site, ...)        \
+  do {                                \
+    ::rvn::KernelScope _ks(site);     \
+    __VA_ARGS__;                      \
+    RVN_LAUNCH_CHECK();               \
+  } while (0)
+
 // 8 x u32 overlap record == biosoup::Overlap minus the alignment string.
 struct Overlap {
   u32 lhs_id, lhs_begin, lhs_end, rhs_id, rhs_begin, rhs_end, score, strand;
@@ -79,8 +135,11 @@ void exclusive_scan_u8_u32(const u8* in, u32* out, u64 n, DevBuf& tmp, hipStream
 // Stable LSD radix sort of (key, value) pairs on key bits [0, key_bits).
 // Ping-pongs between (k0,v0) and (k1,v1); returns 0 if the sorted data ends in
 // (k0,v0), 1 if in (k1,v1).
-int radix_sort_pairs_u32_u64(u32* k0, u32* k1, u64* v0, u64* v1, u64 n, int key_bits, DevBuf& tmp, DevBuf& tmp2, hipStream_t s);
-int radix_sort_pairs_u64_u64(u64* k0, u64* k1, u64* v0, u64* v1, u64 n, int key_bits, DevBuf& tmp, DevBuf& tmp2, hipStream_t s);
-int radix_sort_pairs_u32_u32(u32* k0, u32* k1, u32* v0, u32* v1, u64 n, int key_bits, DevBuf& tmp, DevBuf& tmp2, hipStream_t s);
+int radix_sort_pairs_u32_u64(u32* k0, u32* k1, u64* v0, u64* v1, u64 n, int key_bits, DevBuf& tmp, DevBuf& tmp2, hipStream_t s,
+                             int site_up = kKRsUpsweep, int site_down = kKRsDownsweep);
+int radix_sort_pairs_u64_u64(u64* k0, u64* k1, u64* v0, u64* v1, u64 n, int key_bits, DevBuf& tmp, DevBuf& tmp2, hipStream_t s,
+                             int site_up = kKRsUpsweep, int site_down = kKRsDownsweep);
+int radix_sort_pairs_u32_u32(u32* k0, u32* k1, u32* v0, u32* v1, u64 n, int key_bits, DevBuf& tmp, DevBuf& tmp2, hipStream_t s,
+                             int site_up = kKRsUpsweep, int site_down = kKRsDownsweep);
 
 }  // namespace rvn

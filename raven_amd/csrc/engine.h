@@ -89,6 +89,7 @@ struct Engine {
   DevBuf seg_off, iv_slot_begin, iv_slot_end, iv_cnt, iv_off, iv_begin, iv_end;
   DevBuf lis_min, lis_pred, ovl_slots, ovl_flags, ovl_scan;
   StageTimes times;
+  KernelTimers ktimers;
   // counters for algorithmic bytes
   u64 c_index_bases = 0, c_index_min = 0, c_index_keys = 0, c_query_bases = 0, c_query_min = 0, c_matches = 0,
       c_overlaps = 0;

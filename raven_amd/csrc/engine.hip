@@ -52,6 +52,14 @@ const char* kStageNames[StageTimes::kNum] = {"sketch", "sort", "index", "filter"
                                              "seg_sort", "intervals", "chain", "compact", "merge", "pile",
                                              "truncate"};
 
+struct UseTimers {
+  explicit UseTimers(Engine& e) {
+    e.ktimers.stream = e.stream;
+    g_kernel_timers = &e.ktimers;
+  }
+  ~UseTimers() { g_kernel_timers = nullptr; }
+};
+
 void do_minimize(Engine& e, const ReadsDev& r, u32 first, u32 last, bool minhash) {
   {
     StageTimer t(e, StageTimes::kSketch);
@@ -163,6 +171,7 @@ int rvn_engine_minimize(rvn_engine* h, const rvn_reads* r, uint32_t first, uint3
   return guarded([&]() -> int {
     if (!h || !r || first > last || last > r->r.n) return fail(RVN_EINVAL, "[raven_hip] rvn_engine_minimize: bad range");
     RVN_HIP(hipSetDevice(h->e.device));
+    UseTimers ut(h->e);
     do_minimize(h->e, r->r, first, last, minhash != 0);
     RVN_HIP(hipStreamSynchronize(h->e.stream));
     return RVN_OK;
@@ -174,6 +183,7 @@ int rvn_engine_filter(rvn_engine* h, double f) {
     if (!h) return fail(RVN_EINVAL, "[raven_hip] NULL engine");
     if (!(0 <= f && f <= 1)) return fail(RVN_EINVAL, "[ram::MinimizerEngine::Filter] error: invalid frequency");
     RVN_HIP(hipSetDevice(h->e.device));
+    UseTimers ut(h->e);
     index_filter(h->e, f);
     return RVN_OK;
   });
@@ -186,6 +196,7 @@ int rvn_engine_map_batch(rvn_engine* h, const rvn_reads* r, uint32_t first, uint
   return guarded([&]() -> int {
     if (!h || !r || first > last || last > r->r.n) return fail(RVN_EINVAL, "[raven_hip] rvn_engine_map_batch: bad range");
     RVN_HIP(hipSetDevice(h->e.device));
+    UseTimers ut(h->e);
     map_batch(h->e, r->r, first, last, avoid_equal != 0, avoid_symmetric != 0, minhash != 0, want_filtered != 0,
               h->e.map_out);
     h->e.c_intervals += h->e.map_out.n_intervals;
@@ -252,6 +263,7 @@ int rvn_find_overlaps_and_create_piles(rvn_engine* h, const rvn_reads* rr, doubl
     for (u32 i = 0; i < r.n; ++i)
       if (r.h_id[i] != i) return fail(RVN_EINVAL, "[raven_hip] FindOverlapsAndCreatePiles requires ids[i] == i");
     RVN_HIP(hipSetDevice(e.device));
+    UseTimers ut(e);
     std::unique_ptr<rvn_pass1> p(new rvn_pass1());
     p->e = &e;
     piles_init(e, r, p->ps);
@@ -339,6 +351,7 @@ int rvn_engine_sketch(rvn_engine* h, const rvn_reads* r, uint32_t first, uint32_
   return guarded([&]() -> int {
     if (!h || !r || first > last || last > r->r.n) return fail(RVN_EINVAL, "[raven_hip] rvn_engine_sketch: bad range");
     RVN_HIP(hipSetDevice(h->e.device));
+    UseTimers ut(h->e);
     sketch_range(h->e, r->r, first, last, minhash != 0, h->e.query_sketch);
     RVN_HIP(hipStreamSynchronize(h->e.stream));
     if (count) *count = h->e.query_sketch.count;
@@ -422,12 +435,33 @@ void rvn_engine_reset_stats(rvn_engine* h) {
   if (!h) return;
   Engine& e = h->e;
   e.times = StageTimes();
+  e.ktimers.reset();
   e.c_index_bases = e.c_index_min = e.c_index_keys = e.c_query_bases = e.c_query_min = e.c_matches = e.c_overlaps =
       e.c_intervals = 0;
 }
 
 void rvn_engine_set_timing(rvn_engine* h, int enabled) {
   if (h) h->e.timing = enabled != 0;
+}
+
+void rvn_engine_set_kernel_timing(rvn_engine* h, int enabled) {
+  if (h) h->e.ktimers.enabled = enabled != 0;
+}
+int rvn_engine_num_kernel_sites(void) { return kKNumSites; }
+const char* rvn_engine_kernel_site_name(int i) { return (i >= 0 && i < kKNumSites) ? kKernelSiteNames[i] : ""; }
+int rvn_engine_kernel_ms(rvn_engine* h, double* ms, uint64_t* launches, int n) {
+  return guarded([&]() -> int {
+    if (!h) return fail(RVN_EINVAL, "[raven_hip] NULL engine");
+    Engine& e = h->e;
+    RVN_HIP(hipSetDevice(e.device));
+    RVN_HIP(hipStreamSynchronize(e.stream));
+    e.ktimers.resolve();
+    for (int i = 0; i < n && i < kKNumSites; ++i) {
+      if (ms) ms[i] = e.ktimers.ms[i];
+      if (launches) launches[i] = e.ktimers.launches[i];
+    }
+    return RVN_OK;
+  });
 }
 
 // ---- host test hooks ---------------------------------------------------------------------------

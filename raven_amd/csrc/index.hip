@@ -97,8 +97,7 @@ void index_build_impl(Engine& e, Sketch& sk) {
     ix.table_bits = 1;
     ix.shift = 2 * e.k > 1 ? 2 * e.k - 1 : 0;
     u32* table = ix.table.get<u32>(3);
-    table_empty_kernel<<<1, 64, 0, s>>>(table, 2);
-    RVN_LAUNCH_CHECK();
+    RVN_KLAUNCH(kKTable, table_empty_kernel<<<1, 64, 0, s>>>(table, 2));
     ix.u_val.reserve(16);
     ix.u_start.reserve(16);
     RVN_HIP(hipMemsetAsync(ix.u_start.ptr, 0, 8, s));
@@ -122,8 +121,7 @@ void index_build_impl(Engine& e, Sketch& sk) {
   const V* sv = ix.s_val[ix.cur].as<V>();
   u8* flags = e.tmp_c.get<u8>(m + 1);
   u32* fscan = e.tmp_d.get<u32>(m + 1);
-  heads_kernel<V><<<div_up(m, 256), 256, 0, s>>>(sv, m, flags);
-  RVN_LAUNCH_CHECK();
+  RVN_KLAUNCH(kKHeads, heads_kernel<V><<<div_up(m, 256), 256, 0, s>>>(sv, m, flags));
   exclusive_scan_u8_u32(flags, fscan, m, e.scan_tmp, s);
   u32 u = 0;
   RVN_HIP(hipMemcpyAsync(&u, fscan + m, 4, hipMemcpyDeviceToHost, s));
@@ -131,8 +129,7 @@ void index_build_impl(Engine& e, Sketch& sk) {
   ix.u = u;
   V* u_val = ix.u_val.get<V>(static_cast<size_t>(u) + 1);
   u32* u_start = ix.u_start.get<u32>(static_cast<size_t>(u) + 2);
-  unique_kernel<V><<<div_up(m, 256), 256, 0, s>>>(sv, flags, fscan, m, u_val, u_start, u);
-  RVN_LAUNCH_CHECK();
+  RVN_KLAUNCH(kKUnique, unique_kernel<V><<<div_up(m, 256), 256, 0, s>>>(sv, flags, fscan, m, u_val, u_start, u));
 
   int bits = 1;
   while ((1ULL << bits) < 2ULL * u) ++bits;
@@ -142,8 +139,7 @@ void index_build_impl(Engine& e, Sketch& sk) {
   ix.shift = 2 * e.k - bits;
   const u32 B = 1u << bits;
   u32* table = ix.table.get<u32>(static_cast<size_t>(B) + 2);
-  table_kernel<V><<<div_up(u, 256), 256, 0, s>>>(u_val, u, ix.shift, B, table);
-  RVN_LAUNCH_CHECK();
+  RVN_KLAUNCH(kKTable, table_kernel<V><<<div_up(u, 256), 256, 0, s>>>(u_val, u, ix.shift, B, table));
   t.stop();
 }
 
@@ -169,8 +165,7 @@ void index_filter(Engine& e, double freq) {
   RVN_HIP(hipMemsetAsync(hist, 0, (kHistBins + 1) * 4, s));
   const u32 u = static_cast<u32>(ix.u);
   const u32 grid = std::min<u32>(div_up(u, 256), 2048);
-  occ_hist_kernel<<<grid, 256, 0, s>>>(ix.u_start.as<u32>(), u, hist, ovl, hist + kHistBins, overflow_cap);
-  RVN_LAUNCH_CHECK();
+  RVN_KLAUNCH(kKOccHist, occ_hist_kernel<<<grid, 256, 0, s>>>(ix.u_start.as<u32>(), u, hist, ovl, hist + kHistBins, overflow_cap));
   std::vector<u32> h(kHistBins + 1);
   RVN_HIP(hipMemcpyAsync(h.data(), hist, (kHistBins + 1) * 4, hipMemcpyDeviceToHost, s));
   RVN_HIP(hipStreamSynchronize(s));

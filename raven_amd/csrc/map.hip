@@ -428,11 +428,10 @@ void map_batch_impl(Engine& e, const ReadsDev& r, u32 first, u32 last, bool avoi
     u32* q_cnt = e.q_cnt.get<u32>(nq + 1);
     u8* filt = want_filtered ? out.filtered.get<u8>(nq + 1) : nullptr;
     u64* m_off = e.m_off.get<u64>(nq + 2);
-    match_count_kernel<V><<<div_up(nq, 256), 256, 0, s>>>(
+    RVN_KLAUNCH(kKMatchCount, match_count_kernel<V><<<div_up(nq, 256), 256, 0, s>>>(
         qs.val.as<V>(), qs.org.as<u64>(), nq, ix.u_val.as<V>(), ix.u_start.as<u32>(), ix.table.as<u32>(), ix.shift,
         static_cast<u32>(ix.u), ix.s_org[ix.cur].as<u64>(), ix.occurrence, avoid_equal, avoid_symmetric, q_start, q_n,
-        q_cnt, filt);
-    RVN_LAUNCH_CHECK();
+        q_cnt, filt));
     exclusive_scan_u32_u64(q_cnt, m_off, nq, e.scan_tmp, s);
     RVN_HIP(hipMemcpyAsync(&H, m_off + nq, 8, hipMemcpyDeviceToHost, s));
     RVN_HIP(hipStreamSynchronize(s));
@@ -443,9 +442,8 @@ void map_batch_impl(Engine& e, const ReadsDev& r, u32 first, u32 last, bool avoi
       u64* p0 = e.m_pos[0].get<u64>(H + 1);
       e.m_grp[1].reserve((H + 1) * 8);
       e.m_pos[1].reserve((H + 1) * 8);
-      match_emit_kernel<<<div_up(nq, 256), 256, 0, s>>>(qs.org.as<u64>(), nq, ix.s_org[ix.cur].as<u64>(), q_start,
-                                                        q_n, m_off, avoid_equal, avoid_symmetric, g0, p0);
-      RVN_LAUNCH_CHECK();
+      RVN_KLAUNCH(kKMatchEmit, match_emit_kernel<<<div_up(nq, 256), 256, 0, s>>>(qs.org.as<u64>(), nq, ix.s_org[ix.cur].as<u64>(), q_start,
+                                                        q_n, m_off, avoid_equal, avoid_symmetric, g0, p0));
     }
     t.stop();
   }
@@ -460,11 +458,9 @@ void map_batch_impl(Engine& e, const ReadsDev& r, u32 first, u32 last, bool avoi
   u64* seg_off = e.seg_off.get<u64>(static_cast<size_t>(nr) + 1);
   {
     StageTimer t(e, StageTimes::kSegSort);
-    gather_u64_by_u32_kernel<<<div_up(nr + 1, 256), 256, 0, s>>>(e.m_off.as<u64>(), qs.read_off.as<u32>(), seg_off,
-                                                                 nr + 1);
-    RVN_LAUNCH_CHECK();
-    seg_sort_off_kernel<<<div_up(nr, 4), 256, 0, s>>>(g0, g1, p0, p1, seg_off, nr);
-    RVN_LAUNCH_CHECK();
+    RVN_KLAUNCH(kKGather, gather_u64_by_u32_kernel<<<div_up(nr + 1, 256), 256, 0, s>>>(e.m_off.as<u64>(), qs.read_off.as<u32>(), seg_off,
+                                                                 nr + 1));
+    RVN_KLAUNCH(kKSegSortGroup, seg_sort_off_kernel<<<div_up(nr, 4), 256, 0, s>>>(g0, g1, p0, p1, seg_off, nr));
     t.stop();
   }
   u32 NI = 0;
@@ -475,8 +471,7 @@ void map_batch_impl(Engine& e, const ReadsDev& r, u32 first, u32 last, bool avoi
     u64* slot_end = e.iv_slot_end.get<u64>(n_slots4 + 1);
     u32* iv_cnt = e.iv_cnt.get<u32>(static_cast<size_t>(nr) + 1);
     u32* iv_off = e.iv_off.get<u32>(static_cast<size_t>(nr) + 2);
-    intervals_kernel<<<div_up(nr, 4), 256, 0, s>>>(g0, seg_off, nr, e.bandwidth, slot_begin, slot_end, iv_cnt);
-    RVN_LAUNCH_CHECK();
+    RVN_KLAUNCH(kKIntervals, intervals_kernel<<<div_up(nr, 4), 256, 0, s>>>(g0, seg_off, nr, e.bandwidth, slot_begin, slot_end, iv_cnt));
     exclusive_scan_u32_u32(iv_cnt, iv_off, nr, e.scan_tmp, s);
     RVN_HIP(hipMemcpyAsync(&NI, iv_off + nr, 4, hipMemcpyDeviceToHost, s));
     RVN_HIP(hipStreamSynchronize(s));
@@ -485,9 +480,8 @@ void map_batch_impl(Engine& e, const ReadsDev& r, u32 first, u32 last, bool avoi
       u64* iv_begin = e.iv_begin.get<u64>(static_cast<size_t>(NI) + 1);
       u64* iv_end = e.iv_end.get<u64>(static_cast<size_t>(NI) + 1);
       u32* iv_read = e.tmp_b.get<u32>(static_cast<size_t>(NI) + 1);
-      intervals_gather_kernel<<<div_up(nr, 4), 256, 0, s>>>(slot_begin, slot_end, seg_off, iv_off, nr, iv_begin,
-                                                            iv_end, iv_read);
-      RVN_LAUNCH_CHECK();
+      RVN_KLAUNCH(kKIntervalsGather, intervals_gather_kernel<<<div_up(nr, 4), 256, 0, s>>>(slot_begin, slot_end, seg_off, iv_off, nr, iv_begin,
+                                                            iv_end, iv_read));
     }
     t.stop();
   }
@@ -505,15 +499,13 @@ void map_batch_impl(Engine& e, const ReadsDev& r, u32 first, u32 last, bool avoi
     u64* iv_end = e.iv_end.as<u64>();
     u32* iv_read = e.tmp_b.as<u32>();
     // sort every interval by positions (payload = group)
-    seg_sort_be_kernel<<<div_up(NI, 4), 256, 0, s>>>(p0, p1, g0, g1, iv_begin, iv_end, NI, e.chain);
-    RVN_LAUNCH_CHECK();
+    RVN_KLAUNCH(kKSegSortPos, seg_sort_be_kernel<<<div_up(NI, 4), 256, 0, s>>>(p0, p1, g0, g1, iv_begin, iv_end, NI, e.chain));
     u32* lis_min = e.lis_min.get<u32>(H + NI + 1);
     u32* lis_pred = e.lis_pred.get<u32>(H + 1);
     RVN_HIP(hipMemsetAsync(slot_flags, 0, n_slots + 1, s));
-    chain_kernel<<<div_up(NI, 64), 64, 0, s>>>(g0, p0, iv_begin, iv_end, iv_read, NI, r.id.as<u32>(), first, e.k,
+    RVN_KLAUNCH(kKChain, chain_kernel<<<div_up(NI, 64), 64, 0, s>>>(g0, p0, iv_begin, iv_end, iv_read, NI, r.id.as<u32>(), first, e.k,
                                                e.chain, e.matches, e.gap, slot_div, lis_min, lis_pred, slots,
-                                               slot_flags);
-    RVN_LAUNCH_CHECK();
+                                               slot_flags));
     t.stop();
   }
   {
@@ -526,10 +518,8 @@ void map_batch_impl(Engine& e, const ReadsDev& r, u32 first, u32 last, bool avoi
     out.n_overlaps = O;
     e.c_overlaps += O;
     Overlap* ovl = out.ovl.get<Overlap>(static_cast<size_t>(O) + 1);
-    compact_overlaps_kernel<<<div_up(n_slots, 256), 256, 0, s>>>(slots, slot_flags, scan, n_slots, ovl);
-    RVN_LAUNCH_CHECK();
-    read_ovl_off_kernel<<<div_up(nr + 1, 256), 256, 0, s>>>(seg_off, scan, slot_div, nr + 1, ovl_read_off);
-    RVN_LAUNCH_CHECK();
+    RVN_KLAUNCH(kKCompactOverlaps, compact_overlaps_kernel<<<div_up(n_slots, 256), 256, 0, s>>>(slots, slot_flags, scan, n_slots, ovl));
+    RVN_KLAUNCH(kKGather, read_ovl_off_kernel<<<div_up(nr + 1, 256), 256, 0, s>>>(seg_off, scan, slot_div, nr + 1, ovl_read_off));
     t.stop();
   }
 }

@@ -190,8 +190,7 @@ void pile_add_layers_single(Engine& e, PileState& ps, const u32* d_ids, const Ov
   u32* offs = ps.tmp3.get<u32>(4);
   const u32 h_offs[4] = {0, n, 0, 0};  // list_off = {0, n}; kept_off = {0, 0}
   RVN_HIP(hipMemcpyAsync(offs, h_offs, sizeof(h_offs), hipMemcpyHostToDevice, s));
-  add_layers_kernel<<<1, 256, 0, s>>>(list, offs, offs + 2, ps.pile_off.as<u64>(), d_ids, ps.pile_data.as<u16>());
-  RVN_LAUNCH_CHECK();
+  RVN_KLAUNCH(kKAddLayers, add_layers_kernel<<<1, 256, 0, s>>>(list, offs, offs + 2, ps.pile_off.as<u64>(), d_ids, ps.pile_data.as<u16>()));
   RVN_HIP(hipStreamSynchronize(s));
 }
 
@@ -214,14 +213,13 @@ void piles_merge(Engine& e, const ReadsDev& r, const MapOut& mo, u32 kmax, PileS
   u32 *in_cnt = base, *in_off = base + stride, *tot = base + 2 * stride, *list_off = base + 3 * stride,
       *new_kept_cnt = base + 4 * stride, *new_kept_off = base + 5 * stride;
   RVN_HIP(hipMemsetAsync(in_cnt, 0, stride * 4, s));
-  rhs_keys_kernel<<<div_up(O, 256), 256, 0, s>>>(ovl, O, keys0, idx0, in_cnt);
-  RVN_LAUNCH_CHECK();
-  const int cur = radix_sort_pairs_u32_u32(keys0, keys1, idx0, idx1, O, 32, e.sort_tmp, e.scan_tmp, s);
+  RVN_KLAUNCH(kKPileKeys, rhs_keys_kernel<<<div_up(O, 256), 256, 0, s>>>(ovl, O, keys0, idx0, in_cnt));
+  const int cur = radix_sort_pairs_u32_u32(keys0, keys1, idx0, idx1, O, 32, e.sort_tmp, e.scan_tmp, s, kKPileSortUp,
+                                           kKPileSortDown);
   const u32* in_idx_sorted = cur ? idx1 : idx0;
   exclusive_scan_u32_u32(in_cnt, in_off, n, e.scan_tmp, s);
-  pile_counts_kernel<<<div_up(n, 256), 256, 0, s>>>(in_cnt, ovl_read_off, mo.first, mo.last, ps.kept_off.as<u32>(), n,
-                                                    kmax, tot, new_kept_cnt);
-  RVN_LAUNCH_CHECK();
+  RVN_KLAUNCH(kKPileCounts, pile_counts_kernel<<<div_up(n, 256), 256, 0, s>>>(in_cnt, ovl_read_off, mo.first, mo.last, ps.kept_off.as<u32>(), n,
+                                                    kmax, tot, new_kept_cnt));
   exclusive_scan_u32_u32(tot, list_off, n, e.scan_tmp, s);
   exclusive_scan_u32_u32(new_kept_cnt, new_kept_off, n, e.scan_tmp, s);
   u32 totals[2] = {0, 0};
@@ -230,26 +228,22 @@ void piles_merge(Engine& e, const ReadsDev& r, const MapOut& mo, u32 kmax, PileS
   RVN_HIP(hipStreamSynchronize(s));
   const u32 L = totals[0], K = totals[1];
   Overlap* list = ps.new_list.get<Overlap>(static_cast<size_t>(L) + 1);
-  pile_build_kernel<<<div_up(n, 4), 256, 0, s>>>(ovl, ovl_read_off, mo.first, mo.last, in_idx_sorted, in_off,
-                                                 ps.kept.as<Overlap>(), ps.kept_off.as<u32>(), list_off, n, list);
-  RVN_LAUNCH_CHECK();
+  RVN_KLAUNCH(kKPileBuild, pile_build_kernel<<<div_up(n, 4), 256, 0, s>>>(ovl, ovl_read_off, mo.first, mo.last, in_idx_sorted, in_off,
+                                                 ps.kept.as<Overlap>(), ps.kept_off.as<u32>(), list_off, n, list));
   tm.stop();
   {
     StageTimer t(e, StageTimes::kPile);
-    add_layers_kernel<<<n, 256, 0, s>>>(list, list_off, ps.kept_off.as<u32>(), ps.pile_off.as<u64>(),
-                                        r.id.as<u32>(), ps.pile_data.as<u16>());
-    RVN_LAUNCH_CHECK();
+    RVN_KLAUNCH(kKAddLayers, add_layers_kernel<<<n, 256, 0, s>>>(list, list_off, ps.kept_off.as<u32>(), ps.pile_off.as<u64>(),
+                                        r.id.as<u32>(), ps.pile_data.as<u16>()));
     t.stop();
   }
   {
     StageTimer t(e, StageTimes::kTruncate);
     u64* skeys = ps.tmp4.get<u64>(static_cast<size_t>(L) + 1);
-    truncate_sort_kernel<<<div_up(n, 64), 64, 0, s>>>(list, list_off, n, kmax, skeys);
-    RVN_LAUNCH_CHECK();
+    RVN_KLAUNCH(kKTruncateSort, truncate_sort_kernel<<<div_up(n, 64), 64, 0, s>>>(list, list_off, n, kmax, skeys));
     Overlap* kept_new = ps.tmp5.get<Overlap>(static_cast<size_t>(K) + 1);
-    kept_write_kernel<<<div_up(n, 4), 256, 0, s>>>(list, list_off, skeys, ps.kept.as<Overlap>(),
-                                                   ps.kept_off.as<u32>(), new_kept_off, n, kept_new);
-    RVN_LAUNCH_CHECK();
+    RVN_KLAUNCH(kKKeptWrite, kept_write_kernel<<<div_up(n, 4), 256, 0, s>>>(list, list_off, skeys, ps.kept.as<Overlap>(),
+                                                   ps.kept_off.as<u32>(), new_kept_off, n, kept_new));
     // adopt: kept <- kept_new, kept_off <- new_kept_off
     std::swap(ps.kept.ptr, ps.tmp5.ptr);
     std::swap(ps.kept.cap, ps.tmp5.cap);

@@ -81,21 +81,56 @@ __global__ void scan_empty_kernel(Out* out) { out[0] = 0; }
 template <typename In, typename Out>
 void exclusive_scan_impl(const In* in, Out* out, u64 n, DevBuf& tmp, hipStream_t s) {
   if (n == 0) {
-    scan_empty_kernel<Out><<<1, 1, 0, s>>>(out);
-    RVN_LAUNCH_CHECK();
+    RVN_KLAUNCH(kKScan, scan_empty_kernel<Out><<<1, 1, 0, s>>>(out));
     return;
   }
   u32 nb = div_up(n, kScanTile);
   u64* sums = tmp.get<u64>(static_cast<size_t>(nb) + 1);
-  scan_reduce_kernel<In><<<nb, kScanThreads, 0, s>>>(in, n, sums);
-  RVN_LAUNCH_CHECK();
-  scan_block_sums_kernel<<<1, kScanThreads, 0, s>>>(sums, nb);
-  RVN_LAUNCH_CHECK();
-  scan_downsweep_kernel<In, Out><<<nb, kScanThreads, 0, s>>>(in, out, n, sums, nb);
-  RVN_LAUNCH_CHECK();
+  RVN_KLAUNCH(kKScan, scan_reduce_kernel<In><<<nb, kScanThreads, 0, s>>>(in, n, sums);
+              scan_block_sums_kernel<<<1, kScanThreads, 0, s>>>(sums, nb);
+              scan_downsweep_kernel<In, Out><<<nb, kScanThreads, 0, s>>>(in, out, n, sums, nb));
 }
 
 }  // namespace
+
+const char* const kKernelSiteNames[kKNumSites] = {
+    "sketch_count", "sketch_write", "minhash_select", "compact_sketch", "scan", "rs_bits", "rs_upsweep",
+    "rs_downsweep", "heads", "unique", "table", "occ_hist", "match_count", "match_emit", "seg_sort_group",
+    "intervals", "intervals_gather", "seg_sort_pos", "chain", "compact_overlaps", "pile_keys", "pile_counts",
+    "pile_build", "add_layers", "truncate_sort", "kept_write", "gather", "pile_sort_up", "pile_sort_down"};
+
+thread_local KernelTimers* g_kernel_timers = nullptr;
+
+KernelTimers::~KernelTimers() {
+  for (auto ev : pool) (void)hipEventDestroy(ev);
+}
+size_t KernelTimers::next_event() {
+  if (used == pool.size()) {
+    hipEvent_t ev;
+    RVN_HIP(hipEventCreate(&ev));
+    pool.push_back(ev);
+  }
+  return used++;
+}
+void KernelTimers::resolve() {
+  for (const auto& r : recs) {
+    float t = 0;
+    if (hipEventElapsedTime(&t, pool[r.e0], pool[r.e1]) == hipSuccess) {
+      ms[r.site] += t;
+      launches[r.site] += 1;
+    }
+  }
+  recs.clear();
+  used = 0;
+}
+void KernelTimers::reset() {
+  recs.clear();
+  used = 0;
+  for (int i = 0; i < kKNumSites; ++i) {
+    ms[i] = 0;
+    launches[i] = 0;
+  }
+}
 
 void exclusive_scan_u32_u64(const u32* in, u64* out, u64 n, DevBuf& tmp, hipStream_t s) {
   exclusive_scan_impl<u32, u64>(in, out, n, tmp, s);

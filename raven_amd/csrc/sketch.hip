@@ -261,10 +261,9 @@ void sketch_range_impl(Engine& e, const ReadsDev& r, u32 first, u32 last, bool m
   }
   u32* tile_cnt = e.tmp_a.get<u32>(nt);
   u32* tile_off = e.tmp_b.get<u32>(static_cast<size_t>(nt) + 1);
-  sketch_kernel<V, false><<<nt, kThreads, 0, s>>>(r.packed.as<u64>(), r.word_off.as<u64>(), r.len.as<u32>(),
+  RVN_KLAUNCH(kKSketchCount, sketch_kernel<V, false><<<nt, kThreads, 0, s>>>(r.packed.as<u64>(), r.word_off.as<u64>(), r.len.as<u32>(),
                                                   r.id.as<u32>(), r.tile_read.as<u32>(), r.tile_start.as<u32>(),
-                                                  tf, e.k, e.w, tile_cnt, nullptr, nullptr, nullptr);
-  RVN_LAUNCH_CHECK();
+                                                  tf, e.k, e.w, tile_cnt, nullptr, nullptr, nullptr));
   exclusive_scan_u32_u32(tile_cnt, tile_off, nt, e.scan_tmp, s);
   u32 total = 0;
   RVN_HIP(hipMemcpyAsync(&total, tile_off + nt, 4, hipMemcpyDeviceToHost, s));
@@ -274,14 +273,12 @@ void sketch_range_impl(Engine& e, const ReadsDev& r, u32 first, u32 last, bool m
   DevBuf& obuf = minhash ? e.raw_org : out.org;
   V* val = vbuf.get<V>(static_cast<size_t>(total) + 1);
   u64* org = obuf.get<u64>(static_cast<size_t>(total) + 1);
-  sketch_kernel<V, true><<<nt, kThreads, 0, s>>>(r.packed.as<u64>(), r.word_off.as<u64>(), r.len.as<u32>(),
+  RVN_KLAUNCH(kKSketchWrite, sketch_kernel<V, true><<<nt, kThreads, 0, s>>>(r.packed.as<u64>(), r.word_off.as<u64>(), r.len.as<u32>(),
                                                  r.id.as<u32>(), r.tile_read.as<u32>(), r.tile_start.as<u32>(), tf,
-                                                 e.k, e.w, nullptr, tile_off, val, org);
-  RVN_LAUNCH_CHECK();
+                                                 e.k, e.w, nullptr, tile_off, val, org));
   u32* raw_read_off = minhash ? e.raw_read_off.get<u32>(static_cast<size_t>(nr) + 1) : read_off_final;
-  gather_u32_kernel<<<div_up(nr + 1, 256), 256, 0, s>>>(tile_off, r.read_tile_off.as<u32>() + first, tf,
-                                                        raw_read_off, nr + 1);
-  RVN_LAUNCH_CHECK();
+  RVN_KLAUNCH(kKGather, gather_u32_kernel<<<div_up(nr + 1, 256), 256, 0, s>>>(tile_off, r.read_tile_off.as<u32>() + first, tf,
+                                                        raw_read_off, nr + 1));
   if (!minhash) {
     out.count = total;
     return;
@@ -289,9 +286,8 @@ void sketch_range_impl(Engine& e, const ReadsDev& r, u32 first, u32 last, bool m
   u8* flags = e.tmp_c.get<u8>(static_cast<size_t>(total) + 1);
   u32* fscan = e.tmp_d.get<u32>(static_cast<size_t>(total) + 1);
   const int nbytes = (2 * e.k + 7) / 8;
-  minhash_select_kernel<V><<<nr, kThreads, 0, s>>>(val, raw_read_off, r.len.as<u32>(), first, e.k,
-                                                   8 * (nbytes - 1), flags);
-  RVN_LAUNCH_CHECK();
+  RVN_KLAUNCH(kKMinhashSelect, minhash_select_kernel<V><<<nr, kThreads, 0, s>>>(val, raw_read_off, r.len.as<u32>(), first, e.k,
+                                                   8 * (nbytes - 1), flags));
   exclusive_scan_u8_u32(flags, fscan, total, e.scan_tmp, s);
   u32 kept = 0;
   RVN_HIP(hipMemcpyAsync(&kept, fscan + total, 4, hipMemcpyDeviceToHost, s));
@@ -299,12 +295,10 @@ void sketch_range_impl(Engine& e, const ReadsDev& r, u32 first, u32 last, bool m
   V* oval = out.val.get<V>(static_cast<size_t>(kept) + 1);
   u64* oorg = out.org.get<u64>(static_cast<size_t>(kept) + 1);
   if (total) {
-    compact_sketch_kernel<V><<<div_up(total, 256), 256, 0, s>>>(val, org, flags, fscan, total, oval, oorg);
-    RVN_LAUNCH_CHECK();
+    RVN_KLAUNCH(kKCompactSketch, compact_sketch_kernel<V><<<div_up(total, 256), 256, 0, s>>>(val, org, flags, fscan, total, oval, oorg));
   }
   // read_off_final[i] = fscan[raw_read_off[i]]
-  gather_u32_kernel<<<div_up(nr + 1, 256), 256, 0, s>>>(fscan, raw_read_off, 0, read_off_final, nr + 1);
-  RVN_LAUNCH_CHECK();
+  RVN_KLAUNCH(kKGather, gather_u32_kernel<<<div_up(nr + 1, 256), 256, 0, s>>>(fscan, raw_read_off, 0, read_off_final, nr + 1));
   out.count = kept;
 }
 

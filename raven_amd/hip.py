@@ -30,7 +30,8 @@ SYMBOLS = [
     "rvn_pass1_fetch_piles", "rvn_pass1_fetch_overlaps", "rvn_pass1_destroy", "rvn_pile_add_layers",
     "rvn_engine_sketch", "rvn_engine_sketch_fetch", "rvn_engine_index_size", "rvn_engine_index_fetch",
     "rvn_engine_counters", "rvn_engine_num_stages", "rvn_engine_stage_name", "rvn_engine_stage_ms",
-    "rvn_engine_reset_stats", "rvn_engine_set_timing", "rvn_test_hash", "rvn_test_canonical",
+    "rvn_engine_reset_stats", "rvn_engine_set_timing", "rvn_engine_set_kernel_timing",
+    "rvn_engine_num_kernel_sites", "rvn_engine_kernel_site_name", "rvn_engine_kernel_ms", "rvn_test_hash", "rvn_test_canonical",
     "rvn_test_std_sort_lendesc", "rvn_test_heap_sort_lendesc",
 ]
 
@@ -87,6 +88,11 @@ def lib():
     L.rvn_engine_stage_ms.argtypes = [vp, vp, vp, i32]
     L.rvn_engine_reset_stats.argtypes = [vp]
     L.rvn_engine_set_timing.argtypes = [vp, i32]
+    L.rvn_engine_set_kernel_timing.argtypes = [vp, i32]
+    L.rvn_engine_num_kernel_sites.restype = i32
+    L.rvn_engine_kernel_site_name.restype = C.c_char_p
+    L.rvn_engine_kernel_site_name.argtypes = [i32]
+    L.rvn_engine_kernel_ms.argtypes = [vp, vp, vp, i32]
     L.rvn_test_hash.restype = u64
     L.rvn_test_hash.argtypes = [u64, u32, i32]
     L.rvn_test_canonical.restype = i32
@@ -267,6 +273,18 @@ class Engine:
         la = np.zeros(n, dtype=np.uint64)
         _check(L.rvn_engine_stage_ms(self._h, _p(ms), _p(la), n))
         return {L.rvn_engine_stage_name(i).decode(): (float(ms[i]), int(la[i])) for i in range(n)}
+
+    def set_kernel_timing(self, enabled: bool):
+        lib().rvn_engine_set_kernel_timing(self._h, int(enabled))
+
+    def kernel_ms(self):
+        """{site: (total device ms, launches)} since the last reset_stats()."""
+        L = lib()
+        n = L.rvn_engine_num_kernel_sites()
+        ms = np.zeros(n, dtype=np.float64)
+        la = np.zeros(n, dtype=np.uint64)
+        _check(L.rvn_engine_kernel_ms(self._h, _p(ms), _p(la), n))
+        return {L.rvn_engine_kernel_site_name(i).decode(): (float(ms[i]), int(la[i])) for i in range(n)}
 
     def reset_stats(self):
         lib().rvn_engine_reset_stats(self._h)

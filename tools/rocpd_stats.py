@@ -1,0 +1,22 @@
+#!/usr/bin/env python3
+"""Export the per-kernel summary (rocprofv3 --kernel-trace --stats, rocpd SQLite output) as CSV:
+    python tools/rocpd_stats.py gpurun_out/prof1/r01_results.db profiles/r01_kernel_stats.csv"""
+import csv
+import sqlite3
+import sys
+
+
+def main(db_path, out_path):
+    db = sqlite3.connect(db_path)
+    cur = db.cursor()
+    rows = list(cur.execute("select name, total_calls, total_duration, average, percentage from top_kernels"))
+    with open(out_path, "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["Name", "Calls", "TotalDurationUs", "AverageUs", "Percentage"])
+        for name, calls, tot, avg, pct in rows:
+            w.writerow([name, calls, "%.3f" % tot, "%.3f" % avg, "%.4f" % pct])
+    print("wrote %s (%d kernels)" % (out_path, len(rows)))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2])
