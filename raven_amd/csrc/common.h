@@ -136,10 +136,13 @@ void exclusive_scan_u8_u32(const u8* in, u32* out, u64 n, DevBuf& tmp, hipStream
 // Ping-pongs between (k0,v0) and (k1,v1); returns 0 if the sorted data ends in
 // (k0,v0), 1 if in (k1,v1).
 int radix_sort_pairs_u32_u64(u32* k0, u32* k1, u64* v0, u64* v1, u64 n, int key_bits, DevBuf& tmp, DevBuf& tmp2, hipStream_t s,
-                             int site_up = kKRsUpsweep, int site_down = kKRsDownsweep);
+                             int site_up = kKRsUpsweep, int site_down = kKRsDownsweep,
+                             bool skip_constant_digits = true);
 int radix_sort_pairs_u64_u64(u64* k0, u64* k1, u64* v0, u64* v1, u64 n, int key_bits, DevBuf& tmp, DevBuf& tmp2, hipStream_t s,
-                             int site_up = kKRsUpsweep, int site_down = kKRsDownsweep);
+                             int site_up = kKRsUpsweep, int site_down = kKRsDownsweep,
+                             bool skip_constant_digits = true);
 int radix_sort_pairs_u32_u32(u32* k0, u32* k1, u32* v0, u32* v1, u64 n, int key_bits, DevBuf& tmp, DevBuf& tmp2, hipStream_t s,
-                             int site_up = kKRsUpsweep, int site_down = kKRsDownsweep);
+                             int site_up = kKRsUpsweep, int site_down = kKRsDownsweep,
+                             bool skip_constant_digits = true);
 
 }  // namespace rvn

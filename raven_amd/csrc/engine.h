@@ -79,11 +79,14 @@ struct Engine {
   bool val64 = false;  // true when minimizer values need 64 bits
   hipStream_t stream = nullptr;
   Index index;
-  Sketch index_sketch, query_sketch;
+  Sketch index_sketch, query_sketch, raw_sketch;
+  // query sketch prepared ahead of map_batch (valid for exactly this range / minhash flag)
+  bool query_ready = false;
+  u32 query_ready_first = 0, query_ready_last = 0;
+  bool query_ready_minhash = false;
   MapOut map_out;
   // scratch
   DevBuf tmp_a, tmp_b, tmp_c, tmp_d, tmp_e, tmp_f, scan_tmp, sort_tmp;
-  DevBuf raw_val, raw_org, raw_read_off;
   DevBuf q_start, q_cnt, m_off;
   DevBuf m_grp[2], m_pos[2];
   DevBuf seg_off, iv_slot_begin, iv_slot_end, iv_cnt, iv_off, iv_begin, iv_end;
@@ -118,6 +121,8 @@ struct StageTimer {
 
 // ---- stages (one translation unit each) -------------------------------------
 void reads_build_tiles(Engine& e, ReadsDev& r);
+void sketch_raw(Engine& e, const ReadsDev& r, u32 first, u32 last, Sketch& out);
+void sketch_minhash(Engine& e, const ReadsDev& r, const Sketch& raw, Sketch& out);
 void sketch_range(Engine& e, const ReadsDev& r, u32 first, u32 last, bool minhash, Sketch& out);
 void index_build(Engine& e, Sketch& sk);                 // consumes sk.val/sk.org
 void index_filter(Engine& e, double freq);               // sets e.index.occurrence

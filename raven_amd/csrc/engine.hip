@@ -60,10 +60,50 @@ struct UseTimers {
   ~UseTimers() { g_kernel_timers = nullptr; }
 };
 
-void do_minimize(Engine& e, const ReadsDev& r, u32 first, u32 last, bool minhash) {
+void swap_bufs(DevBuf& a, DevBuf& b) {
+  std::swap(a.ptr, b.ptr);
+  std::swap(a.cap, b.cap);
+}
+
+// Sketch [first,last) and build the index.  With prefetch_query the minhash QUERY sketch of the same
+// range (construct.cc:62 always maps with minhash=true) is derived from the same raw sketch before the
+// index sort consumes it, so map_batch over that range does not sketch again.
+void do_minimize(Engine& e, const ReadsDev& r, u32 first, u32 last, bool minhash, bool prefetch_query = false) {
   {
     StageTimer t(e, StageTimes::kSketch);
-    sketch_range(e, r, first, last, minhash, e.index_sketch);
+    e.query_ready = false;
+    sketch_raw(e, r, first, last, e.raw_sketch);
+    if (prefetch_query) {
+      sketch_minhash(e, r, e.raw_sketch, e.query_sketch);
+      e.query_ready = true;
+      e.query_ready_first = first;
+      e.query_ready_last = last;
+      e.query_ready_minhash = true;
+    }
+    Sketch& is = e.index_sketch;
+    if (!minhash) {
+      swap_bufs(is.val, e.raw_sketch.val);
+      swap_bufs(is.org, e.raw_sketch.org);
+      swap_bufs(is.read_off, e.raw_sketch.read_off);
+      is.first = first;
+      is.last = last;
+      is.count = e.raw_sketch.count;
+      e.raw_sketch.count = 0;
+    } else if (prefetch_query) {
+      const Sketch& qs = e.query_sketch;
+      const size_t vb = e.val64 ? 8 : 4;
+      is.first = first;
+      is.last = last;
+      is.count = qs.count;
+      is.val.reserve((qs.count + 1) * vb);
+      is.org.reserve((qs.count + 1) * 8);
+      if (qs.count) {
+        RVN_HIP(hipMemcpyAsync(is.val.ptr, qs.val.ptr, qs.count * vb, hipMemcpyDeviceToDevice, e.stream));
+        RVN_HIP(hipMemcpyAsync(is.org.ptr, qs.org.ptr, qs.count * 8, hipMemcpyDeviceToDevice, e.stream));
+      }
+    } else {
+      sketch_minhash(e, r, e.raw_sketch, is);
+    }
     t.stop();
   }
   for (u32 i = first; i < last; ++i) e.c_index_bases += r.h_len[i];
@@ -274,7 +314,19 @@ int rvn_find_overlaps_and_create_piles(rvn_engine* h, const rvn_reads* rr, doubl
       bytes += r.h_len[i];
       if (i != n - 1 && bytes < index_batch_bases) continue;
       bytes = 0;
-      do_minimize(e, r, j, i + 1, use_minhash != 0);
+      // does the first query flush cover exactly the index range [j, i+1)?  (always true for one batch)
+      bool prefetch = false;
+      if (j == 0) {
+        u64 fb = 0;
+        u32 kk = 0;
+        for (; kk < i + 1; ++kk) {
+          fb += r.h_len[kk];
+          if (kk != i && fb < flush_bases) continue;
+          break;
+        }
+        prefetch = (kk == i);
+      }
+      do_minimize(e, r, j, i + 1, use_minhash != 0, prefetch);
       index_filter(e, freq);
       u32 flush_first = 0;
       for (u32 k = 0; k < i + 1; ++k) {

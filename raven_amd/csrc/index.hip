@@ -36,15 +36,41 @@ __global__ void unique_kernel(const V* __restrict__ val, const u8* __restrict__ 
 }
 
 // table[b] = first distinct-key index j with (u_val[j] >> shift) >= b, for b in [0, B]; B = 1 << bits.
+// Minimizer hashes are window MINIMA, so they crowd the low end of the value range and the top of
+// the table is sparse: a lane may own a gap of 10^3..10^6 buckets.  Short gaps are filled by their
+// lane; long gaps are filled by the whole wave (64 coalesced stores per step).
 template <typename V>
-__global__ void table_kernel(const V* __restrict__ u_val, u32 u, int shift, u32 B, u32* __restrict__ table) {
-  u32 j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= u) return;
-  const long long bj = static_cast<long long>(static_cast<u64>(u_val[j]) >> shift);
-  const long long bp = j ? static_cast<long long>(static_cast<u64>(u_val[j - 1]) >> shift) : -1;
-  for (long long b = bp + 1; b <= bj; ++b) table[b] = j;
-  if (j == u - 1)
-    for (long long b = bj + 1; b <= static_cast<long long>(B); ++b) table[b] = u;
+__global__ __launch_bounds__(256) void table_kernel(const V* __restrict__ u_val, u32 u, int shift,
+                                                   u32* __restrict__ table) {
+  const u32 j = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = lane_id();
+  u32 start = 0, len = 0;
+  if (j < u) {
+    const long long bj = static_cast<long long>(static_cast<u64>(u_val[j]) >> shift);
+    const long long bp = j ? static_cast<long long>(static_cast<u64>(u_val[j - 1]) >> shift) : -1;
+    start = static_cast<u32>(bp + 1);
+    len = static_cast<u32>(bj - bp);
+  }
+  if (len <= 8) {
+    for (u32 i = 0; i < len; ++i) table[start + i] = j;
+  }
+  unsigned long long longmask = __ballot(len > 8);
+  while (longmask) {
+    const int l = __ffsll(static_cast<long long>(longmask)) - 1;
+    longmask &= longmask - 1;
+    const u32 s = __shfl(start, l, 64), n = __shfl(len, l, 64), v = __shfl(j, l, 64);
+    for (u32 i = lane; i < n; i += 64) table[s + i] = v;
+  }
+}
+
+// buckets above the largest key: table[b] = u for b in (u_val[u-1] >> shift, B]
+template <typename V>
+__global__ __launch_bounds__(256) void table_tail_kernel(const V* __restrict__ u_val, u32 u, int shift, u32 B,
+                                                        u32* __restrict__ table) {
+  const u64 first = (static_cast<u64>(u_val[u - 1]) >> shift) + 1;
+  for (u64 b = first + static_cast<u64>(blockIdx.x) * blockDim.x + threadIdx.x; b <= B;
+       b += static_cast<u64>(gridDim.x) * blockDim.x)
+    table[b] = u;
 }
 
 __global__ void table_empty_kernel(u32* table, u32 B) {
@@ -111,10 +137,10 @@ void index_build_impl(Engine& e, Sketch& sk) {
     StageTimer t(e, StageTimes::kSort);
     if (sizeof(V) == 4)
       ix.cur = radix_sort_pairs_u32_u64(reinterpret_cast<u32*>(v0), reinterpret_cast<u32*>(v1), o0, o1, m, 2 * e.k,
-                                        e.sort_tmp, e.scan_tmp, s);
+                                        e.sort_tmp, e.scan_tmp, s, kKRsUpsweep, kKRsDownsweep, false);
     else
       ix.cur = radix_sort_pairs_u64_u64(reinterpret_cast<u64*>(v0), reinterpret_cast<u64*>(v1), o0, o1, m, 2 * e.k,
-                                        e.sort_tmp, e.scan_tmp, s);
+                                        e.sort_tmp, e.scan_tmp, s, kKRsUpsweep, kKRsDownsweep, false);
     t.stop();
   }
   StageTimer t(e, StageTimes::kIndex);
@@ -139,7 +165,8 @@ void index_build_impl(Engine& e, Sketch& sk) {
   ix.shift = 2 * e.k - bits;
   const u32 B = 1u << bits;
   u32* table = ix.table.get<u32>(static_cast<size_t>(B) + 2);
-  RVN_KLAUNCH(kKTable, table_kernel<V><<<div_up(u, 256), 256, 0, s>>>(u_val, u, ix.shift, B, table));
+  RVN_KLAUNCH(kKTable, table_kernel<V><<<div_up(u, 256), 256, 0, s>>>(u_val, u, ix.shift, table);
+              table_tail_kernel<V><<<256, 256, 0, s>>>(u_val, u, ix.shift, B, table));
   t.stop();
 }
 

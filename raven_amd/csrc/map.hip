@@ -405,7 +405,10 @@ void map_batch_impl(Engine& e, const ReadsDev& r, u32 first, u32 last, bool avoi
   Sketch& qs = e.query_sketch;
   {
     StageTimer t(e, StageTimes::kQuery);
-    sketch_range(e, r, first, last, minhash, qs);
+    const bool ready = e.query_ready && e.query_ready_first == first && e.query_ready_last == last &&
+                       e.query_ready_minhash == minhash;
+    e.query_ready = false;
+    if (!ready) sketch_range(e, r, first, last, minhash, qs);
     t.stop();
   }
   const u64 nq = qs.count;

@@ -126,7 +126,7 @@ __global__ void rs_bits_init_kernel(u64* out2) {
 
 template <typename K, typename V>
 int radix_sort_impl(K* k0, K* k1, V* v0, V* v1, u64 n, int key_bits, DevBuf& tmp, DevBuf& tmp2, hipStream_t s,
-                    int site_up, int site_down) {
+                    int site_up, int site_down, bool skip_constant_digits) {
   if (n <= 1 || key_bits <= 0) return 0;
   if (n >= (1ULL << 32)) throw HipError("[raven_hip] radix_sort: n >= 2^32 not supported");
   u32 nb = div_up(n, kTile);
@@ -141,13 +141,16 @@ int radix_sort_impl(K* k0, K* k1, V* v0, V* v1, u64 n, int key_bits, DevBuf& tmp
   u32* hist = reinterpret_cast<u32*>(base + off_hist);
   u32* scanned = reinterpret_cast<u32*>(base + off_scanned);
 
+  u64 varying = ~0ULL;
+  if (skip_constant_digits) {
   RVN_KLAUNCH(kKRsBits, rs_bits_init_kernel<<<1, 1, 0, s>>>(bits));
   u32 gb = nb < 2048 ? (nb * 16 < 1 ? 1 : (nb * 16 > 2048 ? 2048 : nb * 16)) : 2048;
   RVN_KLAUNCH(kKRsBits, rs_bits_kernel<K><<<gb, kThreads, 0, s>>>(k0, n, bits));
   u64 hbits[2];
   RVN_HIP(hipMemcpyAsync(hbits, bits, 16, hipMemcpyDeviceToHost, s));
   RVN_HIP(hipStreamSynchronize(s));
-  const u64 varying = hbits[0] ^ hbits[1];
+  varying = hbits[0] ^ hbits[1];
+  }
 
   int cur = 0;
   for (int shift = 0; shift < key_bits; shift += 8) {
@@ -168,16 +171,16 @@ int radix_sort_impl(K* k0, K* k1, V* v0, V* v1, u64 n, int key_bits, DevBuf& tmp
 }  // namespace
 
 int radix_sort_pairs_u32_u64(u32* k0, u32* k1, u64* v0, u64* v1, u64 n, int key_bits, DevBuf& tmp, DevBuf& tmp2, hipStream_t s,
-                    int site_up, int site_down) {
-  return radix_sort_impl<u32, u64>(k0, k1, v0, v1, n, key_bits, tmp, tmp2, s, site_up, site_down);
+                    int site_up, int site_down, bool skip_constant_digits) {
+  return radix_sort_impl<u32, u64>(k0, k1, v0, v1, n, key_bits, tmp, tmp2, s, site_up, site_down, skip_constant_digits);
 }
 int radix_sort_pairs_u64_u64(u64* k0, u64* k1, u64* v0, u64* v1, u64 n, int key_bits, DevBuf& tmp, DevBuf& tmp2, hipStream_t s,
-                    int site_up, int site_down) {
-  return radix_sort_impl<u64, u64>(k0, k1, v0, v1, n, key_bits, tmp, tmp2, s, site_up, site_down);
+                    int site_up, int site_down, bool skip_constant_digits) {
+  return radix_sort_impl<u64, u64>(k0, k1, v0, v1, n, key_bits, tmp, tmp2, s, site_up, site_down, skip_constant_digits);
 }
 int radix_sort_pairs_u32_u32(u32* k0, u32* k1, u32* v0, u32* v1, u64 n, int key_bits, DevBuf& tmp, DevBuf& tmp2, hipStream_t s,
-                    int site_up, int site_down) {
-  return radix_sort_impl<u32, u32>(k0, k1, v0, v1, n, key_bits, tmp, tmp2, s, site_up, site_down);
+                    int site_up, int site_down, bool skip_constant_digits) {
+  return radix_sort_impl<u32, u32>(k0, k1, v0, v1, n, key_bits, tmp, tmp2, s, site_up, site_down, skip_constant_digits);
 }
 
 }  // namespace rvn

@@ -246,59 +246,77 @@ __global__ void compact_sketch_kernel(const V* __restrict__ val, const u64* __re
 }
 
 template <typename V>
-void sketch_range_impl(Engine& e, const ReadsDev& r, u32 first, u32 last, bool minhash, Sketch& out) {
+void sketch_raw_impl(Engine& e, const ReadsDev& r, u32 first, u32 last, Sketch& out) {
   hipStream_t s = e.stream;
   out.first = first;
   out.last = last;
   out.count = 0;
   const u32 nr = last - first;
-  u32* read_off_final = out.read_off.get<u32>(static_cast<size_t>(nr) + 1);
+  u32* read_off = out.read_off.get<u32>(static_cast<size_t>(nr) + 1);
   const u32 tf = r.h_read_tile_off[first], tl = r.h_read_tile_off[last];
   const u32 nt = tl - tf;
   if (nt == 0) {
-    RVN_HIP(hipMemsetAsync(read_off_final, 0, (static_cast<size_t>(nr) + 1) * 4, s));
+    RVN_HIP(hipMemsetAsync(read_off, 0, (static_cast<size_t>(nr) + 1) * 4, s));
+    out.val.reserve(16);
+    out.org.reserve(16);
     return;
   }
   u32* tile_cnt = e.tmp_a.get<u32>(nt);
   u32* tile_off = e.tmp_b.get<u32>(static_cast<size_t>(nt) + 1);
-  RVN_KLAUNCH(kKSketchCount, sketch_kernel<V, false><<<nt, kThreads, 0, s>>>(r.packed.as<u64>(), r.word_off.as<u64>(), r.len.as<u32>(),
-                                                  r.id.as<u32>(), r.tile_read.as<u32>(), r.tile_start.as<u32>(),
-                                                  tf, e.k, e.w, tile_cnt, nullptr, nullptr, nullptr));
+  RVN_KLAUNCH(kKSketchCount, sketch_kernel<V, false><<<nt, kThreads, 0, s>>>(
+                                 r.packed.as<u64>(), r.word_off.as<u64>(), r.len.as<u32>(), r.id.as<u32>(),
+                                 r.tile_read.as<u32>(), r.tile_start.as<u32>(), tf, e.k, e.w, tile_cnt, nullptr,
+                                 nullptr, nullptr));
   exclusive_scan_u32_u32(tile_cnt, tile_off, nt, e.scan_tmp, s);
   u32 total = 0;
   RVN_HIP(hipMemcpyAsync(&total, tile_off + nt, 4, hipMemcpyDeviceToHost, s));
   RVN_HIP(hipStreamSynchronize(s));
+  V* val = out.val.get<V>(static_cast<size_t>(total) + 1);
+  u64* org = out.org.get<u64>(static_cast<size_t>(total) + 1);
+  RVN_KLAUNCH(kKSketchWrite, sketch_kernel<V, true><<<nt, kThreads, 0, s>>>(
+                                 r.packed.as<u64>(), r.word_off.as<u64>(), r.len.as<u32>(), r.id.as<u32>(),
+                                 r.tile_read.as<u32>(), r.tile_start.as<u32>(), tf, e.k, e.w, nullptr, tile_off, val,
+                                 org));
+  RVN_KLAUNCH(kKGather, gather_u32_kernel<<<div_up(nr + 1, 256), 256, 0, s>>>(
+                            tile_off, r.read_tile_off.as<u32>() + first, tf, read_off, nr + 1));
+  out.count = total;
+}
 
-  DevBuf& vbuf = minhash ? e.raw_val : out.val;
-  DevBuf& obuf = minhash ? e.raw_org : out.org;
-  V* val = vbuf.get<V>(static_cast<size_t>(total) + 1);
-  u64* org = obuf.get<u64>(static_cast<size_t>(total) + 1);
-  RVN_KLAUNCH(kKSketchWrite, sketch_kernel<V, true><<<nt, kThreads, 0, s>>>(r.packed.as<u64>(), r.word_off.as<u64>(), r.len.as<u32>(),
-                                                 r.id.as<u32>(), r.tile_read.as<u32>(), r.tile_start.as<u32>(), tf,
-                                                 e.k, e.w, nullptr, tile_off, val, org));
-  u32* raw_read_off = minhash ? e.raw_read_off.get<u32>(static_cast<size_t>(nr) + 1) : read_off_final;
-  RVN_KLAUNCH(kKGather, gather_u32_kernel<<<div_up(nr + 1, 256), 256, 0, s>>>(tile_off, r.read_tile_off.as<u32>() + first, tf,
-                                                        raw_read_off, nr + 1));
-  if (!minhash) {
-    out.count = total;
+template <typename V>
+void sketch_minhash_impl(Engine& e, const ReadsDev& r, const Sketch& raw, Sketch& out) {
+  hipStream_t s = e.stream;
+  const u32 first = raw.first, last = raw.last;
+  const u32 nr = last - first;
+  const u64 total = raw.count;
+  out.first = first;
+  out.last = last;
+  out.count = 0;
+  u32* read_off_final = out.read_off.get<u32>(static_cast<size_t>(nr) + 1);
+  if (total == 0) {
+    RVN_HIP(hipMemsetAsync(read_off_final, 0, (static_cast<size_t>(nr) + 1) * 4, s));
+    out.val.reserve(16);
+    out.org.reserve(16);
     return;
   }
+  const V* val = raw.val.as<V>();
+  const u64* org = raw.org.as<u64>();
+  const u32* raw_read_off = raw.read_off.as<u32>();
   u8* flags = e.tmp_c.get<u8>(static_cast<size_t>(total) + 1);
   u32* fscan = e.tmp_d.get<u32>(static_cast<size_t>(total) + 1);
   const int nbytes = (2 * e.k + 7) / 8;
-  RVN_KLAUNCH(kKMinhashSelect, minhash_select_kernel<V><<<nr, kThreads, 0, s>>>(val, raw_read_off, r.len.as<u32>(), first, e.k,
-                                                   8 * (nbytes - 1), flags));
+  RVN_KLAUNCH(kKMinhashSelect, minhash_select_kernel<V><<<nr, kThreads, 0, s>>>(val, raw_read_off, r.len.as<u32>(),
+                                                                                first, e.k, 8 * (nbytes - 1), flags));
   exclusive_scan_u8_u32(flags, fscan, total, e.scan_tmp, s);
   u32 kept = 0;
   RVN_HIP(hipMemcpyAsync(&kept, fscan + total, 4, hipMemcpyDeviceToHost, s));
   RVN_HIP(hipStreamSynchronize(s));
   V* oval = out.val.get<V>(static_cast<size_t>(kept) + 1);
   u64* oorg = out.org.get<u64>(static_cast<size_t>(kept) + 1);
-  if (total) {
-    RVN_KLAUNCH(kKCompactSketch, compact_sketch_kernel<V><<<div_up(total, 256), 256, 0, s>>>(val, org, flags, fscan, total, oval, oorg));
-  }
+  RVN_KLAUNCH(kKCompactSketch,
+              compact_sketch_kernel<V><<<div_up(total, 256), 256, 0, s>>>(val, org, flags, fscan, total, oval, oorg));
   // read_off_final[i] = fscan[raw_read_off[i]]
-  RVN_KLAUNCH(kKGather, gather_u32_kernel<<<div_up(nr + 1, 256), 256, 0, s>>>(fscan, raw_read_off, 0, read_off_final, nr + 1));
+  RVN_KLAUNCH(kKGather,
+              gather_u32_kernel<<<div_up(nr + 1, 256), 256, 0, s>>>(fscan, raw_read_off, 0, read_off_final, nr + 1));
   out.count = kept;
 }
 
@@ -330,9 +348,23 @@ void reads_build_tiles(Engine& e, ReadsDev& r) {
   RVN_HIP(hipMemcpy(d_rto, r.h_read_tile_off.data(), (static_cast<size_t>(r.n) + 1) * 4, hipMemcpyHostToDevice));
 }
 
+void sketch_raw(Engine& e, const ReadsDev& r, u32 first, u32 last, Sketch& out) {
+  if (e.val64) sketch_raw_impl<u64>(e, r, first, last, out);
+  else sketch_raw_impl<u32>(e, r, first, last, out);
+}
+
+void sketch_minhash(Engine& e, const ReadsDev& r, const Sketch& raw, Sketch& out) {
+  if (e.val64) sketch_minhash_impl<u64>(e, r, raw, out);
+  else sketch_minhash_impl<u32>(e, r, raw, out);
+}
+
 void sketch_range(Engine& e, const ReadsDev& r, u32 first, u32 last, bool minhash, Sketch& out) {
-  if (e.val64) sketch_range_impl<u64>(e, r, first, last, minhash, out);
-  else sketch_range_impl<u32>(e, r, first, last, minhash, out);
+  if (!minhash) {
+    sketch_raw(e, r, first, last, out);
+    return;
+  }
+  sketch_raw(e, r, first, last, e.raw_sketch);
+  sketch_minhash(e, r, e.raw_sketch, out);
 }
 
 }  // namespace rvn
