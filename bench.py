@@ -24,6 +24,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+from raven_amd import dist as rdist  # noqa: E402
 from raven_amd import hip, synth  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured copy)
@@ -90,9 +91,7 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    rank, world, local_rank = rdist.env_rank()
 
     import torch  # plumbing only: device selection, barrier, max-over-ranks
     if not torch.cuda.is_available():
@@ -114,8 +113,9 @@ def main():
 
     # ---- synthetic shard of this rank (seeded; rank-dependent so shards are independent) ----
     t0 = time.time()
-    genome = synth.make_genome(args.genome, seed=0x5EED0001 + 1000 * rank)
-    rs, _ = synth.make_reads(genome, args.coverage, args.read_len, seed=0x5EED0002 + 1000 * rank)
+    genome_seed, reads_seed = rdist.shard_seeds(rank)
+    genome = synth.make_genome(args.genome, seed=genome_seed)
+    rs, _ = synth.make_reads(genome, args.coverage, args.read_len, seed=reads_seed)
     t_gen = time.time() - t0
 
     eng = hip.Engine(args.k, args.w, device=local_rank)
@@ -139,15 +139,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
 
-    if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-        tb = torch.tensor([float(rs.total_bases)], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tb, op=dist.ReduceOp.SUM)
-        total_bases = float(tb.item())
-    else:
-        total_bases = float(rs.total_bases)
+    dt, total_bases = rdist.aggregate(dt, float(rs.total_bases), dist, device="cuda")
 
     if rank == 0:
         steps = max(args.steps, 1)
@@ -177,7 +169,7 @@ def main():
                             "kernel_ms_share": round(kms[dom][0] / tot, 3) if tot else None}
         out = {
             "metric": "read Gbase/s through overlap+polish",
-            "value": round(total_bases * args.steps / dt / 1e9, 4),
+            "value": round(rdist.throughput(dt, total_bases, args.steps) / 1e9, 4),
             "unit": "Gbase/s",
             "n_gpus": world,
             "steps": args.steps,

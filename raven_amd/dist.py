@@ -1,0 +1,33 @@
+"""Multi-GPU plumbing for the overlap path: one process per GPU, shards are independent (no data-path
+collective this round); torch.distributed (RCCL on GPU, gloo in the CPU tests) is used only for
+the barrier and the max-over-ranks / sum-over-ranks reductions of the bench contract."""
+from __future__ import annotations
+
+import os
+
+
+def env_rank():
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")),
+            int(os.environ.get("LOCAL_RANK", "0")))
+
+
+def shard_seeds(rank: int, base_genome_seed: int = 0x5EED0001, base_reads_seed: int = 0x5EED0002):
+    """Independent synthetic shard of rank r (weak scaling: per-GPU work fixed)."""
+    return base_genome_seed + 1000 * rank, base_reads_seed + 1000 * rank
+
+
+def aggregate(dt: float, units: float, dist=None, device="cpu"):
+    """(max over ranks of dt, sum over ranks of units). `dist` is torch.distributed or None."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return dt, units
+    import torch
+    t = torch.tensor([dt], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    u = torch.tensor([units], dtype=torch.float64, device=device)
+    dist.all_reduce(u, op=dist.ReduceOp.SUM)
+    return float(t.item()), float(u.item())
+
+
+def throughput(dt_max: float, units_total: float, steps: int) -> float:
+    """Whole-job units per second (units processed by ALL ranks / max-over-ranks time)."""
+    return units_total * steps / dt_max

@@ -1,0 +1,67 @@
+"""The C++ facade (include/ram/minimizer_engine.hpp + include/raven_hip/find_overlaps.hpp) compiled with g++
+against tests/cpp test doubles of biosoup, run on the GPU and compared with the ctypes path."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from raven_amd import hip, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _build(tmp_path):
+    exe = str(tmp_path / "facade_test")
+    lib = os.path.join(ROOT, "raven_amd", "lib")
+    cmd = ["g++", "-std=c++17", "-O2", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "tests", "cpp"),
+           "-o", exe, os.path.join(ROOT, "tests", "cpp", "facade_test.cpp"), "-L", lib, "-lraven_hip",
+           "-Wl,-rpath," + lib, "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"]
+    subprocess.check_call(cmd)
+    return exe
+
+
+def _write_reads(tmp_path, rs):
+    path = str(tmp_path / "reads.txt")
+    with open(path, "wb") as f:
+        for i in range(rs.n):
+            f.write(rs.inflate(i) + b"\n")
+    return path
+
+
+def test_facade_compiles_and_fails_loudly_without_gpu(tmp_path):
+    if hip.device_count() > 0:
+        pytest.skip("GPU present")
+    exe = _build(tmp_path)
+    p = tmp_path / "one.txt"
+    p.write_text("ACGTACGTACGTACGTACGTACGTACGT\n")
+    r = subprocess.run([exe, str(p)], capture_output=True, text=True)
+    assert r.returncode == 1 and "no HIP device" in r.stdout
+
+
+@pytest.mark.gpu
+def test_facade_matches_c_abi(tmp_path):
+    exe = _build(tmp_path)
+    g = synth.make_genome(80_000, seed=41)
+    rs, _ = synth.make_reads(g, 12, 5000, seed=42)
+    path = _write_reads(tmp_path, rs)
+    r = subprocess.run([exe, path], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = r.stdout.strip().split("\n")
+    assert lines[0] == "filter_throws 1"
+    eng = hip.Engine(15, 5)
+    rd = eng.upload(rs)
+    p = eng.find_overlaps_and_create_piles(rd)
+    data, _ = p.piles()
+    ovl, off = p.overlaps()
+    cov = 0
+    for v in data.tolist():
+        cov = (cov * 1000003 + v) & 0xFFFFFFFFFFFFFFFF
+    assert lines[1] == "piles %d cov_hash %d" % (rs.n, cov)
+    got = [tuple(int(x) for x in ln.split()[1:]) for ln in lines if ln.startswith("O ")]
+    pile_of = np.repeat(np.arange(rs.n), np.diff(off.astype(np.int64)))
+    want = [(int(pi), int(o["lhs_id"]), int(o["lhs_begin"]), int(o["lhs_end"]), int(o["rhs_id"]), int(o["rhs_begin"]),
+             int(o["rhs_end"]), int(o["score"]), int(o["strand"])) for pi, o in zip(pile_of, ovl)]
+    assert got == want and len(got) > 100
+    assert lines[-1].startswith("map_single_vs_batch mismatches 0 total ")
+    assert int(lines[-1].split()[-1]) > 0
