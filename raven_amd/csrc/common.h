@@ -68,7 +68,7 @@ enum KernelSite {
   kKSketchCount, kKSketchWrite, kKMinhashSelect, kKCompactSketch, kKScan, kKRsBits, kKRsUpsweep, kKRsDownsweep,
   kKHeads, kKUnique, kKTable, kKOccHist, kKMatchCount, kKMatchEmit, kKSegSortGroup, kKIntervals,
   kKIntervalsGather, kKSegSortPos, kKChain, kKCompactOverlaps, kKPileKeys, kKPileCounts, kKPileBuild,
-  kKAddLayers, kKTruncateSort, kKKeptWrite, kKGather, kKPileSortUp, kKPileSortDown, kKNumSites
+  kKAddLayers, kKTruncateSort, kKKeptWrite, kKGather, kKPileSortUp, kKPileSortDown, kKChainSmall, kKJoinCount, kKJoinEmit, kKNumSites
 };
 extern const char* const kKernelSiteNames[kKNumSites];
 
@@ -119,6 +119,11 @@ struct KernelScope {
   } while (0)
 
 // 8 x u32 overlap record == biosoup::Overlap minus the alignment string.
+// Bit 63 of an index origin marks "this minimizer is also a (minhash) query minimizer" (self-join path);
+// read ids must therefore stay below 2^31.  Every consumer of an origin's id masks it.
+constexpr u64 kQueryFlag = 1ULL << 63;
+__host__ __device__ inline u32 origin_id(u64 org) { return static_cast<u32>(org >> 32) & 0x7FFFFFFFu; }
+
 struct Overlap {
   u32 lhs_id, lhs_begin, lhs_end, rhs_id, rhs_begin, rhs_end, score, strand;
 };

@@ -23,6 +23,7 @@ struct ReadsDev {
   DevBuf id;        // u32[n]
   std::vector<u64> h_word_off;
   std::vector<u32> h_len, h_id;
+  bool ids_are_indices = false;  // ids[i] == i and all < 2^31 (needed by the pass-1 merge and the self-join)
   // sketch tiles for the owning engine's (k, w)
   u32 n_tiles = 0;
   DevBuf tile_read;      // u32[n_tiles]  read index of the tile
@@ -52,6 +53,10 @@ struct Index {
   DevBuf u_start;  // u32[u + 1]
   DevBuf table;    // u32[2^table_bits + 1]
   u32 occurrence = 0xFFFFFFFFu;
+  bool table_built = false;      // u_val / table are built lazily (only the probe path needs them)
+  bool has_query_flags = false;  // origins carry kQueryFlag
+  bool all_query = false;        // every index entry is a query minimizer (index built with minhash)
+  u32 first = 0, last = 0;       // read range the index was built from
 };
 
 struct MapOut {
@@ -84,13 +89,14 @@ struct Engine {
   bool query_ready = false;
   u32 query_ready_first = 0, query_ready_last = 0;
   bool query_ready_minhash = false;
+  u64 join_query_count = 0;  // number of query minimizers flagged in the index (self-join path)
   MapOut map_out;
   // scratch
   DevBuf tmp_a, tmp_b, tmp_c, tmp_d, tmp_e, tmp_f, scan_tmp, sort_tmp;
   DevBuf q_start, q_cnt, m_off;
   DevBuf m_grp[2], m_pos[2];
   DevBuf seg_off, iv_slot_begin, iv_slot_end, iv_cnt, iv_off, iv_begin, iv_end;
-  DevBuf lis_min, lis_pred, ovl_slots, ovl_flags, ovl_scan;
+  DevBuf lis_min, lis_pred, lis_tail, lis_mask, ovl_slots, ovl_flags, ovl_scan;
   StageTimes times;
   KernelTimers ktimers;
   // counters for algorithmic bytes
@@ -99,7 +105,16 @@ struct Engine {
   u64 c_intervals = 0;
   bool timing = true;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  u64* h_pin = nullptr;  // pinned host scratch for small device->host size read-backs
 };
+
+// Reads one 4- or 8-byte value from the device through pinned memory (stream-ordered, then synchronises).
+inline u64 read_back(Engine& e, const void* dptr, size_t bytes) {
+  e.h_pin[0] = 0;
+  RVN_HIP(hipMemcpyAsync(e.h_pin, dptr, bytes, hipMemcpyDeviceToHost, e.stream));
+  RVN_HIP(hipStreamSynchronize(e.stream));
+  return e.h_pin[0];
+}
 
 // Stage timing helper: records HIP events on the engine stream around a stage.
 struct StageTimer {
@@ -124,7 +139,10 @@ void reads_build_tiles(Engine& e, ReadsDev& r);
 void sketch_raw(Engine& e, const ReadsDev& r, u32 first, u32 last, Sketch& out);
 void sketch_minhash(Engine& e, const ReadsDev& r, const Sketch& raw, Sketch& out);
 void sketch_range(Engine& e, const ReadsDev& r, u32 first, u32 last, bool minhash, Sketch& out);
-void index_build(Engine& e, Sketch& sk);                 // consumes sk.val/sk.org
+void index_build(Engine& e, Sketch& sk, bool build_table = true);  // consumes sk.val/sk.org
+void index_build_table(Engine& e);                               // lazy: distinct keys + direct-address table
+// minhash-select on a raw sketch, marking the selected minimizers with kQueryFlag in raw.org; returns their count
+u64 sketch_flag_queries(Engine& e, const ReadsDev& r, Sketch& raw);
 void index_filter(Engine& e, double freq);               // sets e.index.occurrence
 void map_batch(Engine& e, const ReadsDev& r, u32 first, u32 last, bool avoid_equal, bool avoid_symmetric,
                bool minhash, bool want_filtered, MapOut& out);

@@ -72,8 +72,15 @@ void do_minimize(Engine& e, const ReadsDev& r, u32 first, u32 last, bool minhash
   {
     StageTimer t(e, StageTimes::kSketch);
     e.query_ready = false;
+    Index& ix = e.index;
+    ix.has_query_flags = false;
+    ix.all_query = false;
     sketch_raw(e, r, first, last, e.raw_sketch);
-    if (prefetch_query) {
+    const bool join = prefetch_query && r.ids_are_indices;  // map_batch will self-join instead of probing
+    if (join && !minhash) {
+      e.join_query_count = sketch_flag_queries(e, r, e.raw_sketch);
+      ix.has_query_flags = true;
+    } else if (prefetch_query && !join) {
       sketch_minhash(e, r, e.raw_sketch, e.query_sketch);
       e.query_ready = true;
       e.query_ready_first = first;
@@ -81,7 +88,10 @@ void do_minimize(Engine& e, const ReadsDev& r, u32 first, u32 last, bool minhash
       e.query_ready_minhash = true;
     }
     Sketch& is = e.index_sketch;
-    if (!minhash) {
+    if (join && minhash) {
+      sketch_minhash(e, r, e.raw_sketch, is);
+      ix.all_query = true;
+    } else if (!minhash) {
       swap_bufs(is.val, e.raw_sketch.val);
       swap_bufs(is.org, e.raw_sketch.org);
       swap_bufs(is.read_off, e.raw_sketch.read_off);
@@ -108,7 +118,7 @@ void do_minimize(Engine& e, const ReadsDev& r, u32 first, u32 last, bool minhash
   }
   for (u32 i = first; i < last; ++i) e.c_index_bases += r.h_len[i];
   e.c_index_min += e.index_sketch.count;
-  index_build(e, e.index_sketch);
+  index_build(e, e.index_sketch, !(e.index.has_query_flags || e.index.all_query));
   e.c_index_keys += e.index.u;
 }
 
@@ -150,6 +160,7 @@ int rvn_engine_create(rvn_engine** out, uint32_t k, uint32_t w, uint32_t bandwid
     RVN_HIP(hipStreamCreateWithFlags(&e.stream, hipStreamNonBlocking));
     RVN_HIP(hipEventCreate(&e.ev0));
     RVN_HIP(hipEventCreate(&e.ev1));
+    RVN_HIP(hipHostMalloc(reinterpret_cast<void**>(&e.h_pin), 4096, hipHostMallocDefault));
     *out = h.release();
     return RVN_OK;
   });
@@ -162,6 +173,7 @@ void rvn_engine_destroy(rvn_engine* h) {
   if (h->e.ev0) (void)hipEventDestroy(h->e.ev0);
   if (h->e.ev1) (void)hipEventDestroy(h->e.ev1);
   if (h->e.stream) (void)hipStreamDestroy(h->e.stream);
+  if (h->e.h_pin) (void)hipHostFree(h->e.h_pin);
   delete h;
 }
 
@@ -178,7 +190,12 @@ int rvn_reads_upload(rvn_engine* h, const uint64_t* packed, uint64_t n_words, co
     r.h_word_off.assign(word_offsets, word_offsets + n + 1);
     r.h_len.assign(lengths, lengths + n);
     r.h_id.resize(n);
-    for (u32 i = 0; i < n; ++i) r.h_id[i] = ids ? ids[i] : i;
+    r.ids_are_indices = true;
+    for (u32 i = 0; i < n; ++i) {
+      r.h_id[i] = ids ? ids[i] : i;
+      if (r.h_id[i] != i || i >= (1u << 31)) r.ids_are_indices = false;
+      if (r.h_id[i] >= (1u << 31)) return fail(RVN_EINVAL, "[raven_hip] read ids must be below 2^31");
+    }
     r.total_bases = 0;
     for (u32 i = 0; i < n; ++i) {
       r.total_bases += lengths[i];
@@ -452,7 +469,10 @@ int rvn_engine_index_fetch(rvn_engine* h, uint64_t* values, uint64_t* origins) {
     Index& ix = e.index;
     RVN_HIP(hipSetDevice(e.device));
     fetch_values(e, ix.s_val[ix.cur], ix.m, values);
-    if (origins && ix.m) RVN_HIP(hipMemcpy(origins, ix.s_org[ix.cur].ptr, ix.m * 8, hipMemcpyDeviceToHost));
+    if (origins && ix.m) {
+      RVN_HIP(hipMemcpy(origins, ix.s_org[ix.cur].ptr, ix.m * 8, hipMemcpyDeviceToHost));
+      for (u64 i = 0; i < ix.m; ++i) origins[i] &= ~kQueryFlag;
+    }
     return RVN_OK;
   });
 }

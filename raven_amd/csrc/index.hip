@@ -103,8 +103,78 @@ __global__ __launch_bounds__(256) void occ_hist_kernel(const u32* __restrict__ u
   if (lh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], lh[threadIdx.x]);
 }
 
+// (1-f) quantile of the per-key counts from the count-of-counts histogram: smallest c with
+// cum(c) > nth.  One workgroup; out[0] = c, out[1] = number of keys with count < c ("below").
+__global__ __launch_bounds__(256) void occ_quantile_kernel(const u32* __restrict__ hist, u64 nth,
+                                                          u64* __restrict__ out) {
+  __shared__ u64 smem[4];
+  __shared__ u64 s_base[256];
+  const u32 t = threadIdx.x;
+  u64 sum = 0;
+  for (u32 i = 0; i < kHistBins / 256; ++i) sum += hist[t * (kHistBins / 256) + i];
+  u64 total;
+  const u64 ex = block_exclusive_sum_256<u64>(sum, smem, &total);
+  s_base[t] = ex;
+  __syncthreads();
+  if (ex <= nth && nth < ex + sum) {
+    u64 cum = ex;
+    for (u32 i = 0; i < kHistBins / 256; ++i) {
+      const u32 c = t * (kHistBins / 256) + i;
+      const u64 h = hist[c];
+      if (cum + h > nth) {
+        out[0] = c;
+        out[1] = cum;
+        break;
+      }
+      cum += h;
+    }
+  }
+}
+
+// run boundaries: u_start[U+1] (and, for the probe path, the distinct keys u_val[U])
 template <typename V>
-void index_build_impl(Engine& e, Sketch& sk) {
+void index_runs_impl(Engine& e) {
+  hipStream_t s = e.stream;
+  Index& ix = e.index;
+  const u64 m = ix.m;
+  StageTimer t(e, StageTimes::kIndex);
+  const V* sv = ix.s_val[ix.cur].as<V>();
+  u8* flags = e.tmp_c.get<u8>(m + 1);
+  u32* fscan = e.tmp_d.get<u32>(m + 1);
+  RVN_KLAUNCH(kKHeads, heads_kernel<V><<<div_up(m, 256), 256, 0, s>>>(sv, m, flags));
+  exclusive_scan_u8_u32(flags, fscan, m, e.scan_tmp, s);
+  const u32 u = static_cast<u32>(read_back(e, fscan + m, 4));
+  ix.u = u;
+  V* u_val = ix.u_val.get<V>(static_cast<size_t>(u) + 1);
+  u32* u_start = ix.u_start.get<u32>(static_cast<size_t>(u) + 2);
+  RVN_KLAUNCH(kKUnique, unique_kernel<V><<<div_up(m, 256), 256, 0, s>>>(sv, flags, fscan, m, u_val, u_start, u));
+  t.stop();
+}
+
+template <typename V>
+void index_table_impl(Engine& e) {
+  hipStream_t s = e.stream;
+  Index& ix = e.index;
+  if (ix.table_built || ix.m == 0) return;
+  StageTimer t(e, StageTimes::kIndex);
+  const u32 u = static_cast<u32>(ix.u);
+  int bits = 1;
+  while ((1ULL << bits) < 2ULL * u) ++bits;
+  bits = std::max(8, bits);
+  bits = std::min(bits, std::min<int>(2 * e.k, 26));
+  ix.table_bits = bits;
+  ix.shift = 2 * e.k - bits;
+  const u32 B = 1u << bits;
+  u32* table = ix.table.get<u32>(static_cast<size_t>(B) + 2);
+  const V* u_val = ix.u_val.as<V>();
+  RVN_KLAUNCH(kKTable, table_kernel<V><<<div_up(u, 256), 256, 0, s>>>(u_val, u, ix.shift, table);
+              table_tail_kernel<V><<<256, 256, 0, s>>>(u_val, u, ix.shift, B, table));
+  ix.table_built = true;
+  t.stop();
+}
+
+template <typename V>
+void index_build_impl(Engine& e, Sketch& sk, bool build_table) {
   hipStream_t s = e.stream;
   Index& ix = e.index;
   const u64 m = sk.count;
@@ -127,6 +197,7 @@ void index_build_impl(Engine& e, Sketch& sk) {
     ix.u_val.reserve(16);
     ix.u_start.reserve(16);
     RVN_HIP(hipMemsetAsync(ix.u_start.ptr, 0, 8, s));
+    ix.table_built = true;
     return;
   }
   V* v0 = ix.s_val[0].as<V>();
@@ -143,38 +214,23 @@ void index_build_impl(Engine& e, Sketch& sk) {
                                         e.sort_tmp, e.scan_tmp, s, kKRsUpsweep, kKRsDownsweep, false);
     t.stop();
   }
-  StageTimer t(e, StageTimes::kIndex);
-  const V* sv = ix.s_val[ix.cur].as<V>();
-  u8* flags = e.tmp_c.get<u8>(m + 1);
-  u32* fscan = e.tmp_d.get<u32>(m + 1);
-  RVN_KLAUNCH(kKHeads, heads_kernel<V><<<div_up(m, 256), 256, 0, s>>>(sv, m, flags));
-  exclusive_scan_u8_u32(flags, fscan, m, e.scan_tmp, s);
-  u32 u = 0;
-  RVN_HIP(hipMemcpyAsync(&u, fscan + m, 4, hipMemcpyDeviceToHost, s));
-  RVN_HIP(hipStreamSynchronize(s));
-  ix.u = u;
-  V* u_val = ix.u_val.get<V>(static_cast<size_t>(u) + 1);
-  u32* u_start = ix.u_start.get<u32>(static_cast<size_t>(u) + 2);
-  RVN_KLAUNCH(kKUnique, unique_kernel<V><<<div_up(m, 256), 256, 0, s>>>(sv, flags, fscan, m, u_val, u_start, u));
-
-  int bits = 1;
-  while ((1ULL << bits) < 2ULL * u) ++bits;
-  bits = std::max(8, bits);
-  bits = std::min(bits, std::min<int>(2 * e.k, 26));
-  ix.table_bits = bits;
-  ix.shift = 2 * e.k - bits;
-  const u32 B = 1u << bits;
-  u32* table = ix.table.get<u32>(static_cast<size_t>(B) + 2);
-  RVN_KLAUNCH(kKTable, table_kernel<V><<<div_up(u, 256), 256, 0, s>>>(u_val, u, ix.shift, table);
-              table_tail_kernel<V><<<256, 256, 0, s>>>(u_val, u, ix.shift, B, table));
-  t.stop();
+  ix.table_built = false;
+  index_runs_impl<V>(e);
+  if (build_table) index_table_impl<V>(e);
 }
 
 }  // namespace
 
-void index_build(Engine& e, Sketch& sk) {
-  if (e.val64) index_build_impl<u64>(e, sk);
-  else index_build_impl<u32>(e, sk);
+void index_build(Engine& e, Sketch& sk, bool build_table) {
+  e.index.first = sk.first;
+  e.index.last = sk.last;
+  if (e.val64) index_build_impl<u64>(e, sk, build_table);
+  else index_build_impl<u32>(e, sk, build_table);
+}
+
+void index_build_table(Engine& e) {
+  if (e.val64) index_table_impl<u64>(e);
+  else index_table_impl<u32>(e);
 }
 
 // ram Filter: occurrence_ = (value at index (1-f)*U of the sorted per-key counts) + 1; f == 0 -> no filter.
@@ -193,25 +249,22 @@ void index_filter(Engine& e, double freq) {
   const u32 u = static_cast<u32>(ix.u);
   const u32 grid = std::min<u32>(div_up(u, 256), 2048);
   RVN_KLAUNCH(kKOccHist, occ_hist_kernel<<<grid, 256, 0, s>>>(ix.u_start.as<u32>(), u, hist, ovl, hist + kHistBins, overflow_cap));
-  std::vector<u32> h(kHistBins + 1);
-  RVN_HIP(hipMemcpyAsync(h.data(), hist, (kHistBins + 1) * 4, hipMemcpyDeviceToHost, s));
-  RVN_HIP(hipStreamSynchronize(s));
   size_t nth = static_cast<size_t>((1 - freq) * u);
   if (nth >= u) nth = u - 1;
-  u64 cum = 0;
-  u32 c = 0;
-  for (c = 0; c < kHistBins; ++c) {
-    cum += h[c];
-    if (cum > nth) break;
-  }
+  u64* qout = e.tmp_e.get<u64>(4);
+  RVN_KLAUNCH(kKOccHist, occ_quantile_kernel<<<1, 256, 0, s>>>(hist, nth, qout));
+  RVN_HIP(hipMemcpyAsync(e.h_pin, qout, 16, hipMemcpyDeviceToHost, s));
+  RVN_HIP(hipMemcpyAsync(e.h_pin + 2, hist + kHistBins, 4, hipMemcpyDeviceToHost, s));
+  RVN_HIP(hipStreamSynchronize(s));
+  u32 c = static_cast<u32>(e.h_pin[0]);
   if (c >= kHistBins - 1) {
     // quantile lands among run lengths >= 65535: resolve exactly from the overflow list
-    const u32 n_over = h[kHistBins];
+    const u64 below = e.h_pin[1];
+    const u32 n_over = static_cast<u32>(e.h_pin[2]);
     if (n_over > overflow_cap) throw HipError("[raven_hip] Filter: overflow list too small");
     std::vector<u32> over(n_over);
     RVN_HIP(hipMemcpy(over.data(), ovl, static_cast<size_t>(n_over) * 4, hipMemcpyDeviceToHost));
     std::sort(over.begin(), over.end());
-    const u64 below = cum - h[kHistBins - 1];
     c = over[nth - below];
   }
   ix.occurrence = c + 1;

@@ -49,7 +49,7 @@ __global__ void match_count_kernel(const V* __restrict__ q_val, const u64* __res
   u64 q = static_cast<u64>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (q >= nq) return;
   const V v = q_val[q];
-  const u32 qid = static_cast<u32>(q_org[q] >> 32);
+  const u32 qid = origin_id(q_org[q]);
   u32 start = 0, count = 0, cnt = 0;
   u8 filt = 0;
   if (n_keys && index_find<V>(u_val, u_start, table, shift, v, &start, &count)) {
@@ -58,7 +58,7 @@ __global__ void match_count_kernel(const V* __restrict__ q_val, const u64* __res
       count = 0;
     } else {
       for (u32 j = 0; j < count; ++j) {
-        const u32 rid = static_cast<u32>(s_org[start + j] >> 32);
+        const u32 rid = origin_id(s_org[start + j]);
         if (avoid_equal && qid == rid) continue;
         if (avoid_symmetric && qid > rid) continue;
         ++cnt;
@@ -80,14 +80,14 @@ __global__ void match_emit_kernel(const u64* __restrict__ q_org, u64 nq, const u
   const u32 count = q_n[q];
   if (count == 0) return;
   const u64 qo = q_org[q];
-  const u32 qid = static_cast<u32>(qo >> 32);
+  const u32 qid = origin_id(qo);
   const u64 lhs_pos = static_cast<u32>(qo) >> 1;
   const u32 qstrand = static_cast<u32>(qo) & 1u;
   const u32 start = q_start[q];
   u64 o = m_off[q];
   for (u32 j = 0; j < count; ++j) {
     const u64 ro = s_org[start + j];
-    const u32 rid = static_cast<u32>(ro >> 32);
+    const u32 rid = origin_id(ro);
     if (avoid_equal && qid == rid) continue;
     if (avoid_symmetric && qid > rid) continue;
     const u64 rhs_pos = static_cast<u32>(ro) >> 1;
@@ -96,6 +96,60 @@ __global__ void match_emit_kernel(const u64* __restrict__ q_org, u64 nq, const u
     m_grp[o] = (((static_cast<u64>(rid) << 1) | strand) << 32) | diagonal;
     m_pos[o] = (lhs_pos << 32) | rhs_pos;
     ++o;
+  }
+}
+
+// ---- self-join over the sorted index ----------------------------------------------------------------
+// When the query reads are exactly the indexed reads, every query minimizer is itself an index entry
+// (flagged kQueryFlag), so Map's probes become one streaming pass over the runs of equal value: for each
+// flagged entry of a run (count <= occurrence), every other entry of the run is a match.  No table, no random
+// access (the probe path fetched ~3 GB of cache lines per pass, profiles/r01_c_pmc_fetch_size.csv).
+// Matches of one read land in that read's segment in arbitrary order; the result does not depend on it
+// because the following sorts are total orders (group, then positions).
+template <bool EMIT>
+__global__ __launch_bounds__(256) void join_kernel(const u32* __restrict__ u_start, u32 n_runs,
+                                                  const u64* __restrict__ s_org, u32 occurrence, int all_query,
+                                                  int avoid_equal, int avoid_symmetric, u32 first,
+                                                  u32* __restrict__ read_cnt, const u64* __restrict__ seg_off,
+                                                  u32* __restrict__ cursor, u64* __restrict__ m_grp,
+                                                  u64* __restrict__ m_pos) {
+  const u32 run = blockIdx.x * blockDim.x + threadIdx.x;
+  if (run >= n_runs) return;
+  const u32 s = u_start[run];
+  const u32 c = u_start[run + 1] - s;
+  if (c > occurrence) return;
+  if (c == 1 && avoid_equal) return;
+  for (u32 i = 0; i < c; ++i) {
+    const u64 qo = s_org[s + i];
+    if (!all_query && !(qo & kQueryFlag)) continue;
+    const u32 qid = origin_id(qo);
+    u32 cnt = 0;
+    for (u32 j = 0; j < c; ++j) {
+      const u32 rid = origin_id(s_org[s + j]);
+      if (avoid_equal && qid == rid) continue;
+      if (avoid_symmetric && qid > rid) continue;
+      ++cnt;
+    }
+    if (cnt == 0) continue;
+    if (!EMIT) {
+      atomicAdd(&read_cnt[qid - first], cnt);
+    } else {
+      u64 o = seg_off[qid - first] + atomicAdd(&cursor[qid - first], cnt);
+      const u64 lhs_pos = static_cast<u32>(qo) >> 1;
+      const u32 qstrand = static_cast<u32>(qo) & 1u;
+      for (u32 j = 0; j < c; ++j) {
+        const u64 ro = s_org[s + j];
+        const u32 rid = origin_id(ro);
+        if (avoid_equal && qid == rid) continue;
+        if (avoid_symmetric && qid > rid) continue;
+        const u64 rhs_pos = static_cast<u32>(ro) >> 1;
+        const u64 strand = (qstrand == (static_cast<u32>(ro) & 1u)) ? 1 : 0;
+        const u64 diagonal = !strand ? rhs_pos + lhs_pos : rhs_pos - lhs_pos + (3ULL << 30);
+        m_grp[o] = (((static_cast<u64>(rid) << 1) | strand) << 32) | diagonal;
+        m_pos[o] = (lhs_pos << 32) | rhs_pos;
+        ++o;
+      }
+    }
   }
 }
 
@@ -281,56 +335,17 @@ __global__ __launch_bounds__(256) void intervals_gather_kernel(const u64* __rest
 }
 
 // ---- LIS chain + overlap emission (ram Chain second loop + LongestSubsequence) ----------------
-__global__ __launch_bounds__(64) void chain_kernel(const u64* __restrict__ grp, const u64* __restrict__ pos,
-                                                  const u64* __restrict__ iv_begin, const u64* __restrict__ iv_end,
-                                                  const u32* __restrict__ iv_read, u32 n_iv,
-                                                  const u32* __restrict__ ids, u32 first, u32 k, u32 chain,
-                                                  u32 min_matches, u32 gap, u32 slot_div,
-                                                  u32* __restrict__ lis_min, u32* __restrict__ lis_pred,
-                                                  Overlap* __restrict__ slots, u8* __restrict__ slot_flags) {
-  const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= n_iv) return;
-  const u64 b = iv_begin[t], e = iv_end[t];
-  const u32 n = static_cast<u32>(e - b);
-  if (n < chain) return;
-  u32* minimal = lis_min + b + t;  // n + 1 entries
-  u32* pred = lis_pred + b;        // n entries
-  const u64* p = pos + b;
-  const u64 g0 = grp[b];
-  const bool strand = (g0 >> 32) & 1;
-  u32 longest = 0;
-  minimal[0] = 0;
-  for (u32 it = 0; it < n; ++it) {
-    const u64 cur = p[it];
-    const u32 lhs = static_cast<u32>(cur >> 32), rhs = static_cast<u32>(cur);
-    u32 lo = 1, hi = longest;
-    while (lo <= hi) {
-      const u32 mid = lo + (hi - lo) / 2;
-      const u64 q = p[minimal[mid]];
-      const u32 ql = static_cast<u32>(q >> 32), qr = static_cast<u32>(q);
-      const bool ok = ql < lhs && (strand ? qr < rhs : qr > rhs);
-      if (ok) lo = mid + 1;
-      else hi = mid - 1;
-    }
-    pred[it] = minimal[lo - 1];
-    minimal[lo] = it;
-    longest = longest > lo ? longest : lo;
-  }
-  if (longest < chain) return;
-  {
-    u32 j = minimal[longest];
-    for (u32 i = 0; i < longest; ++i) {
-      const u32 nj = pred[j];
-      minimal[longest - 1 - i] = j;  // chain indices ascending in minimal[0 .. longest)
-      j = nj;
-    }
-  }
-  const u64 slot_base = (b + slot_div - 1) / slot_div;
+// ram Chain: split the chain where consecutive lhs positions differ by more than `gap`, score each piece by
+// covered bases, emit the overlaps.  cp(m) = packed positions of chain element m (ascending).
+template <typename CP>
+__device__ __forceinline__ void chain_emit(CP cp, u32 longest, bool strand, u64 g0, u32 lhs_id, u32 k, u32 chain,
+                                           u32 min_matches, u32 gap, Overlap* __restrict__ slots,
+                                           u8* __restrict__ slot_flags, bool writer) {
   u32 emitted = 0;
   u32 l = 0;
   for (u32 kk = 1; kk <= longest; ++kk) {
-    const u32 lhs_k = kk < longest ? static_cast<u32>(p[minimal[kk]] >> 32) : 0xFFFFFFFFu;
-    const u32 lhs_km1 = static_cast<u32>(p[minimal[kk - 1]] >> 32);
+    const u32 lhs_k = kk < longest ? static_cast<u32>(cp(kk) >> 32) : 0xFFFFFFFFu;
+    const u32 lhs_km1 = static_cast<u32>(cp(kk - 1) >> 32);
     if (lhs_k - lhs_km1 > gap) {
       if (kk - l < chain) {
         l = kk;
@@ -339,7 +354,7 @@ __global__ __launch_bounds__(64) void chain_kernel(const u64* __restrict__ grp, 
       u32 lhs_matches = 0, lhs_begin = 0, lhs_end = 0;
       u32 rhs_matches = 0, rhs_begin = 0, rhs_end = 0;
       for (u32 m = l; m < kk; ++m) {
-        const u64 mm = p[minimal[m]];
+        const u64 mm = cp(m);
         const u32 lhs_pos = static_cast<u32>(mm >> 32);
         if (lhs_pos > lhs_end) {
           lhs_matches += lhs_end - lhs_begin;
@@ -361,21 +376,221 @@ __global__ __launch_bounds__(64) void chain_kernel(const u64* __restrict__ grp, 
         l = kk;
         continue;
       }
-      const u64 ml = p[minimal[l]], mr = p[minimal[kk - 1]];
-      Overlap o;
-      o.lhs_id = ids[first + iv_read[t]];
-      o.lhs_begin = static_cast<u32>(ml >> 32);
-      o.lhs_end = k + static_cast<u32>(mr >> 32);
-      o.rhs_id = static_cast<u32>(g0 >> 33);
-      o.rhs_begin = strand ? static_cast<u32>(ml) : static_cast<u32>(mr);
-      o.rhs_end = k + (strand ? static_cast<u32>(mr) : static_cast<u32>(ml));
-      o.score = score;
-      o.strand = strand ? 1u : 0u;
-      slots[slot_base + emitted] = o;
-      slot_flags[slot_base + emitted] = 1;
+      if (writer) {
+        const u64 ml = cp(l), mr = cp(kk - 1);
+        Overlap o;
+        o.lhs_id = lhs_id;
+        o.lhs_begin = static_cast<u32>(ml >> 32);
+        o.lhs_end = k + static_cast<u32>(mr >> 32);
+        o.rhs_id = static_cast<u32>(g0 >> 33);
+        o.rhs_begin = strand ? static_cast<u32>(ml) : static_cast<u32>(mr);
+        o.rhs_end = k + (strand ? static_cast<u32>(mr) : static_cast<u32>(ml));
+        o.score = score;
+        o.strand = strand ? 1u : 0u;
+        slots[emitted] = o;
+        slot_flags[emitted] = 1;
+      }
       ++emitted;
       l = kk;
     }
+  }
+}
+
+// Small intervals (chain <= n <= kChainSmallCap): one LANE per interval, every array private to the lane in LDS
+// ([element][lane] layout: bank = lane, conflict-free), no cross-lane traffic at all.
+constexpr u32 kChainSmallCap = 32;
+__global__ __launch_bounds__(64) void chain_small_kernel(const u64* __restrict__ grp, const u64* __restrict__ pos,
+                                                        const u64* __restrict__ iv_begin,
+                                                        const u64* __restrict__ iv_end,
+                                                        const u32* __restrict__ iv_read, u32 n_iv,
+                                                        const u32* __restrict__ ids, u32 first, u32 k, u32 chain,
+                                                        u32 min_matches, u32 gap, u32 slot_div,
+                                                        Overlap* __restrict__ slots, u8* __restrict__ slot_flags) {
+  __shared__ u64 s_pos[kChainSmallCap][64];
+  __shared__ u64 s_tail[kChainSmallCap + 1][64];
+  __shared__ u8 s_tidx[kChainSmallCap + 1][64];
+  __shared__ u8 s_pred[kChainSmallCap][64];
+  const u32 lane = threadIdx.x;
+  const u32 t = blockIdx.x * 64 + lane;
+  if (t >= n_iv) return;
+  const u64 b = iv_begin[t];
+  const u64 n64 = iv_end[t] - b;
+  if (n64 < chain || n64 > kChainSmallCap) return;  // larger intervals: chain_kernel
+  const u32 n = static_cast<u32>(n64);
+  const u64* p = pos + b;
+  const u64 g0 = grp[b];
+  const bool strand = (g0 >> 32) & 1;
+#pragma unroll 8
+  for (u32 i = 0; i < kChainSmallCap; ++i)
+    if (i < n) s_pos[i][lane] = p[i];
+  u32 longest = 0;
+  for (u32 it = 0; it < n; ++it) {
+    const u64 cur = s_pos[it][lane];
+    const u32 lhs = static_cast<u32>(cur >> 32), rhs = static_cast<u32>(cur);
+    u32 lo = 1, hi = longest;
+    while (lo <= hi) {
+      const u32 mid = lo + (hi - lo) / 2;
+      const u64 q = s_tail[mid][lane];
+      const u32 ql = static_cast<u32>(q >> 32), qr = static_cast<u32>(q);
+      if (ql < lhs && (strand ? qr < rhs : qr > rhs)) lo = mid + 1;
+      else hi = mid - 1;
+    }
+    s_pred[it][lane] = lo > 1 ? s_tidx[lo - 1][lane] : static_cast<u8>(0);
+    s_tidx[lo][lane] = static_cast<u8>(it);
+    s_tail[lo][lane] = cur;
+    longest = longest > lo ? longest : lo;
+  }
+  if (longest < chain) return;
+  {
+    u32 j = s_tidx[longest][lane];
+    for (u32 i = 0; i < longest; ++i) {
+      const u32 nj = s_pred[j][lane];
+      s_tidx[longest - 1 - i][lane] = static_cast<u8>(j);
+      j = nj;
+    }
+    for (u32 m = 0; m < longest; ++m) s_tail[m][lane] = s_pos[s_tidx[m][lane]][lane];
+  }
+  const u64 slot_base = (b + slot_div - 1) / slot_div;
+  chain_emit([&](u32 m) { return s_tail[m][lane]; }, longest, strand, g0, ids[first + iv_read[t]], k, chain,
+             min_matches, gap, slots + slot_base, slot_flags + slot_base, true);
+}
+
+// One WAVE per interval.  ram's patience LIS is sequential over the elements, but its binary search only
+// needs the predicate "tail[len] precedes cur" at the probed lengths: all 64 lanes evaluate the predicate
+// for 64 lengths at once (tails live in LDS), a ballot turns it into a bit mask and the *same* probe
+// sequence ram would follow is then replayed on the mask with scalar ALU only.  Intervals of up to
+// kChainLdsCap matches run entirely out of LDS; larger ones use the same code on global scratch.
+constexpr u32 kChainLdsCap = 1024;
+constexpr u32 kChainPerWave = 16;
+constexpr u32 kChainLdsBytes = (kChainLdsCap + 1) * 8 + (kChainLdsCap + 2) * 2 + kChainLdsCap * 2 + 16 * 8;
+
+template <bool GLOBAL>
+__device__ __forceinline__ void chain_sync() {
+  if (GLOBAL) __threadfence_block();  // lane 0's global stores must be visible to the other lanes' loads
+  __builtin_amdgcn_wave_barrier();
+}
+
+template <typename IdxT, bool GLOBAL>
+__device__ void chain_wave(const u64* __restrict__ p, u32 n, bool strand, u64 g0, u32 lhs_id, u32 k, u32 chain,
+                           u32 min_matches, u32 gap, u64* tail_pos, IdxT* tail_idx, IdxT* pred, u64* maskbuf,
+                           Overlap* __restrict__ slots, u8* __restrict__ slot_flags) {
+  const int lane = lane_id();
+  u32 longest = 0;
+  for (u32 base = 0; base < n; base += 64) {
+    const u64 mine = (base + lane < n) ? p[base + lane] : 0;
+    const u32 cnt = min(64u, n - base);
+    for (u32 t = 0; t < cnt; ++t) {
+      const u64 cur = __shfl(mine, static_cast<int>(t), 64);
+      const u32 lhs = static_cast<u32>(cur >> 32), rhs = static_cast<u32>(cur);
+      u32 lo = 1, hi = longest;
+      if (longest <= 64) {
+        bool ok = false;
+        if (static_cast<u32>(lane) < longest) {
+          const u64 q = tail_pos[lane + 1];
+          const u32 ql = static_cast<u32>(q >> 32), qr = static_cast<u32>(q);
+          ok = ql < lhs && (strand ? qr < rhs : qr > rhs);
+        }
+        const unsigned long long m = __ballot(ok);
+        while (lo <= hi) {
+          const u32 mid = lo + (hi - lo) / 2;
+          if ((m >> (mid - 1)) & 1ULL) lo = mid + 1;
+          else hi = mid - 1;
+        }
+      } else {
+        const u32 nchunks = (longest + 63) >> 6;
+        for (u32 c = 0; c < nchunks; ++c) {
+          const u32 len = c * 64 + lane + 1;
+          bool ok = false;
+          if (len <= longest) {
+            const u64 q = tail_pos[len];
+            const u32 ql = static_cast<u32>(q >> 32), qr = static_cast<u32>(q);
+            ok = ql < lhs && (strand ? qr < rhs : qr > rhs);
+          }
+          const unsigned long long m = __ballot(ok);
+          if (lane == 0) maskbuf[c] = m;
+        }
+        chain_sync<GLOBAL>();
+        while (lo <= hi) {
+          const u32 mid = lo + (hi - lo) / 2;
+          if ((maskbuf[(mid - 1) >> 6] >> ((mid - 1) & 63)) & 1ULL) lo = mid + 1;
+          else hi = mid - 1;
+        }
+      }
+      const u32 it = base + t;
+      const IdxT prev = lo > 1 ? tail_idx[lo - 1] : static_cast<IdxT>(0);  // minimal[0] == 0 in ram
+      chain_sync<GLOBAL>();  // every lane has read maskbuf / tail_idx before lane 0 overwrites
+      if (lane == 0) {
+        pred[it] = prev;
+        tail_idx[lo] = static_cast<IdxT>(it);
+        tail_pos[lo] = cur;
+      }
+      chain_sync<GLOBAL>();
+      longest = longest > lo ? longest : lo;
+    }
+  }
+  if (longest < chain) return;
+  {
+    // backtrack: chain indices ascending into tail_idx[0 .. longest)
+    u32 j = tail_idx[longest];
+    chain_sync<GLOBAL>();
+    for (u32 i = 0; i < longest; ++i) {
+      const u32 nj = pred[j];
+      if (lane == 0) tail_idx[longest - 1 - i] = static_cast<IdxT>(j);
+      j = nj;
+    }
+    chain_sync<GLOBAL>();
+    // positions of the chain elements into tail_pos[0 .. longest)
+    for (u32 m = lane; m < longest; m += 64) tail_pos[m] = p[tail_idx[m]];
+    chain_sync<GLOBAL>();
+  }
+  chain_emit([&](u32 m) { return tail_pos[m]; }, longest, strand, g0, lhs_id, k, chain, min_matches, gap, slots,
+             slot_flags, lane == 0);
+}
+
+__global__ __launch_bounds__(256) void chain_kernel(const u64* __restrict__ grp, const u64* __restrict__ pos,
+                                                   const u64* __restrict__ iv_begin,
+                                                   const u64* __restrict__ iv_end, const u32* __restrict__ iv_read,
+                                                   u32 n_iv, const u32* __restrict__ ids, u32 first, u32 k,
+                                                   u32 chain, u32 min_matches, u32 gap, u32 slot_div,
+                                                   u64* __restrict__ g_tail_pos, u32* __restrict__ g_tail_idx,
+                                                   u32* __restrict__ g_pred, u64* __restrict__ g_mask,
+                                                   Overlap* __restrict__ slots, u8* __restrict__ slot_flags) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[4][(kChainLdsBytes + 15) & ~15u];
+  const int wv = threadIdx.x >> 6;
+  // each wave owns kChainPerWave consecutive intervals and processes the large ones (n > kChainSmallCap)
+  const u32 t0 = (blockIdx.x * 4 + wv) * kChainPerWave;
+  if (t0 >= n_iv) return;
+  const int lane = lane_id();
+  u64 my_b = 0, my_n = 0;
+  if (lane < static_cast<int>(kChainPerWave) && t0 + lane < n_iv) {
+    my_b = iv_begin[t0 + lane];
+    my_n = iv_end[t0 + lane] - my_b;
+  }
+  unsigned long long todo = __ballot(my_n > kChainSmallCap && my_n >= chain);
+  while (todo) {
+    const int l = __ffsll(static_cast<long long>(todo)) - 1;
+    todo &= todo - 1;
+    const u32 t = t0 + l;
+    const u64 b = __shfl(my_b, l, 64);
+    const u32 n = static_cast<u32>(__shfl(my_n, l, 64));
+    const u64 g0 = grp[b];
+    const bool strand = (g0 >> 32) & 1;
+    const u32 lhs_id = ids[first + iv_read[t]];
+    const u64 slot_base = (b + slot_div - 1) / slot_div;
+    if (n <= kChainLdsCap) {
+      unsigned char* base = smem[wv];
+      u64* tail_pos = reinterpret_cast<u64*>(base);
+      u64* maskbuf = tail_pos + (kChainLdsCap + 1);
+      u16* tail_idx = reinterpret_cast<u16*>(maskbuf + 16);
+      u16* pred = tail_idx + (kChainLdsCap + 2);
+      chain_wave<u16, false>(pos + b, n, strand, g0, lhs_id, k, chain, min_matches, gap, tail_pos, tail_idx, pred,
+                             maskbuf, slots + slot_base, slot_flags + slot_base);
+    } else {
+      chain_wave<u32, true>(pos + b, n, strand, g0, lhs_id, k, chain, min_matches, gap, g_tail_pos + b + t,
+                            g_tail_idx + b + t, g_pred + b, g_mask + (b >> 6) + t, slots + slot_base,
+                            slot_flags + slot_base);
+    }
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -402,7 +617,44 @@ void map_batch_impl(Engine& e, const ReadsDev& r, u32 first, u32 last, bool avoi
   out.n_query = out.n_matches = out.n_intervals = out.n_overlaps = 0;
   u32* ovl_read_off = out.ovl_read_off.get<u32>(static_cast<size_t>(nr) + 1);
 
+  u64* seg_off = e.seg_off.get<u64>(static_cast<size_t>(nr) + 2);
+  u64 H = 0;
+  // self-join path: queries == indexed reads, flags in the index, bounded run lengths, ids == read indices
+  const bool join = minhash && !want_filtered && ix.m != 0 && ix.first == first && ix.last == last &&
+                    (ix.has_query_flags || ix.all_query) && ix.occurrence <= 4096 && r.ids_are_indices;
+  if (join) {
+    StageTimer t(e, StageTimes::kMatch);
+    e.query_ready = false;
+    for (u32 i = first; i < last; ++i) e.c_query_bases += r.h_len[i];
+    out.n_query = ix.all_query ? ix.m : e.join_query_count;
+    e.c_query_min += out.n_query;
+    u32* read_cnt = e.q_cnt.get<u32>(2 * (static_cast<size_t>(nr) + 1));
+    u32* cursor = read_cnt + nr + 1;
+    RVN_HIP(hipMemsetAsync(read_cnt, 0, 2 * (static_cast<size_t>(nr) + 1) * 4, s));
+    const u32 n_runs = static_cast<u32>(ix.u);
+    const u64* sorg = ix.s_org[ix.cur].as<u64>();
+    RVN_KLAUNCH(kKJoinCount, join_kernel<false><<<div_up(n_runs, 256), 256, 0, s>>>(
+                                 ix.u_start.as<u32>(), n_runs, sorg, ix.occurrence, ix.all_query, avoid_equal,
+                                 avoid_symmetric, r.h_id.empty() ? 0 : r.h_id[first], read_cnt, nullptr, nullptr,
+                                 nullptr, nullptr));
+    exclusive_scan_u32_u64(read_cnt, seg_off, nr, e.scan_tmp, s);
+    H = read_back(e, seg_off + nr, 8);
+    out.n_matches = H;
+    e.c_matches += H;
+    if (H) {
+      u64* g0 = e.m_grp[0].get<u64>(H + 1);
+      u64* p0 = e.m_pos[0].get<u64>(H + 1);
+      e.m_grp[1].reserve((H + 1) * 8);
+      e.m_pos[1].reserve((H + 1) * 8);
+      RVN_KLAUNCH(kKJoinEmit, join_kernel<true><<<div_up(n_runs, 256), 256, 0, s>>>(
+                                  ix.u_start.as<u32>(), n_runs, sorg, ix.occurrence, ix.all_query, avoid_equal,
+                                  avoid_symmetric, r.h_id[first], nullptr, seg_off, cursor, g0, p0));
+    }
+    t.stop();
+  }
   Sketch& qs = e.query_sketch;
+  if (!join) {
+    index_build_table(e);
   {
     StageTimer t(e, StageTimes::kQuery);
     const bool ready = e.query_ready && e.query_ready_first == first && e.query_ready_last == last &&
@@ -423,7 +675,6 @@ void map_batch_impl(Engine& e, const ReadsDev& r, u32 first, u32 last, bool avoi
     }
     return;
   }
-  u64 H = 0;
   {
     StageTimer t(e, StageTimes::kMatch);
     u32* q_start = e.q_start.get<u32>(nq + 1);
@@ -436,8 +687,7 @@ void map_batch_impl(Engine& e, const ReadsDev& r, u32 first, u32 last, bool avoi
         static_cast<u32>(ix.u), ix.s_org[ix.cur].as<u64>(), ix.occurrence, avoid_equal, avoid_symmetric, q_start, q_n,
         q_cnt, filt));
     exclusive_scan_u32_u64(q_cnt, m_off, nq, e.scan_tmp, s);
-    RVN_HIP(hipMemcpyAsync(&H, m_off + nq, 8, hipMemcpyDeviceToHost, s));
-    RVN_HIP(hipStreamSynchronize(s));
+    H = read_back(e, m_off + nq, 8);
     out.n_matches = H;
     e.c_matches += H;
     if (H) {
@@ -448,8 +698,13 @@ void map_batch_impl(Engine& e, const ReadsDev& r, u32 first, u32 last, bool avoi
       RVN_KLAUNCH(kKMatchEmit, match_emit_kernel<<<div_up(nq, 256), 256, 0, s>>>(qs.org.as<u64>(), nq, ix.s_org[ix.cur].as<u64>(), q_start,
                                                         q_n, m_off, avoid_equal, avoid_symmetric, g0, p0));
     }
+    if (H) {
+      RVN_KLAUNCH(kKGather, gather_u64_by_u32_kernel<<<div_up(nr + 1, 256), 256, 0, s>>>(
+                                e.m_off.as<u64>(), qs.read_off.as<u32>(), seg_off, nr + 1));
+    }
     t.stop();
   }
+  }  // !join
   if (H == 0) {
     RVN_HIP(hipMemsetAsync(ovl_read_off, 0, (static_cast<size_t>(nr) + 1) * 4, s));
     return;
@@ -458,11 +713,8 @@ void map_batch_impl(Engine& e, const ReadsDev& r, u32 first, u32 last, bool avoi
   u64* g1 = e.m_grp[1].as<u64>();
   u64* p0 = e.m_pos[0].as<u64>();
   u64* p1 = e.m_pos[1].as<u64>();
-  u64* seg_off = e.seg_off.get<u64>(static_cast<size_t>(nr) + 1);
   {
     StageTimer t(e, StageTimes::kSegSort);
-    RVN_KLAUNCH(kKGather, gather_u64_by_u32_kernel<<<div_up(nr + 1, 256), 256, 0, s>>>(e.m_off.as<u64>(), qs.read_off.as<u32>(), seg_off,
-                                                                 nr + 1));
     RVN_KLAUNCH(kKSegSortGroup, seg_sort_off_kernel<<<div_up(nr, 4), 256, 0, s>>>(g0, g1, p0, p1, seg_off, nr));
     t.stop();
   }
@@ -476,15 +728,14 @@ void map_batch_impl(Engine& e, const ReadsDev& r, u32 first, u32 last, bool avoi
     u32* iv_off = e.iv_off.get<u32>(static_cast<size_t>(nr) + 2);
     RVN_KLAUNCH(kKIntervals, intervals_kernel<<<div_up(nr, 4), 256, 0, s>>>(g0, seg_off, nr, e.bandwidth, slot_begin, slot_end, iv_cnt));
     exclusive_scan_u32_u32(iv_cnt, iv_off, nr, e.scan_tmp, s);
-    RVN_HIP(hipMemcpyAsync(&NI, iv_off + nr, 4, hipMemcpyDeviceToHost, s));
-    RVN_HIP(hipStreamSynchronize(s));
+    NI = static_cast<u32>(read_back(e, iv_off + nr, 4));
     out.n_intervals = NI;
     if (NI) {
       u64* iv_begin = e.iv_begin.get<u64>(static_cast<size_t>(NI) + 1);
       u64* iv_end = e.iv_end.get<u64>(static_cast<size_t>(NI) + 1);
       u32* iv_read = e.tmp_b.get<u32>(static_cast<size_t>(NI) + 1);
-      RVN_KLAUNCH(kKIntervalsGather, intervals_gather_kernel<<<div_up(nr, 4), 256, 0, s>>>(slot_begin, slot_end, seg_off, iv_off, nr, iv_begin,
-                                                            iv_end, iv_read));
+      RVN_KLAUNCH(kKIntervalsGather, intervals_gather_kernel<<<div_up(nr, 4), 256, 0, s>>>(
+                                         slot_begin, slot_end, seg_off, iv_off, nr, iv_begin, iv_end, iv_read));
     }
     t.stop();
   }
@@ -505,19 +756,23 @@ void map_batch_impl(Engine& e, const ReadsDev& r, u32 first, u32 last, bool avoi
     RVN_KLAUNCH(kKSegSortPos, seg_sort_be_kernel<<<div_up(NI, 4), 256, 0, s>>>(p0, p1, g0, g1, iv_begin, iv_end, NI, e.chain));
     u32* lis_min = e.lis_min.get<u32>(H + NI + 1);
     u32* lis_pred = e.lis_pred.get<u32>(H + 1);
+    u64* lis_tail = e.lis_tail.get<u64>(H + NI + 1);
+    u64* lis_mask = e.lis_mask.get<u64>((H >> 6) + NI + 2);
     RVN_HIP(hipMemsetAsync(slot_flags, 0, n_slots + 1, s));
-    RVN_KLAUNCH(kKChain, chain_kernel<<<div_up(NI, 64), 64, 0, s>>>(g0, p0, iv_begin, iv_end, iv_read, NI, r.id.as<u32>(), first, e.k,
-                                               e.chain, e.matches, e.gap, slot_div, lis_min, lis_pred, slots,
-                                               slot_flags));
+    RVN_KLAUNCH(kKChainSmall, chain_small_kernel<<<div_up(NI, 64), 64, 0, s>>>(
+                                  g0, p0, iv_begin, iv_end, iv_read, NI, r.id.as<u32>(), first, e.k, e.chain, e.matches,
+                                  e.gap, slot_div, slots, slot_flags));
+    RVN_KLAUNCH(kKChain, chain_kernel<<<div_up(NI, 4 * kChainPerWave), 256, 0, s>>>(g0, p0, iv_begin, iv_end, iv_read, NI,
+                                                                     r.id.as<u32>(), first, e.k, e.chain, e.matches,
+                                                                     e.gap, slot_div, lis_tail, lis_min, lis_pred,
+                                                                     lis_mask, slots, slot_flags));
     t.stop();
   }
   {
     StageTimer t(e, StageTimes::kCompact);
     u32* scan = e.ovl_scan.get<u32>(n_slots + 2);
     exclusive_scan_u8_u32(slot_flags, scan, n_slots, e.scan_tmp, s);
-    u32 O = 0;
-    RVN_HIP(hipMemcpyAsync(&O, scan + n_slots, 4, hipMemcpyDeviceToHost, s));
-    RVN_HIP(hipStreamSynchronize(s));
+    const u32 O = static_cast<u32>(read_back(e, scan + n_slots, 4));
     out.n_overlaps = O;
     e.c_overlaps += O;
     Overlap* ovl = out.ovl.get<Overlap>(static_cast<size_t>(O) + 1);

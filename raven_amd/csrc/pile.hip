@@ -222,11 +222,10 @@ void piles_merge(Engine& e, const ReadsDev& r, const MapOut& mo, u32 kmax, PileS
                                                     kmax, tot, new_kept_cnt));
   exclusive_scan_u32_u32(tot, list_off, n, e.scan_tmp, s);
   exclusive_scan_u32_u32(new_kept_cnt, new_kept_off, n, e.scan_tmp, s);
-  u32 totals[2] = {0, 0};
-  RVN_HIP(hipMemcpyAsync(&totals[0], list_off + n, 4, hipMemcpyDeviceToHost, s));
-  RVN_HIP(hipMemcpyAsync(&totals[1], new_kept_off + n, 4, hipMemcpyDeviceToHost, s));
+  RVN_HIP(hipMemcpyAsync(e.h_pin, list_off + n, 4, hipMemcpyDeviceToHost, s));
+  RVN_HIP(hipMemcpyAsync(e.h_pin + 1, new_kept_off + n, 4, hipMemcpyDeviceToHost, s));
   RVN_HIP(hipStreamSynchronize(s));
-  const u32 L = totals[0], K = totals[1];
+  const u32 L = static_cast<u32>(e.h_pin[0]), K = static_cast<u32>(e.h_pin[1]);
   Overlap* list = ps.new_list.get<Overlap>(static_cast<size_t>(L) + 1);
   RVN_KLAUNCH(kKPileBuild, pile_build_kernel<<<div_up(n, 4), 256, 0, s>>>(ovl, ovl_read_off, mo.first, mo.last, in_idx_sorted, in_off,
                                                  ps.kept.as<Overlap>(), ps.kept_off.as<u32>(), list_off, n, list));

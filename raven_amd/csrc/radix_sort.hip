@@ -36,28 +36,35 @@ __global__ __launch_bounds__(kThreads) void rs_upsweep_kernel(const K* __restric
   block_hist[static_cast<u64>(threadIdx.x) * nb + blockIdx.x] = hist[threadIdx.x];
 }
 
+// Downsweep with an LDS-staged scatter: items are first placed in tile-sorted order in LDS, then written
+// out so that consecutive lanes store consecutive addresses of the same digit run (the direct scatter wrote
+// 4-8 byte fragments: PMC WRITE_SIZE was 2.1x the algorithmic bytes, profiles/r01_c_pmc_write_size.csv).
 template <typename K, typename V>
 __global__ __launch_bounds__(kThreads) void rs_downsweep_kernel(const K* __restrict__ keys_in,
                                                                const V* __restrict__ vals_in,
                                                                K* __restrict__ keys_out, V* __restrict__ vals_out,
                                                                u64 n, int shift,
                                                                const u32* __restrict__ block_hist_scanned, u32 nb) {
-  __shared__ u32 wave_cnt[kWaves][256];
-  __shared__ u32 wave_off[kWaves][256];
+  __shared__ K s_keys[kTile];
+  __shared__ V s_vals[kTile];
+  __shared__ u16 wave_cnt[kWaves][256];  // per-wave digit counts, then per-wave tile-local offsets
+  __shared__ u32 digit_gbase[256];       // global base of (digit, block) minus the digit's tile-local start
+  __shared__ u32 smem4[4];
   const int w = threadIdx.x >> 6;
   const int lane = lane_id();
   for (int i = threadIdx.x; i < kWaves * 256; i += kThreads) (&wave_cnt[0][0])[i] = 0;
   __syncthreads();
 
-  const u64 wbase = static_cast<u64>(blockIdx.x) * kTile + static_cast<u64>(w) * kWaveItems;
+  const u64 tile_base = static_cast<u64>(blockIdx.x) * kTile;
+  const u64 wbase = tile_base + static_cast<u64>(w) * kWaveItems;
   K key[kRows];
   V val[kRows];
-  u32 rank[kRows];
+  u16 rank[kRows];
   const unsigned long long lt = lanemask_lt();
 #pragma unroll
   for (int r = 0; r < kRows; ++r) {
-    u64 idx = wbase + static_cast<u64>(r) * 64 + lane;
-    bool valid = idx < n;
+    const u64 idx = wbase + static_cast<u64>(r) * 64 + lane;
+    const bool valid = idx < n;
     if (valid) {
       key[r] = keys_in[idx];
       val[r] = vals_in[idx];
@@ -65,35 +72,63 @@ __global__ __launch_bounds__(kThreads) void rs_downsweep_kernel(const K* __restr
       key[r] = 0;
       val[r] = V{};
     }
-    unsigned d = static_cast<unsigned>((key[r] >> shift) & 0xFF);
-    unsigned long long peers = match_digit8(d, valid);
+  }
+#pragma unroll
+  for (int r = 0; r < kRows; ++r) {
+    const u64 idx = wbase + static_cast<u64>(r) * 64 + lane;
+    const bool valid = idx < n;
+    const unsigned d = static_cast<unsigned>((key[r] >> shift) & 0xFF);
+    const unsigned long long peers = match_digit8(d, valid);
     u32 before = 0;
     if (valid) before = wave_cnt[w][d];
     __builtin_amdgcn_wave_barrier();
-    rank[r] = before + __popcll(peers & lt);
-    if (valid && (peers & lt) == 0) wave_cnt[w][d] = before + __popcll(peers);  // lowest peer lane updates
+    rank[r] = static_cast<u16>(before + __popcll(peers & lt));
+    if (valid && (peers & lt) == 0) wave_cnt[w][d] = static_cast<u16>(before + __popcll(peers));
     __builtin_amdgcn_wave_barrier();
   }
   __syncthreads();
   {
-    // digit t: prefix over waves + global base of (digit, block)
+    // digit t: counts per wave -> tile-local start of the digit (block scan) and per-wave offsets
     const int t = threadIdx.x;
-    u32 run = block_hist_scanned[static_cast<u64>(t) * nb + blockIdx.x];
+    u32 c[kWaves];
+    u32 tot = 0;
 #pragma unroll
     for (int i = 0; i < kWaves; ++i) {
-      wave_off[i][t] = run;
-      run += wave_cnt[i][t];
+      c[i] = wave_cnt[i][t];
+      tot += c[i];
+    }
+    u32 total;
+    const u32 start = block_exclusive_sum_256<u32>(tot, smem4, &total);
+    digit_gbase[t] = block_hist_scanned[static_cast<u64>(t) * nb + blockIdx.x] - start;
+    u32 run = start;
+#pragma unroll
+    for (int i = 0; i < kWaves; ++i) {
+      wave_cnt[i][t] = static_cast<u16>(run);
+      run += c[i];
     }
   }
   __syncthreads();
 #pragma unroll
   for (int r = 0; r < kRows; ++r) {
-    u64 idx = wbase + static_cast<u64>(r) * 64 + lane;
+    const u64 idx = wbase + static_cast<u64>(r) * 64 + lane;
     if (idx < n) {
-      unsigned d = static_cast<unsigned>((key[r] >> shift) & 0xFF);
-      u32 dst = wave_off[w][d] + rank[r];
-      keys_out[dst] = key[r];
-      vals_out[dst] = val[r];
+      const unsigned d = static_cast<unsigned>((key[r] >> shift) & 0xFF);
+      const u32 lp = static_cast<u32>(wave_cnt[w][d]) + rank[r];
+      s_keys[lp] = key[r];
+      s_vals[lp] = val[r];
+    }
+  }
+  __syncthreads();
+  const u32 valid_n = static_cast<u32>(n - tile_base < static_cast<u64>(kTile) ? n - tile_base : kTile);
+#pragma unroll
+  for (int i = 0; i < kTile / kThreads; ++i) {
+    const u32 lp = i * kThreads + threadIdx.x;
+    if (lp < valid_n) {
+      const K kk = s_keys[lp];
+      const unsigned d = static_cast<unsigned>((kk >> shift) & 0xFF);
+      const u32 dst = digit_gbase[d] + lp;
+      keys_out[dst] = kk;
+      vals_out[dst] = s_vals[lp];
     }
   }
 }

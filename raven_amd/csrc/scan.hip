@@ -13,20 +13,7 @@ constexpr int kScanTile = kScanThreads * kScanItems;
 
 template <typename In>
 __global__ __launch_bounds__(kScanThreads) void scan_reduce_kernel(const In* __restrict__ in, u64 n,
-                                                                  u64* __restrict__ block_sums) {
-  __shared__ u64 smem[4];
-  const u64 base = static_cast<u64>(blockIdx.x) * kScanTile;
-  u64 sum = 0;
-#pragma unroll
-  for (int i = 0; i < kScanItems; ++i) {
-    u64 idx = base + static_cast<u64>(i) * kScanThreads + threadIdx.x;
-    if (idx < n) sum += in[idx];
-  }
-  sum = wave_sum(sum);
-  if (lane_id() == 0) smem[threadIdx.x >> 6] = sum;
-  __syncthreads();
-  if (threadIdx.x == 0) block_sums[blockIdx.x] = smem[0] + smem[1] + smem[2] + smem[3];
-}
+                                                                  u64* __restrict__ block_sums);
 
 // Single block: in-place exclusive scan of block sums; total written to sums[nb].
 __global__ __launch_bounds__(kScanThreads) void scan_block_sums_kernel(u64* __restrict__ sums, u32 nb) {
@@ -48,6 +35,63 @@ __global__ __launch_bounds__(kScanThreads) void scan_block_sums_kernel(u64* __re
   if (threadIdx.x == 0) sums[nb] = carry_s;
 }
 
+// 16 consecutive items of one thread, vectorised (16-byte accesses) when the chunk is in range and aligned.
+template <typename T>
+__device__ __forceinline__ void load16(const T* __restrict__ in, u64 base, u64 n, u64 (&vals)[kScanItems]) {
+  constexpr int kVec = 16 / sizeof(T);  // items per 16-byte access
+  const bool fast = base + kScanItems <= n && (reinterpret_cast<uintptr_t>(in + base) & 15) == 0;
+  if (fast) {
+    const uint4* src = reinterpret_cast<const uint4*>(in + base);
+#pragma unroll
+    for (int v = 0; v < kScanItems / kVec; ++v) {
+      const uint4 q = src[v];
+      const T* e = reinterpret_cast<const T*>(&q);
+#pragma unroll
+      for (int j = 0; j < kVec; ++j) vals[v * kVec + j] = static_cast<u64>(e[j]);
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < kScanItems; ++i) vals[i] = (base + i < n) ? static_cast<u64>(in[base + i]) : 0;
+  }
+}
+
+template <typename T>
+__device__ __forceinline__ void store16(T* __restrict__ out, u64 base, u64 n, const u64 (&vals)[kScanItems]) {
+  constexpr int kVec = 16 / sizeof(T);
+  const bool fast = base + kScanItems <= n && (reinterpret_cast<uintptr_t>(out + base) & 15) == 0;
+  if (fast) {
+    uint4* dst = reinterpret_cast<uint4*>(out + base);
+#pragma unroll
+    for (int v = 0; v < kScanItems / kVec; ++v) {
+      uint4 q;
+      T* e = reinterpret_cast<T*>(&q);
+#pragma unroll
+      for (int j = 0; j < kVec; ++j) e[j] = static_cast<T>(vals[v * kVec + j]);
+      dst[v] = q;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < kScanItems; ++i)
+      if (base + i < n) out[base + i] = static_cast<T>(vals[i]);
+  }
+}
+
+template <typename In>
+__global__ __launch_bounds__(kScanThreads) void scan_reduce_kernel(const In* __restrict__ in, u64 n,
+                                                                  u64* __restrict__ block_sums) {
+  __shared__ u64 smem[4];
+  const u64 base = static_cast<u64>(blockIdx.x) * kScanTile + static_cast<u64>(threadIdx.x) * kScanItems;
+  u64 vals[kScanItems];
+  load16<In>(in, base, n, vals);
+  u64 sum = 0;
+#pragma unroll
+  for (int i = 0; i < kScanItems; ++i) sum += vals[i];
+  sum = wave_sum(sum);
+  if (lane_id() == 0) smem[threadIdx.x >> 6] = sum;
+  __syncthreads();
+  if (threadIdx.x == 0) block_sums[blockIdx.x] = smem[0] + smem[1] + smem[2] + smem[3];
+}
+
 template <typename In, typename Out>
 __global__ __launch_bounds__(kScanThreads) void scan_downsweep_kernel(const In* __restrict__ in, Out* __restrict__ out,
                                                                      u64 n, const u64* __restrict__ block_sums,
@@ -56,22 +100,20 @@ __global__ __launch_bounds__(kScanThreads) void scan_downsweep_kernel(const In* 
   // blocked arrangement: thread t owns items [t*16, t*16+16) of the tile
   const u64 base = static_cast<u64>(blockIdx.x) * kScanTile + static_cast<u64>(threadIdx.x) * kScanItems;
   u64 vals[kScanItems];
+  load16<In>(in, base, n, vals);
   u64 sum = 0;
 #pragma unroll
-  for (int i = 0; i < kScanItems; ++i) {
-    u64 idx = base + i;
-    vals[i] = idx < n ? static_cast<u64>(in[idx]) : 0;
-    sum += vals[i];
-  }
+  for (int i = 0; i < kScanItems; ++i) sum += vals[i];
   u64 total;
   u64 ex = block_exclusive_sum_256<u64>(sum, smem, &total);
   u64 run = block_sums[blockIdx.x] + ex;
 #pragma unroll
   for (int i = 0; i < kScanItems; ++i) {
-    u64 idx = base + i;
-    if (idx < n) out[idx] = static_cast<Out>(run);
-    run += vals[i];
+    const u64 v = vals[i];
+    vals[i] = run;
+    run += v;
   }
+  store16<Out>(out, base, n, vals);
   if (blockIdx.x == nb - 1 && threadIdx.x == 0) out[n] = static_cast<Out>(block_sums[nb]);
 }
 
@@ -97,7 +139,7 @@ const char* const kKernelSiteNames[kKNumSites] = {
     "sketch_count", "sketch_write", "minhash_select", "compact_sketch", "scan", "rs_bits", "rs_upsweep",
     "rs_downsweep", "heads", "unique", "table", "occ_hist", "match_count", "match_emit", "seg_sort_group",
     "intervals", "intervals_gather", "seg_sort_pos", "chain", "compact_overlaps", "pile_keys", "pile_counts",
-    "pile_build", "add_layers", "truncate_sort", "kept_write", "gather", "pile_sort_up", "pile_sort_down"};
+    "pile_build", "add_layers", "truncate_sort", "kept_write", "gather", "pile_sort_up", "pile_sort_down", "chain_small", "join_count", "join_emit"};
 
 thread_local KernelTimers* g_kernel_timers = nullptr;
 

@@ -158,7 +158,9 @@ template <typename V>
 __global__ __launch_bounds__(kThreads) void minhash_select_kernel(const V* __restrict__ val,
                                                                  const u32* __restrict__ read_off,
                                                                  const u32* __restrict__ lens, u32 first, u32 k,
-                                                                 int top_shift, u8* __restrict__ flags) {
+                                                                 int top_shift, u8* __restrict__ flags,
+                                                                 u64* __restrict__ org_flag,
+                                                                 unsigned long long* __restrict__ kept_total) {
   __shared__ u32 hist[256];
   __shared__ u64 s_prefix;
   __shared__ u32 s_remaining;
@@ -171,8 +173,13 @@ __global__ __launch_bounds__(kThreads) void minhash_select_kernel(const V* __res
   const u32 R = min(n, lens[first + r] / k);
   const V* v = val + b;
   u8* fl = flags + b;
+  u64* og = org_flag ? org_flag + b : nullptr;
+  if (kept_total && threadIdx.x == 0) atomicAdd(kept_total, static_cast<unsigned long long>(R));
   if (R == n || R == 0) {
-    for (u32 i = threadIdx.x; i < n; i += kThreads) fl[i] = R ? 1 : 0;
+    for (u32 i = threadIdx.x; i < n; i += kThreads) {
+      fl[i] = R ? 1 : 0;
+      if (og && R) og[i] |= kQueryFlag;
+    }
     return;
   }
   if (threadIdx.x == 0) {
@@ -226,7 +233,11 @@ __global__ __launch_bounds__(kThreads) void minhash_select_kernel(const V* __res
     u32 basec = s_run;
     for (int q = 0; q < wv; ++q) basec += s_wt[q];
     const u32 rank = basec + __popcll(bm & lanemask_lt());
-    if (valid) fl[i] = (x < T || (eq && rank < rem)) ? 1 : 0;
+    if (valid) {
+      const bool sel = x < T || (eq && rank < rem);
+      fl[i] = sel ? 1 : 0;
+      if (og && sel) og[i] |= kQueryFlag;
+    }
     __syncthreads();
     if (threadIdx.x == 0) s_run += s_wt[0] + s_wt[1] + s_wt[2] + s_wt[3];
     __syncthreads();
@@ -268,9 +279,7 @@ void sketch_raw_impl(Engine& e, const ReadsDev& r, u32 first, u32 last, Sketch& 
                                  r.tile_read.as<u32>(), r.tile_start.as<u32>(), tf, e.k, e.w, tile_cnt, nullptr,
                                  nullptr, nullptr));
   exclusive_scan_u32_u32(tile_cnt, tile_off, nt, e.scan_tmp, s);
-  u32 total = 0;
-  RVN_HIP(hipMemcpyAsync(&total, tile_off + nt, 4, hipMemcpyDeviceToHost, s));
-  RVN_HIP(hipStreamSynchronize(s));
+  const u32 total = static_cast<u32>(read_back(e, tile_off + nt, 4));
   V* val = out.val.get<V>(static_cast<size_t>(total) + 1);
   u64* org = out.org.get<u64>(static_cast<size_t>(total) + 1);
   RVN_KLAUNCH(kKSketchWrite, sketch_kernel<V, true><<<nt, kThreads, 0, s>>>(
@@ -305,11 +314,10 @@ void sketch_minhash_impl(Engine& e, const ReadsDev& r, const Sketch& raw, Sketch
   u32* fscan = e.tmp_d.get<u32>(static_cast<size_t>(total) + 1);
   const int nbytes = (2 * e.k + 7) / 8;
   RVN_KLAUNCH(kKMinhashSelect, minhash_select_kernel<V><<<nr, kThreads, 0, s>>>(val, raw_read_off, r.len.as<u32>(),
-                                                                                first, e.k, 8 * (nbytes - 1), flags));
+                                                                                first, e.k, 8 * (nbytes - 1), flags, nullptr,
+                                                                                nullptr));
   exclusive_scan_u8_u32(flags, fscan, total, e.scan_tmp, s);
-  u32 kept = 0;
-  RVN_HIP(hipMemcpyAsync(&kept, fscan + total, 4, hipMemcpyDeviceToHost, s));
-  RVN_HIP(hipStreamSynchronize(s));
+  const u32 kept = static_cast<u32>(read_back(e, fscan + total, 4));
   V* oval = out.val.get<V>(static_cast<size_t>(kept) + 1);
   u64* oorg = out.org.get<u64>(static_cast<size_t>(kept) + 1);
   RVN_KLAUNCH(kKCompactSketch,
@@ -356,6 +364,27 @@ void sketch_raw(Engine& e, const ReadsDev& r, u32 first, u32 last, Sketch& out) 
 void sketch_minhash(Engine& e, const ReadsDev& r, const Sketch& raw, Sketch& out) {
   if (e.val64) sketch_minhash_impl<u64>(e, r, raw, out);
   else sketch_minhash_impl<u32>(e, r, raw, out);
+}
+
+u64 sketch_flag_queries(Engine& e, const ReadsDev& r, Sketch& raw) {
+  hipStream_t s = e.stream;
+  const u64 total = raw.count;
+  if (total == 0) return 0;
+  const u32 nr = raw.last - raw.first;
+  u8* flags = e.tmp_c.get<u8>(static_cast<size_t>(total) + 1);
+  unsigned long long* kept = e.tmp_e.get<unsigned long long>(2);
+  RVN_HIP(hipMemsetAsync(kept, 0, 8, s));
+  const int nbytes = (2 * e.k + 7) / 8;
+  if (e.val64) {
+    RVN_KLAUNCH(kKMinhashSelect, minhash_select_kernel<u64><<<nr, kThreads, 0, s>>>(
+                                     raw.val.as<u64>(), raw.read_off.as<u32>(), r.len.as<u32>(), raw.first, e.k,
+                                     8 * (nbytes - 1), flags, raw.org.as<u64>(), kept));
+  } else {
+    RVN_KLAUNCH(kKMinhashSelect, minhash_select_kernel<u32><<<nr, kThreads, 0, s>>>(
+                                     raw.val.as<u32>(), raw.read_off.as<u32>(), r.len.as<u32>(), raw.first, e.k,
+                                     8 * (nbytes - 1), flags, raw.org.as<u64>(), kept));
+  }
+  return read_back(e, kept, 8);
 }
 
 void sketch_range(Engine& e, const ReadsDev& r, u32 first, u32 last, bool minhash, Sketch& out) {

@@ -124,6 +124,25 @@ def test_pass1_k19_hifi_like(gpu):
     assert ref["counters"]["matches"] > 10 * ref["counters"]["overlaps"]
 
 
+def test_pass1_long_intervals(gpu):
+    """30 kb low-error reads: intervals with > 1024 matches take the chain kernel's global-scratch path."""
+    g = synth.make_genome(120_000, seed=51)
+    rs, _ = synth.make_reads(g, 10, 30000, seed=52, sub=0.001, ins=0.0005, dele=0.0005)
+    he, oe = _mk()
+    rd = he.upload(rs)
+    errs, ref = pu.compare_pass1(he, oe, rd, rs)
+    assert errs == []
+    c = ref["counters"]
+    assert c["matches"] / max(1, c["overlaps"]) > 400
+    # and the un-minhashed query side (5x more matches per interval)
+    he.minimize(rd, 0, rs.n, False)
+    oe.minimize(rs, 0, rs.n, False)
+    he.filter(0.001)
+    oe.filter(0.001)
+    errs, _ = pu.compare_map(he, oe, rd, rs, 0, rs.n, False)
+    assert errs == []
+
+
 def test_pass1_ragged_and_empty(gpu):
     rng = np.random.default_rng(5)
     g = synth.make_genome(60_000, seed=31)
