@@ -91,6 +91,19 @@ void rvn_pass1_destroy(rvn_pass1* p);
 int rvn_pile_add_layers(rvn_engine* e, uint16_t* data, uint32_t cells, uint32_t id, const rvn_overlap* overlaps,
                         uint64_t n);
 
+/* Batched edlibAlign(lhs, rhs, edlibDefaultAlignConfig()).editDistance (global / NW, unit costs) between
+ * spans of uploaded reads: RavenLib/src/construct.cc:176-199 (identity filter of ResolveContainedReads) and
+ * :393-416 (second pass).  lhs/rhs_read are read INDICES in `r`; strand == 0 reverse-complements the rhs span
+ * first (construct.cc:184-188).  distances[i] is the exact edit distance (any size; no threshold). */
+typedef struct rvn_ed_pair {
+  uint32_t lhs_read, lhs_begin, lhs_len;
+  uint32_t rhs_read, rhs_begin, rhs_len;
+  uint32_t strand;
+  uint32_t reserved;
+} rvn_ed_pair;
+int rvn_edit_distance_batch(rvn_engine* e, const rvn_reads* r, const rvn_ed_pair* pairs, uint32_t n_pairs,
+                            uint32_t* distances, double* device_ms, uint64_t* cells);
+
 /* ---- introspection used by the parity tests and bench.py ------------------------------------- */
 /* sketch of reads [first,last) == ram Minimize(sequence, minhash) per read; values widened to u64 */
 int rvn_engine_sketch(rvn_engine* e, const rvn_reads* r, uint32_t first, uint32_t last, int minhash,

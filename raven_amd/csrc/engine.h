@@ -147,6 +147,10 @@ void index_filter(Engine& e, double freq);               // sets e.index.occurre
 void map_batch(Engine& e, const ReadsDev& r, u32 first, u32 last, bool avoid_equal, bool avoid_symmetric,
                bool minhash, bool want_filtered, MapOut& out);
 
+// Batched exact edit distance (edit_distance.hip). h_pairs: n_pairs x {a_idx,a_begin,a_len,b_idx,b_begin,b_len,strand,0}
+void edit_distance_batch(Engine& e, const ReadsDev& r, const u32* h_pairs, u32 n_pairs, u32* h_out, double* kernel_ms,
+                         u64* cells);
+
 // Pass-1 state: per-pile kept overlaps + coverage (pile.hip)
 struct PileState {
   u32 n = 0;

@@ -416,6 +416,26 @@ int rvn_pile_add_layers(rvn_engine* h, uint16_t* data, uint32_t cells, uint32_t 
   });
 }
 
+int rvn_edit_distance_batch(rvn_engine* h, const rvn_reads* r, const rvn_ed_pair* pairs, uint32_t n_pairs,
+                            uint32_t* distances, double* device_ms, uint64_t* cells) {
+  return guarded([&]() -> int {
+    if (!h || !r || (n_pairs && (!pairs || !distances))) return fail(RVN_EINVAL, "[raven_hip] NULL argument");
+    const ReadsDev& rd = r->r;
+    for (uint32_t i = 0; i < n_pairs; ++i) {
+      const rvn_ed_pair& p = pairs[i];
+      if (p.lhs_read >= rd.n || p.rhs_read >= rd.n ||
+          static_cast<u64>(p.lhs_begin) + p.lhs_len > rd.h_len[p.lhs_read] ||
+          static_cast<u64>(p.rhs_begin) + p.rhs_len > rd.h_len[p.rhs_read])
+        return fail(RVN_EINVAL, "[raven_hip] rvn_edit_distance_batch: span outside its read");
+    }
+    RVN_HIP(hipSetDevice(h->e.device));
+    UseTimers ut(h->e);
+    static_assert(sizeof(rvn_ed_pair) == 32, "pair layout");
+    edit_distance_batch(h->e, rd, reinterpret_cast<const u32*>(pairs), n_pairs, distances, device_ms, cells);
+    return RVN_OK;
+  });
+}
+
 int rvn_engine_sketch(rvn_engine* h, const rvn_reads* r, uint32_t first, uint32_t last, int minhash, uint64_t* count) {
   return guarded([&]() -> int {
     if (!h || !r || first > last || last > r->r.n) return fail(RVN_EINVAL, "[raven_hip] rvn_engine_sketch: bad range");

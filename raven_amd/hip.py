@@ -19,6 +19,11 @@ OVERLAP_DTYPE = np.dtype([
     ("rhs_id", "<u4"), ("rhs_begin", "<u4"), ("rhs_end", "<u4"),
     ("score", "<u4"), ("strand", "<u4")])
 
+ED_PAIR_DTYPE = np.dtype([
+    ("lhs_read", "<u4"), ("lhs_begin", "<u4"), ("lhs_len", "<u4"),
+    ("rhs_read", "<u4"), ("rhs_begin", "<u4"), ("rhs_len", "<u4"),
+    ("strand", "<u4"), ("reserved", "<u4")])
+
 RVN_OK, RVN_EINVAL, RVN_ENODEVICE, RVN_EHIP, RVN_ENOMEM = 0, -1, -2, -3, -4
 
 # every symbol include/raven_hip.h declares (checked by tests/test_abi.py)
@@ -28,6 +33,7 @@ SYMBOLS = [
     "rvn_engine_map_batch", "rvn_engine_map_fetch", "rvn_engine_map_fetch_filtered",
     "rvn_find_overlaps_and_create_piles", "rvn_pass1_pile_words", "rvn_pass1_num_overlaps",
     "rvn_pass1_fetch_piles", "rvn_pass1_fetch_overlaps", "rvn_pass1_destroy", "rvn_pile_add_layers",
+    "rvn_edit_distance_batch",
     "rvn_engine_sketch", "rvn_engine_sketch_fetch", "rvn_engine_index_size", "rvn_engine_index_fetch",
     "rvn_engine_counters", "rvn_engine_num_stages", "rvn_engine_stage_name", "rvn_engine_stage_ms",
     "rvn_engine_reset_stats", "rvn_engine_set_timing", "rvn_engine_set_kernel_timing",
@@ -77,6 +83,7 @@ def lib():
     L.rvn_pass1_fetch_overlaps.argtypes = [vp, vp, vp]
     L.rvn_pass1_destroy.argtypes = [vp]
     L.rvn_pile_add_layers.argtypes = [vp, vp, u32, u32, vp, u64]
+    L.rvn_edit_distance_batch.argtypes = [vp, vp, vp, u32, vp, C.POINTER(dbl), C.POINTER(u64)]
     L.rvn_engine_sketch.argtypes = [vp, vp, u32, u32, i32, C.POINTER(u64)]
     L.rvn_engine_sketch_fetch.argtypes = [vp, vp, vp, vp]
     L.rvn_engine_index_size.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
@@ -240,6 +247,16 @@ class Engine:
         overlaps = np.ascontiguousarray(overlaps)
         _check(lib().rvn_pile_add_layers(self._h, _p(data), data.shape[0], pile_id, _p(overlaps),
                                          overlaps.shape[0]))
+
+    # -- edlibAlign(default config).editDistance, batched -----------------------------------------
+    def edit_distance_batch(self, reads: Reads, pairs: np.ndarray):
+        """pairs: array of ED_PAIR_DTYPE; returns (uint32 distances, device ms, DP cells)."""
+        pairs = np.ascontiguousarray(pairs, dtype=ED_PAIR_DTYPE)
+        out = np.zeros(pairs.shape[0], dtype=np.uint32)
+        ms, cells = C.c_double(0), C.c_uint64(0)
+        _check(lib().rvn_edit_distance_batch(self._h, reads._h, _p(pairs), pairs.shape[0], _p(out), C.byref(ms),
+                                             C.byref(cells)))
+        return out, ms.value, cells.value
 
     # -- introspection ---------------------------------------------------------------------
     def sketch(self, reads: Reads, first=0, last=None, minhash=False):
