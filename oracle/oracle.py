@@ -21,8 +21,8 @@ OVERLAP_DTYPE = np.dtype([
 
 
 def build(force: bool = False) -> str:
-    src = os.path.join(_HERE, "raven_oracle.cpp")
-    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("raven_oracle.cpp", "poa_oracle.cpp")]
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(x) for x in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return _LIB_PATH
 
@@ -67,6 +67,10 @@ def lib():
             fn.restype = rt
             fn.argtypes = [vp]
         L.orc_antiqsort.argtypes = [vp, u32]
+        L.orc_poa_window.restype = i32
+        L.orc_poa_window.argtypes = [vp, vp, vp, vp, vp, u32, i32, i32, i32, i32, vp, u32, C.POINTER(u32)]
+        L.orc_poa_align_score_linear.restype = i32
+        L.orc_poa_align_score_linear.argtypes = [vp, u32, vp, u32, i32, i32, i32]
         L.orc_edit_distance.restype = u32
         L.orc_edit_distance.argtypes = [C.c_char_p, u32, C.c_char_p, u32]
         _lib = L
@@ -198,6 +202,36 @@ def antiqsort(n: int) -> np.ndarray:
     out = np.zeros(n, dtype=np.uint32)
     lib().orc_antiqsort(_p(out), n)
     return out
+
+
+def poa_window(layers, begins=None, ends=None, quals=None, m=3, n=-5, g=-4, trim=True):
+    """racon Window::GenerateConsensus: layers = list of uint8 code arrays (layers[0] = backbone), begins/ends =
+    backbone positions of each layer (ignored for the backbone), quals = list of uint8 Phred+33 arrays or None.
+    Returns (consensus codes, polished flag)."""
+    k = len(layers)
+    off = np.zeros(k + 1, dtype=np.uint64)
+    np.cumsum([len(x) for x in layers], out=off[1:])
+    codes = np.concatenate([np.asarray(x, dtype=np.uint8) for x in layers]) if k else np.zeros(0, np.uint8)
+    q = None
+    if quals is not None:
+        q = np.concatenate([np.asarray(x, dtype=np.uint8) for x in quals])
+    blen = len(layers[0])
+    b = np.asarray([0] * k if begins is None else begins, dtype=np.uint32)
+    e = np.asarray([blen - 1] * k if ends is None else ends, dtype=np.uint32)
+    cap = int(off[-1]) + 16
+    out = np.zeros(cap, dtype=np.uint8)
+    n_out = C.c_uint32(0)
+    polished = lib().orc_poa_window(_p(codes), _p(q), _p(off), _p(b), _p(e), k, m, n, g, int(trim), _p(out), cap,
+                                    C.byref(n_out))
+    if polished < 0:
+        raise ValueError("[racon::Window::AddLayer] error: layer begin and end positions are invalid!")
+    return out[:n_out.value].copy(), bool(polished)
+
+
+def poa_align_score_linear(target, query, m=3, n=-5, g=-4) -> int:
+    t = np.ascontiguousarray(target, dtype=np.uint8)
+    q = np.ascontiguousarray(query, dtype=np.uint8)
+    return int(lib().orc_poa_align_score_linear(_p(t), t.shape[0], _p(q), q.shape[0], m, n, g))
 
 
 def edit_distance(a: bytes, b: bytes) -> int:

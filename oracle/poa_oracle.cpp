@@ -1,0 +1,477 @@
+// poa_oracle.cpp — CPU restatement of the window consensus that raven::Polish reaches through
+// racon::Polisher::Polish (RavenLib/src/polish.cc:43-51): racon `Window::GenerateConsensus` over spoa's
+// partial-order graph, linear-gap global (kNW) alignment (m=3, n=-5, g=-4: polish.hpp:13-17) and
+// heaviest-bundle consensus with TGS trimming.
+//
+// *** TEST INFRASTRUCTURE ONLY (see raven_oracle.cpp header). ***
+// PARITY STATUS: parity unpinned — racon (branch `library`, Raven.deps.cmake:39-44) and spoa are not in the
+// reference tree; this follows their published sources as recollected:
+//   spoa::Graph::{AddAlignment, AddSequence, AddEdge, TopologicalSort, Subgraph, UpdateAlignment,
+//                 TraverseHeaviestBundle, BranchCompletion, GenerateConsensus(summary), Node::Coverage}
+//   spoa::SisdAlignmentEngine::Linear (the SIMD engine computes the same matrix)
+//   racon::Window::GenerateConsensus
+// Definitional pins live in tests/test_oracle_poa.py (error-free layers reproduce the truth, majority vote
+// beats a wrong backbone, alignment score equals an independent DP on linear graphs, ...).
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <limits>
+#include <memory>
+#include <stack>
+#include <string>
+#include <unordered_set>
+#include <utility>
+#include <vector>
+
+namespace poa {
+
+using Alignment = std::vector<std::pair<std::int32_t, std::int32_t>>;  // (node id | -1, sequence pos | -1)
+
+struct Graph {
+  struct Edge {
+    std::uint32_t tail, head;
+    std::vector<std::uint32_t> labels;
+    std::int64_t weight;
+  };
+  struct Node {
+    std::uint32_t code;
+    std::vector<std::uint32_t> inedges, outedges;  // edge indices, insertion order
+    std::vector<std::uint32_t> aligned;            // node ids, insertion order
+  };
+  std::vector<Node> nodes;
+  std::vector<Edge> edges;
+  std::vector<std::uint32_t> rank_to_node;
+  std::uint32_t num_sequences = 0;
+  std::vector<std::uint32_t> consensus;  // node ids
+
+  std::uint32_t AddNode(std::uint32_t code) {
+    nodes.push_back(Node{code, {}, {}, {}});
+    return nodes.size() - 1;
+  }
+  void AddEdge(std::uint32_t tail, std::uint32_t head, std::int64_t weight) {
+    for (auto e : nodes[tail].outedges) {
+      if (edges[e].head == head) {
+        edges[e].labels.push_back(num_sequences);
+        edges[e].weight += weight;
+        return;
+      }
+    }
+    edges.push_back(Edge{tail, head, {num_sequences}, weight});
+    nodes[tail].outedges.push_back(edges.size() - 1);
+    nodes[head].inedges.push_back(edges.size() - 1);
+  }
+  // returns first node of the run or -1
+  std::int32_t AddSequence(const std::uint8_t* codes, const std::vector<std::uint32_t>& weights, std::uint32_t begin,
+                           std::uint32_t end) {
+    if (begin == end) return -1;
+    std::int32_t prev = -1, first = -1;
+    for (std::uint32_t i = begin; i < end; ++i) {
+      std::int32_t curr = AddNode(codes[i]);
+      if (first < 0) first = curr;
+      if (prev >= 0) AddEdge(prev, curr, weights[i - 1] + weights[i]);
+      prev = curr;
+    }
+    return first;
+  }
+  void AddAlignment(const Alignment& alignment, const std::uint8_t* codes, std::uint32_t len,
+                    const std::vector<std::uint32_t>& weights) {
+    if (len == 0) return;
+    if (alignment.empty()) {
+      AddSequence(codes, weights, 0, len);
+      ++num_sequences;
+      TopologicalSort();
+      return;
+    }
+    std::vector<std::uint32_t> valid;
+    for (const auto& it : alignment)
+      if (it.second != -1) valid.push_back(it.second);
+    std::uint32_t tmp = nodes.size();
+    std::int32_t begin = AddSequence(codes, weights, 0, valid.front());
+    std::int32_t prev = tmp == nodes.size() ? -1 : static_cast<std::int32_t>(nodes.size() - 1);
+    std::int32_t last = AddSequence(codes, weights, valid.back() + 1, len);
+    for (const auto& it : alignment) {
+      if (it.second == -1) continue;
+      std::uint32_t code = codes[it.second];
+      std::int32_t curr = -1;
+      if (it.first == -1) {
+        curr = AddNode(code);
+      } else {
+        std::uint32_t jt = it.first;
+        if (nodes[jt].code == code) {
+          curr = jt;
+        } else {
+          for (auto kt : nodes[jt].aligned) {
+            if (nodes[kt].code == code) {
+              curr = kt;
+              break;
+            }
+          }
+          if (curr < 0) {
+            curr = AddNode(code);
+            auto al = nodes[jt].aligned;  // copy: the loop mutates other nodes' lists only
+            for (auto kt : al) {
+              nodes[kt].aligned.push_back(curr);
+              nodes[curr].aligned.push_back(kt);
+            }
+            nodes[jt].aligned.push_back(curr);
+            nodes[curr].aligned.push_back(jt);
+          }
+        }
+      }
+      if (begin < 0) begin = curr;
+      if (prev >= 0) AddEdge(prev, curr, weights[it.second - 1] + weights[it.second]);
+      prev = curr;
+    }
+    if (last >= 0) AddEdge(prev, last, weights[valid.back()] + weights[valid.back() + 1]);
+    ++num_sequences;
+    TopologicalSort();
+  }
+  void TopologicalSort() {
+    rank_to_node.clear();
+    std::vector<std::uint8_t> marks(nodes.size(), 0);
+    std::vector<bool> ignored(nodes.size(), false);
+    std::stack<std::uint32_t> stack;
+    for (std::uint32_t it = 0; it < nodes.size(); ++it) {
+      if (marks[it] != 0) continue;
+      stack.push(it);
+      while (!stack.empty()) {
+        auto curr = stack.top();
+        bool is_valid = true;
+        if (marks[curr] != 2) {
+          for (auto e : nodes[curr].inedges) {
+            if (marks[edges[e].tail] != 2) {
+              stack.push(edges[e].tail);
+              is_valid = false;
+            }
+          }
+          if (!ignored[curr]) {
+            for (auto jt : nodes[curr].aligned) {
+              if (marks[jt] != 2) {
+                stack.push(jt);
+                ignored[jt] = true;
+                is_valid = false;
+              }
+            }
+          }
+          if (is_valid) {
+            marks[curr] = 2;
+            if (!ignored[curr]) {
+              rank_to_node.push_back(curr);
+              for (auto jt : nodes[curr].aligned) rank_to_node.push_back(jt);
+            }
+          } else {
+            marks[curr] = 1;
+          }
+        }
+        if (is_valid) stack.pop();
+      }
+    }
+  }
+  // spoa Graph::Subgraph(begin, end, &mapping): ancestors of node `end` with id >= begin
+  Graph Subgraph(std::uint32_t begin, std::uint32_t end, std::vector<std::uint32_t>* sub_to_graph) const {
+    std::vector<bool> in(nodes.size(), false);
+    std::stack<std::uint32_t> stack;
+    stack.push(end);
+    while (!stack.empty()) {
+      auto curr = stack.top();
+      stack.pop();
+      if (!in[curr] && curr >= begin) {
+        for (auto e : nodes[curr].inedges) stack.push(edges[e].tail);
+        for (auto jt : nodes[curr].aligned) stack.push(jt);
+        in[curr] = true;
+      }
+    }
+    Graph sub;
+    sub_to_graph->clear();
+    std::vector<std::int32_t> g2s(nodes.size(), -1);
+    for (std::uint32_t it = 0; it < nodes.size(); ++it) {
+      if (!in[it]) continue;
+      g2s[it] = sub.AddNode(nodes[it].code);
+      sub_to_graph->push_back(it);
+    }
+    for (std::uint32_t it = 0; it < nodes.size(); ++it) {
+      if (!in[it]) continue;
+      for (auto e : nodes[it].inedges)
+        if (g2s[edges[e].tail] >= 0) sub.AddEdge(g2s[edges[e].tail], g2s[it], edges[e].weight);
+      for (auto kt : nodes[it].aligned)
+        if (g2s[kt] >= 0) sub.nodes[g2s[it]].aligned.push_back(g2s[kt]);
+    }
+    sub.TopologicalSort();
+    return sub;
+  }
+  std::uint32_t Coverage(std::uint32_t id) const {
+    std::unordered_set<std::uint32_t> labels;
+    for (auto e : nodes[id].inedges) labels.insert(edges[e].labels.begin(), edges[e].labels.end());
+    for (auto e : nodes[id].outedges) labels.insert(edges[e].labels.begin(), edges[e].labels.end());
+    return labels.size();
+  }
+  std::uint32_t BranchCompletion(std::uint32_t rank, std::vector<std::int64_t>* scores,
+                                 std::vector<std::int32_t>* predecessors) {
+    auto start = rank_to_node[rank];
+    for (auto e : nodes[start].outedges)
+      for (auto f : nodes[edges[e].head].inedges)
+        if (edges[f].tail != start) (*scores)[edges[f].tail] = -1;
+    std::int32_t max = -1;
+    for (std::uint32_t i = rank + 1; i < rank_to_node.size(); ++i) {
+      auto it = rank_to_node[i];
+      (*scores)[it] = -1;
+      (*predecessors)[it] = -1;
+      for (auto e : nodes[it].inedges) {
+        const auto& jt = edges[e];
+        if ((*scores)[jt.tail] == -1) continue;
+        if (((*scores)[it] < jt.weight) ||
+            ((*scores)[it] == jt.weight && (*scores)[(*predecessors)[it]] <= (*scores)[jt.tail])) {
+          (*scores)[it] = jt.weight;
+          (*predecessors)[it] = jt.tail;
+        }
+      }
+      if ((*predecessors)[it] != -1) (*scores)[it] += (*scores)[(*predecessors)[it]];
+      if (max == -1 || (*scores)[max] < (*scores)[it]) max = it;
+    }
+    return max;
+  }
+  void TraverseHeaviestBundle() {
+    consensus.clear();
+    if (rank_to_node.empty()) return;
+    std::vector<std::int32_t> predecessors(nodes.size(), -1);
+    std::vector<std::int64_t> scores(nodes.size(), -1);
+    std::int32_t max = -1;
+    for (auto it : rank_to_node) {
+      for (auto e : nodes[it].inedges) {
+        const auto& jt = edges[e];
+        if ((scores[it] < jt.weight) ||
+            (scores[it] == jt.weight && scores[predecessors[it]] <= scores[jt.tail])) {
+          scores[it] = jt.weight;
+          predecessors[it] = jt.tail;
+        }
+      }
+      if (predecessors[it] != -1) scores[it] += scores[predecessors[it]];
+      if (max == -1 || scores[max] < scores[it]) max = it;
+    }
+    if (!nodes[max].outedges.empty()) {
+      std::vector<std::uint32_t> node_id_to_rank(nodes.size(), 0);
+      for (std::uint32_t i = 0; i < rank_to_node.size(); ++i) node_id_to_rank[rank_to_node[i]] = i;
+      while (!nodes[max].outedges.empty()) max = BranchCompletion(node_id_to_rank[max], &scores, &predecessors);
+    }
+    while (predecessors[max] != -1) {
+      consensus.push_back(max);
+      max = predecessors[max];
+    }
+    consensus.push_back(max);
+    std::reverse(consensus.begin(), consensus.end());
+  }
+};
+
+// spoa SisdAlignmentEngine::Linear, AlignmentType::kNW
+static Alignment AlignNW(const std::uint8_t* seq, std::uint32_t len, const Graph& graph, std::int8_t m, std::int8_t n,
+                         std::int8_t g, std::int32_t* score_out = nullptr) {
+  if (graph.nodes.empty() || len == 0) return {};
+  const std::uint32_t w = len + 1;
+  const std::uint32_t rows = graph.rank_to_node.size() + 1;
+  const std::int32_t kNegInf = std::numeric_limits<std::int32_t>::min() + 1024;
+  std::vector<std::int32_t> H(static_cast<std::size_t>(rows) * w);
+  std::vector<std::uint32_t> node_id_to_rank(graph.nodes.size(), 0);
+  for (std::uint32_t i = 0; i < graph.rank_to_node.size(); ++i) node_id_to_rank[graph.rank_to_node[i]] = i;
+  for (std::uint32_t j = 0; j < w; ++j) H[j] = static_cast<std::int32_t>(j) * g;
+  for (std::uint32_t i = 1; i < rows; ++i) {
+    const auto& node = graph.nodes[graph.rank_to_node[i - 1]];
+    std::int32_t penalty = node.inedges.empty() ? 0 : kNegInf;
+    for (auto e : node.inedges) {
+      std::uint32_t pred_i = node_id_to_rank[graph.edges[e].tail] + 1;
+      penalty = std::max(penalty, H[static_cast<std::size_t>(pred_i) * w]);
+    }
+    H[static_cast<std::size_t>(i) * w] = penalty + g;
+  }
+  std::int32_t max_score = kNegInf;
+  std::uint32_t max_i = 0, max_j = 0;
+  for (std::uint32_t i = 1; i < rows; ++i) {
+    const auto& node = graph.nodes[graph.rank_to_node[i - 1]];
+    std::int32_t* H_row = &H[static_cast<std::size_t>(i) * w];
+    std::uint32_t pred_i = node.inedges.empty() ? 0 : node_id_to_rank[graph.edges[node.inedges[0]].tail] + 1;
+    const std::int32_t* H_pred = &H[static_cast<std::size_t>(pred_i) * w];
+    for (std::uint32_t j = 1; j < w; ++j) {
+      std::int32_t s = node.code == seq[j - 1] ? m : n;
+      H_row[j] = std::max(H_pred[j - 1] + s, H_pred[j] + g);
+    }
+    for (std::uint32_t p = 1; p < node.inedges.size(); ++p) {
+      pred_i = node_id_to_rank[graph.edges[node.inedges[p]].tail] + 1;
+      H_pred = &H[static_cast<std::size_t>(pred_i) * w];
+      for (std::uint32_t j = 1; j < w; ++j) {
+        std::int32_t s = node.code == seq[j - 1] ? m : n;
+        H_row[j] = std::max(H_pred[j - 1] + s, std::max(H_row[j], H_pred[j] + g));
+      }
+    }
+    for (std::uint32_t j = 1; j < w; ++j) H_row[j] = std::max(H_row[j - 1] + g, H_row[j]);
+    if (node.outedges.empty() && max_score < H_row[w - 1]) {
+      max_score = H_row[w - 1];
+      max_i = i;
+      max_j = w - 1;
+    }
+  }
+  if (score_out) *score_out = max_score;
+  Alignment alignment;
+  std::uint32_t i = max_i, j = max_j, prev_i = 0, prev_j = 0;
+  while (!(i == 0 && j == 0)) {
+    const std::int32_t H_ij = H[static_cast<std::size_t>(i) * w + j];
+    bool found = false;
+    if (i != 0 && j != 0) {
+      const auto& it = graph.nodes[graph.rank_to_node[i - 1]];
+      std::int32_t match_cost = it.code == seq[j - 1] ? m : n;
+      std::uint32_t pred_i = it.inedges.empty() ? 0 : node_id_to_rank[graph.edges[it.inedges[0]].tail] + 1;
+      if (H_ij == H[static_cast<std::size_t>(pred_i) * w + (j - 1)] + match_cost) {
+        prev_i = pred_i;
+        prev_j = j - 1;
+        found = true;
+      } else {
+        for (std::uint32_t p = 1; p < it.inedges.size(); ++p) {
+          pred_i = node_id_to_rank[graph.edges[it.inedges[p]].tail] + 1;
+          if (H_ij == H[static_cast<std::size_t>(pred_i) * w + (j - 1)] + match_cost) {
+            prev_i = pred_i;
+            prev_j = j - 1;
+            found = true;
+            break;
+          }
+        }
+      }
+    }
+    if (!found && i != 0) {
+      const auto& it = graph.nodes[graph.rank_to_node[i - 1]];
+      std::uint32_t pred_i = it.inedges.empty() ? 0 : node_id_to_rank[graph.edges[it.inedges[0]].tail] + 1;
+      if (H_ij == H[static_cast<std::size_t>(pred_i) * w + j] + g) {
+        prev_i = pred_i;
+        prev_j = j;
+        found = true;
+      } else {
+        for (std::uint32_t p = 1; p < it.inedges.size(); ++p) {
+          pred_i = node_id_to_rank[graph.edges[it.inedges[p]].tail] + 1;
+          if (H_ij == H[static_cast<std::size_t>(pred_i) * w + j] + g) {
+            prev_i = pred_i;
+            prev_j = j;
+            found = true;
+            break;
+          }
+        }
+      }
+    }
+    if (!found && j != 0 && H_ij == H[static_cast<std::size_t>(i) * w + j - 1] + g) {
+      prev_i = i;
+      prev_j = j - 1;
+      found = true;
+    }
+    if (!found) break;  // cannot happen for a consistent matrix
+    alignment.emplace_back(i == prev_i ? -1 : static_cast<std::int32_t>(graph.rank_to_node[i - 1]),
+                           j == prev_j ? -1 : static_cast<std::int32_t>(j - 1));
+    i = prev_i;
+    j = prev_j;
+  }
+  std::reverse(alignment.begin(), alignment.end());
+  return alignment;
+}
+
+struct Layer {
+  const std::uint8_t* codes;
+  const std::uint8_t* qual;  // Phred+33 characters or nullptr
+  std::uint32_t len, begin, end;
+};
+
+static std::vector<std::uint32_t> Weights(const Layer& l) {
+  std::vector<std::uint32_t> w(l.len, 1);
+  if (l.qual)
+    for (std::uint32_t i = 0; i < l.len; ++i) w[i] = static_cast<std::uint32_t>(l.qual[i]) - 33;
+  return w;
+}
+
+// racon Window::GenerateConsensus (TGS). layers[0] is the backbone. Returns polished flag.
+static bool WindowConsensus(const std::vector<Layer>& layers, std::int8_t m, std::int8_t n, std::int8_t g, bool trim,
+                            std::vector<std::uint8_t>* consensus, std::vector<std::uint32_t>* coverages_out) {
+  const Layer& bb = layers.front();
+  if (layers.size() < 3) {
+    consensus->assign(bb.codes, bb.codes + bb.len);
+    return false;
+  }
+  Graph graph;
+  graph.AddAlignment(Alignment(), bb.codes, bb.len, Weights(bb));
+  std::vector<std::uint32_t> rank(layers.size());
+  for (std::uint32_t i = 0; i < layers.size(); ++i) rank[i] = i;
+  std::stable_sort(rank.begin() + 1, rank.end(),
+                   [&](std::uint32_t lhs, std::uint32_t rhs) { return layers[lhs].begin < layers[rhs].begin; });
+  std::uint32_t offset = 0.01 * bb.len;
+  for (std::uint32_t j = 1; j < layers.size(); ++j) {
+    const Layer& l = layers[rank[j]];
+    Alignment alignment;
+    if (l.begin < offset && l.end > bb.len - offset) {
+      alignment = AlignNW(l.codes, l.len, graph, m, n, g);
+    } else {
+      std::vector<std::uint32_t> mapping;
+      auto subgraph = graph.Subgraph(l.begin, l.end, &mapping);
+      alignment = AlignNW(l.codes, l.len, subgraph, m, n, g);
+      for (auto& it : alignment)
+        if (it.first != -1) it.first = mapping[it.first];
+    }
+    graph.AddAlignment(alignment, l.codes, l.len, Weights(l));
+  }
+  graph.TraverseHeaviestBundle();
+  std::vector<std::uint32_t> coverages;
+  consensus->clear();
+  for (auto id : graph.consensus) {
+    consensus->push_back(graph.nodes[id].code);
+    std::uint32_t c = graph.Coverage(id);
+    for (auto jt : graph.nodes[id].aligned) c += graph.Coverage(jt);
+    coverages.push_back(c);
+  }
+  if (trim) {
+    std::uint32_t average_coverage = (layers.size() - 1) / 2;
+    std::int32_t begin = 0, end = static_cast<std::int32_t>(consensus->size()) - 1;
+    for (; begin < static_cast<std::int32_t>(consensus->size()); ++begin)
+      if (coverages[begin] >= average_coverage) break;
+    for (; end >= 0; --end)
+      if (coverages[end] >= average_coverage) break;
+    if (begin < end) {  // else: racon warns "might be chimeric" and keeps the untrimmed consensus
+      consensus->assign(consensus->begin() + begin, consensus->begin() + end + 1);
+      coverages.assign(coverages.begin() + begin, coverages.begin() + end + 1);
+    }
+  }
+  if (coverages_out) *coverages_out = coverages;
+  return true;
+}
+
+}  // namespace poa
+
+extern "C" {
+
+// One window. Layers are concatenated: codes (0..3) [total], optional quals (Phred+33) [total] or NULL,
+// offsets[n_layers+1], begins/ends[n_layers] (layer 0 = backbone; its begin/end are ignored).
+// Returns 1 if polished (>= 3 sequences), 0 if the backbone was returned unchanged.
+int orc_poa_window(const std::uint8_t* codes, const std::uint8_t* quals, const std::uint64_t* offsets,
+                   const std::uint32_t* begins, const std::uint32_t* ends, std::uint32_t n_layers, int m, int n, int g,
+                   int trim, std::uint8_t* out, std::uint32_t out_cap, std::uint32_t* out_len) {
+  std::vector<poa::Layer> layers(n_layers);
+  for (std::uint32_t i = 0; i < n_layers; ++i) {
+    layers[i].codes = codes + offsets[i];
+    layers[i].qual = quals ? quals + offsets[i] : nullptr;
+    layers[i].len = static_cast<std::uint32_t>(offsets[i + 1] - offsets[i]);
+    layers[i].begin = begins[i];
+    layers[i].end = ends[i];
+  }
+  // racon Window::AddLayer rejects begin >= end and positions beyond the backbone
+  for (std::uint32_t i = 1; i < n_layers; ++i)
+    if (layers[i].len && (begins[i] >= ends[i] || ends[i] >= layers[0].len)) return -1;
+  std::vector<std::uint8_t> cons;
+  bool polished = poa::WindowConsensus(layers, m, n, g, trim != 0, &cons, nullptr);
+  *out_len = cons.size();
+  std::memcpy(out, cons.data(), std::min<std::size_t>(cons.size(), out_cap));
+  return polished ? 1 : 0;
+}
+
+// NW score of a sequence against the LINEAR graph of another sequence (unit-test hook for AlignNW).
+int orc_poa_align_score_linear(const std::uint8_t* target, std::uint32_t tlen, const std::uint8_t* query,
+                               std::uint32_t qlen, int m, int n, int g) {
+  poa::Graph graph;
+  std::vector<std::uint32_t> w(tlen, 1);
+  graph.AddAlignment(poa::Alignment(), target, tlen, w);
+  std::int32_t score = 0;
+  poa::AlignNW(query, qlen, graph, m, n, g, &score);
+  return score;
+}
+
+}  // extern "C"
