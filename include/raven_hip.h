@@ -104,6 +104,25 @@ typedef struct rvn_ed_pair {
 int rvn_edit_distance_batch(rvn_engine* e, const rvn_reads* r, const rvn_ed_pair* pairs, uint32_t n_pairs,
                             uint32_t* distances, double* device_ms, uint64_t* cells);
 
+/* Batched racon Window::GenerateConsensus (the POA consensus behind racon::Polisher::Polish,
+ * RavenLib/src/polish.cc:43-51; scores = AlignCfg of polish.hpp:13-17): for every window, layer 0 is the
+ * backbone, the others are the read pieces aligned to it.
+ *   codes            base codes 0..3 of all layers of all windows, concatenated
+ *   quals            Phred+33 characters parallel to codes, or NULL; has_qual[layer] selects per layer
+ *                    (racon gives a backbone without quality a dummy '!' string, i.e. weight 0)
+ *   layer_offsets    [n_layers+1] into codes;  begins/ends [n_layers]: first/last covered backbone position
+ *   window_offsets   [n_windows+1] into the layer tables
+ *   consensus        output codes, window w at consensus_offsets[w] (capacity = next offset - this one)
+ *   status           0: fewer than 3 sequences, backbone returned (racon: unpolished)   1: polished
+ *                    2: window exceeds the device limits (nodes / layer length / in-degree), backbone returned
+ * Results agree with the CPU path within edit-distance tolerance (ties between equal-score paths may resolve
+ * differently). */
+int rvn_poa_consensus_batch(rvn_engine* e, const uint8_t* codes, const uint8_t* quals, const uint64_t* layer_offsets,
+                            const uint32_t* begins, const uint32_t* ends, const uint32_t* has_qual,
+                            const uint32_t* window_offsets, uint32_t n_windows, int match, int mismatch, int gap,
+                            int trim, uint8_t* consensus, const uint64_t* consensus_offsets, uint32_t* consensus_len,
+                            uint32_t* status, double* device_ms);
+
 /* ---- introspection used by the parity tests and bench.py ------------------------------------- */
 /* sketch of reads [first,last) == ram Minimize(sequence, minhash) per read; values widened to u64 */
 int rvn_engine_sketch(rvn_engine* e, const rvn_reads* r, uint32_t first, uint32_t last, int minhash,

@@ -16,6 +16,7 @@ using u16 = std::uint16_t;
 using u32 = std::uint32_t;
 using u64 = std::uint64_t;
 using i32 = std::int32_t;
+using i16 = std::int16_t;
 
 struct HipError : std::runtime_error {
   using std::runtime_error::runtime_error;
@@ -68,7 +69,7 @@ enum KernelSite {
   kKSketchCount, kKSketchWrite, kKMinhashSelect, kKCompactSketch, kKScan, kKRsBits, kKRsUpsweep, kKRsDownsweep,
   kKHeads, kKUnique, kKTable, kKOccHist, kKMatchCount, kKMatchEmit, kKSegSortGroup, kKIntervals,
   kKIntervalsGather, kKSegSortPos, kKChain, kKCompactOverlaps, kKPileKeys, kKPileCounts, kKPileBuild,
-  kKAddLayers, kKTruncateSort, kKKeptWrite, kKGather, kKPileSortUp, kKPileSortDown, kKChainSmall, kKJoinCount, kKJoinEmit, kKEditBanded, kKEditFull, kKNumSites
+  kKAddLayers, kKTruncateSort, kKKeptWrite, kKGather, kKPileSortUp, kKPileSortDown, kKChainSmall, kKJoinCount, kKJoinEmit, kKEditBanded, kKEditFull, kKPoa, kKNumSites
 };
 extern const char* const kKernelSiteNames[kKNumSites];
 

@@ -97,6 +97,7 @@ struct Engine {
   DevBuf m_grp[2], m_pos[2];
   DevBuf seg_off, iv_slot_begin, iv_slot_end, iv_cnt, iv_off, iv_begin, iv_end;
   DevBuf lis_min, lis_pred, lis_tail, lis_mask, ovl_slots, ovl_flags, ovl_scan;
+  DevBuf poa_scratch;
   StageTimes times;
   KernelTimers ktimers;
   // counters for algorithmic bytes
@@ -150,6 +151,12 @@ void map_batch(Engine& e, const ReadsDev& r, u32 first, u32 last, bool avoid_equ
 // Batched exact edit distance (edit_distance.hip). h_pairs: n_pairs x {a_idx,a_begin,a_len,b_idx,b_begin,b_len,strand,0}
 void edit_distance_batch(Engine& e, const ReadsDev& r, const u32* h_pairs, u32 n_pairs, u32* h_out, double* kernel_ms,
                          u64* cells);
+
+// Batched POA window consensus (poa.hip); all arrays are host pointers, see rvn_poa_consensus_batch
+void poa_consensus_batch(Engine& e, const u8* h_codes, const u8* h_quals, const u64* h_layer_off, const u32* h_begins,
+                         const u32* h_ends, const u32* h_has_qual, const u32* h_win_off, u32 n_windows, int m, int n,
+                         int g, int trim, u8* h_out, const u64* h_out_off, u32* h_out_len, u32* h_status,
+                         double* device_ms);
 
 // Pass-1 state: per-pile kept overlaps + coverage (pile.hip)
 struct PileState {

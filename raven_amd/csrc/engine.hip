@@ -436,6 +436,31 @@ int rvn_edit_distance_batch(rvn_engine* h, const rvn_reads* r, const rvn_ed_pair
   });
 }
 
+int rvn_poa_consensus_batch(rvn_engine* h, const uint8_t* codes, const uint8_t* quals, const uint64_t* layer_offsets,
+                            const uint32_t* begins, const uint32_t* ends, const uint32_t* has_qual,
+                            const uint32_t* window_offsets, uint32_t n_windows, int match, int mismatch, int gap,
+                            int trim, uint8_t* consensus, const uint64_t* consensus_offsets, uint32_t* consensus_len,
+                            uint32_t* status, double* device_ms) {
+  return guarded([&]() -> int {
+    if (!h || (n_windows && (!codes || !layer_offsets || !begins || !ends || !window_offsets || !consensus ||
+                             !consensus_offsets || !consensus_len || !status)))
+      return fail(RVN_EINVAL, "[raven_hip] NULL argument");
+    for (uint32_t w = 0; w < n_windows; ++w) {
+      const uint32_t f = window_offsets[w], l = window_offsets[w + 1];
+      if (l <= f) return fail(RVN_EINVAL, "[raven_hip] rvn_poa_consensus_batch: window without a backbone");
+      const uint64_t blen = layer_offsets[f + 1] - layer_offsets[f];
+      for (uint32_t i = f + 1; i < l; ++i)  // racon Window::AddLayer checks
+        if (layer_offsets[i + 1] > layer_offsets[i] && (begins[i] >= ends[i] || ends[i] >= blen))
+          return fail(RVN_EINVAL, "[racon::Window::AddLayer] error: layer begin and end positions are invalid!");
+    }
+    RVN_HIP(hipSetDevice(h->e.device));
+    UseTimers ut(h->e);
+    poa_consensus_batch(h->e, codes, quals, layer_offsets, begins, ends, has_qual, window_offsets, n_windows, match,
+                        mismatch, gap, trim, consensus, consensus_offsets, consensus_len, status, device_ms);
+    return RVN_OK;
+  });
+}
+
 int rvn_engine_sketch(rvn_engine* h, const rvn_reads* r, uint32_t first, uint32_t last, int minhash, uint64_t* count) {
   return guarded([&]() -> int {
     if (!h || !r || first > last || last > r->r.n) return fail(RVN_EINVAL, "[raven_hip] rvn_engine_sketch: bad range");

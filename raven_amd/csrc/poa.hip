@@ -1,0 +1,706 @@
+// poa.hip — batched partial-order-alignment window consensus on the device (the kernel behind the racon
+// polishing rounds that raven::Polish drives, RavenLib/src/polish.cc:43-51; racon Window::GenerateConsensus
+// over spoa: graph + linear-gap NW (m,n,g of polish.hpp:13-17) + heaviest bundle + TGS trim).
+//
+// One WAVE per window, persistent over windows (slot = wave): the graph lives in a per-slot global scratch
+// (SoA: code, in-edge lists with weights, aligned groups, visit counts, topological order), the current layer
+// (bases + weights) in LDS.  Per layer:
+//   1. (partial layers only) spoa's Subgraph = ancestors of backbone node `end` with id >= begin (lane-0 DFS);
+//   2. NW over the nodes in topological order: one DP row per node, 64 columns per step; diagonal/vertical
+//      terms from every predecessor row, the horizontal gap chain as a wave prefix-max of (H - j*g);
+//      int16 scores in an (N+1) x (L+1) matrix in HBM;
+//   3. traceback with spoa's move priority (diagonal over in-edges in insertion order, vertical, horizontal);
+//   4. spoa Graph::AddAlignment (lane 0), new nodes created in path order;
+//   5. the topological order is maintained incrementally instead of re-sorted: a new node goes right after the
+//      last old node of its path (new rank of old r = r + #new nodes anchored before it; of the t-th new node =
+//      anchor slot + t) — any valid order gives the same DP matrix; only equal-score ties can resolve differently
+//      from spoa's DFS order, which is why consensus parity is tolerance-based.
+// Integer VALU + L2 bound; no MFMA.
+#include <algorithm>
+#include <vector>
+
+#include "engine.h"
+#include "wave.h"
+
+namespace rvn {
+
+namespace {
+
+constexpr int kPoaMaxIn = 12;     // in-edges per node kept (overflow -> window reported as failed)
+constexpr int kPoaMaxSeq = 1024;  // longest layer (bases)
+constexpr i32 kNegInf16 = -30000;
+
+struct PoaWindow {  // host-prepared, one per window
+  u32 layer_first, n_layers;  // range in the (begin-sorted) layer table; layer_first = backbone
+  u32 out_off, out_cap;
+};
+struct PoaLayer {
+  u64 code_off;
+  u32 len, begin, end, has_qual;
+};
+
+struct PoaSlot {
+  i16* H;
+  u8* code;
+  u8* in_cnt;
+  u16* in_tail;
+  i32* in_w;
+  u16* out_cnt;
+  u8* al_cnt;
+  u16* al;
+  u16* visits;
+  u16* rank_of;
+  u16* order;
+  u16* order2;
+  u8* mark;
+  u16* sub_out;
+  i32* aln_node;
+  i32* aln_pos;
+  u16* new_slot;
+  i32* scores;
+  i32* preds;
+  u16* stack;
+};
+
+__host__ __device__ inline size_t poa_slot_bytes(u32 nmax, u32 lmax) {
+  size_t b = 0;
+  auto add = [&](size_t x) { b += (x + 255) & ~size_t(255); };
+  add(static_cast<size_t>(nmax + 1) * (lmax + 1) * 2);  // H
+  add(nmax);                                            // code
+  add(nmax);                                            // in_cnt
+  add(static_cast<size_t>(nmax) * kPoaMaxIn * 2);       // in_tail
+  add(static_cast<size_t>(nmax) * kPoaMaxIn * 4);       // in_w
+  add(nmax * 2);                                        // out_cnt
+  add(nmax);                                            // al_cnt
+  add(nmax * 4 * 2);                                    // al
+  add(nmax * 2);                                        // visits
+  add(nmax * 2);                                        // rank_of
+  add(nmax * 2);                                        // order
+  add(nmax * 2);                                        // order2
+  add(nmax);                                            // mark
+  add(nmax * 2);                                        // sub_out
+  add(static_cast<size_t>(nmax + lmax + 2) * 4);        // aln_node
+  add(static_cast<size_t>(nmax + lmax + 2) * 4);        // aln_pos
+  add(static_cast<size_t>(lmax + 2) * 2);               // new_slot
+  add(nmax * 4);                                        // scores
+  add(nmax * 4);                                        // preds
+  add(nmax * 2);                                        // stack
+  return b;
+}
+
+__device__ inline PoaSlot poa_carve(unsigned char* base, u32 nmax, u32 lmax) {
+  PoaSlot s;
+  size_t o = 0;
+  auto take = [&](size_t x) {
+    unsigned char* p = base + o;
+    o += (x + 255) & ~size_t(255);
+    return p;
+  };
+  s.H = reinterpret_cast<i16*>(take(static_cast<size_t>(nmax + 1) * (lmax + 1) * 2));
+  s.code = take(nmax);
+  s.in_cnt = take(nmax);
+  s.in_tail = reinterpret_cast<u16*>(take(static_cast<size_t>(nmax) * kPoaMaxIn * 2));
+  s.in_w = reinterpret_cast<i32*>(take(static_cast<size_t>(nmax) * kPoaMaxIn * 4));
+  s.out_cnt = reinterpret_cast<u16*>(take(nmax * 2));
+  s.al_cnt = take(nmax);
+  s.al = reinterpret_cast<u16*>(take(nmax * 4 * 2));
+  s.visits = reinterpret_cast<u16*>(take(nmax * 2));
+  s.rank_of = reinterpret_cast<u16*>(take(nmax * 2));
+  s.order = reinterpret_cast<u16*>(take(nmax * 2));
+  s.order2 = reinterpret_cast<u16*>(take(nmax * 2));
+  s.mark = take(nmax);
+  s.sub_out = reinterpret_cast<u16*>(take(nmax * 2));
+  s.aln_node = reinterpret_cast<i32*>(take(static_cast<size_t>(nmax + lmax + 2) * 4));
+  s.aln_pos = reinterpret_cast<i32*>(take(static_cast<size_t>(nmax + lmax + 2) * 4));
+  s.new_slot = reinterpret_cast<u16*>(take(static_cast<size_t>(lmax + 2) * 2));
+  s.scores = reinterpret_cast<i32*>(take(nmax * 4));
+  s.preds = reinterpret_cast<i32*>(take(nmax * 4));
+  s.stack = reinterpret_cast<u16*>(take(nmax * 2));
+  return s;
+}
+
+__device__ __forceinline__ void wsync() {
+  __threadfence_block();
+  __builtin_amdgcn_wave_barrier();
+}
+
+// spoa Graph::AddEdge on the SoA graph (lane 0). Returns false on in-degree overflow.
+__device__ inline bool poa_add_edge(PoaSlot& g, u32 tail, u32 head, i32 weight) {
+  const u32 c = g.in_cnt[head];
+  for (u32 i = 0; i < c; ++i) {
+    if (g.in_tail[head * kPoaMaxIn + i] == tail) {
+      g.in_w[head * kPoaMaxIn + i] += weight;
+      return true;
+    }
+  }
+  if (c >= kPoaMaxIn) return false;
+  g.in_tail[head * kPoaMaxIn + c] = static_cast<u16>(tail);
+  g.in_w[head * kPoaMaxIn + c] = weight;
+  g.in_cnt[head] = static_cast<u8>(c + 1);
+  g.out_cnt[tail] += 1;
+  return true;
+}
+
+__device__ inline u32 poa_add_node(PoaSlot& g, u32& n_nodes, u32 code) {
+  const u32 id = n_nodes++;
+  g.code[id] = static_cast<u8>(code);
+  g.in_cnt[id] = 0;
+  g.out_cnt[id] = 0;
+  g.al_cnt[id] = 0;
+  g.visits[id] = 0;
+  return id;
+}
+
+// One window. Returns status: 0 = backbone returned (< 3 sequences), 1 = polished, 2 = limits exceeded.
+__device__ u32 poa_window(const PoaWindow& win, const PoaLayer* __restrict__ layers, const u8* __restrict__ codes,
+                          const u8* __restrict__ quals, PoaSlot& g, u32 nmax, u32 lmax, int m, int n_, int gp, int trim,
+                          u8* s_seq, u8* s_w, u8* __restrict__ out, u32* out_len) {
+  const int lane = lane_id();
+  const PoaLayer bb = layers[win.layer_first];
+  const u32 blen = bb.len;
+  auto copy_backbone = [&]() {
+    const u32 n = blen < win.out_cap ? blen : win.out_cap;
+    for (u32 i = lane; i < n; i += 64) out[i] = codes[bb.code_off + i];
+    if (lane == 0) *out_len = n;
+  };
+  if (win.n_layers < 3) {
+    copy_backbone();
+    return 0;
+  }
+  if (blen == 0 || blen > nmax || blen > lmax) {
+    copy_backbone();
+    return 2;
+  }
+  // ---- backbone graph (spoa AddAlignment with an empty alignment) ----
+  u32 n_nodes = blen;
+  for (u32 i = lane; i < blen; i += 64) {
+    g.code[i] = codes[bb.code_off + i];
+    g.al_cnt[i] = 0;
+    g.visits[i] = blen >= 2 ? 1 : 0;
+    g.rank_of[i] = static_cast<u16>(i);
+    g.order[i] = static_cast<u16>(i);
+    const i32 wi = bb.has_qual ? static_cast<i32>(quals[bb.code_off + i]) - 33 : 1;
+    if (i > 0) {
+      const i32 wp = bb.has_qual ? static_cast<i32>(quals[bb.code_off + i - 1]) - 33 : 1;
+      g.in_cnt[i] = 1;
+      g.in_tail[i * kPoaMaxIn] = static_cast<u16>(i - 1);
+      g.in_w[i * kPoaMaxIn] = wp + wi;
+    } else {
+      g.in_cnt[i] = 0;
+    }
+    g.out_cnt[i] = i + 1 < blen ? 1 : 0;
+  }
+  wsync();
+  const u32 offset = static_cast<u32>(0.01 * blen);
+  bool failed = false;
+
+  for (u32 li = 1; li < win.n_layers && !failed; ++li) {
+    const PoaLayer L = layers[win.layer_first + li];
+    const u32 len = L.len;
+    if (len == 0) continue;
+    if (len > lmax || len > kPoaMaxSeq) {
+      failed = true;
+      break;
+    }
+    for (u32 i = lane; i < len; i += 64) {
+      s_seq[i] = codes[L.code_off + i];
+      s_w[i] = L.has_qual ? static_cast<u8>(quals[L.code_off + i] - 33) : 1;
+    }
+    const bool full = L.begin < offset && L.end > blen - offset;
+    // ---- 1. subgraph marks ----
+    if (!full) {
+      for (u32 i = lane; i < n_nodes; i += 64) {
+        g.mark[i] = 0;
+        g.sub_out[i] = 0;
+      }
+      wsync();
+      if (lane == 0) {
+        u32 sp = 0;
+        g.stack[sp++] = static_cast<u16>(L.end);
+        while (sp) {
+          const u32 curr = g.stack[--sp];
+          if (!g.mark[curr] && curr >= L.begin) {
+            const u32 c = g.in_cnt[curr];
+            for (u32 k = 0; k < c && sp < nmax; ++k) g.stack[sp++] = g.in_tail[curr * kPoaMaxIn + k];
+            const u32 a = g.al_cnt[curr];
+            for (u32 k = 0; k < a && sp < nmax; ++k) g.stack[sp++] = g.al[curr * 4 + k];
+            g.mark[curr] = 1;
+          }
+        }
+      }
+      wsync();
+      // out-degree inside the subgraph
+      for (u32 v = lane; v < n_nodes; v += 64) {
+        if (!g.mark[v]) continue;
+        const u32 c = g.in_cnt[v];
+        for (u32 k = 0; k < c; ++k) {
+          const u32 t = g.in_tail[v * kPoaMaxIn + k];
+          if (g.mark[t]) atomicAdd(reinterpret_cast<unsigned int*>(g.sub_out) + (t >> 1), (t & 1) ? 0x10000u : 1u);
+        }
+      }
+      wsync();
+    }
+    // ---- 2. NW matrix ----
+    const u32 w = len + 1;
+    for (u32 j = lane; j < w; j += 64) g.H[j] = static_cast<i16>(static_cast<i32>(j) * gp);
+    wsync();
+    i32 best_score = -0x7FFFFFFF;
+    u32 best_row = 0;
+    for (u32 r = 0; r < n_nodes; ++r) {
+      const u32 v = g.order[r];
+      if (!full && !g.mark[v]) continue;
+      const u32 row = r + 1;
+      // predecessor rows (in-edges whose tail is inside the subgraph), in insertion order
+      u32 prow[kPoaMaxIn];
+      u32 np = 0;
+      {
+        const u32 c = g.in_cnt[v];
+        for (u32 k = 0; k < c; ++k) {
+          const u32 t = g.in_tail[v * kPoaMaxIn + k];
+          if (full || g.mark[t]) prow[np++] = static_cast<u32>(g.rank_of[t]) + 1;
+        }
+      }
+      const bool no_pred = np == 0;
+      if (no_pred) {
+        prow[0] = 0;
+        np = 1;
+      }
+      const u32 vc = g.code[v];
+      i16* Hr = g.H + static_cast<size_t>(row) * w;
+      i32 carry_h = 0;  // H[row][c0 - 1] of the previous chunk
+      for (u32 c0 = 0; c0 < w; c0 += 64) {
+        const u32 j = c0 + lane;
+        const bool valid = j < w;
+        i32 best = -0x3FFFFFFF;
+        i32 col0 = -0x3FFFFFFF;
+        for (u32 k = 0; k < np; ++k) {
+          const i16* Hp = g.H + static_cast<size_t>(prow[k]) * w;
+          const i32 up = valid ? static_cast<i32>(Hp[j]) : kNegInf16;
+          i32 diag = __shfl_up(up, 1, 64);
+          if (lane == 0) diag = c0 ? static_cast<i32>(Hp[c0 - 1]) : kNegInf16;
+          if (j >= 1 && valid) {
+            const i32 s = (vc == s_seq[j - 1]) ? m : n_;
+            const i32 a = diag + s, b = up + gp;
+            const i32 x = a > b ? a : b;
+            best = x > best ? x : best;
+          }
+          col0 = up > col0 ? up : col0;
+        }
+        if (j == 0) best = (no_pred ? 0 : col0) + gp;
+        // horizontal chain: H[j] = max_k<=j (best[k] + (j-k) g)  ->  prefix max of (best - j g)
+        i32 x = valid ? best - static_cast<i32>(j) * gp : -0x3FFFFFFF;
+        x = wave_inclusive_max(x);
+        i32 h = x + static_cast<i32>(j) * gp;
+        if (c0) {
+          const i32 viac = carry_h + static_cast<i32>(lane + 1) * gp;
+          h = viac > h ? viac : h;
+        }
+        if (valid) Hr[j] = static_cast<i16>(h < kNegInf16 ? kNegInf16 : h);
+        carry_h = __shfl(h, 63, 64);
+      }
+      wsync();
+      const u32 outc = full ? g.out_cnt[v] : g.sub_out[v];
+      if (outc == 0) {
+        const i32 sc = Hr[w - 1];
+        if (sc > best_score) {
+          best_score = sc;
+          best_row = row;
+        }
+      }
+    }
+    if (best_row == 0) {  // no end node inside the subgraph (cannot happen for a valid layer)
+      failed = true;
+      break;
+    }
+    // ---- 3. traceback (lane 0), pairs stored end -> start ----
+    u32 n_aln = 0;
+    if (lane == 0) {
+      u32 i = best_row, j = w - 1;
+      while (!(i == 0 && j == 0) && n_aln < nmax + lmax) {
+        const i32 Hij = g.H[static_cast<size_t>(i) * w + j];
+        bool found = false;
+        u32 pi = 0, pj = 0;
+        u32 v = 0, c = 0;
+        if (i != 0) {
+          v = g.order[i - 1];
+          c = g.in_cnt[v];
+        }
+        if (i != 0 && j != 0) {
+          const i32 mc = (g.code[v] == s_seq[j - 1]) ? m : n_;
+          bool any = false;
+          for (u32 k = 0; k < c && !found; ++k) {
+            const u32 t = g.in_tail[v * kPoaMaxIn + k];
+            if (!(full || g.mark[t])) continue;
+            any = true;
+            const u32 pr = static_cast<u32>(g.rank_of[t]) + 1;
+            if (Hij == g.H[static_cast<size_t>(pr) * w + j - 1] + mc) {
+              pi = pr;
+              pj = j - 1;
+              found = true;
+            }
+          }
+          if (!any && Hij == g.H[j - 1] + mc) {
+            pi = 0;
+            pj = j - 1;
+            found = true;
+          }
+        }
+        if (!found && i != 0) {
+          bool any = false;
+          for (u32 k = 0; k < c && !found; ++k) {
+            const u32 t = g.in_tail[v * kPoaMaxIn + k];
+            if (!(full || g.mark[t])) continue;
+            any = true;
+            const u32 pr = static_cast<u32>(g.rank_of[t]) + 1;
+            if (Hij == g.H[static_cast<size_t>(pr) * w + j] + gp) {
+              pi = pr;
+              pj = j;
+              found = true;
+            }
+          }
+          if (!any && Hij == g.H[j] + gp) {
+            pi = 0;
+            pj = j;
+            found = true;
+          }
+        }
+        if (!found && j != 0 && Hij == g.H[static_cast<size_t>(i) * w + j - 1] + gp) {
+          pi = i;
+          pj = j - 1;
+          found = true;
+        }
+        if (!found) {
+          n_aln = 0xFFFFFFFFu;
+          break;
+        }
+        g.aln_node[n_aln] = (i == pi) ? -1 : static_cast<i32>(g.order[i - 1]);
+        g.aln_pos[n_aln] = (j == pj) ? -1 : static_cast<i32>(j - 1);
+        ++n_aln;
+        i = pi;
+        j = pj;
+      }
+    }
+    n_aln = __shfl(n_aln, 0, 64);
+    if (n_aln == 0xFFFFFFFFu || n_aln == 0) {
+      failed = true;
+      break;
+    }
+    // ---- 4. spoa AddAlignment (lane 0); new nodes in path order, each with its order slot ----
+    const u32 n_old = n_nodes;
+    u32 n_new = 0;
+    u32 ok = 1;
+    if (lane == 0) {
+      // first / last aligned sequence positions
+      i32 first_pos = -1, last_pos = -1;
+      for (u32 a = n_aln; a-- > 0;) {
+        if (g.aln_pos[a] != -1) {
+          if (first_pos < 0) first_pos = g.aln_pos[a];
+          last_pos = g.aln_pos[a];
+        }
+      }
+      // slot of the unaligned prefix: right before the first old node on the path
+      u32 first_old_rank = n_old;
+      for (u32 a = n_aln; a-- > 0;) {
+        if (g.aln_node[a] != -1 && g.aln_pos[a] != -1) {
+          first_old_rank = g.rank_of[g.aln_node[a]];
+          break;
+        }
+      }
+      i32 prev = -1;
+      u32 cur_slot = first_old_rank;  // new nodes go right before old rank `cur_slot`
+      auto new_node = [&](u32 code) -> i32 {
+        if (n_nodes >= nmax || n_new >= lmax) {
+          ok = 0;
+          return -1;
+        }
+        const u32 id = poa_add_node(g, n_nodes, code);
+        g.new_slot[n_new++] = static_cast<u16>(cur_slot);
+        return static_cast<i32>(id);
+      };
+      auto visit = [&](i32 node) { g.visits[node] += 1; };
+      // unaligned prefix [0, first_pos)
+      for (i32 p = 0; p < first_pos && ok; ++p) {
+        const i32 curr = new_node(s_seq[p]);
+        if (curr < 0) break;
+        if (prev >= 0) ok &= poa_add_edge(g, prev, curr, static_cast<i32>(s_w[p - 1]) + s_w[p]);
+        if (len >= 2) visit(curr);
+        prev = curr;
+      }
+      // aligned part
+      for (u32 a = n_aln; a-- > 0 && ok;) {
+        const i32 sp = g.aln_pos[a];
+        if (sp == -1) continue;
+        const u32 code = s_seq[sp];
+        const i32 an = g.aln_node[a];
+        i32 curr = -1;
+        if (an == -1) {
+          curr = new_node(code);
+        } else {
+          cur_slot = static_cast<u32>(g.rank_of[an]) + 1;  // later new nodes follow this old node
+          if (g.code[an] == code) {
+            curr = an;
+          } else {
+            const u32 ac = g.al_cnt[an];
+            for (u32 k = 0; k < ac; ++k) {
+              const u32 kt = g.al[an * 4 + k];
+              if (g.code[kt] == code) {
+                curr = static_cast<i32>(kt);
+                break;
+              }
+            }
+            if (curr < 0) {
+              curr = new_node(code);
+              if (curr >= 0) {
+                for (u32 k = 0; k < ac; ++k) {
+                  const u32 kt = g.al[an * 4 + k];
+                  if (g.al_cnt[kt] < 4) g.al[kt * 4 + g.al_cnt[kt]++] = static_cast<u16>(curr);
+                  if (g.al_cnt[curr] < 4) g.al[curr * 4 + g.al_cnt[curr]++] = static_cast<u16>(kt);
+                }
+                if (g.al_cnt[an] < 4) g.al[an * 4 + g.al_cnt[an]++] = static_cast<u16>(curr);
+                if (g.al_cnt[curr] < 4) g.al[curr * 4 + g.al_cnt[curr]++] = static_cast<u16>(an);
+              }
+            }
+          }
+        }
+        if (curr < 0) {
+          ok = 0;
+          break;
+        }
+        if (prev >= 0) ok &= poa_add_edge(g, prev, curr, static_cast<i32>(s_w[sp - 1]) + s_w[sp]);
+        if (len >= 2) visit(curr);
+        prev = curr;
+      }
+      // unaligned suffix (last_pos, len)
+      for (i32 p = last_pos + 1; p < static_cast<i32>(len) && ok; ++p) {
+        const i32 curr = new_node(s_seq[p]);
+        if (curr < 0) break;
+        if (prev >= 0) ok &= poa_add_edge(g, prev, curr, static_cast<i32>(s_w[p - 1]) + s_w[p]);
+        if (len >= 2) visit(curr);
+        prev = curr;
+      }
+    }
+    wsync();
+    ok = __shfl(ok, 0, 64);
+    n_nodes = __shfl(n_nodes, 0, 64);
+    n_new = __shfl(n_new, 0, 64);
+    if (!ok) {
+      failed = true;
+      break;
+    }
+    // ---- 5. order rebuild: old rank r -> r + #(new slots <= r); t-th new node -> slot_t + t ----
+    if (n_new) {
+      for (u32 r = lane; r < n_old; r += 64) {
+        u32 lo = 0, hi = n_new;  // upper_bound(new_slot, r)
+        while (lo < hi) {
+          const u32 mid = (lo + hi) >> 1;
+          if (g.new_slot[mid] <= r) lo = mid + 1;
+          else hi = mid;
+        }
+        g.order2[r + lo] = g.order[r];
+      }
+      for (u32 t = lane; t < n_new; t += 64) g.order2[static_cast<u32>(g.new_slot[t]) + t] = static_cast<u16>(n_old + t);
+      wsync();
+      for (u32 r = lane; r < n_nodes; r += 64) {
+        const u32 v = g.order2[r];
+        g.order[r] = static_cast<u16>(v);
+        g.rank_of[v] = static_cast<u16>(r);
+      }
+      wsync();
+    }
+  }
+  if (failed) {
+    copy_backbone();
+    return 2;
+  }
+  // ---- consensus: spoa TraverseHeaviestBundle + BranchCompletion (lane 0) ----
+  u32 cons_len = 0;
+  if (lane == 0) {
+    i32 maxn = -1;
+    for (u32 r = 0; r < n_nodes; ++r) {
+      const u32 it = g.order[r];
+      i32 sc = -1, pd = -1;
+      const u32 c = g.in_cnt[it];
+      for (u32 k = 0; k < c; ++k) {
+        const i32 wgt = g.in_w[it * kPoaMaxIn + k];
+        const i32 t = g.in_tail[it * kPoaMaxIn + k];
+        if (sc < wgt || (sc == wgt && g.scores[pd] <= g.scores[t])) {
+          sc = wgt;
+          pd = t;
+        }
+      }
+      if (pd != -1) sc += g.scores[pd];
+      g.scores[it] = sc;
+      g.preds[it] = pd;
+      if (maxn == -1 || g.scores[maxn] < sc) maxn = static_cast<i32>(it);
+    }
+    u32 guard = 0;
+    while (g.out_cnt[maxn] != 0 && guard++ < nmax) {
+      // BranchCompletion(rank of maxn)
+      const u32 start = static_cast<u32>(maxn);
+      const u32 rank = g.rank_of[start];
+      for (u32 r = 0; r < n_nodes; ++r) {  // heads of start's out-edges: other tails lose their score
+        const u32 hd = g.order[r];
+        const u32 c = g.in_cnt[hd];
+        bool from_start = false;
+        for (u32 k = 0; k < c; ++k) from_start |= g.in_tail[hd * kPoaMaxIn + k] == start;
+        if (!from_start) continue;
+        for (u32 k = 0; k < c; ++k) {
+          const u32 t = g.in_tail[hd * kPoaMaxIn + k];
+          if (t != start) g.scores[t] = -1;
+        }
+      }
+      i32 mx = -1;
+      for (u32 r = rank + 1; r < n_nodes; ++r) {
+        const u32 it = g.order[r];
+        i32 sc = -1, pd = -1;
+        const u32 c = g.in_cnt[it];
+        for (u32 k = 0; k < c; ++k) {
+          const i32 t = g.in_tail[it * kPoaMaxIn + k];
+          if (g.scores[t] == -1) continue;
+          const i32 wgt = g.in_w[it * kPoaMaxIn + k];
+          if (sc < wgt || (sc == wgt && g.scores[pd] <= g.scores[t])) {
+            sc = wgt;
+            pd = t;
+          }
+        }
+        if (pd != -1) sc += g.scores[pd];
+        g.scores[it] = sc;
+        g.preds[it] = pd;
+        if (mx == -1 || g.scores[mx] < sc) mx = static_cast<i32>(it);
+      }
+      if (mx == -1) break;
+      maxn = mx;
+    }
+    // traceback into stack (reverse), then forward with coverage + trim
+    u32 cl = 0;
+    i32 cur = maxn;
+    while (cur != -1 && cl < nmax) {
+      g.stack[cl++] = static_cast<u16>(cur);
+      cur = g.preds[cur];
+    }
+    // coverage of consensus node = visits of the node + its aligned nodes (spoa Node::Coverage summed, racon)
+    i32 begin = 0, end = static_cast<i32>(cl) - 1;
+    if (trim) {
+      const u32 avg = (win.n_layers - 1) / 2;
+      auto cov = [&](i32 pos) -> u32 {  // pos in forward consensus coordinates
+        const u32 v = g.stack[cl - 1 - pos];
+        u32 c = g.visits[v];
+        for (u32 k = 0; k < g.al_cnt[v]; ++k) c += g.visits[g.al[v * 4 + k]];
+        return c;
+      };
+      for (; begin < static_cast<i32>(cl); ++begin)
+        if (cov(begin) >= avg) break;
+      for (; end >= 0; --end)
+        if (cov(end) >= avg) break;
+      if (begin >= end) {  // racon: warning only, consensus kept untrimmed
+        begin = 0;
+        end = static_cast<i32>(cl) - 1;
+      }
+    }
+    for (i32 p = begin; p <= end && cons_len < win.out_cap; ++p) out[cons_len++] = g.code[g.stack[cl - 1 - p]];
+    *out_len = cons_len;
+  }
+  wsync();
+  return 1;
+}
+
+__global__ __launch_bounds__(256) void poa_kernel(const PoaWindow* __restrict__ windows, u32 n_windows,
+                                                 const PoaLayer* __restrict__ layers, const u8* __restrict__ codes,
+                                                 const u8* __restrict__ quals, unsigned char* __restrict__ scratch,
+                                                 size_t slot_bytes, u32 n_slots, u32 nmax, u32 lmax, int m, int n_,
+                                                 int gp, int trim, u8* __restrict__ out, u32* __restrict__ out_len,
+                                                 u32* __restrict__ status) {
+  __shared__ u8 s_seq[4][kPoaMaxSeq];
+  __shared__ u8 s_w[4][kPoaMaxSeq];
+  const u32 wv = threadIdx.x >> 6;
+  const u32 slot = blockIdx.x * 4 + wv;
+  if (slot >= n_slots) return;
+  PoaSlot g = poa_carve(scratch + static_cast<size_t>(slot) * slot_bytes, nmax, lmax);
+  for (u32 wi = slot; wi < n_windows; wi += n_slots) {
+    const PoaWindow win = windows[wi];
+    const u32 st = poa_window(win, layers, codes, quals, g, nmax, lmax, m, n_, gp, trim, s_seq[wv], s_w[wv],
+                              out + win.out_off, out_len + wi);
+    if (lane_id() == 0) status[wi] = st;
+    wsync();
+  }
+}
+
+}  // namespace
+
+// Host entry: see rvn_poa_consensus_batch in raven_hip.h
+void poa_consensus_batch(Engine& e, const u8* h_codes, const u8* h_quals, const u64* h_layer_off,
+                         const u32* h_begins, const u32* h_ends, const u32* h_has_qual, const u32* h_win_off,
+                         u32 n_windows, int m, int n, int g, int trim, u8* h_out, const u64* h_out_off,
+                         u32* h_out_len, u32* h_status, double* device_ms) {
+  if (n_windows == 0) return;
+  hipStream_t s = e.stream;
+  const u32 n_layers = h_win_off[n_windows];
+  const u64 total = h_layer_off[n_layers];
+  std::vector<PoaWindow> wins(n_windows);
+  std::vector<PoaLayer> lays(n_layers);
+  u32 max_bb = 1, max_len = 1, max_layers = 1;
+  for (u32 w = 0; w < n_windows; ++w) {
+    const u32 f = h_win_off[w], l = h_win_off[w + 1];
+    wins[w].layer_first = f;
+    wins[w].n_layers = l - f;
+    wins[w].out_off = static_cast<u32>(h_out_off[w]);
+    wins[w].out_cap = static_cast<u32>(h_out_off[w + 1] - h_out_off[w]);
+    // racon: rank = stable sort of layers 1.. by begin position
+    std::vector<u32> rank(l - f);
+    for (u32 i = 0; i < l - f; ++i) rank[i] = f + i;
+    if (l - f > 1)
+      std::stable_sort(rank.begin() + 1, rank.end(), [&](u32 a, u32 b) { return h_begins[a] < h_begins[b]; });
+    for (u32 i = 0; i < l - f; ++i) {
+      const u32 src = rank[i];
+      PoaLayer& L = lays[f + i];
+      L.code_off = h_layer_off[src];
+      L.len = static_cast<u32>(h_layer_off[src + 1] - h_layer_off[src]);
+      L.begin = h_begins[src];
+      L.end = h_ends[src];
+      L.has_qual = (h_quals && h_has_qual && h_has_qual[src]) ? 1 : 0;
+      if (i == 0) max_bb = std::max(max_bb, L.len);
+      max_len = std::max(max_len, L.len);
+    }
+    max_layers = std::max(max_layers, l - f);
+  }
+  // limits: nodes <= nmax, layer length <= lmax (windows beyond them come back with status 2)
+  const u32 lmax = std::min<u32>(kPoaMaxSeq, std::max<u32>(64, ((max_len + 63) / 64) * 64));
+  const u32 nmax = std::min<u32>(4096, std::max<u32>(256, max_bb * 4));
+  const size_t slot_bytes = poa_slot_bytes(nmax, lmax);
+  size_t free_b = 0, total_b = 0;
+  RVN_HIP(hipMemGetInfo(&free_b, &total_b));
+  u32 n_slots = std::min<u32>(n_windows, 256 * 16);
+  const size_t budget = free_b / 2;
+  if (static_cast<size_t>(n_slots) * slot_bytes > budget) n_slots = static_cast<u32>(std::max<size_t>(1, budget / slot_bytes));
+  n_slots = ((n_slots + 3) / 4) * 4;
+
+  u8* d_codes = e.tmp_a.get<u8>(total + 16);
+  u8* d_quals = h_quals ? e.tmp_b.get<u8>(total + 16) : nullptr;
+  PoaWindow* d_wins = e.tmp_c.get<PoaWindow>(n_windows + 1);
+  PoaLayer* d_lays = e.tmp_d.get<PoaLayer>(n_layers + 1);
+  const u64 out_total = h_out_off[n_windows];
+  u8* d_out = e.tmp_e.get<u8>(out_total + 16);
+  u32* d_len = e.tmp_f.get<u32>(2 * static_cast<size_t>(n_windows) + 2);
+  u32* d_status = d_len + n_windows + 1;
+  unsigned char* d_scratch = e.poa_scratch.get<unsigned char>(static_cast<size_t>(n_slots) * slot_bytes + 256);
+  RVN_HIP(hipMemcpyAsync(d_codes, h_codes, total, hipMemcpyHostToDevice, s));
+  if (d_quals) RVN_HIP(hipMemcpyAsync(d_quals, h_quals, total, hipMemcpyHostToDevice, s));
+  RVN_HIP(hipMemcpyAsync(d_wins, wins.data(), wins.size() * sizeof(PoaWindow), hipMemcpyHostToDevice, s));
+  RVN_HIP(hipMemcpyAsync(d_lays, lays.data(), lays.size() * sizeof(PoaLayer), hipMemcpyHostToDevice, s));
+  RVN_HIP(hipEventRecord(e.ev0, s));
+  RVN_KLAUNCH(kKPoa, poa_kernel<<<n_slots / 4, 256, 0, s>>>(d_wins, n_windows, d_lays, d_codes, d_quals, d_scratch,
+                                                             slot_bytes, n_slots, nmax, lmax, m, n, g, trim, d_out,
+                                                             d_len, d_status));
+  RVN_HIP(hipEventRecord(e.ev1, s));
+  RVN_HIP(hipMemcpyAsync(h_out, d_out, out_total, hipMemcpyDeviceToHost, s));
+  RVN_HIP(hipMemcpyAsync(h_out_len, d_len, static_cast<size_t>(n_windows) * 4, hipMemcpyDeviceToHost, s));
+  RVN_HIP(hipMemcpyAsync(h_status, d_status, static_cast<size_t>(n_windows) * 4, hipMemcpyDeviceToHost, s));
+  RVN_HIP(hipStreamSynchronize(s));
+  if (device_ms) {
+    float ms = 0;
+    RVN_HIP(hipEventElapsedTime(&ms, e.ev0, e.ev1));
+    *device_ms = ms;
+  }
+}
+
+}  // namespace rvn

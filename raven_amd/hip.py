@@ -33,7 +33,7 @@ SYMBOLS = [
     "rvn_engine_map_batch", "rvn_engine_map_fetch", "rvn_engine_map_fetch_filtered",
     "rvn_find_overlaps_and_create_piles", "rvn_pass1_pile_words", "rvn_pass1_num_overlaps",
     "rvn_pass1_fetch_piles", "rvn_pass1_fetch_overlaps", "rvn_pass1_destroy", "rvn_pile_add_layers",
-    "rvn_edit_distance_batch",
+    "rvn_edit_distance_batch", "rvn_poa_consensus_batch",
     "rvn_engine_sketch", "rvn_engine_sketch_fetch", "rvn_engine_index_size", "rvn_engine_index_fetch",
     "rvn_engine_counters", "rvn_engine_num_stages", "rvn_engine_stage_name", "rvn_engine_stage_ms",
     "rvn_engine_reset_stats", "rvn_engine_set_timing", "rvn_engine_set_kernel_timing",
@@ -84,6 +84,8 @@ def lib():
     L.rvn_pass1_destroy.argtypes = [vp]
     L.rvn_pile_add_layers.argtypes = [vp, vp, u32, u32, vp, u64]
     L.rvn_edit_distance_batch.argtypes = [vp, vp, vp, u32, vp, C.POINTER(dbl), C.POINTER(u64)]
+    L.rvn_poa_consensus_batch.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, u32, i32, i32, i32, i32, vp, vp, vp, vp,
+                                          C.POINTER(dbl)]
     L.rvn_engine_sketch.argtypes = [vp, vp, u32, u32, i32, C.POINTER(u64)]
     L.rvn_engine_sketch_fetch.argtypes = [vp, vp, vp, vp]
     L.rvn_engine_index_size.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
@@ -257,6 +259,50 @@ class Engine:
         _check(lib().rvn_edit_distance_batch(self._h, reads._h, _p(pairs), pairs.shape[0], _p(out), C.byref(ms),
                                              C.byref(cells)))
         return out, ms.value, cells.value
+
+    # -- racon Window::GenerateConsensus, batched --------------------------------------------------
+    def poa_consensus_batch(self, windows, m=3, n=-5, g=-4, trim=True):
+        """windows: list of dicts {layers: [uint8 code arrays, layer 0 = backbone], begins, ends, quals (list of
+        uint8 Phred+33 arrays or None entries) or None}.  Returns (list of consensus code arrays, status array, ms)."""
+        codes, quals, loff, begins, ends, hasq, woff, ooff = [], [], [0], [], [], [], [0], [0]
+        any_q = False
+        for wdw in windows:
+            layers = wdw["layers"]
+            k = len(layers)
+            blen = len(layers[0])
+            b = wdw.get("begins") or [0] * k
+            e_ = wdw.get("ends") or [max(blen - 1, 0)] * k
+            q = wdw.get("quals")
+            for i, lay in enumerate(layers):
+                lay = np.asarray(lay, dtype=np.uint8)
+                codes.append(lay)
+                loff.append(loff[-1] + lay.shape[0])
+                begins.append(int(b[i]))
+                ends.append(int(e_[i]))
+                if q is not None and q[i] is not None:
+                    quals.append(np.asarray(q[i], dtype=np.uint8))
+                    hasq.append(1)
+                    any_q = True
+                else:
+                    quals.append(np.full(lay.shape[0], 33, dtype=np.uint8))
+                    hasq.append(0)
+            woff.append(woff[-1] + k)
+            ooff.append(ooff[-1] + 4 * blen + 256)
+        nw = len(windows)
+        codes_a = np.concatenate(codes) if codes else np.zeros(0, np.uint8)
+        quals_a = np.concatenate(quals) if any_q else None
+        out = np.zeros(ooff[-1] + 16, dtype=np.uint8)
+        out_len = np.zeros(nw, dtype=np.uint32)
+        status = np.zeros(nw, dtype=np.uint32)
+        ms = C.c_double(0)
+        ooff_a = np.asarray(ooff, dtype=np.uint64)
+        _check(lib().rvn_poa_consensus_batch(
+            self._h, _p(codes_a), _p(quals_a), _p(np.asarray(loff, dtype=np.uint64)),
+            _p(np.asarray(begins, dtype=np.uint32)), _p(np.asarray(ends, dtype=np.uint32)),
+            _p(np.asarray(hasq, dtype=np.uint32)), _p(np.asarray(woff, dtype=np.uint32)), nw, m, n, g, int(trim),
+            _p(out), _p(ooff_a), _p(out_len), _p(status), C.byref(ms)))
+        cons = [out[ooff[i]: ooff[i] + int(out_len[i])].copy() for i in range(nw)]
+        return cons, status, ms.value
 
     # -- introspection ---------------------------------------------------------------------
     def sketch(self, reads: Reads, first=0, last=None, minhash=False):

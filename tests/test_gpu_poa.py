@@ -1,0 +1,115 @@
+"""GPU parity of rvn_poa_consensus_batch against the POA oracle (racon Window::GenerateConsensus restatement).
+Tolerance-based where ties can differ (north_star: 'polished consensus within stated edit-distance tolerance'):
+per window ED(gpu, cpu) <= 1 % of the window length, and ED(gpu, truth) <= ED(cpu, truth) + 2; the simple
+cases must be identical."""
+import numpy as np
+import pytest
+
+from oracle import oracle
+from raven_amd import hip
+
+pytestmark = pytest.mark.gpu
+
+
+def _mutate(rng, codes, sub, ins, dele):
+    out = []
+    for c in codes:
+        u = rng.random()
+        if u < dele:
+            continue
+        if u < dele + sub:
+            c = (c + rng.integers(1, 4)) & 3
+        out.append(int(c))
+        if rng.random() < ins:
+            out.append(int(rng.integers(0, 4)))
+    return np.array(out, dtype=np.uint8)
+
+
+def _ed(a, b):
+    return oracle.edit_distance(bytes(np.asarray(a, np.uint8) + 65), bytes(np.asarray(b, np.uint8) + 65))
+
+
+def _oracle(w, trim=True):
+    return oracle.poa_window(w["layers"], begins=w.get("begins"), ends=w.get("ends"), quals=w.get("quals"), trim=trim)
+
+
+def _window(rng, length=500, n_reads=30, err=(0.04, 0.03, 0.03), partial=0.0, qual=False):
+    truth = rng.integers(0, 4, size=length, dtype=np.uint8)
+    bb = _mutate(rng, truth, 0.03, 0.02, 0.02)
+    layers, begins, ends = [bb], [0], [len(bb) - 1]
+    quals = [np.full(len(bb), 33, np.uint8)] if qual else None
+    for _ in range(n_reads):
+        if rng.random() < partial:
+            b = int(rng.integers(0, length // 2))
+            e = int(rng.integers(b + length // 4, length))
+        else:
+            b, e = 0, length
+        piece = _mutate(rng, truth[b:e], *err)
+        if len(piece) < 2:
+            continue
+        layers.append(piece)
+        # racon: breaking points on the backbone; approximate by scaling to the backbone length
+        bb_b = min(len(bb) - 2, int(b * len(bb) / length))
+        bb_e = min(len(bb) - 1, max(bb_b + 1, int(e * len(bb) / length) - 1))
+        begins.append(bb_b)
+        ends.append(bb_e)
+        if qual:
+            quals.append((33 + rng.integers(5, 40, size=len(piece))).astype(np.uint8))
+    return dict(layers=layers, begins=begins, ends=ends, quals=quals), truth
+
+
+def test_simple_windows_identical():
+    rng = np.random.default_rng(1)
+    truth = rng.integers(0, 4, size=300, dtype=np.uint8)
+    bb = _mutate(rng, truth, 0.03, 0.02, 0.02)
+    wins = [
+        dict(layers=[bb] + [truth.copy() for _ in range(6)]),            # error-free layers fix the backbone
+        dict(layers=[bb, truth.copy()]),                                  # < 3 sequences: backbone back
+        dict(layers=[bb]),
+        dict(layers=[truth.copy()] + [truth[50:250].copy() for _ in range(8)], begins=[0] + [50] * 8,
+             ends=[299] + [249] * 8),                                     # trimming of thin ends
+    ]
+    eng = hip.Engine()
+    cons, status, _ = eng.poa_consensus_batch(wins)
+    assert status.tolist() == [1, 0, 0, 1]
+    assert np.array_equal(cons[0], truth)
+    assert np.array_equal(cons[1], bb) and np.array_equal(cons[2], bb)
+    assert np.array_equal(cons[3], truth[50:250])
+    for w, c in zip(wins, cons):
+        assert np.array_equal(c, _oracle(w)[0])
+    cons_nt, _, _ = eng.poa_consensus_batch(wins[3:], trim=False)
+    assert np.array_equal(cons_nt[0], truth)
+
+
+@pytest.mark.parametrize("qual,partial", [(False, 0.0), (True, 0.0), (False, 0.3), (True, 0.3)])
+def test_noisy_windows_within_tolerance(qual, partial):
+    rng = np.random.default_rng(7 + int(qual) + int(partial * 10))
+    wins, truths = [], []
+    for _ in range(24):
+        w, t = _window(rng, length=int(rng.integers(300, 520)), n_reads=int(rng.integers(8, 35)), partial=partial,
+                       qual=qual)
+        wins.append(w)
+        truths.append(t)
+    eng = hip.Engine()
+    cons, status, ms = eng.poa_consensus_batch(wins)
+    assert np.all(status == 1)
+    identical = 0
+    for w, t, c in zip(wins, truths, cons):
+        ref, polished = _oracle(w)
+        assert polished
+        d = _ed(c, ref)
+        identical += d == 0
+        assert d <= max(2, 0.01 * len(ref)), (d, len(ref))
+        assert _ed(c, t) <= _ed(ref, t) + 2
+    assert identical >= 0.75 * len(wins)
+
+
+def test_limits_are_reported_not_hidden():
+    rng = np.random.default_rng(3)
+    long_bb = rng.integers(0, 4, size=1500, dtype=np.uint8)   # layer longer than the device limit (1024)
+    w = dict(layers=[long_bb, long_bb.copy(), long_bb.copy()])
+    eng = hip.Engine()
+    cons, status, _ = eng.poa_consensus_batch([w])
+    assert status[0] == 2 and np.array_equal(cons[0], long_bb)
+    with pytest.raises(ValueError):
+        eng.poa_consensus_batch([dict(layers=[long_bb[:100], long_bb[:50], long_bb[:50]], begins=[0, 60, 0], ends=[99, 40, 99])])
