@@ -69,6 +69,8 @@ def lib():
         L.orc_antiqsort.argtypes = [vp, u32]
         L.orc_poa_window.restype = i32
         L.orc_poa_window.argtypes = [vp, vp, vp, vp, vp, u32, i32, i32, i32, i32, vp, u32, C.POINTER(u32)]
+        L.orc_poa_order_check.restype = i32
+        L.orc_poa_order_check.argtypes = [vp, vp, vp, vp, u32, i32, i32, i32, vp]
         L.orc_poa_align_score_linear.restype = i32
         L.orc_poa_align_score_linear.argtypes = [vp, u32, vp, u32, i32, i32, i32]
         L.orc_edit_distance.restype = u32
@@ -226,6 +228,20 @@ def poa_window(layers, begins=None, ends=None, quals=None, m=3, n=-5, g=-4, trim
     if polished < 0:
         raise ValueError("[racon::Window::AddLayer] error: layer begin and end positions are invalid!")
     return out[:n_out.value].copy(), bool(polished)
+
+
+def poa_order_check(layers, begins=None, ends=None, m=3, n=-5, g=-4):
+    """Replays the device kernel's incremental topological-order rule beside spoa's graph construction;
+    returns -1 if every edge keeps rank(tail) < rank(head) after every layer, else the failing layer."""
+    k = len(layers)
+    off = np.zeros(k + 1, dtype=np.uint64)
+    np.cumsum([len(x) for x in layers], out=off[1:])
+    codes = np.concatenate([np.asarray(x, dtype=np.uint8) for x in layers])
+    blen = len(layers[0])
+    b = np.asarray([0] * k if begins is None else begins, dtype=np.uint32)
+    e = np.asarray([blen - 1] * k if ends is None else ends, dtype=np.uint32)
+    info = np.zeros(8, dtype=np.int64)
+    return int(lib().orc_poa_order_check(_p(codes), _p(off), _p(b), _p(e), k, m, n, g, _p(info))), info
 
 
 def poa_align_score_linear(target, query, m=3, n=-5, g=-4) -> int:

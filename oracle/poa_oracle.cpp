@@ -43,6 +43,8 @@ struct Graph {
   std::vector<std::uint32_t> rank_to_node;
   std::uint32_t num_sequences = 0;
   std::vector<std::uint32_t> consensus;  // node ids
+  // debug trace of the last AddAlignment: path node ids in path order and the DP node each was aligned to (-1: none)
+  std::vector<std::int32_t> path_nodes, path_aligned;
 
   std::uint32_t AddNode(std::uint32_t code) {
     nodes.push_back(Node{code, {}, {}, {}});
@@ -88,7 +90,15 @@ struct Graph {
     std::uint32_t tmp = nodes.size();
     std::int32_t begin = AddSequence(codes, weights, 0, valid.front());
     std::int32_t prev = tmp == nodes.size() ? -1 : static_cast<std::int32_t>(nodes.size() - 1);
+    path_nodes.clear();
+    path_aligned.clear();
+    for (std::uint32_t x = tmp; x < nodes.size(); ++x) {
+      path_nodes.push_back(x);
+      path_aligned.push_back(-1);
+    }
+    std::uint32_t suffix_first = nodes.size();
     std::int32_t last = AddSequence(codes, weights, valid.back() + 1, len);
+    std::uint32_t suffix_end = nodes.size();
     for (const auto& it : alignment) {
       if (it.second == -1) continue;
       std::uint32_t code = codes[it.second];
@@ -121,6 +131,12 @@ struct Graph {
       if (begin < 0) begin = curr;
       if (prev >= 0) AddEdge(prev, curr, weights[it.second - 1] + weights[it.second]);
       prev = curr;
+      path_nodes.push_back(curr);
+      path_aligned.push_back(it.first);
+    }
+    for (std::uint32_t x = suffix_first; x < suffix_end; ++x) {
+      path_nodes.push_back(x);
+      path_aligned.push_back(-1);
     }
     if (last >= 0) AddEdge(prev, last, weights[valid.back()] + weights[valid.back() + 1]);
     ++num_sequences;
@@ -461,6 +477,102 @@ int orc_poa_window(const std::uint8_t* codes, const std::uint8_t* quals, const s
   *out_len = cons.size();
   std::memcpy(out, cons.data(), std::min<std::size_t>(cons.size(), out_cap));
   return polished ? 1 : 0;
+}
+
+// DEBUG: replays the device kernel's incremental topological-order rule (raven_amd/csrc/poa.hip step 5) next to
+// the real graph construction and returns the first layer after which some edge has rank(tail) >= rank(head)
+// (-1 if the order stays valid). info[0..3] = tail, head, rank(tail), rank(head) of the first violation.
+int orc_poa_order_check(const std::uint8_t* codes, const std::uint64_t* offsets, const std::uint32_t* begins,
+                        const std::uint32_t* ends, std::uint32_t n_layers, int m, int n, int g, std::int64_t* info) {
+  std::vector<poa::Layer> layers(n_layers);
+  for (std::uint32_t i = 0; i < n_layers; ++i) {
+    layers[i].codes = codes + offsets[i];
+    layers[i].qual = nullptr;
+    layers[i].len = static_cast<std::uint32_t>(offsets[i + 1] - offsets[i]);
+    layers[i].begin = begins[i];
+    layers[i].end = ends[i];
+  }
+  poa::Graph graph;
+  const poa::Layer& bb = layers.front();
+  graph.AddAlignment(poa::Alignment(), bb.codes, bb.len, poa::Weights(bb));
+  std::vector<std::uint32_t> rank_of(bb.len);
+  for (std::uint32_t i = 0; i < bb.len; ++i) rank_of[i] = i;
+  std::vector<std::uint32_t> rk(n_layers);
+  for (std::uint32_t i = 0; i < n_layers; ++i) rk[i] = i;
+  std::stable_sort(rk.begin() + 1, rk.end(), [&](std::uint32_t a, std::uint32_t b) { return layers[a].begin < layers[b].begin; });
+  std::uint32_t offset = 0.01 * bb.len;
+  for (std::uint32_t j = 1; j < n_layers; ++j) {
+    const poa::Layer& l = layers[rk[j]];
+    poa::Alignment alignment;
+    if (l.begin < offset && l.end > bb.len - offset) {
+      alignment = poa::AlignNW(l.codes, l.len, graph, m, n, g);
+    } else {
+      std::vector<std::uint32_t> mapping;
+      auto sub = graph.Subgraph(l.begin, l.end, &mapping);
+      alignment = poa::AlignNW(l.codes, l.len, sub, m, n, g);
+      for (auto& it : alignment)
+        if (it.first != -1) it.first = mapping[it.first];
+    }
+    const std::uint32_t n_old = graph.nodes.size();
+    graph.AddAlignment(alignment, l.codes, l.len, poa::Weights(l));
+    // kernel rule
+    auto gmax = [&](std::uint32_t v) {
+      std::uint32_t r = rank_of[v];
+      for (auto a : graph.nodes[v].aligned) if (a < n_old) r = std::max(r, rank_of[a]);
+      return r;
+    };
+    auto gmin = [&](std::uint32_t v) {
+      std::uint32_t r = rank_of[v];
+      for (auto a : graph.nodes[v].aligned) if (a < n_old) r = std::min(r, rank_of[a]);
+      return r;
+    };
+    std::uint32_t first_old_rank = n_old;
+    for (std::size_t q = 0; q < graph.path_nodes.size(); ++q)
+      if (graph.path_aligned[q] != -1) { first_old_rank = gmin(graph.path_aligned[q]); break; }
+    std::uint32_t cur_slot = first_old_rank;
+    std::vector<std::pair<std::uint32_t, std::uint32_t>> news;  // (slot, node id) in path order
+    for (std::size_t q = 0; q < graph.path_nodes.size(); ++q) {
+      std::uint32_t curr = graph.path_nodes[q];
+      std::int32_t an = graph.path_aligned[q];
+      if (an != -1) {
+        if (gmax(an) + 1 < cur_slot) {  // DEBUG: anchor slot would move backwards
+          info[0] = -3; info[1] = an; info[2] = rank_of[an]; info[3] = cur_slot; info[4] = n_old; info[5] = q;
+          info[6] = curr; info[7] = q ? graph.path_nodes[q - 1] : -1;
+          return static_cast<int>(j);
+        }
+        cur_slot = gmax(an) + 1;  // after the whole aligned group (column) of the DP node
+      }
+      if (curr >= n_old) news.emplace_back(cur_slot, curr);
+    }
+    std::vector<std::uint32_t> nr(graph.nodes.size(), 0);
+    std::vector<std::uint32_t> slots;
+    for (auto& p : news) slots.push_back(p.first);
+    for (std::uint32_t v = 0; v < n_old; ++v) {
+      std::uint32_t r = rank_of[v];
+      std::uint32_t ub = std::upper_bound(slots.begin(), slots.end(), r) - slots.begin();
+      nr[v] = r + ub;
+    }
+    for (std::size_t t = 0; t < news.size(); ++t) nr[news[t].second] = news[t].first + t;
+    rank_of = nr;
+    for (const auto& e : graph.edges) {
+      if (rank_of[e.tail] >= rank_of[e.head]) {
+        info[0] = e.tail; info[1] = e.head; info[2] = rank_of[e.tail]; info[3] = rank_of[e.head];
+        info[4] = n_old;
+        info[5] = info[6] = info[7] = -9;
+        for (std::size_t q = 0; q < graph.path_nodes.size(); ++q)
+          if (graph.path_nodes[q] == static_cast<std::int32_t>(e.head)) {
+            info[5] = q; info[6] = graph.path_aligned[q]; info[7] = q ? graph.path_nodes[q - 1] : -1;
+          }
+        return static_cast<int>(j);
+      }
+    }
+    std::vector<std::uint32_t> seen(graph.nodes.size(), 0);
+    for (auto r : rank_of) {
+      if (r >= graph.nodes.size() || seen[r]) { info[0] = -2; info[1] = r; return static_cast<int>(j); }
+      seen[r] = 1;
+    }
+  }
+  return -1;
 }
 
 // NW score of a sequence against the LINEAR graph of another sequence (unit-test hook for AlignNW).

@@ -26,7 +26,7 @@ namespace rvn {
 
 namespace {
 
-constexpr int kPoaMaxIn = 12;     // in-edges per node kept (overflow -> window reported as failed)
+constexpr int kPoaMaxIn = 16;     // in-edges per node kept (overflow -> window reported as failed)
 constexpr int kPoaMaxSeq = 1024;  // longest layer (bases)
 constexpr i32 kNegInf16 = -30000;
 
@@ -169,7 +169,7 @@ __device__ u32 poa_window(const PoaWindow& win, const PoaLayer* __restrict__ lay
   }
   if (blen == 0 || blen > nmax || blen > lmax) {
     copy_backbone();
-    return 2;
+    return 4;
   }
   // ---- backbone graph (spoa AddAlignment with an empty alignment) ----
   u32 n_nodes = blen;
@@ -192,14 +192,14 @@ __device__ u32 poa_window(const PoaWindow& win, const PoaLayer* __restrict__ lay
   }
   wsync();
   const u32 offset = static_cast<u32>(0.01 * blen);
-  bool failed = false;
+  u32 failed = 0;  // 2 nodes, 3 in-degree, 4 layer length, 5 internal
 
   for (u32 li = 1; li < win.n_layers && !failed; ++li) {
     const PoaLayer L = layers[win.layer_first + li];
     const u32 len = L.len;
     if (len == 0) continue;
     if (len > lmax || len > kPoaMaxSeq) {
-      failed = true;
+      failed = 4;
       break;
     }
     for (u32 i = lane; i < len; i += 64) {
@@ -246,6 +246,16 @@ __device__ u32 poa_window(const PoaWindow& win, const PoaLayer* __restrict__ lay
     wsync();
     i32 best_score = -0x7FFFFFFF;
     u32 best_row = 0;
+    // the row computed last stays in registers (lane l holds columns c*64+l): it is the predecessor of most
+    // rows, so the common case needs no global load and no store->load fence
+    i32 lastrow[kPoaMaxSeq / 64 + 1];
+#pragma unroll
+    for (int c = 0; c < kPoaMaxSeq / 64 + 1; ++c) {
+      const u32 j = c * 64 + lane;
+      lastrow[c] = j < w ? static_cast<i32>(j) * gp : kNegInf16;
+    }
+    u32 last_row_idx = 0;
+    bool dirty = false;  // rows stored since the last fence
     for (u32 r = 0; r < n_nodes; ++r) {
       const u32 v = g.order[r];
       if (!full && !g.mark[v]) continue;
@@ -268,16 +278,34 @@ __device__ u32 poa_window(const PoaWindow& win, const PoaLayer* __restrict__ lay
       const u32 vc = g.code[v];
       i16* Hr = g.H + static_cast<size_t>(row) * w;
       i32 carry_h = 0;  // H[row][c0 - 1] of the previous chunk
-      for (u32 c0 = 0; c0 < w; c0 += 64) {
+      bool far = false;
+      for (u32 k = 0; k < np; ++k) far |= prow[k] != last_row_idx;
+      if (far && dirty) {  // a predecessor row comes from memory: earlier stores must have landed
+        wsync();
+        dirty = false;
+      }
+      i32 prev_chunk_last = kNegInf16;  // lastrow value of column c0-1 (diag for lane 0)
+      i32 end_score = kNegInf16;
+#pragma unroll
+      for (int ci = 0; ci < kPoaMaxSeq / 64 + 1; ++ci) {
+        const u32 c0 = ci * 64;
+        if (c0 >= w) continue;
         const u32 j = c0 + lane;
         const bool valid = j < w;
         i32 best = -0x3FFFFFFF;
         i32 col0 = -0x3FFFFFFF;
         for (u32 k = 0; k < np; ++k) {
-          const i16* Hp = g.H + static_cast<size_t>(prow[k]) * w;
-          const i32 up = valid ? static_cast<i32>(Hp[j]) : kNegInf16;
-          i32 diag = __shfl_up(up, 1, 64);
-          if (lane == 0) diag = c0 ? static_cast<i32>(Hp[c0 - 1]) : kNegInf16;
+          i32 up, diag;
+          if (prow[k] == last_row_idx) {
+            up = lastrow[ci];
+            diag = __shfl_up(up, 1, 64);
+            if (lane == 0) diag = prev_chunk_last;
+          } else {
+            const i16* Hp = g.H + static_cast<size_t>(prow[k]) * w;
+            up = valid ? static_cast<i32>(Hp[j]) : kNegInf16;
+            diag = __shfl_up(up, 1, 64);
+            if (lane == 0) diag = c0 ? static_cast<i32>(Hp[c0 - 1]) : kNegInf16;
+          }
           if (j >= 1 && valid) {
             const i32 s = (vc == s_seq[j - 1]) ? m : n_;
             const i32 a = diag + s, b = up + gp;
@@ -295,21 +323,27 @@ __device__ u32 poa_window(const PoaWindow& win, const PoaLayer* __restrict__ lay
           const i32 viac = carry_h + static_cast<i32>(lane + 1) * gp;
           h = viac > h ? viac : h;
         }
-        if (valid) Hr[j] = static_cast<i16>(h < kNegInf16 ? kNegInf16 : h);
+        h = h < kNegInf16 ? kNegInf16 : h;
+        if (valid) Hr[j] = static_cast<i16>(h);
         carry_h = __shfl(h, 63, 64);
+        prev_chunk_last = __shfl(lastrow[ci], 63, 64);
+        lastrow[ci] = valid ? h : kNegInf16;  // in place: this chunk's old values are no longer needed
+        if (c0 + 64 >= w) end_score = __shfl(h, static_cast<int>((w - 1) & 63), 64);
       }
-      wsync();
+      last_row_idx = row;
+      dirty = true;
       const u32 outc = full ? g.out_cnt[v] : g.sub_out[v];
       if (outc == 0) {
-        const i32 sc = Hr[w - 1];
+        const i32 sc = end_score;
         if (sc > best_score) {
           best_score = sc;
           best_row = row;
         }
       }
     }
+    wsync();  // the whole matrix must be visible to the traceback
     if (best_row == 0) {  // no end node inside the subgraph (cannot happen for a valid layer)
-      failed = true;
+      failed = 5 | (li << 8);
       break;
     }
     // ---- 3. traceback (lane 0), pairs stored end -> start ----
@@ -382,13 +416,14 @@ __device__ u32 poa_window(const PoaWindow& win, const PoaLayer* __restrict__ lay
     }
     n_aln = __shfl(n_aln, 0, 64);
     if (n_aln == 0xFFFFFFFFu || n_aln == 0) {
-      failed = true;
+      failed = (n_aln == 0 ? 7u : 6u) | (li << 8);
       break;
     }
     // ---- 4. spoa AddAlignment (lane 0); new nodes in path order, each with its order slot ----
     const u32 n_old = n_nodes;
     u32 n_new = 0;
     u32 ok = 1;
+    u32 why = 3;  // failure reason if !ok: in-degree overflow unless a node limit was hit
     if (lane == 0) {
       // first / last aligned sequence positions
       i32 first_pos = -1, last_pos = -1;
@@ -398,11 +433,25 @@ __device__ u32 poa_window(const PoaWindow& win, const PoaLayer* __restrict__ lay
           last_pos = g.aln_pos[a];
         }
       }
-      // slot of the unaligned prefix: right before the first old node on the path
+      // A column = an aligned group.  New nodes anchored after a column go after ALL its members (a later read
+      // may leave the column through any alternative); the unaligned prefix goes before all members of the
+      // first column.
+      auto group_max = [&](u32 v) -> u32 {
+        u32 r = g.rank_of[v];
+        for (u32 k = 0; k < g.al_cnt[v]; ++k) {
+          const u32 a = g.al[v * 4 + k];
+          if (a < n_old && g.rank_of[a] > r) r = g.rank_of[a];
+        }
+        return r;
+      };
       u32 first_old_rank = n_old;
       for (u32 a = n_aln; a-- > 0;) {
         if (g.aln_node[a] != -1 && g.aln_pos[a] != -1) {
-          first_old_rank = g.rank_of[g.aln_node[a]];
+          const u32 v = g.aln_node[a];
+          u32 r = g.rank_of[v];
+          for (u32 k = 0; k < g.al_cnt[v]; ++k)
+            if (g.rank_of[g.al[v * 4 + k]] < r) r = g.rank_of[g.al[v * 4 + k]];
+          first_old_rank = r;
           break;
         }
       }
@@ -411,6 +460,7 @@ __device__ u32 poa_window(const PoaWindow& win, const PoaLayer* __restrict__ lay
       auto new_node = [&](u32 code) -> i32 {
         if (n_nodes >= nmax || n_new >= lmax) {
           ok = 0;
+          why = 2;
           return -1;
         }
         const u32 id = poa_add_node(g, n_nodes, code);
@@ -436,7 +486,7 @@ __device__ u32 poa_window(const PoaWindow& win, const PoaLayer* __restrict__ lay
         if (an == -1) {
           curr = new_node(code);
         } else {
-          cur_slot = static_cast<u32>(g.rank_of[an]) + 1;  // later new nodes follow this old node
+          cur_slot = group_max(static_cast<u32>(an)) + 1;  // later new nodes follow this column
           if (g.code[an] == code) {
             curr = an;
           } else {
@@ -483,8 +533,9 @@ __device__ u32 poa_window(const PoaWindow& win, const PoaLayer* __restrict__ lay
     ok = __shfl(ok, 0, 64);
     n_nodes = __shfl(n_nodes, 0, 64);
     n_new = __shfl(n_new, 0, 64);
+    why = __shfl(why, 0, 64);
     if (!ok) {
-      failed = true;
+      failed = why;
       break;
     }
     // ---- 5. order rebuild: old rank r -> r + #(new slots <= r); t-th new node -> slot_t + t ----
@@ -510,7 +561,7 @@ __device__ u32 poa_window(const PoaWindow& win, const PoaLayer* __restrict__ lay
   }
   if (failed) {
     copy_backbone();
-    return 2;
+    return failed;
   }
   // ---- consensus: spoa TraverseHeaviestBundle + BranchCompletion (lane 0) ----
   u32 cons_len = 0;
@@ -665,11 +716,11 @@ void poa_consensus_batch(Engine& e, const u8* h_codes, const u8* h_quals, const 
   }
   // limits: nodes <= nmax, layer length <= lmax (windows beyond them come back with status 2)
   const u32 lmax = std::min<u32>(kPoaMaxSeq, std::max<u32>(64, ((max_len + 63) / 64) * 64));
-  const u32 nmax = std::min<u32>(4096, std::max<u32>(256, max_bb * 4));
+  const u32 nmax = std::min<u32>(8192, std::max<u32>(512, max_bb * 6));
   const size_t slot_bytes = poa_slot_bytes(nmax, lmax);
   size_t free_b = 0, total_b = 0;
   RVN_HIP(hipMemGetInfo(&free_b, &total_b));
-  u32 n_slots = std::min<u32>(n_windows, 256 * 16);
+  u32 n_slots = std::min<u32>(n_windows, 256 * 8);
   const size_t budget = free_b / 2;
   if (static_cast<size_t>(n_slots) * slot_bytes > budget) n_slots = static_cast<u32>(std::max<size_t>(1, budget / slot_bytes));
   n_slots = ((n_slots + 3) / 4) * 4;

@@ -117,3 +117,25 @@ def test_trim_cuts_low_coverage_ends():
     assert np.array_equal(cons, truth[50:250])
     cons, _ = oracle.poa_window(layers, begins=begins, ends=ends, trim=False)
     assert np.array_equal(cons, truth)
+
+
+def test_incremental_topological_order_rule_stays_valid():
+    """The device kernel keeps the topological order incrementally (new nodes go after the whole aligned group of
+    their anchor column).  Replayed here next to spoa's graph construction: no edge may ever point backwards."""
+    rng = np.random.default_rng(11)
+    for _ in range(40):
+        truth = rng.integers(0, 4, size=int(rng.integers(200, 500)), dtype=np.uint8)
+        bb = _mutate(rng, truth, 0.03, 0.02, 0.02)
+        layers, begins, ends = [bb], [0], [len(bb) - 1]
+        for _ in range(int(rng.integers(10, 32))):
+            if rng.random() < 0.25:
+                b0 = int(rng.integers(0, len(truth) // 2))
+                e0 = int(rng.integers(b0 + len(truth) // 4, len(truth)))
+            else:
+                b0, e0 = 0, len(truth)
+            layers.append(_mutate(rng, truth[b0:e0], 0.05, 0.04, 0.04))
+            bb_b = min(len(bb) - 2, int(b0 * len(bb) / len(truth)))
+            begins.append(bb_b)
+            ends.append(min(len(bb) - 1, max(bb_b + 1, int(e0 * len(bb) / len(truth)) - 1)))
+        bad, info = oracle.poa_order_check(layers, begins, ends)
+        assert bad == -1, (bad, info)
