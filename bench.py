@@ -30,6 +30,19 @@ from raven_amd import hip, synth  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured copy)
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (profiles/pmc_traffic.json,
+    made by tools/pmc_traffic.py from separate FETCH_SIZE / WRITE_SIZE runs of this same bench command):
+    2 x FETCH_SIZE KiB (gfx950: FETCH_SIZE counts 128-B requests as 64 B, MI355X_MICROARCH.md §HBM) + WRITE_SIZE KiB."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            t = json.load(f)
+        e = t["kernels"].get(kernel)
+        return int(e["hbm_bytes_per_launch"]) if e else None
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def algorithmic_bytes(site, c, val_bytes):
     """ALGORITHMIC bytes of ONE launch of kernel `site`, from the exact engine counters of
     one step: N index bases, Mi index minimizers, U keys, Mq query minimizers, H matches, O overlaps."""
@@ -164,7 +177,7 @@ def main():
                 avg_s = kms[dom][0] / kms[dom][1] / 1e3
                 achieved = b / avg_s / 1e9
                 roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(dom),
                             "algorithmic_bytes_per_launch": int(b), "avg_launch_ms": round(avg_s * 1e3, 5),
                             "kernel_ms_share": round(kms[dom][0] / tot, 3) if tot else None}
         out = {

@@ -123,6 +123,10 @@ int rvn_poa_consensus_batch(rvn_engine* e, const uint8_t* codes, const uint8_t* 
                             int trim, uint8_t* consensus, const uint64_t* consensus_offsets, uint32_t* consensus_len,
                             uint32_t* status, double* device_ms);
 
+/* shader-clock cycles summed over all windows of the last rvn_poa_consensus_batch call, per phase:
+ * {subgraph, NW matrix, traceback, AddAlignment, order rebuild, consensus} */
+void rvn_poa_phase_cycles(const rvn_engine* e, uint64_t out[6]);
+
 /* ---- introspection used by the parity tests and bench.py ------------------------------------- */
 /* sketch of reads [first,last) == ram Minimize(sequence, minhash) per read; values widened to u64 */
 int rvn_engine_sketch(rvn_engine* e, const rvn_reads* r, uint32_t first, uint32_t last, int minhash,

@@ -98,6 +98,7 @@ struct Engine {
   DevBuf seg_off, iv_slot_begin, iv_slot_end, iv_cnt, iv_off, iv_begin, iv_end;
   DevBuf lis_min, lis_pred, lis_tail, lis_mask, ovl_slots, ovl_flags, ovl_scan;
   DevBuf poa_scratch;
+  unsigned long long poa_phase_cycles[6] = {};  // subgraph, dp, traceback, add, order, consensus (last call)
   StageTimes times;
   KernelTimers ktimers;
   // counters for algorithmic bytes

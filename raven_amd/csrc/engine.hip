@@ -461,6 +461,10 @@ int rvn_poa_consensus_batch(rvn_engine* h, const uint8_t* codes, const uint8_t* 
   });
 }
 
+void rvn_poa_phase_cycles(const rvn_engine* h, uint64_t out[6]) {
+  for (int i = 0; i < 6; ++i) out[i] = h ? h->e.poa_phase_cycles[i] : 0;
+}
+
 int rvn_engine_sketch(rvn_engine* h, const rvn_reads* r, uint32_t first, uint32_t last, int minhash, uint64_t* count) {
   return guarded([&]() -> int {
     if (!h || !r || first > last || last > r->r.n) return fail(RVN_EINVAL, "[raven_hip] rvn_engine_sketch: bad range");

@@ -154,8 +154,12 @@ __device__ inline u32 poa_add_node(PoaSlot& g, u32& n_nodes, u32 code) {
 // One window. Returns status: 0 = backbone returned (< 3 sequences), 1 = polished, 2 = limits exceeded.
 __device__ u32 poa_window(const PoaWindow& win, const PoaLayer* __restrict__ layers, const u8* __restrict__ codes,
                           const u8* __restrict__ quals, PoaSlot& g, u32 nmax, u32 lmax, int m, int n_, int gp, int trim,
-                          u8* s_seq, u8* s_w, u8* __restrict__ out, u32* out_len) {
+                          u8* s_seq, u8* s_w, u8* __restrict__ out, u32* out_len,
+                          unsigned long long* __restrict__ phase_cycles) {
   const int lane = lane_id();
+  unsigned long long t_sub = 0, t_dp = 0, t_tb = 0, t_add = 0, t_ord = 0, t_cons = 0, t0 = 0;
+  auto tick = [&]() { t0 = __builtin_readcyclecounter(); };
+  auto tock = [&](unsigned long long& acc) { acc += __builtin_readcyclecounter() - t0; };
   const PoaLayer bb = layers[win.layer_first];
   const u32 blen = bb.len;
   auto copy_backbone = [&]() {
@@ -207,6 +211,7 @@ __device__ u32 poa_window(const PoaWindow& win, const PoaLayer* __restrict__ lay
       s_w[i] = L.has_qual ? static_cast<u8>(quals[L.code_off + i] - 33) : 1;
     }
     const bool full = L.begin < offset && L.end > blen - offset;
+    tick();
     // ---- 1. subgraph marks ----
     if (!full) {
       for (u32 i = lane; i < n_nodes; i += 64) {
@@ -240,6 +245,8 @@ __device__ u32 poa_window(const PoaWindow& win, const PoaLayer* __restrict__ lay
       }
       wsync();
     }
+    tock(t_sub);
+    tick();
     // ---- 2. NW matrix ----
     const u32 w = len + 1;
     for (u32 j = lane; j < w; j += 64) g.H[j] = static_cast<i16>(static_cast<i32>(j) * gp);
@@ -256,14 +263,42 @@ __device__ u32 poa_window(const PoaWindow& win, const PoaLayer* __restrict__ lay
     }
     u32 last_row_idx = 0;
     bool dirty = false;  // rows stored since the last fence
-    for (u32 r = 0; r < n_nodes; ++r) {
-      const u32 v = g.order[r];
-      if (!full && !g.mark[v]) continue;
+    for (u32 r0 = 0; r0 < n_nodes; r0 += 64) {
+     // Row metadata for 64 rows at once, one row per lane: the order -> in-edges -> rank chain of dependent
+     // loads is paid once per 64 rows instead of once per row (it was ~80 % of the row time).
+     int m_v = 0, m_np = 0, m_p0 = 0, m_p1 = 0, m_code = 0, m_outc = 1, m_marked = 0;
+     if (r0 + lane < n_nodes) {
+       m_v = g.order[r0 + lane];
+       m_marked = (full || g.mark[m_v]) ? 1 : 0;
+       if (m_marked) {
+         m_code = g.code[m_v];
+         m_outc = full ? g.out_cnt[m_v] : g.sub_out[m_v];
+         const u32 c = g.in_cnt[m_v];
+         for (u32 k = 0; k < c; ++k) {
+           const u32 t = g.in_tail[m_v * kPoaMaxIn + k];
+           if (full || g.mark[t]) {
+             const int pr = static_cast<int>(g.rank_of[t]) + 1;
+             if (m_np == 0) m_p0 = pr;
+             else if (m_np == 1) m_p1 = pr;
+             ++m_np;
+           }
+         }
+       }
+     }
+     const u32 rows_here = n_nodes - r0 < 64 ? n_nodes - r0 : 64;
+     for (u32 ri = 0; ri < rows_here; ++ri) {
+      const u32 r = r0 + ri;
+      if (!__shfl(m_marked, static_cast<int>(ri), 64)) continue;
+      const u32 v = static_cast<u32>(__shfl(m_v, static_cast<int>(ri), 64));
       const u32 row = r + 1;
       // predecessor rows (in-edges whose tail is inside the subgraph), in insertion order
       u32 prow[kPoaMaxIn];
-      u32 np = 0;
-      {
+      u32 np = static_cast<u32>(__shfl(m_np, static_cast<int>(ri), 64));
+      if (np <= 2) {
+        prow[0] = static_cast<u32>(__shfl(m_p0, static_cast<int>(ri), 64));
+        prow[1] = static_cast<u32>(__shfl(m_p1, static_cast<int>(ri), 64));
+      } else {
+        np = 0;
         const u32 c = g.in_cnt[v];
         for (u32 k = 0; k < c; ++k) {
           const u32 t = g.in_tail[v * kPoaMaxIn + k];
@@ -275,7 +310,7 @@ __device__ u32 poa_window(const PoaWindow& win, const PoaLayer* __restrict__ lay
         prow[0] = 0;
         np = 1;
       }
-      const u32 vc = g.code[v];
+      const u32 vc = static_cast<u32>(__shfl(m_code, static_cast<int>(ri), 64));
       i16* Hr = g.H + static_cast<size_t>(row) * w;
       i32 carry_h = 0;  // H[row][c0 - 1] of the previous chunk
       bool far = false;
@@ -298,13 +333,12 @@ __device__ u32 poa_window(const PoaWindow& win, const PoaLayer* __restrict__ lay
           i32 up, diag;
           if (prow[k] == last_row_idx) {
             up = lastrow[ci];
-            diag = __shfl_up(up, 1, 64);
-            if (lane == 0) diag = prev_chunk_last;
+            diag = dpp_wave_shr1(up, prev_chunk_last);
           } else {
             const i16* Hp = g.H + static_cast<size_t>(prow[k]) * w;
             up = valid ? static_cast<i32>(Hp[j]) : kNegInf16;
-            diag = __shfl_up(up, 1, 64);
-            if (lane == 0) diag = c0 ? static_cast<i32>(Hp[c0 - 1]) : kNegInf16;
+            const i32 edge = c0 ? static_cast<i32>(Hp[c0 - 1]) : kNegInf16;
+            diag = dpp_wave_shr1(up, edge);
           }
           if (j >= 1 && valid) {
             const i32 s = (vc == s_seq[j - 1]) ? m : n_;
@@ -317,7 +351,7 @@ __device__ u32 poa_window(const PoaWindow& win, const PoaLayer* __restrict__ lay
         if (j == 0) best = (no_pred ? 0 : col0) + gp;
         // horizontal chain: H[j] = max_k<=j (best[k] + (j-k) g)  ->  prefix max of (best - j g)
         i32 x = valid ? best - static_cast<i32>(j) * gp : -0x3FFFFFFF;
-        x = wave_inclusive_max(x);
+        x = wave_inclusive_max_dpp(x, -0x3FFFFFFF);
         i32 h = x + static_cast<i32>(j) * gp;
         if (c0) {
           const i32 viac = carry_h + static_cast<i32>(lane + 1) * gp;
@@ -325,14 +359,14 @@ __device__ u32 poa_window(const PoaWindow& win, const PoaLayer* __restrict__ lay
         }
         h = h < kNegInf16 ? kNegInf16 : h;
         if (valid) Hr[j] = static_cast<i16>(h);
-        carry_h = __shfl(h, 63, 64);
-        prev_chunk_last = __shfl(lastrow[ci], 63, 64);
+        carry_h = __builtin_amdgcn_readlane(h, 63);
+        prev_chunk_last = __builtin_amdgcn_readlane(lastrow[ci], 63);
         lastrow[ci] = valid ? h : kNegInf16;  // in place: this chunk's old values are no longer needed
         if (c0 + 64 >= w) end_score = __shfl(h, static_cast<int>((w - 1) & 63), 64);
       }
       last_row_idx = row;
       dirty = true;
-      const u32 outc = full ? g.out_cnt[v] : g.sub_out[v];
+      const u32 outc = static_cast<u32>(__shfl(m_outc, static_cast<int>(ri), 64));
       if (outc == 0) {
         const i32 sc = end_score;
         if (sc > best_score) {
@@ -340,8 +374,11 @@ __device__ u32 poa_window(const PoaWindow& win, const PoaLayer* __restrict__ lay
           best_row = row;
         }
       }
+     }
     }
     wsync();  // the whole matrix must be visible to the traceback
+    tock(t_dp);
+    tick();
     if (best_row == 0) {  // no end node inside the subgraph (cannot happen for a valid layer)
       failed = 5 | (li << 8);
       break;
@@ -415,6 +452,8 @@ __device__ u32 poa_window(const PoaWindow& win, const PoaLayer* __restrict__ lay
       }
     }
     n_aln = __shfl(n_aln, 0, 64);
+    tock(t_tb);
+    tick();
     if (n_aln == 0xFFFFFFFFu || n_aln == 0) {
       failed = (n_aln == 0 ? 7u : 6u) | (li << 8);
       break;
@@ -538,6 +577,8 @@ __device__ u32 poa_window(const PoaWindow& win, const PoaLayer* __restrict__ lay
       failed = why;
       break;
     }
+    tock(t_add);
+    tick();
     // ---- 5. order rebuild: old rank r -> r + #(new slots <= r); t-th new node -> slot_t + t ----
     if (n_new) {
       for (u32 r = lane; r < n_old; r += 64) {
@@ -558,12 +599,14 @@ __device__ u32 poa_window(const PoaWindow& win, const PoaLayer* __restrict__ lay
       }
       wsync();
     }
+    tock(t_ord);
   }
   if (failed) {
     copy_backbone();
     return failed;
   }
   // ---- consensus: spoa TraverseHeaviestBundle + BranchCompletion (lane 0) ----
+  tick();
   u32 cons_len = 0;
   if (lane == 0) {
     i32 maxn = -1;
@@ -652,6 +695,15 @@ __device__ u32 poa_window(const PoaWindow& win, const PoaLayer* __restrict__ lay
     *out_len = cons_len;
   }
   wsync();
+  tock(t_cons);
+  if (phase_cycles && lane == 0) {
+    atomicAdd(&phase_cycles[0], t_sub);
+    atomicAdd(&phase_cycles[1], t_dp);
+    atomicAdd(&phase_cycles[2], t_tb);
+    atomicAdd(&phase_cycles[3], t_add);
+    atomicAdd(&phase_cycles[4], t_ord);
+    atomicAdd(&phase_cycles[5], t_cons);
+  }
   return 1;
 }
 
@@ -660,7 +712,8 @@ __global__ __launch_bounds__(256) void poa_kernel(const PoaWindow* __restrict__ 
                                                  const u8* __restrict__ quals, unsigned char* __restrict__ scratch,
                                                  size_t slot_bytes, u32 n_slots, u32 nmax, u32 lmax, int m, int n_,
                                                  int gp, int trim, u8* __restrict__ out, u32* __restrict__ out_len,
-                                                 u32* __restrict__ status) {
+                                                 u32* __restrict__ status,
+                                                 unsigned long long* __restrict__ phase_cycles) {
   __shared__ u8 s_seq[4][kPoaMaxSeq];
   __shared__ u8 s_w[4][kPoaMaxSeq];
   const u32 wv = threadIdx.x >> 6;
@@ -670,7 +723,7 @@ __global__ __launch_bounds__(256) void poa_kernel(const PoaWindow* __restrict__ 
   for (u32 wi = slot; wi < n_windows; wi += n_slots) {
     const PoaWindow win = windows[wi];
     const u32 st = poa_window(win, layers, codes, quals, g, nmax, lmax, m, n_, gp, trim, s_seq[wv], s_w[wv],
-                              out + win.out_off, out_len + wi);
+                              out + win.out_off, out_len + wi, phase_cycles);
     if (lane_id() == 0) status[wi] = st;
     wsync();
   }
@@ -733,6 +786,8 @@ void poa_consensus_batch(Engine& e, const u8* h_codes, const u8* h_quals, const 
   u8* d_out = e.tmp_e.get<u8>(out_total + 16);
   u32* d_len = e.tmp_f.get<u32>(2 * static_cast<size_t>(n_windows) + 2);
   u32* d_status = d_len + n_windows + 1;
+  unsigned long long* d_phase = e.q_start.get<unsigned long long>(8);
+  RVN_HIP(hipMemsetAsync(d_phase, 0, 64, s));
   unsigned char* d_scratch = e.poa_scratch.get<unsigned char>(static_cast<size_t>(n_slots) * slot_bytes + 256);
   RVN_HIP(hipMemcpyAsync(d_codes, h_codes, total, hipMemcpyHostToDevice, s));
   if (d_quals) RVN_HIP(hipMemcpyAsync(d_quals, h_quals, total, hipMemcpyHostToDevice, s));
@@ -741,11 +796,12 @@ void poa_consensus_batch(Engine& e, const u8* h_codes, const u8* h_quals, const 
   RVN_HIP(hipEventRecord(e.ev0, s));
   RVN_KLAUNCH(kKPoa, poa_kernel<<<n_slots / 4, 256, 0, s>>>(d_wins, n_windows, d_lays, d_codes, d_quals, d_scratch,
                                                              slot_bytes, n_slots, nmax, lmax, m, n, g, trim, d_out,
-                                                             d_len, d_status));
+                                                             d_len, d_status, d_phase));
   RVN_HIP(hipEventRecord(e.ev1, s));
   RVN_HIP(hipMemcpyAsync(h_out, d_out, out_total, hipMemcpyDeviceToHost, s));
   RVN_HIP(hipMemcpyAsync(h_out_len, d_len, static_cast<size_t>(n_windows) * 4, hipMemcpyDeviceToHost, s));
   RVN_HIP(hipMemcpyAsync(h_status, d_status, static_cast<size_t>(n_windows) * 4, hipMemcpyDeviceToHost, s));
+  RVN_HIP(hipMemcpyAsync(e.poa_phase_cycles, d_phase, 48, hipMemcpyDeviceToHost, s));
   RVN_HIP(hipStreamSynchronize(s));
   if (device_ms) {
     float ms = 0;

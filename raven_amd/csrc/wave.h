@@ -56,6 +56,31 @@ __device__ __forceinline__ T wave_inclusive_max(T v) {
   return v;
 }
 
+// ---- DPP cross-lane primitives (single VALU instructions on gfx9-family, vs ~100-cycle ds_bpermute) ----
+// value of lane-1 (whole-wave shift right by one); lane 0 receives `fill`
+__device__ __forceinline__ int dpp_wave_shr1(int v, int fill) {
+  return __builtin_amdgcn_update_dpp(fill, v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+}
+// inclusive prefix max over the 64 lanes (the classic row_shr 1/2/3/4/8 + row_bcast 15/31 ladder)
+__device__ __forceinline__ int wave_inclusive_max_dpp(int v, int identity) {
+  int a = v;
+  int t = __builtin_amdgcn_update_dpp(identity, v, 0x111 /* row_shr:1 */, 0xf, 0xf, false);
+  a = t > a ? t : a;
+  t = __builtin_amdgcn_update_dpp(identity, v, 0x112 /* row_shr:2 */, 0xf, 0xf, false);
+  a = t > a ? t : a;
+  t = __builtin_amdgcn_update_dpp(identity, v, 0x113 /* row_shr:3 */, 0xf, 0xf, false);
+  a = t > a ? t : a;
+  t = __builtin_amdgcn_update_dpp(identity, a, 0x114 /* row_shr:4 */, 0xf, 0xe, false);
+  a = t > a ? t : a;
+  t = __builtin_amdgcn_update_dpp(identity, a, 0x118 /* row_shr:8 */, 0xf, 0xc, false);
+  a = t > a ? t : a;
+  t = __builtin_amdgcn_update_dpp(identity, a, 0x142 /* row_bcast:15 */, 0xa, 0xf, false);
+  a = t > a ? t : a;
+  t = __builtin_amdgcn_update_dpp(identity, a, 0x143 /* row_bcast:31 */, 0xc, 0xf, false);
+  a = t > a ? t : a;
+  return a;
+}
+
 // Mask of lanes (among `valid` lanes) whose 8-bit digit equals this lane's digit.
 __device__ __forceinline__ unsigned long long match_digit8(unsigned d, bool valid) {
   unsigned long long peers = __ballot(valid);

@@ -33,7 +33,7 @@ SYMBOLS = [
     "rvn_engine_map_batch", "rvn_engine_map_fetch", "rvn_engine_map_fetch_filtered",
     "rvn_find_overlaps_and_create_piles", "rvn_pass1_pile_words", "rvn_pass1_num_overlaps",
     "rvn_pass1_fetch_piles", "rvn_pass1_fetch_overlaps", "rvn_pass1_destroy", "rvn_pile_add_layers",
-    "rvn_edit_distance_batch", "rvn_poa_consensus_batch",
+    "rvn_edit_distance_batch", "rvn_poa_consensus_batch", "rvn_poa_phase_cycles",
     "rvn_engine_sketch", "rvn_engine_sketch_fetch", "rvn_engine_index_size", "rvn_engine_index_fetch",
     "rvn_engine_counters", "rvn_engine_num_stages", "rvn_engine_stage_name", "rvn_engine_stage_ms",
     "rvn_engine_reset_stats", "rvn_engine_set_timing", "rvn_engine_set_kernel_timing",
@@ -86,6 +86,7 @@ def lib():
     L.rvn_edit_distance_batch.argtypes = [vp, vp, vp, u32, vp, C.POINTER(dbl), C.POINTER(u64)]
     L.rvn_poa_consensus_batch.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, u32, i32, i32, i32, i32, vp, vp, vp, vp,
                                           C.POINTER(dbl)]
+    L.rvn_poa_phase_cycles.argtypes = [vp, vp]
     L.rvn_engine_sketch.argtypes = [vp, vp, u32, u32, i32, C.POINTER(u64)]
     L.rvn_engine_sketch_fetch.argtypes = [vp, vp, vp, vp]
     L.rvn_engine_index_size.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
@@ -303,6 +304,11 @@ class Engine:
             _p(out), _p(ooff_a), _p(out_len), _p(status), C.byref(ms)))
         cons = [out[ooff[i]: ooff[i] + int(out_len[i])].copy() for i in range(nw)]
         return cons, status, ms.value
+
+    def poa_phase_cycles(self):
+        c = np.zeros(6, dtype=np.uint64)
+        lib().rvn_poa_phase_cycles(self._h, _p(c))
+        return dict(zip(("subgraph", "dp", "traceback", "add_alignment", "order", "consensus"), (int(x) for x in c)))
 
     # -- introspection ---------------------------------------------------------------------
     def sketch(self, reads: Reads, first=0, last=None, minhash=False):

@@ -53,6 +53,7 @@ def main():
            "windows_per_s": n_windows / ms * 1e3, "approx_gcups": cells / ms / 1e6,
            "status_counts": {int(k): int(v) for k, v in zip(*np.unique(status & 0xFF, return_counts=True))},
            "fail_layers": [int(x) >> 8 for x in status[status > 1][:20]], "fail_windows": [int(i) for i in np.nonzero(status > 1)[0][:20]],
+           "phase_cycles": eng.poa_phase_cycles(),
            "read_bases_per_s": sum(sum(len(x) for x in w["layers"][1:]) for w in wins) / ms * 1e3}
     if n_check:
         from oracle import oracle
