@@ -235,6 +235,112 @@ __device__ void wave_sort_segment(u64* __restrict__ k0, u64* __restrict__ k1, u6
   }
 }
 
+// ---- block-level segmented sort in LDS (per-read group sort) ---------------------------------------
+// One workgroup per segment of <= kSegLdsCap (key, payload) pairs: all LSD passes ping-pong between two LDS
+// buffers, HBM sees one coalesced read and one coalesced write (the global-memory version moved ~20x the
+// data, profiles/r01_g_final_pmc_*).  Larger segments are left to seg_sort_off_kernel.
+constexpr u32 kSegLdsCap = 2048;
+__global__ __launch_bounds__(256) void seg_sort_lds_kernel(u64* __restrict__ keys, u64* __restrict__ pays,
+                                                          const u64* __restrict__ off, u32 n_seg) {
+  __shared__ u64 s_k[2][kSegLdsCap];
+  __shared__ u64 s_p[2][kSegLdsCap];
+  __shared__ u16 wave_cnt[4][256];
+  __shared__ u32 s4[4];
+  __shared__ u64 s_or[4], s_and[4];
+  const u32 seg = blockIdx.x;
+  if (seg >= n_seg) return;
+  const u64 b = off[seg];
+  const u32 n = static_cast<u32>(off[seg + 1] - b);
+  if (n < 2 || n > kSegLdsCap) return;
+  const int lane = lane_id();
+  const int w = threadIdx.x >> 6;
+  u64 o = 0, a = ~0ULL;
+  for (u32 i = threadIdx.x; i < n; i += 256) {
+    const u64 k = keys[b + i];
+    s_k[0][i] = k;
+    s_p[0][i] = pays[b + i];
+    o |= k;
+    a &= k;
+  }
+#pragma unroll
+  for (int x = 32; x > 0; x >>= 1) {
+    o |= __shfl_xor(o, x, 64);
+    a &= __shfl_xor(a, x, 64);
+  }
+  if (lane == 0) {
+    s_or[w] = o;
+    s_and[w] = a;
+  }
+  __syncthreads();
+  const u64 varying = (s_or[0] | s_or[1] | s_or[2] | s_or[3]) ^ (s_and[0] & s_and[1] & s_and[2] & s_and[3]);
+  // wave w owns the contiguous quarter [q0, q1) of the segment (stable: rank order == index order)
+  const u32 per = (n + 3) / 4;
+  const u32 q0 = min(n, w * per), q1 = min(n, q0 + per);
+  const unsigned long long lt = lanemask_lt();
+  int cur = 0;
+  for (int shift = 0; shift < 64; shift += 8) {
+    if (((varying >> shift) & 0xFF) == 0) continue;
+    for (int i = threadIdx.x; i < 4 * 256; i += 256) (&wave_cnt[0][0])[i] = 0;
+    __syncthreads();
+    // pass 1: per-wave digit counts (kept as running ranks per element in registers is not possible for
+    // arbitrary n, so ranks are recomputed in pass 2 with the same ballot order)
+    for (u32 base = q0; base < q1; base += 64) {
+      const u32 i = base + lane;
+      const bool valid = i < q1;
+      const unsigned d = valid ? static_cast<unsigned>((s_k[cur][i] >> shift) & 0xFF) : 0;
+      const unsigned long long peers = match_digit8(d, valid);
+      if (valid && (peers & lt) == 0) wave_cnt[w][d] += static_cast<u16>(__popcll(peers));
+      __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    {
+      const int t = threadIdx.x;
+      u32 c[4], tot = 0;
+#pragma unroll
+      for (int x = 0; x < 4; ++x) {
+        c[x] = wave_cnt[x][t];
+        tot += c[x];
+      }
+      u32 total;
+      u32 run = block_exclusive_sum_256<u32>(tot, s4, &total);
+#pragma unroll
+      for (int x = 0; x < 4; ++x) {
+        wave_cnt[x][t] = static_cast<u16>(run);
+        run += c[x];
+      }
+    }
+    __syncthreads();
+    // pass 2: scatter in index order
+    for (u32 base = q0; base < q1; base += 64) {
+      const u32 i = base + lane;
+      const bool valid = i < q1;
+      u64 k = 0, pv = 0;
+      if (valid) {
+        k = s_k[cur][i];
+        pv = s_p[cur][i];
+      }
+      const unsigned d = static_cast<unsigned>((k >> shift) & 0xFF);
+      const unsigned long long peers = match_digit8(d, valid);
+      u32 before = 0;
+      if (valid) before = wave_cnt[w][d];
+      __builtin_amdgcn_wave_barrier();
+      if (valid && (peers & lt) == 0) wave_cnt[w][d] = static_cast<u16>(before + __popcll(peers));
+      __builtin_amdgcn_wave_barrier();
+      if (valid) {
+        const u32 dst = before + __popcll(peers & lt);
+        s_k[cur ^ 1][dst] = k;
+        s_p[cur ^ 1][dst] = pv;
+      }
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+  for (u32 i = threadIdx.x; i < n; i += 256) {
+    keys[b + i] = s_k[cur][i];
+    pays[b + i] = s_p[cur][i];
+  }
+}
+
 // segments given by off[seg], off[seg+1]
 __global__ __launch_bounds__(256) void seg_sort_off_kernel(u64* k0, u64* k1, u64* p0, u64* p1,
                                                           const u64* __restrict__ off, u32 n_seg) {
@@ -242,7 +348,7 @@ __global__ __launch_bounds__(256) void seg_sort_off_kernel(u64* k0, u64* k1, u64
   const u32 seg = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (seg >= n_seg) return;
   const u64 b = off[seg], e = off[seg + 1];
-  if (e - b < 2) return;
+  if (e - b <= kSegLdsCap) return;  // sorted by seg_sort_lds_kernel
   wave_sort_segment(k0, k1, p0, p1, b, e - b, hist[threadIdx.x >> 6]);
 }
 
@@ -423,6 +529,17 @@ __global__ __launch_bounds__(64) void chain_small_kernel(const u64* __restrict__
 #pragma unroll 8
   for (u32 i = 0; i < kChainSmallCap; ++i)
     if (i < n) s_pos[i][lane] = p[i];
+  // ram sorts the interval by positions before the LIS: <= 32 elements, private to the lane -> insertion sort
+  // (positions are distinct, so the result is the unique sorted order)
+  for (u32 i = 1; i < n; ++i) {
+    const u64 key = s_pos[i][lane];
+    u32 j = i;
+    while (j > 0 && s_pos[j - 1][lane] > key) {
+      s_pos[j][lane] = s_pos[j - 1][lane];
+      --j;
+    }
+    s_pos[j][lane] = key;
+  }
   u32 longest = 0;
   for (u32 it = 0; it < n; ++it) {
     const u64 cur = s_pos[it][lane];
@@ -715,7 +832,8 @@ void map_batch_impl(Engine& e, const ReadsDev& r, u32 first, u32 last, bool avoi
   u64* p1 = e.m_pos[1].as<u64>();
   {
     StageTimer t(e, StageTimes::kSegSort);
-    RVN_KLAUNCH(kKSegSortGroup, seg_sort_off_kernel<<<div_up(nr, 4), 256, 0, s>>>(g0, g1, p0, p1, seg_off, nr));
+    RVN_KLAUNCH(kKSegSortGroup, seg_sort_lds_kernel<<<nr, 256, 0, s>>>(g0, p0, seg_off, nr);
+                seg_sort_off_kernel<<<div_up(nr, 4), 256, 0, s>>>(g0, g1, p0, p1, seg_off, nr));
     t.stop();
   }
   u32 NI = 0;
@@ -753,7 +871,8 @@ void map_batch_impl(Engine& e, const ReadsDev& r, u32 first, u32 last, bool avoi
     u64* iv_end = e.iv_end.as<u64>();
     u32* iv_read = e.tmp_b.as<u32>();
     // sort every interval by positions (payload = group)
-    RVN_KLAUNCH(kKSegSortPos, seg_sort_be_kernel<<<div_up(NI, 4), 256, 0, s>>>(p0, p1, g0, g1, iv_begin, iv_end, NI, e.chain));
+    RVN_KLAUNCH(kKSegSortPos, seg_sort_be_kernel<<<div_up(NI, 4), 256, 0, s>>>(p0, p1, g0, g1, iv_begin, iv_end, NI,
+                                                                           std::max(e.chain, kChainSmallCap + 1)));
     u32* lis_min = e.lis_min.get<u32>(H + NI + 1);
     u32* lis_pred = e.lis_pred.get<u32>(H + 1);
     u64* lis_tail = e.lis_tail.get<u64>(H + NI + 1);
