@@ -91,6 +91,14 @@ void rvn_pass1_destroy(rvn_pass1* p);
 int rvn_pile_add_layers(rvn_engine* e, uint16_t* data, uint32_t cells, uint32_t id, const rvn_overlap* overlaps,
                         uint64_t n);
 
+/* raven::Pile::AddKmers (RavenLib/src/pile.cc:64-120; call site construct.cc:382) for reads
+ * [first_read, first_read + n_reads): `positions` are the `filtered` outputs of Map (rvn_engine_map_fetch_filtered)
+ * concatenated with position_offsets[n_reads+1]; `kmers` holds, per read, Pile::kmers_ as (len >> 4) + 1 bytes
+ * (0/1) at kmers_offsets[i]; cells of k-mers that pass the low-complexity filter are set to 1. */
+int rvn_pile_add_kmers_batch(rvn_engine* e, const rvn_reads* r, uint32_t first_read, uint32_t n_reads,
+                             const uint32_t* positions, const uint64_t* position_offsets, uint8_t* kmers,
+                             const uint64_t* kmers_offsets);
+
 /* Batched edlibAlign(lhs, rhs, edlibDefaultAlignConfig()).editDistance (global / NW, unit costs) between
  * spans of uploaded reads: RavenLib/src/construct.cc:176-199 (identity filter of ResolveContainedReads) and
  * :393-416 (second pass).  lhs/rhs_read are read INDICES in `r`; strand == 0 reverse-complements the rhs span
@@ -154,6 +162,7 @@ int rvn_engine_kernel_ms(rvn_engine* e, double* ms, uint64_t* launches, int n);
 /* host-side test hooks for the __host__ __device__ building blocks (no GPU needed) */
 uint64_t rvn_test_hash(uint64_t key, uint32_t k, int use32);
 int rvn_test_canonical(const uint64_t* words, uint32_t pos, uint32_t k, int use32, uint64_t* value, uint32_t* strand);
+int rvn_test_low_complexity(const uint8_t* codes, uint32_t k);
 void rvn_test_std_sort_lendesc(uint64_t* data, uint64_t n);
 void rvn_test_heap_sort_lendesc(uint64_t* data, uint64_t n);
 

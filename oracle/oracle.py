@@ -66,6 +66,7 @@ def lib():
             fn = getattr(L, "orc_pass1_" + name)
             fn.restype = rt
             fn.argtypes = [vp]
+        L.orc_pile_add_kmers.argtypes = [vp, u32, vp, u64, u32, vp]
         L.orc_antiqsort.argtypes = [vp, u32]
         L.orc_poa_window.restype = i32
         L.orc_poa_window.argtypes = [vp, vp, vp, vp, vp, u32, i32, i32, i32, i32, vp, u32, C.POINTER(u32)]
@@ -197,6 +198,16 @@ def truncate(overlaps: np.ndarray, kmax: int) -> np.ndarray:
     o = np.ascontiguousarray(overlaps).copy()
     n = lib().orc_truncate(_p(o), o.shape[0], kmax)
     return o[:n]
+
+
+def pile_add_kmers(rs, i: int, positions: np.ndarray, kmer_len: int) -> np.ndarray:
+    """Pile::AddKmers on read i: returns the kmers_ bitmap (cells + 1 entries, uint8)."""
+    cells = int(rs.lengths[i]) >> 4
+    out = np.zeros(cells + 1, dtype=np.uint8)
+    positions = np.ascontiguousarray(positions, dtype=np.uint32)
+    words = rs.packed[int(rs.word_offsets[i]):]
+    lib().orc_pile_add_kmers(_p(words), int(rs.lengths[i]), _p(positions), positions.shape[0], kmer_len, _p(out))
+    return out
 
 
 def antiqsort(n: int) -> np.ndarray:

@@ -762,6 +762,43 @@ std::uint32_t orc_pass1_occurrence(orc_pass1* p) { return p->r.last_occurrence; 
 double orc_pass1_t_minimize(orc_pass1* p) { return p->r.t_minimize; }
 double orc_pass1_t_map(orc_pass1* p) { return p->r.t_map; }
 
+// raven::Pile::AddKmers (RavenLib/src/pile.cc:64-120), literal: `kmers_cells` has cells + 1 entries
+// (pile.cc:71: kmers_.resize(data_.size() + 1)); positions are the `filtered` output of Map.
+void orc_pile_add_kmers(const std::uint64_t* words, std::uint32_t len, const std::uint32_t* positions,
+                        std::uint64_t n, std::uint32_t kmer_len, std::uint8_t* kmers_cells) {
+  orc::Read r{words, len, 0};
+  for (std::uint64_t q = 0; q < n; ++q) {
+    const std::uint32_t it = positions[q];
+    std::string kmer;
+    for (std::uint32_t i = 0; i < kmer_len; ++i) kmer += "ACGT"[r.Code(it + i)];  // InflateData(it, kmer_len)
+    std::vector<std::string> polymers;
+    for (const auto& c : kmer) polymers.emplace_back(1, c);
+    polymers.erase(std::unique(polymers.begin(), polymers.end()), polymers.end());
+    kmer.clear();
+    for (const auto& p : polymers) kmer += p;
+    if (kmer.size() < kmer_len / 2 + 1) continue;
+    polymers.clear();
+    for (auto jt = kmer.begin(); jt != kmer.end(); ++jt) {
+      if ((jt - kmer.begin()) % 2 == 1) polymers.back() += *jt;
+      else polymers.emplace_back(1, *jt);
+    }
+    polymers.erase(std::unique(polymers.begin(), polymers.end()), polymers.end());
+    kmer.clear();
+    for (const auto& p : polymers) kmer += p;
+    if (kmer.size() < kmer_len / 2 + 1) continue;
+    polymers.clear();
+    for (auto jt = kmer.begin(); jt != kmer.end(); ++jt) {
+      if (!polymers.empty() && (jt - kmer.begin()) % 2 == 0) polymers.back() += *jt;
+      else polymers.emplace_back(1, *jt);
+    }
+    polymers.erase(std::unique(polymers.begin(), polymers.end()), polymers.end());
+    kmer.clear();
+    for (const auto& p : polymers) kmer += p;
+    if (kmer.size() < kmer_len / 2 + 1) continue;
+    kmers_cells[it >> orc::kPSS] = 1;
+  }
+}
+
 // McIlroy's "killer adversary for quicksort" run against std::sort itself: produces values on which
 // libstdc++'s introsort exhausts its depth limit and falls back to heapsort (used to test that the device
 // restatement of std::sort follows the same path).

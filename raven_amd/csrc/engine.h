@@ -172,6 +172,9 @@ struct PileState {
 };
 void piles_init(Engine& e, const ReadsDev& r, PileState& ps);
 void piles_merge(Engine& e, const ReadsDev& r, const MapOut& mo, u32 kmax, PileState& ps);
+// Pile::AddKmers for reads [first_read, first_read + n_reads) (pile.hip)
+void pile_add_kmers_batch(Engine& e, const ReadsDev& r, const u32* h_pos, const u64* h_pos_off, u32 n_reads,
+                          u32 first_read, u8* h_out, const u64* h_out_off);
 // Pile::AddLayers on a single pile (ps initialised for one read); h_ovl is a host array
 void pile_add_layers_single(Engine& e, PileState& ps, const u32* d_ids, const Overlap* h_ovl, u32 n);
 

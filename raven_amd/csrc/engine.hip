@@ -8,6 +8,7 @@
 #include "../../include/raven_hip.h"
 #include "introsort.h"
 #include "kmer.h"
+#include "lowcomplexity.h"
 
 using namespace rvn;
 
@@ -416,6 +417,29 @@ int rvn_pile_add_layers(rvn_engine* h, uint16_t* data, uint32_t cells, uint32_t 
   });
 }
 
+int rvn_pile_add_kmers_batch(rvn_engine* h, const rvn_reads* r, uint32_t first_read, uint32_t n_reads,
+                             const uint32_t* positions, const uint64_t* position_offsets, uint8_t* kmers,
+                             const uint64_t* kmers_offsets) {
+  return guarded([&]() -> int {
+    if (!h || !r || (n_reads && (!position_offsets || !kmers || !kmers_offsets)))
+      return fail(RVN_EINVAL, "[raven_hip] NULL argument");
+    const ReadsDev& rd = r->r;
+    if (static_cast<u64>(first_read) + n_reads > rd.n) return fail(RVN_EINVAL, "[raven_hip] bad read range");
+    for (uint32_t i = 0; i < n_reads; ++i) {
+      const u32 len = rd.h_len[first_read + i];
+      if (kmers_offsets[i + 1] - kmers_offsets[i] < (static_cast<u64>(len) >> 4) + 1)
+        return fail(RVN_EINVAL, "[raven_hip] rvn_pile_add_kmers_batch: kmers buffer smaller than (len >> 4) + 1");
+      for (uint64_t q = position_offsets[i]; q < position_offsets[i + 1]; ++q)
+        if (static_cast<u64>(positions[q]) + h->e.k > len)
+          return fail(RVN_EINVAL, "[raven_hip] rvn_pile_add_kmers_batch: k-mer position outside its read");
+    }
+    RVN_HIP(hipSetDevice(h->e.device));
+    UseTimers ut(h->e);
+    pile_add_kmers_batch(h->e, rd, positions, position_offsets, n_reads, first_read, kmers, kmers_offsets);
+    return RVN_OK;
+  });
+}
+
 int rvn_edit_distance_batch(rvn_engine* h, const rvn_reads* r, const rvn_ed_pair* pairs, uint32_t n_pairs,
                             uint32_t* distances, double* device_ms, uint64_t* cells) {
   return guarded([&]() -> int {
@@ -611,6 +635,8 @@ int rvn_test_canonical(const uint64_t* words, uint32_t pos, uint32_t k, int use3
   *strand = st;
   return ok ? 1 : 0;
 }
+
+int rvn_test_low_complexity(const uint8_t* codes, uint32_t k) { return lc_kmer_passes(codes, k) ? 1 : 0; }
 
 void rvn_test_std_sort_lendesc(uint64_t* data, uint64_t n) { std_sort(data, data + n, LenDesc()); }
 void rvn_test_heap_sort_lendesc(uint64_t* data, uint64_t n) { intro::heap_sort(data, data + n, LenDesc()); }

@@ -183,6 +183,56 @@ void piles_init(Engine& e, const ReadsDev& r, PileState& ps) {
   RVN_HIP(hipStreamSynchronize(e.stream));  // `off` is a stack-owned host buffer
 }
 
+}  // namespace rvn
+#include "kmer.h"
+#include "lowcomplexity.h"
+namespace rvn {
+namespace {
+// Pile::AddKmers for a batch of reads: one lane per filtered position; marks out[pile_off[read] + (pos >> 4)].
+__global__ void add_kmers_kernel(const u64* __restrict__ packed, const u64* __restrict__ word_off,
+                                 const u32* __restrict__ pos, const u32* __restrict__ pos_read, u64 n, u32 k,
+                                 const u64* __restrict__ out_off, u8* __restrict__ out) {
+  const u64 q = static_cast<u64>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (q >= n) return;
+  const u32 r = pos_read[q], p = pos[q];
+  const u64* w = packed + word_off[r];
+  const u64 mask = (1ULL << (2 * k)) - 1;
+  const u32 bit = 2 * p;
+  const u64 x = extract_bits(w[bit >> 6], w[(bit >> 6) + 1], bit & 63, mask);
+  u8 codes[32];
+  for (u32 i = 0; i < k; ++i) codes[i] = static_cast<u8>((x >> (2 * i)) & 3);
+  if (lc_kmer_passes(codes, k)) out[out_off[r] + (p >> kPSS)] = 1;
+}
+}  // namespace
+
+// h_pos: filtered positions of all reads concatenated, h_pos_off[n_reads+1]; h_out: per read (len>>4)+1 bytes,
+// concatenated at h_out_off (OR-ed into the existing content, like repeated AddKmers calls)
+void pile_add_kmers_batch(Engine& e, const ReadsDev& r, const u32* h_pos, const u64* h_pos_off, u32 n_reads,
+                          u32 first_read, u8* h_out, const u64* h_out_off) {
+  const u64 n = h_pos_off[n_reads];
+  if (n == 0) return;
+  hipStream_t s = e.stream;
+  std::vector<u32> pos_read(n);
+  for (u32 i = 0; i < n_reads; ++i)
+    for (u64 q = h_pos_off[i]; q < h_pos_off[i + 1]; ++q) pos_read[q] = first_read + i;
+  // out_off indexed by absolute read index
+  std::vector<u64> off(static_cast<size_t>(r.n) + 1, 0);
+  for (u32 i = 0; i < n_reads; ++i) off[first_read + i] = h_out_off[i];
+  const u64 out_total = h_out_off[n_reads];
+  u32* d_pos = e.tmp_a.get<u32>(n + 1);
+  u32* d_pr = e.tmp_b.get<u32>(n + 1);
+  u64* d_off = e.tmp_c.get<u64>(off.size() + 1);
+  u8* d_out = e.tmp_d.get<u8>(out_total + 16);
+  RVN_HIP(hipMemcpyAsync(d_pos, h_pos, n * 4, hipMemcpyHostToDevice, s));
+  RVN_HIP(hipMemcpyAsync(d_pr, pos_read.data(), n * 4, hipMemcpyHostToDevice, s));
+  RVN_HIP(hipMemcpyAsync(d_off, off.data(), off.size() * 8, hipMemcpyHostToDevice, s));
+  RVN_HIP(hipMemcpyAsync(d_out, h_out, out_total, hipMemcpyHostToDevice, s));
+  RVN_KLAUNCH(kKAddKmers, add_kmers_kernel<<<div_up(n, 256), 256, 0, s>>>(r.packed.as<u64>(), r.word_off.as<u64>(), d_pos,
+                                                                          d_pr, n, e.k, d_off, d_out));
+  RVN_HIP(hipMemcpyAsync(h_out, d_out, out_total, hipMemcpyDeviceToHost, s));
+  RVN_HIP(hipStreamSynchronize(s));
+}
+
 void pile_add_layers_single(Engine& e, PileState& ps, const u32* d_ids, const Overlap* h_ovl, u32 n) {
   hipStream_t s = e.stream;
   Overlap* list = ps.new_list.get<Overlap>(static_cast<size_t>(n) + 1);

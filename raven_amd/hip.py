@@ -33,7 +33,8 @@ SYMBOLS = [
     "rvn_engine_map_batch", "rvn_engine_map_fetch", "rvn_engine_map_fetch_filtered",
     "rvn_find_overlaps_and_create_piles", "rvn_pass1_pile_words", "rvn_pass1_num_overlaps",
     "rvn_pass1_fetch_piles", "rvn_pass1_fetch_overlaps", "rvn_pass1_destroy", "rvn_pile_add_layers",
-    "rvn_edit_distance_batch", "rvn_poa_consensus_batch", "rvn_poa_phase_cycles",
+    "rvn_edit_distance_batch", "rvn_poa_consensus_batch", "rvn_poa_phase_cycles", "rvn_pile_add_kmers_batch",
+    "rvn_test_low_complexity",
     "rvn_engine_sketch", "rvn_engine_sketch_fetch", "rvn_engine_index_size", "rvn_engine_index_fetch",
     "rvn_engine_counters", "rvn_engine_num_stages", "rvn_engine_stage_name", "rvn_engine_stage_ms",
     "rvn_engine_reset_stats", "rvn_engine_set_timing", "rvn_engine_set_kernel_timing",
@@ -83,6 +84,9 @@ def lib():
     L.rvn_pass1_fetch_overlaps.argtypes = [vp, vp, vp]
     L.rvn_pass1_destroy.argtypes = [vp]
     L.rvn_pile_add_layers.argtypes = [vp, vp, u32, u32, vp, u64]
+    L.rvn_pile_add_kmers_batch.argtypes = [vp, vp, u32, u32, vp, vp, vp, vp]
+    L.rvn_test_low_complexity.restype = i32
+    L.rvn_test_low_complexity.argtypes = [vp, u32]
     L.rvn_edit_distance_batch.argtypes = [vp, vp, vp, u32, vp, C.POINTER(dbl), C.POINTER(u64)]
     L.rvn_poa_consensus_batch.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, u32, i32, i32, i32, i32, vp, vp, vp, vp,
                                           C.POINTER(dbl)]
@@ -250,6 +254,22 @@ class Engine:
         overlaps = np.ascontiguousarray(overlaps)
         _check(lib().rvn_pile_add_layers(self._h, _p(data), data.shape[0], pile_id, _p(overlaps),
                                          overlaps.shape[0]))
+
+    # -- raven::Pile::AddKmers, batched ---------------------------------------------------------------
+    def pile_add_kmers_batch(self, reads: Reads, first, positions_per_read):
+        """positions_per_read: list of uint32 arrays (the `filtered` output of Map per read, starting at read
+        `first`).  Returns a list of uint8 arrays, Pile::kmers_ of each read ((len >> 4) + 1 entries)."""
+        n = len(positions_per_read)
+        poff = np.zeros(n + 1, dtype=np.uint64)
+        np.cumsum([len(x) for x in positions_per_read], out=poff[1:])
+        pos = (np.concatenate([np.asarray(x, dtype=np.uint32) for x in positions_per_read])
+               if n and poff[-1] else np.zeros(1, np.uint32))
+        sizes = [(int(reads.rs.lengths[first + i]) >> 4) + 1 for i in range(n)]
+        koff = np.zeros(n + 1, dtype=np.uint64)
+        np.cumsum(sizes, out=koff[1:])
+        out = np.zeros(int(koff[-1]) + 1, dtype=np.uint8)
+        _check(lib().rvn_pile_add_kmers_batch(self._h, reads._h, first, n, _p(pos), _p(poff), _p(out), _p(koff)))
+        return [out[int(koff[i]): int(koff[i + 1])].copy() for i in range(n)]
 
     # -- edlibAlign(default config).editDistance, batched -----------------------------------------
     def edit_distance_batch(self, reads: Reads, pairs: np.ndarray):

@@ -231,3 +231,35 @@ def test_full_size_properties(gpu):
     # recoverable after truncation either; check saturation-free and plausibility (30x, both directions)
     assert data.max() < 65535 and 15 < data.mean() < 40
     assert c["index_bases"] == rs.total_bases and c["query_bases"] == rs.total_bases
+
+
+def test_second_pass_pieces_filtered_and_add_kmers(gpu):
+    """Device pieces of FindOverlapsAndRepetetiveRegions (construct.cc:363-382): full (non-minhash) index,
+    Map(..., minhash=false, &filtered) and Pile::AddKmers on the filtered positions, on a genome with repeats."""
+    g = synth.make_genome(60_000, seed=61)
+    rep = g[1000:3000].copy()
+    for off in (10_000, 25_000, 40_000, 52_000):  # 2 kb repeat, 5 copies -> high-occurrence minimizers
+        g[off:off + 2000] = rep
+    g[30_000:30_400] = 0                            # a homopolymer island (low complexity)
+    rs, _ = synth.make_reads(g, 15, 5000, seed=62, sub=0.01, ins=0.005, dele=0.005)
+    he, oe = _mk()
+    rd = he.upload(rs)
+    he.minimize(rd, 0, rs.n, False)
+    oe.minimize(rs, 0, rs.n, False)
+    he.filter(0.02)
+    oe.filter(0.02)
+    assert he.occurrence == oe.occurrence
+    res = he.map_batch(rd, 0, rs.n, True, True, False, want_filtered=True)
+    per_read = [res["filtered"][res["filtered_offsets"][i]: res["filtered_offsets"][i + 1]] for i in range(rs.n)]
+    assert sum(len(x) for x in per_read) > 100
+    got = he.pile_add_kmers_batch(rd, 0, per_read)
+    marked = 0
+    for i in range(rs.n):
+        ref = oe.map(rs, i, True, True, False)
+        assert np.array_equal(per_read[i], ref["filtered"])
+        want = oracle.pile_add_kmers(rs, i, ref["filtered"], 15)
+        assert np.array_equal(got[i], want), i
+        marked += int(want.sum())
+    assert marked > 10
+    with pytest.raises(ValueError):
+        he.pile_add_kmers_batch(rd, 0, [np.array([int(rs.lengths[0])], np.uint32)])

@@ -113,3 +113,33 @@ def test_device_heapsort_is_a_sort():
         got = (keys >> np.uint64(32)).astype(np.int64)
         assert np.all(np.diff(got) <= 0)
         assert sorted((keys & np.uint64(0xFFFFFFFF)).tolist()) == list(range(n))
+
+
+@pytest.mark.parametrize("k", [5, 15, 16, 19, 31])
+def test_low_complexity_filter_matches_pile_cc(k):
+    """rvn::lc_kmer_passes (used by the AddKmers kernel) vs the literal std::string restatement of
+    RavenLib/src/pile.cc:73-117 in the oracle, on random, homopolymer-rich and short-period k-mers."""
+    L = hip.lib()
+    rng = np.random.default_rng(k)
+    reads = []
+    for period in (1, 2, 3, 4, 5, 7):
+        unit = rng.integers(0, 4, size=period, dtype=np.uint8)
+        rep = np.tile(unit, 400 // period + 1)[:400]
+        noise = rng.random(400) < 0.08
+        rep[noise] = rng.integers(0, 4, size=int(noise.sum()), dtype=np.uint8)
+        reads.append(rep)
+    reads.append(rng.integers(0, 4, size=600, dtype=np.uint8))
+    runs = np.repeat(rng.integers(0, 4, size=200, dtype=np.uint8), rng.integers(1, 6, size=200))
+    reads.append(runs[:600].astype(np.uint8))
+    rs = seqio.pack_reads(reads)
+    n_pass = n_fail = 0
+    for i in range(rs.n):
+        codes = rs.codes(i)
+        for p in range(0, codes.shape[0] - k + 1, 3):
+            want = oracle.pile_add_kmers(rs, i, np.array([p], np.uint32), k)
+            kc = np.ascontiguousarray(codes[p:p + k])
+            got = L.rvn_test_low_complexity(kc.ctypes.data_as(C.c_void_p), k)
+            assert got == int(want[p >> 4]), (i, p, kc.tolist())
+            n_pass += got
+            n_fail += 1 - got
+    assert n_pass > 20 and n_fail > 20
