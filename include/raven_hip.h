@@ -131,6 +131,23 @@ int rvn_poa_consensus_batch(rvn_engine* e, const uint8_t* codes, const uint8_t* 
                             int trim, uint8_t* consensus, const uint64_t* consensus_offsets, uint32_t* consensus_len,
                             uint32_t* status, double* device_ms);
 
+/* One polishing round == racon::Polisher::Polish(targets, sequences, drop_unpolished = false) as raven::Polish calls
+ * it (RavenLib/src/polish.cc:43-51: e = 0.3, w = 500, trim = true; `q` = the average read quality computed at
+ * polish.cc:26-41; match/mismatch/gap = AlignCfg).  `e` must have been created with k = 15, w = 5 (racon's own
+ * minimizer engine).  targets / reads are uploaded read sets; read_quals = per-base Phred+33 of every read
+ * concatenated in read order (qual_offsets[n_reads+1]) or NULL.  Output: polished base codes of target t at
+ * out_offsets[t] (capacity out_offsets[t+1]-out_offsets[t]; 2 x length + 1024 is ample), out_len[t], and the
+ * polished-window ratio racon writes into the XC:f: tag (polish.cc:57-59 tests it for > 0).
+ * Window breakpoints come from the mapping's chain anchors instead of an edlib path. */
+typedef struct rvn_polish_stats {
+  uint64_t n_overlaps, n_reads_used, n_layers, n_windows, n_polished_windows, n_failed_windows;
+  double poa_ms;
+} rvn_polish_stats;
+int rvn_polish_round(rvn_engine* e, rvn_reads* targets, rvn_reads* reads, const uint8_t* read_quals,
+                     const uint64_t* qual_offsets, double q, double err, uint32_t w, int trim, int match, int mismatch,
+                     int gap, uint8_t* out_codes, const uint64_t* out_offsets, uint32_t* out_len, double* ratio,
+                     rvn_polish_stats* stats);
+
 /* shader-clock cycles summed over all windows of the last rvn_poa_consensus_batch call, per phase:
  * {subgraph, NW matrix, traceback, AddAlignment, order rebuild, consensus} */
 void rvn_poa_phase_cycles(const rvn_engine* e, uint64_t out[6]);

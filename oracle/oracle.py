@@ -67,6 +67,9 @@ def lib():
             fn.restype = rt
             fn.argtypes = [vp]
         L.orc_pile_add_kmers.argtypes = [vp, u32, vp, u64, u32, vp]
+        L.orc_polish_round.restype = i32
+        L.orc_polish_round.argtypes = [vp, vp, vp, vp, u32, vp, vp, vp, vp, u32, vp, vp, dbl, dbl, u32, i32, i32, i32, i32, vp, vp,
+                                       vp, vp]
         L.orc_antiqsort.argtypes = [vp, u32]
         L.orc_poa_window.restype = i32
         L.orc_poa_window.argtypes = [vp, vp, vp, vp, vp, u32, i32, i32, i32, i32, vp, u32, C.POINTER(u32)]
@@ -208,6 +211,27 @@ def pile_add_kmers(rs, i: int, positions: np.ndarray, kmer_len: int) -> np.ndarr
     words = rs.packed[int(rs.word_offsets[i]):]
     lib().orc_pile_add_kmers(_p(words), int(rs.lengths[i]), _p(positions), positions.shape[0], kmer_len, _p(out))
     return out
+
+
+def polish_round(targets, reads, quals=None, q=0.0, err=0.3, w=500, trim=True, m=3, n=-5, g=-4):
+    """racon::Polisher::Polish restatement (one round). targets/reads: ReadSet; quals: list of Phred+33 arrays."""
+    nt = targets.n
+    ooff = np.zeros(nt + 1, dtype=np.uint64)
+    np.cumsum(2 * targets.lengths.astype(np.uint64) + 1024, out=ooff[1:])
+    out = np.zeros(int(ooff[-1]) + 1, dtype=np.uint8)
+    out_len = np.zeros(nt, dtype=np.uint32)
+    ratio = np.zeros(nt, dtype=np.float64)
+    qa = qo = None
+    if quals is not None:
+        qo = np.zeros(len(quals) + 1, dtype=np.uint64)
+        np.cumsum([len(x) for x in quals], out=qo[1:])
+        qa = np.concatenate([np.asarray(x, dtype=np.uint8) for x in quals])
+    rc = lib().orc_polish_round(_p(targets.packed), _p(targets.word_offsets), _p(targets.lengths), _p(targets.ids), nt,
+                                _p(reads.packed), _p(reads.word_offsets), _p(reads.lengths), _p(reads.ids), reads.n,
+                                _p(qa), _p(qo), float(q), float(err), w, int(trim), m, n, g, _p(out), _p(ooff),
+                                _p(out_len), _p(ratio))
+    assert rc == 0
+    return [out[int(ooff[i]): int(ooff[i]) + int(out_len[i])].copy() for i in range(nt)], ratio
 
 
 def antiqsort(n: int) -> np.ndarray:

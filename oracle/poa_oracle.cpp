@@ -23,6 +23,8 @@
 #include <utility>
 #include <vector>
 
+#include "poa_oracle.h"
+
 namespace poa {
 
 using Alignment = std::vector<std::pair<std::int32_t, std::int32_t>>;  // (node id | -1, sequence pos | -1)
@@ -384,12 +386,6 @@ static Alignment AlignNW(const std::uint8_t* seq, std::uint32_t len, const Graph
   return alignment;
 }
 
-struct Layer {
-  const std::uint8_t* codes;
-  const std::uint8_t* qual;  // Phred+33 characters or nullptr
-  std::uint32_t len, begin, end;
-};
-
 static std::vector<std::uint32_t> Weights(const Layer& l) {
   std::vector<std::uint32_t> w(l.len, 1);
   if (l.qual)
@@ -398,7 +394,7 @@ static std::vector<std::uint32_t> Weights(const Layer& l) {
 }
 
 // racon Window::GenerateConsensus (TGS). layers[0] is the backbone. Returns polished flag.
-static bool WindowConsensus(const std::vector<Layer>& layers, std::int8_t m, std::int8_t n, std::int8_t g, bool trim,
+bool WindowConsensus(const std::vector<Layer>& layers, std::int8_t m, std::int8_t n, std::int8_t g, bool trim,
                             std::vector<std::uint8_t>* consensus, std::vector<std::uint32_t>* coverages_out) {
   const Layer& bb = layers.front();
   if (layers.size() < 3) {

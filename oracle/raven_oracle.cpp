@@ -31,6 +31,8 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstdint>
 #include <cstring>
 #include <deque>
@@ -41,6 +43,8 @@
 #include <unordered_map>
 #include <utility>
 #include <vector>
+
+#include "poa_oracle.h"
 
 namespace orc {
 
@@ -798,6 +802,169 @@ void orc_pile_add_kmers(const std::uint64_t* words, std::uint32_t len, const std
     kmers_cells[it >> orc::kPSS] = 1;
   }
 }
+
+}  // extern "C" (reopened below)
+
+// ---- racon::Polisher::Polish, one round (recollection of racon@library polisher.cpp /
+// overlap.cpp / window.cpp; raven call site RavenLib/src/polish.cc:43-51) --------------------------------
+// (1) ram(15,5) index of the targets, Filter(0.001), Map(read, false, false); keep the longest overlap per read,
+// drop it if 1 - min(span)/max(span) > e; (2) reverse-complement reads on the opposite strand; (3) global NW
+// path (edlib EDLIB_TASK_PATH: any optimal unit-cost path; here a plain DP with diagonal-first traceback)
+// -> standard CIGAR -> racon's find_breaking_points_from_cigar; (4) windows of w target bases with a dummy '!'
+// backbone quality, layers >= 0.02 w and mean quality >= q; (5) Window::GenerateConsensus; (6) stitch + ratio.
+namespace orc {
+
+static void NwPath(const std::vector<std::uint8_t>& q, const std::vector<std::uint8_t>& t, std::vector<char>* ops) {
+  // ops from the start: 'M' (match/mismatch), 'I' (query base only), 'D' (target base only)
+  const std::size_t n = q.size(), m = t.size();
+  std::vector<std::uint32_t> prev(m + 1), cur(m + 1);
+  std::vector<std::uint8_t> dir((n + 1) * (m + 1));
+  for (std::size_t j = 0; j <= m; ++j) { prev[j] = j; dir[j] = 2; }
+  for (std::size_t i = 1; i <= n; ++i) {
+    cur[0] = i;
+    dir[i * (m + 1)] = 1;
+    for (std::size_t j = 1; j <= m; ++j) {
+      std::uint32_t d = prev[j - 1] + (q[i - 1] != t[j - 1]), u = prev[j] + 1, l = cur[j - 1] + 1;
+      std::uint32_t best = std::min(d, std::min(u, l));
+      cur[j] = best;
+      dir[i * (m + 1) + j] = best == d ? 0 : (best == u ? 1 : 2);
+    }
+    prev.swap(cur);
+  }
+  ops->clear();
+  std::size_t i = n, j = m;
+  while (i > 0 || j > 0) {
+    std::uint8_t d = dir[i * (m + 1) + j];
+    if (i > 0 && j > 0 && d == 0) { ops->push_back('M'); --i; --j; }
+    else if (i > 0 && (d == 1 || j == 0)) { ops->push_back('I'); --i; }
+    else { ops->push_back('D'); --j; }
+  }
+  std::reverse(ops->begin(), ops->end());
+}
+
+}  // namespace orc
+
+extern "C" int orc_polish_round(const std::uint64_t* t_packed, const std::uint64_t* t_word_off, const std::uint32_t* t_len,
+                     const std::uint32_t* t_ids, std::uint32_t n_targets, const std::uint64_t* r_packed,
+                     const std::uint64_t* r_word_off, const std::uint32_t* r_len, const std::uint32_t* r_ids,
+                     std::uint32_t n_reads, const std::uint8_t* quals, const std::uint64_t* qual_off, double q_thr,
+                     double err_thr, std::uint32_t w, int trim, int m, int n, int g, std::uint8_t* out,
+                     const std::uint64_t* out_off, std::uint32_t* out_len, double* ratio) {
+  auto targets = MakeReads(t_packed, t_word_off, t_len, t_ids, n_targets);
+  auto reads = MakeReads(r_packed, r_word_off, r_len, r_ids, n_reads);
+  orc::MinimizerEngine engine(15, 5, 500, 4, 100, 10000);
+  engine.Minimize(targets.data(), targets.data() + n_targets, false, 1);
+  engine.Filter(0.001);
+  std::vector<std::uint32_t> id_to_t;
+  for (std::uint32_t t = 0; t < n_targets; ++t) {
+    if (targets[t].id >= id_to_t.size()) id_to_t.resize(targets[t].id + 1, 0xFFFFFFFFu);
+    id_to_t[targets[t].id] = t;
+  }
+  std::vector<std::uint64_t> first_window(n_targets + 1, 0);
+  for (std::uint32_t t = 0; t < n_targets; ++t) first_window[t + 1] = first_window[t] + (targets[t].len + w - 1) / w;
+  struct LayerData { std::vector<std::uint8_t> codes, qual; std::uint32_t begin, end; };
+  std::vector<std::vector<LayerData>> win_layers(first_window[n_targets]);
+
+  for (std::uint32_t r = 0; r < n_reads; ++r) {
+    auto ovl = engine.Map(reads[r], false, false, false, nullptr);
+    if (ovl.empty()) continue;
+    auto length = [](const orc::Overlap& o) { return std::max(o.lhs_end - o.lhs_begin, o.rhs_end - o.rhs_begin); };
+    orc::Overlap best = ovl.front();
+    for (const auto& o : ovl) if (length(best) < length(o)) best = o;
+    double a = best.lhs_end - best.lhs_begin, b = best.rhs_end - best.rhs_begin;
+    if (1.0 - std::min(a, b) / std::max(a, b) > err_thr) continue;
+    if (best.rhs_id >= id_to_t.size() || id_to_t[best.rhs_id] == 0xFFFFFFFFu) continue;
+    const std::uint32_t t = id_to_t[best.rhs_id];
+    const std::uint32_t qlen = reads[r].len;
+    // read in the target's orientation, with qualities
+    std::vector<std::uint8_t> rq(qlen), rqual;
+    const bool rc = !best.strand;
+    for (std::uint32_t i = 0; i < qlen; ++i) rq[i] = rc ? 3 - reads[r].Code(qlen - 1 - i) : reads[r].Code(i);
+    if (quals) {
+      rqual.resize(qlen);
+      for (std::uint32_t i = 0; i < qlen; ++i) rqual[i] = quals[qual_off[r] + (rc ? qlen - 1 - i : i)];
+    }
+    const std::uint32_t q_begin = rc ? qlen - best.lhs_end : best.lhs_begin;
+    const std::uint32_t q_end = rc ? qlen - best.lhs_begin : best.lhs_end;
+    std::vector<std::uint8_t> qs(rq.begin() + q_begin, rq.begin() + q_end), ts(best.rhs_end - best.rhs_begin);
+    for (std::uint32_t i = 0; i < ts.size(); ++i) ts[i] = targets[t].Code(best.rhs_begin + i);
+    std::vector<char> ops;
+    orc::NwPath(qs, ts, &ops);
+    // racon Overlap::find_breaking_points_from_cigar
+    std::vector<std::int64_t> window_ends;
+    for (std::uint32_t i = 0; i < best.rhs_end; i += w)
+      if (i > best.rhs_begin) window_ends.push_back(static_cast<std::int64_t>(i) - 1);
+    window_ends.push_back(static_cast<std::int64_t>(best.rhs_end) - 1);
+    std::vector<std::pair<std::uint32_t, std::uint32_t>> bp;
+    std::size_t wi = 0;
+    bool found_first = false;
+    std::pair<std::uint32_t, std::uint32_t> first_match{0, 0}, last_match{0, 0};
+    std::int64_t q_ptr = static_cast<std::int64_t>(q_begin) - 1, t_ptr = static_cast<std::int64_t>(best.rhs_begin) - 1;
+    for (char op : ops) {
+      if (op == 'M') {
+        ++q_ptr; ++t_ptr;
+        if (!found_first) { found_first = true; first_match = {static_cast<std::uint32_t>(t_ptr), static_cast<std::uint32_t>(q_ptr)}; }
+        last_match = {static_cast<std::uint32_t>(t_ptr + 1), static_cast<std::uint32_t>(q_ptr + 1)};
+        if (wi < window_ends.size() && t_ptr == window_ends[wi]) {
+          if (found_first) { bp.push_back(first_match); bp.push_back(last_match); }
+          found_first = false;
+          ++wi;
+        }
+      } else if (op == 'I') {
+        ++q_ptr;
+      } else {
+        ++t_ptr;
+        if (wi < window_ends.size() && t_ptr == window_ends[wi]) {
+          if (found_first) { bp.push_back(first_match); bp.push_back(last_match); }
+          found_first = false;
+          ++wi;
+        }
+      }
+    }
+    for (std::size_t j = 0; j + 1 < bp.size(); j += 2) {
+      if (bp[j + 1].second - bp[j].second < 0.02 * w) continue;
+      if (quals) {
+        double sum = 0;
+        for (std::uint32_t x = bp[j].second; x < bp[j + 1].second; ++x) sum += static_cast<double>(rqual[x]) - 33.0;
+        if (sum / (bp[j + 1].second - bp[j].second) < q_thr) continue;
+      }
+      const std::uint64_t window_id = first_window[t] + bp[j].first / w;
+      const std::uint32_t window_start = (bp[j].first / w) * w;
+      LayerData L;
+      L.codes.assign(rq.begin() + bp[j].second, rq.begin() + bp[j + 1].second);
+      if (quals) L.qual.assign(rqual.begin() + bp[j].second, rqual.begin() + bp[j + 1].second);
+      L.begin = bp[j].first - window_start;
+      L.end = bp[j + 1].first - window_start - 1;
+      if (L.begin >= L.end) continue;  // racon's AddLayer would reject it
+      win_layers[window_id].push_back(std::move(L));
+    }
+  }
+  for (std::uint32_t t = 0; t < n_targets; ++t) {
+    std::vector<std::uint8_t> polished;
+    std::uint64_t nw = first_window[t + 1] - first_window[t], n_pol = 0;
+    for (std::uint64_t k = 0; k < nw; ++k) {
+      const std::uint32_t ws = static_cast<std::uint32_t>(k) * w;
+      const std::uint32_t bl = std::min<std::uint32_t>(w, targets[t].len - ws);
+      std::vector<std::uint8_t> bb(bl), bbq(bl, '!');
+      for (std::uint32_t x = 0; x < bl; ++x) bb[x] = targets[t].Code(ws + x);
+      std::vector<poa::Layer> layers;
+      layers.push_back(poa::Layer{bb.data(), bbq.data(), bl, 0, bl ? bl - 1 : 0});
+      for (const auto& L : win_layers[first_window[t] + k])
+        layers.push_back(poa::Layer{L.codes.data(), L.qual.empty() ? nullptr : L.qual.data(),
+                                    static_cast<std::uint32_t>(L.codes.size()), L.begin, std::min(L.end, bl - 1)});
+      std::vector<std::uint8_t> cons;
+      n_pol += poa::WindowConsensus(layers, m, n, g, trim != 0, &cons, nullptr) ? 1 : 0;
+      polished.insert(polished.end(), cons.begin(), cons.end());
+    }
+    if (polished.size() > out_off[t + 1] - out_off[t]) return -1;
+    std::memcpy(out + out_off[t], polished.data(), polished.size());
+    out_len[t] = polished.size();
+    ratio[t] = nw ? static_cast<double>(n_pol) / nw : 0.0;
+  }
+  return 0;
+}
+
+extern "C" {
 
 // McIlroy's "killer adversary for quicksort" run against std::sort itself: produces values on which
 // libstdc++'s introsort exhausts its depth limit and falls back to heapsort (used to test that the device

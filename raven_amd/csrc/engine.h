@@ -22,6 +22,7 @@ struct ReadsDev {
   DevBuf len;       // u32[n]
   DevBuf id;        // u32[n]
   std::vector<u64> h_word_off;
+  std::vector<u64> h_packed;  // host copy of the packed words (needed by the polishing front end)
   std::vector<u32> h_len, h_id;
   bool ids_are_indices = false;  // ids[i] == i and all < 2^31 (needed by the pass-1 merge and the self-join)
   // sketch tiles for the owning engine's (k, w)
@@ -68,6 +69,11 @@ struct MapOut {
   DevBuf ovl;          // Overlap[n_overlaps] in (query read, emission) order
   DevBuf ovl_read_off; // u32[last - first + 1]
   DevBuf filtered;     // u8[n_query] (1 = skipped by the occurrence filter); valid when requested
+  // chain anchors of every overlap (lhs_pos << 32 | rhs_pos, ascending along the chain); when requested
+  bool has_anchors = false;
+  DevBuf anchors;      // u64[n_matches] (sparse: regions of the emitting intervals)
+  DevBuf anchor_off;   // u64[n_overlaps] index of an overlap's first anchor in `anchors`
+  DevBuf anchor_cnt;   // u32[n_overlaps]
 };
 
 struct StageTimes {
@@ -98,6 +104,8 @@ struct Engine {
   DevBuf seg_off, iv_slot_begin, iv_slot_end, iv_cnt, iv_off, iv_begin, iv_end;
   DevBuf lis_min, lis_pred, lis_tail, lis_mask, ovl_slots, ovl_flags, ovl_scan;
   DevBuf poa_scratch;
+  DevBuf anc_slot_off, anc_slot_cnt;
+  bool keep_anchors = false;  // map_batch also returns the chain anchors of every overlap
   unsigned long long poa_phase_cycles[6] = {};  // subgraph, dp, traceback, add, order, consensus (last call)
   StageTimes times;
   KernelTimers ktimers;
@@ -158,6 +166,15 @@ void poa_consensus_batch(Engine& e, const u8* h_codes, const u8* h_quals, const 
                          const u32* h_ends, const u32* h_has_qual, const u32* h_win_off, u32 n_windows, int m, int n,
                          int g, int trim, u8* h_out, const u64* h_out_off, u32* h_out_len, u32* h_status,
                          double* device_ms);
+
+struct PolishStats {
+  u64 n_overlaps = 0, n_reads_used = 0, n_layers = 0, n_windows = 0, n_polished_windows = 0, n_failed_windows = 0;
+  double poa_ms = 0;
+};
+// One racon polishing round (polish.hip): targets T, reads R, optional per-base Phred+33 qualities of the reads
+void polish_round(Engine& e, ReadsDev& T, ReadsDev& R, const u8* h_quals, const u64* h_qual_off, double q_thr,
+                  double err_thr, u32 w, bool trim, int m, int n, int g, std::vector<std::vector<u8>>& polished,
+                  std::vector<double>& ratio, PolishStats& stats);
 
 // Pass-1 state: per-pile kept overlaps + coverage (pile.hip)
 struct PileState {

@@ -206,6 +206,8 @@ int rvn_reads_upload(rvn_engine* h, const uint64_t* packed, uint64_t n_words, co
         return fail(RVN_EINVAL, "[raven_hip] rvn_reads_upload: word_offsets inconsistent with lengths");
     }
     r.n_words = n_words;
+    r.h_packed.assign(packed, packed + n_words);
+    r.h_packed.push_back(0);
     u64* d_packed = r.packed.get<u64>(n_words + 2);
     if (n_words) RVN_HIP(hipMemcpy(d_packed, packed, n_words * 8, hipMemcpyHostToDevice));
     RVN_HIP(hipMemset(d_packed + n_words, 0, 16));  // pad words: kernels may read one word past a read
@@ -436,6 +438,42 @@ int rvn_pile_add_kmers_batch(rvn_engine* h, const rvn_reads* r, uint32_t first_r
     RVN_HIP(hipSetDevice(h->e.device));
     UseTimers ut(h->e);
     pile_add_kmers_batch(h->e, rd, positions, position_offsets, n_reads, first_read, kmers, kmers_offsets);
+    return RVN_OK;
+  });
+}
+
+int rvn_polish_round(rvn_engine* h, rvn_reads* targets, rvn_reads* reads, const uint8_t* read_quals,
+                     const uint64_t* qual_offsets, double q, double err, uint32_t w, int trim, int match, int mismatch,
+                     int gap, uint8_t* out_codes, const uint64_t* out_offsets, uint32_t* out_len, double* ratio,
+                     rvn_polish_stats* stats) {
+  return guarded([&]() -> int {
+    if (!h || !targets || !reads || !out_codes || !out_offsets || !out_len)
+      return fail(RVN_EINVAL, "[raven_hip] NULL argument");
+    if (w == 0) return fail(RVN_EINVAL, "[racon::Polisher::Create] error: invalid window length!");
+    if (read_quals && !qual_offsets) return fail(RVN_EINVAL, "[raven_hip] qualities without offsets");
+    RVN_HIP(hipSetDevice(h->e.device));
+    UseTimers ut(h->e);
+    std::vector<std::vector<u8>> polished;
+    std::vector<double> rt;
+    PolishStats st;
+    polish_round(h->e, targets->r, reads->r, read_quals, qual_offsets, q, err, w, trim != 0, match, mismatch, gap,
+                 polished, rt, st);
+    for (u32 t = 0; t < targets->r.n; ++t) {
+      const u64 cap = out_offsets[t + 1] - out_offsets[t];
+      if (polished[t].size() > cap) return fail(RVN_EINVAL, "[raven_hip] rvn_polish_round: output buffer too small");
+      std::memcpy(out_codes + out_offsets[t], polished[t].data(), polished[t].size());
+      out_len[t] = static_cast<uint32_t>(polished[t].size());
+      if (ratio) ratio[t] = rt[t];
+    }
+    if (stats) {
+      stats->n_overlaps = st.n_overlaps;
+      stats->n_reads_used = st.n_reads_used;
+      stats->n_layers = st.n_layers;
+      stats->n_windows = st.n_windows;
+      stats->n_polished_windows = st.n_polished_windows;
+      stats->n_failed_windows = st.n_failed_windows;
+      stats->poa_ms = st.poa_ms;
+    }
     return RVN_OK;
   });
 }

@@ -446,7 +446,10 @@ __global__ __launch_bounds__(256) void intervals_gather_kernel(const u64* __rest
 template <typename CP>
 __device__ __forceinline__ void chain_emit(CP cp, u32 longest, bool strand, u64 g0, u32 lhs_id, u32 k, u32 chain,
                                            u32 min_matches, u32 gap, Overlap* __restrict__ slots,
-                                           u8* __restrict__ slot_flags, bool writer) {
+                                           u8* __restrict__ slot_flags, bool writer,
+                                           u64* __restrict__ anchors /* region of this interval or null */,
+                                           u64 anchor_base, u64* __restrict__ slot_aoff,
+                                           u32* __restrict__ slot_acnt) {
   u32 emitted = 0;
   u32 l = 0;
   for (u32 kk = 1; kk <= longest; ++kk) {
@@ -495,6 +498,11 @@ __device__ __forceinline__ void chain_emit(CP cp, u32 longest, bool strand, u64 
         o.strand = strand ? 1u : 0u;
         slots[emitted] = o;
         slot_flags[emitted] = 1;
+        if (anchors) {  // the chain pieces are disjoint sub-ranges of [0, longest): store them in place
+          for (u32 m = l; m < kk; ++m) anchors[m] = cp(m);
+          slot_aoff[emitted] = anchor_base + l;
+          slot_acnt[emitted] = kk - l;
+        }
       }
       ++emitted;
       l = kk;
@@ -511,7 +519,9 @@ __global__ __launch_bounds__(64) void chain_small_kernel(const u64* __restrict__
                                                         const u32* __restrict__ iv_read, u32 n_iv,
                                                         const u32* __restrict__ ids, u32 first, u32 k, u32 chain,
                                                         u32 min_matches, u32 gap, u32 slot_div,
-                                                        Overlap* __restrict__ slots, u8* __restrict__ slot_flags) {
+                                                        Overlap* __restrict__ slots, u8* __restrict__ slot_flags,
+                                                        u64* __restrict__ anchors, u64* __restrict__ slot_aoff,
+                                                        u32* __restrict__ slot_acnt) {
   __shared__ u64 s_pos[kChainSmallCap][64];
   __shared__ u64 s_tail[kChainSmallCap + 1][64];
   __shared__ u8 s_tidx[kChainSmallCap + 1][64];
@@ -569,7 +579,8 @@ __global__ __launch_bounds__(64) void chain_small_kernel(const u64* __restrict__
   }
   const u64 slot_base = (b + slot_div - 1) / slot_div;
   chain_emit([&](u32 m) { return s_tail[m][lane]; }, longest, strand, g0, ids[first + iv_read[t]], k, chain,
-             min_matches, gap, slots + slot_base, slot_flags + slot_base, true);
+             min_matches, gap, slots + slot_base, slot_flags + slot_base, true, anchors ? anchors + b : nullptr, b,
+             slot_aoff ? slot_aoff + slot_base : nullptr, slot_acnt ? slot_acnt + slot_base : nullptr);
 }
 
 // One WAVE per interval.  ram's patience LIS is sequential over the elements, but its binary search only
@@ -590,7 +601,8 @@ __device__ __forceinline__ void chain_sync() {
 template <typename IdxT, bool GLOBAL>
 __device__ void chain_wave(const u64* __restrict__ p, u32 n, bool strand, u64 g0, u32 lhs_id, u32 k, u32 chain,
                            u32 min_matches, u32 gap, u64* tail_pos, IdxT* tail_idx, IdxT* pred, u64* maskbuf,
-                           Overlap* __restrict__ slots, u8* __restrict__ slot_flags) {
+                           Overlap* __restrict__ slots, u8* __restrict__ slot_flags, u64* __restrict__ anchors,
+                           u64 anchor_base, u64* __restrict__ slot_aoff, u32* __restrict__ slot_acnt) {
   const int lane = lane_id();
   u32 longest = 0;
   for (u32 base = 0; base < n; base += 64) {
@@ -661,7 +673,7 @@ __device__ void chain_wave(const u64* __restrict__ p, u32 n, bool strand, u64 g0
     chain_sync<GLOBAL>();
   }
   chain_emit([&](u32 m) { return tail_pos[m]; }, longest, strand, g0, lhs_id, k, chain, min_matches, gap, slots,
-             slot_flags, lane == 0);
+             slot_flags, lane == 0, anchors, anchor_base, slot_aoff, slot_acnt);
 }
 
 __global__ __launch_bounds__(256) void chain_kernel(const u64* __restrict__ grp, const u64* __restrict__ pos,
@@ -671,7 +683,9 @@ __global__ __launch_bounds__(256) void chain_kernel(const u64* __restrict__ grp,
                                                    u32 chain, u32 min_matches, u32 gap, u32 slot_div,
                                                    u64* __restrict__ g_tail_pos, u32* __restrict__ g_tail_idx,
                                                    u32* __restrict__ g_pred, u64* __restrict__ g_mask,
-                                                   Overlap* __restrict__ slots, u8* __restrict__ slot_flags) {
+                                                   Overlap* __restrict__ slots, u8* __restrict__ slot_flags,
+                                                   u64* __restrict__ anchors, u64* __restrict__ slot_aoff,
+                                                   u32* __restrict__ slot_acnt) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[4][(kChainLdsBytes + 15) & ~15u];
   const int wv = threadIdx.x >> 6;
   // each wave owns kChainPerWave consecutive intervals and processes the large ones (n > kChainSmallCap)
@@ -701,11 +715,13 @@ __global__ __launch_bounds__(256) void chain_kernel(const u64* __restrict__ grp,
       u16* tail_idx = reinterpret_cast<u16*>(maskbuf + 16);
       u16* pred = tail_idx + (kChainLdsCap + 2);
       chain_wave<u16, false>(pos + b, n, strand, g0, lhs_id, k, chain, min_matches, gap, tail_pos, tail_idx, pred,
-                             maskbuf, slots + slot_base, slot_flags + slot_base);
+                             maskbuf, slots + slot_base, slot_flags + slot_base, anchors ? anchors + b : nullptr, b,
+                             slot_aoff ? slot_aoff + slot_base : nullptr, slot_acnt ? slot_acnt + slot_base : nullptr);
     } else {
       chain_wave<u32, true>(pos + b, n, strand, g0, lhs_id, k, chain, min_matches, gap, g_tail_pos + b + t,
                             g_tail_idx + b + t, g_pred + b, g_mask + (b >> 6) + t, slots + slot_base,
-                            slot_flags + slot_base);
+                            slot_flags + slot_base, anchors ? anchors + b : nullptr, b,
+                            slot_aoff ? slot_aoff + slot_base : nullptr, slot_acnt ? slot_acnt + slot_base : nullptr);
     }
     __builtin_amdgcn_wave_barrier();
   }
@@ -715,6 +731,16 @@ __global__ void compact_overlaps_kernel(const Overlap* __restrict__ slots, const
                                         const u32* __restrict__ scan, u64 n_slots, Overlap* __restrict__ out) {
   u64 i = static_cast<u64>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (i < n_slots && flags[i]) out[scan[i]] = slots[i];
+}
+
+__global__ void compact_aux_kernel(const u64* __restrict__ slot_aoff, const u32* __restrict__ slot_acnt,
+                                   const u8* __restrict__ flags, const u32* __restrict__ scan, u64 n_slots,
+                                   u64* __restrict__ aoff, u32* __restrict__ acnt) {
+  u64 i = static_cast<u64>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n_slots && flags[i]) {
+    aoff[scan[i]] = slot_aoff[i];
+    acnt[scan[i]] = slot_acnt[i];
+  }
 }
 
 __global__ void read_ovl_off_kernel(const u64* __restrict__ seg_off, const u32* __restrict__ scan, u32 slot_div,
@@ -878,13 +904,22 @@ void map_batch_impl(Engine& e, const ReadsDev& r, u32 first, u32 last, bool avoi
     u64* lis_tail = e.lis_tail.get<u64>(H + NI + 1);
     u64* lis_mask = e.lis_mask.get<u64>((H >> 6) + NI + 2);
     RVN_HIP(hipMemsetAsync(slot_flags, 0, n_slots + 1, s));
+    u64* anchors = nullptr;
+    u64* slot_aoff = nullptr;
+    u32* slot_acnt = nullptr;
+    if (e.keep_anchors) {
+      anchors = out.anchors.get<u64>(H + 1);
+      slot_aoff = e.anc_slot_off.get<u64>(n_slots + 1);
+      slot_acnt = e.anc_slot_cnt.get<u32>(n_slots + 1);
+    }
     RVN_KLAUNCH(kKChainSmall, chain_small_kernel<<<div_up(NI, 64), 64, 0, s>>>(
                                   g0, p0, iv_begin, iv_end, iv_read, NI, r.id.as<u32>(), first, e.k, e.chain, e.matches,
-                                  e.gap, slot_div, slots, slot_flags));
+                                  e.gap, slot_div, slots, slot_flags, anchors, slot_aoff, slot_acnt));
     RVN_KLAUNCH(kKChain, chain_kernel<<<div_up(NI, 4 * kChainPerWave), 256, 0, s>>>(g0, p0, iv_begin, iv_end, iv_read, NI,
                                                                      r.id.as<u32>(), first, e.k, e.chain, e.matches,
                                                                      e.gap, slot_div, lis_tail, lis_min, lis_pred,
-                                                                     lis_mask, slots, slot_flags));
+                                                                     lis_mask, slots, slot_flags, anchors, slot_aoff,
+                                                                     slot_acnt));
     t.stop();
   }
   {
@@ -896,6 +931,14 @@ void map_batch_impl(Engine& e, const ReadsDev& r, u32 first, u32 last, bool avoi
     e.c_overlaps += O;
     Overlap* ovl = out.ovl.get<Overlap>(static_cast<size_t>(O) + 1);
     RVN_KLAUNCH(kKCompactOverlaps, compact_overlaps_kernel<<<div_up(n_slots, 256), 256, 0, s>>>(slots, slot_flags, scan, n_slots, ovl));
+    out.has_anchors = e.keep_anchors;
+    if (e.keep_anchors) {
+      u64* aoff = out.anchor_off.get<u64>(static_cast<size_t>(O) + 1);
+      u32* acnt = out.anchor_cnt.get<u32>(static_cast<size_t>(O) + 1);
+      RVN_KLAUNCH(kKCompactOverlaps, compact_aux_kernel<<<div_up(n_slots, 256), 256, 0, s>>>(
+                                         e.anc_slot_off.as<u64>(), e.anc_slot_cnt.as<u32>(), slot_flags, scan, n_slots,
+                                         aoff, acnt));
+    }
     RVN_KLAUNCH(kKGather, read_ovl_off_kernel<<<div_up(nr + 1, 256), 256, 0, s>>>(seg_off, scan, slot_div, nr + 1, ovl_read_off));
     t.stop();
   }

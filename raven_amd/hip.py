@@ -34,7 +34,7 @@ SYMBOLS = [
     "rvn_find_overlaps_and_create_piles", "rvn_pass1_pile_words", "rvn_pass1_num_overlaps",
     "rvn_pass1_fetch_piles", "rvn_pass1_fetch_overlaps", "rvn_pass1_destroy", "rvn_pile_add_layers",
     "rvn_edit_distance_batch", "rvn_poa_consensus_batch", "rvn_poa_phase_cycles", "rvn_pile_add_kmers_batch",
-    "rvn_test_low_complexity",
+    "rvn_test_low_complexity", "rvn_polish_round",
     "rvn_engine_sketch", "rvn_engine_sketch_fetch", "rvn_engine_index_size", "rvn_engine_index_fetch",
     "rvn_engine_counters", "rvn_engine_num_stages", "rvn_engine_stage_name", "rvn_engine_stage_ms",
     "rvn_engine_reset_stats", "rvn_engine_set_timing", "rvn_engine_set_kernel_timing",
@@ -87,6 +87,7 @@ def lib():
     L.rvn_pile_add_kmers_batch.argtypes = [vp, vp, u32, u32, vp, vp, vp, vp]
     L.rvn_test_low_complexity.restype = i32
     L.rvn_test_low_complexity.argtypes = [vp, u32]
+    L.rvn_polish_round.argtypes = [vp, vp, vp, vp, vp, dbl, dbl, u32, i32, i32, i32, i32, vp, vp, vp, vp, vp]
     L.rvn_edit_distance_batch.argtypes = [vp, vp, vp, u32, vp, C.POINTER(dbl), C.POINTER(u64)]
     L.rvn_poa_consensus_batch.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, u32, i32, i32, i32, i32, vp, vp, vp, vp,
                                           C.POINTER(dbl)]
@@ -254,6 +255,30 @@ class Engine:
         overlaps = np.ascontiguousarray(overlaps)
         _check(lib().rvn_pile_add_layers(self._h, _p(data), data.shape[0], pile_id, _p(overlaps),
                                          overlaps.shape[0]))
+
+    # -- racon::Polisher::Polish, one round ------------------------------------------------------------
+    def polish_round(self, targets: Reads, reads: Reads, quals=None, q=0.0, err=0.3, w=500, trim=True, m=3, n=-5, g=-4):
+        """quals: list of uint8 Phred+33 arrays (one per read) or None.  Returns (list of polished code arrays,
+        ratio array, stats dict).  The engine must have k=15, w=5 (racon's mapping parameters)."""
+        nt = targets.n
+        ooff = np.zeros(nt + 1, dtype=np.uint64)
+        np.cumsum(2 * targets.rs.lengths.astype(np.uint64) + 1024, out=ooff[1:])
+        out = np.zeros(int(ooff[-1]) + 1, dtype=np.uint8)
+        out_len = np.zeros(nt, dtype=np.uint32)
+        ratio = np.zeros(nt, dtype=np.float64)
+        stats = np.zeros(7, dtype=np.uint64)
+        qa = qo = None
+        if quals is not None:
+            qo = np.zeros(len(quals) + 1, dtype=np.uint64)
+            np.cumsum([len(x) for x in quals], out=qo[1:])
+            qa = np.concatenate([np.asarray(x, dtype=np.uint8) for x in quals])
+        _check(lib().rvn_polish_round(self._h, targets._h, reads._h, _p(qa), _p(qo), float(q), float(err), w, int(trim),
+                                      m, n, g, _p(out), _p(ooff), _p(out_len), _p(ratio), _p(stats)))
+        cons = [out[int(ooff[i]): int(ooff[i]) + int(out_len[i])].copy() for i in range(nt)]
+        keys = ("n_overlaps", "n_reads_used", "n_layers", "n_windows", "n_polished_windows", "n_failed_windows")
+        st = {k2: int(v) for k2, v in zip(keys, stats[:6])}
+        st["poa_ms"] = float(stats[6:7].view(np.float64)[0])
+        return cons, ratio, st
 
     # -- raven::Pile::AddKmers, batched ---------------------------------------------------------------
     def pile_add_kmers_batch(self, reads: Reads, first, positions_per_read):

@@ -1,0 +1,51 @@
+"""GPU polishing round (rvn_polish_round: device mapping + anchors -> windows -> POA kernel -> stitch) against the
+CPU restatement of racon's round (exact NW path breakpoints).  Tolerance parity (north_star: 'polished consensus
+within stated edit-distance tolerance'): ED(gpu, cpu) <= 1 % of the target and ED(gpu, truth) <= 1.25 x
+ED(cpu, truth) + 30."""
+import numpy as np
+import pytest
+
+from oracle import oracle
+from raven_amd import hip, seqio
+from tests import polish_util as pu2
+
+pytestmark = pytest.mark.gpu
+
+
+def _ed(a, b):
+    return oracle.edit_distance(bytes(np.asarray(a, np.uint8) + 65), bytes(np.asarray(b, np.uint8) + 65))
+
+
+@pytest.mark.parametrize("with_qual,n_targets", [(False, 1), (True, 1), (False, 3)])
+def test_polish_round_matches_cpu_within_tolerance(with_qual, n_targets):
+    truths, drafts, targets, reads, quals = pu2.make_case(genome_len=24_000, coverage=25, read_len=2500, seed=7,
+                                                         with_qual=with_qual, n_targets=n_targets)
+    eng = hip.Engine(15, 5)
+    td, rd = eng.upload(targets), eng.upload(reads)
+    q = 10.0 if with_qual else 0.0
+    cons, ratio, st = eng.polish_round(td, rd, quals=quals, q=q)
+    ref, ref_ratio = oracle.polish_round(targets, reads, quals=quals, q=q)
+    assert st["n_failed_windows"] == 0 and st["n_reads_used"] > 0.8 * reads.n
+    for t in range(n_targets):
+        assert ratio[t] > 0.85 and abs(ratio[t] - ref_ratio[t]) < 0.1
+        ed_draft, ed_cpu, ed_gpu = _ed(drafts[t], truths[t]), _ed(ref[t], truths[t]), _ed(cons[t], truths[t])
+        assert ed_gpu < ed_draft, (ed_draft, ed_gpu)
+        assert ed_gpu <= 1.25 * ed_cpu + 30, (ed_draft, ed_cpu, ed_gpu)
+        assert _ed(cons[t], ref[t]) <= 0.01 * len(ref[t]) + 30, (len(ref[t]), _ed(cons[t], ref[t]))
+
+
+def test_polish_two_rounds_and_low_quality_reads_are_dropped():
+    truths, drafts, targets, reads, quals = pu2.make_case(genome_len=16_000, coverage=20, read_len=2000, seed=9,
+                                                         with_qual=True)
+    eng = hip.Engine(15, 5)
+    rd = eng.upload(reads)
+    cur = targets
+    eds = [_ed(drafts[0], truths[0])]
+    for _ in range(2):  # raven's default num_rounds = 2 (polish.hpp:28)
+        cons, ratio, _ = eng.polish_round(eng.upload(cur), rd, quals=quals, q=10.0, trim=False)
+        eds.append(_ed(cons[0], truths[0]))
+        cur = seqio.pack_reads([cons[0]])
+    assert eds[1] < 0.5 * eds[0] and eds[2] <= eds[1] + 10, eds
+    # quality threshold above every read's mean quality (12): no layer survives -> nothing is polished (racon)
+    cons, ratio, st = eng.polish_round(eng.upload(targets), rd, quals=quals, q=20.0)
+    assert st["n_layers"] == 0 and ratio[0] == 0.0 and np.array_equal(cons[0], drafts[0])

@@ -139,3 +139,22 @@ def test_incremental_topological_order_rule_stays_valid():
             ends.append(min(len(bb) - 1, max(bb_b + 1, int(e0 * len(bb) / len(truth)) - 1)))
         bad, info = oracle.poa_order_check(layers, begins, ends)
         assert bad == -1, (bad, info)
+
+
+def test_polish_round_oracle_improves_draft():
+    """racon round restatement: polishing a 1-2 % error draft with 25x ONT-like reads removes most errors."""
+    from tests import polish_util as pu2
+    truths, drafts, targets, reads, _ = pu2.make_case(genome_len=20_000, coverage=25, read_len=2500, seed=5)
+    cons, ratio = oracle.polish_round(targets, reads)
+    assert ratio[0] > 0.9
+    ed_draft = _ed(drafts[0], truths[0])
+    ed_pol = _ed(cons[0], truths[0])
+    # racon's TGS trimming cuts the low-coverage contig ends: errors = edits beyond the plain length loss
+    lost = len(truths[0]) - len(cons[0])
+    assert ed_draft > 300 and 0 <= lost < 800 and ed_pol - lost < 0.2 * ed_draft, (ed_draft, ed_pol, lost)
+    untrimmed, _ = oracle.polish_round(targets, reads, trim=False)
+    assert _ed(untrimmed[0], truths[0]) < 0.2 * ed_draft
+    # second round on the polished sequence does not make it worse
+    from raven_amd import seqio
+    cons2, _ = oracle.polish_round(seqio.pack_reads([cons[0]]), reads)
+    assert _ed(cons2[0], truths[0]) - (len(truths[0]) - len(cons2[0])) <= ed_pol - lost + 25
