@@ -152,6 +152,15 @@ int rvn_polish_round(rvn_engine* e, rvn_reads* targets, rvn_reads* reads, const 
  * {subgraph, NW matrix, traceback, AddAlignment, order rebuild, consensus} */
 void rvn_poa_phase_cycles(const rvn_engine* e, uint64_t out[6]);
 
+/* Which window kernel rvn_poa_consensus_batch / rvn_polish_round use: 0 (default) = banded LDS kernel with a
+ * 64-column band; windows whose alignment touches the band edge are repeated with a 128-column band, and what is
+ * left (or beyond a limit) by the full-matrix kernel; 1 = full-matrix kernel only; 2 = 64-column band only;
+ * 3 = 128-column band only (2, 3: flagged windows come back with status 8).  Returns the previous mode. */
+int rvn_poa_set_mode(rvn_engine* e, int mode);
+/* number of windows of the last batch that were re-run by the full-matrix kernel / with the wide band (mode 0) */
+uint32_t rvn_poa_fallback_windows(const rvn_engine* e);
+uint32_t rvn_poa_wide_windows(const rvn_engine* e);
+
 /* ---- introspection used by the parity tests and bench.py ------------------------------------- */
 /* sketch of reads [first,last) == ram Minimize(sequence, minhash) per read; values widened to u64 */
 int rvn_engine_sketch(rvn_engine* e, const rvn_reads* r, uint32_t first, uint32_t last, int minhash,

@@ -527,6 +527,16 @@ void rvn_poa_phase_cycles(const rvn_engine* h, uint64_t out[6]) {
   for (int i = 0; i < 6; ++i) out[i] = h ? h->e.poa_phase_cycles[i] : 0;
 }
 
+int rvn_poa_set_mode(rvn_engine* h, int mode) {
+  if (!h) return -1;
+  const int prev = h->e.poa_mode;
+  if (mode >= 0 && mode <= 3) h->e.poa_mode = mode;
+  return prev;
+}
+
+uint32_t rvn_poa_fallback_windows(const rvn_engine* h) { return h ? h->e.poa_fallback_windows : 0; }
+uint32_t rvn_poa_wide_windows(const rvn_engine* h) { return h ? h->e.poa_wide_windows : 0; }
+
 int rvn_engine_sketch(rvn_engine* h, const rvn_reads* r, uint32_t first, uint32_t last, int minhash, uint64_t* count) {
   return guarded([&]() -> int {
     if (!h || !r || first > last || last > r->r.n) return fail(RVN_EINVAL, "[raven_hip] rvn_engine_sketch: bad range");

@@ -1,0 +1,198 @@
+// poa.h — pieces shared by the two POA window kernels (poa.hip: full-matrix kernel, the exact fallback;
+// poa2.hip: banded LDS kernel, the fast path).  Both keep the spoa graph as SoA arrays in a per-slot global
+// scratch with the same field names, so the graph-only steps (Subgraph marks, heaviest-bundle consensus) are
+// written once here as templates over the slot type.
+#pragma once
+
+#include "engine.h"
+#include "wave.h"
+
+namespace rvn {
+
+constexpr int kPoaMaxIn = 16;     // in-edges per node kept (overflow -> window reported as failed)
+constexpr int kPoaMaxSeq = 1024;  // longest layer (bases)
+constexpr i32 kNegInf16 = -30000;
+
+struct PoaWindow {  // host-prepared, one per window
+  u32 layer_first, n_layers;  // range in the (begin-sorted) layer table; layer_first = backbone
+  u32 out_off, out_cap;
+};
+struct PoaLayer {
+  u64 code_off;
+  u32 len, begin, end, has_qual;
+};
+
+// window status: 0 backbone returned (< 3 sequences), 1 polished, 2 node limit, 3 in-degree limit, 4 length limit,
+// 5..7 internal (| layer << 8), 8 alignment left the band (banded kernel only; such windows are re-run by the
+// full-matrix kernel)
+constexpr u32 kPoaBandHit = 8;
+
+struct PoaBatchDev {  // device-side batch description shared by both launchers
+  const PoaWindow* wins;
+  u32 n_windows;
+  const PoaLayer* layers;
+  const u8* codes;
+  const u8* quals;
+  u32 nmax, lmax;
+  int m, n, g, trim;
+  u8* out;
+  u32* out_len;
+  u32* status;
+  unsigned long long* phase_cycles;
+};
+
+void poa_v1_launch(Engine& e, const PoaBatchDev& b);  // poa.hip
+void poa_v2_launch(Engine& e, const PoaBatchDev& b, int nch);  // poa2.hip: band = 64 * nch columns
+
+__device__ __forceinline__ void wsync() {
+  __threadfence_block();
+  __builtin_amdgcn_wave_barrier();
+}
+
+// spoa Graph::AddEdge on the SoA graph. Returns false on in-degree overflow.  Touches only head's in-edge list
+// and tail's out-degree, so lanes working on distinct (tail, head) pairs do not conflict.
+template <class G>
+__device__ inline bool poa_add_edge(G& g, u32 tail, u32 head, i32 weight) {
+  const u32 c = g.in_cnt[head];
+  for (u32 i = 0; i < c; ++i) {
+    if (g.in_tail[head * kPoaMaxIn + i] == tail) {
+      g.in_w[head * kPoaMaxIn + i] += weight;
+      return true;
+    }
+  }
+  if (c >= kPoaMaxIn) return false;
+  g.in_tail[head * kPoaMaxIn + c] = static_cast<u16>(tail);
+  g.in_w[head * kPoaMaxIn + c] = weight;
+  g.in_cnt[head] = static_cast<u8>(c + 1);
+  g.out_cnt[tail] += 1;
+  return true;
+}
+
+// spoa Graph::Subgraph as marks: ancestors (through in-edges and aligned nodes) of backbone node `end` with
+// id >= begin; sub_out = out-degree inside the subgraph.  Whole wave; lane 0 runs the DFS.
+template <class G>
+__device__ inline void poa_subgraph_marks(G& g, u32 n_nodes, u32 nmax, u32 begin, u32 end) {
+  const int lane = lane_id();
+  for (u32 i = lane; i < n_nodes; i += 64) {
+    g.mark[i] = 0;
+    g.sub_out[i] = 0;
+  }
+  wsync();
+  if (lane == 0) {
+    u32 sp = 0;
+    g.stack[sp++] = static_cast<u16>(end);
+    while (sp) {
+      const u32 curr = g.stack[--sp];
+      if (!g.mark[curr] && curr >= begin) {
+        const u32 c = g.in_cnt[curr];
+        for (u32 k = 0; k < c && sp < nmax; ++k) g.stack[sp++] = g.in_tail[curr * kPoaMaxIn + k];
+        const u32 a = g.al_cnt[curr];
+        for (u32 k = 0; k < a && sp < nmax; ++k) g.stack[sp++] = g.al[curr * 4 + k];
+        g.mark[curr] = 1;
+      }
+    }
+  }
+  wsync();
+  for (u32 v = lane; v < n_nodes; v += 64) {
+    if (!g.mark[v]) continue;
+    const u32 c = g.in_cnt[v];
+    for (u32 k = 0; k < c; ++k) {
+      const u32 t = g.in_tail[v * kPoaMaxIn + k];
+      if (g.mark[t]) atomicAdd(reinterpret_cast<unsigned int*>(g.sub_out) + (t >> 1), (t & 1) ? 0x10000u : 1u);
+    }
+  }
+  wsync();
+}
+
+// Consensus: spoa TraverseHeaviestBundle + BranchCompletion, racon's coverage trim (lane 0).
+template <class G>
+__device__ inline void poa_consensus_lane0(G& g, u32 n_nodes, u32 nmax, const PoaWindow& win, int trim,
+                                           u8* __restrict__ out, u32* out_len) {
+  u32 cons_len = 0;
+  i32 maxn = -1;
+  for (u32 r = 0; r < n_nodes; ++r) {
+    const u32 it = g.order[r];
+    i32 sc = -1, pd = -1;
+    const u32 c = g.in_cnt[it];
+    for (u32 k = 0; k < c; ++k) {
+      const i32 wgt = g.in_w[it * kPoaMaxIn + k];
+      const i32 t = g.in_tail[it * kPoaMaxIn + k];
+      if (sc < wgt || (sc == wgt && g.scores[pd] <= g.scores[t])) {
+        sc = wgt;
+        pd = t;
+      }
+    }
+    if (pd != -1) sc += g.scores[pd];
+    g.scores[it] = sc;
+    g.preds[it] = pd;
+    if (maxn == -1 || g.scores[maxn] < sc) maxn = static_cast<i32>(it);
+  }
+  u32 guard = 0;
+  while (g.out_cnt[maxn] != 0 && guard++ < nmax) {
+    // BranchCompletion(rank of maxn)
+    const u32 start = static_cast<u32>(maxn);
+    const u32 rank = g.rank_of[start];
+    for (u32 r = 0; r < n_nodes; ++r) {  // heads of start's out-edges: other tails lose their score
+      const u32 hd = g.order[r];
+      const u32 c = g.in_cnt[hd];
+      bool from_start = false;
+      for (u32 k = 0; k < c; ++k) from_start |= g.in_tail[hd * kPoaMaxIn + k] == start;
+      if (!from_start) continue;
+      for (u32 k = 0; k < c; ++k) {
+        const u32 t = g.in_tail[hd * kPoaMaxIn + k];
+        if (t != start) g.scores[t] = -1;
+      }
+    }
+    i32 mx = -1;
+    for (u32 r = rank + 1; r < n_nodes; ++r) {
+      const u32 it = g.order[r];
+      i32 sc = -1, pd = -1;
+      const u32 c = g.in_cnt[it];
+      for (u32 k = 0; k < c; ++k) {
+        const i32 t = g.in_tail[it * kPoaMaxIn + k];
+        if (g.scores[t] == -1) continue;
+        const i32 wgt = g.in_w[it * kPoaMaxIn + k];
+        if (sc < wgt || (sc == wgt && g.scores[pd] <= g.scores[t])) {
+          sc = wgt;
+          pd = t;
+        }
+      }
+      if (pd != -1) sc += g.scores[pd];
+      g.scores[it] = sc;
+      g.preds[it] = pd;
+      if (mx == -1 || g.scores[mx] < sc) mx = static_cast<i32>(it);
+    }
+    if (mx == -1) break;
+    maxn = mx;
+  }
+  // traceback into stack (reverse), then forward with coverage + trim
+  u32 cl = 0;
+  i32 cur = maxn;
+  while (cur != -1 && cl < nmax) {
+    g.stack[cl++] = static_cast<u16>(cur);
+    cur = g.preds[cur];
+  }
+  // coverage of consensus node = visits of the node + its aligned nodes (spoa Node::Coverage summed, racon)
+  i32 begin = 0, end = static_cast<i32>(cl) - 1;
+  if (trim) {
+    const u32 avg = (win.n_layers - 1) / 2;
+    auto cov = [&](i32 pos) -> u32 {  // pos in forward consensus coordinates
+      const u32 v = g.stack[cl - 1 - pos];
+      u32 c = g.visits[v];
+      for (u32 k = 0; k < g.al_cnt[v]; ++k) c += g.visits[g.al[v * 4 + k]];
+      return c;
+    };
+    for (; begin < static_cast<i32>(cl); ++begin)
+      if (cov(begin) >= avg) break;
+    for (; end >= 0; --end)
+      if (cov(end) >= avg) break;
+    if (begin >= end) {  // racon: warning only, consensus kept untrimmed
+      begin = 0;
+      end = static_cast<i32>(cl) - 1;
+    }
+  }
+  for (i32 p = begin; p <= end && cons_len < win.out_cap; ++p) out[cons_len++] = g.code[g.stack[cl - 1 - p]];
+  *out_len = cons_len;
+}
+
+}  // namespace rvn

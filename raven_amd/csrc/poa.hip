@@ -19,25 +19,11 @@
 #include <algorithm>
 #include <vector>
 
-#include "engine.h"
-#include "wave.h"
+#include "poa.h"
 
 namespace rvn {
 
 namespace {
-
-constexpr int kPoaMaxIn = 16;     // in-edges per node kept (overflow -> window reported as failed)
-constexpr int kPoaMaxSeq = 1024;  // longest layer (bases)
-constexpr i32 kNegInf16 = -30000;
-
-struct PoaWindow {  // host-prepared, one per window
-  u32 layer_first, n_layers;  // range in the (begin-sorted) layer table; layer_first = backbone
-  u32 out_off, out_cap;
-};
-struct PoaLayer {
-  u64 code_off;
-  u32 len, begin, end, has_qual;
-};
 
 struct PoaSlot {
   i16* H;
@@ -119,28 +105,6 @@ __device__ inline PoaSlot poa_carve(unsigned char* base, u32 nmax, u32 lmax) {
   return s;
 }
 
-__device__ __forceinline__ void wsync() {
-  __threadfence_block();
-  __builtin_amdgcn_wave_barrier();
-}
-
-// spoa Graph::AddEdge on the SoA graph (lane 0). Returns false on in-degree overflow.
-__device__ inline bool poa_add_edge(PoaSlot& g, u32 tail, u32 head, i32 weight) {
-  const u32 c = g.in_cnt[head];
-  for (u32 i = 0; i < c; ++i) {
-    if (g.in_tail[head * kPoaMaxIn + i] == tail) {
-      g.in_w[head * kPoaMaxIn + i] += weight;
-      return true;
-    }
-  }
-  if (c >= kPoaMaxIn) return false;
-  g.in_tail[head * kPoaMaxIn + c] = static_cast<u16>(tail);
-  g.in_w[head * kPoaMaxIn + c] = weight;
-  g.in_cnt[head] = static_cast<u8>(c + 1);
-  g.out_cnt[tail] += 1;
-  return true;
-}
-
 __device__ inline u32 poa_add_node(PoaSlot& g, u32& n_nodes, u32 code) {
   const u32 id = n_nodes++;
   g.code[id] = static_cast<u8>(code);
@@ -214,36 +178,7 @@ __device__ u32 poa_window(const PoaWindow& win, const PoaLayer* __restrict__ lay
     tick();
     // ---- 1. subgraph marks ----
     if (!full) {
-      for (u32 i = lane; i < n_nodes; i += 64) {
-        g.mark[i] = 0;
-        g.sub_out[i] = 0;
-      }
-      wsync();
-      if (lane == 0) {
-        u32 sp = 0;
-        g.stack[sp++] = static_cast<u16>(L.end);
-        while (sp) {
-          const u32 curr = g.stack[--sp];
-          if (!g.mark[curr] && curr >= L.begin) {
-            const u32 c = g.in_cnt[curr];
-            for (u32 k = 0; k < c && sp < nmax; ++k) g.stack[sp++] = g.in_tail[curr * kPoaMaxIn + k];
-            const u32 a = g.al_cnt[curr];
-            for (u32 k = 0; k < a && sp < nmax; ++k) g.stack[sp++] = g.al[curr * 4 + k];
-            g.mark[curr] = 1;
-          }
-        }
-      }
-      wsync();
-      // out-degree inside the subgraph
-      for (u32 v = lane; v < n_nodes; v += 64) {
-        if (!g.mark[v]) continue;
-        const u32 c = g.in_cnt[v];
-        for (u32 k = 0; k < c; ++k) {
-          const u32 t = g.in_tail[v * kPoaMaxIn + k];
-          if (g.mark[t]) atomicAdd(reinterpret_cast<unsigned int*>(g.sub_out) + (t >> 1), (t & 1) ? 0x10000u : 1u);
-        }
-      }
-      wsync();
+      poa_subgraph_marks(g, n_nodes, nmax, L.begin, L.end);
     }
     tock(t_sub);
     tick();
@@ -607,93 +542,7 @@ __device__ u32 poa_window(const PoaWindow& win, const PoaLayer* __restrict__ lay
   }
   // ---- consensus: spoa TraverseHeaviestBundle + BranchCompletion (lane 0) ----
   tick();
-  u32 cons_len = 0;
-  if (lane == 0) {
-    i32 maxn = -1;
-    for (u32 r = 0; r < n_nodes; ++r) {
-      const u32 it = g.order[r];
-      i32 sc = -1, pd = -1;
-      const u32 c = g.in_cnt[it];
-      for (u32 k = 0; k < c; ++k) {
-        const i32 wgt = g.in_w[it * kPoaMaxIn + k];
-        const i32 t = g.in_tail[it * kPoaMaxIn + k];
-        if (sc < wgt || (sc == wgt && g.scores[pd] <= g.scores[t])) {
-          sc = wgt;
-          pd = t;
-        }
-      }
-      if (pd != -1) sc += g.scores[pd];
-      g.scores[it] = sc;
-      g.preds[it] = pd;
-      if (maxn == -1 || g.scores[maxn] < sc) maxn = static_cast<i32>(it);
-    }
-    u32 guard = 0;
-    while (g.out_cnt[maxn] != 0 && guard++ < nmax) {
-      // BranchCompletion(rank of maxn)
-      const u32 start = static_cast<u32>(maxn);
-      const u32 rank = g.rank_of[start];
-      for (u32 r = 0; r < n_nodes; ++r) {  // heads of start's out-edges: other tails lose their score
-        const u32 hd = g.order[r];
-        const u32 c = g.in_cnt[hd];
-        bool from_start = false;
-        for (u32 k = 0; k < c; ++k) from_start |= g.in_tail[hd * kPoaMaxIn + k] == start;
-        if (!from_start) continue;
-        for (u32 k = 0; k < c; ++k) {
-          const u32 t = g.in_tail[hd * kPoaMaxIn + k];
-          if (t != start) g.scores[t] = -1;
-        }
-      }
-      i32 mx = -1;
-      for (u32 r = rank + 1; r < n_nodes; ++r) {
-        const u32 it = g.order[r];
-        i32 sc = -1, pd = -1;
-        const u32 c = g.in_cnt[it];
-        for (u32 k = 0; k < c; ++k) {
-          const i32 t = g.in_tail[it * kPoaMaxIn + k];
-          if (g.scores[t] == -1) continue;
-          const i32 wgt = g.in_w[it * kPoaMaxIn + k];
-          if (sc < wgt || (sc == wgt && g.scores[pd] <= g.scores[t])) {
-            sc = wgt;
-            pd = t;
-          }
-        }
-        if (pd != -1) sc += g.scores[pd];
-        g.scores[it] = sc;
-        g.preds[it] = pd;
-        if (mx == -1 || g.scores[mx] < sc) mx = static_cast<i32>(it);
-      }
-      if (mx == -1) break;
-      maxn = mx;
-    }
-    // traceback into stack (reverse), then forward with coverage + trim
-    u32 cl = 0;
-    i32 cur = maxn;
-    while (cur != -1 && cl < nmax) {
-      g.stack[cl++] = static_cast<u16>(cur);
-      cur = g.preds[cur];
-    }
-    // coverage of consensus node = visits of the node + its aligned nodes (spoa Node::Coverage summed, racon)
-    i32 begin = 0, end = static_cast<i32>(cl) - 1;
-    if (trim) {
-      const u32 avg = (win.n_layers - 1) / 2;
-      auto cov = [&](i32 pos) -> u32 {  // pos in forward consensus coordinates
-        const u32 v = g.stack[cl - 1 - pos];
-        u32 c = g.visits[v];
-        for (u32 k = 0; k < g.al_cnt[v]; ++k) c += g.visits[g.al[v * 4 + k]];
-        return c;
-      };
-      for (; begin < static_cast<i32>(cl); ++begin)
-        if (cov(begin) >= avg) break;
-      for (; end >= 0; --end)
-        if (cov(end) >= avg) break;
-      if (begin >= end) {  // racon: warning only, consensus kept untrimmed
-        begin = 0;
-        end = static_cast<i32>(cl) - 1;
-      }
-    }
-    for (i32 p = begin; p <= end && cons_len < win.out_cap; ++p) out[cons_len++] = g.code[g.stack[cl - 1 - p]];
-    *out_len = cons_len;
-  }
+  if (lane == 0) poa_consensus_lane0(g, n_nodes, nmax, win, trim, out, out_len);
   wsync();
   tock(t_cons);
   if (phase_cycles && lane == 0) {
@@ -716,7 +565,7 @@ __global__ __launch_bounds__(256) void poa_kernel(const PoaWindow* __restrict__ 
                                                  unsigned long long* __restrict__ phase_cycles) {
   __shared__ u8 s_seq[4][kPoaMaxSeq];
   __shared__ u8 s_w[4][kPoaMaxSeq];
-  const u32 wv = threadIdx.x >> 6;
+  const u32 wv = static_cast<u32>(__builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6)));
   const u32 slot = blockIdx.x * 4 + wv;
   if (slot >= n_slots) return;
   PoaSlot g = poa_carve(scratch + static_cast<size_t>(slot) * slot_bytes, nmax, lmax);
@@ -731,7 +580,26 @@ __global__ __launch_bounds__(256) void poa_kernel(const PoaWindow* __restrict__ 
 
 }  // namespace
 
-// Host entry: see rvn_poa_consensus_batch in raven_hip.h
+void poa_v1_launch(Engine& e, const PoaBatchDev& b) {
+  if (b.n_windows == 0) return;
+  const size_t slot_bytes = poa_slot_bytes(b.nmax, b.lmax);
+  size_t free_b = 0, total_b = 0;
+  RVN_HIP(hipMemGetInfo(&free_b, &total_b));
+  u32 n_slots = std::min<u32>(b.n_windows, 256 * 8);
+  const size_t budget = e.poa_scratch.cap + free_b / 2;
+  if (static_cast<size_t>(n_slots) * slot_bytes > budget) n_slots = static_cast<u32>(std::max<size_t>(1, budget / slot_bytes));
+  n_slots = ((n_slots + 3) / 4) * 4;
+  unsigned char* d_scratch = e.poa_scratch.get<unsigned char>(static_cast<size_t>(n_slots) * slot_bytes + 256);
+  RVN_KLAUNCH(kKPoa, poa_kernel<<<n_slots / 4, 256, 0, e.stream>>>(b.wins, b.n_windows, b.layers, b.codes, b.quals,
+                                                                    d_scratch, slot_bytes, n_slots, b.nmax, b.lmax, b.m,
+                                                                    b.n, b.g, b.trim, b.out, b.out_len, b.status,
+                                                                    b.phase_cycles));
+}
+
+// Host entry: see rvn_poa_consensus_batch in raven_hip.h.  Every window first goes through the banded LDS kernel
+// (poa2.hip) with a 64-column band; windows whose alignment touches the band edge are repeated with 128 columns,
+// and what is left (or beyond a limit) is re-run by the full-matrix kernel above, so a status >= 2 in the result
+// means the window is beyond ALL of them.
 void poa_consensus_batch(Engine& e, const u8* h_codes, const u8* h_quals, const u64* h_layer_off,
                          const u32* h_begins, const u32* h_ends, const u32* h_has_qual, const u32* h_win_off,
                          u32 n_windows, int m, int n, int g, int trim, u8* h_out, const u64* h_out_off,
@@ -742,7 +610,7 @@ void poa_consensus_batch(Engine& e, const u8* h_codes, const u8* h_quals, const 
   const u64 total = h_layer_off[n_layers];
   std::vector<PoaWindow> wins(n_windows);
   std::vector<PoaLayer> lays(n_layers);
-  u32 max_bb = 1, max_len = 1, max_layers = 1;
+  u32 max_bb = 1, max_len = 1;
   for (u32 w = 0; w < n_windows; ++w) {
     const u32 f = h_win_off[w], l = h_win_off[w + 1];
     wins[w].layer_first = f;
@@ -765,42 +633,92 @@ void poa_consensus_batch(Engine& e, const u8* h_codes, const u8* h_quals, const 
       if (i == 0) max_bb = std::max(max_bb, L.len);
       max_len = std::max(max_len, L.len);
     }
-    max_layers = std::max(max_layers, l - f);
   }
-  // limits: nodes <= nmax, layer length <= lmax (windows beyond them come back with status 2)
-  const u32 lmax = std::min<u32>(kPoaMaxSeq, std::max<u32>(64, ((max_len + 63) / 64) * 64));
-  const u32 nmax = std::min<u32>(8192, std::max<u32>(512, max_bb * 6));
-  const size_t slot_bytes = poa_slot_bytes(nmax, lmax);
-  size_t free_b = 0, total_b = 0;
-  RVN_HIP(hipMemGetInfo(&free_b, &total_b));
-  u32 n_slots = std::min<u32>(n_windows, 256 * 8);
-  const size_t budget = free_b / 2;
-  if (static_cast<size_t>(n_slots) * slot_bytes > budget) n_slots = static_cast<u32>(std::max<size_t>(1, budget / slot_bytes));
-  n_slots = ((n_slots + 3) / 4) * 4;
+  // limits: nodes <= nmax, layer length <= lmax (windows beyond them come back with status 2 / 4)
+  PoaBatchDev b{};
+  b.lmax = std::min<u32>(kPoaMaxSeq, std::max<u32>(64, ((max_len + 63) / 64) * 64));
+  b.nmax = std::min<u32>(8192, std::max<u32>(512, max_bb * 6));
+  b.m = m;
+  b.n = n;
+  b.g = g;
+  b.trim = trim;
+  b.n_windows = n_windows;
 
   u8* d_codes = e.tmp_a.get<u8>(total + 16);
   u8* d_quals = h_quals ? e.tmp_b.get<u8>(total + 16) : nullptr;
-  PoaWindow* d_wins = e.tmp_c.get<PoaWindow>(n_windows + 1);
+  PoaWindow* d_wins = e.tmp_c.get<PoaWindow>(2 * static_cast<size_t>(n_windows) + 2);
   PoaLayer* d_lays = e.tmp_d.get<PoaLayer>(n_layers + 1);
   const u64 out_total = h_out_off[n_windows];
   u8* d_out = e.tmp_e.get<u8>(out_total + 16);
-  u32* d_len = e.tmp_f.get<u32>(2 * static_cast<size_t>(n_windows) + 2);
+  u32* d_len = e.tmp_f.get<u32>(4 * static_cast<size_t>(n_windows) + 4);
   u32* d_status = d_len + n_windows + 1;
   unsigned long long* d_phase = e.q_start.get<unsigned long long>(8);
   RVN_HIP(hipMemsetAsync(d_phase, 0, 64, s));
-  unsigned char* d_scratch = e.poa_scratch.get<unsigned char>(static_cast<size_t>(n_slots) * slot_bytes + 256);
   RVN_HIP(hipMemcpyAsync(d_codes, h_codes, total, hipMemcpyHostToDevice, s));
   if (d_quals) RVN_HIP(hipMemcpyAsync(d_quals, h_quals, total, hipMemcpyHostToDevice, s));
   RVN_HIP(hipMemcpyAsync(d_wins, wins.data(), wins.size() * sizeof(PoaWindow), hipMemcpyHostToDevice, s));
   RVN_HIP(hipMemcpyAsync(d_lays, lays.data(), lays.size() * sizeof(PoaLayer), hipMemcpyHostToDevice, s));
+  b.wins = d_wins;
+  b.layers = d_lays;
+  b.codes = d_codes;
+  b.quals = d_quals;
+  b.out = d_out;
+  b.out_len = d_len;
+  b.status = d_status;
+  b.phase_cycles = d_phase;
   RVN_HIP(hipEventRecord(e.ev0, s));
-  RVN_KLAUNCH(kKPoa, poa_kernel<<<n_slots / 4, 256, 0, s>>>(d_wins, n_windows, d_lays, d_codes, d_quals, d_scratch,
-                                                             slot_bytes, n_slots, nmax, lmax, m, n, g, trim, d_out,
-                                                             d_len, d_status, d_phase));
-  RVN_HIP(hipEventRecord(e.ev1, s));
-  RVN_HIP(hipMemcpyAsync(h_out, d_out, out_total, hipMemcpyDeviceToHost, s));
+  if (e.poa_mode == 1) poa_v1_launch(e, b);
+  else poa_v2_launch(e, b, e.poa_mode == 3 ? 2 : 1);
   RVN_HIP(hipMemcpyAsync(h_out_len, d_len, static_cast<size_t>(n_windows) * 4, hipMemcpyDeviceToHost, s));
   RVN_HIP(hipMemcpyAsync(h_status, d_status, static_cast<size_t>(n_windows) * 4, hipMemcpyDeviceToHost, s));
+  RVN_HIP(hipStreamSynchronize(s));
+  e.poa_fallback_windows = 0;
+  e.poa_wide_windows = 0;
+  if (e.poa_mode == 0) {
+    // escalate what the 64-column band could not do: band hits -> 128-column band -> full matrix; windows beyond a
+    // limit (nodes / in-degree / length) -> full matrix directly
+    PoaWindow* d_rw = d_wins + n_windows + 1;
+    u32* d_rlen = d_status + n_windows + 1;
+    auto rerun = [&](const std::vector<u32>& redo, int which) {
+      std::vector<PoaWindow> rw(redo.size());
+      for (size_t i = 0; i < redo.size(); ++i) rw[i] = wins[redo[i]];
+      u32* d_rstatus = d_rlen + redo.size() + 1;
+      RVN_HIP(hipMemcpyAsync(d_rw, rw.data(), rw.size() * sizeof(PoaWindow), hipMemcpyHostToDevice, s));
+      PoaBatchDev rb = b;
+      rb.wins = d_rw;
+      rb.n_windows = static_cast<u32>(redo.size());
+      rb.out_len = d_rlen;
+      rb.status = d_rstatus;
+      if (which == 2) poa_v2_launch(e, rb, 2);
+      else poa_v1_launch(e, rb);
+      std::vector<u32> rl(redo.size()), rs(redo.size());
+      RVN_HIP(hipMemcpyAsync(rl.data(), d_rlen, rl.size() * 4, hipMemcpyDeviceToHost, s));
+      RVN_HIP(hipMemcpyAsync(rs.data(), d_rstatus, rs.size() * 4, hipMemcpyDeviceToHost, s));
+      RVN_HIP(hipStreamSynchronize(s));
+      for (size_t i = 0; i < redo.size(); ++i) {
+        h_out_len[redo[i]] = rl[i];
+        h_status[redo[i]] = rs[i];
+      }
+    };
+    std::vector<u32> wide, fullm;
+    for (u32 w = 0; w < n_windows; ++w) {
+      const u32 st = h_status[w] & 0xFF;
+      if (st == kPoaBandHit) wide.push_back(w);
+      else if (st >= 2) fullm.push_back(w);
+    }
+    if (!wide.empty()) {
+      rerun(wide, 2);
+      e.poa_wide_windows = static_cast<u32>(wide.size());
+      for (u32 w : wide)
+        if ((h_status[w] & 0xFF) >= 2) fullm.push_back(w);
+    }
+    if (!fullm.empty()) {
+      rerun(fullm, 1);
+      e.poa_fallback_windows = static_cast<u32>(fullm.size());
+    }
+  }
+  RVN_HIP(hipEventRecord(e.ev1, s));
+  RVN_HIP(hipMemcpyAsync(h_out, d_out, out_total, hipMemcpyDeviceToHost, s));
   RVN_HIP(hipMemcpyAsync(e.poa_phase_cycles, d_phase, 48, hipMemcpyDeviceToHost, s));
   RVN_HIP(hipStreamSynchronize(s));
   if (device_ms) {

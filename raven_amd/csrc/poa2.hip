@@ -1,0 +1,739 @@
+// poa2.hip — banded, LDS-staged POA window kernel: the fast path behind rvn_poa_consensus_batch (racon
+// Window::GenerateConsensus over spoa, as driven by raven::Polish, RavenLib/src/polish.cc:43-51).
+//
+// Same algorithm and graph layout as poa.hip (one wave per window, SoA graph in a per-slot global scratch,
+// incremental topological order), re-cut so that no serial step waits on HBM:
+//   * NW is BANDED: every node carries its backbone coordinate (`bpos`), the band of its row is the 128 columns
+//     around the layer position that coordinate maps to ((bpos - begin) * len / span).  4x fewer cells than the
+//     full matrix for racon's 500-bp windows; a layer whose traceback comes within 2 cells of a band edge marks the
+//     window kPoaBandHit and the host re-runs it through the full-matrix kernel, so banding never silently
+//     changes a result.
+//   * predecessor rows come from a 32-row score ring in LDS (hit rate ~all: an incremental order keeps a
+//     node's in-edges within a few ranks); only ring misses read the int16 copy in HBM.
+//   * the DP writes one BACKPOINTER byte per cell (which in-edge, diagonal/vertical/horizontal, chosen with
+//     spoa's traceback priority), so the traceback is a walk over bytes: blocks of 64 rows x 128 B are staged
+//     into LDS with one coalesced load, together with a per-row table (node, band start, first 4 predecessor
+//     ranks), and the walk itself touches only LDS.
+//   * spoa's AddAlignment runs lane-parallel, one sequence position per lane: the nodes on an alignment path are
+//     distinct and belong to distinct aligned groups, so target lookup, node creation, group updates and the
+//     edge (p-1 -> p) are conflict-free; new ids and order slots come from ballots/prefix counts in path order,
+//     identical to the serial order of creation.
+// Integer VALU + LDS bound; no MFMA.
+#include <algorithm>
+#include <vector>
+
+#include "poa.h"
+
+namespace rvn {
+
+namespace {
+
+constexpr int kRing = 32;  // score rows kept in LDS
+// The band is NCH chunks of 64 columns (one column per lane and chunk).  NCH = 1 (+-32 around the expected
+// column) is the first attempt; windows whose traceback touches the band edge are repeated with NCH = 2 and, if
+// that is not enough either, by the full-matrix kernel.
+constexpr u32 kNone = 0xFFFFu;
+constexpr i32 kNegBig = -0x3FFFFFFF;
+
+struct Poa2Slot {
+  i16* Hs;    // (nmax + 1) x band scores (ring misses only)
+  u8* BP;     // (nmax + 1) x band backpointers: 0..15 diagonal via in-edge k, 16..31 vertical, 32 horizontal
+  uint4* tb;  // per row: x = band start | node << 16, y = #in-edges, z = rows of in-edges 0,1, w = in-edges 2,3
+  u8* code;
+  u8* in_cnt;
+  u16* in_tail;
+  i32* in_w;
+  u16* out_cnt;
+  u8* al_cnt;
+  u16* al;
+  u16* visits;
+  u16* rank_of;
+  u16* order;
+  u16* order2;
+  u8* mark;
+  u16* sub_out;
+  u16* bpos;
+  u16* new_slot;
+  i32* scores;
+  i32* preds;
+  u16* stack;
+};
+
+template <class F>
+__host__ __device__ inline void poa2_fields(u32 nmax, u32 lmax, u32 band, F&& f) {
+  f(0, static_cast<size_t>(nmax + 1) * band * 2);
+  f(1, static_cast<size_t>(nmax + 1) * band);
+  f(2, static_cast<size_t>(nmax + 1) * 16);
+  f(3, nmax);
+  f(4, nmax);
+  f(5, static_cast<size_t>(nmax) * kPoaMaxIn * 2);
+  f(6, static_cast<size_t>(nmax) * kPoaMaxIn * 4);
+  f(7, static_cast<size_t>(nmax) * 2);
+  f(8, nmax);
+  f(9, static_cast<size_t>(nmax) * 4 * 2);
+  f(10, static_cast<size_t>(nmax) * 2);
+  f(11, static_cast<size_t>(nmax) * 2);
+  f(12, static_cast<size_t>(nmax) * 2);
+  f(13, static_cast<size_t>(nmax) * 2);
+  f(14, nmax);
+  f(15, static_cast<size_t>(nmax) * 2 + 4);
+  f(16, static_cast<size_t>(nmax) * 2);
+  f(17, static_cast<size_t>(lmax + 2) * 2);
+  f(18, static_cast<size_t>(nmax) * 4);
+  f(19, static_cast<size_t>(nmax) * 4);
+  f(20, static_cast<size_t>(nmax) * 2);
+}
+
+inline size_t poa2_slot_bytes(u32 nmax, u32 lmax, u32 band) {
+  size_t b = 0;
+  poa2_fields(nmax, lmax, band, [&](int, size_t x) { b += (x + 255) & ~size_t(255); });
+  return b;
+}
+
+__device__ inline Poa2Slot poa2_carve(unsigned char* base, u32 nmax, u32 lmax, u32 band) {
+  unsigned char* p[21];
+  size_t o = 0;
+  poa2_fields(nmax, lmax, band, [&](int i, size_t x) {
+    p[i] = base + o;
+    o += (x + 255) & ~size_t(255);
+  });
+  Poa2Slot s;
+  s.Hs = reinterpret_cast<i16*>(p[0]);
+  s.BP = p[1];
+  s.tb = reinterpret_cast<uint4*>(p[2]);
+  s.code = p[3];
+  s.in_cnt = p[4];
+  s.in_tail = reinterpret_cast<u16*>(p[5]);
+  s.in_w = reinterpret_cast<i32*>(p[6]);
+  s.out_cnt = reinterpret_cast<u16*>(p[7]);
+  s.al_cnt = p[8];
+  s.al = reinterpret_cast<u16*>(p[9]);
+  s.visits = reinterpret_cast<u16*>(p[10]);
+  s.rank_of = reinterpret_cast<u16*>(p[11]);
+  s.order = reinterpret_cast<u16*>(p[12]);
+  s.order2 = reinterpret_cast<u16*>(p[13]);
+  s.mark = p[14];
+  s.sub_out = reinterpret_cast<u16*>(p[15]);
+  s.bpos = reinterpret_cast<u16*>(p[16]);
+  s.new_slot = reinterpret_cast<u16*>(p[17]);
+  s.scores = reinterpret_cast<i32*>(p[18]);
+  s.preds = reinterpret_cast<i32*>(p[19]);
+  s.stack = reinterpret_cast<u16*>(p[20]);
+  return s;
+}
+
+template <int NCH>
+struct alignas(16) Poa2Lds {  // per wave
+  static constexpr int kBand = 64 * NCH;
+  static constexpr int kRingStride = kBand + 2;
+  union {
+    // DP: score rows, slot = (row - 1) % kRing.  Every row is [pad][kBand cells][pad] with the pads (and one guard
+    // cell in front of row 0) holding -inf, so a clamped index replaces the "is this column in the predecessor's
+    // band" branches: cell c of the band is ring[2 + slot * kRingStride + c].
+    i16 ring[2 + kRing * kRingStride];
+    u8 stage[64 * kBand];  // traceback: backpointer rows of one 64-row block
+    struct {
+      u16 tgt[kPoaMaxSeq];  // AddAlignment: graph node of every sequence position
+    } add;
+  } u;
+  u8 seq[kPoaMaxSeq];
+  u8 wgt[kPoaMaxSeq];
+  u16 pos_node[kPoaMaxSeq];  // traceback result: node aligned to position p, or kNone
+  uint4 tb[64];              // traceback: row table of the staged block (Poa2Slot::tb)
+};
+
+// k-th in-edge (among those inside the subgraph) of v, as a row index (rank + 1); slow path for in-degree > 4
+__device__ __noinline__ u32 poa2_nth_pred(const Poa2Slot& g, u32 v, u32 k, bool full) {
+  const u32 c = g.in_cnt[v];
+  u32 seen = 0;
+  for (u32 i = 0; i < c; ++i) {
+    const u32 t = g.in_tail[v * kPoaMaxIn + i];
+    if (full || g.mark[t]) {
+      if (seen == k) return static_cast<u32>(g.rank_of[t]) + 1;
+      ++seen;
+    }
+  }
+  return 0;
+}
+
+// Ring miss: predecessor row `pr` from the int16 copy in HBM.  Out of line on purpose: on gfx9 the vector memory
+// counter is shared by loads and stores, so a load on the common path would make every DP row wait for the
+// previous row's stores.
+__device__ __noinline__ int4 poa2_fetch_miss(const Poa2Slot& g, u32 pr, i32 j0, i32 j1, bool two, i32 kBand) {
+  const i32 pb = static_cast<i32>(g.tb[pr].x & 0xFFFFu);
+  const i16* R = g.Hs + static_cast<size_t>(pr) * kBand;
+  const i32 i0 = j0 - pb, i1 = j1 - pb;
+  const i32 a0 = i0 < 0 ? 0 : (i0 > kBand - 1 ? kBand - 1 : i0);
+  const i32 a0m = i0 < 1 ? 0 : (i0 > kBand ? kBand - 1 : i0 - 1);
+  const i32 u0 = R[a0], d0 = R[a0m];
+  int4 r;
+  r.x = (i0 >= 0 && i0 < kBand) ? u0 : kNegInf16;
+  r.y = (i0 >= 1 && i0 <= kBand) ? d0 : kNegInf16;
+  r.z = kNegInf16;
+  r.w = kNegInf16;
+  if (two) {
+    const i32 a1 = i1 < 0 ? 0 : (i1 > kBand - 1 ? kBand - 1 : i1);
+    const i32 a1m = i1 < 1 ? 0 : (i1 > kBand ? kBand - 1 : i1 - 1);
+    const i32 u1 = R[a1], d1 = R[a1m];
+    r.z = (i1 >= 0 && i1 < kBand) ? u1 : kNegInf16;
+    r.w = (i1 >= 1 && i1 <= kBand) ? d1 : kNegInf16;
+  }
+  return r;
+}
+
+__device__ __forceinline__ int rl(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+__device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+template <int NCH>
+__device__ __forceinline__ u32 poa2_window(const PoaWindow& win, const PoaLayer* __restrict__ layers,
+                                           const u8* __restrict__ codes, const u8* __restrict__ quals, Poa2Slot& g,
+                                           u32 nmax, u32 lmax, int m, int n_, int gp, int trim, Poa2Lds<NCH>& S,
+                                           u8* __restrict__ out, u32* out_len,
+                                           unsigned long long* __restrict__ phase_cycles) {
+  constexpr int kBand = 64 * NCH;
+  constexpr int kRingStride = kBand + 2;
+  const int lane = lane_id();
+  unsigned long long t_sub = 0, t_dp = 0, t_tb = 0, t_add = 0, t_ord = 0, t_cons = 0, t0 = 0;
+  auto tick = [&]() { t0 = __builtin_readcyclecounter(); };
+  auto tock = [&](unsigned long long& acc) { acc += __builtin_readcyclecounter() - t0; };
+  const PoaLayer bb = layers[win.layer_first];
+  const u32 blen = bb.len;
+  auto copy_backbone = [&]() {
+    const u32 n = blen < win.out_cap ? blen : win.out_cap;
+    for (u32 i = lane; i < n; i += 64) out[i] = codes[bb.code_off + i];
+    if (lane == 0) *out_len = n;
+  };
+  if (win.n_layers < 3) {
+    copy_backbone();
+    return 0;
+  }
+  if (blen == 0 || blen > nmax || blen > lmax) {
+    copy_backbone();
+    return 4;
+  }
+  // ---- backbone graph (spoa AddAlignment with an empty alignment) ----
+  u32 n_nodes = blen;
+  for (u32 i = lane; i < blen; i += 64) {
+    g.code[i] = codes[bb.code_off + i];
+    g.al_cnt[i] = 0;
+    g.visits[i] = blen >= 2 ? 1 : 0;
+    g.rank_of[i] = static_cast<u16>(i);
+    g.order[i] = static_cast<u16>(i);
+    g.bpos[i] = static_cast<u16>(i);
+    const i32 wi = bb.has_qual ? static_cast<i32>(quals[bb.code_off + i]) - 33 : 1;
+    if (i > 0) {
+      const i32 wp = bb.has_qual ? static_cast<i32>(quals[bb.code_off + i - 1]) - 33 : 1;
+      g.in_cnt[i] = 1;
+      g.in_tail[i * kPoaMaxIn] = static_cast<u16>(i - 1);
+      g.in_w[i * kPoaMaxIn] = wp + wi;
+    } else {
+      g.in_cnt[i] = 0;
+    }
+    g.out_cnt[i] = i + 1 < blen ? 1 : 0;
+  }
+  wsync();
+  const u32 offset = static_cast<u32>(0.01 * blen);
+  u32 failed = 0;
+
+  for (u32 li = 1; li < win.n_layers && !failed; ++li) {
+    const PoaLayer L = layers[win.layer_first + li];
+    const u32 len = L.len;
+    if (len == 0) continue;
+    if (len > lmax || len > kPoaMaxSeq) {
+      failed = 4;
+      break;
+    }
+    for (u32 i = lane; i < len; i += 64) {
+      S.seq[i] = codes[L.code_off + i];
+      S.wgt[i] = L.has_qual ? static_cast<u8>(quals[L.code_off + i] - 33) : 1;
+      S.pos_node[i] = static_cast<u16>(kNone);
+    }
+    const bool full = L.begin < offset && L.end > blen - offset;
+    tick();
+    // ---- 1. subgraph marks ----
+    if (!full) poa_subgraph_marks(g, n_nodes, nmax, L.begin, L.end);
+    tock(t_sub);
+    tick();
+    // ---- 2. banded NW ----
+    const u32 w = len + 1;
+    const i32 lb = full ? 0 : static_cast<i32>(L.begin);
+    const i32 span = full ? static_cast<i32>(blen) : static_cast<i32>(L.end - L.begin + 1);
+    i32 best_score = -0x7FFFFFFF;
+    u32 best_row = 0;
+    int ring_tag = 0, ring_b = 0;  // lane s describes ring slot s: row stored there (0 = none), its band start
+    {  // -inf pads (the union is reused by the traceback / AddAlignment of the previous layer)
+      const u32 sl = static_cast<u32>(lane) >> 1;
+      S.u.ring[1 + sl * kRingStride + ((lane & 1) ? kBand + 1 : 0)] = static_cast<i16>(kNegInf16);
+      if (lane == 0) S.u.ring[0] = static_cast<i16>(kNegInf16);
+    }
+    bool dirty = false;  // HBM score rows stored since the last fence
+    for (u32 r0 = 0; r0 < n_nodes; r0 += 64) {
+      // metadata of 64 rows at once, one row per lane; it is also the traceback's row table
+      int m_v = 0, m_np = 0, m_p01 = 0, m_p23 = 0, m_code = 0, m_outc = 1, m_marked = 0, m_b = 0;
+      if (r0 + lane < n_nodes) {
+        m_v = g.order[r0 + lane];
+        m_marked = (full || g.mark[m_v]) ? 1 : 0;
+        if (m_marked) {
+          m_code = g.code[m_v];
+          m_outc = full ? g.out_cnt[m_v] : g.sub_out[m_v];
+          const u32 c = g.in_cnt[m_v];
+          for (u32 k = 0; k < c; ++k) {
+            const u32 t = g.in_tail[m_v * kPoaMaxIn + k];
+            if (full || g.mark[t]) {
+              const int pr = static_cast<int>(g.rank_of[t]) + 1;
+              if (m_np < 2) m_p01 |= pr << (16 * m_np);
+              else if (m_np < 4) m_p23 |= pr << (16 * (m_np - 2));
+              ++m_np;
+            }
+          }
+          i32 b = (static_cast<i32>(g.bpos[m_v]) - lb) * static_cast<i32>(len) / span - kBand / 2;
+          const i32 bmax = static_cast<i32>(w) - kBand;
+          b = b > bmax ? bmax : b;
+          b = b < 0 ? 0 : b;
+          m_b = b;
+        }
+        uint4 t;
+        t.x = static_cast<u32>(m_b) | (static_cast<u32>(m_v) << 16);
+        t.y = static_cast<u32>(m_np);
+        t.z = static_cast<u32>(m_p01);
+        t.w = static_cast<u32>(m_p23);
+        g.tb[r0 + lane + 1] = t;
+      }
+      // every load above must have returned BEFORE the row loop: a wait for them inside the loop would also wait
+      // for the rows' own stores (loads and stores share the vector memory counter)
+      asm volatile("" ::"v"(m_v), "v"(m_np), "v"(m_p01), "v"(m_p23), "v"(m_code), "v"(m_outc), "v"(m_marked), "v"(m_b));
+      const u32 rows_here = n_nodes - r0 < 64 ? n_nodes - r0 : 64;
+      for (u32 ri = 0; ri < rows_here; ++ri) {
+        if (!rl(m_marked, static_cast<int>(ri))) continue;
+        const u32 row = r0 + ri + 1;
+        const u32 v = static_cast<u32>(rl(m_v, static_cast<int>(ri)));
+        u32 np = static_cast<u32>(rl(m_np, static_cast<int>(ri)));
+        const u32 p01 = static_cast<u32>(rl(m_p01, static_cast<int>(ri)));
+        const u32 p23 = static_cast<u32>(rl(m_p23, static_cast<int>(ri)));
+        const i32 b = rl(m_b, static_cast<int>(ri));
+        const u32 vc = static_cast<u32>(rl(m_code, static_cast<int>(ri)));
+        if (np == 0) np = 1;  // no in-edge inside the subgraph: the virtual start row (p01 == 0)
+        const bool two = NCH > 1 && b + 64 < static_cast<i32>(w);  // second chunk has columns of the sequence
+        i32 j[NCH], sc[NCH], bd[NCH], bv[NCH];
+        u32 kd[NCH], kv[NCH];
+        bool val[NCH], dok[NCH];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+          j[c] = b + 64 * c + lane;
+          val[c] = j[c] < static_cast<i32>(w);
+          dok[c] = val[c] && j[c] >= 1;
+          // match/mismatch per column (clamped read; masked by dok)
+          const i32 qi = j[c] >= 1 ? (j[c] - 1 < kPoaMaxSeq ? j[c] - 1 : kPoaMaxSeq - 1) : 0;
+          sc[c] = vc == S.seq[qi] ? m : n_;
+          bd[c] = kNegBig;
+          bv[c] = kNegBig;
+          kd[c] = 0;
+          kv[c] = 0;
+        }
+        for (u32 k = 0; k < np; ++k) {
+          u32 pr;
+          if (k < 2) pr = (p01 >> (16 * k)) & 0xFFFFu;
+          else if (k < 4) pr = (p23 >> (16 * (k - 2))) & 0xFFFFu;
+          else pr = poa2_nth_pred(g, v, k, full);
+          i32 up[NCH], dg[NCH];
+          if (pr == 0) {  // H[0][j] = j * g
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+              up[c] = j[c] * gp;
+              dg[c] = (j[c] - 1) * gp;
+            }
+          } else {
+            const u32 slot = (pr - 1) & (kRing - 1);
+            if (static_cast<u32>(rl(ring_tag, static_cast<int>(slot))) == pr) {
+              // column j of the predecessor = cell (j - pb); out-of-band cells land on a -inf pad
+              const i32 pb = rl(ring_b, static_cast<int>(slot));
+              const i32 base = 2 + static_cast<i32>(slot) * kRingStride;
+#pragma unroll
+              for (int c = 0; c < NCH; ++c) {
+                i32 cc = j[c] - pb;
+                cc = cc < -1 ? -1 : (cc > kBand ? kBand : cc);
+                up[c] = S.u.ring[base + cc];
+                dg[c] = S.u.ring[base + cc - 1];
+              }
+            } else {  // ring miss (rare): the int16 copy in HBM
+              if (dirty) {  // earlier stores must have landed
+                wsync();
+                dirty = false;
+              }
+              const int4 r = poa2_fetch_miss(g, pr, j[0], j[NCH - 1], two, kBand);
+              up[0] = r.x;
+              dg[0] = r.y;
+              if (NCH > 1) {
+                up[NCH - 1] = r.z;
+                dg[NCH - 1] = r.w;
+              }
+            }
+          }
+#pragma unroll
+          for (int c = 0; c < NCH; ++c) {
+            const i32 d = dok[c] ? dg[c] + sc[c] : kNegBig;
+            kd[c] = d > bd[c] ? k : kd[c];
+            bd[c] = d > bd[c] ? d : bd[c];
+            const i32 x = val[c] ? up[c] + gp : kNegBig;
+            kv[c] = x > bv[c] ? k : kv[c];
+            bv[c] = x > bv[c] ? x : bv[c];
+          }
+        }
+        // spoa's traceback priority: diagonal (first in-edge reaching the max), vertical, horizontal
+        const u32 rslot = (row - 1) & (kRing - 1);
+        const u32 rbase = 2 + rslot * kRingStride;
+        i32 h[NCH];
+        i32 carry = 0;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+          if (c == 0 || two) {
+            const i32 best = bd[c] >= bv[c] ? bd[c] : bv[c];
+            u32 code = bd[c] >= bv[c] ? kd[c] : 16u + kv[c];
+            i32 x = val[c] ? best - j[c] * gp : kNegBig;
+            x = wave_inclusive_max_dpp(x, kNegBig);
+            i32 hh = x + j[c] * gp;
+            if (c > 0) {  // the gap chain entering from the previous chunk
+              const i32 viac = carry + (lane + 1) * gp;
+              hh = viac > hh ? viac : hh;
+            }
+            if (hh > best) code = 32u;
+            hh = hh < kNegInf16 ? kNegInf16 : hh;
+            h[c] = hh;
+            carry = rl(hh, 63);
+            S.u.ring[rbase + 64 * c + lane] = static_cast<i16>(hh);
+            g.Hs[static_cast<size_t>(row) * kBand + 64 * c + lane] = static_cast<i16>(hh);
+            g.BP[static_cast<size_t>(row) * kBand + 64 * c + lane] = static_cast<u8>(code);
+          } else {
+            h[c] = kNegInf16;
+          }
+        }
+        if (lane == static_cast<int>(rslot)) {
+          ring_tag = static_cast<int>(row);
+          ring_b = b;
+        }
+        dirty = true;
+        if (rl(m_outc, static_cast<int>(ri)) == 0) {  // an end node: score of the last column if the band has it
+          const i32 idx = static_cast<i32>(w) - 1 - b;
+          i32 sce = -0x7FFFFFFF;
+          if (idx >= 0 && idx < 64) sce = rl(h[0], idx);
+          else if (NCH > 1 && idx >= 64 && idx < kBand && two) sce = rl(h[NCH - 1], idx - 64);
+          if (sce > best_score) {
+            best_score = sce;
+            best_row = row;
+          }
+        }
+      }
+    }
+    wsync();  // backpointers visible to the traceback
+    tock(t_dp);
+    tick();
+    if (best_row == 0) {  // the last column is in no end node's band
+      failed = kPoaBandHit | (li << 8);
+      break;
+    }
+    // ---- 3. traceback over backpointer bytes, block-staged in LDS ----
+    // Lane t speculates on cell (i - t, j - t): a run of diagonal moves through rank-adjacent rows (the common
+    // case on a mostly linear graph) is committed in one step; anything else is a single generic step of lane 0.
+    u32 bad = 0, band_hit = 0;
+    {
+      u32 i = best_row;
+      i32 j = static_cast<i32>(w) - 1;
+      u32 cur_blk = 0xFFFFFFFFu;
+      u32 steps = 0;
+      while (i != 0) {  // once on the virtual row only insertions remain: pos_node already says kNone
+        if (++steps > nmax + lmax + 2) {
+          bad = 6;
+          break;
+        }
+        const u32 blk = (i - 1) >> 6;
+        if (blk != cur_blk) {
+          wsync();
+          const u32 row0 = blk * 64 + 1;
+          const u32 nrows = n_nodes + 1 - row0 < 64 ? n_nodes + 1 - row0 : 64;
+          const uint4* src = reinterpret_cast<const uint4*>(g.BP + static_cast<size_t>(row0) * kBand);
+          uint4* dst = reinterpret_cast<uint4*>(S.u.stage);
+#pragma unroll
+          for (u32 it = 0; it < 4 * NCH; ++it) {  // 64 rows x kBand bytes, 16 B per lane and step
+            const u32 q = it * 64 + lane;
+            if (q / (kBand / 16) < nrows) dst[q] = src[q];
+          }
+          if (static_cast<u32>(lane) < nrows) S.tb[lane] = g.tb[row0 + lane];
+          wsync();
+          cur_blk = blk;
+        }
+        const i32 l = static_cast<i32>((i - 1) & 63);
+        const i32 lt = l - lane;
+        const i32 jt = j - lane;
+        const bool in_blk = lt >= 0 && jt >= 0;
+        const uint4 t = S.tb[in_blk ? lt : 0];
+        const i32 bt = static_cast<i32>(t.x & 0xFFFFu);
+        const u32 nodet = t.x >> 16;
+        const i32 idx = jt - bt;
+        const bool inband = in_blk && idx >= 0 && idx < kBand;
+        const u32 code = S.u.stage[inband ? lt * kBand + idx : 0];
+        const u32 k = code & 15u;
+        u32 prt = 0xFFFFFFFFu;  // predecessor row the backpointer names (in-edges beyond the 4th: slow path below)
+        if (t.y == 0) prt = 0;
+        else if (k < 2) prt = (t.z >> (16 * k)) & 0xFFFFu;
+        else if (k < 4) prt = (t.w >> (16 * (k - 2))) & 0xFFFFu;
+        const bool edge = inband && ((idx < 2 && bt > 0) || (idx > kBand - 3 && bt + kBand < static_cast<i32>(w)));
+        const bool good = inband && code < 16u && jt >= 1 && prt == i - static_cast<u32>(lane) - 1;
+        const unsigned long long gb = __ballot(good);
+        const u32 run = ~gb ? static_cast<u32>(__builtin_ctzll(~gb)) : 64u;
+        if (run) {
+          if (static_cast<u32>(lane) < run) S.pos_node[jt - 1] = static_cast<u16>(nodet);
+          const unsigned long long in_run = run == 64 ? ~0ULL : ((1ULL << run) - 1ULL);
+          if (__ballot(edge) & in_run) band_hit = 1;
+          i -= run;
+          j -= static_cast<i32>(run);
+          continue;
+        }
+        // generic step for cell (i, j) = lane 0's cell
+        if (!rfl(inband ? 1 : 0)) {
+          bad = 6;
+          break;
+        }
+        if (rfl(edge ? 1 : 0)) band_hit = 1;
+        const u32 code0 = static_cast<u32>(rfl(static_cast<int>(code)));
+        if (code0 == 32u) {
+          if (j == 0) {
+            bad = 6;
+            break;
+          }
+          --j;  // insertion: pos_node[j] stays kNone
+        } else {
+          const u32 node = static_cast<u32>(rfl(static_cast<int>(nodet)));
+          u32 pr = static_cast<u32>(rfl(static_cast<int>(prt)));
+          if (pr == 0xFFFFFFFFu) pr = poa2_nth_pred(g, node, code0 & 15u, full);
+          if (code0 < 16u) {
+            if (j == 0) {
+              bad = 6;
+              break;
+            }
+            --j;
+            if (lane == 0) S.pos_node[j] = static_cast<u16>(node);
+          }
+          i = pr;
+        }
+      }
+    }
+    wsync();
+    tock(t_tb);
+    tick();
+    if (bad) {
+      failed = bad | (li << 8);
+      break;
+    }
+    if (band_hit) {
+      failed = kPoaBandHit | (li << 8);
+      break;
+    }
+    // ---- 4. spoa AddAlignment, one sequence position per lane ----
+    const u32 n_old = n_nodes;
+    u32 first_p = 0xFFFFFFFFu;
+    for (u32 p0 = 0; p0 < len && first_p == 0xFFFFFFFFu; p0 += 64) {
+      const u32 p = p0 + lane;
+      const unsigned long long bal = __ballot(p < len && S.pos_node[p] != kNone);
+      if (bal) first_p = p0 + static_cast<u32>(__builtin_ctzll(bal));
+    }
+    // New nodes anchored after a column (aligned group) go after ALL its members; the unaligned prefix goes
+    // before all members of the first column.
+    u32 carry_slot = n_old, carry_b = static_cast<u32>(lb);
+    if (first_p != 0xFFFFFFFFu) {
+      const u32 an = S.pos_node[first_p];
+      u32 r = g.rank_of[an];
+      const u32 ac = g.al_cnt[an];
+      for (u32 k = 0; k < ac; ++k) {
+        const u32 rk = g.rank_of[g.al[an * 4 + k]];
+        r = rk < r ? rk : r;
+      }
+      carry_slot = r;
+      carry_b = g.bpos[an];
+    }
+    u32 total_new = 0;
+    u32 ok = 1, why = 3;
+    for (u32 p0 = 0; p0 < len; p0 += 64) {
+      const u32 p = p0 + lane;
+      const bool valid = p < len;
+      const u32 an = valid ? S.pos_node[p] : kNone;
+      const u32 letter = valid ? S.seq[p] : 0u;
+      const bool has = valid && an != kNone;
+      u32 tgt = kNone, gslot = 0, gb = 0, ac = 0;
+      if (has) {
+        u32 rmax = g.rank_of[an];
+        ac = g.al_cnt[an];
+        if (g.code[an] == letter) tgt = an;
+        for (u32 k = 0; k < ac; ++k) {
+          const u32 kt = g.al[an * 4 + k];
+          const u32 rk = g.rank_of[kt];
+          rmax = rk > rmax ? rk : rmax;
+          if (tgt == kNone && g.code[kt] == letter) tgt = kt;
+        }
+        gslot = rmax + 1;
+        gb = g.bpos[an];
+      }
+      // order slot / backbone coordinate of the last aligned position at or before p
+      const unsigned long long bal = __ballot(has);
+      const unsigned long long below = bal & (lane == 63 ? ~0ULL : ((2ULL << lane) - 1ULL));
+      const int src = below ? 63 - __builtin_clzll(below) : 0;
+      const u32 s_sh = static_cast<u32>(__shfl(static_cast<int>(gslot), src, 64));
+      const u32 b_sh = static_cast<u32>(__shfl(static_cast<int>(gb), src, 64));
+      const u32 fslot = below ? s_sh : carry_slot;
+      const u32 fb = below ? b_sh : carry_b;
+      if (bal) {
+        const int top = 63 - __builtin_clzll(bal);
+        carry_slot = static_cast<u32>(rl(static_cast<int>(gslot), top));
+        carry_b = static_cast<u32>(rl(static_cast<int>(gb), top));
+      }
+      const bool is_new = valid && tgt == kNone;
+      const unsigned long long nb = __ballot(is_new);
+      const u32 cnt = static_cast<u32>(__builtin_popcountll(nb));
+      if (n_old + total_new + cnt > nmax || total_new + cnt > lmax) {
+        ok = 0;
+        why = 2;
+        break;
+      }
+      if (is_new) {
+        const u32 t = total_new + static_cast<u32>(__builtin_popcountll(nb & lanemask_lt()));
+        const u32 id = n_old + t;
+        tgt = id;
+        g.code[id] = static_cast<u8>(letter);
+        g.in_cnt[id] = 0;
+        g.out_cnt[id] = 0;
+        g.visits[id] = 0;
+        g.new_slot[t] = static_cast<u16>(fslot);
+        g.bpos[id] = static_cast<u16>(fb);
+        u32 c2 = 0;
+        if (has) {  // joins an's aligned group
+          for (u32 k = 0; k < ac; ++k) {
+            const u32 kt = g.al[an * 4 + k];
+            const u32 ck = g.al_cnt[kt];
+            if (ck < 4) {
+              g.al[kt * 4 + ck] = static_cast<u16>(id);
+              g.al_cnt[kt] = static_cast<u8>(ck + 1);
+            }
+            if (c2 < 4) g.al[id * 4 + c2++] = static_cast<u16>(kt);
+          }
+          if (ac < 4) {
+            g.al[an * 4 + ac] = static_cast<u16>(id);
+            g.al_cnt[an] = static_cast<u8>(ac + 1);
+          }
+          if (c2 < 4) g.al[id * 4 + c2++] = static_cast<u16>(an);
+        }
+        g.al_cnt[id] = static_cast<u8>(c2);
+      }
+      total_new += cnt;
+      if (valid) {
+        S.u.add.tgt[p] = static_cast<u16>(tgt);
+        if (len >= 2) g.visits[tgt] += 1;
+      }
+    }
+    wsync();
+    if (ok) {
+      for (u32 p0 = 0; p0 < len; p0 += 64) {
+        const u32 p = p0 + lane;
+        bool okl = true;
+        if (p >= 1 && p < len)
+          okl = poa_add_edge(g, S.u.add.tgt[p - 1], S.u.add.tgt[p], static_cast<i32>(S.wgt[p - 1]) + S.wgt[p]);
+        if (__ballot(!okl)) {
+          ok = 0;
+          why = 3;
+        }
+      }
+    }
+    wsync();
+    if (!ok) {
+      failed = why;
+      break;
+    }
+    const u32 n_new = total_new;
+    n_nodes = n_old + n_new;
+    tock(t_add);
+    tick();
+    // ---- 5. order rebuild: old rank r -> r + #(new slots <= r); t-th new node -> slot_t + t ----
+    if (n_new) {
+      for (u32 r = lane; r < n_old; r += 64) {
+        u32 lo = 0, hi = n_new;  // upper_bound(new_slot, r)
+        while (lo < hi) {
+          const u32 mid = (lo + hi) >> 1;
+          if (g.new_slot[mid] <= r) lo = mid + 1;
+          else hi = mid;
+        }
+        g.order2[r + lo] = g.order[r];
+      }
+      for (u32 t = lane; t < n_new; t += 64) g.order2[static_cast<u32>(g.new_slot[t]) + t] = static_cast<u16>(n_old + t);
+      wsync();
+      for (u32 r = lane; r < n_nodes; r += 64) {
+        const u32 v = g.order2[r];
+        g.order[r] = static_cast<u16>(v);
+        g.rank_of[v] = static_cast<u16>(r);
+      }
+      wsync();
+    }
+    tock(t_ord);
+  }
+  if (failed) {
+    copy_backbone();
+    return failed;
+  }
+  tick();
+  if (lane == 0) poa_consensus_lane0(g, n_nodes, nmax, win, trim, out, out_len);
+  wsync();
+  tock(t_cons);
+  if (phase_cycles && lane == 0) {
+    atomicAdd(&phase_cycles[0], t_sub);
+    atomicAdd(&phase_cycles[1], t_dp);
+    atomicAdd(&phase_cycles[2], t_tb);
+    atomicAdd(&phase_cycles[3], t_add);
+    atomicAdd(&phase_cycles[4], t_ord);
+    atomicAdd(&phase_cycles[5], t_cons);
+  }
+  return 1;
+}
+
+template <int NCH>
+__global__ __launch_bounds__(256) void poa2_kernel(const PoaWindow* __restrict__ windows, u32 n_windows,
+                                                  const PoaLayer* __restrict__ layers, const u8* __restrict__ codes,
+                                                  const u8* __restrict__ quals, unsigned char* __restrict__ scratch,
+                                                  size_t slot_bytes, u32 n_slots, u32 nmax, u32 lmax, int m, int n_,
+                                                  int gp, int trim, u8* __restrict__ out, u32* __restrict__ out_len,
+                                                  u32* __restrict__ status,
+                                                  unsigned long long* __restrict__ phase_cycles) {
+  __shared__ Poa2Lds<NCH> lds[4];
+  const u32 wv = static_cast<u32>(__builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6)));
+  const u32 slot = blockIdx.x * 4 + wv;
+  if (slot >= n_slots) return;
+  Poa2Slot g = poa2_carve(scratch + static_cast<size_t>(slot) * slot_bytes, nmax, lmax, 64 * NCH);
+  for (u32 wi = slot; wi < n_windows; wi += n_slots) {
+    const PoaWindow win = windows[wi];
+    const u32 st = poa2_window<NCH>(win, layers, codes, quals, g, nmax, lmax, m, n_, gp, trim, lds[wv],
+                               out + win.out_off, out_len + wi, phase_cycles);
+    if (lane_id() == 0) status[wi] = st;
+    wsync();
+  }
+}
+
+}  // namespace
+
+void poa_v2_launch(Engine& e, const PoaBatchDev& b, int nch) {
+  if (b.n_windows == 0) return;
+  const size_t slot_bytes = poa2_slot_bytes(b.nmax, b.lmax, 64u * nch);
+  size_t free_b = 0, total_b = 0;
+  RVN_HIP(hipMemGetInfo(&free_b, &total_b));
+  u32 n_slots = std::min<u32>(b.n_windows, 256 * 16);  // up to 4 workgroups of 4 waves per CU
+  const size_t budget = e.poa2_scratch.cap + free_b / 2;
+  if (static_cast<size_t>(n_slots) * slot_bytes > budget) n_slots = static_cast<u32>(std::max<size_t>(1, budget / slot_bytes));
+  n_slots = ((n_slots + 3) / 4) * 4;
+  unsigned char* d_scratch = e.poa2_scratch.get<unsigned char>(static_cast<size_t>(n_slots) * slot_bytes + 256);
+  if (nch == 1) {
+    RVN_KLAUNCH(kKPoaBanded, poa2_kernel<1><<<n_slots / 4, 256, 0, e.stream>>>(
+                                 b.wins, b.n_windows, b.layers, b.codes, b.quals, d_scratch, slot_bytes, n_slots, b.nmax,
+                                 b.lmax, b.m, b.n, b.g, b.trim, b.out, b.out_len, b.status, b.phase_cycles));
+  } else {
+    RVN_KLAUNCH(kKPoaBanded, poa2_kernel<2><<<n_slots / 4, 256, 0, e.stream>>>(
+                                 b.wins, b.n_windows, b.layers, b.codes, b.quals, d_scratch, slot_bytes, n_slots, b.nmax,
+                                 b.lmax, b.m, b.n, b.g, b.trim, b.out, b.out_len, b.status, b.phase_cycles));
+  }
+}
+
+}  // namespace rvn

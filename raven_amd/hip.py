@@ -33,7 +33,7 @@ SYMBOLS = [
     "rvn_engine_map_batch", "rvn_engine_map_fetch", "rvn_engine_map_fetch_filtered",
     "rvn_find_overlaps_and_create_piles", "rvn_pass1_pile_words", "rvn_pass1_num_overlaps",
     "rvn_pass1_fetch_piles", "rvn_pass1_fetch_overlaps", "rvn_pass1_destroy", "rvn_pile_add_layers",
-    "rvn_edit_distance_batch", "rvn_poa_consensus_batch", "rvn_poa_phase_cycles", "rvn_pile_add_kmers_batch",
+    "rvn_edit_distance_batch", "rvn_poa_consensus_batch", "rvn_poa_phase_cycles", "rvn_poa_set_mode", "rvn_poa_fallback_windows", "rvn_poa_wide_windows", "rvn_pile_add_kmers_batch",
     "rvn_test_low_complexity", "rvn_polish_round",
     "rvn_engine_sketch", "rvn_engine_sketch_fetch", "rvn_engine_index_size", "rvn_engine_index_fetch",
     "rvn_engine_counters", "rvn_engine_num_stages", "rvn_engine_stage_name", "rvn_engine_stage_ms",
@@ -92,6 +92,12 @@ def lib():
     L.rvn_poa_consensus_batch.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, u32, i32, i32, i32, i32, vp, vp, vp, vp,
                                           C.POINTER(dbl)]
     L.rvn_poa_phase_cycles.argtypes = [vp, vp]
+    L.rvn_poa_set_mode.argtypes = [vp, i32]
+    L.rvn_poa_set_mode.restype = i32
+    L.rvn_poa_fallback_windows.argtypes = [vp]
+    L.rvn_poa_fallback_windows.restype = u32
+    L.rvn_poa_wide_windows.argtypes = [vp]
+    L.rvn_poa_wide_windows.restype = u32
     L.rvn_engine_sketch.argtypes = [vp, vp, u32, u32, i32, C.POINTER(u64)]
     L.rvn_engine_sketch_fetch.argtypes = [vp, vp, vp, vp]
     L.rvn_engine_index_size.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
@@ -354,6 +360,16 @@ class Engine:
         c = np.zeros(6, dtype=np.uint64)
         lib().rvn_poa_phase_cycles(self._h, _p(c))
         return dict(zip(("subgraph", "dp", "traceback", "add_alignment", "order", "consensus"), (int(x) for x in c)))
+
+    def poa_set_mode(self, mode):
+        """0 band 64 -> 128 -> full matrix (default), 1 full matrix only, 2 band 64 only, 3 band 128 only."""
+        return int(lib().rvn_poa_set_mode(self._h, int(mode)))
+
+    def poa_fallback_windows(self):
+        return int(lib().rvn_poa_fallback_windows(self._h))
+
+    def poa_wide_windows(self):
+        return int(lib().rvn_poa_wide_windows(self._h))
 
     # -- introspection ---------------------------------------------------------------------
     def sketch(self, reads: Reads, first=0, last=None, minhash=False):

@@ -45,6 +45,7 @@ def main():
         truths.append(truth)
         cells += sum(len(r) for r in reads) * 650  # ~nodes x layer length, order of magnitude
     eng = hip.Engine()
+    eng.poa_set_mode(int(os.environ.get("RVN_POA_MODE", "0")))
     eng.poa_consensus_batch(wins[:64])  # warm-up / allocation
     t = time.time()
     cons, status, ms = eng.poa_consensus_batch(wins)
@@ -53,7 +54,8 @@ def main():
            "windows_per_s": n_windows / ms * 1e3, "approx_gcups": cells / ms / 1e6,
            "status_counts": {int(k): int(v) for k, v in zip(*np.unique(status & 0xFF, return_counts=True))},
            "fail_layers": [int(x) >> 8 for x in status[status > 1][:20]], "fail_windows": [int(i) for i in np.nonzero(status > 1)[0][:20]],
-           "phase_cycles": eng.poa_phase_cycles(),
+           "phase_cycles": eng.poa_phase_cycles(), "fallback_windows": eng.poa_fallback_windows(), "wide_windows": eng.poa_wide_windows(),
+           "kernel_ms": {k: v for k, v in eng.kernel_ms().items() if k.startswith("poa")} if hasattr(eng, "kernel_ms") else None,
            "read_bases_per_s": sum(sum(len(x) for x in w["layers"][1:]) for w in wins) / ms * 1e3}
     if n_check:
         from oracle import oracle
