@@ -141,7 +141,9 @@ int rvn_poa_consensus_batch(rvn_engine* e, const uint8_t* codes, const uint8_t* 
  * Window breakpoints come from the mapping's chain anchors instead of an edlib path. */
 typedef struct rvn_polish_stats {
   uint64_t n_overlaps, n_reads_used, n_layers, n_windows, n_polished_windows, n_failed_windows;
-  double poa_ms;
+  double poa_ms;                    /* device time of the window-consensus batch */
+  double map_ms, host_ms, total_ms; /* wall: index+map+read-back | host window/layer building + stitching | whole call */
+  uint64_t n_dropped_layers;        /* read pieces dropped because their length contradicts their target span */
 } rvn_polish_stats;
 int rvn_polish_round(rvn_engine* e, rvn_reads* targets, rvn_reads* reads, const uint8_t* read_quals,
                      const uint64_t* qual_offsets, double q, double err, uint32_t w, int trim, int match, int mismatch,

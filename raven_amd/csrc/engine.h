@@ -103,7 +103,7 @@ struct Engine {
   DevBuf m_grp[2], m_pos[2];
   DevBuf seg_off, iv_slot_begin, iv_slot_end, iv_cnt, iv_off, iv_begin, iv_end;
   DevBuf lis_min, lis_pred, lis_tail, lis_mask, ovl_slots, ovl_flags, ovl_scan;
-  DevBuf poa_scratch, poa2_scratch;
+  DevBuf poa_scratch, poa2_scratch, polish_quals;
   int poa_mode = 0;  // 0 banded 64 -> 128 -> full matrix; 1 full matrix only; 2 band 64 only; 3 band 128 only (tests)
   u32 poa_fallback_windows = 0;  // windows of the last batch re-run by the full-matrix kernel
   u32 poa_wide_windows = 0;      // windows of the last batch re-run with the 128-column band
@@ -172,7 +172,9 @@ void poa_consensus_batch(Engine& e, const u8* h_codes, const u8* h_quals, const 
 
 struct PolishStats {
   u64 n_overlaps = 0, n_reads_used = 0, n_layers = 0, n_windows = 0, n_polished_windows = 0, n_failed_windows = 0;
-  double poa_ms = 0;
+  u64 n_dropped_layers = 0;  // pieces whose length contradicts their target span (misplaced breakpoints)
+  double poa_ms = 0;                            // device time of the POA batch
+  double map_ms = 0, host_ms = 0, total_ms = 0;  // wall: index + map + read-back | host window/layer building | all
 };
 // One racon polishing round (polish.hip): targets T, reads R, optional per-base Phred+33 qualities of the reads
 void polish_round(Engine& e, ReadsDev& T, ReadsDev& R, const u8* h_quals, const u64* h_qual_off, double q_thr,

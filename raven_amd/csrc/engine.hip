@@ -473,6 +473,10 @@ int rvn_polish_round(rvn_engine* h, rvn_reads* targets, rvn_reads* reads, const 
       stats->n_polished_windows = st.n_polished_windows;
       stats->n_failed_windows = st.n_failed_windows;
       stats->poa_ms = st.poa_ms;
+      stats->map_ms = st.map_ms;
+      stats->host_ms = st.host_ms;
+      stats->total_ms = st.total_ms;
+      stats->n_dropped_layers = st.n_dropped_layers;
     }
     return RVN_OK;
   });

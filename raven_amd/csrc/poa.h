@@ -4,6 +4,8 @@
 // written once here as templates over the slot type.
 #pragma once
 
+#include <vector>
+
 #include "engine.h"
 #include "wave.h"
 
@@ -17,10 +19,49 @@ struct PoaWindow {  // host-prepared, one per window
   u32 layer_first, n_layers;  // range in the (begin-sorted) layer table; layer_first = backbone
   u32 out_off, out_cap;
 };
-struct PoaLayer {
-  u64 code_off;
-  u32 len, begin, end, has_qual;
+// A layer is either a run of one-byte codes (rvn_poa_consensus_batch: caller-built windows) or a slice of a 2-bit
+// packed read set already resident in HBM (rvn_polish_round: no host-side expansion of the reads).
+enum : u32 {
+  kLayerQual = 1u,      // weights = Phred - 33 from the quality array (else unit weight)
+  kLayerPacked = 2u,    // bases come from a packed read set: code_off = first word of the read
+  kLayerRc = 4u,        // packed: reverse complement of the read
+  kLayerTarget = 8u,    // packed: the read set is the target set (backbones)
+  kLayerZeroW = 16u,    // weight 0 (racon's dummy '!' backbone quality)
 };
+struct PoaLayer {
+  u64 code_off;  // bytes: offset into codes | packed: word offset of the read
+  u64 qual_off;  // offset of the layer (bytes) / of the read (packed) in the quality array
+  u32 len, begin, end, flags;
+  u32 q_begin, q_len;  // packed: first base of the layer in the (oriented) read, length of the read
+};
+struct PoaSrc {
+  const u8* codes;
+  const u8* quals;
+  const u64* packed_reads;
+  const u64* packed_targets;
+  const u8* read_quals;    // per-base Phred+33 of the packed reads (nullable)
+  const u8* layer_ok;      // per layer: 0 = dropped by the mean-quality filter (nullable = all kept)
+};
+
+__device__ __forceinline__ u32 poa_layer_src_pos(const PoaLayer& L, u32 i) {
+  const u32 pos = L.q_begin + i;
+  return (L.flags & kLayerRc) ? L.q_len - 1 - pos : pos;
+}
+__device__ __forceinline__ u32 poa_layer_code(const PoaSrc& src, const PoaLayer& L, u32 i) {
+  if (L.flags & kLayerPacked) {
+    const u64* P = (L.flags & kLayerTarget) ? src.packed_targets : src.packed_reads;
+    const u32 sp = poa_layer_src_pos(L, i);
+    const u32 c = static_cast<u32>(P[L.code_off + (sp >> 5)] >> ((sp & 31) << 1)) & 3u;
+    return (L.flags & kLayerRc) ? 3u - c : c;
+  }
+  return src.codes[L.code_off + i];
+}
+__device__ __forceinline__ i32 poa_layer_weight(const PoaSrc& src, const PoaLayer& L, u32 i) {
+  if (L.flags & kLayerZeroW) return 0;
+  if (!(L.flags & kLayerQual)) return 1;
+  if (L.flags & kLayerPacked) return static_cast<i32>(src.read_quals[L.qual_off + poa_layer_src_pos(L, i)]) - 33;
+  return static_cast<i32>(src.quals[L.qual_off + i]) - 33;
+}
 
 // window status: 0 backbone returned (< 3 sequences), 1 polished, 2 node limit, 3 in-degree limit, 4 length limit,
 // 5..7 internal (| layer << 8), 8 alignment left the band (banded kernel only; such windows are re-run by the
@@ -31,18 +72,32 @@ struct PoaBatchDev {  // device-side batch description shared by both launchers
   const PoaWindow* wins;
   u32 n_windows;
   const PoaLayer* layers;
-  const u8* codes;
-  const u8* quals;
+  PoaSrc src;
   u32 nmax, lmax;
   int m, n, g, trim;
   u8* out;
   u32* out_len;
   u32* status;
   unsigned long long* phase_cycles;
+  const u32* sched;  // window order for the persistent waves (heaviest first), or null
+  u32* next;         // work counter (zeroed by the launcher)
 };
 
 void poa_v1_launch(Engine& e, const PoaBatchDev& b);  // poa.hip
+// windows + begin-sorted layer descriptors on the host, all sources of `src` resident in HBM (poa.hip)
+void poa_run(Engine& e, const std::vector<PoaWindow>& wins, const std::vector<PoaLayer>& lays, const PoaSrc& src,
+             u32 max_bb, u32 max_len, int m, int n, int g, int trim, u8* h_out, u64 out_total, u32* h_out_len,
+             u32* h_status, double* device_ms);
 void poa_v2_launch(Engine& e, const PoaBatchDev& b, int nch);  // poa2.hip: band = 64 * nch columns
+
+// Persistent waves take windows from a shared counter (longest-processing-time-first order when `sched` is given).
+__device__ __forceinline__ u32 poa_next_window(u32* next, const u32* sched, u32 n_windows) {
+  u32 i = 0;
+  if (lane_id() == 0) i = atomicAdd(next, 1u);
+  i = static_cast<u32>(__builtin_amdgcn_readfirstlane(static_cast<int>(i)));
+  if (i >= n_windows) return 0xFFFFFFFFu;
+  return sched ? sched[i] : i;
+}
 
 __device__ __forceinline__ void wsync() {
   __threadfence_block();

@@ -17,6 +17,8 @@
 //      from spoa's DFS order, which is why consensus parity is tolerance-based.
 // Integer VALU + L2 bound; no MFMA.
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 #include "poa.h"
@@ -116,8 +118,8 @@ __device__ inline u32 poa_add_node(PoaSlot& g, u32& n_nodes, u32 code) {
 }
 
 // One window. Returns status: 0 = backbone returned (< 3 sequences), 1 = polished, 2 = limits exceeded.
-__device__ u32 poa_window(const PoaWindow& win, const PoaLayer* __restrict__ layers, const u8* __restrict__ codes,
-                          const u8* __restrict__ quals, PoaSlot& g, u32 nmax, u32 lmax, int m, int n_, int gp, int trim,
+__device__ u32 poa_window(const PoaWindow& win, const PoaLayer* __restrict__ layers, const PoaSrc& src,
+                          PoaSlot& g, u32 nmax, u32 lmax, int m, int n_, int gp, int trim,
                           u8* s_seq, u8* s_w, u8* __restrict__ out, u32* out_len,
                           unsigned long long* __restrict__ phase_cycles) {
   const int lane = lane_id();
@@ -128,10 +130,17 @@ __device__ u32 poa_window(const PoaWindow& win, const PoaLayer* __restrict__ lay
   const u32 blen = bb.len;
   auto copy_backbone = [&]() {
     const u32 n = blen < win.out_cap ? blen : win.out_cap;
-    for (u32 i = lane; i < n; i += 64) out[i] = codes[bb.code_off + i];
+    for (u32 i = lane; i < n; i += 64) out[i] = static_cast<u8>(poa_layer_code(src, bb, i));
     if (lane == 0) *out_len = n;
   };
-  if (win.n_layers < 3) {
+  // layers dropped by racon's mean-quality filter do not count as sequences of the window
+  u32 n_eff = win.n_layers;
+  if (src.layer_ok) {
+    u32 cnt = 0;
+    for (u32 i = 1 + lane; i < win.n_layers; i += 64) cnt += src.layer_ok[win.layer_first + i] ? 1u : 0u;
+    n_eff = 1 + wave_sum(cnt);
+  }
+  if (n_eff < 3) {
     copy_backbone();
     return 0;
   }
@@ -142,14 +151,14 @@ __device__ u32 poa_window(const PoaWindow& win, const PoaLayer* __restrict__ lay
   // ---- backbone graph (spoa AddAlignment with an empty alignment) ----
   u32 n_nodes = blen;
   for (u32 i = lane; i < blen; i += 64) {
-    g.code[i] = codes[bb.code_off + i];
+    g.code[i] = static_cast<u8>(poa_layer_code(src, bb, i));
     g.al_cnt[i] = 0;
     g.visits[i] = blen >= 2 ? 1 : 0;
     g.rank_of[i] = static_cast<u16>(i);
     g.order[i] = static_cast<u16>(i);
-    const i32 wi = bb.has_qual ? static_cast<i32>(quals[bb.code_off + i]) - 33 : 1;
+    const i32 wi = poa_layer_weight(src, bb, i);
     if (i > 0) {
-      const i32 wp = bb.has_qual ? static_cast<i32>(quals[bb.code_off + i - 1]) - 33 : 1;
+      const i32 wp = poa_layer_weight(src, bb, i - 1);
       g.in_cnt[i] = 1;
       g.in_tail[i * kPoaMaxIn] = static_cast<u16>(i - 1);
       g.in_w[i * kPoaMaxIn] = wp + wi;
@@ -165,14 +174,14 @@ __device__ u32 poa_window(const PoaWindow& win, const PoaLayer* __restrict__ lay
   for (u32 li = 1; li < win.n_layers && !failed; ++li) {
     const PoaLayer L = layers[win.layer_first + li];
     const u32 len = L.len;
-    if (len == 0) continue;
+    if (len == 0 || (src.layer_ok && !src.layer_ok[win.layer_first + li])) continue;
     if (len > lmax || len > kPoaMaxSeq) {
       failed = 4;
       break;
     }
     for (u32 i = lane; i < len; i += 64) {
-      s_seq[i] = codes[L.code_off + i];
-      s_w[i] = L.has_qual ? static_cast<u8>(quals[L.code_off + i] - 33) : 1;
+      s_seq[i] = static_cast<u8>(poa_layer_code(src, L, i));
+      s_w[i] = static_cast<u8>(poa_layer_weight(src, L, i));
     }
     const bool full = L.begin < offset && L.end > blen - offset;
     tick();
@@ -542,7 +551,9 @@ __device__ u32 poa_window(const PoaWindow& win, const PoaLayer* __restrict__ lay
   }
   // ---- consensus: spoa TraverseHeaviestBundle + BranchCompletion (lane 0) ----
   tick();
-  if (lane == 0) poa_consensus_lane0(g, n_nodes, nmax, win, trim, out, out_len);
+  PoaWindow weff = win;
+  weff.n_layers = n_eff;
+  if (lane == 0) poa_consensus_lane0(g, n_nodes, nmax, weff, trim, out, out_len);
   wsync();
   tock(t_cons);
   if (phase_cycles && lane == 0) {
@@ -557,21 +568,24 @@ __device__ u32 poa_window(const PoaWindow& win, const PoaLayer* __restrict__ lay
 }
 
 __global__ __launch_bounds__(256) void poa_kernel(const PoaWindow* __restrict__ windows, u32 n_windows,
-                                                 const PoaLayer* __restrict__ layers, const u8* __restrict__ codes,
-                                                 const u8* __restrict__ quals, unsigned char* __restrict__ scratch,
+                                                 const PoaLayer* __restrict__ layers, const PoaSrc src,
+                                                 unsigned char* __restrict__ scratch,
                                                  size_t slot_bytes, u32 n_slots, u32 nmax, u32 lmax, int m, int n_,
                                                  int gp, int trim, u8* __restrict__ out, u32* __restrict__ out_len,
                                                  u32* __restrict__ status,
-                                                 unsigned long long* __restrict__ phase_cycles) {
+                                                 unsigned long long* __restrict__ phase_cycles,
+                                                 const u32* __restrict__ sched, u32* __restrict__ next) {
   __shared__ u8 s_seq[4][kPoaMaxSeq];
   __shared__ u8 s_w[4][kPoaMaxSeq];
   const u32 wv = static_cast<u32>(__builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6)));
   const u32 slot = blockIdx.x * 4 + wv;
   if (slot >= n_slots) return;
   PoaSlot g = poa_carve(scratch + static_cast<size_t>(slot) * slot_bytes, nmax, lmax);
-  for (u32 wi = slot; wi < n_windows; wi += n_slots) {
+  for (;;) {
+    const u32 wi = poa_next_window(next, sched, n_windows);
+    if (wi == 0xFFFFFFFFu) break;
     const PoaWindow win = windows[wi];
-    const u32 st = poa_window(win, layers, codes, quals, g, nmax, lmax, m, n_, gp, trim, s_seq[wv], s_w[wv],
+    const u32 st = poa_window(win, layers, src, g, nmax, lmax, m, n_, gp, trim, s_seq[wv], s_w[wv],
                               out + win.out_off, out_len + wi, phase_cycles);
     if (lane_id() == 0) status[wi] = st;
     wsync();
@@ -590,50 +604,24 @@ void poa_v1_launch(Engine& e, const PoaBatchDev& b) {
   if (static_cast<size_t>(n_slots) * slot_bytes > budget) n_slots = static_cast<u32>(std::max<size_t>(1, budget / slot_bytes));
   n_slots = ((n_slots + 3) / 4) * 4;
   unsigned char* d_scratch = e.poa_scratch.get<unsigned char>(static_cast<size_t>(n_slots) * slot_bytes + 256);
-  RVN_KLAUNCH(kKPoa, poa_kernel<<<n_slots / 4, 256, 0, e.stream>>>(b.wins, b.n_windows, b.layers, b.codes, b.quals,
+  RVN_HIP(hipMemsetAsync(b.next, 0, 4, e.stream));
+  RVN_KLAUNCH(kKPoa, poa_kernel<<<n_slots / 4, 256, 0, e.stream>>>(b.wins, b.n_windows, b.layers, b.src,
                                                                     d_scratch, slot_bytes, n_slots, b.nmax, b.lmax, b.m,
                                                                     b.n, b.g, b.trim, b.out, b.out_len, b.status,
-                                                                    b.phase_cycles));
+                                                                    b.phase_cycles, b.sched, b.next));
 }
 
-// Host entry: see rvn_poa_consensus_batch in raven_hip.h.  Every window first goes through the banded LDS kernel
-// (poa2.hip) with a 64-column band; windows whose alignment touches the band edge are repeated with 128 columns,
-// and what is left (or beyond a limit) is re-run by the full-matrix kernel above, so a status >= 2 in the result
-// means the window is beyond ALL of them.
-void poa_consensus_batch(Engine& e, const u8* h_codes, const u8* h_quals, const u64* h_layer_off,
-                         const u32* h_begins, const u32* h_ends, const u32* h_has_qual, const u32* h_win_off,
-                         u32 n_windows, int m, int n, int g, int trim, u8* h_out, const u64* h_out_off,
-                         u32* h_out_len, u32* h_status, double* device_ms) {
+// Core of a batch: windows + (begin-sorted) layer descriptors are on the host, every base/quality source named by
+// `src` is already in HBM.  Every window first goes through the banded LDS kernel (poa2.hip) with a 64-column band;
+// windows whose alignment touches the band edge are repeated with 128 columns, and what is left (or beyond a
+// limit) is re-run by the full-matrix kernel above, so a status >= 2 in the result means the window is beyond ALL
+// of them.
+void poa_run(Engine& e, const std::vector<PoaWindow>& wins, const std::vector<PoaLayer>& lays, const PoaSrc& src,
+             u32 max_bb, u32 max_len, int m, int n, int g, int trim, u8* h_out, u64 out_total, u32* h_out_len,
+             u32* h_status, double* device_ms) {
+  const u32 n_windows = static_cast<u32>(wins.size());
   if (n_windows == 0) return;
   hipStream_t s = e.stream;
-  const u32 n_layers = h_win_off[n_windows];
-  const u64 total = h_layer_off[n_layers];
-  std::vector<PoaWindow> wins(n_windows);
-  std::vector<PoaLayer> lays(n_layers);
-  u32 max_bb = 1, max_len = 1;
-  for (u32 w = 0; w < n_windows; ++w) {
-    const u32 f = h_win_off[w], l = h_win_off[w + 1];
-    wins[w].layer_first = f;
-    wins[w].n_layers = l - f;
-    wins[w].out_off = static_cast<u32>(h_out_off[w]);
-    wins[w].out_cap = static_cast<u32>(h_out_off[w + 1] - h_out_off[w]);
-    // racon: rank = stable sort of layers 1.. by begin position
-    std::vector<u32> rank(l - f);
-    for (u32 i = 0; i < l - f; ++i) rank[i] = f + i;
-    if (l - f > 1)
-      std::stable_sort(rank.begin() + 1, rank.end(), [&](u32 a, u32 b) { return h_begins[a] < h_begins[b]; });
-    for (u32 i = 0; i < l - f; ++i) {
-      const u32 src = rank[i];
-      PoaLayer& L = lays[f + i];
-      L.code_off = h_layer_off[src];
-      L.len = static_cast<u32>(h_layer_off[src + 1] - h_layer_off[src]);
-      L.begin = h_begins[src];
-      L.end = h_ends[src];
-      L.has_qual = (h_quals && h_has_qual && h_has_qual[src]) ? 1 : 0;
-      if (i == 0) max_bb = std::max(max_bb, L.len);
-      max_len = std::max(max_len, L.len);
-    }
-  }
   // limits: nodes <= nmax, layer length <= lmax (windows beyond them come back with status 2 / 4)
   PoaBatchDev b{};
   b.lmax = std::min<u32>(kPoaMaxSeq, std::max<u32>(64, ((max_len + 63) / 64) * 64));
@@ -643,25 +631,26 @@ void poa_consensus_batch(Engine& e, const u8* h_codes, const u8* h_quals, const 
   b.g = g;
   b.trim = trim;
   b.n_windows = n_windows;
-
-  u8* d_codes = e.tmp_a.get<u8>(total + 16);
-  u8* d_quals = h_quals ? e.tmp_b.get<u8>(total + 16) : nullptr;
+  b.src = src;
   PoaWindow* d_wins = e.tmp_c.get<PoaWindow>(2 * static_cast<size_t>(n_windows) + 2);
-  PoaLayer* d_lays = e.tmp_d.get<PoaLayer>(n_layers + 1);
-  const u64 out_total = h_out_off[n_windows];
+  PoaLayer* d_lays = e.tmp_d.get<PoaLayer>(lays.size() + 1);
   u8* d_out = e.tmp_e.get<u8>(out_total + 16);
   u32* d_len = e.tmp_f.get<u32>(4 * static_cast<size_t>(n_windows) + 4);
   u32* d_status = d_len + n_windows + 1;
-  unsigned long long* d_phase = e.q_start.get<unsigned long long>(8);
-  RVN_HIP(hipMemsetAsync(d_phase, 0, 64, s));
-  RVN_HIP(hipMemcpyAsync(d_codes, h_codes, total, hipMemcpyHostToDevice, s));
-  if (d_quals) RVN_HIP(hipMemcpyAsync(d_quals, h_quals, total, hipMemcpyHostToDevice, s));
+  unsigned long long* d_phase = e.q_start.get<unsigned long long>(10);
+  RVN_HIP(hipMemsetAsync(d_phase, 0, 80, s));
+  // heaviest windows first: cost ~ number of layers
+  std::vector<u32> sched(n_windows);
+  for (u32 i = 0; i < n_windows; ++i) sched[i] = i;
+  std::stable_sort(sched.begin(), sched.end(), [&](u32 a, u32 c) { return wins[a].n_layers > wins[c].n_layers; });
+  u32* d_sched = e.q_cnt.get<u32>(n_windows + 1);
+  RVN_HIP(hipMemcpyAsync(d_sched, sched.data(), sched.size() * 4, hipMemcpyHostToDevice, s));
+  b.sched = d_sched;
+  b.next = reinterpret_cast<u32*>(d_phase + 8);
   RVN_HIP(hipMemcpyAsync(d_wins, wins.data(), wins.size() * sizeof(PoaWindow), hipMemcpyHostToDevice, s));
   RVN_HIP(hipMemcpyAsync(d_lays, lays.data(), lays.size() * sizeof(PoaLayer), hipMemcpyHostToDevice, s));
   b.wins = d_wins;
   b.layers = d_lays;
-  b.codes = d_codes;
-  b.quals = d_quals;
   b.out = d_out;
   b.out_len = d_len;
   b.status = d_status;
@@ -689,6 +678,7 @@ void poa_consensus_batch(Engine& e, const u8* h_codes, const u8* h_quals, const 
       rb.n_windows = static_cast<u32>(redo.size());
       rb.out_len = d_rlen;
       rb.status = d_rstatus;
+      rb.sched = nullptr;
       if (which == 2) poa_v2_launch(e, rb, 2);
       else poa_v1_launch(e, rb);
       std::vector<u32> rl(redo.size()), rs(redo.size());
@@ -705,6 +695,14 @@ void poa_consensus_batch(Engine& e, const u8* h_codes, const u8* h_quals, const 
       const u32 st = h_status[w] & 0xFF;
       if (st == kPoaBandHit) wide.push_back(w);
       else if (st >= 2) fullm.push_back(w);
+    }
+    if (std::getenv("RVN_POA_DEBUG")) {
+      for (u32 w : wide) {
+        const PoaLayer& L = lays[wins[w].layer_first + (h_status[w] >> 8)];
+        std::fprintf(stderr, "[raven_hip] poa: window %u band hit at layer %u of %u (len %u begin %u end %u, backbone %u)\n",
+                     w, h_status[w] >> 8, wins[w].n_layers, L.len, L.begin, L.end, lays[wins[w].layer_first].len);
+      }
+      for (u32 w : fullm) std::fprintf(stderr, "[raven_hip] poa: window %u status %u -> full matrix\n", w, h_status[w]);
     }
     if (!wide.empty()) {
       rerun(wide, 2);
@@ -726,6 +724,54 @@ void poa_consensus_batch(Engine& e, const u8* h_codes, const u8* h_quals, const 
     RVN_HIP(hipEventElapsedTime(&ms, e.ev0, e.ev1));
     *device_ms = ms;
   }
+}
+
+// Host entry: see rvn_poa_consensus_batch in raven_hip.h (caller-built windows: one-byte codes on the host).
+void poa_consensus_batch(Engine& e, const u8* h_codes, const u8* h_quals, const u64* h_layer_off,
+                         const u32* h_begins, const u32* h_ends, const u32* h_has_qual, const u32* h_win_off,
+                         u32 n_windows, int m, int n, int g, int trim, u8* h_out, const u64* h_out_off,
+                         u32* h_out_len, u32* h_status, double* device_ms) {
+  if (n_windows == 0) return;
+  hipStream_t s = e.stream;
+  const u32 n_layers = h_win_off[n_windows];
+  const u64 total = h_layer_off[n_layers];
+  std::vector<PoaWindow> wins(n_windows);
+  std::vector<PoaLayer> lays(n_layers);
+  u32 max_bb = 1, max_len = 1;
+  for (u32 w = 0; w < n_windows; ++w) {
+    const u32 f = h_win_off[w], l = h_win_off[w + 1];
+    wins[w].layer_first = f;
+    wins[w].n_layers = l - f;
+    wins[w].out_off = static_cast<u32>(h_out_off[w]);
+    wins[w].out_cap = static_cast<u32>(h_out_off[w + 1] - h_out_off[w]);
+    // racon: rank = stable sort of layers 1.. by begin position
+    std::vector<u32> rank(l - f);
+    for (u32 i = 0; i < l - f; ++i) rank[i] = f + i;
+    if (l - f > 1)
+      std::stable_sort(rank.begin() + 1, rank.end(), [&](u32 a, u32 b) { return h_begins[a] < h_begins[b]; });
+    for (u32 i = 0; i < l - f; ++i) {
+      const u32 src = rank[i];
+      PoaLayer& L = lays[f + i];
+      L = PoaLayer{};
+      L.code_off = h_layer_off[src];
+      L.qual_off = h_layer_off[src];
+      L.len = static_cast<u32>(h_layer_off[src + 1] - h_layer_off[src]);
+      L.begin = h_begins[src];
+      L.end = h_ends[src];
+      L.flags = (h_quals && h_has_qual && h_has_qual[src]) ? kLayerQual : 0u;
+      if (i == 0) max_bb = std::max(max_bb, L.len);
+      max_len = std::max(max_len, L.len);
+    }
+  }
+  u8* d_codes = e.tmp_a.get<u8>(total + 16);
+  u8* d_quals = h_quals ? e.tmp_b.get<u8>(total + 16) : nullptr;
+  RVN_HIP(hipMemcpyAsync(d_codes, h_codes, total, hipMemcpyHostToDevice, s));
+  if (d_quals) RVN_HIP(hipMemcpyAsync(d_quals, h_quals, total, hipMemcpyHostToDevice, s));
+  PoaSrc src{};
+  src.codes = d_codes;
+  src.quals = d_quals;
+  poa_run(e, wins, lays, src, max_bb, max_len, m, n, g, trim, h_out, h_out_off[n_windows], h_out_len, h_status,
+          device_ms);
 }
 
 }  // namespace rvn

@@ -186,7 +186,7 @@ __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlan
 
 template <int NCH>
 __device__ __forceinline__ u32 poa2_window(const PoaWindow& win, const PoaLayer* __restrict__ layers,
-                                           const u8* __restrict__ codes, const u8* __restrict__ quals, Poa2Slot& g,
+                                           const PoaSrc& src, Poa2Slot& g,
                                            u32 nmax, u32 lmax, int m, int n_, int gp, int trim, Poa2Lds<NCH>& S,
                                            u8* __restrict__ out, u32* out_len,
                                            unsigned long long* __restrict__ phase_cycles) {
@@ -200,10 +200,17 @@ __device__ __forceinline__ u32 poa2_window(const PoaWindow& win, const PoaLayer*
   const u32 blen = bb.len;
   auto copy_backbone = [&]() {
     const u32 n = blen < win.out_cap ? blen : win.out_cap;
-    for (u32 i = lane; i < n; i += 64) out[i] = codes[bb.code_off + i];
+    for (u32 i = lane; i < n; i += 64) out[i] = static_cast<u8>(poa_layer_code(src, bb, i));
     if (lane == 0) *out_len = n;
   };
-  if (win.n_layers < 3) {
+  // layers dropped by racon's mean-quality filter do not count as sequences of the window
+  u32 n_eff = win.n_layers;
+  if (src.layer_ok) {
+    u32 cnt = 0;
+    for (u32 i = 1 + lane; i < win.n_layers; i += 64) cnt += src.layer_ok[win.layer_first + i] ? 1u : 0u;
+    n_eff = 1 + wave_sum(cnt);
+  }
+  if (n_eff < 3) {
     copy_backbone();
     return 0;
   }
@@ -214,15 +221,15 @@ __device__ __forceinline__ u32 poa2_window(const PoaWindow& win, const PoaLayer*
   // ---- backbone graph (spoa AddAlignment with an empty alignment) ----
   u32 n_nodes = blen;
   for (u32 i = lane; i < blen; i += 64) {
-    g.code[i] = codes[bb.code_off + i];
+    g.code[i] = static_cast<u8>(poa_layer_code(src, bb, i));
     g.al_cnt[i] = 0;
     g.visits[i] = blen >= 2 ? 1 : 0;
     g.rank_of[i] = static_cast<u16>(i);
     g.order[i] = static_cast<u16>(i);
     g.bpos[i] = static_cast<u16>(i);
-    const i32 wi = bb.has_qual ? static_cast<i32>(quals[bb.code_off + i]) - 33 : 1;
+    const i32 wi = poa_layer_weight(src, bb, i);
     if (i > 0) {
-      const i32 wp = bb.has_qual ? static_cast<i32>(quals[bb.code_off + i - 1]) - 33 : 1;
+      const i32 wp = poa_layer_weight(src, bb, i - 1);
       g.in_cnt[i] = 1;
       g.in_tail[i * kPoaMaxIn] = static_cast<u16>(i - 1);
       g.in_w[i * kPoaMaxIn] = wp + wi;
@@ -238,14 +245,14 @@ __device__ __forceinline__ u32 poa2_window(const PoaWindow& win, const PoaLayer*
   for (u32 li = 1; li < win.n_layers && !failed; ++li) {
     const PoaLayer L = layers[win.layer_first + li];
     const u32 len = L.len;
-    if (len == 0) continue;
+    if (len == 0 || (src.layer_ok && !src.layer_ok[win.layer_first + li])) continue;
     if (len > lmax || len > kPoaMaxSeq) {
       failed = 4;
       break;
     }
     for (u32 i = lane; i < len; i += 64) {
-      S.seq[i] = codes[L.code_off + i];
-      S.wgt[i] = L.has_qual ? static_cast<u8>(quals[L.code_off + i] - 33) : 1;
+      S.seq[i] = static_cast<u8>(poa_layer_code(src, L, i));
+      S.wgt[i] = static_cast<u8>(poa_layer_weight(src, L, i));
       S.pos_node[i] = static_cast<u16>(kNone);
     }
     const bool full = L.begin < offset && L.end > blen - offset;
@@ -677,7 +684,9 @@ __device__ __forceinline__ u32 poa2_window(const PoaWindow& win, const PoaLayer*
     return failed;
   }
   tick();
-  if (lane == 0) poa_consensus_lane0(g, n_nodes, nmax, win, trim, out, out_len);
+  PoaWindow weff = win;
+  weff.n_layers = n_eff;
+  if (lane == 0) poa_consensus_lane0(g, n_nodes, nmax, weff, trim, out, out_len);
   wsync();
   tock(t_cons);
   if (phase_cycles && lane == 0) {
@@ -693,20 +702,23 @@ __device__ __forceinline__ u32 poa2_window(const PoaWindow& win, const PoaLayer*
 
 template <int NCH>
 __global__ __launch_bounds__(256) void poa2_kernel(const PoaWindow* __restrict__ windows, u32 n_windows,
-                                                  const PoaLayer* __restrict__ layers, const u8* __restrict__ codes,
-                                                  const u8* __restrict__ quals, unsigned char* __restrict__ scratch,
+                                                  const PoaLayer* __restrict__ layers, const PoaSrc src,
+                                                  unsigned char* __restrict__ scratch,
                                                   size_t slot_bytes, u32 n_slots, u32 nmax, u32 lmax, int m, int n_,
                                                   int gp, int trim, u8* __restrict__ out, u32* __restrict__ out_len,
                                                   u32* __restrict__ status,
-                                                  unsigned long long* __restrict__ phase_cycles) {
+                                                  unsigned long long* __restrict__ phase_cycles,
+                                                  const u32* __restrict__ sched, u32* __restrict__ next) {
   __shared__ Poa2Lds<NCH> lds[4];
   const u32 wv = static_cast<u32>(__builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6)));
   const u32 slot = blockIdx.x * 4 + wv;
   if (slot >= n_slots) return;
   Poa2Slot g = poa2_carve(scratch + static_cast<size_t>(slot) * slot_bytes, nmax, lmax, 64 * NCH);
-  for (u32 wi = slot; wi < n_windows; wi += n_slots) {
+  for (;;) {
+    const u32 wi = poa_next_window(next, sched, n_windows);
+    if (wi == 0xFFFFFFFFu) break;
     const PoaWindow win = windows[wi];
-    const u32 st = poa2_window<NCH>(win, layers, codes, quals, g, nmax, lmax, m, n_, gp, trim, lds[wv],
+    const u32 st = poa2_window<NCH>(win, layers, src, g, nmax, lmax, m, n_, gp, trim, lds[wv],
                                out + win.out_off, out_len + wi, phase_cycles);
     if (lane_id() == 0) status[wi] = st;
     wsync();
@@ -725,14 +737,15 @@ void poa_v2_launch(Engine& e, const PoaBatchDev& b, int nch) {
   if (static_cast<size_t>(n_slots) * slot_bytes > budget) n_slots = static_cast<u32>(std::max<size_t>(1, budget / slot_bytes));
   n_slots = ((n_slots + 3) / 4) * 4;
   unsigned char* d_scratch = e.poa2_scratch.get<unsigned char>(static_cast<size_t>(n_slots) * slot_bytes + 256);
+  RVN_HIP(hipMemsetAsync(b.next, 0, 4, e.stream));
   if (nch == 1) {
     RVN_KLAUNCH(kKPoaBanded, poa2_kernel<1><<<n_slots / 4, 256, 0, e.stream>>>(
-                                 b.wins, b.n_windows, b.layers, b.codes, b.quals, d_scratch, slot_bytes, n_slots, b.nmax,
-                                 b.lmax, b.m, b.n, b.g, b.trim, b.out, b.out_len, b.status, b.phase_cycles));
+                                 b.wins, b.n_windows, b.layers, b.src, d_scratch, slot_bytes, n_slots, b.nmax,
+                                 b.lmax, b.m, b.n, b.g, b.trim, b.out, b.out_len, b.status, b.phase_cycles, b.sched, b.next));
   } else {
     RVN_KLAUNCH(kKPoaBanded, poa2_kernel<2><<<n_slots / 4, 256, 0, e.stream>>>(
-                                 b.wins, b.n_windows, b.layers, b.codes, b.quals, d_scratch, slot_bytes, n_slots, b.nmax,
-                                 b.lmax, b.m, b.n, b.g, b.trim, b.out, b.out_len, b.status, b.phase_cycles));
+                                 b.wins, b.n_windows, b.layers, b.src, d_scratch, slot_bytes, n_slots, b.nmax,
+                                 b.lmax, b.m, b.n, b.g, b.trim, b.out, b.out_len, b.status, b.phase_cycles, b.sched, b.next));
   }
 }
 

@@ -12,16 +12,32 @@
 // Step 3 is a deliberate, documented deviation from racon (no per-base path alignment on the device yet); the
 // consensus is compared with the CPU restatement of racon's own pipeline within tolerance.
 #include <algorithm>
+#include <chrono>
+#include <cmath>
 #include <vector>
 
-#include "engine.h"
+#include "poa.h"
 
 namespace rvn {
 
 namespace {
 
-inline u8 code_at(const std::vector<u64>& packed, u64 word_off, u32 i) {
-  return static_cast<u8>((packed[word_off + (i >> 5)] >> ((i << 1) & 63)) & 3);
+// racon: a layer is used only if the mean Phred of its bases reaches q.  One wave per layer.
+__global__ __launch_bounds__(256) void layer_quality_kernel(const PoaLayer* __restrict__ layers, u32 n_layers,
+                                                           const u8* __restrict__ read_quals, double q_thr,
+                                                           u8* __restrict__ ok) {
+  const u32 li = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (li >= n_layers) return;
+  const PoaLayer L = layers[li];
+  const int lane = lane_id();
+  if (!(L.flags & kLayerQual) || (L.flags & kLayerTarget) || L.len == 0) {
+    if (lane == 0) ok[li] = 1;
+    return;
+  }
+  u32 sum = 0;
+  for (u32 i = lane; i < L.len; i += 64) sum += static_cast<u32>(read_quals[L.qual_off + poa_layer_src_pos(L, i)]) - 33u;
+  sum = wave_sum(sum);
+  if (lane == 0) ok[li] = static_cast<double>(sum) / static_cast<double>(L.len) >= q_thr ? 1 : 0;
 }
 
 struct BestOverlap {
@@ -37,12 +53,13 @@ void polish_round(Engine& e, ReadsDev& T, ReadsDev& R, const u8* h_quals, const 
                   double err_thr, u32 w, bool trim, int m, int n, int g, std::vector<std::vector<u8>>& polished,
                   std::vector<double>& ratio, PolishStats& stats) {
   hipStream_t s = e.stream;
+  using clk = std::chrono::steady_clock;
+  auto ms_since = [](clk::time_point a) { return std::chrono::duration<double, std::milli>(clk::now() - a).count(); };
+  const auto t_all = clk::now();
   polished.assign(T.n, {});
   ratio.assign(T.n, 0.0);
   stats = PolishStats();
   if (T.n == 0) return;
-  if (T.h_packed.empty() || (R.n && R.h_packed.empty()))
-    throw std::invalid_argument("[raven_hip] polish needs read sets uploaded with host copies (rvn_reads_upload)");
 
   // ---- 1. map reads to targets --------------------------------------------------------------------
   {
@@ -80,6 +97,8 @@ void polish_round(Engine& e, ReadsDev& T, ReadsDev& R, const u8* h_quals, const 
   }
   RVN_HIP(hipMemcpy(roff.data(), mo.ovl_read_off.ptr, roff.size() * 4, hipMemcpyDeviceToHost));
   stats.n_overlaps = O;
+  stats.map_ms = ms_since(t_all);
+  const auto t_host = clk::now();
 
   // ---- 2. best overlap per read ------------------------------------------------------------------------
   auto span_len = [](const Overlap& o) {
@@ -164,73 +183,103 @@ void polish_round(Engine& e, ReadsDev& T, ReadsDev& R, const u8* h_quals, const 
       u32 q_e = t_e == t_last_end ? q_last_end : q_at(t_e);
       if (q_e > qlen) q_e = qlen;
       if (q_e <= q_b || (q_e - q_b) < 0.02 * w) continue;
-      bool ok = true;
-      if (h_quals) {  // racon: mean quality of the layer must reach q
-        double sum = 0;
-        const u64 qb = h_qual_off[r];
-        for (u32 x = q_b; x < q_e; ++x) {
-          const u32 src = rc ? qlen - 1 - x : x;
-          sum += static_cast<double>(h_quals[qb + src]) - 33.0;
+      {  // interpolated breakpoints can be off where the chain has a long anchor-free stretch across a window
+         // boundary; a piece whose length disagrees with its target span by more than any plausible indel
+         // imbalance is misplaced, and racon's exact breakpoints would never have produced it: drop it
+        const double span = t_e - t_b, ql = q_e - q_b;
+        if (std::abs(ql - span) > std::max(24.0, 0.15 * span)) {
+          ++stats.n_dropped_layers;
+          continue;
         }
-        ok = sum / (q_e - q_b) >= q_thr;
       }
-      if (ok) win_layers[first_window[t] + wi].push_back(LayerRef{r, q_b, q_e - q_b, t_b - ws, t_e - 1 - ws, rc});
+      win_layers[first_window[t] + wi].push_back(LayerRef{r, q_b, q_e - q_b, t_b - ws, t_e - 1 - ws, rc});
     }
   }
 
-  // ---- 4. flatten for the POA batch ------------------------------------------------------------------------
-  std::vector<u8> codes, quals;
-  std::vector<u64> layer_off{0}, out_off{0};
-  std::vector<u32> begins, ends, hasq, win_off{0};
+  // ---- 4. layer descriptors for the POA batch: bases and qualities stay in HBM (packed read sets) ---------------
+  std::vector<PoaWindow> wins(n_windows);
+  std::vector<PoaLayer> lays;
+  std::vector<u64> out_off{0};
+  lays.reserve(n_windows * 32);
   const bool any_q = h_quals != nullptr;
+  u32 max_bb = 1, max_len = 1;
   for (u32 t = 0; t < T.n; ++t) {
     const u32 tlen = T.h_len[t];
     for (u64 wi = 0; wi < first_window[t + 1] - first_window[t]; ++wi) {
+      const u64 gw = first_window[t] + wi;
       const u32 ws = static_cast<u32>(wi) * w;
       const u32 bl = std::min<u32>(w, tlen - ws);
-      for (u32 x = 0; x < bl; ++x) codes.push_back(code_at(T.h_packed, T.h_word_off[t], ws + x));
-      if (any_q) quals.insert(quals.end(), bl, static_cast<u8>('!'));  // racon's dummy backbone quality
-      layer_off.push_back(codes.size());
-      begins.push_back(0);
-      ends.push_back(bl ? bl - 1 : 0);
-      hasq.push_back(1);  // backbone weight 0 ('!'), as racon's dummy quality
-      for (const auto& L : win_layers[first_window[t] + wi]) {
-        const u32 qlen = R.h_len[L.read];
-        for (u32 x = 0; x < L.q_len; ++x) {
-          const u32 pos = L.q_begin + x;
-          const u8 c = L.rc ? static_cast<u8>(3 - code_at(R.h_packed, R.h_word_off[L.read], qlen - 1 - pos))
-                            : code_at(R.h_packed, R.h_word_off[L.read], pos);
-          codes.push_back(c);
-          if (any_q) quals.push_back(h_quals[h_qual_off[L.read] + (L.rc ? qlen - 1 - pos : pos)]);
-        }
-        layer_off.push_back(codes.size());
-        begins.push_back(L.t_begin);
-        ends.push_back(std::min(L.t_end, bl - 1));
-        hasq.push_back(any_q ? 1 : 0);
+      wins[gw].layer_first = static_cast<u32>(lays.size());
+      PoaLayer B{};
+      B.code_off = T.h_word_off[t];
+      B.len = bl;
+      B.begin = 0;
+      B.end = bl ? bl - 1 : 0;
+      B.flags = kLayerPacked | kLayerTarget | kLayerZeroW;  // weight 0 = racon's dummy '!' backbone quality
+      B.q_begin = ws;
+      B.q_len = tlen;
+      lays.push_back(B);
+      max_bb = std::max(max_bb, bl);
+      auto& wl = win_layers[gw];
+      // racon: layers in stable order of their begin position
+      std::stable_sort(wl.begin(), wl.end(), [](const LayerRef& a, const LayerRef& b) { return a.t_begin < b.t_begin; });
+      for (const auto& L : wl) {
+        PoaLayer P{};
+        P.code_off = R.h_word_off[L.read];
+        P.qual_off = any_q ? h_qual_off[L.read] : 0;
+        P.len = L.q_len;
+        P.begin = L.t_begin;
+        P.end = std::min(L.t_end, bl - 1);
+        P.flags = kLayerPacked | (L.rc ? kLayerRc : 0u) | (any_q ? kLayerQual : 0u);
+        P.q_begin = L.q_begin;
+        P.q_len = R.h_len[L.read];
+        lays.push_back(P);
+        max_len = std::max(max_len, L.q_len);
         ++stats.n_layers;
       }
-      win_off.push_back(static_cast<u32>(begins.size()));
+      wins[gw].n_layers = static_cast<u32>(lays.size()) - wins[gw].layer_first;
+      wins[gw].out_off = static_cast<u32>(out_off.back());
+      wins[gw].out_cap = 4 * bl + 256;
       out_off.push_back(out_off.back() + 4ULL * bl + 256);
     }
   }
-  // a backbone-only quality array is still needed when no read has qualities (backbone weight must be 0)
-  std::vector<u8> bb_quals;
-  const u8* q_ptr = nullptr;
+  max_len = std::max(max_len, max_bb);
+  PoaSrc src{};
+  src.packed_reads = R.packed.as<u64>();
+  src.packed_targets = T.packed.as<u64>();
   if (any_q) {
-    q_ptr = quals.data();
-  } else {
-    bb_quals.assign(codes.size(), static_cast<u8>('!'));
-    q_ptr = bb_quals.data();
-    // only backbones have has_qual = 1 here
+    // qualities to HBM once per call; racon's mean-quality filter as per-layer flags computed on the device
+    const u64 qtotal = h_qual_off[R.n];
+    u8* d_q = e.polish_quals.get<u8>(qtotal + 16);
+    RVN_HIP(hipMemcpyAsync(d_q, h_quals, qtotal, hipMemcpyHostToDevice, s));
+    PoaLayer* d_l = e.tmp_d.get<PoaLayer>(lays.size() + 1);
+    RVN_HIP(hipMemcpyAsync(d_l, lays.data(), lays.size() * sizeof(PoaLayer), hipMemcpyHostToDevice, s));
+    u8* d_ok = e.tmp_a.get<u8>(lays.size() + 16);
+    const u32 nl = static_cast<u32>(lays.size());
+    layer_quality_kernel<<<(nl + 3) / 4, 256, 0, s>>>(d_l, nl, d_q, q_thr, d_ok);
+    RVN_HIP(hipGetLastError());
+    src.read_quals = d_q;
+    src.layer_ok = d_ok;
+    if (q_thr > 0) {  // only for the statistics: how many layers survive
+      std::vector<u8> okh(nl);
+      RVN_HIP(hipMemcpyAsync(okh.data(), d_ok, nl, hipMemcpyDeviceToHost, s));
+      RVN_HIP(hipStreamSynchronize(s));
+      u64 kept = 0;
+      for (u32 i = 0; i < nl; ++i) kept += (okh[i] && !(lays[i].flags & kLayerTarget)) ? 1 : 0;
+      stats.n_layers = kept;
+    }
   }
   stats.n_windows = n_windows;
   std::vector<u8> cons(out_off.back() + 16);
   std::vector<u32> cons_len(n_windows), status(n_windows);
   double ms = 0;
-  poa_consensus_batch(e, codes.data(), q_ptr, layer_off.data(), begins.data(), ends.data(), hasq.data(), win_off.data(),
-                      static_cast<u32>(n_windows), m, n, g, trim ? 1 : 0, cons.data(), out_off.data(), cons_len.data(),
-                      status.data(), &ms);
+  stats.host_ms = ms_since(t_host);
+  const auto t_poa = clk::now();
+  poa_run(e, wins, lays, src, max_bb, max_len, m, n, g, trim ? 1 : 0, cons.data(), out_off.back(), cons_len.data(),
+          status.data(), &ms);
   stats.poa_ms = ms;
+  const double poa_wall = ms_since(t_poa);
+  const auto t_st = clk::now();
 
   // ---- 5. stitch -------------------------------------------------------------------------------------------
   for (u32 t = 0; t < T.n; ++t) {
@@ -245,6 +294,8 @@ void polish_round(Engine& e, ReadsDev& T, ReadsDev& R, const u8* h_quals, const 
     ratio[t] = nw ? static_cast<double>(polished_windows) / nw : 0.0;
     stats.n_polished_windows += polished_windows;
   }
+  stats.host_ms += ms_since(t_st) + (poa_wall - ms);  // stitching + the batch's host-side preparation and copies
+  stats.total_ms = ms_since(t_all);
 }
 
 }  // namespace rvn

@@ -272,7 +272,7 @@ class Engine:
         out = np.zeros(int(ooff[-1]) + 1, dtype=np.uint8)
         out_len = np.zeros(nt, dtype=np.uint32)
         ratio = np.zeros(nt, dtype=np.float64)
-        stats = np.zeros(7, dtype=np.uint64)
+        stats = np.zeros(11, dtype=np.uint64)
         qa = qo = None
         if quals is not None:
             qo = np.zeros(len(quals) + 1, dtype=np.uint64)
@@ -283,7 +283,9 @@ class Engine:
         cons = [out[int(ooff[i]): int(ooff[i]) + int(out_len[i])].copy() for i in range(nt)]
         keys = ("n_overlaps", "n_reads_used", "n_layers", "n_windows", "n_polished_windows", "n_failed_windows")
         st = {k2: int(v) for k2, v in zip(keys, stats[:6])}
-        st["poa_ms"] = float(stats[6:7].view(np.float64)[0])
+        for i, k2 in enumerate(("poa_ms", "map_ms", "host_ms", "total_ms")):
+            st[k2] = float(stats[6 + i: 7 + i].view(np.float64)[0])
+        st["n_dropped_layers"] = int(stats[10])
         return cons, ratio, st
 
     # -- raven::Pile::AddKmers, batched ---------------------------------------------------------------

@@ -113,3 +113,54 @@ def test_limits_are_reported_not_hidden():
     assert status[0] == 4 and np.array_equal(cons[0], long_bb)  # 4 = layer longer than the device limit
     with pytest.raises(ValueError):
         eng.poa_consensus_batch([dict(layers=[long_bb[:100], long_bb[:50], long_bb[:50]], begins=[0, 60, 0], ends=[99, 40, 99])])
+
+
+def test_band_escalation_matches_full_matrix_kernel():
+    """Layers with a long deletion / insertion leave the 64-column (and, for the longest, the 128-column) band:
+    the banded kernel must flag them (status 8 in band-only modes), and the default mode must hand them on so the
+    result equals the full-matrix kernel's."""
+    rng = np.random.default_rng(21)
+    wins = []
+    for gap in (0, 45, 90, 150):
+        truth = rng.integers(0, 4, size=500, dtype=np.uint8)
+        bb = _mutate(rng, truth, 0.03, 0.02, 0.02)
+        layers = [bb] + [_mutate(rng, truth, 0.04, 0.03, 0.03) for _ in range(12)]
+        if gap:
+            cut = np.concatenate([truth[:200], truth[200 + gap:]])          # deletion of `gap` bases
+            grown = np.concatenate([truth[:300], rng.integers(0, 4, size=gap, dtype=np.uint8), truth[300:]])
+            layers += [_mutate(rng, cut, 0.04, 0.03, 0.03) for _ in range(2)]
+            layers += [_mutate(rng, grown, 0.04, 0.03, 0.03)[:1000] for _ in range(2)]
+        wins.append(dict(layers=layers))
+    eng = hip.Engine()
+    eng.poa_set_mode(1)
+    ref, st_ref, _ = eng.poa_consensus_batch(wins)
+    assert np.all(st_ref == 1)
+    eng.poa_set_mode(2)
+    _, st64, _ = eng.poa_consensus_batch(wins)
+    eng.poa_set_mode(3)
+    _, st128, _ = eng.poa_consensus_batch(wins)
+    assert (st64 & 0xFF).tolist()[0] == 1 and np.all((st64 & 0xFF)[2:] == 8), st64
+    assert (st128 & 0xFF).tolist()[:2] == [1, 1] and (st128 & 0xFF)[3] == 8, st128
+    assert eng.poa_set_mode(0) == 3
+    cons, st, _ = eng.poa_consensus_batch(wins)
+    assert np.all(st == 1)
+    assert eng.poa_wide_windows() == int(np.sum((st64 & 0xFF) == 8))
+    assert eng.poa_fallback_windows() == int(np.sum((st128 & 0xFF) == 8)) >= 1
+    for i, (c, r, w) in enumerate(zip(cons, ref, wins)):
+        assert _ed(c, r) <= 2, i                       # banded and full-matrix kernels agree (ties aside)
+        o, _ = _oracle(w)
+        assert _ed(c, o) <= max(2, 0.01 * len(o)), i
+
+
+def test_kernel_modes_agree_on_noisy_windows():
+    rng = np.random.default_rng(33)
+    wins = [_window(rng, length=int(rng.integers(300, 520)), n_reads=int(rng.integers(8, 35)), partial=0.3)[0]
+            for _ in range(32)]
+    eng = hip.Engine()
+    out = {}
+    for mode in (1, 2, 3):
+        eng.poa_set_mode(mode)
+        out[mode], st, _ = eng.poa_consensus_batch(wins)
+        assert np.all(st == 1), (mode, st)
+    for a, b, c in zip(out[1], out[2], out[3]):
+        assert np.array_equal(a, b) and np.array_equal(a, c)
