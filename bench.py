@@ -102,6 +102,9 @@ def main():
     ap.add_argument("--cpu-single", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-polish", action="store_true", help="skip the configs[2] polishing leg (reported beside, "
+                    "never part of `value`)")
+    ap.add_argument("--polish-rounds", type=int, default=2)
     args = ap.parse_args()
 
     rank, world, local_rank = rdist.env_rank()
@@ -154,10 +157,51 @@ def main():
 
     dt, total_bases = rdist.aggregate(dt, float(rs.total_bases), dist, device="cuda")
 
+    counters_raw = eng.counters()
+    kms_raw = eng.kernel_ms() if not args.no_kernel_timing else {}
+    eng.reset_stats()
+
+    # ---- configs[2] leg: -p 2, racon-style polishing rounds of this shard's draft assembly with the same reads ----
+    polish = None
+    if not args.no_polish and args.polish_rounds > 0:
+        from raven_amd import seqio
+        peng = eng if (args.k, args.w) == (15, 5) else hip.Engine(15, 5, device=local_rank)  # racon maps with (15, 5)
+        preads = reads if peng is eng else peng.upload(rs)
+        draft = synth.make_draft(genome, seed=genome_seed + 7)
+        peng.polish_round(peng.upload(seqio.pack_reads([draft[:100_000]])), preads)  # warm-up (allocations)
+        peng.reset_stats()
+        cur = seqio.pack_reads([draft])
+        barrier()
+        tp0 = time.perf_counter()
+        last = None
+        n_windows = 0
+        for _ in range(args.polish_rounds):
+            cons, ratio, last = peng.polish_round(peng.upload(cur), preads)
+            n_windows += last["n_windows"]
+            cur = seqio.pack_reads([cons[0]])
+        barrier()
+        dtp = time.perf_counter() - tp0
+        dtp, _ = rdist.aggregate(dtp, float(rs.total_bases), dist, device="cuda")
+        polish = {
+            "workload": "BASELINE.json configs[2]: same genome/reads, -p %d: draft = genome with 2.6%% iid errors, "
+                        "racon-style rounds (map reads to the draft, 500-bp windows, POA consensus m/n/g = 3/-5/-4)"
+                        % args.polish_rounds,
+            "rounds": args.polish_rounds, "s_per_round": round(dtp / args.polish_rounds, 4),
+            "read_gbase_per_s_per_round": round(total_bases / (dtp / args.polish_rounds) / 1e9, 4),
+            "windows_per_s": round(n_windows * world / dtp, 1),
+            "overlap_plus_polish_gbase_per_s": round(total_bases / (dt / max(args.steps, 1) + dtp) / 1e9, 4),
+            "last_round": {k: (round(v, 3) if isinstance(v, float) else v) for k, v in last.items()},
+            "polished_ratio": round(float(ratio[0]), 4),
+            "kernels_ms_per_round": {k: round(v[0] / args.polish_rounds, 3) for k, v in
+                                     sorted(peng.kernel_ms().items(), key=lambda x: -x[1][0])[:6] if v[1]}
+            if not args.no_kernel_timing else None,
+            "windows_rerun_wide_band": peng.poa_wide_windows(), "windows_rerun_full_matrix": peng.poa_fallback_windows(),
+        }
+
     if rank == 0:
         steps = max(args.steps, 1)
-        counters = {k: v // steps for k, v in eng.counters().items()}
-        kms = eng.kernel_ms() if not args.no_kernel_timing else {}
+        counters = {k: v // steps for k, v in counters_raw.items()}
+        kms = kms_raw
         val_bytes = 4 if 2 * eng.k < 32 else 8
         roofline = None
         kernels = {}
@@ -205,6 +249,7 @@ def main():
             "counters_per_step": counters,
             "roofline": roofline,
             "kernels": kernels,
+            "polish": polish,
             "host": {"gen_s": round(t_gen, 2), "h2d_s": round(t_h2d, 3),
                      "h2d_inclusive_gbase_s": round(rs.total_bases / (dt / steps + t_h2d) / 1e9, 4)},
         }

@@ -187,7 +187,7 @@ void polish_round(Engine& e, ReadsDev& T, ReadsDev& R, const u8* h_quals, const 
          // boundary; a piece whose length disagrees with its target span by more than any plausible indel
          // imbalance is misplaced, and racon's exact breakpoints would never have produced it: drop it
         const double span = t_e - t_b, ql = q_e - q_b;
-        if (std::abs(ql - span) > std::max(24.0, 0.15 * span)) {
+        if (std::abs(ql - span) > std::max(16.0, 0.08 * span)) {
           ++stats.n_dropped_layers;
           continue;
         }

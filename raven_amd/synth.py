@@ -106,3 +106,25 @@ def make_reads(genome: np.ndarray, coverage: float, read_len: int = 10000, *, le
     rs = ReadSet(packed, woffs, lengths, np.arange(n_reads, dtype=np.uint32))
     truth = dict(start=start, src_len=src_len, strand=strand)
     return rs, truth
+
+
+def mutate(rng, codes, sub, ins, dele):
+    """iid substitutions / insertions / deletions on a code array (vectorised)."""
+    L = codes.shape[0]
+    u = rng.random(L)
+    keep = u >= dele
+    base = codes.copy()
+    s = (u >= dele) & (u < dele + sub)
+    base[s] = (base[s] + rng.integers(1, 4, size=int(s.sum()))) & 3
+    insm = rng.random(L) < ins
+    emit = keep.astype(np.int64) + insm
+    seq = np.repeat(base, emit)
+    off = np.cumsum(emit)
+    slots = off[insm] - 1
+    seq[slots] = rng.integers(0, 4, size=slots.shape[0])
+    return seq.astype(np.uint8)
+
+
+def make_draft(genome, seed, sub=0.01, ins=0.008, dele=0.008):
+    """An unpolished assembly of `genome` (what raven's layout hands to racon): the truth with iid errors."""
+    return mutate(np.random.default_rng(seed), genome, sub, ins, dele)

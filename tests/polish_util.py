@@ -5,20 +5,7 @@ import numpy as np
 from raven_amd import seqio, synth
 
 
-def mutate(rng, codes, sub, ins, dele):
-    L = codes.shape[0]
-    u = rng.random(L)
-    keep = u >= dele
-    base = codes.copy()
-    s = (u >= dele) & (u < dele + sub)
-    base[s] = (base[s] + rng.integers(1, 4, size=int(s.sum()))) & 3
-    insm = rng.random(L) < ins
-    emit = keep.astype(np.int64) + insm
-    seq = np.repeat(base, emit)
-    off = np.cumsum(emit)
-    slots = off[insm] - 1
-    seq[slots] = rng.integers(0, 4, size=slots.shape[0])
-    return seq.astype(np.uint8)
+mutate = synth.mutate
 
 
 def make_case(genome_len=30_000, coverage=25, read_len=3000, draft_err=(0.01, 0.008, 0.008), seed=5, with_qual=False,
