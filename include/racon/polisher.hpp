@@ -1,0 +1,115 @@
+// racon/polisher.hpp — drop-in facade with the interface of racon::Polisher as Raven uses it
+// (RavenLib/src/polish.cc:43-51: Create(thread_pool, q, e, w, trim, m, n, g, cuda_poa_batches, cuda_banded,
+// cuda_aln_batches) and Polish(targets, sequences, drop_unpolished)), backed by rvn_polish_round of raven_hip.h:
+// read -> target mapping, window layers, POA consensus and stitching all run on the MI355X.  Header-only; link with
+// -lraven_hip.  Needs the caller's biosoup::NucleicAcid (name / deflated_data / block_quality / inflated_len and
+// the (name, data) constructor), like racon's own header.
+//
+// What a maintainer should know:
+//  * one Polish() call = one racon round; raven::Polish's loop over rounds (polish.cc:49-85) stays as it is;
+//  * the three cuda_* arguments and the thread pool are accepted and ignored;
+//  * result names carry racon's tags " LN:i:<len> RC:i:<reads used> XC:f:<polished window ratio>" — Raven parses the
+//    float after the last ':' (polish.cc:57-59) and the node id after "Utg" (polish.cc:55);
+//  * qualities: biosoup keeps one mean Phred per 64-base block (block_quality); they are expanded to per-base
+//    Phred+33 for the C ABI, as racon's InflateQuality() does.  Sets without qualities use unit weights;
+//  * errors of the C ABI are rethrown (std::invalid_argument for RVN_EINVAL, std::runtime_error otherwise); with
+//    no GPU, Create() throws — there is no CPU fallback.
+#ifndef RACON_POLISHER_HPP_  // same guard as racon's header: include one or the other
+#define RACON_POLISHER_HPP_
+
+#include <cstdint>
+#include <cstdio>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "ram/minimizer_engine.hpp"
+
+namespace racon {
+
+class Polisher {
+ public:
+  using Sequences = std::vector<std::unique_ptr<biosoup::NucleicAcid>>;
+
+  static std::unique_ptr<Polisher> Create(std::shared_ptr<thread_pool::ThreadPool> /*thread_pool*/ = nullptr,
+                                          double quality_threshold = 10.0, double error_threshold = 0.3,
+                                          std::uint32_t window_len = 500, bool trim_consensus = true,
+                                          std::int8_t match = 3, std::int8_t mismatch = -5, std::int8_t gap = -4,
+                                          std::uint32_t /*cuda_poa_batches*/ = 0, bool /*cuda_banded*/ = false,
+                                          std::uint32_t /*cuda_aln_batches*/ = 0, int device = 0) {
+    if (window_len == 0) throw std::invalid_argument("[racon::Polisher::Create] error: invalid window length");
+    if (gap > 0) throw std::invalid_argument("[racon::Polisher::Create] error: gap penalty must be non-positive");
+    return std::unique_ptr<Polisher>(
+        new Polisher(quality_threshold, error_threshold, window_len, trim_consensus, match, mismatch, gap, device));
+  }
+
+  Polisher(const Polisher&) = delete;
+  Polisher& operator=(const Polisher&) = delete;
+  ~Polisher() { rvn_engine_destroy(engine_); }
+
+  // racon: one polishing round of `targets` with `sequences`; targets without a polished window are dropped when
+  // drop_unpolished (polish.cc:51 passes false)
+  Sequences Polish(const Sequences& targets, const Sequences& sequences, bool drop_unpolished) {
+    Sequences dst;
+    if (targets.empty()) return dst;
+    ram::detail::ReadsHandle t, r;
+    t.Upload(engine_, targets.begin(), targets.end());
+    r.Upload(engine_, sequences.begin(), sequences.end());
+
+    // per-base Phred+33 from biosoup's block qualities, only if every read has them
+    bool has_q = !sequences.empty();
+    for (const auto& s : sequences) has_q = has_q && !s->block_quality.empty();
+    std::vector<std::uint8_t> quals;
+    std::vector<std::uint64_t> qoff;
+    if (has_q) {
+      qoff.push_back(0);
+      for (const auto& s : sequences) {
+        for (std::uint32_t i = 0; i < s->inflated_len; ++i)
+          quals.push_back(static_cast<std::uint8_t>(s->block_quality[i >> 6] + 33));
+        qoff.push_back(quals.size());
+      }
+    }
+
+    const std::size_t n = targets.size();
+    std::vector<std::uint64_t> ooff(n + 1, 0);
+    for (std::size_t i = 0; i < n; ++i) ooff[i + 1] = ooff[i] + 2ULL * targets[i]->inflated_len + 1024;
+    std::vector<std::uint8_t> codes(ooff[n] + 1);
+    std::vector<std::uint32_t> len(n), used(n);
+    std::vector<double> ratio(n);
+    rvn_polish_stats st{};
+    ram::detail::Check(rvn_polish_round(engine_, t.h, r.h, has_q ? quals.data() : nullptr, has_q ? qoff.data() : nullptr,
+                                        q_, e_, w_, trim_ ? 1 : 0, m_, n_, g_, codes.data(), ooff.data(), len.data(),
+                                        ratio.data(), &st));
+    ram::detail::Check(rvn_polish_target_reads(engine_, used.data(), static_cast<std::uint32_t>(n)));
+    for (std::size_t i = 0; i < n; ++i) {
+      if (drop_unpolished && ratio[i] == 0.0) continue;
+      std::string data(len[i], 'A');
+      for (std::uint32_t j = 0; j < len[i]; ++j) data[j] = "ACGT"[codes[ooff[i] + j] & 3];
+      char tags[96];
+      std::snprintf(tags, sizeof(tags), " LN:i:%u RC:i:%u XC:f:%.6f", len[i], used[i], ratio[i]);
+      const std::string& name = targets[i]->name;
+      dst.emplace_back(new biosoup::NucleicAcid(name.substr(0, name.find(' ')) + tags, data));
+    }
+    return dst;
+  }
+
+  rvn_engine* handle() const { return engine_; }
+
+ private:
+  Polisher(double q, double e, std::uint32_t w, bool trim, std::int8_t m, std::int8_t n, std::int8_t g, int device)
+      : q_(q), e_(e), w_(w), trim_(trim), m_(m), n_(n), g_(g) {
+    // racon maps with ram's (k = 15, w = 5, bandwidth 500, chain 4, matches 100, gap 10000)
+    ram::detail::Check(rvn_engine_create(&engine_, 15, 5, 500, 4, 100, 10000, device));
+  }
+
+  double q_, e_;
+  std::uint32_t w_;
+  bool trim_;
+  int m_, n_, g_;
+  rvn_engine* engine_ = nullptr;
+};
+
+}  // namespace racon
+
+#endif  // RACON_POLISHER_HPP_

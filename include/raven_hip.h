@@ -150,6 +150,10 @@ int rvn_polish_round(rvn_engine* e, rvn_reads* targets, rvn_reads* reads, const 
                      int gap, uint8_t* out_codes, const uint64_t* out_offsets, uint32_t* out_len, double* ratio,
                      rvn_polish_stats* stats);
 
+/* reads used per target (their best overlap passed the error filter) in the last rvn_polish_round call: the RC:i:
+ * tag racon writes next to XC:f: */
+int rvn_polish_target_reads(const rvn_engine* e, uint32_t* counts, uint32_t n_targets);
+
 /* shader-clock cycles summed over all windows of the last rvn_poa_consensus_batch call, per phase:
  * {subgraph, NW matrix, traceback, AddAlignment, order rebuild, consensus} */
 void rvn_poa_phase_cycles(const rvn_engine* e, uint64_t out[6]);

@@ -104,6 +104,7 @@ struct Engine {
   DevBuf seg_off, iv_slot_begin, iv_slot_end, iv_cnt, iv_off, iv_begin, iv_end;
   DevBuf lis_min, lis_pred, lis_tail, lis_mask, ovl_slots, ovl_flags, ovl_scan;
   DevBuf poa_scratch, poa2_scratch, polish_quals;
+  std::vector<u32> polish_target_reads;  // reads used per target in the last polishing round
   int poa_mode = 0;  // 0 banded 64 -> 128 -> full matrix; 1 full matrix only; 2 band 64 only; 3 band 128 only (tests)
   u32 poa_fallback_windows = 0;  // windows of the last batch re-run by the full-matrix kernel
   u32 poa_wide_windows = 0;      // windows of the last batch re-run with the 128-column band

@@ -527,6 +527,13 @@ int rvn_poa_consensus_batch(rvn_engine* h, const uint8_t* codes, const uint8_t* 
   });
 }
 
+int rvn_polish_target_reads(const rvn_engine* h, uint32_t* counts, uint32_t n_targets) {
+  if (!h || !counts || n_targets != h->e.polish_target_reads.size())
+    return fail(RVN_EINVAL, "[raven_hip] rvn_polish_target_reads: no polishing round with that many targets");
+  for (uint32_t i = 0; i < n_targets; ++i) counts[i] = h->e.polish_target_reads[i];
+  return RVN_OK;
+}
+
 void rvn_poa_phase_cycles(const rvn_engine* h, uint64_t out[6]) {
   for (int i = 0; i < 6; ++i) out[i] = h ? h->e.poa_phase_cycles[i] : 0;
 }

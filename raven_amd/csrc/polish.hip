@@ -139,6 +139,7 @@ void polish_round(Engine& e, ReadsDev& T, ReadsDev& R, const u8* h_quals, const 
   };
   std::vector<std::vector<LayerRef>> win_layers(n_windows);
   const u32 k = e.k;
+  e.polish_target_reads.assign(T.n, 0);
   for (u32 r = 0; r < R.n; ++r) {
     if (!best[r].valid) continue;
     const Overlap& o = best[r].o;
@@ -147,6 +148,7 @@ void polish_round(Engine& e, ReadsDev& T, ReadsDev& R, const u8* h_quals, const 
     const u32 qlen = R.h_len[r];
     const bool rc = o.strand == 0;
     ++stats.n_reads_used;
+    ++e.polish_target_reads[t];
     // anchors as (t, q') increasing in both; q' in the orientation that matches the target
     std::vector<std::pair<u32, u32>> an(best[r].acnt);
     for (u32 i = 0; i < best[r].acnt; ++i) {

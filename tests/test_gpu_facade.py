@@ -11,11 +11,11 @@ from raven_amd import hip, synth
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _build(tmp_path):
-    exe = str(tmp_path / "facade_test")
+def _build(tmp_path, name="facade_test"):
+    exe = str(tmp_path / name)
     lib = os.path.join(ROOT, "raven_amd", "lib")
     cmd = ["g++", "-std=c++17", "-O2", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "tests", "cpp"),
-           "-o", exe, os.path.join(ROOT, "tests", "cpp", "facade_test.cpp"), "-L", lib, "-lraven_hip",
+           "-o", exe, os.path.join(ROOT, "tests", "cpp", name + ".cpp"), "-L", lib, "-lraven_hip",
            "-Wl,-rpath," + lib, "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"]
     subprocess.check_call(cmd)
     return exe
@@ -65,3 +65,44 @@ def test_facade_matches_c_abi(tmp_path):
     assert got == want and len(got) > 100
     assert lines[-1].startswith("map_single_vs_batch mismatches 0 total ")
     assert int(lines[-1].split()[-1]) > 0
+
+
+def test_polisher_facade_compiles_and_fails_loudly_without_gpu(tmp_path):
+    if hip.device_count() > 0:
+        pytest.skip("GPU present")
+    exe = _build(tmp_path, "polisher_test")
+    p = tmp_path / "one.txt"
+    p.write_text("ACGTACGTACGTACGTACGTACGTACGT\n")
+    r = subprocess.run([exe, str(p), str(p)], capture_output=True, text=True)
+    assert r.returncode == 1 and "no HIP device" in r.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("q", [None, 12])
+def test_polisher_facade_matches_c_abi(tmp_path, q):
+    """racon::Polisher facade == rvn_polish_round through ctypes, incl. the name tags Raven parses."""
+    from raven_amd import seqio
+    from tests import polish_util
+    truths, drafts, targets, reads, _ = polish_util.make_case(genome_len=30_000, coverage=20, read_len=2500, seed=11,
+                                                              n_targets=2)
+    tpath, rpath = _write_reads(tmp_path, targets), str(tmp_path / "r.txt")
+    os.rename(tpath, str(tmp_path / "t.txt"))
+    os.rename(_write_reads(tmp_path, reads), rpath)
+    exe = _build(tmp_path, "polisher_test")
+    r = subprocess.run([exe, str(tmp_path / "t.txt"), rpath] + ([str(q)] if q is not None else []),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = r.stdout.strip().split("\n")
+    assert lines[0] == "zero_window_throws 1" and lines[1] == "polished 2" and lines[-1] == "dropped_without_reads 2"
+    eng = hip.Engine(15, 5)
+    quals = [np.full(int(n), 33 + q, dtype=np.uint8) for n in reads.lengths] if q is not None else None
+    cons, ratio, st = eng.polish_round(eng.upload(targets), eng.upload(reads), quals=quals, q=10.0 if q else 0.0)
+    P = [ln.split(" ", 3) for ln in lines if ln.startswith("P ")]
+    S = [ln[2:] for ln in lines if ln.startswith("S ")]
+    for t in range(2):
+        assert int(P[t][1]) == t and abs(float(P[t][2]) - ratio[t]) < 1e-6 and ratio[t] > 0.9
+        name = P[t][3]
+        assert name.startswith("Utg%d LN:i:%d RC:i:" % (t, len(cons[t]))) and " XC:f:" in name
+        assert S[t].encode() == bytes(np.frombuffer(b"ACGT", dtype=np.uint8)[cons[t]])
+    used = [int(p[3].split("RC:i:")[1].split()[0]) for p in P]
+    assert sum(used) == st["n_reads_used"]
