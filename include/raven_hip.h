@@ -150,6 +150,37 @@ int rvn_polish_round(rvn_engine* e, rvn_reads* targets, rvn_reads* reads, const 
                      int gap, uint8_t* out_codes, const uint64_t* out_offsets, uint32_t* out_len, double* ratio,
                      rvn_polish_stats* stats);
 
+/* ---- stage-level entry points of the SHARDED single-genome pass (one engine per GPU) ------------
+ * FindOverlapsAndCreatePiles (construct.cc:14-121) split where the data has to move between GPUs.  Reads are
+ * range-partitioned by pile (rank g owns a contiguous id range and uploads only those reads, ids = global read
+ * indices), minimizer values are partitioned by hash class.  Host side: raven_amd/sharded.py.
+ *   1. rvn_shard_sketch           own reads -> (value, origin) with the minhash-selected entries flagged (bit 63 of
+ *                                 origin) == the per-read part of ram Minimize + the query sketch of Map
+ *      -- all-to-all #1: every minimizer to the owner of its hash class --
+ *   2. rvn_shard_index_build      owner: stable sort by value == its hash class of ram's index, same relative order
+ *   3. rvn_shard_key_counts       per-key counts -> all-reduce of the count histogram -> exact global Filter
+ *      rvn_engine_set_occurrence
+ *   4. rvn_shard_join             owner: index probes of Map for every query entry of its hash class; matches
+ *                                 segmented by the query read's GLOBAL id
+ *      -- all-to-all #2: every match to the owner of its query read (the candidate-pair exchange) --
+ *   5. rvn_shard_chain            read owner: sort / bands / LIS / emission of Map -> rvn_engine_map_fetch
+ *      -- all-to-all #3: every overlap also to the owner of its rhs read --
+ *   6. rvn_shard_piles            pile owner: merge (construct.cc:72-77), AddLayers, top-kMax truncation
+ * The result for the reads a rank owns is bit-identical to the single-GPU pass (tests/test_gpu_sharded.py). */
+int rvn_shard_sketch(rvn_engine* e, const rvn_reads* own_reads, int index_minhash, uint64_t* count);
+int rvn_shard_sketch_fetch(rvn_engine* e, uint64_t* values, uint64_t* origins);
+int rvn_shard_index_build(rvn_engine* e, const uint64_t* values, const uint64_t* origins, uint64_t n, int all_query);
+int rvn_shard_key_counts(rvn_engine* e, uint32_t* counts /* n_keys of rvn_engine_index_size */);
+int rvn_engine_set_occurrence(rvn_engine* e, uint32_t occurrence);
+int rvn_shard_join(rvn_engine* e, uint32_t n_reads_total, int avoid_equal, int avoid_symmetric, uint64_t* n_matches);
+int rvn_shard_join_fetch(rvn_engine* e, uint64_t* group, uint64_t* positions, uint64_t* seg_off /* n_reads_total+1 */);
+int rvn_shard_chain(rvn_engine* e, const rvn_reads* own_reads, const uint64_t* group, const uint64_t* positions,
+                    const uint64_t* seg_off /* own n + 1 */, uint64_t* n_overlaps);
+/* overlaps: Map outputs in (query read, emission) order over ALL reads' id space; only piles of reads whose
+ * overlaps are complete in the list (the caller's own range) are meaningful in the returned handle */
+int rvn_shard_piles(rvn_engine* e, const uint32_t* lengths, uint32_t n_reads_total, const rvn_overlap* overlaps,
+                    uint64_t n, uint32_t kmax, rvn_pass1** out);
+
 /* reads used per target (their best overlap passed the error filter) in the last rvn_polish_round call: the RC:i:
  * tag racon writes next to XC:f: */
 int rvn_polish_target_reads(const rvn_engine* e, uint32_t* counts, uint32_t n_targets);

@@ -96,6 +96,9 @@ struct Engine {
   u32 query_ready_first = 0, query_ready_last = 0;
   bool query_ready_minhash = false;
   u64 join_query_count = 0;  // number of query minimizers flagged in the index (self-join path)
+  bool shard_sketch_minhash = false;           // which sketch rvn_shard_sketch left its result in
+  u32 shard_join_reads = 0;                    // rvn_shard_join: segments of the last join
+  u64 shard_join_matches = 0;
   MapOut map_out;
   // scratch
   DevBuf tmp_a, tmp_b, tmp_c, tmp_d, tmp_e, tmp_f, scan_tmp, sort_tmp;
@@ -160,6 +163,11 @@ u64 sketch_flag_queries(Engine& e, const ReadsDev& r, Sketch& raw);
 void index_filter(Engine& e, double freq);               // sets e.index.occurrence
 void map_batch(Engine& e, const ReadsDev& r, u32 first, u32 last, bool avoid_equal, bool avoid_symmetric,
                bool minhash, bool want_filtered, MapOut& out);
+
+// self-join of the index for global query ids 0..n_reads-1 -> e.m_grp[0] / e.m_pos[0] / e.seg_off (map.hip)
+u64 join_index_matches(Engine& e, u32 n_reads, bool avoid_equal, bool avoid_symmetric);
+// chain stage of Map on matches already in e.m_grp[0] / e.m_pos[0] / e.seg_off (map.hip)
+void chain_matches(Engine& e, const ReadsDev& r, u32 first, u32 last, u64 H, MapOut& out);
 
 // Batched exact edit distance (edit_distance.hip). h_pairs: n_pairs x {a_idx,a_begin,a_len,b_idx,b_begin,b_len,strand,0}
 void edit_distance_batch(Engine& e, const ReadsDev& r, const u32* h_pairs, u32 n_pairs, u32* h_out, double* kernel_ms,

@@ -61,6 +61,8 @@ struct UseTimers {
   ~UseTimers() { g_kernel_timers = nullptr; }
 };
 
+int fetch_values(Engine& e, const DevBuf& val, u64 n, uint64_t* values);
+
 void swap_bufs(DevBuf& a, DevBuf& b) {
   std::swap(a.ptr, b.ptr);
   std::swap(a.cap, b.cap);
@@ -527,6 +529,213 @@ int rvn_poa_consensus_batch(rvn_engine* h, const uint8_t* codes, const uint8_t* 
   });
 }
 
+// ---- stage-level entry points of the sharded single-genome pass (host side raven_amd/sharded.py) ----
+int rvn_shard_sketch(rvn_engine* h, const rvn_reads* rr, int index_minhash, uint64_t* count) {
+  return guarded([&]() -> int {
+    if (!h || !rr || !count) return fail(RVN_EINVAL, "[raven_hip] rvn_shard_sketch: NULL argument");
+    Engine& e = h->e;
+    const ReadsDev& r = rr->r;
+    RVN_HIP(hipSetDevice(e.device));
+    UseTimers ut(e);
+    StageTimer t(e, StageTimes::kSketch);
+    e.query_ready = false;
+    sketch_raw(e, r, 0, r.n, e.raw_sketch);
+    if (index_minhash) {
+      sketch_minhash(e, r, e.raw_sketch, e.index_sketch);
+      e.shard_sketch_minhash = true;
+      *count = e.index_sketch.count;
+    } else {
+      e.join_query_count = sketch_flag_queries(e, r, e.raw_sketch);  // minhash-selected entries get kQueryFlag
+      e.shard_sketch_minhash = false;
+      *count = e.raw_sketch.count;
+    }
+    for (u32 i = 0; i < r.n; ++i) e.c_index_bases += r.h_len[i];
+    t.stop();
+    RVN_HIP(hipStreamSynchronize(e.stream));
+    return RVN_OK;
+  });
+}
+
+int rvn_shard_sketch_fetch(rvn_engine* h, uint64_t* values, uint64_t* origins) {
+  return guarded([&]() -> int {
+    if (!h) return fail(RVN_EINVAL, "[raven_hip] NULL engine");
+    Engine& e = h->e;
+    Sketch& s = e.shard_sketch_minhash ? e.index_sketch : e.raw_sketch;
+    RVN_HIP(hipSetDevice(e.device));
+    fetch_values(e, s.val, s.count, values);
+    if (origins && s.count) RVN_HIP(hipMemcpy(origins, s.org.ptr, s.count * 8, hipMemcpyDeviceToHost));
+    return RVN_OK;
+  });
+}
+
+int rvn_shard_index_build(rvn_engine* h, const uint64_t* values, const uint64_t* origins, uint64_t n, int all_query) {
+  return guarded([&]() -> int {
+    if (!h || (n && (!values || !origins))) return fail(RVN_EINVAL, "[raven_hip] rvn_shard_index_build: NULL argument");
+    Engine& e = h->e;
+    RVN_HIP(hipSetDevice(e.device));
+    UseTimers ut(e);
+    Sketch& sk = e.index_sketch;
+    sk.first = 0;
+    sk.last = 0;
+    sk.count = n;
+    u64 flagged = 0;
+    if (e.val64) {
+      u64* dv = sk.val.get<u64>(n + 1);
+      if (n) RVN_HIP(hipMemcpy(dv, values, n * 8, hipMemcpyHostToDevice));
+    } else {
+      std::vector<u32> tmp(n);
+      for (u64 i = 0; i < n; ++i) tmp[i] = static_cast<u32>(values[i]);
+      u32* dv = sk.val.get<u32>(n + 1);
+      if (n) RVN_HIP(hipMemcpy(dv, tmp.data(), n * 4, hipMemcpyHostToDevice));
+    }
+    u64* dorg = sk.org.get<u64>(n + 1);
+    if (n) RVN_HIP(hipMemcpy(dorg, origins, n * 8, hipMemcpyHostToDevice));
+    for (u64 i = 0; i < n; ++i) flagged += (origins[i] & kQueryFlag) ? 1 : 0;
+    e.c_index_min += n;
+    index_build(e, sk, false);
+    e.c_index_keys += e.index.u;
+    e.index.has_query_flags = !all_query;
+    e.index.all_query = all_query != 0;
+    e.join_query_count = all_query ? n : flagged;
+    RVN_HIP(hipStreamSynchronize(e.stream));
+    return RVN_OK;
+  });
+}
+
+int rvn_shard_key_counts(rvn_engine* h, uint32_t* counts) {
+  return guarded([&]() -> int {
+    if (!h) return fail(RVN_EINVAL, "[raven_hip] NULL engine");
+    Engine& e = h->e;
+    const u64 u = e.index.u;
+    if (u == 0) return RVN_OK;
+    if (!counts) return fail(RVN_EINVAL, "[raven_hip] rvn_shard_key_counts: NULL argument");
+    RVN_HIP(hipSetDevice(e.device));
+    std::vector<u32> st(u + 1);
+    RVN_HIP(hipMemcpy(st.data(), e.index.u_start.ptr, (u + 1) * 4, hipMemcpyDeviceToHost));
+    for (u64 i = 0; i < u; ++i) counts[i] = st[i + 1] - st[i];
+    return RVN_OK;
+  });
+}
+
+int rvn_engine_set_occurrence(rvn_engine* h, uint32_t occurrence) {
+  if (!h) return fail(RVN_EINVAL, "[raven_hip] NULL engine");
+  h->e.index.occurrence = occurrence;
+  return RVN_OK;
+}
+
+int rvn_shard_join(rvn_engine* h, uint32_t n_reads_total, int avoid_equal, int avoid_symmetric, uint64_t* n_matches) {
+  return guarded([&]() -> int {
+    if (!h || !n_matches) return fail(RVN_EINVAL, "[raven_hip] rvn_shard_join: NULL argument");
+    Engine& e = h->e;
+    RVN_HIP(hipSetDevice(e.device));
+    UseTimers ut(e);
+    e.shard_join_reads = n_reads_total;
+    e.shard_join_matches = join_index_matches(e, n_reads_total, avoid_equal != 0, avoid_symmetric != 0);
+    *n_matches = e.shard_join_matches;
+    RVN_HIP(hipStreamSynchronize(e.stream));
+    return RVN_OK;
+  });
+}
+
+int rvn_shard_join_fetch(rvn_engine* h, uint64_t* grp, uint64_t* pos, uint64_t* seg_off) {
+  return guarded([&]() -> int {
+    if (!h) return fail(RVN_EINVAL, "[raven_hip] NULL engine");
+    Engine& e = h->e;
+    RVN_HIP(hipSetDevice(e.device));
+    const u64 H = e.shard_join_matches;
+    if (H && grp) RVN_HIP(hipMemcpy(grp, e.m_grp[0].ptr, H * 8, hipMemcpyDeviceToHost));
+    if (H && pos) RVN_HIP(hipMemcpy(pos, e.m_pos[0].ptr, H * 8, hipMemcpyDeviceToHost));
+    if (seg_off)
+      RVN_HIP(hipMemcpy(seg_off, e.seg_off.ptr, (static_cast<size_t>(e.shard_join_reads) + 1) * 8, hipMemcpyDeviceToHost));
+    return RVN_OK;
+  });
+}
+
+int rvn_shard_chain(rvn_engine* h, const rvn_reads* own, const uint64_t* grp, const uint64_t* pos,
+                    const uint64_t* seg_off, uint64_t* n_overlaps) {
+  return guarded([&]() -> int {
+    if (!h || !own || !seg_off || !n_overlaps) return fail(RVN_EINVAL, "[raven_hip] rvn_shard_chain: NULL argument");
+    Engine& e = h->e;
+    const ReadsDev& r = own->r;
+    RVN_HIP(hipSetDevice(e.device));
+    UseTimers ut(e);
+    const u32 nr = r.n;
+    const u64 H = seg_off[nr];
+    if (H && (!grp || !pos)) return fail(RVN_EINVAL, "[raven_hip] rvn_shard_chain: NULL matches");
+    u64* d_seg = e.seg_off.get<u64>(static_cast<size_t>(nr) + 2);
+    RVN_HIP(hipMemcpy(d_seg, seg_off, (static_cast<size_t>(nr) + 1) * 8, hipMemcpyHostToDevice));
+    u64* g0 = e.m_grp[0].get<u64>(H + 1);
+    u64* p0 = e.m_pos[0].get<u64>(H + 1);
+    e.m_grp[1].reserve((H + 1) * 8);
+    e.m_pos[1].reserve((H + 1) * 8);
+    if (H) {
+      RVN_HIP(hipMemcpy(g0, grp, H * 8, hipMemcpyHostToDevice));
+      RVN_HIP(hipMemcpy(p0, pos, H * 8, hipMemcpyHostToDevice));
+    }
+    MapOut& out = e.map_out;
+    out.first = 0;
+    out.last = nr;
+    out.n_query = 0;
+    out.n_matches = H;
+    out.n_intervals = out.n_overlaps = 0;
+    for (u32 i = 0; i < nr; ++i) e.c_query_bases += r.h_len[i];
+    chain_matches(e, r, 0, nr, H, out);
+    e.c_intervals += out.n_intervals;
+    RVN_HIP(hipStreamSynchronize(e.stream));
+    *n_overlaps = out.n_overlaps;
+    return RVN_OK;
+  });
+}
+
+int rvn_shard_piles(rvn_engine* h, const uint32_t* lengths, uint32_t n_reads_total, const rvn_overlap* overlaps,
+                    uint64_t n, uint32_t kmax, rvn_pass1** out) {
+  return guarded([&]() -> int {
+    if (!h || !lengths || !out || (n && !overlaps)) return fail(RVN_EINVAL, "[raven_hip] rvn_shard_piles: NULL argument");
+    Engine& e = h->e;
+    RVN_HIP(hipSetDevice(e.device));
+    UseTimers ut(e);
+    // metadata-only read set: piles need lengths and ids (== indices), not bases
+    ReadsDev meta;
+    meta.n = n_reads_total;
+    meta.h_len.assign(lengths, lengths + n_reads_total);
+    meta.h_id.resize(n_reads_total);
+    for (u32 i = 0; i < n_reads_total; ++i) meta.h_id[i] = i;
+    meta.ids_are_indices = true;
+    u32* d_len = meta.len.get<u32>(static_cast<size_t>(n_reads_total) + 1);
+    u32* d_id = meta.id.get<u32>(static_cast<size_t>(n_reads_total) + 1);
+    if (n_reads_total) {
+      RVN_HIP(hipMemcpy(d_len, meta.h_len.data(), static_cast<size_t>(n_reads_total) * 4, hipMemcpyHostToDevice));
+      RVN_HIP(hipMemcpy(d_id, meta.h_id.data(), static_cast<size_t>(n_reads_total) * 4, hipMemcpyHostToDevice));
+    }
+    // overlaps arrive in (query read k, emission) order; per-k offsets as Map would have produced them
+    std::vector<u32> off(static_cast<size_t>(n_reads_total) + 1, 0);
+    const Overlap* ov = reinterpret_cast<const Overlap*>(overlaps);
+    u32 prev = 0;
+    for (u64 i = 0; i < n; ++i) {
+      if (ov[i].lhs_id >= n_reads_total || ov[i].rhs_id >= n_reads_total || ov[i].lhs_id < prev)
+        return fail(RVN_EINVAL, "[raven_hip] rvn_shard_piles: overlaps must be ordered by lhs_id and ids < n_reads");
+      prev = ov[i].lhs_id;
+      ++off[ov[i].lhs_id + 1];
+    }
+    for (u32 i = 0; i < n_reads_total; ++i) off[i + 1] += off[i];
+    MapOut mo;
+    mo.first = 0;
+    mo.last = n_reads_total;
+    mo.n_overlaps = n;
+    Overlap* d_ov = mo.ovl.get<Overlap>(n + 1);
+    if (n) RVN_HIP(hipMemcpy(d_ov, ov, n * sizeof(Overlap), hipMemcpyHostToDevice));
+    u32* d_off = mo.ovl_read_off.get<u32>(off.size());
+    RVN_HIP(hipMemcpy(d_off, off.data(), off.size() * 4, hipMemcpyHostToDevice));
+    std::unique_ptr<rvn_pass1> p(new rvn_pass1());
+    p->e = &e;
+    piles_init(e, meta, p->ps);
+    piles_merge(e, meta, mo, kmax, p->ps);
+    RVN_HIP(hipStreamSynchronize(e.stream));
+    *out = p.release();
+    return RVN_OK;
+  });
+}
+
 int rvn_polish_target_reads(const rvn_engine* h, uint32_t* counts, uint32_t n_targets) {
   if (!h || !counts || n_targets != h->e.polish_target_reads.size())
     return fail(RVN_EINVAL, "[raven_hip] rvn_polish_target_reads: no polishing round with that many targets");
@@ -560,7 +769,8 @@ int rvn_engine_sketch(rvn_engine* h, const rvn_reads* r, uint32_t first, uint32_
   });
 }
 
-static int fetch_values(Engine& e, const DevBuf& val, u64 n, uint64_t* values) {
+namespace {
+int fetch_values(Engine& e, const DevBuf& val, u64 n, uint64_t* values) {
   if (!values || n == 0) return RVN_OK;
   if (e.val64) {
     RVN_HIP(hipMemcpy(values, val.ptr, n * 8, hipMemcpyDeviceToHost));
@@ -571,6 +781,7 @@ static int fetch_values(Engine& e, const DevBuf& val, u64 n, uint64_t* values) {
   }
   return RVN_OK;
 }
+}  // namespace
 
 int rvn_engine_sketch_fetch(rvn_engine* h, uint64_t* values, uint64_t* origins, uint32_t* read_offsets) {
   return guarded([&]() -> int {

@@ -749,6 +749,114 @@ __global__ void read_ovl_off_kernel(const u64* __restrict__ seg_off, const u32* 
   if (i < n) out[i] = scan[(seg_off[i] + slot_div - 1) / slot_div];
 }
 
+}  // namespace
+
+// Chain stage: matches of reads [first, last) are in e.m_grp[0] / e.m_pos[0] (both ping-pong sides reserved for
+// H + 1 entries), segmented per read by e.seg_off[nr + 1] -> overlaps in (read, emission) order in `out`.
+// (ram Map after the index probes: sort by group, diagonal bands, per-band LIS, overlap emission.)
+void chain_matches(Engine& e, const ReadsDev& r, u32 first, u32 last, u64 H, MapOut& out) {
+  hipStream_t s = e.stream;
+  const u32 nr = last - first;
+  u32* ovl_read_off = out.ovl_read_off.get<u32>(static_cast<size_t>(nr) + 1);
+  u64* seg_off = e.seg_off.as<u64>();
+  if (H == 0) {
+    RVN_HIP(hipMemsetAsync(ovl_read_off, 0, (static_cast<size_t>(nr) + 1) * 4, s));
+    return;
+  }
+  u64* g0 = e.m_grp[0].as<u64>();
+  u64* g1 = e.m_grp[1].as<u64>();
+  u64* p0 = e.m_pos[0].as<u64>();
+  u64* p1 = e.m_pos[1].as<u64>();
+  {
+    StageTimer t(e, StageTimes::kSegSort);
+    RVN_KLAUNCH(kKSegSortGroup, seg_sort_lds_kernel<<<nr, 256, 0, s>>>(g0, p0, seg_off, nr);
+                seg_sort_off_kernel<<<div_up(nr, 4), 256, 0, s>>>(g0, g1, p0, p1, seg_off, nr));
+    t.stop();
+  }
+  u32 NI = 0;
+  const u64 n_slots4 = (H + 3) / 4 + 1;
+  {
+    StageTimer t(e, StageTimes::kIntervals);
+    u64* slot_begin = e.iv_slot_begin.get<u64>(n_slots4 + 1);
+    u64* slot_end = e.iv_slot_end.get<u64>(n_slots4 + 1);
+    u32* iv_cnt = e.iv_cnt.get<u32>(static_cast<size_t>(nr) + 1);
+    u32* iv_off = e.iv_off.get<u32>(static_cast<size_t>(nr) + 2);
+    RVN_KLAUNCH(kKIntervals, intervals_kernel<<<div_up(nr, 4), 256, 0, s>>>(g0, seg_off, nr, e.bandwidth, slot_begin, slot_end, iv_cnt));
+    exclusive_scan_u32_u32(iv_cnt, iv_off, nr, e.scan_tmp, s);
+    NI = static_cast<u32>(read_back(e, iv_off + nr, 4));
+    out.n_intervals = NI;
+    if (NI) {
+      u64* iv_begin = e.iv_begin.get<u64>(static_cast<size_t>(NI) + 1);
+      u64* iv_end = e.iv_end.get<u64>(static_cast<size_t>(NI) + 1);
+      u32* iv_read = e.tmp_b.get<u32>(static_cast<size_t>(NI) + 1);
+      RVN_KLAUNCH(kKIntervalsGather, intervals_gather_kernel<<<div_up(nr, 4), 256, 0, s>>>(
+                                         slot_begin, slot_end, seg_off, iv_off, nr, iv_begin, iv_end, iv_read));
+    }
+    t.stop();
+  }
+  if (NI == 0) {
+    RVN_HIP(hipMemsetAsync(ovl_read_off, 0, (static_cast<size_t>(nr) + 1) * 4, s));
+    return;
+  }
+  const u32 slot_div = std::max(1u, std::min(4u, e.chain));
+  const u64 n_slots = (H + slot_div - 1) / slot_div + 1;
+  Overlap* slots = e.ovl_slots.get<Overlap>(n_slots + 1);
+  u8* slot_flags = e.ovl_flags.get<u8>(n_slots + 1);
+  {
+    StageTimer t(e, StageTimes::kChain);
+    u64* iv_begin = e.iv_begin.as<u64>();
+    u64* iv_end = e.iv_end.as<u64>();
+    u32* iv_read = e.tmp_b.as<u32>();
+    // sort every interval by positions (payload = group)
+    RVN_KLAUNCH(kKSegSortPos, seg_sort_be_kernel<<<div_up(NI, 4), 256, 0, s>>>(p0, p1, g0, g1, iv_begin, iv_end, NI,
+                                                                           std::max(e.chain, kChainSmallCap + 1)));
+    u32* lis_min = e.lis_min.get<u32>(H + NI + 1);
+    u32* lis_pred = e.lis_pred.get<u32>(H + 1);
+    u64* lis_tail = e.lis_tail.get<u64>(H + NI + 1);
+    u64* lis_mask = e.lis_mask.get<u64>((H >> 6) + NI + 2);
+    RVN_HIP(hipMemsetAsync(slot_flags, 0, n_slots + 1, s));
+    u64* anchors = nullptr;
+    u64* slot_aoff = nullptr;
+    u32* slot_acnt = nullptr;
+    if (e.keep_anchors) {
+      anchors = out.anchors.get<u64>(H + 1);
+      slot_aoff = e.anc_slot_off.get<u64>(n_slots + 1);
+      slot_acnt = e.anc_slot_cnt.get<u32>(n_slots + 1);
+    }
+    RVN_KLAUNCH(kKChainSmall, chain_small_kernel<<<div_up(NI, 64), 64, 0, s>>>(
+                                  g0, p0, iv_begin, iv_end, iv_read, NI, r.id.as<u32>(), first, e.k, e.chain, e.matches,
+                                  e.gap, slot_div, slots, slot_flags, anchors, slot_aoff, slot_acnt));
+    RVN_KLAUNCH(kKChain, chain_kernel<<<div_up(NI, 4 * kChainPerWave), 256, 0, s>>>(g0, p0, iv_begin, iv_end, iv_read, NI,
+                                                                     r.id.as<u32>(), first, e.k, e.chain, e.matches,
+                                                                     e.gap, slot_div, lis_tail, lis_min, lis_pred,
+                                                                     lis_mask, slots, slot_flags, anchors, slot_aoff,
+                                                                     slot_acnt));
+    t.stop();
+  }
+  {
+    StageTimer t(e, StageTimes::kCompact);
+    u32* scan = e.ovl_scan.get<u32>(n_slots + 2);
+    exclusive_scan_u8_u32(slot_flags, scan, n_slots, e.scan_tmp, s);
+    const u32 O = static_cast<u32>(read_back(e, scan + n_slots, 4));
+    out.n_overlaps = O;
+    e.c_overlaps += O;
+    Overlap* ovl = out.ovl.get<Overlap>(static_cast<size_t>(O) + 1);
+    RVN_KLAUNCH(kKCompactOverlaps, compact_overlaps_kernel<<<div_up(n_slots, 256), 256, 0, s>>>(slots, slot_flags, scan, n_slots, ovl));
+    out.has_anchors = e.keep_anchors;
+    if (e.keep_anchors) {
+      u64* aoff = out.anchor_off.get<u64>(static_cast<size_t>(O) + 1);
+      u32* acnt = out.anchor_cnt.get<u32>(static_cast<size_t>(O) + 1);
+      RVN_KLAUNCH(kKCompactOverlaps, compact_aux_kernel<<<div_up(n_slots, 256), 256, 0, s>>>(
+                                         e.anc_slot_off.as<u64>(), e.anc_slot_cnt.as<u32>(), slot_flags, scan, n_slots,
+                                         aoff, acnt));
+    }
+    RVN_KLAUNCH(kKGather, read_ovl_off_kernel<<<div_up(nr + 1, 256), 256, 0, s>>>(seg_off, scan, slot_div, nr + 1, ovl_read_off));
+    t.stop();
+  }
+}
+
+namespace {
+
 template <typename V>
 void map_batch_impl(Engine& e, const ReadsDev& r, u32 first, u32 last, bool avoid_equal, bool avoid_symmetric,
                     bool minhash, bool want_filtered, MapOut& out) {
@@ -848,103 +956,44 @@ void map_batch_impl(Engine& e, const ReadsDev& r, u32 first, u32 last, bool avoi
     t.stop();
   }
   }  // !join
-  if (H == 0) {
-    RVN_HIP(hipMemsetAsync(ovl_read_off, 0, (static_cast<size_t>(nr) + 1) * 4, s));
-    return;
-  }
-  u64* g0 = e.m_grp[0].as<u64>();
-  u64* g1 = e.m_grp[1].as<u64>();
-  u64* p0 = e.m_pos[0].as<u64>();
-  u64* p1 = e.m_pos[1].as<u64>();
-  {
-    StageTimer t(e, StageTimes::kSegSort);
-    RVN_KLAUNCH(kKSegSortGroup, seg_sort_lds_kernel<<<nr, 256, 0, s>>>(g0, p0, seg_off, nr);
-                seg_sort_off_kernel<<<div_up(nr, 4), 256, 0, s>>>(g0, g1, p0, p1, seg_off, nr));
-    t.stop();
-  }
-  u32 NI = 0;
-  const u64 n_slots4 = (H + 3) / 4 + 1;
-  {
-    StageTimer t(e, StageTimes::kIntervals);
-    u64* slot_begin = e.iv_slot_begin.get<u64>(n_slots4 + 1);
-    u64* slot_end = e.iv_slot_end.get<u64>(n_slots4 + 1);
-    u32* iv_cnt = e.iv_cnt.get<u32>(static_cast<size_t>(nr) + 1);
-    u32* iv_off = e.iv_off.get<u32>(static_cast<size_t>(nr) + 2);
-    RVN_KLAUNCH(kKIntervals, intervals_kernel<<<div_up(nr, 4), 256, 0, s>>>(g0, seg_off, nr, e.bandwidth, slot_begin, slot_end, iv_cnt));
-    exclusive_scan_u32_u32(iv_cnt, iv_off, nr, e.scan_tmp, s);
-    NI = static_cast<u32>(read_back(e, iv_off + nr, 4));
-    out.n_intervals = NI;
-    if (NI) {
-      u64* iv_begin = e.iv_begin.get<u64>(static_cast<size_t>(NI) + 1);
-      u64* iv_end = e.iv_end.get<u64>(static_cast<size_t>(NI) + 1);
-      u32* iv_read = e.tmp_b.get<u32>(static_cast<size_t>(NI) + 1);
-      RVN_KLAUNCH(kKIntervalsGather, intervals_gather_kernel<<<div_up(nr, 4), 256, 0, s>>>(
-                                         slot_begin, slot_end, seg_off, iv_off, nr, iv_begin, iv_end, iv_read));
-    }
-    t.stop();
-  }
-  if (NI == 0) {
-    RVN_HIP(hipMemsetAsync(ovl_read_off, 0, (static_cast<size_t>(nr) + 1) * 4, s));
-    return;
-  }
-  const u32 slot_div = std::max(1u, std::min(4u, e.chain));
-  const u64 n_slots = (H + slot_div - 1) / slot_div + 1;
-  Overlap* slots = e.ovl_slots.get<Overlap>(n_slots + 1);
-  u8* slot_flags = e.ovl_flags.get<u8>(n_slots + 1);
-  {
-    StageTimer t(e, StageTimes::kChain);
-    u64* iv_begin = e.iv_begin.as<u64>();
-    u64* iv_end = e.iv_end.as<u64>();
-    u32* iv_read = e.tmp_b.as<u32>();
-    // sort every interval by positions (payload = group)
-    RVN_KLAUNCH(kKSegSortPos, seg_sort_be_kernel<<<div_up(NI, 4), 256, 0, s>>>(p0, p1, g0, g1, iv_begin, iv_end, NI,
-                                                                           std::max(e.chain, kChainSmallCap + 1)));
-    u32* lis_min = e.lis_min.get<u32>(H + NI + 1);
-    u32* lis_pred = e.lis_pred.get<u32>(H + 1);
-    u64* lis_tail = e.lis_tail.get<u64>(H + NI + 1);
-    u64* lis_mask = e.lis_mask.get<u64>((H >> 6) + NI + 2);
-    RVN_HIP(hipMemsetAsync(slot_flags, 0, n_slots + 1, s));
-    u64* anchors = nullptr;
-    u64* slot_aoff = nullptr;
-    u32* slot_acnt = nullptr;
-    if (e.keep_anchors) {
-      anchors = out.anchors.get<u64>(H + 1);
-      slot_aoff = e.anc_slot_off.get<u64>(n_slots + 1);
-      slot_acnt = e.anc_slot_cnt.get<u32>(n_slots + 1);
-    }
-    RVN_KLAUNCH(kKChainSmall, chain_small_kernel<<<div_up(NI, 64), 64, 0, s>>>(
-                                  g0, p0, iv_begin, iv_end, iv_read, NI, r.id.as<u32>(), first, e.k, e.chain, e.matches,
-                                  e.gap, slot_div, slots, slot_flags, anchors, slot_aoff, slot_acnt));
-    RVN_KLAUNCH(kKChain, chain_kernel<<<div_up(NI, 4 * kChainPerWave), 256, 0, s>>>(g0, p0, iv_begin, iv_end, iv_read, NI,
-                                                                     r.id.as<u32>(), first, e.k, e.chain, e.matches,
-                                                                     e.gap, slot_div, lis_tail, lis_min, lis_pred,
-                                                                     lis_mask, slots, slot_flags, anchors, slot_aoff,
-                                                                     slot_acnt));
-    t.stop();
-  }
-  {
-    StageTimer t(e, StageTimes::kCompact);
-    u32* scan = e.ovl_scan.get<u32>(n_slots + 2);
-    exclusive_scan_u8_u32(slot_flags, scan, n_slots, e.scan_tmp, s);
-    const u32 O = static_cast<u32>(read_back(e, scan + n_slots, 4));
-    out.n_overlaps = O;
-    e.c_overlaps += O;
-    Overlap* ovl = out.ovl.get<Overlap>(static_cast<size_t>(O) + 1);
-    RVN_KLAUNCH(kKCompactOverlaps, compact_overlaps_kernel<<<div_up(n_slots, 256), 256, 0, s>>>(slots, slot_flags, scan, n_slots, ovl));
-    out.has_anchors = e.keep_anchors;
-    if (e.keep_anchors) {
-      u64* aoff = out.anchor_off.get<u64>(static_cast<size_t>(O) + 1);
-      u32* acnt = out.anchor_cnt.get<u32>(static_cast<size_t>(O) + 1);
-      RVN_KLAUNCH(kKCompactOverlaps, compact_aux_kernel<<<div_up(n_slots, 256), 256, 0, s>>>(
-                                         e.anc_slot_off.as<u64>(), e.anc_slot_cnt.as<u32>(), slot_flags, scan, n_slots,
-                                         aoff, acnt));
-    }
-    RVN_KLAUNCH(kKGather, read_ovl_off_kernel<<<div_up(nr + 1, 256), 256, 0, s>>>(seg_off, scan, slot_div, nr + 1, ovl_read_off));
-    t.stop();
-  }
+  out.n_matches = H;
+  chain_matches(e, r, first, last, H, out);
 }
 
 }  // namespace
+
+// Self-join of the whole (shard of the) index for query read ids 0..n_reads-1 (ids are global read indices):
+// matches land in e.m_grp[0] / e.m_pos[0], segmented by query id through e.seg_off[n_reads + 1].  The hash-owner
+// side of the sharded pass: the owner of a hash class joins its runs and ships every read's matches
+// to the GPU that owns the read.  Returns the number of matches.
+u64 join_index_matches(Engine& e, u32 n_reads, bool avoid_equal, bool avoid_symmetric) {
+  hipStream_t s = e.stream;
+  Index& ix = e.index;
+  u64* seg_off = e.seg_off.get<u64>(static_cast<size_t>(n_reads) + 2);
+  RVN_HIP(hipMemsetAsync(seg_off, 0, (static_cast<size_t>(n_reads) + 2) * 8, s));
+  if (ix.m == 0 || ix.u == 0) return 0;
+  if (!(ix.has_query_flags || ix.all_query)) throw std::invalid_argument("[raven_hip] join: index has no query flags");
+  StageTimer t(e, StageTimes::kMatch);
+  u32* read_cnt = e.q_cnt.get<u32>(2 * (static_cast<size_t>(n_reads) + 1));
+  u32* cursor = read_cnt + n_reads + 1;
+  RVN_HIP(hipMemsetAsync(read_cnt, 0, 2 * (static_cast<size_t>(n_reads) + 1) * 4, s));
+  const u32 n_runs = static_cast<u32>(ix.u);
+  const u64* sorg = ix.s_org[ix.cur].as<u64>();
+  RVN_KLAUNCH(kKJoinCount, join_kernel<false><<<div_up(n_runs, 256), 256, 0, s>>>(
+                               ix.u_start.as<u32>(), n_runs, sorg, ix.occurrence, ix.all_query, avoid_equal,
+                               avoid_symmetric, 0, read_cnt, nullptr, nullptr, nullptr, nullptr));
+  exclusive_scan_u32_u64(read_cnt, seg_off, n_reads, e.scan_tmp, s);
+  const u64 H = read_back(e, seg_off + n_reads, 8);
+  e.c_matches += H;
+  u64* g0 = e.m_grp[0].get<u64>(H + 1);
+  u64* p0 = e.m_pos[0].get<u64>(H + 1);
+  if (H)
+    RVN_KLAUNCH(kKJoinEmit, join_kernel<true><<<div_up(n_runs, 256), 256, 0, s>>>(
+                                ix.u_start.as<u32>(), n_runs, sorg, ix.occurrence, ix.all_query, avoid_equal,
+                                avoid_symmetric, 0, nullptr, seg_off, cursor, g0, p0));
+  t.stop();
+  return H;
+}
 
 void map_batch(Engine& e, const ReadsDev& r, u32 first, u32 last, bool avoid_equal, bool avoid_symmetric,
                bool minhash, bool want_filtered, MapOut& out) {

@@ -33,7 +33,9 @@ SYMBOLS = [
     "rvn_engine_map_batch", "rvn_engine_map_fetch", "rvn_engine_map_fetch_filtered",
     "rvn_find_overlaps_and_create_piles", "rvn_pass1_pile_words", "rvn_pass1_num_overlaps",
     "rvn_pass1_fetch_piles", "rvn_pass1_fetch_overlaps", "rvn_pass1_destroy", "rvn_pile_add_layers",
-    "rvn_edit_distance_batch", "rvn_poa_consensus_batch", "rvn_poa_phase_cycles", "rvn_polish_target_reads", "rvn_poa_set_mode", "rvn_poa_fallback_windows", "rvn_poa_wide_windows", "rvn_pile_add_kmers_batch",
+    "rvn_edit_distance_batch", "rvn_poa_consensus_batch", "rvn_poa_phase_cycles", "rvn_polish_target_reads", "rvn_shard_sketch", "rvn_shard_sketch_fetch",
+    "rvn_shard_index_build", "rvn_shard_key_counts", "rvn_engine_set_occurrence", "rvn_shard_join",
+    "rvn_shard_join_fetch", "rvn_shard_chain", "rvn_shard_piles", "rvn_poa_set_mode", "rvn_poa_fallback_windows", "rvn_poa_wide_windows", "rvn_pile_add_kmers_batch",
     "rvn_test_low_complexity", "rvn_polish_round",
     "rvn_engine_sketch", "rvn_engine_sketch_fetch", "rvn_engine_index_size", "rvn_engine_index_fetch",
     "rvn_engine_counters", "rvn_engine_num_stages", "rvn_engine_stage_name", "rvn_engine_stage_ms",
@@ -92,6 +94,16 @@ def lib():
     L.rvn_poa_consensus_batch.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, u32, i32, i32, i32, i32, vp, vp, vp, vp,
                                           C.POINTER(dbl)]
     L.rvn_poa_phase_cycles.argtypes = [vp, vp]
+    L.rvn_polish_target_reads.argtypes = [vp, vp, u32]
+    L.rvn_shard_sketch.argtypes = [vp, vp, i32, C.POINTER(u64)]
+    L.rvn_shard_sketch_fetch.argtypes = [vp, vp, vp]
+    L.rvn_shard_index_build.argtypes = [vp, vp, vp, u64, i32]
+    L.rvn_shard_key_counts.argtypes = [vp, vp]
+    L.rvn_engine_set_occurrence.argtypes = [vp, u32]
+    L.rvn_shard_join.argtypes = [vp, u32, i32, i32, C.POINTER(u64)]
+    L.rvn_shard_join_fetch.argtypes = [vp, vp, vp, vp]
+    L.rvn_shard_chain.argtypes = [vp, vp, vp, vp, vp, C.POINTER(u64)]
+    L.rvn_shard_piles.argtypes = [vp, vp, u32, vp, u64, u32, C.POINTER(vp)]
     L.rvn_poa_set_mode.argtypes = [vp, i32]
     L.rvn_poa_set_mode.restype = i32
     L.rvn_poa_fallback_windows.argtypes = [vp]
@@ -255,6 +267,59 @@ class Engine:
         _check(lib().rvn_find_overlaps_and_create_piles(self._h, reads._h, float(freq), kmax, int(use_minhash),
                                                         index_batch_bases, flush_bases, C.byref(h)))
         return Pass1(h, reads.n)
+
+    # -- stage-level entry points of the sharded pass (raven_amd/sharded.py) ------------------------
+    def shard_sketch(self, own_reads: Reads, index_minhash=False):
+        n = C.c_uint64(0)
+        _check(lib().rvn_shard_sketch(self._h, own_reads._h, int(index_minhash), C.byref(n)))
+        values = np.zeros(n.value, dtype=np.uint64)
+        origins = np.zeros(n.value, dtype=np.uint64)
+        _check(lib().rvn_shard_sketch_fetch(self._h, _p(values), _p(origins)))
+        return values, origins
+
+    def shard_index_build(self, values, origins, all_query=False):
+        values = np.ascontiguousarray(values, dtype=np.uint64)
+        origins = np.ascontiguousarray(origins, dtype=np.uint64)
+        _check(lib().rvn_shard_index_build(self._h, _p(values), _p(origins), values.shape[0], int(all_query)))
+
+    def shard_key_counts(self):
+        m, u = C.c_uint64(0), C.c_uint64(0)
+        _check(lib().rvn_engine_index_size(self._h, C.byref(m), C.byref(u)))
+        counts = np.zeros(u.value, dtype=np.uint32)
+        _check(lib().rvn_shard_key_counts(self._h, _p(counts)))
+        return counts
+
+    def set_occurrence(self, occurrence):
+        _check(lib().rvn_engine_set_occurrence(self._h, int(occurrence)))
+
+    def shard_join(self, n_reads_total, avoid_equal=True, avoid_symmetric=True):
+        h = C.c_uint64(0)
+        _check(lib().rvn_shard_join(self._h, n_reads_total, int(avoid_equal), int(avoid_symmetric), C.byref(h)))
+        grp = np.zeros(h.value, dtype=np.uint64)
+        pos = np.zeros(h.value, dtype=np.uint64)
+        seg = np.zeros(n_reads_total + 1, dtype=np.uint64)
+        _check(lib().rvn_shard_join_fetch(self._h, _p(grp), _p(pos), _p(seg)))
+        return grp, pos, seg
+
+    def shard_chain(self, own_reads: Reads, grp, pos, seg_off):
+        grp = np.ascontiguousarray(grp, dtype=np.uint64)
+        pos = np.ascontiguousarray(pos, dtype=np.uint64)
+        seg_off = np.ascontiguousarray(seg_off, dtype=np.uint64)
+        assert seg_off.shape[0] == own_reads.n + 1
+        n = C.c_uint64(0)
+        _check(lib().rvn_shard_chain(self._h, own_reads._h, _p(grp), _p(pos), _p(seg_off), C.byref(n)))
+        ovl = np.zeros(n.value, dtype=OVERLAP_DTYPE)
+        off = np.zeros(own_reads.n + 1, dtype=np.uint32)
+        _check(lib().rvn_engine_map_fetch(self._h, _p(ovl), _p(off)))
+        return ovl, off
+
+    def shard_piles(self, lengths, overlaps, kmax=32) -> Pass1:
+        lengths = np.ascontiguousarray(lengths, dtype=np.uint32)
+        overlaps = np.ascontiguousarray(overlaps, dtype=OVERLAP_DTYPE)
+        h = C.c_void_p()
+        _check(lib().rvn_shard_piles(self._h, _p(lengths), lengths.shape[0], _p(overlaps), overlaps.shape[0], kmax,
+                                     C.byref(h)))
+        return Pass1(h, lengths.shape[0])
 
     def pile_add_layers(self, data: np.ndarray, pile_id: int, overlaps: np.ndarray):
         assert data.dtype == np.uint16 and overlaps.dtype == OVERLAP_DTYPE

@@ -1,0 +1,207 @@
+"""Sharded single-genome FindOverlapsAndCreatePiles (construct.cc:14-121 split across GPUs).
+
+One process per GPU.  Reads are range-partitioned by pile (rank g owns a contiguous id range, balanced by bases, and
+uploads only those reads); minimizer values are partitioned by hash class.  Three exchanges over
+``torch.distributed`` (RCCL all-to-all on a multi-GPU node, gloo in the tests):
+
+  1. every minimizer (value, origin+query flag) to the owner of its hash class  -> owner builds its index shard
+     (all-reduce of the per-key count histogram -> the exact global ``Filter`` cutoff on every rank)
+  2. every match (candidate pair) from the hash owner's self-join to the owner of the query read -> chaining
+  3. every overlap also to the owner of its rhs read -> merge, ``AddLayers``, top-kMax truncation per pile
+
+The compute of every stage is the same device code as the single-GPU pass (``rvn_shard_*`` in raven_hip.h); this file
+is only the partitioning and the exchanges.  Result for the reads a rank owns: bit-identical to the single-GPU pass
+(tests/test_gpu_sharded.py), because (a) pieces are concatenated in source-rank order = global (read, position)
+order, which is the order ram's stable sort and the reference's serial merge see, and (b) the order of a read's
+matches does not matter (total-order sorts follow).  Limits of this round: one index batch and one flush window
+(total bases < 2^30, i.e. configs[1]/[2]); buffers cross the exchange through host memory.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import seqio
+
+_MIX = np.uint64(0x9E3779B97F4A7C15)
+
+
+def partition_reads(lengths: np.ndarray, world: int) -> np.ndarray:
+    """Contiguous read ranges balanced by bases: bounds[world + 1]."""
+    n = int(lengths.shape[0])
+    cum = np.concatenate([[0], np.cumsum(lengths.astype(np.uint64))]).astype(np.float64)
+    targets = cum[-1] * np.arange(1, world) / world
+    inner = np.searchsorted(cum, targets, side="left")
+    bounds = np.concatenate([[0], inner, [n]]).astype(np.int64)
+    return np.maximum.accumulate(bounds)
+
+
+def slice_reads(rs: seqio.ReadSet, lo: int, hi: int) -> seqio.ReadSet:
+    """Reads [lo, hi) as their own packed set; ids stay the GLOBAL read indices."""
+    w0, w1 = int(rs.word_offsets[lo]), int(rs.word_offsets[hi])
+    return seqio.ReadSet(packed=np.ascontiguousarray(rs.packed[w0:w1]),
+                         word_offsets=(rs.word_offsets[lo:hi + 1] - np.uint64(w0)).astype(np.uint64),
+                         lengths=np.ascontiguousarray(rs.lengths[lo:hi]),
+                         ids=np.arange(lo, hi, dtype=np.uint32))
+
+
+def hash_owner(values: np.ndarray, world: int) -> np.ndarray:
+    """Owner rank of a minimizer value (multiplicative mix: window minima are skewed towards small values)."""
+    if world == 1:
+        return np.zeros(values.shape[0], dtype=np.int64)
+    with np.errstate(over="ignore"):
+        h = (values.astype(np.uint64) * _MIX) >> np.uint64(33)
+    return (h % np.uint64(world)).astype(np.int64)
+
+
+def global_occurrence(key_counts: np.ndarray, freq: float, comm) -> int:
+    """ram Filter over ALL hash classes: (value at index (1-f)*U of the sorted per-key counts) + 1."""
+    if freq == 0:
+        return 0xFFFFFFFF
+    hist = np.bincount(np.minimum(key_counts, 65535), minlength=65536).astype(np.int64)
+    over = comm.all_gather_v(key_counts[key_counts >= 65535].astype(np.int64))
+    hist = comm.all_reduce_sum(hist)
+    u = int(hist.sum())
+    if u == 0:
+        return 0xFFFFFFFF
+    nth = min(int((1 - freq) * u), u - 1)
+    cum = np.cumsum(hist)
+    c = int(np.searchsorted(cum, nth + 1, side="left"))
+    if c >= 65535:
+        below = int(cum[65534])
+        c = int(np.sort(over)[nth - below])
+    return c + 1
+
+
+def regroup_by_read(counts_per_src, data_per_src):
+    """Received per-source (per-read counts, flat arrays...) -> (per-read offsets, arrays grouped by read)."""
+    n = counts_per_src[0].shape[0]
+    total = np.zeros(n, dtype=np.int64)
+    for c in counts_per_src:
+        total += c.astype(np.int64)
+    seg = np.zeros(n + 1, dtype=np.uint64)
+    np.cumsum(total, out=seg[1:])
+    outs = [np.zeros(int(seg[-1]), dtype=d.dtype) for d in data_per_src[0]]
+    start = seg[:-1].astype(np.int64).copy()
+    for c, datas in zip(counts_per_src, data_per_src):
+        c = c.astype(np.int64)
+        m = int(c.sum())
+        if m:
+            src_off = np.concatenate([[0], np.cumsum(c)[:-1]])
+            dest = np.repeat(start - src_off, c) + np.arange(m, dtype=np.int64)
+            for o, d in zip(outs, datas):
+                o[dest] = d
+        start += c
+    return seg, outs
+
+
+class Comm:
+    """Variable-size exchanges of numpy arrays over torch.distributed (None / world 1 = identity)."""
+
+    def __init__(self, dist=None, device="cpu"):
+        self.dist = dist if (dist is not None and dist.is_initialized() and dist.get_world_size() > 1) else None
+        self.device = device
+        self.rank = self.dist.get_rank() if self.dist else 0
+        self.world = self.dist.get_world_size() if self.dist else 1
+        self.bytes_sent = 0
+
+    def _t(self, a):
+        import torch
+        return torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
+
+    def all_to_all_v(self, parts):
+        """parts[h] = array for rank h (all the same dtype, itemsize multiple of 8 or int64/uint64).  Returns the list
+        of arrays received, indexed by source rank."""
+        if self.dist is None:
+            return [parts[0]]
+        import torch
+        dt = parts[0].dtype
+        words = [np.ascontiguousarray(p).view(np.int64).reshape(-1) for p in parts]
+        per = dt.itemsize // 8
+        cnt_in = torch.tensor([w.shape[0] for w in words], dtype=torch.int64, device=self.device)
+        cnt_out = torch.zeros(self.world, dtype=torch.int64, device=self.device)
+        self.dist.all_to_all_single(cnt_out, cnt_in)
+        cnt_out_l = [int(x) for x in cnt_out.tolist()]
+        inp = self._t(np.concatenate(words) if words else np.zeros(0, np.int64))
+        out = torch.zeros(sum(cnt_out_l), dtype=torch.int64, device=self.device)
+        self.dist.all_to_all_single(out, inp, cnt_out_l, [w.shape[0] for w in words])
+        self.bytes_sent += 8 * sum(w.shape[0] for i, w in enumerate(words) if i != self.rank)
+        flat = out.cpu().numpy()
+        res, o = [], 0
+        for c in cnt_out_l:
+            res.append(flat[o:o + c].view(dt).reshape(-1) if per else flat[o:o + c])
+            o += c
+        return res
+
+    def all_reduce_sum(self, a):
+        if self.dist is None:
+            return a
+        t = self._t(a.astype(np.int64))
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return t.cpu().numpy()
+
+    def all_gather_v(self, a):
+        if self.dist is None:
+            return a
+        return np.concatenate(self.all_to_all_v([a.astype(np.int64)] * self.world))
+
+
+def find_overlaps_and_create_piles_sharded(eng, rs_all: seqio.ReadSet, comm: Comm, freq=0.001, kmax=32,
+                                           use_minhash=False):
+    """Returns dict(lo, hi, pile_data, pile_off, overlaps, overlap_off, stats) for the reads [lo, hi) this rank
+    owns; arrays are laid out like rvn_pass1_fetch_* restricted to that range."""
+    from . import hip
+    g, world = comm.rank, comm.world
+    n_total = rs_all.n
+    if rs_all.total_bases >= (1 << 30):
+        raise ValueError("sharded pass: one flush window only this round (total bases must be < 2^30)")
+    bounds = partition_reads(rs_all.lengths, world)
+    lo, hi = int(bounds[g]), int(bounds[g + 1])
+    own = eng.upload(slice_reads(rs_all, lo, hi))
+
+    # 1. sketch own reads; minimizers to the owner of their hash class (stable: keeps (read, position) order)
+    val, org = eng.shard_sketch(own, index_minhash=use_minhash)
+    owner = hash_owner(val, world)
+    order = np.argsort(owner, kind="stable")
+    cnt = np.bincount(owner, minlength=world)
+    cuts = np.concatenate([[0], np.cumsum(cnt)])
+    val_s, org_s = val[order], org[order]
+    val_r = comm.all_to_all_v([val_s[cuts[h]:cuts[h + 1]] for h in range(world)])
+    org_r = comm.all_to_all_v([org_s[cuts[h]:cuts[h + 1]] for h in range(world)])
+
+    # 2. index shard of this hash class; 3. exact global Filter
+    eng.shard_index_build(np.concatenate(val_r), np.concatenate(org_r), all_query=use_minhash)
+    occ = global_occurrence(eng.shard_key_counts(), freq, comm)
+    eng.set_occurrence(occ)
+
+    # 4. self-join of the shard; matches (candidate pairs) to the owner of the query read
+    grp, pos, seg = eng.shard_join(n_total, True, True)
+    per_read = np.diff(seg.astype(np.int64))
+    m_cuts = [int(seg[bounds[h]]) for h in range(world)] + [int(seg[n_total])]
+    cnt_r = comm.all_to_all_v([per_read[bounds[h]:bounds[h + 1]] for h in range(world)])
+    grp_r = comm.all_to_all_v([grp[m_cuts[h]:m_cuts[h + 1]] for h in range(world)])
+    pos_r = comm.all_to_all_v([pos[m_cuts[h]:m_cuts[h + 1]] for h in range(world)])
+    seg_own, (grp_own, pos_own) = regroup_by_read(cnt_r, list(zip(grp_r, pos_r)))
+
+    # 5. chain own reads' matches
+    ovl, _ = eng.shard_chain(own, grp_own, pos_own, seg_own)
+
+    # 6. overlaps also to the owner of their rhs read (own ones are already here); merge + piles
+    rhs_owner = np.searchsorted(bounds, ovl["rhs_id"].astype(np.int64), side="right") - 1
+    empty = np.zeros(0, dtype=hip.OVERLAP_DTYPE)
+    recv = comm.all_to_all_v([ovl[rhs_owner == h] if h != g else empty for h in range(world)])
+    for s in range(g + 1, world):
+        assert recv[s].shape[0] == 0, "avoid_symmetric: overlaps only travel to higher ranks"
+    combined = np.concatenate([recv[s] for s in range(g)] + [ovl]) if world > 1 else ovl
+    p = eng.shard_piles(rs_all.lengths, combined, kmax)
+    data, poff = p.piles()
+    kept, koff = p.overlaps()
+    p.close()
+    res = dict(lo=lo, hi=hi, occurrence=occ,
+               pile_data=data[int(poff[lo]):int(poff[hi])].copy(),
+               pile_off=(poff[lo:hi + 1] - poff[lo]).astype(np.uint64),
+               overlaps=kept[int(koff[lo]):int(koff[hi])].copy(),
+               overlap_off=(koff[lo:hi + 1] - koff[lo]).astype(np.uint32),
+               stats=dict(minimizers_sent=int(val.shape[0] - cnt[g]), matches_sent=int(grp.shape[0] - (m_cuts[g + 1] - m_cuts[g])),
+                          overlaps_sent=int(ovl.shape[0] and np.sum(rhs_owner != g)), map_overlaps=int(ovl.shape[0]),
+                          bytes_sent=comm.bytes_sent))
+    return res

@@ -1,0 +1,93 @@
+"""Sharded single-genome FindOverlapsAndCreatePiles (raven_amd/sharded.py over the rvn_shard_* stages) against
+the single-GPU pass: every rank's slice of pile coverage and truncated overlap lists must be BIT-IDENTICAL.
+Virtual ranks = threads with one engine each on the one GPU of the test box; plus a real two-process run over
+torch.distributed (gloo) sharing that GPU — on a multi-GPU node the same code runs one rank per GPU over RCCL."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from raven_amd import hip, sharded, synth
+from tests import sharded_util
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _single(rs, **kw):
+    eng = hip.Engine(15, 5)
+    p = eng.find_overlaps_and_create_piles(eng.upload(rs), **kw)
+    data, poff = p.piles()
+    kept, koff = p.overlaps()
+    occ = eng.occurrence
+    p.close()
+    return data, poff, kept, koff, occ
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 4])
+@pytest.mark.parametrize("use_minhash", [False, True])
+def test_sharded_pass_is_bit_identical(world, use_minhash):
+    g = synth.make_genome(300_000, seed=61)
+    rs, _ = synth.make_reads(g, 20, 6000, seed=62)
+    data, poff, kept, koff, occ = _single(rs, use_minhash=use_minhash)
+    assert kept.shape[0] > 5000
+
+    def rank_fn(r, comm):
+        return sharded.find_overlaps_and_create_piles_sharded(hip.Engine(15, 5), rs, comm, use_minhash=use_minhash)
+
+    res = sharded_util.run_ranks(world, rank_fn)
+    assert [x["lo"] for x in res] + [res[-1]["hi"]] == sharded.partition_reads(rs.lengths, world).tolist()
+    for x in res:
+        assert x["occurrence"] == occ
+        sharded_util.check_against_single(x, data, poff, kept, koff)
+    if world > 1:
+        assert sum(x["stats"]["matches_sent"] for x in res) > 0 and sum(x["stats"]["overlaps_sent"] for x in res) > 0
+
+
+def test_sharded_pass_repeats_and_small_kmax():
+    """Repeats exercise the global Filter cutoff (hash classes see different key-count distributions)."""
+    rng = np.random.default_rng(5)
+    g = synth.make_genome(200_000, seed=71)
+    rep = g[1000:6000].copy()
+    for at in rng.integers(10_000, 190_000, size=12):
+        g[at:at + 5000] = rep
+    rs, _ = synth.make_reads(g, 15, 5000, seed=72)
+    data, poff, kept, koff, occ = _single(rs, freq=0.01, kmax=4)
+    res = sharded_util.run_ranks(3, lambda r, comm: sharded.find_overlaps_and_create_piles_sharded(
+        hip.Engine(15, 5), rs, comm, freq=0.01, kmax=4))
+    assert occ < 0xFFFFFFFF
+    for x in res:
+        assert x["occurrence"] == occ
+        sharded_util.check_against_single(x, data, poff, kept, koff)
+
+
+WORKER = r"""
+import numpy as np, torch.distributed as dist
+from raven_amd import hip, sharded, synth
+from tests import sharded_util
+dist.init_process_group("gloo")
+g = synth.make_genome(250_000, seed=81)
+rs, _ = synth.make_reads(g, 20, 6000, seed=82)
+eng = hip.Engine(15, 5, device=0)   # both ranks share the one GPU of the test box
+res = sharded.find_overlaps_and_create_piles_sharded(eng, rs, sharded.Comm(dist))
+ref = hip.Engine(15, 5, device=0)
+p = ref.find_overlaps_and_create_piles(ref.upload(rs))
+data, poff = p.piles(); kept, koff = p.overlaps()
+sharded_util.check_against_single(res, data, poff, kept, koff)
+assert res["occurrence"] == ref.occurrence and res["stats"]["bytes_sent"] > 0
+dist.barrier(); dist.destroy_process_group()
+print("OK", res["lo"], res["hi"], res["overlaps"].shape[0])
+"""
+
+
+def test_sharded_pass_two_processes_over_torch_distributed(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29544", str(script)], capture_output=True,
+                       text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert r.stdout.count("OK ") == 2

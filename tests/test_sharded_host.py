@@ -1,0 +1,107 @@
+"""Host logic of the sharded pass (raven_amd/sharded.py): partitioning, regrouping, the global Filter cutoff, and
+the communicator over gloo with world_size 2 (CPU)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+from raven_amd import sharded
+from tests import sharded_util
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_partition_is_contiguous_and_balanced():
+    rng = np.random.default_rng(0)
+    lengths = rng.integers(1000, 60000, size=997).astype(np.uint32)
+    for world in (1, 2, 3, 8):
+        b = sharded.partition_reads(lengths, world)
+        assert b[0] == 0 and b[-1] == lengths.shape[0] and np.all(np.diff(b) >= 0) and b.shape[0] == world + 1
+        per = [int(lengths[b[i]:b[i + 1]].sum()) for i in range(world)]
+        assert max(per) - min(per) <= 2 * int(lengths.max())
+    assert sharded.partition_reads(np.zeros(0, np.uint32), 4).tolist() == [0, 0, 0, 0, 0]
+
+
+def test_slice_reads_keeps_global_ids_and_bases():
+    from raven_amd import synth
+    g = synth.make_genome(30_000, seed=1)
+    rs, _ = synth.make_reads(g, 5, 2000, seed=2)
+    s = sharded.slice_reads(rs, 10, 25)
+    assert s.ids.tolist() == list(range(10, 25)) and s.n == 15
+    for i in range(15):
+        assert s.inflate(i) == rs.inflate(10 + i)
+
+
+def test_hash_owner_is_deterministic_and_spreads_small_values():
+    v = np.arange(100_000, dtype=np.uint64)  # window minima are small values: must still spread
+    for world in (2, 3, 8):
+        o = sharded.hash_owner(v, world)
+        assert np.array_equal(o, sharded.hash_owner(v.copy(), world)) and o.min() == 0 and o.max() == world - 1
+        cnt = np.bincount(o, minlength=world)
+        assert cnt.max() < 1.1 * cnt.mean()
+    assert np.all(sharded.hash_owner(v, 1) == 0)
+
+
+def test_regroup_by_read_merges_sources_per_read():
+    rng = np.random.default_rng(3)
+    n, srcs = 50, 3
+    counts = [rng.integers(0, 5, size=n) for _ in range(srcs)]
+    datas = []
+    for s in range(srcs):
+        read_of = np.repeat(np.arange(n), counts[s])
+        a = (read_of * 1000 + s).astype(np.uint64)
+        datas.append((a, a + np.uint64(7)))
+    seg, (x, y) = sharded.regroup_by_read(counts, datas)
+    assert int(seg[-1]) == sum(int(c.sum()) for c in counts) and np.array_equal(y, x + np.uint64(7))
+    for i in range(n):
+        got = x[int(seg[i]):int(seg[i + 1])]
+        assert np.all(got // 1000 == i)
+        assert sorted((got % 1000).tolist()) == sorted(sum(([s] * int(counts[s][i]) for s in range(srcs)), []))
+
+
+def test_global_occurrence_equals_single_quantile():
+    rng = np.random.default_rng(4)
+    counts = np.concatenate([rng.geometric(0.3, size=20_000), rng.integers(100, 200_000, size=30)]).astype(np.uint32)
+    for freq in (0.0, 0.001, 0.01, 0.5, 1.0):
+        want = 0xFFFFFFFF if freq == 0 else int(np.sort(counts)[min(int((1 - freq) * counts.shape[0]), counts.shape[0] - 1)]) + 1
+        for world in (1, 2, 3):
+            perm = rng.permutation(counts.shape[0])
+            parts = np.array_split(counts[perm], world)
+            got = sharded_util.run_ranks(world, lambda r, comm: sharded.global_occurrence(parts[r], freq, comm))
+            assert got == [want] * world, (freq, world, got, want)
+
+
+WORKER = r"""
+import numpy as np, torch.distributed as dist
+from raven_amd import sharded
+dist.init_process_group("gloo")
+c = sharded.Comm(dist)
+r, w = c.rank, c.world
+dt = np.dtype([("a", "<u4"), ("b", "<u4"), ("c", "<u8")])
+parts = []
+for h in range(w):
+    p = np.zeros(3 + r + 2 * h, dtype=dt)
+    p["a"], p["b"], p["c"] = r, h, np.arange(p.shape[0]) + 2 ** 40
+    parts.append(p)
+got = c.all_to_all_v(parts)
+for s in range(w):
+    assert got[s].shape[0] == 3 + s + 2 * r and np.all(got[s]["a"] == s) and np.all(got[s]["b"] == r)
+    assert np.array_equal(got[s]["c"], np.arange(got[s].shape[0]) + 2 ** 40)
+assert c.all_reduce_sum(np.arange(5) * (r + 1)).tolist() == (np.arange(5) * sum(range(1, w + 1))).tolist()
+assert c.all_gather_v(np.arange(r + 1)).tolist() == sum((list(range(s + 1)) for s in range(w)), [])
+assert c.bytes_sent > 0
+dist.destroy_process_group()
+print("OK", r)
+"""
+
+
+def test_comm_over_gloo_world2(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29533", str(script)], capture_output=True,
+                       text=True, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "OK 0" in r.stdout and "OK 1" in r.stdout
