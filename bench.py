@@ -86,6 +86,43 @@ def cpu_baseline(args, cores):
     return {"value": rs.total_bases / tc / 1e9, "unit": "Gbase/s", "cores": cores, "kind": "port", "sample": sample}
 
 
+def bench_sharded(args, rank, world, local_rank, dist, barrier):
+    """Strong-scaling leg: every rank generates the SAME genome/reads, owns a slice of the piles, and the pass runs
+    through raven_amd/sharded.py (all-to-all over RCCL).  Exchanged buffers cross host memory this round."""
+    from raven_amd import sharded
+    genome_seed, reads_seed = rdist.shard_seeds(0)
+    genome = synth.make_genome(args.genome, seed=genome_seed)
+    rs, _ = synth.make_reads(genome, args.coverage, args.read_len, seed=reads_seed)
+    eng = hip.Engine(args.k, args.w, device=local_rank)
+    eng.set_timing(False)
+    comm = sharded.Comm(dist, device="cuda" if dist is not None else "cpu")
+    res = None
+    for _ in range(args.warmup):
+        res = sharded.find_overlaps_and_create_piles_sharded(eng, rs, comm, freq=args.freq, kmax=args.kmax)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = sharded.find_overlaps_and_create_piles_sharded(eng, rs, comm, freq=args.freq, kmax=args.kmax)
+    barrier()
+    dt = time.perf_counter() - t0
+    dt, _ = rdist.aggregate(dt, 0.0, dist, device="cuda")
+    if rank == 0:
+        steps = max(args.steps, 1)
+        print(json.dumps({
+            "metric": "read Gbase/s through overlap+polish", "value": round(rs.total_bases * steps / dt / 1e9, 4),
+            "unit": "Gbase/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[1] as ONE genome sharded over the ranks: %.1f Mb, %gx, %d bp "
+                                   "reads, -p 0" % (args.genome / 1e6, args.coverage, args.read_len),
+                       "parallelism": "reads by pile, minimizers by hash class; all-to-all x3 (host-staged)",
+                       "rank0": {k: res[k] for k in ("lo", "hi", "occurrence", "stats")}},
+            "roofline": None, "cpu_baseline": None}), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -102,6 +139,9 @@ def main():
     ap.add_argument("--cpu-single", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--sharded", action="store_true", help="ONE genome sharded across the ranks (SURVEY 8(e): reads by "
+                    "pile, minimizers by hash class, three all-to-all exchanges) instead of one independent shard per "
+                    "GPU; strong scaling, overlap pass only")
     ap.add_argument("--no-polish", action="store_true", help="skip the configs[2] polishing leg (reported beside, "
                     "never part of `value`)")
     ap.add_argument("--polish-rounds", type=int, default=2)
@@ -126,6 +166,9 @@ def main():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
+
+    if args.sharded:
+        return bench_sharded(args, rank, world, local_rank, dist, barrier)
 
     # ---- synthetic shard of this rank (seeded; rank-dependent so shards are independent) ----
     t0 = time.time()
