@@ -64,6 +64,31 @@ struct DevBuf {
   }
 };
 
+// Growable pinned host buffer (device -> host read-backs of bulk results at PCIe speed, no page-fault zeroing).
+struct PinBuf {
+  void* ptr = nullptr;
+  size_t cap = 0;
+  PinBuf() = default;
+  PinBuf(const PinBuf&) = delete;
+  PinBuf& operator=(const PinBuf&) = delete;
+  ~PinBuf() {
+    if (ptr) (void)hipHostFree(ptr);
+  }
+  template <typename T>
+  T* get(size_t count) {
+    const size_t bytes = count * sizeof(T);
+    if (bytes > cap) {
+      if (ptr) RVN_HIP(hipHostFree(ptr));
+      ptr = nullptr;
+      cap = 0;
+      const size_t want = bytes + bytes / 8 + 4096;
+      RVN_HIP(hipHostMalloc(&ptr, want, hipHostMallocDefault));
+      cap = want;
+    }
+    return reinterpret_cast<T*>(ptr);
+  }
+};
+
 // ---- per-kernel-site timing (HIP events on the engine stream, no host sync while recording) ----
 enum KernelSite {
   kKSketchCount, kKSketchWrite, kKMinhashSelect, kKCompactSketch, kKScan, kKRsBits, kKRsUpsweep, kKRsDownsweep,

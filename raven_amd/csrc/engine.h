@@ -123,6 +123,7 @@ struct Engine {
   bool timing = true;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   u64* h_pin = nullptr;  // pinned host scratch for small device->host size read-backs
+  PinBuf pin_big;        // pinned staging for bulk read-backs (polishing: chain anchors)
 };
 
 // Reads one 4- or 8-byte value from the device through pinned memory (stream-ordered, then synchronises).

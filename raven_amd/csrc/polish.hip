@@ -3,17 +3,20 @@
 //   1. index the targets (unitigs), Filter(0.001), Map every read (avoid_equal = avoid_symmetric = false) — the
 //      same device engine as the overlap phase, with the chain ANCHORS of every overlap kept;
 //   2. keep each read's longest overlap, drop it when 1 - min(span)/max(span) > e;
-//   3. cut the read into window layers.  racon takes the breakpoints from an edlib NW path (CIGAR); here they
-//      come from the chain anchors (exact k-mer matches the alignment path passes through): the read position at
-//      a window boundary is exact when the boundary falls inside an anchor's k-mer and interpolated linearly
-//      between the bracketing anchors otherwise, so the layers tile the windows like racon's do.  Layers shorter
-//      than 0.02 w, or (with qualities) below the mean-quality threshold q, are dropped exactly as in racon;
+//   3. cut the read into window layers.  racon takes the breakpoints from an edlib NW path of the whole overlap
+//      (CIGAR); here they come from the chain anchors: a window boundary inside an anchor's k-mer, or inside the
+//      exact-match extension of the two anchors around it, is cut exactly; otherwise a small unit-cost NW of the
+//      unmatched remainder of that one anchor gap (a few bases to a few hundred) decides, and pieces begin / end on
+//      aligned pairs exactly as racon's find_breaking_points does.  No base-level alignment of whole reads is
+//      needed.  Layers shorter than 0.02 w, or (with qualities) below the mean-quality threshold q, are dropped
+//      exactly as in racon;
 //   4. window consensus = the POA kernel (poa.hip); 5. stitch the windows, polished ratio per target.
-// Step 3 is a deliberate, documented deviation from racon (no per-base path alignment on the device yet); the
-// consensus is compared with the CPU restatement of racon's own pipeline within tolerance.
+// Step 3 differs from racon only in which optimal alignment decides a cut when several exist; the consensus is
+// compared with the CPU restatement of racon's own pipeline (identical or within a few edits).
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <thread>
 #include <vector>
 
 #include "poa.h"
@@ -21,6 +24,12 @@
 namespace rvn {
 
 namespace {
+
+constexpr u32 kCutMax = 4096;  // longest unmatched remainder of an anchor gap aligned on the host for a window cut
+
+inline u32 code_at(const std::vector<u64>& packed, u64 word_off, u32 i) {
+  return static_cast<u32>(packed[word_off + (i >> 5)] >> ((i << 1) & 63)) & 3u;
+}
 
 // racon: a layer is used only if the mean Phred of its bases reaches q.  One wave per layer.
 __global__ __launch_bounds__(256) void layer_quality_kernel(const PoaLayer* __restrict__ layers, u32 n_layers,
@@ -60,6 +69,8 @@ void polish_round(Engine& e, ReadsDev& T, ReadsDev& R, const u8* h_quals, const 
   ratio.assign(T.n, 0.0);
   stats = PolishStats();
   if (T.n == 0) return;
+  if (T.h_packed.empty() || (R.n && R.h_packed.empty()))
+    throw std::invalid_argument("[raven_hip] polish needs read sets uploaded with host copies (rvn_reads_upload)");
 
   // ---- 1. map reads to targets --------------------------------------------------------------------
   {
@@ -88,12 +99,13 @@ void polish_round(Engine& e, ReadsDev& T, ReadsDev& R, const u8* h_quals, const 
   std::vector<u32> roff(static_cast<size_t>(R.n) + 1, 0);
   std::vector<u64> aoff(O);
   std::vector<u32> acnt(O);
-  std::vector<u64> anchors(mo.n_matches);
+  const u64* anchors = e.pin_big.get<u64>(mo.n_matches + 1);  // pinned: the anchors are the bulk of the read-back
   if (O) {
+    RVN_HIP(hipMemcpyAsync(e.pin_big.ptr, mo.anchors.ptr, mo.n_matches * 8, hipMemcpyDeviceToHost, s));
     RVN_HIP(hipMemcpy(ovl.data(), mo.ovl.ptr, O * sizeof(Overlap), hipMemcpyDeviceToHost));
     RVN_HIP(hipMemcpy(aoff.data(), mo.anchor_off.ptr, O * 8, hipMemcpyDeviceToHost));
     RVN_HIP(hipMemcpy(acnt.data(), mo.anchor_cnt.ptr, O * 4, hipMemcpyDeviceToHost));
-    RVN_HIP(hipMemcpy(anchors.data(), mo.anchors.ptr, mo.n_matches * 8, hipMemcpyDeviceToHost));
+    RVN_HIP(hipStreamSynchronize(s));
   }
   RVN_HIP(hipMemcpy(roff.data(), mo.ovl_read_off.ptr, roff.size() * 4, hipMemcpyDeviceToHost));
   stats.n_overlaps = O;
@@ -140,62 +152,216 @@ void polish_round(Engine& e, ReadsDev& T, ReadsDev& R, const u8* h_quals, const 
   std::vector<std::vector<LayerRef>> win_layers(n_windows);
   const u32 k = e.k;
   e.polish_target_reads.assign(T.n, 0);
-  for (u32 r = 0; r < R.n; ++r) {
-    if (!best[r].valid) continue;
-    const Overlap& o = best[r].o;
-    if (o.rhs_id >= id_to_t.size() || id_to_t[o.rhs_id] == 0xFFFFFFFFu) continue;
-    const u32 t = id_to_t[o.rhs_id];
-    const u32 qlen = R.h_len[r];
-    const bool rc = o.strand == 0;
-    ++stats.n_reads_used;
-    ++e.polish_target_reads[t];
-    // anchors as (t, q') increasing in both; q' in the orientation that matches the target
-    std::vector<std::pair<u32, u32>> an(best[r].acnt);
-    for (u32 i = 0; i < best[r].acnt; ++i) {
-      const u64 a = anchors[best[r].aoff + i];
-      const u32 qp = static_cast<u32>(a >> 32), tp = static_cast<u32>(a);
-      an[i] = rc ? std::make_pair(tp, qlen - qp - k) : std::make_pair(tp, qp);
-    }
-    if (rc) std::reverse(an.begin(), an.end());
-    if (an.size() < 2) continue;
-    // read position at target coordinate B (a window boundary inside the chain): exact inside an anchor's k-mer,
-    // linear between the end of the anchor before and the start of the anchor after otherwise
-    auto q_at = [&](u32 B) -> u32 {
-      size_t lo = 0, hi = an.size();  // last anchor with t <= B
-      while (hi - lo > 1) {
-        const size_t mid = (lo + hi) / 2;
-        if (an[mid].first <= B) lo = mid;
-        else hi = mid;
+  // reads are independent: host threads each take a contiguous range of reads and emit (window, layer) pairs;
+  // the ranges are appended in read order, so a window's layers keep racon's order (overlap order, then the stable
+  // sort by begin position in step 4)
+  struct Emit {
+    u64 window;
+    LayerRef layer;
+  };
+  struct Part {
+    std::vector<Emit> emits;
+    std::vector<u32> target_reads;
+    u64 used = 0, dropped = 0;
+  };
+  const u32 n_thr = std::max(1u, std::min<u32>(64u, std::min<u32>(std::thread::hardware_concurrency(), R.n / 128 + 1)));
+  std::vector<Part> parts(n_thr);
+  auto work = [&](u32 ti) {
+    Part& P = parts[ti];
+    P.target_reads.assign(T.n, 0);
+    const u32 r_lo = static_cast<u32>(static_cast<u64>(R.n) * ti / n_thr);
+    const u32 r_hi = static_cast<u32>(static_cast<u64>(R.n) * (ti + 1) / n_thr);
+    std::vector<std::pair<u32, u32>> an;
+    std::vector<u16> dpbuf;  // NW of an unmatched remainder (cut())
+    std::vector<i32> cen;
+    std::vector<u8> qrem;
+    for (u32 r = r_lo; r < r_hi; ++r) {
+      if (!best[r].valid) continue;
+      const Overlap& o = best[r].o;
+      if (o.rhs_id >= id_to_t.size() || id_to_t[o.rhs_id] == 0xFFFFFFFFu) continue;
+      const u32 t = id_to_t[o.rhs_id];
+      const u32 qlen = R.h_len[r];
+      const bool rc = o.strand == 0;
+      ++P.used;
+      ++P.target_reads[t];
+      // anchors as (t, q') increasing in both; q' in the orientation that matches the target
+      an.resize(best[r].acnt);
+      for (u32 i = 0; i < best[r].acnt; ++i) {
+        const u64 a = anchors[best[r].aoff + i];
+        const u32 qp = static_cast<u32>(a >> 32), tp = static_cast<u32>(a);
+        an[i] = rc ? std::make_pair(tp, qlen - qp - k) : std::make_pair(tp, qp);
       }
-      const u32 ta = an[lo].first, qa = an[lo].second;
-      if (B < ta + k || lo + 1 >= an.size()) return qa + (B - ta);
-      const u32 tc = an[lo + 1].first, qc = an[lo + 1].second;
-      if (tc <= ta + k || qc <= qa + k) return qa + k;
-      const double f = static_cast<double>(B - ta - k) / static_cast<double>(tc - ta - k);
-      return qa + k + static_cast<u32>(f * static_cast<double>(qc - qa - k) + 0.5);
-    };
-    const u32 t_first = an.front().first, t_last_end = an.back().first + k;  // chain covers [t_first, t_last_end)
-    const u32 q_first = an.front().second, q_last_end = an.back().second + k;
-    for (u32 wi = t_first / w; static_cast<u64>(wi) * w < t_last_end; ++wi) {
-      const u32 ws = wi * w;
-      const u32 we = std::min<u32>(T.h_len[t], ws + w);  // exclusive
-      const u32 t_b = std::max(ws, t_first), t_e = std::min(we, t_last_end);  // [t_b, t_e)
-      if (t_e <= t_b + 1) continue;
-      const u32 q_b = t_b == t_first ? q_first : q_at(t_b);
-      u32 q_e = t_e == t_last_end ? q_last_end : q_at(t_e);
-      if (q_e > qlen) q_e = qlen;
-      if (q_e <= q_b || (q_e - q_b) < 0.02 * w) continue;
-      {  // interpolated breakpoints can be off where the chain has a long anchor-free stretch across a window
-         // boundary; a piece whose length disagrees with its target span by more than any plausible indel
-         // imbalance is misplaced, and racon's exact breakpoints would never have produced it: drop it
-        const double span = t_e - t_b, ql = q_e - q_b;
-        if (std::abs(ql - span) > std::max(16.0, 0.08 * span)) {
-          ++stats.n_dropped_layers;
-          continue;
+      if (rc) std::reverse(an.begin(), an.end());
+      if (an.size() < 2) continue;
+      // read position at target coordinate B (a window boundary inside the chain): exact inside an anchor's
+      // k-mer or inside the exact-match extension of the bracketing anchors (the bases are compared on the host
+      // copies of the packed sets); only the unmatched remainder of the gap — a handful of bases around the
+      // error that ended the matches — is split proportionally
+      const u64 t_wo = T.h_word_off[t], r_wo = R.h_word_off[r];
+      auto tbase = [&](u32 x) -> u32 { return code_at(T.h_packed, t_wo, x); };
+      auto qbase = [&](u32 x) -> u32 {  // read in the orientation of the target
+        return rc ? 3u - code_at(R.h_packed, r_wo, qlen - 1 - x) : code_at(R.h_packed, r_wo, x);
+      };
+      // cut(B): the (read, target) position pairs at which the piece left of boundary B ends (target <= B) and the
+      // piece right of it begins (target >= B).  Inside an exact-match region both are (q(B), B); when B falls into
+      // the unmatched remainder of an anchor gap — the few bases around the error(s) that ended the exact
+      // extensions — a small unit-cost NW of the two remainders decides, so pieces tile the windows exactly as
+      // racon's CIGAR breakpoints do.  Only a remainder longer than kCutMax is given to neither window (the piece
+      // on the left ends where the exact region before it ends, the one on the right begins where the exact
+      // region after it begins): a guessed cut would append true neighbour bases to a window.
+      struct Cut {
+        u32 ql, tl, qr, tr;  // left piece ends at (ql, tl) exclusive; right piece begins at (qr, tr)
+      };
+      auto cut = [&](u32 B) -> Cut {
+        size_t lo = 0, hi = an.size();  // last anchor with t <= B
+        while (hi - lo > 1) {
+          const size_t mid = (lo + hi) / 2;
+          if (an[mid].first <= B) lo = mid;
+          else hi = mid;
         }
+        const u32 ta = an[lo].first, qa = an[lo].second;
+        if (B < ta + k || lo + 1 >= an.size()) return {qa + (B - ta), B, qa + (B - ta), B};
+        const u32 tc = an[lo + 1].first, qc = an[lo + 1].second;
+        u32 t0 = ta + k, q0 = qa + k;  // gap [t0, tc) <-> [q0, qc)
+        if (tc > t0 && qc > q0) {
+          while (t0 < tc && q0 < qc && t0 <= B && tbase(t0) == qbase(q0)) {
+            ++t0;
+            ++q0;
+          }
+          if (B < t0) return {q0 - (t0 - B), B, q0 - (t0 - B), B};
+          u32 t1 = tc, q1 = qc;
+          while (t1 > t0 && q1 > q0 && t1 > B && tbase(t1 - 1) == qbase(q1 - 1)) {
+            --t1;
+            --q1;
+          }
+          if (B >= t1) return {q1 + (B - t1), B, q1 + (B - t1), B};
+          // B lies in the unmatched remainder [t0, t1) <-> [q0, q1) around the error(s): a unit-cost NW of the two
+          // short segments decides where B maps, as racon's base-level path would
+          const u32 nt = t1 - t0, nq = q1 - q0;
+          if (nt <= kCutMax && nq <= kCutMax) {
+            // dp(i, j): unit-cost NW of target remainder [0, i) vs read remainder [0, j).  Small remainders (the
+            // common case) use a full matrix; long ones a band around the straight line between the exact regions.
+            const bool small = nt <= 48 && nq <= 48;
+            const u32 W = small ? 48 : 24 + (nt > nq ? nt - nq : nq - nt);
+            const u32 bw = small ? nq + 1 : 2 * W + 1;
+            const u32 kInf = 0xFFFFu;
+            dpbuf.assign(static_cast<size_t>(nt + 1) * bw, static_cast<u16>(kInf));
+            cen.resize(nt + 1);
+            for (u32 i = 0; i <= nt; ++i)
+              cen[i] = small ? static_cast<i32>(W) : static_cast<i32>(static_cast<u64>(i) * nq / std::max(nt, 1u));
+            u16* dp = dpbuf.data();
+            auto at = [&](u32 i, i32 j) -> u32 {  // dp value or inf outside the band / matrix
+              if (j < 0 || j > static_cast<i32>(nq)) return kInf;
+              const i32 o = j - cen[i] + static_cast<i32>(W);
+              if (o < 0 || o >= static_cast<i32>(bw)) return kInf;
+              return dp[static_cast<size_t>(i) * bw + o];
+            };
+            qrem.resize(nq);
+            for (u32 j = 0; j < nq; ++j) qrem[j] = static_cast<u8>(qbase(q0 + j));
+            for (u32 i = 0; i <= nt; ++i) {
+              const i32 c = cen[i];
+              const u32 tb_ = i ? tbase(t0 + i - 1) : 0;
+              const i32 jlo = std::max<i32>(0, c - static_cast<i32>(W)), jhi = std::min<i32>(nq, c + static_cast<i32>(W));
+              for (i32 j = jlo; j <= jhi; ++j) {
+                u32 v;
+                if (i == 0) v = static_cast<u32>(j);
+                else if (j == 0) v = i;
+                else {
+                  const u32 d = at(i - 1, j - 1) + (tb_ != qrem[j - 1] ? 1u : 0u);
+                  const u32 u = at(i - 1, j) + 1u, l = at(i, j - 1) + 1u;
+                  v = std::min(d, std::min(u, l));
+                }
+                dp[static_cast<size_t>(i) * bw + (j - c + static_cast<i32>(W))] = static_cast<u16>(std::min(v, kInf));
+              }
+            }
+            // like racon's breakpoints, a piece ends / begins on an aligned pair (CIGAR 'M'): the left piece ends
+            // after the last pair with target < B, the right piece begins at the first pair with target >= B;
+            // unaligned bases in between belong to neither
+            const u32 ib = B - t0;
+            u32 i = nt;
+            i32 j = static_cast<i32>(nq);
+            u32 li = 0, lj = 0;    // end (exclusive) of the last pair left of the cut; (0, 0) = exact region before
+            u32 ri = nt, rj = nq;  // first pair at/after the cut; (nt, nq) = exact region after
+            bool have_left = false;
+            while ((i > 0 || j > 0) && !have_left) {
+              const u32 here = at(i, j);
+              if (i > 0 && j > 0 && here == at(i - 1, j - 1) + (tbase(t0 + i - 1) != qrem[j - 1] ? 1u : 0u)) {
+                --i;
+                --j;  // pair (target t0 + i, read q0 + j)
+                if (i >= ib) {
+                  ri = i;
+                  rj = static_cast<u32>(j);
+                } else {
+                  li = i + 1;
+                  lj = static_cast<u32>(j) + 1;
+                  have_left = true;
+                }
+              } else if (i > 0 && here == at(i - 1, j) + 1u) {
+                --i;
+              } else if (j > 0) {
+                --j;
+              } else {
+                --i;
+              }
+            }
+            return {q0 + lj, t0 + li, q0 + rj, t0 + ri};
+          }
+          return {q0, t0, q1, t1};
+        }
+        // overlapping / out-of-order anchors: cut at the anchor ends
+        return {q0, t0, qc, tc};
+      };
+      const u32 t_first = an.front().first, t_last_end = an.back().first + k;  // chain covers [t_first, t_last_end)
+      const u32 q_first = an.front().second, q_last_end = an.back().second + k;
+      Cut carry{q_first, t_first, q_first, t_first};
+      u32 carry_at = 0xFFFFFFFFu;  // boundary `carry` was computed for
+      for (u32 wi = t_first / w; static_cast<u64>(wi) * w < t_last_end; ++wi) {
+        const u32 ws = wi * w;
+        const u32 we = std::min<u32>(T.h_len[t], ws + w);  // exclusive
+        u32 t_b = std::max(ws, t_first), t_e = std::min(we, t_last_end);  // [t_b, t_e)
+        if (t_e <= t_b + 1) continue;
+        u32 q_b = q_first, q_e = q_last_end;
+        if (t_b != t_first) {  // the cut at this window's start is normally the previous window's end cut
+          if (carry_at != t_b) {
+            carry = cut(t_b);
+            carry_at = t_b;
+          }
+          q_b = carry.qr;
+          t_b = carry.tr;
+        }
+        if (t_e != t_last_end) {
+          carry = cut(t_e);
+          carry_at = t_e;
+          q_e = carry.ql;
+          t_e = carry.tl;
+        }
+        if (t_e <= t_b + 1 || t_e > we) continue;
+        if (q_e > qlen) q_e = qlen;
+        if (q_e <= q_b || (q_e - q_b) < 0.02 * w) continue;
+        {  // interpolated breakpoints can be off where the chain has a long anchor-free stretch across a window
+           // boundary; a piece whose length disagrees with its target span by more than any plausible indel
+           // imbalance is misplaced, and racon's exact breakpoints would never have produced it: drop it
+          const double span = t_e - t_b, ql = q_e - q_b;
+          if (std::abs(ql - span) > std::max(16.0, 0.08 * span)) {
+            ++P.dropped;
+            continue;
+          }
+        }
+        P.emits.push_back(Emit{first_window[t] + wi, LayerRef{r, q_b, q_e - q_b, t_b - ws, t_e - 1 - ws, rc}});
       }
-      win_layers[first_window[t] + wi].push_back(LayerRef{r, q_b, q_e - q_b, t_b - ws, t_e - 1 - ws, rc});
     }
+  };
+  {
+    std::vector<std::thread> pool;
+    for (u32 ti = 1; ti < n_thr; ++ti) pool.emplace_back(work, ti);
+    work(0);
+    for (auto& th : pool) th.join();
+  }
+  for (const Part& P : parts) {  // thread order == read order
+    stats.n_reads_used += P.used;
+    stats.n_dropped_layers += P.dropped;
+    for (u32 t = 0; t < T.n; ++t) e.polish_target_reads[t] += P.target_reads[t];
+    for (const Emit& em : P.emits) win_layers[em.window].push_back(em.layer);
   }
 
   // ---- 4. layer descriptors for the POA batch: bases and qualities stay in HBM (packed read sets) ---------------
@@ -241,8 +407,8 @@ void polish_round(Engine& e, ReadsDev& T, ReadsDev& R, const u8* h_quals, const 
       }
       wins[gw].n_layers = static_cast<u32>(lays.size()) - wins[gw].layer_first;
       wins[gw].out_off = static_cast<u32>(out_off.back());
-      wins[gw].out_cap = 4 * bl + 256;
-      out_off.push_back(out_off.back() + 4ULL * bl + 256);
+      wins[gw].out_cap = 2 * bl + 128;
+      out_off.push_back(out_off.back() + 2ULL * bl + 128);
     }
   }
   max_len = std::max(max_len, max_bb);

@@ -1,7 +1,7 @@
 """GPU polishing round (rvn_polish_round: device mapping + anchors -> windows -> POA kernel -> stitch) against the
-CPU restatement of racon's round (exact NW path breakpoints).  Tolerance parity (north_star: 'polished consensus
-within stated edit-distance tolerance'): ED(gpu, cpu) <= 1 % of the target and ED(gpu, truth) <= 1.25 x
-ED(cpu, truth) + 30."""
+CPU restatement of racon's round (whole-overlap NW path -> CIGAR breakpoints).  Tolerance parity (north_star:
+'polished consensus within stated edit-distance tolerance'): ED(gpu, cpu) <= 0.2 % of the target + 10 and
+ED(gpu, truth) <= 1.1 x ED(cpu, truth) + 10 (measured: 0-1 edits apart with trimming, tools/eval_polish.py)."""
 import numpy as np
 import pytest
 
@@ -30,8 +30,8 @@ def test_polish_round_matches_cpu_within_tolerance(with_qual, n_targets):
         assert ratio[t] > 0.85 and abs(ratio[t] - ref_ratio[t]) < 0.1
         ed_draft, ed_cpu, ed_gpu = _ed(drafts[t], truths[t]), _ed(ref[t], truths[t]), _ed(cons[t], truths[t])
         assert ed_gpu < ed_draft, (ed_draft, ed_gpu)
-        assert ed_gpu <= 1.25 * ed_cpu + 30, (ed_draft, ed_cpu, ed_gpu)
-        assert _ed(cons[t], ref[t]) <= 0.01 * len(ref[t]) + 30, (len(ref[t]), _ed(cons[t], ref[t]))
+        assert ed_gpu <= 1.1 * ed_cpu + 10, (ed_draft, ed_cpu, ed_gpu)
+        assert _ed(cons[t], ref[t]) <= 0.002 * len(ref[t]) + 10, (len(ref[t]), _ed(cons[t], ref[t]))
 
 
 def test_polish_two_rounds_and_low_quality_reads_are_dropped():
