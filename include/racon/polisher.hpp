@@ -46,30 +46,43 @@ class Polisher {
 
   Polisher(const Polisher&) = delete;
   Polisher& operator=(const Polisher&) = delete;
-  ~Polisher() { rvn_engine_destroy(engine_); }
+  ~Polisher() {
+    rvn_reads_destroy(reads_.h);  // before the engine it belongs to
+    reads_.h = nullptr;
+    rvn_engine_destroy(engine_);
+  }
 
   // racon: one polishing round of `targets` with `sequences`; targets without a polished window are dropped when
   // drop_unpolished (polish.cc:51 passes false)
   Sequences Polish(const Sequences& targets, const Sequences& sequences, bool drop_unpolished) {
     Sequences dst;
     if (targets.empty()) return dst;
-    ram::detail::ReadsHandle t, r;
+    ram::detail::ReadsHandle t;
     t.Upload(engine_, targets.begin(), targets.end());
-    r.Upload(engine_, sequences.begin(), sequences.end());
-
-    // per-base Phred+33 from biosoup's block qualities, only if every read has them
-    bool has_q = !sequences.empty();
-    for (const auto& s : sequences) has_q = has_q && !s->block_quality.empty();
-    std::vector<std::uint8_t> quals;
-    std::vector<std::uint64_t> qoff;
-    if (has_q) {
-      qoff.push_back(0);
-      for (const auto& s : sequences) {
-        for (std::uint32_t i = 0; i < s->inflated_len; ++i)
-          quals.push_back(static_cast<std::uint8_t>(s->block_quality[i >> 6] + 33));
-        qoff.push_back(quals.size());
+    // raven::Polish calls Polish() once per round with the SAME read set (polish.cc:50-51): upload it (and expand
+    // its qualities) only when the container changes
+    if (reads_.h == nullptr || reads_key_ != sequences.data() || reads_n_ != sequences.size()) {
+      reads_.Upload(engine_, sequences.begin(), sequences.end());
+      reads_key_ = sequences.data();
+      reads_n_ = sequences.size();
+      // per-base Phred+33 from biosoup's block qualities, only if every read has them
+      has_q_ = !sequences.empty();
+      for (const auto& s : sequences) has_q_ = has_q_ && !s->block_quality.empty();
+      quals_.clear();
+      qoff_.clear();
+      if (has_q_) {
+        qoff_.push_back(0);
+        for (const auto& s : sequences) {
+          for (std::uint32_t i = 0; i < s->inflated_len; ++i)
+            quals_.push_back(static_cast<std::uint8_t>(s->block_quality[i >> 6] + 33));
+          qoff_.push_back(quals_.size());
+        }
       }
     }
+    const bool has_q = has_q_;
+    const std::vector<std::uint8_t>& quals = quals_;
+    const std::vector<std::uint64_t>& qoff = qoff_;
+    ram::detail::ReadsHandle& r = reads_;
 
     const std::size_t n = targets.size();
     std::vector<std::uint64_t> ooff(n + 1, 0);
@@ -108,6 +121,13 @@ class Polisher {
   bool trim_;
   int m_, n_, g_;
   rvn_engine* engine_ = nullptr;
+  // read set of the previous Polish() call, kept on the device
+  ram::detail::ReadsHandle reads_;
+  const void* reads_key_ = nullptr;
+  std::size_t reads_n_ = 0;
+  bool has_q_ = false;
+  std::vector<std::uint8_t> quals_;
+  std::vector<std::uint64_t> qoff_;
 };
 
 }  // namespace racon

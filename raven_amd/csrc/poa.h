@@ -33,7 +33,26 @@ struct PoaLayer {
   u64 qual_off;  // offset of the layer (bytes) / of the read (packed) in the quality array
   u32 len, begin, end, flags;
   u32 q_begin, q_len;  // packed: first base of the layer in the (oriented) read, length of the read
+  // Band guide of the banded kernel: layer offsets that backbone positions begin + i * span / 8 (i = 1..7,
+  // span = end - begin + 1) map to.  A straight line (i * len / 8) when nothing better is known; the polishing front
+  // end fills it from the chain anchors, so the band follows the read through local indel bursts.
+  u16 way[7];
+  u16 pad_;
 };
+inline void poa_layer_linear_way(PoaLayer& L) {
+  for (u32 i = 1; i < 8; ++i) L.way[i - 1] = static_cast<u16>(static_cast<u64>(L.len) * i / 8);
+  L.pad_ = 0;
+}
+// expected layer offset of backbone position begin + x (x clamped to [0, span]), piecewise linear through `way`
+__device__ __forceinline__ i32 poa_layer_center(const PoaLayer& L, i32 x, i32 span) {
+  x = x < 0 ? 0 : (x > span ? span : x);
+  const i32 seg = (x * 8) / (span > 0 ? span : 1);      // 0..8
+  const i32 s = seg > 7 ? 7 : seg;
+  const i32 x0 = (s * span) / 8, x1 = ((s + 1) * span) / 8;
+  const i32 w0 = s == 0 ? 0 : static_cast<i32>(L.way[s - 1]);
+  const i32 w1 = s == 7 ? static_cast<i32>(L.len) : static_cast<i32>(L.way[s]);
+  return w0 + (x - x0) * (w1 - w0) / (x1 > x0 ? x1 - x0 : 1);
+}
 struct PoaSrc {
   const u8* codes;
   const u8* quals;

@@ -759,6 +759,7 @@ void poa_consensus_batch(Engine& e, const u8* h_codes, const u8* h_quals, const 
       L.begin = h_begins[src];
       L.end = h_ends[src];
       L.flags = (h_quals && h_has_qual && h_has_qual[src]) ? kLayerQual : 0u;
+      poa_layer_linear_way(L);
       if (i == 0) max_bb = std::max(max_bb, L.len);
       max_len = std::max(max_len, L.len);
     }

@@ -263,8 +263,8 @@ __device__ __forceinline__ u32 poa2_window(const PoaWindow& win, const PoaLayer*
     tick();
     // ---- 2. banded NW ----
     const u32 w = len + 1;
-    const i32 lb = full ? 0 : static_cast<i32>(L.begin);
-    const i32 span = full ? static_cast<i32>(blen) : static_cast<i32>(L.end - L.begin + 1);
+    const i32 lb = static_cast<i32>(L.begin);
+    const i32 span = static_cast<i32>(L.end) - static_cast<i32>(L.begin) + 1;
     i32 best_score = -0x7FFFFFFF;
     u32 best_row = 0;
     int ring_tag = 0, ring_b = 0;  // lane s describes ring slot s: row stored there (0 = none), its band start
@@ -293,7 +293,7 @@ __device__ __forceinline__ u32 poa2_window(const PoaWindow& win, const PoaLayer*
               ++m_np;
             }
           }
-          i32 b = (static_cast<i32>(g.bpos[m_v]) - lb) * static_cast<i32>(len) / span - kBand / 2;
+          i32 b = poa_layer_center(L, static_cast<i32>(g.bpos[m_v]) - lb, span) - kBand / 2;
           const i32 bmax = static_cast<i32>(w) - kBand;
           b = b > bmax ? bmax : b;
           b = b < 0 ? 0 : b;
@@ -496,8 +496,8 @@ __device__ __forceinline__ u32 poa2_window(const PoaWindow& win, const PoaLayer*
           continue;
         }
         // generic step for cell (i, j) = lane 0's cell
-        if (!rfl(inband ? 1 : 0)) {
-          bad = 6;
+        if (!rfl(inband ? 1 : 0)) {  // the path left the stored band: the alignment does not fit this band width
+          band_hit = 1;
           break;
         }
         if (rfl(edge ? 1 : 0)) band_hit = 1;

@@ -148,6 +148,7 @@ void polish_round(Engine& e, ReadsDev& T, ReadsDev& R, const u8* h_quals, const 
   const u64 n_windows = first_window[T.n];
   struct LayerRef {
     u32 read, q_begin, q_len, t_begin, t_end, rc;
+    u16 way[7];  // PoaLayer::way: where the chain says the piece is at 1/8 .. 7/8 of its target span
   };
   std::vector<std::vector<LayerRef>> win_layers(n_windows);
   const u32 k = e.k;
@@ -338,16 +339,39 @@ void polish_round(Engine& e, ReadsDev& T, ReadsDev& R, const u8* h_quals, const 
         if (t_e <= t_b + 1 || t_e > we) continue;
         if (q_e > qlen) q_e = qlen;
         if (q_e <= q_b || (q_e - q_b) < 0.02 * w) continue;
-        {  // interpolated breakpoints can be off where the chain has a long anchor-free stretch across a window
-           // boundary; a piece whose length disagrees with its target span by more than any plausible indel
-           // imbalance is misplaced, and racon's exact breakpoints would never have produced it: drop it
+        {  // cuts are exact, so a piece may legitimately be much shorter or longer than its target span (real
+           // reads lose whole homopolymer runs); only an absurd ratio — a chain that jumped a repeat copy — is dropped
           const double span = t_e - t_b, ql = q_e - q_b;
-          if (std::abs(ql - span) > std::max(16.0, 0.08 * span)) {
+          if (ql > 2.0 * span + 32 || span > 2.0 * ql + 32) {
             ++P.dropped;
             continue;
           }
         }
-        P.emits.push_back(Emit{first_window[t] + wi, LayerRef{r, q_b, q_e - q_b, t_b - ws, t_e - 1 - ws, rc}});
+        LayerRef lr{r, q_b, q_e - q_b, t_b - ws, t_e - 1 - ws, rc, {}};
+        {  // band guide: read offsets at eighths of the target span, linear between the bracketing anchors
+          const u32 span = t_e - t_b;
+          u32 prev = 0;
+          for (u32 i = 1; i < 8; ++i) {
+            const u32 tau = t_b + static_cast<u32>(static_cast<u64>(span) * i / 8);
+            size_t lo = 0, hi = an.size();
+            while (hi - lo > 1) {
+              const size_t mid = (lo + hi) / 2;
+              if (an[mid].first <= tau) lo = mid;
+              else hi = mid;
+            }
+            u32 q = an[lo].second + (tau >= an[lo].first ? std::min(tau - an[lo].first, k) : 0u);
+            if (tau > an[lo].first + k && lo + 1 < an.size() && an[lo + 1].first > an[lo].first + k &&
+                an[lo + 1].second > an[lo].second + k) {
+              const double f = static_cast<double>(tau - an[lo].first - k) / (an[lo + 1].first - an[lo].first - k);
+              q = an[lo].second + k + static_cast<u32>(f * (an[lo + 1].second - an[lo].second - k));
+            }
+            u32 off = q > q_b ? q - q_b : 0;
+            off = std::min(std::max(off, prev), q_e - q_b);
+            lr.way[i - 1] = static_cast<u16>(std::min<u32>(off, 0xFFFFu));
+            prev = off;
+          }
+        }
+        P.emits.push_back(Emit{first_window[t] + wi, lr});
       }
     }
   };
@@ -386,6 +410,7 @@ void polish_round(Engine& e, ReadsDev& T, ReadsDev& R, const u8* h_quals, const 
       B.flags = kLayerPacked | kLayerTarget | kLayerZeroW;  // weight 0 = racon's dummy '!' backbone quality
       B.q_begin = ws;
       B.q_len = tlen;
+      poa_layer_linear_way(B);
       lays.push_back(B);
       max_bb = std::max(max_bb, bl);
       auto& wl = win_layers[gw];
@@ -401,6 +426,7 @@ void polish_round(Engine& e, ReadsDev& T, ReadsDev& R, const u8* h_quals, const 
         P.flags = kLayerPacked | (L.rc ? kLayerRc : 0u) | (any_q ? kLayerQual : 0u);
         P.q_begin = L.q_begin;
         P.q_len = R.h_len[L.read];
+        for (int i = 0; i < 7; ++i) P.way[i] = L.way[i];
         lays.push_back(P);
         max_len = std::max(max_len, L.q_len);
         ++stats.n_layers;

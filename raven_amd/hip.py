@@ -175,7 +175,10 @@ class Reads:
             self._h = None
 
     def __del__(self):
-        self.close()
+        try:
+            self.close()
+        except Exception:  # interpreter shutdown: module globals may already be gone
+            pass
 
 
 class Pass1:
@@ -205,7 +208,10 @@ class Pass1:
             self._h = None
 
     def __del__(self):
-        self.close()
+        try:
+            self.close()
+        except Exception:  # interpreter shutdown: module globals may already be gone
+            pass
 
 
 class Engine:
@@ -223,7 +229,10 @@ class Engine:
             self._h = None
 
     def __del__(self):
-        self.close()
+        try:
+            self.close()
+        except Exception:  # interpreter shutdown: module globals may already be gone
+            pass
 
     def upload(self, rs) -> Reads:
         return Reads(self, rs)

@@ -8,7 +8,8 @@ import pytest
 
 from oracle import oracle
 
-GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lambda_pass1.npz")
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+GOLD = os.path.join(GOLDEN, "lambda_pass1.npz")
 
 
 @pytest.fixture(scope="module")
@@ -59,3 +60,20 @@ def test_hip_matches_golden(lambda_reads, gold):
         assert np.array_equal(data, gold["pass1_%d_pile_data" % mh])
         assert np.array_equal(poff, gold["pass1_%d_pile_offsets" % mh])
         p.close()
+
+
+def test_lambda_polish_fixture_is_reproducible_and_improves_the_draft():
+    """tests/golden/lambda_polish.npz (oracle polishing round on the reference's own lambda data): inputs rebuild
+    byte-identically from the committed generator, and the stored distances are what the consensus really has."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden_polish", os.path.join(GOLDEN, "make_golden_polish.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    rs, truth, draft, quals, avg_q = mg.inputs()
+    fx = np.load(os.path.join(GOLDEN, "lambda_polish.npz"))
+    assert np.array_equal(draft, fx["draft"]) and abs(avg_q - float(fx["avg_q"][0])) < 1e-9
+    assert 9.0 < avg_q < 12.0 and all(len(q) == int(n) for q, n in zip(quals, rs.lengths))
+    t = bytes(truth + 65)
+    assert oracle.edit_distance(bytes(fx["consensus"] + 65), t) == int(fx["ed_consensus"][0])
+    assert int(fx["ed_consensus"][0]) < int(fx["ed_consensus_noqual"][0]) < int(fx["ed_draft"][0])
+    assert float(fx["ratio"][0]) == 1.0

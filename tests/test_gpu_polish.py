@@ -49,3 +49,27 @@ def test_polish_two_rounds_and_low_quality_reads_are_dropped():
     # quality threshold above every read's mean quality (12): no layer survives -> nothing is polished (racon)
     cons, ratio, st = eng.polish_round(eng.upload(targets), rd, quals=quals, q=20.0)
     assert st["n_layers"] == 0 and ratio[0] == 0.0 and np.array_equal(cons[0], drafts[0])
+
+
+@pytest.mark.parametrize("with_qual", [True, False])
+def test_lambda_polish_matches_golden_fixture(with_qual):
+    """The reference's own test data (RavenTest/data: ERA476754 reads, NC_001416): one polishing round of a seeded
+    draft of lambda on the device vs the committed oracle result (tests/golden/lambda_polish.npz), with Raven's
+    block-mean qualities and its avg_q threshold (polish.cc:25-47) and without qualities."""
+    import importlib.util
+    import os
+    golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    spec = importlib.util.spec_from_file_location("make_golden_polish", os.path.join(golden, "make_golden_polish.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    rs, truth, draft, quals, avg_q = mg.inputs()
+    fx = np.load(os.path.join(golden, "lambda_polish.npz"))
+    eng = hip.Engine(15, 5)
+    cons, ratio, st = eng.polish_round(eng.upload(seqio.pack_reads([draft])), eng.upload(rs),
+                                       quals=quals if with_qual else None, q=avg_q if with_qual else 0.0)
+    ref = fx["consensus" if with_qual else "consensus_noqual"]
+    ed_ref = int(fx["ed_consensus" if with_qual else "ed_consensus_noqual"][0])
+    assert st["n_failed_windows"] == 0 and ratio[0] == 1.0
+    d = _ed(cons[0], ref)
+    assert d <= 0.002 * len(ref) + 10, (d, len(ref), len(cons[0]))
+    assert _ed(cons[0], truth) <= 1.1 * ed_ref + 10

@@ -77,8 +77,11 @@ p = ref.find_overlaps_and_create_piles(ref.upload(rs))
 data, poff = p.piles(); kept, koff = p.overlaps()
 sharded_util.check_against_single(res, data, poff, kept, koff)
 assert res["occurrence"] == ref.occurrence and res["stats"]["bytes_sent"] > 0
+rank = dist.get_rank()
 dist.barrier(); dist.destroy_process_group()
-print("OK", res["lo"], res["hi"], res["overlaps"].shape[0])
+import sys
+sys.stdout.write("SHARD_OK_%d lo=%d hi=%d kept=%d\n" % (rank, res["lo"], res["hi"], res["overlaps"].shape[0]))
+sys.stdout.flush()
 """
 
 
@@ -90,4 +93,4 @@ def test_sharded_pass_two_processes_over_torch_distributed(tmp_path):
                         "--master-addr", "127.0.0.1", "--master-port", "29544", str(script)], capture_output=True,
                        text=True, timeout=600, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
-    assert r.stdout.count("OK ") == 2
+    assert "SHARD_OK_0" in r.stdout and "SHARD_OK_1" in r.stdout, r.stdout[-2000:]

@@ -92,7 +92,9 @@ assert c.all_reduce_sum(np.arange(5) * (r + 1)).tolist() == (np.arange(5) * sum(
 assert c.all_gather_v(np.arange(r + 1)).tolist() == sum((list(range(s + 1)) for s in range(w)), [])
 assert c.bytes_sent > 0
 dist.destroy_process_group()
-print("OK", r)
+import sys
+sys.stdout.write("COMM_OK_%d\n" % r)
+sys.stdout.flush()
 """
 
 
@@ -104,4 +106,4 @@ def test_comm_over_gloo_world2(tmp_path):
                         "--master-addr", "127.0.0.1", "--master-port", "29533", str(script)], capture_output=True,
                        text=True, timeout=300, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert "OK 0" in r.stdout and "OK 1" in r.stdout
+    assert "COMM_OK_0" in r.stdout and "COMM_OK_1" in r.stdout, r.stdout[-2000:]
