@@ -88,21 +88,23 @@ def cpu_baseline(args, cores):
 
 def bench_sharded(args, rank, world, local_rank, dist, barrier):
     """Strong-scaling leg: every rank generates the SAME genome/reads, owns a slice of the piles, and the pass runs
-    through raven_amd/sharded.py (all-to-all over RCCL).  Exchanged buffers cross host memory this round."""
+    through raven_amd/sharded.py (all-to-all over RCCL on torch CUDA tensors; nothing crosses PCIe between stages)."""
     from raven_amd import sharded
     genome_seed, reads_seed = rdist.shard_seeds(0)
     genome = synth.make_genome(args.genome, seed=genome_seed)
     rs, _ = synth.make_reads(genome, args.coverage, args.read_len, seed=reads_seed)
     eng = hip.Engine(args.k, args.w, device=local_rank)
     eng.set_timing(False)
-    comm = sharded.Comm(dist, device="cuda" if dist is not None else "cpu")
+    import torch
+    comm = sharded.DeviceComm(dist, device="cuda")
+    dev = torch.device("cuda", local_rank)
     res = None
     for _ in range(args.warmup):
-        res = sharded.find_overlaps_and_create_piles_sharded(eng, rs, comm, freq=args.freq, kmax=args.kmax)
+        res = sharded.find_overlaps_and_create_piles_sharded_dev(eng, rs, comm, dev, freq=args.freq, kmax=args.kmax)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        res = sharded.find_overlaps_and_create_piles_sharded(eng, rs, comm, freq=args.freq, kmax=args.kmax)
+        res = sharded.find_overlaps_and_create_piles_sharded_dev(eng, rs, comm, dev, freq=args.freq, kmax=args.kmax)
     barrier()
     dt = time.perf_counter() - t0
     dt, _ = rdist.aggregate(dt, 0.0, dist, device="cuda")
@@ -115,7 +117,7 @@ def bench_sharded(args, rank, world, local_rank, dist, barrier):
             "vs_baseline": None, "dtype": "u32", "data": "synthetic",
             "config": {"workload": "BASELINE.json configs[1] as ONE genome sharded over the ranks: %.1f Mb, %gx, %d bp "
                                    "reads, -p 0" % (args.genome / 1e6, args.coverage, args.read_len),
-                       "parallelism": "reads by pile, minimizers by hash class; all-to-all x3 (host-staged)",
+                       "parallelism": "reads by pile, minimizers by hash class; all-to-all x3 on CUDA tensors (RCCL)",
                        "rank0": {k: res[k] for k in ("lo", "hi", "occurrence", "stats")}},
             "roofline": None, "cpu_baseline": None}), flush=True)
     if dist is not None:

@@ -181,6 +181,23 @@ int rvn_shard_chain(rvn_engine* e, const rvn_reads* own_reads, const uint64_t* g
 int rvn_shard_piles(rvn_engine* e, const uint32_t* lengths, uint32_t n_reads_total, const rvn_overlap* overlaps,
                     uint64_t n, uint32_t kmax, rvn_pass1** out);
 
+/* Device-pointer variants of the same stages: every d_* argument is a pointer into HBM owned by the caller (the
+ * torch CUDA tensors the exchanges run on), so nothing crosses PCIe between the stages.  Calls are synchronous with
+ * respect to the engine's stream; the caller synchronises its own stream before passing buffers in. */
+int rvn_shard_sketch_fetch_dev(rvn_engine* e, uint64_t* d_values, uint64_t* d_origins);
+int rvn_shard_index_build_dev(rvn_engine* e, const uint64_t* d_values, const uint64_t* d_origins, uint64_t n,
+                              int all_query, uint64_t n_flagged /* origins with bit 63 set */);
+/* count-of-counts of this shard's keys: hist[65536] (host; bin 65535 = number of keys with count >= 65535, whose
+ * counts go to over[0..*n_over)) */
+int rvn_shard_key_histogram(rvn_engine* e, uint64_t* hist, uint32_t* over, uint32_t over_cap, uint32_t* n_over);
+int rvn_shard_join_fetch_dev(rvn_engine* e, uint64_t* d_group, uint64_t* d_positions, uint64_t* d_seg_off);
+int rvn_shard_chain_dev(rvn_engine* e, const rvn_reads* own_reads, const uint64_t* d_group, const uint64_t* d_positions,
+                        const uint64_t* d_seg_off, uint64_t n_matches, uint64_t* n_overlaps);
+int rvn_engine_map_fetch_dev(rvn_engine* e, rvn_overlap* d_overlaps, uint32_t* d_read_offsets);
+int rvn_shard_piles_dev(rvn_engine* e, const uint32_t* lengths /* host */, uint32_t n_reads_total,
+                        const rvn_overlap* d_overlaps, const uint32_t* d_overlap_read_off /* n_reads_total + 1 */,
+                        uint64_t n, uint32_t kmax, rvn_pass1** out);
+
 /* reads used per target (their best overlap passed the error filter) in the last rvn_polish_round call: the RC:i:
  * tag racon writes next to XC:f: */
 int rvn_polish_target_reads(const rvn_engine* e, uint32_t* counts, uint32_t n_targets);

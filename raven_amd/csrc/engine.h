@@ -162,6 +162,7 @@ void index_build_table(Engine& e);                               // lazy: distin
 // minhash-select on a raw sketch, marking the selected minimizers with kQueryFlag in raw.org; returns their count
 u64 sketch_flag_queries(Engine& e, const ReadsDev& r, Sketch& raw);
 void index_filter(Engine& e, double freq);               // sets e.index.occurrence
+void index_key_histogram(Engine& e, std::vector<u64>& hist, std::vector<u32>& over);  // count-of-counts (65536 bins)
 void map_batch(Engine& e, const ReadsDev& r, u32 first, u32 last, bool avoid_equal, bool avoid_symmetric,
                bool minhash, bool want_filtered, MapOut& out);
 

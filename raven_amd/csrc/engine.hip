@@ -736,6 +736,188 @@ int rvn_shard_piles(rvn_engine* h, const uint32_t* lengths, uint32_t n_reads_tot
   });
 }
 
+// ---- device-pointer variants: the exchange buffers of the sharded pass stay in HBM (torch CUDA tensors) ----
+namespace {
+__global__ void widen_u32_u64_kernel(const u32* __restrict__ src, u64* __restrict__ dst, u64 n) {
+  const u64 i = static_cast<u64>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[i];
+}
+__global__ void narrow_u64_u32_kernel(const u64* __restrict__ src, u32* __restrict__ dst, u64 n) {
+  const u64 i = static_cast<u64>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = static_cast<u32>(src[i]);
+}
+}  // namespace
+
+int rvn_shard_sketch_fetch_dev(rvn_engine* h, uint64_t* d_values, uint64_t* d_origins) {
+  return guarded([&]() -> int {
+    if (!h) return fail(RVN_EINVAL, "[raven_hip] NULL engine");
+    Engine& e = h->e;
+    Sketch& s = e.shard_sketch_minhash ? e.index_sketch : e.raw_sketch;
+    RVN_HIP(hipSetDevice(e.device));
+    if (s.count == 0) return RVN_OK;
+    if (!d_values || !d_origins) return fail(RVN_EINVAL, "[raven_hip] rvn_shard_sketch_fetch_dev: NULL argument");
+    if (e.val64) RVN_HIP(hipMemcpyAsync(d_values, s.val.ptr, s.count * 8, hipMemcpyDeviceToDevice, e.stream));
+    else widen_u32_u64_kernel<<<static_cast<u32>((s.count + 255) / 256), 256, 0, e.stream>>>(s.val.as<u32>(), d_values, s.count);
+    RVN_HIP(hipMemcpyAsync(d_origins, s.org.ptr, s.count * 8, hipMemcpyDeviceToDevice, e.stream));
+    RVN_HIP(hipStreamSynchronize(e.stream));
+    return RVN_OK;
+  });
+}
+
+int rvn_shard_index_build_dev(rvn_engine* h, const uint64_t* d_values, const uint64_t* d_origins, uint64_t n,
+                              int all_query, uint64_t n_flagged) {
+  return guarded([&]() -> int {
+    if (!h || (n && (!d_values || !d_origins))) return fail(RVN_EINVAL, "[raven_hip] rvn_shard_index_build_dev: NULL argument");
+    Engine& e = h->e;
+    RVN_HIP(hipSetDevice(e.device));
+    UseTimers ut(e);
+    Sketch& sk = e.index_sketch;
+    sk.first = 0;
+    sk.last = 0;
+    sk.count = n;
+    if (e.val64) {
+      u64* dv = sk.val.get<u64>(n + 1);
+      if (n) RVN_HIP(hipMemcpyAsync(dv, d_values, n * 8, hipMemcpyDeviceToDevice, e.stream));
+    } else {
+      u32* dv = sk.val.get<u32>(n + 1);
+      if (n) narrow_u64_u32_kernel<<<static_cast<u32>((n + 255) / 256), 256, 0, e.stream>>>(d_values, dv, n);
+    }
+    u64* dorg = sk.org.get<u64>(n + 1);
+    if (n) RVN_HIP(hipMemcpyAsync(dorg, d_origins, n * 8, hipMemcpyDeviceToDevice, e.stream));
+    e.c_index_min += n;
+    index_build(e, sk, false);
+    e.c_index_keys += e.index.u;
+    e.index.has_query_flags = !all_query;
+    e.index.all_query = all_query != 0;
+    e.join_query_count = all_query ? n : n_flagged;
+    RVN_HIP(hipStreamSynchronize(e.stream));
+    return RVN_OK;
+  });
+}
+
+int rvn_shard_key_histogram(rvn_engine* h, uint64_t* hist, uint32_t* over, uint32_t over_cap, uint32_t* n_over) {
+  return guarded([&]() -> int {
+    if (!h || !hist || !n_over) return fail(RVN_EINVAL, "[raven_hip] rvn_shard_key_histogram: NULL argument");
+    Engine& e = h->e;
+    RVN_HIP(hipSetDevice(e.device));
+    UseTimers ut(e);
+    std::vector<u64> hv;
+    std::vector<u32> ov;
+    index_key_histogram(e, hv, ov);
+    for (size_t i = 0; i < hv.size(); ++i) hist[i] = hv[i];
+    *n_over = static_cast<u32>(ov.size());
+    if (ov.size() > over_cap) return fail(RVN_EINVAL, "[raven_hip] rvn_shard_key_histogram: overflow list does not fit");
+    for (size_t i = 0; i < ov.size(); ++i) over[i] = ov[i];
+    return RVN_OK;
+  });
+}
+
+int rvn_shard_join_fetch_dev(rvn_engine* h, uint64_t* d_grp, uint64_t* d_pos, uint64_t* d_seg_off) {
+  return guarded([&]() -> int {
+    if (!h) return fail(RVN_EINVAL, "[raven_hip] NULL engine");
+    Engine& e = h->e;
+    RVN_HIP(hipSetDevice(e.device));
+    const u64 H = e.shard_join_matches;
+    if (H && d_grp) RVN_HIP(hipMemcpyAsync(d_grp, e.m_grp[0].ptr, H * 8, hipMemcpyDeviceToDevice, e.stream));
+    if (H && d_pos) RVN_HIP(hipMemcpyAsync(d_pos, e.m_pos[0].ptr, H * 8, hipMemcpyDeviceToDevice, e.stream));
+    if (d_seg_off)
+      RVN_HIP(hipMemcpyAsync(d_seg_off, e.seg_off.ptr, (static_cast<size_t>(e.shard_join_reads) + 1) * 8,
+                             hipMemcpyDeviceToDevice, e.stream));
+    RVN_HIP(hipStreamSynchronize(e.stream));
+    return RVN_OK;
+  });
+}
+
+int rvn_shard_chain_dev(rvn_engine* h, const rvn_reads* own, const uint64_t* d_grp, const uint64_t* d_pos,
+                        const uint64_t* d_seg_off, uint64_t n_matches, uint64_t* n_overlaps) {
+  return guarded([&]() -> int {
+    if (!h || !own || !d_seg_off || !n_overlaps) return fail(RVN_EINVAL, "[raven_hip] rvn_shard_chain_dev: NULL argument");
+    Engine& e = h->e;
+    const ReadsDev& r = own->r;
+    RVN_HIP(hipSetDevice(e.device));
+    UseTimers ut(e);
+    const u32 nr = r.n;
+    const u64 H = n_matches;
+    if (H && (!d_grp || !d_pos)) return fail(RVN_EINVAL, "[raven_hip] rvn_shard_chain_dev: NULL matches");
+    u64* d_seg = e.seg_off.get<u64>(static_cast<size_t>(nr) + 2);
+    RVN_HIP(hipMemcpyAsync(d_seg, d_seg_off, (static_cast<size_t>(nr) + 1) * 8, hipMemcpyDeviceToDevice, e.stream));
+    u64* g0 = e.m_grp[0].get<u64>(H + 1);
+    u64* p0 = e.m_pos[0].get<u64>(H + 1);
+    e.m_grp[1].reserve((H + 1) * 8);
+    e.m_pos[1].reserve((H + 1) * 8);
+    if (H) {
+      RVN_HIP(hipMemcpyAsync(g0, d_grp, H * 8, hipMemcpyDeviceToDevice, e.stream));
+      RVN_HIP(hipMemcpyAsync(p0, d_pos, H * 8, hipMemcpyDeviceToDevice, e.stream));
+    }
+    MapOut& out = e.map_out;
+    out.first = 0;
+    out.last = nr;
+    out.n_query = 0;
+    out.n_matches = H;
+    out.n_intervals = out.n_overlaps = 0;
+    for (u32 i = 0; i < nr; ++i) e.c_query_bases += r.h_len[i];
+    chain_matches(e, r, 0, nr, H, out);
+    e.c_intervals += out.n_intervals;
+    RVN_HIP(hipStreamSynchronize(e.stream));
+    *n_overlaps = out.n_overlaps;
+    return RVN_OK;
+  });
+}
+
+int rvn_engine_map_fetch_dev(rvn_engine* h, rvn_overlap* d_overlaps, uint32_t* d_read_offsets) {
+  return guarded([&]() -> int {
+    if (!h) return fail(RVN_EINVAL, "[raven_hip] NULL engine");
+    MapOut& m = h->e.map_out;
+    RVN_HIP(hipSetDevice(h->e.device));
+    if (d_overlaps && m.n_overlaps)
+      RVN_HIP(hipMemcpyAsync(d_overlaps, m.ovl.ptr, m.n_overlaps * sizeof(Overlap), hipMemcpyDeviceToDevice, h->e.stream));
+    if (d_read_offsets)
+      RVN_HIP(hipMemcpyAsync(d_read_offsets, m.ovl_read_off.ptr, (static_cast<size_t>(m.last - m.first) + 1) * 4,
+                             hipMemcpyDeviceToDevice, h->e.stream));
+    RVN_HIP(hipStreamSynchronize(h->e.stream));
+    return RVN_OK;
+  });
+}
+
+int rvn_shard_piles_dev(rvn_engine* h, const uint32_t* lengths, uint32_t n_reads_total, const rvn_overlap* d_overlaps,
+                        const uint32_t* d_ovl_read_off, uint64_t n, uint32_t kmax, rvn_pass1** out) {
+  return guarded([&]() -> int {
+    if (!h || !lengths || !out || !d_ovl_read_off || (n && !d_overlaps))
+      return fail(RVN_EINVAL, "[raven_hip] rvn_shard_piles_dev: NULL argument");
+    Engine& e = h->e;
+    RVN_HIP(hipSetDevice(e.device));
+    UseTimers ut(e);
+    ReadsDev meta;
+    meta.n = n_reads_total;
+    meta.h_len.assign(lengths, lengths + n_reads_total);
+    meta.h_id.resize(n_reads_total);
+    for (u32 i = 0; i < n_reads_total; ++i) meta.h_id[i] = i;
+    meta.ids_are_indices = true;
+    u32* d_len = meta.len.get<u32>(static_cast<size_t>(n_reads_total) + 1);
+    u32* d_id = meta.id.get<u32>(static_cast<size_t>(n_reads_total) + 1);
+    if (n_reads_total) {
+      RVN_HIP(hipMemcpy(d_len, meta.h_len.data(), static_cast<size_t>(n_reads_total) * 4, hipMemcpyHostToDevice));
+      RVN_HIP(hipMemcpy(d_id, meta.h_id.data(), static_cast<size_t>(n_reads_total) * 4, hipMemcpyHostToDevice));
+    }
+    MapOut mo;
+    mo.first = 0;
+    mo.last = n_reads_total;
+    mo.n_overlaps = n;
+    Overlap* d_ov = mo.ovl.get<Overlap>(n + 1);
+    if (n) RVN_HIP(hipMemcpyAsync(d_ov, d_overlaps, n * sizeof(Overlap), hipMemcpyDeviceToDevice, e.stream));
+    u32* d_off = mo.ovl_read_off.get<u32>(static_cast<size_t>(n_reads_total) + 1);
+    RVN_HIP(hipMemcpyAsync(d_off, d_ovl_read_off, (static_cast<size_t>(n_reads_total) + 1) * 4, hipMemcpyDeviceToDevice,
+                           e.stream));
+    std::unique_ptr<rvn_pass1> p(new rvn_pass1());
+    p->e = &e;
+    piles_init(e, meta, p->ps);
+    piles_merge(e, meta, mo, kmax, p->ps);
+    RVN_HIP(hipStreamSynchronize(e.stream));
+    *out = p.release();
+    return RVN_OK;
+  });
+}
+
 int rvn_polish_target_reads(const rvn_engine* h, uint32_t* counts, uint32_t n_targets) {
   if (!h || !counts || n_targets != h->e.polish_target_reads.size())
     return fail(RVN_EINVAL, "[raven_hip] rvn_polish_target_reads: no polishing round with that many targets");

@@ -233,6 +233,32 @@ void index_build_table(Engine& e) {
   else index_table_impl<u32>(e);
 }
 
+// Count-of-counts histogram of the per-key run lengths (bins 0..65534; `over` = the run lengths >= 65535): what a
+// rank contributes to the all-reduce behind the sharded pass's global Filter.
+void index_key_histogram(Engine& e, std::vector<u64>& hist, std::vector<u32>& over) {
+  Index& ix = e.index;
+  hist.assign(kHistBins, 0);
+  over.clear();
+  if (ix.u == 0) return;
+  hipStream_t s = e.stream;
+  const u32 overflow_cap = 1u << 20;
+  u32* d_hist = e.tmp_a.get<u32>(kHistBins + 1);
+  u32* d_over = e.tmp_b.get<u32>(overflow_cap + 1);
+  RVN_HIP(hipMemsetAsync(d_hist, 0, (kHistBins + 1) * 4, s));
+  const u32 u = static_cast<u32>(ix.u);
+  const u32 grid = std::min<u32>(div_up(u, 256), 2048);
+  RVN_KLAUNCH(kKOccHist, occ_hist_kernel<<<grid, 256, 0, s>>>(ix.u_start.as<u32>(), u, d_hist, d_over, d_hist + kHistBins, overflow_cap));
+  std::vector<u32> h(kHistBins + 1);
+  RVN_HIP(hipMemcpyAsync(h.data(), d_hist, (kHistBins + 1) * 4, hipMemcpyDeviceToHost, s));
+  RVN_HIP(hipStreamSynchronize(s));
+  const u32 n_over = h[kHistBins];
+  if (n_over > overflow_cap) throw HipError("[raven_hip] key histogram: overflow list too small");
+  for (u32 i = 0; i < kHistBins; ++i) hist[i] = h[i];
+  hist[kHistBins - 1] = n_over;
+  over.resize(n_over);
+  if (n_over) RVN_HIP(hipMemcpy(over.data(), d_over, static_cast<size_t>(n_over) * 4, hipMemcpyDeviceToHost));
+}
+
 // ram Filter: occurrence_ = (value at index (1-f)*U of the sorted per-key counts) + 1; f == 0 -> no filter.
 void index_filter(Engine& e, double freq) {
   Index& ix = e.index;

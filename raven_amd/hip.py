@@ -35,7 +35,9 @@ SYMBOLS = [
     "rvn_pass1_fetch_piles", "rvn_pass1_fetch_overlaps", "rvn_pass1_destroy", "rvn_pile_add_layers",
     "rvn_edit_distance_batch", "rvn_poa_consensus_batch", "rvn_poa_phase_cycles", "rvn_polish_target_reads", "rvn_shard_sketch", "rvn_shard_sketch_fetch",
     "rvn_shard_index_build", "rvn_shard_key_counts", "rvn_engine_set_occurrence", "rvn_shard_join",
-    "rvn_shard_join_fetch", "rvn_shard_chain", "rvn_shard_piles", "rvn_poa_set_mode", "rvn_poa_fallback_windows", "rvn_poa_wide_windows", "rvn_pile_add_kmers_batch",
+    "rvn_shard_join_fetch", "rvn_shard_chain", "rvn_shard_piles", "rvn_shard_sketch_fetch_dev",
+    "rvn_shard_index_build_dev", "rvn_shard_key_histogram", "rvn_shard_join_fetch_dev", "rvn_shard_chain_dev",
+    "rvn_engine_map_fetch_dev", "rvn_shard_piles_dev", "rvn_poa_set_mode", "rvn_poa_fallback_windows", "rvn_poa_wide_windows", "rvn_pile_add_kmers_batch",
     "rvn_test_low_complexity", "rvn_polish_round",
     "rvn_engine_sketch", "rvn_engine_sketch_fetch", "rvn_engine_index_size", "rvn_engine_index_fetch",
     "rvn_engine_counters", "rvn_engine_num_stages", "rvn_engine_stage_name", "rvn_engine_stage_ms",
@@ -104,6 +106,13 @@ def lib():
     L.rvn_shard_join_fetch.argtypes = [vp, vp, vp, vp]
     L.rvn_shard_chain.argtypes = [vp, vp, vp, vp, vp, C.POINTER(u64)]
     L.rvn_shard_piles.argtypes = [vp, vp, u32, vp, u64, u32, C.POINTER(vp)]
+    L.rvn_shard_sketch_fetch_dev.argtypes = [vp, vp, vp]
+    L.rvn_shard_index_build_dev.argtypes = [vp, vp, vp, u64, i32, u64]
+    L.rvn_shard_key_histogram.argtypes = [vp, vp, vp, u32, C.POINTER(u32)]
+    L.rvn_shard_join_fetch_dev.argtypes = [vp, vp, vp, vp]
+    L.rvn_shard_chain_dev.argtypes = [vp, vp, vp, vp, vp, u64, C.POINTER(u64)]
+    L.rvn_engine_map_fetch_dev.argtypes = [vp, vp, vp]
+    L.rvn_shard_piles_dev.argtypes = [vp, vp, u32, vp, vp, u64, u32, C.POINTER(vp)]
     L.rvn_poa_set_mode.argtypes = [vp, i32]
     L.rvn_poa_set_mode.restype = i32
     L.rvn_poa_fallback_windows.argtypes = [vp]
@@ -328,6 +337,48 @@ class Engine:
         h = C.c_void_p()
         _check(lib().rvn_shard_piles(self._h, _p(lengths), lengths.shape[0], _p(overlaps), overlaps.shape[0], kmax,
                                      C.byref(h)))
+        return Pass1(h, lengths.shape[0])
+
+    # device-pointer variants (pointers are integers, e.g. torch.Tensor.data_ptr() of CUDA tensors)
+    def shard_sketch_count(self, own_reads: Reads, index_minhash=False) -> int:
+        n = C.c_uint64(0)
+        _check(lib().rvn_shard_sketch(self._h, own_reads._h, int(index_minhash), C.byref(n)))
+        return int(n.value)
+
+    def shard_sketch_fetch_dev(self, d_values, d_origins):
+        _check(lib().rvn_shard_sketch_fetch_dev(self._h, d_values, d_origins))
+
+    def shard_index_build_dev(self, d_values, d_origins, n, all_query, n_flagged):
+        _check(lib().rvn_shard_index_build_dev(self._h, d_values, d_origins, int(n), int(all_query), int(n_flagged)))
+
+    def shard_key_histogram(self):
+        hist = np.zeros(65536, dtype=np.uint64)
+        over = np.zeros(1 << 20, dtype=np.uint32)
+        n = C.c_uint32(0)
+        _check(lib().rvn_shard_key_histogram(self._h, _p(hist), _p(over), over.shape[0], C.byref(n)))
+        return hist.astype(np.int64), over[:n.value].astype(np.int64)
+
+    def shard_join_count(self, n_reads_total, avoid_equal=True, avoid_symmetric=True) -> int:
+        h = C.c_uint64(0)
+        _check(lib().rvn_shard_join(self._h, n_reads_total, int(avoid_equal), int(avoid_symmetric), C.byref(h)))
+        return int(h.value)
+
+    def shard_join_fetch_dev(self, d_grp, d_pos, d_seg):
+        _check(lib().rvn_shard_join_fetch_dev(self._h, d_grp, d_pos, d_seg))
+
+    def shard_chain_dev(self, own_reads: Reads, d_grp, d_pos, d_seg, n_matches) -> int:
+        n = C.c_uint64(0)
+        _check(lib().rvn_shard_chain_dev(self._h, own_reads._h, d_grp, d_pos, d_seg, int(n_matches), C.byref(n)))
+        return int(n.value)
+
+    def map_fetch_dev(self, d_overlaps, d_read_off):
+        _check(lib().rvn_engine_map_fetch_dev(self._h, d_overlaps, d_read_off))
+
+    def shard_piles_dev(self, lengths, d_overlaps, d_read_off, n, kmax=32) -> Pass1:
+        lengths = np.ascontiguousarray(lengths, dtype=np.uint32)
+        h = C.c_void_p()
+        _check(lib().rvn_shard_piles_dev(self._h, _p(lengths), lengths.shape[0], d_overlaps, d_read_off, int(n), kmax,
+                                         C.byref(h)))
         return Pass1(h, lengths.shape[0])
 
     def pile_add_layers(self, data: np.ndarray, pile_id: int, overlaps: np.ndarray):

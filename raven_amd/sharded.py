@@ -14,7 +14,9 @@ is only the partitioning and the exchanges.  Result for the reads a rank owns: b
 (tests/test_gpu_sharded.py), because (a) pieces are concatenated in source-rank order = global (read, position)
 order, which is the order ram's stable sort and the reference's serial merge see, and (b) the order of a read's
 matches does not matter (total-order sorts follow).  Limits of this round: one index batch and one flush window
-(total bases < 2^30, i.e. configs[1]/[2]); buffers cross the exchange through host memory.
+(total bases < 2^30, i.e. configs[1]/[2]).  Two variants: `find_overlaps_and_create_piles_sharded` stages the
+exchange buffers through host memory (numpy; gloo or RCCL), `find_overlaps_and_create_piles_sharded_dev` keeps them in
+HBM as torch CUDA tensors (RCCL) — initialise torch.cuda before creating engines in that process.
 """
 from __future__ import annotations
 
@@ -58,8 +60,16 @@ def global_occurrence(key_counts: np.ndarray, freq: float, comm) -> int:
     if freq == 0:
         return 0xFFFFFFFF
     hist = np.bincount(np.minimum(key_counts, 65535), minlength=65536).astype(np.int64)
-    over = comm.all_gather_v(key_counts[key_counts >= 65535].astype(np.int64))
-    hist = comm.all_reduce_sum(hist)
+    return occurrence_from_histogram(hist, key_counts[key_counts >= 65535].astype(np.int64), freq, comm)
+
+
+def occurrence_from_histogram(hist: np.ndarray, over: np.ndarray, freq: float, comm) -> int:
+    """Same from this rank's count-of-counts (bins 0..65534, bin 65535 = #keys with count >= 65535, listed in `over`):
+    all-reduce of the histogram, all-gather of the overflow counts."""
+    if freq == 0:
+        return 0xFFFFFFFF
+    over = comm.all_gather_v(np.asarray(over, dtype=np.int64))
+    hist = comm.all_reduce_sum(np.asarray(hist, dtype=np.int64))
     u = int(hist.sum())
     if u == 0:
         return 0xFFFFFFFF
@@ -205,3 +215,142 @@ def find_overlaps_and_create_piles_sharded(eng, rs_all: seqio.ReadSet, comm: Com
                           overlaps_sent=int(ovl.shape[0] and np.sum(rhs_owner != g)), map_overlaps=int(ovl.shape[0]),
                           bytes_sent=comm.bytes_sent))
     return res
+
+
+# ---- device-resident variant: the exchange buffers are torch CUDA tensors, nothing crosses PCIe between stages ----
+_MIX_I64 = 0x9E3779B97F4A7C15 - (1 << 64)
+
+
+def hash_owner_t(values, world: int):
+    """hash_owner on an int64 torch tensor (same bits as the numpy version: logical shift emulated by masking)."""
+    import torch
+    if world == 1:
+        return torch.zeros_like(values)
+    h = ((values * _MIX_I64) >> 33) & ((1 << 31) - 1)
+    return h % world
+
+
+def regroup_by_read_t(counts_per_src, data_per_src):
+    """regroup_by_read on the device: per-source (per-read counts, tuple of flat int64 tensors)."""
+    import torch
+    total = torch.zeros_like(counts_per_src[0])
+    for c in counts_per_src:
+        total = total + c
+    seg = torch.zeros(total.shape[0] + 1, dtype=torch.int64, device=total.device)
+    torch.cumsum(total, 0, out=seg[1:])
+    n_out = int(seg[-1].item())
+    outs = [torch.empty(n_out, dtype=torch.int64, device=total.device) for _ in data_per_src[0]]
+    start = seg[:-1].clone()
+    for c, datas in zip(counts_per_src, data_per_src):
+        m = int(c.sum().item())
+        if m:
+            src_off = torch.cumsum(c, 0) - c
+            dest = torch.repeat_interleave(start - src_off, c) + torch.arange(m, dtype=torch.int64, device=c.device)
+            for o, d in zip(outs, datas):
+                o[dest] = d
+        start = start + c
+    return seg, outs
+
+
+class DeviceComm(Comm):
+    """Comm whose payloads are int64 torch tensors on the GPU (RCCL: backend "nccl")."""
+
+    def all_to_all_t(self, parts):
+        """parts[h]: 1-D int64 CUDA tensor for rank h.  Returns the list received, indexed by source rank."""
+        import torch
+        if self.dist is None:
+            return [parts[0]]
+        dev = parts[0].device
+        cnt_in = torch.tensor([int(p.shape[0]) for p in parts], dtype=torch.int64, device=dev)
+        cnt_out = torch.zeros(self.world, dtype=torch.int64, device=dev)
+        self.dist.all_to_all_single(cnt_out, cnt_in)
+        out_l = [int(x) for x in cnt_out.tolist()]
+        inp = torch.cat(parts) if parts else torch.zeros(0, dtype=torch.int64, device=dev)
+        out = torch.empty(sum(out_l), dtype=torch.int64, device=dev)
+        self.dist.all_to_all_single(out, inp, out_l, [int(p.shape[0]) for p in parts])
+        self.bytes_sent += 8 * sum(int(p.shape[0]) for i, p in enumerate(parts) if i != self.rank)
+        return list(torch.split(out, out_l))
+
+
+def find_overlaps_and_create_piles_sharded_dev(eng, rs_all: seqio.ReadSet, comm, device, freq=0.001, kmax=32,
+                                               use_minhash=False):
+    """find_overlaps_and_create_piles_sharded with every exchange buffer resident in HBM (`device`: torch device of
+    the engine's GPU; `comm`: DeviceComm or a test double with all_to_all_t / all_reduce_sum / all_gather_v)."""
+    import torch
+    g, world = comm.rank, comm.world
+    n_total = rs_all.n
+    if rs_all.total_bases >= (1 << 30):
+        raise ValueError("sharded pass: one flush window only this round (total bases must be < 2^30)")
+    bounds = partition_reads(rs_all.lengths, world)
+    lo, hi = int(bounds[g]), int(bounds[g + 1])
+    own = eng.upload(slice_reads(rs_all, lo, hi))
+    i64 = dict(dtype=torch.int64, device=device)
+
+    # 1. sketch; minimizers to the owner of their hash class (stable sort keeps (read, position) order)
+    n = eng.shard_sketch_count(own, index_minhash=use_minhash)
+    val, org = torch.empty(n, **i64), torch.empty(n, **i64)
+    eng.shard_sketch_fetch_dev(val.data_ptr(), org.data_ptr())
+    owner = hash_owner_t(val, world)
+    order = torch.sort(owner, stable=True).indices
+    cnt = torch.bincount(owner, minlength=world).tolist()
+    val_r = comm.all_to_all_t(list(torch.split(val[order], cnt)))
+    org_r = comm.all_to_all_t(list(torch.split(org[order], cnt)))
+    vcat, ocat = torch.cat(val_r).contiguous(), torch.cat(org_r).contiguous()
+
+    # 2. index shard; 3. exact global Filter
+    n_flagged = int((ocat < 0).sum().item())
+    torch.cuda.synchronize(device)
+    eng.shard_index_build_dev(vcat.data_ptr(), ocat.data_ptr(), vcat.shape[0], use_minhash, n_flagged)
+    hist, over = eng.shard_key_histogram()
+    occ = occurrence_from_histogram(hist, over, freq, comm)
+    eng.set_occurrence(occ)
+
+    # 4. self-join; candidate pairs to the owner of the query read
+    n_m = eng.shard_join_count(n_total, True, True)
+    grp, pos = torch.empty(n_m, **i64), torch.empty(n_m, **i64)
+    seg = torch.empty(n_total + 1, **i64)
+    eng.shard_join_fetch_dev(grp.data_ptr(), pos.data_ptr(), seg.data_ptr())
+    per_read = seg[1:] - seg[:-1]
+    b_list = [int(x) for x in bounds]
+    m_cuts = seg[torch.tensor(b_list, device=device)].tolist()
+    m_split = [int(m_cuts[h + 1] - m_cuts[h]) for h in range(world)]
+    r_split = [b_list[h + 1] - b_list[h] for h in range(world)]
+    cnt_r = comm.all_to_all_t(list(torch.split(per_read, r_split)))
+    grp_r = comm.all_to_all_t(list(torch.split(grp, m_split)))
+    pos_r = comm.all_to_all_t(list(torch.split(pos, m_split)))
+    seg_own, (grp_own, pos_own) = regroup_by_read_t(cnt_r, list(zip(grp_r, pos_r)))
+
+    # 5. chain
+    torch.cuda.synchronize(device)
+    n_o = eng.shard_chain_dev(own, grp_own.data_ptr(), pos_own.data_ptr(), seg_own.data_ptr(), grp_own.shape[0])
+    ovl = torch.empty((n_o, 4), **i64)
+    off_own = torch.empty(own.n + 1, dtype=torch.int32, device=device)
+    eng.map_fetch_dev(ovl.data_ptr(), off_own.data_ptr())
+
+    # 6. overlaps also to the owner of their rhs read; merge + piles
+    bounds_t = torch.tensor(b_list, **i64)
+    rhs = (ovl[:, 1] >> 32) & 0xFFFFFFFF
+    rhs_owner = torch.searchsorted(bounds_t, rhs, right=True) - 1
+    parts = [ovl[rhs_owner == h].reshape(-1) if h != g else torch.zeros(0, **i64) for h in range(world)]
+    sent = sum(int(p.shape[0]) for p in parts) // 4
+    recv = comm.all_to_all_t(parts)
+    for s in range(g + 1, world):
+        assert recv[s].shape[0] == 0, "avoid_symmetric: overlaps only travel to higher ranks"
+    combined = torch.cat([recv[s].reshape(-1, 4) for s in range(g)] + [ovl]).contiguous() if world > 1 else ovl
+    lhs = combined[:, 0] & 0xFFFFFFFF
+    off_all = torch.zeros(n_total + 1, **i64)
+    if combined.shape[0]:
+        torch.cumsum(torch.bincount(lhs, minlength=n_total), 0, out=off_all[1:])
+    off32 = off_all.to(torch.int32).contiguous()
+    torch.cuda.synchronize(device)
+    p = eng.shard_piles_dev(rs_all.lengths, combined.data_ptr(), off32.data_ptr(), combined.shape[0], kmax)
+    data, poff = p.piles()
+    kept, koff = p.overlaps()
+    p.close()
+    return dict(lo=lo, hi=hi, occurrence=occ,
+                pile_data=data[int(poff[lo]):int(poff[hi])].copy(),
+                pile_off=(poff[lo:hi + 1] - poff[lo]).astype(np.uint64),
+                overlaps=kept[int(koff[lo]):int(koff[hi])].copy(),
+                overlap_off=(koff[lo:hi + 1] - koff[lo]).astype(np.uint32),
+                stats=dict(minimizers_sent=int(n - cnt[g]), matches_sent=int(n_m - m_split[g]), overlaps_sent=int(sent),
+                           map_overlaps=int(n_o), bytes_sent=comm.bytes_sent))

@@ -21,6 +21,15 @@ def pytest_sessionstart(session):
     if not all(os.path.exists(p) for p in need):
         import __graft_entry__
         __graft_entry__.build()
+    # The device-resident sharded pass hands torch CUDA tensors to libraven_hip in the same process.  torch ships its
+    # own HIP runtime; it has to initialise BEFORE libraven_hip touches the GPU (the order bench.py has anyway),
+    # otherwise torch reports "No HIP GPUs are available".
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:  # no torch / no GPU: the CPU suite does not need it
+        pass
 
 
 @pytest.fixture(scope="session")

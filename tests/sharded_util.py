@@ -30,6 +30,15 @@ class LocalComm:
         self.g.barrier.wait()
         return res
 
+    def all_to_all_t(self, parts):
+        """torch tensors (same device) between threads."""
+        self.g.slots[self.rank] = parts
+        self.g.barrier.wait()
+        res = [self.g.slots[s][self.rank].clone() for s in range(self.world)]
+        self.bytes_sent += sum(8 * int(p.shape[0]) for i, p in enumerate(parts) if i != self.rank)
+        self.g.barrier.wait()
+        return res
+
     def all_reduce_sum(self, a):
         parts = self.all_to_all_v([a] * self.world)
         return np.sum(parts, axis=0)

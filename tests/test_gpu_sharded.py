@@ -94,3 +94,33 @@ def test_sharded_pass_two_processes_over_torch_distributed(tmp_path):
                        text=True, timeout=600, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "SHARD_OK_0" in r.stdout and "SHARD_OK_1" in r.stdout, r.stdout[-2000:]
+
+
+@pytest.mark.parametrize("world", [1, 3])
+def test_device_resident_sharded_pass_is_bit_identical(world):
+    """Same pass with every exchange buffer in HBM (torch CUDA tensors, rvn_shard_*_dev)."""
+    import torch
+    dev = torch.device("cuda", 0)
+    g = synth.make_genome(300_000, seed=91)
+    rs, _ = synth.make_reads(g, 20, 6000, seed=92)
+    data, poff, kept, koff, occ = _single(rs)
+
+    def rank_fn(r, comm):
+        return sharded.find_overlaps_and_create_piles_sharded_dev(hip.Engine(15, 5), rs, comm, dev)
+
+    res = sharded_util.run_ranks(world, rank_fn)
+    for x in res:
+        assert x["occurrence"] == occ
+        sharded_util.check_against_single(x, data, poff, kept, koff)
+    if world > 1:
+        assert sum(x["stats"]["matches_sent"] for x in res) > 0 and sum(x["stats"]["overlaps_sent"] for x in res) > 0
+
+
+def test_hash_owner_torch_equals_numpy():
+    import torch
+    v = np.random.default_rng(1).integers(0, 1 << 62, size=10_000, dtype=np.uint64)
+    v[:100] = np.arange(100, dtype=np.uint64)
+    for world in (2, 3, 8):
+        a = sharded.hash_owner(v, world)
+        b = sharded.hash_owner_t(torch.from_numpy(v.view(np.int64)).cuda(), world).cpu().numpy()
+        assert np.array_equal(a, b)
