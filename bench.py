@@ -86,6 +86,22 @@ def cpu_baseline(args, cores):
     return {"value": rs.total_bases / tc / 1e9, "unit": "Gbase/s", "cores": cores, "kind": "port", "sample": sample}
 
 
+def cpu_baseline_polish():
+    """The CPU restatement of one racon round (oracle.polish_round, 1 thread: whole-overlap NW path + spoa-style POA)
+    on a bounded sample of the same generator: 20 kb draft, 30x, 5 kb reads."""
+    from oracle import oracle
+    from raven_amd import seqio
+    g = synth.make_genome(20_000, seed=0x5EED0003)
+    rs, _ = synth.make_reads(g, 30, 5000, seed=0x5EED0004)
+    targets = seqio.pack_reads([synth.make_draft(g, seed=0x5EED0005)])
+    t0 = time.perf_counter()
+    oracle.polish_round(targets, rs)
+    dt = time.perf_counter() - t0
+    return {"value": round(rs.total_bases / dt / 1e9, 6), "unit": "Gbase/s per round", "cores": 1, "kind": "port",
+            "sample": "%d reads / %d bases on a 20 kb draft (5 kb reads: the checker aligns every read with a full "
+                      "NW matrix), oracle.polish_round: %.1f s" % (rs.n, rs.total_bases, dt)}
+
+
 def bench_sharded(args, rank, world, local_rank, dist, barrier):
     """Strong-scaling leg: every rank generates the SAME genome/reads, owns a slice of the piles, and the pass runs
     through raven_amd/sharded.py (all-to-all over RCCL on torch CUDA tensors; nothing crosses PCIe between stages)."""
@@ -301,6 +317,8 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             cores = os.cpu_count() or 1
             out["cpu_baseline"] = cpu_baseline(args, cores)
+            if polish is not None:
+                polish["cpu_baseline"] = cpu_baseline_polish()
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

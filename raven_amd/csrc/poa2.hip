@@ -274,6 +274,7 @@ __device__ __forceinline__ u32 poa2_window(const PoaWindow& win, const PoaLayer*
       if (lane == 0) S.u.ring[0] = static_cast<i16>(kNegInf16);
     }
     bool dirty = false;  // HBM score rows stored since the last fence
+    const i32 lane_gp = lane * gp;
     for (u32 r0 = 0; r0 < n_nodes; r0 += 64) {
       // metadata of 64 rows at once, one row per lane; it is also the traceback's row table
       int m_v = 0, m_np = 0, m_p01 = 0, m_p23 = 0, m_code = 0, m_outc = 1, m_marked = 0, m_b = 0;
@@ -312,7 +313,7 @@ __device__ __forceinline__ u32 poa2_window(const PoaWindow& win, const PoaLayer*
       const u32 rows_here = n_nodes - r0 < 64 ? n_nodes - r0 : 64;
       for (u32 ri = 0; ri < rows_here; ++ri) {
         if (!rl(m_marked, static_cast<int>(ri))) continue;
-        const u32 row = r0 + ri + 1;
+        const u32 row = static_cast<u32>(rfl(static_cast<int>(r0 + ri + 1)));  // uniform: keeps the row addressing scalar
         const u32 v = static_cast<u32>(rl(m_v, static_cast<int>(ri)));
         u32 np = static_cast<u32>(rl(m_np, static_cast<int>(ri)));
         const u32 p01 = static_cast<u32>(rl(m_p01, static_cast<int>(ri)));
@@ -321,12 +322,13 @@ __device__ __forceinline__ u32 poa2_window(const PoaWindow& win, const PoaLayer*
         const u32 vc = static_cast<u32>(rl(m_code, static_cast<int>(ri)));
         if (np == 0) np = 1;  // no in-edge inside the subgraph: the virtual start row (p01 == 0)
         const bool two = NCH > 1 && b + 64 < static_cast<i32>(w);  // second chunk has columns of the sequence
-        i32 j[NCH], sc[NCH], bd[NCH], bv[NCH];
+        i32 j[NCH], jg[NCH], sc[NCH], bd[NCH], bv[NCH];
         u32 kd[NCH], kv[NCH];
         bool val[NCH], dok[NCH];
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
           j[c] = b + 64 * c + lane;
+          jg[c] = (b + 64 * c) * gp + lane_gp;  // j * g without a vector multiply
           val[c] = j[c] < static_cast<i32>(w);
           dok[c] = val[c] && j[c] >= 1;
           // match/mismatch per column (clamped read; masked by dok)
@@ -346,8 +348,8 @@ __device__ __forceinline__ u32 poa2_window(const PoaWindow& win, const PoaLayer*
           if (pr == 0) {  // H[0][j] = j * g
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
-              up[c] = j[c] * gp;
-              dg[c] = (j[c] - 1) * gp;
+              up[c] = jg[c];
+              dg[c] = jg[c] - gp;
             }
           } else {
             const u32 slot = (pr - 1) & (kRing - 1);
@@ -396,11 +398,11 @@ __device__ __forceinline__ u32 poa2_window(const PoaWindow& win, const PoaLayer*
           if (c == 0 || two) {
             const i32 best = bd[c] >= bv[c] ? bd[c] : bv[c];
             u32 code = bd[c] >= bv[c] ? kd[c] : 16u + kv[c];
-            i32 x = val[c] ? best - j[c] * gp : kNegBig;
+            i32 x = val[c] ? best - jg[c] : kNegBig;
             x = wave_inclusive_max_dpp(x, kNegBig);
-            i32 hh = x + j[c] * gp;
+            i32 hh = x + jg[c];
             if (c > 0) {  // the gap chain entering from the previous chunk
-              const i32 viac = carry + (lane + 1) * gp;
+              const i32 viac = carry + lane_gp + gp;
               hh = viac > hh ? viac : hh;
             }
             if (hh > best) code = 32u;
