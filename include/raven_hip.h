@@ -198,6 +198,17 @@ int rvn_shard_piles_dev(rvn_engine* e, const uint32_t* lengths /* host */, uint3
                         const rvn_overlap* d_overlaps, const uint32_t* d_overlap_read_off /* n_reads_total + 1 */,
                         uint64_t n, uint32_t kmax, rvn_pass1** out);
 
+/* Same round restricted to the windows [window_first, window_last) of the global numbering (windows of target 0,
+ * then of target 1, ...; ceil(len / w) per target): what one GPU does when a round is sharded by windows
+ * (windows are independent).  out_codes receives, per target, the consensus of ITS windows inside the
+ * range only (possibly empty), n_windows / n_polished the per-target window counts inside the range; concatenating the
+ * per-target pieces of consecutive ranges reproduces rvn_polish_round exactly (raven_amd/sharded.py). */
+int rvn_polish_round_range(rvn_engine* e, rvn_reads* targets, rvn_reads* reads, const uint8_t* read_quals,
+                           const uint64_t* qual_offsets, double q, double err, uint32_t w, int trim, int match,
+                           int mismatch, int gap, uint64_t window_first, uint64_t window_last, uint8_t* out_codes,
+                           const uint64_t* out_offsets, uint32_t* out_len, double* ratio, uint32_t* n_windows,
+                           uint32_t* n_polished, rvn_polish_stats* stats);
+
 /* reads used per target (their best overlap passed the error filter) in the last rvn_polish_round call: the RC:i:
  * tag racon writes next to XC:f: */
 int rvn_polish_target_reads(const rvn_engine* e, uint32_t* counts, uint32_t n_targets);

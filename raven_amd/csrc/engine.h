@@ -190,7 +190,8 @@ struct PolishStats {
 // One racon polishing round (polish.hip): targets T, reads R, optional per-base Phred+33 qualities of the reads
 void polish_round(Engine& e, ReadsDev& T, ReadsDev& R, const u8* h_quals, const u64* h_qual_off, double q_thr,
                   double err_thr, u32 w, bool trim, int m, int n, int g, std::vector<std::vector<u8>>& polished,
-                  std::vector<double>& ratio, PolishStats& stats);
+                  std::vector<double>& ratio, PolishStats& stats, u64 win_first = 0, u64 win_last = ~0ULL,
+                  std::vector<u32>* win_count = nullptr, std::vector<u32>* win_polished = nullptr);
 
 // Pass-1 state: per-pile kept overlaps + coverage (pile.hip)
 struct PileState {

@@ -444,10 +444,11 @@ int rvn_pile_add_kmers_batch(rvn_engine* h, const rvn_reads* r, uint32_t first_r
   });
 }
 
-int rvn_polish_round(rvn_engine* h, rvn_reads* targets, rvn_reads* reads, const uint8_t* read_quals,
-                     const uint64_t* qual_offsets, double q, double err, uint32_t w, int trim, int match, int mismatch,
-                     int gap, uint8_t* out_codes, const uint64_t* out_offsets, uint32_t* out_len, double* ratio,
-                     rvn_polish_stats* stats) {
+int rvn_polish_round_range(rvn_engine* h, rvn_reads* targets, rvn_reads* reads, const uint8_t* read_quals,
+                           const uint64_t* qual_offsets, double q, double err, uint32_t w, int trim, int match,
+                           int mismatch, int gap, uint64_t window_first, uint64_t window_last, uint8_t* out_codes,
+                           const uint64_t* out_offsets, uint32_t* out_len, double* ratio, uint32_t* n_windows,
+                           uint32_t* n_polished, rvn_polish_stats* stats) {
   return guarded([&]() -> int {
     if (!h || !targets || !reads || !out_codes || !out_offsets || !out_len)
       return fail(RVN_EINVAL, "[raven_hip] NULL argument");
@@ -458,14 +459,17 @@ int rvn_polish_round(rvn_engine* h, rvn_reads* targets, rvn_reads* reads, const 
     std::vector<std::vector<u8>> polished;
     std::vector<double> rt;
     PolishStats st;
+    std::vector<u32> wc, wp;
     polish_round(h->e, targets->r, reads->r, read_quals, qual_offsets, q, err, w, trim != 0, match, mismatch, gap,
-                 polished, rt, st);
+                 polished, rt, st, window_first, window_last, &wc, &wp);
     for (u32 t = 0; t < targets->r.n; ++t) {
       const u64 cap = out_offsets[t + 1] - out_offsets[t];
-      if (polished[t].size() > cap) return fail(RVN_EINVAL, "[raven_hip] rvn_polish_round: output buffer too small");
+      if (polished[t].size() > cap) return fail(RVN_EINVAL, "[raven_hip] rvn_polish_round_range: output buffer too small");
       std::memcpy(out_codes + out_offsets[t], polished[t].data(), polished[t].size());
       out_len[t] = static_cast<uint32_t>(polished[t].size());
       if (ratio) ratio[t] = rt[t];
+      if (n_windows) n_windows[t] = wc[t];
+      if (n_polished) n_polished[t] = wp[t];
     }
     if (stats) {
       stats->n_overlaps = st.n_overlaps;
@@ -527,6 +531,14 @@ int rvn_poa_consensus_batch(rvn_engine* h, const uint8_t* codes, const uint8_t* 
                         mismatch, gap, trim, consensus, consensus_offsets, consensus_len, status, device_ms);
     return RVN_OK;
   });
+}
+
+int rvn_polish_round(rvn_engine* h, rvn_reads* targets, rvn_reads* reads, const uint8_t* read_quals,
+                     const uint64_t* qual_offsets, double q, double err, uint32_t w, int trim, int match, int mismatch,
+                     int gap, uint8_t* out_codes, const uint64_t* out_offsets, uint32_t* out_len, double* ratio,
+                     rvn_polish_stats* stats) {
+  return rvn_polish_round_range(h, targets, reads, read_quals, qual_offsets, q, err, w, trim, match, mismatch, gap, 0,
+                                ~0ULL, out_codes, out_offsets, out_len, ratio, nullptr, nullptr, stats);
 }
 
 // ---- stage-level entry points of the sharded single-genome pass (host side raven_amd/sharded.py) ----

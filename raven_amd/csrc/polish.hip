@@ -60,7 +60,8 @@ struct BestOverlap {
 
 void polish_round(Engine& e, ReadsDev& T, ReadsDev& R, const u8* h_quals, const u64* h_qual_off, double q_thr,
                   double err_thr, u32 w, bool trim, int m, int n, int g, std::vector<std::vector<u8>>& polished,
-                  std::vector<double>& ratio, PolishStats& stats) {
+                  std::vector<double>& ratio, PolishStats& stats, u64 win_first, u64 win_last,
+                  std::vector<u32>* win_count, std::vector<u32>* win_polished) {
   hipStream_t s = e.stream;
   using clk = std::chrono::steady_clock;
   auto ms_since = [](clk::time_point a) { return std::chrono::duration<double, std::milli>(clk::now() - a).count(); };
@@ -317,6 +318,7 @@ void polish_round(Engine& e, ReadsDev& T, ReadsDev& R, const u8* h_quals, const 
       Cut carry{q_first, t_first, q_first, t_first};
       u32 carry_at = 0xFFFFFFFFu;  // boundary `carry` was computed for
       for (u32 wi = t_first / w; static_cast<u64>(wi) * w < t_last_end; ++wi) {
+        if (first_window[t] + wi + 1 < win_first || first_window[t] + wi > win_last) continue;  // far from this rank's range
         const u32 ws = wi * w;
         const u32 we = std::min<u32>(T.h_len[t], ws + w);  // exclusive
         u32 t_b = std::max(ws, t_first), t_e = std::min(we, t_last_end);  // [t_b, t_e)
@@ -371,6 +373,7 @@ void polish_round(Engine& e, ReadsDev& T, ReadsDev& R, const u8* h_quals, const 
             prev = off;
           }
         }
+        if (first_window[t] + wi < win_first || first_window[t] + wi >= win_last) continue;  // another rank's window
         P.emits.push_back(Emit{first_window[t] + wi, lr});
       }
     }
@@ -475,18 +478,24 @@ void polish_round(Engine& e, ReadsDev& T, ReadsDev& R, const u8* h_quals, const 
   const double poa_wall = ms_since(t_poa);
   const auto t_st = clk::now();
 
-  // ---- 5. stitch -------------------------------------------------------------------------------------------
+  // ---- 5. stitch (only the windows of this call's range; the others were given no layers) ---------------------
+  if (win_count) win_count->assign(T.n, 0);
+  if (win_polished) win_polished->assign(T.n, 0);
   for (u32 t = 0; t < T.n; ++t) {
     u64 polished_windows = 0;
-    const u64 nw = first_window[t + 1] - first_window[t];
-    for (u64 wi = 0; wi < nw; ++wi) {
+    u64 nw = 0;
+    for (u64 wi = 0; wi < first_window[t + 1] - first_window[t]; ++wi) {
       const u64 gw = first_window[t] + wi;
+      if (gw < win_first || gw >= win_last) continue;
+      ++nw;
       polished_windows += status[gw] == 1 ? 1 : 0;
       if (status[gw] >= 2) ++stats.n_failed_windows;
       polished[t].insert(polished[t].end(), cons.begin() + out_off[gw], cons.begin() + out_off[gw] + cons_len[gw]);
     }
     ratio[t] = nw ? static_cast<double>(polished_windows) / nw : 0.0;
     stats.n_polished_windows += polished_windows;
+    if (win_count) (*win_count)[t] = static_cast<u32>(nw);
+    if (win_polished) (*win_polished)[t] = static_cast<u32>(polished_windows);
   }
   stats.host_ms += ms_since(t_st) + (poa_wall - ms);  // stitching + the batch's host-side preparation and copies
   stats.total_ms = ms_since(t_all);

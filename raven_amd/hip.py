@@ -33,7 +33,7 @@ SYMBOLS = [
     "rvn_engine_map_batch", "rvn_engine_map_fetch", "rvn_engine_map_fetch_filtered",
     "rvn_find_overlaps_and_create_piles", "rvn_pass1_pile_words", "rvn_pass1_num_overlaps",
     "rvn_pass1_fetch_piles", "rvn_pass1_fetch_overlaps", "rvn_pass1_destroy", "rvn_pile_add_layers",
-    "rvn_edit_distance_batch", "rvn_poa_consensus_batch", "rvn_poa_phase_cycles", "rvn_polish_target_reads", "rvn_shard_sketch", "rvn_shard_sketch_fetch",
+    "rvn_edit_distance_batch", "rvn_poa_consensus_batch", "rvn_poa_phase_cycles", "rvn_polish_target_reads", "rvn_polish_round_range", "rvn_shard_sketch", "rvn_shard_sketch_fetch",
     "rvn_shard_index_build", "rvn_shard_key_counts", "rvn_engine_set_occurrence", "rvn_shard_join",
     "rvn_shard_join_fetch", "rvn_shard_chain", "rvn_shard_piles", "rvn_shard_sketch_fetch_dev",
     "rvn_shard_index_build_dev", "rvn_shard_key_histogram", "rvn_shard_join_fetch_dev", "rvn_shard_chain_dev",
@@ -388,6 +388,33 @@ class Engine:
                                          overlaps.shape[0]))
 
     # -- racon::Polisher::Polish, one round ------------------------------------------------------------
+    def polish_round_range(self, targets: Reads, reads: Reads, window_first, window_last, quals=None, q=0.0, err=0.3,
+                           w=500, trim=True, m=3, n=-5, g=-4):
+        """One round restricted to global windows [window_first, window_last): returns (per-target partial consensus,
+        per-target window counts in range, per-target polished counts, stats)."""
+        nt = targets.n
+        ooff = np.zeros(nt + 1, dtype=np.uint64)
+        np.cumsum(2 * targets.rs.lengths.astype(np.uint64) + 1024, out=ooff[1:])
+        out = np.zeros(int(ooff[-1]) + 1, dtype=np.uint8)
+        out_len = np.zeros(nt, dtype=np.uint32)
+        nw = np.zeros(nt, dtype=np.uint32)
+        npol = np.zeros(nt, dtype=np.uint32)
+        stats = np.zeros(11, dtype=np.uint64)
+        qa = qo = None
+        if quals is not None:
+            qo = np.zeros(len(quals) + 1, dtype=np.uint64)
+            np.cumsum([len(x) for x in quals], out=qo[1:])
+            qa = np.concatenate([np.asarray(x, dtype=np.uint8) for x in quals])
+        L = lib()
+        L.rvn_polish_round_range.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double,
+                                             C.c_double, C.c_uint32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                             C.c_uint64, C.c_uint64] + [C.c_void_p] * 7
+        _check(L.rvn_polish_round_range(self._h, targets._h, reads._h, _p(qa), _p(qo), float(q), float(err), w,
+                                        int(trim), m, n, g, int(window_first), int(window_last), _p(out), _p(ooff),
+                                        _p(out_len), None, _p(nw), _p(npol), _p(stats)))
+        cons = [out[int(ooff[i]): int(ooff[i]) + int(out_len[i])].copy() for i in range(nt)]
+        return cons, nw, npol, {"n_windows": int(stats[3]), "n_layers": int(stats[2])}
+
     def polish_round(self, targets: Reads, reads: Reads, quals=None, q=0.0, err=0.3, w=500, trim=True, m=3, n=-5, g=-4):
         """quals: list of uint8 Phred+33 arrays (one per read) or None.  Returns (list of polished code arrays,
         ratio array, stats dict).  The engine must have k=15, w=5 (racon's mapping parameters)."""

@@ -354,3 +354,38 @@ def find_overlaps_and_create_piles_sharded_dev(eng, rs_all: seqio.ReadSet, comm,
                 overlap_off=(koff[lo:hi + 1] - koff[lo]).astype(np.uint32),
                 stats=dict(minimizers_sent=int(n - cnt[g]), matches_sent=int(n_m - m_split[g]), overlaps_sent=int(sent),
                            map_overlaps=int(n_o), bytes_sent=comm.bytes_sent))
+
+
+# ---- polishing round sharded by windows (windows are independent; no data-path collective but the final gather) ----
+def polish_round_sharded(eng, targets, reads, comm, targets_rs, quals=None, q=0.0, err=0.3, w=500, trim=True,
+                         m=3, n=-5, g=-4):
+    """One racon round with the window range split evenly over the ranks.  Every rank holds the targets and the read
+    set (`targets`, `reads`: uploaded handles; `targets_rs`: the host ReadSet of the targets), maps the reads (replicated,
+    ~15 % of a round) and runs the POA of its own windows only; the per-target consensus pieces are all-gathered and
+    concatenated in rank order, which reproduces the single-GPU round byte for byte.  Returns (consensus list, ratio)."""
+    lengths = targets_rs.lengths.astype(np.int64)
+    n_win = int(((lengths + w - 1) // w).sum())
+    lo = n_win * comm.rank // comm.world
+    hi = n_win * (comm.rank + 1) // comm.world
+    cons, nw, npol, _ = eng.polish_round_range(targets, reads, lo, hi, quals=quals, q=q, err=err, w=w, trim=trim, m=m,
+                                               n=n, g=g)
+    nt = len(cons)
+    lens = np.array([len(c) for c in cons], dtype=np.int64)
+    all_lens = comm.all_gather_v(lens).reshape(comm.world, nt)
+    flat = np.concatenate(cons) if nt else np.zeros(0, np.uint8)
+    pad = (-flat.shape[0]) % 8
+    words = np.concatenate([flat, np.zeros(pad, np.uint8)]).view(np.int64)
+    word_cnt = comm.all_gather_v(np.array([words.shape[0]], dtype=np.int64))
+    all_words = comm.all_gather_v(words)
+    counts = comm.all_reduce_sum(np.stack([nw.astype(np.int64), npol.astype(np.int64)]))
+    out = [[] for _ in range(nt)]
+    wo = 0
+    for r in range(comm.world):
+        b = all_words[wo:wo + int(word_cnt[r])].view(np.uint8)
+        wo += int(word_cnt[r])
+        o = 0
+        for t in range(nt):
+            out[t].append(b[o:o + int(all_lens[r, t])])
+            o += int(all_lens[r, t])
+    ratio = np.where(counts[0] > 0, counts[1] / np.maximum(counts[0], 1), 0.0)
+    return [np.concatenate(p) if p else np.zeros(0, np.uint8) for p in out], ratio

@@ -124,3 +124,23 @@ def test_hash_owner_torch_equals_numpy():
         a = sharded.hash_owner(v, world)
         b = sharded.hash_owner_t(torch.from_numpy(v.view(np.int64)).cuda(), world).cpu().numpy()
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_polishing_round_sharded_by_windows_is_byte_identical(world):
+    from raven_amd import seqio
+    from tests import polish_util
+    truths, drafts, targets_rs, reads_rs, _ = polish_util.make_case(genome_len=40_000, coverage=20, read_len=3000, seed=31,
+                                                                    n_targets=3)
+    eng0 = hip.Engine(15, 5)
+    ref, ref_ratio, _ = eng0.polish_round(eng0.upload(targets_rs), eng0.upload(reads_rs))
+
+    def rank_fn(r, comm):
+        eng = hip.Engine(15, 5)
+        return sharded.polish_round_sharded(eng, eng.upload(targets_rs), eng.upload(reads_rs), comm, targets_rs)
+
+    res = sharded_util.run_ranks(world, rank_fn)
+    for cons, ratio in res:
+        assert np.allclose(ratio, ref_ratio)
+        for t in range(3):
+            assert np.array_equal(cons[t], ref[t])
