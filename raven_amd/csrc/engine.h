@@ -2,6 +2,7 @@
 #pragma once
 
 #include <string>
+#include <memory>
 #include <vector>
 
 #include "common.h"
@@ -84,6 +85,8 @@ struct StageTimes {
   u64 launches[kNum] = {};
 };
 
+struct PileState;
+
 struct Engine {
   u32 k, w, bandwidth, chain, matches, gap;
   int device = 0;
@@ -124,6 +127,8 @@ struct Engine {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   u64* h_pin = nullptr;  // pinned host scratch for small device->host size read-backs
   PinBuf pin_big;        // pinned staging for bulk read-backs (polishing: chain anchors)
+  PileState* pile_pool = nullptr;  // buffers of the last destroyed pass, adopted by the next one (engine.hip)
+  std::shared_ptr<int> life = std::make_shared<int>(0);  // lets handles notice that their engine is gone
 };
 
 // Reads one 4- or 8-byte value from the device through pinned memory (stream-ordered, then synchronises).

@@ -20,9 +20,20 @@ struct rvn_engine {
 struct rvn_reads {
   ReadsDev r;
 };
+// The pile buffers (coverage, kept lists, merge scratch: a dozen allocations) are recycled through the engine:
+// destroying a pass hands them back, the next pass adopts them, so steady-state passes do not touch the allocator.
 struct rvn_pass1 {
   Engine* e = nullptr;
-  PileState ps;
+  std::unique_ptr<PileState> state;
+  PileState& ps;
+  std::weak_ptr<int> engine_life;  // a handle may outlive its engine (e.g. interpreter teardown order)
+  explicit rvn_pass1(Engine& eng)
+      : e(&eng), state(eng.pile_pool ? eng.pile_pool : new PileState()), ps(*state), engine_life(eng.life) {
+    eng.pile_pool = nullptr;
+  }
+  ~rvn_pass1() {
+    if (!engine_life.expired() && !e->pile_pool) e->pile_pool = state.release();
+  }
 };
 
 namespace {
@@ -177,6 +188,8 @@ void rvn_engine_destroy(rvn_engine* h) {
   if (h->e.ev1) (void)hipEventDestroy(h->e.ev1);
   if (h->e.stream) (void)hipStreamDestroy(h->e.stream);
   if (h->e.h_pin) (void)hipHostFree(h->e.h_pin);
+  delete h->e.pile_pool;
+  h->e.pile_pool = nullptr;
   delete h;
 }
 
@@ -326,8 +339,7 @@ int rvn_find_overlaps_and_create_piles(rvn_engine* h, const rvn_reads* rr, doubl
       if (r.h_id[i] != i) return fail(RVN_EINVAL, "[raven_hip] FindOverlapsAndCreatePiles requires ids[i] == i");
     RVN_HIP(hipSetDevice(e.device));
     UseTimers ut(e);
-    std::unique_ptr<rvn_pass1> p(new rvn_pass1());
-    p->e = &e;
+    std::unique_ptr<rvn_pass1> p(new rvn_pass1(e));
     piles_init(e, r, p->ps);
     const u32 n = r.n;
     // construct.cc:32-120
@@ -738,8 +750,7 @@ int rvn_shard_piles(rvn_engine* h, const uint32_t* lengths, uint32_t n_reads_tot
     if (n) RVN_HIP(hipMemcpy(d_ov, ov, n * sizeof(Overlap), hipMemcpyHostToDevice));
     u32* d_off = mo.ovl_read_off.get<u32>(off.size());
     RVN_HIP(hipMemcpy(d_off, off.data(), off.size() * 4, hipMemcpyHostToDevice));
-    std::unique_ptr<rvn_pass1> p(new rvn_pass1());
-    p->e = &e;
+    std::unique_ptr<rvn_pass1> p(new rvn_pass1(e));
     piles_init(e, meta, p->ps);
     piles_merge(e, meta, mo, kmax, p->ps);
     RVN_HIP(hipStreamSynchronize(e.stream));
@@ -920,8 +931,7 @@ int rvn_shard_piles_dev(rvn_engine* h, const uint32_t* lengths, uint32_t n_reads
     u32* d_off = mo.ovl_read_off.get<u32>(static_cast<size_t>(n_reads_total) + 1);
     RVN_HIP(hipMemcpyAsync(d_off, d_ovl_read_off, (static_cast<size_t>(n_reads_total) + 1) * 4, hipMemcpyDeviceToDevice,
                            e.stream));
-    std::unique_ptr<rvn_pass1> p(new rvn_pass1());
-    p->e = &e;
+    std::unique_ptr<rvn_pass1> p(new rvn_pass1(e));
     piles_init(e, meta, p->ps);
     piles_merge(e, meta, mo, kmax, p->ps);
     RVN_HIP(hipStreamSynchronize(e.stream));
