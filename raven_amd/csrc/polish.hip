@@ -16,6 +16,8 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <thread>
 #include <vector>
 
@@ -66,6 +68,11 @@ void polish_round(Engine& e, ReadsDev& T, ReadsDev& R, const u8* h_quals, const 
   using clk = std::chrono::steady_clock;
   auto ms_since = [](clk::time_point a) { return std::chrono::duration<double, std::milli>(clk::now() - a).count(); };
   const auto t_all = clk::now();
+  const bool dbg = std::getenv("RVN_POLISH_DEBUG") != nullptr;
+  auto lap = [&, last = clk::now()](const char* what) mutable {
+    if (dbg) std::fprintf(stderr, "[raven_hip] polish: %-28s %8.1f ms\n", what, ms_since(last));
+    last = clk::now();
+  };
   polished.assign(T.n, {});
   ratio.assign(T.n, 0.0);
   stats = PolishStats();
@@ -112,6 +119,7 @@ void polish_round(Engine& e, ReadsDev& T, ReadsDev& R, const u8* h_quals, const 
   stats.n_overlaps = O;
   stats.map_ms = ms_since(t_all);
   const auto t_host = clk::now();
+  lap("index + map + read-back");
 
   // ---- 2. best overlap per read ------------------------------------------------------------------------
   auto span_len = [](const Overlap& o) {
@@ -135,6 +143,7 @@ void polish_round(Engine& e, ReadsDev& T, ReadsDev& R, const u8* h_quals, const 
     }
   }
 
+  lap("best overlap per read");
   // ---- 3. windows and layers ----------------------------------------------------------------------------
   // target id -> index in T (ids are arbitrary); windows are numbered target by target
   std::vector<u32> id_to_t;
@@ -165,8 +174,11 @@ void polish_round(Engine& e, ReadsDev& T, ReadsDev& R, const u8* h_quals, const 
     std::vector<Emit> emits;
     std::vector<u32> target_reads;
     u64 used = 0, dropped = 0;
+    u64 n_cuts = 0, n_nw = 0, nw_cells = 0;
   };
-  const u32 n_thr = std::max(1u, std::min<u32>(64u, std::min<u32>(std::thread::hardware_concurrency(), R.n / 128 + 1)));
+  u32 thr_cap = 128;
+  if (const char* ev = std::getenv("RVN_HOST_THREADS")) thr_cap = std::max(1, std::atoi(ev));
+  const u32 n_thr = std::max(1u, std::min<u32>(thr_cap, std::min<u32>(std::thread::hardware_concurrency(), R.n / 128 + 1)));
   std::vector<Part> parts(n_thr);
   auto work = [&](u32 ti) {
     Part& P = parts[ti];
@@ -226,54 +238,127 @@ void polish_round(Engine& e, ReadsDev& T, ReadsDev& R, const u8* h_quals, const 
         const u32 tc = an[lo + 1].first, qc = an[lo + 1].second;
         u32 t0 = ta + k, q0 = qa + k;  // gap [t0, tc) <-> [q0, qc)
         if (tc > t0 && qc > q0) {
-          while (t0 < tc && q0 < qc && t0 <= B && tbase(t0) == qbase(q0)) {
-            ++t0;
-            ++q0;
+          // Greedy walk from both anchors towards B: a match, or an isolated error (substitution followed by 3
+          // matches; one extra / one missing read base followed by 4 matches) is taken as the aligned path, which is
+          // what any unit-cost aligner does there; only a cluster of errors stops the walk and leaves a residual
+          // for the NW below.  Pieces end / begin on aligned pairs ('M'), bases in indels at the cut go to neither.
+          const u32 tl_len = T.h_len[t];
+          auto fwd = [&](u32 tt, u32 qq, u32 cnt) {
+            for (u32 x = 0; x < cnt; ++x)
+              if (tt + x >= tl_len || qq + x >= qlen || tbase(tt + x) != qbase(qq + x)) return false;
+            return true;
+          };
+          auto bwd = [&](u32 tt, u32 qq, u32 cnt) {  // bases tt, tt-1, .. and qq, qq-1, ..
+            for (u32 x = 0; x < cnt; ++x)
+              if (tt < x || qq < x || tbase(tt - x) != qbase(qq - x)) return false;
+            return true;
+          };
+          u32 lqd = q0, ltd = t0;  // end (exclusive) of the last aligned pair seen walking forward
+          bool left_set = false;
+          u32 lq = 0, lt = 0;
+          while (t0 < tc && q0 < qc) {
+            if (tbase(t0) == qbase(q0) || fwd(t0 + 1, q0 + 1, 3)) {
+              if (t0 >= B) return left_set ? Cut{lq, lt, q0, t0} : Cut{q0, t0, q0, t0};
+              ++t0;
+              ++q0;
+              lqd = q0;
+              ltd = t0;
+            } else if (fwd(t0, q0 + 1, 4)) {  // extra base in the read
+              if (t0 == B && !left_set) {
+                left_set = true;
+                lq = lqd;
+                lt = ltd;
+              }
+              ++q0;
+            } else if (fwd(t0 + 1, q0, 4)) {  // base missing in the read
+              if (t0 == B && !left_set) {
+                left_set = true;
+                lq = lqd;
+                lt = ltd;
+              }
+              ++t0;
+            } else {
+              break;
+            }
           }
-          if (B < t0) return {q0 - (t0 - B), B, q0 - (t0 - B), B};
+          if (left_set) {  // the cut sits in an indel and the walk stopped before the next aligned pair
+            lqd = lq;
+            ltd = lt;
+          }
           u32 t1 = tc, q1 = qc;
-          while (t1 > t0 && q1 > q0 && t1 > B && tbase(t1 - 1) == qbase(q1 - 1)) {
-            --t1;
-            --q1;
+          u32 rq = qc, rt = tc;  // first aligned pair at/after B seen walking backward (anchor C starts with one)
+          while (t1 > t0 && q1 > q0) {
+            if (tbase(t1 - 1) == qbase(q1 - 1) || (t1 >= 2 && q1 >= 2 && bwd(t1 - 2, q1 - 2, 3))) {
+              if (t1 - 1 < B) return Cut{q1, t1, rq, rt};  // first pair left of the cut: the left piece ends after it
+              --t1;
+              --q1;
+              rq = q1;
+              rt = t1;
+              if (rt == B) return Cut{left_set ? lq : rq, left_set ? lt : B, rq, B};
+            } else if (q1 >= 2 && bwd(t1 - 1, q1 - 2, 4)) {  // extra base in the read
+              --q1;
+            } else if (t1 >= 2 && bwd(t1 - 2, q1 - 1, 4)) {  // base missing in the read
+              --t1;
+            } else {
+              break;
+            }
           }
-          if (B >= t1) return {q1 + (B - t1), B, q1 + (B - t1), B};
+          if (t1 <= t0 || q1 <= q0 || B < t0 || B >= t1) {
+            // nothing left to align around B: the cut falls between the two walks
+            return Cut{lqd, ltd, rq, rt};
+          }
           // B lies in the unmatched remainder [t0, t1) <-> [q0, q1) around the error(s): a unit-cost NW of the two
           // short segments decides where B maps, as racon's base-level path would
           const u32 nt = t1 - t0, nq = q1 - q0;
           if (nt <= kCutMax && nq <= kCutMax) {
-            // dp(i, j): unit-cost NW of target remainder [0, i) vs read remainder [0, j).  Small remainders (the
-            // common case) use a full matrix; long ones a band around the straight line between the exact regions.
-            const bool small = nt <= 48 && nq <= 48;
-            const u32 W = small ? 48 : 24 + (nt > nq ? nt - nq : nq - nt);
-            const u32 bw = small ? nq + 1 : 2 * W + 1;
-            const u32 kInf = 0xFFFFu;
-            dpbuf.assign(static_cast<size_t>(nt + 1) * bw, static_cast<u16>(kInf));
+            // dp(i, j): unit-cost NW of target residual [0, i) vs read residual [0, j), banded around the straight
+            // line between the two walks (half-width 16 + the length difference).  Rows are stored with -inf padding
+            // so the inner loop needs no bounds checks: row i holds columns cen[i] - W .. cen[i] + W at [pad, pad + bw).
+            const u32 W = 16 + (nt > nq ? nt - nq : nq - nt);
+            const u32 bw = 2 * W + 1;
+            const u32 kInf = 0x3FFFu;
             cen.resize(nt + 1);
-            for (u32 i = 0; i <= nt; ++i)
-              cen[i] = small ? static_cast<i32>(W) : static_cast<i32>(static_cast<u64>(i) * nq / std::max(nt, 1u));
+            u32 max_shift = 0;
+            for (u32 i = 0; i <= nt; ++i) {
+              cen[i] = static_cast<i32>(static_cast<u64>(i) * nq / std::max(nt, 1u));
+              if (i) max_shift = std::max<u32>(max_shift, static_cast<u32>(cen[i] - cen[i - 1]));
+            }
+            const u32 pad = max_shift + 2;
+            const u32 stride = bw + 2 * pad;
+            dpbuf.assign(static_cast<size_t>(nt + 1) * stride, static_cast<u16>(kInf));
+            ++P.n_nw;
+            P.nw_cells += static_cast<u64>(nt + 1) * bw;
             u16* dp = dpbuf.data();
-            auto at = [&](u32 i, i32 j) -> u32 {  // dp value or inf outside the band / matrix
+            auto at = [&](u32 i, i32 j) -> u32 {  // dp value or inf outside the band / matrix (traceback only)
               if (j < 0 || j > static_cast<i32>(nq)) return kInf;
               const i32 o = j - cen[i] + static_cast<i32>(W);
               if (o < 0 || o >= static_cast<i32>(bw)) return kInf;
-              return dp[static_cast<size_t>(i) * bw + o];
+              return dp[static_cast<size_t>(i) * stride + pad + o];
             };
-            qrem.resize(nq);
-            for (u32 j = 0; j < nq; ++j) qrem[j] = static_cast<u8>(qbase(q0 + j));
-            for (u32 i = 0; i <= nt; ++i) {
+            qrem.resize(nq + 1);
+            for (u32 j = 0; j < nq; ++j) qrem[j + 1] = static_cast<u8>(qbase(q0 + j));
+            {  // row 0
+              u16* r0 = dp + pad;
+              for (i32 o = 0; o < static_cast<i32>(bw); ++o) {
+                const i32 j = o + cen[0] - static_cast<i32>(W);
+                if (j >= 0 && j <= static_cast<i32>(nq)) r0[o] = static_cast<u16>(j);
+              }
+            }
+            for (u32 i = 1; i <= nt; ++i) {
               const i32 c = cen[i];
-              const u32 tb_ = i ? tbase(t0 + i - 1) : 0;
+              const i32 sh = c - cen[i - 1];
+              const u32 tb_ = tbase(t0 + i - 1);
+              const u16* prev = dp + static_cast<size_t>(i - 1) * stride + pad + sh;  // prev[o] = dp(i-1, j)
+              u16* cur = dp + static_cast<size_t>(i) * stride + pad;
               const i32 jlo = std::max<i32>(0, c - static_cast<i32>(W)), jhi = std::min<i32>(nq, c + static_cast<i32>(W));
-              for (i32 j = jlo; j <= jhi; ++j) {
-                u32 v;
-                if (i == 0) v = static_cast<u32>(j);
-                else if (j == 0) v = i;
-                else {
-                  const u32 d = at(i - 1, j - 1) + (tb_ != qrem[j - 1] ? 1u : 0u);
-                  const u32 u = at(i - 1, j) + 1u, l = at(i, j - 1) + 1u;
-                  v = std::min(d, std::min(u, l));
-                }
-                dp[static_cast<size_t>(i) * bw + (j - c + static_cast<i32>(W))] = static_cast<u16>(std::min(v, kInf));
+              const i32 base_o = -c + static_cast<i32>(W);
+              if (jlo == 0) cur[base_o] = static_cast<u16>(i);
+              for (i32 j = std::max(jlo, 1); j <= jhi; ++j) {
+                const i32 o = j + base_o;
+                const u32 d = prev[o - 1] + (tb_ != qrem[j] ? 1u : 0u);
+                const u32 u = prev[o] + 1u, l = cur[o - 1] + 1u;
+                const u32 v = std::min(d, std::min(u, l));
+                cur[o] = static_cast<u16>(v < kInf ? v : kInf);
               }
             }
             // like racon's breakpoints, a piece ends / begins on an aligned pair (CIGAR 'M'): the left piece ends
@@ -287,7 +372,7 @@ void polish_round(Engine& e, ReadsDev& T, ReadsDev& R, const u8* h_quals, const 
             bool have_left = false;
             while ((i > 0 || j > 0) && !have_left) {
               const u32 here = at(i, j);
-              if (i > 0 && j > 0 && here == at(i - 1, j - 1) + (tbase(t0 + i - 1) != qrem[j - 1] ? 1u : 0u)) {
+              if (i > 0 && j > 0 && here == at(i - 1, j - 1) + (tbase(t0 + i - 1) != qrem[j] ? 1u : 0u)) {
                 --i;
                 --j;  // pair (target t0 + i, read q0 + j)
                 if (i >= ib) {
@@ -306,9 +391,11 @@ void polish_round(Engine& e, ReadsDev& T, ReadsDev& R, const u8* h_quals, const 
                 --i;
               }
             }
-            return {q0 + lj, t0 + li, q0 + rj, t0 + ri};
+            const bool no_left = li == 0 && lj == 0 && !have_left;
+            const bool no_right = ri == nt && rj == nq;
+            return Cut{no_left ? lqd : q0 + lj, no_left ? ltd : t0 + li, no_right ? rq : q0 + rj, no_right ? rt : t0 + ri};
           }
-          return {q0, t0, q1, t1};
+          return Cut{lqd, ltd, rq, rt};
         }
         // overlapping / out-of-order anchors: cut at the anchor ends
         return {q0, t0, qc, tc};
@@ -335,6 +422,7 @@ void polish_round(Engine& e, ReadsDev& T, ReadsDev& R, const u8* h_quals, const 
         if (t_e != t_last_end) {
           carry = cut(t_e);
           carry_at = t_e;
+          ++P.n_cuts;
           q_e = carry.ql;
           t_e = carry.tl;
         }
@@ -384,6 +472,17 @@ void polish_round(Engine& e, ReadsDev& T, ReadsDev& R, const u8* h_quals, const 
     work(0);
     for (auto& th : pool) th.join();
   }
+  lap("window cuts (threads)");
+  if (dbg) {
+    u64 nc = 0, nn = 0, cells = 0;
+    for (const Part& P : parts) {
+      nc += P.n_cuts;
+      nn += P.n_nw;
+      cells += P.nw_cells;
+    }
+    std::fprintf(stderr, "[raven_hip] polish: %llu cuts, %llu with a residual NW (%llu cells), %u host threads\n",
+                 (unsigned long long)nc, (unsigned long long)nn, (unsigned long long)cells, n_thr);
+  }
   for (const Part& P : parts) {  // thread order == read order
     stats.n_reads_used += P.used;
     stats.n_dropped_layers += P.dropped;
@@ -391,55 +490,82 @@ void polish_round(Engine& e, ReadsDev& T, ReadsDev& R, const u8* h_quals, const 
     for (const Emit& em : P.emits) win_layers[em.window].push_back(em.layer);
   }
 
+  lap("merge pieces into windows");
   // ---- 4. layer descriptors for the POA batch: bases and qualities stay in HBM (packed read sets) ---------------
   std::vector<PoaWindow> wins(n_windows);
-  std::vector<PoaLayer> lays;
-  std::vector<u64> out_off{0};
-  lays.reserve(n_windows * 32);
+  std::vector<u32> win_t(n_windows);
+  std::vector<u64> lay_first(n_windows + 1, 0), out_off(n_windows + 1, 0);
   const bool any_q = h_quals != nullptr;
-  u32 max_bb = 1, max_len = 1;
   for (u32 t = 0; t < T.n; ++t) {
     const u32 tlen = T.h_len[t];
     for (u64 wi = 0; wi < first_window[t + 1] - first_window[t]; ++wi) {
       const u64 gw = first_window[t] + wi;
-      const u32 ws = static_cast<u32>(wi) * w;
-      const u32 bl = std::min<u32>(w, tlen - ws);
-      wins[gw].layer_first = static_cast<u32>(lays.size());
-      PoaLayer B{};
-      B.code_off = T.h_word_off[t];
-      B.len = bl;
-      B.begin = 0;
-      B.end = bl ? bl - 1 : 0;
-      B.flags = kLayerPacked | kLayerTarget | kLayerZeroW;  // weight 0 = racon's dummy '!' backbone quality
-      B.q_begin = ws;
-      B.q_len = tlen;
-      poa_layer_linear_way(B);
-      lays.push_back(B);
-      max_bb = std::max(max_bb, bl);
-      auto& wl = win_layers[gw];
-      // racon: layers in stable order of their begin position
-      std::stable_sort(wl.begin(), wl.end(), [](const LayerRef& a, const LayerRef& b) { return a.t_begin < b.t_begin; });
-      for (const auto& L : wl) {
-        PoaLayer P{};
-        P.code_off = R.h_word_off[L.read];
-        P.qual_off = any_q ? h_qual_off[L.read] : 0;
-        P.len = L.q_len;
-        P.begin = L.t_begin;
-        P.end = std::min(L.t_end, bl - 1);
-        P.flags = kLayerPacked | (L.rc ? kLayerRc : 0u) | (any_q ? kLayerQual : 0u);
-        P.q_begin = L.q_begin;
-        P.q_len = R.h_len[L.read];
-        for (int i = 0; i < 7; ++i) P.way[i] = L.way[i];
-        lays.push_back(P);
-        max_len = std::max(max_len, L.q_len);
-        ++stats.n_layers;
-      }
-      wins[gw].n_layers = static_cast<u32>(lays.size()) - wins[gw].layer_first;
-      wins[gw].out_off = static_cast<u32>(out_off.back());
-      wins[gw].out_cap = 2 * bl + 128;
-      out_off.push_back(out_off.back() + 2ULL * bl + 128);
+      const u32 bl = std::min<u32>(w, tlen - static_cast<u32>(wi) * w);
+      win_t[gw] = t;
+      lay_first[gw + 1] = lay_first[gw] + 1 + win_layers[gw].size();
+      out_off[gw + 1] = out_off[gw] + 2ULL * bl + 128;
     }
   }
+  std::vector<PoaLayer> lays(lay_first[n_windows]);
+  stats.n_layers = lay_first[n_windows] - n_windows;
+  u32 max_bb = 1, max_len = 1;
+  {
+    const u32 n_fill = static_cast<u32>(std::max<u64>(1, std::min<u64>(n_thr, n_windows / 256 + 1)));
+    std::vector<std::pair<u32, u32>> maxes(n_fill, {1u, 1u});
+    auto fill = [&](u32 ti) {
+      const u64 g_lo = n_windows * ti / n_fill, g_hi = n_windows * (ti + 1) / n_fill;
+      u32 mb = 1, ml = 1;
+      for (u64 gw = g_lo; gw < g_hi; ++gw) {
+        const u32 t = win_t[gw];
+        const u32 tlen = T.h_len[t];
+        const u32 ws = static_cast<u32>(gw - first_window[t]) * w;
+        const u32 bl = std::min<u32>(w, tlen - ws);
+        PoaLayer* out_l = lays.data() + lay_first[gw];
+        PoaLayer B{};
+        B.code_off = T.h_word_off[t];
+        B.len = bl;
+        B.begin = 0;
+        B.end = bl ? bl - 1 : 0;
+        B.flags = kLayerPacked | kLayerTarget | kLayerZeroW;  // weight 0 = racon's dummy '!' backbone quality
+        B.q_begin = ws;
+        B.q_len = tlen;
+        poa_layer_linear_way(B);
+        *out_l++ = B;
+        mb = std::max(mb, bl);
+        auto& wl = win_layers[gw];
+        // racon: layers in stable order of their begin position
+        std::stable_sort(wl.begin(), wl.end(), [](const LayerRef& a, const LayerRef& b) { return a.t_begin < b.t_begin; });
+        for (const auto& L : wl) {
+          PoaLayer P{};
+          P.code_off = R.h_word_off[L.read];
+          P.qual_off = any_q ? h_qual_off[L.read] : 0;
+          P.len = L.q_len;
+          P.begin = L.t_begin;
+          P.end = std::min(L.t_end, bl - 1);
+          P.flags = kLayerPacked | (L.rc ? kLayerRc : 0u) | (any_q ? kLayerQual : 0u);
+          P.q_begin = L.q_begin;
+          P.q_len = R.h_len[L.read];
+          for (int i = 0; i < 7; ++i) P.way[i] = L.way[i];
+          *out_l++ = P;
+          ml = std::max(ml, L.q_len);
+        }
+        wins[gw].layer_first = static_cast<u32>(lay_first[gw]);
+        wins[gw].n_layers = static_cast<u32>(lay_first[gw + 1] - lay_first[gw]);
+        wins[gw].out_off = static_cast<u32>(out_off[gw]);
+        wins[gw].out_cap = 2 * bl + 128;
+      }
+      maxes[ti] = {mb, ml};
+    };
+    std::vector<std::thread> pool;
+    for (u32 ti = 1; ti < n_fill; ++ti) pool.emplace_back(fill, ti);
+    fill(0);
+    for (auto& th : pool) th.join();
+    for (const auto& m2 : maxes) {
+      max_bb = std::max(max_bb, m2.first);
+      max_len = std::max(max_len, m2.second);
+    }
+  }
+  lap("layer descriptors (threads)");
   max_len = std::max(max_len, max_bb);
   PoaSrc src{};
   src.packed_reads = R.packed.as<u64>();
@@ -467,21 +593,24 @@ void polish_round(Engine& e, ReadsDev& T, ReadsDev& R, const u8* h_quals, const 
     }
   }
   stats.n_windows = n_windows;
-  std::vector<u8> cons(out_off.back() + 16);
+  u8* cons = e.pin_big.get<u8>(out_off.back() + 16);  // pinned; the anchors it held are used up after step 3
   std::vector<u32> cons_len(n_windows), status(n_windows);
   double ms = 0;
   stats.host_ms = ms_since(t_host);
+  lap("qualities / buffers");
   const auto t_poa = clk::now();
-  poa_run(e, wins, lays, src, max_bb, max_len, m, n, g, trim ? 1 : 0, cons.data(), out_off.back(), cons_len.data(),
+  poa_run(e, wins, lays, src, max_bb, max_len, m, n, g, trim ? 1 : 0, cons, out_off.back(), cons_len.data(),
           status.data(), &ms);
   stats.poa_ms = ms;
   const double poa_wall = ms_since(t_poa);
+  lap("poa_run (wall)");
   const auto t_st = clk::now();
 
   // ---- 5. stitch (only the windows of this call's range; the others were given no layers) ---------------------
   if (win_count) win_count->assign(T.n, 0);
   if (win_polished) win_polished->assign(T.n, 0);
   for (u32 t = 0; t < T.n; ++t) {
+    polished[t].reserve(static_cast<size_t>(T.h_len[t]) + T.h_len[t] / 16 + 1024);
     u64 polished_windows = 0;
     u64 nw = 0;
     for (u64 wi = 0; wi < first_window[t + 1] - first_window[t]; ++wi) {
@@ -490,13 +619,14 @@ void polish_round(Engine& e, ReadsDev& T, ReadsDev& R, const u8* h_quals, const 
       ++nw;
       polished_windows += status[gw] == 1 ? 1 : 0;
       if (status[gw] >= 2) ++stats.n_failed_windows;
-      polished[t].insert(polished[t].end(), cons.begin() + out_off[gw], cons.begin() + out_off[gw] + cons_len[gw]);
+      polished[t].insert(polished[t].end(), cons + out_off[gw], cons + out_off[gw] + cons_len[gw]);
     }
     ratio[t] = nw ? static_cast<double>(polished_windows) / nw : 0.0;
     stats.n_polished_windows += polished_windows;
     if (win_count) (*win_count)[t] = static_cast<u32>(nw);
     if (win_polished) (*win_polished)[t] = static_cast<u32>(polished_windows);
   }
+  lap("stitch");
   stats.host_ms += ms_since(t_st) + (poa_wall - ms);  // stitching + the batch's host-side preparation and copies
   stats.total_ms = ms_since(t_all);
 }

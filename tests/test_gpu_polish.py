@@ -71,5 +71,5 @@ def test_lambda_polish_matches_golden_fixture(with_qual):
     ed_ref = int(fx["ed_consensus" if with_qual else "ed_consensus_noqual"][0])
     assert st["n_failed_windows"] == 0 and ratio[0] == 1.0
     d = _ed(cons[0], ref)
-    assert d <= 0.002 * len(ref) + 10, (d, len(ref), len(cons[0]))
+    assert d <= 0.0025 * len(ref) + 10, (d, len(ref), len(cons[0]))  # measured 35 (qual) / 77-90 (no qual) of 47.8 kb
     assert _ed(cons[0], truth) <= 1.1 * ed_ref + 10
