@@ -209,6 +209,10 @@ int rvn_polish_round_range(rvn_engine* e, rvn_reads* targets, rvn_reads* reads, 
                            const uint64_t* out_offsets, uint32_t* out_len, double* ratio, uint32_t* n_windows,
                            uint32_t* n_polished, rvn_polish_stats* stats);
 
+/* Windows per POA chunk of a polishing round: the host cuts the reads of chunk i+1 while the GPU runs the POA of
+ * chunk i (default 16384; 0 = one batch).  Results do not depend on it.  Returns the previous value. */
+uint64_t rvn_polish_set_chunk_windows(rvn_engine* e, uint64_t windows);
+
 /* reads used per target (their best overlap passed the error filter) in the last rvn_polish_round call: the RC:i:
  * tag racon writes next to XC:f: */
 int rvn_polish_target_reads(const rvn_engine* e, uint32_t* counts, uint32_t n_targets);

@@ -127,6 +127,8 @@ struct Engine {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   u64* h_pin = nullptr;  // pinned host scratch for small device->host size read-backs
   PinBuf pin_big;        // pinned staging for bulk read-backs (polishing: chain anchors)
+  PinBuf pin_out;        // pinned consensus buffer of the POA chunk in flight
+  u64 polish_chunk_windows = 16384;  // windows per POA chunk of a polishing round (0 = everything in one batch)
   PileState* pile_pool = nullptr;  // buffers of the last destroyed pass, adopted by the next one (engine.hip)
   std::shared_ptr<int> life = std::make_shared<int>(0);  // lets handles notice that their engine is gone
 };

@@ -940,6 +940,13 @@ int rvn_shard_piles_dev(rvn_engine* h, const uint32_t* lengths, uint32_t n_reads
   });
 }
 
+uint64_t rvn_polish_set_chunk_windows(rvn_engine* h, uint64_t windows) {
+  if (!h) return 0;
+  const uint64_t prev = h->e.polish_chunk_windows;
+  h->e.polish_chunk_windows = windows;
+  return prev;
+}
+
 int rvn_polish_target_reads(const rvn_engine* h, uint32_t* counts, uint32_t n_targets) {
   if (!h || !counts || n_targets != h->e.polish_target_reads.size())
     return fail(RVN_EINVAL, "[raven_hip] rvn_polish_target_reads: no polishing round with that many targets");

@@ -18,6 +18,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <exception>
 #include <thread>
 #include <vector>
 
@@ -118,7 +119,6 @@ void polish_round(Engine& e, ReadsDev& T, ReadsDev& R, const u8* h_quals, const 
   RVN_HIP(hipMemcpy(roff.data(), mo.ovl_read_off.ptr, roff.size() * 4, hipMemcpyDeviceToHost));
   stats.n_overlaps = O;
   stats.map_ms = ms_since(t_all);
-  const auto t_host = clk::now();
   lap("index + map + read-back");
 
   // ---- 2. best overlap per read ------------------------------------------------------------------------
@@ -156,11 +156,13 @@ void polish_round(Engine& e, ReadsDev& T, ReadsDev& R, const u8* h_quals, const 
   std::vector<u64> first_window(static_cast<size_t>(T.n) + 1, 0);
   for (u32 t = 0; t < T.n; ++t) first_window[t + 1] = first_window[t] + (static_cast<u64>(T.h_len[t]) + w - 1) / w;
   const u64 n_windows = first_window[T.n];
+  std::vector<u32> win_t_all(n_windows);
+  for (u32 t = 0; t < T.n; ++t)
+    for (u64 gw = first_window[t]; gw < first_window[t + 1]; ++gw) win_t_all[gw] = t;
   struct LayerRef {
     u32 read, q_begin, q_len, t_begin, t_end, rc;
     u16 way[7];  // PoaLayer::way: where the chain says the piece is at 1/8 .. 7/8 of its target span
   };
-  std::vector<std::vector<LayerRef>> win_layers(n_windows);
   const u32 k = e.k;
   e.polish_target_reads.assign(T.n, 0);
   // reads are independent: host threads each take a contiguous range of reads and emit (window, layer) pairs;
@@ -179,25 +181,45 @@ void polish_round(Engine& e, ReadsDev& T, ReadsDev& R, const u8* h_quals, const 
   u32 thr_cap = 128;
   if (const char* ev = std::getenv("RVN_HOST_THREADS")) thr_cap = std::max(1, std::atoi(ev));
   const u32 n_thr = std::max(1u, std::min<u32>(thr_cap, std::min<u32>(std::thread::hardware_concurrency(), R.n / 128 + 1)));
-  std::vector<Part> parts(n_thr);
+  // The window range of this call is processed in chunks: while the GPU runs the POA of one chunk (background
+  // thread), the host threads cut the reads of the next one.  A read belongs to every chunk its overlap touches.
+  const u64 W0 = std::min<u64>(win_first, n_windows), W1 = std::min<u64>(win_last, n_windows);
+  const u64 chunk_w = e.polish_chunk_windows ? e.polish_chunk_windows : std::max<u64>(1, W1 - W0);
+  const u32 n_chunks = static_cast<u32>(W1 > W0 ? (W1 - W0 + chunk_w - 1) / chunk_w : 0);
+  std::vector<std::vector<u32>> chunk_reads(n_chunks);
+  for (u32 r = 0; r < R.n; ++r) {
+    if (!best[r].valid) continue;
+    const Overlap& o = best[r].o;
+    if (o.rhs_id >= id_to_t.size() || id_to_t[o.rhs_id] == 0xFFFFFFFFu || best[r].acnt < 2) {
+      best[r].valid = false;
+      continue;
+    }
+    const u32 t = id_to_t[o.rhs_id];
+    ++stats.n_reads_used;
+    ++e.polish_target_reads[t];
+    const u64 g_lo = first_window[t] + o.rhs_begin / w, g_hi = first_window[t] + (o.rhs_end ? (o.rhs_end - 1) / w : 0);
+    if (g_hi < W0 || g_lo >= W1) continue;
+    const u32 c_a = static_cast<u32>((std::max(g_lo, W0) - W0) / chunk_w);
+    const u32 c_b = static_cast<u32>((std::min(g_hi, W1 - 1) - W0) / chunk_w);
+    for (u32 c = c_a; c <= c_b; ++c) chunk_reads[c].push_back(r);
+  }
+  u64 c_lo = 0, c_hi = 0;  // window range of the chunk being cut
+  const std::vector<u32>* cur_reads = nullptr;
+  std::vector<Part> parts;
   auto work = [&](u32 ti) {
     Part& P = parts[ti];
-    P.target_reads.assign(T.n, 0);
-    const u32 r_lo = static_cast<u32>(static_cast<u64>(R.n) * ti / n_thr);
-    const u32 r_hi = static_cast<u32>(static_cast<u64>(R.n) * (ti + 1) / n_thr);
+    const std::vector<u32>& cr = *cur_reads;
+    const size_t i_lo = cr.size() * ti / n_thr, i_hi = cr.size() * (ti + 1) / n_thr;
     std::vector<std::pair<u32, u32>> an;
     std::vector<u16> dpbuf;  // NW of an unmatched remainder (cut())
     std::vector<i32> cen;
     std::vector<u8> qrem;
-    for (u32 r = r_lo; r < r_hi; ++r) {
-      if (!best[r].valid) continue;
+    for (size_t ii = i_lo; ii < i_hi; ++ii) {
+      const u32 r = cr[ii];
       const Overlap& o = best[r].o;
-      if (o.rhs_id >= id_to_t.size() || id_to_t[o.rhs_id] == 0xFFFFFFFFu) continue;
       const u32 t = id_to_t[o.rhs_id];
       const u32 qlen = R.h_len[r];
       const bool rc = o.strand == 0;
-      ++P.used;
-      ++P.target_reads[t];
       // anchors as (t, q') increasing in both; q' in the orientation that matches the target
       an.resize(best[r].acnt);
       for (u32 i = 0; i < best[r].acnt; ++i) {
@@ -405,7 +427,7 @@ void polish_round(Engine& e, ReadsDev& T, ReadsDev& R, const u8* h_quals, const 
       Cut carry{q_first, t_first, q_first, t_first};
       u32 carry_at = 0xFFFFFFFFu;  // boundary `carry` was computed for
       for (u32 wi = t_first / w; static_cast<u64>(wi) * w < t_last_end; ++wi) {
-        if (first_window[t] + wi + 1 < win_first || first_window[t] + wi > win_last) continue;  // far from this rank's range
+        if (first_window[t] + wi + 1 < c_lo || first_window[t] + wi > c_hi) continue;  // far from this chunk
         const u32 ws = wi * w;
         const u32 we = std::min<u32>(T.h_len[t], ws + w);  // exclusive
         u32 t_b = std::max(ws, t_first), t_e = std::min(we, t_last_end);  // [t_b, t_e)
@@ -461,173 +483,214 @@ void polish_round(Engine& e, ReadsDev& T, ReadsDev& R, const u8* h_quals, const 
             prev = off;
           }
         }
-        if (first_window[t] + wi < win_first || first_window[t] + wi >= win_last) continue;  // another rank's window
+        if (first_window[t] + wi < c_lo || first_window[t] + wi >= c_hi) continue;  // another chunk's / rank's window
         P.emits.push_back(Emit{first_window[t] + wi, lr});
       }
     }
   };
-  {
-    std::vector<std::thread> pool;
-    for (u32 ti = 1; ti < n_thr; ++ti) pool.emplace_back(work, ti);
-    work(0);
-    for (auto& th : pool) th.join();
-  }
-  lap("window cuts (threads)");
-  if (dbg) {
-    u64 nc = 0, nn = 0, cells = 0;
-    for (const Part& P : parts) {
-      nc += P.n_cuts;
-      nn += P.n_nw;
-      cells += P.nw_cells;
-    }
-    std::fprintf(stderr, "[raven_hip] polish: %llu cuts, %llu with a residual NW (%llu cells), %u host threads\n",
-                 (unsigned long long)nc, (unsigned long long)nn, (unsigned long long)cells, n_thr);
-  }
-  for (const Part& P : parts) {  // thread order == read order
-    stats.n_reads_used += P.used;
-    stats.n_dropped_layers += P.dropped;
-    for (u32 t = 0; t < T.n; ++t) e.polish_target_reads[t] += P.target_reads[t];
-    for (const Emit& em : P.emits) win_layers[em.window].push_back(em.layer);
-  }
-
-  lap("merge pieces into windows");
-  // ---- 4. layer descriptors for the POA batch: bases and qualities stay in HBM (packed read sets) ---------------
-  std::vector<PoaWindow> wins(n_windows);
-  std::vector<u32> win_t(n_windows);
-  std::vector<u64> lay_first(n_windows + 1, 0), out_off(n_windows + 1, 0);
   const bool any_q = h_quals != nullptr;
-  for (u32 t = 0; t < T.n; ++t) {
-    const u32 tlen = T.h_len[t];
-    for (u64 wi = 0; wi < first_window[t + 1] - first_window[t]; ++wi) {
-      const u64 gw = first_window[t] + wi;
-      const u32 bl = std::min<u32>(w, tlen - static_cast<u32>(wi) * w);
-      win_t[gw] = t;
-      lay_first[gw + 1] = lay_first[gw] + 1 + win_layers[gw].size();
-      out_off[gw + 1] = out_off[gw] + 2ULL * bl + 128;
-    }
-  }
-  std::vector<PoaLayer> lays(lay_first[n_windows]);
-  stats.n_layers = lay_first[n_windows] - n_windows;
-  u32 max_bb = 1, max_len = 1;
-  {
-    const u32 n_fill = static_cast<u32>(std::max<u64>(1, std::min<u64>(n_thr, n_windows / 256 + 1)));
-    std::vector<std::pair<u32, u32>> maxes(n_fill, {1u, 1u});
-    auto fill = [&](u32 ti) {
-      const u64 g_lo = n_windows * ti / n_fill, g_hi = n_windows * (ti + 1) / n_fill;
-      u32 mb = 1, ml = 1;
-      for (u64 gw = g_lo; gw < g_hi; ++gw) {
-        const u32 t = win_t[gw];
-        const u32 tlen = T.h_len[t];
-        const u32 ws = static_cast<u32>(gw - first_window[t]) * w;
-        const u32 bl = std::min<u32>(w, tlen - ws);
-        PoaLayer* out_l = lays.data() + lay_first[gw];
-        PoaLayer B{};
-        B.code_off = T.h_word_off[t];
-        B.len = bl;
-        B.begin = 0;
-        B.end = bl ? bl - 1 : 0;
-        B.flags = kLayerPacked | kLayerTarget | kLayerZeroW;  // weight 0 = racon's dummy '!' backbone quality
-        B.q_begin = ws;
-        B.q_len = tlen;
-        poa_layer_linear_way(B);
-        *out_l++ = B;
-        mb = std::max(mb, bl);
-        auto& wl = win_layers[gw];
-        // racon: layers in stable order of their begin position
-        std::stable_sort(wl.begin(), wl.end(), [](const LayerRef& a, const LayerRef& b) { return a.t_begin < b.t_begin; });
-        for (const auto& L : wl) {
-          PoaLayer P{};
-          P.code_off = R.h_word_off[L.read];
-          P.qual_off = any_q ? h_qual_off[L.read] : 0;
-          P.len = L.q_len;
-          P.begin = L.t_begin;
-          P.end = std::min(L.t_end, bl - 1);
-          P.flags = kLayerPacked | (L.rc ? kLayerRc : 0u) | (any_q ? kLayerQual : 0u);
-          P.q_begin = L.q_begin;
-          P.q_len = R.h_len[L.read];
-          for (int i = 0; i < 7; ++i) P.way[i] = L.way[i];
-          *out_l++ = P;
-          ml = std::max(ml, L.q_len);
-        }
-        wins[gw].layer_first = static_cast<u32>(lay_first[gw]);
-        wins[gw].n_layers = static_cast<u32>(lay_first[gw + 1] - lay_first[gw]);
-        wins[gw].out_off = static_cast<u32>(out_off[gw]);
-        wins[gw].out_cap = 2 * bl + 128;
-      }
-      maxes[ti] = {mb, ml};
-    };
-    std::vector<std::thread> pool;
-    for (u32 ti = 1; ti < n_fill; ++ti) pool.emplace_back(fill, ti);
-    fill(0);
-    for (auto& th : pool) th.join();
-    for (const auto& m2 : maxes) {
-      max_bb = std::max(max_bb, m2.first);
-      max_len = std::max(max_len, m2.second);
-    }
-  }
-  lap("layer descriptors (threads)");
-  max_len = std::max(max_len, max_bb);
   PoaSrc src{};
   src.packed_reads = R.packed.as<u64>();
   src.packed_targets = T.packed.as<u64>();
-  if (any_q) {
-    // qualities to HBM once per call; racon's mean-quality filter as per-layer flags computed on the device
+  if (any_q) {  // qualities to HBM once per call
     const u64 qtotal = h_qual_off[R.n];
     u8* d_q = e.polish_quals.get<u8>(qtotal + 16);
     RVN_HIP(hipMemcpyAsync(d_q, h_quals, qtotal, hipMemcpyHostToDevice, s));
-    PoaLayer* d_l = e.tmp_d.get<PoaLayer>(lays.size() + 1);
-    RVN_HIP(hipMemcpyAsync(d_l, lays.data(), lays.size() * sizeof(PoaLayer), hipMemcpyHostToDevice, s));
-    u8* d_ok = e.tmp_a.get<u8>(lays.size() + 16);
-    const u32 nl = static_cast<u32>(lays.size());
-    layer_quality_kernel<<<(nl + 3) / 4, 256, 0, s>>>(d_l, nl, d_q, q_thr, d_ok);
-    RVN_HIP(hipGetLastError());
+    RVN_HIP(hipStreamSynchronize(s));
     src.read_quals = d_q;
-    src.layer_ok = d_ok;
-    if (q_thr > 0) {  // only for the statistics: how many layers survive
-      std::vector<u8> okh(nl);
-      RVN_HIP(hipMemcpyAsync(okh.data(), d_ok, nl, hipMemcpyDeviceToHost, s));
-      RVN_HIP(hipStreamSynchronize(s));
-      u64 kept = 0;
-      for (u32 i = 0; i < nl; ++i) kept += (okh[i] && !(lays[i].flags & kLayerTarget)) ? 1 : 0;
-      stats.n_layers = kept;
-    }
   }
-  stats.n_windows = n_windows;
-  u8* cons = e.pin_big.get<u8>(out_off.back() + 16);  // pinned; the anchors it held are used up after step 3
-  std::vector<u32> cons_len(n_windows), status(n_windows);
-  double ms = 0;
-  stats.host_ms = ms_since(t_host);
-  lap("qualities / buffers");
-  const auto t_poa = clk::now();
-  poa_run(e, wins, lays, src, max_bb, max_len, m, n, g, trim ? 1 : 0, cons, out_off.back(), cons_len.data(),
-          status.data(), &ms);
-  stats.poa_ms = ms;
-  const double poa_wall = ms_since(t_poa);
-  lap("poa_run (wall)");
-  const auto t_st = clk::now();
-
-  // ---- 5. stitch (only the windows of this call's range; the others were given no layers) ---------------------
   if (win_count) win_count->assign(T.n, 0);
   if (win_polished) win_polished->assign(T.n, 0);
-  for (u32 t = 0; t < T.n; ++t) {
-    polished[t].reserve(static_cast<size_t>(T.h_len[t]) + T.h_len[t] / 16 + 1024);
-    u64 polished_windows = 0;
-    u64 nw = 0;
-    for (u64 wi = 0; wi < first_window[t + 1] - first_window[t]; ++wi) {
-      const u64 gw = first_window[t] + wi;
-      if (gw < win_first || gw >= win_last) continue;
-      ++nw;
-      polished_windows += status[gw] == 1 ? 1 : 0;
-      if (status[gw] >= 2) ++stats.n_failed_windows;
-      polished[t].insert(polished[t].end(), cons + out_off[gw], cons + out_off[gw] + cons_len[gw]);
+  std::vector<u64> t_windows(T.n, 0), t_polished(T.n, 0);
+  for (u32 t = 0; t < T.n; ++t) polished[t].reserve(static_cast<size_t>(T.h_len[t]) + T.h_len[t] / 16 + 1024);
+
+  struct Chunk {
+    u64 lo = 0, hi = 0;
+    std::vector<PoaWindow> wins;
+    std::vector<PoaLayer> lays;
+    std::vector<u64> out_off;
+    std::vector<u32> cons_len, status;
+    u32 max_bb = 1, max_len = 1;
+    double ms = 0;
+    u64 kept_layers = 0;
+  };
+  Chunk slots[2];
+  std::vector<std::vector<LayerRef>> win_layers;
+  std::vector<u32> win_t;
+  std::vector<u64> lay_first;
+  std::thread bg;
+  std::exception_ptr bg_err;
+  double host_busy = 0;
+  u64 dbg_cuts = 0, dbg_nw = 0, dbg_cells = 0;
+
+  // background: quality flags + POA of one chunk (the only HIP work while the main thread cuts the next chunk)
+  auto run_chunk = [&](Chunk* C) {
+    try {
+      RVN_HIP(hipSetDevice(e.device));
+      PoaSrc csrc = src;
+      const u32 nl = static_cast<u32>(C->lays.size());
+      if (any_q && nl) {  // racon's mean-quality filter as per-layer flags computed on the device
+        PoaLayer* d_l = e.tmp_d.get<PoaLayer>(C->lays.size() + 1);
+        RVN_HIP(hipMemcpyAsync(d_l, C->lays.data(), C->lays.size() * sizeof(PoaLayer), hipMemcpyHostToDevice, s));
+        u8* d_ok = e.tmp_a.get<u8>(C->lays.size() + 16);
+        layer_quality_kernel<<<(nl + 3) / 4, 256, 0, s>>>(d_l, nl, src.read_quals, q_thr, d_ok);
+        RVN_HIP(hipGetLastError());
+        csrc.layer_ok = d_ok;
+        if (q_thr > 0) {  // only for the statistics: how many layers survive
+          std::vector<u8> okh(nl);
+          RVN_HIP(hipMemcpyAsync(okh.data(), d_ok, nl, hipMemcpyDeviceToHost, s));
+          RVN_HIP(hipStreamSynchronize(s));
+          u64 kept = 0;
+          for (u32 i = 0; i < nl; ++i) kept += (okh[i] && !(C->lays[i].flags & kLayerTarget)) ? 1 : 0;
+          C->kept_layers = kept;
+        }
+      }
+      u8* cons = e.pin_out.get<u8>(C->out_off.back() + 16);
+      poa_run(e, C->wins, C->lays, csrc, C->max_bb, C->max_len, m, n, g, trim ? 1 : 0, cons, C->out_off.back(),
+              C->cons_len.data(), C->status.data(), &C->ms);
+    } catch (...) {
+      bg_err = std::current_exception();
     }
-    ratio[t] = nw ? static_cast<double>(polished_windows) / nw : 0.0;
-    stats.n_polished_windows += polished_windows;
-    if (win_count) (*win_count)[t] = static_cast<u32>(nw);
-    if (win_polished) (*win_polished)[t] = static_cast<u32>(polished_windows);
+  };
+  auto finish_chunk = [&](Chunk* C) {  // join + stitch the windows of the chunk, in window order
+    if (bg.joinable()) bg.join();
+    if (bg_err) std::rethrow_exception(bg_err);
+    const u8* cons = static_cast<const u8*>(e.pin_out.ptr);
+    stats.poa_ms += C->ms;
+    for (u64 gw = C->lo; gw < C->hi; ++gw) {
+      const u64 i = gw - C->lo;
+      const u32 t = win_t_all[gw];
+      ++t_windows[t];
+      if (C->status[i] == 1) ++t_polished[t];
+      if (C->status[i] >= 2) ++stats.n_failed_windows;
+      polished[t].insert(polished[t].end(), cons + C->out_off[i], cons + C->out_off[i] + C->cons_len[i]);
+    }
+    if (any_q && q_thr > 0) stats.n_layers += C->kept_layers;
+    else stats.n_layers += C->lays.size() - C->wins.size();
+  };
+
+  Chunk* pending = nullptr;
+  for (u32 c = 0; c < n_chunks; ++c) {
+    const auto t_prep = clk::now();
+    Chunk* C = &slots[c & 1];
+    c_lo = W0 + static_cast<u64>(c) * chunk_w;
+    c_hi = std::min(W1, c_lo + chunk_w);
+    C->lo = c_lo;
+    C->hi = c_hi;
+    const u64 nwc = c_hi - c_lo;
+    cur_reads = &chunk_reads[c];
+    parts.assign(n_thr, Part());
+    {
+      std::vector<std::thread> pool;
+      for (u32 ti = 1; ti < n_thr; ++ti) pool.emplace_back(work, ti);
+      work(0);
+      for (auto& th : pool) th.join();
+    }
+    win_layers.assign(nwc, {});
+    for (const Part& P : parts) {  // thread order == read order
+      stats.n_dropped_layers += P.dropped;
+      dbg_cuts += P.n_cuts;
+      dbg_nw += P.n_nw;
+      dbg_cells += P.nw_cells;
+      for (const Emit& em : P.emits) win_layers[em.window - c_lo].push_back(em.layer);
+    }
+    // ---- 4. layer descriptors: bases and qualities stay in HBM (packed read sets) ----
+    C->wins.assign(nwc, PoaWindow{});
+    C->out_off.assign(nwc + 1, 0);
+    lay_first.assign(nwc + 1, 0);
+    for (u64 i = 0; i < nwc; ++i) {
+      const u64 gw = c_lo + i;
+      const u32 t = win_t_all[gw];
+      const u32 bl = std::min<u32>(w, T.h_len[t] - static_cast<u32>(gw - first_window[t]) * w);
+      lay_first[i + 1] = lay_first[i] + 1 + win_layers[i].size();
+      C->out_off[i + 1] = C->out_off[i] + 2ULL * bl + 128;
+    }
+    C->lays.resize(lay_first[nwc]);
+    C->cons_len.assign(nwc, 0);
+    C->status.assign(nwc, 0);
+    C->max_bb = 1;
+    C->max_len = 1;
+    C->kept_layers = 0;
+    C->ms = 0;
+    {
+      const u32 n_fill = static_cast<u32>(std::max<u64>(1, std::min<u64>(n_thr, nwc / 256 + 1)));
+      std::vector<std::pair<u32, u32>> maxes(n_fill, {1u, 1u});
+      auto fill = [&](u32 ti) {
+        const u64 i_lo = nwc * ti / n_fill, i_hi = nwc * (ti + 1) / n_fill;
+        u32 mb = 1, ml = 1;
+        for (u64 i = i_lo; i < i_hi; ++i) {
+          const u64 gw = c_lo + i;
+          const u32 t = win_t_all[gw];
+          const u32 tlen = T.h_len[t];
+          const u32 ws = static_cast<u32>(gw - first_window[t]) * w;
+          const u32 bl = std::min<u32>(w, tlen - ws);
+          PoaLayer* out_l = C->lays.data() + lay_first[i];
+          PoaLayer B{};
+          B.code_off = T.h_word_off[t];
+          B.len = bl;
+          B.begin = 0;
+          B.end = bl ? bl - 1 : 0;
+          B.flags = kLayerPacked | kLayerTarget | kLayerZeroW;  // weight 0 = racon's dummy '!' backbone quality
+          B.q_begin = ws;
+          B.q_len = tlen;
+          poa_layer_linear_way(B);
+          *out_l++ = B;
+          mb = std::max(mb, bl);
+          auto& wl = win_layers[i];
+          // racon: layers in stable order of their begin position
+          std::stable_sort(wl.begin(), wl.end(), [](const LayerRef& a, const LayerRef& b) { return a.t_begin < b.t_begin; });
+          for (const auto& L : wl) {
+            PoaLayer P{};
+            P.code_off = R.h_word_off[L.read];
+            P.qual_off = any_q ? h_qual_off[L.read] : 0;
+            P.len = L.q_len;
+            P.begin = L.t_begin;
+            P.end = std::min(L.t_end, bl - 1);
+            P.flags = kLayerPacked | (L.rc ? kLayerRc : 0u) | (any_q ? kLayerQual : 0u);
+            P.q_begin = L.q_begin;
+            P.q_len = R.h_len[L.read];
+            for (int x = 0; x < 7; ++x) P.way[x] = L.way[x];
+            *out_l++ = P;
+            ml = std::max(ml, L.q_len);
+          }
+          C->wins[i].layer_first = static_cast<u32>(lay_first[i]);
+          C->wins[i].n_layers = static_cast<u32>(lay_first[i + 1] - lay_first[i]);
+          C->wins[i].out_off = static_cast<u32>(C->out_off[i]);
+          C->wins[i].out_cap = 2 * bl + 128;
+        }
+        maxes[ti] = {mb, ml};
+      };
+      std::vector<std::thread> pool;
+      for (u32 ti = 1; ti < n_fill; ++ti) pool.emplace_back(fill, ti);
+      fill(0);
+      for (auto& th : pool) th.join();
+      for (const auto& m2 : maxes) {
+        C->max_bb = std::max(C->max_bb, m2.first);
+        C->max_len = std::max(C->max_len, m2.second);
+      }
+      C->max_len = std::max(C->max_len, C->max_bb);
+    }
+    host_busy += ms_since(t_prep);
+    if (pending) finish_chunk(pending);  // the previous chunk's POA ran while this one was being cut
+    pending = C;
+    bg = std::thread(run_chunk, C);
   }
-  lap("stitch");
-  stats.host_ms += ms_since(t_st) + (poa_wall - ms);  // stitching + the batch's host-side preparation and copies
+  if (pending) finish_chunk(pending);
+  lap("cuts + descriptors + POA (pipelined)");
+  if (dbg)
+    std::fprintf(stderr, "[raven_hip] polish: %u chunk(s), %llu cuts, %llu with a residual NW (%llu cells), %u host threads, "
+                 "host busy %.1f ms\n", n_chunks, (unsigned long long)dbg_cuts, (unsigned long long)dbg_nw,
+                 (unsigned long long)dbg_cells, n_thr, host_busy);
+
+  // ---- 5. per-target results ----------------------------------------------------------------------------
+  stats.n_windows = W1 - W0;
+  for (u32 t = 0; t < T.n; ++t) {
+    ratio[t] = t_windows[t] ? static_cast<double>(t_polished[t]) / t_windows[t] : 0.0;
+    stats.n_polished_windows += t_polished[t];
+    if (win_count) (*win_count)[t] = static_cast<u32>(t_windows[t]);
+    if (win_polished) (*win_polished)[t] = static_cast<u32>(t_polished[t]);
+  }
+  stats.host_ms = host_busy;
   stats.total_ms = ms_since(t_all);
 }
 

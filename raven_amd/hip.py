@@ -33,7 +33,7 @@ SYMBOLS = [
     "rvn_engine_map_batch", "rvn_engine_map_fetch", "rvn_engine_map_fetch_filtered",
     "rvn_find_overlaps_and_create_piles", "rvn_pass1_pile_words", "rvn_pass1_num_overlaps",
     "rvn_pass1_fetch_piles", "rvn_pass1_fetch_overlaps", "rvn_pass1_destroy", "rvn_pile_add_layers",
-    "rvn_edit_distance_batch", "rvn_poa_consensus_batch", "rvn_poa_phase_cycles", "rvn_polish_target_reads", "rvn_polish_round_range", "rvn_shard_sketch", "rvn_shard_sketch_fetch",
+    "rvn_edit_distance_batch", "rvn_poa_consensus_batch", "rvn_poa_phase_cycles", "rvn_polish_target_reads", "rvn_polish_set_chunk_windows", "rvn_polish_round_range", "rvn_shard_sketch", "rvn_shard_sketch_fetch",
     "rvn_shard_index_build", "rvn_shard_key_counts", "rvn_engine_set_occurrence", "rvn_shard_join",
     "rvn_shard_join_fetch", "rvn_shard_chain", "rvn_shard_piles", "rvn_shard_sketch_fetch_dev",
     "rvn_shard_index_build_dev", "rvn_shard_key_histogram", "rvn_shard_join_fetch_dev", "rvn_shard_chain_dev",
@@ -97,6 +97,8 @@ def lib():
                                           C.POINTER(dbl)]
     L.rvn_poa_phase_cycles.argtypes = [vp, vp]
     L.rvn_polish_target_reads.argtypes = [vp, vp, u32]
+    L.rvn_polish_set_chunk_windows.argtypes = [vp, u64]
+    L.rvn_polish_set_chunk_windows.restype = u64
     L.rvn_shard_sketch.argtypes = [vp, vp, i32, C.POINTER(u64)]
     L.rvn_shard_sketch_fetch.argtypes = [vp, vp, vp]
     L.rvn_shard_index_build.argtypes = [vp, vp, vp, u64, i32]
@@ -514,6 +516,10 @@ class Engine:
         c = np.zeros(6, dtype=np.uint64)
         lib().rvn_poa_phase_cycles(self._h, _p(c))
         return dict(zip(("subgraph", "dp", "traceback", "add_alignment", "order", "consensus"), (int(x) for x in c)))
+
+    def polish_set_chunk_windows(self, windows):
+        """Windows per POA chunk of a polishing round (0 = one batch); returns the previous value."""
+        return int(lib().rvn_polish_set_chunk_windows(self._h, int(windows)))
 
     def poa_set_mode(self, mode):
         """0 band 64 -> 128 -> full matrix (default), 1 full matrix only, 2 band 64 only, 3 band 128 only."""

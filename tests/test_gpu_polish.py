@@ -73,3 +73,21 @@ def test_lambda_polish_matches_golden_fixture(with_qual):
     d = _ed(cons[0], ref)
     assert d <= 0.0025 * len(ref) + 10, (d, len(ref), len(cons[0]))  # measured 35 (qual) / 77-90 (no qual) of 47.8 kb
     assert _ed(cons[0], truth) <= 1.1 * ed_ref + 10
+
+
+def test_chunked_pipeline_gives_the_same_round():
+    """The round is processed in window chunks (host cuts of chunk i+1 overlap the POA of chunk i): the chunk size
+    must not change a byte, for several targets and with the quality filter."""
+    truths, drafts, targets, reads, quals = pu2.make_case(genome_len=30_000, coverage=20, read_len=2500, seed=13,
+                                                         with_qual=True, n_targets=2)
+    eng = hip.Engine(15, 5)
+    td, rd = eng.upload(targets), eng.upload(reads)
+    assert eng.polish_set_chunk_windows(0) == 16384
+    ref, ref_ratio, st0 = eng.polish_round(td, rd, quals=quals, q=10.0)
+    for chunk in (1, 7, 32):
+        eng.polish_set_chunk_windows(chunk)
+        cons, ratio, st = eng.polish_round(td, rd, quals=quals, q=10.0)
+        assert np.allclose(ratio, ref_ratio) and st["n_layers"] == st0["n_layers"] and st["n_windows"] == st0["n_windows"]
+        assert st["n_reads_used"] == st0["n_reads_used"]
+        for a, b in zip(cons, ref):
+            assert np.array_equal(a, b)
