@@ -81,7 +81,7 @@ struct PinBuf {
       if (ptr) RVN_HIP(hipHostFree(ptr));
       ptr = nullptr;
       cap = 0;
-      const size_t want = bytes + bytes / 8 + 4096;
+      const size_t want = bytes + bytes / 4 + 4096;  // pinning is slow (~1-2 GB/s): leave room for the next round
       RVN_HIP(hipHostMalloc(&ptr, want, hipHostMallocDefault));
       cap = want;
     }

@@ -106,7 +106,7 @@ void poa_v1_launch(Engine& e, const PoaBatchDev& b);  // poa.hip
 // windows + begin-sorted layer descriptors on the host, all sources of `src` resident in HBM (poa.hip)
 void poa_run(Engine& e, const std::vector<PoaWindow>& wins, const std::vector<PoaLayer>& lays, const PoaSrc& src,
              u32 max_bb, u32 max_len, int m, int n, int g, int trim, u8* h_out, u64 out_total, u32* h_out_len,
-             u32* h_status, double* device_ms);
+             u32* h_status, double* device_ms, bool allow_full = true);  // allow_full: escalate to the full-matrix kernel
 void poa_v2_launch(Engine& e, const PoaBatchDev& b, int nch);  // poa2.hip: band = 64 * nch columns
 
 // Persistent waves take windows from a shared counter (longest-processing-time-first order when `sched` is given).

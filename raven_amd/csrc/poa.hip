@@ -618,7 +618,7 @@ void poa_v1_launch(Engine& e, const PoaBatchDev& b) {
 // of them.
 void poa_run(Engine& e, const std::vector<PoaWindow>& wins, const std::vector<PoaLayer>& lays, const PoaSrc& src,
              u32 max_bb, u32 max_len, int m, int n, int g, int trim, u8* h_out, u64 out_total, u32* h_out_len,
-             u32* h_status, double* device_ms) {
+             u32* h_status, double* device_ms, bool allow_full) {
   const u32 n_windows = static_cast<u32>(wins.size());
   if (n_windows == 0) return;
   hipStream_t s = e.stream;
@@ -710,7 +710,7 @@ void poa_run(Engine& e, const std::vector<PoaWindow>& wins, const std::vector<Po
       for (u32 w : wide)
         if ((h_status[w] & 0xFF) >= 2) fullm.push_back(w);
     }
-    if (!fullm.empty()) {
+    if (!fullm.empty() && allow_full) {
       rerun(fullm, 1);
       e.poa_fallback_windows = static_cast<u32>(fullm.size());
     }

@@ -523,6 +523,12 @@ void polish_round(Engine& e, ReadsDev& T, ReadsDev& R, const u8* h_quals, const 
   double host_busy = 0;
   u64 dbg_cuts = 0, dbg_nw = 0, dbg_cells = 0;
 
+  std::vector<std::vector<u8>> win_cons(W1 - W0);  // consensus of every window of the range, stitched at the end
+  std::vector<u32> win_status(W1 - W0, 0);
+  std::vector<PoaWindow> fb_wins;  // windows both bands could not do, with their layers
+  std::vector<PoaLayer> fb_lays;
+  std::vector<u64> fb_gw;
+
   // background: quality flags + POA of one chunk (the only HIP work while the main thread cuts the next chunk)
   auto run_chunk = [&](Chunk* C) {
     try {
@@ -546,8 +552,10 @@ void polish_round(Engine& e, ReadsDev& T, ReadsDev& R, const u8* h_quals, const 
         }
       }
       u8* cons = e.pin_out.get<u8>(C->out_off.back() + 16);
+      // with several chunks the rare windows that need the full-matrix kernel are collected and run ONCE at the end
+      // (that kernel's latency is ~0.25 s per launch, whatever the number of windows)
       poa_run(e, C->wins, C->lays, csrc, C->max_bb, C->max_len, m, n, g, trim ? 1 : 0, cons, C->out_off.back(),
-              C->cons_len.data(), C->status.data(), &C->ms);
+              C->cons_len.data(), C->status.data(), &C->ms, n_chunks == 1);
     } catch (...) {
       bg_err = std::current_exception();
     }
@@ -559,11 +567,16 @@ void polish_round(Engine& e, ReadsDev& T, ReadsDev& R, const u8* h_quals, const 
     stats.poa_ms += C->ms;
     for (u64 gw = C->lo; gw < C->hi; ++gw) {
       const u64 i = gw - C->lo;
-      const u32 t = win_t_all[gw];
-      ++t_windows[t];
-      if (C->status[i] == 1) ++t_polished[t];
-      if (C->status[i] >= 2) ++stats.n_failed_windows;
-      polished[t].insert(polished[t].end(), cons + C->out_off[i], cons + C->out_off[i] + C->cons_len[i]);
+      win_status[gw - W0] = C->status[i];
+      win_cons[gw - W0].assign(cons + C->out_off[i], cons + C->out_off[i] + C->cons_len[i]);
+      if (n_chunks > 1 && (C->status[i] & 0xFF) >= 2) {  // keep its layers for the final full-matrix batch
+        PoaWindow fw = C->wins[i];
+        const u32 lf = fw.layer_first;
+        fw.layer_first = static_cast<u32>(fb_lays.size());
+        fb_lays.insert(fb_lays.end(), C->lays.begin() + lf, C->lays.begin() + lf + fw.n_layers);
+        fb_wins.push_back(fw);
+        fb_gw.push_back(gw);
+      }
     }
     if (any_q && q_thr > 0) stats.n_layers += C->kept_layers;
     else stats.n_layers += C->lays.size() - C->wins.size();
@@ -682,7 +695,53 @@ void polish_round(Engine& e, ReadsDev& T, ReadsDev& R, const u8* h_quals, const 
                  "host busy %.1f ms\n", n_chunks, (unsigned long long)dbg_cuts, (unsigned long long)dbg_nw,
                  (unsigned long long)dbg_cells, n_thr, host_busy);
 
-  // ---- 5. per-target results ----------------------------------------------------------------------------
+  if (!fb_wins.empty()) {  // one full-matrix batch for what neither band width could align
+    u64 oo = 0;
+    u32 mb = 1, ml = 1;
+    for (auto& fw : fb_wins) {
+      fw.out_off = static_cast<u32>(oo);
+      oo += fw.out_cap;
+      mb = std::max(mb, fb_lays[fw.layer_first].len);
+      for (u32 x = 0; x < fw.n_layers; ++x) ml = std::max(ml, fb_lays[fw.layer_first + x].len);
+    }
+    PoaSrc fsrc = src;
+    if (any_q) {
+      const u32 nl = static_cast<u32>(fb_lays.size());
+      PoaLayer* d_l = e.tmp_d.get<PoaLayer>(fb_lays.size() + 1);
+      RVN_HIP(hipMemcpyAsync(d_l, fb_lays.data(), fb_lays.size() * sizeof(PoaLayer), hipMemcpyHostToDevice, s));
+      u8* d_ok = e.tmp_a.get<u8>(fb_lays.size() + 16);
+      layer_quality_kernel<<<(nl + 3) / 4, 256, 0, s>>>(d_l, nl, src.read_quals, q_thr, d_ok);
+      RVN_HIP(hipGetLastError());
+      fsrc.layer_ok = d_ok;
+    }
+    u8* cons = e.pin_out.get<u8>(oo + 16);
+    std::vector<u32> fl(fb_wins.size()), fs(fb_wins.size());
+    double fms = 0;
+    const int mode = e.poa_mode;
+    e.poa_mode = 1;
+    try {
+      poa_run(e, fb_wins, fb_lays, fsrc, mb, ml, m, n, g, trim ? 1 : 0, cons, oo, fl.data(), fs.data(), &fms);
+    } catch (...) {
+      e.poa_mode = mode;
+      throw;
+    }
+    e.poa_mode = mode;
+    stats.poa_ms += fms;
+    for (size_t i = 0; i < fb_wins.size(); ++i) {
+      win_status[fb_gw[i] - W0] = fs[i];
+      win_cons[fb_gw[i] - W0].assign(cons + fb_wins[i].out_off, cons + fb_wins[i].out_off + fl[i]);
+    }
+    e.poa_fallback_windows = static_cast<u32>(fb_wins.size());
+  }
+  // ---- 5. stitch the windows in order; per-target results -----------------------------------------------
+  for (u64 gw = W0; gw < W1; ++gw) {
+    const u32 t = win_t_all[gw];
+    const u32 st = win_status[gw - W0];
+    ++t_windows[t];
+    if (st == 1) ++t_polished[t];
+    if (st >= 2) ++stats.n_failed_windows;
+    polished[t].insert(polished[t].end(), win_cons[gw - W0].begin(), win_cons[gw - W0].end());
+  }
   stats.n_windows = W1 - W0;
   for (u32 t = 0; t < T.n; ++t) {
     ratio[t] = t_windows[t] ? static_cast<double>(t_polished[t]) / t_windows[t] : 0.0;
