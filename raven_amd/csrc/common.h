@@ -3,6 +3,9 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+#include <new>
+
 #include <cstdint>
 #include <cstdio>
 #include <stdexcept>
@@ -84,6 +87,31 @@ struct PinBuf {
       const size_t want = bytes + bytes / 4 + 4096;  // pinning is slow (~1-2 GB/s): leave room for the next round
       RVN_HIP(hipHostMalloc(&ptr, want, hipHostMallocDefault));
       cap = want;
+    }
+    return reinterpret_cast<T*>(ptr);
+  }
+};
+
+// Growable plain host buffer, never initialised (bulk read-backs too large to be worth pinning: pinning runs at
+// ~2 GB/s, a pageable copy at ~10 GB/s).
+struct HostBuf {
+  void* ptr = nullptr;
+  size_t cap = 0;
+  HostBuf() = default;
+  HostBuf(const HostBuf&) = delete;
+  HostBuf& operator=(const HostBuf&) = delete;
+  ~HostBuf() { std::free(ptr); }
+  template <typename T>
+  T* get(size_t count) {
+    const size_t bytes = count * sizeof(T);
+    if (bytes > cap) {
+      std::free(ptr);
+      cap = bytes + bytes / 4 + 4096;
+      ptr = std::malloc(cap);
+      if (!ptr) {
+        cap = 0;
+        throw std::bad_alloc();
+      }
     }
     return reinterpret_cast<T*>(ptr);
   }

@@ -126,7 +126,8 @@ struct Engine {
   bool timing = true;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   u64* h_pin = nullptr;  // pinned host scratch for small device->host size read-backs
-  PinBuf pin_big;        // pinned staging for bulk read-backs (polishing: chain anchors)
+  PinBuf pin_big;        // pinned staging for bulk read-backs up to 256 MB (polishing: chain anchors)
+  HostBuf host_big;      // ... and the unpinned one for larger ones
   PinBuf pin_out;        // pinned consensus buffer of the POA chunk in flight
   u64 polish_chunk_windows = 16384;  // windows per POA chunk of a polishing round (0 = everything in one batch)
   PileState* pile_pool = nullptr;  // buffers of the last destroyed pass, adopted by the next one (engine.hip)

@@ -108,9 +108,11 @@ void polish_round(Engine& e, ReadsDev& T, ReadsDev& R, const u8* h_quals, const 
   std::vector<u32> roff(static_cast<size_t>(R.n) + 1, 0);
   std::vector<u64> aoff(O);
   std::vector<u32> acnt(O);
-  const u64* anchors = e.pin_big.get<u64>(mo.n_matches + 1);  // pinned: the anchors are the bulk of the read-back
+  // the anchors are the bulk of the read-back: pinned staging while that is cheap, a plain buffer beyond 256 MB
+  const bool pin_anchors = (mo.n_matches + 1) * 8 <= (256ULL << 20);
+  u64* anchors = pin_anchors ? e.pin_big.get<u64>(mo.n_matches + 1) : e.host_big.get<u64>(mo.n_matches + 1);
   if (O) {
-    RVN_HIP(hipMemcpyAsync(e.pin_big.ptr, mo.anchors.ptr, mo.n_matches * 8, hipMemcpyDeviceToHost, s));
+    RVN_HIP(hipMemcpyAsync(anchors, mo.anchors.ptr, mo.n_matches * 8, hipMemcpyDeviceToHost, s));
     RVN_HIP(hipMemcpy(ovl.data(), mo.ovl.ptr, O * sizeof(Overlap), hipMemcpyDeviceToHost));
     RVN_HIP(hipMemcpy(aoff.data(), mo.anchor_off.ptr, O * 8, hipMemcpyDeviceToHost));
     RVN_HIP(hipMemcpy(acnt.data(), mo.anchor_cnt.ptr, O * 4, hipMemcpyDeviceToHost));
