@@ -1,8 +1,12 @@
-/* raven_hip.h — C ABI of the MI355X-native overlap engine for Raven (libraven_hip.so).
+/* raven_hip.h — C ABI of the MI355X-native overlap-and-polish engine for Raven (libraven_hip.so).
  *
- * Drop-in boundary: the entry points below are what a binding for Raven's overlap hot
- * path would bind instead of the un-vendored ram::MinimizerEngine; each cites the reference interface
- * it replaces (paths relative to the lbcb-sci/raven tree).  Plain pointers and sizes only.
+ * Drop-in boundary: the entry points below are what a binding for Raven's overlap and
+ * polishing hot path would bind instead of the un-vendored ram::MinimizerEngine, edlib and racon::Polisher;
+ * each cites the reference interface it replaces (paths relative to the lbcb-sci/raven tree).  Plain
+ * pointers and sizes only.  Groups: engine / reads; Minimize / Filter / Map; FindOverlapsAndCreatePiles;
+ * Pile::AddLayers / AddKmers; edit distance; POA window consensus; polishing round (whole, or a window range
+ * for sharding); stage-level entry points of the sharded pass (host and device-pointer variants);
+ * introspection and test hooks.
  *
  * Conventions
  *   - every function returning int returns RVN_OK (0) or a negative RVN_E* code; rvn_last_error()
