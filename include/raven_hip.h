@@ -262,6 +262,11 @@ int rvn_engine_kernel_ms(rvn_engine* e, double* ms, uint64_t* launches, int n);
 uint64_t rvn_test_hash(uint64_t key, uint32_t k, int use32);
 int rvn_test_canonical(const uint64_t* words, uint32_t pos, uint32_t k, int use32, uint64_t* value, uint32_t* strand);
 int rvn_test_low_complexity(const uint8_t* codes, uint32_t k);
+/* the window cut of the polishing front end (polish_cut.h) on one-byte codes; anchors = (target, read) positions of
+ * exact k-mer matches, increasing; out = {ql, tl, qr, tr}; returns the number of residual NWs (>= 0) or RVN_EINVAL */
+int rvn_test_window_cut(const uint8_t* target, uint32_t tlen, const uint8_t* read, uint32_t qlen,
+                        const uint32_t* anchor_t, const uint32_t* anchor_q, uint32_t n_anchors, uint32_t k,
+                        uint32_t boundary, uint32_t out[4]);
 void rvn_test_std_sort_lendesc(uint64_t* data, uint64_t n);
 void rvn_test_heap_sort_lendesc(uint64_t* data, uint64_t n);
 

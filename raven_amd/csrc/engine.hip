@@ -7,6 +7,7 @@
 
 #include "../../include/raven_hip.h"
 #include "introsort.h"
+#include "polish_cut.h"
 #include "kmer.h"
 #include "lowcomplexity.h"
 
@@ -1115,6 +1116,23 @@ int rvn_test_canonical(const uint64_t* words, uint32_t pos, uint32_t k, int use3
   }
   *strand = st;
   return ok ? 1 : 0;
+}
+
+int rvn_test_window_cut(const uint8_t* target, uint32_t tlen, const uint8_t* read, uint32_t qlen,
+                        const uint32_t* anchor_t, const uint32_t* anchor_q, uint32_t n_anchors, uint32_t k, uint32_t boundary,
+                        uint32_t out[4]) {
+  if (!target || !read || !anchor_t || !anchor_q || !out || n_anchors < 2) return RVN_EINVAL;
+  std::vector<std::pair<u32, u32>> an(n_anchors);
+  for (u32 i = 0; i < n_anchors; ++i) an[i] = {anchor_t[i], anchor_q[i]};
+  if (boundary < an.front().first || boundary >= an.back().first + k) return RVN_EINVAL;
+  CutScratch sc;
+  const WindowCut c = window_cut(an, k, boundary, tlen, qlen, [&](u32 x) -> u32 { return target[x] & 3u; },
+                                 [&](u32 x) -> u32 { return read[x] & 3u; }, sc);
+  out[0] = c.ql;
+  out[1] = c.tl;
+  out[2] = c.qr;
+  out[3] = c.tr;
+  return static_cast<int>(sc.n_nw);
 }
 
 int rvn_test_low_complexity(const uint8_t* codes, uint32_t k) { return lc_kmer_passes(codes, k) ? 1 : 0; }

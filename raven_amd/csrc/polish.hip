@@ -23,12 +23,11 @@
 #include <vector>
 
 #include "poa.h"
+#include "polish_cut.h"
 
 namespace rvn {
 
 namespace {
-
-constexpr u32 kCutMax = 4096;  // longest unmatched remainder of an anchor gap aligned on the host for a window cut
 
 inline u32 code_at(const std::vector<u64>& packed, u64 word_off, u32 i) {
   return static_cast<u32>(packed[word_off + (i >> 5)] >> ((i << 1) & 63)) & 3u;
@@ -213,9 +212,7 @@ void polish_round(Engine& e, ReadsDev& T, ReadsDev& R, const u8* h_quals, const 
     const std::vector<u32>& cr = *cur_reads;
     const size_t i_lo = cr.size() * ti / n_thr, i_hi = cr.size() * (ti + 1) / n_thr;
     std::vector<std::pair<u32, u32>> an;
-    std::vector<u16> dpbuf;  // NW of an unmatched remainder (cut())
-    std::vector<i32> cen;
-    std::vector<u8> qrem;
+    CutScratch sc;
     for (size_t ii = i_lo; ii < i_hi; ++ii) {
       const u32 r = cr[ii];
       const Overlap& o = best[r].o;
@@ -247,186 +244,10 @@ void polish_round(Engine& e, ReadsDev& T, ReadsDev& R, const u8* h_quals, const 
       // racon's CIGAR breakpoints do.  Only a remainder longer than kCutMax is given to neither window (the piece
       // on the left ends where the exact region before it ends, the one on the right begins where the exact
       // region after it begins): a guessed cut would append true neighbour bases to a window.
-      struct Cut {
-        u32 ql, tl, qr, tr;  // left piece ends at (ql, tl) exclusive; right piece begins at (qr, tr)
-      };
-      auto cut = [&](u32 B) -> Cut {
-        size_t lo = 0, hi = an.size();  // last anchor with t <= B
-        while (hi - lo > 1) {
-          const size_t mid = (lo + hi) / 2;
-          if (an[mid].first <= B) lo = mid;
-          else hi = mid;
-        }
-        const u32 ta = an[lo].first, qa = an[lo].second;
-        if (B < ta + k || lo + 1 >= an.size()) return {qa + (B - ta), B, qa + (B - ta), B};
-        const u32 tc = an[lo + 1].first, qc = an[lo + 1].second;
-        u32 t0 = ta + k, q0 = qa + k;  // gap [t0, tc) <-> [q0, qc)
-        if (tc > t0 && qc > q0) {
-          // Greedy walk from both anchors towards B: a match, or an isolated error (substitution followed by 3
-          // matches; one extra / one missing read base followed by 4 matches) is taken as the aligned path, which is
-          // what any unit-cost aligner does there; only a cluster of errors stops the walk and leaves a residual
-          // for the NW below.  Pieces end / begin on aligned pairs ('M'), bases in indels at the cut go to neither.
-          const u32 tl_len = T.h_len[t];
-          auto fwd = [&](u32 tt, u32 qq, u32 cnt) {
-            for (u32 x = 0; x < cnt; ++x)
-              if (tt + x >= tl_len || qq + x >= qlen || tbase(tt + x) != qbase(qq + x)) return false;
-            return true;
-          };
-          auto bwd = [&](u32 tt, u32 qq, u32 cnt) {  // bases tt, tt-1, .. and qq, qq-1, ..
-            for (u32 x = 0; x < cnt; ++x)
-              if (tt < x || qq < x || tbase(tt - x) != qbase(qq - x)) return false;
-            return true;
-          };
-          u32 lqd = q0, ltd = t0;  // end (exclusive) of the last aligned pair seen walking forward
-          bool left_set = false;
-          u32 lq = 0, lt = 0;
-          while (t0 < tc && q0 < qc) {
-            if (tbase(t0) == qbase(q0) || fwd(t0 + 1, q0 + 1, 3)) {
-              if (t0 >= B) return left_set ? Cut{lq, lt, q0, t0} : Cut{q0, t0, q0, t0};
-              ++t0;
-              ++q0;
-              lqd = q0;
-              ltd = t0;
-            } else if (fwd(t0, q0 + 1, 4)) {  // extra base in the read
-              if (t0 == B && !left_set) {
-                left_set = true;
-                lq = lqd;
-                lt = ltd;
-              }
-              ++q0;
-            } else if (fwd(t0 + 1, q0, 4)) {  // base missing in the read
-              if (t0 == B && !left_set) {
-                left_set = true;
-                lq = lqd;
-                lt = ltd;
-              }
-              ++t0;
-            } else {
-              break;
-            }
-          }
-          if (left_set) {  // the cut sits in an indel and the walk stopped before the next aligned pair
-            lqd = lq;
-            ltd = lt;
-          }
-          u32 t1 = tc, q1 = qc;
-          u32 rq = qc, rt = tc;  // first aligned pair at/after B seen walking backward (anchor C starts with one)
-          while (t1 > t0 && q1 > q0) {
-            if (tbase(t1 - 1) == qbase(q1 - 1) || (t1 >= 2 && q1 >= 2 && bwd(t1 - 2, q1 - 2, 3))) {
-              if (t1 - 1 < B) return Cut{q1, t1, rq, rt};  // first pair left of the cut: the left piece ends after it
-              --t1;
-              --q1;
-              rq = q1;
-              rt = t1;
-              if (rt == B) return Cut{left_set ? lq : rq, left_set ? lt : B, rq, B};
-            } else if (q1 >= 2 && bwd(t1 - 1, q1 - 2, 4)) {  // extra base in the read
-              --q1;
-            } else if (t1 >= 2 && bwd(t1 - 2, q1 - 1, 4)) {  // base missing in the read
-              --t1;
-            } else {
-              break;
-            }
-          }
-          if (t1 <= t0 || q1 <= q0 || B < t0 || B >= t1) {
-            // nothing left to align around B: the cut falls between the two walks
-            return Cut{lqd, ltd, rq, rt};
-          }
-          // B lies in the unmatched remainder [t0, t1) <-> [q0, q1) around the error(s): a unit-cost NW of the two
-          // short segments decides where B maps, as racon's base-level path would
-          const u32 nt = t1 - t0, nq = q1 - q0;
-          if (nt <= kCutMax && nq <= kCutMax) {
-            // dp(i, j): unit-cost NW of target residual [0, i) vs read residual [0, j), banded around the straight
-            // line between the two walks (half-width 16 + the length difference).  Rows are stored with -inf padding
-            // so the inner loop needs no bounds checks: row i holds columns cen[i] - W .. cen[i] + W at [pad, pad + bw).
-            const u32 W = 16 + (nt > nq ? nt - nq : nq - nt);
-            const u32 bw = 2 * W + 1;
-            const u32 kInf = 0x3FFFu;
-            cen.resize(nt + 1);
-            u32 max_shift = 0;
-            for (u32 i = 0; i <= nt; ++i) {
-              cen[i] = static_cast<i32>(static_cast<u64>(i) * nq / std::max(nt, 1u));
-              if (i) max_shift = std::max<u32>(max_shift, static_cast<u32>(cen[i] - cen[i - 1]));
-            }
-            const u32 pad = max_shift + 2;
-            const u32 stride = bw + 2 * pad;
-            dpbuf.assign(static_cast<size_t>(nt + 1) * stride, static_cast<u16>(kInf));
-            ++P.n_nw;
-            P.nw_cells += static_cast<u64>(nt + 1) * bw;
-            u16* dp = dpbuf.data();
-            auto at = [&](u32 i, i32 j) -> u32 {  // dp value or inf outside the band / matrix (traceback only)
-              if (j < 0 || j > static_cast<i32>(nq)) return kInf;
-              const i32 o = j - cen[i] + static_cast<i32>(W);
-              if (o < 0 || o >= static_cast<i32>(bw)) return kInf;
-              return dp[static_cast<size_t>(i) * stride + pad + o];
-            };
-            qrem.resize(nq + 1);
-            for (u32 j = 0; j < nq; ++j) qrem[j + 1] = static_cast<u8>(qbase(q0 + j));
-            {  // row 0
-              u16* r0 = dp + pad;
-              for (i32 o = 0; o < static_cast<i32>(bw); ++o) {
-                const i32 j = o + cen[0] - static_cast<i32>(W);
-                if (j >= 0 && j <= static_cast<i32>(nq)) r0[o] = static_cast<u16>(j);
-              }
-            }
-            for (u32 i = 1; i <= nt; ++i) {
-              const i32 c = cen[i];
-              const i32 sh = c - cen[i - 1];
-              const u32 tb_ = tbase(t0 + i - 1);
-              const u16* prev = dp + static_cast<size_t>(i - 1) * stride + pad + sh;  // prev[o] = dp(i-1, j)
-              u16* cur = dp + static_cast<size_t>(i) * stride + pad;
-              const i32 jlo = std::max<i32>(0, c - static_cast<i32>(W)), jhi = std::min<i32>(nq, c + static_cast<i32>(W));
-              const i32 base_o = -c + static_cast<i32>(W);
-              if (jlo == 0) cur[base_o] = static_cast<u16>(i);
-              for (i32 j = std::max(jlo, 1); j <= jhi; ++j) {
-                const i32 o = j + base_o;
-                const u32 d = prev[o - 1] + (tb_ != qrem[j] ? 1u : 0u);
-                const u32 u = prev[o] + 1u, l = cur[o - 1] + 1u;
-                const u32 v = std::min(d, std::min(u, l));
-                cur[o] = static_cast<u16>(v < kInf ? v : kInf);
-              }
-            }
-            // like racon's breakpoints, a piece ends / begins on an aligned pair (CIGAR 'M'): the left piece ends
-            // after the last pair with target < B, the right piece begins at the first pair with target >= B;
-            // unaligned bases in between belong to neither
-            const u32 ib = B - t0;
-            u32 i = nt;
-            i32 j = static_cast<i32>(nq);
-            u32 li = 0, lj = 0;    // end (exclusive) of the last pair left of the cut; (0, 0) = exact region before
-            u32 ri = nt, rj = nq;  // first pair at/after the cut; (nt, nq) = exact region after
-            bool have_left = false;
-            while ((i > 0 || j > 0) && !have_left) {
-              const u32 here = at(i, j);
-              if (i > 0 && j > 0 && here == at(i - 1, j - 1) + (tbase(t0 + i - 1) != qrem[j] ? 1u : 0u)) {
-                --i;
-                --j;  // pair (target t0 + i, read q0 + j)
-                if (i >= ib) {
-                  ri = i;
-                  rj = static_cast<u32>(j);
-                } else {
-                  li = i + 1;
-                  lj = static_cast<u32>(j) + 1;
-                  have_left = true;
-                }
-              } else if (i > 0 && here == at(i - 1, j) + 1u) {
-                --i;
-              } else if (j > 0) {
-                --j;
-              } else {
-                --i;
-              }
-            }
-            const bool no_left = li == 0 && lj == 0 && !have_left;
-            const bool no_right = ri == nt && rj == nq;
-            return Cut{no_left ? lqd : q0 + lj, no_left ? ltd : t0 + li, no_right ? rq : q0 + rj, no_right ? rt : t0 + ri};
-          }
-          return Cut{lqd, ltd, rq, rt};
-        }
-        // overlapping / out-of-order anchors: cut at the anchor ends
-        return {q0, t0, qc, tc};
-      };
+      auto cut = [&](u32 B) -> WindowCut { return window_cut(an, k, B, T.h_len[t], qlen, tbase, qbase, sc); };
       const u32 t_first = an.front().first, t_last_end = an.back().first + k;  // chain covers [t_first, t_last_end)
       const u32 q_first = an.front().second, q_last_end = an.back().second + k;
-      Cut carry{q_first, t_first, q_first, t_first};
+      WindowCut carry{q_first, t_first, q_first, t_first};
       u32 carry_at = 0xFFFFFFFFu;  // boundary `carry` was computed for
       for (u32 wi = t_first / w; static_cast<u64>(wi) * w < t_last_end; ++wi) {
         if (first_window[t] + wi + 1 < c_lo || first_window[t] + wi > c_hi) continue;  // far from this chunk
@@ -489,6 +310,8 @@ void polish_round(Engine& e, ReadsDev& T, ReadsDev& R, const u8* h_quals, const 
         P.emits.push_back(Emit{first_window[t] + wi, lr});
       }
     }
+    P.n_nw = sc.n_nw;
+    P.nw_cells = sc.nw_cells;
   };
   const bool any_q = h_quals != nullptr;
   PoaSrc src{};

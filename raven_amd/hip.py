@@ -38,7 +38,7 @@ SYMBOLS = [
     "rvn_shard_join_fetch", "rvn_shard_chain", "rvn_shard_piles", "rvn_shard_sketch_fetch_dev",
     "rvn_shard_index_build_dev", "rvn_shard_key_histogram", "rvn_shard_join_fetch_dev", "rvn_shard_chain_dev",
     "rvn_engine_map_fetch_dev", "rvn_shard_piles_dev", "rvn_poa_set_mode", "rvn_poa_fallback_windows", "rvn_poa_wide_windows", "rvn_pile_add_kmers_batch",
-    "rvn_test_low_complexity", "rvn_polish_round",
+    "rvn_test_low_complexity", "rvn_test_window_cut", "rvn_polish_round",
     "rvn_engine_sketch", "rvn_engine_sketch_fetch", "rvn_engine_index_size", "rvn_engine_index_fetch",
     "rvn_engine_counters", "rvn_engine_num_stages", "rvn_engine_stage_name", "rvn_engine_stage_ms",
     "rvn_engine_reset_stats", "rvn_engine_set_timing", "rvn_engine_set_kernel_timing",
@@ -91,6 +91,8 @@ def lib():
     L.rvn_pile_add_kmers_batch.argtypes = [vp, vp, u32, u32, vp, vp, vp, vp]
     L.rvn_test_low_complexity.restype = i32
     L.rvn_test_low_complexity.argtypes = [vp, u32]
+    L.rvn_test_window_cut.argtypes = [vp, u32, vp, u32, vp, vp, u32, u32, u32, vp]
+    L.rvn_test_window_cut.restype = i32
     L.rvn_polish_round.argtypes = [vp, vp, vp, vp, vp, dbl, dbl, u32, i32, i32, i32, i32, vp, vp, vp, vp, vp]
     L.rvn_edit_distance_batch.argtypes = [vp, vp, vp, u32, vp, C.POINTER(dbl), C.POINTER(u64)]
     L.rvn_poa_consensus_batch.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, u32, i32, i32, i32, i32, vp, vp, vp, vp,
@@ -581,3 +583,17 @@ class Engine:
 
     def set_timing(self, enabled: bool):
         lib().rvn_engine_set_timing(self._h, int(enabled))
+
+
+def test_window_cut(target, read, anchors_t, anchors_q, k, boundary):
+    """polish_cut.h::window_cut on one-byte codes (host code, works without a GPU): (ql, tl, qr, tr, n_nw)."""
+    target = np.ascontiguousarray(target, dtype=np.uint8)
+    read = np.ascontiguousarray(read, dtype=np.uint8)
+    at = np.ascontiguousarray(anchors_t, dtype=np.uint32)
+    aq = np.ascontiguousarray(anchors_q, dtype=np.uint32)
+    out = np.zeros(4, dtype=np.uint32)
+    rc = lib().rvn_test_window_cut(_p(target), target.shape[0], _p(read), read.shape[0], _p(at), _p(aq), at.shape[0], k,
+                                   int(boundary), _p(out))
+    if rc < 0:
+        raise ValueError("rvn_test_window_cut: invalid arguments")
+    return int(out[0]), int(out[1]), int(out[2]), int(out[3]), rc
