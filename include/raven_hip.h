@@ -87,6 +87,14 @@ uint64_t rvn_pass1_num_overlaps(const rvn_pass1* p); /* sum of per-pile list siz
 /* pile coverage: uint16 data of all piles concatenated + offsets[n+1] (Pile::data_, pile.h:133) */
 int rvn_pass1_fetch_piles(const rvn_pass1* p, uint16_t* data, uint64_t* offsets);
 /* overlaps[i] of construct.cc:666, concatenated + offsets[n+1] */
+/* raven::TrimAndAnnotatePiles' first two steps on the coverage arrays where they are, in HBM
+ * (RavenLib/src/construct.cc:131-139): Pile::FindValidRegion(coverage) + UpdateValidRegion + FindMedian
+ * (pile.cc:122-174) for every pile.  begin / end in cells (Pile::begin_ / end_, i.e. bases >> 4), invalid = the
+ * pile's is_invalid flag (the caller clears overlaps[i] for those, construct.cc:134-135); the coverage of valid piles
+ * is zeroed outside the region exactly as UpdateValidRegion does (visible through rvn_pass1_fetch_piles).
+ * FindChimericRegions (double-precision slopes) stays on the host. */
+int rvn_pass1_trim_and_annotate(rvn_pass1* p, uint32_t coverage, uint32_t* begin, uint32_t* end, uint16_t* median,
+                                uint8_t* invalid);
 int rvn_pass1_fetch_overlaps(const rvn_pass1* p, rvn_overlap* overlaps, uint32_t* offsets);
 void rvn_pass1_destroy(rvn_pass1* p);
 

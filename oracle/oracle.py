@@ -55,6 +55,7 @@ def lib():
         L.orc_chain.restype = u64
         L.orc_chain.argtypes = [vp, u32, vp, vp, u64, vp, u64]
         L.orc_pile_add_layers.argtypes = [vp, u32, vp, u64]
+        L.orc_pile_trim_and_median.argtypes = [vp, u32, C.c_uint16, vp, vp, vp, vp]
         L.orc_truncate.restype = u64
         L.orc_truncate.argtypes = [vp, u64, u64]
         L.orc_find_overlaps_and_create_piles.restype = vp
@@ -287,3 +288,13 @@ def poa_align_score_linear(target, query, m=3, n=-5, g=-4) -> int:
 
 def edit_distance(a: bytes, b: bytes) -> int:
     return int(lib().orc_edit_distance(a, len(a), b, len(b)))
+
+
+def pile_trim_and_median(data, coverage=4):
+    """raven::Pile::FindValidRegion(coverage) + FindMedian on one pile (uint16 cells, modified in place as the reference
+    does).  Returns (begin, end, median, invalid) in cell units."""
+    assert data.dtype == np.uint16 and data.flags["C_CONTIGUOUS"]
+    b, e = np.zeros(1, np.uint32), np.zeros(1, np.uint32)
+    m, inv = np.zeros(1, np.uint16), np.zeros(1, np.uint8)
+    lib().orc_pile_trim_and_median(_p(data), data.shape[0], coverage, _p(b), _p(e), _p(m), _p(inv))
+    return int(b[0]), int(e[0]), int(m[0]), bool(inv[0])

@@ -721,6 +721,47 @@ std::uint64_t orc_chain(orc_engine* e, std::uint32_t lhs_id, const std::uint64_t
   return o.size();
 }
 
+// raven::Pile::FindValidRegion(coverage) + UpdateValidRegion + FindMedian (RavenLib/src/pile.cc:122-174, called from
+// TrimAndAnnotatePiles, construct.cc:131-139) on one pile given as cells [0, n) (begin_ = 0, end_ = n):
+// valid region = the first longest maximal run of cells >= coverage that is TERMINATED by a lower cell (a run that
+// reaches the end of the pile is not considered — the reference's loop only records a run when it finds its end);
+// shorter than 1260 >> 4 cells (or none) -> invalid, data untouched; else cells outside the region are zeroed and the
+// median is the element at sorted position size / 2 of the region.
+void orc_pile_trim_and_median(std::uint16_t* data, std::uint32_t n, std::uint16_t coverage, std::uint32_t* begin,
+                              std::uint32_t* end, std::uint16_t* median, std::uint8_t* invalid) {
+  std::uint32_t best_b = 0, best_e = 0;
+  std::uint32_t i = 0;
+  while (i < n) {
+    if (data[i] < coverage) {
+      ++i;
+      continue;
+    }
+    std::uint32_t j = i + 1;
+    while (j < n && data[j] >= coverage) ++j;
+    if (j == n) break;  // no terminating cell: every later start fails the same way
+    if (best_e - best_b < j - i) {
+      best_b = i;
+      best_e = j;
+    }
+    i = j + 1;
+  }
+  *median = 0;
+  if (best_b >= best_e || best_e - best_b < (1260u >> orc::kPSS)) {
+    *invalid = 1;
+    *begin = 0;
+    *end = n;
+    return;
+  }
+  *invalid = 0;
+  for (std::uint32_t x = 0; x < best_b; ++x) data[x] = 0;
+  for (std::uint32_t x = best_e; x < n; ++x) data[x] = 0;
+  *begin = best_b;
+  *end = best_e;
+  std::vector<std::uint16_t> tmp(data + best_b, data + best_e);
+  std::nth_element(tmp.begin(), tmp.begin() + tmp.size() / 2, tmp.end());
+  *median = tmp[tmp.size() / 2];
+}
+
 void orc_pile_add_layers(std::uint16_t* data, std::uint32_t id, const orc::Overlap* ovl, std::uint64_t n) {
   orc::PileAddLayers(data, id, ovl, ovl + n);
 }

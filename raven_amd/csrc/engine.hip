@@ -396,6 +396,18 @@ int rvn_pass1_fetch_piles(const rvn_pass1* p, uint16_t* data, uint64_t* offsets)
   });
 }
 
+int rvn_pass1_trim_and_annotate(rvn_pass1* p, uint32_t coverage, uint32_t* begin, uint32_t* end, uint16_t* median,
+                                uint8_t* invalid) {
+  return guarded([&]() -> int {
+    if (!p) return fail(RVN_EINVAL, "[raven_hip] NULL pass1");
+    if (coverage > 65535) return fail(RVN_EINVAL, "[raven_hip] coverage threshold above 65535");
+    RVN_HIP(hipSetDevice(p->e->device));
+    UseTimers ut(*p->e);
+    piles_trim_and_median(*p->e, p->ps, coverage, begin, end, median, invalid);
+    return RVN_OK;
+  });
+}
+
 int rvn_pass1_fetch_overlaps(const rvn_pass1* p, rvn_overlap* overlaps, uint32_t* offsets) {
   return guarded([&]() -> int {
     if (!p) return fail(RVN_EINVAL, "[raven_hip] NULL pass1");

@@ -303,4 +303,140 @@ void piles_merge(Engine& e, const ReadsDev& r, const MapOut& mo, u32 kmax, PileS
   }
 }
 
+
+// ---- raven::Pile::FindValidRegion(coverage) + UpdateValidRegion + FindMedian on every pile of a pass ----------------
+// (RavenLib/src/pile.cc:122-174 as called by TrimAndAnnotatePiles, construct.cc:131-139; SURVEY 8(f) rank 1: consumes
+// the coverage arrays where they are, in HBM.)  One wave per pile.  Valid region = the first longest maximal run of
+// cells >= coverage that is terminated by a lower cell (the reference never records a run that reaches the end of the
+// pile); median = radix select (two 8-bit passes over an LDS histogram) of the element at sorted position size / 2.
+namespace {
+__global__ __launch_bounds__(256) void pile_trim_kernel(u16* __restrict__ data, const u64* __restrict__ pile_off, u32 n,
+                                                       u32 coverage, u32 min_cells, u32* __restrict__ out_begin,
+                                                       u32* __restrict__ out_end, u16* __restrict__ out_median,
+                                                       u8* __restrict__ out_invalid) {
+  __shared__ u32 s_hist[4][256];
+  const u32 wv = threadIdx.x >> 6;
+  const u32 pile = blockIdx.x * 4 + wv;
+  if (pile >= n) return;
+  const int lane = lane_id();
+  const u64 off = pile_off[pile];
+  const u32 len = static_cast<u32>(pile_off[pile + 1] - off);
+  u16* d = data + off;
+  u32 best_b = 0, best_e = 0, run_start = 0;
+  bool in_run = false;
+  for (u32 base = 0; base < len; base += 64) {
+    const u32 cnt = len - base < 64 ? len - base : 64;
+    const bool ge = static_cast<u32>(lane) < cnt && d[base + lane] >= coverage;
+    const unsigned long long m = __ballot(ge);
+    const unsigned long long valid = cnt == 64 ? ~0ULL : ((1ULL << cnt) - 1ULL);
+    u32 pos = 0;
+    while (pos < cnt) {
+      if (in_run) {
+        const unsigned long long z = (~m & valid) >> pos;  // next cell below the threshold
+        if (!z) break;
+        const u32 p = pos + static_cast<u32>(__builtin_ctzll(z));
+        const u32 rl_ = base + p - run_start;
+        if (best_e - best_b < rl_) {
+          best_b = run_start;
+          best_e = base + p;
+        }
+        in_run = false;
+        pos = p + 1;
+      } else {
+        const unsigned long long o = m >> pos;
+        if (!o) break;
+        const u32 p = pos + static_cast<u32>(__builtin_ctzll(o));
+        run_start = base + p;
+        in_run = true;
+        pos = p + 1;
+      }
+    }
+  }
+  const bool invalid = best_b >= best_e || best_e - best_b < min_cells;
+  if (invalid) {
+    if (lane == 0) {
+      out_begin[pile] = 0;
+      out_end[pile] = len;
+      out_median[pile] = 0;
+      out_invalid[pile] = 1;
+    }
+    return;
+  }
+  for (u32 i = lane; i < len; i += 64)
+    if (i < best_b || i >= best_e) d[i] = 0;
+  // median of d[best_b, best_e)
+  const u32 msize = best_e - best_b;
+  u32 rank = msize / 2;
+  u32* hist = s_hist[wv];
+  u32 prefix_val = 0;  // high byte once known
+  for (int pass = 0; pass < 2; ++pass) {
+    for (u32 i = lane; i < 256; i += 64) hist[i] = 0;
+    __builtin_amdgcn_wave_barrier();
+    for (u32 i = best_b + lane; i < best_e; i += 64) {
+      const u32 v = d[i];
+      if (pass == 0) atomicAdd(&hist[v >> 8], 1u);
+      else if ((v >> 8) == prefix_val) atomicAdd(&hist[v & 255u], 1u);
+    }
+    __builtin_amdgcn_wave_barrier();
+    const u32 h0 = hist[lane * 4], h1 = hist[lane * 4 + 1], h2 = hist[lane * 4 + 2], h3 = hist[lane * 4 + 3];
+    const u32 sum4 = h0 + h1 + h2 + h3;
+    const u32 incl = wave_inclusive_sum(sum4);
+    const u32 excl = incl - sum4;
+    const unsigned long long hit = __ballot(rank >= excl && rank < incl);
+    const int src = __builtin_ctzll(hit);
+    // the lane that owns the bin resolves it
+    u32 bin = 0, before = 0;
+    if (lane == src) {
+      u32 c = excl;
+      bin = lane * 4;
+      before = c;
+      if (rank >= c + h0) {
+        c += h0;
+        bin = lane * 4 + 1;
+        before = c;
+        if (rank >= c + h1) {
+          c += h1;
+          bin = lane * 4 + 2;
+          before = c;
+          if (rank >= c + h2) {
+            c += h2;
+            bin = lane * 4 + 3;
+            before = c;
+          }
+        }
+      }
+    }
+    bin = static_cast<u32>(__shfl(static_cast<int>(bin), src, 64));
+    before = static_cast<u32>(__shfl(static_cast<int>(before), src, 64));
+    rank -= before;
+    if (pass == 0) prefix_val = bin;
+    else prefix_val = (prefix_val << 8) | bin;
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (lane == 0) {
+    out_begin[pile] = best_b;
+    out_end[pile] = best_e;
+    out_median[pile] = static_cast<u16>(prefix_val);
+    out_invalid[pile] = 0;
+  }
+}
+}  // namespace
+
+void piles_trim_and_median(Engine& e, PileState& ps, u32 coverage, u32* h_begin, u32* h_end, u16* h_median, u8* h_invalid) {
+  const u32 n = ps.n;
+  if (n == 0) return;
+  hipStream_t s = e.stream;
+  u32* d_begin = e.tmp_a.get<u32>(static_cast<size_t>(n) + 1);
+  u32* d_end = e.tmp_b.get<u32>(static_cast<size_t>(n) + 1);
+  u16* d_med = e.tmp_c.get<u16>(static_cast<size_t>(n) + 1);
+  u8* d_inv = e.tmp_d.get<u8>(static_cast<size_t>(n) + 1);
+  RVN_KLAUNCH(kKPileTrim, pile_trim_kernel<<<div_up(n, 4), 256, 0, s>>>(ps.pile_data.as<u16>(), ps.pile_off.as<u64>(), n,
+                                                                       coverage, 1260u >> kPSS, d_begin, d_end, d_med, d_inv));
+  if (h_begin) RVN_HIP(hipMemcpyAsync(h_begin, d_begin, static_cast<size_t>(n) * 4, hipMemcpyDeviceToHost, s));
+  if (h_end) RVN_HIP(hipMemcpyAsync(h_end, d_end, static_cast<size_t>(n) * 4, hipMemcpyDeviceToHost, s));
+  if (h_median) RVN_HIP(hipMemcpyAsync(h_median, d_med, static_cast<size_t>(n) * 2, hipMemcpyDeviceToHost, s));
+  if (h_invalid) RVN_HIP(hipMemcpyAsync(h_invalid, d_inv, static_cast<size_t>(n), hipMemcpyDeviceToHost, s));
+  RVN_HIP(hipStreamSynchronize(s));
+}
+
 }  // namespace rvn

@@ -33,7 +33,7 @@ SYMBOLS = [
     "rvn_engine_map_batch", "rvn_engine_map_fetch", "rvn_engine_map_fetch_filtered",
     "rvn_find_overlaps_and_create_piles", "rvn_pass1_pile_words", "rvn_pass1_num_overlaps",
     "rvn_pass1_fetch_piles", "rvn_pass1_fetch_overlaps", "rvn_pass1_destroy", "rvn_pile_add_layers",
-    "rvn_edit_distance_batch", "rvn_poa_consensus_batch", "rvn_poa_phase_cycles", "rvn_polish_target_reads", "rvn_polish_set_chunk_windows", "rvn_polish_round_range", "rvn_shard_sketch", "rvn_shard_sketch_fetch",
+    "rvn_edit_distance_batch", "rvn_poa_consensus_batch", "rvn_pass1_trim_and_annotate", "rvn_poa_phase_cycles", "rvn_polish_target_reads", "rvn_polish_set_chunk_windows", "rvn_polish_round_range", "rvn_shard_sketch", "rvn_shard_sketch_fetch",
     "rvn_shard_index_build", "rvn_shard_key_counts", "rvn_engine_set_occurrence", "rvn_shard_join",
     "rvn_shard_join_fetch", "rvn_shard_chain", "rvn_shard_piles", "rvn_shard_sketch_fetch_dev",
     "rvn_shard_index_build_dev", "rvn_shard_key_histogram", "rvn_shard_join_fetch_dev", "rvn_shard_chain_dev",
@@ -206,6 +206,17 @@ class Pass1:
         off = np.zeros(self.n + 1, dtype=np.uint64)
         _check(L.rvn_pass1_fetch_piles(self._h, _p(data), _p(off)))
         return data, off
+
+    def trim_and_annotate(self, coverage=4):
+        """Pile::FindValidRegion(coverage) + FindMedian for every pile, in place in HBM: (begin, end, median, invalid)."""
+        L = lib()
+        L.rvn_pass1_trim_and_annotate.argtypes = [C.c_void_p, C.c_uint32] + [C.c_void_p] * 4
+        b = np.zeros(self.n, dtype=np.uint32)
+        e = np.zeros(self.n, dtype=np.uint32)
+        m = np.zeros(self.n, dtype=np.uint16)
+        inv = np.zeros(self.n, dtype=np.uint8)
+        _check(L.rvn_pass1_trim_and_annotate(self._h, int(coverage), _p(b), _p(e), _p(m), _p(inv)))
+        return b, e, m, inv.astype(bool)
 
     def overlaps(self):
         L = lib()

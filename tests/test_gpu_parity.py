@@ -263,3 +263,29 @@ def test_second_pass_pieces_filtered_and_add_kmers(gpu):
     assert marked > 10
     with pytest.raises(ValueError):
         he.pile_add_kmers_batch(rd, 0, [np.array([int(rs.lengths[0])], np.uint32)])
+
+
+def test_pile_trim_and_median_on_device_matches_oracle():
+    """SURVEY 8(f) rank 1: Pile::FindValidRegion(4) + FindMedian on the coverage arrays in HBM
+    (rvn_pass1_trim_and_annotate) vs the restatement of pile.cc:122-174, on the piles of a real pass plus
+    low-coverage and long reads (invalid piles, runs without a terminator, multi-chunk piles)."""
+    g = synth.make_genome(150_000, seed=77)
+    rs, _ = synth.make_reads(g, 12, 9000, length_model="lognormal", seed=78)
+    eng = hip.Engine(15, 5)
+    p = eng.find_overlaps_and_create_piles(eng.upload(rs))
+    data, off = p.piles()
+    b, e, m, inv = p.trim_and_annotate(4)
+    after, _ = p.piles()
+    n_valid = 0
+    for i in range(rs.n):
+        want = data[int(off[i]):int(off[i + 1])].copy()
+        wb, we, wm, winv = oracle.pile_trim_and_median(want, 4)
+        assert (int(b[i]), int(e[i]), int(m[i]), bool(inv[i])) == (wb, we, wm, winv), i
+        assert np.array_equal(after[int(off[i]):int(off[i + 1])], want), i
+        n_valid += not winv
+    assert 0.3 * rs.n < n_valid < rs.n            # both outcomes occur
+    # idempotent on the trimmed data only where the region was terminated by the zeroed cells: run it again
+    b2, e2, m2, inv2 = p.trim_and_annotate(4)
+    ok = ~inv
+    assert np.array_equal(b2[ok], b[ok]) and np.array_equal(e2[ok], e[ok]) and np.array_equal(m2[ok], m[ok])
+    p.close()

@@ -248,3 +248,48 @@ def test_edit_distance():
         assert oracle.edit_distance(a, b) == refimpl.edit_distance(a, b)
     assert oracle.edit_distance(b"", b"ACGT") == 4
     assert oracle.edit_distance(b"ACGT", b"ACGT") == 0
+
+
+def _brute_trim(data, coverage=4, min_cells=1260 >> 4):
+    """Independent restatement of Pile::FindValidRegion + UpdateValidRegion + FindMedian (pile.cc:122-174) with numpy:
+    maximal runs of cells >= coverage that are followed by a lower cell; first longest wins."""
+    ge = np.concatenate([[False], data >= coverage, [False]])
+    starts = np.nonzero(ge[1:] & ~ge[:-1])[0]
+    ends = np.nonzero(~ge[1:] & ge[:-1])[0]
+    runs = [(int(s), int(e)) for s, e in zip(starts, ends) if e < data.shape[0]]  # terminated inside the pile
+    best = (0, 0)
+    for s, e in runs:
+        if e - s > best[1] - best[0]:
+            best = (s, e)
+    out = data.copy()
+    if best[1] - best[0] < min_cells:
+        return 0, data.shape[0], 0, True, out
+    out[:best[0]] = 0
+    out[best[1]:] = 0
+    return best[0], best[1], int(np.sort(data[best[0]:best[1]])[(best[1] - best[0]) // 2]), False, out
+
+
+def test_pile_trim_and_median_restatement():
+    rng = np.random.default_rng(17)
+    cases = [np.zeros(0, np.uint16), np.full(200, 9, np.uint16), np.array([9] * 100 + [0], np.uint16),
+             np.array([0, 5, 5, 5, 1] + [9] * 100 + [0] + [7] * 90, np.uint16),
+             np.array([9] * 77 + [0] + [9] * 78 + [0] + [9] * 78 + [0], np.uint16)]  # two equally long runs: first wins
+    for _ in range(200):
+        n = int(rng.integers(1, 700))
+        d = rng.integers(0, 12, size=n).astype(np.uint16)
+        # plant plateaus so that long runs exist
+        for _ in range(int(rng.integers(0, 4))):
+            a = int(rng.integers(0, n))
+            d[a:a + int(rng.integers(1, 300))] += np.uint16(rng.integers(4, 4000))
+        cases.append(d)
+    n_valid = 0
+    for d in cases:
+        got = d.copy()
+        b, e, m, inv = oracle.pile_trim_and_median(got)
+        wb, we, wm, winv, wout = _brute_trim(d)
+        assert (b, e, m, inv) == (wb, we, wm, winv), (d.tolist()[:20], (b, e, m, inv), (wb, we, wm, winv))
+        assert np.array_equal(got, wout)
+        n_valid += not inv
+    assert n_valid > 20
+    b, e, m, inv = oracle.pile_trim_and_median(cases[4].copy())
+    assert (b, e, inv) == (78, 156, False)
