@@ -80,3 +80,11 @@ def check_against_single(res, data, poff, kept, koff):
     assert np.array_equal(res["pile_data"], data[int(poff[lo]):int(poff[hi])])
     assert np.array_equal(res["overlap_off"], koff[lo:hi + 1] - koff[lo])
     assert np.array_equal(res["overlaps"], kept[int(koff[lo]):int(koff[hi])])
+
+
+def free_port():
+    """A TCP port nobody listens on right now (rendezvous of the multi-process tests)."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]

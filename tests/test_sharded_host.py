@@ -103,7 +103,7 @@ def test_comm_over_gloo_world2(tmp_path):
     script.write_text(WORKER)
     env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                        "--master-addr", "127.0.0.1", "--master-port", "29533", str(script)], capture_output=True,
+                        "--master-addr", "127.0.0.1", "--master-port", str(sharded_util.free_port()), str(script)], capture_output=True,
                        text=True, timeout=300, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "COMM_OK_0" in r.stdout and "COMM_OK_1" in r.stdout, r.stdout[-2000:]
