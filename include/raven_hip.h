@@ -234,11 +234,12 @@ int rvn_polish_target_reads(const rvn_engine* e, uint32_t* counts, uint32_t n_ta
 void rvn_poa_phase_cycles(const rvn_engine* e, uint64_t out[6]);
 
 /* Which window kernel rvn_poa_consensus_batch / rvn_polish_round use: 0 (default) = banded LDS kernel with a
- * 64-column band; windows whose alignment touches the band edge are repeated with a 128-column band, and what is
- * left (or beyond a limit) by the full-matrix kernel; 1 = full-matrix kernel only; 2 = 64-column band only;
- * 3 = 128-column band only (2, 3: flagged windows come back with status 8).  Returns the previous mode. */
+ * 64-column band; windows whose alignment touches the band edge are repeated with 128 and then 256 columns, and
+ * what is left (or beyond a limit) by the full-matrix kernel; 1 = full-matrix kernel only; 2 / 3 / 4 = 64- / 128- /
+ * 256-column band only (flagged windows come back with status 8).  Returns the previous mode. */
 int rvn_poa_set_mode(rvn_engine* e, int mode);
-/* number of windows of the last batch that were re-run by the full-matrix kernel / with the wide band (mode 0) */
+/* mode 0: windows of the last batch repeated with the 128-column band (wide) / that needed more than that (fallback:
+ * 256 columns or the full matrix) */
 uint32_t rvn_poa_fallback_windows(const rvn_engine* e);
 uint32_t rvn_poa_wide_windows(const rvn_engine* e);
 

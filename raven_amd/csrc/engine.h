@@ -111,8 +111,9 @@ struct Engine {
   DevBuf lis_min, lis_pred, lis_tail, lis_mask, ovl_slots, ovl_flags, ovl_scan;
   DevBuf poa_scratch, poa2_scratch, polish_quals;
   std::vector<u32> polish_target_reads;  // reads used per target in the last polishing round
-  int poa_mode = 0;  // 0 banded 64 -> 128 -> full matrix; 1 full matrix only; 2 band 64 only; 3 band 128 only (tests)
-  u32 poa_fallback_windows = 0;  // windows of the last batch re-run by the full-matrix kernel
+  int poa_mode = 0;  // 0 banded 64 -> 128 -> 256 -> full matrix; 1 full matrix only; 2 / 3 / 4 band 64 / 128 / 256 only (tests)
+  u32 poa_fallback_windows = 0;  // windows of the last batch that needed more than the 128-column band
+  u32 poa_fullmatrix_windows = 0;  // ... of which re-run by the full-matrix kernel
   u32 poa_wide_windows = 0;      // windows of the last batch re-run with the 128-column band
   DevBuf anc_slot_off, anc_slot_cnt;
   bool keep_anchors = false;  // map_batch also returns the chain anchors of every overlap

@@ -657,12 +657,13 @@ void poa_run(Engine& e, const std::vector<PoaWindow>& wins, const std::vector<Po
   b.phase_cycles = d_phase;
   RVN_HIP(hipEventRecord(e.ev0, s));
   if (e.poa_mode == 1) poa_v1_launch(e, b);
-  else poa_v2_launch(e, b, e.poa_mode == 3 ? 2 : 1);
+  else poa_v2_launch(e, b, e.poa_mode == 3 ? 2 : (e.poa_mode == 4 ? 4 : 1));
   RVN_HIP(hipMemcpyAsync(h_out_len, d_len, static_cast<size_t>(n_windows) * 4, hipMemcpyDeviceToHost, s));
   RVN_HIP(hipMemcpyAsync(h_status, d_status, static_cast<size_t>(n_windows) * 4, hipMemcpyDeviceToHost, s));
   RVN_HIP(hipStreamSynchronize(s));
   e.poa_fallback_windows = 0;
   e.poa_wide_windows = 0;
+  e.poa_fullmatrix_windows = 0;
   if (e.poa_mode == 0) {
     // escalate what the 64-column band could not do: band hits -> 128-column band -> full matrix; windows beyond a
     // limit (nodes / in-degree / length) -> full matrix directly
@@ -679,7 +680,7 @@ void poa_run(Engine& e, const std::vector<PoaWindow>& wins, const std::vector<Po
       rb.out_len = d_rlen;
       rb.status = d_rstatus;
       rb.sched = nullptr;
-      if (which == 2) poa_v2_launch(e, rb, 2);
+      if (which == 2 || which == 4) poa_v2_launch(e, rb, which);
       else poa_v1_launch(e, rb);
       std::vector<u32> rl(redo.size()), rs(redo.size());
       RVN_HIP(hipMemcpyAsync(rl.data(), d_rlen, rl.size() * 4, hipMemcpyDeviceToHost, s));
@@ -690,7 +691,7 @@ void poa_run(Engine& e, const std::vector<PoaWindow>& wins, const std::vector<Po
         h_status[redo[i]] = rs[i];
       }
     };
-    std::vector<u32> wide, fullm;
+    std::vector<u32> wide, wider, fullm;
     for (u32 w = 0; w < n_windows; ++w) {
       const u32 st = h_status[w] & 0xFF;
       if (st == kPoaBandHit) wide.push_back(w);
@@ -704,15 +705,26 @@ void poa_run(Engine& e, const std::vector<PoaWindow>& wins, const std::vector<Po
       }
       for (u32 w : fullm) std::fprintf(stderr, "[raven_hip] poa: window %u status %u -> full matrix\n", w, h_status[w]);
     }
-    if (!wide.empty()) {
+    if (!wide.empty()) {  // 128 columns
       rerun(wide, 2);
       e.poa_wide_windows = static_cast<u32>(wide.size());
-      for (u32 w : wide)
+      for (u32 w : wide) {
+        const u32 st = h_status[w] & 0xFF;
+        if (st == kPoaBandHit) wider.push_back(w);
+        else if (st >= 2) fullm.push_back(w);
+      }
+    }
+    const size_t direct_full = fullm.size();  // limits hit in the first two stages: not a matter of band width
+    if (!wider.empty()) {  // 256 columns
+      rerun(wider, 4);
+      e.poa_fallback_windows = static_cast<u32>(wider.size() + direct_full);
+      for (u32 w : wider)
         if ((h_status[w] & 0xFF) >= 2) fullm.push_back(w);
     }
+    if (wider.empty()) e.poa_fallback_windows = static_cast<u32>(direct_full);
     if (!fullm.empty() && allow_full) {
       rerun(fullm, 1);
-      e.poa_fallback_windows = static_cast<u32>(fullm.size());
+      e.poa_fullmatrix_windows = static_cast<u32>(fullm.size());
     }
   }
   RVN_HIP(hipEventRecord(e.ev1, s));

@@ -31,7 +31,7 @@ namespace {
 constexpr int kRing = 32;  // score rows kept in LDS
 // The band is NCH chunks of 64 columns (one column per lane and chunk).  NCH = 1 (+-32 around the expected
 // column) is the first attempt; windows whose traceback touches the band edge are repeated with NCH = 2 and, if
-// that is not enough either, by the full-matrix kernel.
+// that is not enough either with NCH = 4 (256 columns, two waves per workgroup) before the full-matrix kernel.
 constexpr u32 kNone = 0xFFFFu;
 constexpr i32 kNegBig = -0x3FFFFFFF;
 
@@ -159,26 +159,18 @@ __device__ __noinline__ u32 poa2_nth_pred(const Poa2Slot& g, u32 v, u32 k, bool 
 // Ring miss: predecessor row `pr` from the int16 copy in HBM.  Out of line on purpose: on gfx9 the vector memory
 // counter is shared by loads and stores, so a load on the common path would make every DP row wait for the
 // previous row's stores.
-__device__ __noinline__ int4 poa2_fetch_miss(const Poa2Slot& g, u32 pr, i32 j0, i32 j1, bool two, i32 kBand) {
+__device__ __noinline__ void poa2_fetch_miss(const Poa2Slot& g, u32 pr, i32 j_first, int nch, i32 kBand, i32* up,
+                                             i32* dg) {
   const i32 pb = static_cast<i32>(g.tb[pr].x & 0xFFFFu);
   const i16* R = g.Hs + static_cast<size_t>(pr) * kBand;
-  const i32 i0 = j0 - pb, i1 = j1 - pb;
-  const i32 a0 = i0 < 0 ? 0 : (i0 > kBand - 1 ? kBand - 1 : i0);
-  const i32 a0m = i0 < 1 ? 0 : (i0 > kBand ? kBand - 1 : i0 - 1);
-  const i32 u0 = R[a0], d0 = R[a0m];
-  int4 r;
-  r.x = (i0 >= 0 && i0 < kBand) ? u0 : kNegInf16;
-  r.y = (i0 >= 1 && i0 <= kBand) ? d0 : kNegInf16;
-  r.z = kNegInf16;
-  r.w = kNegInf16;
-  if (two) {
-    const i32 a1 = i1 < 0 ? 0 : (i1 > kBand - 1 ? kBand - 1 : i1);
-    const i32 a1m = i1 < 1 ? 0 : (i1 > kBand ? kBand - 1 : i1 - 1);
-    const i32 u1 = R[a1], d1 = R[a1m];
-    r.z = (i1 >= 0 && i1 < kBand) ? u1 : kNegInf16;
-    r.w = (i1 >= 1 && i1 <= kBand) ? d1 : kNegInf16;
+  for (int c = 0; c < nch; ++c) {
+    const i32 i0 = j_first + 64 * c - pb;
+    const i32 a0 = i0 < 0 ? 0 : (i0 > kBand - 1 ? kBand - 1 : i0);
+    const i32 a0m = i0 < 1 ? 0 : (i0 > kBand ? kBand - 1 : i0 - 1);
+    const i32 u0 = R[a0], d0 = R[a0m];
+    up[c] = (i0 >= 0 && i0 < kBand) ? u0 : kNegInf16;
+    dg[c] = (i0 >= 1 && i0 <= kBand) ? d0 : kNegInf16;
   }
-  return r;
 }
 
 __device__ __forceinline__ int rl(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
@@ -321,7 +313,6 @@ __device__ __forceinline__ u32 poa2_window(const PoaWindow& win, const PoaLayer*
         const i32 b = rl(m_b, static_cast<int>(ri));
         const u32 vc = static_cast<u32>(rl(m_code, static_cast<int>(ri)));
         if (np == 0) np = 1;  // no in-edge inside the subgraph: the virtual start row (p01 == 0)
-        const bool two = NCH > 1 && b + 64 < static_cast<i32>(w);  // second chunk has columns of the sequence
         i32 j[NCH], jg[NCH], sc[NCH], bd[NCH], bv[NCH];
         u32 kd[NCH], kv[NCH];
         bool val[NCH], dok[NCH];
@@ -369,13 +360,7 @@ __device__ __forceinline__ u32 poa2_window(const PoaWindow& win, const PoaLayer*
                 wsync();
                 dirty = false;
               }
-              const int4 r = poa2_fetch_miss(g, pr, j[0], j[NCH - 1], two, kBand);
-              up[0] = r.x;
-              dg[0] = r.y;
-              if (NCH > 1) {
-                up[NCH - 1] = r.z;
-                dg[NCH - 1] = r.w;
-              }
+              poa2_fetch_miss(g, pr, j[0], NCH, kBand, up, dg);
             }
           }
 #pragma unroll
@@ -395,7 +380,7 @@ __device__ __forceinline__ u32 poa2_window(const PoaWindow& win, const PoaLayer*
         i32 carry = 0;
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
-          if (c == 0 || two) {
+          if (c == 0 || b + 64 * c < static_cast<i32>(w)) {  // the chunk has columns of the sequence
             const i32 best = bd[c] >= bv[c] ? bd[c] : bv[c];
             u32 code = bd[c] >= bv[c] ? kd[c] : 16u + kv[c];
             i32 x = val[c] ? best - jg[c] : kNegBig;
@@ -424,8 +409,9 @@ __device__ __forceinline__ u32 poa2_window(const PoaWindow& win, const PoaLayer*
         if (rl(m_outc, static_cast<int>(ri)) == 0) {  // an end node: score of the last column if the band has it
           const i32 idx = static_cast<i32>(w) - 1 - b;
           i32 sce = -0x7FFFFFFF;
-          if (idx >= 0 && idx < 64) sce = rl(h[0], idx);
-          else if (NCH > 1 && idx >= 64 && idx < kBand && two) sce = rl(h[NCH - 1], idx - 64);
+#pragma unroll
+          for (int c = 0; c < NCH; ++c)
+            if (idx >= 64 * c && idx < 64 * (c + 1)) sce = rl(h[c], idx - 64 * c);  // that chunk is active: idx < w - b
           if (sce > best_score) {
             best_score = sce;
             best_row = row;
@@ -702,8 +688,8 @@ __device__ __forceinline__ u32 poa2_window(const PoaWindow& win, const PoaLayer*
   return 1;
 }
 
-template <int NCH>
-__global__ __launch_bounds__(256) void poa2_kernel(const PoaWindow* __restrict__ windows, u32 n_windows,
+template <int NCH, int WPB>
+__global__ __launch_bounds__(64 * WPB) void poa2_kernel(const PoaWindow* __restrict__ windows, u32 n_windows,
                                                   const PoaLayer* __restrict__ layers, const PoaSrc src,
                                                   unsigned char* __restrict__ scratch,
                                                   size_t slot_bytes, u32 n_slots, u32 nmax, u32 lmax, int m, int n_,
@@ -711,9 +697,9 @@ __global__ __launch_bounds__(256) void poa2_kernel(const PoaWindow* __restrict__
                                                   u32* __restrict__ status,
                                                   unsigned long long* __restrict__ phase_cycles,
                                                   const u32* __restrict__ sched, u32* __restrict__ next) {
-  __shared__ Poa2Lds<NCH> lds[4];
+  __shared__ Poa2Lds<NCH> lds[WPB];
   const u32 wv = static_cast<u32>(__builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6)));
-  const u32 slot = blockIdx.x * 4 + wv;
+  const u32 slot = blockIdx.x * WPB + wv;
   if (slot >= n_slots) return;
   Poa2Slot g = poa2_carve(scratch + static_cast<size_t>(slot) * slot_bytes, nmax, lmax, 64 * NCH);
   for (;;) {
@@ -741,13 +727,17 @@ void poa_v2_launch(Engine& e, const PoaBatchDev& b, int nch) {
   unsigned char* d_scratch = e.poa2_scratch.get<unsigned char>(static_cast<size_t>(n_slots) * slot_bytes + 256);
   RVN_HIP(hipMemsetAsync(b.next, 0, 4, e.stream));
   if (nch == 1) {
-    RVN_KLAUNCH(kKPoaBanded, poa2_kernel<1><<<n_slots / 4, 256, 0, e.stream>>>(
+    RVN_KLAUNCH(kKPoaBanded, (poa2_kernel<1, 4><<<n_slots / 4, 256, 0, e.stream>>>(
                                  b.wins, b.n_windows, b.layers, b.src, d_scratch, slot_bytes, n_slots, b.nmax,
-                                 b.lmax, b.m, b.n, b.g, b.trim, b.out, b.out_len, b.status, b.phase_cycles, b.sched, b.next));
-  } else {
-    RVN_KLAUNCH(kKPoaBanded, poa2_kernel<2><<<n_slots / 4, 256, 0, e.stream>>>(
+                                 b.lmax, b.m, b.n, b.g, b.trim, b.out, b.out_len, b.status, b.phase_cycles, b.sched, b.next)));
+  } else if (nch == 2) {
+    RVN_KLAUNCH(kKPoaBanded, (poa2_kernel<2, 4><<<n_slots / 4, 256, 0, e.stream>>>(
                                  b.wins, b.n_windows, b.layers, b.src, d_scratch, slot_bytes, n_slots, b.nmax,
-                                 b.lmax, b.m, b.n, b.g, b.trim, b.out, b.out_len, b.status, b.phase_cycles, b.sched, b.next));
+                                 b.lmax, b.m, b.n, b.g, b.trim, b.out, b.out_len, b.status, b.phase_cycles, b.sched, b.next)));
+  } else {  // 256 columns: 21.6 KB of LDS per wave -> 2 waves per workgroup
+    RVN_KLAUNCH(kKPoaBanded, (poa2_kernel<4, 2><<<n_slots / 2, 128, 0, e.stream>>>(
+                                 b.wins, b.n_windows, b.layers, b.src, d_scratch, slot_bytes, n_slots, b.nmax,
+                                 b.lmax, b.m, b.n, b.g, b.trim, b.out, b.out_len, b.status, b.phase_cycles, b.sched, b.next)));
   }
 }
 

@@ -139,6 +139,10 @@ def test_band_escalation_matches_full_matrix_kernel():
     _, st64, _ = eng.poa_consensus_batch(wins)
     eng.poa_set_mode(3)
     _, st128, _ = eng.poa_consensus_batch(wins)
+    eng.poa_set_mode(4)
+    c256, st256, _ = eng.poa_consensus_batch(wins)
+    assert np.all(st256 == 1)          # 256 columns hold even the 150-base indels
+    assert eng.poa_set_mode(3) == 4
     assert (st64 & 0xFF).tolist()[0] == 1 and np.all((st64 & 0xFF)[2:] == 8), st64
     assert (st128 & 0xFF).tolist()[:2] == [1, 1] and (st128 & 0xFF)[3] == 8, st128
     assert eng.poa_set_mode(0) == 3
@@ -158,9 +162,9 @@ def test_kernel_modes_agree_on_noisy_windows():
             for _ in range(32)]
     eng = hip.Engine()
     out = {}
-    for mode in (1, 2, 3):
+    for mode in (1, 2, 3, 4):
         eng.poa_set_mode(mode)
         out[mode], st, _ = eng.poa_consensus_batch(wins)
         assert np.all(st == 1), (mode, st)
-    for a, b, c in zip(out[1], out[2], out[3]):
-        assert np.array_equal(a, b) and np.array_equal(a, c)
+    for a, b, c, d in zip(out[1], out[2], out[3], out[4]):
+        assert np.array_equal(a, b) and np.array_equal(a, c) and np.array_equal(a, d)

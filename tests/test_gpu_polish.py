@@ -68,12 +68,12 @@ def test_lambda_polish_matches_golden_fixture(with_qual):
     cons, ratio, st = eng.polish_round(eng.upload(seqio.pack_reads([draft])), eng.upload(rs),
                                        quals=quals if with_qual else None, q=avg_q if with_qual else 0.0)
     if not with_qual:
-        # real reads without the quality filter need the wide band / full-matrix kernel for some windows: with small
-        # chunks those are collected and run in one final batch, which must not change a byte
+        # real reads without the quality filter need more than the 128-column band for some windows (256 columns or the
+        # full-matrix kernel; with small chunks the latter are collected and run in one final batch): no byte may change
         assert eng.poa_fallback_windows() >= 1
         eng.polish_set_chunk_windows(16)
         cons2, ratio2, _ = eng.polish_round(eng.upload(seqio.pack_reads([draft])), eng.upload(rs))
-        assert np.array_equal(cons2[0], cons[0]) and ratio2[0] == ratio[0] and eng.poa_fallback_windows() >= 1
+        assert np.array_equal(cons2[0], cons[0]) and ratio2[0] == ratio[0]
     ref = fx["consensus" if with_qual else "consensus_noqual"]
     ed_ref = int(fx["ed_consensus" if with_qual else "ed_consensus_noqual"][0])
     assert st["n_failed_windows"] == 0 and ratio[0] == 1.0
