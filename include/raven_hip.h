@@ -185,6 +185,10 @@ int rvn_shard_index_build(rvn_engine* e, const uint64_t* values, const uint64_t*
 int rvn_shard_key_counts(rvn_engine* e, uint32_t* counts /* n_keys of rvn_engine_index_size */);
 int rvn_engine_set_occurrence(rvn_engine* e, uint32_t occurrence);
 int rvn_shard_join(rvn_engine* e, uint32_t n_reads_total, int avoid_equal, int avoid_symmetric, uint64_t* n_matches);
+/* same, restricted to the query reads [query_first, query_last) of one flush window (construct.cc:56-70): a pass with
+ * several flush windows joins, chains and merges window by window, exactly as the reference flushes */
+int rvn_shard_join_range(rvn_engine* e, uint32_t n_reads_total, int avoid_equal, int avoid_symmetric,
+                         uint32_t query_first, uint32_t query_last, uint64_t* n_matches);
 int rvn_shard_join_fetch(rvn_engine* e, uint64_t* group, uint64_t* positions, uint64_t* seg_off /* n_reads_total+1 */);
 int rvn_shard_chain(rvn_engine* e, const rvn_reads* own_reads, const uint64_t* group, const uint64_t* positions,
                     const uint64_t* seg_off /* own n + 1 */, uint64_t* n_overlaps);
@@ -192,6 +196,13 @@ int rvn_shard_chain(rvn_engine* e, const rvn_reads* own_reads, const uint64_t* g
  * overlaps are complete in the list (the caller's own range) are meaningful in the returned handle */
 int rvn_shard_piles(rvn_engine* e, const uint32_t* lengths, uint32_t n_reads_total, const rvn_overlap* overlaps,
                     uint64_t n, uint32_t kmax, rvn_pass1** out);
+
+/* piles kept across the flush windows of a pass: create once, merge the Map outputs of every window (each merge =
+ * the serial merge + AddLayers + top-kMax truncation of one flush, construct.cc:72-110); rvn_shard_piles = both */
+int rvn_shard_piles_create(rvn_engine* e, const uint32_t* lengths, uint32_t n_reads_total, rvn_pass1** out);
+int rvn_shard_piles_merge(rvn_pass1* p, const rvn_overlap* overlaps, uint64_t n, uint32_t kmax);
+int rvn_shard_piles_merge_dev(rvn_pass1* p, const rvn_overlap* d_overlaps, const uint32_t* d_overlap_read_off, uint64_t n,
+                              uint32_t kmax);
 
 /* Device-pointer variants of the same stages: every d_* argument is a pointer into HBM owned by the caller (the
  * torch CUDA tensors the exchanges run on), so nothing crosses PCIe between the stages.  Calls are synchronous with

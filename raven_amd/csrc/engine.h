@@ -176,7 +176,8 @@ void map_batch(Engine& e, const ReadsDev& r, u32 first, u32 last, bool avoid_equ
                bool minhash, bool want_filtered, MapOut& out);
 
 // self-join of the index for global query ids 0..n_reads-1 -> e.m_grp[0] / e.m_pos[0] / e.seg_off (map.hip)
-u64 join_index_matches(Engine& e, u32 n_reads, bool avoid_equal, bool avoid_symmetric);
+u64 join_index_matches(Engine& e, u32 n_reads, bool avoid_equal, bool avoid_symmetric, u32 q_lo = 0,
+                       u32 q_hi = 0xFFFFFFFFu);  // only query reads with q_lo <= id < q_hi
 // chain stage of Map on matches already in e.m_grp[0] / e.m_pos[0] / e.seg_off (map.hip)
 void chain_matches(Engine& e, const ReadsDev& r, u32 first, u32 last, u64 H, MapOut& out);
 

@@ -28,6 +28,7 @@ struct rvn_pass1 {
   std::unique_ptr<PileState> state;
   PileState& ps;
   std::weak_ptr<int> engine_life;  // a handle may outlive its engine (e.g. interpreter teardown order)
+  std::unique_ptr<ReadsDev> meta;  // sharded pass: lengths / ids of ALL reads (piles need no bases)
   explicit rvn_pass1(Engine& eng)
       : e(&eng), state(eng.pile_pool ? eng.pile_pool : new PileState()), ps(*state), engine_life(eng.life) {
     eng.pile_pool = nullptr;
@@ -661,13 +662,18 @@ int rvn_engine_set_occurrence(rvn_engine* h, uint32_t occurrence) {
 }
 
 int rvn_shard_join(rvn_engine* h, uint32_t n_reads_total, int avoid_equal, int avoid_symmetric, uint64_t* n_matches) {
+  return rvn_shard_join_range(h, n_reads_total, avoid_equal, avoid_symmetric, 0, n_reads_total, n_matches);
+}
+
+int rvn_shard_join_range(rvn_engine* h, uint32_t n_reads_total, int avoid_equal, int avoid_symmetric, uint32_t query_first,
+                         uint32_t query_last, uint64_t* n_matches) {
   return guarded([&]() -> int {
     if (!h || !n_matches) return fail(RVN_EINVAL, "[raven_hip] rvn_shard_join: NULL argument");
     Engine& e = h->e;
     RVN_HIP(hipSetDevice(e.device));
     UseTimers ut(e);
     e.shard_join_reads = n_reads_total;
-    e.shard_join_matches = join_index_matches(e, n_reads_total, avoid_equal != 0, avoid_symmetric != 0);
+    e.shard_join_matches = join_index_matches(e, n_reads_total, avoid_equal != 0, avoid_symmetric != 0, query_first, query_last);
     *n_matches = e.shard_join_matches;
     RVN_HIP(hipStreamSynchronize(e.stream));
     return RVN_OK;
@@ -724,15 +730,15 @@ int rvn_shard_chain(rvn_engine* h, const rvn_reads* own, const uint64_t* grp, co
   });
 }
 
-int rvn_shard_piles(rvn_engine* h, const uint32_t* lengths, uint32_t n_reads_total, const rvn_overlap* overlaps,
-                    uint64_t n, uint32_t kmax, rvn_pass1** out) {
+int rvn_shard_piles_create(rvn_engine* h, const uint32_t* lengths, uint32_t n_reads_total, rvn_pass1** out) {
   return guarded([&]() -> int {
-    if (!h || !lengths || !out || (n && !overlaps)) return fail(RVN_EINVAL, "[raven_hip] rvn_shard_piles: NULL argument");
+    if (!h || !lengths || !out) return fail(RVN_EINVAL, "[raven_hip] rvn_shard_piles_create: NULL argument");
     Engine& e = h->e;
     RVN_HIP(hipSetDevice(e.device));
-    UseTimers ut(e);
+    std::unique_ptr<rvn_pass1> p(new rvn_pass1(e));
     // metadata-only read set: piles need lengths and ids (== indices), not bases
-    ReadsDev meta;
+    p->meta.reset(new ReadsDev());
+    ReadsDev& meta = *p->meta;
     meta.n = n_reads_total;
     meta.h_len.assign(lengths, lengths + n_reads_total);
     meta.h_id.resize(n_reads_total);
@@ -744,6 +750,20 @@ int rvn_shard_piles(rvn_engine* h, const uint32_t* lengths, uint32_t n_reads_tot
       RVN_HIP(hipMemcpy(d_len, meta.h_len.data(), static_cast<size_t>(n_reads_total) * 4, hipMemcpyHostToDevice));
       RVN_HIP(hipMemcpy(d_id, meta.h_id.data(), static_cast<size_t>(n_reads_total) * 4, hipMemcpyHostToDevice));
     }
+    piles_init(e, meta, p->ps);
+    *out = p.release();
+    return RVN_OK;
+  });
+}
+
+// One flush (construct.cc:79-110) of a sharded pass: merge the Map outputs of the window into the piles, AddLayers, truncate.
+int rvn_shard_piles_merge(rvn_pass1* p, const rvn_overlap* overlaps, uint64_t n, uint32_t kmax) {
+  return guarded([&]() -> int {
+    if (!p || !p->meta || (n && !overlaps)) return fail(RVN_EINVAL, "[raven_hip] rvn_shard_piles_merge: bad handle or NULL overlaps");
+    Engine& e = *p->e;
+    RVN_HIP(hipSetDevice(e.device));
+    UseTimers ut(e);
+    const u32 n_reads_total = p->meta->n;
     // overlaps arrive in (query read k, emission) order; per-k offsets as Map would have produced them
     std::vector<u32> off(static_cast<size_t>(n_reads_total) + 1, 0);
     const Overlap* ov = reinterpret_cast<const Overlap*>(overlaps);
@@ -763,13 +783,49 @@ int rvn_shard_piles(rvn_engine* h, const uint32_t* lengths, uint32_t n_reads_tot
     if (n) RVN_HIP(hipMemcpy(d_ov, ov, n * sizeof(Overlap), hipMemcpyHostToDevice));
     u32* d_off = mo.ovl_read_off.get<u32>(off.size());
     RVN_HIP(hipMemcpy(d_off, off.data(), off.size() * 4, hipMemcpyHostToDevice));
-    std::unique_ptr<rvn_pass1> p(new rvn_pass1(e));
-    piles_init(e, meta, p->ps);
-    piles_merge(e, meta, mo, kmax, p->ps);
+    piles_merge(e, *p->meta, mo, kmax, p->ps);
     RVN_HIP(hipStreamSynchronize(e.stream));
-    *out = p.release();
     return RVN_OK;
   });
+}
+
+int rvn_shard_piles_merge_dev(rvn_pass1* p, const rvn_overlap* d_overlaps, const uint32_t* d_ovl_read_off, uint64_t n,
+                              uint32_t kmax) {
+  return guarded([&]() -> int {
+    if (!p || !p->meta || !d_ovl_read_off || (n && !d_overlaps))
+      return fail(RVN_EINVAL, "[raven_hip] rvn_shard_piles_merge_dev: bad handle or NULL argument");
+    Engine& e = *p->e;
+    RVN_HIP(hipSetDevice(e.device));
+    UseTimers ut(e);
+    const u32 n_reads_total = p->meta->n;
+    MapOut mo;
+    mo.first = 0;
+    mo.last = n_reads_total;
+    mo.n_overlaps = n;
+    Overlap* d_ov = mo.ovl.get<Overlap>(n + 1);
+    if (n) RVN_HIP(hipMemcpyAsync(d_ov, d_overlaps, n * sizeof(Overlap), hipMemcpyDeviceToDevice, e.stream));
+    u32* d_off = mo.ovl_read_off.get<u32>(static_cast<size_t>(n_reads_total) + 1);
+    RVN_HIP(hipMemcpyAsync(d_off, d_ovl_read_off, (static_cast<size_t>(n_reads_total) + 1) * 4, hipMemcpyDeviceToDevice,
+                           e.stream));
+    piles_merge(e, *p->meta, mo, kmax, p->ps);
+    RVN_HIP(hipStreamSynchronize(e.stream));
+    return RVN_OK;
+  });
+}
+
+int rvn_shard_piles(rvn_engine* h, const uint32_t* lengths, uint32_t n_reads_total, const rvn_overlap* overlaps,
+                    uint64_t n, uint32_t kmax, rvn_pass1** out) {
+  if (!out) return fail(RVN_EINVAL, "[raven_hip] rvn_shard_piles: NULL argument");
+  rvn_pass1* p = nullptr;
+  int rc = rvn_shard_piles_create(h, lengths, n_reads_total, &p);
+  if (rc != RVN_OK) return rc;
+  rc = rvn_shard_piles_merge(p, overlaps, n, kmax);
+  if (rc != RVN_OK) {
+    rvn_pass1_destroy(p);
+    return rc;
+  }
+  *out = p;
+  return RVN_OK;
 }
 
 // ---- device-pointer variants: the exchange buffers of the sharded pass stay in HBM (torch CUDA tensors) ----
@@ -917,40 +973,17 @@ int rvn_engine_map_fetch_dev(rvn_engine* h, rvn_overlap* d_overlaps, uint32_t* d
 
 int rvn_shard_piles_dev(rvn_engine* h, const uint32_t* lengths, uint32_t n_reads_total, const rvn_overlap* d_overlaps,
                         const uint32_t* d_ovl_read_off, uint64_t n, uint32_t kmax, rvn_pass1** out) {
-  return guarded([&]() -> int {
-    if (!h || !lengths || !out || !d_ovl_read_off || (n && !d_overlaps))
-      return fail(RVN_EINVAL, "[raven_hip] rvn_shard_piles_dev: NULL argument");
-    Engine& e = h->e;
-    RVN_HIP(hipSetDevice(e.device));
-    UseTimers ut(e);
-    ReadsDev meta;
-    meta.n = n_reads_total;
-    meta.h_len.assign(lengths, lengths + n_reads_total);
-    meta.h_id.resize(n_reads_total);
-    for (u32 i = 0; i < n_reads_total; ++i) meta.h_id[i] = i;
-    meta.ids_are_indices = true;
-    u32* d_len = meta.len.get<u32>(static_cast<size_t>(n_reads_total) + 1);
-    u32* d_id = meta.id.get<u32>(static_cast<size_t>(n_reads_total) + 1);
-    if (n_reads_total) {
-      RVN_HIP(hipMemcpy(d_len, meta.h_len.data(), static_cast<size_t>(n_reads_total) * 4, hipMemcpyHostToDevice));
-      RVN_HIP(hipMemcpy(d_id, meta.h_id.data(), static_cast<size_t>(n_reads_total) * 4, hipMemcpyHostToDevice));
-    }
-    MapOut mo;
-    mo.first = 0;
-    mo.last = n_reads_total;
-    mo.n_overlaps = n;
-    Overlap* d_ov = mo.ovl.get<Overlap>(n + 1);
-    if (n) RVN_HIP(hipMemcpyAsync(d_ov, d_overlaps, n * sizeof(Overlap), hipMemcpyDeviceToDevice, e.stream));
-    u32* d_off = mo.ovl_read_off.get<u32>(static_cast<size_t>(n_reads_total) + 1);
-    RVN_HIP(hipMemcpyAsync(d_off, d_ovl_read_off, (static_cast<size_t>(n_reads_total) + 1) * 4, hipMemcpyDeviceToDevice,
-                           e.stream));
-    std::unique_ptr<rvn_pass1> p(new rvn_pass1(e));
-    piles_init(e, meta, p->ps);
-    piles_merge(e, meta, mo, kmax, p->ps);
-    RVN_HIP(hipStreamSynchronize(e.stream));
-    *out = p.release();
-    return RVN_OK;
-  });
+  if (!out) return fail(RVN_EINVAL, "[raven_hip] rvn_shard_piles_dev: NULL argument");
+  rvn_pass1* p = nullptr;
+  int rc = rvn_shard_piles_create(h, lengths, n_reads_total, &p);
+  if (rc != RVN_OK) return rc;
+  rc = rvn_shard_piles_merge_dev(p, d_overlaps, d_ovl_read_off, n, kmax);
+  if (rc != RVN_OK) {
+    rvn_pass1_destroy(p);
+    return rc;
+  }
+  *out = p;
+  return RVN_OK;
 }
 
 uint64_t rvn_polish_set_chunk_windows(rvn_engine* h, uint64_t windows) {

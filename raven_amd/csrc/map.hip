@@ -109,7 +109,7 @@ __global__ void match_emit_kernel(const u64* __restrict__ q_org, u64 nq, const u
 template <bool EMIT>
 __global__ __launch_bounds__(256) void join_kernel(const u32* __restrict__ u_start, u32 n_runs,
                                                   const u64* __restrict__ s_org, u32 occurrence, int all_query,
-                                                  int avoid_equal, int avoid_symmetric, u32 first,
+                                                  int avoid_equal, int avoid_symmetric, u32 first, u32 q_lo, u32 q_hi,
                                                   u32* __restrict__ read_cnt, const u64* __restrict__ seg_off,
                                                   u32* __restrict__ cursor, u64* __restrict__ m_grp,
                                                   u64* __restrict__ m_pos) {
@@ -123,6 +123,7 @@ __global__ __launch_bounds__(256) void join_kernel(const u32* __restrict__ u_sta
     const u64 qo = s_org[s + i];
     if (!all_query && !(qo & kQueryFlag)) continue;
     const u32 qid = origin_id(qo);
+    if (qid < q_lo || qid >= q_hi) continue;  // query reads of another flush window (sharded pass)
     u32 cnt = 0;
     for (u32 j = 0; j < c; ++j) {
       const u32 rid = origin_id(s_org[s + j]);
@@ -886,7 +887,7 @@ void map_batch_impl(Engine& e, const ReadsDev& r, u32 first, u32 last, bool avoi
     const u64* sorg = ix.s_org[ix.cur].as<u64>();
     RVN_KLAUNCH(kKJoinCount, join_kernel<false><<<div_up(n_runs, 256), 256, 0, s>>>(
                                  ix.u_start.as<u32>(), n_runs, sorg, ix.occurrence, ix.all_query, avoid_equal,
-                                 avoid_symmetric, r.h_id.empty() ? 0 : r.h_id[first], read_cnt, nullptr, nullptr,
+                                 avoid_symmetric, r.h_id.empty() ? 0 : r.h_id[first], 0u, 0xFFFFFFFFu, read_cnt, nullptr, nullptr,
                                  nullptr, nullptr));
     exclusive_scan_u32_u64(read_cnt, seg_off, nr, e.scan_tmp, s);
     H = read_back(e, seg_off + nr, 8);
@@ -899,7 +900,7 @@ void map_batch_impl(Engine& e, const ReadsDev& r, u32 first, u32 last, bool avoi
       e.m_pos[1].reserve((H + 1) * 8);
       RVN_KLAUNCH(kKJoinEmit, join_kernel<true><<<div_up(n_runs, 256), 256, 0, s>>>(
                                   ix.u_start.as<u32>(), n_runs, sorg, ix.occurrence, ix.all_query, avoid_equal,
-                                  avoid_symmetric, r.h_id[first], nullptr, seg_off, cursor, g0, p0));
+                                  avoid_symmetric, r.h_id[first], 0u, 0xFFFFFFFFu, nullptr, seg_off, cursor, g0, p0));
     }
     t.stop();
   }
@@ -966,7 +967,7 @@ void map_batch_impl(Engine& e, const ReadsDev& r, u32 first, u32 last, bool avoi
 // matches land in e.m_grp[0] / e.m_pos[0], segmented by query id through e.seg_off[n_reads + 1].  The hash-owner
 // side of the sharded pass: the owner of a hash class joins its runs and ships every read's matches
 // to the GPU that owns the read.  Returns the number of matches.
-u64 join_index_matches(Engine& e, u32 n_reads, bool avoid_equal, bool avoid_symmetric) {
+u64 join_index_matches(Engine& e, u32 n_reads, bool avoid_equal, bool avoid_symmetric, u32 q_lo, u32 q_hi) {
   hipStream_t s = e.stream;
   Index& ix = e.index;
   u64* seg_off = e.seg_off.get<u64>(static_cast<size_t>(n_reads) + 2);
@@ -981,7 +982,7 @@ u64 join_index_matches(Engine& e, u32 n_reads, bool avoid_equal, bool avoid_symm
   const u64* sorg = ix.s_org[ix.cur].as<u64>();
   RVN_KLAUNCH(kKJoinCount, join_kernel<false><<<div_up(n_runs, 256), 256, 0, s>>>(
                                ix.u_start.as<u32>(), n_runs, sorg, ix.occurrence, ix.all_query, avoid_equal,
-                               avoid_symmetric, 0, read_cnt, nullptr, nullptr, nullptr, nullptr));
+                               avoid_symmetric, 0, q_lo, q_hi, read_cnt, nullptr, nullptr, nullptr, nullptr));
   exclusive_scan_u32_u64(read_cnt, seg_off, n_reads, e.scan_tmp, s);
   const u64 H = read_back(e, seg_off + n_reads, 8);
   e.c_matches += H;
@@ -990,7 +991,7 @@ u64 join_index_matches(Engine& e, u32 n_reads, bool avoid_equal, bool avoid_symm
   if (H)
     RVN_KLAUNCH(kKJoinEmit, join_kernel<true><<<div_up(n_runs, 256), 256, 0, s>>>(
                                 ix.u_start.as<u32>(), n_runs, sorg, ix.occurrence, ix.all_query, avoid_equal,
-                                avoid_symmetric, 0, nullptr, seg_off, cursor, g0, p0));
+                                avoid_symmetric, 0, q_lo, q_hi, nullptr, seg_off, cursor, g0, p0));
   t.stop();
   return H;
 }

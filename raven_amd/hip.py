@@ -35,7 +35,8 @@ SYMBOLS = [
     "rvn_pass1_fetch_piles", "rvn_pass1_fetch_overlaps", "rvn_pass1_destroy", "rvn_pile_add_layers",
     "rvn_edit_distance_batch", "rvn_poa_consensus_batch", "rvn_pass1_trim_and_annotate", "rvn_poa_phase_cycles", "rvn_polish_target_reads", "rvn_polish_set_chunk_windows", "rvn_polish_round_range", "rvn_shard_sketch", "rvn_shard_sketch_fetch",
     "rvn_shard_index_build", "rvn_shard_key_counts", "rvn_engine_set_occurrence", "rvn_shard_join",
-    "rvn_shard_join_fetch", "rvn_shard_chain", "rvn_shard_piles", "rvn_shard_sketch_fetch_dev",
+    "rvn_shard_join_fetch", "rvn_shard_chain", "rvn_shard_piles", "rvn_shard_join_range", "rvn_shard_piles_create",
+    "rvn_shard_piles_merge", "rvn_shard_piles_merge_dev", "rvn_shard_sketch_fetch_dev",
     "rvn_shard_index_build_dev", "rvn_shard_key_histogram", "rvn_shard_join_fetch_dev", "rvn_shard_chain_dev",
     "rvn_engine_map_fetch_dev", "rvn_shard_piles_dev", "rvn_poa_set_mode", "rvn_poa_fallback_windows", "rvn_poa_wide_windows", "rvn_pile_add_kmers_batch",
     "rvn_test_low_complexity", "rvn_test_window_cut", "rvn_polish_round",
@@ -108,6 +109,10 @@ def lib():
     L.rvn_engine_set_occurrence.argtypes = [vp, u32]
     L.rvn_shard_join.argtypes = [vp, u32, i32, i32, C.POINTER(u64)]
     L.rvn_shard_join_fetch.argtypes = [vp, vp, vp, vp]
+    L.rvn_shard_join_range.argtypes = [vp, u32, i32, i32, u32, u32, C.POINTER(u64)]
+    L.rvn_shard_piles_create.argtypes = [vp, vp, u32, C.POINTER(vp)]
+    L.rvn_shard_piles_merge.argtypes = [vp, vp, u64, u32]
+    L.rvn_shard_piles_merge_dev.argtypes = [vp, vp, vp, u64, u32]
     L.rvn_shard_chain.argtypes = [vp, vp, vp, vp, vp, C.POINTER(u64)]
     L.rvn_shard_piles.argtypes = [vp, vp, u32, vp, u64, u32, C.POINTER(vp)]
     L.rvn_shard_sketch_fetch_dev.argtypes = [vp, vp, vp]
@@ -206,6 +211,14 @@ class Pass1:
         off = np.zeros(self.n + 1, dtype=np.uint64)
         _check(L.rvn_pass1_fetch_piles(self._h, _p(data), _p(off)))
         return data, off
+
+    def merge(self, overlaps, kmax=32):
+        """Sharded pass: one flush (merge + AddLayers + truncation) of overlaps in (query read, emission) order."""
+        overlaps = np.ascontiguousarray(overlaps, dtype=OVERLAP_DTYPE)
+        _check(lib().rvn_shard_piles_merge(self._h, _p(overlaps), overlaps.shape[0], kmax))
+
+    def merge_dev(self, d_overlaps, d_read_off, n, kmax=32):
+        _check(lib().rvn_shard_piles_merge_dev(self._h, d_overlaps, d_read_off, int(n), kmax))
 
     def trim_and_annotate(self, coverage=4):
         """Pile::FindValidRegion(coverage) + FindMedian for every pile, in place in HBM: (begin, end, median, invalid)."""
@@ -325,9 +338,11 @@ class Engine:
     def set_occurrence(self, occurrence):
         _check(lib().rvn_engine_set_occurrence(self._h, int(occurrence)))
 
-    def shard_join(self, n_reads_total, avoid_equal=True, avoid_symmetric=True):
+    def shard_join(self, n_reads_total, avoid_equal=True, avoid_symmetric=True, query_first=0, query_last=None):
         h = C.c_uint64(0)
-        _check(lib().rvn_shard_join(self._h, n_reads_total, int(avoid_equal), int(avoid_symmetric), C.byref(h)))
+        query_last = n_reads_total if query_last is None else query_last
+        _check(lib().rvn_shard_join_range(self._h, n_reads_total, int(avoid_equal), int(avoid_symmetric), query_first,
+                                          query_last, C.byref(h)))
         grp = np.zeros(h.value, dtype=np.uint64)
         pos = np.zeros(h.value, dtype=np.uint64)
         seg = np.zeros(n_reads_total + 1, dtype=np.uint64)
@@ -345,6 +360,13 @@ class Engine:
         off = np.zeros(own_reads.n + 1, dtype=np.uint32)
         _check(lib().rvn_engine_map_fetch(self._h, _p(ovl), _p(off)))
         return ovl, off
+
+    def shard_piles_create(self, lengths) -> Pass1:
+        """Empty piles of ALL reads; Pass1.merge / merge_dev add the Map outputs of one flush window each."""
+        lengths = np.ascontiguousarray(lengths, dtype=np.uint32)
+        h = C.c_void_p()
+        _check(lib().rvn_shard_piles_create(self._h, _p(lengths), lengths.shape[0], C.byref(h)))
+        return Pass1(h, lengths.shape[0])
 
     def shard_piles(self, lengths, overlaps, kmax=32) -> Pass1:
         lengths = np.ascontiguousarray(lengths, dtype=np.uint32)
@@ -373,9 +395,11 @@ class Engine:
         _check(lib().rvn_shard_key_histogram(self._h, _p(hist), _p(over), over.shape[0], C.byref(n)))
         return hist.astype(np.int64), over[:n.value].astype(np.int64)
 
-    def shard_join_count(self, n_reads_total, avoid_equal=True, avoid_symmetric=True) -> int:
+    def shard_join_count(self, n_reads_total, avoid_equal=True, avoid_symmetric=True, query_first=0, query_last=None) -> int:
         h = C.c_uint64(0)
-        _check(lib().rvn_shard_join(self._h, n_reads_total, int(avoid_equal), int(avoid_symmetric), C.byref(h)))
+        query_last = n_reads_total if query_last is None else query_last
+        _check(lib().rvn_shard_join_range(self._h, n_reads_total, int(avoid_equal), int(avoid_symmetric), query_first,
+                                          query_last, C.byref(h)))
         return int(h.value)
 
     def shard_join_fetch_dev(self, d_grp, d_pos, d_seg):

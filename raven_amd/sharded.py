@@ -13,8 +13,10 @@ The compute of every stage is the same device code as the single-GPU pass (``rvn
 is only the partitioning and the exchanges.  Result for the reads a rank owns: bit-identical to the single-GPU pass
 (tests/test_gpu_sharded.py), because (a) pieces are concatenated in source-rank order = global (read, position)
 order, which is the order ram's stable sort and the reference's serial merge see, and (b) the order of a read's
-matches does not matter (total-order sorts follow).  Limits of this round: one index batch and one flush window
-(total bases < 2^30, i.e. configs[1]/[2]).  Two variants: `find_overlaps_and_create_piles_sharded` stages the
+matches does not matter (total-order sorts follow).  Flush windows (2^30 bases of query reads each, construct.cc:56-70)
+are processed one after the other — join of the window's query reads, exchange, chain, exchange, merge + AddLayers +
+truncation into piles that persist across the windows — exactly as the reference flushes, so a pass with several
+windows (configs[3]/[4]) is bit-identical as well; one index batch (total bases < 2^32) is the limit.  Two variants: `find_overlaps_and_create_piles_sharded` stages the
 exchange buffers through host memory (numpy; gloo or RCCL), `find_overlaps_and_create_piles_sharded_dev` keeps them in
 HBM as torch CUDA tensors (RCCL) — initialise torch.cuda before creating engines in that process.
 """
@@ -44,6 +46,20 @@ def slice_reads(rs: seqio.ReadSet, lo: int, hi: int) -> seqio.ReadSet:
                          word_offsets=(rs.word_offsets[lo:hi + 1] - np.uint64(w0)).astype(np.uint64),
                          lengths=np.ascontiguousarray(rs.lengths[lo:hi]),
                          ids=np.arange(lo, hi, dtype=np.uint32))
+
+
+def flush_windows(lengths: np.ndarray, flush_bases: int):
+    """Query windows of a pass as the reference flushes them (construct.cc:56-70): a window closes with the read that
+    brings its bases to flush_bases, or with the last read."""
+    out, first, acc = [], 0, 0
+    n = int(lengths.shape[0])
+    for k in range(n):
+        acc += int(lengths[k])
+        if k != n - 1 and acc < flush_bases:
+            continue
+        out.append((first, k + 1))
+        first, acc = k + 1, 0
+    return out
 
 
 def hash_owner(values: np.ndarray, world: int) -> np.ndarray:
@@ -156,14 +172,14 @@ class Comm:
 
 
 def find_overlaps_and_create_piles_sharded(eng, rs_all: seqio.ReadSet, comm: Comm, freq=0.001, kmax=32,
-                                           use_minhash=False):
+                                           use_minhash=False, flush_bases=1 << 30):
     """Returns dict(lo, hi, pile_data, pile_off, overlaps, overlap_off, stats) for the reads [lo, hi) this rank
     owns; arrays are laid out like rvn_pass1_fetch_* restricted to that range."""
     from . import hip
     g, world = comm.rank, comm.world
     n_total = rs_all.n
-    if rs_all.total_bases >= (1 << 30):
-        raise ValueError("sharded pass: one flush window only this round (total bases must be < 2^30)")
+    if rs_all.total_bases >= (1 << 32):
+        raise ValueError("sharded pass: one index batch only (total bases must be < 2^32)")
     bounds = partition_reads(rs_all.lengths, world)
     lo, hi = int(bounds[g]), int(bounds[g + 1])
     own = eng.upload(slice_reads(rs_all, lo, hi))
@@ -183,26 +199,31 @@ def find_overlaps_and_create_piles_sharded(eng, rs_all: seqio.ReadSet, comm: Com
     occ = global_occurrence(eng.shard_key_counts(), freq, comm)
     eng.set_occurrence(occ)
 
-    # 4. self-join of the shard; matches (candidate pairs) to the owner of the query read
-    grp, pos, seg = eng.shard_join(n_total, True, True)
-    per_read = np.diff(seg.astype(np.int64))
-    m_cuts = [int(seg[bounds[h]]) for h in range(world)] + [int(seg[n_total])]
-    cnt_r = comm.all_to_all_v([per_read[bounds[h]:bounds[h + 1]] for h in range(world)])
-    grp_r = comm.all_to_all_v([grp[m_cuts[h]:m_cuts[h + 1]] for h in range(world)])
-    pos_r = comm.all_to_all_v([pos[m_cuts[h]:m_cuts[h + 1]] for h in range(world)])
-    seg_own, (grp_own, pos_own) = regroup_by_read(cnt_r, list(zip(grp_r, pos_r)))
-
-    # 5. chain own reads' matches
-    ovl, _ = eng.shard_chain(own, grp_own, pos_own, seg_own)
-
-    # 6. overlaps also to the owner of their rhs read (own ones are already here); merge + piles
-    rhs_owner = np.searchsorted(bounds, ovl["rhs_id"].astype(np.int64), side="right") - 1
+    # 4.-6. per flush window of query reads, exactly as the reference flushes (merge + AddLayers + truncation per window)
     empty = np.zeros(0, dtype=hip.OVERLAP_DTYPE)
-    recv = comm.all_to_all_v([ovl[rhs_owner == h] if h != g else empty for h in range(world)])
-    for s in range(g + 1, world):
-        assert recv[s].shape[0] == 0, "avoid_symmetric: overlaps only travel to higher ranks"
-    combined = np.concatenate([recv[s] for s in range(g)] + [ovl]) if world > 1 else ovl
-    p = eng.shard_piles(rs_all.lengths, combined, kmax)
+    p = eng.shard_piles_create(rs_all.lengths)
+    n_matches_sent = n_overlaps_sent = n_map_overlaps = 0
+    for q_a, q_b in flush_windows(rs_all.lengths, flush_bases):
+        # self-join of the shard for the window's query reads; candidate pairs to the owner of the query read
+        grp, pos, seg = eng.shard_join(n_total, True, True, q_a, q_b)
+        per_read = np.diff(seg.astype(np.int64))
+        m_cuts = [int(seg[bounds[h]]) for h in range(world)] + [int(seg[n_total])]
+        cnt_r = comm.all_to_all_v([per_read[bounds[h]:bounds[h + 1]] for h in range(world)])
+        grp_r = comm.all_to_all_v([grp[m_cuts[h]:m_cuts[h + 1]] for h in range(world)])
+        pos_r = comm.all_to_all_v([pos[m_cuts[h]:m_cuts[h + 1]] for h in range(world)])
+        seg_own, (grp_own, pos_own) = regroup_by_read(cnt_r, list(zip(grp_r, pos_r)))
+        n_matches_sent += int(grp.shape[0] - (m_cuts[g + 1] - m_cuts[g]))
+        # chain own reads' matches
+        ovl, _ = eng.shard_chain(own, grp_own, pos_own, seg_own)
+        n_map_overlaps += int(ovl.shape[0])
+        # overlaps also to the owner of their rhs read (own ones are already here); merge + piles
+        rhs_owner = np.searchsorted(bounds, ovl["rhs_id"].astype(np.int64), side="right") - 1
+        recv = comm.all_to_all_v([ovl[rhs_owner == h] if h != g else empty for h in range(world)])
+        n_overlaps_sent += int(np.sum(rhs_owner != g)) if ovl.shape[0] else 0
+        for s_ in range(g + 1, world):
+            assert recv[s_].shape[0] == 0, "avoid_symmetric: overlaps only travel to higher ranks"
+        combined = np.concatenate([recv[s_] for s_ in range(g)] + [ovl]) if world > 1 else ovl
+        p.merge(combined, kmax)
     data, poff = p.piles()
     kept, koff = p.overlaps()
     p.close()
@@ -211,9 +232,8 @@ def find_overlaps_and_create_piles_sharded(eng, rs_all: seqio.ReadSet, comm: Com
                pile_off=(poff[lo:hi + 1] - poff[lo]).astype(np.uint64),
                overlaps=kept[int(koff[lo]):int(koff[hi])].copy(),
                overlap_off=(koff[lo:hi + 1] - koff[lo]).astype(np.uint32),
-               stats=dict(minimizers_sent=int(val.shape[0] - cnt[g]), matches_sent=int(grp.shape[0] - (m_cuts[g + 1] - m_cuts[g])),
-                          overlaps_sent=int(ovl.shape[0] and np.sum(rhs_owner != g)), map_overlaps=int(ovl.shape[0]),
-                          bytes_sent=comm.bytes_sent))
+               stats=dict(minimizers_sent=int(val.shape[0] - cnt[g]), matches_sent=n_matches_sent,
+                          overlaps_sent=n_overlaps_sent, map_overlaps=n_map_overlaps, bytes_sent=comm.bytes_sent))
     return res
 
 
@@ -273,14 +293,14 @@ class DeviceComm(Comm):
 
 
 def find_overlaps_and_create_piles_sharded_dev(eng, rs_all: seqio.ReadSet, comm, device, freq=0.001, kmax=32,
-                                               use_minhash=False):
+                                               use_minhash=False, flush_bases=1 << 30):
     """find_overlaps_and_create_piles_sharded with every exchange buffer resident in HBM (`device`: torch device of
     the engine's GPU; `comm`: DeviceComm or a test double with all_to_all_t / all_reduce_sum / all_gather_v)."""
     import torch
     g, world = comm.rank, comm.world
     n_total = rs_all.n
-    if rs_all.total_bases >= (1 << 30):
-        raise ValueError("sharded pass: one flush window only this round (total bases must be < 2^30)")
+    if rs_all.total_bases >= (1 << 32):
+        raise ValueError("sharded pass: one index batch only (total bases must be < 2^32)")
     bounds = partition_reads(rs_all.lengths, world)
     lo, hi = int(bounds[g]), int(bounds[g + 1])
     own = eng.upload(slice_reads(rs_all, lo, hi))
@@ -289,6 +309,10 @@ def find_overlaps_and_create_piles_sharded_dev(eng, rs_all: seqio.ReadSet, comm,
     # 1. sketch; minimizers to the owner of their hash class (stable sort keeps (read, position) order)
     n = eng.shard_sketch_count(own, index_minhash=use_minhash)
     val, org = torch.empty(n, **i64), torch.empty(n, **i64)
+    # rule of this function: the engine works on its own stream, so before it WRITES into freshly allocated torch memory
+    # (which the caching allocator may have recycled from tensors with torch work still in flight) and before it READS
+    # tensors torch produced, the device is synchronised
+    torch.cuda.synchronize(device)
     eng.shard_sketch_fetch_dev(val.data_ptr(), org.data_ptr())
     owner = hash_owner_t(val, world)
     order = torch.sort(owner, stable=True).indices
@@ -305,45 +329,50 @@ def find_overlaps_and_create_piles_sharded_dev(eng, rs_all: seqio.ReadSet, comm,
     occ = occurrence_from_histogram(hist, over, freq, comm)
     eng.set_occurrence(occ)
 
-    # 4. self-join; candidate pairs to the owner of the query read
-    n_m = eng.shard_join_count(n_total, True, True)
-    grp, pos = torch.empty(n_m, **i64), torch.empty(n_m, **i64)
-    seg = torch.empty(n_total + 1, **i64)
-    eng.shard_join_fetch_dev(grp.data_ptr(), pos.data_ptr(), seg.data_ptr())
-    per_read = seg[1:] - seg[:-1]
+    # 4.-6. per flush window of query reads (merge + AddLayers + truncation per window, as the reference flushes)
     b_list = [int(x) for x in bounds]
-    m_cuts = seg[torch.tensor(b_list, device=device)].tolist()
-    m_split = [int(m_cuts[h + 1] - m_cuts[h]) for h in range(world)]
-    r_split = [b_list[h + 1] - b_list[h] for h in range(world)]
-    cnt_r = comm.all_to_all_t(list(torch.split(per_read, r_split)))
-    grp_r = comm.all_to_all_t(list(torch.split(grp, m_split)))
-    pos_r = comm.all_to_all_t(list(torch.split(pos, m_split)))
-    seg_own, (grp_own, pos_own) = regroup_by_read_t(cnt_r, list(zip(grp_r, pos_r)))
-
-    # 5. chain
-    torch.cuda.synchronize(device)
-    n_o = eng.shard_chain_dev(own, grp_own.data_ptr(), pos_own.data_ptr(), seg_own.data_ptr(), grp_own.shape[0])
-    ovl = torch.empty((n_o, 4), **i64)
-    off_own = torch.empty(own.n + 1, dtype=torch.int32, device=device)
-    eng.map_fetch_dev(ovl.data_ptr(), off_own.data_ptr())
-
-    # 6. overlaps also to the owner of their rhs read; merge + piles
     bounds_t = torch.tensor(b_list, **i64)
-    rhs = (ovl[:, 1] >> 32) & 0xFFFFFFFF
-    rhs_owner = torch.searchsorted(bounds_t, rhs, right=True) - 1
-    parts = [ovl[rhs_owner == h].reshape(-1) if h != g else torch.zeros(0, **i64) for h in range(world)]
-    sent = sum(int(p.shape[0]) for p in parts) // 4
-    recv = comm.all_to_all_t(parts)
-    for s in range(g + 1, world):
-        assert recv[s].shape[0] == 0, "avoid_symmetric: overlaps only travel to higher ranks"
-    combined = torch.cat([recv[s].reshape(-1, 4) for s in range(g)] + [ovl]).contiguous() if world > 1 else ovl
-    lhs = combined[:, 0] & 0xFFFFFFFF
-    off_all = torch.zeros(n_total + 1, **i64)
-    if combined.shape[0]:
-        torch.cumsum(torch.bincount(lhs, minlength=n_total), 0, out=off_all[1:])
-    off32 = off_all.to(torch.int32).contiguous()
-    torch.cuda.synchronize(device)
-    p = eng.shard_piles_dev(rs_all.lengths, combined.data_ptr(), off32.data_ptr(), combined.shape[0], kmax)
+    r_split = [b_list[h + 1] - b_list[h] for h in range(world)]
+    p = eng.shard_piles_create(rs_all.lengths)
+    n_matches_sent = n_sent = n_map = 0
+    for q_a, q_b in flush_windows(rs_all.lengths, flush_bases):
+        n_m = eng.shard_join_count(n_total, True, True, q_a, q_b)
+        grp, pos = torch.empty(n_m, **i64), torch.empty(n_m, **i64)
+        seg = torch.empty(n_total + 1, **i64)
+        torch.cuda.synchronize(device)
+        eng.shard_join_fetch_dev(grp.data_ptr(), pos.data_ptr(), seg.data_ptr())
+        per_read = seg[1:] - seg[:-1]
+        m_cuts = seg[bounds_t].tolist()
+        m_split = [int(m_cuts[h + 1] - m_cuts[h]) for h in range(world)]
+        cnt_r = comm.all_to_all_t(list(torch.split(per_read, r_split)))
+        grp_r = comm.all_to_all_t(list(torch.split(grp, m_split)))
+        pos_r = comm.all_to_all_t(list(torch.split(pos, m_split)))
+        seg_own, (grp_own, pos_own) = regroup_by_read_t(cnt_r, list(zip(grp_r, pos_r)))
+        n_matches_sent += int(n_m - m_split[g])
+        # chain
+        torch.cuda.synchronize(device)
+        n_o = eng.shard_chain_dev(own, grp_own.data_ptr(), pos_own.data_ptr(), seg_own.data_ptr(), grp_own.shape[0])
+        ovl = torch.empty((n_o, 4), **i64)
+        off_own = torch.empty(own.n + 1, dtype=torch.int32, device=device)
+        torch.cuda.synchronize(device)
+        eng.map_fetch_dev(ovl.data_ptr(), off_own.data_ptr())
+        n_map += int(n_o)
+        # overlaps also to the owner of their rhs read; merge + piles
+        rhs = (ovl[:, 1] >> 32) & 0xFFFFFFFF
+        rhs_owner = torch.searchsorted(bounds_t, rhs, right=True) - 1
+        parts = [ovl[rhs_owner == h].reshape(-1) if h != g else torch.zeros(0, **i64) for h in range(world)]
+        n_sent += sum(int(x.shape[0]) for x in parts) // 4
+        recv = comm.all_to_all_t(parts)
+        for s_ in range(g + 1, world):
+            assert recv[s_].shape[0] == 0, "avoid_symmetric: overlaps only travel to higher ranks"
+        combined = torch.cat([recv[s_].reshape(-1, 4) for s_ in range(g)] + [ovl]).contiguous() if world > 1 else ovl
+        lhs = combined[:, 0] & 0xFFFFFFFF
+        off_all = torch.zeros(n_total + 1, **i64)
+        if combined.shape[0]:
+            torch.cumsum(torch.bincount(lhs, minlength=n_total), 0, out=off_all[1:])
+        off32 = off_all.to(torch.int32).contiguous()
+        torch.cuda.synchronize(device)
+        p.merge_dev(combined.data_ptr(), off32.data_ptr(), combined.shape[0], kmax)
     data, poff = p.piles()
     kept, koff = p.overlaps()
     p.close()
@@ -352,8 +381,8 @@ def find_overlaps_and_create_piles_sharded_dev(eng, rs_all: seqio.ReadSet, comm,
                 pile_off=(poff[lo:hi + 1] - poff[lo]).astype(np.uint64),
                 overlaps=kept[int(koff[lo]):int(koff[hi])].copy(),
                 overlap_off=(koff[lo:hi + 1] - koff[lo]).astype(np.uint32),
-                stats=dict(minimizers_sent=int(n - cnt[g]), matches_sent=int(n_m - m_split[g]), overlaps_sent=int(sent),
-                           map_overlaps=int(n_o), bytes_sent=comm.bytes_sent))
+                stats=dict(minimizers_sent=int(n - cnt[g]), matches_sent=n_matches_sent, overlaps_sent=int(n_sent),
+                           map_overlaps=n_map, bytes_sent=comm.bytes_sent))
 
 
 # ---- polishing round sharded by windows (windows are independent; no data-path collective but the final gather) ----

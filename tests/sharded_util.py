@@ -35,6 +35,8 @@ class LocalComm:
         self.g.slots[self.rank] = parts
         self.g.barrier.wait()
         res = [self.g.slots[s][self.rank].clone() for s in range(self.world)]
+        import torch
+        torch.cuda.synchronize()  # the copies must have happened before the senders may recycle their buffers
         self.bytes_sent += sum(8 * int(p.shape[0]) for i, p in enumerate(parts) if i != self.rank)
         self.g.barrier.wait()
         return res

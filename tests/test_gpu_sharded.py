@@ -144,3 +144,30 @@ def test_polishing_round_sharded_by_windows_is_byte_identical(world):
         assert np.allclose(ratio, ref_ratio)
         for t in range(3):
             assert np.array_equal(cons[t], ref[t])
+
+
+@pytest.mark.parametrize("variant", ["host", "device"])
+def test_sharded_pass_with_several_flush_windows(variant):
+    """A pass whose query reads are flushed in several windows (2^30 bases each in the reference; 300 kb here): piles
+    persist across the windows, truncation happens per flush — the result depends on the flush schedule and must match
+    the single-GPU pass run with the same one."""
+    import torch
+    g = synth.make_genome(200_000, seed=101)
+    rs, _ = synth.make_reads(g, 25, 5000, seed=102)
+    flush = 300_000
+    assert len(sharded.flush_windows(rs.lengths, flush)) >= 10
+    data, poff, kept, koff, occ = _single(rs, kmax=8, flush_bases=flush)
+    one_flush = _single(rs, kmax=8)
+    assert not np.array_equal(one_flush[2], kept)          # the schedule does change the result ...
+
+    def rank_fn(r, comm):
+        eng = hip.Engine(15, 5)
+        if variant == "host":
+            return sharded.find_overlaps_and_create_piles_sharded(eng, rs, comm, kmax=8, flush_bases=flush)
+        return sharded.find_overlaps_and_create_piles_sharded_dev(eng, rs, comm, torch.device("cuda", 0), kmax=8,
+                                                                  flush_bases=flush)
+
+    for world in (1, 3):
+        for x in sharded_util.run_ranks(world, rank_fn):
+            assert x["occurrence"] == occ
+            sharded_util.check_against_single(x, data, poff, kept, koff)   # ... and the sharded pass follows it

@@ -107,3 +107,13 @@ def test_comm_over_gloo_world2(tmp_path):
                        text=True, timeout=300, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "COMM_OK_0" in r.stdout and "COMM_OK_1" in r.stdout, r.stdout[-2000:]
+
+
+def test_flush_windows_follow_the_reference_schedule():
+    # construct.cc:56-70: bytes += len; flush when bytes >= limit or at the last read
+    L = np.array([5, 5, 5, 5, 5], dtype=np.uint32)
+    assert sharded.flush_windows(L, 10) == [(0, 2), (2, 4), (4, 5)]
+    assert sharded.flush_windows(L, 11) == [(0, 3), (3, 5)]
+    assert sharded.flush_windows(L, 1000) == [(0, 5)]
+    assert sharded.flush_windows(L, 1) == [(i, i + 1) for i in range(5)]
+    assert sharded.flush_windows(np.zeros(0, np.uint32), 10) == []
