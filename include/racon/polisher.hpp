@@ -61,10 +61,13 @@ class Polisher {
     t.Upload(engine_, targets.begin(), targets.end());
     // raven::Polish calls Polish() once per round with the SAME read set (polish.cc:50-51): upload it (and expand
     // its qualities) only when the container changes
-    if (reads_.h == nullptr || reads_key_ != sequences.data() || reads_n_ != sequences.size()) {
+    // (same storage, same size AND same content fingerprint: a caller may refill the vector in place)
+    const std::uint64_t fp = Fingerprint(sequences);
+    if (reads_.h == nullptr || reads_key_ != sequences.data() || reads_n_ != sequences.size() || reads_fp_ != fp) {
       reads_.Upload(engine_, sequences.begin(), sequences.end());
       reads_key_ = sequences.data();
       reads_n_ = sequences.size();
+      reads_fp_ = fp;
       // per-base Phred+33 from biosoup's block qualities, only if every read has them
       has_q_ = !sequences.empty();
       for (const auto& s : sequences) has_q_ = has_q_ && !s->block_quality.empty();
@@ -108,8 +111,28 @@ class Polisher {
   }
 
   rvn_engine* handle() const { return engine_; }
+  // forget the device copy of the read set (the next Polish() uploads again)
+  void Invalidate() {
+    rvn_reads_destroy(reads_.h);
+    reads_.h = nullptr;
+  }
 
  private:
+  // cheap content fingerprint of a read set: ids, lengths and one data word of every read (FNV-1a)
+  static std::uint64_t Fingerprint(const Sequences& sequences) {
+    std::uint64_t h = 1469598103934665603ULL;
+    auto mix = [&h](std::uint64_t v) {
+      h ^= v;
+      h *= 1099511628211ULL;
+    };
+    for (const auto& s : sequences) {
+      mix(s->id);
+      mix(s->inflated_len);
+      if (!s->deflated_data.empty()) mix(s->deflated_data[s->deflated_data.size() / 2]);
+    }
+    return h;
+  }
+
   Polisher(double q, double e, std::uint32_t w, bool trim, std::int8_t m, std::int8_t n, std::int8_t g, int device)
       : q_(q), e_(e), w_(w), trim_(trim), m_(m), n_(n), g_(g) {
     // racon maps with ram's (k = 15, w = 5, bandwidth 500, chain 4, matches 100, gap 10000)
@@ -125,6 +148,7 @@ class Polisher {
   ram::detail::ReadsHandle reads_;
   const void* reads_key_ = nullptr;
   std::size_t reads_n_ = 0;
+  std::uint64_t reads_fp_ = 0;
   bool has_q_ = false;
   std::vector<std::uint8_t> quals_;
   std::vector<std::uint64_t> qoff_;

@@ -7,8 +7,9 @@
 //
 // Differences a maintainer should know about:
 //  * the thread pool argument is accepted and ignored (parallelism is on the device);
-//  * Map() on a single sequence works but uploads that one read per call; hot loops should use MapBatch()
-//    or raven_hip/find_overlaps.hpp, which is what FindOverlapsAndCreatePiles does;
+//  * Map() is const and thread-safe like ram's.  For a sequence of the indexed range (both of Raven's passes) the
+//    first call maps that whole range in one device pass and every later call reads the cached result; any other
+//    sequence is uploaded and mapped on its own.  MapBatch() / raven_hip/find_overlaps.hpp remain the fast path;
 //  * errors of the C ABI are rethrown as the exception types ram/biosoup use (std::invalid_argument for
 //    RVN_EINVAL, std::runtime_error otherwise).
 #ifndef RAM_MINIMIZER_ENGINE_HPP_  // same guard as ram's header: include one or the other
@@ -16,6 +17,7 @@
 
 #include <cstdint>
 #include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <utility>
@@ -95,18 +97,47 @@ class MinimizerEngine {
 
   // ram: transform set of sequences to minimizer index (construct.cc:42-43, :363)
   void Minimize(Sequences::const_iterator first, Sequences::const_iterator last, bool minhash = false) {
+    std::lock_guard<std::mutex> lk(mu_);
+    cache_.valid = false;
     index_reads_.Upload(engine_, first, last);
+    index_first_ = first == last ? nullptr : &*first;
+    index_count_ = static_cast<std::size_t>(last - first);
     detail::Check(rvn_engine_minimize(engine_, index_reads_.h, 0, static_cast<std::uint32_t>(last - first), minhash));
   }
 
   // ram: set occurrence frequency threshold (construct.cc:44, :372); throws std::invalid_argument outside [0,1]
-  void Filter(double frequency) { detail::Check(rvn_engine_filter(engine_, frequency)); }
+  void Filter(double frequency) {
+    std::lock_guard<std::mutex> lk(mu_);
+    cache_.valid = false;
+    detail::Check(rvn_engine_filter(engine_, frequency));
+  }
 
-  // ram: find overlaps in the index (construct.cc:62, :377-381)
+  // ram: find overlaps in the index (construct.cc:62, :377-381).  const and safe under concurrent callers, as
+  // ram's is (Raven calls it from its pool workers).  When `sequence` is one of the sequences the index was built
+  // from — which is how both of Raven's passes call it — the first call maps the WHOLE indexed range in one device
+  // pass and later calls (any thread) are served from that result; other sequences are mapped one at a time.
   std::vector<biosoup::Overlap> Map(const std::unique_ptr<biosoup::NucleicAcid>& sequence, bool avoid_equal,
                                     bool avoid_symmetric, bool minhash = false,
                                     std::vector<std::uint32_t>* filtered = nullptr) const {
     const std::unique_ptr<biosoup::NucleicAcid>* first = &sequence;
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      if (index_first_ && first >= index_first_ && first < index_first_ + index_count_) {
+        const std::size_t i = static_cast<std::size_t>(first - index_first_);
+        const int flags = (avoid_equal ? 1 : 0) | (avoid_symmetric ? 2 : 0) | (minhash ? 4 : 0);
+        if (!cache_.valid || cache_.flags != flags || (filtered && !cache_.has_filtered)) {
+          auto res = MapUploaded(index_reads_.h, 0, static_cast<std::uint32_t>(index_count_), avoid_equal,
+                                 avoid_symmetric, minhash, filtered ? 1 : 0);
+          cache_.overlaps = std::move(res.first);
+          cache_.filtered = std::move(res.second);
+          cache_.flags = flags;
+          cache_.has_filtered = filtered != nullptr;
+          cache_.valid = true;
+        }
+        if (filtered) *filtered = cache_.filtered[i];
+        return cache_.overlaps[i];
+      }
+    }
     detail::ReadsHandle q;
     q.Upload(engine_, first, first + 1);
     auto res = MapUploaded(q.h, 0, 1, avoid_equal, avoid_symmetric, minhash, filtered ? 1 : 0);
@@ -129,15 +160,18 @@ class MinimizerEngine {
   rvn_engine* handle() const { return engine_; }
 
  private:
+  // one critical section inside the library (rvn_engine_map_collect): map + fetch of THIS call's result
   std::pair<std::vector<std::vector<biosoup::Overlap>>, std::vector<std::vector<std::uint32_t>>> MapUploaded(
       rvn_reads* reads, std::uint32_t first, std::uint32_t last, bool avoid_equal, bool avoid_symmetric, bool minhash,
       int want_filtered) const {
-    std::uint64_t n = 0;
-    detail::Check(rvn_engine_map_batch(engine_, reads, first, last, avoid_equal, avoid_symmetric, minhash,
-                                       want_filtered, &n));
-    std::vector<rvn_overlap> flat(n);
-    std::vector<std::uint32_t> off(last - first + 1);
-    detail::Check(rvn_engine_map_fetch(engine_, flat.data(), off.data()));
+    rvn_overlap* flat = nullptr;
+    std::uint32_t *off = nullptr, *pos = nullptr, *foff = nullptr;
+    detail::Check(rvn_engine_map_collect(engine_, reads, first, last, avoid_equal, avoid_symmetric, minhash,
+                                         want_filtered, &flat, &off, &pos, &foff));
+    struct Free {
+      void* p;
+      ~Free() { rvn_free(p); }
+    } f0{flat}, f1{off}, f2{pos}, f3{foff};
     std::vector<std::vector<biosoup::Overlap>> out(last - first);
     for (std::uint32_t i = 0; i < last - first; ++i) {
       out[i].reserve(off[i + 1] - off[i]);
@@ -145,16 +179,22 @@ class MinimizerEngine {
     }
     std::vector<std::vector<std::uint32_t>> filt;
     if (want_filtered) {
-      std::uint64_t total = 0;
-      detail::Check(rvn_engine_map_fetch_filtered(engine_, nullptr, nullptr, &total));
-      std::vector<std::uint32_t> pos(total), foff(last - first + 1);
-      detail::Check(rvn_engine_map_fetch_filtered(engine_, pos.data(), foff.data(), &total));
       filt.resize(last - first);
-      for (std::uint32_t i = 0; i < last - first; ++i) filt[i].assign(pos.begin() + foff[i], pos.begin() + foff[i + 1]);
+      for (std::uint32_t i = 0; i < last - first; ++i) filt[i].assign(pos + foff[i], pos + foff[i + 1]);
     }
     return {std::move(out), std::move(filt)};
   }
 
+  struct Cache {
+    bool valid = false, has_filtered = false;
+    int flags = 0;
+    std::vector<std::vector<biosoup::Overlap>> overlaps;
+    std::vector<std::vector<std::uint32_t>> filtered;
+  };
+  mutable std::mutex mu_;  // guards the cache and the index read set
+  mutable Cache cache_;
+  const std::unique_ptr<biosoup::NucleicAcid>* index_first_ = nullptr;  // the caller's sequences the index covers
+  std::size_t index_count_ = 0;
   rvn_engine* engine_ = nullptr;
   detail::ReadsHandle index_reads_;
 };

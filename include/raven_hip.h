@@ -74,6 +74,16 @@ int rvn_engine_map_fetch(rvn_engine* e, rvn_overlap* overlaps, uint32_t* read_of
 /* positions of query minimizers skipped by the occurrence filter (`filtered` argument of Map),
  * per read: offsets (last-first+1) into `positions`.  Pass positions == NULL to query the total. */
 int rvn_engine_map_fetch_filtered(rvn_engine* e, uint32_t* positions, uint32_t* read_offsets, uint64_t* total);
+/* Map + fetch as ONE critical section: ram::MinimizerEngine::Map is const and Raven calls it concurrently from its
+ * pool workers (construct.cc:60-64, :373-381), so a caller that cannot hold its own lock across
+ * rvn_engine_map_batch / rvn_engine_map_fetch uses this.  Every entry point of this library takes the engine's lock,
+ * so concurrent calls on one engine are safe; this one additionally returns the results of ITS map (not a later
+ * caller's).  Outputs are malloc'ed by the library (overlaps of all reads concatenated, read_offsets[last-first+1];
+ * with want_filtered also the `filtered` positions and their offsets) and released with rvn_free. */
+int rvn_engine_map_collect(rvn_engine* e, const rvn_reads* r, uint32_t first, uint32_t last, int avoid_equal,
+                           int avoid_symmetric, int minhash, int want_filtered, rvn_overlap** overlaps,
+                           uint32_t** read_offsets, uint32_t** filtered, uint32_t** filtered_offsets);
+void rvn_free(void* p);
 
 /* raven::FindOverlapsAndCreatePiles (RavenLib/src/construct.cc:14-121; decl construct.h:22-29):
  * index batches of `index_batch_bases` (reference: 1<<32), query flushes of `flush_bases` (reference:

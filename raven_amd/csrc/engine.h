@@ -3,6 +3,7 @@
 
 #include <string>
 #include <memory>
+#include <mutex>
 #include <vector>
 
 #include "common.h"
@@ -88,6 +89,10 @@ struct StageTimes {
 struct PileState;
 
 struct Engine {
+  // Every C-ABI entry point that touches the engine's state (scratch buffers, stream, last Map result) holds this
+  // lock for its whole duration: ram::MinimizerEngine::Map is const and called concurrently from Raven's pool workers
+  // (RavenLib/src/construct.cc:60-64, :373-381), so the boundary has to be safe under concurrent callers.
+  std::recursive_mutex mu;
   u32 k, w, bandwidth, chain, matches, gap;
   int device = 0;
   bool val64 = false;  // true when minimizer values need 64 bits

@@ -62,6 +62,14 @@ int guarded(F f) {
   }
 }
 
+// same, holding the engine's lock for the whole call (nullptr: the lambda reports the NULL handle itself)
+template <typename F>
+int guarded(Engine* e, F f) {
+  if (!e) return guarded(f);
+  std::lock_guard<std::recursive_mutex> lk(e->mu);
+  return guarded(f);
+}
+
 const char* kStageNames[StageTimes::kNum] = {"sketch", "sort", "index", "filter", "query_sketch", "match",
                                              "seg_sort", "intervals", "chain", "compact", "merge", "pile",
                                              "truncate"};
@@ -197,7 +205,7 @@ void rvn_engine_destroy(rvn_engine* h) {
 
 int rvn_reads_upload(rvn_engine* h, const uint64_t* packed, uint64_t n_words, const uint64_t* word_offsets,
                      const uint32_t* lengths, const uint32_t* ids, uint32_t n, rvn_reads** out) {
-  return guarded([&]() -> int {
+  return guarded(h ? &h->e : nullptr, [&]() -> int {
     if (!h || !out || (n && (!packed || !word_offsets || !lengths)))
       return fail(RVN_EINVAL, "[raven_hip] rvn_reads_upload: NULL argument");
     Engine& e = h->e;
@@ -245,7 +253,7 @@ int rvn_reads_upload(rvn_engine* h, const uint64_t* packed, uint64_t n_words, co
 void rvn_reads_destroy(rvn_reads* r) { delete r; }
 
 int rvn_engine_minimize(rvn_engine* h, const rvn_reads* r, uint32_t first, uint32_t last, int minhash) {
-  return guarded([&]() -> int {
+  return guarded(h ? &h->e : nullptr, [&]() -> int {
     if (!h || !r || first > last || last > r->r.n) return fail(RVN_EINVAL, "[raven_hip] rvn_engine_minimize: bad range");
     RVN_HIP(hipSetDevice(h->e.device));
     UseTimers ut(h->e);
@@ -256,7 +264,7 @@ int rvn_engine_minimize(rvn_engine* h, const rvn_reads* r, uint32_t first, uint3
 }
 
 int rvn_engine_filter(rvn_engine* h, double f) {
-  return guarded([&]() -> int {
+  return guarded(h ? &h->e : nullptr, [&]() -> int {
     if (!h) return fail(RVN_EINVAL, "[raven_hip] NULL engine");
     if (!(0 <= f && f <= 1)) return fail(RVN_EINVAL, "[ram::MinimizerEngine::Filter] error: invalid frequency");
     RVN_HIP(hipSetDevice(h->e.device));
@@ -270,7 +278,7 @@ uint32_t rvn_engine_occurrence(const rvn_engine* h) { return h ? h->e.index.occu
 
 int rvn_engine_map_batch(rvn_engine* h, const rvn_reads* r, uint32_t first, uint32_t last, int avoid_equal,
                          int avoid_symmetric, int minhash, int want_filtered, uint64_t* n_overlaps) {
-  return guarded([&]() -> int {
+  return guarded(h ? &h->e : nullptr, [&]() -> int {
     if (!h || !r || first > last || last > r->r.n) return fail(RVN_EINVAL, "[raven_hip] rvn_engine_map_batch: bad range");
     RVN_HIP(hipSetDevice(h->e.device));
     UseTimers ut(h->e);
@@ -284,7 +292,7 @@ int rvn_engine_map_batch(rvn_engine* h, const rvn_reads* r, uint32_t first, uint
 }
 
 int rvn_engine_map_fetch(rvn_engine* h, rvn_overlap* overlaps, uint32_t* read_offsets) {
-  return guarded([&]() -> int {
+  return guarded(h ? &h->e : nullptr, [&]() -> int {
     if (!h) return fail(RVN_EINVAL, "[raven_hip] NULL engine");
     MapOut& m = h->e.map_out;
     RVN_HIP(hipSetDevice(h->e.device));
@@ -298,7 +306,7 @@ int rvn_engine_map_fetch(rvn_engine* h, rvn_overlap* overlaps, uint32_t* read_of
 }
 
 int rvn_engine_map_fetch_filtered(rvn_engine* h, uint32_t* positions, uint32_t* read_offsets, uint64_t* total) {
-  return guarded([&]() -> int {
+  return guarded(h ? &h->e : nullptr, [&]() -> int {
     if (!h) return fail(RVN_EINVAL, "[raven_hip] NULL engine");
     Engine& e = h->e;
     MapOut& m = e.map_out;
@@ -329,10 +337,69 @@ int rvn_engine_map_fetch_filtered(rvn_engine* h, uint32_t* positions, uint32_t* 
   });
 }
 
+void rvn_free(void* p) { std::free(p); }
+
+int rvn_engine_map_collect(rvn_engine* h, const rvn_reads* r, uint32_t first, uint32_t last, int avoid_equal,
+                           int avoid_symmetric, int minhash, int want_filtered, rvn_overlap** overlaps,
+                           uint32_t** read_offsets, uint32_t** filtered, uint32_t** filtered_offsets) {
+  return guarded(h ? &h->e : nullptr, [&]() -> int {
+    if (!h || !r || !overlaps || !read_offsets || first > last || last > r->r.n)
+      return fail(RVN_EINVAL, "[raven_hip] rvn_engine_map_collect: bad argument");
+    if (want_filtered && (!filtered || !filtered_offsets))
+      return fail(RVN_EINVAL, "[raven_hip] rvn_engine_map_collect: filtered requested without output pointers");
+    *overlaps = nullptr;
+    *read_offsets = nullptr;
+    if (filtered) *filtered = nullptr;
+    if (filtered_offsets) *filtered_offsets = nullptr;
+    uint64_t n = 0;
+    int rc = rvn_engine_map_batch(h, r, first, last, avoid_equal, avoid_symmetric, minhash, want_filtered, &n);
+    if (rc != RVN_OK) return rc;
+    const size_t nr = last - first;
+    auto* ov = static_cast<rvn_overlap*>(std::malloc((n + 1) * sizeof(rvn_overlap)));
+    auto* off = static_cast<uint32_t*>(std::malloc((nr + 1) * 4));
+    uint32_t *fp = nullptr, *fo = nullptr;
+    auto drop = [&]() {
+      std::free(ov);
+      std::free(off);
+      std::free(fp);
+      std::free(fo);
+    };
+    if (!ov || !off) {
+      drop();
+      return fail(RVN_ENOMEM, "[raven_hip] out of host memory");
+    }
+    rc = rvn_engine_map_fetch(h, ov, off);
+    if (rc == RVN_OK && want_filtered) {
+      uint64_t total = 0;
+      rc = rvn_engine_map_fetch_filtered(h, nullptr, nullptr, &total);
+      if (rc == RVN_OK) {
+        fp = static_cast<uint32_t*>(std::malloc((total + 1) * 4));
+        fo = static_cast<uint32_t*>(std::malloc((nr + 1) * 4));
+        if (!fp || !fo) {
+          drop();
+          return fail(RVN_ENOMEM, "[raven_hip] out of host memory");
+        }
+        rc = rvn_engine_map_fetch_filtered(h, fp, fo, &total);
+      }
+    }
+    if (rc != RVN_OK) {
+      drop();
+      return rc;
+    }
+    *overlaps = ov;
+    *read_offsets = off;
+    if (want_filtered) {
+      *filtered = fp;
+      *filtered_offsets = fo;
+    }
+    return RVN_OK;
+  });
+}
+
 int rvn_find_overlaps_and_create_piles(rvn_engine* h, const rvn_reads* rr, double freq, uint32_t kmax,
                                        int use_minhash, uint64_t index_batch_bases, uint64_t flush_bases,
                                        rvn_pass1** out) {
-  return guarded([&]() -> int {
+  return guarded(h ? &h->e : nullptr, [&]() -> int {
     if (!h || !rr || !out) return fail(RVN_EINVAL, "[raven_hip] NULL argument");
     if (!(0 <= freq && freq <= 1)) return fail(RVN_EINVAL, "[ram::MinimizerEngine::Filter] error: invalid frequency");
     Engine& e = h->e;
@@ -386,7 +453,7 @@ uint64_t rvn_pass1_pile_words(const rvn_pass1* p) { return p ? p->ps.pile_words 
 uint64_t rvn_pass1_num_overlaps(const rvn_pass1* p) { return p ? p->ps.kept_total : 0; }
 
 int rvn_pass1_fetch_piles(const rvn_pass1* p, uint16_t* data, uint64_t* offsets) {
-  return guarded([&]() -> int {
+  return guarded(p ? p->e : nullptr, [&]() -> int {
     if (!p) return fail(RVN_EINVAL, "[raven_hip] NULL pass1");
     RVN_HIP(hipSetDevice(p->e->device));
     if (data && p->ps.pile_words)
@@ -399,7 +466,7 @@ int rvn_pass1_fetch_piles(const rvn_pass1* p, uint16_t* data, uint64_t* offsets)
 
 int rvn_pass1_trim_and_annotate(rvn_pass1* p, uint32_t coverage, uint32_t* begin, uint32_t* end, uint16_t* median,
                                 uint8_t* invalid) {
-  return guarded([&]() -> int {
+  return guarded(p ? p->e : nullptr, [&]() -> int {
     if (!p) return fail(RVN_EINVAL, "[raven_hip] NULL pass1");
     if (coverage > 65535) return fail(RVN_EINVAL, "[raven_hip] coverage threshold above 65535");
     RVN_HIP(hipSetDevice(p->e->device));
@@ -410,7 +477,7 @@ int rvn_pass1_trim_and_annotate(rvn_pass1* p, uint32_t coverage, uint32_t* begin
 }
 
 int rvn_pass1_fetch_overlaps(const rvn_pass1* p, rvn_overlap* overlaps, uint32_t* offsets) {
-  return guarded([&]() -> int {
+  return guarded(p ? p->e : nullptr, [&]() -> int {
     if (!p) return fail(RVN_EINVAL, "[raven_hip] NULL pass1");
     RVN_HIP(hipSetDevice(p->e->device));
     if (overlaps && p->ps.kept_total)
@@ -425,7 +492,7 @@ void rvn_pass1_destroy(rvn_pass1* p) { delete p; }
 
 int rvn_pile_add_layers(rvn_engine* h, uint16_t* data, uint32_t cells, uint32_t id, const rvn_overlap* overlaps,
                         uint64_t n) {
-  return guarded([&]() -> int {
+  return guarded(h ? &h->e : nullptr, [&]() -> int {
     if (!h || (cells && !data) || (n && !overlaps)) return fail(RVN_EINVAL, "[raven_hip] NULL argument");
     if (n == 0 || cells == 0) return RVN_OK;
     if (n >= (1ULL << 31)) return fail(RVN_EINVAL, "[raven_hip] too many overlaps");
@@ -450,7 +517,7 @@ int rvn_pile_add_layers(rvn_engine* h, uint16_t* data, uint32_t cells, uint32_t 
 int rvn_pile_add_kmers_batch(rvn_engine* h, const rvn_reads* r, uint32_t first_read, uint32_t n_reads,
                              const uint32_t* positions, const uint64_t* position_offsets, uint8_t* kmers,
                              const uint64_t* kmers_offsets) {
-  return guarded([&]() -> int {
+  return guarded(h ? &h->e : nullptr, [&]() -> int {
     if (!h || !r || (n_reads && (!position_offsets || !kmers || !kmers_offsets)))
       return fail(RVN_EINVAL, "[raven_hip] NULL argument");
     const ReadsDev& rd = r->r;
@@ -475,7 +542,7 @@ int rvn_polish_round_range(rvn_engine* h, rvn_reads* targets, rvn_reads* reads, 
                            int mismatch, int gap, uint64_t window_first, uint64_t window_last, uint8_t* out_codes,
                            const uint64_t* out_offsets, uint32_t* out_len, double* ratio, uint32_t* n_windows,
                            uint32_t* n_polished, rvn_polish_stats* stats) {
-  return guarded([&]() -> int {
+  return guarded(h ? &h->e : nullptr, [&]() -> int {
     if (!h || !targets || !reads || !out_codes || !out_offsets || !out_len)
       return fail(RVN_EINVAL, "[raven_hip] NULL argument");
     if (w == 0) return fail(RVN_EINVAL, "[racon::Polisher::Create] error: invalid window length!");
@@ -516,7 +583,7 @@ int rvn_polish_round_range(rvn_engine* h, rvn_reads* targets, rvn_reads* reads, 
 
 int rvn_edit_distance_batch(rvn_engine* h, const rvn_reads* r, const rvn_ed_pair* pairs, uint32_t n_pairs,
                             uint32_t* distances, double* device_ms, uint64_t* cells) {
-  return guarded([&]() -> int {
+  return guarded(h ? &h->e : nullptr, [&]() -> int {
     if (!h || !r || (n_pairs && (!pairs || !distances))) return fail(RVN_EINVAL, "[raven_hip] NULL argument");
     const ReadsDev& rd = r->r;
     for (uint32_t i = 0; i < n_pairs; ++i) {
@@ -539,7 +606,7 @@ int rvn_poa_consensus_batch(rvn_engine* h, const uint8_t* codes, const uint8_t* 
                             const uint32_t* window_offsets, uint32_t n_windows, int match, int mismatch, int gap,
                             int trim, uint8_t* consensus, const uint64_t* consensus_offsets, uint32_t* consensus_len,
                             uint32_t* status, double* device_ms) {
-  return guarded([&]() -> int {
+  return guarded(h ? &h->e : nullptr, [&]() -> int {
     if (!h || (n_windows && (!codes || !layer_offsets || !begins || !ends || !window_offsets || !consensus ||
                              !consensus_offsets || !consensus_len || !status)))
       return fail(RVN_EINVAL, "[raven_hip] NULL argument");
@@ -569,7 +636,7 @@ int rvn_polish_round(rvn_engine* h, rvn_reads* targets, rvn_reads* reads, const 
 
 // ---- stage-level entry points of the sharded single-genome pass (host side raven_amd/sharded.py) ----
 int rvn_shard_sketch(rvn_engine* h, const rvn_reads* rr, int index_minhash, uint64_t* count) {
-  return guarded([&]() -> int {
+  return guarded(h ? &h->e : nullptr, [&]() -> int {
     if (!h || !rr || !count) return fail(RVN_EINVAL, "[raven_hip] rvn_shard_sketch: NULL argument");
     Engine& e = h->e;
     const ReadsDev& r = rr->r;
@@ -595,7 +662,7 @@ int rvn_shard_sketch(rvn_engine* h, const rvn_reads* rr, int index_minhash, uint
 }
 
 int rvn_shard_sketch_fetch(rvn_engine* h, uint64_t* values, uint64_t* origins) {
-  return guarded([&]() -> int {
+  return guarded(h ? &h->e : nullptr, [&]() -> int {
     if (!h) return fail(RVN_EINVAL, "[raven_hip] NULL engine");
     Engine& e = h->e;
     Sketch& s = e.shard_sketch_minhash ? e.index_sketch : e.raw_sketch;
@@ -607,7 +674,7 @@ int rvn_shard_sketch_fetch(rvn_engine* h, uint64_t* values, uint64_t* origins) {
 }
 
 int rvn_shard_index_build(rvn_engine* h, const uint64_t* values, const uint64_t* origins, uint64_t n, int all_query) {
-  return guarded([&]() -> int {
+  return guarded(h ? &h->e : nullptr, [&]() -> int {
     if (!h || (n && (!values || !origins))) return fail(RVN_EINVAL, "[raven_hip] rvn_shard_index_build: NULL argument");
     Engine& e = h->e;
     RVN_HIP(hipSetDevice(e.device));
@@ -641,7 +708,7 @@ int rvn_shard_index_build(rvn_engine* h, const uint64_t* values, const uint64_t*
 }
 
 int rvn_shard_key_counts(rvn_engine* h, uint32_t* counts) {
-  return guarded([&]() -> int {
+  return guarded(h ? &h->e : nullptr, [&]() -> int {
     if (!h) return fail(RVN_EINVAL, "[raven_hip] NULL engine");
     Engine& e = h->e;
     const u64 u = e.index.u;
@@ -667,7 +734,7 @@ int rvn_shard_join(rvn_engine* h, uint32_t n_reads_total, int avoid_equal, int a
 
 int rvn_shard_join_range(rvn_engine* h, uint32_t n_reads_total, int avoid_equal, int avoid_symmetric, uint32_t query_first,
                          uint32_t query_last, uint64_t* n_matches) {
-  return guarded([&]() -> int {
+  return guarded(h ? &h->e : nullptr, [&]() -> int {
     if (!h || !n_matches) return fail(RVN_EINVAL, "[raven_hip] rvn_shard_join: NULL argument");
     Engine& e = h->e;
     RVN_HIP(hipSetDevice(e.device));
@@ -681,7 +748,7 @@ int rvn_shard_join_range(rvn_engine* h, uint32_t n_reads_total, int avoid_equal,
 }
 
 int rvn_shard_join_fetch(rvn_engine* h, uint64_t* grp, uint64_t* pos, uint64_t* seg_off) {
-  return guarded([&]() -> int {
+  return guarded(h ? &h->e : nullptr, [&]() -> int {
     if (!h) return fail(RVN_EINVAL, "[raven_hip] NULL engine");
     Engine& e = h->e;
     RVN_HIP(hipSetDevice(e.device));
@@ -696,7 +763,7 @@ int rvn_shard_join_fetch(rvn_engine* h, uint64_t* grp, uint64_t* pos, uint64_t* 
 
 int rvn_shard_chain(rvn_engine* h, const rvn_reads* own, const uint64_t* grp, const uint64_t* pos,
                     const uint64_t* seg_off, uint64_t* n_overlaps) {
-  return guarded([&]() -> int {
+  return guarded(h ? &h->e : nullptr, [&]() -> int {
     if (!h || !own || !seg_off || !n_overlaps) return fail(RVN_EINVAL, "[raven_hip] rvn_shard_chain: NULL argument");
     Engine& e = h->e;
     const ReadsDev& r = own->r;
@@ -731,7 +798,7 @@ int rvn_shard_chain(rvn_engine* h, const rvn_reads* own, const uint64_t* grp, co
 }
 
 int rvn_shard_piles_create(rvn_engine* h, const uint32_t* lengths, uint32_t n_reads_total, rvn_pass1** out) {
-  return guarded([&]() -> int {
+  return guarded(h ? &h->e : nullptr, [&]() -> int {
     if (!h || !lengths || !out) return fail(RVN_EINVAL, "[raven_hip] rvn_shard_piles_create: NULL argument");
     Engine& e = h->e;
     RVN_HIP(hipSetDevice(e.device));
@@ -758,7 +825,7 @@ int rvn_shard_piles_create(rvn_engine* h, const uint32_t* lengths, uint32_t n_re
 
 // One flush (construct.cc:79-110) of a sharded pass: merge the Map outputs of the window into the piles, AddLayers, truncate.
 int rvn_shard_piles_merge(rvn_pass1* p, const rvn_overlap* overlaps, uint64_t n, uint32_t kmax) {
-  return guarded([&]() -> int {
+  return guarded(p ? p->e : nullptr, [&]() -> int {
     if (!p || !p->meta || (n && !overlaps)) return fail(RVN_EINVAL, "[raven_hip] rvn_shard_piles_merge: bad handle or NULL overlaps");
     Engine& e = *p->e;
     RVN_HIP(hipSetDevice(e.device));
@@ -791,7 +858,7 @@ int rvn_shard_piles_merge(rvn_pass1* p, const rvn_overlap* overlaps, uint64_t n,
 
 int rvn_shard_piles_merge_dev(rvn_pass1* p, const rvn_overlap* d_overlaps, const uint32_t* d_ovl_read_off, uint64_t n,
                               uint32_t kmax) {
-  return guarded([&]() -> int {
+  return guarded(p ? p->e : nullptr, [&]() -> int {
     if (!p || !p->meta || !d_ovl_read_off || (n && !d_overlaps))
       return fail(RVN_EINVAL, "[raven_hip] rvn_shard_piles_merge_dev: bad handle or NULL argument");
     Engine& e = *p->e;
@@ -841,7 +908,7 @@ __global__ void narrow_u64_u32_kernel(const u64* __restrict__ src, u32* __restri
 }  // namespace
 
 int rvn_shard_sketch_fetch_dev(rvn_engine* h, uint64_t* d_values, uint64_t* d_origins) {
-  return guarded([&]() -> int {
+  return guarded(h ? &h->e : nullptr, [&]() -> int {
     if (!h) return fail(RVN_EINVAL, "[raven_hip] NULL engine");
     Engine& e = h->e;
     Sketch& s = e.shard_sketch_minhash ? e.index_sketch : e.raw_sketch;
@@ -858,7 +925,7 @@ int rvn_shard_sketch_fetch_dev(rvn_engine* h, uint64_t* d_values, uint64_t* d_or
 
 int rvn_shard_index_build_dev(rvn_engine* h, const uint64_t* d_values, const uint64_t* d_origins, uint64_t n,
                               int all_query, uint64_t n_flagged) {
-  return guarded([&]() -> int {
+  return guarded(h ? &h->e : nullptr, [&]() -> int {
     if (!h || (n && (!d_values || !d_origins))) return fail(RVN_EINVAL, "[raven_hip] rvn_shard_index_build_dev: NULL argument");
     Engine& e = h->e;
     RVN_HIP(hipSetDevice(e.device));
@@ -888,7 +955,7 @@ int rvn_shard_index_build_dev(rvn_engine* h, const uint64_t* d_values, const uin
 }
 
 int rvn_shard_key_histogram(rvn_engine* h, uint64_t* hist, uint32_t* over, uint32_t over_cap, uint32_t* n_over) {
-  return guarded([&]() -> int {
+  return guarded(h ? &h->e : nullptr, [&]() -> int {
     if (!h || !hist || !n_over) return fail(RVN_EINVAL, "[raven_hip] rvn_shard_key_histogram: NULL argument");
     Engine& e = h->e;
     RVN_HIP(hipSetDevice(e.device));
@@ -905,7 +972,7 @@ int rvn_shard_key_histogram(rvn_engine* h, uint64_t* hist, uint32_t* over, uint3
 }
 
 int rvn_shard_join_fetch_dev(rvn_engine* h, uint64_t* d_grp, uint64_t* d_pos, uint64_t* d_seg_off) {
-  return guarded([&]() -> int {
+  return guarded(h ? &h->e : nullptr, [&]() -> int {
     if (!h) return fail(RVN_EINVAL, "[raven_hip] NULL engine");
     Engine& e = h->e;
     RVN_HIP(hipSetDevice(e.device));
@@ -922,7 +989,7 @@ int rvn_shard_join_fetch_dev(rvn_engine* h, uint64_t* d_grp, uint64_t* d_pos, ui
 
 int rvn_shard_chain_dev(rvn_engine* h, const rvn_reads* own, const uint64_t* d_grp, const uint64_t* d_pos,
                         const uint64_t* d_seg_off, uint64_t n_matches, uint64_t* n_overlaps) {
-  return guarded([&]() -> int {
+  return guarded(h ? &h->e : nullptr, [&]() -> int {
     if (!h || !own || !d_seg_off || !n_overlaps) return fail(RVN_EINVAL, "[raven_hip] rvn_shard_chain_dev: NULL argument");
     Engine& e = h->e;
     const ReadsDev& r = own->r;
@@ -957,7 +1024,7 @@ int rvn_shard_chain_dev(rvn_engine* h, const rvn_reads* own, const uint64_t* d_g
 }
 
 int rvn_engine_map_fetch_dev(rvn_engine* h, rvn_overlap* d_overlaps, uint32_t* d_read_offsets) {
-  return guarded([&]() -> int {
+  return guarded(h ? &h->e : nullptr, [&]() -> int {
     if (!h) return fail(RVN_EINVAL, "[raven_hip] NULL engine");
     MapOut& m = h->e.map_out;
     RVN_HIP(hipSetDevice(h->e.device));
@@ -1015,7 +1082,7 @@ uint32_t rvn_poa_fallback_windows(const rvn_engine* h) { return h ? h->e.poa_fal
 uint32_t rvn_poa_wide_windows(const rvn_engine* h) { return h ? h->e.poa_wide_windows : 0; }
 
 int rvn_engine_sketch(rvn_engine* h, const rvn_reads* r, uint32_t first, uint32_t last, int minhash, uint64_t* count) {
-  return guarded([&]() -> int {
+  return guarded(h ? &h->e : nullptr, [&]() -> int {
     if (!h || !r || first > last || last > r->r.n) return fail(RVN_EINVAL, "[raven_hip] rvn_engine_sketch: bad range");
     RVN_HIP(hipSetDevice(h->e.device));
     UseTimers ut(h->e);
@@ -1041,7 +1108,7 @@ int fetch_values(Engine& e, const DevBuf& val, u64 n, uint64_t* values) {
 }  // namespace
 
 int rvn_engine_sketch_fetch(rvn_engine* h, uint64_t* values, uint64_t* origins, uint32_t* read_offsets) {
-  return guarded([&]() -> int {
+  return guarded(h ? &h->e : nullptr, [&]() -> int {
     if (!h) return fail(RVN_EINVAL, "[raven_hip] NULL engine");
     Engine& e = h->e;
     Sketch& s = e.query_sketch;
@@ -1063,7 +1130,7 @@ int rvn_engine_index_size(const rvn_engine* h, uint64_t* n_minimizers, uint64_t*
 }
 
 int rvn_engine_index_fetch(rvn_engine* h, uint64_t* values, uint64_t* origins) {
-  return guarded([&]() -> int {
+  return guarded(h ? &h->e : nullptr, [&]() -> int {
     if (!h) return fail(RVN_EINVAL, "[raven_hip] NULL engine");
     Engine& e = h->e;
     Index& ix = e.index;
@@ -1122,7 +1189,7 @@ void rvn_engine_set_kernel_timing(rvn_engine* h, int enabled) {
 int rvn_engine_num_kernel_sites(void) { return kKNumSites; }
 const char* rvn_engine_kernel_site_name(int i) { return (i >= 0 && i < kKNumSites) ? kKernelSiteNames[i] : ""; }
 int rvn_engine_kernel_ms(rvn_engine* h, double* ms, uint64_t* launches, int n) {
-  return guarded([&]() -> int {
+  return guarded(h ? &h->e : nullptr, [&]() -> int {
     if (!h) return fail(RVN_EINVAL, "[raven_hip] NULL engine");
     Engine& e = h->e;
     RVN_HIP(hipSetDevice(e.device));

@@ -80,53 +80,71 @@ __global__ __launch_bounds__(256) void pile_build_kernel(const Overlap* __restri
 }
 
 // Pile::AddLayers (pile.cc:33-62) as an order-free per-cell sum: coverage(cell) = #{begin events <= cell}
-// - #{end events <= cell} in uint32 wrap-around arithmetic, data = clamp(data + coverage).
-// One workgroup per pile; events staged in LDS in chunks.
-constexpr int kEvChunk = 1024;
+// - #{end events <= cell} in uint32 wrap-around arithmetic (the reference's `coverage` is a uint32_t that is allowed
+// to wrap, pile.cc:60), data = clamp(data + coverage) ONCE per cell per call, as the reference's sweep does.
+// One workgroup per pile: the events are scattered into a difference array in LDS (+1 at the begin cell, -1 at the
+// end cell, wrapping adds), a block-wide prefix sum turns it into the coverage of every cell — O(events + cells),
+// whatever the depth of the pile.  Piles longer than the LDS tile are processed tile by tile with a carried prefix.
+constexpr u32 kCellTile = 8192;
+__device__ __forceinline__ u32 diff_slot(u32 c) { return c + (c >> 5); }  // one pad word per 32: segment scans hit distinct banks
 __global__ __launch_bounds__(256) void add_layers_kernel(const Overlap* __restrict__ list,
                                                         const u32* __restrict__ list_off,
                                                         const u32* __restrict__ kept_off,
                                                         const u64* __restrict__ pile_off,
                                                         const u32* __restrict__ ids, u16* __restrict__ data) {
-  __shared__ u32 ev_b[kEvChunk];
-  __shared__ u32 ev_e[kEvChunk];
+  __shared__ u32 diff[kCellTile + kCellTile / 32 + 1];
+  __shared__ u32 red[4];
   const u32 p = blockIdx.x;
   const u32 lb = list_off[p], le = list_off[p + 1];
   if (le == lb) return;
   const u32 kn = kept_off[p + 1] - kept_off[p];
   const u32 nb = lb + kn;  // first new overlap
   const u32 nn = le - nb;
+  if (nn == 0) return;
   const u32 id = ids[p];
   const u64 d0 = pile_off[p];
   const u32 cells = static_cast<u32>(pile_off[p + 1] - d0);
-  for (u32 c0 = 0; c0 < nn; c0 += kEvChunk) {
-    const u32 cn = min(static_cast<u32>(kEvChunk), nn - c0);
+  for (u32 tile_lo = 0; tile_lo < cells; tile_lo += kCellTile) {
+    const u32 tile_n = min(kCellTile, cells - tile_lo);
     __syncthreads();
-    for (u32 i = threadIdx.x; i < cn; i += 256) {
-      const Overlap o = list[nb + c0 + i];
-      u32 b = 0xFFFFFFFFu, e = 0xFFFFFFFFu;  // "never reached" for overlaps touching neither side
+    for (u32 c = threadIdx.x; c < diff_slot(tile_n) + 1; c += 256) diff[c] = 0;
+    __syncthreads();
+    u32 carry_part = 0;  // events before this tile
+    for (u32 i = threadIdx.x; i < nn; i += 256) {
+      const Overlap o = list[nb + i];
+      u32 b, e;
       if (o.lhs_id == id) {
         b = (o.lhs_begin >> kPSS) + 1;
         e = (o.lhs_end >> kPSS) - 1;
       } else if (o.rhs_id == id) {
         b = (o.rhs_begin >> kPSS) + 1;
         e = (o.rhs_end >> kPSS) - 1;
+      } else {
+        continue;
       }
-      // the reference stores events as (x << 1 | flag) in 32 bits and compares x = event >> 1
-      ev_b[i] = (b << 1) >> 1;
-      ev_e[i] = ((e << 1) | 1u) >> 1;
-      if (o.lhs_id != id && o.rhs_id != id) ev_b[i] = ev_e[i] = 0xFFFFFFFFu;
+      // the reference stores events as (x << 1 | flag) in 32 bits and sweeps over x = event >> 1
+      b = (b << 1) >> 1;
+      e = ((e << 1) | 1u) >> 1;
+      if (b < tile_lo) carry_part += 1u;
+      else if (b - tile_lo < tile_n) atomicAdd(&diff[diff_slot(b - tile_lo)], 1u);
+      if (e < tile_lo) carry_part -= 1u;
+      else if (e - tile_lo < tile_n) atomicAdd(&diff[diff_slot(e - tile_lo)], 0xFFFFFFFFu);
     }
     __syncthreads();
-    for (u32 cell = threadIdx.x; cell < cells; cell += 256) {
-      u32 cov = 0;
-      for (u32 i = 0; i < cn; ++i) {
-        cov += (ev_b[i] <= cell) ? 1u : 0u;
-        cov -= (ev_e[i] <= cell) ? 1u : 0u;
-      }
-      if (cov) {
-        const u32 v = static_cast<u32>(data[d0 + cell]) + cov;
-        data[d0 + cell] = static_cast<u16>(v < 65535u ? v : 65535u);
+    const u32 seg = (tile_n + 255) / 256;
+    const u32 lo = min(threadIdx.x * seg, tile_n), hi = min(lo + seg, tile_n);
+    u32 seg_sum = 0;
+    for (u32 c = lo; c < hi; ++c) seg_sum += diff[diff_slot(c)];
+    // coverage just before this thread's first cell = all events before the tile + the segments of the threads before
+    u32 carry_total = 0, seg_total = 0;
+    (void)block_exclusive_sum_256(carry_part, red, &carry_total);
+    const u32 excl = block_exclusive_sum_256(seg_sum, red, &seg_total);
+    u32 run = carry_total + excl;
+    for (u32 c = lo; c < hi; ++c) {
+      run += diff[diff_slot(c)];
+      if (run) {
+        const u32 v = static_cast<u32>(data[d0 + tile_lo + c]) + run;
+        data[d0 + tile_lo + c] = static_cast<u16>(v < 65535u ? v : 65535u);
       }
     }
   }

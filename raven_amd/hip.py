@@ -44,7 +44,7 @@ SYMBOLS = [
     "rvn_engine_counters", "rvn_engine_num_stages", "rvn_engine_stage_name", "rvn_engine_stage_ms",
     "rvn_engine_reset_stats", "rvn_engine_set_timing", "rvn_engine_set_kernel_timing",
     "rvn_engine_num_kernel_sites", "rvn_engine_kernel_site_name", "rvn_engine_kernel_ms", "rvn_test_hash", "rvn_test_canonical",
-    "rvn_test_std_sort_lendesc", "rvn_test_heap_sort_lendesc",
+    "rvn_test_std_sort_lendesc", "rvn_test_heap_sort_lendesc", "rvn_engine_map_collect", "rvn_free",
 ]
 
 
@@ -80,6 +80,8 @@ def lib():
     L.rvn_engine_map_batch.argtypes = [vp, vp, u32, u32, i32, i32, i32, i32, C.POINTER(u64)]
     L.rvn_engine_map_fetch.argtypes = [vp, vp, vp]
     L.rvn_engine_map_fetch_filtered.argtypes = [vp, vp, vp, C.POINTER(u64)]
+    L.rvn_engine_map_collect.argtypes = [vp, vp, u32, u32, i32, i32, i32, i32, pp, pp, pp, pp]
+    L.rvn_free.argtypes = [vp]
     L.rvn_find_overlaps_and_create_piles.argtypes = [vp, vp, dbl, u32, i32, u64, u64, pp]
     L.rvn_pass1_pile_words.restype = u64
     L.rvn_pass1_pile_words.argtypes = [vp]

@@ -25,6 +25,14 @@ class NucleicAcid {
       deflated_data[i >> 5] |= c << ((i << 1) & 63);
     }
   }
+  std::string InflateData(std::uint32_t i = 0, std::uint32_t len = 0xFFFFFFFFu) const {
+    std::string out;
+    if (i >= inflated_len) return out;
+    len = len < inflated_len - i ? len : inflated_len - i;
+    out.reserve(len);
+    for (std::uint32_t p = i; p < i + len; ++p) out += "ACGT"[(deflated_data[p >> 5] >> ((p << 1) & 63)) & 3];
+    return out;
+  }
   static std::atomic<std::uint32_t> num_objects;
   std::uint32_t id;
   std::string name;

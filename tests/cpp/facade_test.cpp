@@ -6,6 +6,7 @@
 #include <fstream>
 #include <iostream>
 #include <string>
+#include <thread>
 
 #include "raven_hip/find_overlaps.hpp"
 
@@ -64,6 +65,48 @@ int main(int argc, char** argv) {
           if (one[j].lhs_begin != batch[i][j].lhs_begin || one[j].rhs_id != batch[i][j].rhs_id || one[j].score != batch[i][j].score) ++mism;
     }
     std::printf("map_single_vs_batch mismatches %zu total %zu\n", mism, total);
+
+    // Map() from concurrent threads, the way construct.cc:60-64 / :373-381 submit it to the pool: indexed sequences
+    // (served from one batched pass) and a copy that is NOT part of the indexed vector (mapped on its own)
+    {
+      std::vector<std::vector<biosoup::Overlap>> got(sequences.size());
+      std::vector<std::vector<std::uint32_t>> got_f(sequences.size());
+      auto batch_f = std::vector<std::vector<std::uint32_t>>();
+      auto batch2 = minimizer_engine.MapBatch(sequences.begin(), sequences.end(), true, true, false, &batch_f);
+      const unsigned n_thr = 8;
+      std::vector<std::thread> pool;
+      std::vector<std::unique_ptr<biosoup::NucleicAcid>> outsiders;
+      for (std::size_t i = 0; i < sequences.size() && i < 6; ++i) {
+        outsiders.emplace_back(new biosoup::NucleicAcid(sequences[i]->name, sequences[i]->InflateData()));
+        outsiders.back()->id = sequences[i]->id;
+      }
+      std::vector<std::vector<biosoup::Overlap>> got_out(outsiders.size());
+      for (unsigned t = 0; t < n_thr; ++t)
+        pool.emplace_back([&, t]() {
+          for (std::size_t i = t; i < sequences.size(); i += n_thr)
+            got[i] = minimizer_engine.Map(sequences[i], true, true, false, &got_f[i]);
+          for (std::size_t i = t; i < outsiders.size(); i += n_thr)
+            got_out[i] = minimizer_engine.Map(outsiders[i], true, true, false);
+        });
+      for (auto& th : pool) th.join();
+      auto same = [](const std::vector<biosoup::Overlap>& a, const std::vector<biosoup::Overlap>& b) {
+        if (a.size() != b.size()) return false;
+        for (std::size_t j = 0; j < a.size(); ++j)
+          if (a[j].lhs_id != b[j].lhs_id || a[j].lhs_begin != b[j].lhs_begin || a[j].lhs_end != b[j].lhs_end ||
+              a[j].rhs_id != b[j].rhs_id || a[j].rhs_begin != b[j].rhs_begin || a[j].rhs_end != b[j].rhs_end ||
+              a[j].score != b[j].score || a[j].strand != b[j].strand)
+            return false;
+        return true;
+      };
+      std::size_t bad = 0, n_ovl = 0;
+      for (std::size_t i = 0; i < sequences.size(); ++i) {
+        n_ovl += got[i].size();
+        if (!same(got[i], batch2[i]) || got_f[i] != batch_f[i]) ++bad;
+      }
+      for (std::size_t i = 0; i < outsiders.size(); ++i)
+        if (!same(got_out[i], batch2[i])) ++bad;
+      std::printf("map_concurrent mismatches %zu total %zu\n", bad, n_ovl);
+    }
   } catch (const std::exception& ex) {
     std::printf("EXCEPTION %s\n", ex.what());
     return 1;

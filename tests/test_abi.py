@@ -25,6 +25,18 @@ def test_header_symbols_exported():
     assert sorted(hip.SYMBOLS) == declared, "raven_amd/hip.py SYMBOLS out of sync with include/raven_hip.h"
 
 
+def test_edlib_dropin_symbols_exported():
+    """include/edlib.h (the edlibAlign drop-in of construct.cc:190-199) is served by the same library."""
+    text = open(os.path.join(ROOT, "include", "edlib.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(edlib[A-Za-z]+)\s*\(", text)))
+    assert declared == ["edlibAlign", "edlibAlignmentToCigar", "edlibDefaultAlignConfig", "edlibFreeAlignResult",
+                        "edlibNewAlignConfig"]
+    L = hip.lib()
+    for name in declared:
+        assert hasattr(L, name), "missing export: " + name
+
+
 def test_no_oracle_in_product():
     """The product package must not import / link / reference the oracle."""
     pkg = os.path.join(ROOT, "raven_amd")

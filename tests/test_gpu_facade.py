@@ -63,8 +63,10 @@ def test_facade_matches_c_abi(tmp_path):
     want = [(int(pi), int(o["lhs_id"]), int(o["lhs_begin"]), int(o["lhs_end"]), int(o["rhs_id"]), int(o["rhs_begin"]),
              int(o["rhs_end"]), int(o["score"]), int(o["strand"])) for pi, o in zip(pile_of, ovl)]
     assert got == want and len(got) > 100
-    assert lines[-1].startswith("map_single_vs_batch mismatches 0 total ")
-    assert int(lines[-1].split()[-1]) > 0
+    assert lines[-2].startswith("map_single_vs_batch mismatches 0 total ")
+    assert int(lines[-2].split()[-1]) > 0
+    # Map() called from 8 threads at once (indexed sequences and outsiders) == MapBatch, incl. `filtered`
+    assert lines[-1].startswith("map_concurrent mismatches 0 total ") and int(lines[-1].split()[-1]) > 0
 
 
 def test_polisher_facade_compiles_and_fails_loudly_without_gpu(tmp_path):
@@ -106,3 +108,40 @@ def test_polisher_facade_matches_c_abi(tmp_path, q):
         assert S[t].encode() == bytes(np.frombuffer(b"ACGT", dtype=np.uint8)[cons[t]])
     used = [int(p[3].split("RC:i:")[1].split()[0]) for p in P]
     assert sum(used) == st["n_reads_used"]
+
+
+def test_edlib_dropin_compiles_and_fails_loudly_without_gpu(tmp_path):
+    """include/edlib.h: construct.cc:190-199's call pattern compiles; without a GPU edlibAlign reports
+    EDLIB_STATUS_ERROR (the reference then scores the overlap 0) instead of computing anything on the CPU."""
+    if hip.device_count() > 0:
+        pytest.skip("GPU present")
+    exe = _build(tmp_path, "edlib_test")
+    p = tmp_path / "two.txt"
+    p.write_text("ACGTACGTACGTACGTACGTACGTACGT\nACGTACGAACGTACGTACGTACGTACGT\n")
+    r = subprocess.run([exe, str(p)], capture_output=True, text=True)
+    lines = r.stdout.strip().split("\n")
+    assert lines[0] == "default_config -1 0 0" and lines[1] == "hw_mode_status 1" and lines[2] == "five_symbols_status 1"
+    assert r.returncode == 1 and lines[3] == "NO_DEVICE status 1"
+
+
+@pytest.mark.gpu
+def test_edlib_dropin_matches_dp(tmp_path):
+    """edlibAlign drop-in called from 8 threads (combined into device batches) == textbook DP, both strands."""
+    exe = _build(tmp_path, "edlib_test")
+    g = synth.make_genome(3000, seed=5)
+    rng = np.random.default_rng(6)
+    seqs = []
+    for i in range(41):
+        a = int(rng.integers(0, 800))
+        piece = synth.mutate(rng, g[a:a + int(rng.integers(300, 2200))], 0.04, 0.03, 0.03)
+        if i % 7 == 3:
+            piece = piece[:int(rng.integers(0, 5))]  # empty / tiny sequences
+        seqs.append(bytes(np.frombuffer(b"ACGT", dtype=np.uint8)[piece]))
+    path = tmp_path / "seqs.txt"
+    path.write_bytes(b"\n".join(seqs) + b"\n")
+    r = subprocess.run([exe, str(path)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = r.stdout.strip().split("\n")
+    assert lines[3].startswith("self 0 locations 1 end %d alphabet " % (len(seqs[0]) - 1))
+    assert lines[4] == "pairs 40 mismatches 0"
+    assert lines[5] == "k_below -1" and lines[6] == "k_equal 1"

@@ -171,13 +171,19 @@ def test_pass1_ragged_and_empty(gpu):
 def test_add_layers_c_abi(gpu):
     rng = np.random.default_rng(9)
     he, _ = _mk()
-    for trial in range(12):
-        L = int(rng.integers(200, 60000))
+    for trial in range(16):
+        # trials 12..15: deep piles (several thousand overlaps in ONE AddLayers call, saturating), piles longer than
+        # the kernel's LDS tile (8192 cells), and overlaps shorter than 32 bases whose end event precedes their begin
+        # event (the reference's uint32 coverage wraps around, pile.cc:60)
+        L = int(rng.integers(200, 60000)) if trial < 12 else int(rng.integers(150_000, 400_000))
         cells = L >> 4
-        n = int(rng.integers(1, 3000 if trial == 0 else 200))
+        n = int(rng.integers(1, 3000 if trial == 0 else 200)) if trial < 12 else int(rng.integers(3000, 9000))
         ovl = np.zeros(n, hip.OVERLAP_DTYPE)
         b = rng.integers(0, max(1, L - 120), size=n)
         en = np.minimum(L, b + rng.integers(100, L, size=n))
+        if trial >= 14:
+            tiny = (rng.random(n) < 0.02) & (b >= 16)  # (end >> 4) - 1 must not underflow (UB in the reference)
+            en = np.where(tiny, np.minimum(L, b + rng.integers(1, 31, size=n)), en)
         side = rng.integers(0, 3, size=n)
         ovl["lhs_id"] = np.where(side == 0, 42, 7)
         ovl["rhs_id"] = np.where(side == 1, 42, 8)
@@ -185,7 +191,7 @@ def test_add_layers_c_abi(gpu):
         ovl["rhs_begin"], ovl["rhs_end"] = np.where(side == 1, b, 9), np.where(side == 1, en, 900)
         data = rng.integers(0, 50, size=cells).astype(np.uint16)
         if trial % 4 == 0:
-            data[:] = 65500  # saturation at 65535
+            data[:] = 65500 if trial < 12 else 62000  # saturation at 65535
         want = data.copy()
         oracle.pile_add_layers(want, 42, ovl.astype(oracle.OVERLAP_DTYPE))
         got = data.copy()
