@@ -1,15 +1,22 @@
 #!/usr/bin/env python3
-"""bench.py — read Gbase/s through raven's overlap hot path (FindOverlapsAndCreatePiles) on MI355X.
+"""bench.py — read Gbase/s through raven's overlap + polish hot path (FindOverlapsAndCreatePiles + Polish) on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
     (N > 1: launched by torch.distributed.run, one rank per GPU)
 
-Workload (BASELINE.json configs[1]): synthetic 5 Mb genome, 30x ONT-like 10 kb reads (10 % error),
-k=15 w=5, -p 0 (no polishing rounds): one "step" = one full raven::FindOverlapsAndCreatePiles pass over the
-whole read set — sketch, index (sort), filter, map/chain of every read, merge, Pile::AddLayers, top-kMax
-truncation — with the packed reads already resident in HBM and results left in HBM.
-Multi-GPU: every rank owns an independent shard (its own genome + reads), no data-path collective ->
-"scaling": "weak"; value = bases processed by all ranks / max-over-ranks time.
+Workload = the configuration BASELINE.json's metric is quoted on (configs[3] on ONE GPU at N = 1, sharded over the ranks
+at N > 1): synthetic 100 Mb genome, 30x ONT-length reads (log-normal, median 9 kb, 10 % errors), k = 15 w = 5, -p 2.
+One "step" = the whole hot path over the whole read set:
+    raven::FindOverlapsAndCreatePiles   sketch, index (sort), filter, map/chain of every read in flush windows of 2^30
+                                        bases, merge, Pile::AddLayers, top-kMax truncation             (construct.cc:14-121)
+  + 2 x racon::Polisher::Polish         map reads to the draft contigs, best overlap, alignment path + breakpoints,
+                                        window layers, POA consensus, stitch; the consensus of round 1 is the target of
+                                        round 2                                                         (polish.cc:43-74)
+with the packed reads already resident in HBM when the timed region starts.  value = read bases x steps / wall time of
+the timed region (barrier + synchronize on both sides, max over ranks).
+--workload c2 runs BASELINE.json configs[2] instead (5 Mb, 10 kb reads, -p 2); --polish-rounds 0 gives configs[1].
+N > 1: ONE genome sharded across the ranks ("scaling": "strong"): reads by pile, minimizers by hash class, three
+all-to-alls + one all-reduce per flush window (raven_amd/sharded.py), polishing windows sharded by range.
 
 Prints ONE JSON line on rank 0 (metric contract + "roofline" + "cpu_baseline").
 """
@@ -17,6 +24,7 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -25,22 +33,31 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from raven_amd import dist as rdist  # noqa: E402
-from raven_amd import hip, synth  # noqa: E402
+from raven_amd import hip, seqio, synth  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured copy)
+HBM_PEAK_GBS = 8000.0   # MI355X spec (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured copy)
+# integer VALU peak: 256 CU x 4 SIMD x 32 lanes... counted as 64-lane wave instructions:
+# 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 VALU instruction = 1.23e12 wave-instructions/s = 78.6e12 lane-ops/s
+VALU_PEAK_LANE_OPS = 78.6e12
+# a linear-gap POA cell needs at least: one add + one max per candidate (diagonal, vertical per predecessor,
+# horizontal) ~ 6 lane-ops; the graded "peak" cell rate is the lane-op peak / 6
+POA_MIN_OPS_PER_CELL = 6.0
 
 
 def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (profiles/pmc_traffic.json,
-    made by tools/pmc_traffic.py from separate FETCH_SIZE / WRITE_SIZE runs of this same bench command):
-    2 x FETCH_SIZE KiB (gfx950: FETCH_SIZE counts 128-B requests as 64 B, MI355X_MICROARCH.md §HBM) + WRITE_SIZE KiB."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            t = json.load(f)
-        e = t["kernels"].get(kernel)
-        return int(e["hbm_bytes_per_launch"]) if e else None
-    except (OSError, ValueError, KeyError):
-        return None
+    """HBM bytes per launch of `kernel` from this round's rocprofv3 --pmc passes (profiles/r02_pmc_traffic.json, made
+    by tools/pmc_traffic.py from separate FETCH_SIZE / WRITE_SIZE runs of this same bench command): 2 x FETCH_SIZE KiB
+    (gfx950: FETCH_SIZE counts 128-B requests as 64 B, MI355X_MICROARCH.md §HBM) + WRITE_SIZE KiB."""
+    for name in ("r02_pmc_traffic.json",):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                t = json.load(f)
+            e = t["kernels"].get(kernel)
+            if e:
+                return int(e["hbm_bytes_per_launch"])
+        except (OSError, ValueError, KeyError):
+            pass
+    return None
 
 
 def algorithmic_bytes(site, c, val_bytes):
@@ -56,7 +73,6 @@ def algorithmic_bytes(site, c, val_bytes):
         "rs_downsweep": 2.0 * rec * Mi,          # read + write every (value, origin) once
         "heads": (val_bytes + 1) * Mi,
         "unique": (val_bytes + 1 + 4) * Mi + (val_bytes + 4) * U,
-        "scan": None,
         "table": val_bytes * U + 4.0 * (1 << 26),
         "match_count": rec * Mq + 8.0 * H + 12.0 * Mq,
         "match_emit": 8.0 * Mq + 8.0 * H + 16.0 * H,
@@ -69,105 +85,98 @@ def algorithmic_bytes(site, c, val_bytes):
 
 
 def cpu_baseline(args, cores):
-    """Oracle (CPU restatement, 'port') timed on a bounded sample of the same workload."""
+    """The CPU restatement ('port') of the same path timed on bounded samples of the same generator, on this box's
+    cores: the overlap pass multi-threaded on one sample, the polishing round as `threads` independent samples in
+    parallel (the restatement of racon's round is single-threaded per call).  Combined like the metric:
+    bases / (t_overlap + rounds x t_round) per base."""
     from oracle import oracle
+    threads = max(1, min(cores, 64))
     g = synth.make_genome(args.cpu_sample_genome, seed=0xC0FFEE)
-    rs, _ = synth.make_reads(g, args.coverage, args.read_len, seed=0xC0FFEF)
+    rs, _ = synth.make_reads(g, args.coverage, 10000, seed=0xC0FFEF)
     t = time.time()
-    r1 = oracle.Engine(args.k, args.w).find_overlaps_and_create_piles(rs, threads=1) if args.cpu_single else None
-    t1 = time.time() - t
-    t = time.time()
-    oracle.Engine(args.k, args.w).find_overlaps_and_create_piles(rs, threads=cores)
-    tc = time.time() - t
-    sample = "%d reads / %d bases of the same generator (%.2f Mb genome, %gx), oracle FindOverlapsAndCreatePiles, %d threads: %.2f s" % (
-        rs.n, rs.total_bases, args.cpu_sample_genome / 1e6, args.coverage, cores, tc)
-    if r1 is not None:
-        sample += "; 1 thread: %.2f s = %.4f Gbase/s" % (t1, rs.total_bases / t1 / 1e9)
-    return {"value": rs.total_bases / tc / 1e9, "unit": "Gbase/s", "cores": cores, "kind": "port", "sample": sample}
+    oracle.Engine(args.k, args.w).find_overlaps_and_create_piles(rs, threads=threads)
+    t_ovl = time.time() - t
+    v_ovl = rs.total_bases / t_ovl
+    sample = "overlap: %d reads / %d bases (%.1f Mb genome, %gx, 10 kb reads), oracle FindOverlapsAndCreatePiles on %d " \
+             "threads: %.2f s = %.4f Gbase/s" % (rs.n, rs.total_bases, args.cpu_sample_genome / 1e6, args.coverage, threads,
+                                                 t_ovl, v_ovl / 1e9)
+    v = v_ovl
+    if args.polish_rounds > 0:
+        cases = []
+        for i in range(threads):
+            gg = synth.make_genome(12_000, seed=0x5EED0003 + i)
+            prs, _ = synth.make_reads(gg, 30, 3000, seed=0x5EED1004 + i)
+            cases.append((seqio.pack_reads([synth.make_draft(gg, seed=0x5EED2005 + i)]), prs))
+        t = time.time()
+        ths = [threading.Thread(target=oracle.polish_round, args=c) for c in cases]
+        for th in ths:
+            th.start()
+        for th in ths:
+            th.join()
+        t_pol = time.time() - t
+        pol_bases = sum(c[1].total_bases for c in cases)
+        v_pol = pol_bases / t_pol
+        sample += "; polish: %d independent rounds in parallel (12 kb draft, 30x, 3 kb reads each; %d bases), " \
+                  "oracle.polish_round: %.2f s = %.5f Gbase/s per round" % (threads, pol_bases, t_pol, v_pol / 1e9)
+        v = 1.0 / (1.0 / v_ovl + args.polish_rounds / v_pol)
+    return {"value": round(v / 1e9, 6), "unit": "Gbase/s", "cores": threads, "kind": "port", "sample": sample}
 
 
-def cpu_baseline_polish():
-    """The CPU restatement of one racon round (oracle.polish_round, 1 thread: whole-overlap NW path + spoa-style POA)
-    on a bounded sample of the same generator: 20 kb draft, 30x, 5 kb reads."""
-    from oracle import oracle
-    from raven_amd import seqio
-    g = synth.make_genome(20_000, seed=0x5EED0003)
-    rs, _ = synth.make_reads(g, 30, 5000, seed=0x5EED0004)
-    targets = seqio.pack_reads([synth.make_draft(g, seed=0x5EED0005)])
-    t0 = time.perf_counter()
-    oracle.polish_round(targets, rs)
-    dt = time.perf_counter() - t0
-    return {"value": round(rs.total_bases / dt / 1e9, 6), "unit": "Gbase/s per round", "cores": 1, "kind": "port",
-            "sample": "%d reads / %d bases on a 20 kb draft (5 kb reads: the checker aligns every read with a full "
-                      "NW matrix), oracle.polish_round: %.1f s" % (rs.n, rs.total_bases, dt)}
-
-
-def bench_sharded(args, rank, world, local_rank, dist, barrier):
-    """Strong-scaling leg: every rank generates the SAME genome/reads, owns a slice of the piles, and the pass runs
-    through raven_amd/sharded.py (all-to-all over RCCL on torch CUDA tensors; nothing crosses PCIe between stages)."""
-    from raven_amd import sharded
-    genome_seed, reads_seed = rdist.shard_seeds(0)
-    genome = synth.make_genome(args.genome, seed=genome_seed)
-    rs, _ = synth.make_reads(genome, args.coverage, args.read_len, seed=reads_seed)
-    eng = hip.Engine(args.k, args.w, device=local_rank)
-    eng.set_timing(False)
+def make_workload(args, device):
+    """Seeded synthetic genome, reads and draft contigs of the workload, generated on the GPU (torch as the random /
+    scatter engine), handed over as host arrays like any caller's data."""
     import torch
-    comm = sharded.DeviceComm(dist, device="cuda")
-    dev = torch.device("cuda", local_rank)
-    res = None
-    for _ in range(args.warmup):
-        res = sharded.find_overlaps_and_create_piles_sharded_dev(eng, rs, comm, dev, freq=args.freq, kmax=args.kmax)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res = sharded.find_overlaps_and_create_piles_sharded_dev(eng, rs, comm, dev, freq=args.freq, kmax=args.kmax)
-    barrier()
-    dt = time.perf_counter() - t0
-    dt, _ = rdist.aggregate(dt, 0.0, dist, device="cuda")
-    if rank == 0:
-        steps = max(args.steps, 1)
-        print(json.dumps({
-            "metric": "read Gbase/s through overlap+polish", "value": round(rs.total_bases * steps / dt / 1e9, 4),
-            "unit": "Gbase/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[1] as ONE genome sharded over the ranks: %.1f Mb, %gx, %d bp "
-                                   "reads, -p 0" % (args.genome / 1e6, args.coverage, args.read_len),
-                       "parallelism": "reads by pile, minimizers by hash class; all-to-all x3 on CUDA tensors (RCCL)",
-                       "rank0": {k: res[k] for k in ("lo", "hi", "occurrence", "stats")}},
-            "roofline": None, "cpu_baseline": None}), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    t0 = time.time()
+    dev = torch.device("cuda", device)
+    genome = synth.make_genome_torch(args.genome, seed=0x5EED0001, device=dev)
+    rs, _ = synth.make_reads_torch(genome, args.coverage, args.read_len, length_model=args.length_model, seed=0x5EED0002)
+    drafts = []
+    if args.polish_rounds > 0:
+        n_contigs = max(1, (args.genome + args.contig - 1) // args.contig)
+        bounds = np.linspace(0, args.genome, n_contigs + 1).astype(np.int64)
+        for i in range(n_contigs):  # what raven's layout hands to racon: the truth with ~2.6 % errors, in contigs
+            d = synth.mutate_torch(genome[int(bounds[i]):int(bounds[i + 1])], 0.01, 0.008, 0.008, seed=0x5EED0007 + i)
+            drafts.append(d.cpu().numpy())
+    del genome
+    torch.cuda.empty_cache()
+    return rs, drafts, time.time() - t0
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--genome", type=int, default=5_000_000)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", choices=["c4", "c2"], default="c4",
+                    help="c4: 100 Mb, 30x ONT-length reads (configs[3]; the metric's config).  c2: 5 Mb, 10 kb reads (configs[2])")
+    ap.add_argument("--genome", type=int, default=None)
     ap.add_argument("--coverage", type=float, default=30.0)
-    ap.add_argument("--read-len", type=int, default=10000)
+    ap.add_argument("--read-len", type=int, default=None)
+    ap.add_argument("--length-model", default=None)
+    ap.add_argument("--contig", type=int, default=5_000_000, help="draft contig (unitig) length for the polishing rounds")
     ap.add_argument("--k", type=int, default=15)
     ap.add_argument("--w", type=int, default=5)
     ap.add_argument("--freq", type=float, default=0.001)
     ap.add_argument("--kmax", type=int, default=32)
-    ap.add_argument("--cpu-sample-genome", type=int, default=1_000_000)
-    ap.add_argument("--cpu-single", type=int, default=1)
+    ap.add_argument("--polish-rounds", type=int, default=2)
+    ap.add_argument("--cpu-sample-genome", type=int, default=2_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
-    ap.add_argument("--sharded", action="store_true", help="ONE genome sharded across the ranks (SURVEY 8(e): reads by "
-                    "pile, minimizers by hash class, three all-to-all exchanges) instead of one independent shard per "
-                    "GPU; strong scaling, overlap pass only")
-    ap.add_argument("--no-polish", action="store_true", help="skip the configs[2] polishing leg (reported beside, "
-                    "never part of `value`)")
-    ap.add_argument("--polish-rounds", type=int, default=2)
+    ap.add_argument("--replicas", action="store_true", help="N > 1: independent shard per GPU (weak scaling, no "
+                    "collective) instead of one genome sharded across the ranks")
     args = ap.parse_args()
+    if args.workload == "c4":
+        args.genome = args.genome or 100_000_000
+        args.read_len = args.read_len or 9000
+        args.length_model = args.length_model or "lognormal"
+    else:
+        args.genome = args.genome or 5_000_000
+        args.read_len = args.read_len or 10000
+        args.length_model = args.length_model or "fixed"
 
     rank, world, local_rank = rdist.env_rank()
 
-    import torch  # plumbing only: device selection, barrier, max-over-ranks
+    import torch  # plumbing only: device selection, data generation, barrier, collectives
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (torch.cuda.is_available() is False)")
     torch.cuda.set_device(local_rank)
@@ -185,140 +194,179 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    if args.sharded:
-        return bench_sharded(args, rank, world, local_rank, dist, barrier)
-
-    # ---- synthetic shard of this rank (seeded; rank-dependent so shards are independent) ----
-    t0 = time.time()
-    genome_seed, reads_seed = rdist.shard_seeds(rank)
-    genome = synth.make_genome(args.genome, seed=genome_seed)
-    rs, _ = synth.make_reads(genome, args.coverage, args.read_len, seed=reads_seed)
-    t_gen = time.time() - t0
+    sharded_mode = world > 1 and not args.replicas
+    if world > 1 and args.replicas:  # independent shards: rank-dependent seeds would go here; same data is fine
+        pass
+    rs, drafts, t_gen = make_workload(args, local_rank)
 
     eng = hip.Engine(args.k, args.w, device=local_rank)
+    peng = eng if (args.k, args.w) == (15, 5) else hip.Engine(15, 5, device=local_rank)  # racon maps with (15, 5)
     t0 = time.time()
     reads = eng.upload(rs)  # H2D once; resident for every step
+    preads = reads if peng is eng else peng.upload(rs)
     t_h2d = time.time() - t0
     eng.set_timing(False)  # no per-stage host syncs inside the timed region
+    peng.set_timing(False)
     eng.set_kernel_timing(not args.no_kernel_timing)
+    peng.set_kernel_timing(not args.no_kernel_timing)
 
-    def step():
-        p = eng.find_overlaps_and_create_piles(reads, freq=args.freq, kmax=args.kmax)  # synchronous: returns when done
-        p.close()
+    comm = None
+    if sharded_mode:
+        from raven_amd import sharded
+        comm = sharded.DeviceComm(dist, device="cuda")
+    dev = torch.device("cuda", local_rank)
+    legs = {"overlap_s": 0.0, "polish_s": 0.0}
+    last = {}
+
+    def step(timed):
+        t_a = time.perf_counter()
+        if sharded_mode:
+            res = sharded.find_overlaps_and_create_piles_sharded_dev(eng, rs, comm, dev, freq=args.freq, kmax=args.kmax)
+            last["overlap"] = {k: res[k] for k in ("lo", "hi", "occurrence", "stats")}
+        else:
+            p = eng.find_overlaps_and_create_piles(reads, freq=args.freq, kmax=args.kmax)  # synchronous
+            p.close()
+        t_b = time.perf_counter()
+        cur = None
+        n_windows = 0
+        for rnd in range(args.polish_rounds):
+            targets = peng.upload_codes(drafts if cur is None else cur)
+            if sharded_mode:
+                cur, ratio = sharded.polish_round_sharded(peng, targets, preads, comm, targets.rs)
+                st = {"n_windows": int(((targets.rs.lengths.astype(np.int64) + 499) // 500).sum())}
+            else:
+                cur, ratio, st = peng.polish_round(targets, preads)
+            targets.close()
+            n_windows += st["n_windows"]
+            last["polish"] = st
+            last["ratio"] = float(np.mean(ratio)) if len(ratio) else 0.0
+        t_c = time.perf_counter()
+        if timed:
+            legs["overlap_s"] += t_b - t_a
+            legs["polish_s"] += t_c - t_b
+            last["n_windows"] = n_windows
 
     for _ in range(args.warmup):
-        step()
+        step(False)
     eng.reset_stats()
+    if peng is not eng:
+        peng.reset_stats()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        step(True)
     barrier()
     dt = time.perf_counter() - t0
 
-    dt, total_bases = rdist.aggregate(dt, float(rs.total_bases), dist, device="cuda")
+    units = float(rs.total_bases) if (world == 1 or not sharded_mode) else float(rs.total_bases) / world
+    dt, total_bases = rdist.aggregate(dt, units, dist, device="cuda")
+    if sharded_mode:
+        total_bases = float(rs.total_bases)
 
     counters_raw = eng.counters()
-    kms_raw = eng.kernel_ms() if not args.no_kernel_timing else {}
-    eng.reset_stats()
-
-    # ---- configs[2] leg: -p 2, racon-style polishing rounds of this shard's draft assembly with the same reads ----
-    polish = None
-    if not args.no_polish and args.polish_rounds > 0:
-        from raven_amd import seqio
-        peng = eng if (args.k, args.w) == (15, 5) else hip.Engine(15, 5, device=local_rank)  # racon maps with (15, 5)
-        preads = reads if peng is eng else peng.upload(rs)
-        draft = synth.make_draft(genome, seed=genome_seed + 7)
-        peng.polish_round(peng.upload(seqio.pack_reads([draft[:100_000]])), preads)  # warm-up (allocations)
-        peng.reset_stats()
-        cur = seqio.pack_reads([draft])
-        barrier()
-        tp0 = time.perf_counter()
-        last = None
-        n_windows = 0
-        for _ in range(args.polish_rounds):
-            cons, ratio, last = peng.polish_round(peng.upload(cur), preads)
-            n_windows += last["n_windows"]
-            cur = seqio.pack_reads([cons[0]])
-        barrier()
-        dtp = time.perf_counter() - tp0
-        dtp, _ = rdist.aggregate(dtp, float(rs.total_bases), dist, device="cuda")
-        polish = {
-            "workload": "BASELINE.json configs[2]: same genome/reads, -p %d: draft = genome with 2.6%% iid errors, "
-                        "racon-style rounds (map reads to the draft, 500-bp windows, POA consensus m/n/g = 3/-5/-4)"
-                        % args.polish_rounds,
-            "rounds": args.polish_rounds, "s_per_round": round(dtp / args.polish_rounds, 4),
-            "read_gbase_per_s_per_round": round(total_bases / (dtp / args.polish_rounds) / 1e9, 4),
-            "windows_per_s": round(n_windows * world / dtp, 1),
-            "overlap_plus_polish_gbase_per_s": round(total_bases / (dt / max(args.steps, 1) + dtp) / 1e9, 4),
-            "last_round": {k: (round(v, 3) if isinstance(v, float) else v) for k, v in last.items()},
-            "polished_ratio": round(float(ratio[0]), 4),
-            "kernels_ms_per_round": {k: round(v[0] / args.polish_rounds, 3) for k, v in
-                                     sorted(peng.kernel_ms().items(), key=lambda x: -x[1][0])[:6] if v[1]}
-            if not args.no_kernel_timing else None,
-            "windows_rerun_wide_band": peng.poa_wide_windows(), "windows_rerun_full_matrix": peng.poa_fallback_windows(),
-        }
+    kms = {}
+    if not args.no_kernel_timing:
+        kms = dict(eng.kernel_ms())
+        if peng is not eng:
+            for k2, v in peng.kernel_ms().items():
+                a = kms.get(k2, (0.0, 0))
+                kms[k2] = (a[0] + v[0], a[1] + v[1])
+    poa_cells = peng.poa_cells()
 
     if rank == 0:
         steps = max(args.steps, 1)
         counters = {k: v // steps for k, v in counters_raw.items()}
-        kms = kms_raw
         val_bytes = 4 if 2 * eng.k < 32 else 8
-        roofline = None
-        kernels = {}
+        kernels, roofline, roofline_hbm = {}, None, None
         if kms:
             tot = sum(v[0] for v in kms.values())
             for name, (ms, la) in sorted(kms.items(), key=lambda x: -x[1][0]):
                 if la:
                     kernels[name] = {"ms_per_step": round(ms / steps, 4), "launches_per_step": la / steps,
-                                     "avg_launch_ms": round(ms / la, 5)}
-            dom = None
-            for name in kernels:  # dominant kernel with a defined algorithmic byte count
-                if algorithmic_bytes(name, counters, val_bytes):
-                    dom = name
+                                     "avg_launch_ms": round(ms / la, 5), "share": round(ms / tot, 4) if tot else None}
+            # dominant kernel of the WHOLE step: the banded POA kernel (integer VALU bound)
+            dom = next(iter(kernels), None)
+            if dom == "poa_banded" and poa_cells["cells_full"]:
+                ms, la = kms[dom]
+                cells = poa_cells["cells_full"] / max(poa_cells["calls"], 1) * 1.0  # per polishing round (one launch set)
+                launches_per_round = la / max(poa_cells["calls"], 1)
+                avg_s = ms / la / 1e3
+                cells_per_launch = cells / launches_per_round
+                achieved_tops = cells_per_launch * POA_MIN_OPS_PER_CELL / avg_s / 1e12
+                roofline = {"bound": "valu", "kernel": dom,
+                            "achieved": round(achieved_tops, 3), "peak": round(VALU_PEAK_LANE_OPS / 1e12, 1),
+                            "unit": "T lane-ops/s", "frac": round(achieved_tops * 1e12 / VALU_PEAK_LANE_OPS, 4),
+                            "traffic": pmc_traffic(dom),
+                            "algorithmic_cells_per_launch": int(cells_per_launch),
+                            "algorithmic_ops_per_cell": POA_MIN_OPS_PER_CELL,
+                            "gcups_algorithmic": round(cells_per_launch / avg_s / 1e9, 1),
+                            "gcups_banded_computed": round(poa_cells["cells_banded"] / max(poa_cells["calls"], 1) /
+                                                           launches_per_round / avg_s / 1e9, 1),
+                            "avg_launch_ms": round(avg_s * 1e3, 3),
+                            "kernel_ms_share": round(ms / tot, 3) if tot else None,
+                            "note": "algorithmic cells = graph rows x layer length of every layer alignment (what "
+                                    "spoa's full NW computes); the kernel computes a 64-column band of them"}
+            # the dominant HBM-bound kernel (second entry)
+            for name in kernels:
+                b = algorithmic_bytes(name, counters, val_bytes)
+                if b:
+                    avg_s = kms[name][0] / kms[name][1] / 1e3
+                    achieved = b / avg_s / 1e9
+                    roofline_hbm = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(name),
+                                    "algorithmic_bytes_per_launch": int(b), "avg_launch_ms": round(avg_s * 1e3, 5),
+                                    "kernel_ms_share": round(kms[name][0] / tot, 3) if tot else None}
                     break
-            if dom:
-                b = algorithmic_bytes(dom, counters, val_bytes)
-                avg_s = kms[dom][0] / kms[dom][1] / 1e3
-                achieved = b / avg_s / 1e9
-                roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(dom),
-                            "algorithmic_bytes_per_launch": int(b), "avg_launch_ms": round(avg_s * 1e3, 5),
-                            "kernel_ms_share": round(kms[dom][0] / tot, 3) if tot else None}
+            if roofline is None:
+                roofline = roofline_hbm
+        ovl_s, pol_s = legs["overlap_s"] / steps, legs["polish_s"] / steps
+        rounds = args.polish_rounds
         out = {
             "metric": "read Gbase/s through overlap+polish",
-            "value": round(rdist.throughput(dt, total_bases, args.steps) / 1e9, 4),
+            "value": round(total_bases * args.steps / dt / 1e9, 4),
             "unit": "Gbase/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(dt / steps * 1e3, 3),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if sharded_mode else "weak",
             "vs_baseline": None,
             "dtype": "u32" if val_bytes == 4 else "u64",
             "data": "synthetic",
             "config": {
-                "workload": "BASELINE.json configs[1]: synthetic %.1f Mb genome, %gx ONT-like %d bp reads "
-                            "(4%% sub, 3%% ins, 3%% del), k=%d w=%d, -p 0 (FindOverlapsAndCreatePiles only, "
-                            "no polishing rounds), 1 shard per GPU" % (args.genome / 1e6, args.coverage,
-                                                                       args.read_len, args.k, args.w),
-                "reads_per_gpu": rs.n, "bases_per_gpu": rs.total_bases, "freq": args.freq, "kmax": args.kmax,
-                "parallelism": "independent shard per GPU (no data-path collective)",
+                "workload": "BASELINE.json configs[%d]%s: synthetic %.0f Mb genome, %gx ONT-like reads (%s %d bp; 4%% sub, "
+                            "3%% ins, 3%% del), k=%d w=%d, FindOverlapsAndCreatePiles + -p %d (racon rounds on %.0f Mb "
+                            "draft contigs with 2.6%% errors)" % (
+                                3 if args.workload == "c4" else (2 if rounds else 1),
+                                " on one GPU" if world == 1 and args.workload == "c4" else "",
+                                args.genome / 1e6, args.coverage, args.length_model, args.read_len, args.k, args.w, rounds,
+                                args.contig / 1e6),
+                "reads": rs.n, "read_bases": rs.total_bases, "freq": args.freq, "kmax": args.kmax,
+                "draft_contigs": len(drafts),
+                "parallelism": ("one genome sharded over %d GPUs: reads by pile, minimizers by hash class, 3 all-to-all + "
+                                "1 all-reduce per flush window over RCCL; polishing windows by range" % world)
+                if sharded_mode else ("independent replica per GPU (no data-path collective)" if world > 1 else "1 GPU"),
             },
-            "overlaps_per_s": round(counters["overlaps"] * world * args.steps / dt, 1),
+            "legs": {"overlap_s_per_step": round(ovl_s, 4), "polish_s_per_step": round(pol_s, 4),
+                     "overlap_gbase_per_s": round(rs.total_bases / ovl_s / 1e9, 3) if ovl_s else None,
+                     "polish_gbase_per_s_per_round": round(rs.total_bases / (pol_s / rounds) / 1e9, 3) if rounds and pol_s else None,
+                     "windows_per_s": round(last.get("n_windows", 0) / pol_s, 1) if pol_s else None,
+                     "polished_ratio": last.get("ratio")},
+            "overlaps_per_s": round(counters["overlaps"] / ovl_s, 1) if ovl_s else None,
             "counters_per_step": counters,
+            "last_polish_round": {k: (round(v, 3) if isinstance(v, float) else v) for k, v in last.get("polish", {}).items()},
             "roofline": roofline,
-            "kernels": kernels,
-            "polish": polish,
+            "roofline_hbm": roofline_hbm,
+            "kernels": dict(list(kernels.items())[:16]),
             "host": {"gen_s": round(t_gen, 2), "h2d_s": round(t_h2d, 3),
                      "h2d_inclusive_gbase_s": round(rs.total_bases / (dt / steps + t_h2d) / 1e9, 4)},
+            "cpu_baseline": None,
         }
+        if sharded_mode:
+            out["rank0"] = last.get("overlap")
         if not args.no_cpu_baseline and world == 1:
-            cores = os.cpu_count() or 1
-            out["cpu_baseline"] = cpu_baseline(args, cores)
-            if polish is not None:
-                polish["cpu_baseline"] = cpu_baseline_polish()
+            out["cpu_baseline"] = cpu_baseline(args, os.cpu_count() or 1)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -68,23 +68,22 @@ class Polisher {
       reads_key_ = sequences.data();
       reads_n_ = sequences.size();
       reads_fp_ = fp;
-      // per-base Phred+33 from biosoup's block qualities, only if every read has them
+      // biosoup keeps one mean Phred per 64 bases (block_quality) and racon only ever sees that mean: the block
+      // bytes go to HBM once, beside the bases, and stay there for every round — only if every read has them
       has_q_ = !sequences.empty();
       for (const auto& s : sequences) has_q_ = has_q_ && !s->block_quality.empty();
-      quals_.clear();
-      qoff_.clear();
       if (has_q_) {
-        qoff_.push_back(0);
+        std::vector<std::uint8_t> quals;
+        std::vector<std::uint64_t> qoff(1, 0);
         for (const auto& s : sequences) {
-          for (std::uint32_t i = 0; i < s->inflated_len; ++i)
-            quals_.push_back(static_cast<std::uint8_t>(s->block_quality[i >> 6] + 33));
-          qoff_.push_back(quals_.size());
+          const std::size_t nb = (static_cast<std::size_t>(s->inflated_len) + 63) / 64;
+          for (std::size_t i = 0; i < nb; ++i)
+            quals.push_back(static_cast<std::uint8_t>((i < s->block_quality.size() ? s->block_quality[i] : 0) + 33));
+          qoff.push_back(quals.size());
         }
+        ram::detail::Check(rvn_reads_attach_quality(engine_, reads_.h, quals.data(), qoff.data(), 6));
       }
     }
-    const bool has_q = has_q_;
-    const std::vector<std::uint8_t>& quals = quals_;
-    const std::vector<std::uint64_t>& qoff = qoff_;
     ram::detail::ReadsHandle& r = reads_;
 
     const std::size_t n = targets.size();
@@ -94,9 +93,9 @@ class Polisher {
     std::vector<std::uint32_t> len(n), used(n);
     std::vector<double> ratio(n);
     rvn_polish_stats st{};
-    ram::detail::Check(rvn_polish_round(engine_, t.h, r.h, has_q ? quals.data() : nullptr, has_q ? qoff.data() : nullptr,
-                                        q_, e_, w_, trim_ ? 1 : 0, m_, n_, g_, codes.data(), ooff.data(), len.data(),
-                                        ratio.data(), &st));
+    // qualities: the ones attached to the read set (none attached = unit weights, no quality filter)
+    ram::detail::Check(rvn_polish_round(engine_, t.h, r.h, nullptr, nullptr, q_, e_, w_, trim_ ? 1 : 0, m_, n_, g_,
+                                        codes.data(), ooff.data(), len.data(), ratio.data(), &st));
     ram::detail::Check(rvn_polish_target_reads(engine_, used.data(), static_cast<std::uint32_t>(n)));
     for (std::size_t i = 0; i < n; ++i) {
       if (drop_unpolished && ratio[i] == 0.0) continue;
@@ -150,8 +149,6 @@ class Polisher {
   std::size_t reads_n_ = 0;
   std::uint64_t reads_fp_ = 0;
   bool has_q_ = false;
-  std::vector<std::uint8_t> quals_;
-  std::vector<std::uint64_t> qoff_;
 };
 
 }  // namespace racon

@@ -57,7 +57,18 @@ void rvn_engine_destroy(rvn_engine* e);
  * (the reference keeps std::vector<std::unique_ptr<biosoup::NucleicAcid>> in RAM, RavenExe/src/main.cc:258-299). */
 int rvn_reads_upload(rvn_engine* e, const uint64_t* packed, uint64_t n_words, const uint64_t* word_offsets,
                      const uint32_t* lengths, const uint32_t* ids, uint32_t n_reads, rvn_reads** out);
+/* Same from one-byte base codes (0..3; read i = codes[offsets[i] .. offsets[i+1])): the 2-bit packing happens on the
+ * device.  This is how the consensus of one polishing round becomes the target set of the next
+ * (RavenLib/src/polish.cc:50-71 rebuilds biosoup::NucleicAcid objects from the polished strings). */
+int rvn_reads_upload_codes(rvn_engine* e, const uint8_t* codes, const uint64_t* offsets, const uint32_t* ids,
+                           uint32_t n_reads, rvn_reads** out);
 void rvn_reads_destroy(rvn_reads* r);
+/* Base qualities of an uploaded read set, kept in HBM beside the bases for every later polishing round
+ * (biosoup::NucleicAcid::block_quality; raven::Polish computes its threshold from them, polish.cc:26-41).
+ * quals: Phred+33 bytes, one per 2^block_shift bases of a read (block_shift 0: per base; 6: biosoup's block qualities
+ * = the mean of 64 bases + 33, which is all racon ever sees of them), read i at offsets[i] (offsets[n_reads+1]).
+ * rvn_polish_round uses them when called with read_quals == NULL.  quals == NULL detaches. */
+int rvn_reads_attach_quality(rvn_engine* e, rvn_reads* r, const uint8_t* quals, const uint64_t* offsets, int block_shift);
 
 /* ram::MinimizerEngine::Minimize(first, last, minhash) — builds the index (construct.cc:42-43, :363). */
 int rvn_engine_minimize(rvn_engine* e, const rvn_reads* r, uint32_t first, uint32_t last, int minhash);
@@ -160,12 +171,17 @@ int rvn_poa_consensus_batch(rvn_engine* e, const uint8_t* codes, const uint8_t* 
  * concatenated in read order (qual_offsets[n_reads+1]) or NULL.  Output: polished base codes of target t at
  * out_offsets[t] (capacity out_offsets[t+1]-out_offsets[t]; 2 x length + 1024 is ample), out_len[t], and the
  * polished-window ratio racon writes into the XC:f: tag (polish.cc:57-59 tests it for > 0).
- * Window breakpoints come from the mapping's chain anchors instead of an edlib path. */
+ * Window breakpoints come from the exact global alignment path of every read's best overlap, as in racon
+ * (DESIGN.md §3.7); read_quals == NULL uses the qualities attached with rvn_reads_attach_quality, if any. */
 typedef struct rvn_polish_stats {
   uint64_t n_overlaps, n_reads_used, n_layers, n_windows, n_polished_windows, n_failed_windows;
   double poa_ms;                    /* device time of the window-consensus batch */
-  double map_ms, host_ms, total_ms; /* wall: index+map+read-back | host window/layer building + stitching | whole call */
-  uint64_t n_dropped_layers;        /* read pieces dropped because their length contradicts their target span */
+  double map_ms, host_ms, total_ms; /* wall: index + map + best overlap | host planning (jobs, window tables) | whole call */
+  uint64_t n_dropped_layers;        /* reads left out because their alignment is beyond the path kernel (band > ~32 000) */
+  double align_ms;                  /* device time of the alignment-path stage (banded NW forward + traceback) */
+  uint64_t n_aligned, n_align_retries; /* read-to-target alignments done | attempts repeated with a doubled band */
+  uint64_t align_band_cells;        /* DP cells inside the computed bands (all attempts) */
+  uint64_t align_store_bytes;       /* largest band store of one batch (16 + 4 bytes per 64 cells) */
 } rvn_polish_stats;
 int rvn_polish_round(rvn_engine* e, rvn_reads* targets, rvn_reads* reads, const uint8_t* read_quals,
                      const uint64_t* qual_offsets, double q, double err, uint32_t w, int trim, int match, int mismatch,
@@ -242,9 +258,16 @@ int rvn_polish_round_range(rvn_engine* e, rvn_reads* targets, rvn_reads* reads, 
                            const uint64_t* out_offsets, uint32_t* out_len, double* ratio, uint32_t* n_windows,
                            uint32_t* n_polished, rvn_polish_stats* stats);
 
-/* Windows per POA chunk of a polishing round: the host cuts the reads of chunk i+1 while the GPU runs the POA of
- * chunk i (default 16384; 0 = one batch).  Results do not depend on it.  Returns the previous value. */
+/* Kept for source compatibility: a round no longer has a host cutting stage to overlap with the POA, all windows
+ * of a call are one device batch.  Stores the value, returns the previous one; results never depended on it. */
 uint64_t rvn_polish_set_chunk_windows(rvn_engine* e, uint64_t windows);
+
+/* The window layers of the last rvn_polish_round / _range call, as racon would have added them (steps 1-4 of its
+ * round: mapping, best overlap, alignment path, breakpoints, layer rules — all integer work, compared bit-exactly with
+ * the CPU restatement by the tests): 7 uint32 per layer {global window, read index, first base in the oriented read,
+ * bases, begin, end, reverse-complemented}, windows in order, layers in racon's order, layers dropped by the
+ * mean-quality filter left out.  out == NULL or cap too small: only *n is set. */
+int rvn_polish_fetch_layers(rvn_engine* e, uint32_t* out, uint64_t cap, uint64_t* n);
 
 /* reads used per target (their best overlap passed the error filter) in the last rvn_polish_round call: the RC:i:
  * tag racon writes next to XC:f: */
@@ -253,6 +276,11 @@ int rvn_polish_target_reads(const rvn_engine* e, uint32_t* counts, uint32_t n_ta
 /* shader-clock cycles summed over all windows of the last rvn_poa_consensus_batch call, per phase:
  * {subgraph, NW matrix, traceback, AddAlignment, order rebuild, consensus} */
 void rvn_poa_phase_cycles(const rvn_engine* e, uint64_t out[6]);
+
+/* DP work of the banded window kernel since the last rvn_engine_reset_stats: {cells of the full-matrix equivalent =
+ * graph rows x layer length over every layer alignment (what spoa's NW computes; windows repeated with a wider band
+ * count again), cells inside the computed bands, POA batches}.  bench.py prices the kernel's roofline with it. */
+void rvn_poa_work(const rvn_engine* e, uint64_t out[3]);
 
 /* Which window kernel rvn_poa_consensus_batch / rvn_polish_round use: 0 (default) = banded LDS kernel with a
  * 64-column band; windows whose alignment touches the band edge are repeated with 128 and then 256 columns, and
@@ -292,11 +320,16 @@ int rvn_engine_kernel_ms(rvn_engine* e, double* ms, uint64_t* launches, int n);
 uint64_t rvn_test_hash(uint64_t key, uint32_t k, int use32);
 int rvn_test_canonical(const uint64_t* words, uint32_t pos, uint32_t k, int use32, uint64_t* value, uint32_t* strand);
 int rvn_test_low_complexity(const uint8_t* codes, uint32_t k);
-/* the window cut of the polishing front end (polish_cut.h) on one-byte codes; anchors = (target, read) positions of
- * exact k-mer matches, increasing; out = {ql, tl, qr, tr}; returns the number of residual NWs (>= 0) or RVN_EINVAL */
-int rvn_test_window_cut(const uint8_t* target, uint32_t tlen, const uint8_t* read, uint32_t qlen,
-                        const uint32_t* anchor_t, const uint32_t* anchor_q, uint32_t n_anchors, uint32_t k,
-                        uint32_t boundary, uint32_t out[4]);
+/* the alignment-path stage of a polishing round (nwpath.h) stepped on the CPU: the forward sweep's lane code driven
+ * for 64 emulated lanes + the traceback, i.e. exactly what the kernels execute.  Rows = target span
+ * [t_begin, t_begin + n) of a packed target, columns = span [q_begin, q_begin + m) of the read in the target's
+ * orientation (rc: the read is reverse-complemented).  k = first band threshold (doubled until exact), force_r = 0
+ * or the blocks per lane (1 / 2 / 4 / 8).  recs: one 32-byte record per window of w target bases touched by the span
+ * {first_t, first_q, last_t, last_q, u16 grid[8]}; distance = exact edit distance; band = {k, lanes, R} used.
+ * Returns 0, 1 if the walk did not end at cost 0, < 0 on invalid arguments. */
+int rvn_test_nw_breakpoints(const uint64_t* t_words, uint32_t t_len, const uint64_t* r_words, uint32_t r_len,
+                            uint32_t t_begin, uint32_t n, uint32_t q_begin, uint32_t m, int rc, uint32_t w, uint32_t k,
+                            int force_r, uint32_t* recs, uint32_t* distance, uint32_t* band);
 void rvn_test_std_sort_lendesc(uint64_t* data, uint64_t n);
 void rvn_test_heap_sort_lendesc(uint64_t* data, uint64_t n);
 

@@ -235,6 +235,45 @@ def polish_round(targets, reads, quals=None, q=0.0, err=0.3, w=500, trim=True, m
     return [out[int(ooff[i]): int(ooff[i]) + int(out_len[i])].copy() for i in range(nt)], ratio
 
 
+def polish_layers(targets, reads, quals=None, q=0.0, err=0.3, w=500):
+    """Steps 1-4 of racon's round (map, best overlap, NW path, breakpoints, layer rules): uint32[n, 7] rows
+    {window, read, first base in the oriented read, bases, begin, end, rc}, in racon's order."""
+    qa = qo = None
+    if quals is not None:
+        qo = np.zeros(len(quals) + 1, dtype=np.uint64)
+        np.cumsum([len(x) for x in quals], out=qo[1:])
+        qa = np.concatenate([np.asarray(x, dtype=np.uint8) for x in quals])
+    L = lib()
+    L.orc_polish_layers.restype = C.c_uint64
+    L.orc_polish_layers.argtypes = [C.c_void_p] * 4 + [C.c_uint32] + [C.c_void_p] * 4 + [C.c_uint32, C.c_void_p, C.c_void_p,
+                                    C.c_double, C.c_double, C.c_uint32, C.c_void_p, C.c_uint64]
+    cap = int(reads.n) * (int(targets.lengths.max()) // w + 2) + 16
+    cap = min(cap, int(sum((int(x) // w + 2) for x in reads.lengths)) + 16)
+    out = np.zeros((cap, 7), dtype=np.uint32)
+    n = L.orc_polish_layers(_p(targets.packed), _p(targets.word_offsets), _p(targets.lengths), _p(targets.ids), targets.n,
+                            _p(reads.packed), _p(reads.word_offsets), _p(reads.lengths), _p(reads.ids), reads.n,
+                            _p(qa), _p(qo), float(q), float(err), w, _p(out), cap)
+    assert n <= cap
+    return out[:n].copy()
+
+
+def nw_breakpoints(query: np.ndarray, target: np.ndarray, q_begin: int, t_begin: int, w: int):
+    """Global alignment path of two code arrays (plain DP, ties: diagonal, then query base only, then target base
+    only) -> racon's find_breaking_points_from_cigar.  Returns (pairs[(t, q)] two per window with an aligned pair,
+    edit distance)."""
+    query = np.ascontiguousarray(query, dtype=np.uint8)
+    target = np.ascontiguousarray(target, dtype=np.uint8)
+    cap = 4 * ((t_begin + len(target)) // w + 2)
+    out = np.zeros(cap, dtype=np.uint32)
+    dist = np.zeros(1, dtype=np.uint32)
+    L = lib()
+    L.orc_nw_breakpoints.restype = C.c_uint64
+    L.orc_nw_breakpoints.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                     C.c_void_p, C.c_uint64, C.c_void_p]
+    n = L.orc_nw_breakpoints(_p(query), len(query), _p(target), len(target), q_begin, t_begin, w, _p(out), cap, _p(dist))
+    return out[: 2 * n].reshape(-1, 2).copy(), int(dist[0])
+
+
 def antiqsort(n: int) -> np.ndarray:
     """Values (ascending-sort killer) that drive libstdc++'s introsort into its heapsort fallback."""
     out = np.zeros(n, dtype=np.uint32)

@@ -30,6 +30,7 @@
 // same library routine the reference would be linked with.
 
 #include <algorithm>
+#include <array>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -883,14 +884,83 @@ static void NwPath(const std::vector<std::uint8_t>& q, const std::vector<std::ui
   std::reverse(ops->begin(), ops->end());
 }
 
+// racon Overlap::find_breaking_points_from_cigar: for every window of w target bases the first aligned pair
+// (t, q) and one past the last aligned pair, in window order; windows without an aligned pair contribute nothing
+static void BreakingPoints(const std::vector<char>& ops, std::uint32_t q_begin, std::uint32_t t_begin,
+                           std::uint32_t t_end, std::uint32_t w,
+                           std::vector<std::pair<std::uint32_t, std::uint32_t>>* out) {
+  std::vector<std::int64_t> window_ends;
+  for (std::uint32_t i = 0; i < t_end; i += w)
+    if (i > t_begin) window_ends.push_back(static_cast<std::int64_t>(i) - 1);
+  window_ends.push_back(static_cast<std::int64_t>(t_end) - 1);
+  auto& bp = *out;
+  bp.clear();
+  std::size_t wi = 0;
+  bool found_first = false;
+  std::pair<std::uint32_t, std::uint32_t> first_match{0, 0}, last_match{0, 0};
+  std::int64_t q_ptr = static_cast<std::int64_t>(q_begin) - 1, t_ptr = static_cast<std::int64_t>(t_begin) - 1;
+  for (char op : ops) {
+    if (op == 'M') {
+      ++q_ptr; ++t_ptr;
+      if (!found_first) { found_first = true; first_match = {static_cast<std::uint32_t>(t_ptr), static_cast<std::uint32_t>(q_ptr)}; }
+      last_match = {static_cast<std::uint32_t>(t_ptr + 1), static_cast<std::uint32_t>(q_ptr + 1)};
+      if (wi < window_ends.size() && t_ptr == window_ends[wi]) {
+        if (found_first) { bp.push_back(first_match); bp.push_back(last_match); }
+        found_first = false;
+        ++wi;
+      }
+    } else if (op == 'I') {
+      ++q_ptr;
+    } else {
+      ++t_ptr;
+      if (wi < window_ends.size() && t_ptr == window_ends[wi]) {
+        if (found_first) { bp.push_back(first_match); bp.push_back(last_match); }
+        found_first = false;
+        ++wi;
+      }
+    }
+  }
+}
+
 }  // namespace orc
 
-extern "C" int orc_polish_round(const std::uint64_t* t_packed, const std::uint64_t* t_word_off, const std::uint32_t* t_len,
+// query / target: one-byte codes of the two spans; out: (t, q) pairs, two per window that has an aligned pair
+extern "C" std::uint64_t orc_nw_breakpoints(const std::uint8_t* query, std::uint32_t n, const std::uint8_t* target,
+                                            std::uint32_t m, std::uint32_t q_begin, std::uint32_t t_begin,
+                                            std::uint32_t w, std::uint32_t* out, std::uint64_t cap,
+                                            std::uint32_t* distance) {
+  std::vector<std::uint8_t> q(query, query + n), t(target, target + m);
+  std::vector<char> ops;
+  orc::NwPath(q, t, &ops);
+  if (distance) {
+    std::uint32_t d = 0;
+    std::size_t qi = 0, ti = 0;
+    for (char op : ops) {
+      if (op == 'M') { d += q[qi] != t[ti]; ++qi; ++ti; }
+      else if (op == 'I') { ++d; ++qi; }
+      else { ++d; ++ti; }
+    }
+    *distance = d;
+  }
+  std::vector<std::pair<std::uint32_t, std::uint32_t>> bp;
+  orc::BreakingPoints(ops, q_begin, t_begin, t_begin + m, w, &bp);
+  for (std::size_t i = 0; i < bp.size() && 2 * i + 1 < cap; ++i) {
+    out[2 * i] = bp[i].first;
+    out[2 * i + 1] = bp[i].second;
+  }
+  return bp.size();
+}
+
+// one layer of a window as racon would add it: {window, read index, first base in the oriented read, bases, begin,
+// end, reverse-complemented}
+using LayerDump = std::vector<std::array<std::uint32_t, 7>>;
+
+static int PolishRound(const std::uint64_t* t_packed, const std::uint64_t* t_word_off, const std::uint32_t* t_len,
                      const std::uint32_t* t_ids, std::uint32_t n_targets, const std::uint64_t* r_packed,
                      const std::uint64_t* r_word_off, const std::uint32_t* r_len, const std::uint32_t* r_ids,
                      std::uint32_t n_reads, const std::uint8_t* quals, const std::uint64_t* qual_off, double q_thr,
                      double err_thr, std::uint32_t w, int trim, int m, int n, int g, std::uint8_t* out,
-                     const std::uint64_t* out_off, std::uint32_t* out_len, double* ratio) {
+                     const std::uint64_t* out_off, std::uint32_t* out_len, double* ratio, LayerDump* dump) {
   auto targets = MakeReads(t_packed, t_word_off, t_len, t_ids, n_targets);
   auto reads = MakeReads(r_packed, r_word_off, r_len, r_ids, n_reads);
   orc::MinimizerEngine engine(15, 5, 500, 4, 100, 10000);
@@ -931,37 +1001,8 @@ extern "C" int orc_polish_round(const std::uint64_t* t_packed, const std::uint64
     for (std::uint32_t i = 0; i < ts.size(); ++i) ts[i] = targets[t].Code(best.rhs_begin + i);
     std::vector<char> ops;
     orc::NwPath(qs, ts, &ops);
-    // racon Overlap::find_breaking_points_from_cigar
-    std::vector<std::int64_t> window_ends;
-    for (std::uint32_t i = 0; i < best.rhs_end; i += w)
-      if (i > best.rhs_begin) window_ends.push_back(static_cast<std::int64_t>(i) - 1);
-    window_ends.push_back(static_cast<std::int64_t>(best.rhs_end) - 1);
     std::vector<std::pair<std::uint32_t, std::uint32_t>> bp;
-    std::size_t wi = 0;
-    bool found_first = false;
-    std::pair<std::uint32_t, std::uint32_t> first_match{0, 0}, last_match{0, 0};
-    std::int64_t q_ptr = static_cast<std::int64_t>(q_begin) - 1, t_ptr = static_cast<std::int64_t>(best.rhs_begin) - 1;
-    for (char op : ops) {
-      if (op == 'M') {
-        ++q_ptr; ++t_ptr;
-        if (!found_first) { found_first = true; first_match = {static_cast<std::uint32_t>(t_ptr), static_cast<std::uint32_t>(q_ptr)}; }
-        last_match = {static_cast<std::uint32_t>(t_ptr + 1), static_cast<std::uint32_t>(q_ptr + 1)};
-        if (wi < window_ends.size() && t_ptr == window_ends[wi]) {
-          if (found_first) { bp.push_back(first_match); bp.push_back(last_match); }
-          found_first = false;
-          ++wi;
-        }
-      } else if (op == 'I') {
-        ++q_ptr;
-      } else {
-        ++t_ptr;
-        if (wi < window_ends.size() && t_ptr == window_ends[wi]) {
-          if (found_first) { bp.push_back(first_match); bp.push_back(last_match); }
-          found_first = false;
-          ++wi;
-        }
-      }
-    }
+    orc::BreakingPoints(ops, q_begin, best.rhs_begin, best.rhs_end, w, &bp);
     for (std::size_t j = 0; j + 1 < bp.size(); j += 2) {
       if (bp[j + 1].second - bp[j].second < 0.02 * w) continue;
       if (quals) {
@@ -977,8 +1018,19 @@ extern "C" int orc_polish_round(const std::uint64_t* t_packed, const std::uint64
       L.begin = bp[j].first - window_start;
       L.end = bp[j + 1].first - window_start - 1;
       if (L.begin >= L.end) continue;  // racon's AddLayer would reject it
+      if (dump) {
+        const std::uint32_t bl = std::min<std::uint32_t>(w, targets[t].len - window_start);
+        dump->push_back({static_cast<std::uint32_t>(window_id), r, bp[j].second, bp[j + 1].second - bp[j].second, L.begin,
+                         std::min(L.end, bl - 1), rc ? 1u : 0u});
+      }
       win_layers[window_id].push_back(std::move(L));
     }
+  }
+  if (dump) {  // racon: layers of a window in the stable order of their begin position
+    std::stable_sort(dump->begin(), dump->end(), [](const std::array<std::uint32_t, 7>& a, const std::array<std::uint32_t, 7>& b) {
+      return a[0] < b[0] || (a[0] == b[0] && a[4] < b[4]);
+    });
+    return 0;
   }
   for (std::uint32_t t = 0; t < n_targets; ++t) {
     std::vector<std::uint8_t> polished;
@@ -1003,6 +1055,32 @@ extern "C" int orc_polish_round(const std::uint64_t* t_packed, const std::uint64
     ratio[t] = nw ? static_cast<double>(n_pol) / nw : 0.0;
   }
   return 0;
+}
+
+extern "C" int orc_polish_round(const std::uint64_t* t_packed, const std::uint64_t* t_word_off, const std::uint32_t* t_len,
+                     const std::uint32_t* t_ids, std::uint32_t n_targets, const std::uint64_t* r_packed,
+                     const std::uint64_t* r_word_off, const std::uint32_t* r_len, const std::uint32_t* r_ids,
+                     std::uint32_t n_reads, const std::uint8_t* quals, const std::uint64_t* qual_off, double q_thr,
+                     double err_thr, std::uint32_t w, int trim, int m, int n, int g, std::uint8_t* out,
+                     const std::uint64_t* out_off, std::uint32_t* out_len, double* ratio) {
+  return PolishRound(t_packed, t_word_off, t_len, t_ids, n_targets, r_packed, r_word_off, r_len, r_ids, n_reads, quals,
+                     qual_off, q_thr, err_thr, w, trim, m, n, g, out, out_off, out_len, ratio, nullptr);
+}
+
+// The layers racon would hand to its windows (steps 1-4 of the round, no consensus): 7 uint32 per layer, windows in
+// order, layers of a window in the stable order of their begin position.  Returns the number of layers.
+extern "C" std::uint64_t orc_polish_layers(const std::uint64_t* t_packed, const std::uint64_t* t_word_off,
+                                           const std::uint32_t* t_len, const std::uint32_t* t_ids, std::uint32_t n_targets,
+                                           const std::uint64_t* r_packed, const std::uint64_t* r_word_off,
+                                           const std::uint32_t* r_len, const std::uint32_t* r_ids, std::uint32_t n_reads,
+                                           const std::uint8_t* quals, const std::uint64_t* qual_off, double q_thr,
+                                           double err_thr, std::uint32_t w, std::uint32_t* out, std::uint64_t cap) {
+  LayerDump dump;
+  PolishRound(t_packed, t_word_off, t_len, t_ids, n_targets, r_packed, r_word_off, r_len, r_ids, n_reads, quals, qual_off,
+              q_thr, err_thr, w, 0, 3, -5, -4, nullptr, nullptr, nullptr, nullptr, &dump);
+  for (std::uint64_t i = 0; i < dump.size() && i < cap; ++i)
+    for (int x = 0; x < 7; ++x) out[7 * i + x] = dump[i][x];
+  return dump.size();
 }
 
 extern "C" {

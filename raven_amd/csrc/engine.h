@@ -24,8 +24,12 @@ struct ReadsDev {
   DevBuf len;       // u32[n]
   DevBuf id;        // u32[n]
   std::vector<u64> h_word_off;
-  std::vector<u64> h_packed;  // host copy of the packed words (needed by the polishing front end)
   std::vector<u32> h_len, h_id;
+  // qualities attached to the read set (rvn_reads_attach_quality): Phred+33, one byte per 2^qual_shift bases,
+  // read i at qual_off[i]; used by the polishing rounds when the caller passes none
+  DevBuf quals, qual_off;
+  std::vector<u64> h_qual_off;
+  int qual_shift = -1;  // -1: none attached
   bool ids_are_indices = false;  // ids[i] == i and all < 2^31 (needed by the pass-1 merge and the self-join)
   // sketch tiles for the owning engine's (k, w)
   u32 n_tiles = 0;
@@ -115,14 +119,29 @@ struct Engine {
   DevBuf seg_off, iv_slot_begin, iv_slot_end, iv_cnt, iv_off, iv_begin, iv_end;
   DevBuf lis_min, lis_pred, lis_tail, lis_mask, ovl_slots, ovl_flags, ovl_scan;
   DevBuf poa_scratch, poa2_scratch, polish_quals;
+  DevBuf poa_sched, poa_redo_w, poa_redo_i;  // LPT order / escalation lists of a POA batch (poa_run_dev)
+  // alignment-path stage of a polishing round (nwpath.hip): stored band words + scores, jobs, results
+  DevBuf nw_pm, nw_sc, nw_jobs, nw_res;
+  double nw_rate = -1.0;  // running estimate of edit distance / length of the read-to-target alignments (< 0: unknown)
+  // polishing front end (polish.hip): best overlaps, window records, layer tables, consensus
+  DevBuf pl_best, pl_best_t, pl_idmap, pl_recs, pl_keep, pl_win_cnt, pl_win_off, pl_win_fill, pl_win_meta, pl_first_window,
+      pl_keys, pl_lays_tmp, pl_lays, pl_wins, pl_out, pl_len, pl_status, pl_ok, pl_cons_off, pl_final, pl_qual_off, pl_misc;
   std::vector<u32> polish_target_reads;  // reads used per target in the last polishing round
+  // layer table of the last polishing round (still in pl_wins / pl_lays / pl_ok), for rvn_polish_fetch_layers
+  u32 polish_last_windows = 0;
+  u64 polish_last_layers = 0, polish_last_w0 = 0;
+  bool polish_last_has_ok = false;
+  std::vector<u64> polish_last_read_off;
   int poa_mode = 0;  // 0 banded 64 -> 128 -> 256 -> full matrix; 1 full matrix only; 2 / 3 / 4 band 64 / 128 / 256 only (tests)
   u32 poa_fallback_windows = 0;  // windows of the last batch that needed more than the 128-column band
   u32 poa_fullmatrix_windows = 0;  // ... of which re-run by the full-matrix kernel
   u32 poa_wide_windows = 0;      // windows of the last batch re-run with the 128-column band
   DevBuf anc_slot_off, anc_slot_cnt;
   bool keep_anchors = false;  // map_batch also returns the chain anchors of every overlap
-  unsigned long long poa_phase_cycles[6] = {};  // subgraph, dp, traceback, add, order, consensus (last call)
+  unsigned long long poa_phase_cycles[8] = {};  // subgraph, dp, traceback, add, order, consensus (last call); [6], [7]: DP cells
+  // DP cells of the banded POA kernel since the last reset_stats: full-matrix equivalent (graph rows x layer length of
+  // every layer alignment: what spoa computes) / inside the computed band; number of batches
+  u64 poa_cells_full = 0, poa_cells_band = 0, poa_calls = 0;
   StageTimes times;
   KernelTimers ktimers;
   // counters for algorithmic bytes
@@ -168,6 +187,9 @@ struct StageTimer {
 
 // ---- stages (one translation unit each) -------------------------------------
 void reads_build_tiles(Engine& e, ReadsDev& r);
+// 2-bit packing of one-byte codes already in HBM: read i = codes[base_off[i] ..), words at word_off[i] (sketch.hip)
+void pack_codes_on_device(Engine& e, const u8* d_codes, const u64* d_base_off, const u64* d_word_off, u32 n_reads,
+                          u64 n_words, u64* d_packed);
 void sketch_raw(Engine& e, const ReadsDev& r, u32 first, u32 last, Sketch& out);
 void sketch_minhash(Engine& e, const ReadsDev& r, const Sketch& raw, Sketch& out);
 void sketch_range(Engine& e, const ReadsDev& r, u32 first, u32 last, bool minhash, Sketch& out);
@@ -198,10 +220,26 @@ void poa_consensus_batch(Engine& e, const u8* h_codes, const u8* h_quals, const 
 
 struct PolishStats {
   u64 n_overlaps = 0, n_reads_used = 0, n_layers = 0, n_windows = 0, n_polished_windows = 0, n_failed_windows = 0;
-  u64 n_dropped_layers = 0;  // pieces whose length contradicts their target span (misplaced breakpoints)
+  u64 n_dropped_layers = 0;  // reads whose alignment is beyond the path kernel (band threshold > ~32 000): not used
   double poa_ms = 0;                            // device time of the POA batch
-  double map_ms = 0, host_ms = 0, total_ms = 0;  // wall: index + map + read-back | host window/layer building | all
+  double map_ms = 0, host_ms = 0, total_ms = 0;  // wall: index + map | host planning (jobs, window tables) | all
+  double align_ms = 0;                           // device time of the alignment-path stage (forward + traceback)
+  u64 n_aligned = 0, n_align_retries = 0, align_band_cells = 0, align_store_bytes = 0;
 };
+
+// alignment-path stage (nwpath.hip)
+struct NwJob;
+struct NwWindowRec;
+struct NwStats {
+  u64 n_aligned = 0, n_retries = 0, n_unaligned = 0, n_batches = 0;
+  u64 band_cells = 0, sum_distance = 0, store_bytes = 0;
+  double ms = 0;
+};
+void nw_breakpoints(Engine& e, const ReadsDev& T, const ReadsDev& R, std::vector<NwJob>& jobs, u32 w, NwWindowRec* d_recs,
+                    u64 n_recs, NwStats& st);
+// the same code stepped on the CPU (64 emulated lanes): test hook, see rvn_test_nw_breakpoints
+int nw_breakpoints_host(const u64* t_words, u32 t_len, const u64* r_words, u32 r_len, u32 t_begin, u32 n, u32 q_begin, u32 m,
+                        int rc, u32 w, u32 k, int force_R, NwWindowRec* recs, u32* distance, u32* band);
 // One racon polishing round (polish.hip): targets T, reads R, optional per-base Phred+33 qualities of the reads
 void polish_round(Engine& e, ReadsDev& T, ReadsDev& R, const u8* h_quals, const u64* h_qual_off, double q_thr,
                   double err_thr, u32 w, bool trim, int m, int n, int g, std::vector<std::vector<u8>>& polished,

@@ -7,7 +7,8 @@
 
 #include "../../include/raven_hip.h"
 #include "introsort.h"
-#include "polish_cut.h"
+#include "nwpath.h"
+#include "poa.h"
 #include "kmer.h"
 #include "lowcomplexity.h"
 
@@ -231,8 +232,6 @@ int rvn_reads_upload(rvn_engine* h, const uint64_t* packed, uint64_t n_words, co
         return fail(RVN_EINVAL, "[raven_hip] rvn_reads_upload: word_offsets inconsistent with lengths");
     }
     r.n_words = n_words;
-    r.h_packed.assign(packed, packed + n_words);
-    r.h_packed.push_back(0);
     u64* d_packed = r.packed.get<u64>(n_words + 2);
     if (n_words) RVN_HIP(hipMemcpy(d_packed, packed, n_words * 8, hipMemcpyHostToDevice));
     RVN_HIP(hipMemset(d_packed + n_words, 0, 16));  // pad words: kernels may read one word past a read
@@ -251,6 +250,89 @@ int rvn_reads_upload(rvn_engine* h, const uint64_t* packed, uint64_t n_words, co
 }
 
 void rvn_reads_destroy(rvn_reads* r) { delete r; }
+
+int rvn_reads_upload_codes(rvn_engine* h, const uint8_t* codes, const uint64_t* offsets, const uint32_t* ids, uint32_t n,
+                           rvn_reads** out) {
+  return guarded(h ? &h->e : nullptr, [&]() -> int {
+    if (!h || !out || (n && (!codes || !offsets))) return fail(RVN_EINVAL, "[raven_hip] rvn_reads_upload_codes: NULL argument");
+    Engine& e = h->e;
+    RVN_HIP(hipSetDevice(e.device));
+    std::vector<u64> woff(static_cast<size_t>(n) + 1, 0);
+    std::vector<u32> lens(n);
+    for (u32 i = 0; i < n; ++i) {
+      if (offsets[i + 1] < offsets[i] || offsets[i + 1] - offsets[i] > 0xFFFFFFFFULL)
+        return fail(RVN_EINVAL, "[raven_hip] rvn_reads_upload_codes: bad offsets");
+      lens[i] = static_cast<u32>(offsets[i + 1] - offsets[i]);
+      woff[i + 1] = woff[i] + (static_cast<u64>(lens[i]) + 31) / 32;
+    }
+    const u64 n_words = woff[n], n_codes = n ? offsets[n] - offsets[0] : 0;
+    // bases to HBM as bytes, packed there (one thread per word)
+    u8* d_codes = e.tmp_a.get<u8>(n_codes + 16);
+    u64* d_boff = e.tmp_b.get<u64>(static_cast<size_t>(n) + 1);
+    u64* d_woff = e.tmp_c.get<u64>(static_cast<size_t>(n) + 1);
+    if (n_codes) RVN_HIP(hipMemcpy(d_codes, codes + (n ? offsets[0] : 0), n_codes, hipMemcpyHostToDevice));
+    std::vector<u64> boff(static_cast<size_t>(n) + 1);
+    for (u32 i = 0; i <= n; ++i) boff[i] = offsets[i] - offsets[0];
+    RVN_HIP(hipMemcpy(d_boff, boff.data(), boff.size() * 8, hipMemcpyHostToDevice));
+    RVN_HIP(hipMemcpy(d_woff, woff.data(), woff.size() * 8, hipMemcpyHostToDevice));
+    std::unique_ptr<rvn_reads> rr(new rvn_reads());
+    ReadsDev& r = rr->r;
+    u64* d_packed = r.packed.get<u64>(n_words + 2);
+    pack_codes_on_device(e, d_codes, d_boff, d_woff, n, n_words, d_packed);
+    RVN_HIP(hipMemsetAsync(d_packed + n_words, 0, 16, e.stream));
+    RVN_HIP(hipStreamSynchronize(e.stream));
+    r.n = n;
+    r.h_word_off = woff;
+    r.h_len = lens;
+    r.h_id.resize(n);
+    r.ids_are_indices = true;
+    r.total_bases = n_codes;
+    for (u32 i = 0; i < n; ++i) {
+      r.h_id[i] = ids ? ids[i] : i;
+      if (r.h_id[i] != i || i >= (1u << 31)) r.ids_are_indices = false;
+      if (r.h_id[i] >= (1u << 31)) return fail(RVN_EINVAL, "[raven_hip] read ids must be below 2^31");
+    }
+    r.n_words = n_words;
+    u64* d_wo = r.word_off.get<u64>(static_cast<size_t>(n) + 1);
+    RVN_HIP(hipMemcpy(d_wo, r.h_word_off.data(), (static_cast<size_t>(n) + 1) * 8, hipMemcpyHostToDevice));
+    u32* d_len = r.len.get<u32>(static_cast<size_t>(n) + 1);
+    u32* d_id = r.id.get<u32>(static_cast<size_t>(n) + 1);
+    if (n) {
+      RVN_HIP(hipMemcpy(d_len, r.h_len.data(), static_cast<size_t>(n) * 4, hipMemcpyHostToDevice));
+      RVN_HIP(hipMemcpy(d_id, r.h_id.data(), static_cast<size_t>(n) * 4, hipMemcpyHostToDevice));
+    }
+    reads_build_tiles(e, r);
+    *out = rr.release();
+    return RVN_OK;
+  });
+}
+
+int rvn_reads_attach_quality(rvn_engine* h, rvn_reads* rr, const uint8_t* quals, const uint64_t* offsets, int block_shift) {
+  return guarded(h ? &h->e : nullptr, [&]() -> int {
+    if (!h || !rr) return fail(RVN_EINVAL, "[raven_hip] rvn_reads_attach_quality: NULL argument");
+    ReadsDev& r = rr->r;
+    if (!quals) {  // detach
+      r.qual_shift = -1;
+      return RVN_OK;
+    }
+    if (!offsets || (block_shift != 0 && block_shift != 6))
+      return fail(RVN_EINVAL, "[raven_hip] rvn_reads_attach_quality: offsets missing or block_shift not 0 / 6");
+    for (u32 i = 0; i < r.n; ++i) {
+      const u64 need = (static_cast<u64>(r.h_len[i]) + (1u << block_shift) - 1) >> block_shift;
+      if (offsets[i + 1] < offsets[i] || offsets[i + 1] - offsets[i] < need)
+        return fail(RVN_EINVAL, "[raven_hip] rvn_reads_attach_quality: offsets inconsistent with the read lengths");
+    }
+    RVN_HIP(hipSetDevice(h->e.device));
+    const u64 total = offsets[r.n];
+    u8* dq = r.quals.get<u8>(total + 16);
+    u64* dqo = r.qual_off.get<u64>(static_cast<size_t>(r.n) + 1);
+    if (total) RVN_HIP(hipMemcpy(dq, quals, total, hipMemcpyHostToDevice));
+    RVN_HIP(hipMemcpy(dqo, offsets, (static_cast<size_t>(r.n) + 1) * 8, hipMemcpyHostToDevice));
+    r.h_qual_off.assign(offsets, offsets + r.n + 1);
+    r.qual_shift = block_shift;
+    return RVN_OK;
+  });
+}
 
 int rvn_engine_minimize(rvn_engine* h, const rvn_reads* r, uint32_t first, uint32_t last, int minhash) {
   return guarded(h ? &h->e : nullptr, [&]() -> int {
@@ -576,6 +658,11 @@ int rvn_polish_round_range(rvn_engine* h, rvn_reads* targets, rvn_reads* reads, 
       stats->host_ms = st.host_ms;
       stats->total_ms = st.total_ms;
       stats->n_dropped_layers = st.n_dropped_layers;
+      stats->align_ms = st.align_ms;
+      stats->n_aligned = st.n_aligned;
+      stats->n_align_retries = st.n_align_retries;
+      stats->align_band_cells = st.align_band_cells;
+      stats->align_store_bytes = st.align_store_bytes;
     }
     return RVN_OK;
   });
@@ -1177,6 +1264,14 @@ void rvn_engine_reset_stats(rvn_engine* h) {
   e.ktimers.reset();
   e.c_index_bases = e.c_index_min = e.c_index_keys = e.c_query_bases = e.c_query_min = e.c_matches = e.c_overlaps =
       e.c_intervals = 0;
+  e.poa_cells_full = e.poa_cells_band = e.poa_calls = 0;
+}
+
+void rvn_poa_work(const rvn_engine* h, uint64_t out[3]) {
+  if (!h || !out) return;
+  out[0] = h->e.poa_cells_full;
+  out[1] = h->e.poa_cells_band;
+  out[2] = h->e.poa_calls;
 }
 
 void rvn_engine_set_timing(rvn_engine* h, int enabled) {
@@ -1230,21 +1325,53 @@ int rvn_test_canonical(const uint64_t* words, uint32_t pos, uint32_t k, int use3
   return ok ? 1 : 0;
 }
 
-int rvn_test_window_cut(const uint8_t* target, uint32_t tlen, const uint8_t* read, uint32_t qlen,
-                        const uint32_t* anchor_t, const uint32_t* anchor_q, uint32_t n_anchors, uint32_t k, uint32_t boundary,
-                        uint32_t out[4]) {
-  if (!target || !read || !anchor_t || !anchor_q || !out || n_anchors < 2) return RVN_EINVAL;
-  std::vector<std::pair<u32, u32>> an(n_anchors);
-  for (u32 i = 0; i < n_anchors; ++i) an[i] = {anchor_t[i], anchor_q[i]};
-  if (boundary < an.front().first || boundary >= an.back().first + k) return RVN_EINVAL;
-  CutScratch sc;
-  const WindowCut c = window_cut(an, k, boundary, tlen, qlen, [&](u32 x) -> u32 { return target[x] & 3u; },
-                                 [&](u32 x) -> u32 { return read[x] & 3u; }, sc);
-  out[0] = c.ql;
-  out[1] = c.tl;
-  out[2] = c.qr;
-  out[3] = c.tr;
-  return static_cast<int>(sc.n_nw);
+int rvn_polish_fetch_layers(rvn_engine* h, uint32_t* out, uint64_t cap, uint64_t* n_out) {
+  return guarded(h ? &h->e : nullptr, [&]() -> int {
+    if (!h || !n_out) return fail(RVN_EINVAL, "[raven_hip] rvn_polish_fetch_layers: NULL argument");
+    Engine& e = h->e;
+    RVN_HIP(hipSetDevice(e.device));
+    const u32 nw = e.polish_last_windows;
+    const u64 nl = e.polish_last_layers;
+    std::vector<PoaWindow> wins(nw);
+    std::vector<PoaLayer> lays(nl);
+    std::vector<u8> ok(nl, 1);
+    if (nw) RVN_HIP(hipMemcpy(wins.data(), e.pl_wins.ptr, nw * sizeof(PoaWindow), hipMemcpyDeviceToHost));
+    if (nl) RVN_HIP(hipMemcpy(lays.data(), e.pl_lays.ptr, nl * sizeof(PoaLayer), hipMemcpyDeviceToHost));
+    if (nl && e.polish_last_has_ok) RVN_HIP(hipMemcpy(ok.data(), e.pl_ok.ptr, nl, hipMemcpyDeviceToHost));
+    const std::vector<u64>& ro = e.polish_last_read_off;
+    u64 n = 0;
+    for (u32 i = 0; i < nw; ++i) {
+      for (u32 x = 1; x < wins[i].n_layers; ++x) {  // layer 0 = backbone
+        const u64 li = static_cast<u64>(wins[i].layer_first) + x;
+        if (!ok[li]) continue;
+        const PoaLayer& L = lays[li];
+        if (out && n < cap) {
+          const u64 read = static_cast<u64>(std::upper_bound(ro.begin(), ro.end(), L.code_off) - ro.begin()) - 1;
+          uint32_t* o = out + 7 * n;
+          o[0] = static_cast<uint32_t>(e.polish_last_w0 + i);
+          o[1] = static_cast<uint32_t>(read);
+          o[2] = L.q_begin;
+          o[3] = L.len;
+          o[4] = L.begin;
+          o[5] = L.end;
+          o[6] = (L.flags & kLayerRc) ? 1u : 0u;
+        }
+        ++n;
+      }
+    }
+    *n_out = n;
+    return RVN_OK;
+  });
+}
+
+int rvn_test_nw_breakpoints(const uint64_t* t_words, uint32_t t_len, const uint64_t* r_words, uint32_t r_len,
+                            uint32_t t_begin, uint32_t n, uint32_t q_begin, uint32_t m, int rc, uint32_t w, uint32_t k,
+                            int force_r, uint32_t* recs, uint32_t* distance, uint32_t* band) {
+  if (!t_words || !r_words || !recs || !distance || w == 0) return RVN_EINVAL;
+  if (static_cast<u64>(t_begin) + n > t_len || static_cast<u64>(q_begin) + m > r_len) return RVN_EINVAL;
+  static_assert(sizeof(NwWindowRec) == 32, "record layout");
+  return nw_breakpoints_host(t_words, t_len, r_words, r_len, t_begin, n, q_begin, m, rc, w, k, force_r,
+                             reinterpret_cast<NwWindowRec*>(recs), distance, band);
 }
 
 int rvn_test_low_complexity(const uint8_t* codes, uint32_t k) { return lc_kmer_passes(codes, k) ? 1 : 0; }

@@ -58,7 +58,8 @@ struct PoaSrc {
   const u8* quals;
   const u64* packed_reads;
   const u64* packed_targets;
-  const u8* read_quals;    // per-base Phred+33 of the packed reads (nullable)
+  const u8* read_quals;    // Phred+33 of the packed reads, one byte per 2^qual_shift bases (nullable)
+  u32 qual_shift;          // 0: per base; 6: biosoup's block qualities (mean of 64 bases)
   const u8* layer_ok;      // per layer: 0 = dropped by the mean-quality filter (nullable = all kept)
 };
 
@@ -78,7 +79,8 @@ __device__ __forceinline__ u32 poa_layer_code(const PoaSrc& src, const PoaLayer&
 __device__ __forceinline__ i32 poa_layer_weight(const PoaSrc& src, const PoaLayer& L, u32 i) {
   if (L.flags & kLayerZeroW) return 0;
   if (!(L.flags & kLayerQual)) return 1;
-  if (L.flags & kLayerPacked) return static_cast<i32>(src.read_quals[L.qual_off + poa_layer_src_pos(L, i)]) - 33;
+  if (L.flags & kLayerPacked)
+    return static_cast<i32>(src.read_quals[L.qual_off + (poa_layer_src_pos(L, i) >> src.qual_shift)]) - 33;
   return static_cast<i32>(src.quals[L.qual_off + i]) - 33;
 }
 
@@ -107,6 +109,10 @@ void poa_v1_launch(Engine& e, const PoaBatchDev& b);  // poa.hip
 void poa_run(Engine& e, const std::vector<PoaWindow>& wins, const std::vector<PoaLayer>& lays, const PoaSrc& src,
              u32 max_bb, u32 max_len, int m, int n, int g, int trim, u8* h_out, u64 out_total, u32* h_out_len,
              u32* h_status, double* device_ms, bool allow_full = true);  // allow_full: escalate to the full-matrix kernel
+// the same with windows, layers and outputs resident in HBM (polish.hip); h_status receives the per-window status
+void poa_run_dev(Engine& e, const PoaWindow* d_wins, const PoaLayer* d_lays, u32 n_windows, const PoaSrc& src, u32 max_bb,
+                 u32 max_len, int m, int n, int g, int trim, u8* d_out, u32* d_len, u32* d_status,
+                 std::vector<u32>& h_status, double* device_ms, bool allow_full = true);
 void poa_v2_launch(Engine& e, const PoaBatchDev& b, int nch);  // poa2.hip: band = 64 * nch columns
 
 // Persistent waves take windows from a shared counter (longest-processing-time-first order when `sched` is given).

@@ -611,15 +611,42 @@ void poa_v1_launch(Engine& e, const PoaBatchDev& b) {
                                                                     b.phase_cycles, b.sched, b.next));
 }
 
-// Core of a batch: windows + (begin-sorted) layer descriptors are on the host, every base/quality source named by
-// `src` is already in HBM.  Every window first goes through the banded LDS kernel (poa2.hip) with a 64-column band;
-// windows whose alignment touches the band edge are repeated with 128 columns, and what is left (or beyond a
-// limit) is re-run by the full-matrix kernel above, so a status >= 2 in the result means the window is beyond ALL
-// of them.
-void poa_run(Engine& e, const std::vector<PoaWindow>& wins, const std::vector<PoaLayer>& lays, const PoaSrc& src,
-             u32 max_bb, u32 max_len, int m, int n, int g, int trim, u8* h_out, u64 out_total, u32* h_out_len,
-             u32* h_status, double* device_ms, bool allow_full) {
-  const u32 n_windows = static_cast<u32>(wins.size());
+namespace {
+
+// LPT order of the persistent waves: windows by decreasing number of layers (stable), built on the device
+__global__ void poa_sched_keys_kernel(const PoaWindow* __restrict__ wins, u32 n, u32* __restrict__ keys, u32* __restrict__ vals) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const u32 nl = wins[i].n_layers;
+  keys[i] = 0xFFFFu - (nl < 0xFFFFu ? nl : 0xFFFFu);
+  vals[i] = i;
+}
+__global__ void poa_gather_windows_kernel(const PoaWindow* __restrict__ wins, const u32* __restrict__ idx, u32 n,
+                                          PoaWindow* __restrict__ out) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = wins[idx[i]];
+}
+__global__ void poa_scatter_results_kernel(const u32* __restrict__ idx, u32 n, const u32* __restrict__ rlen,
+                                           const u32* __restrict__ rstatus, u32* __restrict__ len, u32* __restrict__ status) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    len[idx[i]] = rlen[i];
+    status[idx[i]] = rstatus[i];
+  }
+}
+
+}  // namespace
+
+// Core of a batch, everything resident in HBM: windows, (begin-sorted) layer descriptors, every base / quality source
+// named by `src`, and the outputs (consensus bytes at each window's out_off, d_len / d_status per window).  Every
+// window first goes through the banded LDS kernel (poa2.hip) with a 64-column band; windows whose alignment touches
+// the band edge are repeated with 128 and then 256 columns, and what is left (or beyond a limit) is re-run by the
+// full-matrix kernel above, so a status >= 2 in the result means the window is beyond ALL of them.  Only the
+// per-window status words cross PCIe (the escalation lists are decided on the host); h_status receives them.
+void poa_run_dev(Engine& e, const PoaWindow* d_wins, const PoaLayer* d_lays, u32 n_windows, const PoaSrc& src, u32 max_bb,
+                 u32 max_len, int m, int n, int g, int trim, u8* d_out, u32* d_len, u32* d_status,
+                 std::vector<u32>& h_status, double* device_ms, bool allow_full) {
+  h_status.assign(n_windows, 0);
   if (n_windows == 0) return;
   hipStream_t s = e.stream;
   // limits: nodes <= nmax, layer length <= lmax (windows beyond them come back with status 2 / 4)
@@ -632,23 +659,19 @@ void poa_run(Engine& e, const std::vector<PoaWindow>& wins, const std::vector<Po
   b.trim = trim;
   b.n_windows = n_windows;
   b.src = src;
-  PoaWindow* d_wins = e.tmp_c.get<PoaWindow>(2 * static_cast<size_t>(n_windows) + 2);
-  PoaLayer* d_lays = e.tmp_d.get<PoaLayer>(lays.size() + 1);
-  u8* d_out = e.tmp_e.get<u8>(out_total + 16);
-  u32* d_len = e.tmp_f.get<u32>(4 * static_cast<size_t>(n_windows) + 4);
-  u32* d_status = d_len + n_windows + 1;
   unsigned long long* d_phase = e.q_start.get<unsigned long long>(10);
   RVN_HIP(hipMemsetAsync(d_phase, 0, 80, s));
   // heaviest windows first: cost ~ number of layers
-  std::vector<u32> sched(n_windows);
-  for (u32 i = 0; i < n_windows; ++i) sched[i] = i;
-  std::stable_sort(sched.begin(), sched.end(), [&](u32 a, u32 c) { return wins[a].n_layers > wins[c].n_layers; });
-  u32* d_sched = e.q_cnt.get<u32>(n_windows + 1);
-  RVN_HIP(hipMemcpyAsync(d_sched, sched.data(), sched.size() * 4, hipMemcpyHostToDevice, s));
-  b.sched = d_sched;
+  u32* d_sk = e.poa_sched.get<u32>(4 * static_cast<size_t>(n_windows) + 8);
+  u32* d_sk1 = d_sk + n_windows + 1;
+  u32* d_sv = d_sk1 + n_windows + 1;
+  u32* d_sv1 = d_sv + n_windows + 1;
+  poa_sched_keys_kernel<<<div_up(n_windows, 256), 256, 0, s>>>(d_wins, n_windows, d_sk, d_sv);
+  RVN_LAUNCH_CHECK();
+  const int which = radix_sort_pairs_u32_u32(d_sk, d_sk1, d_sv, d_sv1, n_windows, 16, e.sort_tmp, e.scan_tmp, s,
+                                             kKPileSortUp, kKPileSortDown, false);
+  b.sched = which ? d_sv1 : d_sv;
   b.next = reinterpret_cast<u32*>(d_phase + 8);
-  RVN_HIP(hipMemcpyAsync(d_wins, wins.data(), wins.size() * sizeof(PoaWindow), hipMemcpyHostToDevice, s));
-  RVN_HIP(hipMemcpyAsync(d_lays, lays.data(), lays.size() * sizeof(PoaLayer), hipMemcpyHostToDevice, s));
   b.wins = d_wins;
   b.layers = d_lays;
   b.out = d_out;
@@ -658,38 +681,37 @@ void poa_run(Engine& e, const std::vector<PoaWindow>& wins, const std::vector<Po
   RVN_HIP(hipEventRecord(e.ev0, s));
   if (e.poa_mode == 1) poa_v1_launch(e, b);
   else poa_v2_launch(e, b, e.poa_mode == 3 ? 2 : (e.poa_mode == 4 ? 4 : 1));
-  RVN_HIP(hipMemcpyAsync(h_out_len, d_len, static_cast<size_t>(n_windows) * 4, hipMemcpyDeviceToHost, s));
-  RVN_HIP(hipMemcpyAsync(h_status, d_status, static_cast<size_t>(n_windows) * 4, hipMemcpyDeviceToHost, s));
+  RVN_HIP(hipMemcpyAsync(h_status.data(), d_status, static_cast<size_t>(n_windows) * 4, hipMemcpyDeviceToHost, s));
   RVN_HIP(hipStreamSynchronize(s));
   e.poa_fallback_windows = 0;
   e.poa_wide_windows = 0;
   e.poa_fullmatrix_windows = 0;
   if (e.poa_mode == 0) {
-    // escalate what the 64-column band could not do: band hits -> 128-column band -> full matrix; windows beyond a
-    // limit (nodes / in-degree / length) -> full matrix directly
-    PoaWindow* d_rw = d_wins + n_windows + 1;
-    u32* d_rlen = d_status + n_windows + 1;
-    auto rerun = [&](const std::vector<u32>& redo, int which) {
-      std::vector<PoaWindow> rw(redo.size());
-      for (size_t i = 0; i < redo.size(); ++i) rw[i] = wins[redo[i]];
-      u32* d_rstatus = d_rlen + redo.size() + 1;
-      RVN_HIP(hipMemcpyAsync(d_rw, rw.data(), rw.size() * sizeof(PoaWindow), hipMemcpyHostToDevice, s));
+    // escalate what the 64-column band could not do: band hits -> 128-column band -> 256 -> full matrix; windows
+    // beyond a limit (nodes / in-degree / length) -> full matrix directly
+    auto rerun = [&](const std::vector<u32>& redo, int which_kernel) {
+      const u32 nr = static_cast<u32>(redo.size());
+      PoaWindow* d_rw = e.poa_redo_w.get<PoaWindow>(nr + 1);
+      u32* d_ridx = e.poa_redo_i.get<u32>(3 * static_cast<size_t>(nr) + 4);
+      u32* d_rlen = d_ridx + nr + 1;
+      u32* d_rstatus = d_rlen + nr + 1;
+      RVN_HIP(hipMemcpyAsync(d_ridx, redo.data(), nr * 4, hipMemcpyHostToDevice, s));
+      poa_gather_windows_kernel<<<div_up(nr, 256), 256, 0, s>>>(d_wins, d_ridx, nr, d_rw);
+      RVN_LAUNCH_CHECK();
       PoaBatchDev rb = b;
       rb.wins = d_rw;
-      rb.n_windows = static_cast<u32>(redo.size());
+      rb.n_windows = nr;
       rb.out_len = d_rlen;
       rb.status = d_rstatus;
       rb.sched = nullptr;
-      if (which == 2 || which == 4) poa_v2_launch(e, rb, which);
+      if (which_kernel == 2 || which_kernel == 4) poa_v2_launch(e, rb, which_kernel);
       else poa_v1_launch(e, rb);
-      std::vector<u32> rl(redo.size()), rs(redo.size());
-      RVN_HIP(hipMemcpyAsync(rl.data(), d_rlen, rl.size() * 4, hipMemcpyDeviceToHost, s));
+      poa_scatter_results_kernel<<<div_up(nr, 256), 256, 0, s>>>(d_ridx, nr, d_rlen, d_rstatus, d_len, d_status);
+      RVN_LAUNCH_CHECK();
+      std::vector<u32> rs(nr);
       RVN_HIP(hipMemcpyAsync(rs.data(), d_rstatus, rs.size() * 4, hipMemcpyDeviceToHost, s));
       RVN_HIP(hipStreamSynchronize(s));
-      for (size_t i = 0; i < redo.size(); ++i) {
-        h_out_len[redo[i]] = rl[i];
-        h_status[redo[i]] = rs[i];
-      }
+      for (u32 i = 0; i < nr; ++i) h_status[redo[i]] = rs[i];
     };
     std::vector<u32> wide, wider, fullm;
     for (u32 w = 0; w < n_windows; ++w) {
@@ -698,11 +720,8 @@ void poa_run(Engine& e, const std::vector<PoaWindow>& wins, const std::vector<Po
       else if (st >= 2) fullm.push_back(w);
     }
     if (std::getenv("RVN_POA_DEBUG")) {
-      for (u32 w : wide) {
-        const PoaLayer& L = lays[wins[w].layer_first + (h_status[w] >> 8)];
-        std::fprintf(stderr, "[raven_hip] poa: window %u band hit at layer %u of %u (len %u begin %u end %u, backbone %u)\n",
-                     w, h_status[w] >> 8, wins[w].n_layers, L.len, L.begin, L.end, lays[wins[w].layer_first].len);
-      }
+      for (u32 w : wide)
+        std::fprintf(stderr, "[raven_hip] poa: window %u band hit at layer %u\n", w, h_status[w] >> 8);
       for (u32 w : fullm) std::fprintf(stderr, "[raven_hip] poa: window %u status %u -> full matrix\n", w, h_status[w]);
     }
     if (!wide.empty()) {  // 128 columns
@@ -728,14 +747,40 @@ void poa_run(Engine& e, const std::vector<PoaWindow>& wins, const std::vector<Po
     }
   }
   RVN_HIP(hipEventRecord(e.ev1, s));
-  RVN_HIP(hipMemcpyAsync(h_out, d_out, out_total, hipMemcpyDeviceToHost, s));
-  RVN_HIP(hipMemcpyAsync(e.poa_phase_cycles, d_phase, 48, hipMemcpyDeviceToHost, s));
+  RVN_HIP(hipMemcpyAsync(e.poa_phase_cycles, d_phase, 64, hipMemcpyDeviceToHost, s));
   RVN_HIP(hipStreamSynchronize(s));
+  e.poa_cells_full += e.poa_phase_cycles[6];
+  e.poa_cells_band += e.poa_phase_cycles[7];
+  e.poa_calls += 1;
   if (device_ms) {
     float ms = 0;
     RVN_HIP(hipEventElapsedTime(&ms, e.ev0, e.ev1));
     *device_ms = ms;
   }
+}
+
+// Same batch with the windows / layer descriptors and the results on the host (rvn_poa_consensus_batch).
+void poa_run(Engine& e, const std::vector<PoaWindow>& wins, const std::vector<PoaLayer>& lays, const PoaSrc& src,
+             u32 max_bb, u32 max_len, int m, int n, int g, int trim, u8* h_out, u64 out_total, u32* h_out_len,
+             u32* h_status, double* device_ms, bool allow_full) {
+  const u32 n_windows = static_cast<u32>(wins.size());
+  if (n_windows == 0) return;
+  hipStream_t s = e.stream;
+  PoaWindow* d_wins = e.tmp_c.get<PoaWindow>(static_cast<size_t>(n_windows) + 2);
+  PoaLayer* d_lays = e.tmp_d.get<PoaLayer>(lays.size() + 1);
+  u8* d_out = e.tmp_e.get<u8>(out_total + 16);
+  u32* d_len = e.tmp_f.get<u32>(2 * static_cast<size_t>(n_windows) + 4);
+  u32* d_status = d_len + n_windows + 1;
+  RVN_HIP(hipMemcpyAsync(d_wins, wins.data(), wins.size() * sizeof(PoaWindow), hipMemcpyHostToDevice, s));
+  RVN_HIP(hipMemcpyAsync(d_lays, lays.data(), lays.size() * sizeof(PoaLayer), hipMemcpyHostToDevice, s));
+  RVN_HIP(hipMemsetAsync(d_len, 0, static_cast<size_t>(n_windows) * 4, s));
+  std::vector<u32> st;
+  poa_run_dev(e, d_wins, d_lays, n_windows, src, max_bb, max_len, m, n, g, trim, d_out, d_len, d_status, st, device_ms,
+              allow_full);
+  RVN_HIP(hipMemcpyAsync(h_out_len, d_len, static_cast<size_t>(n_windows) * 4, hipMemcpyDeviceToHost, s));
+  RVN_HIP(hipMemcpyAsync(h_out, d_out, out_total, hipMemcpyDeviceToHost, s));
+  RVN_HIP(hipStreamSynchronize(s));
+  for (u32 w = 0; w < n_windows; ++w) h_status[w] = st[w];
 }
 
 // Host entry: see rvn_poa_consensus_batch in raven_hip.h (caller-built windows: one-byte codes on the host).

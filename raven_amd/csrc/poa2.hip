@@ -186,6 +186,7 @@ __device__ __forceinline__ u32 poa2_window(const PoaWindow& win, const PoaLayer*
   constexpr int kRingStride = kBand + 2;
   const int lane = lane_id();
   unsigned long long t_sub = 0, t_dp = 0, t_tb = 0, t_add = 0, t_ord = 0, t_cons = 0, t0 = 0;
+  unsigned long long c_full = 0, c_band = 0;  // DP cells: full-matrix equivalent / inside the computed band
   auto tick = [&]() { t0 = __builtin_readcyclecounter(); };
   auto tock = [&](unsigned long long& acc) { acc += __builtin_readcyclecounter() - t0; };
   const PoaLayer bb = layers[win.layer_first];
@@ -303,6 +304,11 @@ __device__ __forceinline__ u32 poa2_window(const PoaWindow& win, const PoaLayer*
       // for the rows' own stores (loads and stores share the vector memory counter)
       asm volatile("" ::"v"(m_v), "v"(m_np), "v"(m_p01), "v"(m_p23), "v"(m_code), "v"(m_outc), "v"(m_marked), "v"(m_b));
       const u32 rows_here = n_nodes - r0 < 64 ? n_nodes - r0 : 64;
+      {  // work counters: rows of this layer's (sub)graph x layer length = the cells spoa's full NW computes
+        const u32 marked_rows = static_cast<u32>(__popcll(__ballot(m_marked != 0)));
+        c_full += static_cast<unsigned long long>(marked_rows) * len;
+        c_band += static_cast<unsigned long long>(marked_rows) * (w < static_cast<u32>(kBand) ? w : static_cast<u32>(kBand));
+      }
       for (u32 ri = 0; ri < rows_here; ++ri) {
         if (!rl(m_marked, static_cast<int>(ri))) continue;
         const u32 row = static_cast<u32>(rfl(static_cast<int>(r0 + ri + 1)));  // uniform: keeps the row addressing scalar
@@ -684,6 +690,8 @@ __device__ __forceinline__ u32 poa2_window(const PoaWindow& win, const PoaLayer*
     atomicAdd(&phase_cycles[3], t_add);
     atomicAdd(&phase_cycles[4], t_ord);
     atomicAdd(&phase_cycles[5], t_cons);
+    atomicAdd(&phase_cycles[6], c_full);
+    atomicAdd(&phase_cycles[7], c_band);
   }
   return 1;
 }

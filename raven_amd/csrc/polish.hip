@@ -1,42 +1,36 @@
 // polish.hip — one racon polishing round on the device (racon::Polisher::Polish as driven by raven::Polish,
-// RavenLib/src/polish.cc:43-51 with e = 0.3, w = 500, trim = true, AlignCfg m/n/g):
-//   1. index the targets (unitigs), Filter(0.001), Map every read (avoid_equal = avoid_symmetric = false) — the
-//      same device engine as the overlap phase, with the chain ANCHORS of every overlap kept;
-//   2. keep each read's longest overlap, drop it when 1 - min(span)/max(span) > e;
-//   3. cut the read into window layers.  racon takes the breakpoints from an edlib NW path of the whole overlap
-//      (CIGAR); here they come from the chain anchors: a window boundary inside an anchor's k-mer, or inside the
-//      exact-match extension of the two anchors around it, is cut exactly; otherwise a small unit-cost NW of the
-//      unmatched remainder of that one anchor gap (a few bases to a few hundred) decides, and pieces begin / end on
-//      aligned pairs exactly as racon's find_breaking_points does.  No base-level alignment of whole reads is
-//      needed.  Layers shorter than 0.02 w, or (with qualities) below the mean-quality threshold q, are dropped
-//      exactly as in racon;
-//   4. window consensus = the POA kernel (poa.hip); 5. stitch the windows, polished ratio per target.
-// Step 3 differs from racon only in which optimal alignment decides a cut when several exist; the consensus is
-// compared with the CPU restatement of racon's own pipeline (identical or within a few edits).
+// RavenLib/src/polish.cc:43-51 with e = 0.3, w = 500, trim = true, AlignCfg m/n/g), racon's own pipeline stage by stage:
+//   1. index the targets (unitigs) with ram(15, 5), Filter(0.001), Map every read (avoid_equal = avoid_symmetric =
+//      false) in windows of 2^30 read bases; per read keep the longest overlap, drop it when
+//      1 - min(span)/max(span) > e                                                     [map.hip + best_overlap_kernel]
+//   2. global alignment PATH of every kept read against its target span (edlib NW, EDLIB_TASK_PATH in racon) and the
+//      breakpoints at every multiple of w on the target: first / last aligned pair per window
+//      (racon find_breaking_points_from_cigar)                                                          [nwpath.hip]
+//   3. window layers: a piece is used if it has >= 0.02 w bases, begin < end, and (with qualities) a mean Phred >= q;
+//      layers of a window in the stable order of their begin position; the backbone carries racon's dummy '!' quality
+//      (weight 0).  Layers are descriptors into the packed read sets already in HBM       [layer_* kernels below]
+//   4. window consensus = the POA kernels (poa2.hip / poa.hip)
+//   5. stitch the windows of each target, polished ratio per target                              [stitch_kernel]
+// Everything between the mapping and the final consensus bytes stays in HBM; the host plans the alignment batches
+// from one 36-byte record per read and reads back per-window status words.
 #include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
-#include <exception>
-#include <thread>
 #include <vector>
 
+#include "nwpath.h"
 #include "poa.h"
-#include "polish_cut.h"
 
 namespace rvn {
 
 namespace {
 
-inline u32 code_at(const std::vector<u64>& packed, u64 word_off, u32 i) {
-  return static_cast<u32>(packed[word_off + (i >> 5)] >> ((i << 1) & 63)) & 3u;
-}
-
 // racon: a layer is used only if the mean Phred of its bases reaches q.  One wave per layer.
 __global__ __launch_bounds__(256) void layer_quality_kernel(const PoaLayer* __restrict__ layers, u32 n_layers,
-                                                           const u8* __restrict__ read_quals, double q_thr,
-                                                           u8* __restrict__ ok) {
+                                                           const u8* __restrict__ read_quals, u32 qual_shift,
+                                                           double q_thr, u8* __restrict__ ok) {
   const u32 li = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (li >= n_layers) return;
   const PoaLayer L = layers[li];
@@ -46,17 +40,200 @@ __global__ __launch_bounds__(256) void layer_quality_kernel(const PoaLayer* __re
     return;
   }
   u32 sum = 0;
-  for (u32 i = lane; i < L.len; i += 64) sum += static_cast<u32>(read_quals[L.qual_off + poa_layer_src_pos(L, i)]) - 33u;
+  for (u32 i = lane; i < L.len; i += 64)
+    sum += static_cast<u32>(read_quals[L.qual_off + (poa_layer_src_pos(L, i) >> qual_shift)]) - 33u;
   sum = wave_sum(sum);
   if (lane == 0) ok[li] = static_cast<double>(sum) / static_cast<double>(L.len) >= q_thr ? 1 : 0;
 }
 
-struct BestOverlap {
-  bool valid = false;
-  Overlap o{};
-  u64 aoff = 0;
-  u32 acnt = 0;
+__device__ __forceinline__ u32 span_len(const Overlap& o) {
+  const u32 a = o.lhs_end - o.lhs_begin, b = o.rhs_end - o.rhs_begin;
+  return a > b ? a : b;
+}
+
+// racon: the longest overlap of every read (the first one among equals), dropped when its two spans differ by more
+// than the error threshold.  One thread per read of the mapped window [first, first + n).
+__global__ void best_overlap_kernel(const Overlap* __restrict__ ovl, const u32* __restrict__ roff, u32 first, u32 n,
+                                    double err_thr, const u32* __restrict__ id_to_t, u32 n_ids,
+                                    Overlap* __restrict__ best, u32* __restrict__ best_t) {
+  const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  const u32 b = roff[r], e = roff[r + 1];
+  u32 bt = 0xFFFFFFFFu;
+  Overlap bo{};
+  if (e > b) {
+    bo = ovl[b];
+    u32 bl = span_len(bo);
+    for (u32 i = b + 1; i < e; ++i) {
+      const Overlap o = ovl[i];
+      const u32 l = span_len(o);
+      if (bl < l) {
+        bo = o;
+        bl = l;
+      }
+    }
+    const double a = bo.lhs_end - bo.lhs_begin, c = bo.rhs_end - bo.rhs_begin;
+    const double err = 1.0 - (a < c ? a : c) / (a > c ? a : c);
+    if (!(err > err_thr) && bo.rhs_id < n_ids) bt = id_to_t[bo.rhs_id];
+  }
+  best[first + r] = bo;
+  best_t[first + r] = bt;
+}
+
+struct WinMeta {  // host-built, one per window of the processed range
+  u64 t_word;     // first word of the window's target
+  u32 target, start, len, t_len;  // target index, first base, bases (<= w), length of the target
+  u32 out_off, pad_;
 };
+
+// racon's layer rules on one window record; true = the piece becomes a layer of window `wi` of its target
+__device__ __forceinline__ bool layer_rules(const NwWindowRec& rec, u32 w, u32* begin, u32* end) {
+  if (rec.first_t == 0xFFFFFFFFu) return false;
+  const u32 qlen = rec.last_q - rec.first_q;
+  if (static_cast<double>(qlen) < 0.02 * w) return false;  // racon: breaking_points[j+1].second - [j].second < 0.02 * w
+  const u32 ws = (rec.first_t / w) * w;
+  *begin = rec.first_t - ws;
+  *end = rec.last_t - ws - 1;
+  return *begin < *end;  // racon Window::AddLayer rejects begin >= end
+}
+
+// pass 1: layers per window.  One thread per alignment job.
+__global__ void layer_count_kernel(const NwJob* __restrict__ jobs, u32 n_jobs, const NwWindowRec* __restrict__ recs,
+                                   const u64* __restrict__ first_window, u32 w, u64 W0, u64 W1,
+                                   u32* __restrict__ win_cnt, u8* __restrict__ keep) {
+  const u32 ji = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ji >= n_jobs) return;
+  const NwJob J = jobs[ji];
+  for (u32 x = 0; x < J.n_windows; ++x) {
+    const NwWindowRec rec = recs[J.bp_off + x];
+    u32 b, e;
+    u8 k = 0;
+    if (layer_rules(rec, w, &b, &e)) {
+      const u64 gw = first_window[J.target] + rec.first_t / w;
+      if (gw >= W0 && gw < W1) {
+        atomicAdd(&win_cnt[gw - W0], 1u);
+        k = 1;
+      }
+    }
+    keep[J.bp_off + x] = k;
+  }
+}
+
+// pass 2: layer descriptors into their window's segment (any order; window_finish_kernel sorts them)
+__global__ void layer_fill_kernel(const NwJob* __restrict__ jobs, u32 n_jobs, const NwWindowRec* __restrict__ recs,
+                                  const u8* __restrict__ keep, const u64* __restrict__ first_window, u32 w, u64 W0,
+                                  const u32* __restrict__ win_off, u32* __restrict__ win_fill,
+                                  const WinMeta* __restrict__ meta, const u64* __restrict__ qual_off, u32 qual_flag,
+                                  PoaLayer* __restrict__ lays, u64* __restrict__ keys, u32* __restrict__ max_len) {
+  const u32 ji = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ji >= n_jobs) return;
+  const NwJob J = jobs[ji];
+  u32 local_max = 0;
+  for (u32 x = 0; x < J.n_windows; ++x) {
+    if (!keep[J.bp_off + x]) continue;
+    const NwWindowRec rec = recs[J.bp_off + x];
+    u32 b, e;
+    layer_rules(rec, w, &b, &e);
+    const u32 wi = static_cast<u32>(first_window[J.target] + rec.first_t / w - W0);
+    const u32 slot = win_off[wi] + wi + 1 + atomicAdd(&win_fill[wi], 1u);
+    const u32 bl = meta[wi].len;
+    PoaLayer L{};
+    L.code_off = J.r_word;
+    L.qual_off = qual_flag ? qual_off[J.read] : 0;
+    L.len = rec.last_q - rec.first_q;
+    L.begin = b;
+    L.end = e < bl - 1 ? e : bl - 1;
+    L.flags = kLayerPacked | (J.rc ? kLayerRc : 0u) | (qual_flag ? kLayerQual : 0u);
+    L.q_begin = rec.first_q;
+    L.q_len = J.r_len;
+    // band guide: layer offsets at eighths of the target span, interpolated between the path's samples
+    {
+      const u32 ws = (rec.first_t / w) * w;
+      const u32 span = rec.last_t - rec.first_t;  // == end - begin + 1 before the clamp
+      u32 pt = rec.first_t, po = 0;               // last known point at or before tau
+      int g = 0;
+      u32 prev = 0;
+      for (u32 i = 1; i < 8; ++i) {
+        const u32 tau = rec.first_t + static_cast<u32>((static_cast<u64>(span) * i) / 8);
+        u32 nt = rec.last_t, no = L.len;  // next known point after tau
+        for (; g < 8; ++g) {
+          const u32 gt = ws + static_cast<u32>((static_cast<u64>(g) * w) / 8);
+          if (rec.grid[g] == 0xFFFFu || gt <= rec.first_t || gt >= rec.last_t) continue;
+          if (gt <= tau) {
+            pt = gt;
+            po = rec.grid[g];
+            continue;
+          }
+          nt = gt;
+          no = rec.grid[g];
+          break;
+        }
+        u32 off = po;
+        if (nt > pt && no > po) off = po + static_cast<u32>((static_cast<u64>(tau - pt) * (no - po)) / (nt - pt));
+        off = off < prev ? prev : off;
+        off = off > L.len ? L.len : off;
+        L.way[i - 1] = static_cast<u16>(off < 0xFFFFu ? off : 0xFFFFu);
+        prev = off;
+      }
+      L.pad_ = 0;
+    }
+    lays[slot] = L;
+    keys[slot] = (static_cast<u64>(b) << 32) | ji;  // racon: stable sort by begin; jobs are in read (= overlap) order
+    local_max = local_max > L.len ? local_max : L.len;
+  }
+  if (local_max) atomicMax(max_len, local_max);
+}
+
+// pass 3, one wave per window: backbone descriptor, layers into racon's order (begin, then read), PoaWindow
+__global__ __launch_bounds__(256) void window_finish_kernel(const WinMeta* __restrict__ meta, u32 n_windows,
+                                                           const u32* __restrict__ win_off,
+                                                           const u32* __restrict__ win_cnt,
+                                                           const PoaLayer* __restrict__ lays_in,
+                                                           const u64* __restrict__ keys, PoaLayer* __restrict__ lays,
+                                                           PoaWindow* __restrict__ wins) {
+  const u32 wi = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (wi >= n_windows) return;
+  const int lane = lane_id();
+  const u32 base = win_off[wi] + wi;
+  const u32 n = win_cnt[wi];
+  const WinMeta M = meta[wi];
+  if (lane == 0) {
+    PoaLayer B{};
+    B.code_off = M.t_word;
+    B.len = M.len;
+    B.begin = 0;
+    B.end = M.len ? M.len - 1 : 0;
+    B.flags = kLayerPacked | kLayerTarget | kLayerZeroW;  // weight 0 = racon's dummy '!' backbone quality
+    B.q_begin = M.start;
+    B.q_len = M.t_len;
+    for (u32 i = 1; i < 8; ++i) B.way[i - 1] = static_cast<u16>(static_cast<u64>(B.len) * i / 8);
+    B.pad_ = 0;
+    lays[base] = B;
+    PoaWindow W;
+    W.layer_first = base;
+    W.n_layers = n + 1;
+    W.out_off = M.out_off;
+    W.out_cap = 2 * M.len + 128;
+    wins[wi] = W;
+  }
+  for (u32 a = lane; a < n; a += 64) {
+    const u64 ka = keys[base + 1 + a];
+    u32 rank = 0;
+    for (u32 b = 0; b < n; ++b) rank += keys[base + 1 + b] < ka ? 1u : 0u;  // keys are distinct (job index)
+    lays[base + 1 + rank] = lays_in[base + 1 + a];
+  }
+}
+
+// consensus of window wi -> its place in the stitched output.  One workgroup per window.
+__global__ __launch_bounds__(256) void stitch_kernel(const PoaWindow* __restrict__ wins, const u32* __restrict__ len,
+                                                    const u64* __restrict__ cons_off, const u8* __restrict__ out,
+                                                    u8* __restrict__ final_out) {
+  const u32 wi = blockIdx.x;
+  const u32 n = len[wi];
+  const u8* src = out + wins[wi].out_off;
+  u8* dst = final_out + cons_off[wi];
+  for (u32 i = threadIdx.x; i < n; i += 256) dst[i] = src[i];
+}
 
 }  // namespace
 
@@ -70,17 +247,22 @@ void polish_round(Engine& e, ReadsDev& T, ReadsDev& R, const u8* h_quals, const 
   const auto t_all = clk::now();
   const bool dbg = std::getenv("RVN_POLISH_DEBUG") != nullptr;
   auto lap = [&, last = clk::now()](const char* what) mutable {
-    if (dbg) std::fprintf(stderr, "[raven_hip] polish: %-28s %8.1f ms\n", what, ms_since(last));
+    if (dbg) {
+      (void)hipStreamSynchronize(s);
+      std::fprintf(stderr, "[raven_hip] polish: %-32s %8.1f ms\n", what, ms_since(last));
+    }
     last = clk::now();
   };
   polished.assign(T.n, {});
   ratio.assign(T.n, 0.0);
   stats = PolishStats();
+  e.polish_target_reads.assign(T.n, 0);
+  if (win_count) win_count->assign(T.n, 0);
+  if (win_polished) win_polished->assign(T.n, 0);
   if (T.n == 0) return;
-  if (T.h_packed.empty() || (R.n && R.h_packed.empty()))
-    throw std::invalid_argument("[raven_hip] polish needs read sets uploaded with host copies (rvn_reads_upload)");
+  double host_ms = 0;
 
-  // ---- 1. map reads to targets --------------------------------------------------------------------
+  // ---- 1. map the reads to the targets; best overlap per read (device) ---------------------------------------------
   {
     StageTimer t(e, StageTimes::kSketch);
     e.query_ready = false;
@@ -91,490 +273,258 @@ void polish_round(Engine& e, ReadsDev& T, ReadsDev& R, const u8* h_quals, const 
   }
   index_build(e, e.index_sketch, true);
   index_filter(e, 0.001);
+  u32 max_id = 0;
+  for (u32 t = 0; t < T.n; ++t) max_id = std::max(max_id, T.h_id[t]);
+  {
+    std::vector<u32> id_to_t(static_cast<size_t>(max_id) + 1, 0xFFFFFFFFu);
+    for (u32 t = 0; t < T.n; ++t) id_to_t[T.h_id[t]] = t;
+    u32* d = e.pl_idmap.get<u32>(id_to_t.size());
+    RVN_HIP(hipMemcpyAsync(d, id_to_t.data(), id_to_t.size() * 4, hipMemcpyHostToDevice, s));
+    RVN_HIP(hipStreamSynchronize(s));
+  }
+  Overlap* d_best = e.pl_best.get<Overlap>(static_cast<size_t>(R.n) + 1);
+  u32* d_best_t = e.pl_best_t.get<u32>(static_cast<size_t>(R.n) + 1);
   const bool keep = e.keep_anchors;
-  e.keep_anchors = true;
-  MapOut& mo = e.map_out;
+  e.keep_anchors = false;
   try {
-    map_batch(e, R, 0, R.n, false, false, false, false, mo);
+    // racon maps its reads in batches of about 1 GB; the match / overlap memory of a round is that of one batch
+    u64 bases = 0;
+    for (u32 r0 = 0, r = 0; r < R.n; ++r) {
+      bases += R.h_len[r];
+      if (r != R.n - 1 && bases < (1ULL << 30)) continue;
+      bases = 0;
+      MapOut& mo = e.map_out;
+      map_batch(e, R, r0, r + 1, false, false, false, false, mo);
+      stats.n_overlaps += mo.n_overlaps;
+      const u32 nr = r + 1 - r0;
+      RVN_KLAUNCH(kKBestOverlap, best_overlap_kernel<<<div_up(nr, 256), 256, 0, s>>>(
+                                     mo.ovl.as<Overlap>(), mo.ovl_read_off.as<u32>(), r0, nr, err_thr,
+                                     e.pl_idmap.as<u32>(), max_id + 1, d_best, d_best_t));
+      r0 = r + 1;
+    }
   } catch (...) {
     e.keep_anchors = keep;
     throw;
   }
   e.keep_anchors = keep;
+  std::vector<Overlap> best(R.n);
+  std::vector<u32> best_t(R.n);
+  if (R.n) {
+    RVN_HIP(hipMemcpyAsync(best.data(), d_best, static_cast<size_t>(R.n) * sizeof(Overlap), hipMemcpyDeviceToHost, s));
+    RVN_HIP(hipMemcpyAsync(best_t.data(), d_best_t, static_cast<size_t>(R.n) * 4, hipMemcpyDeviceToHost, s));
+  }
   RVN_HIP(hipStreamSynchronize(s));
-  const u64 O = mo.n_overlaps;
-  std::vector<Overlap> ovl(O);
-  std::vector<u32> roff(static_cast<size_t>(R.n) + 1, 0);
-  std::vector<u64> aoff(O);
-  std::vector<u32> acnt(O);
-  // the anchors are the bulk of the read-back: pinned staging while that is cheap, a plain buffer beyond 256 MB
-  const bool pin_anchors = (mo.n_matches + 1) * 8 <= (256ULL << 20);
-  u64* anchors = pin_anchors ? e.pin_big.get<u64>(mo.n_matches + 1) : e.host_big.get<u64>(mo.n_matches + 1);
-  if (O) {
-    RVN_HIP(hipMemcpyAsync(anchors, mo.anchors.ptr, mo.n_matches * 8, hipMemcpyDeviceToHost, s));
-    RVN_HIP(hipMemcpy(ovl.data(), mo.ovl.ptr, O * sizeof(Overlap), hipMemcpyDeviceToHost));
-    RVN_HIP(hipMemcpy(aoff.data(), mo.anchor_off.ptr, O * 8, hipMemcpyDeviceToHost));
-    RVN_HIP(hipMemcpy(acnt.data(), mo.anchor_cnt.ptr, O * 4, hipMemcpyDeviceToHost));
-    RVN_HIP(hipStreamSynchronize(s));
-  }
-  RVN_HIP(hipMemcpy(roff.data(), mo.ovl_read_off.ptr, roff.size() * 4, hipMemcpyDeviceToHost));
-  stats.n_overlaps = O;
   stats.map_ms = ms_since(t_all);
-  lap("index + map + read-back");
+  lap("index + map + best overlap");
 
-  // ---- 2. best overlap per read ------------------------------------------------------------------------
-  auto span_len = [](const Overlap& o) {
-    return std::max(o.lhs_end - o.lhs_begin, o.rhs_end - o.rhs_begin);
-  };
-  std::vector<BestOverlap> best(R.n);
-  for (u32 r = 0; r < R.n; ++r) {
-    for (u32 i = roff[r]; i < roff[r + 1]; ++i) {
-      if (!best[r].valid || span_len(best[r].o) < span_len(ovl[i])) {
-        best[r].valid = true;
-        best[r].o = ovl[i];
-        best[r].aoff = aoff[i];
-        best[r].acnt = acnt[i];
-      }
-    }
-    if (best[r].valid) {
-      const Overlap& o = best[r].o;
-      const double a = o.lhs_end - o.lhs_begin, b = o.rhs_end - o.rhs_begin;
-      const double err = 1.0 - std::min(a, b) / std::max(a, b);
-      if (err > err_thr) best[r].valid = false;
-    }
-  }
-
-  lap("best overlap per read");
-  // ---- 3. windows and layers ----------------------------------------------------------------------------
-  // target id -> index in T (ids are arbitrary); windows are numbered target by target
-  std::vector<u32> id_to_t;
-  {
-    u32 max_id = 0;
-    for (u32 t = 0; t < T.n; ++t) max_id = std::max(max_id, T.h_id[t]);
-    id_to_t.assign(static_cast<size_t>(max_id) + 1, 0xFFFFFFFFu);
-    for (u32 t = 0; t < T.n; ++t) id_to_t[T.h_id[t]] = t;
-  }
+  // ---- host planning: window tables of the processed range, one alignment job per used read -------------------------
+  auto t_host = clk::now();
   std::vector<u64> first_window(static_cast<size_t>(T.n) + 1, 0);
   for (u32 t = 0; t < T.n; ++t) first_window[t + 1] = first_window[t] + (static_cast<u64>(T.h_len[t]) + w - 1) / w;
-  const u64 n_windows = first_window[T.n];
-  std::vector<u32> win_t_all(n_windows);
-  for (u32 t = 0; t < T.n; ++t)
-    for (u64 gw = first_window[t]; gw < first_window[t + 1]; ++gw) win_t_all[gw] = t;
-  struct LayerRef {
-    u32 read, q_begin, q_len, t_begin, t_end, rc;
-    u16 way[7];  // PoaLayer::way: where the chain says the piece is at 1/8 .. 7/8 of its target span
-  };
-  const u32 k = e.k;
-  e.polish_target_reads.assign(T.n, 0);
-  // reads are independent: host threads each take a contiguous range of reads and emit (window, layer) pairs;
-  // the ranges are appended in read order, so a window's layers keep racon's order (overlap order, then the stable
-  // sort by begin position in step 4)
-  struct Emit {
-    u64 window;
-    LayerRef layer;
-  };
-  struct Part {
-    std::vector<Emit> emits;
-    std::vector<u32> target_reads;
-    u64 used = 0, dropped = 0;
-    u64 n_cuts = 0, n_nw = 0, nw_cells = 0;
-  };
-  u32 thr_cap = 128;
-  if (const char* ev = std::getenv("RVN_HOST_THREADS")) thr_cap = std::max(1, std::atoi(ev));
-  const u32 n_thr = std::max(1u, std::min<u32>(thr_cap, std::min<u32>(std::thread::hardware_concurrency(), R.n / 128 + 1)));
-  // The window range of this call is processed in chunks: while the GPU runs the POA of one chunk (background
-  // thread), the host threads cut the reads of the next one.  A read belongs to every chunk its overlap touches.
-  const u64 W0 = std::min<u64>(win_first, n_windows), W1 = std::min<u64>(win_last, n_windows);
-  const u64 chunk_w = e.polish_chunk_windows ? e.polish_chunk_windows : std::max<u64>(1, W1 - W0);
-  const u32 n_chunks = static_cast<u32>(W1 > W0 ? (W1 - W0 + chunk_w - 1) / chunk_w : 0);
-  std::vector<std::vector<u32>> chunk_reads(n_chunks);
+  const u64 n_windows_all = first_window[T.n];
+  const u64 W0 = std::min<u64>(win_first, n_windows_all), W1 = std::min<u64>(win_last, n_windows_all);
+  const u32 nw = static_cast<u32>(W1 > W0 ? W1 - W0 : 0);
+  std::vector<NwJob> jobs;
+  jobs.reserve(R.n);
+  u64 n_recs = 0;
   for (u32 r = 0; r < R.n; ++r) {
-    if (!best[r].valid) continue;
-    const Overlap& o = best[r].o;
-    if (o.rhs_id >= id_to_t.size() || id_to_t[o.rhs_id] == 0xFFFFFFFFu || best[r].acnt < 2) {
-      best[r].valid = false;
-      continue;
-    }
-    const u32 t = id_to_t[o.rhs_id];
+    if (best_t[r] == 0xFFFFFFFFu) continue;
+    const Overlap& o = best[r];
+    const u32 t = best_t[r];
     ++stats.n_reads_used;
     ++e.polish_target_reads[t];
-    const u64 g_lo = first_window[t] + o.rhs_begin / w, g_hi = first_window[t] + (o.rhs_end ? (o.rhs_end - 1) / w : 0);
-    if (g_hi < W0 || g_lo >= W1) continue;
-    const u32 c_a = static_cast<u32>((std::max(g_lo, W0) - W0) / chunk_w);
-    const u32 c_b = static_cast<u32>((std::min(g_hi, W1 - 1) - W0) / chunk_w);
-    for (u32 c = c_a; c <= c_b; ++c) chunk_reads[c].push_back(r);
+    if (o.rhs_end <= o.rhs_begin || o.lhs_end <= o.lhs_begin) continue;
+    const u64 g_lo = first_window[t] + o.rhs_begin / w, g_hi = first_window[t] + (o.rhs_end - 1) / w;
+    if (g_hi < W0 || g_lo >= W1) continue;  // another rank's windows
+    const u32 qlen = R.h_len[r];
+    const bool rc = o.strand == 0;
+    NwJob J{};
+    J.t_word = T.h_word_off[t];
+    J.r_word = R.h_word_off[r];
+    J.t_begin = o.rhs_begin;
+    J.n = o.rhs_end - o.rhs_begin;
+    J.q_begin = rc ? qlen - o.lhs_end : o.lhs_begin;  // racon reverse-complements the read (step 2 of its pipeline)
+    J.m = o.lhs_end - o.lhs_begin;
+    J.r_len = qlen;
+    J.rc = rc ? 1 : 0;
+    J.read = r;
+    J.target = t;
+    J.n_windows = (o.rhs_end - 1) / w - o.rhs_begin / w + 1;
+    J.bp_off = n_recs;
+    n_recs += J.n_windows;
+    jobs.push_back(J);
   }
-  u64 c_lo = 0, c_hi = 0;  // window range of the chunk being cut
-  const std::vector<u32>* cur_reads = nullptr;
-  std::vector<Part> parts;
-  auto work = [&](u32 ti) {
-    Part& P = parts[ti];
-    const std::vector<u32>& cr = *cur_reads;
-    const size_t i_lo = cr.size() * ti / n_thr, i_hi = cr.size() * (ti + 1) / n_thr;
-    std::vector<std::pair<u32, u32>> an;
-    CutScratch sc;
-    for (size_t ii = i_lo; ii < i_hi; ++ii) {
-      const u32 r = cr[ii];
-      const Overlap& o = best[r].o;
-      const u32 t = id_to_t[o.rhs_id];
-      const u32 qlen = R.h_len[r];
-      const bool rc = o.strand == 0;
-      // anchors as (t, q') increasing in both; q' in the orientation that matches the target
-      an.resize(best[r].acnt);
-      for (u32 i = 0; i < best[r].acnt; ++i) {
-        const u64 a = anchors[best[r].aoff + i];
-        const u32 qp = static_cast<u32>(a >> 32), tp = static_cast<u32>(a);
-        an[i] = rc ? std::make_pair(tp, qlen - qp - k) : std::make_pair(tp, qp);
-      }
-      if (rc) std::reverse(an.begin(), an.end());
-      if (an.size() < 2) continue;
-      // read position at target coordinate B (a window boundary inside the chain): exact inside an anchor's
-      // k-mer or inside the exact-match extension of the bracketing anchors (the bases are compared on the host
-      // copies of the packed sets); only the unmatched remainder of the gap — a handful of bases around the
-      // error that ended the matches — is split proportionally
-      const u64 t_wo = T.h_word_off[t], r_wo = R.h_word_off[r];
-      auto tbase = [&](u32 x) -> u32 { return code_at(T.h_packed, t_wo, x); };
-      auto qbase = [&](u32 x) -> u32 {  // read in the orientation of the target
-        return rc ? 3u - code_at(R.h_packed, r_wo, qlen - 1 - x) : code_at(R.h_packed, r_wo, x);
-      };
-      // cut(B): the (read, target) position pairs at which the piece left of boundary B ends (target <= B) and the
-      // piece right of it begins (target >= B).  Inside an exact-match region both are (q(B), B); when B falls into
-      // the unmatched remainder of an anchor gap — the few bases around the error(s) that ended the exact
-      // extensions — a small unit-cost NW of the two remainders decides, so pieces tile the windows exactly as
-      // racon's CIGAR breakpoints do.  Only a remainder longer than kCutMax is given to neither window (the piece
-      // on the left ends where the exact region before it ends, the one on the right begins where the exact
-      // region after it begins): a guessed cut would append true neighbour bases to a window.
-      auto cut = [&](u32 B) -> WindowCut { return window_cut(an, k, B, T.h_len[t], qlen, tbase, qbase, sc); };
-      const u32 t_first = an.front().first, t_last_end = an.back().first + k;  // chain covers [t_first, t_last_end)
-      const u32 q_first = an.front().second, q_last_end = an.back().second + k;
-      WindowCut carry{q_first, t_first, q_first, t_first};
-      u32 carry_at = 0xFFFFFFFFu;  // boundary `carry` was computed for
-      for (u32 wi = t_first / w; static_cast<u64>(wi) * w < t_last_end; ++wi) {
-        if (first_window[t] + wi + 1 < c_lo || first_window[t] + wi > c_hi) continue;  // far from this chunk
-        const u32 ws = wi * w;
-        const u32 we = std::min<u32>(T.h_len[t], ws + w);  // exclusive
-        u32 t_b = std::max(ws, t_first), t_e = std::min(we, t_last_end);  // [t_b, t_e)
-        if (t_e <= t_b + 1) continue;
-        u32 q_b = q_first, q_e = q_last_end;
-        if (t_b != t_first) {  // the cut at this window's start is normally the previous window's end cut
-          if (carry_at != t_b) {
-            carry = cut(t_b);
-            carry_at = t_b;
-          }
-          q_b = carry.qr;
-          t_b = carry.tr;
-        }
-        if (t_e != t_last_end) {
-          carry = cut(t_e);
-          carry_at = t_e;
-          ++P.n_cuts;
-          q_e = carry.ql;
-          t_e = carry.tl;
-        }
-        if (t_e <= t_b + 1 || t_e > we) continue;
-        if (q_e > qlen) q_e = qlen;
-        if (q_e <= q_b || (q_e - q_b) < 0.02 * w) continue;
-        {  // cuts are exact, so a piece may legitimately be much shorter or longer than its target span (real
-           // reads lose whole homopolymer runs); only an absurd ratio — a chain that jumped a repeat copy — is dropped
-          const double span = t_e - t_b, ql = q_e - q_b;
-          if (ql > 2.0 * span + 32 || span > 2.0 * ql + 32) {
-            ++P.dropped;
-            continue;
-          }
-        }
-        LayerRef lr{r, q_b, q_e - q_b, t_b - ws, t_e - 1 - ws, rc, {}};
-        {  // band guide: read offsets at eighths of the target span, linear between the bracketing anchors
-          const u32 span = t_e - t_b;
-          u32 prev = 0;
-          for (u32 i = 1; i < 8; ++i) {
-            const u32 tau = t_b + static_cast<u32>(static_cast<u64>(span) * i / 8);
-            size_t lo = 0, hi = an.size();
-            while (hi - lo > 1) {
-              const size_t mid = (lo + hi) / 2;
-              if (an[mid].first <= tau) lo = mid;
-              else hi = mid;
-            }
-            u32 q = an[lo].second + (tau >= an[lo].first ? std::min(tau - an[lo].first, k) : 0u);
-            if (tau > an[lo].first + k && lo + 1 < an.size() && an[lo + 1].first > an[lo].first + k &&
-                an[lo + 1].second > an[lo].second + k) {
-              const double f = static_cast<double>(tau - an[lo].first - k) / (an[lo + 1].first - an[lo].first - k);
-              q = an[lo].second + k + static_cast<u32>(f * (an[lo + 1].second - an[lo].second - k));
-            }
-            u32 off = q > q_b ? q - q_b : 0;
-            off = std::min(std::max(off, prev), q_e - q_b);
-            lr.way[i - 1] = static_cast<u16>(std::min<u32>(off, 0xFFFFu));
-            prev = off;
-          }
-        }
-        if (first_window[t] + wi < c_lo || first_window[t] + wi >= c_hi) continue;  // another chunk's / rank's window
-        P.emits.push_back(Emit{first_window[t] + wi, lr});
-      }
+  std::vector<WinMeta> meta(nw);
+  {
+    u32 t = 0;
+    u64 out_total = 0;
+    for (u32 i = 0; i < nw; ++i) {
+      const u64 gw = W0 + i;
+      while (first_window[t + 1] <= gw) ++t;
+      WinMeta& M = meta[i];
+      M.target = t;
+      M.t_word = T.h_word_off[t];
+      M.start = static_cast<u32>(gw - first_window[t]) * w;
+      M.t_len = T.h_len[t];
+      M.len = std::min<u32>(w, M.t_len - M.start);
+      if (out_total + 2ULL * M.len + 128 > 0xFFFFFFFFULL)
+        throw std::invalid_argument("[raven_hip] polishing round: window range too large for one batch (use rvn_polish_round_range)");
+      M.out_off = static_cast<u32>(out_total);
+      M.pad_ = 0;
+      out_total += 2ULL * M.len + 128;
     }
-    P.n_nw = sc.n_nw;
-    P.nw_cells = sc.nw_cells;
-  };
-  const bool any_q = h_quals != nullptr;
+    stats.n_windows = nw;
+    host_ms += ms_since(t_host);
+    if (nw == 0) {
+      stats.host_ms = host_ms;
+      stats.total_ms = ms_since(t_all);
+      return;
+    }
+    WinMeta* d_meta = e.pl_win_meta.get<WinMeta>(nw + 1);
+    u64* d_fw = e.pl_first_window.get<u64>(first_window.size());
+    RVN_HIP(hipMemcpyAsync(d_meta, meta.data(), nw * sizeof(WinMeta), hipMemcpyHostToDevice, s));
+    RVN_HIP(hipMemcpyAsync(d_fw, first_window.data(), first_window.size() * 8, hipMemcpyHostToDevice, s));
+    (void)e.pl_out.get<u8>(out_total + 16);
+  }
+  const WinMeta* d_meta = e.pl_win_meta.as<WinMeta>();
+  const u64* d_fw = e.pl_first_window.as<u64>();
+  u8* d_out = e.pl_out.as<u8>();
+  lap("planning");
+
+  // ---- 2. alignment paths + breakpoints ------------------------------------------------------------------------------
+  NwWindowRec* d_recs = e.pl_recs.get<NwWindowRec>(n_recs + 1);
+  NwStats nst;
+  nw_breakpoints(e, T, R, jobs, w, d_recs, n_recs, nst);
+  stats.align_ms = nst.ms;
+  stats.n_aligned = nst.n_aligned;
+  stats.n_align_retries = nst.n_retries;
+  stats.n_dropped_layers = nst.n_unaligned;
+  stats.align_band_cells = nst.band_cells;
+  stats.align_store_bytes = nst.store_bytes;
+  lap("alignment paths + breakpoints");
+
+  // ---- 3. window layers (descriptors; bases and qualities stay where they are) ----------------------------------------
+  const u32 nj = static_cast<u32>(jobs.size());
   PoaSrc src{};
   src.packed_reads = R.packed.as<u64>();
   src.packed_targets = T.packed.as<u64>();
-  if (any_q) {  // qualities to HBM once per call
+  src.qual_shift = 0;
+  const u64* d_qual_off = nullptr;
+  if (h_quals != nullptr) {  // caller-supplied per-base qualities: to HBM for this call
     const u64 qtotal = h_qual_off[R.n];
     u8* d_q = e.polish_quals.get<u8>(qtotal + 16);
+    u64* d_qo = e.pl_qual_off.get<u64>(static_cast<size_t>(R.n) + 1);
     RVN_HIP(hipMemcpyAsync(d_q, h_quals, qtotal, hipMemcpyHostToDevice, s));
-    RVN_HIP(hipStreamSynchronize(s));
+    RVN_HIP(hipMemcpyAsync(d_qo, h_qual_off, (static_cast<size_t>(R.n) + 1) * 8, hipMemcpyHostToDevice, s));
     src.read_quals = d_q;
+    d_qual_off = d_qo;
+  } else if (R.qual_shift >= 0) {  // qualities attached to the read set: already resident
+    src.read_quals = R.quals.as<u8>();
+    src.qual_shift = static_cast<u32>(R.qual_shift);
+    d_qual_off = R.qual_off.as<u64>();
   }
-  if (win_count) win_count->assign(T.n, 0);
-  if (win_polished) win_polished->assign(T.n, 0);
+  const bool any_q = src.read_quals != nullptr;
+  NwJob* d_jobs = e.nw_jobs.get<NwJob>(nj + 1);
+  if (nj) RVN_HIP(hipMemcpyAsync(d_jobs, jobs.data(), static_cast<size_t>(nj) * sizeof(NwJob), hipMemcpyHostToDevice, s));
+  u32* d_win_cnt = e.pl_win_cnt.get<u32>(nw + 1);
+  u32* d_win_fill = e.pl_win_fill.get<u32>(nw + 1);
+  u32* d_win_off = e.pl_win_off.get<u32>(nw + 2);
+  u8* d_keep = e.pl_keep.get<u8>(n_recs + 1);
+  u32* d_misc = e.pl_misc.get<u32>(4);
+  RVN_HIP(hipMemsetAsync(d_win_cnt, 0, static_cast<size_t>(nw) * 4, s));
+  RVN_HIP(hipMemsetAsync(d_win_fill, 0, static_cast<size_t>(nw) * 4, s));
+  RVN_HIP(hipMemsetAsync(d_misc, 0, 16, s));
+  if (nj)
+    RVN_KLAUNCH(kKLayerBuild, layer_count_kernel<<<div_up(nj, 128), 128, 0, s>>>(d_jobs, nj, d_recs, d_fw, w, W0, W1,
+                                                                                 d_win_cnt, d_keep));
+  exclusive_scan_u32_u32(d_win_cnt, d_win_off, nw, e.scan_tmp, s);
+  const u64 n_read_layers = read_back(e, d_win_off + nw, 4);
+  const u64 n_lay = n_read_layers + nw;
+  if (n_lay >= 0xFFFFFFFFULL) throw std::invalid_argument("[raven_hip] polishing round: too many layers for one batch");
+  PoaLayer* d_lays_tmp = e.pl_lays_tmp.get<PoaLayer>(n_lay + 1);
+  PoaLayer* d_lays = e.pl_lays.get<PoaLayer>(n_lay + 1);
+  u64* d_keys = e.pl_keys.get<u64>(n_lay + 1);
+  PoaWindow* d_wins = e.pl_wins.get<PoaWindow>(nw + 1);
+  if (nj)
+    RVN_KLAUNCH(kKLayerBuild, layer_fill_kernel<<<div_up(nj, 128), 128, 0, s>>>(
+                                  d_jobs, nj, d_recs, d_keep, d_fw, w, W0, d_win_off, d_win_fill, d_meta, d_qual_off,
+                                  any_q ? 1u : 0u, d_lays_tmp, d_keys, d_misc));
+  RVN_KLAUNCH(kKLayerBuild, window_finish_kernel<<<div_up(nw, 4), 256, 0, s>>>(d_meta, nw, d_win_off, d_win_cnt,
+                                                                              d_lays_tmp, d_keys, d_lays, d_wins));
+  const u32 max_len = static_cast<u32>(read_back(e, d_misc, 4));
+  if (any_q) {  // racon's mean-quality filter as per-layer flags
+    u8* d_ok = e.pl_ok.get<u8>(n_lay + 16);
+    layer_quality_kernel<<<div_up(n_lay, 4), 256, 0, s>>>(d_lays, static_cast<u32>(n_lay), src.read_quals, src.qual_shift,
+                                                           q_thr, d_ok);
+    RVN_LAUNCH_CHECK();
+    src.layer_ok = d_ok;
+    if (q_thr > 0) {  // statistics only: layers that survive
+      std::vector<u8> okh(n_lay);
+      RVN_HIP(hipMemcpyAsync(okh.data(), d_ok, n_lay, hipMemcpyDeviceToHost, s));
+      RVN_HIP(hipStreamSynchronize(s));
+      u64 kept = 0;
+      for (u64 i = 0; i < n_lay; ++i) kept += okh[i];
+      stats.n_layers = kept - nw;  // backbones are always flagged ok
+    } else {
+      stats.n_layers = n_read_layers;
+    }
+  } else {
+    stats.n_layers = n_read_layers;
+  }
+  e.polish_last_windows = nw;
+  e.polish_last_layers = n_lay;
+  e.polish_last_w0 = W0;
+  e.polish_last_has_ok = any_q;
+  e.polish_last_read_off = R.h_word_off;
+  lap("window layers");
+
+  // ---- 4. window consensus -----------------------------------------------------------------------------------------------
+  u32* d_len = e.pl_len.get<u32>(nw + 1);
+  u32* d_status = e.pl_status.get<u32>(nw + 1);
+  RVN_HIP(hipMemsetAsync(d_len, 0, static_cast<size_t>(nw) * 4, s));
+  std::vector<u32> h_status;
+  double poa_ms = 0;
+  poa_run_dev(e, d_wins, d_lays, nw, src, w, std::max<u32>(max_len, w), m, n, g, trim ? 1 : 0, d_out, d_len, d_status,
+              h_status, &poa_ms);
+  stats.poa_ms = poa_ms;
+  lap("POA");
+
+  // ---- 5. stitch the windows in order; per-target results -----------------------------------------------------------
+  u64* d_cons_off = e.pl_cons_off.get<u64>(nw + 2);
+  exclusive_scan_u32_u64(d_len, d_cons_off, nw, e.scan_tmp, s);
+  std::vector<u64> cons_off(nw + 1);
+  RVN_HIP(hipMemcpyAsync(cons_off.data(), d_cons_off, (static_cast<size_t>(nw) + 1) * 8, hipMemcpyDeviceToHost, s));
+  RVN_HIP(hipStreamSynchronize(s));
+  const u64 total = cons_off[nw];
+  u8* d_final = e.pl_final.get<u8>(total + 16);
+  RVN_KLAUNCH(kKStitch, stitch_kernel<<<nw, 256, 0, s>>>(d_wins, d_len, d_cons_off, d_out, d_final));
+  u8* h_final = e.pin_out.get<u8>(total + 16);
+  RVN_HIP(hipMemcpyAsync(h_final, d_final, total, hipMemcpyDeviceToHost, s));
+  RVN_HIP(hipStreamSynchronize(s));
+  t_host = clk::now();
   std::vector<u64> t_windows(T.n, 0), t_polished(T.n, 0);
-  for (u32 t = 0; t < T.n; ++t) polished[t].reserve(static_cast<size_t>(T.h_len[t]) + T.h_len[t] / 16 + 1024);
-
-  struct Chunk {
-    u64 lo = 0, hi = 0;
-    std::vector<PoaWindow> wins;
-    std::vector<PoaLayer> lays;
-    std::vector<u64> out_off;
-    std::vector<u32> cons_len, status;
-    u32 max_bb = 1, max_len = 1;
-    double ms = 0;
-    u64 kept_layers = 0;
-  };
-  Chunk slots[2];
-  std::vector<std::vector<LayerRef>> win_layers;
-  std::vector<u32> win_t;
-  std::vector<u64> lay_first;
-  std::thread bg;
-  std::exception_ptr bg_err;
-  double host_busy = 0;
-  u64 dbg_cuts = 0, dbg_nw = 0, dbg_cells = 0;
-
-  std::vector<std::vector<u8>> win_cons(W1 - W0);  // consensus of every window of the range, stitched at the end
-  std::vector<u32> win_status(W1 - W0, 0);
-  std::vector<PoaWindow> fb_wins;  // windows both bands could not do, with their layers
-  std::vector<PoaLayer> fb_lays;
-  std::vector<u64> fb_gw;
-
-  // background: quality flags + POA of one chunk (the only HIP work while the main thread cuts the next chunk)
-  auto run_chunk = [&](Chunk* C) {
-    try {
-      RVN_HIP(hipSetDevice(e.device));
-      PoaSrc csrc = src;
-      const u32 nl = static_cast<u32>(C->lays.size());
-      if (any_q && nl) {  // racon's mean-quality filter as per-layer flags computed on the device
-        PoaLayer* d_l = e.tmp_d.get<PoaLayer>(C->lays.size() + 1);
-        RVN_HIP(hipMemcpyAsync(d_l, C->lays.data(), C->lays.size() * sizeof(PoaLayer), hipMemcpyHostToDevice, s));
-        u8* d_ok = e.tmp_a.get<u8>(C->lays.size() + 16);
-        layer_quality_kernel<<<(nl + 3) / 4, 256, 0, s>>>(d_l, nl, src.read_quals, q_thr, d_ok);
-        RVN_HIP(hipGetLastError());
-        csrc.layer_ok = d_ok;
-        if (q_thr > 0) {  // only for the statistics: how many layers survive
-          std::vector<u8> okh(nl);
-          RVN_HIP(hipMemcpyAsync(okh.data(), d_ok, nl, hipMemcpyDeviceToHost, s));
-          RVN_HIP(hipStreamSynchronize(s));
-          u64 kept = 0;
-          for (u32 i = 0; i < nl; ++i) kept += (okh[i] && !(C->lays[i].flags & kLayerTarget)) ? 1 : 0;
-          C->kept_layers = kept;
-        }
-      }
-      u8* cons = e.pin_out.get<u8>(C->out_off.back() + 16);
-      // with several chunks the rare windows that need the full-matrix kernel are collected and run ONCE at the end
-      // (that kernel's latency is ~0.25 s per launch, whatever the number of windows)
-      poa_run(e, C->wins, C->lays, csrc, C->max_bb, C->max_len, m, n, g, trim ? 1 : 0, cons, C->out_off.back(),
-              C->cons_len.data(), C->status.data(), &C->ms, n_chunks == 1);
-    } catch (...) {
-      bg_err = std::current_exception();
-    }
-  };
-  auto finish_chunk = [&](Chunk* C) {  // join + stitch the windows of the chunk, in window order
-    if (bg.joinable()) bg.join();
-    if (bg_err) std::rethrow_exception(bg_err);
-    const u8* cons = static_cast<const u8*>(e.pin_out.ptr);
-    stats.poa_ms += C->ms;
-    for (u64 gw = C->lo; gw < C->hi; ++gw) {
-      const u64 i = gw - C->lo;
-      win_status[gw - W0] = C->status[i];
-      win_cons[gw - W0].assign(cons + C->out_off[i], cons + C->out_off[i] + C->cons_len[i]);
-      if (n_chunks > 1 && (C->status[i] & 0xFF) >= 2) {  // keep its layers for the final full-matrix batch
-        PoaWindow fw = C->wins[i];
-        const u32 lf = fw.layer_first;
-        fw.layer_first = static_cast<u32>(fb_lays.size());
-        fb_lays.insert(fb_lays.end(), C->lays.begin() + lf, C->lays.begin() + lf + fw.n_layers);
-        fb_wins.push_back(fw);
-        fb_gw.push_back(gw);
-      }
-    }
-    if (any_q && q_thr > 0) stats.n_layers += C->kept_layers;
-    else stats.n_layers += C->lays.size() - C->wins.size();
-  };
-
-  Chunk* pending = nullptr;
-  for (u32 c = 0; c < n_chunks; ++c) {
-    const auto t_prep = clk::now();
-    Chunk* C = &slots[c & 1];
-    c_lo = W0 + static_cast<u64>(c) * chunk_w;
-    c_hi = std::min(W1, c_lo + chunk_w);
-    C->lo = c_lo;
-    C->hi = c_hi;
-    const u64 nwc = c_hi - c_lo;
-    cur_reads = &chunk_reads[c];
-    parts.assign(n_thr, Part());
-    {
-      std::vector<std::thread> pool;
-      for (u32 ti = 1; ti < n_thr; ++ti) pool.emplace_back(work, ti);
-      work(0);
-      for (auto& th : pool) th.join();
-    }
-    win_layers.assign(nwc, {});
-    for (const Part& P : parts) {  // thread order == read order
-      stats.n_dropped_layers += P.dropped;
-      dbg_cuts += P.n_cuts;
-      dbg_nw += P.n_nw;
-      dbg_cells += P.nw_cells;
-      for (const Emit& em : P.emits) win_layers[em.window - c_lo].push_back(em.layer);
-    }
-    // ---- 4. layer descriptors: bases and qualities stay in HBM (packed read sets) ----
-    C->wins.assign(nwc, PoaWindow{});
-    C->out_off.assign(nwc + 1, 0);
-    lay_first.assign(nwc + 1, 0);
-    for (u64 i = 0; i < nwc; ++i) {
-      const u64 gw = c_lo + i;
-      const u32 t = win_t_all[gw];
-      const u32 bl = std::min<u32>(w, T.h_len[t] - static_cast<u32>(gw - first_window[t]) * w);
-      lay_first[i + 1] = lay_first[i] + 1 + win_layers[i].size();
-      C->out_off[i + 1] = C->out_off[i] + 2ULL * bl + 128;
-    }
-    C->lays.resize(lay_first[nwc]);
-    C->cons_len.assign(nwc, 0);
-    C->status.assign(nwc, 0);
-    C->max_bb = 1;
-    C->max_len = 1;
-    C->kept_layers = 0;
-    C->ms = 0;
-    {
-      const u32 n_fill = static_cast<u32>(std::max<u64>(1, std::min<u64>(n_thr, nwc / 256 + 1)));
-      std::vector<std::pair<u32, u32>> maxes(n_fill, {1u, 1u});
-      auto fill = [&](u32 ti) {
-        const u64 i_lo = nwc * ti / n_fill, i_hi = nwc * (ti + 1) / n_fill;
-        u32 mb = 1, ml = 1;
-        for (u64 i = i_lo; i < i_hi; ++i) {
-          const u64 gw = c_lo + i;
-          const u32 t = win_t_all[gw];
-          const u32 tlen = T.h_len[t];
-          const u32 ws = static_cast<u32>(gw - first_window[t]) * w;
-          const u32 bl = std::min<u32>(w, tlen - ws);
-          PoaLayer* out_l = C->lays.data() + lay_first[i];
-          PoaLayer B{};
-          B.code_off = T.h_word_off[t];
-          B.len = bl;
-          B.begin = 0;
-          B.end = bl ? bl - 1 : 0;
-          B.flags = kLayerPacked | kLayerTarget | kLayerZeroW;  // weight 0 = racon's dummy '!' backbone quality
-          B.q_begin = ws;
-          B.q_len = tlen;
-          poa_layer_linear_way(B);
-          *out_l++ = B;
-          mb = std::max(mb, bl);
-          auto& wl = win_layers[i];
-          // racon: layers in stable order of their begin position
-          std::stable_sort(wl.begin(), wl.end(), [](const LayerRef& a, const LayerRef& b) { return a.t_begin < b.t_begin; });
-          for (const auto& L : wl) {
-            PoaLayer P{};
-            P.code_off = R.h_word_off[L.read];
-            P.qual_off = any_q ? h_qual_off[L.read] : 0;
-            P.len = L.q_len;
-            P.begin = L.t_begin;
-            P.end = std::min(L.t_end, bl - 1);
-            P.flags = kLayerPacked | (L.rc ? kLayerRc : 0u) | (any_q ? kLayerQual : 0u);
-            P.q_begin = L.q_begin;
-            P.q_len = R.h_len[L.read];
-            for (int x = 0; x < 7; ++x) P.way[x] = L.way[x];
-            *out_l++ = P;
-            ml = std::max(ml, L.q_len);
-          }
-          C->wins[i].layer_first = static_cast<u32>(lay_first[i]);
-          C->wins[i].n_layers = static_cast<u32>(lay_first[i + 1] - lay_first[i]);
-          C->wins[i].out_off = static_cast<u32>(C->out_off[i]);
-          C->wins[i].out_cap = 2 * bl + 128;
-        }
-        maxes[ti] = {mb, ml};
-      };
-      std::vector<std::thread> pool;
-      for (u32 ti = 1; ti < n_fill; ++ti) pool.emplace_back(fill, ti);
-      fill(0);
-      for (auto& th : pool) th.join();
-      for (const auto& m2 : maxes) {
-        C->max_bb = std::max(C->max_bb, m2.first);
-        C->max_len = std::max(C->max_len, m2.second);
-      }
-      C->max_len = std::max(C->max_len, C->max_bb);
-    }
-    host_busy += ms_since(t_prep);
-    if (pending) finish_chunk(pending);  // the previous chunk's POA ran while this one was being cut
-    pending = C;
-    bg = std::thread(run_chunk, C);
-  }
-  if (pending) finish_chunk(pending);
-  lap("cuts + descriptors + POA (pipelined)");
-  if (dbg)
-    std::fprintf(stderr, "[raven_hip] polish: %u chunk(s), %llu cuts, %llu with a residual NW (%llu cells), %u host threads, "
-                 "host busy %.1f ms\n", n_chunks, (unsigned long long)dbg_cuts, (unsigned long long)dbg_nw,
-                 (unsigned long long)dbg_cells, n_thr, host_busy);
-
-  if (!fb_wins.empty()) {  // one full-matrix batch for what neither band width could align
-    u64 oo = 0;
-    u32 mb = 1, ml = 1;
-    for (auto& fw : fb_wins) {
-      fw.out_off = static_cast<u32>(oo);
-      oo += fw.out_cap;
-      mb = std::max(mb, fb_lays[fw.layer_first].len);
-      for (u32 x = 0; x < fw.n_layers; ++x) ml = std::max(ml, fb_lays[fw.layer_first + x].len);
-    }
-    PoaSrc fsrc = src;
-    if (any_q) {
-      const u32 nl = static_cast<u32>(fb_lays.size());
-      PoaLayer* d_l = e.tmp_d.get<PoaLayer>(fb_lays.size() + 1);
-      RVN_HIP(hipMemcpyAsync(d_l, fb_lays.data(), fb_lays.size() * sizeof(PoaLayer), hipMemcpyHostToDevice, s));
-      u8* d_ok = e.tmp_a.get<u8>(fb_lays.size() + 16);
-      layer_quality_kernel<<<(nl + 3) / 4, 256, 0, s>>>(d_l, nl, src.read_quals, q_thr, d_ok);
-      RVN_HIP(hipGetLastError());
-      fsrc.layer_ok = d_ok;
-    }
-    u8* cons = e.pin_out.get<u8>(oo + 16);
-    std::vector<u32> fl(fb_wins.size()), fs(fb_wins.size());
-    double fms = 0;
-    const int mode = e.poa_mode;
-    e.poa_mode = 1;
-    try {
-      poa_run(e, fb_wins, fb_lays, fsrc, mb, ml, m, n, g, trim ? 1 : 0, cons, oo, fl.data(), fs.data(), &fms);
-    } catch (...) {
-      e.poa_mode = mode;
-      throw;
-    }
-    e.poa_mode = mode;
-    stats.poa_ms += fms;
-    for (size_t i = 0; i < fb_wins.size(); ++i) {
-      win_status[fb_gw[i] - W0] = fs[i];
-      win_cons[fb_gw[i] - W0].assign(cons + fb_wins[i].out_off, cons + fb_wins[i].out_off + fl[i]);
-    }
-    e.poa_fallback_windows = static_cast<u32>(fb_wins.size());
-  }
-  // ---- 5. stitch the windows in order; per-target results -----------------------------------------------
-  for (u64 gw = W0; gw < W1; ++gw) {
-    const u32 t = win_t_all[gw];
-    const u32 st = win_status[gw - W0];
+  for (u32 i = 0; i < nw; ++i) {
+    const u32 t = meta[i].target;
+    const u32 st = h_status[i];
     ++t_windows[t];
     if (st == 1) ++t_polished[t];
     if (st >= 2) ++stats.n_failed_windows;
-    polished[t].insert(polished[t].end(), win_cons[gw - W0].begin(), win_cons[gw - W0].end());
   }
-  stats.n_windows = W1 - W0;
-  for (u32 t = 0; t < T.n; ++t) {
-    ratio[t] = t_windows[t] ? static_cast<double>(t_polished[t]) / t_windows[t] : 0.0;
-    stats.n_polished_windows += t_polished[t];
-    if (win_count) (*win_count)[t] = static_cast<u32>(t_windows[t]);
-    if (win_polished) (*win_polished)[t] = static_cast<u32>(t_polished[t]);
+  {
+    u32 i = 0;
+    for (u32 t = 0; t < T.n; ++t) {
+      const u32 i0 = i;
+      while (i < nw && meta[i].target == t) ++i;
+      if (i > i0) polished[t].assign(h_final + cons_off[i0], h_final + cons_off[i]);
+      ratio[t] = t_windows[t] ? static_cast<double>(t_polished[t]) / t_windows[t] : 0.0;
+      stats.n_polished_windows += t_polished[t];
+      if (win_count) (*win_count)[t] = static_cast<u32>(t_windows[t]);
+      if (win_polished) (*win_polished)[t] = static_cast<u32>(t_polished[t]);
+    }
   }
-  stats.host_ms = host_busy;
+  host_ms += ms_since(t_host);
+  lap("stitch + read-back");
+  stats.host_ms = host_ms;
   stats.total_ms = ms_since(t_all);
 }
 

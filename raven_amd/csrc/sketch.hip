@@ -396,4 +396,32 @@ void sketch_range(Engine& e, const ReadsDev& r, u32 first, u32 last, bool minhas
   sketch_minhash(e, r, e.raw_sketch, out);
 }
 
+// ---- packing of one-byte codes (rvn_reads_upload_codes: consensus of a polishing round -> targets of the next) ------
+namespace {
+__global__ void pack_codes_kernel(const u8* __restrict__ codes, const u64* __restrict__ base_off,
+                                  const u64* __restrict__ word_off, u32 n_reads, u64 n_words, u64* __restrict__ packed) {
+  const u64 wi = static_cast<u64>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (wi >= n_words) return;
+  // read of this word: last i with word_off[i] <= wi
+  u32 lo = 0, hi = n_reads;
+  while (hi - lo > 1) {
+    const u32 mid = lo + (hi - lo) / 2;
+    if (word_off[mid] <= wi) lo = mid;
+    else hi = mid;
+  }
+  const u64 first = base_off[lo] + (wi - word_off[lo]) * 32;
+  const u64 end = base_off[lo + 1];
+  u64 w = 0;
+  for (u32 x = 0; x < 32 && first + x < end; ++x) w |= static_cast<u64>(codes[first + x] & 3u) << (2 * x);
+  packed[wi] = w;
+}
+}  // namespace
+
+void pack_codes_on_device(Engine& e, const u8* d_codes, const u64* d_base_off, const u64* d_word_off, u32 n_reads,
+                          u64 n_words, u64* d_packed) {
+  if (n_words == 0 || n_reads == 0) return;
+  pack_codes_kernel<<<div_up(n_words, 256), 256, 0, e.stream>>>(d_codes, d_base_off, d_word_off, n_reads, n_words, d_packed);
+  RVN_LAUNCH_CHECK();
+}
+
 }  // namespace rvn

@@ -39,7 +39,7 @@ SYMBOLS = [
     "rvn_shard_piles_merge", "rvn_shard_piles_merge_dev", "rvn_shard_sketch_fetch_dev",
     "rvn_shard_index_build_dev", "rvn_shard_key_histogram", "rvn_shard_join_fetch_dev", "rvn_shard_chain_dev",
     "rvn_engine_map_fetch_dev", "rvn_shard_piles_dev", "rvn_poa_set_mode", "rvn_poa_fallback_windows", "rvn_poa_wide_windows", "rvn_pile_add_kmers_batch",
-    "rvn_test_low_complexity", "rvn_test_window_cut", "rvn_polish_round",
+    "rvn_test_low_complexity", "rvn_test_nw_breakpoints", "rvn_reads_attach_quality", "rvn_polish_fetch_layers", "rvn_poa_work", "rvn_reads_upload_codes", "rvn_polish_round",
     "rvn_engine_sketch", "rvn_engine_sketch_fetch", "rvn_engine_index_size", "rvn_engine_index_fetch",
     "rvn_engine_counters", "rvn_engine_num_stages", "rvn_engine_stage_name", "rvn_engine_stage_ms",
     "rvn_engine_reset_stats", "rvn_engine_set_timing", "rvn_engine_set_kernel_timing",
@@ -94,8 +94,13 @@ def lib():
     L.rvn_pile_add_kmers_batch.argtypes = [vp, vp, u32, u32, vp, vp, vp, vp]
     L.rvn_test_low_complexity.restype = i32
     L.rvn_test_low_complexity.argtypes = [vp, u32]
-    L.rvn_test_window_cut.argtypes = [vp, u32, vp, u32, vp, vp, u32, u32, u32, vp]
-    L.rvn_test_window_cut.restype = i32
+    L.rvn_test_nw_breakpoints.argtypes = [vp, u32, vp, u32, u32, u32, u32, u32, i32, u32, u32, i32, vp, vp, vp]
+    L.rvn_test_nw_breakpoints.restype = i32
+    L.rvn_reads_attach_quality.argtypes = [vp, vp, vp, vp, i32]
+    L.rvn_reads_upload_codes.argtypes = [vp, vp, vp, vp, u32, pp]
+    L.rvn_poa_work.argtypes = [vp, vp]
+    L.rvn_poa_work.restype = None
+    L.rvn_polish_fetch_layers.argtypes = [vp, vp, u64, C.POINTER(u64)]
     L.rvn_polish_round.argtypes = [vp, vp, vp, vp, vp, dbl, dbl, u32, i32, i32, i32, i32, vp, vp, vp, vp, vp]
     L.rvn_edit_distance_batch.argtypes = [vp, vp, vp, u32, vp, C.POINTER(dbl), C.POINTER(u64)]
     L.rvn_poa_consensus_batch.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, u32, i32, i32, i32, i32, vp, vp, vp, vp,
@@ -172,11 +177,32 @@ def device_count() -> int:
     return int(lib().rvn_device_count())
 
 
+class CodeSet:
+    """Just enough of a ReadSet for a Reads handle made from one-byte codes (Engine.upload_codes)."""
+
+    def __init__(self, lengths):
+        self.lengths = np.asarray(lengths, dtype=np.uint32)
+        self.n = int(self.lengths.shape[0])
+        self.ids = np.arange(self.n, dtype=np.uint32)
+
+    @property
+    def total_bases(self):
+        return int(self.lengths.astype(np.int64).sum())
+
+
 class Reads:
-    def __init__(self, engine: "Engine", rs):
+    def __init__(self, engine: "Engine", rs, codes=None):
         self.rs = rs
         self.engine = engine
         h = C.c_void_p()
+        if codes is not None:  # one-byte codes, packed on the device
+            off = np.zeros(rs.n + 1, dtype=np.uint64)
+            np.cumsum(rs.lengths.astype(np.uint64), out=off[1:])
+            flat = np.ascontiguousarray(codes, dtype=np.uint8)
+            assert flat.shape[0] == int(off[-1])
+            _check(lib().rvn_reads_upload_codes(engine._h, _p(flat), _p(off), None, rs.n, C.byref(h)))
+            self._h = h
+            return
         packed = np.ascontiguousarray(rs.packed, dtype=np.uint64)
         n_words = int(rs.word_offsets[-1])
         _check(lib().rvn_reads_upload(engine._h, _p(packed), n_words,
@@ -188,6 +214,16 @@ class Reads:
     @property
     def n(self):
         return self.rs.n
+
+    def attach_quality(self, quals, block_shift=0):
+        """Keep the reads' qualities in HBM for the polishing rounds: `quals` = list of per-read uint8 arrays of
+        Phred+33 bytes, one per 2^block_shift bases (0: per base; 6: biosoup block qualities + 33)."""
+        lens = np.array([len(q) for q in quals], dtype=np.uint64)
+        off = np.zeros(self.rs.n + 1, dtype=np.uint64)
+        np.cumsum(lens, out=off[1:])
+        flat = np.ascontiguousarray(np.concatenate([np.asarray(q, dtype=np.uint8) for q in quals])
+                                    if len(quals) else np.zeros(0, np.uint8))
+        _check(lib().rvn_reads_attach_quality(self.engine._h, self._h, _p(flat), _p(off), int(block_shift)))
 
     def close(self):
         if getattr(self, "_h", None):
@@ -275,6 +311,13 @@ class Engine:
 
     def upload(self, rs) -> Reads:
         return Reads(self, rs)
+
+    def upload_codes(self, code_arrays) -> Reads:
+        """Read set from one-byte code arrays (values 0..3), packed on the device (rvn_reads_upload_codes): how the
+        consensus of one polishing round becomes the target set of the next."""
+        lens = [int(len(c)) for c in code_arrays]
+        flat = np.concatenate([np.asarray(c, dtype=np.uint8) for c in code_arrays]) if lens else np.zeros(0, np.uint8)
+        return Reads(self, CodeSet(lens), codes=flat)
 
     # -- ram::MinimizerEngine interface -----------------------------------------------------
     def minimize(self, reads: Reads, first=0, last=None, minhash=False):
@@ -440,7 +483,7 @@ class Engine:
         out_len = np.zeros(nt, dtype=np.uint32)
         nw = np.zeros(nt, dtype=np.uint32)
         npol = np.zeros(nt, dtype=np.uint32)
-        stats = np.zeros(11, dtype=np.uint64)
+        stats = np.zeros(16, dtype=np.uint64)
         qa = qo = None
         if quals is not None:
             qo = np.zeros(len(quals) + 1, dtype=np.uint64)
@@ -456,6 +499,21 @@ class Engine:
         cons = [out[int(ooff[i]): int(ooff[i]) + int(out_len[i])].copy() for i in range(nt)]
         return cons, nw, npol, {"n_windows": int(stats[3]), "n_layers": int(stats[2])}
 
+    def poa_cells(self):
+        """DP work of the banded POA kernel since the last reset_stats (rvn_poa_work)."""
+        out = np.zeros(3, dtype=np.uint64)
+        lib().rvn_poa_work(self._h, _p(out))
+        return {"cells_full": int(out[0]), "cells_banded": int(out[1]), "calls": int(out[2])}
+
+    def polish_layers(self):
+        """Layer table of the last polishing round: uint32[n, 7] rows {window, read, first base in the oriented read,
+        bases, begin, end, rc} in racon's order (rvn_polish_fetch_layers)."""
+        n = C.c_uint64(0)
+        _check(lib().rvn_polish_fetch_layers(self._h, None, 0, C.byref(n)))
+        out = np.zeros((n.value, 7), dtype=np.uint32)
+        _check(lib().rvn_polish_fetch_layers(self._h, _p(out), n.value, C.byref(n)))
+        return out
+
     def polish_round(self, targets: Reads, reads: Reads, quals=None, q=0.0, err=0.3, w=500, trim=True, m=3, n=-5, g=-4):
         """quals: list of uint8 Phred+33 arrays (one per read) or None.  Returns (list of polished code arrays,
         ratio array, stats dict).  The engine must have k=15, w=5 (racon's mapping parameters)."""
@@ -465,7 +523,7 @@ class Engine:
         out = np.zeros(int(ooff[-1]) + 1, dtype=np.uint8)
         out_len = np.zeros(nt, dtype=np.uint32)
         ratio = np.zeros(nt, dtype=np.float64)
-        stats = np.zeros(11, dtype=np.uint64)
+        stats = np.zeros(16, dtype=np.uint64)
         qa = qo = None
         if quals is not None:
             qo = np.zeros(len(quals) + 1, dtype=np.uint64)
@@ -479,6 +537,9 @@ class Engine:
         for i, k2 in enumerate(("poa_ms", "map_ms", "host_ms", "total_ms")):
             st[k2] = float(stats[6 + i: 7 + i].view(np.float64)[0])
         st["n_dropped_layers"] = int(stats[10])
+        st["align_ms"] = float(stats[11:12].view(np.float64)[0])
+        st["n_aligned"], st["n_align_retries"] = int(stats[12]), int(stats[13])
+        st["align_band_cells"], st["align_store_bytes"] = int(stats[14]), int(stats[15])
         return cons, ratio, st
 
     # -- raven::Pile::AddKmers, batched ---------------------------------------------------------------
@@ -622,15 +683,21 @@ class Engine:
         lib().rvn_engine_set_timing(self._h, int(enabled))
 
 
-def test_window_cut(target, read, anchors_t, anchors_q, k, boundary):
-    """polish_cut.h::window_cut on one-byte codes (host code, works without a GPU): (ql, tl, qr, tr, n_nw)."""
-    target = np.ascontiguousarray(target, dtype=np.uint8)
-    read = np.ascontiguousarray(read, dtype=np.uint8)
-    at = np.ascontiguousarray(anchors_t, dtype=np.uint32)
-    aq = np.ascontiguousarray(anchors_q, dtype=np.uint32)
-    out = np.zeros(4, dtype=np.uint32)
-    rc = lib().rvn_test_window_cut(_p(target), target.shape[0], _p(read), read.shape[0], _p(at), _p(aq), at.shape[0], k,
-                                   int(boundary), _p(out))
-    if rc < 0:
-        raise ValueError("rvn_test_window_cut: invalid arguments")
-    return int(out[0]), int(out[1]), int(out[2]), int(out[3]), rc
+NW_REC_DTYPE = np.dtype([("first_t", "<u4"), ("first_q", "<u4"), ("last_t", "<u4"), ("last_q", "<u4"),
+                         ("grid", "<u2", (8,))])
+
+
+def test_nw_breakpoints(t_words, t_len, r_words, r_len, t_begin, n, q_begin, m, rc, w, k=64, force_r=0):
+    """nwpath.h stepped on the CPU (no GPU needed): the forward sweep's lane code for 64 emulated lanes + the
+    traceback.  Returns (records per window, exact distance, (k, lanes, R), status)."""
+    t_words = np.ascontiguousarray(t_words, dtype=np.uint64)
+    r_words = np.ascontiguousarray(r_words, dtype=np.uint64)
+    n_win = (t_begin + n - 1) // w - t_begin // w + 1
+    recs = np.zeros(n_win, dtype=NW_REC_DTYPE)
+    dist = np.zeros(1, dtype=np.uint32)
+    band = np.zeros(3, dtype=np.uint32)
+    rc_ = lib().rvn_test_nw_breakpoints(_p(t_words), t_len, _p(r_words), r_len, t_begin, n, q_begin, m, int(rc), w, k,
+                                        force_r, _p(recs), _p(dist), _p(band))
+    if rc_ < 0:
+        raise ValueError("rvn_test_nw_breakpoints: %d" % rc_)
+    return recs, int(dist[0]), tuple(int(x) for x in band), rc_

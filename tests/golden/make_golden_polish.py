@@ -47,9 +47,12 @@ def main():
     targets = seqio.pack_reads([draft])
     cons, ratio = oracle.polish_round(targets, rs, quals=quals, q=avg_q)
     cons_nq, ratio_nq = oracle.polish_round(targets, rs)
+    # the integer half of the round (mapping, best overlap, alignment path, breakpoints, layer rules): bit-exact target
+    layers = oracle.polish_layers(targets, rs, quals=quals, q=avg_q)
+    layers_nq = oracle.polish_layers(targets, rs)
     ed = lambda a: oracle.edit_distance(bytes(np.asarray(a, np.uint8) + 65), bytes(truth + 65))  # noqa: E731
     out = dict(draft=draft, avg_q=np.array([avg_q]), consensus=cons[0], ratio=np.array([ratio[0]]),
-               consensus_noqual=cons_nq[0], ratio_noqual=np.array([ratio_nq[0]]),
+               consensus_noqual=cons_nq[0], ratio_noqual=np.array([ratio_nq[0]]), layers=layers, layers_noqual=layers_nq,
                ed_draft=np.array([ed(draft)]), ed_consensus=np.array([ed(cons[0])]), ed_consensus_noqual=np.array([ed(cons_nq[0])]))
     np.savez_compressed(os.path.join(HERE, "lambda_polish.npz"), **out)
     print("wrote lambda_polish.npz", {k: (v.shape, v[:1]) for k, v in out.items()})

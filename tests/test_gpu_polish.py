@@ -1,7 +1,17 @@
-"""GPU polishing round (rvn_polish_round: device mapping + anchors -> windows -> POA kernel -> stitch) against the
-CPU restatement of racon's round (whole-overlap NW path -> CIGAR breakpoints).  Tolerance parity (north_star:
-'polished consensus within stated edit-distance tolerance'): ED(gpu, cpu) <= 0.2 % of the target + 10 and
-ED(gpu, truth) <= 1.1 x ED(cpu, truth) + 10 (measured: 0-1 edits apart with trimming, tools/eval_polish.py)."""
+"""GPU polishing round (rvn_polish_round: device mapping -> best overlap -> alignment path + breakpoints -> window layers
+-> POA kernels -> stitch) against the CPU restatement of racon's round.
+
+Two levels of parity:
+  * the integer half of the round — mapping, best overlap per read, the global alignment path of every read and racon's
+    breakpoints, the layer rules and the layer order — is BIT-EXACT: the table of window layers the device built
+    (rvn_polish_fetch_layers) equals the oracle's (oracle.polish_layers), row for row;
+  * the consensus is within the tolerance SURVEY.md §8(d) states (north_star: 'polished consensus within stated
+    edit-distance tolerance'): per target ED(gpu, cpu) <= 0.1 % of its length and ED(gpu, truth) <= 1.05 x
+    ED(cpu, truth) (rounded up to whole edits).  The only source of differences left is which of several equal-score
+    POA paths is taken."""
+import math
+import os
+
 import numpy as np
 import pytest
 
@@ -11,27 +21,62 @@ from tests import polish_util as pu2
 
 pytestmark = pytest.mark.gpu
 
+TOL_CPU = 0.001   # ED(gpu, cpu) <= 0.1 % of the length
+TOL_TRUTH = 1.05  # ED(gpu, truth) <= 1.05 x ED(cpu, truth)
+
 
 def _ed(a, b):
     return oracle.edit_distance(bytes(np.asarray(a, np.uint8) + 65), bytes(np.asarray(b, np.uint8) + 65))
 
 
+def _assert_tolerance(cons, ref, truth):
+    d = _ed(cons, ref)
+    assert d <= math.ceil(TOL_CPU * len(ref)), (d, len(ref))
+    ed_cpu, ed_gpu = _ed(ref, truth), _ed(cons, truth)
+    assert ed_gpu <= math.ceil(TOL_TRUTH * ed_cpu), (ed_cpu, ed_gpu)
+    return d, ed_cpu, ed_gpu
+
+
 @pytest.mark.parametrize("with_qual,n_targets", [(False, 1), (True, 1), (False, 3)])
-def test_polish_round_matches_cpu_within_tolerance(with_qual, n_targets):
+def test_polish_round_layers_bit_exact_and_consensus_within_tolerance(with_qual, n_targets):
     truths, drafts, targets, reads, quals = pu2.make_case(genome_len=24_000, coverage=25, read_len=2500, seed=7,
                                                          with_qual=with_qual, n_targets=n_targets)
     eng = hip.Engine(15, 5)
     td, rd = eng.upload(targets), eng.upload(reads)
     q = 10.0 if with_qual else 0.0
     cons, ratio, st = eng.polish_round(td, rd, quals=quals, q=q)
+    got_layers = eng.polish_layers()
+    want_layers = oracle.polish_layers(targets, reads, quals=quals, q=q)
+    assert got_layers.shape == want_layers.shape and np.array_equal(got_layers, want_layers)
+    assert got_layers.shape[0] == st["n_layers"] > 10 * st["n_windows"]
+    assert (got_layers[:, 6] == 1).any() and (got_layers[:, 6] == 0).any()  # both strands
+    assert st["n_aligned"] == st["n_reads_used"] and st["n_dropped_layers"] == 0
     ref, ref_ratio = oracle.polish_round(targets, reads, quals=quals, q=q)
     assert st["n_failed_windows"] == 0 and st["n_reads_used"] > 0.8 * reads.n
     for t in range(n_targets):
-        assert ratio[t] > 0.85 and abs(ratio[t] - ref_ratio[t]) < 0.1
-        ed_draft, ed_cpu, ed_gpu = _ed(drafts[t], truths[t]), _ed(ref[t], truths[t]), _ed(cons[t], truths[t])
-        assert ed_gpu < ed_draft, (ed_draft, ed_gpu)
-        assert ed_gpu <= 1.1 * ed_cpu + 10, (ed_draft, ed_cpu, ed_gpu)
-        assert _ed(cons[t], ref[t]) <= 0.002 * len(ref[t]) + 10, (len(ref[t]), _ed(cons[t], ref[t]))
+        assert ratio[t] > 0.85 and abs(ratio[t] - ref_ratio[t]) < 1e-9
+        assert _ed(cons[t], truths[t]) < _ed(drafts[t], truths[t])
+        _assert_tolerance(cons[t], ref[t], truths[t])
+
+
+def test_first_call_pilot_and_later_calls_give_the_same_layers():
+    """The band thresholds of the alignment stage come from a pilot sample on an engine's first round and from the
+    running error-rate estimate afterwards (fewer retries, narrower bands): the result never depends on them."""
+    truths, drafts, targets, reads, _ = pu2.make_case(genome_len=20_000, coverage=20, read_len=3000, seed=17)
+    eng = hip.Engine(15, 5)
+    td, rd = eng.upload(targets), eng.upload(reads)
+    cons1, _, st1 = eng.polish_round(td, rd)
+    lay1 = eng.polish_layers()
+    cons2, _, st2 = eng.polish_round(td, rd)
+    lay2 = eng.polish_layers()
+    assert np.array_equal(lay1, lay2) and np.array_equal(cons1[0], cons2[0])
+    assert st2["align_band_cells"] <= st1["align_band_cells"]
+    os.environ["RVN_NW_BUDGET_MB"] = "64"  # many small batches instead of one
+    try:
+        cons3, _, st3 = eng.polish_round(td, rd)
+    finally:
+        del os.environ["RVN_NW_BUDGET_MB"]
+    assert np.array_equal(eng.polish_layers(), lay1) and np.array_equal(cons3[0], cons1[0])
 
 
 def test_polish_two_rounds_and_low_quality_reads_are_dropped():
@@ -49,15 +94,36 @@ def test_polish_two_rounds_and_low_quality_reads_are_dropped():
     # quality threshold above every read's mean quality (12): no layer survives -> nothing is polished (racon)
     cons, ratio, st = eng.polish_round(eng.upload(targets), rd, quals=quals, q=20.0)
     assert st["n_layers"] == 0 and ratio[0] == 0.0 and np.array_equal(cons[0], drafts[0])
+    assert eng.polish_layers().shape[0] == 0
+
+
+def test_attached_block_qualities_equal_per_base_qualities():
+    """biosoup keeps one mean quality per 64 bases (block_quality) and racon only ever sees that mean: attaching the
+    block bytes to the read set once (rvn_reads_attach_quality, shift 6) gives the same round as handing in the
+    per-base expansion with every call."""
+    truths, drafts, targets, reads, _ = pu2.make_case(genome_len=16_000, coverage=20, read_len=2000, seed=23)
+    rng = np.random.default_rng(3)
+    blocks = [rng.integers(5, 20, size=(int(n) + 63) // 64).astype(np.uint8) + 33 for n in reads.lengths]
+    per_base = [np.repeat(b, 64)[:int(n)] for b, n in zip(blocks, reads.lengths)]
+    eng = hip.Engine(15, 5)
+    td, rd = eng.upload(targets), eng.upload(reads)
+    cons_a, ratio_a, st_a = eng.polish_round(td, rd, quals=per_base, q=11.0)
+    lay_a = eng.polish_layers()
+    rd.attach_quality(blocks, block_shift=6)
+    cons_b, ratio_b, st_b = eng.polish_round(td, rd, quals=None, q=11.0)
+    assert np.array_equal(eng.polish_layers(), lay_a) and st_a["n_layers"] == st_b["n_layers"]
+    assert 0 < st_a["n_layers"] < lay_a.shape[0] + 1 and np.array_equal(cons_a[0], cons_b[0]) and ratio_a[0] == ratio_b[0]
+    want = oracle.polish_layers(targets, reads, quals=per_base, q=11.0)
+    assert np.array_equal(lay_a, want)
 
 
 @pytest.mark.parametrize("with_qual", [True, False])
 def test_lambda_polish_matches_golden_fixture(with_qual):
     """The reference's own test data (RavenTest/data: ERA476754 reads, NC_001416): one polishing round of a seeded
     draft of lambda on the device vs the committed oracle result (tests/golden/lambda_polish.npz), with Raven's
-    block-mean qualities and its avg_q threshold (polish.cc:25-47) and without qualities."""
+    block-mean qualities and its avg_q threshold (polish.cc:25-47) and without qualities: layer table bit-exact,
+    consensus within the stated tolerance."""
     import importlib.util
-    import os
     golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
     spec = importlib.util.spec_from_file_location("make_golden_polish", os.path.join(golden, "make_golden_polish.py"))
     mg = importlib.util.module_from_spec(spec)
@@ -67,34 +133,9 @@ def test_lambda_polish_matches_golden_fixture(with_qual):
     eng = hip.Engine(15, 5)
     cons, ratio, st = eng.polish_round(eng.upload(seqio.pack_reads([draft])), eng.upload(rs),
                                        quals=quals if with_qual else None, q=avg_q if with_qual else 0.0)
-    if not with_qual:
-        # real reads without the quality filter need more than the 128-column band for some windows (256 columns or the
-        # full-matrix kernel; with small chunks the latter are collected and run in one final batch): no byte may change
-        assert eng.poa_fallback_windows() >= 1
-        eng.polish_set_chunk_windows(16)
-        cons2, ratio2, _ = eng.polish_round(eng.upload(seqio.pack_reads([draft])), eng.upload(rs))
-        assert np.array_equal(cons2[0], cons[0]) and ratio2[0] == ratio[0]
+    want_layers = fx["layers" if with_qual else "layers_noqual"]
+    got_layers = eng.polish_layers()
+    assert got_layers.shape == want_layers.shape and np.array_equal(got_layers, want_layers)
     ref = fx["consensus" if with_qual else "consensus_noqual"]
-    ed_ref = int(fx["ed_consensus" if with_qual else "ed_consensus_noqual"][0])
     assert st["n_failed_windows"] == 0 and ratio[0] == 1.0
-    d = _ed(cons[0], ref)
-    assert d <= 0.0025 * len(ref) + 10, (d, len(ref), len(cons[0]))  # measured 35 (qual) / 77-90 (no qual) of 47.8 kb
-    assert _ed(cons[0], truth) <= 1.1 * ed_ref + 10
-
-
-def test_chunked_pipeline_gives_the_same_round():
-    """The round is processed in window chunks (host cuts of chunk i+1 overlap the POA of chunk i): the chunk size
-    must not change a byte, for several targets and with the quality filter."""
-    truths, drafts, targets, reads, quals = pu2.make_case(genome_len=30_000, coverage=20, read_len=2500, seed=13,
-                                                         with_qual=True, n_targets=2)
-    eng = hip.Engine(15, 5)
-    td, rd = eng.upload(targets), eng.upload(reads)
-    assert eng.polish_set_chunk_windows(0) == 16384
-    ref, ref_ratio, st0 = eng.polish_round(td, rd, quals=quals, q=10.0)
-    for chunk in (1, 7, 32):
-        eng.polish_set_chunk_windows(chunk)
-        cons, ratio, st = eng.polish_round(td, rd, quals=quals, q=10.0)
-        assert np.allclose(ratio, ref_ratio) and st["n_layers"] == st0["n_layers"] and st["n_windows"] == st0["n_windows"]
-        assert st["n_reads_used"] == st0["n_reads_used"]
-        for a, b in zip(cons, ref):
-            assert np.array_equal(a, b)
+    _assert_tolerance(cons[0], ref, truth)

@@ -1,0 +1,148 @@
+"""The alignment-path stage of a polishing round (raven_amd/csrc/nwpath.h: banded Myers forward sweep with stored
+vertical deltas + traceback + racon's find_breaking_points) against the oracle's plain-DP path and breakpoints.
+
+No GPU needed: rvn_test_nw_breakpoints drives the SAME __host__ __device__ code the kernels execute — the forward
+sweep's per-lane step for 64 emulated lanes (ring reuse, systolic carries through the emulated shuffles) and the
+single-thread traceback — so the arithmetic, the band geometry, the store layout and the tie rule are all pinned here;
+the GPU tests (tests/test_gpu_polish.py) then only have to show that the wave executes it the same way."""
+import numpy as np
+import pytest
+
+from oracle import oracle
+from raven_amd import hip, seqio, synth
+
+
+def _pack(codes):
+    rs = seqio.pack_reads([np.asarray(codes, dtype=np.uint8)])
+    return np.concatenate([rs.packed, np.zeros(2, np.uint64)])
+
+
+def _oriented(read_codes, rc):
+    return (3 - read_codes[::-1]) if rc else read_codes
+
+
+def _check(target, read, t_begin, n, q_begin, m, rc, w, k=64, force_r=0):
+    """read: codes as stored (original orientation); the alignment uses its reverse complement when rc."""
+    tw, rw = _pack(target), _pack(read)
+    recs, dist, band, status = hip.test_nw_breakpoints(tw, len(target), rw, len(read), t_begin, n, q_begin, m, rc, w,
+                                                       k=k, force_r=force_r)
+    assert status == 0
+    rq = _oriented(np.asarray(read, dtype=np.uint8), rc)
+    want, want_dist = oracle.nw_breakpoints(rq[q_begin:q_begin + m], np.asarray(target[t_begin:t_begin + n], np.uint8),
+                                            q_begin, t_begin, w)
+    assert dist == want_dist
+    got = []
+    for x, r in enumerate(recs):
+        if r["first_t"] == 0xFFFFFFFF:
+            continue
+        assert r["first_t"] // w == t_begin // w + x  # record x belongs to window x of the span
+        got.append((int(r["first_t"]), int(r["first_q"])))
+        got.append((int(r["last_t"]), int(r["last_q"])))
+        # band guide: monotone read offsets inside the piece, at the fixed target positions the path covers
+        g = [int(v) for v in r["grid"] if v != 0xFFFF]
+        assert g == sorted(g) and all(v <= r["last_q"] - r["first_q"] for v in g)
+    assert got == [tuple(int(v) for v in p) for p in want]
+    return dist, band
+
+
+def _noisy_pair(rng, n, sub, ins, dele):
+    t = rng.integers(0, 4, size=n, dtype=np.uint8)
+    q = synth.mutate(rng, t, sub, ins, dele)
+    return t, q
+
+
+@pytest.mark.parametrize("rc", [0, 1])
+def test_breakpoints_match_oracle_ont_like(rc):
+    rng = np.random.default_rng(100 + rc)
+    for trial in range(6):
+        n = int(rng.integers(700, 3000))
+        t, q = _noisy_pair(rng, n, 0.04, 0.03, 0.03)
+        # embed the spans inside longer sequences at unaligned offsets
+        tl, ql = int(rng.integers(0, 700)), int(rng.integers(0, 90))
+        target = np.concatenate([rng.integers(0, 4, tl, dtype=np.uint8), t, rng.integers(0, 4, 77, dtype=np.uint8)])
+        read_o = np.concatenate([rng.integers(0, 4, ql, dtype=np.uint8), q, rng.integers(0, 4, 33, dtype=np.uint8)])
+        read = _oriented(read_o, rc)  # stored orientation: reverse complement when the overlap is on the other strand
+        dist, band = _check(target, read, tl, len(t), ql, len(q), rc, 500)
+        assert band[0] >= dist and dist > 0.05 * n
+
+
+def test_low_error_and_identical():
+    rng = np.random.default_rng(7)
+    t, q = _noisy_pair(rng, 4000, 0.001, 0.002, 0.002)
+    _check(t, q, 0, len(t), 0, len(q), 0, 500)
+    t = rng.integers(0, 4, 1500, dtype=np.uint8)
+    dist, _ = _check(t, t.copy(), 0, 1500, 0, 1500, 0, 500)
+    assert dist == 0
+
+
+def test_band_doubling_and_blocks_per_lane():
+    """A first threshold far below the distance is doubled until exact; every blocks-per-lane variant of the forward
+    kernel (R = 1, 2, 4, 8) gives the same path."""
+    rng = np.random.default_rng(21)
+    t, q = _noisy_pair(rng, 2600, 0.06, 0.05, 0.05)
+    d1, b1 = _check(t, q, 0, len(t), 0, len(q), 0, 500, k=8)
+    assert b1[0] >= d1 and b1[0] <= max(4 * d1, 64)
+    for R in (2, 4, 8):
+        d, b = _check(t, q, 0, len(t), 0, len(q), 0, 500, k=8, force_r=R)
+        assert d == d1 and b[2] == R
+
+
+def test_length_difference_and_indel_bursts():
+    rng = np.random.default_rng(33)
+    t = rng.integers(0, 4, 2500, dtype=np.uint8)
+    q = np.concatenate([t[:800], rng.integers(0, 4, 300, dtype=np.uint8), t[800:1700], t[1950:]])  # +300 / -250
+    _check(t, q, 0, len(t), 0, len(q), 0, 500)
+    _check(q, t, 0, len(q), 0, len(t), 0, 500)
+    # very different lengths: the band is one-sided
+    _check(t[:400], np.concatenate([t[:400], rng.integers(0, 4, 900, dtype=np.uint8)]), 0, 400, 0, 1300, 0, 100)
+    _check(np.concatenate([t[:400], rng.integers(0, 4, 900, dtype=np.uint8)]), t[:400], 0, 1300, 0, 400, 0, 100)
+
+
+def test_small_and_degenerate_spans():
+    rng = np.random.default_rng(5)
+    for n, m in [(1, 1), (1, 7), (9, 1), (63, 64), (64, 64), (65, 63), (128, 129), (5, 200)]:
+        t = rng.integers(0, 4, n, dtype=np.uint8)
+        q = rng.integers(0, 4, m, dtype=np.uint8)
+        _check(t, q, 0, n, 0, m, 0, 50)
+    h = np.zeros(300, dtype=np.uint8)  # homopolymers: every path is optimal, the tie rule decides
+    _check(h, h[:250], 0, 300, 0, 250, 0, 100)
+    _check(h[:250], h, 0, 250, 0, 300, 0, 100)
+
+
+def test_unrelated_sequences_and_window_sizes():
+    rng = np.random.default_rng(9)
+    t = rng.integers(0, 4, 900, dtype=np.uint8)
+    q = rng.integers(0, 4, 1000, dtype=np.uint8)
+    _check(t, q, 0, 900, 0, 1000, 0, 500)
+    t, q = _noisy_pair(rng, 1800, 0.03, 0.03, 0.03)
+    for w in (37, 64, 500, 1023):
+        _check(t, q, 0, len(t), 0, len(q), 0, w)
+    for tb in (0, 1, 499, 500, 501):  # spans starting at / around a window boundary
+        target = np.concatenate([rng.integers(0, 4, tb, dtype=np.uint8), t])
+        _check(target, q, tb, len(t), 0, len(q), 0, 500)
+
+
+def test_real_reads_lambda(lambda_reads, lambda_genome):
+    """The reference's own test data (RavenTest/data): the first reads against the slices of NC_001416 they map to."""
+    eng = oracle.Engine(15, 5)
+    eng.minimize(lambda_genome, minhash=False)
+    eng.filter(0.001)
+    done = 0
+    for r in range(lambda_reads.n):
+        if lambda_reads.lengths[r] > 4200:
+            continue
+        ovl = eng.map(lambda_reads, r, avoid_equal=False, avoid_symmetric=False, minhash=False)["overlaps"]
+        if len(ovl) == 0:
+            continue
+        o = max(ovl, key=lambda x: max(int(x["lhs_end"]) - int(x["lhs_begin"]), int(x["rhs_end"]) - int(x["rhs_begin"])))
+        read = lambda_reads.codes(r)
+        target = lambda_genome.codes(0)
+        rc = int(o["strand"]) == 0
+        qlen = len(read)
+        q_begin = qlen - int(o["lhs_end"]) if rc else int(o["lhs_begin"])
+        _check(target, read, int(o["rhs_begin"]), int(o["rhs_end"]) - int(o["rhs_begin"]), q_begin,
+               int(o["lhs_end"]) - int(o["lhs_begin"]), int(rc), 500)
+        done += 1
+        if done == 3:
+            break
+    assert done == 3
