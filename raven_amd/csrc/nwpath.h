@@ -3,49 +3,53 @@
 // for every window of w target bases the first and the last aligned ('M') pair; call site of the whole round:
 // RavenLib/src/polish.cc:43-51).  The polishing front end (polish.hip) runs this for the best overlap of every read.
 //
-// Formulation for the device (kernels in nwpath.hip; everything here is __host__ __device__ so that the very same
-// code can be stepped lane by lane on the CPU, rvn_test_nw_breakpoints):
-//   forward   Myers' bit-vector blocks over a DIAGONAL band that contains every alignment of cost <= k
-//             (offsets row - column in [-lo, hi], lo + hi = k - |n - m| + |n - m|): one wave per alignment, lanes =
-//             64-row blocks (R per lane) reused as a ring, systolic over the columns exactly like the distance
-//             kernel (edit_distance.hip) — but every block update also stores its (Pv, Mv) vertical-delta words and
-//             its bottom score, time-major ([step][lane][r]) so that the 64 lanes of a step write one contiguous run.
-//             The result is exact iff it is <= k (edlib's criterion); otherwise the job is redone with 2k.
-//   traceback one thread per alignment walks from (n, m) to (0, 0).  Equal bases always take the diagonal
-//             (D(i,j) = D(i-1,j-1) when the bases match, so no score is needed); at a mismatch the three neighbour
-//             scores come from the stored words (block bottom score -/+ popcounts of the deltas above the row).
-//             Preference on ties: diagonal, then query-base-only ('I'), then target-base-only ('D') — the rule of the
-//             CPU restatement (oracle NwPath); edlib documents no tie rule for paths found by its Hirschberg split,
-//             any optimal path is "the" edlib path.  Banded values equal the full-matrix values on every cell the
-//             walk can take (each lies on an optimal alignment, which the band contains, and a too-large banded value
-//             of a cell that is NOT a valid predecessor stays invalid), so the path is the full-matrix path.
-//             The walk emits no CIGAR: it folds find_breaking_points in and writes, per window, the first / last
-//             aligned pair and the read offsets at eight fixed target positions (the POA band guide).
+// Formulation for the device (kernel in nwpath.hip; everything here is __host__ __device__ so that the very same
+// code can be stepped lane by lane on the CPU, rvn_test_nw_breakpoints).  One wave owns one alignment from start to end:
+//   sweep     Myers' bit-vector blocks over a DIAGONAL band that contains every alignment of cost <= k (offsets
+//             row - column in [-lo, hi]): lanes = 64-row blocks (R per lane) reused as a ring, systolic over the
+//             columns exactly like the distance kernel (edit_distance.hip).  The result is exact iff it is <= k
+//             (edlib's criterion); otherwise k is doubled and the sweep repeated, in the kernel.
+//   pass 1    one sweep over all columns that keeps only a CHECKPOINT of the band every kNwSeg columns
+//             ((Pv, Mv, bottom score) of every block inside the band at that column): O(m / kNwSeg x band) memory
+//             per alignment instead of O(m x band) — whole-matrix stores made the stage quadratic in the read length.
+//   walk      the path is walked backwards segment by segment: the wave re-sweeps the kNwSeg columns of a segment from
+//             its checkpoint, this time storing every block update into a small per-wave scratch, then walks through
+//             them.  Equal bases always take the diagonal (D(i,j) = D(i-1,j-1) when the bases match, so no score is
+//             needed); at a mismatch the neighbour scores come from the stored words (block bottom score -/+ popcounts
+//             of the deltas below the row).  Preference on ties: diagonal, then query-base-only ('I'), then
+//             target-base-only ('D') — the rule of the CPU restatement (oracle NwPath); edlib documents no tie rule for
+//             paths found by its Hirschberg split, any optimal path is "the" edlib path.  Banded values equal the
+//             full-matrix values on every cell the walk can take (each lies on an optimal alignment, which the band
+//             contains, and a too-large banded value of a cell that is NOT a valid predecessor stays invalid), so the
+//             path is the full-matrix path.  The walk emits no CIGAR: it folds find_breaking_points in and writes, per
+//             window, the first / last aligned pair and the read offsets at eight fixed target positions (POA band guide).
 #pragma once
 
 #include "myers.h"
 
 namespace rvn {
 
+constexpr int kNwSeg = 256;  // columns per segment (checkpoint spacing)
+
 // rows = target span (pattern, forward strand), columns = read span in the target's orientation (text)
 struct NwJob {
   u64 t_word;   // first word of the target in the packed target set
   u64 r_word;   // first word of the read in the packed read set
-  u64 store;    // first slot of this job in the (Pv, Mv) / score arrays
+  u64 ckpt;     // first checkpoint slot of this job
   u64 bp_off;   // first window record of this job
   u32 t_begin, n;  // target span [t_begin, t_begin + n)
   u32 q_begin, m;  // read span [q_begin, q_begin + m) in the orientation of the target
   u32 r_len;       // length of the read
   u32 rc;          // 1: the read is reverse-complemented (overlap on the opposite strand)
-  u32 k;           // cost threshold of this attempt (>= |n - m|)
-  u32 lo, hi;      // band: -lo <= row - column <= hi
-  u32 L;           // ring lanes in use (<= 64)
+  u32 k;           // first cost threshold (>= |n - m|); doubled in the kernel up to kcap
+  u32 kcap;        // largest threshold this launch may use (ring of <= 64 lanes with R blocks each, checkpoint rows)
+  u32 ckpt_nb;     // checkpoint row stride: blocks inside the band at kcap
   u32 R;           // blocks per lane
   u32 read, target;  // indices in their sets
   u32 n_windows;     // windows touched by the target span
   u32 pad_;
 };
-static_assert(sizeof(NwJob) == 96, "NwJob layout");
+static_assert(sizeof(NwJob) == 88, "NwJob layout");
 
 struct NwWindowRec {  // per (job, window): racon's breakpoint pair + band guide
   u32 first_t, first_q;  // first aligned pair of the window (target / oriented read position); first_t == ~0: none
@@ -57,6 +61,12 @@ static_assert(sizeof(NwWindowRec) == 32, "NwWindowRec layout");
 
 constexpr u32 kNwInf = 0x3FFFFFFFu;
 
+// All row / column / block / step indices fit 32 bits (spans are shorter than 2^31 bases): plain ints keep the
+// kernels' register count down; only final addresses are computed in 64 bits.
+struct NwBand {  // diagonal band of threshold k: -lo <= row - column <= hi; L ring lanes
+  int lo, hi, nb, n_super;
+  int L;
+};
 __host__ __device__ inline u32 nw_band_lo(u32 n, u32 m, u32 k) {  // most negative offset: (k - |d|) / 2 (+ |d| if m > n)
   const u32 d = n > m ? n - m : m - n;
   return (k - d) / 2 + (m > n ? d : 0u);
@@ -69,30 +79,59 @@ __host__ __device__ inline u32 nw_band_hi(u32 n, u32 m, u32 k) {
 __host__ __device__ inline u32 nw_ring_lanes(u32 lo, u32 hi, u32 R) {
   const u64 num = 64ULL * R + lo + hi;
   const u64 den = 64ULL * R + 1;
-  return static_cast<u32>((num + den - 1) / den);
+  const u64 l = (num + den - 1) / den;
+  return static_cast<u32>(l < 1 ? 1 : l);
 }
-__host__ __device__ inline u64 nw_store_slots(u32 n, u32 m, u32 L, u32 R) {
-  const u64 nb = (static_cast<u64>(n) + 63) >> 6;
-  const u64 n_super = (nb + R - 1) / R;
-  return (static_cast<u64>(m) + n_super + 1) * L * R;
+__host__ __device__ inline NwBand nw_band(u32 n, u32 m, u32 k, u32 R) {
+  NwBand B;
+  B.lo = static_cast<int>(nw_band_lo(n, m, k));
+  B.hi = static_cast<int>(nw_band_hi(n, m, k));
+  B.nb = static_cast<int>((static_cast<u64>(n) + 63) >> 6);
+  B.n_super = (B.nb + static_cast<int>(R) - 1) / static_cast<int>(R);
+  B.L = static_cast<int>(nw_ring_lanes(static_cast<u32>(B.lo), static_cast<u32>(B.hi), R));
+  return B;
 }
 // first / last column at which block b is inside the band
-__host__ __device__ inline long long nw_jin(long long b, long long hi) {
-  const long long j = 64 * b + 1 - hi;
+__host__ __device__ inline int nw_jin(int b, int hi) {
+  const int j = 64 * b + 1 - hi;
   return j < 1 ? 1 : j;
 }
-__host__ __device__ inline long long nw_jout(long long b, long long lo) { return 64 * b + 64 + lo; }
-__host__ __device__ inline u64 nw_slot(long long b, long long j, u32 L, u32 R) {
-  const long long s = b / R;
-  return (static_cast<u64>(j + s) * L + static_cast<u64>(s % L)) * R + static_cast<u64>(b % R);
+__host__ __device__ inline int nw_jout(int b, int lo) { return 64 * b + 64 + lo; }
+// first / last block inside the band at column j
+__host__ __device__ inline int nw_bfirst(int j, int lo) {
+  const int x = j - 64 - lo;  // smallest b with 64 b + 64 + lo >= j
+  return x <= 0 ? 0 : (x + 63) >> 6;
 }
+__host__ __device__ inline int nw_blast(int j, int hi, int nb) {
+  const int b = (j + hi - 1) >> 6;  // largest b with 64 b + 1 - hi <= j  (j >= 1, hi >= 0)
+  return b < nb - 1 ? b : nb - 1;
+}
+// blocks per checkpoint row at threshold k
+__host__ __device__ inline u32 nw_ckpt_blocks(u32 n, u32 m, u32 k) {
+  return (nw_band_lo(n, m, k) + nw_band_hi(n, m, k)) / 64 + 3;
+}
+__host__ __device__ inline u64 nw_ckpt_slots(u32 m, u32 ckpt_nb) {
+  return (static_cast<u64>(m) / kNwSeg + 1) * ckpt_nb;
+}
+// rows (systolic steps) of the per-wave segment scratch; one row = 64 lanes x R entries
+__host__ __device__ constexpr u32 nw_seg_rows() { return kNwSeg + 64 + kNwSeg / 64 + 6; }
 
 struct NwPm {
   u64 pv, mv;
 };
 
-// One lane of the forward sweep.  The kernel (and the CPU stepper) calls step(t, ...) for t = 0 .. m + n_super with
-// the producer lane's (hout_last, score_last) of the previous step.
+// Where a sweep keeps block states.
+struct NwStore {
+  NwPm* ck_pm;   // checkpoints of the job: [column / kNwSeg][block - bfirst(column)], stride ckpt_nb
+  int* ck_sc;
+  u32 ckpt_nb;
+  NwPm* seg_pm;  // scratch of the segment being walked: [step - t0][lane][r]
+  int* seg_sc;
+};
+
+// One lane of a sweep over columns (j0, j_end] of the band.  The kernel (and the CPU stepper) calls step(t, ...) for
+// t = t0 .. t1 with the producer lane's (hout_last, score_last) of the previous step.
+// mode 0: pass 1 — every kNwSeg-th column is checkpointed;  mode 1: segment — every block update goes to the scratch.
 template <int R>
 struct NwLane {
   const u64* a_words;
@@ -100,19 +139,20 @@ struct NwLane {
   u64 a_base, b_base;
   u32 n, m;
   bool rc;
-  long long lo, hi, nb, n_super;
-  int L, lane;
-  NwPm* st_pm;
-  int* st_sc;
+  NwBand B;
+  int lane, mode;
+  int j0, j_end, t0;
+  NwStore st;
   u64 Pv[R], Mv[R], peq[R][4];
   int score[R];
-  long long s;
+  int s;
   bool fresh;
   TextCursor tc;
   int hout_last, score_last;
   u32 result;  // D(n, m) + 1 on the one lane that computes it
 
-  __host__ __device__ void init(const NwJob& J, const u64* t_words, const u64* r_words, NwPm* pm, int* sc, int lane_) {
+  __host__ __device__ void init(const NwJob& J, const u64* t_words, const u64* r_words, const NwBand& band,
+                                const NwStore& store, int lane_) {
     a_words = t_words + J.t_word;
     a_base = J.t_begin;
     n = J.n;
@@ -120,36 +160,47 @@ struct NwLane {
     rc = J.rc != 0;
     m = J.m;
     b_base = rc ? static_cast<u64>(J.r_len) - J.q_begin - J.m : J.q_begin;
-    lo = J.lo;
-    hi = J.hi;
-    nb = (static_cast<long long>(n) + 63) >> 6;
-    n_super = (nb + R - 1) / R;
-    L = static_cast<int>(J.L);
+    B = band;
+    st = store;
     lane = lane_;
-    st_pm = pm + J.store;
-    st_sc = sc + J.store;
-    s = lane < L ? lane : n_super;  // lanes beyond the ring never work
+  }
+
+  // first / last step of a sweep over columns (j0, j_end]
+  __host__ __device__ static int sweep_t0(const NwBand& B, int j0) { return j0 + 1 + nw_bfirst(j0 + 1, B.lo) / R; }
+  __host__ __device__ static int sweep_t1(const NwBand& B, int j_end) { return j_end + nw_blast(j_end, B.hi, B.nb) / R; }
+
+  __host__ __device__ void begin_sweep(int j0_, int j_end_, int mode_) {
+    j0 = j0_;
+    j_end = j_end_;
+    mode = mode_;
+    t0 = sweep_t0(B, j0);
+    s = lane < B.L ? lane : B.n_super;  // lanes beyond the ring never work
+    while (s < B.n_super) {  // super-blocks that left the band before the sweep begins
+      const int last_b = s * R + R - 1 < B.nb ? s * R + R - 1 : B.nb - 1;
+      if (nw_jout(last_b, B.lo) < j0 + 1) s += B.L;
+      else break;
+    }
     fresh = true;
     hout_last = 1;
     score_last = 0;
     result = 0;
   }
 
-  __host__ __device__ void step(long long t, int hin_prev, int score_prev) {
-    while (s < n_super) {  // retire finished super-blocks (ring advance)
-      const long long last_b = s * R + R - 1 < nb ? s * R + R - 1 : nb - 1;
-      const long long jout = nw_jout(last_b, lo);
-      if (t - s > (jout < m ? jout : m)) {
-        s += L;
+  __host__ __device__ void step(int t, int hin_prev, int score_prev) {
+    while (s < B.n_super) {  // retire finished super-blocks (ring advance)
+      const int last_b = s * R + R - 1 < B.nb ? s * R + R - 1 : B.nb - 1;
+      const int jout = nw_jout(last_b, B.lo);
+      if (t - s > (jout < j_end ? jout : j_end)) {
+        s += B.L;
         fresh = true;
       } else {
         break;
       }
     }
-    if (s >= n_super) return;
-    const long long j = t - s;
-    const long long b0 = s * R;
-    if (j < nw_jin(b0, hi) || j > m) return;
+    if (s >= B.n_super) return;
+    const int j = t - s;
+    const int b0 = s * R;
+    if (j <= j0 || j < nw_jin(b0, B.hi) || j > j_end) return;
     if (fresh) {
 #pragma unroll
       for (int r = 0; r < R; ++r) load_peq(a_words, a_base, n, static_cast<u32>(b0 + r), peq[r]);
@@ -158,24 +209,32 @@ struct NwLane {
     }
     const unsigned c = tc.get(j);
     // producer block b0-1 (previous lane of the ring): inside the band at column j iff j <= jout(b0 - 1)
-    const bool prod_active = b0 > 0 && j <= nw_jout(b0 - 1, lo);
+    const bool prod_active = b0 > 0 && j <= nw_jout(b0 - 1, B.lo);
     int hin = prod_active ? hin_prev : 1;
     int above_prev_col = prod_active ? score_prev - hin_prev : score_prev;  // score of block b-1 at column j-1
-    const u64 slot0 = (static_cast<u64>(t) * L + static_cast<u64>(lane)) * R;
+    const u64 seg_slot0 = (static_cast<u64>(t - t0) * B.L + static_cast<u64>(lane)) * R;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      const long long b = b0 + r;
-      if (b >= nb) break;
-      const long long jin = nw_jin(b, hi);
+      const int b = b0 + r;
+      if (b >= B.nb) break;
+      const int jin = nw_jin(b, B.hi);
       if (j < jin) break;  // this and all lower blocks are still below the band
-      if (j > nw_jout(b, lo)) {  // retired above the band: the block below sees the +1 boundary
+      if (j > nw_jout(b, B.lo)) {  // retired above the band: the block below sees the +1 boundary
         hin = 1;
         continue;
       }
-      if (j == jin) {
-        Pv[r] = ~0ULL;
-        Mv[r] = 0;
-        score[r] = jin == 1 ? static_cast<int>(64 * (b + 1)) : above_prev_col + 64;
+      if (j == (jin > j0 + 1 ? jin : j0 + 1)) {  // first column of this block in this sweep
+        if (jin <= j0) {  // inside the band before the sweep began: resume from the checkpoint of column j0
+          const u64 cs = static_cast<u64>(j0 / kNwSeg) * st.ckpt_nb + static_cast<u64>(b - nw_bfirst(j0, B.lo));
+          const NwPm v = st.ck_pm[cs];
+          Pv[r] = v.pv;
+          Mv[r] = v.mv;
+          score[r] = st.ck_sc[cs];
+        } else {  // enters the band here: edlib's all-(+1) upper bound
+          Pv[r] = ~0ULL;
+          Mv[r] = 0;
+          score[r] = jin == 1 ? static_cast<int>(64 * (b + 1)) : above_prev_col + 64;
+        }
       }
       const int old = score[r];
       const u64 eq = c == 0 ? peq[r][0] : (c == 1 ? peq[r][1] : (c == 2 ? peq[r][2] : peq[r][3]));
@@ -183,9 +242,15 @@ struct NwLane {
       score[r] = old + hout;
       above_prev_col = old;
       hin = hout;
-      st_pm[slot0 + r] = NwPm{Pv[r], Mv[r]};
-      st_sc[slot0 + r] = score[r];
-      if (b == nb - 1 && j == m) {
+      if (mode == 1) {
+        st.seg_pm[seg_slot0 + r] = NwPm{Pv[r], Mv[r]};
+        st.seg_sc[seg_slot0 + r] = score[r];
+      } else if (j % kNwSeg == 0) {
+        const u64 cs = static_cast<u64>(j / kNwSeg) * st.ckpt_nb + static_cast<u64>(b - nw_bfirst(j, B.lo));
+        st.ck_pm[cs] = NwPm{Pv[r], Mv[r]};
+        st.ck_sc[cs] = score[r];
+      }
+      if (b == B.nb - 1 && j == m) {
         // D[n][m] = bottom score of the last block minus the vertical deltas of the padded rows
         const u32 used = n - static_cast<u32>(64 * b);
         const u64 padmask = used >= 64 ? 0ULL : ~((1ULL << used) - 1ULL);
@@ -197,48 +262,108 @@ struct NwLane {
   }
 };
 
-// D(x, y) of the banded matrix (x rows of the target span, y columns of the read span); kNwInf outside the band
-__host__ __device__ inline u32 nw_cell(const NwJob& J, const NwPm* __restrict__ pm, const int* __restrict__ sc, long long x,
-                                       long long y) {
-  if (x == 0) return static_cast<u32>(y);
-  if (y == 0) return static_cast<u32>(x);
-  const long long b = (x - 1) >> 6;
-  if (y < nw_jin(b, J.hi) || y > nw_jout(b, J.lo)) return kNwInf;
-  const u64 slot = J.store + nw_slot(b, y, J.L, J.R);
-  const NwPm v = pm[slot];
-  const unsigned bit = static_cast<unsigned>((x - 1) & 63);
-  const u64 above = bit == 63 ? 0ULL : (~0ULL << (bit + 1));  // rows of the block below row x
-  return static_cast<u32>(sc[slot] - static_cast<int>(RVN_POPC64(v.pv & above)) + static_cast<int>(RVN_POPC64(v.mv & above)));
-}
-
-// Walks the optimal path of job J backwards and writes one NwWindowRec per window of the target span.
-// `distance` = D(n, m) from the forward sweep (exact).  Returns 0, or 1 when the walk did not end with cost 0 (which
-// would mean the stored band is inconsistent — reported, never ignored).
-__host__ __device__ inline int nw_traceback(const NwJob& J, const u64* __restrict__ t_words_all,
-                                            const u64* __restrict__ r_words_all, const NwPm* __restrict__ pm,
-                                            const int* __restrict__ sc, u32 distance, u32 w,
-                                            NwWindowRec* __restrict__ recs_all) {
-  const u64* tw = t_words_all + J.t_word;
-  const u64* rw = r_words_all + J.r_word;
-  NwWindowRec* recs = recs_all + J.bp_off;
-  const u32 win0 = J.t_begin / w;
-  for (u32 x = 0; x < J.n_windows; ++x) {
-    NwWindowRec e;
-    e.first_t = e.first_q = e.last_t = e.last_q = 0xFFFFFFFFu;
-    for (int g = 0; g < 8; ++g) e.grid[g] = 0xFFFFu;
-    recs[x] = e;
-  }
-  long long i = J.n, j = J.m;
-  u32 cur = distance;
-  // state of the window being walked through (windows are visited from the last to the first)
-  u32 cw = 0xFFFFFFFFu;
-  bool have = false;
-  u32 first_t = 0, first_q = 0, last_t = 0, last_q = 0;
+// The backward walk, resumable segment by segment.
+struct NwWalker {
+  // job
+  const u64* tw;
+  const u64* rw;
+  u32 t_begin, q_begin, r_len, w, win0, R;
+  bool rc;
+  NwWindowRec* recs;
+  // band + stores of the segment currently in the scratch
+  NwBand B;
+  NwStore st;
+  int seg_j0, seg_t0;
+  // position
+  int i, j;
+  u32 cur;
+  // window being walked through (windows are visited from the last to the first)
+  u32 cw;
+  bool have;
+  u32 first_t, first_q, last_t, last_q;
   u32 gq[8];
-  int gx = -1;
-  u32 gt = 0;
-  auto flush = [&]() {
-    if (cw == 0xFFFFFFFFu) return;
+  int gx;
+  u32 gt;
+  // one-word caches of the two sequences
+  u64 t_wi, t_wv, q_wi, q_wv;
+
+  __host__ __device__ void init(const NwJob& J, const u64* t_words_all, const u64* r_words_all, const NwBand& band,
+                                const NwStore& store, u32 distance, u32 w_, NwWindowRec* recs_all) {
+    tw = t_words_all + J.t_word;
+    rw = r_words_all + J.r_word;
+    t_begin = J.t_begin;
+    q_begin = J.q_begin;
+    r_len = J.r_len;
+    w = w_;
+    win0 = J.t_begin / w_;
+    R = J.R;
+    rc = J.rc != 0;
+    recs = recs_all + J.bp_off;
+    B = band;
+    st = store;
+    i = static_cast<int>(J.n);
+    j = static_cast<int>(J.m);
+    cur = distance;
+    cw = 0xFFFFFFFFu;
+    have = false;
+    first_t = first_q = last_t = last_q = 0;
+    for (int g = 0; g < 8; ++g) gq[g] = 0xFFFFFFFFu;
+    gx = -1;
+    gt = 0;
+    t_wi = q_wi = ~0ULL;
+    t_wv = q_wv = 0;
+  }
+  __host__ __device__ void set_segment(int j0, int t0) {
+    seg_j0 = j0;
+    seg_t0 = t0;
+  }
+
+  __host__ __device__ u32 tcode(int row) {
+    const u64 pos = static_cast<u64>(t_begin) + row - 1;
+    const u64 wi = pos >> 5;
+    if (wi != t_wi) {
+      t_wi = wi;
+      t_wv = tw[wi];
+    }
+    return static_cast<u32>(t_wv >> ((pos & 31) << 1)) & 3u;
+  }
+  __host__ __device__ u32 qcode(int col) {
+    const u64 x = static_cast<u64>(q_begin) + col - 1;  // position in the oriented read
+    const u64 pos = rc ? static_cast<u64>(r_len) - 1 - x : x;
+    const u64 wi = pos >> 5;
+    if (wi != q_wi) {
+      q_wi = wi;
+      q_wv = rw[wi];
+    }
+    const u32 c = static_cast<u32>(q_wv >> ((pos & 31) << 1)) & 3u;
+    return rc ? 3u - c : c;
+  }
+
+  // D(x, y) of the banded matrix for y in [seg_j0, seg_j0 + kNwSeg]; kNwInf outside the band
+  __host__ __device__ u32 cell(int x, int y) const {
+    if (x == 0) return static_cast<u32>(y);
+    if (y == 0) return static_cast<u32>(x);
+    const int b = (x - 1) >> 6;
+    if (y < nw_jin(b, B.hi) || y > nw_jout(b, B.lo)) return kNwInf;
+    NwPm v;
+    int sc;
+    if (y == seg_j0) {  // the checkpointed column
+      const u64 cs = static_cast<u64>(y / kNwSeg) * st.ckpt_nb + static_cast<u64>(b - nw_bfirst(y, B.lo));
+      v = st.ck_pm[cs];
+      sc = st.ck_sc[cs];
+    } else {
+      const int s = b / static_cast<int>(R);
+      const u64 slot = (static_cast<u64>(y + s - seg_t0) * B.L + static_cast<u64>(s % B.L)) * R + static_cast<u64>(b % static_cast<int>(R));
+      v = st.seg_pm[slot];
+      sc = st.seg_sc[slot];
+    }
+    const unsigned bit = static_cast<unsigned>((x - 1) & 63);
+    const u64 below = bit == 63 ? 0ULL : (~0ULL << (bit + 1));  // rows of the block below row x
+    return static_cast<u32>(sc - static_cast<int>(RVN_POPC64(v.pv & below)) + static_cast<int>(RVN_POPC64(v.mv & below)));
+  }
+
+  __host__ __device__ void flush(bool write) {
+    if (cw == 0xFFFFFFFFu || !write) return;
     NwWindowRec e;
     e.first_t = have ? first_t : 0xFFFFFFFFu;
     e.first_q = first_q;
@@ -255,64 +380,74 @@ __host__ __device__ inline int nw_traceback(const NwJob& J, const u64* __restric
       e.grid[g] = static_cast<u16>(off);
     }
     recs[cw - win0] = e;
-  };
-  auto enter = [&](u32 wi) {
-    flush();
-    cw = wi;
-    have = false;
-    for (int g = 0; g < 8; ++g) gq[g] = 0xFFFFFFFFu;
-    gx = 7;
-    gt = wi * w + static_cast<u32>((7ULL * w) / 8);
-  };
+  }
   // the path consumes target base t with the read standing at oriented position q
-  auto on_target_base = [&](u32 t, u32 q) {
+  __host__ __device__ void on_target_base(u32 t, u32 q, bool write) {
     const u32 wi = t / w;
-    if (wi != cw) enter(wi);
+    if (wi != cw) {
+      flush(write);
+      cw = wi;
+      have = false;
+      for (int g = 0; g < 8; ++g) gq[g] = 0xFFFFFFFFu;
+      gx = 7;
+      gt = wi * w + static_cast<u32>((7ULL * w) / 8);
+    }
     while (gx >= 0 && t < gt) {
       --gx;
       if (gx >= 0) gt = wi * w + static_cast<u32>((static_cast<u64>(gx) * w) / 8);
     }
-    if (gx >= 0 && t == gt) gq[gx] = q;
-  };
-  const bool rc = J.rc != 0;
-  auto tcode = [&](long long row) -> u32 { return packed_code(tw, static_cast<u64>(J.t_begin) + row - 1); };
-  auto qcode = [&](long long col) -> u32 {
-    const u64 x = static_cast<u64>(J.q_begin) + col - 1;  // position in the oriented read
-    return rc ? 3u - packed_code(rw, static_cast<u64>(J.r_len) - 1 - x) : packed_code(rw, x);
-  };
-  while (i > 0 || j > 0) {
-    bool diag = false;
-    if (i > 0 && j > 0) {
+    if (gx >= 0 && t == gt) {
+#pragma unroll
+      for (int g = 0; g < 8; ++g)
+        if (g == gx) gq[g] = q;  // unrolled select: a runtime index would push the array to scratch memory
+    }
+  }
+  __host__ __device__ void take_diag(bool write) {  // CIGAR 'M'
+    const u32 t = t_begin + static_cast<u32>(i - 1), q = q_begin + static_cast<u32>(j - 1);
+    on_target_base(t, q, write);
+    if (!have) {
+      have = true;
+      last_t = t + 1;
+      last_q = q + 1;
+    }
+    first_t = t;
+    first_q = q;
+    --i;
+    --j;
+  }
+
+  // walks while the current column lies inside the segment in the scratch (j > seg_j0) and rows remain
+  __host__ __device__ void walk(bool write) {
+    while (i > 0 && j > seg_j0) {
       if (tcode(i) == qcode(j)) {
-        diag = true;
-      } else if (nw_cell(J, pm, sc, i - 1, j - 1) + 1 == cur) {
-        diag = true;
+        take_diag(write);
+      } else if (cell(i - 1, j - 1) + 1 == cur) {
+        --cur;
+        take_diag(write);
+      } else if (cell(i, j - 1) + 1 == cur) {  // 'I': read base only
+        --j;
+        --cur;
+      } else {  // 'D': target base only
+        on_target_base(t_begin + static_cast<u32>(i - 1), q_begin + static_cast<u32>(j), write);
+        --i;
         --cur;
       }
     }
-    if (diag) {  // CIGAR 'M'
-      const u32 t = J.t_begin + static_cast<u32>(i - 1), q = J.q_begin + static_cast<u32>(j - 1);
-      on_target_base(t, q);
-      if (!have) {
-        have = true;
-        last_t = t + 1;
-        last_q = q + 1;
-      }
-      first_t = t;
-      first_q = q;
-      --i;
-      --j;
-    } else if (j > 0 && (i == 0 || nw_cell(J, pm, sc, i, j - 1) + 1 == cur)) {  // 'I': read base only
+  }
+  // the rest needs no scores: only read bases (i == 0) or only target bases (j == 0) are left
+  __host__ __device__ int finish(bool write) {
+    while (j > 0 && i == 0) {
       --j;
       --cur;
-    } else {  // 'D': target base only
-      on_target_base(J.t_begin + static_cast<u32>(i - 1), J.q_begin + static_cast<u32>(j));
+    }
+    while (i > 0 && j == 0) {
+      on_target_base(t_begin + static_cast<u32>(i - 1), q_begin, write);
       --i;
       --cur;
     }
+    flush(write);
+    return (cur == 0 && i == 0 && j == 0) ? 0 : 1;
   }
-  flush();
-  return cur == 0 ? 0 : 1;
-}
+};
 
 }  // namespace rvn

@@ -1,13 +1,14 @@
-// nwpath.hip — kernels and host driver of the alignment-path stage of a polishing round (see nwpath.h): for every
+// nwpath.hip — kernel and host driver of the alignment-path stage of a polishing round (see nwpath.h): for every
 // read's best overlap, the global alignment path against its target span and racon's per-window breakpoints
 // (racon Overlap::find_breaking_points, reached from RavenLib/src/polish.cc:51).
 //
-//   nw_forward_kernel<R>   one wave per alignment: banded Myers sweep that stores every block's (Pv, Mv, score)
-//   nw_traceback_kernel    one thread per alignment: path walk + breakpoints + band-guide samples -> NwWindowRec
+//   nw_path_kernel<R>   persistent waves, one alignment per wave at a time (longest first): pass 1 (banded Myers sweep
+//                       keeping a checkpoint every kNwSeg columns; threshold doubled in place until exact), then the
+//                       walk back through the segments (re-sweep of a segment into the wave's scratch, walk, next).
 //
-// Host side: band thresholds k from the running error-rate estimate of the engine (first call: a pilot sample with
-// threshold doubling), jobs packed into batches that fit the store budget, failed attempts (distance > k) redone
-// with 2k — the result is always the exact optimal path, the estimate only decides how much band is computed.
+// Host side: first thresholds k from the running error-rate estimate of the engine (first call: a generous default),
+// blocks-per-lane R from k, jobs that outgrow their R (distance > kcap) are relaunched with the next R — the result is
+// always the exact optimal path, the estimate only decides how much band is computed.
 #include <algorithm>
 #include <cstdlib>
 #include <vector>
@@ -20,68 +21,139 @@ namespace rvn {
 
 namespace {
 
+__device__ __forceinline__ void nw_wsync() {
+  __threadfence_block();
+  __builtin_amdgcn_wave_barrier();
+}
+
 template <int R>
-__global__ __launch_bounds__(256) void nw_forward_kernel(const NwJob* __restrict__ jobs, const u32* __restrict__ idx,
-                                                        u32 n_idx, const u64* __restrict__ t_words,
-                                                        const u64* __restrict__ r_words, NwPm* __restrict__ pm,
-                                                        int* __restrict__ sc, u32* __restrict__ result) {
-  const u32 q = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (q >= n_idx) return;
-  const u32 ji = idx[q];
-  const NwJob J = jobs[ji];
+__global__ __launch_bounds__(256) void nw_path_kernel(const NwJob* __restrict__ jobs, const u32* __restrict__ idx,
+                                                     u32 n_idx, const u64* __restrict__ t_words,
+                                                     const u64* __restrict__ r_words, NwPm* __restrict__ ck_pm,
+                                                     int* __restrict__ ck_sc, NwPm* __restrict__ seg_pm,
+                                                     int* __restrict__ seg_sc, u64 seg_stride, u32 n_slots, u32 w,
+                                                     NwWindowRec* __restrict__ recs, u32* __restrict__ result,
+                                                     u32* __restrict__ status, u32* __restrict__ k_used,
+                                                     u32* __restrict__ next) {
+  __shared__ NwWalker s_walker[4];
+  const u32 slot = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (slot >= n_slots) return;
   const int lane = lane_id();
-  NwLane<R> ln;
-  ln.init(J, t_words, r_words, pm, sc, lane);
-  const int src = lane == 0 ? static_cast<int>(J.L) - 1 : lane - 1;
-  const long long t_end = static_cast<long long>(J.m) + ln.n_super;
-  for (long long t = 0; t < t_end; ++t) {
-    const int hp = __shfl(ln.hout_last, src, 64);
-    const int sp = __shfl(ln.score_last, src, 64);
-    ln.step(t, hp, sp);
+  for (;;) {
+    u32 q = 0;
+    if (lane == 0) q = atomicAdd(next, 1u);
+    q = static_cast<u32>(__builtin_amdgcn_readfirstlane(static_cast<int>(q)));
+    if (q >= n_idx) break;
+    const u32 ji = idx[q];
+    const NwJob J = jobs[ji];
+    NwStore st;
+    st.ck_pm = ck_pm + J.ckpt;
+    st.ck_sc = ck_sc + J.ckpt;
+    st.ckpt_nb = J.ckpt_nb;
+    st.seg_pm = seg_pm + static_cast<u64>(slot) * seg_stride;
+    st.seg_sc = seg_sc + static_cast<u64>(slot) * seg_stride;
+    // ---- pass 1: distance + checkpoints; the threshold is doubled until the banded result is exact ----
+    u32 k = J.k;
+    NwBand B;
+    NwLane<R> ln;
+    u32 res = 0;
+    bool ok = false;
+    for (;;) {
+      B = nw_band(J.n, J.m, k, R);
+      ln.init(J, t_words, r_words, B, st, lane);
+      ln.begin_sweep(0, J.m, 0);
+      const int src = lane == 0 ? B.L - 1 : lane - 1;
+      const int t1 = NwLane<R>::sweep_t1(B, static_cast<int>(J.m));
+      for (int t = ln.t0; t <= t1; ++t) {
+        const int hp = __shfl(ln.hout_last, src, 64);
+        const int sp = __shfl(ln.score_last, src, 64);
+        ln.step(t, hp, sp);
+      }
+      res = wave_max(ln.result) - 1u;  // exactly one lane holds D(n, m) + 1
+      if (res <= k) {
+        ok = true;
+        break;
+      }
+      if (k >= J.kcap) break;
+      k = 2 * k < J.kcap ? 2 * k : J.kcap;
+    }
+    if (lane == 0) {
+      result[ji] = res;
+      k_used[ji] = k;
+    }
+    if (!ok) {  // beyond this launch's ring: the host relaunches the job with more blocks per lane
+      if (lane == 0) status[ji] = 2;
+      continue;
+    }
+    nw_wsync();  // checkpoints visible to every lane
+    // ---- the walk, segment by segment from the end ----
+    // The walker's state lives in LDS between the segments (it is not needed while the wave re-sweeps a segment, and
+    // keeping it in registers across the sweep loop costs occupancy); every lane holds an identical copy.
+    NwWalker& swk = s_walker[threadIdx.x >> 6];
+    {
+      NwWalker wk;
+      wk.init(J, t_words, r_words, B, st, res, w, recs);
+      if (lane == 0) swk = wk;
+    }
+    const int src = lane == 0 ? B.L - 1 : lane - 1;
+    int rows_left = static_cast<int>(J.n);
+    for (int sg = (static_cast<int>(J.m) - 1) / kNwSeg; sg >= 0 && rows_left > 0; --sg) {
+      const int j0 = sg * kNwSeg;
+      const int j_end = j0 + kNwSeg < static_cast<int>(J.m) ? j0 + kNwSeg : static_cast<int>(J.m);
+      ln.begin_sweep(j0, j_end, 1);
+      const int t1 = NwLane<R>::sweep_t1(B, j_end);
+      for (int t = ln.t0; t <= t1; ++t) {
+        const int hp = __shfl(ln.hout_last, src, 64);
+        const int sp = __shfl(ln.score_last, src, 64);
+        ln.step(t, hp, sp);
+      }
+      nw_wsync();  // the segment's block states (and the walker in LDS) visible to every lane
+      NwWalker wk = swk;
+      wk.set_segment(j0, ln.t0);
+      wk.walk(lane == 0);  // every lane walks the same path (uniform control flow); lane 0 writes the records
+      rows_left = wk.i;
+      nw_wsync();          // all reads of the scratch done before the next segment overwrites it
+      if (lane == 0) swk = wk;
+    }
+    nw_wsync();
+    NwWalker wk = swk;
+    const int bad = wk.finish(lane == 0);
+    if (lane == 0) status[ji] = static_cast<u32>(bad);
+    nw_wsync();
   }
-  const u32 res = wave_max(ln.result);  // exactly one lane holds D(n, m) + 1
-  if (lane == 0) result[ji] = res - 1u;
-}
-
-__global__ __launch_bounds__(64) void nw_traceback_kernel(const NwJob* __restrict__ jobs, u32 n_jobs,
-                                                         const u64* __restrict__ t_words, const u64* __restrict__ r_words,
-                                                         const NwPm* __restrict__ pm, const int* __restrict__ sc,
-                                                         const u32* __restrict__ result, u32 w,
-                                                         NwWindowRec* __restrict__ recs, u32* __restrict__ status) {
-  const u32 ji = blockIdx.x * 64 + threadIdx.x;
-  if (ji >= n_jobs) return;
-  const NwJob J = jobs[ji];
-  const u32 d = result[ji];
-  if (d > J.k) {  // the band was too narrow for this pair: redone with a larger threshold
-    status[ji] = 2;
-    return;
-  }
-  status[ji] = static_cast<u32>(nw_traceback(J, t_words, r_words, pm, sc, d, w, recs));
 }
 
 template <int R>
-void launch_forward(Engine& e, const NwJob* d_jobs, const u32* d_idx, u32 n_idx, const ReadsDev& T, const ReadsDev& Rd,
-                    NwPm* pm, int* sc, u32* d_result) {
+void launch_path(Engine& e, const NwJob* d_jobs, const u32* d_idx, u32 n_idx, const ReadsDev& T, const ReadsDev& Rd, u32 w,
+                 NwWindowRec* d_recs, u32* d_result, u32* d_status, u32* d_kused, u32* d_next) {
   if (n_idx == 0) return;
-  RVN_KLAUNCH(kKNwForward, nw_forward_kernel<R><<<div_up(n_idx, 4), 256, 0, e.stream>>>(
-                               d_jobs, d_idx, n_idx, T.packed.as<u64>(), Rd.packed.as<u64>(), pm, sc, d_result));
+  hipStream_t s = e.stream;
+  // per-wave scratch of one segment: nw_seg_rows() systolic steps x 64 lanes x R blocks
+  const u64 seg_stride = static_cast<u64>(nw_seg_rows()) * 64 * R;
+  u32 n_slots = std::min<u32>(n_idx, 256u * 4u * (R == 1 ? 5u : (R == 2 ? 4u : (R == 4 ? 3u : 2u))));
+  n_slots = ((n_slots + 3) / 4) * 4;
+  NwPm* seg_pm = e.nw_pm.get<NwPm>(static_cast<u64>(n_slots) * seg_stride + 1);
+  int* seg_sc = e.nw_sc.get<int>(static_cast<u64>(n_slots) * seg_stride + 1);
+  RVN_HIP(hipMemsetAsync(d_next, 0, 4, s));
+  RVN_KLAUNCH(kKNwForward, nw_path_kernel<R><<<n_slots / 4, 256, 0, s>>>(
+                               d_jobs, d_idx, n_idx, T.packed.as<u64>(), Rd.packed.as<u64>(), e.nw_ck_pm.as<NwPm>(),
+                               e.nw_ck_sc.as<int>(), seg_pm, seg_sc, seg_stride, n_slots, w, d_recs, d_result, d_status,
+                               d_kused, d_next));
 }
 
-// smallest supported R whose ring holds the band of threshold k; 0 = beyond the kernel (k > ~32 000)
-u32 pick_R(u32 lo, u32 hi, u32* L) {
-  for (u32 R : {1u, 2u, 4u, 8u}) {
-    const u32 l = nw_ring_lanes(lo, hi, R);
-    if (l <= 64) {
-      *L = l < 1 ? 1 : l;
-      return R;
-    }
-  }
-  return 0;
+// largest threshold whose band fits a ring of 64 lanes with R blocks each
+u32 kcap_of(u32 n, u32 m, u32 R) {
+  const u32 d = n > m ? n - m : m - n;
+  // nw_ring_lanes(lo, hi, R) <= 64  <=>  64R + lo + hi <= 64 (64R + 1);  lo + hi = 2 floor((k - d) / 2) + d
+  const u64 room = 64ULL * (64ULL * R + 1) - 64ULL * R;
+  if (room < d) return 0;
+  const u64 k = d + ((room - d) / 2) * 2 + 1;  // (k - d) / 2 floors: an odd surplus costs nothing
+  return static_cast<u32>(std::min<u64>(k, static_cast<u64>(n) + m));
 }
 
 }  // namespace
 
-// Fills the band fields of `jobs` (k, lo, hi, L, R, store) and produces every job's window records in d_recs
+// Fills the band fields of `jobs` (k, kcap, R, ckpt) and produces every job's window records in d_recs
 // (records of a job start at its bp_off; jobs that cannot be aligned keep all-invalid records and are counted).
 void nw_breakpoints(Engine& e, const ReadsDev& T, const ReadsDev& Rd, std::vector<NwJob>& jobs, u32 w,
                     NwWindowRec* d_recs, u64 n_recs, NwStats& st) {
@@ -91,33 +163,28 @@ void nw_breakpoints(Engine& e, const ReadsDev& T, const ReadsDev& Rd, std::vecto
   RVN_HIP(hipMemsetAsync(d_recs, 0xFF, n_recs * sizeof(NwWindowRec), s));
   if (nj == 0) return;
   RVN_HIP(hipEventRecord(e.ev0, s));
+  static const u32 kRs[4] = {1, 2, 4, 8};
+  const double rate = e.nw_rate > 0 ? e.nw_rate : 0.13;  // first call: ONT-like; too small only costs a doubling
 
-  size_t free_b = 0, total_b = 0;
-  RVN_HIP(hipMemGetInfo(&free_b, &total_b));
-  u64 budget = std::min<u64>(32ULL << 30, static_cast<u64>((free_b + e.nw_pm.cap + e.nw_sc.cap) * 0.4));
-  if (const char* ev = std::getenv("RVN_NW_BUDGET_MB")) budget = static_cast<u64>(std::atoll(ev)) << 20;
-  const u64 budget_slots = std::max<u64>(budget / 20, 1);
-
-  auto set_band = [&](NwJob& J, u64 k) -> bool {
+  // plan: first threshold from the estimate, the smallest R whose ring holds twice that, checkpoint rows for kcap
+  std::vector<u32> level(nj, 0);  // index into kRs
+  std::vector<u32> todo;
+  auto plan = [&](NwJob& J, u32 lvl, u64 k_first) -> bool {
     const u32 d = J.n > J.m ? J.n - J.m : J.m - J.n;
-    k = std::max<u64>(k, d);
-    k = std::min<u64>(k, static_cast<u64>(J.n) + J.m);  // D(n, m) <= n + m: this threshold always succeeds
-    J.k = static_cast<u32>(k);
-    J.lo = nw_band_lo(J.n, J.m, J.k);
-    J.hi = nw_band_hi(J.n, J.m, J.k);
-    J.R = pick_R(J.lo, J.hi, &J.L);
-    return J.R != 0;
+    k_first = std::max<u64>(std::max<u64>(k_first, d), 16);
+    k_first = std::min<u64>(k_first, static_cast<u64>(J.n) + J.m);  // D(n, m) <= n + m: that threshold never fails
+    for (; lvl < 4; ++lvl) {
+      const u32 cap = kcap_of(J.n, J.m, kRs[lvl]);
+      if (cap >= k_first && (cap >= 2 * k_first || lvl == 3 || cap >= static_cast<u64>(J.n) + J.m)) {
+        J.R = kRs[lvl];
+        J.k = static_cast<u32>(std::min<u64>(k_first, cap));
+        J.kcap = static_cast<u32>(std::min<u64>(cap, std::max<u64>(4 * k_first, 64)));
+        J.ckpt_nb = nw_ckpt_blocks(J.n, J.m, J.kcap);
+        return true;
+      }
+    }
+    return false;
   };
-
-  // thresholds: from the engine's running estimate of distance / length, or a pilot sample on the first call
-  std::vector<u32> pending;
-  std::vector<u32> later;
-  const bool pilot = e.nw_rate < 0;
-  std::vector<u8> in_pilot(nj, 0);
-  if (pilot) {
-    const u32 n_pilot = std::min<u32>(nj, 256);
-    for (u32 x = 0; x < n_pilot; ++x) in_pilot[static_cast<u64>(x) * nj / n_pilot] = 1;
-  }
   for (u32 i = 0; i < nj; ++i) {
     NwJob& J = jobs[i];
     if (J.n == 0 || J.m == 0) {
@@ -125,105 +192,80 @@ void nw_breakpoints(Engine& e, const ReadsDev& T, const ReadsDev& Rd, std::vecto
       continue;
     }
     const u32 len = std::max(J.n, J.m);
-    const u64 k0 = pilot ? std::max<u64>(64, static_cast<u64>(0.03 * len))
-                         : std::max<u64>(32, static_cast<u64>(e.nw_rate * len) + 16);
-    if (!set_band(J, k0)) {
-      ++st.n_unaligned;
-      continue;
-    }
-    if (pilot && !in_pilot[i]) later.push_back(i);
-    else pending.push_back(i);
+    if (plan(J, 0, static_cast<u64>(rate * len) + 16)) todo.push_back(i);
+    else ++st.n_unaligned;
   }
 
   std::vector<double> rates;
-  std::vector<NwJob> batch;
-  std::vector<u32> batch_src, idxR[4], h_result, h_status;
-  while (!pending.empty() || !later.empty()) {
-    if (pending.empty()) {  // the pilot is done: thresholds of everything else from its distances
-      if (!rates.empty()) {
-        std::sort(rates.begin(), rates.end());
-        e.nw_rate = rates[std::min(rates.size() - 1, static_cast<size_t>(rates.size() * 0.9))] * 1.1 + 0.002;
-      } else {
-        e.nw_rate = 0.15;
-      }
-      for (u32 i : later) {
-        NwJob& J = jobs[i];
-        const u32 len = std::max(J.n, J.m);
-        if (set_band(J, std::max<u64>(32, static_cast<u64>(e.nw_rate * len) + 16))) pending.push_back(i);
-        else ++st.n_unaligned;
-      }
-      later.clear();
-      continue;
+  std::vector<u32> h_result, h_status, h_kused, order;
+  while (!todo.empty()) {
+    // checkpoints of all jobs of this launch; longest alignments first (persistent waves: no long tail)
+    u64 ck = 0;
+    for (u32 i : todo) {
+      jobs[i].ckpt = ck;
+      ck += nw_ckpt_slots(jobs[i].m, jobs[i].ckpt_nb);
     }
-    // ---- one batch: as many pending jobs as the store budget holds ----
-    batch.clear();
-    batch_src.clear();
-    for (auto& v : idxR) v.clear();
-    u64 slots = 0;
-    size_t taken = 0;
-    for (; taken < pending.size(); ++taken) {
-      NwJob& J = jobs[pending[taken]];
-      const u64 need = nw_store_slots(J.n, J.m, J.L, J.R);
-      if (!batch.empty() && slots + need > budget_slots) break;
-      J.store = slots;
-      slots += need;
-      const u32 bi = static_cast<u32>(batch.size());
-      idxR[J.R == 1 ? 0 : (J.R == 2 ? 1 : (J.R == 4 ? 2 : 3))].push_back(bi);
-      batch.push_back(J);
-      batch_src.push_back(pending[taken]);
-    }
-    pending.erase(pending.begin(), pending.begin() + taken);
-    const u32 nb = static_cast<u32>(batch.size());
-    NwPm* pm = e.nw_pm.get<NwPm>(slots + 1);
-    int* sc = e.nw_sc.get<int>(slots + 1);
-    NwJob* d_jobs = e.nw_jobs.get<NwJob>(nb + 1);
-    u32* d_res = e.nw_res.get<u32>(3 * static_cast<size_t>(nb) + 4);
-    u32* d_status = d_res + nb + 1;
-    u32* d_idx = d_status + nb + 1;
-    RVN_HIP(hipMemcpyAsync(d_jobs, batch.data(), nb * sizeof(NwJob), hipMemcpyHostToDevice, s));
-    {
-      std::vector<u32> all_idx;
-      u32 off[5] = {0, 0, 0, 0, 0};
-      for (int x = 0; x < 4; ++x) {
-        all_idx.insert(all_idx.end(), idxR[x].begin(), idxR[x].end());
-        off[x + 1] = static_cast<u32>(all_idx.size());
-      }
-      RVN_HIP(hipMemcpyAsync(d_idx, all_idx.data(), all_idx.size() * 4, hipMemcpyHostToDevice, s));
-      RVN_HIP(hipStreamSynchronize(s));  // all_idx is a local
-      launch_forward<1>(e, d_jobs, d_idx + off[0], off[1] - off[0], T, Rd, pm, sc, d_res);
-      launch_forward<2>(e, d_jobs, d_idx + off[1], off[2] - off[1], T, Rd, pm, sc, d_res);
-      launch_forward<4>(e, d_jobs, d_idx + off[2], off[3] - off[2], T, Rd, pm, sc, d_res);
-      launch_forward<8>(e, d_jobs, d_idx + off[3], off[4] - off[3], T, Rd, pm, sc, d_res);
-    }
-    RVN_KLAUNCH(kKNwTraceback, nw_traceback_kernel<<<div_up(nb, 64), 64, 0, s>>>(
-                                   d_jobs, nb, T.packed.as<u64>(), Rd.packed.as<u64>(), pm, sc, d_res, w, d_recs, d_status));
-    h_result.resize(nb);
-    h_status.resize(nb);
-    RVN_HIP(hipMemcpyAsync(h_result.data(), d_res, nb * 4, hipMemcpyDeviceToHost, s));
-    RVN_HIP(hipMemcpyAsync(h_status.data(), d_status, nb * 4, hipMemcpyDeviceToHost, s));
+    (void)e.nw_ck_pm.get<NwPm>(ck + 1);
+    (void)e.nw_ck_sc.get<int>(ck + 1);
+    st.store_bytes = std::max<u64>(st.store_bytes, ck * 20);
+    NwJob* d_jobs = e.nw_jobs.get<NwJob>(nj + 1);
+    RVN_HIP(hipMemcpyAsync(d_jobs, jobs.data(), static_cast<size_t>(nj) * sizeof(NwJob), hipMemcpyHostToDevice, s));
+    u32* d_res = e.nw_res.get<u32>(4 * static_cast<size_t>(nj) + 16);
+    u32* d_status = d_res + nj + 1;
+    u32* d_kused = d_status + nj + 1;
+    u32* d_idx = d_kused + nj + 1;
+    u32* d_next = d_idx + nj + 1;
+    order = todo;
+    std::stable_sort(order.begin(), order.end(), [&](u32 a, u32 b) {
+      if (jobs[a].R != jobs[b].R) return jobs[a].R < jobs[b].R;
+      return static_cast<u64>(jobs[a].m) * jobs[a].k > static_cast<u64>(jobs[b].m) * jobs[b].k;
+    });
+    u32 off[5] = {0, 0, 0, 0, 0};
+    for (u32 i : order) off[(jobs[i].R == 1 ? 0 : (jobs[i].R == 2 ? 1 : (jobs[i].R == 4 ? 2 : 3))) + 1]++;
+    for (int x = 0; x < 4; ++x) off[x + 1] += off[x];
+    RVN_HIP(hipMemcpyAsync(d_idx, order.data(), order.size() * 4, hipMemcpyHostToDevice, s));
+    RVN_HIP(hipStreamSynchronize(s));
+    launch_path<1>(e, d_jobs, d_idx + off[0], off[1] - off[0], T, Rd, w, d_recs, d_res, d_status, d_kused, d_next);
+    launch_path<2>(e, d_jobs, d_idx + off[1], off[2] - off[1], T, Rd, w, d_recs, d_res, d_status, d_kused, d_next);
+    launch_path<4>(e, d_jobs, d_idx + off[2], off[3] - off[2], T, Rd, w, d_recs, d_res, d_status, d_kused, d_next);
+    launch_path<8>(e, d_jobs, d_idx + off[3], off[4] - off[3], T, Rd, w, d_recs, d_res, d_status, d_kused, d_next);
+    h_result.resize(nj);
+    h_status.resize(nj);
+    h_kused.resize(nj);
+    RVN_HIP(hipMemcpyAsync(h_result.data(), d_res, static_cast<size_t>(nj) * 4, hipMemcpyDeviceToHost, s));
+    RVN_HIP(hipMemcpyAsync(h_status.data(), d_status, static_cast<size_t>(nj) * 4, hipMemcpyDeviceToHost, s));
+    RVN_HIP(hipMemcpyAsync(h_kused.data(), d_kused, static_cast<size_t>(nj) * 4, hipMemcpyDeviceToHost, s));
     RVN_HIP(hipStreamSynchronize(s));
     ++st.n_batches;
-    st.store_bytes = std::max<u64>(st.store_bytes, slots * 20);
-    for (u32 bi = 0; bi < nb; ++bi) {
-      NwJob& J = jobs[batch_src[bi]];
-      st.band_cells += static_cast<u64>(J.m) * (J.lo + J.hi + 1);
-      if (h_status[bi] == 2) {  // distance above the threshold: double it
+    std::vector<u32> again;
+    for (u32 i : todo) {
+      NwJob& J = jobs[i];
+      // cells of every attempt: thresholds k, 2k, .. up to the one used
+      for (u64 kk = J.k;; kk = std::min<u64>(2 * kk, J.kcap)) {
+        st.band_cells += static_cast<u64>(J.m) * (nw_band_lo(J.n, J.m, static_cast<u32>(kk)) + nw_band_hi(J.n, J.m, static_cast<u32>(kk)) + 1);
+        if (kk >= h_kused[i]) break;
         ++st.n_retries;
-        const u64 k2 = std::max<u64>(static_cast<u64>(J.k) * 2, 64);
-        if (J.k >= static_cast<u64>(J.n) + J.m || !set_band(J, k2)) ++st.n_unaligned;
-        else pending.push_back(batch_src[bi]);
-      } else if (h_status[bi] != 0) {
-        throw HipError("[raven_hip] alignment path: traceback left the stored band (internal error)");
+      }
+      if (h_status[i] == 2) {  // distance above this launch's largest threshold: next blocks-per-lane level
+        u32 lvl = 0;
+        while (lvl < 4 && kRs[lvl] != J.R) ++lvl;
+        const u64 k2 = static_cast<u64>(h_kused[i]) * 2;
+        if (J.kcap >= static_cast<u64>(J.n) + J.m || !plan(J, J.kcap < kcap_of(J.n, J.m, J.R) ? lvl : lvl + 1, k2)) ++st.n_unaligned;
+        else again.push_back(i);
+      } else if (h_status[i] != 0) {
+        throw HipError("[raven_hip] alignment path: the walk left the stored band (internal error)");
       } else {
         ++st.n_aligned;
-        st.sum_distance += h_result[bi];
-        rates.push_back(static_cast<double>(h_result[bi]) / std::max(J.n, J.m));
+        st.sum_distance += h_result[i];
+        st.band_cells += static_cast<u64>(J.m) * (nw_band_lo(J.n, J.m, h_kused[i]) + nw_band_hi(J.n, J.m, h_kused[i]) + 1);  // the re-sweeps
+        rates.push_back(static_cast<double>(h_result[i]) / std::max(J.n, J.m));
       }
     }
+    todo.swap(again);
   }
-  if (!pilot && rates.size() >= 64) {  // keep the estimate current (rounds get more accurate)
+  if (rates.size() >= 32) {  // threshold estimate for the next call: most alignments succeed at the first attempt
     std::sort(rates.begin(), rates.end());
-    e.nw_rate = rates[std::min(rates.size() - 1, static_cast<size_t>(rates.size() * 0.9))] * 1.1 + 0.002;
+    e.nw_rate = rates[std::min(rates.size() - 1, static_cast<size_t>(rates.size() * 0.9))] * 1.05 + 0.002;
   }
   RVN_HIP(hipEventRecord(e.ev1, s));
   RVN_HIP(hipEventSynchronize(e.ev1));
@@ -234,74 +276,107 @@ void nw_breakpoints(Engine& e, const ReadsDev& T, const ReadsDev& Rd, std::vecto
 
 // ---- CPU stepper of the same code (test hook rvn_test_nw_breakpoints): 64 emulated lanes, host arrays --------------
 template <int R>
-static u32 emulate_forward(const NwJob& J, const u64* t_words, const u64* r_words, NwPm* pm, int* sc) {
+static int emulate_job(const NwJob& J, const u64* t_words, const u64* r_words, u32 w, NwWindowRec* recs, u32* distance,
+                       u32* band) {
+  std::vector<NwPm> ck_pm(nw_ckpt_slots(J.m, J.ckpt_nb) + 1), seg_pm(static_cast<size_t>(nw_seg_rows()) * 64 * R + 1);
+  std::vector<int> ck_sc(ck_pm.size()), seg_sc(seg_pm.size());
+  NwStore st{ck_pm.data(), ck_sc.data(), J.ckpt_nb, seg_pm.data(), seg_sc.data()};
   std::vector<NwLane<R>> lanes(64);
-  for (int l = 0; l < 64; ++l) lanes[l].init(J, t_words, r_words, pm, sc, l);
-  const long long t_end = static_cast<long long>(J.m) + lanes[0].n_super;
   std::vector<int> hp(64), sp(64);
-  for (long long t = 0; t < t_end; ++t) {
-    for (int l = 0; l < 64; ++l) {  // the shuffles read the producer's values of the previous step
-      const int src = l == 0 ? static_cast<int>(J.L) - 1 : l - 1;
-      hp[l] = lanes[src].hout_last;
-      sp[l] = lanes[src].score_last;
+  NwBand B;
+  auto sweep = [&](int j0, int j_end, int mode) {
+    for (int l = 0; l < 64; ++l) lanes[l].begin_sweep(j0, j_end, mode);
+    const int t1 = NwLane<R>::sweep_t1(B, j_end);
+    for (int t = lanes[0].t0; t <= t1; ++t) {
+      for (int l = 0; l < 64; ++l) {  // the shuffles read the producer's values of the previous step
+        const int src = l == 0 ? B.L - 1 : l - 1;
+        hp[l] = lanes[src].hout_last;
+        sp[l] = lanes[src].score_last;
+      }
+      for (int l = 0; l < 64; ++l) lanes[l].step(t, hp[l], sp[l]);
+      if (mode == 1 && static_cast<u64>(t - lanes[0].t0) >= nw_seg_rows()) return false;  // scratch rows exceeded
     }
-    for (int l = 0; l < 64; ++l) lanes[l].step(t, hp[l], sp[l]);
+    return true;
+  };
+  u32 k = J.k, res = 0;
+  for (;;) {
+    B = nw_band(J.n, J.m, k, R);
+    if (B.L > 64) return -2;
+    for (int l = 0; l < 64; ++l) lanes[l].init(J, t_words, r_words, B, st, l);
+    sweep(0, static_cast<int>(J.m), 0);
+    res = 0;
+    for (int l = 0; l < 64; ++l) res = std::max(res, lanes[l].result);
+    res -= 1u;
+    if (res <= k) break;
+    if (k >= J.kcap) return -3;
+    k = std::min<u32>(2 * k, J.kcap);
   }
-  u32 res = 0;
-  for (int l = 0; l < 64; ++l) res = std::max(res, lanes[l].result);
-  return res - 1u;
+  *distance = res;
+  if (band) {
+    band[0] = k;
+    band[1] = static_cast<u32>(B.L);
+    band[2] = R;
+  }
+  NwWalker wk;
+  wk.init(J, t_words, r_words, B, st, res, w, recs);
+  for (int sg = (static_cast<int>(J.m) - 1) / kNwSeg; sg >= 0 && wk.i > 0; --sg) {
+    const int j0 = sg * kNwSeg;
+    const int j_end = std::min<int>(j0 + kNwSeg, static_cast<int>(J.m));
+    if (!sweep(j0, j_end, 1)) return -4;
+    wk.set_segment(j0, lanes[0].t0);
+    wk.walk(true);
+  }
+  return wk.finish(true);
 }
 
 int nw_breakpoints_host(const u64* t_words, u32 t_len, const u64* r_words, u32 r_len, u32 t_begin, u32 n, u32 q_begin,
                         u32 m, int rc, u32 w, u32 k, int force_R, NwWindowRec* recs, u32* distance, u32* band) {
+  (void)t_len;
+  if (n == 0 || m == 0) return -1;
   NwJob J{};
-  J.t_word = 0;
-  J.r_word = 0;
-  J.store = 0;
-  J.bp_off = 0;
   J.t_begin = t_begin;
   J.n = n;
   J.q_begin = q_begin;
   J.m = m;
   J.r_len = r_len;
   J.rc = rc ? 1 : 0;
-  (void)t_len;
-  if (n == 0 || m == 0) return -1;
-  const u32 d = n > m ? n - m : m - n;
   J.n_windows = (t_begin + n - 1) / w - t_begin / w + 1;
-  u64 kk = std::max<u64>(k, d);
-  for (;;) {
-    kk = std::min<u64>(kk, static_cast<u64>(n) + m);
-    J.k = static_cast<u32>(kk);
-    J.lo = nw_band_lo(n, m, J.k);
-    J.hi = nw_band_hi(n, m, J.k);
-    J.R = force_R ? static_cast<u32>(force_R) : pick_R(J.lo, J.hi, &J.L);
-    if (force_R) J.L = nw_ring_lanes(J.lo, J.hi, J.R);
-    if (J.R == 0 || J.L > 64) return -2;
-    const u64 slots = nw_store_slots(n, m, J.L, J.R);
-    std::vector<NwPm> pm(slots + 1);
-    std::vector<int> sc(slots + 1);
-    u32 res = 0;
-    switch (J.R) {
-      case 1: res = emulate_forward<1>(J, t_words, r_words, pm.data(), sc.data()); break;
-      case 2: res = emulate_forward<2>(J, t_words, r_words, pm.data(), sc.data()); break;
-      case 4: res = emulate_forward<4>(J, t_words, r_words, pm.data(), sc.data()); break;
-      case 8: res = emulate_forward<8>(J, t_words, r_words, pm.data(), sc.data()); break;
-      default: return -2;
-    }
-    if (res > J.k) {
-      if (J.k >= static_cast<u64>(n) + m) return -3;
-      kk = std::max<u64>(2 * kk, 64);
+  for (u32 x = 0; x < J.n_windows; ++x) {
+    recs[x].first_t = recs[x].first_q = recs[x].last_t = recs[x].last_q = 0xFFFFFFFFu;
+    for (int g = 0; g < 8; ++g) recs[x].grid[g] = 0xFFFFu;
+  }
+  const u32 d = n > m ? n - m : m - n;
+  static const u32 kRs[4] = {1, 2, 4, 8};
+  u32 lvl = 0;
+  if (force_R) {
+    while (lvl < 4 && kRs[lvl] != static_cast<u32>(force_R)) ++lvl;
+    if (lvl == 4) return -2;
+  }
+  u64 kk = std::min<u64>(std::max<u64>(std::max<u64>(k, d), 1), static_cast<u64>(n) + m);
+  for (; lvl < 4; ++lvl) {
+    J.R = kRs[lvl];
+    const u32 cap = kcap_of(n, m, J.R);
+    if (cap < kk) {
+      if (force_R) return -2;
       continue;
     }
-    *distance = res;
-    if (band) {
-      band[0] = J.k;
-      band[1] = J.L;
-      band[2] = J.R;
+    J.k = static_cast<u32>(kk);
+    J.kcap = cap;
+    J.ckpt_nb = nw_ckpt_blocks(n, m, J.kcap);
+    int rcode;
+    switch (J.R) {
+      case 1: rcode = emulate_job<1>(J, t_words, r_words, w, recs, distance, band); break;
+      case 2: rcode = emulate_job<2>(J, t_words, r_words, w, recs, distance, band); break;
+      case 4: rcode = emulate_job<4>(J, t_words, r_words, w, recs, distance, band); break;
+      default: rcode = emulate_job<8>(J, t_words, r_words, w, recs, distance, band); break;
     }
-    return nw_traceback(J, t_words, r_words, pm.data(), sc.data(), res, w, recs);
+    if (rcode == -3 && !force_R) {  // distance above this R's largest threshold
+      kk = std::min<u64>(static_cast<u64>(cap) * 2, static_cast<u64>(n) + m);
+      continue;
+    }
+    return rcode;
   }
+  return -3;
 }
 
 }  // namespace rvn
