@@ -119,6 +119,37 @@ int rvn_pass1_trim_and_annotate(rvn_pass1* p, uint32_t coverage, uint32_t* begin
 int rvn_pass1_fetch_overlaps(const rvn_pass1* p, rvn_overlap* overlaps, uint32_t* offsets);
 void rvn_pass1_destroy(rvn_pass1* p);
 
+/* raven::FindOverlapsAndRepetetiveRegions (RavenLib/src/construct.cc:316-491; decl construct.h:49-54), the second
+ * all-vs-all pass on the VALID reads: valid reads first by id, index batches of `batch_bases` (reference: 1 << 30)
+ * without minhash, Map(read, true, true, false, &filtered) + Pile::AddKmers(filtered, kmer_len) (pile.cc:64-120),
+ * the identity filter when identity != 0 (construct.cc:385-424: OverlapUpdate, edlibAlign of the two spans, drop below
+ * the threshold), then the merge of construct.cc:430-455 — OverlapUpdate, GetOverlapType (overlap_utils.cc:14-113),
+ * containment flags, consecutive overlaps of the same pair keep the longer — the contained piles turned invalid and
+ * the final OverlapUpdate sweep (construct.cc:466-480), all on the device.
+ *   r               ALL reads, ids[i] == i
+ *   pile_begin/end  Pile::begin() / Pile::end() of every pile in BASES (begin_ << 4), pile_invalid = Pile::is_invalid()
+ * Result (rvn_pass2_fetch): the overlaps the reference leaves in the extra slot overlaps.back(), contained[n] = piles
+ * this pass marked with set_is_contained() (the caller also sets them invalid, construct.cc:466-470), and the k-mer
+ * cells Pile::kmers_ of the valid reads: (len >> 4) + 1 bytes (0/1) per valid read at kmers_offsets[id], nothing for
+ * invalid reads (kmers_offsets has n + 1 entries; rvn_pass2_kmer_cells = their total). */
+typedef struct rvn_pass2 rvn_pass2;
+int rvn_find_overlaps_and_repetitive_regions(rvn_engine* e, const rvn_reads* r, const uint32_t* pile_begin,
+                                             const uint32_t* pile_end, const uint8_t* pile_invalid, double freq,
+                                             uint32_t kmer_len, double identity, uint64_t batch_bases, rvn_pass2** out);
+uint64_t rvn_pass2_num_overlaps(const rvn_pass2* p);
+uint64_t rvn_pass2_kmer_cells(const rvn_pass2* p);
+int rvn_pass2_fetch(const rvn_pass2* p, rvn_overlap* overlaps, uint8_t* contained, uint8_t* kmers, uint64_t* kmers_offsets);
+void rvn_pass2_destroy(rvn_pass2* p);
+
+/* The identity filter loop of raven::ResolveContainedReads (RavenLib/src/construct.cc:162-217) on the per-pile overlap
+ * lists overlaps[i] (concatenated, offsets[n+1], both updated in place): every overlap goes through OverlapUpdate
+ * (overlap_utils.cc:14-80; dropped when it fails), its two spans through the batched exact edit distance (rhs
+ * reverse-complemented on the opposite strand), and is kept with its updated coordinates when
+ * 1 - distance / max(length) >= identity.  The containment marking that follows in the reference is host graph logic. */
+int rvn_filter_overlaps_by_identity(rvn_engine* e, const rvn_reads* r, rvn_overlap* overlaps, uint32_t* offsets,
+                                    const uint32_t* pile_begin, const uint32_t* pile_end, const uint8_t* pile_invalid,
+                                    double identity);
+
 /* raven::Pile::AddLayers on one pile (RavenLib/src/pile.cc:33-62): `data` (cells = len >> 4) is updated
  * in place with the coverage of `n` overlaps touching pile `id`. */
 int rvn_pile_add_layers(rvn_engine* e, uint16_t* data, uint32_t cells, uint32_t id, const rvn_overlap* overlaps,
@@ -330,6 +361,10 @@ int rvn_test_low_complexity(const uint8_t* codes, uint32_t k);
 int rvn_test_nw_breakpoints(const uint64_t* t_words, uint32_t t_len, const uint64_t* r_words, uint32_t r_len,
                             uint32_t t_begin, uint32_t n, uint32_t q_begin, uint32_t m, int rc, uint32_t w, uint32_t k,
                             int force_r, uint32_t* recs, uint32_t* distance, uint32_t* band);
+/* OverlapUpdate + GetOverlapType (overlap_rules.h, the __host__ __device__ code the kernels run) on a list: ok[i] =
+ * OverlapUpdate result (the overlap is updated in place when ok), type[i] = GetOverlapType of the updated overlap */
+int rvn_test_overlap_update_and_type(rvn_overlap* overlaps, uint64_t n, const uint32_t* pile_begin, const uint32_t* pile_end,
+                                     const uint8_t* pile_invalid, uint32_t n_piles, uint8_t* ok, uint32_t* type);
 void rvn_test_std_sort_lendesc(uint64_t* data, uint64_t n);
 void rvn_test_heap_sort_lendesc(uint64_t* data, uint64_t n);
 

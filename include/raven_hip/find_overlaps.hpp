@@ -57,6 +57,56 @@ void FindOverlapsAndCreatePiles(const std::shared_ptr<thread_pool::ThreadPool>& 
   }
 }
 
+// raven::FindOverlapsAndRepetetiveRegions (RavenLib/src/construct.cc:316-491, decl construct.h:49-54) with the
+// reference's signature: the second all-vs-all pass on the valid reads, one C-ABI call.  The reference re-sorts
+// `sequences` valid-first for the duration of the call and restores the id order before returning (construct.cc:324-332,
+// :486-490); the device pass selects the valid reads itself, so `sequences` is left as it is (ids must equal positions,
+// the invariant of construct.cc:25).  Effects, as in the reference: overlaps gets the extra slot overlaps.back(),
+// contained piles are marked and set invalid, Pile::kmers_ of the valid piles is filled.
+// PileT must provide begin(), end(), is_invalid(), set_is_contained(), set_is_invalid() (all raven::Pile members) and
+//   void AdoptKmers(const std::uint8_t* cells, std::size_t n)      // replaces Pile::kmers_ (n == (len >> 4) + 1)
+template <typename PileT>
+void FindOverlapsAndRepetetiveRegions(const std::shared_ptr<thread_pool::ThreadPool>& /*thread_pool*/,
+                                      ram::MinimizerEngine& minimizer_engine, double freq, std::uint8_t kmer_len,
+                                      double identity, const std::vector<std::unique_ptr<PileT>>& piles,
+                                      std::vector<std::vector<biosoup::Overlap>>& overlaps,
+                                      std::vector<std::unique_ptr<biosoup::NucleicAcid>>& sequences,
+                                      std::uint64_t batch_bases = 1ULL << 30) {
+  const std::size_t n = sequences.size();
+  overlaps.resize(n + 1);  // construct.cc:352
+  if (n == 0) return;
+  ram::detail::ReadsHandle reads;
+  reads.Upload(minimizer_engine.handle(), sequences.begin(), sequences.end());
+  std::vector<std::uint32_t> begin(n), end(n);
+  std::vector<std::uint8_t> invalid(n);
+  for (std::size_t i = 0; i < n; ++i) {
+    begin[i] = piles[i]->begin();
+    end[i] = piles[i]->end();
+    invalid[i] = piles[i]->is_invalid() ? 1 : 0;
+  }
+  rvn_pass2* p = nullptr;
+  ram::detail::Check(rvn_find_overlaps_and_repetitive_regions(minimizer_engine.handle(), reads.h, begin.data(), end.data(),
+                                                              invalid.data(), freq, kmer_len, identity, batch_bases, &p));
+  struct Guard {
+    rvn_pass2* p;
+    ~Guard() { rvn_pass2_destroy(p); }
+  } guard{p};
+  std::vector<rvn_overlap> flat(rvn_pass2_num_overlaps(p));
+  std::vector<std::uint8_t> contained(n), kmers(rvn_pass2_kmer_cells(p));
+  std::vector<std::uint64_t> koff(n + 1);
+  ram::detail::Check(rvn_pass2_fetch(p, flat.data(), contained.data(), kmers.data(), koff.data()));
+  for (std::size_t i = 0; i < n; ++i) {
+    if (koff[i + 1] > koff[i]) piles[i]->AdoptKmers(kmers.data() + koff[i], koff[i + 1] - koff[i]);
+    if (contained[i]) {  // construct.cc:438-441, :466-470
+      piles[i]->set_is_contained();
+      piles[i]->set_is_invalid();
+    }
+  }
+  auto& back = overlaps.back();
+  back.reserve(back.size() + flat.size());
+  for (const auto& o : flat) back.emplace_back(ram::detail::ToOverlap(o));
+}
+
 }  // namespace raven
 
 #endif  // RAVEN_HIP_FIND_OVERLAPS_HPP_

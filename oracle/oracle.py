@@ -235,6 +235,59 @@ def polish_round(targets, reads, quals=None, q=0.0, err=0.3, w=500, trim=True, m
     return [out[int(ooff[i]): int(ooff[i]) + int(out_len[i])].copy() for i in range(nt)], ratio
 
 
+def overlap_update_and_type(overlaps, pile_begin, pile_end, pile_invalid):
+    """OverlapUpdate + GetOverlapType (overlap_utils.cc:14-113) on a list: (updated overlaps, ok, type)."""
+    o = np.ascontiguousarray(overlaps, dtype=OVERLAP_DTYPE).copy()
+    b = np.ascontiguousarray(pile_begin, dtype=np.uint32)
+    ok = np.zeros(o.shape[0], dtype=np.uint8)
+    ty = np.zeros(o.shape[0], dtype=np.uint32)
+    lib().orc_overlap_update_and_type(_p(o), C.c_uint64(o.shape[0]), _p(b), _p(np.ascontiguousarray(pile_end, dtype=np.uint32)),
+                                      _p(np.ascontiguousarray(pile_invalid, dtype=np.uint8)), C.c_uint32(b.shape[0]), _p(ok),
+                                      _p(ty))
+    return o, ok, ty
+
+
+def identity_filter(rs, overlaps, offsets, pile_begin, pile_end, pile_invalid, identity):
+    """Identity filter loop of ResolveContainedReads (construct.cc:162-217) on per-pile lists (CSR)."""
+    o = np.ascontiguousarray(overlaps, dtype=OVERLAP_DTYPE).copy()
+    off = np.ascontiguousarray(offsets, dtype=np.uint32).copy()
+    L = lib()
+    L.orc_identity_filter.restype = C.c_uint64
+    L.orc_identity_filter.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.c_void_p, C.c_double]
+    n = L.orc_identity_filter(_p(rs.packed), _p(rs.word_offsets), _p(rs.lengths), rs.n, _p(o), _p(off),
+                              _p(np.ascontiguousarray(pile_begin, dtype=np.uint32)),
+                              _p(np.ascontiguousarray(pile_end, dtype=np.uint32)),
+                              _p(np.ascontiguousarray(pile_invalid, dtype=np.uint8)), float(identity))
+    return o[:n], off
+
+
+def second_pass(k, w, rs, pile_begin, pile_end, pile_invalid, freq=0.001, kmer_len=None, identity=0.0, batch_bases=1 << 30):
+    """raven::FindOverlapsAndRepetetiveRegions (construct.cc:316-491) restated: dict(overlaps, contained, kmers)."""
+    eng = Engine(k, w)
+    n = rs.n
+    inv = np.ascontiguousarray(pile_invalid, dtype=np.uint8)
+    koff = np.zeros(n + 1, dtype=np.uint64)
+    np.cumsum((rs.lengths.astype(np.uint64) >> np.uint64(4)) + np.uint64(1), out=koff[1:])
+    kmers = np.zeros(int(koff[-1]), dtype=np.uint8)
+    contained = np.zeros(n, dtype=np.uint8)
+    cap = 64 * n + 1024
+    out = np.zeros(cap, dtype=OVERLAP_DTYPE)
+    L = lib()
+    L.orc_second_pass.restype = C.c_int64
+    L.orc_second_pass.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
+                                  C.c_void_p, C.c_double, C.c_uint32, C.c_double, C.c_uint64, C.c_void_p, C.c_uint64,
+                                  C.c_void_p, C.c_void_p, C.c_void_p]
+    m = L.orc_second_pass(eng._h, _p(rs.packed), _p(rs.word_offsets), _p(rs.lengths), n,
+                          _p(np.ascontiguousarray(pile_begin, dtype=np.uint32)),
+                          _p(np.ascontiguousarray(pile_end, dtype=np.uint32)), _p(inv), float(freq),
+                          int(k if kmer_len is None else kmer_len), float(identity), int(batch_bases), _p(out), cap,
+                          _p(contained), _p(kmers), _p(koff))
+    assert m >= 0
+    return dict(overlaps=out[:m].copy(), contained=contained,
+                kmers=[kmers[int(koff[i]):int(koff[i + 1])] if not inv[i] else kmers[:0] for i in range(n)])
+
+
 def polish_layers(targets, reads, quals=None, q=0.0, err=0.3, w=500):
     """Steps 1-4 of racon's round (map, best overlap, NW path, breakpoints, layer rules): uint32[n, 7] rows
     {window, read, first base in the oriented read, bases, begin, end, rc}, in racon's order."""

@@ -847,6 +847,190 @@ void orc_pile_add_kmers(const std::uint64_t* words, std::uint32_t len, const std
 
 }  // extern "C" (reopened below)
 
+// ---- overlap bookkeeping against the piles' valid regions (RavenLib/src/overlap_utils.cc, in the reference tree) ----
+namespace orc {
+
+struct PileView {  // what OverlapUpdate / GetOverlapType read from a raven::Pile (pile.h:37-47)
+  std::uint32_t begin, end;  // Pile::begin() / end(): bases (begin_ << kPSS)
+  bool invalid;
+};
+
+// overlap_utils.cc:14-80
+static bool OverlapUpdate(Overlap& o, const std::vector<PileView>& piles) {
+  if (piles[o.lhs_id].invalid || piles[o.rhs_id].invalid) return false;
+  if (o.lhs_begin >= piles[o.lhs_id].end || o.lhs_end <= piles[o.lhs_id].begin ||
+      o.rhs_begin >= piles[o.rhs_id].end || o.rhs_end <= piles[o.rhs_id].begin) return false;
+  std::uint32_t lhs_begin = o.lhs_begin + (o.strand
+      ? (o.rhs_begin < piles[o.rhs_id].begin ? piles[o.rhs_id].begin - o.rhs_begin : 0)
+      : (o.rhs_end > piles[o.rhs_id].end ? o.rhs_end - piles[o.rhs_id].end : 0));
+  std::uint32_t lhs_end = o.lhs_end - (o.strand
+      ? (o.rhs_end > piles[o.rhs_id].end ? o.rhs_end - piles[o.rhs_id].end : 0)
+      : (o.rhs_begin < piles[o.rhs_id].begin ? piles[o.rhs_id].begin - o.rhs_begin : 0));
+  std::uint32_t rhs_begin = o.rhs_begin + (o.strand
+      ? (o.lhs_begin < piles[o.lhs_id].begin ? piles[o.lhs_id].begin - o.lhs_begin : 0)
+      : (o.lhs_end > piles[o.lhs_id].end ? o.lhs_end - piles[o.lhs_id].end : 0));
+  std::uint32_t rhs_end = o.rhs_end - (o.strand
+      ? (o.lhs_end > piles[o.lhs_id].end ? o.lhs_end - piles[o.lhs_id].end : 0)
+      : (o.lhs_begin < piles[o.lhs_id].begin ? piles[o.lhs_id].begin - o.lhs_begin : 0));
+  if (lhs_begin >= piles[o.lhs_id].end || lhs_end <= piles[o.lhs_id].begin ||
+      rhs_begin >= piles[o.rhs_id].end || rhs_end <= piles[o.rhs_id].begin) return false;
+  lhs_begin = std::max(lhs_begin, piles[o.lhs_id].begin);
+  lhs_end = std::min(lhs_end, piles[o.lhs_id].end);
+  rhs_begin = std::max(rhs_begin, piles[o.rhs_id].begin);
+  rhs_end = std::min(rhs_end, piles[o.rhs_id].end);
+  if (lhs_begin >= lhs_end || lhs_end - lhs_begin < 84 || rhs_begin >= rhs_end || rhs_end - rhs_begin < 84) return false;
+  o.lhs_begin = lhs_begin;
+  o.lhs_end = lhs_end;
+  o.rhs_begin = rhs_begin;
+  o.rhs_end = rhs_end;
+  return true;
+}
+
+// overlap_utils.cc:82-113
+static std::uint32_t GetOverlapType(const Overlap& o, const std::vector<PileView>& piles) {
+  std::uint32_t lhs_length = piles[o.lhs_id].end - piles[o.lhs_id].begin;
+  std::uint32_t lhs_begin = o.lhs_begin - piles[o.lhs_id].begin;
+  std::uint32_t lhs_end = o.lhs_end - piles[o.lhs_id].begin;
+  std::uint32_t rhs_length = piles[o.rhs_id].end - piles[o.rhs_id].begin;
+  std::uint32_t rhs_begin = o.strand ? o.rhs_begin - piles[o.rhs_id].begin
+                                     : rhs_length - (o.rhs_end - piles[o.rhs_id].begin);
+  std::uint32_t rhs_end = o.strand ? o.rhs_end - piles[o.rhs_id].begin
+                                   : rhs_length - (o.rhs_begin - piles[o.rhs_id].begin);
+  std::uint32_t overhang = std::min(lhs_begin, rhs_begin) + std::min(lhs_length - lhs_end, rhs_length - rhs_end);
+  if (lhs_end - lhs_begin < (lhs_end - lhs_begin + overhang) * 0.875 ||
+      rhs_end - rhs_begin < (rhs_end - rhs_begin + overhang) * 0.875) return 0;  // internal
+  if (lhs_begin <= rhs_begin && lhs_length - lhs_end <= rhs_length - rhs_end) return 1;  // lhs contained
+  if (rhs_begin <= lhs_begin && rhs_length - rhs_end <= lhs_length - lhs_end) return 2;  // rhs contained
+  if (lhs_begin > rhs_begin) return 3;  // lhs -> rhs
+  return 4;                             // rhs -> lhs
+}
+
+// the identity score of construct.cc:176-203 / :393-420: spans inflated, rhs reverse-complemented on the opposite
+// strand, edlibAlign(default) -> 1 - distance / max(length)
+static double IdentityScore(const Overlap& it, const Read& lhs_seq, const Read& rhs_seq) {
+  std::string lhs, rhs;
+  for (std::uint32_t i = it.lhs_begin; i < it.lhs_end; ++i) lhs += "ACGT"[lhs_seq.Code(i)];
+  for (std::uint32_t i = it.rhs_begin; i < it.rhs_end; ++i) rhs += "ACGT"[rhs_seq.Code(i)];
+  if (!it.strand) {
+    std::string rc(rhs.rbegin(), rhs.rend());
+    for (auto& c : rc) c = c == 'A' ? 'T' : (c == 'C' ? 'G' : (c == 'G' ? 'C' : 'A'));
+    rhs = rc;
+  }
+  const std::uint32_t d = EditDistance(lhs.c_str(), lhs.size(), rhs.c_str(), rhs.size());
+  return 1. - static_cast<double>(d) / std::max(lhs.size(), rhs.size());
+}
+
+}  // namespace orc
+
+extern "C" {
+
+// OverlapUpdate + GetOverlapType on a list (tests of the device classification): ok[i] = OverlapUpdate result, the
+// overlap is updated in place when ok, type[i] = GetOverlapType of the updated overlap (undefined when !ok)
+void orc_overlap_update_and_type(orc::Overlap* ovl, std::uint64_t n, const std::uint32_t* begin, const std::uint32_t* end,
+                                 const std::uint8_t* invalid, std::uint32_t n_piles, std::uint8_t* ok, std::uint32_t* type) {
+  std::vector<orc::PileView> piles(n_piles);
+  for (std::uint32_t i = 0; i < n_piles; ++i) piles[i] = orc::PileView{begin[i], end[i], invalid[i] != 0};
+  for (std::uint64_t i = 0; i < n; ++i) {
+    ok[i] = orc::OverlapUpdate(ovl[i], piles) ? 1 : 0;
+    type[i] = ok[i] ? orc::GetOverlapType(ovl[i], piles) : 0xFFFFFFFFu;
+  }
+}
+
+// The identity filter loop of ResolveContainedReads (construct.cc:162-217) on per-pile overlap lists (CSR, in place):
+// returns the new total; offsets are rewritten.
+std::uint64_t orc_identity_filter(const std::uint64_t* packed, const std::uint64_t* word_offsets, const std::uint32_t* lengths,
+                                  std::uint32_t n_reads, orc::Overlap* ovl, std::uint32_t* offsets,
+                                  const std::uint32_t* begin, const std::uint32_t* end, const std::uint8_t* invalid,
+                                  double identity) {
+  auto reads = MakeReads(packed, word_offsets, lengths, nullptr, n_reads);
+  std::vector<orc::PileView> piles(n_reads);
+  for (std::uint32_t i = 0; i < n_reads; ++i) piles[i] = orc::PileView{begin[i], end[i], invalid[i] != 0};
+  std::uint64_t out = 0;
+  std::uint32_t prev_end = offsets[0];
+  for (std::uint32_t i = 0; i < n_reads; ++i) {
+    const std::uint32_t b = prev_end, e = offsets[i + 1];
+    prev_end = e;
+    offsets[i] = static_cast<std::uint32_t>(out);
+    for (std::uint32_t j = b; j < e; ++j) {
+      orc::Overlap o = ovl[j];
+      if (!orc::OverlapUpdate(o, piles)) continue;
+      if (orc::IdentityScore(o, reads[o.lhs_id], reads[o.rhs_id]) < identity) continue;
+      ovl[out++] = o;
+    }
+  }
+  offsets[n_reads] = static_cast<std::uint32_t>(out);
+  return out;
+}
+
+// raven::FindOverlapsAndRepetetiveRegions (construct.cc:316-491) restated: valid reads first (by id), index batches of
+// `batch_bases` (reference 1 << 30) of valid reads without minhash, Map(true, true, false, &filtered) of every valid
+// read up to the batch end, Pile::AddKmers of the filtered positions, optional identity filter, then the serial
+// merge: OverlapUpdate, GetOverlapType, containment flags, consecutive same-pair overlaps keep the longer; finally
+// contained piles become invalid and the list is re-checked with OverlapUpdate.
+// Outputs: overlaps (the extra slot overlaps.back()), contained[n] (set_is_contained by this pass), kmers: per read
+// (len >> 4) + 1 cells at kmers_off[i] (all reads; untouched = 0).  Returns the number of overlaps (<= cap or -1).
+std::int64_t orc_second_pass(orc_engine* eng, const std::uint64_t* packed, const std::uint64_t* word_offsets,
+                             const std::uint32_t* lengths, std::uint32_t n_reads, const std::uint32_t* begin,
+                             const std::uint32_t* end, const std::uint8_t* invalid, double freq, std::uint32_t kmer_len,
+                             double identity, std::uint64_t batch_bases, orc::Overlap* out, std::uint64_t cap,
+                             std::uint8_t* contained, std::uint8_t* kmers, const std::uint64_t* kmers_off) {
+  auto all = MakeReads(packed, word_offsets, lengths, nullptr, n_reads);
+  std::vector<orc::PileView> piles(n_reads);
+  for (std::uint32_t i = 0; i < n_reads; ++i) piles[i] = orc::PileView{begin[i], end[i], invalid[i] != 0};
+  // construct.cc:324-332: valid first, each group by id
+  std::vector<orc::Read> sequences;
+  for (std::uint32_t i = 0; i < n_reads; ++i) if (!piles[i].invalid) sequences.push_back(all[i]);
+  const std::uint32_t s = sequences.size();
+  std::vector<orc::Overlap> back;
+  std::uint64_t bytes = 0;
+  for (std::uint32_t i = 0, j = 0; i < s; ++i) {
+    bytes += sequences[i].len;
+    if (i != s - 1 && bytes < batch_bases) continue;
+    bytes = 0;
+    eng->e.Minimize(sequences.data() + j, sequences.data() + i + 1, false, 1);
+    eng->e.Filter(freq);
+    for (std::uint32_t k = 0; k < i + 1; ++k) {
+      std::vector<std::uint32_t> filtered;
+      auto dst = eng->e.Map(sequences[k], true, true, false, &filtered);
+      if (!filtered.empty())
+        orc_pile_add_kmers(sequences[k].words, sequences[k].len, filtered.data(), filtered.size(), kmer_len,
+                           kmers + kmers_off[sequences[k].id]);
+      if (identity != 0) {
+        std::uint32_t kk = 0;
+        for (std::uint32_t x = 0; x < dst.size(); ++x) {
+          if (!orc::OverlapUpdate(dst[x], piles)) continue;
+          if (orc::IdentityScore(dst[x], all[dst[x].lhs_id], all[dst[x].rhs_id]) < identity) continue;
+          dst[kk++] = dst[x];
+        }
+        dst.resize(kk);
+      }
+      for (auto& jt : dst) {  // construct.cc:430-455
+        if (!orc::OverlapUpdate(jt, piles)) continue;
+        const std::uint32_t type = orc::GetOverlapType(jt, piles);
+        if (type == 0) continue;
+        if (type == 1) contained[jt.lhs_id] = 1;
+        else if (type == 2) contained[jt.rhs_id] = 1;
+        else if (!back.empty() && back.back().lhs_id == jt.lhs_id && back.back().rhs_id == jt.rhs_id) {
+          if (orc::GetOverlapLength(back.back()) < orc::GetOverlapLength(jt)) back.back() = jt;
+        } else {
+          back.push_back(jt);
+        }
+      }
+    }
+    j = i + 1;
+  }
+  for (std::uint32_t i = 0; i < n_reads; ++i) if (contained[i]) piles[i].invalid = true;  // construct.cc:466-470
+  std::uint64_t k = 0;
+  for (std::uint64_t i = 0; i < back.size(); ++i)
+    if (orc::OverlapUpdate(back[i], piles)) back[k++] = back[i];
+  back.resize(k);
+  if (k > cap) return -1;
+  for (std::uint64_t i = 0; i < k; ++i) out[i] = back[i];
+  return static_cast<std::int64_t>(k);
+}
+
+}  // extern "C"
+
 // ---- racon::Polisher::Polish, one round (recollection of racon@library polisher.cpp /
 // overlap.cpp / window.cpp; raven call site RavenLib/src/polish.cc:43-51) --------------------------------
 // (1) ram(15,5) index of the targets, Filter(0.001), Map(read, false, false); keep the longest overlap per read,

@@ -208,7 +208,51 @@ __global__ __launch_bounds__(64) void ed_full_kernel(const u64* __restrict__ pac
   if (lane == 0) out[p] = result - 1u;
 }
 
+__global__ void ed_count_overflow_kernel(const u32* __restrict__ out, u32 n, u32* __restrict__ cnt) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && out[i] == kEdOverflow) atomicAdd(cnt, 1u);
+}
+
 }  // namespace
+
+// pairs and results resident in HBM: d_pairs = n_pairs x {a_idx,a_begin,a_len,b_idx,b_begin,b_len,strand,0}, d_out u32[n]
+void edit_distance_dev(Engine& e, const ReadsDev& r, const u32* d_pairs_raw, u32 n_pairs, u32* d_out) {
+  if (n_pairs == 0) return;
+  hipStream_t s = e.stream;
+  const EdPair* d_pairs = reinterpret_cast<const EdPair*>(d_pairs_raw);
+  RVN_KLAUNCH(kKEditBanded, ed_banded_kernel<4><<<div_up(n_pairs, 4), 256, 0, s>>>(
+                                r.packed.as<u64>(), r.word_off.as<u64>(), d_pairs, n_pairs, d_out));
+  // pairs beyond the ring capacity (rare): unbanded striped sweep
+  u32* d_cnt = e.ed_cnt.get<u32>(4);
+  RVN_HIP(hipMemsetAsync(d_cnt, 0, 4, s));
+  ed_count_overflow_kernel<<<div_up(n_pairs, 256), 256, 0, s>>>(d_out, n_pairs, d_cnt);
+  RVN_LAUNCH_CHECK();
+  if (read_back(e, d_cnt, 4) == 0) return;
+  std::vector<u32> h_out(n_pairs);
+  std::vector<EdPair> hp(n_pairs);
+  RVN_HIP(hipMemcpyAsync(h_out.data(), d_out, static_cast<size_t>(n_pairs) * 4, hipMemcpyDeviceToHost, s));
+  RVN_HIP(hipMemcpyAsync(hp.data(), d_pairs, static_cast<size_t>(n_pairs) * sizeof(EdPair), hipMemcpyDeviceToHost, s));
+  RVN_HIP(hipStreamSynchronize(s));
+  std::vector<u32> todo;
+  std::vector<u64> hb_off;
+  u64 hb_total = 0;
+  for (u32 i = 0; i < n_pairs; ++i) {
+    if (h_out[i] == kEdOverflow) {
+      todo.push_back(i);
+      hb_off.push_back(hb_total);
+      hb_total += 2ULL * (static_cast<u64>(hp[i].b_len) + 1);
+    }
+  }
+  u32* d_todo = e.tmp_c.get<u32>(todo.size() + 1);
+  u64* d_off = e.tmp_d.get<u64>(hb_off.size() + 1);
+  signed char* d_hb = e.tmp_f.get<signed char>(hb_total + 16);
+  RVN_HIP(hipMemcpyAsync(d_todo, todo.data(), todo.size() * 4, hipMemcpyHostToDevice, s));
+  RVN_HIP(hipMemcpyAsync(d_off, hb_off.data(), hb_off.size() * 8, hipMemcpyHostToDevice, s));
+  RVN_KLAUNCH(kKEditFull, ed_full_kernel<<<static_cast<u32>(todo.size()), 64, 0, s>>>(
+                              r.packed.as<u64>(), r.word_off.as<u64>(), d_pairs, d_todo,
+                              static_cast<u32>(todo.size()), d_off, d_hb, d_out));
+  RVN_HIP(hipStreamSynchronize(s));  // the host lists above are locals
+}
 
 // pairs: host array of n_pairs x 8 u32 {a_idx,a_begin,a_len,b_idx,b_begin,b_len,strand,0}; out: host u32[n_pairs]
 void edit_distance_batch(Engine& e, const ReadsDev& r, const u32* h_pairs, u32 n_pairs, u32* h_out,
@@ -219,35 +263,10 @@ void edit_distance_batch(Engine& e, const ReadsDev& r, const u32* h_pairs, u32 n
   u32* d_out = e.tmp_b.get<u32>(static_cast<size_t>(n_pairs) + 1);
   RVN_HIP(hipMemcpyAsync(d_pairs, h_pairs, static_cast<size_t>(n_pairs) * sizeof(EdPair), hipMemcpyHostToDevice, s));
   RVN_HIP(hipEventRecord(e.ev0, s));
-  RVN_KLAUNCH(kKEditBanded, ed_banded_kernel<4><<<div_up(n_pairs, 4), 256, 0, s>>>(
-                                r.packed.as<u64>(), r.word_off.as<u64>(), d_pairs, n_pairs, d_out));
+  edit_distance_dev(e, r, reinterpret_cast<const u32*>(d_pairs), n_pairs, d_out);
+  RVN_HIP(hipEventRecord(e.ev1, s));
   RVN_HIP(hipMemcpyAsync(h_out, d_out, static_cast<size_t>(n_pairs) * 4, hipMemcpyDeviceToHost, s));
   RVN_HIP(hipStreamSynchronize(s));
-  // pairs beyond the ring capacity: unbanded striped sweep
-  std::vector<u32> todo;
-  std::vector<u64> hb_off;
-  u64 hb_total = 0;
-  const EdPair* hp = reinterpret_cast<const EdPair*>(h_pairs);
-  for (u32 i = 0; i < n_pairs; ++i) {
-    if (h_out[i] == kEdOverflow) {
-      todo.push_back(i);
-      hb_off.push_back(hb_total);
-      hb_total += 2ULL * (static_cast<u64>(hp[i].b_len) + 1);
-    }
-  }
-  if (!todo.empty()) {
-    u32* d_todo = e.tmp_c.get<u32>(todo.size() + 1);
-    u64* d_off = e.tmp_d.get<u64>(hb_off.size() + 1);
-    signed char* d_hb = e.tmp_f.get<signed char>(hb_total + 16);
-    RVN_HIP(hipMemcpyAsync(d_todo, todo.data(), todo.size() * 4, hipMemcpyHostToDevice, s));
-    RVN_HIP(hipMemcpyAsync(d_off, hb_off.data(), hb_off.size() * 8, hipMemcpyHostToDevice, s));
-    RVN_KLAUNCH(kKEditFull, ed_full_kernel<<<static_cast<u32>(todo.size()), 64, 0, s>>>(
-                                r.packed.as<u64>(), r.word_off.as<u64>(), d_pairs, d_todo,
-                                static_cast<u32>(todo.size()), d_off, d_hb, d_out));
-    RVN_HIP(hipMemcpyAsync(h_out, d_out, static_cast<size_t>(n_pairs) * 4, hipMemcpyDeviceToHost, s));
-    RVN_HIP(hipStreamSynchronize(s));
-  }
-  RVN_HIP(hipEventRecord(e.ev1, s));
   RVN_HIP(hipEventSynchronize(e.ev1));
   if (kernel_ms) {
     float ms = 0;
@@ -255,6 +274,7 @@ void edit_distance_batch(Engine& e, const ReadsDev& r, const u32* h_pairs, u32 n
     *kernel_ms = ms;
   }
   if (cells) {
+    const EdPair* hp = reinterpret_cast<const EdPair*>(h_pairs);
     u64 c = 0;
     for (u32 i = 0; i < n_pairs; ++i) c += static_cast<u64>(hp[i].a_len) * hp[i].b_len;
     *cells = c;

@@ -119,6 +119,9 @@ struct Engine {
   DevBuf seg_off, iv_slot_begin, iv_slot_end, iv_cnt, iv_off, iv_begin, iv_end;
   DevBuf lis_min, lis_pred, lis_tail, lis_mask, ovl_slots, ovl_flags, ovl_scan;
   DevBuf poa_scratch, poa2_scratch, polish_quals;
+  DevBuf ed_cnt;
+  // second pass / identity filters (pass2.hip)
+  DevBuf p2_slot, p2_pairs, p2_dist, p2_regions, p2_index_of, p2_kmers_off, p2_ok, p2_keep, p2_tmp_ovl;
   DevBuf poa_sched, poa_redo_w, poa_redo_i;  // LPT order / escalation lists of a POA batch (poa_run_dev)
   // alignment-path stage of a polishing round (nwpath.hip): stored band words + scores, jobs, results
   DevBuf nw_pm, nw_sc, nw_ck_pm, nw_ck_sc, nw_jobs, nw_res;  // segment scratch of the waves, checkpoints, jobs, results
@@ -211,6 +214,8 @@ void chain_matches(Engine& e, const ReadsDev& r, u32 first, u32 last, u64 H, Map
 // Batched exact edit distance (edit_distance.hip). h_pairs: n_pairs x {a_idx,a_begin,a_len,b_idx,b_begin,b_len,strand,0}
 void edit_distance_batch(Engine& e, const ReadsDev& r, const u32* h_pairs, u32 n_pairs, u32* h_out, double* kernel_ms,
                          u64* cells);
+// the same with pairs and distances resident in HBM (pass2.hip: identity filters)
+void edit_distance_dev(Engine& e, const ReadsDev& r, const u32* d_pairs, u32 n_pairs, u32* d_out);
 
 // Batched POA window consensus (poa.hip); all arrays are host pointers, see rvn_poa_consensus_batch
 void poa_consensus_batch(Engine& e, const u8* h_codes, const u8* h_quals, const u64* h_layer_off, const u32* h_begins,
@@ -245,6 +250,24 @@ void polish_round(Engine& e, ReadsDev& T, ReadsDev& R, const u8* h_quals, const 
                   double err_thr, u32 w, bool trim, int m, int n, int g, std::vector<std::vector<u8>>& polished,
                   std::vector<double>& ratio, PolishStats& stats, u64 win_first = 0, u64 win_last = ~0ULL,
                   std::vector<u32>* win_count = nullptr, std::vector<u32>* win_polished = nullptr);
+
+// Result of the second mapping pass (pass2.hip), resident in HBM
+struct Pass2State {
+  u32 n = 0;
+  u64 n_overlaps = 0;
+  DevBuf ovl;        // Overlap[n_overlaps]: overlaps.back() of construct.cc:352,451
+  DevBuf contained;  // u8[n]: piles this pass marked as contained
+  DevBuf kmers;      // Pile::kmers_ cells: (len >> 4) + 1 bytes per VALID read at h_kmers_off[id] (0 bytes for invalid ones)
+  std::vector<u64> h_kmers_off;
+  u64 kmers_total = 0;
+};
+// ram::MinimizerEngine::Minimize(first, last, minhash) on a read set (engine.hip)
+void engine_minimize(Engine& e, const ReadsDev& r, u32 first, u32 last, bool minhash);
+void reads_subset(Engine& e, const ReadsDev& R, const std::vector<u32>& src, ReadsDev& V);
+void second_pass(Engine& e, const ReadsDev& R, const u32* h_begin, const u32* h_end, const u8* h_invalid, double freq,
+                 u32 kmer_len, double identity, u64 batch_bases, Pass2State& out);
+void identity_filter_lists(Engine& e, const ReadsDev& R, Overlap* h_ovl, u32* h_off, const u32* h_begin, const u32* h_end,
+                           const u8* h_invalid, double identity);
 
 // Pass-1 state: per-pile kept overlaps + coverage (pile.hip)
 struct PileState {

@@ -8,6 +8,7 @@
 #include "../../include/raven_hip.h"
 #include "introsort.h"
 #include "nwpath.h"
+#include "overlap_rules.h"
 #include "poa.h"
 #include "kmer.h"
 #include "lowcomplexity.h"
@@ -148,6 +149,18 @@ void do_minimize(Engine& e, const ReadsDev& r, u32 first, u32 last, bool minhash
 }
 
 }  // namespace
+
+namespace rvn {
+void engine_minimize(Engine& e, const ReadsDev& r, u32 first, u32 last, bool minhash) {
+  do_minimize(e, r, first, last, minhash);
+}
+}  // namespace rvn
+
+struct rvn_pass2 {
+  Engine* e = nullptr;
+  Pass2State st;
+  std::weak_ptr<int> engine_life;
+};
 
 extern "C" {
 
@@ -571,6 +584,83 @@ int rvn_pass1_fetch_overlaps(const rvn_pass1* p, rvn_overlap* overlaps, uint32_t
 }
 
 void rvn_pass1_destroy(rvn_pass1* p) { delete p; }
+
+int rvn_find_overlaps_and_repetitive_regions(rvn_engine* h, const rvn_reads* rr, const uint32_t* pile_begin,
+                                             const uint32_t* pile_end, const uint8_t* pile_invalid, double freq,
+                                             uint32_t kmer_len, double identity, uint64_t batch_bases, rvn_pass2** out) {
+  return guarded(h ? &h->e : nullptr, [&]() -> int {
+    if (!h || !rr || !out || (rr->r.n && (!pile_begin || !pile_end || !pile_invalid)))
+      return fail(RVN_EINVAL, "[raven_hip] rvn_find_overlaps_and_repetitive_regions: NULL argument");
+    if (!(0 <= freq && freq <= 1)) return fail(RVN_EINVAL, "[ram::MinimizerEngine::Filter] error: invalid frequency");
+    if (kmer_len == 0 || kmer_len > 32) return fail(RVN_EINVAL, "[raven_hip] kmer_len must be in [1, 32]");
+    if (batch_bases == 0) return fail(RVN_EINVAL, "[raven_hip] batch_bases must be positive");
+    Engine& e = h->e;
+    const ReadsDev& r = rr->r;
+    for (u32 i = 0; i < r.n; ++i)
+      if (r.h_id[i] != i) return fail(RVN_EINVAL, "[raven_hip] FindOverlapsAndRepetetiveRegions requires ids[i] == i");
+    RVN_HIP(hipSetDevice(e.device));
+    UseTimers ut(e);
+    std::unique_ptr<rvn_pass2> p(new rvn_pass2());
+    p->e = &e;
+    p->engine_life = e.life;
+    second_pass(e, r, pile_begin, pile_end, pile_invalid, freq, kmer_len, identity, batch_bases, p->st);
+    *out = p.release();
+    return RVN_OK;
+  });
+}
+
+uint64_t rvn_pass2_num_overlaps(const rvn_pass2* p) { return p ? p->st.n_overlaps : 0; }
+uint64_t rvn_pass2_kmer_cells(const rvn_pass2* p) { return p ? p->st.kmers_total : 0; }
+
+int rvn_pass2_fetch(const rvn_pass2* p, rvn_overlap* overlaps, uint8_t* contained, uint8_t* kmers, uint64_t* kmers_offsets) {
+  if (!p) return fail(RVN_EINVAL, "[raven_hip] NULL pass2");
+  if (p->engine_life.expired()) return fail(RVN_EINVAL, "[raven_hip] the engine of this result is gone");
+  return guarded(p->e, [&]() -> int {
+    RVN_HIP(hipSetDevice(p->e->device));
+    const Pass2State& st = p->st;
+    if (overlaps && st.n_overlaps)
+      RVN_HIP(hipMemcpy(overlaps, st.ovl.ptr, st.n_overlaps * sizeof(Overlap), hipMemcpyDeviceToHost));
+    if (contained && st.n) RVN_HIP(hipMemcpy(contained, st.contained.ptr, st.n, hipMemcpyDeviceToHost));
+    if (kmers && st.kmers_total) RVN_HIP(hipMemcpy(kmers, st.kmers.ptr, st.kmers_total, hipMemcpyDeviceToHost));
+    if (kmers_offsets) std::memcpy(kmers_offsets, st.h_kmers_off.data(), st.h_kmers_off.size() * 8);
+    return RVN_OK;
+  });
+}
+
+void rvn_pass2_destroy(rvn_pass2* p) { delete p; }
+
+int rvn_filter_overlaps_by_identity(rvn_engine* h, const rvn_reads* rr, rvn_overlap* overlaps, uint32_t* offsets,
+                                    const uint32_t* pile_begin, const uint32_t* pile_end, const uint8_t* pile_invalid,
+                                    double identity) {
+  return guarded(h ? &h->e : nullptr, [&]() -> int {
+    if (!h || !rr || !offsets || !pile_begin || !pile_end || !pile_invalid || (offsets[rr->r.n] && !overlaps))
+      return fail(RVN_EINVAL, "[raven_hip] rvn_filter_overlaps_by_identity: NULL argument");
+    const ReadsDev& r = rr->r;
+    for (u32 i = 0; i < r.n; ++i)
+      if (r.h_id[i] != i) return fail(RVN_EINVAL, "[raven_hip] the identity filter requires ids[i] == i");
+    for (u64 x = 0; x < offsets[r.n]; ++x)
+      if (overlaps[x].lhs_id >= r.n || overlaps[x].rhs_id >= r.n)
+        return fail(RVN_EINVAL, "[raven_hip] rvn_filter_overlaps_by_identity: overlap of an unknown read");
+    RVN_HIP(hipSetDevice(h->e.device));
+    UseTimers ut(h->e);
+    identity_filter_lists(h->e, r, reinterpret_cast<Overlap*>(overlaps), offsets, pile_begin, pile_end, pile_invalid, identity);
+    return RVN_OK;
+  });
+}
+
+int rvn_test_overlap_update_and_type(rvn_overlap* overlaps, uint64_t n, const uint32_t* pile_begin, const uint32_t* pile_end,
+                                     const uint8_t* pile_invalid, uint32_t n_piles, uint8_t* ok, uint32_t* type) {
+  if (!overlaps || !pile_begin || !pile_end || !pile_invalid || !ok || !type) return RVN_EINVAL;
+  for (uint64_t i = 0; i < n; ++i) {
+    Overlap& o = reinterpret_cast<Overlap*>(overlaps)[i];
+    if (o.lhs_id >= n_piles || o.rhs_id >= n_piles) return RVN_EINVAL;
+    const PileRegion L{pile_begin[o.lhs_id], pile_end[o.lhs_id], pile_invalid[o.lhs_id] ? 1u : 0u};
+    const PileRegion R{pile_begin[o.rhs_id], pile_end[o.rhs_id], pile_invalid[o.rhs_id] ? 1u : 0u};
+    ok[i] = overlap_update(o, L, R) ? 1 : 0;
+    type[i] = ok[i] ? overlap_type(o, L, R) : 0xFFFFFFFFu;
+  }
+  return RVN_OK;
+}
 
 int rvn_pile_add_layers(rvn_engine* h, uint16_t* data, uint32_t cells, uint32_t id, const rvn_overlap* overlaps,
                         uint64_t n) {

@@ -45,6 +45,8 @@ SYMBOLS = [
     "rvn_engine_reset_stats", "rvn_engine_set_timing", "rvn_engine_set_kernel_timing",
     "rvn_engine_num_kernel_sites", "rvn_engine_kernel_site_name", "rvn_engine_kernel_ms", "rvn_test_hash", "rvn_test_canonical",
     "rvn_test_std_sort_lendesc", "rvn_test_heap_sort_lendesc", "rvn_engine_map_collect", "rvn_free",
+    "rvn_find_overlaps_and_repetitive_regions", "rvn_pass2_num_overlaps", "rvn_pass2_kmer_cells", "rvn_pass2_fetch",
+    "rvn_pass2_destroy", "rvn_filter_overlaps_by_identity", "rvn_test_overlap_update_and_type",
 ]
 
 
@@ -98,6 +100,15 @@ def lib():
     L.rvn_test_nw_breakpoints.restype = i32
     L.rvn_reads_attach_quality.argtypes = [vp, vp, vp, vp, i32]
     L.rvn_reads_upload_codes.argtypes = [vp, vp, vp, vp, u32, pp]
+    L.rvn_find_overlaps_and_repetitive_regions.argtypes = [vp, vp, vp, vp, vp, dbl, u32, dbl, u64, pp]
+    L.rvn_pass2_num_overlaps.argtypes = [vp]
+    L.rvn_pass2_num_overlaps.restype = u64
+    L.rvn_pass2_kmer_cells.argtypes = [vp]
+    L.rvn_pass2_kmer_cells.restype = u64
+    L.rvn_pass2_fetch.argtypes = [vp, vp, vp, vp, vp]
+    L.rvn_pass2_destroy.argtypes = [vp]
+    L.rvn_filter_overlaps_by_identity.argtypes = [vp, vp, vp, vp, vp, vp, vp, dbl]
+    L.rvn_test_overlap_update_and_type.argtypes = [vp, u64, vp, vp, vp, u32, vp, vp]
     L.rvn_poa_work.argtypes = [vp, vp]
     L.rvn_poa_work.restype = None
     L.rvn_polish_fetch_layers.argtypes = [vp, vp, u64, C.POINTER(u64)]
@@ -499,6 +510,43 @@ class Engine:
         cons = [out[int(ooff[i]): int(ooff[i]) + int(out_len[i])].copy() for i in range(nt)]
         return cons, nw, npol, {"n_windows": int(stats[3]), "n_layers": int(stats[2])}
 
+    # -- second mapping pass and identity filter (construct.cc:316-491, :162-217) ------------------------------------
+    def find_overlaps_and_repetitive_regions(self, reads: Reads, pile_begin, pile_end, pile_invalid, freq=0.001,
+                                             kmer_len=None, identity=0.0, batch_bases=1 << 30):
+        """raven::FindOverlapsAndRepetetiveRegions on the device.  pile_begin / pile_end in bases (Pile::begin() /
+        end()), pile_invalid 0/1.  Returns dict(overlaps, contained[n], kmers (list of per-read uint8 cell arrays, empty
+        for invalid reads))."""
+        n = reads.n
+        b = np.ascontiguousarray(pile_begin, dtype=np.uint32)
+        en = np.ascontiguousarray(pile_end, dtype=np.uint32)
+        inv = np.ascontiguousarray(pile_invalid, dtype=np.uint8)
+        assert b.shape[0] == n and en.shape[0] == n and inv.shape[0] == n
+        h = C.c_void_p()
+        L = lib()
+        _check(L.rvn_find_overlaps_and_repetitive_regions(self._h, reads._h, _p(b), _p(en), _p(inv), float(freq),
+                                                          int(self.k if kmer_len is None else kmer_len), float(identity),
+                                                          int(batch_bases), C.byref(h)))
+        try:
+            no, nk = int(L.rvn_pass2_num_overlaps(h)), int(L.rvn_pass2_kmer_cells(h))
+            ovl = np.zeros(no, dtype=OVERLAP_DTYPE)
+            contained = np.zeros(n, dtype=np.uint8)
+            kmers = np.zeros(nk, dtype=np.uint8)
+            koff = np.zeros(n + 1, dtype=np.uint64)
+            _check(L.rvn_pass2_fetch(h, _p(ovl), _p(contained), _p(kmers), _p(koff)))
+        finally:
+            L.rvn_pass2_destroy(h)
+        return dict(overlaps=ovl, contained=contained, kmers=[kmers[int(koff[i]):int(koff[i + 1])] for i in range(n)])
+
+    def filter_overlaps_by_identity(self, reads: Reads, overlaps, offsets, pile_begin, pile_end, pile_invalid, identity):
+        """Identity filter loop of ResolveContainedReads on per-pile lists: returns (overlaps, offsets) filtered."""
+        o = np.ascontiguousarray(overlaps, dtype=OVERLAP_DTYPE).copy()
+        off = np.ascontiguousarray(offsets, dtype=np.uint32).copy()
+        _check(lib().rvn_filter_overlaps_by_identity(self._h, reads._h, _p(o), _p(off),
+                                                     _p(np.ascontiguousarray(pile_begin, dtype=np.uint32)),
+                                                     _p(np.ascontiguousarray(pile_end, dtype=np.uint32)),
+                                                     _p(np.ascontiguousarray(pile_invalid, dtype=np.uint8)), float(identity)))
+        return o[:int(off[-1])], off
+
     def poa_cells(self):
         """DP work of the banded POA kernel since the last reset_stats (rvn_poa_work)."""
         out = np.zeros(3, dtype=np.uint64)
@@ -681,6 +729,20 @@ class Engine:
 
     def set_timing(self, enabled: bool):
         lib().rvn_engine_set_timing(self._h, int(enabled))
+
+
+def test_overlap_update_and_type(overlaps, pile_begin, pile_end, pile_invalid):
+    """overlap_rules.h on the host (the __host__ __device__ code of the kernels): (updated overlaps, ok, type)."""
+    o = np.ascontiguousarray(overlaps, dtype=OVERLAP_DTYPE).copy()
+    b = np.ascontiguousarray(pile_begin, dtype=np.uint32)
+    ok = np.zeros(o.shape[0], dtype=np.uint8)
+    ty = np.zeros(o.shape[0], dtype=np.uint32)
+    rc = lib().rvn_test_overlap_update_and_type(_p(o), o.shape[0], _p(b), _p(np.ascontiguousarray(pile_end, dtype=np.uint32)),
+                                                _p(np.ascontiguousarray(pile_invalid, dtype=np.uint8)), b.shape[0], _p(ok),
+                                                _p(ty))
+    if rc != 0:
+        raise ValueError("rvn_test_overlap_update_and_type")
+    return o, ok, ty
 
 
 NW_REC_DTYPE = np.dtype([("first_t", "<u4"), ("first_q", "<u4"), ("last_t", "<u4"), ("last_q", "<u4"),
