@@ -91,4 +91,6 @@ def test_identity_filter_of_contained_read_resolution_matches_oracle(identity):
     want_o, want_off = oracle.identity_filter(rs, ovl.astype(oracle.OVERLAP_DTYPE), off, begin, end, invalid, identity)
     assert np.array_equal(got_off, want_off)
     assert np.array_equal(got_o, want_o.astype(hip.OVERLAP_DTYPE))
-    assert 0 < got_o.shape[0] <= ovl.shape[0]
+    assert got_o.shape[0] <= ovl.shape[0]
+    if identity < 0.85:  # ONT-like reads are ~80 % identical to each other: nothing passes 0.9
+        assert got_o.shape[0] > 0
