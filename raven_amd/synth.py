@@ -204,6 +204,14 @@ def make_reads_torch(genome, coverage: float, read_len: int = 10000, *, length_m
         n_reads = int(torch.searchsorted(cs, torch.tensor([target], device=dev, dtype=torch.int64))[0]) + 1
         n_reads = min(n_reads, n_try)
         src_len = L[:n_reads]
+    elif length_model == "normal":  # HiFi-like: N(read_len, 0.1 read_len)
+        n_try = int(target / read_len * 1.1) + 4096
+        L = torch.empty(n_try, device=dev, dtype=torch.float64).normal_(float(read_len), 0.1 * read_len, generator=g)
+        L = L.clamp(min_len, min(max_len, G)).to(torch.int64)
+        cs = torch.cumsum(L, 0)
+        n_reads = int(torch.searchsorted(cs, torch.tensor([target], device=dev, dtype=torch.int64))[0]) + 1
+        n_reads = min(n_reads, n_try)
+        src_len = L[:n_reads]
     else:
         raise ValueError(length_model)
     start = (torch.rand(n_reads, device=dev, dtype=torch.float64, generator=g) * (G - src_len + 1).to(torch.float64)).to(torch.int64)
