@@ -95,6 +95,11 @@ int rvn_engine_map_collect(rvn_engine* e, const rvn_reads* r, uint32_t first, ui
                            int avoid_symmetric, int minhash, int want_filtered, rvn_overlap** overlaps,
                            uint32_t** read_offsets, uint32_t** filtered, uint32_t** filtered_offsets);
 void rvn_free(void* p);
+/* Hands the engine's scratch and intermediate buffers (index, sketches, last Map result, stage scratch) back to the
+ * allocator.  They only ever grow, so that steady-state calls never touch the allocator; the stage entry points
+ * (first pass, second pass, polishing round) call this themselves when less than a third of the HBM is free.
+ * Result handles (rvn_reads, rvn_pass1, rvn_pass2) are not affected; rvn_engine_map_fetch results are. */
+int rvn_engine_release_scratch(rvn_engine* e);
 
 /* raven::FindOverlapsAndCreatePiles (RavenLib/src/construct.cc:14-121; decl construct.h:22-29):
  * index batches of `index_batch_bases` (reference: 1<<32), query flushes of `flush_bases` (reference:

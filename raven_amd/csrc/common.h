@@ -47,6 +47,11 @@ struct DevBuf {
   ~DevBuf() {
     if (ptr) (void)hipFree(ptr);
   }
+  void release() {
+    if (ptr) (void)hipFree(ptr);
+    ptr = nullptr;
+    cap = 0;
+  }
   void reserve(size_t bytes) {
     if (bytes <= cap) return;
     if (ptr) RVN_HIP(hipFree(ptr));

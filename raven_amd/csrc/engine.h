@@ -162,6 +162,14 @@ struct Engine {
   std::shared_ptr<int> life = std::make_shared<int>(0);  // lets handles notice that their engine is gone
 };
 
+// Hands every scratch / intermediate buffer of the engine back to the allocator (index, sketches, last Map result,
+// stage scratch).  Buffers only ever grow, so a stage with a very different footprint (HiFi first pass -> polishing)
+// can otherwise find the HBM full of the previous stage's scratch.  Only valid between stages: nothing of the
+// released state may be needed afterwards (every stage entry point rebuilds what it uses).
+void engine_release_scratch(Engine& e);
+// ... when less than a third of the device memory is free (called at stage entry points)
+void engine_release_scratch_if_tight(Engine& e);
+
 // Reads one 4- or 8-byte value from the device through pinned memory (stream-ordered, then synchronises).
 inline u64 read_back(Engine& e, const void* dptr, size_t bytes) {
   e.h_pin[0] = 0;

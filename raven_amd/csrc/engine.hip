@@ -151,6 +151,37 @@ void do_minimize(Engine& e, const ReadsDev& r, u32 first, u32 last, bool minhash
 }  // namespace
 
 namespace rvn {
+void engine_release_scratch(Engine& e) {
+  if (e.stream) (void)hipStreamSynchronize(e.stream);
+  e.query_ready = false;
+  DevBuf* bufs[] = {
+      &e.index.s_val[0], &e.index.s_val[1], &e.index.s_org[0], &e.index.s_org[1], &e.index.u_val, &e.index.u_start,
+      &e.index.table, &e.index_sketch.val, &e.index_sketch.org, &e.index_sketch.read_off, &e.query_sketch.val,
+      &e.query_sketch.org, &e.query_sketch.read_off, &e.raw_sketch.val, &e.raw_sketch.org, &e.raw_sketch.read_off,
+      &e.map_out.ovl, &e.map_out.ovl_read_off, &e.map_out.filtered, &e.map_out.anchors, &e.map_out.anchor_off,
+      &e.map_out.anchor_cnt, &e.tmp_a, &e.tmp_b, &e.tmp_c, &e.tmp_d, &e.tmp_e, &e.tmp_f, &e.scan_tmp, &e.sort_tmp,
+      &e.q_start, &e.q_cnt, &e.m_off, &e.m_grp[0], &e.m_grp[1], &e.m_pos[0], &e.m_pos[1], &e.seg_off, &e.iv_slot_begin,
+      &e.iv_slot_end, &e.iv_cnt, &e.iv_off, &e.iv_begin, &e.iv_end, &e.lis_min, &e.lis_pred, &e.lis_tail, &e.lis_mask,
+      &e.ovl_slots, &e.ovl_flags, &e.ovl_scan, &e.poa_scratch, &e.poa2_scratch, &e.polish_quals, &e.ed_cnt, &e.p2_slot,
+      &e.p2_pairs, &e.p2_dist, &e.p2_regions, &e.p2_index_of, &e.p2_kmers_off, &e.p2_ok, &e.p2_keep, &e.p2_tmp_ovl,
+      &e.poa_sched, &e.poa_redo_w, &e.poa_redo_i, &e.nw_pm, &e.nw_sc, &e.nw_ck_pm, &e.nw_ck_sc, &e.nw_jobs, &e.nw_res,
+      &e.pl_best, &e.pl_best_t, &e.pl_idmap, &e.pl_recs, &e.pl_keep, &e.pl_win_cnt, &e.pl_win_off, &e.pl_win_fill,
+      &e.pl_win_meta, &e.pl_first_window, &e.pl_keys, &e.pl_lays_tmp, &e.pl_lays, &e.pl_wins, &e.pl_out, &e.pl_len,
+      &e.pl_status, &e.pl_ok, &e.pl_cons_off, &e.pl_final, &e.pl_qual_off, &e.pl_misc, &e.anc_slot_off, &e.anc_slot_cnt};
+  for (DevBuf* b : bufs) b->release();
+  e.index.m = e.index.u = 0;
+  e.index.table_built = false;
+  e.map_out = MapOut();
+  e.polish_last_windows = 0;
+  e.polish_last_layers = 0;
+  delete e.pile_pool;
+  e.pile_pool = nullptr;
+}
+void engine_release_scratch_if_tight(Engine& e) {
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return;
+  if (free_b * 3 < total_b) engine_release_scratch(e);
+}
 void engine_minimize(Engine& e, const ReadsDev& r, u32 first, u32 last, bool minhash) {
   do_minimize(e, r, first, last, minhash);
 }
@@ -434,6 +465,15 @@ int rvn_engine_map_fetch_filtered(rvn_engine* h, uint32_t* positions, uint32_t* 
 
 void rvn_free(void* p) { std::free(p); }
 
+int rvn_engine_release_scratch(rvn_engine* h) {
+  return guarded(h ? &h->e : nullptr, [&]() -> int {
+    if (!h) return fail(RVN_EINVAL, "[raven_hip] NULL engine");
+    RVN_HIP(hipSetDevice(h->e.device));
+    engine_release_scratch(h->e);
+    return RVN_OK;
+  });
+}
+
 int rvn_engine_map_collect(rvn_engine* h, const rvn_reads* r, uint32_t first, uint32_t last, int avoid_equal,
                            int avoid_symmetric, int minhash, int want_filtered, rvn_overlap** overlaps,
                            uint32_t** read_offsets, uint32_t** filtered, uint32_t** filtered_offsets) {
@@ -503,6 +543,7 @@ int rvn_find_overlaps_and_create_piles(rvn_engine* h, const rvn_reads* rr, doubl
       if (r.h_id[i] != i) return fail(RVN_EINVAL, "[raven_hip] FindOverlapsAndCreatePiles requires ids[i] == i");
     RVN_HIP(hipSetDevice(e.device));
     UseTimers ut(e);
+    engine_release_scratch_if_tight(e);
     std::unique_ptr<rvn_pass1> p(new rvn_pass1(e));
     piles_init(e, r, p->ps);
     const u32 n = r.n;
@@ -600,6 +641,7 @@ int rvn_find_overlaps_and_repetitive_regions(rvn_engine* h, const rvn_reads* rr,
       if (r.h_id[i] != i) return fail(RVN_EINVAL, "[raven_hip] FindOverlapsAndRepetetiveRegions requires ids[i] == i");
     RVN_HIP(hipSetDevice(e.device));
     UseTimers ut(e);
+    engine_release_scratch_if_tight(e);
     std::unique_ptr<rvn_pass2> p(new rvn_pass2());
     p->e = &e;
     p->engine_life = e.life;
@@ -721,6 +763,7 @@ int rvn_polish_round_range(rvn_engine* h, rvn_reads* targets, rvn_reads* reads, 
     if (read_quals && !qual_offsets) return fail(RVN_EINVAL, "[raven_hip] qualities without offsets");
     RVN_HIP(hipSetDevice(h->e.device));
     UseTimers ut(h->e);
+    engine_release_scratch_if_tight(h->e);
     std::vector<std::vector<u8>> polished;
     std::vector<double> rt;
     PolishStats st;

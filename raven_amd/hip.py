@@ -46,7 +46,7 @@ SYMBOLS = [
     "rvn_engine_num_kernel_sites", "rvn_engine_kernel_site_name", "rvn_engine_kernel_ms", "rvn_test_hash", "rvn_test_canonical",
     "rvn_test_std_sort_lendesc", "rvn_test_heap_sort_lendesc", "rvn_engine_map_collect", "rvn_free",
     "rvn_find_overlaps_and_repetitive_regions", "rvn_pass2_num_overlaps", "rvn_pass2_kmer_cells", "rvn_pass2_fetch",
-    "rvn_pass2_destroy", "rvn_filter_overlaps_by_identity", "rvn_test_overlap_update_and_type",
+    "rvn_pass2_destroy", "rvn_engine_release_scratch", "rvn_filter_overlaps_by_identity", "rvn_test_overlap_update_and_type",
 ]
 
 
@@ -107,6 +107,7 @@ def lib():
     L.rvn_pass2_kmer_cells.restype = u64
     L.rvn_pass2_fetch.argtypes = [vp, vp, vp, vp, vp]
     L.rvn_pass2_destroy.argtypes = [vp]
+    L.rvn_engine_release_scratch.argtypes = [vp]
     L.rvn_filter_overlaps_by_identity.argtypes = [vp, vp, vp, vp, vp, vp, vp, dbl]
     L.rvn_test_overlap_update_and_type.argtypes = [vp, u64, vp, vp, vp, u32, vp, vp]
     L.rvn_poa_work.argtypes = [vp, vp]
@@ -546,6 +547,9 @@ class Engine:
                                                      _p(np.ascontiguousarray(pile_end, dtype=np.uint32)),
                                                      _p(np.ascontiguousarray(pile_invalid, dtype=np.uint8)), float(identity)))
         return o[:int(off[-1])], off
+
+    def release_scratch(self):
+        _check(lib().rvn_engine_release_scratch(self._h))
 
     def poa_cells(self):
         """DP work of the banded POA kernel since the last reset_stats (rvn_poa_work)."""
