@@ -171,7 +171,9 @@ void engine_release_scratch(Engine& e) {
   for (DevBuf* b : bufs) b->release();
   e.index.m = e.index.u = 0;
   e.index.table_built = false;
-  e.map_out = MapOut();
+  e.map_out.n_query = e.map_out.n_matches = e.map_out.n_intervals = e.map_out.n_overlaps = 0;
+  e.map_out.first = e.map_out.last = 0;
+  e.map_out.has_anchors = false;
   e.polish_last_windows = 0;
   e.polish_last_layers = 0;
   delete e.pile_pool;
