@@ -16,6 +16,8 @@
 //   * pairs whose distance exceeds the ring capacity fall back to an unbanded striped sweep (same block
 //     update, stripe boundaries through a small global array).
 // Integer VALU bound (no MFMA, negligible HBM): report cell updates/s.
+#include <algorithm>
+
 #include "engine.h"
 #include "myers.h"
 #include "wave.h"
@@ -118,36 +120,181 @@ __device__ u32 ed_banded(const u64* __restrict__ a_words, u64 a_base, u32 n, con
   return result - 1u;
 }
 
+constexpr u32 kEdAbove = 0xFFFFFFFEu;  // bounded mode: the distance exceeds the pair's threshold (its exact value is not needed)
+
+// One wave per pair.  todo: indices of the pairs to process (null = all).  kmax (nullable): per-pair threshold — a
+// caller that only needs to know whether the distance is <= kmax (the identity filters: score >= identity) gets the
+// exact distance when it is, kEdAbove otherwise, from ONE sweep at that threshold instead of a doubling sequence.
 template <int R>
 __global__ __launch_bounds__(256) void ed_banded_kernel(const u64* __restrict__ packed,
                                                        const u64* __restrict__ word_off,
-                                                       const EdPair* __restrict__ pairs, u32 n_pairs,
+                                                       const EdPair* __restrict__ pairs, const u32* __restrict__ todo,
+                                                       u32 n_todo, const u32* __restrict__ kmax,
                                                        u32* __restrict__ out) {
-  const u32 p = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (p >= n_pairs) return;
+  const u32 q = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (q >= n_todo) return;
+  const u32 p = todo ? todo[q] : q;
   const EdPair pr = pairs[p];
   const u32 n = pr.a_len, m = pr.b_len;
+  const long long km = kmax ? static_cast<long long>(kmax[p]) : (1LL << 40);
   u32 res;
   if (n == 0 || m == 0) {
     res = n + m;
+    if (static_cast<long long>(res) > km) res = kEdAbove;
   } else {
     const u64* aw = packed + word_off[pr.a_idx];
     const u64* bw = packed + word_off[pr.b_idx];
     const long long cap = 32LL * R * 63;  // ring capacity
-    long long k = n > m ? n - m : m - n;
-    if (k < 64) k = 64;
+    const long long d = n > m ? n - m : m - n;
+    long long k = d < 64 ? 64 : d;
     res = kEdOverflow;
-    while (k <= cap) {
-      const u32 r = ed_banded<R>(aw, pr.a_begin, n, bw, pr.b_begin, m, pr.strand == 0, k);
-      if (static_cast<long long>(r) <= k) {
-        res = r;
-        break;
+    if (d > km) {
+      res = kEdAbove;  // the distance is at least the length difference
+    } else {
+      if (kmax && km <= cap && km > k) k = km;  // bounded: one sweep at the threshold decides
+      while (k <= cap) {
+        const u32 r = ed_banded<R>(aw, pr.a_begin, n, bw, pr.b_begin, m, pr.strand == 0, k);
+        if (static_cast<long long>(r) <= k) {
+          res = static_cast<long long>(r) <= km ? r : kEdAbove;
+          break;
+        }
+        if (k >= km) {  // distance > k >= threshold
+          res = kEdAbove;
+          break;
+        }
+        if (k == cap) break;
+        k = 2 * k < cap ? 2 * k : cap;
       }
-      if (k == cap) break;
-      k = 2 * k < cap ? 2 * k : cap;
     }
   }
   if (lane_id() == 0) out[p] = res;
+}
+
+// One LANE per pair: banded Myers over a window of B consecutive 64-row blocks that slides down the diagonal, all
+// state in registers.  For pairs whose band is a few blocks wide (HiFi-like spans: distance ~1 % of the length) the
+// wave-per-pair systolic kernel above keeps 1 of 64 lanes busy; here 64 pairs share a wave.  Threshold = the largest
+// one whose band fits B blocks (or the pair's kmax if smaller); result exact if <= threshold, else kEdAbove (kmax
+// reached) or kEdOverflow (the pair needs the wave kernel).  `order`: pairs sorted by text length, so that the lanes of
+// a wave run loops of similar length.
+template <int B>
+__global__ __launch_bounds__(64) void ed_lane_kernel(const u64* __restrict__ packed, const u64* __restrict__ word_off,
+                                                    const EdPair* __restrict__ pairs, const u32* __restrict__ order,
+                                                    u32 n_order, const u32* __restrict__ kmax, u32* __restrict__ out) {
+  const u32 q = blockIdx.x * 64 + threadIdx.x;
+  if (q >= n_order) return;
+  const u32 p = order[q];
+  const EdPair pr = pairs[p];
+  const u32 n = pr.a_len, m = pr.b_len;
+  const u32 km = kmax ? kmax[p] : 0xFFFFFFF0u;
+  if (n == 0 || m == 0) {
+    out[p] = (n + m) > km ? kEdAbove : n + m;
+    return;
+  }
+  const u32 d = n > m ? n - m : m - n;
+  if (d > km) {
+    out[p] = kEdAbove;
+    return;
+  }
+  constexpr u32 room = 64u * (B - 2);  // lo + hi of the widest band B blocks can hold
+  if (d > room) {
+    out[p] = kEdOverflow;
+    return;
+  }
+  u32 k = d + ((room - d) / 2) * 2 + 1;
+  if (k > km) k = km;
+  const int lo = static_cast<int>((k - d) / 2 + (m > n ? d : 0u));
+  const int hi = static_cast<int>((k - d) / 2 + (n > m ? d : 0u));
+  const int nb = static_cast<int>((n + 63) >> 6);
+  const u64* aw = packed + word_off[pr.a_idx];
+  const u64* bw = packed + word_off[pr.b_idx];
+  u64 Pv[B], Mv[B], peq[B][4];
+  int sc[B];
+  int base = 0;                    // block held by slot 0
+  int top = -1;                    // last block initialised so far
+  TextCursor tc;
+  tc.init(bw, pr.b_begin, m, pr.strand == 0, 1);
+  u32 result = 0xFFFFFFFFu;
+  for (int j = 1; j <= static_cast<int>(m); ++j) {
+    // slide: blocks whose last band column is behind leave at the top
+    while (64 * base + 64 + lo < j) {
+#pragma unroll
+      for (int i = 0; i + 1 < B; ++i) {
+        Pv[i] = Pv[i + 1];
+        Mv[i] = Mv[i + 1];
+        sc[i] = sc[i + 1];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) peq[i][c] = peq[i + 1][c];
+      }
+      ++base;
+    }
+    // enter: blocks whose first band column is j (or earlier, at the start)
+    int bl = (j + hi - 1) >> 6;
+    bl = bl < nb - 1 ? bl : nb - 1;
+    while (top < bl) {
+      ++top;
+      const int slot = top - base;
+      u64 tp[4];
+      load_peq(aw, pr.a_begin, n, static_cast<u32>(top), tp);
+      int above = 0;  // score of the block above at column j-1 (it is always still inside the band when a block enters)
+#pragma unroll
+      for (int x = 0; x + 1 < B; ++x)
+        if (x + 1 == slot) above = sc[x];
+      // first band column 1: column 0 holds D(i, 0) = i; later: edlib's all-(+1) upper bound below the block above
+      const int first = (64 * top + 1 - hi <= 1) ? 64 * (top + 1) : above + 64;
+#pragma unroll
+      for (int i = 0; i < B; ++i) {
+        if (i == slot) {
+          Pv[i] = ~0ULL;
+          Mv[i] = 0;
+          sc[i] = first;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) peq[i][c] = tp[c];
+        }
+      }
+    }
+    const unsigned c = tc.get(j);
+    int hin = 1;  // above the first band block: the matrix border or a block that left the band (+1 boundary)
+#pragma unroll
+    for (int i = 0; i < B; ++i) {
+      if (base + i <= bl) {
+        const u64 eq = c == 0 ? peq[i][0] : (c == 1 ? peq[i][1] : (c == 2 ? peq[i][2] : peq[i][3]));
+        const int hout = myers_block(Pv[i], Mv[i], eq, hin);
+        sc[i] += hout;
+        hin = hout;
+      }
+    }
+    if (j == static_cast<int>(m)) {
+      const int slot = nb - 1 - base;
+#pragma unroll
+      for (int i = 0; i < B; ++i) {
+        if (i == slot) {
+          const u32 used = n - static_cast<u32>(64 * (nb - 1));
+          const u64 padmask = used >= 64 ? 0ULL : ~((1ULL << used) - 1ULL);
+          result = static_cast<u32>(sc[i] - RVN_POPC64(Pv[i] & padmask) + RVN_POPC64(Mv[i] & padmask));
+        }
+      }
+    }
+  }
+  u32 res;
+  if (result <= k) res = result;
+  else if (k >= km) res = kEdAbove;
+  else res = kEdOverflow;
+  out[p] = res;
+}
+
+__global__ void ed_keys_kernel(const EdPair* __restrict__ pairs, u32 n, u32* __restrict__ keys, u32* __restrict__ vals) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  keys[i] = 0xFFFFFFFFu - pairs[i].b_len;  // longest text first
+  vals[i] = i;
+}
+__global__ void ed_collect_overflow_kernel(const u32* __restrict__ out, u32 n, u32* __restrict__ todo, u32* __restrict__ cnt) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && out[i] == kEdOverflow) todo[atomicAdd(cnt, 1u)] = i;
+}
+__global__ void ed_count_done_kernel(const u32* __restrict__ out, const u32* __restrict__ order, u32 n, u32* __restrict__ cnt) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && out[order[i]] != kEdOverflow) atomicAdd(cnt, 1u);
 }
 
 // Unbanded striped sweep (fallback; any distance): stripes of 64 blocks, lane = block, boundary hout per column
@@ -208,49 +355,72 @@ __global__ __launch_bounds__(64) void ed_full_kernel(const u64* __restrict__ pac
   if (lane == 0) out[p] = result - 1u;
 }
 
-__global__ void ed_count_overflow_kernel(const u32* __restrict__ out, u32 n, u32* __restrict__ cnt) {
-  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n && out[i] == kEdOverflow) atomicAdd(cnt, 1u);
-}
-
 }  // namespace
 
-// pairs and results resident in HBM: d_pairs = n_pairs x {a_idx,a_begin,a_len,b_idx,b_begin,b_len,strand,0}, d_out u32[n]
-void edit_distance_dev(Engine& e, const ReadsDev& r, const u32* d_pairs_raw, u32 n_pairs, u32* d_out) {
+// pairs and results resident in HBM: d_pairs = n_pairs x {a_idx,a_begin,a_len,b_idx,b_begin,b_len,strand,0}, d_out u32[n].
+// d_kmax (nullable): per-pair thresholds — distances above them come back as 0xFFFFFFFE (see ed_banded_kernel).
+void edit_distance_dev(Engine& e, const ReadsDev& r, const u32* d_pairs_raw, u32 n_pairs, u32* d_out, const u32* d_kmax) {
   if (n_pairs == 0) return;
   hipStream_t s = e.stream;
   const EdPair* d_pairs = reinterpret_cast<const EdPair*>(d_pairs_raw);
-  RVN_KLAUNCH(kKEditBanded, ed_banded_kernel<4><<<div_up(n_pairs, 4), 256, 0, s>>>(
-                                r.packed.as<u64>(), r.word_off.as<u64>(), d_pairs, n_pairs, d_out));
-  // pairs beyond the ring capacity (rare): unbanded striped sweep
-  u32* d_cnt = e.ed_cnt.get<u32>(4);
-  RVN_HIP(hipMemsetAsync(d_cnt, 0, 4, s));
-  ed_count_overflow_kernel<<<div_up(n_pairs, 256), 256, 0, s>>>(d_out, n_pairs, d_cnt);
+  u32* d_cnt = e.ed_cnt.get<u32>(8);
+  RVN_HIP(hipMemsetAsync(d_cnt, 0, 32, s));
+  RVN_HIP(hipMemsetAsync(d_out, 0xFF, static_cast<size_t>(n_pairs) * 4, s));  // everything starts as "needs the wave kernel"
+  // ---- stage 1: one lane per pair for narrow bands.  Tried on a sample first: it pays only when most pairs are
+  // closer than ~384 edits (HiFi-like); for ONT-like spans nearly every pair would come back as overflow.
+  u32* d_sk = e.ed_sort.get<u32>(4 * static_cast<size_t>(n_pairs) + 8);
+  u32* d_sk1 = d_sk + n_pairs + 1;
+  u32* d_sv = d_sk1 + n_pairs + 1;
+  u32* d_sv1 = d_sv + n_pairs + 1;
+  ed_keys_kernel<<<div_up(n_pairs, 256), 256, 0, s>>>(d_pairs, n_pairs, d_sk, d_sv);
   RVN_LAUNCH_CHECK();
-  if (read_back(e, d_cnt, 4) == 0) return;
-  std::vector<u32> h_out(n_pairs);
+  const int which = radix_sort_pairs_u32_u32(d_sk, d_sk1, d_sv, d_sv1, n_pairs, 32, e.sort_tmp, e.scan_tmp, s, kKPileSortUp,
+                                             kKPileSortDown);
+  const u32* d_order = which ? d_sv1 : d_sv;
+  const u32 n_sample = std::min<u32>(n_pairs, 2048);
+  // the sample: every (n_pairs / n_sample)-th pair of the sorted order would need a gather; the shortest pairs (the
+  // tail of the order) are the cheapest probe and representative of the error level
+  const u32* d_sample = d_order + (n_pairs - n_sample);
+  RVN_KLAUNCH(kKEditLane, ed_lane_kernel<8><<<div_up(n_sample, 64), 64, 0, s>>>(r.packed.as<u64>(), r.word_off.as<u64>(), d_pairs,
+                                                                               d_sample, n_sample, d_kmax, d_out));
+  ed_count_done_kernel<<<div_up(n_sample, 256), 256, 0, s>>>(d_out, d_sample, n_sample, d_cnt + 1);
+  RVN_LAUNCH_CHECK();
+  const u32 done = static_cast<u32>(read_back(e, d_cnt + 1, 4));
+  if (2 * done >= n_sample && n_pairs > n_sample)
+    RVN_KLAUNCH(kKEditLane, ed_lane_kernel<8><<<div_up(n_pairs - n_sample, 64), 64, 0, s>>>(
+                                r.packed.as<u64>(), r.word_off.as<u64>(), d_pairs, d_order, n_pairs - n_sample, d_kmax, d_out));
+  // ---- stage 2: the wave-per-pair kernel for what is left ----
+  u32* d_todo = e.ed_todo.get<u32>(static_cast<size_t>(n_pairs) + 1);
+  ed_collect_overflow_kernel<<<div_up(n_pairs, 256), 256, 0, s>>>(d_out, n_pairs, d_todo, d_cnt);
+  RVN_LAUNCH_CHECK();
+  const u32 n_todo = static_cast<u32>(read_back(e, d_cnt, 4));
+  if (n_todo == 0) return;
+  RVN_KLAUNCH(kKEditBanded, ed_banded_kernel<4><<<div_up(n_todo, 4), 256, 0, s>>>(
+                                r.packed.as<u64>(), r.word_off.as<u64>(), d_pairs, d_todo, n_todo, d_kmax, d_out));
+  // ---- stage 3: pairs beyond the ring capacity (rare): unbanded striped sweep, exact ----
+  RVN_HIP(hipMemsetAsync(d_cnt, 0, 4, s));
+  ed_collect_overflow_kernel<<<div_up(n_pairs, 256), 256, 0, s>>>(d_out, n_pairs, d_todo, d_cnt);
+  RVN_LAUNCH_CHECK();
+  const u32 n_full = static_cast<u32>(read_back(e, d_cnt, 4));
+  if (n_full == 0) return;
+  std::vector<u32> todo(n_full);
   std::vector<EdPair> hp(n_pairs);
-  RVN_HIP(hipMemcpyAsync(h_out.data(), d_out, static_cast<size_t>(n_pairs) * 4, hipMemcpyDeviceToHost, s));
+  RVN_HIP(hipMemcpyAsync(todo.data(), d_todo, static_cast<size_t>(n_full) * 4, hipMemcpyDeviceToHost, s));
   RVN_HIP(hipMemcpyAsync(hp.data(), d_pairs, static_cast<size_t>(n_pairs) * sizeof(EdPair), hipMemcpyDeviceToHost, s));
   RVN_HIP(hipStreamSynchronize(s));
-  std::vector<u32> todo;
+  std::sort(todo.begin(), todo.end());
   std::vector<u64> hb_off;
   u64 hb_total = 0;
-  for (u32 i = 0; i < n_pairs; ++i) {
-    if (h_out[i] == kEdOverflow) {
-      todo.push_back(i);
-      hb_off.push_back(hb_total);
-      hb_total += 2ULL * (static_cast<u64>(hp[i].b_len) + 1);
-    }
+  for (u32 i : todo) {
+    hb_off.push_back(hb_total);
+    hb_total += 2ULL * (static_cast<u64>(hp[i].b_len) + 1);
   }
-  u32* d_todo = e.tmp_c.get<u32>(todo.size() + 1);
   u64* d_off = e.tmp_d.get<u64>(hb_off.size() + 1);
   signed char* d_hb = e.tmp_f.get<signed char>(hb_total + 16);
   RVN_HIP(hipMemcpyAsync(d_todo, todo.data(), todo.size() * 4, hipMemcpyHostToDevice, s));
   RVN_HIP(hipMemcpyAsync(d_off, hb_off.data(), hb_off.size() * 8, hipMemcpyHostToDevice, s));
-  RVN_KLAUNCH(kKEditFull, ed_full_kernel<<<static_cast<u32>(todo.size()), 64, 0, s>>>(
-                              r.packed.as<u64>(), r.word_off.as<u64>(), d_pairs, d_todo,
-                              static_cast<u32>(todo.size()), d_off, d_hb, d_out));
+  RVN_KLAUNCH(kKEditFull, ed_full_kernel<<<n_full, 64, 0, s>>>(r.packed.as<u64>(), r.word_off.as<u64>(), d_pairs, d_todo, n_full,
+                                                               d_off, d_hb, d_out));
   RVN_HIP(hipStreamSynchronize(s));  // the host lists above are locals
 }
 
@@ -263,7 +433,7 @@ void edit_distance_batch(Engine& e, const ReadsDev& r, const u32* h_pairs, u32 n
   u32* d_out = e.tmp_b.get<u32>(static_cast<size_t>(n_pairs) + 1);
   RVN_HIP(hipMemcpyAsync(d_pairs, h_pairs, static_cast<size_t>(n_pairs) * sizeof(EdPair), hipMemcpyHostToDevice, s));
   RVN_HIP(hipEventRecord(e.ev0, s));
-  edit_distance_dev(e, r, reinterpret_cast<const u32*>(d_pairs), n_pairs, d_out);
+  edit_distance_dev(e, r, reinterpret_cast<const u32*>(d_pairs), n_pairs, d_out, nullptr);
   RVN_HIP(hipEventRecord(e.ev1, s));
   RVN_HIP(hipMemcpyAsync(h_out, d_out, static_cast<size_t>(n_pairs) * 4, hipMemcpyDeviceToHost, s));
   RVN_HIP(hipStreamSynchronize(s));

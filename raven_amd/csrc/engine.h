@@ -119,7 +119,7 @@ struct Engine {
   DevBuf seg_off, iv_slot_begin, iv_slot_end, iv_cnt, iv_off, iv_begin, iv_end;
   DevBuf lis_min, lis_pred, lis_tail, lis_mask, ovl_slots, ovl_flags, ovl_scan;
   DevBuf poa_scratch, poa2_scratch, polish_quals;
-  DevBuf ed_cnt;
+  DevBuf ed_cnt, ed_sort, ed_todo;
   // second pass / identity filters (pass2.hip)
   DevBuf p2_slot, p2_pairs, p2_dist, p2_regions, p2_index_of, p2_kmers_off, p2_ok, p2_keep, p2_tmp_ovl;
   DevBuf poa_sched, poa_redo_w, poa_redo_i;  // LPT order / escalation lists of a POA batch (poa_run_dev)
@@ -223,7 +223,7 @@ void chain_matches(Engine& e, const ReadsDev& r, u32 first, u32 last, u64 H, Map
 void edit_distance_batch(Engine& e, const ReadsDev& r, const u32* h_pairs, u32 n_pairs, u32* h_out, double* kernel_ms,
                          u64* cells);
 // the same with pairs and distances resident in HBM (pass2.hip: identity filters)
-void edit_distance_dev(Engine& e, const ReadsDev& r, const u32* d_pairs, u32 n_pairs, u32* d_out);
+void edit_distance_dev(Engine& e, const ReadsDev& r, const u32* d_pairs, u32 n_pairs, u32* d_out, const u32* d_kmax = nullptr);
 
 // Batched POA window consensus (poa.hip); all arrays are host pointers, see rvn_poa_consensus_batch
 void poa_consensus_batch(Engine& e, const u8* h_codes, const u8* h_quals, const u64* h_layer_off, const u32* h_begins,

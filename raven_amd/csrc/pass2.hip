@@ -81,13 +81,28 @@ struct EdPairRec {
 };
 
 // edlibAlign(lhs span, rhs span [reverse-complemented on the opposite strand]) pairs of the overlaps that survived the update
+// the reference's keep rule on a distance x: !(1. - x / max(length) < identity), in double
+__device__ __forceinline__ bool identity_keeps(u32 x, u32 maxlen, double identity) {
+  return !(1. - static_cast<double>(x) / static_cast<double>(maxlen) < identity);
+}
+
+// Also the largest distance that still passes the filter (kmax): the edit-distance stage then needs ONE sweep at that
+// threshold per pair — "exact distance if <= kmax, else above" decides the overlap exactly as the unbounded distance would.
 __global__ void ed_pairs_kernel(const Overlap* __restrict__ ovl, const u8* __restrict__ ok, const u32* __restrict__ slot,
-                                u64 n, const u32* __restrict__ index_of, EdPairRec* __restrict__ pairs) {
+                                u64 n, const u32* __restrict__ index_of, double identity, EdPairRec* __restrict__ pairs,
+                                u32* __restrict__ kmax) {
   const u64 i = static_cast<u64>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (i >= n || !ok[i]) return;
   const Overlap o = ovl[i];
-  pairs[slot[i]] = EdPairRec{index_of[o.lhs_id], o.lhs_begin, o.lhs_end - o.lhs_begin,
-                             index_of[o.rhs_id], o.rhs_begin, o.rhs_end - o.rhs_begin, o.strand ? 1u : 0u, 0u};
+  const u32 a = o.lhs_end - o.lhs_begin, b = o.rhs_end - o.rhs_begin;
+  pairs[slot[i]] = EdPairRec{index_of[o.lhs_id], o.lhs_begin, a, index_of[o.rhs_id], o.rhs_begin, b, o.strand ? 1u : 0u, 0u};
+  const u32 maxlen = a > b ? a : b;
+  double guess = (1. - identity) * static_cast<double>(maxlen);
+  guess = guess < 0 ? 0 : (guess > static_cast<double>(maxlen) ? static_cast<double>(maxlen) : guess);
+  u32 t = static_cast<u32>(guess);
+  while (t < maxlen && identity_keeps(t + 1, maxlen, identity)) ++t;  // the rule is monotone in the distance
+  while (t > 0 && !identity_keeps(t, maxlen, identity)) --t;
+  kmax[slot[i]] = t;
 }
 
 // score = 1 - distance / max(length) in double; overlaps below the identity threshold lose their ok flag
@@ -97,6 +112,7 @@ __global__ void identity_keep_kernel(const Overlap* __restrict__ ovl, u8* __rest
   if (i >= n || !ok[i]) return;
   const Overlap o = ovl[i];
   const u32 a = o.lhs_end - o.lhs_begin, b = o.rhs_end - o.rhs_begin;
+  // dist is exact up to the pair's kmax and 0xFFFFFFFE above it: the rule gives the same answer either way
   const double score = 1. - static_cast<double>(dist[slot[i]]) / static_cast<double>(a > b ? a : b);
   if (score < identity) ok[i] = 0;
 }
@@ -187,10 +203,11 @@ void update_and_identity(Engine& e, const ReadsDev& r, Overlap* d_ovl, u64 n, co
   if (np == 0) return;
   if (np >= 0xFFFFFFFFULL) throw std::invalid_argument("[raven_hip] identity filter: too many pairs in one batch");
   EdPairRec* d_pairs = e.p2_pairs.get<EdPairRec>(np + 1);
-  u32* d_dist = e.p2_dist.get<u32>(np + 1);
-  ed_pairs_kernel<<<div_up(n, 256), 256, 0, s>>>(d_ovl, d_ok, d_slot, n, d_index_of, d_pairs);
+  u32* d_dist = e.p2_dist.get<u32>(2 * (np + 1));
+  u32* d_kmax = d_dist + np + 1;
+  ed_pairs_kernel<<<div_up(n, 256), 256, 0, s>>>(d_ovl, d_ok, d_slot, n, d_index_of, identity, d_pairs, d_kmax);
   RVN_LAUNCH_CHECK();
-  edit_distance_dev(e, r, reinterpret_cast<const u32*>(d_pairs), static_cast<u32>(np), d_dist);
+  edit_distance_dev(e, r, reinterpret_cast<const u32*>(d_pairs), static_cast<u32>(np), d_dist, d_kmax);
   identity_keep_kernel<<<div_up(n, 256), 256, 0, s>>>(d_ovl, d_ok, d_slot, n, d_dist, identity);
   RVN_LAUNCH_CHECK();
 }
