@@ -73,7 +73,13 @@ def _polish_properties(eng, rd, g, drafts, bounds, rounds, n_slices=3):
     truth = g.cpu().numpy()
     cur = drafts
     slices = [int(x) for x in np.linspace(0, len(drafts) - 1, n_slices).astype(int)]
-    eds = [[_ed(cur[c][:20_000], truth[int(bounds[c]):int(bounds[c]) + 21_000][:20_000 + 200]) for c in slices]]
+
+    def errors(seq, c):
+        # the first 20 kb of contig c against a truth prefix that is 200 bases longer (the draft's indels shift the end):
+        # the distance is 200 + the errors of the prefix
+        return _ed(seq[:20_000], truth[int(bounds[c]):int(bounds[c]) + 20_200]) - 200
+
+    eds = [[errors(cur[c], c) for c in slices]]
     stats = []
     for _ in range(rounds):
         td = eng.upload_codes(cur)
@@ -83,7 +89,7 @@ def _polish_properties(eng, rd, g, drafts, bounds, rounds, n_slices=3):
         assert st["n_polished_windows"] >= 0.999 * st["n_windows"] and min(ratio) > 0.99
         assert st["n_aligned"] == st["n_reads_used"] > 0.95 * rd.n
         cur = cons
-        eds.append([_ed(cur[c][:20_000], truth[int(bounds[c]):int(bounds[c]) + 21_000][:20_000 + 200]) for c in slices])
+        eds.append([errors(cur[c], c) for c in slices])
         stats.append(st)
     return cur, eds, stats
 
@@ -96,8 +102,8 @@ def test_configs2_polish_full_size():
     drafts, bounds = _drafts(g, 5_000_000, 77)
     cons, eds, stats = _polish_properties(eng, rd, g, drafts, bounds, rounds=2, n_slices=1)
     assert stats[0]["n_windows"] >= 10_000
-    # the prefix gets closer to the truth every round (the 200-base slack of the truth slice is a constant ~200)
-    assert eds[1][0] < 0.5 * eds[0][0] and eds[2][0] <= eds[1][0] + 5, eds
+    # the prefix gets closer to the truth every round
+    assert eds[1][0] < 0.4 * eds[0][0] and eds[2][0] <= eds[1][0] + 5, eds
     # window-range invariance: the round in two halves (what two GPUs would do) reproduces it byte for byte
     td = eng.upload_codes(drafts)
     whole, _, st = eng.polish_round(td, rd)
@@ -120,7 +126,7 @@ def test_configs3_workload_on_one_gpu():
     cons, eds, stats = _polish_properties(eng, rd, g, drafts, bounds, rounds=1)
     assert stats[0]["n_windows"] >= 200_000
     for before, after in zip(eds[0], eds[1]):
-        assert after < 0.5 * before, eds
+        assert after < 0.4 * before, eds
 
 
 def test_configs4_workload_hifi_identity_on_one_gpu():
@@ -146,4 +152,4 @@ def test_configs4_workload_hifi_identity_on_one_gpu():
     drafts, bounds = _drafts(g, 5_000_000, 199)
     cons, eds, stats = _polish_properties(eng, rd, g, drafts, bounds, rounds=1)
     for before, after in zip(eds[0], eds[1]):
-        assert after < 0.25 * before, eds
+        assert after < 0.1 * before, eds  # HiFi layers: (nearly) every draft error is corrected in one round
