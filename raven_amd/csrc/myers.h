@@ -70,6 +70,30 @@ __host__ __device__ __forceinline__ void load_peq(const u64* __restrict__ words,
   }
 }
 
+// Bit planes of pattern block b: bit i of lo / hi = low / high bit of the code of row 64b + i; rows beyond n are marked in
+// `pad` (they never match).  The match mask of symbol c is then 4 bit operations instead of a 4-entry table of 64-bit
+// words per block: eq(c) = (c & 1 ? lo : ~lo) & (c & 2 ? hi : ~hi) & ~pad.
+struct BlockPlanes {
+  u64 lo, hi, valid;
+};
+__host__ __device__ __forceinline__ BlockPlanes load_planes(const u64* __restrict__ words, u64 a_base, u32 n, u32 b) {
+  const u32 row0 = b * 64;
+  u64 w0 = 0, w1 = 0;
+  if (row0 < n) w0 = load_bases32(words, a_base + row0);
+  if (row0 + 32 < n) w1 = load_bases32(words, a_base + row0 + 32);
+  const u32 valid = n > row0 ? (n - row0 >= 64 ? 64u : n - row0) : 0u;
+  BlockPlanes p;
+  p.lo = compress_even(w0) | (compress_even(w1) << 32);
+  p.hi = compress_even(w0 >> 1) | (compress_even(w1 >> 1) << 32);
+  p.valid = valid >= 64 ? ~0ULL : ((1ULL << valid) - 1ULL);
+  return p;
+}
+__host__ __device__ __forceinline__ u64 planes_eq(const BlockPlanes& p, unsigned c) {
+  const u64 a = (c & 1u) ? p.lo : ~p.lo;
+  const u64 b = (c & 2u) ? p.hi : ~p.hi;
+  return a & b & p.valid;
+}
+
 // text symbol of column j (1-based) with a one-word look-ahead so the load latency is off the critical path
 struct TextCursor {
   const u64* words;

@@ -47,7 +47,7 @@ struct NwJob {
   u32 R;           // blocks per lane
   u32 read, target;  // indices in their sets
   u32 n_windows;     // windows touched by the target span
-  u32 pad_;
+  u32 bin;           // 0: wave-per-alignment kernel (R blocks per lane); 1..4: lane-per-alignment kernel, ring of 8 * bin blocks
 };
 static_assert(sizeof(NwJob) == 88, "NwJob layout");
 
@@ -143,7 +143,8 @@ struct NwLane {
   int lane, mode;
   int j0, j_end, t0;
   NwStore st;
-  u64 Pv[R], Mv[R], peq[R][4];
+  u64 Pv[R], Mv[R];
+  BlockPlanes pl[R];  // match masks of the lane's blocks as bit planes (myers.h)
   int score[R];
   int s;
   bool fresh;
@@ -203,7 +204,7 @@ struct NwLane {
     if (j <= j0 || j < nw_jin(b0, B.hi) || j > j_end) return;
     if (fresh) {
 #pragma unroll
-      for (int r = 0; r < R; ++r) load_peq(a_words, a_base, n, static_cast<u32>(b0 + r), peq[r]);
+      for (int r = 0; r < R; ++r) pl[r] = load_planes(a_words, a_base, n, static_cast<u32>(b0 + r));
       tc.init(b_words, b_base, m, rc, j);
       fresh = false;
     }
@@ -237,8 +238,7 @@ struct NwLane {
         }
       }
       const int old = score[r];
-      const u64 eq = c == 0 ? peq[r][0] : (c == 1 ? peq[r][1] : (c == 2 ? peq[r][2] : peq[r][3]));
-      const int hout = myers_block(Pv[r], Mv[r], eq, hin);
+      const int hout = myers_block(Pv[r], Mv[r], planes_eq(pl[r], c), hin);
       score[r] = old + hout;
       above_prev_col = old;
       hin = hout;
@@ -262,18 +262,47 @@ struct NwLane {
   }
 };
 
-// The backward walk, resumable segment by segment.
-struct NwWalker {
-  // job
-  const u64* tw;
-  const u64* rw;
-  u32 t_begin, q_begin, r_len, w, win0, R;
-  bool rc;
-  NwWindowRec* recs;
-  // band + stores of the segment currently in the scratch
+// Cell values of the segment held in the wave kernel's scratch (time-major [step][lane][r]) + the checkpoint column
+struct NwSegCells {
   NwBand B;
   NwStore st;
   int seg_j0, seg_t0;
+  u32 R;
+  // D(x, y) of the banded matrix for y in [seg_j0, seg_j0 + kNwSeg]; kNwInf outside the band
+  __host__ __device__ u32 get(int x, int y) const {
+    if (x == 0) return static_cast<u32>(y);
+    if (y == 0) return static_cast<u32>(x);
+    const int b = (x - 1) >> 6;
+    if (y < nw_jin(b, B.hi) || y > nw_jout(b, B.lo)) return kNwInf;
+    NwPm v;
+    int sc;
+    if (y == seg_j0) {  // the checkpointed column
+      const u64 cs = static_cast<u64>(y / kNwSeg) * st.ckpt_nb + static_cast<u64>(b - nw_bfirst(y, B.lo));
+      v = st.ck_pm[cs];
+      sc = st.ck_sc[cs];
+    } else {
+      const int s = b / static_cast<int>(R);
+      const u64 slot = (static_cast<u64>(y + s - seg_t0) * B.L + static_cast<u64>(s % B.L)) * R + static_cast<u64>(b % static_cast<int>(R));
+      v = st.seg_pm[slot];
+      sc = st.seg_sc[slot];
+    }
+    const unsigned bit = static_cast<unsigned>((x - 1) & 63);
+    const u64 below = bit == 63 ? 0ULL : (~0ULL << (bit + 1));  // rows of the block below row x
+    return static_cast<u32>(sc - static_cast<int>(RVN_POPC64(v.pv & below)) + static_cast<int>(RVN_POPC64(v.mv & below)));
+  }
+};
+
+// The backward walk, resumable segment by segment.  Cells::get(x, y) = D(x, y) for the columns of the current segment.
+template <class Cells>
+struct NwWalkerT {
+  Cells cells;
+  // job
+  const u64* tw;
+  const u64* rw;
+  u32 t_begin, q_begin, r_len, w, win0;
+  bool rc;
+  NwWindowRec* recs;
+  int seg_j0;
   // position
   int i, j;
   u32 cur;
@@ -287,8 +316,8 @@ struct NwWalker {
   // one-word caches of the two sequences
   u64 t_wi, t_wv, q_wi, q_wv;
 
-  __host__ __device__ void init(const NwJob& J, const u64* t_words_all, const u64* r_words_all, const NwBand& band,
-                                const NwStore& store, u32 distance, u32 w_, NwWindowRec* recs_all) {
+  __host__ __device__ void init(const NwJob& J, const u64* t_words_all, const u64* r_words_all, u32 distance, u32 w_,
+                                NwWindowRec* recs_all) {
     tw = t_words_all + J.t_word;
     rw = r_words_all + J.r_word;
     t_begin = J.t_begin;
@@ -296,11 +325,9 @@ struct NwWalker {
     r_len = J.r_len;
     w = w_;
     win0 = J.t_begin / w_;
-    R = J.R;
     rc = J.rc != 0;
     recs = recs_all + J.bp_off;
-    B = band;
-    st = store;
+    seg_j0 = 0;
     i = static_cast<int>(J.n);
     j = static_cast<int>(J.m);
     cur = distance;
@@ -313,10 +340,7 @@ struct NwWalker {
     t_wi = q_wi = ~0ULL;
     t_wv = q_wv = 0;
   }
-  __host__ __device__ void set_segment(int j0, int t0) {
-    seg_j0 = j0;
-    seg_t0 = t0;
-  }
+  __host__ __device__ u32 cell(int x, int y) const { return cells.get(x, y); }
 
   __host__ __device__ u32 tcode(int row) {
     const u64 pos = static_cast<u64>(t_begin) + row - 1;
@@ -337,29 +361,6 @@ struct NwWalker {
     }
     const u32 c = static_cast<u32>(q_wv >> ((pos & 31) << 1)) & 3u;
     return rc ? 3u - c : c;
-  }
-
-  // D(x, y) of the banded matrix for y in [seg_j0, seg_j0 + kNwSeg]; kNwInf outside the band
-  __host__ __device__ u32 cell(int x, int y) const {
-    if (x == 0) return static_cast<u32>(y);
-    if (y == 0) return static_cast<u32>(x);
-    const int b = (x - 1) >> 6;
-    if (y < nw_jin(b, B.hi) || y > nw_jout(b, B.lo)) return kNwInf;
-    NwPm v;
-    int sc;
-    if (y == seg_j0) {  // the checkpointed column
-      const u64 cs = static_cast<u64>(y / kNwSeg) * st.ckpt_nb + static_cast<u64>(b - nw_bfirst(y, B.lo));
-      v = st.ck_pm[cs];
-      sc = st.ck_sc[cs];
-    } else {
-      const int s = b / static_cast<int>(R);
-      const u64 slot = (static_cast<u64>(y + s - seg_t0) * B.L + static_cast<u64>(s % B.L)) * R + static_cast<u64>(b % static_cast<int>(R));
-      v = st.seg_pm[slot];
-      sc = st.seg_sc[slot];
-    }
-    const unsigned bit = static_cast<unsigned>((x - 1) & 63);
-    const u64 below = bit == 63 ? 0ULL : (~0ULL << (bit + 1));  // rows of the block below row x
-    return static_cast<u32>(sc - static_cast<int>(RVN_POPC64(v.pv & below)) + static_cast<int>(RVN_POPC64(v.mv & below)));
   }
 
   __host__ __device__ void flush(bool write) {
@@ -447,6 +448,24 @@ struct NwWalker {
     }
     flush(write);
     return (cur == 0 && i == 0 && j == 0) ? 0 : 1;
+  }
+};
+
+// the wave kernel's walker
+struct NwWalker : NwWalkerT<NwSegCells> {
+  __host__ __device__ void init(const NwJob& J, const u64* t_words_all, const u64* r_words_all, const NwBand& band,
+                                const NwStore& store, u32 distance, u32 w_, NwWindowRec* recs_all) {
+    NwWalkerT<NwSegCells>::init(J, t_words_all, r_words_all, distance, w_, recs_all);
+    cells.B = band;
+    cells.st = store;
+    cells.R = J.R;
+    cells.seg_j0 = 0;
+    cells.seg_t0 = 0;
+  }
+  __host__ __device__ void set_segment(int j0, int t0) {
+    seg_j0 = j0;
+    cells.seg_j0 = j0;
+    cells.seg_t0 = t0;
   }
 };
 

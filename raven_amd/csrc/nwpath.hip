@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "engine.h"
+#include "nwlane.h"
 #include "nwpath.h"
 #include "wave.h"
 
@@ -132,13 +133,83 @@ void launch_path(Engine& e, const NwJob* d_jobs, const u32* d_idx, u32 n_idx, co
   const u64 seg_stride = static_cast<u64>(nw_seg_rows()) * 64 * R;
   u32 n_slots = std::min<u32>(n_idx, 256u * 4u * (R == 1 ? 5u : (R == 2 ? 4u : (R == 4 ? 3u : 2u))));
   n_slots = ((n_slots + 3) / 4) * 4;
-  NwPm* seg_pm = e.nw_pm.get<NwPm>(static_cast<u64>(n_slots) * seg_stride + 1);
-  int* seg_sc = e.nw_sc.get<int>(static_cast<u64>(n_slots) * seg_stride + 1);
+  NwPm* seg_pm = e.nw_pm.as<NwPm>();  // sized by nw_breakpoints for the largest launch of the batch
+  int* seg_sc = e.nw_sc.as<int>();
+  if (static_cast<u64>(n_slots) * seg_stride * sizeof(NwPm) > e.nw_pm.cap) throw HipError("[raven_hip] alignment path: scratch too small");
   RVN_HIP(hipMemsetAsync(d_next, 0, 4, s));
   RVN_KLAUNCH(kKNwForward, nw_path_kernel<R><<<n_slots / 4, 256, 0, s>>>(
                                d_jobs, d_idx, n_idx, T.packed.as<u64>(), Rd.packed.as<u64>(), e.nw_ck_pm.as<NwPm>(),
                                e.nw_ck_sc.as<int>(), seg_pm, seg_sc, seg_stride, n_slots, w, d_recs, d_result, d_status,
                                d_kused, d_next));
+}
+
+// One lane per alignment (nwlane.h): persistent workgroups of one wave; group g = 64 consecutive jobs of the bin's list
+template <int NB>
+__global__ __launch_bounds__(64) void nw_lane_kernel(const NwJob* __restrict__ jobs, const u32* __restrict__ idx, u32 n_idx,
+                                                    const u64* __restrict__ t_words, const u64* __restrict__ r_words,
+                                                    NwPm* __restrict__ ck_pm, int* __restrict__ ck_sc,
+                                                    NwPm* __restrict__ seg_pm, int* __restrict__ seg_sc, u64 seg_stride, u32 w,
+                                                    NwWindowRec* __restrict__ recs, u32* __restrict__ result,
+                                                    u32* __restrict__ status, u32* __restrict__ k_used) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char nw_lds[];
+  u64* s_pv = reinterpret_cast<u64*>(nw_lds);
+  u64* s_mv = s_pv + NB * 64;
+  u64* s_plo = s_mv + NB * 64;
+  u64* s_phi = s_plo + NB * 64;
+  int* s_sc = reinterpret_cast<int*>(s_phi + NB * 64);
+  const int lane = static_cast<int>(threadIdx.x);
+  const u32 n_groups = (n_idx + 63) / 64;
+  for (u32 g = blockIdx.x; g < n_groups; g += gridDim.x) {
+    const u32 q = g * 64 + threadIdx.x;
+    if (q >= n_idx) continue;
+    const u32 ji = idx[q];
+    const NwJob J = jobs[ji];
+    NwLaneMem<NB, 64> M{s_pv, s_mv, s_plo, s_phi, s_sc, lane};
+    NwLaneStore st;
+    st.ck_pm = ck_pm + J.ckpt;
+    st.ck_sc = ck_sc + J.ckpt;
+    st.ckpt_nb = J.ckpt_nb;
+    st.seg_pm = seg_pm + static_cast<u64>(blockIdx.x) * seg_stride;
+    st.seg_sc = seg_sc + static_cast<u64>(blockIdx.x) * seg_stride;
+    u32 dist = 0, ku = 0;
+    const int rc = nw_lane_job<NB, 64>(J, t_words, r_words, M, st, w, recs, &dist, &ku);
+    result[ji] = dist;
+    k_used[ji] = ku;
+    status[ji] = static_cast<u32>(rc);
+  }
+}
+
+template <int NB>
+void launch_lane(Engine& e, const NwJob* d_jobs, const u32* d_idx, u32 n_idx, const ReadsDev& T, const ReadsDev& Rd, u32 w,
+                 NwWindowRec* d_recs, u32* d_result, u32* d_status, u32* d_kused) {
+  if (n_idx == 0) return;
+  hipStream_t s = e.stream;
+  const size_t lds = static_cast<size_t>(NB) * 64 * 36;
+  static bool attr_set = false;
+  if (!attr_set) {
+    RVN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(nw_lane_kernel<NB>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                static_cast<int>(lds)));
+    attr_set = true;
+  }
+  const u32 per_cu = static_cast<u32>(std::max<size_t>(1, std::min<size_t>(8, (160u << 10) / lds)));
+  const u32 n_groups = (n_idx + 63) / 64;
+  const u32 n_blocks = std::min<u32>(n_groups, 256u * per_cu);
+  const u64 seg_stride = static_cast<u64>(kNwSeg) * NB * 64;
+  NwPm* seg_pm = e.nw_pm.as<NwPm>();
+  int* seg_sc = e.nw_sc.as<int>();
+  if (static_cast<u64>(n_blocks) * seg_stride * sizeof(NwPm) > e.nw_pm.cap) throw HipError("[raven_hip] alignment path: scratch too small");
+  RVN_KLAUNCH(kKNwLane, nw_lane_kernel<NB><<<n_blocks, 64, lds, s>>>(d_jobs, d_idx, n_idx, T.packed.as<u64>(), Rd.packed.as<u64>(),
+                                                                      e.nw_ck_pm.as<NwPm>(), e.nw_ck_sc.as<int>(), seg_pm, seg_sc,
+                                                                      seg_stride, w, d_recs, d_result, d_status, d_kused));
+}
+
+// largest threshold whose band (checkpoint row) fits NB blocks: (lo + hi) / 64 + 3 <= NB
+u32 kcap_of_blocks(u32 n, u32 m, u32 NB) {
+  const u32 d = n > m ? n - m : m - n;
+  const u64 room = 64ULL * (NB - 3) + 63;  // largest lo + hi
+  if (room < d) return 0;
+  const u64 k = d + ((room - d) / 2) * 2 + 1;
+  return static_cast<u32>(std::min<u64>(k, static_cast<u64>(n) + m));
 }
 
 // largest threshold whose band fits a ring of 64 lanes with R blocks each
@@ -169,10 +240,26 @@ void nw_breakpoints(Engine& e, const ReadsDev& T, const ReadsDev& Rd, std::vecto
   // plan: first threshold from the estimate, the smallest R whose ring holds twice that, checkpoint rows for kcap
   std::vector<u32> level(nj, 0);  // index into kRs
   std::vector<u32> todo;
+  const bool lane_ok = std::getenv("RVN_NW_NO_LANE") == nullptr;
   auto plan = [&](NwJob& J, u32 lvl, u64 k_first) -> bool {
     const u32 d = J.n > J.m ? J.n - J.m : J.m - J.n;
     k_first = std::max<u64>(std::max<u64>(k_first, d), 16);
     k_first = std::min<u64>(k_first, static_cast<u64>(J.n) + J.m);  // D(n, m) <= n + m: that threshold never fails
+    J.bin = 0;
+    if (lane_ok && lvl == 0) {  // narrow band: one lane per alignment, ring of 8 / 16 / 24 / 32 blocks in LDS
+      const u64 want = std::min<u64>(2 * k_first, static_cast<u64>(J.n) + J.m);  // room for one doubling
+      for (u32 bin = 1; bin <= 4; ++bin) {
+        const u32 cap = kcap_of_blocks(J.n, J.m, 8 * bin);
+        if (cap >= want) {
+          J.bin = bin;
+          J.R = 1;
+          J.k = static_cast<u32>(k_first);
+          J.kcap = static_cast<u32>(std::min<u64>(cap, std::max<u64>(4 * k_first, 64)));
+          J.ckpt_nb = nw_ckpt_blocks(J.n, J.m, J.kcap);
+          return true;
+        }
+      }
+    }
     for (; lvl < 4; ++lvl) {
       const u32 cap = kcap_of(J.n, J.m, kRs[lvl]);
       if (cap >= k_first && (cap >= 2 * k_first || lvl == 3 || cap >= static_cast<u64>(J.n) + J.m)) {
@@ -216,15 +303,47 @@ void nw_breakpoints(Engine& e, const ReadsDev& T, const ReadsDev& Rd, std::vecto
     u32* d_idx = d_kused + nj + 1;
     u32* d_next = d_idx + nj + 1;
     order = todo;
+    // classes: lane bins 1..4 first, then the wave kernel by R; inside a class the largest jobs first
+    auto cls = [&](u32 i) -> u32 {
+      const NwJob& J = jobs[i];
+      return J.bin ? J.bin - 1 : 4 + (J.R == 1 ? 0 : (J.R == 2 ? 1 : (J.R == 4 ? 2 : 3)));
+    };
     std::stable_sort(order.begin(), order.end(), [&](u32 a, u32 b) {
-      if (jobs[a].R != jobs[b].R) return jobs[a].R < jobs[b].R;
+      if (cls(a) != cls(b)) return cls(a) < cls(b);
+      if (jobs[a].bin) return jobs[a].m > jobs[b].m;  // lanes of a wave run loops of similar length
       return static_cast<u64>(jobs[a].m) * jobs[a].k > static_cast<u64>(jobs[b].m) * jobs[b].k;
     });
-    u32 off[5] = {0, 0, 0, 0, 0};
-    for (u32 i : order) off[(jobs[i].R == 1 ? 0 : (jobs[i].R == 2 ? 1 : (jobs[i].R == 4 ? 2 : 3))) + 1]++;
-    for (int x = 0; x < 4; ++x) off[x + 1] += off[x];
+    u32 coff[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (u32 i : order) coff[cls(i) + 1]++;
+    for (int x = 0; x < 8; ++x) coff[x + 1] += coff[x];
+    const u32* off = coff + 4;
+    {  // one scratch allocation for the largest launch (the launches are asynchronous: no reallocation in between)
+      u64 need = 1;
+      for (u32 bin = 1; bin <= 4; ++bin) {
+        const u32 cnt = coff[bin] - coff[bin - 1];
+        if (!cnt) continue;
+        const size_t lds = static_cast<size_t>(8 * bin) * 64 * 36;
+        const u32 per_cu = static_cast<u32>(std::max<size_t>(1, std::min<size_t>(8, (160u << 10) / lds)));
+        const u64 blocks = std::min<u64>((cnt + 63) / 64, 256ULL * per_cu);
+        need = std::max<u64>(need, blocks * kNwSeg * (8ULL * bin) * 64);
+      }
+      for (int x = 0; x < 4; ++x) {
+        const u32 cnt = off[x + 1] - off[x];
+        if (!cnt) continue;
+        const u32 R = kRs[x];
+        u64 slots = std::min<u64>(cnt, 256ULL * 4 * (R == 1 ? 5 : (R == 2 ? 4 : (R == 4 ? 3 : 2))));
+        slots = ((slots + 3) / 4) * 4;
+        need = std::max<u64>(need, slots * nw_seg_rows() * 64ULL * R);
+      }
+      (void)e.nw_pm.get<NwPm>(need + 1);
+      (void)e.nw_sc.get<int>(need + 1);
+    }
     RVN_HIP(hipMemcpyAsync(d_idx, order.data(), order.size() * 4, hipMemcpyHostToDevice, s));
     RVN_HIP(hipStreamSynchronize(s));
+    launch_lane<8>(e, d_jobs, d_idx + coff[0], coff[1] - coff[0], T, Rd, w, d_recs, d_res, d_status, d_kused);
+    launch_lane<16>(e, d_jobs, d_idx + coff[1], coff[2] - coff[1], T, Rd, w, d_recs, d_res, d_status, d_kused);
+    launch_lane<24>(e, d_jobs, d_idx + coff[2], coff[3] - coff[2], T, Rd, w, d_recs, d_res, d_status, d_kused);
+    launch_lane<32>(e, d_jobs, d_idx + coff[3], coff[4] - coff[3], T, Rd, w, d_recs, d_res, d_status, d_kused);
     launch_path<1>(e, d_jobs, d_idx + off[0], off[1] - off[0], T, Rd, w, d_recs, d_res, d_status, d_kused, d_next);
     launch_path<2>(e, d_jobs, d_idx + off[1], off[2] - off[1], T, Rd, w, d_recs, d_res, d_status, d_kused, d_next);
     launch_path<4>(e, d_jobs, d_idx + off[2], off[3] - off[2], T, Rd, w, d_recs, d_res, d_status, d_kused, d_next);
@@ -250,7 +369,10 @@ void nw_breakpoints(Engine& e, const ReadsDev& T, const ReadsDev& Rd, std::vecto
         u32 lvl = 0;
         while (lvl < 4 && kRs[lvl] != J.R) ++lvl;
         const u64 k2 = static_cast<u64>(h_kused[i]) * 2;
-        if (J.kcap >= static_cast<u64>(J.n) + J.m || !plan(J, J.kcap < kcap_of(J.n, J.m, J.R) ? lvl : lvl + 1, k2)) ++st.n_unaligned;
+        const bool was_lane = J.bin != 0;
+        if (J.kcap >= static_cast<u64>(J.n) + J.m ||
+            !plan(J, was_lane ? 0 : (J.kcap < kcap_of(J.n, J.m, J.R) ? lvl : lvl + 1), k2))
+          ++st.n_unaligned;
         else again.push_back(i);
       } else if (h_status[i] != 0) {
         throw HipError("[raven_hip] alignment path: the walk left the stored band (internal error)");
@@ -329,10 +451,60 @@ static int emulate_job(const NwJob& J, const u64* t_words, const u64* r_words, u
   return wk.finish(true);
 }
 
+template <int NB>
+static int emulate_lane_job(const NwJob& J, const u64* t_words, const u64* r_words, u32 w, NwWindowRec* recs, u32* distance,
+                            u32* band) {
+  std::vector<u64> pv(NB), mv(NB), plo(NB), phi(NB);
+  std::vector<int> sc(NB);
+  std::vector<NwPm> ck_pm(nw_ckpt_slots(J.m, J.ckpt_nb) + 1), seg_pm(static_cast<size_t>(kNwSeg) * NB + 1);
+  std::vector<int> ck_sc(ck_pm.size()), seg_sc(seg_pm.size());
+  NwLaneMem<NB, 1> M{pv.data(), mv.data(), plo.data(), phi.data(), sc.data(), 0};
+  NwLaneStore st{ck_pm.data(), ck_sc.data(), J.ckpt_nb, seg_pm.data(), seg_sc.data()};
+  u32 ku = 0;
+  const int rcode = nw_lane_job<NB, 1>(J, t_words, r_words, M, st, w, recs, distance, &ku);
+  if (band) {
+    band[0] = ku;
+    band[1] = NB;
+    band[2] = 0;
+  }
+  return rcode == 2 ? -3 : rcode;
+}
+
 int nw_breakpoints_host(const u64* t_words, u32 t_len, const u64* r_words, u32 r_len, u32 t_begin, u32 n, u32 q_begin,
                         u32 m, int rc, u32 w, u32 k, int force_R, NwWindowRec* recs, u32* distance, u32* band) {
   (void)t_len;
   if (n == 0 || m == 0) return -1;
+  if (force_R < 0) {  // the lane-per-alignment kernel's code with a ring of -force_R blocks
+    const u32 NB = static_cast<u32>(-force_R);
+    if (NB != 8 && NB != 16 && NB != 24 && NB != 32) return -2;
+    NwJob J{};
+    J.t_begin = t_begin;
+    J.n = n;
+    J.q_begin = q_begin;
+    J.m = m;
+    J.r_len = r_len;
+    J.rc = rc ? 1 : 0;
+    J.R = 1;
+    J.bin = NB / 8;
+    J.n_windows = (t_begin + n - 1) / w - t_begin / w + 1;
+    for (u32 x = 0; x < J.n_windows; ++x) {
+      recs[x].first_t = recs[x].first_q = recs[x].last_t = recs[x].last_q = 0xFFFFFFFFu;
+      for (int g = 0; g < 8; ++g) recs[x].grid[g] = 0xFFFFu;
+    }
+    const u32 d = n > m ? n - m : m - n;
+    const u32 cap = kcap_of_blocks(n, m, NB);
+    const u64 kk = std::min<u64>(std::max<u64>(std::max<u64>(k, d), 1), static_cast<u64>(n) + m);
+    if (cap < kk) return -2;
+    J.k = static_cast<u32>(kk);
+    J.kcap = cap;
+    J.ckpt_nb = nw_ckpt_blocks(n, m, J.kcap);
+    switch (NB) {
+      case 8: return emulate_lane_job<8>(J, t_words, r_words, w, recs, distance, band);
+      case 16: return emulate_lane_job<16>(J, t_words, r_words, w, recs, distance, band);
+      case 24: return emulate_lane_job<24>(J, t_words, r_words, w, recs, distance, band);
+      default: return emulate_lane_job<32>(J, t_words, r_words, w, recs, distance, band);
+    }
+  }
   NwJob J{};
   J.t_begin = t_begin;
   J.n = n;

@@ -87,6 +87,29 @@ def test_band_doubling_and_blocks_per_lane():
         assert d == d1 and b[2] == R
 
 
+def test_lane_per_alignment_variant_gives_the_same_breakpoints():
+    """The narrow-band kernel (one lane per alignment, band ring in LDS: nwlane.h) stepped on the CPU with every ring
+    size: same distance, same breakpoints as the oracle; a band wider than the ring is refused, not truncated."""
+    rng = np.random.default_rng(44)
+    for trial in range(4):
+        n = int(rng.integers(500, 2600))
+        t, q = _noisy_pair(rng, n, 0.04, 0.03, 0.03)
+        rc = trial & 1
+        read = _oriented(q, rc)
+        for nb in (16, 24, 32):
+            d, band = _check(t, read, 0, len(t), 0, len(q), rc, 500, k=32, force_r=-nb)
+            assert band[1] == nb and band[0] >= d
+    t, q = _noisy_pair(rng, 3000, 0.002, 0.002, 0.002)  # HiFi-like: the smallest ring
+    _check(t, q, 0, len(t), 0, len(q), 0, 500, k=16, force_r=-8)
+    for n, m in [(1, 1), (1, 7), (9, 1), (64, 64), (65, 63), (300, 250)]:
+        tt = rng.integers(0, 4, n, dtype=np.uint8)
+        qq = rng.integers(0, 4, m, dtype=np.uint8)
+        _check(tt, qq, 0, n, 0, m, 0, 50, k=4, force_r=-16)
+    t, q = _noisy_pair(rng, 2500, 0.08, 0.06, 0.06)  # distance ~450: beyond a ring of 8 blocks
+    with pytest.raises(ValueError):
+        _check(t, q, 0, len(t), 0, len(q), 0, 500, k=600, force_r=-8)
+
+
 def test_length_difference_and_indel_bursts():
     rng = np.random.default_rng(33)
     t = rng.integers(0, 4, 2500, dtype=np.uint8)
