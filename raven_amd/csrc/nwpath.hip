@@ -247,14 +247,18 @@ void nw_breakpoints(Engine& e, const ReadsDev& T, const ReadsDev& Rd, std::vecto
     k_first = std::min<u64>(k_first, static_cast<u64>(J.n) + J.m);  // D(n, m) <= n + m: that threshold never fails
     J.bin = 0;
     if (lane_ok && lvl == 0) {  // narrow band: one lane per alignment, ring of 8 / 16 / 24 / 32 blocks in LDS
-      const u64 want = std::min<u64>(2 * k_first, static_cast<u64>(J.n) + J.m);  // room for one doubling
+      // the ring must hold the first threshold with a little headroom; when it cannot also hold a doubling, the sweep
+      // starts at the ring's largest threshold right away (a wider band on an efficient kernel beats a retry)
+      const u64 total = static_cast<u64>(J.n) + J.m;
+      const u64 want = std::min<u64>(k_first + k_first / 8, total);
       for (u32 bin = 1; bin <= 4; ++bin) {
         const u32 cap = kcap_of_blocks(J.n, J.m, 8 * bin);
         if (cap >= want) {
           J.bin = bin;
           J.R = 1;
-          J.k = static_cast<u32>(k_first);
+          J.k = static_cast<u32>(cap >= 2 * k_first ? k_first : cap);
           J.kcap = static_cast<u32>(std::min<u64>(cap, std::max<u64>(4 * k_first, 64)));
+          if (J.kcap < J.k) J.kcap = J.k;
           J.ckpt_nb = nw_ckpt_blocks(J.n, J.m, J.kcap);
           return true;
         }
