@@ -82,27 +82,45 @@ __host__ __device__ inline u32 nw_lane_sweep(const NwJob& J, const u64* __restri
       M.phi[s] = p.hi;
     }
     int hin = 1;  // above the first band block: the matrix border or a block that left the band (+1 boundary)
+    // The block loop is software-pipelined: the state of block b + 1 is fetched from LDS before block b is computed, so
+    // that the loads' latency overlaps the ~60 dependent ALU instructions of a block update (a lane-per-alignment wave
+    // has little else to hide it behind: the band rings of 64 alignments fill most of a CU's LDS).
+    int sl = bf % NB;
+    int s = M.at(sl);
+    u64 pv = M.pv[s], mv = M.mv[s], lo = M.plo[s], hi = M.phi[s];
+    int sc = M.sc[s];
+    const u64 seg0 = (static_cast<u64>(j - j0 - 1) * NB) * LANES + M.lane;
+    const bool ck = mode == 0 && (j % kNwSeg == 0);
+    const u64 ck0 = static_cast<u64>(j / kNwSeg) * st.ckpt_nb;
     for (int b = bf; b <= bl; ++b) {
-      const int s = M.at(b % NB);
-      u64 pv = M.pv[s], mv = M.mv[s];
-      const u64 lo = M.plo[s], hi = M.phi[s];
+      const int sl_n = sl + 1 == NB ? 0 : sl + 1;
+      const int s_n = M.at(sl_n);
+      u64 pv_n = 0, mv_n = 0, lo_n = 0, hi_n = 0;
+      int sc_n = 0;
+      if (b < bl) {
+        pv_n = M.pv[s_n];
+        mv_n = M.mv[s_n];
+        lo_n = M.plo[s_n];
+        hi_n = M.phi[s_n];
+        sc_n = M.sc[s_n];
+      }
       u64 eq = ((c & 1u) ? lo : ~lo) & ((c & 2u) ? hi : ~hi);
       if (b == B.nb - 1) {  // rows beyond n never match
         const u32 used = n - static_cast<u32>(64 * b);
         if (used < 64) eq &= (1ULL << used) - 1ULL;
       }
       const int hout = myers_block(pv, mv, eq, hin);
-      const int sc = M.sc[s] + hout;
+      sc += hout;
       M.pv[s] = pv;
       M.mv[s] = mv;
       M.sc[s] = sc;
       hin = hout;
       if (mode == 1) {
-        const u64 slot = (static_cast<u64>(j - j0 - 1) * NB + static_cast<u64>(b - bf)) * LANES + M.lane;
+        const u64 slot = seg0 + static_cast<u64>(b - bf) * LANES;
         st.seg_pm[slot] = NwPm{pv, mv};
         st.seg_sc[slot] = sc;
-      } else if (j % kNwSeg == 0) {
-        const u64 cs = static_cast<u64>(j / kNwSeg) * st.ckpt_nb + static_cast<u64>(b - bf);
+      } else if (ck) {
+        const u64 cs = ck0 + static_cast<u64>(b - bf);
         st.ck_pm[cs] = NwPm{pv, mv};
         st.ck_sc[cs] = sc;
       }
@@ -111,6 +129,13 @@ __host__ __device__ inline u32 nw_lane_sweep(const NwJob& J, const u64* __restri
         const u64 padmask = used >= 64 ? 0ULL : ~((1ULL << used) - 1ULL);
         result = static_cast<u32>(sc - RVN_POPC64(pv & padmask) + RVN_POPC64(mv & padmask)) + 1u;
       }
+      sl = sl_n;
+      s = s_n;
+      pv = pv_n;
+      mv = mv_n;
+      lo = lo_n;
+      hi = hi_n;
+      sc = sc_n;
     }
   }
   return result;
