@@ -27,6 +27,13 @@ __device__ __forceinline__ void nw_wsync() {
   __builtin_amdgcn_wave_barrier();
 }
 
+// value of the previous lane of the ring of L lanes (lane 0 <- lane L-1): a DPP whole-wave shift (one VALU instruction)
+// plus a scalar read of lane L-1, instead of a ds_bpermute on the critical path of every systolic step
+__device__ __forceinline__ int ring_prev(int v, int L) {
+  const int wrap = __builtin_amdgcn_readlane(v, L - 1);
+  return __builtin_amdgcn_update_dpp(wrap, v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+}
+
 template <int R>
 __global__ __launch_bounds__(256) void nw_path_kernel(const NwJob* __restrict__ jobs, const u32* __restrict__ idx,
                                                      u32 n_idx, const u64* __restrict__ t_words,
@@ -63,11 +70,10 @@ __global__ __launch_bounds__(256) void nw_path_kernel(const NwJob* __restrict__ 
       B = nw_band(J.n, J.m, k, R);
       ln.init(J, t_words, r_words, B, st, lane);
       ln.begin_sweep(0, J.m, 0);
-      const int src = lane == 0 ? B.L - 1 : lane - 1;
       const int t1 = NwLane<R>::sweep_t1(B, static_cast<int>(J.m));
       for (int t = ln.t0; t <= t1; ++t) {
-        const int hp = __shfl(ln.hout_last, src, 64);
-        const int sp = __shfl(ln.score_last, src, 64);
+        const int hp = ring_prev(ln.hout_last, B.L);
+        const int sp = ring_prev(ln.score_last, B.L);
         ln.step(t, hp, sp);
       }
       res = wave_max(ln.result) - 1u;  // exactly one lane holds D(n, m) + 1
@@ -96,7 +102,6 @@ __global__ __launch_bounds__(256) void nw_path_kernel(const NwJob* __restrict__ 
       wk.init(J, t_words, r_words, B, st, res, w, recs);
       if (lane == 0) swk = wk;
     }
-    const int src = lane == 0 ? B.L - 1 : lane - 1;
     int rows_left = static_cast<int>(J.n);
     for (int sg = (static_cast<int>(J.m) - 1) / kNwSeg; sg >= 0 && rows_left > 0; --sg) {
       const int j0 = sg * kNwSeg;
@@ -104,8 +109,8 @@ __global__ __launch_bounds__(256) void nw_path_kernel(const NwJob* __restrict__ 
       ln.begin_sweep(j0, j_end, 1);
       const int t1 = NwLane<R>::sweep_t1(B, j_end);
       for (int t = ln.t0; t <= t1; ++t) {
-        const int hp = __shfl(ln.hout_last, src, 64);
-        const int sp = __shfl(ln.score_last, src, 64);
+        const int hp = ring_prev(ln.hout_last, B.L);
+        const int sp = ring_prev(ln.score_last, B.L);
         ln.step(t, hp, sp);
       }
       nw_wsync();  // the segment's block states (and the walker in LDS) visible to every lane
@@ -240,7 +245,12 @@ void nw_breakpoints(Engine& e, const ReadsDev& T, const ReadsDev& Rd, std::vecto
   // plan: first threshold from the estimate, the smallest R whose ring holds twice that, checkpoint rows for kcap
   std::vector<u32> level(nj, 0);  // index into kRs
   std::vector<u32> todo;
-  const bool lane_ok = std::getenv("RVN_NW_NO_LANE") == nullptr;
+  // lane-per-alignment bins in use: rings of up to 16 blocks by default (HiFi-like / short alignments).  Wider rings fit
+  // too few alignments per CU (LDS) to beat the wave-per-alignment kernel (measured: r02_j / r02_k); RVN_NW_LANE_BINS=4
+  // enables all of them, 0 none.
+  u32 max_bin = 2;
+  if (const char* ev = std::getenv("RVN_NW_LANE_BINS")) max_bin = static_cast<u32>(std::atoi(ev));
+  const bool lane_ok = max_bin > 0;
   auto plan = [&](NwJob& J, u32 lvl, u64 k_first) -> bool {
     const u32 d = J.n > J.m ? J.n - J.m : J.m - J.n;
     k_first = std::max<u64>(std::max<u64>(k_first, d), 16);
@@ -251,7 +261,7 @@ void nw_breakpoints(Engine& e, const ReadsDev& T, const ReadsDev& Rd, std::vecto
       // starts at the ring's largest threshold right away (a wider band on an efficient kernel beats a retry)
       const u64 total = static_cast<u64>(J.n) + J.m;
       const u64 want = std::min<u64>(k_first + k_first / 8, total);
-      for (u32 bin = 1; bin <= 4; ++bin) {
+      for (u32 bin = 1; bin <= max_bin && bin <= 4; ++bin) {
         const u32 cap = kcap_of_blocks(J.n, J.m, 8 * bin);
         if (cap >= want) {
           J.bin = bin;
