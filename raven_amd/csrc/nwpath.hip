@@ -27,14 +27,30 @@ __device__ __forceinline__ void nw_wsync() {
   __builtin_amdgcn_wave_barrier();
 }
 
-// value of the previous lane of the ring of L lanes (lane 0 <- lane L-1): a DPP whole-wave shift (one VALU instruction)
-// plus a scalar read of lane L-1, instead of a ds_bpermute on the critical path of every systolic step
-__device__ __forceinline__ int ring_prev(int v, int L) {
-  const int wrap = __builtin_amdgcn_readlane(v, L - 1);
-  return __builtin_amdgcn_update_dpp(wrap, v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+// alignment slots (lane groups) of a launch of the wave kernel: waves per SIMD by register budget x groups per wave
+inline u32 path_slots(u32 R, u32 G) {
+  const u32 occ = R == 1 ? 3u : 2u;
+  return 256u * 4u * occ * (64u / G);
 }
 
-template <int R>
+// A wave is split into 64 / G lane groups of G lanes; every group owns one alignment at a time (its ring of L <= G lanes).
+// Control flow is uniform inside a group and may diverge between groups; every cross-lane operation below stays inside
+// the caller's group, whose lanes are always active together.
+template <int G>
+__device__ __forceinline__ int group_prev(int v, int lig, int gbase, int L) {  // lane - 1 of the ring (lane 0 <- lane L - 1)
+  return __shfl(v, lig == 0 ? gbase + L - 1 : gbase + lig - 1, 64);
+}
+template <int G>
+__device__ __forceinline__ u32 group_max(u32 v) {
+#pragma unroll
+  for (int off = G / 2; off > 0; off >>= 1) {
+    const u32 o = __shfl_xor(v, off, 64);
+    v = o > v ? o : v;
+  }
+  return v;
+}
+
+template <int R, int G>
 __global__ __launch_bounds__(256) void nw_path_kernel(const NwJob* __restrict__ jobs, const u32* __restrict__ idx,
                                                      u32 n_idx, const u64* __restrict__ t_words,
                                                      const u64* __restrict__ r_words, NwPm* __restrict__ ck_pm,
@@ -43,14 +59,16 @@ __global__ __launch_bounds__(256) void nw_path_kernel(const NwJob* __restrict__ 
                                                      NwWindowRec* __restrict__ recs, u32* __restrict__ result,
                                                      u32* __restrict__ status, u32* __restrict__ k_used,
                                                      u32* __restrict__ next) {
-  __shared__ NwWalker s_walker[4];
-  const u32 slot = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (slot >= n_slots) return;
+  constexpr int NG = 64 / G;
+  __shared__ NwWalker s_walker[4][NG];
   const int lane = lane_id();
+  const int group = lane / G, lig = lane % G, gbase = group * G;
+  const u32 slot = (blockIdx.x * 4 + (threadIdx.x >> 6)) * NG + static_cast<u32>(group);
+  if (slot >= n_slots) return;
   for (;;) {
     u32 q = 0;
-    if (lane == 0) q = atomicAdd(next, 1u);
-    q = static_cast<u32>(__builtin_amdgcn_readfirstlane(static_cast<int>(q)));
+    if (lig == 0) q = atomicAdd(next, 1u);
+    q = static_cast<u32>(__shfl(static_cast<int>(q), gbase, 64));
     if (q >= n_idx) break;
     const u32 ji = idx[q];
     const NwJob J = jobs[ji];
@@ -68,15 +86,15 @@ __global__ __launch_bounds__(256) void nw_path_kernel(const NwJob* __restrict__ 
     bool ok = false;
     for (;;) {
       B = nw_band(J.n, J.m, k, R);
-      ln.init(J, t_words, r_words, B, st, lane);
+      ln.init(J, t_words, r_words, B, st, lig);
       ln.begin_sweep(0, J.m, 0);
       const int t1 = NwLane<R>::sweep_t1(B, static_cast<int>(J.m));
       for (int t = ln.t0; t <= t1; ++t) {
-        const int hp = ring_prev(ln.hout_last, B.L);
-        const int sp = ring_prev(ln.score_last, B.L);
+        const int hp = group_prev<G>(ln.hout_last, lig, gbase, B.L);
+        const int sp = group_prev<G>(ln.score_last, lig, gbase, B.L);
         ln.step(t, hp, sp);
       }
-      res = wave_max(ln.result) - 1u;  // exactly one lane holds D(n, m) + 1
+      res = group_max<G>(ln.result) - 1u;  // exactly one lane of the group holds D(n, m) + 1
       if (res <= k) {
         ok = true;
         break;
@@ -84,23 +102,23 @@ __global__ __launch_bounds__(256) void nw_path_kernel(const NwJob* __restrict__ 
       if (k >= J.kcap) break;
       k = 2 * k < J.kcap ? 2 * k : J.kcap;
     }
-    if (lane == 0) {
+    if (lig == 0) {
       result[ji] = res;
       k_used[ji] = k;
     }
-    if (!ok) {  // beyond this launch's ring: the host relaunches the job with more blocks per lane
-      if (lane == 0) status[ji] = 2;
+    if (!ok) {  // beyond this launch's ring: the host relaunches the job with a larger ring / more blocks per lane
+      if (lig == 0) status[ji] = 2;
       continue;
     }
     nw_wsync();  // checkpoints visible to every lane
     // ---- the walk, segment by segment from the end ----
-    // The walker's state lives in LDS between the segments (it is not needed while the wave re-sweeps a segment, and
-    // keeping it in registers across the sweep loop costs occupancy); every lane holds an identical copy.
-    NwWalker& swk = s_walker[threadIdx.x >> 6];
+    // The walker's state lives in LDS between the segments (it is not needed while the group re-sweeps a segment, and
+    // keeping it in registers across the sweep loop costs occupancy); every lane of the group holds an identical copy.
+    NwWalker& swk = s_walker[threadIdx.x >> 6][group];
     {
       NwWalker wk;
       wk.init(J, t_words, r_words, B, st, res, w, recs);
-      if (lane == 0) swk = wk;
+      if (lig == 0) swk = wk;
     }
     int rows_left = static_cast<int>(J.n);
     for (int sg = (static_cast<int>(J.m) - 1) / kNwSeg; sg >= 0 && rows_left > 0; --sg) {
@@ -109,43 +127,44 @@ __global__ __launch_bounds__(256) void nw_path_kernel(const NwJob* __restrict__ 
       ln.begin_sweep(j0, j_end, 1);
       const int t1 = NwLane<R>::sweep_t1(B, j_end);
       for (int t = ln.t0; t <= t1; ++t) {
-        const int hp = ring_prev(ln.hout_last, B.L);
-        const int sp = ring_prev(ln.score_last, B.L);
+        const int hp = group_prev<G>(ln.hout_last, lig, gbase, B.L);
+        const int sp = group_prev<G>(ln.score_last, lig, gbase, B.L);
         ln.step(t, hp, sp);
       }
       nw_wsync();  // the segment's block states (and the walker in LDS) visible to every lane
       NwWalker wk = swk;
       wk.set_segment(j0, ln.t0);
-      wk.walk(lane == 0);  // every lane walks the same path (uniform control flow); lane 0 writes the records
+      wk.walk(lig == 0);  // every lane of the group walks the same path; its first lane writes the records
       rows_left = wk.i;
-      nw_wsync();          // all reads of the scratch done before the next segment overwrites it
-      if (lane == 0) swk = wk;
+      nw_wsync();         // all reads of the scratch done before the next segment overwrites it
+      if (lig == 0) swk = wk;
     }
     nw_wsync();
     NwWalker wk = swk;
-    const int bad = wk.finish(lane == 0);
-    if (lane == 0) status[ji] = static_cast<u32>(bad);
+    const int bad = wk.finish(lig == 0);
+    if (lig == 0) status[ji] = static_cast<u32>(bad);
     nw_wsync();
   }
 }
 
-template <int R>
+template <int R, int G>
 void launch_path(Engine& e, const NwJob* d_jobs, const u32* d_idx, u32 n_idx, const ReadsDev& T, const ReadsDev& Rd, u32 w,
                  NwWindowRec* d_recs, u32* d_result, u32* d_status, u32* d_kused, u32* d_next) {
   if (n_idx == 0) return;
   hipStream_t s = e.stream;
-  // per-wave scratch of one segment: nw_seg_rows() systolic steps x 64 lanes x R blocks
-  const u64 seg_stride = static_cast<u64>(nw_seg_rows()) * 64 * R;
-  u32 n_slots = std::min<u32>(n_idx, 256u * 4u * (R == 1 ? 5u : (R == 2 ? 4u : (R == 4 ? 3u : 2u))));
-  n_slots = ((n_slots + 3) / 4) * 4;
+  constexpr u32 NG = 64 / G;
+  // per-group scratch of one segment: nw_seg_rows() systolic steps x G lanes x R blocks
+  const u64 seg_stride = static_cast<u64>(nw_seg_rows()) * G * R;
+  u32 n_slots = std::min<u32>(n_idx, path_slots(R, G));
+  n_slots = ((n_slots + 4 * NG - 1) / (4 * NG)) * (4 * NG);
   NwPm* seg_pm = e.nw_pm.as<NwPm>();  // sized by nw_breakpoints for the largest launch of the batch
   int* seg_sc = e.nw_sc.as<int>();
   if (static_cast<u64>(n_slots) * seg_stride * sizeof(NwPm) > e.nw_pm.cap) throw HipError("[raven_hip] alignment path: scratch too small");
   RVN_HIP(hipMemsetAsync(d_next, 0, 4, s));
-  RVN_KLAUNCH(kKNwForward, nw_path_kernel<R><<<n_slots / 4, 256, 0, s>>>(
+  RVN_KLAUNCH(kKNwForward, (nw_path_kernel<R, G><<<n_slots / (4 * NG), 256, 0, s>>>(
                                d_jobs, d_idx, n_idx, T.packed.as<u64>(), Rd.packed.as<u64>(), e.nw_ck_pm.as<NwPm>(),
                                e.nw_ck_sc.as<int>(), seg_pm, seg_sc, seg_stride, n_slots, w, d_recs, d_result, d_status,
-                               d_kused, d_next));
+                               d_kused, d_next)));
 }
 
 // One lane per alignment (nwlane.h): persistent workgroups of one wave; group g = 64 consecutive jobs of the bin's list
@@ -218,10 +237,10 @@ u32 kcap_of_blocks(u32 n, u32 m, u32 NB) {
 }
 
 // largest threshold whose band fits a ring of 64 lanes with R blocks each
-u32 kcap_of(u32 n, u32 m, u32 R) {
+u32 kcap_of(u32 n, u32 m, u32 R, u32 G = 64) {
   const u32 d = n > m ? n - m : m - n;
-  // nw_ring_lanes(lo, hi, R) <= 64  <=>  64R + lo + hi <= 64 (64R + 1);  lo + hi = 2 floor((k - d) / 2) + d
-  const u64 room = 64ULL * (64ULL * R + 1) - 64ULL * R;
+  // nw_ring_lanes(lo, hi, R) <= G  <=>  64R + lo + hi <= G (64R + 1);  lo + hi = 2 floor((k - d) / 2) + d
+  const u64 room = static_cast<u64>(G) * (64ULL * R + 1) - 64ULL * R;
   if (room < d) return 0;
   const u64 k = d + ((room - d) / 2) * 2 + 1;  // (k - d) / 2 floors: an odd surplus costs nothing
   return static_cast<u32>(std::min<u64>(k, static_cast<u64>(n) + m));
@@ -239,7 +258,10 @@ void nw_breakpoints(Engine& e, const ReadsDev& T, const ReadsDev& Rd, std::vecto
   RVN_HIP(hipMemsetAsync(d_recs, 0xFF, n_recs * sizeof(NwWindowRec), s));
   if (nj == 0) return;
   RVN_HIP(hipEventRecord(e.ev0, s));
-  static const u32 kRs[4] = {1, 2, 4, 8};
+  // levels of the wave kernel: (blocks per lane R, lanes per alignment G); narrow rings share a wave (64 / G alignments)
+  static const u32 kRs[6] = {1, 1, 1, 2, 4, 8};
+  static const u32 kGs[6] = {16, 32, 64, 64, 64, 64};
+  constexpr u32 kLevels = 6;
   const double rate = e.nw_rate > 0 ? e.nw_rate : 0.13;  // first call: ONT-like; too small only costs a doubling
 
   // plan: first threshold from the estimate, the smallest R whose ring holds twice that, checkpoint rows for kcap
@@ -274,10 +296,11 @@ void nw_breakpoints(Engine& e, const ReadsDev& T, const ReadsDev& Rd, std::vecto
         }
       }
     }
-    for (; lvl < 4; ++lvl) {
-      const u32 cap = kcap_of(J.n, J.m, kRs[lvl]);
-      if (cap >= k_first && (cap >= 2 * k_first || lvl == 3 || cap >= static_cast<u64>(J.n) + J.m)) {
+    for (; lvl < kLevels; ++lvl) {
+      const u32 cap = kcap_of(J.n, J.m, kRs[lvl], kGs[lvl]);
+      if (cap >= k_first && (cap >= 2 * k_first || lvl == kLevels - 1 || cap >= static_cast<u64>(J.n) + J.m)) {
         J.R = kRs[lvl];
+        J.bin = kGs[lvl] == 64 ? 0 : kGs[lvl];  // 16 / 32: lanes per alignment of the wave kernel (0 = the whole wave)
         J.k = static_cast<u32>(std::min<u64>(k_first, cap));
         J.kcap = static_cast<u32>(std::min<u64>(cap, std::max<u64>(4 * k_first, 64)));
         J.ckpt_nb = nw_ckpt_blocks(J.n, J.m, J.kcap);
@@ -317,19 +340,23 @@ void nw_breakpoints(Engine& e, const ReadsDev& T, const ReadsDev& Rd, std::vecto
     u32* d_idx = d_kused + nj + 1;
     u32* d_next = d_idx + nj + 1;
     order = todo;
-    // classes: lane bins 1..4 first, then the wave kernel by R; inside a class the largest jobs first
+    // classes: lane bins 1..4 first, then the wave kernel's levels; inside a class the largest jobs first
+    auto level_of = [&](const NwJob& J) -> u32 {
+      if (J.R == 1) return J.bin == 16 ? 0 : (J.bin == 32 ? 1 : 2);
+      return J.R == 2 ? 3 : (J.R == 4 ? 4 : 5);
+    };
     auto cls = [&](u32 i) -> u32 {
       const NwJob& J = jobs[i];
-      return J.bin ? J.bin - 1 : 4 + (J.R == 1 ? 0 : (J.R == 2 ? 1 : (J.R == 4 ? 2 : 3)));
+      return (J.bin >= 1 && J.bin <= 4) ? J.bin - 1 : 4 + level_of(J);
     };
     std::stable_sort(order.begin(), order.end(), [&](u32 a, u32 b) {
       if (cls(a) != cls(b)) return cls(a) < cls(b);
-      if (jobs[a].bin) return jobs[a].m > jobs[b].m;  // lanes of a wave run loops of similar length
+      if (cls(a) < 4) return jobs[a].m > jobs[b].m;  // lanes of a wave run loops of similar length
       return static_cast<u64>(jobs[a].m) * jobs[a].k > static_cast<u64>(jobs[b].m) * jobs[b].k;
     });
-    u32 coff[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    u32 coff[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (u32 i : order) coff[cls(i) + 1]++;
-    for (int x = 0; x < 8; ++x) coff[x + 1] += coff[x];
+    for (int x = 0; x < 10; ++x) coff[x + 1] += coff[x];
     const u32* off = coff + 4;
     {  // one scratch allocation for the largest launch (the launches are asynchronous: no reallocation in between)
       u64 need = 1;
@@ -341,13 +368,13 @@ void nw_breakpoints(Engine& e, const ReadsDev& T, const ReadsDev& Rd, std::vecto
         const u64 blocks = std::min<u64>((cnt + 63) / 64, 256ULL * per_cu);
         need = std::max<u64>(need, blocks * kNwSeg * (8ULL * bin) * 64);
       }
-      for (int x = 0; x < 4; ++x) {
+      for (u32 x = 0; x < kLevels; ++x) {
         const u32 cnt = off[x + 1] - off[x];
         if (!cnt) continue;
-        const u32 R = kRs[x];
-        u64 slots = std::min<u64>(cnt, 256ULL * 4 * (R == 1 ? 5 : (R == 2 ? 4 : (R == 4 ? 3 : 2))));
-        slots = ((slots + 3) / 4) * 4;
-        need = std::max<u64>(need, slots * nw_seg_rows() * 64ULL * R);
+        const u32 R = kRs[x], G = kGs[x], NG = 64 / G;
+        u64 slots = std::min<u64>(cnt, path_slots(R, G));
+        slots = ((slots + 4 * NG - 1) / (4 * NG)) * (4 * NG);
+        need = std::max<u64>(need, slots * nw_seg_rows() * static_cast<u64>(G) * R);
       }
       (void)e.nw_pm.get<NwPm>(need + 1);
       (void)e.nw_sc.get<int>(need + 1);
@@ -358,10 +385,12 @@ void nw_breakpoints(Engine& e, const ReadsDev& T, const ReadsDev& Rd, std::vecto
     launch_lane<16>(e, d_jobs, d_idx + coff[1], coff[2] - coff[1], T, Rd, w, d_recs, d_res, d_status, d_kused);
     launch_lane<24>(e, d_jobs, d_idx + coff[2], coff[3] - coff[2], T, Rd, w, d_recs, d_res, d_status, d_kused);
     launch_lane<32>(e, d_jobs, d_idx + coff[3], coff[4] - coff[3], T, Rd, w, d_recs, d_res, d_status, d_kused);
-    launch_path<1>(e, d_jobs, d_idx + off[0], off[1] - off[0], T, Rd, w, d_recs, d_res, d_status, d_kused, d_next);
-    launch_path<2>(e, d_jobs, d_idx + off[1], off[2] - off[1], T, Rd, w, d_recs, d_res, d_status, d_kused, d_next);
-    launch_path<4>(e, d_jobs, d_idx + off[2], off[3] - off[2], T, Rd, w, d_recs, d_res, d_status, d_kused, d_next);
-    launch_path<8>(e, d_jobs, d_idx + off[3], off[4] - off[3], T, Rd, w, d_recs, d_res, d_status, d_kused, d_next);
+    launch_path<1, 16>(e, d_jobs, d_idx + off[0], off[1] - off[0], T, Rd, w, d_recs, d_res, d_status, d_kused, d_next);
+    launch_path<1, 32>(e, d_jobs, d_idx + off[1], off[2] - off[1], T, Rd, w, d_recs, d_res, d_status, d_kused, d_next);
+    launch_path<1, 64>(e, d_jobs, d_idx + off[2], off[3] - off[2], T, Rd, w, d_recs, d_res, d_status, d_kused, d_next);
+    launch_path<2, 64>(e, d_jobs, d_idx + off[3], off[4] - off[3], T, Rd, w, d_recs, d_res, d_status, d_kused, d_next);
+    launch_path<4, 64>(e, d_jobs, d_idx + off[4], off[5] - off[4], T, Rd, w, d_recs, d_res, d_status, d_kused, d_next);
+    launch_path<8, 64>(e, d_jobs, d_idx + off[5], off[6] - off[5], T, Rd, w, d_recs, d_res, d_status, d_kused, d_next);
     h_result.resize(nj);
     h_status.resize(nj);
     h_kused.resize(nj);
@@ -380,12 +409,11 @@ void nw_breakpoints(Engine& e, const ReadsDev& T, const ReadsDev& Rd, std::vecto
         ++st.n_retries;
       }
       if (h_status[i] == 2) {  // distance above this launch's largest threshold: next blocks-per-lane level
-        u32 lvl = 0;
-        while (lvl < 4 && kRs[lvl] != J.R) ++lvl;
         const u64 k2 = static_cast<u64>(h_kused[i]) * 2;
-        const bool was_lane = J.bin != 0;
+        const bool was_lane = J.bin >= 1 && J.bin <= 4;
+        const u32 lvl = was_lane ? 0 : level_of(J);
         if (J.kcap >= static_cast<u64>(J.n) + J.m ||
-            !plan(J, was_lane ? 0 : (J.kcap < kcap_of(J.n, J.m, J.R) ? lvl : lvl + 1), k2))
+            !plan(J, was_lane ? 0 : (J.kcap < kcap_of(J.n, J.m, kRs[lvl], kGs[lvl]) ? lvl : lvl + 1), k2))
           ++st.n_unaligned;
         else again.push_back(i);
       } else if (h_status[i] != 0) {
@@ -532,7 +560,7 @@ int nw_breakpoints_host(const u64* t_words, u32 t_len, const u64* r_words, u32 r
     for (int g = 0; g < 8; ++g) recs[x].grid[g] = 0xFFFFu;
   }
   const u32 d = n > m ? n - m : m - n;
-  static const u32 kRs[4] = {1, 2, 4, 8};
+  static const u32 kRs[4] = {1, 2, 4, 8};  // the stepper emulates whole-wave rings (lane groups only change which lanes a ring uses)
   u32 lvl = 0;
   if (force_R) {
     while (lvl < 4 && kRs[lvl] != static_cast<u32>(force_R)) ++lvl;
