@@ -65,84 +65,90 @@ __global__ __launch_bounds__(256) void nw_path_kernel(const NwJob* __restrict__ 
   const int group = lane / G, lig = lane % G, gbase = group * G;
   const u32 slot = (blockIdx.x * 4 + (threadIdx.x >> 6)) * NG + static_cast<u32>(group);
   if (slot >= n_slots) return;
+  // The groups of a wave take a bundle of 64 / G consecutive jobs together and run through its phases in lockstep
+  // (pass 1, then segment by segment: sweep, walk): control flow that differs between the groups of a wave is serialised
+  // by the hardware, so groups drifting into different phases would cost more than they share.  Jobs are sorted by
+  // size, the jobs of a bundle have nearly the same number of columns and segments.
   for (;;) {
-    u32 q = 0;
-    if (lig == 0) q = atomicAdd(next, 1u);
-    q = static_cast<u32>(__shfl(static_cast<int>(q), gbase, 64));
-    if (q >= n_idx) break;
-    const u32 ji = idx[q];
-    const NwJob J = jobs[ji];
-    NwStore st;
-    st.ck_pm = ck_pm + J.ckpt;
-    st.ck_sc = ck_sc + J.ckpt;
-    st.ckpt_nb = J.ckpt_nb;
-    st.seg_pm = seg_pm + static_cast<u64>(slot) * seg_stride;
-    st.seg_sc = seg_sc + static_cast<u64>(slot) * seg_stride;
-    // ---- pass 1: distance + checkpoints; the threshold is doubled until the banded result is exact ----
-    u32 k = J.k;
-    NwBand B;
-    NwLane<R> ln;
-    u32 res = 0;
-    bool ok = false;
-    for (;;) {
-      B = nw_band(J.n, J.m, k, R);
-      ln.init(J, t_words, r_words, B, st, lig);
-      ln.begin_sweep(0, J.m, 0);
-      const int t1 = NwLane<R>::sweep_t1(B, static_cast<int>(J.m));
-      for (int t = ln.t0; t <= t1; ++t) {
-        const int hp = group_prev<G>(ln.hout_last, lig, gbase, B.L);
-        const int sp = group_prev<G>(ln.score_last, lig, gbase, B.L);
-        ln.step(t, hp, sp);
+    u32 q0 = 0;
+    if (lane == 0) q0 = atomicAdd(next, static_cast<u32>(NG));
+    q0 = static_cast<u32>(__builtin_amdgcn_readfirstlane(static_cast<int>(q0)));
+    if (q0 >= n_idx) break;
+    const u32 q = q0 + static_cast<u32>(group);
+    if (q < n_idx) {
+      const u32 ji = idx[q];
+      const NwJob J = jobs[ji];
+      NwStore st;
+      st.ck_pm = ck_pm + J.ckpt;
+      st.ck_sc = ck_sc + J.ckpt;
+      st.ckpt_nb = J.ckpt_nb;
+      st.seg_pm = seg_pm + static_cast<u64>(slot) * seg_stride;
+      st.seg_sc = seg_sc + static_cast<u64>(slot) * seg_stride;
+      // ---- pass 1: distance + checkpoints; the threshold is doubled until the banded result is exact ----
+      u32 k = J.k;
+      NwBand B;
+      NwLane<R> ln;
+      u32 res = 0;
+      bool ok = false;
+      for (;;) {
+        B = nw_band(J.n, J.m, k, R);
+        ln.init(J, t_words, r_words, B, st, lig);
+        ln.begin_sweep(0, J.m, 0);
+        const int t1 = NwLane<R>::sweep_t1(B, static_cast<int>(J.m));
+        for (int t = ln.t0; t <= t1; ++t) {
+          const int hp = group_prev<G>(ln.hout_last, lig, gbase, B.L);
+          const int sp = group_prev<G>(ln.score_last, lig, gbase, B.L);
+          ln.step(t, hp, sp);
+        }
+        res = group_max<G>(ln.result) - 1u;  // exactly one lane of the group holds D(n, m) + 1
+        if (res <= k) {
+          ok = true;
+          break;
+        }
+        if (k >= J.kcap) break;
+        k = 2 * k < J.kcap ? 2 * k : J.kcap;
       }
-      res = group_max<G>(ln.result) - 1u;  // exactly one lane of the group holds D(n, m) + 1
-      if (res <= k) {
-        ok = true;
-        break;
+      if (lig == 0) {
+        result[ji] = res;
+        k_used[ji] = k;
+        if (!ok) status[ji] = 2;  // beyond this launch's ring: the host relaunches the job with a larger ring
       }
-      if (k >= J.kcap) break;
-      k = 2 * k < J.kcap ? 2 * k : J.kcap;
-    }
-    if (lig == 0) {
-      result[ji] = res;
-      k_used[ji] = k;
-    }
-    if (!ok) {  // beyond this launch's ring: the host relaunches the job with a larger ring / more blocks per lane
-      if (lig == 0) status[ji] = 2;
-      continue;
-    }
-    nw_wsync();  // checkpoints visible to every lane
-    // ---- the walk, segment by segment from the end ----
-    // The walker's state lives in LDS between the segments (it is not needed while the group re-sweeps a segment, and
-    // keeping it in registers across the sweep loop costs occupancy); every lane of the group holds an identical copy.
-    NwWalker& swk = s_walker[threadIdx.x >> 6][group];
-    {
-      NwWalker wk;
-      wk.init(J, t_words, r_words, B, st, res, w, recs);
-      if (lig == 0) swk = wk;
-    }
-    int rows_left = static_cast<int>(J.n);
-    for (int sg = (static_cast<int>(J.m) - 1) / kNwSeg; sg >= 0 && rows_left > 0; --sg) {
-      const int j0 = sg * kNwSeg;
-      const int j_end = j0 + kNwSeg < static_cast<int>(J.m) ? j0 + kNwSeg : static_cast<int>(J.m);
-      ln.begin_sweep(j0, j_end, 1);
-      const int t1 = NwLane<R>::sweep_t1(B, j_end);
-      for (int t = ln.t0; t <= t1; ++t) {
-        const int hp = group_prev<G>(ln.hout_last, lig, gbase, B.L);
-        const int sp = group_prev<G>(ln.score_last, lig, gbase, B.L);
-        ln.step(t, hp, sp);
+      nw_wsync();  // checkpoints visible to every lane
+      if (ok) {
+        // ---- the walk, segment by segment from the end ----
+        // The walker's state lives in LDS between the segments (it is not needed while the group re-sweeps a segment,
+        // and keeping it in registers across the sweep loop costs occupancy); every lane of the group holds a copy.
+        NwWalker& swk = s_walker[threadIdx.x >> 6][group];
+        {
+          NwWalker wk;
+          wk.init(J, t_words, r_words, B, st, res, w, recs);
+          if (lig == 0) swk = wk;
+        }
+        int rows_left = static_cast<int>(J.n);
+        for (int sg = (static_cast<int>(J.m) - 1) / kNwSeg; sg >= 0 && rows_left > 0; --sg) {
+          const int j0 = sg * kNwSeg;
+          const int j_end = j0 + kNwSeg < static_cast<int>(J.m) ? j0 + kNwSeg : static_cast<int>(J.m);
+          ln.begin_sweep(j0, j_end, 1);
+          const int t1 = NwLane<R>::sweep_t1(B, j_end);
+          for (int t = ln.t0; t <= t1; ++t) {
+            const int hp = group_prev<G>(ln.hout_last, lig, gbase, B.L);
+            const int sp = group_prev<G>(ln.score_last, lig, gbase, B.L);
+            ln.step(t, hp, sp);
+          }
+          nw_wsync();  // the segment's block states (and the walker in LDS) visible to every lane
+          NwWalker wk = swk;
+          wk.set_segment(j0, ln.t0);
+          wk.walk(lig == 0);  // every lane of the group walks the same path; its first lane writes the records
+          rows_left = wk.i;
+          nw_wsync();         // all reads of the scratch done before the next segment overwrites it
+          if (lig == 0) swk = wk;
+        }
+        nw_wsync();
+        NwWalker wk = swk;
+        const int bad = wk.finish(lig == 0);
+        if (lig == 0) status[ji] = static_cast<u32>(bad);
       }
-      nw_wsync();  // the segment's block states (and the walker in LDS) visible to every lane
-      NwWalker wk = swk;
-      wk.set_segment(j0, ln.t0);
-      wk.walk(lig == 0);  // every lane of the group walks the same path; its first lane writes the records
-      rows_left = wk.i;
-      nw_wsync();         // all reads of the scratch done before the next segment overwrites it
-      if (lig == 0) swk = wk;
     }
-    nw_wsync();
-    NwWalker wk = swk;
-    const int bad = wk.finish(lig == 0);
-    if (lig == 0) status[ji] = static_cast<u32>(bad);
     nw_wsync();
   }
 }
@@ -352,7 +358,7 @@ void nw_breakpoints(Engine& e, const ReadsDev& T, const ReadsDev& Rd, std::vecto
     std::stable_sort(order.begin(), order.end(), [&](u32 a, u32 b) {
       if (cls(a) != cls(b)) return cls(a) < cls(b);
       if (cls(a) < 4) return jobs[a].m > jobs[b].m;  // lanes of a wave run loops of similar length
-      return static_cast<u64>(jobs[a].m) * jobs[a].k > static_cast<u64>(jobs[b].m) * jobs[b].k;
+      return jobs[a].m > jobs[b].m;  // longest first; the groups of a wave get jobs of (nearly) the same length
     });
     u32 coff[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (u32 i : order) coff[cls(i) + 1]++;
