@@ -304,7 +304,9 @@ void nw_breakpoints(Engine& e, const ReadsDev& T, const ReadsDev& Rd, std::vecto
     }
     for (; lvl < kLevels; ++lvl) {
       const u32 cap = kcap_of(J.n, J.m, kRs[lvl], kGs[lvl]);
-      if (cap >= k_first && (cap >= 2 * k_first || lvl == kLevels - 1 || cap >= static_cast<u64>(J.n) + J.m)) {
+      // headroom of a quarter over the first threshold (the p90-based estimate): the few alignments beyond it come
+      // back with status 2 and are redone one level up
+      if (cap >= k_first && (cap >= k_first + k_first / 4 || lvl == kLevels - 1 || cap >= static_cast<u64>(J.n) + J.m)) {
         J.R = kRs[lvl];
         J.bin = kGs[lvl] == 64 ? 0 : kGs[lvl];  // 16 / 32: lanes per alignment of the wave kernel (0 = the whole wave)
         J.k = static_cast<u32>(std::min<u64>(k_first, cap));
