@@ -121,6 +121,14 @@ int rvn_pass1_fetch_piles(const rvn_pass1* p, uint16_t* data, uint64_t* offsets)
  * FindChimericRegions (double-precision slopes) stays on the host. */
 int rvn_pass1_trim_and_annotate(rvn_pass1* p, uint32_t coverage, uint32_t* begin, uint32_t* end, uint16_t* median,
                                 uint8_t* invalid);
+/* The third step of raven::TrimAndAnnotatePiles (construct.cc:139): Pile::FindChimericRegions (pile.cc:176-187) =
+ * FindSlopes(1.82) (pile.cc:403-600: coverage drops / rises against the sliding maxima within 52 cells, evaluated in
+ * double as the reference does), down-slope / up-slope pairing and MergeRegions (pile.cc:373-400), for every pile that
+ * rvn_pass1_trim_and_annotate left valid (`invalid` = its output), on the coverage arrays in HBM.  Output: the piles'
+ * chimeric_regions_ as (begin, end) cell pairs, pile i at region_offsets[i] .. region_offsets[i+1] (pairs; n + 1 entries,
+ * caller's array); *regions is malloc'ed by the library (2 uint32 per pair), release with rvn_free.
+ * Pile::is_maybe_chimeric() == (region_offsets[i+1] > region_offsets[i]). */
+int rvn_pass1_find_chimeric_regions(rvn_pass1* p, const uint8_t* invalid, uint32_t* region_offsets, uint32_t** regions);
 int rvn_pass1_fetch_overlaps(const rvn_pass1* p, rvn_overlap* overlaps, uint32_t* offsets);
 void rvn_pass1_destroy(rvn_pass1* p);
 
@@ -366,6 +374,9 @@ int rvn_test_low_complexity(const uint8_t* codes, uint32_t k);
 int rvn_test_nw_breakpoints(const uint64_t* t_words, uint32_t t_len, const uint64_t* r_words, uint32_t r_len,
                             uint32_t t_begin, uint32_t n, uint32_t q_begin, uint32_t m, int rc, uint32_t w, uint32_t k,
                             int force_r, uint32_t* recs, uint32_t* distance, uint32_t* band);
+/* Pile::FindChimericRegions (slopes.h, the __host__ __device__ code the kernel runs) on one coverage array: out = (begin,
+ * end) cell pairs; returns their number, -5 if a capacity was exceeded */
+int64_t rvn_test_find_chimeric_regions(const uint16_t* data, uint32_t size, uint32_t* out, uint64_t cap_pairs);
 /* OverlapUpdate + GetOverlapType (overlap_rules.h, the __host__ __device__ code the kernels run) on a list: ok[i] =
  * OverlapUpdate result (the overlap is updated in place when ok), type[i] = GetOverlapType of the updated overlap */
 int rvn_test_overlap_update_and_type(rvn_overlap* overlaps, uint64_t n, const uint32_t* pile_begin, const uint32_t* pile_end,

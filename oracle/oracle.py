@@ -235,6 +235,18 @@ def polish_round(targets, reads, quals=None, q=0.0, err=0.3, w=500, trim=True, m
     return [out[int(ooff[i]): int(ooff[i]) + int(out_len[i])].copy() for i in range(nt)], ratio
 
 
+def find_chimeric_regions(data):
+    """Pile::FindChimericRegions (pile.cc:176-187 with FindSlopes / MergeRegions) of one coverage array."""
+    d = np.ascontiguousarray(data, dtype=np.uint16)
+    out = np.zeros(max(2, d.shape[0]), dtype=np.uint32)
+    L = lib()
+    L.orc_find_chimeric_regions.restype = C.c_int64
+    L.orc_find_chimeric_regions.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64]
+    n = L.orc_find_chimeric_regions(_p(d), d.shape[0], _p(out), out.shape[0] // 2)
+    assert n >= 0
+    return out[:2 * n].reshape(-1, 2).copy()
+
+
 def overlap_update_and_type(overlaps, pile_begin, pile_end, pile_invalid):
     """OverlapUpdate + GetOverlapType (overlap_utils.cc:14-113) on a list: (updated overlaps, ok, type)."""
     o = np.ascontiguousarray(overlaps, dtype=OVERLAP_DTYPE).copy()

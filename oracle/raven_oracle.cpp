@@ -847,6 +847,194 @@ void orc_pile_add_kmers(const std::uint64_t* words, std::uint32_t len, const std
 
 }  // extern "C" (reopened below)
 
+// ---- Pile::FindSlopes / FindChimericRegions / MergeRegions (RavenLib/src/pile.cc:176-187, :373-400, :403-600; the file
+// is in the reference tree) restated with the reference's own data structures (monotone deques, std::sort, vectors) ----
+namespace orc {
+
+using Region = std::pair<std::uint32_t, std::uint32_t>;
+
+static std::vector<Region> MergeRegions(const std::vector<Region>& src) {  // pile.cc:373-400
+  std::vector<Region> dst;
+  std::vector<bool> is_merged(src.size(), 0);
+  for (std::uint32_t i = 0; i < src.size(); ++i) {
+    if (is_merged[i]) continue;
+    Region r = src[i];
+    while (true) {
+      is_merged[i] = false;
+      for (std::uint32_t j = i + 1; j < src.size(); ++j) {
+        if (is_merged[j]) continue;
+        if (r.first < src[j].second && r.second > src[j].first) {
+          is_merged[i] = true;
+          is_merged[j] = true;
+          r.first = std::min(r.first, src[j].first);
+          r.second = std::max(r.second, src[j].second);
+        }
+      }
+      if (!is_merged[i]) break;
+    }
+    dst.emplace_back(r);
+  }
+  return dst;
+}
+
+static std::vector<Region> FindSlopes(const std::vector<std::uint16_t>& data_, double q) {  // pile.cc:403-600
+  using Subpile = std::deque<std::pair<std::int32_t, std::uint16_t>>;
+  auto subpile_add = [](Subpile& s, std::uint16_t value, std::int32_t position) -> void {
+    while (!s.empty() && s.back().second <= value) s.pop_back();
+    s.emplace_back(position, value);
+  };
+  auto subpile_update = [](Subpile& s, std::int32_t position) {
+    while (!s.empty() && s.front().first <= position) s.pop_front();
+  };
+  std::vector<Region> dst;
+  std::int32_t w = 847 >> kPSS;
+  std::int32_t data_size = data_.size();
+  Subpile left_subpile;
+  std::uint32_t first_down = 0, last_down = 0;
+  bool found_down = false;
+  Subpile right_subpile;
+  std::uint32_t first_up = 0, last_up = 0;
+  bool found_up = false;
+  for (std::int32_t i = 0; i < w && i < data_size; ++i) subpile_add(right_subpile, data_[i], i);  // (reference: i < w only)
+  for (std::int32_t i = 0; i < data_size; ++i) {
+    if (i > 0) subpile_add(left_subpile, data_[i - 1], i - 1);
+    subpile_update(left_subpile, i - 1 - w);
+    if (i < data_size - w) subpile_add(right_subpile, data_[i + w], i + w);
+    subpile_update(right_subpile, i);
+    std::uint16_t d = clamp16(data_[i] * q);
+    if (i != 0 && left_subpile.front().second > d) {
+      if (found_down) {
+        if (i - last_down > 1) {
+          dst.emplace_back(first_down << 1 | 0, last_down);
+          first_down = i;
+        }
+      } else {
+        found_down = true;
+        first_down = i;
+      }
+      last_down = i;
+    }
+    if (i != (data_size - 1) && right_subpile.front().second > d) {
+      if (found_up) {
+        if (i - last_up > 1) {
+          dst.emplace_back(first_up << 1 | 1, last_up);
+          first_up = i;
+        }
+      } else {
+        found_up = true;
+        first_up = i;
+      }
+      last_up = i;
+    }
+  }
+  if (found_down) dst.emplace_back(first_down << 1 | 0, last_down);
+  if (found_up) dst.emplace_back(first_up << 1 | 1, last_up);
+  if (dst.empty()) return dst;
+  while (true) {  // separate overlapping slopes
+    std::sort(dst.begin(), dst.end());
+    bool is_changed = false;
+    for (std::uint32_t i = 0; i < dst.size() - 1; ++i) {
+      if (dst[i].second < (dst[i + 1].first >> 1)) continue;
+      if (dst[i].first & 1) {
+        right_subpile.clear();
+        found_up = false;
+        std::uint32_t subpile_begin = dst[i].first >> 1;
+        std::uint32_t subpile_end = std::min(dst[i].second, dst[i + 1].second);
+        for (std::uint32_t j = subpile_begin; j < subpile_end + 1; ++j) subpile_add(right_subpile, data_[j], j);
+        for (std::uint32_t j = subpile_begin; j < subpile_end; ++j) {
+          subpile_update(right_subpile, j);
+          if (clamp16(data_[j] * q) < right_subpile.front().second) {
+            if (found_up) {
+              if (j - last_up > 1) {
+                dst.emplace_back(first_up << 1 | 1, last_up);
+                first_up = j;
+              }
+            } else {
+              found_up = true;
+              first_up = j;
+            }
+            last_up = j;
+          }
+        }
+        if (found_up) dst.emplace_back(first_up << 1 | 1, last_up);
+        dst[i].first = subpile_end << 1 | 1;
+      } else {
+        if (dst[i].second == (dst[i + 1].first >> 1)) continue;
+        left_subpile.clear();
+        found_down = false;
+        std::uint32_t subpile_begin = std::max(dst[i].first >> 1, dst[i + 1].first >> 1);
+        std::uint32_t subpile_end = dst[i].second;
+        for (std::uint32_t j = subpile_begin; j < subpile_end + 1; ++j) {
+          if (left_subpile.empty() == false && clamp16(data_[j] * q) < left_subpile.front().second) {
+            if (found_down) {
+              if (j - last_down > 1) {
+                dst.emplace_back(first_down << 1, last_down);
+                first_down = j;
+              }
+            } else {
+              found_down = true;
+              first_down = j;
+            }
+            last_down = j;
+          }
+          subpile_add(left_subpile, data_[j], j);
+        }
+        if (found_down) dst.emplace_back(first_down << 1, last_down);
+        dst[i].second = subpile_begin;
+      }
+      is_changed = true;
+      break;
+    }
+    if (!is_changed) break;
+  }
+  for (std::uint32_t i = 0; i < dst.size() - 1; ++i) {  // narrow slopes
+    if ((dst[i].first & 1) && !(dst[i + 1].first & 1)) {
+      std::uint32_t subpile_begin = dst[i].second;
+      std::uint32_t subpile_end = dst[i + 1].first >> 1;
+      if (subpile_end - subpile_begin > static_cast<std::uint32_t>(w)) continue;
+      std::uint16_t max_coverage = 0;
+      for (std::uint32_t j = subpile_begin + 1; j < subpile_end; ++j) max_coverage = std::max(max_coverage, data_[j]);
+      std::uint32_t valid_point = dst[i].first >> 1;
+      for (std::uint32_t j = dst[i].first >> 1; j <= subpile_begin; ++j)
+        if (max_coverage > clamp16(data_[j] * q)) valid_point = j;
+      dst[i].second = valid_point;
+      valid_point = dst[i + 1].second;
+      for (std::uint32_t j = subpile_end; j <= dst[i + 1].second; ++j) {
+        if (max_coverage > clamp16(data_[j] * q)) {
+          valid_point = j;
+          break;
+        }
+      }
+      dst[i + 1].first = valid_point << 1 | 0;
+    }
+  }
+  return dst;
+}
+
+}  // namespace orc
+
+extern "C" {
+
+// Pile::FindChimericRegions on one coverage array: out = (begin, end) cell pairs; returns their number (<= cap or -1)
+std::int64_t orc_find_chimeric_regions(const std::uint16_t* data, std::uint32_t size, std::uint32_t* out, std::uint64_t cap) {
+  std::vector<std::uint16_t> d(data, data + size);
+  auto slopes = orc::FindSlopes(d, 1.82);
+  std::vector<orc::Region> regions;
+  if (!slopes.empty()) {
+    for (std::uint32_t i = 0; i < slopes.size() - 1; ++i)
+      if (!(slopes[i].first & 1) && (slopes[i + 1].first & 1)) regions.emplace_back(slopes[i].first >> 1, slopes[i + 1].second);
+    regions = orc::MergeRegions(regions);
+  }
+  if (regions.size() > cap) return -1;
+  for (std::size_t i = 0; i < regions.size(); ++i) {
+    out[2 * i] = regions[i].first;
+    out[2 * i + 1] = regions[i].second;
+  }
+  return static_cast<std::int64_t>(regions.size());
+}
+
+}  // extern "C"
+
 // ---- overlap bookkeeping against the piles' valid regions (RavenLib/src/overlap_utils.cc, in the reference tree) ----
 namespace orc {
 

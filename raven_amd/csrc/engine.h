@@ -292,6 +292,9 @@ void piles_init(Engine& e, const ReadsDev& r, PileState& ps);
 void piles_merge(Engine& e, const ReadsDev& r, const MapOut& mo, u32 kmax, PileState& ps);
 // Pile::FindValidRegion(coverage) + FindMedian on every pile, in place in HBM (pile.hip); host output arrays of n
 void piles_trim_and_median(Engine& e, PileState& ps, u32 coverage, u32* h_begin, u32* h_end, u16* h_median, u8* h_invalid);
+// Pile::FindChimericRegions of every valid pile on the coverage in HBM (pile.hip): CSR of (begin, end) cell pairs
+void piles_find_chimeric_regions(Engine& e, PileState& ps, const u8* h_invalid, std::vector<u32>& h_off,
+                                 std::vector<u32>& h_regions);
 // Pile::AddKmers for reads [first_read, first_read + n_reads) (pile.hip)
 void pile_add_kmers_batch(Engine& e, const ReadsDev& r, const u32* h_pos, const u64* h_pos_off, u32 n_reads,
                           u32 first_read, u8* h_out, const u64* h_out_off);

@@ -9,6 +9,7 @@
 #include "introsort.h"
 #include "nwpath.h"
 #include "overlap_rules.h"
+#include "slopes.h"
 #include "poa.h"
 #include "kmer.h"
 #include "lowcomplexity.h"
@@ -614,6 +615,23 @@ int rvn_pass1_trim_and_annotate(rvn_pass1* p, uint32_t coverage, uint32_t* begin
   });
 }
 
+int rvn_pass1_find_chimeric_regions(rvn_pass1* p, const uint8_t* invalid, uint32_t* region_offsets, uint32_t** regions) {
+  return guarded(p ? p->e : nullptr, [&]() -> int {
+    if (!p || !invalid || !region_offsets || !regions) return fail(RVN_EINVAL, "[raven_hip] NULL argument");
+    *regions = nullptr;
+    RVN_HIP(hipSetDevice(p->e->device));
+    UseTimers ut(*p->e);
+    std::vector<u32> off, reg;
+    piles_find_chimeric_regions(*p->e, p->ps, invalid, off, reg);
+    std::memcpy(region_offsets, off.data(), off.size() * 4);
+    auto* out = static_cast<uint32_t*>(std::malloc((reg.size() + 1) * 4));
+    if (!out) return fail(RVN_ENOMEM, "[raven_hip] out of host memory");
+    if (!reg.empty()) std::memcpy(out, reg.data(), reg.size() * 4);
+    *regions = out;
+    return RVN_OK;
+  });
+}
+
 int rvn_pass1_fetch_overlaps(const rvn_pass1* p, rvn_overlap* overlaps, uint32_t* offsets) {
   return guarded(p ? p->e : nullptr, [&]() -> int {
     if (!p) return fail(RVN_EINVAL, "[raven_hip] NULL pass1");
@@ -690,6 +708,16 @@ int rvn_filter_overlaps_by_identity(rvn_engine* h, const rvn_reads* rr, rvn_over
     identity_filter_lists(h->e, r, reinterpret_cast<Overlap*>(overlaps), offsets, pile_begin, pile_end, pile_invalid, identity);
     return RVN_OK;
   });
+}
+
+int64_t rvn_test_find_chimeric_regions(const uint16_t* data, uint32_t size, uint32_t* out, uint64_t cap_pairs) {
+  if (!data || !out || size == 0) return RVN_EINVAL;
+  std::vector<SlopeRegion> slopes(size + 1);
+  std::vector<u16> tmp(size + 1);
+  bool overflow = false;
+  const u32 n = find_chimeric_regions(data, static_cast<int>(size), slopes.data(), size, tmp.data(), out,
+                                      static_cast<u32>(std::min<uint64_t>(cap_pairs, size / 2)), &overflow);
+  return overflow ? -5 : static_cast<int64_t>(n);
 }
 
 int rvn_test_overlap_update_and_type(rvn_overlap* overlaps, uint64_t n, const uint32_t* pile_begin, const uint32_t* pile_end,

@@ -14,6 +14,7 @@
 
 #include "engine.h"
 #include "introsort.h"
+#include "slopes.h"
 #include "wave.h"
 
 namespace rvn {
@@ -455,6 +456,77 @@ void piles_trim_and_median(Engine& e, PileState& ps, u32 coverage, u32* h_begin,
   if (h_median) RVN_HIP(hipMemcpyAsync(h_median, d_med, static_cast<size_t>(n) * 2, hipMemcpyDeviceToHost, s));
   if (h_invalid) RVN_HIP(hipMemcpyAsync(h_invalid, d_inv, static_cast<size_t>(n), hipMemcpyDeviceToHost, s));
   RVN_HIP(hipStreamSynchronize(s));
+}
+
+
+// ---- Pile::FindChimericRegions for every valid pile (construct.cc:139 inside TrimAndAnnotatePiles) ---------------------
+namespace {
+// one thread per pile: FindSlopes(1.82) + pit pairing + MergeRegions (slopes.h) on the coverage array where it is
+__global__ __launch_bounds__(64) void pile_chimeric_kernel(const u16* __restrict__ data, const u64* __restrict__ pile_off,
+                                                          const u8* __restrict__ invalid, u32 n,
+                                                          SlopeRegion* __restrict__ slopes, u16* __restrict__ tmp,
+                                                          u32* __restrict__ out_tmp, u32* __restrict__ count,
+                                                          u32* __restrict__ n_overflow) {
+  const u32 p = blockIdx.x * 64 + threadIdx.x;
+  if (p >= n) return;
+  u32 c = 0;
+  if (!invalid[p]) {
+    const u64 off = pile_off[p];
+    const u32 len = static_cast<u32>(pile_off[p + 1] - off);
+    bool overflow = false;
+    c = find_chimeric_regions(data + off, static_cast<int>(len), slopes + off, len, tmp + off, out_tmp + off, len / 2, &overflow);
+    if (overflow) {
+      atomicAdd(n_overflow, 1u);
+      c = 0;
+    }
+  }
+  count[p] = c;
+}
+__global__ void chimeric_gather_kernel(const u32* __restrict__ out_tmp, const u64* __restrict__ pile_off,
+                                       const u32* __restrict__ count, const u32* __restrict__ roff, u32 n,
+                                       u32* __restrict__ regions) {
+  const u32 p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const u32 c = count[p];
+  const u32* src = out_tmp + pile_off[p];
+  u32* dst = regions + 2ULL * roff[p];
+  for (u32 i = 0; i < 2 * c; ++i) dst[i] = src[i];
+}
+}  // namespace
+
+// h_invalid: the piles' is_invalid flags (from piles_trim_and_median); h_off[n + 1] / regions: CSR of (begin, end) cell pairs
+void piles_find_chimeric_regions(Engine& e, PileState& ps, const u8* h_invalid, std::vector<u32>& h_off,
+                                 std::vector<u32>& h_regions) {
+  hipStream_t s = e.stream;
+  const u32 n = ps.n;
+  h_off.assign(static_cast<size_t>(n) + 1, 0);
+  h_regions.clear();
+  if (n == 0 || ps.pile_words == 0) return;
+  u8* d_inv = e.tmp_a.get<u8>(static_cast<size_t>(n) + 16);
+  RVN_HIP(hipMemcpyAsync(d_inv, h_invalid, n, hipMemcpyHostToDevice, s));
+  SlopeRegion* d_slopes = e.tmp_b.get<SlopeRegion>(ps.pile_words + 1);
+  u16* d_tmp = e.tmp_c.get<u16>(ps.pile_words + 1);
+  u32* d_out = e.tmp_d.get<u32>(ps.pile_words + 2);
+  u32* d_cnt = e.tmp_e.get<u32>(2 * static_cast<size_t>(n) + 8);
+  u32* d_roff = d_cnt + n + 1;
+  u32* d_ovf = e.tmp_f.get<u32>(4);
+  RVN_HIP(hipMemsetAsync(d_ovf, 0, 4, s));
+  RVN_KLAUNCH(kKPileTrim, pile_chimeric_kernel<<<div_up(n, 64), 64, 0, s>>>(ps.pile_data.as<u16>(), ps.pile_off.as<u64>(), d_inv, n,
+                                                                           d_slopes, d_tmp, d_out, d_cnt, d_ovf));
+  exclusive_scan_u32_u32(d_cnt, d_roff, n, e.scan_tmp, s);
+  RVN_HIP(hipMemcpyAsync(h_off.data(), d_roff, (static_cast<size_t>(n) + 1) * 4, hipMemcpyDeviceToHost, s));
+  if (read_back(e, d_ovf, 4) != 0)
+    throw HipError("[raven_hip] FindChimericRegions: a pile produced more slope regions than cells (internal error)");
+  RVN_HIP(hipStreamSynchronize(s));
+  const u32 total = h_off[n];
+  h_regions.assign(2ULL * total, 0);
+  if (total) {
+    u32* d_regions = e.sort_tmp.get<u32>(2ULL * total + 2);
+    chimeric_gather_kernel<<<div_up(n, 256), 256, 0, s>>>(d_out, ps.pile_off.as<u64>(), d_cnt, d_roff, n, d_regions);
+    RVN_LAUNCH_CHECK();
+    RVN_HIP(hipMemcpyAsync(h_regions.data(), d_regions, 2ULL * total * 4, hipMemcpyDeviceToHost, s));
+    RVN_HIP(hipStreamSynchronize(s));
+  }
 }
 
 }  // namespace rvn

@@ -46,7 +46,7 @@ SYMBOLS = [
     "rvn_engine_num_kernel_sites", "rvn_engine_kernel_site_name", "rvn_engine_kernel_ms", "rvn_test_hash", "rvn_test_canonical",
     "rvn_test_std_sort_lendesc", "rvn_test_heap_sort_lendesc", "rvn_engine_map_collect", "rvn_free",
     "rvn_find_overlaps_and_repetitive_regions", "rvn_pass2_num_overlaps", "rvn_pass2_kmer_cells", "rvn_pass2_fetch",
-    "rvn_pass2_destroy", "rvn_engine_release_scratch", "rvn_filter_overlaps_by_identity", "rvn_test_overlap_update_and_type",
+    "rvn_pass2_destroy", "rvn_engine_release_scratch", "rvn_filter_overlaps_by_identity", "rvn_test_overlap_update_and_type", "rvn_pass1_find_chimeric_regions", "rvn_test_find_chimeric_regions",
 ]
 
 
@@ -109,6 +109,9 @@ def lib():
     L.rvn_pass2_destroy.argtypes = [vp]
     L.rvn_engine_release_scratch.argtypes = [vp]
     L.rvn_filter_overlaps_by_identity.argtypes = [vp, vp, vp, vp, vp, vp, vp, dbl]
+    L.rvn_pass1_find_chimeric_regions.argtypes = [vp, vp, vp, pp]
+    L.rvn_test_find_chimeric_regions.argtypes = [vp, u32, vp, u64]
+    L.rvn_test_find_chimeric_regions.restype = C.c_int64
     L.rvn_test_overlap_update_and_type.argtypes = [vp, u64, vp, vp, vp, u32, vp, vp]
     L.rvn_poa_work.argtypes = [vp, vp]
     L.rvn_poa_work.restype = None
@@ -280,6 +283,21 @@ class Pass1:
         inv = np.zeros(self.n, dtype=np.uint8)
         _check(L.rvn_pass1_trim_and_annotate(self._h, int(coverage), _p(b), _p(e), _p(m), _p(inv)))
         return b, e, m, inv.astype(bool)
+
+    def find_chimeric_regions(self, invalid):
+        """Pile::FindChimericRegions of every valid pile (after trim_and_annotate): list of (k, 2) uint32 arrays of
+        (begin, end) cells, one per pile."""
+        inv = np.ascontiguousarray(invalid, dtype=np.uint8)
+        off = np.zeros(self.n + 1, dtype=np.uint32)
+        ptr = C.c_void_p()
+        _check(lib().rvn_pass1_find_chimeric_regions(self._h, _p(inv), _p(off), C.byref(ptr)))
+        total = int(off[-1])
+        try:
+            flat = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint32)), shape=(max(2 * total, 1),))[:2 * total].copy()
+        finally:
+            lib().rvn_free(ptr)
+        flat = flat.reshape(-1, 2)
+        return [flat[int(off[i]):int(off[i + 1])] for i in range(self.n)]
 
     def overlaps(self):
         L = lib()
@@ -733,6 +751,16 @@ class Engine:
 
     def set_timing(self, enabled: bool):
         lib().rvn_engine_set_timing(self._h, int(enabled))
+
+
+def test_find_chimeric_regions(data):
+    """slopes.h on the host: Pile::FindChimericRegions of one coverage array -> (k, 2) uint32 (begin, end) cells."""
+    d = np.ascontiguousarray(data, dtype=np.uint16)
+    out = np.zeros(max(2, d.shape[0]), dtype=np.uint32)
+    n = lib().rvn_test_find_chimeric_regions(_p(d), d.shape[0], _p(out), out.shape[0] // 2)
+    if n < 0:
+        raise ValueError("rvn_test_find_chimeric_regions: %d" % n)
+    return out[:2 * n].reshape(-1, 2).copy()
 
 
 def test_overlap_update_and_type(overlaps, pile_begin, pile_end, pile_invalid):

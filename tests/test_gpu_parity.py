@@ -295,3 +295,32 @@ def test_pile_trim_and_median_on_device_matches_oracle():
     ok = ~inv
     assert np.array_equal(b2[ok], b[ok]) and np.array_equal(e2[ok], e[ok]) and np.array_equal(m2[ok], m[ok])
     p.close()
+
+
+def test_find_chimeric_regions_on_device_matches_oracle():
+    """SURVEY 8(f) rank 1, third step of TrimAndAnnotatePiles: Pile::FindChimericRegions (FindSlopes(1.82), pit pairing,
+    MergeRegions; pile.cc:176-187, :373-400, :403-600) on the trimmed coverage arrays in HBM vs the oracle's restatement,
+    on the piles of a real pass over reads that include chimeras (two distant genome segments joined)."""
+    g = synth.make_genome(200_000, seed=91)
+    rs, truth = synth.make_reads(g, 25, 8000, seed=92)
+    # make every 7th read chimeric: second half replaced by the first half of another read
+    from raven_amd import seqio
+    codes = [rs.codes(i) for i in range(rs.n)]
+    for i in range(0, rs.n - 1, 7):
+        codes[i] = np.concatenate([codes[i][:len(codes[i]) // 2], codes[(i + rs.n // 2) % rs.n][:4000]])
+    rs = seqio.pack_reads(codes)
+    eng = hip.Engine(15, 5)
+    p = eng.find_overlaps_and_create_piles(eng.upload(rs))
+    b, e, m, inv = p.trim_and_annotate(4)
+    data, off = p.piles()
+    got = p.find_chimeric_regions(inv)
+    n_regions = 0
+    for i in range(rs.n):
+        if inv[i]:
+            assert got[i].shape[0] == 0
+            continue
+        want = oracle.find_chimeric_regions(data[int(off[i]):int(off[i + 1])])
+        assert got[i].shape == want.shape and np.array_equal(got[i], want), i
+        n_regions += want.shape[0]
+    assert n_regions > 10  # the chimeric reads show coverage pits
+    p.close()
