@@ -63,6 +63,25 @@ int rvn_reads_upload(rvn_engine* e, const uint64_t* packed, uint64_t n_words, co
 int rvn_reads_upload_codes(rvn_engine* e, const uint8_t* codes, const uint64_t* offsets, const uint32_t* ids,
                            uint32_t n_reads, rvn_reads** out);
 void rvn_reads_destroy(rvn_reads* r);
+/* The input path: raven::CreateParser(path) + Parse(-1) (RavenLib/src/io.cc:7-41, RavenExe/src/main.cc:258-299) straight
+ * into HBM.  Format by extension exactly as io.cc (.fasta / .fa / .fastq / .fq, optionally .gz; anything else is
+ * RVN_EINVAL with the reference's message); a host thread inflates and parses into pinned staging buffers while the
+ * previous chunk is copied and 2-bit packed on the device (biosoup's coder table: IUPAC folded, any other character is
+ * RVN_EINVAL "not a nucleotide").  Read ids = 0 .. n-1 in file order.  FASTQ: biosoup's block qualities (integer mean of
+ * every 64-base block) are computed on the device and attached to the read set (as rvn_reads_attach_quality with
+ * block_shift 6 would).  rvn_reads_name: first word of the header of sequence i. */
+typedef struct rvn_load_stats {
+  uint64_t n_sequences, n_bases;
+  int has_quality;
+  double parse_s, device_s, total_s; /* producer thread (inflate + parse) | copy + packing on the device | whole call */
+} rvn_load_stats;
+int rvn_reads_load(rvn_engine* e, const char* path, rvn_reads** out, rvn_load_stats* stats);
+const char* rvn_reads_name(const rvn_reads* r, uint32_t i);
+int rvn_reads_info(const rvn_reads* r, uint32_t* n_reads, uint64_t* n_words, uint64_t* n_bases, uint64_t* n_quality_bytes,
+                   int* quality_shift);
+/* read-back of a device-resident read set (tests, callers that need the packed words on the host) */
+int rvn_reads_fetch(const rvn_reads* r, uint64_t* packed, uint64_t* word_offsets, uint32_t* lengths, uint8_t* quals,
+                    uint64_t* quality_offsets);
 /* Base qualities of an uploaded read set, kept in HBM beside the bases for every later polishing round
  * (biosoup::NucleicAcid::block_quality; raven::Polish computes its threshold from them, polish.cc:26-41).
  * quals: Phred+33 bytes, one per 2^block_shift bases of a read (block_shift 0: per base; 6: biosoup's block qualities

@@ -7,7 +7,7 @@ mkdir -p "$OUT" "$HERE/obj"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function"
 pids=()
-for f in scan radix_sort sketch index map pile edit_distance poa poa2 polish nwpath pass2 engine edlib_dropin; do
+for f in scan radix_sort sketch index map pile edit_distance poa poa2 polish nwpath pass2 io engine edlib_dropin; do
   src="$HERE/$f.hip"; obj="$HERE/obj/$f.o"
   if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ -n "$(find "$HERE" -maxdepth 1 -name '*.h' -newer "$obj" -print -quit)" ] || [ "$HERE/../../include/raven_hip.h" -nt "$obj" ]; then
     $HIPCC $FLAGS -c "$src" -o "$obj" &
@@ -15,5 +15,5 @@ for f in scan radix_sort sketch index map pile edit_distance poa poa2 polish nwp
   fi
 done
 for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/libraven_hip.so" "$HERE"/obj/*.o
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/libraven_hip.so" "$HERE"/obj/*.o -lz
 echo "built $OUT/libraven_hip.so"

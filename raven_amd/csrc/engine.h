@@ -196,6 +196,14 @@ struct StageTimer {
   }
 };
 
+// input path (io.hip)
+struct LoadStats {
+  u64 n_sequences = 0, n_bases = 0;
+  int has_quality = 0;
+  double parse_s = 0, device_s = 0, total_s = 0;  // producer thread wall | copy + packing on the device | whole call
+};
+void reads_load(Engine& e, const std::string& path, ReadsDev& R, std::vector<std::string>& names, LoadStats& st);
+
 // ---- stages (one translation unit each) -------------------------------------
 void reads_build_tiles(Engine& e, ReadsDev& r);
 // 2-bit packing of one-byte codes already in HBM: read i = codes[base_off[i] ..), words at word_off[i] (sketch.hip)

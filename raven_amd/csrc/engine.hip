@@ -23,6 +23,7 @@ struct rvn_engine {
 };
 struct rvn_reads {
   ReadsDev r;
+  std::vector<std::string> names;  // rvn_reads_load: the sequences' names
 };
 // The pile buffers (coverage, kept lists, merge scratch: a dozen allocations) are recycled through the engine:
 // destroying a pass hands them back, the next pass adopts them, so steady-state passes do not touch the allocator.
@@ -350,6 +351,58 @@ int rvn_reads_upload_codes(rvn_engine* h, const uint8_t* codes, const uint64_t* 
     }
     reads_build_tiles(e, r);
     *out = rr.release();
+    return RVN_OK;
+  });
+}
+
+int rvn_reads_load(rvn_engine* h, const char* path, rvn_reads** out, rvn_load_stats* stats) {
+  return guarded(h ? &h->e : nullptr, [&]() -> int {
+    if (!h || !path || !out) return fail(RVN_EINVAL, "[raven_hip] rvn_reads_load: NULL argument");
+    *out = nullptr;
+    RVN_HIP(hipSetDevice(h->e.device));
+    std::unique_ptr<rvn_reads> rr(new rvn_reads());
+    LoadStats st;
+    reads_load(h->e, path, rr->r, rr->names, st);
+    if (stats) {
+      stats->n_sequences = st.n_sequences;
+      stats->n_bases = st.n_bases;
+      stats->has_quality = st.has_quality;
+      stats->parse_s = st.parse_s;
+      stats->device_s = st.device_s;
+      stats->total_s = st.total_s;
+    }
+    *out = rr.release();
+    return RVN_OK;
+  });
+}
+
+const char* rvn_reads_name(const rvn_reads* r, uint32_t i) {
+  return (r && i < r->names.size()) ? r->names[i].c_str() : "";
+}
+
+int rvn_reads_info(const rvn_reads* r, uint32_t* n_reads, uint64_t* n_words, uint64_t* n_bases, uint64_t* n_quality_bytes,
+                   int* quality_shift) {
+  if (!r) return fail(RVN_EINVAL, "[raven_hip] NULL read set");
+  if (n_reads) *n_reads = r->r.n;
+  if (n_words) *n_words = r->r.n_words;
+  if (n_bases) *n_bases = r->r.total_bases;
+  if (n_quality_bytes) *n_quality_bytes = r->r.qual_shift >= 0 && !r->r.h_qual_off.empty() ? r->r.h_qual_off.back() : 0;
+  if (quality_shift) *quality_shift = r->r.qual_shift;
+  return RVN_OK;
+}
+
+int rvn_reads_fetch(const rvn_reads* r, uint64_t* packed, uint64_t* word_offsets, uint32_t* lengths, uint8_t* quals,
+                    uint64_t* quality_offsets) {
+  return guarded([&]() -> int {
+    if (!r) return fail(RVN_EINVAL, "[raven_hip] NULL read set");
+    const ReadsDev& rd = r->r;
+    if (packed && rd.n_words) RVN_HIP(hipMemcpy(packed, rd.packed.ptr, rd.n_words * 8, hipMemcpyDeviceToHost));
+    if (word_offsets) std::memcpy(word_offsets, rd.h_word_off.data(), rd.h_word_off.size() * 8);
+    if (lengths && rd.n) std::memcpy(lengths, rd.h_len.data(), static_cast<size_t>(rd.n) * 4);
+    if (rd.qual_shift >= 0 && !rd.h_qual_off.empty()) {
+      if (quals && rd.h_qual_off.back()) RVN_HIP(hipMemcpy(quals, rd.quals.ptr, rd.h_qual_off.back(), hipMemcpyDeviceToHost));
+      if (quality_offsets) std::memcpy(quality_offsets, rd.h_qual_off.data(), rd.h_qual_off.size() * 8);
+    }
     return RVN_OK;
   });
 }

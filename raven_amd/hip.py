@@ -47,6 +47,7 @@ SYMBOLS = [
     "rvn_test_std_sort_lendesc", "rvn_test_heap_sort_lendesc", "rvn_engine_map_collect", "rvn_free",
     "rvn_find_overlaps_and_repetitive_regions", "rvn_pass2_num_overlaps", "rvn_pass2_kmer_cells", "rvn_pass2_fetch",
     "rvn_pass2_destroy", "rvn_engine_release_scratch", "rvn_filter_overlaps_by_identity", "rvn_test_overlap_update_and_type", "rvn_pass1_find_chimeric_regions", "rvn_test_find_chimeric_regions",
+    "rvn_reads_load", "rvn_reads_name", "rvn_reads_info", "rvn_reads_fetch",
 ]
 
 
@@ -109,6 +110,11 @@ def lib():
     L.rvn_pass2_destroy.argtypes = [vp]
     L.rvn_engine_release_scratch.argtypes = [vp]
     L.rvn_filter_overlaps_by_identity.argtypes = [vp, vp, vp, vp, vp, vp, vp, dbl]
+    L.rvn_reads_load.argtypes = [vp, C.c_char_p, pp, vp]
+    L.rvn_reads_name.argtypes = [vp, u32]
+    L.rvn_reads_name.restype = C.c_char_p
+    L.rvn_reads_info.argtypes = [vp, vp, vp, vp, vp, vp]
+    L.rvn_reads_fetch.argtypes = [vp, vp, vp, vp, vp, vp]
     L.rvn_pass1_find_chimeric_regions.argtypes = [vp, vp, vp, pp]
     L.rvn_test_find_chimeric_regions.argtypes = [vp, u32, vp, u64]
     L.rvn_test_find_chimeric_regions.restype = C.c_int64
@@ -230,6 +236,19 @@ class Reads:
     def n(self):
         return self.rs.n
 
+    def fetch(self):
+        """Device-resident read set back on the host: (packed words, word offsets, lengths, quality bytes or None,
+        quality offsets or None, quality shift)."""
+        n, nw, nb, nq, sh = C.c_uint32(0), C.c_uint64(0), C.c_uint64(0), C.c_uint64(0), C.c_int(0)
+        _check(lib().rvn_reads_info(self._h, C.byref(n), C.byref(nw), C.byref(nb), C.byref(nq), C.byref(sh)))
+        packed = np.zeros(nw.value, dtype=np.uint64)
+        woff = np.zeros(n.value + 1, dtype=np.uint64)
+        lens = np.zeros(n.value, dtype=np.uint32)
+        q = np.zeros(nq.value, dtype=np.uint8) if sh.value >= 0 else None
+        qoff = np.zeros(n.value + 1, dtype=np.uint64) if sh.value >= 0 else None
+        _check(lib().rvn_reads_fetch(self._h, _p(packed), _p(woff), _p(lens), _p(q), _p(qoff)))
+        return packed, woff, lens, q, qoff, sh.value
+
     def attach_quality(self, quals, block_shift=0):
         """Keep the reads' qualities in HBM for the polishing rounds: `quals` = list of per-read uint8 arrays of
         Phred+33 bytes, one per 2^block_shift bases (0: per base; 6: biosoup block qualities + 33)."""
@@ -341,6 +360,25 @@ class Engine:
 
     def upload(self, rs) -> Reads:
         return Reads(self, rs)
+
+    def load(self, path) -> Reads:
+        """raven::CreateParser(path) + Parse(-1) straight into HBM (rvn_reads_load): gz FASTA / FASTQ parsed on a host
+        thread, packed on the device.  The returned handle's .rs holds lengths / ids / names and .load_stats."""
+        h = C.c_void_p()
+        st = np.zeros(6, dtype=np.uint64)
+        _check(lib().rvn_reads_load(self._h, str(path).encode(), C.byref(h), _p(st)))
+        n = C.c_uint32(0)
+        lib().rvn_reads_info(h, C.byref(n), None, None, None, None)
+        lengths = np.zeros(n.value, dtype=np.uint32)
+        lib().rvn_reads_fetch(h, None, None, _p(lengths), None, None)
+        rs = CodeSet(lengths)
+        rs.names = [lib().rvn_reads_name(h, i).decode() for i in range(n.value)]
+        r = Reads.__new__(Reads)
+        r.rs, r.engine, r._h = rs, self, h
+        r.load_stats = {"n_sequences": int(st[0]), "n_bases": int(st[1]), "has_quality": int(st[2] & 0xFFFFFFFF),
+                        "parse_s": float(st[3:4].view(np.float64)[0]), "device_s": float(st[4:5].view(np.float64)[0]),
+                        "total_s": float(st[5:6].view(np.float64)[0])}
+        return r
 
     def upload_codes(self, code_arrays) -> Reads:
         """Read set from one-byte code arrays (values 0..3), packed on the device (rvn_reads_upload_codes): how the

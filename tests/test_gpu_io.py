@@ -1,0 +1,96 @@
+"""The input path (rvn_reads_load: gz FASTA / FASTQ -> host parser thread -> pinned staging -> 2-bit packing and block
+qualities on the device; RavenLib/src/io.cc:7-41 + biosoup::NucleicAcid) against the Python restatement of the same
+rules (raven_amd/seqio.py) on the reference's own data files and on synthetic multi-chunk files."""
+import gzip
+import os
+
+import numpy as np
+import pytest
+
+from raven_amd import hip, seqio, synth
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _same_reads(rd, rs):
+    packed, woff, lens, q, qoff, shift = rd.fetch()
+    assert np.array_equal(lens, rs.lengths) and np.array_equal(woff, rs.word_offsets)
+    assert np.array_equal(packed, rs.packed[: int(rs.word_offsets[-1])])
+    return q, qoff, shift
+
+
+def test_lambda_fastq_gz_matches_python_loader():
+    path = os.path.join(GOLDEN, "ERA476754.fastq.gz")
+    rs = seqio.load_reads(path)
+    eng = hip.Engine(15, 5)
+    rd = eng.load(path)
+    assert rd.n == rs.n == 236 and rd.rs.names == rs.names and rd.load_stats["has_quality"] == 1
+    assert rd.load_stats["n_bases"] == rs.total_bases
+    q, qoff, shift = _same_reads(rd, rs)
+    assert shift == 6
+    for i in range(rs.n):  # biosoup block_quality: integer mean of every 64-base block (+33 as stored)
+        ph = np.asarray(rs.qualities[i], dtype=np.int64)
+        nb = (ph.shape[0] + 63) // 64
+        want = np.array([int(ph[b * 64:(b + 1) * 64].sum()) // len(ph[b * 64:(b + 1) * 64]) for b in range(nb)], np.int64) + 33
+        assert np.array_equal(q[int(qoff[i]):int(qoff[i + 1])].astype(np.int64), want), i
+    # the loaded set is a working read set: the first pass gives what the uploaded one gives
+    a = eng.find_overlaps_and_create_piles(rd)
+    b = eng.find_overlaps_and_create_piles(eng.upload(rs))
+    assert np.array_equal(a.overlaps()[0], b.overlaps()[0]) and np.array_equal(a.piles()[0], b.piles()[0])
+
+
+def test_lambda_fasta_gz_multi_line_records():
+    path = os.path.join(GOLDEN, "NC_001416.fasta.gz")
+    rs = seqio.load_reads(path)
+    eng = hip.Engine(15, 5)
+    rd = eng.load(path)
+    assert rd.n == 1 and rd.rs.names == rs.names and rd.load_stats["has_quality"] == 0
+    _, _, shift = _same_reads(rd, rs)
+    assert shift == -1
+
+
+def test_multi_chunk_plain_fasta_and_iupac(tmp_path):
+    g = synth.make_genome(400_000, seed=3)
+    rs, _ = synth.make_reads(g, 190, 10000, seed=4)  # ~76 MB of bases: more than one 64 MB staging chunk
+    path = str(tmp_path / "reads.fa")
+    with open(path, "wb") as f:
+        for i in range(rs.n):
+            s = rs.inflate(i)
+            f.write(b">r%d some description\n" % i)
+            for x in range(0, len(s), 70000):  # wrapped lines
+                f.write(s[x:x + 70000] + b"\r\n")
+    eng = hip.Engine(15, 5)
+    rd = eng.load(path)
+    assert rd.n == rs.n and rd.rs.names == ["r%d" % i for i in range(rs.n)]
+    _same_reads(rd, rs)
+    # IUPAC codes fold to ACGT exactly as biosoup's coder table does
+    iupac = b"ACGTUacgtuNnRrYyKkMmSsWwBbDdHhVv-"
+    p2 = str(tmp_path / "iupac.fasta.gz")
+    with gzip.open(p2, "wb") as f:
+        f.write(b">x\n" + iupac + b"\n>empty\n\n>y\nAC\n")
+    rd2 = eng.load(p2)
+    want = seqio.pack_reads([seqio.encode(iupac), seqio.encode(b""), seqio.encode(b"AC")])
+    assert rd2.n == 3 and rd2.rs.names == ["x", "empty", "y"]
+    _same_reads(rd2, want)
+
+
+def test_errors_are_the_references(tmp_path):
+    eng = hip.Engine(15, 5)
+    with pytest.raises(ValueError, match="unsupported format extension"):
+        eng.load(str(tmp_path / "reads.txt"))
+    with pytest.raises(ValueError, match="unable to open"):
+        eng.load(str(tmp_path / "missing.fasta"))
+    bad = tmp_path / "bad.fa"
+    bad.write_bytes(b">a\nACGTXACGT\n")
+    with pytest.raises(ValueError, match="not a nucleotide"):
+        eng.load(str(bad))
+    trunc = tmp_path / "trunc.fastq"
+    trunc.write_bytes(b"@a\nACGTACGT\n+\nIIII\n")
+    with pytest.raises(ValueError, match="invalid file format"):
+        eng.load(str(trunc))
+    nofa = tmp_path / "nofa.fasta"
+    nofa.write_bytes(b"ACGT\n")
+    with pytest.raises(ValueError, match="invalid file format"):
+        eng.load(str(nofa))
