@@ -311,16 +311,23 @@ def test_find_chimeric_regions_on_device_matches_oracle():
     rs = seqio.pack_reads(codes)
     eng = hip.Engine(15, 5)
     p = eng.find_overlaps_and_create_piles(eng.upload(rs))
+
+    def check(inv):
+        data, off = p.piles()
+        got = p.find_chimeric_regions(inv)
+        n_regions = 0
+        for i in range(rs.n):
+            if inv[i]:
+                assert got[i].shape[0] == 0
+                continue
+            want = oracle.find_chimeric_regions(data[int(off[i]):int(off[i + 1])])
+            assert got[i].shape == want.shape and np.array_equal(got[i], want), i
+            n_regions += want.shape[0]
+        return n_regions
+
+    # on the raw coverage the junctions of the chimeric reads are pits down to ~0 ...
+    assert check(np.zeros(rs.n, dtype=bool)) > 10
+    # ... and in raven's order (FindValidRegion(4) first: the trim usually cuts a chimeric read at its junction)
     b, e, m, inv = p.trim_and_annotate(4)
-    data, off = p.piles()
-    got = p.find_chimeric_regions(inv)
-    n_regions = 0
-    for i in range(rs.n):
-        if inv[i]:
-            assert got[i].shape[0] == 0
-            continue
-        want = oracle.find_chimeric_regions(data[int(off[i]):int(off[i + 1])])
-        assert got[i].shape == want.shape and np.array_equal(got[i], want), i
-        n_regions += want.shape[0]
-    assert n_regions > 10  # the chimeric reads show coverage pits
+    check(inv)
     p.close()
