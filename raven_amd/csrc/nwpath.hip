@@ -29,7 +29,7 @@ __device__ __forceinline__ void nw_wsync() {
 
 // alignment slots (lane groups) of a launch of the wave kernel: waves per SIMD by register budget x groups per wave
 inline u32 path_slots(u32 R, u32 G) {
-  const u32 occ = R == 1 ? 3u : 2u;
+  const u32 occ = R == 1 ? 4u : 2u;
   return 256u * 4u * occ * (64u / G);
 }
 
@@ -51,7 +51,7 @@ __device__ __forceinline__ u32 group_max(u32 v) {
 }
 
 template <int R, int G>
-__global__ __launch_bounds__(256) void nw_path_kernel(const NwJob* __restrict__ jobs, const u32* __restrict__ idx,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(R == 1 ? 4 : 1))) void nw_path_kernel(const NwJob* __restrict__ jobs, const u32* __restrict__ idx,
                                                      u32 n_idx, const u64* __restrict__ t_words,
                                                      const u64* __restrict__ r_words, NwPm* __restrict__ ck_pm,
                                                      int* __restrict__ ck_sc, NwPm* __restrict__ seg_pm,

@@ -697,7 +697,7 @@ __device__ __forceinline__ u32 poa2_window(const PoaWindow& win, const PoaLayer*
 }
 
 template <int NCH, int WPB>
-__global__ __launch_bounds__(64 * WPB) void poa2_kernel(const PoaWindow* __restrict__ windows, u32 n_windows,
+__global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(NCH == 1 ? 4 : 1))) void poa2_kernel(const PoaWindow* __restrict__ windows, u32 n_windows,
                                                   const PoaLayer* __restrict__ layers, const PoaSrc src,
                                                   unsigned char* __restrict__ scratch,
                                                   size_t slot_bytes, u32 n_slots, u32 nmax, u32 lmax, int m, int n_,
