@@ -117,7 +117,7 @@ struct Engine {
   DevBuf q_start, q_cnt, m_off;
   DevBuf m_grp[2], m_pos[2];
   DevBuf seg_off, iv_slot_begin, iv_slot_end, iv_cnt, iv_off, iv_begin, iv_end;
-  DevBuf lis_min, lis_pred, lis_tail, lis_mask, ovl_slots, ovl_flags, ovl_scan;
+  DevBuf lis_min, lis_pred, lis_tail, lis_mask, ovl_slots, ovl_flags, ovl_scan, chain_big;
   DevBuf poa_scratch, poa2_scratch, polish_quals;
   DevBuf ed_cnt, ed_sort, ed_todo;
   // second pass / identity filters (pass2.hip)

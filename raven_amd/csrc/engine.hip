@@ -164,7 +164,7 @@ void engine_release_scratch(Engine& e) {
       &e.map_out.anchor_cnt, &e.tmp_a, &e.tmp_b, &e.tmp_c, &e.tmp_d, &e.tmp_e, &e.tmp_f, &e.scan_tmp, &e.sort_tmp,
       &e.q_start, &e.q_cnt, &e.m_off, &e.m_grp[0], &e.m_grp[1], &e.m_pos[0], &e.m_pos[1], &e.seg_off, &e.iv_slot_begin,
       &e.iv_slot_end, &e.iv_cnt, &e.iv_off, &e.iv_begin, &e.iv_end, &e.lis_min, &e.lis_pred, &e.lis_tail, &e.lis_mask,
-      &e.ovl_slots, &e.ovl_flags, &e.ovl_scan, &e.poa_scratch, &e.poa2_scratch, &e.polish_quals, &e.ed_cnt, &e.ed_sort, &e.ed_todo, &e.p2_slot,
+      &e.ovl_slots, &e.ovl_flags, &e.ovl_scan, &e.chain_big, &e.poa_scratch, &e.poa2_scratch, &e.polish_quals, &e.ed_cnt, &e.ed_sort, &e.ed_todo, &e.p2_slot,
       &e.p2_pairs, &e.p2_dist, &e.p2_regions, &e.p2_index_of, &e.p2_kmers_off, &e.p2_ok, &e.p2_keep, &e.p2_tmp_ovl,
       &e.poa_sched, &e.poa_redo_w, &e.poa_redo_i, &e.nw_pm, &e.nw_sc, &e.nw_ck_pm, &e.nw_ck_sc, &e.nw_jobs, &e.nw_res,
       &e.pl_best, &e.pl_best_t, &e.pl_idmap, &e.pl_recs, &e.pl_keep, &e.pl_win_cnt, &e.pl_win_off, &e.pl_win_fill,

@@ -590,7 +590,8 @@ __global__ __launch_bounds__(64) void chain_small_kernel(const u64* __restrict__
 // sequence ram would follow is then replayed on the mask with scalar ALU only.  Intervals of up to
 // kChainLdsCap matches run entirely out of LDS; larger ones use the same code on global scratch.
 constexpr u32 kChainLdsCap = 1024;
-constexpr u32 kChainPerWave = 16;
+constexpr u32 kChainPerWave = 1;   // one interval per wave: large intervals are few and long, they need the parallelism
+constexpr u32 kChainBigCap = 8192;  // intervals of up to this many matches run out of a whole workgroup's LDS (chain_big_kernel)
 constexpr u32 kChainLdsBytes = (kChainLdsCap + 1) * 8 + (kChainLdsCap + 2) * 2 + kChainLdsCap * 2 + 16 * 8;
 
 template <bool GLOBAL>
@@ -613,7 +614,17 @@ __device__ void chain_wave(const u64* __restrict__ p, u32 n, bool strand, u64 g0
       const u64 cur = __shfl(mine, static_cast<int>(t), 64);
       const u32 lhs = static_cast<u32>(cur >> 32), rhs = static_cast<u32>(cur);
       u32 lo = 1, hi = longest;
-      if (longest <= 64) {
+      if (!GLOBAL && longest > 192) {
+        // long chains: ram's binary search probes ~log2(longest) tails; evaluating ALL tails first (below) costs
+        // longest / 64 rounds per element.  Every lane replays the probes on the tails in LDS (broadcast reads).
+        while (lo <= hi) {
+          const u32 mid = lo + (hi - lo) / 2;
+          const u64 q = tail_pos[mid];
+          const u32 ql = static_cast<u32>(q >> 32), qr = static_cast<u32>(q);
+          if (ql < lhs && (strand ? qr < rhs : qr > rhs)) lo = mid + 1;
+          else hi = mid - 1;
+        }
+      } else if (longest <= 64) {
         bool ok = false;
         if (static_cast<u32>(lane) < longest) {
           const u64 q = tail_pos[lane + 1];
@@ -709,6 +720,7 @@ __global__ __launch_bounds__(256) void chain_kernel(const u64* __restrict__ grp,
     const bool strand = (g0 >> 32) & 1;
     const u32 lhs_id = ids[first + iv_read[t]];
     const u64 slot_base = (b + slot_div - 1) / slot_div;
+    if (n > kChainLdsCap && n <= kChainBigCap) continue;  // chain_big_kernel's
     if (n <= kChainLdsCap) {
       unsigned char* base = smem[wv];
       u64* tail_pos = reinterpret_cast<u64*>(base);
@@ -726,6 +738,42 @@ __global__ __launch_bounds__(256) void chain_kernel(const u64* __restrict__ grp,
     }
     __builtin_amdgcn_wave_barrier();
   }
+}
+
+// Intervals of kChainLdsCap < n <= kChainBigCap matches (a long read mapped to its unitig, HiFi overlaps): one wave per
+// workgroup with the tails of the whole interval in dynamic LDS, so that the probes of ram's binary search stay LDS reads.
+__global__ __launch_bounds__(64) void chain_big_kernel(const u64* __restrict__ grp, const u64* __restrict__ pos,
+                                                      const u64* __restrict__ iv_begin, const u64* __restrict__ iv_end,
+                                                      const u32* __restrict__ iv_read, const u32* __restrict__ big_idx,
+                                                      u32 n_big, const u32* __restrict__ ids, u32 first, u32 k, u32 chain,
+                                                      u32 min_matches, u32 gap, u32 slot_div, Overlap* __restrict__ slots,
+                                                      u8* __restrict__ slot_flags, u64* __restrict__ anchors,
+                                                      u64* __restrict__ slot_aoff, u32* __restrict__ slot_acnt) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char big_smem[];
+  if (blockIdx.x >= n_big) return;
+  const u32 t = big_idx[blockIdx.x];
+  const u64 b = iv_begin[t];
+  const u32 n = static_cast<u32>(iv_end[t] - b);
+  const u64 g0 = grp[b];
+  const bool strand = (g0 >> 32) & 1;
+  const u32 lhs_id = ids[first + iv_read[t]];
+  const u64 slot_base = (b + slot_div - 1) / slot_div;
+  u64* tail_pos = reinterpret_cast<u64*>(big_smem);
+  u64* maskbuf = tail_pos + (kChainBigCap + 1);
+  u16* tail_idx = reinterpret_cast<u16*>(maskbuf + (kChainBigCap / 64 + 2));
+  u16* pred = tail_idx + (kChainBigCap + 2);
+  chain_wave<u16, false>(pos + b, n, strand, g0, lhs_id, k, chain, min_matches, gap, tail_pos, tail_idx, pred, maskbuf,
+                         slots + slot_base, slot_flags + slot_base, anchors ? anchors + b : nullptr, b,
+                         slot_aoff ? slot_aoff + slot_base : nullptr, slot_acnt ? slot_acnt + slot_base : nullptr);
+}
+constexpr size_t kChainBigLds = (kChainBigCap + 1) * 8 + (kChainBigCap / 64 + 2) * 8 + (kChainBigCap + 2) * 2 + kChainBigCap * 2 + 64;
+
+__global__ void chain_big_list_kernel(const u64* __restrict__ iv_begin, const u64* __restrict__ iv_end, u32 n_iv,
+                                      u32* __restrict__ big_idx, u32* __restrict__ cnt) {
+  const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_iv) return;
+  const u64 n = iv_end[t] - iv_begin[t];
+  if (n > kChainLdsCap && n <= kChainBigCap) big_idx[atomicAdd(cnt, 1u)] = t;
 }
 
 __global__ void compact_overlaps_kernel(const Overlap* __restrict__ slots, const u8* __restrict__ flags,
@@ -832,6 +880,26 @@ void chain_matches(Engine& e, const ReadsDev& r, u32 first, u32 last, u64 H, Map
                                                                      e.gap, slot_div, lis_tail, lis_min, lis_pred,
                                                                      lis_mask, slots, slot_flags, anchors, slot_aoff,
                                                                      slot_acnt));
+    {  // mid-size intervals: whole-LDS kernel (order of the list does not matter: outputs go to per-interval slots)
+      u32* big_idx = e.chain_big.get<u32>(static_cast<size_t>(NI) + 2);
+      u32* d_cnt = big_idx + NI;
+      RVN_HIP(hipMemsetAsync(d_cnt, 0, 4, s));
+      chain_big_list_kernel<<<div_up(NI, 256), 256, 0, s>>>(iv_begin, iv_end, NI, big_idx, d_cnt);
+      RVN_LAUNCH_CHECK();
+      const u32 n_big = static_cast<u32>(read_back(e, d_cnt, 4));
+      if (n_big) {
+        static bool attr_set = false;
+        if (!attr_set) {
+          RVN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_big_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      static_cast<int>(kChainBigLds)));
+          attr_set = true;
+        }
+        RVN_KLAUNCH(kKChain, chain_big_kernel<<<n_big, 64, kChainBigLds, s>>>(g0, p0, iv_begin, iv_end, iv_read, big_idx, n_big,
+                                                                            r.id.as<u32>(), first, e.k, e.chain, e.matches,
+                                                                            e.gap, slot_div, slots, slot_flags, anchors,
+                                                                            slot_aoff, slot_acnt));
+      }
+    }
     t.stop();
   }
   {
