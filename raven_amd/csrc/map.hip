@@ -13,6 +13,8 @@
 //                              covered-bases score
 #include <algorithm>
 
+#include <cstring>
+
 #include "engine.h"
 #include "wave.h"
 
@@ -588,11 +590,8 @@ __global__ __launch_bounds__(64) void chain_small_kernel(const u64* __restrict__
 // needs the predicate "tail[len] precedes cur" at the probed lengths: all 64 lanes evaluate the predicate
 // for 64 lengths at once (tails live in LDS), a ballot turns it into a bit mask and the *same* probe
 // sequence ram would follow is then replayed on the mask with scalar ALU only.  Intervals of up to
-// kChainLdsCap matches run entirely out of LDS; larger ones use the same code on global scratch.
-constexpr u32 kChainLdsCap = 1024;
-constexpr u32 kChainPerWave = 1;   // one interval per wave: large intervals are few and long, they need the parallelism
+// kChainBigCap matches run entirely out of LDS; larger ones use the same code on global scratch.
 constexpr u32 kChainBigCap = 8192;  // intervals of up to this many matches run out of a whole workgroup's LDS (chain_big_kernel)
-constexpr u32 kChainLdsBytes = (kChainLdsCap + 1) * 8 + (kChainLdsCap + 2) * 2 + kChainLdsCap * 2 + 16 * 8;
 
 template <bool GLOBAL>
 __device__ __forceinline__ void chain_sync() {
@@ -614,15 +613,41 @@ __device__ void chain_wave(const u64* __restrict__ p, u32 n, bool strand, u64 g0
       const u64 cur = __shfl(mine, static_cast<int>(t), 64);
       const u32 lhs = static_cast<u32>(cur >> 32), rhs = static_cast<u32>(cur);
       u32 lo = 1, hi = longest;
-      if (!GLOBAL && longest > 192) {
-        // long chains: ram's binary search probes ~log2(longest) tails; evaluating ALL tails first (below) costs
-        // longest / 64 rounds per element.  Every lane replays the probes on the tails in LDS (broadcast reads).
+      if (longest > 512) {
+        // Long chains: ram's binary search probes ~log2(longest) tails, one after the other.  Here six levels of its
+        // search tree are evaluated at once: lane h (heap index 1..63) derives the (lo, hi) range ram would have at tree
+        // node h from the current range, tests the predicate at that node's midpoint, a ballot collects the 63 answers
+        // and the walk down the six levels is scalar bit tests — ram's exact probe sequence (the predicate need not be
+        // monotone), two round trips to the tails for chains of up to 4096 instead of twelve dependent reads.
         while (lo <= hi) {
-          const u32 mid = lo + (hi - lo) / 2;
-          const u64 q = tail_pos[mid];
-          const u32 ql = static_cast<u32>(q >> 32), qr = static_cast<u32>(q);
-          if (ql < lhs && (strand ? qr < rhs : qr > rhs)) lo = mid + 1;
-          else hi = mid - 1;
+          const u32 h = static_cast<u32>(lane);
+          u32 l = lo, r = hi;
+          bool valid = h >= 1;
+          if (valid) {
+            const int depth = 31 - __clz(static_cast<int>(h));
+            for (int d = depth - 1; d >= 0; --d) {
+              if (l > r) break;
+              const u32 mid = l + (r - l) / 2;
+              if ((h >> d) & 1u) l = mid + 1;
+              else r = mid - 1;
+            }
+            valid = l <= r;
+          }
+          bool ok = false;
+          if (valid) {
+            const u64 q = tail_pos[l + (r - l) / 2];
+            const u32 ql = static_cast<u32>(q >> 32), qr = static_cast<u32>(q);
+            ok = ql < lhs && (strand ? qr < rhs : qr > rhs);
+          }
+          const unsigned long long m = __ballot(ok);
+          u32 node = 1;
+          for (int level = 0; level < 6 && lo <= hi; ++level) {
+            const u32 mid = lo + (hi - lo) / 2;
+            const u32 bit = static_cast<u32>((m >> node) & 1ULL);
+            if (bit) lo = mid + 1;
+            else hi = mid - 1;
+            node = 2 * node + bit;
+          }
         }
       } else if (longest <= 64) {
         bool ok = false;
@@ -688,92 +713,75 @@ __device__ void chain_wave(const u64* __restrict__ p, u32 n, bool strand, u64 g0
              slot_flags, lane == 0, anchors, anchor_base, slot_aoff, slot_acnt);
 }
 
-__global__ __launch_bounds__(256) void chain_kernel(const u64* __restrict__ grp, const u64* __restrict__ pos,
-                                                   const u64* __restrict__ iv_begin,
-                                                   const u64* __restrict__ iv_end, const u32* __restrict__ iv_read,
-                                                   u32 n_iv, const u32* __restrict__ ids, u32 first, u32 k,
-                                                   u32 chain, u32 min_matches, u32 gap, u32 slot_div,
-                                                   u64* __restrict__ g_tail_pos, u32* __restrict__ g_tail_idx,
-                                                   u32* __restrict__ g_pred, u64* __restrict__ g_mask,
-                                                   Overlap* __restrict__ slots, u8* __restrict__ slot_flags,
-                                                   u64* __restrict__ anchors, u64* __restrict__ slot_aoff,
-                                                   u32* __restrict__ slot_acnt) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[4][(kChainLdsBytes + 15) & ~15u];
-  const int wv = threadIdx.x >> 6;
-  // each wave owns kChainPerWave consecutive intervals and processes the large ones (n > kChainSmallCap)
-  const u32 t0 = (blockIdx.x * 4 + wv) * kChainPerWave;
-  if (t0 >= n_iv) return;
-  const int lane = lane_id();
-  u64 my_b = 0, my_n = 0;
-  if (lane < static_cast<int>(kChainPerWave) && t0 + lane < n_iv) {
-    my_b = iv_begin[t0 + lane];
-    my_n = iv_end[t0 + lane] - my_b;
-  }
-  unsigned long long todo = __ballot(my_n > kChainSmallCap && my_n >= chain);
-  while (todo) {
-    const int l = __ffsll(static_cast<long long>(todo)) - 1;
-    todo &= todo - 1;
-    const u32 t = t0 + l;
-    const u64 b = __shfl(my_b, l, 64);
-    const u32 n = static_cast<u32>(__shfl(my_n, l, 64));
-    const u64 g0 = grp[b];
-    const bool strand = (g0 >> 32) & 1;
-    const u32 lhs_id = ids[first + iv_read[t]];
-    const u64 slot_base = (b + slot_div - 1) / slot_div;
-    if (n > kChainLdsCap && n <= kChainBigCap) continue;  // chain_big_kernel's
-    if (n <= kChainLdsCap) {
-      unsigned char* base = smem[wv];
-      u64* tail_pos = reinterpret_cast<u64*>(base);
-      u64* maskbuf = tail_pos + (kChainLdsCap + 1);
-      u16* tail_idx = reinterpret_cast<u16*>(maskbuf + 16);
-      u16* pred = tail_idx + (kChainLdsCap + 2);
-      chain_wave<u16, false>(pos + b, n, strand, g0, lhs_id, k, chain, min_matches, gap, tail_pos, tail_idx, pred,
-                             maskbuf, slots + slot_base, slot_flags + slot_base, anchors ? anchors + b : nullptr, b,
-                             slot_aoff ? slot_aoff + slot_base : nullptr, slot_acnt ? slot_acnt + slot_base : nullptr);
-    } else {
-      chain_wave<u32, true>(pos + b, n, strand, g0, lhs_id, k, chain, min_matches, gap, g_tail_pos + b + t,
-                            g_tail_idx + b + t, g_pred + b, g_mask + (b >> 6) + t, slots + slot_base,
-                            slot_flags + slot_base, anchors ? anchors + b : nullptr, b,
-                            slot_aoff ? slot_aoff + slot_base : nullptr, slot_acnt ? slot_acnt + slot_base : nullptr);
-    }
-    __builtin_amdgcn_wave_barrier();
-  }
+// Size classes of the chain stage.  Every interval of more than kChainSmallCap matches is handled by ONE wave = one
+// workgroup whose dynamic LDS is sized for the class (tails, tail indices, predecessors of the whole interval), so the
+// number of resident waves per CU follows the interval size (3 KB for <= 256 matches ... 99 KB for <= 8192) and no wave
+// waits for a sibling's longer interval.  Larger intervals run the same code on global scratch (class kChainClasses).
+constexpr int kChainClasses = 5;
+__constant__ u32 kChainClassCap[kChainClasses] = {256, 1024, 2048, 4096, kChainBigCap};
+static const u32 kChainClassCapHost[kChainClasses] = {256, 1024, 2048, 4096, kChainBigCap};
+inline size_t chain_class_lds(u32 cap) {
+  return static_cast<size_t>(cap + 1) * 8 + (cap / 64 + 2) * 8 + static_cast<size_t>(cap + 2) * 2 + static_cast<size_t>(cap) * 2 + 64;
 }
 
-// Intervals of kChainLdsCap < n <= kChainBigCap matches (a long read mapped to its unitig, HiFi overlaps): one wave per
-// workgroup with the tails of the whole interval in dynamic LDS, so that the probes of ram's binary search stay LDS reads.
-__global__ __launch_bounds__(64) void chain_big_kernel(const u64* __restrict__ grp, const u64* __restrict__ pos,
-                                                      const u64* __restrict__ iv_begin, const u64* __restrict__ iv_end,
-                                                      const u32* __restrict__ iv_read, const u32* __restrict__ big_idx,
-                                                      u32 n_big, const u32* __restrict__ ids, u32 first, u32 k, u32 chain,
-                                                      u32 min_matches, u32 gap, u32 slot_div, Overlap* __restrict__ slots,
-                                                      u8* __restrict__ slot_flags, u64* __restrict__ anchors,
-                                                      u64* __restrict__ slot_aoff, u32* __restrict__ slot_acnt) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char big_smem[];
-  if (blockIdx.x >= n_big) return;
-  const u32 t = big_idx[blockIdx.x];
+__global__ __launch_bounds__(64) void chain_kernel(const u64* __restrict__ grp, const u64* __restrict__ pos,
+                                                  const u64* __restrict__ iv_begin, const u64* __restrict__ iv_end,
+                                                  const u32* __restrict__ iv_read, const u32* __restrict__ list,
+                                                  u32 n_list, u32 cap, const u32* __restrict__ ids, u32 first, u32 k,
+                                                  u32 chain, u32 min_matches, u32 gap, u32 slot_div,
+                                                  u64* __restrict__ g_tail_pos, u32* __restrict__ g_tail_idx,
+                                                  u32* __restrict__ g_pred, u64* __restrict__ g_mask,
+                                                  Overlap* __restrict__ slots, u8* __restrict__ slot_flags,
+                                                  u64* __restrict__ anchors, u64* __restrict__ slot_aoff,
+                                                  u32* __restrict__ slot_acnt) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char chain_smem[];
+  if (blockIdx.x >= n_list) return;
+  const u32 t = list[blockIdx.x];
   const u64 b = iv_begin[t];
   const u32 n = static_cast<u32>(iv_end[t] - b);
   const u64 g0 = grp[b];
   const bool strand = (g0 >> 32) & 1;
   const u32 lhs_id = ids[first + iv_read[t]];
   const u64 slot_base = (b + slot_div - 1) / slot_div;
-  u64* tail_pos = reinterpret_cast<u64*>(big_smem);
-  u64* maskbuf = tail_pos + (kChainBigCap + 1);
-  u16* tail_idx = reinterpret_cast<u16*>(maskbuf + (kChainBigCap / 64 + 2));
-  u16* pred = tail_idx + (kChainBigCap + 2);
-  chain_wave<u16, false>(pos + b, n, strand, g0, lhs_id, k, chain, min_matches, gap, tail_pos, tail_idx, pred, maskbuf,
-                         slots + slot_base, slot_flags + slot_base, anchors ? anchors + b : nullptr, b,
-                         slot_aoff ? slot_aoff + slot_base : nullptr, slot_acnt ? slot_acnt + slot_base : nullptr);
+  if (cap) {
+    u64* tail_pos = reinterpret_cast<u64*>(chain_smem);
+    u64* maskbuf = tail_pos + (cap + 1);
+    u16* tail_idx = reinterpret_cast<u16*>(maskbuf + (cap / 64 + 2));
+    u16* pred = tail_idx + (cap + 2);
+    chain_wave<u16, false>(pos + b, n, strand, g0, lhs_id, k, chain, min_matches, gap, tail_pos, tail_idx, pred, maskbuf,
+                           slots + slot_base, slot_flags + slot_base, anchors ? anchors + b : nullptr, b,
+                           slot_aoff ? slot_aoff + slot_base : nullptr, slot_acnt ? slot_acnt + slot_base : nullptr);
+  } else {
+    chain_wave<u32, true>(pos + b, n, strand, g0, lhs_id, k, chain, min_matches, gap, g_tail_pos + b + t,
+                          g_tail_idx + b + t, g_pred + b, g_mask + (b >> 6) + t, slots + slot_base,
+                          slot_flags + slot_base, anchors ? anchors + b : nullptr, b,
+                          slot_aoff ? slot_aoff + slot_base : nullptr, slot_acnt ? slot_acnt + slot_base : nullptr);
+  }
 }
-constexpr size_t kChainBigLds = (kChainBigCap + 1) * 8 + (kChainBigCap / 64 + 2) * 8 + (kChainBigCap + 2) * 2 + kChainBigCap * 2 + 64;
 
-__global__ void chain_big_list_kernel(const u64* __restrict__ iv_begin, const u64* __restrict__ iv_end, u32 n_iv,
-                                      u32* __restrict__ big_idx, u32* __restrict__ cnt) {
+// lists[c * n_iv ...] <- intervals of class c (order within a list is irrelevant: results go to per-interval slots)
+__global__ __launch_bounds__(256) void chain_class_list_kernel(const u64* __restrict__ iv_begin,
+                                                              const u64* __restrict__ iv_end, u32 n_iv, u32 chain,
+                                                              u32* __restrict__ lists, u32* __restrict__ cnt) {
   const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= n_iv) return;
-  const u64 n = iv_end[t] - iv_begin[t];
-  if (n > kChainLdsCap && n <= kChainBigCap) big_idx[atomicAdd(cnt, 1u)] = t;
+  int cls = -1;
+  if (t < n_iv) {
+    const u64 n = iv_end[t] - iv_begin[t];
+    if (n > kChainSmallCap && n >= chain) {
+      cls = kChainClasses;
+      for (int c = kChainClasses - 1; c >= 0; --c)
+        if (n <= kChainClassCap[c]) cls = c;
+    }
+  }
+  const int lane = lane_id();
+  for (int c = 0; c <= kChainClasses; ++c) {
+    const unsigned long long m = __ballot(cls == c);
+    if (!m) continue;
+    u32 base = 0;
+    if (lane == 0) base = atomicAdd(cnt + c, static_cast<u32>(__popcll(m)));
+    base = __shfl(base, 0, 64);
+    if (cls == c) lists[static_cast<size_t>(c) * n_iv + base + __popcll(m & ((1ULL << lane) - 1ULL))] = t;
+  }
 }
 
 __global__ void compact_overlaps_kernel(const Overlap* __restrict__ slots, const u8* __restrict__ flags,
@@ -875,29 +883,31 @@ void chain_matches(Engine& e, const ReadsDev& r, u32 first, u32 last, u64 H, Map
     RVN_KLAUNCH(kKChainSmall, chain_small_kernel<<<div_up(NI, 64), 64, 0, s>>>(
                                   g0, p0, iv_begin, iv_end, iv_read, NI, r.id.as<u32>(), first, e.k, e.chain, e.matches,
                                   e.gap, slot_div, slots, slot_flags, anchors, slot_aoff, slot_acnt));
-    RVN_KLAUNCH(kKChain, chain_kernel<<<div_up(NI, 4 * kChainPerWave), 256, 0, s>>>(g0, p0, iv_begin, iv_end, iv_read, NI,
-                                                                     r.id.as<u32>(), first, e.k, e.chain, e.matches,
-                                                                     e.gap, slot_div, lis_tail, lis_min, lis_pred,
-                                                                     lis_mask, slots, slot_flags, anchors, slot_aoff,
-                                                                     slot_acnt));
-    {  // mid-size intervals: whole-LDS kernel (order of the list does not matter: outputs go to per-interval slots)
-      u32* big_idx = e.chain_big.get<u32>(static_cast<size_t>(NI) + 2);
-      u32* d_cnt = big_idx + NI;
-      RVN_HIP(hipMemsetAsync(d_cnt, 0, 4, s));
-      chain_big_list_kernel<<<div_up(NI, 256), 256, 0, s>>>(iv_begin, iv_end, NI, big_idx, d_cnt);
+    {
+      u32* lists = e.chain_big.get<u32>(static_cast<size_t>(NI) * (kChainClasses + 1) + 16);
+      u32* d_cnt = lists + static_cast<size_t>(NI) * (kChainClasses + 1);
+      RVN_HIP(hipMemsetAsync(d_cnt, 0, (kChainClasses + 1) * 4, s));
+      chain_class_list_kernel<<<div_up(NI, 256), 256, 0, s>>>(iv_begin, iv_end, NI, e.chain, lists, d_cnt);
       RVN_LAUNCH_CHECK();
-      const u32 n_big = static_cast<u32>(read_back(e, d_cnt, 4));
-      if (n_big) {
-        static bool attr_set = false;
-        if (!attr_set) {
-          RVN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_big_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      static_cast<int>(kChainBigLds)));
-          attr_set = true;
-        }
-        RVN_KLAUNCH(kKChain, chain_big_kernel<<<n_big, 64, kChainBigLds, s>>>(g0, p0, iv_begin, iv_end, iv_read, big_idx, n_big,
-                                                                            r.id.as<u32>(), first, e.k, e.chain, e.matches,
-                                                                            e.gap, slot_div, slots, slot_flags, anchors,
-                                                                            slot_aoff, slot_acnt));
+      read_back(e, d_cnt, (kChainClasses + 1) * 4);
+      u32 n_cls[kChainClasses + 1];
+      std::memcpy(n_cls, e.h_pin, sizeof(n_cls));
+      static bool attr_set = false;
+      if (!attr_set) {
+        RVN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    static_cast<int>(chain_class_lds(kChainBigCap))));
+        attr_set = true;
+      }
+      // largest classes first: their waves run longest
+      for (int c = kChainClasses; c >= 0; --c) {
+        if (!n_cls[c]) continue;
+        const u32 cap = c < kChainClasses ? kChainClassCapHost[c] : 0u;
+        const size_t lds = cap ? chain_class_lds(cap) : 0;
+        RVN_KLAUNCH(kKChain, chain_kernel<<<n_cls[c], 64, lds, s>>>(g0, p0, iv_begin, iv_end, iv_read,
+                                                                   lists + static_cast<size_t>(c) * NI, n_cls[c], cap,
+                                                                   r.id.as<u32>(), first, e.k, e.chain, e.matches, e.gap,
+                                                                   slot_div, lis_tail, lis_min, lis_pred, lis_mask, slots,
+                                                                   slot_flags, anchors, slot_aoff, slot_acnt));
       }
     }
     t.stop();
