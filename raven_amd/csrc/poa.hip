@@ -679,14 +679,19 @@ void poa_run_dev(Engine& e, const PoaWindow* d_wins, const PoaLayer* d_lays, u32
   b.status = d_status;
   b.phase_cycles = d_phase;
   RVN_HIP(hipEventRecord(e.ev0, s));
-  if (e.poa_mode == 1) poa_v1_launch(e, b);
-  else poa_v2_launch(e, b, e.poa_mode == 3 ? 2 : (e.poa_mode == 4 ? 4 : 1));
+  // the banded kernels keep scores as int16 (and add the match / mismatch / gap terms as packed int16): scoring
+  // parameters far beyond spoa's usual single digits go straight to the int32 full-matrix kernel
+  const auto mag = [](int x) { return x < 0 ? -x : x; };
+  const bool int16_ok = mag(m) <= 24 && mag(n) <= 24 && mag(g) <= 24;
+  const int mode = int16_ok ? e.poa_mode : 1;
+  if (mode == 1) poa_v1_launch(e, b);
+  else poa_v2_launch(e, b, mode == 3 ? 2 : (mode == 4 ? 4 : 1));
   RVN_HIP(hipMemcpyAsync(h_status.data(), d_status, static_cast<size_t>(n_windows) * 4, hipMemcpyDeviceToHost, s));
   RVN_HIP(hipStreamSynchronize(s));
   e.poa_fallback_windows = 0;
   e.poa_wide_windows = 0;
   e.poa_fullmatrix_windows = 0;
-  if (e.poa_mode == 0) {
+  if (mode == 0) {
     // escalate what the 64-column band could not do: band hits -> 128-column band -> 256 -> full matrix; windows
     // beyond a limit (nodes / in-degree / length) -> full matrix directly
     auto rerun = [&](const std::vector<u32>& redo, int which_kernel) {

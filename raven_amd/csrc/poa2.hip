@@ -11,7 +11,7 @@
 //   * predecessor rows come from a 32-row score ring in LDS (hit rate ~all: an incremental order keeps a
 //     node's in-edges within a few ranks); only ring misses read the int16 copy in HBM.
 //   * the DP writes one BACKPOINTER byte per cell (which in-edge, diagonal/vertical/horizontal, chosen with
-//     spoa's traceback priority), so the traceback is a walk over bytes: blocks of 64 rows x 128 B are staged
+//     spoa's traceback priority; stored at column mod band width), so the traceback is a walk over bytes: blocks of 64 rows x band B are staged
 //     into LDS with one coalesced load, together with a per-row table (node, band start, first 4 predecessor
 //     ranks), and the walk itself touches only LDS.
 //   * spoa's AddAlignment runs lane-parallel, one sequence position per lane: the nodes on an alignment path are
@@ -136,7 +136,7 @@ struct alignas(16) Poa2Lds {  // per wave
       u16 tgt[kPoaMaxSeq];  // AddAlignment: graph node of every sequence position
     } add;
   } u;
-  u8 seq[kPoaMaxSeq];
+  u8 seq_pad[kPoaMaxSeq + 8];  // the layer's codes at seq_pad + 4; seq_pad[3] = 0xFF (position -1 matches nothing)
   u8 wgt[kPoaMaxSeq];
   u16 pos_node[kPoaMaxSeq];  // traceback result: node aligned to position p, or kNone
   uint4 tb[64];              // traceback: row table of the staged block (Poa2Slot::tb)
@@ -156,22 +156,25 @@ __device__ __noinline__ u32 poa2_nth_pred(const Poa2Slot& g, u32 v, u32 k, bool 
   return 0;
 }
 
-// Ring miss: predecessor row `pr` from the int16 copy in HBM.  Out of line on purpose: on gfx9 the vector memory
-// counter is shared by loads and stores, so a load on the common path would make every DP row wait for the
-// previous row's stores.
-__device__ __noinline__ void poa2_fetch_miss(const Poa2Slot& g, u32 pr, i32 j_first, int nch, i32 kBand, i32* up,
-                                             i32* dg) {
-  const i32 pb = static_cast<i32>(g.tb[pr].x & 0xFFFFu);
-  const i16* R = g.Hs + static_cast<size_t>(pr) * kBand;
-  for (int c = 0; c < nch; ++c) {
-    const i32 i0 = j_first + 64 * c - pb;
-    const i32 a0 = i0 < 0 ? 0 : (i0 > kBand - 1 ? kBand - 1 : i0);
-    const i32 a0m = i0 < 1 ? 0 : (i0 > kBand ? kBand - 1 : i0 - 1);
-    const i32 u0 = R[a0], d0 = R[a0m];
-    up[c] = (i0 >= 0 && i0 < kBand) ? u0 : kNegInf16;
-    dg[c] = (i0 >= 1 && i0 <= kBand) ? d0 : kNegInf16;
-  }
+// Ring miss: predecessor row `pr` from the int16 copy in HBM, one chunk of 64 columns; returns up | dg << 32.  Out of
+// line AND returning in registers on purpose: on gfx9 the vector memory counter is shared by loads and stores, so a
+// load (or a result handed back through scratch memory) on the common path makes every DP row wait for the previous
+// row's stores to be acknowledged — the wait for this load stays inside the function.
+__device__ __noinline__ unsigned long long poa2_fetch_miss(const i16* __restrict__ Hs, const uint4* __restrict__ tb, u32 pr,
+                                                           i32 j_first, i32 kBand) {
+  const i32 pb = static_cast<i32>(tb[pr].x & 0xFFFFu);
+  const i16* R = Hs + static_cast<size_t>(pr) * kBand;
+  const i32 i0 = j_first - pb;
+  const i32 a0 = i0 < 0 ? 0 : (i0 > kBand - 1 ? kBand - 1 : i0);
+  const i32 a0m = i0 < 1 ? 0 : (i0 > kBand ? kBand - 1 : i0 - 1);
+  const i32 u0 = R[a0], d0 = R[a0m];
+  const i32 up = (i0 >= 0 && i0 < kBand) ? u0 : kNegInf16;
+  const i32 dg = (i0 >= 1 && i0 <= kBand) ? d0 : kNegInf16;
+  return static_cast<unsigned long long>(static_cast<u32>(up)) | (static_cast<unsigned long long>(static_cast<u32>(dg)) << 32);
 }
+
+typedef short pk16 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ pk16 as_pk16(u32 x) { return __builtin_bit_cast(pk16, x); }
 
 __device__ __forceinline__ int rl(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -234,6 +237,9 @@ __device__ __forceinline__ u32 poa2_window(const PoaWindow& win, const PoaLayer*
   wsync();
   const u32 offset = static_cast<u32>(0.01 * blen);
   u32 failed = 0;
+  // (match | gap << 16), (mismatch | gap << 16): what v_pk_add_i16 adds to a (diagonal, vertical) candidate pair
+  const u32 pk_match = (static_cast<u32>(m) & 0xFFFFu) | (static_cast<u32>(gp) << 16);
+  const u32 pk_mismatch = (static_cast<u32>(n_) & 0xFFFFu) | (static_cast<u32>(gp) << 16);
 
   for (u32 li = 1; li < win.n_layers && !failed; ++li) {
     const PoaLayer L = layers[win.layer_first + li];
@@ -244,10 +250,11 @@ __device__ __forceinline__ u32 poa2_window(const PoaWindow& win, const PoaLayer*
       break;
     }
     for (u32 i = lane; i < len; i += 64) {
-      S.seq[i] = static_cast<u8>(poa_layer_code(src, L, i));
+      S.seq_pad[4 + i] = static_cast<u8>(poa_layer_code(src, L, i));
       S.wgt[i] = static_cast<u8>(poa_layer_weight(src, L, i));
       S.pos_node[i] = static_cast<u16>(kNone);
     }
+    if (lane == 0) S.seq_pad[3] = 0xFF;
     const bool full = L.begin < offset && L.end > blen - offset;
     tick();
     // ---- 1. subgraph marks ----
@@ -261,6 +268,9 @@ __device__ __forceinline__ u32 poa2_window(const PoaWindow& win, const PoaLayer*
     i32 best_score = -0x7FFFFFFF;
     u32 best_row = 0;
     int ring_tag = 0, ring_b = 0;  // lane s describes ring slot s: row stored there (0 = none), its band start
+    u32 last_row = 0xFFFFFFFFu;  // NCH == 1: the row computed last, its band start and its cells (one per lane)
+    i32 last_b = 0, last_h = 0;
+    u32 ring_miss = 0;  // != 0: a predecessor row was no longer in the ring
     {  // -inf pads (the union is reused by the traceback / AddAlignment of the previous layer)
       const u32 sl = static_cast<u32>(lane) >> 1;
       S.u.ring[1 + sl * kRingStride + ((lane & 1) ? kBand + 1 : 0)] = static_cast<i16>(kNegInf16);
@@ -271,6 +281,7 @@ __device__ __forceinline__ u32 poa2_window(const PoaWindow& win, const PoaLayer*
     for (u32 r0 = 0; r0 < n_nodes; r0 += 64) {
       // metadata of 64 rows at once, one row per lane; it is also the traceback's row table
       int m_v = 0, m_np = 0, m_p01 = 0, m_p23 = 0, m_code = 0, m_outc = 1, m_marked = 0, m_b = 0;
+      int m_meta = 0;  // NCH == 1: marked | #in-edges << 1 | code << 6 | end node << 8, one readlane per row
       if (r0 + lane < n_nodes) {
         m_v = g.order[r0 + lane];
         m_marked = (full || g.mark[m_v]) ? 1 : 0;
@@ -299,16 +310,109 @@ __device__ __forceinline__ u32 poa2_window(const PoaWindow& win, const PoaLayer*
         t.z = static_cast<u32>(m_p01);
         t.w = static_cast<u32>(m_p23);
         g.tb[r0 + lane + 1] = t;
+        m_meta = m_marked | (m_np << 1) | (m_code << 6) | ((m_outc == 0 ? 1 : 0) << 8);
       }
       // every load above must have returned BEFORE the row loop: a wait for them inside the loop would also wait
       // for the rows' own stores (loads and stores share the vector memory counter)
-      asm volatile("" ::"v"(m_v), "v"(m_np), "v"(m_p01), "v"(m_p23), "v"(m_code), "v"(m_outc), "v"(m_marked), "v"(m_b));
-      const u32 rows_here = n_nodes - r0 < 64 ? n_nodes - r0 : 64;
+      asm volatile("" ::"v"(m_v), "v"(m_np), "v"(m_p01), "v"(m_p23), "v"(m_code), "v"(m_outc), "v"(m_marked), "v"(m_b), "v"(m_meta));
+      const u32 rows_here = static_cast<u32>(rfl(static_cast<int>(n_nodes - r0 < 64 ? n_nodes - r0 : 64)));  // uniform loop
       {  // work counters: rows of this layer's (sub)graph x layer length = the cells spoa's full NW computes
         const u32 marked_rows = static_cast<u32>(__popcll(__ballot(m_marked != 0)));
         c_full += static_cast<unsigned long long>(marked_rows) * len;
         c_band += static_cast<unsigned long long>(marked_rows) * (w < static_cast<u32>(kBand) ? w : static_cast<u32>(kBand));
       }
+      if constexpr (NCH == 1) {
+        // One chunk of 64 columns.  The two candidates a predecessor row contributes to a cell — diagonal from its
+        // column j - 1, vertical from its column j — are adjacent int16 cells of the ring row, i.e. ONE 32-bit LDS
+        // read, and stay packed: v_pk_add_i16 adds (match/mismatch, gap) to both, v_pk_max_i16 folds the in-edges.
+        // When the predecessor is the row computed just before and its band starts at the same or the previous
+        // column (the chain case), the pair comes out of that row's registers through one DPP shift.  (Reading the
+        // other rows' pairs one row ahead was tried: the loop is issue-bound, the extra instructions cost more than
+        // the hidden LDS latency.)  Columns beyond the layer (only
+        // when the layer is shorter than the band) and column 0's diagonal need no masks: no valid cell ever reads
+        // them (column 0 reads the -inf pad or the explicit -inf of the virtual row).  A predecessor that has left
+        // the ring is not looked up in HBM: the window is repeated by the full-matrix kernel (status 7); it does
+        // not happen on racon-like windows.
+        unsigned long long todo = __ballot((m_meta & 1) != 0);
+        auto ring_pair = [&](u32 pr, i32 jv) -> u32 {
+          const u32 slot = (pr - 1) & (kRing - 1);
+          const u32 tagb = static_cast<u32>(rl(ring_tag, static_cast<int>(slot)));  // row << 16 | band start
+          ring_miss |= (tagb >> 16) ^ pr;
+          i32 cc = jv - static_cast<i32>(tagb & 0xFFFFu);
+          cc = cc < -1 ? -1 : (cc > kBand ? kBand : cc);
+          u32 pair;  // low half: predecessor's column j - 1 (diagonal), high half: its column j (vertical)
+          __builtin_memcpy(&pair, &S.u.ring[2 + static_cast<i32>(slot) * kRingStride + cc - 1], 4);
+          return pair;
+        };
+        while (todo) {
+          const int ri = __builtin_ctzll(todo);
+          todo &= todo - 1;
+          const u32 row = r0 + static_cast<u32>(ri) + 1;
+          const int meta = rl(m_meta, ri);
+          const i32 b = rl(m_b, ri);
+          const u32 p01 = static_cast<u32>(rl(m_p01, ri));
+          u32 np = (static_cast<u32>(meta) >> 1) & 31u;
+          if (np == 0) np = 1;  // no in-edge inside the subgraph: the virtual start row (p01 == 0)
+          const u32 vc = (static_cast<u32>(meta) >> 6) & 3u;
+          const i32 jv = b + lane;
+          const i32 jgv = __mul24(jv, gp);
+          const u32 ch = S.seq_pad[3 + jv];
+          const pk16 addc = as_pk16(ch == vc ? pk_match : pk_mismatch);
+          pk16 acc;
+          u32 kd = 0, kv = 0;
+          for (u32 k = 0; k < np; ++k) {
+            u32 pr;
+            if (k < 2) pr = (p01 >> (16 * k)) & 0xFFFFu;
+            else if (k < 4) pr = (static_cast<u32>(rl(m_p23, ri)) >> (16 * (k - 2))) & 0xFFFFu;
+            else pr = static_cast<u32>(rfl(static_cast<int>(poa2_nth_pred(g, static_cast<u32>(rl(m_v, ri)), k, full))));
+            u32 pair;
+            const u32 shift = static_cast<u32>(b - last_b);
+            if (pr == last_row && shift <= 1u) {
+              // last_h: lane l holds column last_b + l of row last_row
+              const i32 nb = shift ? __builtin_amdgcn_update_dpp(kNegInf16, last_h, 0x130 /* wave_shl:1 */, 0xf, 0xf, false)
+                                   : __builtin_amdgcn_update_dpp(kNegInf16, last_h, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+              const i32 upv = shift ? nb : last_h, dgv = shift ? last_h : nb;
+              pair = (static_cast<u32>(dgv) & 0xFFFFu) | (static_cast<u32>(upv) << 16);
+            } else if (pr == 0) {  // H[0][j] = j * g
+              const i32 dgv = jv >= 1 ? jgv - gp : kNegInf16;
+              pair = (static_cast<u32>(dgv) & 0xFFFFu) | (static_cast<u32>(jgv) << 16);
+            } else {
+              pair = ring_pair(pr, jv);
+            }
+            const pk16 cand = as_pk16(pair) + addc;
+            if (k == 0) {
+              acc = cand;
+            } else {  // spoa: the FIRST in-edge reaching the maximum wins -> strict comparisons
+              kd = cand.x > acc.x ? k : kd;
+              kv = cand.y > acc.y ? k : kv;
+              acc = __builtin_elementwise_max(acc, cand);
+            }
+          }
+          const i32 bdv = acc.x, bvv = acc.y;
+          const i32 best = bdv >= bvv ? bdv : bvv;
+          u32 code = bdv >= bvv ? kd : 16u + kv;
+          // spoa's traceback priority: diagonal (first in-edge reaching the max), vertical, horizontal
+          const i32 xs = wave_inclusive_max_fused(best - jgv);
+          i32 hh = xs + jgv;
+          if (hh > best) code = 32u;
+          hh = hh < kNegInf16 ? kNegInf16 : hh;
+          const u32 rslot = (row - 1) & (kRing - 1);
+          S.u.ring[2 + rslot * kRingStride + lane] = static_cast<i16>(hh);
+          g.BP[static_cast<size_t>(row) * kBand + (jv & (kBand - 1))] = static_cast<u8>(code);  // by absolute column
+          if (lane == static_cast<int>(rslot)) ring_tag = static_cast<int>((row << 16) | static_cast<u32>(b));
+          last_row = static_cast<u32>(rfl(static_cast<int>(row)));
+          last_b = rfl(b);
+          last_h = hh;
+          if (meta & 256) {  // an end node: score of the last column if the band has it
+            const i32 idx = static_cast<i32>(w) - 1 - b;
+            const i32 sce = (idx >= 0 && idx < 64) ? rl(hh, idx) : -0x7FFFFFFF;
+            if (sce > best_score) {
+              best_score = sce;
+              best_row = row;
+            }
+          }
+        }
+      } else
       for (u32 ri = 0; ri < rows_here; ++ri) {
         if (!rl(m_marked, static_cast<int>(ri))) continue;
         const u32 row = static_cast<u32>(rfl(static_cast<int>(r0 + ri + 1)));  // uniform: keeps the row addressing scalar
@@ -330,7 +434,7 @@ __device__ __forceinline__ u32 poa2_window(const PoaWindow& win, const PoaLayer*
           dok[c] = val[c] && j[c] >= 1;
           // match/mismatch per column (clamped read; masked by dok)
           const i32 qi = j[c] >= 1 ? (j[c] - 1 < kPoaMaxSeq ? j[c] - 1 : kPoaMaxSeq - 1) : 0;
-          sc[c] = vc == S.seq[qi] ? m : n_;
+          sc[c] = vc == S.seq_pad[4 + qi] ? m : n_;
           bd[c] = kNegBig;
           bv[c] = kNegBig;
           kd[c] = 0;
@@ -366,7 +470,12 @@ __device__ __forceinline__ u32 poa2_window(const PoaWindow& win, const PoaLayer*
                 wsync();
                 dirty = false;
               }
-              poa2_fetch_miss(g, pr, j[0], NCH, kBand, up, dg);
+#pragma unroll
+              for (int c = 0; c < NCH; ++c) {
+                const unsigned long long ud = poa2_fetch_miss(g.Hs, g.tb, pr, j[c], kBand);
+                up[c] = static_cast<i32>(static_cast<u32>(ud));
+                dg[c] = static_cast<i32>(static_cast<u32>(ud >> 32));
+              }
             }
           }
 #pragma unroll
@@ -402,7 +511,7 @@ __device__ __forceinline__ u32 poa2_window(const PoaWindow& win, const PoaLayer*
             carry = rl(hh, 63);
             S.u.ring[rbase + 64 * c + lane] = static_cast<i16>(hh);
             g.Hs[static_cast<size_t>(row) * kBand + 64 * c + lane] = static_cast<i16>(hh);
-            g.BP[static_cast<size_t>(row) * kBand + 64 * c + lane] = static_cast<u8>(code);
+            g.BP[static_cast<size_t>(row) * kBand + (j[c] & (kBand - 1))] = static_cast<u8>(code);  // by absolute column
           } else {
             h[c] = kNegInf16;
           }
@@ -428,6 +537,10 @@ __device__ __forceinline__ u32 poa2_window(const PoaWindow& win, const PoaLayer*
     wsync();  // backpointers visible to the traceback
     tock(t_dp);
     tick();
+    if (ring_miss) {
+      failed = 7u | (li << 8);
+      break;
+    }
     if (best_row == 0) {  // the last column is in no end node's band
       failed = kPoaBandHit | (li << 8);
       break;
@@ -471,7 +584,9 @@ __device__ __forceinline__ u32 poa2_window(const PoaWindow& win, const PoaLayer*
         const u32 nodet = t.x >> 16;
         const i32 idx = jt - bt;
         const bool inband = in_blk && idx >= 0 && idx < kBand;
-        const u32 code = S.u.stage[inband ? lt * kBand + idx : 0];
+        // a row's backpointers are stored by absolute column (mod the band width): the read does not wait for the
+        // row table's band start
+        const u32 code = S.u.stage[in_blk ? lt * kBand + (jt & (kBand - 1)) : 0];
         const u32 k = code & 15u;
         u32 prt = 0xFFFFFFFFu;  // predecessor row the backpointer names (in-edges beyond the 4th: slow path below)
         if (t.y == 0) prt = 0;
@@ -557,7 +672,7 @@ __device__ __forceinline__ u32 poa2_window(const PoaWindow& win, const PoaLayer*
       const u32 p = p0 + lane;
       const bool valid = p < len;
       const u32 an = valid ? S.pos_node[p] : kNone;
-      const u32 letter = valid ? S.seq[p] : 0u;
+      const u32 letter = valid ? S.seq_pad[4 + p] : 0u;
       const bool has = valid && an != kNone;
       u32 tgt = kNone, gslot = 0, gb = 0, ac = 0;
       if (has) {

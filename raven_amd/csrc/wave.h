@@ -81,6 +81,21 @@ __device__ __forceinline__ int wave_inclusive_max_dpp(int v, int identity) {
   return a;
 }
 
+// The same prefix max with the DPP operand fused into v_max (one instruction per step instead of v_mov_dpp + v_max):
+// a lane without a source (bound_ctrl off) is simply not written and keeps its value, which is the identity of max.
+// All 64 lanes must be active.  s_nop 1 = the two wait states a DPP read needs after a VALU write of the register.
+__device__ __forceinline__ int wave_inclusive_max_fused(int x) {
+  asm volatile(
+      "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf"
+      : "+v"(x));
+  return x;
+}
+
 // Mask of lanes (among `valid` lanes) whose 8-bit digit equals this lane's digit.
 __device__ __forceinline__ unsigned long long match_digit8(unsigned d, bool valid) {
   unsigned long long peers = __ballot(valid);
