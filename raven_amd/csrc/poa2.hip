@@ -11,7 +11,7 @@
 //   * predecessor rows come from a 32-row score ring in LDS (hit rate ~all: an incremental order keeps a
 //     node's in-edges within a few ranks); only ring misses read the int16 copy in HBM.
 //   * the DP writes one BACKPOINTER byte per cell (which in-edge, diagonal/vertical/horizontal, chosen with
-//     spoa's traceback priority; stored at column mod band width), so the traceback is a walk over bytes: blocks of 64 rows x band B are staged
+//     spoa's traceback priority), so the traceback is a walk over bytes: blocks of 64 rows x band B are staged
 //     into LDS with one coalesced load, together with a per-row table (node, band start, first 4 predecessor
 //     ranks), and the walk itself touches only LDS.
 //   * spoa's AddAlignment runs lane-parallel, one sequence position per lane: the nodes on an alignment path are
@@ -139,7 +139,6 @@ struct alignas(16) Poa2Lds {  // per wave
   u8 seq_pad[kPoaMaxSeq + 8];  // the layer's codes at seq_pad + 4; seq_pad[3] = 0xFF (position -1 matches nothing)
   u8 wgt[kPoaMaxSeq];
   u16 pos_node[kPoaMaxSeq];  // traceback result: node aligned to position p, or kNone
-  uint4 tb[64];              // traceback: row table of the staged block (Poa2Slot::tb)
 };
 
 // k-th in-edge (among those inside the subgraph) of v, as a row index (rank + 1); slow path for in-degree > 4
@@ -171,6 +170,13 @@ __device__ __noinline__ unsigned long long poa2_fetch_miss(const i16* __restrict
   const i32 up = (i0 >= 0 && i0 < kBand) ? u0 : kNegInf16;
   const i32 dg = (i0 >= 1 && i0 <= kBand) ? d0 : kNegInf16;
   return static_cast<unsigned long long>(static_cast<u32>(up)) | (static_cast<unsigned long long>(static_cast<u32>(dg)) << 32);
+}
+
+// (diagonal, vertical) candidate pair out of the virtual start row H[0][j] = j * g; out of line so that its four
+// instructions are not hoisted into every row (only rows without an in-edge inside the subgraph use it)
+__device__ __noinline__ u32 poa2_virtual_pair(i32 jv, i32 jgv, i32 gp) {
+  const i32 dgv = jv >= 1 ? jgv - gp : kNegInf16;
+  return (static_cast<u32>(dgv) & 0xFFFFu) | (static_cast<u32>(jgv) << 16);
 }
 
 typedef short pk16 __attribute__((ext_vector_type(2)));
@@ -271,6 +277,7 @@ __device__ __forceinline__ u32 poa2_window(const PoaWindow& win, const PoaLayer*
     u32 last_row = 0xFFFFFFFFu;  // NCH == 1: the row computed last, its band start and its cells (one per lane)
     i32 last_b = 0, last_h = 0;
     u32 ring_miss = 0;  // != 0: a predecessor row was no longer in the ring
+    int m_b_last = 0;
     {  // -inf pads (the union is reused by the traceback / AddAlignment of the previous layer)
       const u32 sl = static_cast<u32>(lane) >> 1;
       S.u.ring[1 + sl * kRingStride + ((lane & 1) ? kBand + 1 : 0)] = static_cast<i16>(kNegInf16);
@@ -282,6 +289,7 @@ __device__ __forceinline__ u32 poa2_window(const PoaWindow& win, const PoaLayer*
       // metadata of 64 rows at once, one row per lane; it is also the traceback's row table
       int m_v = 0, m_np = 0, m_p01 = 0, m_p23 = 0, m_code = 0, m_outc = 1, m_marked = 0, m_b = 0;
       int m_meta = 0;  // NCH == 1: marked | #in-edges << 1 | code << 6 | end node << 8, one readlane per row
+      const int m_b_prev = m_b_last;  // band starts of the previous block of 64 rows
       if (r0 + lane < n_nodes) {
         m_v = g.order[r0 + lane];
         m_marked = (full || g.mark[m_v]) ? 1 : 0;
@@ -315,6 +323,7 @@ __device__ __forceinline__ u32 poa2_window(const PoaWindow& win, const PoaLayer*
       // every load above must have returned BEFORE the row loop: a wait for them inside the loop would also wait
       // for the rows' own stores (loads and stores share the vector memory counter)
       asm volatile("" ::"v"(m_v), "v"(m_np), "v"(m_p01), "v"(m_p23), "v"(m_code), "v"(m_outc), "v"(m_marked), "v"(m_b), "v"(m_meta));
+      m_b_last = m_b;
       const u32 rows_here = static_cast<u32>(rfl(static_cast<int>(n_nodes - r0 < 64 ? n_nodes - r0 : 64)));  // uniform loop
       {  // work counters: rows of this layer's (sub)graph x layer length = the cells spoa's full NW computes
         const u32 marked_rows = static_cast<u32>(__popcll(__ballot(m_marked != 0)));
@@ -334,17 +343,21 @@ __device__ __forceinline__ u32 poa2_window(const PoaWindow& win, const PoaLayer*
         // the ring is not looked up in HBM: the window is repeated by the full-matrix kernel (status 7); it does
         // not happen on racon-like windows.
         unsigned long long todo = __ballot((m_meta & 1) != 0);
-        auto ring_pair = [&](u32 pr, i32 jv) -> u32 {
+        // A predecessor at most kRing rows back is still in its ring slot (no later row has wrapped onto it); its band
+        // start comes from the block metadata (this block's or the previous one's), so the ring needs no tags.
+        auto ring_pair = [&](u32 pr, i32 jv, u32 row) -> u32 {
+          ring_miss |= (row - pr > static_cast<u32>(kRing)) ? 1u : 0u;
           const u32 slot = (pr - 1) & (kRing - 1);
-          const u32 tagb = static_cast<u32>(rl(ring_tag, static_cast<int>(slot)));  // row << 16 | band start
-          ring_miss |= (tagb >> 16) ^ pr;
-          i32 cc = jv - static_cast<i32>(tagb & 0xFFFFu);
+          const i32 pb = (pr - 1 >= r0) ? rl(m_b, static_cast<int>((pr - 1) & 63)) : rl(m_b_prev, static_cast<int>((pr - 1) & 63));
+          i32 cc = jv - pb;
           cc = cc < -1 ? -1 : (cc > kBand ? kBand : cc);
           u32 pair;  // low half: predecessor's column j - 1 (diagonal), high half: its column j (vertical)
           __builtin_memcpy(&pair, &S.u.ring[2 + static_cast<i32>(slot) * kRingStride + cc - 1], 4);
           return pair;
         };
+        u32 pkm_v = pk_match, pkx_v = pk_mismatch;
         while (todo) {
+          asm volatile("" : "+v"(pkm_v), "+v"(pkx_v));  // keep both in VGPRs: one v_cndmask per row instead of rebuilding them
           const int ri = __builtin_ctzll(todo);
           todo &= todo - 1;
           const u32 row = r0 + static_cast<u32>(ri) + 1;
@@ -357,7 +370,7 @@ __device__ __forceinline__ u32 poa2_window(const PoaWindow& win, const PoaLayer*
           const i32 jv = b + lane;
           const i32 jgv = __mul24(jv, gp);
           const u32 ch = S.seq_pad[3 + jv];
-          const pk16 addc = as_pk16(ch == vc ? pk_match : pk_mismatch);
+          const pk16 addc = as_pk16(ch == vc ? pkm_v : pkx_v);
           pk16 acc;
           u32 kd = 0, kv = 0;
           for (u32 k = 0; k < np; ++k) {
@@ -374,10 +387,9 @@ __device__ __forceinline__ u32 poa2_window(const PoaWindow& win, const PoaLayer*
               const i32 upv = shift ? nb : last_h, dgv = shift ? last_h : nb;
               pair = (static_cast<u32>(dgv) & 0xFFFFu) | (static_cast<u32>(upv) << 16);
             } else if (pr == 0) {  // H[0][j] = j * g
-              const i32 dgv = jv >= 1 ? jgv - gp : kNegInf16;
-              pair = (static_cast<u32>(dgv) & 0xFFFFu) | (static_cast<u32>(jgv) << 16);
+              pair = poa2_virtual_pair(jv, jgv, gp);
             } else {
-              pair = ring_pair(pr, jv);
+              pair = ring_pair(pr, jv, row);
             }
             const pk16 cand = as_pk16(pair) + addc;
             if (k == 0) {
@@ -398,8 +410,7 @@ __device__ __forceinline__ u32 poa2_window(const PoaWindow& win, const PoaLayer*
           hh = hh < kNegInf16 ? kNegInf16 : hh;
           const u32 rslot = (row - 1) & (kRing - 1);
           S.u.ring[2 + rslot * kRingStride + lane] = static_cast<i16>(hh);
-          g.BP[static_cast<size_t>(row) * kBand + (jv & (kBand - 1))] = static_cast<u8>(code);  // by absolute column
-          if (lane == static_cast<int>(rslot)) ring_tag = static_cast<int>((row << 16) | static_cast<u32>(b));
+          g.BP[static_cast<size_t>(row) * kBand + lane] = static_cast<u8>(code);
           last_row = static_cast<u32>(rfl(static_cast<int>(row)));
           last_b = rfl(b);
           last_h = hh;
@@ -511,7 +522,7 @@ __device__ __forceinline__ u32 poa2_window(const PoaWindow& win, const PoaLayer*
             carry = rl(hh, 63);
             S.u.ring[rbase + 64 * c + lane] = static_cast<i16>(hh);
             g.Hs[static_cast<size_t>(row) * kBand + 64 * c + lane] = static_cast<i16>(hh);
-            g.BP[static_cast<size_t>(row) * kBand + (j[c] & (kBand - 1))] = static_cast<u8>(code);  // by absolute column
+            g.BP[static_cast<size_t>(row) * kBand + 64 * c + lane] = static_cast<u8>(code);
           } else {
             h[c] = kNegInf16;
           }
@@ -546,16 +557,23 @@ __device__ __forceinline__ u32 poa2_window(const PoaWindow& win, const PoaLayer*
       break;
     }
     // ---- 3. traceback over backpointer bytes, block-staged in LDS ----
-    // Lane t speculates on cell (i - t, j - t): a run of diagonal moves through rank-adjacent rows (the common
-    // case on a mostly linear graph) is committed in one step; anything else is a single generic step of lane 0.
+    // A scalar walk: the row table of the staged 64-row block lives in registers (lane l = row l of the block, read with
+    // v_readlane), the backpointer of the current cell is one uniform LDS read, everything else is SALU — about one LDS
+    // latency per step.  (Committing runs of diagonal moves through rank-adjacent rows with 64 speculating lanes was
+    // the earlier scheme; on a graph that already holds 20 layers consecutive path nodes are rarely rank-adjacent and
+    // the speculation cost more per step than it saved.)
     u32 bad = 0, band_hit = 0;
     {
-      u32 i = best_row;
-      i32 j = static_cast<i32>(w) - 1;
+      // every walk variable is wave-uniform; readfirstlane tells the compiler so (scalar registers, scalar branches)
+      u32 i = static_cast<u32>(rfl(static_cast<int>(best_row)));
+      i32 j = rfl(static_cast<i32>(w) - 1);
+      const u32 n_rows_total = static_cast<u32>(rfl(static_cast<int>(n_nodes))) + 1;
+      const u32 max_steps = static_cast<u32>(rfl(static_cast<int>(nmax + lmax + 2)));
       u32 cur_blk = 0xFFFFFFFFu;
       u32 steps = 0;
+      int tbx = 0, tby = 0, tbz = 0, tbw = 0;
       while (i != 0) {  // once on the virtual row only insertions remain: pos_node already says kNone
-        if (++steps > nmax + lmax + 2) {
+        if (++steps > max_steps) {
           bad = 6;
           break;
         }
@@ -563,74 +581,63 @@ __device__ __forceinline__ u32 poa2_window(const PoaWindow& win, const PoaLayer*
         if (blk != cur_blk) {
           wsync();
           const u32 row0 = blk * 64 + 1;
-          const u32 nrows = n_nodes + 1 - row0 < 64 ? n_nodes + 1 - row0 : 64;
+          const u32 nrows = n_rows_total - row0 < 64 ? n_rows_total - row0 : 64;
           const uint4* src = reinterpret_cast<const uint4*>(g.BP + static_cast<size_t>(row0) * kBand);
           uint4* dst = reinterpret_cast<uint4*>(S.u.stage);
+          // 64 rows x kBand bytes, 16 B per lane and step, global -> LDS without passing through registers (one memory
+          // round trip per block).  Indices beyond the last row clamp to the block's first bytes: those LDS rows are
+          // never read.
+          const u32 q_end = nrows * (kBand / 16);
 #pragma unroll
-          for (u32 it = 0; it < 4 * NCH; ++it) {  // 64 rows x kBand bytes, 16 B per lane and step
+          for (u32 it = 0; it < 4 * NCH; ++it) {
             const u32 q = it * 64 + lane;
-            if (q / (kBand / 16) < nrows) dst[q] = src[q];
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)(src + (q < q_end ? q : 0)),
+                (__attribute__((address_space(3))) void*)(dst + it * 64), 16, 0, 0);
           }
-          if (static_cast<u32>(lane) < nrows) S.tb[lane] = g.tb[row0 + lane];
+          const uint4 t = g.tb[row0 + (static_cast<u32>(lane) < nrows ? lane : 0)];
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          tbx = static_cast<int>(t.x);
+          tby = static_cast<int>(t.y);
+          tbz = static_cast<int>(t.z);
+          tbw = static_cast<int>(t.w);
           wsync();
           cur_blk = blk;
         }
-        const i32 l = static_cast<i32>((i - 1) & 63);
-        const i32 lt = l - lane;
-        const i32 jt = j - lane;
-        const bool in_blk = lt >= 0 && jt >= 0;
-        const uint4 t = S.tb[in_blk ? lt : 0];
-        const i32 bt = static_cast<i32>(t.x & 0xFFFFu);
-        const u32 nodet = t.x >> 16;
-        const i32 idx = jt - bt;
-        const bool inband = in_blk && idx >= 0 && idx < kBand;
-        // a row's backpointers are stored by absolute column (mod the band width): the read does not wait for the
-        // row table's band start
-        const u32 code = S.u.stage[in_blk ? lt * kBand + (jt & (kBand - 1)) : 0];
-        const u32 k = code & 15u;
-        u32 prt = 0xFFFFFFFFu;  // predecessor row the backpointer names (in-edges beyond the 4th: slow path below)
-        if (t.y == 0) prt = 0;
-        else if (k < 2) prt = (t.z >> (16 * k)) & 0xFFFFu;
-        else if (k < 4) prt = (t.w >> (16 * (k - 2))) & 0xFFFFu;
-        const bool edge = inband && ((idx < 2 && bt > 0) || (idx > kBand - 3 && bt + kBand < static_cast<i32>(w)));
-        const bool good = inband && code < 16u && jt >= 1 && prt == i - static_cast<u32>(lane) - 1;
-        const unsigned long long gb = __ballot(good);
-        const u32 run = ~gb ? static_cast<u32>(__builtin_ctzll(~gb)) : 64u;
-        if (run) {
-          if (static_cast<u32>(lane) < run) S.pos_node[jt - 1] = static_cast<u16>(nodet);
-          const unsigned long long in_run = run == 64 ? ~0ULL : ((1ULL << run) - 1ULL);
-          if (__ballot(edge) & in_run) band_hit = 1;
-          i -= run;
-          j -= static_cast<i32>(run);
-          continue;
-        }
-        // generic step for cell (i, j) = lane 0's cell
-        if (!rfl(inband ? 1 : 0)) {  // the path left the stored band: the alignment does not fit this band width
+        const int l = static_cast<int>((i - 1) & 63);
+        const u32 x = static_cast<u32>(rl(tbx, l));
+        const i32 bt = static_cast<i32>(x & 0xFFFFu);
+        const u32 node = x >> 16;
+        const i32 idx = j - bt;
+        if (idx < 0 || idx >= kBand) {  // the path left the stored band: the alignment does not fit this band width
           band_hit = 1;
           break;
         }
-        if (rfl(edge ? 1 : 0)) band_hit = 1;
-        const u32 code0 = static_cast<u32>(rfl(static_cast<int>(code)));
-        if (code0 == 32u) {
+        if ((idx < 2 && bt > 0) || (idx > kBand - 3 && bt + kBand < static_cast<i32>(w))) band_hit = 1;
+        const u32 code = static_cast<u32>(rfl(static_cast<int>(S.u.stage[l * kBand + idx])));
+        if (code == 32u) {
           if (j == 0) {
             bad = 6;
             break;
           }
           --j;  // insertion: pos_node[j] stays kNone
-        } else {
-          const u32 node = static_cast<u32>(rfl(static_cast<int>(nodet)));
-          u32 pr = static_cast<u32>(rfl(static_cast<int>(prt)));
-          if (pr == 0xFFFFFFFFu) pr = poa2_nth_pred(g, node, code0 & 15u, full);
-          if (code0 < 16u) {
-            if (j == 0) {
-              bad = 6;
-              break;
-            }
-            --j;
-            if (lane == 0) S.pos_node[j] = static_cast<u16>(node);
-          }
-          i = pr;
+          continue;
         }
+        const u32 k = code & 15u;
+        u32 pr;
+        if (rl(tby, l) == 0) pr = 0;
+        else if (k < 2) pr = (static_cast<u32>(rl(tbz, l)) >> (16 * k)) & 0xFFFFu;
+        else if (k < 4) pr = (static_cast<u32>(rl(tbw, l)) >> (16 * (k - 2))) & 0xFFFFu;
+        else pr = static_cast<u32>(rfl(static_cast<int>(poa2_nth_pred(g, node, k, full))));
+        if (code < 16u) {
+          if (j == 0) {
+            bad = 6;
+            break;
+          }
+          --j;
+          S.pos_node[j] = static_cast<u16>(node);  // every lane stores the same value
+        }
+        i = pr;
       }
     }
     wsync();
