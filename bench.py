@@ -164,6 +164,8 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--replicas", action="store_true", help="N > 1: independent shard per GPU (weak scaling, no "
                     "collective) instead of one genome sharded across the ranks")
+    ap.add_argument("--sharded", action="store_true", help="run the sharded code path even at N = 1 (one rank owning "
+                    "every read and hash class): measures what the partition / regroup steps cost before any link traffic")
     args = ap.parse_args()
     if args.workload == "c4":
         args.genome = args.genome or 100_000_000
@@ -194,7 +196,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    sharded_mode = world > 1 and not args.replicas
+    sharded_mode = (world > 1 and not args.replicas) or args.sharded
     if world > 1 and args.replicas:  # independent shards: rank-dependent seeds would go here; same data is fine
         pass
     rs, drafts, t_gen = make_workload(args, local_rank)
@@ -215,13 +217,20 @@ def main():
         from raven_amd import sharded
         comm = sharded.DeviceComm(dist, device="cuda")
     dev = torch.device("cuda", local_rank)
+    own_reads, shard_laps = None, ({} if os.environ.get("RVN_SHARD_LAPS") else None)
+    if sharded_mode:  # this rank's reads, resident for every step like `reads` of the single-GPU pass
+        b = sharded.partition_reads(rs.lengths, world)
+        own_reads = eng.upload(sharded.slice_reads(rs, int(b[rank]), int(b[rank + 1])))
     legs = {"overlap_s": 0.0, "polish_s": 0.0}
     last = {}
 
     def step(timed):
         t_a = time.perf_counter()
         if sharded_mode:
-            res = sharded.find_overlaps_and_create_piles_sharded_dev(eng, rs, comm, dev, freq=args.freq, kmax=args.kmax)
+            res = sharded.find_overlaps_and_create_piles_sharded_dev(eng, rs, comm, dev, freq=args.freq, kmax=args.kmax,
+                                                                     own=own_reads, laps=shard_laps if timed else None,
+                                                                     fetch=False)  # results stay in HBM, as in the 1-GPU leg
+            res["pass1"].close()
             last["overlap"] = {k: res[k] for k in ("lo", "hi", "occurrence", "stats")}
         else:
             p = eng.find_overlaps_and_create_piles(reads, freq=args.freq, kmax=args.kmax)  # synchronous
@@ -273,6 +282,9 @@ def main():
                 kms[k2] = (a[0] + v[0], a[1] + v[1])
     poa_cells = peng.poa_cells()
 
+    if rank == 0 and shard_laps:
+        print("[bench] sharded pass laps (s, summed over the timed steps):", {k: round(v, 4) for k, v in shard_laps.items()},
+              file=sys.stderr)
     if rank == 0:
         steps = max(args.steps, 1)
         counters = {k: v // steps for k, v in counters_raw.items()}

@@ -306,9 +306,43 @@ int rvn_shard_join_fetch_dev(rvn_engine* e, uint64_t* d_group, uint64_t* d_posit
 int rvn_shard_chain_dev(rvn_engine* e, const rvn_reads* own_reads, const uint64_t* d_group, const uint64_t* d_positions,
                         const uint64_t* d_seg_off, uint64_t n_matches, uint64_t* n_overlaps);
 int rvn_engine_map_fetch_dev(rvn_engine* e, rvn_overlap* d_overlaps, uint32_t* d_read_offsets);
+/* Partition / regroup steps between the stages (device pointers; `counts`, `bounds`, `n_per_source` and the pointer tables
+ * themselves are host memory).  They replace what a host would do with sort / bincount / gather:
+ *   split_minimizers  stable partition of (value, origin) by owner rank = hash class of the value (the order inside a
+ *                     rank's part is the input order = ram's (read, position) order); counts[world]
+ *   count_flagged     number of origins with bit 63 set (the minhash-selected query entries) in a received buffer
+ *   adjacent_diff     per-read match counts out of the per-read offsets of rvn_shard_join_fetch_dev
+ *   regroup           matches received from every index owner -> per-read segments, sources in rank order
+ *   split_overlaps    stable partition of Map's overlaps by the owner of their rhs read (bounds[world + 1] = read ranges);
+ *                     counts[world + 1], the last bucket = overlaps whose rhs read is `self`'s (they stay and are not copied
+ *                     to d_out's first buckets)
+ *   merge_parts       rvn_shard_piles_merge_dev on the concatenation of `n_parts` lists (received parts in rank order, own
+ *                     overlaps last), per-read offsets computed on the device */
+int rvn_shard_split_minimizers_dev(rvn_engine* e, const uint64_t* d_values, const uint64_t* d_origins, uint64_t n,
+                                   uint32_t world, uint64_t* d_values_out, uint64_t* d_origins_out, uint64_t* counts);
+int rvn_shard_count_flagged_dev(rvn_engine* e, const uint64_t* d_origins, uint64_t n, uint64_t* count);
+int rvn_shard_adjacent_diff_dev(rvn_engine* e, const uint64_t* d_seg_off, uint64_t n, uint64_t* d_counts);
+int rvn_shard_regroup_dev(rvn_engine* e, uint32_t world, const uint64_t* const* d_counts, const uint64_t* const* d_group,
+                          const uint64_t* const* d_positions, const uint64_t* n_per_source, uint32_t n_reads,
+                          uint64_t* d_seg_off, uint64_t* d_group_out, uint64_t* d_positions_out);
+int rvn_shard_split_overlaps_dev(rvn_engine* e, const rvn_overlap* d_overlaps, uint64_t n, const uint32_t* bounds,
+                                 uint32_t world, uint32_t self, rvn_overlap* d_out, uint64_t* counts);
+int rvn_shard_piles_merge_parts_dev(rvn_pass1* p, uint32_t n_parts, const rvn_overlap* const* d_parts,
+                                    const uint64_t* n_per_part, uint32_t kmax);
 int rvn_shard_piles_dev(rvn_engine* e, const uint32_t* lengths /* host */, uint32_t n_reads_total,
                         const rvn_overlap* d_overlaps, const uint32_t* d_overlap_read_off /* n_reads_total + 1 */,
                         uint64_t n, uint32_t kmax, rvn_pass1** out);
+
+/* The two halves of the first step of a round, for the sharded round: reads are mapped independently of
+ * each other, so rank g maps the slice [read_first, read_last) of the reads and the ranks all-gather the table.
+ *   rvn_polish_map_best  index the targets, map the slice, best overlap per read (racon Polisher::Initialize: longest
+ *                        overlap after the error filter); best[i] / best_target[i] describe read read_first + i,
+ *                        best_target = index into `targets` or 0xFFFFFFFF when the read is not used.
+ *   rvn_polish_set_best  hands the complete table (n_reads = size of the read set) to the NEXT rvn_polish_round[_range]
+ *                        call on this engine, which then skips its own mapping; the table is consumed by that call. */
+int rvn_polish_map_best(rvn_engine* e, rvn_reads* targets, rvn_reads* reads, uint32_t read_first, uint32_t read_last,
+                        double err, rvn_overlap* best, uint32_t* best_target, uint64_t* n_overlaps);
+int rvn_polish_set_best(rvn_engine* e, const rvn_overlap* best, const uint32_t* best_target, uint32_t n_reads);
 
 /* Same round restricted to the windows [window_first, window_last) of the global numbering (windows of target 0,
  * then of target 1, ...; ceil(len / w) per target): what one GPU does when a round is sharded by windows

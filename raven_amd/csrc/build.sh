@@ -7,7 +7,7 @@ mkdir -p "$OUT" "$HERE/obj"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function"
 pids=()
-for f in scan radix_sort sketch index map pile edit_distance poa poa2 polish nwpath pass2 io engine edlib_dropin; do
+for f in scan radix_sort sketch index map pile edit_distance poa poa2 polish nwpath pass2 io shard engine edlib_dropin; do
   src="$HERE/$f.hip"; obj="$HERE/obj/$f.o"
   if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ -n "$(find "$HERE" -maxdepth 1 -name '*.h' -newer "$obj" -print -quit)" ] || [ "$HERE/../../include/raven_hip.h" -nt "$obj" ]; then
     $HIPCC $FLAGS -c "$src" -o "$obj" &

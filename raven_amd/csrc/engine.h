@@ -114,6 +114,7 @@ struct Engine {
   MapOut map_out;
   // scratch
   DevBuf tmp_a, tmp_b, tmp_c, tmp_d, tmp_e, tmp_f, scan_tmp, sort_tmp;
+  DevBuf sh_hist, sh_off, sh_ptrs;  // shard.hip: tile histograms / offsets / pointer tables of the partition steps
   DevBuf q_start, q_cnt, m_off;
   DevBuf m_grp[2], m_pos[2];
   DevBuf seg_off, iv_slot_begin, iv_slot_end, iv_cnt, iv_off, iv_begin, iv_end;
@@ -130,6 +131,10 @@ struct Engine {
   DevBuf pl_best, pl_best_t, pl_idmap, pl_recs, pl_keep, pl_win_cnt, pl_win_off, pl_win_fill, pl_win_meta, pl_first_window,
       pl_keys, pl_lays_tmp, pl_lays, pl_wins, pl_out, pl_len, pl_status, pl_ok, pl_cons_off, pl_final, pl_qual_off, pl_misc;
   std::vector<u32> polish_target_reads;  // reads used per target in the last polishing round
+  // best-overlap table for the NEXT polishing round (rvn_polish_set_best; consumed by that round)
+  std::vector<Overlap> polish_given_best;
+  std::vector<u32> polish_given_best_t;
+  bool polish_given_valid = false;
   // layer table of the last polishing round (still in pl_wins / pl_lays / pl_ok), for rvn_polish_fetch_layers
   u32 polish_last_windows = 0;
   u64 polish_last_layers = 0, polish_last_w0 = 0;
@@ -262,6 +267,18 @@ void nw_breakpoints(Engine& e, const ReadsDev& T, const ReadsDev& R, std::vector
 int nw_breakpoints_host(const u64* t_words, u32 t_len, const u64* r_words, u32 r_len, u32 t_begin, u32 n, u32 q_begin, u32 m,
                         int rc, u32 w, u32 k, int force_R, NwWindowRec* recs, u32* distance, u32* band);
 // One racon polishing round (polish.hip): targets T, reads R, optional per-base Phred+33 qualities of the reads
+// shard.hip — partition / regroup steps of the sharded pass, all pointers device pointers unless noted
+void shard_split_minimizers(Engine& e, const u64* d_val, const u64* d_org, u64 n, u32 world, u64* d_val_out, u64* d_org_out,
+                            u64* counts /* host [world] */);
+void shard_split_overlaps(Engine& e, const Overlap* d_ovl, u64 n, const u32* bounds /* host [world + 1] */, u32 world, u32 self,
+                          Overlap* d_out, u64* counts /* host [world + 1], [world] = overlaps that stay */);
+u64 shard_count_flagged(Engine& e, const u64* d_org, u64 n);
+void shard_adjacent_diff(Engine& e, const u64* d_seg, u64 n, u64* d_cnt);
+void shard_regroup(Engine& e, u32 world, const u64* const* d_cnt, const u64* const* d_grp, const u64* const* d_pos,
+                   const u64* n_src /* host */, u32 n_reads, u64* d_seg, u64* d_grp_out, u64* d_pos_out);
+void shard_lhs_offsets(Engine& e, const Overlap* d_ovl, u64 n, u32 n_reads, u32* d_off);
+void polish_map_best(Engine& e, ReadsDev& T, ReadsDev& R, u32 r_first, u32 r_last, double err_thr,
+                     std::vector<Overlap>& best, std::vector<u32>& best_t, u64* n_overlaps);
 void polish_round(Engine& e, ReadsDev& T, ReadsDev& R, const u8* h_quals, const u64* h_qual_off, double q_thr,
                   double err_thr, u32 w, bool trim, int m, int n, int g, std::vector<std::vector<u8>>& polished,
                   std::vector<double>& ratio, PolishStats& stats, u64 win_first = 0, u64 win_last = ~0ULL,

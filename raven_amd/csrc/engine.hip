@@ -164,7 +164,7 @@ void engine_release_scratch(Engine& e) {
       &e.map_out.anchor_cnt, &e.tmp_a, &e.tmp_b, &e.tmp_c, &e.tmp_d, &e.tmp_e, &e.tmp_f, &e.scan_tmp, &e.sort_tmp,
       &e.q_start, &e.q_cnt, &e.m_off, &e.m_grp[0], &e.m_grp[1], &e.m_pos[0], &e.m_pos[1], &e.seg_off, &e.iv_slot_begin,
       &e.iv_slot_end, &e.iv_cnt, &e.iv_off, &e.iv_begin, &e.iv_end, &e.lis_min, &e.lis_pred, &e.lis_tail, &e.lis_mask,
-      &e.ovl_slots, &e.ovl_flags, &e.ovl_scan, &e.chain_big, &e.poa_scratch, &e.poa2_scratch, &e.polish_quals, &e.ed_cnt, &e.ed_sort, &e.ed_todo, &e.p2_slot,
+      &e.ovl_slots, &e.ovl_flags, &e.ovl_scan, &e.chain_big, &e.sh_hist, &e.sh_off, &e.sh_ptrs, &e.poa_scratch, &e.poa2_scratch, &e.polish_quals, &e.ed_cnt, &e.ed_sort, &e.ed_todo, &e.p2_slot,
       &e.p2_pairs, &e.p2_dist, &e.p2_regions, &e.p2_index_of, &e.p2_kmers_off, &e.p2_ok, &e.p2_keep, &e.p2_tmp_ovl,
       &e.poa_sched, &e.poa_redo_w, &e.poa_redo_i, &e.nw_pm, &e.nw_sc, &e.nw_ck_pm, &e.nw_ck_sc, &e.nw_jobs, &e.nw_res,
       &e.pl_best, &e.pl_best_t, &e.pl_idmap, &e.pl_recs, &e.pl_keep, &e.pl_win_cnt, &e.pl_win_off, &e.pl_win_fill,
@@ -929,6 +929,37 @@ int rvn_poa_consensus_batch(rvn_engine* h, const uint8_t* codes, const uint8_t* 
   });
 }
 
+int rvn_polish_map_best(rvn_engine* h, rvn_reads* targets, rvn_reads* reads, uint32_t read_first, uint32_t read_last,
+                        double err, rvn_overlap* best, uint32_t* best_target, uint64_t* n_overlaps) {
+  return guarded(h ? &h->e : nullptr, [&]() -> int {
+    if (!h || !targets || !reads || !best || !best_target) return fail(RVN_EINVAL, "[raven_hip] rvn_polish_map_best: NULL argument");
+    if (read_first > read_last || read_last > reads->r.n) return fail(RVN_EINVAL, "[raven_hip] rvn_polish_map_best: bad read range");
+    RVN_HIP(hipSetDevice(h->e.device));
+    UseTimers ut(h->e);
+    engine_release_scratch_if_tight(h->e);
+    std::vector<Overlap> b;
+    std::vector<u32> bt;
+    u64 n = 0;
+    polish_map_best(h->e, targets->r, reads->r, read_first, read_last, err, b, bt, &n);
+    if (!b.empty()) std::memcpy(best, b.data(), b.size() * sizeof(Overlap));
+    if (!bt.empty()) std::memcpy(best_target, bt.data(), bt.size() * 4);
+    if (n_overlaps) *n_overlaps = n;
+    return RVN_OK;
+  });
+}
+
+int rvn_polish_set_best(rvn_engine* h, const rvn_overlap* best, const uint32_t* best_target, uint32_t n_reads) {
+  return guarded(h ? &h->e : nullptr, [&]() -> int {
+    if (!h || (n_reads && (!best || !best_target))) return fail(RVN_EINVAL, "[raven_hip] rvn_polish_set_best: NULL argument");
+    Engine& e = h->e;
+    e.polish_given_best.resize(n_reads);
+    e.polish_given_best_t.assign(best_target, best_target + n_reads);
+    if (n_reads) std::memcpy(e.polish_given_best.data(), best, static_cast<size_t>(n_reads) * sizeof(Overlap));
+    e.polish_given_valid = true;
+    return RVN_OK;
+  });
+}
+
 int rvn_polish_round(rvn_engine* h, rvn_reads* targets, rvn_reads* reads, const uint8_t* read_quals,
                      const uint64_t* qual_offsets, double q, double err, uint32_t w, int trim, int match, int mismatch,
                      int gap, uint8_t* out_codes, const uint64_t* out_offsets, uint32_t* out_len, double* ratio,
@@ -1354,6 +1385,95 @@ int rvn_shard_piles_dev(rvn_engine* h, const uint32_t* lengths, uint32_t n_reads
   }
   *out = p;
   return RVN_OK;
+}
+
+// ---- partition / regroup steps of the sharded pass on device pointers (shard.hip) ----
+int rvn_shard_split_minimizers_dev(rvn_engine* h, const uint64_t* d_values, const uint64_t* d_origins, uint64_t n,
+                                   uint32_t world, uint64_t* d_values_out, uint64_t* d_origins_out, uint64_t* counts) {
+  return guarded(h ? &h->e : nullptr, [&]() -> int {
+    if (!h || !counts || world == 0 || world > 16 || (n && (!d_values || !d_origins || !d_values_out || !d_origins_out)))
+      return fail(RVN_EINVAL, "[raven_hip] rvn_shard_split_minimizers_dev: bad argument");
+    RVN_HIP(hipSetDevice(h->e.device));
+    UseTimers ut(h->e);
+    shard_split_minimizers(h->e, d_values, d_origins, n, world, d_values_out, d_origins_out, counts);
+    return RVN_OK;
+  });
+}
+
+int rvn_shard_split_overlaps_dev(rvn_engine* h, const rvn_overlap* d_overlaps, uint64_t n, const uint32_t* bounds,
+                                 uint32_t world, uint32_t self, rvn_overlap* d_out, uint64_t* counts) {
+  return guarded(h ? &h->e : nullptr, [&]() -> int {
+    if (!h || !counts || !bounds || world == 0 || world > 16 || self >= world || (n && (!d_overlaps || !d_out)))
+      return fail(RVN_EINVAL, "[raven_hip] rvn_shard_split_overlaps_dev: bad argument");
+    RVN_HIP(hipSetDevice(h->e.device));
+    UseTimers ut(h->e);
+    shard_split_overlaps(h->e, reinterpret_cast<const Overlap*>(d_overlaps), n, bounds, world, self,
+                         reinterpret_cast<Overlap*>(d_out), counts);
+    return RVN_OK;
+  });
+}
+
+int rvn_shard_count_flagged_dev(rvn_engine* h, const uint64_t* d_origins, uint64_t n, uint64_t* count) {
+  return guarded(h ? &h->e : nullptr, [&]() -> int {
+    if (!h || !count || (n && !d_origins)) return fail(RVN_EINVAL, "[raven_hip] rvn_shard_count_flagged_dev: bad argument");
+    RVN_HIP(hipSetDevice(h->e.device));
+    *count = shard_count_flagged(h->e, d_origins, n);
+    return RVN_OK;
+  });
+}
+
+int rvn_shard_adjacent_diff_dev(rvn_engine* h, const uint64_t* d_seg_off, uint64_t n, uint64_t* d_counts) {
+  return guarded(h ? &h->e : nullptr, [&]() -> int {
+    if (!h || (n && (!d_seg_off || !d_counts))) return fail(RVN_EINVAL, "[raven_hip] rvn_shard_adjacent_diff_dev: bad argument");
+    RVN_HIP(hipSetDevice(h->e.device));
+    shard_adjacent_diff(h->e, d_seg_off, n, d_counts);
+    RVN_HIP(hipStreamSynchronize(h->e.stream));
+    return RVN_OK;
+  });
+}
+
+int rvn_shard_regroup_dev(rvn_engine* h, uint32_t world, const uint64_t* const* d_counts, const uint64_t* const* d_group,
+                          const uint64_t* const* d_positions, const uint64_t* n_per_source, uint32_t n_reads,
+                          uint64_t* d_seg_off, uint64_t* d_group_out, uint64_t* d_positions_out) {
+  return guarded(h ? &h->e : nullptr, [&]() -> int {
+    if (!h || world == 0 || world > 16 || !d_counts || !d_group || !d_positions || !n_per_source || !d_seg_off)
+      return fail(RVN_EINVAL, "[raven_hip] rvn_shard_regroup_dev: bad argument");
+    RVN_HIP(hipSetDevice(h->e.device));
+    UseTimers ut(h->e);
+    shard_regroup(h->e, world, d_counts, d_group, d_positions, n_per_source, n_reads, d_seg_off, d_group_out, d_positions_out);
+    RVN_HIP(hipStreamSynchronize(h->e.stream));
+    return RVN_OK;
+  });
+}
+
+int rvn_shard_piles_merge_parts_dev(rvn_pass1* p, uint32_t n_parts, const rvn_overlap* const* d_parts,
+                                    const uint64_t* n_per_part, uint32_t kmax) {
+  return guarded(p ? p->e : nullptr, [&]() -> int {
+    if (!p || !p->meta || (n_parts && (!d_parts || !n_per_part)))
+      return fail(RVN_EINVAL, "[raven_hip] rvn_shard_piles_merge_parts_dev: bad handle or NULL argument");
+    Engine& e = *p->e;
+    RVN_HIP(hipSetDevice(e.device));
+    UseTimers ut(e);
+    const u32 n_reads_total = p->meta->n;
+    u64 n = 0;
+    for (u32 i = 0; i < n_parts; ++i) n += n_per_part[i];
+    MapOut mo;
+    mo.first = 0;
+    mo.last = n_reads_total;
+    mo.n_overlaps = n;
+    Overlap* d_ov = mo.ovl.get<Overlap>(n + 1);
+    u64 at = 0;
+    for (u32 i = 0; i < n_parts; ++i) {  // parts in ascending lhs-owner order: the list stays grouped by lhs read
+      if (n_per_part[i])
+        RVN_HIP(hipMemcpyAsync(d_ov + at, d_parts[i], n_per_part[i] * sizeof(Overlap), hipMemcpyDeviceToDevice, e.stream));
+      at += n_per_part[i];
+    }
+    u32* d_off = mo.ovl_read_off.get<u32>(static_cast<size_t>(n_reads_total) + 1);
+    shard_lhs_offsets(e, d_ov, n, n_reads_total, d_off);
+    piles_merge(e, *p->meta, mo, kmax, p->ps);
+    RVN_HIP(hipStreamSynchronize(e.stream));
+    return RVN_OK;
+  });
 }
 
 uint64_t rvn_polish_set_chunk_windows(rvn_engine* h, uint64_t windows) {

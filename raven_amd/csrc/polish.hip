@@ -237,32 +237,20 @@ __global__ __launch_bounds__(256) void stitch_kernel(const PoaWindow* __restrict
 
 }  // namespace
 
-void polish_round(Engine& e, ReadsDev& T, ReadsDev& R, const u8* h_quals, const u64* h_qual_off, double q_thr,
-                  double err_thr, u32 w, bool trim, int m, int n, int g, std::vector<std::vector<u8>>& polished,
-                  std::vector<double>& ratio, PolishStats& stats, u64 win_first, u64 win_last,
-                  std::vector<u32>* win_count, std::vector<u32>* win_polished) {
+// Step 1 of a racon round for the reads [r_first, r_last): index the targets, map the reads (batches of about 1 GB as in
+// racon), keep the best overlap of every read (longest, error filter `err_thr`; racon Polisher::Initialize).
+// best[i] / best_t[i] describe read r_first + i; best_t == 0xFFFFFFFF: the read is not used.  Reads are independent of
+// each other here, which is what lets the sharded round map a slice per rank and all-gather the (small) table.
+void polish_map_best(Engine& e, ReadsDev& T, ReadsDev& R, u32 r_first, u32 r_last, double err_thr,
+                     std::vector<Overlap>& best, std::vector<u32>& best_t, u64* n_overlaps) {
   hipStream_t s = e.stream;
-  using clk = std::chrono::steady_clock;
-  auto ms_since = [](clk::time_point a) { return std::chrono::duration<double, std::milli>(clk::now() - a).count(); };
-  const auto t_all = clk::now();
-  const bool dbg = std::getenv("RVN_POLISH_DEBUG") != nullptr;
-  auto lap = [&, last = clk::now()](const char* what) mutable {
-    if (dbg) {
-      (void)hipStreamSynchronize(s);
-      std::fprintf(stderr, "[raven_hip] polish: %-32s %8.1f ms\n", what, ms_since(last));
-    }
-    last = clk::now();
-  };
-  polished.assign(T.n, {});
-  ratio.assign(T.n, 0.0);
-  stats = PolishStats();
-  e.polish_target_reads.assign(T.n, 0);
-  if (win_count) win_count->assign(T.n, 0);
-  if (win_polished) win_polished->assign(T.n, 0);
-  if (T.n == 0) return;
-  double host_ms = 0;
-
-  // ---- 1. map the reads to the targets; best overlap per read (device) ---------------------------------------------
+  r_last = std::min(r_last, R.n);
+  r_first = std::min(r_first, r_last);
+  const u32 nr_all = r_last - r_first;
+  best.assign(nr_all, Overlap{});
+  best_t.assign(nr_all, 0xFFFFFFFFu);
+  if (n_overlaps) *n_overlaps = 0;
+  if (T.n == 0 || nr_all == 0) return;
   {
     StageTimer t(e, StageTimes::kSketch);
     e.query_ready = false;
@@ -289,13 +277,13 @@ void polish_round(Engine& e, ReadsDev& T, ReadsDev& R, const u8* h_quals, const 
   try {
     // racon maps its reads in batches of about 1 GB; the match / overlap memory of a round is that of one batch
     u64 bases = 0;
-    for (u32 r0 = 0, r = 0; r < R.n; ++r) {
+    for (u32 r0 = r_first, r = r_first; r < r_last; ++r) {
       bases += R.h_len[r];
-      if (r != R.n - 1 && bases < (1ULL << 30)) continue;
+      if (r != r_last - 1 && bases < (1ULL << 30)) continue;
       bases = 0;
       MapOut& mo = e.map_out;
       map_batch(e, R, r0, r + 1, false, false, false, false, mo);
-      stats.n_overlaps += mo.n_overlaps;
+      if (n_overlaps) *n_overlaps += mo.n_overlaps;
       const u32 nr = r + 1 - r0;
       RVN_KLAUNCH(kKBestOverlap, best_overlap_kernel<<<div_up(nr, 256), 256, 0, s>>>(
                                      mo.ovl.as<Overlap>(), mo.ovl_read_off.as<u32>(), r0, nr, err_thr,
@@ -307,13 +295,53 @@ void polish_round(Engine& e, ReadsDev& T, ReadsDev& R, const u8* h_quals, const 
     throw;
   }
   e.keep_anchors = keep;
-  std::vector<Overlap> best(R.n);
-  std::vector<u32> best_t(R.n);
-  if (R.n) {
-    RVN_HIP(hipMemcpyAsync(best.data(), d_best, static_cast<size_t>(R.n) * sizeof(Overlap), hipMemcpyDeviceToHost, s));
-    RVN_HIP(hipMemcpyAsync(best_t.data(), d_best_t, static_cast<size_t>(R.n) * 4, hipMemcpyDeviceToHost, s));
-  }
+  RVN_HIP(hipMemcpyAsync(best.data(), d_best + r_first, static_cast<size_t>(nr_all) * sizeof(Overlap), hipMemcpyDeviceToHost, s));
+  RVN_HIP(hipMemcpyAsync(best_t.data(), d_best_t + r_first, static_cast<size_t>(nr_all) * 4, hipMemcpyDeviceToHost, s));
   RVN_HIP(hipStreamSynchronize(s));
+}
+
+void polish_round(Engine& e, ReadsDev& T, ReadsDev& R, const u8* h_quals, const u64* h_qual_off, double q_thr,
+                  double err_thr, u32 w, bool trim, int m, int n, int g, std::vector<std::vector<u8>>& polished,
+                  std::vector<double>& ratio, PolishStats& stats, u64 win_first, u64 win_last,
+                  std::vector<u32>* win_count, std::vector<u32>* win_polished) {
+  hipStream_t s = e.stream;
+  using clk = std::chrono::steady_clock;
+  auto ms_since = [](clk::time_point a) { return std::chrono::duration<double, std::milli>(clk::now() - a).count(); };
+  const auto t_all = clk::now();
+  const bool dbg = std::getenv("RVN_POLISH_DEBUG") != nullptr;
+  auto lap = [&, last = clk::now()](const char* what) mutable {
+    if (dbg) {
+      (void)hipStreamSynchronize(s);
+      std::fprintf(stderr, "[raven_hip] polish: %-32s %8.1f ms\n", what, ms_since(last));
+    }
+    last = clk::now();
+  };
+  polished.assign(T.n, {});
+  ratio.assign(T.n, 0.0);
+  stats = PolishStats();
+  e.polish_target_reads.assign(T.n, 0);
+  if (win_count) win_count->assign(T.n, 0);
+  if (win_polished) win_polished->assign(T.n, 0);
+  if (T.n == 0) return;
+  double host_ms = 0;
+
+  // ---- 1. map the reads to the targets; best overlap per read (device), unless the caller supplies the table -----------
+  std::vector<Overlap> best;
+  std::vector<u32> best_t;
+  if (e.polish_given_valid) {  // rvn_polish_set_best: the sharded round maps a slice of the reads per rank
+    if (e.polish_given_best.size() != R.n)
+      throw std::invalid_argument("[raven_hip] polishing round: the supplied best-overlap table does not match the read set");
+    best.swap(e.polish_given_best);
+    best_t.swap(e.polish_given_best_t);
+    e.polish_given_valid = false;
+    for (u32 r = 0; r < R.n; ++r)
+      if (best_t[r] != 0xFFFFFFFFu && best_t[r] >= T.n)
+        throw std::invalid_argument("[raven_hip] polishing round: best-overlap table names a target that does not exist");
+  } else {
+    u64 n_ovl = 0;
+    polish_map_best(e, T, R, 0, R.n, err_thr, best, best_t, &n_ovl);
+    stats.n_overlaps = n_ovl;
+  }
   stats.map_ms = ms_since(t_all);
   lap("index + map + best overlap");
 

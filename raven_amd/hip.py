@@ -33,11 +33,13 @@ SYMBOLS = [
     "rvn_engine_map_batch", "rvn_engine_map_fetch", "rvn_engine_map_fetch_filtered",
     "rvn_find_overlaps_and_create_piles", "rvn_pass1_pile_words", "rvn_pass1_num_overlaps",
     "rvn_pass1_fetch_piles", "rvn_pass1_fetch_overlaps", "rvn_pass1_destroy", "rvn_pile_add_layers",
-    "rvn_edit_distance_batch", "rvn_poa_consensus_batch", "rvn_pass1_trim_and_annotate", "rvn_poa_phase_cycles", "rvn_polish_target_reads", "rvn_polish_set_chunk_windows", "rvn_polish_round_range", "rvn_shard_sketch", "rvn_shard_sketch_fetch",
+    "rvn_edit_distance_batch", "rvn_poa_consensus_batch", "rvn_pass1_trim_and_annotate", "rvn_poa_phase_cycles", "rvn_polish_target_reads", "rvn_polish_set_chunk_windows", "rvn_polish_round_range", "rvn_polish_map_best", "rvn_polish_set_best", "rvn_shard_sketch", "rvn_shard_sketch_fetch",
     "rvn_shard_index_build", "rvn_shard_key_counts", "rvn_engine_set_occurrence", "rvn_shard_join",
     "rvn_shard_join_fetch", "rvn_shard_chain", "rvn_shard_piles", "rvn_shard_join_range", "rvn_shard_piles_create",
     "rvn_shard_piles_merge", "rvn_shard_piles_merge_dev", "rvn_shard_sketch_fetch_dev",
     "rvn_shard_index_build_dev", "rvn_shard_key_histogram", "rvn_shard_join_fetch_dev", "rvn_shard_chain_dev",
+    "rvn_shard_split_minimizers_dev", "rvn_shard_count_flagged_dev", "rvn_shard_adjacent_diff_dev", "rvn_shard_regroup_dev",
+    "rvn_shard_split_overlaps_dev", "rvn_shard_piles_merge_parts_dev",
     "rvn_engine_map_fetch_dev", "rvn_shard_piles_dev", "rvn_poa_set_mode", "rvn_poa_fallback_windows", "rvn_poa_wide_windows", "rvn_pile_add_kmers_batch",
     "rvn_test_low_complexity", "rvn_test_nw_breakpoints", "rvn_reads_attach_quality", "rvn_polish_fetch_layers", "rvn_poa_work", "rvn_reads_upload_codes", "rvn_polish_round",
     "rvn_engine_sketch", "rvn_engine_sketch_fetch", "rvn_engine_index_size", "rvn_engine_index_fetch",
@@ -289,6 +291,15 @@ class Pass1:
         overlaps = np.ascontiguousarray(overlaps, dtype=OVERLAP_DTYPE)
         _check(lib().rvn_shard_piles_merge(self._h, _p(overlaps), overlaps.shape[0], kmax))
 
+    def merge_parts_dev(self, parts, kmax=32):
+        """rvn_shard_piles_merge_parts_dev: parts = [(device pointer, number of overlaps), ...] in ascending lhs order."""
+        n = len(parts)
+        ptrs = (C.c_void_p * max(n, 1))(*[int(a) for a, _ in parts])
+        cnts = (C.c_uint64 * max(n, 1))(*[int(c) for _, c in parts])
+        L = lib()
+        L.rvn_shard_piles_merge_parts_dev.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32]
+        _check(L.rvn_shard_piles_merge_parts_dev(self._h, n, ptrs, cnts, kmax))
+
     def merge_dev(self, d_overlaps, d_read_off, n, kmax=32):
         _check(lib().rvn_shard_piles_merge_dev(self._h, d_overlaps, d_read_off, int(n), kmax))
 
@@ -515,6 +526,46 @@ class Engine:
                                           query_last, C.byref(h)))
         return int(h.value)
 
+    # partition / regroup steps of the sharded pass on device pointers (shard.hip)
+    def shard_split_minimizers_dev(self, d_val, d_org, n, world, d_val_out, d_org_out):
+        counts = (C.c_uint64 * world)()
+        L = lib()
+        L.rvn_shard_split_minimizers_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32,
+                                                     C.c_void_p, C.c_void_p, C.c_void_p]
+        _check(L.rvn_shard_split_minimizers_dev(self._h, d_val, d_org, int(n), world, d_val_out, d_org_out, counts))
+        return [int(x) for x in counts]
+
+    def shard_count_flagged_dev(self, d_org, n) -> int:
+        c = C.c_uint64(0)
+        L = lib()
+        L.rvn_shard_count_flagged_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+        _check(L.rvn_shard_count_flagged_dev(self._h, d_org, int(n), C.byref(c)))
+        return int(c.value)
+
+    def shard_adjacent_diff_dev(self, d_seg, n, d_cnt):
+        L = lib()
+        L.rvn_shard_adjacent_diff_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+        _check(L.rvn_shard_adjacent_diff_dev(self._h, d_seg, int(n), d_cnt))
+
+    def shard_regroup_dev(self, d_cnt, d_grp, d_pos, n_src, n_reads, d_seg, d_grp_out, d_pos_out):
+        world = len(d_cnt)
+        arr = lambda xs: (C.c_void_p * world)(*[int(x) for x in xs])
+        ns = (C.c_uint64 * world)(*[int(x) for x in n_src])
+        L = lib()
+        L.rvn_shard_regroup_dev.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+        _check(L.rvn_shard_regroup_dev(self._h, world, arr(d_cnt), arr(d_grp), arr(d_pos), ns, int(n_reads), d_seg,
+                                       d_grp_out, d_pos_out))
+
+    def shard_split_overlaps_dev(self, d_ovl, n, bounds, world, self_rank, d_out):
+        b = np.ascontiguousarray(bounds, dtype=np.uint32)
+        counts = (C.c_uint64 * (world + 1))()
+        L = lib()
+        L.rvn_shard_split_overlaps_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_uint32,
+                                                   C.c_void_p, C.c_void_p]
+        _check(L.rvn_shard_split_overlaps_dev(self._h, d_ovl, int(n), _p(b), world, self_rank, d_out, counts))
+        return [int(x) for x in counts]
+
     def shard_join_fetch_dev(self, d_grp, d_pos, d_seg):
         _check(lib().rvn_shard_join_fetch_dev(self._h, d_grp, d_pos, d_seg))
 
@@ -566,6 +617,31 @@ class Engine:
                                         _p(out_len), None, _p(nw), _p(npol), _p(stats)))
         cons = [out[int(ooff[i]): int(ooff[i]) + int(out_len[i])].copy() for i in range(nt)]
         return cons, nw, npol, {"n_windows": int(stats[3]), "n_layers": int(stats[2])}
+
+    def polish_map_best(self, targets: Reads, reads: Reads, read_first=0, read_last=None, err=0.3):
+        """First step of a round for the reads [read_first, read_last): (best overlaps [n, 8] uint32 rows of rvn_overlap,
+        best target index per read uint32 with 0xFFFFFFFF = unused, number of overlaps found)."""
+        read_last = reads.n if read_last is None else int(read_last)
+        n = read_last - int(read_first)
+        best = np.zeros((max(n, 1), 8), dtype=np.uint32)
+        bt = np.zeros(max(n, 1), dtype=np.uint32)
+        n_ovl = C.c_uint64(0)
+        L = lib()
+        L.rvn_polish_map_best.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_double,
+                                          C.c_void_p, C.c_void_p, C.c_void_p]
+        _check(L.rvn_polish_map_best(self._h, targets._h, reads._h, int(read_first), read_last, float(err), _p(best),
+                                     _p(bt), C.byref(n_ovl)))
+        return best[:n], bt[:n], int(n_ovl.value)
+
+    def polish_set_best(self, best, best_target):
+        """Hands the complete best-overlap table to the next polish_round / polish_round_range call (which then skips
+        its own mapping)."""
+        best = np.ascontiguousarray(best, dtype=np.uint32).reshape(-1, 8)
+        bt = np.ascontiguousarray(best_target, dtype=np.uint32)
+        assert best.shape[0] == bt.shape[0]
+        L = lib()
+        L.rvn_polish_set_best.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
+        _check(L.rvn_polish_set_best(self._h, _p(best), _p(bt), int(bt.shape[0])))
 
     # -- second mapping pass and identity filter (construct.cc:316-491, :162-217) ------------------------------------
     def find_overlaps_and_repetitive_regions(self, reads: Reads, pile_begin, pile_end, pile_invalid, freq=0.001,

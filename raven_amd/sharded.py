@@ -292,10 +292,33 @@ class DeviceComm(Comm):
         return list(torch.split(out, out_l))
 
 
+def _all_to_all_flat_t(self, flat, send_lens):
+    """flat: 1-D int64 CUDA tensor holding the parts for ranks 0..world-1 back to back (send_lens elements each).
+    Returns (flat receive tensor, receive lengths by source rank)."""
+    import torch
+    send_lens = [int(x) for x in send_lens]
+    if self.dist is None:
+        return flat[:send_lens[0]], [send_lens[0]]
+    dev = flat.device
+    cnt_in = torch.tensor(send_lens, dtype=torch.int64, device=dev)
+    cnt_out = torch.zeros(self.world, dtype=torch.int64, device=dev)
+    self.dist.all_to_all_single(cnt_out, cnt_in)
+    out_l = [int(x) for x in cnt_out.tolist()]
+    out = torch.empty(sum(out_l), dtype=torch.int64, device=dev)
+    self.dist.all_to_all_single(out, flat[:sum(send_lens)].contiguous(), out_l, send_lens)
+    self.bytes_sent += 8 * sum(c for i, c in enumerate(send_lens) if i != self.rank)
+    return out, out_l
+
+
+DeviceComm.all_to_all_flat_t = _all_to_all_flat_t
+
+
 def find_overlaps_and_create_piles_sharded_dev(eng, rs_all: seqio.ReadSet, comm, device, freq=0.001, kmax=32,
-                                               use_minhash=False, flush_bases=1 << 30):
+                                               use_minhash=False, flush_bases=1 << 30, own=None, laps=None, fetch=True):
     """find_overlaps_and_create_piles_sharded with every exchange buffer resident in HBM (`device`: torch device of
-    the engine's GPU; `comm`: DeviceComm or a test double with all_to_all_t / all_reduce_sum / all_gather_v)."""
+    the engine's GPU; `comm`: DeviceComm or a test double with all_to_all_t / all_reduce_sum / all_gather_v).
+    torch allocates the exchange buffers and carries the collectives; partitioning by owner, regrouping per read and
+    the merge offsets are the engine's own kernels (raven_amd/csrc/shard.hip)."""
     import torch
     g, world = comm.rank, comm.world
     n_total = rs_all.n
@@ -303,99 +326,149 @@ def find_overlaps_and_create_piles_sharded_dev(eng, rs_all: seqio.ReadSet, comm,
         raise ValueError("sharded pass: one index batch only (total bases must be < 2^32)")
     bounds = partition_reads(rs_all.lengths, world)
     lo, hi = int(bounds[g]), int(bounds[g + 1])
-    own = eng.upload(slice_reads(rs_all, lo, hi))
+    if own is None:  # `own`: this rank's reads already resident (uploaded once, as a caller running several passes does)
+        own = eng.upload(slice_reads(rs_all, lo, hi))
     i64 = dict(dtype=torch.int64, device=device)
+    import time as _time
+    _t = [_time.perf_counter()]
 
-    # 1. sketch; minimizers to the owner of their hash class (stable sort keeps (read, position) order)
+    def lap(name):  # laps: optional dict collecting wall time per stage (synchronising: debugging / DESIGN.md numbers)
+        if laps is not None:
+            torch.cuda.synchronize(device)
+            now = _time.perf_counter()
+            laps[name] = laps.get(name, 0.0) + (now - _t[0])
+            _t[0] = now
+
+    def sync():
+        # the engine works on its own stream: before it WRITES into freshly allocated torch memory (which the caching
+        # allocator may have recycled from tensors with torch / RCCL work still in flight) and before it READS what a
+        # collective produced, the device is synchronised
+        torch.cuda.synchronize(device)
+
+    # 1. sketch; minimizers to the owner of their hash class (stable partition keeps (read, position) order)
     n = eng.shard_sketch_count(own, index_minhash=use_minhash)
     val, org = torch.empty(n, **i64), torch.empty(n, **i64)
-    # rule of this function: the engine works on its own stream, so before it WRITES into freshly allocated torch memory
-    # (which the caching allocator may have recycled from tensors with torch work still in flight) and before it READS
-    # tensors torch produced, the device is synchronised
-    torch.cuda.synchronize(device)
+    val_p, org_p = (torch.empty(n, **i64), torch.empty(n, **i64)) if world > 1 else (None, None)
+    sync()
     eng.shard_sketch_fetch_dev(val.data_ptr(), org.data_ptr())
-    owner = hash_owner_t(val, world)
-    order = torch.sort(owner, stable=True).indices
-    cnt = torch.bincount(owner, minlength=world).tolist()
-    val_r = comm.all_to_all_t(list(torch.split(val[order], cnt)))
-    org_r = comm.all_to_all_t(list(torch.split(org[order], cnt)))
-    vcat, ocat = torch.cat(val_r).contiguous(), torch.cat(org_r).contiguous()
+    if world == 1:  # one owner: nothing to partition
+        val_p, org_p, cnt = val, org, [n]
+    else:
+        cnt = eng.shard_split_minimizers_dev(val.data_ptr(), org.data_ptr(), n, world, val_p.data_ptr(), org_p.data_ptr())
+    del val, org
+    vcat = comm.all_to_all_flat_t(val_p, cnt)[0]
+    ocat = comm.all_to_all_flat_t(org_p, cnt)[0]
+    del val_p, org_p
+    lap("sketch+split+exchange1")
 
     # 2. index shard; 3. exact global Filter
-    n_flagged = int((ocat < 0).sum().item())
-    torch.cuda.synchronize(device)
+    sync()
+    n_flagged = eng.shard_count_flagged_dev(ocat.data_ptr(), ocat.shape[0])
     eng.shard_index_build_dev(vcat.data_ptr(), ocat.data_ptr(), vcat.shape[0], use_minhash, n_flagged)
     hist, over = eng.shard_key_histogram()
     occ = occurrence_from_histogram(hist, over, freq, comm)
     eng.set_occurrence(occ)
+    lap("index+filter")
 
     # 4.-6. per flush window of query reads (merge + AddLayers + truncation per window, as the reference flushes)
     b_list = [int(x) for x in bounds]
-    bounds_t = torch.tensor(b_list, **i64)
     r_split = [b_list[h + 1] - b_list[h] for h in range(world)]
+    n_own = hi - lo
     p = eng.shard_piles_create(rs_all.lengths)
     n_matches_sent = n_sent = n_map = 0
     for q_a, q_b in flush_windows(rs_all.lengths, flush_bases):
         n_m = eng.shard_join_count(n_total, True, True, q_a, q_b)
         grp, pos = torch.empty(n_m, **i64), torch.empty(n_m, **i64)
         seg = torch.empty(n_total + 1, **i64)
-        torch.cuda.synchronize(device)
+        per_read = torch.empty(n_total, **i64)
+        sync()
         eng.shard_join_fetch_dev(grp.data_ptr(), pos.data_ptr(), seg.data_ptr())
-        per_read = seg[1:] - seg[:-1]
-        m_cuts = seg[bounds_t].tolist()
+        eng.shard_adjacent_diff_dev(seg.data_ptr(), n_total, per_read.data_ptr())
+        lap("join")
+        m_cuts = seg[b_list].tolist()  # matches are in read order: the cut points of the read ranges
         m_split = [int(m_cuts[h + 1] - m_cuts[h]) for h in range(world)]
-        cnt_r = comm.all_to_all_t(list(torch.split(per_read, r_split)))
-        grp_r = comm.all_to_all_t(list(torch.split(grp, m_split)))
-        pos_r = comm.all_to_all_t(list(torch.split(pos, m_split)))
-        seg_own, (grp_own, pos_own) = regroup_by_read_t(cnt_r, list(zip(grp_r, pos_r)))
+        cnt_flat, cnt_lens = comm.all_to_all_flat_t(per_read, r_split)
+        grp_flat, m_lens = comm.all_to_all_flat_t(grp, m_split)
+        pos_flat, _ = comm.all_to_all_flat_t(pos, m_split)
+        n_in = sum(m_lens)
+        seg_own = torch.empty(n_own + 1, **i64)
+        grp_own, pos_own = torch.empty(n_in, **i64), torch.empty(n_in, **i64)
+        sync()
+        c_ptr, g_ptr, p_ptr, at_c, at_m = [], [], [], 0, 0
+        for h in range(world):  # per-source views into the flat receive buffers
+            c_ptr.append(cnt_flat.data_ptr() + 8 * at_c)
+            g_ptr.append(grp_flat.data_ptr() + 8 * at_m)
+            p_ptr.append(pos_flat.data_ptr() + 8 * at_m)
+            at_c += cnt_lens[h]
+            at_m += m_lens[h]
+        eng.shard_regroup_dev(c_ptr, g_ptr, p_ptr, m_lens, n_own, seg_own.data_ptr(), grp_own.data_ptr(), pos_own.data_ptr())
         n_matches_sent += int(n_m - m_split[g])
+        lap("exchange2+regroup")
         # chain
-        torch.cuda.synchronize(device)
-        n_o = eng.shard_chain_dev(own, grp_own.data_ptr(), pos_own.data_ptr(), seg_own.data_ptr(), grp_own.shape[0])
+        n_o = eng.shard_chain_dev(own, grp_own.data_ptr(), pos_own.data_ptr(), seg_own.data_ptr(), n_in)
         ovl = torch.empty((n_o, 4), **i64)
+        ovl_p = torch.empty((n_o, 4), **i64)
         off_own = torch.empty(own.n + 1, dtype=torch.int32, device=device)
-        torch.cuda.synchronize(device)
+        sync()
         eng.map_fetch_dev(ovl.data_ptr(), off_own.data_ptr())
         n_map += int(n_o)
-        # overlaps also to the owner of their rhs read; merge + piles
-        rhs = (ovl[:, 1] >> 32) & 0xFFFFFFFF
-        rhs_owner = torch.searchsorted(bounds_t, rhs, right=True) - 1
-        parts = [ovl[rhs_owner == h].reshape(-1) if h != g else torch.zeros(0, **i64) for h in range(world)]
-        n_sent += sum(int(x.shape[0]) for x in parts) // 4
-        recv = comm.all_to_all_t(parts)
+        lap("chain")
+        # overlaps also to the owner of their rhs read (stable partition; the own ones stay); merge + piles
+        o_cnt = eng.shard_split_overlaps_dev(ovl.data_ptr(), n_o, b_list, world, g, ovl_p.data_ptr())
+        send = [4 * c for c in o_cnt[:world]]
+        n_sent += sum(o_cnt[:world])
+        recv_flat, recv_lens = comm.all_to_all_flat_t(ovl_p.reshape(-1)[:sum(send)], send)
         for s_ in range(g + 1, world):
-            assert recv[s_].shape[0] == 0, "avoid_symmetric: overlaps only travel to higher ranks"
-        combined = torch.cat([recv[s_].reshape(-1, 4) for s_ in range(g)] + [ovl]).contiguous() if world > 1 else ovl
-        lhs = combined[:, 0] & 0xFFFFFFFF
-        off_all = torch.zeros(n_total + 1, **i64)
-        if combined.shape[0]:
-            torch.cumsum(torch.bincount(lhs, minlength=n_total), 0, out=off_all[1:])
-        off32 = off_all.to(torch.int32).contiguous()
-        torch.cuda.synchronize(device)
-        p.merge_dev(combined.data_ptr(), off32.data_ptr(), combined.shape[0], kmax)
+            assert recv_lens[s_] == 0, "avoid_symmetric: overlaps only travel to higher ranks"
+        sync()
+        parts, at = [], 0
+        for s_ in range(world):
+            if recv_lens[s_]:
+                parts.append((recv_flat.data_ptr() + 8 * at, recv_lens[s_] // 4))
+            at += recv_lens[s_]
+        parts.append((ovl.data_ptr(), n_o))
+        p.merge_parts_dev(parts, kmax)
+        lap("exchange3+merge")
+    stats = dict(minimizers_sent=int(n - cnt[g]), matches_sent=n_matches_sent, overlaps_sent=int(n_sent),
+                 map_overlaps=n_map, bytes_sent=comm.bytes_sent)
+    if not fetch:  # the piles and overlap lists of this rank's reads stay in HBM: p.piles() / p.overlaps() / p.close()
+        return dict(lo=lo, hi=hi, occurrence=occ, pass1=p, stats=stats)
     data, poff = p.piles()
     kept, koff = p.overlaps()
     p.close()
+    lap("fetch piles+overlaps")
     return dict(lo=lo, hi=hi, occurrence=occ,
                 pile_data=data[int(poff[lo]):int(poff[hi])].copy(),
                 pile_off=(poff[lo:hi + 1] - poff[lo]).astype(np.uint64),
                 overlaps=kept[int(koff[lo]):int(koff[hi])].copy(),
                 overlap_off=(koff[lo:hi + 1] - koff[lo]).astype(np.uint32),
-                stats=dict(minimizers_sent=int(n - cnt[g]), matches_sent=n_matches_sent, overlaps_sent=int(n_sent),
-                           map_overlaps=n_map, bytes_sent=comm.bytes_sent))
+                stats=stats)
 
 
 # ---- polishing round sharded by windows (windows are independent; no data-path collective but the final gather) ----
 def polish_round_sharded(eng, targets, reads, comm, targets_rs, quals=None, q=0.0, err=0.3, w=500, trim=True,
                          m=3, n=-5, g=-4):
-    """One racon round with the window range split evenly over the ranks.  Every rank holds the targets and the read
-    set (`targets`, `reads`: uploaded handles; `targets_rs`: the host ReadSet of the targets), maps the reads (replicated,
-    ~15 % of a round) and runs the POA of its own windows only; the per-target consensus pieces are all-gathered and
-    concatenated in rank order, which reproduces the single-GPU round byte for byte.  Returns (consensus list, ratio)."""
+    """One racon round sharded over the ranks.  Every rank holds the targets and the read set (`targets`, `reads`:
+    uploaded handles; `targets_rs`: the host ReadSet of the targets).
+      1. reads are mapped independently of each other: rank g maps the reads [n g / N, n (g+1) / N) against the (replicated,
+         cheap) target index and keeps the best overlap per read; the table (36 B per read) is all-gathered;
+      2. windows are independent: rank g aligns the overlaps that touch its window range and runs the POA of those
+         windows only; the per-target consensus pieces are all-gathered and concatenated in rank order.
+    Both splits reproduce the single-GPU round byte for byte.  Returns (consensus list, ratio)."""
     lengths = targets_rs.lengths.astype(np.int64)
     n_win = int(((lengths + w - 1) // w).sum())
     lo = n_win * comm.rank // comm.world
     hi = n_win * (comm.rank + 1) // comm.world
+    if comm.world > 1:
+        n_reads = reads.n
+        r_lo = n_reads * comm.rank // comm.world
+        r_hi = n_reads * (comm.rank + 1) // comm.world
+        best, bt, _ = eng.polish_map_best(targets, reads, r_lo, r_hi, err=err)
+        packed = np.concatenate([best.astype(np.uint32), bt.reshape(-1, 1).astype(np.uint32),
+                                 np.zeros((bt.shape[0], 1), np.uint32)], axis=1)  # 10 words per read -> 5 int64
+        table = comm.all_gather_v(np.ascontiguousarray(packed).reshape(-1).view(np.int64)).view(np.uint32).reshape(-1, 10)
+        assert table.shape[0] == n_reads
+        eng.polish_set_best(table[:, :8], table[:, 8])
     cons, nw, npol, _ = eng.polish_round_range(targets, reads, lo, hi, quals=quals, q=q, err=err, w=w, trim=trim, m=m,
                                                n=n, g=g)
     nt = len(cons)

@@ -41,6 +41,15 @@ class LocalComm:
         self.g.barrier.wait()
         return res
 
+    def all_to_all_flat_t(self, flat, send_lens):
+        """DeviceComm.all_to_all_flat_t: parts back to back in one tensor; returns (flat receive tensor, lengths)."""
+        import torch
+        send_lens = [int(x) for x in send_lens]
+        parts = list(torch.split(flat[:sum(send_lens)], send_lens))
+        res = self.all_to_all_t(parts)
+        lens = [int(x.shape[0]) for x in res]
+        return (torch.cat(res) if res else flat[:0]), lens
+
     def all_reduce_sum(self, a):
         parts = self.all_to_all_v([a] * self.world)
         return np.sum(parts, axis=0)

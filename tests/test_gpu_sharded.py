@@ -171,3 +171,70 @@ def test_sharded_pass_with_several_flush_windows(variant):
         for x in sharded_util.run_ranks(world, rank_fn):
             assert x["occurrence"] == occ
             sharded_util.check_against_single(x, data, poff, kept, koff)   # ... and the sharded pass follows it
+
+
+@pytest.mark.parametrize("world", [1, 3, 8])
+def test_partition_and_regroup_kernels_equal_the_host_formulas(world):
+    """shard.hip against the numpy statements of the same steps (raven_amd/sharded.py host variant)."""
+    import torch
+    dev = torch.device("cuda", 0)
+    eng = hip.Engine(15, 5)
+    rng = np.random.default_rng(100 + world)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).to(dev)
+    # minimizers by hash class, stable
+    n = 100_003
+    val = rng.integers(0, 1 << 40, size=n, dtype=np.uint64)
+    val[:500] = np.arange(500, dtype=np.uint64)
+    org = rng.integers(0, 1 << 63, size=n, dtype=np.uint64) | (rng.integers(0, 2, size=n, dtype=np.uint64) << np.uint64(63))
+    v_d, o_d = t(val), t(org)
+    v_o, o_o = torch.empty_like(v_d), torch.empty_like(o_d)
+    torch.cuda.synchronize()
+    cnt = eng.shard_split_minimizers_dev(v_d.data_ptr(), o_d.data_ptr(), n, world, v_o.data_ptr(), o_o.data_ptr())
+    owner = sharded.hash_owner(val, world)
+    order = np.argsort(owner, kind="stable")
+    assert cnt == np.bincount(owner, minlength=world).tolist()
+    assert np.array_equal(v_o.cpu().numpy().view(np.uint64), val[order])
+    assert np.array_equal(o_o.cpu().numpy().view(np.uint64), org[order])
+    assert eng.shard_count_flagged_dev(o_d.data_ptr(), n) == int((org >> np.uint64(63)).sum())
+    # overlaps by the owner of the rhs read, own ones stay
+    n_reads, m = 5000, 40_001
+    bounds = np.unique(np.concatenate([[0, n_reads], rng.integers(1, n_reads, size=world - 1)])).astype(np.uint32)
+    while bounds.shape[0] < world + 1:  # duplicates collapsed: pad with empty trailing ranges
+        bounds = np.concatenate([bounds, [n_reads]]).astype(np.uint32)
+    ovl = rng.integers(0, 1 << 20, size=(m, 8), dtype=np.uint32)
+    ovl[:, 3] = rng.integers(0, n_reads, size=m)
+    me = world // 2
+    o_dv = torch.from_numpy(ovl.view(np.int64)).to(dev)
+    o_out = torch.empty_like(o_dv)
+    torch.cuda.synchronize()
+    oc = eng.shard_split_overlaps_dev(o_dv.data_ptr(), m, bounds, world, me, o_out.data_ptr())
+    rhs_owner = np.searchsorted(bounds, ovl[:, 3], side="right") - 1
+    rhs_owner = np.minimum(rhs_owner, world - 1)
+    want = np.concatenate([ovl[rhs_owner == h] for h in range(world) if h != me] + [ovl[rhs_owner == me]])
+    key = np.where(rhs_owner == me, world, rhs_owner)
+    assert oc == np.bincount(key, minlength=world + 1).tolist()
+    got = o_out.cpu().numpy().view(np.uint32).reshape(m, 8)
+    want2 = ovl[np.argsort(key, kind="stable")]
+    assert np.array_equal(got, want2) and want.shape == want2.shape
+    # regroup of the matches of every source per read
+    nr = 3001
+    cnts = [rng.integers(0, 6, size=nr).astype(np.int64) for _ in range(world)]
+    datas = [(rng.integers(0, 1 << 62, size=int(c.sum()), dtype=np.int64), rng.integers(0, 1 << 62, size=int(c.sum()), dtype=np.int64))
+             for c in cnts]
+    seg_w, (g_w, p_w) = sharded.regroup_by_read(cnts, datas)
+    c_d = [t(c) for c in cnts]
+    g_d = [t(d[0]) for d in datas]
+    p_d = [t(d[1]) for d in datas]
+    total = int(seg_w[-1])
+    seg_o = torch.empty(nr + 1, dtype=torch.int64, device=dev)
+    g_o, p_o = torch.empty(total, dtype=torch.int64, device=dev), torch.empty(total, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+    eng.shard_regroup_dev([x.data_ptr() for x in c_d], [x.data_ptr() for x in g_d], [x.data_ptr() for x in p_d],
+                          [int(c.sum()) for c in cnts], nr, seg_o.data_ptr(), g_o.data_ptr(), p_o.data_ptr())
+    assert np.array_equal(seg_o.cpu().numpy().view(np.uint64), seg_w)
+    assert np.array_equal(g_o.cpu().numpy(), g_w) and np.array_equal(p_o.cpu().numpy(), p_w)
+    # adjacent differences
+    cnt_o = torch.empty(nr, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+    eng.shard_adjacent_diff_dev(seg_o.data_ptr(), nr, cnt_o.data_ptr())
+    assert np.array_equal(cnt_o.cpu().numpy(), np.diff(seg_w.astype(np.int64)))
