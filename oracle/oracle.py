@@ -129,6 +129,12 @@ class Engine:
     def occurrence(self):
         return int(lib().orc_engine_occurrence(self._h))
 
+    def set_occurrence(self, occurrence):
+        L = lib()
+        L.orc_engine_set_occurrence.argtypes = [C.c_void_p, C.c_uint32]
+        L.orc_engine_set_occurrence.restype = None
+        L.orc_engine_set_occurrence(self._h, int(occurrence))
+
     def find(self, value, cap=1 << 16):
         o = np.zeros(cap, dtype=np.uint64)
         n = lib().orc_engine_find(self._h, int(value), _p(o), cap)

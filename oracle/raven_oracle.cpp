@@ -674,6 +674,8 @@ void orc_engine_minimize(orc_engine* e, const std::uint64_t* packed, const std::
 
 int orc_engine_filter(orc_engine* e, double f) { return e->e.Filter(f) ? 0 : -1; }
 std::uint32_t orc_engine_occurrence(orc_engine* e) { return e->e.occurrence_; }
+// tools/filter_sensitivity.py: what the uncertain +1 of Filter is worth on a data set
+void orc_engine_set_occurrence(orc_engine* e, std::uint32_t occurrence) { e->e.occurrence_ = occurrence; }
 
 // index lookup: number of origins for `value`, copies up to cap
 std::uint32_t orc_engine_find(orc_engine* e, std::uint64_t value, std::uint64_t* origins, std::uint32_t cap) {

@@ -109,6 +109,45 @@ def test_comm_over_gloo_world2(tmp_path):
     assert "COMM_OK_0" in r.stdout and "COMM_OK_1" in r.stdout, r.stdout[-2000:]
 
 
+WORKER_DEV = r"""
+import torch, torch.distributed as dist
+from raven_amd import sharded
+dist.init_process_group("gloo")
+c = sharded.DeviceComm(dist, device="cpu")   # the tensor collectives of the device-resident pass, on CPU tensors over gloo
+r, w = c.rank, c.world
+send = [2 + r + 3 * h for h in range(w)]
+flat = torch.cat([torch.full((send[h],), 1000 * r + h, dtype=torch.int64) for h in range(w)] + [torch.zeros(5, dtype=torch.int64)])
+out, lens = c.all_to_all_flat_t(flat, send)   # trailing slack after the parts is ignored
+assert lens == [2 + s + 3 * r for s in range(w)], lens
+o = 0
+for s in range(w):
+    assert torch.all(out[o:o + lens[s]] == 1000 * s + r)
+    o += lens[s]
+assert o == out.shape[0]
+parts = c.all_to_all_t([torch.arange(1 + r + h, dtype=torch.int64) + 10 * r for h in range(w)])
+for s in range(w):
+    assert parts[s].tolist() == [x + 10 * s for x in range(1 + s + r)]
+empty, elens = c.all_to_all_flat_t(torch.zeros(0, dtype=torch.int64), [0] * w)
+assert empty.shape[0] == 0 and elens == [0] * w
+assert c.bytes_sent > 0
+dist.destroy_process_group()
+import sys
+sys.stdout.write("DEVCOMM_OK_%d\n" % r)
+sys.stdout.flush()
+"""
+
+
+def test_device_comm_tensor_exchanges_over_gloo_world2(tmp_path):
+    script = tmp_path / "worker_dev.py"
+    script.write_text(WORKER_DEV)
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(sharded_util.free_port()), str(script)], capture_output=True,
+                       text=True, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "DEVCOMM_OK_0" in r.stdout and "DEVCOMM_OK_1" in r.stdout, r.stdout[-2000:]
+
+
 def test_flush_windows_follow_the_reference_schedule():
     # construct.cc:56-70: bytes += len; flush when bytes >= limit or at the last read
     L = np.array([5, 5, 5, 5, 5], dtype=np.uint32)
