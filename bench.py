@@ -42,13 +42,14 @@ VALU_PEAK_LANE_OPS = 78.6e12
 # a linear-gap POA cell needs at least: one add + one max per candidate (diagonal, vertical per predecessor,
 # horizontal) ~ 6 lane-ops; the graded "peak" cell rate is the lane-op peak / 6
 POA_MIN_OPS_PER_CELL = 6.0
+NW_MIN_OPS_PER_CELL = 50.0 / 64.0  # Myers block update + match mask: ~25 64-bit operations per 64 cells
 
 
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from this round's rocprofv3 --pmc passes (profiles/r02_pmc_traffic.json, made
     by tools/pmc_traffic.py from separate FETCH_SIZE / WRITE_SIZE runs of this same bench command): 2 x FETCH_SIZE KiB
     (gfx950: FETCH_SIZE counts 128-B requests as 64 B, MI355X_MICROARCH.md §HBM) + WRITE_SIZE KiB."""
-    for name in ("r02_pmc_traffic.json",):
+    for name in ("r02_pmc_traffic.json",):  # per round: the file of the round whose kernels these are
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 t = json.load(f)
@@ -289,7 +290,7 @@ def main():
         steps = max(args.steps, 1)
         counters = {k: v // steps for k, v in counters_raw.items()}
         val_bytes = 4 if 2 * eng.k < 32 else 8
-        kernels, roofline, roofline_hbm = {}, None, None
+        kernels, roofline, roofline_hbm, roofline_poa = {}, None, None, None
         if kms:
             tot = sum(v[0] for v in kms.values())
             for name, (ms, la) in sorted(kms.items(), key=lambda x: -x[1][0]):
@@ -298,17 +299,17 @@ def main():
                                      "avg_launch_ms": round(ms / la, 5), "share": round(ms / tot, 4) if tot else None}
             # dominant kernel of the WHOLE step: the banded POA kernel (integer VALU bound)
             dom = next(iter(kernels), None)
-            if dom == "poa_banded" and poa_cells["cells_full"]:
-                ms, la = kms[dom]
+            if "poa_banded" in kms and kms["poa_banded"][1] and poa_cells["cells_full"]:
+                ms, la = kms["poa_banded"]
                 cells = poa_cells["cells_full"] / max(poa_cells["calls"], 1) * 1.0  # per polishing round (one launch set)
                 launches_per_round = la / max(poa_cells["calls"], 1)
                 avg_s = ms / la / 1e3
                 cells_per_launch = cells / launches_per_round
                 achieved_tops = cells_per_launch * POA_MIN_OPS_PER_CELL / avg_s / 1e12
-                roofline = {"bound": "valu", "kernel": dom,
+                roofline_poa = {"bound": "valu", "kernel": "poa_banded",
                             "achieved": round(achieved_tops, 3), "peak": round(VALU_PEAK_LANE_OPS / 1e12, 1),
                             "unit": "T lane-ops/s", "frac": round(achieved_tops * 1e12 / VALU_PEAK_LANE_OPS, 4),
-                            "traffic": pmc_traffic(dom),
+                            "traffic": pmc_traffic("poa_banded"),
                             "algorithmic_cells_per_launch": int(cells_per_launch),
                             "algorithmic_ops_per_cell": POA_MIN_OPS_PER_CELL,
                             "gcups_algorithmic": round(cells_per_launch / avg_s / 1e9, 1),
@@ -318,6 +319,26 @@ def main():
                             "kernel_ms_share": round(ms / tot, 3) if tot else None,
                             "note": "algorithmic cells = graph rows x layer length of every layer alignment (what "
                                     "spoa's full NW computes); the kernel computes a 64-column band of them"}
+            if dom == "poa_banded":
+                roofline = roofline_poa
+            if dom == "nw_forward" and last.get("polish", {}).get("align_band_cells"):
+                # the alignment-path kernel (Myers bit-vector band, racon's edlib NW): integer VALU bound as well
+                ms, la = kms[dom]
+                launches_per_round = la / max(args.steps * args.polish_rounds, 1)
+                cells_per_launch = last["polish"]["align_band_cells"] / max(launches_per_round, 1e-9)
+                avg_s = ms / la / 1e3
+                achieved_tops = cells_per_launch * NW_MIN_OPS_PER_CELL / avg_s / 1e12
+                roofline = {"bound": "valu", "kernel": dom, "achieved": round(achieved_tops, 3),
+                            "peak": round(VALU_PEAK_LANE_OPS / 1e12, 1), "unit": "T lane-ops/s",
+                            "frac": round(achieved_tops * 1e12 / VALU_PEAK_LANE_OPS, 4), "traffic": pmc_traffic(dom),
+                            "algorithmic_cells_per_launch": int(cells_per_launch),
+                            "algorithmic_ops_per_cell": round(NW_MIN_OPS_PER_CELL, 3),
+                            "gcups_band": round(cells_per_launch / avg_s / 1e9, 1), "avg_launch_ms": round(avg_s * 1e3, 3),
+                            "kernel_ms_share": round(ms / tot, 3) if tot else None,
+                            "note": "algorithmic cells = cells of the Ukkonen band edlib needs for each alignment at the "
+                                    "threshold that succeeds (one sweep); the kernel sweeps them twice (checkpoints, then "
+                                    "per-segment re-sweep for the traceback).  50 32-bit lane operations per 64-cell block "
+                                    "step of Myers' recurrence incl. the match mask."}
             # the dominant HBM-bound kernel (second entry)
             for name in kernels:
                 b = algorithmic_bytes(name, counters, val_bytes)
@@ -370,6 +391,7 @@ def main():
             "last_polish_round": {k: (round(v, 3) if isinstance(v, float) else v) for k, v in last.get("polish", {}).items()},
             "roofline": roofline,
             "roofline_hbm": roofline_hbm,
+            "roofline_poa": roofline_poa if roofline is not roofline_poa else None,
             "kernels": dict(list(kernels.items())[:16]),
             "host": {"gen_s": round(t_gen, 2), "h2d_s": round(t_h2d, 3),
                      "h2d_inclusive_gbase_s": round(rs.total_bases / (dt / steps + t_h2d) / 1e9, 4)},

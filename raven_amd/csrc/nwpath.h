@@ -149,8 +149,17 @@ struct NwLane {
   int s;
   bool fresh;
   TextCursor tc;
-  int hout_last, score_last;
+  bool tc_valid;  // tc stands at the lane's current column (only the block at the top of the band reads the text itself)
+  // what the consumer (next lane of the ring) reads one step later: (hout + 1) | text symbol << 2 of the column just done.
+  // The symbol of column j travels down the band with the horizontal deltas, so only the topmost block of the band at
+  // column j loads it — a load on every lane's path would make every step wait on the vector-memory counter, which
+  // the kernel's stores share.
+  int xfer_last, score_last;
   u32 result;  // D(n, m) + 1 on the one lane that computes it
+  // R == 1: column range (c_ja .. c_jb) of the block the lane holds and the last column (c_prod) at which the block above
+  // is still inside the band, valid while c_s == s — what the plain block update (fast_step) needs instead of re-deriving
+  // the band geometry at every step
+  int c_s, c_ja, c_jb, c_prod;
 
   __host__ __device__ void init(const NwJob& J, const u64* t_words, const u64* r_words, const NwBand& band,
                                 const NwStore& store, int lane_) {
@@ -182,12 +191,61 @@ struct NwLane {
       else break;
     }
     fresh = true;
-    hout_last = 1;
+    tc_valid = false;
+    xfer_last = 2;  // hout = +1, symbol 0
     score_last = 0;
     result = 0;
+    c_s = -1;
   }
 
-  __host__ __device__ void step(int t, int hin_prev, int score_prev) {
+  __host__ __device__ void refresh_cache() {
+    c_s = s;
+    if (s < B.n_super) {
+      const int b = s * R;
+      const int jin = nw_jin(b, B.hi), jout = nw_jout(b, B.lo);
+      c_ja = jin > j0 + 1 ? jin : j0 + 1;
+      c_jb = jout < j_end ? jout : j_end;
+      c_prod = b > 0 ? nw_jout(b - 1, B.lo) : -1;
+    }
+  }
+
+  // What step(t, ..) would do on this lane (R == 1): 0 = nothing, 1 = the plain update of its block at column t - s
+  // (fast_step does exactly that), 2 = anything else (ring advance, first column of a block, the final cell, ...).
+  // The kernels take the short path when no lane of the wave says 2.
+  __host__ __device__ int classify(int t) const {
+    if (s >= B.n_super) return 0;
+    if (c_s != s) return 2;
+    const int j = t - s;
+    if (j > c_jb) return 2;  // the block leaves the band or the sweep: ring advance
+    if (j < c_ja) return 0;  // not inside the band / the sweep yet
+    if (fresh || j == c_ja) return 2;
+    if (j > c_prod && !tc_valid) return 2;  // the block above has left the band: this one starts reading the text
+    if (s * R == B.nb - 1 && j == static_cast<int>(m)) return 2;
+    return 1;
+  }
+
+  __host__ __device__ void fast_step(int t, int x_prev) {
+    const int j = t - s;
+    const bool fed = j <= c_prod;
+    const unsigned c = fed ? static_cast<unsigned>(x_prev >> 2) : tc.get(j);
+    const int hin = fed ? (x_prev & 3) - 1 : 1;
+    const int hout = myers_block(Pv[0], Mv[0], planes_eq(pl[0], c), hin);
+    score[0] += hout;
+    if (mode == 1) {
+      const u64 slot = (static_cast<u64>(t - t0) * B.L + static_cast<u64>(lane)) * R;
+      st.seg_pm[slot] = NwPm{Pv[0], Mv[0]};
+      st.seg_sc[slot] = score[0];
+    } else if (j % kNwSeg == 0) {
+      const u64 cs = static_cast<u64>(j / kNwSeg) * st.ckpt_nb + static_cast<u64>(s * R - nw_bfirst(j, B.lo));
+      st.ck_pm[cs] = NwPm{Pv[0], Mv[0]};
+      st.ck_sc[cs] = score[0];
+    }
+    xfer_last = (hout + 1) | static_cast<int>(c << 2);
+    score_last = score[0];
+  }
+
+  __host__ __device__ void step(int t, int x_prev, int score_prev) {
+    const int hin_prev = (x_prev & 3) - 1;
     while (s < B.n_super) {  // retire finished super-blocks (ring advance)
       const int last_b = s * R + R - 1 < B.nb ? s * R + R - 1 : B.nb - 1;
       const int jout = nw_jout(last_b, B.lo);
@@ -205,12 +263,22 @@ struct NwLane {
     if (fresh) {
 #pragma unroll
       for (int r = 0; r < R; ++r) pl[r] = load_planes(a_words, a_base, n, static_cast<u32>(b0 + r));
-      tc.init(b_words, b_base, m, rc, j);
+      tc_valid = false;
       fresh = false;
     }
-    const unsigned c = tc.get(j);
     // producer block b0-1 (previous lane of the ring): inside the band at column j iff j <= jout(b0 - 1)
     const bool prod_active = b0 > 0 && j <= nw_jout(b0 - 1, B.lo);
+    unsigned c;
+    if (prod_active) {  // the symbol of column j arrives with the producer's delta
+      c = static_cast<unsigned>(x_prev >> 2);
+      tc_valid = false;
+    } else {
+      if (!tc_valid) {
+        tc.init(b_words, b_base, m, rc, j);
+        tc_valid = true;
+      }
+      c = tc.get(j);
+    }
     int hin = prod_active ? hin_prev : 1;
     int above_prev_col = prod_active ? score_prev - hin_prev : score_prev;  // score of block b-1 at column j-1
     const u64 seg_slot0 = (static_cast<u64>(t - t0) * B.L + static_cast<u64>(lane)) * R;
@@ -257,7 +325,7 @@ struct NwLane {
         result = static_cast<u32>(score[r] - RVN_POPC64(Pv[r] & padmask) + RVN_POPC64(Mv[r] & padmask)) + 1u;
       }
     }
-    hout_last = hin;
+    xfer_last = (hin + 1) | static_cast<int>(c << 2);
     score_last = score[R - 1];
   }
 };

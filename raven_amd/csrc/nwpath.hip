@@ -10,6 +10,7 @@
 // blocks-per-lane R from k, jobs that outgrow their R (distance > kcap) are relaunched with the next R — the result is
 // always the exact optimal path, the estimate only decides how much band is computed.
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <vector>
 
@@ -50,6 +51,9 @@ __device__ __forceinline__ u32 group_max(u32 v) {
   return v;
 }
 
+// wave-cycles per phase (pass 1 / segment re-sweeps / walks / whole kernel), printed by nw_breakpoints under RVN_NW_DEBUG
+__device__ unsigned long long g_nw_phase[8];
+
 template <int R, int G>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(R == 1 ? 4 : 1))) void nw_path_kernel(const NwJob* __restrict__ jobs, const u32* __restrict__ idx,
                                                      u32 n_idx, const u64* __restrict__ t_words,
@@ -65,6 +69,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(R == 1 ? 4 
   const int group = lane / G, lig = lane % G, gbase = group * G;
   const u32 slot = (blockIdx.x * 4 + (threadIdx.x >> 6)) * NG + static_cast<u32>(group);
   if (slot >= n_slots) return;
+  unsigned long long c_p1 = 0, c_sw = 0, c_wk = 0, n_fast = 0, n_slow = 0;
+  const unsigned long long c_begin = __builtin_readcyclecounter();
   // The groups of a wave take a bundle of 64 / G consecutive jobs together and run through its phases in lockstep
   // (pass 1, then segment by segment: sweep, walk): control flow that differs between the groups of a wave is serialised
   // by the hardware, so groups drifting into different phases would cost more than they share.  Jobs are sorted by
@@ -90,15 +96,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(R == 1 ? 4 
       NwLane<R> ln;
       u32 res = 0;
       bool ok = false;
+      const unsigned long long c0 = __builtin_readcyclecounter();
       for (;;) {
         B = nw_band(J.n, J.m, k, R);
         ln.init(J, t_words, r_words, B, st, lig);
         ln.begin_sweep(0, J.m, 0);
         const int t1 = NwLane<R>::sweep_t1(B, static_cast<int>(J.m));
         for (int t = ln.t0; t <= t1; ++t) {
-          const int hp = group_prev<G>(ln.hout_last, lig, gbase, B.L);
+          const int hp = group_prev<G>(ln.xfer_last, lig, gbase, B.L);
+          if constexpr (R == 1) {  // most steps are plain block updates on every lane of the wave
+            const int cls = ln.classify(t);
+            if (__ballot(cls == 2) == 0) {
+              if (cls == 1) ln.fast_step(t, hp);
+              ++n_fast;
+              continue;
+            }
+            ++n_slow;
+          }
           const int sp = group_prev<G>(ln.score_last, lig, gbase, B.L);
           ln.step(t, hp, sp);
+          if constexpr (R == 1) ln.refresh_cache();
         }
         res = group_max<G>(ln.result) - 1u;  // exactly one lane of the group holds D(n, m) + 1
         if (res <= k) {
@@ -114,6 +131,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(R == 1 ? 4 
         if (!ok) status[ji] = 2;  // beyond this launch's ring: the host relaunches the job with a larger ring
       }
       nw_wsync();  // checkpoints visible to every lane
+      c_p1 += __builtin_readcyclecounter() - c0;
       if (ok) {
         // ---- the walk, segment by segment from the end ----
         // The walker's state lives in LDS between the segments (it is not needed while the group re-sweeps a segment,
@@ -128,19 +146,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(R == 1 ? 4 
         for (int sg = (static_cast<int>(J.m) - 1) / kNwSeg; sg >= 0 && rows_left > 0; --sg) {
           const int j0 = sg * kNwSeg;
           const int j_end = j0 + kNwSeg < static_cast<int>(J.m) ? j0 + kNwSeg : static_cast<int>(J.m);
+          const unsigned long long c1 = __builtin_readcyclecounter();
           ln.begin_sweep(j0, j_end, 1);
           const int t1 = NwLane<R>::sweep_t1(B, j_end);
           for (int t = ln.t0; t <= t1; ++t) {
-            const int hp = group_prev<G>(ln.hout_last, lig, gbase, B.L);
+            const int hp = group_prev<G>(ln.xfer_last, lig, gbase, B.L);
+            if constexpr (R == 1) {
+              const int cls = ln.classify(t);
+              if (__ballot(cls == 2) == 0) {
+                if (cls == 1) ln.fast_step(t, hp);
+                ++n_fast;
+                continue;
+              }
+              ++n_slow;
+            }
             const int sp = group_prev<G>(ln.score_last, lig, gbase, B.L);
             ln.step(t, hp, sp);
+            if constexpr (R == 1) ln.refresh_cache();
           }
           nw_wsync();  // the segment's block states (and the walker in LDS) visible to every lane
+          const unsigned long long c2 = __builtin_readcyclecounter();
+          c_sw += c2 - c1;
           NwWalker wk = swk;
           wk.set_segment(j0, ln.t0);
           wk.walk(lig == 0);  // every lane of the group walks the same path; its first lane writes the records
           rows_left = wk.i;
           nw_wsync();         // all reads of the scratch done before the next segment overwrites it
+          c_wk += __builtin_readcyclecounter() - c2;
           if (lig == 0) swk = wk;
         }
         nw_wsync();
@@ -150,6 +182,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(R == 1 ? 4 
       }
     }
     nw_wsync();
+  }
+  if (lane == 0) {
+    atomicAdd(&g_nw_phase[0], c_p1);
+    atomicAdd(&g_nw_phase[1], c_sw);
+    atomicAdd(&g_nw_phase[2], c_wk);
+    atomicAdd(&g_nw_phase[3], __builtin_readcyclecounter() - c_begin);
+    atomicAdd(&g_nw_phase[4], n_fast);
+    atomicAdd(&g_nw_phase[5], n_slow);
   }
 }
 
@@ -444,6 +484,12 @@ void nw_breakpoints(Engine& e, const ReadsDev& T, const ReadsDev& Rd, std::vecto
   float ms = 0;
   RVN_HIP(hipEventElapsedTime(&ms, e.ev0, e.ev1));
   st.ms = ms;
+  if (std::getenv("RVN_NW_DEBUG")) {  // cumulative since the library was loaded
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    RVN_HIP(hipMemcpyFromSymbol(ph, HIP_SYMBOL(g_nw_phase), sizeof(ph)));
+    std::fprintf(stderr, "[raven_hip] nw_path wave-cycles (cumulative): pass1 %.3e  re-sweep %.3e  walk %.3e  total %.3e; fast steps %.3e slow %.3e; this call %.1f ms, %u jobs\n",
+                 static_cast<double>(ph[0]), static_cast<double>(ph[1]), static_cast<double>(ph[2]), static_cast<double>(ph[3]), static_cast<double>(ph[4]), static_cast<double>(ph[5]), ms, nj);
+  }
 }
 
 // ---- CPU stepper of the same code (test hook rvn_test_nw_breakpoints): 64 emulated lanes, host arrays --------------
@@ -462,10 +508,21 @@ static int emulate_job(const NwJob& J, const u64* t_words, const u64* r_words, u
     for (int t = lanes[0].t0; t <= t1; ++t) {
       for (int l = 0; l < 64; ++l) {  // the shuffles read the producer's values of the previous step
         const int src = l == 0 ? B.L - 1 : l - 1;
-        hp[l] = lanes[src].hout_last;
+        hp[l] = lanes[src].xfer_last;
         sp[l] = lanes[src].score_last;
       }
-      for (int l = 0; l < 64; ++l) lanes[l].step(t, hp[l], sp[l]);
+      bool any_slow = R != 1;
+      if (R == 1)
+        for (int l = 0; l < 64; ++l) any_slow = any_slow || lanes[l].classify(t) == 2;
+      if (!any_slow) {  // the kernel's short path: no lane of the wave needs more than the plain block update
+        for (int l = 0; l < 64; ++l)
+          if (lanes[l].classify(t) == 1) lanes[l].fast_step(t, hp[l]);
+      } else {
+        for (int l = 0; l < 64; ++l) {
+          lanes[l].step(t, hp[l], sp[l]);
+          if (R == 1) lanes[l].refresh_cache();
+        }
+      }
       if (mode == 1 && static_cast<u64>(t - lanes[0].t0) >= nw_seg_rows()) return false;  // scratch rows exceeded
     }
     return true;

@@ -278,6 +278,7 @@ __device__ __forceinline__ u32 poa2_window(const PoaWindow& win, const PoaLayer*
     i32 last_b = 0, last_h = 0;
     u32 ring_miss = 0;  // != 0: a predecessor row was no longer in the ring
     int m_b_last = 0;
+    u32 marked_before = 0;
     {  // -inf pads (the union is reused by the traceback / AddAlignment of the previous layer)
       const u32 sl = static_cast<u32>(lane) >> 1;
       S.u.ring[1 + sl * kRingStride + ((lane & 1) ? kBand + 1 : 0)] = static_cast<i16>(kNegInf16);
@@ -289,7 +290,8 @@ __device__ __forceinline__ u32 poa2_window(const PoaWindow& win, const PoaLayer*
       // metadata of 64 rows at once, one row per lane; it is also the traceback's row table
       int m_v = 0, m_np = 0, m_p01 = 0, m_p23 = 0, m_code = 0, m_outc = 1, m_marked = 0, m_b = 0;
       int m_meta = 0;  // NCH == 1: marked | #in-edges << 1 | code << 6 | end node << 8, one readlane per row
-      const int m_b_prev = m_b_last;  // band starts of the previous block of 64 rows
+      const int m_b_prev = m_b_last;  // band start | ring index << 16 of the previous block of 64 rows
+      int m_bi = 0;                   // NCH == 1: band start | (number of marked rows before this one) << 16
       if (r0 + lane < n_nodes) {
         m_v = g.order[r0 + lane];
         m_marked = (full || g.mark[m_v]) ? 1 : 0;
@@ -323,7 +325,13 @@ __device__ __forceinline__ u32 poa2_window(const PoaWindow& win, const PoaLayer*
       // every load above must have returned BEFORE the row loop: a wait for them inside the loop would also wait
       // for the rows' own stores (loads and stores share the vector memory counter)
       asm volatile("" ::"v"(m_v), "v"(m_np), "v"(m_p01), "v"(m_p23), "v"(m_code), "v"(m_outc), "v"(m_marked), "v"(m_b), "v"(m_meta));
-      m_b_last = m_b;
+      {  // ring slots are handed out per COMPUTED row, so rows outside the layer's subgraph do not age the ring
+        const unsigned long long mk = __ballot(m_marked != 0);
+        const unsigned long long below = (1ULL << lane) - 1ULL;
+        m_bi = m_b | static_cast<int>(((marked_before + static_cast<u32>(__popcll(mk & below))) & 0xFFFFu) << 16);
+        marked_before += static_cast<u32>(__popcll(mk));
+      }
+      m_b_last = m_bi;
       const u32 rows_here = static_cast<u32>(rfl(static_cast<int>(n_nodes - r0 < 64 ? n_nodes - r0 : 64)));  // uniform loop
       {  // work counters: rows of this layer's (sub)graph x layer length = the cells spoa's full NW computes
         const u32 marked_rows = static_cast<u32>(__popcll(__ballot(m_marked != 0)));
@@ -343,13 +351,16 @@ __device__ __forceinline__ u32 poa2_window(const PoaWindow& win, const PoaLayer*
         // the ring is not looked up in HBM: the window is repeated by the full-matrix kernel (status 7); it does
         // not happen on racon-like windows.
         unsigned long long todo = __ballot((m_meta & 1) != 0);
-        // A predecessor at most kRing rows back is still in its ring slot (no later row has wrapped onto it); its band
-        // start comes from the block metadata (this block's or the previous one's), so the ring needs no tags.
-        auto ring_pair = [&](u32 pr, i32 jv, u32 row) -> u32 {
-          ring_miss |= (row - pr > static_cast<u32>(kRing)) ? 1u : 0u;
-          const u32 slot = (pr - 1) & (kRing - 1);
-          const i32 pb = (pr - 1 >= r0) ? rl(m_b, static_cast<int>((pr - 1) & 63)) : rl(m_b_prev, static_cast<int>((pr - 1) & 63));
-          i32 cc = jv - pb;
+        // Ring slot of a row = its index among the computed (marked) rows mod kRing, so a predecessor is still in its slot
+        // iff at most kRing rows were computed since; index and band start of a predecessor come from the block metadata
+        // (this block's or the previous one's): the ring needs no tags.
+        auto ring_pair = [&](u32 pr, i32 jv, u32 cur_idx) -> u32 {
+          const u32 pbi = static_cast<u32>((pr - 1 >= r0) ? rl(m_bi, static_cast<int>((pr - 1) & 63))
+                                                           : rl(m_b_prev, static_cast<int>((pr - 1) & 63)));
+          const u32 pidx = pbi >> 16;
+          ring_miss |= (((cur_idx - pidx) & 0xFFFFu) > static_cast<u32>(kRing) || pr + 63 < r0) ? 1u : 0u;
+          const u32 slot = pidx & (kRing - 1);
+          i32 cc = jv - static_cast<i32>(pbi & 0xFFFFu);
           cc = cc < -1 ? -1 : (cc > kBand ? kBand : cc);
           u32 pair;  // low half: predecessor's column j - 1 (diagonal), high half: its column j (vertical)
           __builtin_memcpy(&pair, &S.u.ring[2 + static_cast<i32>(slot) * kRingStride + cc - 1], 4);
@@ -362,7 +373,9 @@ __device__ __forceinline__ u32 poa2_window(const PoaWindow& win, const PoaLayer*
           todo &= todo - 1;
           const u32 row = r0 + static_cast<u32>(ri) + 1;
           const int meta = rl(m_meta, ri);
-          const i32 b = rl(m_b, ri);
+          const u32 bi = static_cast<u32>(rl(m_bi, ri));
+          const i32 b = static_cast<i32>(bi & 0xFFFFu);
+          const u32 cur_idx = bi >> 16;
           const u32 p01 = static_cast<u32>(rl(m_p01, ri));
           u32 np = (static_cast<u32>(meta) >> 1) & 31u;
           if (np == 0) np = 1;  // no in-edge inside the subgraph: the virtual start row (p01 == 0)
@@ -389,7 +402,7 @@ __device__ __forceinline__ u32 poa2_window(const PoaWindow& win, const PoaLayer*
             } else if (pr == 0) {  // H[0][j] = j * g
               pair = poa2_virtual_pair(jv, jgv, gp);
             } else {
-              pair = ring_pair(pr, jv, row);
+              pair = ring_pair(pr, jv, cur_idx);
             }
             const pk16 cand = as_pk16(pair) + addc;
             if (k == 0) {
@@ -408,7 +421,7 @@ __device__ __forceinline__ u32 poa2_window(const PoaWindow& win, const PoaLayer*
           i32 hh = xs + jgv;
           if (hh > best) code = 32u;
           hh = hh < kNegInf16 ? kNegInf16 : hh;
-          const u32 rslot = (row - 1) & (kRing - 1);
+          const u32 rslot = cur_idx & (kRing - 1);
           S.u.ring[2 + rslot * kRingStride + lane] = static_cast<i16>(hh);
           g.BP[static_cast<size_t>(row) * kBand + lane] = static_cast<u8>(code);
           last_row = static_cast<u32>(rfl(static_cast<int>(row)));

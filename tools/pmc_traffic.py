@@ -1,49 +1,59 @@
 #!/usr/bin/env python3
 """Combine the FETCH_SIZE and WRITE_SIZE rocprofv3 --pmc passes into per-kernel HBM bytes per launch:
-    python tools/pmc_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> profiles/pmc_traffic.json
+    python tools/pmc_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> profiles/r02_pmc_traffic.json
 hbm_bytes = 2 * FETCH_SIZE * 1024 + WRITE_SIZE * 1024  (gfx950 correction of MI355X_MICROARCH.md §HBM: FETCH_SIZE
-reports half the bytes of wide coalesced reads; WRITE_SIZE is taken as is, uncalibrated)."""
+reports half the bytes of wide coalesced reads; WRITE_SIZE is taken as is, uncalibrated).  Template instances of one
+kernel site (bench.py's kernel names) are pooled: bytes per launch = sum over the instances / number of launches."""
 import collections
 import csv
 import json
 import re
 import sys
 
-SITE = {  # kernel name -> bench.py kernel-site name
-    "rs_downsweep_kernel<unsigned int, unsigned long>": "rs_downsweep", "rs_upsweep_kernel<unsigned int>": "rs_upsweep",
-    "sketch_kernel<unsigned int, false>": "sketch_count", "sketch_kernel<unsigned int, true>": "sketch_write",
-    "join_kernel<false>": "join_count", "join_kernel<true>": "join_emit", "seg_sort_off_kernel": "seg_sort_group",
-    "seg_sort_be_kernel": "seg_sort_pos", "chain_kernel": "chain", "chain_small_kernel": "chain_small",
-    "minhash_select_kernel<unsigned int>": "minhash_select", "unique_kernel<unsigned int>": "unique",
-    "heads_kernel<unsigned int>": "heads", "match_count_kernel<unsigned int>": "match_count",
-    "match_emit_kernel": "match_emit", "table_kernel<unsigned int>": "table",
-}
+SITES = [  # (regex on the demangled kernel name, bench.py kernel-site name)
+    (r"nw_path_kernel", "nw_forward"), (r"nw_lane_kernel", "nw_lane"), (r"poa2_kernel", "poa_banded"),
+    (r"\bpoa_kernel", "poa"), (r"chain_small_kernel", "chain_small"), (r"chain_kernel", "chain"),
+    (r"rs_downsweep_kernel", "rs_downsweep"), (r"rs_upsweep_kernel", "rs_upsweep"),
+    (r"sketch_kernel<[^>]*false>", "sketch_count"), (r"sketch_kernel<[^>]*true>", "sketch_write"),
+    (r"join_kernel<false>", "join_count"), (r"join_kernel<true>", "join_emit"), (r"seg_sort_off_kernel", "seg_sort_group"),
+    (r"seg_sort_lds_kernel", "seg_sort_group"), (r"seg_sort_be_kernel", "seg_sort_pos"),
+    (r"minhash_select_kernel", "minhash_select"), (r"unique_kernel", "unique"), (r"heads_kernel", "heads"),
+    (r"match_count_kernel", "match_count"), (r"match_emit_kernel", "match_emit"), (r"table_kernel", "table"),
+    (r"add_layers_kernel", "add_layers"), (r"ed_banded_kernel", "edit_distance"), (r"ed_lane_kernel", "edit_distance_lane"),
+]
 
 
-def short(name):
+def site_of(name):
     name = name.replace("(anonymous namespace)::", "")
-    m = re.match(r"(?:void )?(?:rvn::)?([A-Za-z_0-9]+(?:<[^(]*>)?)", name)
+    for rx, site in SITES:
+        if re.search(rx, name):
+            return site
+    m = re.match(r"(?:void )?(?:rvn::)?([A-Za-z_0-9]+)", name)
     return m.group(1) if m else name
 
 
 def load(path):
     agg = collections.defaultdict(lambda: [0, 0.0])
     for r in csv.DictReader(open(path)):
-        a = agg[short(r["Kernel_Name"])]
+        a = agg[site_of(r["Kernel_Name"])]
         a[0] += 1
         a[1] += float(r["Counter_Value"])
-    return {k: v[1] / v[0] for k, v in agg.items()}
+    return agg
 
 
 def main(fetch_csv, write_csv, out):
     f, w = load(fetch_csv), load(write_csv)
     kernels = {}
     for k in sorted(set(f) | set(w)):
-        fe, wr = f.get(k, 0.0) * 1024, w.get(k, 0.0) * 1024
-        kernels[SITE.get(k, k)] = {"kernel": k, "fetch_size_bytes": int(fe), "write_size_bytes": int(wr),
-                                   "hbm_bytes_per_launch": int(2 * fe + wr)}
-    json.dump({"method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of `bench.py --steps 2`; "
-                         "hbm = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950 FETCH correction)", "kernels": kernels},
+        nf, fe = f.get(k, [0, 0.0])
+        nw, wr = w.get(k, [0, 0.0])
+        fe_l = fe * 1024 / max(nf, 1)
+        wr_l = wr * 1024 / max(nw, 1)
+        kernels[k] = {"launches_fetch_pass": nf, "launches_write_pass": nw, "fetch_size_bytes_per_launch": int(fe_l),
+                      "write_size_bytes_per_launch": int(wr_l), "hbm_bytes_per_launch": int(2 * fe_l + wr_l)}
+    json.dump({"method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE in separate passes of `python bench.py "
+                         "--no-cpu-baseline`; hbm = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 per launch (gfx950: FETCH_SIZE counts "
+                         "128-B requests as 64 B, MI355X_MICROARCH.md HBM section; WRITE_SIZE uncalibrated)", "kernels": kernels},
               open(out, "w"), indent=1, sort_keys=True)
     print("wrote", out)
 

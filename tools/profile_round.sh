@@ -1,14 +1,22 @@
 #!/bin/bash
-# Collects the evidence files of a round on the GPU box (run through gpurun): POA bench, PMC passes of the banded
-# POA kernel, rocprofv3 kernel stats of bench.py.  Outputs under gpurun_out/; copy what should be judged to profiles/.
+# Collects the evidence files of a round on the GPU box (run through gpurun):
+#   1. rocprofv3 --kernel-trace --stats of the default bench command (the N = 1 line: 100 Mb, -p 2)
+#   2. / 3. separate --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of the same command (HBM traffic per launch)
+# Outputs under gpurun_out/<tag>_*; tools/pmc_traffic.py + the stats CSV are what gets copied to profiles/.
 R=${GRAFT_REPO_ROOT:-/root/repo}
-TAG=${1:-r01_i}
+TAG=${1:-r02}
+WORKLOAD=${2:-c4}
 mkdir -p $R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
-RVN_POA_MODE=2 python $R/tools/bench_poa.py 16384 100 > $R/gpurun_out/${TAG}_poa_banded_bench.json 2>/dev/null
-RVN_POA_MODE=2 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU --output-format csv -d $R/gpurun_out/${TAG}_pmc_a -o p -- python $R/tools/bench_poa.py 16384 0 > /dev/null 2>&1
-RVN_POA_MODE=2 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES SQ_WAVES --output-format csv -d $R/gpurun_out/${TAG}_pmc_b -o p -- python $R/tools/bench_poa.py 16384 0 > /dev/null 2>&1
-RVN_POA_MODE=2 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/${TAG}_pmc_fetch -o p -- python $R/tools/bench_poa.py 16384 0 > /dev/null 2>&1
-RVN_POA_MODE=2 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/${TAG}_pmc_write -o p -- python $R/tools/bench_poa.py 16384 0 > /dev/null 2>&1
-rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${TAG}_stats -o s -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $R/gpurun_out/${TAG}_bench_under_rocprof.json 2>/dev/null
-ls $R/gpurun_out/${TAG}_stats | head
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_stats -o s -- python $R/bench.py --workload $WORKLOAD --no-cpu-baseline > $R/gpurun_out/${TAG}_bench_under_rocprof.json 2> $R/gpurun_out/${TAG}_stats.err
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/${TAG}_pmc_fetch -o p -- python $R/bench.py --workload $WORKLOAD --no-cpu-baseline --no-kernel-timing > /dev/null 2> $R/gpurun_out/${TAG}_pmc_fetch.err
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/${TAG}_pmc_write -o p -- python $R/bench.py --workload $WORKLOAD --no-cpu-baseline --no-kernel-timing > /dev/null 2> $R/gpurun_out/${TAG}_pmc_write.err
+F=$(find $R/gpurun_out/${TAG}_pmc_fetch -name '*counter_collection.csv' | head -1)
+W=$(find $R/gpurun_out/${TAG}_pmc_write -name '*counter_collection.csv' | head -1)
+python $R/tools/pmc_traffic.py "$F" "$W" $R/gpurun_out/${TAG}_pmc_traffic.json
+S=$(find $R/gpurun_out/${TAG}_stats -name '*kernel_stats.csv' | head -1)
+cp "$S" $R/gpurun_out/${TAG}_kernel_stats.csv
+# the raw per-dispatch files are large: keep only the summaries
+rm -rf $R/gpurun_out/${TAG}_pmc_fetch $R/gpurun_out/${TAG}_pmc_write $R/gpurun_out/${TAG}_stats
+head -12 $R/gpurun_out/${TAG}_kernel_stats.csv
+tail -1 $R/gpurun_out/${TAG}_bench_under_rocprof.json | cut -c1-300
