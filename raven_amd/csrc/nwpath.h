@@ -212,16 +212,14 @@ struct NwLane {
   // What step(t, ..) would do on this lane (R == 1): 0 = nothing, 1 = the plain update of its block at column t - s
   // (fast_step does exactly that), 2 = anything else (ring advance, first column of a block, the final cell, ...).
   // The kernels take the short path when no lane of the wave says 2.
-  __host__ __device__ int classify(int t) const {
-    if (s >= B.n_super) return 0;
-    if (c_s != s) return 2;
+  __host__ __device__ int classify(int t) const {  // branch-free: it runs on every lane at every step
     const int j = t - s;
-    if (j > c_jb) return 2;  // the block leaves the band or the sweep: ring advance
-    if (j < c_ja) return 0;  // not inside the band / the sweep yet
-    if (fresh || j == c_ja) return 2;
-    if (j > c_prod && !tc_valid) return 2;  // the block above has left the band: this one starts reading the text
-    if (s * R == B.nb - 1 && j == static_cast<int>(m)) return 2;
-    return 1;
+    const bool live = s < B.n_super;
+    const bool inside = j >= c_ja && j <= c_jb;  // inside the band and the sweep
+    const bool event = (c_s != s) || j > c_jb  // stale cache / the block leaves the band or the sweep: ring advance
+                       || (inside && (fresh || j == c_ja || (j > c_prod && !tc_valid)  // first column / starts reading the text
+                                      || (s * R == B.nb - 1 && j == static_cast<int>(m))));  // the final cell
+    return live ? (event ? 2 : (inside ? 1 : 0)) : 0;
   }
 
   __host__ __device__ void fast_step(int t, int x_prev) {
@@ -381,8 +379,10 @@ struct NwWalkerT {
   u32 gq[8];
   int gx;
   u32 gt;
-  // one-word caches of the two sequences
-  u64 t_wi, t_wv, q_wi, q_wv;
+  // the next (up to 32) bases of the target and of the oriented read, the current one in the top two bits; the walk
+  // compares 32 bases per step with them and takes a whole run of matches at once
+  u64 t_tail, q_tail;
+  int t_have, q_have;
 
   __host__ __device__ void init(const NwJob& J, const u64* t_words_all, const u64* r_words_all, u32 distance, u32 w_,
                                 NwWindowRec* recs_all) {
@@ -405,30 +405,64 @@ struct NwWalkerT {
     for (int g = 0; g < 8; ++g) gq[g] = 0xFFFFFFFFu;
     gx = -1;
     gt = 0;
-    t_wi = q_wi = ~0ULL;
-    t_wv = q_wv = 0;
+    t_tail = q_tail = 0;
+    t_have = q_have = 0;
   }
   __host__ __device__ u32 cell(int x, int y) const { return cells.get(x, y); }
 
-  __host__ __device__ u32 tcode(int row) {
-    const u64 pos = static_cast<u64>(t_begin) + row - 1;
-    const u64 wi = pos >> 5;
-    if (wi != t_wi) {
-      t_wi = wi;
-      t_wv = tw[wi];
-    }
-    return static_cast<u32>(t_wv >> ((pos & 31) << 1)) & 3u;
+  // order of the 32 two-bit groups reversed
+  __host__ __device__ static u64 rev2(u64 v) {
+    v = ((v & 0x3333333333333333ULL) << 2) | ((v >> 2) & 0x3333333333333333ULL);
+    v = ((v & 0x0F0F0F0F0F0F0F0FULL) << 4) | ((v >> 4) & 0x0F0F0F0F0F0F0F0FULL);
+    v = ((v & 0x00FF00FF00FF00FFULL) << 8) | ((v >> 8) & 0x00FF00FF00FF00FFULL);
+    v = ((v & 0x0000FFFF0000FFFFULL) << 16) | ((v >> 16) & 0x0000FFFF0000FFFFULL);
+    return (v << 32) | (v >> 32);
   }
-  __host__ __device__ u32 qcode(int col) {
-    const u64 x = static_cast<u64>(q_begin) + col - 1;  // position in the oriented read
-    const u64 pos = rc ? static_cast<u64>(r_len) - 1 - x : x;
-    const u64 wi = pos >> 5;
-    if (wi != q_wi) {
-      q_wi = wi;
-      q_wv = rw[wi];
+  // bases [first, first + cnt) of a packed sequence (1 <= cnt <= 32), base `first` in the low bits; never touches a
+  // word that holds none of them
+  __host__ __device__ static u64 load_span(const u64* words, u64 first, int cnt) {
+    const u64 wi = first >> 5;
+    const unsigned off = static_cast<unsigned>(first & 31) * 2;
+    u64 x = words[wi] >> off;
+    if (off && ((first + static_cast<u64>(cnt) - 1) >> 5) != wi) x |= words[wi + 1] << (64 - off);
+    return x;
+  }
+  __host__ __device__ void refill_t() {  // rows i, i - 1, ...
+    const u64 pos = static_cast<u64>(t_begin) + static_cast<u64>(i) - 1;
+    const int cnt = i < 32 ? i : 32;
+    t_tail = load_span(tw, pos - static_cast<u64>(cnt - 1), cnt) << (2 * (32 - cnt));
+    t_have = cnt;
+  }
+  __host__ __device__ void refill_q() {  // columns j, j - 1, ... of the oriented read
+    const u64 x = static_cast<u64>(q_begin) + static_cast<u64>(j) - 1;
+    const int cnt = j < 32 ? j : 32;
+    if (!rc) {
+      q_tail = load_span(rw, x - static_cast<u64>(cnt - 1), cnt) << (2 * (32 - cnt));
+    } else {  // stored position r_len - 1 - x and upwards, complemented
+      q_tail = ~rev2(load_span(rw, static_cast<u64>(r_len) - 1 - x, cnt));
     }
-    const u32 c = static_cast<u32>(q_wv >> ((pos & 31) << 1)) & 3u;
-    return rc ? 3u - c : c;
+    q_have = cnt;
+  }
+  // number of matches going down the diagonal from (i, j), at most `lim` (>= 1) and at most what the tails hold
+  __host__ __device__ int match_run(int lim) {
+    if (t_have == 0) refill_t();
+    if (q_have == 0) refill_q();
+    int avail = t_have < q_have ? t_have : q_have;
+    avail = avail < lim ? avail : lim;
+    const u64 x = t_tail ^ q_tail;
+    const u64 y = (x | (x >> 1)) & 0x5555555555555555ULL;  // one bit per differing base, the current base at bit 62
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int run = y ? (__clzll(static_cast<long long>(y)) >> 1) : 32;
+#else
+    const int run = y ? (__builtin_clzll(y) >> 1) : 32;
+#endif
+    return run < avail ? run : avail;
+  }
+  __host__ __device__ void consume(int dt, int dq) {  // the walk moved dt rows and dq columns
+    t_tail = dt >= 32 ? 0 : t_tail << (2 * dt);
+    t_have -= dt;
+    q_tail = dq >= 32 ? 0 : q_tail << (2 * dq);
+    q_have -= dq;
   }
 
   __host__ __device__ void flush(bool write) {
@@ -483,23 +517,61 @@ struct NwWalkerT {
     first_q = q;
     --i;
     --j;
+    consume(1, 1);
+  }
+  // r >= 1 consecutive 'M' steps whose target bases lie in one window: what r calls of take_diag leave behind
+  __host__ __device__ void take_diag_run(int r, bool write) {
+    const u32 t_hi = t_begin + static_cast<u32>(i - 1), q_hi = q_begin + static_cast<u32>(j - 1);
+    const u32 t_lo = t_hi - static_cast<u32>(r - 1);
+    on_target_base(t_hi, q_hi, write);
+    if (!have) {
+      have = true;
+      last_t = t_hi + 1;
+      last_q = q_hi + 1;
+    }
+    // the bases t_hi - 1 .. t_lo: only the grid points among them leave a trace
+    u32 t_prev = t_hi;
+    while (t_prev > t_lo) {
+      while (gx >= 0 && gt >= t_prev) {  // on_target_base(t_prev - 1, ..) would step past these
+        --gx;
+        if (gx >= 0) gt = cw * w + static_cast<u32>((static_cast<u64>(gx) * w) / 8);
+      }
+      if (gx < 0 || gt < t_lo) break;
+      const u32 qv = q_hi - (t_hi - gt);
+#pragma unroll
+      for (int g = 0; g < 8; ++g)
+        if (g == gx) gq[g] = qv;
+      t_prev = gt;
+    }
+    first_t = t_lo;
+    first_q = q_hi - static_cast<u32>(r - 1);
+    i -= r;
+    j -= r;
+    consume(r, r);
   }
 
   // walks while the current column lies inside the segment in the scratch (j > seg_j0) and rows remain
   __host__ __device__ void walk(bool write) {
     while (i > 0 && j > seg_j0) {
-      if (tcode(i) == qcode(j)) {
-        take_diag(write);
+      const int room = i < j - seg_j0 ? i : j - seg_j0;
+      int r = match_run(room);
+      if (r > 0) {  // a match is always taken diagonally: the whole run at once, window by window
+        const u32 t_hi = t_begin + static_cast<u32>(i - 1);
+        const u32 in_window = t_hi - (t_hi / w) * w + 1;  // bases from t_hi down to the start of its window
+        r = static_cast<u32>(r) < in_window ? r : static_cast<int>(in_window);
+        take_diag_run(r, write);
       } else if (cell(i - 1, j - 1) + 1 == cur) {
         --cur;
         take_diag(write);
       } else if (cell(i, j - 1) + 1 == cur) {  // 'I': read base only
         --j;
         --cur;
+        consume(0, 1);
       } else {  // 'D': target base only
         on_target_base(t_begin + static_cast<u32>(i - 1), q_begin + static_cast<u32>(j), write);
         --i;
         --cur;
+        consume(1, 0);
       }
     }
   }
