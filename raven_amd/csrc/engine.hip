@@ -184,7 +184,11 @@ void engine_release_scratch(Engine& e) {
 void engine_release_scratch_if_tight(Engine& e) {
   size_t free_b = 0, total_b = 0;
   if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return;
-  if (free_b * 3 < total_b) engine_release_scratch(e);
+  const bool tight = free_b * 3 < total_b;
+  if (std::getenv("RVN_DEBUG_MEM"))
+    std::fprintf(stderr, "[raven_hip] stage entry: %.1f GB free of %.1f GB%s\n", free_b / 1e9, total_b / 1e9,
+                 tight ? " -> releasing scratch" : "");
+  if (tight) engine_release_scratch(e);
 }
 void engine_minimize(Engine& e, const ReadsDev& r, u32 first, u32 last, bool minhash) {
   do_minimize(e, r, first, last, minhash);
