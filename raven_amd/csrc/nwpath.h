@@ -159,7 +159,8 @@ struct NwLane {
   // R == 1: column range (c_ja .. c_jb) of the block the lane holds and the last column (c_prod) at which the block above
   // is still inside the band, valid while c_s == s — what the plain block update (fast_step) needs instead of re-deriving
   // the band geometry at every step
-  int c_s, c_ja, c_jb, c_prod;
+  int c_s, c_any, c_ja, c_jb, c_end, c_prod, c_rn;
+  bool c_final;
 
   __host__ __device__ void init(const NwJob& J, const u64* t_words, const u64* r_words, const NwBand& band,
                                 const NwStore& store, int lane_) {
@@ -201,45 +202,59 @@ struct NwLane {
   __host__ __device__ void refresh_cache() {
     c_s = s;
     if (s < B.n_super) {
-      const int b = s * R;
-      const int jin = nw_jin(b, B.hi), jout = nw_jout(b, B.lo);
-      c_ja = jin > j0 + 1 ? jin : j0 + 1;
-      c_jb = jout < j_end ? jout : j_end;
-      c_prod = b > 0 ? nw_jout(b - 1, B.lo) : -1;
+      const int b0 = s * R;
+      const int b_last = b0 + R - 1 < B.nb ? b0 + R - 1 : B.nb - 1;
+      const int jin0 = nw_jin(b0, B.hi), jin_last = nw_jin(b_last, B.hi);
+      const int jout0 = nw_jout(b0, B.lo), jout_last = nw_jout(b_last, B.lo);
+      c_any = jin0 > j0 + 1 ? jin0 : j0 + 1;          // first column at which a block of the lane is active
+      c_ja = jin_last > j0 + 1 ? jin_last : j0 + 1;   // first column of the last block to enter
+      c_jb = jout0 < j_end ? jout0 : j_end;           // last column with every block inside
+      c_end = jout_last < j_end ? jout_last : j_end;  // last column of the lane's blocks (then: ring advance)
+      c_prod = b0 > 0 ? nw_jout(b0 - 1, B.lo) : -1;
+      c_rn = b_last - b0 + 1;
+      c_final = b_last == B.nb - 1;
     }
   }
 
-  // What step(t, ..) would do on this lane (R == 1): 0 = nothing, 1 = the plain update of its block at column t - s
-  // (fast_step does exactly that), 2 = anything else (ring advance, first column of a block, the final cell, ...).
-  // The kernels take the short path when no lane of the wave says 2.
+  // What step(t, ..) would do on this lane: 0 = nothing, 1 = the plain update of ALL its blocks at column t - s
+  // (fast_step does exactly that), 2 = anything else (ring advance, a block entering or leaving the band, first
+  // columns, the final cell, ...).  The kernels take the short path when no lane of the wave says 2.
   __host__ __device__ int classify(int t) const {  // branch-free: it runs on every lane at every step
     const int j = t - s;
     const bool live = s < B.n_super;
-    const bool inside = j >= c_ja && j <= c_jb;  // inside the band and the sweep
-    const bool event = (c_s != s) || j > c_jb  // stale cache / the block leaves the band or the sweep: ring advance
-                       || (inside && (fresh || j == c_ja || (j > c_prod && !tc_valid)  // first column / starts reading the text
-                                      || (s * R == B.nb - 1 && j == static_cast<int>(m))));  // the final cell
-    return live ? (event ? 2 : (inside ? 1 : 0)) : 0;
+    const bool active = j >= c_any && j <= c_end;  // some block of the lane is inside the band and the sweep
+    const bool plain = j > c_ja && j <= c_jb;      // all of them are, and none is at its first column
+    const bool event = (c_s != s) || j > c_end     // stale cache / ring advance
+                       || (active && (!plain || fresh || (j > c_prod && !tc_valid)  // partial / starts reading the text
+                                      || (c_final && j == static_cast<int>(m))));    // the final cell
+    return live ? (event ? 2 : (active ? 1 : 0)) : 0;
   }
 
   __host__ __device__ void fast_step(int t, int x_prev) {
     const int j = t - s;
     const bool fed = j <= c_prod;
     const unsigned c = fed ? static_cast<unsigned>(x_prev >> 2) : tc.get(j);
-    const int hin = fed ? (x_prev & 3) - 1 : 1;
-    const int hout = myers_block(Pv[0], Mv[0], planes_eq(pl[0], c), hin);
-    score[0] += hout;
-    if (mode == 1) {
-      const u64 slot = (static_cast<u64>(t - t0) * B.L + static_cast<u64>(lane)) * R;
-      st.seg_pm[slot] = NwPm{Pv[0], Mv[0]};
-      st.seg_sc[slot] = score[0];
-    } else if (j % kNwSeg == 0) {
-      const u64 cs = static_cast<u64>(j / kNwSeg) * st.ckpt_nb + static_cast<u64>(s * R - nw_bfirst(j, B.lo));
-      st.ck_pm[cs] = NwPm{Pv[0], Mv[0]};
-      st.ck_sc[cs] = score[0];
+    int hin = fed ? (x_prev & 3) - 1 : 1;
+    const u32 slot0 = (static_cast<u32>(t - t0) * static_cast<u32>(B.L) + static_cast<u32>(lane)) * R;
+    const bool ckpt = mode != 1 && j % kNwSeg == 0;
+    const u64 cs0 = ckpt ? static_cast<u64>(j / kNwSeg) * st.ckpt_nb + static_cast<u64>(s * R - nw_bfirst(j, B.lo)) : 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      if (r < c_rn) {
+        const int hout = myers_block(Pv[r], Mv[r], planes_eq(pl[r], c), hin);
+        score[r] += hout;
+        hin = hout;
+        if (mode == 1) {
+          st.seg_pm[slot0 + r] = NwPm{Pv[r], Mv[r]};
+          st.seg_sc[slot0 + r] = score[r];
+        } else if (ckpt) {
+          st.ck_pm[cs0 + r] = NwPm{Pv[r], Mv[r]};
+          st.ck_sc[cs0 + r] = score[r];
+        }
+      }
     }
-    xfer_last = (hout + 1) | static_cast<int>(c << 2);
-    score_last = score[0];
+    xfer_last = (hin + 1) | static_cast<int>(c << 2);
+    score_last = score[R - 1];
   }
 
   __host__ __device__ void step(int t, int x_prev, int score_prev) {
@@ -372,8 +387,8 @@ struct NwWalkerT {
   // position
   int i, j;
   u32 cur;
-  // window being walked through (windows are visited from the last to the first)
-  u32 cw;
+  // window being walked through (windows are visited from the last to the first); cw_lo = its first target base
+  u32 cw, cw_lo;
   bool have;
   u32 first_t, first_q, last_t, last_q;
   u32 gq[8];
@@ -400,6 +415,7 @@ struct NwWalkerT {
     j = static_cast<int>(J.m);
     cur = distance;
     cw = 0xFFFFFFFFu;
+    cw_lo = 0;
     have = false;
     first_t = first_q = last_t = last_q = 0;
     for (int g = 0; g < 8; ++g) gq[g] = 0xFFFFFFFFu;
@@ -486,18 +502,19 @@ struct NwWalkerT {
   }
   // the path consumes target base t with the read standing at oriented position q
   __host__ __device__ void on_target_base(u32 t, u32 q, bool write) {
-    const u32 wi = t / w;
-    if (wi != cw) {
+    if (cw == 0xFFFFFFFFu || t < cw_lo || t - cw_lo >= w) {  // another window (the division only here)
+      const u32 wi = t / w;
       flush(write);
       cw = wi;
+      cw_lo = wi * w;
       have = false;
       for (int g = 0; g < 8; ++g) gq[g] = 0xFFFFFFFFu;
       gx = 7;
-      gt = wi * w + static_cast<u32>((7ULL * w) / 8);
+      gt = cw_lo + static_cast<u32>((7ULL * w) / 8);
     }
     while (gx >= 0 && t < gt) {
       --gx;
-      if (gx >= 0) gt = wi * w + static_cast<u32>((static_cast<u64>(gx) * w) / 8);
+      if (gx >= 0) gt = cw_lo + static_cast<u32>((static_cast<u64>(gx) * w) / 8);
     }
     if (gx >= 0 && t == gt) {
 #pragma unroll
@@ -534,7 +551,7 @@ struct NwWalkerT {
     while (t_prev > t_lo) {
       while (gx >= 0 && gt >= t_prev) {  // on_target_base(t_prev - 1, ..) would step past these
         --gx;
-        if (gx >= 0) gt = cw * w + static_cast<u32>((static_cast<u64>(gx) * w) / 8);
+        if (gx >= 0) gt = cw_lo + static_cast<u32>((static_cast<u64>(gx) * w) / 8);
       }
       if (gx < 0 || gt < t_lo) break;
       const u32 qv = q_hi - (t_hi - gt);
@@ -557,7 +574,9 @@ struct NwWalkerT {
       int r = match_run(room);
       if (r > 0) {  // a match is always taken diagonally: the whole run at once, window by window
         const u32 t_hi = t_begin + static_cast<u32>(i - 1);
-        const u32 in_window = t_hi - (t_hi / w) * w + 1;  // bases from t_hi down to the start of its window
+        // bases from t_hi down to the start of its window
+        const bool same = cw != 0xFFFFFFFFu && t_hi >= cw_lo && t_hi - cw_lo < w;
+        const u32 in_window = same ? t_hi - cw_lo + 1 : t_hi - (t_hi / w) * w + 1;
         r = static_cast<u32>(r) < in_window ? r : static_cast<int>(in_window);
         take_diag_run(r, write);
       } else if (cell(i - 1, j - 1) + 1 == cur) {

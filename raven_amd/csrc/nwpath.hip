@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(R == 1 ? 4 
         const int t1 = NwLane<R>::sweep_t1(B, static_cast<int>(J.m));
         for (int t = ln.t0; t <= t1; ++t) {
           const int hp = group_prev<G>(ln.xfer_last, lig, gbase, B.L);
-          if constexpr (R == 1) {  // most steps are plain block updates on every lane of the wave
+          {  // most steps are plain block updates on every lane of the wave
             const int cls = ln.classify(t);
             if (__ballot(cls == 2) == 0) {
               if (cls == 1) ln.fast_step(t, hp);
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(R == 1 ? 4 
           }
           const int sp = group_prev<G>(ln.score_last, lig, gbase, B.L);
           ln.step(t, hp, sp);
-          if constexpr (R == 1) ln.refresh_cache();
+          ln.refresh_cache();
         }
         res = group_max<G>(ln.result) - 1u;  // exactly one lane of the group holds D(n, m) + 1
         if (res <= k) {
@@ -147,11 +147,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(R == 1 ? 4 
           const int j0 = sg * kNwSeg;
           const int j_end = j0 + kNwSeg < static_cast<int>(J.m) ? j0 + kNwSeg : static_cast<int>(J.m);
           const unsigned long long c1 = __builtin_readcyclecounter();
+          // The walk only moves up: rows below the one it stands on are never read again, and a block never depends
+          // on the blocks below it — the re-sweep stops at the block of the walker's row (on average half the band).
+          NwBand Bs = B;
+          const int nb_need = ((rows_left - 1) >> 6) + 1;
+          if (nb_need < Bs.nb) {
+            Bs.nb = nb_need;
+            Bs.n_super = (nb_need + R - 1) / R;
+          }
+          ln.B = Bs;
           ln.begin_sweep(j0, j_end, 1);
-          const int t1 = NwLane<R>::sweep_t1(B, j_end);
+          const int t1 = NwLane<R>::sweep_t1(Bs, j_end);
           for (int t = ln.t0; t <= t1; ++t) {
             const int hp = group_prev<G>(ln.xfer_last, lig, gbase, B.L);
-            if constexpr (R == 1) {
+            {
               const int cls = ln.classify(t);
               if (__ballot(cls == 2) == 0) {
                 if (cls == 1) ln.fast_step(t, hp);
@@ -162,7 +171,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(R == 1 ? 4 
             }
             const int sp = group_prev<G>(ln.score_last, lig, gbase, B.L);
             ln.step(t, hp, sp);
-            if constexpr (R == 1) ln.refresh_cache();
+            ln.refresh_cache();
           }
           nw_wsync();  // the segment's block states (and the walker in LDS) visible to every lane
           const unsigned long long c2 = __builtin_readcyclecounter();
@@ -511,16 +520,15 @@ static int emulate_job(const NwJob& J, const u64* t_words, const u64* r_words, u
         hp[l] = lanes[src].xfer_last;
         sp[l] = lanes[src].score_last;
       }
-      bool any_slow = R != 1;
-      if (R == 1)
-        for (int l = 0; l < 64; ++l) any_slow = any_slow || lanes[l].classify(t) == 2;
+      bool any_slow = false;
+      for (int l = 0; l < 64; ++l) any_slow = any_slow || lanes[l].classify(t) == 2;
       if (!any_slow) {  // the kernel's short path: no lane of the wave needs more than the plain block update
         for (int l = 0; l < 64; ++l)
           if (lanes[l].classify(t) == 1) lanes[l].fast_step(t, hp[l]);
       } else {
         for (int l = 0; l < 64; ++l) {
           lanes[l].step(t, hp[l], sp[l]);
-          if (R == 1) lanes[l].refresh_cache();
+          lanes[l].refresh_cache();
         }
       }
       if (mode == 1 && static_cast<u64>(t - lanes[0].t0) >= nw_seg_rows()) return false;  // scratch rows exceeded
@@ -551,7 +559,20 @@ static int emulate_job(const NwJob& J, const u64* t_words, const u64* r_words, u
   for (int sg = (static_cast<int>(J.m) - 1) / kNwSeg; sg >= 0 && wk.i > 0; --sg) {
     const int j0 = sg * kNwSeg;
     const int j_end = std::min<int>(j0 + kNwSeg, static_cast<int>(J.m));
-    if (!sweep(j0, j_end, 1)) return -4;
+    {  // as in the kernel: the re-sweep stops at the block of the walker's row
+      NwBand Bs = B;
+      const int nb_need = ((wk.i - 1) >> 6) + 1;
+      if (nb_need < Bs.nb) {
+        Bs.nb = nb_need;
+        Bs.n_super = (nb_need + R - 1) / R;
+      }
+      for (int l = 0; l < 64; ++l) lanes[l].B = Bs;
+      const NwBand keep = B;
+      B = Bs;
+      const bool ok_sweep = sweep(j0, j_end, 1);
+      B = keep;
+      if (!ok_sweep) return -4;
+    }
     wk.set_segment(j0, lanes[0].t0);
     wk.walk(true);
   }
