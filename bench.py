@@ -290,7 +290,7 @@ def main():
         steps = max(args.steps, 1)
         counters = {k: v // steps for k, v in counters_raw.items()}
         val_bytes = 4 if 2 * eng.k < 32 else 8
-        kernels, roofline, roofline_hbm, roofline_poa = {}, None, None, None
+        kernels, roofline, roofline_hbm, roofline_poa, roofline_nw = {}, None, None, None, None
         if kms:
             tot = sum(v[0] for v in kms.values())
             for name, (ms, la) in sorted(kms.items(), key=lambda x: -x[1][0]):
@@ -321,16 +321,16 @@ def main():
                                     "spoa's full NW computes); the kernel computes a 64-column band of them"}
             if dom == "poa_banded":
                 roofline = roofline_poa
-            if dom == "nw_forward" and last.get("polish", {}).get("align_band_cells"):
+            if "nw_forward" in kms and kms["nw_forward"][1] and last.get("polish", {}).get("align_band_cells"):
                 # the alignment-path kernel (Myers bit-vector band, racon's edlib NW): integer VALU bound as well
-                ms, la = kms[dom]
+                ms, la = kms["nw_forward"]
                 launches_per_round = la / max(args.steps * args.polish_rounds, 1)
                 cells_per_launch = last["polish"]["align_band_cells"] / max(launches_per_round, 1e-9)
                 avg_s = ms / la / 1e3
                 achieved_tops = cells_per_launch * NW_MIN_OPS_PER_CELL / avg_s / 1e12
-                roofline = {"bound": "valu", "kernel": dom, "achieved": round(achieved_tops, 3),
+                roofline_nw = {"bound": "valu", "kernel": "nw_forward", "achieved": round(achieved_tops, 3),
                             "peak": round(VALU_PEAK_LANE_OPS / 1e12, 1), "unit": "T lane-ops/s",
-                            "frac": round(achieved_tops * 1e12 / VALU_PEAK_LANE_OPS, 4), "traffic": pmc_traffic(dom),
+                            "frac": round(achieved_tops * 1e12 / VALU_PEAK_LANE_OPS, 4), "traffic": pmc_traffic("nw_forward"),
                             "algorithmic_cells_per_launch": int(cells_per_launch),
                             "algorithmic_ops_per_cell": round(NW_MIN_OPS_PER_CELL, 3),
                             "gcups_band": round(cells_per_launch / avg_s / 1e9, 1), "avg_launch_ms": round(avg_s * 1e3, 3),
@@ -339,6 +339,8 @@ def main():
                                     "threshold that succeeds (one sweep); the kernel sweeps them twice (checkpoints, then "
                                     "per-segment re-sweep for the traceback).  50 32-bit lane operations per 64-cell block "
                                     "step of Myers' recurrence incl. the match mask."}
+            if dom == "nw_forward":
+                roofline = roofline_nw
             # the dominant HBM-bound kernel (second entry)
             for name in kernels:
                 b = algorithmic_bytes(name, counters, val_bytes)
@@ -392,6 +394,7 @@ def main():
             "roofline": roofline,
             "roofline_hbm": roofline_hbm,
             "roofline_poa": roofline_poa if roofline is not roofline_poa else None,
+            "roofline_nw": roofline_nw if roofline is not roofline_nw else None,
             "kernels": dict(list(kernels.items())[:16]),
             "host": {"gen_s": round(t_gen, 2), "h2d_s": round(t_h2d, 3),
                      "h2d_inclusive_gbase_s": round(rs.total_bases / (dt / steps + t_h2d) / 1e9, 4)},
