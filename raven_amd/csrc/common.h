@@ -1,6 +1,7 @@
 // common.h — host-side plumbing shared by the HIP translation units.
 #pragma once
 
+#include <chrono>
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
@@ -130,6 +131,18 @@ enum KernelSite {
   kKAddLayers, kKTruncateSort, kKKeptWrite, kKGather, kKPileSortUp, kKPileSortDown, kKChainSmall, kKJoinCount, kKJoinEmit, kKEditBanded, kKEditFull, kKPoa, kKAddKmers, kKPoaBanded, kKPileTrim, kKNwForward, kKNwTraceback, kKEditLane, kKNwLane, kKBestOverlap, kKLayerBuild, kKStitch, kKNumSites
 };
 extern const char* const kKernelSiteNames[kKNumSites];
+
+// hipStreamSynchronize that polls the stream for a while before it blocks: a blocking wait costs a wake-up latency of
+// several milliseconds on some hosts, and a pass has ~60 short waits (size read-backs between stages) — at C4 they added
+// up to 0.5 s per pass on such hosts although the kernels took 0.29 s.  Long waits fall back to the blocking call.
+inline hipError_t rvn_stream_sync(hipStream_t s) {
+  const auto t0 = std::chrono::steady_clock::now();
+  for (;;) {
+    const hipError_t q = hipStreamQuery(s);
+    if (q != hipErrorNotReady) return q;
+    if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(100)) return hipStreamSynchronize(s);
+  }
+}
 
 struct KernelTimers {
   bool enabled = false;

@@ -407,7 +407,7 @@ void edit_distance_dev(Engine& e, const ReadsDev& r, const u32* d_pairs_raw, u32
   std::vector<EdPair> hp(n_pairs);
   RVN_HIP(hipMemcpyAsync(todo.data(), d_todo, static_cast<size_t>(n_full) * 4, hipMemcpyDeviceToHost, s));
   RVN_HIP(hipMemcpyAsync(hp.data(), d_pairs, static_cast<size_t>(n_pairs) * sizeof(EdPair), hipMemcpyDeviceToHost, s));
-  RVN_HIP(hipStreamSynchronize(s));
+  RVN_HIP(rvn_stream_sync(s));
   std::sort(todo.begin(), todo.end());
   std::vector<u64> hb_off;
   u64 hb_total = 0;
@@ -421,7 +421,7 @@ void edit_distance_dev(Engine& e, const ReadsDev& r, const u32* d_pairs_raw, u32
   RVN_HIP(hipMemcpyAsync(d_off, hb_off.data(), hb_off.size() * 8, hipMemcpyHostToDevice, s));
   RVN_KLAUNCH(kKEditFull, ed_full_kernel<<<n_full, 64, 0, s>>>(r.packed.as<u64>(), r.word_off.as<u64>(), d_pairs, d_todo, n_full,
                                                                d_off, d_hb, d_out));
-  RVN_HIP(hipStreamSynchronize(s));  // the host lists above are locals
+  RVN_HIP(rvn_stream_sync(s));  // the host lists above are locals
 }
 
 // pairs: host array of n_pairs x 8 u32 {a_idx,a_begin,a_len,b_idx,b_begin,b_len,strand,0}; out: host u32[n_pairs]
@@ -436,7 +436,7 @@ void edit_distance_batch(Engine& e, const ReadsDev& r, const u32* h_pairs, u32 n
   edit_distance_dev(e, r, reinterpret_cast<const u32*>(d_pairs), n_pairs, d_out, nullptr);
   RVN_HIP(hipEventRecord(e.ev1, s));
   RVN_HIP(hipMemcpyAsync(h_out, d_out, static_cast<size_t>(n_pairs) * 4, hipMemcpyDeviceToHost, s));
-  RVN_HIP(hipStreamSynchronize(s));
+  RVN_HIP(rvn_stream_sync(s));
   RVN_HIP(hipEventSynchronize(e.ev1));
   if (kernel_ms) {
     float ms = 0;

@@ -179,7 +179,7 @@ void engine_release_scratch_if_tight(Engine& e);
 inline u64 read_back(Engine& e, const void* dptr, size_t bytes) {
   e.h_pin[0] = 0;
   RVN_HIP(hipMemcpyAsync(e.h_pin, dptr, bytes, hipMemcpyDeviceToHost, e.stream));
-  RVN_HIP(hipStreamSynchronize(e.stream));
+  RVN_HIP(rvn_stream_sync(e.stream));
   return e.h_pin[0];
 }
 

@@ -1,6 +1,7 @@
 // engine.hip — host orchestration + the C ABI declared in include/raven_hip.h.
 #include "engine.h"
 
+#include <chrono>
 #include <cstring>
 #include <memory>
 #include <new>
@@ -81,6 +82,13 @@ const char* kStageNames[StageTimes::kNum] = {"sketch", "sort", "index", "filter"
 struct UseTimers {
   explicit UseTimers(Engine& e) {
     e.ktimers.stream = e.stream;
+    // Fold the event pairs of the previous entry point into the per-site sums now (the stream is idle between entry
+    // points): the events are reused instead of growing the pool by two hipEventCreate per launch, which cost more
+    // than the launches themselves on a slow host (0.5 s per pass at C4).
+    if (e.ktimers.enabled && !e.ktimers.recs.empty()) {
+      (void)rvn_stream_sync(e.stream);
+      e.ktimers.resolve();
+    }
     g_kernel_timers = &e.ktimers;
   }
   ~UseTimers() { g_kernel_timers = nullptr; }
@@ -154,7 +162,7 @@ void do_minimize(Engine& e, const ReadsDev& r, u32 first, u32 last, bool minhash
 
 namespace rvn {
 void engine_release_scratch(Engine& e) {
-  if (e.stream) (void)hipStreamSynchronize(e.stream);
+  if (e.stream) (void)rvn_stream_sync(e.stream);
   e.query_ready = false;
   DevBuf* bufs[] = {
       &e.index.s_val[0], &e.index.s_val[1], &e.index.s_org[0], &e.index.s_org[1], &e.index.u_val, &e.index.u_start,
@@ -246,7 +254,7 @@ int rvn_engine_create(rvn_engine** out, uint32_t k, uint32_t w, uint32_t bandwid
 void rvn_engine_destroy(rvn_engine* h) {
   if (!h) return;
   (void)hipSetDevice(h->e.device);
-  if (h->e.stream) (void)hipStreamSynchronize(h->e.stream);
+  if (h->e.stream) (void)rvn_stream_sync(h->e.stream);
   if (h->e.ev0) (void)hipEventDestroy(h->e.ev0);
   if (h->e.ev1) (void)hipEventDestroy(h->e.ev1);
   if (h->e.stream) (void)hipStreamDestroy(h->e.stream);
@@ -332,7 +340,7 @@ int rvn_reads_upload_codes(rvn_engine* h, const uint8_t* codes, const uint64_t* 
     u64* d_packed = r.packed.get<u64>(n_words + 2);
     pack_codes_on_device(e, d_codes, d_boff, d_woff, n, n_words, d_packed);
     RVN_HIP(hipMemsetAsync(d_packed + n_words, 0, 16, e.stream));
-    RVN_HIP(hipStreamSynchronize(e.stream));
+    RVN_HIP(rvn_stream_sync(e.stream));
     r.n = n;
     r.h_word_off = woff;
     r.h_len = lens;
@@ -444,7 +452,7 @@ int rvn_engine_minimize(rvn_engine* h, const rvn_reads* r, uint32_t first, uint3
     RVN_HIP(hipSetDevice(h->e.device));
     UseTimers ut(h->e);
     do_minimize(h->e, r->r, first, last, minhash != 0);
-    RVN_HIP(hipStreamSynchronize(h->e.stream));
+    RVN_HIP(rvn_stream_sync(h->e.stream));
     return RVN_OK;
   });
 }
@@ -471,7 +479,7 @@ int rvn_engine_map_batch(rvn_engine* h, const rvn_reads* r, uint32_t first, uint
     map_batch(h->e, r->r, first, last, avoid_equal != 0, avoid_symmetric != 0, minhash != 0, want_filtered != 0,
               h->e.map_out);
     h->e.c_intervals += h->e.map_out.n_intervals;
-    RVN_HIP(hipStreamSynchronize(h->e.stream));
+    RVN_HIP(rvn_stream_sync(h->e.stream));
     if (n_overlaps) *n_overlaps = h->e.map_out.n_overlaps;
     return RVN_OK;
   });
@@ -599,13 +607,27 @@ int rvn_find_overlaps_and_create_piles(rvn_engine* h, const rvn_reads* rr, doubl
     if (!(0 <= freq && freq <= 1)) return fail(RVN_EINVAL, "[ram::MinimizerEngine::Filter] error: invalid frequency");
     Engine& e = h->e;
     const ReadsDev& r = rr->r;
+    const bool dbg = std::getenv("RVN_DEBUG_PASS1") != nullptr;  // host wall time per stage (synchronising)
+    auto t_last = std::chrono::steady_clock::now();
     for (u32 i = 0; i < r.n; ++i)
       if (r.h_id[i] != i) return fail(RVN_EINVAL, "[raven_hip] FindOverlapsAndCreatePiles requires ids[i] == i");
     RVN_HIP(hipSetDevice(e.device));
     UseTimers ut(e);
+    if (dbg) std::fprintf(stderr, "[raven_hip] pass1: %-12s %8.1f ms\n", "timers",
+                          std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_last).count());
     engine_release_scratch_if_tight(e);
+    auto lap = [&](const char* what) {
+      if (!dbg) return;
+      (void)rvn_stream_sync(e.stream);
+      const auto now = std::chrono::steady_clock::now();
+      std::fprintf(stderr, "[raven_hip] pass1: %-12s %8.1f ms\n", what,
+                   std::chrono::duration<double, std::milli>(now - t_last).count());
+      t_last = now;
+    };
     std::unique_ptr<rvn_pass1> p(new rvn_pass1(e));
+    lap("handle");
     piles_init(e, r, p->ps);
+    lap("piles_init");
     const u32 n = r.n;
     // construct.cc:32-120
     u64 bytes = 0;
@@ -626,20 +648,24 @@ int rvn_find_overlaps_and_create_piles(rvn_engine* h, const rvn_reads* rr, doubl
         prefetch = (kk == i);
       }
       do_minimize(e, r, j, i + 1, use_minhash != 0, prefetch);
+      lap("minimize");
       index_filter(e, freq);
+      lap("filter");
       u32 flush_first = 0;
       for (u32 k = 0; k < i + 1; ++k) {
         bytes += r.h_len[k];
         if (k != i && bytes < flush_bases) continue;
         bytes = 0;
         map_batch(e, r, flush_first, k + 1, true, true, true, false, e.map_out);
+        lap("map_batch");
         e.c_intervals += e.map_out.n_intervals;
         piles_merge(e, r, e.map_out, kmax, p->ps);
+        lap("piles_merge");
         flush_first = k + 1;
       }
       j = i + 1;
     }
-    RVN_HIP(hipStreamSynchronize(e.stream));
+    RVN_HIP(rvn_stream_sync(e.stream));
     *out = p.release();
     return RVN_OK;
   });
@@ -994,7 +1020,7 @@ int rvn_shard_sketch(rvn_engine* h, const rvn_reads* rr, int index_minhash, uint
     }
     for (u32 i = 0; i < r.n; ++i) e.c_index_bases += r.h_len[i];
     t.stop();
-    RVN_HIP(hipStreamSynchronize(e.stream));
+    RVN_HIP(rvn_stream_sync(e.stream));
     return RVN_OK;
   });
 }
@@ -1040,7 +1066,7 @@ int rvn_shard_index_build(rvn_engine* h, const uint64_t* values, const uint64_t*
     e.index.has_query_flags = !all_query;
     e.index.all_query = all_query != 0;
     e.join_query_count = all_query ? n : flagged;
-    RVN_HIP(hipStreamSynchronize(e.stream));
+    RVN_HIP(rvn_stream_sync(e.stream));
     return RVN_OK;
   });
 }
@@ -1080,7 +1106,7 @@ int rvn_shard_join_range(rvn_engine* h, uint32_t n_reads_total, int avoid_equal,
     e.shard_join_reads = n_reads_total;
     e.shard_join_matches = join_index_matches(e, n_reads_total, avoid_equal != 0, avoid_symmetric != 0, query_first, query_last);
     *n_matches = e.shard_join_matches;
-    RVN_HIP(hipStreamSynchronize(e.stream));
+    RVN_HIP(rvn_stream_sync(e.stream));
     return RVN_OK;
   });
 }
@@ -1129,7 +1155,7 @@ int rvn_shard_chain(rvn_engine* h, const rvn_reads* own, const uint64_t* grp, co
     for (u32 i = 0; i < nr; ++i) e.c_query_bases += r.h_len[i];
     chain_matches(e, r, 0, nr, H, out);
     e.c_intervals += out.n_intervals;
-    RVN_HIP(hipStreamSynchronize(e.stream));
+    RVN_HIP(rvn_stream_sync(e.stream));
     *n_overlaps = out.n_overlaps;
     return RVN_OK;
   });
@@ -1189,7 +1215,7 @@ int rvn_shard_piles_merge(rvn_pass1* p, const rvn_overlap* overlaps, uint64_t n,
     u32* d_off = mo.ovl_read_off.get<u32>(off.size());
     RVN_HIP(hipMemcpy(d_off, off.data(), off.size() * 4, hipMemcpyHostToDevice));
     piles_merge(e, *p->meta, mo, kmax, p->ps);
-    RVN_HIP(hipStreamSynchronize(e.stream));
+    RVN_HIP(rvn_stream_sync(e.stream));
     return RVN_OK;
   });
 }
@@ -1213,7 +1239,7 @@ int rvn_shard_piles_merge_dev(rvn_pass1* p, const rvn_overlap* d_overlaps, const
     RVN_HIP(hipMemcpyAsync(d_off, d_ovl_read_off, (static_cast<size_t>(n_reads_total) + 1) * 4, hipMemcpyDeviceToDevice,
                            e.stream));
     piles_merge(e, *p->meta, mo, kmax, p->ps);
-    RVN_HIP(hipStreamSynchronize(e.stream));
+    RVN_HIP(rvn_stream_sync(e.stream));
     return RVN_OK;
   });
 }
@@ -1256,7 +1282,7 @@ int rvn_shard_sketch_fetch_dev(rvn_engine* h, uint64_t* d_values, uint64_t* d_or
     if (e.val64) RVN_HIP(hipMemcpyAsync(d_values, s.val.ptr, s.count * 8, hipMemcpyDeviceToDevice, e.stream));
     else widen_u32_u64_kernel<<<static_cast<u32>((s.count + 255) / 256), 256, 0, e.stream>>>(s.val.as<u32>(), d_values, s.count);
     RVN_HIP(hipMemcpyAsync(d_origins, s.org.ptr, s.count * 8, hipMemcpyDeviceToDevice, e.stream));
-    RVN_HIP(hipStreamSynchronize(e.stream));
+    RVN_HIP(rvn_stream_sync(e.stream));
     return RVN_OK;
   });
 }
@@ -1287,7 +1313,7 @@ int rvn_shard_index_build_dev(rvn_engine* h, const uint64_t* d_values, const uin
     e.index.has_query_flags = !all_query;
     e.index.all_query = all_query != 0;
     e.join_query_count = all_query ? n : n_flagged;
-    RVN_HIP(hipStreamSynchronize(e.stream));
+    RVN_HIP(rvn_stream_sync(e.stream));
     return RVN_OK;
   });
 }
@@ -1320,7 +1346,7 @@ int rvn_shard_join_fetch_dev(rvn_engine* h, uint64_t* d_grp, uint64_t* d_pos, ui
     if (d_seg_off)
       RVN_HIP(hipMemcpyAsync(d_seg_off, e.seg_off.ptr, (static_cast<size_t>(e.shard_join_reads) + 1) * 8,
                              hipMemcpyDeviceToDevice, e.stream));
-    RVN_HIP(hipStreamSynchronize(e.stream));
+    RVN_HIP(rvn_stream_sync(e.stream));
     return RVN_OK;
   });
 }
@@ -1355,7 +1381,7 @@ int rvn_shard_chain_dev(rvn_engine* h, const rvn_reads* own, const uint64_t* d_g
     for (u32 i = 0; i < nr; ++i) e.c_query_bases += r.h_len[i];
     chain_matches(e, r, 0, nr, H, out);
     e.c_intervals += out.n_intervals;
-    RVN_HIP(hipStreamSynchronize(e.stream));
+    RVN_HIP(rvn_stream_sync(e.stream));
     *n_overlaps = out.n_overlaps;
     return RVN_OK;
   });
@@ -1371,7 +1397,7 @@ int rvn_engine_map_fetch_dev(rvn_engine* h, rvn_overlap* d_overlaps, uint32_t* d
     if (d_read_offsets)
       RVN_HIP(hipMemcpyAsync(d_read_offsets, m.ovl_read_off.ptr, (static_cast<size_t>(m.last - m.first) + 1) * 4,
                              hipMemcpyDeviceToDevice, h->e.stream));
-    RVN_HIP(hipStreamSynchronize(h->e.stream));
+    RVN_HIP(rvn_stream_sync(h->e.stream));
     return RVN_OK;
   });
 }
@@ -1431,7 +1457,7 @@ int rvn_shard_adjacent_diff_dev(rvn_engine* h, const uint64_t* d_seg_off, uint64
     if (!h || (n && (!d_seg_off || !d_counts))) return fail(RVN_EINVAL, "[raven_hip] rvn_shard_adjacent_diff_dev: bad argument");
     RVN_HIP(hipSetDevice(h->e.device));
     shard_adjacent_diff(h->e, d_seg_off, n, d_counts);
-    RVN_HIP(hipStreamSynchronize(h->e.stream));
+    RVN_HIP(rvn_stream_sync(h->e.stream));
     return RVN_OK;
   });
 }
@@ -1445,7 +1471,7 @@ int rvn_shard_regroup_dev(rvn_engine* h, uint32_t world, const uint64_t* const* 
     RVN_HIP(hipSetDevice(h->e.device));
     UseTimers ut(h->e);
     shard_regroup(h->e, world, d_counts, d_group, d_positions, n_per_source, n_reads, d_seg_off, d_group_out, d_positions_out);
-    RVN_HIP(hipStreamSynchronize(h->e.stream));
+    RVN_HIP(rvn_stream_sync(h->e.stream));
     return RVN_OK;
   });
 }
@@ -1475,7 +1501,7 @@ int rvn_shard_piles_merge_parts_dev(rvn_pass1* p, uint32_t n_parts, const rvn_ov
     u32* d_off = mo.ovl_read_off.get<u32>(static_cast<size_t>(n_reads_total) + 1);
     shard_lhs_offsets(e, d_ov, n, n_reads_total, d_off);
     piles_merge(e, *p->meta, mo, kmax, p->ps);
-    RVN_HIP(hipStreamSynchronize(e.stream));
+    RVN_HIP(rvn_stream_sync(e.stream));
     return RVN_OK;
   });
 }
@@ -1514,7 +1540,7 @@ int rvn_engine_sketch(rvn_engine* h, const rvn_reads* r, uint32_t first, uint32_
     RVN_HIP(hipSetDevice(h->e.device));
     UseTimers ut(h->e);
     sketch_range(h->e, r->r, first, last, minhash != 0, h->e.query_sketch);
-    RVN_HIP(hipStreamSynchronize(h->e.stream));
+    RVN_HIP(rvn_stream_sync(h->e.stream));
     if (count) *count = h->e.query_sketch.count;
     return RVN_OK;
   });
@@ -1628,7 +1654,7 @@ int rvn_engine_kernel_ms(rvn_engine* h, double* ms, uint64_t* launches, int n) {
     if (!h) return fail(RVN_EINVAL, "[raven_hip] NULL engine");
     Engine& e = h->e;
     RVN_HIP(hipSetDevice(e.device));
-    RVN_HIP(hipStreamSynchronize(e.stream));
+    RVN_HIP(rvn_stream_sync(e.stream));
     e.ktimers.resolve();
     for (int i = 0; i < n && i < kKNumSites; ++i) {
       if (ms) ms[i] = e.ktimers.ms[i];

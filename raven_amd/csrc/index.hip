@@ -250,7 +250,7 @@ void index_key_histogram(Engine& e, std::vector<u64>& hist, std::vector<u32>& ov
   RVN_KLAUNCH(kKOccHist, occ_hist_kernel<<<grid, 256, 0, s>>>(ix.u_start.as<u32>(), u, d_hist, d_over, d_hist + kHistBins, overflow_cap));
   std::vector<u32> h(kHistBins + 1);
   RVN_HIP(hipMemcpyAsync(h.data(), d_hist, (kHistBins + 1) * 4, hipMemcpyDeviceToHost, s));
-  RVN_HIP(hipStreamSynchronize(s));
+  RVN_HIP(rvn_stream_sync(s));
   const u32 n_over = h[kHistBins];
   if (n_over > overflow_cap) throw HipError("[raven_hip] key histogram: overflow list too small");
   for (u32 i = 0; i < kHistBins; ++i) hist[i] = h[i];
@@ -281,7 +281,7 @@ void index_filter(Engine& e, double freq) {
   RVN_KLAUNCH(kKOccHist, occ_quantile_kernel<<<1, 256, 0, s>>>(hist, nth, qout));
   RVN_HIP(hipMemcpyAsync(e.h_pin, qout, 16, hipMemcpyDeviceToHost, s));
   RVN_HIP(hipMemcpyAsync(e.h_pin + 2, hist + kHistBins, 4, hipMemcpyDeviceToHost, s));
-  RVN_HIP(hipStreamSynchronize(s));
+  RVN_HIP(rvn_stream_sync(s));
   u32 c = static_cast<u32>(e.h_pin[0]);
   if (c >= kHistBins - 1) {
     // quantile lands among run lengths >= 65535: resolve exactly from the overflow list

@@ -99,7 +99,7 @@ void ensure_capacity(DevBuf& buf, u64 used_bytes, u64 need_bytes, hipStream_t s)
   DevBuf bigger;
   bigger.reserve(std::max<u64>(need_bytes * 2, 1 << 20));
   if (used_bytes) RVN_HIP(hipMemcpyAsync(bigger.ptr, buf.ptr, used_bytes, hipMemcpyDeviceToDevice, s));
-  RVN_HIP(hipStreamSynchronize(s));
+  RVN_HIP(rvn_stream_sync(s));
   std::swap(buf.ptr, bigger.ptr);
   std::swap(buf.cap, bigger.cap);
 }
@@ -340,7 +340,7 @@ void reads_load(Engine& e, const std::string& path, ReadsDev& R, std::vector<std
           RVN_LAUNCH_CHECK();
         }
       }
-      RVN_HIP(hipStreamSynchronize(s));  // the staging slot and the local offset arrays are free again
+      RVN_HIP(rvn_stream_sync(s));  // the staging slot and the local offset arrays are free again
       for (u32 i = 0; i < nr; ++i) {
         R.h_len.push_back(C.lengths[i]);
         R.h_word_off.push_back(words_used + woff[i + 1]);
@@ -387,7 +387,7 @@ void reads_load(Engine& e, const std::string& path, ReadsDev& R, std::vector<std
     R.h_qual_off = h_qoff;
     R.qual_shift = 6;
   }
-  RVN_HIP(hipStreamSynchronize(s));
+  RVN_HIP(rvn_stream_sync(s));
   reads_build_tiles(e, R);
   st.n_sequences = n;
   st.n_bases = R.total_bases;

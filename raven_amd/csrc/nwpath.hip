@@ -437,7 +437,7 @@ void nw_breakpoints(Engine& e, const ReadsDev& T, const ReadsDev& Rd, std::vecto
       (void)e.nw_sc.get<int>(need + 1);
     }
     RVN_HIP(hipMemcpyAsync(d_idx, order.data(), order.size() * 4, hipMemcpyHostToDevice, s));
-    RVN_HIP(hipStreamSynchronize(s));
+    RVN_HIP(rvn_stream_sync(s));
     launch_lane<8>(e, d_jobs, d_idx + coff[0], coff[1] - coff[0], T, Rd, w, d_recs, d_res, d_status, d_kused);
     launch_lane<16>(e, d_jobs, d_idx + coff[1], coff[2] - coff[1], T, Rd, w, d_recs, d_res, d_status, d_kused);
     launch_lane<24>(e, d_jobs, d_idx + coff[2], coff[3] - coff[2], T, Rd, w, d_recs, d_res, d_status, d_kused);
@@ -454,7 +454,7 @@ void nw_breakpoints(Engine& e, const ReadsDev& T, const ReadsDev& Rd, std::vecto
     RVN_HIP(hipMemcpyAsync(h_result.data(), d_res, static_cast<size_t>(nj) * 4, hipMemcpyDeviceToHost, s));
     RVN_HIP(hipMemcpyAsync(h_status.data(), d_status, static_cast<size_t>(nj) * 4, hipMemcpyDeviceToHost, s));
     RVN_HIP(hipMemcpyAsync(h_kused.data(), d_kused, static_cast<size_t>(nj) * 4, hipMemcpyDeviceToHost, s));
-    RVN_HIP(hipStreamSynchronize(s));
+    RVN_HIP(rvn_stream_sync(s));
     ++st.n_batches;
     std::vector<u32> again;
     for (u32 i : todo) {

@@ -183,7 +183,7 @@ u64 compact(Engine& e, DevBuf& list, u64 n, const u8* d_keep, DevBuf& tmp_slot, 
   Overlap* d_out = tmp_out.get<Overlap>(m + 1);
   compact_kernel<<<div_up(n, 256), 256, 0, s>>>(list.as<Overlap>(), d_keep, d_slot, n, d_out);
   RVN_LAUNCH_CHECK();
-  RVN_HIP(hipStreamSynchronize(s));
+  RVN_HIP(rvn_stream_sync(s));
   std::swap(list.ptr, tmp_out.ptr);
   std::swap(list.cap, tmp_out.cap);
   return m;
@@ -217,7 +217,7 @@ PileRegion* upload_regions(Engine& e, const u32* h_begin, const u32* h_end, cons
   for (u32 i = 0; i < n; ++i) reg[i] = PileRegion{h_begin[i], h_end[i], h_invalid[i] ? 1u : 0u};
   PileRegion* d = e.p2_regions.get<PileRegion>(static_cast<size_t>(n) + 1);
   RVN_HIP(hipMemcpyAsync(d, reg.data(), static_cast<size_t>(n) * sizeof(PileRegion), hipMemcpyHostToDevice, e.stream));
-  RVN_HIP(hipStreamSynchronize(e.stream));
+  RVN_HIP(rvn_stream_sync(e.stream));
   return d;
 }
 
@@ -257,7 +257,7 @@ void reads_subset(Engine& e, const ReadsDev& R, const std::vector<u32>& src, Rea
     }
   }
   RVN_HIP(hipMemsetAsync(d_packed + V.n_words, 0, 16, s));
-  RVN_HIP(hipStreamSynchronize(s));
+  RVN_HIP(rvn_stream_sync(s));
   reads_build_tiles(e, V);
 }
 
@@ -289,7 +289,7 @@ void second_pass(Engine& e, const ReadsDev& R, const u32* h_begin, const u32* h_
   RVN_HIP(hipMemsetAsync(d_kmers, 0, out.kmers_total + 16, s));
   const u32 sv = static_cast<u32>(valid.size());
   if (sv == 0) {
-    RVN_HIP(hipStreamSynchronize(s));
+    RVN_HIP(rvn_stream_sync(s));
     return;
   }
   ReadsDev V;
@@ -301,7 +301,7 @@ void second_pass(Engine& e, const ReadsDev& R, const u32* h_begin, const u32* h_
   v_kmers_off[sv] = out.kmers_total;
   u64* d_v_kmers_off = e.p2_kmers_off.get<u64>(static_cast<size_t>(sv) + 1);
   RVN_HIP(hipMemcpyAsync(d_v_kmers_off, v_kmers_off.data(), v_kmers_off.size() * 8, hipMemcpyHostToDevice, s));
-  RVN_HIP(hipStreamSynchronize(s));
+  RVN_HIP(rvn_stream_sync(s));
 
   u64 acc_n = 0;  // survivors of all batches so far, in the reference's merge order (out.ovl)
   u64 bytes = 0;
@@ -337,7 +337,7 @@ void second_pass(Engine& e, const ReadsDev& R, const u32* h_begin, const u32* h_
           DevBuf bigger;
           bigger.reserve((acc_n + m + 1) * sizeof(Overlap) * 2);
           if (acc_n) RVN_HIP(hipMemcpyAsync(bigger.ptr, out.ovl.ptr, acc_n * sizeof(Overlap), hipMemcpyDeviceToDevice, s));
-          RVN_HIP(hipStreamSynchronize(s));
+          RVN_HIP(rvn_stream_sync(s));
           std::swap(out.ovl.ptr, bigger.ptr);
           std::swap(out.ovl.cap, bigger.cap);
         }
@@ -365,7 +365,7 @@ void second_pass(Engine& e, const ReadsDev& R, const u32* h_begin, const u32* h_
     RVN_LAUNCH_CHECK();
     acc_n = compact(e, out.ovl, acc_n, d_ok, e.p2_slot, e.p2_tmp_ovl);
   }
-  RVN_HIP(hipStreamSynchronize(s));
+  RVN_HIP(rvn_stream_sync(s));
   out.n_overlaps = acc_n;
 }
 
@@ -390,7 +390,7 @@ void identity_filter_lists(Engine& e, const ReadsDev& R, Overlap* h_ovl, u32* h_
   std::vector<Overlap> upd(O);
   RVN_HIP(hipMemcpyAsync(ok.data(), d_ok, O, hipMemcpyDeviceToHost, s));
   RVN_HIP(hipMemcpyAsync(upd.data(), d_ovl, O * sizeof(Overlap), hipMemcpyDeviceToHost, s));
-  RVN_HIP(hipStreamSynchronize(s));
+  RVN_HIP(rvn_stream_sync(s));
   u64 k = 0;
   u32 prev_end = h_off[0];
   for (u32 i = 0; i < n; ++i) {  // per-pile compaction of the survivors (construct.cc:208-210)

@@ -199,7 +199,7 @@ void piles_init(Engine& e, const ReadsDev& r, PileState& ps) {
   RVN_HIP(hipMemsetAsync(ko, 0, (static_cast<size_t>(r.n) + 1) * 4, e.stream));
   ps.kept.reserve(64);
   ps.kept_total = 0;
-  RVN_HIP(hipStreamSynchronize(e.stream));  // `off` is a stack-owned host buffer
+  RVN_HIP(rvn_stream_sync(e.stream));  // `off` is a stack-owned host buffer
 }
 
 }  // namespace rvn
@@ -249,7 +249,7 @@ void pile_add_kmers_batch(Engine& e, const ReadsDev& r, const u32* h_pos, const 
   RVN_KLAUNCH(kKAddKmers, add_kmers_kernel<<<div_up(n, 256), 256, 0, s>>>(r.packed.as<u64>(), r.word_off.as<u64>(), d_pos,
                                                                           d_pr, n, e.k, d_off, d_out));
   RVN_HIP(hipMemcpyAsync(h_out, d_out, out_total, hipMemcpyDeviceToHost, s));
-  RVN_HIP(hipStreamSynchronize(s));
+  RVN_HIP(rvn_stream_sync(s));
 }
 
 void pile_add_layers_single(Engine& e, PileState& ps, const u32* d_ids, const Overlap* h_ovl, u32 n) {
@@ -260,7 +260,7 @@ void pile_add_layers_single(Engine& e, PileState& ps, const u32* d_ids, const Ov
   const u32 h_offs[4] = {0, n, 0, 0};  // list_off = {0, n}; kept_off = {0, 0}
   RVN_HIP(hipMemcpyAsync(offs, h_offs, sizeof(h_offs), hipMemcpyHostToDevice, s));
   RVN_KLAUNCH(kKAddLayers, add_layers_kernel<<<1, 256, 0, s>>>(list, offs, offs + 2, ps.pile_off.as<u64>(), d_ids, ps.pile_data.as<u16>()));
-  RVN_HIP(hipStreamSynchronize(s));
+  RVN_HIP(rvn_stream_sync(s));
 }
 
 void piles_merge(Engine& e, const ReadsDev& r, const MapOut& mo, u32 kmax, PileState& ps) {
@@ -293,7 +293,7 @@ void piles_merge(Engine& e, const ReadsDev& r, const MapOut& mo, u32 kmax, PileS
   exclusive_scan_u32_u32(new_kept_cnt, new_kept_off, n, e.scan_tmp, s);
   RVN_HIP(hipMemcpyAsync(e.h_pin, list_off + n, 4, hipMemcpyDeviceToHost, s));
   RVN_HIP(hipMemcpyAsync(e.h_pin + 1, new_kept_off + n, 4, hipMemcpyDeviceToHost, s));
-  RVN_HIP(hipStreamSynchronize(s));
+  RVN_HIP(rvn_stream_sync(s));
   const u32 L = static_cast<u32>(e.h_pin[0]), K = static_cast<u32>(e.h_pin[1]);
   Overlap* list = ps.new_list.get<Overlap>(static_cast<size_t>(L) + 1);
   RVN_KLAUNCH(kKPileBuild, pile_build_kernel<<<div_up(n, 4), 256, 0, s>>>(ovl, ovl_read_off, mo.first, mo.last, in_idx_sorted, in_off,
@@ -455,7 +455,7 @@ void piles_trim_and_median(Engine& e, PileState& ps, u32 coverage, u32* h_begin,
   if (h_end) RVN_HIP(hipMemcpyAsync(h_end, d_end, static_cast<size_t>(n) * 4, hipMemcpyDeviceToHost, s));
   if (h_median) RVN_HIP(hipMemcpyAsync(h_median, d_med, static_cast<size_t>(n) * 2, hipMemcpyDeviceToHost, s));
   if (h_invalid) RVN_HIP(hipMemcpyAsync(h_invalid, d_inv, static_cast<size_t>(n), hipMemcpyDeviceToHost, s));
-  RVN_HIP(hipStreamSynchronize(s));
+  RVN_HIP(rvn_stream_sync(s));
 }
 
 
@@ -517,7 +517,7 @@ void piles_find_chimeric_regions(Engine& e, PileState& ps, const u8* h_invalid, 
   RVN_HIP(hipMemcpyAsync(h_off.data(), d_roff, (static_cast<size_t>(n) + 1) * 4, hipMemcpyDeviceToHost, s));
   if (read_back(e, d_ovf, 4) != 0)
     throw HipError("[raven_hip] FindChimericRegions: a pile produced more slope regions than cells (internal error)");
-  RVN_HIP(hipStreamSynchronize(s));
+  RVN_HIP(rvn_stream_sync(s));
   const u32 total = h_off[n];
   h_regions.assign(2ULL * total, 0);
   if (total) {
@@ -525,7 +525,7 @@ void piles_find_chimeric_regions(Engine& e, PileState& ps, const u8* h_invalid, 
     chimeric_gather_kernel<<<div_up(n, 256), 256, 0, s>>>(d_out, ps.pile_off.as<u64>(), d_cnt, d_roff, n, d_regions);
     RVN_LAUNCH_CHECK();
     RVN_HIP(hipMemcpyAsync(h_regions.data(), d_regions, 2ULL * total * 4, hipMemcpyDeviceToHost, s));
-    RVN_HIP(hipStreamSynchronize(s));
+    RVN_HIP(rvn_stream_sync(s));
   }
 }
 

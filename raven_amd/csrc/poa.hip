@@ -687,7 +687,7 @@ void poa_run_dev(Engine& e, const PoaWindow* d_wins, const PoaLayer* d_lays, u32
   if (mode == 1) poa_v1_launch(e, b);
   else poa_v2_launch(e, b, mode == 3 ? 2 : (mode == 4 ? 4 : 1));
   RVN_HIP(hipMemcpyAsync(h_status.data(), d_status, static_cast<size_t>(n_windows) * 4, hipMemcpyDeviceToHost, s));
-  RVN_HIP(hipStreamSynchronize(s));
+  RVN_HIP(rvn_stream_sync(s));
   e.poa_fallback_windows = 0;
   e.poa_wide_windows = 0;
   e.poa_fullmatrix_windows = 0;
@@ -715,13 +715,15 @@ void poa_run_dev(Engine& e, const PoaWindow* d_wins, const PoaLayer* d_lays, u32
       RVN_LAUNCH_CHECK();
       std::vector<u32> rs(nr);
       RVN_HIP(hipMemcpyAsync(rs.data(), d_rstatus, rs.size() * 4, hipMemcpyDeviceToHost, s));
-      RVN_HIP(hipStreamSynchronize(s));
+      RVN_HIP(rvn_stream_sync(s));
       for (u32 i = 0; i < nr; ++i) h_status[redo[i]] = rs[i];
     };
     std::vector<u32> wide, wider, fullm;
     for (u32 w = 0; w < n_windows; ++w) {
       const u32 st = h_status[w] & 0xFF;
-      if (st == kPoaBandHit) wide.push_back(w);
+      // 7 = a predecessor row had left the 64-column kernel's LDS ring: the wider kernels keep a score copy in HBM
+      // for that case (one window in 400 000 at C4 — not worth a full-matrix launch)
+      if (st == kPoaBandHit || st == 7u) wide.push_back(w);
       else if (st >= 2) fullm.push_back(w);
     }
     if (std::getenv("RVN_POA_DEBUG")) {
@@ -753,7 +755,7 @@ void poa_run_dev(Engine& e, const PoaWindow* d_wins, const PoaLayer* d_lays, u32
   }
   RVN_HIP(hipEventRecord(e.ev1, s));
   RVN_HIP(hipMemcpyAsync(e.poa_phase_cycles, d_phase, 64, hipMemcpyDeviceToHost, s));
-  RVN_HIP(hipStreamSynchronize(s));
+  RVN_HIP(rvn_stream_sync(s));
   e.poa_cells_full += e.poa_phase_cycles[6];
   e.poa_cells_band += e.poa_phase_cycles[7];
   e.poa_calls += 1;
@@ -784,7 +786,7 @@ void poa_run(Engine& e, const std::vector<PoaWindow>& wins, const std::vector<Po
               allow_full);
   RVN_HIP(hipMemcpyAsync(h_out_len, d_len, static_cast<size_t>(n_windows) * 4, hipMemcpyDeviceToHost, s));
   RVN_HIP(hipMemcpyAsync(h_out, d_out, out_total, hipMemcpyDeviceToHost, s));
-  RVN_HIP(hipStreamSynchronize(s));
+  RVN_HIP(rvn_stream_sync(s));
   for (u32 w = 0; w < n_windows; ++w) h_status[w] = st[w];
 }
 

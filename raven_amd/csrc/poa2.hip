@@ -348,7 +348,8 @@ __device__ __forceinline__ u32 poa2_window(const PoaWindow& win, const PoaLayer*
         // the hidden LDS latency.)  Columns beyond the layer (only
         // when the layer is shorter than the band) and column 0's diagonal need no masks: no valid cell ever reads
         // them (column 0 reads the -inf pad or the explicit -inf of the virtual row).  A predecessor that has left
-        // the ring is not looked up in HBM: the window is repeated by the full-matrix kernel (status 7); it does
+        // the ring is not looked up in HBM: the window is repeated by the 128-column kernel, which keeps a score copy
+        // in HBM for that case (status 7); it does
         // not happen on racon-like windows.
         unsigned long long todo = __ballot((m_meta & 1) != 0);
         // Ring slot of a row = its index among the computed (marked) rows mod kRing, so a predecessor is still in its slot

@@ -268,7 +268,7 @@ void polish_map_best(Engine& e, ReadsDev& T, ReadsDev& R, u32 r_first, u32 r_las
     for (u32 t = 0; t < T.n; ++t) id_to_t[T.h_id[t]] = t;
     u32* d = e.pl_idmap.get<u32>(id_to_t.size());
     RVN_HIP(hipMemcpyAsync(d, id_to_t.data(), id_to_t.size() * 4, hipMemcpyHostToDevice, s));
-    RVN_HIP(hipStreamSynchronize(s));
+    RVN_HIP(rvn_stream_sync(s));
   }
   Overlap* d_best = e.pl_best.get<Overlap>(static_cast<size_t>(R.n) + 1);
   u32* d_best_t = e.pl_best_t.get<u32>(static_cast<size_t>(R.n) + 1);
@@ -297,7 +297,7 @@ void polish_map_best(Engine& e, ReadsDev& T, ReadsDev& R, u32 r_first, u32 r_las
   e.keep_anchors = keep;
   RVN_HIP(hipMemcpyAsync(best.data(), d_best + r_first, static_cast<size_t>(nr_all) * sizeof(Overlap), hipMemcpyDeviceToHost, s));
   RVN_HIP(hipMemcpyAsync(best_t.data(), d_best_t + r_first, static_cast<size_t>(nr_all) * 4, hipMemcpyDeviceToHost, s));
-  RVN_HIP(hipStreamSynchronize(s));
+  RVN_HIP(rvn_stream_sync(s));
 }
 
 void polish_round(Engine& e, ReadsDev& T, ReadsDev& R, const u8* h_quals, const u64* h_qual_off, double q_thr,
@@ -311,7 +311,7 @@ void polish_round(Engine& e, ReadsDev& T, ReadsDev& R, const u8* h_quals, const 
   const bool dbg = std::getenv("RVN_POLISH_DEBUG") != nullptr;
   auto lap = [&, last = clk::now()](const char* what) mutable {
     if (dbg) {
-      (void)hipStreamSynchronize(s);
+      (void)rvn_stream_sync(s);
       std::fprintf(stderr, "[raven_hip] polish: %-32s %8.1f ms\n", what, ms_since(last));
     }
     last = clk::now();
@@ -489,7 +489,7 @@ void polish_round(Engine& e, ReadsDev& T, ReadsDev& R, const u8* h_quals, const 
     if (q_thr > 0) {  // statistics only: layers that survive
       std::vector<u8> okh(n_lay);
       RVN_HIP(hipMemcpyAsync(okh.data(), d_ok, n_lay, hipMemcpyDeviceToHost, s));
-      RVN_HIP(hipStreamSynchronize(s));
+      RVN_HIP(rvn_stream_sync(s));
       u64 kept = 0;
       for (u64 i = 0; i < n_lay; ++i) kept += okh[i];
       stats.n_layers = kept - nw;  // backbones are always flagged ok
@@ -522,13 +522,13 @@ void polish_round(Engine& e, ReadsDev& T, ReadsDev& R, const u8* h_quals, const 
   exclusive_scan_u32_u64(d_len, d_cons_off, nw, e.scan_tmp, s);
   std::vector<u64> cons_off(nw + 1);
   RVN_HIP(hipMemcpyAsync(cons_off.data(), d_cons_off, (static_cast<size_t>(nw) + 1) * 8, hipMemcpyDeviceToHost, s));
-  RVN_HIP(hipStreamSynchronize(s));
+  RVN_HIP(rvn_stream_sync(s));
   const u64 total = cons_off[nw];
   u8* d_final = e.pl_final.get<u8>(total + 16);
   RVN_KLAUNCH(kKStitch, stitch_kernel<<<nw, 256, 0, s>>>(d_wins, d_len, d_cons_off, d_out, d_final));
   u8* h_final = e.pin_out.get<u8>(total + 16);
   RVN_HIP(hipMemcpyAsync(h_final, d_final, total, hipMemcpyDeviceToHost, s));
-  RVN_HIP(hipStreamSynchronize(s));
+  RVN_HIP(rvn_stream_sync(s));
   t_host = clk::now();
   std::vector<u64> t_windows(T.n, 0), t_polished(T.n, 0);
   for (u32 i = 0; i < nw; ++i) {

@@ -183,7 +183,7 @@ int radix_sort_impl(K* k0, K* k1, V* v0, V* v1, u64 n, int key_bits, DevBuf& tmp
   RVN_KLAUNCH(kKRsBits, rs_bits_kernel<K><<<gb, kThreads, 0, s>>>(k0, n, bits));
   u64 hbits[2];
   RVN_HIP(hipMemcpyAsync(hbits, bits, 16, hipMemcpyDeviceToHost, s));
-  RVN_HIP(hipStreamSynchronize(s));
+  RVN_HIP(rvn_stream_sync(s));
   varying = hbits[0] ^ hbits[1];
   }
 

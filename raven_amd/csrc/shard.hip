@@ -139,7 +139,7 @@ void multi_split(Engine& e, Key key, const u64* const* src_cols, u64* const* dst
   gather_bucket_starts_kernel<<<1, 64, 0, s>>>(d_off, n_blocks, nb, d_starts);
   RVN_LAUNCH_CHECK();
   RVN_HIP(hipMemcpyAsync(e.h_pin, d_starts, (nb + 1) * 8, hipMemcpyDeviceToHost, s));
-  RVN_HIP(hipStreamSynchronize(s));
+  RVN_HIP(rvn_stream_sync(s));
   for (u32 b = 0; b < nb; ++b) counts[b] = e.h_pin[b + 1] - e.h_pin[b];
 }
 
