@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libraven_hip.so")
+LIB_PATH = os.environ.get("RVN_LIB_PATH") or os.path.join(_HERE, "lib", "libraven_hip.so")  # override: A/B builds
 
 OVERLAP_DTYPE = np.dtype([
     ("lhs_id", "<u4"), ("lhs_begin", "<u4"), ("lhs_end", "<u4"),
