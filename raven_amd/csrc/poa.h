@@ -185,10 +185,9 @@ __device__ inline void poa_subgraph_marks(G& g, u32 n_nodes, u32 nmax, u32 begin
 }
 
 // Consensus: spoa TraverseHeaviestBundle + BranchCompletion, racon's coverage trim (lane 0).
+// Part 1: heaviest-path scores and predecessors of every node in topological order; returns the best-scoring node.
 template <class G>
-__device__ inline void poa_consensus_lane0(G& g, u32 n_nodes, u32 nmax, const PoaWindow& win, int trim,
-                                           u8* __restrict__ out, u32* out_len) {
-  u32 cons_len = 0;
+__device__ inline i32 poa_consensus_scores_lane0(G& g, u32 n_nodes) {
   i32 maxn = -1;
   for (u32 r = 0; r < n_nodes; ++r) {
     const u32 it = g.order[r];
@@ -207,6 +206,14 @@ __device__ inline void poa_consensus_lane0(G& g, u32 n_nodes, u32 nmax, const Po
     g.preds[it] = pd;
     if (maxn == -1 || g.scores[maxn] < sc) maxn = static_cast<i32>(it);
   }
+  return maxn;
+}
+
+// Part 2: branch completion from `maxn`, traceback into g.stack (reverse order), racon's coverage trim.
+// Consensus position p (begin <= p <= end) is node g.stack[cl - 1 - p].
+template <class G>
+__device__ inline void poa_consensus_trace_lane0(G& g, u32 n_nodes, u32 nmax, const PoaWindow& win, int trim, i32 maxn,
+                                                 u32* cl_out, i32* begin_out, i32* end_out) {
   u32 guard = 0;
   while (g.out_cnt[maxn] != 0 && guard++ < nmax) {
     // BranchCompletion(rank of maxn)
@@ -271,6 +278,19 @@ __device__ inline void poa_consensus_lane0(G& g, u32 n_nodes, u32 nmax, const Po
       end = static_cast<i32>(cl) - 1;
     }
   }
+  *cl_out = cl;
+  *begin_out = begin;
+  *end_out = end;
+}
+
+template <class G>
+__device__ inline void poa_consensus_lane0(G& g, u32 n_nodes, u32 nmax, const PoaWindow& win, int trim,
+                                           u8* __restrict__ out, u32* out_len) {
+  const i32 maxn = poa_consensus_scores_lane0(g, n_nodes);
+  u32 cl = 0;
+  i32 begin = 0, end = -1;
+  poa_consensus_trace_lane0(g, n_nodes, nmax, win, trim, maxn, &cl, &begin, &end);
+  u32 cons_len = 0;
   for (i32 p = begin; p <= end && cons_len < win.out_cap; ++p) out[cons_len++] = g.code[g.stack[cl - 1 - p]];
   *out_len = cons_len;
 }

@@ -185,6 +185,87 @@ __device__ __forceinline__ pk16 as_pk16(u32 x) { return __builtin_bit_cast(pk16,
 __device__ __forceinline__ int rl(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
+// Consensus of a finished window.  The heaviest-path pass (spoa TraverseHeaviestBundle) walks the nodes in topological
+// order and looks up the scores of their in-edges' tails: with the scores in the wave's LDS (the DP buffers are dead by
+// now; one int32 per node) and the first four in-edges of 64 nodes at a time in registers, a node costs one LDS round
+// trip instead of three dependent global loads.  Same scalar rule as poa_consensus_scores_lane0, same results.
+template <int NCH>
+__device__ void poa2_consensus(Poa2Slot& g, u32 n_nodes, u32 nmax, const PoaWindow& win, int trim, Poa2Lds<NCH>& S,
+                               u8* __restrict__ out, u32* out_len) {
+  const int lane = lane_id();
+  constexpr u32 kCap = sizeof(Poa2Lds<NCH>) / 4;
+  i32* lsc = reinterpret_cast<i32*>(&S);
+  i32 maxn = -1;
+  if (n_nodes > kCap) {
+    if (lane == 0) maxn = poa_consensus_scores_lane0(g, n_nodes);
+    maxn = rfl(maxn);
+  } else {
+    i32 max_sc = 0;
+    const u32 nn = static_cast<u32>(rfl(static_cast<int>(n_nodes)));
+    for (u32 r0 = 0; r0 < nn; r0 += 64) {
+      const u32 rows = nn - r0 < 64 ? nn - r0 : 64;
+      int m_it = 0, m_c = 0, m_t01 = 0, m_t23 = 0, m_w0 = 0, m_w1 = 0, m_w2 = 0, m_w3 = 0;
+      if (static_cast<u32>(lane) < rows) {
+        m_it = g.order[r0 + lane];
+        m_c = g.in_cnt[m_it];
+        const u16* tp = g.in_tail + static_cast<size_t>(m_it) * kPoaMaxIn;
+        const i32* wp = g.in_w + static_cast<size_t>(m_it) * kPoaMaxIn;
+        m_t01 = static_cast<int>(static_cast<u32>(tp[0]) | (static_cast<u32>(tp[1]) << 16));
+        m_t23 = static_cast<int>(static_cast<u32>(tp[2]) | (static_cast<u32>(tp[3]) << 16));
+        m_w0 = wp[0];
+        m_w1 = wp[1];
+        m_w2 = wp[2];
+        m_w3 = wp[3];
+      }
+      for (u32 l = 0; l < rows; ++l) {
+        const u32 it = static_cast<u32>(rl(m_it, static_cast<int>(l)));
+        const u32 c = static_cast<u32>(rl(m_c, static_cast<int>(l)));
+        const u32 t01 = static_cast<u32>(rl(m_t01, static_cast<int>(l))), t23 = static_cast<u32>(rl(m_t23, static_cast<int>(l)));
+        i32 sc = -1, pd = -1, pd_sc = 0;
+        for (u32 k = 0; k < c; ++k) {
+          i32 wgt, t;
+          if (k < 4) {
+            t = static_cast<i32>(((k < 2 ? t01 : t23) >> (16 * (k & 1))) & 0xFFFFu);
+            wgt = k == 0 ? rl(m_w0, static_cast<int>(l)) : (k == 1 ? rl(m_w1, static_cast<int>(l)) : (k == 2 ? rl(m_w2, static_cast<int>(l)) : rl(m_w3, static_cast<int>(l))));
+          } else {
+            wgt = rfl(g.in_w[static_cast<size_t>(it) * kPoaMaxIn + k]);
+            t = rfl(static_cast<int>(g.in_tail[static_cast<size_t>(it) * kPoaMaxIn + k]));
+          }
+          const i32 st = rfl(lsc[t]);
+          if (sc < wgt || (sc == wgt && pd_sc <= st)) {
+            sc = wgt;
+            pd = t;
+            pd_sc = st;
+          }
+        }
+        if (pd != -1) sc += pd_sc;
+        if (lane == 0) {
+          lsc[it] = sc;
+          g.scores[it] = sc;
+          g.preds[it] = pd;
+        }
+        if (maxn == -1 || max_sc < sc) {
+          maxn = static_cast<i32>(it);
+          max_sc = sc;
+        }
+      }
+    }
+  }
+  wsync();  // scores / predecessors in HBM visible to lane 0's branch completion and traceback
+  u32 cl = 0;
+  i32 begin = 0, end = -1;
+  if (lane == 0) poa_consensus_trace_lane0(g, n_nodes, nmax, win, trim, maxn, &cl, &begin, &end);
+  cl = static_cast<u32>(rfl(static_cast<int>(cl)));
+  begin = rfl(begin);
+  end = rfl(end);
+  wsync();  // g.stack
+  i32 n_out = end - begin + 1;
+  if (n_out < 0) n_out = 0;
+  if (static_cast<u32>(n_out) > win.out_cap) n_out = static_cast<i32>(win.out_cap);
+  for (i32 p = lane; p < n_out; p += 64) out[p] = g.code[g.stack[cl - 1 - static_cast<u32>(begin + p)]];
+  if (lane == 0) *out_len = static_cast<u32>(n_out);
+}
+
 template <int NCH>
 __device__ __forceinline__ u32 poa2_window(const PoaWindow& win, const PoaLayer* __restrict__ layers,
                                            const PoaSrc& src, Poa2Slot& g,
@@ -816,7 +897,7 @@ __device__ __forceinline__ u32 poa2_window(const PoaWindow& win, const PoaLayer*
   tick();
   PoaWindow weff = win;
   weff.n_layers = n_eff;
-  if (lane == 0) poa_consensus_lane0(g, n_nodes, nmax, weff, trim, out, out_len);
+  poa2_consensus<NCH>(g, n_nodes, nmax, weff, trim, S, out, out_len);
   wsync();
   tock(t_cons);
   if (phase_cycles && lane == 0) {
