@@ -156,3 +156,58 @@ def test_flush_windows_follow_the_reference_schedule():
     assert sharded.flush_windows(L, 1000) == [(0, 5)]
     assert sharded.flush_windows(L, 1) == [(i, i + 1) for i in range(5)]
     assert sharded.flush_windows(np.zeros(0, np.uint32), 10) == []
+
+
+def test_polish_round_sharded_host_logic_with_a_stub_engine():
+    """The host side of the sharded polishing round (read slices for the mapping, all-gather of the best-overlap table,
+    window ranges, gather of the consensus pieces) with a stub in place of the engine: every rank must hand the SAME
+    complete table to the round, ask for ITS window range, and the pieces must come back in rank and target order."""
+    from raven_amd import seqio
+
+    class Handle:
+        def __init__(self, n):
+            self.n = n
+
+    n_reads, world, w = 37, 3, 500
+    lengths = np.array([1200, 499, 2001], dtype=np.uint32)  # 3 + 1 + 5 = 9 windows
+    targets_rs = seqio.ReadSet(packed=np.zeros(1, np.uint64), word_offsets=np.zeros(4, np.uint64), lengths=lengths,
+                               ids=np.arange(3, dtype=np.uint32))
+    rng = np.random.default_rng(5)
+    full_best = rng.integers(0, 1 << 31, size=(n_reads, 8), dtype=np.uint32)
+    full_bt = rng.integers(0, 3, size=n_reads).astype(np.uint32)
+    full_bt[::7] = 0xFFFFFFFF
+    seen = {}
+
+    class StubEngine:
+        def __init__(self, rank):
+            self.rank, self.table = rank, None
+
+        def polish_map_best(self, targets, reads, first, last, err=0.3):
+            seen.setdefault("slices", {})[self.rank] = (first, last)
+            return full_best[first:last], full_bt[first:last], 0
+
+        def polish_set_best(self, best, bt):
+            self.table = (np.array(best, copy=True), np.array(bt, copy=True))
+
+        def polish_round_range(self, targets, reads, lo, hi, **kw):
+            assert self.table is not None and np.array_equal(self.table[0], full_best) and np.array_equal(self.table[1], full_bt)
+            seen.setdefault("ranges", {})[self.rank] = (lo, hi)
+            # the piece of target t = one byte per window of t inside [lo, hi), valued by the global window index
+            first = np.concatenate([[0], np.cumsum((lengths.astype(np.int64) + w - 1) // w)])
+            cons, nw, npol = [], np.zeros(3, np.uint32), np.zeros(3, np.uint32)
+            for t in range(3):
+                a, b = max(lo, int(first[t])), min(hi, int(first[t + 1]))
+                cons.append(np.arange(a, max(a, b), dtype=np.uint8))
+                nw[t] = max(0, b - a)
+                npol[t] = max(0, b - a - (1 if t == 1 else 0))
+            return cons, nw, npol, {}
+
+    def rank_fn(r, comm):
+        return sharded.polish_round_sharded(StubEngine(r), Handle(3), Handle(n_reads), comm, targets_rs, w=w)
+
+    res = sharded_util.run_ranks(world, rank_fn)
+    assert sorted(seen["slices"].values()) == [(0, 12), (12, 24), (24, 37)]
+    assert sorted(seen["ranges"].values()) == [(0, 3), (3, 6), (6, 9)]
+    for cons, ratio in res:
+        assert [c.tolist() for c in cons] == [[0, 1, 2], [3], [4, 5, 6, 7, 8]]
+        assert np.allclose(ratio, [1.0, 0.0, 1.0])
