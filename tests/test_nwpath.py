@@ -169,3 +169,83 @@ def test_real_reads_lambda(lambda_reads, lambda_genome):
         if done == 3:
             break
     assert done == 3
+
+
+def _reference_records(tq, tt, q_begin, t_begin, w):
+    """Independent statement of what the walker records, from a plain full-matrix NW (unit costs) walked back with
+    racon's CIGAR rule (match => diagonal; else substitution, then read-only base, then target-only base): per window of
+    the target the first / last match pair and, at the 8 grid positions start + g w / 8, the oriented read position at the
+    moment the path consumed that target base (the next read position for a target-only step)."""
+    n, m = len(tt), len(tq)
+    D = np.zeros((n + 1, m + 1), dtype=np.int64)
+    D[:, 0] = np.arange(n + 1)
+    D[0, :] = np.arange(m + 1)
+    for i in range(1, n + 1):
+        row, prev = D[i], D[i - 1]
+        ti = tt[i - 1]
+        for j in range(1, m + 1):
+            row[j] = min(prev[j - 1] + (0 if ti == tq[j - 1] else 1), row[j - 1] + 1, prev[j] + 1)
+    wins = {}
+
+    def consume(t, q, is_match):
+        rec = wins.setdefault(t // w, dict(first=None, last=None, grid={}))
+        start = (t // w) * w
+        for g in range(8):  # windows shorter than 8 bases: several g share a position, the largest one holds the sample
+            if t == start + (g * w) // 8 and (g == 7 or ((g + 1) * w) // 8 != (g * w) // 8):
+                rec["grid"][g] = q
+        if is_match:
+            if rec["last"] is None:
+                rec["last"] = (t + 1, q + 1)
+            rec["first"] = (t, q)
+
+    i, j = n, m
+    while i > 0 and j > 0:
+        if tt[i - 1] == tq[j - 1] or D[i - 1, j - 1] + 1 == D[i, j]:
+            consume(t_begin + i - 1, q_begin + j - 1, True)
+            i, j = i - 1, j - 1
+        elif D[i, j - 1] + 1 == D[i, j]:
+            j -= 1
+        else:
+            consume(t_begin + i - 1, q_begin + j, False)
+            i -= 1
+    while i > 0:
+        consume(t_begin + i - 1, q_begin, False)
+        i -= 1
+    return int(D[n, m]), wins
+
+
+@pytest.mark.parametrize("w", [7, 50, 64, 500])
+def test_window_records_and_grid_samples_equal_an_independent_traceback(w):
+    """The walk takes whole runs of matches at once and applies the window bookkeeping in closed form: every field of the
+    records, grid samples included, must equal a base-by-base traceback written independently in Python."""
+    rng = np.random.default_rng(900 + w)
+    for trial in range(5):
+        n = int(rng.integers(60, 330))
+        t, q = _noisy_pair(rng, n, 0.05, 0.04, 0.04)
+        if trial == 3:  # a long run of identical bases and a long gap
+            q = np.concatenate([t[:n // 3], t[n // 3 + 25:]])
+        rc = trial & 1
+        tl, ql = int(rng.integers(0, 3 * w + 5)), int(rng.integers(0, 40))
+        target = np.concatenate([rng.integers(0, 4, tl, dtype=np.uint8), t, rng.integers(0, 4, 9, dtype=np.uint8)])
+        read_o = np.concatenate([rng.integers(0, 4, ql, dtype=np.uint8), q, rng.integers(0, 4, 5, dtype=np.uint8)])
+        read = _oriented(read_o, rc)
+        for force_r in (0, -8):  # wave kernel's code and the lane-per-alignment variant
+            recs, dist, band, status = hip.test_nw_breakpoints(_pack(target), len(target), _pack(read), len(read), tl, len(t),
+                                                               ql, len(q), rc, w, k=16, force_r=force_r)
+            assert status == 0
+            want_dist, wins = _reference_records(q, t, ql, tl, w)
+            assert dist == want_dist
+            for x, r in enumerate(recs):
+                ref = wins.get(tl // w + x)
+                if ref is None or ref["first"] is None:
+                    assert r["first_t"] == 0xFFFFFFFF
+                    continue
+                assert (int(r["first_t"]), int(r["first_q"])) == ref["first"]
+                assert (int(r["last_t"]), int(r["last_q"])) == ref["last"]
+                span = ref["last"][1] - ref["first"][1]
+                for g in range(8):
+                    if g in ref["grid"]:
+                        off = min(max(ref["grid"][g] - ref["first"][1], 0), span, 0xFFFE)
+                        assert int(r["grid"][g]) == off, (trial, x, g)
+                    else:
+                        assert int(r["grid"][g]) == 0xFFFF
