@@ -29,6 +29,7 @@ namespace rvn {
 namespace {
 
 constexpr int kRing = 32;  // score rows kept in LDS
+constexpr int kPoa2MaxSeq = 896;  // longest layer of the banded kernels (longer ones: full-matrix kernel); sizes the LDS buffers
 // The band is NCH chunks of 64 columns (one column per lane and chunk).  NCH = 1 (+-32 around the expected
 // column) is the first attempt; windows whose traceback touches the band edge are repeated with NCH = 2 and, if
 // that is not enough either with NCH = 4 (256 columns, two waves per workgroup) before the full-matrix kernel.
@@ -133,12 +134,12 @@ struct alignas(16) Poa2Lds {  // per wave
     i16 ring[2 + kRing * kRingStride];
     u8 stage[64 * kBand];  // traceback: backpointer rows of one 64-row block
     struct {
-      u16 tgt[kPoaMaxSeq];  // AddAlignment: graph node of every sequence position
+      u16 tgt[kPoa2MaxSeq];  // AddAlignment: graph node of every sequence position
     } add;
   } u;
-  u8 seq_pad[kPoaMaxSeq + 8];  // the layer's codes at seq_pad + 4; seq_pad[3] = 0xFF (position -1 matches nothing)
-  u8 wgt[kPoaMaxSeq];
-  u16 pos_node[kPoaMaxSeq];  // traceback result: node aligned to position p, or kNone
+  u8 seq_pad[kPoa2MaxSeq + 8];  // the layer's codes at seq_pad + 4; seq_pad[3] = 0xFF (position -1 matches nothing)
+  u8 wgt[kPoa2MaxSeq];
+  u16 pos_node[kPoa2MaxSeq];  // traceback result: node aligned to position p, or kNone
 };
 
 // k-th in-edge (among those inside the subgraph) of v, as a row index (rank + 1); slow path for in-degree > 4
@@ -332,7 +333,7 @@ __device__ __forceinline__ u32 poa2_window(const PoaWindow& win, const PoaLayer*
     const PoaLayer L = layers[win.layer_first + li];
     const u32 len = L.len;
     if (len == 0 || (src.layer_ok && !src.layer_ok[win.layer_first + li])) continue;
-    if (len > lmax || len > kPoaMaxSeq) {
+    if (len > lmax || len > kPoa2MaxSeq) {
       failed = 4;
       break;
     }
@@ -539,7 +540,7 @@ __device__ __forceinline__ u32 poa2_window(const PoaWindow& win, const PoaLayer*
           val[c] = j[c] < static_cast<i32>(w);
           dok[c] = val[c] && j[c] >= 1;
           // match/mismatch per column (clamped read; masked by dok)
-          const i32 qi = j[c] >= 1 ? (j[c] - 1 < kPoaMaxSeq ? j[c] - 1 : kPoaMaxSeq - 1) : 0;
+          const i32 qi = j[c] >= 1 ? (j[c] - 1 < kPoa2MaxSeq ? j[c] - 1 : kPoa2MaxSeq - 1) : 0;
           sc[c] = vc == S.seq_pad[4 + qi] ? m : n_;
           bd[c] = kNegBig;
           bv[c] = kNegBig;
@@ -914,7 +915,7 @@ __device__ __forceinline__ u32 poa2_window(const PoaWindow& win, const PoaLayer*
 }
 
 template <int NCH, int WPB>
-__global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(NCH == 1 ? 4 : 1))) void poa2_kernel(const PoaWindow* __restrict__ windows, u32 n_windows,
+__global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(NCH == 1 ? 5 : 1))) void poa2_kernel(const PoaWindow* __restrict__ windows, u32 n_windows,
                                                   const PoaLayer* __restrict__ layers, const PoaSrc src,
                                                   unsigned char* __restrict__ scratch,
                                                   size_t slot_bytes, u32 n_slots, u32 nmax, u32 lmax, int m, int n_,
@@ -945,7 +946,7 @@ void poa_v2_launch(Engine& e, const PoaBatchDev& b, int nch) {
   const size_t slot_bytes = poa2_slot_bytes(b.nmax, b.lmax, 64u * nch);
   size_t free_b = 0, total_b = 0;
   RVN_HIP(hipMemGetInfo(&free_b, &total_b));
-  u32 n_slots = std::min<u32>(b.n_windows, 256 * 16);  // up to 4 workgroups of 4 waves per CU
+  u32 n_slots = std::min<u32>(b.n_windows, nch == 1 ? 256 * 20 : 256 * 16);  // up to 4 workgroups of 4 waves per CU
   const size_t budget = e.poa2_scratch.cap + free_b / 2;
   if (static_cast<size_t>(n_slots) * slot_bytes > budget) n_slots = static_cast<u32>(std::max<size_t>(1, budget / slot_bytes));
   n_slots = ((n_slots + 3) / 4) * 4;
