@@ -53,3 +53,18 @@ def test_fails_loudly_without_gpu():
     with pytest.raises(hip.RavenHipError) as ei:
         hip.Engine()
     assert "no HIP device" in str(ei.value)
+
+
+def test_cpp_facade_programs_compile_and_link(tmp_path):
+    """Every program under tests/cpp (the reference's call sequences against the header-only facades) compiles with g++
+    and links against libraven_hip.so — no GPU needed; running them is tests/test_gpu_facade.py's job."""
+    import glob
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "raven_amd", "lib")
+    for src in sorted(glob.glob(os.path.join(root, "tests", "cpp", "*.cpp"))):
+        exe = str(tmp_path / os.path.basename(src)[:-4])
+        subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(root, "include"), "-I",
+                               os.path.join(root, "tests", "cpp"), "-o", exe, src, "-L", lib, "-lraven_hip",
+                               "-Wl,-rpath," + lib, "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"])
+        assert os.path.exists(exe)

@@ -145,3 +145,33 @@ def test_edlib_dropin_matches_dp(tmp_path):
     assert lines[3].startswith("self 0 locations 1 end %d alphabet " % (len(seqs[0]) - 1))
     assert lines[4] == "pairs 40 mismatches 0"
     assert lines[5] == "k_below -1" and lines[6] == "k_equal 1"
+
+
+@pytest.mark.gpu
+def test_second_pass_facade_matches_c_abi(tmp_path):
+    """raven::FindOverlapsAndRepetetiveRegions<Pile> (include/raven_hip/find_overlaps.hpp) with the reference's
+    signature, after the first-pass template, against the ctypes path of the same two C-ABI calls."""
+    exe = _build(tmp_path, "pass2_facade_test")
+    g = synth.make_genome(60_000, seed=51)
+    rs, _ = synth.make_reads(g, 14, 4000, seed=52)
+    path = _write_reads(tmp_path, rs)
+    r = subprocess.run([exe, path], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = r.stdout.strip().split("\n")
+    eng = hip.Engine(15, 5)
+    rd = eng.upload(rs)
+    eng.find_overlaps_and_create_piles(rd).close()  # the facade ran the first pass before (same engine state order)
+    begin = np.zeros(rs.n, dtype=np.uint32)
+    end = (rs.lengths.astype(np.uint32) >> 4) << 4
+    res = eng.find_overlaps_and_repetitive_regions(rd, begin, end, np.zeros(rs.n, np.uint8), kmer_len=28)
+    assert lines[0] == "lists %d" % (rs.n + 1)
+    want = ["O %d %d %d %d %d %d %d %d" % (o["lhs_id"], o["lhs_begin"], o["lhs_end"], o["rhs_id"], o["rhs_begin"],
+                                            o["rhs_end"], o["score"], 1 if o["strand"] else 0) for o in res["overlaps"]]
+    got = [ln for ln in lines if ln.startswith("O ")]
+    assert len(want) > 50 and got == want
+    for i in range(rs.n):
+        h = 0
+        for v in res["kmers"][i].tolist():
+            h = (h * 1000003 + v) & 0xFFFFFFFFFFFFFFFF
+        c = int(res["contained"][i])
+        assert "P %d %d %d %d %d" % (i, c, c, res["kmers"][i].shape[0], h) in lines
