@@ -125,7 +125,7 @@ struct Engine {
   DevBuf p2_slot, p2_pairs, p2_dist, p2_regions, p2_index_of, p2_kmers_off, p2_ok, p2_keep, p2_tmp_ovl;
   DevBuf poa_sched, poa_redo_w, poa_redo_i;  // LPT order / escalation lists of a POA batch (poa_run_dev)
   // alignment-path stage of a polishing round (nwpath.hip): stored band words + scores, jobs, results
-  DevBuf nw_pm, nw_sc, nw_ck_pm, nw_ck_sc, nw_jobs, nw_res;  // segment scratch of the waves, checkpoints, jobs, results
+  DevBuf nw_hs, nw_ck, nw_jobs, nw_res;  // alignment paths: horizontal-delta streams, checkpoints, jobs, results
   double nw_rate = -1.0;  // running estimate of edit distance / length of the read-to-target alignments (< 0: unknown)
   // polishing front end (polish.hip): best overlaps, window records, layer tables, consensus
   DevBuf pl_best, pl_best_t, pl_idmap, pl_recs, pl_keep, pl_win_cnt, pl_win_off, pl_win_fill, pl_win_meta, pl_first_window,

@@ -2,8 +2,9 @@
 vertical deltas + traceback + racon's find_breaking_points) against the oracle's plain-DP path and breakpoints.
 
 No GPU needed: rvn_test_nw_breakpoints drives the SAME __host__ __device__ code the kernels execute — the forward
-sweep's per-lane step for 64 emulated lanes (ring reuse, systolic carries through the emulated shuffles) and the
-single-thread traceback — so the arithmetic, the band geometry, the store layout and the tie rule are all pinned here;
+sweep's per-lane step for 64 emulated lanes (nwsweep.h: ring reuse, systolic carries through the emulated shuffles, the
+hs / checkpoint stores) and the one-lane traceback that recomputes one block at a time from them (nwtrace.h) — so the
+arithmetic, the band geometry, the store layout and the tie rule are all pinned here;
 the GPU tests (tests/test_gpu_polish.py) then only have to show that the wave executes it the same way."""
 import numpy as np
 import pytest
@@ -87,27 +88,28 @@ def test_band_doubling_and_blocks_per_lane():
         assert d == d1 and b[2] == R
 
 
-def test_lane_per_alignment_variant_gives_the_same_breakpoints():
-    """The narrow-band kernel (one lane per alignment, band ring in LDS: nwlane.h) stepped on the CPU with every ring
-    size: same distance, same breakpoints as the oracle; a band wider than the ring is refused, not truncated."""
+def test_lane_group_variants_give_the_same_breakpoints():
+    """The narrow variants of the sweep (rings of at most 4 / 8 / 16 / 32 lanes sharing a wave) stepped on the CPU: same
+    distance, same breakpoints as the oracle; a band wider than the ring is refused, not truncated."""
     rng = np.random.default_rng(44)
     for trial in range(4):
         n = int(rng.integers(500, 2600))
         t, q = _noisy_pair(rng, n, 0.04, 0.03, 0.03)
         rc = trial & 1
         read = _oriented(q, rc)
-        for nb in (16, 24, 32):
-            d, band = _check(t, read, 0, len(t), 0, len(q), rc, 500, k=32, force_r=-nb)
-            assert band[1] == nb and band[0] >= d
+        for g in (16, 32, 64):
+            d, band = _check(t, read, 0, len(t), 0, len(q), rc, 500, k=32, force_r=-g)
+            assert band[1] <= g and band[0] >= d
     t, q = _noisy_pair(rng, 3000, 0.002, 0.002, 0.002)  # HiFi-like: the smallest ring
-    _check(t, q, 0, len(t), 0, len(q), 0, 500, k=16, force_r=-8)
+    _, band = _check(t, q, 0, len(t), 0, len(q), 0, 500, k=16, force_r=-4)
+    assert band[1] <= 4
     for n, m in [(1, 1), (1, 7), (9, 1), (64, 64), (65, 63), (300, 250)]:
         tt = rng.integers(0, 4, n, dtype=np.uint8)
         qq = rng.integers(0, 4, m, dtype=np.uint8)
-        _check(tt, qq, 0, n, 0, m, 0, 50, k=4, force_r=-16)
-    t, q = _noisy_pair(rng, 2500, 0.08, 0.06, 0.06)  # distance ~450: beyond a ring of 8 blocks
+        _check(tt, qq, 0, n, 0, m, 0, 50, k=4, force_r=-8)
+    t, q = _noisy_pair(rng, 2500, 0.08, 0.06, 0.06)  # distance ~450: beyond a ring of 4 lanes
     with pytest.raises(ValueError):
-        _check(t, q, 0, len(t), 0, len(q), 0, 500, k=600, force_r=-8)
+        _check(t, q, 0, len(t), 0, len(q), 0, 500, k=600, force_r=-4)
 
 
 def test_length_difference_and_indel_bursts():
@@ -229,7 +231,7 @@ def test_window_records_and_grid_samples_equal_an_independent_traceback(w):
         target = np.concatenate([rng.integers(0, 4, tl, dtype=np.uint8), t, rng.integers(0, 4, 9, dtype=np.uint8)])
         read_o = np.concatenate([rng.integers(0, 4, ql, dtype=np.uint8), q, rng.integers(0, 4, 5, dtype=np.uint8)])
         read = _oriented(read_o, rc)
-        for force_r in (0, -8):  # wave kernel's code and the lane-per-alignment variant
+        for force_r in (0, -8, 2):  # the narrowest variant that fits, a ring of <= 8 lanes, two blocks per lane
             recs, dist, band, status = hip.test_nw_breakpoints(_pack(target), len(target), _pack(read), len(read), tl, len(t),
                                                                ql, len(q), rc, w, k=16, force_r=force_r)
             assert status == 0
