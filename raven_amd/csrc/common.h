@@ -167,18 +167,21 @@ extern thread_local KernelTimers* g_kernel_timers;
 struct KernelScope {
   KernelTimers* kt;
   size_t e1 = 0;
-  explicit KernelScope(int site) : kt(g_kernel_timers) {
+  hipStream_t st = nullptr;
+  // `on`: the stream the kernel is launched on when it is not the engine's main stream (the event pair must sit on it)
+  explicit KernelScope(int site, hipStream_t on = nullptr) : kt(g_kernel_timers) {
     if (kt && kt->enabled) {
+      st = on ? on : kt->stream;
       size_t e0 = kt->next_event();
       e1 = kt->next_event();
       kt->recs.push_back({site, e0, e1});
-      RVN_HIP(hipEventRecord(kt->pool[e0], kt->stream));
+      RVN_HIP(hipEventRecord(kt->pool[e0], st));
     } else {
       kt = nullptr;
     }
   }
   ~KernelScope() {
-    if (kt) (void)hipEventRecord(kt->pool[e1], kt->stream);
+    if (kt) (void)hipEventRecord(kt->pool[e1], st);
   }
 };
 
@@ -188,6 +191,14 @@ struct KernelScope {
     ::rvn::KernelScope _ks(site);     \
     __VA_ARGS__;                      \
     RVN_LAUNCH_CHECK();               \
+  } while (0)
+
+// the same on another stream of the engine
+#define RVN_KLAUNCH_ON(site, stream, ...)     \
+  do {                                        \
+    ::rvn::KernelScope _ks(site, stream);     \
+    __VA_ARGS__;                              \
+    RVN_LAUNCH_CHECK();                       \
   } while (0)
 
 // 8 x u32 overlap record == biosoup::Overlap minus the alignment string.

@@ -149,35 +149,72 @@ __host__ __device__ __forceinline__ int nw_delta(int bits) { return (bits & 1) -
 // 16 text symbols (2 bits each, the symbol of column col0 in bits 0-1) of columns col0 .. col0 + 15 of the read span in
 // the target's orientation; columns outside 1 .. m hold arbitrary symbols (nobody uses them).
 // first = index (in the read's packed words) of the base of column 1: b_base forward, b_base + m - 1 reverse-complemented.
-__host__ __device__ __forceinline__ u32 nw_bases16(const u64* __restrict__ words, long long base) {  // bases base .. base + 15
+// Split in two so that a kernel can issue the loads a whole group of steps before it needs the symbols: both words are
+// loaded unconditionally (every packed set has slack behind its last word), nothing waits in between.
+struct NwRaw {
+  u64 w0, w1;
+};
+__host__ __device__ __forceinline__ long long nw_text16_base(long long first, bool rc, int col0) {
+  // reverse-complemented: stored positions first - (col - 1), descending — the 16 bases ENDING at the one of col0
+  return rc ? first - col0 - 14 : first + col0 - 1;
+}
+__host__ __device__ __forceinline__ NwRaw nw_text16_load(const u64* __restrict__ words, long long base) {
+  if (base < 0) base = 0;  // before the first word of the read: the finish shifts garbage columns in instead
+  const u64 wi = static_cast<u64>(base) >> 5;
+  return NwRaw{words[wi], words[wi + 1]};
+}
+__host__ __device__ __forceinline__ u32 nw_text16_finish(const NwRaw& r, long long base, bool rc) {
   int sh = 0;
-  if (base < 0) {  // before the first word of the set: shift the garbage columns in instead of reading there
+  if (base < 0) {
     sh = base < -16 ? 32 : static_cast<int>(-base) * 2;
     base = 0;
   }
-  const u64 bit = static_cast<u64>(base) * 2;
-  const u64 wi = bit >> 6;
-  const unsigned off = static_cast<unsigned>(bit & 63);
-  u64 x = words[wi] >> off;
-  if (off > 32) x |= words[wi + 1] << (64 - off);
-  const u32 v = static_cast<u32>(x);
-  return sh >= 32 ? 0u : v << sh;
+  const unsigned off = static_cast<unsigned>(static_cast<u64>(base) * 2) & 63u;
+  u64 x = r.w0 >> off;
+  if (off) x |= r.w1 << (64 - off);
+  u32 v = static_cast<u32>(x);
+  v = sh >= 32 ? 0u : v << sh;
+  if (rc) {  // reverse the 16 bases, complement
+#if defined(__HIP_DEVICE_COMPILE__)
+    v = __brev(v);
+#else
+    v = ((v & 0x0000FFFFu) << 16) | (v >> 16);
+    v = ((v & 0x00FF00FFu) << 8) | ((v >> 8) & 0x00FF00FFu);
+    v = ((v & 0x0F0F0F0Fu) << 4) | ((v >> 4) & 0x0F0F0F0Fu);
+    v = ((v & 0x33333333u) << 2) | ((v >> 2) & 0x33333333u);
+    v = ((v & 0x55555555u) << 1) | ((v >> 1) & 0x55555555u);
+#endif
+    v = ~(((v & 0x55555555u) << 1) | ((v >> 1) & 0x55555555u));  // the two bits of a base back in order
+  }
+  return v;
 }
 __host__ __device__ __forceinline__ u32 nw_text16(const u64* __restrict__ words, long long first, bool rc, int col0) {
-  if (!rc) return nw_bases16(words, first + col0 - 1);
-  // stored positions first - (col - 1), descending: read the 16 bases ending at the one of col0, reverse, complement
-  u32 v = nw_bases16(words, first - col0 - 14);
-#if defined(__HIP_DEVICE_COMPILE__)
-  v = __brev(v);
-#else
-  v = ((v & 0x0000FFFFu) << 16) | (v >> 16);
-  v = ((v & 0x00FF00FFu) << 8) | ((v >> 8) & 0x00FF00FFu);
-  v = ((v & 0x0F0F0F0Fu) << 4) | ((v >> 4) & 0x0F0F0F0Fu);
-  v = ((v & 0x33333333u) << 2) | ((v >> 2) & 0x33333333u);
-  v = ((v & 0x55555555u) << 1) | ((v >> 1) & 0x55555555u);
-#endif
-  v = ((v & 0x55555555u) << 1) | ((v >> 1) & 0x55555555u);  // the two bits of a base back in order
-  return ~v;
+  const long long base = nw_text16_base(first, rc, col0);
+  return nw_text16_finish(nw_text16_load(words, base), base, rc);
+}
+
+// Bit planes of pattern block b (myers.h load_planes) with three unconditional loads: nothing waits on a loaded value to
+// decide about the next load
+__host__ __device__ __forceinline__ BlockPlanes nw_load_planes(const u64* __restrict__ words, u64 a_base, u32 n, u32 b) {
+  const u64 row0 = static_cast<u64>(b) * 64;
+  BlockPlanes p;
+  if (row0 >= n) {
+    p.lo = p.hi = p.valid = 0;
+    return p;
+  }
+  const u64 bit = (a_base + row0) * 2;
+  const u64 wi = bit >> 6;
+  const unsigned off = static_cast<unsigned>(bit & 63);
+  const u64 x0 = words[wi], x1 = words[wi + 1], x2 = words[wi + 2];
+  const u64 w0 = off ? (x0 >> off) | (x1 << (64 - off)) : x0;
+  const u64 w1 = off ? (x1 >> off) | (x2 << (64 - off)) : x1;
+  const u32 valid = n - row0 >= 64 ? 64u : static_cast<u32>(n - row0);
+  p.lo = compress_even(w0) | (compress_even(w1) << 32);
+  p.hi = compress_even(w0 >> 1) | (compress_even(w1 >> 1) << 32);
+  p.valid = valid >= 64 ? ~0ULL : ((1ULL << valid) - 1ULL);
+  p.lo &= p.valid;
+  p.hi &= p.valid;
+  return p;
 }
 
 // The backward walk, resumable strip by strip.  Cells answers, for a mismatching cell (i, j) of the strip it holds (rows
@@ -186,10 +223,7 @@ template <class Cells>
 struct NwWalkerT {
   Cells cells;
   // job
-  const u64* tw;
-  const u64* rw;
-  u32 t_begin, q_begin, r_len, w, win0;
-  bool rc;
+  u32 t_begin, q_begin, w, win0;
   NwWindowRec* recs;
   int seg_j0;   // the strip in `cells`: columns seg_j0 + 1 .. and rows row_lo + 1 ..
   int row_lo;
@@ -203,21 +237,12 @@ struct NwWalkerT {
   u32 gq[8];
   int gx;
   u32 gt;
-  // the next (up to 32) bases of the target and of the oriented read, the current one in the top two bits; the walk
-  // compares 32 bases per step with them and takes a whole run of matches at once
-  u64 t_tail, q_tail;
-  int t_have, q_have;
 
-  __host__ __device__ void init(const NwJob& J, const u64* t_words_all, const u64* r_words_all, u32 distance, u32 w_,
-                                NwWindowRec* recs_all) {
-    tw = t_words_all + J.t_word;
-    rw = r_words_all + J.r_word;
+  __host__ __device__ void init(const NwJob& J, u32 distance, u32 w_, NwWindowRec* recs_all) {
     t_begin = J.t_begin;
     q_begin = J.q_begin;
-    r_len = J.r_len;
     w = w_;
     win0 = J.t_begin / w_;
-    rc = J.rc != 0;
     recs = recs_all + J.bp_off;
     seg_j0 = 0;
     row_lo = 0;
@@ -228,66 +253,10 @@ struct NwWalkerT {
     cw_lo = 0;
     have = false;
     first_t = first_q = last_t = last_q = 0;
+#pragma unroll
     for (int g = 0; g < 8; ++g) gq[g] = 0xFFFFFFFFu;
     gx = -1;
     gt = 0;
-    t_tail = q_tail = 0;
-    t_have = q_have = 0;
-  }
-
-  // order of the 32 two-bit groups reversed
-  __host__ __device__ static u64 rev2(u64 v) {
-    v = ((v & 0x3333333333333333ULL) << 2) | ((v >> 2) & 0x3333333333333333ULL);
-    v = ((v & 0x0F0F0F0F0F0F0F0FULL) << 4) | ((v >> 4) & 0x0F0F0F0F0F0F0F0FULL);
-    v = ((v & 0x00FF00FF00FF00FFULL) << 8) | ((v >> 8) & 0x00FF00FF00FF00FFULL);
-    v = ((v & 0x0000FFFF0000FFFFULL) << 16) | ((v >> 16) & 0x0000FFFF0000FFFFULL);
-    return (v << 32) | (v >> 32);
-  }
-  // bases [first, first + cnt) of a packed sequence (1 <= cnt <= 32), base `first` in the low bits; never touches a
-  // word that holds none of them
-  __host__ __device__ static u64 load_span(const u64* words, u64 first, int cnt) {
-    const u64 wi = first >> 5;
-    const unsigned off = static_cast<unsigned>(first & 31) * 2;
-    u64 x = words[wi] >> off;
-    if (off && ((first + static_cast<u64>(cnt) - 1) >> 5) != wi) x |= words[wi + 1] << (64 - off);
-    return x;
-  }
-  __host__ __device__ void refill_t() {  // rows i, i - 1, ...
-    const u64 pos = static_cast<u64>(t_begin) + static_cast<u64>(i) - 1;
-    const int cnt = i < 32 ? i : 32;
-    t_tail = load_span(tw, pos - static_cast<u64>(cnt - 1), cnt) << (2 * (32 - cnt));
-    t_have = cnt;
-  }
-  __host__ __device__ void refill_q() {  // columns j, j - 1, ... of the oriented read
-    const u64 x = static_cast<u64>(q_begin) + static_cast<u64>(j) - 1;
-    const int cnt = j < 32 ? j : 32;
-    if (!rc) {
-      q_tail = load_span(rw, x - static_cast<u64>(cnt - 1), cnt) << (2 * (32 - cnt));
-    } else {  // stored position r_len - 1 - x and upwards, complemented
-      q_tail = ~rev2(load_span(rw, static_cast<u64>(r_len) - 1 - x, cnt));
-    }
-    q_have = cnt;
-  }
-  // number of matches going down the diagonal from (i, j), at most `lim` (>= 1) and at most what the tails hold
-  __host__ __device__ int match_run(int lim) {
-    if (t_have == 0) refill_t();
-    if (q_have == 0) refill_q();
-    int avail = t_have < q_have ? t_have : q_have;
-    avail = avail < lim ? avail : lim;
-    const u64 x = t_tail ^ q_tail;
-    const u64 y = (x | (x >> 1)) & 0x5555555555555555ULL;  // one bit per differing base, the current base at bit 62
-#if defined(__HIP_DEVICE_COMPILE__)
-    const int run = y ? (__clzll(static_cast<long long>(y)) >> 1) : 32;
-#else
-    const int run = y ? (__builtin_clzll(y) >> 1) : 32;
-#endif
-    return run < avail ? run : avail;
-  }
-  __host__ __device__ void consume(int dt, int dq) {  // the walk moved dt rows and dq columns
-    t_tail = dt >= 32 ? 0 : t_tail << (2 * dt);
-    t_have -= dt;
-    q_tail = dq >= 32 ? 0 : q_tail << (2 * dq);
-    q_have -= dq;
   }
 
   __host__ __device__ void flush(bool write) {
@@ -297,6 +266,7 @@ struct NwWalkerT {
     e.first_q = first_q;
     e.last_t = last_t;
     e.last_q = last_q;
+#pragma unroll
     for (int g = 0; g < 8; ++g) {
       u32 off = 0xFFFFu;
       if (have && gq[g] != 0xFFFFFFFFu) {
@@ -311,12 +281,15 @@ struct NwWalkerT {
   }
   // the path consumes target base t with the read standing at oriented position q
   __host__ __device__ void on_target_base(u32 t, u32 q, bool write) {
+    // the common case first: same window, and the next grid position lies further down
+    if (cw != 0xFFFFFFFFu && t >= cw_lo && t - cw_lo < w && (gx < 0 || gt < t)) return;
     if (cw == 0xFFFFFFFFu || t < cw_lo || t - cw_lo >= w) {  // another window (the division only here)
       const u32 wi = t / w;
       flush(write);
       cw = wi;
       cw_lo = wi * w;
       have = false;
+#pragma unroll
       for (int g = 0; g < 8; ++g) gq[g] = 0xFFFFFFFFu;
       gx = 7;
       gt = cw_lo + static_cast<u32>((7ULL * w) / 8);
@@ -343,7 +316,6 @@ struct NwWalkerT {
     first_q = q;
     --i;
     --j;
-    consume(1, 1);
   }
   // r >= 1 consecutive 'M' steps whose target bases lie in one window: what r calls of take_diag leave behind
   __host__ __device__ void take_diag_run(int r, bool write) {
@@ -373,33 +345,39 @@ struct NwWalkerT {
     first_q = q_hi - static_cast<u32>(r - 1);
     i -= r;
     j -= r;
-    consume(r, r);
   }
 
   // walks while the current cell lies inside the strip (j > seg_j0, i > row_lo)
   __host__ __device__ void walk(bool write) {
     while (i > row_lo && j > seg_j0) {
       const int room = i - row_lo < j - seg_j0 ? i - row_lo : j - seg_j0;
-      int r = match_run(room);
+      int r = cells.match_run(i, j, room);  // bases come from the strip: no memory access in the walk
       if (r > 0) {  // a match is always taken diagonally: the whole run at once, window by window
         const u32 t_hi = t_begin + static_cast<u32>(i - 1);
+        const u32 t_lo = t_hi - static_cast<u32>(r - 1);
+        if (have && cw != 0xFFFFFFFFu && t_lo >= cw_lo && t_hi - cw_lo < w && (gx < 0 || gt < t_lo)) {
+          // the whole run inside the current window and above the next grid position: only the first pair moves
+          first_t = t_lo;
+          first_q = q_begin + static_cast<u32>(j - r);
+          i -= r;
+          j -= r;
+          continue;
+        }
         // bases from t_hi down to the start of its window
         const bool same = cw != 0xFFFFFFFFu && t_hi >= cw_lo && t_hi - cw_lo < w;
         const u32 in_window = same ? t_hi - cw_lo + 1 : t_hi - (t_hi / w) * w + 1;
         r = static_cast<u32>(r) < in_window ? r : static_cast<int>(in_window);
         take_diag_run(r, write);
-      } else if (cells.sub_ok(i, j)) {
+      } else if (const int mv = cells.decide(i, j); mv == 0) {  // substitution: the diagonal
         --cur;
         take_diag(write);
-      } else if (cells.ins_ok(i, j)) {  // 'I': read base only
+      } else if (mv == 1) {  // 'I': read base only
         --j;
         --cur;
-        consume(0, 1);
       } else {  // 'D': target base only
         on_target_base(t_begin + static_cast<u32>(i - 1), q_begin + static_cast<u32>(j), write);
         --i;
         --cur;
-        consume(1, 0);
       }
     }
   }

@@ -15,6 +15,7 @@
 // the result is always the exact optimal path, the estimate only decides how much band is computed.  hs + ck of a launch
 // are budgeted (RVN_NW_BUDGET_MB, default: a quarter of the free HBM, at most 64 GB); more jobs than fit go in chunks.
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -131,26 +132,30 @@ void nw_sweep_kernel(const NwJob* __restrict__ jobs, const u32* __restrict__ idx
   }
 }
 
+// STRIP_LDS: the walker's strip in LDS (33 KB per wave: four waves per CU) or in a per-wave scratch in HBM / L2
+// ([column][lane], coalesced; occupancy limited by registers only)
+template <bool STRIP_LDS>
 __global__ __launch_bounds__(64) void nw_trace_kernel(const NwJob* __restrict__ jobs, const u32* __restrict__ idx, u32 n_idx,
                                                       const u64* __restrict__ t_words, const u64* __restrict__ r_words,
                                                       const u32* __restrict__ hs, const NwPm* __restrict__ ck,
                                                       const u32* __restrict__ result, u32* __restrict__ status, u32 w,
-                                                      NwWindowRec* __restrict__ recs) {
-  __shared__ u64 s_pv[kNwStripCols * 64];
-  __shared__ u64 s_mv[kNwStripCols * 64];
+                                                      NwWindowRec* __restrict__ recs, u64* __restrict__ scratch) {
+  __shared__ u64 s_pv[STRIP_LDS ? kNwStripCols * 64 : 1];
+  __shared__ u64 s_mv[STRIP_LDS ? kNwStripCols * 64 : 1];
   const u32 q = blockIdx.x * 64 + threadIdx.x;
   if (q >= n_idx) return;
   const u32 ji = idx[q];
   if (status[ji] != 0) return;
   const NwJob J = jobs[ji];
   const NwGeo geo = nw_geo(J.n, J.m, J.k, J.R);
-  const NwStripMem<64> mem{s_pv, s_mv, static_cast<int>(threadIdx.x)};
+  u64* g_pv = scratch + static_cast<u64>(blockIdx.x) * (2 * kNwStripCols * 64);
+  const NwStripMem<64> mem{STRIP_LDS ? s_pv : g_pv, STRIP_LDS ? s_mv : g_pv + kNwStripCols * 64, static_cast<int>(threadIdx.x)};
   status[ji] = static_cast<u32>(nw_trace_job<64>(J, geo, t_words, r_words, hs + J.hs, ck + J.ckpt, mem, result[ji], w, recs));
 }
 
 template <int R, int G>
 void launch_sweep(Engine& e, const NwJob* d_jobs, const u32* d_idx, u32 n_idx, const ReadsDev& T, const ReadsDev& Rd,
-                  u32* d_result, u32* d_status, u32* d_next) {
+                  u32* d_hs, NwPm* d_ck, u32* d_result, u32* d_status, u32* d_next) {
   if (n_idx == 0) return;
   hipStream_t s = e.stream;
   constexpr u32 NG = 64 / G;
@@ -158,8 +163,8 @@ void launch_sweep(Engine& e, const NwJob* d_jobs, const u32* d_idx, u32 n_idx, c
   const u32 waves = std::min<u32>(bundles, 256u * 4u * static_cast<u32>(sweep_waves_per_simd<R>()));
   RVN_HIP(hipMemsetAsync(d_next, 0, 4, s));
   RVN_KLAUNCH(kKNwForward, (nw_sweep_kernel<R, G><<<(waves + 3) / 4, 256, 0, s>>>(
-                               d_jobs, d_idx, n_idx, T.packed.as<u64>(), Rd.packed.as<u64>(), e.nw_hs.as<u32>(),
-                               e.nw_ck.as<NwPm>(), d_result, d_status, d_next)));
+                               d_jobs, d_idx, n_idx, T.packed.as<u64>(), Rd.packed.as<u64>(), d_hs, d_ck, d_result,
+                               d_status, d_next)));
 }
 
 // largest threshold whose band fits a ring of G lanes with R blocks each
@@ -182,6 +187,11 @@ u32 level_of(const NwJob& J) {
 
 // Fills the band fields of `jobs` (k, kcap, R, G, hs, ckpt) and produces every job's window records in d_recs
 // (records of a job start at its bp_off; jobs that cannot be aligned keep all-invalid records and are counted).
+//
+// Schedule: the jobs of a pass go in chunks whose hs + ck fit half the budget, longest jobs first.  The sweeps run on the
+// engine's stream, the walk of chunk i on a second stream beside the sweeps of chunk i + 1 (two buffer sets): a walk is
+// one lane per alignment and latency-bound (~1 us per column), a sweep fills the VALUs — together they cost the time of
+// the sweeps plus the walk of the last, shortest jobs.
 void nw_breakpoints(Engine& e, const ReadsDev& T, const ReadsDev& Rd, std::vector<NwJob>& jobs, u32 w,
                     NwWindowRec* d_recs, u64 n_recs, NwStats& st) {
   st = NwStats();
@@ -190,6 +200,11 @@ void nw_breakpoints(Engine& e, const ReadsDev& T, const ReadsDev& Rd, std::vecto
   RVN_HIP(hipMemsetAsync(d_recs, 0xFF, n_recs * sizeof(NwWindowRec), s));
   if (nj == 0) return;
   RVN_HIP(hipEventRecord(e.ev0, s));
+  if (!e.stream2) {
+    RVN_HIP(hipStreamCreateWithFlags(&e.stream2, hipStreamNonBlocking));
+    for (hipEvent_t& ev : e.nw_ev) RVN_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  }
+  hipStream_t s2 = e.stream2;
   double rate = e.nw_rate > 0 ? e.nw_rate : 0.13;  // first call: ONT-like; too small only costs a repeat
   if (const char* ev = std::getenv("RVN_NW_RATE")) rate = std::atof(ev);  // tests: force repeats
 
@@ -210,27 +225,24 @@ void nw_breakpoints(Engine& e, const ReadsDev& T, const ReadsDev& Rd, std::vecto
     }
     return false;
   };
-  std::vector<u32> todo;
+  std::vector<u32> valid;
   for (u32 i = 0; i < nj; ++i) {
-    NwJob& J = jobs[i];
-    if (J.n == 0 || J.m == 0 || J.n >= (1u << 30) || J.m >= (1u << 30)) {
-      ++st.n_unaligned;
-      continue;
-    }
-    const u32 len = std::max(J.n, J.m);
-    if (plan(J, static_cast<u64>(rate * len) + 16)) todo.push_back(i);
-    else ++st.n_unaligned;
+    const NwJob& J = jobs[i];
+    if (J.n == 0 || J.m == 0 || J.n >= (1u << 30) || J.m >= (1u << 30)) ++st.n_unaligned;
+    else valid.push_back(i);
   }
 
   u64 budget = 0;
   {
     size_t free_b = 0, total_b = 0;
     RVN_HIP(hipMemGetInfo(&free_b, &total_b));
-    budget = std::min<u64>(static_cast<u64>(free_b) / 4 + e.nw_hs.cap + e.nw_ck.cap, 64ULL << 30);
+    const u64 held = e.nw_hs.cap + e.nw_ck.cap + e.nw_hs2.cap + e.nw_ck2.cap;
+    budget = std::min<u64>(static_cast<u64>(free_b) / 4 + held, 64ULL << 30);
     if (const char* ev = std::getenv("RVN_NW_BUDGET_MB")) budget = static_cast<u64>(std::atoll(ev)) << 20;
     budget = std::max<u64>(budget, 64ULL << 20);
   }
-
+  const bool trace_lds = !(std::getenv("RVN_NW_TRACE_MEM") && std::atoi(std::getenv("RVN_NW_TRACE_MEM")) == 1);
+  const bool one_stream = std::getenv("RVN_NW_ONE_STREAM") != nullptr;
   const bool dbg_sync = std::getenv("RVN_NW_DEBUG") && std::atoi(std::getenv("RVN_NW_DEBUG")) >= 2;
   std::vector<double> rates;
   std::vector<u32> h_result(nj), h_status(nj), order;
@@ -239,90 +251,240 @@ void nw_breakpoints(Engine& e, const ReadsDev& T, const ReadsDev& Rd, std::vecto
   u32* d_status = d_res + nj + 1;
   u32* d_idx = d_status + nj + 1;
   u32* d_next = d_idx + nj + 1;
-  while (!todo.empty()) {
-    // classes = kernel variants; inside a class the longest alignments first (persistent waves: no long tail; the groups
-    // of a wave get jobs of nearly the same length)
-    order = todo;
-    std::stable_sort(order.begin(), order.end(), [&](u32 a, u32 b) {
-      const u32 la = level_of(jobs[a]), lb = level_of(jobs[b]);
-      if (la != lb) return la < lb;
-      return jobs[a].m > jobs[b].m;
-    });
-    // chunks of the order whose hs + ck fit the budget (a job larger than the budget goes alone)
-    size_t c0 = 0;
-    while (c0 < order.size()) {
-      u64 hs_w = 0, ck_e = 0;
-      size_t c1 = c0;
-      u32 coff[kLevels + 1] = {};
-      while (c1 < order.size()) {
-        NwJob& J = jobs[order[c1]];
-        const NwGeo g = nw_geo(J.n, J.m, J.k, J.R);
-        const u64 hw = g.hs_words(), ce = g.ck_entries();
-        if (c1 > c0 && (hs_w + hw) * 4 + (ck_e + ce) * 16 > budget) break;
-        J.hs = hs_w;
-        J.ckpt = ck_e;
-        hs_w += hw;
-        ck_e += ce;
-        st.band_cells += static_cast<u64>(J.m) * (static_cast<u64>(g.lo) + g.hi + 1);
-        coff[level_of(J) + 1]++;
-        ++c1;
+  struct Obs {
+    double len, d;
+  };
+  std::vector<Obs> obs;
+  struct Chunk {
+    size_t c0, c1;
+    u64 hs_w, ck_e;
+    u32 coff[kLevels + 1];
+  };
+  // aligns every job of `todo` (already planned), repeating the ones beyond their threshold with twice the band
+  auto run = [&](std::vector<u32> todo, bool sweep_only) {
+    while (!todo.empty()) {
+      // longest jobs first: they go through the widest variants, and the pass ends with the walks of the shortest ones
+      order = todo;
+      std::stable_sort(order.begin(), order.end(), [&](u32 a, u32 b) {
+        const u32 la = level_of(jobs[a]), lb = level_of(jobs[b]);
+        if (la != lb) return la > lb;
+        return jobs[a].m > jobs[b].m;
+      });
+      // chunks of the order whose hs + ck fit half the budget (a job larger than that goes alone)
+      std::vector<Chunk> chunks;
+      u64 max_hs = 0, max_ck = 0;
+      for (size_t c0 = 0; c0 < order.size();) {
+        Chunk C{};
+        C.c0 = c0;
+        size_t c1 = c0;
+        while (c1 < order.size()) {
+          NwJob& J = jobs[order[c1]];
+          const NwGeo g = nw_geo(J.n, J.m, J.k, J.R);
+          const u64 hw = g.hs_words(), ce = g.ck_entries();
+          if (c1 > c0 && (C.hs_w + hw) * 4 + (C.ck_e + ce) * 16 > budget / 2) break;
+          J.hs = C.hs_w;
+          J.ckpt = C.ck_e;
+          C.hs_w += hw;
+          C.ck_e += ce;
+          st.band_cells += static_cast<u64>(J.m) * (static_cast<u64>(g.lo) + g.hi + 1);
+          C.coff[level_of(J) + 1]++;
+          ++c1;
+        }
+        // the order is by descending level: offsets of the classes inside the chunk, in that order
+        u32 run_off = 0, cnt[kLevels];
+        for (u32 x = 0; x < kLevels; ++x) cnt[x] = C.coff[x + 1];
+        for (int x = static_cast<int>(kLevels) - 1; x >= 0; --x) {
+          C.coff[x] = run_off;
+          run_off += cnt[x];
+        }
+        C.coff[kLevels] = run_off;  // count of class x = offset of class x - 1 (or the chunk's end) - its own offset
+        C.c1 = c1;
+        max_hs = std::max(max_hs, C.hs_w);
+        max_ck = std::max(max_ck, C.ck_e);
+        st.store_bytes = std::max<u64>(st.store_bytes, C.hs_w * 4 + C.ck_e * 16);
+        chunks.push_back(C);
+        c0 = c1;
       }
-      for (u32 x = 0; x < kLevels; ++x) coff[x + 1] += coff[x];
-      (void)e.nw_hs.get<u32>(hs_w + 4 * 64 * 8 + 16);  // + slack: the walk reads up to two words past a job's last one
-      (void)e.nw_ck.get<NwPm>(ck_e + 16);
-      st.store_bytes = std::max<u64>(st.store_bytes, hs_w * 4 + ck_e * 16);
-      const u32 cn = static_cast<u32>(c1 - c0);
+      DevBuf* hs_buf[2] = {&e.nw_hs, &e.nw_hs2};
+      DevBuf* ck_buf[2] = {&e.nw_ck, &e.nw_ck2};
+      const int n_sets = chunks.size() > 1 ? 2 : 1;
+      for (int b = 0; b < n_sets; ++b) {
+        (void)hs_buf[b]->get<u32>(max_hs + 4 * 64 * 8 + 16);  // + slack: the walk reads up to two words past a job's last one
+        (void)ck_buf[b]->get<NwPm>(max_ck + 16);
+      }
+      u64* d_strip = nullptr;
+      if (!trace_lds) {
+        size_t mc = 0;
+        for (const Chunk& C : chunks) mc = std::max(mc, C.c1 - C.c0);
+        d_strip = e.nw_strip.get<u64>(static_cast<size_t>((mc + 63) / 64) * 2 * kNwStripCols * 64 * 2 + 16);
+      }
       RVN_HIP(hipMemcpyAsync(d_jobs, jobs.data(), static_cast<size_t>(nj) * sizeof(NwJob), hipMemcpyHostToDevice, s));
-      RVN_HIP(hipMemcpyAsync(d_idx, order.data() + c0, static_cast<size_t>(cn) * 4, hipMemcpyHostToDevice, s));
+      RVN_HIP(hipMemcpyAsync(d_idx, order.data(), order.size() * 4, hipMemcpyHostToDevice, s));
       RVN_HIP(rvn_stream_sync(s));  // `jobs` / `order` are pageable: the copies must be done before the host goes on
+      for (size_t ci = 0; ci < chunks.size(); ++ci) {
+        const Chunk& C = chunks[ci];
+        const int b = static_cast<int>(ci & 1);
+        u32* hs = hs_buf[b]->as<u32>();
+        NwPm* ck = ck_buf[b]->as<NwPm>();
+        const u32* idx_c = d_idx + C.c0;
+        const u32 cn = static_cast<u32>(C.c1 - C.c0);
+        if (ci >= 2) RVN_HIP(hipStreamWaitEvent(s, e.nw_ev[b], 0));  // the walk of chunk ci - 2 is done with this buffer set
+        auto count_of = [&](u32 x) -> u32 {  // classes are laid out from the widest variant down
+          const u32 next_off = x == 0 ? cn : C.coff[x - 1];
+          return next_off - C.coff[x];
+        };
 #define RVN_SWEEP(x, R_, G_)                                                                                         \
   do {                                                                                                               \
-    launch_sweep<R_, G_>(e, d_jobs, d_idx + coff[x], coff[x + 1] - coff[x], T, Rd, d_res, d_status, d_next);           \
-    if (dbg_sync && coff[x + 1] > coff[x]) {                                                                         \
+    launch_sweep<R_, G_>(e, d_jobs, idx_c + C.coff[x], count_of(x), T, Rd, hs, ck, d_res, d_status, d_next);           \
+    if (dbg_sync && count_of(x)) {                                                                                   \
       RVN_HIP(hipStreamSynchronize(s));                                                                              \
-      std::fprintf(stderr, "[raven_hip] nw: sweep R=%d G=%d done, %u jobs\n", R_, G_, coff[x + 1] - coff[x]);          \
+      std::fprintf(stderr, "[raven_hip] nw: sweep R=%d G=%d done, %u jobs\n", R_, G_, count_of(x));                   \
     }                                                                                                                \
   } while (0)
-      RVN_SWEEP(0, 1, 4);
-      RVN_SWEEP(1, 1, 8);
-      RVN_SWEEP(2, 1, 16);
-      RVN_SWEEP(3, 1, 32);
-      RVN_SWEEP(4, 1, 64);
-      RVN_SWEEP(5, 2, 64);
-      RVN_SWEEP(6, 4, 64);
-      RVN_SWEEP(7, 8, 64);
+        RVN_SWEEP(7, 8, 64);
+        RVN_SWEEP(6, 4, 64);
+        RVN_SWEEP(5, 2, 64);
+        RVN_SWEEP(4, 1, 64);
+        RVN_SWEEP(3, 1, 32);
+        RVN_SWEEP(2, 1, 16);
+        RVN_SWEEP(1, 1, 8);
+        RVN_SWEEP(0, 1, 4);
 #undef RVN_SWEEP
-      RVN_KLAUNCH(kKNwTraceback, (nw_trace_kernel<<<(cn + 63) / 64, 64, 0, s>>>(
-                                     d_jobs, d_idx, cn, T.packed.as<u64>(), Rd.packed.as<u64>(), e.nw_hs.as<u32>(),
-                                     e.nw_ck.as<NwPm>(), d_res, d_status, w, d_recs)));
-      if (dbg_sync) {
-        RVN_HIP(hipStreamSynchronize(s));
-        std::fprintf(stderr, "[raven_hip] nw: trace done, %u jobs\n", cn);
+        if (sweep_only) {
+          ++st.n_batches;
+          continue;
+        }
+        hipStream_t ts = one_stream ? s : s2;
+        if (!one_stream) {
+          RVN_HIP(hipEventRecord(e.nw_ev[2], s));
+          RVN_HIP(hipStreamWaitEvent(s2, e.nw_ev[2], 0));
+        }
+        if (trace_lds) {
+          RVN_KLAUNCH_ON(kKNwTraceback, ts, (nw_trace_kernel<true><<<(cn + 63) / 64, 64, 0, ts>>>(
+                                                d_jobs, idx_c, cn, T.packed.as<u64>(), Rd.packed.as<u64>(), hs, ck, d_res,
+                                                d_status, w, d_recs, nullptr)));
+        } else {
+          RVN_KLAUNCH_ON(kKNwTraceback, ts, (nw_trace_kernel<false><<<(cn + 63) / 64, 64, 0, ts>>>(
+                                                d_jobs, idx_c, cn, T.packed.as<u64>(), Rd.packed.as<u64>(), hs, ck, d_res,
+                                                d_status, w, d_recs,
+                                                d_strip + static_cast<size_t>(b) * ((e.nw_strip.cap / 16) & ~size_t(63)))));
+        }
+        if (!one_stream) RVN_HIP(hipEventRecord(e.nw_ev[b], s2));
+        if (dbg_sync) {
+          RVN_HIP(hipStreamSynchronize(ts));
+          std::fprintf(stderr, "[raven_hip] nw: trace done, %u jobs\n", cn);
+        }
+        ++st.n_batches;
       }
-      ++st.n_batches;
-      c0 = c1;
+      if (!one_stream && !sweep_only) {  // everything of this pass done before the results are read
+        RVN_HIP(hipEventRecord(e.nw_ev[2], s2));
+        RVN_HIP(hipStreamWaitEvent(s, e.nw_ev[2], 0));
+      }
+      RVN_HIP(hipMemcpyAsync(h_result.data(), d_res, static_cast<size_t>(nj) * 4, hipMemcpyDeviceToHost, s));
+      RVN_HIP(hipMemcpyAsync(h_status.data(), d_status, static_cast<size_t>(nj) * 4, hipMemcpyDeviceToHost, s));
+      RVN_HIP(rvn_stream_sync(s));
+      std::vector<u32> again;
+      for (u32 i : todo) {
+        NwJob& J = jobs[i];
+        if (h_status[i] == 2) {  // distance above the threshold: twice the band (and the variant that holds it)
+          ++st.n_retries;
+          if (J.k >= static_cast<u64>(J.n) + J.m || !plan(J, static_cast<u64>(J.k) * 2)) ++st.n_unaligned;
+          else again.push_back(i);
+        } else if (h_status[i] != 0) {
+          throw HipError("[raven_hip] alignment path: the walk left the stored band (internal error)");
+        } else {
+          if (!sweep_only) {
+            ++st.n_aligned;
+            st.sum_distance += h_result[i];
+            rates.push_back(static_cast<double>(h_result[i]) / std::max(J.n, J.m));
+          }
+          obs.push_back(Obs{static_cast<double>(std::max(J.n, J.m)), static_cast<double>(h_result[i])});
+        }
+      }
+      todo.swap(again);
     }
-    RVN_HIP(hipMemcpyAsync(h_result.data(), d_res, static_cast<size_t>(nj) * 4, hipMemcpyDeviceToHost, s));
-    RVN_HIP(hipMemcpyAsync(h_status.data(), d_status, static_cast<size_t>(nj) * 4, hipMemcpyDeviceToHost, s));
-    RVN_HIP(rvn_stream_sync(s));
-    std::vector<u32> again;
-    for (u32 i : todo) {
+  };
+
+  // Thresholds.  A pilot sample (every call: the error level changes from round to round) is aligned with a generous
+  // band; its distances give the mean rate mu and the spread around mu x len as  var = a len + b len^2  (a: base-level
+  // noise, b: differences between reads).  Everyone gets  k = mu len + 4.5 sqrt(a len + b len^2) + 6 : with a normal
+  // spread a few alignments in a million are repeated (a repeat pass ends with lonely, latency-bound walks, so it is
+  // worth ~3 % more band to make it rare), against one in ten with a 90th-percentile rule.  The pilot is swept for its
+  // distances only and skips the longest quarter of the reads.  Small batches keep the previous call's estimate.
+  std::vector<u32> rest;
+  double mu = -1, va = 0, vb = 0;
+  if (valid.size() >= 4096 && !std::getenv("RVN_NW_RATE")) {
+    std::vector<u32> lens;
+    for (u32 i : valid) lens.push_back(std::max(jobs[i].n, jobs[i].m));
+    std::nth_element(lens.begin(), lens.begin() + lens.size() * 3 / 4, lens.end());
+    const u32 len_cap = lens[lens.size() * 3 / 4];
+    std::vector<u32> pilot;
+    const size_t stride = valid.size() / 1400;
+    for (size_t x = 0; x < valid.size(); ++x) {
+      const NwJob& J = jobs[valid[x]];
+      if (x % stride == stride / 2 && pilot.size() < 1024 && std::max(J.n, J.m) <= len_cap) pilot.push_back(valid[x]);
+      rest.push_back(valid[x]);  // the pilot is swept for its distances only; its jobs are aligned with everyone else
+    }
+    std::vector<u32> ok;
+    for (u32 i : pilot) {
       NwJob& J = jobs[i];
-      if (h_status[i] == 2) {  // distance above the threshold: twice the band (and the variant that holds it)
-        ++st.n_retries;
-        if (J.k >= static_cast<u64>(J.n) + J.m || !plan(J, static_cast<u64>(J.k) * 2)) ++st.n_unaligned;
-        else again.push_back(i);
-      } else if (h_status[i] != 0) {
-        throw HipError("[raven_hip] alignment path: the walk left the stored band (internal error)");
-      } else {
-        ++st.n_aligned;
-        st.sum_distance += h_result[i];
-        rates.push_back(static_cast<double>(h_result[i]) / std::max(J.n, J.m));
-      }
+      if (plan(J, static_cast<u64>((rate * 1.25 + 0.02) * std::max(J.n, J.m)) + 16)) ok.push_back(i);
     }
-    todo.swap(again);
+    run(ok, true);
+    if (obs.size() >= 256) {
+      double sl = 0, sd = 0;
+      for (const Obs& o : obs) {
+        sl += o.len;
+        sd += o.d;
+      }
+      mu = sd / sl;
+      // least squares of the squared residuals on (len, len^2), the 2 % largest standardised residuals left out
+      std::vector<double> zs;
+      for (const Obs& o : obs) zs.push_back(std::fabs(o.d - mu * o.len) / std::sqrt(o.len));
+      std::vector<double> zsorted = zs;
+      std::sort(zsorted.begin(), zsorted.end());
+      const double zcut = zsorted[static_cast<size_t>(zsorted.size() * 0.98)];
+      double s11 = 0, s12 = 0, s22 = 0, t1 = 0, t2 = 0, sr = 0, sn = 0;
+      for (size_t x = 0; x < obs.size(); ++x) {
+        if (zs[x] > zcut) continue;
+        const double L = obs[x].len * 1e-3, r2 = (obs[x].d - mu * obs[x].len) * (obs[x].d - mu * obs[x].len);
+        s11 += L * L;
+        s12 += L * L * L;
+        s22 += L * L * L * L;
+        t1 += r2 * L;
+        t2 += r2 * L * L;
+        sr += r2 / L;
+        sn += 1;
+      }
+      const double det = s11 * s22 - s12 * s12;
+      double a = -1, b = -1;
+      if (det > 1e-9 * s11 * s22) {
+        a = (t1 * s22 - t2 * s12) / det;
+        b = (t2 * s11 - t1 * s12) / det;
+      }
+      if (!(a >= 0) || !(b >= 0)) {  // one length only, or a fit outside the model: all spread on the linear term
+        a = sn > 0 ? sr / sn : mu * 1e3;
+        b = 0;
+      }
+      va = std::max(a * 1e-3, 0.25 * mu);  // back to bases; never below a quarter of the Poisson level
+      vb = b * 1e-6;
+    }
+  } else {
+    rest = valid;
   }
-  if (rates.size() >= 32) {  // threshold estimate for the next call: most alignments succeed at the first attempt
+  {
+    std::vector<u32> ok;
+    for (u32 i : rest) {
+      NwJob& J = jobs[i];
+      const double len = std::max(J.n, J.m);
+      const double z = 4.5;
+      const u64 k = mu > 0 ? static_cast<u64>(mu * len + z * std::sqrt(va * len + vb * len * len)) + 6 : static_cast<u64>(rate * len) + 16;
+      if (plan(J, k)) ok.push_back(i);
+      else ++st.n_unaligned;
+    }
+    run(ok, false);
+  }
+  if (rates.size() >= 32) {  // rate estimate for the next call (the pilot's first threshold / small batches)
     std::sort(rates.begin(), rates.end());
     e.nw_rate = rates[std::min(rates.size() - 1, static_cast<size_t>(rates.size() * 0.9))] * 1.05 + 0.002;
   }
@@ -332,9 +494,9 @@ void nw_breakpoints(Engine& e, const ReadsDev& T, const ReadsDev& Rd, std::vecto
   RVN_HIP(hipEventElapsedTime(&ms, e.ev0, e.ev1));
   st.ms = ms;
   if (std::getenv("RVN_NW_DEBUG"))
-    std::fprintf(stderr, "[raven_hip] nw: %u jobs, %llu aligned, %llu retries, %llu chunks, %.3e band cells, %.1f MB hs + ck, %.1f ms\n", nj,
+    std::fprintf(stderr, "[raven_hip] nw: %u jobs, %llu aligned, %llu retries, %llu chunks, %.3e band cells, %.1f MB hs + ck, %.1f ms; pilot mu %.4f a %.4f b %.3e\n", nj,
                  static_cast<unsigned long long>(st.n_aligned), static_cast<unsigned long long>(st.n_retries),
-                 static_cast<unsigned long long>(st.n_batches), static_cast<double>(st.band_cells), st.store_bytes / 1048576.0, ms);
+                 static_cast<unsigned long long>(st.n_batches), static_cast<double>(st.band_cells), st.store_bytes / 1048576.0, ms, mu, va, vb);
 }
 
 // ---- CPU stepper of the same code (test hook rvn_test_nw_breakpoints): 64 emulated lanes, host arrays --------------

@@ -47,6 +47,7 @@ struct NwSweepLane {
   u64 eq[R];      // match masks of the column of the NEXT step (prefetched)
   u32 acc[R];     // horizontal deltas out of each block, the 16 steps of the current hs word
   u32 w_cur, w_nxt;  // text symbols of the current / next group of 16 steps
+  NwRaw raw;         // words of the group after that, in flight
   int xf;         // what the next lane of the ring reads one step later (2 bits)
   u32 result;     // D(n, m) + 1 on the lane that retired the last super-block
 
@@ -75,6 +76,7 @@ struct NwSweepLane {
     }
     sc = 0;
     w_cur = w_nxt = 0;
+    raw = NwRaw{0, 0};
     xf = 1;
     result = 0;
   }
@@ -101,6 +103,7 @@ struct NwSweepLane {
     }
     sc = 0;
     w_cur = w_nxt = 0;
+    raw = NwRaw{0, 0};
     xf = 1;
     result = 0;
   }
@@ -110,6 +113,17 @@ struct NwSweepLane {
     const int col0 = kNwHsSteps * gi + 1 - s;
     if (col0 > g.m || b_words == nullptr) return 0;  // nothing of the read there (and nothing beyond it to load)
     return nw_text16(b_words, b_first, rc, col0);
+  }
+  // the same in two halves: loads now, symbols one group of steps later
+  __host__ __device__ void window_load(int gi) {
+    const int col0 = kNwHsSteps * gi + 1 - s;
+    if (col0 > g.m || b_words == nullptr) return;
+    raw = nw_text16_load(b_words, nw_text16_base(b_first, rc, col0));
+  }
+  __host__ __device__ u32 window_finish(int gi) const {
+    const int col0 = kNwHsSteps * gi + 1 - s;
+    if (col0 > g.m || b_words == nullptr) return 0;
+    return nw_text16_finish(raw, nw_text16_base(b_first, rc, col0), rc);
   }
   __host__ __device__ void fetch_eq(unsigned c) {
 #pragma unroll
@@ -145,10 +159,9 @@ struct NwSweepLane {
       for (int r = 0; r < R; ++r) {
         Pv[r] = ~0ULL;
         Mv[r] = 0;
-        u64 p4[4];
-        load_peq(a_words, a_base, static_cast<u32>(g.n), static_cast<u32>(s * R + r), p4);
+        const BlockPlanes pl = nw_load_planes(a_words, a_base, static_cast<u32>(g.n), static_cast<u32>(s * R + r));
 #pragma unroll
-        for (int c = 0; c < 4; ++c) peq[(r * 4 + c) * LANES + lane] = p4[c];
+        for (int c = 0; c < 4; ++c) peq[(r * 4 + c) * LANES + lane] = planes_eq(pl, static_cast<unsigned>(c));
       }
       t_fed = g.jfed(s) + (s > 0 ? s : 0);
       t_evt = g.je(s) + s + 1;
@@ -156,6 +169,7 @@ struct NwSweepLane {
       const int u = t - 1;
       w_cur = window(u >> 4);
       w_nxt = window((u >> 4) + 1);
+      window_load((u >> 4) + 2);
       fetch_eq((w_cur >> (2 * (u & 15))) & 3u);
     }
   }
@@ -180,7 +194,8 @@ struct NwSweepLane {
 #pragma unroll
     for (int r = 0; r < R; ++r) acc[r] = 0;
     w_cur = w_nxt;
-    w_nxt = window((t >> 4) + 1);  // t = 16 (gi + 1): the group after the one that starts now
+    w_nxt = window_finish((t >> 4) + 1);  // t = 16 (gi + 1): the group after the one that starts now; loaded 16 steps ago
+    window_load((t >> 4) + 2);
   }
 };
 

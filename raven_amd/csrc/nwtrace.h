@@ -35,6 +35,24 @@ struct NwStripCells {
   NwStripMem<LANES> mem;
   int j0;     // column of strip entry 0
   u64 hinw;   // horizontal input of the block at columns j0 + 1 .. j0 + 32, 2 bits each
+  u64 tlo, thi;  // bit planes of the block's 64 target bases (bit p = row p of the block)
+  u32 rlo, rhi;  // bit planes of the read bases of columns j0 + 1 .. j0 + 32 (bit x = column j0 + 1 + x)
+  // number of matches going up the diagonal from (i, j), at most lim (<= rows left in the block, <= columns left in
+  // the strip): both sequences are in registers, 32 bases are compared at once
+  __host__ __device__ int match_run(int i, int j, int lim) const {
+    const int p = (i - 1) & 63, x0 = j - j0 - 1;
+    const int sh = p - x0;
+    const u32 a_lo = sh >= 0 ? static_cast<u32>(tlo >> sh) : static_cast<u32>(tlo << -sh);
+    const u32 a_hi = sh >= 0 ? static_cast<u32>(thi >> sh) : static_cast<u32>(thi << -sh);
+    const u32 below = x0 >= 31 ? 0xFFFFFFFFu : ((2u << x0) - 1u);  // columns j0 + 1 .. j
+    const u32 mism = ((a_lo ^ rlo) | (a_hi ^ rhi)) & below;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int run = mism ? x0 - (31 - __clz(static_cast<int>(mism))) : x0 + 1;
+#else
+    const int run = mism ? x0 - (31 - __builtin_clz(mism)) : x0 + 1;
+#endif
+    return run < lim ? run : lim;
+  }
   // dh(i-1, j) and the two vertical deltas at (i, j) / (i, j-1)
   __host__ __device__ void deltas(int i, int j, int* a, int* dvj, int* dv1) const {
     const int c = j - j0;
@@ -48,15 +66,12 @@ struct NwStripCells {
     *dvj = static_cast<int>((pvj >> p) & 1ULL) - static_cast<int>((mvj >> p) & 1ULL);
     *dv1 = static_cast<int>((pv1 >> p) & 1ULL) - static_cast<int>((mv1 >> p) & 1ULL);
   }
-  __host__ __device__ bool sub_ok(int i, int j) const {
+  // which neighbour the path takes from a mismatching cell: 0 the diagonal, 1 the left one (read base only), 2 the
+  // upper one (target base only) — racon's order
+  __host__ __device__ int decide(int i, int j) const {
     int a, dvj, dv1;
     deltas(i, j, &a, &dvj, &dv1);
-    return dvj + a == 1;
-  }
-  __host__ __device__ bool ins_ok(int i, int j) const {
-    int a, dvj, dv1;
-    deltas(i, j, &a, &dvj, &dv1);
-    return a + dvj - dv1 == 1;
+    return dvj + a == 1 ? 0 : (a + dvj - dv1 == 1 ? 1 : 2);
   }
 };
 
@@ -67,9 +82,10 @@ __host__ __device__ inline u64 nw_hs_bits(const u32* __restrict__ hs, const NwGe
   const u64 g0 = static_cast<u64>(u_first) >> 4;
   const u32* p = hs + g0 * stride + static_cast<u64>(lane) * static_cast<u64>(g.R) + static_cast<u64>(r);
   const unsigned sh = 2u * (static_cast<unsigned>(u_first) & 15u);
-  const u64 lo = static_cast<u64>(p[0]) | (static_cast<u64>(p[stride]) << 32);
+  const u32 x0 = p[0], x1 = p[stride], x2 = p[2 * stride];  // all three at once (the buffer has slack behind the last job)
+  const u64 lo = static_cast<u64>(x0) | (static_cast<u64>(x1) << 32);
   u64 v = lo >> sh;
-  if (sh) v |= static_cast<u64>(p[2 * stride]) << (64 - sh);
+  if (sh) v |= static_cast<u64>(x2) << (64 - sh);
   return v;
 }
 
@@ -86,7 +102,7 @@ __host__ __device__ inline int nw_trace_job(const NwJob& J, const NwGeo& g, cons
   const long long b_first = rc ? b_base + static_cast<long long>(J.m) - 1 : b_base;
   NwWalkerT<NwStripCells<LANES>> wk;
   wk.cells.mem = mem;
-  wk.init(J, t_words_all, r_words_all, distance, w, recs_all);
+  wk.init(J, distance, w, recs_all);
   const int R = g.R, L = g.L;
   while (wk.i > 0 && wk.j > 0) {
     const int b = (wk.i - 1) >> 6;
@@ -122,7 +138,7 @@ __host__ __device__ inline int nw_trace_job(const NwJob& J, const NwGeo& g, cons
     } else {
       hinw = 0x5555555555555555ULL;  // +1 everywhere: the matrix border or a retired block above
     }
-    const BlockPlanes pl = load_planes(tw, J.t_begin, static_cast<u32>(g.n), static_cast<u32>(b));
+    const BlockPlanes pl = nw_load_planes(tw, J.t_begin, static_cast<u32>(g.n), static_cast<u32>(b));
     u64 text = static_cast<u64>(nw_text16(rw, b_first, rc, j0 + 1));
     if (len > 16) text |= static_cast<u64>(nw_text16(rw, b_first, rc, j0 + 17)) << 32;
     mem.pv[mem.at(0)] = pv;
@@ -135,6 +151,10 @@ __host__ __device__ inline int nw_trace_job(const NwJob& J, const NwGeo& g, cons
     }
     wk.cells.j0 = j0;
     wk.cells.hinw = hinw;
+    wk.cells.tlo = pl.lo;
+    wk.cells.thi = pl.hi;
+    wk.cells.rlo = static_cast<u32>(compress_even(text));
+    wk.cells.rhi = static_cast<u32>(compress_even(text >> 1));
     wk.seg_j0 = j0;
     wk.row_lo = 64 * b;
     wk.walk(true);
