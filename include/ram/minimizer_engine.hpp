@@ -102,6 +102,10 @@ class MinimizerEngine {
     index_reads_.Upload(engine_, first, last);
     index_first_ = first == last ? nullptr : &*first;
     index_count_ = static_cast<std::size_t>(last - first);
+    // what sat in every slot when the index was built: Raven re-sorts `sequences` in place (construct.cc:324, :486), and a
+    // cached answer must not be served for whatever read occupies the slot afterwards
+    index_print_.resize(index_count_);
+    for (std::size_t i = 0; i < index_count_; ++i) index_print_[i] = Fingerprint(*(first + i));
     detail::Check(rvn_engine_minimize(engine_, index_reads_.h, 0, static_cast<std::uint32_t>(last - first), minhash));
   }
 
@@ -122,7 +126,8 @@ class MinimizerEngine {
     const std::unique_ptr<biosoup::NucleicAcid>* first = &sequence;
     {
       std::lock_guard<std::mutex> lk(mu_);
-      if (index_first_ && first >= index_first_ && first < index_first_ + index_count_) {
+      if (index_first_ && first >= index_first_ && first < index_first_ + index_count_ &&
+          Fingerprint(sequence) == index_print_[static_cast<std::size_t>(first - index_first_)]) {
         const std::size_t i = static_cast<std::size_t>(first - index_first_);
         const int flags = (avoid_equal ? 1 : 0) | (avoid_symmetric ? 2 : 0) | (minhash ? 4 : 0);
         if (!cache_.valid || cache_.flags != flags || (filtered && !cache_.has_filtered)) {
@@ -132,10 +137,16 @@ class MinimizerEngine {
           cache_.filtered = std::move(res.second);
           cache_.flags = flags;
           cache_.has_filtered = filtered != nullptr;
+          cache_.served.assign(index_count_, false);
           cache_.valid = true;
         }
-        if (filtered) *filtered = cache_.filtered[i];
-        return cache_.overlaps[i];
+        // every entry is served once per pass (Raven maps each read once): hand it over instead of copying it, so the
+        // host copy of a ~1 Gbase batch's overlaps shrinks as it is consumed; a second request re-maps that read singly
+        if (!cache_.served[i]) {
+          cache_.served[i] = true;
+          if (filtered) *filtered = std::move(cache_.filtered[i]);
+          return std::move(cache_.overlaps[i]);
+        }
       }
     }
     detail::ReadsHandle q;
@@ -190,10 +201,26 @@ class MinimizerEngine {
     int flags = 0;
     std::vector<std::vector<biosoup::Overlap>> overlaps;
     std::vector<std::vector<std::uint32_t>> filtered;
+    std::vector<bool> served;
   };
+  struct Print {  // identity of the read in an indexed slot
+    std::uint32_t id = 0, len = 0;
+    std::uint64_t word = 0;
+    bool operator==(const Print& o) const { return id == o.id && len == o.len && word == o.word; }
+  };
+  static Print Fingerprint(const std::unique_ptr<biosoup::NucleicAcid>& s) {
+    Print p;
+    if (s) {
+      p.id = static_cast<std::uint32_t>(s->id);
+      p.len = s->inflated_len;
+      p.word = s->deflated_data.empty() ? 0 : s->deflated_data[s->deflated_data.size() / 2];
+    }
+    return p;
+  }
   mutable std::mutex mu_;  // guards the cache and the index read set
   mutable Cache cache_;
   const std::unique_ptr<biosoup::NucleicAcid>* index_first_ = nullptr;  // the caller's sequences the index covers
+  std::vector<Print> index_print_;
   std::size_t index_count_ = 0;
   rvn_engine* engine_ = nullptr;
   detail::ReadsHandle index_reads_;

@@ -5,6 +5,12 @@
 // PileT must provide PileT(std::uint32_t id, std::uint32_t len) and
 //   void AdoptCoverage(const std::uint16_t* data, std::size_t n)   // replaces Pile::data_ (n == len >> 4)
 // (a two-line addition to raven::Pile; AddLayers itself is no longer called on this path).
+//
+// Optional: pass a raven::Pass1Handle to FindOverlapsAndCreatePiles and the coverage stays in HBM for
+// raven::TrimAndAnnotatePiles(thread_pool, piles, overlaps, handle) below — construct.cc:123-152 (FindValidRegion(4),
+// FindMedian, FindChimericRegions of every pile) on the device instead of Pile's host loops; PileT then also provides
+//   void AdoptAnnotation(std::uint32_t begin, std::uint32_t end, std::uint16_t median, bool invalid)   // cells, as Pile::begin_ / end_
+//   void AdoptChimericRegions(const std::uint32_t* pairs, std::size_t n)                                // Pile::chimeric_regions_
 #ifndef RAVEN_HIP_FIND_OVERLAPS_HPP_
 #define RAVEN_HIP_FIND_OVERLAPS_HPP_
 
@@ -17,6 +23,15 @@
 
 namespace raven {
 
+// the first pass's result in HBM, kept alive between FindOverlapsAndCreatePiles and TrimAndAnnotatePiles
+struct Pass1Handle {
+  rvn_pass1* p = nullptr;
+  Pass1Handle() = default;
+  Pass1Handle(const Pass1Handle&) = delete;
+  Pass1Handle& operator=(const Pass1Handle&) = delete;
+  ~Pass1Handle() { rvn_pass1_destroy(p); }
+};
+
 template <typename PileT>
 void FindOverlapsAndCreatePiles(const std::shared_ptr<thread_pool::ThreadPool>& /*thread_pool*/,
                                 ram::MinimizerEngine& minimizer_engine,
@@ -24,7 +39,8 @@ void FindOverlapsAndCreatePiles(const std::shared_ptr<thread_pool::ThreadPool>& 
                                 std::vector<std::unique_ptr<PileT>>& piles,
                                 std::vector<std::vector<biosoup::Overlap>>& overlaps,
                                 std::size_t kMaxNumOverlaps = 32, bool useMinhash = false,
-                                std::uint64_t index_batch_bases = 1ULL << 32, std::uint64_t flush_bases = 1ULL << 30) {
+                                std::uint64_t index_batch_bases = 1ULL << 32, std::uint64_t flush_bases = 1ULL << 30,
+                                Pass1Handle* keep = nullptr) {
   piles.reserve(sequences.size());
   for (const auto& it : sequences) piles.emplace_back(new PileT(it->id, it->inflated_len));
   if (sequences.empty()) return;
@@ -38,8 +54,16 @@ void FindOverlapsAndCreatePiles(const std::shared_ptr<thread_pool::ThreadPool>& 
                                                         index_batch_bases, flush_bases, &p));
   struct Guard {
     rvn_pass1* p;
-    ~Guard() { rvn_pass1_destroy(p); }
-  } guard{p};
+    Pass1Handle* keep;
+    ~Guard() {
+      if (keep) {
+        rvn_pass1_destroy(keep->p);
+        keep->p = p;
+      } else {
+        rvn_pass1_destroy(p);
+      }
+    }
+  } guard{p, keep};
 
   const std::size_t n = sequences.size();
   std::vector<std::uint16_t> data(rvn_pass1_pile_words(p));
@@ -54,6 +78,37 @@ void FindOverlapsAndCreatePiles(const std::shared_ptr<thread_pool::ThreadPool>& 
     overlaps[i].clear();
     overlaps[i].reserve(ooff[i + 1] - ooff[i]);
     for (std::uint32_t j = ooff[i]; j < ooff[i + 1]; ++j) overlaps[i].emplace_back(ram::detail::ToOverlap(flat[j]));
+  }
+}
+
+// raven::TrimAndAnnotatePiles (RavenLib/src/construct.cc:123-152) on the coverage arrays the first pass left in HBM:
+// Pile::FindValidRegion(4) (+ UpdateValidRegion), FindMedian and FindChimericRegions of every pile in two device calls;
+// overlaps[i] of an invalid pile is released as the reference does (:134-135).  The piles get their trimmed coverage,
+// valid region, median, validity and chimeric regions through the Adopt* hooks (see the top of this file).
+template <typename PileT>
+void TrimAndAnnotatePiles(const std::shared_ptr<thread_pool::ThreadPool>& /*thread_pool*/,
+                          const std::vector<std::unique_ptr<PileT>>& piles,
+                          std::vector<std::vector<biosoup::Overlap>>& overlaps, Pass1Handle& pass) {
+  const std::size_t n = piles.size();
+  if (n == 0 || pass.p == nullptr) return;
+  std::vector<std::uint32_t> begin(n), end(n), roff(n + 1);
+  std::vector<std::uint16_t> median(n);
+  std::vector<std::uint8_t> invalid(n);
+  ram::detail::Check(rvn_pass1_trim_and_annotate(pass.p, 4, begin.data(), end.data(), median.data(), invalid.data()));
+  std::uint32_t* regions = nullptr;
+  ram::detail::Check(rvn_pass1_find_chimeric_regions(pass.p, invalid.data(), roff.data(), &regions));
+  struct Free {
+    void* p;
+    ~Free() { rvn_free(p); }
+  } free_regions{regions};
+  std::vector<std::uint16_t> data(rvn_pass1_pile_words(pass.p));
+  std::vector<std::uint64_t> poff(n + 1);
+  ram::detail::Check(rvn_pass1_fetch_piles(pass.p, data.data(), poff.data()));
+  for (std::size_t i = 0; i < n; ++i) {
+    piles[i]->AdoptCoverage(data.data() + poff[i], poff[i + 1] - poff[i]);
+    piles[i]->AdoptAnnotation(begin[i], end[i], median[i], invalid[i] != 0);
+    piles[i]->AdoptChimericRegions(regions + 2 * static_cast<std::size_t>(roff[i]), roff[i + 1] - roff[i]);
+    if (invalid[i]) std::vector<biosoup::Overlap>().swap(overlaps[i]);
   }
 }
 

@@ -1170,7 +1170,9 @@ std::int64_t orc_second_pass(orc_engine* eng, const std::uint64_t* packed, const
   // construct.cc:324-332: valid first, each group by id
   std::vector<orc::Read> sequences;
   for (std::uint32_t i = 0; i < n_reads; ++i) if (!piles[i].invalid) sequences.push_back(all[i]);
-  const std::uint32_t s = sequences.size();
+  // construct.cc:343-349: s = position of the first invalid pile, 0 when there is none (the reference's loop leaves it
+  // at its initial value: with every pile valid nothing is mapped)
+  const std::uint32_t s = sequences.size() == n_reads ? 0 : sequences.size();
   std::vector<orc::Overlap> back;
   std::uint64_t bytes = 0;
   for (std::uint32_t i = 0, j = 0; i < s; ++i) {

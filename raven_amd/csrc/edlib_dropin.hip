@@ -100,7 +100,15 @@ struct Service {
       std::vector<Request*> batch;
       batch.swap(queue);
       lk.unlock();
-      run(batch);
+      // nothing may escape from here: a follower waits on `done`, and this is reached through extern "C" edlibAlign.
+      // An exception in the host-side staging (std::bad_alloc, ...) fails the batch instead of stranding the followers.
+      try {
+        run(batch);
+      } catch (const std::bad_alloc&) {
+        for (Request* r : batch) r->rc = RVN_ENOMEM;
+      } catch (...) {
+        for (Request* r : batch) r->rc = RVN_EHIP;
+      }
       lk.lock();
       for (Request* r : batch) r->done = true;
       cv_done.notify_all();

@@ -125,7 +125,7 @@ struct Engine {
   DevBuf p2_slot, p2_pairs, p2_dist, p2_regions, p2_index_of, p2_kmers_off, p2_ok, p2_keep, p2_tmp_ovl;
   DevBuf poa_sched, poa_redo_w, poa_redo_i;  // LPT order / escalation lists of a POA batch (poa_run_dev)
   // alignment-path stage of a polishing round (nwpath.hip): stored band words + scores, jobs, results
-  DevBuf nw_hs, nw_ck, nw_hs2, nw_ck2, nw_strip, nw_jobs, nw_res;  // alignment paths: horizontal-delta streams, checkpoints, jobs, results
+  DevBuf nw_hs, nw_ck, nw_hs2, nw_ck2, nw_hs3, nw_ck3, nw_strip, nw_jobs, nw_res;  // alignment paths: horizontal-delta streams, checkpoints, jobs, results
   double nw_rate = -1.0;  // running estimate of edit distance / length of the read-to-target alignments (< 0: unknown)
   // polishing front end (polish.hip): best overlaps, window records, layer tables, consensus
   DevBuf pl_best, pl_best_t, pl_idmap, pl_recs, pl_keep, pl_win_cnt, pl_win_off, pl_win_fill, pl_win_meta, pl_first_window,
@@ -158,8 +158,8 @@ struct Engine {
   u64 c_intervals = 0;
   bool timing = true;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  hipStream_t stream2 = nullptr;  // second stream of the alignment-path stage (walks beside the next chunk's sweeps)
-  hipEvent_t nw_ev[3] = {nullptr, nullptr, nullptr};
+  hipStream_t nw_streams[3] = {nullptr, nullptr, nullptr};  // walk streams of the alignment-path stage (beside the sweeps)
+  hipEvent_t nw_ev[4] = {nullptr, nullptr, nullptr, nullptr};
   u64* h_pin = nullptr;  // pinned host scratch for small device->host size read-backs
   PinBuf pin_big;        // pinned staging for bulk read-backs up to 256 MB (polishing: chain anchors)
   HostBuf host_big;      // ... and the unpinned one for larger ones

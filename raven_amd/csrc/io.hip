@@ -157,7 +157,18 @@ void reads_load(Engine& e, const std::string& path, ReadsDev& R, std::vector<std
         if (pos == have) {
           if (eof) return !out.empty();
           const int n = gzread(gz, buf.data(), static_cast<unsigned>(buf.size()));
-          if (n <= 0) {
+          if (n < 0 || (n == 0 && !gzeof(gz))) {  // Z_DATA_ERROR / Z_BUF_ERROR: a corrupt or truncated archive is not an end of file
+            int zerr = 0;
+            const char* zmsg = gzerror(gz, &zerr);
+            throw std::invalid_argument(std::string("[bioparser] error: corrupt or truncated file (zlib: ") +
+                                        (zmsg && *zmsg ? zmsg : "unexpected end") + ")");
+          }
+          if (n == 0) {
+            // gzread returns 0 with gzeof() set also when the stream ends inside a member: zlib flags that case in gzerror
+            int zerr = 0;
+            (void)gzerror(gz, &zerr);
+            if (zerr != Z_OK && zerr != Z_STREAM_END)
+              throw std::invalid_argument("[bioparser] error: corrupt or truncated file (zlib: unexpected end of file)");
             eof = true;
             have = pos = 0;
             return !out.empty();

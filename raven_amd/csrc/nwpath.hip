@@ -15,6 +15,7 @@
 // the result is always the exact optimal path, the estimate only decides how much band is computed.  hs + ck of a launch
 // are budgeted (RVN_NW_BUDGET_MB, default: a quarter of the free HBM, at most 64 GB); more jobs than fit go in chunks.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -142,6 +143,9 @@ __global__ __launch_bounds__(64) void nw_trace_kernel(const NwJob* __restrict__ 
                                                       NwWindowRec* __restrict__ recs, u64* __restrict__ scratch) {
   __shared__ u64 s_pv[STRIP_LDS ? kNwStripCols * 64 : 1];
   __shared__ u64 s_mv[STRIP_LDS ? kNwStripCols * 64 : 1];
+  // one lane per alignment, a long dependent chain per column: these waves run beside the next chunk's sweep (which keeps
+  // the VALUs full) and must not queue behind it for every instruction
+  __builtin_amdgcn_s_setprio(3);
   const u32 q = blockIdx.x * 64 + threadIdx.x;
   if (q >= n_idx) return;
   const u32 ji = idx[q];
@@ -160,7 +164,10 @@ void launch_sweep(Engine& e, const NwJob* d_jobs, const u32* d_idx, u32 n_idx, c
   hipStream_t s = e.stream;
   constexpr u32 NG = 64 / G;
   const u32 bundles = (n_idx + NG - 1) / NG;
-  const u32 waves = std::min<u32>(bundles, 256u * 4u * static_cast<u32>(sweep_waves_per_simd<R>()));
+  // persistent waves: not every slot of the machine — the walks of the previous chunk run beside this sweep on the other
+  // stream and need wave slots (and LDS) of their own; the sweep is VALU-bound long before its last two waves per SIMD
+  const u32 per_simd = static_cast<u32>(sweep_waves_per_simd<R>());
+  const u32 waves = std::min<u32>(bundles, 256u * 4u * (per_simd > 4 ? per_simd - 2 : per_simd));
   RVN_HIP(hipMemsetAsync(d_next, 0, 4, s));
   RVN_KLAUNCH(kKNwForward, (nw_sweep_kernel<R, G><<<(waves + 3) / 4, 256, 0, s>>>(
                                d_jobs, d_idx, n_idx, T.packed.as<u64>(), Rd.packed.as<u64>(), d_hs, d_ck, d_result,
@@ -200,11 +207,10 @@ void nw_breakpoints(Engine& e, const ReadsDev& T, const ReadsDev& Rd, std::vecto
   RVN_HIP(hipMemsetAsync(d_recs, 0xFF, n_recs * sizeof(NwWindowRec), s));
   if (nj == 0) return;
   RVN_HIP(hipEventRecord(e.ev0, s));
-  if (!e.stream2) {
-    RVN_HIP(hipStreamCreateWithFlags(&e.stream2, hipStreamNonBlocking));
+  if (!e.nw_streams[0]) {
+    for (hipStream_t& st2 : e.nw_streams) RVN_HIP(hipStreamCreateWithFlags(&st2, hipStreamNonBlocking));
     for (hipEvent_t& ev : e.nw_ev) RVN_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
   }
-  hipStream_t s2 = e.stream2;
   double rate = e.nw_rate > 0 ? e.nw_rate : 0.13;  // first call: ONT-like; too small only costs a repeat
   if (const char* ev = std::getenv("RVN_NW_RATE")) rate = std::atof(ev);  // tests: force repeats
 
@@ -236,7 +242,7 @@ void nw_breakpoints(Engine& e, const ReadsDev& T, const ReadsDev& Rd, std::vecto
   {
     size_t free_b = 0, total_b = 0;
     RVN_HIP(hipMemGetInfo(&free_b, &total_b));
-    const u64 held = e.nw_hs.cap + e.nw_ck.cap + e.nw_hs2.cap + e.nw_ck2.cap;
+    const u64 held = e.nw_hs.cap + e.nw_ck.cap + e.nw_hs2.cap + e.nw_ck2.cap + e.nw_hs3.cap + e.nw_ck3.cap;
     budget = std::min<u64>(static_cast<u64>(free_b) / 4 + held, 64ULL << 30);
     if (const char* ev = std::getenv("RVN_NW_BUDGET_MB")) budget = static_cast<u64>(std::atoll(ev)) << 20;
     budget = std::max<u64>(budget, 64ULL << 20);
@@ -254,6 +260,9 @@ void nw_breakpoints(Engine& e, const ReadsDev& T, const ReadsDev& Rd, std::vecto
   struct Obs {
     double len, d;
   };
+  using clk = std::chrono::steady_clock;
+  double h_plan = 0, h_order = 0, h_up = 0, h_res = 0;  // host milliseconds between the launches (RVN_NW_DEBUG)
+  auto since = [](clk::time_point t) { return std::chrono::duration<double, std::milli>(clk::now() - t).count(); };
   std::vector<Obs> obs;
   struct Chunk {
     size_t c0, c1;
@@ -264,12 +273,27 @@ void nw_breakpoints(Engine& e, const ReadsDev& T, const ReadsDev& Rd, std::vecto
   auto run = [&](std::vector<u32> todo, bool sweep_only) {
     while (!todo.empty()) {
       // longest jobs first: they go through the widest variants, and the pass ends with the walks of the shortest ones
-      order = todo;
-      std::stable_sort(order.begin(), order.end(), [&](u32 a, u32 b) {
-        const u32 la = level_of(jobs[a]), lb = level_of(jobs[b]);
-        if (la != lb) return la > lb;
-        return jobs[a].m > jobs[b].m;
-      });
+      auto t_h = clk::now();
+      {  // descending by (variant, columns), ties in job order: two counting passes (12 + 12 key bits) instead of a sort
+        const size_t nt = todo.size();
+        std::vector<u32> key(nt), tmp(nt), idx(nt);
+        for (size_t x = 0; x < nt; ++x) {
+          const NwJob& J = jobs[todo[x]];
+          const u32 mm = std::min<u32>(J.m >> 3, (1u << 21) - 1);  // 8-base resolution is plenty for the ordering
+          key[x] = 0xFFFFFFu - ((level_of(J) << 21) | mm);
+          idx[x] = static_cast<u32>(x);
+        }
+        for (int pass = 0; pass < 2; ++pass) {
+          u32 cnt[4097] = {};
+          const int sh = 12 * pass;
+          for (size_t x = 0; x < nt; ++x) cnt[((key[idx[x]] >> sh) & 4095u) + 1]++;
+          for (int c = 0; c < 4096; ++c) cnt[c + 1] += cnt[c];
+          for (size_t x = 0; x < nt; ++x) tmp[cnt[(key[idx[x]] >> sh) & 4095u]++] = idx[x];
+          idx.swap(tmp);
+        }
+        order.resize(nt);
+        for (size_t x = 0; x < nt; ++x) order[x] = todo[idx[x]];
+      }
       // chunks of the order whose hs + ck fit half the budget (a job larger than that goes alone)
       std::vector<Chunk> chunks;
       u64 max_hs = 0, max_ck = 0;
@@ -281,7 +305,10 @@ void nw_breakpoints(Engine& e, const ReadsDev& T, const ReadsDev& Rd, std::vecto
           NwJob& J = jobs[order[c1]];
           const NwGeo g = nw_geo(J.n, J.m, J.k, J.R);
           const u64 hw = g.hs_words(), ce = g.ck_entries();
-          if (c1 > c0 && (C.hs_w + hw) * 4 + (C.ck_e + ce) * 16 > budget / 2) break;
+          // three buffer sets; the first chunk (the longest alignments: its walk is latency-bound and must end while the
+          // other chunks are still being swept) takes a quarter of a share
+          const u64 share = chunks.empty() ? budget / 12 : budget / 3;
+          if (c1 > c0 && (C.hs_w + hw) * 4 + (C.ck_e + ce) * 16 > share) break;
           J.hs = C.hs_w;
           J.ckpt = C.ck_e;
           C.hs_w += hw;
@@ -305,9 +332,9 @@ void nw_breakpoints(Engine& e, const ReadsDev& T, const ReadsDev& Rd, std::vecto
         chunks.push_back(C);
         c0 = c1;
       }
-      DevBuf* hs_buf[2] = {&e.nw_hs, &e.nw_hs2};
-      DevBuf* ck_buf[2] = {&e.nw_ck, &e.nw_ck2};
-      const int n_sets = chunks.size() > 1 ? 2 : 1;
+      DevBuf* hs_buf[3] = {&e.nw_hs, &e.nw_hs2, &e.nw_hs3};
+      DevBuf* ck_buf[3] = {&e.nw_ck, &e.nw_ck2, &e.nw_ck3};
+      const int n_sets = static_cast<int>(std::min<size_t>(chunks.size(), 3));
       for (int b = 0; b < n_sets; ++b) {
         (void)hs_buf[b]->get<u32>(max_hs + 4 * 64 * 8 + 16);  // + slack: the walk reads up to two words past a job's last one
         (void)ck_buf[b]->get<NwPm>(max_ck + 16);
@@ -316,19 +343,22 @@ void nw_breakpoints(Engine& e, const ReadsDev& T, const ReadsDev& Rd, std::vecto
       if (!trace_lds) {
         size_t mc = 0;
         for (const Chunk& C : chunks) mc = std::max(mc, C.c1 - C.c0);
-        d_strip = e.nw_strip.get<u64>(static_cast<size_t>((mc + 63) / 64) * 2 * kNwStripCols * 64 * 2 + 16);
+        d_strip = e.nw_strip.get<u64>(static_cast<size_t>((mc + 63) / 64) * 2 * kNwStripCols * 64 * 3 + 64);
       }
+      h_order += since(t_h);
+      t_h = clk::now();
       RVN_HIP(hipMemcpyAsync(d_jobs, jobs.data(), static_cast<size_t>(nj) * sizeof(NwJob), hipMemcpyHostToDevice, s));
       RVN_HIP(hipMemcpyAsync(d_idx, order.data(), order.size() * 4, hipMemcpyHostToDevice, s));
       RVN_HIP(rvn_stream_sync(s));  // `jobs` / `order` are pageable: the copies must be done before the host goes on
+      h_up += since(t_h);
       for (size_t ci = 0; ci < chunks.size(); ++ci) {
         const Chunk& C = chunks[ci];
-        const int b = static_cast<int>(ci & 1);
+        const int b = static_cast<int>(ci % 3);
         u32* hs = hs_buf[b]->as<u32>();
         NwPm* ck = ck_buf[b]->as<NwPm>();
         const u32* idx_c = d_idx + C.c0;
         const u32 cn = static_cast<u32>(C.c1 - C.c0);
-        if (ci >= 2) RVN_HIP(hipStreamWaitEvent(s, e.nw_ev[b], 0));  // the walk of chunk ci - 2 is done with this buffer set
+        if (ci >= 3) RVN_HIP(hipStreamWaitEvent(s, e.nw_ev[b], 0));  // the walk of chunk ci - 3 is done with this buffer set
         auto count_of = [&](u32 x) -> u32 {  // classes are laid out from the widest variant down
           const u32 next_off = x == 0 ? cn : C.coff[x - 1];
           return next_off - C.coff[x];
@@ -354,10 +384,12 @@ void nw_breakpoints(Engine& e, const ReadsDev& T, const ReadsDev& Rd, std::vecto
           ++st.n_batches;
           continue;
         }
-        hipStream_t ts = one_stream ? s : s2;
+        // one walk stream per buffer set: the walk of the longest alignments (chunk 0: few waves, tens of milliseconds of
+        // latency) must not hold back the walks of the chunks behind it
+        hipStream_t ts = one_stream ? s : e.nw_streams[b];
         if (!one_stream) {
-          RVN_HIP(hipEventRecord(e.nw_ev[2], s));
-          RVN_HIP(hipStreamWaitEvent(s2, e.nw_ev[2], 0));
+          RVN_HIP(hipEventRecord(e.nw_ev[3], s));
+          RVN_HIP(hipStreamWaitEvent(ts, e.nw_ev[3], 0));
         }
         if (trace_lds) {
           RVN_KLAUNCH_ON(kKNwTraceback, ts, (nw_trace_kernel<true><<<(cn + 63) / 64, 64, 0, ts>>>(
@@ -367,9 +399,9 @@ void nw_breakpoints(Engine& e, const ReadsDev& T, const ReadsDev& Rd, std::vecto
           RVN_KLAUNCH_ON(kKNwTraceback, ts, (nw_trace_kernel<false><<<(cn + 63) / 64, 64, 0, ts>>>(
                                                 d_jobs, idx_c, cn, T.packed.as<u64>(), Rd.packed.as<u64>(), hs, ck, d_res,
                                                 d_status, w, d_recs,
-                                                d_strip + static_cast<size_t>(b) * ((e.nw_strip.cap / 16) & ~size_t(63)))));
+                                                d_strip + static_cast<size_t>(b) * ((e.nw_strip.cap / 24) & ~size_t(63)))));
         }
-        if (!one_stream) RVN_HIP(hipEventRecord(e.nw_ev[b], s2));
+        if (!one_stream) RVN_HIP(hipEventRecord(e.nw_ev[b], ts));
         if (dbg_sync) {
           RVN_HIP(hipStreamSynchronize(ts));
           std::fprintf(stderr, "[raven_hip] nw: trace done, %u jobs\n", cn);
@@ -377,12 +409,12 @@ void nw_breakpoints(Engine& e, const ReadsDev& T, const ReadsDev& Rd, std::vecto
         ++st.n_batches;
       }
       if (!one_stream && !sweep_only) {  // everything of this pass done before the results are read
-        RVN_HIP(hipEventRecord(e.nw_ev[2], s2));
-        RVN_HIP(hipStreamWaitEvent(s, e.nw_ev[2], 0));
+        for (int b = 0; b < n_sets; ++b) RVN_HIP(hipStreamWaitEvent(s, e.nw_ev[b], 0));
       }
       RVN_HIP(hipMemcpyAsync(h_result.data(), d_res, static_cast<size_t>(nj) * 4, hipMemcpyDeviceToHost, s));
       RVN_HIP(hipMemcpyAsync(h_status.data(), d_status, static_cast<size_t>(nj) * 4, hipMemcpyDeviceToHost, s));
       RVN_HIP(rvn_stream_sync(s));
+      t_h = clk::now();
       std::vector<u32> again;
       for (u32 i : todo) {
         NwJob& J = jobs[i];
@@ -402,6 +434,7 @@ void nw_breakpoints(Engine& e, const ReadsDev& T, const ReadsDev& Rd, std::vecto
         }
       }
       todo.swap(again);
+      h_res += since(t_h);
     }
   };
 
@@ -473,6 +506,7 @@ void nw_breakpoints(Engine& e, const ReadsDev& T, const ReadsDev& Rd, std::vecto
     rest = valid;
   }
   {
+    auto t_h = clk::now();
     std::vector<u32> ok;
     for (u32 i : rest) {
       NwJob& J = jobs[i];
@@ -482,6 +516,7 @@ void nw_breakpoints(Engine& e, const ReadsDev& T, const ReadsDev& Rd, std::vecto
       if (plan(J, k)) ok.push_back(i);
       else ++st.n_unaligned;
     }
+    h_plan += since(t_h);
     run(ok, false);
   }
   if (rates.size() >= 32) {  // rate estimate for the next call (the pilot's first threshold / small batches)
@@ -493,6 +528,9 @@ void nw_breakpoints(Engine& e, const ReadsDev& T, const ReadsDev& Rd, std::vecto
   float ms = 0;
   RVN_HIP(hipEventElapsedTime(&ms, e.ev0, e.ev1));
   st.ms = ms;
+  if (std::getenv("RVN_NW_DEBUG"))
+    std::fprintf(stderr, "[raven_hip] nw host: plan %.1f ms, order + chunks %.1f ms, uploads %.1f ms, results %.1f ms\n", h_plan, h_order, h_up,
+                 h_res);
   if (std::getenv("RVN_NW_DEBUG"))
     std::fprintf(stderr, "[raven_hip] nw: %u jobs, %llu aligned, %llu retries, %llu chunks, %.3e band cells, %.1f MB hs + ck, %.1f ms; pilot mu %.4f a %.4f b %.3e\n", nj,
                  static_cast<unsigned long long>(st.n_aligned), static_cast<unsigned long long>(st.n_retries),

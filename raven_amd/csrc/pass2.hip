@@ -287,7 +287,10 @@ void second_pass(Engine& e, const ReadsDev& R, const u32* h_begin, const u32* h_
   out.kmers_total = out.h_kmers_off[n];
   u8* d_kmers = out.kmers.get<u8>(out.kmers_total + 16);
   RVN_HIP(hipMemsetAsync(d_kmers, 0, out.kmers_total + 16, s));
-  const u32 sv = static_cast<u32>(valid.size());
+  // construct.cc:343-349: `s` is the position of the FIRST INVALID pile after the valid-first sort and stays 0 when no
+  // pile is invalid at all — the reference then maps nothing and overlaps.back() stays empty.  Reproduced on purpose
+  // (results identical to the reference's on the same input); real read sets always have contained, hence invalid, piles.
+  const u32 sv = valid.size() == n ? 0u : static_cast<u32>(valid.size());
   if (sv == 0) {
     RVN_HIP(rvn_stream_sync(s));
     return;

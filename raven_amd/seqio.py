@@ -1,13 +1,13 @@
-"""Host-side sequence plumbing: FASTA/FASTQ(.gz) parsing and biosoup-style 2-bit packing.
+"""Host-side sequence plumbing of the ctypes binding: biosoup-style 2-bit packing of in-memory sequences.
 
-Mirrors what the reference gets from bioparser + biosoup::NucleicAcid (io.cc:7-41,
-SURVEY §8 a6): 32 bases per uint64, base i at bits (2i mod 64) LSB-first,
+Files are read by the library itself (rvn_reads_load, raven_amd/csrc/io.hip); the independent Python FASTA / FASTQ
+parser the tests check it against lives in oracle/seqio_oracle.py (test infrastructure).
+Mirrors biosoup::NucleicAcid: 32 bases per uint64, base i at bits (2i mod 64) LSB-first,
 A=0 C=1 G=2 T=3, IUPAC folded to 0..3, anything else -> ValueError
 (biosoup throws std::invalid_argument).  Every read starts on a word boundary.
 """
 from __future__ import annotations
 
-import gzip
 from dataclasses import dataclass
 
 import numpy as np
@@ -83,61 +83,3 @@ def pack_reads(code_arrays, ids=None, names=None, qualities=None) -> ReadSet:
     if ids is None:
         ids = np.arange(len(code_arrays), dtype=np.uint32)
     return ReadSet(packed, word_offsets, lengths, np.asarray(ids, dtype=np.uint32), names, qualities)
-
-
-def _open(path):
-    return gzip.open(path, "rb") if str(path).endswith(".gz") else open(path, "rb")
-
-
-def parse_fastq(path, limit: int | None = None):
-    names, seqs, quals = [], [], []
-    with _open(path) as f:
-        while True:
-            h = f.readline()
-            if not h:
-                break
-            s = f.readline().rstrip(b"\r\n")
-            f.readline()
-            q = f.readline().rstrip(b"\r\n")
-            names.append(h[1:].split()[0].decode())
-            seqs.append(s)
-            quals.append(np.frombuffer(q, dtype=np.uint8) - 33)
-            if limit is not None and len(seqs) >= limit:
-                break
-    return names, seqs, quals
-
-
-def parse_fasta(path, limit: int | None = None):
-    names, seqs = [], []
-    cur = []
-    with _open(path) as f:
-        for line in f:
-            if line.startswith(b">"):
-                if cur or names:
-                    seqs.append(b"".join(cur))
-                    cur = []
-                    if limit is not None and len(seqs) >= limit:
-                        names = names[:limit]
-                        return names, seqs
-                names.append(line[1:].split()[0].decode())
-            else:
-                cur.append(line.strip())
-    if names:
-        seqs.append(b"".join(cur))
-    return names, seqs
-
-
-def load_reads(path, limit: int | None = None) -> ReadSet:
-    """Extension sniffing as in io.cc:7-41."""
-    p = str(path)
-    base = p[:-3] if p.endswith(".gz") else p
-    if base.endswith((".fastq", ".fq")):
-        names, seqs, quals = parse_fastq(p, limit)
-    elif base.endswith((".fasta", ".fa")):
-        names, seqs = parse_fasta(p, limit)
-        quals = None
-    else:
-        raise ValueError(
-            "[raven_amd::seqio] error: file %s has unsupported format extension "
-            "(valid extensions: .fasta, .fasta.gz, .fa, .fa.gz, .fastq, .fastq.gz, .fq, .fq.gz)" % p)
-    return pack_reads([encode(s) for s in seqs], names=names, qualities=quals)

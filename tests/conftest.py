@@ -9,6 +9,8 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+from oracle import seqio_oracle  # noqa: E402  (the independent FASTA / FASTQ parser: test infrastructure)
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
@@ -35,13 +37,13 @@ def pytest_sessionstart(session):
 @pytest.fixture(scope="session")
 def lambda_reads():
     from raven_amd import seqio
-    return seqio.load_reads(os.path.join(GOLDEN, "ERA476754.fastq.gz"))
+    return seqio_oracle.load_reads(os.path.join(GOLDEN, "ERA476754.fastq.gz"))
 
 
 @pytest.fixture(scope="session")
 def lambda_genome():
     from raven_amd import seqio
-    return seqio.load_reads(os.path.join(GOLDEN, "NC_001416.fasta.gz"))
+    return seqio_oracle.load_reads(os.path.join(GOLDEN, "NC_001416.fasta.gz"))
 
 
 @pytest.fixture(scope="session")

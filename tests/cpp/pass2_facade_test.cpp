@@ -41,7 +41,9 @@ int main(int argc, char** argv) {
     std::vector<std::unique_ptr<TestPile>> piles;
     std::vector<std::vector<biosoup::Overlap>> overlaps(sequences.size());
     raven::FindOverlapsAndCreatePiles<TestPile>(nullptr, minimizer_engine, sequences, 0.001, piles, overlaps, 32, false);
-    // TrimAndAnnotatePiles would set begin_/end_/invalid here (construct.cc:123-152); the stand-in keeps whole piles valid
+    // TrimAndAnnotatePiles would set begin_/end_/invalid here (construct.cc:123-152); the stand-in keeps whole piles and
+    // invalidates the last one: with NO invalid pile the reference maps nothing at all (its `s`, construct.cc:343-349)
+    if (!piles.empty()) piles.back()->invalid = true;
     raven::FindOverlapsAndRepetetiveRegions<TestPile>(nullptr, minimizer_engine, 0.001, 28, identity, piles, overlaps, sequences);
     std::printf("lists %zu\n", overlaps.size());
     for (const auto& o : overlaps.back())

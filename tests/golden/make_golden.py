@@ -16,10 +16,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 
 from oracle import oracle  # noqa: E402
 from raven_amd import seqio  # noqa: E402
+from oracle import seqio_oracle
 
 
 def main():
-    rs = seqio.load_reads(os.path.join(HERE, "ERA476754.fastq.gz"))
+    rs = seqio_oracle.load_reads(os.path.join(HERE, "ERA476754.fastq.gz"))
     out = {"n_reads": np.array([rs.n]), "total_bases": np.array([rs.total_bases])}
     e = oracle.Engine(15, 5)
     for i in range(4):

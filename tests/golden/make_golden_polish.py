@@ -19,6 +19,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 
 from oracle import oracle  # noqa: E402
 from raven_amd import seqio, synth  # noqa: E402
+from oracle import seqio_oracle
 
 
 def block_qualities(rs):
@@ -34,8 +35,8 @@ def block_qualities(rs):
 
 
 def inputs():
-    rs = seqio.load_reads(os.path.join(HERE, "ERA476754.fastq.gz"))
-    ref = seqio.load_reads(os.path.join(HERE, "NC_001416.fasta.gz"))
+    rs = seqio_oracle.load_reads(os.path.join(HERE, "ERA476754.fastq.gz"))
+    ref = seqio_oracle.load_reads(os.path.join(HERE, "NC_001416.fasta.gz"))
     truth = ref.codes(0)
     draft = synth.make_draft(truth, seed=20260926)
     quals, avg_q = block_qualities(rs)

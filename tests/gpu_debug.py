@@ -13,6 +13,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 from oracle import oracle  # noqa: E402
 from raven_amd import hip, seqio, synth  # noqa: E402
+from oracle import seqio_oracle
 from tests import parity_util as pu  # noqa: E402
 
 
@@ -73,7 +74,7 @@ def main():
     print("devices:", hip.device_count(), flush=True)
     here = os.path.dirname(os.path.abspath(__file__))
     ok = True
-    lam = seqio.load_reads(os.path.join(here, "golden", "ERA476754.fastq.gz"))
+    lam = seqio_oracle.load_reads(os.path.join(here, "golden", "ERA476754.fastq.gz"))
     ok &= run_set("lambda", lam)
     g = synth.make_genome(200_000, seed=11)
     rs, _ = synth.make_reads(g, 20, 8000, seed=12)

@@ -163,7 +163,9 @@ def test_second_pass_facade_matches_c_abi(tmp_path):
     eng.find_overlaps_and_create_piles(rd).close()  # the facade ran the first pass before (same engine state order)
     begin = np.zeros(rs.n, dtype=np.uint32)
     end = (rs.lengths.astype(np.uint32) >> 4) << 4
-    res = eng.find_overlaps_and_repetitive_regions(rd, begin, end, np.zeros(rs.n, np.uint8), kmer_len=28)
+    invalid = np.zeros(rs.n, np.uint8)
+    invalid[-1] = 1  # as the program does: without any invalid pile the reference's loop maps nothing
+    res = eng.find_overlaps_and_repetitive_regions(rd, begin, end, invalid, kmer_len=28)
     assert lines[0] == "lists %d" % (rs.n + 1)
     want = ["O %d %d %d %d %d %d %d %d" % (o["lhs_id"], o["lhs_begin"], o["lhs_end"], o["rhs_id"], o["rhs_begin"],
                                             o["rhs_end"], o["score"], 1 if o["strand"] else 0) for o in res["overlaps"]]
@@ -174,4 +176,4 @@ def test_second_pass_facade_matches_c_abi(tmp_path):
         for v in res["kmers"][i].tolist():
             h = (h * 1000003 + v) & 0xFFFFFFFFFFFFFFFF
         c = int(res["contained"][i])
-        assert "P %d %d %d %d %d" % (i, c, c, res["kmers"][i].shape[0], h) in lines
+        assert "P %d %d %d %d %d" % (i, c, 1 if (c or invalid[i]) else 0, res["kmers"][i].shape[0], h) in lines

@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 
 from raven_amd import hip, seqio, synth
+from oracle import seqio_oracle
 
 pytestmark = pytest.mark.gpu
 
@@ -23,7 +24,7 @@ def _same_reads(rd, rs):
 
 def test_lambda_fastq_gz_matches_python_loader():
     path = os.path.join(GOLDEN, "ERA476754.fastq.gz")
-    rs = seqio.load_reads(path)
+    rs = seqio_oracle.load_reads(path)
     eng = hip.Engine(15, 5)
     rd = eng.load(path)
     assert rd.n == rs.n == 236 and rd.rs.names == rs.names and rd.load_stats["has_quality"] == 1
@@ -43,7 +44,7 @@ def test_lambda_fastq_gz_matches_python_loader():
 
 def test_lambda_fasta_gz_multi_line_records():
     path = os.path.join(GOLDEN, "NC_001416.fasta.gz")
-    rs = seqio.load_reads(path)
+    rs = seqio_oracle.load_reads(path)
     eng = hip.Engine(15, 5)
     rd = eng.load(path)
     assert rd.n == 1 and rd.rs.names == rs.names and rd.load_stats["has_quality"] == 0
@@ -94,3 +95,30 @@ def test_errors_are_the_references(tmp_path):
     nofa.write_bytes(b"ACGT\n")
     with pytest.raises(ValueError, match="invalid file format"):
         eng.load(str(nofa))
+
+
+def test_truncated_or_corrupt_gz_is_an_error_not_a_shorter_read_set(tmp_path):
+    """zlib reports a cut or damaged archive through gzread's return value / gzerror: that must surface as the parser's
+    error, never as a clean end of file (a truncated .gz used to load as a shorter read set)."""
+    import gzip
+    eng = hip.Engine(15, 5)
+    rng = np.random.default_rng(5)
+    recs = []
+    for i in range(400):
+        seq = "".join("ACGT"[x] for x in rng.integers(0, 4, 700))
+        recs.append("@r%d\n%s\n+\n%s\n" % (i, seq, "I" * 700))
+    blob = gzip.compress("".join(recs).encode())
+    whole = tmp_path / "whole.fastq.gz"
+    whole.write_bytes(blob)
+    assert eng.load(str(whole)).n == 400
+    cut = tmp_path / "cut.fastq.gz"
+    cut.write_bytes(blob[:len(blob) // 2])
+    with pytest.raises(ValueError, match="corrupt or truncated"):
+        eng.load(str(cut))
+    bad = bytearray(blob)
+    for k in range(len(bad) // 2, len(bad) // 2 + 64):
+        bad[k] ^= 0x5A
+    dmg = tmp_path / "damaged.fasta.gz"
+    dmg.write_bytes(bytes(bad))
+    with pytest.raises(ValueError, match="corrupt or truncated|invalid file format|not a nucleotide"):
+        eng.load(str(dmg))

@@ -69,10 +69,18 @@ def test_second_pass_degenerate_inputs():
     # every pile invalid: nothing to do
     got = eng.find_overlaps_and_repetitive_regions(rd, full_b, full_e, np.ones(rs.n, np.uint8))
     assert got["overlaps"].shape[0] == 0 and got["contained"].sum() == 0 and all(len(k) == 0 for k in got["kmers"])
-    # untrimmed piles, everything valid
+    # untrimmed piles, everything valid: the reference's `s` (construct.cc:343-349, position of the first invalid pile)
+    # stays 0, so it maps NOTHING — reproduced, not "fixed"
     inv = np.zeros(rs.n, np.uint8)
     got = eng.find_overlaps_and_repetitive_regions(rd, full_b, full_e, inv)
     want = oracle.second_pass(15, 5, rs, full_b, full_e, inv)
+    assert want["overlaps"].shape[0] == 0
+    _compare(got, want, rs)
+    # one invalid pile is enough for the pass to run over all the valid ones
+    inv[rs.n // 2] = 1
+    got = eng.find_overlaps_and_repetitive_regions(rd, full_b, full_e, inv)
+    want = oracle.second_pass(15, 5, rs, full_b, full_e, inv)
+    assert want["overlaps"].shape[0] > 0
     _compare(got, want, rs)
 
 

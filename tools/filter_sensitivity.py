@@ -16,6 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from oracle import oracle  # noqa: E402
 from raven_amd import seqio  # noqa: E402
+from oracle import seqio_oracle
 
 
 def map_all(eng, rs, minhash):
@@ -29,7 +30,7 @@ def map_all(eng, rs, minhash):
 def main():
     path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "tests", "golden", "ERA476754.fastq.gz")
     freq = float(sys.argv[2]) if len(sys.argv) > 2 else 0.001
-    rs = seqio.load_reads(path)
+    rs = seqio_oracle.load_reads(path)
     report = {"reads": rs.n, "bases": int(rs.total_bases), "freq": freq}
     for minhash in (False, True):
         eng = oracle.Engine(15, 5)

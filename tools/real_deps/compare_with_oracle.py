@@ -11,6 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 from oracle import oracle  # noqa: E402
 from raven_amd import seqio  # noqa: E402
+from oracle import seqio_oracle
 
 READS = os.path.join(ROOT, "tests", "golden", "ERA476754.fastq.gz")
 GENOME = os.path.join(ROOT, "tests", "golden", "NC_001416.fasta.gz")
@@ -22,7 +23,7 @@ def run(harness, *args):
 
 def main():
     harness = sys.argv[1]
-    rs = seqio.load_reads(READS)
+    rs = seqio_oracle.load_reads(READS)
     bad = 0
     for minhash in (0, 1):
         real = np.array([[int(x) for x in ln.split()] for ln in run(harness, "map", READS, 15, 5, 0.001, minhash)], dtype=np.int64)
@@ -42,7 +43,7 @@ def main():
     print("edlib distances:", "IDENTICAL" if d_real == d_mine else "DIFFERENT")
     bad += d_real != d_mine
     cons_real = run(harness, "polish", READS, GENOME)
-    targets = seqio.load_reads(GENOME)
+    targets = seqio_oracle.load_reads(GENOME)
     cons_mine, _ = oracle.polish_round(targets, rs)[:2]
     ok = len(cons_real) == len(cons_mine) and all(a == "".join("ACGT"[c] for c in b) for a, b in zip(cons_real, cons_mine))
     print("racon round on lambda:", "IDENTICAL" if ok else "DIFFERENT")

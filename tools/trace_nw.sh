@@ -1,0 +1,21 @@
+#!/bin/bash
+# kernel timeline of the alignment stage (start / end per dispatch, both streams) -> gpurun_out/<tag>_nw_timeline.csv
+R=${GRAFT_REPO_ROOT:-/root/repo}
+TAG=${1:-r03}
+cd /tmp && export TMPDIR=/tmp
+export RVN_POLISH_SKIP_POA=1
+rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/${TAG}_nw_tl -o t -- python $R/bench.py --no-cpu-baseline --no-kernel-timing --steps 1 --warmup 0 > /dev/null 2> $R/gpurun_out/${TAG}_nw_tl.err
+F=$(find $R/gpurun_out/${TAG}_nw_tl -name '*kernel_trace.csv' | head -1)
+python - "$F" $R/gpurun_out/${TAG}_nw_timeline.csv <<'PY'
+import csv, sys
+rows = [r for r in csv.DictReader(open(sys.argv[1])) if "nw_" in r["Kernel_Name"]]
+t0 = min(int(r["Start_Timestamp"]) for r in rows)
+with open(sys.argv[2], "w") as f:
+    f.write("kernel,queue,start_ms,end_ms,dur_ms,grid\n")
+    for r in sorted(rows, key=lambda r: int(r["Start_Timestamp"])):
+        n = r["Kernel_Name"].split("rvn::")[-1].split("(")[0][:40]
+        s, e = int(r["Start_Timestamp"]) - t0, int(r["End_Timestamp"]) - t0
+        f.write("%s,%s,%.2f,%.2f,%.2f,%s\n" % (n, r.get("Queue_Id", ""), s / 1e6, e / 1e6, (e - s) / 1e6, r.get("Grid_Size", r.get("Grid_Size_X", ""))))
+PY
+rm -rf $R/gpurun_out/${TAG}_nw_tl
+cat $R/gpurun_out/${TAG}_nw_timeline.csv | head -60
