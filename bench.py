@@ -45,20 +45,55 @@ POA_MIN_OPS_PER_CELL = 6.0
 NW_MIN_OPS_PER_CELL = 50.0 / 64.0  # Myers block update + match mask: ~25 64-bit operations per 64 cells
 
 
+def kernel_source_hash():
+    """sha1 over the kernels' sources (raven_amd/csrc/*.hip, *.h, sorted): what a traffic profile is valid for."""
+    import glob
+    import hashlib
+    h = hashlib.sha1()
+    d = os.path.join(ROOT, "raven_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.h"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
+_TRAFFIC = None
+
+
+def pmc_traffic_file():
+    """This round's rocprofv3 --pmc result (profiles/r03_pmc_traffic.json, made by tools/pmc_traffic.py from separate
+    FETCH_SIZE / WRITE_SIZE passes of this same bench command; tools/profile_round.sh stamps it with the hash of the
+    kernel sources it was taken on)."""
+    global _TRAFFIC
+    if _TRAFFIC is None:
+        _TRAFFIC = {}
+        for name in ("r03_pmc_traffic.json",):
+            try:
+                with open(os.path.join(ROOT, "profiles", name)) as f:
+                    _TRAFFIC = json.load(f)
+                _TRAFFIC["file"] = "profiles/" + name
+                break
+            except (OSError, ValueError):
+                pass
+    return _TRAFFIC
+
+
 def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from this round's rocprofv3 --pmc passes (profiles/r02_pmc_traffic.json, made
-    by tools/pmc_traffic.py from separate FETCH_SIZE / WRITE_SIZE runs of this same bench command): 2 x FETCH_SIZE KiB
-    (gfx950: FETCH_SIZE counts 128-B requests as 64 B, MI355X_MICROARCH.md §HBM) + WRITE_SIZE KiB."""
-    for name in ("r02_pmc_traffic.json",):  # per round: the file of the round whose kernels these are
-        try:
-            with open(os.path.join(ROOT, "profiles", name)) as f:
-                t = json.load(f)
-            e = t["kernels"].get(kernel)
-            if e:
-                return int(e["hbm_bytes_per_launch"])
-        except (OSError, ValueError, KeyError):
-            pass
-    return None
+    """HBM bytes per launch of `kernel`: 2 x FETCH_SIZE KiB (gfx950: FETCH_SIZE counts 128-B requests as 64 B,
+    MI355X_MICROARCH.md, HBM) + WRITE_SIZE KiB; None when this round has no profile of it."""
+    e = pmc_traffic_file().get("kernels", {}).get(kernel)
+    return int(e["hbm_bytes_per_launch"]) if e else None
+
+
+def traffic_provenance():
+    t = pmc_traffic_file()
+    if not t.get("kernels"):
+        return None
+    sha = t.get("kernel_source_sha1")
+    return {"file": t.get("file"), "kernel_source_sha1": sha,
+            "stale": (sha != kernel_source_hash()) if sha else True,
+            "note": "measured by tools/profile_round.sh (separate --pmc FETCH_SIZE / WRITE_SIZE passes of this command); "
+                    "stale = the kernel sources changed since"}
 
 
 def algorithmic_bytes(site, c, val_bytes):
@@ -162,6 +197,8 @@ def main():
     ap.add_argument("--polish-rounds", type=int, default=2)
     ap.add_argument("--cpu-sample-genome", type=int, default=2_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--load-bases", type=int, default=150_000_000,
+                    help="bases of the gz FASTQ the input path (rvn_reads_load) is timed on, outside the timed region (0 = skip)")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--replicas", action="store_true", help="N > 1: independent shard per GPU (weak scaling, no "
                     "collective) instead of one genome sharded across the ranks")
@@ -304,10 +341,49 @@ def main():
         boundary = {"upload_s": round(tb1 - tb0, 4), "pass_s": round(tb2 - tb1, 4), "fetch_s": round(tb3 - tb2, 4),
                     "fetched_bytes": int(pd.nbytes + po.nbytes),
                     "overlap_gbase_per_s": round(rs.total_bases / (tb3 - tb0) / 1e9, 3)}
+        # the annotation the reference runs right after the pass (TrimAndAnnotatePiles, construct.cc:123-152), on the
+        # coverage still in HBM: FindValidRegion(4) + FindMedian, then FindChimericRegions of the valid piles
+        tb4 = time.perf_counter()
+        _, _, _, inv = p2.trim_and_annotate(4)
+        tb5 = time.perf_counter()
+        p2.find_chimeric_regions(inv)
+        tb6 = time.perf_counter()
+        boundary["trim_and_median_s"] = round(tb5 - tb4, 4)
+        boundary["find_chimeric_regions_s"] = round(tb6 - tb5, 4)
         p2.close()
         del pd, po
         if r2 is not reads:
             r2.close()
+    # input path (rvn_reads_load: gz FASTQ -> host parser thread -> pinned staging -> packing on the device), on a
+    # gzip'ed FASTQ of the first reads of this workload; bounded so that the default run stays within minutes
+    load_stats = None
+    if rank == 0 and not sharded_mode and args.load_bases > 0:
+        import gzip
+        import tempfile
+        tl0 = time.perf_counter()
+        n_take, acc = 0, 0
+        while n_take < rs.n and acc < args.load_bases:
+            acc += int(rs.lengths[n_take])
+            n_take += 1
+        tmpd = tempfile.mkdtemp(prefix="rvn_load_")
+        path = os.path.join(tmpd, "reads.fastq.gz")
+        with gzip.open(path, "wb", compresslevel=1) as f:
+            for i in range(n_take):
+                sq = rs.inflate(i)
+                f.write(b"@r%d\n" % i + sq + b"\n+\n" + b"+" * len(sq) + b"\n")
+        t_write = time.perf_counter() - tl0
+        tl1 = time.perf_counter()
+        lr = eng.load(path)
+        t_load = time.perf_counter() - tl1
+        st = lr.load_stats
+        load_stats = {"bases": int(st["n_bases"]), "reads": int(st["n_sequences"]), "gz_bytes": os.path.getsize(path),
+                      "load_s": round(t_load, 3), "parse_thread_s": round(st["parse_s"], 3), "device_s": round(st["device_s"], 3),
+                      "load_gbase_per_s": round(st["n_bases"] / t_load / 1e9, 4), "file_written_in_s": round(t_write, 1),
+                      "note": "zlib inflate + FASTQ parsing run on ONE host thread (bioparser's role); the device side is "
+                              "device_s of load_s"}
+        lr.close()
+        os.remove(path)
+        os.rmdir(tmpd)
 
     if rank == 0 and shard_laps:
         print("[bench] sharded pass laps (s, summed over the timed steps):", {k: round(v, 4) for k, v in shard_laps.items()},
@@ -348,23 +424,27 @@ def main():
             if dom == "poa_banded":
                 roofline = roofline_poa
             if "nw_forward" in kms and kms["nw_forward"][1] and last.get("polish", {}).get("align_band_cells"):
-                # the alignment-path kernel (Myers bit-vector band, racon's edlib NW): integer VALU bound as well
+                # the alignment-path sweep (Myers bit-vector band, racon's edlib NW): integer VALU bound as well.  A round
+                # launches it once per kernel variant and chunk (different sizes): cells of the round / summed launch time
                 ms, la = kms["nw_forward"]
-                launches_per_round = la / max(args.steps * args.polish_rounds, 1)
-                cells_per_launch = last["polish"]["align_band_cells"] / max(launches_per_round, 1e-9)
-                avg_s = ms / la / 1e3
-                achieved_tops = cells_per_launch * NW_MIN_OPS_PER_CELL / avg_s / 1e12
+                rounds_timed = max(args.steps * args.polish_rounds, 1)
+                cells_per_round = last["polish"]["align_band_cells"]
+                s_per_round = ms / rounds_timed / 1e3
+                achieved_tops = cells_per_round * NW_MIN_OPS_PER_CELL / s_per_round / 1e12
                 roofline_nw = {"bound": "valu", "kernel": "nw_forward", "achieved": round(achieved_tops, 3),
                             "peak": round(VALU_PEAK_LANE_OPS / 1e12, 1), "unit": "T lane-ops/s",
                             "frac": round(achieved_tops * 1e12 / VALU_PEAK_LANE_OPS, 4), "traffic": pmc_traffic("nw_forward"),
-                            "algorithmic_cells_per_launch": int(cells_per_launch),
+                            "algorithmic_cells_per_round": int(cells_per_round),
+                            "launches_per_round": la / rounds_timed, "ms_per_round": round(s_per_round * 1e3, 3),
                             "algorithmic_ops_per_cell": round(NW_MIN_OPS_PER_CELL, 3),
-                            "gcups_band": round(cells_per_launch / avg_s / 1e9, 1), "avg_launch_ms": round(avg_s * 1e3, 3),
+                            "gcups_band": round(cells_per_round / s_per_round / 1e9, 1),
+                            "traceback_ms_per_round": round(kms.get("nw_traceback", (0.0, 0))[0] / rounds_timed, 3),
                             "kernel_ms_share": round(ms / tot, 3) if tot else None,
-                            "note": "algorithmic cells = cells of the Ukkonen band edlib needs for each alignment at the "
-                                    "threshold that succeeds (one sweep); the kernel sweeps them twice (checkpoints, then "
-                                    "per-segment re-sweep for the traceback).  50 32-bit lane operations per 64-cell block "
-                                    "step of Myers' recurrence incl. the match mask."}
+                            "note": "algorithmic cells = cells of the Ukkonen band of every sweep the round ran (one per "
+                                    "alignment; the few repeats with a doubled threshold and the 1024-job pilot "
+                                    "included), each swept ONCE; achieved = cells x 50/64 lane-ops / summed launch time "
+                                    "of the sweep kernels (HIP events on their stream).  The walk (nw_traceback) runs "
+                                    "on other streams beside the sweeps; its launch times overlap them."}
             if dom == "nw_forward":
                 roofline = roofline_nw
             # the dominant HBM-bound kernel (second entry)
@@ -391,7 +471,9 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(dt / steps * 1e3, 3),
             "higher_is_better": True,
-            "scaling": "strong" if sharded_mode else "weak",
+            # N > 1 shards ONE genome over the ranks (total work fixed): the N = 1 line is the first point of that curve;
+            # --replicas (independent shard per GPU) is the weak-scaling variant
+            "scaling": "weak" if (world > 1 and args.replicas) else "strong",
             "vs_baseline": None,
             "dtype": "u32" if val_bytes == 4 else "u64",
             "data": "synthetic",
@@ -418,13 +500,14 @@ def main():
             "counters_per_step": counters,
             "last_polish_round": {k: (round(v, 3) if isinstance(v, float) else v) for k, v in last.get("polish", {}).items()},
             "roofline": roofline,
+            "roofline_traffic_source": traffic_provenance(),
             "roofline_hbm": roofline_hbm,
             "roofline_poa": roofline_poa if roofline is not roofline_poa else None,
             "roofline_nw": roofline_nw if roofline is not roofline_nw else None,
             "kernels": dict(list(kernels.items())[:16]),
             "host": {"gen_s": round(t_gen, 2), "h2d_s": round(t_h2d, 3),
                      "h2d_inclusive_gbase_s": round(rs.total_bases / (dt / steps + t_h2d) / 1e9, 4),
-                     "overlap_pass_through_boundary": boundary},
+                     "overlap_pass_through_boundary": boundary, "input_path": load_stats},
             "cpu_baseline": None,
         }
         if sharded_mode:

@@ -355,6 +355,35 @@ int rvn_polish_round_range(rvn_engine* e, rvn_reads* targets, rvn_reads* reads, 
                            const uint64_t* out_offsets, uint32_t* out_len, double* ratio, uint32_t* n_windows,
                            uint32_t* n_polished, rvn_polish_stats* stats);
 
+/* ---- N GPUs behind ONE host process (the engine with a device list; 8(e): reads by pile, minimizers by hash
+ * class, three exchanges per flush window) --------------------------------------------------------------------------------
+ * raven::ConstructGraph / raven::Polish own one ram::MinimizerEngine / one racon::Polisher (RavenLib/src/construct.cc:661-669,
+ * polish.cc:43-51), so "all visible GPUs" lives behind one handle: a group = one engine + one worker thread per listed
+ * device (a device may be listed more than once: virtual ranks).  The stages are the rvn_shard_* entry points above; the
+ * exchanges are pairwise hipMemcpyPeerAsync pulls between the engines' buffers (xGMI between devices) bracketed by
+ * in-process barriers — the all-to-all a torch.distributed job performs with RCCL (raven_amd/sharded.py), without leaving
+ * the process.  Results are bit-identical to the single-engine calls.
+ *   rvn_group_find_overlaps_and_create_piles   = rvn_find_overlaps_and_create_piles over all devices: bounds[n_devices + 1]
+ *       receives the read ranges, out[r] a pass handle whose piles / overlap lists are complete for the reads
+ *       [bounds[r], bounds[r+1]) (fetch them with rvn_pass1_fetch_* — arrays are indexed by GLOBAL read id — and release
+ *       with rvn_pass1_destroy).  One index batch: total bases < 2^32.
+ *   rvn_group_polish_round                     = rvn_polish_round over all devices (reads mapped by slice, windows by range,
+ *       pieces concatenated in rank order); host arrays in, consensus out as in rvn_polish_round. */
+typedef struct rvn_group rvn_group;
+int rvn_group_create(rvn_group** out, uint32_t k, uint32_t w, uint32_t bandwidth, uint32_t chain, uint32_t matches,
+                     uint32_t gap, const int* devices, uint32_t n_devices);
+void rvn_group_destroy(rvn_group* g);
+uint32_t rvn_group_size(const rvn_group* g);
+rvn_engine* rvn_group_engine(rvn_group* g, uint32_t rank);
+int rvn_group_find_overlaps_and_create_piles(rvn_group* g, const uint64_t* packed, const uint64_t* word_offsets,
+                                             const uint32_t* lengths, uint32_t n_reads, double freq, uint32_t kmax,
+                                             int use_minhash, uint64_t flush_bases, uint32_t* bounds, rvn_pass1** out);
+int rvn_group_polish_round(rvn_group* g, const uint64_t* t_packed, const uint64_t* t_word_offsets, const uint32_t* t_lengths,
+                           uint32_t n_targets, const uint64_t* r_packed, const uint64_t* r_word_offsets,
+                           const uint32_t* r_lengths, uint32_t n_reads, double q, double err, uint32_t w, int trim, int match,
+                           int mismatch, int gap, uint8_t* out_codes, const uint64_t* out_offsets, uint32_t* out_len,
+                           double* ratio);
+
 /* Kept for source compatibility: a round no longer has a host cutting stage to overlap with the POA, all windows
  * of a call are one device batch.  Stores the value, returns the previous one; results never depended on it. */
 uint64_t rvn_polish_set_chunk_windows(rvn_engine* e, uint64_t windows);

@@ -52,6 +52,14 @@ int fail(int code, const std::string& msg) {
   return code;
 }
 
+}  // namespace
+
+namespace rvn {
+void set_last_error(const std::string& msg) { g_err = msg; }  // group.hip: errors of its worker threads, to the caller
+}  // namespace rvn
+
+namespace {
+
 template <typename F>
 int guarded(F f) {
   try {

@@ -28,6 +28,8 @@ RVN_OK, RVN_EINVAL, RVN_ENODEVICE, RVN_EHIP, RVN_ENOMEM = 0, -1, -2, -3, -4
 
 # every symbol include/raven_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
+    "rvn_group_create", "rvn_group_destroy", "rvn_group_size", "rvn_group_engine",
+    "rvn_group_find_overlaps_and_create_piles", "rvn_group_polish_round",
     "rvn_last_error", "rvn_device_count", "rvn_engine_create", "rvn_engine_destroy", "rvn_reads_upload",
     "rvn_reads_destroy", "rvn_engine_minimize", "rvn_engine_filter", "rvn_engine_occurrence",
     "rvn_engine_map_batch", "rvn_engine_map_fetch", "rvn_engine_map_fetch_filtered",

@@ -1,0 +1,37 @@
+"""N engines behind one host process (rvn_group_*, raven_amd/csrc/group.hip): the C++ driver of the sharded pass and the
+sharded polishing round — SURVEY 8(b)'s engine with a device list, 8(e)'s exchanges, without Python or torch in the loop.
+tests/cpp/group_test.cpp runs 2 and 3 virtual ranks on the one GPU of the test box and compares every rank's slice with
+the single-engine result itself; here its verdicts are checked."""
+import subprocess
+
+import numpy as np
+import pytest
+
+from raven_amd import synth
+from tests.test_gpu_facade import _build, _write_reads
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("n_ranks,flush", [(2, 1 << 30), (3, 400_000)])
+def test_group_pass_and_round_are_bit_identical_to_the_single_engine(tmp_path, n_ranks, flush):
+    exe = _build(tmp_path, "group_test")
+    g = synth.make_genome(250_000, seed=41)
+    rs, _ = synth.make_reads(g, 20, 6000, seed=42)
+    rpath = _write_reads(tmp_path, rs)
+    drafts = [synth.make_draft(g[:120_000], seed=43), synth.make_draft(g[120_000:], seed=44)]
+    dpath = str(tmp_path / "drafts.txt")
+    with open(dpath, "wb") as f:
+        for d in drafts:
+            f.write(bytes(np.frombuffer(b"ACGT", np.uint8)[d]) + b"\n")
+    r = subprocess.run([exe, rpath, dpath, str(n_ranks), str(flush)], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = r.stdout.strip().split("\n")
+    assert int(lines[0].split()[-1]) > 5000                       # the single pass found overlaps
+    bounds = [int(x) for x in lines[1].split()[1:]]
+    assert bounds[0] == 0 and bounds[-1] == rs.n and len(bounds) == n_ranks + 1 and all(np.diff(bounds) > 0)
+    ranks = [ln for ln in lines if ln.startswith("rank ")]
+    assert len(ranks) == n_ranks and all(ln.endswith("identical 1") for ln in ranks), ranks
+    targets = [ln for ln in lines if ln.startswith("target ")]
+    assert len(targets) == 2 and all(ln.endswith("identical 1") for ln in targets), targets
+    assert all(float(ln.split()[5]) > 0.99 for ln in targets)     # (nearly) every window polished

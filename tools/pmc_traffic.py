@@ -11,7 +11,7 @@ import re
 import sys
 
 SITES = [  # (regex on the demangled kernel name, bench.py kernel-site name)
-    (r"nw_path_kernel", "nw_forward"), (r"nw_lane_kernel", "nw_lane"), (r"poa2_kernel", "poa_banded"),
+    (r"nw_sweep_kernel", "nw_forward"), (r"nw_trace_kernel", "nw_traceback"), (r"poa2_kernel", "poa_banded"),
     (r"\bpoa_kernel", "poa"), (r"chain_small_kernel", "chain_small"), (r"chain_kernel", "chain"),
     (r"rs_downsweep_kernel", "rs_downsweep"), (r"rs_upsweep_kernel", "rs_upsweep"),
     (r"sketch_kernel<[^>]*false>", "sketch_count"), (r"sketch_kernel<[^>]*true>", "sketch_write"),
@@ -41,6 +41,19 @@ def load(path):
     return agg
 
 
+def kernel_source_hash():
+    """the same hash bench.py computes: what this profile is valid for"""
+    import glob
+    import hashlib
+    import os
+    h = hashlib.sha1()
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "raven_amd", "csrc")
+    for fn in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.h"))):
+        h.update(os.path.basename(fn).encode())
+        h.update(open(fn, "rb").read())
+    return h.hexdigest()
+
+
 def main(fetch_csv, write_csv, out):
     f, w = load(fetch_csv), load(write_csv)
     kernels = {}
@@ -53,7 +66,8 @@ def main(fetch_csv, write_csv, out):
                       "write_size_bytes_per_launch": int(wr_l), "hbm_bytes_per_launch": int(2 * fe_l + wr_l)}
     json.dump({"method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE in separate passes of `python bench.py "
                          "--no-cpu-baseline`; hbm = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 per launch (gfx950: FETCH_SIZE counts "
-                         "128-B requests as 64 B, MI355X_MICROARCH.md HBM section; WRITE_SIZE uncalibrated)", "kernels": kernels},
+                         "128-B requests as 64 B, MI355X_MICROARCH.md HBM section; WRITE_SIZE uncalibrated)",
+               "kernel_source_sha1": kernel_source_hash(), "kernels": kernels},
               open(out, "w"), indent=1, sort_keys=True)
     print("wrote", out)
 

@@ -4,7 +4,7 @@
 #   2. / 3. separate --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of the same command (HBM traffic per launch)
 # Outputs under gpurun_out/<tag>_*; tools/pmc_traffic.py + the stats CSV are what gets copied to profiles/.
 R=${GRAFT_REPO_ROOT:-/root/repo}
-TAG=${1:-r02}
+TAG=${1:-r03}
 WORKLOAD=${2:-c4}
 mkdir -p $R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
