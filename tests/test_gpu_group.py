@@ -35,3 +35,22 @@ def test_group_pass_and_round_are_bit_identical_to_the_single_engine(tmp_path, n
     targets = [ln for ln in lines if ln.startswith("target ")]
     assert len(targets) == 2 and all(ln.endswith("identical 1") for ln in targets), targets
     assert all(float(ln.split()[5]) > 0.99 for ln in targets)     # (nearly) every window polished
+
+
+def test_device_group_facade_equals_the_single_device_templates(tmp_path):
+    """raven::FindOverlapsAndCreatePiles<Pile> / raven::PolishRound over a raven::DeviceGroup
+    (include/raven_hip/multi_gpu.hpp) against the single-device facades on the same input."""
+    exe = _build(tmp_path, "multi_gpu_facade_test")
+    g = synth.make_genome(150_000, seed=61)
+    rs, _ = synth.make_reads(g, 18, 5000, seed=62)
+    rpath = _write_reads(tmp_path, rs)
+    dpath = str(tmp_path / "drafts.txt")
+    with open(dpath, "wb") as f:
+        for d in (synth.make_draft(g[:70_000], seed=63), synth.make_draft(g[70_000:], seed=64)):
+            f.write(bytes(np.frombuffer(b"ACGT", np.uint8)[d]) + b"\n")
+    r = subprocess.run([exe, rpath, dpath, "2"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = r.stdout.strip().split("\n")
+    a = lines[0].split()
+    assert a[:2] == ["ranks", "2"] and int(a[3]) > 2000 and a[5] == "0", lines[0]
+    assert lines[1] == "polished 2 differing_targets 0"
