@@ -32,14 +32,13 @@ namespace rvn {
 namespace {
 
 // kernel variants: (blocks per lane R, lanes per alignment G); narrow rings share a wave (64 / G alignments).  Ordered by
-// the band they hold (G (64 R + 1) - 64 R offsets), i.e. roughly by alignment length.  A band that fits several variants
-// goes to the cheapest one: a wave-step costs about c0 + c1 R instructions (the ~27 around the recurrence are shared by
-// the lane's R blocks) and serves 64 / G alignments, so cost per alignment-step ~ G (c0 + c1 R) — more blocks per lane in
-// a narrower ring wins as long as registers and LDS keep enough waves resident (R <= 4 here; R = 8 only for bands
-// nothing else holds).
-constexpr u32 kLevels = 14;
-const u32 kRs[kLevels] = {1, 1, 1, 2, 1, 2, 4, 1, 2, 4, 2, 4, 4, 8};
-const u32 kGs[kLevels] = {4, 8, 16, 8, 32, 16, 8, 64, 32, 16, 64, 32, 64, 64};
+// the band they hold (G (64 R + 1) - 64 R offsets), i.e. by alignment length.  Several blocks per lane are only used
+// where one block per lane cannot hold the band: variants (2, 8) ... (4, 32) — fewer instructions per block step on
+// paper — were measured and lost (C4 sweep 178 ms with R = 1 wherever possible, 187 ms allowing R = 2, 225 ms allowing
+// R = 4: more registers = fewer waves, a coarser band, costlier ring events).
+constexpr u32 kLevels = 8;
+const u32 kRs[kLevels] = {1, 1, 1, 1, 1, 2, 4, 8};
+const u32 kGs[kLevels] = {4, 8, 16, 32, 64, 64, 64, 64};
 
 template <int G>
 __device__ __forceinline__ u32 group_max(u32 v) {
@@ -53,7 +52,7 @@ __device__ __forceinline__ u32 group_max(u32 v) {
 
 template <int R>
 constexpr int sweep_waves_per_simd() {
-  return R == 1 ? 8 : (R == 2 ? 6 : (R == 4 ? 5 : 2));
+  return R == 1 ? 8 : (R == 2 ? 6 : (R == 4 ? 4 : 2));
 }
 
 template <int R, int G>
@@ -219,33 +218,22 @@ void nw_breakpoints(Engine& e, const ReadsDev& T, const ReadsDev& Rd, std::vecto
   double rate = e.nw_rate > 0 ? e.nw_rate : 0.13;  // first call: ONT-like; too small only costs a repeat
   if (const char* ev = std::getenv("RVN_NW_RATE")) rate = std::atof(ev);  // tests: force repeats
 
-  // plan: the cheapest variant whose ring holds the band of k (cost per alignment-step ~ G (c0 + c1 R), see kRs / kGs)
-  double c0 = 27, c1 = 30;
-  u32 max_r = 4;
-  if (const char* ev = std::getenv("RVN_NW_COST")) std::sscanf(ev, "%lf,%lf", &c0, &c1);
-  if (const char* ev = std::getenv("RVN_NW_MAXR")) max_r = static_cast<u32>(std::atoi(ev));
+  // plan: the narrowest variant whose ring holds the band of k
   auto plan = [&](NwJob& J, u64 k) -> bool {
     const u32 d = J.n > J.m ? J.n - J.m : J.m - J.n;
     k = std::max<u64>(std::max<u64>(k, d), 16);
     k = std::min<u64>(k, static_cast<u64>(J.n) + J.m);  // D(n, m) <= n + m: that threshold never fails
-    int best = -1;
-    double best_cost = 0;
     for (u32 lvl = 0; lvl < kLevels; ++lvl) {
-      if (kRs[lvl] > max_r && best >= 0) continue;  // wide lanes only where nothing else holds the band
       const u32 cap = kcap_of(J.n, J.m, kRs[lvl], kGs[lvl]);
-      if (cap < k) continue;
-      const double cost = kGs[lvl] * (c0 + c1 * kRs[lvl]) * (kRs[lvl] > max_r ? 1e3 : 1.0);
-      if (best < 0 || cost < best_cost) {
-        best = static_cast<int>(lvl);
-        best_cost = cost;
+      if (cap >= k) {
+        J.R = kRs[lvl];
+        J.G = kGs[lvl];
+        J.k = static_cast<u32>(k);
+        J.kcap = cap;
+        return true;
       }
     }
-    if (best < 0) return false;
-    J.R = kRs[best];
-    J.G = kGs[best];
-    J.k = static_cast<u32>(k);
-    J.kcap = kcap_of(J.n, J.m, J.R, J.G);
-    return true;
+    return false;
   };
   std::vector<u32> valid;
   for (u32 i = 0; i < nj; ++i) {
@@ -295,8 +283,9 @@ void nw_breakpoints(Engine& e, const ReadsDev& T, const ReadsDev& Rd, std::vecto
         std::vector<u32> key(nt), tmp(nt), idx(nt);
         for (size_t x = 0; x < nt; ++x) {
           const NwJob& J = jobs[todo[x]];
-          const u32 mm = std::min<u32>(J.m >> 3, (1u << 21) - 1);  // 8-base resolution is plenty for the ordering
-          key[x] = 0xFFFFFFu - ((level_of(J) << 21) | mm);
+          const u32 mm = std::min<u32>(J.m >> 3, (1u << 20) - 1);  // 8-base resolution is plenty for the ordering
+          static_assert(kLevels <= 16, "4 bits of variant + 20 bits of length = the 24 key bits of the two passes");
+          key[x] = 0xFFFFFFu - ((level_of(J) << 20) | mm);
           idx[x] = static_cast<u32>(x);
         }
         for (int pass = 0; pass < 2; ++pass) {
@@ -387,17 +376,11 @@ void nw_breakpoints(Engine& e, const ReadsDev& T, const ReadsDev& Rd, std::vecto
       std::fprintf(stderr, "[raven_hip] nw: sweep R=%d G=%d done, %u jobs\n", R_, G_, count_of(x));                   \
     }                                                                                                                \
   } while (0)
-        RVN_SWEEP(13, 8, 64);
-        RVN_SWEEP(12, 4, 64);
-        RVN_SWEEP(11, 4, 32);
-        RVN_SWEEP(10, 2, 64);
-        RVN_SWEEP(9, 4, 16);
-        RVN_SWEEP(8, 2, 32);
-        RVN_SWEEP(7, 1, 64);
-        RVN_SWEEP(6, 4, 8);
-        RVN_SWEEP(5, 2, 16);
-        RVN_SWEEP(4, 1, 32);
-        RVN_SWEEP(3, 2, 8);
+        RVN_SWEEP(7, 8, 64);
+        RVN_SWEEP(6, 4, 64);
+        RVN_SWEEP(5, 2, 64);
+        RVN_SWEEP(4, 1, 64);
+        RVN_SWEEP(3, 1, 32);
         RVN_SWEEP(2, 1, 16);
         RVN_SWEEP(1, 1, 8);
         RVN_SWEEP(0, 1, 4);

@@ -112,21 +112,6 @@ def test_lane_group_variants_give_the_same_breakpoints():
         _check(t, q, 0, len(t), 0, len(q), 0, 500, k=600, force_r=-4)
 
 
-def test_blocks_per_lane_in_narrow_rings():
-    """The variants that put several blocks per lane into a ring shared with other alignments of the wave ((R, G) =
-    (2, 8) ... (4, 32): fewer instructions per block step than one block per lane in a wider ring): same distance and
-    breakpoints as the oracle, and a band beyond the ring is refused."""
-    rng = np.random.default_rng(71)
-    for trial, (R, G, n) in enumerate([(2, 8, 900), (2, 16, 2400), (4, 8, 2600), (4, 16, 3000), (2, 32, 3000), (4, 32, 2800)]):
-        t, q = _noisy_pair(rng, n, 0.04, 0.03, 0.03)
-        rc = trial & 1
-        d, band = _check(t, _oriented(q, rc), 0, len(t), 0, len(q), rc, 500, k=24, force_r=R * 1000 + G)
-        assert band[2] == R and band[1] <= G and band[0] >= d
-    t, q = _noisy_pair(rng, 3000, 0.08, 0.06, 0.06)  # threshold 1200: a band of ~19 blocks, beyond a ring of 8 lanes with two blocks each
-    with pytest.raises(ValueError):
-        _check(t, q, 0, len(t), 0, len(q), 0, 500, k=1200, force_r=2 * 1000 + 8)
-
-
 def test_length_difference_and_indel_bursts():
     rng = np.random.default_rng(33)
     t = rng.integers(0, 4, 2500, dtype=np.uint8)
