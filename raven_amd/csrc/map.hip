@@ -717,9 +717,11 @@ __device__ void chain_wave(const u64* __restrict__ p, u32 n, bool strand, u64 g0
 // workgroup whose dynamic LDS is sized for the class (tails, tail indices, predecessors of the whole interval), so the
 // number of resident waves per CU follows the interval size (3 KB for <= 256 matches ... 99 KB for <= 8192) and no wave
 // waits for a sibling's longer interval.  Larger intervals run the same code on global scratch (class kChainClasses).
-constexpr int kChainClasses = 5;
-__constant__ u32 kChainClassCap[kChainClasses] = {256, 1024, 2048, 4096, kChainBigCap};
-static const u32 kChainClassCapHost[kChainClasses] = {256, 1024, 2048, 4096, kChainBigCap};
+// (finer classes in the range where the intervals of a polishing round's read-to-contig maps fall, 300 - 700 matches: a
+// wave's LDS is ~12 B per match of its class, and the stage is a serial LIS per wave — occupancy is its throughput)
+constexpr int kChainClasses = 8;
+__constant__ u32 kChainClassCap[kChainClasses] = {128, 256, 512, 768, 1024, 2048, 4096, kChainBigCap};
+static const u32 kChainClassCapHost[kChainClasses] = {128, 256, 512, 768, 1024, 2048, 4096, kChainBigCap};
 inline size_t chain_class_lds(u32 cap) {
   return static_cast<size_t>(cap + 1) * 8 + (cap / 64 + 2) * 8 + static_cast<size_t>(cap + 2) * 2 + static_cast<size_t>(cap) * 2 + 64;
 }

@@ -20,6 +20,7 @@
 //     identical to the serial order of creation.
 // Integer VALU + LDS bound; no MFMA.
 #include <algorithm>
+#include <cstdlib>
 #include <vector>
 
 #include "poa.h"
@@ -58,6 +59,7 @@ struct Poa2Slot {
   i32* scores;
   i32* preds;
   u16* stack;
+  u16* pos_node;  // traceback result of the current layer: node aligned to position p, or kNone
 };
 
 template <class F>
@@ -83,6 +85,7 @@ __host__ __device__ inline void poa2_fields(u32 nmax, u32 lmax, u32 band, F&& f)
   f(18, static_cast<size_t>(nmax) * 4);
   f(19, static_cast<size_t>(nmax) * 4);
   f(20, static_cast<size_t>(nmax) * 2);
+  f(21, static_cast<size_t>(lmax + 8) * 2);
 }
 
 inline size_t poa2_slot_bytes(u32 nmax, u32 lmax, u32 band) {
@@ -92,7 +95,7 @@ inline size_t poa2_slot_bytes(u32 nmax, u32 lmax, u32 band) {
 }
 
 __device__ inline Poa2Slot poa2_carve(unsigned char* base, u32 nmax, u32 lmax, u32 band) {
-  unsigned char* p[21];
+  unsigned char* p[22];
   size_t o = 0;
   poa2_fields(nmax, lmax, band, [&](int i, size_t x) {
     p[i] = base + o;
@@ -120,6 +123,7 @@ __device__ inline Poa2Slot poa2_carve(unsigned char* base, u32 nmax, u32 lmax, u
   s.scores = reinterpret_cast<i32*>(p[18]);
   s.preds = reinterpret_cast<i32*>(p[19]);
   s.stack = reinterpret_cast<u16*>(p[20]);
+  s.pos_node = reinterpret_cast<u16*>(p[21]);
   return s;
 }
 
@@ -138,9 +142,7 @@ struct alignas(16) Poa2Lds {  // per wave
     } add;
   } u;
   u8 seq_pad[kPoa2MaxSeq + 8];  // the layer's codes at seq_pad + 4; seq_pad[3] = 0xFF (position -1 matches nothing)
-  u8 wgt[kPoa2MaxSeq];
-  u16 pos_node[kPoa2MaxSeq];  // traceback result: node aligned to position p, or kNone
-};
+};  // (the layer's weights and the traceback's position -> node table live in HBM: every KB here is occupancy)
 
 // k-th in-edge (among those inside the subgraph) of v, as a row index (rank + 1); slow path for in-degree > 4
 __device__ __noinline__ u32 poa2_nth_pred(const Poa2Slot& g, u32 v, u32 k, bool full) {
@@ -339,8 +341,7 @@ __device__ __forceinline__ u32 poa2_window(const PoaWindow& win, const PoaLayer*
     }
     for (u32 i = lane; i < len; i += 64) {
       S.seq_pad[4 + i] = static_cast<u8>(poa_layer_code(src, L, i));
-      S.wgt[i] = static_cast<u8>(poa_layer_weight(src, L, i));
-      S.pos_node[i] = static_cast<u16>(kNone);
+      g.pos_node[i] = static_cast<u16>(kNone);
     }
     if (lane == 0) S.seq_pad[3] = 0xFF;
     const bool full = L.begin < offset && L.end > blen - offset;
@@ -731,7 +732,7 @@ __device__ __forceinline__ u32 poa2_window(const PoaWindow& win, const PoaLayer*
             break;
           }
           --j;
-          S.pos_node[j] = static_cast<u16>(node);  // every lane stores the same value
+          g.pos_node[j] = static_cast<u16>(node);  // every lane stores the same value
         }
         i = pr;
       }
@@ -752,14 +753,14 @@ __device__ __forceinline__ u32 poa2_window(const PoaWindow& win, const PoaLayer*
     u32 first_p = 0xFFFFFFFFu;
     for (u32 p0 = 0; p0 < len && first_p == 0xFFFFFFFFu; p0 += 64) {
       const u32 p = p0 + lane;
-      const unsigned long long bal = __ballot(p < len && S.pos_node[p] != kNone);
+      const unsigned long long bal = __ballot(p < len && g.pos_node[p] != kNone);
       if (bal) first_p = p0 + static_cast<u32>(__builtin_ctzll(bal));
     }
     // New nodes anchored after a column (aligned group) go after ALL its members; the unaligned prefix goes
     // before all members of the first column.
     u32 carry_slot = n_old, carry_b = static_cast<u32>(lb);
     if (first_p != 0xFFFFFFFFu) {
-      const u32 an = S.pos_node[first_p];
+      const u32 an = g.pos_node[first_p];
       u32 r = g.rank_of[an];
       const u32 ac = g.al_cnt[an];
       for (u32 k = 0; k < ac; ++k) {
@@ -774,7 +775,7 @@ __device__ __forceinline__ u32 poa2_window(const PoaWindow& win, const PoaLayer*
     for (u32 p0 = 0; p0 < len; p0 += 64) {
       const u32 p = p0 + lane;
       const bool valid = p < len;
-      const u32 an = valid ? S.pos_node[p] : kNone;
+      const u32 an = valid ? g.pos_node[p] : kNone;
       const u32 letter = valid ? S.seq_pad[4 + p] : 0u;
       const bool has = valid && an != kNone;
       u32 tgt = kNone, gslot = 0, gb = 0, ac = 0;
@@ -853,7 +854,9 @@ __device__ __forceinline__ u32 poa2_window(const PoaWindow& win, const PoaLayer*
         const u32 p = p0 + lane;
         bool okl = true;
         if (p >= 1 && p < len)
-          okl = poa_add_edge(g, S.u.add.tgt[p - 1], S.u.add.tgt[p], static_cast<i32>(S.wgt[p - 1]) + S.wgt[p]);
+          okl = poa_add_edge(g, S.u.add.tgt[p - 1], S.u.add.tgt[p],
+                             static_cast<i32>(static_cast<u8>(poa_layer_weight(src, L, p - 1))) +
+                                 static_cast<i32>(static_cast<u8>(poa_layer_weight(src, L, p))));
         if (__ballot(!okl)) {
           ok = 0;
           why = 3;
@@ -914,8 +917,8 @@ __device__ __forceinline__ u32 poa2_window(const PoaWindow& win, const PoaLayer*
   return 1;
 }
 
-template <int NCH, int WPB>
-__global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(NCH == 1 ? 5 : 1))) void poa2_kernel(const PoaWindow* __restrict__ windows, u32 n_windows,
+template <int NCH, int WPB, int OCC>
+__global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(OCC))) void poa2_kernel(const PoaWindow* __restrict__ windows, u32 n_windows,
                                                   const PoaLayer* __restrict__ layers, const PoaSrc src,
                                                   unsigned char* __restrict__ scratch,
                                                   size_t slot_bytes, u32 n_slots, u32 nmax, u32 lmax, int m, int n_,
@@ -946,22 +949,35 @@ void poa_v2_launch(Engine& e, const PoaBatchDev& b, int nch) {
   const size_t slot_bytes = poa2_slot_bytes(b.nmax, b.lmax, 64u * nch);
   size_t free_b = 0, total_b = 0;
   RVN_HIP(hipMemGetInfo(&free_b, &total_b));
-  u32 n_slots = std::min<u32>(b.n_windows, nch == 1 ? 256 * 20 : 256 * 16);  // up to 4 workgroups of 4 waves per CU
+  u32 occ = 6;  // waves per SIMD the 64-column kernel is built for (80 VGPRs; LDS allows 7 workgroups of 4 waves per CU): measured 5 / 6 / 7 -> 158.7k / 170.9k / 170.1k windows/s
+  if (const char* ev = std::getenv("RVN_POA_OCC")) occ = static_cast<u32>(std::atoi(ev));
+  occ = occ < 5 ? 5 : (occ > 7 ? 7 : occ);
+  u32 per_cu = nch == 1 ? 4 * occ : 16;
+  if (const char* ev = std::getenv("RVN_POA_WAVES_PER_CU")) per_cu = static_cast<u32>(std::atoi(ev));  // occupancy experiments
+  u32 n_slots = std::min<u32>(b.n_windows, 256 * per_cu);
   const size_t budget = e.poa2_scratch.cap + free_b / 2;
   if (static_cast<size_t>(n_slots) * slot_bytes > budget) n_slots = static_cast<u32>(std::max<size_t>(1, budget / slot_bytes));
   n_slots = ((n_slots + 3) / 4) * 4;
   unsigned char* d_scratch = e.poa2_scratch.get<unsigned char>(static_cast<size_t>(n_slots) * slot_bytes + 256);
   RVN_HIP(hipMemsetAsync(b.next, 0, 4, e.stream));
-  if (nch == 1) {
-    RVN_KLAUNCH(kKPoaBanded, (poa2_kernel<1, 4><<<n_slots / 4, 256, 0, e.stream>>>(
+  if (nch == 1 && occ == 5) {
+    RVN_KLAUNCH(kKPoaBanded, (poa2_kernel<1, 4, 5><<<n_slots / 4, 256, 0, e.stream>>>(
+                                 b.wins, b.n_windows, b.layers, b.src, d_scratch, slot_bytes, n_slots, b.nmax,
+                                 b.lmax, b.m, b.n, b.g, b.trim, b.out, b.out_len, b.status, b.phase_cycles, b.sched, b.next)));
+  } else if (nch == 1 && occ == 6) {
+    RVN_KLAUNCH(kKPoaBanded, (poa2_kernel<1, 4, 6><<<n_slots / 4, 256, 0, e.stream>>>(
+                                 b.wins, b.n_windows, b.layers, b.src, d_scratch, slot_bytes, n_slots, b.nmax,
+                                 b.lmax, b.m, b.n, b.g, b.trim, b.out, b.out_len, b.status, b.phase_cycles, b.sched, b.next)));
+  } else if (nch == 1) {
+    RVN_KLAUNCH(kKPoaBanded, (poa2_kernel<1, 4, 7><<<n_slots / 4, 256, 0, e.stream>>>(
                                  b.wins, b.n_windows, b.layers, b.src, d_scratch, slot_bytes, n_slots, b.nmax,
                                  b.lmax, b.m, b.n, b.g, b.trim, b.out, b.out_len, b.status, b.phase_cycles, b.sched, b.next)));
   } else if (nch == 2) {
-    RVN_KLAUNCH(kKPoaBanded, (poa2_kernel<2, 4><<<n_slots / 4, 256, 0, e.stream>>>(
+    RVN_KLAUNCH(kKPoaBanded, (poa2_kernel<2, 4, 1><<<n_slots / 4, 256, 0, e.stream>>>(
                                  b.wins, b.n_windows, b.layers, b.src, d_scratch, slot_bytes, n_slots, b.nmax,
                                  b.lmax, b.m, b.n, b.g, b.trim, b.out, b.out_len, b.status, b.phase_cycles, b.sched, b.next)));
   } else {  // 256 columns: 21.6 KB of LDS per wave -> 2 waves per workgroup
-    RVN_KLAUNCH(kKPoaBanded, (poa2_kernel<4, 2><<<n_slots / 2, 128, 0, e.stream>>>(
+    RVN_KLAUNCH(kKPoaBanded, (poa2_kernel<4, 2, 1><<<n_slots / 2, 128, 0, e.stream>>>(
                                  b.wins, b.n_windows, b.layers, b.src, d_scratch, slot_bytes, n_slots, b.nmax,
                                  b.lmax, b.m, b.n, b.g, b.trim, b.out, b.out_len, b.status, b.phase_cycles, b.sched, b.next)));
   }
