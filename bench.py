@@ -447,15 +447,24 @@ def main():
                                     "on other streams beside the sweeps; its launch times overlap them."}
             if dom == "nw_forward":
                 roofline = roofline_nw
-            # the dominant HBM-bound kernel (second entry)
+            # the dominant HBM-bound kernel (second entry).  Kernels whose launches PARTITION a step's work (one launch per
+            # flush window / interval class) are priced step against step: algorithmic bytes of the step / their summed
+            # launch time; the others (one launch = one pass over everything, e.g. a radix digit pass) per launch
+            partitioned = {"match_count", "match_emit", "seg_sort_group", "seg_sort_pos", "chain"}
             for name in kernels:
                 b = algorithmic_bytes(name, counters, val_bytes)
                 if b:
-                    avg_s = kms[name][0] / kms[name][1] / 1e3
-                    achieved = b / avg_s / 1e9
+                    if name in partitioned:
+                        t_s = kms[name][0] / steps / 1e3
+                        basis = "step"
+                    else:
+                        t_s = kms[name][0] / kms[name][1] / 1e3
+                        basis = "launch"
+                    achieved = b / t_s / 1e9
                     roofline_hbm = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(name),
-                                    "algorithmic_bytes_per_launch": int(b), "avg_launch_ms": round(avg_s * 1e3, 5),
+                                    "algorithmic_bytes": int(b), "per": basis, "seconds": round(t_s, 6),
+                                    "launches_per_step": kms[name][1] / steps,
                                     "kernel_ms_share": round(kms[name][0] / tot, 3) if tot else None}
                     break
             if roofline is None:
