@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "engine.h"
+#include "simt.h"
 #include "wave.h"
 
 namespace rvn {
@@ -14,6 +15,7 @@ namespace rvn {
 constexpr int kPoaMaxIn = 16;     // in-edges per node kept (overflow -> window reported as failed)
 constexpr int kPoaMaxSeq = 1024;  // longest layer (bases)
 constexpr i32 kNegInf16 = -30000;
+constexpr int kPoa2MaxSeq = 896;  // longest layer of the banded kernels (longer ones: full-matrix kernel); sizes the LDS buffers
 
 struct PoaWindow {  // host-prepared, one per window
   u32 layer_first, n_layers;  // range in the (begin-sorted) layer table; layer_first = backbone
@@ -44,7 +46,7 @@ inline void poa_layer_linear_way(PoaLayer& L) {
   L.pad_ = 0;
 }
 // expected layer offset of backbone position begin + x (x clamped to [0, span]), piecewise linear through `way`
-__device__ __forceinline__ i32 poa_layer_center(const PoaLayer& L, i32 x, i32 span) {
+__host__ __device__ __forceinline__ i32 poa_layer_center(const PoaLayer& L, i32 x, i32 span) {
   x = x < 0 ? 0 : (x > span ? span : x);
   const i32 seg = (x * 8) / (span > 0 ? span : 1);      // 0..8
   const i32 s = seg > 7 ? 7 : seg;
@@ -63,11 +65,11 @@ struct PoaSrc {
   const u8* layer_ok;      // per layer: 0 = dropped by the mean-quality filter (nullable = all kept)
 };
 
-__device__ __forceinline__ u32 poa_layer_src_pos(const PoaLayer& L, u32 i) {
+__host__ __device__ __forceinline__ u32 poa_layer_src_pos(const PoaLayer& L, u32 i) {
   const u32 pos = L.q_begin + i;
   return (L.flags & kLayerRc) ? L.q_len - 1 - pos : pos;
 }
-__device__ __forceinline__ u32 poa_layer_code(const PoaSrc& src, const PoaLayer& L, u32 i) {
+__host__ __device__ __forceinline__ u32 poa_layer_code(const PoaSrc& src, const PoaLayer& L, u32 i) {
   if (L.flags & kLayerPacked) {
     const u64* P = (L.flags & kLayerTarget) ? src.packed_targets : src.packed_reads;
     const u32 sp = poa_layer_src_pos(L, i);
@@ -76,7 +78,7 @@ __device__ __forceinline__ u32 poa_layer_code(const PoaSrc& src, const PoaLayer&
   }
   return src.codes[L.code_off + i];
 }
-__device__ __forceinline__ i32 poa_layer_weight(const PoaSrc& src, const PoaLayer& L, u32 i) {
+__host__ __device__ __forceinline__ i32 poa_layer_weight(const PoaSrc& src, const PoaLayer& L, u32 i) {
   if (L.flags & kLayerZeroW) return 0;
   if (!(L.flags & kLayerQual)) return 1;
   if (L.flags & kLayerPacked)
@@ -104,6 +106,98 @@ struct PoaBatchDev {  // device-side batch description shared by both launchers
   u32* next;         // work counter (zeroed by the launcher)
 };
 
+// Per-window scratch of the banded kernels (poa2.hip, poa3.hip): the spoa graph as SoA arrays, the backpointer matrix of
+// the current layer and the traceback's row table, carved out of one allocation per resident window.
+struct Poa2Slot {
+  i16* Hs;    // (nmax + 1) x band scores (ring misses only)
+  u8* BP;     // (nmax + 1) x band backpointers: 0..15 diagonal via in-edge k, 16..31 vertical, 32 horizontal
+  uint4* tb;  // per row: x = band start | node << 16, y = #in-edges, z = rows of in-edges 0,1, w = in-edges 2,3
+  u8* code;
+  u8* in_cnt;
+  u16* in_tail;
+  i32* in_w;
+  u16* out_cnt;
+  u8* al_cnt;
+  u16* al;
+  u16* visits;
+  u16* rank_of;
+  u16* order;
+  u16* order2;
+  u8* mark;
+  u16* sub_out;
+  u16* bpos;
+  u16* new_slot;
+  i32* scores;
+  i32* preds;
+  u16* stack;
+  u16* pos_node;  // traceback result of the current layer: node aligned to position p, or kNone
+};
+
+template <class F>
+__host__ __device__ inline void poa2_fields(u32 nmax, u32 lmax, u32 band, F&& f, bool hs = true) {
+  f(0, hs ? static_cast<size_t>(nmax + 1) * band * 2 : 0);
+  f(1, static_cast<size_t>(nmax + 1) * band);
+  f(2, static_cast<size_t>(nmax + 1) * 16);
+  f(3, nmax);
+  f(4, nmax);
+  f(5, static_cast<size_t>(nmax) * kPoaMaxIn * 2);
+  f(6, static_cast<size_t>(nmax) * kPoaMaxIn * 4);
+  f(7, static_cast<size_t>(nmax) * 2);
+  f(8, nmax);
+  f(9, static_cast<size_t>(nmax) * 4 * 2);
+  f(10, static_cast<size_t>(nmax) * 2);
+  f(11, static_cast<size_t>(nmax) * 2);
+  f(12, static_cast<size_t>(nmax) * 2);
+  f(13, static_cast<size_t>(nmax) * 2);
+  f(14, nmax);
+  f(15, static_cast<size_t>(nmax) * 2 + 4);
+  f(16, static_cast<size_t>(nmax) * 2);
+  f(17, static_cast<size_t>(lmax + 2) * 2);
+  f(18, static_cast<size_t>(nmax) * 4);
+  f(19, static_cast<size_t>(nmax) * 4);
+  f(20, static_cast<size_t>(nmax) * 2);
+  f(21, static_cast<size_t>(lmax + 8) * 2);
+}
+
+inline size_t poa2_slot_bytes(u32 nmax, u32 lmax, u32 band, bool hs = true) {
+  size_t b = 0;
+  poa2_fields(nmax, lmax, band, [&](int, size_t x) { b += (x + 255) & ~size_t(255); }, hs);
+  return b;
+}
+
+__host__ __device__ inline Poa2Slot poa2_carve(unsigned char* base, u32 nmax, u32 lmax, u32 band, bool hs = true) {
+  unsigned char* p[22];
+  size_t o = 0;
+  poa2_fields(nmax, lmax, band, [&](int i, size_t x) {
+    p[i] = base + o;
+    o += (x + 255) & ~size_t(255);
+  }, hs);
+  Poa2Slot s;
+  s.Hs = reinterpret_cast<i16*>(p[0]);
+  s.BP = p[1];
+  s.tb = reinterpret_cast<uint4*>(p[2]);
+  s.code = p[3];
+  s.in_cnt = p[4];
+  s.in_tail = reinterpret_cast<u16*>(p[5]);
+  s.in_w = reinterpret_cast<i32*>(p[6]);
+  s.out_cnt = reinterpret_cast<u16*>(p[7]);
+  s.al_cnt = p[8];
+  s.al = reinterpret_cast<u16*>(p[9]);
+  s.visits = reinterpret_cast<u16*>(p[10]);
+  s.rank_of = reinterpret_cast<u16*>(p[11]);
+  s.order = reinterpret_cast<u16*>(p[12]);
+  s.order2 = reinterpret_cast<u16*>(p[13]);
+  s.mark = p[14];
+  s.sub_out = reinterpret_cast<u16*>(p[15]);
+  s.bpos = reinterpret_cast<u16*>(p[16]);
+  s.new_slot = reinterpret_cast<u16*>(p[17]);
+  s.scores = reinterpret_cast<i32*>(p[18]);
+  s.preds = reinterpret_cast<i32*>(p[19]);
+  s.stack = reinterpret_cast<u16*>(p[20]);
+  s.pos_node = reinterpret_cast<u16*>(p[21]);
+  return s;
+}
+
 void poa_v1_launch(Engine& e, const PoaBatchDev& b);  // poa.hip
 // windows + begin-sorted layer descriptors on the host, all sources of `src` resident in HBM (poa.hip)
 void poa_run(Engine& e, const std::vector<PoaWindow>& wins, const std::vector<PoaLayer>& lays, const PoaSrc& src,
@@ -114,6 +208,10 @@ void poa_run_dev(Engine& e, const PoaWindow* d_wins, const PoaLayer* d_lays, u32
                  u32 max_len, int m, int n, int g, int trim, u8* d_out, u32* d_len, u32* d_status,
                  std::vector<u32>& h_status, double* device_ms, bool allow_full = true);
 void poa_v2_launch(Engine& e, const PoaBatchDev& b, int nch);  // poa2.hip: band = 64 * nch columns
+void poa_v3_launch(Engine& e, const PoaBatchDev& b);           // poa3.hip: 64 columns, four windows per wave
+// poa3.hip's kernel source run on the host under the wavefront emulator (test infrastructure; host arrays everywhere)
+void poa_v3_emulate(const std::vector<PoaWindow>& wins, const std::vector<PoaLayer>& lays, const PoaSrc& src, u32 max_bb,
+                    u32 max_len, int m, int n, int g, int trim, u8* out, u32* out_len, u32* status);
 
 // Persistent waves take windows from a shared counter (longest-processing-time-first order when `sched` is given).
 __device__ __forceinline__ u32 poa_next_window(u32* next, const u32* sched, u32 n_windows) {
@@ -124,15 +222,12 @@ __device__ __forceinline__ u32 poa_next_window(u32* next, const u32* sched, u32 
   return sched ? sched[i] : i;
 }
 
-__device__ __forceinline__ void wsync() {
-  __threadfence_block();
-  __builtin_amdgcn_wave_barrier();
-}
+__host__ __device__ __forceinline__ void wsync() { sv::sync(); }
 
 // spoa Graph::AddEdge on the SoA graph. Returns false on in-degree overflow.  Touches only head's in-edge list
 // and tail's out-degree, so lanes working on distinct (tail, head) pairs do not conflict.
 template <class G>
-__device__ inline bool poa_add_edge(G& g, u32 tail, u32 head, i32 weight) {
+__host__ __device__ inline bool poa_add_edge(G& g, u32 tail, u32 head, i32 weight) {
   const u32 c = g.in_cnt[head];
   for (u32 i = 0; i < c; ++i) {
     if (g.in_tail[head * kPoaMaxIn + i] == tail) {
@@ -151,8 +246,8 @@ __device__ inline bool poa_add_edge(G& g, u32 tail, u32 head, i32 weight) {
 // spoa Graph::Subgraph as marks: ancestors (through in-edges and aligned nodes) of backbone node `end` with
 // id >= begin; sub_out = out-degree inside the subgraph.  Whole wave; lane 0 runs the DFS.
 template <class G>
-__device__ inline void poa_subgraph_marks(G& g, u32 n_nodes, u32 nmax, u32 begin, u32 end) {
-  const int lane = lane_id();
+__host__ __device__ inline void poa_subgraph_marks(G& g, u32 n_nodes, u32 nmax, u32 begin, u32 end) {
+  const int lane = sv::lane();
   for (u32 i = lane; i < n_nodes; i += 64) {
     g.mark[i] = 0;
     g.sub_out[i] = 0;
@@ -178,7 +273,7 @@ __device__ inline void poa_subgraph_marks(G& g, u32 n_nodes, u32 nmax, u32 begin
     const u32 c = g.in_cnt[v];
     for (u32 k = 0; k < c; ++k) {
       const u32 t = g.in_tail[v * kPoaMaxIn + k];
-      if (g.mark[t]) atomicAdd(reinterpret_cast<unsigned int*>(g.sub_out) + (t >> 1), (t & 1) ? 0x10000u : 1u);
+      if (g.mark[t]) sv::atomic_add(reinterpret_cast<unsigned int*>(g.sub_out) + (t >> 1), (t & 1) ? 0x10000u : 1u);
     }
   }
   wsync();
@@ -187,7 +282,7 @@ __device__ inline void poa_subgraph_marks(G& g, u32 n_nodes, u32 nmax, u32 begin
 // Consensus: spoa TraverseHeaviestBundle + BranchCompletion, racon's coverage trim (lane 0).
 // Part 1: heaviest-path scores and predecessors of every node in topological order; returns the best-scoring node.
 template <class G>
-__device__ inline i32 poa_consensus_scores_lane0(G& g, u32 n_nodes) {
+__host__ __device__ inline i32 poa_consensus_scores_lane0(G& g, u32 n_nodes) {
   i32 maxn = -1;
   for (u32 r = 0; r < n_nodes; ++r) {
     const u32 it = g.order[r];
@@ -212,7 +307,7 @@ __device__ inline i32 poa_consensus_scores_lane0(G& g, u32 n_nodes) {
 // Part 2: branch completion from `maxn`, traceback into g.stack (reverse order), racon's coverage trim.
 // Consensus position p (begin <= p <= end) is node g.stack[cl - 1 - p].
 template <class G>
-__device__ inline void poa_consensus_trace_lane0(G& g, u32 n_nodes, u32 nmax, const PoaWindow& win, int trim, i32 maxn,
+__host__ __device__ inline void poa_consensus_trace_lane0(G& g, u32 n_nodes, u32 nmax, const PoaWindow& win, int trim, i32 maxn,
                                                  u32* cl_out, i32* begin_out, i32* end_out) {
   u32 guard = 0;
   while (g.out_cnt[maxn] != 0 && guard++ < nmax) {
@@ -284,7 +379,7 @@ __device__ inline void poa_consensus_trace_lane0(G& g, u32 n_nodes, u32 nmax, co
 }
 
 template <class G>
-__device__ inline void poa_consensus_lane0(G& g, u32 n_nodes, u32 nmax, const PoaWindow& win, int trim,
+__host__ __device__ inline void poa_consensus_lane0(G& g, u32 n_nodes, u32 nmax, const PoaWindow& win, int trim,
                                            u8* __restrict__ out, u32* out_len) {
   const i32 maxn = poa_consensus_scores_lane0(g, n_nodes);
   u32 cl = 0;

@@ -684,7 +684,13 @@ void poa_run_dev(Engine& e, const PoaWindow* d_wins, const PoaLayer* d_lays, u32
   const auto mag = [](int x) { return x < 0 ? -x : x; };
   const bool int16_ok = mag(m) <= 24 && mag(n) <= 24 && mag(g) <= 24;
   const int mode = int16_ok ? e.poa_mode : 1;
+  // first attempt with the 64-column band: four windows per wave (poa3.hip) or one (poa2.hip)
+  static const bool v3_default = [] {
+    const char* ev = std::getenv("RVN_POA3");
+    return ev ? std::atoi(ev) != 0 : false;
+  }();
   if (mode == 1) poa_v1_launch(e, b);
+  else if (mode == 5 || (mode == 0 && v3_default)) poa_v3_launch(e, b);
   else poa_v2_launch(e, b, mode == 3 ? 2 : (mode == 4 ? 4 : 1));
   RVN_HIP(hipMemcpyAsync(h_status.data(), d_status, static_cast<size_t>(n_windows) * 4, hipMemcpyDeviceToHost, s));
   RVN_HIP(rvn_stream_sync(s));
@@ -790,18 +796,15 @@ void poa_run(Engine& e, const std::vector<PoaWindow>& wins, const std::vector<Po
   for (u32 w = 0; w < n_windows; ++w) h_status[w] = st[w];
 }
 
-// Host entry: see rvn_poa_consensus_batch in raven_hip.h (caller-built windows: one-byte codes on the host).
-void poa_consensus_batch(Engine& e, const u8* h_codes, const u8* h_quals, const u64* h_layer_off,
-                         const u32* h_begins, const u32* h_ends, const u32* h_has_qual, const u32* h_win_off,
-                         u32 n_windows, int m, int n, int g, int trim, u8* h_out, const u64* h_out_off,
-                         u32* h_out_len, u32* h_status, double* device_ms) {
-  if (n_windows == 0) return;
-  hipStream_t s = e.stream;
+// windows + begin-sorted layer descriptors of a caller-built batch (one-byte codes on the host)
+static void poa_build_host_batch(const u64* h_layer_off, const u32* h_begins, const u32* h_ends, const u32* h_has_qual,
+                                 bool have_quals, const u32* h_win_off, u32 n_windows, const u64* h_out_off,
+                                 std::vector<PoaWindow>& wins, std::vector<PoaLayer>& lays, u32& max_bb, u32& max_len) {
   const u32 n_layers = h_win_off[n_windows];
-  const u64 total = h_layer_off[n_layers];
-  std::vector<PoaWindow> wins(n_windows);
-  std::vector<PoaLayer> lays(n_layers);
-  u32 max_bb = 1, max_len = 1;
+  wins.assign(n_windows, PoaWindow{});
+  lays.assign(n_layers, PoaLayer{});
+  max_bb = 1;
+  max_len = 1;
   for (u32 w = 0; w < n_windows; ++w) {
     const u32 f = h_win_off[w], l = h_win_off[w + 1];
     wins[w].layer_first = f;
@@ -822,12 +825,28 @@ void poa_consensus_batch(Engine& e, const u8* h_codes, const u8* h_quals, const 
       L.len = static_cast<u32>(h_layer_off[src + 1] - h_layer_off[src]);
       L.begin = h_begins[src];
       L.end = h_ends[src];
-      L.flags = (h_quals && h_has_qual && h_has_qual[src]) ? kLayerQual : 0u;
+      L.flags = (have_quals && h_has_qual && h_has_qual[src]) ? kLayerQual : 0u;
       poa_layer_linear_way(L);
       if (i == 0) max_bb = std::max(max_bb, L.len);
       max_len = std::max(max_len, L.len);
     }
   }
+}
+
+// Host entry: see rvn_poa_consensus_batch in raven_hip.h (caller-built windows: one-byte codes on the host).
+void poa_consensus_batch(Engine& e, const u8* h_codes, const u8* h_quals, const u64* h_layer_off,
+                         const u32* h_begins, const u32* h_ends, const u32* h_has_qual, const u32* h_win_off,
+                         u32 n_windows, int m, int n, int g, int trim, u8* h_out, const u64* h_out_off,
+                         u32* h_out_len, u32* h_status, double* device_ms) {
+  if (n_windows == 0) return;
+  hipStream_t s = e.stream;
+  const u32 n_layers = h_win_off[n_windows];
+  const u64 total = h_layer_off[n_layers];
+  std::vector<PoaWindow> wins;
+  std::vector<PoaLayer> lays;
+  u32 max_bb = 1, max_len = 1;
+  poa_build_host_batch(h_layer_off, h_begins, h_ends, h_has_qual, h_quals != nullptr, h_win_off, n_windows, h_out_off, wins,
+                       lays, max_bb, max_len);
   u8* d_codes = e.tmp_a.get<u8>(total + 16);
   u8* d_quals = h_quals ? e.tmp_b.get<u8>(total + 16) : nullptr;
   RVN_HIP(hipMemcpyAsync(d_codes, h_codes, total, hipMemcpyHostToDevice, s));
@@ -837,6 +856,24 @@ void poa_consensus_batch(Engine& e, const u8* h_codes, const u8* h_quals, const 
   src.quals = d_quals;
   poa_run(e, wins, lays, src, max_bb, max_len, m, n, g, trim, h_out, h_out_off[n_windows], h_out_len, h_status,
           device_ms);
+}
+
+// The four-windows-per-wave banded kernel (poa3.hip) stepped through on the HOST by the wavefront emulator: same batch
+// description as poa_consensus_batch, first attempt only (status 8 / 7 = the window needs the wider kernels).  Test
+// infrastructure for the CPU suite; needs no GPU and no engine.
+void poa_banded_emulate(const u8* h_codes, const u8* h_quals, const u64* h_layer_off, const u32* h_begins,
+                        const u32* h_ends, const u32* h_has_qual, const u32* h_win_off, u32 n_windows, int m, int n, int g,
+                        int trim, u8* h_out, const u64* h_out_off, u32* h_out_len, u32* h_status) {
+  if (n_windows == 0) return;
+  std::vector<PoaWindow> wins;
+  std::vector<PoaLayer> lays;
+  u32 max_bb = 1, max_len = 1;
+  poa_build_host_batch(h_layer_off, h_begins, h_ends, h_has_qual, h_quals != nullptr, h_win_off, n_windows, h_out_off, wins,
+                       lays, max_bb, max_len);
+  PoaSrc src{};
+  src.codes = h_codes;
+  src.quals = h_quals;
+  poa_v3_emulate(wins, lays, src, max_bb, max_len, m, n, g, trim, h_out, h_out_len, h_status);
 }
 
 }  // namespace rvn

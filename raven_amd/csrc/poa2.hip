@@ -30,102 +30,11 @@ namespace rvn {
 namespace {
 
 constexpr int kRing = 32;  // score rows kept in LDS
-constexpr int kPoa2MaxSeq = 896;  // longest layer of the banded kernels (longer ones: full-matrix kernel); sizes the LDS buffers
 // The band is NCH chunks of 64 columns (one column per lane and chunk).  NCH = 1 (+-32 around the expected
 // column) is the first attempt; windows whose traceback touches the band edge are repeated with NCH = 2 and, if
 // that is not enough either with NCH = 4 (256 columns, two waves per workgroup) before the full-matrix kernel.
 constexpr u32 kNone = 0xFFFFu;
 constexpr i32 kNegBig = -0x3FFFFFFF;
-
-struct Poa2Slot {
-  i16* Hs;    // (nmax + 1) x band scores (ring misses only)
-  u8* BP;     // (nmax + 1) x band backpointers: 0..15 diagonal via in-edge k, 16..31 vertical, 32 horizontal
-  uint4* tb;  // per row: x = band start | node << 16, y = #in-edges, z = rows of in-edges 0,1, w = in-edges 2,3
-  u8* code;
-  u8* in_cnt;
-  u16* in_tail;
-  i32* in_w;
-  u16* out_cnt;
-  u8* al_cnt;
-  u16* al;
-  u16* visits;
-  u16* rank_of;
-  u16* order;
-  u16* order2;
-  u8* mark;
-  u16* sub_out;
-  u16* bpos;
-  u16* new_slot;
-  i32* scores;
-  i32* preds;
-  u16* stack;
-  u16* pos_node;  // traceback result of the current layer: node aligned to position p, or kNone
-};
-
-template <class F>
-__host__ __device__ inline void poa2_fields(u32 nmax, u32 lmax, u32 band, F&& f) {
-  f(0, static_cast<size_t>(nmax + 1) * band * 2);
-  f(1, static_cast<size_t>(nmax + 1) * band);
-  f(2, static_cast<size_t>(nmax + 1) * 16);
-  f(3, nmax);
-  f(4, nmax);
-  f(5, static_cast<size_t>(nmax) * kPoaMaxIn * 2);
-  f(6, static_cast<size_t>(nmax) * kPoaMaxIn * 4);
-  f(7, static_cast<size_t>(nmax) * 2);
-  f(8, nmax);
-  f(9, static_cast<size_t>(nmax) * 4 * 2);
-  f(10, static_cast<size_t>(nmax) * 2);
-  f(11, static_cast<size_t>(nmax) * 2);
-  f(12, static_cast<size_t>(nmax) * 2);
-  f(13, static_cast<size_t>(nmax) * 2);
-  f(14, nmax);
-  f(15, static_cast<size_t>(nmax) * 2 + 4);
-  f(16, static_cast<size_t>(nmax) * 2);
-  f(17, static_cast<size_t>(lmax + 2) * 2);
-  f(18, static_cast<size_t>(nmax) * 4);
-  f(19, static_cast<size_t>(nmax) * 4);
-  f(20, static_cast<size_t>(nmax) * 2);
-  f(21, static_cast<size_t>(lmax + 8) * 2);
-}
-
-inline size_t poa2_slot_bytes(u32 nmax, u32 lmax, u32 band) {
-  size_t b = 0;
-  poa2_fields(nmax, lmax, band, [&](int, size_t x) { b += (x + 255) & ~size_t(255); });
-  return b;
-}
-
-__device__ inline Poa2Slot poa2_carve(unsigned char* base, u32 nmax, u32 lmax, u32 band) {
-  unsigned char* p[22];
-  size_t o = 0;
-  poa2_fields(nmax, lmax, band, [&](int i, size_t x) {
-    p[i] = base + o;
-    o += (x + 255) & ~size_t(255);
-  });
-  Poa2Slot s;
-  s.Hs = reinterpret_cast<i16*>(p[0]);
-  s.BP = p[1];
-  s.tb = reinterpret_cast<uint4*>(p[2]);
-  s.code = p[3];
-  s.in_cnt = p[4];
-  s.in_tail = reinterpret_cast<u16*>(p[5]);
-  s.in_w = reinterpret_cast<i32*>(p[6]);
-  s.out_cnt = reinterpret_cast<u16*>(p[7]);
-  s.al_cnt = p[8];
-  s.al = reinterpret_cast<u16*>(p[9]);
-  s.visits = reinterpret_cast<u16*>(p[10]);
-  s.rank_of = reinterpret_cast<u16*>(p[11]);
-  s.order = reinterpret_cast<u16*>(p[12]);
-  s.order2 = reinterpret_cast<u16*>(p[13]);
-  s.mark = p[14];
-  s.sub_out = reinterpret_cast<u16*>(p[15]);
-  s.bpos = reinterpret_cast<u16*>(p[16]);
-  s.new_slot = reinterpret_cast<u16*>(p[17]);
-  s.scores = reinterpret_cast<i32*>(p[18]);
-  s.preds = reinterpret_cast<i32*>(p[19]);
-  s.stack = reinterpret_cast<u16*>(p[20]);
-  s.pos_node = reinterpret_cast<u16*>(p[21]);
-  return s;
-}
 
 template <int NCH>
 struct alignas(16) Poa2Lds {  // per wave

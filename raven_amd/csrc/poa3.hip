@@ -1,0 +1,1188 @@
+// poa3.hip — banded POA window kernel, FOUR windows per wave: the first attempt of rvn_poa_consensus_batch / of a
+// polishing round's consensus stage (racon Window::GenerateConsensus over spoa, as driven by raven::Polish,
+// RavenLib/src/polish.cc:43-51).  Same algorithm, graph layout, band rule and tie rules as poa2.hip's 64-column kernel
+// (results are identical window for window); what changes is how the work sits on the wave.
+//
+// poa2 gives a window a whole wave: one DP row of 64 cells per loop iteration, every per-row decision (which
+// predecessor rows, where their band starts, which ring slot) decoded by the scalar unit — 58 vector + 86 scalar
+// instructions per row, and the scalar issue slots are what the kernel runs out of (profiles/r03_sq_poa_*.csv).
+// Here a window owns a ROW OF 16 LANES (the unit DPP row operations work on), each lane four adjacent band columns, so
+// one instruction stream advances four windows at once and everything that was scalar per row becomes a
+// vector value that is uniform inside a 16-lane group:
+//   * NW rows: the row's descriptor (band start, ring slot, node code, in-degree) and the descriptors of its first four
+//     predecessor rows (ring slot + band start, resolved once per 16-row block by the lane that owns the row) reach
+//     the group through ds_bpermute; the two candidates a predecessor contributes to a cell (diagonal from its column
+//     j - 1, vertical from column j) come from one 12-byte LDS read per lane (five adjacent int16 cells of the
+//     predecessor's ring row, -inf pads instead of range checks) and are folded with v_max3 on
+//     (score << 6 | diagonal << 5 | 15 - in-edge): the maximum carries spoa's tie rule (diagonal before vertical, first
+//     in-edge first) and the backpointer falls out of its low bits.  The horizontal gap chain is a prefix maximum of
+//     H - j*g: three in-lane steps + four DPP row shifts.
+//   * traceback: four walks in lockstep, one per group; 32-row blocks of backpointers and their row table staged in
+//     the group's LDS.
+//   * the graph update (spoa AddAlignment), the order rebuild, the subgraph marks and the consensus stay wave-wide per
+//     window (they are 14 % of poa2's cycles) and run for the wave's windows one after the other.
+// Per wave: 13.1 KB of LDS (16 ring rows + the layer's codes per window) -> 12 waves = 48 windows per CU (poa2: 24).
+//
+// Written against sv:: (simt.h): the same source runs under the host wavefront emulator, which is how the CPU suite
+// checks this kernel against the oracle (tests/test_poa3_emulation.py -> rvn_poa_banded_emulate).
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "poa.h"
+
+namespace rvn {
+
+namespace {
+
+constexpr int kG = 4;            // windows per wave
+constexpr int kRing3 = 16;       // score rows a window keeps in LDS
+constexpr int kPad3 = 6;         // -inf cells either side of a ring row
+constexpr int kStride3 = 64 + 2 * kPad3;  // int16 cells per ring row
+constexpr int kTbRows = 32;      // rows per traceback block
+constexpr u32 kNone3 = 0xFFFFu;
+constexpr u32 kDescVirtual = 1u << 30, kDescMiss = 1u << 31;
+constexpr i32 kVeryNeg = -0x40000000;
+unsigned long long g_emu_lost_rows = 0;  // host emulation only: predecessor rows fetched from the HBM copy
+
+struct alignas(16) Poa3Group {
+  union {
+    u32 ring32[kRing3 * kStride3 / 2];  // DP: [kRing3][kPad3 | 64 cells | kPad3] int16, slot = computed-row index % kRing3
+    struct {
+      u8 bp[kTbRows * 64];   // traceback: backpointer rows of one block
+      u32 tb[kTbRows * 3];   // and their row table: band start | node << 16, in-edge rows 0,1, in-edge rows 2,3
+    } tr;
+    u16 tgt[kPoa2MaxSeq];    // AddAlignment: graph node of every sequence position
+  } u;
+  u8 seq_pad[kPoa2MaxSeq + 16];  // the layer's codes at seq_pad + 4; seq_pad[3] = 0xFF (position -1 matches nothing)
+};
+struct alignas(16) Poa3Lds {
+  Poa3Group g[kG];
+};
+static_assert(sizeof(Poa3Lds) <= 13648, "twelve waves per CU need <= 13.3 KB of LDS each");
+
+struct Poa3Args {
+  const PoaWindow* windows;
+  u32 n_windows;
+  const PoaLayer* layers;
+  PoaSrc src;
+  unsigned char* scratch;
+  size_t slot_bytes;
+  u32 nmax, lmax;
+  int m, n_, gp, trim;
+  u8* out;
+  u32* out_len;
+  u32* status;
+  unsigned long long* phase_cycles;
+  const u32* sched;
+  u32* next;
+};
+
+__host__ __device__ __forceinline__ u32 funnel_shr(u32 hi, u32 lo, u32 sh) {  // v_alignbit_b32; sh in [0, 31]
+  return static_cast<u32>(((static_cast<unsigned long long>(hi) << 32) | lo) >> sh);
+}
+__host__ __device__ __forceinline__ i32 sext16(u32 x) { return static_cast<i32>(static_cast<i16>(x & 0xFFFFu)); }
+__host__ __device__ __forceinline__ i32 max3(i32 a, i32 b, i32 c) {
+  const i32 ab = a > b ? a : b;
+  return ab > c ? ab : c;
+}
+// LDS traffic of one wave is executed in order on the GPU; the emulator's fibres need a rendezvous between a lane's
+// LDS write and another lane's read of it
+__host__ __device__ __forceinline__ void lds_order() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_wave_barrier();
+#else
+  sv::sync();
+#endif
+}
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define P3_MARK(x) asm volatile("; P3MARK " x)
+#define P3_NO_IF_CONVERSION() asm volatile("")  // keeps a rare, wave-uniform branch a branch
+#define P3_PHASE  // (noinline phases were tried: generic pointers turn every access into FLAT loads that also hold the LDS counter)
+#else
+#define P3_MARK(x)
+#define P3_NO_IF_CONVERSION()
+#define P3_PHASE
+#endif
+
+__host__ __device__ __forceinline__ i32 mul24(i32 a, i32 b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __mul24(a, b);
+#else
+  return a * b;
+#endif
+}
+
+// inclusive prefix maximum over the 16 lanes of a DPP row
+__host__ __device__ __forceinline__ i32 row_prefix_max(i32 x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  // the DPP operand fused into v_max: a lane without a source (bound_ctrl off) is not written and keeps its value;
+  // s_nop 1 = the two wait states a DPP read needs after a VALU write of the register
+  asm volatile(
+      "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf"
+      : "+v"(x));
+  return x;
+#else
+  i32 o;
+  o = sv::row_shr<1>(x, kVeryNeg);
+  x = o > x ? o : x;
+  o = sv::row_shr<2>(x, kVeryNeg);
+  x = o > x ? o : x;
+  o = sv::row_shr<4>(x, kVeryNeg);
+  x = o > x ? o : x;
+  o = sv::row_shr<8>(x, kVeryNeg);
+  x = o > x ? o : x;
+  return x;
+#endif
+}
+
+// k-th in-edge (among those inside the subgraph) of v, as a row index (rank + 1)
+__host__ __device__ inline u32 poa3_nth_pred(const Poa2Slot& g, u32 v, u32 k, bool full) {
+  const u32 c = g.in_cnt[v];
+  u32 seen = 0;
+  for (u32 i = 0; i < c; ++i) {
+    const u32 t = g.in_tail[v * kPoaMaxIn + i];
+    if (full || g.mark[t]) {
+      if (seen == k) return static_cast<u32>(g.rank_of[t]) + 1;
+      ++seen;
+    }
+  }
+  return 0;
+}
+
+// Descriptor of predecessor row `pr` for the row whose computed-row index is cur_idx: band start | ring slot << 16,
+// kDescMiss if the row is no longer in the ring.  bi_cur / bi_prev: (band start | computed index << 16) of row pr as the
+// current / the previous 16-row block holds it.
+__host__ __device__ __forceinline__ u32 poa3_desc(u32 pr, u32 r0, u32 cur_idx, u32 bi_cur, u32 bi_prev) {
+  const bool in_cur = pr >= r0 + 1;
+  const bool in_prev = !in_cur && pr + 16 >= r0 + 1;
+  const u32 pbi = in_cur ? bi_cur : bi_prev;
+  const bool miss = !(in_cur || in_prev) || ((cur_idx - (pbi >> 16)) & 0xFFFFu) > static_cast<u32>(kRing3);
+  return (pbi & 0xFFFFu) | (((pbi >> 16) & (kRing3 - 1)) << 16) | (miss ? kDescMiss : 0u);
+}
+
+// ---- banded NW of one layer per group (four windows in lockstep) ---------------------------------------------------
+// Group-uniform inputs: act (this group aligns a layer now), nn (graph nodes), full, the layer.  Outputs (group-uniform):
+// best_row (0: the last column is in no end node's band).
+__host__ __device__ P3_PHASE inline void poa3_dp(const Poa3Args& A, Poa3Lds& S, const Poa2Slot& g, bool act, u32 nn, bool full,
+                                        const PoaLayer* Lp, u32 len, i32 lb, i32 span, u32& best_row,
+                                        unsigned long long& c_full, unsigned long long& c_band) {
+  const int lane = sv::lane();
+  const int gl = lane & 15, gbase = lane & 48;
+  Poa3Group& Sg = S.g[lane >> 4];
+  i16* ring16 = reinterpret_cast<i16*>(Sg.u.ring32);
+  const u32 w = len + 1;
+  const i32 gp = A.gp;
+  // -inf pads of the ring rows (the union is reused by the traceback / AddAlignment of the previous layer)
+  for (int idx = gl; idx < kRing3 * 2 * kPad3; idx += 16) {
+    const int r = idx / (2 * kPad3), c = idx % (2 * kPad3);
+    ring16[r * kStride3 + (c < kPad3 ? c : 64 + c)] = static_cast<i16>(kNegInf16);
+  }
+  lds_order();
+  // what a candidate adds to (predecessor cell << 6): (match | mismatch | gap) << 6, + 32 for a diagonal, + 15 - in-edge
+  const i32 mD15 = A.m * 64 + 32 + 15, nD15 = A.n_ * 64 + 32 + 15, gV15 = gp * 64 + 15;
+  i32 best_score = -0x7FFFFFFF;
+  best_row = 0;
+  u32 marked_before = 0;
+  int m_bi_prev = 0;
+  const u32 max_nn = static_cast<u32>(sv::wave_max(act ? static_cast<int>(nn) : 0));
+  // the layer's band guide in registers (poa_layer_center without its loads)
+  const u32* wayp = reinterpret_cast<const u32*>(Lp->way);
+  const u32 way0 = wayp[0], way1 = wayp[1], way2 = wayp[2], way3 = wayp[3];
+  auto way_at = [&](i32 idx) -> i32 {
+    const u32 ws = idx < 4 ? (idx < 2 ? way0 : way1) : (idx < 6 ? way2 : way3);
+    return static_cast<i32>((ws >> (16 * (idx & 1))) & 0xFFFFu);
+  };
+  auto center = [&](i32 x) -> i32 {
+    x = x < 0 ? 0 : (x > span ? span : x);
+    const i32 seg = (x * 8) / (span > 0 ? span : 1);
+    const i32 sg = seg > 7 ? 7 : seg;
+    const i32 x0 = (sg * span) / 8, x1 = ((sg + 1) * span) / 8;
+    const i32 wa = sg == 0 ? 0 : way_at(sg - 1);
+    const i32 wb = sg == 7 ? static_cast<i32>(len) : way_at(sg);
+    return wa + (x - x0) * (wb - wa) / (x1 > x0 ? x1 - x0 : 1);
+  };
+  // Metadata of a block's 16 rows, one row per lane of the group, is a chain of dependent gathers (order -> node
+  // fields and in-edge tails -> ranks of the tails).  The chain of block b + 1 is issued in three stages spread over
+  // the row loop of block b, so its latency hides behind four rows of DP per stage.
+  bool nx_ok = false;
+  int nx_v = 0;
+  u32 nx_marked = 0, nx_code = 0, nx_outc = 1, nx_c = 0, nx_bpos = 0, nx_t01 = 0, nx_t23 = 0;
+  u32 nx_rk0 = 0, nx_rk1 = 0, nx_rk2 = 0, nx_rk3 = 0, nx_m0 = 1, nx_m1 = 1, nx_m2 = 1, nx_m3 = 1;
+  auto stage1 = [&](u32 rbase) {
+    nx_ok = act && rbase + static_cast<u32>(gl) < nn;
+    nx_v = nx_ok ? static_cast<int>(g.order[rbase + gl]) : 0;
+  };
+  auto stage2 = [&]() {
+    nx_marked = 0;
+    if (nx_ok) {
+      nx_marked = full ? 1u : g.mark[nx_v];
+      nx_code = g.code[nx_v];
+      nx_outc = full ? g.out_cnt[nx_v] : g.sub_out[nx_v];
+      nx_c = g.in_cnt[nx_v];
+      nx_bpos = g.bpos[nx_v];
+      const u32* tp = reinterpret_cast<const u32*>(g.in_tail + static_cast<size_t>(nx_v) * kPoaMaxIn);
+      nx_t01 = tp[0];
+      nx_t23 = tp[1];
+    }
+  };
+  auto stage3 = [&]() {
+    if (nx_ok && nx_marked) {  // tails beyond the in-degree are stale memory: clamp them to node 0
+      const u32 t0 = nx_c > 0 ? nx_t01 & 0xFFFFu : 0u, t1 = nx_c > 1 ? nx_t01 >> 16 : 0u;
+      const u32 t2 = nx_c > 2 ? nx_t23 & 0xFFFFu : 0u, t3 = nx_c > 3 ? nx_t23 >> 16 : 0u;
+      nx_rk0 = g.rank_of[t0];
+      nx_rk1 = g.rank_of[t1];
+      nx_rk2 = g.rank_of[t2];
+      nx_rk3 = g.rank_of[t3];
+      if (!full) {  // (the values are only looked at when the block starts: no wait for them here)
+        nx_m0 = g.mark[t0];
+        nx_m1 = g.mark[t1];
+        nx_m2 = g.mark[t2];
+        nx_m3 = g.mark[t3];
+      }
+    }
+  };
+  stage1(0);
+  stage2();
+  stage3();
+  for (u32 r0 = 0; r0 < max_nn; r0 += 16) {
+    // ---- the block's 16 rows, one per lane of the group: metadata, traceback row table, predecessor descriptors ----
+    const int m_v = nx_v;
+    int m_np = 0, m_code = 0, m_outc = 1, m_marked = 0, m_b = 0;
+    u32 p0 = 0, p1 = 0, p2 = 0, p3 = 0;
+    if (nx_ok) {
+      m_marked = nx_marked ? 1 : 0;
+      if (m_marked) {
+        m_code = static_cast<int>(nx_code);
+        m_outc = static_cast<int>(nx_outc);
+        auto take = [&](u32 pr) {
+          if (m_np == 0) p0 = pr;
+          else if (m_np == 1) p1 = pr;
+          else if (m_np == 2) p2 = pr;
+          else if (m_np == 3) p3 = pr;
+          ++m_np;
+        };
+        if (nx_c > 0 && (full || nx_m0)) take(nx_rk0 + 1);
+        if (nx_c > 1 && (full || nx_m1)) take(nx_rk1 + 1);
+        if (nx_c > 2 && (full || nx_m2)) take(nx_rk2 + 1);
+        if (nx_c > 3 && (full || nx_m3)) take(nx_rk3 + 1);
+        for (u32 k = 4; k < nx_c; ++k) {  // rare
+          const u32 t = g.in_tail[m_v * kPoaMaxIn + k];
+          if (full || g.mark[t]) take(static_cast<u32>(g.rank_of[t]) + 1);
+        }
+        i32 b = center(static_cast<i32>(nx_bpos) - lb) - 32;
+        const i32 bmax = static_cast<i32>(w) - 64;
+        b = b > bmax ? bmax : b;
+        b = b < 0 ? 0 : b;
+        m_b = b;
+      }
+      uint4 t;
+      t.x = static_cast<u32>(m_b) | (static_cast<u32>(m_v) << 16);
+      t.y = static_cast<u32>(m_np);
+      t.z = p0 | (p1 << 16);
+      t.w = p2 | (p3 << 16);
+      g.tb[r0 + gl + 1] = t;
+    }
+    // ring slots are handed out per COMPUTED row, so rows outside the layer's subgraph do not age the ring
+    const u32 grp = static_cast<u32>(sv::ballot(m_marked != 0) >> gbase) & 0xFFFFu;
+    const u32 idx_in = (marked_before + static_cast<u32>(__builtin_popcount(grp & ((1u << gl) - 1u)))) & 0xFFFFu;
+    marked_before += static_cast<u32>(__builtin_popcount(grp));
+    const int m_bi = m_b | static_cast<int>(idx_in << 16);
+    if (gl == 0) {  // work counters: rows of this layer's (sub)graph x layer length = the cells spoa's full NW computes
+      const u32 rows = static_cast<u32>(__builtin_popcount(grp));
+      c_full += static_cast<unsigned long long>(rows) * len;
+      c_band += static_cast<unsigned long long>(rows) * (w < 64u ? w : 64u);
+    }
+    u32 desc0 = 0, desc1 = 0, desc2 = 0, desc3 = 0;
+    {
+      const u32 bc0 = static_cast<u32>(sv::bperm(m_bi, gbase | static_cast<int>((p0 - 1) & 15u)));
+      const u32 bp0 = static_cast<u32>(sv::bperm(m_bi_prev, gbase | static_cast<int>((p0 - 1) & 15u)));
+      desc0 = m_np == 0 ? kDescVirtual : poa3_desc(p0, r0, idx_in, bc0, bp0);
+      if (sv::any(m_np > 1)) {
+        const u32 bc1 = static_cast<u32>(sv::bperm(m_bi, gbase | static_cast<int>((p1 - 1) & 15u)));
+        const u32 bp1 = static_cast<u32>(sv::bperm(m_bi_prev, gbase | static_cast<int>((p1 - 1) & 15u)));
+        desc1 = poa3_desc(p1, r0, idx_in, bc1, bp1);
+      }
+      if (sv::any(m_np > 2)) {
+        const u32 bc2 = static_cast<u32>(sv::bperm(m_bi, gbase | static_cast<int>((p2 - 1) & 15u)));
+        const u32 bp2 = static_cast<u32>(sv::bperm(m_bi_prev, gbase | static_cast<int>((p2 - 1) & 15u)));
+        desc2 = poa3_desc(p2, r0, idx_in, bc2, bp2);
+        const u32 bc3 = static_cast<u32>(sv::bperm(m_bi, gbase | static_cast<int>((p3 - 1) & 15u)));
+        const u32 bp3 = static_cast<u32>(sv::bperm(m_bi_prev, gbase | static_cast<int>((p3 - 1) & 15u)));
+        desc3 = poa3_desc(p3, r0, idx_in, bc3, bp3);
+      }
+    }
+    // marked | #in-edges << 1 | code << 6 | end node << 8 | band start << 9 | ring slot << 19
+    const int m_w0 = m_marked | ((m_np > 31 ? 31 : m_np) << 1) | (m_code << 6) | ((m_outc == 0 ? 1 : 0) << 8) | (m_b << 9) |
+                     static_cast<int>((idx_in & (kRing3 - 1)) << 19);
+    u32 W0n = static_cast<u32>(sv::bperm(m_w0, gbase));  // row 0's words; row ri + 1's are fetched during row ri
+    u32 d0n = static_cast<u32>(sv::bperm(static_cast<int>(desc0), gbase));
+    // ---- the rows, in order; row ri of every group in the same iteration ----
+    auto do_row = [&](int ri) {
+      P3_MARK("row_begin");
+      const int src = gbase | ri;
+      const u32 W0 = W0n;
+      u32 d = d0n;
+      W0n = static_cast<u32>(sv::bperm(m_w0, gbase | ((ri + 1) & 15)));
+      d0n = static_cast<u32>(sv::bperm(static_cast<int>(desc0), gbase | ((ri + 1) & 15)));
+      const bool actv = (W0 & 1u) != 0;
+      if (!sv::any(actv)) return;
+      const u32 np = (W0 >> 1) & 31u;
+      const u32 npe = np ? np : 1u;  // no in-edge inside the subgraph: the virtual start row
+      const u32 vc = (W0 >> 6) & 3u;
+      const bool endn = ((W0 >> 8) & 1u) != 0;
+      const i32 b = static_cast<i32>((W0 >> 9) & 1023u);
+      const u32 slot = (W0 >> 19) & 15u;
+      const u32 row = r0 + static_cast<u32>(ri) + 1;
+      const i32 j0 = b + 4 * gl;
+      // the layer's codes under the lane's four columns (column j compares with position j - 1)
+      const u32 sa = static_cast<u32>(3 + j0);
+      const u32* sq = reinterpret_cast<const u32*>(Sg.seq_pad);
+      const u32 chars = funnel_shr(sq[(sa >> 2) + 1], sq[sa >> 2], 8u * (sa & 3u));
+      i32 subD[4], best[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) subD[t] = ((chars >> (8 * t)) & 0xFFu) == vc ? mD15 : nD15;
+      // five adjacent cells of predecessor row `dd` starting under this lane's column j0 - 1.  `pk` = the in-edge's row as
+      // the row's owner lane holds it: only looked at when the row has left the LDS ring (one row in ~10^5: a long
+      // bubble ahead of it) — then the cells come from the int16 copy every row leaves in HBM.
+      auto pred_cells = [&](u32 dd, bool valid, u32 pk, i32(&cell)[5]) {
+        const i32 pb = static_cast<i32>(dd & 0xFFFFu);
+        const u32 pslot = (dd >> 16) & 15u;
+        i32 start = j0 - pb - 1;
+        start = start < -5 ? -5 : (start > 64 ? 64 : start);
+        const u32 base = pslot * kStride3 + kPad3 + static_cast<u32>(start);
+        const u32 dw = base >> 1, par16 = (base & 1u) * 16u;
+        const u32 x0 = Sg.u.ring32[dw], x1 = Sg.u.ring32[dw + 1], x2 = Sg.u.ring32[dw + 2];
+        const u32 c01 = funnel_shr(x1, x0, par16), c23 = funnel_shr(x2, x1, par16), c4 = x2 >> par16;
+        cell[0] = sext16(c01);
+        cell[1] = sext16(c01 >> 16);
+        cell[2] = sext16(c23);
+        cell[3] = sext16(c23 >> 16);
+        cell[4] = sext16(c4);
+        const bool lost = valid && (dd & kDescMiss) != 0;
+        if (sv::any(lost)) {
+          P3_NO_IF_CONVERSION();
+          const u32 prow = static_cast<u32>(sv::bperm(static_cast<int>(pk), src));
+          sv::sync();  // the rows' stores have landed
+#if !defined(__HIP_DEVICE_COMPILE__)
+          if (lost && gl == 0) ++g_emu_lost_rows;
+#endif
+          if (lost) {
+            const i32 pbx = static_cast<i32>(g.tb[prow].x & 0xFFFFu);
+            const i16* hrow = g.Hs + static_cast<size_t>(prow) * 64;
+#pragma unroll
+            for (int u = 0; u < 5; ++u) {
+              const i32 c = j0 - pbx - 1 + u;
+              cell[u] = (c >= 0 && c < 64) ? static_cast<i32>(hrow[c]) : kNegInf16;
+            }
+          }
+        }
+      };
+      P3_MARK("edges_begin");
+      {  // in-edge 0 (or the virtual start row): every computed row has it
+        i32 cell[5];
+        pred_cells(d, actv, p0, cell);
+        const bool virt = (d & kDescVirtual) != 0;
+        if (sv::any(actv && virt)) {  // H[0][j] = j * g
+          P3_NO_IF_CONVERSION();
+#pragma unroll
+          for (int u = 0; u < 5; ++u) {
+            const i32 jc = j0 - 1 + u;
+            const i32 vcell = jc >= 0 ? mul24(jc, gp) : kNegInf16;
+            cell[u] = virt ? vcell : cell[u];
+          }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const i32 D = cell[t] * 64 + subD[t];
+          const i32 V = cell[t + 1] * 64 + gV15;
+          best[t] = D > V ? D : V;
+        }
+      }
+      if (sv::any(actv && npe > 1u)) {
+        P3_NO_IF_CONVERSION();
+        for (u32 k = 1;; ++k) {
+          const bool vk = actv && k < npe;
+          if (!sv::any(vk)) break;
+          u32 prk = k == 1 ? p1 : (k == 2 ? p2 : p3);
+          if (k == 1) d = static_cast<u32>(sv::bperm(static_cast<int>(desc1), src));
+          else if (k == 2) d = static_cast<u32>(sv::bperm(static_cast<int>(desc2), src));
+          else if (k == 3) d = static_cast<u32>(sv::bperm(static_cast<int>(desc3), src));
+          else {  // rare: the row's owner looks the in-edge up, the group resolves its ring slot
+            prk = 0;
+            if (vk && gl == ri) prk = poa3_nth_pred(g, static_cast<u32>(m_v), k, full);
+            prk = static_cast<u32>(sv::bperm(static_cast<int>(prk), src));
+            const int sl = gbase | static_cast<int>((prk - 1) & 15u);
+            const u32 bc = static_cast<u32>(sv::bperm(m_bi, sl));
+            const u32 bp = static_cast<u32>(sv::bperm(m_bi_prev, sl));
+            const u32 cur_idx = static_cast<u32>(sv::bperm(m_bi, src)) >> 16;
+            d = poa3_desc(prk, r0, cur_idx, bc, bp);
+          }
+          i32 cell[5];
+          pred_cells(d, vk, prk, cell);
+          const i32 ki = static_cast<i32>(k);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const i32 D = cell[t] * 64 + (subD[t] - ki);
+            const i32 V = cell[t + 1] * 64 + (gV15 - ki);
+            const i32 nb = max3(best[t], D, V);
+            best[t] = vk ? nb : best[t];
+          }
+        }
+      }
+      P3_MARK("edges_end");
+      // spoa's traceback priority: diagonal (first in-edge reaching the max), vertical, horizontal
+      const i32 jg0 = mul24(j0, gp);
+      i32 sc[4], y[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        sc[t] = best[t] >> 6;
+        y[t] = sc[t] - (jg0 + t * gp);
+      }
+      y[1] = y[1] > y[0] ? y[1] : y[0];
+      y[2] = y[2] > y[1] ? y[2] : y[1];
+      y[3] = y[3] > y[2] ? y[3] : y[2];
+      const i32 s = row_prefix_max(y[3]);
+      const i32 ex = sv::row_shr<1>(s, kVeryNeg);  // lanes to the left of this one
+      i32 hh[4];
+      u32 codes = 0;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const i32 yt = y[t] > ex ? y[t] : ex;
+        i32 h = yt + (jg0 + t * gp);
+        const u32 low = static_cast<u32>(best[t]) & 63u;
+        u32 code = 31u - (low & 15u) - ((low & 32u) >> 1);
+        if (h > sc[t]) code = 32u;
+        h = h < kNegInf16 ? kNegInf16 : h;
+        hh[t] = h;
+        codes |= code << (8 * t);
+      }
+      if (actv) {
+        const u32 cell0 = (slot * kStride3 + kPad3) / 2 + 2u * static_cast<u32>(gl);
+        const u32 h01 = (static_cast<u32>(hh[0]) & 0xFFFFu) | (static_cast<u32>(hh[1]) << 16);
+        const u32 h23 = (static_cast<u32>(hh[2]) & 0xFFFFu) | (static_cast<u32>(hh[3]) << 16);
+        Sg.u.ring32[cell0] = h01;
+        Sg.u.ring32[cell0 + 1] = h23;
+        *reinterpret_cast<uint2*>(g.Hs + static_cast<size_t>(row) * 64 + 4 * gl) = uint2{h01, h23};
+        *reinterpret_cast<u32*>(g.BP + static_cast<size_t>(row) * 64 + 4 * gl) = codes;
+      }
+      if (sv::any(actv && endn)) {  // an end node: score of the last column if the band has it
+        const i32 idx = static_cast<i32>(w) - 1 - b;
+        const int sel = idx & 3;
+        const i32 mine = sel == 0 ? hh[0] : (sel == 1 ? hh[1] : (sel == 2 ? hh[2] : hh[3]));
+        const i32 sce = sv::bperm(mine, gbase | ((idx >> 2) & 15));
+        if (actv && endn && idx >= 0 && idx < 64 && sce > best_score) {
+          best_score = sce;
+          best_row = row;
+        }
+      }
+      lds_order();
+      P3_MARK("row_end");
+    };
+    // the next block's gather chain, one stage every five rows (beyond the last block every lane is switched off)
+    stage1(r0 + 16);
+    for (int ri = 0; ri < 5; ++ri) do_row(ri);
+    stage2();
+    for (int ri = 5; ri < 10; ++ri) do_row(ri);
+    stage3();
+    for (int ri = 10; ri < 16; ++ri) do_row(ri);
+    m_bi_prev = m_bi;
+  }
+}
+
+// ---- traceback of the four groups in lockstep ----------------------------------------------------------------------
+__host__ __device__ P3_PHASE inline void poa3_traceback(const Poa3Args& A, Poa3Lds& S, const Poa2Slot& g, bool act, u32 nn, bool full,
+                                               u32 len, u32 best_row, u32& bad, u32& band_hit) {
+  const int lane = sv::lane();
+  const int gl = lane & 15;
+  Poa3Group& Sg = S.g[lane >> 4];
+  const u32 w = len + 1;
+  bad = 0;
+  band_hit = 0;
+  u32 i = act ? best_row : 0;
+  i32 j = static_cast<i32>(w) - 1;
+  bool done = !act || i == 0;
+  u32 cur_blk = 0xFFFFFFFFu;
+  u32 steps = 0;
+  const u32 max_steps = A.nmax + A.lmax + 2;
+  const u32 n_rows_total = nn + 1;
+  // A block (32 rows of backpointers + their row table) is fetched into registers one block AHEAD of the walk — the
+  // walk moves up through the rows, so while it is inside block b the loads of block b - 1 are in flight — and only
+  // copied into the group's LDS when the walk gets there: no global-memory round trip on the walk's critical path.
+  // (named registers, not arrays: an array that lives across the walk loop ends up in scratch memory)
+  static_assert(kTbRows == 32, "eight 16-byte chunks of backpointers and two table rows per lane");
+  uint4 pb0{}, pb1{}, pb2{}, pb3{}, pb4{}, pb5{}, pb6{}, pb7{}, pt0{}, pt1{};
+  u32 pf_blk = 0xFFFFFFFFu;
+  auto fetch = [&](u32 b) {
+    const u32 row0 = b * kTbRows + 1;
+    const u32 nrows = n_rows_total - row0 < static_cast<u32>(kTbRows) ? n_rows_total - row0 : static_cast<u32>(kTbRows);
+    const uint4* bsrc = reinterpret_cast<const uint4*>(g.BP + static_cast<size_t>(row0) * 64);
+    const u32 ugl = static_cast<u32>(gl);
+    auto chunk = [&](u32 it) -> uint4 {
+      const u32 c = it * 16 + ugl;  // 16-byte chunk: row c >> 2
+      return bsrc[(c >> 2) < nrows ? c : 0];
+    };
+    pb0 = chunk(0);
+    pb1 = chunk(1);
+    pb2 = chunk(2);
+    pb3 = chunk(3);
+    pb4 = chunk(4);
+    pb5 = chunk(5);
+    pb6 = chunk(6);
+    pb7 = chunk(7);
+    pt0 = g.tb[row0 + (ugl < nrows ? ugl : 0)];
+    pt1 = g.tb[row0 + (16 + ugl < nrows ? 16 + ugl : 0)];
+    pf_blk = b;
+  };
+  while (sv::any(!done)) {
+    P3_MARK("tb_top");
+    const u32 blk = done ? cur_blk : (i - 1) >> 5;
+    const bool need = !done && blk != cur_blk;
+    if (sv::any(need)) {
+      lds_order();
+      if (need) {
+        if (pf_blk != blk) fetch(blk);
+        uint4* bdst = reinterpret_cast<uint4*>(Sg.u.tr.bp) + gl;
+        bdst[0] = pb0;
+        bdst[16] = pb1;
+        bdst[32] = pb2;
+        bdst[48] = pb3;
+        bdst[64] = pb4;
+        bdst[80] = pb5;
+        bdst[96] = pb6;
+        bdst[112] = pb7;
+        u32* tdst = Sg.u.tr.tb + 3 * gl;
+        tdst[0] = pt0.x;
+        tdst[1] = pt0.z;
+        tdst[2] = pt0.w;
+        tdst[48] = pt1.x;
+        tdst[49] = pt1.z;
+        tdst[50] = pt1.w;
+        cur_blk = blk;
+        if (blk > 0) fetch(blk - 1);
+      }
+      lds_order();
+    }
+    P3_MARK("tb_step");
+    if (!done) {
+      if (++steps > max_steps) {
+        bad = 6;
+        done = true;
+      } else {
+        const u32 l = (i - 1) & (kTbRows - 1);
+        const u32 x = Sg.u.tr.tb[l * 3], z01 = Sg.u.tr.tb[l * 3 + 1];  // one ds_read2
+        const i32 bt = static_cast<i32>(x & 0xFFFFu);
+        const u32 node = x >> 16;
+        const i32 idx = j - bt;
+        if (idx < 0 || idx >= 64) {  // the path left the stored band: the alignment does not fit this band width
+          band_hit = 1;
+          done = true;
+        } else {
+          if ((idx < 2 && bt > 0) || (idx > 64 - 3 && bt + 64 < static_cast<i32>(w))) band_hit = 1;
+          const u32 code = Sg.u.tr.bp[l * 64 + static_cast<u32>(idx)];
+          if (code == 32u) {
+            if (j == 0) {
+              bad = 6;
+              done = true;
+            } else {
+              --j;  // insertion: pos_node[j] stays kNone
+            }
+          } else {
+            const u32 k = code & 15u;
+            u32 pr;
+            if (k < 2) pr = (z01 >> (16 * k)) & 0xFFFFu;
+            else if (k < 4) pr = (Sg.u.tr.tb[l * 3 + 2] >> (16 * (k - 2))) & 0xFFFFu;
+            else pr = poa3_nth_pred(g, node, k, full);
+            if (code < 16u) {
+              if (j == 0) {
+                bad = 6;
+                done = true;
+              } else {
+                --j;
+                if (gl == 0) g.pos_node[j] = static_cast<u16>(node);
+              }
+            }
+            if (!done) {
+              i = pr;
+              if (i == 0) done = true;  // on the virtual row only insertions remain: pos_node already says kNone
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+// ---- wave-wide per-window steps (as in poa2.hip) -------------------------------------------------------------------
+__host__ __device__ inline void poa3_copy_backbone(const Poa3Args& A, const PoaWindow& win, const PoaLayer& bb, u8* out,
+                                                   u32* out_len) {
+  const int lane = sv::lane();
+  const u32 n = bb.len < win.out_cap ? bb.len : win.out_cap;
+  for (u32 i = lane; i < n; i += 64) out[i] = static_cast<u8>(poa_layer_code(A.src, bb, i));
+  if (lane == 0) *out_len = n;
+}
+
+// window set-up: 0 = backbone returned (< 3 sequences), 4 = beyond a length limit (backbone returned), 1 = graph built
+__host__ __device__ P3_PHASE inline u32 poa3_init_window(const Poa3Args& A, const PoaWindow& win, Poa2Slot& g, u32 wi, u32& n_nodes,
+                                                u32& n_eff) {
+  const int lane = sv::lane();
+  const PoaLayer bb = A.layers[win.layer_first];
+  const u32 blen = bb.len;
+  n_eff = win.n_layers;
+  if (A.src.layer_ok) {  // layers dropped by racon's mean-quality filter do not count as sequences of the window
+    u32 cnt = 0;
+    for (u32 i = 1 + lane; i < win.n_layers; i += 64) cnt += A.src.layer_ok[win.layer_first + i] ? 1u : 0u;
+    n_eff = 1 + sv::wave_sum(cnt);
+  }
+  n_nodes = 0;
+  if (n_eff < 3) {
+    poa3_copy_backbone(A, win, bb, A.out + win.out_off, A.out_len + wi);
+    return 0;
+  }
+  if (blen == 0 || blen > A.nmax || blen > A.lmax) {
+    poa3_copy_backbone(A, win, bb, A.out + win.out_off, A.out_len + wi);
+    return 4;
+  }
+  // backbone graph (spoa AddAlignment with an empty alignment)
+  n_nodes = blen;
+  for (u32 i = lane; i < blen; i += 64) {
+    g.code[i] = static_cast<u8>(poa_layer_code(A.src, bb, i));
+    g.al_cnt[i] = 0;
+    g.visits[i] = blen >= 2 ? 1 : 0;
+    g.rank_of[i] = static_cast<u16>(i);
+    g.order[i] = static_cast<u16>(i);
+    g.bpos[i] = static_cast<u16>(i);
+    const i32 wgt = poa_layer_weight(A.src, bb, i);
+    if (i > 0) {
+      const i32 wp = poa_layer_weight(A.src, bb, i - 1);
+      g.in_cnt[i] = 1;
+      g.in_tail[i * kPoaMaxIn] = static_cast<u16>(i - 1);
+      g.in_w[i * kPoaMaxIn] = wp + wgt;
+    } else {
+      g.in_cnt[i] = 0;
+    }
+    g.out_cnt[i] = i + 1 < blen ? 1 : 0;
+  }
+  sv::sync();
+  return 1;
+}
+
+// spoa AddAlignment, one sequence position per lane, + the incremental order rebuild.  Returns 0 or the failure code.
+__host__ __device__ P3_PHASE inline u32 poa3_add_alignment(const Poa3Args& A, Poa2Slot& g, Poa3Group& Sg, const PoaLayer& L,
+                                                  u32& n_nodes, unsigned long long& t_add, unsigned long long& t_ord) {
+  const int lane = sv::lane();
+  const u32 len = L.len;
+  const u32 nmax = A.nmax, lmax = A.lmax;
+  const u32 lb = L.begin;
+  unsigned long long t0 = sv::clock();
+  const u32 n_old = n_nodes;
+  u32 first_p = 0xFFFFFFFFu;
+  for (u32 p0 = 0; p0 < len && first_p == 0xFFFFFFFFu; p0 += 64) {
+    const u32 p = p0 + lane;
+    const unsigned long long bal = sv::ballot(p < len && g.pos_node[p] != kNone3);
+    if (bal) first_p = p0 + static_cast<u32>(__builtin_ctzll(bal));
+  }
+  // New nodes anchored after a column (aligned group) go after ALL its members; the unaligned prefix goes
+  // before all members of the first column.
+  u32 carry_slot = n_old, carry_b = lb;
+  if (first_p != 0xFFFFFFFFu) {
+    const u32 an = g.pos_node[first_p];
+    u32 r = g.rank_of[an];
+    const u32 ac = g.al_cnt[an];
+    for (u32 k = 0; k < ac; ++k) {
+      const u32 rk = g.rank_of[g.al[an * 4 + k]];
+      r = rk < r ? rk : r;
+    }
+    carry_slot = r;
+    carry_b = g.bpos[an];
+  }
+  u32 total_new = 0;
+  u32 ok = 1, why = 3;
+  for (u32 p0 = 0; p0 < len; p0 += 64) {
+    const u32 p = p0 + lane;
+    const bool valid = p < len;
+    const u32 an = valid ? g.pos_node[p] : kNone3;
+    const u32 letter = valid ? Sg.seq_pad[4 + p] : 0u;
+    const bool has = valid && an != kNone3;
+    u32 tgt = kNone3, gslot = 0, gb = 0, ac = 0;
+    if (has) {
+      u32 rmax = g.rank_of[an];
+      ac = g.al_cnt[an];
+      if (g.code[an] == letter) tgt = an;
+      for (u32 k = 0; k < ac; ++k) {
+        const u32 kt = g.al[an * 4 + k];
+        const u32 rk = g.rank_of[kt];
+        rmax = rk > rmax ? rk : rmax;
+        if (tgt == kNone3 && g.code[kt] == letter) tgt = kt;
+      }
+      gslot = rmax + 1;
+      gb = g.bpos[an];
+    }
+    // order slot / backbone coordinate of the last aligned position at or before p
+    const unsigned long long bal = sv::ballot(has);
+    const unsigned long long below = bal & (lane == 63 ? ~0ULL : ((2ULL << lane) - 1ULL));
+    const int src = below ? 63 - __builtin_clzll(below) : 0;
+    const u32 s_sh = static_cast<u32>(sv::bperm(static_cast<int>(gslot), src));
+    const u32 b_sh = static_cast<u32>(sv::bperm(static_cast<int>(gb), src));
+    const u32 fslot = below ? s_sh : carry_slot;
+    const u32 fb = below ? b_sh : carry_b;
+    {
+      const int top = bal ? 63 - __builtin_clzll(bal) : 0;
+      const u32 cs = static_cast<u32>(sv::rl(static_cast<int>(gslot), top));
+      const u32 cb = static_cast<u32>(sv::rl(static_cast<int>(gb), top));
+      if (bal) {
+        carry_slot = cs;
+        carry_b = cb;
+      }
+    }
+    const bool is_new = valid && tgt == kNone3;
+    const unsigned long long nb = sv::ballot(is_new);
+    const u32 cnt = static_cast<u32>(__builtin_popcountll(nb));
+    if (n_old + total_new + cnt > nmax || total_new + cnt > lmax) {
+      ok = 0;
+      why = 2;
+      break;
+    }
+    if (is_new) {
+      const u32 t = total_new + static_cast<u32>(__builtin_popcountll(nb & ((1ULL << lane) - 1ULL)));
+      const u32 id = n_old + t;
+      tgt = id;
+      g.code[id] = static_cast<u8>(letter);
+      g.in_cnt[id] = 0;
+      g.out_cnt[id] = 0;
+      g.visits[id] = 0;
+      g.new_slot[t] = static_cast<u16>(fslot);
+      g.bpos[id] = static_cast<u16>(fb);
+      u32 c2 = 0;
+      if (has) {  // joins an's aligned group
+        for (u32 k = 0; k < ac; ++k) {
+          const u32 kt = g.al[an * 4 + k];
+          const u32 ck = g.al_cnt[kt];
+          if (ck < 4) {
+            g.al[kt * 4 + ck] = static_cast<u16>(id);
+            g.al_cnt[kt] = static_cast<u8>(ck + 1);
+          }
+          if (c2 < 4) g.al[id * 4 + c2++] = static_cast<u16>(kt);
+        }
+        if (ac < 4) {
+          g.al[an * 4 + ac] = static_cast<u16>(id);
+          g.al_cnt[an] = static_cast<u8>(ac + 1);
+        }
+        if (c2 < 4) g.al[id * 4 + c2++] = static_cast<u16>(an);
+      }
+      g.al_cnt[id] = static_cast<u8>(c2);
+    }
+    total_new += cnt;
+    if (valid) {
+      Sg.u.tgt[p] = static_cast<u16>(tgt);
+      if (len >= 2) g.visits[tgt] += 1;
+    }
+  }
+  sv::sync();
+  if (ok) {
+    for (u32 p0 = 0; p0 < len; p0 += 64) {
+      const u32 p = p0 + lane;
+      bool okl = true;
+      if (p >= 1 && p < len)
+        okl = poa_add_edge(g, Sg.u.tgt[p - 1], Sg.u.tgt[p],
+                           static_cast<i32>(static_cast<u8>(poa_layer_weight(A.src, L, p - 1))) +
+                               static_cast<i32>(static_cast<u8>(poa_layer_weight(A.src, L, p))));
+      if (sv::ballot(!okl)) {
+        ok = 0;
+        why = 3;
+      }
+    }
+  }
+  sv::sync();
+  if (!ok) return why;
+  const u32 n_new = total_new;
+  n_nodes = n_old + n_new;
+  t_add += sv::clock() - t0;
+  t0 = sv::clock();
+  // order rebuild: old rank r -> r + #(new slots <= r); t-th new node -> slot_t + t
+  if (n_new) {
+    for (u32 r = lane; r < n_old; r += 64) {
+      u32 lo = 0, hi = n_new;  // upper_bound(new_slot, r)
+      while (lo < hi) {
+        const u32 mid = (lo + hi) >> 1;
+        if (g.new_slot[mid] <= r) lo = mid + 1;
+        else hi = mid;
+      }
+      g.order2[r + lo] = g.order[r];
+    }
+    for (u32 t = lane; t < n_new; t += 64) g.order2[static_cast<u32>(g.new_slot[t]) + t] = static_cast<u16>(n_old + t);
+    sv::sync();
+    for (u32 r = lane; r < n_nodes; r += 64) {
+      const u32 v = g.order2[r];
+      g.order[r] = static_cast<u16>(v);
+      g.rank_of[v] = static_cast<u16>(r);
+    }
+    sv::sync();
+  }
+  t_ord += sv::clock() - t0;
+  return 0;
+}
+
+// Consensus of a finished window: spoa's heaviest bundle with the node scores in the WAVE's LDS (all four groups'
+// buffers: the DP of every window of the wave is over by now), first four in-edges of 64 nodes at a time in registers
+// (as poa2_consensus), then branch completion + racon's coverage trim on lane 0 and a parallel output copy.
+__host__ __device__ P3_PHASE inline void poa3_consensus(Poa2Slot& g, u32 n_nodes, u32 nmax, const PoaWindow& win, int trim, Poa3Lds& S,
+                                               u8* out, u32* out_len) {
+  const int lane = sv::lane();
+  constexpr u32 kCap = sizeof(Poa3Lds) / 4;
+  i32* lsc = reinterpret_cast<i32*>(&S);
+  i32 maxn = -1;
+  if (n_nodes > kCap) {
+    if (lane == 0) maxn = poa_consensus_scores_lane0(g, n_nodes);
+    maxn = sv::rfl(maxn);
+  } else {
+    i32 max_sc = 0;
+    const u32 nn = n_nodes;
+    for (u32 r0 = 0; r0 < nn; r0 += 64) {
+      const u32 rows = nn - r0 < 64 ? nn - r0 : 64;
+      int m_it = 0, m_c = 0, m_t01 = 0, m_t23 = 0, m_w0 = 0, m_w1 = 0, m_w2 = 0, m_w3 = 0;
+      if (static_cast<u32>(lane) < rows) {
+        m_it = g.order[r0 + lane];
+        m_c = g.in_cnt[m_it];
+        const u16* tp = g.in_tail + static_cast<size_t>(m_it) * kPoaMaxIn;
+        const i32* wp = g.in_w + static_cast<size_t>(m_it) * kPoaMaxIn;
+        m_t01 = static_cast<int>(static_cast<u32>(tp[0]) | (static_cast<u32>(tp[1]) << 16));
+        m_t23 = static_cast<int>(static_cast<u32>(tp[2]) | (static_cast<u32>(tp[3]) << 16));
+        m_w0 = wp[0];
+        m_w1 = wp[1];
+        m_w2 = wp[2];
+        m_w3 = wp[3];
+      }
+      for (u32 l = 0; l < rows; ++l) {
+        const int li = static_cast<int>(l);
+        const u32 it = static_cast<u32>(sv::rl(m_it, li));
+        const u32 c = static_cast<u32>(sv::rl(m_c, li));
+        const u32 t01 = static_cast<u32>(sv::rl(m_t01, li)), t23 = static_cast<u32>(sv::rl(m_t23, li));
+        const i32 w0 = sv::rl(m_w0, li), w1 = sv::rl(m_w1, li), w2 = sv::rl(m_w2, li), w3 = sv::rl(m_w3, li);
+        i32 sc = -1, pd = -1, pd_sc = 0;
+        for (u32 k = 0; k < c; ++k) {
+          i32 wgt, t;
+          if (k < 4) {
+            t = static_cast<i32>(((k < 2 ? t01 : t23) >> (16 * (k & 1))) & 0xFFFFu);
+            wgt = k == 0 ? w0 : (k == 1 ? w1 : (k == 2 ? w2 : w3));
+          } else {
+            wgt = g.in_w[static_cast<size_t>(it) * kPoaMaxIn + k];
+            t = static_cast<i32>(g.in_tail[static_cast<size_t>(it) * kPoaMaxIn + k]);
+          }
+          const i32 st = lsc[t];
+          if (sc < wgt || (sc == wgt && pd_sc <= st)) {
+            sc = wgt;
+            pd = t;
+            pd_sc = st;
+          }
+        }
+        if (pd != -1) sc += pd_sc;
+        lds_order();  // every lane has read the scores it needs before this node's is written
+        if (lane == 0) {
+          lsc[it] = sc;
+          g.scores[it] = sc;
+          g.preds[it] = pd;
+        }
+        lds_order();
+        if (maxn == -1 || max_sc < sc) {
+          maxn = static_cast<i32>(it);
+          max_sc = sc;
+        }
+      }
+    }
+  }
+  sv::sync();  // scores / predecessors in HBM visible to lane 0's branch completion and traceback
+  u32 cl = 0;
+  i32 begin = 0, end = -1;
+  if (lane == 0) poa_consensus_trace_lane0(g, n_nodes, nmax, win, trim, maxn, &cl, &begin, &end);
+  cl = static_cast<u32>(sv::rfl(static_cast<int>(cl)));
+  begin = sv::rfl(begin);
+  end = sv::rfl(end);
+  sv::sync();  // g.stack
+  i32 n_out = end - begin + 1;
+  if (n_out < 0) n_out = 0;
+  if (static_cast<u32>(n_out) > win.out_cap) n_out = static_cast<i32>(win.out_cap);
+  for (i32 p = lane; p < n_out; p += 64) out[p] = g.code[g.stack[cl - 1 - static_cast<u32>(begin + p)]];
+  if (lane == 0) *out_len = static_cast<u32>(n_out);
+}
+
+// ---- one persistent wave: takes four windows at a time ------------------------------------------------------------
+enum : u32 { kIdle = 0, kRunning = 1, kLayersDone = 2, kFinal = 3, kFailed = 4 };
+
+__host__ __device__ inline void poa3_wave(const Poa3Args& A, Poa3Lds& S, u32 slot0) {
+  const int lane = sv::lane();
+  const int q = lane >> 4;
+  unsigned long long t_sub = 0, t_dp = 0, t_tb = 0, t_add = 0, t_ord = 0, t_cons = 0, t0 = 0;
+  unsigned long long c_full = 0, c_band = 0;
+  const Poa2Slot gq = poa2_carve(A.scratch + static_cast<size_t>(slot0 + q) * A.slot_bytes, A.nmax, A.lmax, 64, true);
+  for (;;) {
+    u32 first = 0;
+    if (lane == 0) first = sv::atomic_add(A.next, static_cast<u32>(kG));
+    first = static_cast<u32>(sv::rfl(static_cast<int>(first)));
+    if (first >= A.n_windows) break;
+    // group-uniform state of the lane's window
+    const u32 pos = first + static_cast<u32>(q);
+    const bool have = pos < A.n_windows;
+    const u32 wi = have ? (A.sched ? A.sched[pos] : pos) : 0u;
+    const PoaWindow win = A.windows[wi];
+    u32 phase = have ? kRunning : kIdle;
+    u32 status = 0, nn = 0, n_eff = 0, li = 1;
+    auto window_of = [&](int q2, u32& wi2) -> PoaWindow {  // group q2's window as wave-uniform values
+      PoaWindow wq;
+      wq.layer_first = static_cast<u32>(sv::rl(static_cast<int>(win.layer_first), q2 * 16));
+      wq.n_layers = static_cast<u32>(sv::rl(static_cast<int>(win.n_layers), q2 * 16));
+      wq.out_off = static_cast<u32>(sv::rl(static_cast<int>(win.out_off), q2 * 16));
+      wq.out_cap = static_cast<u32>(sv::rl(static_cast<int>(win.out_cap), q2 * 16));
+      wi2 = static_cast<u32>(sv::rl(static_cast<int>(wi), q2 * 16));
+      return wq;
+    };
+    for (int q2 = 0; q2 < kG; ++q2) {
+      if (sv::rl(static_cast<int>(phase), q2 * 16) != static_cast<int>(kRunning)) continue;
+      u32 wi2;
+      const PoaWindow wq = window_of(q2, wi2);
+      Poa2Slot g = poa2_carve(A.scratch + static_cast<size_t>(slot0 + q2) * A.slot_bytes, A.nmax, A.lmax, 64, true);
+      u32 nn2 = 0, ne2 = 0;
+      const u32 r = poa3_init_window(A, wq, g, wi2, nn2, ne2);
+      if (q == q2) {
+        nn = nn2;
+        n_eff = ne2;
+        if (r != 1) {
+          phase = kFinal;
+          status = r;
+        }
+      }
+    }
+    // ---- layers: every window of the wave aligns its next layer in the same round ----
+    for (;;) {
+      bool act = false, full = false;
+      u32 len = 0;
+      i32 lb = 0, span = 0;
+      const PoaLayer* Lp = A.layers;
+      for (int q2 = 0; q2 < kG; ++q2) {
+        if (sv::rl(static_cast<int>(phase), q2 * 16) != static_cast<int>(kRunning)) continue;
+        u32 wi2;
+        const PoaWindow wq = window_of(q2, wi2);
+        u32 liq = static_cast<u32>(sv::rl(static_cast<int>(li), q2 * 16));
+        const u32 nnq = static_cast<u32>(sv::rl(static_cast<int>(nn), q2 * 16));
+        while (liq < wq.n_layers && (A.layers[wq.layer_first + liq].len == 0 ||
+                                     (A.src.layer_ok && !A.src.layer_ok[wq.layer_first + liq])))
+          ++liq;
+        if (liq >= wq.n_layers) {
+          if (q == q2) phase = kLayersDone;
+          continue;
+        }
+        const PoaLayer L = A.layers[wq.layer_first + liq];
+        if (L.len > A.lmax || L.len > static_cast<u32>(kPoa2MaxSeq)) {
+          if (q == q2) {
+            phase = kFailed;
+            status = 4;
+          }
+          continue;
+        }
+        Poa2Slot g = poa2_carve(A.scratch + static_cast<size_t>(slot0 + q2) * A.slot_bytes, A.nmax, A.lmax, 64, true);
+        Poa3Group& Sg = S.g[q2];
+        for (u32 i = lane; i < L.len; i += 64) {
+          Sg.seq_pad[4 + i] = static_cast<u8>(poa_layer_code(A.src, L, i));
+          g.pos_node[i] = static_cast<u16>(kNone3);
+        }
+        if (lane == 0) Sg.seq_pad[3] = 0xFF;
+        const u32 blen = A.layers[wq.layer_first].len;
+        const u32 offset = static_cast<u32>(0.01 * blen);
+        const bool fullq = L.begin < offset && L.end > blen - offset;
+        t0 = sv::clock();
+        if (!fullq) poa_subgraph_marks(g, nnq, A.nmax, L.begin, L.end);
+        t_sub += sv::clock() - t0;
+        if (q == q2) {
+          act = true;
+          full = fullq;
+          len = L.len;
+          lb = static_cast<i32>(L.begin);
+          span = static_cast<i32>(L.end) - static_cast<i32>(L.begin) + 1;
+          Lp = A.layers + wq.layer_first + liq;
+          li = liq;
+        }
+      }
+      if (!sv::any(act)) break;
+      sv::sync();
+      t0 = sv::clock();
+      u32 best_row = 0;
+      poa3_dp(A, S, gq, act, nn, full, Lp, len, lb, span, best_row, c_full, c_band);
+      sv::sync();  // backpointers visible to the traceback
+      t_dp += sv::clock() - t0;
+      t0 = sv::clock();
+      const bool had = act;
+      if (act && best_row == 0) {  // the last column is in no end node's band
+        phase = kFailed;
+        status = kPoaBandHit | (li << 8);
+        act = false;
+      }
+      u32 bad = 0, band_hit = 0;
+      poa3_traceback(A, S, gq, act, nn, full, len, best_row, bad, band_hit);
+      if (act && bad) {
+        phase = kFailed;
+        status = bad | (li << 8);
+        act = false;
+      } else if (act && band_hit) {
+        phase = kFailed;
+        status = kPoaBandHit | (li << 8);
+        act = false;
+      }
+      sv::sync();  // pos_node
+      t_tb += sv::clock() - t0;
+      for (int q2 = 0; q2 < kG; ++q2) {
+        if (!sv::rl(act ? 1 : 0, q2 * 16)) continue;
+        u32 wi2;
+        const PoaWindow wq = window_of(q2, wi2);
+        const u32 liq = static_cast<u32>(sv::rl(static_cast<int>(li), q2 * 16));
+        u32 nnq = static_cast<u32>(sv::rl(static_cast<int>(nn), q2 * 16));
+        const PoaLayer L = A.layers[wq.layer_first + liq];
+        Poa2Slot g = poa2_carve(A.scratch + static_cast<size_t>(slot0 + q2) * A.slot_bytes, A.nmax, A.lmax, 64, true);
+        const u32 why = poa3_add_alignment(A, g, S.g[q2], L, nnq, t_add, t_ord);
+        if (q == q2) {
+          if (why) {
+            phase = kFailed;
+            status = why;
+          } else {
+            nn = nnq;
+          }
+        }
+      }
+      if (had) ++li;
+    }
+    // ---- results ----
+    t0 = sv::clock();
+    for (int q2 = 0; q2 < kG; ++q2) {
+      const u32 ph = static_cast<u32>(sv::rl(static_cast<int>(phase), q2 * 16));
+      if (ph == kIdle) continue;
+      u32 wi2;
+      PoaWindow wq = window_of(q2, wi2);
+      u32 st = static_cast<u32>(sv::rl(static_cast<int>(status), q2 * 16));
+      if (ph == kFailed) {
+        poa3_copy_backbone(A, wq, A.layers[wq.layer_first], A.out + wq.out_off, A.out_len + wi2);
+      } else if (ph == kLayersDone) {
+        Poa2Slot g = poa2_carve(A.scratch + static_cast<size_t>(slot0 + q2) * A.slot_bytes, A.nmax, A.lmax, 64, true);
+        const u32 nnq = static_cast<u32>(sv::rl(static_cast<int>(nn), q2 * 16));
+        wq.n_layers = static_cast<u32>(sv::rl(static_cast<int>(n_eff), q2 * 16));
+        sv::sync();
+        poa3_consensus(g, nnq, A.nmax, wq, A.trim, S, A.out + wq.out_off, A.out_len + wi2);
+        sv::sync();
+        st = 1;
+      }
+      if (lane == 0) A.status[wi2] = st;
+    }
+    t_cons += sv::clock() - t0;
+    sv::sync();
+  }
+  if (A.phase_cycles) {
+    if (lane == 0) {
+      sv::atomic_add(&A.phase_cycles[0], t_sub);
+      sv::atomic_add(&A.phase_cycles[1], t_dp);
+      sv::atomic_add(&A.phase_cycles[2], t_tb);
+      sv::atomic_add(&A.phase_cycles[3], t_add);
+      sv::atomic_add(&A.phase_cycles[4], t_ord);
+      sv::atomic_add(&A.phase_cycles[5], t_cons);
+    }
+    if ((lane & 15) == 0 && c_full) {
+      sv::atomic_add(&A.phase_cycles[6], c_full);
+      sv::atomic_add(&A.phase_cycles[7], c_band);
+    }
+  }
+}
+
+template <int OCC>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void poa3_kernel(const Poa3Args A, u32 n_waves) {
+  __shared__ Poa3Lds lds;
+  if (blockIdx.x >= n_waves) return;
+  poa3_wave(A, lds, blockIdx.x * kG);
+}
+
+struct EmuCall {
+  const Poa3Args* A;
+  Poa3Lds* S;
+};
+void emu_entry(void* p) {
+  EmuCall* c = static_cast<EmuCall*>(p);
+  poa3_wave(*c->A, *c->S, 0);
+}
+
+}  // namespace
+
+void poa_v3_launch(Engine& e, const PoaBatchDev& b) {
+  if (b.n_windows == 0) return;
+  const size_t slot_bytes = poa2_slot_bytes(b.nmax, b.lmax, 64u, true);
+  size_t free_b = 0, total_b = 0;
+  RVN_HIP(hipMemGetInfo(&free_b, &total_b));
+  u32 per_cu = 12;  // waves per CU the LDS footprint allows
+  if (const char* ev = std::getenv("RVN_POA_WAVES_PER_CU")) per_cu = static_cast<u32>(std::atoi(ev));  // occupancy experiments
+  per_cu = per_cu < 1 ? 1 : per_cu;
+  u32 n_waves = std::min<u32>((b.n_windows + kG - 1) / kG, 256 * per_cu);
+  const size_t budget = e.poa2_scratch.cap + free_b / 2;
+  if (static_cast<size_t>(n_waves) * kG * slot_bytes > budget)
+    n_waves = static_cast<u32>(std::max<size_t>(1, budget / (slot_bytes * kG)));
+  unsigned char* d_scratch = e.poa2_scratch.get<unsigned char>(static_cast<size_t>(n_waves) * kG * slot_bytes + 256);
+  RVN_HIP(hipMemsetAsync(b.next, 0, 4, e.stream));
+  Poa3Args A{};
+  A.windows = b.wins;
+  A.n_windows = b.n_windows;
+  A.layers = b.layers;
+  A.src = b.src;
+  A.scratch = d_scratch;
+  A.slot_bytes = slot_bytes;
+  A.nmax = b.nmax;
+  A.lmax = b.lmax;
+  A.m = b.m;
+  A.n_ = b.n;
+  A.gp = b.g;
+  A.trim = b.trim;
+  A.out = b.out;
+  A.out_len = b.out_len;
+  A.status = b.status;
+  A.phase_cycles = b.phase_cycles;
+  A.sched = b.sched;
+  A.next = b.next;
+  RVN_KLAUNCH(kKPoaBanded, (poa3_kernel<3><<<n_waves, 64, 0, e.stream>>>(A, n_waves)));
+}
+
+// The same kernel source on the host, one emulated wave (simt_emu): windows / layers / sources are host arrays.  TEST
+// INFRASTRUCTURE (rvn_poa_banded_emulate); first attempt only — a window that needs a wider band comes back flagged.
+void poa_v3_emulate(const std::vector<PoaWindow>& wins, const std::vector<PoaLayer>& lays, const PoaSrc& src, u32 max_bb,
+                    u32 max_len, int m, int n, int g, int trim, u8* out, u32* out_len, u32* status) {
+  if (wins.empty()) return;
+  Poa3Args A{};
+  A.lmax = std::min<u32>(kPoaMaxSeq, std::max<u32>(64, ((max_len + 63) / 64) * 64));
+  A.nmax = std::min<u32>(8192, std::max<u32>(512, max_bb * 6));
+  A.slot_bytes = poa2_slot_bytes(A.nmax, A.lmax, 64u, true);
+  std::vector<unsigned char> scratch(A.slot_bytes * kG + 256, 0);
+  unsigned long long phase[10] = {};
+  u32 next = 0;
+  A.windows = wins.data();
+  A.n_windows = static_cast<u32>(wins.size());
+  A.layers = lays.data();
+  A.src = src;
+  A.scratch = scratch.data();
+  A.m = m;
+  A.n_ = n;
+  A.gp = g;
+  A.trim = trim;
+  A.out = out;
+  A.out_len = out_len;
+  A.status = status;
+  A.phase_cycles = phase;
+  A.sched = nullptr;
+  A.next = &next;
+  std::vector<Poa3Lds> lds(1);
+  std::memset(lds.data(), 0, sizeof(Poa3Lds));
+  EmuCall call{&A, lds.data()};
+  g_emu_lost_rows = 0;
+  simt_emu::run_wave(&emu_entry, &call);
+  if (std::getenv("RVN_POA3_DEBUG"))
+    std::fprintf(stderr, "[raven_hip] poa3 emulation: %llu predecessor rows read from the HBM copy\n", g_emu_lost_rows);
+}
+
+}  // namespace rvn

@@ -35,7 +35,7 @@ SYMBOLS = [
     "rvn_engine_map_batch", "rvn_engine_map_fetch", "rvn_engine_map_fetch_filtered",
     "rvn_find_overlaps_and_create_piles", "rvn_pass1_pile_words", "rvn_pass1_num_overlaps",
     "rvn_pass1_fetch_piles", "rvn_pass1_fetch_overlaps", "rvn_pass1_destroy", "rvn_pile_add_layers",
-    "rvn_edit_distance_batch", "rvn_poa_consensus_batch", "rvn_pass1_trim_and_annotate", "rvn_poa_phase_cycles", "rvn_polish_target_reads", "rvn_polish_set_chunk_windows", "rvn_polish_round_range", "rvn_polish_map_best", "rvn_polish_set_best", "rvn_shard_sketch", "rvn_shard_sketch_fetch",
+    "rvn_edit_distance_batch", "rvn_poa_consensus_batch", "rvn_poa_banded_emulate", "rvn_pass1_trim_and_annotate", "rvn_poa_phase_cycles", "rvn_polish_target_reads", "rvn_polish_set_chunk_windows", "rvn_polish_round_range", "rvn_polish_map_best", "rvn_polish_set_best", "rvn_shard_sketch", "rvn_shard_sketch_fetch",
     "rvn_shard_index_build", "rvn_shard_key_counts", "rvn_engine_set_occurrence", "rvn_shard_join",
     "rvn_shard_join_fetch", "rvn_shard_chain", "rvn_shard_piles", "rvn_shard_join_range", "rvn_shard_piles_create",
     "rvn_shard_piles_merge", "rvn_shard_piles_merge_dev", "rvn_shard_sketch_fetch_dev",
@@ -130,6 +130,7 @@ def lib():
     L.rvn_edit_distance_batch.argtypes = [vp, vp, vp, u32, vp, C.POINTER(dbl), C.POINTER(u64)]
     L.rvn_poa_consensus_batch.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, u32, i32, i32, i32, i32, vp, vp, vp, vp,
                                           C.POINTER(dbl)]
+    L.rvn_poa_banded_emulate.argtypes = [vp, vp, vp, vp, vp, vp, vp, u32, i32, i32, i32, i32, vp, vp, vp, vp]
     L.rvn_poa_phase_cycles.argtypes = [vp, vp]
     L.rvn_polish_target_reads.argtypes = [vp, vp, u32]
     L.rvn_polish_set_chunk_windows.argtypes = [vp, u64]
@@ -349,6 +350,57 @@ class Pass1:
             self.close()
         except Exception:  # interpreter shutdown: module globals may already be gone
             pass
+
+
+def _pack_poa_windows(windows):
+    """Flat arrays of a window batch as rvn_poa_consensus_batch / rvn_poa_banded_emulate take them."""
+    codes, quals, loff, begins, ends, hasq, woff, ooff = [], [], [0], [], [], [], [0], [0]
+    any_q = False
+    for wdw in windows:
+        layers = wdw["layers"]
+        k = len(layers)
+        blen = len(layers[0])
+        b = wdw.get("begins") or [0] * k
+        e_ = wdw.get("ends") or [max(blen - 1, 0)] * k
+        q = wdw.get("quals")
+        for i, lay in enumerate(layers):
+            lay = np.asarray(lay, dtype=np.uint8)
+            codes.append(lay)
+            loff.append(loff[-1] + lay.shape[0])
+            begins.append(int(b[i]))
+            ends.append(int(e_[i]))
+            if q is not None and q[i] is not None:
+                quals.append(np.asarray(q[i], dtype=np.uint8))
+                hasq.append(1)
+                any_q = True
+            else:
+                quals.append(np.full(lay.shape[0], 33, dtype=np.uint8))
+                hasq.append(0)
+        woff.append(woff[-1] + k)
+        ooff.append(ooff[-1] + 4 * blen + 256)
+    nw = len(windows)
+    return dict(codes=np.concatenate(codes) if codes else np.zeros(0, np.uint8),
+                quals=np.concatenate(quals) if any_q else None, loff=np.asarray(loff, dtype=np.uint64),
+                begins=np.asarray(begins, dtype=np.uint32), ends=np.asarray(ends, dtype=np.uint32),
+                hasq=np.asarray(hasq, dtype=np.uint32), woff=np.asarray(woff, dtype=np.uint32), nw=nw,
+                out=np.zeros(ooff[-1] + 16, dtype=np.uint8), ooff=np.asarray(ooff, dtype=np.uint64),
+                out_len=np.zeros(nw, dtype=np.uint32), status=np.zeros(nw, dtype=np.uint32))
+
+
+def _unpack_poa_consensus(a):
+    ooff = a["ooff"]
+    return [a["out"][int(ooff[i]): int(ooff[i]) + int(a["out_len"][i])].copy() for i in range(a["nw"])]
+
+
+def poa_banded_emulate(windows, m=3, n=-5, g=-4, trim=True):
+    """TEST INFRASTRUCTURE: poa3.hip's kernel source stepped through on the HOST by the wavefront emulator (no GPU, no
+    engine).  First attempt of the escalation chain only: status 8 / 7 = the window needs a wider band.  Returns
+    (list of consensus code arrays, status array)."""
+    a = _pack_poa_windows(windows)
+    _check(lib().rvn_poa_banded_emulate(
+        _p(a["codes"]), _p(a["quals"]), _p(a["loff"]), _p(a["begins"]), _p(a["ends"]), _p(a["hasq"]), _p(a["woff"]),
+        a["nw"], m, n, g, int(trim), _p(a["out"]), _p(a["ooff"]), _p(a["out_len"]), _p(a["status"])))
+    return _unpack_poa_consensus(a), a["status"]
 
 
 class Engine:
@@ -758,45 +810,13 @@ class Engine:
     def poa_consensus_batch(self, windows, m=3, n=-5, g=-4, trim=True):
         """windows: list of dicts {layers: [uint8 code arrays, layer 0 = backbone], begins, ends, quals (list of
         uint8 Phred+33 arrays or None entries) or None}.  Returns (list of consensus code arrays, status array, ms)."""
-        codes, quals, loff, begins, ends, hasq, woff, ooff = [], [], [0], [], [], [], [0], [0]
-        any_q = False
-        for wdw in windows:
-            layers = wdw["layers"]
-            k = len(layers)
-            blen = len(layers[0])
-            b = wdw.get("begins") or [0] * k
-            e_ = wdw.get("ends") or [max(blen - 1, 0)] * k
-            q = wdw.get("quals")
-            for i, lay in enumerate(layers):
-                lay = np.asarray(lay, dtype=np.uint8)
-                codes.append(lay)
-                loff.append(loff[-1] + lay.shape[0])
-                begins.append(int(b[i]))
-                ends.append(int(e_[i]))
-                if q is not None and q[i] is not None:
-                    quals.append(np.asarray(q[i], dtype=np.uint8))
-                    hasq.append(1)
-                    any_q = True
-                else:
-                    quals.append(np.full(lay.shape[0], 33, dtype=np.uint8))
-                    hasq.append(0)
-            woff.append(woff[-1] + k)
-            ooff.append(ooff[-1] + 4 * blen + 256)
-        nw = len(windows)
-        codes_a = np.concatenate(codes) if codes else np.zeros(0, np.uint8)
-        quals_a = np.concatenate(quals) if any_q else None
-        out = np.zeros(ooff[-1] + 16, dtype=np.uint8)
-        out_len = np.zeros(nw, dtype=np.uint32)
-        status = np.zeros(nw, dtype=np.uint32)
+        a = _pack_poa_windows(windows)
         ms = C.c_double(0)
-        ooff_a = np.asarray(ooff, dtype=np.uint64)
         _check(lib().rvn_poa_consensus_batch(
-            self._h, _p(codes_a), _p(quals_a), _p(np.asarray(loff, dtype=np.uint64)),
-            _p(np.asarray(begins, dtype=np.uint32)), _p(np.asarray(ends, dtype=np.uint32)),
-            _p(np.asarray(hasq, dtype=np.uint32)), _p(np.asarray(woff, dtype=np.uint32)), nw, m, n, g, int(trim),
-            _p(out), _p(ooff_a), _p(out_len), _p(status), C.byref(ms)))
-        cons = [out[ooff[i]: ooff[i] + int(out_len[i])].copy() for i in range(nw)]
-        return cons, status, ms.value
+            self._h, _p(a["codes"]), _p(a["quals"]), _p(a["loff"]), _p(a["begins"]), _p(a["ends"]), _p(a["hasq"]),
+            _p(a["woff"]), a["nw"], m, n, g, int(trim), _p(a["out"]), _p(a["ooff"]), _p(a["out_len"]), _p(a["status"]),
+            C.byref(ms)))
+        return _unpack_poa_consensus(a), a["status"], ms.value
 
     def poa_phase_cycles(self):
         c = np.zeros(6, dtype=np.uint64)

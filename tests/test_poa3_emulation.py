@@ -1,0 +1,134 @@
+"""The four-windows-per-wave banded POA kernel (raven_amd/csrc/poa3.hip) stepped through on the CPU: the kernel source is
+written against sv:: (csrc/simt.h) and runs unchanged under the 64-fibre wavefront emulator (csrc/simt_emu.hip), so the
+whole kernel — group-parallel NW rows, lock-step tracebacks, graph update, consensus — is compared with the POA oracle
+(racon Window::GenerateConsensus over spoa) here, without a GPU.  First attempt of the escalation chain only: a window
+whose alignment touches the 64-column band comes back flagged (status 8) and is not compared.
+The GPU side of the same comparison is tests/test_gpu_poa.py (mode 5) and tools/check_poa3.py."""
+import numpy as np
+
+from oracle import oracle
+from raven_amd import hip
+
+
+def _mutate(rng, codes, sub, ins, dele):
+    out = []
+    for c in codes:
+        u = rng.random()
+        if u < dele:
+            continue
+        if u < dele + sub:
+            c = (c + rng.integers(1, 4)) & 3
+        out.append(int(c))
+        if rng.random() < ins:
+            out.append(int(rng.integers(0, 4)))
+    return np.array(out, dtype=np.uint8)
+
+
+def _window(rng, length, n_reads, err=(0.05, 0.04, 0.04), partial=0.0, qual=False):
+    truth = rng.integers(0, 4, size=length, dtype=np.uint8)
+    bb = _mutate(rng, truth, 0.03, 0.02, 0.02)
+    layers, begins, ends = [bb], [0], [len(bb) - 1]
+    quals = [np.full(len(bb), 33, np.uint8)] if qual else None
+    for _ in range(n_reads):
+        if rng.random() < partial:
+            b = int(rng.integers(0, length // 2))
+            e = int(rng.integers(b + length // 4, length))
+        else:
+            b, e = 0, length
+        piece = _mutate(rng, truth[b:e], *err)
+        if len(piece) < 2:
+            continue
+        layers.append(piece)
+        bb_b = min(len(bb) - 2, int(b * len(bb) / length))
+        bb_e = min(len(bb) - 1, max(bb_b + 1, int(e * len(bb) / length) - 1))
+        begins.append(bb_b)
+        ends.append(bb_e)
+        if qual:
+            quals.append((33 + rng.integers(5, 40, size=len(piece))).astype(np.uint8))
+    return dict(layers=layers, begins=begins, ends=ends, quals=quals)
+
+
+def _oracle(w, trim=True):
+    return oracle.poa_window(w["layers"], begins=w.get("begins"), ends=w.get("ends"), quals=w.get("quals"), trim=trim)[0]
+
+
+def _compare(wins, min_polished, **kw):
+    cons, status = hip.poa_banded_emulate(wins, **kw)
+    polished = 0
+    for w, c, st in zip(wins, cons, status):
+        if (int(st) & 0xFF) == 1:
+            polished += 1
+            assert np.array_equal(c, _oracle(w, trim=kw.get("trim", True)))
+        else:
+            assert (int(st) & 0xFF) in (0, 8), st
+    assert polished >= min_polished
+    return cons, status
+
+
+def test_simple_windows():
+    rng = np.random.default_rng(1)
+    truth = rng.integers(0, 4, size=150, dtype=np.uint8)
+    bb = _mutate(rng, truth, 0.03, 0.02, 0.02)
+    wins = [
+        dict(layers=[bb] + [truth.copy() for _ in range(6)]),      # error-free layers fix the backbone
+        dict(layers=[bb, truth.copy()]),                            # < 3 sequences: backbone back
+        dict(layers=[bb]),
+        dict(layers=[truth.copy()] + [truth[30:120].copy() for _ in range(8)], begins=[0] + [30] * 8,
+             ends=[149] + [119] * 8),                               # trimming of thin ends
+        dict(layers=[bb] + [truth.copy() for _ in range(3)]),       # a fifth window: the wave's second batch of four
+    ]
+    cons, status = hip.poa_banded_emulate(wins)
+    assert status.tolist() == [1, 0, 0, 1, 1]
+    assert np.array_equal(cons[0], truth)
+    assert np.array_equal(cons[1], bb) and np.array_equal(cons[2], bb)
+    assert np.array_equal(cons[3], truth[30:120])
+    for w, c in zip(wins, cons):
+        assert np.array_equal(c, _oracle(w))
+    cons_nt, _ = hip.poa_banded_emulate(wins[3:4], trim=False)
+    assert np.array_equal(cons_nt[0], _oracle(wins[3], trim=False))
+
+
+def test_noisy_windows_ragged_groups():
+    """Windows of different sizes, layer counts, partial layers and qualities share a wave: the four groups run out of
+    rows, layers and traceback steps at different times."""
+    rng = np.random.default_rng(5)
+    wins = []
+    for i in range(14):
+        wins.append(_window(rng, int(rng.integers(70, 260)), int(rng.integers(3, 14)), partial=0.3 if i % 2 else 0.0,
+                            qual=(i % 3 == 0)))
+    _compare(wins, min_polished=12)
+
+
+def test_window_sized_like_racon():
+    """500-base windows with 30 layers (the shape a polishing round produces), two of them with partial layers."""
+    rng = np.random.default_rng(11)
+    wins = [_window(rng, 500 + 20 * i, 30, partial=0.25 if i % 2 else 0.0, qual=(i == 0)) for i in range(4)]
+    _compare(wins, min_polished=4)
+
+
+def test_rows_that_left_the_ring():
+    """A long private insertion in half of the reads puts more than 16 rows between a node and one of its
+    predecessors: those rows come from the HBM copy of the score rows instead of the LDS ring."""
+    rng = np.random.default_rng(3)
+    wins = []
+    for _ in range(4):
+        truth = rng.integers(0, 4, size=220, dtype=np.uint8)
+        layers = [_mutate(rng, truth, 0.03, 0.02, 0.02)]
+        for r in range(10):
+            t = truth
+            if r % 2 == 0:
+                pos = 100 + int(rng.integers(0, 5))
+                t = np.concatenate([truth[:pos], rng.integers(0, 4, size=int(rng.integers(18, 30)), dtype=np.uint8), truth[pos:]])
+            layers.append(_mutate(rng, t, 0.03, 0.02, 0.02))
+        wins.append(dict(layers=layers))
+    _compare(wins, min_polished=3)
+
+
+def test_scoring_parameters():
+    rng = np.random.default_rng(21)
+    wins = [_window(rng, 120, 8) for _ in range(4)]
+    cons, status = hip.poa_banded_emulate(wins, m=5, n=-4, g=-8)
+    for w, c, st in zip(wins, cons, status):
+        if (int(st) & 0xFF) == 1:
+            o = oracle.poa_window(w["layers"], begins=w["begins"], ends=w["ends"], quals=w["quals"], m=5, n=-4, g=-8)[0]
+            assert np.array_equal(c, o)
