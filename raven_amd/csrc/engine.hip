@@ -807,11 +807,11 @@ int rvn_filter_overlaps_by_identity(rvn_engine* h, const rvn_reads* rr, rvn_over
 
 int64_t rvn_test_find_chimeric_regions(const uint16_t* data, uint32_t size, uint32_t* out, uint64_t cap_pairs) {
   if (!data || !out || size == 0) return RVN_EINVAL;
-  std::vector<SlopeRegion> slopes(size + 1);
+  std::vector<SlopeRegion> slopes(2 * static_cast<size_t>(size) + 2);  // same bounds as the device path (pile.hip)
   std::vector<u16> tmp(size + 1);
   bool overflow = false;
-  const u32 n = find_chimeric_regions(data, static_cast<int>(size), slopes.data(), size, tmp.data(), out,
-                                      static_cast<u32>(std::min<uint64_t>(cap_pairs, size / 2)), &overflow);
+  const u32 n = find_chimeric_regions(data, static_cast<int>(size), slopes.data(), 2 * size, tmp.data(), out,
+                                      static_cast<u32>(std::min<uint64_t>(cap_pairs, size)), &overflow);
   return overflow ? -5 : static_cast<int64_t>(n);
 }
 

@@ -65,14 +65,14 @@ __global__ void add_kmers_flags_kernel(const u64* __restrict__ packed, const u64
   if (lc_kmer_passes(codes, k)) kmers[kmers_off[lo] + (p >> kPSS2)] = 1;
 }
 
-// OverlapUpdate of every overlap: updated copy + ok flag
-__global__ void update_kernel(const Overlap* __restrict__ in, u64 n, const PileRegion* __restrict__ regions,
-                              Overlap* __restrict__ out, u8* __restrict__ ok) {
+// OverlapUpdate of every overlap, in place: updated coordinates + ok flag
+__global__ void update_kernel(Overlap* __restrict__ ovl, u64 n, const PileRegion* __restrict__ regions,
+                              u8* __restrict__ ok) {
   const u64 i = static_cast<u64>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  Overlap o = in[i];
+  Overlap o = ovl[i];
   const bool good = overlap_update(o, regions[o.lhs_id], regions[o.rhs_id]);
-  out[i] = o;
+  ovl[i] = o;
   ok[i] = good ? 1 : 0;
 }
 
@@ -194,7 +194,7 @@ void update_and_identity(Engine& e, const ReadsDev& r, Overlap* d_ovl, u64 n, co
                          const u32* d_index_of, double identity, u8* d_ok) {
   if (n == 0) return;
   hipStream_t s = e.stream;
-  update_kernel<<<div_up(n, 256), 256, 0, s>>>(d_ovl, n, d_regions, d_ovl, d_ok);
+  update_kernel<<<div_up(n, 256), 256, 0, s>>>(d_ovl, n, d_regions, d_ok);
   RVN_LAUNCH_CHECK();
   if (identity == 0) return;
   u32* d_slot = e.p2_slot.get<u32>(n + 2);
@@ -364,7 +364,7 @@ void second_pass(Engine& e, const ReadsDev& R, const u32* h_begin, const u32* h_
   RVN_LAUNCH_CHECK();
   if (acc_n) {
     u8* d_ok = e.p2_ok.get<u8>(acc_n + 16);
-    update_kernel<<<div_up(acc_n, 256), 256, 0, s>>>(out.ovl.as<Overlap>(), acc_n, d_regions, out.ovl.as<Overlap>(), d_ok);
+    update_kernel<<<div_up(acc_n, 256), 256, 0, s>>>(out.ovl.as<Overlap>(), acc_n, d_regions, d_ok);
     RVN_LAUNCH_CHECK();
     acc_n = compact(e, out.ovl, acc_n, d_ok, e.p2_slot, e.p2_tmp_ovl);
   }

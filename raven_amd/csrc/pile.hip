@@ -474,7 +474,12 @@ __global__ __launch_bounds__(64) void pile_chimeric_kernel(const u16* __restrict
     const u64 off = pile_off[p];
     const u32 len = static_cast<u32>(pile_off[p + 1] - off);
     bool overflow = false;
-    c = find_chimeric_regions(data + off, static_cast<int>(len), slopes + off, len, tmp + off, out_tmp + off, len / 2, &overflow);
+    // Scratch bound (slopes.h): slope regions of one kind are pairwise disjoint, non-empty runs of cells at every moment
+    // of the 'separate overlapping slopes' loop — a re-evaluated region is cut back to the part its new runs do not
+    // touch — so there are never more than len of each kind, 2 * len in all; the pits paired from them are at most half
+    // of the final list (<= len), which is also what the merged-flag scratch (len cells) and the output hold.
+    c = find_chimeric_regions(data + off, static_cast<int>(len), slopes + 2 * off, 2 * len, tmp + off, out_tmp + 2 * off, len,
+                              &overflow);
     if (overflow) {
       atomicAdd(n_overflow, 1u);
       c = 0;
@@ -488,7 +493,7 @@ __global__ void chimeric_gather_kernel(const u32* __restrict__ out_tmp, const u6
   const u32 p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n) return;
   const u32 c = count[p];
-  const u32* src = out_tmp + pile_off[p];
+  const u32* src = out_tmp + 2 * pile_off[p];
   u32* dst = regions + 2ULL * roff[p];
   for (u32 i = 0; i < 2 * c; ++i) dst[i] = src[i];
 }
@@ -504,9 +509,9 @@ void piles_find_chimeric_regions(Engine& e, PileState& ps, const u8* h_invalid, 
   if (n == 0 || ps.pile_words == 0) return;
   u8* d_inv = e.tmp_a.get<u8>(static_cast<size_t>(n) + 16);
   RVN_HIP(hipMemcpyAsync(d_inv, h_invalid, n, hipMemcpyHostToDevice, s));
-  SlopeRegion* d_slopes = e.tmp_b.get<SlopeRegion>(ps.pile_words + 1);
+  SlopeRegion* d_slopes = e.tmp_b.get<SlopeRegion>(2 * ps.pile_words + 2);
   u16* d_tmp = e.tmp_c.get<u16>(ps.pile_words + 1);
-  u32* d_out = e.tmp_d.get<u32>(ps.pile_words + 2);
+  u32* d_out = e.tmp_d.get<u32>(2 * ps.pile_words + 4);
   u32* d_cnt = e.tmp_e.get<u32>(2 * static_cast<size_t>(n) + 8);
   u32* d_roff = d_cnt + n + 1;
   u32* d_ovf = e.tmp_f.get<u32>(4);
@@ -516,7 +521,7 @@ void piles_find_chimeric_regions(Engine& e, PileState& ps, const u8* h_invalid, 
   exclusive_scan_u32_u32(d_cnt, d_roff, n, e.scan_tmp, s);
   RVN_HIP(hipMemcpyAsync(h_off.data(), d_roff, (static_cast<size_t>(n) + 1) * 4, hipMemcpyDeviceToHost, s));
   if (read_back(e, d_ovf, 4) != 0)
-    throw HipError("[raven_hip] FindChimericRegions: a pile produced more slope regions than cells (internal error)");
+    throw HipError("[raven_hip] FindChimericRegions: a pile produced more than two slope regions per cell (internal error: the bound in pile.hip is a proof)");
   RVN_HIP(rvn_stream_sync(s));
   const u32 total = h_off[n];
   h_regions.assign(2ULL * total, 0);

@@ -101,11 +101,19 @@ __host__ __device__ __forceinline__ void lds_order() {
 #if defined(__HIP_DEVICE_COMPILE__)
 #define P3_MARK(x) asm volatile("; P3MARK " x)
 #define P3_NO_IF_CONVERSION() asm volatile("")  // keeps a rare, wave-uniform branch a branch
-#define P3_PHASE  // (noinline phases were tried: generic pointers turn every access into FLAT loads that also hold the LDS counter)
+// a group-parallel phase is its own function = its own register allocation (the kernel is built for 168 VGPRs); the
+// address spaces the inliner would have seen are handed over as assumptions, or every access becomes a FLAT one
+#define P3_PHASE  // (noinline was measured: no fewer spills inside the DP, and FLAT accesses where an assumption is not enough)
+#define P3_ASSUME_GLOBAL(p) \
+  __builtin_assume(!__builtin_amdgcn_is_shared((const void*)(p))); \
+  __builtin_assume(!__builtin_amdgcn_is_private((const void*)(p)))
+#define P3_ASSUME_LDS(p) __builtin_assume(__builtin_amdgcn_is_shared((const void*)(p)))
 #else
 #define P3_MARK(x)
 #define P3_NO_IF_CONVERSION()
 #define P3_PHASE
+#define P3_ASSUME_GLOBAL(p)
+#define P3_ASSUME_LDS(p)
 #endif
 
 __host__ __device__ __forceinline__ i32 mul24(i32 a, i32 b) {
@@ -113,6 +121,48 @@ __host__ __device__ __forceinline__ i32 mul24(i32 a, i32 b) {
   return __mul24(a, b);
 #else
   return a * b;
+#endif
+}
+
+// The lane's slot pointer, made opaque to the optimiser: field addresses derived from it are computed where they are
+// used instead of being hoisted out of the row loop and kept (or spilled) there — the DP is built for 168 VGPRs.
+__host__ __device__ __forceinline__ unsigned char* opaque(unsigned char* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("" : "+v"(p));
+#endif
+  return p;
+}
+
+// int16 half of `w` (HI: the upper one) * 64 + add: v_mad_i32_i16 reads the half through op_sel, so the score cells
+// stay packed as the LDS read delivered them
+template <bool HI>
+__host__ __device__ __forceinline__ i32 cell_x64_plus(u32 w, i32 add) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  i32 d;
+  if constexpr (HI) asm("v_mad_i32_i16 %0, %1, 64, %2 op_sel:[1,0,0,0]" : "=v"(d) : "v"(w), "v"(add));
+  else asm("v_mad_i32_i16 %0, %1, 64, %2" : "=v"(d) : "v"(w), "v"(add));
+  return d;
+#else
+  return static_cast<i32>(static_cast<i16>((HI ? w >> 16 : w) & 0xFFFFu)) * 64 + add;
+#endif
+}
+// (lo & 0xFFFF) | hi << 16
+__host__ __device__ __forceinline__ u32 pack16(i32 lo, i32 hi) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_perm(static_cast<u32>(hi), static_cast<u32>(lo), 0x05040100u);
+#else
+  return (static_cast<u32>(lo) & 0xFFFFu) | (static_cast<u32>(hi) << 16);
+#endif
+}
+// both int16 halves clamped from below to kNegInf16
+__host__ __device__ __forceinline__ u32 clamp_pair(u32 w) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef short pk16 __attribute__((ext_vector_type(2)));
+  const pk16 lim = {static_cast<short>(kNegInf16), static_cast<short>(kNegInf16)};
+  return __builtin_bit_cast(u32, __builtin_elementwise_max(__builtin_bit_cast(pk16, w), lim));
+#else
+  const i32 a = sext16(w), b = sext16(w >> 16);
+  return pack16(a < kNegInf16 ? kNegInf16 : a, b < kNegInf16 ? kNegInf16 : b);
 #endif
 }
 
@@ -156,26 +206,66 @@ __host__ __device__ inline u32 poa3_nth_pred(const Poa2Slot& g, u32 v, u32 k, bo
   return 0;
 }
 
-// Descriptor of predecessor row `pr` for the row whose computed-row index is cur_idx: band start | ring slot << 16,
-// kDescMiss if the row is no longer in the ring.  bi_cur / bi_prev: (band start | computed index << 16) of row pr as the
+#if defined(__HIP_DEVICE_COMPILE__)
+#define P3_RARE __attribute__((noinline))
+#else
+#define P3_RARE
+#endif
+// Five cells (columns j0 - 1 .. j0 + 3, packed like the LDS read delivers them) of the k-th in-edge's row of `row`, for
+// a predecessor that has left the LDS ring (one row in ~10^5: a long bubble ahead of it): from the int16 copy every row
+// leaves in HBM.  Out of line on purpose — its registers and loads stay out of the row loop.
+__host__ __device__ P3_RARE uint4 poa3_lost_cells(unsigned char* slot_mem, u32 nmax, u32 lmax, u32 row, u32 k, bool full,
+                                                  i32 j0) {
+  const Poa2Slot g = poa2_carve(slot_mem, nmax, lmax, 64, true);
+  const uint4 t = g.tb[row];
+  u32 prow;
+  if (k < 2) prow = (t.z >> (16 * k)) & 0xFFFFu;
+  else if (k < 4) prow = (t.w >> (16 * (k - 2))) & 0xFFFFu;
+  else prow = poa3_nth_pred(g, t.x >> 16, k, full);
+  const i32 pbx = static_cast<i32>(g.tb[prow].x & 0xFFFFu);
+  const i16* hrow = g.Hs + static_cast<size_t>(prow) * 64;
+  i32 cell[5];
+#pragma unroll
+  for (int u = 0; u < 5; ++u) {
+    const i32 c = j0 - pbx - 1 + u;
+    cell[u] = (c >= 0 && c < 64) ? static_cast<i32>(hrow[c]) : kNegInf16;
+  }
+  uint4 r;
+  r.x = (static_cast<u32>(cell[0]) & 0xFFFFu) | (static_cast<u32>(cell[1]) << 16);
+  r.y = (static_cast<u32>(cell[2]) & 0xFFFFu) | (static_cast<u32>(cell[3]) << 16);
+  r.z = static_cast<u32>(cell[4]) & 0xFFFFu;
+  r.w = 0;
+  return r;
+}
+
+// Descriptor of predecessor row `pr` for the row whose computed-row index is cur_idx: int16(-band start - 1) | the ring
+// row's first cell (slot * stride + pad) << 16, so that the predecessor's cell under column j is at
+// (desc >> 16) + clamp(j + int16(desc)); kDescMiss if the row is no longer in the ring.  bi_cur / bi_prev: (band start | computed index << 16) of row pr as the
 // current / the previous 16-row block holds it.
 __host__ __device__ __forceinline__ u32 poa3_desc(u32 pr, u32 r0, u32 cur_idx, u32 bi_cur, u32 bi_prev) {
   const bool in_cur = pr >= r0 + 1;
   const bool in_prev = !in_cur && pr + 16 >= r0 + 1;
   const u32 pbi = in_cur ? bi_cur : bi_prev;
   const bool miss = !(in_cur || in_prev) || ((cur_idx - (pbi >> 16)) & 0xFFFFu) > static_cast<u32>(kRing3);
-  return (pbi & 0xFFFFu) | (((pbi >> 16) & (kRing3 - 1)) << 16) | (miss ? kDescMiss : 0u);
+  const u32 rel = (0u - (pbi & 0xFFFFu) - 1u) & 0xFFFFu;
+  const u32 first = ((pbi >> 16) & (kRing3 - 1)) * kStride3 + kPad3;  // <= 1146: 11 bits
+  return rel | (first << 16) | (miss ? kDescMiss : 0u);
 }
 
 // ---- banded NW of one layer per group (four windows in lockstep) ---------------------------------------------------
 // Group-uniform inputs: act (this group aligns a layer now), nn (graph nodes), full, the layer.  Outputs (group-uniform):
 // best_row (0: the last column is in no end node's band).
-__host__ __device__ P3_PHASE inline void poa3_dp(const Poa3Args& A, Poa3Lds& S, const Poa2Slot& g, bool act, u32 nn, bool full,
-                                        const PoaLayer* Lp, u32 len, i32 lb, i32 span, u32& best_row,
-                                        unsigned long long& c_full, unsigned long long& c_band) {
+__host__ __device__ P3_PHASE inline void poa3_dp(const Poa3Args A, Poa3Lds& S, unsigned char* slot_mem, bool act, u32 nn, bool full,
+                                        const PoaLayer* Lp, u32 len, i32 lb, i32 span, u32& best_row) {
+  P3_ASSUME_GLOBAL(slot_mem);
+  P3_ASSUME_GLOBAL(Lp);
+  P3_ASSUME_GLOBAL(A.phase_cycles);
+  P3_ASSUME_LDS(&S);
   const int lane = sv::lane();
   const int gl = lane & 15, gbase = lane & 48;
   Poa3Group& Sg = S.g[lane >> 4];
+  u8* const bp_rows = poa2_carve(slot_mem, A.nmax, A.lmax, 64, true).BP + 4 * gl;   // the two stores of every row
+  i16* const hs_rows = poa2_carve(slot_mem, A.nmax, A.lmax, 64, true).Hs + 4 * gl;
   i16* ring16 = reinterpret_cast<i16*>(Sg.u.ring32);
   const u32 w = len + 1;
   const i32 gp = A.gp;
@@ -216,10 +306,12 @@ __host__ __device__ P3_PHASE inline void poa3_dp(const Poa3Args& A, Poa3Lds& S, 
   u32 nx_marked = 0, nx_code = 0, nx_outc = 1, nx_c = 0, nx_bpos = 0, nx_t01 = 0, nx_t23 = 0;
   u32 nx_rk0 = 0, nx_rk1 = 0, nx_rk2 = 0, nx_rk3 = 0, nx_m0 = 1, nx_m1 = 1, nx_m2 = 1, nx_m3 = 1;
   auto stage1 = [&](u32 rbase) {
+    const Poa2Slot g = poa2_carve(opaque(slot_mem), A.nmax, A.lmax, 64, true);
     nx_ok = act && rbase + static_cast<u32>(gl) < nn;
     nx_v = nx_ok ? static_cast<int>(g.order[rbase + gl]) : 0;
   };
   auto stage2 = [&]() {
+    const Poa2Slot g = poa2_carve(opaque(slot_mem), A.nmax, A.lmax, 64, true);
     nx_marked = 0;
     if (nx_ok) {
       nx_marked = full ? 1u : g.mark[nx_v];
@@ -233,6 +325,7 @@ __host__ __device__ P3_PHASE inline void poa3_dp(const Poa3Args& A, Poa3Lds& S, 
     }
   };
   auto stage3 = [&]() {
+    const Poa2Slot g = poa2_carve(opaque(slot_mem), A.nmax, A.lmax, 64, true);
     if (nx_ok && nx_marked) {  // tails beyond the in-degree are stale memory: clamp them to node 0
       const u32 t0 = nx_c > 0 ? nx_t01 & 0xFFFFu : 0u, t1 = nx_c > 1 ? nx_t01 >> 16 : 0u;
       const u32 t2 = nx_c > 2 ? nx_t23 & 0xFFFFu : 0u, t3 = nx_c > 3 ? nx_t23 >> 16 : 0u;
@@ -257,6 +350,7 @@ __host__ __device__ P3_PHASE inline void poa3_dp(const Poa3Args& A, Poa3Lds& S, 
     int m_np = 0, m_code = 0, m_outc = 1, m_marked = 0, m_b = 0;
     u32 p0 = 0, p1 = 0, p2 = 0, p3 = 0;
     if (nx_ok) {
+      const Poa2Slot g = poa2_carve(opaque(slot_mem), A.nmax, A.lmax, 64, true);
       m_marked = nx_marked ? 1 : 0;
       if (m_marked) {
         m_code = static_cast<int>(nx_code);
@@ -294,11 +388,6 @@ __host__ __device__ P3_PHASE inline void poa3_dp(const Poa3Args& A, Poa3Lds& S, 
     const u32 idx_in = (marked_before + static_cast<u32>(__builtin_popcount(grp & ((1u << gl) - 1u)))) & 0xFFFFu;
     marked_before += static_cast<u32>(__builtin_popcount(grp));
     const int m_bi = m_b | static_cast<int>(idx_in << 16);
-    if (gl == 0) {  // work counters: rows of this layer's (sub)graph x layer length = the cells spoa's full NW computes
-      const u32 rows = static_cast<u32>(__builtin_popcount(grp));
-      c_full += static_cast<unsigned long long>(rows) * len;
-      c_band += static_cast<unsigned long long>(rows) * (w < 64u ? w : 64u);
-    }
     u32 desc0 = 0, desc1 = 0, desc2 = 0, desc3 = 0;
     {
       const u32 bc0 = static_cast<u32>(sv::bperm(m_bi, gbase | static_cast<int>((p0 - 1) & 15u)));
@@ -348,75 +437,68 @@ __host__ __device__ P3_PHASE inline void poa3_dp(const Poa3Args& A, Poa3Lds& S, 
       i32 subD[4], best[4];
 #pragma unroll
       for (int t = 0; t < 4; ++t) subD[t] = ((chars >> (8 * t)) & 0xFFu) == vc ? mD15 : nD15;
-      // five adjacent cells of predecessor row `dd` starting under this lane's column j0 - 1.  `pk` = the in-edge's row as
-      // the row's owner lane holds it: only looked at when the row has left the LDS ring (one row in ~10^5: a long
-      // bubble ahead of it) — then the cells come from the int16 copy every row leaves in HBM.
-      auto pred_cells = [&](u32 dd, bool valid, u32 pk, i32(&cell)[5]) {
-        const i32 pb = static_cast<i32>(dd & 0xFFFFu);
-        const u32 pslot = (dd >> 16) & 15u;
-        i32 start = j0 - pb - 1;
+      // five adjacent cells of predecessor row `dd` (the row's k-th in-edge) starting under this lane's column j0 - 1
+      auto pred_cells = [&](u32 dd, bool valid, u32 k, u32& c01, u32& c23, u32& c4) {
+        i32 start = j0 + sext16(dd);  // the predecessor's cell under this lane's column j0 - 1
         start = start < -5 ? -5 : (start > 64 ? 64 : start);
-        const u32 base = pslot * kStride3 + kPad3 + static_cast<u32>(start);
+        const u32 base = ((dd >> 16) & 0x7FFu) + static_cast<u32>(start);
         const u32 dw = base >> 1, par16 = (base & 1u) * 16u;
         const u32 x0 = Sg.u.ring32[dw], x1 = Sg.u.ring32[dw + 1], x2 = Sg.u.ring32[dw + 2];
-        const u32 c01 = funnel_shr(x1, x0, par16), c23 = funnel_shr(x2, x1, par16), c4 = x2 >> par16;
-        cell[0] = sext16(c01);
-        cell[1] = sext16(c01 >> 16);
-        cell[2] = sext16(c23);
-        cell[3] = sext16(c23 >> 16);
-        cell[4] = sext16(c4);
+        c01 = funnel_shr(x1, x0, par16);
+        c23 = funnel_shr(x2, x1, par16);
+        c4 = x2 >> par16;
         const bool lost = valid && (dd & kDescMiss) != 0;
-        if (sv::any(lost)) {
+        if (sv::any(lost)) {  // the row has left the ring
           P3_NO_IF_CONVERSION();
-          const u32 prow = static_cast<u32>(sv::bperm(static_cast<int>(pk), src));
           sv::sync();  // the rows' stores have landed
 #if !defined(__HIP_DEVICE_COMPILE__)
           if (lost && gl == 0) ++g_emu_lost_rows;
 #endif
           if (lost) {
-            const i32 pbx = static_cast<i32>(g.tb[prow].x & 0xFFFFu);
-            const i16* hrow = g.Hs + static_cast<size_t>(prow) * 64;
-#pragma unroll
-            for (int u = 0; u < 5; ++u) {
-              const i32 c = j0 - pbx - 1 + u;
-              cell[u] = (c >= 0 && c < 64) ? static_cast<i32>(hrow[c]) : kNegInf16;
-            }
+            const uint4 r = poa3_lost_cells(slot_mem, A.nmax, A.lmax, row, k, full, j0);
+            c01 = r.x;
+            c23 = r.y;
+            c4 = r.z;
           }
         }
       };
       P3_MARK("edges_begin");
       {  // in-edge 0 (or the virtual start row): every computed row has it
-        i32 cell[5];
-        pred_cells(d, actv, p0, cell);
+        u32 c01, c23, c4;
+        pred_cells(d, actv, 0u, c01, c23, c4);
         const bool virt = (d & kDescVirtual) != 0;
         if (sv::any(actv && virt)) {  // H[0][j] = j * g
           P3_NO_IF_CONVERSION();
+          i32 vc5[5];
 #pragma unroll
           for (int u = 0; u < 5; ++u) {
             const i32 jc = j0 - 1 + u;
-            const i32 vcell = jc >= 0 ? mul24(jc, gp) : kNegInf16;
-            cell[u] = virt ? vcell : cell[u];
+            vc5[u] = jc >= 0 ? mul24(jc, gp) : kNegInf16;
           }
+          c01 = virt ? pack16(vc5[0], vc5[1]) : c01;
+          c23 = virt ? pack16(vc5[2], vc5[3]) : c23;
+          c4 = virt ? pack16(vc5[4], 0) : c4;
         }
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const i32 D = cell[t] * 64 + subD[t];
-          const i32 V = cell[t + 1] * 64 + gV15;
-          best[t] = D > V ? D : V;
-        }
+        const i32 d0 = cell_x64_plus<false>(c01, subD[0]), v0 = cell_x64_plus<true>(c01, gV15);
+        const i32 d1 = cell_x64_plus<true>(c01, subD[1]), v1 = cell_x64_plus<false>(c23, gV15);
+        const i32 d2 = cell_x64_plus<false>(c23, subD[2]), v2 = cell_x64_plus<true>(c23, gV15);
+        const i32 d3 = cell_x64_plus<true>(c23, subD[3]), v3 = cell_x64_plus<false>(c4, gV15);
+        best[0] = d0 > v0 ? d0 : v0;
+        best[1] = d1 > v1 ? d1 : v1;
+        best[2] = d2 > v2 ? d2 : v2;
+        best[3] = d3 > v3 ? d3 : v3;
       }
       if (sv::any(actv && npe > 1u)) {
         P3_NO_IF_CONVERSION();
         for (u32 k = 1;; ++k) {
           const bool vk = actv && k < npe;
           if (!sv::any(vk)) break;
-          u32 prk = k == 1 ? p1 : (k == 2 ? p2 : p3);
           if (k == 1) d = static_cast<u32>(sv::bperm(static_cast<int>(desc1), src));
           else if (k == 2) d = static_cast<u32>(sv::bperm(static_cast<int>(desc2), src));
           else if (k == 3) d = static_cast<u32>(sv::bperm(static_cast<int>(desc3), src));
           else {  // rare: the row's owner looks the in-edge up, the group resolves its ring slot
-            prk = 0;
-            if (vk && gl == ri) prk = poa3_nth_pred(g, static_cast<u32>(m_v), k, full);
+            u32 prk = 0;
+            if (vk && gl == ri) prk = poa3_nth_pred(poa2_carve(opaque(slot_mem), A.nmax, A.lmax, 64, true), static_cast<u32>(m_v), k, full);
             prk = static_cast<u32>(sv::bperm(static_cast<int>(prk), src));
             const int sl = gbase | static_cast<int>((prk - 1) & 15u);
             const u32 bc = static_cast<u32>(sv::bperm(m_bi, sl));
@@ -424,16 +506,19 @@ __host__ __device__ P3_PHASE inline void poa3_dp(const Poa3Args& A, Poa3Lds& S, 
             const u32 cur_idx = static_cast<u32>(sv::bperm(m_bi, src)) >> 16;
             d = poa3_desc(prk, r0, cur_idx, bc, bp);
           }
-          i32 cell[5];
-          pred_cells(d, vk, prk, cell);
-          const i32 ki = static_cast<i32>(k);
-#pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            const i32 D = cell[t] * 64 + (subD[t] - ki);
-            const i32 V = cell[t + 1] * 64 + (gV15 - ki);
-            const i32 nb = max3(best[t], D, V);
-            best[t] = vk ? nb : best[t];
-          }
+          u32 c01, c23, c4;
+          pred_cells(d, vk, k, c01, c23, c4);
+          // a group without a k-th in-edge subtracts 2^29 instead of k: its candidates never win
+          const i32 off = vk ? static_cast<i32>(k) : 0x20000000;
+          const i32 gk = gV15 - off;
+          const i32 d0 = cell_x64_plus<false>(c01, subD[0] - off), v0 = cell_x64_plus<true>(c01, gk);
+          const i32 d1 = cell_x64_plus<true>(c01, subD[1] - off), v1 = cell_x64_plus<false>(c23, gk);
+          const i32 d2 = cell_x64_plus<false>(c23, subD[2] - off), v2 = cell_x64_plus<true>(c23, gk);
+          const i32 d3 = cell_x64_plus<true>(c23, subD[3] - off), v3 = cell_x64_plus<false>(c4, gk);
+          best[0] = max3(best[0], d0, v0);
+          best[1] = max3(best[1], d1, v1);
+          best[2] = max3(best[2], d2, v2);
+          best[3] = max3(best[3], d3, v3);
         }
       }
       P3_MARK("edges_end");
@@ -450,32 +535,28 @@ __host__ __device__ P3_PHASE inline void poa3_dp(const Poa3Args& A, Poa3Lds& S, 
       y[3] = y[3] > y[2] ? y[3] : y[2];
       const i32 s = row_prefix_max(y[3]);
       const i32 ex = sv::row_shr<1>(s, kVeryNeg);  // lanes to the left of this one
+      // backpointer byte: 64 = horizontal, else the winner's key bits (diagonal << 5 | 15 - in-edge)
       i32 hh[4];
       u32 codes = 0;
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const i32 yt = y[t] > ex ? y[t] : ex;
-        i32 h = yt + (jg0 + t * gp);
-        const u32 low = static_cast<u32>(best[t]) & 63u;
-        u32 code = 31u - (low & 15u) - ((low & 32u) >> 1);
-        if (h > sc[t]) code = 32u;
-        h = h < kNegInf16 ? kNegInf16 : h;
+        const i32 h = yt + (jg0 + t * gp);
+        const u32 code = h > sc[t] ? 64u : (static_cast<u32>(best[t]) & 63u);
         hh[t] = h;
         codes |= code << (8 * t);
       }
+      const u32 h01 = clamp_pair(pack16(hh[0], hh[1])), h23 = clamp_pair(pack16(hh[2], hh[3]));
       if (actv) {
         const u32 cell0 = (slot * kStride3 + kPad3) / 2 + 2u * static_cast<u32>(gl);
-        const u32 h01 = (static_cast<u32>(hh[0]) & 0xFFFFu) | (static_cast<u32>(hh[1]) << 16);
-        const u32 h23 = (static_cast<u32>(hh[2]) & 0xFFFFu) | (static_cast<u32>(hh[3]) << 16);
         Sg.u.ring32[cell0] = h01;
         Sg.u.ring32[cell0 + 1] = h23;
-        *reinterpret_cast<uint2*>(g.Hs + static_cast<size_t>(row) * 64 + 4 * gl) = uint2{h01, h23};
-        *reinterpret_cast<u32*>(g.BP + static_cast<size_t>(row) * 64 + 4 * gl) = codes;
+        *reinterpret_cast<uint2*>(hs_rows + static_cast<size_t>(row) * 64) = uint2{h01, h23};
+        *reinterpret_cast<u32*>(bp_rows + static_cast<size_t>(row) * 64) = codes;
       }
       if (sv::any(actv && endn)) {  // an end node: score of the last column if the band has it
         const i32 idx = static_cast<i32>(w) - 1 - b;
-        const int sel = idx & 3;
-        const i32 mine = sel == 0 ? hh[0] : (sel == 1 ? hh[1] : (sel == 2 ? hh[2] : hh[3]));
+        const i32 mine = sext16(((idx & 2) ? h23 : h01) >> (16 * (idx & 1)));
         const i32 sce = sv::bperm(mine, gbase | ((idx >> 2) & 15));
         if (actv && endn && idx >= 0 && idx < 64 && sce > best_score) {
           best_score = sce;
@@ -494,14 +575,22 @@ __host__ __device__ P3_PHASE inline void poa3_dp(const Poa3Args& A, Poa3Lds& S, 
     for (int ri = 10; ri < 16; ++ri) do_row(ri);
     m_bi_prev = m_bi;
   }
+  // work counters: rows of this layer's (sub)graph x layer length = the cells spoa's full NW computes | cells in the band
+  if (gl == 0 && act && A.phase_cycles) {
+    sv::atomic_add(&A.phase_cycles[6], static_cast<unsigned long long>(marked_before) * len);
+    sv::atomic_add(&A.phase_cycles[7], static_cast<unsigned long long>(marked_before) * (w < 64u ? w : 64u));
+  }
 }
 
 // ---- traceback of the four groups in lockstep ----------------------------------------------------------------------
-__host__ __device__ P3_PHASE inline void poa3_traceback(const Poa3Args& A, Poa3Lds& S, const Poa2Slot& g, bool act, u32 nn, bool full,
+__host__ __device__ P3_PHASE inline void poa3_traceback(const Poa3Args A, Poa3Lds& S, unsigned char* slot, bool act, u32 nn, bool full,
                                                u32 len, u32 best_row, u32& bad, u32& band_hit) {
+  P3_ASSUME_GLOBAL(slot);
+  P3_ASSUME_LDS(&S);
   const int lane = sv::lane();
   const int gl = lane & 15;
   Poa3Group& Sg = S.g[lane >> 4];
+  const Poa2Slot g = poa2_carve(slot, A.nmax, A.lmax, 64, true);
   const u32 w = len + 1;
   bad = 0;
   band_hit = 0;
@@ -586,7 +675,7 @@ __host__ __device__ P3_PHASE inline void poa3_traceback(const Poa3Args& A, Poa3L
         } else {
           if ((idx < 2 && bt > 0) || (idx > 64 - 3 && bt + 64 < static_cast<i32>(w))) band_hit = 1;
           const u32 code = Sg.u.tr.bp[l * 64 + static_cast<u32>(idx)];
-          if (code == 32u) {
+          if (code == 64u) {
             if (j == 0) {
               bad = 6;
               done = true;
@@ -594,12 +683,12 @@ __host__ __device__ P3_PHASE inline void poa3_traceback(const Poa3Args& A, Poa3L
               --j;  // insertion: pos_node[j] stays kNone
             }
           } else {
-            const u32 k = code & 15u;
+            const u32 k = 15u - (code & 15u);
             u32 pr;
             if (k < 2) pr = (z01 >> (16 * k)) & 0xFFFFu;
             else if (k < 4) pr = (Sg.u.tr.tb[l * 3 + 2] >> (16 * (k - 2))) & 0xFFFFu;
             else pr = poa3_nth_pred(g, node, k, full);
-            if (code < 16u) {
+            if (code & 32u) {  // diagonal
               if (j == 0) {
                 bad = 6;
                 done = true;
@@ -629,7 +718,7 @@ __host__ __device__ inline void poa3_copy_backbone(const Poa3Args& A, const PoaW
 }
 
 // window set-up: 0 = backbone returned (< 3 sequences), 4 = beyond a length limit (backbone returned), 1 = graph built
-__host__ __device__ P3_PHASE inline u32 poa3_init_window(const Poa3Args& A, const PoaWindow& win, Poa2Slot& g, u32 wi, u32& n_nodes,
+__host__ __device__ inline u32 poa3_init_window(const Poa3Args& A, const PoaWindow& win, Poa2Slot& g, u32 wi, u32& n_nodes,
                                                 u32& n_eff) {
   const int lane = sv::lane();
   const PoaLayer bb = A.layers[win.layer_first];
@@ -674,7 +763,7 @@ __host__ __device__ P3_PHASE inline u32 poa3_init_window(const Poa3Args& A, cons
 }
 
 // spoa AddAlignment, one sequence position per lane, + the incremental order rebuild.  Returns 0 or the failure code.
-__host__ __device__ P3_PHASE inline u32 poa3_add_alignment(const Poa3Args& A, Poa2Slot& g, Poa3Group& Sg, const PoaLayer& L,
+__host__ __device__ inline u32 poa3_add_alignment(const Poa3Args& A, Poa2Slot& g, Poa3Group& Sg, const PoaLayer& L,
                                                   u32& n_nodes, unsigned long long& t_add, unsigned long long& t_ord) {
   const int lane = sv::lane();
   const u32 len = L.len;
@@ -832,7 +921,7 @@ __host__ __device__ P3_PHASE inline u32 poa3_add_alignment(const Poa3Args& A, Po
 // Consensus of a finished window: spoa's heaviest bundle with the node scores in the WAVE's LDS (all four groups'
 // buffers: the DP of every window of the wave is over by now), first four in-edges of 64 nodes at a time in registers
 // (as poa2_consensus), then branch completion + racon's coverage trim on lane 0 and a parallel output copy.
-__host__ __device__ P3_PHASE inline void poa3_consensus(Poa2Slot& g, u32 n_nodes, u32 nmax, const PoaWindow& win, int trim, Poa3Lds& S,
+__host__ __device__ inline void poa3_consensus(Poa2Slot& g, u32 n_nodes, u32 nmax, const PoaWindow& win, int trim, Poa3Lds& S,
                                                u8* out, u32* out_len) {
   const int lane = sv::lane();
   constexpr u32 kCap = sizeof(Poa3Lds) / 4;
@@ -919,8 +1008,7 @@ __host__ __device__ inline void poa3_wave(const Poa3Args& A, Poa3Lds& S, u32 slo
   const int lane = sv::lane();
   const int q = lane >> 4;
   unsigned long long t_sub = 0, t_dp = 0, t_tb = 0, t_add = 0, t_ord = 0, t_cons = 0, t0 = 0;
-  unsigned long long c_full = 0, c_band = 0;
-  const Poa2Slot gq = poa2_carve(A.scratch + static_cast<size_t>(slot0 + q) * A.slot_bytes, A.nmax, A.lmax, 64, true);
+  unsigned char* const my_slot = A.scratch + static_cast<size_t>(slot0 + q) * A.slot_bytes;  // per lane: its group's window
   for (;;) {
     u32 first = 0;
     if (lane == 0) first = sv::atomic_add(A.next, static_cast<u32>(kG));
@@ -1012,7 +1100,7 @@ __host__ __device__ inline void poa3_wave(const Poa3Args& A, Poa3Lds& S, u32 slo
       sv::sync();
       t0 = sv::clock();
       u32 best_row = 0;
-      poa3_dp(A, S, gq, act, nn, full, Lp, len, lb, span, best_row, c_full, c_band);
+      poa3_dp(A, S, my_slot, act, nn, full, Lp, len, lb, span, best_row);
       sv::sync();  // backpointers visible to the traceback
       t_dp += sv::clock() - t0;
       t0 = sv::clock();
@@ -1023,7 +1111,7 @@ __host__ __device__ inline void poa3_wave(const Poa3Args& A, Poa3Lds& S, u32 slo
         act = false;
       }
       u32 bad = 0, band_hit = 0;
-      poa3_traceback(A, S, gq, act, nn, full, len, best_row, bad, band_hit);
+      poa3_traceback(A, S, my_slot, act, nn, full, len, best_row, bad, band_hit);
       if (act && bad) {
         phase = kFailed;
         status = bad | (li << 8);
@@ -1087,10 +1175,6 @@ __host__ __device__ inline void poa3_wave(const Poa3Args& A, Poa3Lds& S, u32 slo
       sv::atomic_add(&A.phase_cycles[3], t_add);
       sv::atomic_add(&A.phase_cycles[4], t_ord);
       sv::atomic_add(&A.phase_cycles[5], t_cons);
-    }
-    if ((lane & 15) == 0 && c_full) {
-      sv::atomic_add(&A.phase_cycles[6], c_full);
-      sv::atomic_add(&A.phase_cycles[7], c_band);
     }
   }
 }

@@ -183,7 +183,7 @@ __host__ __device__ inline u32 find_chimeric_regions(const u16* __restrict__ dat
     }
   }
   // Pile::MergeRegions: every not yet merged region absorbs, repeatedly, all later regions it overlaps
-  for (u32 i = 0; i < nr; ++i) tmp[i] = 0;  // is_merged (nr <= cap <= size is guaranteed by the caller)
+  for (u32 i = 0; i < nr; ++i) tmp[i] = 0;  // is_merged (nr <= ns / 2 <= cap / 2 <= size is guaranteed by the caller)
   u32 no = 0;
   for (u32 i = 0; i < nr; ++i) {
     if (tmp[i]) continue;

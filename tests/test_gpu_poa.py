@@ -162,9 +162,34 @@ def test_kernel_modes_agree_on_noisy_windows():
             for _ in range(32)]
     eng = hip.Engine()
     out = {}
-    for mode in (1, 2, 3, 4):
+    for mode in (1, 2, 3, 4, 5):
         eng.poa_set_mode(mode)
         out[mode], st, _ = eng.poa_consensus_batch(wins)
         assert np.all(st == 1), (mode, st)
-    for a, b, c, d in zip(out[1], out[2], out[3], out[4]):
-        assert np.array_equal(a, b) and np.array_equal(a, c) and np.array_equal(a, d)
+    for a, b, c, d, e in zip(out[1], out[2], out[3], out[4], out[5]):
+        assert np.array_equal(a, b) and np.array_equal(a, c) and np.array_equal(a, d) and np.array_equal(a, e)
+
+
+def test_four_windows_per_wave_kernel_equals_one_window_per_wave():
+    """poa3.hip (mode 5: four windows per wave, 16 lanes each) against poa2.hip's 64-column kernel (mode 2) on a batch
+    large enough for ragged groups, partial layers, qualities, predecessor rows beyond the 16-row LDS ring (windows
+    278 and 365 of this seed) and band hits: same status and same consensus, window for window — and the emulated
+    kernel of the CPU suite (tests/test_poa3_emulation.py) gives the same bytes as the GPU for the first windows."""
+    rng = np.random.default_rng(7)
+    wins = []
+    for i in range(400):
+        w, _ = _window(rng, length=int(rng.integers(300, 560)), n_reads=int(rng.integers(5, 34)), err=(0.05, 0.04, 0.04),
+                       partial=0.25 if i % 2 else 0.0, qual=(i % 3 == 0))
+        wins.append(w)
+    eng = hip.Engine()
+    eng.poa_set_mode(2)
+    c2, s2, _ = eng.poa_consensus_batch(wins)
+    eng.poa_set_mode(5)
+    c5, s5, _ = eng.poa_consensus_batch(wins)
+    assert np.array_equal(s2 & 0xFF, s5 & 0xFF)
+    assert int(np.sum((s5 & 0xFF) == 1)) >= 390
+    for a, b, st in zip(c2, c5, s5):
+        assert np.array_equal(a, b), st
+    emu, st_emu = hip.poa_banded_emulate(wins[:8])
+    for a, b, sa, sb in zip(emu, c5[:8], st_emu, s5[:8]):
+        assert (int(sa) & 0xFF) == (int(sb) & 0xFF) and np.array_equal(a, b)
