@@ -613,7 +613,26 @@ __device__ void chain_wave(const u64* __restrict__ p, u32 n, bool strand, u64 g0
       const u64 cur = __shfl(mine, static_cast<int>(t), 64);
       const u32 lhs = static_cast<u32>(cur >> 32), rhs = static_cast<u32>(cur);
       u32 lo = 1, hi = longest;
-      if (longest > 512) {
+      bool appended = false;
+      if (longest > 64) {
+        // The common case of a colinear interval: cur extends the longest chain.  ram's search then answers "precedes" at
+        // every probe, and that probe path is known in advance — probe i looks at length
+        // longest + 1 - a + (a - 1) / 2 with a = longest >> i, while a >= 1 — so lane i tests probe i, and one ballot
+        // says whether the search ends at longest + 1.  (Any failed probe: the general replay below.)
+        const u32 a = lane < 32 ? longest >> lane : 0u;
+        bool fail = false;
+        if (a >= 1) {
+          const u64 q = tail_pos[longest + 1 - a + ((a - 1) >> 1)];
+          const u32 ql = static_cast<u32>(q >> 32), qr = static_cast<u32>(q);
+          fail = !(ql < lhs && (strand ? qr < rhs : qr > rhs));
+        }
+        if (!__ballot(fail)) {
+          lo = longest + 1;
+          appended = true;
+        }
+      }
+      if (appended) {
+      } else if (longest > 512) {
         // Long chains: ram's binary search probes ~log2(longest) tails, one after the other.  Here six levels of its
         // search tree are evaluated at once: lane h (heap index 1..63) derives the (lo, hi) range ram would have at tree
         // node h from the current range, tests the predicate at that node's midpoint, a ballot collects the 63 answers
