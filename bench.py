@@ -259,7 +259,7 @@ def main():
     if sharded_mode:  # this rank's reads, resident for every step like `reads` of the single-GPU pass
         b = sharded.partition_reads(rs.lengths, world)
         own_reads = eng.upload(sharded.slice_reads(rs, int(b[rank]), int(b[rank + 1])))
-    legs = {"overlap_s": 0.0, "polish_s": 0.0}
+    legs = {"overlap_s": 0.0, "polish_s": 0.0, "overlap_steps": [], "polish_steps": []}
     last = {}
 
     def step(timed):
@@ -295,6 +295,8 @@ def main():
         if timed:
             legs["overlap_s"] += t_b - t_a
             legs["polish_s"] += t_c - t_b
+            legs["overlap_steps"].append(round(t_b - t_a, 4))
+            legs["polish_steps"].append(round(t_c - t_b, 4))
             last["n_windows"] = n_windows
 
     for _ in range(args.warmup):
@@ -501,6 +503,7 @@ def main():
                 if sharded_mode else ("independent replica per GPU (no data-path collective)" if world > 1 else "1 GPU"),
             },
             "legs": {"overlap_s_per_step": round(ovl_s, 4), "polish_s_per_step": round(pol_s, 4),
+                     "overlap_s_of_each_step": legs["overlap_steps"], "polish_s_of_each_step": legs["polish_steps"],
                      "overlap_gbase_per_s": round(rs.total_bases / ovl_s / 1e9, 3) if ovl_s else None,
                      "polish_gbase_per_s_per_round": round(rs.total_bases / (pol_s / rounds) / 1e9, 3) if rounds and pol_s else None,
                      "windows_per_s": round(last.get("n_windows", 0) / pol_s, 1) if pol_s else None,

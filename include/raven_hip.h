@@ -411,18 +411,19 @@ void rvn_poa_work(const rvn_engine* e, uint64_t out[3]);
 /* Which window kernel rvn_poa_consensus_batch / rvn_polish_round use: 0 (default) = banded LDS kernel with a
  * 64-column band; windows whose alignment touches the band edge are repeated with 128 and then 256 columns, and
  * what is left (or beyond a limit) by the full-matrix kernel; 1 = full-matrix kernel only; 2 / 3 / 4 = 64- / 128- /
- * 256-column band only (flagged windows come back with status 8); 5 = the 64-column band with four windows per wave
- * (poa3.hip) only.  Returns the previous mode. */
+ * 256-column band only (flagged windows come back with status 8); 5 .. 8 = poa3.hip only (several windows per wave):
+ * four windows with a 64-column band / four windows, 32 columns / two windows, 32 columns / two windows, 64 columns.
+ * Returns the previous mode. */
 int rvn_poa_set_mode(rvn_engine* e, int mode);
 /* TEST INFRASTRUCTURE: the four-windows-per-wave banded kernel (poa3.hip) stepped through on the HOST by a 64-fibre
- * wavefront emulator — the same kernel source, no GPU and no engine needed.  Arguments as rvn_poa_consensus_batch;
- * first attempt only (status 8 / 7: the window needs the wider band of the real escalation chain).  The CPU suite
+ * wavefront emulator — the same kernel source, no GPU and no engine needed.  Arguments as rvn_poa_consensus_batch +
+ * variant (0 .. 3 = the kernels of modes 5 .. 8); first attempt only (status 8: the window needs a wider band).  The CPU suite
  * compares it with the oracle (tests/test_poa3_emulation.py); nothing on the product path calls it. */
 int rvn_poa_banded_emulate(const uint8_t* codes, const uint8_t* quals, const uint64_t* layer_offsets,
                            const uint32_t* begins, const uint32_t* ends, const uint32_t* has_qual,
                            const uint32_t* window_offsets, uint32_t n_windows, int match, int mismatch, int gap,
                            int trim, uint8_t* consensus, const uint64_t* consensus_offsets, uint32_t* consensus_len,
-                           uint32_t* status);
+                           uint32_t* status, int variant);
 /* mode 0: windows of the last batch repeated with the 128-column band (wide) / that needed more than that (fallback:
  * 256 columns or the full matrix) */
 uint32_t rvn_poa_fallback_windows(const rvn_engine* e);

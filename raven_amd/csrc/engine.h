@@ -140,10 +140,11 @@ struct Engine {
   u64 polish_last_layers = 0, polish_last_w0 = 0;
   bool polish_last_has_ok = false;
   std::vector<u64> polish_last_read_off;
-  int poa_mode = 0;  // 0 banded 64 -> 128 -> 256 -> full matrix; 1 full matrix only; 2 / 3 / 4 band 64 / 128 / 256 only (tests); 5 band 64, four windows per wave only
+  int poa_mode = 0;  // 0 banded 64 -> 128 -> 256 -> full matrix; 1 full matrix only; 2 / 3 / 4 band 64 / 128 / 256 only (tests); 5 .. 8 poa3.hip only: four windows per wave band 64 / four windows band 32 / two windows band 32 / two windows band 64
   u32 poa_fallback_windows = 0;  // windows of the last batch that needed more than the 128-column band
   u32 poa_fullmatrix_windows = 0;  // ... of which re-run by the full-matrix kernel
   u32 poa_wide_windows = 0;      // windows of the last batch re-run with the 128-column band
+  u32 poa_narrow_windows = 0;    // windows of a 32-column first attempt (poa3.hip) re-run with the 64-column band
   DevBuf anc_slot_off, anc_slot_cnt;
   bool keep_anchors = false;  // map_batch also returns the chain anchors of every overlap
   unsigned long long poa_phase_cycles[8] = {};  // subgraph, dp, traceback, add, order, consensus (last call); [6], [7]: DP cells
@@ -249,7 +250,7 @@ void poa_consensus_batch(Engine& e, const u8* h_codes, const u8* h_quals, const 
 // poa3.hip's kernel stepped through on the host (wavefront emulator): see rvn_poa_banded_emulate
 void poa_banded_emulate(const u8* h_codes, const u8* h_quals, const u64* h_layer_off, const u32* h_begins,
                         const u32* h_ends, const u32* h_has_qual, const u32* h_win_off, u32 n_windows, int m, int n, int g,
-                        int trim, u8* h_out, const u64* h_out_off, u32* h_out_len, u32* h_status);
+                        int trim, u8* h_out, const u64* h_out_off, u32* h_out_len, u32* h_status, int variant);
 
 struct PolishStats {
   u64 n_overlaps = 0, n_reads_used = 0, n_layers = 0, n_windows = 0, n_polished_windows = 0, n_failed_windows = 0;

@@ -974,7 +974,7 @@ int rvn_poa_consensus_batch(rvn_engine* h, const uint8_t* codes, const uint8_t* 
 int rvn_poa_banded_emulate(const uint8_t* codes, const uint8_t* quals, const uint64_t* layer_offsets, const uint32_t* begins,
                            const uint32_t* ends, const uint32_t* has_qual, const uint32_t* window_offsets,
                            uint32_t n_windows, int match, int mismatch, int gap, int trim, uint8_t* consensus,
-                           const uint64_t* consensus_offsets, uint32_t* consensus_len, uint32_t* status) {
+                           const uint64_t* consensus_offsets, uint32_t* consensus_len, uint32_t* status, int variant) {
   return guarded([&]() -> int {
     if (n_windows && (!codes || !layer_offsets || !begins || !ends || !window_offsets || !consensus || !consensus_offsets ||
                       !consensus_len || !status))
@@ -983,7 +983,7 @@ int rvn_poa_banded_emulate(const uint8_t* codes, const uint8_t* quals, const uin
       if (window_offsets[w + 1] <= window_offsets[w])
         return fail(RVN_EINVAL, "[raven_hip] rvn_poa_banded_emulate: window without a backbone");
     poa_banded_emulate(codes, quals, layer_offsets, begins, ends, has_qual, window_offsets, n_windows, match, mismatch, gap,
-                       trim, consensus, consensus_offsets, consensus_len, status);
+                       trim, consensus, consensus_offsets, consensus_len, status, variant);
     return RVN_OK;
   });
 }
@@ -1556,7 +1556,7 @@ void rvn_poa_phase_cycles(const rvn_engine* h, uint64_t out[6]) {
 int rvn_poa_set_mode(rvn_engine* h, int mode) {
   if (!h) return -1;
   const int prev = h->e.poa_mode;
-  if (mode >= 0 && mode <= 5) h->e.poa_mode = mode;
+  if (mode >= 0 && mode <= 8) h->e.poa_mode = mode;
   return prev;
 }
 

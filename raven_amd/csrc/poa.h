@@ -104,6 +104,8 @@ struct PoaBatchDev {  // device-side batch description shared by both launchers
   unsigned long long* phase_cycles;
   const u32* sched;  // window order for the persistent waves (heaviest first), or null
   u32* next;         // work counter (zeroed by the launcher)
+  u32 probe;         // diagnostics (RVN_POA_BAND_PROBE): a polished window's status carries, << 16, how far its alignment
+                     // paths strayed from the band's centre (0..31 columns) — what a narrower band would have to hold
 };
 
 // Per-window scratch of the banded kernels (poa2.hip, poa3.hip): the spoa graph as SoA arrays, the backpointer matrix of
@@ -131,6 +133,7 @@ struct Poa2Slot {
   i32* preds;
   u16* stack;
   u16* pos_node;  // traceback result of the current layer: node aligned to position p, or kNone
+  u16* tgt;       // AddAlignment: graph node of every sequence position (poa3.hip; poa2.hip keeps it in LDS)
 };
 
 template <class F>
@@ -157,6 +160,7 @@ __host__ __device__ inline void poa2_fields(u32 nmax, u32 lmax, u32 band, F&& f,
   f(19, static_cast<size_t>(nmax) * 4);
   f(20, static_cast<size_t>(nmax) * 2);
   f(21, static_cast<size_t>(lmax + 8) * 2);
+  f(22, static_cast<size_t>(lmax + 8) * 2);
 }
 
 inline size_t poa2_slot_bytes(u32 nmax, u32 lmax, u32 band, bool hs = true) {
@@ -166,7 +170,7 @@ inline size_t poa2_slot_bytes(u32 nmax, u32 lmax, u32 band, bool hs = true) {
 }
 
 __host__ __device__ inline Poa2Slot poa2_carve(unsigned char* base, u32 nmax, u32 lmax, u32 band, bool hs = true) {
-  unsigned char* p[22];
+  unsigned char* p[23];
   size_t o = 0;
   poa2_fields(nmax, lmax, band, [&](int i, size_t x) {
     p[i] = base + o;
@@ -195,6 +199,7 @@ __host__ __device__ inline Poa2Slot poa2_carve(unsigned char* base, u32 nmax, u3
   s.preds = reinterpret_cast<i32*>(p[19]);
   s.stack = reinterpret_cast<u16*>(p[20]);
   s.pos_node = reinterpret_cast<u16*>(p[21]);
+  s.tgt = reinterpret_cast<u16*>(p[22]);
   return s;
 }
 
@@ -208,10 +213,13 @@ void poa_run_dev(Engine& e, const PoaWindow* d_wins, const PoaLayer* d_lays, u32
                  u32 max_len, int m, int n, int g, int trim, u8* d_out, u32* d_len, u32* d_status,
                  std::vector<u32>& h_status, double* device_ms, bool allow_full = true);
 void poa_v2_launch(Engine& e, const PoaBatchDev& b, int nch);  // poa2.hip: band = 64 * nch columns
-void poa_v3_launch(Engine& e, const PoaBatchDev& b);           // poa3.hip: 64 columns, four windows per wave
+// poa3.hip: several windows per wave; variant 0 = four windows, 64-column band; 1 = four windows, 32 columns; 2 = two
+// windows, 32 columns; 3 = two windows, 64 columns
+void poa_v3_launch(Engine& e, const PoaBatchDev& b, int variant);
+int poa_v3_band(int variant);
 // poa3.hip's kernel source run on the host under the wavefront emulator (test infrastructure; host arrays everywhere)
 void poa_v3_emulate(const std::vector<PoaWindow>& wins, const std::vector<PoaLayer>& lays, const PoaSrc& src, u32 max_bb,
-                    u32 max_len, int m, int n, int g, int trim, u8* out, u32* out_len, u32* status);
+                    u32 max_len, int m, int n, int g, int trim, u8* out, u32* out_len, u32* status, int variant);
 
 // Persistent waves take windows from a shared counter (longest-processing-time-first order when `sched` is given).
 __device__ __forceinline__ u32 poa_next_window(u32* next, const u32* sched, u32 n_windows) {

@@ -678,6 +678,7 @@ void poa_run_dev(Engine& e, const PoaWindow* d_wins, const PoaLayer* d_lays, u32
   b.out_len = d_len;
   b.status = d_status;
   b.phase_cycles = d_phase;
+  b.probe = std::getenv("RVN_POA_BAND_PROBE") ? 1u : 0u;
   RVN_HIP(hipEventRecord(e.ev0, s));
   // the banded kernels keep scores as int16 (and add the match / mismatch / gap terms as packed int16): scoring
   // parameters far beyond spoa's usual single digits go straight to the int32 full-matrix kernel
@@ -685,16 +686,38 @@ void poa_run_dev(Engine& e, const PoaWindow* d_wins, const PoaLayer* d_lays, u32
   const bool int16_ok = mag(m) <= 24 && mag(n) <= 24 && mag(g) <= 24;
   const int mode = int16_ok ? e.poa_mode : 1;
   // first attempt with the 64-column band: four windows per wave (poa3.hip) or one (poa2.hip)
-  static const bool v3_default = [] {
+  // (RVN_POA3 = 1 .. 4: poa3.hip's variant 0 .. 3 as the first attempt of mode 0)
+  static const int v3_default = [] {
     const char* ev = std::getenv("RVN_POA3");
-    return ev ? std::atoi(ev) != 0 : false;
+    const int v = ev ? std::atoi(ev) : 0;
+    return v >= 1 && v <= 4 ? v - 1 : -1;
   }();
+  const int v3 = mode >= 5 && mode <= 8 ? mode - 5 : (mode == 0 ? v3_default : -1);
   if (mode == 1) poa_v1_launch(e, b);
-  else if (mode == 5 || (mode == 0 && v3_default)) poa_v3_launch(e, b);
+  else if (v3 >= 0) poa_v3_launch(e, b, v3);
   else poa_v2_launch(e, b, mode == 3 ? 2 : (mode == 4 ? 4 : 1));
   RVN_HIP(hipMemcpyAsync(h_status.data(), d_status, static_cast<size_t>(n_windows) * 4, hipMemcpyDeviceToHost, s));
   RVN_HIP(rvn_stream_sync(s));
+  if (b.probe) {  // diagnostics only: histogram of the paths' largest distance from the band centre, first attempt
+    unsigned long long hist[33] = {};
+    u32 polished = 0;
+    for (u32 w = 0; w < n_windows; ++w) {
+      if ((h_status[w] & 0xFFu) != 1u) continue;
+      ++polished;
+      const u32 dv = (h_status[w] >> 16) & 0xFFu;
+      ++hist[dv > 32 ? 32 : dv];
+      h_status[w] = 1;
+    }
+    std::fprintf(stderr, "[raven_hip] poa band probe: %u polished windows of %u; largest distance from the band centre:", polished, n_windows);
+    unsigned long long acc = 0;
+    for (int d = 0; d <= 32; ++d) {
+      acc += hist[d];
+      if (hist[d]) std::fprintf(stderr, " %d:%.4f", d, static_cast<double>(acc) / (polished ? polished : 1));
+    }
+    std::fprintf(stderr, " (cumulative share)\n");
+  }
   e.poa_fallback_windows = 0;
+  e.poa_narrow_windows = 0;
   e.poa_wide_windows = 0;
   e.poa_fullmatrix_windows = 0;
   if (mode == 0) {
@@ -716,6 +739,7 @@ void poa_run_dev(Engine& e, const PoaWindow* d_wins, const PoaLayer* d_lays, u32
       rb.status = d_rstatus;
       rb.sched = nullptr;
       if (which_kernel == 2 || which_kernel == 4) poa_v2_launch(e, rb, which_kernel);
+      else if (which_kernel == 64) poa_v2_launch(e, rb, 1);
       else poa_v1_launch(e, rb);
       poa_scatter_results_kernel<<<div_up(nr, 256), 256, 0, s>>>(d_ridx, nr, d_rlen, d_rstatus, d_len, d_status);
       RVN_LAUNCH_CHECK();
@@ -725,6 +749,13 @@ void poa_run_dev(Engine& e, const PoaWindow* d_wins, const PoaLayer* d_lays, u32
       for (u32 i = 0; i < nr; ++i) h_status[redo[i]] = rs[i];
     };
     std::vector<u32> wide, wider, fullm;
+    if (v3 >= 0 && poa_v3_band(v3) < 64) {  // a 32-column first attempt: what touched its edge gets the 64-column band next
+      std::vector<u32> narrow;
+      for (u32 w = 0; w < n_windows; ++w)
+        if ((h_status[w] & 0xFF) == kPoaBandHit) narrow.push_back(w);
+      if (!narrow.empty()) rerun(narrow, 64);
+      e.poa_narrow_windows = static_cast<u32>(narrow.size());
+    }
     for (u32 w = 0; w < n_windows; ++w) {
       const u32 st = h_status[w] & 0xFF;
       // 7 = a predecessor row had left the 64-column kernel's LDS ring: the wider kernels keep a score copy in HBM
@@ -863,7 +894,7 @@ void poa_consensus_batch(Engine& e, const u8* h_codes, const u8* h_quals, const 
 // infrastructure for the CPU suite; needs no GPU and no engine.
 void poa_banded_emulate(const u8* h_codes, const u8* h_quals, const u64* h_layer_off, const u32* h_begins,
                         const u32* h_ends, const u32* h_has_qual, const u32* h_win_off, u32 n_windows, int m, int n, int g,
-                        int trim, u8* h_out, const u64* h_out_off, u32* h_out_len, u32* h_status) {
+                        int trim, u8* h_out, const u64* h_out_off, u32* h_out_len, u32* h_status, int variant) {
   if (n_windows == 0) return;
   std::vector<PoaWindow> wins;
   std::vector<PoaLayer> lays;
@@ -873,7 +904,7 @@ void poa_banded_emulate(const u8* h_codes, const u8* h_quals, const u64* h_layer
   PoaSrc src{};
   src.codes = h_codes;
   src.quals = h_quals;
-  poa_v3_emulate(wins, lays, src, max_bb, max_len, m, n, g, trim, h_out, h_out_len, h_status);
+  poa_v3_emulate(wins, lays, src, max_bb, max_len, m, n, g, trim, h_out, h_out_len, h_status, variant);
 }
 
 }  // namespace rvn

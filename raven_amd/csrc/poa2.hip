@@ -183,7 +183,7 @@ __device__ __forceinline__ u32 poa2_window(const PoaWindow& win, const PoaLayer*
                                            const PoaSrc& src, Poa2Slot& g,
                                            u32 nmax, u32 lmax, int m, int n_, int gp, int trim, Poa2Lds<NCH>& S,
                                            u8* __restrict__ out, u32* out_len,
-                                           unsigned long long* __restrict__ phase_cycles) {
+                                           unsigned long long* __restrict__ phase_cycles, u32 probe) {
   constexpr int kBand = 64 * NCH;
   constexpr int kRingStride = kBand + 2;
   const int lane = lane_id();
@@ -236,6 +236,7 @@ __device__ __forceinline__ u32 poa2_window(const PoaWindow& win, const PoaLayer*
   wsync();
   const u32 offset = static_cast<u32>(0.01 * blen);
   u32 failed = 0;
+  u32 dev_max = 0;  // probe: largest distance of a traceback cell from the centre of its row's band
   // (match | gap << 16), (mismatch | gap << 16): what v_pk_add_i16 adds to a (diagonal, vertical) candidate pair
   const u32 pk_match = (static_cast<u32>(m) & 0xFFFFu) | (static_cast<u32>(gp) << 16);
   const u32 pk_mismatch = (static_cast<u32>(n_) & 0xFFFFu) | (static_cast<u32>(gp) << 16);
@@ -620,6 +621,10 @@ __device__ __forceinline__ u32 poa2_window(const PoaWindow& win, const PoaLayer*
           break;
         }
         if ((idx < 2 && bt > 0) || (idx > kBand - 3 && bt + kBand < static_cast<i32>(w))) band_hit = 1;
+        if (probe && (idx >= kBand / 2 ? bt + kBand < static_cast<i32>(w) : bt > 0)) {  // (not where the band is clamped to the layer's ends)
+          const u32 dv = static_cast<u32>(idx >= kBand / 2 ? idx - kBand / 2 : kBand / 2 - 1 - idx);
+          dev_max = dv > dev_max ? dv : dev_max;
+        }
         const u32 code = static_cast<u32>(rfl(static_cast<int>(S.u.stage[l * kBand + idx])));
         if (code == 32u) {
           if (j == 0) {
@@ -823,7 +828,7 @@ __device__ __forceinline__ u32 poa2_window(const PoaWindow& win, const PoaLayer*
     atomicAdd(&phase_cycles[6], c_full);
     atomicAdd(&phase_cycles[7], c_band);
   }
-  return 1;
+  return 1u | (probe ? (dev_max > 255u ? 255u : dev_max) << 16 : 0u);
 }
 
 template <int NCH, int WPB, int OCC>
@@ -834,7 +839,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(OCC)))
                                                   int gp, int trim, u8* __restrict__ out, u32* __restrict__ out_len,
                                                   u32* __restrict__ status,
                                                   unsigned long long* __restrict__ phase_cycles,
-                                                  const u32* __restrict__ sched, u32* __restrict__ next) {
+                                                  const u32* __restrict__ sched, u32* __restrict__ next, u32 probe) {
   __shared__ Poa2Lds<NCH> lds[WPB];
   const u32 wv = static_cast<u32>(__builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6)));
   const u32 slot = blockIdx.x * WPB + wv;
@@ -845,7 +850,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(OCC)))
     if (wi == 0xFFFFFFFFu) break;
     const PoaWindow win = windows[wi];
     const u32 st = poa2_window<NCH>(win, layers, src, g, nmax, lmax, m, n_, gp, trim, lds[wv],
-                               out + win.out_off, out_len + wi, phase_cycles);
+                               out + win.out_off, out_len + wi, phase_cycles, probe);
     if (lane_id() == 0) status[wi] = st;
     wsync();
   }
@@ -872,23 +877,23 @@ void poa_v2_launch(Engine& e, const PoaBatchDev& b, int nch) {
   if (nch == 1 && occ == 5) {
     RVN_KLAUNCH(kKPoaBanded, (poa2_kernel<1, 4, 5><<<n_slots / 4, 256, 0, e.stream>>>(
                                  b.wins, b.n_windows, b.layers, b.src, d_scratch, slot_bytes, n_slots, b.nmax,
-                                 b.lmax, b.m, b.n, b.g, b.trim, b.out, b.out_len, b.status, b.phase_cycles, b.sched, b.next)));
+                                 b.lmax, b.m, b.n, b.g, b.trim, b.out, b.out_len, b.status, b.phase_cycles, b.sched, b.next, b.probe)));
   } else if (nch == 1 && occ == 6) {
     RVN_KLAUNCH(kKPoaBanded, (poa2_kernel<1, 4, 6><<<n_slots / 4, 256, 0, e.stream>>>(
                                  b.wins, b.n_windows, b.layers, b.src, d_scratch, slot_bytes, n_slots, b.nmax,
-                                 b.lmax, b.m, b.n, b.g, b.trim, b.out, b.out_len, b.status, b.phase_cycles, b.sched, b.next)));
+                                 b.lmax, b.m, b.n, b.g, b.trim, b.out, b.out_len, b.status, b.phase_cycles, b.sched, b.next, b.probe)));
   } else if (nch == 1) {
     RVN_KLAUNCH(kKPoaBanded, (poa2_kernel<1, 4, 7><<<n_slots / 4, 256, 0, e.stream>>>(
                                  b.wins, b.n_windows, b.layers, b.src, d_scratch, slot_bytes, n_slots, b.nmax,
-                                 b.lmax, b.m, b.n, b.g, b.trim, b.out, b.out_len, b.status, b.phase_cycles, b.sched, b.next)));
+                                 b.lmax, b.m, b.n, b.g, b.trim, b.out, b.out_len, b.status, b.phase_cycles, b.sched, b.next, b.probe)));
   } else if (nch == 2) {
     RVN_KLAUNCH(kKPoaBanded, (poa2_kernel<2, 4, 1><<<n_slots / 4, 256, 0, e.stream>>>(
                                  b.wins, b.n_windows, b.layers, b.src, d_scratch, slot_bytes, n_slots, b.nmax,
-                                 b.lmax, b.m, b.n, b.g, b.trim, b.out, b.out_len, b.status, b.phase_cycles, b.sched, b.next)));
+                                 b.lmax, b.m, b.n, b.g, b.trim, b.out, b.out_len, b.status, b.phase_cycles, b.sched, b.next, b.probe)));
   } else {  // 256 columns: 21.6 KB of LDS per wave -> 2 waves per workgroup
     RVN_KLAUNCH(kKPoaBanded, (poa2_kernel<4, 2, 1><<<n_slots / 2, 128, 0, e.stream>>>(
                                  b.wins, b.n_windows, b.layers, b.src, d_scratch, slot_bytes, n_slots, b.nmax,
-                                 b.lmax, b.m, b.n, b.g, b.trim, b.out, b.out_len, b.status, b.phase_cycles, b.sched, b.next)));
+                                 b.lmax, b.m, b.n, b.g, b.trim, b.out, b.out_len, b.status, b.phase_cycles, b.sched, b.next, b.probe)));
   }
 }
 

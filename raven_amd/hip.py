@@ -130,7 +130,7 @@ def lib():
     L.rvn_edit_distance_batch.argtypes = [vp, vp, vp, u32, vp, C.POINTER(dbl), C.POINTER(u64)]
     L.rvn_poa_consensus_batch.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, u32, i32, i32, i32, i32, vp, vp, vp, vp,
                                           C.POINTER(dbl)]
-    L.rvn_poa_banded_emulate.argtypes = [vp, vp, vp, vp, vp, vp, vp, u32, i32, i32, i32, i32, vp, vp, vp, vp]
+    L.rvn_poa_banded_emulate.argtypes = [vp, vp, vp, vp, vp, vp, vp, u32, i32, i32, i32, i32, vp, vp, vp, vp, i32]
     L.rvn_poa_phase_cycles.argtypes = [vp, vp]
     L.rvn_polish_target_reads.argtypes = [vp, vp, u32]
     L.rvn_polish_set_chunk_windows.argtypes = [vp, u64]
@@ -392,14 +392,15 @@ def _unpack_poa_consensus(a):
     return [a["out"][int(ooff[i]): int(ooff[i]) + int(a["out_len"][i])].copy() for i in range(a["nw"])]
 
 
-def poa_banded_emulate(windows, m=3, n=-5, g=-4, trim=True):
+def poa_banded_emulate(windows, m=3, n=-5, g=-4, trim=True, variant=0):
     """TEST INFRASTRUCTURE: poa3.hip's kernel source stepped through on the HOST by the wavefront emulator (no GPU, no
-    engine).  First attempt of the escalation chain only: status 8 / 7 = the window needs a wider band.  Returns
-    (list of consensus code arrays, status array)."""
+    engine).  variant 0 .. 3 = the kernels of poa_set_mode(5 .. 8): four windows per wave with a 64- / 32-column band,
+    two windows with a 32- / 64-column band.  First attempt of the escalation chain only: status 8 = the window needs
+    a wider band.  Returns (list of consensus code arrays, status array)."""
     a = _pack_poa_windows(windows)
     _check(lib().rvn_poa_banded_emulate(
         _p(a["codes"]), _p(a["quals"]), _p(a["loff"]), _p(a["begins"]), _p(a["ends"]), _p(a["hasq"]), _p(a["woff"]),
-        a["nw"], m, n, g, int(trim), _p(a["out"]), _p(a["ooff"]), _p(a["out_len"]), _p(a["status"])))
+        a["nw"], m, n, g, int(trim), _p(a["out"]), _p(a["ooff"]), _p(a["out_len"]), _p(a["status"]), int(variant)))
     return _unpack_poa_consensus(a), a["status"]
 
 
@@ -828,7 +829,8 @@ class Engine:
         return int(lib().rvn_polish_set_chunk_windows(self._h, int(windows)))
 
     def poa_set_mode(self, mode):
-        """0 band 64 -> 128 -> full matrix (default), 1 full matrix only, 2 band 64 only, 3 band 128 only."""
+        """0 band 64 -> 128 -> 256 -> full matrix (default), 1 full matrix only, 2 / 3 / 4 band 64 / 128 / 256 only,
+        5 .. 8 the grouped kernels of poa3.hip only (4 windows x band 64, 4 x 32, 2 x 32, 2 x 64)."""
         return int(lib().rvn_poa_set_mode(self._h, int(mode)))
 
     def poa_fallback_windows(self):

@@ -190,6 +190,19 @@ def test_four_windows_per_wave_kernel_equals_one_window_per_wave():
     assert int(np.sum((s5 & 0xFF) == 1)) >= 390
     for a, b, st in zip(c2, c5, s5):
         assert np.array_equal(a, b), st
+    # the other lane layouts of the same source: four windows x 32 columns, two windows x 32 / x 64 columns; a
+    # 32-column band flags more windows (8), whatever it polishes is the same consensus
+    for mode, band in ((6, 32), (7, 32), (8, 64)):
+        eng.poa_set_mode(mode)
+        cm, sm, _ = eng.poa_consensus_batch(wins)
+        both = 0
+        for a, b, sa, sb in zip(c2, cm, s2, sm):
+            assert (int(sb) & 0xFF) in (1, 8)
+            if (int(sa) & 0xFF) == 1 and (int(sb) & 0xFF) == 1:
+                both += 1
+                assert np.array_equal(a, b), mode
+        assert both >= (390 if band == 64 else 340), (mode, both)
+    eng.poa_set_mode(0)
     emu, st_emu = hip.poa_banded_emulate(wins[:8])
     for a, b, sa, sb in zip(emu, c5[:8], st_emu, s5[:8]):
         assert (int(sa) & 0xFF) == (int(sb) & 0xFF) and np.array_equal(a, b)

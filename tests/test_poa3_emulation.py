@@ -5,6 +5,7 @@ whole kernel — group-parallel NW rows, lock-step tracebacks, graph update, con
 whose alignment touches the 64-column band comes back flagged (status 8) and is not compared.
 The GPU side of the same comparison is tests/test_gpu_poa.py (mode 5) and tools/check_poa3.py."""
 import numpy as np
+import pytest
 
 from oracle import oracle
 from raven_amd import hip
@@ -55,10 +56,10 @@ def _oracle(w, trim=True):
 def _compare(wins, min_polished, **kw):
     cons, status = hip.poa_banded_emulate(wins, **kw)
     polished = 0
-    for w, c, st in zip(wins, cons, status):
+    for i, (w, c, st) in enumerate(zip(wins, cons, status)):
         if (int(st) & 0xFF) == 1:
             polished += 1
-            assert np.array_equal(c, _oracle(w, trim=kw.get("trim", True)))
+            assert np.array_equal(c, _oracle(w, trim=kw.get("trim", True))), (i, kw)
         else:
             assert (int(st) & 0xFF) in (0, 8), st
     assert polished >= min_polished
@@ -122,6 +123,27 @@ def test_rows_that_left_the_ring():
             layers.append(_mutate(rng, t, 0.03, 0.02, 0.02))
         wins.append(dict(layers=layers))
     _compare(wins, min_polished=3)
+
+
+@pytest.mark.parametrize("variant", [1, 2, 3])
+def test_other_lane_layouts(variant):
+    """The same kernel source with the other (windows per wave, columns per lane) layouts: 1 = four windows with a
+    32-column band (16 lanes x 2 columns), 2 = two windows with a 32-column band (32 lanes x 1), 3 = two windows with a
+    64-column band (32 lanes x 2).  A 32-column band flags the long-insertion windows (status 8) instead of polishing
+    them; everything polished equals the oracle."""
+    rng = np.random.default_rng(5)
+    wins = [_window(rng, int(rng.integers(80, 300)), int(rng.integers(3, 14)), err=(0.03, 0.02, 0.02),
+                    partial=0.3 if i % 2 else 0.0, qual=(i % 3 == 0)) for i in range(10)]
+    truth = rng.integers(0, 4, size=220, dtype=np.uint8)
+    layers = [_mutate(rng, truth, 0.03, 0.02, 0.02)]
+    for r in range(10):  # rows beyond the ring (band 64) / beyond the band (band 32)
+        t = truth
+        if r % 2 == 0:
+            t = np.concatenate([truth[:100], rng.integers(0, 4, size=24, dtype=np.uint8), truth[100:]])
+        layers.append(_mutate(rng, t, 0.03, 0.02, 0.02))
+    wins.append(dict(layers=layers))
+    cons, status = _compare(wins, min_polished=10, variant=variant)
+    assert (int(status[-1]) & 0xFF) == (8 if variant in (1, 2) else 1)
 
 
 def test_scoring_parameters():
