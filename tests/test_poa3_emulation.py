@@ -154,3 +154,36 @@ def test_scoring_parameters():
         if (int(st) & 0xFF) == 1:
             o = oracle.poa_window(w["layers"], begins=w["begins"], ends=w["ends"], quals=w["quals"], m=5, n=-4, g=-8)[0]
             assert np.array_equal(c, o)
+
+
+def test_nodes_with_many_in_edges():
+    """Insertions of every letter (and of two letters) in front of the same backbone position give that node five and
+    more in-edges: the row's fifth in-edge is looked up by the row's owner lane and resolved by the group (the slow
+    path of the row loop and of the traceback)."""
+    rng = np.random.default_rng(17)
+    truth = rng.integers(0, 4, size=160, dtype=np.uint8)
+    layers = [truth.copy()]
+    for rep in range(2):
+        for letter in range(4):
+            layers.append(np.concatenate([truth[:70], np.array([letter], np.uint8), truth[70:]]))
+            layers.append(np.concatenate([truth[:70], np.array([letter, (letter + 1) & 3], np.uint8), truth[70:]]))
+    layers += [truth.copy() for _ in range(3)]
+    for variant in (0, 1, 2):
+        cons, status = hip.poa_banded_emulate([dict(layers=layers)] * 2 + [dict(layers=layers[:9])], variant=variant)
+        assert [int(s) & 0xFF for s in status] == [1, 1, 1]
+        assert np.array_equal(cons[0], _oracle(dict(layers=layers)))
+        assert np.array_equal(cons[2], _oracle(dict(layers=layers[:9])))
+
+
+def test_limits_are_reported():
+    """A layer longer than the banded kernels take (896 bases) comes back as status 4 with the backbone as output, as on
+    the GPU, and does not disturb the other windows of its wave."""
+    rng = np.random.default_rng(23)
+    bb = rng.integers(0, 4, size=950, dtype=np.uint8)
+    long_w = dict(layers=[bb, bb.copy(), bb.copy()])
+    ok_w = _window(rng, 120, 6)
+    cons, status = hip.poa_banded_emulate([long_w, ok_w, long_w, ok_w, ok_w])
+    for i in (0, 2):
+        assert (int(status[i]) & 0xFF) == 4 and np.array_equal(cons[i], bb)
+    for i in (1, 3, 4):
+        assert (int(status[i]) & 0xFF) == 1 and np.array_equal(cons[i], _oracle(ok_w))
