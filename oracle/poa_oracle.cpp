@@ -478,6 +478,61 @@ int orc_poa_window(const std::uint8_t* codes, const std::uint8_t* quals, const s
 // DEBUG: replays the device kernel's incremental topological-order rule (raven_amd/csrc/poa.hip step 5) next to
 // the real graph construction and returns the first layer after which some edge has rank(tail) >= rank(head)
 // (-1 if the order stays valid). info[0..3] = tail, head, rank(tail), rank(head) of the first violation.
+// Graph-shape statistics gathered while orc_poa_order_check replays the kernel's incremental order (design input for
+// the rows-on-lanes POA kernel): per layer, BEFORE the layer is added, over the graph in kernel rank order.
+//  [0] layers  [1] sum nodes  [2] sum edges  [3] sum over ranks of max in-degree within the aligned block of 16 ranks
+//  [4] the same over blocks of 64 ranks  [5] max lookback (rank(head) - rank(tail))  [6] edges with lookback > 15
+//  [7] edges with lookback > 31  [8] rank pairs where bpos decreases  [9] max in-degree  [10..26] in-degree histogram 0..16
+//  [27] edges with lookback > 47  [28] sum over ranks of in-degree clipped at 4 block-of-64 max  [29] nodes with in-degree > 4
+//  [30] nodes with in-degree > 6 [31] nodes with in-degree > 8
+static std::int64_t* g_stats = nullptr;
+void orc_poa_stats_buffer(std::int64_t* buf) { g_stats = buf; }
+static void poa_graph_stats(const poa::Graph& graph, const std::vector<std::uint32_t>& rank_of,
+                            const std::vector<std::uint32_t>& bpos) {
+  if (!g_stats) return;
+  const std::uint32_t n = graph.nodes.size();
+  std::vector<std::uint32_t> deg_by_rank(n, 0), node_at(n, 0);
+  for (std::uint32_t v = 0; v < n; ++v) {
+    deg_by_rank[rank_of[v]] = graph.nodes[v].inedges.size();
+    node_at[rank_of[v]] = v;
+  }
+  g_stats[0] += 1;
+  g_stats[1] += n;
+  g_stats[2] += graph.edges.size();
+  for (std::uint32_t r0 = 0; r0 < n; r0 += 16) {
+    std::uint32_t mx = 0, cnt = 0;
+    for (std::uint32_t r = r0; r < std::min(n, r0 + 16); ++r) { mx = std::max(mx, deg_by_rank[r]); ++cnt; }
+    g_stats[3] += static_cast<std::int64_t>(mx) * cnt;
+  }
+  for (std::uint32_t r0 = 0; r0 < n; r0 += 64) {
+    std::uint32_t mx = 0, cnt = 0;
+    for (std::uint32_t r = r0; r < std::min(n, r0 + 64); ++r) { mx = std::max(mx, deg_by_rank[r]); ++cnt; }
+    g_stats[4] += static_cast<std::int64_t>(mx) * cnt;
+  }
+  for (const auto& e : graph.edges) {
+    const std::int64_t lb = static_cast<std::int64_t>(rank_of[e.head]) - rank_of[e.tail];
+    g_stats[5] = std::max(g_stats[5], lb);
+    if (lb > 15) g_stats[6] += 1;
+    if (lb > 31) g_stats[7] += 1;
+    if (lb > 47) g_stats[27] += 1;
+    if (lb > 23) g_stats[32] += 1;
+    const std::int64_t db = static_cast<std::int64_t>(bpos[e.head]) - bpos[e.tail];
+    g_stats[33] = std::max(g_stats[33], db);
+    if (db > 8) g_stats[34] += 1;
+    if (db > 14) g_stats[35] += 1;
+  }
+  for (std::uint32_t r = 1; r < n; ++r)
+    if (bpos[node_at[r]] < bpos[node_at[r - 1]]) g_stats[8] += 1;
+  for (std::uint32_t v = 0; v < n; ++v) {
+    const std::uint32_t d = graph.nodes[v].inedges.size();
+    g_stats[9] = std::max<std::int64_t>(g_stats[9], d);
+    g_stats[10 + std::min<std::uint32_t>(d, 16)] += 1;
+    if (d > 4) g_stats[29] += 1;
+    if (d > 6) g_stats[30] += 1;
+    if (d > 8) g_stats[31] += 1;
+  }
+}
+
 int orc_poa_order_check(const std::uint8_t* codes, const std::uint64_t* offsets, const std::uint32_t* begins,
                         const std::uint32_t* ends, std::uint32_t n_layers, int m, int n, int g, std::int64_t* info) {
   std::vector<poa::Layer> layers(n_layers);
@@ -493,6 +548,8 @@ int orc_poa_order_check(const std::uint8_t* codes, const std::uint64_t* offsets,
   graph.AddAlignment(poa::Alignment(), bb.codes, bb.len, poa::Weights(bb));
   std::vector<std::uint32_t> rank_of(bb.len);
   for (std::uint32_t i = 0; i < bb.len; ++i) rank_of[i] = i;
+  std::vector<std::uint32_t> bpos(bb.len);  // the kernel's backbone coordinate of a node (anchor column; carried over insertions)
+  for (std::uint32_t i = 0; i < bb.len; ++i) bpos[i] = i;
   std::vector<std::uint32_t> rk(n_layers);
   for (std::uint32_t i = 0; i < n_layers; ++i) rk[i] = i;
   std::stable_sort(rk.begin() + 1, rk.end(), [&](std::uint32_t a, std::uint32_t b) { return layers[a].begin < layers[b].begin; });
@@ -509,8 +566,19 @@ int orc_poa_order_check(const std::uint8_t* codes, const std::uint64_t* offsets,
       for (auto& it : alignment)
         if (it.first != -1) it.first = mapping[it.first];
     }
+    poa_graph_stats(graph, rank_of, bpos);
     const std::uint32_t n_old = graph.nodes.size();
     graph.AddAlignment(alignment, l.codes, l.len, poa::Weights(l));
+    {  // backbone coordinates of the new nodes, as the kernel assigns them
+      bpos.resize(graph.nodes.size(), 0);
+      std::uint32_t carry = l.begin;
+      for (std::size_t q = 0; q < graph.path_nodes.size(); ++q)
+        if (graph.path_aligned[q] != -1) { carry = bpos[graph.path_aligned[q]]; break; }
+      for (std::size_t q = 0; q < graph.path_nodes.size(); ++q) {
+        if (graph.path_aligned[q] != -1) carry = bpos[graph.path_aligned[q]];
+        if (static_cast<std::uint32_t>(graph.path_nodes[q]) >= n_old) bpos[graph.path_nodes[q]] = carry;
+      }
+    }
     // kernel rule
     auto gmax = [&](std::uint32_t v) {
       std::uint32_t r = rank_of[v];

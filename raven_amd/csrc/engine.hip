@@ -1556,7 +1556,7 @@ void rvn_poa_phase_cycles(const rvn_engine* h, uint64_t out[6]) {
 int rvn_poa_set_mode(rvn_engine* h, int mode) {
   if (!h) return -1;
   const int prev = h->e.poa_mode;
-  if (mode >= 0 && mode <= 8) h->e.poa_mode = mode;
+  if (mode >= 0 && mode <= 9) h->e.poa_mode = mode;
   return prev;
 }
 

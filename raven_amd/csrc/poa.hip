@@ -693,7 +693,14 @@ void poa_run_dev(Engine& e, const PoaWindow* d_wins, const PoaLayer* d_lays, u32
     return v >= 1 && v <= 4 ? v - 1 : -1;
   }();
   const int v3 = mode >= 5 && mode <= 8 ? mode - 5 : (mode == 0 ? v3_default : -1);
+  // rows on lanes (poa4.hip, 32-column band): mode 9 alone, or the first attempt of mode 0 with RVN_POA4=1
+  static const bool v4_default = [] {
+    const char* ev = std::getenv("RVN_POA4");
+    return ev && std::atoi(ev) != 0;
+  }();
+  const bool v4 = mode == 9 || (mode == 0 && v3 < 0 && v4_default);
   if (mode == 1) poa_v1_launch(e, b);
+  else if (v4) poa_v4_launch(e, b);
   else if (v3 >= 0) poa_v3_launch(e, b, v3);
   else poa_v2_launch(e, b, mode == 3 ? 2 : (mode == 4 ? 4 : 1));
   RVN_HIP(hipMemcpyAsync(h_status.data(), d_status, static_cast<size_t>(n_windows) * 4, hipMemcpyDeviceToHost, s));
@@ -749,7 +756,7 @@ void poa_run_dev(Engine& e, const PoaWindow* d_wins, const PoaLayer* d_lays, u32
       for (u32 i = 0; i < nr; ++i) h_status[redo[i]] = rs[i];
     };
     std::vector<u32> wide, wider, fullm;
-    if (v3 >= 0 && poa_v3_band(v3) < 64) {  // a 32-column first attempt: what touched its edge gets the 64-column band next
+    if (v4 || (v3 >= 0 && poa_v3_band(v3) < 64)) {  // a 32-column first attempt: what touched its edge gets the 64-column band next
       std::vector<u32> narrow;
       for (u32 w = 0; w < n_windows; ++w)
         if ((h_status[w] & 0xFF) == kPoaBandHit) narrow.push_back(w);
@@ -904,7 +911,8 @@ void poa_banded_emulate(const u8* h_codes, const u8* h_quals, const u64* h_layer
   PoaSrc src{};
   src.codes = h_codes;
   src.quals = h_quals;
-  poa_v3_emulate(wins, lays, src, max_bb, max_len, m, n, g, trim, h_out, h_out_len, h_status, variant);
+  if (variant == 4) poa_v4_emulate(wins, lays, src, max_bb, max_len, m, n, g, trim, h_out, h_out_len, h_status);
+  else poa_v3_emulate(wins, lays, src, max_bb, max_len, m, n, g, trim, h_out, h_out_len, h_status, variant);
 }
 
 }  // namespace rvn

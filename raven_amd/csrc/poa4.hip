@@ -1,0 +1,1357 @@
+// poa4.hip — banded POA window kernel with the graph ROWS ON THE LANES: the first attempt of rvn_poa_consensus_batch / of
+// a polishing round's consensus stage (racon Window::GenerateConsensus over spoa, as driven by raven::Polish,
+// RavenLib/src/polish.cc:43-51; scores RavenLib/include/raven/graph/polish.hpp:13-17).  Same algorithm, graph layout, tie
+// rules and escalation as poa2.hip (a window whose alignment touches the 32-column band goes on to poa2's 64 / 128 /
+// 256 columns and the full-matrix kernel); what changes is how the NW of a layer sits on the wave.
+//
+// poa2 advances ONE graph row per loop iteration (64 lanes = 64 columns): every iteration is a dependent chain
+// (ring write -> ring read -> candidates -> 6-step prefix maximum -> ring write) behind ~90 scalar instructions of row
+// decode, and the kernel waits more than it issues.  Here a window owns 16 lanes, a lane owns a whole graph row and
+// walks it left to right, two columns per step, so
+//   * the horizontal gap chain is two max instructions inside the lane (no cross-lane prefix),
+//   * a predecessor row is read from the window's LDS ring where another lane left it >= 1 step earlier (one aligned
+//     32-bit read per in-edge and step: the static schedule below guarantees the cells exist), and a row's descriptor
+//     (band start, match mask against the layer, LDS addresses of up to 8 predecessor rows) is one 32-byte record built
+//     by a per-layer pre-pass, so the step loop decodes nothing,
+//   * in-edges are folded with v_max on (score << 6 | diagonal << 5 | 15 - in-edge) keys: spoa's tie rule (diagonal
+//     before vertical, first in-edge first) is the maximum's and the backpointer falls out of its low bits,
+//   * backpointers leave as ONE coalesced 16-byte store per lane and 8 steps into a time-major stream (step, lane); the
+//     traceback maps (row, column) -> (step, lane) through the descriptor.
+// Schedule (all band starts even and non-decreasing along the topological order): row rho of the layer's rank range
+// runs on lane rho % 16 during steps S - 1 .. S + 15, S = rho + rho / 16 + (b_rho - b_0) / 2 + 1 (step S - 1 only reads:
+// it loads the cell left of the first column), computing columns b + 2k, b + 2k + 1 at step S + k.  A predecessor pi
+// < rho with band start b_pi <= b_rho has written column j by step S_pi + (j - b_pi) / 2 <= S_rho + (j - b_rho) / 2 - 1:
+// one step before it is read.  Sixteen lanes are always busy except for the (b - b_0) / 2 drift (~20 % of the steps).
+//
+// Integer VALU + LDS bound; no MFMA.  Written against sv:: (simt.h): the same source runs under the host wavefront
+// emulator (tests/test_poa4_emulation.py -> rvn_poa_banded_emulate, variant 4).
+#include <algorithm>
+#include <cstddef>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "poa.h"
+
+namespace rvn {
+
+namespace {
+
+struct P4 {
+  static constexpr int G = 4, GS = 16, kBand = 32;
+  static constexpr int kRing = 24;    // score rows a window keeps in LDS = longest in-edge (in ranks) + 1
+  static constexpr int kRowB = 104;   // bytes per ring row: 2 -inf cells | 32 cells | 18 -inf cells
+  static constexpr int kMaxD = 16;    // largest band-start difference along an in-edge (the right pads cover it)
+  static constexpr int kEdges = 8;    // in-edges a row descriptor holds; a row with more sends the window to poa2
+  static constexpr int kU = 8;        // steps between two service points (descriptor prefetch, backpointer store)
+  static constexpr int kTbBlocks = 7; // 8-step blocks of the backpointer stream staged per 16 traceback rows
+};
+constexpr u32 kNone4 = 0xFFFFu;
+constexpr i32 kNegKey = kNegInf16 * 64;
+constexpr i32 kNegU = -0x30000000;
+constexpr u32 kInactiveS = 0x7FFFu;
+
+struct alignas(16) Poa4Group {
+  union {
+    u32 ring32[P4::kRing * P4::kRowB / 4];  // DP: [kRing][2 pads | 32 cells | 18 pads] int16, slot = rho % kRing
+    struct {
+      u32 d[16 * 4];                     // traceback: d0, d1, d7 of the 16 rows of a block
+      uint4 bp[P4::kTbBlocks * 16];      // and the 8-step blocks of the backpointer stream that cover them
+    } tb;
+    u8 bytes[kPoa2MaxSeq + 16];          // layer set-up: one-byte codes before they are packed
+  } u;
+  u32 seq2[60];  // the layer, 2 bits per base, position p at bits 2 (p + 1): column j's base sits at bit 2 j
+  u32 dump[16];  // where rows outside the layer's subgraph leave their cells
+};
+struct alignas(16) Poa4Lds {
+  Poa4Group g[P4::G];
+  u32 neg[20];  // -inf cells: what a descriptor's unused in-edges point at
+};
+static_assert(sizeof(Poa4Lds) <= 11520, "fourteen waves per CU need <= 11.4 KB of LDS each");
+
+struct Poa4Args {
+  const PoaWindow* windows;
+  u32 n_windows;
+  const PoaLayer* layers;
+  PoaSrc src;
+  unsigned char* scratch;
+  size_t slot_bytes;
+  u32 nmax, lmax;
+  int m, n_, gp, trim;
+  u8* out;
+  u32* out_len;
+  u32* status;
+  unsigned long long* phase_cycles;
+  const u32* sched;
+  u32* next;
+};
+
+// Per-window scratch: poa2's graph arrays + the row descriptors of the current layer + its backpointer stream.
+struct Poa4Slot {
+  Poa2Slot g;
+  uint4* desc;   // 2 per row: {S | own << 16, node | b << 16 | np << 26 | marked << 30 | end << 31, match mask, e0 | e1 << 16},
+                 //            {e2 | e3 << 16, e4 | e5 << 16, e6 | e7 << 16, rank distances of in-edges 0..5 (5 bits each)}
+  u16* blk_s;    // S of the first row of every block of 16 rows
+  uint4* bps;    // backpointer stream: [step / 8][lane of the window] 16 bytes = 8 steps x 2 columns
+};
+__host__ __device__ inline u32 poa4_desc_rows(u32 nmax) { return nmax + 64; }
+__host__ __device__ inline u32 poa4_steps(u32 nmax, u32 lmax) { return nmax + nmax / 16 + lmax / 2 + 96; }
+inline size_t poa4_slot_bytes(u32 nmax, u32 lmax) {
+  size_t b = poa2_slot_bytes(nmax, lmax, 0, false);
+  b += static_cast<size_t>(poa4_desc_rows(nmax)) * 32;
+  b += ((static_cast<size_t>(poa4_desc_rows(nmax)) / 16 + 8) * 2 + 255) & ~size_t(255);
+  b += (static_cast<size_t>(poa4_steps(nmax, lmax)) / P4::kU + 2) * 16 * 16;
+  return (b + 255) & ~size_t(255);
+}
+__host__ __device__ inline Poa4Slot poa4_carve(unsigned char* base, u32 nmax, u32 lmax) {
+  Poa4Slot s;
+  s.g = poa2_carve(base, nmax, lmax, 0, false);
+  size_t o = 0;
+  poa2_fields(nmax, lmax, 0, [&](int, size_t x) { o += (x + 255) & ~size_t(255); }, false);
+  s.desc = reinterpret_cast<uint4*>(base + o);
+  o += static_cast<size_t>(poa4_desc_rows(nmax)) * 32;
+  s.blk_s = reinterpret_cast<u16*>(base + o);
+  o += ((static_cast<size_t>(poa4_desc_rows(nmax)) / 16 + 8) * 2 + 255) & ~size_t(255);
+  s.bps = reinterpret_cast<uint4*>(base + o);
+  return s;
+}
+
+// ---- small instruction-level helpers (one CDNA4 instruction each; plain C++ under the emulator) ----------------------
+__host__ __device__ __forceinline__ u32 funnel_shr(u32 hi, u32 lo, u32 sh) {  // v_alignbit_b32; sh in [0, 31]
+  return static_cast<u32>(((static_cast<unsigned long long>(hi) << 32) | lo) >> sh);
+}
+__host__ __device__ __forceinline__ i32 sext16(u32 x) { return static_cast<i32>(static_cast<i16>(x & 0xFFFFu)); }
+__host__ __device__ __forceinline__ i32 imax(i32 a, i32 b) { return a > b ? a : b; }
+__host__ __device__ __forceinline__ i32 imin(i32 a, i32 b) { return a < b ? a : b; }
+// a + (p & 0xFFFF) / a + (p >> 16): v_add_u32 with an SDWA source select, so two 16-bit fields share a register
+template <bool HI>
+__host__ __device__ __forceinline__ u32 add_half(u32 a, u32 p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  u32 d;
+  if constexpr (HI)
+    asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(d) : "v"(a), "v"(p));
+  else
+    asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(d) : "v"(a), "v"(p));
+  return d;
+#else
+  return a + (HI ? p >> 16 : p & 0xFFFFu);
+#endif
+}
+// int16 half of w * 64 + tag: v_mad_i32_i16 reads the half through op_sel, the cells stay packed as the LDS read delivers them
+template <bool HI, int TAG>
+__host__ __device__ __forceinline__ i32 cell_key(u32 w) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  i32 d;
+  if constexpr (HI) asm("v_mad_i32_i16 %0, %1, 64, %2 op_sel:[1,0,0,0]" : "=v"(d) : "v"(w), "n"(TAG));
+  else asm("v_mad_i32_i16 %0, %1, 64, %2" : "=v"(d) : "v"(w), "n"(TAG));
+  return d;
+#else
+  return static_cast<i32>(static_cast<i16>((HI ? w >> 16 : w) & 0xFFFFu)) * 64 + TAG;
+#endif
+}
+__host__ __device__ __forceinline__ u32 pack16(i32 lo, i32 hi) {  // (lo & 0xFFFF) | hi << 16
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_perm(static_cast<u32>(hi), static_cast<u32>(lo), 0x05040100u);
+#else
+  return (static_cast<u32>(lo) & 0xFFFFu) | (static_cast<u32>(hi) << 16);
+#endif
+}
+__host__ __device__ __forceinline__ u32 clamp_pair(u32 w) {  // both int16 halves clamped from below to kNegInf16
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef short pk16 __attribute__((ext_vector_type(2)));
+  const pk16 lim = {static_cast<short>(kNegInf16), static_cast<short>(kNegInf16)};
+  return __builtin_bit_cast(u32, __builtin_elementwise_max(__builtin_bit_cast(pk16, w), lim));
+#else
+  const i32 a = sext16(w), b = sext16(w >> 16);
+  return pack16(a < kNegInf16 ? kNegInf16 : a, b < kNegInf16 ? kNegInf16 : b);
+#endif
+}
+// LDS of the wave as bytes from the start of its Poa4Lds (on the GPU the struct is the kernel's only __shared__ object)
+__host__ __device__ __forceinline__ u32 lds_ld32(const Poa4Lds& S, u32 off) {
+  return *reinterpret_cast<const u32*>(reinterpret_cast<const unsigned char*>(&S) + off);
+}
+__host__ __device__ __forceinline__ void lds_st32(Poa4Lds& S, u32 off, u32 v) {
+  *reinterpret_cast<u32*>(reinterpret_cast<unsigned char*>(&S) + off) = v;
+}
+__host__ __device__ __forceinline__ i32 lds_ld16(const Poa4Lds& S, u32 off) {
+  return *reinterpret_cast<const i16*>(reinterpret_cast<const unsigned char*>(&S) + off);
+}
+// LDS traffic of one wave is executed in order on the GPU; the emulator's fibres need a rendezvous between a lane's LDS
+// write and another lane's read of it
+__host__ __device__ __forceinline__ void lds_order() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_wave_barrier();
+#else
+  sv::sync();
+#endif
+}
+#if defined(__HIP_DEVICE_COMPILE__)
+#define P4_MARK(x) asm volatile("; P4MARK " x)
+#define P4_ASSUME_GLOBAL(p) \
+  __builtin_assume(!__builtin_amdgcn_is_shared((const void*)(p))); \
+  __builtin_assume(!__builtin_amdgcn_is_private((const void*)(p)))
+#define P4_ASSUME_LDS(p) __builtin_assume(__builtin_amdgcn_is_shared((const void*)(p)))
+#else
+#define P4_MARK(x)
+#define P4_ASSUME_GLOBAL(p)
+#define P4_ASSUME_LDS(p)
+#endif
+
+__host__ __device__ inline u32 group_min_u(u32 v) {
+#pragma unroll
+  for (int off = 8; off > 0; off >>= 1) {
+    const u32 o = static_cast<u32>(sv::bperm(static_cast<int>(v), sv::lane() ^ off));
+    v = o < v ? o : v;
+  }
+  return v;
+}
+__host__ __device__ inline i32 group_max_i(i32 v) {
+#pragma unroll
+  for (int off = 8; off > 0; off >>= 1) {
+    const i32 o = sv::bperm(v, sv::lane() ^ off);
+    v = o > v ? o : v;
+  }
+  return v;
+}
+
+// k-th in-edge (among those inside the subgraph) of v as a rank
+__host__ __device__ inline u32 poa4_nth_pred_rank(const Poa2Slot& g, u32 v, u32 k, bool full) {
+  const u32 c = g.in_cnt[v];
+  u32 seen = 0;
+  for (u32 i = 0; i < c; ++i) {
+    const u32 t = g.in_tail[v * kPoaMaxIn + i];
+    if (full || g.mark[t]) {
+      if (seen == k) return g.rank_of[t];
+      ++seen;
+    }
+  }
+  return 0;
+}
+
+// ---- per-layer pre-pass: the row descriptors ---------------------------------------------------------------------------
+// The wave's windows side by side, one row per lane and iteration.  Group-uniform inputs: act, nn, full, the layer.
+// Outputs (group-uniform): r_lo (rank of row 0), n_rows, t_end (steps of the layer's DP), flag (!= 0: the layer does
+// not fit this kernel's limits -> the window goes to the 64-column kernel), marked rows (work counter).
+template <class K>
+__host__ __device__ inline void poa4_prepass(const Poa4Args A, Poa4Lds& S, unsigned char* slot_mem, bool act, u32 nn, bool full,
+                                             const PoaLayer* Lp, u32 len, i32 lb, i32 span, u32& r_lo_out, u32& n_rows_out,
+                                             u32& t_end_out, u32& flag_out, u32& marked_out) {
+  P4_ASSUME_GLOBAL(slot_mem);
+  P4_ASSUME_GLOBAL(Lp);
+  P4_ASSUME_LDS(&S);
+  const int lane = sv::lane();
+  const int gl = lane & 15, gbase = lane & ~15, q = lane >> 4;
+  const Poa4Slot sl = poa4_carve(slot_mem, A.nmax, A.lmax);
+  const Poa2Slot& g = sl.g;
+  const Poa4Group& Sg = S.g[q];
+  const u32 w = len + 1;
+  // the layer's band guide in registers (poa_layer_center without its loads)
+  const u32* wayp = reinterpret_cast<const u32*>(Lp->way);
+  const u32 way0 = wayp[0], way1 = wayp[1], way2 = wayp[2], way3 = wayp[3];
+  auto way_at = [&](i32 idx) -> i32 {
+    const u32 ws = idx < 4 ? (idx < 2 ? way0 : way1) : (idx < 6 ? way2 : way3);
+    return static_cast<i32>((ws >> (16 * (idx & 1))) & 0xFFFFu);
+  };
+  auto band_start = [&](i32 bpos) -> i32 {  // even, in [0, max(0, w - 31)]
+    i32 x = bpos - lb;
+    x = x < 0 ? 0 : (x > span ? span : x);
+    const i32 seg = (x * 8) / (span > 0 ? span : 1);
+    const i32 sg = seg > 7 ? 7 : seg;
+    const i32 x0 = (sg * span) / 8, x1 = ((sg + 1) * span) / 8;
+    const i32 wa = sg == 0 ? 0 : way_at(sg - 1);
+    const i32 wb = sg == 7 ? static_cast<i32>(len) : way_at(sg);
+    i32 b = wa + (x - x0) * (wb - wa) / (x1 > x0 ? x1 - x0 : 1) - K::kBand / 2;
+    const i32 bmax = static_cast<i32>(w) - K::kBand;
+    b = b > bmax ? bmax : b;
+    b = b < 0 ? 0 : b;
+    // even; at the right limit rounded UP, so that the band still holds the layer's last column
+    return (b == bmax && bmax > 0) ? (b + 1) & ~1 : b & ~1;
+  };
+  // ---- the rank range that holds the layer's subgraph ----
+  u32 r_lo = 0, r_hi = act ? nn : 0;
+  if (sv::any(act && !full)) {
+    const bool part = act && !full;
+    u32 first = 0xFFFFFFFFu;
+    i32 last = 0;
+    const u32 max_nn = static_cast<u32>(sv::wave_max(part ? static_cast<int>(nn) : 0));
+    for (u32 r0 = 0; r0 < max_nn; r0 += 16) {
+      const u32 r = r0 + static_cast<u32>(gl);
+      if (part && r < nn) {
+        const u32 v = g.order[r];
+        if (g.mark[v]) {
+          first = r < first ? r : first;
+          last = static_cast<i32>(r) + 1;
+        }
+      }
+    }
+    first = group_min_u(first);
+    last = group_max_i(last);
+    if (part) {
+      r_lo = first == 0xFFFFFFFFu ? 0u : first;
+      r_hi = first == 0xFFFFFFFFu ? 0u : static_cast<u32>(last);
+    }
+  }
+  const u32 n_rows = r_hi - r_lo;
+  const u32 ring_off = static_cast<u32>(offsetof(Poa4Lds, g)) + static_cast<u32>(q) * static_cast<u32>(sizeof(Poa4Group));
+  const u32 dump_off = ring_off + static_cast<u32>(offsetof(Poa4Group, dump));
+  const u32 neg_off = static_cast<u32>(offsetof(Poa4Lds, neg));
+  const u32 neg2 = neg_off | (neg_off << 16);
+  u32 flag = 0, marked_rows = 0;
+  i32 t_end = 0;
+  i32 b_first = 0;
+  i32 b_prev1 = 0, b_prev2 = 0;  // band starts of the lane's rows in the previous two blocks
+  const u32 max_rows = static_cast<u32>(sv::wave_max(act ? static_cast<int>(n_rows) : 0));
+  for (u32 rho0 = 0; rho0 < max_rows + 32; rho0 += 16) {
+    const u32 rho = rho0 + static_cast<u32>(gl);
+    const u32 r = r_lo + rho;
+    const bool ok = act && rho < n_rows;
+    u32 v = 0, c = 0, code = 0, outc = 1;
+    bool marked = false;
+    i32 bpos = 0;
+    uint4 tl = uint4{0, 0, 0, 0};
+    if (ok) {
+      v = g.order[r];
+      marked = full || g.mark[v] != 0;
+      code = g.code[v];
+      outc = full ? g.out_cnt[v] : g.sub_out[v];
+      c = g.in_cnt[v];
+      bpos = g.bpos[v];
+      tl = *reinterpret_cast<const uint4*>(g.in_tail + static_cast<size_t>(v) * kPoaMaxIn);
+    }
+    i32 b = ok ? band_start(bpos) : 0;
+    if (rho0 == 0) b_first = sv::bperm(b, gbase);
+    {  // band starts must not decrease along the order (they never do: a node's backbone coordinate is its column)
+      const i32 carry = sv::bperm(b_prev1, gbase | 15);
+      const i32 below = sv::row_shr<1>(b, carry);
+      if (ok && rho > 0 && b < below) flag = 7;
+    }
+    u32 ep[4] = {neg2, neg2, neg2, neg2};
+    u32 np = 0, lbw = 0;
+    if (!marked) c = 0;
+    for (u32 k = 0; k < static_cast<u32>(kPoaMaxIn); ++k) {
+      const bool has = k < c;
+      if (!sv::any(has)) break;
+      u32 t = 0;
+      if (has) {
+        if (k < 8) {
+          const u32 wd = k < 2 ? tl.x : (k < 4 ? tl.y : (k < 6 ? tl.z : tl.w));
+          t = (wd >> (16 * (k & 1))) & 0xFFFFu;
+        } else {
+          t = g.in_tail[static_cast<size_t>(v) * kPoaMaxIn + k];
+        }
+      }
+      u32 pr = 0;
+      bool inside = false;
+      if (has) {
+        inside = full || g.mark[t] != 0;
+        pr = g.rank_of[t];
+      }
+      const u32 lbk = r - pr;  // >= 1 for an in-edge
+      const u32 prho = rho - lbk;
+      const int owner = gbase | static_cast<int>(prho & 15u);
+      const u32 dblk = (rho >> 4) - (prho >> 4);
+      const i32 bp0 = sv::bperm(b, owner), bp1 = sv::bperm(b_prev1, owner), bp2 = sv::bperm(b_prev2, owner);
+      if (has && inside) {
+        const i32 bpred = dblk == 0 ? bp0 : (dblk == 1 ? bp1 : bp2);
+        const i32 d = b - bpred;
+        if (lbk < 1 || lbk > static_cast<u32>(K::kRing - 1) || lbk > rho || dblk > 2 || d < 0 || d > K::kMaxD) {
+          flag = 7;
+        } else if (np < static_cast<u32>(K::kEdges)) {
+          const u32 e = ring_off + (prho % static_cast<u32>(K::kRing)) * static_cast<u32>(K::kRowB) + 2u * static_cast<u32>(d);
+          const u32 idx = np >> 1;
+          const u32 keep = (np & 1) ? 0x0000FFFFu : 0xFFFF0000u;
+          const u32 put = (np & 1) ? e << 16 : e;
+#pragma unroll
+          for (u32 i = 0; i < 4; ++i) ep[i] = i == idx ? ((ep[i] & keep) | put) : ep[i];
+          if (np < 6) lbw |= lbk << (5 * np);
+        }
+        ++np;
+      }
+    }
+    if (np > static_cast<u32>(K::kEdges)) flag = 3;
+    // match mask of the row's 32 columns against the layer
+    u32 mm = 0;
+    {
+      const u32 wi = static_cast<u32>(b) >> 4, sh = 2u * (static_cast<u32>(b) & 15u);
+      const u32 x0 = Sg.seq2[wi], x1 = Sg.seq2[wi + 1], x2 = Sg.seq2[wi + 2];
+      const u32 pat = code * 0x55555555u;
+      const u32 elo = funnel_shr(x1, x0, sh) ^ pat, ehi = funnel_shr(x2, x1, sh) ^ pat;
+      auto even_bits = [](u32 y) -> u32 {
+        y = ~(y | (y >> 1)) & 0x55555555u;
+        y = (y | (y >> 1)) & 0x33333333u;
+        y = (y | (y >> 2)) & 0x0F0F0F0Fu;
+        y = (y | (y >> 4)) & 0x00FF00FFu;
+        y = (y | (y >> 8)) & 0x0000FFFFu;
+        return y;
+      };
+      mm = even_bits(elo) | (even_bits(ehi) << 16);
+    }
+    i32 sdiff = b - b_first;
+    sdiff = sdiff < 0 ? 0 : sdiff;
+    const u32 Srow = ok ? rho + (rho >> 4) + (static_cast<u32>(sdiff) >> 1) + 1u : kInactiveS;
+    const u32 own = (ok && marked) ? ring_off + (rho % static_cast<u32>(K::kRing)) * static_cast<u32>(K::kRowB) + 4u : dump_off;
+    const bool endn = marked && outc == 0;
+    uint4 da, db;
+    da.x = Srow | (own << 16);
+    da.y = v | (static_cast<u32>(b) << 16) | ((np > 15u ? 15u : np) << 26) | (marked ? 1u << 30 : 0u) | (endn ? 1u << 31 : 0u);
+    da.z = mm;
+    da.w = ep[0];
+    db.x = ep[1];
+    db.y = ep[2];
+    db.z = ep[3];
+    db.w = lbw;
+    if (act) {
+      sl.desc[2 * static_cast<size_t>(rho)] = da;
+      sl.desc[2 * static_cast<size_t>(rho) + 1] = db;
+      if (gl == 0) sl.blk_s[rho0 >> 4] = static_cast<u16>(Srow);
+    }
+    if (ok) t_end = static_cast<i32>(Srow) + 17;
+    marked_rows += static_cast<u32>(__builtin_popcount(static_cast<u32>(sv::ballot(marked) >> gbase) & 0xFFFFu));
+    b_prev2 = b_prev1;
+    b_prev1 = b;
+  }
+  t_end = group_max_i(t_end);
+  flag = static_cast<u32>(group_max_i(static_cast<i32>(flag)));
+  if (static_cast<u32>(t_end) + 8u > poa4_steps(A.nmax, A.lmax)) flag = 7;
+  r_lo_out = r_lo;
+  n_rows_out = n_rows;
+  t_end_out = static_cast<u32>(t_end);
+  flag_out = flag;
+  marked_out = marked_rows;
+}
+
+// ---- banded NW of one layer per window, rows on lanes ---------------------------------------------------------------
+// Outputs (group-uniform): best_rho1 = 1 + row (rho) of the end node with the best score in the last column, 0: the last
+// column is in no end node's band.
+template <class K>
+__host__ __device__ inline void poa4_dp(const Poa4Args A, Poa4Lds& S, unsigned char* slot_mem, bool act, u32 t_end, u32 len,
+                                        u32& best_rho1) {
+  P4_ASSUME_GLOBAL(slot_mem);
+  P4_ASSUME_LDS(&S);
+  const int lane = sv::lane();
+  const int gl = lane & 15, q = lane >> 4;
+  const Poa4Slot sl = poa4_carve(slot_mem, A.nmax, A.lmax);
+  const u32 ring_off = static_cast<u32>(offsetof(Poa4Lds, g)) + static_cast<u32>(q) * static_cast<u32>(sizeof(Poa4Group));
+  // -inf pads of the ring rows (the union is reused by the layer set-up and by the traceback), the wave's -inf cells
+  {
+    const u32 neg = pack16(kNegInf16, kNegInf16);
+    for (int idx = gl; idx < K::kRing * 10; idx += 16) {
+      const int rr = idx / 10, cc = idx % 10;
+      lds_st32(S, ring_off + static_cast<u32>(rr * K::kRowB + (cc == 0 ? 0 : 64 + 4 * cc)), neg);
+    }
+    if (lane < 20) S.neg[lane] = neg;
+  }
+  lds_order();
+  const i32 mD = A.m * 64 + 32, xD = A.n_ * 64 + 32, g64 = A.gp * 64;
+  const i32 gp = A.gp;
+  const i32 dD = mD - xD;
+  // current row (the raw descriptor words), the next one, the one being fetched
+  u32 c0, c1, cM, ce0, ce1, ce2, ce3;
+  u32 n0, n1, nM, ne0, ne1, ne2, ne3;
+  u32 l0 = 0, l1 = 0, lM = 0, le0 = 0, le1 = 0, le2 = 0, le3 = 0;
+  u32 cur_rho = static_cast<u32>(gl);
+  {
+    const uint4 a = sl.desc[2 * static_cast<size_t>(cur_rho)], b = sl.desc[2 * static_cast<size_t>(cur_rho) + 1];
+    const u32 neg_off = static_cast<u32>(offsetof(Poa4Lds, neg));
+    const u32 neg2 = neg_off | (neg_off << 16);
+    c0 = act ? (a.x | 0u) : (kInactiveS | (neg_off << 16));  // (a group without a layer in this round has no descriptors: it idles on -inf cells)
+    c1 = act ? a.y : 0u;
+    cM = a.z;
+    ce0 = act ? a.w : neg2;
+    ce1 = act ? b.x : neg2;
+    ce2 = act ? b.y : neg2;
+    ce3 = act ? b.z : neg2;
+    const uint4 a2 = sl.desc[2 * static_cast<size_t>(cur_rho + 16)], b2 = sl.desc[2 * static_cast<size_t>(cur_rho + 16) + 1];
+    n0 = act ? a2.x : kInactiveS;
+    n1 = act ? a2.y : 0u;
+    nM = a2.z;
+    ne0 = act ? a2.w : neg2;
+    ne1 = act ? b2.x : neg2;
+    ne2 = act ? b2.y : neg2;
+    ne3 = act ? b2.z : neg2;
+  }
+  bool nx_full = true, ld_pending = false;
+  i32 Am1 = kNegKey, U = kNegU;
+  i32 best_score = -0x7FFFFFFF;
+  u32 best_row = 0;
+  const u32 T = static_cast<u32>(sv::wave_max(act ? static_cast<int>(t_end) : 0));
+  for (u32 t0 = 0; t0 < T; t0 += K::kU) {
+    // ---- service point: the descriptor fetched 8 steps ago becomes the lane's next row; a lane whose next row is
+    // missing fetches it (it is needed 17 steps after the switch that consumed the previous one at the earliest) ----
+    if (ld_pending) {
+      n0 = l0;
+      n1 = l1;
+      nM = lM;
+      ne0 = le0;
+      ne1 = le1;
+      ne2 = le2;
+      ne3 = le3;
+      nx_full = true;
+      ld_pending = false;
+    } else if (!nx_full && act) {
+      const uint4 a = sl.desc[2 * static_cast<size_t>(cur_rho + 16)], b = sl.desc[2 * static_cast<size_t>(cur_rho + 16) + 1];
+      l0 = a.x;
+      l1 = a.y;
+      lM = a.z;
+      le0 = a.w;
+      le1 = b.x;
+      le2 = b.y;
+      le3 = b.z;
+      ld_pending = true;
+    }
+    u32 acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0;
+#pragma unroll
+    for (int u = 0; u < K::kU; ++u) {
+      P4_MARK("step_begin");
+      const u32 t = t0 + static_cast<u32>(u);
+      i32 k = static_cast<i32>(t) - static_cast<i32>(c0 & 0xFFFFu);
+      if (k == 16) {  // the row is finished: its end-node score, then the next row
+#if !defined(__HIP_DEVICE_COMPILE__)
+        if (std::getenv("RVN_POA4_DEBUG2"))
+          std::fprintf(stderr, "[poa4] lane %d t %u finished rho %u c0 %08x c1 %08x b %u end %u np %u H[0..3] %d %d %d %d\n", lane, t, cur_rho, c0, c1, (c1 >> 16) & 0x3FFu, c1 >> 31, (c1 >> 26) & 15,
+                       lds_ld16(S, (c0 >> 16)), lds_ld16(S, (c0 >> 16) + 2), lds_ld16(S, (c0 >> 16) + 4), lds_ld16(S, (c0 >> 16) + 6));
+#endif
+        if (c1 >> 31) {
+          const i32 idx = static_cast<i32>(len) - static_cast<i32>((c1 >> 16) & 0x3FFu);
+          if (idx >= 0 && idx < K::kBand) {
+            const i32 sce = lds_ld16(S, (c0 >> 16) + 2u * static_cast<u32>(idx));
+            if (sce > best_score || (sce == best_score && cur_rho + 1 < best_row)) {
+              best_score = sce;
+              best_row = cur_rho + 1;
+            }
+          }
+        }
+        c0 = n0;
+        c1 = n1;
+        cM = nM;
+        ce0 = ne0;
+        ce1 = ne1;
+        ce2 = ne2;
+        ce3 = ne3;
+        cur_rho += 16;
+        nx_full = false;
+        Am1 = kNegKey;
+        k = static_cast<i32>(t) - static_cast<i32>(c0 & 0xFFFFu);
+      }
+      i32 kk = k + 1;
+      kk = kk < 0 ? 0 : (kk > 16 ? 16 : kk);
+      const u32 off4 = static_cast<u32>(kk) << 2;
+      const u32 np = (c1 >> 26) & 15u;
+      // ---- in-edges: one aligned pair of predecessor cells each (columns j, j + 1 of this step) ----
+      u32 wd = lds_ld32(S, add_half<false>(off4, ce0));
+      if (sv::any(np == 0)) {  // no in-edge inside the subgraph: the virtual start row H[0][j] = j * g
+        const i32 bb = static_cast<i32>((c1 >> 16) & 0x3FFu);
+        const i32 j0 = bb - 2 + 2 * kk;
+        u32 vp = pack16(j0 * gp, (j0 + 1) * gp);
+        if (j0 < 0) vp = pack16(kNegInf16, kNegInf16);
+        wd = np == 0 ? vp : wd;
+      }
+      i32 A0 = cell_key<false, 15>(wd), A1 = cell_key<true, 15>(wd);
+#define P4_EDGE(E, REG, HI)                                        \
+  if (sv::any(np > E)) {                                           \
+    const u32 we = lds_ld32(S, add_half<HI>(off4, REG));           \
+    A0 = imax(A0, cell_key<false, 15 - E>(we));                    \
+    A1 = imax(A1, cell_key<true, 15 - E>(we));
+      P4_EDGE(1, ce0, true)
+      P4_EDGE(2, ce1, false)
+      P4_EDGE(3, ce1, true)
+      P4_EDGE(4, ce2, false)
+      P4_EDGE(5, ce2, true)
+      P4_EDGE(6, ce3, false)
+      P4_EDGE(7, ce3, true)
+      }}}}}}}
+#undef P4_EDGE
+      // ---- the two cells: spoa's priority diagonal (first in-edge reaching the maximum), vertical, horizontal ----
+      const u32 bits = (cM >> (static_cast<u32>(2 * k) & 31u)) & 3u;
+      const i32 sd0 = xD + static_cast<i32>(bits & 1u) * dD, sd1 = xD + static_cast<i32>(bits >> 1) * dD;
+      const i32 b0 = imax(Am1 + sd0, A0 + g64);
+      const i32 h0 = U + gp, s0 = b0 >> 6;
+      const i32 U0 = imax(s0, h0);
+      const u32 code0 = h0 > s0 ? 64u : (static_cast<u32>(b0) & 63u);
+      const i32 b1 = imax(A0 + sd1, A1 + g64);
+      const i32 h1 = U0 + gp, s1 = b1 >> 6;
+      const i32 U1 = imax(s1, h1);
+      const u32 code1 = h1 > s1 ? 64u : (static_cast<u32>(b1) & 63u);
+      if (static_cast<u32>(k) < 16u) lds_st32(S, add_half<true>(static_cast<u32>(k) << 2, c0), clamp_pair(pack16(U0, U1)));
+      const u32 cp = code0 | (code1 << 8);
+      if (u == 0) acc0 = cp;
+      else if (u == 1) acc0 |= cp << 16;
+      else if (u == 2) acc1 = cp;
+      else if (u == 3) acc1 |= cp << 16;
+      else if (u == 4) acc2 = cp;
+      else if (u == 5) acc2 |= cp << 16;
+      else if (u == 6) acc3 = cp;
+      else acc3 |= cp << 16;
+      Am1 = A1;
+      U = kk == 0 ? kNegU : U1;
+      lds_order();
+      P4_MARK("step_end");
+    }
+    if (act) sl.bps[static_cast<size_t>(t0 / K::kU) * 16 + static_cast<size_t>(gl)] = uint4{acc0, acc1, acc2, acc3};
+  }
+  // rows that finished in the very last step of the loop
+  {
+    const i32 k = static_cast<i32>(T) - static_cast<i32>(c0 & 0xFFFFu);
+    if (act && k >= 16 && (c1 >> 31)) {
+      const i32 idx = static_cast<i32>(len) - static_cast<i32>((c1 >> 16) & 0x3FFu);
+      if (idx >= 0 && idx < K::kBand) {
+        const i32 sce = lds_ld16(S, (c0 >> 16) + 2u * static_cast<u32>(idx));
+        if (sce > best_score || (sce == best_score && cur_rho + 1 < best_row)) {
+          best_score = sce;
+          best_row = cur_rho + 1;
+        }
+      }
+    }
+  }
+  // the first row (lowest rank) among the end nodes with the best score, as poa2's rank-order scan picks it
+  {
+    const i32 gs = group_max_i(best_score);
+    const u32 cand = (best_score == gs && best_row != 0) ? best_row : 0xFFFFFFFFu;
+    const u32 br = group_min_u(cand);
+    best_rho1 = (act && br != 0xFFFFFFFFu) ? br : 0u;
+  }
+}
+
+// ---- traceback of the wave's windows in lockstep -------------------------------------------------------------------
+template <class K>
+__host__ __device__ inline void poa4_traceback(const Poa4Args A, Poa4Lds& S, unsigned char* slot_mem, bool act, u32 r_lo,
+                                               u32 n_rows, bool full, u32 len, u32 best_rho1, u32& bad, u32& band_hit) {
+  P4_ASSUME_GLOBAL(slot_mem);
+  P4_ASSUME_LDS(&S);
+  const int lane = sv::lane();
+  const int gl = lane & 15;
+  Poa4Group& Sg = S.g[lane >> 4];
+  const Poa4Slot sl = poa4_carve(slot_mem, A.nmax, A.lmax);
+  const Poa2Slot& g = sl.g;
+  const u32 w = len + 1;
+  bad = 0;
+  band_hit = 0;
+  u32 i = act ? best_rho1 : 0;  // 1 + rho of the current row; 0 = the virtual start row
+  i32 j = static_cast<i32>(w) - 1;
+  bool done = !act || i == 0;
+  u32 cur_blk = 0xFFFFFFFFu, cur_tb0 = 0;
+  u32 steps = 0;
+  const u32 max_steps = A.nmax + A.lmax + 2;
+  // A block (16 rows' descriptors + the 8-step blocks of the backpointer stream that cover them) is fetched into
+  // registers one block AHEAD of the walk and copied into the group's LDS when the walk gets there.
+  uint4 pb0{}, pb1{}, pb2{}, pb3{}, pb4{}, pb5{}, pb6{};
+  u32 pd0 = 0, pd1 = 0, pd7 = 0, pf_tb0 = 0;
+  u32 pf_blk = 0xFFFFFFFFu;
+  // tb0: first 8-step block of the stream to stage.  The walk's first block takes it from blk_s; for the block below a
+  // staged one it is guessed from that block's first step (rows start 17 steps + half the band shift apart): a row
+  // whose steps fall outside the staged blocks is read from the stream in HBM, so a bad guess costs time only.
+  auto fetch = [&](u32 b, u32 tb0) {
+    const u32 rho = b * 16 + static_cast<u32>(gl);
+    const uint4 da = sl.desc[2 * static_cast<size_t>(rho)];
+    pd0 = da.x;
+    pd1 = da.y;
+    pd7 = sl.desc[2 * static_cast<size_t>(rho) + 1].w;
+    const uint4* src = sl.bps + static_cast<size_t>(tb0) * 16 + static_cast<size_t>(gl);
+    pb0 = src[0];
+    pb1 = src[16];
+    pb2 = src[32];
+    pb3 = src[48];
+    pb4 = src[64];
+    pb5 = src[80];
+    pb6 = src[96];
+    pf_tb0 = tb0;
+    pf_blk = b;
+  };
+  while (sv::any(!done)) {
+    const u32 blk = done ? cur_blk : (i - 1) >> 4;
+    const bool need = !done && blk != cur_blk;
+    if (sv::any(need)) {
+      lds_order();
+      if (need) {
+        if (pf_blk != blk) fetch(blk, static_cast<u32>(sl.blk_s[blk]) / K::kU);
+        Sg.u.tb.d[4 * gl] = pd0;
+        Sg.u.tb.d[4 * gl + 1] = pd1;
+        Sg.u.tb.d[4 * gl + 2] = pd7;
+        uint4* bdst = Sg.u.tb.bp + gl;
+        bdst[0] = pb0;
+        bdst[16] = pb1;
+        bdst[32] = pb2;
+        bdst[48] = pb3;
+        bdst[64] = pb4;
+        bdst[80] = pb5;
+        bdst[96] = pb6;
+        cur_blk = blk;
+        cur_tb0 = pf_tb0;
+      }
+      lds_order();
+      if (need && blk > 0) {
+        const u32 s_first = Sg.u.tb.d[0] & 0xFFFFu;
+        fetch(blk - 1, (s_first > 25u ? s_first - 25u : 0u) / K::kU);
+      }
+    }
+    if (!done) {
+      if (++steps > max_steps) {
+        bad = 6;
+        done = true;
+      } else {
+        const u32 rho = i - 1;
+        const u32 l = rho & 15u;
+        const u32 d0 = Sg.u.tb.d[4 * l], d1 = Sg.u.tb.d[4 * l + 1];
+        const i32 bt = static_cast<i32>((d1 >> 16) & 0x3FFu);
+        const u32 node = d1 & 0xFFFFu;
+        const u32 np = (d1 >> 26) & 15u;
+        const i32 idx = j - bt;
+        if (idx < 0 || idx >= K::kBand) {  // the path left the stored band: the alignment does not fit this band width
+          band_hit = 1;
+          done = true;
+        } else {
+          if ((idx < 2 && bt > 0) || (idx > K::kBand - 3 && bt + K::kBand < static_cast<i32>(w))) band_hit = 1;
+          const u32 ts = (d0 & 0xFFFFu) + (static_cast<u32>(idx) >> 1);
+          const u32 tblk = ts / K::kU - cur_tb0;
+          const u32 boff = l * 16 + (ts % K::kU) * 2 + (static_cast<u32>(idx) & 1u);
+          u32 code;
+          if (tblk < static_cast<u32>(K::kTbBlocks))
+            code = reinterpret_cast<const u8*>(Sg.u.tb.bp)[tblk * 256 + boff];
+          else  // (a block of rows whose steps spread beyond the staged range: straight from the stream)
+            code = reinterpret_cast<const u8*>(sl.bps)[static_cast<size_t>(ts / K::kU) * 256 + boff];
+          if (code == 64u) {
+            if (j == 0) {
+              bad = 6;
+              done = true;
+            } else {
+              --j;  // insertion: pos_node[j] stays kNone
+            }
+          } else {
+            const u32 k = 15u - (code & 15u);
+            u32 pr1;  // 1 + rho of the predecessor row, 0 = the virtual row
+            if (np == 0) {
+              pr1 = 0;
+            } else if (k < 6) {
+              const u32 lbk = (Sg.u.tb.d[4 * l + 2] >> (5 * k)) & 31u;
+              pr1 = i - lbk;
+            } else {
+              pr1 = poa4_nth_pred_rank(g, node, k, full) - r_lo + 1;
+            }
+            if (code & 32u) {  // diagonal
+              if (j == 0) {
+                bad = 6;
+                done = true;
+              } else {
+                --j;
+                if (gl == 0) g.pos_node[j] = static_cast<u16>(node);
+              }
+            }
+            if (!done) {
+              i = pr1;
+              if (i == 0) done = true;  // on the virtual row only insertions remain: pos_node already says kNone
+            }
+          }
+        }
+      }
+    }
+  }
+  (void)n_rows;
+}
+
+// ---- wave-wide per-window steps (as in poa2.hip) -------------------------------------------------------------------
+__host__ __device__ inline void poa4_copy_backbone(const Poa4Args& A, const PoaWindow& win, const PoaLayer& bb, u8* out,
+                                                   u32* out_len) {
+  const int lane = sv::lane();
+  const u32 n = bb.len < win.out_cap ? bb.len : win.out_cap;
+  for (u32 i = lane; i < n; i += 64) out[i] = static_cast<u8>(poa_layer_code(A.src, bb, i));
+  if (lane == 0) *out_len = n;
+}
+
+// window set-up: 0 = backbone returned (< 3 sequences), 4 = beyond a length limit (backbone returned), 1 = graph built
+__host__ __device__ inline u32 poa4_init_window(const Poa4Args& A, const PoaWindow& win, Poa2Slot& g, u32 wi, u32& n_nodes,
+                                                u32& n_eff) {
+  const int lane = sv::lane();
+  const PoaLayer bb = A.layers[win.layer_first];
+  const u32 blen = bb.len;
+  n_eff = win.n_layers;
+  if (A.src.layer_ok) {  // layers dropped by racon's mean-quality filter do not count as sequences of the window
+    u32 cnt = 0;
+    for (u32 i = 1 + lane; i < win.n_layers; i += 64) cnt += A.src.layer_ok[win.layer_first + i] ? 1u : 0u;
+    n_eff = 1 + sv::wave_sum(cnt);
+  }
+  n_nodes = 0;
+  if (n_eff < 3) {
+    poa4_copy_backbone(A, win, bb, A.out + win.out_off, A.out_len + wi);
+    return 0;
+  }
+  if (blen == 0 || blen > A.nmax || blen > A.lmax) {
+    poa4_copy_backbone(A, win, bb, A.out + win.out_off, A.out_len + wi);
+    return 4;
+  }
+  // backbone graph (spoa AddAlignment with an empty alignment)
+  n_nodes = blen;
+  for (u32 i = lane; i < blen; i += 64) {
+    g.code[i] = static_cast<u8>(poa_layer_code(A.src, bb, i));
+    g.al_cnt[i] = 0;
+    g.visits[i] = blen >= 2 ? 1 : 0;
+    g.rank_of[i] = static_cast<u16>(i);
+    g.order[i] = static_cast<u16>(i);
+    g.bpos[i] = static_cast<u16>(i);
+    const i32 wgt = poa_layer_weight(A.src, bb, i);
+    if (i > 0) {
+      const i32 wp = poa_layer_weight(A.src, bb, i - 1);
+      g.in_cnt[i] = 1;
+      g.in_tail[i * kPoaMaxIn] = static_cast<u16>(i - 1);
+      g.in_w[i * kPoaMaxIn] = wp + wgt;
+    } else {
+      g.in_cnt[i] = 0;
+    }
+    g.out_cnt[i] = i + 1 < blen ? 1 : 0;
+  }
+  sv::sync();
+  return 1;
+}
+
+__host__ __device__ __forceinline__ u32 poa4_letter(const Poa4Group& Sg, u32 p) {
+  return (Sg.seq2[(p + 1) >> 4] >> (2 * ((p + 1) & 15u))) & 3u;
+}
+
+// spoa AddAlignment, one sequence position per lane, + the incremental order rebuild.  Returns 0 or the failure code.
+__host__ __device__ inline u32 poa4_add_alignment(const Poa4Args& A, Poa2Slot& g, const Poa4Group& Sg, const PoaLayer& L,
+                                                  u32& n_nodes, unsigned long long& t_add, unsigned long long& t_ord) {
+  const int lane = sv::lane();
+  const u32 len = L.len;
+  const u32 nmax = A.nmax, lmax = A.lmax;
+  const u32 lb = L.begin;
+  unsigned long long t0 = sv::clock();
+  const u32 n_old = n_nodes;
+  u32 first_p = 0xFFFFFFFFu;
+  for (u32 p0 = 0; p0 < len && first_p == 0xFFFFFFFFu; p0 += 64) {
+    const u32 p = p0 + lane;
+    const unsigned long long bal = sv::ballot(p < len && g.pos_node[p] != kNone4);
+    if (bal) first_p = p0 + static_cast<u32>(__builtin_ctzll(bal));
+  }
+  // New nodes anchored after a column (aligned group) go after ALL its members; the unaligned prefix goes
+  // before all members of the first column.
+  u32 carry_slot = n_old, carry_b = lb;
+  if (first_p != 0xFFFFFFFFu) {
+    const u32 an = g.pos_node[first_p];
+    u32 r = g.rank_of[an];
+    const u32 ac = g.al_cnt[an];
+    for (u32 k = 0; k < ac; ++k) {
+      const u32 rk = g.rank_of[g.al[an * 4 + k]];
+      r = rk < r ? rk : r;
+    }
+    carry_slot = r;
+    carry_b = g.bpos[an];
+  }
+  u32 total_new = 0;
+  u32 ok = 1, why = 3;
+  for (u32 p0 = 0; p0 < len; p0 += 64) {
+    const u32 p = p0 + lane;
+    const bool valid = p < len;
+    const u32 an = valid ? g.pos_node[p] : kNone4;
+    const u32 letter = valid ? poa4_letter(Sg, p) : 0u;
+    const bool has = valid && an != kNone4;
+    u32 tgt = kNone4, gslot = 0, gb = 0, ac = 0;
+    if (has) {
+      u32 rmax = g.rank_of[an];
+      ac = g.al_cnt[an];
+      if (g.code[an] == letter) tgt = an;
+      for (u32 k = 0; k < ac; ++k) {
+        const u32 kt = g.al[an * 4 + k];
+        const u32 rk = g.rank_of[kt];
+        rmax = rk > rmax ? rk : rmax;
+        if (tgt == kNone4 && g.code[kt] == letter) tgt = kt;
+      }
+      gslot = rmax + 1;
+      gb = g.bpos[an];
+    }
+    // order slot / backbone coordinate of the last aligned position at or before p
+    const unsigned long long bal = sv::ballot(has);
+    const unsigned long long below = bal & (lane == 63 ? ~0ULL : ((2ULL << lane) - 1ULL));
+    const int src = below ? 63 - __builtin_clzll(below) : 0;
+    const u32 s_sh = static_cast<u32>(sv::bperm(static_cast<int>(gslot), src));
+    const u32 b_sh = static_cast<u32>(sv::bperm(static_cast<int>(gb), src));
+    const u32 fslot = below ? s_sh : carry_slot;
+    const u32 fb = below ? b_sh : carry_b;
+    {
+      const int top = bal ? 63 - __builtin_clzll(bal) : 0;
+      const u32 cs = static_cast<u32>(sv::rl(static_cast<int>(gslot), top));
+      const u32 cb = static_cast<u32>(sv::rl(static_cast<int>(gb), top));
+      if (bal) {
+        carry_slot = cs;
+        carry_b = cb;
+      }
+    }
+    const bool is_new = valid && tgt == kNone4;
+    const unsigned long long nb = sv::ballot(is_new);
+    const u32 cnt = static_cast<u32>(__builtin_popcountll(nb));
+    if (n_old + total_new + cnt > nmax || total_new + cnt > lmax) {
+      ok = 0;
+      why = 2;
+      break;
+    }
+    if (is_new) {
+      const u32 t = total_new + static_cast<u32>(__builtin_popcountll(nb & ((1ULL << lane) - 1ULL)));
+      const u32 id = n_old + t;
+      tgt = id;
+      g.code[id] = static_cast<u8>(letter);
+      g.in_cnt[id] = 0;
+      g.out_cnt[id] = 0;
+      g.visits[id] = 0;
+      g.new_slot[t] = static_cast<u16>(fslot);
+      g.bpos[id] = static_cast<u16>(fb);
+      u32 c2 = 0;
+      if (has) {  // joins an's aligned group
+        for (u32 k = 0; k < ac; ++k) {
+          const u32 kt = g.al[an * 4 + k];
+          const u32 ck = g.al_cnt[kt];
+          if (ck < 4) {
+            g.al[kt * 4 + ck] = static_cast<u16>(id);
+            g.al_cnt[kt] = static_cast<u8>(ck + 1);
+          }
+          if (c2 < 4) g.al[id * 4 + c2++] = static_cast<u16>(kt);
+        }
+        if (ac < 4) {
+          g.al[an * 4 + ac] = static_cast<u16>(id);
+          g.al_cnt[an] = static_cast<u8>(ac + 1);
+        }
+        if (c2 < 4) g.al[id * 4 + c2++] = static_cast<u16>(an);
+      }
+      g.al_cnt[id] = static_cast<u8>(c2);
+    }
+    total_new += cnt;
+    if (valid) {
+      g.tgt[p] = static_cast<u16>(tgt);
+      if (len >= 2) g.visits[tgt] += 1;
+    }
+  }
+  sv::sync();
+  if (ok) {
+    for (u32 p0 = 0; p0 < len; p0 += 64) {
+      const u32 p = p0 + lane;
+      bool okl = true;
+      if (p >= 1 && p < len)
+        okl = poa_add_edge(g, g.tgt[p - 1], g.tgt[p],
+                           static_cast<i32>(static_cast<u8>(poa_layer_weight(A.src, L, p - 1))) +
+                               static_cast<i32>(static_cast<u8>(poa_layer_weight(A.src, L, p))));
+      if (sv::ballot(!okl)) {
+        ok = 0;
+        why = 3;
+      }
+    }
+  }
+  sv::sync();
+  if (!ok) return why;
+  const u32 n_new = total_new;
+  n_nodes = n_old + n_new;
+  t_add += sv::clock() - t0;
+  t0 = sv::clock();
+  // order rebuild: old rank r -> r + #(new slots <= r); t-th new node -> slot_t + t
+  if (n_new) {
+    for (u32 r = lane; r < n_old; r += 64) {
+      u32 lo = 0, hi = n_new;  // upper_bound(new_slot, r)
+      while (lo < hi) {
+        const u32 mid = (lo + hi) >> 1;
+        if (g.new_slot[mid] <= r) lo = mid + 1;
+        else hi = mid;
+      }
+      g.order2[r + lo] = g.order[r];
+    }
+    for (u32 t = lane; t < n_new; t += 64) g.order2[static_cast<u32>(g.new_slot[t]) + t] = static_cast<u16>(n_old + t);
+    sv::sync();
+    for (u32 r = lane; r < n_nodes; r += 64) {
+      const u32 v = g.order2[r];
+      g.order[r] = static_cast<u16>(v);
+      g.rank_of[v] = static_cast<u16>(r);
+    }
+    sv::sync();
+  }
+  t_ord += sv::clock() - t0;
+  return 0;
+}
+
+// Consensus of a finished window: spoa's heaviest bundle with the node scores in the WAVE's LDS (the DP of every window
+// of the wave is over by now), first four in-edges of 64 nodes at a time in registers (as poa2_consensus), then branch
+// completion + racon's coverage trim on lane 0 and a parallel output copy.
+__host__ __device__ inline void poa4_consensus(Poa2Slot& g, u32 n_nodes, u32 nmax, const PoaWindow& win, int trim, Poa4Lds& S,
+                                               u8* out, u32* out_len) {
+  const int lane = sv::lane();
+  constexpr u32 kCap = sizeof(Poa4Lds) / 4;
+  i32* lsc = reinterpret_cast<i32*>(&S);
+  i32 maxn = -1;
+  if (n_nodes > kCap) {
+    if (lane == 0) maxn = poa_consensus_scores_lane0(g, n_nodes);
+    maxn = sv::rfl(maxn);
+  } else {
+    i32 max_sc = 0;
+    const u32 nn = n_nodes;
+    for (u32 r0 = 0; r0 < nn; r0 += 64) {
+      const u32 rows = nn - r0 < 64 ? nn - r0 : 64;
+      int m_it = 0, m_c = 0, m_t01 = 0, m_t23 = 0, m_w0 = 0, m_w1 = 0, m_w2 = 0, m_w3 = 0;
+      if (static_cast<u32>(lane) < rows) {
+        m_it = g.order[r0 + lane];
+        m_c = g.in_cnt[m_it];
+        const u16* tp = g.in_tail + static_cast<size_t>(m_it) * kPoaMaxIn;
+        const i32* wp = g.in_w + static_cast<size_t>(m_it) * kPoaMaxIn;
+        m_t01 = static_cast<int>(static_cast<u32>(tp[0]) | (static_cast<u32>(tp[1]) << 16));
+        m_t23 = static_cast<int>(static_cast<u32>(tp[2]) | (static_cast<u32>(tp[3]) << 16));
+        m_w0 = wp[0];
+        m_w1 = wp[1];
+        m_w2 = wp[2];
+        m_w3 = wp[3];
+      }
+      for (u32 l = 0; l < rows; ++l) {
+        const int li = static_cast<int>(l);
+        const u32 it = static_cast<u32>(sv::rl(m_it, li));
+        const u32 c = static_cast<u32>(sv::rl(m_c, li));
+        const u32 t01 = static_cast<u32>(sv::rl(m_t01, li)), t23 = static_cast<u32>(sv::rl(m_t23, li));
+        const i32 w0 = sv::rl(m_w0, li), w1 = sv::rl(m_w1, li), w2 = sv::rl(m_w2, li), w3 = sv::rl(m_w3, li);
+        i32 sc = -1, pd = -1, pd_sc = 0;
+        for (u32 k = 0; k < c; ++k) {
+          i32 wgt, t;
+          if (k < 4) {
+            t = static_cast<i32>(((k < 2 ? t01 : t23) >> (16 * (k & 1))) & 0xFFFFu);
+            wgt = k == 0 ? w0 : (k == 1 ? w1 : (k == 2 ? w2 : w3));
+          } else {
+            wgt = g.in_w[static_cast<size_t>(it) * kPoaMaxIn + k];
+            t = static_cast<i32>(g.in_tail[static_cast<size_t>(it) * kPoaMaxIn + k]);
+          }
+          const i32 st = lsc[t];
+          if (sc < wgt || (sc == wgt && pd_sc <= st)) {
+            sc = wgt;
+            pd = t;
+            pd_sc = st;
+          }
+        }
+        if (pd != -1) sc += pd_sc;
+        lds_order();  // every lane has read the scores it needs before this node's is written
+        if (lane == 0) {
+          lsc[it] = sc;
+          g.scores[it] = sc;
+          g.preds[it] = pd;
+        }
+        lds_order();
+        if (maxn == -1 || max_sc < sc) {
+          maxn = static_cast<i32>(it);
+          max_sc = sc;
+        }
+      }
+    }
+  }
+  sv::sync();  // scores / predecessors in HBM visible to lane 0's branch completion and traceback
+  u32 cl = 0;
+  i32 begin = 0, end = -1;
+  if (lane == 0) poa_consensus_trace_lane0(g, n_nodes, nmax, win, trim, maxn, &cl, &begin, &end);
+  cl = static_cast<u32>(sv::rfl(static_cast<int>(cl)));
+  begin = sv::rfl(begin);
+  end = sv::rfl(end);
+  sv::sync();  // g.stack
+  i32 n_out = end - begin + 1;
+  if (n_out < 0) n_out = 0;
+  if (static_cast<u32>(n_out) > win.out_cap) n_out = static_cast<i32>(win.out_cap);
+  for (i32 p = lane; p < n_out; p += 64) out[p] = g.code[g.stack[cl - 1 - static_cast<u32>(begin + p)]];
+  if (lane == 0) *out_len = static_cast<u32>(n_out);
+}
+
+// ---- one persistent wave: takes four windows at a time ------------------------------------------------------------
+enum : u32 { kIdle = 0, kRunning = 1, kLayersDone = 2, kFinal = 3, kFailed = 4 };
+
+template <class K>
+__host__ __device__ inline void poa4_wave(const Poa4Args& A, Poa4Lds& S, u32 slot0) {
+  constexpr int kG = K::G, GS = K::GS;
+  const int lane = sv::lane();
+  const int q = lane / GS;
+  unsigned long long t_sub = 0, t_dp = 0, t_tb = 0, t_add = 0, t_ord = 0, t_cons = 0, t0 = 0;
+  unsigned char* const my_slot = A.scratch + static_cast<size_t>(slot0 + q) * A.slot_bytes;  // per lane: its group's window
+  for (;;) {
+    u32 first = 0;
+    if (lane == 0) first = sv::atomic_add(A.next, static_cast<u32>(kG));
+    first = static_cast<u32>(sv::rfl(static_cast<int>(first)));
+    if (first >= A.n_windows) break;
+    // group-uniform state of the lane's window
+    const u32 pos = first + static_cast<u32>(q);
+    const bool have = pos < A.n_windows;
+    const u32 wi = have ? (A.sched ? A.sched[pos] : pos) : 0u;
+    const PoaWindow win = A.windows[wi];
+    u32 phase = have ? kRunning : kIdle;
+    u32 status = 0, nn = 0, n_eff = 0, li = 1;
+    auto window_of = [&](int q2, u32& wi2) -> PoaWindow {  // group q2's window as wave-uniform values
+      PoaWindow wq;
+      wq.layer_first = static_cast<u32>(sv::rl(static_cast<int>(win.layer_first), q2 * GS));
+      wq.n_layers = static_cast<u32>(sv::rl(static_cast<int>(win.n_layers), q2 * GS));
+      wq.out_off = static_cast<u32>(sv::rl(static_cast<int>(win.out_off), q2 * GS));
+      wq.out_cap = static_cast<u32>(sv::rl(static_cast<int>(win.out_cap), q2 * GS));
+      wi2 = static_cast<u32>(sv::rl(static_cast<int>(wi), q2 * GS));
+      return wq;
+    };
+    for (int q2 = 0; q2 < kG; ++q2) {
+      if (sv::rl(static_cast<int>(phase), q2 * GS) != static_cast<int>(kRunning)) continue;
+      u32 wi2;
+      const PoaWindow wq = window_of(q2, wi2);
+      Poa2Slot g = poa4_carve(A.scratch + static_cast<size_t>(slot0 + q2) * A.slot_bytes, A.nmax, A.lmax).g;
+      u32 nn2 = 0, ne2 = 0;
+      const u32 r = poa4_init_window(A, wq, g, wi2, nn2, ne2);
+      if (q == q2) {
+        nn = nn2;
+        n_eff = ne2;
+        if (r != 1) {
+          phase = kFinal;
+          status = r;
+        }
+      }
+    }
+    // ---- layers: every window of the wave aligns its next layer in the same round ----
+    for (;;) {
+      bool act = false, full = false;
+      u32 len = 0;
+      i32 lb = 0, span = 0;
+      const PoaLayer* Lp = A.layers;
+      for (int q2 = 0; q2 < kG; ++q2) {
+        if (sv::rl(static_cast<int>(phase), q2 * GS) != static_cast<int>(kRunning)) continue;
+        u32 wi2;
+        const PoaWindow wq = window_of(q2, wi2);
+        u32 liq = static_cast<u32>(sv::rl(static_cast<int>(li), q2 * GS));
+        const u32 nnq = static_cast<u32>(sv::rl(static_cast<int>(nn), q2 * GS));
+        while (liq < wq.n_layers && (A.layers[wq.layer_first + liq].len == 0 ||
+                                     (A.src.layer_ok && !A.src.layer_ok[wq.layer_first + liq])))
+          ++liq;
+        if (liq >= wq.n_layers) {
+          if (q == q2) phase = kLayersDone;
+          continue;
+        }
+        const PoaLayer L = A.layers[wq.layer_first + liq];
+        if (L.len > A.lmax || L.len > static_cast<u32>(kPoa2MaxSeq)) {
+          if (q == q2) {
+            phase = kFailed;
+            status = 4;
+          }
+          continue;
+        }
+        Poa2Slot g = poa4_carve(A.scratch + static_cast<size_t>(slot0 + q2) * A.slot_bytes, A.nmax, A.lmax).g;
+        Poa4Group& Sg = S.g[q2];
+        // the layer's codes: bytes first (the ring is free), then 16 to a word
+        for (u32 i = lane; i < L.len; i += 64) {
+          Sg.u.bytes[i] = static_cast<u8>(poa_layer_code(A.src, L, i));
+          g.pos_node[i] = static_cast<u16>(kNone4);
+        }
+        lds_order();
+        for (u32 wd = lane; wd < 60; wd += 64) {
+          u32 x = 0;
+          for (u32 c = 0; c < 16; ++c) {
+            const i32 p = static_cast<i32>(wd * 16 + c) - 1;
+            if (p >= 0 && p < static_cast<i32>(L.len)) x |= static_cast<u32>(Sg.u.bytes[p] & 3u) << (2 * c);
+          }
+          Sg.seq2[wd] = x;
+        }
+        const u32 blen = A.layers[wq.layer_first].len;
+        const u32 offset = static_cast<u32>(0.01 * blen);
+        const bool fullq = L.begin < offset && L.end > blen - offset;
+        t0 = sv::clock();
+        if (!fullq) poa_subgraph_marks(g, nnq, A.nmax, L.begin, L.end);
+        t_sub += sv::clock() - t0;
+        if (q == q2) {
+          act = true;
+          full = fullq;
+          len = L.len;
+          lb = static_cast<i32>(L.begin);
+          span = static_cast<i32>(L.end) - static_cast<i32>(L.begin) + 1;
+          Lp = A.layers + wq.layer_first + liq;
+          li = liq;
+        }
+      }
+      if (!sv::any(act)) break;
+      sv::sync();
+      t0 = sv::clock();
+      u32 r_lo = 0, n_rows = 0, t_end = 0, flag = 0, marked_rows = 0;
+      poa4_prepass<K>(A, S, my_slot, act, nn, full, Lp, len, lb, span, r_lo, n_rows, t_end, flag, marked_rows);
+      if ((lane & (GS - 1)) == 0 && act && A.phase_cycles) {
+        sv::atomic_add(&A.phase_cycles[6], static_cast<unsigned long long>(marked_rows) * len);
+        sv::atomic_add(&A.phase_cycles[7], static_cast<unsigned long long>(marked_rows) * (len + 1 < 32u ? len + 1 : 32u));
+      }
+#if !defined(__HIP_DEVICE_COMPILE__)
+      if (std::getenv("RVN_POA4_DEBUG") && (lane & 15) == 0 && act)
+        std::fprintf(stderr, "[poa4] group %d layer %u: nn %u r_lo %u n_rows %u t_end %u flag %u len %u full %d\n", q, li, nn, r_lo, n_rows, t_end, flag, len, int(full));
+#endif
+      const bool had = act;
+      if (act && flag) {  // beyond this kernel's limits (in-degree, in-edge length, band step): the 64-column kernel's job
+        phase = kFailed;
+        status = kPoaBandHit | (li << 8);
+        act = false;
+      }
+      sv::sync();  // descriptors visible
+      t_sub += sv::clock() - t0;
+      t0 = sv::clock();
+      u32 best_rho1 = 0;
+      poa4_dp<K>(A, S, my_slot, act, t_end, len, best_rho1);
+      sv::sync();  // backpointers visible to the traceback
+      t_dp += sv::clock() - t0;
+      t0 = sv::clock();
+#if !defined(__HIP_DEVICE_COMPILE__)
+      if (std::getenv("RVN_POA4_DEBUG") && (lane & 15) == 0 && act)
+        std::fprintf(stderr, "[poa4] group %d layer %u: best_rho1 %u\n", q, li, best_rho1);
+#endif
+      if (act && best_rho1 == 0) {  // the last column is in no end node's band
+        phase = kFailed;
+        status = kPoaBandHit | (li << 8);
+        act = false;
+      }
+      u32 bad = 0, band_hit = 0;
+      poa4_traceback<K>(A, S, my_slot, act, r_lo, n_rows, full, len, best_rho1, bad, band_hit);
+      if (act && bad) {
+        phase = kFailed;
+        status = bad | (li << 8);
+        act = false;
+      } else if (act && band_hit) {
+        phase = kFailed;
+        status = kPoaBandHit | (li << 8);
+        act = false;
+      }
+#if !defined(__HIP_DEVICE_COMPILE__)
+      if (std::getenv("RVN_POA4_DEBUG") && (lane & 15) == 0 && had)
+        std::fprintf(stderr, "[poa4] group %d layer %u: traceback bad %u band_hit %u\n", q, li, bad, band_hit);
+#endif
+      sv::sync();  // pos_node
+      t_tb += sv::clock() - t0;
+      for (int q2 = 0; q2 < kG; ++q2) {
+        if (!sv::rl(act ? 1 : 0, q2 * GS)) continue;
+        u32 wi2;
+        const PoaWindow wq = window_of(q2, wi2);
+        const u32 liq = static_cast<u32>(sv::rl(static_cast<int>(li), q2 * GS));
+        u32 nnq = static_cast<u32>(sv::rl(static_cast<int>(nn), q2 * GS));
+        const PoaLayer L = A.layers[wq.layer_first + liq];
+        Poa2Slot g = poa4_carve(A.scratch + static_cast<size_t>(slot0 + q2) * A.slot_bytes, A.nmax, A.lmax).g;
+        const u32 why = poa4_add_alignment(A, g, S.g[q2], L, nnq, t_add, t_ord);
+        if (q == q2) {
+          if (why) {
+            phase = kFailed;
+            status = why;
+          } else {
+            nn = nnq;
+          }
+        }
+      }
+      if (had) ++li;
+    }
+    // ---- results ----
+    t0 = sv::clock();
+    for (int q2 = 0; q2 < kG; ++q2) {
+      const u32 ph = static_cast<u32>(sv::rl(static_cast<int>(phase), q2 * GS));
+      if (ph == kIdle) continue;
+      u32 wi2;
+      PoaWindow wq = window_of(q2, wi2);
+      u32 st = static_cast<u32>(sv::rl(static_cast<int>(status), q2 * GS));
+      if (ph == kFailed) {
+        poa4_copy_backbone(A, wq, A.layers[wq.layer_first], A.out + wq.out_off, A.out_len + wi2);
+      } else if (ph == kLayersDone) {
+        Poa2Slot g = poa4_carve(A.scratch + static_cast<size_t>(slot0 + q2) * A.slot_bytes, A.nmax, A.lmax).g;
+        const u32 nnq = static_cast<u32>(sv::rl(static_cast<int>(nn), q2 * GS));
+        wq.n_layers = static_cast<u32>(sv::rl(static_cast<int>(n_eff), q2 * GS));
+        sv::sync();
+        poa4_consensus(g, nnq, A.nmax, wq, A.trim, S, A.out + wq.out_off, A.out_len + wi2);
+        sv::sync();
+        st = 1;
+      }
+      if (lane == 0) A.status[wi2] = st;
+    }
+    t_cons += sv::clock() - t0;
+    sv::sync();
+  }
+  if (A.phase_cycles) {
+    if (lane == 0) {
+      sv::atomic_add(&A.phase_cycles[0], t_sub);
+      sv::atomic_add(&A.phase_cycles[1], t_dp);
+      sv::atomic_add(&A.phase_cycles[2], t_tb);
+      sv::atomic_add(&A.phase_cycles[3], t_add);
+      sv::atomic_add(&A.phase_cycles[4], t_ord);
+      sv::atomic_add(&A.phase_cycles[5], t_cons);
+    }
+  }
+}
+
+template <int OCC>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void poa4_kernel(const Poa4Args A, u32 n_waves) {
+  __shared__ Poa4Lds lds;
+  if (blockIdx.x >= n_waves) return;
+  poa4_wave<P4>(A, lds, blockIdx.x * P4::G);
+}
+
+struct EmuCall4 {
+  const Poa4Args* A;
+  Poa4Lds* S;
+};
+void emu_entry4(void* p) {
+  EmuCall4* c = static_cast<EmuCall4*>(p);
+  poa4_wave<P4>(*c->A, *c->S, 0);
+}
+
+Poa4Args args_of4(const PoaBatchDev& b, unsigned char* scratch, size_t slot_bytes) {
+  Poa4Args A{};
+  A.windows = b.wins;
+  A.n_windows = b.n_windows;
+  A.layers = b.layers;
+  A.src = b.src;
+  A.scratch = scratch;
+  A.slot_bytes = slot_bytes;
+  A.nmax = b.nmax;
+  A.lmax = b.lmax;
+  A.m = b.m;
+  A.n_ = b.n;
+  A.gp = b.g;
+  A.trim = b.trim;
+  A.out = b.out;
+  A.out_len = b.out_len;
+  A.status = b.status;
+  A.phase_cycles = b.phase_cycles;
+  A.sched = b.sched;
+  A.next = b.next;
+  return A;
+}
+
+}  // namespace
+
+void poa_v4_launch(Engine& e, const PoaBatchDev& b) {
+  if (b.n_windows == 0) return;
+  const size_t slot_bytes = poa4_slot_bytes(b.nmax, b.lmax);
+  size_t free_b = 0, total_b = 0;
+  RVN_HIP(hipMemGetInfo(&free_b, &total_b));
+  constexpr int kOcc = 3;
+  u32 per_cu = std::min<u32>(static_cast<u32>((160u * 1024u) / sizeof(Poa4Lds)), 4u * kOcc);
+  if (const char* ev = std::getenv("RVN_POA_WAVES_PER_CU")) per_cu = static_cast<u32>(std::atoi(ev));  // occupancy experiments
+  per_cu = per_cu < 1 ? 1 : per_cu;
+  u32 n_waves = std::min<u32>((b.n_windows + P4::G - 1) / P4::G, 256 * per_cu);
+  const size_t budget = e.poa2_scratch.cap + free_b / 2;
+  if (static_cast<size_t>(n_waves) * P4::G * slot_bytes > budget)
+    n_waves = static_cast<u32>(std::max<size_t>(1, budget / (slot_bytes * P4::G)));
+  unsigned char* d_scratch = e.poa2_scratch.get<unsigned char>(static_cast<size_t>(n_waves) * P4::G * slot_bytes + 256);
+  RVN_HIP(hipMemsetAsync(b.next, 0, 4, e.stream));
+  const Poa4Args A = args_of4(b, d_scratch, slot_bytes);
+  RVN_KLAUNCH(kKPoaBanded, (poa4_kernel<kOcc><<<n_waves, 64, 0, e.stream>>>(A, n_waves)));
+}
+
+// The same kernel source on the host, one emulated wave (simt_emu): windows / layers / sources are host arrays.  TEST
+// INFRASTRUCTURE (rvn_poa_banded_emulate); first attempt only — a window that needs a wider band comes back flagged.
+void poa_v4_emulate(const std::vector<PoaWindow>& wins, const std::vector<PoaLayer>& lays, const PoaSrc& src, u32 max_bb,
+                    u32 max_len, int m, int n, int g, int trim, u8* out, u32* out_len, u32* status) {
+  if (wins.empty()) return;
+  PoaBatchDev b{};
+  b.lmax = std::min<u32>(kPoaMaxSeq, std::max<u32>(64, ((max_len + 63) / 64) * 64));
+  b.nmax = std::min<u32>(8192, std::max<u32>(512, max_bb * 6));
+  const size_t slot_bytes = poa4_slot_bytes(b.nmax, b.lmax);
+  std::vector<unsigned char> scratch(slot_bytes * P4::G + 256, 0);
+  unsigned long long phase[10] = {};
+  u32 next = 0;
+  b.wins = wins.data();
+  b.n_windows = static_cast<u32>(wins.size());
+  b.layers = lays.data();
+  b.src = src;
+  b.m = m;
+  b.n = n;
+  b.g = g;
+  b.trim = trim;
+  b.out = out;
+  b.out_len = out_len;
+  b.status = status;
+  b.phase_cycles = phase;
+  b.sched = nullptr;
+  b.next = &next;
+  const Poa4Args A = args_of4(b, scratch.data(), slot_bytes);
+  std::vector<Poa4Lds> lds(1);
+  std::memset(static_cast<void*>(lds.data()), 0, sizeof(Poa4Lds));
+  EmuCall4 call{&A, lds.data()};
+  simt_emu::run_wave(&emu_entry4, &call);
+}
+
+}  // namespace rvn

@@ -1,0 +1,138 @@
+"""The rows-on-lanes banded POA kernel (raven_amd/csrc/poa4.hip) stepped through on the CPU: the kernel source is written
+against sv:: (csrc/simt.h) and runs unchanged under the 64-fibre wavefront emulator (csrc/simt_emu.hip), so the whole
+kernel — per-layer row descriptors, the systolic NW (a graph row per lane, two columns per step), lock-step tracebacks
+through the time-major backpointer stream, graph update, consensus — is compared with the POA oracle (racon
+Window::GenerateConsensus over spoa) here, without a GPU.  First attempt of the escalation chain only: a window whose
+alignment touches the 32-column band, or whose graph is beyond the kernel's limits (an in-edge longer than the LDS ring,
+more than eight in-edges), comes back flagged (status 8) and is not compared.
+The GPU side of the same comparison is tests/test_gpu_poa.py (mode 9)."""
+import numpy as np
+import pytest
+
+from oracle import oracle
+from raven_amd import hip
+from tests.test_poa3_emulation import _mutate, _oracle, _window
+
+
+def _compare(wins, min_polished, **kw):
+    cons, status = hip.poa_banded_emulate(wins, variant=4, **kw)
+    polished = 0
+    for i, (w, c, st) in enumerate(zip(wins, cons, status)):
+        if (int(st) & 0xFF) == 1:
+            polished += 1
+            assert np.array_equal(c, _oracle(w, trim=kw.get("trim", True))), (i, kw)
+        else:
+            assert (int(st) & 0xFF) in (0, 8), st
+    assert polished >= min_polished, status
+    return cons, status
+
+
+def test_simple_windows():
+    rng = np.random.default_rng(1)
+    truth = rng.integers(0, 4, size=150, dtype=np.uint8)
+    bb = _mutate(rng, truth, 0.03, 0.02, 0.02)
+    wins = [
+        dict(layers=[bb] + [truth.copy() for _ in range(6)]),      # error-free layers fix the backbone
+        dict(layers=[bb, truth.copy()]),                            # < 3 sequences: backbone back
+        dict(layers=[bb]),
+        dict(layers=[truth.copy()] + [truth[30:120].copy() for _ in range(8)], begins=[0] + [30] * 8,
+             ends=[149] + [119] * 8),                               # trimming of thin ends
+        dict(layers=[bb] + [truth.copy() for _ in range(3)]),       # a fifth window: the wave's second batch of four
+    ]
+    cons, status = hip.poa_banded_emulate(wins, variant=4)
+    assert status.tolist() == [1, 0, 0, 1, 1]
+    assert np.array_equal(cons[0], truth)
+    assert np.array_equal(cons[1], bb) and np.array_equal(cons[2], bb)
+    assert np.array_equal(cons[3], truth[30:120])
+    for w, c in zip(wins, cons):
+        assert np.array_equal(c, _oracle(w))
+    cons_nt, _ = hip.poa_banded_emulate(wins[3:4], trim=False, variant=4)
+    assert np.array_equal(cons_nt[0], _oracle(wins[3], trim=False))
+
+
+def test_noisy_windows_ragged_groups():
+    """Windows of different sizes, layer counts, partial layers and qualities share a wave: the four groups run out of
+    rows, steps, layers and traceback steps at different times."""
+    rng = np.random.default_rng(5)
+    wins = []
+    for i in range(14):
+        wins.append(_window(rng, int(rng.integers(70, 260)), int(rng.integers(3, 14)), partial=0.3 if i % 2 else 0.0,
+                            qual=(i % 3 == 0)))
+    _compare(wins, min_polished=11)
+
+
+def test_window_sized_like_racon():
+    """500-base windows with 30 layers (the shape a polishing round produces), two of them with partial layers."""
+    rng = np.random.default_rng(11)
+    wins = [_window(rng, 500 + 20 * i, 30, partial=0.25 if i % 2 else 0.0, qual=(i == 0)) for i in range(4)]
+    _compare(wins, min_polished=3)
+
+
+def test_short_and_tiny_windows():
+    """Layers shorter than the band (every row holds the whole layer), windows shorter than a block of 16 rows."""
+    rng = np.random.default_rng(9)
+    wins = [_window(rng, n, 6, err=(0.03, 0.02, 0.02)) for n in (5, 12, 17, 30, 33, 47, 64, 65)]
+    _compare(wins, min_polished=6)
+
+
+def test_long_private_insertion_is_flagged_or_exact():
+    """A long private insertion in half of the reads: an in-edge that spans more rows than the LDS ring keeps (or an
+    alignment that leaves the 32-column band) sends the window on to the 64-column kernel; whatever is polished here is
+    exact."""
+    rng = np.random.default_rng(3)
+    wins = []
+    for _ in range(4):
+        truth = rng.integers(0, 4, size=220, dtype=np.uint8)
+        layers = [_mutate(rng, truth, 0.03, 0.02, 0.02)]
+        for r in range(10):
+            t = truth
+            if r % 2 == 0:
+                pos = 100 + int(rng.integers(0, 5))
+                t = np.concatenate([truth[:pos], rng.integers(0, 4, size=int(rng.integers(18, 30)), dtype=np.uint8), truth[pos:]])
+            layers.append(_mutate(rng, t, 0.03, 0.02, 0.02))
+        wins.append(dict(layers=layers))
+    _compare(wins, min_polished=0)
+
+
+def test_scoring_parameters():
+    rng = np.random.default_rng(21)
+    wins = [_window(rng, 120, 8) for _ in range(4)]
+    cons, status = hip.poa_banded_emulate(wins, m=5, n=-4, g=-8, variant=4)
+    polished = 0
+    for w, c, st in zip(wins, cons, status):
+        if (int(st) & 0xFF) == 1:
+            polished += 1
+            o = oracle.poa_window(w["layers"], begins=w["begins"], ends=w["ends"], quals=w["quals"], m=5, n=-4, g=-8)[0]
+            assert np.array_equal(c, o)
+    assert polished >= 3
+
+
+def test_nodes_with_many_in_edges():
+    """Insertions of every letter (and of two letters) in front of the same backbone position give that node five and
+    more in-edges: in-edges 0..7 sit in the row descriptor (the traceback resolves 6 and 7 through the graph)."""
+    rng = np.random.default_rng(17)
+    truth = rng.integers(0, 4, size=160, dtype=np.uint8)
+    layers = [truth.copy()]
+    for rep in range(2):
+        for letter in range(4):
+            layers.append(np.concatenate([truth[:70], np.array([letter], np.uint8), truth[70:]]))
+            layers.append(np.concatenate([truth[:70], np.array([letter, (letter + 1) & 3], np.uint8), truth[70:]]))
+    layers += [truth.copy() for _ in range(3)]
+    cons, status = hip.poa_banded_emulate([dict(layers=layers)] * 2 + [dict(layers=layers[:9])], variant=4)
+    assert [int(s) & 0xFF for s in status] == [1, 1, 1]
+    assert np.array_equal(cons[0], _oracle(dict(layers=layers)))
+    assert np.array_equal(cons[2], _oracle(dict(layers=layers[:9])))
+
+
+def test_limits_are_reported():
+    """A layer longer than the banded kernels take (896 bases) comes back as status 4 with the backbone as output, as on
+    the GPU, and does not disturb the other windows of its wave."""
+    rng = np.random.default_rng(23)
+    bb = rng.integers(0, 4, size=950, dtype=np.uint8)
+    long_w = dict(layers=[bb, bb.copy(), bb.copy()])
+    ok_w = _window(rng, 120, 6)
+    cons, status = hip.poa_banded_emulate([long_w, ok_w, long_w, ok_w, ok_w], variant=4)
+    for i in (0, 2):
+        assert (int(status[i]) & 0xFF) == 4 and np.array_equal(cons[i], bb)
+    for i in (1, 3, 4):
+        assert (int(status[i]) & 0xFF) == 1 and np.array_equal(cons[i], _oracle(ok_w))
