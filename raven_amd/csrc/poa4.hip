@@ -248,10 +248,12 @@ __host__ __device__ inline void poa4_prepass(const Poa4Args A, Poa4Lds& S, unsig
   const u32 w = len + 1;
   // the layer's band guide in registers (poa_layer_center without its loads)
   const u32* wayp = reinterpret_cast<const u32*>(Lp->way);
-  const u32 way0 = wayp[0], way1 = wayp[1], way2 = wayp[2], way3 = wayp[3];
-  auto way_at = [&](i32 idx) -> i32 {
-    const u32 ws = idx < 4 ? (idx < 2 ? way0 : way1) : (idx < 6 ? way2 : way3);
-    return static_cast<i32>((ws >> (16 * (idx & 1))) & 0xFFFFu);
+  // (two 64-bit words shifted by the index: a select between four captured values becomes a private array, which the
+  // backend parks in LDS)
+  const unsigned long long way_lo = static_cast<unsigned long long>(wayp[0]) | (static_cast<unsigned long long>(wayp[1]) << 32);
+  const unsigned long long way_hi = static_cast<unsigned long long>(wayp[2]) | (static_cast<unsigned long long>(wayp[3]) << 32);
+  auto way_at = [way_lo, way_hi](i32 idx) -> i32 {
+    return static_cast<i32>(((idx < 4 ? way_lo : way_hi) >> (16 * (idx & 3))) & 0xFFFFu);
   };
   auto band_start = [&](i32 bpos) -> i32 {  // even, in [0, max(0, w - 31)]
     i32 x = bpos - lb;
@@ -547,20 +549,34 @@ __host__ __device__ inline void poa4_dp(const Poa4Args A, Poa4Lds& S, unsigned c
         if (j0 < 0) vp = pack16(kNegInf16, kNegInf16);
         wd = np == 0 ? vp : wd;
       }
+      // (a row's unused in-edges point at -inf cells: in-edges 1..3 are read whether the row has them or not, so the
+      // four reads are in flight together; 99 % of the rows have at most four)
+      const u32 w1 = lds_ld32(S, add_half<true>(off4, ce0));
+      const u32 w2 = lds_ld32(S, add_half<false>(off4, ce1));
+      const u32 w3 = lds_ld32(S, add_half<true>(off4, ce1));
       i32 A0 = cell_key<false, 15>(wd), A1 = cell_key<true, 15>(wd);
+      A0 = imax(A0, cell_key<false, 14>(w1));
+      A1 = imax(A1, cell_key<true, 14>(w1));
+      A0 = imax(A0, cell_key<false, 13>(w2));
+      A1 = imax(A1, cell_key<true, 13>(w2));
+      A0 = imax(A0, cell_key<false, 12>(w3));
+      A1 = imax(A1, cell_key<true, 12>(w3));
 #define P4_EDGE(E, REG, HI)                                        \
-  if (sv::any(np > E)) {                                           \
+  {                                                                \
     const u32 we = lds_ld32(S, add_half<HI>(off4, REG));           \
     A0 = imax(A0, cell_key<false, 15 - E>(we));                    \
-    A1 = imax(A1, cell_key<true, 15 - E>(we));
-      P4_EDGE(1, ce0, true)
-      P4_EDGE(2, ce1, false)
-      P4_EDGE(3, ce1, true)
-      P4_EDGE(4, ce2, false)
-      P4_EDGE(5, ce2, true)
-      P4_EDGE(6, ce3, false)
-      P4_EDGE(7, ce3, true)
-      }}}}}}}
+    A1 = imax(A1, cell_key<true, 15 - E>(we));                     \
+  }
+      if (sv::any(np > 4)) {
+        P4_EDGE(4, ce2, false)
+        if (sv::any(np > 5)) {
+          P4_EDGE(5, ce2, true)
+          if (sv::any(np > 6)) {
+            P4_EDGE(6, ce3, false)
+            P4_EDGE(7, ce3, true)
+          }
+        }
+      }
 #undef P4_EDGE
       // ---- the two cells: spoa's priority diagonal (first in-edge reaching the maximum), vertical, horizontal ----
       const u32 bits = (cM >> (static_cast<u32>(2 * k) & 31u)) & 3u;
@@ -574,7 +590,10 @@ __host__ __device__ inline void poa4_dp(const Poa4Args A, Poa4Lds& S, unsigned c
       const i32 U1 = imax(s1, h1);
       const u32 code1 = h1 > s1 ? 64u : (static_cast<u32>(b1) & 63u);
       if (static_cast<u32>(k) < 16u) lds_st32(S, add_half<true>(static_cast<u32>(k) << 2, c0), clamp_pair(pack16(U0, U1)));
-      const u32 cp = code0 | (code1 << 8);
+      u32 cp = code0 | (code1 << 8);
+#if defined(__HIP_DEVICE_COMPILE__)
+      asm volatile("" : "+v"(cp));  // computed here: sunk to the store it would keep three registers per step alive
+#endif
       if (u == 0) acc0 = cp;
       else if (u == 1) acc0 |= cp << 16;
       else if (u == 2) acc1 = cp;
