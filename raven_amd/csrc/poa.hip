@@ -659,8 +659,8 @@ void poa_run_dev(Engine& e, const PoaWindow* d_wins, const PoaLayer* d_lays, u32
   b.trim = trim;
   b.n_windows = n_windows;
   b.src = src;
-  unsigned long long* d_phase = e.q_start.get<unsigned long long>(10);
-  RVN_HIP(hipMemsetAsync(d_phase, 0, 80, s));
+  unsigned long long* d_phase = e.q_start.get<unsigned long long>(16);  // [0..7] phases + cells, [8] work counter, [10..15] kernel statistics
+  RVN_HIP(hipMemsetAsync(d_phase, 0, 128, s));
   // heaviest windows first: cost ~ number of layers
   u32* d_sk = e.poa_sched.get<u32>(4 * static_cast<size_t>(n_windows) + 8);
   u32* d_sk1 = d_sk + n_windows + 1;
@@ -799,7 +799,13 @@ void poa_run_dev(Engine& e, const PoaWindow* d_wins, const PoaLayer* d_lays, u32
   }
   RVN_HIP(hipEventRecord(e.ev1, s));
   RVN_HIP(hipMemcpyAsync(e.poa_phase_cycles, d_phase, 64, hipMemcpyDeviceToHost, s));
+  unsigned long long kstats[6] = {};
+  const bool want_stats = std::getenv("RVN_POA_STATS") != nullptr;
+  if (want_stats) RVN_HIP(hipMemcpyAsync(kstats, d_phase + 10, 48, hipMemcpyDeviceToHost, s));
   RVN_HIP(rvn_stream_sync(s));
+  if (want_stats)
+    std::fprintf(stderr, "[raven_hip] poa kernel statistics (poa4.hip): prepass cycles %llu, traceback steps %llu block switches %llu stream reads %llu, dp wave-steps %llu, layer set-up cycles %llu\n",
+                 kstats[0], kstats[1], kstats[2], kstats[3], kstats[4], kstats[5]);
   e.poa_cells_full += e.poa_phase_cycles[6];
   e.poa_cells_band += e.poa_phase_cycles[7];
   e.poa_calls += 1;

@@ -45,7 +45,6 @@ struct P4 {
   static constexpr int kMaxD = 16;    // largest band-start difference along an in-edge (the right pads cover it)
   static constexpr int kEdges = 8;    // in-edges a row descriptor holds; a row with more sends the window to poa2
   static constexpr int kU = 8;        // steps between two service points (descriptor prefetch, backpointer store)
-  static constexpr int kTbBlocks = 7; // 8-step blocks of the backpointer stream staged per 16 traceback rows
 };
 constexpr u32 kNone4 = 0xFFFFu;
 constexpr i32 kNegKey = kNegInf16 * 64;
@@ -55,11 +54,8 @@ constexpr u32 kInactiveS = 0x7FFFu;
 struct alignas(16) Poa4Group {
   union {
     u32 ring32[P4::kRing * P4::kRowB / 4];  // DP: [kRing][2 pads | 32 cells | 18 pads] int16, slot = rho % kRing
-    struct {
-      u32 d[16 * 4];                     // traceback: d0, d1, d7 of the 16 rows of a block
-      uint4 bp[P4::kTbBlocks * 16];      // and the 8-step blocks of the backpointer stream that cover them
-    } tb;
     u8 bytes[kPoa2MaxSeq + 16];          // layer set-up: one-byte codes before they are packed
+    u32 segtab[32];                      // pre-pass: the layer's band guide, {x0, wa, wb - wa, magic(x1 - x0)} per segment
   } u;
   u32 seq2[60];  // the layer, 2 bits per base, position p at bits 2 (p + 1): column j's base sits at bit 2 j
   u32 dump[16];  // where rows outside the layer's subgraph leave their cells
@@ -92,7 +88,7 @@ struct Poa4Slot {
   Poa2Slot g;
   uint4* desc;   // 2 per row: {S | own << 16, node | b << 16 | np << 26 | marked << 30 | end << 31, match mask, e0 | e1 << 16},
                  //            {e2 | e3 << 16, e4 | e5 << 16, e6 | e7 << 16, rank distances of in-edges 0..5 (5 bits each)}
-  u16* blk_s;    // S of the first row of every block of 16 rows
+  u32* rb;       // per node: rank | band start in this layer << 16
   uint4* bps;    // backpointer stream: [step / 8][lane of the window] 16 bytes = 8 steps x 2 columns
 };
 __host__ __device__ inline u32 poa4_desc_rows(u32 nmax) { return nmax + 64; }
@@ -100,7 +96,7 @@ __host__ __device__ inline u32 poa4_steps(u32 nmax, u32 lmax) { return nmax + nm
 inline size_t poa4_slot_bytes(u32 nmax, u32 lmax) {
   size_t b = poa2_slot_bytes(nmax, lmax, 0, false);
   b += static_cast<size_t>(poa4_desc_rows(nmax)) * 32;
-  b += ((static_cast<size_t>(poa4_desc_rows(nmax)) / 16 + 8) * 2 + 255) & ~size_t(255);
+  b += (static_cast<size_t>(nmax) * 4 + 255) & ~size_t(255);
   b += (static_cast<size_t>(poa4_steps(nmax, lmax)) / P4::kU + 2) * 16 * 16;
   return (b + 255) & ~size_t(255);
 }
@@ -111,8 +107,8 @@ __host__ __device__ inline Poa4Slot poa4_carve(unsigned char* base, u32 nmax, u3
   poa2_fields(nmax, lmax, 0, [&](int, size_t x) { o += (x + 255) & ~size_t(255); }, false);
   s.desc = reinterpret_cast<uint4*>(base + o);
   o += static_cast<size_t>(poa4_desc_rows(nmax)) * 32;
-  s.blk_s = reinterpret_cast<u16*>(base + o);
-  o += ((static_cast<size_t>(poa4_desc_rows(nmax)) / 16 + 8) * 2 + 255) & ~size_t(255);
+  s.rb = reinterpret_cast<u32*>(base + o);
+  o += (static_cast<size_t>(nmax) * 4 + 255) & ~size_t(255);
   s.bps = reinterpret_cast<uint4*>(base + o);
   return s;
 }
@@ -230,9 +226,24 @@ __host__ __device__ inline u32 poa4_nth_pred_rank(const Poa2Slot& g, u32 v, u32 
 }
 
 // ---- per-layer pre-pass: the row descriptors ---------------------------------------------------------------------------
-// The wave's windows side by side, one row per lane and iteration.  Group-uniform inputs: act, nn, full, the layer.
+// The wave's windows side by side.  Group-uniform inputs: act, nn, full, the layer.  Two sweeps over the NODES (not the
+// ranks: everything a node contributes is then a coalesced load, and only its in-edges' tails are gathered):
+//   A  rb[v] = rank | band start << 16 (the band start from the layer's guide through per-segment reciprocals kept in LDS),
+//      and the rank range [r_lo, r_hi) that holds the layer's subgraph;
+//   B  the descriptor of every node whose rank lies in the range, written at its row rho = rank - r_lo.
 // Outputs (group-uniform): r_lo (rank of row 0), n_rows, t_end (steps of the layer's DP), flag (!= 0: the layer does
 // not fit this kernel's limits -> the window goes to the 64-column kernel), marked rows (work counter).
+__host__ __device__ __forceinline__ u32 mulhi_u32(u32 a, u32 b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __umulhi(a, b);
+#else
+  return static_cast<u32>((static_cast<unsigned long long>(a) * b) >> 32);
+#endif
+}
+// n / d for n * d < 2^32 through m = magic_of(d): floor(2^32 / d) + 1, 0 standing for d == 1
+__host__ __device__ __forceinline__ u32 magic_of(u32 d) { return d <= 1 ? 0u : static_cast<u32>(0x100000000ULL / d) + 1u; }
+__host__ __device__ __forceinline__ u32 div_magic(u32 n, u32 m) { return m ? mulhi_u32(n, m) : n; }
+
 template <class K>
 __host__ __device__ inline void poa4_prepass(const Poa4Args A, Poa4Lds& S, unsigned char* slot_mem, bool act, u32 nn, bool full,
                                              const PoaLayer* Lp, u32 len, i32 lb, i32 span, u32& r_lo_out, u32& n_rows_out,
@@ -244,123 +255,131 @@ __host__ __device__ inline void poa4_prepass(const Poa4Args A, Poa4Lds& S, unsig
   const int gl = lane & 15, gbase = lane & ~15, q = lane >> 4;
   const Poa4Slot sl = poa4_carve(slot_mem, A.nmax, A.lmax);
   const Poa2Slot& g = sl.g;
-  const Poa4Group& Sg = S.g[q];
+  Poa4Group& Sg = S.g[q];
   const u32 w = len + 1;
-  // the layer's band guide in registers (poa_layer_center without its loads)
-  const u32* wayp = reinterpret_cast<const u32*>(Lp->way);
-  // (two 64-bit words shifted by the index: a select between four captured values becomes a private array, which the
-  // backend parks in LDS)
-  const unsigned long long way_lo = static_cast<unsigned long long>(wayp[0]) | (static_cast<unsigned long long>(wayp[1]) << 32);
-  const unsigned long long way_hi = static_cast<unsigned long long>(wayp[2]) | (static_cast<unsigned long long>(wayp[3]) << 32);
-  auto way_at = [way_lo, way_hi](i32 idx) -> i32 {
-    return static_cast<i32>(((idx < 4 ? way_lo : way_hi) >> (16 * (idx & 3))) & 0xFFFFu);
-  };
-  auto band_start = [&](i32 bpos) -> i32 {  // even, in [0, max(0, w - 31)]
+  // ---- the layer's band guide as eight segments {x0, wa, wb - wa, magic(x1 - x0)} in LDS ----
+  if (act && gl < 8) {
+    const i32 sg = gl;
+    const i32 x0 = (sg * span) / 8, x1 = ((sg + 1) * span) / 8;
+    const i32 wa = sg == 0 ? 0 : static_cast<i32>(Lp->way[sg - 1]);
+    const i32 wb = sg == 7 ? static_cast<i32>(len) : static_cast<i32>(Lp->way[sg]);
+    Sg.u.segtab[4 * sg] = static_cast<u32>(x0);
+    Sg.u.segtab[4 * sg + 1] = static_cast<u32>(wa);
+    Sg.u.segtab[4 * sg + 2] = static_cast<u32>(wb - wa);
+    Sg.u.segtab[4 * sg + 3] = magic_of(static_cast<u32>(x1 > x0 ? x1 - x0 : 1));
+  }
+  lds_order();
+  const u32 span_magic = magic_of(static_cast<u32>(span > 0 ? span : 1));
+  const i32 bmax = static_cast<i32>(w) - K::kBand;
+  auto band_start = [&](i32 bpos) -> i32 {  // even, in [0, max(0, w - 31)]; = poa_layer_center(bpos - lb) - 16 clamped
     i32 x = bpos - lb;
     x = x < 0 ? 0 : (x > span ? span : x);
-    const i32 seg = (x * 8) / (span > 0 ? span : 1);
-    const i32 sg = seg > 7 ? 7 : seg;
-    const i32 x0 = (sg * span) / 8, x1 = ((sg + 1) * span) / 8;
-    const i32 wa = sg == 0 ? 0 : way_at(sg - 1);
-    const i32 wb = sg == 7 ? static_cast<i32>(len) : way_at(sg);
-    i32 b = wa + (x - x0) * (wb - wa) / (x1 > x0 ? x1 - x0 : 1) - K::kBand / 2;
-    const i32 bmax = static_cast<i32>(w) - K::kBand;
+    const u32 seg = div_magic(static_cast<u32>(x) * 8u, span_magic);
+    const u32 sg = seg > 7u ? 7u : seg;
+    const uint4 st = *reinterpret_cast<const uint4*>(&Sg.u.segtab[4 * sg]);
+    const i32 dw = static_cast<i32>(st.z);
+    const u32 num = static_cast<u32>(x - static_cast<i32>(st.x)) * static_cast<u32>(dw < 0 ? -dw : dw);
+    const i32 qn = static_cast<i32>(div_magic(num, st.w));
+    i32 b = static_cast<i32>(st.y) + (dw < 0 ? -qn : qn) - K::kBand / 2;
     b = b > bmax ? bmax : b;
     b = b < 0 ? 0 : b;
     // even; at the right limit rounded UP, so that the band still holds the layer's last column
     return (b == bmax && bmax > 0) ? (b + 1) & ~1 : b & ~1;
   };
-  // ---- the rank range that holds the layer's subgraph ----
-  u32 r_lo = 0, r_hi = act ? nn : 0;
-  if (sv::any(act && !full)) {
-    const bool part = act && !full;
-    u32 first = 0xFFFFFFFFu;
-    i32 last = 0;
-    const u32 max_nn = static_cast<u32>(sv::wave_max(part ? static_cast<int>(nn) : 0));
-    for (u32 r0 = 0; r0 < max_nn; r0 += 16) {
-      const u32 r = r0 + static_cast<u32>(gl);
-      if (part && r < nn) {
-        const u32 v = g.order[r];
-        if (g.mark[v]) {
-          first = r < first ? r : first;
-          last = static_cast<i32>(r) + 1;
+  const u32 max_nn = static_cast<u32>(sv::wave_max(act ? static_cast<int>(nn) : 0));
+  // ---- sweep A: rank | band start of every node; the rank range of the subgraph ----
+  u32 first = 0xFFFFFFFFu;
+  i32 last = 0;
+  for (u32 v0 = 0; v0 < max_nn; v0 += 64) {
+    u32 vv[4], rk[4];
+    i32 bp[4];
+    u32 mk[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      vv[u] = v0 + 16u * static_cast<u32>(u) + static_cast<u32>(gl);
+      const bool ok = act && vv[u] < nn;
+      rk[u] = ok ? g.rank_of[vv[u]] : 0u;
+      bp[u] = ok ? static_cast<i32>(g.bpos[vv[u]]) : 0;
+      mk[u] = (ok && !full) ? g.mark[vv[u]] : 1u;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (act && vv[u] < nn) {
+        sl.rb[vv[u]] = rk[u] | (static_cast<u32>(band_start(bp[u])) << 16);
+        if (mk[u]) {
+          first = rk[u] < first ? rk[u] : first;
+          last = static_cast<i32>(rk[u]) + 1 > last ? static_cast<i32>(rk[u]) + 1 : last;
         }
       }
     }
+  }
+  u32 r_lo = 0, r_hi = act ? nn : 0;
+  if (sv::any(act && !full)) {
     first = group_min_u(first);
     last = group_max_i(last);
-    if (part) {
+    if (act && !full) {
       r_lo = first == 0xFFFFFFFFu ? 0u : first;
       r_hi = first == 0xFFFFFFFFu ? 0u : static_cast<u32>(last);
     }
   }
   const u32 n_rows = r_hi - r_lo;
+  sv::sync();  // rb visible
+  i32 b_first = 0;
+  if (act && n_rows) b_first = static_cast<i32>(sl.rb[g.order[r_lo]] >> 16);
   const u32 ring_off = static_cast<u32>(offsetof(Poa4Lds, g)) + static_cast<u32>(q) * static_cast<u32>(sizeof(Poa4Group));
   const u32 dump_off = ring_off + static_cast<u32>(offsetof(Poa4Group, dump));
   const u32 neg_off = static_cast<u32>(offsetof(Poa4Lds, neg));
   const u32 neg2 = neg_off | (neg_off << 16);
   u32 flag = 0, marked_rows = 0;
   i32 t_end = 0;
-  i32 b_first = 0;
-  i32 b_prev1 = 0, b_prev2 = 0;  // band starts of the lane's rows in the previous two blocks
-  const u32 max_rows = static_cast<u32>(sv::wave_max(act ? static_cast<int>(n_rows) : 0));
-  for (u32 rho0 = 0; rho0 < max_rows + 32; rho0 += 16) {
-    const u32 rho = rho0 + static_cast<u32>(gl);
-    const u32 r = r_lo + rho;
-    const bool ok = act && rho < n_rows;
-    u32 v = 0, c = 0, code = 0, outc = 1;
-    bool marked = false;
-    i32 bpos = 0;
-    uint4 tl = uint4{0, 0, 0, 0};
-    if (ok) {
-      v = g.order[r];
-      marked = full || g.mark[v] != 0;
-      code = g.code[v];
-      outc = full ? g.out_cnt[v] : g.sub_out[v];
-      c = g.in_cnt[v];
-      bpos = g.bpos[v];
-      tl = *reinterpret_cast<const uint4*>(g.in_tail + static_cast<size_t>(v) * kPoaMaxIn);
+  // ---- sweep B: descriptors, two nodes per lane and iteration (their loads in flight together) ----
+  for (u32 v0 = 0; v0 < max_nn; v0 += 32) {
+    u32 vv[2], rbv[2], cc[2], code[2], outc[2], mk[2];
+    uint4 tl[2];
+    bool ok[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      vv[u] = v0 + 16u * static_cast<u32>(u) + static_cast<u32>(gl);
+      ok[u] = act && vv[u] < nn;
+      const u32 v = ok[u] ? vv[u] : 0u;
+      rbv[u] = sl.rb[v];
+      cc[u] = g.in_cnt[v];
+      code[u] = g.code[v];
+      outc[u] = full ? g.out_cnt[v] : g.sub_out[v];
+      mk[u] = full ? 1u : g.mark[v];
+      tl[u] = *reinterpret_cast<const uint4*>(g.in_tail + static_cast<size_t>(v) * kPoaMaxIn);
     }
-    i32 b = ok ? band_start(bpos) : 0;
-    if (rho0 == 0) b_first = sv::bperm(b, gbase);
-    {  // band starts must not decrease along the order (they never do: a node's backbone coordinate is its column)
-      const i32 carry = sv::bperm(b_prev1, gbase | 15);
-      const i32 below = sv::row_shr<1>(b, carry);
-      if (ok && rho > 0 && b < below) flag = 7;
+    u32 trb[2][8], tmk[2][8];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const u32 r = rbv[u] & 0xFFFFu;
+      ok[u] = ok[u] && r >= r_lo && r < r_hi;
+      if (!(ok[u] && mk[u])) cc[u] = 0;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const u32 wd = k < 2 ? tl[u].x : (k < 4 ? tl[u].y : (k < 6 ? tl[u].z : tl[u].w));
+        const u32 t = static_cast<u32>(k) < cc[u] ? (wd >> (16 * (k & 1))) & 0xFFFFu : 0u;
+        trb[u][k] = sl.rb[t];
+        tmk[u][k] = full ? 1u : g.mark[t];
+      }
     }
-    u32 ep[4] = {neg2, neg2, neg2, neg2};
-    u32 np = 0, lbw = 0;
-    if (!marked) c = 0;
-    for (u32 k = 0; k < static_cast<u32>(kPoaMaxIn); ++k) {
-      const bool has = k < c;
-      if (!sv::any(has)) break;
-      u32 t = 0;
-      if (has) {
-        if (k < 8) {
-          const u32 wd = k < 2 ? tl.x : (k < 4 ? tl.y : (k < 6 ? tl.z : tl.w));
-          t = (wd >> (16 * (k & 1))) & 0xFFFFu;
-        } else {
-          t = g.in_tail[static_cast<size_t>(v) * kPoaMaxIn + k];
-        }
-      }
-      u32 pr = 0;
-      bool inside = false;
-      if (has) {
-        inside = full || g.mark[t] != 0;
-        pr = g.rank_of[t];
-      }
-      const u32 lbk = r - pr;  // >= 1 for an in-edge
-      const u32 prho = rho - lbk;
-      const int owner = gbase | static_cast<int>(prho & 15u);
-      const u32 dblk = (rho >> 4) - (prho >> 4);
-      const i32 bp0 = sv::bperm(b, owner), bp1 = sv::bperm(b_prev1, owner), bp2 = sv::bperm(b_prev2, owner);
-      if (has && inside) {
-        const i32 bpred = dblk == 0 ? bp0 : (dblk == 1 ? bp1 : bp2);
-        const i32 d = b - bpred;
-        if (lbk < 1 || lbk > static_cast<u32>(K::kRing - 1) || lbk > rho || dblk > 2 || d < 0 || d > K::kMaxD) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const u32 v = vv[u];
+      const u32 r = rbv[u] & 0xFFFFu;
+      const i32 b = static_cast<i32>(rbv[u] >> 16);
+      const u32 rho = r - r_lo;
+      const bool marked = ok[u] && mk[u] != 0;
+      u32 ep[4] = {neg2, neg2, neg2, neg2};
+      u32 np = 0, lbw = 0;
+      auto edge = [&](u32 rbt, bool inside) {
+        if (!inside) return;
+        const u32 lbk = r - (rbt & 0xFFFFu);
+        const i32 d = b - static_cast<i32>(rbt >> 16);
+        if (lbk < 1 || lbk > static_cast<u32>(K::kRing - 1) || lbk > rho || d < 0 || d > K::kMaxD) {
           flag = 7;
         } else if (np < static_cast<u32>(K::kEdges)) {
-          const u32 e = ring_off + (prho % static_cast<u32>(K::kRing)) * static_cast<u32>(K::kRowB) + 2u * static_cast<u32>(d);
+          const u32 e = ring_off + ((rho - lbk) % static_cast<u32>(K::kRing)) * static_cast<u32>(K::kRowB) + 2u * static_cast<u32>(d);
           const u32 idx = np >> 1;
           const u32 keep = (np & 1) ? 0x0000FFFFu : 0xFFFF0000u;
           const u32 put = (np & 1) ? e << 16 : e;
@@ -369,58 +388,80 @@ __host__ __device__ inline void poa4_prepass(const Poa4Args A, Poa4Lds& S, unsig
           if (np < 6) lbw |= lbk << (5 * np);
         }
         ++np;
+      };
+#pragma unroll
+      for (int k = 0; k < 8; ++k) edge(trb[u][k], static_cast<u32>(k) < cc[u] && tmk[u][k] != 0);
+      for (u32 k = 8; k < cc[u]; ++k) {  // rare
+        const u32 t = g.in_tail[static_cast<size_t>(v) * kPoaMaxIn + k];
+        edge(sl.rb[t], full || g.mark[t] != 0);
+      }
+      if (np > static_cast<u32>(K::kEdges)) flag = 3;
+      if (ok[u]) {
+        // match mask of the row's 32 columns against the layer
+        u32 mm = 0;
+        {
+          const u32 wi = static_cast<u32>(b) >> 4, sh = 2u * (static_cast<u32>(b) & 15u);
+          const u32 x0 = Sg.seq2[wi], x1 = Sg.seq2[wi + 1], x2 = Sg.seq2[wi + 2];
+          const u32 pat = code[u] * 0x55555555u;
+          const u32 elo = funnel_shr(x1, x0, sh) ^ pat, ehi = funnel_shr(x2, x1, sh) ^ pat;
+          auto even_bits = [](u32 y) -> u32 {
+            y = ~(y | (y >> 1)) & 0x55555555u;
+            y = (y | (y >> 1)) & 0x33333333u;
+            y = (y | (y >> 2)) & 0x0F0F0F0Fu;
+            y = (y | (y >> 4)) & 0x00FF00FFu;
+            y = (y | (y >> 8)) & 0x0000FFFFu;
+            return y;
+          };
+          mm = even_bits(elo) | (even_bits(ehi) << 16);
+        }
+        i32 sdiff = b - b_first;
+        if (sdiff < 0) {  // (never: a node's backbone coordinate does not decrease along the order)
+          flag = 7;
+          sdiff = 0;
+        }
+        const u32 Srow = rho + (rho >> 4) + (static_cast<u32>(sdiff) >> 1) + 1u;
+        const u32 own = marked ? ring_off + (rho % static_cast<u32>(K::kRing)) * static_cast<u32>(K::kRowB) + 4u : dump_off;
+        const bool endn = marked && outc[u] == 0;
+        uint4 da, db;
+        da.x = Srow | (own << 16);
+        da.y = v | (static_cast<u32>(b) << 16) | ((np > 15u ? 15u : np) << 26) | (marked ? 1u << 30 : 0u) | (endn ? 1u << 31 : 0u);
+        da.z = mm;
+        da.w = ep[0];
+        db.x = ep[1];
+        db.y = ep[2];
+        db.z = ep[3];
+        db.w = lbw;
+        sl.desc[2 * static_cast<size_t>(rho)] = da;
+        sl.desc[2 * static_cast<size_t>(rho) + 1] = db;
+        t_end = static_cast<i32>(Srow) + 17 > t_end ? static_cast<i32>(Srow) + 17 : t_end;
+        if (marked) ++marked_rows;
       }
     }
-    if (np > static_cast<u32>(K::kEdges)) flag = 3;
-    // match mask of the row's 32 columns against the layer
-    u32 mm = 0;
-    {
-      const u32 wi = static_cast<u32>(b) >> 4, sh = 2u * (static_cast<u32>(b) & 15u);
-      const u32 x0 = Sg.seq2[wi], x1 = Sg.seq2[wi + 1], x2 = Sg.seq2[wi + 2];
-      const u32 pat = code * 0x55555555u;
-      const u32 elo = funnel_shr(x1, x0, sh) ^ pat, ehi = funnel_shr(x2, x1, sh) ^ pat;
-      auto even_bits = [](u32 y) -> u32 {
-        y = ~(y | (y >> 1)) & 0x55555555u;
-        y = (y | (y >> 1)) & 0x33333333u;
-        y = (y | (y >> 2)) & 0x0F0F0F0Fu;
-        y = (y | (y >> 4)) & 0x00FF00FFu;
-        y = (y | (y >> 8)) & 0x0000FFFFu;
-        return y;
-      };
-      mm = even_bits(elo) | (even_bits(ehi) << 16);
+  }
+  // rows beyond the last one: what the lanes' descriptor prefetch runs into
+  if (act) {
+#pragma unroll
+    for (u32 u = 0; u < 2; ++u) {
+      const size_t rho = static_cast<size_t>(n_rows) + 16 * u + static_cast<size_t>(gl);
+      sl.desc[2 * rho] = uint4{kInactiveS | (dump_off << 16), 0u, 0u, neg2};
+      sl.desc[2 * rho + 1] = uint4{neg2, neg2, neg2, 0u};
     }
-    i32 sdiff = b - b_first;
-    sdiff = sdiff < 0 ? 0 : sdiff;
-    const u32 Srow = ok ? rho + (rho >> 4) + (static_cast<u32>(sdiff) >> 1) + 1u : kInactiveS;
-    const u32 own = (ok && marked) ? ring_off + (rho % static_cast<u32>(K::kRing)) * static_cast<u32>(K::kRowB) + 4u : dump_off;
-    const bool endn = marked && outc == 0;
-    uint4 da, db;
-    da.x = Srow | (own << 16);
-    da.y = v | (static_cast<u32>(b) << 16) | ((np > 15u ? 15u : np) << 26) | (marked ? 1u << 30 : 0u) | (endn ? 1u << 31 : 0u);
-    da.z = mm;
-    da.w = ep[0];
-    db.x = ep[1];
-    db.y = ep[2];
-    db.z = ep[3];
-    db.w = lbw;
-    if (act) {
-      sl.desc[2 * static_cast<size_t>(rho)] = da;
-      sl.desc[2 * static_cast<size_t>(rho) + 1] = db;
-      if (gl == 0) sl.blk_s[rho0 >> 4] = static_cast<u16>(Srow);
-    }
-    if (ok) t_end = static_cast<i32>(Srow) + 17;
-    marked_rows += static_cast<u32>(__builtin_popcount(static_cast<u32>(sv::ballot(marked) >> gbase) & 0xFFFFu));
-    b_prev2 = b_prev1;
-    b_prev1 = b;
   }
   t_end = group_max_i(t_end);
   flag = static_cast<u32>(group_max_i(static_cast<i32>(flag)));
+  {
+    u32 mr = marked_rows;
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) mr += static_cast<u32>(sv::bperm(static_cast<int>(mr), lane ^ off));
+    marked_rows = mr;
+  }
   if (static_cast<u32>(t_end) + 8u > poa4_steps(A.nmax, A.lmax)) flag = 7;
   r_lo_out = r_lo;
   n_rows_out = n_rows;
   t_end_out = static_cast<u32>(t_end);
   flag_out = flag;
   marked_out = marked_rows;
+  (void)gbase;
 }
 
 // ---- banded NW of one layer per window, rows on lanes ---------------------------------------------------------------
@@ -473,7 +514,7 @@ __host__ __device__ inline void poa4_dp(const Poa4Args A, Poa4Lds& S, unsigned c
     ne2 = act ? b2.y : neg2;
     ne3 = act ? b2.z : neg2;
   }
-  bool nx_full = true, ld_pending = false;
+  bool nx_full = true, ld_pending = false, sched_bad = false;
   i32 Am1 = kNegKey, U = kNegU;
   i32 best_score = -0x7FFFFFFF;
   u32 best_row = 0;
@@ -535,6 +576,7 @@ __host__ __device__ inline void poa4_dp(const Poa4Args A, Poa4Lds& S, unsigned c
         nx_full = false;
         Am1 = kNegKey;
         k = static_cast<i32>(t) - static_cast<i32>(c0 & 0xFFFFu);
+        if (k >= 0) sched_bad = true;  // the next row's first step is already over: band starts decreased along the order
       }
       i32 kk = k + 1;
       kk = kk < 0 ? 0 : (kk > 16 ? 16 : kk);
@@ -609,6 +651,7 @@ __host__ __device__ inline void poa4_dp(const Poa4Args A, Poa4Lds& S, unsigned c
     }
     if (act) sl.bps[static_cast<size_t>(t0 / K::kU) * 16 + static_cast<size_t>(gl)] = uint4{acc0, acc1, acc2, acc3};
   }
+  if (A.phase_cycles && lane == 0) sv::atomic_add(&A.phase_cycles[14], static_cast<unsigned long long>((T + K::kU - 1) / K::kU * K::kU));
   // rows that finished in the very last step of the loop
   {
     const i32 k = static_cast<i32>(T) - static_cast<i32>(c0 & 0xFFFFu);
@@ -629,18 +672,29 @@ __host__ __device__ inline void poa4_dp(const Poa4Args A, Poa4Lds& S, unsigned c
     const u32 cand = (best_score == gs && best_row != 0) ? best_row : 0xFFFFFFFFu;
     const u32 br = group_min_u(cand);
     best_rho1 = (act && br != 0xFFFFFFFFu) ? br : 0u;
+    if (sv::any(sched_bad)) {
+      const u32 any_bad = static_cast<u32>(sv::ballot(sched_bad) >> (lane & ~15)) & 0xFFFFu;
+      if (any_bad) best_rho1 = 0;  // (reported as a band miss: the 64-column kernel takes the window)
+    }
   }
 }
 
-// ---- traceback of the wave's windows in lockstep -------------------------------------------------------------------
+// ---- traceback of the wave's windows, block-synchronous ------------------------------------------------------------
+// A round = every window walks through the 16 rows of its current block; lane l of a window holds row 16 * block + l in
+// registers: three descriptor words and the 48 bytes of the backpointer stream that hold the row's 32 codes (its 16
+// steps lie in at most three 8-step blocks of the stream).  A step is lane-local — every lane looks up the code of ITS
+// row under column j and works out where that sends the walk — followed by one ds_bpermute from the lane that owns the
+// current row; no LDS, no staging.  The blocks below are fetched one (codes) and two (descriptors) rounds ahead, and all
+// four windows switch blocks at the same point of the loop, so the wait at a switch is for loads issued a round ago, not
+// for another window's prefetch of a moment ago (which is what a per-window switch waits for: the counter is the wave's).
 template <class K>
 __host__ __device__ inline void poa4_traceback(const Poa4Args A, Poa4Lds& S, unsigned char* slot_mem, bool act, u32 r_lo,
                                                u32 n_rows, bool full, u32 len, u32 best_rho1, u32& bad, u32& band_hit) {
   P4_ASSUME_GLOBAL(slot_mem);
-  P4_ASSUME_LDS(&S);
+  (void)S;
+  (void)n_rows;
   const int lane = sv::lane();
-  const int gl = lane & 15;
-  Poa4Group& Sg = S.g[lane >> 4];
+  const int gl = lane & 15, gbase = lane & ~15;
   const Poa4Slot sl = poa4_carve(slot_mem, A.nmax, A.lmax);
   const Poa2Slot& g = sl.g;
   const u32 w = len + 1;
@@ -649,123 +703,134 @@ __host__ __device__ inline void poa4_traceback(const Poa4Args A, Poa4Lds& S, uns
   u32 i = act ? best_rho1 : 0;  // 1 + rho of the current row; 0 = the virtual start row
   i32 j = static_cast<i32>(w) - 1;
   bool done = !act || i == 0;
-  u32 cur_blk = 0xFFFFFFFFu, cur_tb0 = 0;
-  u32 steps = 0;
+  u32 steps = 0, n_switch = 0;
   const u32 max_steps = A.nmax + A.lmax + 2;
-  // A block (16 rows' descriptors + the 8-step blocks of the backpointer stream that cover them) is fetched into
-  // registers one block AHEAD of the walk and copied into the group's LDS when the walk gets there.
-  uint4 pb0{}, pb1{}, pb2{}, pb3{}, pb4{}, pb5{}, pb6{};
-  u32 pd0 = 0, pd1 = 0, pd7 = 0, pf_tb0 = 0;
-  u32 pf_blk = 0xFFFFFFFFu;
-  // tb0: first 8-step block of the stream to stage.  The walk's first block takes it from blk_s; for the block below a
-  // staged one it is guessed from that block's first step (rows start 17 steps + half the band shift apart): a row
-  // whose steps fall outside the staged blocks is read from the stream in HBM, so a bad guess costs time only.
-  auto fetch = [&](u32 b, u32 tb0) {
-    const u32 rho = b * 16 + static_cast<u32>(gl);
-    const uint4 da = sl.desc[2 * static_cast<size_t>(rho)];
-    pd0 = da.x;
-    pd1 = da.y;
-    pd7 = sl.desc[2 * static_cast<size_t>(rho) + 1].w;
-    const uint4* src = sl.bps + static_cast<size_t>(tb0) * 16 + static_cast<size_t>(gl);
-    pb0 = src[0];
-    pb1 = src[16];
-    pb2 = src[32];
-    pb3 = src[48];
-    pb4 = src[64];
-    pb5 = src[80];
-    pb6 = src[96];
-    pf_tb0 = tb0;
-    pf_blk = b;
+  // block data: current (c), the block below (p: descriptor + codes), two below (q: descriptor)
+  u32 cd0 = 0, cd1 = 0, cd7 = 0, pd0 = 0, pd1 = 0, pd7 = 0, qd0 = 0, qd1 = 0, qd7 = 0;
+  uint4 cc0{}, cc1{}, cc2{}, pc0{}, pc1{}, pc2{};
+  u32 c_blk = 0xFFFFFFFFu, p_blk = 0xFFFFFFFFu, q_blk = 0xFFFFFFFFu;  // which blocks they hold (p: codes included)
+  auto load_desc = [&](u32 blk, u32& d0, u32& d1, u32& d7) {
+    const size_t rho = static_cast<size_t>(blk) * 16 + static_cast<size_t>(gl);
+    const uint4 da = sl.desc[2 * rho];
+    d0 = da.x;
+    d1 = da.y;
+    d7 = sl.desc[2 * rho + 1].w;
+  };
+  auto load_codes = [&](u32 d0, uint4& c0, uint4& c1, uint4& c2) {
+    const u32 s = d0 & 0xFFFFu;
+    const size_t tb = s == kInactiveS ? 0u : s / K::kU;
+    const uint4* src = sl.bps + tb * 16 + static_cast<size_t>(gl);
+    c0 = src[0];
+    c1 = src[16];
+    c2 = src[32];
   };
   while (sv::any(!done)) {
-    const u32 blk = done ? cur_blk : (i - 1) >> 4;
-    const bool need = !done && blk != cur_blk;
-    if (sv::any(need)) {
-      lds_order();
-      if (need) {
-        if (pf_blk != blk) fetch(blk, static_cast<u32>(sl.blk_s[blk]) / K::kU);
-        Sg.u.tb.d[4 * gl] = pd0;
-        Sg.u.tb.d[4 * gl + 1] = pd1;
-        Sg.u.tb.d[4 * gl + 2] = pd7;
-        uint4* bdst = Sg.u.tb.bp + gl;
-        bdst[0] = pb0;
-        bdst[16] = pb1;
-        bdst[32] = pb2;
-        bdst[48] = pb3;
-        bdst[64] = pb4;
-        bdst[80] = pb5;
-        bdst[96] = pb6;
-        cur_blk = blk;
-        cur_tb0 = pf_tb0;
+    // ---- block switch, all windows at once ----
+    const u32 blk = done ? c_blk : (i - 1) >> 4;
+    if (!done && blk != c_blk) {
+      ++n_switch;
+      if (blk == p_blk) {  // the usual case: one block down
+        cd0 = pd0;
+        cd1 = pd1;
+        cd7 = pd7;
+        cc0 = pc0;
+        cc1 = pc1;
+        cc2 = pc2;
+      } else {
+        load_desc(blk, cd0, cd1, cd7);
+        load_codes(cd0, cc0, cc1, cc2);
       }
-      lds_order();
-      if (need && blk > 0) {
-        const u32 s_first = Sg.u.tb.d[0] & 0xFFFFu;
-        fetch(blk - 1, (s_first > 25u ? s_first - 25u : 0u) / K::kU);
+      c_blk = blk;
+      if (blk >= 1) {
+        if (q_blk == blk - 1) {
+          pd0 = qd0;
+          pd1 = qd1;
+          pd7 = qd7;
+        } else {
+          load_desc(blk - 1, pd0, pd1, pd7);
+        }
+        load_codes(pd0, pc0, pc1, pc2);
+        p_blk = blk - 1;
+      } else {
+        p_blk = 0xFFFFFFFFu;
+      }
+      if (blk >= 2) {
+        load_desc(blk - 2, qd0, qd1, qd7);
+        q_blk = blk - 2;
+      } else {
+        q_blk = 0xFFFFFFFFu;
       }
     }
-    if (!done) {
-      if (++steps > max_steps) {
-        bad = 6;
-        done = true;
+    // ---- walk inside the block ----
+    const i32 bt = static_cast<i32>((cd1 >> 16) & 0x3FFu);
+    const u32 node = cd1 & 0xFFFFu;
+    const u32 np = (cd1 >> 26) & 15u;
+    const u32 srow = cd0 & 0xFFFFu;
+    const u32 my_i = c_blk * 16 + static_cast<u32>(gl) + 1;
+    bool in_block = !done;
+    while (sv::any(in_block)) {
+      // what the walk does on THIS lane's row under column j: packed as i' | j' << 14 | flags << 24
+      //   flags: 1 diagonal (position j' gets this row's node), 2 band edge touched, 4 left the band, 8 walked off the layer
+      const i32 idx = j - bt;
+      u32 res;
+      if (idx < 0 || idx >= K::kBand) {
+        res = 4u << 24;
       } else {
-        const u32 rho = i - 1;
-        const u32 l = rho & 15u;
-        const u32 d0 = Sg.u.tb.d[4 * l], d1 = Sg.u.tb.d[4 * l + 1];
-        const i32 bt = static_cast<i32>((d1 >> 16) & 0x3FFu);
-        const u32 node = d1 & 0xFFFFu;
-        const u32 np = (d1 >> 26) & 15u;
-        const i32 idx = j - bt;
-        if (idx < 0 || idx >= K::kBand) {  // the path left the stored band: the alignment does not fit this band width
-          band_hit = 1;
-          done = true;
+        u32 fl = ((idx < 2 && bt > 0) || (idx > K::kBand - 3 && bt + K::kBand < static_cast<i32>(w))) ? 2u : 0u;
+        const u32 bo = (srow % K::kU + (static_cast<u32>(idx) >> 1)) * 2 + (static_cast<u32>(idx) & 1u);  // byte among the row's 48
+        const u32 dwi = bo >> 2;
+        const uint4 cq = dwi < 4 ? cc0 : (dwi < 8 ? cc1 : cc2);
+        const u32 wsel = (dwi & 2) ? ((dwi & 1) ? cq.w : cq.z) : ((dwi & 1) ? cq.y : cq.x);
+        const u32 code = (wsel >> (8 * (bo & 3u))) & 0xFFu;
+        u32 ni = my_i;
+        i32 nj = j;
+        if (code == 64u) {
+          if (j == 0) fl |= 8u;
+          else nj = j - 1;  // insertion: pos_node[j - 1] stays kNone
         } else {
-          if ((idx < 2 && bt > 0) || (idx > K::kBand - 3 && bt + K::kBand < static_cast<i32>(w))) band_hit = 1;
-          const u32 ts = (d0 & 0xFFFFu) + (static_cast<u32>(idx) >> 1);
-          const u32 tblk = ts / K::kU - cur_tb0;
-          const u32 boff = l * 16 + (ts % K::kU) * 2 + (static_cast<u32>(idx) & 1u);
-          u32 code;
-          if (tblk < static_cast<u32>(K::kTbBlocks))
-            code = reinterpret_cast<const u8*>(Sg.u.tb.bp)[tblk * 256 + boff];
-          else  // (a block of rows whose steps spread beyond the staged range: straight from the stream)
-            code = reinterpret_cast<const u8*>(sl.bps)[static_cast<size_t>(ts / K::kU) * 256 + boff];
-          if (code == 64u) {
-            if (j == 0) {
-              bad = 6;
-              done = true;
-            } else {
-              --j;  // insertion: pos_node[j] stays kNone
-            }
-          } else {
-            const u32 k = 15u - (code & 15u);
-            u32 pr1;  // 1 + rho of the predecessor row, 0 = the virtual row
-            if (np == 0) {
-              pr1 = 0;
-            } else if (k < 6) {
-              const u32 lbk = (Sg.u.tb.d[4 * l + 2] >> (5 * k)) & 31u;
-              pr1 = i - lbk;
-            } else {
-              pr1 = poa4_nth_pred_rank(g, node, k, full) - r_lo + 1;
-            }
-            if (code & 32u) {  // diagonal
-              if (j == 0) {
-                bad = 6;
-                done = true;
-              } else {
-                --j;
-                if (gl == 0) g.pos_node[j] = static_cast<u16>(node);
-              }
-            }
-            if (!done) {
-              i = pr1;
-              if (i == 0) done = true;  // on the virtual row only insertions remain: pos_node already says kNone
+          const u32 k = 15u - (code & 15u);
+          if (np == 0) ni = 0;
+          else if (k < 6) ni = my_i - ((cd7 >> (5 * k)) & 31u);
+          else ni = poa4_nth_pred_rank(g, node, k, full) - r_lo + 1;
+          if (code & 32u) {  // diagonal
+            if (j == 0) fl |= 8u;
+            else {
+              nj = j - 1;
+              fl |= 1u;
             }
           }
         }
+        res = ni | (static_cast<u32>(nj) << 14) | (fl << 24);
+      }
+      const bool mine = in_block && my_i == i;
+      const u32 got = static_cast<u32>(sv::bperm(static_cast<int>(res), gbase | static_cast<int>((i - 1) & 15u)));
+      if (in_block) {
+        const u32 fl = got >> 24;
+        if (++steps > max_steps) {
+          bad = 6;
+          done = true;
+        } else if (fl & 4u) {  // the path left the stored band: the alignment does not fit this band width
+          band_hit = 1;
+          done = true;
+        } else if (fl & 8u) {
+          bad = 6;
+          done = true;
+        } else {
+          if (fl & 2u) band_hit = 1;
+          const i32 nj = static_cast<i32>((got >> 14) & 0x3FFu);
+          if (mine && (fl & 1u)) g.pos_node[nj] = static_cast<u16>(node);
+          j = nj;
+          i = got & 0x3FFFu;
+          if (i == 0) done = true;  // on the virtual row only insertions remain: pos_node already says kNone
+        }
+        in_block = !done && ((i - 1) >> 4) == c_blk;
       }
     }
   }
-  (void)n_rows;
+  if (A.phase_cycles && gl == 0 && act) {
+    sv::atomic_add(&A.phase_cycles[11], static_cast<unsigned long long>(steps));
+    sv::atomic_add(&A.phase_cycles[12], static_cast<unsigned long long>(n_switch));
+  }
 }
 
 // ---- wave-wide per-window steps (as in poa2.hip) -------------------------------------------------------------------
@@ -1073,7 +1138,7 @@ __host__ __device__ inline void poa4_wave(const Poa4Args& A, Poa4Lds& S, u32 slo
   constexpr int kG = K::G, GS = K::GS;
   const int lane = sv::lane();
   const int q = lane / GS;
-  unsigned long long t_sub = 0, t_dp = 0, t_tb = 0, t_add = 0, t_ord = 0, t_cons = 0, t0 = 0;
+  unsigned long long t_sub = 0, t_dp = 0, t_tb = 0, t_add = 0, t_ord = 0, t_cons = 0, t0 = 0, t_pre = 0, t_set = 0, t1 = 0;
   unsigned char* const my_slot = A.scratch + static_cast<size_t>(slot0 + q) * A.slot_bytes;  // per lane: its group's window
   for (;;) {
     u32 first = 0;
@@ -1118,6 +1183,7 @@ __host__ __device__ inline void poa4_wave(const Poa4Args& A, Poa4Lds& S, u32 slo
       u32 len = 0;
       i32 lb = 0, span = 0;
       const PoaLayer* Lp = A.layers;
+      t1 = sv::clock();
       for (int q2 = 0; q2 < kG; ++q2) {
         if (sv::rl(static_cast<int>(phase), q2 * GS) != static_cast<int>(kRunning)) continue;
         u32 wi2;
@@ -1173,6 +1239,7 @@ __host__ __device__ inline void poa4_wave(const Poa4Args& A, Poa4Lds& S, u32 slo
       }
       if (!sv::any(act)) break;
       sv::sync();
+      t_set += sv::clock() - t1;
       t0 = sv::clock();
       u32 r_lo = 0, n_rows = 0, t_end = 0, flag = 0, marked_rows = 0;
       poa4_prepass<K>(A, S, my_slot, act, nn, full, Lp, len, lb, span, r_lo, n_rows, t_end, flag, marked_rows);
@@ -1192,6 +1259,7 @@ __host__ __device__ inline void poa4_wave(const Poa4Args& A, Poa4Lds& S, u32 slo
       }
       sv::sync();  // descriptors visible
       t_sub += sv::clock() - t0;
+      t_pre += sv::clock() - t0;
       t0 = sv::clock();
       u32 best_rho1 = 0;
       poa4_dp<K>(A, S, my_slot, act, t_end, len, best_rho1);
@@ -1276,6 +1344,8 @@ __host__ __device__ inline void poa4_wave(const Poa4Args& A, Poa4Lds& S, u32 slo
       sv::atomic_add(&A.phase_cycles[3], t_add);
       sv::atomic_add(&A.phase_cycles[4], t_ord);
       sv::atomic_add(&A.phase_cycles[5], t_cons);
+      sv::atomic_add(&A.phase_cycles[10], t_pre);
+      sv::atomic_add(&A.phase_cycles[15], t_set);
     }
   }
 }
@@ -1350,7 +1420,7 @@ void poa_v4_emulate(const std::vector<PoaWindow>& wins, const std::vector<PoaLay
   b.nmax = std::min<u32>(8192, std::max<u32>(512, max_bb * 6));
   const size_t slot_bytes = poa4_slot_bytes(b.nmax, b.lmax);
   std::vector<unsigned char> scratch(slot_bytes * P4::G + 256, 0);
-  unsigned long long phase[10] = {};
+  unsigned long long phase[16] = {};
   u32 next = 0;
   b.wins = wins.data();
   b.n_windows = static_cast<u32>(wins.size());
