@@ -194,6 +194,15 @@ __host__ __device__ __forceinline__ void lds_order() {
 #define P4_ASSUME_LDS(p)
 #endif
 
+// The lane's slot pointer, made opaque to the optimiser: field addresses derived from it are computed where they are used
+// instead of being hoisted out of a loop and kept (or spilled: a reload is a memory load the loop then waits for) there.
+__host__ __device__ __forceinline__ unsigned char* opaque(unsigned char* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("" : "+v"(p));
+#endif
+  return p;
+}
+
 __host__ __device__ inline u32 group_min_u(u32 v) {
 #pragma unroll
   for (int off = 8; off > 0; off >>= 1) {
@@ -684,19 +693,19 @@ __host__ __device__ inline void poa4_dp(const Poa4Args A, Poa4Lds& S, unsigned c
 // registers: three descriptor words and the 48 bytes of the backpointer stream that hold the row's 32 codes (its 16
 // steps lie in at most three 8-step blocks of the stream).  A step is lane-local — every lane looks up the code of ITS
 // row under column j and works out where that sends the walk — followed by one ds_bpermute from the lane that owns the
-// current row; no LDS, no staging.  The blocks below are fetched one (codes) and two (descriptors) rounds ahead, and all
-// four windows switch blocks at the same point of the loop, so the wait at a switch is for loads issued a round ago, not
-// for another window's prefetch of a moment ago (which is what a per-window switch waits for: the counter is the wave's).
+// current row; no LDS, no staging.  The blocks below the current one sit in a register queue, codes kDepth blocks and
+// descriptors kDepth + 1 blocks ahead (a memory round trip under load takes several rounds of ~10 steps), and all four
+// windows shift their queues at the same point of the loop, so the wait at a shift is for loads issued kDepth rounds
+// ago, not for another window's prefetch of a moment ago (the memory counter is the wave's, not the window's).
 template <class K>
 __host__ __device__ inline void poa4_traceback(const Poa4Args A, Poa4Lds& S, unsigned char* slot_mem, bool act, u32 r_lo,
                                                u32 n_rows, bool full, u32 len, u32 best_rho1, u32& bad, u32& band_hit) {
   P4_ASSUME_GLOBAL(slot_mem);
   (void)S;
   (void)n_rows;
+  constexpr int kDepth = 3;
   const int lane = sv::lane();
   const int gl = lane & 15, gbase = lane & ~15;
-  const Poa4Slot sl = poa4_carve(slot_mem, A.nmax, A.lmax);
-  const Poa2Slot& g = sl.g;
   const u32 w = len + 1;
   bad = 0;
   band_hit = 0;
@@ -705,63 +714,65 @@ __host__ __device__ inline void poa4_traceback(const Poa4Args A, Poa4Lds& S, uns
   bool done = !act || i == 0;
   u32 steps = 0, n_switch = 0;
   const u32 max_steps = A.nmax + A.lmax + 2;
-  // block data: current (c), the block below (p: descriptor + codes), two below (q: descriptor)
-  u32 cd0 = 0, cd1 = 0, cd7 = 0, pd0 = 0, pd1 = 0, pd7 = 0, qd0 = 0, qd1 = 0, qd7 = 0;
-  uint4 cc0{}, cc1{}, cc2{}, pc0{}, pc1{}, pc2{};
-  u32 c_blk = 0xFFFFFFFFu, p_blk = 0xFFFFFFFFu, q_blk = 0xFFFFFFFFu;  // which blocks they hold (p: codes included)
-  auto load_desc = [&](u32 blk, u32& d0, u32& d1, u32& d7) {
+  // queue entry e = block (c_blk - e): descriptors for e = 0 .. kDepth + 1, codes for e = 0 .. kDepth
+  u32 qd0[kDepth + 2] = {}, qd1[kDepth + 2] = {}, qd7[kDepth + 2] = {};
+  uint4 qa[kDepth + 1] = {}, qb[kDepth + 1] = {}, qc[kDepth + 1] = {};
+  u32 c_blk = 0xFFFFFFFFu;
+  auto load_desc = [&](i32 blk, u32& d0, u32& d1, u32& d7) {
+    if (blk < 0) {
+      d0 = kInactiveS;
+      d1 = 0;
+      d7 = 0;
+      return;
+    }
     const size_t rho = static_cast<size_t>(blk) * 16 + static_cast<size_t>(gl);
-    const uint4 da = sl.desc[2 * rho];
+    const uint4* dsc = poa4_carve(opaque(slot_mem), A.nmax, A.lmax).desc;
+    const uint4 da = dsc[2 * rho];
     d0 = da.x;
     d1 = da.y;
-    d7 = sl.desc[2 * rho + 1].w;
+    d7 = dsc[2 * rho + 1].w;
   };
   auto load_codes = [&](u32 d0, uint4& c0, uint4& c1, uint4& c2) {
     const u32 s = d0 & 0xFFFFu;
     const size_t tb = s == kInactiveS ? 0u : s / K::kU;
-    const uint4* src = sl.bps + tb * 16 + static_cast<size_t>(gl);
+    const uint4* src = poa4_carve(opaque(slot_mem), A.nmax, A.lmax).bps + tb * 16 + static_cast<size_t>(gl);
     c0 = src[0];
     c1 = src[16];
     c2 = src[32];
   };
   while (sv::any(!done)) {
-    // ---- block switch, all windows at once ----
+    // ---- queue shift, all windows at once ----
     const u32 blk = done ? c_blk : (i - 1) >> 4;
     if (!done && blk != c_blk) {
       ++n_switch;
-      if (blk == p_blk) {  // the usual case: one block down
-        cd0 = pd0;
-        cd1 = pd1;
-        cd7 = pd7;
-        cc0 = pc0;
-        cc1 = pc1;
-        cc2 = pc2;
-      } else {
-        load_desc(blk, cd0, cd1, cd7);
-        load_codes(cd0, cc0, cc1, cc2);
+      if (c_blk == 0xFFFFFFFFu || blk + 2 < c_blk) {  // first block of the walk (or a jump the queue does not cover)
+#pragma unroll
+        for (int e = 0; e < kDepth + 2; ++e) load_desc(static_cast<i32>(blk) - e, qd0[e], qd1[e], qd7[e]);
+#pragma unroll
+        for (int e = 0; e < kDepth + 1; ++e) load_codes(qd0[e], qa[e], qb[e], qc[e]);
+        c_blk = blk;
       }
-      c_blk = blk;
-      if (blk >= 1) {
-        if (q_blk == blk - 1) {
-          pd0 = qd0;
-          pd1 = qd1;
-          pd7 = qd7;
-        } else {
-          load_desc(blk - 1, pd0, pd1, pd7);
+      while (c_blk != blk) {  // one block down (two when an in-edge spans more than 16 rows)
+#pragma unroll
+        for (int e = 0; e < kDepth + 1; ++e) {
+          qd0[e] = qd0[e + 1];
+          qd1[e] = qd1[e + 1];
+          qd7[e] = qd7[e + 1];
         }
-        load_codes(pd0, pc0, pc1, pc2);
-        p_blk = blk - 1;
-      } else {
-        p_blk = 0xFFFFFFFFu;
-      }
-      if (blk >= 2) {
-        load_desc(blk - 2, qd0, qd1, qd7);
-        q_blk = blk - 2;
-      } else {
-        q_blk = 0xFFFFFFFFu;
+#pragma unroll
+        for (int e = 0; e < kDepth; ++e) {
+          qa[e] = qa[e + 1];
+          qb[e] = qb[e + 1];
+          qc[e] = qc[e + 1];
+        }
+        --c_blk;
+        load_codes(qd0[kDepth], qa[kDepth], qb[kDepth], qc[kDepth]);
+        load_desc(static_cast<i32>(c_blk) - (kDepth + 1), qd0[kDepth + 1], qd1[kDepth + 1], qd7[kDepth + 1]);
       }
     }
     // ---- walk inside the block ----
+    const u32 cd0 = qd0[0], cd1 = qd1[0], cd7 = qd7[0];
+    const uint4 cc0 = qa[0], cc1 = qb[0], cc2 = qc[0];
     const i32 bt = static_cast<i32>((cd1 >> 16) & 0x3FFu);
     const u32 node = cd1 & 0xFFFFu;
     const u32 np = (cd1 >> 26) & 15u;
@@ -791,7 +802,7 @@ __host__ __device__ inline void poa4_traceback(const Poa4Args A, Poa4Lds& S, uns
           const u32 k = 15u - (code & 15u);
           if (np == 0) ni = 0;
           else if (k < 6) ni = my_i - ((cd7 >> (5 * k)) & 31u);
-          else ni = poa4_nth_pred_rank(g, node, k, full) - r_lo + 1;
+          else ni = poa4_nth_pred_rank(poa4_carve(opaque(slot_mem), A.nmax, A.lmax).g, node, k, full) - r_lo + 1;
           if (code & 32u) {  // diagonal
             if (j == 0) fl |= 8u;
             else {
@@ -818,7 +829,7 @@ __host__ __device__ inline void poa4_traceback(const Poa4Args A, Poa4Lds& S, uns
         } else {
           if (fl & 2u) band_hit = 1;
           const i32 nj = static_cast<i32>((got >> 14) & 0x3FFu);
-          if (mine && (fl & 1u)) g.pos_node[nj] = static_cast<u16>(node);
+          if (mine && (fl & 1u)) poa4_carve(opaque(slot_mem), A.nmax, A.lmax).g.pos_node[nj] = static_cast<u16>(node);
           j = nj;
           i = got & 0x3FFFu;
           if (i == 0) done = true;  // on the virtual row only insertions remain: pos_node already says kNone
