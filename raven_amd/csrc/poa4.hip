@@ -255,8 +255,8 @@ __host__ __device__ __forceinline__ u32 div_magic(u32 n, u32 m) { return m ? mul
 
 template <class K>
 __host__ __device__ inline void poa4_prepass(const Poa4Args A, Poa4Lds& S, unsigned char* slot_mem, bool act, u32 nn, bool full,
-                                             const PoaLayer* Lp, u32 len, i32 lb, i32 span, u32& r_lo_out, u32& n_rows_out,
-                                             u32& t_end_out, u32& flag_out, u32& marked_out) {
+                                             bool flip, const PoaLayer* Lp, u32 len, i32 lb, i32 span, u32& r_lo_out,
+                                             u32& n_rows_out, u32& t_end_out, u32& flag_out, u32& marked_out) {
   P4_ASSUME_GLOBAL(slot_mem);
   P4_ASSUME_GLOBAL(Lp);
   P4_ASSUME_LDS(&S);
@@ -334,7 +334,7 @@ __host__ __device__ inline void poa4_prepass(const Poa4Args A, Poa4Lds& S, unsig
   const u32 n_rows = r_hi - r_lo;
   sv::sync();  // rb visible
   i32 b_first = 0;
-  if (act && n_rows) b_first = static_cast<i32>(sl.rb[g.order[r_lo]] >> 16);
+  if (act && n_rows) b_first = static_cast<i32>(sl.rb[(flip ? g.order2 : g.order)[r_lo]] >> 16);
   const u32 ring_off = static_cast<u32>(offsetof(Poa4Lds, g)) + static_cast<u32>(q) * static_cast<u32>(sizeof(Poa4Group));
   const u32 dump_off = ring_off + static_cast<u32>(offsetof(Poa4Group, dump));
   const u32 neg_off = static_cast<u32>(offsetof(Poa4Lds, neg));
@@ -894,6 +894,12 @@ __host__ __device__ inline u32 poa4_init_window(const Poa4Args& A, const PoaWind
     }
     g.out_cnt[i] = i + 1 < blen ? 1 : 0;
   }
+  // nodes to come: poa4_update_graph counts on zero in-degree / out-degree / visits of an id it hands out
+  for (u32 i = blen + lane; i < A.nmax; i += 64) {
+    g.in_cnt[i] = 0;
+    g.out_cnt[i] = 0;
+    g.visits[i] = 0;
+  }
   sv::sync();
   return 1;
 }
@@ -902,160 +908,311 @@ __host__ __device__ __forceinline__ u32 poa4_letter(const Poa4Group& Sg, u32 p) 
   return (Sg.seq2[(p + 1) >> 4] >> (2 * ((p + 1) & 15u))) & 3u;
 }
 
-// spoa AddAlignment, one sequence position per lane, + the incremental order rebuild.  Returns 0 or the failure code.
-__host__ __device__ inline u32 poa4_add_alignment(const Poa4Args& A, Poa2Slot& g, const Poa4Group& Sg, const PoaLayer& L,
-                                                  u32& n_nodes, unsigned long long& t_add, unsigned long long& t_ord) {
-  const int lane = sv::lane();
-  const u32 len = L.len;
-  const u32 nmax = A.nmax, lmax = A.lmax;
-  const u32 lb = L.begin;
-  unsigned long long t0 = sv::clock();
-  const u32 n_old = n_nodes;
-  u32 first_p = 0xFFFFFFFFu;
-  for (u32 p0 = 0; p0 < len && first_p == 0xFFFFFFFFu; p0 += 64) {
-    const u32 p = p0 + lane;
-    const unsigned long long bal = sv::ballot(p < len && g.pos_node[p] != kNone4);
-    if (bal) first_p = p0 + static_cast<u32>(__builtin_ctzll(bal));
+// ---- graph update of the wave's windows side by side: spoa AddAlignment + the incremental order rebuild ---------------
+// Sixteen lanes per window, four sequence positions per lane and iteration, every level of the gather chain
+// (position -> aligned node -> its aligned group -> the node the position lands on) issued for all four positions before
+// any is consumed.  A path visits distinct nodes of distinct columns, so target lookup, node creation, group updates and
+// the edge (p - 1 -> p) are conflict-free between positions; new ids and order slots come from ballots / prefix counts
+// in path order, identical to the serial order of creation.  in_cnt / out_cnt / visits of every node id are zero from
+// the window's set-up on, so creating a node writes only what is not zero, and an edge's weight and its tail's
+// out-degree are added with atomics (no read-modify-write round trip).  The new nodes' order slots stay in the group's
+// LDS (the DP ring is free); ranks move by a binary search there, and the order array is rebuilt into the window's
+// second order buffer (`flip` says which of the two is current).  Returns 0 or the failure code (group-uniform).
+__host__ __device__ __forceinline__ Poa2Slot poa4_graph(unsigned char* slot_mem, u32 nmax, u32 lmax, bool flip) {
+  Poa2Slot g = poa4_carve(slot_mem, nmax, lmax).g;
+  if (flip) {
+    u16* t = g.order;
+    g.order = g.order2;
+    g.order2 = t;
   }
-  // New nodes anchored after a column (aligned group) go after ALL its members; the unaligned prefix goes
-  // before all members of the first column.
+  return g;
+}
+__host__ __device__ __forceinline__ void atomic_add_i32(i32* p, i32 v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
+  *p += v;
+#endif
+}
+__host__ __device__ __forceinline__ void atomic_inc_u16(u16* base, u32 idx) {  // base 4-byte aligned
+#if defined(__HIP_DEVICE_COMPILE__)
+  __hip_atomic_fetch_add(reinterpret_cast<u32*>(base) + (idx >> 1), (idx & 1u) ? 0x10000u : 1u, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
+  base[idx] += 1;
+#endif
+}
+
+template <class K>
+__host__ __device__ inline u32 poa4_update_graph(const Poa4Args A, Poa4Lds& S, unsigned char* slot_mem, bool act,
+                                                 const PoaLayer* Lp, u32 len, u32 lb, u32& nn, bool& flip,
+                                                 unsigned long long& t_add, unsigned long long& t_ord) {
+  P4_ASSUME_GLOBAL(slot_mem);
+  P4_ASSUME_GLOBAL(Lp);
+  P4_ASSUME_LDS(&S);
+  const int lane = sv::lane();
+  const int gl = lane & 15, gbase = lane & ~15, q = lane >> 4;
+  Poa4Group& Sg = S.g[q];
+  u16* nslot = reinterpret_cast<u16*>(Sg.u.ring32);  // order slots of the new nodes (<= 896 of them; the ring holds 1248)
+  const Poa2Slot g = poa4_graph(slot_mem, A.nmax, A.lmax, flip);
+  const PoaLayer L = *Lp;
+  const u32 nmax = A.nmax, lmax = A.lmax;
+  unsigned long long t0 = sv::clock();
+  const u32 n_old = nn;
+  const u32 max_len = static_cast<u32>(sv::wave_max(act ? static_cast<int>(len) : 0));
+  auto gballot = [&](bool p) -> u32 { return static_cast<u32>(sv::ballot(p) >> gbase) & 0xFFFFu; };
+  // ---- the first aligned position: the unaligned prefix goes before all members of its column ----
+  u32 first_p = 0xFFFFFFFFu;
+  for (u32 p0 = 0; p0 < max_len; p0 += 64) {
+    if (!sv::any(act && first_p == 0xFFFFFFFFu && p0 < len)) break;
+    u32 pn[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const u32 p = p0 + 16u * static_cast<u32>(u) + static_cast<u32>(gl);
+      pn[u] = (act && p < len) ? g.pos_node[p] : kNone4;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const u32 bal = gballot(pn[u] != kNone4);
+      if (first_p == 0xFFFFFFFFu && bal) first_p = p0 + 16u * static_cast<u32>(u) + static_cast<u32>(__builtin_ctz(bal));
+    }
+  }
   u32 carry_slot = n_old, carry_b = lb;
-  if (first_p != 0xFFFFFFFFu) {
+  if (act && first_p != 0xFFFFFFFFu) {
     const u32 an = g.pos_node[first_p];
     u32 r = g.rank_of[an];
     const u32 ac = g.al_cnt[an];
-    for (u32 k = 0; k < ac; ++k) {
-      const u32 rk = g.rank_of[g.al[an * 4 + k]];
-      r = rk < r ? rk : r;
-    }
+    const uint2 al2 = *reinterpret_cast<const uint2*>(g.al + static_cast<size_t>(an) * 4);
+    const u32 a0 = al2.x & 0xFFFFu, a1 = al2.x >> 16, a2 = al2.y & 0xFFFFu;
+    const u32 r0 = g.rank_of[ac > 0 ? a0 : an], r1 = g.rank_of[ac > 1 ? a1 : an], r2 = g.rank_of[ac > 2 ? a2 : an];
+    r = r0 < r ? r0 : r;
+    r = r1 < r ? r1 : r;
+    r = r2 < r ? r2 : r;
     carry_slot = r;
     carry_b = g.bpos[an];
   }
   u32 total_new = 0;
-  u32 ok = 1, why = 3;
-  for (u32 p0 = 0; p0 < len; p0 += 64) {
-    const u32 p = p0 + lane;
-    const bool valid = p < len;
-    const u32 an = valid ? g.pos_node[p] : kNone4;
-    const u32 letter = valid ? poa4_letter(Sg, p) : 0u;
-    const bool has = valid && an != kNone4;
-    u32 tgt = kNone4, gslot = 0, gb = 0, ac = 0;
-    if (has) {
-      u32 rmax = g.rank_of[an];
-      ac = g.al_cnt[an];
-      if (g.code[an] == letter) tgt = an;
-      for (u32 k = 0; k < ac; ++k) {
-        const u32 kt = g.al[an * 4 + k];
-        const u32 rk = g.rank_of[kt];
-        rmax = rk > rmax ? rk : rmax;
-        if (tgt == kNone4 && g.code[kt] == letter) tgt = kt;
+  u32 why = 0;  // != 0: the window has failed; its lanes keep step with the wave without touching the graph
+  u32 prev_tgt = kNone4;   // node of position p0 - 1 (the last position of the previous iteration)
+  i32 prev_w = 0;          // its weight
+  for (u32 p0 = 0; p0 < max_len; p0 += 64) {
+    const bool go = act && why == 0;
+    u32 p[4], an[4], letter[4];
+    bool valid[4], has[4];
+    // level 1: the nodes the positions are aligned to
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      p[u] = p0 + 16u * static_cast<u32>(u) + static_cast<u32>(gl);
+      valid[u] = go && p[u] < len;
+      an[u] = valid[u] ? g.pos_node[p[u]] : kNone4;
+      letter[u] = valid[u] ? poa4_letter(Sg, p[u]) : 0u;
+    }
+    // level 2: those nodes
+    u32 c_an[4], ac[4], rk_an[4], bp_an[4];
+    uint2 al2[4];
+    i32 wgt[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      has[u] = valid[u] && an[u] != kNone4;
+      const u32 a = has[u] ? an[u] : 0u;
+      c_an[u] = g.code[a];
+      ac[u] = g.al_cnt[a];
+      rk_an[u] = g.rank_of[a];
+      bp_an[u] = g.bpos[a];
+      al2[u] = *reinterpret_cast<const uint2*>(g.al + static_cast<size_t>(a) * 4);
+      wgt[u] = valid[u] ? static_cast<i32>(static_cast<u8>(poa_layer_weight(A.src, L, p[u]))) : 0;
+    }
+    // level 3: their aligned groups (at most three other letters)
+    u32 kt[4][3], c_kt[4][3], rk_kt[4][3];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (!has[u]) ac[u] = 0;
+      kt[u][0] = al2[u].x & 0xFFFFu;
+      kt[u][1] = al2[u].x >> 16;
+      kt[u][2] = al2[u].y & 0xFFFFu;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const u32 t = static_cast<u32>(k) < ac[u] ? kt[u][k] : 0u;
+        c_kt[u][k] = g.code[t];
+        rk_kt[u][k] = g.rank_of[t];
       }
-      gslot = rmax + 1;
-      gb = g.bpos[an];
     }
-    // order slot / backbone coordinate of the last aligned position at or before p
-    const unsigned long long bal = sv::ballot(has);
-    const unsigned long long below = bal & (lane == 63 ? ~0ULL : ((2ULL << lane) - 1ULL));
-    const int src = below ? 63 - __builtin_clzll(below) : 0;
-    const u32 s_sh = static_cast<u32>(sv::bperm(static_cast<int>(gslot), src));
-    const u32 b_sh = static_cast<u32>(sv::bperm(static_cast<int>(gb), src));
-    const u32 fslot = below ? s_sh : carry_slot;
-    const u32 fb = below ? b_sh : carry_b;
-    {
-      const int top = bal ? 63 - __builtin_clzll(bal) : 0;
-      const u32 cs = static_cast<u32>(sv::rl(static_cast<int>(gslot), top));
-      const u32 cb = static_cast<u32>(sv::rl(static_cast<int>(gb), top));
-      if (bal) {
-        carry_slot = cs;
-        carry_b = cb;
-      }
-    }
-    const bool is_new = valid && tgt == kNone4;
-    const unsigned long long nb = sv::ballot(is_new);
-    const u32 cnt = static_cast<u32>(__builtin_popcountll(nb));
-    if (n_old + total_new + cnt > nmax || total_new + cnt > lmax) {
-      ok = 0;
-      why = 2;
-      break;
-    }
-    if (is_new) {
-      const u32 t = total_new + static_cast<u32>(__builtin_popcountll(nb & ((1ULL << lane) - 1ULL)));
-      const u32 id = n_old + t;
-      tgt = id;
-      g.code[id] = static_cast<u8>(letter);
-      g.in_cnt[id] = 0;
-      g.out_cnt[id] = 0;
-      g.visits[id] = 0;
-      g.new_slot[t] = static_cast<u16>(fslot);
-      g.bpos[id] = static_cast<u16>(fb);
-      u32 c2 = 0;
-      if (has) {  // joins an's aligned group
-        for (u32 k = 0; k < ac; ++k) {
-          const u32 kt = g.al[an * 4 + k];
-          const u32 ck = g.al_cnt[kt];
-          if (ck < 4) {
-            g.al[kt * 4 + ck] = static_cast<u16>(id);
-            g.al_cnt[kt] = static_cast<u8>(ck + 1);
+    // where every position lands; order slot / backbone coordinate of the last aligned position at or before it
+    u32 tgt[4], id_new[4];
+    bool is_new[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      u32 t = kNone4, rmax = rk_an[u];
+      if (has[u]) {
+        if (c_an[u] == letter[u]) t = an[u];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          if (static_cast<u32>(k) < ac[u]) {
+            rmax = rk_kt[u][k] > rmax ? rk_kt[u][k] : rmax;
+            if (t == kNone4 && c_kt[u][k] == letter[u]) t = kt[u][k];
           }
-          if (c2 < 4) g.al[id * 4 + c2++] = static_cast<u16>(kt);
         }
-        if (ac < 4) {
-          g.al[an * 4 + ac] = static_cast<u16>(id);
-          g.al_cnt[an] = static_cast<u8>(ac + 1);
+      }
+      const u32 gslot = rmax + 1, gb = bp_an[u];
+      const u32 bal = gballot(has[u]);
+      const u32 below = bal & ((2u << gl) - 1u);
+      const int src = below ? 31 - __builtin_clz(below) : 0;
+      const u32 s_sh = static_cast<u32>(sv::bperm(static_cast<int>(gslot), gbase | src));
+      const u32 b_sh = static_cast<u32>(sv::bperm(static_cast<int>(gb), gbase | src));
+      const u32 fslot = below ? s_sh : carry_slot;
+      const u32 fb = below ? b_sh : carry_b;
+      {
+        const int top = bal ? 31 - __builtin_clz(bal) : 0;
+        const u32 cs = static_cast<u32>(sv::bperm(static_cast<int>(gslot), gbase | top));
+        const u32 cb = static_cast<u32>(sv::bperm(static_cast<int>(gb), gbase | top));
+        if (bal) {
+          carry_slot = cs;
+          carry_b = cb;
         }
-        if (c2 < 4) g.al[id * 4 + c2++] = static_cast<u16>(an);
       }
-      g.al_cnt[id] = static_cast<u8>(c2);
+      is_new[u] = valid[u] && t == kNone4;
+      const u32 nb = gballot(is_new[u]);
+      const u32 cnt = static_cast<u32>(__builtin_popcount(nb));
+      if (go && why == 0 && (n_old + total_new + cnt > nmax || total_new + cnt > lmax)) why = 2;
+      id_new[u] = 0;
+      if (is_new[u] && why == 0) {
+        const u32 tn = total_new + static_cast<u32>(__builtin_popcount(nb & ((1u << gl) - 1u)));
+        const u32 id = n_old + tn;
+        id_new[u] = id;
+        t = id;
+        nslot[tn] = static_cast<u16>(fslot);
+        g.code[id] = static_cast<u8>(letter[u]);
+        g.bpos[id] = static_cast<u16>(fb);
+        u32 c2 = 0;
+        uint2 mine = uint2{0, 0};
+        if (has[u]) {  // joins an's aligned group: every member lists every other one
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            if (static_cast<u32>(k) < ac[u]) {
+              g.al[static_cast<size_t>(kt[u][k]) * 4 + ac[u]] = static_cast<u16>(id);
+              g.al_cnt[kt[u][k]] = static_cast<u8>(ac[u] + 1);
+              if (c2 == 0) mine.x = kt[u][k];
+              else if (c2 == 1) mine.x |= kt[u][k] << 16;
+              else mine.y = kt[u][k];
+              ++c2;
+            }
+          }
+          if (ac[u] < 4) {
+            g.al[static_cast<size_t>(an[u]) * 4 + ac[u]] = static_cast<u16>(id);
+            g.al_cnt[an[u]] = static_cast<u8>(ac[u] + 1);
+          }
+          if (c2 == 0) mine.x = an[u];
+          else if (c2 == 1) mine.x |= an[u] << 16;
+          else if (c2 == 2) mine.y = an[u];
+          else mine.y |= an[u] << 16;
+          ++c2;
+        }
+        *reinterpret_cast<uint2*>(g.al + static_cast<size_t>(id) * 4) = mine;
+        g.al_cnt[id] = static_cast<u8>(c2);
+      }
+      if (why == 0) total_new += cnt;
+      tgt[u] = t;
     }
-    total_new += cnt;
-    if (valid) {
-      g.tgt[p] = static_cast<u16>(tgt);
-      if (len >= 2) g.visits[tgt] += 1;
+    // level 4: the in-edge lists of the nodes the positions land on (a new node's is empty)
+    u32 icnt[4];
+    uint4 ta[4], tb[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const bool old = valid[u] && why == 0 && !is_new[u];
+      const u32 t = old ? tgt[u] : 0u;
+      icnt[u] = old ? g.in_cnt[t] : 0u;
+      ta[u] = old ? *reinterpret_cast<const uint4*>(g.in_tail + static_cast<size_t>(t) * kPoaMaxIn) : uint4{0, 0, 0, 0};
+      tb[u] = old ? *reinterpret_cast<const uint4*>(g.in_tail + static_cast<size_t>(t) * kPoaMaxIn + 8) : uint4{0, 0, 0, 0};
     }
-  }
-  sv::sync();
-  if (ok) {
-    for (u32 p0 = 0; p0 < len; p0 += 64) {
-      const u32 p = p0 + lane;
-      bool okl = true;
-      if (p >= 1 && p < len)
-        okl = poa_add_edge(g, g.tgt[p - 1], g.tgt[p],
-                           static_cast<i32>(static_cast<u8>(poa_layer_weight(A.src, L, p - 1))) +
-                               static_cast<i32>(static_cast<u8>(poa_layer_weight(A.src, L, p))));
-      if (sv::ballot(!okl)) {
-        ok = 0;
-        why = 3;
+    // the edges (p - 1 -> p)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      // node and weight of position p - 1: the lane below; lane 0 takes the last lane of the previous quarter
+      const u32 last_t = static_cast<u32>(sv::bperm(static_cast<int>(u == 0 ? prev_tgt : tgt[u > 0 ? u - 1 : 0]), gbase | 15));
+      const i32 last_w = sv::bperm(u == 0 ? prev_w : wgt[u > 0 ? u - 1 : 0], gbase | 15);
+      const u32 tail = static_cast<u32>(sv::row_shr<1>(static_cast<int>(tgt[u]), static_cast<int>(last_t)));
+      const i32 tw = sv::row_shr<1>(wgt[u], last_w);
+      if (valid[u] && why == 0) {
+        const u32 head = tgt[u];
+        if (len >= 2) {
+          if (is_new[u]) g.visits[head] = 1;
+          else atomic_inc_u16(g.visits, head);
+        }
+        if (p[u] >= 1) {
+          const i32 weight = tw + wgt[u];
+          const u32 c = icnt[u];
+          u32 found = 0xFFu;
+#pragma unroll
+          for (int i2 = 0; i2 < 16; ++i2) {
+            const uint4& src4 = i2 < 8 ? ta[u] : tb[u];
+            const u32 wd = (i2 & 7) < 2 ? src4.x : ((i2 & 7) < 4 ? src4.y : ((i2 & 7) < 6 ? src4.z : src4.w));
+            const u32 tt = (wd >> (16 * (i2 & 1))) & 0xFFFFu;
+            if (static_cast<u32>(i2) < c && tt == tail && found == 0xFFu) found = static_cast<u32>(i2);
+          }
+          if (found != 0xFFu) {
+            atomic_add_i32(g.in_w + static_cast<size_t>(head) * kPoaMaxIn + found, weight);
+          } else if (c >= static_cast<u32>(kPoaMaxIn)) {
+            why = 3;
+          } else {
+            g.in_tail[static_cast<size_t>(head) * kPoaMaxIn + c] = static_cast<u16>(tail);
+            g.in_w[static_cast<size_t>(head) * kPoaMaxIn + c] = weight;
+            g.in_cnt[head] = static_cast<u8>(c + 1);
+            atomic_inc_u16(g.out_cnt, tail);
+          }
+        }
       }
     }
+    // a failure anywhere in the window stops the whole window
+    {
+      const u32 wmax = static_cast<u32>(group_max_i(static_cast<i32>(why)));
+      why = wmax;
+    }
+    prev_tgt = static_cast<u32>(sv::bperm(static_cast<int>(tgt[3]), gbase | 15));
+    prev_w = sv::bperm(wgt[3], gbase | 15);
   }
-  sv::sync();
-  if (!ok) return why;
-  const u32 n_new = total_new;
-  n_nodes = n_old + n_new;
   t_add += sv::clock() - t0;
   t0 = sv::clock();
-  // order rebuild: old rank r -> r + #(new slots <= r); t-th new node -> slot_t + t
-  if (n_new) {
-    for (u32 r = lane; r < n_old; r += 64) {
-      u32 lo = 0, hi = n_new;  // upper_bound(new_slot, r)
-      while (lo < hi) {
-        const u32 mid = (lo + hi) >> 1;
-        if (g.new_slot[mid] <= r) lo = mid + 1;
-        else hi = mid;
+  const u32 n_new = total_new;
+  lds_order();  // nslot
+  // ---- order rebuild: old rank r -> r + #(new slots <= r); t-th new node -> slot_t + t ----
+  const bool doit = act && why == 0 && n_new != 0;
+  if (sv::any(doit)) {
+    const u32 max_old = static_cast<u32>(sv::wave_max(doit ? static_cast<int>(n_old) : 0));
+    for (u32 r0 = 0; r0 < max_old; r0 += 64) {
+      u32 rr[4], vv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        rr[u] = r0 + 16u * static_cast<u32>(u) + static_cast<u32>(gl);
+        vv[u] = (doit && rr[u] < n_old) ? g.order[rr[u]] : 0u;
       }
-      g.order2[r + lo] = g.order[r];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (doit && rr[u] < n_old) {
+          u32 lo = 0, hi = n_new;  // upper_bound(nslot, r)
+          while (lo < hi) {
+            const u32 mid = (lo + hi) >> 1;
+            if (nslot[mid] <= rr[u]) lo = mid + 1;
+            else hi = mid;
+          }
+          g.order2[rr[u] + lo] = static_cast<u16>(vv[u]);
+          g.rank_of[vv[u]] = static_cast<u16>(rr[u] + lo);
+        }
+      }
     }
-    for (u32 t = lane; t < n_new; t += 64) g.order2[static_cast<u32>(g.new_slot[t]) + t] = static_cast<u16>(n_old + t);
-    sv::sync();
-    for (u32 r = lane; r < n_nodes; r += 64) {
-      const u32 v = g.order2[r];
-      g.order[r] = static_cast<u16>(v);
-      g.rank_of[v] = static_cast<u16>(r);
+    const u32 max_new = static_cast<u32>(sv::wave_max(doit ? static_cast<int>(n_new) : 0));
+    for (u32 t = static_cast<u32>(gl); t < max_new; t += 16) {
+      if (doit && t < n_new) {
+        const u32 r = static_cast<u32>(nslot[t]) + t;
+        g.order2[r] = static_cast<u16>(n_old + t);
+        g.rank_of[n_old + t] = static_cast<u16>(r);
+      }
     }
-    sv::sync();
+    if (doit) flip = !flip;
   }
+  if (act && why == 0) nn = n_old + n_new;
+  sv::sync();
   t_ord += sv::clock() - t0;
-  return 0;
+  return why;
 }
 
 // Consensus of a finished window: spoa's heaviest bundle with the node scores in the WAVE's LDS (the DP of every window
@@ -1163,6 +1320,7 @@ __host__ __device__ inline void poa4_wave(const Poa4Args& A, Poa4Lds& S, u32 slo
     const PoaWindow win = A.windows[wi];
     u32 phase = have ? kRunning : kIdle;
     u32 status = 0, nn = 0, n_eff = 0, li = 1;
+    bool flip = false;  // which of the window's two order buffers is current
     auto window_of = [&](int q2, u32& wi2) -> PoaWindow {  // group q2's window as wave-uniform values
       PoaWindow wq;
       wq.layer_first = static_cast<u32>(sv::rl(static_cast<int>(win.layer_first), q2 * GS));
@@ -1253,7 +1411,7 @@ __host__ __device__ inline void poa4_wave(const Poa4Args& A, Poa4Lds& S, u32 slo
       t_set += sv::clock() - t1;
       t0 = sv::clock();
       u32 r_lo = 0, n_rows = 0, t_end = 0, flag = 0, marked_rows = 0;
-      poa4_prepass<K>(A, S, my_slot, act, nn, full, Lp, len, lb, span, r_lo, n_rows, t_end, flag, marked_rows);
+      poa4_prepass<K>(A, S, my_slot, act, nn, full, flip, Lp, len, lb, span, r_lo, n_rows, t_end, flag, marked_rows);
       if ((lane & (GS - 1)) == 0 && act && A.phase_cycles) {
         sv::atomic_add(&A.phase_cycles[6], static_cast<unsigned long long>(marked_rows) * len);
         sv::atomic_add(&A.phase_cycles[7], static_cast<unsigned long long>(marked_rows) * (len + 1 < 32u ? len + 1 : 32u));
@@ -1303,22 +1461,11 @@ __host__ __device__ inline void poa4_wave(const Poa4Args& A, Poa4Lds& S, u32 slo
 #endif
       sv::sync();  // pos_node
       t_tb += sv::clock() - t0;
-      for (int q2 = 0; q2 < kG; ++q2) {
-        if (!sv::rl(act ? 1 : 0, q2 * GS)) continue;
-        u32 wi2;
-        const PoaWindow wq = window_of(q2, wi2);
-        const u32 liq = static_cast<u32>(sv::rl(static_cast<int>(li), q2 * GS));
-        u32 nnq = static_cast<u32>(sv::rl(static_cast<int>(nn), q2 * GS));
-        const PoaLayer L = A.layers[wq.layer_first + liq];
-        Poa2Slot g = poa4_carve(A.scratch + static_cast<size_t>(slot0 + q2) * A.slot_bytes, A.nmax, A.lmax).g;
-        const u32 why = poa4_add_alignment(A, g, S.g[q2], L, nnq, t_add, t_ord);
-        if (q == q2) {
-          if (why) {
-            phase = kFailed;
-            status = why;
-          } else {
-            nn = nnq;
-          }
+      {
+        const u32 why = poa4_update_graph<K>(A, S, my_slot, act, Lp, len, static_cast<u32>(lb), nn, flip, t_add, t_ord);
+        if (act && why) {
+          phase = kFailed;
+          status = why;
         }
       }
       if (had) ++li;
@@ -1334,7 +1481,8 @@ __host__ __device__ inline void poa4_wave(const Poa4Args& A, Poa4Lds& S, u32 slo
       if (ph == kFailed) {
         poa4_copy_backbone(A, wq, A.layers[wq.layer_first], A.out + wq.out_off, A.out_len + wi2);
       } else if (ph == kLayersDone) {
-        Poa2Slot g = poa4_carve(A.scratch + static_cast<size_t>(slot0 + q2) * A.slot_bytes, A.nmax, A.lmax).g;
+        Poa2Slot g = poa4_graph(A.scratch + static_cast<size_t>(slot0 + q2) * A.slot_bytes, A.nmax, A.lmax,
+                                sv::rl(flip ? 1 : 0, q2 * GS) != 0);
         const u32 nnq = static_cast<u32>(sv::rl(static_cast<int>(nn), q2 * GS));
         wq.n_layers = static_cast<u32>(sv::rl(static_cast<int>(n_eff), q2 * GS));
         sv::sync();
