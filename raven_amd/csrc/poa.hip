@@ -653,6 +653,7 @@ void poa_run_dev(Engine& e, const PoaWindow* d_wins, const PoaLayer* d_lays, u32
   PoaBatchDev b{};
   b.lmax = std::min<u32>(kPoaMaxSeq, std::max<u32>(64, ((max_len + 63) / 64) * 64));
   b.nmax = std::min<u32>(8192, std::max<u32>(512, max_bb * 6));
+  if (const char* ev = std::getenv("RVN_POA_NMAX_MULT")) b.nmax = std::min<u32>(8192, std::max<u32>(512, max_bb * static_cast<u32>(std::atoi(ev))));  // footprint experiments
   b.m = m;
   b.n = n;
   b.g = g;

@@ -688,24 +688,28 @@ __host__ __device__ inline void poa4_dp(const Poa4Args A, Poa4Lds& S, unsigned c
   }
 }
 
-// ---- traceback of the wave's windows, block-synchronous ------------------------------------------------------------
-// A round = every window walks through the 16 rows of its current block; lane l of a window holds row 16 * block + l in
-// registers: three descriptor words and the 48 bytes of the backpointer stream that hold the row's 32 codes (its 16
-// steps lie in at most three 8-step blocks of the stream).  A step is lane-local — every lane looks up the code of ITS
-// row under column j and works out where that sends the walk — followed by one ds_bpermute from the lane that owns the
-// current row; no LDS, no staging.  The blocks below the current one sit in a register queue, codes kDepth blocks and
-// descriptors kDepth + 1 blocks ahead (a memory round trip under load takes several rounds of ~10 steps), and all four
-// windows shift their queues at the same point of the loop, so the wait at a shift is for loads issued kDepth rounds
-// ago, not for another window's prefetch of a moment ago (the memory counter is the wave's, not the window's).
+// ---- traceback of the wave's windows, round-synchronous -------------------------------------------------------------
+// A round = every window walks through kTbG blocks of 16 rows; lane l of a window holds row 16 * block + l of each of
+// them in registers: three descriptor words and the 48 bytes of the backpointer stream that hold the row's 32 codes
+// (its 16 steps lie in at most three 8-step blocks of the stream).  A step is lane-local — every lane looks up the code
+// of ITS row under column j and works out where that sends the walk — followed by one ds_bpermute from the lane that
+// owns the current row; no LDS, no staging.  The blocks of the next round are fetched while this round is walked
+// (~2 x 9 steps: about a memory round trip under load), and all four windows change rounds at the same point of the loop,
+// so the wait there is for loads issued a round ago, not for another window's prefetch of a moment ago (the memory
+// counter is the wave's, not the window's).
+constexpr int kTbG = 2;
 template <class K>
 __host__ __device__ inline void poa4_traceback(const Poa4Args A, Poa4Lds& S, unsigned char* slot_mem, bool act, u32 r_lo,
                                                u32 n_rows, bool full, u32 len, u32 best_rho1, u32& bad, u32& band_hit) {
   P4_ASSUME_GLOBAL(slot_mem);
   (void)S;
   (void)n_rows;
-  constexpr int kDepth = 3;
   const int lane = sv::lane();
   const int gl = lane & 15, gbase = lane & ~15;
+  const Poa4Slot sl = poa4_carve(slot_mem, A.nmax, A.lmax);
+  const uint4* const dsc = sl.desc;
+  const uint4* const bps = sl.bps;
+  u16* const pos_node = sl.g.pos_node;
   const u32 w = len + 1;
   bad = 0;
   band_hit = 0;
@@ -714,127 +718,123 @@ __host__ __device__ inline void poa4_traceback(const Poa4Args A, Poa4Lds& S, uns
   bool done = !act || i == 0;
   u32 steps = 0, n_switch = 0;
   const u32 max_steps = A.nmax + A.lmax + 2;
-  // queue entry e = block (c_blk - e): descriptors for e = 0 .. kDepth + 1, codes for e = 0 .. kDepth
-  u32 qd0[kDepth + 2] = {}, qd1[kDepth + 2] = {}, qd7[kDepth + 2] = {};
-  uint4 qa[kDepth + 1] = {}, qb[kDepth + 1] = {}, qc[kDepth + 1] = {};
-  u32 c_blk = 0xFFFFFFFFu;
-  auto load_desc = [&](i32 blk, u32& d0, u32& d1, u32& d7) {
-    if (blk < 0) {
-      d0 = kInactiveS;
-      d1 = 0;
-      d7 = 0;
-      return;
+  // slot h of a round = block kTbG * round + h
+  u32 cd0[kTbG] = {}, cd1[kTbG] = {}, cd7[kTbG] = {}, nd0[kTbG] = {}, nd1[kTbG] = {}, nd7[kTbG] = {};
+  uint4 ca[kTbG] = {}, cb[kTbG] = {}, cc[kTbG] = {}, na[kTbG] = {}, nb[kTbG] = {}, nc[kTbG] = {};
+  u32 c_rnd = 0xFFFFFFFFu, n_rnd = 0xFFFFFFFFu;  // rounds the two sets hold
+  auto load_round = [&](u32 rnd, u32 (&d0)[kTbG], u32 (&d1)[kTbG], u32 (&d7)[kTbG], uint4 (&a)[kTbG], uint4 (&b)[kTbG],
+                        uint4 (&c)[kTbG]) {
+#pragma unroll
+    for (int h = 0; h < kTbG; ++h) {
+      const size_t rho = (static_cast<size_t>(rnd) * kTbG + h) * 16 + static_cast<size_t>(gl);
+      const uint4 da = dsc[2 * rho];
+      d0[h] = da.x;
+      d1[h] = da.y;
+      d7[h] = dsc[2 * rho + 1].w;
     }
-    const size_t rho = static_cast<size_t>(blk) * 16 + static_cast<size_t>(gl);
-    const uint4* dsc = poa4_carve(opaque(slot_mem), A.nmax, A.lmax).desc;
-    const uint4 da = dsc[2 * rho];
-    d0 = da.x;
-    d1 = da.y;
-    d7 = dsc[2 * rho + 1].w;
-  };
-  auto load_codes = [&](u32 d0, uint4& c0, uint4& c1, uint4& c2) {
-    const u32 s = d0 & 0xFFFFu;
-    const size_t tb = s == kInactiveS ? 0u : s / K::kU;
-    const uint4* src = poa4_carve(opaque(slot_mem), A.nmax, A.lmax).bps + tb * 16 + static_cast<size_t>(gl);
-    c0 = src[0];
-    c1 = src[16];
-    c2 = src[32];
+#pragma unroll
+    for (int h = 0; h < kTbG; ++h) {
+      const u32 s = d0[h] & 0xFFFFu;
+      const size_t tb = s == kInactiveS ? 0u : s / K::kU;
+      const uint4* src = bps + tb * 16 + static_cast<size_t>(gl);
+      a[h] = src[0];
+      b[h] = src[16];
+      c[h] = src[32];
+    }
   };
   while (sv::any(!done)) {
-    // ---- queue shift, all windows at once ----
-    const u32 blk = done ? c_blk : (i - 1) >> 4;
-    if (!done && blk != c_blk) {
+    // ---- change of round, all windows at once ----
+    const u32 rnd = done ? c_rnd : (i - 1) / (16 * kTbG);
+    if (!done && rnd != c_rnd) {
       ++n_switch;
-      if (c_blk == 0xFFFFFFFFu || blk + 2 < c_blk) {  // first block of the walk (or a jump the queue does not cover)
+      // (the current set is only ever written by these moves, never by a load: its uses in the walk need no wait)
+      if (rnd != n_rnd) load_round(rnd, nd0, nd1, nd7, na, nb, nc);
 #pragma unroll
-        for (int e = 0; e < kDepth + 2; ++e) load_desc(static_cast<i32>(blk) - e, qd0[e], qd1[e], qd7[e]);
-#pragma unroll
-        for (int e = 0; e < kDepth + 1; ++e) load_codes(qd0[e], qa[e], qb[e], qc[e]);
-        c_blk = blk;
+      for (int h = 0; h < kTbG; ++h) {
+        cd0[h] = nd0[h];
+        cd1[h] = nd1[h];
+        cd7[h] = nd7[h];
+        ca[h] = na[h];
+        cb[h] = nb[h];
+        cc[h] = nc[h];
       }
-      while (c_blk != blk) {  // one block down (two when an in-edge spans more than 16 rows)
-#pragma unroll
-        for (int e = 0; e < kDepth + 1; ++e) {
-          qd0[e] = qd0[e + 1];
-          qd1[e] = qd1[e + 1];
-          qd7[e] = qd7[e + 1];
-        }
-#pragma unroll
-        for (int e = 0; e < kDepth; ++e) {
-          qa[e] = qa[e + 1];
-          qb[e] = qb[e + 1];
-          qc[e] = qc[e + 1];
-        }
-        --c_blk;
-        load_codes(qd0[kDepth], qa[kDepth], qb[kDepth], qc[kDepth]);
-        load_desc(static_cast<i32>(c_blk) - (kDepth + 1), qd0[kDepth + 1], qd1[kDepth + 1], qd7[kDepth + 1]);
+      c_rnd = rnd;
+      if (rnd >= 1) {
+        load_round(rnd - 1, nd0, nd1, nd7, na, nb, nc);
+        n_rnd = rnd - 1;
+      } else {
+        n_rnd = 0xFFFFFFFFu;
       }
     }
-    // ---- walk inside the block ----
-    const u32 cd0 = qd0[0], cd1 = qd1[0], cd7 = qd7[0];
-    const uint4 cc0 = qa[0], cc1 = qb[0], cc2 = qc[0];
-    const i32 bt = static_cast<i32>((cd1 >> 16) & 0x3FFu);
-    const u32 node = cd1 & 0xFFFFu;
-    const u32 np = (cd1 >> 26) & 15u;
-    const u32 srow = cd0 & 0xFFFFu;
-    const u32 my_i = c_blk * 16 + static_cast<u32>(gl) + 1;
-    bool in_block = !done;
-    while (sv::any(in_block)) {
-      // what the walk does on THIS lane's row under column j: packed as i' | j' << 14 | flags << 24
-      //   flags: 1 diagonal (position j' gets this row's node), 2 band edge touched, 4 left the band, 8 walked off the layer
-      const i32 idx = j - bt;
-      u32 res;
-      if (idx < 0 || idx >= K::kBand) {
-        res = 4u << 24;
-      } else {
-        u32 fl = ((idx < 2 && bt > 0) || (idx > K::kBand - 3 && bt + K::kBand < static_cast<i32>(w))) ? 2u : 0u;
-        const u32 bo = (srow % K::kU + (static_cast<u32>(idx) >> 1)) * 2 + (static_cast<u32>(idx) & 1u);  // byte among the row's 48
-        const u32 dwi = bo >> 2;
-        const uint4 cq = dwi < 4 ? cc0 : (dwi < 8 ? cc1 : cc2);
-        const u32 wsel = (dwi & 2) ? ((dwi & 1) ? cq.w : cq.z) : ((dwi & 1) ? cq.y : cq.x);
-        const u32 code = (wsel >> (8 * (bo & 3u))) & 0xFFu;
-        u32 ni = my_i;
-        i32 nj = j;
-        if (code == 64u) {
-          if (j == 0) fl |= 8u;
-          else nj = j - 1;  // insertion: pos_node[j - 1] stays kNone
+    // ---- the round's blocks, top down ----
+#pragma unroll
+    for (int h = kTbG - 1; h >= 0; --h) {
+      const u32 c_blk = c_rnd * kTbG + static_cast<u32>(h);
+      const i32 bt = static_cast<i32>((cd1[h] >> 16) & 0x3FFu);
+      const u32 node = cd1[h] & 0xFFFFu;
+      const u32 np = (cd1[h] >> 26) & 15u;
+      const u32 srow = cd0[h] & 0xFFFFu;
+      const u32 my_i = c_blk * 16 + static_cast<u32>(gl) + 1;
+      bool in_block = !done && ((i - 1) >> 4) == c_blk;
+      while (sv::any(in_block)) {
+        P4_MARK("tb_step_begin");
+        // what the walk does on THIS lane's row under column j: packed as i' | j' << 14 | flags << 24
+        //   flags: 1 diagonal (position j' gets this row's node), 2 band edge touched, 4 left the band, 8 walked off the layer
+        const i32 idx = j - bt;
+        u32 res;
+        if (idx < 0 || idx >= K::kBand) {
+          res = 4u << 24;
         } else {
-          const u32 k = 15u - (code & 15u);
-          if (np == 0) ni = 0;
-          else if (k < 6) ni = my_i - ((cd7 >> (5 * k)) & 31u);
-          else ni = poa4_nth_pred_rank(poa4_carve(opaque(slot_mem), A.nmax, A.lmax).g, node, k, full) - r_lo + 1;
-          if (code & 32u) {  // diagonal
+          u32 fl = ((idx < 2 && bt > 0) || (idx > K::kBand - 3 && bt + K::kBand < static_cast<i32>(w))) ? 2u : 0u;
+          const u32 bo = (srow % K::kU + (static_cast<u32>(idx) >> 1)) * 2 + (static_cast<u32>(idx) & 1u);  // byte among the row's 48
+          const u32 dwi = bo >> 2;
+          const uint4 cq = dwi < 4 ? ca[h] : (dwi < 8 ? cb[h] : cc[h]);
+          const u32 wsel = (dwi & 2) ? ((dwi & 1) ? cq.w : cq.z) : ((dwi & 1) ? cq.y : cq.x);
+          const u32 code = (wsel >> (8 * (bo & 3u))) & 0xFFu;
+          u32 ni = my_i;
+          i32 nj = j;
+          if (code == 64u) {
             if (j == 0) fl |= 8u;
-            else {
-              nj = j - 1;
-              fl |= 1u;
+            else nj = j - 1;  // insertion: pos_node[j - 1] stays kNone
+          } else {
+            const u32 k = 15u - (code & 15u);
+            if (np == 0) ni = 0;
+            else if (k < 6) ni = my_i - ((cd7[h] >> (5 * k)) & 31u);
+            else ni = poa4_nth_pred_rank(poa4_carve(opaque(slot_mem), A.nmax, A.lmax).g, node, k, full) - r_lo + 1;
+            if (code & 32u) {  // diagonal
+              if (j == 0) fl |= 8u;
+              else {
+                nj = j - 1;
+                fl |= 1u;
+              }
             }
           }
+          res = ni | (static_cast<u32>(nj) << 14) | (fl << 24);
         }
-        res = ni | (static_cast<u32>(nj) << 14) | (fl << 24);
-      }
-      const bool mine = in_block && my_i == i;
-      const u32 got = static_cast<u32>(sv::bperm(static_cast<int>(res), gbase | static_cast<int>((i - 1) & 15u)));
-      if (in_block) {
-        const u32 fl = got >> 24;
-        if (++steps > max_steps) {
-          bad = 6;
-          done = true;
-        } else if (fl & 4u) {  // the path left the stored band: the alignment does not fit this band width
-          band_hit = 1;
-          done = true;
-        } else if (fl & 8u) {
-          bad = 6;
-          done = true;
-        } else {
-          if (fl & 2u) band_hit = 1;
-          const i32 nj = static_cast<i32>((got >> 14) & 0x3FFu);
-          if (mine && (fl & 1u)) poa4_carve(opaque(slot_mem), A.nmax, A.lmax).g.pos_node[nj] = static_cast<u16>(node);
-          j = nj;
-          i = got & 0x3FFFu;
-          if (i == 0) done = true;  // on the virtual row only insertions remain: pos_node already says kNone
+        const bool mine = in_block && my_i == i;
+        const u32 got = static_cast<u32>(sv::bperm(static_cast<int>(res), gbase | static_cast<int>((i - 1) & 15u)));
+        if (in_block) {
+          const u32 fl = got >> 24;
+          if (++steps > max_steps) {
+            bad = 6;
+            done = true;
+          } else if (fl & 4u) {  // the path left the stored band: the alignment does not fit this band width
+            band_hit = 1;
+            done = true;
+          } else if (fl & 8u) {
+            bad = 6;
+            done = true;
+          } else {
+            if (fl & 2u) band_hit = 1;
+            const i32 nj = static_cast<i32>((got >> 14) & 0x3FFu);
+            if (mine && (fl & 1u)) pos_node[nj] = static_cast<u16>(node);
+            j = nj;
+            i = got & 0x3FFFu;
+            if (i == 0) done = true;  // on the virtual row only insertions remain: pos_node already says kNone
+          }
+          in_block = !done && ((i - 1) >> 4) == c_blk;
         }
-        in_block = !done && ((i - 1) >> 4) == c_blk;
+        P4_MARK("tb_step_end");
       }
     }
   }
@@ -1555,8 +1555,9 @@ void poa_v4_launch(Engine& e, const PoaBatchDev& b) {
   const size_t slot_bytes = poa4_slot_bytes(b.nmax, b.lmax);
   size_t free_b = 0, total_b = 0;
   RVN_HIP(hipMemGetInfo(&free_b, &total_b));
-  constexpr int kOcc = 3;
-  u32 per_cu = std::min<u32>(static_cast<u32>((160u * 1024u) / sizeof(Poa4Lds)), 4u * kOcc);
+  int occ = 3;  // waves per SIMD the kernel is built for (168 / 128 VGPRs)
+  if (const char* ev = std::getenv("RVN_POA4_OCC")) occ = std::atoi(ev) == 4 ? 4 : 3;
+  u32 per_cu = std::min<u32>(static_cast<u32>((160u * 1024u) / sizeof(Poa4Lds)), 4u * static_cast<u32>(occ));
   if (const char* ev = std::getenv("RVN_POA_WAVES_PER_CU")) per_cu = static_cast<u32>(std::atoi(ev));  // occupancy experiments
   per_cu = per_cu < 1 ? 1 : per_cu;
   u32 n_waves = std::min<u32>((b.n_windows + P4::G - 1) / P4::G, 256 * per_cu);
@@ -1566,7 +1567,8 @@ void poa_v4_launch(Engine& e, const PoaBatchDev& b) {
   unsigned char* d_scratch = e.poa2_scratch.get<unsigned char>(static_cast<size_t>(n_waves) * P4::G * slot_bytes + 256);
   RVN_HIP(hipMemsetAsync(b.next, 0, 4, e.stream));
   const Poa4Args A = args_of4(b, d_scratch, slot_bytes);
-  RVN_KLAUNCH(kKPoaBanded, (poa4_kernel<kOcc><<<n_waves, 64, 0, e.stream>>>(A, n_waves)));
+  if (occ == 4) RVN_KLAUNCH(kKPoaBanded, (poa4_kernel<4><<<n_waves, 64, 0, e.stream>>>(A, n_waves)));
+  else RVN_KLAUNCH(kKPoaBanded, (poa4_kernel<3><<<n_waves, 64, 0, e.stream>>>(A, n_waves)));
 }
 
 // The same kernel source on the host, one emulated wave (simt_emu): windows / layers / sources are host arrays.  TEST

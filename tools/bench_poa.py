@@ -46,18 +46,29 @@ def main():
         cells += sum(len(r) for r in reads) * 650  # ~nodes x layer length, order of magnitude
     eng = hip.Engine()
     # RVN_POA_MODES="9,2": the same windows through several kernels in one process (one JSON line each)
-    modes = [int(x) for x in os.environ.get("RVN_POA_MODES", os.environ.get("RVN_POA_MODE", "0")).split(",")]
-    for mode in modes:
-        run_mode(eng, mode, wins, truths, n_windows, n_check, cells)
+    # an entry may carry environment overrides for that run: "9@RVN_POA_WAVES_PER_CU=6@RVN_POA_NMAX_MULT=3"
+    for entry in os.environ.get("RVN_POA_MODES", os.environ.get("RVN_POA_MODE", "0")).split(","):
+        parts = entry.split("@")
+        saved = {}
+        for kv in parts[1:]:
+            k, v = kv.split("=")
+            saved[k] = os.environ.get(k)
+            os.environ[k] = v
+        run_mode(eng, int(parts[0]), wins, truths, n_windows, n_check, cells, entry)
+        for k, v in saved.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
 
 
-def run_mode(eng, mode, wins, truths, n_windows, n_check, cells):
+def run_mode(eng, mode, wins, truths, n_windows, n_check, cells, label=""):
     eng.poa_set_mode(mode)
     eng.poa_consensus_batch(wins[:64])  # warm-up / allocation
     t = time.time()
     cons, status, ms = eng.poa_consensus_batch(wins)
     wall = time.time() - t
-    out = {"mode": mode, "windows": n_windows, "layers_per_window": 30, "device_ms": ms, "wall_s": wall,
+    out = {"mode": mode, "run": label, "windows": n_windows, "layers_per_window": 30, "device_ms": ms, "wall_s": wall,
            "windows_per_s": n_windows / ms * 1e3, "approx_gcups": cells / ms / 1e6,
            "status_counts": {int(k): int(v) for k, v in zip(*np.unique(status & 0xFF, return_counts=True))},
            "fail_layers": [int(x) >> 8 for x in status[status > 1][:20]], "fail_windows": [int(i) for i in np.nonzero(status > 1)[0][:20]],
