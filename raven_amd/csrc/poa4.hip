@@ -88,7 +88,7 @@ struct Poa4Slot {
   Poa2Slot g;
   uint4* desc;   // 2 per row: {S | own << 16, node | b << 16 | np << 26 | marked << 30 | end << 31, match mask, e0 | e1 << 16},
                  //            {e2 | e3 << 16, e4 | e5 << 16, e6 | e7 << 16, rank distances of in-edges 0..5 (5 bits each)}
-  u32* rb;       // per node: rank | band start in this layer << 16
+  u32* rb;       // per node: rank | backbone coordinate << 16 (kept by the set-up and by poa4_update_graph)
   uint4* bps;    // backpointer stream: [step / 8][lane of the window] 16 bytes = 8 steps x 2 columns
 };
 __host__ __device__ inline u32 poa4_desc_rows(u32 nmax) { return nmax + 64; }
@@ -235,11 +235,11 @@ __host__ __device__ inline u32 poa4_nth_pred_rank(const Poa2Slot& g, u32 v, u32 
 }
 
 // ---- per-layer pre-pass: the row descriptors ---------------------------------------------------------------------------
-// The wave's windows side by side.  Group-uniform inputs: act, nn, full, the layer.  Two sweeps over the NODES (not the
-// ranks: everything a node contributes is then a coalesced load, and only its in-edges' tails are gathered):
-//   A  rb[v] = rank | band start << 16 (the band start from the layer's guide through per-segment reciprocals kept in LDS),
-//      and the rank range [r_lo, r_hi) that holds the layer's subgraph;
-//   B  the descriptor of every node whose rank lies in the range, written at its row rho = rank - r_lo.
+// The wave's windows side by side.  Group-uniform inputs: act, nn, full, the layer.
+// one sweep over the NODES (not the ranks: everything a node contributes is then a coalesced load, and only its
+// in-edges' tails are gathered — rb[] holds rank and backbone coordinate of a node in one word, band starts come from the
+// layer's guide through per-segment reciprocals kept in LDS): the descriptor of every node whose rank lies in the rank
+// range [r_lo, r_hi) of the layer's subgraph, written at its row rho = rank - r_lo.
 // Outputs (group-uniform): r_lo (rank of row 0), n_rows, t_end (steps of the layer's DP), flag (!= 0: the layer does
 // not fit this kernel's limits -> the window goes to the 64-column kernel), marked rows (work counter).
 __host__ __device__ __forceinline__ u32 mulhi_u32(u32 a, u32 b) {
@@ -296,45 +296,40 @@ __host__ __device__ inline void poa4_prepass(const Poa4Args A, Poa4Lds& S, unsig
     return (b == bmax && bmax > 0) ? (b + 1) & ~1 : b & ~1;
   };
   const u32 max_nn = static_cast<u32>(sv::wave_max(act ? static_cast<int>(nn) : 0));
-  // ---- sweep A: rank | band start of every node; the rank range of the subgraph ----
-  u32 first = 0xFFFFFFFFu;
-  i32 last = 0;
-  for (u32 v0 = 0; v0 < max_nn; v0 += 64) {
-    u32 vv[4], rk[4];
-    i32 bp[4];
-    u32 mk[4];
+  // ---- a partial layer: the rank range that holds its subgraph ----
+  u32 r_lo = 0, r_hi = act ? nn : 0;
+  if (sv::any(act && !full)) {
+    const bool part = act && !full;
+    u32 first = 0xFFFFFFFFu;
+    i32 last = 0;
+    const u32 max_pn = static_cast<u32>(sv::wave_max(part ? static_cast<int>(nn) : 0));
+    for (u32 v0 = 0; v0 < max_pn; v0 += 64) {
+      u32 rk[4], mk[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      vv[u] = v0 + 16u * static_cast<u32>(u) + static_cast<u32>(gl);
-      const bool ok = act && vv[u] < nn;
-      rk[u] = ok ? g.rank_of[vv[u]] : 0u;
-      bp[u] = ok ? static_cast<i32>(g.bpos[vv[u]]) : 0;
-      mk[u] = (ok && !full) ? g.mark[vv[u]] : 1u;
-    }
+      for (int u = 0; u < 4; ++u) {
+        const u32 v = v0 + 16u * static_cast<u32>(u) + static_cast<u32>(gl);
+        const bool ok = part && v < nn;
+        rk[u] = ok ? sl.rb[v] & 0xFFFFu : 0u;
+        mk[u] = ok ? g.mark[v] : 0u;
+      }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      if (act && vv[u] < nn) {
-        sl.rb[vv[u]] = rk[u] | (static_cast<u32>(band_start(bp[u])) << 16);
+      for (int u = 0; u < 4; ++u) {
         if (mk[u]) {
           first = rk[u] < first ? rk[u] : first;
           last = static_cast<i32>(rk[u]) + 1 > last ? static_cast<i32>(rk[u]) + 1 : last;
         }
       }
     }
-  }
-  u32 r_lo = 0, r_hi = act ? nn : 0;
-  if (sv::any(act && !full)) {
     first = group_min_u(first);
     last = group_max_i(last);
-    if (act && !full) {
+    if (part) {
       r_lo = first == 0xFFFFFFFFu ? 0u : first;
       r_hi = first == 0xFFFFFFFFu ? 0u : static_cast<u32>(last);
     }
   }
   const u32 n_rows = r_hi - r_lo;
-  sv::sync();  // rb visible
   i32 b_first = 0;
-  if (act && n_rows) b_first = static_cast<i32>(sl.rb[(flip ? g.order2 : g.order)[r_lo]] >> 16);
+  if (act && n_rows) b_first = band_start(static_cast<i32>(sl.rb[(flip ? g.order2 : g.order)[r_lo]] >> 16));
   const u32 ring_off = static_cast<u32>(offsetof(Poa4Lds, g)) + static_cast<u32>(q) * static_cast<u32>(sizeof(Poa4Group));
   const u32 dump_off = ring_off + static_cast<u32>(offsetof(Poa4Group, dump));
   const u32 neg_off = static_cast<u32>(offsetof(Poa4Lds, neg));
@@ -376,7 +371,7 @@ __host__ __device__ inline void poa4_prepass(const Poa4Args A, Poa4Lds& S, unsig
     for (int u = 0; u < 2; ++u) {
       const u32 v = vv[u];
       const u32 r = rbv[u] & 0xFFFFu;
-      const i32 b = static_cast<i32>(rbv[u] >> 16);
+      const i32 b = band_start(static_cast<i32>(rbv[u] >> 16));
       const u32 rho = r - r_lo;
       const bool marked = ok[u] && mk[u] != 0;
       u32 ep[4] = {neg2, neg2, neg2, neg2};
@@ -384,7 +379,7 @@ __host__ __device__ inline void poa4_prepass(const Poa4Args A, Poa4Lds& S, unsig
       auto edge = [&](u32 rbt, bool inside) {
         if (!inside) return;
         const u32 lbk = r - (rbt & 0xFFFFu);
-        const i32 d = b - static_cast<i32>(rbt >> 16);
+        const i32 d = b - band_start(static_cast<i32>(rbt >> 16));
         if (lbk < 1 || lbk > static_cast<u32>(K::kRing - 1) || lbk > rho || d < 0 || d > K::kMaxD) {
           flag = 7;
         } else if (np < static_cast<u32>(K::kEdges)) {
@@ -854,8 +849,8 @@ __host__ __device__ inline void poa4_copy_backbone(const Poa4Args& A, const PoaW
 }
 
 // window set-up: 0 = backbone returned (< 3 sequences), 4 = beyond a length limit (backbone returned), 1 = graph built
-__host__ __device__ inline u32 poa4_init_window(const Poa4Args& A, const PoaWindow& win, Poa2Slot& g, u32 wi, u32& n_nodes,
-                                                u32& n_eff) {
+__host__ __device__ inline u32 poa4_init_window(const Poa4Args& A, const PoaWindow& win, Poa2Slot& g, u32* rb, u32 wi,
+                                                u32& n_nodes, u32& n_eff) {
   const int lane = sv::lane();
   const PoaLayer bb = A.layers[win.layer_first];
   const u32 blen = bb.len;
@@ -883,6 +878,7 @@ __host__ __device__ inline u32 poa4_init_window(const Poa4Args& A, const PoaWind
     g.rank_of[i] = static_cast<u16>(i);
     g.order[i] = static_cast<u16>(i);
     g.bpos[i] = static_cast<u16>(i);
+    rb[i] = i | (i << 16);
     const i32 wgt = poa_layer_weight(A.src, bb, i);
     if (i > 0) {
       const i32 wp = poa_layer_weight(A.src, bb, i - 1);
@@ -955,6 +951,7 @@ __host__ __device__ inline u32 poa4_update_graph(const Poa4Args A, Poa4Lds& S, u
   Poa4Group& Sg = S.g[q];
   u16* nslot = reinterpret_cast<u16*>(Sg.u.ring32);  // order slots of the new nodes (<= 896 of them; the ring holds 1248)
   const Poa2Slot g = poa4_graph(slot_mem, A.nmax, A.lmax, flip);
+  u16* const rb16 = reinterpret_cast<u16*>(poa4_carve(slot_mem, A.nmax, A.lmax).rb);  // [2 v] rank, [2 v + 1] backbone coordinate
   const PoaLayer L = *Lp;
   const u32 nmax = A.nmax, lmax = A.lmax;
   unsigned long long t0 = sv::clock();
@@ -1083,6 +1080,7 @@ __host__ __device__ inline u32 poa4_update_graph(const Poa4Args A, Poa4Lds& S, u
         nslot[tn] = static_cast<u16>(fslot);
         g.code[id] = static_cast<u8>(letter[u]);
         g.bpos[id] = static_cast<u16>(fb);
+        rb16[2 * static_cast<size_t>(id) + 1] = static_cast<u16>(fb);
         u32 c2 = 0;
         uint2 mine = uint2{0, 0};
         if (has[u]) {  // joins an's aligned group: every member lists every other one
@@ -1196,6 +1194,7 @@ __host__ __device__ inline u32 poa4_update_graph(const Poa4Args A, Poa4Lds& S, u
           }
           g.order2[rr[u] + lo] = static_cast<u16>(vv[u]);
           g.rank_of[vv[u]] = static_cast<u16>(rr[u] + lo);
+          rb16[2 * static_cast<size_t>(vv[u])] = static_cast<u16>(rr[u] + lo);
         }
       }
     }
@@ -1205,6 +1204,7 @@ __host__ __device__ inline u32 poa4_update_graph(const Poa4Args A, Poa4Lds& S, u
         const u32 r = static_cast<u32>(nslot[t]) + t;
         g.order2[r] = static_cast<u16>(n_old + t);
         g.rank_of[n_old + t] = static_cast<u16>(r);
+        rb16[2 * static_cast<size_t>(n_old + t)] = static_cast<u16>(r);
       }
     }
     if (doit) flip = !flip;
@@ -1334,9 +1334,10 @@ __host__ __device__ inline void poa4_wave(const Poa4Args& A, Poa4Lds& S, u32 slo
       if (sv::rl(static_cast<int>(phase), q2 * GS) != static_cast<int>(kRunning)) continue;
       u32 wi2;
       const PoaWindow wq = window_of(q2, wi2);
-      Poa2Slot g = poa4_carve(A.scratch + static_cast<size_t>(slot0 + q2) * A.slot_bytes, A.nmax, A.lmax).g;
+      const Poa4Slot sl2 = poa4_carve(A.scratch + static_cast<size_t>(slot0 + q2) * A.slot_bytes, A.nmax, A.lmax);
+      Poa2Slot g = sl2.g;
       u32 nn2 = 0, ne2 = 0;
-      const u32 r = poa4_init_window(A, wq, g, wi2, nn2, ne2);
+      const u32 r = poa4_init_window(A, wq, g, sl2.rb, wi2, nn2, ne2);
       if (q == q2) {
         nn = nn2;
         n_eff = ne2;
