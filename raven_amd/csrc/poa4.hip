@@ -90,6 +90,7 @@ struct Poa4Slot {
                  //            {e2 | e3 << 16, e4 | e5 << 16, e6 | e7 << 16, rank distances of in-edges 0..5 (5 bits each)}
   u32* rb;       // per node: rank | backbone coordinate << 16 (kept by the set-up and by poa4_update_graph)
   uint4* bps;    // backpointer stream: [step / 8][lane of the window] 16 bytes = 8 steps x 2 columns
+  u32* seq2g;    // the current layer, 2 bits per base (the LDS image of phase A, for the graph update's launch)
 };
 __host__ __device__ inline u32 poa4_desc_rows(u32 nmax) { return nmax + 64; }
 __host__ __device__ inline u32 poa4_steps(u32 nmax, u32 lmax) { return nmax + nmax / 16 + lmax / 2 + 96; }
@@ -98,6 +99,7 @@ inline size_t poa4_slot_bytes(u32 nmax, u32 lmax) {
   b += static_cast<size_t>(poa4_desc_rows(nmax)) * 32;
   b += (static_cast<size_t>(nmax) * 4 + 255) & ~size_t(255);
   b += (static_cast<size_t>(poa4_steps(nmax, lmax)) / P4::kU + 2) * 16 * 16;
+  b += 256;
   return (b + 255) & ~size_t(255);
 }
 __host__ __device__ inline Poa4Slot poa4_carve(unsigned char* base, u32 nmax, u32 lmax) {
@@ -110,6 +112,8 @@ __host__ __device__ inline Poa4Slot poa4_carve(unsigned char* base, u32 nmax, u3
   s.rb = reinterpret_cast<u32*>(base + o);
   o += (static_cast<size_t>(nmax) * 4 + 255) & ~size_t(255);
   s.bps = reinterpret_cast<uint4*>(base + o);
+  o += (static_cast<size_t>(poa4_steps(nmax, lmax)) / P4::kU + 2) * 16 * 16;
+  s.seq2g = reinterpret_cast<u32*>(base + o);
   return s;
 }
 
@@ -1298,232 +1302,328 @@ __host__ __device__ inline void poa4_consensus(Poa2Slot& g, u32 n_nodes, u32 nma
   if (lane == 0) *out_len = static_cast<u32>(n_out);
 }
 
-// ---- one persistent wave: takes four windows at a time ------------------------------------------------------------
+// ---- one kernel per phase -------------------------------------------------------------------------------------------
+// The windows of a chunk go through their layers in lock step, a launch per phase and round: set-up + row descriptors,
+// NW, traceback, graph update.  Every phase gets its own register allocation and its own occupancy (the NW is
+// issue-bound and wants its 100 registers; the other three wait on gathers and want many waves), and what a window
+// carries from phase to phase lives in a 64-byte record beside its graph.  A wave serves the same four windows in every
+// launch (positions 4 wave .. 4 wave + 3 of the chunk, in scheduling order = heaviest first, so the waves of the late
+// rounds that find nothing to do are the grid's tail).
 enum : u32 { kIdle = 0, kRunning = 1, kLayersDone = 2, kFinal = 3, kFailed = 4 };
 
+struct Poa4Win {  // per window of the chunk
+  u32 wi;        // window index
+  u32 phase, status, nn, n_eff, li, flip;
+  u32 act, full, len, lb, span;  // the layer of this round (act = 0: none)
+  u32 r_lo, n_rows, t_end, best_rho1;
+};
+static_assert(sizeof(Poa4Win) == 64, "state record");
+
+struct Poa4Ctx {  // what a phase function needs beside the batch description
+  Poa4Win* st;    // records of the chunk
+  u32 first;      // position of the chunk's first window in scheduling order
+  u32 count;      // windows in the chunk
+};
+
+__host__ __device__ __forceinline__ unsigned char* poa4_slot_of(const Poa4Args& A, u32 wave, int q) {
+  return A.scratch + (static_cast<size_t>(wave) * P4::G + static_cast<size_t>(q)) * A.slot_bytes;
+}
+// the lane's window of this wave: record index, or 0xFFFFFFFF beyond the chunk
+__host__ __device__ __forceinline__ u32 poa4_my_record(const Poa4Ctx& C, u32 wave, int q) {
+  const u32 idx = wave * P4::G + static_cast<u32>(q);
+  return idx < C.count ? idx : 0xFFFFFFFFu;
+}
+
+// phase 0: graph of the backbone, state record
+__host__ __device__ inline void poa4_phase_init(const Poa4Args& A, const Poa4Ctx& C, u32 wave) {
+  const int lane = sv::lane();
+  for (int q2 = 0; q2 < P4::G; ++q2) {
+    const u32 rec = poa4_my_record(C, wave, q2);
+    if (rec == 0xFFFFFFFFu) continue;
+    const u32 pos = C.first + rec;
+    const u32 wi = A.sched ? A.sched[pos] : pos;
+    const PoaWindow wq = A.windows[wi];
+    const Poa4Slot sl2 = poa4_carve(poa4_slot_of(A, wave, q2), A.nmax, A.lmax);
+    Poa2Slot g = sl2.g;
+    u32 nn2 = 0, ne2 = 0;
+    const u32 r = poa4_init_window(A, wq, g, sl2.rb, wi, nn2, ne2);
+    if (lane == 0) {
+      Poa4Win w{};
+      w.wi = wi;
+      w.phase = r == 1 ? kRunning : kFinal;
+      w.status = r == 1 ? 0u : r;
+      w.nn = nn2;
+      w.n_eff = ne2;
+      w.li = 1;
+      C.st[rec] = w;
+    }
+  }
+}
+
+// phase A of a round: the next layer of every window (codes packed into the window's seq2, subgraph marks), then the
+// row descriptors of the four windows side by side
 template <class K>
-__host__ __device__ inline void poa4_wave(const Poa4Args& A, Poa4Lds& S, u32 slot0) {
-  constexpr int kG = K::G, GS = K::GS;
+__host__ __device__ inline void poa4_phase_layer(const Poa4Args& A, const Poa4Ctx& C, Poa4Lds& S, u32 wave) {
+  constexpr int GS = K::GS;
   const int lane = sv::lane();
   const int q = lane / GS;
-  unsigned long long t_sub = 0, t_dp = 0, t_tb = 0, t_add = 0, t_ord = 0, t_cons = 0, t0 = 0, t_pre = 0, t_set = 0, t1 = 0;
-  unsigned char* const my_slot = A.scratch + static_cast<size_t>(slot0 + q) * A.slot_bytes;  // per lane: its group's window
-  for (;;) {
-    u32 first = 0;
-    if (lane == 0) first = sv::atomic_add(A.next, static_cast<u32>(kG));
-    first = static_cast<u32>(sv::rfl(static_cast<int>(first)));
-    if (first >= A.n_windows) break;
-    // group-uniform state of the lane's window
-    const u32 pos = first + static_cast<u32>(q);
-    const bool have = pos < A.n_windows;
-    const u32 wi = have ? (A.sched ? A.sched[pos] : pos) : 0u;
-    const PoaWindow win = A.windows[wi];
-    u32 phase = have ? kRunning : kIdle;
-    u32 status = 0, nn = 0, n_eff = 0, li = 1;
-    bool flip = false;  // which of the window's two order buffers is current
-    auto window_of = [&](int q2, u32& wi2) -> PoaWindow {  // group q2's window as wave-uniform values
-      PoaWindow wq;
-      wq.layer_first = static_cast<u32>(sv::rl(static_cast<int>(win.layer_first), q2 * GS));
-      wq.n_layers = static_cast<u32>(sv::rl(static_cast<int>(win.n_layers), q2 * GS));
-      wq.out_off = static_cast<u32>(sv::rl(static_cast<int>(win.out_off), q2 * GS));
-      wq.out_cap = static_cast<u32>(sv::rl(static_cast<int>(win.out_cap), q2 * GS));
-      wi2 = static_cast<u32>(sv::rl(static_cast<int>(wi), q2 * GS));
-      return wq;
-    };
-    for (int q2 = 0; q2 < kG; ++q2) {
-      if (sv::rl(static_cast<int>(phase), q2 * GS) != static_cast<int>(kRunning)) continue;
-      u32 wi2;
-      const PoaWindow wq = window_of(q2, wi2);
-      const Poa4Slot sl2 = poa4_carve(A.scratch + static_cast<size_t>(slot0 + q2) * A.slot_bytes, A.nmax, A.lmax);
-      Poa2Slot g = sl2.g;
-      u32 nn2 = 0, ne2 = 0;
-      const u32 r = poa4_init_window(A, wq, g, sl2.rb, wi2, nn2, ne2);
+  unsigned long long t0 = sv::clock();
+  const u32 my_rec = poa4_my_record(C, wave, q);
+  Poa4Win me{};
+  if (my_rec != 0xFFFFFFFFu) me = C.st[my_rec];
+  if (!sv::any(me.phase == kRunning)) return;
+  bool act = false, full = false;
+  u32 len = 0, li = me.li;
+  i32 lb = 0, span = 0;
+  u32 phase = me.phase, status = me.status;
+  const PoaLayer* Lp = A.layers;
+  for (int q2 = 0; q2 < P4::G; ++q2) {
+    if (sv::rl(static_cast<int>(phase), q2 * GS) != static_cast<int>(kRunning)) continue;
+    const u32 wi2 = static_cast<u32>(sv::rl(static_cast<int>(me.wi), q2 * GS));
+    const PoaWindow wq = A.windows[wi2];
+    u32 liq = static_cast<u32>(sv::rl(static_cast<int>(li), q2 * GS));
+    const u32 nnq = static_cast<u32>(sv::rl(static_cast<int>(me.nn), q2 * GS));
+    while (liq < wq.n_layers && (A.layers[wq.layer_first + liq].len == 0 ||
+                                 (A.src.layer_ok && !A.src.layer_ok[wq.layer_first + liq])))
+      ++liq;
+    if (liq >= wq.n_layers) {
+      if (q == q2) phase = kLayersDone;
+      continue;
+    }
+    const PoaLayer L = A.layers[wq.layer_first + liq];
+    if (L.len > A.lmax || L.len > static_cast<u32>(kPoa2MaxSeq)) {
       if (q == q2) {
-        nn = nn2;
-        n_eff = ne2;
-        if (r != 1) {
-          phase = kFinal;
-          status = r;
-        }
+        phase = kFailed;
+        status = 4;
       }
+      continue;
     }
-    // ---- layers: every window of the wave aligns its next layer in the same round ----
-    for (;;) {
-      bool act = false, full = false;
-      u32 len = 0;
-      i32 lb = 0, span = 0;
-      const PoaLayer* Lp = A.layers;
-      t1 = sv::clock();
-      for (int q2 = 0; q2 < kG; ++q2) {
-        if (sv::rl(static_cast<int>(phase), q2 * GS) != static_cast<int>(kRunning)) continue;
-        u32 wi2;
-        const PoaWindow wq = window_of(q2, wi2);
-        u32 liq = static_cast<u32>(sv::rl(static_cast<int>(li), q2 * GS));
-        const u32 nnq = static_cast<u32>(sv::rl(static_cast<int>(nn), q2 * GS));
-        while (liq < wq.n_layers && (A.layers[wq.layer_first + liq].len == 0 ||
-                                     (A.src.layer_ok && !A.src.layer_ok[wq.layer_first + liq])))
-          ++liq;
-        if (liq >= wq.n_layers) {
-          if (q == q2) phase = kLayersDone;
-          continue;
-        }
-        const PoaLayer L = A.layers[wq.layer_first + liq];
-        if (L.len > A.lmax || L.len > static_cast<u32>(kPoa2MaxSeq)) {
-          if (q == q2) {
-            phase = kFailed;
-            status = 4;
-          }
-          continue;
-        }
-        Poa2Slot g = poa4_carve(A.scratch + static_cast<size_t>(slot0 + q2) * A.slot_bytes, A.nmax, A.lmax).g;
-        Poa4Group& Sg = S.g[q2];
-        // the layer's codes: bytes first (the ring is free), then 16 to a word
-        for (u32 i = lane; i < L.len; i += 64) {
-          Sg.u.bytes[i] = static_cast<u8>(poa_layer_code(A.src, L, i));
-          g.pos_node[i] = static_cast<u16>(kNone4);
-        }
-        lds_order();
-        for (u32 wd = lane; wd < 60; wd += 64) {
-          u32 x = 0;
-          for (u32 c = 0; c < 16; ++c) {
-            const i32 p = static_cast<i32>(wd * 16 + c) - 1;
-            if (p >= 0 && p < static_cast<i32>(L.len)) x |= static_cast<u32>(Sg.u.bytes[p] & 3u) << (2 * c);
-          }
-          Sg.seq2[wd] = x;
-        }
-        const u32 blen = A.layers[wq.layer_first].len;
-        const u32 offset = static_cast<u32>(0.01 * blen);
-        const bool fullq = L.begin < offset && L.end > blen - offset;
-        t0 = sv::clock();
-        if (!fullq) poa_subgraph_marks(g, nnq, A.nmax, L.begin, L.end);
-        t_sub += sv::clock() - t0;
-        if (q == q2) {
-          act = true;
-          full = fullq;
-          len = L.len;
-          lb = static_cast<i32>(L.begin);
-          span = static_cast<i32>(L.end) - static_cast<i32>(L.begin) + 1;
-          Lp = A.layers + wq.layer_first + liq;
-          li = liq;
-        }
+    const Poa4Slot sl2 = poa4_carve(poa4_slot_of(A, wave, q2), A.nmax, A.lmax);
+    Poa2Slot g = sl2.g;
+    Poa4Group& Sg = S.g[q2];
+    // the layer's codes: bytes first, then 16 to a word (kept in the window's scratch for the graph update as well)
+    for (u32 i = lane; i < L.len; i += 64) {
+      Sg.u.bytes[i] = static_cast<u8>(poa_layer_code(A.src, L, i));
+      g.pos_node[i] = static_cast<u16>(kNone4);
+    }
+    lds_order();
+    for (u32 wd = lane; wd < 60; wd += 64) {
+      u32 x = 0;
+      for (u32 c = 0; c < 16; ++c) {
+        const i32 p = static_cast<i32>(wd * 16 + c) - 1;
+        if (p >= 0 && p < static_cast<i32>(L.len)) x |= static_cast<u32>(Sg.u.bytes[p] & 3u) << (2 * c);
       }
-      if (!sv::any(act)) break;
+      Sg.seq2[wd] = x;
+      sl2.seq2g[wd] = x;
+    }
+    const u32 blen = A.layers[wq.layer_first].len;
+    const u32 offset = static_cast<u32>(0.01 * blen);
+    const bool fullq = L.begin < offset && L.end > blen - offset;
+    if (!fullq) poa_subgraph_marks(g, nnq, A.nmax, L.begin, L.end);
+    if (q == q2) {
+      act = true;
+      full = fullq;
+      len = L.len;
+      lb = static_cast<i32>(L.begin);
+      span = static_cast<i32>(L.end) - static_cast<i32>(L.begin) + 1;
+      Lp = A.layers + wq.layer_first + liq;
+      li = liq;
+    }
+  }
+  sv::sync();
+  unsigned long long t_set = sv::clock() - t0;
+  t0 = sv::clock();
+  u32 r_lo = 0, n_rows = 0, t_end = 0, flag = 0, marked_rows = 0;
+  if (sv::any(act)) {
+    poa4_prepass<K>(A, S, poa4_slot_of(A, wave, q), act, me.nn, full, me.flip != 0, Lp, len, lb, span, r_lo, n_rows, t_end, flag,
+                    marked_rows);
+    if ((lane & (GS - 1)) == 0 && act && A.phase_cycles) {
+      sv::atomic_add(&A.phase_cycles[6], static_cast<unsigned long long>(marked_rows) * len);
+      sv::atomic_add(&A.phase_cycles[7], static_cast<unsigned long long>(marked_rows) * (len + 1 < 32u ? len + 1 : 32u));
+    }
+    if (act && flag) {  // beyond this kernel's limits (in-degree, in-edge length, band step): the 64-column kernel's job
+      phase = kFailed;
+      status = kPoaBandHit | (li << 8);
+      act = false;
+    }
+  }
+  if (my_rec != 0xFFFFFFFFu && (lane & (GS - 1)) == 0) {
+    me.phase = phase;
+    me.status = status;
+    me.li = li;
+    me.act = act ? 1u : 0u;
+    me.full = full ? 1u : 0u;
+    me.len = len;
+    me.lb = static_cast<u32>(lb);
+    me.span = static_cast<u32>(span);
+    me.r_lo = r_lo;
+    me.n_rows = n_rows;
+    me.t_end = t_end;
+    me.best_rho1 = 0;
+    C.st[my_rec] = me;
+  }
+  if (A.phase_cycles && lane == 0) {
+    sv::atomic_add(&A.phase_cycles[0], t_set + (sv::clock() - t0));
+    sv::atomic_add(&A.phase_cycles[10], sv::clock() - t0);
+    sv::atomic_add(&A.phase_cycles[15], t_set);
+  }
+}
+
+// phase B: the NW
+template <class K>
+__host__ __device__ inline void poa4_phase_dp(const Poa4Args& A, const Poa4Ctx& C, Poa4Lds& S, u32 wave) {
+  const int lane = sv::lane();
+  const int q = lane / K::GS;
+  const unsigned long long t0 = sv::clock();
+  const u32 my_rec = poa4_my_record(C, wave, q);
+  u32 act = 0, t_end = 0, len = 0, li = 0;
+  if (my_rec != 0xFFFFFFFFu) {
+    const Poa4Win& w = C.st[my_rec];
+    act = (w.phase == kRunning && w.act) ? 1u : 0u;
+    t_end = w.t_end;
+    len = w.len;
+    li = w.li;
+  }
+  if (!sv::any(act != 0)) return;
+  u32 best_rho1 = 0;
+  poa4_dp<K>(A, S, poa4_slot_of(A, wave, q), act != 0, t_end, len, best_rho1);
+  if (act && (lane & (K::GS - 1)) == 0) {
+    Poa4Win& w = C.st[my_rec];
+    w.best_rho1 = best_rho1;
+    if (best_rho1 == 0) {  // the last column is in no end node's band
+      w.phase = kFailed;
+      w.status = kPoaBandHit | (li << 8);
+      w.act = 0;
+    }
+  }
+  if (A.phase_cycles && lane == 0) sv::atomic_add(&A.phase_cycles[1], sv::clock() - t0);
+}
+
+// phase C: the traceback
+template <class K>
+__host__ __device__ inline void poa4_phase_tb(const Poa4Args& A, const Poa4Ctx& C, Poa4Lds& S, u32 wave) {
+  const int lane = sv::lane();
+  const int q = lane / K::GS;
+  const unsigned long long t0 = sv::clock();
+  const u32 my_rec = poa4_my_record(C, wave, q);
+  u32 act = 0, r_lo = 0, n_rows = 0, full = 0, len = 0, best = 0, li = 0;
+  if (my_rec != 0xFFFFFFFFu) {
+    const Poa4Win& w = C.st[my_rec];
+    act = (w.phase == kRunning && w.act) ? 1u : 0u;
+    r_lo = w.r_lo;
+    n_rows = w.n_rows;
+    full = w.full;
+    len = w.len;
+    best = w.best_rho1;
+    li = w.li;
+  }
+  if (!sv::any(act != 0)) return;
+  u32 bad = 0, band_hit = 0;
+  poa4_traceback<K>(A, S, poa4_slot_of(A, wave, q), act != 0, r_lo, n_rows, full != 0, len, best, bad, band_hit);
+  if (act && (bad || band_hit) && (lane & (K::GS - 1)) == 0) {
+    Poa4Win& w = C.st[my_rec];
+    w.phase = kFailed;
+    w.status = (bad ? bad : kPoaBandHit) | (li << 8);
+    w.act = 0;
+  }
+  if (A.phase_cycles && lane == 0) sv::atomic_add(&A.phase_cycles[2], sv::clock() - t0);
+}
+
+// phase D: the graph update
+template <class K>
+__host__ __device__ inline void poa4_phase_update(const Poa4Args& A, const Poa4Ctx& C, Poa4Lds& S, u32 wave) {
+  const int lane = sv::lane();
+  const int q = lane / K::GS, gl = lane & (K::GS - 1);
+  const u32 my_rec = poa4_my_record(C, wave, q);
+  Poa4Win me{};
+  if (my_rec != 0xFFFFFFFFu) me = C.st[my_rec];
+  const bool act = me.phase == kRunning && me.act != 0;
+  if (!sv::any(me.phase == kRunning)) return;
+  unsigned char* const my_slot = poa4_slot_of(A, wave, q);
+  if (act) {  // the layer's packed codes back into LDS
+    const u32* src = poa4_carve(my_slot, A.nmax, A.lmax).seq2g;
+    for (u32 wd = static_cast<u32>(gl); wd < 60; wd += 16) S.g[q].seq2[wd] = src[wd];
+  }
+  lds_order();
+  unsigned long long t_add = 0, t_ord = 0;
+  u32 nn = me.nn;
+  bool flip = me.flip != 0;
+  const PoaLayer* Lp = A.layers;
+  if (act) Lp = A.layers + A.windows[me.wi].layer_first + me.li;
+  const u32 why = poa4_update_graph<K>(A, S, my_slot, act, Lp, me.len, me.lb, nn, flip, t_add, t_ord);
+  if (my_rec != 0xFFFFFFFFu && gl == 0 && me.phase == kRunning) {
+    if (act && why) {
+      me.phase = kFailed;
+      me.status = why;
+    } else if (act) {
+      me.nn = nn;
+      me.flip = flip ? 1u : 0u;
+    }
+    me.li = me.li + 1;  // a window without a layer in this round has found its layers exhausted or failed in phase A
+    me.act = 0;
+    C.st[my_rec] = me;
+  }
+  if (A.phase_cycles && lane == 0) {
+    sv::atomic_add(&A.phase_cycles[3], t_add);
+    sv::atomic_add(&A.phase_cycles[4], t_ord);
+  }
+}
+
+// last phase: consensus (or the backbone of a window that failed), status
+__host__ __device__ inline void poa4_phase_final(const Poa4Args& A, const Poa4Ctx& C, Poa4Lds& S, u32 wave) {
+  const int lane = sv::lane();
+  const unsigned long long t0 = sv::clock();
+  for (int q2 = 0; q2 < P4::G; ++q2) {
+    const u32 rec = poa4_my_record(C, wave, q2);
+    if (rec == 0xFFFFFFFFu) continue;
+    const Poa4Win w = C.st[rec];
+    PoaWindow wq = A.windows[w.wi];
+    u32 st = w.status;
+    if (w.phase == kFailed || w.phase == kRunning) {  // (still running: the host stopped the rounds early — never)
+      poa4_copy_backbone(A, wq, A.layers[wq.layer_first], A.out + wq.out_off, A.out_len + w.wi);
+      if (w.phase == kRunning) st = 5;
+    } else if (w.phase == kLayersDone) {
+      Poa2Slot g = poa4_graph(poa4_slot_of(A, wave, q2), A.nmax, A.lmax, w.flip != 0);
+      wq.n_layers = w.n_eff;
+      poa4_consensus(g, w.nn, A.nmax, wq, A.trim, S, A.out + wq.out_off, A.out_len + w.wi);
       sv::sync();
-      t_set += sv::clock() - t1;
-      t0 = sv::clock();
-      u32 r_lo = 0, n_rows = 0, t_end = 0, flag = 0, marked_rows = 0;
-      poa4_prepass<K>(A, S, my_slot, act, nn, full, flip, Lp, len, lb, span, r_lo, n_rows, t_end, flag, marked_rows);
-      if ((lane & (GS - 1)) == 0 && act && A.phase_cycles) {
-        sv::atomic_add(&A.phase_cycles[6], static_cast<unsigned long long>(marked_rows) * len);
-        sv::atomic_add(&A.phase_cycles[7], static_cast<unsigned long long>(marked_rows) * (len + 1 < 32u ? len + 1 : 32u));
-      }
-#if !defined(__HIP_DEVICE_COMPILE__)
-      if (std::getenv("RVN_POA4_DEBUG") && (lane & 15) == 0 && act)
-        std::fprintf(stderr, "[poa4] group %d layer %u: nn %u r_lo %u n_rows %u t_end %u flag %u len %u full %d\n", q, li, nn, r_lo, n_rows, t_end, flag, len, int(full));
-#endif
-      const bool had = act;
-      if (act && flag) {  // beyond this kernel's limits (in-degree, in-edge length, band step): the 64-column kernel's job
-        phase = kFailed;
-        status = kPoaBandHit | (li << 8);
-        act = false;
-      }
-      sv::sync();  // descriptors visible
-      t_sub += sv::clock() - t0;
-      t_pre += sv::clock() - t0;
-      t0 = sv::clock();
-      u32 best_rho1 = 0;
-      poa4_dp<K>(A, S, my_slot, act, t_end, len, best_rho1);
-      sv::sync();  // backpointers visible to the traceback
-      t_dp += sv::clock() - t0;
-      t0 = sv::clock();
-#if !defined(__HIP_DEVICE_COMPILE__)
-      if (std::getenv("RVN_POA4_DEBUG") && (lane & 15) == 0 && act)
-        std::fprintf(stderr, "[poa4] group %d layer %u: best_rho1 %u\n", q, li, best_rho1);
-#endif
-      if (act && best_rho1 == 0) {  // the last column is in no end node's band
-        phase = kFailed;
-        status = kPoaBandHit | (li << 8);
-        act = false;
-      }
-      u32 bad = 0, band_hit = 0;
-      poa4_traceback<K>(A, S, my_slot, act, r_lo, n_rows, full, len, best_rho1, bad, band_hit);
-      if (act && bad) {
-        phase = kFailed;
-        status = bad | (li << 8);
-        act = false;
-      } else if (act && band_hit) {
-        phase = kFailed;
-        status = kPoaBandHit | (li << 8);
-        act = false;
-      }
-#if !defined(__HIP_DEVICE_COMPILE__)
-      if (std::getenv("RVN_POA4_DEBUG") && (lane & 15) == 0 && had)
-        std::fprintf(stderr, "[poa4] group %d layer %u: traceback bad %u band_hit %u\n", q, li, bad, band_hit);
-#endif
-      sv::sync();  // pos_node
-      t_tb += sv::clock() - t0;
-      {
-        const u32 why = poa4_update_graph<K>(A, S, my_slot, act, Lp, len, static_cast<u32>(lb), nn, flip, t_add, t_ord);
-        if (act && why) {
-          phase = kFailed;
-          status = why;
-        }
-      }
-      if (had) ++li;
+      st = 1;
     }
-    // ---- results ----
-    t0 = sv::clock();
-    for (int q2 = 0; q2 < kG; ++q2) {
-      const u32 ph = static_cast<u32>(sv::rl(static_cast<int>(phase), q2 * GS));
-      if (ph == kIdle) continue;
-      u32 wi2;
-      PoaWindow wq = window_of(q2, wi2);
-      u32 st = static_cast<u32>(sv::rl(static_cast<int>(status), q2 * GS));
-      if (ph == kFailed) {
-        poa4_copy_backbone(A, wq, A.layers[wq.layer_first], A.out + wq.out_off, A.out_len + wi2);
-      } else if (ph == kLayersDone) {
-        Poa2Slot g = poa4_graph(A.scratch + static_cast<size_t>(slot0 + q2) * A.slot_bytes, A.nmax, A.lmax,
-                                sv::rl(flip ? 1 : 0, q2 * GS) != 0);
-        const u32 nnq = static_cast<u32>(sv::rl(static_cast<int>(nn), q2 * GS));
-        wq.n_layers = static_cast<u32>(sv::rl(static_cast<int>(n_eff), q2 * GS));
-        sv::sync();
-        poa4_consensus(g, nnq, A.nmax, wq, A.trim, S, A.out + wq.out_off, A.out_len + wi2);
-        sv::sync();
-        st = 1;
-      }
-      if (lane == 0) A.status[wi2] = st;
-    }
-    t_cons += sv::clock() - t0;
-    sv::sync();
+    if (lane == 0) A.status[w.wi] = st;
   }
-  if (A.phase_cycles) {
-    if (lane == 0) {
-      sv::atomic_add(&A.phase_cycles[0], t_sub);
-      sv::atomic_add(&A.phase_cycles[1], t_dp);
-      sv::atomic_add(&A.phase_cycles[2], t_tb);
-      sv::atomic_add(&A.phase_cycles[3], t_add);
-      sv::atomic_add(&A.phase_cycles[4], t_ord);
-      sv::atomic_add(&A.phase_cycles[5], t_cons);
-      sv::atomic_add(&A.phase_cycles[10], t_pre);
-      sv::atomic_add(&A.phase_cycles[15], t_set);
-    }
-  }
+  if (A.phase_cycles && lane == 0) sv::atomic_add(&A.phase_cycles[5], sv::clock() - t0);
 }
 
-template <int OCC>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void poa4_kernel(const Poa4Args A, u32 n_waves) {
+// ---- kernels: one wave per workgroup, wave = blockIdx.x ------------------------------------------------------------
+__global__ __launch_bounds__(64) void poa4_init_kernel(const Poa4Args A, const Poa4Ctx C) {
+  poa4_phase_init(A, C, blockIdx.x);
+}
+__global__ __launch_bounds__(64) void poa4_layer_kernel(const Poa4Args A, const Poa4Ctx C) {
   __shared__ Poa4Lds lds;
-  if (blockIdx.x >= n_waves) return;
-  poa4_wave<P4>(A, lds, blockIdx.x * P4::G);
+  poa4_phase_layer<P4>(A, C, lds, blockIdx.x);
 }
-
-struct EmuCall4 {
-  const Poa4Args* A;
-  Poa4Lds* S;
-};
-void emu_entry4(void* p) {
-  EmuCall4* c = static_cast<EmuCall4*>(p);
-  poa4_wave<P4>(*c->A, *c->S, 0);
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void poa4_dp_kernel(const Poa4Args A, const Poa4Ctx C) {
+  __shared__ Poa4Lds lds;
+  poa4_phase_dp<P4>(A, C, lds, blockIdx.x);
+}
+__global__ __launch_bounds__(64) void poa4_tb_kernel(const Poa4Args A, const Poa4Ctx C) {
+  __shared__ Poa4Lds lds;  // (not touched: the traceback lives in registers)
+  poa4_phase_tb<P4>(A, C, lds, blockIdx.x);
+}
+__global__ __launch_bounds__(64) void poa4_update_kernel(const Poa4Args A, const Poa4Ctx C) {
+  __shared__ Poa4Lds lds;
+  poa4_phase_update<P4>(A, C, lds, blockIdx.x);
+}
+__global__ __launch_bounds__(64) void poa4_final_kernel(const Poa4Args A, const Poa4Ctx C) {
+  __shared__ Poa4Lds lds;
+  poa4_phase_final(A, C, lds, blockIdx.x);
+}
+__global__ void poa4_max_layers_kernel(const PoaWindow* __restrict__ wins, const u32* __restrict__ sched, u32 first, u32 count,
+                                       u32* __restrict__ out) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  const u32 pos = first + i;
+  atomicMax(out, wins[sched ? sched[pos] : pos].n_layers);
 }
 
 Poa4Args args_of4(const PoaBatchDev& b, unsigned char* scratch, size_t slot_bytes) {
@@ -1556,24 +1656,63 @@ void poa_v4_launch(Engine& e, const PoaBatchDev& b) {
   const size_t slot_bytes = poa4_slot_bytes(b.nmax, b.lmax);
   size_t free_b = 0, total_b = 0;
   RVN_HIP(hipMemGetInfo(&free_b, &total_b));
-  int occ = 3;  // waves per SIMD the kernel is built for (168 / 128 VGPRs)
-  if (const char* ev = std::getenv("RVN_POA4_OCC")) occ = std::atoi(ev) == 4 ? 4 : 3;
-  u32 per_cu = std::min<u32>(static_cast<u32>((160u * 1024u) / sizeof(Poa4Lds)), 4u * static_cast<u32>(occ));
-  if (const char* ev = std::getenv("RVN_POA_WAVES_PER_CU")) per_cu = static_cast<u32>(std::atoi(ev));  // occupancy experiments
-  per_cu = per_cu < 1 ? 1 : per_cu;
-  u32 n_waves = std::min<u32>((b.n_windows + P4::G - 1) / P4::G, 256 * per_cu);
+  // a chunk = the windows whose scratch fits the budget (their graphs stay resident from the first to the last round)
   const size_t budget = e.poa2_scratch.cap + free_b / 2;
-  if (static_cast<size_t>(n_waves) * P4::G * slot_bytes > budget)
-    n_waves = static_cast<u32>(std::max<size_t>(1, budget / (slot_bytes * P4::G)));
-  unsigned char* d_scratch = e.poa2_scratch.get<unsigned char>(static_cast<size_t>(n_waves) * P4::G * slot_bytes + 256);
-  RVN_HIP(hipMemsetAsync(b.next, 0, 4, e.stream));
+  size_t per_chunk = std::max<size_t>(P4::G, budget / (slot_bytes + sizeof(Poa4Win)));
+  if (const char* ev = std::getenv("RVN_POA4_CHUNK")) per_chunk = std::max<size_t>(P4::G, static_cast<size_t>(std::atoll(ev)));
+  per_chunk = std::min<size_t>(per_chunk, b.n_windows);
+  per_chunk = (per_chunk + P4::G - 1) / P4::G * P4::G;
+  unsigned char* d_scratch = e.poa2_scratch.get<unsigned char>(per_chunk * (slot_bytes + sizeof(Poa4Win)) + 512);
+  Poa4Win* d_st = reinterpret_cast<Poa4Win*>(d_scratch + per_chunk * slot_bytes + 256);
   const Poa4Args A = args_of4(b, d_scratch, slot_bytes);
-  if (occ == 4) RVN_KLAUNCH(kKPoaBanded, (poa4_kernel<4><<<n_waves, 64, 0, e.stream>>>(A, n_waves)));
-  else RVN_KLAUNCH(kKPoaBanded, (poa4_kernel<3><<<n_waves, 64, 0, e.stream>>>(A, n_waves)));
+  hipStream_t s = e.stream;
+  for (u32 first = 0; first < b.n_windows; first += static_cast<u32>(per_chunk)) {
+    const u32 count = std::min<u32>(static_cast<u32>(per_chunk), b.n_windows - first);
+    const u32 n_waves = (count + P4::G - 1) / P4::G;
+    const Poa4Ctx C{d_st, first, count};
+    // rounds = the most layers a window of the chunk has (one layer per round at most)
+    u32 max_layers = 0;
+    RVN_HIP(hipMemsetAsync(b.next, 0, 4, s));
+    poa4_max_layers_kernel<<<div_up(count, 256), 256, 0, s>>>(b.wins, b.sched, first, count, b.next);
+    RVN_LAUNCH_CHECK();
+    RVN_HIP(hipMemcpyAsync(&max_layers, b.next, 4, hipMemcpyDeviceToHost, s));
+    RVN_HIP(rvn_stream_sync(s));
+    RVN_KLAUNCH(kKPoaBanded, (poa4_init_kernel<<<n_waves, 64, 0, s>>>(A, C)));
+    for (u32 round = 1; round < max_layers; ++round) {
+      RVN_KLAUNCH(kKPoaBanded, (poa4_layer_kernel<<<n_waves, 64, 0, s>>>(A, C)));
+      RVN_KLAUNCH(kKPoaBanded, (poa4_dp_kernel<<<n_waves, 64, 0, s>>>(A, C)));
+      RVN_KLAUNCH(kKPoaBanded, (poa4_tb_kernel<<<n_waves, 64, 0, s>>>(A, C)));
+      RVN_KLAUNCH(kKPoaBanded, (poa4_update_kernel<<<n_waves, 64, 0, s>>>(A, C)));
+    }
+    RVN_KLAUNCH(kKPoaBanded, (poa4_layer_kernel<<<n_waves, 64, 0, s>>>(A, C)));  // every window finds its layers exhausted
+    RVN_KLAUNCH(kKPoaBanded, (poa4_final_kernel<<<n_waves, 64, 0, s>>>(A, C)));
+  }
 }
 
-// The same kernel source on the host, one emulated wave (simt_emu): windows / layers / sources are host arrays.  TEST
-// INFRASTRUCTURE (rvn_poa_banded_emulate); first attempt only — a window that needs a wider band comes back flagged.
+// The same phase functions on the host, wave by wave under the wavefront emulator (simt_emu): windows / layers /
+// sources are host arrays.  TEST INFRASTRUCTURE (rvn_poa_banded_emulate); first attempt only — a window that needs a
+// wider band comes back flagged.
+namespace {
+struct EmuCall4 {
+  const Poa4Args* A;
+  const Poa4Ctx* C;
+  Poa4Lds* S;
+  u32 wave;
+  int phase;
+};
+void emu_entry4(void* p) {
+  EmuCall4* c = static_cast<EmuCall4*>(p);
+  switch (c->phase) {
+    case 0: poa4_phase_init(*c->A, *c->C, c->wave); break;
+    case 1: poa4_phase_layer<P4>(*c->A, *c->C, *c->S, c->wave); break;
+    case 2: poa4_phase_dp<P4>(*c->A, *c->C, *c->S, c->wave); break;
+    case 3: poa4_phase_tb<P4>(*c->A, *c->C, *c->S, c->wave); break;
+    case 4: poa4_phase_update<P4>(*c->A, *c->C, *c->S, c->wave); break;
+    default: poa4_phase_final(*c->A, *c->C, *c->S, c->wave); break;
+  }
+}
+}  // namespace
+
 void poa_v4_emulate(const std::vector<PoaWindow>& wins, const std::vector<PoaLayer>& lays, const PoaSrc& src, u32 max_bb,
                     u32 max_len, int m, int n, int g, int trim, u8* out, u32* out_len, u32* status) {
   if (wins.empty()) return;
@@ -1581,11 +1720,14 @@ void poa_v4_emulate(const std::vector<PoaWindow>& wins, const std::vector<PoaLay
   b.lmax = std::min<u32>(kPoaMaxSeq, std::max<u32>(64, ((max_len + 63) / 64) * 64));
   b.nmax = std::min<u32>(8192, std::max<u32>(512, max_bb * 6));
   const size_t slot_bytes = poa4_slot_bytes(b.nmax, b.lmax);
-  std::vector<unsigned char> scratch(slot_bytes * P4::G + 256, 0);
+  const u32 count = static_cast<u32>(wins.size());
+  const u32 n_waves = (count + P4::G - 1) / P4::G;
+  std::vector<unsigned char> scratch(slot_bytes * n_waves * P4::G + 256, 0);
+  std::vector<Poa4Win> st(static_cast<size_t>(n_waves) * P4::G);
   unsigned long long phase[16] = {};
   u32 next = 0;
   b.wins = wins.data();
-  b.n_windows = static_cast<u32>(wins.size());
+  b.n_windows = count;
   b.layers = lays.data();
   b.src = src;
   b.m = m;
@@ -1599,10 +1741,26 @@ void poa_v4_emulate(const std::vector<PoaWindow>& wins, const std::vector<PoaLay
   b.sched = nullptr;
   b.next = &next;
   const Poa4Args A = args_of4(b, scratch.data(), slot_bytes);
+  const Poa4Ctx C{st.data(), 0, count};
   std::vector<Poa4Lds> lds(1);
-  std::memset(static_cast<void*>(lds.data()), 0, sizeof(Poa4Lds));
-  EmuCall4 call{&A, lds.data()};
-  simt_emu::run_wave(&emu_entry4, &call);
+  u32 max_layers = 0;
+  for (const PoaWindow& w : wins) max_layers = std::max(max_layers, w.n_layers);
+  auto run = [&](int ph) {
+    for (u32 wv = 0; wv < n_waves; ++wv) {
+      std::memset(static_cast<void*>(lds.data()), 0, sizeof(Poa4Lds));  // (a fresh workgroup's LDS holds anything: zeros here)
+      EmuCall4 call{&A, &C, lds.data(), wv, ph};
+      simt_emu::run_wave(&emu_entry4, &call);
+    }
+  };
+  run(0);
+  for (u32 round = 1; round < max_layers; ++round) {
+    run(1);
+    run(2);
+    run(3);
+    run(4);
+  }
+  run(1);
+  run(5);
 }
 
 }  // namespace rvn
