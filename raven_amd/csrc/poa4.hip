@@ -41,8 +41,8 @@ namespace {
 struct P4 {
   static constexpr int G = 4, GS = 16, kBand = 32;
   static constexpr int kRing = 24;    // score rows a window keeps in LDS = longest in-edge (in ranks) + 1
-  static constexpr int kRowB = 104;   // bytes per ring row: 2 -inf cells | 32 cells | 18 -inf cells
-  static constexpr int kMaxD = 16;    // largest band-start difference along an in-edge (the right pads cover it)
+  static constexpr int kRowB = 88;    // bytes per ring row: 2 -inf cells | 32 cells | 10 -inf cells
+  static constexpr int kMaxD = 8;     // largest band-start difference along an in-edge (the right pads cover it)
   static constexpr int kEdges = 8;    // in-edges a row descriptor holds; a row with more sends the window to poa2
   static constexpr int kU = 8;        // steps between two service points (descriptor prefetch, backpointer store)
 };
@@ -51,20 +51,30 @@ constexpr i32 kNegKey = kNegInf16 * 64;
 constexpr i32 kNegU = -0x30000000;
 constexpr u32 kInactiveS = 0x7FFFu;
 
-struct alignas(16) Poa4Group {
+template <int kRingBytes>
+struct alignas(16) Poa4GroupT {
   union {
-    u32 ring32[P4::kRing * P4::kRowB / 4];  // DP: [kRing][2 pads | 32 cells | 18 pads] int16, slot = rho % kRing
-    u8 bytes[kPoa2MaxSeq + 16];          // layer set-up: one-byte codes before they are packed
-    u32 segtab[32];                      // pre-pass: the layer's band guide, {x0, wa, wb - wa, magic(x1 - x0)} per segment
+    u32 ring32[kRingBytes / 4];  // DP: [kRing][2 pads | 32 cells | kMaxD + 2 pads] int16, slot = rho % kRing; graph update: the
+                                 // new nodes' order slots (u16)
+    u8 bytes[kPoa2MaxSeq + 16];  // layer set-up: one-byte codes before they are packed
+    u32 segtab[32];              // pre-pass: the layer's band guide, {x0, wa, wb - wa, magic(x1 - x0)} per segment
   } u;
   u32 seq2[60];  // the layer, 2 bits per base, position p at bits 2 (p + 1): column j's base sits at bit 2 j
   u32 dump[16];  // where rows outside the layer's subgraph leave their cells
 };
-struct alignas(16) Poa4Lds {
-  Poa4Group g[P4::G];
+template <int kRingBytes>
+struct alignas(16) Poa4LdsT {
+  Poa4GroupT<kRingBytes> g[P4::G];
   u32 neg[20];  // -inf cells: what a descriptor's unused in-edges point at
 };
-static_assert(sizeof(Poa4Lds) <= 11520, "fourteen waves per CU need <= 11.4 KB of LDS each");
+// every phase is its own kernel and takes the LDS it needs (occupancy): the NW the score ring, the graph update room for
+// 896 order slots, the set-up + descriptor pass the layer's bytes
+using Poa4Group = Poa4GroupT<P4::kRing * P4::kRowB>;
+using Poa4Lds = Poa4LdsT<P4::kRing * P4::kRowB>;
+using Poa4LdsUpdate = Poa4LdsT<kPoa2MaxSeq * 2>;
+using Poa4LdsLayer = Poa4LdsT<kPoa2MaxSeq + 32>;
+static_assert(sizeof(Poa4Lds) <= 10240, "sixteen waves per CU need <= 10 KB of LDS each");
+static_assert(P4::kRowB == 68 + 2 * (P4::kMaxD + 2), "ring row = 2 pads + 32 cells + kMaxD + 2 pads");
 
 struct Poa4Args {
   const PoaWindow* windows;
@@ -257,8 +267,8 @@ __host__ __device__ __forceinline__ u32 mulhi_u32(u32 a, u32 b) {
 __host__ __device__ __forceinline__ u32 magic_of(u32 d) { return d <= 1 ? 0u : static_cast<u32>(0x100000000ULL / d) + 1u; }
 __host__ __device__ __forceinline__ u32 div_magic(u32 n, u32 m) { return m ? mulhi_u32(n, m) : n; }
 
-template <class K>
-__host__ __device__ inline void poa4_prepass(const Poa4Args A, Poa4Lds& S, unsigned char* slot_mem, bool act, u32 nn, bool full,
+template <class K, class LT>
+__host__ __device__ inline void poa4_prepass(const Poa4Args A, LT& S, unsigned char* slot_mem, bool act, u32 nn, bool full,
                                              bool flip, const PoaLayer* Lp, u32 len, i32 lb, i32 span, u32& r_lo_out,
                                              u32& n_rows_out, u32& t_end_out, u32& flag_out, u32& marked_out) {
   P4_ASSUME_GLOBAL(slot_mem);
@@ -268,7 +278,7 @@ __host__ __device__ inline void poa4_prepass(const Poa4Args A, Poa4Lds& S, unsig
   const int gl = lane & 15, gbase = lane & ~15, q = lane >> 4;
   const Poa4Slot sl = poa4_carve(slot_mem, A.nmax, A.lmax);
   const Poa2Slot& g = sl.g;
-  Poa4Group& Sg = S.g[q];
+  auto& Sg = S.g[q];
   const u32 w = len + 1;
   // ---- the layer's band guide as eight segments {x0, wa, wb - wa, magic(x1 - x0)} in LDS ----
   if (act && gl < 8) {
@@ -487,8 +497,9 @@ __host__ __device__ inline void poa4_dp(const Poa4Args A, Poa4Lds& S, unsigned c
   // -inf pads of the ring rows (the union is reused by the layer set-up and by the traceback), the wave's -inf cells
   {
     const u32 neg = pack16(kNegInf16, kNegInf16);
-    for (int idx = gl; idx < K::kRing * 10; idx += 16) {
-      const int rr = idx / 10, cc = idx % 10;
+    constexpr int kPadW = 1 + (K::kRowB - 68) / 4;  // words of -inf per ring row: one in front, the rest behind the cells
+    for (int idx = gl; idx < K::kRing * kPadW; idx += 16) {
+      const int rr = idx / kPadW, cc = idx % kPadW;
       lds_st32(S, ring_off + static_cast<u32>(rr * K::kRowB + (cc == 0 ? 0 : 64 + 4 * cc)), neg);
     }
     if (lane < 20) S.neg[lane] = neg;
@@ -698,10 +709,9 @@ __host__ __device__ inline void poa4_dp(const Poa4Args A, Poa4Lds& S, unsigned c
 // counter is the wave's, not the window's).
 constexpr int kTbG = 2;
 template <class K>
-__host__ __device__ inline void poa4_traceback(const Poa4Args A, Poa4Lds& S, unsigned char* slot_mem, bool act, u32 r_lo,
-                                               u32 n_rows, bool full, u32 len, u32 best_rho1, u32& bad, u32& band_hit) {
+__host__ __device__ inline void poa4_traceback(const Poa4Args A, unsigned char* slot_mem, bool act, u32 r_lo, u32 n_rows,
+                                               bool full, u32 len, u32 best_rho1, u32& bad, u32& band_hit) {
   P4_ASSUME_GLOBAL(slot_mem);
-  (void)S;
   (void)n_rows;
   const int lane = sv::lane();
   const int gl = lane & 15, gbase = lane & ~15;
@@ -717,12 +727,14 @@ __host__ __device__ inline void poa4_traceback(const Poa4Args A, Poa4Lds& S, uns
   bool done = !act || i == 0;
   u32 steps = 0, n_switch = 0;
   const u32 max_steps = A.nmax + A.lmax + 2;
-  // slot h of a round = block kTbG * round + h
+  // slot h of a round = block kTbG * round + h.  Three sets: the current round (written only by moves, so its uses in
+  // the walk wait for nothing), the next round (descriptors and codes in flight), the round after (descriptors in
+  // flight: the codes' addresses come out of them)
   u32 cd0[kTbG] = {}, cd1[kTbG] = {}, cd7[kTbG] = {}, nd0[kTbG] = {}, nd1[kTbG] = {}, nd7[kTbG] = {};
+  u32 fd0[kTbG] = {}, fd1[kTbG] = {}, fd7[kTbG] = {};
   uint4 ca[kTbG] = {}, cb[kTbG] = {}, cc[kTbG] = {}, na[kTbG] = {}, nb[kTbG] = {}, nc[kTbG] = {};
-  u32 c_rnd = 0xFFFFFFFFu, n_rnd = 0xFFFFFFFFu;  // rounds the two sets hold
-  auto load_round = [&](u32 rnd, u32 (&d0)[kTbG], u32 (&d1)[kTbG], u32 (&d7)[kTbG], uint4 (&a)[kTbG], uint4 (&b)[kTbG],
-                        uint4 (&c)[kTbG]) {
+  u32 c_rnd = 0xFFFFFFFFu, n_rnd = 0xFFFFFFFFu, f_rnd = 0xFFFFFFFFu;  // rounds the sets hold
+  auto load_desc = [&](u32 rnd, u32 (&d0)[kTbG], u32 (&d1)[kTbG], u32 (&d7)[kTbG]) {
 #pragma unroll
     for (int h = 0; h < kTbG; ++h) {
       const size_t rho = (static_cast<size_t>(rnd) * kTbG + h) * 16 + static_cast<size_t>(gl);
@@ -731,6 +743,8 @@ __host__ __device__ inline void poa4_traceback(const Poa4Args A, Poa4Lds& S, uns
       d1[h] = da.y;
       d7[h] = dsc[2 * rho + 1].w;
     }
+  };
+  auto load_codes = [&](const u32 (&d0)[kTbG], uint4 (&a)[kTbG], uint4 (&b)[kTbG], uint4 (&c)[kTbG]) {
 #pragma unroll
     for (int h = 0; h < kTbG; ++h) {
       const u32 s = d0[h] & 0xFFFFu;
@@ -746,8 +760,11 @@ __host__ __device__ inline void poa4_traceback(const Poa4Args A, Poa4Lds& S, uns
     const u32 rnd = done ? c_rnd : (i - 1) / (16 * kTbG);
     if (!done && rnd != c_rnd) {
       ++n_switch;
-      // (the current set is only ever written by these moves, never by a load: its uses in the walk need no wait)
-      if (rnd != n_rnd) load_round(rnd, nd0, nd1, nd7, na, nb, nc);
+      if (rnd != n_rnd) {  // the first round of the walk (or a jump the sets do not cover): both levels right here
+        load_desc(rnd, nd0, nd1, nd7);
+        load_codes(nd0, na, nb, nc);
+        f_rnd = 0xFFFFFFFFu;
+      }
 #pragma unroll
       for (int h = 0; h < kTbG; ++h) {
         cd0[h] = nd0[h];
@@ -759,10 +776,26 @@ __host__ __device__ inline void poa4_traceback(const Poa4Args A, Poa4Lds& S, uns
       }
       c_rnd = rnd;
       if (rnd >= 1) {
-        load_round(rnd - 1, nd0, nd1, nd7, na, nb, nc);
+        if (f_rnd == rnd - 1) {
+#pragma unroll
+          for (int h = 0; h < kTbG; ++h) {
+            nd0[h] = fd0[h];
+            nd1[h] = fd1[h];
+            nd7[h] = fd7[h];
+          }
+        } else {
+          load_desc(rnd - 1, nd0, nd1, nd7);
+        }
+        load_codes(nd0, na, nb, nc);
         n_rnd = rnd - 1;
       } else {
         n_rnd = 0xFFFFFFFFu;
+      }
+      if (rnd >= 2) {
+        load_desc(rnd - 2, fd0, fd1, fd7);
+        f_rnd = rnd - 2;
+      } else {
+        f_rnd = 0xFFFFFFFFu;
       }
     }
     // ---- the round's blocks, top down ----
@@ -904,7 +937,8 @@ __host__ __device__ inline u32 poa4_init_window(const Poa4Args& A, const PoaWind
   return 1;
 }
 
-__host__ __device__ __forceinline__ u32 poa4_letter(const Poa4Group& Sg, u32 p) {
+template <class GT>
+__host__ __device__ __forceinline__ u32 poa4_letter(const GT& Sg, u32 p) {
   return (Sg.seq2[(p + 1) >> 4] >> (2 * ((p + 1) & 15u))) & 3u;
 }
 
@@ -943,8 +977,8 @@ __host__ __device__ __forceinline__ void atomic_inc_u16(u16* base, u32 idx) {  /
 #endif
 }
 
-template <class K>
-__host__ __device__ inline u32 poa4_update_graph(const Poa4Args A, Poa4Lds& S, unsigned char* slot_mem, bool act,
+template <class K, class LT>
+__host__ __device__ inline u32 poa4_update_graph(const Poa4Args A, LT& S, unsigned char* slot_mem, bool act,
                                                  const PoaLayer* Lp, u32 len, u32 lb, u32& nn, bool& flip,
                                                  unsigned long long& t_add, unsigned long long& t_ord) {
   P4_ASSUME_GLOBAL(slot_mem);
@@ -952,7 +986,7 @@ __host__ __device__ inline u32 poa4_update_graph(const Poa4Args A, Poa4Lds& S, u
   P4_ASSUME_LDS(&S);
   const int lane = sv::lane();
   const int gl = lane & 15, gbase = lane & ~15, q = lane >> 4;
-  Poa4Group& Sg = S.g[q];
+  auto& Sg = S.g[q];
   u16* nslot = reinterpret_cast<u16*>(Sg.u.ring32);  // order slots of the new nodes (<= 896 of them; the ring holds 1248)
   const Poa2Slot g = poa4_graph(slot_mem, A.nmax, A.lmax, flip);
   u16* const rb16 = reinterpret_cast<u16*>(poa4_carve(slot_mem, A.nmax, A.lmax).rb);  // [2 v] rank, [2 v + 1] backbone coordinate
@@ -1362,8 +1396,8 @@ __host__ __device__ inline void poa4_phase_init(const Poa4Args& A, const Poa4Ctx
 
 // phase A of a round: the next layer of every window (codes packed into the window's seq2, subgraph marks), then the
 // row descriptors of the four windows side by side
-template <class K>
-__host__ __device__ inline void poa4_phase_layer(const Poa4Args& A, const Poa4Ctx& C, Poa4Lds& S, u32 wave) {
+template <class K, class LT>
+__host__ __device__ inline void poa4_phase_layer(const Poa4Args& A, const Poa4Ctx& C, LT& S, u32 wave) {
   constexpr int GS = K::GS;
   const int lane = sv::lane();
   const int q = lane / GS;
@@ -1400,7 +1434,7 @@ __host__ __device__ inline void poa4_phase_layer(const Poa4Args& A, const Poa4Ct
     }
     const Poa4Slot sl2 = poa4_carve(poa4_slot_of(A, wave, q2), A.nmax, A.lmax);
     Poa2Slot g = sl2.g;
-    Poa4Group& Sg = S.g[q2];
+    auto& Sg = S.g[q2];
     // the layer's codes: bytes first, then 16 to a word (kept in the window's scratch for the graph update as well)
     for (u32 i = lane; i < L.len; i += 64) {
       Sg.u.bytes[i] = static_cast<u8>(poa_layer_code(A.src, L, i));
@@ -1435,7 +1469,7 @@ __host__ __device__ inline void poa4_phase_layer(const Poa4Args& A, const Poa4Ct
   t0 = sv::clock();
   u32 r_lo = 0, n_rows = 0, t_end = 0, flag = 0, marked_rows = 0;
   if (sv::any(act)) {
-    poa4_prepass<K>(A, S, poa4_slot_of(A, wave, q), act, me.nn, full, me.flip != 0, Lp, len, lb, span, r_lo, n_rows, t_end, flag,
+    poa4_prepass<K, LT>(A, S, poa4_slot_of(A, wave, q), act, me.nn, full, me.flip != 0, Lp, len, lb, span, r_lo, n_rows, t_end, flag,
                     marked_rows);
     if ((lane & (GS - 1)) == 0 && act && A.phase_cycles) {
       sv::atomic_add(&A.phase_cycles[6], static_cast<unsigned long long>(marked_rows) * len);
@@ -1501,7 +1535,7 @@ __host__ __device__ inline void poa4_phase_dp(const Poa4Args& A, const Poa4Ctx& 
 
 // phase C: the traceback
 template <class K>
-__host__ __device__ inline void poa4_phase_tb(const Poa4Args& A, const Poa4Ctx& C, Poa4Lds& S, u32 wave) {
+__host__ __device__ inline void poa4_phase_tb(const Poa4Args& A, const Poa4Ctx& C, u32 wave) {
   const int lane = sv::lane();
   const int q = lane / K::GS;
   const unsigned long long t0 = sv::clock();
@@ -1519,7 +1553,7 @@ __host__ __device__ inline void poa4_phase_tb(const Poa4Args& A, const Poa4Ctx& 
   }
   if (!sv::any(act != 0)) return;
   u32 bad = 0, band_hit = 0;
-  poa4_traceback<K>(A, S, poa4_slot_of(A, wave, q), act != 0, r_lo, n_rows, full != 0, len, best, bad, band_hit);
+  poa4_traceback<K>(A, poa4_slot_of(A, wave, q), act != 0, r_lo, n_rows, full != 0, len, best, bad, band_hit);
   if (act && (bad || band_hit) && (lane & (K::GS - 1)) == 0) {
     Poa4Win& w = C.st[my_rec];
     w.phase = kFailed;
@@ -1530,8 +1564,8 @@ __host__ __device__ inline void poa4_phase_tb(const Poa4Args& A, const Poa4Ctx& 
 }
 
 // phase D: the graph update
-template <class K>
-__host__ __device__ inline void poa4_phase_update(const Poa4Args& A, const Poa4Ctx& C, Poa4Lds& S, u32 wave) {
+template <class K, class LT>
+__host__ __device__ inline void poa4_phase_update(const Poa4Args& A, const Poa4Ctx& C, LT& S, u32 wave) {
   const int lane = sv::lane();
   const int q = lane / K::GS, gl = lane & (K::GS - 1);
   const u32 my_rec = poa4_my_record(C, wave, q);
@@ -1550,7 +1584,7 @@ __host__ __device__ inline void poa4_phase_update(const Poa4Args& A, const Poa4C
   bool flip = me.flip != 0;
   const PoaLayer* Lp = A.layers;
   if (act) Lp = A.layers + A.windows[me.wi].layer_first + me.li;
-  const u32 why = poa4_update_graph<K>(A, S, my_slot, act, Lp, me.len, me.lb, nn, flip, t_add, t_ord);
+  const u32 why = poa4_update_graph<K, LT>(A, S, my_slot, act, Lp, me.len, me.lb, nn, flip, t_add, t_ord);
   if (my_rec != 0xFFFFFFFFu && gl == 0 && me.phase == kRunning) {
     if (act && why) {
       me.phase = kFailed;
@@ -1599,20 +1633,19 @@ __global__ __launch_bounds__(64) void poa4_init_kernel(const Poa4Args A, const P
   poa4_phase_init(A, C, blockIdx.x);
 }
 __global__ __launch_bounds__(64) void poa4_layer_kernel(const Poa4Args A, const Poa4Ctx C) {
-  __shared__ Poa4Lds lds;
-  poa4_phase_layer<P4>(A, C, lds, blockIdx.x);
+  __shared__ Poa4LdsLayer lds;
+  poa4_phase_layer<P4, Poa4LdsLayer>(A, C, lds, blockIdx.x);
 }
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void poa4_dp_kernel(const Poa4Args A, const Poa4Ctx C) {
   __shared__ Poa4Lds lds;
   poa4_phase_dp<P4>(A, C, lds, blockIdx.x);
 }
 __global__ __launch_bounds__(64) void poa4_tb_kernel(const Poa4Args A, const Poa4Ctx C) {
-  __shared__ Poa4Lds lds;  // (not touched: the traceback lives in registers)
-  poa4_phase_tb<P4>(A, C, lds, blockIdx.x);
+  poa4_phase_tb<P4>(A, C, blockIdx.x);  // (no LDS: the traceback lives in registers)
 }
 __global__ __launch_bounds__(64) void poa4_update_kernel(const Poa4Args A, const Poa4Ctx C) {
-  __shared__ Poa4Lds lds;
-  poa4_phase_update<P4>(A, C, lds, blockIdx.x);
+  __shared__ Poa4LdsUpdate lds;
+  poa4_phase_update<P4, Poa4LdsUpdate>(A, C, lds, blockIdx.x);
 }
 __global__ __launch_bounds__(64) void poa4_final_kernel(const Poa4Args A, const Poa4Ctx C) {
   __shared__ Poa4Lds lds;
@@ -1697,6 +1730,8 @@ struct EmuCall4 {
   const Poa4Args* A;
   const Poa4Ctx* C;
   Poa4Lds* S;
+  Poa4LdsLayer* SL;
+  Poa4LdsUpdate* SU;
   u32 wave;
   int phase;
 };
@@ -1704,10 +1739,10 @@ void emu_entry4(void* p) {
   EmuCall4* c = static_cast<EmuCall4*>(p);
   switch (c->phase) {
     case 0: poa4_phase_init(*c->A, *c->C, c->wave); break;
-    case 1: poa4_phase_layer<P4>(*c->A, *c->C, *c->S, c->wave); break;
+    case 1: poa4_phase_layer<P4, Poa4LdsLayer>(*c->A, *c->C, *c->SL, c->wave); break;
     case 2: poa4_phase_dp<P4>(*c->A, *c->C, *c->S, c->wave); break;
-    case 3: poa4_phase_tb<P4>(*c->A, *c->C, *c->S, c->wave); break;
-    case 4: poa4_phase_update<P4>(*c->A, *c->C, *c->S, c->wave); break;
+    case 3: poa4_phase_tb<P4>(*c->A, *c->C, c->wave); break;
+    case 4: poa4_phase_update<P4, Poa4LdsUpdate>(*c->A, *c->C, *c->SU, c->wave); break;
     default: poa4_phase_final(*c->A, *c->C, *c->S, c->wave); break;
   }
 }
@@ -1743,12 +1778,16 @@ void poa_v4_emulate(const std::vector<PoaWindow>& wins, const std::vector<PoaLay
   const Poa4Args A = args_of4(b, scratch.data(), slot_bytes);
   const Poa4Ctx C{st.data(), 0, count};
   std::vector<Poa4Lds> lds(1);
+  std::vector<Poa4LdsLayer> ldsl(1);
+  std::vector<Poa4LdsUpdate> ldsu(1);
   u32 max_layers = 0;
   for (const PoaWindow& w : wins) max_layers = std::max(max_layers, w.n_layers);
   auto run = [&](int ph) {
     for (u32 wv = 0; wv < n_waves; ++wv) {
       std::memset(static_cast<void*>(lds.data()), 0, sizeof(Poa4Lds));  // (a fresh workgroup's LDS holds anything: zeros here)
-      EmuCall4 call{&A, &C, lds.data(), wv, ph};
+      std::memset(static_cast<void*>(ldsl.data()), 0, sizeof(Poa4LdsLayer));
+      std::memset(static_cast<void*>(ldsu.data()), 0, sizeof(Poa4LdsUpdate));
+      EmuCall4 call{&A, &C, lds.data(), ldsl.data(), ldsu.data(), wv, ph};
       simt_emu::run_wave(&emu_entry4, &call);
     }
   };
