@@ -699,22 +699,26 @@ __host__ __device__ inline void poa4_dp(const Poa4Args A, Poa4Lds& S, unsigned c
 }
 
 // ---- traceback of the wave's windows, round-synchronous -------------------------------------------------------------
-// A round = every window walks through kTbG blocks of 16 rows; lane l of a window holds row 16 * block + l of each of
-// them in registers: three descriptor words and the 48 bytes of the backpointer stream that hold the row's 32 codes
-// (its 16 steps lie in at most three 8-step blocks of the stream).  A step is lane-local — every lane looks up the code
-// of ITS row under column j and works out where that sends the walk — followed by one ds_bpermute from the lane that
-// owns the current row; no LDS, no staging.  The blocks of the next round are fetched while this round is walked
-// (~2 x 9 steps: about a memory round trip under load), and all four windows change rounds at the same point of the loop,
-// so the wait there is for loads issued a round ago, not for another window's prefetch of a moment ago (the memory
-// counter is the wave's, not the window's).
+// A round = every window walks through kTbG blocks of 16 rows.  Lane l of a window fetches rows 16 * block + l of the
+// round — three descriptor words and the 48 bytes of the backpointer stream that hold the row's 32 codes (its 16 steps
+// lie in at most three 8-step blocks of the stream) — a round AHEAD into registers, descriptors two rounds ahead (the
+// codes' addresses come out of them), and parks them in the window's LDS when the round begins.  The walk itself is the
+// same for all 16 lanes of a window (every lane reads the same two LDS addresses per step: the current row's descriptor,
+// then the code under column j): no cross-lane traffic, no select trees.  All four windows change rounds at the same
+// point of the loop, so the wait there is for loads issued a round ago, not for another window's prefetch of a moment
+// ago (the memory counter is the wave's, not the window's).
 constexpr int kTbG = 2;
+struct alignas(16) Poa4LdsTb {
+  uint4 row[P4::G][16 * kTbG][4];  // per row of the round: 48 bytes of codes, {d0, d1, d7, -}
+};
 template <class K>
-__host__ __device__ inline void poa4_traceback(const Poa4Args A, unsigned char* slot_mem, bool act, u32 r_lo, u32 n_rows,
-                                               bool full, u32 len, u32 best_rho1, u32& bad, u32& band_hit) {
+__host__ __device__ inline void poa4_traceback(const Poa4Args A, Poa4LdsTb& S, unsigned char* slot_mem, bool act, u32 r_lo,
+                                               u32 n_rows, bool full, u32 len, u32 best_rho1, u32& bad, u32& band_hit) {
   P4_ASSUME_GLOBAL(slot_mem);
+  P4_ASSUME_LDS(&S);
   (void)n_rows;
   const int lane = sv::lane();
-  const int gl = lane & 15, gbase = lane & ~15;
+  const int gl = lane & 15, q = lane >> 4;
   const Poa4Slot sl = poa4_carve(slot_mem, A.nmax, A.lmax);
   const uint4* const dsc = sl.desc;
   const uint4* const bps = sl.bps;
@@ -727,13 +731,10 @@ __host__ __device__ inline void poa4_traceback(const Poa4Args A, unsigned char* 
   bool done = !act || i == 0;
   u32 steps = 0, n_switch = 0;
   const u32 max_steps = A.nmax + A.lmax + 2;
-  // slot h of a round = block kTbG * round + h.  Three sets: the current round (written only by moves, so its uses in
-  // the walk wait for nothing), the next round (descriptors and codes in flight), the round after (descriptors in
-  // flight: the codes' addresses come out of them)
-  u32 cd0[kTbG] = {}, cd1[kTbG] = {}, cd7[kTbG] = {}, nd0[kTbG] = {}, nd1[kTbG] = {}, nd7[kTbG] = {};
-  u32 fd0[kTbG] = {}, fd1[kTbG] = {}, fd7[kTbG] = {};
-  uint4 ca[kTbG] = {}, cb[kTbG] = {}, cc[kTbG] = {}, na[kTbG] = {}, nb[kTbG] = {}, nc[kTbG] = {};
-  u32 c_rnd = 0xFFFFFFFFu, n_rnd = 0xFFFFFFFFu, f_rnd = 0xFFFFFFFFu;  // rounds the sets hold
+  // the next round (descriptors and codes in flight), the round after (descriptors in flight)
+  u32 nd0[kTbG] = {}, nd1[kTbG] = {}, nd7[kTbG] = {}, fd0[kTbG] = {}, fd1[kTbG] = {}, fd7[kTbG] = {};
+  uint4 na[kTbG] = {}, nb[kTbG] = {}, nc[kTbG] = {};
+  u32 c_rnd = 0xFFFFFFFFu, n_rnd = 0xFFFFFFFFu, f_rnd = 0xFFFFFFFFu;  // rounds LDS / the two register sets hold
   auto load_desc = [&](u32 rnd, u32 (&d0)[kTbG], u32 (&d1)[kTbG], u32 (&d7)[kTbG]) {
 #pragma unroll
     for (int h = 0; h < kTbG; ++h) {
@@ -758,116 +759,102 @@ __host__ __device__ inline void poa4_traceback(const Poa4Args A, unsigned char* 
   while (sv::any(!done)) {
     // ---- change of round, all windows at once ----
     const u32 rnd = done ? c_rnd : (i - 1) / (16 * kTbG);
-    if (!done && rnd != c_rnd) {
-      ++n_switch;
-      if (rnd != n_rnd) {  // the first round of the walk (or a jump the sets do not cover): both levels right here
-        load_desc(rnd, nd0, nd1, nd7);
-        load_codes(nd0, na, nb, nc);
-        f_rnd = 0xFFFFFFFFu;
-      }
-#pragma unroll
-      for (int h = 0; h < kTbG; ++h) {
-        cd0[h] = nd0[h];
-        cd1[h] = nd1[h];
-        cd7[h] = nd7[h];
-        ca[h] = na[h];
-        cb[h] = nb[h];
-        cc[h] = nc[h];
-      }
-      c_rnd = rnd;
-      if (rnd >= 1) {
-        if (f_rnd == rnd - 1) {
-#pragma unroll
-          for (int h = 0; h < kTbG; ++h) {
-            nd0[h] = fd0[h];
-            nd1[h] = fd1[h];
-            nd7[h] = fd7[h];
-          }
-        } else {
-          load_desc(rnd - 1, nd0, nd1, nd7);
+    const bool change = !done && rnd != c_rnd;
+    if (sv::any(change)) {
+      lds_order();  // the walks of the previous round have read their last row
+      if (change) {
+        ++n_switch;
+        if (rnd != n_rnd) {  // the first round of the walk (or a jump the sets do not cover): both levels right here
+          load_desc(rnd, nd0, nd1, nd7);
+          load_codes(nd0, na, nb, nc);
+          f_rnd = 0xFFFFFFFFu;
         }
-        load_codes(nd0, na, nb, nc);
-        n_rnd = rnd - 1;
-      } else {
-        n_rnd = 0xFFFFFFFFu;
-      }
-      if (rnd >= 2) {
-        load_desc(rnd - 2, fd0, fd1, fd7);
-        f_rnd = rnd - 2;
-      } else {
-        f_rnd = 0xFFFFFFFFu;
-      }
-    }
-    // ---- the round's blocks, top down ----
 #pragma unroll
-    for (int h = kTbG - 1; h >= 0; --h) {
-      const u32 c_blk = c_rnd * kTbG + static_cast<u32>(h);
-      const i32 bt = static_cast<i32>((cd1[h] >> 16) & 0x3FFu);
-      const u32 node = cd1[h] & 0xFFFFu;
-      const u32 np = (cd1[h] >> 26) & 15u;
-      const u32 srow = cd0[h] & 0xFFFFu;
-      const u32 my_i = c_blk * 16 + static_cast<u32>(gl) + 1;
-      bool in_block = !done && ((i - 1) >> 4) == c_blk;
-      while (sv::any(in_block)) {
-        P4_MARK("tb_step_begin");
-        // what the walk does on THIS lane's row under column j: packed as i' | j' << 14 | flags << 24
-        //   flags: 1 diagonal (position j' gets this row's node), 2 band edge touched, 4 left the band, 8 walked off the layer
-        const i32 idx = j - bt;
-        u32 res;
-        if (idx < 0 || idx >= K::kBand) {
-          res = 4u << 24;
+        for (int h = 0; h < kTbG; ++h) {
+          uint4* dst = S.row[q][16 * h + gl];
+          dst[0] = na[h];
+          dst[1] = nb[h];
+          dst[2] = nc[h];
+          dst[3] = uint4{nd0[h], nd1[h], nd7[h], 0u};
+        }
+        c_rnd = rnd;
+        if (rnd >= 1) {
+          if (f_rnd == rnd - 1) {
+#pragma unroll
+            for (int h = 0; h < kTbG; ++h) {
+              nd0[h] = fd0[h];
+              nd1[h] = fd1[h];
+              nd7[h] = fd7[h];
+            }
+          } else {
+            load_desc(rnd - 1, nd0, nd1, nd7);
+          }
+          load_codes(nd0, na, nb, nc);
+          n_rnd = rnd - 1;
         } else {
-          u32 fl = ((idx < 2 && bt > 0) || (idx > K::kBand - 3 && bt + K::kBand < static_cast<i32>(w))) ? 2u : 0u;
-          const u32 bo = (srow % K::kU + (static_cast<u32>(idx) >> 1)) * 2 + (static_cast<u32>(idx) & 1u);  // byte among the row's 48
-          const u32 dwi = bo >> 2;
-          const uint4 cq = dwi < 4 ? ca[h] : (dwi < 8 ? cb[h] : cc[h]);
-          const u32 wsel = (dwi & 2) ? ((dwi & 1) ? cq.w : cq.z) : ((dwi & 1) ? cq.y : cq.x);
-          const u32 code = (wsel >> (8 * (bo & 3u))) & 0xFFu;
-          u32 ni = my_i;
-          i32 nj = j;
+          n_rnd = 0xFFFFFFFFu;
+        }
+        if (rnd >= 2) {
+          load_desc(rnd - 2, fd0, fd1, fd7);
+          f_rnd = rnd - 2;
+        } else {
+          f_rnd = 0xFFFFFFFFu;
+        }
+      }
+      lds_order();
+    }
+    // ---- the walk through the round's rows: every lane of the window does the same ----
+    bool in_round = !done;
+    while (sv::any(in_round)) {
+      P4_MARK("tb_step_begin");
+      if (in_round) {
+        const u32 l = (i - 1) & (16 * kTbG - 1);
+        const uint4 d = S.row[q][l][3];
+        const i32 bt = static_cast<i32>((d.y >> 16) & 0x3FFu);
+        const u32 node = d.y & 0xFFFFu;
+        const i32 idx = j - bt;
+        if (++steps > max_steps) {
+          bad = 6;
+          done = true;
+        } else if (idx < 0 || idx >= K::kBand) {  // the path left the stored band: the alignment does not fit this band width
+          band_hit = 1;
+          done = true;
+        } else {
+          if ((idx < 2 && bt > 0) || (idx > K::kBand - 3 && bt + K::kBand < static_cast<i32>(w))) band_hit = 1;
+          const u32 bo = ((d.x & 0xFFFFu) % K::kU) * 2 + static_cast<u32>(idx);  // byte among the row's 48
+          const u32 code = reinterpret_cast<const u8*>(S.row[q][l])[bo];
           if (code == 64u) {
-            if (j == 0) fl |= 8u;
-            else nj = j - 1;  // insertion: pos_node[j - 1] stays kNone
+            if (j == 0) {
+              bad = 6;
+              done = true;
+            } else {
+              --j;  // insertion: pos_node[j] stays kNone
+            }
           } else {
             const u32 k = 15u - (code & 15u);
+            const u32 np = (d.y >> 26) & 15u;
+            u32 ni;
             if (np == 0) ni = 0;
-            else if (k < 6) ni = my_i - ((cd7[h] >> (5 * k)) & 31u);
+            else if (k < 6) ni = i - ((d.z >> (5 * k)) & 31u);
             else ni = poa4_nth_pred_rank(poa4_carve(opaque(slot_mem), A.nmax, A.lmax).g, node, k, full) - r_lo + 1;
             if (code & 32u) {  // diagonal
-              if (j == 0) fl |= 8u;
-              else {
-                nj = j - 1;
-                fl |= 1u;
+              if (j == 0) {
+                bad = 6;
+                done = true;
+              } else {
+                --j;
+                if (gl == 0) pos_node[j] = static_cast<u16>(node);
               }
             }
+            if (!done) {
+              i = ni;
+              if (i == 0) done = true;  // on the virtual row only insertions remain: pos_node already says kNone
+            }
           }
-          res = ni | (static_cast<u32>(nj) << 14) | (fl << 24);
         }
-        const bool mine = in_block && my_i == i;
-        const u32 got = static_cast<u32>(sv::bperm(static_cast<int>(res), gbase | static_cast<int>((i - 1) & 15u)));
-        if (in_block) {
-          const u32 fl = got >> 24;
-          if (++steps > max_steps) {
-            bad = 6;
-            done = true;
-          } else if (fl & 4u) {  // the path left the stored band: the alignment does not fit this band width
-            band_hit = 1;
-            done = true;
-          } else if (fl & 8u) {
-            bad = 6;
-            done = true;
-          } else {
-            if (fl & 2u) band_hit = 1;
-            const i32 nj = static_cast<i32>((got >> 14) & 0x3FFu);
-            if (mine && (fl & 1u)) pos_node[nj] = static_cast<u16>(node);
-            j = nj;
-            i = got & 0x3FFFu;
-            if (i == 0) done = true;  // on the virtual row only insertions remain: pos_node already says kNone
-          }
-          in_block = !done && ((i - 1) >> 4) == c_blk;
-        }
-        P4_MARK("tb_step_end");
+        in_round = !done && (i - 1) / (16 * kTbG) == c_rnd;
       }
+      P4_MARK("tb_step_end");
     }
   }
   if (A.phase_cycles && gl == 0 && act) {
@@ -1535,7 +1522,7 @@ __host__ __device__ inline void poa4_phase_dp(const Poa4Args& A, const Poa4Ctx& 
 
 // phase C: the traceback
 template <class K>
-__host__ __device__ inline void poa4_phase_tb(const Poa4Args& A, const Poa4Ctx& C, u32 wave) {
+__host__ __device__ inline void poa4_phase_tb(const Poa4Args& A, const Poa4Ctx& C, Poa4LdsTb& S, u32 wave) {
   const int lane = sv::lane();
   const int q = lane / K::GS;
   const unsigned long long t0 = sv::clock();
@@ -1553,7 +1540,7 @@ __host__ __device__ inline void poa4_phase_tb(const Poa4Args& A, const Poa4Ctx& 
   }
   if (!sv::any(act != 0)) return;
   u32 bad = 0, band_hit = 0;
-  poa4_traceback<K>(A, poa4_slot_of(A, wave, q), act != 0, r_lo, n_rows, full != 0, len, best, bad, band_hit);
+  poa4_traceback<K>(A, S, poa4_slot_of(A, wave, q), act != 0, r_lo, n_rows, full != 0, len, best, bad, band_hit);
   if (act && (bad || band_hit) && (lane & (K::GS - 1)) == 0) {
     Poa4Win& w = C.st[my_rec];
     w.phase = kFailed;
@@ -1641,7 +1628,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
   poa4_phase_dp<P4>(A, C, lds, blockIdx.x);
 }
 __global__ __launch_bounds__(64) void poa4_tb_kernel(const Poa4Args A, const Poa4Ctx C) {
-  poa4_phase_tb<P4>(A, C, blockIdx.x);  // (no LDS: the traceback lives in registers)
+  __shared__ Poa4LdsTb lds;
+  poa4_phase_tb<P4>(A, C, lds, blockIdx.x);
 }
 __global__ __launch_bounds__(64) void poa4_update_kernel(const Poa4Args A, const Poa4Ctx C) {
   __shared__ Poa4LdsUpdate lds;
@@ -1732,6 +1720,7 @@ struct EmuCall4 {
   Poa4Lds* S;
   Poa4LdsLayer* SL;
   Poa4LdsUpdate* SU;
+  Poa4LdsTb* ST;
   u32 wave;
   int phase;
 };
@@ -1741,7 +1730,7 @@ void emu_entry4(void* p) {
     case 0: poa4_phase_init(*c->A, *c->C, c->wave); break;
     case 1: poa4_phase_layer<P4, Poa4LdsLayer>(*c->A, *c->C, *c->SL, c->wave); break;
     case 2: poa4_phase_dp<P4>(*c->A, *c->C, *c->S, c->wave); break;
-    case 3: poa4_phase_tb<P4>(*c->A, *c->C, c->wave); break;
+    case 3: poa4_phase_tb<P4>(*c->A, *c->C, *c->ST, c->wave); break;
     case 4: poa4_phase_update<P4, Poa4LdsUpdate>(*c->A, *c->C, *c->SU, c->wave); break;
     default: poa4_phase_final(*c->A, *c->C, *c->S, c->wave); break;
   }
@@ -1780,6 +1769,7 @@ void poa_v4_emulate(const std::vector<PoaWindow>& wins, const std::vector<PoaLay
   std::vector<Poa4Lds> lds(1);
   std::vector<Poa4LdsLayer> ldsl(1);
   std::vector<Poa4LdsUpdate> ldsu(1);
+  std::vector<Poa4LdsTb> ldst(1);
   u32 max_layers = 0;
   for (const PoaWindow& w : wins) max_layers = std::max(max_layers, w.n_layers);
   auto run = [&](int ph) {
@@ -1787,7 +1777,8 @@ void poa_v4_emulate(const std::vector<PoaWindow>& wins, const std::vector<PoaLay
       std::memset(static_cast<void*>(lds.data()), 0, sizeof(Poa4Lds));  // (a fresh workgroup's LDS holds anything: zeros here)
       std::memset(static_cast<void*>(ldsl.data()), 0, sizeof(Poa4LdsLayer));
       std::memset(static_cast<void*>(ldsu.data()), 0, sizeof(Poa4LdsUpdate));
-      EmuCall4 call{&A, &C, lds.data(), ldsl.data(), ldsu.data(), wv, ph};
+      std::memset(static_cast<void*>(ldst.data()), 0, sizeof(Poa4LdsTb));
+      EmuCall4 call{&A, &C, lds.data(), ldsl.data(), ldsu.data(), ldst.data(), wv, ph};
       simt_emu::run_wave(&emu_entry4, &call);
     }
   };
