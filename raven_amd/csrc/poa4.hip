@@ -730,6 +730,7 @@ __host__ __device__ inline void poa4_traceback(const Poa4Args A, Poa4LdsTb& S, u
   i32 j = static_cast<i32>(w) - 1;
   bool done = !act || i == 0;
   u32 steps = 0, n_switch = 0;
+  unsigned long long t_change = 0;
   const u32 max_steps = A.nmax + A.lmax + 2;
   // the next round (descriptors and codes in flight), the round after (descriptors in flight)
   u32 nd0[kTbG] = {}, nd1[kTbG] = {}, nd7[kTbG] = {}, fd0[kTbG] = {}, fd1[kTbG] = {}, fd7[kTbG] = {};
@@ -760,6 +761,7 @@ __host__ __device__ inline void poa4_traceback(const Poa4Args A, Poa4LdsTb& S, u
     // ---- change of round, all windows at once ----
     const u32 rnd = done ? c_rnd : (i - 1) / (16 * kTbG);
     const bool change = !done && rnd != c_rnd;
+    const unsigned long long tc0 = sv::clock();
     if (sv::any(change)) {
       lds_order();  // the walks of the previous round have read their last row
       if (change) {
@@ -803,6 +805,7 @@ __host__ __device__ inline void poa4_traceback(const Poa4Args A, Poa4LdsTb& S, u
       }
       lds_order();
     }
+    t_change += sv::clock() - tc0;
     // ---- the walk through the round's rows: every lane of the window does the same ----
     bool in_round = !done;
     while (sv::any(in_round)) {
@@ -861,6 +864,7 @@ __host__ __device__ inline void poa4_traceback(const Poa4Args A, Poa4LdsTb& S, u
     sv::atomic_add(&A.phase_cycles[11], static_cast<unsigned long long>(steps));
     sv::atomic_add(&A.phase_cycles[12], static_cast<unsigned long long>(n_switch));
   }
+  if (A.phase_cycles && lane == 0) sv::atomic_add(&A.phase_cycles[13], t_change);
 }
 
 // ---- wave-wide per-window steps (as in poa2.hip) -------------------------------------------------------------------
@@ -1341,18 +1345,23 @@ struct Poa4Win {  // per window of the chunk
 static_assert(sizeof(Poa4Win) == 64, "state record");
 
 struct Poa4Ctx {  // what a phase function needs beside the batch description
-  Poa4Win* st;    // records of the chunk
+  Poa4Win* st;    // records of the part
   u32 first;      // position of the chunk's first window in scheduling order
-  u32 count;      // windows in the chunk
+  u32 count;      // windows of the chunk
+  u32 part, n_parts;  // the chunk's waves are dealt out to n_parts streams: this launch serves waves part, part + n_parts, ..
+  u32 slot0;      // first scratch slot of the part
 };
 
-__host__ __device__ __forceinline__ unsigned char* poa4_slot_of(const Poa4Args& A, u32 wave, int q) {
-  return A.scratch + (static_cast<size_t>(wave) * P4::G + static_cast<size_t>(q)) * A.slot_bytes;
+__host__ __device__ __forceinline__ unsigned char* poa4_slot_of(const Poa4Args& A, const Poa4Ctx& C, u32 wave, int q) {
+  return A.scratch + (static_cast<size_t>(C.slot0) + static_cast<size_t>(wave) * P4::G + static_cast<size_t>(q)) * A.slot_bytes;
 }
-// the lane's window of this wave: record index, or 0xFFFFFFFF beyond the chunk
+// the lane's window of this wave: record index (within the part), or 0xFFFFFFFF beyond the chunk
 __host__ __device__ __forceinline__ u32 poa4_my_record(const Poa4Ctx& C, u32 wave, int q) {
-  const u32 idx = wave * P4::G + static_cast<u32>(q);
-  return idx < C.count ? idx : 0xFFFFFFFFu;
+  const u32 pos = (wave * C.n_parts + C.part) * P4::G + static_cast<u32>(q);  // position within the chunk
+  return pos < C.count ? wave * P4::G + static_cast<u32>(q) : 0xFFFFFFFFu;
+}
+__host__ __device__ __forceinline__ u32 poa4_position(const Poa4Ctx& C, u32 wave, int q) {
+  return C.first + (wave * C.n_parts + C.part) * P4::G + static_cast<u32>(q);
 }
 
 // phase 0: graph of the backbone, state record
@@ -1361,10 +1370,10 @@ __host__ __device__ inline void poa4_phase_init(const Poa4Args& A, const Poa4Ctx
   for (int q2 = 0; q2 < P4::G; ++q2) {
     const u32 rec = poa4_my_record(C, wave, q2);
     if (rec == 0xFFFFFFFFu) continue;
-    const u32 pos = C.first + rec;
+    const u32 pos = poa4_position(C, wave, q2);
     const u32 wi = A.sched ? A.sched[pos] : pos;
     const PoaWindow wq = A.windows[wi];
-    const Poa4Slot sl2 = poa4_carve(poa4_slot_of(A, wave, q2), A.nmax, A.lmax);
+    const Poa4Slot sl2 = poa4_carve(poa4_slot_of(A, C, wave, q2), A.nmax, A.lmax);
     Poa2Slot g = sl2.g;
     u32 nn2 = 0, ne2 = 0;
     const u32 r = poa4_init_window(A, wq, g, sl2.rb, wi, nn2, ne2);
@@ -1419,7 +1428,7 @@ __host__ __device__ inline void poa4_phase_layer(const Poa4Args& A, const Poa4Ct
       }
       continue;
     }
-    const Poa4Slot sl2 = poa4_carve(poa4_slot_of(A, wave, q2), A.nmax, A.lmax);
+    const Poa4Slot sl2 = poa4_carve(poa4_slot_of(A, C, wave, q2), A.nmax, A.lmax);
     Poa2Slot g = sl2.g;
     auto& Sg = S.g[q2];
     // the layer's codes: bytes first, then 16 to a word (kept in the window's scratch for the graph update as well)
@@ -1456,7 +1465,7 @@ __host__ __device__ inline void poa4_phase_layer(const Poa4Args& A, const Poa4Ct
   t0 = sv::clock();
   u32 r_lo = 0, n_rows = 0, t_end = 0, flag = 0, marked_rows = 0;
   if (sv::any(act)) {
-    poa4_prepass<K, LT>(A, S, poa4_slot_of(A, wave, q), act, me.nn, full, me.flip != 0, Lp, len, lb, span, r_lo, n_rows, t_end, flag,
+    poa4_prepass<K, LT>(A, S, poa4_slot_of(A, C, wave, q), act, me.nn, full, me.flip != 0, Lp, len, lb, span, r_lo, n_rows, t_end, flag,
                     marked_rows);
     if ((lane & (GS - 1)) == 0 && act && A.phase_cycles) {
       sv::atomic_add(&A.phase_cycles[6], static_cast<unsigned long long>(marked_rows) * len);
@@ -1507,7 +1516,7 @@ __host__ __device__ inline void poa4_phase_dp(const Poa4Args& A, const Poa4Ctx& 
   }
   if (!sv::any(act != 0)) return;
   u32 best_rho1 = 0;
-  poa4_dp<K>(A, S, poa4_slot_of(A, wave, q), act != 0, t_end, len, best_rho1);
+  poa4_dp<K>(A, S, poa4_slot_of(A, C, wave, q), act != 0, t_end, len, best_rho1);
   if (act && (lane & (K::GS - 1)) == 0) {
     Poa4Win& w = C.st[my_rec];
     w.best_rho1 = best_rho1;
@@ -1540,7 +1549,7 @@ __host__ __device__ inline void poa4_phase_tb(const Poa4Args& A, const Poa4Ctx& 
   }
   if (!sv::any(act != 0)) return;
   u32 bad = 0, band_hit = 0;
-  poa4_traceback<K>(A, S, poa4_slot_of(A, wave, q), act != 0, r_lo, n_rows, full != 0, len, best, bad, band_hit);
+  poa4_traceback<K>(A, S, poa4_slot_of(A, C, wave, q), act != 0, r_lo, n_rows, full != 0, len, best, bad, band_hit);
   if (act && (bad || band_hit) && (lane & (K::GS - 1)) == 0) {
     Poa4Win& w = C.st[my_rec];
     w.phase = kFailed;
@@ -1560,7 +1569,7 @@ __host__ __device__ inline void poa4_phase_update(const Poa4Args& A, const Poa4C
   if (my_rec != 0xFFFFFFFFu) me = C.st[my_rec];
   const bool act = me.phase == kRunning && me.act != 0;
   if (!sv::any(me.phase == kRunning)) return;
-  unsigned char* const my_slot = poa4_slot_of(A, wave, q);
+  unsigned char* const my_slot = poa4_slot_of(A, C, wave, q);
   if (act) {  // the layer's packed codes back into LDS
     const u32* src = poa4_carve(my_slot, A.nmax, A.lmax).seq2g;
     for (u32 wd = static_cast<u32>(gl); wd < 60; wd += 16) S.g[q].seq2[wd] = src[wd];
@@ -1604,7 +1613,7 @@ __host__ __device__ inline void poa4_phase_final(const Poa4Args& A, const Poa4Ct
       poa4_copy_backbone(A, wq, A.layers[wq.layer_first], A.out + wq.out_off, A.out_len + w.wi);
       if (w.phase == kRunning) st = 5;
     } else if (w.phase == kLayersDone) {
-      Poa2Slot g = poa4_graph(poa4_slot_of(A, wave, q2), A.nmax, A.lmax, w.flip != 0);
+      Poa2Slot g = poa4_graph(poa4_slot_of(A, C, wave, q2), A.nmax, A.lmax, w.flip != 0);
       wq.n_layers = w.n_eff;
       poa4_consensus(g, w.nn, A.nmax, wq, A.trim, S, A.out + wq.out_off, A.out_len + w.wi);
       sv::sync();
@@ -1683,14 +1692,24 @@ void poa_v4_launch(Engine& e, const PoaBatchDev& b) {
   if (const char* ev = std::getenv("RVN_POA4_CHUNK")) per_chunk = std::max<size_t>(P4::G, static_cast<size_t>(std::atoll(ev)));
   per_chunk = std::min<size_t>(per_chunk, b.n_windows);
   per_chunk = (per_chunk + P4::G - 1) / P4::G * P4::G;
-  unsigned char* d_scratch = e.poa2_scratch.get<unsigned char>(per_chunk * (slot_bytes + sizeof(Poa4Win)) + 512);
-  Poa4Win* d_st = reinterpret_cast<Poa4Win*>(d_scratch + per_chunk * slot_bytes + 256);
+  // The waves of a chunk are dealt out to up to three streams that run their rounds independently: the phases of a round
+  // are one issue-bound kernel (NW) and three that wait on gathers, and two streams in different phases fill each
+  // other's gaps.
+  u32 n_parts = 3;
+  if (const char* ev = std::getenv("RVN_POA4_STREAMS")) n_parts = static_cast<u32>(std::max(1, std::min(3, std::atoi(ev))));
+  if (per_chunk < 4096) n_parts = 1;
+  const size_t slots_alloc = per_chunk + static_cast<size_t>(P4::G) * n_parts;
+  unsigned char* d_scratch = e.poa2_scratch.get<unsigned char>(slots_alloc * (slot_bytes + sizeof(Poa4Win)) + 512);
+  Poa4Win* d_st = reinterpret_cast<Poa4Win*>(d_scratch + slots_alloc * slot_bytes + 256);
   const Poa4Args A = args_of4(b, d_scratch, slot_bytes);
   hipStream_t s = e.stream;
+  if (n_parts > 1 && !e.nw_streams[0]) {
+    for (hipStream_t& st2 : e.nw_streams) RVN_HIP(hipStreamCreateWithFlags(&st2, hipStreamNonBlocking));
+    for (hipEvent_t& ev : e.nw_ev) RVN_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  }
   for (u32 first = 0; first < b.n_windows; first += static_cast<u32>(per_chunk)) {
     const u32 count = std::min<u32>(static_cast<u32>(per_chunk), b.n_windows - first);
-    const u32 n_waves = (count + P4::G - 1) / P4::G;
-    const Poa4Ctx C{d_st, first, count};
+    const u32 waves_total = (count + P4::G - 1) / P4::G;
     // rounds = the most layers a window of the chunk has (one layer per round at most)
     u32 max_layers = 0;
     RVN_HIP(hipMemsetAsync(b.next, 0, 4, s));
@@ -1698,15 +1717,41 @@ void poa_v4_launch(Engine& e, const PoaBatchDev& b) {
     RVN_LAUNCH_CHECK();
     RVN_HIP(hipMemcpyAsync(&max_layers, b.next, 4, hipMemcpyDeviceToHost, s));
     RVN_HIP(rvn_stream_sync(s));
-    RVN_KLAUNCH(kKPoaBanded, (poa4_init_kernel<<<n_waves, 64, 0, s>>>(A, C)));
-    for (u32 round = 1; round < max_layers; ++round) {
-      RVN_KLAUNCH(kKPoaBanded, (poa4_layer_kernel<<<n_waves, 64, 0, s>>>(A, C)));
-      RVN_KLAUNCH(kKPoaBanded, (poa4_dp_kernel<<<n_waves, 64, 0, s>>>(A, C)));
-      RVN_KLAUNCH(kKPoaBanded, (poa4_tb_kernel<<<n_waves, 64, 0, s>>>(A, C)));
-      RVN_KLAUNCH(kKPoaBanded, (poa4_update_kernel<<<n_waves, 64, 0, s>>>(A, C)));
+    Poa4Ctx C[3];
+    u32 n_waves[3] = {0, 0, 0};
+    hipStream_t st[3] = {s, s, s};
+    u32 slot0 = 0;
+    for (u32 p = 0; p < n_parts; ++p) {
+      n_waves[p] = waves_total > p ? (waves_total - p + n_parts - 1) / n_parts : 0;
+      C[p] = Poa4Ctx{d_st + slot0, first, count, p, n_parts, slot0};
+      slot0 += n_waves[p] * P4::G;
+      if (n_parts > 1) st[p] = e.nw_streams[p];
     }
-    RVN_KLAUNCH(kKPoaBanded, (poa4_layer_kernel<<<n_waves, 64, 0, s>>>(A, C)));  // every window finds its layers exhausted
-    RVN_KLAUNCH(kKPoaBanded, (poa4_final_kernel<<<n_waves, 64, 0, s>>>(A, C)));
+    if (n_parts > 1) {
+      RVN_HIP(hipEventRecord(e.nw_ev[3], s));
+      for (u32 p = 0; p < n_parts; ++p) RVN_HIP(hipStreamWaitEvent(st[p], e.nw_ev[3], 0));
+    }
+    for (u32 p = 0; p < n_parts; ++p)
+      if (n_waves[p]) RVN_KLAUNCH_ON(kKPoaBanded, st[p], (poa4_init_kernel<<<n_waves[p], 64, 0, st[p]>>>(A, C[p])));
+    // (the windows are in scheduling order, heaviest first, and dealt out by wave: every part has the same rounds)
+    for (u32 round = 1; round <= max_layers; ++round) {
+      for (u32 p = 0; p < n_parts; ++p) {
+        if (!n_waves[p]) continue;
+        RVN_KLAUNCH_ON(kKPoaBanded, st[p], (poa4_layer_kernel<<<n_waves[p], 64, 0, st[p]>>>(A, C[p])));
+        if (round == max_layers) continue;  // (the last call only lets every window find its layers exhausted)
+        RVN_KLAUNCH_ON(kKPoaBanded, st[p], (poa4_dp_kernel<<<n_waves[p], 64, 0, st[p]>>>(A, C[p])));
+        RVN_KLAUNCH_ON(kKPoaBanded, st[p], (poa4_tb_kernel<<<n_waves[p], 64, 0, st[p]>>>(A, C[p])));
+        RVN_KLAUNCH_ON(kKPoaBanded, st[p], (poa4_update_kernel<<<n_waves[p], 64, 0, st[p]>>>(A, C[p])));
+      }
+    }
+    for (u32 p = 0; p < n_parts; ++p)
+      if (n_waves[p]) RVN_KLAUNCH_ON(kKPoaBanded, st[p], (poa4_final_kernel<<<n_waves[p], 64, 0, st[p]>>>(A, C[p])));
+    if (n_parts > 1) {
+      for (u32 p = 0; p < n_parts; ++p) {
+        RVN_HIP(hipEventRecord(e.nw_ev[p], st[p]));
+        RVN_HIP(hipStreamWaitEvent(s, e.nw_ev[p], 0));
+      }
+    }
   }
 }
 
@@ -1765,7 +1810,7 @@ void poa_v4_emulate(const std::vector<PoaWindow>& wins, const std::vector<PoaLay
   b.sched = nullptr;
   b.next = &next;
   const Poa4Args A = args_of4(b, scratch.data(), slot_bytes);
-  const Poa4Ctx C{st.data(), 0, count};
+  const Poa4Ctx C{st.data(), 0, count, 0, 1, 0};
   std::vector<Poa4Lds> lds(1);
   std::vector<Poa4LdsLayer> ldsl(1);
   std::vector<Poa4LdsUpdate> ldsu(1);
