@@ -72,7 +72,6 @@ struct alignas(16) Poa4LdsT {
 using Poa4Group = Poa4GroupT<P4::kRing * P4::kRowB>;
 using Poa4Lds = Poa4LdsT<P4::kRing * P4::kRowB>;
 using Poa4LdsUpdate = Poa4LdsT<kPoa2MaxSeq * 2>;
-using Poa4LdsLayer = Poa4LdsT<kPoa2MaxSeq + 32>;
 static_assert(sizeof(Poa4Lds) <= 10240, "sixteen waves per CU need <= 10 KB of LDS each");
 static_assert(P4::kRowB == 68 + 2 * (P4::kMaxD + 2), "ring row = 2 pads + 32 cells + kMaxD + 2 pads");
 
@@ -248,14 +247,13 @@ __host__ __device__ inline u32 poa4_nth_pred_rank(const Poa2Slot& g, u32 v, u32 
   return 0;
 }
 
-// ---- per-layer pre-pass: the row descriptors ---------------------------------------------------------------------------
-// The wave's windows side by side.  Group-uniform inputs: act, nn, full, the layer.
-// one sweep over the NODES (not the ranks: everything a node contributes is then a coalesced load, and only its
-// in-edges' tails are gathered — rb[] holds rank and backbone coordinate of a node in one word, band starts come from the
-// layer's guide through per-segment reciprocals kept in LDS): the descriptor of every node whose rank lies in the rank
-// range [r_lo, r_hi) of the layer's subgraph, written at its row rho = rank - r_lo.
-// Outputs (group-uniform): r_lo (rank of row 0), n_rows, t_end (steps of the layer's DP), flag (!= 0: the layer does
-// not fit this kernel's limits -> the window goes to the 64-column kernel), marked rows (work counter).
+// ---- the row descriptors of a layer: flat over the nodes ---------------------------------------------------------------
+// One wave = 64 nodes of one window (a window takes kDescWaves waves; a graph of more than 64 * kDescWaves nodes makes them
+// loop).  Everything a node contributes is a coalesced load (rb[] holds rank and backbone coordinate of a node in one
+// word), only its in-edges' tails are gathered; band starts come from the layer's guide through per-segment reciprocals
+// kept in LDS.  The descriptor of every node whose rank lies in the rank range [r_lo, r_hi) of the layer's subgraph is
+// written at its row rho = rank - r_lo; the steps of the layer's NW, the "beyond this kernel's limits" flag and the work
+// counter are folded into the window's record with atomics.
 __host__ __device__ __forceinline__ u32 mulhi_u32(u32 a, u32 b) {
 #if defined(__HIP_DEVICE_COMPILE__)
   return __umulhi(a, b);
@@ -267,219 +265,44 @@ __host__ __device__ __forceinline__ u32 mulhi_u32(u32 a, u32 b) {
 __host__ __device__ __forceinline__ u32 magic_of(u32 d) { return d <= 1 ? 0u : static_cast<u32>(0x100000000ULL / d) + 1u; }
 __host__ __device__ __forceinline__ u32 div_magic(u32 n, u32 m) { return m ? mulhi_u32(n, m) : n; }
 
-template <class K, class LT>
-__host__ __device__ inline void poa4_prepass(const Poa4Args A, LT& S, unsigned char* slot_mem, bool act, u32 nn, bool full,
-                                             bool flip, const PoaLayer* Lp, u32 len, i32 lb, i32 span, u32& r_lo_out,
-                                             u32& n_rows_out, u32& t_end_out, u32& flag_out, u32& marked_out) {
-  P4_ASSUME_GLOBAL(slot_mem);
-  P4_ASSUME_GLOBAL(Lp);
-  P4_ASSUME_LDS(&S);
+struct alignas(16) Poa4LdsDesc {
+  u32 segtab[32];  // the layer's band guide: {x0, wa, wb - wa, magic(x1 - x0)} per segment
+  u32 seq2[60];    // the layer, 2 bits per base
+  u8 bytes[kPoa2MaxSeq + 16];  // (set-up kernel: one-byte codes before they are packed)
+};
+constexpr u32 kDescWaves = 16;
+
+// the layer's band guide as eight segments in LDS (lanes 0..7), and the band start of a backbone coordinate from it
+__host__ __device__ inline void poa4_guide_to_lds(Poa4LdsDesc& S, const PoaLayer* Lp, u32 len, i32 span) {
   const int lane = sv::lane();
-  const int gl = lane & 15, gbase = lane & ~15, q = lane >> 4;
-  const Poa4Slot sl = poa4_carve(slot_mem, A.nmax, A.lmax);
-  const Poa2Slot& g = sl.g;
-  auto& Sg = S.g[q];
-  const u32 w = len + 1;
-  // ---- the layer's band guide as eight segments {x0, wa, wb - wa, magic(x1 - x0)} in LDS ----
-  if (act && gl < 8) {
-    const i32 sg = gl;
+  if (lane < 8) {
+    const i32 sg = lane;
     const i32 x0 = (sg * span) / 8, x1 = ((sg + 1) * span) / 8;
     const i32 wa = sg == 0 ? 0 : static_cast<i32>(Lp->way[sg - 1]);
     const i32 wb = sg == 7 ? static_cast<i32>(len) : static_cast<i32>(Lp->way[sg]);
-    Sg.u.segtab[4 * sg] = static_cast<u32>(x0);
-    Sg.u.segtab[4 * sg + 1] = static_cast<u32>(wa);
-    Sg.u.segtab[4 * sg + 2] = static_cast<u32>(wb - wa);
-    Sg.u.segtab[4 * sg + 3] = magic_of(static_cast<u32>(x1 > x0 ? x1 - x0 : 1));
+    S.segtab[4 * sg] = static_cast<u32>(x0);
+    S.segtab[4 * sg + 1] = static_cast<u32>(wa);
+    S.segtab[4 * sg + 2] = static_cast<u32>(wb - wa);
+    S.segtab[4 * sg + 3] = magic_of(static_cast<u32>(x1 > x0 ? x1 - x0 : 1));
   }
-  lds_order();
-  const u32 span_magic = magic_of(static_cast<u32>(span > 0 ? span : 1));
-  const i32 bmax = static_cast<i32>(w) - K::kBand;
-  auto band_start = [&](i32 bpos) -> i32 {  // even, in [0, max(0, w - 31)]; = poa_layer_center(bpos - lb) - 16 clamped
-    i32 x = bpos - lb;
-    x = x < 0 ? 0 : (x > span ? span : x);
-    const u32 seg = div_magic(static_cast<u32>(x) * 8u, span_magic);
-    const u32 sg = seg > 7u ? 7u : seg;
-    const uint4 st = *reinterpret_cast<const uint4*>(&Sg.u.segtab[4 * sg]);
-    const i32 dw = static_cast<i32>(st.z);
-    const u32 num = static_cast<u32>(x - static_cast<i32>(st.x)) * static_cast<u32>(dw < 0 ? -dw : dw);
-    const i32 qn = static_cast<i32>(div_magic(num, st.w));
-    i32 b = static_cast<i32>(st.y) + (dw < 0 ? -qn : qn) - K::kBand / 2;
-    b = b > bmax ? bmax : b;
-    b = b < 0 ? 0 : b;
-    // even; at the right limit rounded UP, so that the band still holds the layer's last column
-    return (b == bmax && bmax > 0) ? (b + 1) & ~1 : b & ~1;
-  };
-  const u32 max_nn = static_cast<u32>(sv::wave_max(act ? static_cast<int>(nn) : 0));
-  // ---- a partial layer: the rank range that holds its subgraph ----
-  u32 r_lo = 0, r_hi = act ? nn : 0;
-  if (sv::any(act && !full)) {
-    const bool part = act && !full;
-    u32 first = 0xFFFFFFFFu;
-    i32 last = 0;
-    const u32 max_pn = static_cast<u32>(sv::wave_max(part ? static_cast<int>(nn) : 0));
-    for (u32 v0 = 0; v0 < max_pn; v0 += 64) {
-      u32 rk[4], mk[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const u32 v = v0 + 16u * static_cast<u32>(u) + static_cast<u32>(gl);
-        const bool ok = part && v < nn;
-        rk[u] = ok ? sl.rb[v] & 0xFFFFu : 0u;
-        mk[u] = ok ? g.mark[v] : 0u;
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        if (mk[u]) {
-          first = rk[u] < first ? rk[u] : first;
-          last = static_cast<i32>(rk[u]) + 1 > last ? static_cast<i32>(rk[u]) + 1 : last;
-        }
-      }
-    }
-    first = group_min_u(first);
-    last = group_max_i(last);
-    if (part) {
-      r_lo = first == 0xFFFFFFFFu ? 0u : first;
-      r_hi = first == 0xFFFFFFFFu ? 0u : static_cast<u32>(last);
-    }
-  }
-  const u32 n_rows = r_hi - r_lo;
-  i32 b_first = 0;
-  if (act && n_rows) b_first = band_start(static_cast<i32>(sl.rb[(flip ? g.order2 : g.order)[r_lo]] >> 16));
-  const u32 ring_off = static_cast<u32>(offsetof(Poa4Lds, g)) + static_cast<u32>(q) * static_cast<u32>(sizeof(Poa4Group));
-  const u32 dump_off = ring_off + static_cast<u32>(offsetof(Poa4Group, dump));
-  const u32 neg_off = static_cast<u32>(offsetof(Poa4Lds, neg));
-  const u32 neg2 = neg_off | (neg_off << 16);
-  u32 flag = 0, marked_rows = 0;
-  i32 t_end = 0;
-  // ---- sweep B: descriptors, two nodes per lane and iteration (their loads in flight together) ----
-  for (u32 v0 = 0; v0 < max_nn; v0 += 32) {
-    u32 vv[2], rbv[2], cc[2], code[2], outc[2], mk[2];
-    uint4 tl[2];
-    bool ok[2];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      vv[u] = v0 + 16u * static_cast<u32>(u) + static_cast<u32>(gl);
-      ok[u] = act && vv[u] < nn;
-      const u32 v = ok[u] ? vv[u] : 0u;
-      rbv[u] = sl.rb[v];
-      cc[u] = g.in_cnt[v];
-      code[u] = g.code[v];
-      outc[u] = full ? g.out_cnt[v] : g.sub_out[v];
-      mk[u] = full ? 1u : g.mark[v];
-      tl[u] = *reinterpret_cast<const uint4*>(g.in_tail + static_cast<size_t>(v) * kPoaMaxIn);
-    }
-    u32 trb[2][8], tmk[2][8];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const u32 r = rbv[u] & 0xFFFFu;
-      ok[u] = ok[u] && r >= r_lo && r < r_hi;
-      if (!(ok[u] && mk[u])) cc[u] = 0;
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const u32 wd = k < 2 ? tl[u].x : (k < 4 ? tl[u].y : (k < 6 ? tl[u].z : tl[u].w));
-        const u32 t = static_cast<u32>(k) < cc[u] ? (wd >> (16 * (k & 1))) & 0xFFFFu : 0u;
-        trb[u][k] = sl.rb[t];
-        tmk[u][k] = full ? 1u : g.mark[t];
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const u32 v = vv[u];
-      const u32 r = rbv[u] & 0xFFFFu;
-      const i32 b = band_start(static_cast<i32>(rbv[u] >> 16));
-      const u32 rho = r - r_lo;
-      const bool marked = ok[u] && mk[u] != 0;
-      u32 ep[4] = {neg2, neg2, neg2, neg2};
-      u32 np = 0, lbw = 0;
-      auto edge = [&](u32 rbt, bool inside) {
-        if (!inside) return;
-        const u32 lbk = r - (rbt & 0xFFFFu);
-        const i32 d = b - band_start(static_cast<i32>(rbt >> 16));
-        if (lbk < 1 || lbk > static_cast<u32>(K::kRing - 1) || lbk > rho || d < 0 || d > K::kMaxD) {
-          flag = 7;
-        } else if (np < static_cast<u32>(K::kEdges)) {
-          const u32 e = ring_off + ((rho - lbk) % static_cast<u32>(K::kRing)) * static_cast<u32>(K::kRowB) + 2u * static_cast<u32>(d);
-          const u32 idx = np >> 1;
-          const u32 keep = (np & 1) ? 0x0000FFFFu : 0xFFFF0000u;
-          const u32 put = (np & 1) ? e << 16 : e;
-#pragma unroll
-          for (u32 i = 0; i < 4; ++i) ep[i] = i == idx ? ((ep[i] & keep) | put) : ep[i];
-          if (np < 6) lbw |= lbk << (5 * np);
-        }
-        ++np;
-      };
-#pragma unroll
-      for (int k = 0; k < 8; ++k) edge(trb[u][k], static_cast<u32>(k) < cc[u] && tmk[u][k] != 0);
-      for (u32 k = 8; k < cc[u]; ++k) {  // rare
-        const u32 t = g.in_tail[static_cast<size_t>(v) * kPoaMaxIn + k];
-        edge(sl.rb[t], full || g.mark[t] != 0);
-      }
-      if (np > static_cast<u32>(K::kEdges)) flag = 3;
-      if (ok[u]) {
-        // match mask of the row's 32 columns against the layer
-        u32 mm = 0;
-        {
-          const u32 wi = static_cast<u32>(b) >> 4, sh = 2u * (static_cast<u32>(b) & 15u);
-          const u32 x0 = Sg.seq2[wi], x1 = Sg.seq2[wi + 1], x2 = Sg.seq2[wi + 2];
-          const u32 pat = code[u] * 0x55555555u;
-          const u32 elo = funnel_shr(x1, x0, sh) ^ pat, ehi = funnel_shr(x2, x1, sh) ^ pat;
-          auto even_bits = [](u32 y) -> u32 {
-            y = ~(y | (y >> 1)) & 0x55555555u;
-            y = (y | (y >> 1)) & 0x33333333u;
-            y = (y | (y >> 2)) & 0x0F0F0F0Fu;
-            y = (y | (y >> 4)) & 0x00FF00FFu;
-            y = (y | (y >> 8)) & 0x0000FFFFu;
-            return y;
-          };
-          mm = even_bits(elo) | (even_bits(ehi) << 16);
-        }
-        i32 sdiff = b - b_first;
-        if (sdiff < 0) {  // (never: a node's backbone coordinate does not decrease along the order)
-          flag = 7;
-          sdiff = 0;
-        }
-        const u32 Srow = rho + (rho >> 4) + (static_cast<u32>(sdiff) >> 1) + 1u;
-        const u32 own = marked ? ring_off + (rho % static_cast<u32>(K::kRing)) * static_cast<u32>(K::kRowB) + 4u : dump_off;
-        const bool endn = marked && outc[u] == 0;
-        uint4 da, db;
-        da.x = Srow | (own << 16);
-        da.y = v | (static_cast<u32>(b) << 16) | ((np > 15u ? 15u : np) << 26) | (marked ? 1u << 30 : 0u) | (endn ? 1u << 31 : 0u);
-        da.z = mm;
-        da.w = ep[0];
-        db.x = ep[1];
-        db.y = ep[2];
-        db.z = ep[3];
-        db.w = lbw;
-        sl.desc[2 * static_cast<size_t>(rho)] = da;
-        sl.desc[2 * static_cast<size_t>(rho) + 1] = db;
-        t_end = static_cast<i32>(Srow) + 17 > t_end ? static_cast<i32>(Srow) + 17 : t_end;
-        if (marked) ++marked_rows;
-      }
-    }
-  }
-  // rows beyond the last one: what the lanes' descriptor prefetch runs into
-  if (act) {
-#pragma unroll
-    for (u32 u = 0; u < 2; ++u) {
-      const size_t rho = static_cast<size_t>(n_rows) + 16 * u + static_cast<size_t>(gl);
-      sl.desc[2 * rho] = uint4{kInactiveS | (dump_off << 16), 0u, 0u, neg2};
-      sl.desc[2 * rho + 1] = uint4{neg2, neg2, neg2, 0u};
-    }
-  }
-  t_end = group_max_i(t_end);
-  flag = static_cast<u32>(group_max_i(static_cast<i32>(flag)));
-  {
-    u32 mr = marked_rows;
-#pragma unroll
-    for (int off = 8; off > 0; off >>= 1) mr += static_cast<u32>(sv::bperm(static_cast<int>(mr), lane ^ off));
-    marked_rows = mr;
-  }
-  if (static_cast<u32>(t_end) + 8u > poa4_steps(A.nmax, A.lmax)) flag = 7;
-  r_lo_out = r_lo;
-  n_rows_out = n_rows;
-  t_end_out = static_cast<u32>(t_end);
-  flag_out = flag;
-  marked_out = marked_rows;
-  (void)gbase;
+}
+template <class K>
+__host__ __device__ __forceinline__ i32 poa4_band_start(const Poa4LdsDesc& S, i32 bpos, i32 lb, i32 span, u32 span_magic, u32 len) {
+  // even, in [0, max(0, w - 31)]; = poa_layer_center(bpos - lb) - 16 clamped
+  i32 x = bpos - lb;
+  x = x < 0 ? 0 : (x > span ? span : x);
+  const u32 seg = div_magic(static_cast<u32>(x) * 8u, span_magic);
+  const u32 sg = seg > 7u ? 7u : seg;
+  const uint4 st = *reinterpret_cast<const uint4*>(&S.segtab[4 * sg]);
+  const i32 dw = static_cast<i32>(st.z);
+  const u32 num = static_cast<u32>(x - static_cast<i32>(st.x)) * static_cast<u32>(dw < 0 ? -dw : dw);
+  const i32 qn = static_cast<i32>(div_magic(num, st.w));
+  i32 b = static_cast<i32>(st.y) + (dw < 0 ? -qn : qn) - K::kBand / 2;
+  const i32 bmax = static_cast<i32>(len) + 1 - K::kBand;
+  b = b > bmax ? bmax : b;
+  b = b < 0 ? 0 : b;
+  // even; at the right limit rounded UP, so that the band still holds the layer's last column
+  return (b == bmax && bmax > 0) ? (b + 1) & ~1 : b & ~1;
 }
 
 // ---- banded NW of one layer per window, rows on lanes ---------------------------------------------------------------
@@ -1341,8 +1164,18 @@ struct Poa4Win {  // per window of the chunk
   u32 phase, status, nn, n_eff, li, flip;
   u32 act, full, len, lb, span;  // the layer of this round (act = 0: none)
   u32 r_lo, n_rows, t_end, best_rho1;
+  u32 b_first;   // band start of the layer's first row
+  u32 dflag;     // != 0: the descriptor pass found the layer beyond this kernel's limits
+  u32 pad_[2];
 };
-static_assert(sizeof(Poa4Win) == 64, "state record");
+static_assert(sizeof(Poa4Win) == 80, "state record");
+__host__ __device__ __forceinline__ void atomic_max_u32(u32* p, u32 v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  atomicMax(p, v);
+#else
+  if (v > *p) *p = v;
+#endif
+}
 
 struct Poa4Ctx {  // what a phase function needs beside the batch description
   Poa4Win* st;    // records of the part
@@ -1390,112 +1223,234 @@ __host__ __device__ inline void poa4_phase_init(const Poa4Args& A, const Poa4Ctx
   }
 }
 
-// phase A of a round: the next layer of every window (codes packed into the window's seq2, subgraph marks), then the
-// row descriptors of the four windows side by side
-template <class K, class LT>
-__host__ __device__ inline void poa4_phase_layer(const Poa4Args& A, const Poa4Ctx& C, LT& S, u32 wave) {
-  constexpr int GS = K::GS;
+// phase A1 of a round, one window per wave: the window's next layer (codes packed 2 bits per base into the window's
+// scratch, alignment results reset, subgraph marks and the rank range of the subgraph for a partial layer)
+template <class K>
+__host__ __device__ inline void poa4_phase_setup(const Poa4Args& A, const Poa4Ctx& C, Poa4LdsDesc& S, u32 rec) {
   const int lane = sv::lane();
-  const int q = lane / GS;
-  unsigned long long t0 = sv::clock();
-  const u32 my_rec = poa4_my_record(C, wave, q);
-  Poa4Win me{};
-  if (my_rec != 0xFFFFFFFFu) me = C.st[my_rec];
-  if (!sv::any(me.phase == kRunning)) return;
-  bool act = false, full = false;
-  u32 len = 0, li = me.li;
-  i32 lb = 0, span = 0;
-  u32 phase = me.phase, status = me.status;
-  const PoaLayer* Lp = A.layers;
-  for (int q2 = 0; q2 < P4::G; ++q2) {
-    if (sv::rl(static_cast<int>(phase), q2 * GS) != static_cast<int>(kRunning)) continue;
-    const u32 wi2 = static_cast<u32>(sv::rl(static_cast<int>(me.wi), q2 * GS));
-    const PoaWindow wq = A.windows[wi2];
-    u32 liq = static_cast<u32>(sv::rl(static_cast<int>(li), q2 * GS));
-    const u32 nnq = static_cast<u32>(sv::rl(static_cast<int>(me.nn), q2 * GS));
-    while (liq < wq.n_layers && (A.layers[wq.layer_first + liq].len == 0 ||
-                                 (A.src.layer_ok && !A.src.layer_ok[wq.layer_first + liq])))
-      ++liq;
-    if (liq >= wq.n_layers) {
-      if (q == q2) phase = kLayersDone;
-      continue;
+  const u32 wave_dp = rec / P4::G;
+  const int q = static_cast<int>(rec % P4::G);
+  if (poa4_my_record(C, wave_dp, q) == 0xFFFFFFFFu) return;
+  Poa4Win me = C.st[rec];
+  if (me.phase != kRunning) return;
+  const unsigned long long t0 = sv::clock();
+  const PoaWindow wq = A.windows[me.wi];
+  u32 liq = me.li;
+  while (liq < wq.n_layers &&
+         (A.layers[wq.layer_first + liq].len == 0 || (A.src.layer_ok && !A.src.layer_ok[wq.layer_first + liq])))
+    ++liq;
+  me.act = 0;
+  me.li = liq;
+  if (liq >= wq.n_layers) {
+    me.phase = kLayersDone;
+    if (lane == 0) C.st[rec] = me;
+    return;
+  }
+  const PoaLayer L = A.layers[wq.layer_first + liq];
+  if (L.len > A.lmax || L.len > static_cast<u32>(kPoa2MaxSeq)) {
+    me.phase = kFailed;
+    me.status = 4;
+    if (lane == 0) C.st[rec] = me;
+    return;
+  }
+  const Poa4Slot sl = poa4_carve(poa4_slot_of(A, C, wave_dp, q), A.nmax, A.lmax);
+  Poa2Slot g = sl.g;
+  for (u32 i = lane; i < L.len; i += 64) {
+    S.bytes[i] = static_cast<u8>(poa_layer_code(A.src, L, i));
+    g.pos_node[i] = static_cast<u16>(kNone4);
+  }
+  lds_order();
+  if (lane < 60) {
+    u32 x = 0;
+    for (u32 c = 0; c < 16; ++c) {
+      const i32 p = static_cast<i32>(static_cast<u32>(lane) * 16 + c) - 1;
+      if (p >= 0 && p < static_cast<i32>(L.len)) x |= static_cast<u32>(S.bytes[p] & 3u) << (2 * c);
     }
-    const PoaLayer L = A.layers[wq.layer_first + liq];
-    if (L.len > A.lmax || L.len > static_cast<u32>(kPoa2MaxSeq)) {
-      if (q == q2) {
-        phase = kFailed;
-        status = 4;
+    sl.seq2g[lane] = x;
+  }
+  const u32 blen = A.layers[wq.layer_first].len;
+  const u32 offset = static_cast<u32>(0.01 * blen);
+  const bool full = L.begin < offset && L.end > blen - offset;
+  u32 r_lo = 0, r_hi = me.nn;
+  if (!full) {
+    poa_subgraph_marks(g, me.nn, A.nmax, L.begin, L.end);
+    i32 first_neg = -0x7FFFFFFF, last = 0;  // (-first: both through the wave's maximum)
+    for (u32 v = lane; v < me.nn; v += 64) {
+      if (g.mark[v]) {
+        const i32 r = static_cast<i32>(sl.rb[v] & 0xFFFFu);
+        first_neg = -r > first_neg ? -r : first_neg;
+        last = r + 1 > last ? r + 1 : last;
       }
-      continue;
     }
-    const Poa4Slot sl2 = poa4_carve(poa4_slot_of(A, C, wave, q2), A.nmax, A.lmax);
-    Poa2Slot g = sl2.g;
-    auto& Sg = S.g[q2];
-    // the layer's codes: bytes first, then 16 to a word (kept in the window's scratch for the graph update as well)
-    for (u32 i = lane; i < L.len; i += 64) {
-      Sg.u.bytes[i] = static_cast<u8>(poa_layer_code(A.src, L, i));
-      g.pos_node[i] = static_cast<u16>(kNone4);
+    first_neg = sv::wave_max(first_neg);
+    last = sv::wave_max(last);
+    r_lo = first_neg == -0x7FFFFFFF ? 0u : static_cast<u32>(-first_neg);
+    r_hi = first_neg == -0x7FFFFFFF ? 0u : static_cast<u32>(last);
+  }
+  const i32 lb = static_cast<i32>(L.begin), span = static_cast<i32>(L.end) - static_cast<i32>(L.begin) + 1;
+  poa4_guide_to_lds(S, A.layers + wq.layer_first + liq, L.len, span);
+  lds_order();
+  u32 b_first = 0;
+  if (r_hi > r_lo) {
+    const u32 v0 = (me.flip ? g.order2 : g.order)[r_lo];
+    b_first = static_cast<u32>(poa4_band_start<K>(S, static_cast<i32>(sl.rb[v0] >> 16), lb, span,
+                                                   magic_of(static_cast<u32>(span > 0 ? span : 1)), L.len));
+  }
+  me.act = 1;
+  me.full = full ? 1u : 0u;
+  me.len = L.len;
+  me.lb = L.begin;
+  me.span = static_cast<u32>(span);
+  me.r_lo = r_lo;
+  me.n_rows = r_hi - r_lo;
+  me.t_end = 0;
+  me.best_rho1 = 0;
+  me.b_first = b_first;
+  me.dflag = 0;
+  if (lane == 0) C.st[rec] = me;
+  if (A.phase_cycles && lane == 0) {
+    sv::atomic_add(&A.phase_cycles[0], sv::clock() - t0);
+    sv::atomic_add(&A.phase_cycles[15], sv::clock() - t0);
+  }
+}
+
+// phase A2 of a round: the row descriptors, wave = 64 nodes of one window
+template <class K>
+__host__ __device__ inline void poa4_phase_desc(const Poa4Args& A, const Poa4Ctx& C, Poa4LdsDesc& S, u32 wave) {
+  const int lane = sv::lane();
+  const u32 rec = wave / kDescWaves, chunk = wave % kDescWaves;
+  const u32 wave_dp = rec / P4::G;
+  const int q = static_cast<int>(rec % P4::G);
+  if (poa4_my_record(C, wave_dp, q) == 0xFFFFFFFFu) return;
+  const Poa4Win me = C.st[rec];
+  if (me.phase != kRunning || !me.act) return;
+  const u32 nn = me.nn;
+  if (chunk * 64 >= nn && chunk != 0) return;
+  const unsigned long long t0 = sv::clock();
+  const Poa4Slot sl = poa4_carve(poa4_slot_of(A, C, wave_dp, q), A.nmax, A.lmax);
+  const Poa2Slot& g = sl.g;
+  const bool full = me.full != 0;
+  const u32 len = me.len, r_lo = me.r_lo, n_rows = me.n_rows, r_hi = r_lo + n_rows;
+  const i32 lb = static_cast<i32>(me.lb), span = static_cast<i32>(me.span), b_first = static_cast<i32>(me.b_first);
+  poa4_guide_to_lds(S, A.layers + A.windows[me.wi].layer_first + me.li, len, span);
+  if (lane < 60) S.seq2[lane] = sl.seq2g[lane];
+  lds_order();
+  const u32 span_magic = magic_of(static_cast<u32>(span > 0 ? span : 1));
+  const u32 ring_off = static_cast<u32>(offsetof(Poa4Lds, g)) + static_cast<u32>(q) * static_cast<u32>(sizeof(Poa4Group));
+  const u32 dump_off = ring_off + static_cast<u32>(offsetof(Poa4Group, dump));
+  const u32 neg_off = static_cast<u32>(offsetof(Poa4Lds, neg));
+  const u32 neg2 = neg_off | (neg_off << 16);
+  u32 flag = 0, marked_rows = 0;
+  i32 t_end = 0;
+  for (u32 v0 = chunk * 64; v0 < nn; v0 += 64 * kDescWaves) {
+    const u32 v = v0 + static_cast<u32>(lane);
+    bool ok = v < nn;
+    const u32 vq = ok ? v : 0u;
+    const u32 rbv = sl.rb[vq];
+    u32 cc = g.in_cnt[vq];
+    const u32 code = g.code[vq];
+    const u32 outc = full ? g.out_cnt[vq] : g.sub_out[vq];
+    const u32 mk = full ? 1u : g.mark[vq];
+    const uint4 tl = *reinterpret_cast<const uint4*>(g.in_tail + static_cast<size_t>(vq) * kPoaMaxIn);
+    const u32 r = rbv & 0xFFFFu;
+    ok = ok && r >= r_lo && r < r_hi;
+    const bool marked = ok && mk != 0;
+    if (!marked) cc = 0;
+    u32 trb[8], tmk[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const u32 wd = k < 2 ? tl.x : (k < 4 ? tl.y : (k < 6 ? tl.z : tl.w));
+      const u32 t = static_cast<u32>(k) < cc ? (wd >> (16 * (k & 1))) & 0xFFFFu : 0u;
+      trb[k] = sl.rb[t];
+      tmk[k] = full ? 1u : g.mark[t];
     }
-    lds_order();
-    for (u32 wd = lane; wd < 60; wd += 64) {
-      u32 x = 0;
-      for (u32 c = 0; c < 16; ++c) {
-        const i32 p = static_cast<i32>(wd * 16 + c) - 1;
-        if (p >= 0 && p < static_cast<i32>(L.len)) x |= static_cast<u32>(Sg.u.bytes[p] & 3u) << (2 * c);
+    const i32 b = poa4_band_start<K>(S, static_cast<i32>(rbv >> 16), lb, span, span_magic, len);
+    const u32 rho = r - r_lo;
+    u32 ep[4] = {neg2, neg2, neg2, neg2};
+    u32 np = 0, lbw = 0;
+    auto edge = [&](u32 rbt, bool inside) {
+      if (!inside) return;
+      const u32 lbk = r - (rbt & 0xFFFFu);
+      const i32 d = b - poa4_band_start<K>(S, static_cast<i32>(rbt >> 16), lb, span, span_magic, len);
+      if (lbk < 1 || lbk > static_cast<u32>(K::kRing - 1) || lbk > rho || d < 0 || d > K::kMaxD) {
+        flag = 7;
+      } else if (np < static_cast<u32>(K::kEdges)) {
+        const u32 e = ring_off + ((rho - lbk) % static_cast<u32>(K::kRing)) * static_cast<u32>(K::kRowB) + 2u * static_cast<u32>(d);
+        const u32 idx = np >> 1;
+        const u32 keep = (np & 1) ? 0x0000FFFFu : 0xFFFF0000u;
+        const u32 put = (np & 1) ? e << 16 : e;
+#pragma unroll
+        for (u32 i = 0; i < 4; ++i) ep[i] = i == idx ? ((ep[i] & keep) | put) : ep[i];
+        if (np < 6) lbw |= lbk << (5 * np);
       }
-      Sg.seq2[wd] = x;
-      sl2.seq2g[wd] = x;
+      ++np;
+    };
+#pragma unroll
+    for (int k = 0; k < 8; ++k) edge(trb[k], static_cast<u32>(k) < cc && tmk[k] != 0);
+    for (u32 k = 8; k < cc; ++k) {  // rare
+      const u32 t = g.in_tail[static_cast<size_t>(v) * kPoaMaxIn + k];
+      edge(sl.rb[t], full || g.mark[t] != 0);
     }
-    const u32 blen = A.layers[wq.layer_first].len;
-    const u32 offset = static_cast<u32>(0.01 * blen);
-    const bool fullq = L.begin < offset && L.end > blen - offset;
-    if (!fullq) poa_subgraph_marks(g, nnq, A.nmax, L.begin, L.end);
-    if (q == q2) {
-      act = true;
-      full = fullq;
-      len = L.len;
-      lb = static_cast<i32>(L.begin);
-      span = static_cast<i32>(L.end) - static_cast<i32>(L.begin) + 1;
-      Lp = A.layers + wq.layer_first + liq;
-      li = liq;
+    if (np > static_cast<u32>(K::kEdges)) flag = 3;
+    if (ok) {
+      // match mask of the row's 32 columns against the layer
+      u32 mm = 0;
+      {
+        const u32 wi = static_cast<u32>(b) >> 4, sh = 2u * (static_cast<u32>(b) & 15u);
+        const u32 x0 = S.seq2[wi], x1 = S.seq2[wi + 1], x2 = S.seq2[wi + 2];
+        const u32 pat = code * 0x55555555u;
+        const u32 elo = funnel_shr(x1, x0, sh) ^ pat, ehi = funnel_shr(x2, x1, sh) ^ pat;
+        auto even_bits = [](u32 y) -> u32 {
+          y = ~(y | (y >> 1)) & 0x55555555u;
+          y = (y | (y >> 1)) & 0x33333333u;
+          y = (y | (y >> 2)) & 0x0F0F0F0Fu;
+          y = (y | (y >> 4)) & 0x00FF00FFu;
+          y = (y | (y >> 8)) & 0x0000FFFFu;
+          return y;
+        };
+        mm = even_bits(elo) | (even_bits(ehi) << 16);
+      }
+      i32 sdiff = b - b_first;
+      if (sdiff < 0) {  // (never: a node's backbone coordinate does not decrease along the order)
+        flag = 7;
+        sdiff = 0;
+      }
+      const u32 Srow = rho + (rho >> 4) + (static_cast<u32>(sdiff) >> 1) + 1u;
+      const u32 own = marked ? ring_off + (rho % static_cast<u32>(K::kRing)) * static_cast<u32>(K::kRowB) + 4u : dump_off;
+      const bool endn = marked && outc == 0;
+      uint4 da, db;
+      da.x = Srow | (own << 16);
+      da.y = v | (static_cast<u32>(b) << 16) | ((np > 15u ? 15u : np) << 26) | (marked ? 1u << 30 : 0u) | (endn ? 1u << 31 : 0u);
+      da.z = mm;
+      da.w = ep[0];
+      db.x = ep[1];
+      db.y = ep[2];
+      db.z = ep[3];
+      db.w = lbw;
+      sl.desc[2 * static_cast<size_t>(rho)] = da;
+      sl.desc[2 * static_cast<size_t>(rho) + 1] = db;
+      t_end = static_cast<i32>(Srow) + 17 > t_end ? static_cast<i32>(Srow) + 17 : t_end;
+      if (marked) ++marked_rows;
     }
   }
-  sv::sync();
-  unsigned long long t_set = sv::clock() - t0;
-  t0 = sv::clock();
-  u32 r_lo = 0, n_rows = 0, t_end = 0, flag = 0, marked_rows = 0;
-  if (sv::any(act)) {
-    poa4_prepass<K, LT>(A, S, poa4_slot_of(A, C, wave, q), act, me.nn, full, me.flip != 0, Lp, len, lb, span, r_lo, n_rows, t_end, flag,
-                    marked_rows);
-    if ((lane & (GS - 1)) == 0 && act && A.phase_cycles) {
+  // rows beyond the last one: what the lanes' descriptor prefetch runs into
+  if (chunk == 0 && lane < 32) {
+    const size_t rho = static_cast<size_t>(n_rows) + static_cast<size_t>(lane);
+    sl.desc[2 * rho] = uint4{kInactiveS | (dump_off << 16), 0u, 0u, neg2};
+    sl.desc[2 * rho + 1] = uint4{neg2, neg2, neg2, 0u};
+  }
+  t_end = sv::wave_max(t_end);
+  flag = static_cast<u32>(sv::wave_max(static_cast<i32>(flag)));
+  marked_rows = sv::wave_sum(marked_rows);
+  if (lane == 0) {
+    if (t_end) atomic_max_u32(&C.st[rec].t_end, static_cast<u32>(t_end));
+    if (flag) atomic_max_u32(&C.st[rec].dflag, flag);
+    if (A.phase_cycles) {
       sv::atomic_add(&A.phase_cycles[6], static_cast<unsigned long long>(marked_rows) * len);
       sv::atomic_add(&A.phase_cycles[7], static_cast<unsigned long long>(marked_rows) * (len + 1 < 32u ? len + 1 : 32u));
+      sv::atomic_add(&A.phase_cycles[0], sv::clock() - t0);
+      sv::atomic_add(&A.phase_cycles[10], sv::clock() - t0);
     }
-    if (act && flag) {  // beyond this kernel's limits (in-degree, in-edge length, band step): the 64-column kernel's job
-      phase = kFailed;
-      status = kPoaBandHit | (li << 8);
-      act = false;
-    }
-  }
-  if (my_rec != 0xFFFFFFFFu && (lane & (GS - 1)) == 0) {
-    me.phase = phase;
-    me.status = status;
-    me.li = li;
-    me.act = act ? 1u : 0u;
-    me.full = full ? 1u : 0u;
-    me.len = len;
-    me.lb = static_cast<u32>(lb);
-    me.span = static_cast<u32>(span);
-    me.r_lo = r_lo;
-    me.n_rows = n_rows;
-    me.t_end = t_end;
-    me.best_rho1 = 0;
-    C.st[my_rec] = me;
-  }
-  if (A.phase_cycles && lane == 0) {
-    sv::atomic_add(&A.phase_cycles[0], t_set + (sv::clock() - t0));
-    sv::atomic_add(&A.phase_cycles[10], sv::clock() - t0);
-    sv::atomic_add(&A.phase_cycles[15], t_set);
   }
 }
 
@@ -1508,11 +1463,20 @@ __host__ __device__ inline void poa4_phase_dp(const Poa4Args& A, const Poa4Ctx& 
   const u32 my_rec = poa4_my_record(C, wave, q);
   u32 act = 0, t_end = 0, len = 0, li = 0;
   if (my_rec != 0xFFFFFFFFu) {
-    const Poa4Win& w = C.st[my_rec];
+    Poa4Win& w = C.st[my_rec];
     act = (w.phase == kRunning && w.act) ? 1u : 0u;
     t_end = w.t_end;
     len = w.len;
     li = w.li;
+    if (act && (w.dflag || t_end + 8u > poa4_steps(A.nmax, A.lmax))) {
+      // beyond this kernel's limits (in-degree, in-edge length, band step): the 64-column kernel's job
+      if ((lane & (K::GS - 1)) == 0) {
+        w.phase = kFailed;
+        w.status = kPoaBandHit | (li << 8);
+        w.act = 0;
+      }
+      act = 0;
+    }
   }
   if (!sv::any(act != 0)) return;
   u32 best_rho1 = 0;
@@ -1628,9 +1592,13 @@ __host__ __device__ inline void poa4_phase_final(const Poa4Args& A, const Poa4Ct
 __global__ __launch_bounds__(64) void poa4_init_kernel(const Poa4Args A, const Poa4Ctx C) {
   poa4_phase_init(A, C, blockIdx.x);
 }
-__global__ __launch_bounds__(64) void poa4_layer_kernel(const Poa4Args A, const Poa4Ctx C) {
-  __shared__ Poa4LdsLayer lds;
-  poa4_phase_layer<P4, Poa4LdsLayer>(A, C, lds, blockIdx.x);
+__global__ __launch_bounds__(64) void poa4_setup_kernel(const Poa4Args A, const Poa4Ctx C) {
+  __shared__ Poa4LdsDesc lds;
+  poa4_phase_setup<P4>(A, C, lds, blockIdx.x);
+}
+__global__ __launch_bounds__(64) void poa4_desc_kernel(const Poa4Args A, const Poa4Ctx C) {
+  __shared__ Poa4LdsDesc lds;
+  poa4_phase_desc<P4>(A, C, lds, blockIdx.x);
 }
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void poa4_dp_kernel(const Poa4Args A, const Poa4Ctx C) {
   __shared__ Poa4Lds lds;
@@ -1737,8 +1705,9 @@ void poa_v4_launch(Engine& e, const PoaBatchDev& b) {
     for (u32 round = 1; round <= max_layers; ++round) {
       for (u32 p = 0; p < n_parts; ++p) {
         if (!n_waves[p]) continue;
-        RVN_KLAUNCH_ON(kKPoaBanded, st[p], (poa4_layer_kernel<<<n_waves[p], 64, 0, st[p]>>>(A, C[p])));
+        RVN_KLAUNCH_ON(kKPoaBanded, st[p], (poa4_setup_kernel<<<n_waves[p] * P4::G, 64, 0, st[p]>>>(A, C[p])));
         if (round == max_layers) continue;  // (the last call only lets every window find its layers exhausted)
+        RVN_KLAUNCH_ON(kKPoaBanded, st[p], (poa4_desc_kernel<<<n_waves[p] * P4::G * kDescWaves, 64, 0, st[p]>>>(A, C[p])));
         RVN_KLAUNCH_ON(kKPoaBanded, st[p], (poa4_dp_kernel<<<n_waves[p], 64, 0, st[p]>>>(A, C[p])));
         RVN_KLAUNCH_ON(kKPoaBanded, st[p], (poa4_tb_kernel<<<n_waves[p], 64, 0, st[p]>>>(A, C[p])));
         RVN_KLAUNCH_ON(kKPoaBanded, st[p], (poa4_update_kernel<<<n_waves[p], 64, 0, st[p]>>>(A, C[p])));
@@ -1763,7 +1732,7 @@ struct EmuCall4 {
   const Poa4Args* A;
   const Poa4Ctx* C;
   Poa4Lds* S;
-  Poa4LdsLayer* SL;
+  Poa4LdsDesc* SL;
   Poa4LdsUpdate* SU;
   Poa4LdsTb* ST;
   u32 wave;
@@ -1773,7 +1742,8 @@ void emu_entry4(void* p) {
   EmuCall4* c = static_cast<EmuCall4*>(p);
   switch (c->phase) {
     case 0: poa4_phase_init(*c->A, *c->C, c->wave); break;
-    case 1: poa4_phase_layer<P4, Poa4LdsLayer>(*c->A, *c->C, *c->SL, c->wave); break;
+    case 1: poa4_phase_setup<P4>(*c->A, *c->C, *c->SL, c->wave); break;
+    case 6: poa4_phase_desc<P4>(*c->A, *c->C, *c->SL, c->wave); break;
     case 2: poa4_phase_dp<P4>(*c->A, *c->C, *c->S, c->wave); break;
     case 3: poa4_phase_tb<P4>(*c->A, *c->C, *c->ST, c->wave); break;
     case 4: poa4_phase_update<P4, Poa4LdsUpdate>(*c->A, *c->C, *c->SU, c->wave); break;
@@ -1812,15 +1782,20 @@ void poa_v4_emulate(const std::vector<PoaWindow>& wins, const std::vector<PoaLay
   const Poa4Args A = args_of4(b, scratch.data(), slot_bytes);
   const Poa4Ctx C{st.data(), 0, count, 0, 1, 0};
   std::vector<Poa4Lds> lds(1);
-  std::vector<Poa4LdsLayer> ldsl(1);
+  std::vector<Poa4LdsDesc> ldsl(1);
   std::vector<Poa4LdsUpdate> ldsu(1);
   std::vector<Poa4LdsTb> ldst(1);
   u32 max_layers = 0;
   for (const PoaWindow& w : wins) max_layers = std::max(max_layers, w.n_layers);
   auto run = [&](int ph) {
-    for (u32 wv = 0; wv < n_waves; ++wv) {
+    const u32 waves = ph == 1 ? n_waves * P4::G : (ph == 6 ? n_waves * P4::G * kDescWaves : n_waves);
+    for (u32 wv = 0; wv < waves; ++wv) {
+      if (ph == 6) {  // (waves that would return at once: not worth 64 fibres each)
+        const u32 rec = wv / kDescWaves, chunk = wv % kDescWaves;
+        if (rec >= count || st[rec].phase != kRunning || !st[rec].act || (chunk * 64 >= st[rec].nn && chunk != 0)) continue;
+      }
       std::memset(static_cast<void*>(lds.data()), 0, sizeof(Poa4Lds));  // (a fresh workgroup's LDS holds anything: zeros here)
-      std::memset(static_cast<void*>(ldsl.data()), 0, sizeof(Poa4LdsLayer));
+      std::memset(static_cast<void*>(ldsl.data()), 0, sizeof(Poa4LdsDesc));
       std::memset(static_cast<void*>(ldsu.data()), 0, sizeof(Poa4LdsUpdate));
       std::memset(static_cast<void*>(ldst.data()), 0, sizeof(Poa4LdsTb));
       EmuCall4 call{&A, &C, lds.data(), ldsl.data(), ldsu.data(), ldst.data(), wv, ph};
@@ -1830,6 +1805,7 @@ void poa_v4_emulate(const std::vector<PoaWindow>& wins, const std::vector<PoaLay
   run(0);
   for (u32 round = 1; round < max_layers; ++round) {
     run(1);
+    run(6);
     run(2);
     run(3);
     run(4);
