@@ -71,7 +71,6 @@ struct alignas(16) Poa4LdsT {
 // 896 order slots, the set-up + descriptor pass the layer's bytes
 using Poa4Group = Poa4GroupT<P4::kRing * P4::kRowB>;
 using Poa4Lds = Poa4LdsT<P4::kRing * P4::kRowB>;
-using Poa4LdsUpdate = Poa4LdsT<kPoa2MaxSeq * 2>;
 static_assert(sizeof(Poa4Lds) <= 10240, "sixteen waves per CU need <= 10 KB of LDS each");
 static_assert(P4::kRowB == 68 + 2 * (P4::kMaxD + 2), "ring row = 2 pads + 32 cells + kMaxD + 2 pads");
 
@@ -99,7 +98,8 @@ struct Poa4Slot {
                  //            {e2 | e3 << 16, e4 | e5 << 16, e6 | e7 << 16, rank distances of in-edges 0..5 (5 bits each)}
   u32* rb;       // per node: rank | backbone coordinate << 16 (kept by the set-up and by poa4_update_graph)
   uint4* bps;    // backpointer stream: [step / 8][lane of the window] 16 bytes = 8 steps x 2 columns
-  u32* seq2g;    // the current layer, 2 bits per base (the LDS image of phase A, for the graph update's launch)
+  u32* seq2g;    // the current layer: [0, 60) 2 bits per base, [64, 96) its band guide as eight segments (set-up kernel ->
+                 // descriptor / graph update kernels)
 };
 __host__ __device__ inline u32 poa4_desc_rows(u32 nmax) { return nmax + 64; }
 __host__ __device__ inline u32 poa4_steps(u32 nmax, u32 lmax) { return nmax + nmax / 16 + lmax / 2 + 96; }
@@ -108,7 +108,7 @@ inline size_t poa4_slot_bytes(u32 nmax, u32 lmax) {
   b += static_cast<size_t>(poa4_desc_rows(nmax)) * 32;
   b += (static_cast<size_t>(nmax) * 4 + 255) & ~size_t(255);
   b += (static_cast<size_t>(poa4_steps(nmax, lmax)) / P4::kU + 2) * 16 * 16;
-  b += 256;
+  b += 512;
   return (b + 255) & ~size_t(255);
 }
 __host__ __device__ inline Poa4Slot poa4_carve(unsigned char* base, u32 nmax, u32 lmax) {
@@ -248,8 +248,8 @@ __host__ __device__ inline u32 poa4_nth_pred_rank(const Poa2Slot& g, u32 v, u32 
 }
 
 // ---- the row descriptors of a layer: flat over the nodes ---------------------------------------------------------------
-// One wave = 64 nodes of one window (a window takes kDescWaves waves; a graph of more than 64 * kDescWaves nodes makes them
-// loop).  Everything a node contributes is a coalesced load (rb[] holds rank and backbone coordinate of a node in one
+// One wave = 256 nodes of one window (a launch gives a window ceil(nmax / 256) waves; those beyond its graph return at
+// once).  Everything a node contributes is a coalesced load (rb[] holds rank and backbone coordinate of a node in one
 // word), only its in-edges' tails are gathered; band starts come from the layer's guide through per-segment reciprocals
 // kept in LDS.  The descriptor of every node whose rank lies in the rank range [r_lo, r_hi) of the layer's subgraph is
 // written at its row rho = rank - r_lo; the steps of the layer's NW, the "beyond this kernel's limits" flag and the work
@@ -270,7 +270,6 @@ struct alignas(16) Poa4LdsDesc {
   u32 seq2[60];    // the layer, 2 bits per base
   u8 bytes[kPoa2MaxSeq + 16];  // (set-up kernel: one-byte codes before they are packed)
 };
-constexpr u32 kDescWaves = 16;
 
 // the layer's band guide as eight segments in LDS (lanes 0..7), and the band start of a backbone coordinate from it
 __host__ __device__ inline void poa4_guide_to_lds(Poa4LdsDesc& S, const PoaLayer* Lp, u32 len, i32 span) {
@@ -791,17 +790,30 @@ __host__ __device__ __forceinline__ void atomic_inc_u16(u16* base, u32 idx) {  /
 #endif
 }
 
-template <class K, class LT>
-__host__ __device__ inline u32 poa4_update_graph(const Poa4Args A, LT& S, unsigned char* slot_mem, bool act,
+// GW = lanes per window: 64 (one window per wave, 256 positions per iteration — the update kernel) or 16.
+template <int GW>
+__host__ __device__ inline u32 poa4_update_graph(const Poa4Args A, u16* nslot, const u32* seq2, unsigned char* slot_mem, bool act,
                                                  const PoaLayer* Lp, u32 len, u32 lb, u32& nn, bool& flip,
                                                  unsigned long long& t_add, unsigned long long& t_ord) {
   P4_ASSUME_GLOBAL(slot_mem);
   P4_ASSUME_GLOBAL(Lp);
-  P4_ASSUME_LDS(&S);
+  P4_ASSUME_LDS(nslot);
+  P4_ASSUME_LDS(seq2);
   const int lane = sv::lane();
-  const int gl = lane & 15, gbase = lane & ~15, q = lane >> 4;
-  auto& Sg = S.g[q];
-  u16* nslot = reinterpret_cast<u16*>(Sg.u.ring32);  // order slots of the new nodes (<= 896 of them; the ring holds 1248)
+  const int gl = lane & (GW - 1), gbase = lane & ~(GW - 1);
+  constexpr unsigned long long kGMask = GW == 64 ? ~0ULL : ((1ULL << (GW & 63)) - 1ULL);
+  auto shift1 = [&](int v, int fill) -> int {  // value of the lane below in the window; its first lane gets `fill`
+    if constexpr (GW == 16) {
+      return sv::row_shr<1>(v, fill);
+    } else {
+      const int t = sv::bperm(v, lane - 1);
+      return gl == 0 ? fill : t;
+    }
+  };
+  auto gmax = [&](i32 v) -> i32 {
+    if constexpr (GW == 16) return group_max_i(v);
+    else return sv::wave_max(v);
+  };
   const Poa2Slot g = poa4_graph(slot_mem, A.nmax, A.lmax, flip);
   u16* const rb16 = reinterpret_cast<u16*>(poa4_carve(slot_mem, A.nmax, A.lmax).rb);  // [2 v] rank, [2 v + 1] backbone coordinate
   const PoaLayer L = *Lp;
@@ -809,21 +821,22 @@ __host__ __device__ inline u32 poa4_update_graph(const Poa4Args A, LT& S, unsign
   unsigned long long t0 = sv::clock();
   const u32 n_old = nn;
   const u32 max_len = static_cast<u32>(sv::wave_max(act ? static_cast<int>(len) : 0));
-  auto gballot = [&](bool p) -> u32 { return static_cast<u32>(sv::ballot(p) >> gbase) & 0xFFFFu; };
+  auto gballot = [&](bool p) -> unsigned long long { return (sv::ballot(p) >> gbase) & kGMask; };
+  auto letter_at = [&](u32 p) -> u32 { return (seq2[(p + 1) >> 4] >> (2 * ((p + 1) & 15u))) & 3u; };
   // ---- the first aligned position: the unaligned prefix goes before all members of its column ----
   u32 first_p = 0xFFFFFFFFu;
-  for (u32 p0 = 0; p0 < max_len; p0 += 64) {
+  for (u32 p0 = 0; p0 < max_len; p0 += 4 * GW) {
     if (!sv::any(act && first_p == 0xFFFFFFFFu && p0 < len)) break;
     u32 pn[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const u32 p = p0 + 16u * static_cast<u32>(u) + static_cast<u32>(gl);
+      const u32 p = p0 + static_cast<u32>(GW) * static_cast<u32>(u) + static_cast<u32>(gl);
       pn[u] = (act && p < len) ? g.pos_node[p] : kNone4;
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const u32 bal = gballot(pn[u] != kNone4);
-      if (first_p == 0xFFFFFFFFu && bal) first_p = p0 + 16u * static_cast<u32>(u) + static_cast<u32>(__builtin_ctz(bal));
+      const unsigned long long bal = gballot(pn[u] != kNone4);
+      if (first_p == 0xFFFFFFFFu && bal) first_p = p0 + static_cast<u32>(GW) * static_cast<u32>(u) + static_cast<u32>(__builtin_ctzll(bal));
     }
   }
   u32 carry_slot = n_old, carry_b = lb;
@@ -844,17 +857,17 @@ __host__ __device__ inline u32 poa4_update_graph(const Poa4Args A, LT& S, unsign
   u32 why = 0;  // != 0: the window has failed; its lanes keep step with the wave without touching the graph
   u32 prev_tgt = kNone4;   // node of position p0 - 1 (the last position of the previous iteration)
   i32 prev_w = 0;          // its weight
-  for (u32 p0 = 0; p0 < max_len; p0 += 64) {
+  for (u32 p0 = 0; p0 < max_len; p0 += 4 * GW) {
     const bool go = act && why == 0;
     u32 p[4], an[4], letter[4];
     bool valid[4], has[4];
     // level 1: the nodes the positions are aligned to
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      p[u] = p0 + 16u * static_cast<u32>(u) + static_cast<u32>(gl);
+      p[u] = p0 + static_cast<u32>(GW) * static_cast<u32>(u) + static_cast<u32>(gl);
       valid[u] = go && p[u] < len;
       an[u] = valid[u] ? g.pos_node[p[u]] : kNone4;
-      letter[u] = valid[u] ? poa4_letter(Sg, p[u]) : 0u;
+      letter[u] = valid[u] ? letter_at(p[u]) : 0u;
     }
     // level 2: those nodes
     u32 c_an[4], ac[4], rk_an[4], bp_an[4];
@@ -903,15 +916,15 @@ __host__ __device__ inline u32 poa4_update_graph(const Poa4Args A, LT& S, unsign
         }
       }
       const u32 gslot = rmax + 1, gb = bp_an[u];
-      const u32 bal = gballot(has[u]);
-      const u32 below = bal & ((2u << gl) - 1u);
-      const int src = below ? 31 - __builtin_clz(below) : 0;
+      const unsigned long long bal = gballot(has[u]);
+      const unsigned long long below = bal & (gl == 63 ? ~0ULL : ((2ULL << gl) - 1ULL));
+      const int src = below ? 63 - __builtin_clzll(below) : 0;
       const u32 s_sh = static_cast<u32>(sv::bperm(static_cast<int>(gslot), gbase | src));
       const u32 b_sh = static_cast<u32>(sv::bperm(static_cast<int>(gb), gbase | src));
       const u32 fslot = below ? s_sh : carry_slot;
       const u32 fb = below ? b_sh : carry_b;
       {
-        const int top = bal ? 31 - __builtin_clz(bal) : 0;
+        const int top = bal ? 63 - __builtin_clzll(bal) : 0;
         const u32 cs = static_cast<u32>(sv::bperm(static_cast<int>(gslot), gbase | top));
         const u32 cb = static_cast<u32>(sv::bperm(static_cast<int>(gb), gbase | top));
         if (bal) {
@@ -920,12 +933,12 @@ __host__ __device__ inline u32 poa4_update_graph(const Poa4Args A, LT& S, unsign
         }
       }
       is_new[u] = valid[u] && t == kNone4;
-      const u32 nb = gballot(is_new[u]);
-      const u32 cnt = static_cast<u32>(__builtin_popcount(nb));
+      const unsigned long long nb = gballot(is_new[u]);
+      const u32 cnt = static_cast<u32>(__builtin_popcountll(nb));
       if (go && why == 0 && (n_old + total_new + cnt > nmax || total_new + cnt > lmax)) why = 2;
       id_new[u] = 0;
       if (is_new[u] && why == 0) {
-        const u32 tn = total_new + static_cast<u32>(__builtin_popcount(nb & ((1u << gl) - 1u)));
+        const u32 tn = total_new + static_cast<u32>(__builtin_popcountll(nb & ((1ULL << gl) - 1ULL)));
         const u32 id = n_old + tn;
         id_new[u] = id;
         t = id;
@@ -978,10 +991,10 @@ __host__ __device__ inline u32 poa4_update_graph(const Poa4Args A, LT& S, unsign
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       // node and weight of position p - 1: the lane below; lane 0 takes the last lane of the previous quarter
-      const u32 last_t = static_cast<u32>(sv::bperm(static_cast<int>(u == 0 ? prev_tgt : tgt[u > 0 ? u - 1 : 0]), gbase | 15));
-      const i32 last_w = sv::bperm(u == 0 ? prev_w : wgt[u > 0 ? u - 1 : 0], gbase | 15);
-      const u32 tail = static_cast<u32>(sv::row_shr<1>(static_cast<int>(tgt[u]), static_cast<int>(last_t)));
-      const i32 tw = sv::row_shr<1>(wgt[u], last_w);
+      const u32 last_t = static_cast<u32>(sv::bperm(static_cast<int>(u == 0 ? prev_tgt : tgt[u > 0 ? u - 1 : 0]), gbase | (GW - 1)));
+      const i32 last_w = sv::bperm(u == 0 ? prev_w : wgt[u > 0 ? u - 1 : 0], gbase | (GW - 1));
+      const u32 tail = static_cast<u32>(shift1(static_cast<int>(tgt[u]), static_cast<int>(last_t)));
+      const i32 tw = shift1(wgt[u], last_w);
       if (valid[u] && why == 0) {
         const u32 head = tgt[u];
         if (len >= 2) {
@@ -1014,11 +1027,11 @@ __host__ __device__ inline u32 poa4_update_graph(const Poa4Args A, LT& S, unsign
     }
     // a failure anywhere in the window stops the whole window
     {
-      const u32 wmax = static_cast<u32>(group_max_i(static_cast<i32>(why)));
+      const u32 wmax = static_cast<u32>(gmax(static_cast<i32>(why)));
       why = wmax;
     }
-    prev_tgt = static_cast<u32>(sv::bperm(static_cast<int>(tgt[3]), gbase | 15));
-    prev_w = sv::bperm(wgt[3], gbase | 15);
+    prev_tgt = static_cast<u32>(sv::bperm(static_cast<int>(tgt[3]), gbase | (GW - 1)));
+    prev_w = sv::bperm(wgt[3], gbase | (GW - 1));
   }
   t_add += sv::clock() - t0;
   t0 = sv::clock();
@@ -1028,11 +1041,11 @@ __host__ __device__ inline u32 poa4_update_graph(const Poa4Args A, LT& S, unsign
   const bool doit = act && why == 0 && n_new != 0;
   if (sv::any(doit)) {
     const u32 max_old = static_cast<u32>(sv::wave_max(doit ? static_cast<int>(n_old) : 0));
-    for (u32 r0 = 0; r0 < max_old; r0 += 64) {
+    for (u32 r0 = 0; r0 < max_old; r0 += 4 * GW) {
       u32 rr[4], vv[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        rr[u] = r0 + 16u * static_cast<u32>(u) + static_cast<u32>(gl);
+        rr[u] = r0 + static_cast<u32>(GW) * static_cast<u32>(u) + static_cast<u32>(gl);
         vv[u] = (doit && rr[u] < n_old) ? g.order[rr[u]] : 0u;
       }
 #pragma unroll
@@ -1051,7 +1064,7 @@ __host__ __device__ inline u32 poa4_update_graph(const Poa4Args A, LT& S, unsign
       }
     }
     const u32 max_new = static_cast<u32>(sv::wave_max(doit ? static_cast<int>(n_new) : 0));
-    for (u32 t = static_cast<u32>(gl); t < max_new; t += 16) {
+    for (u32 t = static_cast<u32>(gl); t < max_new; t += GW) {
       if (doit && t < n_new) {
         const u32 r = static_cast<u32>(nslot[t]) + t;
         g.order2[r] = static_cast<u16>(n_old + t);
@@ -1166,7 +1179,7 @@ struct Poa4Win {  // per window of the chunk
   u32 r_lo, n_rows, t_end, best_rho1;
   u32 b_first;   // band start of the layer's first row
   u32 dflag;     // != 0: the descriptor pass found the layer beyond this kernel's limits
-  u32 pad_[2];
+  u32 cells_full, cells_band;  // work counters: rows of the layers' subgraphs x layer length / x band width
 };
 static_assert(sizeof(Poa4Win) == 80, "state record");
 __host__ __device__ __forceinline__ void atomic_max_u32(u32* p, u32 v) {
@@ -1174,6 +1187,13 @@ __host__ __device__ __forceinline__ void atomic_max_u32(u32* p, u32 v) {
   atomicMax(p, v);
 #else
   if (v > *p) *p = v;
+#endif
+}
+__host__ __device__ __forceinline__ void atomic_add_u32(u32* p, u32 v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  atomicAdd(p, v);
+#else
+  *p += v;
 #endif
 }
 
@@ -1290,6 +1310,7 @@ __host__ __device__ inline void poa4_phase_setup(const Poa4Args& A, const Poa4Ct
   const i32 lb = static_cast<i32>(L.begin), span = static_cast<i32>(L.end) - static_cast<i32>(L.begin) + 1;
   poa4_guide_to_lds(S, A.layers + wq.layer_first + liq, L.len, span);
   lds_order();
+  if (lane < 32) sl.seq2g[64 + lane] = S.segtab[lane];
   u32 b_first = 0;
   if (r_hi > r_lo) {
     const u32 v0 = (me.flip ? g.order2 : g.order)[r_lo];
@@ -1308,33 +1329,51 @@ __host__ __device__ inline void poa4_phase_setup(const Poa4Args& A, const Poa4Ct
   me.b_first = b_first;
   me.dflag = 0;
   if (lane == 0) C.st[rec] = me;
-  if (A.phase_cycles && lane == 0) {
-    sv::atomic_add(&A.phase_cycles[0], sv::clock() - t0);
-    sv::atomic_add(&A.phase_cycles[15], sv::clock() - t0);
-  }
+  if (A.phase_cycles && lane == 0) sv::atomic_add(&A.phase_cycles[0], sv::clock() - t0);
 }
 
-// phase A2 of a round: the row descriptors, wave = 64 nodes of one window
+// phase A2 of a round: the row descriptors, wave = 64 x kDescPer nodes of one window.  Two levels of loads: everything that
+// depends only on (window, node) — the window's record, the layer's packed codes and guide, the nodes' own fields — then
+// the gathers of the in-edges' tails.
+constexpr int kDescPer = 4;
 template <class K>
 __host__ __device__ inline void poa4_phase_desc(const Poa4Args& A, const Poa4Ctx& C, Poa4LdsDesc& S, u32 wave) {
   const int lane = sv::lane();
-  const u32 rec = wave / kDescWaves, chunk = wave % kDescWaves;
+  const u32 per_win = (A.nmax + 64 * kDescPer - 1) / (64 * kDescPer);
+  const u32 rec = wave / per_win, chunk = wave % per_win;
   const u32 wave_dp = rec / P4::G;
   const int q = static_cast<int>(rec % P4::G);
   if (poa4_my_record(C, wave_dp, q) == 0xFFFFFFFFu) return;
+  const Poa4Slot sl = poa4_carve(poa4_slot_of(A, C, wave_dp, q), A.nmax, A.lmax);
+  const Poa2Slot& g = sl.g;
   const Poa4Win me = C.st[rec];
   if (me.phase != kRunning || !me.act) return;
   const u32 nn = me.nn;
-  if (chunk * 64 >= nn && chunk != 0) return;
-  const unsigned long long t0 = sv::clock();
-  const Poa4Slot sl = poa4_carve(poa4_slot_of(A, C, wave_dp, q), A.nmax, A.lmax);
-  const Poa2Slot& g = sl.g;
+  if (chunk * kDescPer * 64 >= nn && chunk != 0) return;
+  // level 1
+  const u32 gw = sl.seq2g[lane < 60 ? lane : (lane < 64 ? 64 + (lane - 60) : 0)];
+  const u32 gw2 = lane < 28 ? sl.seq2g[68 + lane] : 0u;
+  u32 vv[kDescPer], rbv[kDescPer], cc[kDescPer], code[kDescPer], outc_f[kDescPer], outc_s[kDescPer], mk[kDescPer];
+  uint4 tl[kDescPer];
+#pragma unroll
+  for (int u = 0; u < kDescPer; ++u) {
+    vv[u] = (chunk * kDescPer + static_cast<u32>(u)) * 64 + static_cast<u32>(lane);
+    const u32 vq = vv[u] < A.nmax ? vv[u] : 0u;
+    rbv[u] = sl.rb[vq];
+    cc[u] = g.in_cnt[vq];
+    code[u] = g.code[vq];
+    outc_f[u] = g.out_cnt[vq];
+    outc_s[u] = g.sub_out[vq];
+    mk[u] = g.mark[vq];
+    tl[u] = *reinterpret_cast<const uint4*>(g.in_tail + static_cast<size_t>(vq) * kPoaMaxIn);
+  }
+  if (lane < 60) S.seq2[lane] = gw;
+  else S.segtab[lane - 60] = gw;
+  if (lane < 28) S.segtab[4 + lane] = gw2;
+  lds_order();
   const bool full = me.full != 0;
   const u32 len = me.len, r_lo = me.r_lo, n_rows = me.n_rows, r_hi = r_lo + n_rows;
   const i32 lb = static_cast<i32>(me.lb), span = static_cast<i32>(me.span), b_first = static_cast<i32>(me.b_first);
-  poa4_guide_to_lds(S, A.layers + A.windows[me.wi].layer_first + me.li, len, span);
-  if (lane < 60) S.seq2[lane] = sl.seq2g[lane];
-  lds_order();
   const u32 span_magic = magic_of(static_cast<u32>(span > 0 ? span : 1));
   const u32 ring_off = static_cast<u32>(offsetof(Poa4Lds, g)) + static_cast<u32>(q) * static_cast<u32>(sizeof(Poa4Group));
   const u32 dump_off = ring_off + static_cast<u32>(offsetof(Poa4Group, dump));
@@ -1342,29 +1381,28 @@ __host__ __device__ inline void poa4_phase_desc(const Poa4Args& A, const Poa4Ctx
   const u32 neg2 = neg_off | (neg_off << 16);
   u32 flag = 0, marked_rows = 0;
   i32 t_end = 0;
-  for (u32 v0 = chunk * 64; v0 < nn; v0 += 64 * kDescWaves) {
-    const u32 v = v0 + static_cast<u32>(lane);
-    bool ok = v < nn;
-    const u32 vq = ok ? v : 0u;
-    const u32 rbv = sl.rb[vq];
-    u32 cc = g.in_cnt[vq];
-    const u32 code = g.code[vq];
-    const u32 outc = full ? g.out_cnt[vq] : g.sub_out[vq];
-    const u32 mk = full ? 1u : g.mark[vq];
-    const uint4 tl = *reinterpret_cast<const uint4*>(g.in_tail + static_cast<size_t>(vq) * kPoaMaxIn);
-    const u32 r = rbv & 0xFFFFu;
-    ok = ok && r >= r_lo && r < r_hi;
-    const bool marked = ok && mk != 0;
-    if (!marked) cc = 0;
-    u32 trb[8], tmk[8];
+  // level 2: the tails of the in-edges
+  bool ok[kDescPer], marked[kDescPer];
+  u32 trb[kDescPer][8], tmk[kDescPer][8];
+#pragma unroll
+  for (int u = 0; u < kDescPer; ++u) {
+    const u32 r = rbv[u] & 0xFFFFu;
+    ok[u] = vv[u] < nn && r >= r_lo && r < r_hi;
+    marked[u] = ok[u] && (full || mk[u] != 0);
+    if (!marked[u]) cc[u] = 0;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      const u32 wd = k < 2 ? tl.x : (k < 4 ? tl.y : (k < 6 ? tl.z : tl.w));
-      const u32 t = static_cast<u32>(k) < cc ? (wd >> (16 * (k & 1))) & 0xFFFFu : 0u;
-      trb[k] = sl.rb[t];
-      tmk[k] = full ? 1u : g.mark[t];
+      const u32 wd = k < 2 ? tl[u].x : (k < 4 ? tl[u].y : (k < 6 ? tl[u].z : tl[u].w));
+      const u32 t = static_cast<u32>(k) < cc[u] ? (wd >> (16 * (k & 1))) & 0xFFFFu : 0u;
+      trb[u][k] = sl.rb[t];
+      tmk[u][k] = full ? 1u : g.mark[t];
     }
-    const i32 b = poa4_band_start<K>(S, static_cast<i32>(rbv >> 16), lb, span, span_magic, len);
+  }
+#pragma unroll
+  for (int u = 0; u < kDescPer; ++u) {
+    const u32 v = vv[u];
+    const u32 r = rbv[u] & 0xFFFFu;
+    const i32 b = poa4_band_start<K>(S, static_cast<i32>(rbv[u] >> 16), lb, span, span_magic, len);
     const u32 rho = r - r_lo;
     u32 ep[4] = {neg2, neg2, neg2, neg2};
     u32 np = 0, lbw = 0;
@@ -1386,19 +1424,19 @@ __host__ __device__ inline void poa4_phase_desc(const Poa4Args& A, const Poa4Ctx
       ++np;
     };
 #pragma unroll
-    for (int k = 0; k < 8; ++k) edge(trb[k], static_cast<u32>(k) < cc && tmk[k] != 0);
-    for (u32 k = 8; k < cc; ++k) {  // rare
+    for (int k = 0; k < 8; ++k) edge(trb[u][k], static_cast<u32>(k) < cc[u] && tmk[u][k] != 0);
+    for (u32 k = 8; k < cc[u]; ++k) {  // rare
       const u32 t = g.in_tail[static_cast<size_t>(v) * kPoaMaxIn + k];
       edge(sl.rb[t], full || g.mark[t] != 0);
     }
     if (np > static_cast<u32>(K::kEdges)) flag = 3;
-    if (ok) {
+    if (ok[u]) {
       // match mask of the row's 32 columns against the layer
       u32 mm = 0;
       {
         const u32 wi = static_cast<u32>(b) >> 4, sh = 2u * (static_cast<u32>(b) & 15u);
         const u32 x0 = S.seq2[wi], x1 = S.seq2[wi + 1], x2 = S.seq2[wi + 2];
-        const u32 pat = code * 0x55555555u;
+        const u32 pat = code[u] * 0x55555555u;
         const u32 elo = funnel_shr(x1, x0, sh) ^ pat, ehi = funnel_shr(x2, x1, sh) ^ pat;
         auto even_bits = [](u32 y) -> u32 {
           y = ~(y | (y >> 1)) & 0x55555555u;
@@ -1416,11 +1454,11 @@ __host__ __device__ inline void poa4_phase_desc(const Poa4Args& A, const Poa4Ctx
         sdiff = 0;
       }
       const u32 Srow = rho + (rho >> 4) + (static_cast<u32>(sdiff) >> 1) + 1u;
-      const u32 own = marked ? ring_off + (rho % static_cast<u32>(K::kRing)) * static_cast<u32>(K::kRowB) + 4u : dump_off;
-      const bool endn = marked && outc == 0;
+      const u32 own = marked[u] ? ring_off + (rho % static_cast<u32>(K::kRing)) * static_cast<u32>(K::kRowB) + 4u : dump_off;
+      const bool endn = marked[u] && (full ? outc_f[u] : outc_s[u]) == 0;
       uint4 da, db;
       da.x = Srow | (own << 16);
-      da.y = v | (static_cast<u32>(b) << 16) | ((np > 15u ? 15u : np) << 26) | (marked ? 1u << 30 : 0u) | (endn ? 1u << 31 : 0u);
+      da.y = v | (static_cast<u32>(b) << 16) | ((np > 15u ? 15u : np) << 26) | (marked[u] ? 1u << 30 : 0u) | (endn ? 1u << 31 : 0u);
       da.z = mm;
       da.w = ep[0];
       db.x = ep[1];
@@ -1430,7 +1468,7 @@ __host__ __device__ inline void poa4_phase_desc(const Poa4Args& A, const Poa4Ctx
       sl.desc[2 * static_cast<size_t>(rho)] = da;
       sl.desc[2 * static_cast<size_t>(rho) + 1] = db;
       t_end = static_cast<i32>(Srow) + 17 > t_end ? static_cast<i32>(Srow) + 17 : t_end;
-      if (marked) ++marked_rows;
+      if (marked[u]) ++marked_rows;
     }
   }
   // rows beyond the last one: what the lanes' descriptor prefetch runs into
@@ -1445,11 +1483,10 @@ __host__ __device__ inline void poa4_phase_desc(const Poa4Args& A, const Poa4Ctx
   if (lane == 0) {
     if (t_end) atomic_max_u32(&C.st[rec].t_end, static_cast<u32>(t_end));
     if (flag) atomic_max_u32(&C.st[rec].dflag, flag);
-    if (A.phase_cycles) {
-      sv::atomic_add(&A.phase_cycles[6], static_cast<unsigned long long>(marked_rows) * len);
-      sv::atomic_add(&A.phase_cycles[7], static_cast<unsigned long long>(marked_rows) * (len + 1 < 32u ? len + 1 : 32u));
-      sv::atomic_add(&A.phase_cycles[0], sv::clock() - t0);
-      sv::atomic_add(&A.phase_cycles[10], sv::clock() - t0);
+    // (work counters go through the window's record: hundreds of thousands of waves adding to one word would queue up)
+    if (marked_rows) {
+      atomic_add_u32(&C.st[rec].cells_full, marked_rows * len);
+      atomic_add_u32(&C.st[rec].cells_band, marked_rows * (len + 1 < 32u ? len + 1 : 32u));
     }
   }
 }
@@ -1523,29 +1560,29 @@ __host__ __device__ inline void poa4_phase_tb(const Poa4Args& A, const Poa4Ctx& 
   if (A.phase_cycles && lane == 0) sv::atomic_add(&A.phase_cycles[2], sv::clock() - t0);
 }
 
-// phase D: the graph update
-template <class K, class LT>
-__host__ __device__ inline void poa4_phase_update(const Poa4Args& A, const Poa4Ctx& C, LT& S, u32 wave) {
+// phase D: the graph update, one window per wave
+struct alignas(16) Poa4LdsUpd {
+  u16 nslot[kPoa2MaxSeq + 16];  // order slots of the layer's new nodes
+  u32 seq2[64];                 // the layer, 2 bits per base
+};
+__host__ __device__ inline void poa4_phase_update(const Poa4Args& A, const Poa4Ctx& C, Poa4LdsUpd& S, u32 rec) {
   const int lane = sv::lane();
-  const int q = lane / K::GS, gl = lane & (K::GS - 1);
-  const u32 my_rec = poa4_my_record(C, wave, q);
-  Poa4Win me{};
-  if (my_rec != 0xFFFFFFFFu) me = C.st[my_rec];
-  const bool act = me.phase == kRunning && me.act != 0;
-  if (!sv::any(me.phase == kRunning)) return;
-  unsigned char* const my_slot = poa4_slot_of(A, C, wave, q);
-  if (act) {  // the layer's packed codes back into LDS
-    const u32* src = poa4_carve(my_slot, A.nmax, A.lmax).seq2g;
-    for (u32 wd = static_cast<u32>(gl); wd < 60; wd += 16) S.g[q].seq2[wd] = src[wd];
-  }
+  const u32 wave_dp = rec / P4::G;
+  const int q = static_cast<int>(rec % P4::G);
+  if (poa4_my_record(C, wave_dp, q) == 0xFFFFFFFFu) return;
+  Poa4Win me = C.st[rec];
+  if (me.phase != kRunning) return;
+  const bool act = me.act != 0;
+  unsigned char* const my_slot = poa4_slot_of(A, C, wave_dp, q);
+  if (act && lane < 60) S.seq2[lane] = poa4_carve(my_slot, A.nmax, A.lmax).seq2g[lane];  // the layer's packed codes back into LDS
   lds_order();
   unsigned long long t_add = 0, t_ord = 0;
   u32 nn = me.nn;
   bool flip = me.flip != 0;
   const PoaLayer* Lp = A.layers;
   if (act) Lp = A.layers + A.windows[me.wi].layer_first + me.li;
-  const u32 why = poa4_update_graph<K, LT>(A, S, my_slot, act, Lp, me.len, me.lb, nn, flip, t_add, t_ord);
-  if (my_rec != 0xFFFFFFFFu && gl == 0 && me.phase == kRunning) {
+  const u32 why = poa4_update_graph<64>(A, S.nslot, S.seq2, my_slot, act, Lp, me.len, me.lb, nn, flip, t_add, t_ord);
+  if (lane == 0) {
     if (act && why) {
       me.phase = kFailed;
       me.status = why;
@@ -1553,9 +1590,9 @@ __host__ __device__ inline void poa4_phase_update(const Poa4Args& A, const Poa4C
       me.nn = nn;
       me.flip = flip ? 1u : 0u;
     }
-    me.li = me.li + 1;  // a window without a layer in this round has found its layers exhausted or failed in phase A
+    me.li = me.li + 1;
     me.act = 0;
-    C.st[my_rec] = me;
+    C.st[rec] = me;
   }
   if (A.phase_cycles && lane == 0) {
     sv::atomic_add(&A.phase_cycles[3], t_add);
@@ -1583,7 +1620,13 @@ __host__ __device__ inline void poa4_phase_final(const Poa4Args& A, const Poa4Ct
       sv::sync();
       st = 1;
     }
-    if (lane == 0) A.status[w.wi] = st;
+    if (lane == 0) {
+      A.status[w.wi] = st;
+      if (A.phase_cycles) {
+        sv::atomic_add(&A.phase_cycles[6], static_cast<unsigned long long>(w.cells_full));
+        sv::atomic_add(&A.phase_cycles[7], static_cast<unsigned long long>(w.cells_band));
+      }
+    }
   }
   if (A.phase_cycles && lane == 0) sv::atomic_add(&A.phase_cycles[5], sv::clock() - t0);
 }
@@ -1609,8 +1652,8 @@ __global__ __launch_bounds__(64) void poa4_tb_kernel(const Poa4Args A, const Poa
   poa4_phase_tb<P4>(A, C, lds, blockIdx.x);
 }
 __global__ __launch_bounds__(64) void poa4_update_kernel(const Poa4Args A, const Poa4Ctx C) {
-  __shared__ Poa4LdsUpdate lds;
-  poa4_phase_update<P4, Poa4LdsUpdate>(A, C, lds, blockIdx.x);
+  __shared__ Poa4LdsUpd lds;
+  poa4_phase_update(A, C, lds, blockIdx.x);
 }
 __global__ __launch_bounds__(64) void poa4_final_kernel(const Poa4Args A, const Poa4Ctx C) {
   __shared__ Poa4Lds lds;
@@ -1707,10 +1750,10 @@ void poa_v4_launch(Engine& e, const PoaBatchDev& b) {
         if (!n_waves[p]) continue;
         RVN_KLAUNCH_ON(kKPoaBanded, st[p], (poa4_setup_kernel<<<n_waves[p] * P4::G, 64, 0, st[p]>>>(A, C[p])));
         if (round == max_layers) continue;  // (the last call only lets every window find its layers exhausted)
-        RVN_KLAUNCH_ON(kKPoaBanded, st[p], (poa4_desc_kernel<<<n_waves[p] * P4::G * kDescWaves, 64, 0, st[p]>>>(A, C[p])));
+        RVN_KLAUNCH_ON(kKPoaBanded, st[p], (poa4_desc_kernel<<<n_waves[p] * P4::G * ((b.nmax + 255) / 256), 64, 0, st[p]>>>(A, C[p])));
         RVN_KLAUNCH_ON(kKPoaBanded, st[p], (poa4_dp_kernel<<<n_waves[p], 64, 0, st[p]>>>(A, C[p])));
         RVN_KLAUNCH_ON(kKPoaBanded, st[p], (poa4_tb_kernel<<<n_waves[p], 64, 0, st[p]>>>(A, C[p])));
-        RVN_KLAUNCH_ON(kKPoaBanded, st[p], (poa4_update_kernel<<<n_waves[p], 64, 0, st[p]>>>(A, C[p])));
+        RVN_KLAUNCH_ON(kKPoaBanded, st[p], (poa4_update_kernel<<<n_waves[p] * P4::G, 64, 0, st[p]>>>(A, C[p])));
       }
     }
     for (u32 p = 0; p < n_parts; ++p)
@@ -1733,7 +1776,7 @@ struct EmuCall4 {
   const Poa4Ctx* C;
   Poa4Lds* S;
   Poa4LdsDesc* SL;
-  Poa4LdsUpdate* SU;
+  Poa4LdsUpd* SU;
   Poa4LdsTb* ST;
   u32 wave;
   int phase;
@@ -1746,7 +1789,7 @@ void emu_entry4(void* p) {
     case 6: poa4_phase_desc<P4>(*c->A, *c->C, *c->SL, c->wave); break;
     case 2: poa4_phase_dp<P4>(*c->A, *c->C, *c->S, c->wave); break;
     case 3: poa4_phase_tb<P4>(*c->A, *c->C, *c->ST, c->wave); break;
-    case 4: poa4_phase_update<P4, Poa4LdsUpdate>(*c->A, *c->C, *c->SU, c->wave); break;
+    case 4: poa4_phase_update(*c->A, *c->C, *c->SU, c->wave); break;
     default: poa4_phase_final(*c->A, *c->C, *c->S, c->wave); break;
   }
 }
@@ -1783,20 +1826,21 @@ void poa_v4_emulate(const std::vector<PoaWindow>& wins, const std::vector<PoaLay
   const Poa4Ctx C{st.data(), 0, count, 0, 1, 0};
   std::vector<Poa4Lds> lds(1);
   std::vector<Poa4LdsDesc> ldsl(1);
-  std::vector<Poa4LdsUpdate> ldsu(1);
+  std::vector<Poa4LdsUpd> ldsu(1);
   std::vector<Poa4LdsTb> ldst(1);
   u32 max_layers = 0;
   for (const PoaWindow& w : wins) max_layers = std::max(max_layers, w.n_layers);
   auto run = [&](int ph) {
-    const u32 waves = ph == 1 ? n_waves * P4::G : (ph == 6 ? n_waves * P4::G * kDescWaves : n_waves);
+    const u32 per_win = (b.nmax + 255) / 256;
+    const u32 waves = (ph == 1 || ph == 4) ? n_waves * P4::G : (ph == 6 ? n_waves * P4::G * per_win : n_waves);
     for (u32 wv = 0; wv < waves; ++wv) {
       if (ph == 6) {  // (waves that would return at once: not worth 64 fibres each)
-        const u32 rec = wv / kDescWaves, chunk = wv % kDescWaves;
-        if (rec >= count || st[rec].phase != kRunning || !st[rec].act || (chunk * 64 >= st[rec].nn && chunk != 0)) continue;
+        const u32 rec = wv / per_win, chunk = wv % per_win;
+        if (rec >= count || st[rec].phase != kRunning || !st[rec].act || (chunk * 256 >= st[rec].nn && chunk != 0)) continue;
       }
       std::memset(static_cast<void*>(lds.data()), 0, sizeof(Poa4Lds));  // (a fresh workgroup's LDS holds anything: zeros here)
       std::memset(static_cast<void*>(ldsl.data()), 0, sizeof(Poa4LdsDesc));
-      std::memset(static_cast<void*>(ldsu.data()), 0, sizeof(Poa4LdsUpdate));
+      std::memset(static_cast<void*>(ldsu.data()), 0, sizeof(Poa4LdsUpd));
       std::memset(static_cast<void*>(ldst.data()), 0, sizeof(Poa4LdsTb));
       EmuCall4 call{&A, &C, lds.data(), ldsl.data(), ldsu.data(), ldst.data(), wv, ph};
       simt_emu::run_wave(&emu_entry4, &call);
