@@ -408,17 +408,16 @@ void rvn_poa_phase_cycles(const rvn_engine* e, uint64_t out[6]);
  * count again), cells inside the computed bands, POA batches}.  bench.py prices the kernel's roofline with it. */
 void rvn_poa_work(const rvn_engine* e, uint64_t out[3]);
 
-/* Which window kernel rvn_poa_consensus_batch / rvn_polish_round use: 0 (default) = banded LDS kernel with a
- * 64-column band; windows whose alignment touches the band edge are repeated with 128 and then 256 columns, and
- * what is left (or beyond a limit) by the full-matrix kernel; 1 = full-matrix kernel only; 2 / 3 / 4 = 64- / 128- /
- * 256-column band only (flagged windows come back with status 8); 5 .. 8 = poa3.hip only (several windows per wave):
- * four windows with a 64-column band / four windows, 32 columns / two windows, 32 columns / two windows, 64 columns.
- * Returns the previous mode. */
+/* Which window kernel rvn_poa_consensus_batch / rvn_polish_round use: 0 (default) = the rows-on-lanes kernel with a
+ * 32-column band (poa4.hip); windows whose alignment touches the band edge, or whose graph is beyond that kernel's
+ * limits, are repeated by the one-row-per-iteration kernel (poa2.hip) with 64, then 128 and 256 columns, and what is
+ * left (or beyond a limit) by the full-matrix kernel; 1 = full-matrix kernel only; 2 / 3 / 4 = 64- / 128- / 256-column
+ * band only (flagged windows come back with status 8); 9 = poa4.hip only.  Returns the previous mode. */
 int rvn_poa_set_mode(rvn_engine* e, int mode);
-/* TEST INFRASTRUCTURE: the four-windows-per-wave banded kernel (poa3.hip) stepped through on the HOST by a 64-fibre
- * wavefront emulator — the same kernel source, no GPU and no engine needed.  Arguments as rvn_poa_consensus_batch +
- * variant (0 .. 3 = the kernels of modes 5 .. 8); first attempt only (status 8: the window needs a wider band).  The CPU suite
- * compares it with the oracle (tests/test_poa3_emulation.py); nothing on the product path calls it. */
+/* TEST INFRASTRUCTURE: the rows-on-lanes banded kernel (poa4.hip) stepped through on the HOST by a 64-fibre
+ * wavefront emulator — the same phase functions, no GPU and no engine needed.  Arguments as rvn_poa_consensus_batch +
+ * variant (ignored: one kernel); first attempt only (status 8: the window needs a wider band).  The CPU suite
+ * compares it with the oracle (tests/test_poa4_emulation.py); nothing on the product path calls it. */
 int rvn_poa_banded_emulate(const uint8_t* codes, const uint8_t* quals, const uint64_t* layer_offsets,
                            const uint32_t* begins, const uint32_t* ends, const uint32_t* has_qual,
                            const uint32_t* window_offsets, uint32_t n_windows, int match, int mismatch, int gap,
@@ -428,6 +427,8 @@ int rvn_poa_banded_emulate(const uint8_t* codes, const uint8_t* quals, const uin
  * 256 columns or the full matrix) */
 uint32_t rvn_poa_fallback_windows(const rvn_engine* e);
 uint32_t rvn_poa_wide_windows(const rvn_engine* e);
+/* mode 0: windows of the last batch that the 32-column first attempt (poa4.hip) handed on to the 64-column kernel */
+uint32_t rvn_poa_narrow_windows(const rvn_engine* e);
 
 /* ---- introspection used by the parity tests and bench.py ------------------------------------- */
 /* sketch of reads [first,last) == ram Minimize(sequence, minhash) per read; values widened to u64 */

@@ -10,7 +10,7 @@ pids=()
 # RVN_NO_EDLIB_SYMBOLS=1: leave the edlibAlign drop-in out (a process that also loads a real shared edlib: INTEGRATION.md 3.1)
 EDLIB=edlib_dropin
 if [ -n "${RVN_NO_EDLIB_SYMBOLS:-}" ]; then EDLIB=""; rm -f "$HERE/obj/edlib_dropin.o"; fi
-for f in scan radix_sort sketch index map pile edit_distance poa poa2 poa3 poa4 simt_emu polish nwpath pass2 io shard group engine $EDLIB; do
+for f in scan radix_sort sketch index map pile edit_distance poa poa2 poa4 simt_emu polish nwpath pass2 io shard group engine $EDLIB; do
   src="$HERE/$f.hip"; obj="$HERE/obj/$f.o"
   if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ -n "$(find "$HERE" -maxdepth 1 -name '*.h' -newer "$obj" -print -quit)" ] || [ "$HERE/../../include/raven_hip.h" -nt "$obj" ]; then
     $HIPCC $FLAGS -c "$src" -o "$obj" &

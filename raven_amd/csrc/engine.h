@@ -140,11 +140,11 @@ struct Engine {
   u64 polish_last_layers = 0, polish_last_w0 = 0;
   bool polish_last_has_ok = false;
   std::vector<u64> polish_last_read_off;
-  int poa_mode = 0;  // 0 banded 64 -> 128 -> 256 -> full matrix; 1 full matrix only; 2 / 3 / 4 band 64 / 128 / 256 only (tests); 5 .. 8 poa3.hip only: four windows per wave band 64 / four windows band 32 / two windows band 32 / two windows band 64
+  int poa_mode = 0;  // 0 banded 32 (poa4.hip) -> 64 -> 128 -> 256 (poa2.hip) -> full matrix; 1 full matrix only; 2 / 3 / 4 band 64 / 128 / 256 only (tests); 9 poa4.hip only (band 32, rows on lanes)
   u32 poa_fallback_windows = 0;  // windows of the last batch that needed more than the 128-column band
   u32 poa_fullmatrix_windows = 0;  // ... of which re-run by the full-matrix kernel
   u32 poa_wide_windows = 0;      // windows of the last batch re-run with the 128-column band
-  u32 poa_narrow_windows = 0;    // windows of a 32-column first attempt (poa3.hip) re-run with the 64-column band
+  u32 poa_narrow_windows = 0;    // windows of the 32-column first attempt (poa4.hip) re-run with the 64-column band
   DevBuf anc_slot_off, anc_slot_cnt;
   bool keep_anchors = false;  // map_batch also returns the chain anchors of every overlap
   unsigned long long poa_phase_cycles[8] = {};  // subgraph, dp, traceback, add, order, consensus (last call); [6], [7]: DP cells
@@ -161,6 +161,8 @@ struct Engine {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   hipStream_t nw_streams[3] = {nullptr, nullptr, nullptr};  // walk streams of the alignment-path stage (beside the sweeps)
   hipEvent_t nw_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipStream_t poa_streams[8] = {};  // streams of the window-consensus stage (poa4.hip: a chunk's waves dealt out to several)
+  hipEvent_t poa_ev[9] = {};
   u64* h_pin = nullptr;  // pinned host scratch for small device->host size read-backs
   PinBuf pin_big;        // pinned staging for bulk read-backs up to 256 MB (polishing: chain anchors)
   HostBuf host_big;      // ... and the unpinned one for larger ones
@@ -247,7 +249,7 @@ void poa_consensus_batch(Engine& e, const u8* h_codes, const u8* h_quals, const 
                          int g, int trim, u8* h_out, const u64* h_out_off, u32* h_out_len, u32* h_status,
                          double* device_ms);
 
-// poa3.hip's kernel stepped through on the host (wavefront emulator): see rvn_poa_banded_emulate
+// poa4.hip's phase functions stepped through on the host (wavefront emulator): see rvn_poa_banded_emulate
 void poa_banded_emulate(const u8* h_codes, const u8* h_quals, const u64* h_layer_off, const u32* h_begins,
                         const u32* h_ends, const u32* h_has_qual, const u32* h_win_off, u32 n_windows, int m, int n, int g,
                         int trim, u8* h_out, const u64* h_out_off, u32* h_out_len, u32* h_status, int variant);

@@ -267,6 +267,10 @@ void rvn_engine_destroy(rvn_engine* h) {
   if (h->e.ev1) (void)hipEventDestroy(h->e.ev1);
   for (hipEvent_t ev : h->e.nw_ev)
     if (ev) (void)hipEventDestroy(ev);
+  for (hipStream_t st2 : h->e.poa_streams)
+    if (st2) (void)hipStreamDestroy(st2);
+  for (hipEvent_t ev : h->e.poa_ev)
+    if (ev) (void)hipEventDestroy(ev);
   for (hipStream_t st2 : h->e.nw_streams)
     if (st2) (void)hipStreamDestroy(st2);
   if (h->e.stream) (void)hipStreamDestroy(h->e.stream);
@@ -1556,12 +1560,13 @@ void rvn_poa_phase_cycles(const rvn_engine* h, uint64_t out[6]) {
 int rvn_poa_set_mode(rvn_engine* h, int mode) {
   if (!h) return -1;
   const int prev = h->e.poa_mode;
-  if (mode >= 0 && mode <= 9) h->e.poa_mode = mode;
+  if ((mode >= 0 && mode <= 4) || mode == 9) h->e.poa_mode = mode;
   return prev;
 }
 
 uint32_t rvn_poa_fallback_windows(const rvn_engine* h) { return h ? h->e.poa_fallback_windows : 0; }
 uint32_t rvn_poa_wide_windows(const rvn_engine* h) { return h ? h->e.poa_wide_windows : 0; }
+uint32_t rvn_poa_narrow_windows(const rvn_engine* h) { return h ? h->e.poa_narrow_windows : 0; }
 
 int rvn_engine_sketch(rvn_engine* h, const rvn_reads* r, uint32_t first, uint32_t last, int minhash, uint64_t* count) {
   return guarded(h ? &h->e : nullptr, [&]() -> int {

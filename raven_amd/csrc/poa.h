@@ -108,7 +108,7 @@ struct PoaBatchDev {  // device-side batch description shared by both launchers
                      // paths strayed from the band's centre (0..31 columns) — what a narrower band would have to hold
 };
 
-// Per-window scratch of the banded kernels (poa2.hip, poa3.hip): the spoa graph as SoA arrays, the backpointer matrix of
+// Per-window scratch of the banded kernels (poa2.hip; poa4.hip adds its own arrays behind it): the spoa graph as SoA arrays, the backpointer matrix of
 // the current layer and the traceback's row table, carved out of one allocation per resident window.
 struct Poa2Slot {
   i16* Hs;    // (nmax + 1) x band scores (ring misses only)
@@ -133,7 +133,7 @@ struct Poa2Slot {
   i32* preds;
   u16* stack;
   u16* pos_node;  // traceback result of the current layer: node aligned to position p, or kNone
-  u16* tgt;       // AddAlignment: graph node of every sequence position (poa3.hip; poa2.hip keeps it in LDS)
+  u16* tgt;       // AddAlignment: graph node of every sequence position (unused: poa2.hip keeps it in LDS)
 };
 
 template <class F>
@@ -213,14 +213,6 @@ void poa_run_dev(Engine& e, const PoaWindow* d_wins, const PoaLayer* d_lays, u32
                  u32 max_len, int m, int n, int g, int trim, u8* d_out, u32* d_len, u32* d_status,
                  std::vector<u32>& h_status, double* device_ms, bool allow_full = true);
 void poa_v2_launch(Engine& e, const PoaBatchDev& b, int nch);  // poa2.hip: band = 64 * nch columns
-// poa3.hip: several windows per wave; variant 0 = four windows, 64-column band; 1 = four windows, 32 columns; 2 = two
-// windows, 32 columns; 3 = two windows, 64 columns
-void poa_v3_launch(Engine& e, const PoaBatchDev& b, int variant);
-int poa_v3_band(int variant);
-// poa3.hip's kernel source run on the host under the wavefront emulator (test infrastructure; host arrays everywhere)
-void poa_v3_emulate(const std::vector<PoaWindow>& wins, const std::vector<PoaLayer>& lays, const PoaSrc& src, u32 max_bb,
-                    u32 max_len, int m, int n, int g, int trim, u8* out, u32* out_len, u32* status, int variant);
-
 // poa4.hip: rows on lanes, four windows per wave, 32-column band (the first attempt of the default mode)
 void poa_v4_launch(Engine& e, const PoaBatchDev& b);
 void poa_v4_emulate(const std::vector<PoaWindow>& wins, const std::vector<PoaLayer>& lays, const PoaSrc& src, u32 max_bb,

@@ -686,23 +686,15 @@ void poa_run_dev(Engine& e, const PoaWindow* d_wins, const PoaLayer* d_lays, u32
   const auto mag = [](int x) { return x < 0 ? -x : x; };
   const bool int16_ok = mag(m) <= 24 && mag(n) <= 24 && mag(g) <= 24;
   const int mode = int16_ok ? e.poa_mode : 1;
-  // first attempt with the 64-column band: four windows per wave (poa3.hip) or one (poa2.hip)
-  // (RVN_POA3 = 1 .. 4: poa3.hip's variant 0 .. 3 as the first attempt of mode 0)
-  static const int v3_default = [] {
-    const char* ev = std::getenv("RVN_POA3");
-    const int v = ev ? std::atoi(ev) : 0;
-    return v >= 1 && v <= 4 ? v - 1 : -1;
-  }();
-  const int v3 = mode >= 5 && mode <= 8 ? mode - 5 : (mode == 0 ? v3_default : -1);
-  // rows on lanes (poa4.hip, 32-column band): mode 9 alone, or the first attempt of mode 0 with RVN_POA4=1
+  // first attempt: rows on lanes with a 32-column band (poa4.hip; RVN_POA4=0: straight to the 64-column kernel of
+  // poa2.hip); mode 9 = poa4.hip alone
   static const bool v4_default = [] {
     const char* ev = std::getenv("RVN_POA4");
-    return ev && std::atoi(ev) != 0;
+    return !(ev && std::atoi(ev) == 0);
   }();
-  const bool v4 = mode == 9 || (mode == 0 && v3 < 0 && v4_default);
+  const bool v4 = mode == 9 || (mode == 0 && v4_default);
   if (mode == 1) poa_v1_launch(e, b);
   else if (v4) poa_v4_launch(e, b);
-  else if (v3 >= 0) poa_v3_launch(e, b, v3);
   else poa_v2_launch(e, b, mode == 3 ? 2 : (mode == 4 ? 4 : 1));
   RVN_HIP(hipMemcpyAsync(h_status.data(), d_status, static_cast<size_t>(n_windows) * 4, hipMemcpyDeviceToHost, s));
   RVN_HIP(rvn_stream_sync(s));
@@ -757,7 +749,7 @@ void poa_run_dev(Engine& e, const PoaWindow* d_wins, const PoaLayer* d_lays, u32
       for (u32 i = 0; i < nr; ++i) h_status[redo[i]] = rs[i];
     };
     std::vector<u32> wide, wider, fullm;
-    if (v4 || (v3 >= 0 && poa_v3_band(v3) < 64)) {  // a 32-column first attempt: what touched its edge gets the 64-column band next
+    if (v4) {  // a 32-column first attempt: what touched its edge (or is beyond poa4.hip's limits) gets the 64-column band next
       std::vector<u32> narrow;
       for (u32 w = 0; w < n_windows; ++w)
         if ((h_status[w] & 0xFF) == kPoaBandHit) narrow.push_back(w);
@@ -903,7 +895,7 @@ void poa_consensus_batch(Engine& e, const u8* h_codes, const u8* h_quals, const 
           device_ms);
 }
 
-// The four-windows-per-wave banded kernel (poa3.hip) stepped through on the HOST by the wavefront emulator: same batch
+// The rows-on-lanes banded kernel (poa4.hip) stepped through on the HOST by the wavefront emulator: same batch
 // description as poa_consensus_batch, first attempt only (status 8 / 7 = the window needs the wider kernels).  Test
 // infrastructure for the CPU suite; needs no GPU and no engine.
 void poa_banded_emulate(const u8* h_codes, const u8* h_quals, const u64* h_layer_off, const u32* h_begins,
@@ -918,8 +910,8 @@ void poa_banded_emulate(const u8* h_codes, const u8* h_quals, const u64* h_layer
   PoaSrc src{};
   src.codes = h_codes;
   src.quals = h_quals;
-  if (variant == 4) poa_v4_emulate(wins, lays, src, max_bb, max_len, m, n, g, trim, h_out, h_out_len, h_status);
-  else poa_v3_emulate(wins, lays, src, max_bb, max_len, m, n, g, trim, h_out, h_out_len, h_status, variant);
+  (void)variant;
+  poa_v4_emulate(wins, lays, src, max_bb, max_len, m, n, g, trim, h_out, h_out_len, h_status);
 }
 
 }  // namespace rvn

@@ -1703,20 +1703,20 @@ void poa_v4_launch(Engine& e, const PoaBatchDev& b) {
   if (const char* ev = std::getenv("RVN_POA4_CHUNK")) per_chunk = std::max<size_t>(P4::G, static_cast<size_t>(std::atoll(ev)));
   per_chunk = std::min<size_t>(per_chunk, b.n_windows);
   per_chunk = (per_chunk + P4::G - 1) / P4::G * P4::G;
-  // The waves of a chunk are dealt out to up to three streams that run their rounds independently: the phases of a round
+  // The waves of a chunk are dealt out to several streams that run their rounds independently: the phases of a round
   // are one issue-bound kernel (NW) and three that wait on gathers, and two streams in different phases fill each
   // other's gaps.
-  u32 n_parts = 3;
-  if (const char* ev = std::getenv("RVN_POA4_STREAMS")) n_parts = static_cast<u32>(std::max(1, std::min(3, std::atoi(ev))));
+  u32 n_parts = 4;
+  if (const char* ev = std::getenv("RVN_POA4_STREAMS")) n_parts = static_cast<u32>(std::max(1, std::min(8, std::atoi(ev))));
   if (per_chunk < 4096) n_parts = 1;
-  const size_t slots_alloc = per_chunk + static_cast<size_t>(P4::G) * n_parts;
+  const size_t slots_alloc = per_chunk + static_cast<size_t>(P4::G) * 8;
   unsigned char* d_scratch = e.poa2_scratch.get<unsigned char>(slots_alloc * (slot_bytes + sizeof(Poa4Win)) + 512);
   Poa4Win* d_st = reinterpret_cast<Poa4Win*>(d_scratch + slots_alloc * slot_bytes + 256);
   const Poa4Args A = args_of4(b, d_scratch, slot_bytes);
   hipStream_t s = e.stream;
-  if (n_parts > 1 && !e.nw_streams[0]) {
-    for (hipStream_t& st2 : e.nw_streams) RVN_HIP(hipStreamCreateWithFlags(&st2, hipStreamNonBlocking));
-    for (hipEvent_t& ev : e.nw_ev) RVN_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  if (n_parts > 1 && !e.poa_streams[0]) {
+    for (hipStream_t& st2 : e.poa_streams) RVN_HIP(hipStreamCreateWithFlags(&st2, hipStreamNonBlocking));
+    for (hipEvent_t& ev : e.poa_ev) RVN_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
   }
   for (u32 first = 0; first < b.n_windows; first += static_cast<u32>(per_chunk)) {
     const u32 count = std::min<u32>(static_cast<u32>(per_chunk), b.n_windows - first);
@@ -1728,19 +1728,19 @@ void poa_v4_launch(Engine& e, const PoaBatchDev& b) {
     RVN_LAUNCH_CHECK();
     RVN_HIP(hipMemcpyAsync(&max_layers, b.next, 4, hipMemcpyDeviceToHost, s));
     RVN_HIP(rvn_stream_sync(s));
-    Poa4Ctx C[3];
-    u32 n_waves[3] = {0, 0, 0};
-    hipStream_t st[3] = {s, s, s};
+    Poa4Ctx C[8];
+    u32 n_waves[8] = {};
+    hipStream_t st[8] = {s, s, s, s, s, s, s, s};
     u32 slot0 = 0;
     for (u32 p = 0; p < n_parts; ++p) {
       n_waves[p] = waves_total > p ? (waves_total - p + n_parts - 1) / n_parts : 0;
       C[p] = Poa4Ctx{d_st + slot0, first, count, p, n_parts, slot0};
       slot0 += n_waves[p] * P4::G;
-      if (n_parts > 1) st[p] = e.nw_streams[p];
+      if (n_parts > 1) st[p] = e.poa_streams[p];
     }
     if (n_parts > 1) {
-      RVN_HIP(hipEventRecord(e.nw_ev[3], s));
-      for (u32 p = 0; p < n_parts; ++p) RVN_HIP(hipStreamWaitEvent(st[p], e.nw_ev[3], 0));
+      RVN_HIP(hipEventRecord(e.poa_ev[8], s));
+      for (u32 p = 0; p < n_parts; ++p) RVN_HIP(hipStreamWaitEvent(st[p], e.poa_ev[8], 0));
     }
     for (u32 p = 0; p < n_parts; ++p)
       if (n_waves[p]) RVN_KLAUNCH_ON(kKPoaBanded, st[p], (poa4_init_kernel<<<n_waves[p], 64, 0, st[p]>>>(A, C[p])));
@@ -1760,8 +1760,8 @@ void poa_v4_launch(Engine& e, const PoaBatchDev& b) {
       if (n_waves[p]) RVN_KLAUNCH_ON(kKPoaBanded, st[p], (poa4_final_kernel<<<n_waves[p], 64, 0, st[p]>>>(A, C[p])));
     if (n_parts > 1) {
       for (u32 p = 0; p < n_parts; ++p) {
-        RVN_HIP(hipEventRecord(e.nw_ev[p], st[p]));
-        RVN_HIP(hipStreamWaitEvent(s, e.nw_ev[p], 0));
+        RVN_HIP(hipEventRecord(e.poa_ev[p], st[p]));
+        RVN_HIP(hipStreamWaitEvent(s, e.poa_ev[p], 0));
       }
     }
   }

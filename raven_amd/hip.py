@@ -35,7 +35,7 @@ SYMBOLS = [
     "rvn_engine_map_batch", "rvn_engine_map_fetch", "rvn_engine_map_fetch_filtered",
     "rvn_find_overlaps_and_create_piles", "rvn_pass1_pile_words", "rvn_pass1_num_overlaps",
     "rvn_pass1_fetch_piles", "rvn_pass1_fetch_overlaps", "rvn_pass1_destroy", "rvn_pile_add_layers",
-    "rvn_edit_distance_batch", "rvn_poa_consensus_batch", "rvn_poa_banded_emulate", "rvn_pass1_trim_and_annotate", "rvn_poa_phase_cycles", "rvn_polish_target_reads", "rvn_polish_set_chunk_windows", "rvn_polish_round_range", "rvn_polish_map_best", "rvn_polish_set_best", "rvn_shard_sketch", "rvn_shard_sketch_fetch",
+    "rvn_edit_distance_batch", "rvn_poa_consensus_batch", "rvn_poa_banded_emulate", "rvn_pass1_trim_and_annotate", "rvn_poa_phase_cycles", "rvn_poa_narrow_windows", "rvn_polish_target_reads", "rvn_polish_set_chunk_windows", "rvn_polish_round_range", "rvn_polish_map_best", "rvn_polish_set_best", "rvn_shard_sketch", "rvn_shard_sketch_fetch",
     "rvn_shard_index_build", "rvn_shard_key_counts", "rvn_engine_set_occurrence", "rvn_shard_join",
     "rvn_shard_join_fetch", "rvn_shard_chain", "rvn_shard_piles", "rvn_shard_join_range", "rvn_shard_piles_create",
     "rvn_shard_piles_merge", "rvn_shard_piles_merge_dev", "rvn_shard_sketch_fetch_dev",
@@ -161,6 +161,8 @@ def lib():
     L.rvn_poa_fallback_windows.restype = u32
     L.rvn_poa_wide_windows.argtypes = [vp]
     L.rvn_poa_wide_windows.restype = u32
+    L.rvn_poa_narrow_windows.argtypes = [vp]
+    L.rvn_poa_narrow_windows.restype = u32
     L.rvn_engine_sketch.argtypes = [vp, vp, u32, u32, i32, C.POINTER(u64)]
     L.rvn_engine_sketch_fetch.argtypes = [vp, vp, vp, vp]
     L.rvn_engine_index_size.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
@@ -392,11 +394,10 @@ def _unpack_poa_consensus(a):
     return [a["out"][int(ooff[i]): int(ooff[i]) + int(a["out_len"][i])].copy() for i in range(a["nw"])]
 
 
-def poa_banded_emulate(windows, m=3, n=-5, g=-4, trim=True, variant=0):
-    """TEST INFRASTRUCTURE: poa3.hip's kernel source stepped through on the HOST by the wavefront emulator (no GPU, no
-    engine).  variant 0 .. 3 = the kernels of poa_set_mode(5 .. 8): four windows per wave with a 64- / 32-column band,
-    two windows with a 32- / 64-column band.  First attempt of the escalation chain only: status 8 = the window needs
-    a wider band.  Returns (list of consensus code arrays, status array)."""
+def poa_banded_emulate(windows, m=3, n=-5, g=-4, trim=True, variant=4):
+    """TEST INFRASTRUCTURE: poa4.hip's phase functions stepped through on the HOST by the wavefront emulator (no GPU,
+    no engine).  First attempt of the escalation chain only: status 8 = the window needs a wider band (or is beyond
+    the kernel's limits).  Returns (list of consensus code arrays, status array)."""
     a = _pack_poa_windows(windows)
     _check(lib().rvn_poa_banded_emulate(
         _p(a["codes"]), _p(a["quals"]), _p(a["loff"]), _p(a["begins"]), _p(a["ends"]), _p(a["hasq"]), _p(a["woff"]),
@@ -829,8 +830,8 @@ class Engine:
         return int(lib().rvn_polish_set_chunk_windows(self._h, int(windows)))
 
     def poa_set_mode(self, mode):
-        """0 band 64 -> 128 -> 256 -> full matrix (default), 1 full matrix only, 2 / 3 / 4 band 64 / 128 / 256 only,
-        5 .. 8 the grouped kernels of poa3.hip only (4 windows x band 64, 4 x 32, 2 x 32, 2 x 64)."""
+        """0 band 32 (rows on lanes, poa4.hip) -> 64 -> 128 -> 256 -> full matrix (default), 1 full matrix only,
+        2 / 3 / 4 band 64 / 128 / 256 only, 9 poa4.hip only."""
         return int(lib().rvn_poa_set_mode(self._h, int(mode)))
 
     def poa_fallback_windows(self):
@@ -838,6 +839,9 @@ class Engine:
 
     def poa_wide_windows(self):
         return int(lib().rvn_poa_wide_windows(self._h))
+
+    def poa_narrow_windows(self):
+        return int(lib().rvn_poa_narrow_windows(self._h))
 
     # -- introspection ---------------------------------------------------------------------
     def sketch(self, reads: Reads, first=0, last=None, minhash=False):

@@ -162,19 +162,20 @@ def test_kernel_modes_agree_on_noisy_windows():
             for _ in range(32)]
     eng = hip.Engine()
     out = {}
-    for mode in (1, 2, 3, 4, 5):
+    for mode in (0, 1, 2, 3, 4):
         eng.poa_set_mode(mode)
         out[mode], st, _ = eng.poa_consensus_batch(wins)
         assert np.all(st == 1), (mode, st)
-    for a, b, c, d, e in zip(out[1], out[2], out[3], out[4], out[5]):
+    for a, b, c, d, e in zip(out[1], out[2], out[3], out[4], out[0]):
         assert np.array_equal(a, b) and np.array_equal(a, c) and np.array_equal(a, d) and np.array_equal(a, e)
 
 
-def test_four_windows_per_wave_kernel_equals_one_window_per_wave():
-    """poa3.hip (mode 5: four windows per wave, 16 lanes each) against poa2.hip's 64-column kernel (mode 2) on a batch
-    large enough for ragged groups, partial layers, qualities, predecessor rows beyond the 16-row LDS ring (windows
-    278 and 365 of this seed) and band hits: same status and same consensus, window for window — and the emulated
-    kernel of the CPU suite (tests/test_poa3_emulation.py) gives the same bytes as the GPU for the first windows."""
+def test_rows_on_lanes_kernel_equals_one_row_per_iteration_kernel():
+    """poa4.hip (mode 9: a graph row per lane, four windows per wave, 32-column band, one kernel per phase) against
+    poa2.hip's 64-column kernel (mode 2) on a batch large enough for ragged groups, partial layers, qualities and band
+    hits: whatever the narrow band polishes is the same consensus, window for window; what it flags (status 8) is
+    exactly what the default mode hands on to the wider kernels, with the same end result as mode 2 — and the emulated
+    kernel of the CPU suite (tests/test_poa4_emulation.py) gives the same bytes as the GPU for the first windows."""
     rng = np.random.default_rng(7)
     wins = []
     for i in range(400):
@@ -184,25 +185,21 @@ def test_four_windows_per_wave_kernel_equals_one_window_per_wave():
     eng = hip.Engine()
     eng.poa_set_mode(2)
     c2, s2, _ = eng.poa_consensus_batch(wins)
-    eng.poa_set_mode(5)
-    c5, s5, _ = eng.poa_consensus_batch(wins)
-    assert np.array_equal(s2 & 0xFF, s5 & 0xFF)
-    assert int(np.sum((s5 & 0xFF) == 1)) >= 390
-    for a, b, st in zip(c2, c5, s5):
-        assert np.array_equal(a, b), st
-    # the other lane layouts of the same source: four windows x 32 columns, two windows x 32 / x 64 columns; a
-    # 32-column band flags more windows (8), whatever it polishes is the same consensus
-    for mode, band in ((6, 32), (7, 32), (8, 64)):
-        eng.poa_set_mode(mode)
-        cm, sm, _ = eng.poa_consensus_batch(wins)
-        both = 0
-        for a, b, sa, sb in zip(c2, cm, s2, sm):
-            assert (int(sb) & 0xFF) in (1, 8)
-            if (int(sa) & 0xFF) == 1 and (int(sb) & 0xFF) == 1:
-                both += 1
-                assert np.array_equal(a, b), mode
-        assert both >= (390 if band == 64 else 340), (mode, both)
+    eng.poa_set_mode(9)
+    c9, s9, _ = eng.poa_consensus_batch(wins)
+    both = 0
+    for a, b, sa, sb in zip(c2, c9, s2, s9):
+        assert (int(sb) & 0xFF) in (1, 8), sb
+        if (int(sa) & 0xFF) == 1 and (int(sb) & 0xFF) == 1:
+            both += 1
+            assert np.array_equal(a, b)
+    assert both >= 340, both
     eng.poa_set_mode(0)
+    c0, s0, _ = eng.poa_consensus_batch(wins)
+    assert np.array_equal(s0 & 0xFF, s2 & 0xFF)
+    for a, b in zip(c0, c2):
+        assert np.array_equal(a, b)
+    assert eng.poa_narrow_windows() == int(np.sum((s9 & 0xFF) == 8))
     emu, st_emu = hip.poa_banded_emulate(wins[:8])
-    for a, b, sa, sb in zip(emu, c5[:8], st_emu, s5[:8]):
+    for a, b, sa, sb in zip(emu, c9[:8], st_emu, s9[:8]):
         assert (int(sa) & 0xFF) == (int(sb) & 0xFF) and np.array_equal(a, b)

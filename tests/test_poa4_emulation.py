@@ -11,7 +11,48 @@ import pytest
 
 from oracle import oracle
 from raven_amd import hip
-from tests.test_poa3_emulation import _mutate, _oracle, _window
+
+
+def _mutate(rng, codes, sub, ins, dele):
+    out = []
+    for c in codes:
+        u = rng.random()
+        if u < dele:
+            continue
+        if u < dele + sub:
+            c = (c + rng.integers(1, 4)) & 3
+        out.append(int(c))
+        if rng.random() < ins:
+            out.append(int(rng.integers(0, 4)))
+    return np.array(out, dtype=np.uint8)
+
+
+def _window(rng, length, n_reads, err=(0.05, 0.04, 0.04), partial=0.0, qual=False):
+    truth = rng.integers(0, 4, size=length, dtype=np.uint8)
+    bb = _mutate(rng, truth, 0.03, 0.02, 0.02)
+    layers, begins, ends = [bb], [0], [len(bb) - 1]
+    quals = [np.full(len(bb), 33, np.uint8)] if qual else None
+    for _ in range(n_reads):
+        if rng.random() < partial:
+            b = int(rng.integers(0, length // 2))
+            e = int(rng.integers(b + length // 4, length))
+        else:
+            b, e = 0, length
+        piece = _mutate(rng, truth[b:e], *err)
+        if len(piece) < 2:
+            continue
+        layers.append(piece)
+        bb_b = min(len(bb) - 2, int(b * len(bb) / length))
+        bb_e = min(len(bb) - 1, max(bb_b + 1, int(e * len(bb) / length) - 1))
+        begins.append(bb_b)
+        ends.append(bb_e)
+        if qual:
+            quals.append((33 + rng.integers(5, 40, size=len(piece))).astype(np.uint8))
+    return dict(layers=layers, begins=begins, ends=ends, quals=quals)
+
+
+def _oracle(w, trim=True):
+    return oracle.poa_window(w["layers"], begins=w.get("begins"), ends=w.get("ends"), quals=w.get("quals"), trim=trim)[0]
 
 
 def _compare(wins, min_polished, **kw):

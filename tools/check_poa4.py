@@ -1,6 +1,6 @@
-"""GPU check of the four-windows-per-wave POA kernel (poa3.hip, mode 5) against the one-window-per-wave kernel
-(poa2.hip, mode 2) on synthetic windows: consensus must be identical window for window wherever both polish; prints
-timings.  usage: check_poa3.py [n_windows] [modes, e.g. 5,6,7,8]"""
+"""GPU check of the rows-on-lanes POA kernel (poa4.hip, mode 9) against the one-row-per-iteration kernel (poa2.hip,
+mode 2) on synthetic windows: consensus must be identical window for window wherever both polish; prints timings.
+usage: check_poa4.py [n_windows] [modes, e.g. 9,0]"""
 import sys
 import time
 
@@ -22,7 +22,7 @@ def main():
         wins.append(w)
     eng = hip.Engine()
     res = {}
-    modes = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [5]
+    modes = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [9]
     for mode in [2] + modes:
         eng.poa_set_mode(mode)
         t = time.time()
@@ -32,7 +32,7 @@ def main():
               dict(zip(*np.unique(status & 0xFF, return_counts=True))), flush=True)
     c2, s2 = res[2]
     total_bad = 0
-    for mode in modes:  # modes 6 / 7 use a 32-column band: more windows flagged (8), the polished ones must agree
+    for mode in modes:  # mode 9 uses a 32-column band: more windows flagged (8), the polished ones must agree
         c5, s5 = res[mode]
         bad = both = 0
         for i in range(n):

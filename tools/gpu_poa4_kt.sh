@@ -3,7 +3,7 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}
 N=${1:-24576}
 cd $R
-timeout 100 python tools/check_poa3.py 400 9 2>&1 | tail -2
+timeout 100 python tools/check_poa4.py 400 9 2>&1 | tail -2
 RVN_POA_STATS=1 RVN_POA_MODES=${2:-9} timeout 250 python tools/bench_poa.py $N 20 > gpurun_out/r04_bx.json 2> gpurun_out/r04_bx.err
 python - <<PY
 import json
@@ -15,7 +15,7 @@ F=$(find $R/gpurun_out/r04_kt -name "*kernel_stats.csv" | head -1)
 python - <<PY
 import csv
 for r in list(csv.DictReader(open("$F")))[:8]:
-    n=r["Name"].split("(")[0].split("::")[-1]
+    import re as _re; _m=_re.search(r"poa[234]_\w+", r["Name"]); n=_m.group(0) if _m else r["Name"][:30]
     print(n, r["Calls"], "total_ms", round(int(r["TotalDurationNs"])/1e6,2), "max_ms", round(int(r["MaxNs"])/1e6,3))
 PY
 cp $F $R/gpurun_out/r04_kt_stats.csv; rm -rf $R/gpurun_out/r04_kt
