@@ -123,6 +123,7 @@ struct Engine {
   DevBuf ed_cnt, ed_sort, ed_todo;
   // second pass / identity filters (pass2.hip)
   DevBuf p2_slot, p2_pairs, p2_dist, p2_regions, p2_index_of, p2_kmers_off, p2_ok, p2_keep, p2_tmp_ovl;
+  DevBuf poa_hist;  // layer-count histogram of a POA chunk (poa4.hip)
   DevBuf poa_sched, poa_redo_w, poa_redo_i;  // LPT order / escalation lists of a POA batch (poa_run_dev)
   // alignment-path stage of a polishing round (nwpath.hip): stored band words + scores, jobs, results
   DevBuf nw_hs, nw_ck, nw_hs2, nw_ck2, nw_hs3, nw_ck3, nw_strip, nw_jobs, nw_res;  // alignment paths: horizontal-delta streams, checkpoints, jobs, results

@@ -1659,12 +1659,15 @@ __global__ __launch_bounds__(64) void poa4_final_kernel(const Poa4Args A, const 
   __shared__ Poa4Lds lds;
   poa4_phase_final(A, C, lds, blockIdx.x);
 }
-__global__ void poa4_max_layers_kernel(const PoaWindow* __restrict__ wins, const u32* __restrict__ sched, u32 first, u32 count,
-                                       u32* __restrict__ out) {
+// histogram of the chunk's layer counts (the host turns it into the number of windows that still have a layer in round r)
+constexpr u32 kLayerHist = 1024;
+__global__ void poa4_layer_hist_kernel(const PoaWindow* __restrict__ wins, const u32* __restrict__ sched, u32 first, u32 count,
+                                       u32* __restrict__ hist) {
   const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= count) return;
   const u32 pos = first + i;
-  atomicMax(out, wins[sched ? sched[pos] : pos].n_layers);
+  const u32 nl = wins[sched ? sched[pos] : pos].n_layers;
+  atomicAdd(&hist[nl < kLayerHist - 1 ? nl : kLayerHist - 1], 1u);
 }
 
 Poa4Args args_of4(const PoaBatchDev& b, unsigned char* scratch, size_t slot_bytes) {
@@ -1721,13 +1724,30 @@ void poa_v4_launch(Engine& e, const PoaBatchDev& b) {
   for (u32 first = 0; first < b.n_windows; first += static_cast<u32>(per_chunk)) {
     const u32 count = std::min<u32>(static_cast<u32>(per_chunk), b.n_windows - first);
     const u32 waves_total = (count + P4::G - 1) / P4::G;
-    // rounds = the most layers a window of the chunk has (one layer per round at most)
-    u32 max_layers = 0;
-    RVN_HIP(hipMemsetAsync(b.next, 0, 4, s));
-    poa4_max_layers_kernel<<<div_up(count, 256), 256, 0, s>>>(b.wins, b.sched, first, count, b.next);
+    // rounds = the most layers a window of the chunk has (one layer per round at most); the windows are in scheduling
+    // order = by decreasing layer count, so the windows that still have a layer in round r are a prefix of the chunk:
+    // the launches of a round cover that prefix only (a window of 100 layers among 100 000 of 30 would otherwise make
+    // 70 rounds of launches over waves that return at once)
+    std::vector<u32> hist(kLayerHist, 0);
+    u32* d_hist = e.poa_hist.get<u32>(kLayerHist);
+    RVN_HIP(hipMemsetAsync(d_hist, 0, kLayerHist * 4, s));
+    poa4_layer_hist_kernel<<<div_up(count, 256), 256, 0, s>>>(b.wins, b.sched, first, count, d_hist);
     RVN_LAUNCH_CHECK();
-    RVN_HIP(hipMemcpyAsync(&max_layers, b.next, 4, hipMemcpyDeviceToHost, s));
+    RVN_HIP(hipMemcpyAsync(hist.data(), d_hist, kLayerHist * 4, hipMemcpyDeviceToHost, s));
     RVN_HIP(rvn_stream_sync(s));
+    u32 max_layers = 0;
+    for (u32 l = 0; l < kLayerHist; ++l)
+      if (hist[l]) max_layers = l;
+    const bool sorted = b.sched != nullptr && max_layers + 1 < kLayerHist;
+    std::vector<u32> alive(max_layers + 2, 0);  // alive[r] = windows with more than r layers
+    for (u32 l = max_layers + 1; l-- > 0;) alive[l] = alive[l + 1] + (l + 1 < kLayerHist ? hist[l + 1] : 0);
+    auto waves_in_round = [&](u32 round, u32 part, u32 part_waves) -> u32 {
+      if (!sorted) return part_waves;
+      const u32 n = round <= max_layers ? alive[round] : 0;  // windows with a layer of index `round` (layers 1 .. n_layers - 1)
+      const u32 waves_alive = (n + P4::G - 1) / P4::G;       // waves 0 .. waves_alive - 1 of the chunk
+      const u32 mine = waves_alive > part ? (waves_alive - part + n_parts - 1) / n_parts : 0;
+      return std::min(mine, part_waves);
+    };
     Poa4Ctx C[8];
     u32 n_waves[8] = {};
     hipStream_t st[8] = {s, s, s, s, s, s, s, s};
@@ -1747,13 +1767,16 @@ void poa_v4_launch(Engine& e, const PoaBatchDev& b) {
     // (the windows are in scheduling order, heaviest first, and dealt out by wave: every part has the same rounds)
     for (u32 round = 1; round <= max_layers; ++round) {
       for (u32 p = 0; p < n_parts; ++p) {
-        if (!n_waves[p]) continue;
-        RVN_KLAUNCH_ON(kKPoaBanded, st[p], (poa4_setup_kernel<<<n_waves[p] * P4::G, 64, 0, st[p]>>>(A, C[p])));
-        if (round == max_layers) continue;  // (the last call only lets every window find its layers exhausted)
-        RVN_KLAUNCH_ON(kKPoaBanded, st[p], (poa4_desc_kernel<<<n_waves[p] * P4::G * ((b.nmax + 255) / 256), 64, 0, st[p]>>>(A, C[p])));
-        RVN_KLAUNCH_ON(kKPoaBanded, st[p], (poa4_dp_kernel<<<n_waves[p], 64, 0, st[p]>>>(A, C[p])));
-        RVN_KLAUNCH_ON(kKPoaBanded, st[p], (poa4_tb_kernel<<<n_waves[p], 64, 0, st[p]>>>(A, C[p])));
-        RVN_KLAUNCH_ON(kKPoaBanded, st[p], (poa4_update_kernel<<<n_waves[p] * P4::G, 64, 0, st[p]>>>(A, C[p])));
+        // the set-up kernel also has to reach the windows whose last layer was the previous round's (they find their
+        // layers exhausted): the prefix of round - 1
+        const u32 w_set = waves_in_round(round - 1, p, n_waves[p]);
+        if (w_set) RVN_KLAUNCH_ON(kKPoaBanded, st[p], (poa4_setup_kernel<<<w_set * P4::G, 64, 0, st[p]>>>(A, C[p])));
+        const u32 w = waves_in_round(round, p, n_waves[p]);
+        if (!w || round == max_layers) continue;
+        RVN_KLAUNCH_ON(kKPoaBanded, st[p], (poa4_desc_kernel<<<w * P4::G * ((b.nmax + 255) / 256), 64, 0, st[p]>>>(A, C[p])));
+        RVN_KLAUNCH_ON(kKPoaBanded, st[p], (poa4_dp_kernel<<<w, 64, 0, st[p]>>>(A, C[p])));
+        RVN_KLAUNCH_ON(kKPoaBanded, st[p], (poa4_tb_kernel<<<w, 64, 0, st[p]>>>(A, C[p])));
+        RVN_KLAUNCH_ON(kKPoaBanded, st[p], (poa4_update_kernel<<<w * P4::G, 64, 0, st[p]>>>(A, C[p])));
       }
     }
     for (u32 p = 0; p < n_parts; ++p)
