@@ -268,7 +268,7 @@ __host__ __device__ __forceinline__ u32 div_magic(u32 n, u32 m) { return m ? mul
 struct alignas(16) Poa4LdsDesc {
   u32 segtab[32];  // the layer's band guide: {x0, wa, wb - wa, magic(x1 - x0)} per segment
   u32 seq2[60];    // the layer, 2 bits per base
-  u8 bytes[kPoa2MaxSeq + 16];  // (set-up kernel: one-byte codes before they are packed)
+  u8 bytes[1024];  // (set-up kernel: one-byte codes before they are packed; then 8192 rank-indexed bits of the subgraph sweep)
 };
 
 // the layer's band guide as eight segments in LDS (lanes 0..7), and the band start of a backbone coordinate from it
@@ -1243,6 +1243,143 @@ __host__ __device__ inline void poa4_phase_init(const Poa4Args& A, const Poa4Ctx
   }
 }
 
+// spoa Graph::Subgraph as marks, for one window by one wave: the ancestors (through in-edges and aligned nodes) of
+// backbone node `end` among the nodes with id >= begin; sub_out = out-degree inside the subgraph; returns the rank range
+// [r_lo, r_hi) that holds the marked nodes.  poa.h's version walks the graph with a stack on lane 0 — a chain of
+// dependent global loads per node.  Here the nodes are swept in DECREASING rank, 64 ranks at a time: the lanes fetch
+// their node's in-edges and aligned group and turn them into rank distances (everything a block needs is in flight
+// together), then the wave walks the block's 64 nodes in order on 64-bit masks of marks kept in scalar registers (this
+// block, the one above, the one below; a push further down goes through a bit array in LDS).  A node is marked iff its
+// id is >= begin and it, or a member of its aligned group, was reached through an in-edge of a marked node: members of
+// a column are reached only from later columns, which the sweep has left behind by then.
+__host__ __device__ inline void poa4_subgraph_marks(Poa2Slot& g, const u32* rb, const u16* order, u32* pend, u32 n_nodes,
+                                                    u32 begin, u32 end, u32& r_lo_out, u32& r_hi_out) {
+  const int lane = sv::lane();
+  for (u32 i = lane; i < n_nodes; i += 64) {
+    g.mark[i] = 0;
+    g.sub_out[i] = 0;
+  }
+  for (u32 i = lane; i < 256; i += 64) pend[i] = 0;  // rank-indexed bits for pushes beyond the block below
+  lds_order();
+  const u32 end_rank = rb[end] & 0xFFFFu;
+  unsigned long long w_cur = 0, w_above = 0, w_low = 0;
+  u32 r_lo = 0xFFFFFFFFu, r_hi = 0;
+  const i32 top_blk = static_cast<i32>(end_rank >> 6);
+  w_cur = 1ULL << (end_rank & 63u);
+  for (i32 blk = top_blk; blk >= 0; --blk) {
+    const u32 r0 = static_cast<u32>(blk) << 6;
+    const u32 r = r0 + static_cast<u32>(lane);
+    const bool in = r < n_nodes && r <= end_rank;
+    const u32 v = in ? order[r] : 0u;
+    u32 c = in ? g.in_cnt[v] : 0u;
+    const u32 ac = in ? g.al_cnt[v] : 0u;
+    const uint4 ta = *reinterpret_cast<const uint4*>(g.in_tail + static_cast<size_t>(v) * kPoaMaxIn);
+    const uint2 al2 = *reinterpret_cast<const uint2*>(g.al + static_cast<size_t>(v) * 4);
+    const bool ok = in && v >= begin;
+    // rank distances of the first eight in-edges' tails (0: none, or a tail below `begin`) and of the aligned nodes
+    u32 rec_a = 0, rec_b = 0, rec_f = ok ? 1u : 0u;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const u32 wd = k < 2 ? ta.x : (k < 4 ? ta.y : (k < 6 ? ta.z : ta.w));
+      const u32 t = static_cast<u32>(k) < c ? (wd >> (16 * (k & 1))) & 0xFFFFu : 0u;
+      const u32 rt = rb[t] & 0xFFFFu;
+      u32 lb = (static_cast<u32>(k) < c && t >= begin) ? r - rt : 0u;
+      if (lb > 254u) {  // (a very long in-edge: through the slow path below)
+        lb = 0;
+        rec_f |= 2u;
+      }
+      if (k < 4) rec_a |= lb << (8 * k);
+      else rec_b |= lb << (8 * (k - 4));
+    }
+    if (c > 8) rec_f |= 2u;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const u32 m = k == 0 ? al2.x & 0xFFFFu : (k == 1 ? al2.x >> 16 : al2.y & 0xFFFFu);
+      const bool has = static_cast<u32>(k) < ac;
+      const u32 rm = rb[has ? m : 0u] & 0xFFFFu;
+      const i32 d = has ? static_cast<i32>(rm) - static_cast<i32>(r) : 0;  // |d| <= 3: a column's nodes are rank-contiguous
+      const u32 enc = (has && d >= -7 && d <= 7 && d != 0) ? static_cast<u32>(d + 8) : 0u;
+      if (has && enc == 0) rec_f |= 2u;
+      rec_f |= enc << (4 + 4 * k);
+    }
+    const int top_l = blk == top_blk ? static_cast<int>(end_rank & 63u) : 63;
+    for (int l = top_l; l >= 0; --l) {
+      const u32 f = static_cast<u32>(sv::rl(static_cast<int>(rec_f), l));
+      bool reached = ((w_cur >> l) & 1ULL) != 0;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const u32 enc = (f >> (4 + 4 * k)) & 15u;
+        if (enc) {
+          const int pos = l + static_cast<int>(enc) - 8;
+          const bool bit = pos >= 64 ? ((w_above >> (pos - 64)) & 1ULL) != 0
+                                     : (pos >= 0 ? ((w_cur >> pos) & 1ULL) != 0 : ((w_low >> (pos + 64)) & 1ULL) != 0);
+          reached = reached || bit;
+        }
+      }
+      if (f & 2u) {  // slow path: a far tail, more than eight in-edges, or an aligned node out of place
+        const u32 vs = order[r0 + static_cast<u32>(l)];
+        const u32 as = g.al_cnt[vs];
+        for (u32 k = 0; k < as; ++k) reached = reached || g.mark[g.al[vs * 4 + k]] != 0 ||
+                                                 ((pend[(rb[g.al[vs * 4 + k]] & 0xFFFFu) >> 5] >> (rb[g.al[vs * 4 + k]] & 31u)) & 1u) != 0;
+      }
+      const bool marked = (f & 1u) != 0 && (reached || ((pend[(r0 + l) >> 5] >> ((r0 + l) & 31u)) & 1u) != 0);
+      if (marked) {
+        w_cur |= 1ULL << l;
+        const u32 a = static_cast<u32>(sv::rl(static_cast<int>(rec_a), l)), b = static_cast<u32>(sv::rl(static_cast<int>(rec_b), l));
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const u32 lb = ((k < 4 ? a : b) >> (8 * (k & 3))) & 0xFFu;
+          if (lb) {
+            const int pos = l - static_cast<int>(lb);
+            if (pos >= 0) w_cur |= 1ULL << pos;
+            else if (pos >= -64) w_low |= 1ULL << (pos + 64);
+            else if (lane == 0) pend[(r0 + l - lb) >> 5] |= 1u << ((r0 + l - lb) & 31u);
+          }
+        }
+        if (f & 2u) {  // slow path: every in-edge straight from the graph
+          const u32 vs = order[r0 + static_cast<u32>(l)];
+          const u32 cs = g.in_cnt[vs];
+          for (u32 k = 0; k < cs; ++k) {
+            const u32 t = g.in_tail[vs * kPoaMaxIn + k];
+            if (t < begin) continue;
+            const u32 rt = rb[t] & 0xFFFFu;
+            if (rt >= r0) w_cur |= 1ULL << (rt - r0);
+            else if (rt + 64 >= r0) w_low |= 1ULL << (rt + 64 - r0);
+            else if (lane == 0) pend[rt >> 5] |= 1u << (rt & 31u);
+          }
+        }
+        lds_order();
+      } else {
+        w_cur &= ~(1ULL << l);
+      }
+    }
+    if (in && ((w_cur >> lane) & 1ULL)) {
+      g.mark[v] = 1;
+      r_lo = r < r_lo ? r : r_lo;
+      r_hi = r + 1 > r_hi ? r + 1 : r_hi;
+    }
+    w_above = w_cur;
+    w_cur = w_low;
+    w_low = 0;
+  }
+  sv::sync();
+  for (u32 v = lane; v < n_nodes; v += 64) {
+    if (!g.mark[v]) continue;
+    const u32 c = g.in_cnt[v];
+    for (u32 k = 0; k < c; ++k) {
+      const u32 t = g.in_tail[v * kPoaMaxIn + k];
+      if (g.mark[t]) sv::atomic_add(reinterpret_cast<unsigned int*>(g.sub_out) + (t >> 1), (t & 1) ? 0x10000u : 1u);
+    }
+  }
+  {
+    const i32 lo_neg = sv::wave_max(r_lo == 0xFFFFFFFFu ? -0x7FFFFFFF : -static_cast<i32>(r_lo));
+    const i32 hi = sv::wave_max(static_cast<i32>(r_hi));
+    r_lo_out = lo_neg == -0x7FFFFFFF ? 0u : static_cast<u32>(-lo_neg);
+    r_hi_out = lo_neg == -0x7FFFFFFF ? 0u : static_cast<u32>(hi);
+  }
+  sv::sync();
+}
+
 // phase A1 of a round, one window per wave: the window's next layer (codes packed 2 bits per base into the window's
 // scratch, alignment results reset, subgraph marks and the rank range of the subgraph for a partial layer)
 template <class K>
@@ -1293,19 +1430,8 @@ __host__ __device__ inline void poa4_phase_setup(const Poa4Args& A, const Poa4Ct
   const bool full = L.begin < offset && L.end > blen - offset;
   u32 r_lo = 0, r_hi = me.nn;
   if (!full) {
-    poa_subgraph_marks(g, me.nn, A.nmax, L.begin, L.end);
-    i32 first_neg = -0x7FFFFFFF, last = 0;  // (-first: both through the wave's maximum)
-    for (u32 v = lane; v < me.nn; v += 64) {
-      if (g.mark[v]) {
-        const i32 r = static_cast<i32>(sl.rb[v] & 0xFFFFu);
-        first_neg = -r > first_neg ? -r : first_neg;
-        last = r + 1 > last ? r + 1 : last;
-      }
-    }
-    first_neg = sv::wave_max(first_neg);
-    last = sv::wave_max(last);
-    r_lo = first_neg == -0x7FFFFFFF ? 0u : static_cast<u32>(-first_neg);
-    r_hi = first_neg == -0x7FFFFFFF ? 0u : static_cast<u32>(last);
+    lds_order();  // (the byte codes are packed: their LDS becomes the sweep's bit array)
+    poa4_subgraph_marks(g, sl.rb, me.flip ? g.order2 : g.order, reinterpret_cast<u32*>(S.bytes), me.nn, L.begin, L.end, r_lo, r_hi);
   }
   const i32 lb = static_cast<i32>(L.begin), span = static_cast<i32>(L.end) - static_cast<i32>(L.begin) + 1;
   poa4_guide_to_lds(S, A.layers + wq.layer_first + liq, L.len, span);
@@ -1701,7 +1827,9 @@ void poa_v4_launch(Engine& e, const PoaBatchDev& b) {
   size_t free_b = 0, total_b = 0;
   RVN_HIP(hipMemGetInfo(&free_b, &total_b));
   // a chunk = the windows whose scratch fits the budget (their graphs stay resident from the first to the last round)
-  const size_t budget = e.poa2_scratch.cap + free_b / 2;
+  // (at most 48 K windows = ~30 GB for racon's 500-base windows: enough waves to fill the chip three times over in every
+  // launch, and the other stages of a polishing round keep their buffers)
+  const size_t budget = std::min<size_t>(e.poa2_scratch.cap + free_b / 2, static_cast<size_t>(49152) * (slot_bytes + sizeof(Poa4Win)));
   size_t per_chunk = std::max<size_t>(P4::G, budget / (slot_bytes + sizeof(Poa4Win)));
   if (const char* ev = std::getenv("RVN_POA4_CHUNK")) per_chunk = std::max<size_t>(P4::G, static_cast<size_t>(std::atoll(ev)));
   per_chunk = std::min<size_t>(per_chunk, b.n_windows);
