@@ -1262,14 +1262,17 @@ __host__ __device__ inline void poa4_subgraph_marks(Poa2Slot& g, const u32* rb, 
   for (u32 i = lane; i < 256; i += 64) pend[i] = 0;  // rank-indexed bits for pushes beyond the block below
   lds_order();
   const u32 end_rank = rb[end] & 0xFFFFu;
+  // (the sweep starts three ranks above `end`: the other letters of its column are reached from it and rank behind it)
+  const u32 top_rank = end_rank + 3 < n_nodes ? end_rank + 3 : n_nodes - 1;
   unsigned long long w_cur = 0, w_above = 0, w_low = 0;
   u32 r_lo = 0xFFFFFFFFu, r_hi = 0;
-  const i32 top_blk = static_cast<i32>(end_rank >> 6);
-  w_cur = 1ULL << (end_rank & 63u);
+  const i32 top_blk = static_cast<i32>(top_rank >> 6);
+  if ((end_rank >> 6) == static_cast<u32>(top_blk)) w_cur = 1ULL << (end_rank & 63u);
+  else w_low = 1ULL << (end_rank & 63u);
   for (i32 blk = top_blk; blk >= 0; --blk) {
     const u32 r0 = static_cast<u32>(blk) << 6;
     const u32 r = r0 + static_cast<u32>(lane);
-    const bool in = r < n_nodes && r <= end_rank;
+    const bool in = r < n_nodes && r <= top_rank;
     const u32 v = in ? order[r] : 0u;
     u32 c = in ? g.in_cnt[v] : 0u;
     const u32 ac = in ? g.al_cnt[v] : 0u;
@@ -1302,7 +1305,7 @@ __host__ __device__ inline void poa4_subgraph_marks(Poa2Slot& g, const u32* rb, 
       if (has && enc == 0) rec_f |= 2u;
       rec_f |= enc << (4 + 4 * k);
     }
-    const int top_l = blk == top_blk ? static_cast<int>(end_rank & 63u) : 63;
+    const int top_l = blk == top_blk ? static_cast<int>(top_rank & 63u) : 63;
     for (int l = top_l; l >= 0; --l) {
       const u32 f = static_cast<u32>(sv::rl(static_cast<int>(rec_f), l));
       bool reached = ((w_cur >> l) & 1ULL) != 0;
