@@ -126,7 +126,18 @@ def cpu_baseline(args, cores):
     parallel (the restatement of racon's round is single-threaded per call).  Combined like the metric:
     bases / (t_overlap + rounds x t_round) per base."""
     from oracle import oracle
-    threads = max(1, min(cores, 64))
+    threads = max(1, cores)  # every core of the box
+    cpu_model = "?"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    cpu_model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    if args.cpu_sample_genome is None:  # large enough that Filter and the flush logic do something; bounded by the cores
+        args.cpu_sample_genome = 20_000_000 if threads >= 96 else (8_000_000 if threads >= 32 else 2_000_000)
     g = synth.make_genome(args.cpu_sample_genome, seed=0xC0FFEE)
     rs, _ = synth.make_reads(g, args.coverage, 10000, seed=0xC0FFEF)
     t = time.time()
@@ -139,7 +150,7 @@ def cpu_baseline(args, cores):
     v = v_ovl
     if args.polish_rounds > 0:
         cases = []
-        for i in range(threads):
+        for i in range(min(threads, 128)):  # (one independent round per thread; more than 128 samples add nothing)
             gg = synth.make_genome(12_000, seed=0x5EED0003 + i)
             prs, _ = synth.make_reads(gg, 30, 3000, seed=0x5EED1004 + i)
             cases.append((seqio.pack_reads([synth.make_draft(gg, seed=0x5EED2005 + i)]), prs))
@@ -153,9 +164,10 @@ def cpu_baseline(args, cores):
         pol_bases = sum(c[1].total_bases for c in cases)
         v_pol = pol_bases / t_pol
         sample += "; polish: %d independent rounds in parallel (12 kb draft, 30x, 3 kb reads each; %d bases), " \
-                  "oracle.polish_round: %.2f s = %.5f Gbase/s per round" % (threads, pol_bases, t_pol, v_pol / 1e9)
+                  "oracle.polish_round (full-matrix NW + scalar POA, nothing like racon's edlib + SIMD spoa): %.2f s = %.5f Gbase/s per round" % (len(cases), pol_bases, t_pol, v_pol / 1e9)
         v = 1.0 / (1.0 / v_ovl + args.polish_rounds / v_pol)
-    return {"value": round(v / 1e9, 6), "unit": "Gbase/s", "cores": threads, "kind": "port", "sample": sample}
+    return {"value": round(v / 1e9, 6), "unit": "Gbase/s", "cores": threads, "cpu_count": os.cpu_count(), "cpu_model": cpu_model,
+            "kind": "port", "sample": sample}
 
 
 def make_workload(args, device):
@@ -198,11 +210,13 @@ def main():
     ap.add_argument("--freq", type=float, default=0.001)
     ap.add_argument("--kmax", type=int, default=32)
     ap.add_argument("--polish-rounds", type=int, default=2)
-    ap.add_argument("--cpu-sample-genome", type=int, default=2_000_000)
+    ap.add_argument("--cpu-sample-genome", type=int, default=None, help="genome of the CPU baseline's overlap sample "
+                    "(default: 20 Mb on >= 96 cores, 8 Mb on >= 32, else 2 Mb)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--load-bases", type=int, default=150_000_000,
                     help="bases of the gz FASTQ the input path (rvn_reads_load) is timed on, outside the timed region (0 = skip)")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-quality", action="store_true", help="polish FASTA-like reads (no block qualities attached)")
     ap.add_argument("--replicas", action="store_true", help="N > 1: independent shard per GPU (weak scaling, no "
                     "collective) instead of one genome sharded across the ranks")
     ap.add_argument("--sharded", action="store_true", help="run the sharded code path even at N = 1 (one rank owning "
@@ -248,6 +262,13 @@ def main():
     reads = eng.upload(rs)  # H2D once; resident for every step
     preads = reads if peng is eng else peng.upload(rs)
     t_h2d = time.time() - t0
+    if args.polish_rounds > 0 and not args.no_quality:
+        # FASTQ reads at Phred 10 — biosoup's block_quality (mean of 64 bases, + 33) kept beside the packed
+        # reads, so that racon's quality filter and quality weights are inside the timed rounds
+        nblk = (rs.lengths.astype(np.int64) + 63) // 64
+        qoff = np.zeros(rs.n + 1, dtype=np.uint64)
+        np.cumsum(nblk, out=qoff[1:])
+        preads.attach_quality((np.full(int(qoff[-1]), 33 + 10, dtype=np.uint8), qoff), block_shift=6)
     eng.set_timing(False)  # no per-stage host syncs inside the timed region
     peng.set_timing(False)
     eng.set_kernel_timing(not args.no_kernel_timing)
@@ -262,7 +283,7 @@ def main():
     if sharded_mode:  # this rank's reads, resident for every step like `reads` of the single-GPU pass
         b = sharded.partition_reads(rs.lengths, world)
         own_reads = eng.upload(sharded.slice_reads(rs, int(b[rank]), int(b[rank + 1])))
-    legs = {"overlap_s": 0.0, "polish_s": 0.0, "overlap_steps": [], "polish_steps": []}
+    legs = {"overlap_s": 0.0, "polish_s": 0.0, "overlap_steps": [], "polish_steps": [], "poa_ms": 0.0, "poa_rounds": 0}
     last = {}
 
     def step(timed):
@@ -293,6 +314,9 @@ def main():
             targets.close()
             n_windows += st["n_windows"]
             last["polish"] = st
+            if timed and "poa_ms" in st:
+                legs["poa_ms"] += float(st["poa_ms"])
+                legs["poa_rounds"] += 1
             last["ratio"] = float(np.mean(ratio)) if len(ratio) else 0.0
         t_c = time.perf_counter()
         if timed:
@@ -406,12 +430,16 @@ def main():
                                      "avg_launch_ms": round(ms / la, 5), "share": round(ms / tot, 4) if tot else None}
             # dominant kernel of the WHOLE step: the banded POA kernel (integer VALU bound)
             dom = next(iter(kernels), None)
-            if "poa_banded" in kms and kms["poa_banded"][1] and poa_cells["cells_full"]:
+            if "poa_banded" in kms and kms["poa_banded"][1] and poa_cells["cells_full"] and legs["poa_rounds"]:
+                # The window-consensus stage is a SET of launches (poa4.hip: five kernels per layer round, dealt out to
+                # four streams; their HIP-event times overlap), so its roofline is priced per polishing round against the
+                # stage's own device time (events around the whole batch on the engine's stream): "one launch" = one round.
                 ms, la = kms["poa_banded"]
                 cells = poa_cells["cells_full"] / max(poa_cells["calls"], 1) * 1.0  # per polishing round (one launch set)
-                launches_per_round = la / max(poa_cells["calls"], 1)
-                avg_s = ms / la / 1e3
-                cells_per_launch = cells / launches_per_round
+                launches_per_round = 1.0
+                avg_s = legs["poa_ms"] / legs["poa_rounds"] / 1e3
+                ms = legs["poa_ms"]
+                cells_per_launch = cells
                 achieved_tops = cells_per_launch * POA_MIN_OPS_PER_CELL / avg_s / 1e12
                 roofline_poa = {"bound": "valu", "kernel": "poa_banded",
                             "achieved": round(achieved_tops, 3), "peak": round(VALU_PEAK_LANE_OPS / 1e12, 1),
@@ -423,10 +451,13 @@ def main():
                             "gcups_banded_computed": round(poa_cells["cells_banded"] / max(poa_cells["calls"], 1) /
                                                            launches_per_round / avg_s / 1e9, 1),
                             "avg_launch_ms": round(avg_s * 1e3, 3),
-                            "kernel_ms_share": round(ms / tot, 3) if tot else None,
+                            "kernel_launches_per_round": kms["poa_banded"][1] / max(poa_cells["calls"], 1),
+                            "stage_share_of_step": round(legs["poa_ms"] / (dt * 1e3), 3),
                             "note": "algorithmic cells = graph rows x layer length of every layer alignment (what "
-                                    "spoa's full NW computes); the kernel computes a 64-column band of them"}
-            if dom == "poa_banded":
+                                    "spoa's full NW computes); the first attempt computes a 32-column band of them "
+                                    "(poa4.hip), what touches it a 64-column band (poa2.hip).  One 'launch' = the launch "
+                                    "set of one polishing round, timed by HIP events around the whole batch."}
+            if dom == "poa_banded" or legs["poa_ms"] > 0.4 * dt * 1e3:
                 roofline = roofline_poa
             if "nw_forward" in kms and kms["nw_forward"][1] and last.get("polish", {}).get("align_band_cells"):
                 # the alignment-path sweep (Myers bit-vector band, racon's edlib NW): integer VALU bound as well.  A round
@@ -479,6 +510,10 @@ def main():
         out = {
             "metric": "read Gbase/s through overlap+polish",
             "value": round(total_bases * args.steps / dt / 1e9, 4),
+            # the same with what the boundary adds to every step when the caller hands over host buffers and takes the
+            # pass's piles and overlap lists back as host vectors (upload + fetch, measured once outside the timed region)
+            "value_through_boundary": (round(total_bases / (dt / steps + boundary["upload_s"] + boundary["fetch_s"]) / 1e9, 4)
+                                       if boundary else None),
             "unit": "Gbase/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -492,9 +527,11 @@ def main():
             "dtype": "u32" if val_bytes == 4 else "u64",
             "data": "synthetic",
             "config": {
-                "workload": "BASELINE.json configs[%d]%s: synthetic %.0f Mb genome, %gx ONT-like reads (%s %d bp; 4%% sub, "
-                            "3%% ins, 3%% del), k=%d w=%d, FindOverlapsAndCreatePiles + -p %d (racon rounds on %.0f Mb "
-                            "draft contigs with 2.6%% errors)" % (
+                "workload": ("BASELINE.json configs[%d]%s: synthetic %.0f Mb genome, %gx ONT-like reads (%s %d bp; 4%% sub, "
+                             "3%% ins, 3%% del), k=%d w=%d, FindOverlapsAndCreatePiles + -p %d (racon rounds on %.0f Mb "
+                             "draft contigs with 2.6%% errors; " +
+                             ("reads WITHOUT qualities: the FASTA variant)" if args.no_quality else
+                              "reads carry biosoup block qualities at Phred 10: the FASTQ variant)")) % (
                                 3 if args.workload == "c4" else (2 if rounds else 1),
                                 " on one GPU" if world == 1 and args.workload == "c4" else "",
                                 args.genome / 1e6, args.coverage, args.length_model, args.read_len, args.k, args.w, rounds,

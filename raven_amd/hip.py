@@ -259,11 +259,15 @@ class Reads:
     def attach_quality(self, quals, block_shift=0):
         """Keep the reads' qualities in HBM for the polishing rounds: `quals` = list of per-read uint8 arrays of
         Phred+33 bytes, one per 2^block_shift bases (0: per base; 6: biosoup block qualities + 33)."""
-        lens = np.array([len(q) for q in quals], dtype=np.uint64)
-        off = np.zeros(self.rs.n + 1, dtype=np.uint64)
-        np.cumsum(lens, out=off[1:])
-        flat = np.ascontiguousarray(np.concatenate([np.asarray(q, dtype=np.uint8) for q in quals])
-                                    if len(quals) else np.zeros(0, np.uint8))
+        if isinstance(quals, tuple):  # (flat uint8 array, uint64 offsets[n + 1]) as they are
+            flat = np.ascontiguousarray(quals[0], dtype=np.uint8)
+            off = np.ascontiguousarray(quals[1], dtype=np.uint64)
+        else:
+            lens = np.array([len(q) for q in quals], dtype=np.uint64)
+            off = np.zeros(self.rs.n + 1, dtype=np.uint64)
+            np.cumsum(lens, out=off[1:])
+            flat = np.ascontiguousarray(np.concatenate([np.asarray(q, dtype=np.uint8) for q in quals])
+                                        if len(quals) else np.zeros(0, np.uint8))
         _check(lib().rvn_reads_attach_quality(self.engine._h, self._h, _p(flat), _p(off), int(block_shift)))
 
     def close(self):
