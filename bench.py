@@ -238,7 +238,9 @@ def main():
         raise SystemExit("bench.py needs a GPU (torch.cuda.is_available() is False)")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    # one rank per GPU over RCCL; a --sharded run launched by torch.distributed.run at world size 1 goes through the
+    # process group as well (the nccl path on the one GPU of a test box)
+    if world > 1 or (args.sharded and "RANK" in os.environ and "MASTER_PORT" in os.environ):
         import torch.distributed as dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist_mod.init_process_group(backend="nccl", rank=rank, world_size=world,
@@ -277,7 +279,7 @@ def main():
     comm = None
     if sharded_mode:
         from raven_amd import sharded
-        comm = sharded.DeviceComm(dist, device="cuda")
+        comm = sharded.DeviceComm(dist, device="cuda", force=dist is not None)
     dev = torch.device("cuda", local_rank)
     own_reads, shard_laps = None, ({} if os.environ.get("RVN_SHARD_LAPS") else None)
     if sharded_mode:  # this rank's reads, resident for every step like `reads` of the single-GPU pass
@@ -541,7 +543,9 @@ def main():
                 "parallelism": ("one genome sharded over %d GPUs: reads by pile, minimizers by hash class, 3 all-to-all + "
                                 "1 all-reduce per flush window over RCCL; polishing windows by range" % world)
                 if sharded_mode else ("independent replica per GPU (no data-path collective)" if world > 1 else "1 GPU"),
+                "collectives": ("nccl" if dist is not None else None),
             },
+            "exchange_bytes_per_step": (int(comm.bytes_sent // max(args.steps + args.warmup, 1)) if comm is not None else None),
             "legs": {"overlap_s_per_step": round(ovl_s, 4), "polish_s_per_step": round(pol_s, 4),
                      "overlap_s_of_each_step": legs["overlap_steps"], "polish_s_of_each_step": legs["polish_steps"],
                      "overlap_gbase_per_s": round(rs.total_bases / ovl_s / 1e9, 3) if ovl_s else None,

@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <memory>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -118,12 +119,16 @@ inline std::vector<std::unique_ptr<biosoup::NucleicAcid>> PolishRound(
                                             r.lengths.data(), static_cast<std::uint32_t>(sequences.size()), 0.0,
                                             error_threshold, window_len, trim ? 1 : 0, match, mismatch, gap, codes.data(),
                                             ooff.data(), len.data(), ratio.data()));
+  // reads used per target (racon's RC:i: tag): every rank holds the complete best-overlap table, so rank 0's counts are
+  // the round's
+  std::vector<std::uint32_t> used(n, 0);
+  ram::detail::Check(rvn_polish_target_reads(rvn_group_engine(group.handle(), 0), used.data(), static_cast<std::uint32_t>(n)));
   for (std::size_t i = 0; i < n; ++i) {
     if (drop_unpolished && ratio[i] == 0.0) continue;
     std::string data(len[i], 'A');
     for (std::uint32_t j = 0; j < len[i]; ++j) data[j] = "ACGT"[codes[ooff[i] + j] & 3];
     char tags[96];
-    std::snprintf(tags, sizeof(tags), " LN:i:%u XC:f:%.6f", len[i], ratio[i]);
+    std::snprintf(tags, sizeof(tags), " LN:i:%u RC:i:%u XC:f:%.6f", len[i], used[i], ratio[i]);
     const std::string& name = targets[i]->name;
     dst.emplace_back(new biosoup::NucleicAcid(name.substr(0, name.find(' ')) + tags, data));
   }

@@ -479,8 +479,8 @@ extern "C" {
 
 int rvn_group_create(rvn_group** out, uint32_t k, uint32_t w, uint32_t bandwidth, uint32_t chain, uint32_t matches,
                      uint32_t gap, const int* devices, uint32_t n_devices) {
-  if (!out || !devices || n_devices == 0) {
-    rvn::set_last_error("[raven_hip] rvn_group_create: invalid argument");
+  if (!out || !devices || n_devices == 0 || n_devices > 16) {  // (the partition kernels of shard.hip take at most 16 ranks)
+    rvn::set_last_error("[raven_hip] rvn_group_create: invalid argument (1 .. 16 devices)");
     return RVN_EINVAL;
   }
   *out = nullptr;
@@ -499,6 +499,8 @@ int rvn_group_create(rvn_group** out, uint32_t k, uint32_t w, uint32_t bandwidth
     hipStream_t s = nullptr;
     if (hipSetDevice(devices[i]) != hipSuccess || hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) {
       for (rvn_engine* x : g->eng) rvn_engine_destroy(x);
+      for (size_t c = 0; c < g->copy_stream.size(); ++c)  // the streams created so far
+        if (hipSetDevice(devices[c]) == hipSuccess) (void)hipStreamDestroy(g->copy_stream[c]);
       rvn::set_last_error("[raven_hip] rvn_group_create: cannot create a copy stream");
       return RVN_EHIP;
     }

@@ -513,6 +513,7 @@ void polish_round(Engine& e, ReadsDev& T, ReadsDev& R, const u8* h_quals, const 
   std::vector<u32> h_status;
   double poa_ms = 0;
   if (std::getenv("RVN_POLISH_SKIP_POA")) {  // profiling of the stages before the consensus only: empty windows
+    std::fprintf(stderr, "[raven_hip] RVN_POLISH_SKIP_POA is set: the round returns UNPOLISHED windows (profiling switch)\n");
     h_status.assign(nw, 0);
   } else {
     poa_run_dev(e, d_wins, d_lays, nw, src, w, std::max<u32>(max_len, w), m, n, g, trim ? 1 : 0, d_out, d_len, d_status,

@@ -123,8 +123,10 @@ def regroup_by_read(counts_per_src, data_per_src):
 class Comm:
     """Variable-size exchanges of numpy arrays over torch.distributed (None / world 1 = identity)."""
 
-    def __init__(self, dist=None, device="cpu"):
-        self.dist = dist if (dist is not None and dist.is_initialized() and dist.get_world_size() > 1) else None
+    def __init__(self, dist=None, device="cpu", force=False):
+        # force: go through the collectives at world size 1 as well (the backend's self-exchange: how a one-GPU box
+        # exercises the RCCL path)
+        self.dist = dist if (dist is not None and dist.is_initialized() and (dist.get_world_size() > 1 or force)) else None
         self.device = device
         self.rank = self.dist.get_rank() if self.dist else 0
         self.world = self.dist.get_world_size() if self.dist else 1

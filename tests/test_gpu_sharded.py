@@ -96,6 +96,69 @@ def test_sharded_pass_two_processes_over_torch_distributed(tmp_path):
     assert "SHARD_OK_0" in r.stdout and "SHARD_OK_1" in r.stdout, r.stdout[-2000:]
 
 
+WORKER_RCCL = r"""
+import os, sys, numpy as np, torch, torch.distributed as dist
+from raven_amd import hip, sharded, synth, seqio
+from tests import sharded_util
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0))    # RCCL on ROCm
+assert dist.get_backend() == "nccl" and dist.get_world_size() == 1
+dev = torch.device("cuda", 0)
+g = synth.make_genome(5_000_000, seed=81)                              # BASELINE configs[2] size
+rs, _ = synth.make_reads(g, 30, 10000, seed=82)
+eng = hip.Engine(15, 5, device=0)
+comm = sharded.DeviceComm(dist, device="cuda", force=True)
+assert comm.dist is not None
+res = sharded.find_overlaps_and_create_piles_sharded_dev(eng, rs, comm, dev)   # all_to_all_single / all_reduce over RCCL
+ref = hip.Engine(15, 5, device=0)
+p = ref.find_overlaps_and_create_piles(ref.upload(rs))
+data, poff = p.piles(); kept, koff = p.overlaps()
+sharded_util.check_against_single(res, data, poff, kept, koff)
+assert res["occurrence"] == ref.occurrence
+# collectives as the pass uses them, on CUDA tensors, through the nccl backend
+t = torch.arange(1000, dtype=torch.int64, device=dev)
+out = comm.all_to_all_t([t])
+assert torch.equal(out[0], t)
+assert int(comm.all_reduce_sum(np.array([7, 9]))[1]) == 9
+assert np.array_equal(comm.all_gather_v(np.arange(5)), np.arange(5))
+# one polishing round through the sharded entry points (reads by slice, windows by range, all-gather of the pieces)
+draft = synth.make_draft(g[:200_000], seed=83)
+peng = hip.Engine(15, 5, device=0)
+preads = peng.upload(rs)
+targets = peng.upload_codes([draft])
+cons_s, ratio_s = sharded.polish_round_sharded(peng, targets, preads, comm, targets.rs)
+cons_1, ratio_1, _ = peng.polish_round(targets, preads)
+assert len(cons_s) == len(cons_1) and all(np.array_equal(a, b) for a, b in zip(cons_s, cons_1))
+dist.barrier(); dist.destroy_process_group()
+sys.stdout.write("RCCL_OK kept=%d\n" % res["overlaps"].shape[0]); sys.stdout.flush()
+"""
+
+
+def test_sharded_pass_over_rccl_world_size_one(tmp_path):
+    """The nccl (= RCCL) backend path itself, on the one GPU a test box has: world size 1 under torch.distributed.run,
+    BASELINE configs[2] size, every exchange of the sharded pass and of the sharded polishing round through
+    all_to_all_single / all_reduce on CUDA tensors; results bit-identical to the fused single-GPU calls.  Then bench.py
+    in the same launch mode prints its JSON line with the exchange volume."""
+    script = tmp_path / "worker_rccl.py"
+    script.write_text(WORKER_RCCL)
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                        "--master-addr", "127.0.0.1", "--master-port", str(sharded_util.free_port()), str(script)], capture_output=True,
+                       text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "RCCL_OK" in r.stdout, r.stdout[-2000:]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                        "--master-addr", "127.0.0.1", "--master-port", str(sharded_util.free_port()),
+                        os.path.join(ROOT, "bench.py"), "--gpus", "1", "--sharded", "--workload", "c2", "--steps", "1",
+                        "--warmup", "1", "--no-cpu-baseline", "--load-bases", "0"], capture_output=True, text=True,
+                       timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    import json
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["value"] > 0 and line["config"]["collectives"] == "nccl"
+    assert line["exchange_bytes_per_step"] is not None
+
+
 @pytest.mark.parametrize("world", [1, 3])
 def test_device_resident_sharded_pass_is_bit_identical(world):
     """Same pass with every exchange buffer in HBM (torch CUDA tensors, rvn_shard_*_dev)."""
