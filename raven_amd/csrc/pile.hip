@@ -12,6 +12,7 @@
 // Pile ids must equal read indices (the reference's own invariant, construct.cc:25,74-75).
 #include <algorithm>
 
+#include <cstdlib>
 #include "engine.h"
 #include "introsort.h"
 #include "slopes.h"
@@ -461,7 +462,8 @@ void piles_trim_and_median(Engine& e, PileState& ps, u32 coverage, u32* h_begin,
 
 // ---- Pile::FindChimericRegions for every valid pile (construct.cc:139 inside TrimAndAnnotatePiles) ---------------------
 namespace {
-// one thread per pile: FindSlopes(1.82) + pit pairing + MergeRegions (slopes.h) on the coverage array where it is
+// one THREAD per pile: FindSlopes(1.82) + pit pairing + MergeRegions (slopes.h) on the coverage array where it is (piles
+// longer than the wave kernel's LDS, and RVN_CHIMERIC_PER_THREAD)
 __global__ __launch_bounds__(64) void pile_chimeric_kernel(const u16* __restrict__ data, const u64* __restrict__ pile_off,
                                                           const u8* __restrict__ invalid, u32 n,
                                                           SlopeRegion* __restrict__ slopes, u16* __restrict__ tmp,
@@ -486,6 +488,129 @@ __global__ __launch_bounds__(64) void pile_chimeric_kernel(const u16* __restrict
     }
   }
   count[p] = c;
+}
+// One WAVE per pile.  The first sweep of FindSlopes — for every cell, is the highest coverage within 52 cells on its left
+// (right) above coverage * q — is the wave's: the coverage sits in LDS, windowed maxima come from five doubling passes
+// (M32[i] = max of cells i .. i + 31; a 52-cell window is two overlapping M32), the runs of flagged cells from ballots.
+// What follows (separating overlapping slopes, narrowing, pit pairing, MergeRegions) works on a handful of regions and
+// is lane 0's, on the same code as the one-thread-per-pile kernel and the CPU hook (slopes.h), reading the LDS copy.
+constexpr int kChimCells = 4096;  // cells (16 bases each) a wave keeps in LDS; longer piles take the one-thread path
+struct alignas(16) ChimLds {
+  u16 data[kChimCells + 192];  // cell i at [64 + i]; zeros outside the pile
+  u16 a[kChimCells + 192];
+  u16 b[kChimCells + 192];
+};
+__global__ __launch_bounds__(64) void pile_chimeric_wave_kernel(const u16* __restrict__ data, const u64* __restrict__ pile_off,
+                                                               const u8* __restrict__ invalid, u32 n,
+                                                               SlopeRegion* __restrict__ slopes, u16* __restrict__ tmp,
+                                                               u32* __restrict__ out_tmp, u32* __restrict__ count,
+                                                               u32* __restrict__ n_overflow) {
+  __shared__ ChimLds S;
+  const u32 p = blockIdx.x;
+  const int lane = static_cast<int>(threadIdx.x);
+  if (p >= n) return;
+  if (invalid[p]) {
+    if (lane == 0) count[p] = 0;
+    return;
+  }
+  const u64 off = pile_off[p];
+  const u32 len = static_cast<u32>(pile_off[p + 1] - off);
+  SlopeRegion* dst = slopes + 2 * off;
+  const u32 cap = 2 * len;
+  bool overflow = false;
+  u32 c = 0;
+  if (len > static_cast<u32>(kChimCells) || len == 0) {
+    if (lane == 0 && len) c = find_chimeric_regions(data + off, static_cast<int>(len), dst, cap, tmp + off, out_tmp + 2 * off, len, &overflow);
+  } else {
+    const int total = static_cast<int>(len) + 192;
+    for (int i = lane; i < total; i += 64) {
+      const int cell = i - 64;
+      S.data[i] = (cell >= 0 && cell < static_cast<int>(len)) ? data[off + cell] : static_cast<u16>(0);
+    }
+    __syncthreads();
+    // M2 -> a, M4 -> b, M8 -> a, M16 -> b, M32 -> a (reads beyond the array's end are never needed: 128 cells of zeros)
+    auto pass = [&](const u16* src, u16* out, int half) {
+      for (int i = lane; i < total - half; i += 64) {
+        const u16 x = src[i], y = src[i + half];
+        out[i] = x > y ? x : y;
+      }
+      for (int i = total - half + lane; i < total; i += 64) out[i] = 0;
+      __syncthreads();
+    };
+    pass(S.data, S.a, 1);
+    pass(S.a, S.b, 2);
+    pass(S.b, S.a, 4);
+    pass(S.a, S.b, 8);
+    pass(S.b, S.a, 16);
+    const u16* M = S.a + 64;  // M[i] = max(data[i .. i + 31])
+    const u16* D = S.data + 64;
+    const int w = 847 >> 4;   // 52
+    auto flags_of = [&](int i, bool& down, bool& up) {
+      const u16 d = static_cast<u16>(slope_clamp(static_cast<double>(D[i]) * 1.82));
+      const u16 l0 = M[i - w], l1 = M[i - 32];
+      const u16 r0 = M[i + 1], r1 = M[i + w - 31];
+      const u16 lmax = l0 > l1 ? l0 : l1, rmax = r0 > r1 ? r0 : r1;
+      down = lmax > d;
+      up = rmax > d;
+    };
+    SlopeRegion* ups = reinterpret_cast<SlopeRegion*>(out_tmp + 2 * off);  // room for len regions; ups are at most len / 2
+    u32 nd = 0, nde = 0, nu = 0, nue = 0;          // runs started / ended so far, per kind
+    bool carry_d = false, carry_u = false;        // flag of the cell before the chunk
+    for (u32 c0 = 0; c0 < len; c0 += 64) {
+      const int i = static_cast<int>(c0) + lane;
+      bool fd = false, fu = false;
+      if (i < static_cast<int>(len)) flags_of(i, fd, fu);
+      bool nd_next = false, nu_next = false;      // flag of the first cell of the next chunk (wave-uniform)
+      if (c0 + 64 < len) flags_of(static_cast<int>(c0) + 64, nd_next, nu_next);
+      const unsigned long long bd = __ballot(fd), bu = __ballot(fu);
+      const unsigned long long sd = bd & ~((bd << 1) | (carry_d ? 1ULL : 0ULL)), su = bu & ~((bu << 1) | (carry_u ? 1ULL : 0ULL));
+      const unsigned long long ed = bd & ~((bd >> 1) | (nd_next ? 1ULL << 63 : 0ULL)), eu = bu & ~((bu >> 1) | (nu_next ? 1ULL << 63 : 0ULL));
+      const unsigned long long below = (1ULL << lane) - 1ULL;
+      // downs go straight to dst, ups to the (still unused) output scratch and behind the downs afterwards
+      if ((sd >> lane) & 1ULL) {
+        const u32 k = nd + static_cast<u32>(__popcll(sd & below));
+        if (k < cap) dst[k].first = static_cast<u32>(i) << 1;
+        else overflow = true;
+      }
+      if ((ed >> lane) & 1ULL) {
+        const u32 k = nde + static_cast<u32>(__popcll(ed & below));
+        if (k < cap) dst[k].second = static_cast<u32>(i);
+      }
+      if ((su >> lane) & 1ULL) {
+        const u32 k = nu + static_cast<u32>(__popcll(su & below));
+        if (k < len) ups[k].first = static_cast<u32>(i) << 1 | 1u;
+        else overflow = true;
+      }
+      if ((eu >> lane) & 1ULL) {
+        const u32 k = nue + static_cast<u32>(__popcll(eu & below));
+        if (k < len) ups[k].second = static_cast<u32>(i);
+      }
+      nd += static_cast<u32>(__popcll(sd));
+      nde += static_cast<u32>(__popcll(ed));
+      nu += static_cast<u32>(__popcll(su));
+      nue += static_cast<u32>(__popcll(eu));
+      carry_d = (bd >> 63) & 1ULL;
+      carry_u = (bu >> 63) & 1ULL;
+    }
+    overflow = __ballot(overflow) != 0 || nd + nu > cap;
+    __threadfence_block();
+    __syncthreads();
+    if (!overflow)
+      for (u32 k = lane; k < nu; k += 64) dst[nd + k] = ups[k];  // the ups behind the downs
+    __threadfence_block();
+    __syncthreads();
+    if (lane == 0 && !overflow) {
+      const u32 ns = find_slopes_rest(D, 1.82, dst, cap, nd + nu, tmp + off, &overflow);
+      c = pair_and_merge_slopes(dst, ns, tmp + off, out_tmp + 2 * off, len, &overflow);
+    }
+  }
+  if (lane == 0) {
+    if (overflow) {
+      atomicAdd(n_overflow, 1u);
+      c = 0;
+    }
+    count[p] = c;
+  }
 }
 __global__ void chimeric_gather_kernel(const u32* __restrict__ out_tmp, const u64* __restrict__ pile_off,
                                        const u32* __restrict__ count, const u32* __restrict__ roff, u32 n,
@@ -516,8 +641,12 @@ void piles_find_chimeric_regions(Engine& e, PileState& ps, const u8* h_invalid, 
   u32* d_roff = d_cnt + n + 1;
   u32* d_ovf = e.tmp_f.get<u32>(4);
   RVN_HIP(hipMemsetAsync(d_ovf, 0, 4, s));
-  RVN_KLAUNCH(kKPileTrim, pile_chimeric_kernel<<<div_up(n, 64), 64, 0, s>>>(ps.pile_data.as<u16>(), ps.pile_off.as<u64>(), d_inv, n,
-                                                                           d_slopes, d_tmp, d_out, d_cnt, d_ovf));
+  if (std::getenv("RVN_CHIMERIC_PER_THREAD"))  // (the earlier layout: one thread per pile; kept for comparisons)
+    RVN_KLAUNCH(kKPileTrim, pile_chimeric_kernel<<<div_up(n, 64), 64, 0, s>>>(ps.pile_data.as<u16>(), ps.pile_off.as<u64>(), d_inv, n,
+                                                                             d_slopes, d_tmp, d_out, d_cnt, d_ovf));
+  else
+    RVN_KLAUNCH(kKPileTrim, pile_chimeric_wave_kernel<<<n, 64, 0, s>>>(ps.pile_data.as<u16>(), ps.pile_off.as<u64>(), d_inv, n,
+                                                                      d_slopes, d_tmp, d_out, d_cnt, d_ovf));
   exclusive_scan_u32_u32(d_cnt, d_roff, n, e.scan_tmp, s);
   RVN_HIP(hipMemcpyAsync(h_off.data(), d_roff, (static_cast<size_t>(n) + 1) * 4, hipMemcpyDeviceToHost, s));
   if (read_back(e, d_ovf, 4) != 0)

@@ -67,6 +67,9 @@ struct RunBuilder {
   }
 };
 
+__host__ __device__ inline u32 find_slopes_rest(const u16* __restrict__ data, double q, SlopeRegion* dst, u32 cap, u32 n,
+                                                u16* __restrict__ tmp, bool* overflow);
+
 // Pile::FindSlopes(q) on data[0, size); dst has room for cap regions; tmp: size u16 cells of scratch.
 // Returns the number of regions (sorted as the reference leaves them); *overflow when cap was too small.
 __host__ __device__ inline u32 find_slopes(const u16* __restrict__ data, int size, double q, SlopeRegion* dst, u32 cap,
@@ -100,6 +103,13 @@ __host__ __device__ inline u32 find_slopes(const u16* __restrict__ data, int siz
     }
     up.finish();
   }
+  return find_slopes_rest(data, q, dst, cap, n, tmp, overflow);
+}
+
+// The part of Pile::FindSlopes after the first sweep: dst[0, n) holds the runs of the first sweep (any order).
+__host__ __device__ inline u32 find_slopes_rest(const u16* __restrict__ data, double q, SlopeRegion* dst, u32 cap, u32 n,
+                                                u16* __restrict__ tmp, bool* overflow) {
+  const int w = 847 >> 4;
   if (n == 0) return 0;
   // separate overlapping slopes
   for (;;) {
@@ -167,12 +177,21 @@ __host__ __device__ inline u32 find_slopes(const u16* __restrict__ data, int siz
   return n;
 }
 
+__host__ __device__ inline u32 pair_and_merge_slopes(SlopeRegion* slopes, u32 ns, u16* __restrict__ tmp, u32* __restrict__ out,
+                                                     u32 out_cap, bool* overflow);
+
 // Pile::FindChimericRegions: out[2 * r], out[2 * r + 1] = the merged (begin, end) cells of region r; returns their number.
 // slopes / tmp: scratch (cap regions / size cells); merged flags reuse tmp.
 __host__ __device__ inline u32 find_chimeric_regions(const u16* __restrict__ data, int size, SlopeRegion* slopes, u32 cap,
                                                      u16* __restrict__ tmp, u32* __restrict__ out, u32 out_cap,
                                                      bool* overflow) {
   const u32 ns = find_slopes(data, size, 1.82, slopes, cap, tmp, overflow);
+  return pair_and_merge_slopes(slopes, ns, tmp, out, out_cap, overflow);
+}
+
+// pit pairing + Pile::MergeRegions on the final slope list
+__host__ __device__ inline u32 pair_and_merge_slopes(SlopeRegion* slopes, u32 ns, u16* __restrict__ tmp, u32* __restrict__ out,
+                                                     u32 out_cap, bool* overflow) {
   if (ns == 0 || *overflow) return 0;
   // a down slope directly followed by an up slope: the pit between them (pile.cc:181-186); collected in place
   u32 nr = 0;
