@@ -200,7 +200,9 @@ void engine_release_scratch(Engine& e) {
 void engine_release_scratch_if_tight(Engine& e) {
   size_t free_b = 0, total_b = 0;
   if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return;
-  const bool tight = free_b * 3 < total_b;
+  // (a quarter, not a third: a C4 step settles at ~220 GB of grow-only stage buffers on a 309 GB device — alignment
+  // store, window-consensus chunk, sort scratch — and handing them back costs seconds of re-allocation in the next step)
+  const bool tight = free_b * 4 < total_b;
   if (std::getenv("RVN_DEBUG_MEM"))
     std::fprintf(stderr, "[raven_hip] stage entry: %.1f GB free of %.1f GB%s\n", free_b / 1e9, total_b / 1e9,
                  tight ? " -> releasing scratch" : "");
