@@ -177,7 +177,8 @@ def make_workload(args, device):
     t0 = time.time()
     dev = torch.device("cuda", device)
     genome = synth.make_genome_torch(args.genome, seed=0x5EED0001, device=dev)
-    rs, _ = synth.make_reads_torch(genome, args.coverage, args.read_len, length_model=args.length_model, seed=0x5EED0002)
+    rs, _ = synth.make_reads_torch(genome, args.coverage, args.read_len, length_model=args.length_model, sub=args.errors[0],
+                                   ins=args.errors[1], dele=args.errors[2], seed=0x5EED0002)
     drafts = []
     if args.polish_rounds > 0:
         n_contigs = max(1, (args.genome + args.contig - 1) // args.contig)
@@ -198,8 +199,11 @@ def main():
     # exchange buffers by ownership between the overlap pass and the polishing rounds, so a buffer can still be too
     # small for its new role in the third pass: 8.8 GB re-allocated inside `minimize`, + 0.38 s — DESIGN.md section 5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", choices=["c4", "c2"], default="c4",
-                    help="c4: 100 Mb, 30x ONT-length reads (configs[3]; the metric's config).  c2: 5 Mb, 10 kb reads (configs[2])")
+    ap.add_argument("--workload", choices=["c4", "c2", "c5"], default="c4",
+                    help="c4: 100 Mb, 30x ONT-length reads (configs[3]; the metric's config).  c2: 5 Mb, 10 kb reads "
+                         "(configs[2]).  c5: 100 Mb, 40x HiFi 15 kb reads, --identity 0.95 (configs[4]'s workload on one GPU: "
+                         "first pass, trimming, identity filter, second pass, two rounds)")
+    ap.add_argument("--identity", type=float, default=None)
     ap.add_argument("--genome", type=int, default=None)
     ap.add_argument("--coverage", type=float, default=30.0)
     ap.add_argument("--read-len", type=int, default=None)
@@ -222,10 +226,19 @@ def main():
     ap.add_argument("--sharded", action="store_true", help="run the sharded code path even at N = 1 (one rank owning "
                     "every read and hash class): measures what the partition / regroup steps cost before any link traffic")
     args = ap.parse_args()
+    args.errors = (0.04, 0.03, 0.03)
     if args.workload == "c4":
         args.genome = args.genome or 100_000_000
         args.read_len = args.read_len or 9000
         args.length_model = args.length_model or "lognormal"
+    elif args.workload == "c5":
+        args.genome = args.genome or 100_000_000
+        args.read_len = args.read_len or 15000
+        args.length_model = args.length_model or "normal"
+        args.errors = (0.001, 0.002, 0.002)
+        if args.coverage == 30.0:
+            args.coverage = 40.0
+        args.identity = 0.95 if args.identity is None else args.identity
     else:
         args.genome = args.genome or 5_000_000
         args.read_len = args.read_len or 10000
@@ -299,6 +312,37 @@ def main():
         else:
             p = eng.find_overlaps_and_create_piles(reads, freq=args.freq, kmax=args.kmax)  # synchronous
             t_x = time.perf_counter()
+            if args.identity:
+                # ConstructGraph's stages -5 .. -4 around the device calls (construct.cc:650-707): TrimAndAnnotatePiles on
+                # the coverage in HBM, the identity filter of ResolveContainedReads on the kept lists, contained reads by
+                # Raven's own overlap rules (host code of the reference: here the library's __host__ build of
+                # overlap_rules.h, timed apart as host_rules_s), then the whole second pass
+                t_s0 = time.perf_counter()
+                ovl, off = p.overlaps()
+                begin, end, median, invalid = p.trim_and_annotate(4)
+                begin, end = (begin.astype(np.uint32) << 4), (end.astype(np.uint32) << 4)
+                t_s1 = time.perf_counter()
+                kept, koff = eng.filter_overlaps_by_identity(reads, ovl, off, begin, end, invalid, args.identity)
+                t_s2 = time.perf_counter()
+                upd, ok, ty = hip.test_overlap_update_and_type(kept, begin, end, invalid.astype(np.uint8))
+                contained = np.zeros(rs.n, bool)
+                contained[upd["lhs_id"][(ok == 1) & (ty == 1)]] = True
+                contained[upd["rhs_id"][(ok == 1) & (ty == 2)]] = True
+                inv2 = (invalid.astype(bool) | contained).astype(np.uint8)
+                t_s3 = time.perf_counter()
+                res2 = eng.find_overlaps_and_repetitive_regions(reads, begin, end, inv2, freq=args.freq, kmer_len=args.k,
+                                                                identity=args.identity)
+                t_s4 = time.perf_counter()
+                if timed:
+                    st5 = legs.setdefault("c5", {"fetch_trim_s": 0.0, "identity_filter_s": 0.0, "host_rules_s": 0.0,
+                                                 "second_pass_s": 0.0})
+                    st5["fetch_trim_s"] += t_s1 - t_s0
+                    st5["identity_filter_s"] += t_s2 - t_s1
+                    st5["host_rules_s"] += t_s3 - t_s2
+                    st5["second_pass_s"] += t_s4 - t_s3
+                    last["c5"] = {"pass1_overlaps": int(ovl.shape[0]), "kept_by_identity": int(kept.shape[0]),
+                                  "invalid_or_contained": float(inv2.mean()), "pass2_overlaps": int(res2["overlaps"].shape[0])}
+                del res2, ovl, kept, upd
             p.close()
             if os.environ.get("RVN_DEBUG_PASS1"):
                 print("[bench] pass1 call %.1f ms, close %.1f ms" % ((t_x - t_a) * 1e3, (time.perf_counter() - t_x) * 1e3),
@@ -529,15 +573,17 @@ def main():
             "dtype": "u32" if val_bytes == 4 else "u64",
             "data": "synthetic",
             "config": {
-                "workload": ("BASELINE.json configs[%d]%s: synthetic %.0f Mb genome, %gx ONT-like reads (%s %d bp; 4%% sub, "
-                             "3%% ins, 3%% del), k=%d w=%d, FindOverlapsAndCreatePiles + -p %d (racon rounds on %.0f Mb "
-                             "draft contigs with 2.6%% errors; " +
-                             ("reads WITHOUT qualities: the FASTA variant)" if args.no_quality else
-                              "reads carry biosoup block qualities at Phred 10: the FASTQ variant)")) % (
-                                3 if args.workload == "c4" else (2 if rounds else 1),
-                                " on one GPU" if world == 1 and args.workload == "c4" else "",
-                                args.genome / 1e6, args.coverage, args.length_model, args.read_len, args.k, args.w, rounds,
-                                args.contig / 1e6),
+                "workload": "BASELINE.json configs[%d]%s: synthetic %.0f Mb genome, %gx reads (%s %d bp; %.1f%% sub, %.1f%% ins, "
+                            "%.1f%% del), k=%d w=%d, FindOverlapsAndCreatePiles%s + -p %d (racon rounds on %.0f Mb draft contigs "
+                            "with 2.6%% errors; %s)" % (
+                                3 if args.workload == "c4" else (4 if args.workload == "c5" else (2 if rounds else 1)),
+                                " on one GPU" if world == 1 and args.workload in ("c4", "c5") else "",
+                                args.genome / 1e6, args.coverage, args.length_model, args.read_len,
+                                100 * args.errors[0], 100 * args.errors[1], 100 * args.errors[2], args.k, args.w,
+                                (" + TrimAndAnnotatePiles + identity filter %.2f + FindOverlapsAndRepetetiveRegions" % args.identity)
+                                if args.identity else "", rounds, args.contig / 1e6,
+                                "reads WITHOUT qualities: the FASTA variant" if args.no_quality else
+                                "reads carry biosoup block qualities at Phred 10: the FASTQ variant"),
                 "reads": rs.n, "read_bases": rs.total_bases, "freq": args.freq, "kmax": args.kmax,
                 "draft_contigs": len(drafts),
                 "parallelism": ("one genome sharded over %d GPUs: reads by pile, minimizers by hash class, 3 all-to-all + "
@@ -552,6 +598,8 @@ def main():
                      "polish_gbase_per_s_per_round": round(rs.total_bases / (pol_s / rounds) / 1e9, 3) if rounds and pol_s else None,
                      "windows_per_s": round(last.get("n_windows", 0) / pol_s, 1) if pol_s else None,
                      "polished_ratio": last.get("ratio")},
+            "c5_stages": ({"seconds_per_step": {k: round(v / steps, 4) for k, v in legs["c5"].items()}, **last.get("c5", {}),
+                           "identity": args.identity} if "c5" in legs else None),
             "overlaps_per_s": round(counters["overlaps"] / ovl_s, 1) if ovl_s else None,
             "counters_per_step": counters,
             "last_polish_round": {k: (round(v, 3) if isinstance(v, float) else v) for k, v in last.get("polish", {}).items()},
