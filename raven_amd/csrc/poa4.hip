@@ -791,7 +791,7 @@ __host__ __device__ __forceinline__ void atomic_inc_u16(u16* base, u32 idx) {  /
 }
 
 // GW = lanes per window: 64 (one window per wave, 256 positions per iteration — the update kernel) or 16.
-template <int GW>
+template <int GW, int UP>
 __host__ __device__ inline u32 poa4_update_graph(const Poa4Args A, u16* nslot, const u32* seq2, unsigned char* slot_mem, bool act,
                                                  const PoaLayer* Lp, u32 len, u32 lb, u32& nn, bool& flip,
                                                  unsigned long long& t_add, unsigned long long& t_ord) {
@@ -825,16 +825,16 @@ __host__ __device__ inline u32 poa4_update_graph(const Poa4Args A, u16* nslot, c
   auto letter_at = [&](u32 p) -> u32 { return (seq2[(p + 1) >> 4] >> (2 * ((p + 1) & 15u))) & 3u; };
   // ---- the first aligned position: the unaligned prefix goes before all members of its column ----
   u32 first_p = 0xFFFFFFFFu;
-  for (u32 p0 = 0; p0 < max_len; p0 += 4 * GW) {
+  for (u32 p0 = 0; p0 < max_len; p0 += UP * GW) {
     if (!sv::any(act && first_p == 0xFFFFFFFFu && p0 < len)) break;
-    u32 pn[4];
+    u32 pn[UP];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < UP; ++u) {
       const u32 p = p0 + static_cast<u32>(GW) * static_cast<u32>(u) + static_cast<u32>(gl);
       pn[u] = (act && p < len) ? g.pos_node[p] : kNone4;
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < UP; ++u) {
       const unsigned long long bal = gballot(pn[u] != kNone4);
       if (first_p == 0xFFFFFFFFu && bal) first_p = p0 + static_cast<u32>(GW) * static_cast<u32>(u) + static_cast<u32>(__builtin_ctzll(bal));
     }
@@ -857,24 +857,24 @@ __host__ __device__ inline u32 poa4_update_graph(const Poa4Args A, u16* nslot, c
   u32 why = 0;  // != 0: the window has failed; its lanes keep step with the wave without touching the graph
   u32 prev_tgt = kNone4;   // node of position p0 - 1 (the last position of the previous iteration)
   i32 prev_w = 0;          // its weight
-  for (u32 p0 = 0; p0 < max_len; p0 += 4 * GW) {
+  for (u32 p0 = 0; p0 < max_len; p0 += UP * GW) {
     const bool go = act && why == 0;
-    u32 p[4], an[4], letter[4];
-    bool valid[4], has[4];
+    u32 p[UP], an[UP], letter[UP];
+    bool valid[UP], has[UP];
     // level 1: the nodes the positions are aligned to
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < UP; ++u) {
       p[u] = p0 + static_cast<u32>(GW) * static_cast<u32>(u) + static_cast<u32>(gl);
       valid[u] = go && p[u] < len;
       an[u] = valid[u] ? g.pos_node[p[u]] : kNone4;
       letter[u] = valid[u] ? letter_at(p[u]) : 0u;
     }
     // level 2: those nodes
-    u32 c_an[4], ac[4], rk_an[4], bp_an[4];
-    uint2 al2[4];
-    i32 wgt[4];
+    u32 c_an[UP], ac[UP], rk_an[UP], bp_an[UP];
+    uint2 al2[UP];
+    i32 wgt[UP];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < UP; ++u) {
       has[u] = valid[u] && an[u] != kNone4;
       const u32 a = has[u] ? an[u] : 0u;
       c_an[u] = g.code[a];
@@ -885,9 +885,9 @@ __host__ __device__ inline u32 poa4_update_graph(const Poa4Args A, u16* nslot, c
       wgt[u] = valid[u] ? static_cast<i32>(static_cast<u8>(poa_layer_weight(A.src, L, p[u]))) : 0;
     }
     // level 3: their aligned groups (at most three other letters)
-    u32 kt[4][3], c_kt[4][3], rk_kt[4][3];
+    u32 kt[UP][3], c_kt[UP][3], rk_kt[UP][3];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < UP; ++u) {
       if (!has[u]) ac[u] = 0;
       kt[u][0] = al2[u].x & 0xFFFFu;
       kt[u][1] = al2[u].x >> 16;
@@ -900,10 +900,10 @@ __host__ __device__ inline u32 poa4_update_graph(const Poa4Args A, u16* nslot, c
       }
     }
     // where every position lands; order slot / backbone coordinate of the last aligned position at or before it
-    u32 tgt[4], id_new[4];
-    bool is_new[4];
+    u32 tgt[UP], id_new[UP];
+    bool is_new[UP];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < UP; ++u) {
       u32 t = kNone4, rmax = rk_an[u];
       if (has[u]) {
         if (c_an[u] == letter[u]) t = an[u];
@@ -977,10 +977,10 @@ __host__ __device__ inline u32 poa4_update_graph(const Poa4Args A, u16* nslot, c
       tgt[u] = t;
     }
     // level 4: the in-edge lists of the nodes the positions land on (a new node's is empty)
-    u32 icnt[4];
-    uint4 ta[4], tb[4];
+    u32 icnt[UP];
+    uint4 ta[UP], tb[UP];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < UP; ++u) {
       const bool old = valid[u] && why == 0 && !is_new[u];
       const u32 t = old ? tgt[u] : 0u;
       icnt[u] = old ? g.in_cnt[t] : 0u;
@@ -989,7 +989,7 @@ __host__ __device__ inline u32 poa4_update_graph(const Poa4Args A, u16* nslot, c
     }
     // the edges (p - 1 -> p)
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < UP; ++u) {
       // node and weight of position p - 1: the lane below; lane 0 takes the last lane of the previous quarter
       const u32 last_t = static_cast<u32>(sv::bperm(static_cast<int>(u == 0 ? prev_tgt : tgt[u > 0 ? u - 1 : 0]), gbase | (GW - 1)));
       const i32 last_w = sv::bperm(u == 0 ? prev_w : wgt[u > 0 ? u - 1 : 0], gbase | (GW - 1));
@@ -1030,8 +1030,8 @@ __host__ __device__ inline u32 poa4_update_graph(const Poa4Args A, u16* nslot, c
       const u32 wmax = static_cast<u32>(gmax(static_cast<i32>(why)));
       why = wmax;
     }
-    prev_tgt = static_cast<u32>(sv::bperm(static_cast<int>(tgt[3]), gbase | (GW - 1)));
-    prev_w = sv::bperm(wgt[3], gbase | (GW - 1));
+    prev_tgt = static_cast<u32>(sv::bperm(static_cast<int>(tgt[UP - 1]), gbase | (GW - 1)));
+    prev_w = sv::bperm(wgt[UP - 1], gbase | (GW - 1));
   }
   t_add += sv::clock() - t0;
   t0 = sv::clock();
@@ -1041,15 +1041,15 @@ __host__ __device__ inline u32 poa4_update_graph(const Poa4Args A, u16* nslot, c
   const bool doit = act && why == 0 && n_new != 0;
   if (sv::any(doit)) {
     const u32 max_old = static_cast<u32>(sv::wave_max(doit ? static_cast<int>(n_old) : 0));
-    for (u32 r0 = 0; r0 < max_old; r0 += 4 * GW) {
-      u32 rr[4], vv[4];
+    for (u32 r0 = 0; r0 < max_old; r0 += UP * GW) {
+      u32 rr[UP], vv[UP];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < UP; ++u) {
         rr[u] = r0 + static_cast<u32>(GW) * static_cast<u32>(u) + static_cast<u32>(gl);
         vv[u] = (doit && rr[u] < n_old) ? g.order[rr[u]] : 0u;
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < UP; ++u) {
         if (doit && rr[u] < n_old) {
           u32 lo = 0, hi = n_new;  // upper_bound(nslot, r)
           while (lo < hi) {
@@ -1203,6 +1203,7 @@ struct Poa4Ctx {  // what a phase function needs beside the batch description
   u32 count;      // windows of the chunk
   u32 part, n_parts;  // the chunk's waves are dealt out to n_parts streams: this launch serves waves part, part + n_parts, ..
   u32 slot0;      // first scratch slot of the part
+  u32 desc_waves; // waves a window gets in the descriptor pass (256 nodes each per turn)
 };
 
 __host__ __device__ __forceinline__ unsigned char* poa4_slot_of(const Poa4Args& A, const Poa4Ctx& C, u32 wave, int q) {
@@ -1465,10 +1466,11 @@ __host__ __device__ inline void poa4_phase_setup(const Poa4Args& A, const Poa4Ct
 // depends only on (window, node) — the window's record, the layer's packed codes and guide, the nodes' own fields — then
 // the gathers of the in-edges' tails.
 constexpr int kDescPer = 4;
+constexpr u32 kDescWavesPerWindow = 6;  // 1536 nodes per turn: the graph of a 500-base window with 30 - 40 layers
 template <class K>
 __host__ __device__ inline void poa4_phase_desc(const Poa4Args& A, const Poa4Ctx& C, Poa4LdsDesc& S, u32 wave) {
   const int lane = sv::lane();
-  const u32 per_win = (A.nmax + 64 * kDescPer - 1) / (64 * kDescPer);
+  const u32 per_win = C.desc_waves;
   const u32 rec = wave / per_win, chunk = wave % per_win;
   const u32 wave_dp = rec / P4::G;
   const int q = static_cast<int>(rec % P4::G);
@@ -1479,27 +1481,6 @@ __host__ __device__ inline void poa4_phase_desc(const Poa4Args& A, const Poa4Ctx
   if (me.phase != kRunning || !me.act) return;
   const u32 nn = me.nn;
   if (chunk * kDescPer * 64 >= nn && chunk != 0) return;
-  // level 1
-  const u32 gw = sl.seq2g[lane < 60 ? lane : (lane < 64 ? 64 + (lane - 60) : 0)];
-  const u32 gw2 = lane < 28 ? sl.seq2g[68 + lane] : 0u;
-  u32 vv[kDescPer], rbv[kDescPer], cc[kDescPer], code[kDescPer], outc_f[kDescPer], outc_s[kDescPer], mk[kDescPer];
-  uint4 tl[kDescPer];
-#pragma unroll
-  for (int u = 0; u < kDescPer; ++u) {
-    vv[u] = (chunk * kDescPer + static_cast<u32>(u)) * 64 + static_cast<u32>(lane);
-    const u32 vq = vv[u] < A.nmax ? vv[u] : 0u;
-    rbv[u] = sl.rb[vq];
-    cc[u] = g.in_cnt[vq];
-    code[u] = g.code[vq];
-    outc_f[u] = g.out_cnt[vq];
-    outc_s[u] = g.sub_out[vq];
-    mk[u] = g.mark[vq];
-    tl[u] = *reinterpret_cast<const uint4*>(g.in_tail + static_cast<size_t>(vq) * kPoaMaxIn);
-  }
-  if (lane < 60) S.seq2[lane] = gw;
-  else S.segtab[lane - 60] = gw;
-  if (lane < 28) S.segtab[4 + lane] = gw2;
-  lds_order();
   const bool full = me.full != 0;
   const u32 len = me.len, r_lo = me.r_lo, n_rows = me.n_rows, r_hi = r_lo + n_rows;
   const i32 lb = static_cast<i32>(me.lb), span = static_cast<i32>(me.span), b_first = static_cast<i32>(me.b_first);
@@ -1510,6 +1491,31 @@ __host__ __device__ inline void poa4_phase_desc(const Poa4Args& A, const Poa4Ctx
   const u32 neg2 = neg_off | (neg_off << 16);
   u32 flag = 0, marked_rows = 0;
   i32 t_end = 0;
+  {  // the layer's packed codes and guide into LDS
+    const u32 gw = sl.seq2g[lane < 60 ? lane : 64 + (lane - 60)];
+    const u32 gw2 = lane < 28 ? sl.seq2g[68 + lane] : 0u;
+    if (lane < 60) S.seq2[lane] = gw;
+    else S.segtab[lane - 60] = gw;
+    if (lane < 28) S.segtab[4 + lane] = gw2;
+  }
+  lds_order();
+  // a window gets desc_waves waves; a graph of more than 256 x desc_waves nodes makes them go round again
+  for (u32 chunk_i = chunk; chunk_i * kDescPer * 64 < nn; chunk_i += per_win) {
+  // level 1
+  u32 vv[kDescPer], rbv[kDescPer], cc[kDescPer], code[kDescPer], outc_f[kDescPer], outc_s[kDescPer], mk[kDescPer];
+  uint4 tl[kDescPer];
+#pragma unroll
+  for (int u = 0; u < kDescPer; ++u) {
+    vv[u] = (chunk_i * kDescPer + static_cast<u32>(u)) * 64 + static_cast<u32>(lane);
+    const u32 vq = vv[u] < A.nmax ? vv[u] : 0u;
+    rbv[u] = sl.rb[vq];
+    cc[u] = g.in_cnt[vq];
+    code[u] = g.code[vq];
+    outc_f[u] = g.out_cnt[vq];
+    outc_s[u] = g.sub_out[vq];
+    mk[u] = g.mark[vq];
+    tl[u] = *reinterpret_cast<const uint4*>(g.in_tail + static_cast<size_t>(vq) * kPoaMaxIn);
+  }
   // level 2: the tails of the in-edges
   bool ok[kDescPer], marked[kDescPer];
   u32 trb[kDescPer][8], tmk[kDescPer][8];
@@ -1600,6 +1606,7 @@ __host__ __device__ inline void poa4_phase_desc(const Poa4Args& A, const Poa4Ctx
       if (marked[u]) ++marked_rows;
     }
   }
+  }  // chunks
   // rows beyond the last one: what the lanes' descriptor prefetch runs into
   if (chunk == 0 && lane < 32) {
     const size_t rho = static_cast<size_t>(n_rows) + static_cast<size_t>(lane);
@@ -1690,10 +1697,12 @@ __host__ __device__ inline void poa4_phase_tb(const Poa4Args& A, const Poa4Ctx& 
 }
 
 // phase D: the graph update, one window per wave
+constexpr int kUpdPer = 2;  // sequence positions per lane and iteration of the graph update
 struct alignas(16) Poa4LdsUpd {
   u16 nslot[kPoa2MaxSeq + 16];  // order slots of the layer's new nodes
   u32 seq2[64];                 // the layer, 2 bits per base
 };
+template <int UP>
 __host__ __device__ inline void poa4_phase_update(const Poa4Args& A, const Poa4Ctx& C, Poa4LdsUpd& S, u32 rec) {
   const int lane = sv::lane();
   const u32 wave_dp = rec / P4::G;
@@ -1710,7 +1719,7 @@ __host__ __device__ inline void poa4_phase_update(const Poa4Args& A, const Poa4C
   bool flip = me.flip != 0;
   const PoaLayer* Lp = A.layers;
   if (act) Lp = A.layers + A.windows[me.wi].layer_first + me.li;
-  const u32 why = poa4_update_graph<64>(A, S.nslot, S.seq2, my_slot, act, Lp, me.len, me.lb, nn, flip, t_add, t_ord);
+  const u32 why = poa4_update_graph<64, UP>(A, S.nslot, S.seq2, my_slot, act, Lp, me.len, me.lb, nn, flip, t_add, t_ord);
   if (lane == 0) {
     if (act && why) {
       me.phase = kFailed;
@@ -1780,9 +1789,10 @@ __global__ __launch_bounds__(64) void poa4_tb_kernel(const Poa4Args A, const Poa
   __shared__ Poa4LdsTb lds;
   poa4_phase_tb<P4>(A, C, lds, blockIdx.x);
 }
+template <int UP>
 __global__ __launch_bounds__(64) void poa4_update_kernel(const Poa4Args A, const Poa4Ctx C) {
   __shared__ Poa4LdsUpd lds;
-  poa4_phase_update(A, C, lds, blockIdx.x);
+  poa4_phase_update<UP>(A, C, lds, blockIdx.x);
 }
 __global__ __launch_bounds__(64) void poa4_final_kernel(const Poa4Args A, const Poa4Ctx C) {
   __shared__ Poa4Lds lds;
@@ -1840,6 +1850,8 @@ void poa_v4_launch(Engine& e, const PoaBatchDev& b) {
   // The waves of a chunk are dealt out to several streams that run their rounds independently: the phases of a round
   // are one issue-bound kernel (NW) and three that wait on gathers, and two streams in different phases fill each
   // other's gaps.
+  int upd_per = kUpdPer;  // (RVN_POA4_UPD=4: four positions per lane in the graph update — half the iterations, 157 registers)
+  if (const char* ev = std::getenv("RVN_POA4_UPD")) upd_per = std::atoi(ev) == 4 ? 4 : kUpdPer;
   u32 n_parts = 4;
   if (const char* ev = std::getenv("RVN_POA4_STREAMS")) n_parts = static_cast<u32>(std::max(1, std::min(8, std::atoi(ev))));
   if (per_chunk < 4096) n_parts = 1;
@@ -1885,7 +1897,7 @@ void poa_v4_launch(Engine& e, const PoaBatchDev& b) {
     u32 slot0 = 0;
     for (u32 p = 0; p < n_parts; ++p) {
       n_waves[p] = waves_total > p ? (waves_total - p + n_parts - 1) / n_parts : 0;
-      C[p] = Poa4Ctx{d_st + slot0, first, count, p, n_parts, slot0};
+      C[p] = Poa4Ctx{d_st + slot0, first, count, p, n_parts, slot0, kDescWavesPerWindow};
       slot0 += n_waves[p] * P4::G;
       if (n_parts > 1) st[p] = e.poa_streams[p];
     }
@@ -1904,10 +1916,11 @@ void poa_v4_launch(Engine& e, const PoaBatchDev& b) {
         if (w_set) RVN_KLAUNCH_ON(kKPoaBanded, st[p], (poa4_setup_kernel<<<w_set * P4::G, 64, 0, st[p]>>>(A, C[p])));
         const u32 w = waves_in_round(round, p, n_waves[p]);
         if (!w || round == max_layers) continue;
-        RVN_KLAUNCH_ON(kKPoaBanded, st[p], (poa4_desc_kernel<<<w * P4::G * ((b.nmax + 255) / 256), 64, 0, st[p]>>>(A, C[p])));
+        RVN_KLAUNCH_ON(kKPoaBanded, st[p], (poa4_desc_kernel<<<w * P4::G * kDescWavesPerWindow, 64, 0, st[p]>>>(A, C[p])));
         RVN_KLAUNCH_ON(kKPoaBanded, st[p], (poa4_dp_kernel<<<w, 64, 0, st[p]>>>(A, C[p])));
         RVN_KLAUNCH_ON(kKPoaBanded, st[p], (poa4_tb_kernel<<<w, 64, 0, st[p]>>>(A, C[p])));
-        RVN_KLAUNCH_ON(kKPoaBanded, st[p], (poa4_update_kernel<<<w * P4::G, 64, 0, st[p]>>>(A, C[p])));
+        if (upd_per == 4) RVN_KLAUNCH_ON(kKPoaBanded, st[p], (poa4_update_kernel<4><<<w * P4::G, 64, 0, st[p]>>>(A, C[p])));
+        else RVN_KLAUNCH_ON(kKPoaBanded, st[p], (poa4_update_kernel<kUpdPer><<<w * P4::G, 64, 0, st[p]>>>(A, C[p])));
       }
     }
     for (u32 p = 0; p < n_parts; ++p)
@@ -1943,7 +1956,7 @@ void emu_entry4(void* p) {
     case 6: poa4_phase_desc<P4>(*c->A, *c->C, *c->SL, c->wave); break;
     case 2: poa4_phase_dp<P4>(*c->A, *c->C, *c->S, c->wave); break;
     case 3: poa4_phase_tb<P4>(*c->A, *c->C, *c->ST, c->wave); break;
-    case 4: poa4_phase_update(*c->A, *c->C, *c->SU, c->wave); break;
+    case 4: poa4_phase_update<kUpdPer>(*c->A, *c->C, *c->SU, c->wave); break;
     default: poa4_phase_final(*c->A, *c->C, *c->S, c->wave); break;
   }
 }
@@ -1977,7 +1990,7 @@ void poa_v4_emulate(const std::vector<PoaWindow>& wins, const std::vector<PoaLay
   b.sched = nullptr;
   b.next = &next;
   const Poa4Args A = args_of4(b, scratch.data(), slot_bytes);
-  const Poa4Ctx C{st.data(), 0, count, 0, 1, 0};
+  const Poa4Ctx C{st.data(), 0, count, 0, 1, 0, 2};  // (two waves per window: graphs beyond 512 nodes go round again)
   std::vector<Poa4Lds> lds(1);
   std::vector<Poa4LdsDesc> ldsl(1);
   std::vector<Poa4LdsUpd> ldsu(1);
@@ -1985,12 +1998,13 @@ void poa_v4_emulate(const std::vector<PoaWindow>& wins, const std::vector<PoaLay
   u32 max_layers = 0;
   for (const PoaWindow& w : wins) max_layers = std::max(max_layers, w.n_layers);
   auto run = [&](int ph) {
-    const u32 per_win = (b.nmax + 255) / 256;
+    const u32 per_win = C.desc_waves;
     const u32 waves = (ph == 1 || ph == 4) ? n_waves * P4::G : (ph == 6 ? n_waves * P4::G * per_win : n_waves);
     for (u32 wv = 0; wv < waves; ++wv) {
       if (ph == 6) {  // (waves that would return at once: not worth 64 fibres each)
         const u32 rec = wv / per_win, chunk = wv % per_win;
         if (rec >= count || st[rec].phase != kRunning || !st[rec].act || (chunk * 256 >= st[rec].nn && chunk != 0)) continue;
+        (void)per_win;
       }
       std::memset(static_cast<void*>(lds.data()), 0, sizeof(Poa4Lds));  // (a fresh workgroup's LDS holds anything: zeros here)
       std::memset(static_cast<void*>(ldsl.data()), 0, sizeof(Poa4LdsDesc));
