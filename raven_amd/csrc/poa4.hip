@@ -1697,7 +1697,8 @@ __host__ __device__ inline void poa4_phase_tb(const Poa4Args& A, const Poa4Ctx& 
 }
 
 // phase D: the graph update, one window per wave
-constexpr int kUpdPer = 2;  // sequence positions per lane and iteration of the graph update
+constexpr int kUpdPer = 4;  // sequence positions per lane and iteration of the graph update (2: 80 registers instead of 157,
+                            // twice the iterations — measured equal at C4)
 struct alignas(16) Poa4LdsUpd {
   u16 nslot[kPoa2MaxSeq + 16];  // order slots of the layer's new nodes
   u32 seq2[64];                 // the layer, 2 bits per base
@@ -1850,8 +1851,8 @@ void poa_v4_launch(Engine& e, const PoaBatchDev& b) {
   // The waves of a chunk are dealt out to several streams that run their rounds independently: the phases of a round
   // are one issue-bound kernel (NW) and three that wait on gathers, and two streams in different phases fill each
   // other's gaps.
-  int upd_per = kUpdPer;  // (RVN_POA4_UPD=4: four positions per lane in the graph update — half the iterations, 157 registers)
-  if (const char* ev = std::getenv("RVN_POA4_UPD")) upd_per = std::atoi(ev) == 4 ? 4 : kUpdPer;
+  int upd_per = kUpdPer;  // (RVN_POA4_UPD=2: two positions per lane in the graph update)
+  if (const char* ev = std::getenv("RVN_POA4_UPD")) upd_per = std::atoi(ev) == 2 ? 2 : kUpdPer;
   u32 n_parts = 4;
   if (const char* ev = std::getenv("RVN_POA4_STREAMS")) n_parts = static_cast<u32>(std::max(1, std::min(8, std::atoi(ev))));
   if (per_chunk < 4096) n_parts = 1;
@@ -1919,7 +1920,7 @@ void poa_v4_launch(Engine& e, const PoaBatchDev& b) {
         RVN_KLAUNCH_ON(kKPoaBanded, st[p], (poa4_desc_kernel<<<w * P4::G * kDescWavesPerWindow, 64, 0, st[p]>>>(A, C[p])));
         RVN_KLAUNCH_ON(kKPoaBanded, st[p], (poa4_dp_kernel<<<w, 64, 0, st[p]>>>(A, C[p])));
         RVN_KLAUNCH_ON(kKPoaBanded, st[p], (poa4_tb_kernel<<<w, 64, 0, st[p]>>>(A, C[p])));
-        if (upd_per == 4) RVN_KLAUNCH_ON(kKPoaBanded, st[p], (poa4_update_kernel<4><<<w * P4::G, 64, 0, st[p]>>>(A, C[p])));
+        if (upd_per == 2) RVN_KLAUNCH_ON(kKPoaBanded, st[p], (poa4_update_kernel<2><<<w * P4::G, 64, 0, st[p]>>>(A, C[p])));
         else RVN_KLAUNCH_ON(kKPoaBanded, st[p], (poa4_update_kernel<kUpdPer><<<w * P4::G, 64, 0, st[p]>>>(A, C[p])));
       }
     }
