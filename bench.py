@@ -61,13 +61,13 @@ _TRAFFIC = None
 
 
 def pmc_traffic_file():
-    """This round's rocprofv3 --pmc result (profiles/r03_pmc_traffic.json, made by tools/pmc_traffic.py from separate
+    """This round's rocprofv3 --pmc result (profiles/r04_pmc_traffic.json, made by tools/pmc_traffic.py from separate
     FETCH_SIZE / WRITE_SIZE passes of this same bench command; tools/profile_round.sh stamps it with the hash of the
     kernel sources it was taken on)."""
     global _TRAFFIC
     if _TRAFFIC is None:
         _TRAFFIC = {}
-        for name in ("r03_pmc_traffic.json",):
+        for name in ("r04_pmc_traffic.json",):
             try:
                 with open(os.path.join(ROOT, "profiles", name)) as f:
                     _TRAFFIC = json.load(f)

@@ -11,7 +11,10 @@ import re
 import sys
 
 SITES = [  # (regex on the demangled kernel name, bench.py kernel-site name)
-    (r"nw_sweep_kernel", "nw_forward"), (r"nw_trace_kernel", "nw_traceback"), (r"poa2_kernel", "poa_banded"),
+    (r"nw_sweep_kernel", "nw_forward"), (r"nw_trace_kernel", "nw_traceback"), (r"poa2_kernel", "poa2"),
+    (r"poa4_dp_kernel", "poa4_dp"), (r"poa4_tb_kernel", "poa4_tb"), (r"poa4_update_kernel", "poa4_update"),
+    (r"poa4_desc_kernel", "poa4_desc"), (r"poa4_setup_kernel", "poa4_setup"), (r"poa4_final_kernel", "poa4_final"),
+    (r"poa4_init_kernel", "poa4_init"),
     (r"\bpoa_kernel", "poa"), (r"chain_small_kernel", "chain_small"), (r"chain_kernel", "chain"),
     (r"rs_downsweep_kernel", "rs_downsweep"), (r"rs_upsweep_kernel", "rs_upsweep"),
     (r"sketch_kernel<[^>]*false>", "sketch_count"), (r"sketch_kernel<[^>]*true>", "sketch_write"),
@@ -54,7 +57,7 @@ def kernel_source_hash():
     return h.hexdigest()
 
 
-def main(fetch_csv, write_csv, out):
+def main(fetch_csv, write_csv, out, rounds=None):
     f, w = load(fetch_csv), load(write_csv)
     kernels = {}
     for k in sorted(set(f) | set(w)):
@@ -64,6 +67,20 @@ def main(fetch_csv, write_csv, out):
         wr_l = wr * 1024 / max(nw, 1)
         kernels[k] = {"launches_fetch_pass": nf, "launches_write_pass": nw, "fetch_size_bytes_per_launch": int(fe_l),
                       "write_size_bytes_per_launch": int(wr_l), "hbm_bytes_per_launch": int(2 * fe_l + wr_l)}
+    # the window-consensus stage is a set of launches per polishing round (poa4.hip's phase kernels + poa2.hip for what the
+    # 32-column band hands on): its traffic is the sum over all of them / the polishing rounds of the profiled command
+    stage = {"fetch": 0.0, "write": 0.0}
+    for k in set(f) | set(w):
+        if k.startswith("poa4_") or k == "poa2":
+            stage["fetch"] += f.get(k, [0, 0.0])[1] * 1024
+            stage["write"] += w.get(k, [0, 0.0])[1] * 1024
+    if rounds:
+        r = float(rounds)
+        kernels["poa_banded"] = {"launches_fetch_pass": int(r), "launches_write_pass": int(r),
+                                 "fetch_size_bytes_per_launch": int(stage["fetch"] / r),
+                                 "write_size_bytes_per_launch": int(stage["write"] / r),
+                                 "hbm_bytes_per_launch": int((2 * stage["fetch"] + stage["write"]) / r),
+                                 "note": "one 'launch' = the launch set of one polishing round (all poa4_* kernels + poa2)"}
     json.dump({"method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE in separate passes of `python bench.py "
                          "--no-cpu-baseline`; hbm = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 per launch (gfx950: FETCH_SIZE counts "
                          "128-B requests as 64 B, MI355X_MICROARCH.md HBM section; WRITE_SIZE uncalibrated)",
@@ -73,4 +90,4 @@ def main(fetch_csv, write_csv, out):
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:4])
+    main(*sys.argv[1:4], rounds=(sys.argv[4] if len(sys.argv) > 4 else None))
