@@ -2,11 +2,15 @@
 Tolerance-based where ties can differ (north_star: 'polished consensus within stated edit-distance tolerance'):
 per window ED(gpu, cpu) <= 1 % of the window length, and ED(gpu, truth) <= ED(cpu, truth) + 2; the simple
 cases must be identical."""
+import os
+
 import numpy as np
 import pytest
 
 from oracle import oracle
 from raven_amd import hip
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
@@ -203,3 +207,19 @@ def test_rows_on_lanes_kernel_equals_one_row_per_iteration_kernel():
     emu, st_emu = hip.poa_banded_emulate(wins[:8])
     for a, b, sa, sb in zip(emu, c9[:8], st_emu, s9[:8]):
         assert (int(sa) & 0xFF) == (int(sb) & 0xFF) and np.array_equal(a, b)
+
+
+def test_consensus_parity_fraction_on_c4_like_windows():
+    """How close 'within tolerance' is: 1500 windows shaped like a C4 polishing round's (500-base backbone, Poisson(31)
+    layers with 10 % errors, a fifth of them partial) through the default chain (poa4 -> poa2 -> ...) and through the POA
+    oracle.  Measured on 4000 windows (tools/poa_parity.py, profiles/r04_poa_parity_4000.json): 99.8 % byte-identical, the
+    rest ONE edit apart (a base present or absent), neither side closer to the truth.  The test holds the stage to that:
+    >= 99 % identical, no window further than 2 edits from the oracle's consensus."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("poa_parity", os.path.join(ROOT, "tools", "poa_parity.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    r = mod.run(1500, threads=os.cpu_count(), mode=0, seed=4242)
+    assert r["polished"] == 1500, r
+    assert r["identical_fraction"] >= 0.99, r
+    assert all(x["ed_device_vs_oracle"] <= 2 for x in r["examples"]) and r["sum_ed_between"] <= 2 * r["different"], r

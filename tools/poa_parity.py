@@ -1,0 +1,99 @@
+#!/usr/bin/env python3
+"""Consensus parity of the window-consensus stage against the repo's own POA oracle (racon Window::GenerateConsensus over
+spoa, oracle/poa_oracle.cpp) on C4-like windows: 500-base backbone with ~2.6 % errors, ~30 ONT-like layers (4 % sub, 3 % ins,
+3 % del), a share of them partial.  Reports the fraction of windows whose consensus is byte-identical and, for the rest, the
+edit distance between the two and of each to the truth.
+    python tools/poa_parity.py [n_windows] [threads] [mode]"""
+import json
+import os
+import sys
+import time
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import oracle  # noqa: E402  (the checker)
+from raven_amd import hip  # noqa: E402
+
+
+def mutate(rng, truth, sub, ins, dele):
+    L = truth.shape[0]
+    u = rng.random(L)
+    keep = u >= dele
+    base = truth.copy()
+    s = (u >= dele) & (u < dele + sub)
+    base[s] = (base[s] + rng.integers(1, 4, size=int(s.sum()))) & 3
+    insm = rng.random(L) < ins
+    emit = keep.astype(np.int64) + insm
+    seq = np.repeat(base, emit)
+    off = np.cumsum(emit)
+    slots = off[insm] - 1
+    seq[slots] = rng.integers(0, 4, size=slots.shape[0])
+    return seq.astype(np.uint8)
+
+
+def make_window(rng, partial_share=0.2):
+    truth = rng.integers(0, 4, size=500, dtype=np.uint8)
+    bb = mutate(rng, truth, 0.01, 0.008, 0.008)
+    layers, begins, ends = [bb], [0], [len(bb) - 1]
+    n_layers = int(np.clip(rng.poisson(31), 3, 90))
+    for _ in range(n_layers):
+        if rng.random() < partial_share:
+            b = int(rng.integers(0, 250))
+            e = int(rng.integers(b + 125, 500))
+        else:
+            b, e = 0, 500
+        piece = mutate(rng, truth[b:e], 0.04, 0.03, 0.03)
+        if len(piece) < 10:
+            continue
+        layers.append(piece)
+        bb_b = min(len(bb) - 2, int(b * len(bb) / 500))
+        bb_e = min(len(bb) - 1, max(bb_b + 1, int(e * len(bb) / 500) - 1))
+        begins.append(bb_b)
+        ends.append(bb_e)
+    return dict(layers=layers, begins=begins, ends=ends, quals=None), truth
+
+
+def run(n_windows=2000, threads=None, mode=0, seed=20260927):
+    rng = np.random.default_rng(seed)
+    wins, truths = [], []
+    for _ in range(n_windows):
+        w, t = make_window(rng)
+        wins.append(w)
+        truths.append(t)
+    eng = hip.Engine()
+    eng.poa_set_mode(mode)
+    cons, status, ms = eng.poa_consensus_batch(wins)
+    t0 = time.time()
+    with ThreadPoolExecutor(max_workers=threads or os.cpu_count() or 1) as ex:  # the oracle releases the GIL inside its C++ call
+        refs = list(ex.map(lambda w: oracle.poa_window(w["layers"], begins=w["begins"], ends=w["ends"])[0], wins))
+    t_cpu = time.time() - t0
+    same, diffs, unpolished = 0, [], 0
+    for i, (c, r, st) in enumerate(zip(cons, refs, status)):
+        if (int(st) & 0xFF) != 1:
+            unpolished += 1
+            continue
+        if np.array_equal(c, r):
+            same += 1
+        else:
+            d = oracle.edit_distance(bytes(c + 65), bytes(r + 65))
+            dg = oracle.edit_distance(bytes(c + 65), bytes(truths[i] + 65))
+            dr = oracle.edit_distance(bytes(r + 65), bytes(truths[i] + 65))
+            diffs.append({"window": i, "layers": len(wins[i]["layers"]), "ed_device_vs_oracle": int(d), "ed_device_vs_truth": int(dg),
+                          "ed_oracle_vs_truth": int(dr), "len_device": int(len(c)), "len_oracle": int(len(r))})
+    polished = n_windows - unpolished
+    return {"windows": n_windows, "mode": mode, "polished": polished, "identical": same,
+            "identical_fraction": round(same / max(polished, 1), 6), "different": len(diffs), "device_ms": ms,
+            "oracle_s": round(t_cpu, 1), "sum_ed_between": int(sum(x["ed_device_vs_oracle"] for x in diffs)),
+            "device_closer_to_truth": int(sum(x["ed_device_vs_truth"] < x["ed_oracle_vs_truth"] for x in diffs)),
+            "oracle_closer_to_truth": int(sum(x["ed_device_vs_truth"] > x["ed_oracle_vs_truth"] for x in diffs)),
+            "equally_close": int(sum(x["ed_device_vs_truth"] == x["ed_oracle_vs_truth"] for x in diffs)),
+            "examples": diffs[:12]}
+
+
+if __name__ == "__main__":
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
+    th = int(sys.argv[2]) if len(sys.argv) > 2 else None
+    mode = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+    print(json.dumps(run(n, th, mode)))

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Collects the evidence files of a round on the GPU box (run through gpurun):
-#   1. timeout 600 rocprofv3 --kernel-trace --stats of the default bench command (the N = 1 line: 100 Mb, -p 2)
+#   1. rocprofv3 --kernel-trace --stats of the default bench command (the N = 1 line: 100 Mb, -p 2)
 #   2. / 3. separate --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of the same command (HBM traffic per launch)
 # Outputs under gpurun_out/<tag>_*; tools/pmc_traffic.py + the stats CSV are what gets copied to profiles/.
 R=${GRAFT_REPO_ROOT:-/root/repo}
