@@ -414,15 +414,6 @@ void rvn_poa_work(const rvn_engine* e, uint64_t out[3]);
  * left (or beyond a limit) by the full-matrix kernel; 1 = full-matrix kernel only; 2 / 3 / 4 = 64- / 128- / 256-column
  * band only (flagged windows come back with status 8); 9 = poa4.hip only.  Returns the previous mode. */
 int rvn_poa_set_mode(rvn_engine* e, int mode);
-/* TEST INFRASTRUCTURE: the rows-on-lanes banded kernel (poa4.hip) stepped through on the HOST by a 64-fibre
- * wavefront emulator — the same phase functions, no GPU and no engine needed.  Arguments as rvn_poa_consensus_batch +
- * variant (ignored: one kernel); first attempt only (status 8: the window needs a wider band).  The CPU suite
- * compares it with the oracle (tests/test_poa4_emulation.py); nothing on the product path calls it. */
-int rvn_poa_banded_emulate(const uint8_t* codes, const uint8_t* quals, const uint64_t* layer_offsets,
-                           const uint32_t* begins, const uint32_t* ends, const uint32_t* has_qual,
-                           const uint32_t* window_offsets, uint32_t n_windows, int match, int mismatch, int gap,
-                           int trim, uint8_t* consensus, const uint64_t* consensus_offsets, uint32_t* consensus_len,
-                           uint32_t* status, int variant);
 /* mode 0: windows of the last batch repeated with the 128-column band (wide) / that needed more than that (fallback:
  * 256 columns or the full matrix) */
 uint32_t rvn_poa_fallback_windows(const rvn_engine* e);
@@ -454,29 +445,8 @@ int rvn_engine_num_kernel_sites(void);
 const char* rvn_engine_kernel_site_name(int site);
 int rvn_engine_kernel_ms(rvn_engine* e, double* ms, uint64_t* launches, int n);
 
-/* host-side test hooks for the __host__ __device__ building blocks (no GPU needed) */
-uint64_t rvn_test_hash(uint64_t key, uint32_t k, int use32);
-int rvn_test_canonical(const uint64_t* words, uint32_t pos, uint32_t k, int use32, uint64_t* value, uint32_t* strand);
-int rvn_test_low_complexity(const uint8_t* codes, uint32_t k);
-/* the alignment-path stage of a polishing round (nwpath.h) stepped on the CPU: the forward sweep's lane code driven
- * for 64 emulated lanes + the traceback, i.e. exactly what the kernels execute.  Rows = target span
- * [t_begin, t_begin + n) of a packed target, columns = span [q_begin, q_begin + m) of the read in the target's
- * orientation (rc: the read is reverse-complemented).  k = first band threshold (doubled until exact), force_r = 0
- * or the blocks per lane (1 / 2 / 4 / 8).  recs: one 32-byte record per window of w target bases touched by the span
- * {first_t, first_q, last_t, last_q, u16 grid[8]}; distance = exact edit distance; band = {k, lanes, R} used.
- * Returns 0, 1 if the walk did not end at cost 0, < 0 on invalid arguments. */
-int rvn_test_nw_breakpoints(const uint64_t* t_words, uint32_t t_len, const uint64_t* r_words, uint32_t r_len,
-                            uint32_t t_begin, uint32_t n, uint32_t q_begin, uint32_t m, int rc, uint32_t w, uint32_t k,
-                            int force_r, uint32_t* recs, uint32_t* distance, uint32_t* band);
-/* Pile::FindChimericRegions (slopes.h, the __host__ __device__ code the kernel runs) on one coverage array: out = (begin,
- * end) cell pairs; returns their number, -5 if a capacity was exceeded */
-int64_t rvn_test_find_chimeric_regions(const uint16_t* data, uint32_t size, uint32_t* out, uint64_t cap_pairs);
-/* OverlapUpdate + GetOverlapType (overlap_rules.h, the __host__ __device__ code the kernels run) on a list: ok[i] =
- * OverlapUpdate result (the overlap is updated in place when ok), type[i] = GetOverlapType of the updated overlap */
-int rvn_test_overlap_update_and_type(rvn_overlap* overlaps, uint64_t n, const uint32_t* pile_begin, const uint32_t* pile_end,
-                                     const uint8_t* pile_invalid, uint32_t n_piles, uint8_t* ok, uint32_t* type);
-void rvn_test_std_sort_lendesc(uint64_t* data, uint64_t n);
-void rvn_test_heap_sort_lendesc(uint64_t* data, uint64_t n);
+/* The host-side test hooks (rvn_test_*, rvn_poa_banded_emulate) are NOT part of this library: include/raven_hip_test.h,
+ * libraven_hip_test.so. */
 
 #ifdef __cplusplus
 }

@@ -10,13 +10,35 @@ pids=()
 # RVN_NO_EDLIB_SYMBOLS=1: leave the edlibAlign drop-in out (a process that also loads a real shared edlib: INTEGRATION.md 3.1)
 EDLIB=edlib_dropin
 if [ -n "${RVN_NO_EDLIB_SYMBOLS:-}" ]; then EDLIB=""; rm -f "$HERE/obj/edlib_dropin.o"; fi
-for f in scan radix_sort sketch index map pile edit_distance poa poa2 poa4 simt_emu polish nwpath pass2 io shard group engine $EDLIB; do
+PRODUCT="scan radix_sort sketch index map pile edit_distance poa poa2 poa4 polish nwpath pass2 io shard group engine $EDLIB"
+# libraven_hip_test.so (TEST INFRASTRUCTURE, include/raven_hip_test.h): the product's objects with these four compiled
+# again under -DRVN_TEST_HOOKS (rvn_test_*, rvn_poa_banded_emulate) + the host wavefront emulator
+HOOKED="engine poa poa4 nwpath"
+mkdir -p "$HERE/obj_test"
+stale() {  # $1 = source, $2 = object
+  [ ! -f "$2" ] || [ "$1" -nt "$2" ] || [ -n "$(find "$HERE" -maxdepth 1 -name '*.h' -newer "$2" -print -quit)" ] || [ "$HERE/../../include/raven_hip.h" -nt "$2" ] || [ "$HERE/../../include/raven_hip_test.h" -nt "$2" ]
+}
+rm -f "$HERE/obj/simt_emu.o"
+for f in $PRODUCT; do
   src="$HERE/$f.hip"; obj="$HERE/obj/$f.o"
-  if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ -n "$(find "$HERE" -maxdepth 1 -name '*.h' -newer "$obj" -print -quit)" ] || [ "$HERE/../../include/raven_hip.h" -nt "$obj" ]; then
+  if stale "$src" "$obj"; then
     $HIPCC $FLAGS -c "$src" -o "$obj" &
     pids+=($!)
   fi
 done
+for f in $HOOKED simt_emu; do
+  src="$HERE/$f.hip"; obj="$HERE/obj_test/$f.o"
+  if stale "$src" "$obj"; then
+    $HIPCC $FLAGS -DRVN_TEST_HOOKS -c "$src" -o "$obj" &
+    pids+=($!)
+  fi
+done
 for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/libraven_hip.so" "$HERE"/obj/*.o -lz
-echo "built $OUT/libraven_hip.so"
+objs=(); tobjs=("$HERE/obj_test/simt_emu.o")
+for f in $PRODUCT; do
+  objs+=("$HERE/obj/$f.o")
+  case " $HOOKED " in *" $f "*) tobjs+=("$HERE/obj_test/$f.o");; *) tobjs+=("$HERE/obj/$f.o");; esac
+done
+$HIPCC --offload-arch=gfx950 -shared -fPIC -Wl,--no-undefined -o "$OUT/libraven_hip.so" "${objs[@]}" -lz
+$HIPCC --offload-arch=gfx950 -shared -fPIC -Wl,--no-undefined -o "$OUT/libraven_hip_test.so" "${tobjs[@]}" -lz
+echo "built $OUT/libraven_hip.so $OUT/libraven_hip_test.so"

@@ -7,6 +7,9 @@
 #include <new>
 
 #include "../../include/raven_hip.h"
+#ifdef RVN_TEST_HOOKS
+#include "../../include/raven_hip_test.h"
+#endif
 #include "introsort.h"
 #include "nwpath.h"
 #include "overlap_rules.h"
@@ -811,6 +814,7 @@ int rvn_filter_overlaps_by_identity(rvn_engine* h, const rvn_reads* rr, rvn_over
   });
 }
 
+#ifdef RVN_TEST_HOOKS
 int64_t rvn_test_find_chimeric_regions(const uint16_t* data, uint32_t size, uint32_t* out, uint64_t cap_pairs) {
   if (!data || !out || size == 0) return RVN_EINVAL;
   std::vector<SlopeRegion> slopes(2 * static_cast<size_t>(size) + 2);  // same bounds as the device path (pile.hip)
@@ -834,6 +838,7 @@ int rvn_test_overlap_update_and_type(rvn_overlap* overlaps, uint64_t n, const ui
   }
   return RVN_OK;
 }
+#endif  // RVN_TEST_HOOKS
 
 int rvn_pile_add_layers(rvn_engine* h, uint16_t* data, uint32_t cells, uint32_t id, const rvn_overlap* overlaps,
                         uint64_t n) {
@@ -977,6 +982,7 @@ int rvn_poa_consensus_batch(rvn_engine* h, const uint8_t* codes, const uint8_t* 
   });
 }
 
+#ifdef RVN_TEST_HOOKS
 int rvn_poa_banded_emulate(const uint8_t* codes, const uint8_t* quals, const uint64_t* layer_offsets, const uint32_t* begins,
                            const uint32_t* ends, const uint32_t* has_qual, const uint32_t* window_offsets,
                            uint32_t n_windows, int match, int mismatch, int gap, int trim, uint8_t* consensus,
@@ -993,6 +999,7 @@ int rvn_poa_banded_emulate(const uint8_t* codes, const uint8_t* quals, const uin
     return RVN_OK;
   });
 }
+#endif  // RVN_TEST_HOOKS
 
 int rvn_polish_map_best(rvn_engine* h, rvn_reads* targets, rvn_reads* reads, uint32_t read_first, uint32_t read_last,
                         double err, rvn_overlap* best, uint32_t* best_target, uint64_t* n_overlaps) {
@@ -1700,6 +1707,7 @@ int rvn_engine_kernel_ms(rvn_engine* h, double* ms, uint64_t* launches, int n) {
   });
 }
 
+#ifdef RVN_TEST_HOOKS
 // ---- host test hooks ---------------------------------------------------------------------------
 uint64_t rvn_test_hash(uint64_t key, uint32_t k, int use32) {
   const u64 mask = (1ULL << (2 * k)) - 1;
@@ -1726,6 +1734,7 @@ int rvn_test_canonical(const uint64_t* words, uint32_t pos, uint32_t k, int use3
   *strand = st;
   return ok ? 1 : 0;
 }
+#endif  // RVN_TEST_HOOKS
 
 int rvn_polish_fetch_layers(rvn_engine* h, uint32_t* out, uint64_t cap, uint64_t* n_out) {
   return guarded(h ? &h->e : nullptr, [&]() -> int {
@@ -1766,6 +1775,7 @@ int rvn_polish_fetch_layers(rvn_engine* h, uint32_t* out, uint64_t cap, uint64_t
   });
 }
 
+#ifdef RVN_TEST_HOOKS
 int rvn_test_nw_breakpoints(const uint64_t* t_words, uint32_t t_len, const uint64_t* r_words, uint32_t r_len,
                             uint32_t t_begin, uint32_t n, uint32_t q_begin, uint32_t m, int rc, uint32_t w, uint32_t k,
                             int force_r, uint32_t* recs, uint32_t* distance, uint32_t* band) {
@@ -1780,5 +1790,6 @@ int rvn_test_low_complexity(const uint8_t* codes, uint32_t k) { return lc_kmer_p
 
 void rvn_test_std_sort_lendesc(uint64_t* data, uint64_t n) { std_sort(data, data + n, LenDesc()); }
 void rvn_test_heap_sort_lendesc(uint64_t* data, uint64_t n) { intro::heap_sort(data, data + n, LenDesc()); }
+#endif  // RVN_TEST_HOOKS
 
 }  // extern "C"

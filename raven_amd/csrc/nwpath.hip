@@ -542,6 +542,7 @@ void nw_breakpoints(Engine& e, const ReadsDev& T, const ReadsDev& Rd, std::vecto
                  static_cast<unsigned long long>(st.n_batches), static_cast<double>(st.band_cells), st.store_bytes / 1048576.0, ms, mu, va, vb);
 }
 
+#ifdef RVN_TEST_HOOKS
 // ---- CPU stepper of the same code (test hook rvn_test_nw_breakpoints): 64 emulated lanes, host arrays --------------
 template <int R>
 static int emulate_job(NwJob J, u32 G, const u64* t_words, const u64* r_words, u32 w, NwWindowRec* recs, u32* distance,
@@ -662,5 +663,7 @@ int nw_breakpoints_host(const u64* t_words, u32 t_len, const u64* r_words, u32 r
   }
   return -3;
 }
+
+#endif  // RVN_TEST_HOOKS
 
 }  // namespace rvn

@@ -895,6 +895,7 @@ void poa_consensus_batch(Engine& e, const u8* h_codes, const u8* h_quals, const 
           device_ms);
 }
 
+#ifdef RVN_TEST_HOOKS
 // The rows-on-lanes banded kernel (poa4.hip) stepped through on the HOST by the wavefront emulator: same batch
 // description as poa_consensus_batch, first attempt only (status 8 / 7 = the window needs the wider kernels).  Test
 // infrastructure for the CPU suite; needs no GPU and no engine.
@@ -913,5 +914,7 @@ void poa_banded_emulate(const u8* h_codes, const u8* h_quals, const u64* h_layer
   (void)variant;
   poa_v4_emulate(wins, lays, src, max_bb, max_len, m, n, g, trim, h_out, h_out_len, h_status);
 }
+
+#endif  // RVN_TEST_HOOKS
 
 }  // namespace rvn

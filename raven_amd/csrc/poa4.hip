@@ -1935,6 +1935,7 @@ void poa_v4_launch(Engine& e, const PoaBatchDev& b) {
   }
 }
 
+#ifdef RVN_TEST_HOOKS
 // The same phase functions on the host, wave by wave under the wavefront emulator (simt_emu): windows / layers /
 // sources are host arrays.  TEST INFRASTRUCTURE (rvn_poa_banded_emulate); first attempt only — a window that needs a
 // wider band comes back flagged.
@@ -2026,5 +2027,7 @@ void poa_v4_emulate(const std::vector<PoaWindow>& wins, const std::vector<PoaLay
   run(1);
   run(5);
 }
+
+#endif  // RVN_TEST_HOOKS
 
 }  // namespace rvn

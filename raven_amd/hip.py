@@ -13,6 +13,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RVN_LIB_PATH") or os.path.join(_HERE, "lib", "libraven_hip.so")  # override: A/B builds
+TEST_LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), "libraven_hip_test.so")  # test hooks + host emulator, never the product
 
 OVERLAP_DTYPE = np.dtype([
     ("lhs_id", "<u4"), ("lhs_begin", "<u4"), ("lhs_end", "<u4"),
@@ -35,7 +36,7 @@ SYMBOLS = [
     "rvn_engine_map_batch", "rvn_engine_map_fetch", "rvn_engine_map_fetch_filtered",
     "rvn_find_overlaps_and_create_piles", "rvn_pass1_pile_words", "rvn_pass1_num_overlaps",
     "rvn_pass1_fetch_piles", "rvn_pass1_fetch_overlaps", "rvn_pass1_destroy", "rvn_pile_add_layers",
-    "rvn_edit_distance_batch", "rvn_poa_consensus_batch", "rvn_poa_banded_emulate", "rvn_pass1_trim_and_annotate", "rvn_poa_phase_cycles", "rvn_poa_narrow_windows", "rvn_polish_target_reads", "rvn_polish_set_chunk_windows", "rvn_polish_round_range", "rvn_polish_map_best", "rvn_polish_set_best", "rvn_shard_sketch", "rvn_shard_sketch_fetch",
+    "rvn_edit_distance_batch", "rvn_poa_consensus_batch", "rvn_pass1_trim_and_annotate", "rvn_poa_phase_cycles", "rvn_poa_narrow_windows", "rvn_polish_target_reads", "rvn_polish_set_chunk_windows", "rvn_polish_round_range", "rvn_polish_map_best", "rvn_polish_set_best", "rvn_shard_sketch", "rvn_shard_sketch_fetch",
     "rvn_shard_index_build", "rvn_shard_key_counts", "rvn_engine_set_occurrence", "rvn_shard_join",
     "rvn_shard_join_fetch", "rvn_shard_chain", "rvn_shard_piles", "rvn_shard_join_range", "rvn_shard_piles_create",
     "rvn_shard_piles_merge", "rvn_shard_piles_merge_dev", "rvn_shard_sketch_fetch_dev",
@@ -43,15 +44,21 @@ SYMBOLS = [
     "rvn_shard_split_minimizers_dev", "rvn_shard_count_flagged_dev", "rvn_shard_adjacent_diff_dev", "rvn_shard_regroup_dev",
     "rvn_shard_split_overlaps_dev", "rvn_shard_piles_merge_parts_dev",
     "rvn_engine_map_fetch_dev", "rvn_shard_piles_dev", "rvn_poa_set_mode", "rvn_poa_fallback_windows", "rvn_poa_wide_windows", "rvn_pile_add_kmers_batch",
-    "rvn_test_low_complexity", "rvn_test_nw_breakpoints", "rvn_reads_attach_quality", "rvn_polish_fetch_layers", "rvn_poa_work", "rvn_reads_upload_codes", "rvn_polish_round",
+    "rvn_reads_attach_quality", "rvn_polish_fetch_layers", "rvn_poa_work", "rvn_reads_upload_codes", "rvn_polish_round",
     "rvn_engine_sketch", "rvn_engine_sketch_fetch", "rvn_engine_index_size", "rvn_engine_index_fetch",
     "rvn_engine_counters", "rvn_engine_num_stages", "rvn_engine_stage_name", "rvn_engine_stage_ms",
     "rvn_engine_reset_stats", "rvn_engine_set_timing", "rvn_engine_set_kernel_timing",
-    "rvn_engine_num_kernel_sites", "rvn_engine_kernel_site_name", "rvn_engine_kernel_ms", "rvn_test_hash", "rvn_test_canonical",
-    "rvn_test_std_sort_lendesc", "rvn_test_heap_sort_lendesc", "rvn_engine_map_collect", "rvn_free",
+    "rvn_engine_num_kernel_sites", "rvn_engine_kernel_site_name", "rvn_engine_kernel_ms",
+    "rvn_engine_map_collect", "rvn_free",
     "rvn_find_overlaps_and_repetitive_regions", "rvn_pass2_num_overlaps", "rvn_pass2_kmer_cells", "rvn_pass2_fetch",
-    "rvn_pass2_destroy", "rvn_engine_release_scratch", "rvn_filter_overlaps_by_identity", "rvn_test_overlap_update_and_type", "rvn_pass1_find_chimeric_regions", "rvn_test_find_chimeric_regions",
+    "rvn_pass2_destroy", "rvn_engine_release_scratch", "rvn_filter_overlaps_by_identity", "rvn_pass1_find_chimeric_regions",
     "rvn_reads_load", "rvn_reads_name", "rvn_reads_info", "rvn_reads_fetch",
+]
+
+# TEST INFRASTRUCTURE: what include/raven_hip_test.h declares on top (libraven_hip_test.so only)
+TEST_SYMBOLS = [
+    "rvn_poa_banded_emulate", "rvn_test_low_complexity", "rvn_test_nw_breakpoints", "rvn_test_hash",
+    "rvn_test_canonical", "rvn_test_std_sort_lendesc", "rvn_test_heap_sort_lendesc", "rvn_test_overlap_update_and_type", "rvn_test_find_chimeric_regions",
 ]
 
 
@@ -72,6 +79,44 @@ def lib():
             "libraven_hip.so not built (%s): run `python -c 'import __graft_entry__ as g; g.build()'` "
             "or raven_amd/csrc/build.sh" % LIB_PATH)
     L = C.CDLL(LIB_PATH)
+    _declare(L)
+    _lib = L
+    return L
+
+
+_test_lib = None
+
+
+def test_lib():
+    """TEST INFRASTRUCTURE: libraven_hip_test.so = the product's objects + the rvn_test_* hooks and the host wavefront
+    emulator (include/raven_hip_test.h).  Only tests/ and tools/ call this; the product binding above never does."""
+    global _test_lib
+    if _test_lib is not None:
+        return _test_lib
+    if not os.path.exists(TEST_LIB_PATH):
+        raise RavenHipError("libraven_hip_test.so not built (%s): run raven_amd/csrc/build.sh" % TEST_LIB_PATH)
+    L = C.CDLL(TEST_LIB_PATH)
+    _declare(L)
+    vp, u32, u64, i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int
+    L.rvn_test_low_complexity.restype = i32
+    L.rvn_test_low_complexity.argtypes = [vp, u32]
+    L.rvn_test_nw_breakpoints.argtypes = [vp, u32, vp, u32, u32, u32, u32, u32, i32, u32, u32, i32, vp, vp, vp]
+    L.rvn_test_nw_breakpoints.restype = i32
+    L.rvn_test_find_chimeric_regions.argtypes = [vp, u32, vp, u64]
+    L.rvn_test_find_chimeric_regions.restype = C.c_int64
+    L.rvn_test_overlap_update_and_type.argtypes = [vp, u64, vp, vp, vp, u32, vp, vp]
+    L.rvn_poa_banded_emulate.argtypes = [vp, vp, vp, vp, vp, vp, vp, u32, i32, i32, i32, i32, vp, vp, vp, vp, i32]
+    L.rvn_test_hash.restype = u64
+    L.rvn_test_hash.argtypes = [u64, u32, i32]
+    L.rvn_test_canonical.restype = i32
+    L.rvn_test_canonical.argtypes = [vp, u32, u32, i32, C.POINTER(u64), C.POINTER(u32)]
+    L.rvn_test_std_sort_lendesc.argtypes = [vp, u64]
+    L.rvn_test_heap_sort_lendesc.argtypes = [vp, u64]
+    _test_lib = L
+    return L
+
+
+def _declare(L):
     vp, u32, u64, i32, dbl = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int, C.c_double
     pp = C.POINTER(C.c_void_p)
     L.rvn_last_error.restype = C.c_char_p
@@ -99,10 +144,6 @@ def lib():
     L.rvn_pass1_destroy.argtypes = [vp]
     L.rvn_pile_add_layers.argtypes = [vp, vp, u32, u32, vp, u64]
     L.rvn_pile_add_kmers_batch.argtypes = [vp, vp, u32, u32, vp, vp, vp, vp]
-    L.rvn_test_low_complexity.restype = i32
-    L.rvn_test_low_complexity.argtypes = [vp, u32]
-    L.rvn_test_nw_breakpoints.argtypes = [vp, u32, vp, u32, u32, u32, u32, u32, i32, u32, u32, i32, vp, vp, vp]
-    L.rvn_test_nw_breakpoints.restype = i32
     L.rvn_reads_attach_quality.argtypes = [vp, vp, vp, vp, i32]
     L.rvn_reads_upload_codes.argtypes = [vp, vp, vp, vp, u32, pp]
     L.rvn_find_overlaps_and_repetitive_regions.argtypes = [vp, vp, vp, vp, vp, dbl, u32, dbl, u64, pp]
@@ -120,9 +161,6 @@ def lib():
     L.rvn_reads_info.argtypes = [vp, vp, vp, vp, vp, vp]
     L.rvn_reads_fetch.argtypes = [vp, vp, vp, vp, vp, vp]
     L.rvn_pass1_find_chimeric_regions.argtypes = [vp, vp, vp, pp]
-    L.rvn_test_find_chimeric_regions.argtypes = [vp, u32, vp, u64]
-    L.rvn_test_find_chimeric_regions.restype = C.c_int64
-    L.rvn_test_overlap_update_and_type.argtypes = [vp, u64, vp, vp, vp, u32, vp, vp]
     L.rvn_poa_work.argtypes = [vp, vp]
     L.rvn_poa_work.restype = None
     L.rvn_polish_fetch_layers.argtypes = [vp, vp, u64, C.POINTER(u64)]
@@ -130,7 +168,6 @@ def lib():
     L.rvn_edit_distance_batch.argtypes = [vp, vp, vp, u32, vp, C.POINTER(dbl), C.POINTER(u64)]
     L.rvn_poa_consensus_batch.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, u32, i32, i32, i32, i32, vp, vp, vp, vp,
                                           C.POINTER(dbl)]
-    L.rvn_poa_banded_emulate.argtypes = [vp, vp, vp, vp, vp, vp, vp, u32, i32, i32, i32, i32, vp, vp, vp, vp, i32]
     L.rvn_poa_phase_cycles.argtypes = [vp, vp]
     L.rvn_polish_target_reads.argtypes = [vp, vp, u32]
     L.rvn_polish_set_chunk_windows.argtypes = [vp, u64]
@@ -179,14 +216,6 @@ def lib():
     L.rvn_engine_kernel_site_name.restype = C.c_char_p
     L.rvn_engine_kernel_site_name.argtypes = [i32]
     L.rvn_engine_kernel_ms.argtypes = [vp, vp, vp, i32]
-    L.rvn_test_hash.restype = u64
-    L.rvn_test_hash.argtypes = [u64, u32, i32]
-    L.rvn_test_canonical.restype = i32
-    L.rvn_test_canonical.argtypes = [vp, u32, u32, i32, C.POINTER(u64), C.POINTER(u32)]
-    L.rvn_test_std_sort_lendesc.argtypes = [vp, u64]
-    L.rvn_test_heap_sort_lendesc.argtypes = [vp, u64]
-    _lib = L
-    return L
 
 
 def _p(a):
@@ -403,9 +432,12 @@ def poa_banded_emulate(windows, m=3, n=-5, g=-4, trim=True, variant=4):
     no engine).  First attempt of the escalation chain only: status 8 = the window needs a wider band (or is beyond
     the kernel's limits).  Returns (list of consensus code arrays, status array)."""
     a = _pack_poa_windows(windows)
-    _check(lib().rvn_poa_banded_emulate(
+    T = test_lib()
+    rc = T.rvn_poa_banded_emulate(
         _p(a["codes"]), _p(a["quals"]), _p(a["loff"]), _p(a["begins"]), _p(a["ends"]), _p(a["hasq"]), _p(a["woff"]),
-        a["nw"], m, n, g, int(trim), _p(a["out"]), _p(a["ooff"]), _p(a["out_len"]), _p(a["status"]), int(variant)))
+        a["nw"], m, n, g, int(trim), _p(a["out"]), _p(a["ooff"]), _p(a["out_len"]), _p(a["status"]), int(variant))
+    if rc != RVN_OK:
+        raise (ValueError if rc == RVN_EINVAL else RavenHipError)(T.rvn_last_error().decode(errors="replace"))
     return _unpack_poa_consensus(a), a["status"]
 
 
@@ -903,7 +935,7 @@ def test_find_chimeric_regions(data):
     """slopes.h on the host: Pile::FindChimericRegions of one coverage array -> (k, 2) uint32 (begin, end) cells."""
     d = np.ascontiguousarray(data, dtype=np.uint16)
     out = np.zeros(max(2, d.shape[0]), dtype=np.uint32)
-    n = lib().rvn_test_find_chimeric_regions(_p(d), d.shape[0], _p(out), out.shape[0] // 2)
+    n = test_lib().rvn_test_find_chimeric_regions(_p(d), d.shape[0], _p(out), out.shape[0] // 2)
     if n < 0:
         raise ValueError("rvn_test_find_chimeric_regions: %d" % n)
     return out[:2 * n].reshape(-1, 2).copy()
@@ -915,7 +947,7 @@ def test_overlap_update_and_type(overlaps, pile_begin, pile_end, pile_invalid):
     b = np.ascontiguousarray(pile_begin, dtype=np.uint32)
     ok = np.zeros(o.shape[0], dtype=np.uint8)
     ty = np.zeros(o.shape[0], dtype=np.uint32)
-    rc = lib().rvn_test_overlap_update_and_type(_p(o), o.shape[0], _p(b), _p(np.ascontiguousarray(pile_end, dtype=np.uint32)),
+    rc = test_lib().rvn_test_overlap_update_and_type(_p(o), o.shape[0], _p(b), _p(np.ascontiguousarray(pile_end, dtype=np.uint32)),
                                                 _p(np.ascontiguousarray(pile_invalid, dtype=np.uint8)), b.shape[0], _p(ok),
                                                 _p(ty))
     if rc != 0:
@@ -936,7 +968,7 @@ def test_nw_breakpoints(t_words, t_len, r_words, r_len, t_begin, n, q_begin, m, 
     recs = np.zeros(n_win, dtype=NW_REC_DTYPE)
     dist = np.zeros(1, dtype=np.uint32)
     band = np.zeros(3, dtype=np.uint32)
-    rc_ = lib().rvn_test_nw_breakpoints(_p(t_words), t_len, _p(r_words), r_len, t_begin, n, q_begin, m, int(rc), w, k,
+    rc_ = test_lib().rvn_test_nw_breakpoints(_p(t_words), t_len, _p(r_words), r_len, t_begin, n, q_begin, m, int(rc), w, k,
                                         force_r, _p(recs), _p(dist), _p(band))
     if rc_ < 0:
         raise ValueError("rvn_test_nw_breakpoints: %d" % rc_)

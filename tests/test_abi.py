@@ -10,8 +10,8 @@ from raven_amd import hip
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared_symbols():
-    text = open(os.path.join(ROOT, "include", "raven_hip.h")).read()
+def _declared_symbols(header="raven_hip.h"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(rvn_[a-z0-9_]+)\s*\(", text)))
 
@@ -23,6 +23,20 @@ def test_header_symbols_exported():
     for name in declared:
         assert hasattr(L, name), "missing export: " + name
     assert sorted(hip.SYMBOLS) == declared, "raven_amd/hip.py SYMBOLS out of sync with include/raven_hip.h"
+
+
+def test_hooks_live_in_the_test_library_only():
+    """a drop-in does not export an emulator.  libraven_hip.so exports NO rvn_test_* symbol, no
+    rvn_poa_banded_emulate and nothing of simt_emu; libraven_hip_test.so (include/raven_hip_test.h) exports the hooks on top
+    of everything the product header declares."""
+    import subprocess
+    hooks = _declared_symbols("raven_hip_test.h")
+    assert sorted(hip.TEST_SYMBOLS) == hooks and len(hooks) == 9
+    names = subprocess.check_output(["nm", "-D", "--defined-only", hip.LIB_PATH]).decode()
+    assert "rvn_test_" not in names and "emulate" not in names and "simt_emu" not in names
+    T = hip.test_lib()
+    for name in hooks + _declared_symbols():
+        assert hasattr(T, name), "missing export in libraven_hip_test.so: " + name
 
 
 def test_edlib_dropin_symbols_exported():

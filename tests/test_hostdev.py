@@ -11,7 +11,7 @@ from tests import refimpl
 
 
 def test_hash32_equals_hash64():
-    L = hip.lib()
+    L = hip.test_lib()
     rng = np.random.default_rng(0)
     for k in (1, 5, 11, 15):
         mask = (1 << (2 * k)) - 1
@@ -31,7 +31,7 @@ def test_hash32_equals_hash64():
 @pytest.mark.parametrize("k", [1, 7, 15, 16, 21, 31])
 def test_canonical_kmer_extraction(k):
     """Direct extraction from the packed stream == ram's rolling forward/reverse registers."""
-    L = hip.lib()
+    L = hip.test_lib()
     rng = np.random.default_rng(k)
     codes = rng.integers(0, 4, size=400, dtype=np.uint8)
     codes[100:100 + 2 * k] = np.tile(np.array([0, 3], np.uint8), k)  # (AT)n -> palindromes when k is even
@@ -68,7 +68,7 @@ def _sort_via_oracle(lens):
 @pytest.mark.parametrize("n", [0, 1, 2, 15, 16, 17, 31, 32, 33, 64, 100, 257, 1000, 5000])
 def test_device_introsort_equals_std_sort(n):
     """rvn::std_sort must reproduce libstdc++'s unstable std::sort permutation exactly (ties included)."""
-    L = hip.lib()
+    L = hip.test_lib()
     rng = np.random.default_rng(n)
     for spread in (1, 3, 20, 10 ** 6):
         for pattern in ("random", "sorted", "reversed", "organ"):
@@ -89,7 +89,7 @@ def test_device_introsort_equals_std_sort(n):
 @pytest.mark.parametrize("n", [100, 1000, 20000])
 def test_device_introsort_depth_limit_path(n):
     """Adversarial input (McIlroy) forces std::sort's depth-limit heapsort fallback; permutations must match."""
-    L = hip.lib()
+    L = hip.test_lib()
     vals = oracle.antiqsort(n)
     lens = (np.uint32(n + 5) - vals).astype(np.uint32)  # descending comparator sees the ascending killer
     keys = (lens.astype(np.uint64) << np.uint64(32)) | np.arange(n, dtype=np.uint64)
@@ -104,7 +104,7 @@ def test_device_introsort_depth_limit_path(n):
 
 
 def test_device_heapsort_is_a_sort():
-    L = hip.lib()
+    L = hip.test_lib()
     rng = np.random.default_rng(1)
     for n in (0, 1, 2, 3, 17, 100, 1001):
         lens = rng.integers(0, 50, size=n).astype(np.uint64)
@@ -119,7 +119,7 @@ def test_device_heapsort_is_a_sort():
 def test_low_complexity_filter_matches_pile_cc(k):
     """rvn::lc_kmer_passes (used by the AddKmers kernel) vs the literal std::string restatement of
     RavenLib/src/pile.cc:73-117 in the oracle, on random, homopolymer-rich and short-period k-mers."""
-    L = hip.lib()
+    L = hip.test_lib()
     rng = np.random.default_rng(k)
     reads = []
     for period in (1, 2, 3, 4, 5, 7):
