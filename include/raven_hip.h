@@ -65,15 +65,19 @@ int rvn_reads_upload_codes(rvn_engine* e, const uint8_t* codes, const uint64_t* 
 void rvn_reads_destroy(rvn_reads* r);
 /* The input path: raven::CreateParser(path) + Parse(-1) (RavenLib/src/io.cc:7-41, RavenExe/src/main.cc:258-299) straight
  * into HBM.  Format by extension exactly as io.cc (.fasta / .fa / .fastq / .fq, optionally .gz; anything else is
- * RVN_EINVAL with the reference's message); a host thread inflates and parses into pinned staging buffers while the
- * previous chunk is copied and 2-bit packed on the device (biosoup's coder table: IUPAC folded, any other character is
- * RVN_EINVAL "not a nucleotide").  Read ids = 0 .. n-1 in file order.  FASTQ: biosoup's block qualities (integer mean of
+ * RVN_EINVAL with the reference's message).  A gzip file is cut into its members (BGZF blocks, concatenated members) and a
+ * pool of host threads inflates them straight into page-locked slabs of the text (a single-member archive is one deflate
+ * stream: one thread, front to back); the caller's thread finds the records with one memchr pass per slab, copies the
+ * slab to HBM as it is, and the device cuts the records out and 2-bit packs them (biosoup's coder table: IUPAC folded,
+ * any other character is RVN_EINVAL "not a nucleotide").  A damaged or truncated archive is RVN_EINVAL.  Read ids = 0 .. n-1 in file order.  FASTQ: biosoup's block qualities (integer mean of
  * every 64-base block) are computed on the device and attached to the read set (as rvn_reads_attach_quality with
  * block_shift 6 would).  rvn_reads_name: first word of the header of sequence i. */
 typedef struct rvn_load_stats {
   uint64_t n_sequences, n_bases;
   int has_quality;
-  double parse_s, device_s, total_s; /* producer thread (inflate + parse) | copy + packing on the device | whole call */
+  double parse_s, device_s, total_s; /* record scanner | copies + packing on the device (caller thread) | whole call */
+  uint32_t inflate_threads, members; /* the inflate pool (host threads) and the gzip members / file pieces it worked on */
+  int32_t streaming, restarted; /* 1: one deflate stream, inflated front to back by one thread | 1: a member cut was wrong */
 } rvn_load_stats;
 int rvn_reads_load(rvn_engine* e, const char* path, rvn_reads** out, rvn_load_stats* stats);
 const char* rvn_reads_name(const rvn_reads* r, uint32_t i);

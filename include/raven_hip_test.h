@@ -45,6 +45,14 @@ int64_t rvn_test_find_chimeric_regions(const uint16_t* data, uint32_t size, uint
  * OverlapUpdate result (the overlap is updated in place when ok), type[i] = GetOverlapType of the updated overlap */
 int rvn_test_overlap_update_and_type(rvn_overlap* overlaps, uint64_t n, const uint32_t* pile_begin, const uint32_t* pile_end,
                                      const uint8_t* pile_invalid, uint32_t n_piles, uint8_t* ok, uint32_t* type);
+/* The host half of rvn_reads_load (io_text.h: gzip member cut, inflate pool, FASTA / FASTQ record scanner) without a
+ * device: fastq 0 / 1; threads 0 = default; force_streaming: one inflate thread front to back; slab_bytes 0 = default.
+ * Outputs malloc'ed (free with rvn_free): all bases back to back, all qualities (FASTQ), lengths[n_records], names
+ * separated by '\n'; info[8] = {gzip, streaming, members found, pool threads, 1 if a wrong cut made it start over,
+ * microseconds of the inflate + scan loop, of which inside the scanner, 0}. */
+int rvn_test_parse_file(const char* path, int fastq, uint32_t threads, int force_streaming, uint64_t slab_bytes,
+                        uint8_t** bases, uint8_t** quals, uint32_t** lengths, uint32_t* n_records, char** names,
+                        uint32_t* info);
 void rvn_test_std_sort_lendesc(uint64_t* data, uint64_t n);
 void rvn_test_heap_sort_lendesc(uint64_t* data, uint64_t n);
 

@@ -124,6 +124,8 @@ struct Engine {
   // second pass / identity filters (pass2.hip)
   DevBuf p2_slot, p2_pairs, p2_dist, p2_regions, p2_index_of, p2_kmers_off, p2_ok, p2_keep, p2_tmp_ovl;
   DevBuf poa_hist;  // layer-count histogram of a POA chunk (poa4.hip)
+  DevBuf io_text[2];  // input path: the file's text in HBM (io.hip)
+  std::vector<std::pair<std::unique_ptr<PinBuf>, bool>> io_pin;  // its page-locked slabs (buffer, handed out)
   DevBuf poa_sched, poa_redo_w, poa_redo_i;  // LPT order / escalation lists of a POA batch (poa_run_dev)
   // alignment-path stage of a polishing round (nwpath.hip): stored band words + scores, jobs, results
   DevBuf nw_hs, nw_ck, nw_hs2, nw_ck2, nw_hs3, nw_ck3, nw_strip, nw_jobs, nw_res;  // alignment paths: horizontal-delta streams, checkpoints, jobs, results
@@ -211,7 +213,9 @@ struct StageTimer {
 struct LoadStats {
   u64 n_sequences = 0, n_bases = 0;
   int has_quality = 0;
-  double parse_s = 0, device_s = 0, total_s = 0;  // producer thread wall | copy + packing on the device | whole call
+  double parse_s = 0, device_s = 0, total_s = 0;  // record scanner | copies + packing on the device (caller thread) | whole call
+  u32 inflate_threads = 0, members = 0;           // the inflate pool and what it found in the archive
+  int streaming = 0, restarted = 0;               // one stream front to back | a wrong member cut made the load start over
 };
 void reads_load(Engine& e, const std::string& path, ReadsDev& R, std::vector<std::string>& names, LoadStats& st);
 

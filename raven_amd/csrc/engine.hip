@@ -17,6 +17,9 @@
 #include "poa.h"
 #include "kmer.h"
 #include "lowcomplexity.h"
+#ifdef RVN_TEST_HOOKS
+#include "io_text.h"
+#endif
 
 using namespace rvn;
 
@@ -403,6 +406,10 @@ int rvn_reads_load(rvn_engine* h, const char* path, rvn_reads** out, rvn_load_st
       stats->parse_s = st.parse_s;
       stats->device_s = st.device_s;
       stats->total_s = st.total_s;
+      stats->inflate_threads = st.inflate_threads;
+      stats->members = st.members;
+      stats->streaming = st.streaming;
+      stats->restarted = st.restarted;
     }
     *out = rr.release();
     return RVN_OK;
@@ -1776,6 +1783,95 @@ int rvn_polish_fetch_layers(rvn_engine* h, uint32_t* out, uint64_t cap, uint64_t
 }
 
 #ifdef RVN_TEST_HOOKS
+// The host half of rvn_reads_load (io_text.h: member cut + inflate pool + record scanner) without a device: the kept
+// text is assembled in host memory exactly as the H2D copies would lay it out in HBM, then cut into the records' fields.
+// Outputs are malloc'ed (rvn_free): bases and qualities back to back, lengths, names separated by '\n';
+// info[8] = {gzip, streaming, members, threads, restarted, loop microseconds, scan microseconds, 0}.
+int rvn_test_parse_file(const char* path, int fastq, uint32_t threads, int force_streaming, uint64_t slab_bytes,
+                        uint8_t** bases, uint8_t** quals, uint32_t** lengths, uint32_t* n_records, char** names,
+                        uint32_t* info) {
+  return guarded([&]() -> int {
+    if (!path || !bases || !quals || !lengths || !n_records || !names) return fail(RVN_EINVAL, "[raven_hip] NULL argument");
+    for (int attempt = 0; attempt < 2; ++attempt) {
+      try {
+        io::SourceOptions opt;
+        opt.threads = threads;
+        opt.force_streaming = force_streaming != 0 || attempt == 1;
+        if (slab_bytes) opt.slab_bytes = slab_bytes;
+        io::TextSource src(path, opt);
+        io::RecordScanner sc(fastq != 0);
+        std::vector<u8> text;
+        std::vector<io::TextRecord> recs;
+        std::vector<std::string> nm;
+        u8* slab = nullptr;
+        u64 n = 0;
+        bool first = true;
+        const bool timing_only = std::getenv("RVN_TEST_IO_TIMING_ONLY") != nullptr;  // records then come back empty
+        const auto t_loop = std::chrono::steady_clock::now();
+        double scan_s = 0;
+        while (src.next(&slab, &n)) {
+          const u8* run = nullptr;
+          u64 run_len = 0, run_base = 0;
+          const auto t_scan = std::chrono::steady_clock::now();
+          sc.scan(slab, n, &run, &run_len, &run_base, recs, nm);
+          scan_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_scan).count();
+          if (!timing_only) {
+            if (text.size() < run_base + run_len) text.resize(run_base + run_len);
+            if (run_len) std::memcpy(text.data() + run_base, run, run_len);
+          }
+          if (!first) src.release();
+          first = false;
+        }
+        const double loop_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_loop).count();
+        u8 extra = 0;
+        const u64 at = sc.text_end();
+        if (sc.finish(recs, nm, &extra)) {
+          text.resize(std::max<u64>(text.size(), at + 1));
+          text[at] = extra;
+        }
+        u64 total = 0, nb = 0;
+        for (const io::TextRecord& r : recs) total += r.len;
+        for (const std::string& x : nm) nb += x.size() + 1;
+        u8* b = static_cast<u8*>(std::malloc(total + 1));
+        u8* q = static_cast<u8*>(std::malloc(total + 1));
+        uint32_t* l = static_cast<uint32_t*>(std::malloc((recs.size() + 1) * 4));
+        char* names_out = static_cast<char*>(std::malloc(nb + 1));
+        if (!b || !q || !l || !names_out) return fail(RVN_ENOMEM, "[raven_hip] out of memory");
+        u64 o = 0, no = 0;
+        if (timing_only) recs.clear();
+        for (size_t i = 0; i < recs.size(); ++i) {
+          std::memcpy(b + o, text.data() + recs[i].seq_off, recs[i].len);
+          if (fastq) std::memcpy(q + o, text.data() + recs[i].qual_off, recs[i].len);
+          l[i] = static_cast<uint32_t>(recs[i].len);
+          o += recs[i].len;
+          std::memcpy(names_out + no, nm[i].data(), nm[i].size());
+          no += nm[i].size();
+          names_out[no++] = '\n';
+        }
+        names_out[no] = 0;
+        *bases = b;
+        *quals = q;
+        *lengths = l;
+        *n_records = static_cast<uint32_t>(recs.size());
+        *names = names_out;
+        if (info) {
+          info[0] = src.gzip();
+          info[1] = src.streaming();
+          info[2] = src.members();
+          info[3] = src.threads();
+          info[4] = static_cast<uint32_t>(attempt);
+          info[5] = static_cast<uint32_t>(loop_s * 1e6);  // inflate + scan + assembling the kept text, microseconds
+          info[6] = static_cast<uint32_t>(scan_s * 1e6);  // of which inside RecordScanner::scan
+        }
+        return RVN_OK;
+      } catch (const io::SpeculationFailed&) {
+        if (attempt == 1) return fail(RVN_EINVAL, "[bioparser] error: corrupt or truncated file");
+      }
+    }
+    return RVN_OK;
+  });
+}
+
 int rvn_test_nw_breakpoints(const uint64_t* t_words, uint32_t t_len, const uint64_t* r_words, uint32_t r_len,
                             uint32_t t_begin, uint32_t n, uint32_t q_begin, uint32_t m, int rc, uint32_t w, uint32_t k,
                             int force_r, uint32_t* recs, uint32_t* distance, uint32_t* band) {

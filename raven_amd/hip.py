@@ -59,6 +59,7 @@ SYMBOLS = [
 TEST_SYMBOLS = [
     "rvn_poa_banded_emulate", "rvn_test_low_complexity", "rvn_test_nw_breakpoints", "rvn_test_hash",
     "rvn_test_canonical", "rvn_test_std_sort_lendesc", "rvn_test_heap_sort_lendesc", "rvn_test_overlap_update_and_type", "rvn_test_find_chimeric_regions",
+    "rvn_test_parse_file",
 ]
 
 
@@ -112,6 +113,8 @@ def test_lib():
     L.rvn_test_canonical.argtypes = [vp, u32, u32, i32, C.POINTER(u64), C.POINTER(u32)]
     L.rvn_test_std_sort_lendesc.argtypes = [vp, u64]
     L.rvn_test_heap_sort_lendesc.argtypes = [vp, u64]
+    pp = C.POINTER(C.c_void_p)
+    L.rvn_test_parse_file.argtypes = [C.c_char_p, i32, u32, i32, u64, pp, pp, pp, C.POINTER(u32), pp, vp]
     _test_lib = L
     return L
 
@@ -465,10 +468,10 @@ class Engine:
         return Reads(self, rs)
 
     def load(self, path) -> Reads:
-        """raven::CreateParser(path) + Parse(-1) straight into HBM (rvn_reads_load): gz FASTA / FASTQ parsed on a host
-        thread, packed on the device.  The returned handle's .rs holds lengths / ids / names and .load_stats."""
+        """raven::CreateParser(path) + Parse(-1) straight into HBM (rvn_reads_load): gzip members inflated by a pool of
+        host threads, records found by one memchr pass, text cut into packed reads on the device.  The returned handle's .rs holds lengths / ids / names and .load_stats."""
         h = C.c_void_p()
-        st = np.zeros(6, dtype=np.uint64)
+        st = np.zeros(8, dtype=np.uint64)
         _check(lib().rvn_reads_load(self._h, str(path).encode(), C.byref(h), _p(st)))
         n = C.c_uint32(0)
         lib().rvn_reads_info(h, C.byref(n), None, None, None, None)
@@ -480,7 +483,8 @@ class Engine:
         r.rs, r.engine, r._h = rs, self, h
         r.load_stats = {"n_sequences": int(st[0]), "n_bases": int(st[1]), "has_quality": int(st[2] & 0xFFFFFFFF),
                         "parse_s": float(st[3:4].view(np.float64)[0]), "device_s": float(st[4:5].view(np.float64)[0]),
-                        "total_s": float(st[5:6].view(np.float64)[0])}
+                        "total_s": float(st[5:6].view(np.float64)[0]), "inflate_threads": int(st[6] & 0xFFFFFFFF),
+                        "members": int(st[6] >> 32), "streaming": int(st[7] & 0xFFFFFFFF), "restarted": int(st[7] >> 32)}
         return r
 
     def upload_codes(self, code_arrays) -> Reads:
@@ -953,6 +957,33 @@ def test_overlap_update_and_type(overlaps, pile_begin, pile_end, pile_invalid):
     if rc != 0:
         raise ValueError("rvn_test_overlap_update_and_type")
     return o, ok, ty
+
+
+def test_parse_file(path, fastq, threads=0, force_streaming=False, slab_bytes=0):
+    """TEST INFRASTRUCTURE: the host half of rvn_reads_load (member cut, inflate pool, record scanner) without a device.
+    Returns (names, list of base strings, list of quality strings or None, info dict)."""
+    T = test_lib()
+    b, q, l, nm = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+    n = C.c_uint32(0)
+    info = np.zeros(8, dtype=np.uint32)
+    rc = T.rvn_test_parse_file(os.fsencode(path), int(fastq), threads, int(force_streaming), slab_bytes, C.byref(b),
+                               C.byref(q), C.byref(l), C.byref(n), C.byref(nm), _p(info))
+    if rc != RVN_OK:
+        raise (ValueError if rc == RVN_EINVAL else RavenHipError)(T.rvn_last_error().decode(errors="replace"))
+    try:
+        lens = np.ctypeslib.as_array(C.cast(l, C.POINTER(C.c_uint32)), shape=(max(n.value, 1),))[:n.value].copy()
+        total = int(lens.sum())
+        bases = C.string_at(b, total)
+        quals = C.string_at(q, total) if fastq else None
+        names = C.string_at(nm).decode().split("\n")[:-1] if n.value else []
+    finally:
+        for x in (b, q, l, nm):
+            T.rvn_free(x)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    seqs = [bases[off[i]:off[i + 1]] for i in range(n.value)]
+    qs = [quals[off[i]:off[i + 1]] for i in range(n.value)] if fastq else None
+    return names, seqs, qs, dict(gzip=int(info[0]), streaming=int(info[1]), members=int(info[2]), threads=int(info[3]),
+                                 restarted=int(info[4]), loop_s=info[5] / 1e6, scan_s=info[6] / 1e6)
 
 
 NW_REC_DTYPE = np.dtype([("first_t", "<u4"), ("first_q", "<u4"), ("last_t", "<u4"), ("last_q", "<u4"),

@@ -1,0 +1,233 @@
+"""The host half of the input path (raven_amd/csrc/io_text.h through rvn_test_parse_file of libraven_hip_test.so; no GPU):
+gzip member cut (BGZF / concatenated members / single member / plain), the inflate pool writing members straight into
+their place of the text, and the FASTA / FASTQ record scanner (multi-line fields, CRLF, blank lines, fields and line
+ends falling on slab boundaries) — against a line-by-line Python parser with bioparser's record rules
+(RavenLib/src/io.cc:7-41 -> bioparser::Parser::Parse)."""
+import gzip
+import os
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+from raven_amd import hip
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _py_parse(text: bytes, fastq: bool):
+    """bioparser's rules on the whole text: names (first word), sequences, qualities."""
+    lines = text.split(b"\n")
+    if lines and lines[-1] == b"":
+        lines.pop()
+    lines = [ln[:-1] if ln.endswith(b"\r") else ln for ln in lines]
+    names, seqs, quals = [], [], []
+    i = 0
+    while i < len(lines):
+        if not lines[i]:
+            i += 1
+            continue
+        h = lines[i]
+        i += 1
+        assert h[:1] == (b"@" if fastq else b">")
+        names.append(h[1:].split()[0].decode() if h[1:].split() else "")
+        s = b""
+        if not fastq:
+            while i < len(lines) and lines[i][:1] != b">":
+                s += lines[i]
+                i += 1
+            seqs.append(s)
+        else:
+            while i < len(lines) and lines[i][:1] != b"+":
+                s += lines[i]
+                i += 1
+            assert i < len(lines)
+            i += 1
+            q = b""
+            while len(q) < len(s) and i < len(lines):
+                q += lines[i]
+                i += 1
+            assert len(q) == len(s)
+            seqs.append(s)
+            quals.append(q)
+    return names, seqs, (quals if fastq else None)
+
+
+def _bgzf(data: bytes, block=65280, level=1) -> bytes:
+    """BGZF (the SAM specification's blocked gzip: 'BC' extra subfield = block size - 1) + its empty EOF block."""
+    out = []
+    for a in list(range(0, len(data), block)) + [None]:
+        chunk = b"" if a is None else data[a:a + block]
+        co = zlib.compressobj(level, zlib.DEFLATED, -15)
+        body = co.compress(chunk) + co.flush()
+        bsize = 12 + 6 + len(body) + 8
+        out.append(b"\x1f\x8b\x08\x04" + b"\0\0\0\0" + b"\x00\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, bsize - 1)
+                   + body + struct.pack("<II", zlib.crc32(chunk), len(chunk)))
+    return b"".join(out)
+
+
+def _members(data: bytes, piece: int) -> bytes:
+    return b"".join(gzip.compress(data[a:a + piece], 1) for a in range(0, max(len(data), 1), piece))
+
+
+def _fastq_text(rng, n, lo, hi, wrap=0, crlf=False, blank=False):
+    nl = b"\r\n" if crlf else b"\n"
+    out = []
+    for i in range(n):
+        ln = int(rng.integers(lo, hi))
+        s = bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), ln))
+        q = bytes(rng.integers(33, 90, ln).astype(np.uint8))
+        if wrap:
+            sw = nl.join(s[a:a + wrap] for a in range(0, max(ln, 1), wrap))
+            qw = nl.join(q[a:a + wrap] for a in range(0, max(ln, 1), wrap))
+        else:
+            sw, qw = s, q
+        out.append(b"@read%d some comment" % i + nl + sw + nl + b"+" + nl + qw + nl + (nl if blank and i % 3 == 0 else b""))
+    return b"".join(out)
+
+
+def _check(path, text, fastq, **kw):
+    names, seqs, quals, info = hip.test_parse_file(path, fastq, **kw)
+    en, es, eq = _py_parse(text, fastq)
+    assert names == en
+    assert seqs == es
+    if fastq:
+        assert quals == eq
+    return info
+
+
+@pytest.mark.parametrize("slab", [0, 1 << 20])
+def test_bgzf_fastq_goes_through_the_pool(tmp_path, slab):
+    rng = np.random.default_rng(5)
+    text = _fastq_text(rng, 400, 2000, 30000)
+    p = str(tmp_path / "r.fastq.gz")
+    open(p, "wb").write(_bgzf(text))
+    info = _check(p, text, True, threads=4, slab_bytes=slab)
+    assert info["gzip"] == 1 and info["streaming"] == 0 and info["restarted"] == 0
+    assert info["members"] == (len(text) + 65279) // 65280 + 1 and info["threads"] == 4
+
+
+def test_concatenated_members_are_cut_at_their_headers(tmp_path):
+    rng = np.random.default_rng(6)
+    text = _fastq_text(rng, 300, 500, 20000)
+    p = str(tmp_path / "r.fq.gz")
+    open(p, "wb").write(_members(text, 700_001))
+    info = _check(p, text, True, threads=3, slab_bytes=1 << 20)
+    assert info["streaming"] == 0 and info["members"] == (len(text) + 700_000) // 700_001 and info["restarted"] == 0
+
+
+def test_single_member_streams_front_to_back(tmp_path):
+    rng = np.random.default_rng(7)
+    text = _fastq_text(rng, 200, 500, 20000)
+    p = str(tmp_path / "r.fastq.gz")
+    open(p, "wb").write(gzip.compress(text, 1))
+    info = _check(p, text, True, slab_bytes=1 << 20)
+    assert info["streaming"] == 1 and info["threads"] == 1
+    # and the same text from a plain file: the pool copies ranges
+    p2 = str(tmp_path / "r.fastq")
+    open(p2, "wb").write(text)
+    info = _check(p2, text, True, threads=3, slab_bytes=1 << 20)
+    assert info["gzip"] == 0 and info["streaming"] == 0
+
+
+def test_wrong_cut_starts_over_in_streaming_mode(tmp_path):
+    """A gzip header look-alike inside a member's data is a wrong cut: the load goes front to back instead and still
+    returns the right records (never a silently different text)."""
+    rng = np.random.default_rng(8)
+    text = _fastq_text(rng, 50, 500, 5000)
+    fake = b"\x1f\x8b\x08\x00\0\0\0\0\x00\x03" + b"\0" * 16
+    # stored (uncompressed) deflate blocks keep the look-alike visible in the archive
+    co = zlib.compressobj(0, zlib.DEFLATED, 31)
+    m1 = co.compress(b"@r0 " + fake + b"\nACGT\n+\nIIII\n") + co.flush()
+    p = str(tmp_path / "r.fastq.gz")
+    open(p, "wb").write(m1 + gzip.compress(text, 1))
+    names, seqs, quals, info = hip.test_parse_file(p, True, threads=2)
+    # either the cut is thrown out at once (the look-alike's "trailer" is no ISIZE) or a member fails to verify
+    assert info["streaming"] == 1
+    en, es, eq = _py_parse(b"@r0 " + fake + b"\nACGT\n+\nIIII\n" + text, True)
+    assert seqs == es and quals == eq and len(names) == len(en)
+
+
+@pytest.mark.parametrize("crlf", [False, True])
+@pytest.mark.parametrize("fastq", [False, True])
+def test_wrapped_fields_crlf_and_blank_lines_at_every_slab_phase(tmp_path, fastq, crlf):
+    """Multi-line sequences / qualities are closed up into one run; with 1 MiB slabs and records of every length the
+    line ends, '\\r' and field starts fall on slab boundaries in all combinations over the shifted copies below."""
+    rng = np.random.default_rng(9 + fastq + 2 * crlf)
+    nl = b"\r\n" if crlf else b"\n"
+    if fastq:
+        body = _fastq_text(rng, 260, 0, 9000, wrap=61, crlf=crlf, blank=True)
+    else:
+        recs = []
+        for i in range(200):
+            ln = int(rng.integers(0, 40000))
+            s = bytes(rng.choice(np.frombuffer(b"ACGTN", dtype=np.uint8), ln))
+            recs.append(b">ctg%d len=%d" % (i, ln) + nl + nl.join(s[a:a + 70] for a in range(0, max(ln, 1), 70)) + nl)
+        body = b"".join(recs)
+    ext = "fastq" if fastq else "fasta"
+    for shift in range(0, 5):
+        # a first record whose length moves every later byte by one
+        lead = (b"@s\n" + b"A" * shift + b"\n+\n" + b"I" * shift + b"\n") if fastq else (b">s\n" + b"A" * shift + b"\n")
+        text = lead + body
+        p = str(tmp_path / ("w%d.%s" % (shift, ext)))
+        open(p, "wb").write(text)
+        _check(p, text, fastq, threads=2, slab_bytes=1 << 20)
+        if shift == 0:  # slabs of a prime number of bytes: several thousand boundaries, every phase of line and field
+            _check(p, text, fastq, threads=3, slab_bytes=1031)
+            _check(p, text, fastq, threads=1, slab_bytes=257)
+    p = str(tmp_path / ("w.%s.gz" % ext))
+    open(p, "wb").write(_bgzf(body))
+    _check(p, body, fastq, threads=3, slab_bytes=1 << 20)
+
+
+def test_file_without_final_newline_and_lone_cr(tmp_path):
+    p = str(tmp_path / "a.fasta")
+    text = b">a x\nACGT\nAC\n>b\nGG"
+    open(p, "wb").write(text)
+    _check(p, text, False)
+    p = str(tmp_path / "a.fastq")
+    text = b"@a\nACGT\n+\nIIII\n@b\nAC\n+anything\nII"
+    open(p, "wb").write(text)
+    _check(p, text, True)
+    # empty file, header only
+    p = str(tmp_path / "e.fasta")
+    open(p, "wb").write(b"")
+    assert hip.test_parse_file(p, False)[0] == []
+    open(p, "wb").write(b">only")
+    names, seqs, _, _ = hip.test_parse_file(p, False)
+    assert names == ["only"] and seqs == [b""]
+
+
+def test_malformed_records_and_damaged_archives_are_errors(tmp_path):
+    def bad(name, blob, fastq):
+        p = str(tmp_path / name)
+        open(p, "wb").write(blob)
+        with pytest.raises(ValueError):
+            hip.test_parse_file(p, fastq, threads=2)
+
+    bad("a.fastq", b"@a\nACGT\n+\nIII\n", True)            # quality shorter than the sequence
+    bad("b.fastq", b"@a\nACGT\n+\nIIIII\n", True)          # longer
+    bad("c.fastq", b"@a\nACGT\n", True)                    # no '+' line
+    bad("d.fastq", b"ACGT\n", True)                        # no header
+    bad("e.fasta", b"ACGT\n>a\nAC\n", False)
+    rng = np.random.default_rng(10)
+    text = _fastq_text(rng, 100, 1000, 8000)
+    whole = _bgzf(text)
+    bad("cut.fastq.gz", whole[:len(whole) * 2 // 3], True)  # truncated inside a block
+    dmg = bytearray(whole)
+    dmg[len(dmg) // 2] ^= 0x55
+    bad("dmg.fastq.gz", bytes(dmg), True)
+    one = gzip.compress(text, 1)
+    bad("cut1.fastq.gz", one[:len(one) // 2], True)
+
+
+def test_golden_lambda_files(tmp_path):
+    for name, fastq in (("ERA476754.fastq.gz", True), ("NC_001416.fasta.gz", False)):
+        path = os.path.join(GOLDEN, name)
+        text = gzip.open(path, "rb").read()
+        _check(path, text, fastq)
+        p = str(tmp_path / ("bgzf_" + name))
+        open(p, "wb").write(_bgzf(text))
+        info = _check(p, text, fastq, threads=4, slab_bytes=1 << 20)
+        assert info["streaming"] == 0
