@@ -83,3 +83,18 @@ def pack_reads(code_arrays, ids=None, names=None, qualities=None) -> ReadSet:
     if ids is None:
         ids = np.arange(len(code_arrays), dtype=np.uint32)
     return ReadSet(packed, word_offsets, lengths, np.asarray(ids, dtype=np.uint32), names, qualities)
+
+
+def bgzf_compress(data: bytes, level: int = 1, block: int = 65280) -> bytes:
+    """Blocked gzip as bgzip writes it (SAM specification 4.1: every member carries its own size in a 'BC' extra
+    subfield, an empty member ends the file): the multi-member form rvn_reads_load inflates with a pool of threads."""
+    import struct
+    import zlib
+    out = []
+    for a in list(range(0, len(data), block)) + [None]:
+        chunk = b"" if a is None else data[a:a + block]
+        co = zlib.compressobj(level, zlib.DEFLATED, -15)
+        body = co.compress(chunk) + co.flush()
+        out.append(b"\x1f\x8b\x08\x04\0\0\0\0\x00\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, len(body) + 25)
+                   + body + struct.pack("<II", zlib.crc32(chunk), len(chunk)))
+    return b"".join(out)
