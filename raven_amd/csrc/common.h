@@ -59,8 +59,13 @@ struct DevBuf {
     ptr = nullptr;
     cap = 0;
     size_t want = bytes + bytes / 8 + 256;
+    static const bool trace = std::getenv("RVN_DEBUG_MEM") != nullptr;  // allocator traffic of the grow-only buffers
+    const auto t0 = std::chrono::steady_clock::now();
     RVN_HIP(hipMalloc(&ptr, want));
     cap = want;
+    if (trace && want >= (256ULL << 20))
+      std::fprintf(stderr, "[raven_hip] DevBuf grows to %.2f GB (%.1f ms)\n", want / 1e9,
+                   std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
   }
   template <typename T>
   T* as() const {

@@ -609,7 +609,43 @@ __device__ void chain_wave(const u64* __restrict__ p, u32 n, bool strand, u64 g0
   for (u32 base = 0; base < n; base += 64) {
     const u64 mine = (base + lane < n) ? p[base + lane] : 0;
     const u32 cnt = min(64u, n - base);
-    for (u32 t = 0; t < cnt; ++t) {
+    // A colinear stretch is a run of elements that each EXTEND the longest chain: ram's search for such an element
+    // answers "precedes" at every probe, and both the probed lengths and the tails found there are then known in
+    // advance for the whole run (element t of the run meets the chain at length longest + t: its probes see old tails
+    // and the run's own earlier elements).  So the run is tried as a whole: lanes t0 .. cnt-1 store their elements at
+    // the lengths they would get, every lane replays its own ~log2(longest) probes against that speculated tail array,
+    // and one ballot gives the first lane whose search would have turned: the elements before it are appended at once
+    // (exactly the state the one-by-one loop below would leave), that element goes through the general replay.  A run
+    // is tried at the start of a block and after every element that extended the chain.
+    bool try_run = true;
+    for (u32 t = 0; t < cnt;) {
+      if (try_run && cnt - t >= 2) {
+        const bool active = static_cast<u32>(lane) >= t && static_cast<u32>(lane) < cnt;
+        const u32 my_long = longest + (static_cast<u32>(lane) - t);  // the chain length this lane's element meets
+        const IdxT first_pred = longest ? tail_idx[longest] : static_cast<IdxT>(0);
+        if (active) tail_pos[my_long + 1] = mine;
+        chain_sync<GLOBAL>();
+        bool turned = false;
+        if (active) {
+          const u32 lhs = static_cast<u32>(mine >> 32), rhs = static_cast<u32>(mine);
+          for (u32 a = my_long; a >= 1 && !turned; a >>= 1) {
+            const u64 q = tail_pos[my_long + 1 - a + ((a - 1) >> 1)];
+            const u32 ql = static_cast<u32>(q >> 32), qr = static_cast<u32>(q);
+            turned = !(ql < lhs && (strand ? qr < rhs : qr > rhs));
+          }
+        }
+        const unsigned long long bad = __ballot(turned);
+        const u32 stop = bad ? static_cast<u32>(__builtin_ctzll(bad)) : cnt;  // first lane whose search turns
+        if (active && static_cast<u32>(lane) < stop) {
+          tail_idx[my_long + 1] = static_cast<IdxT>(base + lane);
+          pred[base + lane] = static_cast<u32>(lane) == t ? first_pred : static_cast<IdxT>(base + lane - 1);
+        }
+        chain_sync<GLOBAL>();
+        longest += stop - t;
+        t = stop;
+        try_run = false;
+        if (t >= cnt) break;
+      }
       const u64 cur = __shfl(mine, static_cast<int>(t), 64);
       const u32 lhs = static_cast<u32>(cur >> 32), rhs = static_cast<u32>(cur);
       u32 lo = 1, hi = longest;
@@ -710,7 +746,9 @@ __device__ void chain_wave(const u64* __restrict__ p, u32 n, bool strand, u64 g0
         tail_pos[lo] = cur;
       }
       chain_sync<GLOBAL>();
+      try_run = lo > longest;  // it extended the chain: the next ones may well do so too
       longest = longest > lo ? longest : lo;
+      ++t;
     }
   }
   if (longest < chain) return;
