@@ -556,9 +556,11 @@ __host__ __device__ inline void poa4_traceback(const Poa4Args A, Poa4LdsTb& S, u
   const u32 max_steps = A.nmax + A.lmax + 2;
   // the next round (descriptors and codes in flight), the round after (descriptors in flight)
   u32 nd0[kTbG] = {}, nd1[kTbG] = {}, nd7[kTbG] = {}, fd0[kTbG] = {}, fd1[kTbG] = {}, fd7[kTbG] = {};
-  uint4 na[kTbG] = {}, nb[kTbG] = {}, nc[kTbG] = {};
+  // (native vectors, not HIP's uint4 class: arrays of the latter stay in scratch memory when passed by reference)
+  typedef u32 v4u __attribute__((ext_vector_type(4)));
+  v4u na[kTbG] = {}, nb[kTbG] = {}, nc[kTbG] = {};
   u32 c_rnd = 0xFFFFFFFFu, n_rnd = 0xFFFFFFFFu, f_rnd = 0xFFFFFFFFu;  // rounds LDS / the two register sets hold
-  auto load_desc = [&](u32 rnd, u32 (&d0)[kTbG], u32 (&d1)[kTbG], u32 (&d7)[kTbG]) {
+  auto load_desc = [&](u32 rnd, u32 (&d0)[kTbG], u32 (&d1)[kTbG], u32 (&d7)[kTbG]) __attribute__((always_inline)) {
 #pragma unroll
     for (int h = 0; h < kTbG; ++h) {
       const size_t rho = (static_cast<size_t>(rnd) * kTbG + h) * 16 + static_cast<size_t>(gl);
@@ -568,12 +570,12 @@ __host__ __device__ inline void poa4_traceback(const Poa4Args A, Poa4LdsTb& S, u
       d7[h] = dsc[2 * rho + 1].w;
     }
   };
-  auto load_codes = [&](const u32 (&d0)[kTbG], uint4 (&a)[kTbG], uint4 (&b)[kTbG], uint4 (&c)[kTbG]) {
+  auto load_codes = [&](const u32 (&d0)[kTbG], v4u (&a)[kTbG], v4u (&b)[kTbG], v4u (&c)[kTbG]) __attribute__((always_inline)) {
 #pragma unroll
     for (int h = 0; h < kTbG; ++h) {
       const u32 s = d0[h] & 0xFFFFu;
       const size_t tb = s == kInactiveS ? 0u : s / K::kU;
-      const uint4* src = bps + tb * 16 + static_cast<size_t>(gl);
+      const v4u* src = reinterpret_cast<const v4u*>(bps + tb * 16 + static_cast<size_t>(gl));
       a[h] = src[0];
       b[h] = src[16];
       c[h] = src[32];
@@ -596,9 +598,9 @@ __host__ __device__ inline void poa4_traceback(const Poa4Args A, Poa4LdsTb& S, u
 #pragma unroll
         for (int h = 0; h < kTbG; ++h) {
           uint4* dst = S.row[q][16 * h + gl];
-          dst[0] = na[h];
-          dst[1] = nb[h];
-          dst[2] = nc[h];
+          dst[0] = uint4{na[h].x, na[h].y, na[h].z, na[h].w};
+          dst[1] = uint4{nb[h].x, nb[h].y, nb[h].z, nb[h].w};
+          dst[2] = uint4{nc[h].x, nc[h].y, nc[h].z, nc[h].w};
           dst[3] = uint4{nd0[h], nd1[h], nd7[h], 0u};
         }
         c_rnd = rnd;
