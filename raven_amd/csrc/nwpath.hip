@@ -19,6 +19,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <exception>
 #include <vector>
 
 #include "engine.h"
@@ -215,6 +216,17 @@ void nw_breakpoints(Engine& e, const ReadsDev& T, const ReadsDev& Rd, std::vecto
     for (hipStream_t& st2 : e.nw_streams) RVN_HIP(hipStreamCreateWithFlags(&st2, hipStreamNonBlocking));
     for (hipEvent_t& ev : e.nw_ev) RVN_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
   }
+  // an error in the middle of a pass (a walk that left its band, an allocation that failed) must not leave walks running
+  // on the side streams against buffers the next call hands out again
+  struct WalkGuard {
+    Engine& e;
+    ~WalkGuard() {
+      if (!std::uncaught_exceptions()) return;
+      for (hipStream_t st2 : e.nw_streams)
+        if (st2) (void)hipStreamSynchronize(st2);
+      (void)hipStreamSynchronize(e.stream);
+    }
+  } walk_guard{e};
   double rate = e.nw_rate > 0 ? e.nw_rate : 0.13;  // first call: ONT-like; too small only costs a repeat
   if (const char* ev = std::getenv("RVN_NW_RATE")) rate = std::atof(ev);  // tests: force repeats
 
@@ -301,7 +313,6 @@ void nw_breakpoints(Engine& e, const ReadsDev& T, const ReadsDev& Rd, std::vecto
       }
       // chunks of the order whose hs + ck fit half the budget (a job larger than that goes alone)
       std::vector<Chunk> chunks;
-      u64 max_hs = 0, max_ck = 0;
       for (size_t c0 = 0; c0 < order.size();) {
         Chunk C{};
         C.c0 = c0;
@@ -331,8 +342,6 @@ void nw_breakpoints(Engine& e, const ReadsDev& T, const ReadsDev& Rd, std::vecto
         }
         C.coff[kLevels] = run_off;  // count of class x = offset of class x - 1 (or the chunk's end) - its own offset
         C.c1 = c1;
-        max_hs = std::max(max_hs, C.hs_w);
-        max_ck = std::max(max_ck, C.ck_e);
         st.store_bytes = std::max<u64>(st.store_bytes, C.hs_w * 4 + C.ck_e * 16);
         chunks.push_back(C);
         c0 = c1;
@@ -341,8 +350,14 @@ void nw_breakpoints(Engine& e, const ReadsDev& T, const ReadsDev& Rd, std::vecto
       DevBuf* ck_buf[3] = {&e.nw_ck, &e.nw_ck2, &e.nw_ck3};
       const int n_sets = static_cast<int>(std::min<size_t>(chunks.size(), 3));
       for (int b = 0; b < n_sets; ++b) {
-        (void)hs_buf[b]->get<u32>(max_hs + 4 * 64 * 8 + 16);  // + slack: the walk reads up to two words past a job's last one
-        (void)ck_buf[b]->get<NwPm>(max_ck + 16);
+        // set b serves chunks b, b + 3, ...: sized for those (a lone job beyond its share enlarges one set, not three)
+        u64 set_hs = 0, set_ck = 0;
+        for (size_t ci = static_cast<size_t>(b); ci < chunks.size(); ci += 3) {
+          set_hs = std::max(set_hs, chunks[ci].hs_w);
+          set_ck = std::max(set_ck, chunks[ci].ck_e);
+        }
+        (void)hs_buf[b]->get<u32>(set_hs + 4 * 64 * 8 + 16);  // + slack: the walk reads up to two words past a job's last one
+        (void)ck_buf[b]->get<NwPm>(set_ck + 16);
       }
       u64* d_strip = nullptr;
       if (!trace_lds) {
