@@ -511,6 +511,8 @@ def main():
                             "gcups_algorithmic": round(cells_per_launch / avg_s / 1e9, 1),
                             "gcups_banded_computed": round(poa_cells["cells_banded"] / max(poa_cells["calls"], 1) /
                                                            launches_per_round / avg_s / 1e9, 1),
+                            "frac_on_computed_cells": round(poa_cells["cells_banded"] / max(poa_cells["calls"], 1) *
+                                                            POA_MIN_OPS_PER_CELL / avg_s / VALU_PEAK_LANE_OPS, 4),
                             "avg_launch_ms": round(avg_s * 1e3, 3),
                             "kernel_launches_per_round": kms["poa_banded"][1] / max(poa_cells["calls"], 1),
                             "stage_share_of_step": round(legs["poa_ms"] / (dt * 1e3), 3),

@@ -352,9 +352,11 @@ def antiqsort(n: int) -> np.ndarray:
     return out
 
 
-def poa_window(layers, begins=None, ends=None, quals=None, m=3, n=-5, g=-4, trim=True):
+def poa_window(layers, begins=None, ends=None, quals=None, m=3, n=-5, g=-4, trim=True, device_order=False):
     """racon Window::GenerateConsensus: layers = list of uint8 code arrays (layers[0] = backbone), begins/ends =
     backbone positions of each layer (ignored for the backbone), quals = list of uint8 Phred+33 arrays or None.
+    device_order: the rows of the graph in the device kernels' incremental order instead of spoa's DFS rank (another
+    valid topological order: only ties between equal scores can come out differently).
     Returns (consensus codes, polished flag)."""
     k = len(layers)
     off = np.zeros(k + 1, dtype=np.uint64)
@@ -369,7 +371,7 @@ def poa_window(layers, begins=None, ends=None, quals=None, m=3, n=-5, g=-4, trim
     cap = int(off[-1]) + 16
     out = np.zeros(cap, dtype=np.uint8)
     n_out = C.c_uint32(0)
-    polished = lib().orc_poa_window(_p(codes), _p(q), _p(off), _p(b), _p(e), k, m, n, g, int(trim), _p(out), cap,
+    polished = lib().orc_poa_window(_p(codes), _p(q), _p(off), _p(b), _p(e), k, m, n, g, int(trim) | (2 if device_order else 0), _p(out), cap,
                                     C.byref(n_out))
     if polished < 0:
         raise ValueError("[racon::Window::AddLayer] error: layer begin and end positions are invalid!")

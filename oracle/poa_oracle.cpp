@@ -186,7 +186,10 @@ struct Graph {
     }
   }
   // spoa Graph::Subgraph(begin, end, &mapping): ancestors of node `end` with id >= begin
-  Graph Subgraph(std::uint32_t begin, std::uint32_t end, std::vector<std::uint32_t>* sub_to_graph) const {
+  // parent_rank != nullptr: the subgraph's rows keep the parent's order (what the device does: it marks the members and
+  // walks the parent's ranks) instead of spoa's own topological sort of the copy.
+  Graph Subgraph(std::uint32_t begin, std::uint32_t end, std::vector<std::uint32_t>* sub_to_graph,
+                 const std::vector<std::uint32_t>* parent_rank = nullptr) const {
     std::vector<bool> in(nodes.size(), false);
     std::stack<std::uint32_t> stack;
     stack.push(end);
@@ -215,6 +218,11 @@ struct Graph {
         if (g2s[kt] >= 0) sub.nodes[g2s[it]].aligned.push_back(g2s[kt]);
     }
     sub.TopologicalSort();
+    if (parent_rank) {
+      std::sort(sub.rank_to_node.begin(), sub.rank_to_node.end(), [&](std::uint32_t a, std::uint32_t b) {
+        return (*parent_rank)[(*sub_to_graph)[a]] < (*parent_rank)[(*sub_to_graph)[b]];
+      });
+    }
     return sub;
   }
   std::uint32_t Coverage(std::uint32_t id) const {
@@ -393,9 +401,54 @@ static std::vector<std::uint32_t> Weights(const Layer& l) {
   return w;
 }
 
+// The device kernels' incremental order rule (raven_amd/csrc/poa4.hip poa4_update_graph): after a
+// layer is added, old nodes keep their relative order and every new node takes the slot right behind the whole aligned
+// group (column) of the last DP node its path met.  rank_of: node id -> rank, updated in place; n_old = nodes before
+// the layer.  Returns false if the rule would break the topological order (never seen; orc_poa_order_check looks for it).
+static bool DeviceOrderUpdate(const Graph& graph, std::uint32_t n_old, std::vector<std::uint32_t>* rank_of_io) {
+  std::vector<std::uint32_t>& rank_of = *rank_of_io;
+  auto gmax = [&](std::uint32_t v) {
+    std::uint32_t r = rank_of[v];
+    for (auto a : graph.nodes[v].aligned) if (a < n_old) r = std::max(r, rank_of[a]);
+    return r;
+  };
+  auto gmin = [&](std::uint32_t v) {
+    std::uint32_t r = rank_of[v];
+    for (auto a : graph.nodes[v].aligned) if (a < n_old) r = std::min(r, rank_of[a]);
+    return r;
+  };
+  std::uint32_t cur_slot = n_old;
+  for (std::size_t q = 0; q < graph.path_nodes.size(); ++q)
+    if (graph.path_aligned[q] != -1) { cur_slot = gmin(graph.path_aligned[q]); break; }
+  std::vector<std::pair<std::uint32_t, std::uint32_t>> news;  // (slot, node id) in path order
+  for (std::size_t q = 0; q < graph.path_nodes.size(); ++q) {
+    const std::uint32_t curr = graph.path_nodes[q];
+    const std::int32_t an = graph.path_aligned[q];
+    if (an != -1) {
+      if (gmax(an) + 1 < cur_slot) return false;
+      cur_slot = gmax(an) + 1;
+    }
+    if (curr >= n_old) news.emplace_back(cur_slot, curr);
+  }
+  std::vector<std::uint32_t> nr(graph.nodes.size(), 0), slots;
+  for (auto& p : news) slots.push_back(p.first);
+  for (std::uint32_t v = 0; v < n_old; ++v)
+    nr[v] = rank_of[v] + static_cast<std::uint32_t>(std::upper_bound(slots.begin(), slots.end(), rank_of[v]) - slots.begin());
+  for (std::size_t t = 0; t < news.size(); ++t) nr[news[t].second] = news[t].first + t;
+  rank_of = nr;
+  for (const auto& e : graph.edges)
+    if (rank_of[e.tail] >= rank_of[e.head]) return false;
+  return true;
+}
+
 // racon Window::GenerateConsensus (TGS). layers[0] is the backbone. Returns polished flag.
+// device_order: spoa's DFS rank (Graph::TopologicalSort) is replaced by the device kernels' incremental order wherever
+// the order of the rows can decide a tie — the end node of an alignment, the node a traceback prefers among equal
+// scores, the start of the heaviest bundle.  Same graph rules, same scores, another valid topological order: it tells
+// whether a consensus that differs from spoa's differs because of such a tie and nothing else (tools/poa_parity.py).
 bool WindowConsensus(const std::vector<Layer>& layers, std::int8_t m, std::int8_t n, std::int8_t g, bool trim,
-                            std::vector<std::uint8_t>* consensus, std::vector<std::uint32_t>* coverages_out) {
+                            std::vector<std::uint8_t>* consensus, std::vector<std::uint32_t>* coverages_out,
+                            bool device_order) {
   const Layer& bb = layers.front();
   if (layers.size() < 3) {
     consensus->assign(bb.codes, bb.codes + bb.len);
@@ -403,6 +456,12 @@ bool WindowConsensus(const std::vector<Layer>& layers, std::int8_t m, std::int8_
   }
   Graph graph;
   graph.AddAlignment(Alignment(), bb.codes, bb.len, Weights(bb));
+  std::vector<std::uint32_t> node_rank(bb.len);  // device_order: node id -> rank by the device's rule
+  for (std::uint32_t i = 0; i < bb.len; ++i) node_rank[i] = i;
+  auto impose = [&]() {
+    if (!device_order) return;
+    for (std::uint32_t v = 0; v < graph.nodes.size(); ++v) graph.rank_to_node[node_rank[v]] = v;
+  };
   std::vector<std::uint32_t> rank(layers.size());
   for (std::uint32_t i = 0; i < layers.size(); ++i) rank[i] = i;
   std::stable_sort(rank.begin() + 1, rank.end(),
@@ -415,12 +474,20 @@ bool WindowConsensus(const std::vector<Layer>& layers, std::int8_t m, std::int8_
       alignment = AlignNW(l.codes, l.len, graph, m, n, g);
     } else {
       std::vector<std::uint32_t> mapping;
-      auto subgraph = graph.Subgraph(l.begin, l.end, &mapping);
+      auto subgraph = graph.Subgraph(l.begin, l.end, &mapping, device_order ? &node_rank : nullptr);
       alignment = AlignNW(l.codes, l.len, subgraph, m, n, g);
       for (auto& it : alignment)
         if (it.first != -1) it.first = mapping[it.first];
     }
+    const std::uint32_t n_old = graph.nodes.size();
     graph.AddAlignment(alignment, l.codes, l.len, Weights(l));
+    if (device_order) {
+      if (!DeviceOrderUpdate(graph, n_old, &node_rank)) {
+        consensus->clear();
+        return false;
+      }
+      impose();
+    }
   }
   graph.TraverseHeaviestBundle();
   std::vector<std::uint32_t> coverages;
@@ -469,7 +536,7 @@ int orc_poa_window(const std::uint8_t* codes, const std::uint8_t* quals, const s
   for (std::uint32_t i = 1; i < n_layers; ++i)
     if (layers[i].len && (begins[i] >= ends[i] || ends[i] >= layers[0].len)) return -1;
   std::vector<std::uint8_t> cons;
-  bool polished = poa::WindowConsensus(layers, m, n, g, trim != 0, &cons, nullptr);
+  bool polished = poa::WindowConsensus(layers, m, n, g, (trim & 1) != 0, &cons, nullptr, (trim & 2) != 0);
   *out_len = cons.size();
   std::memcpy(out, cons.data(), std::min<std::size_t>(cons.size(), out_cap));
   return polished ? 1 : 0;

@@ -10,5 +10,6 @@ struct Layer {
   std::uint32_t len, begin, end;
 };
 bool WindowConsensus(const std::vector<Layer>& layers, std::int8_t m, std::int8_t n, std::int8_t g, bool trim,
-                     std::vector<std::uint8_t>* consensus, std::vector<std::uint32_t>* coverages_out);
+                     std::vector<std::uint8_t>* consensus, std::vector<std::uint32_t>* coverages_out,
+                     bool device_order = false);
 }  // namespace poa

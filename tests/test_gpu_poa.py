@@ -212,8 +212,9 @@ def test_rows_on_lanes_kernel_equals_one_row_per_iteration_kernel():
 def test_consensus_parity_fraction_on_c4_like_windows():
     """How close 'within tolerance' is: 1500 windows shaped like a C4 polishing round's (500-base backbone, Poisson(31)
     layers with 10 % errors, a fifth of them partial) through the default chain (poa4 -> poa2 -> ...) and through the POA
-    oracle.  Measured on 4000 windows (tools/poa_parity.py, profiles/r04_poa_parity_4000.json): 99.8 % byte-identical, the
-    rest ONE edit apart (a base present or absent), neither side closer to the truth.  The test holds the stage to that:
+    oracle.  Measured on 20 000 windows (tools/poa_parity.py, profiles/r04_poa_parity_20000.json): 99.7 % byte-identical, the
+    rest one edit apart (two in one window), and all but one of those the oracle reproduces once its rows run in the
+    device's order.  The test holds the stage to that:
     >= 99 % identical, no window further than 2 edits from the oracle's consensus."""
     import importlib.util
     spec = importlib.util.spec_from_file_location("poa_parity", os.path.join(ROOT, "tools", "poa_parity.py"))
@@ -222,4 +223,7 @@ def test_consensus_parity_fraction_on_c4_like_windows():
     r = mod.run(1500, threads=os.cpu_count(), mode=0, seed=4242)
     assert r["polished"] == 1500, r
     assert r["identical_fraction"] >= 0.99, r
-    assert all(x["ed_device_vs_oracle"] <= 2 for x in r["examples"]) and r["sum_ed_between"] <= 2 * r["different"], r
+    assert r["max_ed_between"] <= 2, r
+    # what differs, differs by a tie that the order of the graph's rows decides: the oracle with its rows in the device's
+    # order gives the device's consensus (20 000 windows: 52 of the 53 differing ones, profiles/r04_poa_parity_20000.json)
+    assert len(r["not_explained"]) <= max(1, r["different"] // 10), r
