@@ -119,6 +119,7 @@ void swap_bufs(DevBuf& a, DevBuf& b) {
 // range (construct.cc:62 always maps with minhash=true) is derived from the same raw sketch before the
 // index sort consumes it, so map_batch over that range does not sketch again.
 void do_minimize(Engine& e, const ReadsDev& r, u32 first, u32 last, bool minhash, bool prefetch_query = false) {
+  bool raw_handed_over = false;
   {
     StageTimer t(e, StageTimes::kSketch);
     e.query_ready = false;
@@ -149,6 +150,7 @@ void do_minimize(Engine& e, const ReadsDev& r, u32 first, u32 last, bool minhash
       is.last = last;
       is.count = e.raw_sketch.count;
       e.raw_sketch.count = 0;
+      raw_handed_over = true;
     } else if (prefetch_query) {
       const Sketch& qs = e.query_sketch;
       const size_t vb = e.val64 ? 8 : 4;
@@ -170,6 +172,13 @@ void do_minimize(Engine& e, const ReadsDev& r, u32 first, u32 last, bool minhash
   e.c_index_min += e.index_sketch.count;
   index_build(e, e.index_sketch, !(e.index.has_query_flags || e.index.all_query));
   e.c_index_keys += e.index.u;
+  // index_build adopted the sketch's buffers and left the ones it displaced in index_sketch: they go back to the raw
+  // sketch, so that TWO sets circulate (raw sketch <-> index side 0) and the second pass already finds its buffers —
+  // left alone, three sets rotate through the three owners and every one of them is grown once (0.5 s at C4).
+  if (raw_handed_over) {
+    if (e.raw_sketch.val.cap < e.index_sketch.val.cap) swap_bufs(e.raw_sketch.val, e.index_sketch.val);
+    if (e.raw_sketch.org.cap < e.index_sketch.org.cap) swap_bufs(e.raw_sketch.org, e.index_sketch.org);
+  }
 }
 
 }  // namespace
