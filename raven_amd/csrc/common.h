@@ -25,6 +25,11 @@ using i16 = std::int16_t;
 struct HipError : std::runtime_error {
   using std::runtime_error::runtime_error;
 };
+// hipMalloc failed with the block pool already empty: the stage entry points hand back every scratch buffer of the
+// engine and run the stage once more before they report it (engine.hip: guarded)
+struct DeviceOutOfMemory : HipError {
+  using HipError::HipError;
+};
 
 #define RVN_HIP(expr)                                                                            \
   do {                                                                                           \
@@ -37,6 +42,24 @@ struct HipError : std::runtime_error {
 
 #define RVN_LAUNCH_CHECK() RVN_HIP(hipGetLastError())
 
+// Device ARENA behind the grow-only buffers, switched on when a workload turns out not to fit the HBM with both of its
+// phases' scratch alive (the HiFi one: 1.1 matches per read base; engine_release_scratch_if_tight).  Such a workload hands
+// ~200 GB of scratch back and takes it again at every change of phase, and hipMalloc of FRESH memory runs at ~25 GB/s on
+// MI355X (17 GB: 0.64 s; a traced step spent 14 s in three such calls).  With the arena that traffic is a first-fit
+// search in a free list: one hipMalloc of (free memory - margin) when it starts, no driver call afterwards; a request
+// the arena cannot hold falls through to the driver, and if that is out of memory too the stage entry point releases
+// every scratch buffer and runs the stage once more (engine.hip: guarded).  Implemented in engine.hip.
+namespace devpool {
+bool active();                 // an arena exists on the current device
+bool start(size_t bytes);      // one hipMalloc; false if the driver refuses
+void* alloc(size_t bytes);     // nullptr: no arena, or no hole of that size
+bool give_back(void* p);       // false: p is not an arena block (the caller hipFree's it)
+size_t free_total();
+size_t free_largest();
+size_t size();
+void stop();                   // back to the driver — only if no block of it is in use
+}  // namespace devpool
+
 // Growable device buffer; capacity only grows, so steady-state iterations do
 // not touch the allocator.
 struct DevBuf {
@@ -45,27 +68,34 @@ struct DevBuf {
   DevBuf() = default;
   DevBuf(const DevBuf&) = delete;
   DevBuf& operator=(const DevBuf&) = delete;
-  ~DevBuf() {
-    if (ptr) (void)hipFree(ptr);
-  }
+  ~DevBuf() { release(); }
   void release() {
-    if (ptr) (void)hipFree(ptr);
+    if (ptr && !devpool::give_back(ptr)) (void)hipFree(ptr);
     ptr = nullptr;
     cap = 0;
   }
   void reserve(size_t bytes) {
     if (bytes <= cap) return;
-    if (ptr) RVN_HIP(hipFree(ptr));
-    ptr = nullptr;
-    cap = 0;
+    release();
     size_t want = bytes + bytes / 8 + 256;
     static const bool trace = std::getenv("RVN_DEBUG_MEM") != nullptr;  // allocator traffic of the grow-only buffers
     const auto t0 = std::chrono::steady_clock::now();
-    RVN_HIP(hipMalloc(&ptr, want));
+    const char* how = "arena";
+    void* p = devpool::alloc(want);
+    if (!p) {
+      how = "driver";
+      const hipError_t err = hipMalloc(&p, want);
+      if (err == hipErrorOutOfMemory) {
+        (void)hipGetLastError();
+        throw DeviceOutOfMemory("[raven_hip] HIP error: out of memory (device buffer of " + std::to_string(want >> 20) + " MB)");
+      }
+      RVN_HIP(err);
+    }
+    ptr = p;
     cap = want;
     if (trace && want >= (256ULL << 20))
-      std::fprintf(stderr, "[raven_hip] DevBuf grows to %.2f GB (%.1f ms)\n", want / 1e9,
-                   std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+      std::fprintf(stderr, "[raven_hip] DevBuf grows to %.2f GB (%.1f ms, %s)\n", want / 1e9,
+                   std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), how);
   }
   template <typename T>
   T* as() const {

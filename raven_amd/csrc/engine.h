@@ -125,6 +125,8 @@ struct Engine {
   DevBuf p2_slot, p2_pairs, p2_dist, p2_regions, p2_index_of, p2_kmers_off, p2_ok, p2_keep, p2_tmp_ovl;
   DevBuf poa_hist;  // layer-count histogram of a POA chunk (poa4.hip)
   DevBuf io_text[2];  // input path: the file's text in HBM (io.hip)
+  int stage_kind = 0;   // the stage entry point running (engine_release_scratch_if_tight)
+  u32 oom_mask = 0;     // kinds of stages that ran out of device memory once: they start from released scratch
   std::vector<std::pair<std::unique_ptr<PinBuf>, bool>> io_pin;  // its page-locked slabs (buffer, handed out)
   DevBuf poa_sched, poa_redo_w, poa_redo_i;  // LPT order / escalation lists of a POA batch (poa_run_dev)
   // alignment-path stage of a polishing round (nwpath.hip): stored band words + scores, jobs, results
@@ -181,7 +183,7 @@ struct Engine {
 // released state may be needed afterwards (every stage entry point rebuilds what it uses).
 void engine_release_scratch(Engine& e);
 // ... when less than a third of the device memory is free (called at stage entry points)
-void engine_release_scratch_if_tight(Engine& e);
+void engine_release_scratch_if_tight(Engine& e, int stage_kind);  // kind: 0 pass 1, 1 pass 2, 2 polishing round, 3 polishing map
 
 // Reads one 4- or 8-byte value from the device through pinned memory (stream-ordered, then synchronises).
 inline u64 read_back(Engine& e, const void* dptr, size_t bytes) {

@@ -3,8 +3,10 @@
 
 #include <chrono>
 #include <cstring>
+#include <map>
 #include <memory>
 #include <new>
+#include <unordered_map>
 
 #include "../../include/raven_hip.h"
 #ifdef RVN_TEST_HOOKS
@@ -82,10 +84,35 @@ int guarded(F f) {
 }
 
 // same, holding the engine's lock for the whole call (nullptr: the lambda reports the NULL handle itself)
+// same, holding the engine's lock for the whole call (nullptr: the lambda reports the NULL handle itself).  A stage
+// that runs out of DEVICE memory is run once more after every scratch buffer of the engine (the other phase's included)
+// and every parked block went back to the driver: the entry points are functions of their arguments, a stage that
+// failed half-way leaves nothing behind but scratch.
 template <typename F>
 int guarded(Engine* e, F f) {
   if (!e) return guarded(f);
   std::lock_guard<std::recursive_mutex> lk(e->mu);
+  try {
+    return f();
+  } catch (const DeviceOutOfMemory& ex) {
+    (void)hipGetLastError();
+    (void)hipDeviceSynchronize();
+    if (std::getenv("RVN_DEBUG_MEM")) std::fprintf(stderr, "[raven_hip] %s: all scratch back to the driver, stage repeated\n", ex.what());
+    e->oom_mask |= 1u << (e->stage_kind & 31);  // next time this kind of stage starts from released scratch
+    try {
+      rvn::engine_release_scratch(*e);
+    } catch (const std::exception& ex2) {
+      return fail(RVN_EHIP, ex2.what());
+    }
+  } catch (const HipError& ex) {
+    return fail(RVN_EHIP, ex.what());
+  } catch (const std::bad_alloc&) {
+    return fail(RVN_ENOMEM, "[raven_hip] out of host memory");
+  } catch (const std::invalid_argument& ex) {
+    return fail(RVN_EINVAL, ex.what());
+  } catch (const std::exception& ex) {
+    return fail(RVN_EHIP, ex.what());
+  }
   return guarded(f);
 }
 
@@ -184,6 +211,123 @@ void do_minimize(Engine& e, const ReadsDev& r, u32 first, u32 last, bool minhash
 }  // namespace
 
 namespace rvn {
+namespace devpool {
+namespace {
+struct Arena {
+  char* base = nullptr;
+  size_t size = 0;
+  std::map<size_t, size_t> holes;                 // offset -> length, coalesced
+  std::unordered_map<const void*, size_t> in_use;  // block -> length
+};
+constexpr int kMaxDevices = 16;
+constexpr size_t kGrain = 64 << 10;
+std::mutex g_mu;
+Arena g_arena[kMaxDevices];
+Arena* mine() {
+  int d = 0;
+  (void)hipGetDevice(&d);
+  return (d >= 0 && d < kMaxDevices) ? &g_arena[d] : nullptr;
+}
+}  // namespace
+bool active() {
+  std::lock_guard<std::mutex> lk(g_mu);
+  const Arena* a = mine();
+  return a && a->base;
+}
+bool start(size_t bytes) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  Arena* a = mine();
+  if (!a || a->base) return a && a->base;
+  bytes = bytes / kGrain * kGrain;
+  if (bytes < (1ULL << 30)) return false;
+  void* p = nullptr;
+  if (hipMalloc(&p, bytes) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  a->base = static_cast<char*>(p);
+  a->size = bytes;
+  a->holes.clear();
+  a->holes[0] = bytes;
+  a->in_use.clear();
+  return true;
+}
+void* alloc(size_t bytes) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  Arena* a = mine();
+  if (!a || !a->base) return nullptr;
+  bytes = (bytes + kGrain - 1) / kGrain * kGrain;
+  for (auto it = a->holes.begin(); it != a->holes.end(); ++it) {  // first fit, lowest address
+    if (it->second < bytes) continue;
+    const size_t off = it->first, len = it->second;
+    a->holes.erase(it);
+    if (len > bytes) a->holes[off + bytes] = len - bytes;
+    a->in_use[a->base + off] = bytes;
+    return a->base + off;
+  }
+  return nullptr;
+}
+bool give_back(void* p) {
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    const Arena* a = mine();
+    if (!a || !a->base || !a->in_use.count(p)) return false;
+  }
+  (void)hipDeviceSynchronize();  // what hipFree does implicitly: nobody still reads the block when the next owner writes
+  std::lock_guard<std::mutex> lk(g_mu);
+  Arena* a = mine();
+  auto it = a->in_use.find(p);
+  if (it == a->in_use.end()) return false;
+  size_t off = static_cast<size_t>(static_cast<char*>(p) - a->base), len = it->second;
+  a->in_use.erase(it);
+  auto next = a->holes.lower_bound(off);
+  if (next != a->holes.end() && off + len == next->first) {
+    len += next->second;
+    next = a->holes.erase(next);
+  }
+  if (next != a->holes.begin()) {
+    auto prev = std::prev(next);
+    if (prev->first + prev->second == off) {
+      off = prev->first;
+      len += prev->second;
+      a->holes.erase(prev);
+    }
+  }
+  a->holes[off] = len;
+  return true;
+}
+size_t free_total() {
+  std::lock_guard<std::mutex> lk(g_mu);
+  const Arena* a = mine();
+  size_t t = 0;
+  if (a && a->base)
+    for (const auto& h : a->holes) t += h.second;
+  return t;
+}
+size_t free_largest() {
+  std::lock_guard<std::mutex> lk(g_mu);
+  const Arena* a = mine();
+  size_t t = 0;
+  if (a && a->base)
+    for (const auto& h : a->holes) t = std::max(t, h.second);
+  return t;
+}
+size_t size() {
+  std::lock_guard<std::mutex> lk(g_mu);
+  const Arena* a = mine();
+  return a && a->base ? a->size : 0;
+}
+void stop() {
+  std::lock_guard<std::mutex> lk(g_mu);
+  Arena* a = mine();
+  if (!a || !a->base || !a->in_use.empty()) return;
+  (void)hipFree(a->base);
+  a->base = nullptr;
+  a->size = 0;
+  a->holes.clear();
+}
+}  // namespace devpool
+
 void engine_release_scratch(Engine& e) {
   if (e.stream) (void)rvn_stream_sync(e.stream);
   e.query_ready = false;
@@ -212,16 +356,44 @@ void engine_release_scratch(Engine& e) {
   delete e.pile_pool;
   e.pile_pool = nullptr;
 }
-void engine_release_scratch_if_tight(Engine& e) {
+void engine_release_scratch_if_tight(Engine& e, int stage_kind) {
+  e.stage_kind = stage_kind;
   size_t free_b = 0, total_b = 0;
   if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return;
+  const bool trace = std::getenv("RVN_DEBUG_MEM") != nullptr;
+  if (devpool::active()) {
+    // the arena is on (the workload did not fit once): a stage starts from an empty arena when less than a quarter of it
+    // is free, or when this kind of stage has run out of memory before with the other phase's scratch alive
+    const size_t afree = devpool::free_total(), asize = devpool::size();
+    const bool tight = afree * 4 < asize || ((e.oom_mask >> stage_kind) & 1u) || std::getenv("RVN_RELEASE_ALWAYS") != nullptr;
+    if (trace)
+      std::fprintf(stderr, "[raven_hip] stage entry (kind %d): arena %.1f GB free of %.1f GB, driver %.1f GB free%s\n", stage_kind,
+                   afree / 1e9, asize / 1e9, free_b / 1e9, tight ? " -> scratch released" : "");
+    if (tight) engine_release_scratch(e);
+    return;
+  }
   // (a quarter, not a third: a C4 step settles at ~220 GB of grow-only stage buffers on a 309 GB device — alignment
   // store, window-consensus chunk, sort scratch — and handing them back costs seconds of re-allocation in the next step)
-  const bool tight = free_b * 4 < total_b;
-  if (std::getenv("RVN_DEBUG_MEM"))
-    std::fprintf(stderr, "[raven_hip] stage entry: %.1f GB free of %.1f GB%s\n", free_b / 1e9, total_b / 1e9,
-                 tight ? " -> releasing scratch" : "");
-  if (tight) engine_release_scratch(e);
+  const bool tight = free_b * 4 < total_b || std::getenv("RVN_RELEASE_ALWAYS") != nullptr;  // (the latter: tests of this path)
+  if (trace)
+    std::fprintf(stderr, "[raven_hip] stage entry (kind %d): %.1f GB free of %.1f GB%s\n", stage_kind, free_b / 1e9, total_b / 1e9,
+                 tight ? " -> scratch released, arena started" : "");
+  if (!tight) return;
+  engine_release_scratch(e);
+  // From here on the scratch lives in one arena (common.h: devpool): everything that is free now except a margin for
+  // the driver's own needs, the buffers that stay outside (reads, pile handles in use) and other users of the device.
+  if (std::getenv("RVN_NO_ARENA")) return;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return;
+  size_t margin = std::max<size_t>(12ULL << 30, total_b / 16);
+  if (const char* ev = std::getenv("RVN_ARENA_MARGIN_MB")) margin = static_cast<size_t>(std::atoll(ev)) << 20;
+  if (const char* ev = std::getenv("RVN_ARENA_MB")) margin = free_b > (static_cast<size_t>(std::atoll(ev)) << 20) ? free_b - (static_cast<size_t>(std::atoll(ev)) << 20) : free_b;
+  if (free_b > margin + (1ULL << 30)) {
+    const auto t0 = std::chrono::steady_clock::now();
+    const bool ok = devpool::start(free_b - margin);
+    if (trace)
+      std::fprintf(stderr, "[raven_hip] arena of %.1f GB %s (%.0f ms)\n", (free_b - margin) / 1e9, ok ? "started" : "refused",
+                   std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+  }
 }
 void engine_minimize(Engine& e, const ReadsDev& r, u32 first, u32 last, bool minhash) {
   do_minimize(e, r, first, last, minhash);
@@ -295,6 +467,7 @@ void rvn_engine_destroy(rvn_engine* h) {
   delete h->e.pile_pool;
   h->e.pile_pool = nullptr;
   delete h;
+  devpool::stop();
 }
 
 int rvn_reads_upload(rvn_engine* h, const uint64_t* packed, uint64_t n_words, const uint64_t* word_offsets,
@@ -575,6 +748,7 @@ int rvn_engine_release_scratch(rvn_engine* h) {
     if (!h) return fail(RVN_EINVAL, "[raven_hip] NULL engine");
     RVN_HIP(hipSetDevice(h->e.device));
     engine_release_scratch(h->e);
+    devpool::stop();  // the caller asked for the memory itself (the arena goes if nothing of it is in use)
     return RVN_OK;
   });
 }
@@ -652,7 +826,7 @@ int rvn_find_overlaps_and_create_piles(rvn_engine* h, const rvn_reads* rr, doubl
     UseTimers ut(e);
     if (dbg) std::fprintf(stderr, "[raven_hip] pass1: %-12s %8.1f ms\n", "timers",
                           std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_last).count());
-    engine_release_scratch_if_tight(e);
+    engine_release_scratch_if_tight(e, 0);
     auto lap = [&](const char* what) {
       if (!dbg) return;
       (void)rvn_stream_sync(e.stream);
@@ -781,7 +955,7 @@ int rvn_find_overlaps_and_repetitive_regions(rvn_engine* h, const rvn_reads* rr,
       if (r.h_id[i] != i) return fail(RVN_EINVAL, "[raven_hip] FindOverlapsAndRepetetiveRegions requires ids[i] == i");
     RVN_HIP(hipSetDevice(e.device));
     UseTimers ut(e);
-    engine_release_scratch_if_tight(e);
+    engine_release_scratch_if_tight(e, 1);
     std::unique_ptr<rvn_pass2> p(new rvn_pass2());
     p->e = &e;
     p->engine_life = e.life;
@@ -915,7 +1089,7 @@ int rvn_polish_round_range(rvn_engine* h, rvn_reads* targets, rvn_reads* reads, 
     if (read_quals && !qual_offsets) return fail(RVN_EINVAL, "[raven_hip] qualities without offsets");
     RVN_HIP(hipSetDevice(h->e.device));
     UseTimers ut(h->e);
-    engine_release_scratch_if_tight(h->e);
+    engine_release_scratch_if_tight(h->e, 2);
     std::vector<std::vector<u8>> polished;
     std::vector<double> rt;
     PolishStats st;
@@ -1024,7 +1198,7 @@ int rvn_polish_map_best(rvn_engine* h, rvn_reads* targets, rvn_reads* reads, uin
     if (read_first > read_last || read_last > reads->r.n) return fail(RVN_EINVAL, "[raven_hip] rvn_polish_map_best: bad read range");
     RVN_HIP(hipSetDevice(h->e.device));
     UseTimers ut(h->e);
-    engine_release_scratch_if_tight(h->e);
+    engine_release_scratch_if_tight(h->e, 3);
     std::vector<Overlap> b;
     std::vector<u32> bt;
     u64 n = 0;

@@ -259,7 +259,7 @@ void nw_breakpoints(Engine& e, const ReadsDev& T, const ReadsDev& Rd, std::vecto
     size_t free_b = 0, total_b = 0;
     RVN_HIP(hipMemGetInfo(&free_b, &total_b));
     const u64 held = e.nw_hs.cap + e.nw_ck.cap + e.nw_hs2.cap + e.nw_ck2.cap + e.nw_hs3.cap + e.nw_ck3.cap;
-    budget = std::min<u64>(static_cast<u64>(free_b) / 4 + held, 64ULL << 30);
+    budget = std::min<u64>((static_cast<u64>(free_b) + devpool::free_total()) / 4 + held, 64ULL << 30);  // parked blocks count as free
     if (const char* ev = std::getenv("RVN_NW_BUDGET_MB")) budget = static_cast<u64>(std::atoll(ev)) << 20;
     budget = std::max<u64>(budget, 64ULL << 20);
   }

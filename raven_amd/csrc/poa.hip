@@ -600,7 +600,7 @@ void poa_v1_launch(Engine& e, const PoaBatchDev& b) {
   size_t free_b = 0, total_b = 0;
   RVN_HIP(hipMemGetInfo(&free_b, &total_b));
   u32 n_slots = std::min<u32>(b.n_windows, 256 * 8);
-  const size_t budget = e.poa_scratch.cap + free_b / 2;
+  const size_t budget = e.poa_scratch.cap + (free_b + devpool::free_total()) / 2;
   if (static_cast<size_t>(n_slots) * slot_bytes > budget) n_slots = static_cast<u32>(std::max<size_t>(1, budget / slot_bytes));
   n_slots = ((n_slots + 3) / 4) * 4;
   unsigned char* d_scratch = e.poa_scratch.get<unsigned char>(static_cast<size_t>(n_slots) * slot_bytes + 256);

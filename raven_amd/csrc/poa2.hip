@@ -869,7 +869,7 @@ void poa_v2_launch(Engine& e, const PoaBatchDev& b, int nch) {
   u32 per_cu = nch == 1 ? 4 * occ : 16;
   if (const char* ev = std::getenv("RVN_POA_WAVES_PER_CU")) per_cu = static_cast<u32>(std::atoi(ev));  // occupancy experiments
   u32 n_slots = std::min<u32>(b.n_windows, 256 * per_cu);
-  const size_t budget = e.poa2_scratch.cap + free_b / 2;
+  const size_t budget = e.poa2_scratch.cap + (free_b + devpool::free_total()) / 2;
   if (static_cast<size_t>(n_slots) * slot_bytes > budget) n_slots = static_cast<u32>(std::max<size_t>(1, budget / slot_bytes));
   n_slots = ((n_slots + 3) / 4) * 4;
   unsigned char* d_scratch = e.poa2_scratch.get<unsigned char>(static_cast<size_t>(n_slots) * slot_bytes + 256);

@@ -1845,7 +1845,9 @@ void poa_v4_launch(Engine& e, const PoaBatchDev& b) {
   // a chunk = the windows whose scratch fits the budget (their graphs stay resident from the first to the last round)
   // (at most 48 K windows = ~30 GB for racon's 500-base windows: enough waves to fill the chip three times over in every
   // launch, and the other stages of a polishing round keep their buffers)
-  const size_t budget = std::min<size_t>(e.poa2_scratch.cap + free_b / 2, static_cast<size_t>(49152) * (slot_bytes + sizeof(Poa4Win)));
+  // (a chunk handed back to the block pool at a stage entry is still there for the taking)
+  const size_t full_chunk = static_cast<size_t>(49152) * (slot_bytes + sizeof(Poa4Win));
+  const size_t budget = std::min<size_t>(std::max(e.poa2_scratch.cap, std::min(devpool::free_largest(), full_chunk + full_chunk / 4)) + free_b / 2, full_chunk);
   size_t per_chunk = std::max<size_t>(P4::G, budget / (slot_bytes + sizeof(Poa4Win)));
   if (const char* ev = std::getenv("RVN_POA4_CHUNK")) per_chunk = std::max<size_t>(P4::G, static_cast<size_t>(std::atoll(ev)));
   per_chunk = std::min<size_t>(per_chunk, b.n_windows);
