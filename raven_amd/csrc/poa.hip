@@ -692,7 +692,12 @@ void poa_run_dev(Engine& e, const PoaWindow* d_wins, const PoaLayer* d_lays, u32
     const char* ev = std::getenv("RVN_POA4");
     return !(ev && std::atoi(ev) == 0);
   }();
-  const bool v4 = mode == 9 || (mode == 0 && v4_default);
+  // A batch too small to fill the chip runs every layer round of poa4's phase kernels at its latency floor (~1.7 ms per
+  // round whatever the batch: 10 000 windows of a configs[2] round take 126 ms there, 65 ms in poa2's one persistent
+  // kernel; at 24 576 windows poa4 is ahead): below the threshold the default mode goes straight to poa2.
+  u32 v4_min_windows = 20000u;
+  if (const char* ev = std::getenv("RVN_POA4_MIN_WINDOWS")) v4_min_windows = static_cast<u32>(std::atoll(ev));  // (read per call: tests set it)
+  const bool v4 = mode == 9 || (mode == 0 && v4_default && n_windows >= v4_min_windows);
   if (mode == 1) poa_v1_launch(e, b);
   else if (v4) poa_v4_launch(e, b);
   else poa_v2_launch(e, b, mode == 3 ? 2 : (mode == 4 ? 4 : 1));

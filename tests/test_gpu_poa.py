@@ -199,7 +199,11 @@ def test_rows_on_lanes_kernel_equals_one_row_per_iteration_kernel():
             assert np.array_equal(a, b)
     assert both >= 340, both
     eng.poa_set_mode(0)
-    c0, s0, _ = eng.poa_consensus_batch(wins)
+    os.environ["RVN_POA4_MIN_WINDOWS"] = "0"  # (a batch this small would skip the rows-on-lanes kernel by default)
+    try:
+        c0, s0, _ = eng.poa_consensus_batch(wins)
+    finally:
+        del os.environ["RVN_POA4_MIN_WINDOWS"]
     assert np.array_equal(s0 & 0xFF, s2 & 0xFF)
     for a, b in zip(c0, c2):
         assert np.array_equal(a, b)
@@ -220,7 +224,11 @@ def test_consensus_parity_fraction_on_c4_like_windows():
     spec = importlib.util.spec_from_file_location("poa_parity", os.path.join(ROOT, "tools", "poa_parity.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    r = mod.run(1500, threads=os.cpu_count(), mode=0, seed=4242)
+    os.environ["RVN_POA4_MIN_WINDOWS"] = "0"  # the rows-on-lanes kernel first, as in a full-size round (small batches skip it)
+    try:
+        r = mod.run(1500, threads=os.cpu_count(), mode=0, seed=4242)
+    finally:
+        del os.environ["RVN_POA4_MIN_WINDOWS"]
     assert r["polished"] == 1500, r
     assert r["identical_fraction"] >= 0.99, r
     assert r["max_ed_between"] <= 2, r
