@@ -446,15 +446,13 @@ static bool DeviceOrderUpdate(const Graph& graph, std::uint32_t n_old, std::vect
 // the order of the rows can decide a tie — the end node of an alignment, the node a traceback prefers among equal
 // scores, the start of the heaviest bundle.  Same graph rules, same scores, another valid topological order: it tells
 // whether a consensus that differs from spoa's differs because of such a tie and nothing else (tools/poa_parity.py).
-bool WindowConsensus(const std::vector<Layer>& layers, std::int8_t m, std::int8_t n, std::int8_t g, bool trim,
-                            std::vector<std::uint8_t>* consensus, std::vector<std::uint32_t>* coverages_out,
-                            bool device_order) {
+// The graph of a window after all its layers (racon Window::GenerateConsensus up to the consensus call); false if the
+// device order rule broke down.
+bool BuildWindowGraph(const std::vector<Layer>& layers, std::int8_t m, std::int8_t n, std::int8_t g, bool device_order,
+                      Graph* out) {
   const Layer& bb = layers.front();
-  if (layers.size() < 3) {
-    consensus->assign(bb.codes, bb.codes + bb.len);
-    return false;
-  }
-  Graph graph;
+  Graph& graph = *out;
+  graph = Graph();
   graph.AddAlignment(Alignment(), bb.codes, bb.len, Weights(bb));
   std::vector<std::uint32_t> node_rank(bb.len);  // device_order: node id -> rank by the device's rule
   for (std::uint32_t i = 0; i < bb.len; ++i) node_rank[i] = i;
@@ -483,11 +481,26 @@ bool WindowConsensus(const std::vector<Layer>& layers, std::int8_t m, std::int8_
     graph.AddAlignment(alignment, l.codes, l.len, Weights(l));
     if (device_order) {
       if (!DeviceOrderUpdate(graph, n_old, &node_rank)) {
-        consensus->clear();
         return false;
       }
       impose();
     }
+  }
+  return true;
+}
+
+bool WindowConsensus(const std::vector<Layer>& layers, std::int8_t m, std::int8_t n, std::int8_t g, bool trim,
+                            std::vector<std::uint8_t>* consensus, std::vector<std::uint32_t>* coverages_out,
+                            bool device_order) {
+  const Layer& bb = layers.front();
+  if (layers.size() < 3) {
+    consensus->assign(bb.codes, bb.codes + bb.len);
+    return false;
+  }
+  Graph graph;
+  if (!BuildWindowGraph(layers, m, n, g, device_order, &graph)) {
+    consensus->clear();
+    return false;
   }
   graph.TraverseHeaviestBundle();
   std::vector<std::uint32_t> coverages;
@@ -704,6 +717,60 @@ int orc_poa_order_check(const std::uint8_t* codes, const std::uint64_t* offsets,
     }
   }
   return -1;
+}
+
+// DEBUG: the tail of a window's final graph (spoa order or device order): for the last `n_tail` ranks: node id, code,
+// out-degree, heaviest-path score and predecessor BEFORE branch completion, in-edges (tail:weight ...).  Text to stderr.
+int orc_poa_dump_tail(const std::uint8_t* codes, const std::uint64_t* offsets, const std::uint32_t* begins,
+                      const std::uint32_t* ends, std::uint32_t n_layers, int m, int n, int g, int device_order, int n_tail) {
+  std::vector<poa::Layer> layers(n_layers);
+  for (std::uint32_t i = 0; i < n_layers; ++i) {
+    layers[i].codes = codes + offsets[i];
+    layers[i].qual = nullptr;
+    layers[i].len = static_cast<std::uint32_t>(offsets[i + 1] - offsets[i]);
+    layers[i].begin = begins[i];
+    layers[i].end = ends[i];
+  }
+  poa::Graph graph;
+  poa::BuildWindowGraph(layers, m, n, g, device_order != 0, &graph);
+  const std::uint32_t N = graph.rank_to_node.size();
+  std::vector<std::int32_t> pred(graph.nodes.size(), -1);
+  std::vector<std::int64_t> sc(graph.nodes.size(), -1);
+  std::int32_t mx = -1;
+  for (auto it : graph.rank_to_node) {
+    for (auto e : graph.nodes[it].inedges) {
+      const auto& jt = graph.edges[e];
+      if (sc[it] < jt.weight || (sc[it] == jt.weight && sc[pred[it]] <= sc[jt.tail])) {
+        sc[it] = jt.weight;
+        pred[it] = jt.tail;
+      }
+    }
+    if (pred[it] != -1) sc[it] += sc[pred[it]];
+    if (mx == -1 || sc[mx] < sc[it]) mx = it;
+  }
+  if (const char* path = std::getenv("ORC_POA_DUMP_GRAPH")) {  // whole graph: "rank node code out_degree | tail:weight ..."
+    if (FILE* f = std::fopen(path, "w")) {
+      for (std::uint32_t r = 0; r < N; ++r) {
+        const auto v = graph.rank_to_node[r];
+        std::fprintf(f, "%u %u %u %zu |", r, v, graph.nodes[v].code & 3, graph.nodes[v].outedges.size());
+        for (auto e : graph.nodes[v].inedges) std::fprintf(f, " %u:%lld", graph.edges[e].tail, static_cast<long long>(graph.edges[e].weight));
+        std::fprintf(f, "\n");
+      }
+      std::fclose(f);
+    }
+  }
+  std::fprintf(stderr, "nodes %u edges %zu best node %d (score %lld, out-degree %zu)\n", N, graph.edges.size(), mx,
+               static_cast<long long>(sc[mx]), graph.nodes[mx].outedges.size());
+  for (std::uint32_t r = N > static_cast<std::uint32_t>(n_tail) ? N - n_tail : 0; r < N; ++r) {
+    const auto v = graph.rank_to_node[r];
+    std::fprintf(stderr, "rank %u node %u %c out %zu score %lld pred %d aligned[", r, v, "ACGT"[graph.nodes[v].code & 3],
+                 graph.nodes[v].outedges.size(), static_cast<long long>(sc[v]), pred[v]);
+    for (auto a : graph.nodes[v].aligned) std::fprintf(stderr, " %u", a);
+    std::fprintf(stderr, " ] in:");
+    for (auto e : graph.nodes[v].inedges) std::fprintf(stderr, " %u:%lld", graph.edges[e].tail, static_cast<long long>(graph.edges[e].weight));
+    std::fprintf(stderr, "\n");
+  }
+  return 0;
 }
 
 // NW score of a sequence against the LINEAR graph of another sequence (unit-test hook for AlignNW).

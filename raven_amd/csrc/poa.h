@@ -291,17 +291,22 @@ __host__ __device__ inline i32 poa_consensus_scores_lane0(G& g, u32 n_nodes) {
   i32 maxn = -1;
   for (u32 r = 0; r < n_nodes; ++r) {
     const u32 it = g.order[r];
-    i32 sc = -1, pd = -1;
+    // (the predecessor's score travels with it: with `g.scores[pd] <= g.scores[t]` in the condition, hipcc 7.2 compiled the
+    // lane-0 scalarised loop of the branch completion below so that a TIE updated sc but not pd — found on one window in
+    // 20 000 whose consensus ended two bases early on the device and not under the host emulator)
+    i32 sc = -1, pd = -1, pd_sc = 0;
     const u32 c = g.in_cnt[it];
     for (u32 k = 0; k < c; ++k) {
       const i32 wgt = g.in_w[it * kPoaMaxIn + k];
       const i32 t = g.in_tail[it * kPoaMaxIn + k];
-      if (sc < wgt || (sc == wgt && g.scores[pd] <= g.scores[t])) {
+      const i32 st = g.scores[t];
+      if (sc < wgt || (sc == wgt && pd_sc <= st)) {
         sc = wgt;
         pd = t;
+        pd_sc = st;
       }
     }
-    if (pd != -1) sc += g.scores[pd];
+    if (pd != -1) sc += pd_sc;
     g.scores[it] = sc;
     g.preds[it] = pd;
     if (maxn == -1 || g.scores[maxn] < sc) maxn = static_cast<i32>(it);
@@ -333,18 +338,20 @@ __host__ __device__ inline void poa_consensus_trace_lane0(G& g, u32 n_nodes, u32
     i32 mx = -1;
     for (u32 r = rank + 1; r < n_nodes; ++r) {
       const u32 it = g.order[r];
-      i32 sc = -1, pd = -1;
+      i32 sc = -1, pd = -1, pd_sc = 0;
       const u32 c = g.in_cnt[it];
       for (u32 k = 0; k < c; ++k) {
         const i32 t = g.in_tail[it * kPoaMaxIn + k];
-        if (g.scores[t] == -1) continue;
+        const i32 st = g.scores[t];
+        if (st == -1) continue;
         const i32 wgt = g.in_w[it * kPoaMaxIn + k];
-        if (sc < wgt || (sc == wgt && g.scores[pd] <= g.scores[t])) {
+        if (sc < wgt || (sc == wgt && pd_sc <= st)) {
           sc = wgt;
           pd = t;
+          pd_sc = st;
         }
       }
-      if (pd != -1) sc += g.scores[pd];
+      if (pd != -1) sc += pd_sc;
       g.scores[it] = sc;
       g.preds[it] = pd;
       if (mx == -1 || g.scores[mx] < sc) mx = static_cast<i32>(it);
