@@ -53,6 +53,11 @@ int rvn_test_overlap_update_and_type(rvn_overlap* overlaps, uint64_t n, const ui
 int rvn_test_parse_file(const char* path, int fastq, uint32_t threads, int force_streaming, uint64_t slab_bytes,
                         uint8_t** bases, uint8_t** quals, uint32_t** lengths, uint32_t* n_records, char** names,
                         uint32_t* info);
+/* freelist.h — the offset bookkeeping of the device arena behind the engine's grow-only buffers — driven by a list of
+ * operations: ops[i] > 0 allocates that many bytes (out[i] = offset, -1 if no hole holds it), ops[i] <= 0 gives back the
+ * block allocated by operation -ops[i] (out[i] = 1, or 0 if it was not in use); state[3] = {bytes free, largest hole,
+ * blocks in use} afterwards. */
+int rvn_test_freelist(uint64_t size, uint64_t grain, const int64_t* ops, uint32_t n_ops, int64_t* out, uint64_t* state);
 void rvn_test_std_sort_lendesc(uint64_t* data, uint64_t n);
 void rvn_test_heap_sort_lendesc(uint64_t* data, uint64_t n);
 

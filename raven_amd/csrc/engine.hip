@@ -19,6 +19,7 @@
 #include "poa.h"
 #include "kmer.h"
 #include "lowcomplexity.h"
+#include "freelist.h"
 #ifdef RVN_TEST_HOOKS
 #include "io_text.h"
 #endif
@@ -215,9 +216,7 @@ namespace devpool {
 namespace {
 struct Arena {
   char* base = nullptr;
-  size_t size = 0;
-  std::map<size_t, size_t> holes;                 // offset -> length, coalesced
-  std::unordered_map<const void*, size_t> in_use;  // block -> length
+  FreeList list;  // freelist.h: offsets of the blocks in use and of the holes
 };
 constexpr int kMaxDevices = 16;
 constexpr size_t kGrain = 64 << 10;
@@ -227,6 +226,10 @@ Arena* mine() {
   int d = 0;
   (void)hipGetDevice(&d);
   return (d >= 0 && d < kMaxDevices) ? &g_arena[d] : nullptr;
+}
+size_t offset_of(const Arena& a, const void* p) { return static_cast<size_t>(static_cast<const char*>(p) - a.base); }
+bool inside(const Arena& a, const void* p) {
+  return a.base && static_cast<const char*>(p) >= a.base && static_cast<const char*>(p) < a.base + a.list.size;
 }
 }  // namespace
 bool active() {
@@ -246,85 +249,49 @@ bool start(size_t bytes) {
     return false;
   }
   a->base = static_cast<char*>(p);
-  a->size = bytes;
-  a->holes.clear();
-  a->holes[0] = bytes;
-  a->in_use.clear();
+  a->list.reset(bytes, kGrain);
   return true;
 }
 void* alloc(size_t bytes) {
   std::lock_guard<std::mutex> lk(g_mu);
   Arena* a = mine();
   if (!a || !a->base) return nullptr;
-  bytes = (bytes + kGrain - 1) / kGrain * kGrain;
-  for (auto it = a->holes.begin(); it != a->holes.end(); ++it) {  // first fit, lowest address
-    if (it->second < bytes) continue;
-    const size_t off = it->first, len = it->second;
-    a->holes.erase(it);
-    if (len > bytes) a->holes[off + bytes] = len - bytes;
-    a->in_use[a->base + off] = bytes;
-    return a->base + off;
-  }
-  return nullptr;
+  size_t off = 0;
+  return a->list.alloc(bytes, &off) ? a->base + off : nullptr;
 }
 bool give_back(void* p) {
   {
     std::lock_guard<std::mutex> lk(g_mu);
     const Arena* a = mine();
-    if (!a || !a->base || !a->in_use.count(p)) return false;
+    if (!a || !inside(*a, p) || !a->list.owns(offset_of(*a, p))) return false;
   }
   (void)hipDeviceSynchronize();  // what hipFree does implicitly: nobody still reads the block when the next owner writes
   std::lock_guard<std::mutex> lk(g_mu);
   Arena* a = mine();
-  auto it = a->in_use.find(p);
-  if (it == a->in_use.end()) return false;
-  size_t off = static_cast<size_t>(static_cast<char*>(p) - a->base), len = it->second;
-  a->in_use.erase(it);
-  auto next = a->holes.lower_bound(off);
-  if (next != a->holes.end() && off + len == next->first) {
-    len += next->second;
-    next = a->holes.erase(next);
-  }
-  if (next != a->holes.begin()) {
-    auto prev = std::prev(next);
-    if (prev->first + prev->second == off) {
-      off = prev->first;
-      len += prev->second;
-      a->holes.erase(prev);
-    }
-  }
-  a->holes[off] = len;
-  return true;
+  return a && inside(*a, p) && a->list.release(offset_of(*a, p));
 }
 size_t free_total() {
   std::lock_guard<std::mutex> lk(g_mu);
   const Arena* a = mine();
-  size_t t = 0;
-  if (a && a->base)
-    for (const auto& h : a->holes) t += h.second;
-  return t;
+  return a && a->base ? a->list.free_total() : 0;
 }
 size_t free_largest() {
   std::lock_guard<std::mutex> lk(g_mu);
   const Arena* a = mine();
-  size_t t = 0;
-  if (a && a->base)
-    for (const auto& h : a->holes) t = std::max(t, h.second);
-  return t;
+  return a && a->base ? a->list.free_largest() : 0;
 }
 size_t size() {
   std::lock_guard<std::mutex> lk(g_mu);
   const Arena* a = mine();
-  return a && a->base ? a->size : 0;
+  return a && a->base ? a->list.size : 0;
 }
 void stop() {
   std::lock_guard<std::mutex> lk(g_mu);
   Arena* a = mine();
-  if (!a || !a->base || !a->in_use.empty()) return;
+  if (!a || !a->base || !a->list.in_use.empty()) return;
   (void)hipFree(a->base);
   a->base = nullptr;
-  a->size = 0;
-  a->holes.clear();
+  a->list.reset(0, kGrain);
 }
 }  // namespace devpool
 
@@ -2053,6 +2020,31 @@ int rvn_test_parse_file(const char* path, int fastq, uint32_t threads, int force
     }
     return RVN_OK;
   });
+}
+
+// freelist.h (the bookkeeping of the device arena) driven by a list of operations: ops[i] > 0 = allocate that many bytes
+// (out[i] = offset, or -1 if no hole holds it), ops[i] <= 0 = give back the block allocated by operation -ops[i] (out[i] = 1,
+// 0 if that was no block in use).  state[3] = {bytes free, largest hole, blocks in use} at the end.
+int rvn_test_freelist(uint64_t size, uint64_t grain, const int64_t* ops, uint32_t n_ops, int64_t* out, uint64_t* state) {
+  if (!ops || !out || !state) return RVN_EINVAL;
+  rvn::FreeList fl;
+  fl.reset(size, grain);
+  std::vector<char> given_back(n_ops, 0);  // (a block is named by the operation that made it: its offset may have a new owner)
+  for (uint32_t i = 0; i < n_ops; ++i) {
+    if (ops[i] > 0) {
+      size_t off = 0;
+      out[i] = fl.alloc(static_cast<size_t>(ops[i]), &off) ? static_cast<int64_t>(off) : -1;
+    } else {
+      const uint64_t j = static_cast<uint64_t>(-ops[i]);
+      const bool ok = j < i && ops[j] > 0 && out[j] >= 0 && !given_back[j] && fl.release(static_cast<size_t>(out[j]));
+      if (ok) given_back[j] = 1;
+      out[i] = ok ? 1 : 0;
+    }
+  }
+  state[0] = fl.free_total();
+  state[1] = fl.free_largest();
+  state[2] = fl.in_use.size();
+  return RVN_OK;
 }
 
 int rvn_test_nw_breakpoints(const uint64_t* t_words, uint32_t t_len, const uint64_t* r_words, uint32_t r_len,

@@ -59,7 +59,7 @@ SYMBOLS = [
 TEST_SYMBOLS = [
     "rvn_poa_banded_emulate", "rvn_test_low_complexity", "rvn_test_nw_breakpoints", "rvn_test_hash",
     "rvn_test_canonical", "rvn_test_std_sort_lendesc", "rvn_test_heap_sort_lendesc", "rvn_test_overlap_update_and_type", "rvn_test_find_chimeric_regions",
-    "rvn_test_parse_file",
+    "rvn_test_parse_file", "rvn_test_freelist",
 ]
 
 
@@ -115,6 +115,7 @@ def test_lib():
     L.rvn_test_heap_sort_lendesc.argtypes = [vp, u64]
     pp = C.POINTER(C.c_void_p)
     L.rvn_test_parse_file.argtypes = [C.c_char_p, i32, u32, i32, u64, pp, pp, pp, C.POINTER(u32), pp, vp]
+    L.rvn_test_freelist.argtypes = [u64, u64, vp, u32, vp, vp]
     _test_lib = L
     return L
 
