@@ -49,10 +49,15 @@ int rvn_test_overlap_update_and_type(rvn_overlap* overlaps, uint64_t n, const ui
  * device: fastq 0 / 1; threads 0 = default; force_streaming: one inflate thread front to back; slab_bytes 0 = default.
  * Outputs malloc'ed (free with rvn_free): all bases back to back, all qualities (FASTQ), lengths[n_records], names
  * separated by '\n'; info[8] = {gzip, streaming, members found, pool threads, 1 if a wrong cut made it start over,
- * microseconds of the inflate + scan loop, of which inside the scanner, 0}. */
+ * microseconds of the inflate + scan loop, of which inside the scanner, 1 if the single stream went through
+ * inflate_fast.h}. */
 int rvn_test_parse_file(const char* path, int fastq, uint32_t threads, int force_streaming, uint64_t slab_bytes,
                         uint8_t** bases, uint8_t** quals, uint32_t** lengths, uint32_t* n_records, char** names,
                         uint32_t* info);
+/* inflate_fast.h (the single-stream deflate decoder of the input path) on ONE gzip member: dst gets the text, out[4] =
+ * {bytes produced, bytes of the member consumed incl. its trailer, CRC-32 and ISIZE found in the trailer}; chunk > 0:
+ * through a drained buffer of that many bytes (as the input path runs it).  RVN_EINVAL + message for an invalid stream. */
+int rvn_test_inflate_fast(const uint8_t* src, uint64_t n, uint8_t* dst, uint64_t cap, uint64_t chunk, uint64_t* out);
 /* freelist.h — the offset bookkeeping of the device arena behind the engine's grow-only buffers — driven by a list of
  * operations: ops[i] > 0 allocates that many bytes (out[i] = offset, -1 if no hole holds it), ops[i] <= 0 gives back the
  * block allocated by operation -ops[i] (out[i] = 1, or 0 if it was not in use); state[3] = {bytes free, largest hole,

@@ -22,6 +22,7 @@
 #include "freelist.h"
 #ifdef RVN_TEST_HOOKS
 #include "io_text.h"
+#include "inflate_fast.h"
 #endif
 
 using namespace rvn;
@@ -1936,7 +1937,7 @@ int rvn_polish_fetch_layers(rvn_engine* h, uint32_t* out, uint64_t cap, uint64_t
 // The host half of rvn_reads_load (io_text.h: member cut + inflate pool + record scanner) without a device: the kept
 // text is assembled in host memory exactly as the H2D copies would lay it out in HBM, then cut into the records' fields.
 // Outputs are malloc'ed (rvn_free): bases and qualities back to back, lengths, names separated by '\n';
-// info[8] = {gzip, streaming, members, threads, restarted, loop microseconds, scan microseconds, 0}.
+// info[8] = {gzip, streaming, members, threads, restarted, loop microseconds, scan microseconds, fast single-stream decoder}.
 int rvn_test_parse_file(const char* path, int fastq, uint32_t threads, int force_streaming, uint64_t slab_bytes,
                         uint8_t** bases, uint8_t** quals, uint32_t** lengths, uint32_t* n_records, char** names,
                         uint32_t* info) {
@@ -2012,12 +2013,65 @@ int rvn_test_parse_file(const char* path, int fastq, uint32_t threads, int force
           info[4] = static_cast<uint32_t>(attempt);
           info[5] = static_cast<uint32_t>(loop_s * 1e6);  // inflate + scan + assembling the kept text, microseconds
           info[6] = static_cast<uint32_t>(scan_s * 1e6);  // of which inside RecordScanner::scan
+          info[7] = src.fast_stream() ? 1 : 0;            // the single stream went through inflate_fast.h
         }
         return RVN_OK;
       } catch (const io::SpeculationFailed&) {
         if (attempt == 1) return fail(RVN_EINVAL, "[bioparser] error: corrupt or truncated file");
       }
     }
+    return RVN_OK;
+  });
+}
+
+// inflate_fast.h on ONE gzip member (header and trailer handled here): dst gets the text, out[4] = {bytes produced, bytes
+// of the member consumed incl. the trailer, CRC-32 found in the trailer, ISIZE found}; chunk > 0: the output is produced
+// through a buffer of that many bytes that is drained whenever it fills (the way the input path uses the decoder).
+// Returns 0, RVN_EINVAL with the decoder's message for an invalid stream.
+int rvn_test_inflate_fast(const uint8_t* src, uint64_t n, uint8_t* dst, uint64_t cap, uint64_t chunk, uint64_t* out) {
+  return guarded([&]() -> int {
+    if (!src || !dst || !out) return fail(RVN_EINVAL, "[raven_hip] NULL argument");
+    const u64 hdr = io::gz_header_len(src, n, nullptr);
+    if (!hdr) return fail(RVN_EINVAL, "not a gzip member");
+    io::FastInflate dec;
+    dec.reset(src + hdr, src + n);
+    u64 produced = 0;
+    if (chunk == 0) {
+      u8* o = dst;
+      const io::FastInflate::Status st = dec.run(dst, &o, dst + cap);
+      produced = static_cast<u64>(o - dst);
+      if (st == io::FastInflate::kOutputFull) return fail(RVN_EINVAL, "output buffer too small");
+      if (st == io::FastInflate::kError) return fail(RVN_EINVAL, dec.error());
+    } else {
+      const u64 hist = 32768;
+      std::vector<u8> buf(hist + chunk + io::FastInflate::kOutMargin);
+      u8* base = buf.data();
+      u8* o = base;  // (no history yet)
+      const u8* valid_from = base;
+      for (;;) {
+        const io::FastInflate::Status st = dec.run(valid_from, &o, base + buf.size());
+        const u8* from = valid_from == base && produced == 0 ? base : base + hist;
+        // drain what is new: everything behind the history area (or the whole buffer the first time round)
+        const u64 fresh = static_cast<u64>(o - from);
+        if (produced + fresh > cap) return fail(RVN_EINVAL, "output buffer too small");
+        std::memcpy(dst + produced, from, fresh);
+        produced += fresh;
+        if (st == io::FastInflate::kError) return fail(RVN_EINVAL, dec.error());
+        if (st == io::FastInflate::kStreamEnd) break;
+        // keep the last 32 KB in front
+        const u64 have = static_cast<u64>(o - base);
+        const u64 keep = std::min<u64>(hist, have);
+        std::memmove(base + hist - keep, o - keep, keep);
+        valid_from = base + hist - keep;
+        o = base + hist;
+      }
+    }
+    const u8* p = dec.input_position();
+    if (p + 8 > src + n) return fail(RVN_EINVAL, "unexpected end of file");
+    out[0] = produced;
+    out[1] = static_cast<u64>(p + 8 - src);
+    out[2] = p[0] | (static_cast<u64>(p[1]) << 8) | (static_cast<u64>(p[2]) << 16) | (static_cast<u64>(p[3]) << 24);
+    out[3] = p[4] | (static_cast<u64>(p[5]) << 8) | (static_cast<u64>(p[6]) << 16) | (static_cast<u64>(p[7]) << 24);
     return RVN_OK;
   });
 }

@@ -29,8 +29,10 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <functional>
@@ -39,6 +41,8 @@
 #include <string>
 #include <thread>
 #include <vector>
+
+#include "inflate_fast.h"
 
 namespace rvn {
 namespace io {
@@ -101,7 +105,8 @@ struct Member {
 
 struct SourceOptions {
   u32 threads = 0;              // 0: hardware_concurrency - 2, at most 32; RVN_IO_THREADS overrides
-  bool force_streaming = false;  // one inflate thread, front to back
+  bool force_streaming = false;  // one zlib inflate thread, front to back (the authority on damaged archives)
+  u32 stream_helpers = 3;        // single-member archive: threads beside the decoder (CRC-32 + copy into the slabs)
   u64 slab_bytes = 8ULL << 20;   // RVN_IO_SLAB_MB overrides
   u32 ring = 8;                  // RVN_IO_RING overrides
   u64 item_bytes = 1ULL << 20;   // text per work item of the pool (BGZF blocks are 64 kB: grouped)
@@ -166,6 +171,7 @@ class TextSource {
   }
   bool gzip() const { return gzip_; }
   bool streaming() const { return streaming_; }
+  bool fast_stream() const { return fast_stream_; }
   u32 members() const { return static_cast<u32>(members_.size()); }
   u32 threads() const { return static_cast<u32>(workers_.size()); }
 
@@ -211,6 +217,10 @@ class TextSource {
       want = std::min(32u, hw > 3 ? hw - 2 : 1u);
     }
     if (streaming_) {
+      // a single member (or a cut that did not work out): one deflate stream, one decoder.  Unless the caller asked for
+      // zlib (force_streaming: the second attempt after anything went wrong) it is inflate_fast.h with a few helpers that
+      // checksum and place what it produces
+      fast_stream_ = !opt_.force_streaming && std::getenv("RVN_IO_ZLIB") == nullptr;
       n_threads_ = 1;
       total_known_ = false;
       slab_bytes_ = opt_.slab_bytes;
@@ -272,7 +282,7 @@ class TextSource {
   // ---- the ring ----
   void start() {
     const u32 n_alloc =
-        total_known_ ? static_cast<u32>(std::min<u64>(opt_.ring, std::max<u64>(1, n_slabs_))) : std::min(opt_.ring, 3u);
+        total_known_ ? static_cast<u32>(std::min<u64>(opt_.ring, std::max<u64>(1, n_slabs_))) : std::min(opt_.ring, fast_stream_ ? 4u : 3u);
     ring_ = n_alloc;
     slabs_.resize(n_alloc);
     for (Slab& s : slabs_) {
@@ -338,7 +348,8 @@ class TextSource {
   void work() {
     try {
       if (streaming_) {
-        stream_all();
+        if (fast_stream_) fast_stream_all();
+        else stream_all();
         return;
       }
       z_stream zs;
@@ -432,6 +443,186 @@ class TextSource {
     }
   }
 
+  // ---- single stream, fast decoder -------------------------------------------------------------------------------
+  // The decoder (this thread) fills one of two linear buffers (32 KB of history in front); what it produced is cut into
+  // pieces that helper threads checksum (zlib crc32, combined in order at the member's end) and copy to their place in
+  // the slabs while the decoder goes on in the other buffer.  Any doubt — a stream the decoder refuses, a CRC-32 or ISIZE
+  // that does not match — ends the attempt as a failed speculation: the caller starts over with zlib, which reports what
+  // is wrong with the archive (or reads it, should the doubt have been this decoder's fault).
+  struct Piece {
+    const u8* src = nullptr;
+    u64 len = 0, text_off = 0;
+    unsigned long crc = 0;
+    bool done = false;
+  };
+  void helper_loop() {
+    for (;;) {
+      Piece* pc = nullptr;
+      {
+        std::unique_lock<std::mutex> lk(hmu_);
+        hcv_.wait(lk, [&] { return hstop_ || !hqueue_.empty(); });
+        if (hqueue_.empty()) return;
+        pc = hqueue_.back();
+        hqueue_.pop_back();
+      }
+      unsigned long c = crc32(0L, Z_NULL, 0);
+      for (u64 at = 0; at < pc->len;) {  // (zlib takes 32-bit lengths)
+        const u64 n = std::min<u64>(pc->len - at, 1ULL << 30);
+        c = crc32(c, pc->src + at, static_cast<uInt>(n));
+        at += n;
+      }
+      pc->crc = c;
+      bool ok = true;
+      for (u64 at = 0; ok && at < pc->len;) {
+        const u64 pos = pc->text_off + at;
+        Slab* sl = writable(pos / slab_bytes_);
+        if (!sl) {
+          ok = false;
+          break;
+        }
+        const u64 in_slab = pos % slab_bytes_, n = std::min(pc->len - at, slab_bytes_ - in_slab);
+        std::memcpy(sl->text + in_slab, pc->src + at, n);
+        wrote(sl, n);
+        at += n;
+      }
+      {
+        std::lock_guard<std::mutex> lk(hmu_);
+        pc->done = true;
+      }
+      hdone_.notify_all();
+    }
+  }
+  void fast_stream_all() {
+    constexpr u64 kHist = 32768, kBuf = 8ULL << 20;
+    const u32 n_help = std::max(1u, opt_.stream_helpers);
+    std::vector<std::thread> helpers;
+    struct Stop {
+      TextSource* t;
+      std::vector<std::thread>* h;
+      ~Stop() {
+        {
+          std::lock_guard<std::mutex> lk(t->hmu_);
+          t->hstop_ = true;
+        }
+        t->hcv_.notify_all();
+        for (std::thread& x : *h)
+          if (x.joinable()) x.join();
+      }
+    } stop{this, &helpers};
+    for (u32 i = 0; i < n_help; ++i) helpers.emplace_back([this] { helper_loop(); });
+    std::vector<u8> lin[2];
+    for (auto& v : lin) v.resize(kHist + kBuf + FastInflate::kOutMargin + 64);
+    std::vector<Piece> pieces[2];
+    auto wait_pieces = [&](std::vector<Piece>& ps) {
+      std::unique_lock<std::mutex> lk(hmu_);
+      hdone_.wait(lk, [&] {
+        for (const Piece& x : ps)
+          if (!x.done) return false;
+        return true;
+      });
+    };
+    u64 text_off = 0;  // text produced so far (all members)
+    u64 in_pos = 0;
+    int cur = 0;
+    bool any_member = false;
+    FastInflate dec;
+    while (in_pos < size_) {
+      u32 unused = 0;
+      if (size_ - in_pos < 2 || base_[in_pos] != 0x1f || base_[in_pos + 1] != 0x8b) {
+        if (!any_member) return fail("", true);
+        break;  // trailing garbage after a complete member: ignored, as zlib does
+      }
+      const u64 hdr = gz_header_len(base_ + in_pos, size_ - in_pos, &unused);
+      if (!hdr) return fail("", true);
+      any_member = true;
+      dec.reset(base_ + in_pos + hdr, base_ + size_);
+      u8* bufp = lin[cur].data();
+      const u8* valid_from = bufp + kHist;  // a member starts without history
+      u8* o = bufp + kHist;
+      unsigned long crc = crc32(0L, Z_NULL, 0);
+      u64 member_len = 0;
+      std::vector<std::pair<unsigned long, u64>> done_crcs;  // (crc, length) of the pieces, in text order
+      for (;;) {
+        const auto t_dec = std::chrono::steady_clock::now();
+        const FastInflate::Status st = dec.run(valid_from, &o, bufp + lin[cur].size());
+        dbg_decode_s_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_dec).count();
+        if (st == FastInflate::kError) return fail("", true);
+        // what is new in this buffer: [bufp + kHist, o) -> pieces for the helpers
+        const u8* from = bufp + kHist;
+        const u64 fresh = static_cast<u64>(o - from);
+        pieces[cur].clear();
+        const u64 per = std::max<u64>(1ULL << 20, (fresh + n_help - 1) / n_help);
+        for (u64 at = 0; at < fresh; at += per) {
+          Piece pc;
+          pc.src = from + at;
+          pc.len = std::min(per, fresh - at);
+          pc.text_off = text_off + at;
+          pieces[cur].push_back(pc);
+        }
+        {
+          std::lock_guard<std::mutex> lk(hmu_);
+          for (Piece& pc : pieces[cur]) hqueue_.push_back(&pc);
+        }
+        hcv_.notify_all();
+        text_off += fresh;
+        member_len += fresh;
+        // the other buffer: its pieces of the round before must be finished before it is written again
+        const int other = cur ^ 1;
+        const auto t_wait = std::chrono::steady_clock::now();
+        wait_pieces(pieces[other]);
+        dbg_wait_s_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_wait).count();
+        for (const Piece& x : pieces[other]) done_crcs.emplace_back(x.crc, x.len);
+        pieces[other].clear();
+        if (stop_requested()) return;
+        if (st == FastInflate::kStreamEnd) break;
+        // history: the last 32 KB of what has been produced go in front of the other buffer
+        u8* nb = lin[other].data();
+        const u64 have = static_cast<u64>(o - valid_from);
+        const u64 keep = std::min<u64>(kHist, have);
+        std::memcpy(nb + kHist - keep, o - keep, keep);
+        valid_from = nb + kHist - keep;
+        o = nb + kHist;
+        bufp = nb;
+        cur = other;
+      }
+      // end of the member: every piece done, checksum and length against the trailer
+      wait_pieces(pieces[cur]);
+      for (const Piece& x : pieces[cur]) done_crcs.emplace_back(x.crc, x.len);
+      pieces[cur].clear();
+      for (const auto& c : done_crcs) crc = crc32_combine(crc, c.first, static_cast<z_off_t>(c.second));
+      const u8* tr = dec.input_position();
+      if (tr + 8 > base_ + size_) return fail("", true);
+      const u64 want_crc = tr[0] | (static_cast<u64>(tr[1]) << 8) | (static_cast<u64>(tr[2]) << 16) | (static_cast<u64>(tr[3]) << 24);
+      const u64 want_len = tr[4] | (static_cast<u64>(tr[5]) << 8) | (static_cast<u64>(tr[6]) << 16) | (static_cast<u64>(tr[7]) << 24);
+      if (want_crc != (crc & 0xFFFFFFFFUL) || want_len != (member_len & 0xFFFFFFFFULL)) return fail("", true);
+      in_pos = static_cast<u64>(tr + 8 - base_);
+    }
+    if (std::getenv("RVN_IO_DEBUG"))
+      std::fprintf(stderr, "[raven_hip] single stream: %.3f s decoding, %.3f s waiting for the helpers, %.1f MB of text\n", dbg_decode_s_,
+                   dbg_wait_s_, text_off / 1e6);
+    // close the text (every piece has been written: the waits above)
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      total_ = text_off;
+      n_slabs_ = (text_off + slab_bytes_ - 1) / slab_bytes_;
+      total_known_ = true;
+      if (n_slabs_) {
+        const u64 k = n_slabs_ - 1;
+        while (next_assign_ <= k) assign(next_assign_++);  // (cannot happen: its pieces were written) 
+        Slab& s = slabs_[k % ring_];
+        if (s.index == k) {
+          s.expect = text_off - k * slab_bytes_;
+          if (s.filled == s.expect) s.done = true;
+        }
+      }
+    }
+    cv_.notify_all();
+  }
+  bool stop_requested() {
+    std::lock_guard<std::mutex> lk(mu_);
+    return stop_ || failed_;
+  }
+
   // the whole archive front to back on this thread (gzread's semantics: members back to back, garbage after the last
   // member ignored, a stream cut short or damaged is an error)
   void stream_all() {
@@ -505,7 +696,7 @@ class TextSource {
   int fd_ = -1;
   const u8* base_ = nullptr;
   u64 size_ = 0, total_ = 0, slab_bytes_ = 0, n_slabs_ = 0;
-  bool gzip_ = false, streaming_ = false, total_known_ = false;
+  bool gzip_ = false, streaming_ = false, total_known_ = false, fast_stream_ = false;
   u32 n_threads_ = 1, ring_ = 1;
   std::vector<Member> members_;
   std::vector<Item> items_;
@@ -514,6 +705,11 @@ class TextSource {
   std::atomic<size_t> next_item_{0};
   std::mutex mu_;
   std::condition_variable cv_;
+  std::mutex hmu_;  // single-stream helpers: queue of pieces
+  std::condition_variable hcv_, hdone_;
+  std::vector<Piece*> hqueue_;
+  bool hstop_ = false;
+  double dbg_decode_s_ = 0, dbg_wait_s_ = 0;
   u64 consumed_ = 0, released_ = 0, next_assign_ = 0;
   bool stop_ = false, failed_ = false, spec_failed_ = false;
   std::string error_;

@@ -59,7 +59,7 @@ SYMBOLS = [
 TEST_SYMBOLS = [
     "rvn_poa_banded_emulate", "rvn_test_low_complexity", "rvn_test_nw_breakpoints", "rvn_test_hash",
     "rvn_test_canonical", "rvn_test_std_sort_lendesc", "rvn_test_heap_sort_lendesc", "rvn_test_overlap_update_and_type", "rvn_test_find_chimeric_regions",
-    "rvn_test_parse_file", "rvn_test_freelist",
+    "rvn_test_parse_file", "rvn_test_freelist", "rvn_test_inflate_fast",
 ]
 
 
@@ -116,6 +116,7 @@ def test_lib():
     pp = C.POINTER(C.c_void_p)
     L.rvn_test_parse_file.argtypes = [C.c_char_p, i32, u32, i32, u64, pp, pp, pp, C.POINTER(u32), pp, vp]
     L.rvn_test_freelist.argtypes = [u64, u64, vp, u32, vp, vp]
+    L.rvn_test_inflate_fast.argtypes = [vp, u64, vp, u64, u64, vp]
     _test_lib = L
     return L
 
@@ -984,7 +985,7 @@ def test_parse_file(path, fastq, threads=0, force_streaming=False, slab_bytes=0)
     seqs = [bases[off[i]:off[i + 1]] for i in range(n.value)]
     qs = [quals[off[i]:off[i + 1]] for i in range(n.value)] if fastq else None
     return names, seqs, qs, dict(gzip=int(info[0]), streaming=int(info[1]), members=int(info[2]), threads=int(info[3]),
-                                 restarted=int(info[4]), loop_s=info[5] / 1e6, scan_s=info[6] / 1e6)
+                                 restarted=int(info[4]), loop_s=info[5] / 1e6, scan_s=info[6] / 1e6, fast=int(info[7]))
 
 
 NW_REC_DTYPE = np.dtype([("first_t", "<u4"), ("first_q", "<u4"), ("last_t", "<u4"), ("last_q", "<u4"),

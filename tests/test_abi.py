@@ -31,7 +31,7 @@ def test_hooks_live_in_the_test_library_only():
     of everything the product header declares."""
     import subprocess
     hooks = _declared_symbols("raven_hip_test.h")
-    assert sorted(hip.TEST_SYMBOLS) == hooks and len(hooks) == 11
+    assert sorted(hip.TEST_SYMBOLS) == hooks and len(hooks) == 12
     names = subprocess.check_output(["nm", "-D", "--defined-only", hip.LIB_PATH]).decode()
     assert "rvn_test_" not in names and "emulate" not in names and "simt_emu" not in names
     T = hip.test_lib()

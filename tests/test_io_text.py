@@ -123,7 +123,11 @@ def test_single_member_streams_front_to_back(tmp_path):
     p = str(tmp_path / "r.fastq.gz")
     open(p, "wb").write(gzip.compress(text, 1))
     info = _check(p, text, True, slab_bytes=1 << 20)
-    assert info["streaming"] == 1 and info["threads"] == 1
+    assert info["streaming"] == 1 and info["threads"] == 1 and info["fast"] == 1  # inflate_fast.h + helpers
+    for slab in (257, 70_001):  # pieces of the helpers straddle slabs in every way
+        assert _check(p, text, True, slab_bytes=slab)["fast"] == 1
+    info = _check(p, text, True, force_streaming=True, slab_bytes=1 << 20)
+    assert info["streaming"] == 1 and info["fast"] == 0  # zlib, the authority
     # and the same text from a plain file: the pool copies ranges
     p2 = str(tmp_path / "r.fastq")
     open(p2, "wb").write(text)
@@ -220,6 +224,31 @@ def test_malformed_records_and_damaged_archives_are_errors(tmp_path):
     bad("dmg.fastq.gz", bytes(dmg), True)
     one = gzip.compress(text, 1)
     bad("cut1.fastq.gz", one[:len(one) // 2], True)
+
+
+def test_single_stream_longer_than_the_decoder_buffers(tmp_path):
+    """40 MB of text in one member: the decoder changes its 8-MB buffer several times (history carried over), the helpers'
+    CRC-32s are combined in order and must match the trailer; a flipped bit anywhere makes the load start over with zlib,
+    which reports it."""
+    rng = np.random.default_rng(31)
+    text = _fastq_text(rng, 1500, 5000, 22000)
+    assert len(text) > 36 << 20
+    blob = gzip.compress(text, 1)
+    p = str(tmp_path / "big.fastq.gz")
+    open(p, "wb").write(blob)
+    info = _check(p, text, True)
+    assert info["fast"] == 1 and info["restarted"] == 0
+    two = str(tmp_path / "two.fastq.gz")  # two members whose second header fails the strict cut test: one stream, two members
+    more = _fastq_text(rng, 300, 5000, 22000)
+    open(two, "wb").write(blob + b"\x1f\x8b\x08\x00\0\0\0\0\x01\x63" + gzip.compress(more, 1)[10:])
+    info = _check(two, text + more, True)
+    assert info["streaming"] == 1 and info["fast"] == 1
+    bad = bytearray(blob)
+    bad[len(bad) // 2] ^= 0x10
+    q = str(tmp_path / "bad.fastq.gz")
+    open(q, "wb").write(bytes(bad))
+    with pytest.raises(ValueError):
+        hip.test_parse_file(q, True)
 
 
 def test_golden_lambda_files(tmp_path):
