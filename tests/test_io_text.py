@@ -251,6 +251,36 @@ def test_single_stream_longer_than_the_decoder_buffers(tmp_path):
         hip.test_parse_file(q, True)
 
 
+def test_host_pipeline_under_thread_sanitizer(tmp_path):
+    """The inflate pool, the single-stream decoder with its helpers, the slab ring and the scanner built with
+    -fsanitize=thread (tests/cpp/tsan_io.cpp) on a single-member archive, a blocked one and a plain file, slabs of 8 MB,
+    70 001 and 1 031 bytes: no race reported, same record counts everywhere."""
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "tsan_io")
+    build = subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=thread", "-I", os.path.join(root, "raven_amd", "csrc"),
+                            os.path.join(root, "tests", "cpp", "tsan_io.cpp"), "-o", exe, "-lz", "-lpthread"],
+                           capture_output=True, text=True)
+    if build.returncode != 0 and "sanitize" in build.stderr:
+        pytest.skip("this g++ has no ThreadSanitizer runtime")
+    assert build.returncode == 0, build.stderr
+    rng = np.random.default_rng(41)
+    text = _fastq_text(rng, 500, 2000, 24000)
+    files = {"one.fastq.gz": gzip.compress(text, 1), "blocked.fastq.gz": _bgzf(text), "plain.fastq": text}
+    args = []
+    for name, blob in files.items():
+        open(str(tmp_path / name), "wb").write(blob)
+        args += ["q", str(tmp_path / name)]
+    run = subprocess.run([exe] + args, capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0 and "ThreadSanitizer" not in run.stderr, run.stderr[-3000:]
+    lines = [ln for ln in run.stdout.splitlines() if "records" in ln]
+    assert len(lines) == 9 and all(": 500 records, %d bytes of text" % len(text) in ln for ln in lines), run.stdout
+    assert sum("fast 1" in ln for ln in lines) == 3  # the single member went through inflate_fast.h + helpers
+
+
 def test_golden_lambda_files(tmp_path):
     for name, fastq in (("ERA476754.fastq.gz", True), ("NC_001416.fasta.gz", False)):
         path = os.path.join(GOLDEN, name)
