@@ -164,7 +164,7 @@ def cpu_baseline(args, cores):
         pol_bases = sum(c[1].total_bases for c in cases)
         v_pol = pol_bases / t_pol
         sample += "; polish: %d independent rounds in parallel (12 kb draft, 30x, 3 kb reads each; %d bases), " \
-                  "oracle.polish_round (full-matrix NW + scalar POA, nothing like racon's edlib + SIMD spoa): %.2f s = %.5f Gbase/s per round" % (len(cases), pol_bases, t_pol, v_pol / 1e9)
+                  "oracle.polish_round (Ukkonen-banded scalar NW paths + scalar POA: not racon's bit-vector edlib + SIMD spoa): %.2f s = %.5f Gbase/s per round" % (len(cases), pol_bases, t_pol, v_pol / 1e9)
         v = 1.0 / (1.0 / v_ovl + args.polish_rounds / v_pol)
     return {"value": round(v / 1e9, 6), "unit": "Gbase/s", "cores": threads, "cpu_count": os.cpu_count(), "cpu_model": cpu_model,
             "kind": "port", "sample": sample}

@@ -328,6 +328,12 @@ def polish_layers(targets, reads, quals=None, q=0.0, err=0.3, w=500):
     return out[:n].copy()
 
 
+def nw_full_matrix(on: bool):
+    """The alignment paths of nw_breakpoints / polish_layers / polish_round from the full DP matrix (True) instead of the
+    Ukkonen band that gives the same path (default; tests/test_oracle.py compares the two)."""
+    lib().orc_nw_full(int(bool(on)))
+
+
 def nw_breakpoints(query: np.ndarray, target: np.ndarray, q_begin: int, t_begin: int, w: int):
     """Global alignment path of two code arrays (plain DP, ties: diagonal, then query base only, then target base
     only) -> racon's find_breaking_points_from_cigar.  Returns (pairs[(t, q)] two per window with an aligned pair,

@@ -1232,7 +1232,7 @@ std::int64_t orc_second_pass(orc_engine* eng, const std::uint64_t* packed, const
 // backbone quality, layers >= 0.02 w and mean quality >= q; (5) Window::GenerateConsensus; (6) stitch + ratio.
 namespace orc {
 
-static void NwPath(const std::vector<std::uint8_t>& q, const std::vector<std::uint8_t>& t, std::vector<char>* ops) {
+static void NwPathFull(const std::vector<std::uint8_t>& q, const std::vector<std::uint8_t>& t, std::vector<char>* ops) {
   // ops from the start: 'M' (match/mismatch), 'I' (query base only), 'D' (target base only)
   const std::size_t n = q.size(), m = t.size();
   std::vector<std::uint32_t> prev(m + 1), cur(m + 1);
@@ -1258,6 +1258,62 @@ static void NwPath(const std::vector<std::uint8_t>& q, const std::vector<std::ui
     else { ops->push_back('D'); --j; }
   }
   std::reverse(ops->begin(), ops->end());
+}
+
+// The same DP restricted to the diagonals an alignment of cost <= k can visit (Ukkonen): j - i in
+// [min(0, m - n) - k, max(0, m - n) + k]; k doubles until the distance found is <= k.  The result is the full matrix's,
+// traceback included: every cell the traceback visits lies on an optimal path, an optimal path of cost d <= k never
+// leaves the band, so its cells (and every predecessor that TIES for the minimum, which is on an optimal path too) carry
+// exact values; cells whose best prefix would leave the band are only too large and never win.  orc_nw_full(1) switches
+// back to the full matrix (tests/test_oracle.py compares the two).
+static bool g_nw_full = false;
+static bool NwPathBand(const std::vector<std::uint8_t>& q, const std::vector<std::uint8_t>& t, std::uint64_t k, std::vector<char>* ops) {
+  const std::int64_t n = q.size(), m = t.size();
+  const std::int64_t lo = std::min<std::int64_t>(0, m - n) - static_cast<std::int64_t>(k);
+  const std::int64_t hi = std::max<std::int64_t>(0, m - n) + static_cast<std::int64_t>(k);
+  const std::int64_t W = hi - lo + 1;
+  const std::uint32_t kInf = 0x3FFFFFFFu;
+  // row i holds columns j = i + lo .. i + hi at index j - i - lo; so (i-1, j-1) is the same index of the row above,
+  // (i-1, j) index + 1 of the row above, (i, j-1) index - 1 of this row
+  std::vector<std::uint32_t> prev(W + 2, kInf), cur(W + 2, kInf);
+  std::vector<std::uint8_t> dir(static_cast<std::size_t>(n + 1) * W);
+  for (std::int64_t x = 0; x < W; ++x) {
+    const std::int64_t j = x + lo;
+    if (j >= 0 && j <= m) { prev[x + 1] = static_cast<std::uint32_t>(j); dir[x] = 2; }
+  }
+  for (std::int64_t i = 1; i <= n; ++i) {
+    std::fill(cur.begin(), cur.end(), kInf);
+    for (std::int64_t x = 0; x < W; ++x) {
+      const std::int64_t j = i + lo + x;
+      if (j < 0 || j > m) continue;
+      if (j == 0) { cur[x + 1] = static_cast<std::uint32_t>(i); dir[i * W + x] = 1; continue; }
+      const std::uint32_t d = prev[x + 1] + (q[i - 1] != t[j - 1]), u = prev[x + 2] + 1, l = cur[x] + 1;
+      const std::uint32_t best = std::min(d, std::min(u, l));
+      cur[x + 1] = best;
+      dir[i * W + x] = best == d ? 0 : (best == u ? 1 : 2);
+    }
+    prev.swap(cur);
+  }
+  const std::int64_t xe = m - n - lo;
+  if (prev[xe + 1] > k) return false;
+  ops->clear();
+  std::int64_t i = n, j = m;
+  while (i > 0 || j > 0) {
+    const std::uint8_t d = dir[i * W + (j - i - lo)];
+    if (i > 0 && j > 0 && d == 0) { ops->push_back('M'); --i; --j; }
+    else if (i > 0 && (d == 1 || j == 0)) { ops->push_back('I'); --i; }
+    else { ops->push_back('D'); --j; }
+  }
+  std::reverse(ops->begin(), ops->end());
+  return true;
+}
+static void NwPath(const std::vector<std::uint8_t>& q, const std::vector<std::uint8_t>& t, std::vector<char>* ops) {
+  if (g_nw_full || q.empty() || t.empty()) return NwPathFull(q, t, ops);
+  const std::uint64_t longest = std::max(q.size(), t.size());
+  for (std::uint64_t k = std::max<std::uint64_t>(32, longest / 8);; k *= 2) {
+    if (k >= longest) return NwPathFull(q, t, ops);
+    if (NwPathBand(q, t, k, ops)) return;
+  }
 }
 
 // racon Overlap::find_breaking_points_from_cigar: for every window of w target bases the first aligned pair
@@ -1301,6 +1357,8 @@ static void BreakingPoints(const std::vector<char>& ops, std::uint32_t q_begin, 
 }  // namespace orc
 
 // query / target: one-byte codes of the two spans; out: (t, q) pairs, two per window that has an aligned pair
+extern "C" void orc_nw_full(int on) { orc::g_nw_full = on != 0; }
+
 extern "C" std::uint64_t orc_nw_breakpoints(const std::uint8_t* query, std::uint32_t n, const std::uint8_t* target,
                                             std::uint32_t m, std::uint32_t q_begin, std::uint32_t t_begin,
                                             std::uint32_t w, std::uint32_t* out, std::uint64_t cap,

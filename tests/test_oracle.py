@@ -293,3 +293,47 @@ def test_pile_trim_and_median_restatement():
     assert n_valid > 20
     b, e, m, inv = oracle.pile_trim_and_median(cases[4].copy())
     assert (b, e, inv) == (78, 156, False)
+
+
+def test_banded_alignment_path_is_the_full_matrix_path():
+    """The oracle's NW path runs in an Ukkonen band that doubles until it holds the distance; path (hence breakpoints) and
+    distance must be the full matrix's, ties included: random pairs from identical to unrelated, lengths that differ,
+    indel bursts that push the path to the band's edge, homopolymers (ties everywhere)."""
+    rng = np.random.default_rng(77)
+
+    def mutate(x, sub, ins, dele):
+        out = []
+        for c in x:
+            u = rng.random()
+            if u < dele:
+                continue
+            out.append((int(c) + int(rng.integers(1, 4))) & 3 if u < dele + sub else int(c))
+            if rng.random() < ins:
+                out.append(int(rng.integers(0, 4)))
+        return np.asarray(out, dtype=np.uint8)
+
+    cases = []
+    for trial in range(60):
+        n = int(rng.integers(1, 1500))
+        t = rng.integers(0, 4, n).astype(np.uint8)
+        e = float(rng.choice([0.0, 0.01, 0.1, 0.3]))
+        q = mutate(t, e, e / 2, e / 2)
+        if trial % 7 == 0:  # an indel burst
+            cut = int(rng.integers(0, max(1, len(q))))
+            q = np.concatenate([q[:cut], rng.integers(0, 4, int(rng.integers(1, 120))).astype(np.uint8), q[cut:]])
+        if trial % 11 == 0:
+            q = q[: max(1, len(q) // 2)]
+        if len(q) == 0:
+            q = np.zeros(1, dtype=np.uint8)
+        cases.append((q, t))
+    cases.append((np.zeros(700, dtype=np.uint8), np.zeros(640, dtype=np.uint8)))  # homopolymers
+    cases.append((rng.integers(0, 4, 900).astype(np.uint8), rng.integers(0, 4, 800).astype(np.uint8)))  # unrelated
+    try:
+        for q, t in cases:
+            oracle.nw_full_matrix(False)
+            a, da = oracle.nw_breakpoints(q, t, 0, 3, 100)
+            oracle.nw_full_matrix(True)
+            b, db = oracle.nw_breakpoints(q, t, 0, 3, 100)
+            assert da == db and np.array_equal(a, b), (len(q), len(t))
+    finally:
+        oracle.nw_full_matrix(False)
