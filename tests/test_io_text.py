@@ -253,7 +253,7 @@ def test_single_stream_longer_than_the_decoder_buffers(tmp_path):
 
 def test_host_pipeline_under_thread_sanitizer(tmp_path):
     """The inflate pool, the single-stream decoder with its helpers, the slab ring and the scanner built with
-    -fsanitize=thread (tests/cpp/tsan_io.cpp) on a single-member archive, a blocked one and a plain file, slabs of 8 MB,
+    -fsanitize=thread (tests/host/tsan_io.cpp) on a single-member archive, a blocked one and a plain file, slabs of 8 MB,
     70 001 and 1 031 bytes: no race reported, same record counts everywhere."""
     import shutil
     import subprocess
@@ -262,7 +262,7 @@ def test_host_pipeline_under_thread_sanitizer(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     exe = str(tmp_path / "tsan_io")
     build = subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=thread", "-I", os.path.join(root, "raven_amd", "csrc"),
-                            os.path.join(root, "tests", "cpp", "tsan_io.cpp"), "-o", exe, "-lz", "-lpthread"],
+                            os.path.join(root, "tests", "host", "tsan_io.cpp"), "-o", exe, "-lz", "-lpthread"],
                            capture_output=True, text=True)
     if build.returncode != 0 and "sanitize" in build.stderr:
         pytest.skip("this g++ has no ThreadSanitizer runtime")
