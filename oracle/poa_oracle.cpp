@@ -288,6 +288,9 @@ struct Graph {
   }
 };
 
+// (diagnostic, orc_poa_end_tie_rule: 0 = spoa's rule, the first end node in rank order among equal scores; 1 / 2 = the
+// one with the smallest / largest node id — to see what a device rule independent of the row order would give)
+static int g_end_tie_rule = 0;
 // spoa SisdAlignmentEngine::Linear, AlignmentType::kNW
 static Alignment AlignNW(const std::uint8_t* seq, std::uint32_t len, const Graph& graph, std::int8_t m, std::int8_t n,
                          std::int8_t g, std::int32_t* score_out = nullptr) {
@@ -328,7 +331,11 @@ static Alignment AlignNW(const std::uint8_t* seq, std::uint32_t len, const Graph
       }
     }
     for (std::uint32_t j = 1; j < w; ++j) H_row[j] = std::max(H_row[j - 1] + g, H_row[j]);
-    if (node.outedges.empty() && max_score < H_row[w - 1]) {
+    if (node.outedges.empty() &&
+        (max_score < H_row[w - 1] ||
+         (g_end_tie_rule && max_score == H_row[w - 1] && max_i != 0 &&
+          (g_end_tie_rule == 1 ? graph.rank_to_node[i - 1] < graph.rank_to_node[max_i - 1]
+                               : graph.rank_to_node[i - 1] > graph.rank_to_node[max_i - 1])))) {
       max_score = H_row[w - 1];
       max_i = i;
       max_j = w - 1;
@@ -441,6 +448,7 @@ static bool DeviceOrderUpdate(const Graph& graph, std::uint32_t n_old, std::vect
   return true;
 }
 
+static int g_order_where = 3;  // orc_poa_order_where: diagnostic split of device_order
 // racon Window::GenerateConsensus (TGS). layers[0] is the backbone. Returns polished flag.
 // device_order: spoa's DFS rank (Graph::TopologicalSort) is replaced by the device kernels' incremental order wherever
 // the order of the rows can decide a tie — the end node of an alignment, the node a traceback prefers among equal
@@ -448,8 +456,10 @@ static bool DeviceOrderUpdate(const Graph& graph, std::uint32_t n_old, std::vect
 // whether a consensus that differs from spoa's differs because of such a tie and nothing else (tools/poa_parity.py).
 // The graph of a window after all its layers (racon Window::GenerateConsensus up to the consensus call); false if the
 // device order rule broke down.
+// where: 1 = the device's order for the alignments (NW rows, Subgraph rows), 2 = for the consensus, 3 = both (diagnostic
+// split: which of the two decides a tie)
 bool BuildWindowGraph(const std::vector<Layer>& layers, std::int8_t m, std::int8_t n, std::int8_t g, bool device_order,
-                      Graph* out) {
+                      Graph* out, int where = 3) {
   const Layer& bb = layers.front();
   Graph& graph = *out;
   graph = Graph();
@@ -460,6 +470,7 @@ bool BuildWindowGraph(const std::vector<Layer>& layers, std::int8_t m, std::int8
     if (!device_order) return;
     for (std::uint32_t v = 0; v < graph.nodes.size(); ++v) graph.rank_to_node[node_rank[v]] = v;
   };
+  const bool in_alignment = device_order && (where & 1), in_consensus = device_order && (where & 2);
   std::vector<std::uint32_t> rank(layers.size());
   for (std::uint32_t i = 0; i < layers.size(); ++i) rank[i] = i;
   std::stable_sort(rank.begin() + 1, rank.end(),
@@ -472,7 +483,7 @@ bool BuildWindowGraph(const std::vector<Layer>& layers, std::int8_t m, std::int8
       alignment = AlignNW(l.codes, l.len, graph, m, n, g);
     } else {
       std::vector<std::uint32_t> mapping;
-      auto subgraph = graph.Subgraph(l.begin, l.end, &mapping, device_order ? &node_rank : nullptr);
+      auto subgraph = graph.Subgraph(l.begin, l.end, &mapping, in_alignment ? &node_rank : nullptr);
       alignment = AlignNW(l.codes, l.len, subgraph, m, n, g);
       for (auto& it : alignment)
         if (it.first != -1) it.first = mapping[it.first];
@@ -483,9 +494,11 @@ bool BuildWindowGraph(const std::vector<Layer>& layers, std::int8_t m, std::int8
       if (!DeviceOrderUpdate(graph, n_old, &node_rank)) {
         return false;
       }
-      impose();
+      if (in_alignment) impose();
     }
   }
+  if (in_consensus) impose();
+  else if (device_order) graph.TopologicalSort();
   return true;
 }
 
@@ -498,7 +511,7 @@ bool WindowConsensus(const std::vector<Layer>& layers, std::int8_t m, std::int8_
     return false;
   }
   Graph graph;
-  if (!BuildWindowGraph(layers, m, n, g, device_order, &graph)) {
+  if (!BuildWindowGraph(layers, m, n, g, device_order, &graph, g_order_where)) {
     consensus->clear();
     return false;
   }
@@ -718,6 +731,9 @@ int orc_poa_order_check(const std::uint8_t* codes, const std::uint64_t* offsets,
   }
   return -1;
 }
+
+void orc_poa_order_where(int where) { poa::g_order_where = where; }
+void orc_poa_end_tie_rule(int rule) { poa::g_end_tie_rule = rule; }
 
 // DEBUG: the tail of a window's final graph (spoa order or device order): for the last `n_tail` ranks: node id, code,
 // out-degree, heaviest-path score and predecessor BEFORE branch completion, in-edges (tail:weight ...).  Text to stderr.
