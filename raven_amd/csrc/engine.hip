@@ -2018,6 +2018,8 @@ int rvn_test_parse_file(const char* path, int fastq, uint32_t threads, int force
         return RVN_OK;
       } catch (const io::SpeculationFailed&) {
         if (attempt == 1) return fail(RVN_EINVAL, "[bioparser] error: corrupt or truncated file");
+      } catch (const std::invalid_argument&) {  // (as reads_load: only the zlib attempt reports an error)
+        if (attempt == 1) throw;
       }
     }
     return RVN_OK;

@@ -328,9 +328,19 @@ void reads_load(Engine& e, const std::string& path, ReadsDev& R, std::vector<std
     coder_table(table);
     RVN_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_coder), table, 256));
   }
+  // The first attempt speculates (member cuts, this repository's own decoder for a single stream).  Whatever goes wrong
+  // there — a cut that was no member boundary, a member that does not verify, but also a record or a character the
+  // scanner / the device refuse in text that speculation produced — is settled by the second attempt: zlib, front to back.
+  // An error is only ever reported from that one (or from a first attempt that found nothing to doubt).
+  bool again = false;
   try {
     load_once(e, path, fastq, false, R, names, st);
-  } catch (const io::SpeculationFailed&) {  // a cut that was no member boundary (or a damaged member): front to back tells
+  } catch (const io::SpeculationFailed&) {
+    again = true;
+  } catch (const std::invalid_argument&) {
+    again = true;
+  }
+  if (again) {
     try {
       load_once(e, path, fastq, true, R, names, st);
     } catch (const io::SpeculationFailed&) {
