@@ -358,11 +358,16 @@ def antiqsort(n: int) -> np.ndarray:
     return out
 
 
-def poa_window(layers, begins=None, ends=None, quals=None, m=3, n=-5, g=-4, trim=True, device_order=False):
+def poa_window(layers, begins=None, ends=None, quals=None, m=3, n=-5, g=-4, trim=True, device_order=False, end_tie=0,
+               order_where=0):
     """racon Window::GenerateConsensus: layers = list of uint8 code arrays (layers[0] = backbone), begins/ends =
     backbone positions of each layer (ignored for the backbone), quals = list of uint8 Phred+33 arrays or None.
     device_order: the rows of the graph in the device kernels' incremental order instead of spoa's DFS rank (another
     valid topological order: only ties between equal scores can come out differently).
+    end_tie: the end node of a layer's alignment among equal scores: 0 = spoa's rule (first in rank order), 1 = smallest
+    node id (the device kernels' rule), 2 = largest.  device_order=True, end_tie=1 is the statement of what the device
+    kernels compute.  order_where (diagnostic): 1 / 2 = the device's order in the alignments / in the consensus only.
+    Both settings apply to this call only.
     Returns (consensus codes, polished flag)."""
     k = len(layers)
     off = np.zeros(k + 1, dtype=np.uint64)
@@ -377,7 +382,7 @@ def poa_window(layers, begins=None, ends=None, quals=None, m=3, n=-5, g=-4, trim
     cap = int(off[-1]) + 16
     out = np.zeros(cap, dtype=np.uint8)
     n_out = C.c_uint32(0)
-    polished = lib().orc_poa_window(_p(codes), _p(q), _p(off), _p(b), _p(e), k, m, n, g, int(trim) | (2 if device_order else 0), _p(out), cap,
+    polished = lib().orc_poa_window(_p(codes), _p(q), _p(off), _p(b), _p(e), k, m, n, g, int(trim) | (2 if device_order else 0) | ((end_tie & 3) << 2) | ((order_where & 3) << 4), _p(out), cap,
                                     C.byref(n_out))
     if polished < 0:
         raise ValueError("[racon::Window::AddLayer] error: layer begin and end positions are invalid!")

@@ -288,9 +288,11 @@ struct Graph {
   }
 };
 
-// (diagnostic, orc_poa_end_tie_rule: 0 = spoa's rule, the first end node in rank order among equal scores; 1 / 2 = the
-// one with the smallest / largest node id — to see what a device rule independent of the row order would give)
-static int g_end_tie_rule = 0;
+// End node of an alignment among equal scores: 0 = spoa's rule, the first end node in rank order; 1 / 2 = the one with the
+// smallest / largest node id.  1 is what the device kernels do since round 5 (a rule that does not depend on the order of
+// the rows; with the device's row order it reproduces spoa's consensus on 19 998 of 20 000 C4-like windows, rule 0 in
+// that order on 19 948).  Per CALL and per thread: set from the flags word of orc_poa_window, restored when it returns.
+static thread_local int g_end_tie_rule = 0;
 // spoa SisdAlignmentEngine::Linear, AlignmentType::kNW
 static Alignment AlignNW(const std::uint8_t* seq, std::uint32_t len, const Graph& graph, std::int8_t m, std::int8_t n,
                          std::int8_t g, std::int32_t* score_out = nullptr) {
@@ -448,7 +450,7 @@ static bool DeviceOrderUpdate(const Graph& graph, std::uint32_t n_old, std::vect
   return true;
 }
 
-static int g_order_where = 3;  // orc_poa_order_where: diagnostic split of device_order
+static thread_local int g_order_where = 3;  // diagnostic split of device_order (flags word of orc_poa_window): 1 = alignments, 2 = consensus
 // racon Window::GenerateConsensus (TGS). layers[0] is the backbone. Returns polished flag.
 // device_order: spoa's DFS rank (Graph::TopologicalSort) is replaced by the device kernels' incremental order wherever
 // the order of the rows can decide a tie — the end node of an alignment, the node a traceback prefers among equal
@@ -561,6 +563,20 @@ int orc_poa_window(const std::uint8_t* codes, const std::uint8_t* quals, const s
   // racon Window::AddLayer rejects begin >= end and positions beyond the backbone
   for (std::uint32_t i = 1; i < n_layers; ++i)
     if (layers[i].len && (begins[i] >= ends[i] || ends[i] >= layers[0].len)) return -1;
+  // flags word `trim`: bit 0 = racon's coverage trim, bit 1 = the device's row order, bits 2-3 = end-node tie rule
+  // (0 spoa's, 1 smallest node id, 2 largest), bits 4-5 = where the device's order applies (0 = everywhere, 1 = in the
+  // alignments only, 2 = in the consensus only).  The two diagnostic settings live for this call on this thread only.
+  struct Knobs {
+    int tie, where;
+    Knobs(int t, int w) : tie(poa::g_end_tie_rule), where(poa::g_order_where) {
+      poa::g_end_tie_rule = t;
+      poa::g_order_where = w ? w : 3;
+    }
+    ~Knobs() {
+      poa::g_end_tie_rule = tie;
+      poa::g_order_where = where;
+    }
+  } knobs((trim >> 2) & 3, (trim >> 4) & 3);
   std::vector<std::uint8_t> cons;
   bool polished = poa::WindowConsensus(layers, m, n, g, (trim & 1) != 0, &cons, nullptr, (trim & 2) != 0);
   *out_len = cons.size();
@@ -732,8 +748,6 @@ int orc_poa_order_check(const std::uint8_t* codes, const std::uint64_t* offsets,
   return -1;
 }
 
-void orc_poa_order_where(int where) { poa::g_order_where = where; }
-void orc_poa_end_tie_rule(int rule) { poa::g_end_tie_rule = rule; }
 
 // DEBUG: the tail of a window's final graph (spoa order or device order): for the last `n_tail` ranks: node id, code,
 // out-degree, heaviest-path score and predecessor BEFORE branch completion, in-edges (tail:weight ...).  Text to stderr.

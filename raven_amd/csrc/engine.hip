@@ -260,16 +260,32 @@ void* alloc(size_t bytes) {
   size_t off = 0;
   return a->list.alloc(bytes, &off) ? a->base + off : nullptr;
 }
+// The arena a pointer lies in, whatever device is current (one virtual address space for all devices of the process): a
+// buffer carved from device i's arena may be released while device j is current — a worker's error path, a handle
+// destroyed from the main thread — and must go back to ITS arena, not be mistaken for a driver allocation.
+namespace {
+int owner_of(const void* p) {
+  for (int d = 0; d < kMaxDevices; ++d)
+    if (inside(g_arena[d], p)) return d;
+  return -1;
+}
+}  // namespace
 bool give_back(void* p) {
+  int owner = -1;
   {
     std::lock_guard<std::mutex> lk(g_mu);
-    const Arena* a = mine();
-    if (!a || !inside(*a, p) || !a->list.owns(offset_of(*a, p))) return false;
+    owner = owner_of(p);
+    if (owner < 0 || !g_arena[owner].list.owns(offset_of(g_arena[owner], p))) return false;
   }
-  (void)hipDeviceSynchronize();  // what hipFree does implicitly: nobody still reads the block when the next owner writes
+  // what hipFree does implicitly: nobody still reads the block when the next owner writes (the owning device's queues)
+  int cur = 0;
+  (void)hipGetDevice(&cur);
+  if (cur != owner) (void)hipSetDevice(owner);
+  (void)hipDeviceSynchronize();
+  if (cur != owner) (void)hipSetDevice(cur);
   std::lock_guard<std::mutex> lk(g_mu);
-  Arena* a = mine();
-  return a && inside(*a, p) && a->list.release(offset_of(*a, p));
+  Arena& a = g_arena[owner];
+  return inside(a, p) && a.list.release(offset_of(a, p));
 }
 size_t free_total() {
   std::lock_guard<std::mutex> lk(g_mu);

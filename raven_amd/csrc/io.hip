@@ -111,7 +111,7 @@ bool has_suffix(const std::string& s, const char* suf) {
 namespace {
 
 // One pass over the file.  streaming: one inflate thread front to back (second attempt after a wrong member cut).
-void load_once(Engine& e, const std::string& path, bool fastq, bool streaming, ReadsDev& R, std::vector<std::string>& names,
+void load_once(Engine& e, const std::string& path, bool fastq, bool streaming, bool& speculated, ReadsDev& R, std::vector<std::string>& names,
                LoadStats& st) {
   auto secs = [](std::chrono::steady_clock::time_point a) {
     return std::chrono::duration<double>(std::chrono::steady_clock::now() - a).count();
@@ -134,7 +134,11 @@ void load_once(Engine& e, const std::string& path, bool fastq, bool streaming, R
     for (auto& slot : e.io_pin)
       if (slot.first->ptr == p) slot.second = false;
   };
+  speculated = false;
   io::TextSource src(path, opt);
+  // did this attempt speculate?  (member cuts, or this repository's own decoder on a single stream: only then can an
+  // error be the speculation's fault and a second attempt tell anything new)
+  speculated = src.gzip() && (!src.streaming() || src.fast_stream());
   io::RecordScanner scanner(fastq);
 
   names.clear();
@@ -332,17 +336,21 @@ void reads_load(Engine& e, const std::string& path, ReadsDev& R, std::vector<std
   // there — a cut that was no member boundary, a member that does not verify, but also a record or a character the
   // scanner / the device refuse in text that speculation produced — is settled by the second attempt: zlib, front to back.
   // An error is only ever reported from that one (or from a first attempt that found nothing to doubt).
-  bool again = false;
+  bool again = false, speculated = false;
   try {
-    load_once(e, path, fastq, false, R, names, st);
+    load_once(e, path, fastq, false, speculated, R, names, st);
   } catch (const io::SpeculationFailed&) {
     again = true;
   } catch (const std::invalid_argument&) {
+    // a plain file, a file that cannot be opened, or a gzip stream zlib itself was reading: nothing was speculated, the
+    // error is the input's and a second pass would only reproduce it
+    if (!speculated) throw;
     again = true;
   }
   if (again) {
+    bool unused = false;
     try {
-      load_once(e, path, fastq, true, R, names, st);
+      load_once(e, path, fastq, true, unused, R, names, st);
     } catch (const io::SpeculationFailed&) {
       throw std::invalid_argument("[bioparser] error: corrupt or truncated file");
     }

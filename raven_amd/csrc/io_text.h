@@ -495,6 +495,12 @@ class TextSource {
   void fast_stream_all() {
     constexpr u64 kHist = 32768, kBuf = 8ULL << 20;
     const u32 n_help = std::max(1u, opt_.stream_helpers);
+    // (order of declaration = reverse order of destruction: the buffers and the piece lists the helpers work on are
+    // declared BEFORE the guard that joins the helpers, so on every exit — an error, a stop request, a trailer that does
+    // not match — the helpers have returned before anything they may still read or write goes out of scope)
+    std::vector<u8> lin[2];
+    for (auto& v : lin) v.resize(kHist + kBuf + FastInflate::kOutMargin + 64);
+    std::vector<Piece> pieces[2];
     std::vector<std::thread> helpers;
     struct Stop {
       TextSource* t;
@@ -503,6 +509,7 @@ class TextSource {
         {
           std::lock_guard<std::mutex> lk(t->hmu_);
           t->hstop_ = true;
+          t->hqueue_.clear();  // pieces nobody has started are dropped; one in progress is finished before the join returns
         }
         t->hcv_.notify_all();
         for (std::thread& x : *h)
@@ -510,9 +517,6 @@ class TextSource {
       }
     } stop{this, &helpers};
     for (u32 i = 0; i < n_help; ++i) helpers.emplace_back([this] { helper_loop(); });
-    std::vector<u8> lin[2];
-    for (auto& v : lin) v.resize(kHist + kBuf + FastInflate::kOutMargin + 64);
-    std::vector<Piece> pieces[2];
     auto wait_pieces = [&](std::vector<Piece>& ps) {
       std::unique_lock<std::mutex> lk(hmu_);
       hdone_.wait(lk, [&] {

@@ -196,7 +196,7 @@ __device__ u32 poa_window(const PoaWindow& win, const PoaLayer* __restrict__ lay
     for (u32 j = lane; j < w; j += 64) g.H[j] = static_cast<i16>(static_cast<i32>(j) * gp);
     wsync();
     i32 best_score = -0x7FFFFFFF;
-    u32 best_row = 0;
+    u32 best_row = 0, best_node = 0;  // end node: equal scores -> smallest node id (as poa2.hip / poa4.hip)
     // the row computed last stays in registers (lane l holds columns c*64+l): it is the predecessor of most
     // rows, so the common case needs no global load and no store->load fence
     i32 lastrow[kPoaMaxSeq / 64 + 1];
@@ -313,9 +313,10 @@ __device__ u32 poa_window(const PoaWindow& win, const PoaLayer* __restrict__ lay
       const u32 outc = static_cast<u32>(__shfl(m_outc, static_cast<int>(ri), 64));
       if (outc == 0) {
         const i32 sc = end_score;
-        if (sc > best_score) {
+        if (sc > best_score || (sc == best_score && best_row != 0 && v < best_node)) {
           best_score = sc;
           best_row = row;
+          best_node = v;
         }
       }
      }

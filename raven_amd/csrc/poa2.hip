@@ -265,7 +265,7 @@ __device__ __forceinline__ u32 poa2_window(const PoaWindow& win, const PoaLayer*
     const i32 lb = static_cast<i32>(L.begin);
     const i32 span = static_cast<i32>(L.end) - static_cast<i32>(L.begin) + 1;
     i32 best_score = -0x7FFFFFFF;
-    u32 best_row = 0;
+    u32 best_row = 0, best_node = 0;  // end node: best score of the last column, equal scores -> smallest node id
     int ring_tag = 0, ring_b = 0;  // lane s describes ring slot s: row stored there (0 = none), its band start
     u32 last_row = 0xFFFFFFFFu;  // NCH == 1: the row computed last, its band start and its cells (one per lane)
     i32 last_b = 0, last_h = 0;
@@ -424,9 +424,11 @@ __device__ __forceinline__ u32 poa2_window(const PoaWindow& win, const PoaLayer*
           if (meta & 256) {  // an end node: score of the last column if the band has it
             const i32 idx = static_cast<i32>(w) - 1 - b;
             const i32 sce = (idx >= 0 && idx < 64) ? rl(hh, idx) : -0x7FFFFFFF;
-            if (sce > best_score) {
+            const u32 vnode = static_cast<u32>(rl(m_v, ri));
+            if (sce > best_score || (sce == best_score && best_row != 0 && vnode < best_node)) {
               best_score = sce;
               best_row = row;
+              best_node = vnode;
             }
           }
         }
@@ -545,9 +547,11 @@ __device__ __forceinline__ u32 poa2_window(const PoaWindow& win, const PoaLayer*
 #pragma unroll
           for (int c = 0; c < NCH; ++c)
             if (idx >= 64 * c && idx < 64 * (c + 1)) sce = rl(h[c], idx - 64 * c);  // that chunk is active: idx < w - b
-          if (sce > best_score) {
+          const u32 vnode = static_cast<u32>(rl(m_v, static_cast<int>(ri)));
+          if (sce > best_score || (sce == best_score && best_row != 0 && vnode < best_node)) {
             best_score = sce;
             best_row = row;
+            best_node = vnode;
           }
         }
       }

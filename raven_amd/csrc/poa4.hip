@@ -400,9 +400,10 @@ __host__ __device__ inline void poa4_dp(const Poa4Args A, Poa4Lds& S, unsigned c
           const i32 idx = static_cast<i32>(len) - static_cast<i32>((c1 >> 16) & 0x3FFu);
           if (idx >= 0 && idx < K::kBand) {
             const i32 sce = lds_ld16(S, (c0 >> 16) + 2u * static_cast<u32>(idx));
-            if (sce > best_score || (sce == best_score && cur_rho + 1 < best_row)) {
+            const u32 cand = ((c1 & 0xFFFFu) << 16) | (cur_rho + 1);  // node id | 1 + row: equal scores -> smallest node id
+            if (sce > best_score || (sce == best_score && cand < best_row)) {
               best_score = sce;
-              best_row = cur_rho + 1;
+              best_row = cand;
             }
           }
         }
@@ -500,19 +501,21 @@ __host__ __device__ inline void poa4_dp(const Poa4Args A, Poa4Lds& S, unsigned c
       const i32 idx = static_cast<i32>(len) - static_cast<i32>((c1 >> 16) & 0x3FFu);
       if (idx >= 0 && idx < K::kBand) {
         const i32 sce = lds_ld16(S, (c0 >> 16) + 2u * static_cast<u32>(idx));
-        if (sce > best_score || (sce == best_score && cur_rho + 1 < best_row)) {
+        const u32 cand = ((c1 & 0xFFFFu) << 16) | (cur_rho + 1);
+        if (sce > best_score || (sce == best_score && cand < best_row)) {
           best_score = sce;
-          best_row = cur_rho + 1;
+          best_row = cand;
         }
       }
     }
   }
-  // the first row (lowest rank) among the end nodes with the best score, as poa2's rank-order scan picks it
+  // among the end nodes with the best score the one with the SMALLEST NODE ID (a rule that does not depend on the order of
+  // the rows: spoa takes the first in ITS rank order, which is not the device's), as poa2 / poa pick it
   {
     const i32 gs = group_max_i(best_score);
     const u32 cand = (best_score == gs && best_row != 0) ? best_row : 0xFFFFFFFFu;
     const u32 br = group_min_u(cand);
-    best_rho1 = (act && br != 0xFFFFFFFFu) ? br : 0u;
+    best_rho1 = (act && br != 0xFFFFFFFFu) ? (br & 0xFFFFu) : 0u;
     if (sv::any(sched_bad)) {
       const u32 any_bad = static_cast<u32>(sv::ballot(sched_bad) >> (lane & ~15)) & 0xFFFFu;
       if (any_bad) best_rho1 = 0;  // (reported as a band miss: the 64-column kernel takes the window)

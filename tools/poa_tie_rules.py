@@ -8,7 +8,7 @@ windows of tools/poa_parity.py's seeded set.
 2. of those: is it the order during the ALIGNMENTS (end node among equal scores, Subgraph rows) or in the CONSENSUS
    (start of the heaviest bundle, branch completion) that decides;
 3. the same comparison with the end node of an alignment chosen by SMALLEST NODE ID among equal scores instead of by
-   rank (orc_poa_end_tie_rule(1)) in the device-order run."""
+   rank (oracle.poa_window(..., end_tie=1): since round 5 the device kernels' rule) in the device-order run."""
 import json
 import os
 import sys
@@ -28,15 +28,15 @@ def main():
     threads = int(sys.argv[2]) if len(sys.argv) > 2 else (os.cpu_count() or 1)
     rng = np.random.default_rng(20260927)
     wins = [pp.make_window(rng)[0] for _ in range(n)]
-    L = oracle.lib()
 
-    def cons(i, device_order):
+    def cons(i, device_order, end_tie=0, order_where=0):
         w = wins[i]
-        return oracle.poa_window(w["layers"], begins=w["begins"], ends=w["ends"], device_order=device_order)[0]
+        return oracle.poa_window(w["layers"], begins=w["begins"], ends=w["ends"], device_order=device_order, end_tie=end_tie,
+                                 order_where=order_where)[0]
 
-    def run(idx, device_order):
+    def run(idx, device_order, end_tie=0, order_where=0):
         with ThreadPoolExecutor(max_workers=threads) as ex:  # (the oracle releases the GIL inside its C++ call)
-            return list(ex.map(lambda i: cons(i, device_order), idx))
+            return list(ex.map(lambda i: cons(i, device_order, end_tie, order_where), idx))
 
     t0 = time.time()
     every = list(range(n))
@@ -46,14 +46,10 @@ def main():
     out = {"windows": n, "differ_between_the_orders": len(differ), "which": differ}
     by_alignment = by_consensus = 0
     for where, name in ((1, "alignments"), (2, "consensus")):
-        L.orc_poa_order_where(where)
-        part = run(differ, True)
-        L.orc_poa_order_where(3)
+        part = run(differ, True, 0, where)
         same = sum(bool(np.array_equal(part[k], dev[i])) for k, i in enumerate(differ))
         out["device_order_in_the_%s_alone_gives_the_device_consensus" % name] = same
-    L.orc_poa_end_tie_rule(1)
-    dev_id = run(every, True)
-    L.orc_poa_end_tie_rule(0)
+    dev_id = run(every, True, 1)
     left = [i for i in every if not np.array_equal(spoa[i], dev_id[i])]
     out["differ_with_end_node_by_smallest_id"] = len(left)
     out["which_with_end_node_by_smallest_id"] = left
