@@ -97,6 +97,7 @@ struct Poa4Slot {
   uint4* desc;   // 2 per row: {S | own << 16, node | b << 16 | np << 26 | marked << 30 | end << 31, match mask, e0 | e1 << 16},
                  //            {e2 | e3 << 16, e4 | e5 << 16, e6 | e7 << 16, rank distances of in-edges 0..5 (5 bits each)}
   u32* rb;       // per node: rank | backbone coordinate << 16 (kept by the set-up and by poa4_update_graph)
+  u32* rbl;      // per node, for the CURRENT layer: rank | band start << 16 (first pass of the descriptor phase)
   uint4* bps;    // backpointer stream: [step / 8][lane of the window] 16 bytes = 8 steps x 2 columns
   u32* seq2g;    // the current layer: [0, 60) 2 bits per base, [64, 96) its band guide as eight segments (set-up kernel ->
                  // descriptor / graph update kernels)
@@ -106,7 +107,7 @@ __host__ __device__ inline u32 poa4_steps(u32 nmax, u32 lmax) { return nmax + nm
 inline size_t poa4_slot_bytes(u32 nmax, u32 lmax) {
   size_t b = poa2_slot_bytes(nmax, lmax, 0, false);
   b += static_cast<size_t>(poa4_desc_rows(nmax)) * 32;
-  b += (static_cast<size_t>(nmax) * 4 + 255) & ~size_t(255);
+  b += 2 * ((static_cast<size_t>(nmax) * 4 + 255) & ~size_t(255));
   b += (static_cast<size_t>(poa4_steps(nmax, lmax)) / P4::kU + 2) * 16 * 16;
   b += 512;
   return (b + 255) & ~size_t(255);
@@ -119,6 +120,8 @@ __host__ __device__ inline Poa4Slot poa4_carve(unsigned char* base, u32 nmax, u3
   s.desc = reinterpret_cast<uint4*>(base + o);
   o += static_cast<size_t>(poa4_desc_rows(nmax)) * 32;
   s.rb = reinterpret_cast<u32*>(base + o);
+  o += (static_cast<size_t>(nmax) * 4 + 255) & ~size_t(255);
+  s.rbl = reinterpret_cast<u32*>(base + o);
   o += (static_cast<size_t>(nmax) * 4 + 255) & ~size_t(255);
   s.bps = reinterpret_cast<uint4*>(base + o);
   o += (static_cast<size_t>(poa4_steps(nmax, lmax)) / P4::kU + 2) * 16 * 16;
@@ -556,7 +559,6 @@ __host__ __device__ inline void poa4_traceback(const Poa4Args A, Poa4LdsTb& S, u
   bool done = !act || i == 0;
   u32 steps = 0, n_switch = 0;
   unsigned long long t_change = 0;
-  const u32 max_steps = A.nmax + A.lmax + 2;
   // the next round (descriptors and codes in flight), the round after (descriptors in flight)
   u32 nd0[kTbG] = {}, nd1[kTbG] = {}, nd7[kTbG] = {}, fd0[kTbG] = {}, fd1[kTbG] = {}, fd7[kTbG] = {};
   // (native vectors, not HIP's uint4 class: arrays of the latter stay in scratch memory when passed by reference)
@@ -634,54 +636,42 @@ __host__ __device__ inline void poa4_traceback(const Poa4Args A, Poa4LdsTb& S, u
     }
     t_change += sv::clock() - tc0;
     // ---- the walk through the round's rows: every lane of the window does the same ----
+    // One step = the row's record and the code under column j out of LDS (two dependent reads), then straight-line
+    // selects: the four windows of a wave are in different cases at every step, so any branch here is taken by somebody
+    // and all of them would be executed anyway.  Every step lowers i + j, so the walk ends without a step counter.
     bool in_round = !done;
     while (sv::any(in_round)) {
       P4_MARK("tb_step_begin");
+      const u32 l = (i - 1) & (16 * kTbG - 1);
+      const uint4 d = S.row[q][l][3];
+      const i32 bt = static_cast<i32>((d.y >> 16) & 0x3FFu);
+      const u32 node = d.y & 0xFFFFu;
+      const i32 idx = j - bt;
+      const bool oob = static_cast<u32>(idx) >= static_cast<u32>(K::kBand);  // the path left the stored band
+      const u32 bo = ((d.x & 0xFFFFu) % K::kU) * 2 + (static_cast<u32>(idx) & static_cast<u32>(K::kBand - 1));  // byte among the row's 48
+      const u32 code = reinterpret_cast<const u8*>(S.row[q][l])[bo];
+      const bool edge_hit = (idx < 2 && bt > 0) || (idx > K::kBand - 3 && bt + K::kBand < static_cast<i32>(w));
+      const bool isH = code == 64u;
+      const bool diag = !isH && (code & 32u) != 0;
+      const u32 k = 15u - (code & 15u);
+      const u32 np = (d.y >> 26) & 15u;
+      u32 ni = np == 0 ? 0u : i - ((d.z >> (5 * (k < 6 ? k : 0u))) & 31u);
+      if (sv::any(in_round && !oob && !isH && np != 0 && k >= 6)) {  // in-edges 6 and 7 of a row: their ranks come from the graph
+        if (in_round && !oob && !isH && np != 0 && k >= 6)
+          ni = poa4_nth_pred_rank(poa4_carve(opaque(slot_mem), A.nmax, A.lmax).g, node, k, full) - r_lo + 1;
+      }
+      const bool mv = isH || diag;                  // the step consumes a base of the layer
+      const bool jerr = !oob && mv && j == 0;       // (never on a consistent stream)
+      const bool stop = oob || jerr;
       if (in_round) {
-        const u32 l = (i - 1) & (16 * kTbG - 1);
-        const uint4 d = S.row[q][l][3];
-        const i32 bt = static_cast<i32>((d.y >> 16) & 0x3FFu);
-        const u32 node = d.y & 0xFFFFu;
-        const i32 idx = j - bt;
-        if (++steps > max_steps) {
-          bad = 6;
-          done = true;
-        } else if (idx < 0 || idx >= K::kBand) {  // the path left the stored band: the alignment does not fit this band width
-          band_hit = 1;
-          done = true;
-        } else {
-          if ((idx < 2 && bt > 0) || (idx > K::kBand - 3 && bt + K::kBand < static_cast<i32>(w))) band_hit = 1;
-          const u32 bo = ((d.x & 0xFFFFu) % K::kU) * 2 + static_cast<u32>(idx);  // byte among the row's 48
-          const u32 code = reinterpret_cast<const u8*>(S.row[q][l])[bo];
-          if (code == 64u) {
-            if (j == 0) {
-              bad = 6;
-              done = true;
-            } else {
-              --j;  // insertion: pos_node[j] stays kNone
-            }
-          } else {
-            const u32 k = 15u - (code & 15u);
-            const u32 np = (d.y >> 26) & 15u;
-            u32 ni;
-            if (np == 0) ni = 0;
-            else if (k < 6) ni = i - ((d.z >> (5 * k)) & 31u);
-            else ni = poa4_nth_pred_rank(poa4_carve(opaque(slot_mem), A.nmax, A.lmax).g, node, k, full) - r_lo + 1;
-            if (code & 32u) {  // diagonal
-              if (j == 0) {
-                bad = 6;
-                done = true;
-              } else {
-                --j;
-                if (gl == 0) pos_node[j] = static_cast<u16>(node);
-              }
-            }
-            if (!done) {
-              i = ni;
-              if (i == 0) done = true;  // on the virtual row only insertions remain: pos_node already says kNone
-            }
-          }
-        }
+        ++steps;
+        if (oob || edge_hit) band_hit = 1;
+        if (jerr) bad = 6;
+        if (diag && !stop && gl == 0) pos_node[j - 1] = static_cast<u16>(node);  // (an insertion leaves pos_node[j] at kNone)
+        j -= (mv && !stop) ? 1 : 0;
+        const bool row_move = !stop && !isH;
+        i = row_move ? ni : i;
+        done = stop || (row_move && ni == 0);  // on the virtual row only insertions remain: pos_node already says kNone
         in_round = !done && (i - 1) / (16 * kTbG) == c_rnd;
       }
       P4_MARK("tb_step_end");
@@ -1398,6 +1388,7 @@ __host__ __device__ inline void poa4_phase_setup(const Poa4Args& A, const Poa4Ct
   const int q = static_cast<int>(rec % P4::G);
   if (poa4_my_record(C, wave_dp, q) == 0xFFFFFFFFu) return;
   Poa4Win me = C.st[rec];
+  sv::sync();  // (read by every lane before lane 0 stores the new state)
   if (me.phase != kRunning) return;
   const unsigned long long t0 = sv::clock();
   const PoaWindow wq = A.windows[me.wi];
@@ -1632,6 +1623,197 @@ __host__ __device__ inline void poa4_phase_desc(const Poa4Args& A, const Poa4Ctx
   }
 }
 
+// The same descriptors by ONE wave per window, in two passes (the graph kernel of round 5).  Pass 1 streams over the nodes
+// and leaves rank | band start of every node for THIS layer in rbl[]; pass 2 builds the descriptors and takes an in-edge
+// tail's rank and band start from rbl[] with one gather — the band start of a tail is no longer recomputed per edge
+// (that was nine evaluations of the guide per node), and in-edges beyond the largest in-degree of the 256 nodes in
+// flight are not looked at at all.
+template <class K>
+__host__ __device__ inline void poa4_phase_desc_onewave(const Poa4Args& A, const Poa4Ctx& C, Poa4LdsDesc& S, u32 rec) {
+  const int lane = sv::lane();
+  const u32 wave_dp = rec / P4::G;
+  const int q = static_cast<int>(rec % P4::G);
+  if (poa4_my_record(C, wave_dp, q) == 0xFFFFFFFFu) return;
+  const Poa4Slot sl = poa4_carve(poa4_slot_of(A, C, wave_dp, q), A.nmax, A.lmax);
+  const Poa2Slot& g = sl.g;
+  const Poa4Win me = C.st[rec];
+  if (me.phase != kRunning || !me.act) return;
+  const u32 nn = me.nn;
+  const bool full = me.full != 0;
+  const u32 len = me.len, r_lo = me.r_lo, n_rows = me.n_rows, r_hi = r_lo + n_rows;
+  const i32 lb = static_cast<i32>(me.lb), span = static_cast<i32>(me.span), b_first = static_cast<i32>(me.b_first);
+  const u32 span_magic = magic_of(static_cast<u32>(span > 0 ? span : 1));
+  const u32 ring_off = static_cast<u32>(offsetof(Poa4Lds, g)) + static_cast<u32>(q) * static_cast<u32>(sizeof(Poa4Group));
+  const u32 dump_off = ring_off + static_cast<u32>(offsetof(Poa4Group, dump));
+  const u32 neg_off = static_cast<u32>(offsetof(Poa4Lds, neg));
+  const u32 neg2 = neg_off | (neg_off << 16);
+  u32 flag = 0, marked_rows = 0;
+  i32 t_end = 0;
+  {  // the layer's packed codes and guide into LDS
+    const u32 gw = sl.seq2g[lane < 60 ? lane : 64 + (lane - 60)];
+    const u32 gw2 = lane < 28 ? sl.seq2g[68 + lane] : 0u;
+    if (lane < 60) S.seq2[lane] = gw;
+    else S.segtab[lane - 60] = gw;
+    if (lane < 28) S.segtab[4 + lane] = gw2;
+  }
+  lds_order();
+  // ---- pass 1: rank | band start of every node ----
+  for (u32 v0 = 0; v0 < nn; v0 += 64 * kDescPer) {
+    u32 rbv[kDescPer];
+#pragma unroll
+    for (int u = 0; u < kDescPer; ++u) {
+      const u32 v = v0 + static_cast<u32>(u) * 64 + static_cast<u32>(lane);
+      rbv[u] = v < nn ? sl.rb[v] : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < kDescPer; ++u) {
+      const u32 v = v0 + static_cast<u32>(u) * 64 + static_cast<u32>(lane);
+      if (v < nn) {
+        const i32 b = poa4_band_start<K>(S, static_cast<i32>(rbv[u] >> 16), lb, span, span_magic, len);
+        sl.rbl[v] = (rbv[u] & 0xFFFFu) | (static_cast<u32>(b) << 16);
+      }
+    }
+  }
+  sv::sync();  // rbl[]: written above by this wave, gathered below
+  // ---- pass 2: the descriptors ----
+  for (u32 v0 = 0; v0 < nn; v0 += 64 * kDescPer) {
+    u32 vv[kDescPer], rbv[kDescPer], cc[kDescPer], code[kDescPer], outc_f[kDescPer], outc_s[kDescPer], mk[kDescPer];
+    uint4 tl[kDescPer];
+#pragma unroll
+    for (int u = 0; u < kDescPer; ++u) {
+      vv[u] = v0 + static_cast<u32>(u) * 64 + static_cast<u32>(lane);
+      const u32 vq = vv[u] < nn ? vv[u] : 0u;
+      rbv[u] = sl.rbl[vq];
+      cc[u] = g.in_cnt[vq];
+      code[u] = g.code[vq];
+      outc_f[u] = g.out_cnt[vq];
+      outc_s[u] = full ? 0u : g.sub_out[vq];
+      mk[u] = full ? 1u : g.mark[vq];
+      tl[u] = *reinterpret_cast<const uint4*>(g.in_tail + static_cast<size_t>(vq) * kPoaMaxIn);
+    }
+    bool ok[kDescPer], marked[kDescPer];
+    u32 cmax = 0;
+#pragma unroll
+    for (int u = 0; u < kDescPer; ++u) {
+      const u32 r = rbv[u] & 0xFFFFu;
+      ok[u] = vv[u] < nn && r >= r_lo && r < r_hi;
+      marked[u] = ok[u] && mk[u] != 0;
+      if (!marked[u]) cc[u] = 0;
+      cmax = cc[u] > cmax ? cc[u] : cmax;
+    }
+    cmax = static_cast<u32>(sv::wave_max(static_cast<i32>(cmax)));  // in-edges anybody of this turn has (uniform)
+    u32 trb[kDescPer][8], tmk[kDescPer][8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      if (static_cast<u32>(k) < cmax) {
+#pragma unroll
+        for (int u = 0; u < kDescPer; ++u) {
+          const u32 wd = k < 2 ? tl[u].x : (k < 4 ? tl[u].y : (k < 6 ? tl[u].z : tl[u].w));
+          const u32 t = static_cast<u32>(k) < cc[u] ? (wd >> (16 * (k & 1))) & 0xFFFFu : 0u;
+          trb[u][k] = sl.rbl[t];
+          tmk[u][k] = full ? 1u : g.mark[t];
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < kDescPer; ++u) {
+          trb[u][k] = 0;
+          tmk[u][k] = 0;
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kDescPer; ++u) {
+      const u32 v = vv[u];
+      const u32 r = rbv[u] & 0xFFFFu;
+      const i32 b = static_cast<i32>(rbv[u] >> 16);
+      const u32 rho = r - r_lo;
+      u32 ep[4] = {neg2, neg2, neg2, neg2};
+      u32 np = 0, lbw = 0;
+      auto edge = [&](u32 rbt, bool inside) {
+        if (!inside) return;
+        const u32 lbk = r - (rbt & 0xFFFFu);
+        const i32 d = b - static_cast<i32>(rbt >> 16);
+        if (lbk < 1 || lbk > static_cast<u32>(K::kRing - 1) || lbk > rho || d < 0 || d > K::kMaxD) {
+          flag = 7;
+        } else if (np < static_cast<u32>(K::kEdges)) {
+          const u32 e = ring_off + ((rho - lbk) % static_cast<u32>(K::kRing)) * static_cast<u32>(K::kRowB) + 2u * static_cast<u32>(d);
+          const u32 idx = np >> 1;
+          const u32 keep = (np & 1) ? 0x0000FFFFu : 0xFFFF0000u;
+          const u32 put = (np & 1) ? e << 16 : e;
+#pragma unroll
+          for (u32 i = 0; i < 4; ++i) ep[i] = i == idx ? ((ep[i] & keep) | put) : ep[i];
+          if (np < 6) lbw |= lbk << (5 * np);
+        }
+        ++np;
+      };
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (static_cast<u32>(k) < cmax) edge(trb[u][k], static_cast<u32>(k) < cc[u] && tmk[u][k] != 0);
+      for (u32 k = 8; k < cc[u]; ++k) {  // rare
+        const u32 t = g.in_tail[static_cast<size_t>(v) * kPoaMaxIn + k];
+        edge(sl.rbl[t], full || g.mark[t] != 0);
+      }
+      if (np > static_cast<u32>(K::kEdges)) flag = 3;
+      if (ok[u]) {
+        // match mask of the row's 32 columns against the layer
+        u32 mm = 0;
+        {
+          const u32 wi = static_cast<u32>(b) >> 4, sh = 2u * (static_cast<u32>(b) & 15u);
+          const u32 x0 = S.seq2[wi], x1 = S.seq2[wi + 1], x2 = S.seq2[wi + 2];
+          const u32 pat = code[u] * 0x55555555u;
+          const u32 elo = funnel_shr(x1, x0, sh) ^ pat, ehi = funnel_shr(x2, x1, sh) ^ pat;
+          auto even_bits = [](u32 y) -> u32 {
+            y = ~(y | (y >> 1)) & 0x55555555u;
+            y = (y | (y >> 1)) & 0x33333333u;
+            y = (y | (y >> 2)) & 0x0F0F0F0Fu;
+            y = (y | (y >> 4)) & 0x00FF00FFu;
+            y = (y | (y >> 8)) & 0x0000FFFFu;
+            return y;
+          };
+          mm = even_bits(elo) | (even_bits(ehi) << 16);
+        }
+        i32 sdiff = b - b_first;
+        if (sdiff < 0) {  // (never: a node's backbone coordinate does not decrease along the order)
+          flag = 7;
+          sdiff = 0;
+        }
+        const u32 Srow = rho + (rho >> 4) + (static_cast<u32>(sdiff) >> 1) + 1u;
+        const u32 own = marked[u] ? ring_off + (rho % static_cast<u32>(K::kRing)) * static_cast<u32>(K::kRowB) + 4u : dump_off;
+        const bool endn = marked[u] && (full ? outc_f[u] : outc_s[u]) == 0;
+        uint4 da, db;
+        da.x = Srow | (own << 16);
+        da.y = v | (static_cast<u32>(b) << 16) | ((np > 15u ? 15u : np) << 26) | (marked[u] ? 1u << 30 : 0u) | (endn ? 1u << 31 : 0u);
+        da.z = mm;
+        da.w = ep[0];
+        db.x = ep[1];
+        db.y = ep[2];
+        db.z = ep[3];
+        db.w = lbw;
+        sl.desc[2 * static_cast<size_t>(rho)] = da;
+        sl.desc[2 * static_cast<size_t>(rho) + 1] = db;
+        t_end = static_cast<i32>(Srow) + 17 > t_end ? static_cast<i32>(Srow) + 17 : t_end;
+        if (marked[u]) ++marked_rows;
+      }
+    }
+  }
+  // rows beyond the last one: what the lanes' descriptor prefetch runs into
+  if (lane < 32) {
+    const size_t rho = static_cast<size_t>(n_rows) + static_cast<size_t>(lane);
+    sl.desc[2 * rho] = uint4{kInactiveS | (dump_off << 16), 0u, 0u, neg2};
+    sl.desc[2 * rho + 1] = uint4{neg2, neg2, neg2, 0u};
+  }
+  t_end = sv::wave_max(t_end);
+  flag = static_cast<u32>(sv::wave_max(static_cast<i32>(flag)));
+  marked_rows = sv::wave_sum(marked_rows);
+  if (lane == 0) {  // (one wave per window: plain stores)
+    Poa4Win& w = C.st[rec];
+    w.t_end = static_cast<u32>(t_end);
+    w.dflag = flag;
+    w.cells_full += marked_rows * len;
+    w.cells_band += marked_rows * (len + 1 < 32u ? len + 1 : 32u);
+  }
+}
+
 // phase B: the NW
 template <class K>
 __host__ __device__ inline void poa4_phase_dp(const Poa4Args& A, const Poa4Ctx& C, Poa4Lds& S, u32 wave) {
@@ -1775,6 +1957,49 @@ __host__ __device__ inline void poa4_phase_final(const Poa4Args& A, const Poa4Ct
   if (A.phase_cycles && lane == 0) sv::atomic_add(&A.phase_cycles[5], sv::clock() - t0);
 }
 
+// ---- two kernels per layer round (round 5) ------------------------------------------------------------------------------
+// The five phase kernels of round 4 handed everything to each other through HBM across launch boundaries and paid five
+// launch floors per round.  Phases of the same SHAPE are now one kernel: the graph side of a round (one window per wave:
+// update with the previous round's alignment -> the next layer's set-up -> its row descriptors, one wave walking all node
+// chunks) and the alignment side (four windows per wave: NW -> traceback).  Between two phases of a kernel the wave's
+// stores are fenced and the CU's L1 is dropped (sv::phase_fence): the next phase reads what this wave just wrote.
+struct alignas(16) Poa4LdsGraph {
+  union {
+    Poa4LdsUpd upd;
+    Poa4LdsDesc desc;
+  } u;
+};
+template <class K, int UP>
+__host__ __device__ inline void poa4_phase_graph(const Poa4Args& A, const Poa4Ctx& C, Poa4LdsGraph& S, u32 rec) {
+  const u32 wave_dp = rec / P4::G;
+  const int q = static_cast<int>(rec % P4::G);
+  if (poa4_my_record(C, wave_dp, q) == 0xFFFFFFFFu) return;
+  {
+    const Poa4Win me = C.st[rec];
+    sv::sync();  // (every lane has the record as the previous round left it before any phase below rewrites it)
+    if (me.phase != kRunning) return;
+    if (me.act) {  // the layer aligned in the previous round goes into the graph
+      poa4_phase_update<UP>(A, C, S.u.upd, rec);
+      sv::phase_fence();
+    }
+  }
+  poa4_phase_setup<K>(A, C, S.u.desc, rec);
+  sv::phase_fence();
+  poa4_phase_desc_onewave<K>(A, C, S.u.desc, rec);
+}
+struct alignas(16) Poa4LdsNw {
+  union {
+    Poa4Lds dp;
+    Poa4LdsTb tb;
+  } u;
+};
+template <class K>
+__host__ __device__ inline void poa4_phase_nw(const Poa4Args& A, const Poa4Ctx& C, Poa4LdsNw& S, u32 wave) {
+  poa4_phase_dp<K>(A, C, S.u.dp, wave);
+  sv::phase_fence();  // backpointer stream and the windows' records: written above, read below
+  poa4_phase_tb<K>(A, C, S.u.tb, wave);
+}
+
 // ---- kernels: one wave per workgroup, wave = blockIdx.x ------------------------------------------------------------
 __global__ __launch_bounds__(64) void poa4_init_kernel(const Poa4Args A, const Poa4Ctx C) {
   poa4_phase_init(A, C, blockIdx.x);
@@ -1799,6 +2024,15 @@ template <int UP>
 __global__ __launch_bounds__(64) void poa4_update_kernel(const Poa4Args A, const Poa4Ctx C) {
   __shared__ Poa4LdsUpd lds;
   poa4_phase_update<UP>(A, C, lds, blockIdx.x);
+}
+template <int UP>
+__global__ __launch_bounds__(64) void poa4_graph_kernel(const Poa4Args A, const Poa4Ctx C) {
+  __shared__ Poa4LdsGraph lds;
+  poa4_phase_graph<P4, UP>(A, C, lds, blockIdx.x);
+}
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void poa4_nw_kernel(const Poa4Args A, const Poa4Ctx C) {
+  __shared__ Poa4LdsNw lds;
+  poa4_phase_nw<P4>(A, C, lds, blockIdx.x);
 }
 __global__ __launch_bounds__(64) void poa4_final_kernel(const Poa4Args A, const Poa4Ctx C) {
   __shared__ Poa4Lds lds;
@@ -1860,6 +2094,8 @@ void poa_v4_launch(Engine& e, const PoaBatchDev& b) {
   // other's gaps.
   int upd_per = kUpdPer;  // (RVN_POA4_UPD=2: two positions per lane in the graph update)
   if (const char* ev = std::getenv("RVN_POA4_UPD")) upd_per = std::atoi(ev) == 2 ? 2 : kUpdPer;
+  bool fused = true;  // two kernels per layer round (graph side, alignment side); RVN_POA4_FUSED=0: round 4's five
+  if (const char* ev = std::getenv("RVN_POA4_FUSED")) fused = std::atoi(ev) != 0;
   u32 n_parts = 4;
   if (const char* ev = std::getenv("RVN_POA4_STREAMS")) n_parts = static_cast<u32>(std::max(1, std::min(8, std::atoi(ev))));
   if (per_chunk < 4096) n_parts = 1;
@@ -1918,11 +2154,20 @@ void poa_v4_launch(Engine& e, const PoaBatchDev& b) {
     // (the windows are in scheduling order, heaviest first, and dealt out by wave: every part has the same rounds)
     for (u32 round = 1; round <= max_layers; ++round) {
       for (u32 p = 0; p < n_parts; ++p) {
-        // the set-up kernel also has to reach the windows whose last layer was the previous round's (they find their
-        // layers exhausted): the prefix of round - 1
+        // the graph kernel also has to reach the windows whose last layer was the previous round's (their last alignment
+        // goes into the graph and they find their layers exhausted): the prefix of round - 1
         const u32 w_set = waves_in_round(round - 1, p, n_waves[p]);
-        if (w_set) RVN_KLAUNCH_ON(kKPoaBanded, st[p], (poa4_setup_kernel<<<w_set * P4::G, 64, 0, st[p]>>>(A, C[p])));
         const u32 w = waves_in_round(round, p, n_waves[p]);
+        if (fused) {
+          if (w_set) {
+            if (upd_per == 2) RVN_KLAUNCH_ON(kKPoaBanded, st[p], (poa4_graph_kernel<2><<<w_set * P4::G, 64, 0, st[p]>>>(A, C[p])));
+            else RVN_KLAUNCH_ON(kKPoaBanded, st[p], (poa4_graph_kernel<kUpdPer><<<w_set * P4::G, 64, 0, st[p]>>>(A, C[p])));
+          }
+          if (!w || round == max_layers) continue;
+          RVN_KLAUNCH_ON(kKPoaBanded, st[p], (poa4_nw_kernel<<<w, 64, 0, st[p]>>>(A, C[p])));
+          continue;
+        }
+        if (w_set) RVN_KLAUNCH_ON(kKPoaBanded, st[p], (poa4_setup_kernel<<<w_set * P4::G, 64, 0, st[p]>>>(A, C[p])));
         if (!w || round == max_layers) continue;
         RVN_KLAUNCH_ON(kKPoaBanded, st[p], (poa4_desc_kernel<<<w * P4::G * kDescWavesPerWindow, 64, 0, st[p]>>>(A, C[p])));
         RVN_KLAUNCH_ON(kKPoaBanded, st[p], (poa4_dp_kernel<<<w, 64, 0, st[p]>>>(A, C[p])));
@@ -1951,9 +2196,8 @@ struct EmuCall4 {
   const Poa4Args* A;
   const Poa4Ctx* C;
   Poa4Lds* S;
-  Poa4LdsDesc* SL;
-  Poa4LdsUpd* SU;
-  Poa4LdsTb* ST;
+  Poa4LdsGraph* SG;
+  Poa4LdsNw* SN;
   u32 wave;
   int phase;
 };
@@ -1961,11 +2205,8 @@ void emu_entry4(void* p) {
   EmuCall4* c = static_cast<EmuCall4*>(p);
   switch (c->phase) {
     case 0: poa4_phase_init(*c->A, *c->C, c->wave); break;
-    case 1: poa4_phase_setup<P4>(*c->A, *c->C, *c->SL, c->wave); break;
-    case 6: poa4_phase_desc<P4>(*c->A, *c->C, *c->SL, c->wave); break;
-    case 2: poa4_phase_dp<P4>(*c->A, *c->C, *c->S, c->wave); break;
-    case 3: poa4_phase_tb<P4>(*c->A, *c->C, *c->ST, c->wave); break;
-    case 4: poa4_phase_update<kUpdPer>(*c->A, *c->C, *c->SU, c->wave); break;
+    case 1: poa4_phase_graph<P4, kUpdPer>(*c->A, *c->C, *c->SG, c->wave); break;
+    case 2: poa4_phase_nw<P4>(*c->A, *c->C, *c->SN, c->wave); break;
     default: poa4_phase_final(*c->A, *c->C, *c->S, c->wave); break;
   }
 }
@@ -2001,37 +2242,26 @@ void poa_v4_emulate(const std::vector<PoaWindow>& wins, const std::vector<PoaLay
   const Poa4Args A = args_of4(b, scratch.data(), slot_bytes);
   const Poa4Ctx C{st.data(), 0, count, 0, 1, 0, 2};  // (two waves per window: graphs beyond 512 nodes go round again)
   std::vector<Poa4Lds> lds(1);
-  std::vector<Poa4LdsDesc> ldsl(1);
-  std::vector<Poa4LdsUpd> ldsu(1);
-  std::vector<Poa4LdsTb> ldst(1);
+  std::vector<Poa4LdsGraph> ldsg(1);
+  std::vector<Poa4LdsNw> ldsn(1);
   u32 max_layers = 0;
   for (const PoaWindow& w : wins) max_layers = std::max(max_layers, w.n_layers);
   auto run = [&](int ph) {
-    const u32 per_win = C.desc_waves;
-    const u32 waves = (ph == 1 || ph == 4) ? n_waves * P4::G : (ph == 6 ? n_waves * P4::G * per_win : n_waves);
+    const u32 waves = ph == 1 ? n_waves * P4::G : n_waves;
     for (u32 wv = 0; wv < waves; ++wv) {
-      if (ph == 6) {  // (waves that would return at once: not worth 64 fibres each)
-        const u32 rec = wv / per_win, chunk = wv % per_win;
-        if (rec >= count || st[rec].phase != kRunning || !st[rec].act || (chunk * 256 >= st[rec].nn && chunk != 0)) continue;
-        (void)per_win;
-      }
+      if (ph == 1 && (wv >= count || st[wv].phase != kRunning)) continue;  // (waves that would return at once: not worth 64 fibres each)
       std::memset(static_cast<void*>(lds.data()), 0, sizeof(Poa4Lds));  // (a fresh workgroup's LDS holds anything: zeros here)
-      std::memset(static_cast<void*>(ldsl.data()), 0, sizeof(Poa4LdsDesc));
-      std::memset(static_cast<void*>(ldsu.data()), 0, sizeof(Poa4LdsUpd));
-      std::memset(static_cast<void*>(ldst.data()), 0, sizeof(Poa4LdsTb));
-      EmuCall4 call{&A, &C, lds.data(), ldsl.data(), ldsu.data(), ldst.data(), wv, ph};
+      std::memset(static_cast<void*>(ldsg.data()), 0, sizeof(Poa4LdsGraph));
+      std::memset(static_cast<void*>(ldsn.data()), 0, sizeof(Poa4LdsNw));
+      EmuCall4 call{&A, &C, lds.data(), ldsg.data(), ldsn.data(), wv, ph};
       simt_emu::run_wave(&emu_entry4, &call);
     }
   };
   run(0);
-  for (u32 round = 1; round < max_layers; ++round) {
+  for (u32 round = 1; round <= max_layers; ++round) {  // as poa_v4_launch: graph side, then (while layers remain) the alignment side
     run(1);
-    run(6);
-    run(2);
-    run(3);
-    run(4);
+    if (round < max_layers) run(2);
   }
-  run(1);
   run(5);
 }
 

@@ -43,6 +43,13 @@ template <int N>
 __device__ __forceinline__ int row_shr(int v, int fill) {
   return __builtin_amdgcn_update_dpp(fill, v, 0x110 + N, 0xf, 0xf, false);
 }
+// between two phases of ONE kernel that hand data to each other through global memory (plain stores, L2 atomics): every
+// store of the wave has landed and the CU's vector L1 holds nothing from before (an L2 atomic does not update a line the
+// L1 still has from an earlier plain access)
+__device__ __forceinline__ void phase_fence() {
+  __threadfence();
+  __builtin_amdgcn_wave_barrier();
+}
 __device__ __forceinline__ unsigned atomic_add(unsigned* p, unsigned v) { return atomicAdd(p, v); }
 __device__ __forceinline__ unsigned long long atomic_add(unsigned long long* p, unsigned long long v) { return atomicAdd(p, v); }
 __device__ __forceinline__ unsigned long long clock() { return __builtin_readcyclecounter(); }
@@ -53,6 +60,7 @@ inline int bperm(int v, int src_lane, int site = __builtin_LINE()) { return simt
 inline int rl(int v, int src_lane, int site = __builtin_LINE()) { return simt_emu::exchange(v, src_lane & 63, site); }
 inline int rfl(int v, int site = __builtin_LINE()) { return simt_emu::exchange(v, 0, site); }
 inline void sync(int site = __builtin_LINE()) { simt_emu::sync(site); }
+inline void phase_fence(int site = __builtin_LINE()) { simt_emu::sync(site); }
 template <int N>
 inline int row_shr(int v, int fill, int site = __builtin_LINE()) {
   const int l = simt_emu::lane();

@@ -216,22 +216,48 @@ def test_rows_on_lanes_kernel_equals_one_row_per_iteration_kernel():
 def test_consensus_parity_fraction_on_c4_like_windows():
     """How close 'within tolerance' is: 1500 windows shaped like a C4 polishing round's (500-base backbone, Poisson(31)
     layers with 10 % errors, a fifth of them partial) through the default chain (poa4 -> poa2 -> ...) and through the POA
-    oracle.  Measured on 20 000 windows (tools/poa_parity.py, profiles/r04_poa_parity_20000.json): 99.7 % byte-identical, the
-    rest one edit apart (two in one window), and all but one of those the oracle reproduces once its rows run in the
-    device's order.  The test holds the stage to that:
-    >= 99 % identical, no window further than 2 edits from the oracle's consensus."""
+    oracle.  Since round 5 the kernels take the end node of a layer's alignment by smallest node id among equal scores
+    (spoa: first in its DFS rank, which the device's incremental order does not reproduce); measured on 20 000 windows
+    (tools/poa_parity.py, profiles/r05_poa_parity_20000.json).  On this seed the oracle's statement of the device's rules
+    (device_order=True, end_tie=1) differs from spoa's consensus in ONE window of the 1500 (CPU, both oracle runs).  The
+    test holds the stage to that: >= 99.9 % identical to spoa's consensus, no window further than 2 edits, and EVERY
+    differing window identical to the oracle's statement of the device's rules (nothing unexplained)."""
     import importlib.util
     spec = importlib.util.spec_from_file_location("poa_parity", os.path.join(ROOT, "tools", "poa_parity.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    os.environ["RVN_POA4_MIN_WINDOWS"] = "0"  # the rows-on-lanes kernel first, as in a full-size round (small batches skip it)
-    try:
-        r = mod.run(1500, threads=os.cpu_count(), mode=0, seed=4242)
-    finally:
-        del os.environ["RVN_POA4_MIN_WINDOWS"]
+    r = mod.run(1500, threads=os.cpu_count(), mode=0, seed=4242)
     assert r["polished"] == 1500, r
-    assert r["identical_fraction"] >= 0.99, r
+    assert r["identical_fraction"] >= 0.999, r
     assert r["max_ed_between"] <= 2, r
-    # what differs, differs by a tie that the order of the graph's rows decides: the oracle with its rows in the device's
-    # order gives the device's consensus (20 000 windows: 52 of the 53 differing ones, profiles/r04_poa_parity_20000.json)
-    assert len(r["not_explained"]) <= max(1, r["different"] // 10), r
+    assert len(r["not_explained"]) == 0, r
+
+
+def test_window_7327_branch_completion_tie_regression():
+    """Window 7327 of tools/poa_parity.py's seed 20260927: its consensus ended two bases early on every device kernel in
+    round 4 — hipcc 7.2 compiled the lane-0 branch completion (poa.h: poa_consensus_trace_lane0) so that a TIE between two
+    in-edge weights (sc == wgt with the candidate's score >= the incumbent's) updated the score but not the predecessor.
+    Found only by a 20 000-window sweep; this is the named case.  Every kernel (first attempt rows-on-lanes, 64-column,
+    full matrix) must give the oracle's consensus, which for this window is the same under spoa's and the device's tie rules."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("poa_parity", os.path.join(ROOT, "tools", "poa_parity.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    rng = np.random.default_rng(20260927)
+    w = None
+    for _ in range(7328):
+        w = mod.make_window(rng)[0]
+    ref = oracle.poa_window(w["layers"], begins=w["begins"], ends=w["ends"])[0]
+    assert np.array_equal(ref, oracle.poa_window(w["layers"], begins=w["begins"], ends=w["ends"], device_order=True, end_tie=1)[0])
+    eng = hip.Engine()
+    # alone and inside a batch (the bug did not depend on it; the batch also gives the rows-on-lanes kernel full waves)
+    rng2 = np.random.default_rng(5)
+    others = [mod.make_window(rng2)[0] for _ in range(7)]
+    for mode in (9, 0, 2, 1):
+        eng.poa_set_mode(mode)
+        for batch in ([w], others[:3] + [w] + others[3:]):
+            cons, st, _ = eng.poa_consensus_batch(batch)
+            k = len(batch) // 2 if len(batch) > 1 else 0
+            assert (int(st[k]) & 0xFF) == 1, (mode, st)
+            assert np.array_equal(cons[k], ref), (mode, len(batch), len(cons[k]), len(ref))
+    eng.poa_set_mode(0)

@@ -2,9 +2,10 @@
 """Consensus parity of the window-consensus stage against the repo's own POA oracle (racon Window::GenerateConsensus over
 spoa, oracle/poa_oracle.cpp) on C4-like windows: 500-base backbone with ~2.6 % errors, ~30 ONT-like layers (4 % sub, 3 % ins,
 3 % del), a share of them partial.  Reports the fraction of windows whose consensus is byte-identical and, for the rest, the
-edit distance between the two and of each to the truth, and whether the oracle run with the graph's rows in the device's
-order (oracle.poa_window(device_order=True): same rules and scores, another valid topological order) gives the device's
-consensus — i.e. whether the difference is a tie that the order of the rows decides.
+edit distance between the two and of each to the truth, and whether the oracle's STATEMENT OF THE DEVICE'S RULES gives the
+device's consensus: oracle.poa_window(device_order=True, end_tie=1) = same graph rules and scores, the graph's rows in the
+device's incremental order (another valid topological order) and the end node of an alignment taken by smallest node id
+among equal scores (round 5; spoa: first in its DFS rank) — i.e. whether the difference is such a tie and nothing else.
     python tools/poa_parity.py [n_windows] [threads] [mode]"""
 import json
 import os
@@ -79,15 +80,15 @@ def run(n_windows=2000, threads=None, mode=0, seed=20260927):
         if np.array_equal(c, r):
             same += 1
         else:
-            # the same window with the graph's rows in the DEVICE's order (a different valid topological order: only ties
-            # between equal scores can fall differently): identical then = the difference to spoa is such a tie
-            r2 = oracle.poa_window(wins[i]["layers"], begins=wins[i]["begins"], ends=wins[i]["ends"], device_order=True)[0]
+            # the same window by the oracle's statement of the device's rules (rows in the DEVICE's order, end node by smallest
+            # id: only ties between equal scores can fall differently): identical then = the difference to spoa is such a tie
+            r2 = oracle.poa_window(wins[i]["layers"], begins=wins[i]["begins"], ends=wins[i]["ends"], device_order=True, end_tie=1)[0]
             d = oracle.edit_distance(bytes(c + 65), bytes(r + 65))
             dg = oracle.edit_distance(bytes(c + 65), bytes(truths[i] + 65))
             dr = oracle.edit_distance(bytes(r + 65), bytes(truths[i] + 65))
             diffs.append({"window": i, "layers": len(wins[i]["layers"]), "ed_device_vs_oracle": int(d), "ed_device_vs_truth": int(dg),
                           "ed_oracle_vs_truth": int(dr), "len_device": int(len(c)), "len_oracle": int(len(r)),
-                          "identical_to_oracle_in_device_order": bool(np.array_equal(c, r2)), "status": int(st)})
+                          "identical_to_oracle_statement_of_device_rules": bool(np.array_equal(c, r2)), "status": int(st)})
     polished = n_windows - unpolished
     return {"windows": n_windows, "mode": mode, "polished": polished, "identical": same,
             "identical_fraction": round(same / max(polished, 1), 6), "different": len(diffs), "device_ms": ms,
@@ -95,9 +96,9 @@ def run(n_windows=2000, threads=None, mode=0, seed=20260927):
             "device_closer_to_truth": int(sum(x["ed_device_vs_truth"] < x["ed_oracle_vs_truth"] for x in diffs)),
             "oracle_closer_to_truth": int(sum(x["ed_device_vs_truth"] > x["ed_oracle_vs_truth"] for x in diffs)),
             "equally_close": int(sum(x["ed_device_vs_truth"] == x["ed_oracle_vs_truth"] for x in diffs)),
-            "different_explained_by_row_order_ties": int(sum(x["identical_to_oracle_in_device_order"] for x in diffs)),
+            "different_explained_by_tie_rules": int(sum(x["identical_to_oracle_statement_of_device_rules"] for x in diffs)),
             "max_ed_between": int(max([x["ed_device_vs_oracle"] for x in diffs] or [0])),
-            "not_explained": [x for x in diffs if not x["identical_to_oracle_in_device_order"]],
+            "not_explained": [x for x in diffs if not x["identical_to_oracle_statement_of_device_rules"]],
             "seed": seed, "examples": diffs[:12]}
 
 
