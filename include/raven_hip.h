@@ -388,6 +388,19 @@ int rvn_group_polish_round(rvn_group* g, const uint64_t* t_packed, const uint64_
                            int mismatch, int gap, uint8_t* out_codes, const uint64_t* out_offsets, uint32_t* out_len,
                            double* ratio);
 
+/* Tuning a deployment may set; 0 restores the built-in default, no option changes a result.  The product library reads
+ * NO environment variable that alters what a call computes or how it is scheduled (the only ones it reads at all:
+ * RVN_EDLIB_DEVICE of the edlibAlign drop-in, RVN_DEVICES of include/raven_hip/multi_gpu.hpp — which device); debugging
+ * switches exist only in libraven_hip_test.so (built with -DRVN_DEBUG_KNOBS).  Options:
+ *   nw_budget_mb       alignment-path stage: HBM for the stored band words (default: a quarter of the free memory, <= 64 GB)
+ *   poa_rows_min_windows  window-consensus stage: smallest batch that starts with the rows-on-lanes kernel (default 20 000;
+ *                      this option has no "0 = default": 0 means every batch)
+ *   io_threads, io_slab_mb, io_ring, io_zlib   rvn_reads_load: inflate threads, page-locked slab size, slabs in flight,
+ *                      != 0: zlib instead of this library's own inflate on a single gzip member
+ *   arena_mb, arena_margin_mb, no_arena, release_always   the device arena behind the scratch buffers
+ * previous (may be NULL) receives the value the option had.  RVN_EINVAL: unknown name or negative value. */
+int rvn_engine_set_option(rvn_engine* e, const char* name, int64_t value, int64_t* previous);
+
 /* Kept for source compatibility: a round no longer has a host cutting stage to overlap with the POA, all windows
  * of a call are one device batch.  Stores the value, returns the previous one; results never depended on it. */
 uint64_t rvn_polish_set_chunk_windows(rvn_engine* e, uint64_t windows);

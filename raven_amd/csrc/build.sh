@@ -11,9 +11,10 @@ pids=()
 EDLIB=edlib_dropin
 if [ -n "${RVN_NO_EDLIB_SYMBOLS:-}" ]; then EDLIB=""; rm -f "$HERE/obj/edlib_dropin.o"; fi
 PRODUCT="scan radix_sort sketch index map pile edit_distance poa poa2 poa4 polish nwpath pass2 io shard group engine $EDLIB"
-# libraven_hip_test.so (TEST INFRASTRUCTURE, include/raven_hip_test.h): the product's objects with these four compiled
-# again under -DRVN_TEST_HOOKS (rvn_test_*, rvn_poa_banded_emulate) + the host wavefront emulator
-HOOKED="engine poa poa4 nwpath"
+# libraven_hip_test.so (TEST INFRASTRUCTURE, include/raven_hip_test.h): every source compiled again under
+# -DRVN_TEST_HOOKS (rvn_test_*, rvn_poa_banded_emulate) -DRVN_DEBUG_KNOBS (the environment switches of experiments and
+# diagnostics: common.h knob() — the product library reads none) + the host wavefront emulator
+HOOKED="$PRODUCT"
 mkdir -p "$HERE/obj_test"
 stale() {  # $1 = source, $2 = object
   [ ! -f "$2" ] || [ "$1" -nt "$2" ] || [ -n "$(find "$HERE" -maxdepth 1 -name '*.h' -newer "$2" -print -quit)" ] || [ "$HERE/../../include/raven_hip.h" -nt "$2" ] || [ "$HERE/../../include/raven_hip_test.h" -nt "$2" ]
@@ -29,7 +30,7 @@ done
 for f in $HOOKED simt_emu; do
   src="$HERE/$f.hip"; obj="$HERE/obj_test/$f.o"
   if stale "$src" "$obj"; then
-    $HIPCC $FLAGS -DRVN_TEST_HOOKS -c "$src" -o "$obj" &
+    $HIPCC $FLAGS -DRVN_TEST_HOOKS -DRVN_DEBUG_KNOBS -c "$src" -o "$obj" &
     pids+=($!)
   fi
 done

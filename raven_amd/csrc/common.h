@@ -42,6 +42,19 @@ struct DeviceOutOfMemory : HipError {
 
 #define RVN_LAUNCH_CHECK() RVN_HIP(hipGetLastError())
 
+// Environment switches.  The PRODUCT library reads none that changes what a call computes or how it is scheduled: tuning
+// a deployment may want is an engine option (rvn_engine_set_option, include/raven_hip.h), and everything else —
+// diagnostics, A/B switches of experiments, "skip this stage" profiling aids — exists only in builds with
+// -DRVN_DEBUG_KNOBS (libraven_hip_test.so, which the tools load through RVN_LIB_PATH): knob() is nullptr otherwise.
+inline const char* knob(const char* name) {
+#ifdef RVN_DEBUG_KNOBS
+  return std::getenv(name);
+#else
+  (void)name;
+  return nullptr;
+#endif
+}
+
 // Device ARENA behind the grow-only buffers, switched on when a workload turns out not to fit the HBM with both of its
 // phases' scratch alive (the HiFi one: 1.1 matches per read base; engine_release_scratch_if_tight).  Such a workload hands
 // ~200 GB of scratch back and takes it again at every change of phase, and hipMalloc of FRESH memory runs at ~25 GB/s on
@@ -78,7 +91,7 @@ struct DevBuf {
     if (bytes <= cap) return;
     release();
     size_t want = bytes + bytes / 8 + 256;
-    static const bool trace = std::getenv("RVN_DEBUG_MEM") != nullptr;  // allocator traffic of the grow-only buffers
+    static const bool trace = knob("RVN_DEBUG_MEM") != nullptr;  // allocator traffic of the grow-only buffers
     const auto t0 = std::chrono::steady_clock::now();
     const char* how = "arena";
     void* p = devpool::alloc(want);

@@ -92,7 +92,25 @@ struct StageTimes {
 
 struct PileState;
 
+// Tuning a deployment may set (rvn_engine_set_option; 0 = the built-in default everywhere).  None of them changes a result.
+struct EngineOptions {
+  long long nw_budget_mb = 0;        // alignment-path stage: HBM for the stored band words (default: a quarter of the free memory, <= 64 GB)
+  long long poa_rows_min_windows = -1;  // window-consensus stage: smallest batch that starts with the rows-on-lanes kernel (poa4.hip);
+                                        // a smaller one starts with the 64-column kernel (poa2.hip).  < 0: the default, 20 000
+  long long io_threads = 0;          // rvn_reads_load: inflate threads (default min(32, cores - 2))
+  long long io_slab_mb = 0;          // ... page-locked slab size (default 8)
+  long long io_ring = 0;             // ... slabs in flight (default 8)
+  long long io_zlib = 0;             // ... != 0: zlib instead of inflate_fast.h on a single gzip member
+  long long arena_mb = 0;            // device arena (common.h: devpool): its size when it starts (default: free memory - margin)
+  long long arena_margin_mb = 0;     // ... memory left to the driver (default max(12 GB, 1/16 of the device))
+  long long no_arena = 0;            // ... != 0: never start one
+  long long release_always = 0;      // != 0: every stage entry hands the scratch back (the tests of that path)
+};
+const char* engine_option_names();   // comma-separated, for the error message
+long long* engine_option(EngineOptions& o, const char* name);
+
 struct Engine {
+  EngineOptions opt;
   // Every C-ABI entry point that touches the engine's state (scratch buffers, stream, last Map result) holds this
   // lock for its whole duration: ram::MinimizerEngine::Map is const and called concurrently from Raven's pool workers
   // (RavenLib/src/construct.cc:60-64, :373-381), so the boundary has to be safe under concurrent callers.
@@ -123,7 +141,6 @@ struct Engine {
   DevBuf ed_cnt, ed_sort, ed_todo;
   // second pass / identity filters (pass2.hip)
   DevBuf p2_slot, p2_pairs, p2_dist, p2_regions, p2_index_of, p2_kmers_off, p2_ok, p2_keep, p2_tmp_ovl;
-  DevBuf poa_hist;  // layer-count histogram of a POA chunk (poa4.hip)
   DevBuf io_text[2];  // input path: the file's text in HBM (io.hip)
   int stage_kind = 0;   // the stage entry point running (engine_release_scratch_if_tight)
   u32 oom_mask = 0;     // kinds of stages that ran out of device memory once: they start from released scratch
@@ -166,8 +183,6 @@ struct Engine {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   hipStream_t nw_streams[3] = {nullptr, nullptr, nullptr};  // walk streams of the alignment-path stage (beside the sweeps)
   hipEvent_t nw_ev[4] = {nullptr, nullptr, nullptr, nullptr};
-  hipStream_t poa_streams[8] = {};  // streams of the window-consensus stage (poa4.hip: a chunk's waves dealt out to several)
-  hipEvent_t poa_ev[9] = {};
   u64* h_pin = nullptr;  // pinned host scratch for small device->host size read-backs
   PinBuf pin_big;        // pinned staging for bulk read-backs up to 256 MB (polishing: chain anchors)
   HostBuf host_big;      // ... and the unpinned one for larger ones

@@ -99,7 +99,7 @@ int guarded(Engine* e, F f) {
   } catch (const DeviceOutOfMemory& ex) {
     (void)hipGetLastError();
     (void)hipDeviceSynchronize();
-    if (std::getenv("RVN_DEBUG_MEM")) std::fprintf(stderr, "[raven_hip] %s: all scratch back to the driver, stage repeated\n", ex.what());
+    if (knob("RVN_DEBUG_MEM")) std::fprintf(stderr, "[raven_hip] %s: all scratch back to the driver, stage repeated\n", ex.what());
     e->oom_mask |= 1u << (e->stage_kind & 31);  // next time this kind of stage starts from released scratch
     try {
       rvn::engine_release_scratch(*e);
@@ -312,6 +312,25 @@ void stop() {
 }
 }  // namespace devpool
 
+const char* engine_option_names() {
+  return "nw_budget_mb, poa_rows_min_windows, io_threads, io_slab_mb, io_ring, io_zlib, arena_mb, arena_margin_mb, "
+         "no_arena, release_always";
+}
+long long* engine_option(EngineOptions& o, const char* name) {
+  const std::string n(name ? name : "");
+  if (n == "nw_budget_mb") return &o.nw_budget_mb;
+  if (n == "poa_rows_min_windows") return &o.poa_rows_min_windows;
+  if (n == "io_threads") return &o.io_threads;
+  if (n == "io_slab_mb") return &o.io_slab_mb;
+  if (n == "io_ring") return &o.io_ring;
+  if (n == "io_zlib") return &o.io_zlib;
+  if (n == "arena_mb") return &o.arena_mb;
+  if (n == "arena_margin_mb") return &o.arena_margin_mb;
+  if (n == "no_arena") return &o.no_arena;
+  if (n == "release_always") return &o.release_always;
+  return nullptr;
+}
+
 void engine_release_scratch(Engine& e) {
   if (e.stream) (void)rvn_stream_sync(e.stream);
   e.query_ready = false;
@@ -344,12 +363,12 @@ void engine_release_scratch_if_tight(Engine& e, int stage_kind) {
   e.stage_kind = stage_kind;
   size_t free_b = 0, total_b = 0;
   if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return;
-  const bool trace = std::getenv("RVN_DEBUG_MEM") != nullptr;
+  const bool trace = knob("RVN_DEBUG_MEM") != nullptr;
   if (devpool::active()) {
     // the arena is on (the workload did not fit once): a stage starts from an empty arena when less than a quarter of it
     // is free, or when this kind of stage has run out of memory before with the other phase's scratch alive
     const size_t afree = devpool::free_total(), asize = devpool::size();
-    const bool tight = afree * 4 < asize || ((e.oom_mask >> stage_kind) & 1u) || std::getenv("RVN_RELEASE_ALWAYS") != nullptr;
+    const bool tight = afree * 4 < asize || ((e.oom_mask >> stage_kind) & 1u) || e.opt.release_always != 0;
     if (trace)
       std::fprintf(stderr, "[raven_hip] stage entry (kind %d): arena %.1f GB free of %.1f GB, driver %.1f GB free%s\n", stage_kind,
                    afree / 1e9, asize / 1e9, free_b / 1e9, tight ? " -> scratch released" : "");
@@ -358,7 +377,7 @@ void engine_release_scratch_if_tight(Engine& e, int stage_kind) {
   }
   // (a quarter, not a third: a C4 step settles at ~220 GB of grow-only stage buffers on a 309 GB device — alignment
   // store, window-consensus chunk, sort scratch — and handing them back costs seconds of re-allocation in the next step)
-  const bool tight = free_b * 4 < total_b || std::getenv("RVN_RELEASE_ALWAYS") != nullptr;  // (the latter: tests of this path)
+  const bool tight = free_b * 4 < total_b || e.opt.release_always != 0;  // (the latter: tests of this path)
   if (trace)
     std::fprintf(stderr, "[raven_hip] stage entry (kind %d): %.1f GB free of %.1f GB%s\n", stage_kind, free_b / 1e9, total_b / 1e9,
                  tight ? " -> scratch released, arena started" : "");
@@ -366,11 +385,11 @@ void engine_release_scratch_if_tight(Engine& e, int stage_kind) {
   engine_release_scratch(e);
   // From here on the scratch lives in one arena (common.h: devpool): everything that is free now except a margin for
   // the driver's own needs, the buffers that stay outside (reads, pile handles in use) and other users of the device.
-  if (std::getenv("RVN_NO_ARENA")) return;
+  if (e.opt.no_arena) return;
   if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return;
   size_t margin = std::max<size_t>(12ULL << 30, total_b / 16);
-  if (const char* ev = std::getenv("RVN_ARENA_MARGIN_MB")) margin = static_cast<size_t>(std::atoll(ev)) << 20;
-  if (const char* ev = std::getenv("RVN_ARENA_MB")) margin = free_b > (static_cast<size_t>(std::atoll(ev)) << 20) ? free_b - (static_cast<size_t>(std::atoll(ev)) << 20) : free_b;
+  if (e.opt.arena_margin_mb > 0) margin = static_cast<size_t>(e.opt.arena_margin_mb) << 20;
+  if (e.opt.arena_mb > 0) margin = free_b > (static_cast<size_t>(e.opt.arena_mb) << 20) ? free_b - (static_cast<size_t>(e.opt.arena_mb) << 20) : free_b;
   if (free_b > margin + (1ULL << 30)) {
     const auto t0 = std::chrono::steady_clock::now();
     const bool ok = devpool::start(free_b - margin);
@@ -439,10 +458,6 @@ void rvn_engine_destroy(rvn_engine* h) {
   if (h->e.ev0) (void)hipEventDestroy(h->e.ev0);
   if (h->e.ev1) (void)hipEventDestroy(h->e.ev1);
   for (hipEvent_t ev : h->e.nw_ev)
-    if (ev) (void)hipEventDestroy(ev);
-  for (hipStream_t st2 : h->e.poa_streams)
-    if (st2) (void)hipStreamDestroy(st2);
-  for (hipEvent_t ev : h->e.poa_ev)
     if (ev) (void)hipEventDestroy(ev);
   for (hipStream_t st2 : h->e.nw_streams)
     if (st2) (void)hipStreamDestroy(st2);
@@ -802,7 +817,7 @@ int rvn_find_overlaps_and_create_piles(rvn_engine* h, const rvn_reads* rr, doubl
     if (!(0 <= freq && freq <= 1)) return fail(RVN_EINVAL, "[ram::MinimizerEngine::Filter] error: invalid frequency");
     Engine& e = h->e;
     const ReadsDev& r = rr->r;
-    const bool dbg = std::getenv("RVN_DEBUG_PASS1") != nullptr;  // host wall time per stage (synchronising)
+    const bool dbg = knob("RVN_DEBUG_PASS1") != nullptr;  // host wall time per stage (synchronising)
     auto t_last = std::chrono::steady_clock::now();
     for (u32 i = 0; i < r.n; ++i)
       if (r.h_id[i] != i) return fail(RVN_EINVAL, "[raven_hip] FindOverlapsAndCreatePiles requires ids[i] == i");
@@ -1722,6 +1737,18 @@ int rvn_shard_piles_merge_parts_dev(rvn_pass1* p, uint32_t n_parts, const rvn_ov
   });
 }
 
+int rvn_engine_set_option(rvn_engine* h, const char* name, int64_t value, int64_t* previous) {
+  if (!h) return fail(RVN_EINVAL, "[raven_hip] rvn_engine_set_option: engine == NULL");
+  long long* slot = engine_option(h->e.opt, name);
+  if (!slot || value < 0)
+    return fail(RVN_EINVAL, std::string("[raven_hip] rvn_engine_set_option: unknown option or negative value (options: ") +
+                                engine_option_names() + ")");
+  std::lock_guard<std::recursive_mutex> lk(h->e.mu);
+  if (previous) *previous = *slot < 0 ? 20000 : *slot;  // (only poa_rows_min_windows starts below zero: its default)
+  *slot = value;
+  return RVN_OK;
+}
+
 uint64_t rvn_polish_set_chunk_windows(rvn_engine* h, uint64_t windows) {
   if (!h) return 0;
   const uint64_t prev = h->e.polish_chunk_windows;
@@ -1973,7 +2000,7 @@ int rvn_test_parse_file(const char* path, int fastq, uint32_t threads, int force
         u8* slab = nullptr;
         u64 n = 0;
         bool first = true;
-        const bool timing_only = std::getenv("RVN_TEST_IO_TIMING_ONLY") != nullptr;  // records then come back empty
+        const bool timing_only = knob("RVN_TEST_IO_TIMING_ONLY") != nullptr;  // records then come back empty
         const auto t_loop = std::chrono::steady_clock::now();
         double scan_s = 0;
         while (src.next(&slab, &n)) {

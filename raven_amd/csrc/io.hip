@@ -119,7 +119,11 @@ void load_once(Engine& e, const std::string& path, bool fastq, bool streaming, b
   hipStream_t s = e.stream;
   io::SourceOptions opt;
   opt.force_streaming = streaming;
-  opt.threads = 0;
+  opt.threads = static_cast<u32>(e.opt.io_threads);
+  if (e.opt.io_slab_mb > 0) opt.slab_bytes = static_cast<u64>(e.opt.io_slab_mb) << 20;
+  if (e.opt.io_ring > 1) opt.ring = static_cast<u32>(e.opt.io_ring);
+  opt.zlib_only = e.opt.io_zlib != 0;
+  opt.debug = knob("RVN_IO_DEBUG") != nullptr;
   // the slabs are page-locked once per engine and handed out again by later loads (pinning runs at 1-2 GB/s)
   opt.alloc = [&e](size_t n) -> void* {
     for (auto& slot : e.io_pin)

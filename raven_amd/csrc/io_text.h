@@ -104,11 +104,13 @@ struct Member {
 };
 
 struct SourceOptions {
-  u32 threads = 0;              // 0: hardware_concurrency - 2, at most 32; RVN_IO_THREADS overrides
+  u32 threads = 0;              // 0: hardware_concurrency - 2, at most 32 (engine option io_threads)
   bool force_streaming = false;  // one zlib inflate thread, front to back (the authority on damaged archives)
+  bool zlib_only = false;        // a single member by zlib from the first attempt on (engine option io_zlib)
+  bool debug = false;            // decoder / helper timings to stderr
   u32 stream_helpers = 3;        // single-member archive: threads beside the decoder (CRC-32 + copy into the slabs)
-  u64 slab_bytes = 8ULL << 20;   // RVN_IO_SLAB_MB overrides
-  u32 ring = 8;                  // RVN_IO_RING overrides
+  u64 slab_bytes = 8ULL << 20;   // (engine option io_slab_mb)
+  u32 ring = 8;                  // (engine option io_ring)
   u64 item_bytes = 1ULL << 20;   // text per work item of the pool (BGZF blocks are 64 kB: grouped)
   // page-locked allocation (hipHostMalloc / hipHostFree in the product; malloc / free in the CPU test hook)
   std::function<void*(size_t)> alloc = [](size_t n) { return std::malloc(n); };
@@ -209,9 +211,6 @@ class TextSource {
       streaming_ = true;
     }
     u32 want = opt_.threads;
-    if (const char* env = std::getenv("RVN_IO_THREADS")) want = static_cast<u32>(std::max(1, std::atoi(env)));
-    if (const char* env = std::getenv("RVN_IO_SLAB_MB")) opt_.slab_bytes = static_cast<u64>(std::max(1, std::atoi(env))) << 20;
-    if (const char* env = std::getenv("RVN_IO_RING")) opt_.ring = static_cast<u32>(std::max(2, std::atoi(env)));
     if (want == 0) {
       const u32 hw = std::max(1u, std::thread::hardware_concurrency());
       want = std::min(32u, hw > 3 ? hw - 2 : 1u);
@@ -220,7 +219,7 @@ class TextSource {
       // a single member (or a cut that did not work out): one deflate stream, one decoder.  Unless the caller asked for
       // zlib (force_streaming: the second attempt after anything went wrong) it is inflate_fast.h with a few helpers that
       // checksum and place what it produces
-      fast_stream_ = !opt_.force_streaming && std::getenv("RVN_IO_ZLIB") == nullptr;
+      fast_stream_ = !opt_.force_streaming && !opt_.zlib_only;
       n_threads_ = 1;
       total_known_ = false;
       slab_bytes_ = opt_.slab_bytes;
@@ -601,7 +600,7 @@ class TextSource {
       if (want_crc != (crc & 0xFFFFFFFFUL) || want_len != (member_len & 0xFFFFFFFFULL)) return fail("", true);
       in_pos = static_cast<u64>(tr + 8 - base_);
     }
-    if (std::getenv("RVN_IO_DEBUG"))
+    if (opt_.debug)
       std::fprintf(stderr, "[raven_hip] single stream: %.3f s decoding, %.3f s waiting for the helpers, %.1f MB of text\n", dbg_decode_s_,
                    dbg_wait_s_, text_off / 1e6);
     // close the text (every piece has been written: the waits above)

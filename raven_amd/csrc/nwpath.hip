@@ -228,7 +228,7 @@ void nw_breakpoints(Engine& e, const ReadsDev& T, const ReadsDev& Rd, std::vecto
     }
   } walk_guard{e};
   double rate = e.nw_rate > 0 ? e.nw_rate : 0.13;  // first call: ONT-like; too small only costs a repeat
-  if (const char* ev = std::getenv("RVN_NW_RATE")) rate = std::atof(ev);  // tests: force repeats
+  if (const char* ev = knob("RVN_NW_RATE")) rate = std::atof(ev);  // (debug builds: force repeats)
 
   // plan: the narrowest variant whose ring holds the band of k
   auto plan = [&](NwJob& J, u64 k) -> bool {
@@ -260,12 +260,12 @@ void nw_breakpoints(Engine& e, const ReadsDev& T, const ReadsDev& Rd, std::vecto
     RVN_HIP(hipMemGetInfo(&free_b, &total_b));
     const u64 held = e.nw_hs.cap + e.nw_ck.cap + e.nw_hs2.cap + e.nw_ck2.cap + e.nw_hs3.cap + e.nw_ck3.cap;
     budget = std::min<u64>((static_cast<u64>(free_b) + devpool::free_total()) / 4 + held, 64ULL << 30);  // parked blocks count as free
-    if (const char* ev = std::getenv("RVN_NW_BUDGET_MB")) budget = static_cast<u64>(std::atoll(ev)) << 20;
+    if (e.opt.nw_budget_mb > 0) budget = static_cast<u64>(e.opt.nw_budget_mb) << 20;
     budget = std::max<u64>(budget, 64ULL << 20);
   }
-  const bool trace_lds = !(std::getenv("RVN_NW_TRACE_MEM") && std::atoi(std::getenv("RVN_NW_TRACE_MEM")) == 1);
-  const bool one_stream = std::getenv("RVN_NW_ONE_STREAM") != nullptr;
-  const bool dbg_sync = std::getenv("RVN_NW_DEBUG") && std::atoi(std::getenv("RVN_NW_DEBUG")) >= 2;
+  const bool trace_lds = !(knob("RVN_NW_TRACE_MEM") && std::atoi(knob("RVN_NW_TRACE_MEM")) == 1);
+  const bool one_stream = knob("RVN_NW_ONE_STREAM") != nullptr;
+  const bool dbg_sync = knob("RVN_NW_DEBUG") && std::atoi(knob("RVN_NW_DEBUG")) >= 2;
   std::vector<double> rates;
   std::vector<u32> h_result(nj), h_status(nj), order;
   NwJob* d_jobs = e.nw_jobs.get<NwJob>(nj + 1);
@@ -466,7 +466,7 @@ void nw_breakpoints(Engine& e, const ReadsDev& T, const ReadsDev& Rd, std::vecto
   // distances only and skips the longest quarter of the reads.  Small batches keep the previous call's estimate.
   std::vector<u32> rest;
   double mu = -1, va = 0, vb = 0;
-  if (valid.size() >= 4096 && !std::getenv("RVN_NW_RATE")) {
+  if (valid.size() >= 4096 && !knob("RVN_NW_RATE")) {
     std::vector<u32> lens;
     for (u32 i : valid) lens.push_back(std::max(jobs[i].n, jobs[i].m));
     std::nth_element(lens.begin(), lens.begin() + lens.size() * 3 / 4, lens.end());
@@ -548,10 +548,10 @@ void nw_breakpoints(Engine& e, const ReadsDev& T, const ReadsDev& Rd, std::vecto
   float ms = 0;
   RVN_HIP(hipEventElapsedTime(&ms, e.ev0, e.ev1));
   st.ms = ms;
-  if (std::getenv("RVN_NW_DEBUG"))
+  if (knob("RVN_NW_DEBUG"))
     std::fprintf(stderr, "[raven_hip] nw host: plan %.1f ms, order + chunks %.1f ms, uploads %.1f ms, results %.1f ms\n", h_plan, h_order, h_up,
                  h_res);
-  if (std::getenv("RVN_NW_DEBUG"))
+  if (knob("RVN_NW_DEBUG"))
     std::fprintf(stderr, "[raven_hip] nw: %u jobs, %llu aligned, %llu retries, %llu chunks, %.3e band cells, %.1f MB hs + ck, %.1f ms; pilot mu %.4f a %.4f b %.3e\n", nj,
                  static_cast<unsigned long long>(st.n_aligned), static_cast<unsigned long long>(st.n_retries),
                  static_cast<unsigned long long>(st.n_batches), static_cast<double>(st.band_cells), st.store_bytes / 1048576.0, ms, mu, va, vb);

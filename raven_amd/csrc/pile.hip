@@ -641,7 +641,7 @@ void piles_find_chimeric_regions(Engine& e, PileState& ps, const u8* h_invalid, 
   u32* d_roff = d_cnt + n + 1;
   u32* d_ovf = e.tmp_f.get<u32>(4);
   RVN_HIP(hipMemsetAsync(d_ovf, 0, 4, s));
-  if (std::getenv("RVN_CHIMERIC_PER_THREAD"))  // (the earlier layout: one thread per pile; kept for comparisons)
+  if (knob("RVN_CHIMERIC_PER_THREAD"))  // (the earlier layout: one thread per pile; kept for comparisons)
     RVN_KLAUNCH(kKPileTrim, pile_chimeric_kernel<<<div_up(n, 64), 64, 0, s>>>(ps.pile_data.as<u16>(), ps.pile_off.as<u64>(), d_inv, n,
                                                                              d_slopes, d_tmp, d_out, d_cnt, d_ovf));
   else

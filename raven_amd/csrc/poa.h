@@ -216,7 +216,7 @@ void poa_v2_launch(Engine& e, const PoaBatchDev& b, int nch);  // poa2.hip: band
 // poa4.hip: rows on lanes, four windows per wave, 32-column band (the first attempt of the default mode)
 void poa_v4_launch(Engine& e, const PoaBatchDev& b);
 void poa_v4_emulate(const std::vector<PoaWindow>& wins, const std::vector<PoaLayer>& lays, const PoaSrc& src, u32 max_bb,
-                    u32 max_len, int m, int n, int g, int trim, u8* out, u32* out_len, u32* status);
+                    u32 max_len, int m, int n, int g, int trim, u8* out, u32* out_len, u32* status, bool persistent = false);
 
 // Persistent waves take windows from a shared counter (longest-processing-time-first order when `sched` is given).
 __device__ __forceinline__ u32 poa_next_window(u32* next, const u32* sched, u32 n_windows) {

@@ -654,7 +654,7 @@ void poa_run_dev(Engine& e, const PoaWindow* d_wins, const PoaLayer* d_lays, u32
   PoaBatchDev b{};
   b.lmax = std::min<u32>(kPoaMaxSeq, std::max<u32>(64, ((max_len + 63) / 64) * 64));
   b.nmax = std::min<u32>(8192, std::max<u32>(512, max_bb * 6));
-  if (const char* ev = std::getenv("RVN_POA_NMAX_MULT")) b.nmax = std::min<u32>(8192, std::max<u32>(512, max_bb * static_cast<u32>(std::atoi(ev))));  // footprint experiments
+  if (const char* ev = knob("RVN_POA_NMAX_MULT")) b.nmax = std::min<u32>(8192, std::max<u32>(512, max_bb * static_cast<u32>(std::atoi(ev))));  // footprint experiments
   b.m = m;
   b.n = n;
   b.g = g;
@@ -680,25 +680,19 @@ void poa_run_dev(Engine& e, const PoaWindow* d_wins, const PoaLayer* d_lays, u32
   b.out_len = d_len;
   b.status = d_status;
   b.phase_cycles = d_phase;
-  b.probe = std::getenv("RVN_POA_BAND_PROBE") ? 1u : 0u;
+  b.probe = knob("RVN_POA_BAND_PROBE") ? 1u : 0u;
   RVN_HIP(hipEventRecord(e.ev0, s));
   // the banded kernels keep scores as int16 (and add the match / mismatch / gap terms as packed int16): scoring
   // parameters far beyond spoa's usual single digits go straight to the int32 full-matrix kernel
   const auto mag = [](int x) { return x < 0 ? -x : x; };
   const bool int16_ok = mag(m) <= 24 && mag(n) <= 24 && mag(g) <= 24;
   const int mode = int16_ok ? e.poa_mode : 1;
-  // first attempt: rows on lanes with a 32-column band (poa4.hip; RVN_POA4=0: straight to the 64-column kernel of
-  // poa2.hip); mode 9 = poa4.hip alone
-  static const bool v4_default = [] {
-    const char* ev = std::getenv("RVN_POA4");
-    return !(ev && std::atoi(ev) == 0);
-  }();
-  // A batch too small to fill the chip runs every layer round of poa4's phase kernels at its latency floor (~1.7 ms per
-  // round whatever the batch: 10 000 windows of a configs[2] round take 126 ms there, 65 ms in poa2's one persistent
-  // kernel; at 24 576 windows poa4 is ahead): below the threshold the default mode goes straight to poa2.
-  u32 v4_min_windows = 20000u;
-  if (const char* ev = std::getenv("RVN_POA4_MIN_WINDOWS")) v4_min_windows = static_cast<u32>(std::atoll(ev));  // (read per call: tests set it)
-  const bool v4 = mode == 9 || (mode == 0 && v4_default && n_windows >= v4_min_windows);
+  // first attempt: rows on lanes with a 32-column band (poa4.hip); mode 9 = poa4.hip alone.  A batch too small to fill the
+  // chip with groups of four windows is faster in poa2's one-window-per-wave kernel (10 000 windows of a configs[2] round:
+  // 108 ms in poa4's persistent kernel, 66 ms in poa2's; at 24 576 windows poa4 is ahead): below the threshold the default
+  // mode goes straight to poa2 (engine option poa_rows_min_windows).
+  const u32 v4_min_windows = e.opt.poa_rows_min_windows >= 0 ? static_cast<u32>(e.opt.poa_rows_min_windows) : 20000u;
+  const bool v4 = mode == 9 || (mode == 0 && n_windows >= v4_min_windows);
   if (mode == 1) poa_v1_launch(e, b);
   else if (v4) poa_v4_launch(e, b);
   else poa_v2_launch(e, b, mode == 3 ? 2 : (mode == 4 ? 4 : 1));
@@ -769,7 +763,7 @@ void poa_run_dev(Engine& e, const PoaWindow* d_wins, const PoaLayer* d_lays, u32
       if (st == kPoaBandHit || st == 7u) wide.push_back(w);
       else if (st >= 2) fullm.push_back(w);
     }
-    if (std::getenv("RVN_POA_DEBUG")) {
+    if (knob("RVN_POA_DEBUG")) {
       for (u32 w : wide)
         std::fprintf(stderr, "[raven_hip] poa: window %u band hit at layer %u\n", w, h_status[w] >> 8);
       for (u32 w : fullm) std::fprintf(stderr, "[raven_hip] poa: window %u status %u -> full matrix\n", w, h_status[w]);
@@ -799,7 +793,7 @@ void poa_run_dev(Engine& e, const PoaWindow* d_wins, const PoaLayer* d_lays, u32
   RVN_HIP(hipEventRecord(e.ev1, s));
   RVN_HIP(hipMemcpyAsync(e.poa_phase_cycles, d_phase, 64, hipMemcpyDeviceToHost, s));
   unsigned long long kstats[6] = {};
-  const bool want_stats = std::getenv("RVN_POA_STATS") != nullptr;
+  const bool want_stats = knob("RVN_POA_STATS") != nullptr;
   if (want_stats) RVN_HIP(hipMemcpyAsync(kstats, d_phase + 10, 48, hipMemcpyDeviceToHost, s));
   RVN_HIP(rvn_stream_sync(s));
   if (want_stats)
@@ -917,8 +911,8 @@ void poa_banded_emulate(const u8* h_codes, const u8* h_quals, const u64* h_layer
   PoaSrc src{};
   src.codes = h_codes;
   src.quals = h_quals;
-  (void)variant;
-  poa_v4_emulate(wins, lays, src, max_bb, max_len, m, n, g, trim, h_out, h_out_len, h_status);
+  // variant 4: the per-round launches (graph side / alignment side), 5: the persistent kernel
+  poa_v4_emulate(wins, lays, src, max_bb, max_len, m, n, g, trim, h_out, h_out_len, h_status, variant == 5);
 }
 
 #endif  // RVN_TEST_HOOKS

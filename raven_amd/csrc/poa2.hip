@@ -868,10 +868,10 @@ void poa_v2_launch(Engine& e, const PoaBatchDev& b, int nch) {
   size_t free_b = 0, total_b = 0;
   RVN_HIP(hipMemGetInfo(&free_b, &total_b));
   u32 occ = 6;  // waves per SIMD the 64-column kernel is built for (80 VGPRs; LDS allows 7 workgroups of 4 waves per CU): measured 5 / 6 / 7 -> 158.7k / 170.9k / 170.1k windows/s
-  if (const char* ev = std::getenv("RVN_POA_OCC")) occ = static_cast<u32>(std::atoi(ev));
+  if (const char* ev = knob("RVN_POA_OCC")) occ = static_cast<u32>(std::atoi(ev));
   occ = occ < 5 ? 5 : (occ > 7 ? 7 : occ);
   u32 per_cu = nch == 1 ? 4 * occ : 16;
-  if (const char* ev = std::getenv("RVN_POA_WAVES_PER_CU")) per_cu = static_cast<u32>(std::atoi(ev));  // occupancy experiments
+  if (const char* ev = knob("RVN_POA_WAVES_PER_CU")) per_cu = static_cast<u32>(std::atoi(ev));  // occupancy experiments
   u32 n_slots = std::min<u32>(b.n_windows, 256 * per_cu);
   const size_t budget = e.poa2_scratch.cap + (free_b + devpool::free_total()) / 2;
   if (static_cast<size_t>(n_slots) * slot_bytes > budget) n_slots = static_cast<u32>(std::max<size_t>(1, budget / slot_bytes));

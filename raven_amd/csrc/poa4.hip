@@ -23,8 +23,16 @@
 // < rho with band start b_pi <= b_rho has written column j by step S_pi + (j - b_pi) / 2 <= S_rho + (j - b_rho) / 2 - 1:
 // one step before it is read.  Sixteen lanes are always busy except for the (b - b_0) / 2 drift (~20 % of the steps).
 //
+// How a batch runs (round 5): ONE launch of persistent waves.  A wave takes a group of four windows (scheduling order =
+// by decreasing layer count) from an atomic counter and carries it from the backbone graphs to the consensus: per layer the
+// graph side of each window in turn (all 64 lanes on one window: graph update with the previous alignment, the next
+// layer's set-up, its row descriptors), then NW and traceback of the four side by side.  Round 4 ran every phase as a
+// kernel of its own over a chunk of windows in lock step (five launches per layer round on four streams): the rounds'
+// barriers left ~45 % of the wave slots idle and every phase met its window's data cold (poa4_persistent below).
+//
 // Integer VALU + LDS bound; no MFMA.  Written against sv:: (simt.h): the same source runs under the host wavefront
-// emulator (tests/test_poa4_emulation.py -> rvn_poa_banded_emulate, variant 4).
+// emulator (tests/test_poa4_emulation.py -> rvn_poa_banded_emulate: variant 5 = the persistent kernel, variant 4 = the
+// same phase functions stepped wave by wave in lock step).
 #include <algorithm>
 #include <cstddef>
 #include <cstdio>
@@ -40,7 +48,10 @@ namespace {
 
 struct P4 {
   static constexpr int G = 4, GS = 16, kBand = 32;
-  static constexpr int kRing = 24;    // score rows a window keeps in LDS = longest in-edge (in ranks) + 1
+  static constexpr int kRing = 24;    // score rows a window keeps in LDS = longest in-edge (in ranks) + 1 (a longer one sends the
+                                      // window to poa2: none in 9 220 layers of 300 C4-like windows, the longest was 17.  19 rows =
+                                      // 8 KB of LDS = five waves per SIMD at 96 registers was measured: 844 instead of 737 ms per C4
+                                      // round — the stage does not want more waves)
   static constexpr int kRowB = 88;    // bytes per ring row: 2 -inf cells | 32 cells | 10 -inf cells
   static constexpr int kMaxD = 8;     // largest band-start difference along an in-edge (the right pads cover it)
   static constexpr int kEdges = 8;    // in-edges a row descriptor holds; a row with more sends the window to poa2
@@ -67,8 +78,8 @@ struct alignas(16) Poa4LdsT {
   Poa4GroupT<kRingBytes> g[P4::G];
   u32 neg[20];  // -inf cells: what a descriptor's unused in-edges point at
 };
-// every phase is its own kernel and takes the LDS it needs (occupancy): the NW the score ring, the graph update room for
-// 896 order slots, the set-up + descriptor pass the layer's bytes
+// (the phases of the kernel share the wave's LDS as a union: the NW the score ring, the graph update room for 896 order
+// slots, the set-up + descriptor pass the layer's bytes, the traceback its staged rows)
 using Poa4Group = Poa4GroupT<P4::kRing * P4::kRowB>;
 using Poa4Lds = Poa4LdsT<P4::kRing * P4::kRowB>;
 static_assert(sizeof(Poa4Lds) <= 10240, "sixteen waves per CU need <= 10 KB of LDS each");
@@ -395,7 +406,7 @@ __host__ __device__ inline void poa4_dp(const Poa4Args A, Poa4Lds& S, unsigned c
       i32 k = static_cast<i32>(t) - static_cast<i32>(c0 & 0xFFFFu);
       if (k == 16) {  // the row is finished: its end-node score, then the next row
 #if !defined(__HIP_DEVICE_COMPILE__)
-        if (std::getenv("RVN_POA4_DEBUG2"))
+        if (knob("RVN_POA4_DEBUG2"))
           std::fprintf(stderr, "[poa4] lane %d t %u finished rho %u c0 %08x c1 %08x b %u end %u np %u H[0..3] %d %d %d %d\n", lane, t, cur_rho, c0, c1, (c1 >> 16) & 0x3FFu, c1 >> 31, (c1 >> 26) & 15,
                        lds_ld16(S, (c0 >> 16)), lds_ld16(S, (c0 >> 16) + 2), lds_ld16(S, (c0 >> 16) + 4), lds_ld16(S, (c0 >> 16) + 6));
 #endif
@@ -1158,16 +1169,12 @@ __host__ __device__ inline void poa4_consensus(Poa2Slot& g, u32 n_nodes, u32 nma
   if (lane == 0) *out_len = static_cast<u32>(n_out);
 }
 
-// ---- one kernel per phase -------------------------------------------------------------------------------------------
-// The windows of a chunk go through their layers in lock step, a launch per phase and round: set-up + row descriptors,
-// NW, traceback, graph update.  Every phase gets its own register allocation and its own occupancy (the NW is
-// issue-bound and wants its 100 registers; the other three wait on gathers and want many waves), and what a window
-// carries from phase to phase lives in a 64-byte record beside its graph.  A wave serves the same four windows in every
-// launch (positions 4 wave .. 4 wave + 3 of the chunk, in scheduling order = heaviest first, so the waves of the late
-// rounds that find nothing to do are the grid's tail).
+// ---- the phases of a window's layer -------------------------------------------------------------------------------------
+// What a window carries from phase to phase lives in an 80-byte record beside its graph (Poa4Win); a phase function reads
+// it, does its part for one window (graph side) or for the wave's four (alignment side) and lane 0 stores the new state.
 enum : u32 { kIdle = 0, kRunning = 1, kLayersDone = 2, kFinal = 3, kFailed = 4 };
 
-struct Poa4Win {  // per window of the chunk
+struct Poa4Win {  // per window in flight (four per resident wave)
   u32 wi;        // window index
   u32 phase, status, nn, n_eff, li, flip;
   u32 act, full, len, lb, span;  // the layer of this round (act = 0: none)
@@ -1193,24 +1200,24 @@ __host__ __device__ __forceinline__ void atomic_add_u32(u32* p, u32 v) {
 }
 
 struct Poa4Ctx {  // what a phase function needs beside the batch description
-  Poa4Win* st;    // records of the part
-  u32 first;      // position of the chunk's first window in scheduling order
-  u32 count;      // windows of the chunk
-  u32 part, n_parts;  // the chunk's waves are dealt out to n_parts streams: this launch serves waves part, part + n_parts, ..
-  u32 slot0;      // first scratch slot of the part
-  u32 desc_waves; // waves a window gets in the descriptor pass (256 nodes each per turn)
+  Poa4Win* st;     // state records, four per resident wave
+  u32 first;       // position of the batch's first window in scheduling order
+  u32 count;       // windows of the batch
+  u32 quad_delta;  // (group of four windows the wave is working on) - (the wave's own index), modulo 2^32: the wave's records
+                   // and scratch slots are its own, the windows are those of the group (0 when the emulator steps the
+                   // phases wave by wave in lock step)
 };
 
-__host__ __device__ __forceinline__ unsigned char* poa4_slot_of(const Poa4Args& A, const Poa4Ctx& C, u32 wave, int q) {
-  return A.scratch + (static_cast<size_t>(C.slot0) + static_cast<size_t>(wave) * P4::G + static_cast<size_t>(q)) * A.slot_bytes;
+__host__ __device__ __forceinline__ unsigned char* poa4_slot_of(const Poa4Args& A, const Poa4Ctx&, u32 wave, int q) {
+  return A.scratch + (static_cast<size_t>(wave) * P4::G + static_cast<size_t>(q)) * A.slot_bytes;
 }
-// the lane's window of this wave: record index (within the part), or 0xFFFFFFFF beyond the chunk
+// the lane's window of this wave: record index, or 0xFFFFFFFF beyond the batch
 __host__ __device__ __forceinline__ u32 poa4_my_record(const Poa4Ctx& C, u32 wave, int q) {
-  const u32 pos = (wave * C.n_parts + C.part) * P4::G + static_cast<u32>(q);  // position within the chunk
+  const u32 pos = (wave + C.quad_delta) * P4::G + static_cast<u32>(q);  // position within the batch
   return pos < C.count ? wave * P4::G + static_cast<u32>(q) : 0xFFFFFFFFu;
 }
 __host__ __device__ __forceinline__ u32 poa4_position(const Poa4Ctx& C, u32 wave, int q) {
-  return C.first + (wave * C.n_parts + C.part) * P4::G + static_cast<u32>(q);
+  return C.first + (wave + C.quad_delta) * P4::G + static_cast<u32>(q);
 }
 
 // phase 0: graph of the backbone, state record
@@ -1458,176 +1465,14 @@ __host__ __device__ inline void poa4_phase_setup(const Poa4Args& A, const Poa4Ct
   if (A.phase_cycles && lane == 0) sv::atomic_add(&A.phase_cycles[0], sv::clock() - t0);
 }
 
-// phase A2 of a round: the row descriptors, wave = 64 x kDescPer nodes of one window.  Two levels of loads: everything that
-// depends only on (window, node) — the window's record, the layer's packed codes and guide, the nodes' own fields — then
-// the gathers of the in-edges' tails.
+// The row descriptors of a layer, by the window's wave in two passes over the nodes (64 x kDescPer nodes per turn).  Pass 1
+// streams over the nodes and leaves rank | band start of every node for THIS layer in rbl[]; pass 2 builds the
+// descriptors: everything that depends only on (window, node) is a coalesced load (rb[] holds rank and backbone coordinate
+// of a node in one word), an in-edge tail's rank and band start come from rbl[] with one gather (round 4 re-evaluated the
+// guide per edge: nine evaluations per node), and in-edges beyond the largest in-degree of the 256 nodes in flight are not
+// looked at at all.  The descriptor of every node whose rank lies in the rank range [r_lo, r_hi) of the layer's subgraph
+// is written at its row rho = rank - r_lo.
 constexpr int kDescPer = 4;
-constexpr u32 kDescWavesPerWindow = 6;  // 1536 nodes per turn: the graph of a 500-base window with 30 - 40 layers
-template <class K>
-__host__ __device__ inline void poa4_phase_desc(const Poa4Args& A, const Poa4Ctx& C, Poa4LdsDesc& S, u32 wave) {
-  const int lane = sv::lane();
-  const u32 per_win = C.desc_waves;
-  const u32 rec = wave / per_win, chunk = wave % per_win;
-  const u32 wave_dp = rec / P4::G;
-  const int q = static_cast<int>(rec % P4::G);
-  if (poa4_my_record(C, wave_dp, q) == 0xFFFFFFFFu) return;
-  const Poa4Slot sl = poa4_carve(poa4_slot_of(A, C, wave_dp, q), A.nmax, A.lmax);
-  const Poa2Slot& g = sl.g;
-  const Poa4Win me = C.st[rec];
-  if (me.phase != kRunning || !me.act) return;
-  const u32 nn = me.nn;
-  if (chunk * kDescPer * 64 >= nn && chunk != 0) return;
-  const bool full = me.full != 0;
-  const u32 len = me.len, r_lo = me.r_lo, n_rows = me.n_rows, r_hi = r_lo + n_rows;
-  const i32 lb = static_cast<i32>(me.lb), span = static_cast<i32>(me.span), b_first = static_cast<i32>(me.b_first);
-  const u32 span_magic = magic_of(static_cast<u32>(span > 0 ? span : 1));
-  const u32 ring_off = static_cast<u32>(offsetof(Poa4Lds, g)) + static_cast<u32>(q) * static_cast<u32>(sizeof(Poa4Group));
-  const u32 dump_off = ring_off + static_cast<u32>(offsetof(Poa4Group, dump));
-  const u32 neg_off = static_cast<u32>(offsetof(Poa4Lds, neg));
-  const u32 neg2 = neg_off | (neg_off << 16);
-  u32 flag = 0, marked_rows = 0;
-  i32 t_end = 0;
-  {  // the layer's packed codes and guide into LDS
-    const u32 gw = sl.seq2g[lane < 60 ? lane : 64 + (lane - 60)];
-    const u32 gw2 = lane < 28 ? sl.seq2g[68 + lane] : 0u;
-    if (lane < 60) S.seq2[lane] = gw;
-    else S.segtab[lane - 60] = gw;
-    if (lane < 28) S.segtab[4 + lane] = gw2;
-  }
-  lds_order();
-  // a window gets desc_waves waves; a graph of more than 256 x desc_waves nodes makes them go round again
-  for (u32 chunk_i = chunk; chunk_i * kDescPer * 64 < nn; chunk_i += per_win) {
-  // level 1
-  u32 vv[kDescPer], rbv[kDescPer], cc[kDescPer], code[kDescPer], outc_f[kDescPer], outc_s[kDescPer], mk[kDescPer];
-  uint4 tl[kDescPer];
-#pragma unroll
-  for (int u = 0; u < kDescPer; ++u) {
-    vv[u] = (chunk_i * kDescPer + static_cast<u32>(u)) * 64 + static_cast<u32>(lane);
-    const u32 vq = vv[u] < A.nmax ? vv[u] : 0u;
-    rbv[u] = sl.rb[vq];
-    cc[u] = g.in_cnt[vq];
-    code[u] = g.code[vq];
-    outc_f[u] = g.out_cnt[vq];
-    outc_s[u] = g.sub_out[vq];
-    mk[u] = g.mark[vq];
-    tl[u] = *reinterpret_cast<const uint4*>(g.in_tail + static_cast<size_t>(vq) * kPoaMaxIn);
-  }
-  // level 2: the tails of the in-edges
-  bool ok[kDescPer], marked[kDescPer];
-  u32 trb[kDescPer][8], tmk[kDescPer][8];
-#pragma unroll
-  for (int u = 0; u < kDescPer; ++u) {
-    const u32 r = rbv[u] & 0xFFFFu;
-    ok[u] = vv[u] < nn && r >= r_lo && r < r_hi;
-    marked[u] = ok[u] && (full || mk[u] != 0);
-    if (!marked[u]) cc[u] = 0;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const u32 wd = k < 2 ? tl[u].x : (k < 4 ? tl[u].y : (k < 6 ? tl[u].z : tl[u].w));
-      const u32 t = static_cast<u32>(k) < cc[u] ? (wd >> (16 * (k & 1))) & 0xFFFFu : 0u;
-      trb[u][k] = sl.rb[t];
-      tmk[u][k] = full ? 1u : g.mark[t];
-    }
-  }
-#pragma unroll
-  for (int u = 0; u < kDescPer; ++u) {
-    const u32 v = vv[u];
-    const u32 r = rbv[u] & 0xFFFFu;
-    const i32 b = poa4_band_start<K>(S, static_cast<i32>(rbv[u] >> 16), lb, span, span_magic, len);
-    const u32 rho = r - r_lo;
-    u32 ep[4] = {neg2, neg2, neg2, neg2};
-    u32 np = 0, lbw = 0;
-    auto edge = [&](u32 rbt, bool inside) {
-      if (!inside) return;
-      const u32 lbk = r - (rbt & 0xFFFFu);
-      const i32 d = b - poa4_band_start<K>(S, static_cast<i32>(rbt >> 16), lb, span, span_magic, len);
-      if (lbk < 1 || lbk > static_cast<u32>(K::kRing - 1) || lbk > rho || d < 0 || d > K::kMaxD) {
-        flag = 7;
-      } else if (np < static_cast<u32>(K::kEdges)) {
-        const u32 e = ring_off + ((rho - lbk) % static_cast<u32>(K::kRing)) * static_cast<u32>(K::kRowB) + 2u * static_cast<u32>(d);
-        const u32 idx = np >> 1;
-        const u32 keep = (np & 1) ? 0x0000FFFFu : 0xFFFF0000u;
-        const u32 put = (np & 1) ? e << 16 : e;
-#pragma unroll
-        for (u32 i = 0; i < 4; ++i) ep[i] = i == idx ? ((ep[i] & keep) | put) : ep[i];
-        if (np < 6) lbw |= lbk << (5 * np);
-      }
-      ++np;
-    };
-#pragma unroll
-    for (int k = 0; k < 8; ++k) edge(trb[u][k], static_cast<u32>(k) < cc[u] && tmk[u][k] != 0);
-    for (u32 k = 8; k < cc[u]; ++k) {  // rare
-      const u32 t = g.in_tail[static_cast<size_t>(v) * kPoaMaxIn + k];
-      edge(sl.rb[t], full || g.mark[t] != 0);
-    }
-    if (np > static_cast<u32>(K::kEdges)) flag = 3;
-    if (ok[u]) {
-      // match mask of the row's 32 columns against the layer
-      u32 mm = 0;
-      {
-        const u32 wi = static_cast<u32>(b) >> 4, sh = 2u * (static_cast<u32>(b) & 15u);
-        const u32 x0 = S.seq2[wi], x1 = S.seq2[wi + 1], x2 = S.seq2[wi + 2];
-        const u32 pat = code[u] * 0x55555555u;
-        const u32 elo = funnel_shr(x1, x0, sh) ^ pat, ehi = funnel_shr(x2, x1, sh) ^ pat;
-        auto even_bits = [](u32 y) -> u32 {
-          y = ~(y | (y >> 1)) & 0x55555555u;
-          y = (y | (y >> 1)) & 0x33333333u;
-          y = (y | (y >> 2)) & 0x0F0F0F0Fu;
-          y = (y | (y >> 4)) & 0x00FF00FFu;
-          y = (y | (y >> 8)) & 0x0000FFFFu;
-          return y;
-        };
-        mm = even_bits(elo) | (even_bits(ehi) << 16);
-      }
-      i32 sdiff = b - b_first;
-      if (sdiff < 0) {  // (never: a node's backbone coordinate does not decrease along the order)
-        flag = 7;
-        sdiff = 0;
-      }
-      const u32 Srow = rho + (rho >> 4) + (static_cast<u32>(sdiff) >> 1) + 1u;
-      const u32 own = marked[u] ? ring_off + (rho % static_cast<u32>(K::kRing)) * static_cast<u32>(K::kRowB) + 4u : dump_off;
-      const bool endn = marked[u] && (full ? outc_f[u] : outc_s[u]) == 0;
-      uint4 da, db;
-      da.x = Srow | (own << 16);
-      da.y = v | (static_cast<u32>(b) << 16) | ((np > 15u ? 15u : np) << 26) | (marked[u] ? 1u << 30 : 0u) | (endn ? 1u << 31 : 0u);
-      da.z = mm;
-      da.w = ep[0];
-      db.x = ep[1];
-      db.y = ep[2];
-      db.z = ep[3];
-      db.w = lbw;
-      sl.desc[2 * static_cast<size_t>(rho)] = da;
-      sl.desc[2 * static_cast<size_t>(rho) + 1] = db;
-      t_end = static_cast<i32>(Srow) + 17 > t_end ? static_cast<i32>(Srow) + 17 : t_end;
-      if (marked[u]) ++marked_rows;
-    }
-  }
-  }  // chunks
-  // rows beyond the last one: what the lanes' descriptor prefetch runs into
-  if (chunk == 0 && lane < 32) {
-    const size_t rho = static_cast<size_t>(n_rows) + static_cast<size_t>(lane);
-    sl.desc[2 * rho] = uint4{kInactiveS | (dump_off << 16), 0u, 0u, neg2};
-    sl.desc[2 * rho + 1] = uint4{neg2, neg2, neg2, 0u};
-  }
-  t_end = sv::wave_max(t_end);
-  flag = static_cast<u32>(sv::wave_max(static_cast<i32>(flag)));
-  marked_rows = sv::wave_sum(marked_rows);
-  if (lane == 0) {
-    if (t_end) atomic_max_u32(&C.st[rec].t_end, static_cast<u32>(t_end));
-    if (flag) atomic_max_u32(&C.st[rec].dflag, flag);
-    // (work counters go through the window's record: hundreds of thousands of waves adding to one word would queue up)
-    if (marked_rows) {
-      atomic_add_u32(&C.st[rec].cells_full, marked_rows * len);
-      atomic_add_u32(&C.st[rec].cells_band, marked_rows * (len + 1 < 32u ? len + 1 : 32u));
-    }
-  }
-}
-
-// The same descriptors by ONE wave per window, in two passes (the graph kernel of round 5).  Pass 1 streams over the nodes
-// and leaves rank | band start of every node for THIS layer in rbl[]; pass 2 builds the descriptors and takes an in-edge
-// tail's rank and band start from rbl[] with one gather — the band start of a tail is no longer recomputed per edge
-// (that was nine evaluations of the guide per node), and in-edges beyond the largest in-degree of the 256 nodes in
-// flight are not looked at at all.
 template <class K>
 __host__ __device__ inline void poa4_phase_desc_onewave(const Poa4Args& A, const Poa4Ctx& C, Poa4LdsDesc& S, u32 rec) {
   const int lane = sv::lane();
@@ -1884,8 +1729,8 @@ __host__ __device__ inline void poa4_phase_tb(const Poa4Args& A, const Poa4Ctx& 
 }
 
 // phase D: the graph update, one window per wave
-constexpr int kUpdPer = 4;  // sequence positions per lane and iteration of the graph update (2: 80 registers instead of 157,
-                            // twice the iterations — measured equal at C4)
+constexpr int kUpdPer = 2;  // sequence positions per lane and iteration of the graph update (4: 117 registers instead of 80 in a
+                            // kernel of its own; inside the persistent kernel's 128 registers the two-position form is faster)
 struct alignas(16) Poa4LdsUpd {
   u16 nslot[kPoa2MaxSeq + 16];  // order slots of the layer's new nodes
   u32 seq2[64];                 // the layer, 2 bits per base
@@ -1957,12 +1802,11 @@ __host__ __device__ inline void poa4_phase_final(const Poa4Args& A, const Poa4Ct
   if (A.phase_cycles && lane == 0) sv::atomic_add(&A.phase_cycles[5], sv::clock() - t0);
 }
 
-// ---- two kernels per layer round (round 5) ------------------------------------------------------------------------------
-// The five phase kernels of round 4 handed everything to each other through HBM across launch boundaries and paid five
-// launch floors per round.  Phases of the same SHAPE are now one kernel: the graph side of a round (one window per wave:
-// update with the previous round's alignment -> the next layer's set-up -> its row descriptors, one wave walking all node
-// chunks) and the alignment side (four windows per wave: NW -> traceback).  Between two phases of a kernel the wave's
-// stores are fenced and the CU's L1 is dropped (sv::phase_fence): the next phase reads what this wave just wrote.
+// ---- the two sides of a layer ----------------------------------------------------------------------------------------------
+// Phases of the same SHAPE follow each other directly: the graph side (one window on the wave's 64 lanes: update with the
+// previous alignment -> the next layer's set-up -> its row descriptors) and the alignment side (the wave's four windows
+// side by side: NW -> traceback).  Between two phases the wave's stores are ordered at workgroup scope (sv::phase_fence):
+// the next phase reads what this wave just wrote, through the CU's own L1 / the XCD's L2.
 struct alignas(16) Poa4LdsGraph {
   union {
     Poa4LdsUpd upd;
@@ -2000,53 +1844,65 @@ __host__ __device__ inline void poa4_phase_nw(const Poa4Args& A, const Poa4Ctx& 
   poa4_phase_tb<K>(A, C, S.u.tb, wave);
 }
 
-// ---- kernels: one wave per workgroup, wave = blockIdx.x ------------------------------------------------------------
-__global__ __launch_bounds__(64) void poa4_init_kernel(const Poa4Args A, const Poa4Ctx C) {
-  poa4_phase_init(A, C, blockIdx.x);
+// ---- one launch for the whole batch: persistent waves (round 5) ------------------------------------------------------------
+// Per-round launches (round 4: five phase kernels; first half of round 5: two) keep every window of a chunk in lock step: a
+// round ends when its slowest wave ends, and the busy wave-cycles of a C4-like batch added up to ~55 % of the slots x time
+// the launches occupied (tools/bench_poa.py phase counters; 918 / 841 ms per C4 round against 739 here).  Here a wave takes a GROUP of four windows (scheduling order = by decreasing layer count, so the four have
+// about the same number of layers) from an atomic counter and carries it from the backbone graph to the consensus without
+// waiting for anybody else: per layer the graph side of each of its windows in turn (all 64 lanes on one window), then
+// the alignment side of the four side by side.  Scratch and state records belong to the WAVE (blockIdx), not to the
+// windows: a launch of n resident waves needs 4 n slots whatever the batch size (~10 GB instead of 30 GB per chunk), no
+// chunks, no layer histogram, no host round trip.
+struct alignas(16) Poa4LdsAll {
+  union {
+    Poa4LdsGraph g;
+    Poa4LdsNw n;
+    Poa4Lds f;
+  } u;
+};
+template <class K, int UP>
+__host__ __device__ inline void poa4_persistent(const Poa4Args& A, const Poa4Ctx& C0, Poa4LdsAll& S, u32 pw) {
+  const int lane = sv::lane();
+  const u32 n_quads = (C0.count + P4::G - 1) / P4::G;
+  for (;;) {
+    // (every lane takes part in the fetch — lane 0 adds one, the others nothing: see nwpath.hip on why not `if (lane == 0)`)
+    u32 quad = sv::atomic_add(A.next, lane == 0 ? 1u : 0u);
+    quad = static_cast<u32>(sv::rfl(static_cast<int>(quad)));
+    if (quad >= n_quads) break;
+    Poa4Ctx C = C0;
+    C.quad_delta = quad - pw;  // (modulo 2^32: position = first + (pw + delta) * 4 + q)
+    poa4_phase_init(A, C, pw);
+    sv::phase_fence();
+    for (;;) {
+      for (int q = 0; q < P4::G; ++q) {
+        poa4_phase_graph<K, UP>(A, C, S.u.g, pw * P4::G + static_cast<u32>(q));
+        sv::phase_fence();
+      }
+      bool any_layer = false;
+      for (int q = 0; q < P4::G; ++q) {
+        const u32 rec = poa4_my_record(C, pw, q);
+        if (rec != 0xFFFFFFFFu) {
+          const Poa4Win& w = C.st[rec];
+          any_layer = any_layer || (w.phase == kRunning && w.act != 0);
+        }
+      }
+      sv::sync();  // (the records are read by every lane before the alignment side rewrites them)
+      if (!any_layer) break;
+      poa4_phase_nw<K>(A, C, S.u.n, pw);
+      sv::phase_fence();
+    }
+    poa4_phase_final(A, C, S.u.f, pw);
+    sv::phase_fence();
+  }
 }
-__global__ __launch_bounds__(64) void poa4_setup_kernel(const Poa4Args A, const Poa4Ctx C) {
-  __shared__ Poa4LdsDesc lds;
-  poa4_phase_setup<P4>(A, C, lds, blockIdx.x);
-}
-__global__ __launch_bounds__(64) void poa4_desc_kernel(const Poa4Args A, const Poa4Ctx C) {
-  __shared__ Poa4LdsDesc lds;
-  poa4_phase_desc<P4>(A, C, lds, blockIdx.x);
-}
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void poa4_dp_kernel(const Poa4Args A, const Poa4Ctx C) {
-  __shared__ Poa4Lds lds;
-  poa4_phase_dp<P4>(A, C, lds, blockIdx.x);
-}
-__global__ __launch_bounds__(64) void poa4_tb_kernel(const Poa4Args A, const Poa4Ctx C) {
-  __shared__ Poa4LdsTb lds;
-  poa4_phase_tb<P4>(A, C, lds, blockIdx.x);
-}
+
+// ---- the kernel: one wave per workgroup, resident waves = the grid ---------------------------------------------------------
+// (four waves per SIMD: 128 registers, 9.7 KB of LDS.  Measured at C4 on one box: three waves per SIMD with 168 registers
+// 869 ms per round, four 766 ms, five — 96 registers, a 19-row score ring = 8 KB of LDS — 844 ms: profiles/r05_poa_occupancy.txt)
 template <int UP>
-__global__ __launch_bounds__(64) void poa4_update_kernel(const Poa4Args A, const Poa4Ctx C) {
-  __shared__ Poa4LdsUpd lds;
-  poa4_phase_update<UP>(A, C, lds, blockIdx.x);
-}
-template <int UP>
-__global__ __launch_bounds__(64) void poa4_graph_kernel(const Poa4Args A, const Poa4Ctx C) {
-  __shared__ Poa4LdsGraph lds;
-  poa4_phase_graph<P4, UP>(A, C, lds, blockIdx.x);
-}
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void poa4_nw_kernel(const Poa4Args A, const Poa4Ctx C) {
-  __shared__ Poa4LdsNw lds;
-  poa4_phase_nw<P4>(A, C, lds, blockIdx.x);
-}
-__global__ __launch_bounds__(64) void poa4_final_kernel(const Poa4Args A, const Poa4Ctx C) {
-  __shared__ Poa4Lds lds;
-  poa4_phase_final(A, C, lds, blockIdx.x);
-}
-// histogram of the chunk's layer counts (the host turns it into the number of windows that still have a layer in round r)
-constexpr u32 kLayerHist = 1024;
-__global__ void poa4_layer_hist_kernel(const PoaWindow* __restrict__ wins, const u32* __restrict__ sched, u32 first, u32 count,
-                                       u32* __restrict__ hist) {
-  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= count) return;
-  const u32 pos = first + i;
-  const u32 nl = wins[sched ? sched[pos] : pos].n_layers;
-  atomicAdd(&hist[nl < kLayerHist - 1 ? nl : kLayerHist - 1], 1u);
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void poa4_persistent_kernel(const Poa4Args A, const Poa4Ctx C) {
+  __shared__ Poa4LdsAll lds;
+  poa4_persistent<P4, UP>(A, C, lds, blockIdx.x);
 }
 
 Poa4Args args_of4(const PoaBatchDev& b, unsigned char* scratch, size_t slot_bytes) {
@@ -2074,117 +1930,32 @@ Poa4Args args_of4(const PoaBatchDev& b, unsigned char* scratch, size_t slot_byte
 
 }  // namespace
 
+// One launch, persistent waves (poa4_persistent).  Resident waves = 16 per CU (four per SIMD); fewer when the batch is
+// small or the scratch does not fit.
 void poa_v4_launch(Engine& e, const PoaBatchDev& b) {
   if (b.n_windows == 0) return;
   const size_t slot_bytes = poa4_slot_bytes(b.nmax, b.lmax);
+  const u32 n_quads = (b.n_windows + P4::G - 1) / P4::G;
+  int dev = 0, cus = 256;
+  RVN_HIP(hipGetDevice(&dev));
+  RVN_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
   size_t free_b = 0, total_b = 0;
   RVN_HIP(hipMemGetInfo(&free_b, &total_b));
-  // a chunk = the windows whose scratch fits the budget (their graphs stay resident from the first to the last round)
-  // (at most 48 K windows = ~30 GB for racon's 500-base windows: enough waves to fill the chip three times over in every
-  // launch, and the other stages of a polishing round keep their buffers)
-  // (a chunk handed back to the block pool at a stage entry is still there for the taking)
-  const size_t full_chunk = static_cast<size_t>(49152) * (slot_bytes + sizeof(Poa4Win));
-  const size_t budget = std::min<size_t>(std::max(e.poa2_scratch.cap, std::min(devpool::free_largest(), full_chunk + full_chunk / 4)) + free_b / 2, full_chunk);
-  size_t per_chunk = std::max<size_t>(P4::G, budget / (slot_bytes + sizeof(Poa4Win)));
-  if (const char* ev = std::getenv("RVN_POA4_CHUNK")) per_chunk = std::max<size_t>(P4::G, static_cast<size_t>(std::atoll(ev)));
-  per_chunk = std::min<size_t>(per_chunk, b.n_windows);
-  per_chunk = (per_chunk + P4::G - 1) / P4::G * P4::G;
-  // The waves of a chunk are dealt out to several streams that run their rounds independently: the phases of a round
-  // are one issue-bound kernel (NW) and three that wait on gathers, and two streams in different phases fill each
-  // other's gaps.
-  int upd_per = kUpdPer;  // (RVN_POA4_UPD=2: two positions per lane in the graph update)
-  if (const char* ev = std::getenv("RVN_POA4_UPD")) upd_per = std::atoi(ev) == 2 ? 2 : kUpdPer;
-  bool fused = true;  // two kernels per layer round (graph side, alignment side); RVN_POA4_FUSED=0: round 4's five
-  if (const char* ev = std::getenv("RVN_POA4_FUSED")) fused = std::atoi(ev) != 0;
-  u32 n_parts = 4;
-  if (const char* ev = std::getenv("RVN_POA4_STREAMS")) n_parts = static_cast<u32>(std::max(1, std::min(8, std::atoi(ev))));
-  if (per_chunk < 4096) n_parts = 1;
-  const size_t slots_alloc = per_chunk + static_cast<size_t>(P4::G) * 8;
-  unsigned char* d_scratch = e.poa2_scratch.get<unsigned char>(slots_alloc * (slot_bytes + sizeof(Poa4Win)) + 512);
-  Poa4Win* d_st = reinterpret_cast<Poa4Win*>(d_scratch + slots_alloc * slot_bytes + 256);
+  const size_t per_wave = P4::G * (slot_bytes + sizeof(Poa4Win));
+  // (a buffer handed back to the block pool at a stage entry is still there for the taking)
+  const size_t budget = std::max(e.poa2_scratch.cap, devpool::free_largest()) + free_b / 2;
+  u32 n_waves = std::min<u32>(n_quads, static_cast<u32>(cus) * 16u);
+  if (static_cast<size_t>(n_waves) * per_wave + 1024 > budget) n_waves = static_cast<u32>(std::max<size_t>(1, (budget - 1024) / per_wave));
+  const size_t slots = static_cast<size_t>(n_waves) * P4::G;
+  unsigned char* d_scratch = e.poa2_scratch.get<unsigned char>(slots * (slot_bytes + sizeof(Poa4Win)) + 512);
+  Poa4Win* d_st = reinterpret_cast<Poa4Win*>(d_scratch + slots * slot_bytes + 256);
   const Poa4Args A = args_of4(b, d_scratch, slot_bytes);
   hipStream_t s = e.stream;
-  if (n_parts > 1 && !e.poa_streams[0]) {
-    for (hipStream_t& st2 : e.poa_streams) RVN_HIP(hipStreamCreateWithFlags(&st2, hipStreamNonBlocking));
-    for (hipEvent_t& ev : e.poa_ev) RVN_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-  }
-  for (u32 first = 0; first < b.n_windows; first += static_cast<u32>(per_chunk)) {
-    const u32 count = std::min<u32>(static_cast<u32>(per_chunk), b.n_windows - first);
-    const u32 waves_total = (count + P4::G - 1) / P4::G;
-    // rounds = the most layers a window of the chunk has (one layer per round at most); the windows are in scheduling
-    // order = by decreasing layer count, so the windows that still have a layer in round r are a prefix of the chunk:
-    // the launches of a round cover that prefix only (a window of 100 layers among 100 000 of 30 would otherwise make
-    // 70 rounds of launches over waves that return at once)
-    std::vector<u32> hist(kLayerHist, 0);
-    u32* d_hist = e.poa_hist.get<u32>(kLayerHist);
-    RVN_HIP(hipMemsetAsync(d_hist, 0, kLayerHist * 4, s));
-    poa4_layer_hist_kernel<<<div_up(count, 256), 256, 0, s>>>(b.wins, b.sched, first, count, d_hist);
-    RVN_LAUNCH_CHECK();
-    RVN_HIP(hipMemcpyAsync(hist.data(), d_hist, kLayerHist * 4, hipMemcpyDeviceToHost, s));
-    RVN_HIP(rvn_stream_sync(s));
-    u32 max_layers = 0;
-    for (u32 l = 0; l < kLayerHist; ++l)
-      if (hist[l]) max_layers = l;
-    const bool sorted = b.sched != nullptr && max_layers + 1 < kLayerHist;
-    std::vector<u32> alive(max_layers + 2, 0);  // alive[r] = windows with more than r layers
-    for (u32 l = max_layers + 1; l-- > 0;) alive[l] = alive[l + 1] + (l + 1 < kLayerHist ? hist[l + 1] : 0);
-    auto waves_in_round = [&](u32 round, u32 part, u32 part_waves) -> u32 {
-      if (!sorted) return part_waves;
-      const u32 n = round <= max_layers ? alive[round] : 0;  // windows with a layer of index `round` (layers 1 .. n_layers - 1)
-      const u32 waves_alive = (n + P4::G - 1) / P4::G;       // waves 0 .. waves_alive - 1 of the chunk
-      const u32 mine = waves_alive > part ? (waves_alive - part + n_parts - 1) / n_parts : 0;
-      return std::min(mine, part_waves);
-    };
-    Poa4Ctx C[8];
-    u32 n_waves[8] = {};
-    hipStream_t st[8] = {s, s, s, s, s, s, s, s};
-    u32 slot0 = 0;
-    for (u32 p = 0; p < n_parts; ++p) {
-      n_waves[p] = waves_total > p ? (waves_total - p + n_parts - 1) / n_parts : 0;
-      C[p] = Poa4Ctx{d_st + slot0, first, count, p, n_parts, slot0, kDescWavesPerWindow};
-      slot0 += n_waves[p] * P4::G;
-      if (n_parts > 1) st[p] = e.poa_streams[p];
-    }
-    if (n_parts > 1) {
-      RVN_HIP(hipEventRecord(e.poa_ev[8], s));
-      for (u32 p = 0; p < n_parts; ++p) RVN_HIP(hipStreamWaitEvent(st[p], e.poa_ev[8], 0));
-    }
-    for (u32 p = 0; p < n_parts; ++p)
-      if (n_waves[p]) RVN_KLAUNCH_ON(kKPoaBanded, st[p], (poa4_init_kernel<<<n_waves[p], 64, 0, st[p]>>>(A, C[p])));
-    // (the windows are in scheduling order, heaviest first, and dealt out by wave: every part has the same rounds)
-    for (u32 round = 1; round <= max_layers; ++round) {
-      for (u32 p = 0; p < n_parts; ++p) {
-        // the graph kernel also has to reach the windows whose last layer was the previous round's (their last alignment
-        // goes into the graph and they find their layers exhausted): the prefix of round - 1
-        const u32 w_set = waves_in_round(round - 1, p, n_waves[p]);
-        const u32 w = waves_in_round(round, p, n_waves[p]);
-        if (fused) {
-          if (w_set) {
-            if (upd_per == 2) RVN_KLAUNCH_ON(kKPoaBanded, st[p], (poa4_graph_kernel<2><<<w_set * P4::G, 64, 0, st[p]>>>(A, C[p])));
-            else RVN_KLAUNCH_ON(kKPoaBanded, st[p], (poa4_graph_kernel<kUpdPer><<<w_set * P4::G, 64, 0, st[p]>>>(A, C[p])));
-          }
-          if (!w || round == max_layers) continue;
-          RVN_KLAUNCH_ON(kKPoaBanded, st[p], (poa4_nw_kernel<<<w, 64, 0, st[p]>>>(A, C[p])));
-          continue;
-        }
-        if (w_set) RVN_KLAUNCH_ON(kKPoaBanded, st[p], (poa4_setup_kernel<<<w_set * P4::G, 64, 0, st[p]>>>(A, C[p])));
-        if (!w || round == max_layers) continue;
-        RVN_KLAUNCH_ON(kKPoaBanded, st[p], (poa4_desc_kernel<<<w * P4::G * kDescWavesPerWindow, 64, 0, st[p]>>>(A, C[p])));
-        RVN_KLAUNCH_ON(kKPoaBanded, st[p], (poa4_dp_kernel<<<w, 64, 0, st[p]>>>(A, C[p])));
-        RVN_KLAUNCH_ON(kKPoaBanded, st[p], (poa4_tb_kernel<<<w, 64, 0, st[p]>>>(A, C[p])));
-        if (upd_per == 2) RVN_KLAUNCH_ON(kKPoaBanded, st[p], (poa4_update_kernel<2><<<w * P4::G, 64, 0, st[p]>>>(A, C[p])));
-        else RVN_KLAUNCH_ON(kKPoaBanded, st[p], (poa4_update_kernel<kUpdPer><<<w * P4::G, 64, 0, st[p]>>>(A, C[p])));
-      }
-    }
-    for (u32 p = 0; p < n_parts; ++p)
-      if (n_waves[p]) RVN_KLAUNCH_ON(kKPoaBanded, st[p], (poa4_final_kernel<<<n_waves[p], 64, 0, st[p]>>>(A, C[p])));
-    if (n_parts > 1) {
-      for (u32 p = 0; p < n_parts; ++p) {
-        RVN_HIP(hipEventRecord(e.poa_ev[p], st[p]));
-        RVN_HIP(hipStreamWaitEvent(s, e.poa_ev[p], 0));
-      }
-    }
-  }
+  RVN_HIP(hipMemsetAsync(b.next, 0, 4, s));
+  const Poa4Ctx C{d_st, 0, b.n_windows, 0};
+  // (two sequence positions per lane and turn of the graph update: the kernel's 128 registers hold it without the spills the
+  // four-position variant brings — 739 against 829 ms per C4 round)
+  RVN_KLAUNCH_ON(kKPoaBanded, s, (poa4_persistent_kernel<kUpdPer><<<n_waves, 64, 0, s>>>(A, C)));
 }
 
 #ifdef RVN_TEST_HOOKS
@@ -2198,6 +1969,7 @@ struct EmuCall4 {
   Poa4Lds* S;
   Poa4LdsGraph* SG;
   Poa4LdsNw* SN;
+  Poa4LdsAll* SA;
   u32 wave;
   int phase;
 };
@@ -2207,13 +1979,14 @@ void emu_entry4(void* p) {
     case 0: poa4_phase_init(*c->A, *c->C, c->wave); break;
     case 1: poa4_phase_graph<P4, kUpdPer>(*c->A, *c->C, *c->SG, c->wave); break;
     case 2: poa4_phase_nw<P4>(*c->A, *c->C, *c->SN, c->wave); break;
+    case 9: poa4_persistent<P4, kUpdPer>(*c->A, *c->C, *c->SA, c->wave); break;
     default: poa4_phase_final(*c->A, *c->C, *c->S, c->wave); break;
   }
 }
 }  // namespace
 
 void poa_v4_emulate(const std::vector<PoaWindow>& wins, const std::vector<PoaLayer>& lays, const PoaSrc& src, u32 max_bb,
-                    u32 max_len, int m, int n, int g, int trim, u8* out, u32* out_len, u32* status) {
+                    u32 max_len, int m, int n, int g, int trim, u8* out, u32* out_len, u32* status, bool persistent) {
   if (wins.empty()) return;
   PoaBatchDev b{};
   b.lmax = std::min<u32>(kPoaMaxSeq, std::max<u32>(64, ((max_len + 63) / 64) * 64));
@@ -2221,8 +1994,8 @@ void poa_v4_emulate(const std::vector<PoaWindow>& wins, const std::vector<PoaLay
   const size_t slot_bytes = poa4_slot_bytes(b.nmax, b.lmax);
   const u32 count = static_cast<u32>(wins.size());
   const u32 n_waves = (count + P4::G - 1) / P4::G;
-  std::vector<unsigned char> scratch(slot_bytes * n_waves * P4::G + 256, 0);
-  std::vector<Poa4Win> st(static_cast<size_t>(n_waves) * P4::G);
+  std::vector<unsigned char> scratch(slot_bytes * std::max<u32>(n_waves, 2) * P4::G + 256, 0);
+  std::vector<Poa4Win> st(static_cast<size_t>(std::max<u32>(n_waves, 2)) * P4::G);
   unsigned long long phase[16] = {};
   u32 next = 0;
   b.wins = wins.data();
@@ -2240,10 +2013,22 @@ void poa_v4_emulate(const std::vector<PoaWindow>& wins, const std::vector<PoaLay
   b.sched = nullptr;
   b.next = &next;
   const Poa4Args A = args_of4(b, scratch.data(), slot_bytes);
-  const Poa4Ctx C{st.data(), 0, count, 0, 1, 0, 2};  // (two waves per window: graphs beyond 512 nodes go round again)
+  const Poa4Ctx C{st.data(), 0, count, 0};
   std::vector<Poa4Lds> lds(1);
   std::vector<Poa4LdsGraph> ldsg(1);
   std::vector<Poa4LdsNw> ldsn(1);
+  if (persistent) {
+    // two "resident" waves; the emulator runs a wave to its end, so wave 1 (started first) takes every group of windows —
+    // with a group index below AND above its own — and wave 0 finds the counter exhausted
+    std::vector<Poa4LdsAll> ldsa(1);
+    const Poa4Ctx CP{st.data(), 0, count, 0};
+    for (u32 pw : {1u, 0u}) {
+      std::memset(static_cast<void*>(ldsa.data()), 0, sizeof(Poa4LdsAll));
+      EmuCall4 call{&A, &CP, lds.data(), ldsg.data(), ldsn.data(), ldsa.data(), pw, 9};
+      simt_emu::run_wave(&emu_entry4, &call);
+    }
+    return;
+  }
   u32 max_layers = 0;
   for (const PoaWindow& w : wins) max_layers = std::max(max_layers, w.n_layers);
   auto run = [&](int ph) {
@@ -2253,7 +2038,7 @@ void poa_v4_emulate(const std::vector<PoaWindow>& wins, const std::vector<PoaLay
       std::memset(static_cast<void*>(lds.data()), 0, sizeof(Poa4Lds));  // (a fresh workgroup's LDS holds anything: zeros here)
       std::memset(static_cast<void*>(ldsg.data()), 0, sizeof(Poa4LdsGraph));
       std::memset(static_cast<void*>(ldsn.data()), 0, sizeof(Poa4LdsNw));
-      EmuCall4 call{&A, &C, lds.data(), ldsg.data(), ldsn.data(), wv, ph};
+      EmuCall4 call{&A, &C, lds.data(), ldsg.data(), ldsn.data(), nullptr, wv, ph};
       simt_emu::run_wave(&emu_entry4, &call);
     }
   };

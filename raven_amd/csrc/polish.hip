@@ -308,7 +308,7 @@ void polish_round(Engine& e, ReadsDev& T, ReadsDev& R, const u8* h_quals, const 
   using clk = std::chrono::steady_clock;
   auto ms_since = [](clk::time_point a) { return std::chrono::duration<double, std::milli>(clk::now() - a).count(); };
   const auto t_all = clk::now();
-  const bool dbg = std::getenv("RVN_POLISH_DEBUG") != nullptr;
+  const bool dbg = knob("RVN_POLISH_DEBUG") != nullptr;
   auto lap = [&, last = clk::now()](const char* what) mutable {
     if (dbg) {
       (void)rvn_stream_sync(s);
@@ -512,7 +512,7 @@ void polish_round(Engine& e, ReadsDev& T, ReadsDev& R, const u8* h_quals, const 
   RVN_HIP(hipMemsetAsync(d_len, 0, static_cast<size_t>(nw) * 4, s));
   std::vector<u32> h_status;
   double poa_ms = 0;
-  if (std::getenv("RVN_POLISH_SKIP_POA")) {  // profiling of the stages before the consensus only: empty windows
+  if (knob("RVN_POLISH_SKIP_POA")) {  // profiling of the stages before the consensus only: empty windows
     std::fprintf(stderr, "[raven_hip] RVN_POLISH_SKIP_POA is set: the round returns UNPOLISHED windows (profiling switch)\n");
     h_status.assign(nw, 0);
   } else {

@@ -43,11 +43,13 @@ template <int N>
 __device__ __forceinline__ int row_shr(int v, int fill) {
   return __builtin_amdgcn_update_dpp(fill, v, 0x110 + N, 0xf, 0xf, false);
 }
-// between two phases of ONE kernel that hand data to each other through global memory (plain stores, L2 atomics): every
-// store of the wave has landed and the CU's vector L1 holds nothing from before (an L2 atomic does not update a line the
-// L1 still has from an earlier plain access)
+// between two phases of ONE kernel that hand data to each other through global memory: the wave's stores and atomics have
+// been issued to the CU's L1 / the XCD's L2 in order, which is all a reader on the SAME CU needs (workgroup scope: the
+// vector L1 is write-through and shared by the CU).  NOT __threadfence(): an agent-scope release on gfx950 writes the
+// XCD's whole L2 back (the L2s of the eight XCDs are not coherent with each other) — measured: two of those per window
+// and layer round doubled the window-consensus stage (profiles/r05: 918 -> 1771 ms per C4 round).
 __device__ __forceinline__ void phase_fence() {
-  __threadfence();
+  __threadfence_block();
   __builtin_amdgcn_wave_barrier();
 }
 __device__ __forceinline__ unsigned atomic_add(unsigned* p, unsigned v) { return atomicAdd(p, v); }

@@ -52,7 +52,7 @@ SYMBOLS = [
     "rvn_engine_map_collect", "rvn_free",
     "rvn_find_overlaps_and_repetitive_regions", "rvn_pass2_num_overlaps", "rvn_pass2_kmer_cells", "rvn_pass2_fetch",
     "rvn_pass2_destroy", "rvn_engine_release_scratch", "rvn_filter_overlaps_by_identity", "rvn_pass1_find_chimeric_regions",
-    "rvn_reads_load", "rvn_reads_name", "rvn_reads_info", "rvn_reads_fetch",
+    "rvn_reads_load", "rvn_reads_name", "rvn_reads_info", "rvn_reads_fetch", "rvn_engine_set_option",
 ]
 
 # TEST INFRASTRUCTURE: what include/raven_hip_test.h declares on top (libraven_hip_test.so only)
@@ -870,6 +870,15 @@ class Engine:
     def polish_set_chunk_windows(self, windows):
         """Windows per POA chunk of a polishing round (0 = one batch); returns the previous value."""
         return int(lib().rvn_polish_set_chunk_windows(self._h, int(windows)))
+
+    def set_option(self, name, value):
+        """rvn_engine_set_option: a tuning option (include/raven_hip.h lists them; 0 = built-in default); returns the
+        previous value.  Unknown names raise."""
+        prev = C.c_int64(0)
+        L = lib()
+        L.rvn_engine_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64, C.c_void_p]
+        _check(L.rvn_engine_set_option(self._h, name.encode(), int(value), C.byref(prev)))
+        return int(prev.value)
 
     def poa_set_mode(self, mode):
         """0 band 32 (rows on lanes, poa4.hip) -> 64 -> 128 -> 256 -> full matrix (default), 1 full matrix only,

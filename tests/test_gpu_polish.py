@@ -71,11 +71,13 @@ def test_first_call_pilot_and_later_calls_give_the_same_layers():
     lay2 = eng.polish_layers()
     assert np.array_equal(lay1, lay2) and np.array_equal(cons1[0], cons2[0])
     assert st2["align_band_cells"] <= st1["align_band_cells"]
-    os.environ["RVN_NW_BUDGET_MB"] = "64"  # many small batches instead of one
+    assert eng.set_option("nw_budget_mb", 64) == 0  # many small batches instead of one
     try:
         cons3, _, st3 = eng.polish_round(td, rd)
     finally:
-        del os.environ["RVN_NW_BUDGET_MB"]
+        eng.set_option("nw_budget_mb", 0)
+    with pytest.raises(ValueError):
+        eng.set_option("no_such_option", 1)
     assert np.array_equal(eng.polish_layers(), lay1) and np.array_equal(cons3[0], cons1[0])
 
 

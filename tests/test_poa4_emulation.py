@@ -13,6 +13,18 @@ from oracle import oracle
 from raven_amd import hip
 
 
+# 4 = the per-round kernels (graph side / alignment side), 5 = the persistent kernel (one launch, a wave carries a group of four
+# windows through all its layers): the same phase functions, scheduled differently — every test runs under both
+VARIANT = [4]
+
+
+@pytest.fixture(autouse=True, params=[4, 5], ids=["per_round", "persistent"])
+def _variant(request):
+    VARIANT[0] = request.param
+    yield
+    VARIANT[0] = 4
+
+
 def _mutate(rng, codes, sub, ins, dele):
     out = []
     for c in codes:
@@ -56,7 +68,7 @@ def _oracle(w, trim=True):
 
 
 def _compare(wins, min_polished, **kw):
-    cons, status = hip.poa_banded_emulate(wins, variant=4, **kw)
+    cons, status = hip.poa_banded_emulate(wins, variant=VARIANT[0], **kw)
     polished = 0
     for i, (w, c, st) in enumerate(zip(wins, cons, status)):
         if (int(st) & 0xFF) == 1:
@@ -80,14 +92,14 @@ def test_simple_windows():
              ends=[149] + [119] * 8),                               # trimming of thin ends
         dict(layers=[bb] + [truth.copy() for _ in range(3)]),       # a fifth window: the wave's second batch of four
     ]
-    cons, status = hip.poa_banded_emulate(wins, variant=4)
+    cons, status = hip.poa_banded_emulate(wins, variant=VARIANT[0])
     assert status.tolist() == [1, 0, 0, 1, 1]
     assert np.array_equal(cons[0], truth)
     assert np.array_equal(cons[1], bb) and np.array_equal(cons[2], bb)
     assert np.array_equal(cons[3], truth[30:120])
     for w, c in zip(wins, cons):
         assert np.array_equal(c, _oracle(w))
-    cons_nt, _ = hip.poa_banded_emulate(wins[3:4], trim=False, variant=4)
+    cons_nt, _ = hip.poa_banded_emulate(wins[3:4], trim=False, variant=VARIANT[0])
     assert np.array_equal(cons_nt[0], _oracle(wins[3], trim=False))
 
 
@@ -138,7 +150,7 @@ def test_long_private_insertion_is_flagged_or_exact():
 def test_scoring_parameters():
     rng = np.random.default_rng(21)
     wins = [_window(rng, 120, 8) for _ in range(4)]
-    cons, status = hip.poa_banded_emulate(wins, m=5, n=-4, g=-8, variant=4)
+    cons, status = hip.poa_banded_emulate(wins, m=5, n=-4, g=-8, variant=VARIANT[0])
     polished = 0
     for w, c, st in zip(wins, cons, status):
         if (int(st) & 0xFF) == 1:
@@ -159,7 +171,7 @@ def test_nodes_with_many_in_edges():
             layers.append(np.concatenate([truth[:70], np.array([letter], np.uint8), truth[70:]]))
             layers.append(np.concatenate([truth[:70], np.array([letter, (letter + 1) & 3], np.uint8), truth[70:]]))
     layers += [truth.copy() for _ in range(3)]
-    cons, status = hip.poa_banded_emulate([dict(layers=layers)] * 2 + [dict(layers=layers[:9])], variant=4)
+    cons, status = hip.poa_banded_emulate([dict(layers=layers)] * 2 + [dict(layers=layers[:9])], variant=VARIANT[0])
     assert [int(s) & 0xFF for s in status] == [1, 1, 1]
     assert np.array_equal(cons[0], _oracle(dict(layers=layers)))
     assert np.array_equal(cons[2], _oracle(dict(layers=layers[:9])))
@@ -172,7 +184,7 @@ def test_limits_are_reported():
     bb = rng.integers(0, 4, size=950, dtype=np.uint8)
     long_w = dict(layers=[bb, bb.copy(), bb.copy()])
     ok_w = _window(rng, 120, 6)
-    cons, status = hip.poa_banded_emulate([long_w, ok_w, long_w, ok_w, ok_w], variant=4)
+    cons, status = hip.poa_banded_emulate([long_w, ok_w, long_w, ok_w, ok_w], variant=VARIANT[0])
     for i in (0, 2):
         assert (int(status[i]) & 0xFF) == 4 and np.array_equal(cons[i], bb)
     for i in (1, 3, 4):

@@ -66,6 +66,7 @@ def run(n_windows=2000, threads=None, mode=0, seed=20260927):
         wins.append(w)
         truths.append(t)
     eng = hip.Engine()
+    eng.set_option("poa_rows_min_windows", 0)  # the chain of a full-size round (rows-on-lanes kernel first) whatever the batch size
     eng.poa_set_mode(mode)
     cons, status, ms = eng.poa_consensus_batch(wins)
     t0 = time.time()
