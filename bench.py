@@ -61,13 +61,13 @@ _TRAFFIC = None
 
 
 def pmc_traffic_file():
-    """This round's rocprofv3 --pmc result (profiles/r04_pmc_traffic.json, made by tools/pmc_traffic.py from separate
+    """This round's rocprofv3 --pmc result (profiles/r05_pmc_traffic.json, made by tools/pmc_traffic.py from separate
     FETCH_SIZE / WRITE_SIZE passes of this same bench command; tools/profile_round.sh stamps it with the hash of the
     kernel sources it was taken on)."""
     global _TRAFFIC
     if _TRAFFIC is None:
         _TRAFFIC = {}
-        for name in ("r04_pmc_traffic.json",):
+        for name in ("r05_pmc_traffic.json",):
             try:
                 with open(os.path.join(ROOT, "profiles", name)) as f:
                     _TRAFFIC = json.load(f)
@@ -80,9 +80,17 @@ def pmc_traffic_file():
 
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel`: 2 x FETCH_SIZE KiB (gfx950: FETCH_SIZE counts 128-B requests as 64 B,
-    MI355X_MICROARCH.md, HBM) + WRITE_SIZE KiB; None when this round has no profile of it."""
+    MI355X_MICROARCH.md, HBM) + WRITE_SIZE KiB — the guide's reading, calibrated on wide coalesced streams; None when this
+    round has no profile of it."""
     e = pmc_traffic_file().get("kernels", {}).get(kernel)
     return int(e["hbm_bytes_per_launch"]) if e else None
+
+
+def pmc_traffic_raw(kernel):
+    """The same counters as rocprofv3 reports them: FETCH_SIZE KiB + WRITE_SIZE KiB per launch (what a kernel of 4- or
+    16-byte gathers is counted at: 64 B per probe, profiles/r05_pmc_traffic.json "calibration")."""
+    e = pmc_traffic_file().get("kernels", {}).get(kernel)
+    return int(e["hbm_bytes_raw_per_launch"]) if e and "hbm_bytes_raw_per_launch" in e else None
 
 
 def traffic_provenance():
@@ -92,8 +100,12 @@ def traffic_provenance():
     sha = t.get("kernel_source_sha1")
     return {"file": t.get("file"), "kernel_source_sha1": sha,
             "stale": (sha != kernel_source_hash()) if sha else True,
+            "calibration_raw_counter_over_known_bytes": {k: v.get("raw_over_known") for k, v in (t.get("calibration") or {}).items()
+                                                         if isinstance(v, dict) and "raw_over_known" in v},
             "note": "measured by tools/profile_round.sh (separate --pmc FETCH_SIZE / WRITE_SIZE passes of this command); "
-                    "stale = the kernel sources changed since"}
+                    "stale = the kernel sources changed since.  'traffic' = 2 x FETCH + WRITE (the guide's correction, right "
+                    "for streams), 'traffic_raw' = FETCH + WRITE; the calibration says what the raw counters read on this box "
+                    "for a known byte count per access pattern (tools/pmc_calibrate.hip)"}
 
 
 def algorithmic_bytes(site, c, val_bytes):
@@ -316,7 +328,8 @@ def main():
                 # ConstructGraph's stages -5 .. -4 around the device calls (construct.cc:650-707): TrimAndAnnotatePiles on
                 # the coverage in HBM, the identity filter of ResolveContainedReads on the kept lists, contained reads by
                 # Raven's own overlap rules (host code of the reference: here the library's __host__ build of
-                # overlap_rules.h, timed apart as host_rules_s), then the whole second pass
+                # overlap_rules.h through the product entry point rvn_overlap_update_and_type, timed apart as host_rules_s),
+                # then the whole second pass
                 t_s0 = time.perf_counter()
                 ovl, off = p.overlaps()
                 begin, end, median, invalid = p.trim_and_annotate(4)
@@ -324,7 +337,7 @@ def main():
                 t_s1 = time.perf_counter()
                 kept, koff = eng.filter_overlaps_by_identity(reads, ovl, off, begin, end, invalid, args.identity)
                 t_s2 = time.perf_counter()
-                upd, ok, ty = hip.test_overlap_update_and_type(kept, begin, end, invalid.astype(np.uint8))
+                upd, ok, ty = hip.overlap_update_and_type(kept, begin, end, invalid.astype(np.uint8))
                 contained = np.zeros(rs.n, bool)
                 contained[upd["lhs_id"][(ok == 1) & (ty == 1)]] = True
                 contained[upd["rhs_id"][(ok == 1) & (ty == 2)]] = True
@@ -357,6 +370,9 @@ def main():
                 st = {"n_windows": int(((targets.rs.lengths.astype(np.int64) + 499) // 500).sum())}
             else:
                 cur, ratio, st = peng.polish_round(targets, preads)
+                # windows the first attempt (32-column band, rows on lanes) handed on to the 64-column kernel / further
+                st["poa_windows_to_64_columns"] = peng.poa_narrow_windows()
+                st["poa_windows_to_128_columns"] = peng.poa_wide_windows()
             targets.close()
             n_windows += st["n_windows"]
             last["polish"] = st
@@ -473,7 +489,8 @@ def main():
                                                  - variants["single_member"]["load_s"], 1)
         load_stats["note"] = ("blocked gzip (bgzip): members inflated by a pool of host threads into page-locked slabs, one "
                               "memchr pass finds the records, the device cuts and packs; single_member: one deflate "
-                              "stream, inflated front to back by one thread (zlib)")
+                              "stream, decoded front to back by one thread (this library's inflate_fast.h, three helper "
+                              "threads checksum and place its output; zlib only if that attempt raises a doubt)")
 
     if rank == 0 and shard_laps:
         print("[bench] sharded pass laps (s, summed over the timed steps):", {k: round(v, 4) for k, v in shard_laps.items()},
@@ -489,12 +506,16 @@ def main():
                 if la:
                     kernels[name] = {"ms_per_step": round(ms / steps, 4), "launches_per_step": la / steps,
                                      "avg_launch_ms": round(ms / la, 5), "share": round(ms / tot, 4) if tot else None}
+                    if name == "nw_traceback":
+                        # launched on streams of their own beside the sweeps of the next chunk: these launch times
+                        # overlap other sites', the stage's wall time is last_polish_round.align_ms
+                        kernels[name]["overlaps_other_sites"] = True
             # dominant kernel of the WHOLE step: the banded POA kernel (integer VALU bound)
             dom = next(iter(kernels), None)
             if "poa_banded" in kms and kms["poa_banded"][1] and poa_cells["cells_full"] and legs["poa_rounds"]:
-                # The window-consensus stage is a SET of launches (poa4.hip: five kernels per layer round, dealt out to
-                # four streams; their HIP-event times overlap), so its roofline is priced per polishing round against the
-                # stage's own device time (events around the whole batch on the engine's stream): "one launch" = one round.
+                # The window-consensus stage of a polishing round = ONE launch of poa4.hip's persistent kernel + the poa2.hip
+                # launch for what the 32-column band hands on: priced per polishing round against the stage's device time
+                # (HIP events around the whole batch on the engine's stream, the stream both kernels run on).
                 ms, la = kms["poa_banded"]
                 cells = poa_cells["cells_full"] / max(poa_cells["calls"], 1) * 1.0  # per polishing round (one launch set)
                 launches_per_round = 1.0
@@ -505,7 +526,7 @@ def main():
                 roofline_poa = {"bound": "valu", "kernel": "poa_banded",
                             "achieved": round(achieved_tops, 3), "peak": round(VALU_PEAK_LANE_OPS / 1e12, 1),
                             "unit": "T lane-ops/s", "frac": round(achieved_tops * 1e12 / VALU_PEAK_LANE_OPS, 4),
-                            "traffic": pmc_traffic("poa_banded"),
+                            "traffic": pmc_traffic("poa_banded"), "traffic_raw": pmc_traffic_raw("poa_banded"),
                             "algorithmic_cells_per_launch": int(cells_per_launch),
                             "algorithmic_ops_per_cell": POA_MIN_OPS_PER_CELL,
                             "gcups_algorithmic": round(cells_per_launch / avg_s / 1e9, 1),
@@ -518,8 +539,8 @@ def main():
                             "stage_share_of_step": round(legs["poa_ms"] / (dt * 1e3), 3),
                             "note": "algorithmic cells = graph rows x layer length of every layer alignment (what "
                                     "spoa's full NW computes); the first attempt computes a 32-column band of them "
-                                    "(poa4.hip), what touches it a 64-column band (poa2.hip).  One 'launch' = the launch "
-                                    "set of one polishing round, timed by HIP events around the whole batch."}
+                                    "(poa4.hip: one persistent kernel), what it hands on a 64-column band (poa2.hip).  One "
+                                    "'launch' = the stage of one polishing round, timed by HIP events around the whole batch."}
             if dom == "poa_banded" or legs["poa_ms"] > 0.4 * dt * 1e3:
                 roofline = roofline_poa
             if "nw_forward" in kms and kms["nw_forward"][1] and last.get("polish", {}).get("align_band_cells"):
@@ -553,6 +574,7 @@ def main():
             for name in kernels:
                 b = algorithmic_bytes(name, counters, val_bytes)
                 if b:
+                    launches = kms[name][1] / steps
                     if name in partitioned:
                         t_s = kms[name][0] / steps / 1e3
                         basis = "step"
@@ -560,11 +582,19 @@ def main():
                         t_s = kms[name][0] / kms[name][1] / 1e3
                         basis = "launch"
                     achieved = b / t_s / 1e9
+                    # traffic on the SAME basis as algorithmic_bytes: the PMC file holds bytes per launch
+                    per_launch, per_launch_raw = pmc_traffic(name), pmc_traffic_raw(name)
+                    scale = launches if basis == "step" else 1.0
                     roofline_hbm = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(name),
+                                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                                    "traffic": int(per_launch * scale) if per_launch else None,
+                                    "traffic_raw": int(per_launch_raw * scale) if per_launch_raw else None,
                                     "algorithmic_bytes": int(b), "per": basis, "seconds": round(t_s, 6),
-                                    "launches_per_step": kms[name][1] / steps,
-                                    "kernel_ms_share": round(kms[name][0] / tot, 3) if tot else None}
+                                    "traffic_over_algorithmic": round(per_launch * scale / b, 2) if per_launch else None,
+                                    "launches_per_step": launches,
+                                    "kernel_ms_share": round(kms[name][0] / tot, 3) if tot else None,
+                                    "note": "traffic, traffic_raw and algorithmic_bytes are all per %s (the PMC file's bytes "
+                                            "per launch x %g launches)" % (basis, scale)}
                     break
             if roofline is None:
                 roofline = roofline_hbm

@@ -388,6 +388,15 @@ int rvn_group_polish_round(rvn_group* g, const uint64_t* t_packed, const uint64_
                            int mismatch, int gap, uint8_t* out_codes, const uint64_t* out_offsets, uint32_t* out_len,
                            double* ratio);
 
+/* raven::OverlapUpdate (RavenLib/src/overlap_utils.cc:14-85) followed by raven::GetOverlapType (:87-121) on a list of
+ * overlaps, on the HOST (the library's __host__ build of the rules its kernels run: raven_amd/csrc/overlap_rules.h) — for
+ * a caller that holds overlaps and pile regions in host arrays between two device stages, as ResolveContainedReads does
+ * (construct.cc:218-254).  pile_begin / pile_end in bases, pile_invalid != 0 = Pile::is_invalid().  ok[i] = OverlapUpdate's
+ * result (the overlap is updated in place when 1); type[i] = GetOverlapType of the updated overlap (0 internal, 1 lhs
+ * contained, 2 rhs contained, 3 / 4 dovetails), 0xFFFFFFFF when ok[i] == 0. */
+int rvn_overlap_update_and_type(rvn_overlap* overlaps, uint64_t n, const uint32_t* pile_begin, const uint32_t* pile_end,
+                                const uint8_t* pile_invalid, uint32_t n_piles, uint8_t* ok, uint32_t* type);
+
 /* Tuning a deployment may set; 0 restores the built-in default, no option changes a result.  The product library reads
  * NO environment variable that alters what a call computes or how it is scheduled (the only ones it reads at all:
  * RVN_EDLIB_DEVICE of the edlibAlign drop-in, RVN_DEVICES of include/raven_hip/multi_gpu.hpp — which device); debugging

@@ -1016,10 +1016,16 @@ int64_t rvn_test_find_chimeric_regions(const uint16_t* data, uint32_t size, uint
 
 int rvn_test_overlap_update_and_type(rvn_overlap* overlaps, uint64_t n, const uint32_t* pile_begin, const uint32_t* pile_end,
                                      const uint8_t* pile_invalid, uint32_t n_piles, uint8_t* ok, uint32_t* type) {
-  if (!overlaps || !pile_begin || !pile_end || !pile_invalid || !ok || !type) return RVN_EINVAL;
+  return rvn_overlap_update_and_type(overlaps, n, pile_begin, pile_end, pile_invalid, n_piles, ok, type);
+}
+#endif  // RVN_TEST_HOOKS
+
+int rvn_overlap_update_and_type(rvn_overlap* overlaps, uint64_t n, const uint32_t* pile_begin, const uint32_t* pile_end,
+                                const uint8_t* pile_invalid, uint32_t n_piles, uint8_t* ok, uint32_t* type) {
+  if (!overlaps || !pile_begin || !pile_end || !pile_invalid || !ok || !type) return fail(RVN_EINVAL, "[raven_hip] NULL argument");
   for (uint64_t i = 0; i < n; ++i) {
     Overlap& o = reinterpret_cast<Overlap*>(overlaps)[i];
-    if (o.lhs_id >= n_piles || o.rhs_id >= n_piles) return RVN_EINVAL;
+    if (o.lhs_id >= n_piles || o.rhs_id >= n_piles) return fail(RVN_EINVAL, "[raven_hip] overlap names a pile beyond n_piles");
     const PileRegion L{pile_begin[o.lhs_id], pile_end[o.lhs_id], pile_invalid[o.lhs_id] ? 1u : 0u};
     const PileRegion R{pile_begin[o.rhs_id], pile_end[o.rhs_id], pile_invalid[o.rhs_id] ? 1u : 0u};
     ok[i] = overlap_update(o, L, R) ? 1 : 0;
@@ -1027,7 +1033,6 @@ int rvn_test_overlap_update_and_type(rvn_overlap* overlaps, uint64_t n, const ui
   }
   return RVN_OK;
 }
-#endif  // RVN_TEST_HOOKS
 
 int rvn_pile_add_layers(rvn_engine* h, uint16_t* data, uint32_t cells, uint32_t id, const rvn_overlap* overlaps,
                         uint64_t n) {

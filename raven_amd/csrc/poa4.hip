@@ -13,9 +13,10 @@
 //     32-bit read per in-edge and step: the static schedule below guarantees the cells exist), and a row's descriptor
 //     (band start, match mask against the layer, LDS addresses of up to 8 predecessor rows) is one 32-byte record built
 //     by a per-layer pre-pass, so the step loop decodes nothing,
-//   * in-edges are folded with v_max on (score << 6 | diagonal << 5 | 15 - in-edge) keys: spoa's tie rule (diagonal
-//     before vertical, first in-edge first) is the maximum's and the backpointer falls out of its low bits,
-//   * backpointers leave as ONE coalesced 16-byte store per lane and 8 steps into a time-major stream (step, lane); the
+//   * in-edges are folded with v_max on (score << 4 | diagonal << 3 | 7 - in-edge) keys: spoa's tie rule (diagonal
+//     before vertical, first in-edge first) is the maximum's and the backpointer falls out of its low bits: FOUR bits per
+//     cell (0 = horizontal; a row with more than seven in-edges sends the window to poa2: 2.5 % of C4-like windows),
+//   * backpointers leave as ONE coalesced 8-byte store per lane and 8 steps into a time-major stream (step, lane); the
 //     traceback maps (row, column) -> (step, lane) through the descriptor.
 // Schedule (all band starts even and non-decreasing along the topological order): row rho of the layer's rank range
 // runs on lane rho % 16 during steps S - 1 .. S + 15, S = rho + rho / 16 + (b_rho - b_0) / 2 + 1 (step S - 1 only reads:
@@ -54,11 +55,12 @@ struct P4 {
                                       // round — the stage does not want more waves)
   static constexpr int kRowB = 88;    // bytes per ring row: 2 -inf cells | 32 cells | 10 -inf cells
   static constexpr int kMaxD = 8;     // largest band-start difference along an in-edge (the right pads cover it)
-  static constexpr int kEdges = 8;    // in-edges a row descriptor holds; a row with more sends the window to poa2
+  static constexpr int kEdges = 7;    // in-edges a row may have (4-bit backpointers: horizontal + 7 x (diagonal, vertical) = 15 codes);
+                                      // a row with more sends the window to poa2
   static constexpr int kU = 8;        // steps between two service points (descriptor prefetch, backpointer store)
 };
 constexpr u32 kNone4 = 0xFFFFu;
-constexpr i32 kNegKey = kNegInf16 * 64;
+constexpr i32 kNegKey = kNegInf16 * 16;
 constexpr i32 kNegU = -0x30000000;
 constexpr u32 kInactiveS = 0x7FFFu;
 
@@ -105,11 +107,12 @@ struct Poa4Args {
 // Per-window scratch: poa2's graph arrays + the row descriptors of the current layer + its backpointer stream.
 struct Poa4Slot {
   Poa2Slot g;
-  uint4* desc;   // 2 per row: {S | own << 16, node | b << 16 | np << 26 | marked << 30 | end << 31, match mask, e0 | e1 << 16},
-                 //            {e2 | e3 << 16, e4 | e5 << 16, e6 | e7 << 16, rank distances of in-edges 0..5 (5 bits each)}
+  uint4* desc;   // 2 per row: {S | own << 16, node | b << 16 | np << 26 | marked << 30 | end << 31, rank distances of in-edges 0..5
+                 //            (5 bits each), e0 | e1 << 16}, {e2 | e3 << 16, e4 | e5 << 16, e6 | e7 << 16, match mask}: what the
+                 //            traceback needs of a row is its first 16 bytes
   u32* rb;       // per node: rank | backbone coordinate << 16 (kept by the set-up and by poa4_update_graph)
   u32* rbl;      // per node, for the CURRENT layer: rank | band start << 16 (first pass of the descriptor phase)
-  uint4* bps;    // backpointer stream: [step / 8][lane of the window] 16 bytes = 8 steps x 2 columns
+  uint2* bps;    // backpointer stream: [step / 8][lane of the window] 8 bytes = 8 steps x 2 columns x 4 bits
   u32* seq2g;    // the current layer: [0, 60) 2 bits per base, [64, 96) its band guide as eight segments (set-up kernel ->
                  // descriptor / graph update kernels)
 };
@@ -119,7 +122,7 @@ inline size_t poa4_slot_bytes(u32 nmax, u32 lmax) {
   size_t b = poa2_slot_bytes(nmax, lmax, 0, false);
   b += static_cast<size_t>(poa4_desc_rows(nmax)) * 32;
   b += 2 * ((static_cast<size_t>(nmax) * 4 + 255) & ~size_t(255));
-  b += (static_cast<size_t>(poa4_steps(nmax, lmax)) / P4::kU + 2) * 16 * 16;
+  b += (static_cast<size_t>(poa4_steps(nmax, lmax)) / P4::kU + 2) * 16 * 8;
   b += 512;
   return (b + 255) & ~size_t(255);
 }
@@ -134,8 +137,8 @@ __host__ __device__ inline Poa4Slot poa4_carve(unsigned char* base, u32 nmax, u3
   o += (static_cast<size_t>(nmax) * 4 + 255) & ~size_t(255);
   s.rbl = reinterpret_cast<u32*>(base + o);
   o += (static_cast<size_t>(nmax) * 4 + 255) & ~size_t(255);
-  s.bps = reinterpret_cast<uint4*>(base + o);
-  o += (static_cast<size_t>(poa4_steps(nmax, lmax)) / P4::kU + 2) * 16 * 16;
+  s.bps = reinterpret_cast<uint2*>(base + o);
+  o += (static_cast<size_t>(poa4_steps(nmax, lmax)) / P4::kU + 2) * 16 * 8;
   s.seq2g = reinterpret_cast<u32*>(base + o);
   return s;
 }
@@ -161,16 +164,16 @@ __host__ __device__ __forceinline__ u32 add_half(u32 a, u32 p) {
   return a + (HI ? p >> 16 : p & 0xFFFFu);
 #endif
 }
-// int16 half of w * 64 + tag: v_mad_i32_i16 reads the half through op_sel, the cells stay packed as the LDS read delivers them
+// int16 half of w * 16 + tag: v_mad_i32_i16 reads the half through op_sel, the cells stay packed as the LDS read delivers them
 template <bool HI, int TAG>
 __host__ __device__ __forceinline__ i32 cell_key(u32 w) {
 #if defined(__HIP_DEVICE_COMPILE__)
   i32 d;
-  if constexpr (HI) asm("v_mad_i32_i16 %0, %1, 64, %2 op_sel:[1,0,0,0]" : "=v"(d) : "v"(w), "n"(TAG));
-  else asm("v_mad_i32_i16 %0, %1, 64, %2" : "=v"(d) : "v"(w), "n"(TAG));
+  if constexpr (HI) asm("v_mad_i32_i16 %0, %1, 16, %2 op_sel:[1,0,0,0]" : "=v"(d) : "v"(w), "n"(TAG));
+  else asm("v_mad_i32_i16 %0, %1, 16, %2" : "=v"(d) : "v"(w), "n"(TAG));
   return d;
 #else
-  return static_cast<i32>(static_cast<i16>((HI ? w >> 16 : w) & 0xFFFFu)) * 64 + TAG;
+  return static_cast<i32>(static_cast<i16>((HI ? w >> 16 : w) & 0xFFFFu)) * 16 + TAG;
 #endif
 }
 __host__ __device__ __forceinline__ u32 pack16(i32 lo, i32 hi) {  // (lo & 0xFFFF) | hi << 16
@@ -248,13 +251,14 @@ __host__ __device__ inline i32 group_max_i(i32 v) {
 }
 
 // k-th in-edge (among those inside the subgraph) of v as a rank
-__host__ __device__ inline u32 poa4_nth_pred_rank(const Poa2Slot& g, u32 v, u32 k, bool full) {
+__host__ __device__ inline u32 poa4_nth_pred_rank(const Poa4Slot& sl, u32 v, u32 k, bool full) {
+  const Poa2Slot& g = sl.g;
   const u32 c = g.in_cnt[v];
   u32 seen = 0;
   for (u32 i = 0; i < c; ++i) {
     const u32 t = g.in_tail[v * kPoaMaxIn + i];
     if (full || g.mark[t]) {
-      if (seen == k) return g.rank_of[t];
+      if (seen == k) return sl.rb[t] & 0xFFFFu;
       ++seen;
     }
   }
@@ -341,7 +345,7 @@ __host__ __device__ inline void poa4_dp(const Poa4Args A, Poa4Lds& S, unsigned c
     if (lane < 20) S.neg[lane] = neg;
   }
   lds_order();
-  const i32 mD = A.m * 64 + 32, xD = A.n_ * 64 + 32, g64 = A.gp * 64;
+  const i32 mD = A.m * 16 + 8, xD = A.n_ * 16 + 8, g64 = A.gp * 16;  // keys = score * 16 + tag; the diagonal's tag bit rides on the score term
   const i32 gp = A.gp;
   const i32 dD = mD - xD;
   // current row (the raw descriptor words), the next one, the one being fetched
@@ -355,7 +359,7 @@ __host__ __device__ inline void poa4_dp(const Poa4Args A, Poa4Lds& S, unsigned c
     const u32 neg2 = neg_off | (neg_off << 16);
     c0 = act ? (a.x | 0u) : (kInactiveS | (neg_off << 16));  // (a group without a layer in this round has no descriptors: it idles on -inf cells)
     c1 = act ? a.y : 0u;
-    cM = a.z;
+    cM = b.w;
     ce0 = act ? a.w : neg2;
     ce1 = act ? b.x : neg2;
     ce2 = act ? b.y : neg2;
@@ -363,7 +367,7 @@ __host__ __device__ inline void poa4_dp(const Poa4Args A, Poa4Lds& S, unsigned c
     const uint4 a2 = sl.desc[2 * static_cast<size_t>(cur_rho + 16)], b2 = sl.desc[2 * static_cast<size_t>(cur_rho + 16) + 1];
     n0 = act ? a2.x : kInactiveS;
     n1 = act ? a2.y : 0u;
-    nM = a2.z;
+    nM = b2.w;
     ne0 = act ? a2.w : neg2;
     ne1 = act ? b2.x : neg2;
     ne2 = act ? b2.y : neg2;
@@ -391,14 +395,14 @@ __host__ __device__ inline void poa4_dp(const Poa4Args A, Poa4Lds& S, unsigned c
       const uint4 a = sl.desc[2 * static_cast<size_t>(cur_rho + 16)], b = sl.desc[2 * static_cast<size_t>(cur_rho + 16) + 1];
       l0 = a.x;
       l1 = a.y;
-      lM = a.z;
+      lM = b.w;
       le0 = a.w;
       le1 = b.x;
       le2 = b.y;
       le3 = b.z;
       ld_pending = true;
     }
-    u32 acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0;
+    u32 acc0 = 0, acc1 = 0;
 #pragma unroll
     for (int u = 0; u < K::kU; ++u) {
       P4_MARK("step_begin");
@@ -452,27 +456,24 @@ __host__ __device__ inline void poa4_dp(const Poa4Args A, Poa4Lds& S, unsigned c
       const u32 w1 = lds_ld32(S, add_half<true>(off4, ce0));
       const u32 w2 = lds_ld32(S, add_half<false>(off4, ce1));
       const u32 w3 = lds_ld32(S, add_half<true>(off4, ce1));
-      i32 A0 = cell_key<false, 15>(wd), A1 = cell_key<true, 15>(wd);
-      A0 = imax(A0, cell_key<false, 14>(w1));
-      A1 = imax(A1, cell_key<true, 14>(w1));
-      A0 = imax(A0, cell_key<false, 13>(w2));
-      A1 = imax(A1, cell_key<true, 13>(w2));
-      A0 = imax(A0, cell_key<false, 12>(w3));
-      A1 = imax(A1, cell_key<true, 12>(w3));
+      i32 A0 = cell_key<false, 7>(wd), A1 = cell_key<true, 7>(wd);
+      A0 = imax(A0, cell_key<false, 6>(w1));
+      A1 = imax(A1, cell_key<true, 6>(w1));
+      A0 = imax(A0, cell_key<false, 5>(w2));
+      A1 = imax(A1, cell_key<true, 5>(w2));
+      A0 = imax(A0, cell_key<false, 4>(w3));
+      A1 = imax(A1, cell_key<true, 4>(w3));
 #define P4_EDGE(E, REG, HI)                                        \
   {                                                                \
     const u32 we = lds_ld32(S, add_half<HI>(off4, REG));           \
-    A0 = imax(A0, cell_key<false, 15 - E>(we));                    \
-    A1 = imax(A1, cell_key<true, 15 - E>(we));                     \
+    A0 = imax(A0, cell_key<false, 7 - E>(we));                     \
+    A1 = imax(A1, cell_key<true, 7 - E>(we));                      \
   }
       if (sv::any(np > 4)) {
         P4_EDGE(4, ce2, false)
         if (sv::any(np > 5)) {
           P4_EDGE(5, ce2, true)
-          if (sv::any(np > 6)) {
-            P4_EDGE(6, ce3, false)
-            P4_EDGE(7, ce3, true)
-          }
+          if (sv::any(np > 6)) P4_EDGE(6, ce3, false)
         }
       }
 #undef P4_EDGE
@@ -480,32 +481,28 @@ __host__ __device__ inline void poa4_dp(const Poa4Args A, Poa4Lds& S, unsigned c
       const u32 bits = (cM >> (static_cast<u32>(2 * k) & 31u)) & 3u;
       const i32 sd0 = xD + static_cast<i32>(bits & 1u) * dD, sd1 = xD + static_cast<i32>(bits >> 1) * dD;
       const i32 b0 = imax(Am1 + sd0, A0 + g64);
-      const i32 h0 = U + gp, s0 = b0 >> 6;
+      const i32 h0 = U + gp, s0 = b0 >> 4;
       const i32 U0 = imax(s0, h0);
-      const u32 code0 = h0 > s0 ? 64u : (static_cast<u32>(b0) & 63u);
+      const u32 code0 = h0 > s0 ? 0u : (static_cast<u32>(b0) & 15u);  // 0: horizontal; else diagonal << 3 | 7 - in-edge
       const i32 b1 = imax(A0 + sd1, A1 + g64);
-      const i32 h1 = U0 + gp, s1 = b1 >> 6;
+      const i32 h1 = U0 + gp, s1 = b1 >> 4;
       const i32 U1 = imax(s1, h1);
-      const u32 code1 = h1 > s1 ? 64u : (static_cast<u32>(b1) & 63u);
+      const u32 code1 = h1 > s1 ? 0u : (static_cast<u32>(b1) & 15u);
       if (static_cast<u32>(k) < 16u) lds_st32(S, add_half<true>(static_cast<u32>(k) << 2, c0), clamp_pair(pack16(U0, U1)));
-      u32 cp = code0 | (code1 << 8);
+      u32 cp = code0 | (code1 << 4);
 #if defined(__HIP_DEVICE_COMPILE__)
       asm volatile("" : "+v"(cp));  // computed here: sunk to the store it would keep three registers per step alive
 #endif
       if (u == 0) acc0 = cp;
-      else if (u == 1) acc0 |= cp << 16;
-      else if (u == 2) acc1 = cp;
-      else if (u == 3) acc1 |= cp << 16;
-      else if (u == 4) acc2 = cp;
-      else if (u == 5) acc2 |= cp << 16;
-      else if (u == 6) acc3 = cp;
-      else acc3 |= cp << 16;
+      else if (u < 4) acc0 |= cp << (8 * u);
+      else if (u == 4) acc1 = cp;
+      else acc1 |= cp << (8 * (u - 4));
       Am1 = A1;
       U = kk == 0 ? kNegU : U1;
       lds_order();
       P4_MARK("step_end");
     }
-    if (act) sl.bps[static_cast<size_t>(t0 / K::kU) * 16 + static_cast<size_t>(gl)] = uint4{acc0, acc1, acc2, acc3};
+    if (act) sl.bps[static_cast<size_t>(t0 / K::kU) * 16 + static_cast<size_t>(gl)] = uint2{acc0, acc1};
   }
   if (A.phase_cycles && lane == 0) sv::atomic_add(&A.phase_cycles[14], static_cast<unsigned long long>((T + K::kU - 1) / K::kU * K::kU));
   // rows that finished in the very last step of the loop
@@ -539,8 +536,8 @@ __host__ __device__ inline void poa4_dp(const Poa4Args A, Poa4Lds& S, unsigned c
 
 // ---- traceback of the wave's windows, round-synchronous -------------------------------------------------------------
 // A round = every window walks through kTbG blocks of 16 rows.  Lane l of a window fetches rows 16 * block + l of the
-// round — three descriptor words and the 48 bytes of the backpointer stream that hold the row's 32 codes (its 16 steps
-// lie in at most three 8-step blocks of the stream) — a round AHEAD into registers, descriptors two rounds ahead (the
+// round — three descriptor words and the 24 bytes of the backpointer stream that hold the row's 32 four-bit codes (its 16
+// steps lie in at most three 8-step blocks of the stream) — a round AHEAD into registers, descriptors two rounds ahead (the
 // codes' addresses come out of them), and parks them in the window's LDS when the round begins.  The walk itself is the
 // same for all 16 lanes of a window (every lane reads the same two LDS addresses per step: the current row's descriptor,
 // then the code under column j): no cross-lane traffic, no select trees.  All four windows change rounds at the same
@@ -548,7 +545,7 @@ __host__ __device__ inline void poa4_dp(const Poa4Args A, Poa4Lds& S, unsigned c
 // ago (the memory counter is the wave's, not the window's).
 constexpr int kTbG = 2;
 struct alignas(16) Poa4LdsTb {
-  uint4 row[P4::G][16 * kTbG][4];  // per row of the round: 48 bytes of codes, {d0, d1, d7, -}
+  uint4 row[P4::G][16 * kTbG][3];  // per row of the round: 24 bytes of codes, 8 unused, {d0, d1, d7, -}
 };
 template <class K>
 __host__ __device__ inline void poa4_traceback(const Poa4Args A, Poa4LdsTb& S, unsigned char* slot_mem, bool act, u32 r_lo,
@@ -560,7 +557,7 @@ __host__ __device__ inline void poa4_traceback(const Poa4Args A, Poa4LdsTb& S, u
   const int gl = lane & 15, q = lane >> 4;
   const Poa4Slot sl = poa4_carve(slot_mem, A.nmax, A.lmax);
   const uint4* const dsc = sl.desc;
-  const uint4* const bps = sl.bps;
+  const uint2* const bps = sl.bps;
   u16* const pos_node = sl.g.pos_node;
   const u32 w = len + 1;
   bad = 0;
@@ -573,8 +570,8 @@ __host__ __device__ inline void poa4_traceback(const Poa4Args A, Poa4LdsTb& S, u
   // the next round (descriptors and codes in flight), the round after (descriptors in flight)
   u32 nd0[kTbG] = {}, nd1[kTbG] = {}, nd7[kTbG] = {}, fd0[kTbG] = {}, fd1[kTbG] = {}, fd7[kTbG] = {};
   // (native vectors, not HIP's uint4 class: arrays of the latter stay in scratch memory when passed by reference)
-  typedef u32 v4u __attribute__((ext_vector_type(4)));
-  v4u na[kTbG] = {}, nb[kTbG] = {}, nc[kTbG] = {};
+  typedef u32 v2u __attribute__((ext_vector_type(2)));
+  v2u na[kTbG] = {}, nb[kTbG] = {}, nc[kTbG] = {};
   u32 c_rnd = 0xFFFFFFFFu, n_rnd = 0xFFFFFFFFu, f_rnd = 0xFFFFFFFFu;  // rounds LDS / the two register sets hold
   auto load_desc = [&](u32 rnd, u32 (&d0)[kTbG], u32 (&d1)[kTbG], u32 (&d7)[kTbG]) __attribute__((always_inline)) {
 #pragma unroll
@@ -583,15 +580,15 @@ __host__ __device__ inline void poa4_traceback(const Poa4Args A, Poa4LdsTb& S, u
       const uint4 da = dsc[2 * rho];
       d0[h] = da.x;
       d1[h] = da.y;
-      d7[h] = dsc[2 * rho + 1].w;
+      d7[h] = da.z;
     }
   };
-  auto load_codes = [&](const u32 (&d0)[kTbG], v4u (&a)[kTbG], v4u (&b)[kTbG], v4u (&c)[kTbG]) __attribute__((always_inline)) {
+  auto load_codes = [&](const u32 (&d0)[kTbG], v2u (&a)[kTbG], v2u (&b)[kTbG], v2u (&c)[kTbG]) __attribute__((always_inline)) {
 #pragma unroll
     for (int h = 0; h < kTbG; ++h) {
       const u32 s = d0[h] & 0xFFFFu;
       const size_t tb = s == kInactiveS ? 0u : s / K::kU;
-      const v4u* src = reinterpret_cast<const v4u*>(bps + tb * 16 + static_cast<size_t>(gl));
+      const v2u* src = reinterpret_cast<const v2u*>(bps + tb * 16 + static_cast<size_t>(gl));
       a[h] = src[0];
       b[h] = src[16];
       c[h] = src[32];
@@ -614,10 +611,9 @@ __host__ __device__ inline void poa4_traceback(const Poa4Args A, Poa4LdsTb& S, u
 #pragma unroll
         for (int h = 0; h < kTbG; ++h) {
           uint4* dst = S.row[q][16 * h + gl];
-          dst[0] = uint4{na[h].x, na[h].y, na[h].z, na[h].w};
-          dst[1] = uint4{nb[h].x, nb[h].y, nb[h].z, nb[h].w};
-          dst[2] = uint4{nc[h].x, nc[h].y, nc[h].z, nc[h].w};
-          dst[3] = uint4{nd0[h], nd1[h], nd7[h], 0u};
+          dst[0] = uint4{na[h].x, na[h].y, nb[h].x, nb[h].y};
+          dst[1] = uint4{nc[h].x, nc[h].y, 0u, 0u};
+          dst[2] = uint4{nd0[h], nd1[h], nd7[h], 0u};
         }
         c_rnd = rnd;
         if (rnd >= 1) {
@@ -654,22 +650,23 @@ __host__ __device__ inline void poa4_traceback(const Poa4Args A, Poa4LdsTb& S, u
     while (sv::any(in_round)) {
       P4_MARK("tb_step_begin");
       const u32 l = (i - 1) & (16 * kTbG - 1);
-      const uint4 d = S.row[q][l][3];
+      const uint4 d = S.row[q][l][2];
       const i32 bt = static_cast<i32>((d.y >> 16) & 0x3FFu);
       const u32 node = d.y & 0xFFFFu;
       const i32 idx = j - bt;
       const bool oob = static_cast<u32>(idx) >= static_cast<u32>(K::kBand);  // the path left the stored band
-      const u32 bo = ((d.x & 0xFFFFu) % K::kU) * 2 + (static_cast<u32>(idx) & static_cast<u32>(K::kBand - 1));  // byte among the row's 48
-      const u32 code = reinterpret_cast<const u8*>(S.row[q][l])[bo];
+      const u32 cidx = static_cast<u32>(idx) & static_cast<u32>(K::kBand - 1);
+      const u32 bo = ((d.x & 0xFFFFu) % K::kU) + (cidx >> 1);  // byte among the row's 24: one step = two columns = one byte
+      const u32 code = (static_cast<u32>(reinterpret_cast<const u8*>(S.row[q][l])[bo]) >> (4u * (cidx & 1u))) & 15u;
       const bool edge_hit = (idx < 2 && bt > 0) || (idx > K::kBand - 3 && bt + K::kBand < static_cast<i32>(w));
-      const bool isH = code == 64u;
-      const bool diag = !isH && (code & 32u) != 0;
-      const u32 k = 15u - (code & 15u);
+      const bool isH = code == 0u;  // (0: horizontal; else diagonal << 3 | 7 - in-edge)
+      const bool diag = (code & 8u) != 0;
+      const u32 k = 7u - (code & 7u);
       const u32 np = (d.y >> 26) & 15u;
       u32 ni = np == 0 ? 0u : i - ((d.z >> (5 * (k < 6 ? k : 0u))) & 31u);
       if (sv::any(in_round && !oob && !isH && np != 0 && k >= 6)) {  // in-edges 6 and 7 of a row: their ranks come from the graph
         if (in_round && !oob && !isH && np != 0 && k >= 6)
-          ni = poa4_nth_pred_rank(poa4_carve(opaque(slot_mem), A.nmax, A.lmax).g, node, k, full) - r_lo + 1;
+          ni = poa4_nth_pred_rank(poa4_carve(opaque(slot_mem), A.nmax, A.lmax), node, k, full) - r_lo + 1;
       }
       const bool mv = isH || diag;                  // the step consumes a base of the layer
       const bool jerr = !oob && mv && j == 0;       // (never on a consistent stream)
@@ -731,10 +728,8 @@ __host__ __device__ inline u32 poa4_init_window(const Poa4Args& A, const PoaWind
     g.code[i] = static_cast<u8>(poa_layer_code(A.src, bb, i));
     g.al_cnt[i] = 0;
     g.visits[i] = blen >= 2 ? 1 : 0;
-    g.rank_of[i] = static_cast<u16>(i);
     g.order[i] = static_cast<u16>(i);
-    g.bpos[i] = static_cast<u16>(i);
-    rb[i] = i | (i << 16);
+    rb[i] = i | (i << 16);  // (rank and backbone coordinate of a node live in rb[] alone here: poa2's rank_of[] / bpos[] are not kept)
     const i32 wgt = poa_layer_weight(A.src, bb, i);
     if (i > 0) {
       const i32 wp = poa_layer_weight(A.src, bb, i - 1);
@@ -821,6 +816,9 @@ __host__ __device__ inline u32 poa4_update_graph(const Poa4Args A, u16* nslot, c
     else return sv::wave_max(v);
   };
   const Poa2Slot g = poa4_graph(slot_mem, A.nmax, A.lmax, flip);
+  // rank and backbone coordinate of a node are ONE word (rb[v] = rank | coordinate << 16): one gather where poa2's separate
+  // rank_of[] / bpos[] arrays took two, one scattered store per node in the order rebuild instead of two
+  const u32* const rb32 = poa4_carve(slot_mem, A.nmax, A.lmax).rb;
   u16* const rb16 = reinterpret_cast<u16*>(poa4_carve(slot_mem, A.nmax, A.lmax).rb);  // [2 v] rank, [2 v + 1] backbone coordinate
   const PoaLayer L = *Lp;
   const u32 nmax = A.nmax, lmax = A.lmax;
@@ -848,16 +846,17 @@ __host__ __device__ inline u32 poa4_update_graph(const Poa4Args A, u16* nslot, c
   u32 carry_slot = n_old, carry_b = lb;
   if (act && first_p != 0xFFFFFFFFu) {
     const u32 an = g.pos_node[first_p];
-    u32 r = g.rank_of[an];
+    const u32 rb_an = rb32[an];
+    u32 r = rb_an & 0xFFFFu;
     const u32 ac = g.al_cnt[an];
     const uint2 al2 = *reinterpret_cast<const uint2*>(g.al + static_cast<size_t>(an) * 4);
     const u32 a0 = al2.x & 0xFFFFu, a1 = al2.x >> 16, a2 = al2.y & 0xFFFFu;
-    const u32 r0 = g.rank_of[ac > 0 ? a0 : an], r1 = g.rank_of[ac > 1 ? a1 : an], r2 = g.rank_of[ac > 2 ? a2 : an];
+    const u32 r0 = rb32[ac > 0 ? a0 : an] & 0xFFFFu, r1 = rb32[ac > 1 ? a1 : an] & 0xFFFFu, r2 = rb32[ac > 2 ? a2 : an] & 0xFFFFu;
     r = r0 < r ? r0 : r;
     r = r1 < r ? r1 : r;
     r = r2 < r ? r2 : r;
     carry_slot = r;
-    carry_b = g.bpos[an];
+    carry_b = rb_an >> 16;
   }
   u32 total_new = 0;
   u32 why = 0;  // != 0: the window has failed; its lanes keep step with the wave without touching the graph
@@ -885,8 +884,9 @@ __host__ __device__ inline u32 poa4_update_graph(const Poa4Args A, u16* nslot, c
       const u32 a = has[u] ? an[u] : 0u;
       c_an[u] = g.code[a];
       ac[u] = g.al_cnt[a];
-      rk_an[u] = g.rank_of[a];
-      bp_an[u] = g.bpos[a];
+      const u32 rba = rb32[a];
+      rk_an[u] = rba & 0xFFFFu;
+      bp_an[u] = rba >> 16;
       al2[u] = *reinterpret_cast<const uint2*>(g.al + static_cast<size_t>(a) * 4);
       wgt[u] = valid[u] ? static_cast<i32>(static_cast<u8>(poa_layer_weight(A.src, L, p[u]))) : 0;
     }
@@ -902,7 +902,7 @@ __host__ __device__ inline u32 poa4_update_graph(const Poa4Args A, u16* nslot, c
       for (int k = 0; k < 3; ++k) {
         const u32 t = static_cast<u32>(k) < ac[u] ? kt[u][k] : 0u;
         c_kt[u][k] = g.code[t];
-        rk_kt[u][k] = g.rank_of[t];
+        rk_kt[u][k] = rb32[t] & 0xFFFFu;
       }
     }
     // where every position lands; order slot / backbone coordinate of the last aligned position at or before it
@@ -950,7 +950,6 @@ __host__ __device__ inline u32 poa4_update_graph(const Poa4Args A, u16* nslot, c
         t = id;
         nslot[tn] = static_cast<u16>(fslot);
         g.code[id] = static_cast<u8>(letter[u]);
-        g.bpos[id] = static_cast<u16>(fb);
         rb16[2 * static_cast<size_t>(id) + 1] = static_cast<u16>(fb);
         u32 c2 = 0;
         uint2 mine = uint2{0, 0};
@@ -1064,7 +1063,6 @@ __host__ __device__ inline u32 poa4_update_graph(const Poa4Args A, u16* nslot, c
             else hi = mid;
           }
           g.order2[rr[u] + lo] = static_cast<u16>(vv[u]);
-          g.rank_of[vv[u]] = static_cast<u16>(rr[u] + lo);
           rb16[2 * static_cast<size_t>(vv[u])] = static_cast<u16>(rr[u] + lo);
         }
       }
@@ -1074,7 +1072,6 @@ __host__ __device__ inline u32 poa4_update_graph(const Poa4Args A, u16* nslot, c
       if (doit && t < n_new) {
         const u32 r = static_cast<u32>(nslot[t]) + t;
         g.order2[r] = static_cast<u16>(n_old + t);
-        g.rank_of[n_old + t] = static_cast<u16>(r);
         rb16[2 * static_cast<size_t>(n_old + t)] = static_cast<u16>(r);
       }
     }
@@ -1092,6 +1089,8 @@ __host__ __device__ inline u32 poa4_update_graph(const Poa4Args A, u16* nslot, c
 __host__ __device__ inline void poa4_consensus(Poa2Slot& g, u32 n_nodes, u32 nmax, const PoaWindow& win, int trim, Poa4Lds& S,
                                                u8* out, u32* out_len) {
   const int lane = sv::lane();
+  // (the lane-0 code shared with poa2.hip wants a node's rank in rank_of[], which this kernel does not keep per layer)
+  for (u32 r = lane; r < n_nodes; r += 64) g.rank_of[g.order[r]] = static_cast<u16>(r);
   constexpr u32 kCap = sizeof(Poa4Lds) / 4;
   i32* lsc = reinterpret_cast<i32*>(&S);
   i32 maxn = -1;
@@ -1628,12 +1627,12 @@ __host__ __device__ inline void poa4_phase_desc_onewave(const Poa4Args& A, const
         uint4 da, db;
         da.x = Srow | (own << 16);
         da.y = v | (static_cast<u32>(b) << 16) | ((np > 15u ? 15u : np) << 26) | (marked[u] ? 1u << 30 : 0u) | (endn ? 1u << 31 : 0u);
-        da.z = mm;
+        da.z = lbw;
         da.w = ep[0];
         db.x = ep[1];
         db.y = ep[2];
         db.z = ep[3];
-        db.w = lbw;
+        db.w = mm;
         sl.desc[2 * static_cast<size_t>(rho)] = da;
         sl.desc[2 * static_cast<size_t>(rho) + 1] = db;
         t_end = static_cast<i32>(Srow) + 17 > t_end ? static_cast<i32>(Srow) + 17 : t_end;

@@ -52,7 +52,7 @@ SYMBOLS = [
     "rvn_engine_map_collect", "rvn_free",
     "rvn_find_overlaps_and_repetitive_regions", "rvn_pass2_num_overlaps", "rvn_pass2_kmer_cells", "rvn_pass2_fetch",
     "rvn_pass2_destroy", "rvn_engine_release_scratch", "rvn_filter_overlaps_by_identity", "rvn_pass1_find_chimeric_regions",
-    "rvn_reads_load", "rvn_reads_name", "rvn_reads_info", "rvn_reads_fetch", "rvn_engine_set_option",
+    "rvn_reads_load", "rvn_reads_name", "rvn_reads_info", "rvn_reads_fetch", "rvn_engine_set_option", "rvn_overlap_update_and_type",
 ]
 
 # TEST INFRASTRUCTURE: what include/raven_hip_test.h declares on top (libraven_hip_test.so only)
@@ -954,6 +954,18 @@ def test_find_chimeric_regions(data):
     if n < 0:
         raise ValueError("rvn_test_find_chimeric_regions: %d" % n)
     return out[:2 * n].reshape(-1, 2).copy()
+
+
+def overlap_update_and_type(overlaps, pile_begin, pile_end, pile_invalid):
+    """rvn_overlap_update_and_type: raven::OverlapUpdate + GetOverlapType on host arrays (overlap_utils.cc:14-121):
+    (updated overlaps, ok, type)."""
+    o = np.ascontiguousarray(overlaps, dtype=OVERLAP_DTYPE).copy()
+    b = np.ascontiguousarray(pile_begin, dtype=np.uint32)
+    ok = np.zeros(o.shape[0], dtype=np.uint8)
+    ty = np.zeros(o.shape[0], dtype=np.uint32)
+    _check(lib().rvn_overlap_update_and_type(_p(o), o.shape[0], _p(b), _p(np.ascontiguousarray(pile_end, dtype=np.uint32)),
+                                             _p(np.ascontiguousarray(pile_invalid, dtype=np.uint8)), b.shape[0], _p(ok), _p(ty)))
+    return o, ok, ty
 
 
 def test_overlap_update_and_type(overlaps, pile_begin, pile_end, pile_invalid):

@@ -45,6 +45,7 @@ for l in sys.stdin:
     parity) timeout 1200 python tools/poa_parity.py $arg > gpurun_out/${TAG}_poa_parity_$arg.json 2> gpurun_out/${TAG}_poa_parity.err; python -c "
 import json; d = json.load(open('gpurun_out/${TAG}_poa_parity_$arg.json')); print({k: v for k, v in d.items() if k not in ('examples', 'not_explained')}, 'unexplained', len(d['not_explained']))";;
     profile) bash tools/profile_round.sh $arg;;
+    sqpoa) bash tools/prof_poa.sh $arg;;
     *) echo "unknown step $step";;
   esac
   echo "[$step] $(( $(date +%s) - t0 )) s"

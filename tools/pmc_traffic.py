@@ -1,9 +1,15 @@
 #!/usr/bin/env python3
 """Combine the FETCH_SIZE and WRITE_SIZE rocprofv3 --pmc passes into per-kernel HBM bytes per launch:
-    python tools/pmc_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> profiles/r02_pmc_traffic.json
-hbm_bytes = 2 * FETCH_SIZE * 1024 + WRITE_SIZE * 1024  (gfx950 correction of MI355X_MICROARCH.md §HBM: FETCH_SIZE
-reports half the bytes of wide coalesced reads; WRITE_SIZE is taken as is, uncalibrated).  Template instances of one
-kernel site (bench.py's kernel names) are pooled: bytes per launch = sum over the instances / number of launches."""
+    python tools/pmc_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> profiles/r05_pmc_traffic.json [rounds] [calibration.json]
+Per kernel site BOTH readings are kept:
+    hbm_bytes_raw_per_launch = FETCH_SIZE * 1024 + WRITE_SIZE * 1024          the counters as rocprofv3 reports them
+    hbm_bytes_per_launch     = 2 * FETCH_SIZE * 1024 + WRITE_SIZE * 1024      the guide's gfx950 correction (MI355X_MICROARCH.md
+                               HBM section: FETCH_SIZE reports half the bytes of WIDE COALESCED reads) — an upper reading for
+                               kernels that gather: tools/pmc_calibrate.sh measures what the counters report for streams,
+                               4-byte / 16-byte gathers and scattered 2-byte stores on this box, and its factors are copied
+                               into the file ("calibration").
+Template instances of one kernel site (bench.py's kernel names) are pooled: bytes per launch = sum over the instances /
+number of launches."""
 import collections
 import csv
 import json
@@ -12,9 +18,7 @@ import sys
 
 SITES = [  # (regex on the demangled kernel name, bench.py kernel-site name)
     (r"nw_sweep_kernel", "nw_forward"), (r"nw_trace_kernel", "nw_traceback"), (r"poa2_kernel", "poa2"),
-    (r"poa4_dp_kernel", "poa4_dp"), (r"poa4_tb_kernel", "poa4_tb"), (r"poa4_update_kernel", "poa4_update"),
-    (r"poa4_desc_kernel", "poa4_desc"), (r"poa4_setup_kernel", "poa4_setup"), (r"poa4_final_kernel", "poa4_final"),
-    (r"poa4_init_kernel", "poa4_init"),
+    (r"poa4_persistent_kernel", "poa4_persistent"),
     (r"\bpoa_kernel", "poa"), (r"chain_small_kernel", "chain_small"), (r"chain_kernel", "chain"),
     (r"rs_downsweep_kernel", "rs_downsweep"), (r"rs_upsweep_kernel", "rs_upsweep"),
     (r"sketch_kernel<[^>]*false>", "sketch_count"), (r"sketch_kernel<[^>]*true>", "sketch_write"),
@@ -57,7 +61,7 @@ def kernel_source_hash():
     return h.hexdigest()
 
 
-def main(fetch_csv, write_csv, out, rounds=None):
+def main(fetch_csv, write_csv, out, rounds=None, calibration=None):
     f, w = load(fetch_csv), load(write_csv)
     kernels = {}
     for k in sorted(set(f) | set(w)):
@@ -66,9 +70,10 @@ def main(fetch_csv, write_csv, out, rounds=None):
         fe_l = fe * 1024 / max(nf, 1)
         wr_l = wr * 1024 / max(nw, 1)
         kernels[k] = {"launches_fetch_pass": nf, "launches_write_pass": nw, "fetch_size_bytes_per_launch": int(fe_l),
-                      "write_size_bytes_per_launch": int(wr_l), "hbm_bytes_per_launch": int(2 * fe_l + wr_l)}
-    # the window-consensus stage is a set of launches per polishing round (poa4.hip's phase kernels + poa2.hip for what the
-    # 32-column band hands on): its traffic is the sum over all of them / the polishing rounds of the profiled command
+                      "write_size_bytes_per_launch": int(wr_l), "hbm_bytes_raw_per_launch": int(fe_l + wr_l),
+                      "hbm_bytes_per_launch": int(2 * fe_l + wr_l)}
+    # the window-consensus stage of a polishing round = one launch of poa4.hip's persistent kernel + poa2.hip for what the
+    # 32-column band hands on: its traffic is the sum over both / the polishing rounds of the profiled command
     stage = {"fetch": 0.0, "write": 0.0}
     for k in set(f) | set(w):
         if k.startswith("poa4_") or k == "poa2":
@@ -79,15 +84,24 @@ def main(fetch_csv, write_csv, out, rounds=None):
         kernels["poa_banded"] = {"launches_fetch_pass": int(r), "launches_write_pass": int(r),
                                  "fetch_size_bytes_per_launch": int(stage["fetch"] / r),
                                  "write_size_bytes_per_launch": int(stage["write"] / r),
+                                 "hbm_bytes_raw_per_launch": int((stage["fetch"] + stage["write"]) / r),
                                  "hbm_bytes_per_launch": int((2 * stage["fetch"] + stage["write"]) / r),
-                                 "note": "one 'launch' = the launch set of one polishing round (all poa4_* kernels + poa2)"}
+                                 "note": "one 'launch' = the launches of one polishing round (poa4_persistent + poa2 escalations)"}
+    cal = None
+    if calibration:
+        try:
+            cal = {k: {x: y for x, y in v.items() if not x.endswith("_KiB")} for k, v in json.load(open(calibration))["patterns"].items()}
+        except (OSError, ValueError, KeyError):
+            cal = None
     json.dump({"method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE in separate passes of `python bench.py "
-                         "--no-cpu-baseline`; hbm = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 per launch (gfx950: FETCH_SIZE counts "
-                         "128-B requests as 64 B, MI355X_MICROARCH.md HBM section; WRITE_SIZE uncalibrated)",
-               "kernel_source_sha1": kernel_source_hash(), "kernels": kernels},
+                         "--no-cpu-baseline`; raw = FETCH_SIZE*1024 + WRITE_SIZE*1024, corrected = 2*FETCH_SIZE*1024 + "
+                         "WRITE_SIZE*1024 per launch (gfx950: FETCH_SIZE counts 128-B requests of wide coalesced reads as 64 B, "
+                         "MI355X_MICROARCH.md HBM section); 'calibration' = counter bytes / known bytes of tools/pmc_calibrate.hip's "
+                         "access patterns on the same box",
+               "kernel_source_sha1": kernel_source_hash(), "calibration": cal, "kernels": kernels},
               open(out, "w"), indent=1, sort_keys=True)
     print("wrote", out)
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:4], rounds=(sys.argv[4] if len(sys.argv) > 4 else None))
+    main(*sys.argv[1:4], rounds=(sys.argv[4] if len(sys.argv) > 4 else None), calibration=(sys.argv[5] if len(sys.argv) > 5 else None))

@@ -4,7 +4,7 @@
 #   2. / 3. separate --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of the same command (HBM traffic per launch)
 # Outputs under gpurun_out/<tag>_*; tools/pmc_traffic.py + the stats CSV are what gets copied to profiles/.
 R=${GRAFT_REPO_ROOT:-/root/repo}
-TAG=${1:-r04}
+TAG=${1:-r05}
 WORKLOAD=${2:-c4}
 mkdir -p $R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
@@ -14,7 +14,9 @@ timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/
 F=$(find $R/gpurun_out/${TAG}_pmc_fetch -name '*counter_collection.csv' | head -1)
 W=$(find $R/gpurun_out/${TAG}_pmc_write -name '*counter_collection.csv' | head -1)
 # the default command = (2 warm-up + 2 timed) steps x 2 polishing rounds
-python $R/tools/pmc_traffic.py "$F" "$W" $R/gpurun_out/${TAG}_pmc_traffic.json 8
+# what the counters report for known byte counts on this box (streams, gathers, scattered stores)
+bash $R/tools/pmc_calibrate.sh $R/gpurun_out/${TAG}_pmc_calibration.json > $R/gpurun_out/${TAG}_pmc_calibration.log 2>&1
+python $R/tools/pmc_traffic.py "$F" "$W" $R/gpurun_out/${TAG}_pmc_traffic.json 8 $R/gpurun_out/${TAG}_pmc_calibration.json
 S=$(find $R/gpurun_out/${TAG}_stats -name '*kernel_stats.csv' | head -1)
 cp "$S" $R/gpurun_out/${TAG}_kernel_stats.csv
 # the raw per-dispatch files are large: keep only the summaries
