@@ -273,6 +273,14 @@ int rvn_polish_round(rvn_engine* e, rvn_reads* targets, rvn_reads* reads, const 
  *   6. rvn_shard_piles            pile owner: merge (construct.cc:72-77), AddLayers, top-kMax truncation
  * The result for the reads a rank owns is bit-identical to the single-GPU pass (tests/test_gpu_sharded.py). */
 int rvn_shard_sketch(rvn_engine* e, const rvn_reads* own_reads, int index_minhash, uint64_t* count);
+/* The same for the reads [first, last) of `own` (indices into the handle).  foreign != 0: these reads belong to an EARLIER
+ * index batch of a pass with several (construct.cc:32-37: an index batch is 2^32 bases; every read up to the batch's end is
+ * mapped against it, :59-64): only their minhash-selected minimizers come back, flagged query-only (bit 62 of the origin
+ * word beside the query flag, bit 63) — the index shard sorts them in beside its members, the self-join matches them
+ * against the members and never counts them towards a key's occurrence.  Fetch with rvn_shard_sketch_fetch[_dev] before
+ * the next call. */
+int rvn_shard_sketch_range(rvn_engine* e, const rvn_reads* own, uint32_t first, uint32_t last, int index_minhash, int foreign,
+                           uint64_t* count);
 int rvn_shard_sketch_fetch(rvn_engine* e, uint64_t* values, uint64_t* origins);
 int rvn_shard_index_build(rvn_engine* e, const uint64_t* values, const uint64_t* origins, uint64_t n, int all_query);
 int rvn_shard_key_counts(rvn_engine* e, uint32_t* counts /* n_keys of rvn_engine_index_size */);
@@ -370,7 +378,8 @@ int rvn_polish_round_range(rvn_engine* e, rvn_reads* targets, rvn_reads* reads, 
  *   rvn_group_find_overlaps_and_create_piles   = rvn_find_overlaps_and_create_piles over all devices: bounds[n_devices + 1]
  *       receives the read ranges, out[r] a pass handle whose piles / overlap lists are complete for the reads
  *       [bounds[r], bounds[r+1]) (fetch them with rvn_pass1_fetch_* — arrays are indexed by GLOBAL read id — and release
- *       with rvn_pass1_destroy).  One index batch: total bases < 2^32.
+ *       with rvn_pass1_destroy).  A read set beyond 2^32 bases is indexed in several batches as construct.cc:32-37 does
+ *       (rvn_group_find_overlaps_and_create_piles_batched takes the batch size: tests force several batches with it).
  *   rvn_group_polish_round                     = rvn_polish_round over all devices (reads mapped by slice, windows by range,
  *       pieces concatenated in rank order); host arrays in, consensus out as in rvn_polish_round. */
 typedef struct rvn_group rvn_group;
@@ -382,11 +391,30 @@ rvn_engine* rvn_group_engine(rvn_group* g, uint32_t rank);
 int rvn_group_find_overlaps_and_create_piles(rvn_group* g, const uint64_t* packed, const uint64_t* word_offsets,
                                              const uint32_t* lengths, uint32_t n_reads, double freq, uint32_t kmax,
                                              int use_minhash, uint64_t flush_bases, uint32_t* bounds, rvn_pass1** out);
+int rvn_group_find_overlaps_and_create_piles_batched(rvn_group* g, const uint64_t* packed, const uint64_t* word_offsets,
+                                                     const uint32_t* lengths, uint32_t n_reads, double freq, uint32_t kmax,
+                                                     int use_minhash, uint64_t index_batch_bases, uint64_t flush_bases,
+                                                     uint32_t* bounds, rvn_pass1** out);
 int rvn_group_polish_round(rvn_group* g, const uint64_t* t_packed, const uint64_t* t_word_offsets, const uint32_t* t_lengths,
                            uint32_t n_targets, const uint64_t* r_packed, const uint64_t* r_word_offsets,
                            const uint32_t* r_lengths, uint32_t n_reads, double q, double err, uint32_t w, int trim, int match,
                            int mismatch, int gap, uint8_t* out_codes, const uint64_t* out_offsets, uint32_t* out_len,
                            double* ratio);
+/* The same round with base qualities (the FASTQ variant of raven::Polish: racon's mean-quality filter against `q`,
+ * polish.cc:26-41, and quality-weighted edges in the window graphs): r_quals = Phred+33 bytes, one per
+ * 2^qual_block_shift bases of a read (6 = biosoup's block_quality), read i at r_qual_offsets[i] — exactly what
+ * rvn_reads_attach_quality takes; every rank attaches them to its copy of the read set.  r_quals == NULL is
+ * rvn_group_polish_round. */
+int rvn_group_polish_round_q(rvn_group* g, const uint64_t* t_packed, const uint64_t* t_word_offsets, const uint32_t* t_lengths,
+                             uint32_t n_targets, const uint64_t* r_packed, const uint64_t* r_word_offsets,
+                             const uint32_t* r_lengths, uint32_t n_reads, const uint8_t* r_quals, const uint64_t* r_qual_offsets,
+                             int qual_block_shift, double q, double err, uint32_t w, int trim, int match, int mismatch, int gap,
+                             uint8_t* out_codes, const uint64_t* out_offsets, uint32_t* out_len, double* ratio);
+/* Which ranks reach each other's memory directly: direct[i * n + j] = 1 when rank i pulls from rank j without staging (the
+ * same device, or hipDeviceCanAccessPeer + hipDeviceEnablePeerAccess succeeded: xGMI on an MI355X node); 0 = the copy goes
+ * through host memory (still correct, PCIe speed).  direct may be NULL.  Returns 1 when every pair is direct, 0 when
+ * some pair is not, RVN_EINVAL for a NULL group. */
+int rvn_group_peer_access(const rvn_group* g, uint8_t* direct);
 
 /* raven::OverlapUpdate (RavenLib/src/overlap_utils.cc:14-85) followed by raven::GetOverlapType (:87-121) on a list of
  * overlaps, on the HOST (the library's __host__ build of the rules its kernels run: raven_amd/csrc/overlap_rules.h) — for

@@ -99,11 +99,14 @@ void FindOverlapsAndCreatePiles(const std::shared_ptr<thread_pool::ThreadPool>& 
 }
 
 // One racon round (racon::Polisher::Polish, polish.cc:51) over the group: same result names and tags as
-// racon/polisher.hpp.  Reads without qualities (unit weights); quality-weighted rounds use racon::Polisher on one device.
+// racon/polisher.hpp.  Qualities as there: when EVERY sequence carries biosoup's block_quality the round is the FASTQ
+// variant (racon's mean-quality filter against quality_threshold — the avg_q of polish.cc:26-41 — and quality-weighted
+// edges); otherwise unit weights and no filter.
 inline std::vector<std::unique_ptr<biosoup::NucleicAcid>> PolishRound(
     DeviceGroup& group, const std::vector<std::unique_ptr<biosoup::NucleicAcid>>& targets,
     const std::vector<std::unique_ptr<biosoup::NucleicAcid>>& sequences, bool drop_unpolished, double error_threshold = 0.3,
-    std::uint32_t window_len = 500, bool trim = true, std::int8_t match = 3, std::int8_t mismatch = -5, std::int8_t gap = -4) {
+    std::uint32_t window_len = 500, bool trim = true, std::int8_t match = 3, std::int8_t mismatch = -5, std::int8_t gap = -4,
+    double quality_threshold = 10.0) {
   std::vector<std::unique_ptr<biosoup::NucleicAcid>> dst;
   if (targets.empty()) return dst;
   ram::detail::PackedReads<decltype(targets.begin())> t(targets.begin(), targets.end());
@@ -114,11 +117,26 @@ inline std::vector<std::unique_ptr<biosoup::NucleicAcid>> PolishRound(
   std::vector<std::uint8_t> codes(ooff[n] + 1);
   std::vector<std::uint32_t> len(n);
   std::vector<double> ratio(n);
-  ram::detail::Check(rvn_group_polish_round(group.handle(), t.packed.data(), t.word_offsets.data(), t.lengths.data(),
-                                            static_cast<std::uint32_t>(n), r.packed.data(), r.word_offsets.data(),
-                                            r.lengths.data(), static_cast<std::uint32_t>(sequences.size()), 0.0,
-                                            error_threshold, window_len, trim ? 1 : 0, match, mismatch, gap, codes.data(),
-                                            ooff.data(), len.data(), ratio.data()));
+  // biosoup keeps one mean Phred per 64 bases (block_quality) and racon only ever sees that mean: block bytes + 33 go over
+  // the boundary as they are (block shift 6), as in racon/polisher.hpp
+  bool has_q = !sequences.empty();
+  for (const auto& s : sequences) has_q = has_q && !s->block_quality.empty();
+  std::vector<std::uint8_t> quals;
+  std::vector<std::uint64_t> qoff(1, 0);
+  if (has_q) {
+    for (const auto& s : sequences) {
+      const std::size_t blocks = (static_cast<std::size_t>(s->inflated_len) + 63) / 64;
+      for (std::size_t i = 0; i < blocks; ++i)
+        quals.push_back(static_cast<std::uint8_t>((i < s->block_quality.size() ? s->block_quality[i] : 0) + 33));
+      qoff.push_back(quals.size());
+    }
+  }
+  ram::detail::Check(rvn_group_polish_round_q(group.handle(), t.packed.data(), t.word_offsets.data(), t.lengths.data(),
+                                              static_cast<std::uint32_t>(n), r.packed.data(), r.word_offsets.data(),
+                                              r.lengths.data(), static_cast<std::uint32_t>(sequences.size()),
+                                              has_q ? quals.data() : nullptr, has_q ? qoff.data() : nullptr, 6,
+                                              has_q ? quality_threshold : 0.0, error_threshold, window_len, trim ? 1 : 0, match,
+                                              mismatch, gap, codes.data(), ooff.data(), len.data(), ratio.data()));
   // reads used per target (racon's RC:i: tag): every rank holds the complete best-overlap table, so rank 0's counts are
   // the round's
   std::vector<std::uint32_t> used(n, 0);

@@ -253,7 +253,25 @@ struct KernelScope {
 // Bit 63 of an index origin marks "this minimizer is also a (minhash) query minimizer" (self-join path);
 // read ids must therefore stay below 2^31.  Every consumer of an origin's id masks it.
 constexpr u64 kQueryFlag = 1ULL << 63;
-__host__ __device__ inline u32 origin_id(u64 org) { return static_cast<u32>(org >> 32) & 0x7FFFFFFFu; }
+// An entry that is a QUERY ONLY: a minimizer of a read that does not belong to the index batch at hand (sharded pass with
+// more than one index batch: reads of earlier batches are mapped against every later batch's index, construct.cc:59-64
+// inside the loop of :32-37).  Such entries take part in the sort so that the self-join finds them beside the index's
+// runs, but they are no members: they do not count towards a key's occurrence and are nobody's match.  Their reads have
+// smaller ids than every member's, and the sort is stable, so they are the FRONT of their run.
+constexpr u64 kForeignFlag = 1ULL << 62;
+__host__ __device__ inline u32 origin_id(u64 org) { return static_cast<u32>(org >> 32) & 0x3FFFFFFFu; }
+// number of foreign entries at the front of the run [s, s + c) of a sorted origin array (binary search: the flag is
+// monotone within a run)
+__host__ __device__ inline u32 run_foreign_prefix(const u64* s_org, u32 s, u32 c) {
+  if (c == 0 || !(s_org[s] & kForeignFlag)) return 0;
+  u32 lo = 1, hi = c;  // first index without the flag lies in [lo, hi]
+  while (lo < hi) {
+    const u32 mid = (lo + hi) >> 1;
+    if (s_org[s + mid] & kForeignFlag) lo = mid + 1;
+    else hi = mid;
+  }
+  return lo;
+}
 
 struct Overlap {
   u32 lhs_id, lhs_begin, lhs_end, rhs_id, rhs_begin, rhs_end, score, strand;

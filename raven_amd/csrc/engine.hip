@@ -485,8 +485,9 @@ int rvn_reads_upload(rvn_engine* h, const uint64_t* packed, uint64_t n_words, co
     r.ids_are_indices = true;
     for (u32 i = 0; i < n; ++i) {
       r.h_id[i] = ids ? ids[i] : i;
-      if (r.h_id[i] != i || i >= (1u << 31)) r.ids_are_indices = false;
-      if (r.h_id[i] >= (1u << 31)) return fail(RVN_EINVAL, "[raven_hip] read ids must be below 2^31");
+      if (r.h_id[i] != i || i >= (1u << 30)) r.ids_are_indices = false;
+      // (bits 63 / 62 of a minimizer's origin word are the query / query-only flags: 30 bits of read id are left)
+      if (r.h_id[i] >= (1u << 30)) return fail(RVN_EINVAL, "[raven_hip] read ids must be below 2^30");
     }
     r.total_bases = 0;
     for (u32 i = 0; i < n; ++i) {
@@ -1261,6 +1262,56 @@ int rvn_shard_sketch(rvn_engine* h, const rvn_reads* rr, int index_minhash, uint
   });
 }
 
+namespace {
+__global__ void or_flags_kernel(u64* __restrict__ org, u64 n, u64 flags) {
+  const u64 i = static_cast<u64>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n) org[i] |= flags;
+}
+}  // namespace
+
+int rvn_shard_sketch_range(rvn_engine* h, const rvn_reads* rr, uint32_t first, uint32_t last, int index_minhash, int foreign,
+                           uint64_t* count) {
+  return guarded(h ? &h->e : nullptr, [&]() -> int {
+    if (!h || !rr || !count) return fail(RVN_EINVAL, "[raven_hip] rvn_shard_sketch_range: NULL argument");
+    Engine& e = h->e;
+    const ReadsDev& r = rr->r;
+    if (first > last || last > r.n) return fail(RVN_EINVAL, "[raven_hip] rvn_shard_sketch_range: range beyond the read set");
+    RVN_HIP(hipSetDevice(e.device));
+    UseTimers ut(e);
+    StageTimer t(e, StageTimes::kSketch);
+    e.query_ready = false;
+    *count = 0;
+    e.shard_sketch_minhash = (index_minhash != 0) || (foreign != 0);
+    Sketch& res = e.shard_sketch_minhash ? e.index_sketch : e.raw_sketch;
+    res.count = 0;
+    if (first == last) {
+      t.stop();
+      return RVN_OK;
+    }
+    sketch_raw(e, r, first, last, e.raw_sketch);
+    if (foreign) {
+      // reads of an EARLIER index batch: only what Map() would look up for them — their minhash-selected minimizers — as
+      // query-only entries
+      sketch_minhash(e, r, e.raw_sketch, e.index_sketch);
+      const u64 n = e.index_sketch.count;
+      if (n) {
+        or_flags_kernel<<<static_cast<u32>((n + 255) / 256), 256, 0, e.stream>>>(e.index_sketch.org.as<u64>(), n, kQueryFlag | kForeignFlag);
+        RVN_LAUNCH_CHECK();
+      }
+    } else if (index_minhash) {
+      sketch_minhash(e, r, e.raw_sketch, e.index_sketch);
+    } else {
+      e.join_query_count = sketch_flag_queries(e, r, e.raw_sketch);  // minhash-selected entries get kQueryFlag
+    }
+    *count = res.count;
+    if (!foreign)
+      for (u32 i = first; i < last; ++i) e.c_index_bases += r.h_len[i];
+    t.stop();
+    RVN_HIP(rvn_stream_sync(e.stream));
+    return RVN_OK;
+  });
+}
+
 int rvn_shard_sketch_fetch(rvn_engine* h, uint64_t* values, uint64_t* origins) {
   return guarded(h ? &h->e : nullptr, [&]() -> int {
     if (!h) return fail(RVN_EINVAL, "[raven_hip] NULL engine");
@@ -1317,7 +1368,11 @@ int rvn_shard_key_counts(rvn_engine* h, uint32_t* counts) {
     RVN_HIP(hipSetDevice(e.device));
     std::vector<u32> st(u + 1);
     RVN_HIP(hipMemcpy(st.data(), e.index.u_start.ptr, (u + 1) * 4, hipMemcpyDeviceToHost));
-    for (u64 i = 0; i < u; ++i) counts[i] = st[i + 1] - st[i];
+    // (members only: query-only entries of reads outside the index batch, kForeignFlag, are the front of their run; a run
+    // without members reports 0 and the caller drops it)
+    std::vector<u64> so(e.index.m);
+    if (e.index.m) RVN_HIP(hipMemcpy(so.data(), e.index.s_org[e.index.cur].ptr, e.index.m * 8, hipMemcpyDeviceToHost));
+    for (u64 i = 0; i < u; ++i) counts[i] = st[i + 1] - st[i] - run_foreign_prefix(so.data(), st[i], st[i + 1] - st[i]);
     return RVN_OK;
   });
 }

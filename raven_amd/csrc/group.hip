@@ -38,6 +38,7 @@ struct rvn_group {
   std::vector<rvn_engine*> eng;
   std::vector<int> dev;
   std::vector<hipStream_t> copy_stream;
+  std::vector<uint8_t> peer_direct;  // [i * world + j]: rank i reaches rank j's memory directly (same device, or peer access on)
   // barrier + shared tables of the collectives
   std::mutex mu;
   std::condition_variable cv;
@@ -220,6 +221,7 @@ struct PassArgs {
   u32 kmax;
   int use_minhash;
   u64 flush_bases;
+  u64 index_batch_bases;
   const std::vector<u32>* bounds;
   rvn_pass1** out;
 };
@@ -242,15 +244,38 @@ void pass_rank(Rank& R, const PassArgs& A) {
     rvn_reads* p;
     ~OwnGuard() { rvn_reads_destroy(p); }
   } own_guard{own};
-  DevBuf val, org, val_p, org_p, vcat, ocat, grp, pos, seg, per_read, cnt_flat, grp_flat, pos_flat, seg_own, grp_own, pos_own, ovl,
+  DevBuf val, org, val_f, org_f, val_p, org_p, vcat, ocat, grp, pos, seg, per_read, cnt_flat, grp_flat, pos_flat, seg_own, grp_own, pos_own, ovl,
       ovl_p, off_own, recv;
 
-  // 1. sketch; minimizers to the owner of their hash class (stable partition keeps (read, position) order)
-  uint64_t n_min = 0;
-  R.check(rvn_shard_sketch(R.e, own, A.use_minhash, &n_min));
+  std::vector<u64> r_split(world);
+  for (u32 h = 0; h < world; ++h) r_split[h] = bounds[h + 1] - bounds[h];
+  rvn_pass1* p = nullptr;
+  R.check(rvn_shard_piles_create(R.e, A.lengths, n_total, &p));
+  A.out[g] = p;
+  // Index batches as the reference cuts them (construct.cc:32-37: a batch closes with the read that brings its bases to
+  // 2^32); every read up to a batch's end is mapped against it (:59-64)
+  for (const auto& batch : flush_windows(A.lengths, n_total, A.index_batch_bases)) {
+  // 1. sketch: the members of the batch and, as query-only entries, the minhash-selected minimizers of this rank's EARLIER
+  //    reads; minimizers to the owner of their hash class (stable partition keeps (read, position) order)
+  const u32 f_hi = std::min(std::max(batch.first, lo), hi) - lo;
+  const u32 m_lo = f_hi, m_hi = std::min(std::max(batch.second, lo), hi) - lo;
+  uint64_t n_for = 0, n_mem = 0;
+  if (f_hi > 0) {
+    R.check(rvn_shard_sketch_range(R.e, own, 0, f_hi, A.use_minhash, 1, &n_for));
+    u64* fv = val_f.get<u64>(n_for + 2);
+    u64* fo = org_f.get<u64>(n_for + 2);
+    if (n_for) R.check(rvn_shard_sketch_fetch_dev(R.e, fv, fo));
+  }
+  if (m_hi > m_lo) R.check(rvn_shard_sketch_range(R.e, own, m_lo, m_hi, A.use_minhash, 0, &n_mem));
+  const uint64_t n_min = n_for + n_mem;
   u64* d_val = val.get<u64>(n_min + 2);
   u64* d_org = org.get<u64>(n_min + 2);
-  R.check(rvn_shard_sketch_fetch_dev(R.e, d_val, d_org));
+  if (n_for) {
+    R.hip(hipMemcpyAsync(d_val, val_f.as<u64>(), n_for * 8, hipMemcpyDeviceToDevice, R.cs), "copy");
+    R.hip(hipMemcpyAsync(d_org, org_f.as<u64>(), n_for * 8, hipMemcpyDeviceToDevice, R.cs), "copy");
+    R.hip(hipStreamSynchronize(R.cs), "copy");
+  }
+  if (n_mem) R.check(rvn_shard_sketch_fetch_dev(R.e, d_val + n_for, d_org + n_for));
   std::vector<u64> cnt(world, 0);
   const u64 *send_v = d_val, *send_o = d_org;
   if (world == 1) {
@@ -281,12 +306,7 @@ void pass_rank(Rank& R, const PassArgs& A) {
   R.check(rvn_engine_set_occurrence(R.e, occurrence_of(R, hist, over, A.freq)));
 
   // 4.-6. per flush window of query reads (merge + AddLayers + truncation per window, as the reference flushes)
-  std::vector<u64> r_split(world);
-  for (u32 h = 0; h < world; ++h) r_split[h] = bounds[h + 1] - bounds[h];
-  rvn_pass1* p = nullptr;
-  R.check(rvn_shard_piles_create(R.e, A.lengths, n_total, &p));
-  A.out[g] = p;
-  for (const auto& win : flush_windows(A.lengths, n_total, A.flush_bases)) {
+  for (const auto& win : flush_windows(A.lengths, batch.second, A.flush_bases)) {
     uint64_t n_m = 0;
     R.check(rvn_shard_join_range(R.e, n_total, 1, 1, win.first, win.second, &n_m));
     u64* d_grp = grp.get<u64>(n_m + 2);
@@ -348,6 +368,7 @@ void pass_rank(Rank& R, const PassArgs& A) {
     part_n.push_back(n_o);
     R.check(rvn_shard_piles_merge_parts_dev(p, static_cast<u32>(parts.size()), parts.data(), part_n.data(), A.kmax));
   }
+  }  // index batches
 }
 
 struct PolishArgs {
@@ -360,6 +381,9 @@ struct PolishArgs {
   double q, err;
   u32 w;
   int trim, m, n, gp;
+  const uint8_t* r_quals;       // Phred+33 per 2^shift bases of a read, or nullptr (unit weights, no quality filter)
+  const uint64_t* r_qual_off;
+  int qual_shift;
   uint8_t* out_codes;
   const uint64_t* out_offsets;
   uint32_t* out_len;
@@ -377,6 +401,9 @@ void polish_rank(Rank& R, const PolishArgs& A) {
     ~Guard() { rvn_reads_destroy(p); }
   } tg{targets}, rg{reads};
   R.check(rvn_reads_upload(R.e, A.r_packed, A.r_woff[A.nr], A.r_woff, A.r_len, nullptr, A.nr, &reads));
+  // qualities travel with the read set (biosoup's block qualities: racon's mean-quality filter and the quality-weighted
+  // edges of the window graphs, polish.cc:26-41): every rank holds all reads, so every rank attaches all of them
+  if (A.r_quals) R.check(rvn_reads_attach_quality(R.e, reads, A.r_quals, A.r_qual_off, A.qual_shift));
   u64 n_win = 0;
   for (u32 t = 0; t < A.nt; ++t) n_win += (static_cast<u64>(A.t_len[t]) + A.w - 1) / A.w;
   const u64 w_lo = n_win * g / world, w_hi = n_win * (g + 1) / world;
@@ -505,8 +532,22 @@ int rvn_group_create(rvn_group** out, uint32_t k, uint32_t w, uint32_t bandwidth
       return RVN_EHIP;
     }
     g->copy_stream.push_back(s);
-    for (uint32_t j = 0; j < n_devices; ++j)  // direct peer access where the devices differ (ignored where it exists already)
-      if (devices[j] != devices[i]) (void)hipDeviceEnablePeerAccess(devices[j], 0);
+    // Direct peer access where the devices differ.  A pair without it still works — hipMemcpyPeerAsync then stages the
+    // copy through host memory — but at PCIe speed instead of xGMI's: the group records which pairs are direct
+    // (rvn_group_peer_access) so that a caller / a bench line can say which it measured.
+    for (uint32_t j = 0; j < n_devices; ++j) {
+      int direct = 1;
+      if (devices[j] != devices[i]) {
+        int can = 0;
+        direct = (hipDeviceCanAccessPeer(&can, devices[i], devices[j]) == hipSuccess && can) ? 1 : 0;
+        if (direct) {
+          const hipError_t pe = hipDeviceEnablePeerAccess(devices[j], 0);
+          if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) direct = 0;
+        }
+        (void)hipGetLastError();
+      }
+      g->peer_direct.push_back(static_cast<uint8_t>(direct));
+    }
   }
   (void)hipGetLastError();
   g->slot.resize(n_devices);
@@ -526,25 +567,32 @@ void rvn_group_destroy(rvn_group* g) {
 
 uint32_t rvn_group_size(const rvn_group* g) { return g ? g->world() : 0; }
 
+int rvn_group_peer_access(const rvn_group* g, uint8_t* direct) {
+  if (!g) return RVN_EINVAL;
+  const size_t n = static_cast<size_t>(g->world()) * g->world();
+  int all = 1;
+  for (size_t i = 0; i < n && i < g->peer_direct.size(); ++i) {
+    if (direct) direct[i] = g->peer_direct[i];
+    all = all && g->peer_direct[i];
+  }
+  return all ? 1 : 0;
+}
+
 rvn_engine* rvn_group_engine(rvn_group* g, uint32_t rank) { return (g && rank < g->world()) ? g->eng[rank] : nullptr; }
 
-int rvn_group_find_overlaps_and_create_piles(rvn_group* g, const uint64_t* packed, const uint64_t* word_offsets,
-                                             const uint32_t* lengths, uint32_t n_reads, double freq, uint32_t kmax,
-                                             int use_minhash, uint64_t flush_bases, uint32_t* bounds, rvn_pass1** out) {
+int rvn_group_find_overlaps_and_create_piles_batched(rvn_group* g, const uint64_t* packed, const uint64_t* word_offsets,
+                                                     const uint32_t* lengths, uint32_t n_reads, double freq, uint32_t kmax,
+                                                     int use_minhash, uint64_t index_batch_bases, uint64_t flush_bases,
+                                                     uint32_t* bounds, rvn_pass1** out) {
   if (!g || !packed || !word_offsets || !lengths || !bounds || !out || n_reads == 0) {
     rvn::set_last_error("[raven_hip] rvn_group_find_overlaps_and_create_piles: invalid argument");
-    return RVN_EINVAL;
-  }
-  u64 total = 0;
-  for (uint32_t i = 0; i < n_reads; ++i) total += lengths[i];
-  if (total >= (1ULL << 32)) {
-    rvn::set_last_error("[raven_hip] sharded pass: one index batch only (total bases must be < 2^32)");
     return RVN_EINVAL;
   }
   const std::vector<u32> b = partition_reads(lengths, n_reads, g->world());
   for (u32 h = 0; h <= g->world(); ++h) bounds[h] = b[h];
   for (u32 h = 0; h < g->world(); ++h) out[h] = nullptr;
-  PassArgs A{packed, word_offsets, lengths, n_reads, freq, kmax, use_minhash, flush_bases ? flush_bases : (1ULL << 30), &b, out};
+  PassArgs A{packed, word_offsets, lengths, n_reads, freq, kmax, use_minhash, flush_bases ? flush_bases : (1ULL << 30),
+             index_batch_bases ? index_batch_bases : (1ULL << 32), &b, out};
   const int rc = run_ranks(g, [&](Rank& R) { pass_rank(R, A); });
   if (rc != RVN_OK)
     for (u32 h = 0; h < g->world(); ++h) {
@@ -554,19 +602,36 @@ int rvn_group_find_overlaps_and_create_piles(rvn_group* g, const uint64_t* packe
   return rc;
 }
 
+int rvn_group_find_overlaps_and_create_piles(rvn_group* g, const uint64_t* packed, const uint64_t* word_offsets,
+                                             const uint32_t* lengths, uint32_t n_reads, double freq, uint32_t kmax,
+                                             int use_minhash, uint64_t flush_bases, uint32_t* bounds, rvn_pass1** out) {
+  return rvn_group_find_overlaps_and_create_piles_batched(g, packed, word_offsets, lengths, n_reads, freq, kmax, use_minhash,
+                                                          1ULL << 32, flush_bases, bounds, out);
+}
+
+int rvn_group_polish_round_q(rvn_group* g, const uint64_t* t_packed, const uint64_t* t_word_offsets, const uint32_t* t_lengths,
+                             uint32_t n_targets, const uint64_t* r_packed, const uint64_t* r_word_offsets,
+                             const uint32_t* r_lengths, uint32_t n_reads, const uint8_t* r_quals, const uint64_t* r_qual_offsets,
+                             int qual_block_shift, double q, double err, uint32_t w, int trim, int match, int mismatch, int gap,
+                             uint8_t* out_codes, const uint64_t* out_offsets, uint32_t* out_len, double* ratio) {
+  if (!g || !t_packed || !t_word_offsets || !t_lengths || !r_packed || !r_word_offsets || !r_lengths || !out_codes ||
+      !out_offsets || !out_len || !ratio || n_targets == 0 || w == 0 || (r_quals && !r_qual_offsets)) {
+    rvn::set_last_error("[raven_hip] rvn_group_polish_round: invalid argument");
+    return RVN_EINVAL;
+  }
+  PolishArgs A{t_packed, t_word_offsets, t_lengths, n_targets, r_packed, r_word_offsets, r_lengths, n_reads, q,  err,
+               w,        trim,           match,     mismatch,  gap,      r_quals,        r_qual_offsets, qual_block_shift,
+               out_codes, out_offsets, out_len, ratio};
+  return run_ranks(g, [&](Rank& R) { polish_rank(R, A); });
+}
+
 int rvn_group_polish_round(rvn_group* g, const uint64_t* t_packed, const uint64_t* t_word_offsets, const uint32_t* t_lengths,
                            uint32_t n_targets, const uint64_t* r_packed, const uint64_t* r_word_offsets,
                            const uint32_t* r_lengths, uint32_t n_reads, double q, double err, uint32_t w, int trim, int match,
                            int mismatch, int gap, uint8_t* out_codes, const uint64_t* out_offsets, uint32_t* out_len,
                            double* ratio) {
-  if (!g || !t_packed || !t_word_offsets || !t_lengths || !r_packed || !r_word_offsets || !r_lengths || !out_codes ||
-      !out_offsets || !out_len || !ratio || n_targets == 0 || w == 0) {
-    rvn::set_last_error("[raven_hip] rvn_group_polish_round: invalid argument");
-    return RVN_EINVAL;
-  }
-  PolishArgs A{t_packed, t_word_offsets, t_lengths, n_targets, r_packed, r_word_offsets, r_lengths, n_reads, q,  err,
-               w,        trim,           match,     mismatch,  gap,      out_codes,      out_offsets, out_len, ratio};
-  return run_ranks(g, [&](Rank& R) { polish_rank(R, A); });
+  return rvn_group_polish_round_q(g, t_packed, t_word_offsets, t_lengths, n_targets, r_packed, r_word_offsets, r_lengths, n_reads,
+                                  nullptr, nullptr, 0, q, err, w, trim, match, mismatch, gap, out_codes, out_offsets, out_len, ratio);
 }
 
 }  // extern "C"

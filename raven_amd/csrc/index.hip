@@ -81,14 +81,21 @@ __global__ void table_empty_kernel(u32* table, u32 B) {
 constexpr u32 kHistBins = 65536;
 
 // count-of-counts histogram of run lengths (bin kHistBins-1 = overflow ">= 65535")
+// (s_org != nullptr: the sorted origins may hold query-only entries, kForeignFlag — a run's count is its MEMBERS', and a
+// run without members is no key of the index)
 __global__ __launch_bounds__(256) void occ_hist_kernel(const u32* __restrict__ u_start, u32 u,
                                                       u32* __restrict__ hist, u32* __restrict__ overflow_list,
-                                                      u32* __restrict__ overflow_n, u32 overflow_cap) {
+                                                      u32* __restrict__ overflow_n, u32 overflow_cap,
+                                                      const u64* __restrict__ s_org) {
   __shared__ u32 lh[256];
   lh[threadIdx.x] = 0;
   __syncthreads();
   for (u32 j = blockIdx.x * 256 + threadIdx.x; j < u; j += gridDim.x * 256) {
-    const u32 c = u_start[j + 1] - u_start[j];
+    u32 c = u_start[j + 1] - u_start[j];
+    if (s_org) {
+      c -= run_foreign_prefix(s_org, u_start[j], c);
+      if (c == 0) continue;
+    }
     if (c < 256) {
       atomicAdd(&lh[c], 1u);
     } else if (c < kHistBins - 1) {
@@ -247,7 +254,8 @@ void index_key_histogram(Engine& e, std::vector<u64>& hist, std::vector<u32>& ov
   RVN_HIP(hipMemsetAsync(d_hist, 0, (kHistBins + 1) * 4, s));
   const u32 u = static_cast<u32>(ix.u);
   const u32 grid = std::min<u32>(div_up(u, 256), 2048);
-  RVN_KLAUNCH(kKOccHist, occ_hist_kernel<<<grid, 256, 0, s>>>(ix.u_start.as<u32>(), u, d_hist, d_over, d_hist + kHistBins, overflow_cap));
+  RVN_KLAUNCH(kKOccHist, occ_hist_kernel<<<grid, 256, 0, s>>>(ix.u_start.as<u32>(), u, d_hist, d_over, d_hist + kHistBins, overflow_cap,
+                                                              ix.s_org[ix.cur].as<u64>()));
   std::vector<u32> h(kHistBins + 1);
   RVN_HIP(hipMemcpyAsync(h.data(), d_hist, (kHistBins + 1) * 4, hipMemcpyDeviceToHost, s));
   RVN_HIP(rvn_stream_sync(s));
@@ -274,7 +282,7 @@ void index_filter(Engine& e, double freq) {
   RVN_HIP(hipMemsetAsync(hist, 0, (kHistBins + 1) * 4, s));
   const u32 u = static_cast<u32>(ix.u);
   const u32 grid = std::min<u32>(div_up(u, 256), 2048);
-  RVN_KLAUNCH(kKOccHist, occ_hist_kernel<<<grid, 256, 0, s>>>(ix.u_start.as<u32>(), u, hist, ovl, hist + kHistBins, overflow_cap));
+  RVN_KLAUNCH(kKOccHist, occ_hist_kernel<<<grid, 256, 0, s>>>(ix.u_start.as<u32>(), u, hist, ovl, hist + kHistBins, overflow_cap, nullptr));
   size_t nth = static_cast<size_t>((1 - freq) * u);
   if (nth >= u) nth = u - 1;
   u64* qout = e.tmp_e.get<u64>(4);

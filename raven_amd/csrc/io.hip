@@ -282,7 +282,7 @@ void load_once(Engine& e, const std::string& path, bool fastq, bool streaming, b
     throw std::invalid_argument("[biosoup::NucleicAcid::NucleicAcid] error: not a nucleotide");
   // finish the read set exactly as rvn_reads_upload does
   const u32 nseq = static_cast<u32>(R.h_len.size());
-  if (R.h_len.size() >= (1ULL << 31)) throw std::invalid_argument("[raven_hip] more than 2^31 sequences");
+  if (R.h_len.size() >= (1ULL << 30)) throw std::invalid_argument("[raven_hip] more than 2^30 sequences");
   R.n = nseq;
   R.n_words = words_used;
   R.h_id.resize(nseq);

@@ -119,7 +119,9 @@ __global__ __launch_bounds__(256) void join_kernel(const u32* __restrict__ u_sta
   if (run >= n_runs) return;
   const u32 s = u_start[run];
   const u32 c = u_start[run + 1] - s;
-  if (c > occurrence) return;
+  // entries [0, f) of the run are queries of reads outside this index batch (kForeignFlag): no members of the index
+  const u32 f = run_foreign_prefix(s_org, s, c);
+  if (c - f > occurrence || c == f) return;
   if (c == 1 && avoid_equal) return;
   for (u32 i = 0; i < c; ++i) {
     const u64 qo = s_org[s + i];
@@ -127,7 +129,7 @@ __global__ __launch_bounds__(256) void join_kernel(const u32* __restrict__ u_sta
     const u32 qid = origin_id(qo);
     if (qid < q_lo || qid >= q_hi) continue;  // query reads of another flush window (sharded pass)
     u32 cnt = 0;
-    for (u32 j = 0; j < c; ++j) {
+    for (u32 j = f; j < c; ++j) {
       const u32 rid = origin_id(s_org[s + j]);
       if (avoid_equal && qid == rid) continue;
       if (avoid_symmetric && qid > rid) continue;
@@ -140,7 +142,7 @@ __global__ __launch_bounds__(256) void join_kernel(const u32* __restrict__ u_sta
       u64 o = seg_off[qid - first] + atomicAdd(&cursor[qid - first], cnt);
       const u64 lhs_pos = static_cast<u32>(qo) >> 1;
       const u32 qstrand = static_cast<u32>(qo) & 1u;
-      for (u32 j = 0; j < c; ++j) {
+      for (u32 j = f; j < c; ++j) {
         const u64 ro = s_org[s + j];
         const u32 rid = origin_id(ro);
         if (avoid_equal && qid == rid) continue;

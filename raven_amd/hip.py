@@ -52,7 +52,7 @@ SYMBOLS = [
     "rvn_engine_map_collect", "rvn_free",
     "rvn_find_overlaps_and_repetitive_regions", "rvn_pass2_num_overlaps", "rvn_pass2_kmer_cells", "rvn_pass2_fetch",
     "rvn_pass2_destroy", "rvn_engine_release_scratch", "rvn_filter_overlaps_by_identity", "rvn_pass1_find_chimeric_regions",
-    "rvn_reads_load", "rvn_reads_name", "rvn_reads_info", "rvn_reads_fetch", "rvn_engine_set_option", "rvn_overlap_update_and_type",
+    "rvn_reads_load", "rvn_reads_name", "rvn_reads_info", "rvn_reads_fetch", "rvn_engine_set_option", "rvn_overlap_update_and_type", "rvn_group_polish_round_q", "rvn_group_peer_access", "rvn_shard_sketch_range", "rvn_group_find_overlaps_and_create_piles_batched",
 ]
 
 # TEST INFRASTRUCTURE: what include/raven_hip_test.h declares on top (libraven_hip_test.so only)
@@ -543,6 +543,21 @@ class Engine:
         values = np.zeros(n.value, dtype=np.uint64)
         origins = np.zeros(n.value, dtype=np.uint64)
         _check(lib().rvn_shard_sketch_fetch(self._h, _p(values), _p(origins)))
+        return values, origins
+
+    def shard_sketch_range_count(self, own_reads: Reads, first, last, index_minhash=False, foreign=False) -> int:
+        """rvn_shard_sketch_range: reads [first, last) of the handle; foreign = reads of an earlier index batch (their
+        minhash-selected minimizers as query-only entries).  Fetch with shard_sketch_fetch / shard_sketch_fetch_dev."""
+        n = C.c_uint64(0)
+        _check(lib().rvn_shard_sketch_range(self._h, own_reads._h, int(first), int(last), int(index_minhash), int(foreign),
+                                            C.byref(n)))
+        return int(n.value)
+
+    def shard_sketch_fetch(self, n):
+        values = np.zeros(n, dtype=np.uint64)
+        origins = np.zeros(n, dtype=np.uint64)
+        if n:
+            _check(lib().rvn_shard_sketch_fetch(self._h, _p(values), _p(origins)))
         return values, origins
 
     def shard_index_build(self, values, origins, all_query=False):

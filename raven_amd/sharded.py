@@ -62,6 +62,13 @@ def flush_windows(lengths: np.ndarray, flush_bases: int):
     return out
 
 
+def index_batches(lengths: np.ndarray, index_batch_bases: int):
+    """Index batches of a pass as the reference cuts them (construct.cc:32-37): a batch closes with the read that brings
+    its bases to index_batch_bases (2^32 there), or with the last read.  Every read up to a batch's end is mapped against
+    it (:59-64), so the flush windows of batch [first, last) are flush_windows(lengths[:last])."""
+    return flush_windows(lengths, index_batch_bases)
+
+
 def hash_owner(values: np.ndarray, world: int) -> np.ndarray:
     """Owner rank of a minimizer value (multiplicative mix: window minima are skewed towards small values)."""
     if world == 1:
@@ -174,58 +181,71 @@ class Comm:
 
 
 def find_overlaps_and_create_piles_sharded(eng, rs_all: seqio.ReadSet, comm: Comm, freq=0.001, kmax=32,
-                                           use_minhash=False, flush_bases=1 << 30):
+                                           use_minhash=False, flush_bases=1 << 30, index_batch_bases=1 << 32):
     """Returns dict(lo, hi, pile_data, pile_off, overlaps, overlap_off, stats) for the reads [lo, hi) this rank
-    owns; arrays are laid out like rvn_pass1_fetch_* restricted to that range."""
+    owns; arrays are laid out like rvn_pass1_fetch_* restricted to that range.  A read set beyond index_batch_bases is
+    indexed in several batches as the reference does (construct.cc:32-37): per batch the members' minimizers and — as
+    query-only entries — the minhash-selected minimizers of every EARLIER read go to the hash owners, the shard is built
+    and filtered, and every read up to the batch's end is mapped against it in flush windows."""
     from . import hip
     g, world = comm.rank, comm.world
     n_total = rs_all.n
-    if rs_all.total_bases >= (1 << 32):
-        raise ValueError("sharded pass: one index batch only (total bases must be < 2^32)")
     bounds = partition_reads(rs_all.lengths, world)
     lo, hi = int(bounds[g]), int(bounds[g + 1])
     own = eng.upload(slice_reads(rs_all, lo, hi))
-
-    # 1. sketch own reads; minimizers to the owner of their hash class (stable: keeps (read, position) order)
-    val, org = eng.shard_sketch(own, index_minhash=use_minhash)
-    owner = hash_owner(val, world)
-    order = np.argsort(owner, kind="stable")
-    cnt = np.bincount(owner, minlength=world)
-    cuts = np.concatenate([[0], np.cumsum(cnt)])
-    val_s, org_s = val[order], org[order]
-    val_r = comm.all_to_all_v([val_s[cuts[h]:cuts[h + 1]] for h in range(world)])
-    org_r = comm.all_to_all_v([org_s[cuts[h]:cuts[h + 1]] for h in range(world)])
-
-    # 2. index shard of this hash class; 3. exact global Filter
-    eng.shard_index_build(np.concatenate(val_r), np.concatenate(org_r), all_query=use_minhash)
-    occ = global_occurrence(eng.shard_key_counts(), freq, comm)
-    eng.set_occurrence(occ)
-
-    # 4.-6. per flush window of query reads, exactly as the reference flushes (merge + AddLayers + truncation per window)
     empty = np.zeros(0, dtype=hip.OVERLAP_DTYPE)
     p = eng.shard_piles_create(rs_all.lengths)
-    n_matches_sent = n_overlaps_sent = n_map_overlaps = 0
-    for q_a, q_b in flush_windows(rs_all.lengths, flush_bases):
-        # self-join of the shard for the window's query reads; candidate pairs to the owner of the query read
-        grp, pos, seg = eng.shard_join(n_total, True, True, q_a, q_b)
-        per_read = np.diff(seg.astype(np.int64))
-        m_cuts = [int(seg[bounds[h]]) for h in range(world)] + [int(seg[n_total])]
-        cnt_r = comm.all_to_all_v([per_read[bounds[h]:bounds[h + 1]] for h in range(world)])
-        grp_r = comm.all_to_all_v([grp[m_cuts[h]:m_cuts[h + 1]] for h in range(world)])
-        pos_r = comm.all_to_all_v([pos[m_cuts[h]:m_cuts[h + 1]] for h in range(world)])
-        seg_own, (grp_own, pos_own) = regroup_by_read(cnt_r, list(zip(grp_r, pos_r)))
-        n_matches_sent += int(grp.shape[0] - (m_cuts[g + 1] - m_cuts[g]))
-        # chain own reads' matches
-        ovl, _ = eng.shard_chain(own, grp_own, pos_own, seg_own)
-        n_map_overlaps += int(ovl.shape[0])
-        # overlaps also to the owner of their rhs read (own ones are already here); merge + piles
-        rhs_owner = np.searchsorted(bounds, ovl["rhs_id"].astype(np.int64), side="right") - 1
-        recv = comm.all_to_all_v([ovl[rhs_owner == h] if h != g else empty for h in range(world)])
-        n_overlaps_sent += int(np.sum(rhs_owner != g)) if ovl.shape[0] else 0
-        for s_ in range(g + 1, world):
-            assert recv[s_].shape[0] == 0, "avoid_symmetric: overlaps only travel to higher ranks"
-        combined = np.concatenate([recv[s_] for s_ in range(g)] + [ovl]) if world > 1 else ovl
-        p.merge(combined, kmax)
+    n_matches_sent = n_overlaps_sent = n_map_overlaps = n_min_sent = 0
+    occ = 0
+    for b_first, b_last in index_batches(rs_all.lengths, index_batch_bases):
+        # 1. sketch own reads: members of the batch, and the earlier reads as query-only entries; minimizers to the owner
+        #    of their hash class (stable: keeps (read, position) order; the earlier reads come first, as their ids do)
+        f_hi = min(max(b_first, lo), hi) - lo            # own reads [0, f_hi) lie before the batch
+        m_lo, m_hi = f_hi, min(max(b_last, lo), hi) - lo  # own reads [m_lo, m_hi) are members
+        pieces = []
+        if f_hi > 0:
+            pieces.append(eng.shard_sketch_fetch(eng.shard_sketch_range_count(own, 0, f_hi, use_minhash, foreign=True)))
+        if m_hi > m_lo:
+            pieces.append(eng.shard_sketch_fetch(eng.shard_sketch_range_count(own, m_lo, m_hi, use_minhash, foreign=False)))
+        val = np.concatenate([x[0] for x in pieces]) if pieces else np.zeros(0, np.uint64)
+        org = np.concatenate([x[1] for x in pieces]) if pieces else np.zeros(0, np.uint64)
+        owner = hash_owner(val, world)
+        order = np.argsort(owner, kind="stable")
+        cnt = np.bincount(owner, minlength=world)
+        cuts = np.concatenate([[0], np.cumsum(cnt)])
+        val_s, org_s = val[order], org[order]
+        val_r = comm.all_to_all_v([val_s[cuts[h]:cuts[h + 1]] for h in range(world)])
+        org_r = comm.all_to_all_v([org_s[cuts[h]:cuts[h + 1]] for h in range(world)])
+        n_min_sent += int(val.shape[0] - cnt[g])
+
+        # 2. index shard of this hash class; 3. exact global Filter (keys = runs with members)
+        eng.shard_index_build(np.concatenate(val_r), np.concatenate(org_r), all_query=use_minhash)
+        counts = eng.shard_key_counts()
+        occ = global_occurrence(counts[counts > 0], freq, comm)
+        eng.set_occurrence(occ)
+
+        # 4.-6. per flush window of query reads, exactly as the reference flushes (merge + AddLayers + truncation per window)
+        for q_a, q_b in flush_windows(rs_all.lengths[:b_last], flush_bases):
+            # self-join of the shard for the window's query reads; candidate pairs to the owner of the query read
+            grp, pos, seg = eng.shard_join(n_total, True, True, q_a, q_b)
+            per_read = np.diff(seg.astype(np.int64))
+            m_cuts = [int(seg[bounds[h]]) for h in range(world)] + [int(seg[n_total])]
+            cnt_r = comm.all_to_all_v([per_read[bounds[h]:bounds[h + 1]] for h in range(world)])
+            grp_r = comm.all_to_all_v([grp[m_cuts[h]:m_cuts[h + 1]] for h in range(world)])
+            pos_r = comm.all_to_all_v([pos[m_cuts[h]:m_cuts[h + 1]] for h in range(world)])
+            seg_own, (grp_own, pos_own) = regroup_by_read(cnt_r, list(zip(grp_r, pos_r)))
+            n_matches_sent += int(grp.shape[0] - (m_cuts[g + 1] - m_cuts[g]))
+            # chain own reads' matches
+            ovl, _ = eng.shard_chain(own, grp_own, pos_own, seg_own)
+            n_map_overlaps += int(ovl.shape[0])
+            # overlaps also to the owner of their rhs read (own ones are already here); merge + piles
+            rhs_owner = np.searchsorted(bounds, ovl["rhs_id"].astype(np.int64), side="right") - 1
+            recv = comm.all_to_all_v([ovl[rhs_owner == h] if h != g else empty for h in range(world)])
+            n_overlaps_sent += int(np.sum(rhs_owner != g)) if ovl.shape[0] else 0
+            for s_ in range(g + 1, world):
+                assert recv[s_].shape[0] == 0, "avoid_symmetric: overlaps only travel to higher ranks"
+            combined = np.concatenate([recv[s_] for s_ in range(g)] + [ovl]) if world > 1 else ovl
+            p.merge(combined, kmax)
     data, poff = p.piles()
     kept, koff = p.overlaps()
     p.close()
@@ -234,7 +254,7 @@ def find_overlaps_and_create_piles_sharded(eng, rs_all: seqio.ReadSet, comm: Com
                pile_off=(poff[lo:hi + 1] - poff[lo]).astype(np.uint64),
                overlaps=kept[int(koff[lo]):int(koff[hi])].copy(),
                overlap_off=(koff[lo:hi + 1] - koff[lo]).astype(np.uint32),
-               stats=dict(minimizers_sent=int(val.shape[0] - cnt[g]), matches_sent=n_matches_sent,
+               stats=dict(minimizers_sent=n_min_sent, matches_sent=n_matches_sent,
                           overlaps_sent=n_overlaps_sent, map_overlaps=n_map_overlaps, bytes_sent=comm.bytes_sent))
     return res
 
@@ -316,16 +336,16 @@ DeviceComm.all_to_all_flat_t = _all_to_all_flat_t
 
 
 def find_overlaps_and_create_piles_sharded_dev(eng, rs_all: seqio.ReadSet, comm, device, freq=0.001, kmax=32,
-                                               use_minhash=False, flush_bases=1 << 30, own=None, laps=None, fetch=True):
+                                               use_minhash=False, flush_bases=1 << 30, own=None, laps=None, fetch=True,
+                                               index_batch_bases=1 << 32):
     """find_overlaps_and_create_piles_sharded with every exchange buffer resident in HBM (`device`: torch device of
     the engine's GPU; `comm`: DeviceComm or a test double with all_to_all_t / all_reduce_sum / all_gather_v).
     torch allocates the exchange buffers and carries the collectives; partitioning by owner, regrouping per read and
-    the merge offsets are the engine's own kernels (raven_amd/csrc/shard.hip)."""
+    the merge offsets are the engine's own kernels (raven_amd/csrc/shard.hip).  Several index batches as in the host
+    variant (construct.cc:32-37)."""
     import torch
     g, world = comm.rank, comm.world
     n_total = rs_all.n
-    if rs_all.total_bases >= (1 << 32):
-        raise ValueError("sharded pass: one index batch only (total bases must be < 2^32)")
     bounds = partition_reads(rs_all.lengths, world)
     lo, hi = int(bounds[g]), int(bounds[g + 1])
     if own is None:  # `own`: this rank's reads already resident (uploaded once, as a caller running several passes does)
@@ -347,91 +367,111 @@ def find_overlaps_and_create_piles_sharded_dev(eng, rs_all: seqio.ReadSet, comm,
         # collective produced, the device is synchronised
         torch.cuda.synchronize(device)
 
-    # 1. sketch; minimizers to the owner of their hash class (stable partition keeps (read, position) order)
-    n = eng.shard_sketch_count(own, index_minhash=use_minhash)
-    val, org = torch.empty(n, **i64), torch.empty(n, **i64)
-    val_p, org_p = (torch.empty(n, **i64), torch.empty(n, **i64)) if world > 1 else (None, None)
-    sync()
-    eng.shard_sketch_fetch_dev(val.data_ptr(), org.data_ptr())
-    if world == 1:  # one owner: nothing to partition
-        val_p, org_p, cnt = val, org, [n]
-    else:
-        cnt = eng.shard_split_minimizers_dev(val.data_ptr(), org.data_ptr(), n, world, val_p.data_ptr(), org_p.data_ptr())
-    del val, org
-    vcat = comm.all_to_all_flat_t(val_p, cnt)[0]
-    ocat = comm.all_to_all_flat_t(org_p, cnt)[0]
-    del val_p, org_p
-    lap("sketch+split+exchange1")
-
-    # 2. index shard; 3. exact global Filter
-    sync()
-    n_flagged = eng.shard_count_flagged_dev(ocat.data_ptr(), ocat.shape[0])
-    eng.shard_index_build_dev(vcat.data_ptr(), ocat.data_ptr(), vcat.shape[0], use_minhash, n_flagged)
-    hist, over = eng.shard_key_histogram()
-    occ = occurrence_from_histogram(hist, over, freq, comm)
-    eng.set_occurrence(occ)
-    lap("index+filter")
-
-    # 4.-6. per flush window of query reads (merge + AddLayers + truncation per window, as the reference flushes)
     b_list = [int(x) for x in bounds]
     r_split = [b_list[h + 1] - b_list[h] for h in range(world)]
     n_own = hi - lo
     p = eng.shard_piles_create(rs_all.lengths)
-    n_matches_sent = n_sent = n_map = 0
-    for q_a, q_b in flush_windows(rs_all.lengths, flush_bases):
-        n_m = eng.shard_join_count(n_total, True, True, q_a, q_b)
-        grp, pos = torch.empty(n_m, **i64), torch.empty(n_m, **i64)
-        seg = torch.empty(n_total + 1, **i64)
-        per_read = torch.empty(n_total, **i64)
+    n_matches_sent = n_sent = n_map = n_min_sent = 0
+    occ = 0
+    for b_first, b_last in index_batches(rs_all.lengths, index_batch_bases):
+        # 1. sketch: the members of the batch and, as query-only entries, the minhash-selected minimizers of this rank's
+        #    EARLIER reads; minimizers to the owner of their hash class (stable partition keeps (read, position) order)
+        f_hi = min(max(b_first, lo), hi) - lo
+        m_lo, m_hi = f_hi, min(max(b_last, lo), hi) - lo
+        pieces = []
+        for first, last, foreign in ((0, f_hi, True), (m_lo, m_hi, False)):
+            if last > first:
+                k = eng.shard_sketch_range_count(own, first, last, use_minhash, foreign=foreign)
+                v, o = torch.empty(k, **i64), torch.empty(k, **i64)
+                sync()
+                if k:
+                    eng.shard_sketch_fetch_dev(v.data_ptr(), o.data_ptr())
+                pieces.append((v, o))
+        if len(pieces) == 1:
+            val, org = pieces[0]
+        elif pieces:
+            val, org = torch.cat([x[0] for x in pieces]), torch.cat([x[1] for x in pieces])
+        else:
+            val, org = torch.empty(0, **i64), torch.empty(0, **i64)
+        del pieces
+        n = int(val.shape[0])
+        if world == 1:  # one owner: nothing to partition
+            val_p, org_p, cnt = val, org, [n]
+        else:
+            val_p, org_p = torch.empty(n, **i64), torch.empty(n, **i64)
+            sync()
+            cnt = eng.shard_split_minimizers_dev(val.data_ptr(), org.data_ptr(), n, world, val_p.data_ptr(), org_p.data_ptr())
+        del val, org
+        vcat = comm.all_to_all_flat_t(val_p, cnt)[0]
+        ocat = comm.all_to_all_flat_t(org_p, cnt)[0]
+        del val_p, org_p
+        n_min_sent += int(n - cnt[g])
+        lap("sketch+split+exchange1")
+
+        # 2. index shard; 3. exact global Filter
         sync()
-        eng.shard_join_fetch_dev(grp.data_ptr(), pos.data_ptr(), seg.data_ptr())
-        eng.shard_adjacent_diff_dev(seg.data_ptr(), n_total, per_read.data_ptr())
-        lap("join")
-        m_cuts = seg[b_list].tolist()  # matches are in read order: the cut points of the read ranges
-        m_split = [int(m_cuts[h + 1] - m_cuts[h]) for h in range(world)]
-        cnt_flat, cnt_lens = comm.all_to_all_flat_t(per_read, r_split)
-        grp_flat, m_lens = comm.all_to_all_flat_t(grp, m_split)
-        pos_flat, _ = comm.all_to_all_flat_t(pos, m_split)
-        n_in = sum(m_lens)
-        seg_own = torch.empty(n_own + 1, **i64)
-        grp_own, pos_own = torch.empty(n_in, **i64), torch.empty(n_in, **i64)
-        sync()
-        c_ptr, g_ptr, p_ptr, at_c, at_m = [], [], [], 0, 0
-        for h in range(world):  # per-source views into the flat receive buffers
-            c_ptr.append(cnt_flat.data_ptr() + 8 * at_c)
-            g_ptr.append(grp_flat.data_ptr() + 8 * at_m)
-            p_ptr.append(pos_flat.data_ptr() + 8 * at_m)
-            at_c += cnt_lens[h]
-            at_m += m_lens[h]
-        eng.shard_regroup_dev(c_ptr, g_ptr, p_ptr, m_lens, n_own, seg_own.data_ptr(), grp_own.data_ptr(), pos_own.data_ptr())
-        n_matches_sent += int(n_m - m_split[g])
-        lap("exchange2+regroup")
-        # chain
-        n_o = eng.shard_chain_dev(own, grp_own.data_ptr(), pos_own.data_ptr(), seg_own.data_ptr(), n_in)
-        ovl = torch.empty((n_o, 4), **i64)
-        ovl_p = torch.empty((n_o, 4), **i64)
-        off_own = torch.empty(own.n + 1, dtype=torch.int32, device=device)
-        sync()
-        eng.map_fetch_dev(ovl.data_ptr(), off_own.data_ptr())
-        n_map += int(n_o)
-        lap("chain")
-        # overlaps also to the owner of their rhs read (stable partition; the own ones stay); merge + piles
-        o_cnt = eng.shard_split_overlaps_dev(ovl.data_ptr(), n_o, b_list, world, g, ovl_p.data_ptr())
-        send = [4 * c for c in o_cnt[:world]]
-        n_sent += sum(o_cnt[:world])
-        recv_flat, recv_lens = comm.all_to_all_flat_t(ovl_p.reshape(-1)[:sum(send)], send)
-        for s_ in range(g + 1, world):
-            assert recv_lens[s_] == 0, "avoid_symmetric: overlaps only travel to higher ranks"
-        sync()
-        parts, at = [], 0
-        for s_ in range(world):
-            if recv_lens[s_]:
-                parts.append((recv_flat.data_ptr() + 8 * at, recv_lens[s_] // 4))
-            at += recv_lens[s_]
-        parts.append((ovl.data_ptr(), n_o))
-        p.merge_parts_dev(parts, kmax)
-        lap("exchange3+merge")
-    stats = dict(minimizers_sent=int(n - cnt[g]), matches_sent=n_matches_sent, overlaps_sent=int(n_sent),
+        n_flagged = eng.shard_count_flagged_dev(ocat.data_ptr(), ocat.shape[0])
+        eng.shard_index_build_dev(vcat.data_ptr(), ocat.data_ptr(), vcat.shape[0], use_minhash, n_flagged)
+        hist, over = eng.shard_key_histogram()
+        occ = occurrence_from_histogram(hist, over, freq, comm)
+        eng.set_occurrence(occ)
+        lap("index+filter")
+
+        # 4.-6. per flush window of query reads (merge + AddLayers + truncation per window, as the reference flushes)
+        for q_a, q_b in flush_windows(rs_all.lengths[:b_last], flush_bases):
+            n_m = eng.shard_join_count(n_total, True, True, q_a, q_b)
+            grp, pos = torch.empty(n_m, **i64), torch.empty(n_m, **i64)
+            seg = torch.empty(n_total + 1, **i64)
+            per_read = torch.empty(n_total, **i64)
+            sync()
+            eng.shard_join_fetch_dev(grp.data_ptr(), pos.data_ptr(), seg.data_ptr())
+            eng.shard_adjacent_diff_dev(seg.data_ptr(), n_total, per_read.data_ptr())
+            lap("join")
+            m_cuts = seg[b_list].tolist()  # matches are in read order: the cut points of the read ranges
+            m_split = [int(m_cuts[h + 1] - m_cuts[h]) for h in range(world)]
+            cnt_flat, cnt_lens = comm.all_to_all_flat_t(per_read, r_split)
+            grp_flat, m_lens = comm.all_to_all_flat_t(grp, m_split)
+            pos_flat, _ = comm.all_to_all_flat_t(pos, m_split)
+            n_in = sum(m_lens)
+            seg_own = torch.empty(n_own + 1, **i64)
+            grp_own, pos_own = torch.empty(n_in, **i64), torch.empty(n_in, **i64)
+            sync()
+            c_ptr, g_ptr, p_ptr, at_c, at_m = [], [], [], 0, 0
+            for h in range(world):  # per-source views into the flat receive buffers
+                c_ptr.append(cnt_flat.data_ptr() + 8 * at_c)
+                g_ptr.append(grp_flat.data_ptr() + 8 * at_m)
+                p_ptr.append(pos_flat.data_ptr() + 8 * at_m)
+                at_c += cnt_lens[h]
+                at_m += m_lens[h]
+            eng.shard_regroup_dev(c_ptr, g_ptr, p_ptr, m_lens, n_own, seg_own.data_ptr(), grp_own.data_ptr(), pos_own.data_ptr())
+            n_matches_sent += int(n_m - m_split[g])
+            lap("exchange2+regroup")
+            # chain
+            n_o = eng.shard_chain_dev(own, grp_own.data_ptr(), pos_own.data_ptr(), seg_own.data_ptr(), n_in)
+            ovl = torch.empty((n_o, 4), **i64)
+            ovl_p = torch.empty((n_o, 4), **i64)
+            off_own = torch.empty(own.n + 1, dtype=torch.int32, device=device)
+            sync()
+            eng.map_fetch_dev(ovl.data_ptr(), off_own.data_ptr())
+            n_map += int(n_o)
+            lap("chain")
+            # overlaps also to the owner of their rhs read (stable partition; the own ones stay); merge + piles
+            o_cnt = eng.shard_split_overlaps_dev(ovl.data_ptr(), n_o, b_list, world, g, ovl_p.data_ptr())
+            send = [4 * c for c in o_cnt[:world]]
+            n_sent += sum(o_cnt[:world])
+            recv_flat, recv_lens = comm.all_to_all_flat_t(ovl_p.reshape(-1)[:sum(send)], send)
+            for s_ in range(g + 1, world):
+                assert recv_lens[s_] == 0, "avoid_symmetric: overlaps only travel to higher ranks"
+            sync()
+            parts, at = [], 0
+            for s_ in range(world):
+                if recv_lens[s_]:
+                    parts.append((recv_flat.data_ptr() + 8 * at, recv_lens[s_] // 4))
+                at += recv_lens[s_]
+            parts.append((ovl.data_ptr(), n_o))
+            p.merge_parts_dev(parts, kmax)
+            lap("exchange3+merge")
+    stats = dict(minimizers_sent=n_min_sent, matches_sent=n_matches_sent, overlaps_sent=int(n_sent),
                  map_overlaps=n_map, bytes_sent=comm.bytes_sent)
     if not fetch:  # the piles and overlap lists of this rank's reads stay in HBM: p.piles() / p.overlaps() / p.close()
         return dict(lo=lo, hi=hi, occurrence=occ, pass1=p, stats=stats)

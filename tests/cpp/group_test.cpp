@@ -73,6 +73,8 @@ int main(int argc, char** argv) {
   const Packed drafts = Load(argv[2]);
   const uint32_t n_ranks = static_cast<uint32_t>(std::atoi(argv[3]));
   const uint64_t flush = argc > 4 ? std::strtoull(argv[4], nullptr, 10) : (1ULL << 30);
+  // (index batch: 2^32 bases in the reference; a smaller value forces several batches on a test-sized read set)
+  const uint64_t index_batch = argc > 5 ? std::strtoull(argv[5], nullptr, 10) : (1ULL << 32);
   const uint32_t n = static_cast<uint32_t>(reads.len.size());
 
   // ---- single engine ----
@@ -81,7 +83,7 @@ int main(int argc, char** argv) {
   rvn_reads* rd = nullptr;
   Check(rvn_reads_upload(e, reads.words.data(), reads.woff[n], reads.woff.data(), reads.len.data(), nullptr, n, &rd), "upload");
   rvn_pass1* p1 = nullptr;
-  Check(rvn_find_overlaps_and_create_piles(e, rd, 0.001, 32, 0, 1ULL << 32, flush, &p1), "pass");
+  Check(rvn_find_overlaps_and_create_piles(e, rd, 0.001, 32, 0, index_batch, flush, &p1), "pass");
   const PassResult single = Fetch(p1, n);
   rvn_pass1_destroy(p1);
   std::printf("single overlaps %zu\n", single.ovl.size());
@@ -92,8 +94,8 @@ int main(int argc, char** argv) {
   Check(rvn_group_create(&g, 15, 5, 500, 4, 100, 10000, devices.data(), n_ranks), "group");
   std::vector<uint32_t> bounds(n_ranks + 1);
   std::vector<rvn_pass1*> passes(n_ranks, nullptr);
-  Check(rvn_group_find_overlaps_and_create_piles(g, reads.words.data(), reads.woff.data(), reads.len.data(), n, 0.001, 32, 0,
-                                                 flush, bounds.data(), passes.data()),
+  Check(rvn_group_find_overlaps_and_create_piles_batched(g, reads.words.data(), reads.woff.data(), reads.len.data(), n, 0.001, 32,
+                                                         0, index_batch, flush, bounds.data(), passes.data()),
         "group pass");
   std::printf("bounds");
   for (uint32_t b : bounds) std::printf(" %u", b);
@@ -132,6 +134,41 @@ int main(int argc, char** argv) {
   for (uint32_t t = 0; t < nt; ++t) {
     const bool same = l1[t] == l2[t] && std::memcmp(&c1[ooff[t]], &c2[ooff[t]], l1[t]) == 0 && r1[t] == r2[t];
     std::printf("target %u len %u ratio %.6f identical %d\n", t, l1[t], r1[t], same ? 1 : 0);
+  }
+  // ---- the same round with block qualities (FASTQ variant: mean-quality filter at q = 10, quality-weighted edges):
+  // seeded block qualities, a fifth of the reads below the threshold ----
+  {
+    std::vector<uint8_t> quals;
+    std::vector<uint64_t> qoff(1, 0);
+    uint64_t state = 0x9E3779B97F4A7C15ULL;
+    for (uint32_t i = 0; i < n; ++i) {
+      state = state * 6364136223846793005ULL + 1442695040888963407ULL;
+      const bool low = (state >> 33) % 5 == 0;
+      const uint32_t blocks = (reads.len[i] + 63) / 64;
+      for (uint32_t b = 0; b < blocks; ++b) {
+        state = state * 6364136223846793005ULL + 1442695040888963407ULL;
+        quals.push_back(static_cast<uint8_t>(33 + (low ? 4 : 12) + (state >> 40) % 8));
+      }
+      qoff.push_back(quals.size());
+    }
+    Check(rvn_reads_attach_quality(e, rd, quals.data(), qoff.data(), 6), "attach");
+    rvn_polish_stats st1{};
+    Check(rvn_polish_round(e, td, rd, nullptr, nullptr, 10.0, 0.3, 500, 1, 3, -5, -4, c1.data(), ooff.data(), l1.data(), r1.data(), &st1),
+          "round with qualities");
+    Check(rvn_group_polish_round_q(g, drafts.words.data(), drafts.woff.data(), drafts.len.data(), nt, reads.words.data(),
+                                   reads.woff.data(), reads.len.data(), n, quals.data(), qoff.data(), 6, 10.0, 0.3, 500, 1, 3, -5, -4,
+                                   c2.data(), ooff.data(), l2.data(), r2.data()),
+          "group round with qualities");
+    for (uint32_t t = 0; t < nt; ++t) {
+      const bool same = l1[t] == l2[t] && std::memcmp(&c1[ooff[t]], &c2[ooff[t]], l1[t]) == 0 && r1[t] == r2[t];
+      std::printf("quality target %u len %u ratio %.6f identical %d dropped_layers %llu\n", t, l1[t], r1[t], same ? 1 : 0,
+                  static_cast<unsigned long long>(st1.n_dropped_layers));
+    }
+  }
+  {
+    std::vector<uint8_t> direct(static_cast<size_t>(n_ranks) * n_ranks, 0);
+    const int all = rvn_group_peer_access(g, direct.data());
+    std::printf("peer access all %d\n", all);
   }
   rvn_reads_destroy(td);
   rvn_reads_destroy(rd);

@@ -13,8 +13,8 @@ from tests.test_gpu_facade import _build, _write_reads
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("n_ranks,flush", [(2, 1 << 30), (3, 400_000)])
-def test_group_pass_and_round_are_bit_identical_to_the_single_engine(tmp_path, n_ranks, flush):
+@pytest.mark.parametrize("n_ranks,flush,index_batch", [(2, 1 << 30, 1 << 32), (3, 400_000, 1 << 32), (3, 400_000, 1_700_000)])
+def test_group_pass_and_round_are_bit_identical_to_the_single_engine(tmp_path, n_ranks, flush, index_batch):
     exe = _build(tmp_path, "group_test")
     g = synth.make_genome(250_000, seed=41)
     rs, _ = synth.make_reads(g, 20, 6000, seed=42)
@@ -24,7 +24,9 @@ def test_group_pass_and_round_are_bit_identical_to_the_single_engine(tmp_path, n
     with open(dpath, "wb") as f:
         for d in drafts:
             f.write(bytes(np.frombuffer(b"ACGT", np.uint8)[d]) + b"\n")
-    r = subprocess.run([exe, rpath, dpath, str(n_ranks), str(flush)], capture_output=True, text=True, timeout=900)
+    # index_batch 1.7 Mb on 5 Mb of reads: three index batches (construct.cc:32-37), every read up to a batch's end mapped
+    # against it — cut inside a rank's read range
+    r = subprocess.run([exe, rpath, dpath, str(n_ranks), str(flush), str(index_batch)], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     lines = r.stdout.strip().split("\n")
     assert int(lines[0].split()[-1]) > 5000                       # the single pass found overlaps
@@ -35,6 +37,13 @@ def test_group_pass_and_round_are_bit_identical_to_the_single_engine(tmp_path, n
     targets = [ln for ln in lines if ln.startswith("target ")]
     assert len(targets) == 2 and all(ln.endswith("identical 1") for ln in targets), targets
     assert all(float(ln.split()[5]) > 0.99 for ln in targets)     # (nearly) every window polished
+    # the same round with block qualities (the FASTQ variant through the group): byte-identical to the
+    # single engine (a fifth of the reads sit below q = 10: their layers fail the mean-quality filter on every rank alike)
+    qt = [ln for ln in lines if ln.startswith("quality target ")]
+    assert len(qt) == 2 and all(" identical 1 " in ln for ln in qt), qt
+    assert all(float(ln.split()[6]) > 0.9 for ln in qt), qt
+    # virtual ranks share one device: every pair reaches the other's memory directly
+    assert "peer access all 1" in lines
 
 
 def test_device_group_facade_equals_the_single_device_templates(tmp_path):

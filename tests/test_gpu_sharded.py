@@ -236,6 +236,38 @@ def test_sharded_pass_with_several_flush_windows(variant):
             sharded_util.check_against_single(x, data, poff, kept, koff)   # ... and the sharded pass follows it
 
 
+@pytest.mark.parametrize("variant", ["host", "device"])
+@pytest.mark.parametrize("use_minhash", [False, True])
+def test_sharded_pass_with_several_index_batches(variant, use_minhash):
+    """More than one index batch (2^32 bases each in the reference, construct.cc:32-37; 1.6 Mb here on 5 Mb of reads, so three
+    batches whose ends fall inside ranks' read ranges): per batch the members' minimizers and, as query-only entries, the
+    minhash-selected minimizers of every earlier read go to the hash owners; every read up to the batch's end is mapped
+    against the shard in flush windows.  Filter runs per batch on the members alone.  Bit-identical to the single-GPU pass
+    with the same batch size, and different from the one-batch result."""
+    import torch
+    g = synth.make_genome(250_000, seed=131)
+    rs, _ = synth.make_reads(g, 20, 5000, seed=132)
+    batch, flush = 1_600_000, 700_000
+    assert len(sharded.index_batches(rs.lengths, batch)) >= 3
+    data, poff, kept, koff, occ = _single(rs, kmax=16, flush_bases=flush, index_batch_bases=batch, use_minhash=use_minhash)
+    one_batch = _single(rs, kmax=16, flush_bases=flush, use_minhash=use_minhash)
+    assert not np.array_equal(one_batch[2], kept)          # the batch schedule does change the result ...
+
+    def rank_fn(r, comm):
+        eng = hip.Engine(15, 5)
+        if variant == "host":
+            return sharded.find_overlaps_and_create_piles_sharded(eng, rs, comm, kmax=16, flush_bases=flush,
+                                                                  index_batch_bases=batch, use_minhash=use_minhash)
+        return sharded.find_overlaps_and_create_piles_sharded_dev(eng, rs, comm, torch.device("cuda", 0), kmax=16,
+                                                                  flush_bases=flush, index_batch_bases=batch,
+                                                                  use_minhash=use_minhash)
+
+    for world in (1, 2, 3):
+        for x in sharded_util.run_ranks(world, rank_fn):
+            assert x["occurrence"] == occ                  # (the last batch's cutoff, as the single engine leaves it)
+            sharded_util.check_against_single(x, data, poff, kept, koff)   # ... and the sharded pass follows it
+
+
 @pytest.mark.parametrize("world", [1, 3, 8])
 def test_partition_and_regroup_kernels_equal_the_host_formulas(world):
     """shard.hip against the numpy statements of the same steps (raven_amd/sharded.py host variant)."""

@@ -148,6 +148,14 @@ def test_device_comm_tensor_exchanges_over_gloo_world2(tmp_path):
     assert "DEVCOMM_OK_0" in r.stdout and "DEVCOMM_OK_1" in r.stdout, r.stdout[-2000:]
 
 
+def test_index_batches_follow_the_reference_schedule():
+    """construct.cc:32-37: a batch closes with the read that brings its bases to the limit, or with the last read."""
+    lengths = np.array([10, 10, 10, 10, 10, 10, 10], dtype=np.uint32)
+    assert sharded.index_batches(lengths, 25) == [(0, 3), (3, 6), (6, 7)]
+    assert sharded.index_batches(lengths, 1 << 32) == [(0, 7)]
+    assert sharded.index_batches(lengths, 1) == [(i, i + 1) for i in range(7)]
+
+
 def test_flush_windows_follow_the_reference_schedule():
     # construct.cc:56-70: bytes += len; flush when bytes >= limit or at the last read
     L = np.array([5, 5, 5, 5, 5], dtype=np.uint32)
