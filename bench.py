@@ -232,6 +232,8 @@ def main():
     ap.add_argument("--load-bases", type=int, default=150_000_000,
                     help="bases of the gz FASTQ the input path (rvn_reads_load) is timed on, outside the timed region (0 = skip)")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--engine-option", action="append", default=[], metavar="NAME=VALUE",
+                    help="rvn_engine_set_option before the run (tuning experiments; repeatable)")
     ap.add_argument("--no-quality", action="store_true", help="polish FASTA-like reads (no block qualities attached)")
     ap.add_argument("--replicas", action="store_true", help="N > 1: independent shard per GPU (weak scaling, no "
                     "collective) instead of one genome sharded across the ranks")
@@ -285,6 +287,10 @@ def main():
 
     eng = hip.Engine(args.k, args.w, device=local_rank)
     peng = eng if (args.k, args.w) == (15, 5) else hip.Engine(15, 5, device=local_rank)  # racon maps with (15, 5)
+    for kv in args.engine_option:
+        name, value = kv.split("=")
+        for x in {id(eng): eng, id(peng): peng}.values():
+            x.set_option(name, int(value))
     t0 = time.time()
     reads = eng.upload(rs)  # H2D once; resident for every step
     preads = reads if peng is eng else peng.upload(rs)

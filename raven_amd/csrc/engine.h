@@ -147,7 +147,7 @@ struct Engine {
   std::vector<std::pair<std::unique_ptr<PinBuf>, bool>> io_pin;  // its page-locked slabs (buffer, handed out)
   DevBuf poa_sched, poa_redo_w, poa_redo_i;  // LPT order / escalation lists of a POA batch (poa_run_dev)
   // alignment-path stage of a polishing round (nwpath.hip): stored band words + scores, jobs, results
-  DevBuf nw_hs, nw_ck, nw_hs2, nw_ck2, nw_hs3, nw_ck3, nw_strip, nw_jobs, nw_res;  // alignment paths: horizontal-delta streams, checkpoints, jobs, results
+  DevBuf nw_hs, nw_ck, nw_hs2, nw_ck2, nw_hs3, nw_ck3, nw_hs4, nw_ck4, nw_strip, nw_jobs, nw_res;  // alignment paths: horizontal-delta streams, checkpoints, jobs, results
   double nw_rate = -1.0;  // running estimate of edit distance / length of the read-to-target alignments (< 0: unknown)
   // polishing front end (polish.hip): best overlaps, window records, layer tables, consensus
   DevBuf pl_best, pl_best_t, pl_idmap, pl_recs, pl_keep, pl_win_cnt, pl_win_off, pl_win_fill, pl_win_meta, pl_first_window,
@@ -181,8 +181,8 @@ struct Engine {
   u64 c_intervals = 0;
   bool timing = true;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  hipStream_t nw_streams[3] = {nullptr, nullptr, nullptr};  // walk streams of the alignment-path stage (beside the sweeps)
-  hipEvent_t nw_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipStream_t nw_streams[4] = {nullptr, nullptr, nullptr, nullptr};  // walk streams of the alignment-path stage (beside the sweeps): one per buffer set
+  hipEvent_t nw_ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // [0..3] the walk of a buffer set is done, [4] sweep -> walk
   u64* h_pin = nullptr;  // pinned host scratch for small device->host size read-backs
   PinBuf pin_big;        // pinned staging for bulk read-backs up to 256 MB (polishing: chain anchors)
   HostBuf host_big;      // ... and the unpinned one for larger ones

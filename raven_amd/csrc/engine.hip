@@ -344,7 +344,7 @@ void engine_release_scratch(Engine& e) {
       &e.iv_slot_end, &e.iv_cnt, &e.iv_off, &e.iv_begin, &e.iv_end, &e.lis_min, &e.lis_pred, &e.lis_tail, &e.lis_mask,
       &e.ovl_slots, &e.ovl_flags, &e.ovl_scan, &e.chain_big, &e.sh_hist, &e.sh_off, &e.sh_ptrs, &e.poa_scratch, &e.poa2_scratch, &e.polish_quals, &e.ed_cnt, &e.ed_sort, &e.ed_todo, &e.p2_slot,
       &e.p2_pairs, &e.p2_dist, &e.p2_regions, &e.p2_index_of, &e.p2_kmers_off, &e.p2_ok, &e.p2_keep, &e.p2_tmp_ovl,
-      &e.poa_sched, &e.poa_redo_w, &e.poa_redo_i, &e.nw_hs, &e.nw_ck, &e.nw_hs2, &e.nw_ck2, &e.nw_hs3, &e.nw_ck3, &e.nw_strip, &e.nw_jobs, &e.nw_res,
+      &e.poa_sched, &e.poa_redo_w, &e.poa_redo_i, &e.nw_hs, &e.nw_ck, &e.nw_hs2, &e.nw_ck2, &e.nw_hs3, &e.nw_ck3, &e.nw_hs4, &e.nw_ck4, &e.nw_strip, &e.nw_jobs, &e.nw_res,
       &e.pl_best, &e.pl_best_t, &e.pl_idmap, &e.pl_recs, &e.pl_keep, &e.pl_win_cnt, &e.pl_win_off, &e.pl_win_fill,
       &e.pl_win_meta, &e.pl_first_window, &e.pl_keys, &e.pl_lays_tmp, &e.pl_lays, &e.pl_wins, &e.pl_out, &e.pl_len,
       &e.pl_status, &e.pl_ok, &e.pl_cons_off, &e.pl_final, &e.pl_qual_off, &e.pl_misc, &e.anc_slot_off, &e.anc_slot_cnt};

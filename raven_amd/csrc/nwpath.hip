@@ -213,7 +213,19 @@ void nw_breakpoints(Engine& e, const ReadsDev& T, const ReadsDev& Rd, std::vecto
   if (nj == 0) return;
   RVN_HIP(hipEventRecord(e.ev0, s));
   if (!e.nw_streams[0]) {
-    for (hipStream_t& st2 : e.nw_streams) RVN_HIP(hipStreamCreateWithFlags(&st2, hipStreamNonBlocking));
+    // HIP multiplexes its streams over a handful of hardware queues (four by default): two walk streams that land on the
+    // same queue run one after the other, and the ~100-ms walk of the longest alignments held the walk queued behind it —
+    // and with it the sweep waiting for that walk's buffer set (profiles/r05_nw_timeline.csv: a walk starting the moment
+    // the long one ended).  Streams of another PRIORITY get hardware queues of their own: the long pole's stream (set 3)
+    // is created at the highest priority, which also suits a kernel of 38 latency-bound waves.
+    int prio_least = 0, prio_greatest = 0;
+    RVN_HIP(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+    for (int b = 0; b < 4; ++b) {
+      if (b == 3 && prio_greatest != prio_least)
+        RVN_HIP(hipStreamCreateWithPriority(&e.nw_streams[b], hipStreamNonBlocking, prio_greatest));
+      else
+        RVN_HIP(hipStreamCreateWithFlags(&e.nw_streams[b], hipStreamNonBlocking));
+    }
     for (hipEvent_t& ev : e.nw_ev) RVN_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
   }
   // an error in the middle of a pass (a walk that left its band, an allocation that failed) must not leave walks running
@@ -258,7 +270,7 @@ void nw_breakpoints(Engine& e, const ReadsDev& T, const ReadsDev& Rd, std::vecto
   {
     size_t free_b = 0, total_b = 0;
     RVN_HIP(hipMemGetInfo(&free_b, &total_b));
-    const u64 held = e.nw_hs.cap + e.nw_ck.cap + e.nw_hs2.cap + e.nw_ck2.cap + e.nw_hs3.cap + e.nw_ck3.cap;
+    const u64 held = e.nw_hs.cap + e.nw_ck.cap + e.nw_hs2.cap + e.nw_ck2.cap + e.nw_hs3.cap + e.nw_ck3.cap + e.nw_hs4.cap + e.nw_ck4.cap;
     budget = std::min<u64>((static_cast<u64>(free_b) + devpool::free_total()) / 4 + held, 64ULL << 30);  // parked blocks count as free
     if (e.opt.nw_budget_mb > 0) budget = static_cast<u64>(e.opt.nw_budget_mb) << 20;
     budget = std::max<u64>(budget, 64ULL << 20);
@@ -311,7 +323,10 @@ void nw_breakpoints(Engine& e, const ReadsDev& T, const ReadsDev& Rd, std::vecto
         order.resize(nt);
         for (size_t x = 0; x < nt; ++x) order[x] = todo[idx[x]];
       }
-      // chunks of the order whose hs + ck fit half the budget (a job larger than that goes alone)
+      // chunks of the order whose hs + ck fit a third of the budget (a job larger than that goes alone).  (Capping the jobs
+      // per chunk — an even eighth, or a third of what is left, so that the uncovered walk of the last chunk gets shorter —
+      // was measured at C4 and did not pay: every extra sweep launch brings its own ramp and tail, +19 ms of sweep time
+      // against ~20 ms less at the end; profiles/r05_nw_timeline.csv.)
       std::vector<Chunk> chunks;
       for (size_t c0 = 0; c0 < order.size();) {
         Chunk C{};
@@ -321,8 +336,9 @@ void nw_breakpoints(Engine& e, const ReadsDev& T, const ReadsDev& Rd, std::vecto
           NwJob& J = jobs[order[c1]];
           const NwGeo g = nw_geo(J.n, J.m, J.k, J.R);
           const u64 hw = g.hs_words(), ce = g.ck_entries();
-          // three buffer sets; the first chunk (the longest alignments: its walk is latency-bound and must end while the
-          // other chunks are still being swept) takes a quarter of a share
+          // three buffer sets in rotation + one of its own for the first chunk (the longest alignments: its walk is
+          // latency-bound — 106 ms for 2 432 alignments at C4 — and a set shared with chunk 3 made that chunk's sweep wait
+          // 17 ms for it), a quarter of a share
           const u64 share = chunks.empty() ? budget / 12 : budget / 3;
           if (c1 > c0 && (C.hs_w + hw) * 4 + (C.ck_e + ce) * 16 > share) break;
           J.hs = C.hs_w;
@@ -346,16 +362,21 @@ void nw_breakpoints(Engine& e, const ReadsDev& T, const ReadsDev& Rd, std::vecto
         chunks.push_back(C);
         c0 = c1;
       }
-      DevBuf* hs_buf[3] = {&e.nw_hs, &e.nw_hs2, &e.nw_hs3};
-      DevBuf* ck_buf[3] = {&e.nw_ck, &e.nw_ck2, &e.nw_ck3};
-      const int n_sets = static_cast<int>(std::min<size_t>(chunks.size(), 3));
-      for (int b = 0; b < n_sets; ++b) {
-        // set b serves chunks b, b + 3, ...: sized for those (a lone job beyond its share enlarges one set, not three)
+      DevBuf* hs_buf[4] = {&e.nw_hs, &e.nw_hs2, &e.nw_hs3, &e.nw_hs4};
+      DevBuf* ck_buf[4] = {&e.nw_ck, &e.nw_ck2, &e.nw_ck3, &e.nw_ck4};
+      // chunk 0 -> set 3 (its own), chunk ci >= 1 -> set (ci - 1) % 3
+      auto set_of = [](size_t ci) -> int { return ci == 0 ? 3 : static_cast<int>((ci - 1) % 3); };
+      for (int b = 0; b < 4; ++b) {
+        // sized for the chunks the set serves (a lone job beyond its share enlarges one set, not all)
         u64 set_hs = 0, set_ck = 0;
-        for (size_t ci = static_cast<size_t>(b); ci < chunks.size(); ci += 3) {
+        bool used = false;
+        for (size_t ci = 0; ci < chunks.size(); ++ci) {
+          if (set_of(ci) != b) continue;
+          used = true;
           set_hs = std::max(set_hs, chunks[ci].hs_w);
           set_ck = std::max(set_ck, chunks[ci].ck_e);
         }
+        if (!used) continue;
         (void)hs_buf[b]->get<u32>(set_hs + 4 * 64 * 8 + 16);  // + slack: the walk reads up to two words past a job's last one
         (void)ck_buf[b]->get<NwPm>(set_ck + 16);
       }
@@ -363,7 +384,7 @@ void nw_breakpoints(Engine& e, const ReadsDev& T, const ReadsDev& Rd, std::vecto
       if (!trace_lds) {
         size_t mc = 0;
         for (const Chunk& C : chunks) mc = std::max(mc, C.c1 - C.c0);
-        d_strip = e.nw_strip.get<u64>(static_cast<size_t>((mc + 63) / 64) * 2 * kNwStripCols * 64 * 3 + 64);
+        d_strip = e.nw_strip.get<u64>(static_cast<size_t>((mc + 63) / 64) * 2 * kNwStripCols * 64 * 4 + 64);
       }
       h_order += since(t_h);
       t_h = clk::now();
@@ -373,12 +394,12 @@ void nw_breakpoints(Engine& e, const ReadsDev& T, const ReadsDev& Rd, std::vecto
       h_up += since(t_h);
       for (size_t ci = 0; ci < chunks.size(); ++ci) {
         const Chunk& C = chunks[ci];
-        const int b = static_cast<int>(ci % 3);
+        const int b = set_of(ci);
         u32* hs = hs_buf[b]->as<u32>();
         NwPm* ck = ck_buf[b]->as<NwPm>();
         const u32* idx_c = d_idx + C.c0;
         const u32 cn = static_cast<u32>(C.c1 - C.c0);
-        if (ci >= 3) RVN_HIP(hipStreamWaitEvent(s, e.nw_ev[b], 0));  // the walk of chunk ci - 3 is done with this buffer set
+        if (ci >= 4) RVN_HIP(hipStreamWaitEvent(s, e.nw_ev[b], 0));  // the walk of chunk ci - 3 is done with this buffer set
         auto count_of = [&](u32 x) -> u32 {  // classes are laid out from the widest variant down
           const u32 next_off = x == 0 ? cn : C.coff[x - 1];
           return next_off - C.coff[x];
@@ -408,8 +429,8 @@ void nw_breakpoints(Engine& e, const ReadsDev& T, const ReadsDev& Rd, std::vecto
         // latency) must not hold back the walks of the chunks behind it
         hipStream_t ts = one_stream ? s : e.nw_streams[b];
         if (!one_stream) {
-          RVN_HIP(hipEventRecord(e.nw_ev[3], s));
-          RVN_HIP(hipStreamWaitEvent(ts, e.nw_ev[3], 0));
+          RVN_HIP(hipEventRecord(e.nw_ev[4], s));
+          RVN_HIP(hipStreamWaitEvent(ts, e.nw_ev[4], 0));
         }
         if (trace_lds) {
           RVN_KLAUNCH_ON(kKNwTraceback, ts, (nw_trace_kernel<true><<<(cn + 63) / 64, 64, 0, ts>>>(
@@ -419,7 +440,7 @@ void nw_breakpoints(Engine& e, const ReadsDev& T, const ReadsDev& Rd, std::vecto
           RVN_KLAUNCH_ON(kKNwTraceback, ts, (nw_trace_kernel<false><<<(cn + 63) / 64, 64, 0, ts>>>(
                                                 d_jobs, idx_c, cn, T.packed.as<u64>(), Rd.packed.as<u64>(), hs, ck, d_res,
                                                 d_status, w, d_recs,
-                                                d_strip + static_cast<size_t>(b) * ((e.nw_strip.cap / 24) & ~size_t(63)))));
+                                                d_strip + static_cast<size_t>(b) * ((e.nw_strip.cap / 32) & ~size_t(63)))));
         }
         if (!one_stream) RVN_HIP(hipEventRecord(e.nw_ev[b], ts));
         if (dbg_sync) {
@@ -429,7 +450,12 @@ void nw_breakpoints(Engine& e, const ReadsDev& T, const ReadsDev& Rd, std::vecto
         ++st.n_batches;
       }
       if (!one_stream && !sweep_only) {  // everything of this pass done before the results are read
-        for (int b = 0; b < n_sets; ++b) RVN_HIP(hipStreamWaitEvent(s, e.nw_ev[b], 0));
+        bool waited[4] = {false, false, false, false};  // (an event stands for the LAST walk recorded on its set)
+        for (size_t ci = 0; ci < chunks.size(); ++ci) {
+          const int b = set_of(ci);
+          if (!waited[b]) RVN_HIP(hipStreamWaitEvent(s, e.nw_ev[b], 0));
+          waited[b] = true;
+        }
       }
       RVN_HIP(hipMemcpyAsync(h_result.data(), d_res, static_cast<size_t>(nj) * 4, hipMemcpyDeviceToHost, s));
       RVN_HIP(hipMemcpyAsync(h_status.data(), d_status, static_cast<size_t>(nj) * 4, hipMemcpyDeviceToHost, s));

@@ -26,6 +26,7 @@ for step in "$@"; do
   t0=$(date +%s)
   case $name in
     tests-poa) timeout 900 python -m pytest tests/test_gpu_poa.py tests/test_gpu_polish.py -x -q -m gpu > gpurun_out/${TAG}_tests_poa.log 2>&1; tail -4 gpurun_out/${TAG}_tests_poa.log;;
+    tests-mgpu) timeout 1500 python -m pytest tests/test_gpu_sharded.py tests/test_gpu_group.py tests/test_gpu_parity.py -x -q -m gpu > gpurun_out/${TAG}_tests_mgpu.log 2>&1; tail -6 gpurun_out/${TAG}_tests_mgpu.log;;
     tests-all) timeout 1500 python -m pytest tests -x -q -m gpu > gpurun_out/${TAG}_tests_all.log 2>&1; tail -4 gpurun_out/${TAG}_tests_all.log;;
     benchpoa_a) RVN_LIB_PATH=$R/raven_amd/lib_a/libraven_hip_test.so RVN_POA_MODES="$arg" timeout 900 python tools/bench_poa.py 24576 0 2>gpurun_out/${TAG}_benchpoa_a.err | tee gpurun_out/${TAG}_benchpoa_a.log | python -c "
 import sys, json
@@ -41,11 +42,13 @@ for l in sys.stdin:
        env RVN_LIB_PATH=$R/raven_amd/lib_a/libraven_hip_test.so $envs timeout 900 python bench.py --workload c4 --steps ${STEPS:-2} --warmup ${WARMUP:-2} --no-cpu-baseline --load-bases 0 > $f 2> ${f%.json}.err; summ $f;;
     c4|c2|c5) f=gpurun_out/${TAG}_${name}_$(echo "$arg" | tr -c 'A-Za-z0-9\n' '_').json
        [ -n "$envs" ] && envs="RVN_LIB_PATH=$R/raven_amd/lib/libraven_hip_test.so $envs"  # (environment switches exist in the debug build only)
-       env $envs timeout 900 python bench.py --workload $name --steps ${STEPS:-2} --warmup ${WARMUP:-2} --no-cpu-baseline --load-bases 0 > $f 2> ${f%.json}.err; summ $f;;
+       env $envs timeout 900 python bench.py --workload $name --steps ${STEPS:-2} --warmup ${WARMUP:-2} --no-cpu-baseline --load-bases 0 $BENCH_ARGS > $f 2> ${f%.json}.err; summ $f;;
     parity) timeout 1200 python tools/poa_parity.py $arg > gpurun_out/${TAG}_poa_parity_$arg.json 2> gpurun_out/${TAG}_poa_parity.err; python -c "
 import json; d = json.load(open('gpurun_out/${TAG}_poa_parity_$arg.json')); print({k: v for k, v in d.items() if k not in ('examples', 'not_explained')}, 'unexplained', len(d['not_explained']))";;
     profile) bash tools/profile_round.sh $arg;;
     sqpoa) bash tools/prof_poa.sh $arg;;
+    tracenw) bash tools/trace_nw.sh $arg;;
+    sqnw) bash tools/prof_nw.sh $arg;;
     *) echo "unknown step $step";;
   esac
   echo "[$step] $(( $(date +%s) - t0 )) s"

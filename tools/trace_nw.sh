@@ -1,9 +1,10 @@
 #!/bin/bash
 # kernel timeline of the alignment stage (start / end per dispatch, both streams) -> gpurun_out/<tag>_nw_timeline.csv
 R=${GRAFT_REPO_ROOT:-/root/repo}
-TAG=${1:-r03}
+TAG=${1:-r05}
 cd /tmp && export TMPDIR=/tmp
 export RVN_POLISH_SKIP_POA=1
+export RVN_LIB_PATH=$R/raven_amd/lib/libraven_hip_test.so  # (the switch above exists in the debug build only)
 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/${TAG}_nw_tl -o t -- python $R/bench.py --no-cpu-baseline --no-kernel-timing --steps 1 --warmup 0 > /dev/null 2> $R/gpurun_out/${TAG}_nw_tl.err
 F=$(find $R/gpurun_out/${TAG}_nw_tl -name '*kernel_trace.csv' | head -1)
 python - "$F" $R/gpurun_out/${TAG}_nw_timeline.csv <<'PY'
@@ -18,4 +19,4 @@ with open(sys.argv[2], "w") as f:
         f.write("%s,%s,%.2f,%.2f,%.2f,%s\n" % (n, r.get("Queue_Id", ""), s / 1e6, e / 1e6, (e - s) / 1e6, r.get("Grid_Size", r.get("Grid_Size_X", ""))))
 PY
 rm -rf $R/gpurun_out/${TAG}_nw_tl
-cat $R/gpurun_out/${TAG}_nw_timeline.csv | head -60
+cat $R/gpurun_out/${TAG}_nw_timeline.csv | head -90
