@@ -1086,7 +1086,7 @@ __host__ __device__ inline u32 poa4_update_graph(const Poa4Args A, u16* nslot, c
 // Consensus of a finished window: spoa's heaviest bundle with the node scores in the WAVE's LDS (the DP of every window
 // of the wave is over by now), first four in-edges of 64 nodes at a time in registers (as poa2_consensus), then branch
 // completion + racon's coverage trim on lane 0 and a parallel output copy.
-__host__ __device__ inline void poa4_consensus(Poa2Slot& g, u32 n_nodes, u32 nmax, const PoaWindow& win, int trim, Poa4Lds& S,
+__host__ __device__ inline void poa4_consensus_general(Poa2Slot& g, u32 n_nodes, u32 nmax, const PoaWindow& win, int trim, Poa4Lds& S,
                                                u8* out, u32* out_len) {
   const int lane = sv::lane();
   // (the lane-0 code shared with poa2.hip wants a node's rank in rank_of[], which this kernel does not keep per layer)
@@ -1165,6 +1165,144 @@ __host__ __device__ inline void poa4_consensus(Poa2Slot& g, u32 n_nodes, u32 nma
   if (n_out < 0) n_out = 0;
   if (static_cast<u32>(n_out) > win.out_cap) n_out = static_cast<i32>(win.out_cap);
   for (i32 p = lane; p < n_out; p += 64) out[p] = g.code[g.stack[cl - 1 - static_cast<u32>(begin + p)]];
+  if (lane == 0) *out_len = static_cast<u32>(n_out);
+}
+
+// The same for the common case, with nothing but registers and LDS between the graph and the consensus (round 5; the
+// general form above took 10 % of the kernel's wave cycles: every node's score went through LDS and the walk back along
+// the predecessors was ~600 dependent loads from global memory on lane 0).  Along the rank order a node's in-edges reach
+// back a few ranks (at most 23 inside any layer's subgraph), so the scores of the last 64 ranks live in ONE vector register
+// — lane = rank mod 64, read with v_readlane, written with v_writelane: the serial loop over the nodes is scalar code with
+// no memory access at all —, the predecessors go to LDS (u16 per node) where the walk back follows them, and the stack of
+// the consensus nodes stays in LDS for the output copy.  A window beyond what this form holds (more than 2 436 nodes, an
+// in-edge reaching back more than 63 ranks) or whose heaviest path does not end in an end node (spoa's branch completion
+// rewrites scores) takes the general form.  Same tie rules, same results.
+__host__ __device__ inline void poa4_consensus(Poa2Slot& g, const u32* rb, u32 n_nodes, u32 nmax, const PoaWindow& win, int trim,
+                                               Poa4Lds& S, u8* out, u32* out_len) {
+  const int lane = sv::lane();
+  constexpr u32 kCapNodes = sizeof(Poa4Lds) / 4;  // u16 predecessor per node + u16 stack entry per consensus node
+  u16* lpred = reinterpret_cast<u16*>(&S);
+  u16* lstack = lpred + kCapNodes;
+  bool general = n_nodes > kCapNodes;
+  i32 maxn = -1, max_sc = 0;
+  if (!general) {
+    int ring = 0;  // lane l: score of the last node computed at a rank = l (mod 64)
+    u32 bad = 0;
+    for (u32 r0 = 0; r0 < n_nodes; r0 += 64) {
+      const u32 rows = n_nodes - r0 < 64 ? n_nodes - r0 : 64;
+      int m_it = 0, m_c = 0, m_lb = 0, m_t01 = 0, m_t23 = 0, m_w0 = 0, m_w1 = 0, m_w2 = 0, m_w3 = 0;
+      if (static_cast<u32>(lane) < rows) {
+        const u32 r = r0 + static_cast<u32>(lane);
+        m_it = g.order[r];
+        m_c = g.in_cnt[m_it];
+        const u16* tp = g.in_tail + static_cast<size_t>(m_it) * kPoaMaxIn;
+        const i32* wp = g.in_w + static_cast<size_t>(m_it) * kPoaMaxIn;
+        const uint2 t4 = *reinterpret_cast<const uint2*>(tp);
+        const int4 w4 = *reinterpret_cast<const int4*>(wp);
+        m_t01 = static_cast<int>(t4.x);
+        m_t23 = static_cast<int>(t4.y);
+        m_w0 = w4.x;
+        m_w1 = w4.y;
+        m_w2 = w4.z;
+        m_w3 = w4.w;
+        u32 lb = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {  // how many ranks the first four in-edges reach back
+          const u32 t = ((k < 2 ? t4.x : t4.y) >> (16 * (k & 1))) & 0xFFFFu;
+          const u32 d = static_cast<u32>(k) < static_cast<u32>(m_c) ? r - (rb[t] & 0xFFFFu) : 1u;
+          if (d < 1 || d > 63) bad = 1;
+          lb |= (d & 63u) << (8 * k);
+        }
+        m_lb = static_cast<int>(lb);
+      }
+      int predv = 0xFFFF;
+      for (u32 l = 0; l < rows; ++l) {
+        const int li = static_cast<int>(l);
+        const u32 r = r0 + l;
+        const u32 it = static_cast<u32>(sv::rl(m_it, li));
+        const u32 c = static_cast<u32>(sv::rl(m_c, li));
+        const u32 lb = static_cast<u32>(sv::rl(m_lb, li));
+        const u32 t01 = static_cast<u32>(sv::rl(m_t01, li)), t23 = static_cast<u32>(sv::rl(m_t23, li));
+        const i32 w0 = sv::rl(m_w0, li), w1 = sv::rl(m_w1, li), w2 = sv::rl(m_w2, li), w3 = sv::rl(m_w3, li);
+        i32 sc = -1, pd = -1, pd_sc = 0;
+        for (u32 k = 0; k < c; ++k) {
+          i32 wgt, t;
+          u32 d;
+          if (k < 4) {
+            t = static_cast<i32>(((k < 2 ? t01 : t23) >> (16 * (k & 1))) & 0xFFFFu);
+            wgt = k == 0 ? w0 : (k == 1 ? w1 : (k == 2 ? w2 : w3));
+            d = (lb >> (8 * k)) & 0xFFu;
+          } else {  // (1 % of the nodes)
+            wgt = g.in_w[static_cast<size_t>(it) * kPoaMaxIn + k];
+            t = static_cast<i32>(g.in_tail[static_cast<size_t>(it) * kPoaMaxIn + k]);
+            d = r - (rb[t] & 0xFFFFu);
+            if (d < 1 || d > 63) {
+              bad = 1;
+              d = 1;
+            }
+          }
+          const i32 st = sv::rl(ring, static_cast<int>((r - d) & 63u));
+          if (sc < wgt || (sc == wgt && pd_sc <= st)) {
+            sc = wgt;
+            pd = t;
+            pd_sc = st;
+          }
+        }
+        if (pd != -1) sc += pd_sc;
+        ring = sv::wl(ring, sc, li);
+        predv = sv::wl(predv, pd == -1 ? 0xFFFF : pd, li);
+        if (maxn == -1 || max_sc < sc) {
+          maxn = static_cast<i32>(it);
+          max_sc = sc;
+        }
+      }
+      if (static_cast<u32>(lane) < rows) lpred[m_it] = static_cast<u16>(predv);
+    }
+    general = sv::any(bad != 0) || (maxn >= 0 && g.out_cnt[maxn] != 0);  // (the latter: spoa's branch completion)
+  }
+  if (general) {
+    sv::sync();
+    poa4_consensus_general(g, n_nodes, nmax, win, trim, S, out, out_len);
+    return;
+  }
+  lds_order();  // lpred
+  u32 cl = 0;
+  i32 begin = 0, end = -1;
+  if (lane == 0) {
+    // the walk back along the predecessors (reverse order into the stack), then racon's coverage trim — as
+    // poa_consensus_trace_lane0 (poa.h), everything it follows in LDS
+    u32 cur = maxn < 0 ? 0xFFFFu : static_cast<u32>(maxn);
+    while (cur != 0xFFFFu && cl < kCapNodes) {
+      lstack[cl++] = static_cast<u16>(cur);
+      cur = lpred[cur];
+    }
+    end = static_cast<i32>(cl) - 1;
+    if (trim) {
+      const u32 avg = (win.n_layers - 1) / 2;
+      auto cov = [&](i32 pos) -> u32 {  // coverage of a consensus node = visits of the node + of its aligned nodes
+        const u32 v = lstack[cl - 1 - static_cast<u32>(pos)];
+        u32 c = g.visits[v];
+        for (u32 k = 0; k < g.al_cnt[v]; ++k) c += g.visits[g.al[v * 4 + k]];
+        return c;
+      };
+      for (; begin < static_cast<i32>(cl); ++begin)
+        if (cov(begin) >= avg) break;
+      for (; end >= 0; --end)
+        if (cov(end) >= avg) break;
+      if (begin >= end) {  // racon: warning only, consensus kept untrimmed
+        begin = 0;
+        end = static_cast<i32>(cl) - 1;
+      }
+    }
+  }
+  cl = static_cast<u32>(sv::rfl(static_cast<int>(cl)));
+  begin = sv::rfl(begin);
+  end = sv::rfl(end);
+  lds_order();  // lstack
+  i32 n_out = end - begin + 1;
+  if (n_out < 0) n_out = 0;
+  if (static_cast<u32>(n_out) > win.out_cap) n_out = static_cast<i32>(win.out_cap);
+  for (i32 p = lane; p < n_out; p += 64) out[p] = g.code[lstack[cl - 1 - static_cast<u32>(begin + p)]];
   if (lane == 0) *out_len = static_cast<u32>(n_out);
 }
 
@@ -1786,7 +1924,8 @@ __host__ __device__ inline void poa4_phase_final(const Poa4Args& A, const Poa4Ct
     } else if (w.phase == kLayersDone) {
       Poa2Slot g = poa4_graph(poa4_slot_of(A, C, wave, q2), A.nmax, A.lmax, w.flip != 0);
       wq.n_layers = w.n_eff;
-      poa4_consensus(g, w.nn, A.nmax, wq, A.trim, S, A.out + wq.out_off, A.out_len + w.wi);
+      poa4_consensus(g, poa4_carve(poa4_slot_of(A, C, wave, q2), A.nmax, A.lmax).rb, w.nn, A.nmax, wq, A.trim, S, A.out + wq.out_off,
+                     A.out_len + w.wi);
       sv::sync();
       st = 1;
     }

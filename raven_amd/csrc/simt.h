@@ -34,6 +34,10 @@ __device__ __forceinline__ unsigned long long ballot(bool p) { return __ballot(p
 __device__ __forceinline__ int bperm(int v, int src_lane) { return __builtin_amdgcn_ds_bpermute(src_lane << 2, v); }
 __device__ __forceinline__ int rl(int v, int src_lane) { return __builtin_amdgcn_readlane(v, src_lane); }
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// v with lane `dst_lane` (wave-uniform) replaced by `value` (wave-uniform): v_writelane_b32
+// (this hipcc has no __builtin_amdgcn_writelane: the LLVM intrinsic by its name; the backend puts the lane select into M0)
+__device__ int rvn_llvm_writelane(int value, int dst_lane, int old) __asm("llvm.amdgcn.writelane.i32");
+__device__ __forceinline__ int wl(int v, int value, int dst_lane) { return rvn_llvm_writelane(value, dst_lane, v); }
 __device__ __forceinline__ void sync() {
   __threadfence_block();
   __builtin_amdgcn_wave_barrier();
@@ -61,6 +65,7 @@ inline unsigned long long ballot(bool p, int site = __builtin_LINE()) { return s
 inline int bperm(int v, int src_lane, int site = __builtin_LINE()) { return simt_emu::exchange(v, src_lane & 63, site); }
 inline int rl(int v, int src_lane, int site = __builtin_LINE()) { return simt_emu::exchange(v, src_lane & 63, site); }
 inline int rfl(int v, int site = __builtin_LINE()) { return simt_emu::exchange(v, 0, site); }
+inline int wl(int v, int value, int dst_lane) { return simt_emu::lane() == (dst_lane & 63) ? value : v; }
 inline void sync(int site = __builtin_LINE()) { simt_emu::sync(site); }
 inline void phase_fence(int site = __builtin_LINE()) { simt_emu::sync(site); }
 template <int N>

@@ -1,7 +1,9 @@
 #!/bin/bash
 # One gpurun call of round 5: runs the named steps on the GPU box, everything under its own timeout, outputs under
 # gpurun_out/<tag>_*.  usage: gpu_run.sh <tag> step [step ...]
-#   tests-poa | tests-all | benchpoa:<modes> | c4[:ENV=V,...] | c2[:ENV=V,...] | c5 | parity:<n> | profile:<tag>
+#   tests-poa | tests-mgpu | tests-all | smoke | benchpoa:<modes> | c4[:ENV=V,...] | c2[:ENV=V,...] | c5 | bench-full:<c4|c2|c5>
+#   | parity:<n> | profile:<tag> | sqpoa:<tag> | sqnw:<tag> | tracenw:<tag>       (ENV=V switches need the debug build: the
+#   script points RVN_LIB_PATH at libraven_hip_test.so for those runs)
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
 mkdir -p gpurun_out
@@ -43,6 +45,10 @@ for l in sys.stdin:
     c4|c2|c5) f=gpurun_out/${TAG}_${name}_$(echo "$arg" | tr -c 'A-Za-z0-9\n' '_').json
        [ -n "$envs" ] && envs="RVN_LIB_PATH=$R/raven_amd/lib/libraven_hip_test.so $envs"  # (environment switches exist in the debug build only)
        env $envs timeout 900 python bench.py --workload $name --steps ${STEPS:-2} --warmup ${WARMUP:-2} --no-cpu-baseline --load-bases 0 $BENCH_ARGS > $f 2> ${f%.json}.err; summ $f;;
+    bench-full) f=gpurun_out/${TAG}_bench_${arg}.json   # the line the driver takes (default steps; CPU baseline at c4)
+       extra="--no-cpu-baseline"; [ "$arg" = "c4" ] && extra=""
+       timeout 1500 python bench.py --workload $arg $extra > $f 2> ${f%.json}.err; summ $f;;
+    smoke) timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3;;
     parity) timeout 1200 python tools/poa_parity.py $arg > gpurun_out/${TAG}_poa_parity_$arg.json 2> gpurun_out/${TAG}_poa_parity.err; python -c "
 import json; d = json.load(open('gpurun_out/${TAG}_poa_parity_$arg.json')); print({k: v for k, v in d.items() if k not in ('examples', 'not_explained')}, 'unexplained', len(d['not_explained']))";;
     profile) bash tools/profile_round.sh $arg;;
