@@ -15,7 +15,9 @@
 //     by a per-layer pre-pass, so the step loop decodes nothing,
 //   * in-edges are folded with v_max on (score << 4 | diagonal << 3 | 7 - in-edge) keys: spoa's tie rule (diagonal
 //     before vertical, first in-edge first) is the maximum's and the backpointer falls out of its low bits: FOUR bits per
-//     cell (0 = horizontal; a row with more than seven in-edges sends the window to poa2: 2.5 % of C4-like windows),
+//     cell.  0 = horizontal AND "vertical through the eighth in-edge" (tag 7 - 7): the traceback cannot tell the two apart,
+//     so a walk that meets code 0 in a row of eight in-edges sends the window to poa2 (a tenth of the 2.5 % of C4-like
+//     windows that have such a row; refusing eight in-edges outright cost 23 ms more of poa2 per C4 round),
 //   * backpointers leave as ONE coalesced 8-byte store per lane and 8 steps into a time-major stream (step, lane); the
 //     traceback maps (row, column) -> (step, lane) through the descriptor.
 // Schedule (all band starts even and non-decreasing along the topological order): row rho of the layer's rank range
@@ -55,8 +57,8 @@ struct P4 {
                                       // round — the stage does not want more waves)
   static constexpr int kRowB = 88;    // bytes per ring row: 2 -inf cells | 32 cells | 10 -inf cells
   static constexpr int kMaxD = 8;     // largest band-start difference along an in-edge (the right pads cover it)
-  static constexpr int kEdges = 7;    // in-edges a row may have (4-bit backpointers: horizontal + 7 x (diagonal, vertical) = 15 codes);
-                                      // a row with more sends the window to poa2
+  static constexpr int kEdges = 8;    // in-edges a row descriptor holds; a row with more sends the window to poa2 (4-bit backpointers:
+                                      // 8 diagonal + 7 vertical codes + 0 = horizontal or vertical through in-edge 7, see above)
   static constexpr int kU = 8;        // steps between two service points (descriptor prefetch, backpointer store)
 };
 constexpr u32 kNone4 = 0xFFFFu;
@@ -473,7 +475,10 @@ __host__ __device__ inline void poa4_dp(const Poa4Args A, Poa4Lds& S, unsigned c
         P4_EDGE(4, ce2, false)
         if (sv::any(np > 5)) {
           P4_EDGE(5, ce2, true)
-          if (sv::any(np > 6)) P4_EDGE(6, ce3, false)
+          if (sv::any(np > 6)) {
+            P4_EDGE(6, ce3, false)
+            P4_EDGE(7, ce3, true)
+          }
         }
       }
 #undef P4_EDGE
@@ -663,6 +668,8 @@ __host__ __device__ inline void poa4_traceback(const Poa4Args A, Poa4LdsTb& S, u
       const bool diag = (code & 8u) != 0;
       const u32 k = 7u - (code & 7u);
       const u32 np = (d.y >> 26) & 15u;
+      // code 0 in a row of eight in-edges is "horizontal" or "vertical through the eighth": not decidable here
+      const bool ambiguous = isH && np >= 8u;
       u32 ni = np == 0 ? 0u : i - ((d.z >> (5 * (k < 6 ? k : 0u))) & 31u);
       if (sv::any(in_round && !oob && !isH && np != 0 && k >= 6)) {  // in-edges 6 and 7 of a row: their ranks come from the graph
         if (in_round && !oob && !isH && np != 0 && k >= 6)
@@ -670,10 +677,10 @@ __host__ __device__ inline void poa4_traceback(const Poa4Args A, Poa4LdsTb& S, u
       }
       const bool mv = isH || diag;                  // the step consumes a base of the layer
       const bool jerr = !oob && mv && j == 0;       // (never on a consistent stream)
-      const bool stop = oob || jerr;
+      const bool stop = oob || jerr || ambiguous;
       if (in_round) {
         ++steps;
-        if (oob || edge_hit) band_hit = 1;
+        if (oob || edge_hit || ambiguous) band_hit = 1;
         if (jerr) bad = 6;
         if (diag && !stop && gl == 0) pos_node[j - 1] = static_cast<u16>(node);  // (an insertion leaves pos_node[j] at kNone)
         j -= (mv && !stop) ? 1 : 0;
