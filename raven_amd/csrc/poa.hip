@@ -797,7 +797,7 @@ void poa_run_dev(Engine& e, const PoaWindow* d_wins, const PoaLayer* d_lays, u32
   if (want_stats) RVN_HIP(hipMemcpyAsync(kstats, d_phase + 10, 48, hipMemcpyDeviceToHost, s));
   RVN_HIP(rvn_stream_sync(s));
   if (want_stats)
-    std::fprintf(stderr, "[raven_hip] poa kernel statistics (poa4.hip): prepass cycles %llu, traceback steps %llu round changes %llu (cycles in them %llu), dp wave-steps %llu, layer set-up cycles %llu\n",
+    std::fprintf(stderr, "[raven_hip] poa kernel statistics (poa4.hip): descriptor-pass cycles %llu, traceback steps %llu round changes %llu (cycles in them %llu), dp wave-steps %llu, window set-up cycles %llu\n",
                  kstats[0], kstats[1], kstats[2], kstats[3], kstats[4], kstats[5]);
   e.poa_cells_full += e.poa_phase_cycles[6];
   e.poa_cells_band += e.poa_phase_cycles[7];

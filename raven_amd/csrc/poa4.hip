@@ -550,8 +550,29 @@ __host__ __device__ inline void poa4_dp(const Poa4Args A, Poa4Lds& S, unsigned c
 // ago (the memory counter is the wave's, not the window's).
 constexpr int kTbG = 2;
 struct alignas(16) Poa4LdsTb {
-  uint4 row[P4::G][16 * kTbG][3];  // per row of the round: 24 bytes of codes, 8 unused, {d0, d1, d7, -}
+  // per row of the round: the 16 code bytes of its 32 columns ALIGNED TO THE COLUMN (byte (j >> 1) & 15 holds the codes of
+  // columns j, j + 1: where the code of (row, j) lies does not depend on the row's band start, so the walk reads it beside
+  // the row's record, not behind it), then {d0, d1, d7, -}
+  uint4 row[P4::G][16 * kTbG][2];
 };
+// the 16 code bytes of a row (its steps 0 .. 15 start at byte S % 8 of the 24 the lane fetched) rotated so that the byte of
+// columns (j, j + 1) sits at index (j >> 1) & 15; bt = the row's (even) band start
+__host__ __device__ __forceinline__ uint4 poa4_align_codes(u32 c0, u32 c1, u32 c2, u32 c3, u32 c4, u32 c5, u32 S, u32 bt) {
+  const u32 sb = S & 7u;
+  const bool hi = sb >= 4u;
+  const u32 w0 = hi ? c1 : c0, w1 = hi ? c2 : c1, w2 = hi ? c3 : c2, w3 = hi ? c4 : c3, w4 = hi ? c5 : c4;
+  const u32 sh = 8u * (sb & 3u);
+  const u32 b0 = funnel_shr(w1, w0, sh), b1 = funnel_shr(w2, w1, sh), b2 = funnel_shr(w3, w2, sh), b3 = funnel_shr(w4, w3, sh);
+  // rotate the 128-bit ring left by r bytes: byte k goes to (k + r) & 15
+  const u32 r = (bt >> 1) & 15u, rw = r >> 2, rs = 8u * (r & 3u);
+  const u32 o0 = rw == 0 ? b0 : (rw == 1 ? b3 : (rw == 2 ? b2 : b1));
+  const u32 o1 = rw == 0 ? b1 : (rw == 1 ? b0 : (rw == 2 ? b3 : b2));
+  const u32 o2 = rw == 0 ? b2 : (rw == 1 ? b1 : (rw == 2 ? b0 : b3));
+  const u32 o3 = rw == 0 ? b3 : (rw == 1 ? b2 : (rw == 2 ? b1 : b0));
+  if (rs == 0) return uint4{o0, o1, o2, o3};
+  const u32 back = 32u - rs;
+  return uint4{funnel_shr(o0, o3, back), funnel_shr(o1, o0, back), funnel_shr(o2, o1, back), funnel_shr(o3, o2, back)};
+}
 template <class K>
 __host__ __device__ inline void poa4_traceback(const Poa4Args A, Poa4LdsTb& S, unsigned char* slot_mem, bool act, u32 r_lo,
                                                u32 n_rows, bool full, u32 len, u32 best_rho1, u32& bad, u32& band_hit) {
@@ -616,9 +637,8 @@ __host__ __device__ inline void poa4_traceback(const Poa4Args A, Poa4LdsTb& S, u
 #pragma unroll
         for (int h = 0; h < kTbG; ++h) {
           uint4* dst = S.row[q][16 * h + gl];
-          dst[0] = uint4{na[h].x, na[h].y, nb[h].x, nb[h].y};
-          dst[1] = uint4{nc[h].x, nc[h].y, 0u, 0u};
-          dst[2] = uint4{nd0[h], nd1[h], nd7[h], 0u};
+          dst[0] = poa4_align_codes(na[h].x, na[h].y, nb[h].x, nb[h].y, nc[h].x, nc[h].y, nd0[h] & 0xFFFFu, (nd1[h] >> 16) & 0x3FFu);
+          dst[1] = uint4{nd0[h], nd1[h], nd7[h], 0u};
         }
         c_rnd = rnd;
         if (rnd >= 1) {
@@ -655,14 +675,14 @@ __host__ __device__ inline void poa4_traceback(const Poa4Args A, Poa4LdsTb& S, u
     while (sv::any(in_round)) {
       P4_MARK("tb_step_begin");
       const u32 l = (i - 1) & (16 * kTbG - 1);
-      const uint4 d = S.row[q][l][2];
+      const uint4 d = S.row[q][l][1];
       const i32 bt = static_cast<i32>((d.y >> 16) & 0x3FFu);
       const u32 node = d.y & 0xFFFFu;
       const i32 idx = j - bt;
       const bool oob = static_cast<u32>(idx) >= static_cast<u32>(K::kBand);  // the path left the stored band
-      const u32 cidx = static_cast<u32>(idx) & static_cast<u32>(K::kBand - 1);
-      const u32 bo = ((d.x & 0xFFFFu) % K::kU) + (cidx >> 1);  // byte among the row's 24: one step = two columns = one byte
-      const u32 code = (static_cast<u32>(reinterpret_cast<const u8*>(S.row[q][l])[bo]) >> (4u * (cidx & 1u))) & 15u;
+      // (the code of column j: byte (j >> 1) & 15 of the row, whatever its band start — read beside the record)
+      const u32 code = (static_cast<u32>(reinterpret_cast<const u8*>(S.row[q][l])[(static_cast<u32>(j) >> 1) & 15u]) >>
+                        (4u * (static_cast<u32>(j) & 1u))) & 15u;
       const bool edge_hit = (idx < 2 && bt > 0) || (idx > K::kBand - 3 && bt + K::kBand < static_cast<i32>(w));
       const bool isH = code == 0u;  // (0: horizontal; else diagonal << 3 | 7 - in-edge)
       const bool diag = (code & 8u) != 0;
@@ -1367,6 +1387,7 @@ __host__ __device__ __forceinline__ u32 poa4_position(const Poa4Ctx& C, u32 wave
 // phase 0: graph of the backbone, state record
 __host__ __device__ inline void poa4_phase_init(const Poa4Args& A, const Poa4Ctx& C, u32 wave) {
   const int lane = sv::lane();
+  const unsigned long long t_init0 = sv::clock();
   for (int q2 = 0; q2 < P4::G; ++q2) {
     const u32 rec = poa4_my_record(C, wave, q2);
     if (rec == 0xFFFFFFFFu) continue;
@@ -1388,6 +1409,7 @@ __host__ __device__ inline void poa4_phase_init(const Poa4Args& A, const Poa4Ctx
       C.st[rec] = w;
     }
   }
+  if (A.phase_cycles && lane == 0) sv::atomic_add(&A.phase_cycles[15], sv::clock() - t_init0);
 }
 
 // spoa Graph::Subgraph as marks, for one window by one wave: the ancestors (through in-edges and aligned nodes) of
@@ -1627,6 +1649,7 @@ __host__ __device__ inline void poa4_phase_desc_onewave(const Poa4Args& A, const
   const Poa2Slot& g = sl.g;
   const Poa4Win me = C.st[rec];
   if (me.phase != kRunning || !me.act) return;
+  const unsigned long long t_desc0 = sv::clock();
   const u32 nn = me.nn;
   const bool full = me.full != 0;
   const u32 len = me.len, r_lo = me.r_lo, n_rows = me.n_rows, r_hi = r_lo + n_rows;
@@ -1801,6 +1824,7 @@ __host__ __device__ inline void poa4_phase_desc_onewave(const Poa4Args& A, const
     w.cells_full += marked_rows * len;
     w.cells_band += marked_rows * (len + 1 < 32u ? len + 1 : 32u);
   }
+  if (A.phase_cycles && lane == 0) sv::atomic_add(&A.phase_cycles[10], sv::clock() - t_desc0);
 }
 
 // phase B: the NW

@@ -53,6 +53,7 @@ for l in sys.stdin:
 import json; d = json.load(open('gpurun_out/${TAG}_poa_parity_$arg.json')); print({k: v for k, v in d.items() if k not in ('examples', 'not_explained')}, 'unexplained', len(d['not_explained']))";;
     profile) bash tools/profile_round.sh $arg;;
     sqpoa) bash tools/prof_poa.sh $arg;;
+    mempoa) bash tools/prof_poa_mem.sh $arg;;
     tracenw) bash tools/trace_nw.sh $arg;;
     sqnw) bash tools/prof_nw.sh $arg;;
     *) echo "unknown step $step";;
