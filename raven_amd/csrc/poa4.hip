@@ -66,26 +66,30 @@ constexpr i32 kNegKey = kNegInf16 * 16;
 constexpr i32 kNegU = -0x30000000;
 constexpr u32 kInactiveS = 0x7FFFu;
 
-template <int kRingBytes>
-struct alignas(16) Poa4GroupT {
-  union {
-    u32 ring32[kRingBytes / 4];  // DP: [kRing][2 pads | 32 cells | kMaxD + 2 pads] int16, slot = rho % kRing; graph update: the
-                                 // new nodes' order slots (u16)
-    u8 bytes[kPoa2MaxSeq + 16];  // layer set-up: one-byte codes before they are packed
-    u32 segtab[32];              // pre-pass: the layer's band guide, {x0, wa, wb - wa, magic(x1 - x0)} per segment
-  } u;
-  u32 seq2[60];  // the layer, 2 bits per base, position p at bits 2 (p + 1): column j's base sits at bit 2 j
-  u32 dump[16];  // where rows outside the layer's subgraph leave their cells
+// LDS of the NW.  The score rings of the two windows of a HALF-WAVE (lanes 0-31: q = 0, 1; lanes 32-63: q = 2, 3) are
+// interleaved word by word — word w of window q's ring at pair base + (2 w + (q & 1)) * 4: a ds_read_b32 serves a half-wave
+// per LDS cycle over 32 banks, window q = even touches even banks only, its partner odd ones, and inside a window the 16
+// lanes (ring slot + 1, column pair - 1 from lane to lane = 2 * 21 interleaved words = bank + 10 mod 32) hit 16 different
+// banks of their parity: the regular part of a step (in-edge 0 = the row before, the own row's store) cannot collide.
+// (Measured against four rings side by side: the POA bench 94 -> 92 ms, the C4 round within noise, and the kernel-wide
+// conflict ratio 42 -> 48 % of the LDS cycles — fewer cycles, a larger share of them conflicts: what collides is the
+// irregular half of the reads, in-edges 1..3 of other ring slots and the -inf words of rows that have no such in-edge.)
+// A ring row = kRowW words: 1 of -inf | 16 of cells (32 int16) | kMaxD / 2 + 1 of -inf; slot = rho % kRing.
+constexpr int kRowW4 = P4::kRowB / 4;
+struct alignas(16) Poa4Lds {
+  u32 ring[2][2 * P4::kRing * kRowW4];
+  u32 dump[P4::G][32];  // where rows outside the layer's subgraph leave their cells (step k at word 2 k)
+  u32 neg[40];          // -inf cells: what a descriptor's unused in-edges point at (window parity p: words p, p + 2, ..)
 };
-template <int kRingBytes>
-struct alignas(16) Poa4LdsT {
-  Poa4GroupT<kRingBytes> g[P4::G];
-  u32 neg[20];  // -inf cells: what a descriptor's unused in-edges point at
-};
-// (the phases of the kernel share the wave's LDS as a union: the NW the score ring, the graph update room for 896 order
+// byte offsets from the start of Poa4Lds (what a row descriptor holds)
+__host__ __device__ __forceinline__ u32 poa4_ring_byte(int q, u32 w) {
+  return static_cast<u32>(offsetof(Poa4Lds, ring)) + static_cast<u32>(q >> 1) * static_cast<u32>(sizeof(u32) * 2 * P4::kRing * kRowW4) +
+         (2u * w + static_cast<u32>(q & 1)) * 4u;
+}
+__host__ __device__ __forceinline__ u32 poa4_dump_byte(int q) { return static_cast<u32>(offsetof(Poa4Lds, dump)) + static_cast<u32>(q) * 128u; }
+__host__ __device__ __forceinline__ u32 poa4_neg_byte(int q) { return static_cast<u32>(offsetof(Poa4Lds, neg)) + static_cast<u32>(q & 1) * 4u; }
+// (the phases of the kernel share the wave's LDS as a union: the NW the score rings, the graph update room for 896 order
 // slots, the set-up + descriptor pass the layer's bytes, the traceback its staged rows)
-using Poa4Group = Poa4GroupT<P4::kRing * P4::kRowB>;
-using Poa4Lds = Poa4LdsT<P4::kRing * P4::kRowB>;
 static_assert(sizeof(Poa4Lds) <= 10240, "sixteen waves per CU need <= 10 KB of LDS each");
 static_assert(P4::kRowB == 68 + 2 * (P4::kMaxD + 2), "ring row = 2 pads + 32 cells + kMaxD + 2 pads");
 
@@ -335,16 +339,15 @@ __host__ __device__ inline void poa4_dp(const Poa4Args A, Poa4Lds& S, unsigned c
   const int lane = sv::lane();
   const int gl = lane & 15, q = lane >> 4;
   const Poa4Slot sl = poa4_carve(slot_mem, A.nmax, A.lmax);
-  const u32 ring_off = static_cast<u32>(offsetof(Poa4Lds, g)) + static_cast<u32>(q) * static_cast<u32>(sizeof(Poa4Group));
   // -inf pads of the ring rows (the union is reused by the layer set-up and by the traceback), the wave's -inf cells
   {
     const u32 neg = pack16(kNegInf16, kNegInf16);
     constexpr int kPadW = 1 + (K::kRowB - 68) / 4;  // words of -inf per ring row: one in front, the rest behind the cells
     for (int idx = gl; idx < K::kRing * kPadW; idx += 16) {
       const int rr = idx / kPadW, cc = idx % kPadW;
-      lds_st32(S, ring_off + static_cast<u32>(rr * K::kRowB + (cc == 0 ? 0 : 64 + 4 * cc)), neg);
+      lds_st32(S, poa4_ring_byte(q, static_cast<u32>(rr * kRowW4 + (cc == 0 ? 0 : 16 + cc))), neg);
     }
-    if (lane < 20) S.neg[lane] = neg;
+    if (lane < 40) S.neg[lane] = neg;
   }
   lds_order();
   const i32 mD = A.m * 16 + 8, xD = A.n_ * 16 + 8, g64 = A.gp * 16;  // keys = score * 16 + tag; the diagonal's tag bit rides on the score term
@@ -357,7 +360,7 @@ __host__ __device__ inline void poa4_dp(const Poa4Args A, Poa4Lds& S, unsigned c
   u32 cur_rho = static_cast<u32>(gl);
   {
     const uint4 a = sl.desc[2 * static_cast<size_t>(cur_rho)], b = sl.desc[2 * static_cast<size_t>(cur_rho) + 1];
-    const u32 neg_off = static_cast<u32>(offsetof(Poa4Lds, neg));
+    const u32 neg_off = poa4_neg_byte(q);
     const u32 neg2 = neg_off | (neg_off << 16);
     c0 = act ? (a.x | 0u) : (kInactiveS | (neg_off << 16));  // (a group without a layer in this round has no descriptors: it idles on -inf cells)
     c1 = act ? a.y : 0u;
@@ -411,15 +414,10 @@ __host__ __device__ inline void poa4_dp(const Poa4Args A, Poa4Lds& S, unsigned c
       const u32 t = t0 + static_cast<u32>(u);
       i32 k = static_cast<i32>(t) - static_cast<i32>(c0 & 0xFFFFu);
       if (k == 16) {  // the row is finished: its end-node score, then the next row
-#if !defined(__HIP_DEVICE_COMPILE__)
-        if (knob("RVN_POA4_DEBUG2"))
-          std::fprintf(stderr, "[poa4] lane %d t %u finished rho %u c0 %08x c1 %08x b %u end %u np %u H[0..3] %d %d %d %d\n", lane, t, cur_rho, c0, c1, (c1 >> 16) & 0x3FFu, c1 >> 31, (c1 >> 26) & 15,
-                       lds_ld16(S, (c0 >> 16)), lds_ld16(S, (c0 >> 16) + 2), lds_ld16(S, (c0 >> 16) + 4), lds_ld16(S, (c0 >> 16) + 6));
-#endif
         if (c1 >> 31) {
           const i32 idx = static_cast<i32>(len) - static_cast<i32>((c1 >> 16) & 0x3FFu);
           if (idx >= 0 && idx < K::kBand) {
-            const i32 sce = lds_ld16(S, (c0 >> 16) + 2u * static_cast<u32>(idx));
+            const i32 sce = lds_ld16(S, (c0 >> 16) + 8u * (static_cast<u32>(idx) >> 1) + 2u * (static_cast<u32>(idx) & 1u));
             const u32 cand = ((c1 & 0xFFFFu) << 16) | (cur_rho + 1);  // node id | 1 + row: equal scores -> smallest node id
             if (sce > best_score || (sce == best_score && cand < best_row)) {
               best_score = sce;
@@ -442,7 +440,7 @@ __host__ __device__ inline void poa4_dp(const Poa4Args A, Poa4Lds& S, unsigned c
       }
       i32 kk = k + 1;
       kk = kk < 0 ? 0 : (kk > 16 ? 16 : kk);
-      const u32 off4 = static_cast<u32>(kk) << 2;
+      const u32 off4 = static_cast<u32>(kk) << 3;  // (interleaved rings: a column pair is 8 bytes on)
       const u32 np = (c1 >> 26) & 15u;
       // ---- in-edges: one aligned pair of predecessor cells each (columns j, j + 1 of this step) ----
       u32 wd = lds_ld32(S, add_half<false>(off4, ce0));
@@ -454,7 +452,9 @@ __host__ __device__ inline void poa4_dp(const Poa4Args A, Poa4Lds& S, unsigned c
         wd = np == 0 ? vp : wd;
       }
       // (a row's unused in-edges point at -inf cells: in-edges 1..3 are read whether the row has them or not, so the
-      // four reads are in flight together; 99 % of the rows have at most four)
+      // four reads are in flight together; 99 % of the rows have at most four.  Issuing them under the exec mask of the lanes
+      // that have the in-edge — 39 % / 17 % of the lanes — was measured: LDS cycles -16 %, bank conflicts -32 %, but +5 %
+      // VALU and +10 % SALU instructions for the masks, and the stage 1 - 6 % slower)
       const u32 w1 = lds_ld32(S, add_half<true>(off4, ce0));
       const u32 w2 = lds_ld32(S, add_half<false>(off4, ce1));
       const u32 w3 = lds_ld32(S, add_half<true>(off4, ce1));
@@ -493,7 +493,7 @@ __host__ __device__ inline void poa4_dp(const Poa4Args A, Poa4Lds& S, unsigned c
       const i32 h1 = U0 + gp, s1 = b1 >> 4;
       const i32 U1 = imax(s1, h1);
       const u32 code1 = h1 > s1 ? 0u : (static_cast<u32>(b1) & 15u);
-      if (static_cast<u32>(k) < 16u) lds_st32(S, add_half<true>(static_cast<u32>(k) << 2, c0), clamp_pair(pack16(U0, U1)));
+      if (static_cast<u32>(k) < 16u) lds_st32(S, add_half<true>(static_cast<u32>(k) << 3, c0), clamp_pair(pack16(U0, U1)));
       u32 cp = code0 | (code1 << 4);
 #if defined(__HIP_DEVICE_COMPILE__)
       asm volatile("" : "+v"(cp));  // computed here: sunk to the store it would keep three registers per step alive
@@ -516,7 +516,7 @@ __host__ __device__ inline void poa4_dp(const Poa4Args A, Poa4Lds& S, unsigned c
     if (act && k >= 16 && (c1 >> 31)) {
       const i32 idx = static_cast<i32>(len) - static_cast<i32>((c1 >> 16) & 0x3FFu);
       if (idx >= 0 && idx < K::kBand) {
-        const i32 sce = lds_ld16(S, (c0 >> 16) + 2u * static_cast<u32>(idx));
+        const i32 sce = lds_ld16(S, (c0 >> 16) + 8u * (static_cast<u32>(idx) >> 1) + 2u * (static_cast<u32>(idx) & 1u));
         const u32 cand = ((c1 & 0xFFFFu) << 16) | (cur_rho + 1);
         if (sce > best_score || (sce == best_score && cand < best_row)) {
           best_score = sce;
@@ -1655,9 +1655,8 @@ __host__ __device__ inline void poa4_phase_desc_onewave(const Poa4Args& A, const
   const u32 len = me.len, r_lo = me.r_lo, n_rows = me.n_rows, r_hi = r_lo + n_rows;
   const i32 lb = static_cast<i32>(me.lb), span = static_cast<i32>(me.span), b_first = static_cast<i32>(me.b_first);
   const u32 span_magic = magic_of(static_cast<u32>(span > 0 ? span : 1));
-  const u32 ring_off = static_cast<u32>(offsetof(Poa4Lds, g)) + static_cast<u32>(q) * static_cast<u32>(sizeof(Poa4Group));
-  const u32 dump_off = ring_off + static_cast<u32>(offsetof(Poa4Group, dump));
-  const u32 neg_off = static_cast<u32>(offsetof(Poa4Lds, neg));
+  const u32 dump_off = poa4_dump_byte(q);
+  const u32 neg_off = poa4_neg_byte(q);
   const u32 neg2 = neg_off | (neg_off << 16);
   u32 flag = 0, marked_rows = 0;
   i32 t_end = 0;
@@ -1748,7 +1747,8 @@ __host__ __device__ inline void poa4_phase_desc_onewave(const Poa4Args& A, const
         if (lbk < 1 || lbk > static_cast<u32>(K::kRing - 1) || lbk > rho || d < 0 || d > K::kMaxD) {
           flag = 7;
         } else if (np < static_cast<u32>(K::kEdges)) {
-          const u32 e = ring_off + ((rho - lbk) % static_cast<u32>(K::kRing)) * static_cast<u32>(K::kRowB) + 2u * static_cast<u32>(d);
+          // (band starts are even: d / 2 whole column pairs)
+          const u32 e = poa4_ring_byte(q, ((rho - lbk) % static_cast<u32>(K::kRing)) * static_cast<u32>(kRowW4) + (static_cast<u32>(d) >> 1));
           const u32 idx = np >> 1;
           const u32 keep = (np & 1) ? 0x0000FFFFu : 0xFFFF0000u;
           const u32 put = (np & 1) ? e << 16 : e;
@@ -1790,7 +1790,7 @@ __host__ __device__ inline void poa4_phase_desc_onewave(const Poa4Args& A, const
           sdiff = 0;
         }
         const u32 Srow = rho + (rho >> 4) + (static_cast<u32>(sdiff) >> 1) + 1u;
-        const u32 own = marked[u] ? ring_off + (rho % static_cast<u32>(K::kRing)) * static_cast<u32>(K::kRowB) + 4u : dump_off;
+        const u32 own = marked[u] ? poa4_ring_byte(q, (rho % static_cast<u32>(K::kRing)) * static_cast<u32>(kRowW4) + 1u) : dump_off;
         const bool endn = marked[u] && (full ? outc_f[u] : outc_s[u]) == 0;
         uint4 da, db;
         da.x = Srow | (own << 16);
