@@ -1,6 +1,6 @@
 """Input path alone on the GPU box: rvn_reads_load of a synthetic FASTQ (N(15 kb, 3 kb) reads, Phred-10 qualities) as
 blocked gzip, as one gzip member and as plain text; every file twice (the second load finds the page-locked slabs of
-the first).  python tools/bench_io.py [Mbase] ; RVN_IO_THREADS / RVN_IO_SLAB_MB / RVN_IO_RING tune the pool."""
+the first).  python tools/bench_io.py [Mbase] [io_threads=N] [io_slab_mb=N] [io_ring=N] [io_zlib=1]  (engine options, include/raven_hip.h)"""
 import gzip
 import json
 import os
@@ -15,7 +15,9 @@ from raven_amd import hip, seqio  # noqa: E402
 
 
 def main():
-    mbase = int(sys.argv[1]) if len(sys.argv) > 1 else 150
+    args = [a for a in sys.argv[1:] if "=" not in a]
+    opts = dict(a.split("=") for a in sys.argv[1:] if "=" in a)
+    mbase = int(args[0]) if args else 150
     rng = np.random.default_rng(1)
     lut = np.frombuffer(b"ACGT", dtype=np.uint8)
     recs, tot = [], 0
@@ -28,7 +30,9 @@ def main():
     del recs
     tmpd = tempfile.mkdtemp(prefix="rvn_io_")
     eng = hip.Engine(15, 5)
-    out = {"cpu_count": os.cpu_count(), "bases": tot, "reads": n_reads, "text_bytes": len(text)}
+    for name, value in opts.items():
+        eng.set_option(name, int(value))
+    out = {"cpu_count": os.cpu_count(), "bases": tot, "reads": n_reads, "text_bytes": len(text), "options": opts}
     for tag, make in (("bgzf", lambda: seqio.bgzf_compress(text, 1)), ("single_member", lambda: gzip.compress(text, 1)),
                       ("plain", lambda: text)):
         path = os.path.join(tmpd, "reads_%s.fastq%s" % (tag, "" if tag == "plain" else ".gz"))
