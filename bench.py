@@ -518,36 +518,44 @@ def main():
                         kernels[name]["overlaps_other_sites"] = True
             # dominant kernel of the WHOLE step: the banded POA kernel (integer VALU bound)
             dom = next(iter(kernels), None)
-            if "poa_banded" in kms and kms["poa_banded"][1] and poa_cells["cells_full"] and legs["poa_rounds"]:
-                # The window-consensus stage of a polishing round = ONE launch of poa4.hip's persistent kernel + the poa2.hip
-                # launch for what the 32-column band hands on: priced per polishing round against the stage's device time
-                # (HIP events around the whole batch on the engine's stream, the stream both kernels run on).
-                ms, la = kms["poa_banded"]
-                cells = poa_cells["cells_full"] / max(poa_cells["calls"], 1) * 1.0  # per polishing round (one launch set)
-                launches_per_round = 1.0
-                avg_s = legs["poa_ms"] / legs["poa_rounds"] / 1e3
-                ms = legs["poa_ms"]
+            site = "poa_rows" if kms.get("poa_rows", (0, 0))[1] else "poa_banded"
+            if site in kms and kms[site][1] and poa_cells["cells_full"] and legs["poa_rounds"]:
+                # The window-consensus stage of a polishing round = ONE launch of poa4.hip's persistent kernel (site
+                # "poa_rows") + the poa2.hip launch(es) for the windows it hands on (site "poa_banded").  The roofline is the
+                # dominant KERNEL's: algorithmic cells of a round / the average duration of the persistent kernel's launch
+                # (HIP events around that launch on the engine's stream: the figure rocprofv3's kernel statistics must agree
+                # with); the whole stage (events around the batch, poa2 included) is priced beside it.
+                ms_k, la_k = kms[site]
+                cells = poa_cells["cells_full"] / max(poa_cells["calls"], 1) * 1.0  # per polishing round
+                kern_s = ms_k / la_k / 1e3 if site == "poa_rows" else legs["poa_ms"] / legs["poa_rounds"] / 1e3
+                stage_s = legs["poa_ms"] / legs["poa_rounds"] / 1e3
                 cells_per_launch = cells
-                achieved_tops = cells_per_launch * POA_MIN_OPS_PER_CELL / avg_s / 1e12
-                roofline_poa = {"bound": "valu", "kernel": "poa_banded",
+                achieved_tops = cells_per_launch * POA_MIN_OPS_PER_CELL / kern_s / 1e12
+                banded = poa_cells["cells_banded"] / max(poa_cells["calls"], 1)
+                pmc_site = "poa4_persistent" if site == "poa_rows" else "poa_banded"
+                roofline_poa = {"bound": "valu", "kernel": "poa4_persistent_kernel" if site == "poa_rows" else "poa_banded",
                             "achieved": round(achieved_tops, 3), "peak": round(VALU_PEAK_LANE_OPS / 1e12, 1),
                             "unit": "T lane-ops/s", "frac": round(achieved_tops * 1e12 / VALU_PEAK_LANE_OPS, 4),
-                            "traffic": pmc_traffic("poa_banded"), "traffic_raw": pmc_traffic_raw("poa_banded"),
+                            "traffic": pmc_traffic(pmc_site), "traffic_raw": pmc_traffic_raw(pmc_site),
                             "algorithmic_cells_per_launch": int(cells_per_launch),
                             "algorithmic_ops_per_cell": POA_MIN_OPS_PER_CELL,
-                            "gcups_algorithmic": round(cells_per_launch / avg_s / 1e9, 1),
-                            "gcups_banded_computed": round(poa_cells["cells_banded"] / max(poa_cells["calls"], 1) /
-                                                           launches_per_round / avg_s / 1e9, 1),
-                            "frac_on_computed_cells": round(poa_cells["cells_banded"] / max(poa_cells["calls"], 1) *
-                                                            POA_MIN_OPS_PER_CELL / avg_s / VALU_PEAK_LANE_OPS, 4),
-                            "avg_launch_ms": round(avg_s * 1e3, 3),
-                            "kernel_launches_per_round": kms["poa_banded"][1] / max(poa_cells["calls"], 1),
-                            "stage_share_of_step": round(legs["poa_ms"] / (dt * 1e3), 3),
+                            "gcups_algorithmic": round(cells_per_launch / kern_s / 1e9, 1),
+                            "gcups_banded_computed": round(banded / kern_s / 1e9, 1),
+                            "frac_on_computed_cells": round(banded * POA_MIN_OPS_PER_CELL / kern_s / VALU_PEAK_LANE_OPS, 4),
+                            "avg_launch_ms": round(kern_s * 1e3, 3),
+                            "launches_per_round": la_k / max(poa_cells["calls"], 1),
+                            "stage": {"ms_per_round": round(stage_s * 1e3, 3),
+                                      "frac": round(cells * POA_MIN_OPS_PER_CELL / stage_s / VALU_PEAK_LANE_OPS, 4),
+                                      "traffic": pmc_traffic("poa_banded"), "traffic_raw": pmc_traffic_raw("poa_banded"),
+                                      "handed_on_kernel_launches_per_round": kms.get("poa_banded", (0, 0))[1] / max(poa_cells["calls"], 1),
+                                      "share_of_step": round(legs["poa_ms"] / (dt * 1e3), 3)},
                             "note": "algorithmic cells = graph rows x layer length of every layer alignment (what "
                                     "spoa's full NW computes); the first attempt computes a 32-column band of them "
-                                    "(poa4.hip: one persistent kernel), what it hands on a 64-column band (poa2.hip).  One "
-                                    "'launch' = the stage of one polishing round, timed by HIP events around the whole batch."}
-            if dom == "poa_banded" or legs["poa_ms"] > 0.4 * dt * 1e3:
+                                    "(poa4.hip: one persistent kernel per polishing round = the launch priced here), what it "
+                                    "hands on a 64-column band (poa2.hip: in 'stage').  avg_launch_ms = HIP events around the "
+                                    "kernel's launch; rocprofv3's average for poa4_persistent_kernel is in "
+                                    "profiles/r05_kernel_stats.csv."}
+            if dom in ("poa_banded", "poa_rows") or legs["poa_ms"] > 0.4 * dt * 1e3:
                 roofline = roofline_poa
             if "nw_forward" in kms and kms["nw_forward"][1] and last.get("polish", {}).get("align_band_cells"):
                 # the alignment-path sweep (Myers bit-vector band, racon's edlib NW): integer VALU bound as well.  A round

@@ -176,7 +176,7 @@ enum KernelSite {
   kKSketchCount, kKSketchWrite, kKMinhashSelect, kKCompactSketch, kKScan, kKRsBits, kKRsUpsweep, kKRsDownsweep,
   kKHeads, kKUnique, kKTable, kKOccHist, kKMatchCount, kKMatchEmit, kKSegSortGroup, kKIntervals,
   kKIntervalsGather, kKSegSortPos, kKChain, kKCompactOverlaps, kKPileKeys, kKPileCounts, kKPileBuild,
-  kKAddLayers, kKTruncateSort, kKKeptWrite, kKGather, kKPileSortUp, kKPileSortDown, kKChainSmall, kKJoinCount, kKJoinEmit, kKEditBanded, kKEditFull, kKPoa, kKAddKmers, kKPoaBanded, kKPileTrim, kKNwForward, kKNwTraceback, kKEditLane, kKNwLane, kKBestOverlap, kKLayerBuild, kKStitch, kKNumSites
+  kKAddLayers, kKTruncateSort, kKKeptWrite, kKGather, kKPileSortUp, kKPileSortDown, kKChainSmall, kKJoinCount, kKJoinEmit, kKEditBanded, kKEditFull, kKPoa, kKAddKmers, kKPoaBanded, kKPileTrim, kKNwForward, kKNwTraceback, kKEditLane, kKNwLane, kKBestOverlap, kKLayerBuild, kKStitch, kKPoaRows, kKNumSites
 };
 extern const char* const kKernelSiteNames[kKNumSites];
 

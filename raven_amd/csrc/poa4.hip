@@ -2124,7 +2124,7 @@ void poa_v4_launch(Engine& e, const PoaBatchDev& b) {
   const Poa4Ctx C{d_st, 0, b.n_windows, 0};
   // (two sequence positions per lane and turn of the graph update: the kernel's 128 registers hold it without the spills the
   // four-position variant brings — 739 against 829 ms per C4 round)
-  RVN_KLAUNCH_ON(kKPoaBanded, s, (poa4_persistent_kernel<kUpdPer><<<n_waves, 64, 0, s>>>(A, C)));
+  RVN_KLAUNCH_ON(kKPoaRows, s, (poa4_persistent_kernel<kUpdPer><<<n_waves, 64, 0, s>>>(A, C)));
 }
 
 #ifdef RVN_TEST_HOOKS

@@ -139,7 +139,7 @@ const char* const kKernelSiteNames[kKNumSites] = {
     "sketch_count", "sketch_write", "minhash_select", "compact_sketch", "scan", "rs_bits", "rs_upsweep",
     "rs_downsweep", "heads", "unique", "table", "occ_hist", "match_count", "match_emit", "seg_sort_group",
     "intervals", "intervals_gather", "seg_sort_pos", "chain", "compact_overlaps", "pile_keys", "pile_counts",
-    "pile_build", "add_layers", "truncate_sort", "kept_write", "gather", "pile_sort_up", "pile_sort_down", "chain_small", "join_count", "join_emit", "edit_banded", "edit_full", "poa", "add_kmers", "poa_banded", "pile_trim", "nw_forward", "nw_traceback", "edit_lane", "nw_lane", "best_overlap", "layer_build", "stitch"};
+    "pile_build", "add_layers", "truncate_sort", "kept_write", "gather", "pile_sort_up", "pile_sort_down", "chain_small", "join_count", "join_emit", "edit_banded", "edit_full", "poa", "add_kmers", "poa_banded", "pile_trim", "nw_forward", "nw_traceback", "edit_lane", "nw_lane", "best_overlap", "layer_build", "stitch", "poa_rows"};
 
 thread_local KernelTimers* g_kernel_timers = nullptr;
 
