@@ -55,8 +55,8 @@ struct P4 {
                                       // window to poa2: none in 9 220 layers of 300 C4-like windows, the longest was 17.  19 rows =
                                       // 8 KB of LDS = five waves per SIMD at 96 registers was measured: 844 instead of 737 ms per C4
                                       // round — the stage does not want more waves)
-  static constexpr int kRowB = 88;    // bytes per ring row: 2 -inf cells | 32 cells | 10 -inf cells
-  static constexpr int kMaxD = 8;     // largest band-start difference along an in-edge (the right pads cover it)
+  static constexpr int kRowB = 64;    // bytes per ring row: the 32 cells of the row's band, addressed by the COLUMN (below)
+  static constexpr int kMaxD = 8;     // largest band-start difference along an in-edge (a larger one sends the window to poa2)
   static constexpr int kEdges = 8;    // in-edges a row descriptor holds; a row with more sends the window to poa2 (4-bit backpointers:
                                       // 8 diagonal + 7 vertical codes + 0 = horizontal or vertical through in-edge 7, see above)
   static constexpr int kU = 8;        // steps between two service points (descriptor prefetch, backpointer store)
@@ -66,19 +66,26 @@ constexpr i32 kNegKey = kNegInf16 * 16;
 constexpr i32 kNegU = -0x30000000;
 constexpr u32 kInactiveS = 0x7FFFu;
 
-// LDS of the NW.  The score rings of the two windows of a HALF-WAVE (lanes 0-31: q = 0, 1; lanes 32-63: q = 2, 3) are
-// interleaved word by word — word w of window q's ring at pair base + (2 w + (q & 1)) * 4: a ds_read_b32 serves a half-wave
-// per LDS cycle over 32 banks, window q = even touches even banks only, its partner odd ones, and inside a window the 16
-// lanes (ring slot + 1, column pair - 1 from lane to lane = 2 * 21 interleaved words = bank + 10 mod 32) hit 16 different
-// banks of their parity: the regular part of a step (in-edge 0 = the row before, the own row's store) cannot collide.
-// (Measured against four rings side by side: the POA bench 94 -> 92 ms, the C4 round within noise, and the kernel-wide
-// conflict ratio 42 -> 48 % of the LDS cycles — fewer cycles, a larger share of them conflicts: what collides is the
-// irregular half of the reads, in-edges 1..3 of other ring slots and the -inf words of rows that have no such in-edge.)
-// A ring row = kRowW words: 1 of -inf | 16 of cells (32 int16) | kMaxD / 2 + 1 of -inf; slot = rho % kRing.
+// LDS of the NW.  A ring row holds the 32 cells of its row's band as 16 words, and the word of column pair p = j / 2 is
+// p mod 16 WHATEVER the row's band start (a band is 16 pairs wide: every pair of it has a word of its own).  The score rings
+// of the two windows of a HALF-WAVE (lanes 0-31: q = 0, 1; lanes 32-63: q = 2, 3) are interleaved word by word — word w of
+// window q's ring at pair base + (2 w + (q & 1)) * 4.  A ds_read_b32 serves a half-wave per LDS cycle over 32 banks; the bank
+// of an access is 2 (p mod 16) + (q & 1), whichever ring slot it goes to: at one step the 16 lanes of a window are at 16
+// consecutive column pairs (lane to lane: one row on, one pair back), so in-edge reads of any slot, the -inf words of the
+// in-edges a row does not have (same addressing) and the own row's store fall into 16 different banks of the window's
+// parity.  (Round 4 / early round 5 addressed a row from its band start, pads of -inf either side: the lane-to-lane bank
+// step was 10 or 8 with the drift of the band along the rows, and 48 % of the kernel's LDS cycles were bank conflicts.)
+// What the pads were for — a predecessor's band ending left of the column asked for, or beginning at it — now reads
+// another cell of the predecessor's row instead of -inf.  That is harmless by construction: such a candidate can only
+// RAISE a cell, every cell the traceback walks is checked to lie inside its row's band (a move through such a candidate
+// lands outside and sends the window to the 64-column kernel, as any band miss), and a walk that never leaves the bands has
+// met only true values — so its score is both an upper and a lower bound of the banded optimum and its moves are the true
+// maxima's.  The ring starts every layer as -inf so that what a first column finds left of a predecessor's
+// band is low, not stale.  slot = rho % kRing.
 constexpr int kRowW4 = P4::kRowB / 4;
 struct alignas(16) Poa4Lds {
   u32 ring[2][2 * P4::kRing * kRowW4];
-  u32 dump[P4::G][32];  // where rows outside the layer's subgraph leave their cells (step k at word 2 k)
+  u32 dump[2][64];      // where rows outside the layer's subgraph leave their cells (interleaved like the rings)
   u32 neg[40];          // -inf cells: what a descriptor's unused in-edges point at (window parity p: words p, p + 2, ..)
 };
 // byte offsets from the start of Poa4Lds (what a row descriptor holds)
@@ -86,12 +93,14 @@ __host__ __device__ __forceinline__ u32 poa4_ring_byte(int q, u32 w) {
   return static_cast<u32>(offsetof(Poa4Lds, ring)) + static_cast<u32>(q >> 1) * static_cast<u32>(sizeof(u32) * 2 * P4::kRing * kRowW4) +
          (2u * w + static_cast<u32>(q & 1)) * 4u;
 }
-__host__ __device__ __forceinline__ u32 poa4_dump_byte(int q) { return static_cast<u32>(offsetof(Poa4Lds, dump)) + static_cast<u32>(q) * 128u; }
+__host__ __device__ __forceinline__ u32 poa4_dump_byte(int q) {
+  return static_cast<u32>(offsetof(Poa4Lds, dump)) + static_cast<u32>(q >> 1) * 256u + static_cast<u32>(q & 1) * 4u;
+}
 __host__ __device__ __forceinline__ u32 poa4_neg_byte(int q) { return static_cast<u32>(offsetof(Poa4Lds, neg)) + static_cast<u32>(q & 1) * 4u; }
 // (the phases of the kernel share the wave's LDS as a union: the NW the score rings, the graph update room for 896 order
 // slots, the set-up + descriptor pass the layer's bytes, the traceback its staged rows)
 static_assert(sizeof(Poa4Lds) <= 10240, "sixteen waves per CU need <= 10 KB of LDS each");
-static_assert(P4::kRowB == 68 + 2 * (P4::kMaxD + 2), "ring row = 2 pads + 32 cells + kMaxD + 2 pads");
+static_assert(P4::kRowB == 2 * P4::kBand, "ring row = the 32 cells of a band");
 
 struct Poa4Args {
   const PoaWindow* windows;
@@ -339,14 +348,10 @@ __host__ __device__ inline void poa4_dp(const Poa4Args A, Poa4Lds& S, unsigned c
   const int lane = sv::lane();
   const int gl = lane & 15, q = lane >> 4;
   const Poa4Slot sl = poa4_carve(slot_mem, A.nmax, A.lmax);
-  // -inf pads of the ring rows (the union is reused by the layer set-up and by the traceback), the wave's -inf cells
+  // the rings start as -inf (the union is reused by the layer set-up and by the traceback), the wave's -inf cells
   {
     const u32 neg = pack16(kNegInf16, kNegInf16);
-    constexpr int kPadW = 1 + (K::kRowB - 68) / 4;  // words of -inf per ring row: one in front, the rest behind the cells
-    for (int idx = gl; idx < K::kRing * kPadW; idx += 16) {
-      const int rr = idx / kPadW, cc = idx % kPadW;
-      lds_st32(S, poa4_ring_byte(q, static_cast<u32>(rr * kRowW4 + (cc == 0 ? 0 : 16 + cc))), neg);
-    }
+    for (int idx = gl; idx < K::kRing * kRowW4; idx += 16) lds_st32(S, poa4_ring_byte(q, static_cast<u32>(idx)), neg);
     if (lane < 40) S.neg[lane] = neg;
   }
   lds_order();
@@ -379,10 +384,17 @@ __host__ __device__ inline void poa4_dp(const Poa4Args A, Poa4Lds& S, unsigned c
     ne3 = act ? b2.z : neg2;
   }
   bool nx_full = true, ld_pending = false, sched_bad = false;
+  u32 cb3 = (c1 >> 14) & 0x78u;  // 8 x (the band start's column pair mod 16): step k is at byte (cb3 + 8 k) & 0x78 of a ring row
   i32 Am1 = kNegKey, U = kNegU;
   i32 best_score = -0x7FFFFFFF;
   u32 best_row = 0;
   const u32 T = static_cast<u32>(sv::wave_max(act ? static_cast<int>(t_end) : 0));
+#if defined(__HIP_DEVICE_COMPILE__)
+  // (a register reloaded from scratch right before the loop is "in flight" for the compiler's wait-count bookkeeping all
+  // through the loop: the row switch below, which uses it, then waits for EVERY outstanding memory operation — the
+  // descriptor prefetch of the same service point included — in every step.  Used here, it is waited for here.)
+  asm volatile("" : "+v"(cur_rho));
+#endif
   for (u32 t0 = 0; t0 < T; t0 += K::kU) {
     // ---- service point: the descriptor fetched 8 steps ago becomes the lane's next row; a lane whose next row is
     // missing fetches it (it is needed 17 steps after the switch that consumed the previous one at the earliest) ----
@@ -417,7 +429,7 @@ __host__ __device__ inline void poa4_dp(const Poa4Args A, Poa4Lds& S, unsigned c
         if (c1 >> 31) {
           const i32 idx = static_cast<i32>(len) - static_cast<i32>((c1 >> 16) & 0x3FFu);
           if (idx >= 0 && idx < K::kBand) {
-            const i32 sce = lds_ld16(S, (c0 >> 16) + 8u * (static_cast<u32>(idx) >> 1) + 2u * (static_cast<u32>(idx) & 1u));
+            const i32 sce = lds_ld16(S, (c0 >> 16) + ((cb3 + 8u * (static_cast<u32>(idx) >> 1)) & 0x78u) + 2u * (static_cast<u32>(idx) & 1u));
             const u32 cand = ((c1 & 0xFFFFu) << 16) | (cur_rho + 1);  // node id | 1 + row: equal scores -> smallest node id
             if (sce > best_score || (sce == best_score && cand < best_row)) {
               best_score = sce;
@@ -432,6 +444,7 @@ __host__ __device__ inline void poa4_dp(const Poa4Args A, Poa4Lds& S, unsigned c
         ce1 = ne1;
         ce2 = ne2;
         ce3 = ne3;
+        cb3 = (c1 >> 14) & 0x78u;
         cur_rho += 16;
         nx_full = false;
         Am1 = kNegKey;
@@ -440,7 +453,9 @@ __host__ __device__ inline void poa4_dp(const Poa4Args A, Poa4Lds& S, unsigned c
       }
       i32 kk = k + 1;
       kk = kk < 0 ? 0 : (kk > 16 ? 16 : kk);
-      const u32 off4 = static_cast<u32>(kk) << 3;  // (interleaved rings: a column pair is 8 bytes on)
+      // the step's column pair (band start / 2 + k; k = -1: the pair left of the band, for the first diagonal) as a byte
+      // offset into ANY ring row (interleaved rings: a pair is 8 bytes on)
+      const u32 off4 = (cb3 + (static_cast<u32>(k) << 3)) & 0x78u;
       const u32 np = (c1 >> 26) & 15u;
       // ---- in-edges: one aligned pair of predecessor cells each (columns j, j + 1 of this step) ----
       u32 wd = lds_ld32(S, add_half<false>(off4, ce0));
@@ -493,7 +508,7 @@ __host__ __device__ inline void poa4_dp(const Poa4Args A, Poa4Lds& S, unsigned c
       const i32 h1 = U0 + gp, s1 = b1 >> 4;
       const i32 U1 = imax(s1, h1);
       const u32 code1 = h1 > s1 ? 0u : (static_cast<u32>(b1) & 15u);
-      if (static_cast<u32>(k) < 16u) lds_st32(S, add_half<true>(static_cast<u32>(k) << 3, c0), clamp_pair(pack16(U0, U1)));
+      if (static_cast<u32>(k) < 16u) lds_st32(S, add_half<true>(off4, c0), clamp_pair(pack16(U0, U1)));
       u32 cp = code0 | (code1 << 4);
 #if defined(__HIP_DEVICE_COMPILE__)
       asm volatile("" : "+v"(cp));  // computed here: sunk to the store it would keep three registers per step alive
@@ -516,7 +531,7 @@ __host__ __device__ inline void poa4_dp(const Poa4Args A, Poa4Lds& S, unsigned c
     if (act && k >= 16 && (c1 >> 31)) {
       const i32 idx = static_cast<i32>(len) - static_cast<i32>((c1 >> 16) & 0x3FFu);
       if (idx >= 0 && idx < K::kBand) {
-        const i32 sce = lds_ld16(S, (c0 >> 16) + 8u * (static_cast<u32>(idx) >> 1) + 2u * (static_cast<u32>(idx) & 1u));
+        const i32 sce = lds_ld16(S, (c0 >> 16) + ((cb3 + 8u * (static_cast<u32>(idx) >> 1)) & 0x78u) + 2u * (static_cast<u32>(idx) & 1u));
         const u32 cand = ((c1 & 0xFFFFu) << 16) | (cur_rho + 1);
         if (sce > best_score || (sce == best_score && cand < best_row)) {
           best_score = sce;
@@ -593,6 +608,7 @@ __host__ __device__ inline void poa4_traceback(const Poa4Args A, Poa4LdsTb& S, u
   bool done = !act || i == 0;
   u32 steps = 0, n_switch = 0;
   unsigned long long t_change = 0;
+  i32 near_lo = 99, near_hi = -1;
   // the next round (descriptors and codes in flight), the round after (descriptors in flight)
   u32 nd0[kTbG] = {}, nd1[kTbG] = {}, nd7[kTbG] = {}, fd0[kTbG] = {}, fd1[kTbG] = {}, fd7[kTbG] = {};
   // (native vectors, not HIP's uint4 class: arrays of the latter stay in scratch memory when passed by reference)
@@ -676,42 +692,40 @@ __host__ __device__ inline void poa4_traceback(const Poa4Args A, Poa4LdsTb& S, u
       P4_MARK("tb_step_begin");
       const u32 l = (i - 1) & (16 * kTbG - 1);
       const uint4 d = S.row[q][l][1];
-      const i32 bt = static_cast<i32>((d.y >> 16) & 0x3FFu);
-      const u32 node = d.y & 0xFFFFu;
-      const i32 idx = j - bt;
-      const bool oob = static_cast<u32>(idx) >= static_cast<u32>(K::kBand);  // the path left the stored band
       // (the code of column j: byte (j >> 1) & 15 of the row, whatever its band start — read beside the record)
       const u32 code = (static_cast<u32>(reinterpret_cast<const u8*>(S.row[q][l])[(static_cast<u32>(j) >> 1) & 15u]) >>
-                        (4u * (static_cast<u32>(j) & 1u))) & 15u;
-      const bool edge_hit = (idx < 2 && bt > 0) || (idx > K::kBand - 3 && bt + K::kBand < static_cast<i32>(w));
-      const bool isH = code == 0u;  // (0: horizontal; else diagonal << 3 | 7 - in-edge)
-      const bool diag = (code & 8u) != 0;
-      const u32 k = 7u - (code & 7u);
-      const u32 np = (d.y >> 26) & 15u;
-      // code 0 in a row of eight in-edges is "horizontal" or "vertical through the eighth": not decidable here
-      const bool ambiguous = isH && np >= 8u;
-      u32 ni = np == 0 ? 0u : i - ((d.z >> (5 * (k < 6 ? k : 0u))) & 31u);
-      if (sv::any(in_round && !oob && !isH && np != 0 && k >= 6)) {  // in-edges 6 and 7 of a row: their ranks come from the graph
-        if (in_round && !oob && !isH && np != 0 && k >= 6)
+                        (4u * (static_cast<u32>(j) & 1u))) & 15u;  // 0: horizontal; else diagonal << 3 | 7 - in-edge
+      const u32 bt = (d.y >> 16) & 0x3FFu, np = (d.y >> 26) & 15u, node = d.y & 0xFFFFu;
+      const u32 idx = static_cast<u32>(j) - bt;
+      const bool oob = idx >= static_cast<u32>(K::kBand);  // the path left the stored band
+      const bool isH = code == 0u;
+      const u32 k = (~code) & 7u;
+      u32 ni = np ? i - ((d.z >> (k < 6 ? 5 * k : 0u)) & 31u) : 0u;
+      bool amb = false;
+      if (sv::any(in_round && np >= 7)) {  // rows of seven or eight in-edges (1 % of the windows have one)
+        // code 0 in a row of eight in-edges is "horizontal" or "vertical through the eighth": not decidable here;
+        // in-edges 6 and 7: their ranks come from the graph
+        amb = isH && np >= 8u;
+        if (in_round && !oob && !isH && k >= 6)
           ni = poa4_nth_pred_rank(poa4_carve(opaque(slot_mem), A.nmax, A.lmax), node, k, full) - r_lo + 1;
       }
-      const bool mv = isH || diag;                  // the step consumes a base of the layer
-      const bool jerr = !oob && mv && j == 0;       // (never on a consistent stream)
-      const bool stop = oob || jerr || ambiguous;
-      if (in_round) {
-        ++steps;
-        if (oob || edge_hit || ambiguous) band_hit = 1;
-        if (jerr) bad = 6;
-        if (diag && !stop && gl == 0) pos_node[j - 1] = static_cast<u16>(node);  // (an insertion leaves pos_node[j] at kNone)
-        j -= (mv && !stop) ? 1 : 0;
-        const bool row_move = !stop && !isH;
-        i = row_move ? ni : i;
-        done = stop || (row_move && ni == 0);  // on the virtual row only insertions remain: pos_node already says kNone
-        in_round = !done && (i - 1) / (16 * kTbG) == c_rnd;
-      }
+      // (a diagonal or horizontal code in column 0 — never on a consistent stream — leaves the band in the next step)
+      const bool ok = in_round && !oob && !amb;
+      if (ok && (code & 8u) && j > 0 && gl == 0) pos_node[j - 1] = static_cast<u16>(node);  // (an insertion leaves pos_node[j] at kNone)
+      // the nearest the path comes to an edge of the band beyond which the matrix goes on (band_hit after the walk)
+      near_lo = imin(near_lo, (ok && bt != 0) ? static_cast<i32>(idx) : 99);
+      near_hi = imax(near_hi, (ok && bt + K::kBand < w) ? static_cast<i32>(idx) : -1);
+      if (in_round && (oob || amb)) band_hit = 1;
+      steps += in_round ? 1u : 0u;
+      j -= ok ? static_cast<i32>(isH ? 1u : (code >> 3)) : 0;
+      const bool row_move = ok && !isH;
+      i = row_move ? ni : i;
+      done = done || (in_round && (!ok || (row_move && ni == 0)));  // on the virtual row only insertions remain
+      in_round = !done && (i - 1) / (16 * kTbG) == c_rnd;
       P4_MARK("tb_step_end");
     }
   }
+  if (near_lo < 2 || near_hi > K::kBand - 3) band_hit = 1;
   if (A.phase_cycles && gl == 0 && act) {
     sv::atomic_add(&A.phase_cycles[11], static_cast<unsigned long long>(steps));
     sv::atomic_add(&A.phase_cycles[12], static_cast<unsigned long long>(n_switch));
@@ -1747,8 +1761,8 @@ __host__ __device__ inline void poa4_phase_desc_onewave(const Poa4Args& A, const
         if (lbk < 1 || lbk > static_cast<u32>(K::kRing - 1) || lbk > rho || d < 0 || d > K::kMaxD) {
           flag = 7;
         } else if (np < static_cast<u32>(K::kEdges)) {
-          // (band starts are even: d / 2 whole column pairs)
-          const u32 e = poa4_ring_byte(q, ((rho - lbk) % static_cast<u32>(K::kRing)) * static_cast<u32>(kRowW4) + (static_cast<u32>(d) >> 1));
+          // (the row of the tail's ring slot: where a column lies in it does not depend on either band start)
+          const u32 e = poa4_ring_byte(q, ((rho - lbk) % static_cast<u32>(K::kRing)) * static_cast<u32>(kRowW4));
           const u32 idx = np >> 1;
           const u32 keep = (np & 1) ? 0x0000FFFFu : 0xFFFF0000u;
           const u32 put = (np & 1) ? e << 16 : e;
@@ -1790,7 +1804,7 @@ __host__ __device__ inline void poa4_phase_desc_onewave(const Poa4Args& A, const
           sdiff = 0;
         }
         const u32 Srow = rho + (rho >> 4) + (static_cast<u32>(sdiff) >> 1) + 1u;
-        const u32 own = marked[u] ? poa4_ring_byte(q, (rho % static_cast<u32>(K::kRing)) * static_cast<u32>(kRowW4) + 1u) : dump_off;
+        const u32 own = marked[u] ? poa4_ring_byte(q, (rho % static_cast<u32>(K::kRing)) * static_cast<u32>(kRowW4)) : dump_off;
         const bool endn = marked[u] && (full ? outc_f[u] : outc_s[u]) == 0;
         uint4 da, db;
         da.x = Srow | (own << 16);
