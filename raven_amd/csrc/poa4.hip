@@ -353,6 +353,22 @@ __host__ __device__ inline void poa4_dp(const Poa4Args A, Poa4Lds& S, unsigned c
     const u32 neg = pack16(kNegInf16, kNegInf16);
     for (int idx = gl; idx < K::kRing * kRowW4; idx += 16) lds_st32(S, poa4_ring_byte(q, static_cast<u32>(idx)), neg);
     if (lane < 40) S.neg[lane] = neg;
+#if !defined(__HIP_DEVICE_COMPILE__) && defined(RVN_DEBUG_KNOBS)
+    // (host emulator only, tests/test_poa4_emulation.py: the rings start as scores of cells far off the diagonal (1), as huge ones (2), as scores around those of a
+    // band's edge in a window's first rows (3) instead
+    // of -inf — what a read beside a predecessor's band then finds is adversarial, and every window that still comes back
+    // polished must equal the oracle: exactness rests on the traceback's band checks, not on what the ring holds)
+    if (const char* f = knob("RVN_POA4_RING_FILL")) {
+      const int mode = std::atoi(f);
+      for (int idx = gl; idx < K::kRing * kRowW4; idx += 16) {
+        u32 h = (static_cast<u32>(idx) * 2654435761u) ^ (static_cast<u32>(q) * 40503u) ^ (len * 97u);
+        h ^= h >> 13;
+        const i32 base = mode == 3 ? 10 : -100, span = mode == 3 ? 50 : 800;
+        const i32 lo = mode == 2 ? 28000 : base - static_cast<i32>(h % span), hi = mode == 2 ? 28000 : base - static_cast<i32>((h >> 12) % span);
+        if (mode >= 1 && mode <= 3) lds_st32(S, poa4_ring_byte(q, static_cast<u32>(idx)), pack16(lo, hi));
+      }
+    }
+#endif
   }
   lds_order();
   const i32 mD = A.m * 16 + 8, xD = A.n_ * 16 + 8, g64 = A.gp * 16;  // keys = score * 16 + tag; the diagonal's tag bit rides on the score term

@@ -189,3 +189,35 @@ def test_limits_are_reported():
         assert (int(status[i]) & 0xFF) == 4 and np.array_equal(cons[i], bb)
     for i in (1, 3, 4):
         assert (int(status[i]) & 0xFF) == 1 and np.array_equal(cons[i], _oracle(ok_w))
+
+
+@pytest.mark.parametrize("fill", [1, 3, 2], ids=["off_diagonal_scores", "band_edge_scores", "huge_scores"])
+def test_what_the_score_ring_holds_beside_a_band_does_not_matter(fill, monkeypatch):
+    """A ring row is the 32 cells of its band, addressed by the column (poa4.hip): a read right of a
+    predecessor's band, or left of it in a first column, finds another cell of that ring row where rounds 3-4 kept pads of
+    -inf.  The claim is that this can only send a window on to the 64-column kernel, never change a consensus: a raised
+    candidate that wins is followed by the traceback out of the band and found out.  Here the rings start every layer as
+    scores of cells far off the diagonal (-100 .. -900: what such a read finds in practice) / as scores of a band's
+    edge in a window's first rows (-40 .. 10: some first columns are raised, some are not — 10 of the 24 windows still
+    polish, all of them exactly) / as scores above any real one instead of -inf (RVN_POA4_RING_FILL, emulator build only): whatever
+    still comes back polished must equal the oracle, and with off-diagonal leftovers nearly everything still does (with huge
+    ones nothing: every first column is raised, every walk is found out)."""
+    rng = np.random.default_rng(29)
+    wins = [_window(rng, int(rng.integers(90, 330)), int(rng.integers(5, 16)), partial=0.3 if i % 2 else 0.0) for i in range(24)]
+    _, base = hip.poa_banded_emulate(wins, variant=VARIANT[0])
+    monkeypatch.setenv("RVN_POA4_RING_FILL", str(fill))
+    cons, status = hip.poa_banded_emulate(wins, variant=VARIANT[0])
+    polished = 0
+    for w, c, st, b in zip(wins, cons, status, base):
+        if (int(st) & 0xFF) == 1:
+            polished += 1
+            assert (int(b) & 0xFF) == 1
+            assert np.array_equal(c, _oracle(w))
+        else:
+            assert (int(st) & 0xFF) == 8, st
+    base_polished = sum((int(b) & 0xFF) == 1 for b in base)
+    if fill == 1:
+        assert polished >= base_polished - 4, (polished, base_polished)
+    if fill == 3:
+        assert 0 < polished < base_polished, (polished, base_polished)  # (the case that tells: both outcomes occur)
+    print("ring fill", fill, "polished", polished, "of", base_polished)

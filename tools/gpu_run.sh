@@ -51,7 +51,9 @@ for l in sys.stdin:
     smoke) timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3;;
     parity) timeout 1200 python tools/poa_parity.py $arg > gpurun_out/${TAG}_poa_parity_$arg.json 2> gpurun_out/${TAG}_poa_parity.err; python -c "
 import json; d = json.load(open('gpurun_out/${TAG}_poa_parity_$arg.json')); print({k: v for k, v in d.items() if k not in ('examples', 'not_explained')}, 'unexplained', len(d['not_explained']))";;
-    profile) bash tools/profile_round.sh $arg;;
+    profile) bash tools/profile_round.sh $arg
+       # (a bench-full step later in the same call reads the traffic file from profiles/: without this its line says stale)
+       for f in pmc_traffic.json pmc_calibration.json kernel_stats.csv bench_under_rocprof.json; do [ -f gpurun_out/${arg}_$f ] && cp gpurun_out/${arg}_$f profiles/; done;;
     sqpoa) bash tools/prof_poa.sh $arg;;
     mempoa) bash tools/prof_poa_mem.sh $arg;;
     tracenw) bash tools/trace_nw.sh $arg;;
