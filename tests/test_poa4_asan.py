@@ -4,7 +4,9 @@ AddressSanitizer (ROCm's clang ships the runtime).  Every access of the phase fu
 allocation it falls into: the wave's LDS image (its own allocation: an index beyond the 9 KB the kernel declares is
 caught), the windows' state records, the batch description, the layers' codes and qualities, the output, and the scratch of
 the batch (ONE allocation for all its window slots: an access beyond the batch's scratch is caught, one that strays into a
-neighbouring field of a slot is not) — on windows that exercise partial layers, qualities, ragged groups and the limits.  Results are compared with the
+neighbouring field of a slot is not) — on windows that exercise partial layers, qualities, ragged groups and the limits.
+UndefinedBehaviorSanitizer rides along: a shift by 32 or more, a signed overflow, a misaligned access are where the C++ the
+emulator executes and the instructions the GPU executes could part ways without either being "wrong".  Results are compared with the
 oracle as in tests/test_poa4_emulation.py (the instrumented build must not change them).
 
 The instrumented library is built into the test's temporary directory from poa4.hip / poa.hip / simt_emu.hip + the test
@@ -54,7 +56,7 @@ def _asan_runtime():
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="no hipcc")
-def test_window_consensus_kernel_source_under_address_sanitizer(tmp_path):
+def test_window_consensus_kernel_source_under_address_and_ub_sanitizers(tmp_path):
     rt = _asan_runtime()
     if rt is None:
         pytest.skip("this ROCm has no shared AddressSanitizer runtime")
@@ -62,7 +64,7 @@ def test_window_consensus_kernel_source_under_address_sanitizer(tmp_path):
     if not all(os.path.exists(o) for o in others):
         pytest.skip("the test library's objects are not in the tree (raven_amd/csrc/build.sh leaves them in obj_test/)")
     flags = ["--offload-arch=gfx950", "-O1", "-g", "-std=c++17", "-fPIC", "-Wno-unused-function", "-DRVN_TEST_HOOKS", "-DRVN_DEBUG_KNOBS",
-             "-fsanitize=address", "-fno-gpu-sanitize", "-shared-libsan"]
+             "-fsanitize=address,undefined", "-fno-sanitize=vptr,function", "-fno-gpu-sanitize", "-shared-libsan"]
     jobs = [subprocess.Popen([HIPCC] + flags + ["-c", os.path.join(CSRC, u + ".hip"), "-o", str(tmp_path / (u + ".o"))],
                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for u in INSTRUMENTED]
     for u, j in zip(INSTRUMENTED, jobs):
@@ -70,10 +72,10 @@ def test_window_consensus_kernel_source_under_address_sanitizer(tmp_path):
         assert j.returncode == 0, (u, err[-2000:])
     lib = str(tmp_path / "libraven_hip_test.so")
     objs = [str(tmp_path / (u + ".o")) if u in INSTRUMENTED else os.path.join(CSRC, "obj_test", u + ".o") for u in UNITS]
-    link = subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-fsanitize=address", "-fno-gpu-sanitize", "-shared-libsan",
+    link = subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-fsanitize=address,undefined", "-fno-gpu-sanitize", "-shared-libsan",
                            "-o", lib] + objs + ["-lz"], capture_output=True, text=True, timeout=900)
     assert link.returncode == 0, link.stderr[-2000:]
     env = dict(os.environ, RVN_LIB_PATH=lib, LD_PRELOAD=rt, ASAN_OPTIONS="detect_leaks=0:halt_on_error=1", PYTHONPATH=ROOT)
     run = subprocess.run([sys.executable, "-c", SCRIPT], cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
-    assert run.returncode == 0 and "AddressSanitizer" not in run.stderr, (run.stdout[-1000:], run.stderr[-3000:])
+    assert run.returncode == 0 and "AddressSanitizer" not in run.stderr and "runtime error" not in run.stderr, (run.stdout[-1000:], run.stderr[-3000:])
     assert run.stdout.count("polished") == 2, run.stdout
