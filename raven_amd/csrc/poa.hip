@@ -792,13 +792,13 @@ void poa_run_dev(Engine& e, const PoaWindow* d_wins, const PoaLayer* d_lays, u32
   }
   RVN_HIP(hipEventRecord(e.ev1, s));
   RVN_HIP(hipMemcpyAsync(e.poa_phase_cycles, d_phase, 64, hipMemcpyDeviceToHost, s));
-  unsigned long long kstats[6] = {};
+  unsigned long long kstats[7] = {};
   const bool want_stats = knob("RVN_POA_STATS") != nullptr;
-  if (want_stats) RVN_HIP(hipMemcpyAsync(kstats, d_phase + 10, 48, hipMemcpyDeviceToHost, s));
+  if (want_stats) RVN_HIP(hipMemcpyAsync(kstats, d_phase + 9, 56, hipMemcpyDeviceToHost, s));
   RVN_HIP(rvn_stream_sync(s));
   if (want_stats)
-    std::fprintf(stderr, "[raven_hip] poa kernel statistics (poa4.hip): descriptor-pass cycles %llu, traceback steps %llu round changes %llu (cycles in them %llu), dp wave-steps %llu, window set-up cycles %llu\n",
-                 kstats[0], kstats[1], kstats[2], kstats[3], kstats[4], kstats[5]);
+    std::fprintf(stderr, "[raven_hip] poa kernel statistics (poa4.hip): descriptor-pass cycles %llu, traceback steps %llu round changes %llu (cycles in them %llu), dp wave-steps %llu (dp cycles %llu, in service points %llu), window set-up cycles %llu\n",
+                 kstats[1], kstats[2], kstats[3], kstats[4], kstats[5], e.poa_phase_cycles[1], kstats[0], kstats[6]);
   e.poa_cells_full += e.poa_phase_cycles[6];
   e.poa_cells_band += e.poa_phase_cycles[7];
   e.poa_calls += 1;

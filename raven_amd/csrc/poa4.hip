@@ -51,10 +51,9 @@ namespace {
 
 struct P4 {
   static constexpr int G = 4, GS = 16, kBand = 32;
-  static constexpr int kRing = 24;    // score rows a window keeps in LDS = longest in-edge (in ranks) + 1 (a longer one sends the
-                                      // window to poa2: none in 9 220 layers of 300 C4-like windows, the longest was 17.  19 rows =
-                                      // 8 KB of LDS = five waves per SIMD at 96 registers was measured: 844 instead of 737 ms per C4
-                                      // round — the stage does not want more waves)
+  static constexpr int kRing = 22;    // score rows a window keeps in LDS = longest in-edge (in ranks) + 1 (a longer one sends the
+                                      // window to poa2: none in 9 220 layers of 300 C4-like windows, the longest was 17.  Rounds 4-5
+                                      // kept 24; round 6 gave two rows' worth of LDS to the lanes' row descriptors (Poa4Lds::qa ..)
   static constexpr int kRowB = 64;    // bytes per ring row: the 32 cells of the row's band, addressed by the COLUMN (below)
   static constexpr int kMaxD = 8;     // largest band-start difference along an in-edge (a larger one sends the window to poa2)
   static constexpr int kEdges = 8;    // in-edges a row descriptor holds; a row with more sends the window to poa2 (4-bit backpointers:
@@ -62,9 +61,8 @@ struct P4 {
   static constexpr int kU = 8;        // steps between two service points (descriptor prefetch, backpointer store)
 };
 constexpr u32 kNone4 = 0xFFFFu;
-constexpr i32 kNegKey = kNegInf16 * 16;
-constexpr i32 kNegU = -0x30000000;
-constexpr u32 kInactiveS = 0x7FFFu;
+constexpr i32 kNegU = -0x30000000;   // the horizontal chain's value left of a band (a key: score << 8)
+constexpr u32 kInactiveS = 0x7FFFu;  // "no row": the 2 S field of a descriptor (odd — a real row's is even — and later than any step)
 
 // LDS of the NW.  A ring row holds the 32 cells of its row's band as 16 words, and the word of column pair p = j / 2 is
 // p mod 16 WHATEVER the row's band start (a band is 16 pairs wide: every pair of it has a word of its own).  The score rings
@@ -84,8 +82,18 @@ constexpr u32 kInactiveS = 0x7FFFu;
 // band is low, not stale.  slot = rho % kRing.
 constexpr int kRowW4 = P4::kRowB / 4;
 struct alignas(16) Poa4Lds {
+  // The row descriptor a lane is working on, and the one it works on next (round 6): two slots per lane, [slot][lane] so that
+  // the 64 lanes' reads fall into different banks whichever slot each lane is at.  The NW step reads its row's words from
+  // here (one ds_read_b128 + one ds_read_b32, issued a step AHEAD) instead of keeping current / next / in-flight copies in
+  // registers: finishing a row is a pointer flip.  Rounds 4-5 copied seven registers under a lane mask at every row switch,
+  // and one of the wave's 64 lanes switches in 98 % of the steps — a third of the step's instructions.
+  uint4 qa[2][64];  // {2 S | own row's ring bytes << 16, in-edges 0 | 1 << 16, in-edges 2 | 3 << 16, match mask}
+  u32 qm[2][64];    // bits 3..6: (8 x (band start / 2 mod 16) - 8 S) mod 128 (the step's column pair as ring bytes = (this + 8 t) & 0x78);
+                    // bit 8 (alone in its byte: one SDWA compare): an end node's row; bits 24..27: in-edges; bit 31: the row has no in-edge, or more than four (the step's rare path)
+  uint2 qe[2][64];  // {in-edges 4 | 5 << 16, in-edges 6 | 7 << 16}
+  u32 qc[2][64];    // node | band start << 16 | in-edges << 26 | marked << 30 | end node << 31 (rare paths only)
   u32 ring[2][2 * P4::kRing * kRowW4];
-  u32 dump[2][64];      // where rows outside the layer's subgraph leave their cells (interleaved like the rings)
+  u32 dump[2][32];      // where rows outside the layer's subgraph leave their cells (interleaved like the rings)
   u32 neg[40];          // -inf cells: what a descriptor's unused in-edges point at (window parity p: words p, p + 2, ..)
 };
 // byte offsets from the start of Poa4Lds (what a row descriptor holds)
@@ -94,9 +102,12 @@ __host__ __device__ __forceinline__ u32 poa4_ring_byte(int q, u32 w) {
          (2u * w + static_cast<u32>(q & 1)) * 4u;
 }
 __host__ __device__ __forceinline__ u32 poa4_dump_byte(int q) {
-  return static_cast<u32>(offsetof(Poa4Lds, dump)) + static_cast<u32>(q >> 1) * 256u + static_cast<u32>(q & 1) * 4u;
+  return static_cast<u32>(offsetof(Poa4Lds, dump)) + static_cast<u32>(q >> 1) * 128u + static_cast<u32>(q & 1) * 4u;
 }
 __host__ __device__ __forceinline__ u32 poa4_neg_byte(int q) { return static_cast<u32>(offsetof(Poa4Lds, neg)) + static_cast<u32>(q & 1) * 4u; }
+static_assert(offsetof(Poa4Lds, qa) == 0, "a lane's slot pointer is a byte offset into qa");
+static_assert(offsetof(Poa4Lds, ring) % 128 == 0 && offsetof(Poa4Lds, dump) % 128 == 0 && (sizeof(u32) * 2 * P4::kRing * kRowW4) % 128 == 0,
+              "a row's ring bytes leave bits 3..6 to the column pair");
 // (the phases of the kernel share the wave's LDS as a union: the NW the score rings, the graph update room for 896 order
 // slots, the set-up + descriptor pass the layer's bytes, the traceback its staged rows)
 static_assert(sizeof(Poa4Lds) <= 10240, "sixteen waves per CU need <= 10 KB of LDS each");
@@ -122,7 +133,7 @@ struct Poa4Args {
 // Per-window scratch: poa2's graph arrays + the row descriptors of the current layer + its backpointer stream.
 struct Poa4Slot {
   Poa2Slot g;
-  uint4* desc;   // 2 per row: {S | own << 16, node | b << 16 | np << 26 | marked << 30 | end << 31, rank distances of in-edges 0..5
+  uint4* desc;   // 2 per row: {2 S | own << 16, node | b << 16 | np << 26 | marked << 30 | end << 31, rank distances of in-edges 0..5
                  //            (5 bits each), e0 | e1 << 16}, {e2 | e3 << 16, e4 | e5 << 16, e6 | e7 << 16, match mask}: what the
                  //            traceback needs of a row is its first 16 bytes
   u32* rb;       // per node: rank | backbone coordinate << 16 (kept by the set-up and by poa4_update_graph)
@@ -179,16 +190,41 @@ __host__ __device__ __forceinline__ u32 add_half(u32 a, u32 p) {
   return a + (HI ? p >> 16 : p & 0xFFFFu);
 #endif
 }
-// int16 half of w * 16 + tag: v_mad_i32_i16 reads the half through op_sel, the cells stay packed as the LDS read delivers them
+// int16 half of w * 256 + tag: v_mad_i32_i16 reads the half through op_sel, the cells stay packed as the LDS read delivers
+// them.  A key is score << 8 | tag (round 6; rounds 4-5: << 4): the score is bytes 1..2 of the key, so the two cells of a step
+// go back into one packed word with ONE v_perm_b32 (keys_to_pair) instead of two shifts and a pack.
 template <bool HI, int TAG>
 __host__ __device__ __forceinline__ i32 cell_key(u32 w) {
 #if defined(__HIP_DEVICE_COMPILE__)
   i32 d;
-  if constexpr (HI) asm("v_mad_i32_i16 %0, %1, 16, %2 op_sel:[1,0,0,0]" : "=v"(d) : "v"(w), "n"(TAG));
-  else asm("v_mad_i32_i16 %0, %1, 16, %2" : "=v"(d) : "v"(w), "n"(TAG));
+  if constexpr (HI) asm("v_mad_i32_i16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(d) : "v"(w), "s"(256), "n"(TAG));
+  else asm("v_mad_i32_i16 %0, %1, %2, %3" : "=v"(d) : "v"(w), "s"(256), "n"(TAG));
   return d;
 #else
-  return static_cast<i32>(static_cast<i16>((HI ? w >> 16 : w) & 0xFFFFu)) * 16 + TAG;
+  return static_cast<i32>(static_cast<i16>((HI ? w >> 16 : w) & 0xFFFFu)) * 256 + TAG;
+#endif
+}
+// (k0 >> 8) & 0xFFFF | (k1 >> 8) << 16
+__host__ __device__ __forceinline__ u32 keys_to_pair(i32 k0, i32 k1) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_perm(static_cast<u32>(k1), static_cast<u32>(k0), 0x06050201u);
+#else
+  return ((static_cast<u32>(k0) >> 8) & 0xFFFFu) | ((static_cast<u32>(k1) >> 8) << 16);
+#endif
+}
+__host__ __device__ __forceinline__ i32 imax3(i32 a, i32 b, i32 c) {
+  const i32 m = a > b ? a : b;
+  return m > c ? m : c;
+}
+// byte B of acc replaced by the low byte of v (v_perm_b32; the other bytes of v are ignored)
+template <int B>
+__host__ __device__ __forceinline__ u32 put_byte(u32 acc, u32 v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr u32 sel = B == 0 ? 0x0C0C0C04u : (B == 1 ? 0x0C0C0400u : (B == 2 ? 0x0C040100u : 0x04020100u));
+  return __builtin_amdgcn_perm(v, acc, sel);
+#else
+  const u32 keep = B == 0 ? 0u : (B == 1 ? 0xFFu : (B == 2 ? 0xFFFFu : 0xFFFFFFu));
+  return (acc & keep) | ((v & 0xFFu) << (8 * B));
 #endif
 }
 __host__ __device__ __forceinline__ u32 pack16(i32 lo, i32 hi) {  // (lo & 0xFFFF) | hi << 16
@@ -340,7 +376,33 @@ __host__ __device__ __forceinline__ i32 poa4_band_start(const Poa4LdsDesc& S, i3
 // ---- banded NW of one layer per window, rows on lanes ---------------------------------------------------------------
 // Outputs (group-uniform): best_rho1 = 1 + row (rho) of the end node with the best score in the last column, 0: the last
 // column is in no end node's band.
-template <class K>
+//
+// The step (round 6).  Counters of round 5 (SQ_* count quad-cycles: 33 G VALU instructions against ~44-51 G SIMD quad-cycles of
+// the launch) say the kernel keeps the vector ALUs busy 65-75 % of the time at four waves per SIMD: a wave's step does not
+// wait for LDS, it waits for the other waves' instructions — so the step is priced in instructions, and round 5's ~88
+// vector instructions for 2 x 64 cells are now ~50:
+//   * the lane's row descriptor is read from LDS a step ahead (Poa4Lds::qa / qm); the end of a row flips a pointer (rounds 4-5:
+//     ~28 instructions under a lane mask in 98 % of the steps: seven register copies, the end-node test, the schedule test);
+//   * keys are score << 8 | tag: both cells return to a packed pair of int16 with one v_perm_b32;
+//   * the horizontal chain stays in the key domain (tag 0 = "horizontal"): a cell is max3(diagonal, vertical, horizontal) and
+//     its backpointer code the key's low nibble — no score / code selects;
+//   * the step's column pair comes from the step counter and a per-row constant ((qm + 8 t) & 0x78), the row's own step number
+//     (k) is only compared; the match bits of the step are two sign-extending bit-field extracts;
+//   * the end-node score is looked at by the service point after the row's last pair has been stored, the schedule is
+//     checked where descriptors are fetched (consecutive rows of a lane start >= 17 steps apart): neither in the step.
+// The scores of the NW: racon's defaults as raven::Polish passes them (m = 3, n = -5, g = -4: RavenLib/include/raven/graph/
+// polish.hpp:13-17) are literals of a specialised instance — the persistent kernel keeps ~100 scalar registers live across the
+// NW, and round 5's step fetched its score constants out of spilled scalar registers (v_readlane) every time; any other
+// scores take the instance that reads them from the batch.
+struct Poa4ScoresAny {
+  i32 m, n, g;
+  __host__ __device__ explicit Poa4ScoresAny(const Poa4Args& A) : m(A.m), n(A.n_), g(A.gp) {}
+};
+struct Poa4ScoresRacon {
+  static constexpr i32 m = 3, n = -5, g = -4;
+  __host__ __device__ explicit Poa4ScoresRacon(const Poa4Args&) {}
+};
+template <class K, class SC>
 __host__ __device__ inline void poa4_dp(const Poa4Args A, Poa4Lds& S, unsigned char* slot_mem, bool act, u32 t_end, u32 len,
                                         u32& best_rho1) {
   P4_ASSUME_GLOBAL(slot_mem);
@@ -370,192 +432,253 @@ __host__ __device__ inline void poa4_dp(const Poa4Args A, Poa4Lds& S, unsigned c
     }
 #endif
   }
-  lds_order();
-  const i32 mD = A.m * 16 + 8, xD = A.n_ * 16 + 8, g64 = A.gp * 16;  // keys = score * 16 + tag; the diagonal's tag bit rides on the score term
-  const i32 gp = A.gp;
-  const i32 dD = mD - xD;
-  // current row (the raw descriptor words), the next one, the one being fetched
-  u32 c0, c1, cM, ce0, ce1, ce2, ce3;
-  u32 n0, n1, nM, ne0, ne1, ne2, ne3;
-  u32 l0 = 0, l1 = 0, lM = 0, le0 = 0, le1 = 0, le2 = 0, le3 = 0;
-  u32 cur_rho = static_cast<u32>(gl);
+  const SC sc(A);
+  const i32 xD = sc.n * 256 + 8, dD = (sc.m - sc.n) * 256, gK = sc.g * 256;  // keys = score * 256 + tag; the diagonal's tag bit rides on the score term
+  const i32 gp = sc.g;
+  const u32 neg_off = poa4_neg_byte(q);
+  const u32 neg2 = neg_off | (neg_off << 16);
+  const u32 negpair = pack16(kNegInf16, kNegInf16);
+  // a descriptor as the desc pass left it (2 x 16 bytes) into one of the lane's two slots; `on` = false: a row that never starts
+  auto park = [&](u32 par, uint4 da, uint4 db, bool on) __attribute__((always_inline)) {
+    const u32 s2 = on ? (da.x & 0xFFFFu) : kInactiveS;
+    const u32 c1 = on ? da.y : 0u;
+    const u32 np = (c1 >> 26) & 15u;
+    // bytes of the band's first column pair in a ring row, minus 8 S: the pair of step t is (this + 8 t) & 0x78
+    const u32 r0 = (((c1 >> 14) & 0x78u) - 4u * s2) & 0x78u;
+    const bool rare = on && s2 != kInactiveS && (np == 0u || np > 4u);
+    S.qa[par][lane] = uint4{on ? da.x : (kInactiveS | (neg_off << 16)), on ? da.w : neg2, on ? db.x : neg2, db.w};
+    S.qm[par][lane] = r0 | ((c1 >> 31) << 8) | (np << 24) | (rare ? 0x80000000u : 0u);
+    S.qe[par][lane] = uint2{on ? db.y : neg2, on ? db.z : neg2};
+    S.qc[par][lane] = c1;
+  };
+  bool sched_bad = false;
+  u32 ld_rho = static_cast<u32>(gl) + 16u;  // the last row whose descriptor went to LDS
+  u32 ld_s2;                                // its 2 S
   {
-    const uint4 a = sl.desc[2 * static_cast<size_t>(cur_rho)], b = sl.desc[2 * static_cast<size_t>(cur_rho) + 1];
-    const u32 neg_off = poa4_neg_byte(q);
-    const u32 neg2 = neg_off | (neg_off << 16);
-    c0 = act ? (a.x | 0u) : (kInactiveS | (neg_off << 16));  // (a group without a layer in this round has no descriptors: it idles on -inf cells)
-    c1 = act ? a.y : 0u;
-    cM = b.w;
-    ce0 = act ? a.w : neg2;
-    ce1 = act ? b.x : neg2;
-    ce2 = act ? b.y : neg2;
-    ce3 = act ? b.z : neg2;
-    const uint4 a2 = sl.desc[2 * static_cast<size_t>(cur_rho + 16)], b2 = sl.desc[2 * static_cast<size_t>(cur_rho + 16) + 1];
-    n0 = act ? a2.x : kInactiveS;
-    n1 = act ? a2.y : 0u;
-    nM = b2.w;
-    ne0 = act ? a2.w : neg2;
-    ne1 = act ? b2.x : neg2;
-    ne2 = act ? b2.y : neg2;
-    ne3 = act ? b2.z : neg2;
+    const uint4 a = sl.desc[2 * static_cast<size_t>(gl)], b = sl.desc[2 * static_cast<size_t>(gl) + 1];
+    const uint4 a2 = sl.desc[2 * static_cast<size_t>(gl + 16)], b2 = sl.desc[2 * static_cast<size_t>(gl + 16) + 1];
+    park(0, a, b, act);  // (a group without a layer in this round has no descriptors: it idles on -inf cells)
+    park(1, a2, b2, act);
+    const u32 s0 = act ? (a.x & 0xFFFFu) : kInactiveS;
+    ld_s2 = act ? (a2.x & 0xFFFFu) : kInactiveS;
+    // consecutive rows of a lane start at least 17 steps apart (band starts do not decrease along the order)
+    if (act && s0 != kInactiveS && ld_s2 < s0 + 34u) sched_bad = true;
   }
-  bool nx_full = true, ld_pending = false, sched_bad = false;
-  u32 cb3 = (c1 >> 14) & 0x78u;  // 8 x (the band start's column pair mod 16): step k is at byte (cb3 + 8 k) & 0x78 of a ring row
-  i32 Am1 = kNegKey, U = kNegU;
+  lds_order();
+  // the lane's slot as bytes into qa (qm = bytes / 4, qe = bytes / 2); the words of the step to come
+  u32 ptr = static_cast<u32>(offsetof(Poa4Lds, qa)) + static_cast<u32>(lane) * 16u;
+  constexpr u32 kFlip = 64u * 16u;
+  uint4 cw = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(&S) + ptr);
+  u32 cm = lds_ld32(S, static_cast<u32>(offsetof(Poa4Lds, qm)) + (ptr >> 2));
+  uint4 lA = uint4{0, 0, 0, 0}, lB = uint4{0, 0, 0, 0};
+  bool ld_pending = false;
+  i32 Am1 = 0, UK = kNegU;
   i32 best_score = -0x7FFFFFFF;
   u32 best_row = 0;
   const u32 T = static_cast<u32>(sv::wave_max(act ? static_cast<int>(t_end) : 0));
-#if defined(__HIP_DEVICE_COMPILE__)
-  // (a register reloaded from scratch right before the loop is "in flight" for the compiler's wait-count bookkeeping all
-  // through the loop: the row switch below, which uses it, then waits for EVERY outstanding memory operation — the
-  // descriptor prefetch of the same service point included — in every step.  Used here, it is waited for here.)
-  asm volatile("" : "+v"(cur_rho));
-#endif
-  for (u32 t0 = 0; t0 < T; t0 += K::kU) {
-    // ---- service point: the descriptor fetched 8 steps ago becomes the lane's next row; a lane whose next row is
-    // missing fetches it (it is needed 17 steps after the switch that consumed the previous one at the earliest) ----
-    if (ld_pending) {
-      n0 = l0;
-      n1 = l1;
-      nM = lM;
-      ne0 = le0;
-      ne1 = le1;
-      ne2 = le2;
-      ne3 = le3;
-      nx_full = true;
-      ld_pending = false;
-    } else if (!nx_full && act) {
-      const uint4 a = sl.desc[2 * static_cast<size_t>(cur_rho + 16)], b = sl.desc[2 * static_cast<size_t>(cur_rho + 16) + 1];
-      l0 = a.x;
-      l1 = a.y;
-      lM = b.w;
-      le0 = a.w;
-      le1 = b.x;
-      le2 = b.y;
-      le3 = b.z;
-      ld_pending = true;
-    }
-    u32 acc0 = 0, acc1 = 0;
-#pragma unroll
-    for (int u = 0; u < K::kU; ++u) {
-      P4_MARK("step_begin");
-      const u32 t = t0 + static_cast<u32>(u);
-      i32 k = static_cast<i32>(t) - static_cast<i32>(c0 & 0xFFFFu);
-      if (k == 16) {  // the row is finished: its end-node score, then the next row
-        if (c1 >> 31) {
-          const i32 idx = static_cast<i32>(len) - static_cast<i32>((c1 >> 16) & 0x3FFu);
-          if (idx >= 0 && idx < K::kBand) {
-            const i32 sce = lds_ld16(S, (c0 >> 16) + ((cb3 + 8u * (static_cast<u32>(idx) >> 1)) & 0x78u) + 2u * (static_cast<u32>(idx) & 1u));
-            const u32 cand = ((c1 & 0xFFFFu) << 16) | (cur_rho + 1);  // node id | 1 + row: equal scores -> smallest node id
-            if (sce > best_score || (sce == best_score && cand < best_row)) {
-              best_score = sce;
-              best_row = cand;
-            }
-          }
-        }
-        c0 = n0;
-        c1 = n1;
-        cM = nM;
-        ce0 = ne0;
-        ce1 = ne1;
-        ce2 = ne2;
-        ce3 = ne3;
-        cb3 = (c1 >> 14) & 0x78u;
-        cur_rho += 16;
-        nx_full = false;
-        Am1 = kNegKey;
-        k = static_cast<i32>(t) - static_cast<i32>(c0 & 0xFFFFu);
-        if (k >= 0) sched_bad = true;  // the next row's first step is already over: band starts decreased along the order
-      }
-      i32 kk = k + 1;
-      kk = kk < 0 ? 0 : (kk > 16 ? 16 : kk);
-      // the step's column pair (band start / 2 + k; k = -1: the pair left of the band, for the first diagonal) as a byte
-      // offset into ANY ring row (interleaved rings: a pair is 8 bytes on)
-      const u32 off4 = (cb3 + (static_cast<u32>(k) << 3)) & 0x78u;
-      const u32 np = (c1 >> 26) & 15u;
-      // ---- in-edges: one aligned pair of predecessor cells each (columns j, j + 1 of this step) ----
-      u32 wd = lds_ld32(S, add_half<false>(off4, ce0));
-      if (sv::any(np == 0)) {  // no in-edge inside the subgraph: the virtual start row H[0][j] = j * g
-        const i32 bb = static_cast<i32>((c1 >> 16) & 0x3FFu);
-        const i32 j0 = bb - 2 + 2 * kk;
-        u32 vp = pack16(j0 * gp, (j0 + 1) * gp);
-        if (j0 < 0) vp = pack16(kNegInf16, kNegInf16);
-        wd = np == 0 ? vp : wd;
-      }
-      // (a row's unused in-edges point at -inf cells: in-edges 1..3 are read whether the row has them or not, so the
-      // four reads are in flight together; 99 % of the rows have at most four.  Issuing them under the exec mask of the lanes
-      // that have the in-edge — 39 % / 17 % of the lanes — was measured: LDS cycles -16 %, bank conflicts -32 %, but +5 %
-      // VALU and +10 % SALU instructions for the masks, and the stage 1 - 6 % slower)
-      const u32 w1 = lds_ld32(S, add_half<true>(off4, ce0));
-      const u32 w2 = lds_ld32(S, add_half<false>(off4, ce1));
-      const u32 w3 = lds_ld32(S, add_half<true>(off4, ce1));
-      i32 A0 = cell_key<false, 7>(wd), A1 = cell_key<true, 7>(wd);
-      A0 = imax(A0, cell_key<false, 6>(w1));
-      A1 = imax(A1, cell_key<true, 6>(w1));
-      A0 = imax(A0, cell_key<false, 5>(w2));
-      A1 = imax(A1, cell_key<true, 5>(w2));
-      A0 = imax(A0, cell_key<false, 4>(w3));
-      A1 = imax(A1, cell_key<true, 4>(w3));
-#define P4_EDGE(E, REG, HI)                                        \
-  {                                                                \
-    const u32 we = lds_ld32(S, add_half<HI>(off4, REG));           \
-    A0 = imax(A0, cell_key<false, 7 - E>(we));                     \
-    A1 = imax(A1, cell_key<true, 7 - E>(we));                      \
-  }
-      if (sv::any(np > 4)) {
-        P4_EDGE(4, ce2, false)
-        if (sv::any(np > 5)) {
-          P4_EDGE(5, ce2, true)
-          if (sv::any(np > 6)) {
-            P4_EDGE(6, ce3, false)
-            P4_EDGE(7, ce3, true)
-          }
-        }
-      }
-#undef P4_EDGE
-      // ---- the two cells: spoa's priority diagonal (first in-edge reaching the maximum), vertical, horizontal ----
-      const u32 bits = (cM >> (static_cast<u32>(2 * k) & 31u)) & 3u;
-      const i32 sd0 = xD + static_cast<i32>(bits & 1u) * dD, sd1 = xD + static_cast<i32>(bits >> 1) * dD;
-      const i32 b0 = imax(Am1 + sd0, A0 + g64);
-      const i32 h0 = U + gp, s0 = b0 >> 4;
-      const i32 U0 = imax(s0, h0);
-      const u32 code0 = h0 > s0 ? 0u : (static_cast<u32>(b0) & 15u);  // 0: horizontal; else diagonal << 3 | 7 - in-edge
-      const i32 b1 = imax(A0 + sd1, A1 + g64);
-      const i32 h1 = U0 + gp, s1 = b1 >> 4;
-      const i32 U1 = imax(s1, h1);
-      const u32 code1 = h1 > s1 ? 0u : (static_cast<u32>(b1) & 15u);
-      if (static_cast<u32>(k) < 16u) lds_st32(S, add_half<true>(off4, c0), clamp_pair(pack16(U0, U1)));
-      u32 cp = code0 | (code1 << 4);
-#if defined(__HIP_DEVICE_COMPILE__)
-      asm volatile("" : "+v"(cp));  // computed here: sunk to the store it would keep three registers per step alive
-#endif
-      if (u == 0) acc0 = cp;
-      else if (u < 4) acc0 |= cp << (8 * u);
-      else if (u == 4) acc1 = cp;
-      else acc1 |= cp << (8 * (u - 4));
-      Am1 = A1;
-      U = kk == 0 ? kNegU : U1;
-      lds_order();
-      P4_MARK("step_end");
-    }
-    if (act) sl.bps[static_cast<size_t>(t0 / K::kU) * 16 + static_cast<size_t>(gl)] = uint2{acc0, acc1};
-  }
-  if (A.phase_cycles && lane == 0) sv::atomic_add(&A.phase_cycles[14], static_cast<unsigned long long>((T + K::kU - 1) / K::kU * K::kU));
-  // rows that finished in the very last step of the loop
-  {
-    const i32 k = static_cast<i32>(T) - static_cast<i32>(c0 & 0xFFFFu);
-    if (act && k >= 16 && (c1 >> 31)) {
+  // An end node's score in the layer's last column, looked at by the first service point after the row's last pair was
+  // stored: the row's descriptor is still in the lane's other slot (the next fetch parks 8 steps after it was issued, and it
+  // is issued here at the earliest), and its cells are still in the ring — the row kRing rows on, which takes the ring slot
+  // over, stores its first pair >= kRing + 1 steps after this row stored its first, i.e. >= 8 steps after this row's last:
+  // not before the step this service point precedes.
+  static_assert(K::kRing >= 16 + K::kU - 2, "an end node's cells outlive the row by a service interval");
+  auto end_check = [&](u32 t0) __attribute__((always_inline)) {
+    const u32 optr = ptr ^ kFlip;
+    const u32 px = lds_ld32(S, optr), pm = lds_ld32(S, static_cast<u32>(offsetof(Poa4Lds, qm)) + (optr >> 2));
+    const i32 fin2 = static_cast<i32>(2u * t0) - static_cast<i32>(px & 0xFFFFu) - 30;  // 2 x steps since the row's last pair
+    const bool hit = (pm & 0x100u) != 0 && fin2 >= 2 && fin2 <= 2 * K::kU;
+    if (sv::any(hit)) {
+      const u32 c1 = lds_ld32(S, static_cast<u32>(offsetof(Poa4Lds, qc)) + (optr >> 2));
       const i32 idx = static_cast<i32>(len) - static_cast<i32>((c1 >> 16) & 0x3FFu);
-      if (idx >= 0 && idx < K::kBand) {
-        const i32 sce = lds_ld16(S, (c0 >> 16) + ((cb3 + 8u * (static_cast<u32>(idx) >> 1)) & 0x78u) + 2u * (static_cast<u32>(idx) & 1u));
-        const u32 cand = ((c1 & 0xFFFFu) << 16) | (cur_rho + 1);
+      if (hit && idx >= 0 && idx < K::kBand) {
+        const u32 cb3 = (c1 >> 14) & 0x78u;
+        const i32 sce = lds_ld16(S, (px >> 16) + ((cb3 + 8u * (static_cast<u32>(idx) >> 1)) & 0x78u) + 2u * (static_cast<u32>(idx) & 1u));
+        const u32 rho = ((cw.x & 0xFFFFu) == ld_s2 ? ld_rho : ld_rho - 16u) - 16u;  // (the lane is at the last row parked, or at the one before)
+        const u32 cand = ((c1 & 0xFFFFu) << 16) | (rho + 1u);  // node id | 1 + row: equal scores -> smallest node id
         if (sce > best_score || (sce == best_score && cand < best_row)) {
           best_score = sce;
           best_row = cand;
         }
       }
     }
+  };
+  u32 t0 = 0, accp0 = 0, accp1 = 0;
+  uint2* bp = sl.bps + gl;  // where the backpointers of the eight steps before go: [step / 8][lane of the window]
+#if defined(RVN_DEBUG_KNOBS)
+  unsigned long long t_sp = 0;
+#endif
+  for (; t0 < T; t0 += K::kU) {
+#if defined(RVN_DEBUG_KNOBS)
+    const unsigned long long sp0 = sv::clock();
+#endif
+    end_check(t0);
+    // ---- service point: the descriptor fetched 8 steps ago goes into the slot of the row the lane finished last; a lane
+    // that has moved on to the last row it holds fetches the one after (needed 17 steps after that switch at the earliest:
+    // fetched <= 8 steps after it, parked <= 16 steps after it).  The backpointers of the PREVIOUS eight steps leave here,
+    // after the two: the only wait for vector memory in the loop that finds anything outstanding is the one in front of the
+    // parking, and what it finds — the fetch and the store of the service point before — was issued eight steps ago.  (Rounds 4-5
+    // stored at the end of the eight steps: the wait at the top of the next eight then sat behind a store issued a moment
+    // ago, every time, for the length of a write to HBM.) ----
+#if defined(__HIP_DEVICE_COMPILE__)
+    // (the loads of the service point before are waited for HERE, by every lane: left to the branch below, the compiler has
+    // to wait again where the next loads overwrite their registers — behind the store issued a moment before)
+    // (an empty asm statement is no use of a register for the compiler's wait counting; an instruction is)
+    {
+      u32 seen = (lA.x | lA.y | lA.z) | (lA.w | lB.x | lB.y) | (lB.z | lB.w);
+      asm volatile("" : "+v"(seen));
+    }
+#endif
+    if (ld_pending) {
+      const u32 rho = ld_rho + 16u;
+      park((rho >> 4) & 1u, lA, lB, true);
+      const u32 s2 = lA.x & 0xFFFFu;
+      if (ld_s2 != kInactiveS && s2 < ld_s2 + 34u) sched_bad = true;  // the row's first step would be over: band starts decreased along the order
+      ld_s2 = s2;
+      ld_rho = rho;
+    }
+    {
+      // (every lane loads at every service point — those with nothing to fetch the wave's first descriptor, one request for all of
+      // them: a load under a lane mask makes its registers a merge of two definitions around the loop, and the compiler then
+      // shuffles — and waits for — the loaded registers right behind the load)
+      const bool want = !ld_pending && act && ld_s2 != kInactiveS && (cw.x & 0xFFFFu) == ld_s2;  // (a lane's rows have increasing S: the row it is at IS the last one parked)
+      const uint4* src = sl.desc + (want ? 2 * static_cast<size_t>(ld_rho + 16) : 0);
+#if defined(P4_EXP) && P4_EXP == 6  // (timing experiment: no descriptor fetch)
+      (void)src;
+      ld_pending = false;
+#else
+      lA = src[0];
+      lB = src[1];
+      ld_pending = want;
+#endif
+    }
+    // (the store BEHIND the loads: the compiler re-waits for "everything" in front of the loads whatever was waited for above
+    // — free when nothing is outstanding, the length of a write to HBM behind a store)
+#if defined(P4_EXP) && (P4_EXP == 3 || P4_EXP == 6)  // (timing experiment: no backpointer store)
+    if (act && t0 != 0 && accp0 == 0x12345678) *bp = uint2{accp0, accp1};
+#else
+    if (act && t0 != 0) *bp = uint2{accp0, accp1};
+#endif
+#if defined(RVN_DEBUG_KNOBS)
+    t_sp += sv::clock() - sp0;
+#endif
+    u32 acc0 = 0, acc1 = 0;
+#pragma unroll
+    for (int u = 0; u < K::kU; ++u) {
+      P4_MARK("step_begin");
+      const u32 t = t0 + static_cast<u32>(u);
+      const i32 k2 = static_cast<i32>(2u * t) - static_cast<i32>(cw.x & 0xFFFFu);  // 2 k: -2 = the pair left of the band, 0 .. 30 the band
+      // the step's column pair as a byte offset into ANY ring row (interleaved rings: a pair is 8 bytes on)
+      const u32 off4 = (cm + 8u * t) & 0x78u;
+      // ---- in-edges: one aligned pair of predecessor cells each (columns j, j + 1 of this step).  A row's unused in-edges
+      // point at -inf cells: in-edges 1..3 are read whether the row has them or not, so the four reads are in flight together
+      // (issuing them under the exec mask of the lanes that have the in-edge was measured in round 5: slower) ----
+#if defined(P4_EXP) && P4_EXP == 1  // (timing experiment: no ring reads)
+      u32 wd = add_half<false>(off4, cw.y);
+      const u32 w1 = add_half<true>(off4, cw.y), w2 = add_half<false>(off4, cw.z), w3 = add_half<true>(off4, cw.z);
+#else
+      u32 wd = lds_ld32(S, add_half<false>(off4, cw.y));
+      const u32 w1 = lds_ld32(S, add_half<true>(off4, cw.y));
+      const u32 w2 = lds_ld32(S, add_half<false>(off4, cw.z));
+      const u32 w3 = lds_ld32(S, add_half<true>(off4, cw.z));
+#endif
+      // ---- the words of the next step: the same row's, or — after the row's last pair — the other slot's ----
+      const u32 nptr = k2 == 30 ? ptr ^ kFlip : ptr;
+#if defined(P4_EXP) && P4_EXP == 2  // (timing experiment: no descriptor reads)
+      const uint4 nw = uint4{cw.x + (nptr & 0x10000u), cw.y, cw.z, cw.w};
+      const u32 nm = cm;
+#else
+      const uint4 nw = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(&S) + nptr);
+      const u32 nm = lds_ld32(S, static_cast<u32>(offsetof(Poa4Lds, qm)) + (nptr >> 2));
+#endif
+      i32 A0, A1;
+      if (sv::any(static_cast<i32>(cm) < 0)) {  // rows without an in-edge inside the subgraph, rows with more than four (1 % of the rows)
+        P4_MARK("rare_begin");
+        const uint2 ce = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned char*>(&S) + offsetof(Poa4Lds, qe) + (ptr >> 1));
+        const u32 np = (cm >> 24) & 15u;
+        if (sv::any(np == 0)) {  // the virtual start row H[0][j] = j * g
+          const u32 c1 = lds_ld32(S, static_cast<u32>(offsetof(Poa4Lds, qc)) + (ptr >> 2));
+          const i32 j0 = static_cast<i32>((c1 >> 16) & 0x3FFu) + k2;
+          u32 vp = pack16(j0 * gp, (j0 + 1) * gp);
+          if (j0 < 0) vp = negpair;
+          wd = np == 0 ? vp : wd;
+        }
+        A0 = cell_key<false, 7>(wd);
+        A1 = cell_key<true, 7>(wd);
+#define P4_EDGE(E, REG, HI)                                        \
+  {                                                                \
+    const u32 we = lds_ld32(S, add_half<HI>(off4, REG));           \
+    A0 = imax(A0, cell_key<false, 7 - E>(we));                     \
+    A1 = imax(A1, cell_key<true, 7 - E>(we));                      \
   }
+        if (sv::any(np > 4)) {
+          P4_EDGE(4, ce.x, false)
+          if (sv::any(np > 5)) {
+            P4_EDGE(5, ce.x, true)
+            if (sv::any(np > 6)) {
+              P4_EDGE(6, ce.y, false)
+              P4_EDGE(7, ce.y, true)
+            }
+          }
+        }
+#undef P4_EDGE
+        P4_MARK("rare_end");
+      } else {
+        A0 = cell_key<false, 7>(wd);
+        A1 = cell_key<true, 7>(wd);
+      }
+      A0 = imax3(A0, cell_key<false, 6>(w1), cell_key<false, 5>(w2));
+      A1 = imax3(A1, cell_key<true, 6>(w1), cell_key<true, 5>(w2));
+      A0 = imax(A0, cell_key<false, 4>(w3));
+      A1 = imax(A1, cell_key<true, 4>(w3));
+      // ---- the two cells: spoa's priority diagonal (first in-edge reaching the maximum), vertical, horizontal — the order of
+      // the tags (8 | 7 - e, 7 - e, 0); equal keys are "vertical through the eighth in-edge" and "horizontal": code 0 for both ----
+      const u32 cs = cw.w >> (static_cast<u32>(k2) & 31u);
+      const i32 m0 = static_cast<i32>(cs << 31) >> 31, m1 = static_cast<i32>(cs << 30) >> 31;  // -1: the row's base matches the column's
+      const i32 M0 = imax3(Am1 + xD + (m0 & dD), A0 + gK, UK + gK);
+      const i32 U0K = M0 & ~0xFF;
+      const i32 M1 = imax3(A0 + xD + (m1 & dD), A1 + gK, U0K + gK);
+      const bool in_band = k2 >= 0;
+#if defined(P4_EXP) && P4_EXP == 4  // (timing experiment: no ring store)
+      if (in_band && M0 == 0x12345678) lds_st32(S, add_half<true>(off4, cw.x), clamp_pair(keys_to_pair(M0, M1)));
+#else
+      if (in_band) lds_st32(S, add_half<true>(off4, cw.x), clamp_pair(keys_to_pair(M0, M1)));
+#endif
+      UK = in_band ? (M1 & ~0xFF) : kNegU;
+      Am1 = A1;
+      u32 cp = (static_cast<u32>(M0) & 15u) | (static_cast<u32>(M1) << 4);  // (byte 0: code of the pair; the rest is dropped by put_byte)
+#if defined(__HIP_DEVICE_COMPILE__)
+      asm volatile("" : "+v"(cp));  // computed here: sunk to the store it would keep the step's two keys alive for eight steps
+#endif
+      if (u == 0) acc0 = put_byte<0>(acc0, cp);
+      else if (u == 1) acc0 = put_byte<1>(acc0, cp);
+      else if (u == 2) acc0 = put_byte<2>(acc0, cp);
+      else if (u == 3) acc0 = put_byte<3>(acc0, cp);
+      else if (u == 4) acc1 = put_byte<0>(acc1, cp);
+      else if (u == 5) acc1 = put_byte<1>(acc1, cp);
+      else if (u == 6) acc1 = put_byte<2>(acc1, cp);
+      else acc1 = put_byte<3>(acc1, cp);
+      lds_order();
+      ptr = nptr;
+      cw = nw;
+      cm = nm;
+      P4_MARK("step_end");
+    }
+#if defined(__HIP_DEVICE_COMPILE__)
+    // (the registers the store above took its data from stay untouched until here: the compiler guards a register that an
+    // outstanding store reads — data or address — against being overwritten by waiting for the store: right behind it, had it been
+    // free to reuse them)
+    asm volatile("" : : "v"(accp0), "v"(accp1), "v"(bp));
+#endif
+    accp0 = acc0;
+    accp1 = acc1;
+    if (t0 != 0) bp += 16;
+  }
+  if (act && t0 != 0) *bp = uint2{accp0, accp1};
+  end_check(t0);  // rows that finished in the loop's last steps
+#if defined(RVN_DEBUG_KNOBS)
+  if (A.phase_cycles && lane == 0) sv::atomic_add(&A.phase_cycles[9], t_sp);
+#endif
+  if (A.phase_cycles && lane == 0) sv::atomic_add(&A.phase_cycles[14], static_cast<unsigned long long>((T + K::kU - 1) / K::kU * K::kU));
   // among the end nodes with the best score the one with the SMALLEST NODE ID (a rule that does not depend on the order of
   // the rows: spoa takes the first in ITS rank order, which is not the device's), as poa2 / poa pick it
   {
@@ -644,8 +767,8 @@ __host__ __device__ inline void poa4_traceback(const Poa4Args A, Poa4LdsTb& S, u
   auto load_codes = [&](const u32 (&d0)[kTbG], v2u (&a)[kTbG], v2u (&b)[kTbG], v2u (&c)[kTbG]) __attribute__((always_inline)) {
 #pragma unroll
     for (int h = 0; h < kTbG; ++h) {
-      const u32 s = d0[h] & 0xFFFFu;
-      const size_t tb = s == kInactiveS ? 0u : s / K::kU;
+      const u32 s2 = d0[h] & 0xFFFFu;
+      const size_t tb = s2 == kInactiveS ? 0u : (s2 >> 1) / K::kU;
       const v2u* src = reinterpret_cast<const v2u*>(bps + tb * 16 + static_cast<size_t>(gl));
       a[h] = src[0];
       b[h] = src[16];
@@ -669,7 +792,7 @@ __host__ __device__ inline void poa4_traceback(const Poa4Args A, Poa4LdsTb& S, u
 #pragma unroll
         for (int h = 0; h < kTbG; ++h) {
           uint4* dst = S.row[q][16 * h + gl];
-          dst[0] = poa4_align_codes(na[h].x, na[h].y, nb[h].x, nb[h].y, nc[h].x, nc[h].y, nd0[h] & 0xFFFFu, (nd1[h] >> 16) & 0x3FFu);
+          dst[0] = poa4_align_codes(na[h].x, na[h].y, nb[h].x, nb[h].y, nc[h].x, nc[h].y, (nd0[h] & 0xFFFFu) >> 1, (nd1[h] >> 16) & 0x3FFu);
           dst[1] = uint4{nd0[h], nd1[h], nd7[h], 0u};
         }
         c_rnd = rnd;
@@ -1823,7 +1946,7 @@ __host__ __device__ inline void poa4_phase_desc_onewave(const Poa4Args& A, const
         const u32 own = marked[u] ? poa4_ring_byte(q, (rho % static_cast<u32>(K::kRing)) * static_cast<u32>(kRowW4)) : dump_off;
         const bool endn = marked[u] && (full ? outc_f[u] : outc_s[u]) == 0;
         uint4 da, db;
-        da.x = Srow | (own << 16);
+        da.x = (2u * Srow) | (own << 16);
         da.y = v | (static_cast<u32>(b) << 16) | ((np > 15u ? 15u : np) << 26) | (marked[u] ? 1u << 30 : 0u) | (endn ? 1u << 31 : 0u);
         da.z = lbw;
         da.w = ep[0];
@@ -1858,7 +1981,7 @@ __host__ __device__ inline void poa4_phase_desc_onewave(const Poa4Args& A, const
 }
 
 // phase B: the NW
-template <class K>
+template <class K, class SC>
 __host__ __device__ inline void poa4_phase_dp(const Poa4Args& A, const Poa4Ctx& C, Poa4Lds& S, u32 wave) {
   const int lane = sv::lane();
   const int q = lane / K::GS;
@@ -1883,7 +2006,7 @@ __host__ __device__ inline void poa4_phase_dp(const Poa4Args& A, const Poa4Ctx& 
   }
   if (!sv::any(act != 0)) return;
   u32 best_rho1 = 0;
-  poa4_dp<K>(A, S, poa4_slot_of(A, C, wave, q), act != 0, t_end, len, best_rho1);
+  poa4_dp<K, SC>(A, S, poa4_slot_of(A, C, wave, q), act != 0, t_end, len, best_rho1);
   if (act && (lane & (K::GS - 1)) == 0) {
     Poa4Win& w = C.st[my_rec];
     w.best_rho1 = best_rho1;
@@ -2036,9 +2159,9 @@ struct alignas(16) Poa4LdsNw {
     Poa4LdsTb tb;
   } u;
 };
-template <class K>
+template <class K, class SC>
 __host__ __device__ inline void poa4_phase_nw(const Poa4Args& A, const Poa4Ctx& C, Poa4LdsNw& S, u32 wave) {
-  poa4_phase_dp<K>(A, C, S.u.dp, wave);
+  poa4_phase_dp<K, SC>(A, C, S.u.dp, wave);
   sv::phase_fence();  // backpointer stream and the windows' records: written above, read below
   poa4_phase_tb<K>(A, C, S.u.tb, wave);
 }
@@ -2059,7 +2182,7 @@ struct alignas(16) Poa4LdsAll {
     Poa4Lds f;
   } u;
 };
-template <class K, int UP>
+template <class K, int UP, class SC>
 __host__ __device__ inline void poa4_persistent(const Poa4Args& A, const Poa4Ctx& C0, Poa4LdsAll& S, u32 pw) {
   const int lane = sv::lane();
   const u32 n_quads = (C0.count + P4::G - 1) / P4::G;
@@ -2087,7 +2210,7 @@ __host__ __device__ inline void poa4_persistent(const Poa4Args& A, const Poa4Ctx
       }
       sv::sync();  // (the records are read by every lane before the alignment side rewrites them)
       if (!any_layer) break;
-      poa4_phase_nw<K>(A, C, S.u.n, pw);
+      poa4_phase_nw<K, SC>(A, C, S.u.n, pw);
       sv::phase_fence();
     }
     poa4_phase_final(A, C, S.u.f, pw);
@@ -2098,10 +2221,13 @@ __host__ __device__ inline void poa4_persistent(const Poa4Args& A, const Poa4Ctx
 // ---- the kernel: one wave per workgroup, resident waves = the grid ---------------------------------------------------------
 // (four waves per SIMD: 128 registers, 9.7 KB of LDS.  Measured at C4 on one box: three waves per SIMD with 168 registers
 // 869 ms per round, four 766 ms, five — 96 registers, a 19-row score ring = 8 KB of LDS — 844 ms: profiles/r05_poa_occupancy.txt)
-template <int UP>
+template <int UP, class SC>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void poa4_persistent_kernel(const Poa4Args A, const Poa4Ctx C) {
   __shared__ Poa4LdsAll lds;
-  poa4_persistent<P4, UP>(A, C, lds, blockIdx.x);
+  poa4_persistent<P4, UP, SC>(A, C, lds, blockIdx.x);
+}
+__host__ __device__ inline bool poa4_racon_scores(const Poa4Args& A) {
+  return A.m == Poa4ScoresRacon::m && A.n_ == Poa4ScoresRacon::n && A.gp == Poa4ScoresRacon::g;
 }
 
 Poa4Args args_of4(const PoaBatchDev& b, unsigned char* scratch, size_t slot_bytes) {
@@ -2154,7 +2280,11 @@ void poa_v4_launch(Engine& e, const PoaBatchDev& b) {
   const Poa4Ctx C{d_st, 0, b.n_windows, 0};
   // (two sequence positions per lane and turn of the graph update: the kernel's 128 registers hold it without the spills the
   // four-position variant brings — 739 against 829 ms per C4 round)
-  RVN_KLAUNCH_ON(kKPoaRows, s, (poa4_persistent_kernel<kUpdPer><<<n_waves, 64, 0, s>>>(A, C)));
+  if (poa4_racon_scores(A)) {
+    RVN_KLAUNCH_ON(kKPoaRows, s, (poa4_persistent_kernel<kUpdPer, Poa4ScoresRacon><<<n_waves, 64, 0, s>>>(A, C)));
+  } else {
+    RVN_KLAUNCH_ON(kKPoaRows, s, (poa4_persistent_kernel<kUpdPer, Poa4ScoresAny><<<n_waves, 64, 0, s>>>(A, C)));
+  }
 }
 
 #ifdef RVN_TEST_HOOKS
@@ -2177,8 +2307,14 @@ void emu_entry4(void* p) {
   switch (c->phase) {
     case 0: poa4_phase_init(*c->A, *c->C, c->wave); break;
     case 1: poa4_phase_graph<P4, kUpdPer>(*c->A, *c->C, *c->SG, c->wave); break;
-    case 2: poa4_phase_nw<P4>(*c->A, *c->C, *c->SN, c->wave); break;
-    case 9: poa4_persistent<P4, kUpdPer>(*c->A, *c->C, *c->SA, c->wave); break;
+    case 2:
+      if (poa4_racon_scores(*c->A)) poa4_phase_nw<P4, Poa4ScoresRacon>(*c->A, *c->C, *c->SN, c->wave);
+      else poa4_phase_nw<P4, Poa4ScoresAny>(*c->A, *c->C, *c->SN, c->wave);
+      break;
+    case 9:
+      if (poa4_racon_scores(*c->A)) poa4_persistent<P4, kUpdPer, Poa4ScoresRacon>(*c->A, *c->C, *c->SA, c->wave);
+      else poa4_persistent<P4, kUpdPer, Poa4ScoresAny>(*c->A, *c->C, *c->SA, c->wave);
+      break;
     default: poa4_phase_final(*c->A, *c->C, *c->S, c->wave); break;
   }
 }

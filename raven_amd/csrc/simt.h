@@ -30,7 +30,7 @@ namespace sv {
 #define RVN_SV_SITE
 #define RVN_SV_SITE_ARG
 __device__ __forceinline__ int lane() { return static_cast<int>(threadIdx.x & 63); }
-__device__ __forceinline__ unsigned long long ballot(bool p) { return __ballot(p); }
+__device__ __forceinline__ unsigned long long ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 __device__ __forceinline__ int bperm(int v, int src_lane) { return __builtin_amdgcn_ds_bpermute(src_lane << 2, v); }
 __device__ __forceinline__ int rl(int v, int src_lane) { return __builtin_amdgcn_readlane(v, src_lane); }
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }

@@ -24,20 +24,67 @@ def test_no_vector_memory_wait_inside_an_nw_step(tmp_path):
                         os.path.join(ROOT, "raven_amd", "csrc", "poa4.hip"), "-I", os.path.join(ROOT, "include"), "-o", str(out)],
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
-    steps, cur = [], None
-    for line in out.read_text().split("\n"):
+    text = out.read_text()
+    # two instances of the kernel (racon's default scores as literals / scores read from the batch): both are checked
+    assert text.count("s_endpgm") == 2
+    steps, cur, rare = [], None, 0
+    for line in text.split("\n"):
         if "P4MARK step_begin" in line:
-            cur = []
+            if cur is not None:  # (block placement moved this step's tail elsewhere: what lies between the markers is checked)
+                steps.append(cur)
+            cur, rare = [], 0
         elif "P4MARK step_end" in line and cur is not None:
             steps.append(cur)
             cur = None
+        elif "P4MARK rare_begin" in line:
+            rare += 1
+        elif "P4MARK rare_end" in line:
+            rare -= 1
         elif cur is not None:
             t = line.strip()
             if t and not t.startswith((";", ".")):
-                cur.append(t)
-    assert len(steps) == 8, len(steps)  # the loop is unrolled over the 8 steps between two service points
+                cur.append((t, rare > 0))
+    if cur is not None:
+        steps.append(cur)
+    # (the loop is laid out rotated: the last step's tail precedes the service point in the text, and what follows its head
+    # is other code — a step that no end marker closed is cut where its common path ends, at the store of the row's cells)
+    for i, ins in enumerate(steps):
+        k = [j for j, (t, r) in enumerate(ins) if t.startswith("ds_write_b32") and not r]
+        if len(ins) > 150 and k:
+            steps[i] = ins[:k[0] + 1]
+    assert len(steps) == 16, len(steps)  # per instance: the loop is unrolled over the 8 steps between two service points
+    common = []
     for ins in steps:
-        waits = [t for t in ins if re.match(r"s_waitcnt\s+vmcnt", t)]
+        waits = [t for t, _ in ins if re.match(r"s_waitcnt\s+vmcnt", t)]
         assert not waits, waits
-        assert not [t for t in ins if "scratch_" in t]            # no spill traffic in a step either
-        assert len([t for t in ins if t.startswith("ds_")]) <= 10  # 4 + 4 in-edge reads, the end-node read, the own row's store
+        assert not [t for t, _ in ins if "scratch_" in t]            # no spill traffic in a step either
+        assert not [t for t, _ in ins if t.startswith(("global_", "flat_", "buffer_"))]  # nor any other vector-memory access
+        main = [t for t, r in ins if not r]
+        # the common path: 4 in-edge reads, the next step's row words (b128 + b32), the own row's store
+        assert len([t for t in main if t.startswith("ds_")]) <= 7, main
+        common.append(len([t for t in main if t.startswith("v_")]))
+    # round 5's step was ~88 vector instructions; the compiler moves a few address computations across the step markers,
+    # so the bound is on the average
+    assert sum(common) / len(common) <= 52, common
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="no hipcc")
+def test_the_nw_loop_waits_for_vector_memory_only_where_nothing_recent_is_outstanding(tmp_path):
+    """Between two blocks of eight steps (the service point) the order is: wait for the descriptor fetched eight steps ago ->
+    park it in LDS -> fetch the next -> store the backpointers.  A vector-memory wait BEHIND the store (round 6 measured it:
+    269 of 902 cycles per step) would wait for a write issued a moment ago."""
+    out = tmp_path / "poa4.s"
+    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-function", "--cuda-device-only", "-S",
+                        os.path.join(ROOT, "raven_amd", "csrc", "poa4.hip"), "-I", os.path.join(ROOT, "include"), "-o", str(out)],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = out.read_text().split("\n")
+    firsts = [i for i, l in enumerate(lines) if "P4MARK step_begin" in l][::8]
+    assert len(firsts) == 2
+    for first in firsts:
+        # walk back from the first step of the block to the backpointer store: no vector-memory wait in between
+        j = first
+        while j > 0 and "global_store_dwordx2" not in lines[j]:
+            assert not re.match(r"\s*s_waitcnt\s+vmcnt", lines[j]), (j, lines[j])
+            j -= 1
+        assert first - j < 60, "the backpointer store is the last vector-memory instruction of the service point"
