@@ -425,17 +425,21 @@ int rvn_group_peer_access(const rvn_group* g, uint8_t* direct);
 int rvn_overlap_update_and_type(rvn_overlap* overlaps, uint64_t n, const uint32_t* pile_begin, const uint32_t* pile_end,
                                 const uint8_t* pile_invalid, uint32_t n_piles, uint8_t* ok, uint32_t* type);
 
-/* Tuning a deployment may set; 0 restores the built-in default, no option changes a result.  The product library reads
+/* Tuning a deployment may set; -1 restores the built-in default of any option (so does 0, except for poa_rows_min_windows).
+ * No option changes an overlap list, a pile or a layer table; poa_rows_min_windows chooses which window-consensus kernel
+ * makes the first attempt, and the two agree on 19 998 of 20 000 C4-like windows, not on every one: a
+ * consensus is reproducible for a fixed value of that option, not across values.  The product library reads
  * NO environment variable that alters what a call computes or how it is scheduled (the only ones it reads at all:
  * RVN_EDLIB_DEVICE of the edlibAlign drop-in, RVN_DEVICES of include/raven_hip/multi_gpu.hpp — which device); debugging
  * switches exist only in libraven_hip_test.so (built with -DRVN_DEBUG_KNOBS).  Options:
  *   nw_budget_mb       alignment-path stage: HBM for the stored band words (default: a quarter of the free memory, <= 64 GB)
  *   poa_rows_min_windows  window-consensus stage: smallest batch that starts with the rows-on-lanes kernel (default 20 000;
- *                      this option has no "0 = default": 0 means every batch)
+ *                      0 means every batch, -1 the default)
  *   io_threads, io_slab_mb, io_ring, io_zlib   rvn_reads_load: inflate threads, page-locked slab size, slabs in flight,
  *                      != 0: zlib instead of this library's own inflate on a single gzip member
  *   arena_mb, arena_margin_mb, no_arena, release_always   the device arena behind the scratch buffers
- * previous (may be NULL) receives the value the option had.  RVN_EINVAL: unknown name or negative value. */
+ * previous (may be NULL) receives the value the option had (its default's value when it was at the default).  RVN_EINVAL:
+ * unknown name, a value below -1, io_ring == 1 (a ring needs two slabs). */
 int rvn_engine_set_option(rvn_engine* e, const char* name, int64_t value, int64_t* previous);
 
 /* Kept for source compatibility: a round no longer has a host cutting stage to overlap with the POA, all windows

@@ -259,6 +259,8 @@ constexpr u64 kQueryFlag = 1ULL << 63;
 // runs, but they are no members: they do not count towards a key's occurrence and are nobody's match.  Their reads have
 // smaller ids than every member's, and the sort is stable, so they are the FRONT of their run.
 constexpr u64 kForeignFlag = 1ULL << 62;
+constexpr u32 kMaxReadId = 1u << 30;                  // read ids are 30 bits: bits 63 / 62 of an origin word are the two flags
+constexpr u64 kForeignPieceBases = 1ULL << 31;        // a query-only (foreign) sketch is taken in pieces of at most this many bases
 __host__ __device__ inline u32 origin_id(u64 org) { return static_cast<u32>(org >> 32) & 0x3FFFFFFFu; }
 // number of foreign entries at the front of the run [s, s + c) of a sorted origin array (binary search: the flag is
 // monotone within a run)

@@ -134,6 +134,8 @@ struct Engine {
   DevBuf tmp_a, tmp_b, tmp_c, tmp_d, tmp_e, tmp_f, scan_tmp, sort_tmp;
   DevBuf sh_hist, sh_off, sh_ptrs;  // shard.hip: tile histograms / offsets / pointer tables of the partition steps
   DevBuf q_start, q_cnt, m_off;
+  DevBuf foreign_val, foreign_org;  // a query-only sketch appended from its pieces (rvn_shard_sketch_range)
+  DevBuf sketch_sum;  // 64-bit total of a sketch whose 32-bit offsets could wrap (sketch.hip)
   DevBuf m_grp[2], m_pos[2];
   DevBuf seg_off, iv_slot_begin, iv_slot_end, iv_cnt, iv_off, iv_begin, iv_end;
   DevBuf lis_min, lis_pred, lis_tail, lis_mask, ovl_slots, ovl_flags, ovl_scan, chain_big;

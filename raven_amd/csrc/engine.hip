@@ -485,9 +485,9 @@ int rvn_reads_upload(rvn_engine* h, const uint64_t* packed, uint64_t n_words, co
     r.ids_are_indices = true;
     for (u32 i = 0; i < n; ++i) {
       r.h_id[i] = ids ? ids[i] : i;
-      if (r.h_id[i] != i || i >= (1u << 30)) r.ids_are_indices = false;
+      if (r.h_id[i] != i || i >= kMaxReadId) r.ids_are_indices = false;
       // (bits 63 / 62 of a minimizer's origin word are the query / query-only flags: 30 bits of read id are left)
-      if (r.h_id[i] >= (1u << 30)) return fail(RVN_EINVAL, "[raven_hip] read ids must be below 2^30");
+      if (r.h_id[i] >= kMaxReadId) return fail(RVN_EINVAL, "[raven_hip] read ids must be below 2^30");
     }
     r.total_bases = 0;
     for (u32 i = 0; i < n; ++i) {
@@ -555,8 +555,8 @@ int rvn_reads_upload_codes(rvn_engine* h, const uint8_t* codes, const uint64_t* 
     r.total_bases = n_codes;
     for (u32 i = 0; i < n; ++i) {
       r.h_id[i] = ids ? ids[i] : i;
-      if (r.h_id[i] != i || i >= (1u << 31)) r.ids_are_indices = false;
-      if (r.h_id[i] >= (1u << 31)) return fail(RVN_EINVAL, "[raven_hip] read ids must be below 2^31");
+      if (r.h_id[i] != i || i >= kMaxReadId) r.ids_are_indices = false;
+      if (r.h_id[i] >= kMaxReadId) return fail(RVN_EINVAL, "[raven_hip] read ids must be below 2^30");  // (bit 62 of an origin word is kForeignFlag: ADVICE r05)
     }
     r.n_words = n_words;
     u64* d_wo = r.word_off.get<u64>(static_cast<size_t>(n) + 1);
@@ -1288,19 +1288,65 @@ int rvn_shard_sketch_range(rvn_engine* h, const rvn_reads* rr, uint32_t first, u
       t.stop();
       return RVN_OK;
     }
-    sketch_raw(e, r, first, last, e.raw_sketch);
     if (foreign) {
       // reads of an EARLIER index batch: only what Map() would look up for them — their minhash-selected minimizers — as
-      // query-only entries
-      sketch_minhash(e, r, e.raw_sketch, e.index_sketch);
+      // query-only entries.  The prefix [0, f_hi) of a late batch has no bound of its own (>= 12.9 Gbases at w = 5
+      // are >= 2^32 raw minimizers, and the sketch's offsets are 32-bit), so it is sketched in pieces of <= kForeignPieceBases
+      // and the minhash-selected entries (at most len / k per read) are appended: what comes out is bounded by its own
+      // count only, which the index build checks against 2^32 (index.hip).
+      u64 piece_bases = kForeignPieceBases;
+#if defined(RVN_DEBUG_KNOBS)
+      if (const char* pb = knob("RVN_FOREIGN_PIECE_BASES")) piece_bases = std::strtoull(pb, nullptr, 10);  // (tests: several pieces on a small set)
+#endif
+      std::vector<u32> cuts{first};
+      u64 acc = 0, bound = 0;
+      for (u32 i = first; i < last; ++i) {
+        if (acc && acc + r.h_len[i] > piece_bases) {
+          cuts.push_back(i);
+          acc = 0;
+        }
+        acc += r.h_len[i];
+        bound += r.h_len[i] / static_cast<u32>(e.k) + 1;
+      }
+      cuts.push_back(last);
+      if (cuts.size() == 2) {
+        sketch_raw(e, r, first, last, e.raw_sketch);
+        sketch_minhash(e, r, e.raw_sketch, e.index_sketch);
+      } else {
+        const size_t vb = e.val64 ? 8 : 4;
+        unsigned char* av = e.foreign_val.get<unsigned char>((bound + 1) * vb);
+        u64* ao = e.foreign_org.get<u64>(bound + 1);
+        u64 n_acc = 0;
+        for (size_t c = 0; c + 1 < cuts.size(); ++c) {
+          sketch_raw(e, r, cuts[c], cuts[c + 1], e.raw_sketch);
+          sketch_minhash(e, r, e.raw_sketch, e.index_sketch);
+          const u64 n = e.index_sketch.count;
+          if (n_acc + n > bound) throw HipError("[raven_hip] rvn_shard_sketch_range: more selected minimizers than len / k per read");
+          if (n) {
+            RVN_HIP(hipMemcpyAsync(av + n_acc * vb, e.index_sketch.val.ptr, n * vb, hipMemcpyDeviceToDevice, e.stream));
+            RVN_HIP(hipMemcpyAsync(ao + n_acc, e.index_sketch.org.ptr, n * 8, hipMemcpyDeviceToDevice, e.stream));
+          }
+          n_acc += n;
+        }
+        RVN_HIP(rvn_stream_sync(e.stream));
+        std::swap(e.index_sketch.val.ptr, e.foreign_val.ptr);
+        std::swap(e.index_sketch.val.cap, e.foreign_val.cap);
+        std::swap(e.index_sketch.org.ptr, e.foreign_org.ptr);
+        std::swap(e.index_sketch.org.cap, e.foreign_org.cap);
+        e.index_sketch.first = first;
+        e.index_sketch.last = last;
+        e.index_sketch.count = n_acc;  // (read_off of the pieces is not kept: nothing downstream of a query-only sketch reads it)
+      }
       const u64 n = e.index_sketch.count;
       if (n) {
         or_flags_kernel<<<static_cast<u32>((n + 255) / 256), 256, 0, e.stream>>>(e.index_sketch.org.as<u64>(), n, kQueryFlag | kForeignFlag);
         RVN_LAUNCH_CHECK();
       }
     } else if (index_minhash) {
+      sketch_raw(e, r, first, last, e.raw_sketch);
       sketch_minhash(e, r, e.raw_sketch, e.index_sketch);
     } else {
+      sketch_raw(e, r, first, last, e.raw_sketch);
       e.join_query_count = sketch_flag_queries(e, r, e.raw_sketch);  // minhash-selected entries get kQueryFlag
     }
     *count = res.count;
@@ -1800,12 +1846,17 @@ int rvn_shard_piles_merge_parts_dev(rvn_pass1* p, uint32_t n_parts, const rvn_ov
 int rvn_engine_set_option(rvn_engine* h, const char* name, int64_t value, int64_t* previous) {
   if (!h) return fail(RVN_EINVAL, "[raven_hip] rvn_engine_set_option: engine == NULL");
   long long* slot = engine_option(h->e.opt, name);
-  if (!slot || value < 0)
-    return fail(RVN_EINVAL, std::string("[raven_hip] rvn_engine_set_option: unknown option or negative value (options: ") +
+  // -1 = "the built-in default" for every option (the one way to get poa_rows_min_windows' default back: its 0 means
+  // "every batch"); any other negative value is refused
+  if (!slot || value < -1)
+    return fail(RVN_EINVAL, std::string("[raven_hip] rvn_engine_set_option: unknown option or value below -1 (options: ") +
                                 engine_option_names() + ")");
+  const bool is_rows = slot == &h->e.opt.poa_rows_min_windows;
+  if (slot == &h->e.opt.io_ring && value == 1)
+    return fail(RVN_EINVAL, "[raven_hip] rvn_engine_set_option: io_ring needs at least 2 slabs in flight (0 or -1: the default)");
   std::lock_guard<std::recursive_mutex> lk(h->e.mu);
   if (previous) *previous = *slot < 0 ? 20000 : *slot;  // (only poa_rows_min_windows starts below zero: its default)
-  *slot = value;
+  *slot = value == -1 ? (is_rows ? -1 : 0) : value;
   return RVN_OK;
 }
 
@@ -1895,7 +1946,9 @@ int rvn_engine_index_fetch(rvn_engine* h, uint64_t* values, uint64_t* origins) {
     fetch_values(e, ix.s_val[ix.cur], ix.m, values);
     if (origins && ix.m) {
       RVN_HIP(hipMemcpy(origins, ix.s_org[ix.cur].ptr, ix.m * 8, hipMemcpyDeviceToHost));
-      for (u64 i = 0; i < ix.m; ++i) origins[i] &= ~kQueryFlag;
+      // (both flag bits: after a multi-batch shard build the index also holds query-only entries of earlier batches'
+      // reads — they come back as plain id << 32 | pos << 1 | strand like the members)
+      for (u64 i = 0; i < ix.m; ++i) origins[i] &= ~(kQueryFlag | kForeignFlag);
     }
     return RVN_OK;
   });

@@ -220,13 +220,27 @@ void nw_breakpoints(Engine& e, const ReadsDev& T, const ReadsDev& Rd, std::vecto
     // is created at the highest priority, which also suits a kernel of 38 latency-bound waves.
     int prio_least = 0, prio_greatest = 0;
     RVN_HIP(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
-    for (int b = 0; b < 4; ++b) {
-      if (b == 3 && prio_greatest != prio_least)
-        RVN_HIP(hipStreamCreateWithPriority(&e.nw_streams[b], hipStreamNonBlocking, prio_greatest));
-      else
-        RVN_HIP(hipStreamCreateWithFlags(&e.nw_streams[b], hipStreamNonBlocking));
+    // created into locals and handed to the engine only when all exist: a creation that throws half-way must not leave
+    // nw_streams[0] set with the others null — the next call would skip this block and launch walks on the null stream
+    hipStream_t made[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t made_ev[sizeof(e.nw_ev) / sizeof(e.nw_ev[0])] = {};
+    try {
+      for (int b = 0; b < 4; ++b) {
+        if (b == 3 && prio_greatest != prio_least)
+          RVN_HIP(hipStreamCreateWithPriority(&made[b], hipStreamNonBlocking, prio_greatest));
+        else
+          RVN_HIP(hipStreamCreateWithFlags(&made[b], hipStreamNonBlocking));
+      }
+      for (hipEvent_t& ev : made_ev) RVN_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    } catch (...) {
+      for (hipStream_t st2 : made)
+        if (st2) (void)hipStreamDestroy(st2);
+      for (hipEvent_t ev : made_ev)
+        if (ev) (void)hipEventDestroy(ev);
+      throw;
     }
-    for (hipEvent_t& ev : e.nw_ev) RVN_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    for (int b = 0; b < 4; ++b) e.nw_streams[b] = made[b];
+    for (size_t i = 0; i < sizeof(e.nw_ev) / sizeof(e.nw_ev[0]); ++i) e.nw_ev[i] = made_ev[i];
   }
   // an error in the middle of a pass (a walk that left its band, an allocation that failed) must not leave walks running
   // on the side streams against buffers the next call hands out again
@@ -392,6 +406,7 @@ void nw_breakpoints(Engine& e, const ReadsDev& T, const ReadsDev& Rd, std::vecto
       RVN_HIP(hipMemcpyAsync(d_idx, order.data(), order.size() * 4, hipMemcpyHostToDevice, s));
       RVN_HIP(rvn_stream_sync(s));  // `jobs` / `order` are pageable: the copies must be done before the host goes on
       h_up += since(t_h);
+      bool set_used[4] = {false, false, false, false};  // a walk of THIS pass has been queued on the buffer set
       for (size_t ci = 0; ci < chunks.size(); ++ci) {
         const Chunk& C = chunks[ci];
         const int b = set_of(ci);
@@ -399,7 +414,10 @@ void nw_breakpoints(Engine& e, const ReadsDev& T, const ReadsDev& Rd, std::vecto
         NwPm* ck = ck_buf[b]->as<NwPm>();
         const u32* idx_c = d_idx + C.c0;
         const u32 cn = static_cast<u32>(C.c1 - C.c0);
-        if (ci >= 4) RVN_HIP(hipStreamWaitEvent(s, e.nw_ev[b], 0));  // the walk of chunk ci - 3 is done with this buffer set
+        // the walk that used this buffer set before — chunk ci - 3 of the rotating sets (set_of: chunk 0 -> set 3, chunk ci ->
+        // set (ci - 1) % 3) — is done with it
+        if (set_used[b]) RVN_HIP(hipStreamWaitEvent(s, e.nw_ev[b], 0));
+        set_used[b] = true;
         auto count_of = [&](u32 x) -> u32 {  // classes are laid out from the widest variant down
           const u32 next_off = x == 0 ? cn : C.coff[x - 1];
           return next_off - C.coff[x];

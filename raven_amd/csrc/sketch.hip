@@ -12,6 +12,9 @@
 //   * compaction in position order by wave ballots.
 // Two passes (count, scan, write) recompute the hashes instead of spilling a worst-case buffer:
 // HBM traffic is N/4 bytes read per pass + 12|16 B per emitted minimizer.
+#include <stdexcept>
+#include <string>
+
 #include "engine.h"
 #include "kmer.h"
 #include "wave.h"
@@ -256,6 +259,13 @@ __global__ void compact_sketch_kernel(const V* __restrict__ val, const u64* __re
   }
 }
 
+__global__ void sum_u32_kernel(const u32* __restrict__ v, u32 n, unsigned long long* __restrict__ out) {
+  unsigned long long acc = 0;
+  for (u64 i = static_cast<u64>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += static_cast<u64>(gridDim.x) * blockDim.x) acc += v[i];
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+  if ((threadIdx.x & 63) == 0 && acc) atomicAdd(out, acc);
+}
+
 template <typename V>
 void sketch_raw_impl(Engine& e, const ReadsDev& r, u32 first, u32 last, Sketch& out) {
   hipStream_t s = e.stream;
@@ -278,6 +288,24 @@ void sketch_raw_impl(Engine& e, const ReadsDev& r, u32 first, u32 last, Sketch& 
                                  r.packed.as<u64>(), r.word_off.as<u64>(), r.len.as<u32>(), r.id.as<u32>(),
                                  r.tile_read.as<u32>(), r.tile_start.as<u32>(), tf, e.k, e.w, tile_cnt, nullptr,
                                  nullptr, nullptr));
+  // The scan of the tile counts is 32-bit (offsets into one sketch are u32 everywhere downstream).  A tile holds at most
+  // kSketchTile minimizers, so fewer than 2^32 / kSketchTile tiles cannot wrap; a larger range (>= 4.3 G k-mer positions)
+  // gets its total summed in 64 bits first and is refused when it does not fit (the foreign prefix of a late
+  // index batch reaches that regime before any other sketch does — rvn_shard_sketch_range cuts it into bounded pieces)
+  u64 limit = 1ULL << 32;
+#if defined(RVN_DEBUG_KNOBS)
+  if (const char* lim = knob("RVN_SKETCH_LIMIT")) limit = std::strtoull(lim, nullptr, 10);  // (tests: the refusal without 13 Gbases)
+#endif
+  if (static_cast<u64>(nt) * kSketchTile >= limit) {
+    unsigned long long* d_sum = e.sketch_sum.get<unsigned long long>(1);
+    RVN_HIP(hipMemsetAsync(d_sum, 0, 8, s));
+    sum_u32_kernel<<<std::min<u32>(div_up(nt, 1024), 4096), 256, 0, s>>>(tile_cnt, nt, d_sum);
+    RVN_LAUNCH_CHECK();
+    const u64 sum = read_back(e, d_sum, 8);
+    if (sum >= limit)
+      throw std::invalid_argument("[raven_hip] a sketch of " + std::to_string(sum) + " minimizers in one call (reads " + std::to_string(first) +
+                                  " .. " + std::to_string(last) + "): 2^32 or more are not supported — sketch the range in pieces");
+  }
   exclusive_scan_u32_u32(tile_cnt, tile_off, nt, e.scan_tmp, s);
   const u32 total = static_cast<u32>(read_back(e, tile_off + nt, 4));
   V* val = out.val.get<V>(static_cast<size_t>(total) + 1);

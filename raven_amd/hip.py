@@ -887,8 +887,9 @@ class Engine:
         return int(lib().rvn_polish_set_chunk_windows(self._h, int(windows)))
 
     def set_option(self, name, value):
-        """rvn_engine_set_option: a tuning option (include/raven_hip.h lists them; 0 = built-in default); returns the
-        previous value.  Unknown names raise."""
+        """rvn_engine_set_option: a tuning option (include/raven_hip.h lists them; -1 = built-in default, and so is 0 for
+        every option but poa_rows_min_windows, whose 0 means "every batch" and selects another first kernel: consensus is
+        reproducible per value of that option, not across values); returns the previous value.  Unknown names raise."""
         prev = C.c_int64(0)
         L = lib()
         L.rvn_engine_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64, C.c_void_p]

@@ -203,7 +203,8 @@ def test_rows_on_lanes_kernel_equals_one_row_per_iteration_kernel():
     try:
         c0, s0, _ = eng.poa_consensus_batch(wins)
     finally:
-        eng.set_option("poa_rows_min_windows", 20000)
+        assert eng.set_option("poa_rows_min_windows", -1) == 0  # (-1: the built-in default, whatever it is)
+        assert eng.set_option("poa_rows_min_windows", -1) == 20000
     assert np.array_equal(s0 & 0xFF, s2 & 0xFF)
     for a, b in zip(c0, c2):
         assert np.array_equal(a, b)

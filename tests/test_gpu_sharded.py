@@ -333,3 +333,55 @@ def test_partition_and_regroup_kernels_equal_the_host_formulas(world):
     torch.cuda.synchronize()
     eng.shard_adjacent_diff_dev(seg_o.data_ptr(), nr, cnt_o.data_ptr())
     assert np.array_equal(cnt_o.cpu().numpy(), np.diff(seg_w.astype(np.int64)))
+
+
+_FOREIGN_PIECES = r"""
+import os, sys, json
+import numpy as np
+from raven_amd import hip, synth
+g = synth.make_genome(120_000, seed=31)
+rs, _ = synth.make_reads(g, 12, 4000, seed=32)
+eng = hip.Engine(15, 5)
+own = eng.upload(rs)
+n = own.n
+def foreign():
+    k = eng.shard_sketch_range_count(own, 0, n, True, foreign=True)
+    v, o = eng.shard_sketch_fetch(k)
+    return np.array(v), np.array(o)
+v1, o1 = foreign()
+os.environ["RVN_FOREIGN_PIECE_BASES"] = "150000"      # ~10 pieces of this read set
+v2, o2 = foreign()
+del os.environ["RVN_FOREIGN_PIECE_BASES"]
+same = bool(np.array_equal(v1, v2) and np.array_equal(o1, o2))
+flags = bool(len(o1) and np.all((o1 >> np.uint64(62)) == 3))
+os.environ["RVN_SKETCH_LIMIT"] = "1000"               # what 2^32 is to a 13-Gbase range
+err = ""
+try:
+    eng.shard_sketch_range_count(own, 0, n, False, foreign=False)
+except ValueError as ex:
+    err = str(ex)
+del os.environ["RVN_SKETCH_LIMIT"]
+k = eng.shard_sketch_range_count(own, 0, n, False, foreign=False)   # the engine is usable after the refusal
+print(json.dumps({"same": same, "flags": flags, "n": int(len(o1)), "err": err, "after": int(k)}))
+"""
+
+
+@pytest.mark.gpu
+def test_query_only_sketch_in_pieces_and_the_refusal_of_a_sketch_beyond_32_bit_offsets(tmp_path):
+    """the reads of earlier index batches are sketched as ONE range per batch, whose raw minimizers have no bound
+    (>= 2^32 from ~12.9 Gbases at w = 5: the sketch's 32-bit offsets would wrap silently).  rvn_shard_sketch_range takes the
+    query-only range in base-bounded pieces and appends the selected entries — identical to the one-piece result — and a
+    sketch whose total would not fit is refused with RVN_EINVAL, not computed modulo 2^32.  Debug library: the piece size and
+    the limit are lowered by environment switches that exist only there."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "raven_amd", "lib", "libraven_hip_test.so")
+    env = dict(os.environ, RVN_LIB_PATH=lib, PYTHONPATH=root)
+    r = subprocess.run([sys.executable, "-c", _FOREIGN_PIECES], capture_output=True, text=True, env=env, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.split("\n") if l.startswith("{")][-1])
+    assert d["same"] and d["flags"] and d["n"] > 1000, d
+    assert "2^32" in d["err"] and "pieces" in d["err"], d
+    assert d["after"] > 1000, d

@@ -49,8 +49,14 @@ for l in sys.stdin:
        extra="--no-cpu-baseline"; [ "$arg" = "c4" ] && extra=""
        timeout 1500 python bench.py --workload $arg $extra > $f 2> ${f%.json}.err; summ $f;;
     smoke) timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3;;
-    parity) timeout 1200 python tools/poa_parity.py $arg > gpurun_out/${TAG}_poa_parity_$arg.json 2> gpurun_out/${TAG}_poa_parity.err; python -c "
-import json; d = json.load(open('gpurun_out/${TAG}_poa_parity_$arg.json')); print({k: v for k, v in d.items() if k not in ('examples', 'not_explained')}, 'unexplained', len(d['not_explained']))";;
+    parity) n=${arg%%/*}; shape=ont; [ "$arg" != "$n" ] && shape=${arg#*/}   # parity:20000 or parity:20000/qual
+       f=gpurun_out/${TAG}_poa_parity_${shape}_$n.json
+       timeout 1200 python tools/poa_parity.py $n 0 0 $shape > $f 2> gpurun_out/${TAG}_poa_parity.err; python -c "
+import json; d = json.load(open('$f')); print({k: v for k, v in d.items() if k not in ('examples', 'not_explained')}, 'unexplained', len(d['not_explained']))";;
+    polishparity) n=${arg%%/*}; shape=q10; [ "$arg" != "$n" ] && shape=${arg#*/}   # polishparity:200/q10 (contigs of 100 windows)
+       f=gpurun_out/${TAG}_polish_parity_${shape}_$n.json
+       timeout 1500 python tools/polish_parity.py $n 0 $shape > $f 2> gpurun_out/${TAG}_polish_parity.err; python -c "
+import json; d = json.load(open('$f')); print({k: v for k, v in d.items() if k != 'different'})";;
     profile) bash tools/profile_round.sh $arg
        # (a bench-full step later in the same call reads the traffic file from profiles/: without this its line says stale)
        for f in pmc_traffic.json pmc_calibration.json kernel_stats.csv bench_under_rocprof.json; do [ -f gpurun_out/${arg}_$f ] && cp gpurun_out/${arg}_$f profiles/; done;;
