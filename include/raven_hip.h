@@ -438,6 +438,10 @@ int rvn_overlap_update_and_type(rvn_overlap* overlaps, uint64_t n, const uint32_
  *   io_threads, io_slab_mb, io_ring, io_zlib   rvn_reads_load: inflate threads, page-locked slab size, slabs in flight,
  *                      != 0: zlib instead of this library's own inflate on a single gzip member
  *   arena_mb, arena_margin_mb, no_arena, release_always   the device arena behind the scratch buffers
+ *   polish_sketch_cache_mb  polishing rounds: HBM for the reads' sketch kept from one round to the next (the reads do not change
+ *                      between rounds; default an eighth of the device, 0 = recompute every round)
+ *   polish_join        != 0: a round maps by sorting the reads' minimizers with the targets' and streaming the runs instead of
+ *                      probing the targets' index — same overlaps, slower at the metric's size
  * previous (may be NULL) receives the value the option had (its default's value when it was at the default).  RVN_EINVAL:
  * unknown name, a value below -1, io_ring == 1 (a ring needs two slabs). */
 int rvn_engine_set_option(rvn_engine* e, const char* name, int64_t value, int64_t* previous);

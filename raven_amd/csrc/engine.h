@@ -2,6 +2,7 @@
 #pragma once
 
 #include <string>
+#include <atomic>
 #include <memory>
 #include <mutex>
 #include <vector>
@@ -15,6 +16,11 @@ constexpr int kMaxWindow = 256;    // largest supported winnowing window w
 
 // Device-resident read set: concatenated 2-bit packed words (every read starts on a word
 // boundary, one pad word at the end), per-read word offsets / lengths / ids.
+inline u64 next_reads_serial() {
+  static std::atomic<u64> counter{0};
+  return ++counter;
+}
+
 struct ReadsDev {
   u32 n = 0;
   u64 total_bases = 0;
@@ -30,6 +36,7 @@ struct ReadsDev {
   DevBuf quals, qual_off;
   std::vector<u64> h_qual_off;
   int qual_shift = -1;  // -1: none attached
+  u64 serial = next_reads_serial();  // unique per read set of the process (what a cache of derived data is keyed by)
   bool ids_are_indices = false;  // ids[i] == i and all < 2^31 (needed by the pass-1 merge and the self-join)
   // sketch tiles for the owning engine's (k, w)
   u32 n_tiles = 0;
@@ -105,6 +112,9 @@ struct EngineOptions {
   long long arena_margin_mb = 0;     // ... memory left to the driver (default max(12 GB, 1/16 of the device))
   long long no_arena = 0;            // ... != 0: never start one
   long long release_always = 0;      // != 0: every stage entry hands the scratch back (the tests of that path)
+  long long polish_join = 0;         // != 0: a polishing round maps by sorting the reads' minimizers with the targets' and streaming
+                                     // the runs instead of probing the targets' index (round 6: built, bit-identical, slower — DESIGN.md 3.7)
+  long long polish_sketch_cache_mb = -1;  // HBM for the reads' sketch kept between polishing rounds (< 0: an eighth of the device; 0: none)
 };
 const char* engine_option_names();   // comma-separated, for the error message
 long long* engine_option(EngineOptions& o, const char* name);
@@ -134,6 +144,15 @@ struct Engine {
   DevBuf tmp_a, tmp_b, tmp_c, tmp_d, tmp_e, tmp_f, scan_tmp, sort_tmp;
   DevBuf sh_hist, sh_off, sh_ptrs;  // shard.hip: tile histograms / offsets / pointer tables of the partition steps
   DevBuf q_start, q_cnt, m_off;
+  // the reads' sketch of a polishing round's mapping, kept for the next round (the reads do not change between rounds; only
+  // the targets do): per read batch, for ONE read set at a time (`owner` = ReadsDev::serial)
+  struct PolishSketch {
+    u32 first = 0, last = 0;
+    Sketch sk;
+  };
+  u64 polish_sketch_owner = 0;
+  std::vector<std::unique_ptr<PolishSketch>> polish_sketches;
+  DevBuf pl_tval, pl_torg;          // the targets' minimizers of a polishing round, appended to every read batch's (polish.hip)
   DevBuf foreign_val, foreign_org;  // a query-only sketch appended from its pieces (rvn_shard_sketch_range)
   DevBuf sketch_sum;  // 64-bit total of a sketch whose 32-bit offsets could wrap (sketch.hip)
   DevBuf m_grp[2], m_pos[2];
@@ -256,6 +275,7 @@ void map_batch(Engine& e, const ReadsDev& r, u32 first, u32 last, bool avoid_equ
                bool minhash, bool want_filtered, MapOut& out);
 
 // self-join of the index for global query ids 0..n_reads-1 -> e.m_grp[0] / e.m_pos[0] / e.seg_off (map.hip)
+void map_batch_query_only(Engine& e, const ReadsDev& r, u32 first, u32 last, u64 n_query, MapOut& out);
 u64 join_index_matches(Engine& e, u32 n_reads, bool avoid_equal, bool avoid_symmetric, u32 q_lo = 0,
                        u32 q_hi = 0xFFFFFFFFu);  // only query reads with q_lo <= id < q_hi
 // chain stage of Map on matches already in e.m_grp[0] / e.m_pos[0] / e.seg_off (map.hip)

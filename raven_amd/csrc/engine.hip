@@ -314,7 +314,7 @@ void stop() {
 
 const char* engine_option_names() {
   return "nw_budget_mb, poa_rows_min_windows, io_threads, io_slab_mb, io_ring, io_zlib, arena_mb, arena_margin_mb, "
-         "no_arena, release_always";
+         "no_arena, release_always, polish_join, polish_sketch_cache_mb";
 }
 long long* engine_option(EngineOptions& o, const char* name) {
   const std::string n(name ? name : "");
@@ -328,6 +328,8 @@ long long* engine_option(EngineOptions& o, const char* name) {
   if (n == "arena_margin_mb") return &o.arena_margin_mb;
   if (n == "no_arena") return &o.no_arena;
   if (n == "release_always") return &o.release_always;
+  if (n == "polish_join") return &o.polish_join;
+  if (n == "polish_sketch_cache_mb") return &o.polish_sketch_cache_mb;
   return nullptr;
 }
 
@@ -349,6 +351,12 @@ void engine_release_scratch(Engine& e) {
       &e.pl_win_meta, &e.pl_first_window, &e.pl_keys, &e.pl_lays_tmp, &e.pl_lays, &e.pl_wins, &e.pl_out, &e.pl_len,
       &e.pl_status, &e.pl_ok, &e.pl_cons_off, &e.pl_final, &e.pl_qual_off, &e.pl_misc, &e.anc_slot_off, &e.anc_slot_cnt};
   for (DevBuf* b : bufs) b->release();
+  e.polish_sketches.clear();  // (the reads' sketch kept between polishing rounds: derived data, recomputed when needed)
+  e.polish_sketch_owner = 0;
+  e.pl_tval.release();
+  e.pl_torg.release();
+  e.foreign_val.release();
+  e.foreign_org.release();
   e.index.m = e.index.u = 0;
   e.index.table_built = false;
   e.map_out.n_query = e.map_out.n_matches = e.map_out.n_intervals = e.map_out.n_overlaps = 0;
@@ -1855,8 +1863,8 @@ int rvn_engine_set_option(rvn_engine* h, const char* name, int64_t value, int64_
   if (slot == &h->e.opt.io_ring && value == 1)
     return fail(RVN_EINVAL, "[raven_hip] rvn_engine_set_option: io_ring needs at least 2 slabs in flight (0 or -1: the default)");
   std::lock_guard<std::recursive_mutex> lk(h->e.mu);
-  if (previous) *previous = *slot < 0 ? 20000 : *slot;  // (only poa_rows_min_windows starts below zero: its default)
-  *slot = value == -1 ? (is_rows ? -1 : 0) : value;
+  if (previous) *previous = *slot < 0 ? (is_rows ? 20000 : -1) : *slot;  // (the value the default stands for where it has one)
+  *slot = value == -1 ? ((is_rows || slot == &h->e.opt.polish_sketch_cache_mb) ? -1 : 0) : value;
   return RVN_OK;
 }
 

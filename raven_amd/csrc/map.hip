@@ -1135,6 +1135,55 @@ u64 join_index_matches(Engine& e, u32 n_reads, bool avoid_equal, bool avoid_symm
   return H;
 }
 
+// Map() of the reads [first, last) against an index in which their OWN minimizers sit as query-only entries (kQueryFlag |
+// kForeignFlag, ahead of the members of every run: the polishing round's mapping, polish.hip).  One streaming pass over the
+// runs instead of one random probe per query minimizer — what the first pass does when the queries are the indexed reads
+// (join_kernel above), extended to queries that are not members.  n_query: the query-only entries (statistics).
+void map_batch_query_only(Engine& e, const ReadsDev& r, u32 first, u32 last, u64 n_query, MapOut& out) {
+  hipStream_t s = e.stream;
+  Index& ix = e.index;
+  const u32 nr = last - first;
+  out.first = first;
+  out.last = last;
+  out.n_query = n_query;
+  out.n_matches = out.n_intervals = out.n_overlaps = 0;
+  (void)out.ovl_read_off.get<u32>(static_cast<size_t>(nr) + 1);
+  u64* seg_off = e.seg_off.get<u64>(static_cast<size_t>(nr) + 2);
+  u64 H = 0;
+  {
+    StageTimer t(e, StageTimes::kMatch);
+    e.query_ready = false;
+    for (u32 i = first; i < last; ++i) e.c_query_bases += r.h_len[i];
+    e.c_query_min += n_query;
+    u32* read_cnt = e.q_cnt.get<u32>(2 * (static_cast<size_t>(nr) + 1));
+    u32* cursor = read_cnt + nr + 1;
+    RVN_HIP(hipMemsetAsync(read_cnt, 0, 2 * (static_cast<size_t>(nr) + 1) * 4, s));
+    RVN_HIP(hipMemsetAsync(seg_off, 0, (static_cast<size_t>(nr) + 2) * 8, s));
+    const u32 n_runs = static_cast<u32>(ix.u);
+    const u64* sorg = ix.s_org[ix.cur].as<u64>();
+    if (n_runs) {
+      RVN_KLAUNCH(kKJoinCount, join_kernel<false><<<div_up(n_runs, 256), 256, 0, s>>>(
+                                   ix.u_start.as<u32>(), n_runs, sorg, ix.occurrence, 0, 0, 0, r.h_id[first], 0u, 0xFFFFFFFFu,
+                                   read_cnt, nullptr, nullptr, nullptr, nullptr));
+      exclusive_scan_u32_u64(read_cnt, seg_off, nr, e.scan_tmp, s);
+      H = read_back(e, seg_off + nr, 8);
+    }
+    e.c_matches += H;
+    if (H) {
+      u64* g0 = e.m_grp[0].get<u64>(H + 1);
+      u64* p0 = e.m_pos[0].get<u64>(H + 1);
+      e.m_grp[1].reserve((H + 1) * 8);
+      e.m_pos[1].reserve((H + 1) * 8);
+      RVN_KLAUNCH(kKJoinEmit, join_kernel<true><<<div_up(n_runs, 256), 256, 0, s>>>(
+                                  ix.u_start.as<u32>(), n_runs, sorg, ix.occurrence, 0, 0, 0, r.h_id[first], 0u, 0xFFFFFFFFu,
+                                  nullptr, seg_off, cursor, g0, p0));
+    }
+    t.stop();
+  }
+  out.n_matches = H;
+  chain_matches(e, r, first, last, H, out);
+}
+
 void map_batch(Engine& e, const ReadsDev& r, u32 first, u32 last, bool avoid_equal, bool avoid_symmetric,
                bool minhash, bool want_filtered, MapOut& out) {
   if (e.val64) map_batch_impl<u64>(e, r, first, last, avoid_equal, avoid_symmetric, minhash, want_filtered, out);

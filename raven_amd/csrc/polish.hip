@@ -241,6 +241,13 @@ __global__ __launch_bounds__(256) void stitch_kernel(const PoaWindow* __restrict
 // racon), keep the best overlap of every read (longest, error filter `err_thr`; racon Polisher::Initialize).
 // best[i] / best_t[i] describe read r_first + i; best_t == 0xFFFFFFFF: the read is not used.  Reads are independent of
 // each other here, which is what lets the sharded round map a slice per rank and all-gather the (small) table.
+namespace {
+__global__ void flag_origins_kernel(const u64* __restrict__ org, u64 n, u64 flags, u64* __restrict__ out) {
+  const u64 i = static_cast<u64>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = org[i] | flags;
+}
+}  // namespace
+
 void polish_map_best(Engine& e, ReadsDev& T, ReadsDev& R, u32 r_first, u32 r_last, double err_thr,
                      std::vector<Overlap>& best, std::vector<u32>& best_t, u64* n_overlaps) {
   hipStream_t s = e.stream;
@@ -259,8 +266,23 @@ void polish_map_best(Engine& e, ReadsDev& T, ReadsDev& R, u32 r_first, u32 r_las
     sketch_raw(e, T, 0, T.n, e.index_sketch);
     t.stop();
   }
-  index_build(e, e.index_sketch, true);
+  // Option polish_join (round 6; VERDICT r03-r05: the probes' over-fetch — one random binary search + origin gather per read
+  // minimizer, 46-89 GB of cache lines per launch for ~7 GB of data): the reads' minimizers are SORTED WITH the targets' —
+  // query-only entries ahead of the members of every run, as the sharded pass carries the reads of earlier index batches
+  // (kForeignFlag) — and one streaming pass over the runs emits the matches (map_batch_query_only).  The targets' sketch is
+  // kept aside and appended to every read batch's; Filter's cutoff is that of the targets' index alone, computed once, as
+  // racon does.  Bit-identical to the probes and SLOWER at C4 (88 against 59 ms of kernels per round: sorting 1.1 G entries
+  // costs what probing them costs) — hence an option, not the default.
+  const bool joined = R.ids_are_indices && e.opt.polish_join != 0;
+  const u64 t_count = e.index_sketch.count;
+  const size_t vb = e.val64 ? 8 : 4;
+  if (joined && t_count) {
+    RVN_HIP(hipMemcpyAsync(e.pl_tval.get<unsigned char>((t_count + 1) * vb), e.index_sketch.val.ptr, t_count * vb, hipMemcpyDeviceToDevice, s));
+    RVN_HIP(hipMemcpyAsync(e.pl_torg.get<u64>(t_count + 1), e.index_sketch.org.ptr, t_count * 8, hipMemcpyDeviceToDevice, s));
+  }
+  index_build(e, e.index_sketch, !joined);
   index_filter(e, 0.001);
+  const u32 occurrence = e.index.occurrence;
   u32 max_id = 0;
   for (u32 t = 0; t < T.n; ++t) max_id = std::max(max_id, T.h_id[t]);
   {
@@ -270,6 +292,21 @@ void polish_map_best(Engine& e, ReadsDev& T, ReadsDev& R, u32 r_first, u32 r_las
     RVN_HIP(hipMemcpyAsync(d, id_to_t.data(), id_to_t.size() * 4, hipMemcpyHostToDevice, s));
     RVN_HIP(rvn_stream_sync(s));
   }
+  u64 cache_default = 0;
+  {
+    size_t free_b = 0, total_b = 0;
+    RVN_HIP(hipMemGetInfo(&free_b, &total_b));
+    cache_default = total_b / 8;
+  }
+  auto swap_sketch = [](Sketch& a, Sketch& b) {
+    std::swap(a.first, b.first);
+    std::swap(a.last, b.last);
+    std::swap(a.count, b.count);
+    for (auto pr : {std::make_pair(&a.val, &b.val), std::make_pair(&a.org, &b.org), std::make_pair(&a.read_off, &b.read_off)}) {
+      std::swap(pr.first->ptr, pr.second->ptr);
+      std::swap(pr.first->cap, pr.second->cap);
+    }
+  };
   Overlap* d_best = e.pl_best.get<Overlap>(static_cast<size_t>(R.n) + 1);
   u32* d_best_t = e.pl_best_t.get<u32>(static_cast<size_t>(R.n) + 1);
   const bool keep = e.keep_anchors;
@@ -282,7 +319,65 @@ void polish_map_best(Engine& e, ReadsDev& T, ReadsDev& R, u32 r_first, u32 r_las
       if (r != r_last - 1 && bases < (1ULL << 30)) continue;
       bases = 0;
       MapOut& mo = e.map_out;
-      map_batch(e, R, r0, r + 1, false, false, false, false, mo);
+      if (joined && t_count) {
+        {
+          StageTimer t(e, StageTimes::kQuery);
+          sketch_raw(e, R, r0, r + 1, e.raw_sketch);
+          t.stop();
+        }
+        const u64 nq = e.raw_sketch.count, m = nq + t_count;
+        if (m >= (1ULL << 32)) throw HipError("[raven_hip] polishing round: a read batch with >= 2^32 minimizers");
+        unsigned char* cv = e.index_sketch.val.get<unsigned char>((m + 1) * vb);
+        u64* co = e.index_sketch.org.get<u64>(m + 1);
+        if (nq) {
+          RVN_HIP(hipMemcpyAsync(cv, e.raw_sketch.val.ptr, nq * vb, hipMemcpyDeviceToDevice, s));
+          RVN_KLAUNCH(kKGather, flag_origins_kernel<<<div_up(nq, 256), 256, 0, s>>>(e.raw_sketch.org.as<u64>(), nq,
+                                                                                    kQueryFlag | kForeignFlag, co));
+        }
+        RVN_HIP(hipMemcpyAsync(cv + nq * vb, e.pl_tval.ptr, t_count * vb, hipMemcpyDeviceToDevice, s));
+        RVN_HIP(hipMemcpyAsync(co + nq, e.pl_torg.ptr, t_count * 8, hipMemcpyDeviceToDevice, s));
+        e.index_sketch.first = r0;
+        e.index_sketch.last = r + 1;
+        e.index_sketch.count = m;
+        index_build(e, e.index_sketch, false);   // stable sort: the reads' entries stay ahead of the targets' in every run
+        e.index.occurrence = occurrence;
+        e.index.has_query_flags = true;
+        e.index.all_query = false;
+        map_batch_query_only(e, R, r0, r + 1, nq, mo);
+      } else {
+        // The reads' sketch does not change between rounds (only the targets do): kept in HBM per read batch and handed to
+        // map_batch as its prepared query sketch (round 6: 32 ms of sketch kernels per C4 round).  One read set at a time,
+        // within the option's budget; handed back with the scratch (engine_release_scratch).
+        Engine::PolishSketch* slot = nullptr;
+        const u64 budget = e.opt.polish_sketch_cache_mb < 0 ? cache_default : static_cast<u64>(e.opt.polish_sketch_cache_mb) << 20;
+        if (budget) {
+          if (e.polish_sketch_owner != R.serial) {
+            e.polish_sketches.clear();
+            e.polish_sketch_owner = R.serial;
+          }
+          for (auto& c : e.polish_sketches)
+            if (c->first == r0 && c->last == r + 1) slot = c.get();
+        }
+        if (slot) {  // the kept sketch becomes the query sketch of this call ...
+          swap_sketch(e.query_sketch, slot->sk);
+          e.query_ready = true;
+          e.query_ready_first = r0;
+          e.query_ready_last = r + 1;
+          e.query_ready_minhash = false;
+        }
+        map_batch(e, R, r0, r + 1, false, false, false, false, mo);
+        if (!slot && budget) {
+          u64 held = 0;
+          for (auto& c : e.polish_sketches) held += c->sk.val.cap + c->sk.org.cap + c->sk.read_off.cap;
+          if (held + e.query_sketch.val.cap + e.query_sketch.org.cap + e.query_sketch.read_off.cap <= budget) {
+            e.polish_sketches.emplace_back(new Engine::PolishSketch());
+            slot = e.polish_sketches.back().get();
+            slot->first = r0;
+            slot->last = r + 1;
+          }
+        }
+        if (slot) swap_sketch(e.query_sketch, slot->sk);  // ... and goes back (or: the one just computed is kept)
+      }
       if (n_overlaps) *n_overlaps += mo.n_overlaps;
       const u32 nr = r + 1 - r0;
       RVN_KLAUNCH(kKBestOverlap, best_overlap_kernel<<<div_up(nr, 256), 256, 0, s>>>(
@@ -292,6 +387,8 @@ void polish_map_best(Engine& e, ReadsDev& T, ReadsDev& R, u32 r_first, u32 r_las
     }
   } catch (...) {
     e.keep_anchors = keep;
+    e.polish_sketches.clear();  // (a kept sketch may be out on loan as the query sketch: nothing kept is trusted after a failure)
+    e.polish_sketch_owner = 0;
     throw;
   }
   e.keep_anchors = keep;

@@ -729,7 +729,11 @@ class Engine:
                                         int(trim), m, n, g, int(window_first), int(window_last), _p(out), _p(ooff),
                                         _p(out_len), None, _p(nw), _p(npol), _p(stats)))
         cons = [out[int(ooff[i]): int(ooff[i]) + int(out_len[i])].copy() for i in range(nt)]
-        return cons, nw, npol, {"n_windows": int(stats[3]), "n_layers": int(stats[2])}
+        st = {"n_windows": int(stats[3]), "n_layers": int(stats[2])}
+        for i, k2 in enumerate(("poa_ms", "map_ms", "host_ms", "total_ms")):
+            st[k2] = float(stats[6 + i: 7 + i].view(np.float64)[0])
+        st["align_ms"] = float(stats[11:12].view(np.float64)[0])
+        return cons, nw, npol, st
 
     def polish_map_best(self, targets: Reads, reads: Reads, read_first=0, read_last=None, err=0.3):
         """First step of a round for the reads [read_first, read_last): (best overlaps [n, 8] uint32 rows of rvn_overlap,

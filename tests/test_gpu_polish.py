@@ -141,3 +141,36 @@ def test_lambda_polish_matches_golden_fixture(with_qual):
     ref = fx["consensus" if with_qual else "consensus_noqual"]
     assert st["n_failed_windows"] == 0 and ratio[0] == 1.0
     _assert_tolerance(cons[0], ref, truth)
+
+
+def test_round_is_the_same_with_the_kept_sketch_and_with_the_sorted_mapping():
+    """Two ways a round's mapping can run (round 6): with the reads' sketch kept in HBM from the round before (default) or
+    recomputed (polish_sketch_cache_mb = 0), and — option polish_join — by sorting the reads' minimizers with the targets'
+    and streaming the runs instead of probing.  Layer tables and consensus are identical in all of them, round after round."""
+    truths, drafts, targets, reads, quals = pu2.make_case(genome_len=40_000, coverage=20, seed=41, n_targets=2)
+    eng = hip.Engine(15, 5)
+    rd = eng.upload(reads)
+
+    def two_rounds():
+        td = eng.upload(targets)
+        c1, _, _ = eng.polish_round(td, rd)
+        l1 = eng.polish_layers()
+        td2 = eng.upload_codes(c1)
+        c2, _, _ = eng.polish_round(td2, rd)   # (the second round finds the reads' sketch of the first)
+        return l1, c1, eng.polish_layers(), c2
+
+    ref = two_rounds()
+    assert eng.set_option("polish_sketch_cache_mb", 0) == -1
+    try:
+        got = two_rounds()
+    finally:
+        eng.set_option("polish_sketch_cache_mb", -1)
+    assert eng.set_option("polish_join", 1) == 0
+    try:
+        joined = two_rounds()
+    finally:
+        eng.set_option("polish_join", 0)
+    for other in (got, joined):
+        assert np.array_equal(ref[0], other[0]) and np.array_equal(ref[2], other[2])
+        for a, b in zip(ref[1] + ref[3], other[1] + other[3]):
+            assert np.array_equal(a, b)

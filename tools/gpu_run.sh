@@ -57,6 +57,12 @@ import json; d = json.load(open('$f')); print({k: v for k, v in d.items() if k n
        f=gpurun_out/${TAG}_polish_parity_${shape}_$n.json
        timeout 1500 python tools/polish_parity.py $n 0 $shape > $f 2> gpurun_out/${TAG}_polish_parity.err; python -c "
 import json; d = json.load(open('$f')); print({k: v for k, v in d.items() if k != 'different'})";;
+    rankshare) f=gpurun_out/${TAG}_rank_share_$(echo "$arg" | tr -c 'A-Za-z0-9\n' '_').json   # rankshare:--ranks=8,--workload=c4
+       timeout 1200 python tools/rank_share.py $(echo "$arg" | tr ',' ' ') > $f 2> ${f%.json}.err; python -c "
+import json; d = json.loads([l for l in open('$f') if l.startswith('{')][-1])
+print({k: d[k] for k in ('ranks', 'single_gpu', 'predicted_step_s_at_n_ranks', 'ideal_step_s', 'predicted_strong_scaling_efficiency', 'sharded_rounds_equal_single_gpu_consensus')})
+print('pass', {k: v for k, v in d['overlap_pass_at_n_ranks'].items() if k != 'stats_rank0'})
+for r in d['polishing_rounds_at_n_ranks']: print(r)" || tail -5 ${f%.json}.err;;
     profile) bash tools/profile_round.sh $arg
        # (a bench-full step later in the same call reads the traffic file from profiles/: without this its line says stale)
        for f in pmc_traffic.json pmc_calibration.json kernel_stats.csv bench_under_rocprof.json; do [ -f gpurun_out/${arg}_$f ] && cp gpurun_out/${arg}_$f profiles/; done;;
