@@ -10,7 +10,9 @@
 #include <cstdint>
 #include <cstdio>
 #include <stdexcept>
+#include <algorithm>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace rvn {
@@ -252,6 +254,21 @@ struct KernelScope {
 // 8 x u32 overlap record == biosoup::Overlap minus the alignment string.
 // Bit 63 of an index origin marks "this minimizer is also a (minhash) query minimizer" (self-join path);
 // read ids must therefore stay below 2^31.  Every consumer of an origin's id masks it.
+// f(begin, end) over [0, n) on a few host threads (the per-job loops of a stage's host planning: 300 000 jobs at C4; the GPU
+// is idle while they run).  Serial below `grain` items per thread.
+template <class F>
+inline void parallel_for(size_t n, size_t grain, F f) {
+  size_t nt = std::min<size_t>(std::min<size_t>(std::thread::hardware_concurrency(), 16), grain ? n / grain : 1);
+  if (nt <= 1) {
+    f(static_cast<size_t>(0), n);
+    return;
+  }
+  std::vector<std::thread> ths;
+  ths.reserve(nt);
+  for (size_t t = 0; t < nt; ++t) ths.emplace_back([=]() { f(n * t / nt, n * (t + 1) / nt); });
+  for (std::thread& th : ths) th.join();
+}
+
 constexpr u64 kQueryFlag = 1ULL << 63;
 // An entry that is a QUERY ONLY: a minimizer of a read that does not belong to the index batch at hand (sharded pass with
 // more than one index batch: reads of earlier batches are mapped against every later batch's index, construct.cc:59-64

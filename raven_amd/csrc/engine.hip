@@ -1112,7 +1112,12 @@ int rvn_polish_round_range(rvn_engine* h, rvn_reads* targets, rvn_reads* reads, 
     for (u32 t = 0; t < targets->r.n; ++t) {
       const u64 cap = out_offsets[t + 1] - out_offsets[t];
       if (polished[t].size() > cap) return fail(RVN_EINVAL, "[raven_hip] rvn_polish_round_range: output buffer too small");
-      std::memcpy(out_codes + out_offsets[t], polished[t].data(), polished[t].size());
+    }
+    // (100 MB of consensus at C4 into the caller's — usually never touched — pages: on a few threads)
+    parallel_for(targets->r.n, 1, [&](size_t t0, size_t t1) {
+      for (size_t t = t0; t < t1; ++t) std::memcpy(out_codes + out_offsets[t], polished[t].data(), polished[t].size());
+    });
+    for (u32 t = 0; t < targets->r.n; ++t) {
       out_len[t] = static_cast<uint32_t>(polished[t].size());
       if (ratio) ratio[t] = rt[t];
       if (n_windows) n_windows[t] = wc[t];

@@ -319,13 +319,15 @@ void nw_breakpoints(Engine& e, const ReadsDev& T, const ReadsDev& Rd, std::vecto
       {  // descending by (variant, columns), ties in job order: two counting passes (12 + 12 key bits) instead of a sort
         const size_t nt = todo.size();
         std::vector<u32> key(nt), tmp(nt), idx(nt);
-        for (size_t x = 0; x < nt; ++x) {
-          const NwJob& J = jobs[todo[x]];
-          const u32 mm = std::min<u32>(J.m >> 3, (1u << 20) - 1);  // 8-base resolution is plenty for the ordering
-          static_assert(kLevels <= 16, "4 bits of variant + 20 bits of length = the 24 key bits of the two passes");
-          key[x] = 0xFFFFFFu - ((level_of(J) << 20) | mm);
-          idx[x] = static_cast<u32>(x);
-        }
+        parallel_for(nt, 16384, [&](size_t x0, size_t x1) {  // (the GPU waits for this planning: a few host threads)
+          for (size_t x = x0; x < x1; ++x) {
+            const NwJob& J = jobs[todo[x]];
+            const u32 mm = std::min<u32>(J.m >> 3, (1u << 20) - 1);  // 8-base resolution is plenty for the ordering
+            static_assert(kLevels <= 16, "4 bits of variant + 20 bits of length = the 24 key bits of the two passes");
+            key[x] = 0xFFFFFFu - ((level_of(J) << 20) | mm);
+            idx[x] = static_cast<u32>(x);
+          }
+        });
         for (int pass = 0; pass < 2; ++pass) {
           u32 cnt[4097] = {};
           const int sh = 12 * pass;
@@ -342,14 +344,25 @@ void nw_breakpoints(Engine& e, const ReadsDev& T, const ReadsDev& Rd, std::vecto
       // was measured at C4 and did not pay: every extra sweep launch brings its own ramp and tail, +19 ms of sweep time
       // against ~20 ms less at the end; profiles/r05_nw_timeline.csv.)
       std::vector<Chunk> chunks;
+      struct Need {
+        u64 hw, ce, cells;
+        u32 level;
+      };
+      std::vector<Need> need(order.size());  // what a job stores and computes: per job in parallel, summed up in order below
+      parallel_for(order.size(), 16384, [&](size_t x0, size_t x1) {
+        for (size_t x = x0; x < x1; ++x) {
+          const NwJob& J = jobs[order[x]];
+          const NwGeo g = nw_geo(J.n, J.m, J.k, J.R);
+          need[x] = Need{g.hs_words(), g.ck_entries(), static_cast<u64>(J.m) * (static_cast<u64>(g.lo) + g.hi + 1), level_of(J)};
+        }
+      });
       for (size_t c0 = 0; c0 < order.size();) {
         Chunk C{};
         C.c0 = c0;
         size_t c1 = c0;
         while (c1 < order.size()) {
           NwJob& J = jobs[order[c1]];
-          const NwGeo g = nw_geo(J.n, J.m, J.k, J.R);
-          const u64 hw = g.hs_words(), ce = g.ck_entries();
+          const u64 hw = need[c1].hw, ce = need[c1].ce;
           // three buffer sets in rotation + one of its own for the first chunk (the longest alignments: its walk is
           // latency-bound — 106 ms for 2 432 alignments at C4 — and a set shared with chunk 3 made that chunk's sweep wait
           // 17 ms for it), a quarter of a share
@@ -359,8 +372,8 @@ void nw_breakpoints(Engine& e, const ReadsDev& T, const ReadsDev& Rd, std::vecto
           J.ckpt = C.ck_e;
           C.hs_w += hw;
           C.ck_e += ce;
-          st.band_cells += static_cast<u64>(J.m) * (static_cast<u64>(g.lo) + g.hi + 1);
-          C.coff[level_of(J) + 1]++;
+          st.band_cells += need[c1].cells;
+          C.coff[need[c1].level + 1]++;
           ++c1;
         }
         // the order is by descending level: offsets of the classes inside the chunk, in that order

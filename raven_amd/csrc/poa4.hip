@@ -13,11 +13,11 @@
 //     32-bit read per in-edge and step: the static schedule below guarantees the cells exist), and a row's descriptor
 //     (band start, match mask against the layer, LDS addresses of up to 8 predecessor rows) is one 32-byte record built
 //     by a per-layer pre-pass, so the step loop decodes nothing,
-//   * in-edges are folded with v_max on (score << 4 | diagonal << 3 | 7 - in-edge) keys: spoa's tie rule (diagonal
+//   * in-edges are folded with v_max on (score << 8 | diagonal << 3 | 7 - in-edge) keys: spoa's tie rule (diagonal
 //     before vertical, first in-edge first) is the maximum's and the backpointer falls out of its low bits: FOUR bits per
-//     cell.  0 = horizontal AND "vertical through the eighth in-edge" (tag 7 - 7): the traceback cannot tell the two apart,
-//     so a walk that meets code 0 in a row of eight in-edges sends the window to poa2 (a tenth of the 2.5 % of C4-like
-//     windows that have such a row; refusing eight in-edges outright cost 23 ms more of poa2 per C4 round),
+//     cell.  0 = horizontal AND "vertical through the eighth in-edge" (tag 7 - 7): for the rows that have eight in-edges
+//     (2.5 % of C4-like windows have one) the NW leaves one bit per column beside the row saying which of the two a code 0
+//     is (Poa4Slot::v7; round 5 sent the window to poa2 when a walk met the case: 836 windows and a second kernel per round),
 //   * backpointers leave as ONE coalesced 8-byte store per lane and 8 steps into a time-major stream (step, lane); the
 //     traceback maps (row, column) -> (step, lane) through the descriptor.
 // Schedule (all band starts even and non-decreasing along the topological order): row rho of the layer's rank range
@@ -138,6 +138,8 @@ struct Poa4Slot {
                  //            traceback needs of a row is its first 16 bytes
   u32* rb;       // per node: rank | backbone coordinate << 16 (kept by the set-up and by poa4_update_graph)
   u32* rbl;      // per node, for the CURRENT layer: rank | band start << 16 (first pass of the descriptor phase)
+  u32* v7;       // per row with eight in-edges: bit c = column band start + c took the VERTICAL move through the eighth in-edge —
+                 // the one move the 4-bit codes cannot tell from "horizontal" (both code 0); written by the NW for such rows only
   uint2* bps;    // backpointer stream: [step / 8][lane of the window] 8 bytes = 8 steps x 2 columns x 4 bits
   u32* seq2g;    // the current layer: [0, 60) 2 bits per base, [64, 96) its band guide as eight segments (set-up kernel ->
                  // descriptor / graph update kernels)
@@ -149,6 +151,7 @@ inline size_t poa4_slot_bytes(u32 nmax, u32 lmax) {
   b += static_cast<size_t>(poa4_desc_rows(nmax)) * 32;
   b += 2 * ((static_cast<size_t>(nmax) * 4 + 255) & ~size_t(255));
   b += (static_cast<size_t>(poa4_steps(nmax, lmax)) / P4::kU + 2) * 16 * 8;
+  b += (static_cast<size_t>(poa4_desc_rows(nmax)) * 4 + 255) & ~size_t(255);
   b += 512;
   return (b + 255) & ~size_t(255);
 }
@@ -165,6 +168,8 @@ __host__ __device__ inline Poa4Slot poa4_carve(unsigned char* base, u32 nmax, u3
   o += (static_cast<size_t>(nmax) * 4 + 255) & ~size_t(255);
   s.bps = reinterpret_cast<uint2*>(base + o);
   o += (static_cast<size_t>(poa4_steps(nmax, lmax)) / P4::kU + 2) * 16 * 8;
+  s.v7 = reinterpret_cast<u32*>(base + o);
+  o += (static_cast<size_t>(poa4_desc_rows(nmax)) * 4 + 255) & ~size_t(255);
   s.seq2g = reinterpret_cast<u32*>(base + o);
   return s;
 }
@@ -473,6 +478,7 @@ __host__ __device__ inline void poa4_dp(const Poa4Args A, Poa4Lds& S, unsigned c
   uint4 lA = uint4{0, 0, 0, 0}, lB = uint4{0, 0, 0, 0};
   bool ld_pending = false;
   i32 Am1 = 0, UK = kNegU;
+  u32 v7m = 0;
   i32 best_score = -0x7FFFFFFF;
   u32 best_row = 0;
   const u32 T = static_cast<u32>(sv::wave_max(act ? static_cast<int>(t_end) : 0));
@@ -591,6 +597,7 @@ __host__ __device__ inline void poa4_dp(const Poa4Args A, Poa4Lds& S, unsigned c
       const u32 nm = lds_ld32(S, static_cast<u32>(offsetof(Poa4Lds, qm)) + (nptr >> 2));
 #endif
       i32 A0, A1;
+      bool wave_has8 = false;  // (wave-uniform: some lane's row has eight in-edges)
       if (sv::any(static_cast<i32>(cm) < 0)) {  // rows without an in-edge inside the subgraph, rows with more than four (1 % of the rows)
         P4_MARK("rare_begin");
         const uint2 ce = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned char*>(&S) + offsetof(Poa4Lds, qe) + (ptr >> 1));
@@ -617,6 +624,7 @@ __host__ __device__ inline void poa4_dp(const Poa4Args A, Poa4Lds& S, unsigned c
             if (sv::any(np > 6)) {
               P4_EDGE(6, ce.y, false)
               P4_EDGE(7, ce.y, true)
+              wave_has8 = sv::any(np > 7);
             }
           }
         }
@@ -644,6 +652,20 @@ __host__ __device__ inline void poa4_dp(const Poa4Args A, Poa4Lds& S, unsigned c
       if (in_band) lds_st32(S, add_half<true>(off4, cw.x), clamp_pair(keys_to_pair(M0, M1)));
 #endif
       UK = in_band ? (M1 & ~0xFF) : kNegU;
+      if (wave_has8) {
+        // A row of eight in-edges (a tenth of the 2.5 % of C4-like windows that have one): "vertical through the eighth" has
+        // tag 0, the code of "horizontal".  Which of the two a code 0 of such a row means goes into a 32-bit mask beside the
+        // row, one bit per column (round 5 handed the window to the 64-column kernel when a walk met the case: 836 windows and
+        // 59 ms of a second kernel per C4 round).  The vertical candidate wins a tie with the horizontal one (max3's key
+        // order), and a diagonal of the same score would have left a tag >= 8.
+        P4_MARK("rare_begin");
+        const bool has8 = ((cm >> 24) & 15u) > 7u;
+        const u32 b0 = (in_band && (M0 & 0xFF) == 0 && M0 == A0 + gK) ? 1u : 0u;
+        const u32 b1 = (in_band && (M1 & 0xFF) == 0 && M1 == A1 + gK) ? 1u : 0u;
+        v7m = (k2 <= 0 ? 0u : v7m) | ((b0 | (b1 << 1)) << (static_cast<u32>(k2) & 31u));
+        if (has8 && k2 == 30) sl.v7[(cw.x & 0xFFFFu) == ld_s2 ? ld_rho : ld_rho - 16u] = v7m;
+        P4_MARK("rare_end");
+      }
       Am1 = A1;
       u32 cp = (static_cast<u32>(M0) & 15u) | (static_cast<u32>(M1) << 4);  // (byte 0: code of the pair; the rest is dropped by put_byte)
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -837,24 +859,26 @@ __host__ __device__ inline void poa4_traceback(const Poa4Args A, Poa4LdsTb& S, u
       const u32 bt = (d.y >> 16) & 0x3FFu, np = (d.y >> 26) & 15u, node = d.y & 0xFFFFu;
       const u32 idx = static_cast<u32>(j) - bt;
       const bool oob = idx >= static_cast<u32>(K::kBand);  // the path left the stored band
-      const bool isH = code == 0u;
+      bool isH = code == 0u;
       const u32 k = (~code) & 7u;
       u32 ni = np ? i - ((d.z >> (k < 6 ? 5 * k : 0u)) & 31u) : 0u;
-      bool amb = false;
       if (sv::any(in_round && np >= 7)) {  // rows of seven or eight in-edges (1 % of the windows have one)
-        // code 0 in a row of eight in-edges is "horizontal" or "vertical through the eighth": not decidable here;
-        // in-edges 6 and 7: their ranks come from the graph
-        amb = isH && np >= 8u;
+        // code 0 in a row of eight in-edges is "horizontal" or "vertical through the eighth": the NW left the answer in the
+        // row's v7 mask; in-edges 6 and 7: their ranks come from the graph
+        if (in_round && !oob && isH && np >= 8u) {
+          const u32 m7 = poa4_carve(opaque(slot_mem), A.nmax, A.lmax).v7[i - 1];
+          if ((m7 >> idx) & 1u) isH = false;  // (k = (~0) & 7 = 7: the eighth in-edge; code >> 3 = 0: no column is left)
+        }
         if (in_round && !oob && !isH && k >= 6)
           ni = poa4_nth_pred_rank(poa4_carve(opaque(slot_mem), A.nmax, A.lmax), node, k, full) - r_lo + 1;
       }
       // (a diagonal or horizontal code in column 0 — never on a consistent stream — leaves the band in the next step)
-      const bool ok = in_round && !oob && !amb;
+      const bool ok = in_round && !oob;
       if (ok && (code & 8u) && j > 0 && gl == 0) pos_node[j - 1] = static_cast<u16>(node);  // (an insertion leaves pos_node[j] at kNone)
       // the nearest the path comes to an edge of the band beyond which the matrix goes on (band_hit after the walk)
       near_lo = imin(near_lo, (ok && bt != 0) ? static_cast<i32>(idx) : 99);
       near_hi = imax(near_hi, (ok && bt + K::kBand < w) ? static_cast<i32>(idx) : -1);
-      if (in_round && (oob || amb)) band_hit = 1;
+      if (in_round && oob) band_hit = 1;
       steps += in_round ? 1u : 0u;
       j -= ok ? static_cast<i32>(isH ? 1u : (code >> 3)) : 0;
       const bool row_move = ok && !isH;

@@ -450,34 +450,57 @@ void polish_round(Engine& e, ReadsDev& T, ReadsDev& R, const u8* h_quals, const 
   const u64 W0 = std::min<u64>(win_first, n_windows_all), W1 = std::min<u64>(win_last, n_windows_all);
   const u32 nw = static_cast<u32>(W1 > W0 ? W1 - W0 : 0);
   std::vector<NwJob> jobs;
-  jobs.reserve(R.n);
   u64 n_recs = 0;
-  for (u32 r = 0; r < R.n; ++r) {
-    if (best_t[r] == 0xFFFFFFFFu) continue;
-    const Overlap& o = best[r];
-    const u32 t = best_t[r];
-    ++stats.n_reads_used;
-    ++e.polish_target_reads[t];
-    if (o.rhs_end <= o.rhs_begin || o.lhs_end <= o.lhs_begin) continue;
-    const u64 g_lo = first_window[t] + o.rhs_begin / w, g_hi = first_window[t] + (o.rhs_end - 1) / w;
-    if (g_hi < W0 || g_lo >= W1) continue;  // another rank's windows
-    const u32 qlen = R.h_len[r];
-    const bool rc = o.strand == 0;
-    NwJob J{};
-    J.t_word = T.h_word_off[t];
-    J.r_word = R.h_word_off[r];
-    J.t_begin = o.rhs_begin;
-    J.n = o.rhs_end - o.rhs_begin;
-    J.q_begin = rc ? qlen - o.lhs_end : o.lhs_begin;  // racon reverse-complements the read (step 2 of its pipeline)
-    J.m = o.lhs_end - o.lhs_begin;
-    J.r_len = qlen;
-    J.rc = rc ? 1 : 0;
-    J.read = r;
-    J.target = t;
-    J.n_windows = (o.rhs_end - 1) / w - o.rhs_begin / w + 1;
-    J.bp_off = n_recs;
-    n_recs += J.n_windows;
-    jobs.push_back(J);
+  {
+    // per read: does it give a job of this window range, and how many window records (in parallel); then the records' offsets
+    // in read order and the jobs themselves (in parallel again) — 295 000 reads at C4, and the GPU waits for this planning
+    std::vector<u32> wins_of(R.n, 0);  // 0: no job
+    parallel_for(R.n, 16384, [&](size_t r0, size_t r1) {
+      for (size_t r = r0; r < r1; ++r) {
+        if (best_t[r] == 0xFFFFFFFFu) continue;
+        const Overlap& o = best[r];
+        if (o.rhs_end <= o.rhs_begin || o.lhs_end <= o.lhs_begin) continue;
+        const u32 t = best_t[r];
+        const u64 g_lo = first_window[t] + o.rhs_begin / w, g_hi = first_window[t] + (o.rhs_end - 1) / w;
+        if (g_hi < W0 || g_lo >= W1) continue;  // another rank's windows
+        wins_of[r] = (o.rhs_end - 1) / w - o.rhs_begin / w + 1;
+      }
+    });
+    std::vector<u64> rec_off(static_cast<size_t>(R.n) + 1, 0);
+    std::vector<u32> job_of(static_cast<size_t>(R.n) + 1, 0);
+    for (u32 r = 0; r < R.n; ++r) {
+      if (best_t[r] != 0xFFFFFFFFu) {
+        ++stats.n_reads_used;
+        ++e.polish_target_reads[best_t[r]];
+      }
+      rec_off[r + 1] = rec_off[r] + wins_of[r];
+      job_of[r + 1] = job_of[r] + (wins_of[r] ? 1u : 0u);
+    }
+    n_recs = rec_off[R.n];
+    jobs.resize(job_of[R.n]);
+    parallel_for(R.n, 16384, [&](size_t r0, size_t r1) {
+      for (size_t r = r0; r < r1; ++r) {
+        if (!wins_of[r]) continue;
+        const Overlap& o = best[r];
+        const u32 t = best_t[r];
+        const u32 qlen = R.h_len[r];
+        const bool rc = o.strand == 0;
+        NwJob J{};
+        J.t_word = T.h_word_off[t];
+        J.r_word = R.h_word_off[r];
+        J.t_begin = o.rhs_begin;
+        J.n = o.rhs_end - o.rhs_begin;
+        J.q_begin = rc ? qlen - o.lhs_end : o.lhs_begin;  // racon reverse-complements the read (step 2 of its pipeline)
+        J.m = o.lhs_end - o.lhs_begin;
+        J.r_len = qlen;
+        J.rc = rc ? 1 : 0;
+        J.read = static_cast<u32>(r);
+        J.target = t;
+        J.n_windows = wins_of[r];
+        J.bp_off = rec_off[r];
+        jobs[job_of[r]] = J;
+      }
+    });
   }
   std::vector<WinMeta> meta(nw);
   {
@@ -641,11 +664,20 @@ void polish_round(Engine& e, ReadsDev& T, ReadsDev& R, const u8* h_quals, const 
     if (st >= 2) ++stats.n_failed_windows;
   }
   {
-    u32 i = 0;
+    std::vector<std::pair<u32, u32>> span(T.n, {0u, 0u});  // windows [first, second) of the range that belong to target t
+    {
+      u32 i = 0;
+      for (u32 t = 0; t < T.n; ++t) {
+        const u32 i0 = i;
+        while (i < nw && meta[i].target == t) ++i;
+        span[t] = {i0, i};
+      }
+    }
+    parallel_for(T.n, 1, [&](size_t t0, size_t t1) {  // (first touch of 100 MB of host vectors at C4: a few threads)
+      for (size_t t = t0; t < t1; ++t)
+        if (span[t].second > span[t].first) polished[t].assign(h_final + cons_off[span[t].first], h_final + cons_off[span[t].second]);
+    });
     for (u32 t = 0; t < T.n; ++t) {
-      const u32 i0 = i;
-      while (i < nw && meta[i].target == t) ++i;
-      if (i > i0) polished[t].assign(h_final + cons_off[i0], h_final + cons_off[i]);
       ratio[t] = t_windows[t] ? static_cast<double>(t_polished[t]) / t_windows[t] : 0.0;
       stats.n_polished_windows += t_polished[t];
       if (win_count) (*win_count)[t] = static_cast<u32>(t_windows[t]);

@@ -58,7 +58,10 @@ def test_no_vector_memory_wait_inside_an_nw_step(tmp_path):
         waits = [t for t, _ in ins if re.match(r"s_waitcnt\s+vmcnt", t)]
         assert not waits, waits
         assert not [t for t, _ in ins if "scratch_" in t]            # no spill traffic in a step either
-        assert not [t for t, _ in ins if t.startswith(("global_", "flat_", "buffer_"))]  # nor any other vector-memory access
+        # nor any other vector-memory access on the common path (the rare path of a row with eight in-edges stores the row's
+        # "vertical through the eighth in-edge" mask, once per such row)
+        assert not [t for t, r in ins if not r and t.startswith(("global_", "flat_", "buffer_"))]
+        assert len([t for t, r in ins if r and t.startswith(("global_", "flat_", "buffer_"))]) <= 1
         main = [t for t, r in ins if not r]
         # the common path: 4 in-edge reads, the next step's row words (b128 + b32), the own row's store
         assert len([t for t in main if t.startswith("ds_")]) <= 7, main
