@@ -515,6 +515,72 @@ __device__ __forceinline__ void chain_emit(CP cp, u32 longest, bool strand, u64 
   }
 }
 
+// The same for a WAVE that holds the chain (chain_wave): the pieces from ballots of the gap test, a piece's covered bases
+// summed by all lanes — the serial loop above adds up the measure of the union of the k-mers [pos, pos + k) of ascending
+// positions, which is sum over consecutive pairs of min(k, difference) + k.
+template <typename CP>
+__device__ __forceinline__ void chain_emit_wave(CP cp, u32 longest, bool strand, u64 g0, u32 lhs_id, u32 k, u32 chain,
+                                                u32 min_matches, u32 gap, Overlap* __restrict__ slots,
+                                                u8* __restrict__ slot_flags, u64* __restrict__ anchors, u64 anchor_base,
+                                                u64* __restrict__ slot_aoff, u32* __restrict__ slot_acnt) {
+  const int lane = lane_id();
+  auto rhs_of = [&](u64 mm) -> u32 {
+    const u32 rhs_pos = static_cast<u32>(mm);
+    return strand ? rhs_pos : (1U << 31) - (rhs_pos + k - 1);
+  };
+  u32 emitted = 0;
+  u32 l = 0;
+  for (u32 base = 1; base <= longest; base += 64) {
+    const u32 kk_mine = base + static_cast<u32>(lane);
+    bool brk = false;
+    if (kk_mine <= longest) {
+      const u32 lhs_k = kk_mine < longest ? static_cast<u32>(cp(kk_mine) >> 32) : 0xFFFFFFFFu;
+      const u32 lhs_km1 = static_cast<u32>(cp(kk_mine - 1) >> 32);
+      brk = lhs_k - lhs_km1 > gap;
+    }
+    unsigned long long pieces = __ballot(brk);
+    while (pieces) {
+      const u32 kk = base + static_cast<u32>(__builtin_ctzll(pieces));
+      pieces &= pieces - 1;
+      if (kk - l >= chain) {
+        u32 lsum = 0, rsum = 0;
+        for (u32 m = l + static_cast<u32>(lane); m + 1 < kk; m += 64) {
+          const u64 a = cp(m), b = cp(m + 1);
+          const u32 dl = static_cast<u32>(b >> 32) - static_cast<u32>(a >> 32), dr = rhs_of(b) - rhs_of(a);
+          lsum += dl < k ? dl : k;
+          rsum += dr < k ? dr : k;
+        }
+        const u32 lhs_matches = wave_sum(lsum) + k, rhs_matches = wave_sum(rsum) + k;
+        const u32 score = lhs_matches < rhs_matches ? lhs_matches : rhs_matches;
+        if (score >= min_matches) {
+          if (lane == 0) {
+            const u64 ml = cp(l), mr = cp(kk - 1);
+            Overlap o;
+            o.lhs_id = lhs_id;
+            o.lhs_begin = static_cast<u32>(ml >> 32);
+            o.lhs_end = k + static_cast<u32>(mr >> 32);
+            o.rhs_id = static_cast<u32>(g0 >> 33);
+            o.rhs_begin = strand ? static_cast<u32>(ml) : static_cast<u32>(mr);
+            o.rhs_end = k + (strand ? static_cast<u32>(mr) : static_cast<u32>(ml));
+            o.score = score;
+            o.strand = strand ? 1u : 0u;
+            slots[emitted] = o;
+            slot_flags[emitted] = 1;
+            if (anchors) {
+              slot_aoff[emitted] = anchor_base + l;
+              slot_acnt[emitted] = kk - l;
+            }
+          }
+          if (anchors)  // the chain pieces are disjoint sub-ranges of [0, longest): stored in place
+            for (u32 m = l + static_cast<u32>(lane); m < kk; m += 64) anchors[m] = cp(m);
+          ++emitted;
+        }
+      }
+      l = kk;
+    }
+  }
+}
+
 // Small intervals (chain <= n <= kChainSmallCap): one LANE per interval, every array private to the lane in LDS
 // ([element][lane] layout: bank = lane, conflict-free), no cross-lane traffic at all.
 constexpr u32 kChainSmallCap = 32;
@@ -755,21 +821,50 @@ __device__ void chain_wave(const u64* __restrict__ p, u32 n, bool strand, u64 g0
   }
   if (longest < chain) return;
   {
-    // backtrack: chain indices ascending into tail_idx[0 .. longest)
+    // backtrack: chain indices ascending into tail_idx[0 .. longest).  Rounds 1-5 followed pred[] one element at a time out
+    // of LDS — `longest` dependent reads of ~100 cycles, every lane doing the same — and the emission below ran two more
+    // serial loops over the chain on all 64 lanes: for the long colinear intervals of HiFi reads (4 500 matches per read in a
+    // polishing round's mapping, one wave per CU in that size class) the three were ~95 % of the stage (round 6: 0.63 ms per
+    // interval of which ~0.02 ms the LIS itself).  Now: the walk back goes 64 elements at a time out of REGISTERS (a block's
+    // predecessors, one per lane; a run of elements that each follow the one before is taken in one step from a ballot),
+    // leaving one membership mask per block, and the indices are written block by block from the masks.
+    const u32 nblk = (n + 63) >> 6;
+    for (u32 b2 = lane; b2 < nblk; b2 += 64) maskbuf[b2] = 0;
     u32 j = tail_idx[longest];
     chain_sync<GLOBAL>();
-    for (u32 i = 0; i < longest; ++i) {
-      const u32 nj = pred[j];
-      if (lane == 0) tail_idx[longest - 1 - i] = static_cast<IdxT>(j);
-      j = nj;
+    u32 left = longest;
+    for (int b2 = static_cast<int>(j >> 6); b2 >= 0 && left; --b2) {
+      const u32 idx = (static_cast<u32>(b2) << 6) + static_cast<u32>(lane);
+      const u32 pr = idx < n ? static_cast<u32>(pred[idx]) : 0u;
+      // bit i: element i of the block follows element i - 1 of the block
+      const unsigned long long cont = __ballot(lane > 0 && idx < n && pr + 1 == idx);
+      unsigned long long m = 0;
+      while (left && static_cast<int>(j >> 6) == b2) {
+        const u32 l = j & 63u;
+        const unsigned long long upto = l == 63 ? ~0ULL : ((2ULL << l) - 1ULL);
+        const unsigned long long stops = ~cont & upto;                                   // (bit 0 is always one of them)
+        u32 r = 63u - static_cast<u32>(__builtin_clzll(stops));                           // the run l, l - 1, .., r
+        if (l - r + 1 > left) r = l + 1 - left;
+        m |= upto & ~((1ULL << r) - 1ULL);
+        left -= l - r + 1;
+        j = static_cast<u32>(__shfl(static_cast<int>(pr), static_cast<int>(r), 64));       // where element r came from
+      }
+      if (lane == 0) maskbuf[b2] = m;
+    }
+    chain_sync<GLOBAL>();
+    u32 at = 0;
+    for (u32 b2 = 0; b2 < nblk; ++b2) {
+      const unsigned long long m = maskbuf[b2];
+      if ((m >> lane) & 1ULL) tail_idx[at + static_cast<u32>(__popcll(m & ((1ULL << lane) - 1ULL)))] = static_cast<IdxT>((b2 << 6) + lane);
+      at += static_cast<u32>(__popcll(m));
     }
     chain_sync<GLOBAL>();
     // positions of the chain elements into tail_pos[0 .. longest)
     for (u32 m = lane; m < longest; m += 64) tail_pos[m] = p[tail_idx[m]];
     chain_sync<GLOBAL>();
   }
-  chain_emit([&](u32 m) { return tail_pos[m]; }, longest, strand, g0, lhs_id, k, chain, min_matches, gap, slots,
-             slot_flags, lane == 0, anchors, anchor_base, slot_aoff, slot_acnt);
+  chain_emit_wave([&](u32 m) { return tail_pos[m]; }, longest, strand, g0, lhs_id, k, chain, min_matches, gap, slots,
+                  slot_flags, anchors, anchor_base, slot_aoff, slot_acnt);
 }
 
 // Size classes of the chain stage.  Every interval of more than kChainSmallCap matches is handled by ONE wave = one
