@@ -728,7 +728,7 @@ constexpr int kTbG = 2;
 struct alignas(16) Poa4LdsTb {
   // per row of the round: the 16 code bytes of its 32 columns ALIGNED TO THE COLUMN (byte (j >> 1) & 15 holds the codes of
   // columns j, j + 1: where the code of (row, j) lies does not depend on the row's band start, so the walk reads it beside
-  // the row's record, not behind it), then {d0, d1, d7, -}
+  // the row's record, not behind it), then {band start | edge flags | in-edges, node, rank distances of in-edges 0..5, -}
   uint4 row[P4::G][16 * kTbG][2];
 };
 // the 16 code bytes of a row (its steps 0 .. 15 start at byte S % 8 of the 24 the lane fetched) rotated so that the byte of
@@ -769,7 +769,7 @@ __host__ __device__ inline void poa4_traceback(const Poa4Args A, Poa4LdsTb& S, u
   bool done = !act || i == 0;
   u32 steps = 0, n_switch = 0;
   unsigned long long t_change = 0;
-  i32 near_lo = 99, near_hi = -1;
+  u32 pbuf = kNone4, pblk = 0xFFFFFFFFu;  // the node of position 16 pblk + lane-of-the-window, for the block the walk is in
   // the next round (descriptors and codes in flight), the round after (descriptors in flight)
   u32 nd0[kTbG] = {}, nd1[kTbG] = {}, nd7[kTbG] = {}, fd0[kTbG] = {}, fd1[kTbG] = {}, fd7[kTbG] = {};
   // (native vectors, not HIP's uint4 class: arrays of the latter stay in scratch memory when passed by reference)
@@ -801,6 +801,9 @@ __host__ __device__ inline void poa4_traceback(const Poa4Args A, Poa4LdsTb& S, u
     // ---- change of round, all windows at once ----
     const u32 rnd = done ? c_rnd : (i - 1) / (16 * kTbG);
     const bool change = !done && rnd != c_rnd;
+    // (the step and cycle counters of this function stay in the product build: without them — nothing else changed — the
+    // kernel measured 18 % SLOWER on the same box, 700 against 592 ms per C4 round, at every setting of the block alignment;
+    // the generated code differs by the two s_memtime reads and a handful of register moves.  Not understood)
     const unsigned long long tc0 = sv::clock();
     if (sv::any(change)) {
       lds_order();  // the walks of the previous round have read their last row
@@ -815,7 +818,9 @@ __host__ __device__ inline void poa4_traceback(const Poa4Args A, Poa4LdsTb& S, u
         for (int h = 0; h < kTbG; ++h) {
           uint4* dst = S.row[q][16 * h + gl];
           dst[0] = poa4_align_codes(na[h].x, na[h].y, nb[h].x, nb[h].y, nc[h].x, nc[h].y, (nd0[h] & 0xFFFFu) >> 1, (nd1[h] >> 16) & 0x3FFu);
-          dst[1] = uint4{nd0[h], nd1[h], nd7[h], 0u};
+          const u32 bt = (nd1[h] >> 16) & 0x3FFu;
+          dst[1] = uint4{bt | (bt != 0 ? 0x10000u : 0u) | (bt + K::kBand < w ? 0x20000u : 0u) | (((nd1[h] >> 26) & 15u) << 20),
+                         nd1[h] & 0xFFFFu, nd7[h], 0u};
         }
         c_rnd = rnd;
         if (rnd >= 1) {
@@ -852,16 +857,22 @@ __host__ __device__ inline void poa4_traceback(const Poa4Args A, Poa4LdsTb& S, u
     while (sv::any(in_round)) {
       P4_MARK("tb_step_begin");
       const u32 l = (i - 1) & (16 * kTbG - 1);
+      // the row's record and the code under column j: ONE round trip to LDS (rounds 4-5 read the rank distances behind a
+      // test of the in-degree, a third dependent read); the code of column j is byte (j >> 1) & 15 of the row whatever its
+      // band start
       const uint4 d = S.row[q][l][1];
-      // (the code of column j: byte (j >> 1) & 15 of the row, whatever its band start — read beside the record)
-      const u32 code = (static_cast<u32>(reinterpret_cast<const u8*>(S.row[q][l])[(static_cast<u32>(j) >> 1) & 15u]) >>
-                        (4u * (static_cast<u32>(j) & 1u))) & 15u;  // 0: horizontal; else diagonal << 3 | 7 - in-edge
-      const u32 bt = (d.y >> 16) & 0x3FFu, np = (d.y >> 26) & 15u, node = d.y & 0xFFFFu;
+      u32 byte = reinterpret_cast<const u8*>(S.row[q][l])[(static_cast<u32>(j) >> 1) & 15u];
+#if defined(__HIP_DEVICE_COMPILE__)
+      asm volatile("" : "+v"(byte) : "v"(d.x), "v"(d.y), "v"(d.z));  // (all of it is wanted here, not where a branch first asks for it)
+#endif
+      const u32 code = (byte >> (4u * (static_cast<u32>(j) & 1u))) & 15u;  // 0: horizontal; else diagonal << 3 | 7 - in-edge
+      // d.x: band start | (band start != 0) << 16 | (the matrix goes on right of the band) << 17 | in-edges << 20; d.y: node
+      const u32 bt = d.x & 0xFFFFu, np = (d.x >> 20) & 15u, node = d.y;
       const u32 idx = static_cast<u32>(j) - bt;
       const bool oob = idx >= static_cast<u32>(K::kBand);  // the path left the stored band
       bool isH = code == 0u;
       const u32 k = (~code) & 7u;
-      u32 ni = np ? i - ((d.z >> (k < 6 ? 5 * k : 0u)) & 31u) : 0u;
+      u32 ni = np ? i - ((d.z >> (5u * k)) & 31u) : 0u;  // (k >= 6: corrected below)
       if (sv::any(in_round && np >= 7)) {  // rows of seven or eight in-edges (1 % of the windows have one)
         // code 0 in a row of eight in-edges is "horizontal" or "vertical through the eighth": the NW left the answer in the
         // row's v7 mask; in-edges 6 and 7: their ranks come from the graph
@@ -874,10 +885,24 @@ __host__ __device__ inline void poa4_traceback(const Poa4Args A, Poa4LdsTb& S, u
       }
       // (a diagonal or horizontal code in column 0 — never on a consistent stream — leaves the band in the next step)
       const bool ok = in_round && !oob;
-      if (ok && (code & 8u) && j > 0 && gl == 0) pos_node[j - 1] = static_cast<u16>(node);  // (an insertion leaves pos_node[j] at kNone)
-      // the nearest the path comes to an edge of the band beyond which the matrix goes on (band_hit after the walk)
-      near_lo = imin(near_lo, (ok && bt != 0) ? static_cast<i32>(idx) : 99);
-      near_hi = imax(near_hi, (ok && bt + K::kBand < w) ? static_cast<i32>(idx) : -1);
+      // ---- the node a diagonal move aligns position j - 1 to: sixteen positions are collected in the window's lanes (lane =
+      // position mod 16) and leave as one 32-byte store when the walk enters another block of sixteen; a position the walk
+      // passes horizontally stays kNone, as the set-up left every position (rounds 4-5: one 2-byte store per diagonal step) ----
+      const bool diag = ok && (code & 8u) != 0 && j > 0;
+      const u32 p = static_cast<u32>(j) - 1u;
+      if (sv::any(diag && (p >> 4) != pblk)) {
+        const bool fl = diag && (p >> 4) != pblk;
+        if (fl && pblk != 0xFFFFFFFFu) pos_node[16u * pblk + static_cast<u32>(gl)] = static_cast<u16>(pbuf);
+        if (fl) {
+          pbuf = kNone4;
+          pblk = p >> 4;
+        }
+      }
+      pbuf = (diag && (p & 15u) == static_cast<u32>(gl)) ? node : pbuf;
+      // ---- how near the path comes to an edge of the band beyond which the matrix goes on: within two cells = a band hit ----
+      if (sv::any(ok && (idx - 2u) > static_cast<u32>(K::kBand - 5))) {
+        if (ok && ((idx < 2u && (d.x & 0x10000u)) || (idx > static_cast<u32>(K::kBand - 3) && (d.x & 0x20000u)))) band_hit = 1;
+      }
       if (in_round && oob) band_hit = 1;
       steps += in_round ? 1u : 0u;
       j -= ok ? static_cast<i32>(isH ? 1u : (code >> 3)) : 0;
@@ -888,7 +913,7 @@ __host__ __device__ inline void poa4_traceback(const Poa4Args A, Poa4LdsTb& S, u
       P4_MARK("tb_step_end");
     }
   }
-  if (near_lo < 2 || near_hi > K::kBand - 3) band_hit = 1;
+  if (pblk != 0xFFFFFFFFu) pos_node[16u * pblk + static_cast<u32>(gl)] = static_cast<u16>(pbuf);  // the positions of the last block
   if (A.phase_cycles && gl == 0 && act) {
     sv::atomic_add(&A.phase_cycles[11], static_cast<unsigned long long>(steps));
     sv::atomic_add(&A.phase_cycles[12], static_cast<unsigned long long>(n_switch));
