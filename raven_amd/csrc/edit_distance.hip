@@ -17,6 +17,7 @@
 //     update, stripe boundaries through a small global array).
 // Integer VALU bound (no MFMA, negligible HBM): report cell updates/s.
 #include <algorithm>
+#include <cstring>
 
 #include "engine.h"
 #include "myers.h"
@@ -121,6 +122,10 @@ __device__ u32 ed_banded(const u64* __restrict__ a_words, u64 a_base, u32 n, con
 }
 
 constexpr u32 kEdAbove = 0xFFFFFFFEu;  // bounded mode: the distance exceeds the pair's threshold (its exact value is not needed)
+// internal to edit_distance_dev: "beyond the WIDEST lane window" (the wave kernel's business; a pair that overflowed a narrower
+// window gets a second lane pass with the widest one first).  Never leaves this file.
+constexpr u32 kEdOverflowWide = 0xFFFFFFFDu;
+constexpr int kEdLaneWidest = 8;  // blocks of the widest lane window
 
 // One wave per pair.  todo: indices of the pairs to process (null = all).  kmax (nullable): per-pair threshold — a
 // caller that only needs to know whether the distance is <= kmax (the identity filters: score >= identity) gets the
@@ -196,8 +201,9 @@ __global__ __launch_bounds__(64) void ed_lane_kernel(const u64* __restrict__ pac
     return;
   }
   constexpr u32 room = 64u * (B - 2);  // lo + hi of the widest band B blocks can hold
+  constexpr u32 kOverflow = B >= kEdLaneWidest ? kEdOverflowWide : kEdOverflow;
   if (d > room) {
-    out[p] = kEdOverflow;
+    out[p] = kOverflow;
     return;
   }
   u32 k = d + ((room - d) / 2) * 2 + 1;
@@ -278,7 +284,7 @@ __global__ __launch_bounds__(64) void ed_lane_kernel(const u64* __restrict__ pac
   u32 res;
   if (result <= k) res = result;
   else if (k >= km) res = kEdAbove;
-  else res = kEdOverflow;
+  else res = kOverflow;
   out[p] = res;
 }
 
@@ -288,13 +294,60 @@ __global__ void ed_keys_kernel(const EdPair* __restrict__ pairs, u32 n, u32* __r
   keys[i] = 0xFFFFFFFFu - pairs[i].b_len;  // longest text first
   vals[i] = i;
 }
-__global__ void ed_collect_overflow_kernel(const u32* __restrict__ out, u32 n, u32* __restrict__ todo, u32* __restrict__ cnt) {
+// wide: also the pairs beyond the widest lane window (what the wave kernel takes); otherwise only those a narrower window lost
+__global__ void ed_collect_overflow_kernel(const u32* __restrict__ out, u32 n, bool wide, u32* __restrict__ todo, u32* __restrict__ cnt) {
   const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n && out[i] == kEdOverflow) todo[atomicAdd(cnt, 1u)] = i;
+  if (i < n && (out[i] == kEdOverflow || (wide && out[i] == kEdOverflowWide))) todo[atomicAdd(cnt, 1u)] = i;
 }
-__global__ void ed_count_done_kernel(const u32* __restrict__ out, const u32* __restrict__ order, u32 n, u32* __restrict__ cnt) {
+// The sample's verdict: cnt[1] = pairs the widest lane window decided, cnt[16 + b] = histogram of distance / length in steps
+// of 1 / 1024 over the pairs whose distance is known (b = 63: 6.2 % and more).
+constexpr u32 kEdHistBins = 64, kEdHistAt = 16, kEdBoundsAt = 2;
+__global__ void ed_sample_kernel(const EdPair* __restrict__ pairs, const u32* __restrict__ out, const u32* __restrict__ sample, u32 n,
+                                 u32* __restrict__ cnt) {
   const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n && out[order[i]] != kEdOverflow) atomicAdd(cnt, 1u);
+  if (i >= n) return;
+  const u32 p = sample[i];
+  const u32 o = out[p];
+  if (o != kEdOverflowWide) atomicAdd(cnt + 1, 1u);
+  if (o < kEdOverflowWide) {
+    const u32 len = max(max(pairs[p].a_len, pairs[p].b_len), 1u);
+    atomicAdd(cnt + kEdHistAt + min<u32>(kEdHistBins - 1, static_cast<u32>((static_cast<u64>(o) << 10) / len)), 1u);
+  }
+}
+// Window classes of the lane kernel.  The pairs are sorted by text length (longest first), the distance a pair is expected
+// to have is rate x length with the rate of the sample's 90th percentile + 10 % + 16: a class is a contiguous piece of the
+// order.  cnt[kEdBoundsAt + c] = first position whose pair fits the window of class c (windows kEdClassB, narrowest first);
+// a wrong guess costs a second pass with the widest window, never a result.
+constexpr int kEdClasses = 4;                        // narrower windows than the widest one
+__constant__ int kEdClassB[kEdClasses] = {3, 4, 5, 6};
+__global__ void ed_classes_kernel(const u32* __restrict__ sorted_keys, u32 n_main, u32* __restrict__ cnt) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  u32 total = 0;
+  for (u32 b = 0; b < kEdHistBins; ++b) total += cnt[kEdHistAt + b];
+  u32 bin = kEdHistBins - 1;
+  if (total) {
+    u32 run = 0;
+    for (u32 b = 0; b < kEdHistBins; ++b) {
+      run += cnt[kEdHistAt + b];
+      if (10ULL * run >= 9ULL * total) {
+        bin = b;
+        break;
+      }
+    }
+  }
+  for (int c = 0; c < kEdClasses; ++c) {
+    const u32 room = 64u * static_cast<u32>(kEdClassB[c] - 2);
+    // rate = (bin + 1) / 1024, need = 1.1 rate len + 16 <= room  <=>  len <= (room - 16) * 1024 / (1.1 (bin + 1))
+    const u32 len_max = total ? static_cast<u32>((static_cast<u64>(room - 16) * 10240ULL) / (11ULL * (bin + 1))) : 0u;
+    const u32 key_min = 0xFFFFFFFFu - len_max;  // keys = 0xFFFFFFFF - text length, ascending
+    u32 lo = 0, hi = n_main;
+    while (lo < hi) {
+      const u32 mid = lo + (hi - lo) / 2;
+      if (sorted_keys[mid] < key_min) lo = mid + 1;
+      else hi = mid;
+    }
+    cnt[kEdBoundsAt + c] = lo;
+  }
 }
 
 // Unbanded striped sweep (fallback; any distance): stripes of 64 blocks, lane = block, boundary hout per column
@@ -363,8 +416,8 @@ void edit_distance_dev(Engine& e, const ReadsDev& r, const u32* d_pairs_raw, u32
   if (n_pairs == 0) return;
   hipStream_t s = e.stream;
   const EdPair* d_pairs = reinterpret_cast<const EdPair*>(d_pairs_raw);
-  u32* d_cnt = e.ed_cnt.get<u32>(8);
-  RVN_HIP(hipMemsetAsync(d_cnt, 0, 32, s));
+  u32* d_cnt = e.ed_cnt.get<u32>(kEdHistAt + kEdHistBins);
+  RVN_HIP(hipMemsetAsync(d_cnt, 0, (kEdHistAt + kEdHistBins) * 4, s));
   RVN_HIP(hipMemsetAsync(d_out, 0xFF, static_cast<size_t>(n_pairs) * 4, s));  // everything starts as "needs the wave kernel"
   // ---- stage 1: one lane per pair for narrow bands.  Tried on a sample first: it pays only when most pairs are
   // closer than ~384 edits (HiFi-like); for ONT-like spans nearly every pair would come back as overflow.
@@ -377,21 +430,68 @@ void edit_distance_dev(Engine& e, const ReadsDev& r, const u32* d_pairs_raw, u32
   const int which = radix_sort_pairs_u32_u32(d_sk, d_sk1, d_sv, d_sv1, n_pairs, 32, e.sort_tmp, e.scan_tmp, s, kKPileSortUp,
                                              kKPileSortDown);
   const u32* d_order = which ? d_sv1 : d_sv;
+  const u32* d_sorted_keys = which ? d_sk1 : d_sk;
   const u32 n_sample = std::min<u32>(n_pairs, 2048);
+  const u32 n_main = n_pairs - n_sample;
   // the sample: every (n_pairs / n_sample)-th pair of the sorted order would need a gather; the shortest pairs (the
   // tail of the order) are the cheapest probe and representative of the error level
-  const u32* d_sample = d_order + (n_pairs - n_sample);
-  RVN_KLAUNCH(kKEditLane, ed_lane_kernel<8><<<div_up(n_sample, 64), 64, 0, s>>>(r.packed.as<u64>(), r.word_off.as<u64>(), d_pairs,
-                                                                               d_sample, n_sample, d_kmax, d_out));
-  ed_count_done_kernel<<<div_up(n_sample, 256), 256, 0, s>>>(d_out, d_sample, n_sample, d_cnt + 1);
+  const u32* d_sample = d_order + n_main;
+  RVN_KLAUNCH(kKEditLane, ed_lane_kernel<kEdLaneWidest><<<div_up(n_sample, 64), 64, 0, s>>>(
+                              r.packed.as<u64>(), r.word_off.as<u64>(), d_pairs, d_sample, n_sample, d_kmax, d_out));
+  ed_sample_kernel<<<div_up(n_sample, 256), 256, 0, s>>>(d_pairs, d_out, d_sample, n_sample, d_cnt);
   RVN_LAUNCH_CHECK();
-  const u32 done = static_cast<u32>(read_back(e, d_cnt + 1, 4));
-  if (2 * done >= n_sample && n_pairs > n_sample)
-    RVN_KLAUNCH(kKEditLane, ed_lane_kernel<8><<<div_up(n_pairs - n_sample, 64), 64, 0, s>>>(
-                                r.packed.as<u64>(), r.word_off.as<u64>(), d_pairs, d_order, n_pairs - n_sample, d_kmax, d_out));
-  // ---- stage 2: the wave-per-pair kernel for what is left ----
+  ed_classes_kernel<<<1, 64, 0, s>>>(d_sorted_keys, n_main, d_cnt);
+  RVN_LAUNCH_CHECK();
+  read_back(e, d_cnt, (kEdBoundsAt + kEdClasses) * 4);
+  u32 h_cnt[kEdBoundsAt + kEdClasses];
+  std::memcpy(h_cnt, e.h_pin, sizeof(h_cnt));
+  const u32 done = h_cnt[1];
+  bool narrow_used = false;
+  if (2 * done >= n_sample && n_main) {
+    // a window as wide as the pair is expected to need (the work of a lane is proportional to the blocks of its window: with
+    // the widest one for everybody the HiFi identity filter computed 8 blocks per column where 3 to 5 hold the band)
+    u32 from = 0;  // positions [from, to) of the order take the window of B blocks; widest (longest pairs) first
+    auto piece = [&](u32 to, int B) {
+      to = std::min(std::max(to, from), n_main);
+      const u32 cn = to - from;
+      const u32* ord = d_order + from;
+      from = to;
+      if (!cn) return;
+#define RVN_ED_LANE(B_)                                                                                        \
+  case B_:                                                                                                      \
+    RVN_KLAUNCH(kKEditLane, ed_lane_kernel<B_><<<div_up(cn, 64), 64, 0, s>>>(r.packed.as<u64>(), r.word_off.as<u64>(), \
+                                                                           d_pairs, ord, cn, d_kmax, d_out));   \
+    break
+      switch (B) {
+        RVN_ED_LANE(3);
+        RVN_ED_LANE(4);
+        RVN_ED_LANE(5);
+        RVN_ED_LANE(6);
+        default:
+          RVN_KLAUNCH(kKEditLane, ed_lane_kernel<kEdLaneWidest><<<div_up(cn, 64), 64, 0, s>>>(
+                                      r.packed.as<u64>(), r.word_off.as<u64>(), d_pairs, ord, cn, d_kmax, d_out));
+      }
+#undef RVN_ED_LANE
+      if (B < kEdLaneWidest) narrow_used = true;
+    };
+    static const int class_b[kEdClasses] = {3, 4, 5, 6};  // (= kEdClassB on the device)
+    piece(h_cnt[kEdBoundsAt + kEdClasses - 1], kEdLaneWidest);
+    for (int c = kEdClasses - 1; c >= 1; --c) piece(h_cnt[kEdBoundsAt + c - 1], class_b[c]);
+    piece(n_main, class_b[0]);
+  }
   u32* d_todo = e.ed_todo.get<u32>(static_cast<size_t>(n_pairs) + 1);
-  ed_collect_overflow_kernel<<<div_up(n_pairs, 256), 256, 0, s>>>(d_out, n_pairs, d_todo, d_cnt);
+  if (narrow_used) {  // second chance with the widest window for the pairs a narrower one lost
+    RVN_HIP(hipMemsetAsync(d_cnt, 0, 4, s));
+    ed_collect_overflow_kernel<<<div_up(n_pairs, 256), 256, 0, s>>>(d_out, n_pairs, false, d_todo, d_cnt);
+    RVN_LAUNCH_CHECK();
+    const u32 n_again = static_cast<u32>(read_back(e, d_cnt, 4));
+    if (n_again)
+      RVN_KLAUNCH(kKEditLane, ed_lane_kernel<kEdLaneWidest><<<div_up(n_again, 64), 64, 0, s>>>(
+                                  r.packed.as<u64>(), r.word_off.as<u64>(), d_pairs, d_todo, n_again, d_kmax, d_out));
+  }
+  // ---- stage 2: the wave-per-pair kernel for what is left ----
+  RVN_HIP(hipMemsetAsync(d_cnt, 0, 4, s));
+  ed_collect_overflow_kernel<<<div_up(n_pairs, 256), 256, 0, s>>>(d_out, n_pairs, true, d_todo, d_cnt);
   RVN_LAUNCH_CHECK();
   const u32 n_todo = static_cast<u32>(read_back(e, d_cnt, 4));
   if (n_todo == 0) return;
@@ -399,7 +499,7 @@ void edit_distance_dev(Engine& e, const ReadsDev& r, const u32* d_pairs_raw, u32
                                 r.packed.as<u64>(), r.word_off.as<u64>(), d_pairs, d_todo, n_todo, d_kmax, d_out));
   // ---- stage 3: pairs beyond the ring capacity (rare): unbanded striped sweep, exact ----
   RVN_HIP(hipMemsetAsync(d_cnt, 0, 4, s));
-  ed_collect_overflow_kernel<<<div_up(n_pairs, 256), 256, 0, s>>>(d_out, n_pairs, d_todo, d_cnt);
+  ed_collect_overflow_kernel<<<div_up(n_pairs, 256), 256, 0, s>>>(d_out, n_pairs, true, d_todo, d_cnt);
   RVN_LAUNCH_CHECK();
   const u32 n_full = static_cast<u32>(read_back(e, d_cnt, 4));
   if (n_full == 0) return;

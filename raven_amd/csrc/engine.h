@@ -202,7 +202,7 @@ struct Engine {
   u64 c_intervals = 0;
   bool timing = true;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  hipStream_t nw_streams[4] = {nullptr, nullptr, nullptr, nullptr};  // walk streams of the alignment-path stage (beside the sweeps): one per buffer set
+  hipStream_t nw_streams[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // alignment-path stage: [0..3] walk streams (beside the sweeps), one per buffer set; [4] uploads of a pass planned while another one sweeps
   hipEvent_t nw_ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // [0..3] the walk of a buffer set is done, [4] sweep -> walk
   u64* h_pin = nullptr;  // pinned host scratch for small device->host size read-backs
   PinBuf pin_big;        // pinned staging for bulk read-backs up to 256 MB (polishing: chain anchors)

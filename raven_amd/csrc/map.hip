@@ -165,16 +165,27 @@ __global__ void gather_u64_by_u32_kernel(const u64* __restrict__ src, const u32*
 }
 
 // ---- wave-level segmented LSD radix sort ---------------------------------------------------------
-// Sorts keys k0[b, b+n) (payload p0) stably by the full 64-bit key; result always ends in k0/p0.
+// Sorts keys k0[b, b+n) (payload p0 when PAY) stably by the full 64-bit key; result always ends in k0/p0.  For the segments
+// that do not fit a workgroup's LDS (HiFi: 10 000 - 100 000 matches of one read).  hist: 2 x 256 counters of the wave.
+// Round 6: a pass is ONE sweep over the segment — the counts of the next digit are taken while the current one is
+// scattered (and those of byte 0 while the varying bits are found), where rounds 1-5 read the keys a second time per pass —
+// and a sweep takes four batches of 64 at a time, all their loads issued before the first rank is computed (a wave's
+// passes are chains of dependent global loads: the stage ran at 4 % of the HBM rate, bound by their latency).
+template <bool PAY>
 __device__ void wave_sort_segment(u64* __restrict__ k0, u64* __restrict__ k1, u64* __restrict__ p0,
                                   u64* __restrict__ p1, u64 b, u64 n, u32* hist) {
   const int lane = lane_id();
   const unsigned long long lt = lanemask_lt();
+  u32* h_cur = hist;         // counts / running offsets of the digit being scattered
+  u32* h_nxt = hist + 256;   // counts of the next digit
+  for (int i = lane; i < 256; i += 64) h_nxt[i] = 0;
+  __builtin_amdgcn_wave_barrier();
   u64 o = 0, a = ~0ULL;
   for (u64 i = lane; i < n; i += 64) {
     const u64 key = k0[b + i];
     o |= key;
     a &= key;
+    atomicAdd(&h_nxt[key & 0xFF], 1u);
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
@@ -183,49 +194,71 @@ __device__ void wave_sort_segment(u64* __restrict__ k0, u64* __restrict__ k1, u6
   }
   const u64 varying = o ^ a;
   int cur = 0;
+  bool have_counts = true;  // h_nxt holds the counts of byte 0
+  int counted_shift = 0;
   for (int shift = 0; shift < 64; shift += 8) {
     if (((varying >> shift) & 0xFF) == 0) continue;
     const u64* kin = cur ? k1 : k0;
     const u64* pin = cur ? p1 : p0;
     u64* kout = cur ? k0 : k1;
     u64* pout = cur ? p0 : p1;
-    for (int i = lane; i < 256; i += 64) hist[i] = 0;
     __builtin_amdgcn_wave_barrier();
-    for (u64 base = 0; base < n; base += 64) {
-      const u64 i = base + lane;
-      if (i < n) atomicAdd(&hist[(kin[b + i] >> shift) & 0xFF], 1u);
+    if (have_counts && counted_shift == shift) {
+      u32* t = h_cur;
+      h_cur = h_nxt;
+      h_nxt = t;
+    } else {  // (the first varying byte is not byte 0: one counting sweep)
+      for (int i = lane; i < 256; i += 64) h_cur[i] = 0;
+      __builtin_amdgcn_wave_barrier();
+      for (u64 i = lane; i < n; i += 64) atomicAdd(&h_cur[(kin[b + i] >> shift) & 0xFF], 1u);
     }
+    int nshift = shift + 8;
+    while (nshift < 64 && ((varying >> nshift) & 0xFF) == 0) nshift += 8;
+    have_counts = nshift < 64;
+    counted_shift = nshift;
     __builtin_amdgcn_wave_barrier();
     {
-      const u32 h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
+      const u32 h0 = h_cur[4 * lane], h1 = h_cur[4 * lane + 1], h2 = h_cur[4 * lane + 2], h3 = h_cur[4 * lane + 3];
       const u32 s = h0 + h1 + h2 + h3;
       const u32 ex = wave_inclusive_sum(s) - s;
       __builtin_amdgcn_wave_barrier();
-      hist[4 * lane] = ex;
-      hist[4 * lane + 1] = ex + h0;
-      hist[4 * lane + 2] = ex + h0 + h1;
-      hist[4 * lane + 3] = ex + h0 + h1 + h2;
+      h_cur[4 * lane] = ex;
+      h_cur[4 * lane + 1] = ex + h0;
+      h_cur[4 * lane + 2] = ex + h0 + h1;
+      h_cur[4 * lane + 3] = ex + h0 + h1 + h2;
+      for (int i = lane; i < 256; i += 64) h_nxt[i] = 0;
     }
     __builtin_amdgcn_wave_barrier();
-    for (u64 base = 0; base < n; base += 64) {
-      const u64 i = base + lane;
-      const bool valid = i < n;
-      u64 key = 0, pay = 0;
-      if (valid) {
-        key = kin[b + i];
-        pay = pin[b + i];
+    for (u64 base = 0; base < n; base += 256) {
+      u64 key[4], pay[4];
+      bool valid[4];
+#pragma unroll
+      for (int x = 0; x < 4; ++x) {
+        const u64 i = base + 64 * x + lane;
+        valid[x] = i < n;
+        key[x] = 0;
+        pay[x] = 0;
+        if (valid[x]) {
+          key[x] = kin[b + i];
+          if (PAY) pay[x] = pin[b + i];
+        }
       }
-      const unsigned d = static_cast<unsigned>((key >> shift) & 0xFF);
-      const unsigned long long peers = match_digit8(d, valid);
-      u32 before = 0;
-      if (valid) before = hist[d];
-      __builtin_amdgcn_wave_barrier();
-      const u32 rank = before + __popcll(peers & lt);
-      if (valid && (peers & lt) == 0) hist[d] = before + __popcll(peers);
-      __builtin_amdgcn_wave_barrier();
-      if (valid) {
-        kout[b + rank] = key;
-        pout[b + rank] = pay;
+#pragma unroll
+      for (int x = 0; x < 4; ++x) {
+        if (base + 64 * x >= n) break;  // (uniform)
+        const unsigned d = static_cast<unsigned>((key[x] >> shift) & 0xFF);
+        const unsigned long long peers = match_digit8(d, valid[x]);
+        u32 before = 0;
+        if (valid[x]) before = h_cur[d];
+        __builtin_amdgcn_wave_barrier();
+        const u32 rank = before + __popcll(peers & lt);
+        if (valid[x] && (peers & lt) == 0) h_cur[d] = before + __popcll(peers);
+        __builtin_amdgcn_wave_barrier();
+        if (valid[x]) {
+          kout[b + rank] = key[x];
+          if (PAY) pout[b + rank] = pay[x];
+          if (have_counts) atomicAdd(&h_nxt[(key[x] >> nshift) & 0xFF], 1u);
+        }
       }
     }
     __threadfence_block();  // this wave's stores must be visible to its other lanes' loads next pass
@@ -234,36 +267,38 @@ __device__ void wave_sort_segment(u64* __restrict__ k0, u64* __restrict__ k1, u6
   if (cur) {
     for (u64 i = lane; i < n; i += 64) {
       k0[b + i] = k1[b + i];
-      p0[b + i] = p1[b + i];
+      if (PAY) p0[b + i] = p1[b + i];
     }
     __threadfence_block();
   }
 }
 
-// ---- block-level segmented sort in LDS (per-read group sort) ---------------------------------------
-// One workgroup per segment of <= kSegLdsCap (key, payload) pairs: all LSD passes ping-pong between two LDS
-// buffers, HBM sees one coalesced read and one coalesced write (the global-memory version moved ~20x the
-// data, profiles/r01_g_final_pmc_*).  Larger segments are left to seg_sort_off_kernel.
+// ---- block-level segmented sort in LDS ----------------------------------------------------------------
+// One workgroup of NT threads per segment of <= cap keys (payloads beside them when PAY): all LSD passes ping-pong between
+// two LDS buffers, HBM sees one coalesced read and one coalesced write (the global-memory version moved ~20x the data,
+// profiles/r01_g_final_pmc_*).  smem: seg_sort_lds_bytes(cap).
 constexpr u32 kSegLdsCap = 2048;
-__global__ __launch_bounds__(256) void seg_sort_lds_kernel(u64* __restrict__ keys, u64* __restrict__ pays,
-                                                          const u64* __restrict__ off, u32 n_seg) {
-  __shared__ u64 s_k[2][kSegLdsCap];
-  __shared__ u64 s_p[2][kSegLdsCap];
-  __shared__ u16 wave_cnt[4][256];
-  __shared__ u32 s4[4];
-  __shared__ u64 s_or[4], s_and[4];
-  const u32 seg = blockIdx.x;
-  if (seg >= n_seg) return;
-  const u64 b = off[seg];
-  const u32 n = static_cast<u32>(off[seg + 1] - b);
-  if (n < 2 || n > kSegLdsCap) return;
+template <int NT, bool PAY>
+constexpr size_t seg_sort_lds_bytes(u32 cap) {
+  return static_cast<size_t>(cap) * 8 * (PAY ? 4 : 2) + (NT / 64) * 256 * 2 + 32 + (NT / 64) * 16;
+}
+template <int NT, bool PAY>
+__device__ void block_sort_lds(u64* __restrict__ keys, u64* __restrict__ pays, u64 b, u32 n, u32 cap, unsigned char* smem) {
+  constexpr int NW = NT / 64;
+  static_assert(NT == 64 || NT == 256, "one wave or four");
+  u64* s_k = reinterpret_cast<u64*>(smem);                         // [2][cap]
+  u64* s_p = s_k + 2 * static_cast<size_t>(cap);                   // [2][cap] when PAY
+  u16* wave_cnt = reinterpret_cast<u16*>(s_p + (PAY ? 2 * static_cast<size_t>(cap) : 0));  // [NW][256]
+  u32* s4 = reinterpret_cast<u32*>(wave_cnt + NW * 256);           // 8 words
+  u64* s_or = reinterpret_cast<u64*>(s4 + 8);                      // [NW]
+  u64* s_and = s_or + NW;                                          // [NW]
   const int lane = lane_id();
   const int w = threadIdx.x >> 6;
   u64 o = 0, a = ~0ULL;
-  for (u32 i = threadIdx.x; i < n; i += 256) {
+  for (u32 i = threadIdx.x; i < n; i += NT) {
     const u64 k = keys[b + i];
-    s_k[0][i] = k;
-    s_p[0][i] = pays[b + i];
+    s_k[i] = k;
+    if (PAY) s_p[i] = pays[b + i];
     o |= k;
     a &= k;
   }
@@ -277,42 +312,61 @@ __global__ __launch_bounds__(256) void seg_sort_lds_kernel(u64* __restrict__ key
     s_and[w] = a;
   }
   __syncthreads();
-  const u64 varying = (s_or[0] | s_or[1] | s_or[2] | s_or[3]) ^ (s_and[0] & s_and[1] & s_and[2] & s_and[3]);
-  // wave w owns the contiguous quarter [q0, q1) of the segment (stable: rank order == index order)
-  const u32 per = (n + 3) / 4;
+  u64 all_or = 0, all_and = ~0ULL;
+#pragma unroll
+  for (int x = 0; x < NW; ++x) {
+    all_or |= s_or[x];
+    all_and &= s_and[x];
+  }
+  const u64 varying = all_or ^ all_and;
+  // wave w owns the contiguous share [q0, q1) of the segment (stable: rank order == index order)
+  const u32 per = (n + NW - 1) / NW;
   const u32 q0 = min(n, w * per), q1 = min(n, q0 + per);
   const unsigned long long lt = lanemask_lt();
-  int cur = 0;
+  u32 cur = 0;
   for (int shift = 0; shift < 64; shift += 8) {
     if (((varying >> shift) & 0xFF) == 0) continue;
-    for (int i = threadIdx.x; i < 4 * 256; i += 256) (&wave_cnt[0][0])[i] = 0;
+    const u64* kin = s_k + static_cast<size_t>(cur) * cap;
+    u64* kout = s_k + static_cast<size_t>(cur ^ 1) * cap;
+    const u64* pin = s_p + static_cast<size_t>(cur) * cap;
+    u64* pout = s_p + static_cast<size_t>(cur ^ 1) * cap;
+    for (int i = threadIdx.x; i < NW * 256; i += NT) wave_cnt[i] = 0;
     __syncthreads();
-    // pass 1: per-wave digit counts (kept as running ranks per element in registers is not possible for
-    // arbitrary n, so ranks are recomputed in pass 2 with the same ballot order)
+    // pass 1: per-wave digit counts (ranks are recomputed in pass 2 with the same ballot order)
+    u16* my_cnt = wave_cnt + w * 256;
     for (u32 base = q0; base < q1; base += 64) {
       const u32 i = base + lane;
       const bool valid = i < q1;
-      const unsigned d = valid ? static_cast<unsigned>((s_k[cur][i] >> shift) & 0xFF) : 0;
+      const unsigned d = valid ? static_cast<unsigned>((kin[i] >> shift) & 0xFF) : 0;
       const unsigned long long peers = match_digit8(d, valid);
-      if (valid && (peers & lt) == 0) wave_cnt[w][d] += static_cast<u16>(__popcll(peers));
+      if (valid && (peers & lt) == 0) my_cnt[d] += static_cast<u16>(__popcll(peers));
       __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();
-    {
+    if (NT == 256) {
       const int t = threadIdx.x;
-      u32 c[4], tot = 0;
+      u32 c[NW], tot = 0;
 #pragma unroll
-      for (int x = 0; x < 4; ++x) {
-        c[x] = wave_cnt[x][t];
+      for (int x = 0; x < NW; ++x) {
+        c[x] = wave_cnt[x * 256 + t];
         tot += c[x];
       }
       u32 total;
       u32 run = block_exclusive_sum_256<u32>(tot, s4, &total);
 #pragma unroll
-      for (int x = 0; x < 4; ++x) {
-        wave_cnt[x][t] = static_cast<u16>(run);
+      for (int x = 0; x < NW; ++x) {
+        wave_cnt[x * 256 + t] = static_cast<u16>(run);
         run += c[x];
       }
+    } else {  // one wave: lane l owns the digits 4 l .. 4 l + 3
+      const u32 h0 = wave_cnt[4 * lane], h1 = wave_cnt[4 * lane + 1], h2 = wave_cnt[4 * lane + 2], h3 = wave_cnt[4 * lane + 3];
+      const u32 sum = h0 + h1 + h2 + h3;
+      const u32 ex = wave_inclusive_sum(sum) - sum;
+      __builtin_amdgcn_wave_barrier();
+      wave_cnt[4 * lane] = static_cast<u16>(ex);
+      wave_cnt[4 * lane + 1] = static_cast<u16>(ex + h0);
+      wave_cnt[4 * lane + 2] = static_cast<u16>(ex + h0 + h1);
+      wave_cnt[4 * lane + 3] = static_cast<u16>(ex + h0 + h1 + h2);
     }
     __syncthreads();
     // pass 2: scatter in index order
@@ -321,52 +375,81 @@ __global__ __launch_bounds__(256) void seg_sort_lds_kernel(u64* __restrict__ key
       const bool valid = i < q1;
       u64 k = 0, pv = 0;
       if (valid) {
-        k = s_k[cur][i];
-        pv = s_p[cur][i];
+        k = kin[i];
+        if (PAY) pv = pin[i];
       }
       const unsigned d = static_cast<unsigned>((k >> shift) & 0xFF);
       const unsigned long long peers = match_digit8(d, valid);
       u32 before = 0;
-      if (valid) before = wave_cnt[w][d];
+      if (valid) before = my_cnt[d];
       __builtin_amdgcn_wave_barrier();
-      if (valid && (peers & lt) == 0) wave_cnt[w][d] = static_cast<u16>(before + __popcll(peers));
+      if (valid && (peers & lt) == 0) my_cnt[d] = static_cast<u16>(before + __popcll(peers));
       __builtin_amdgcn_wave_barrier();
       if (valid) {
         const u32 dst = before + __popcll(peers & lt);
-        s_k[cur ^ 1][dst] = k;
-        s_p[cur ^ 1][dst] = pv;
+        kout[dst] = k;
+        if (PAY) pout[dst] = pv;
       }
     }
     __syncthreads();
     cur ^= 1;
   }
-  for (u32 i = threadIdx.x; i < n; i += 256) {
-    keys[b + i] = s_k[cur][i];
-    pays[b + i] = s_p[cur][i];
+  const u64* kfin = s_k + static_cast<size_t>(cur) * cap;
+  const u64* pfin = s_p + static_cast<size_t>(cur) * cap;
+  for (u32 i = threadIdx.x; i < n; i += NT) {
+    keys[b + i] = kfin[i];
+    if (PAY) pays[b + i] = pfin[i];
   }
+}
+
+// per-read group sort: one workgroup per read segment of <= kSegLdsCap (key, payload) pairs; larger segments are left to
+// seg_sort_off_kernel
+__global__ __launch_bounds__(256) void seg_sort_lds_kernel(u64* __restrict__ keys, u64* __restrict__ pays,
+                                                          const u64* __restrict__ off, u32 n_seg) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[seg_sort_lds_bytes<256, true>(kSegLdsCap)];
+  const u32 seg = blockIdx.x;
+  if (seg >= n_seg) return;
+  const u64 b = off[seg];
+  const u64 n = off[seg + 1] - b;
+  if (n < 2 || n > kSegLdsCap) return;
+  block_sort_lds<256, true>(keys, pays, b, static_cast<u32>(n), kSegLdsCap, smem);
 }
 
 // segments given by off[seg], off[seg+1]
 __global__ __launch_bounds__(256) void seg_sort_off_kernel(u64* k0, u64* k1, u64* p0, u64* p1,
                                                           const u64* __restrict__ off, u32 n_seg) {
-  __shared__ u32 hist[4][256];
+  __shared__ u32 hist[4][512];
   const u32 seg = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (seg >= n_seg) return;
   const u64 b = off[seg], e = off[seg + 1];
   if (e - b <= kSegLdsCap) return;  // sorted by seg_sort_lds_kernel
-  wave_sort_segment(k0, k1, p0, p1, b, e - b, hist[threadIdx.x >> 6]);
+  wave_sort_segment<true>(k0, k1, p0, p1, b, e - b, hist[threadIdx.x >> 6]);
 }
 
-// segments given by begin[seg], end[seg]; segments shorter than min_n are skipped
-__global__ __launch_bounds__(256) void seg_sort_be_kernel(u64* k0, u64* k1, u64* p0, u64* p1,
-                                                         const u64* __restrict__ begin,
-                                                         const u64* __restrict__ end, u32 n_seg, u32 min_n) {
-  __shared__ u32 hist[4][256];
-  const u32 seg = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (seg >= n_seg) return;
-  const u64 b = begin[seg], e = end[seg];
-  if (e - b < 2 || e - b < min_n) return;
-  wave_sort_segment(k0, k1, p0, p1, b, e - b, hist[threadIdx.x >> 6]);
+// Position sort of the intervals of one size class (the chain stage's lists: chain_class_list_kernel), KEYS ONLY — the
+// payload of rounds 1-5, the group words, is the same (target, strand) for every match of an interval and nothing behind
+// this sort reads a group word's diagonal (the chain kernels take target and strand from the interval's first word), so it
+// stays where it is.  One workgroup per interval, the interval in LDS sized for the class.
+template <int NT>
+__global__ __launch_bounds__(NT) void seg_sort_pos_lds_kernel(u64* __restrict__ pos, const u64* __restrict__ iv_begin,
+                                                             const u64* __restrict__ iv_end, const u32* __restrict__ list,
+                                                             u32 n_list, u32 cap) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char seg_smem[];
+  if (blockIdx.x >= n_list) return;
+  const u32 t = list[blockIdx.x];
+  const u64 b = iv_begin[t];
+  block_sort_lds<NT, false>(pos, nullptr, b, static_cast<u32>(iv_end[t] - b), cap, seg_smem);
+}
+// ... and of the intervals beyond the largest class: a wave each, through global memory
+__global__ __launch_bounds__(256) void seg_sort_pos_big_kernel(u64* k0, u64* k1, const u64* __restrict__ iv_begin,
+                                                              const u64* __restrict__ iv_end, const u32* __restrict__ list,
+                                                              u32 n_list) {
+  __shared__ u32 hist[4][512];
+  const u32 q = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (q >= n_list) return;
+  const u32 t = list[q];
+  const u64 b = iv_begin[t], e = iv_end[t];
+  wave_sort_segment<false>(k0, k1, nullptr, nullptr, b, e - b, hist[threadIdx.x >> 6]);
 }
 
 // ---- diagonal-band intervals (ram Chain, first loop) ------------------------------------------
@@ -1020,9 +1103,39 @@ void chain_matches(Engine& e, const ReadsDev& r, u32 first, u32 last, u64 H, Map
     u64* iv_begin = e.iv_begin.as<u64>();
     u64* iv_end = e.iv_end.as<u64>();
     u32* iv_read = e.tmp_b.as<u32>();
-    // sort every interval by positions (payload = group)
-    RVN_KLAUNCH(kKSegSortPos, seg_sort_be_kernel<<<div_up(NI, 4), 256, 0, s>>>(p0, p1, g0, g1, iv_begin, iv_end, NI,
-                                                                           std::max(e.chain, kChainSmallCap + 1)));
+    // size classes of the intervals (position sort and chain kernels both go by them)
+    u32* lists = e.chain_big.get<u32>(static_cast<size_t>(NI) * (kChainClasses + 1) + 16);
+    u32* d_cnt = lists + static_cast<size_t>(NI) * (kChainClasses + 1);
+    RVN_HIP(hipMemsetAsync(d_cnt, 0, (kChainClasses + 1) * 4, s));
+    chain_class_list_kernel<<<div_up(NI, 256), 256, 0, s>>>(iv_begin, iv_end, NI, e.chain, lists, d_cnt);
+    RVN_LAUNCH_CHECK();
+    read_back(e, d_cnt, (kChainClasses + 1) * 4);
+    u32 n_cls[kChainClasses + 1];
+    std::memcpy(n_cls, e.h_pin, sizeof(n_cls));
+    static bool attr_set = false;
+    if (!attr_set) {
+      RVN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  static_cast<int>(chain_class_lds(kChainBigCap))));
+      RVN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(seg_sort_pos_lds_kernel<256>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  static_cast<int>(seg_sort_lds_bytes<256, false>(kChainBigCap))));
+      attr_set = true;
+    }
+    // sort every interval by positions: the largest classes first (their workgroups run longest)
+    if (n_cls[kChainClasses])
+      RVN_KLAUNCH(kKSegSortPos, seg_sort_pos_big_kernel<<<div_up(n_cls[kChainClasses], 4), 256, 0, s>>>(
+                                    p0, p1, iv_begin, iv_end, lists + static_cast<size_t>(kChainClasses) * NI, n_cls[kChainClasses]));
+    for (int c = kChainClasses - 1; c >= 0; --c) {
+      if (!n_cls[c]) continue;
+      const u32 cap = kChainClassCapHost[c];
+      const u32* list = lists + static_cast<size_t>(c) * NI;
+      if (cap <= 512)
+        RVN_KLAUNCH(kKSegSortPos, seg_sort_pos_lds_kernel<64><<<n_cls[c], 64, seg_sort_lds_bytes<64, false>(cap), s>>>(
+                                      p0, iv_begin, iv_end, list, n_cls[c], cap));
+      else
+        RVN_KLAUNCH(kKSegSortPos, seg_sort_pos_lds_kernel<256><<<n_cls[c], 256, seg_sort_lds_bytes<256, false>(cap), s>>>(
+                                      p0, iv_begin, iv_end, list, n_cls[c], cap));
+    }
     u32* lis_min = e.lis_min.get<u32>(H + NI + 1);
     u32* lis_pred = e.lis_pred.get<u32>(H + 1);
     u64* lis_tail = e.lis_tail.get<u64>(H + NI + 1);
@@ -1040,20 +1153,6 @@ void chain_matches(Engine& e, const ReadsDev& r, u32 first, u32 last, u64 H, Map
                                   g0, p0, iv_begin, iv_end, iv_read, NI, r.id.as<u32>(), first, e.k, e.chain, e.matches,
                                   e.gap, slot_div, slots, slot_flags, anchors, slot_aoff, slot_acnt));
     {
-      u32* lists = e.chain_big.get<u32>(static_cast<size_t>(NI) * (kChainClasses + 1) + 16);
-      u32* d_cnt = lists + static_cast<size_t>(NI) * (kChainClasses + 1);
-      RVN_HIP(hipMemsetAsync(d_cnt, 0, (kChainClasses + 1) * 4, s));
-      chain_class_list_kernel<<<div_up(NI, 256), 256, 0, s>>>(iv_begin, iv_end, NI, e.chain, lists, d_cnt);
-      RVN_LAUNCH_CHECK();
-      read_back(e, d_cnt, (kChainClasses + 1) * 4);
-      u32 n_cls[kChainClasses + 1];
-      std::memcpy(n_cls, e.h_pin, sizeof(n_cls));
-      static bool attr_set = false;
-      if (!attr_set) {
-        RVN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    static_cast<int>(chain_class_lds(kChainBigCap))));
-        attr_set = true;
-      }
       // largest classes first: their waves run longest
       for (int c = kChainClasses; c >= 0; --c) {
         if (!n_cls[c]) continue;

@@ -222,11 +222,13 @@ void nw_breakpoints(Engine& e, const ReadsDev& T, const ReadsDev& Rd, std::vecto
     RVN_HIP(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
     // created into locals and handed to the engine only when all exist: a creation that throws half-way must not leave
     // nw_streams[0] set with the others null — the next call would skip this block and launch walks on the null stream
-    hipStream_t made[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipStream_t made[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     hipEvent_t made_ev[sizeof(e.nw_ev) / sizeof(e.nw_ev[0])] = {};
     try {
-      for (int b = 0; b < 4; ++b) {
-        if (b == 3 && prio_greatest != prio_least)
+      for (int b = 0; b < 5; ++b) {
+        // ([4], the upload stream, must not share a hardware queue with the engine's stream either: its copies run while a
+        // pass queued before is sweeping there)
+        if (b >= 3 && prio_greatest != prio_least)
           RVN_HIP(hipStreamCreateWithPriority(&made[b], hipStreamNonBlocking, prio_greatest));
         else
           RVN_HIP(hipStreamCreateWithFlags(&made[b], hipStreamNonBlocking));
@@ -239,7 +241,7 @@ void nw_breakpoints(Engine& e, const ReadsDev& T, const ReadsDev& Rd, std::vecto
         if (ev) (void)hipEventDestroy(ev);
       throw;
     }
-    for (int b = 0; b < 4; ++b) e.nw_streams[b] = made[b];
+    for (int b = 0; b < 5; ++b) e.nw_streams[b] = made[b];
     for (size_t i = 0; i < sizeof(e.nw_ev) / sizeof(e.nw_ev[0]); ++i) e.nw_ev[i] = made_ev[i];
   }
   // an error in the middle of a pass (a walk that left its band, an allocation that failed) must not leave walks running
@@ -293,12 +295,25 @@ void nw_breakpoints(Engine& e, const ReadsDev& T, const ReadsDev& Rd, std::vecto
   const bool one_stream = knob("RVN_NW_ONE_STREAM") != nullptr;
   const bool dbg_sync = knob("RVN_NW_DEBUG") && std::atoi(knob("RVN_NW_DEBUG")) >= 2;
   std::vector<double> rates;
-  std::vector<u32> h_result(nj), h_status(nj), order;
-  NwJob* d_jobs = e.nw_jobs.get<NwJob>(nj + 1);
-  u32* d_res = e.nw_res.get<u32>(3 * static_cast<size_t>(nj) + 16);
+  rates.reserve(nj);  // (growing it inside collect() cost milliseconds of page faults with the GPU idle)
+  std::vector<u32> h_result(nj), h_status(nj);
+  constexpr u32 kHeadMax = 4096;  // jobs of the pass of the longest alignments (below)
+  NwJob* d_jobs = e.nw_jobs.get<NwJob>(static_cast<size_t>(nj) + 1 + 2 * kHeadMax);
+  u32* d_res = e.nw_res.get<u32>(3 * static_cast<size_t>(nj) + 16 + 6 * kHeadMax);
   u32* d_status = d_res + nj + 1;
   u32* d_idx = d_status + nj + 1;
   u32* d_next = d_idx + nj + 1;
+  // A pass = a set of planned jobs queued together: its job records, order, results and states on the device.  The usual
+  // pass addresses them by job id; a COMPACT pass (the head, below) has arrays of its own, addressed by position in its order.
+  struct PassDev {
+    NwJob* jobs;
+    u32 *idx, *res, *status;
+    bool compact;
+  };
+  const PassDev dev_all{d_jobs, d_idx, d_res, d_status, false};
+  const PassDev dev_head{d_jobs + nj + 1, d_next + 4 + 2 * kHeadMax, d_next + 4, d_next + 4 + kHeadMax, true};
+  const PassDev dev_retry{dev_head.jobs + kHeadMax, dev_head.idx + 3 * kHeadMax, dev_head.res + 3 * kHeadMax,
+                          dev_head.status + 3 * kHeadMax, true};
   struct Obs {
     double len, d;
   };
@@ -311,190 +326,242 @@ void nw_breakpoints(Engine& e, const ReadsDev& T, const ReadsDev& Rd, std::vecto
     u64 hs_w, ck_e;
     u32 coff[kLevels + 1];
   };
-  // aligns every job of `todo` (already planned), repeating the ones beyond their threshold with twice the band
-  auto run = [&](std::vector<u32> todo, bool sweep_only) {
-    while (!todo.empty()) {
-      // longest jobs first: they go through the widest variants, and the pass ends with the walks of the shortest ones
-      auto t_h = clk::now();
-      {  // descending by (variant, columns), ties in job order: two counting passes (12 + 12 key bits) instead of a sort
-        const size_t nt = todo.size();
-        std::vector<u32> key(nt), tmp(nt), idx(nt);
-        parallel_for(nt, 16384, [&](size_t x0, size_t x1) {  // (the GPU waits for this planning: a few host threads)
-          for (size_t x = x0; x < x1; ++x) {
-            const NwJob& J = jobs[todo[x]];
-            const u32 mm = std::min<u32>(J.m >> 3, (1u << 20) - 1);  // 8-base resolution is plenty for the ordering
-            static_assert(kLevels <= 16, "4 bits of variant + 20 bits of length = the 24 key bits of the two passes");
-            key[x] = 0xFFFFFFu - ((level_of(J) << 20) | mm);
-            idx[x] = static_cast<u32>(x);
-          }
-        });
-        for (int pass = 0; pass < 2; ++pass) {
-          u32 cnt[4097] = {};
-          const int sh = 12 * pass;
-          for (size_t x = 0; x < nt; ++x) cnt[((key[idx[x]] >> sh) & 4095u) + 1]++;
-          for (int c = 0; c < 4096; ++c) cnt[c + 1] += cnt[c];
-          for (size_t x = 0; x < nt; ++x) tmp[cnt[(key[idx[x]] >> sh) & 4095u]++] = idx[x];
-          idx.swap(tmp);
-        }
-        order.resize(nt);
-        for (size_t x = 0; x < nt; ++x) order[x] = todo[idx[x]];
-      }
-      // chunks of the order whose hs + ck fit a third of the budget (a job larger than that goes alone).  (Capping the jobs
-      // per chunk — an even eighth, or a third of what is left, so that the uncovered walk of the last chunk gets shorter —
-      // was measured at C4 and did not pay: every extra sweep launch brings its own ramp and tail, +19 ms of sweep time
-      // against ~20 ms less at the end; profiles/r05_nw_timeline.csv.)
-      std::vector<Chunk> chunks;
-      struct Need {
-        u64 hw, ce, cells;
-        u32 level;
-      };
-      std::vector<Need> need(order.size());  // what a job stores and computes: per job in parallel, summed up in order below
-      parallel_for(order.size(), 16384, [&](size_t x0, size_t x1) {
+  DevBuf* hs_buf[4] = {&e.nw_hs, &e.nw_hs2, &e.nw_hs3, &e.nw_hs4};
+  DevBuf* ck_buf[4] = {&e.nw_ck, &e.nw_ck2, &e.nw_ck3, &e.nw_ck4};
+  bool set_used[4] = {false, false, false, false};  // a walk queued since the last collect() holds the buffer set
+  struct Queued {  // what collect() reads back
+    std::vector<u32> order;
+    PassDev dev;
+    bool sweep_only;
+    std::vector<u32> res, status;  // (compact passes)
+  };
+  std::vector<Queued> queued;
+  std::vector<u8> early;  // job was handed to retry_early(): its state in the pass that found it stays "above the threshold"
+  // Queues the sweeps and walks of `todo` (already planned) and returns; collect() waits for everything queued and reads
+  // the results.  Chunk layout: kOwnFirst — the first chunk (the longest alignments) on buffer set 3 with a twelfth of the
+  // budget, the others on sets 0-2 in rotation with a third each; kHeadOnly — that first chunk ALONE, what does not fit it
+  // is handed back in `left`; kRotating — sets 0-2 only (the jobs behind a head that is already running).  up: the stream
+  // of the uploads (the host waits for them: not the engine's stream when a pass queued before is sweeping on it).
+  enum Layout { kOwnFirst, kHeadOnly, kRotating };
+  auto enqueue = [&](const std::vector<u32>& todo, bool sweep_only, Layout layout, const PassDev& dev, hipStream_t up,
+                     std::vector<u32>* left) {
+    if (todo.empty()) return;
+    // longest jobs first: they go through the widest variants, and the pass ends with the walks of the shortest ones
+    auto t_h = clk::now();
+    std::vector<u32> order;
+    {  // descending by (variant, columns), ties in job order: two counting passes (12 + 12 key bits) instead of a sort
+      const size_t nt = todo.size();
+      std::vector<u32> key(nt), tmp(nt), idx(nt);
+      parallel_for(nt, 16384, [&](size_t x0, size_t x1) {  // (the GPU waits for this planning: a few host threads)
         for (size_t x = x0; x < x1; ++x) {
-          const NwJob& J = jobs[order[x]];
-          const NwGeo g = nw_geo(J.n, J.m, J.k, J.R);
-          need[x] = Need{g.hs_words(), g.ck_entries(), static_cast<u64>(J.m) * (static_cast<u64>(g.lo) + g.hi + 1), level_of(J)};
+          const NwJob& J = jobs[todo[x]];
+          const u32 mm = std::min<u32>(J.m >> 3, (1u << 20) - 1);  // 8-base resolution is plenty for the ordering
+          static_assert(kLevels <= 16, "4 bits of variant + 20 bits of length = the 24 key bits of the two passes");
+          key[x] = 0xFFFFFFu - ((level_of(J) << 20) | mm);
+          idx[x] = static_cast<u32>(x);
         }
       });
-      for (size_t c0 = 0; c0 < order.size();) {
-        Chunk C{};
-        C.c0 = c0;
-        size_t c1 = c0;
-        while (c1 < order.size()) {
-          NwJob& J = jobs[order[c1]];
-          const u64 hw = need[c1].hw, ce = need[c1].ce;
-          // three buffer sets in rotation + one of its own for the first chunk (the longest alignments: its walk is
-          // latency-bound — 106 ms for 2 432 alignments at C4 — and a set shared with chunk 3 made that chunk's sweep wait
-          // 17 ms for it), a quarter of a share
-          const u64 share = chunks.empty() ? budget / 12 : budget / 3;
-          if (c1 > c0 && (C.hs_w + hw) * 4 + (C.ck_e + ce) * 16 > share) break;
-          J.hs = C.hs_w;
-          J.ckpt = C.ck_e;
-          C.hs_w += hw;
-          C.ck_e += ce;
-          st.band_cells += need[c1].cells;
-          C.coff[need[c1].level + 1]++;
-          ++c1;
-        }
-        // the order is by descending level: offsets of the classes inside the chunk, in that order
-        u32 run_off = 0, cnt[kLevels];
-        for (u32 x = 0; x < kLevels; ++x) cnt[x] = C.coff[x + 1];
-        for (int x = static_cast<int>(kLevels) - 1; x >= 0; --x) {
-          C.coff[x] = run_off;
-          run_off += cnt[x];
-        }
-        C.coff[kLevels] = run_off;  // count of class x = offset of class x - 1 (or the chunk's end) - its own offset
-        C.c1 = c1;
-        st.store_bytes = std::max<u64>(st.store_bytes, C.hs_w * 4 + C.ck_e * 16);
-        chunks.push_back(C);
-        c0 = c1;
+      for (int pass = 0; pass < 2; ++pass) {
+        u32 cnt[4097] = {};
+        const int sh = 12 * pass;
+        for (size_t x = 0; x < nt; ++x) cnt[((key[idx[x]] >> sh) & 4095u) + 1]++;
+        for (int c = 0; c < 4096; ++c) cnt[c + 1] += cnt[c];
+        for (size_t x = 0; x < nt; ++x) tmp[cnt[(key[idx[x]] >> sh) & 4095u]++] = idx[x];
+        idx.swap(tmp);
       }
-      DevBuf* hs_buf[4] = {&e.nw_hs, &e.nw_hs2, &e.nw_hs3, &e.nw_hs4};
-      DevBuf* ck_buf[4] = {&e.nw_ck, &e.nw_ck2, &e.nw_ck3, &e.nw_ck4};
-      // chunk 0 -> set 3 (its own), chunk ci >= 1 -> set (ci - 1) % 3
-      auto set_of = [](size_t ci) -> int { return ci == 0 ? 3 : static_cast<int>((ci - 1) % 3); };
-      for (int b = 0; b < 4; ++b) {
-        // sized for the chunks the set serves (a lone job beyond its share enlarges one set, not all)
-        u64 set_hs = 0, set_ck = 0;
-        bool used = false;
-        for (size_t ci = 0; ci < chunks.size(); ++ci) {
-          if (set_of(ci) != b) continue;
-          used = true;
-          set_hs = std::max(set_hs, chunks[ci].hs_w);
-          set_ck = std::max(set_ck, chunks[ci].ck_e);
-        }
-        if (!used) continue;
-        (void)hs_buf[b]->get<u32>(set_hs + 4 * 64 * 8 + 16);  // + slack: the walk reads up to two words past a job's last one
-        (void)ck_buf[b]->get<NwPm>(set_ck + 16);
+      order.resize(nt);
+      for (size_t x = 0; x < nt; ++x) order[x] = todo[idx[x]];
+    }
+    // chunks of the order whose hs + ck fit a third of the budget (a job larger than that goes alone).  (Capping the jobs
+    // per chunk — an even eighth, or a third of what is left, so that the uncovered walk of the last chunk gets shorter —
+    // was measured at C4 and did not pay: every extra sweep launch brings its own ramp and tail, +19 ms of sweep time
+    // against ~20 ms less at the end; profiles/r05_nw_timeline.csv.)
+    std::vector<Chunk> chunks;
+    struct Need {
+      u64 hw, ce, cells;
+      u32 level;
+    };
+    std::vector<Need> need(order.size());  // what a job stores and computes: per job in parallel, summed up in order below
+    parallel_for(order.size(), 16384, [&](size_t x0, size_t x1) {
+      for (size_t x = x0; x < x1; ++x) {
+        const NwJob& J = jobs[order[x]];
+        const NwGeo g = nw_geo(J.n, J.m, J.k, J.R);
+        need[x] = Need{g.hs_words(), g.ck_entries(), static_cast<u64>(J.m) * (static_cast<u64>(g.lo) + g.hi + 1), level_of(J)};
       }
-      u64* d_strip = nullptr;
-      if (!trace_lds) {
-        size_t mc = 0;
-        for (const Chunk& C : chunks) mc = std::max(mc, C.c1 - C.c0);
-        d_strip = e.nw_strip.get<u64>(static_cast<size_t>((mc + 63) / 64) * 2 * kNwStripCols * 64 * 4 + 64);
+    });
+    for (size_t c0 = 0; c0 < order.size();) {
+      Chunk C{};
+      C.c0 = c0;
+      size_t c1 = c0;
+      while (c1 < order.size()) {
+        NwJob& J = jobs[order[c1]];
+        const u64 hw = need[c1].hw, ce = need[c1].ce;
+        // three buffer sets in rotation + one of its own for the first chunk (the longest alignments: its walk is
+        // latency-bound — 106 ms for 2 432 alignments at C4 — and a set shared with chunk 3 made that chunk's sweep wait
+        // 17 ms for it), a quarter of a share
+        const u64 share = (chunks.empty() && layout != kRotating) ? budget / 12 : budget / 3;
+        if (c1 > c0 && (C.hs_w + hw) * 4 + (C.ck_e + ce) * 16 > share) break;
+        J.hs = C.hs_w;
+        J.ckpt = C.ck_e;
+        C.hs_w += hw;
+        C.ck_e += ce;
+        st.band_cells += need[c1].cells;
+        C.coff[need[c1].level + 1]++;
+        ++c1;
       }
-      h_order += since(t_h);
-      t_h = clk::now();
-      RVN_HIP(hipMemcpyAsync(d_jobs, jobs.data(), static_cast<size_t>(nj) * sizeof(NwJob), hipMemcpyHostToDevice, s));
-      RVN_HIP(hipMemcpyAsync(d_idx, order.data(), order.size() * 4, hipMemcpyHostToDevice, s));
-      RVN_HIP(rvn_stream_sync(s));  // `jobs` / `order` are pageable: the copies must be done before the host goes on
-      h_up += since(t_h);
-      bool set_used[4] = {false, false, false, false};  // a walk of THIS pass has been queued on the buffer set
+      // the order is by descending level: offsets of the classes inside the chunk, in that order
+      u32 run_off = 0, cnt[kLevels];
+      for (u32 x = 0; x < kLevels; ++x) cnt[x] = C.coff[x + 1];
+      for (int x = static_cast<int>(kLevels) - 1; x >= 0; --x) {
+        C.coff[x] = run_off;
+        run_off += cnt[x];
+      }
+      C.coff[kLevels] = run_off;  // count of class x = offset of class x - 1 (or the chunk's end) - its own offset
+      C.c1 = c1;
+      st.store_bytes = std::max<u64>(st.store_bytes, C.hs_w * 4 + C.ck_e * 16);
+      chunks.push_back(C);
+      c0 = c1;
+      if (layout == kHeadOnly) break;
+    }
+    if (layout == kHeadOnly && chunks[0].c1 < order.size()) {  // what the head's share does not hold goes with the rest
+      for (size_t x = chunks[0].c1; x < order.size(); ++x) left->push_back(order[x]);
+      order.resize(chunks[0].c1);
+    }
+    // chunk 0 -> set 3 (its own), chunk ci >= 1 -> set (ci - 1) % 3;  kRotating: chunk ci -> set ci % 3
+    auto set_of = [&](size_t ci) -> int {
+      if (layout == kRotating) return static_cast<int>(ci % 3);
+      return ci == 0 ? 3 : static_cast<int>((ci - 1) % 3);
+    };
+    for (int b = 0; b < 4; ++b) {
+      // sized for the chunks the set serves (a lone job beyond its share enlarges one set, not all)
+      u64 set_hs = 0, set_ck = 0;
+      bool used = false;
       for (size_t ci = 0; ci < chunks.size(); ++ci) {
-        const Chunk& C = chunks[ci];
-        const int b = set_of(ci);
-        u32* hs = hs_buf[b]->as<u32>();
-        NwPm* ck = ck_buf[b]->as<NwPm>();
-        const u32* idx_c = d_idx + C.c0;
-        const u32 cn = static_cast<u32>(C.c1 - C.c0);
-        // the walk that used this buffer set before — chunk ci - 3 of the rotating sets (set_of: chunk 0 -> set 3, chunk ci ->
-        // set (ci - 1) % 3) — is done with it
-        if (set_used[b]) RVN_HIP(hipStreamWaitEvent(s, e.nw_ev[b], 0));
-        set_used[b] = true;
-        auto count_of = [&](u32 x) -> u32 {  // classes are laid out from the widest variant down
-          const u32 next_off = x == 0 ? cn : C.coff[x - 1];
-          return next_off - C.coff[x];
-        };
+        if (set_of(ci) != b) continue;
+        used = true;
+        set_hs = std::max(set_hs, chunks[ci].hs_w);
+        set_ck = std::max(set_ck, chunks[ci].ck_e);
+      }
+      if (!used) continue;
+      (void)hs_buf[b]->get<u32>(set_hs + 4 * 64 * 8 + 16);  // + slack: the walk reads up to two words past a job's last one
+      (void)ck_buf[b]->get<NwPm>(set_ck + 16);
+    }
+    u64* d_strip = nullptr;
+    if (!trace_lds) {
+      size_t mc = 0;
+      for (const Chunk& C : chunks) mc = std::max(mc, C.c1 - C.c0);
+      d_strip = e.nw_strip.get<u64>(static_cast<size_t>((mc + 63) / 64) * 2 * kNwStripCols * 64 * 4 + 64);
+    }
+    h_order += since(t_h);
+    t_h = clk::now();
+    if (dev.compact) {  // records in the order of the pass, addressed by position
+      std::vector<NwJob> hj(order.size());
+      std::vector<u32> iota(order.size());
+      for (size_t x = 0; x < order.size(); ++x) {
+        hj[x] = jobs[order[x]];
+        iota[x] = static_cast<u32>(x);
+      }
+      RVN_HIP(hipMemcpyAsync(dev.jobs, hj.data(), hj.size() * sizeof(NwJob), hipMemcpyHostToDevice, up));
+      RVN_HIP(hipMemcpyAsync(dev.idx, iota.data(), iota.size() * 4, hipMemcpyHostToDevice, up));
+      RVN_HIP(rvn_stream_sync(up));  // (locals)
+    } else {
+      RVN_HIP(hipMemcpyAsync(dev.jobs, jobs.data(), static_cast<size_t>(nj) * sizeof(NwJob), hipMemcpyHostToDevice, up));
+      RVN_HIP(hipMemcpyAsync(dev.idx, order.data(), order.size() * 4, hipMemcpyHostToDevice, up));
+      RVN_HIP(rvn_stream_sync(up));  // `jobs` / `order` are pageable: the copies must be done before the host goes on
+    }
+    h_up += since(t_h);
+    for (size_t ci = 0; ci < chunks.size(); ++ci) {
+      const Chunk& C = chunks[ci];
+      const int b = set_of(ci);
+      u32* hs = hs_buf[b]->as<u32>();
+      NwPm* ck = ck_buf[b]->as<NwPm>();
+      const u32* idx_c = dev.idx + C.c0;
+      const u32 cn = static_cast<u32>(C.c1 - C.c0);
+      // the walk that used this buffer set before (three chunks back in the rotation) is done with it
+      if (set_used[b]) RVN_HIP(hipStreamWaitEvent(s, e.nw_ev[b], 0));
+      auto count_of = [&](u32 x) -> u32 {  // classes are laid out from the widest variant down
+        const u32 next_off = x == 0 ? cn : C.coff[x - 1];
+        return next_off - C.coff[x];
+      };
 #define RVN_SWEEP(x, R_, G_)                                                                                         \
   do {                                                                                                               \
-    launch_sweep<R_, G_>(e, d_jobs, idx_c + C.coff[x], count_of(x), T, Rd, hs, ck, d_res, d_status, d_next);           \
+    launch_sweep<R_, G_>(e, dev.jobs, idx_c + C.coff[x], count_of(x), T, Rd, hs, ck, dev.res, dev.status, d_next);     \
     if (dbg_sync && count_of(x)) {                                                                                   \
       RVN_HIP(hipStreamSynchronize(s));                                                                              \
       std::fprintf(stderr, "[raven_hip] nw: sweep R=%d G=%d done, %u jobs\n", R_, G_, count_of(x));                   \
     }                                                                                                                \
   } while (0)
-        RVN_SWEEP(7, 8, 64);
-        RVN_SWEEP(6, 4, 64);
-        RVN_SWEEP(5, 2, 64);
-        RVN_SWEEP(4, 1, 64);
-        RVN_SWEEP(3, 1, 32);
-        RVN_SWEEP(2, 1, 16);
-        RVN_SWEEP(1, 1, 8);
-        RVN_SWEEP(0, 1, 4);
+      RVN_SWEEP(7, 8, 64);
+      RVN_SWEEP(6, 4, 64);
+      RVN_SWEEP(5, 2, 64);
+      RVN_SWEEP(4, 1, 64);
+      RVN_SWEEP(3, 1, 32);
+      RVN_SWEEP(2, 1, 16);
+      RVN_SWEEP(1, 1, 8);
+      RVN_SWEEP(0, 1, 4);
 #undef RVN_SWEEP
-        if (sweep_only) {
-          ++st.n_batches;
-          continue;
-        }
-        // one walk stream per buffer set: the walk of the longest alignments (chunk 0: few waves, tens of milliseconds of
-        // latency) must not hold back the walks of the chunks behind it
-        hipStream_t ts = one_stream ? s : e.nw_streams[b];
-        if (!one_stream) {
-          RVN_HIP(hipEventRecord(e.nw_ev[4], s));
-          RVN_HIP(hipStreamWaitEvent(ts, e.nw_ev[4], 0));
-        }
-        if (trace_lds) {
-          RVN_KLAUNCH_ON(kKNwTraceback, ts, (nw_trace_kernel<true><<<(cn + 63) / 64, 64, 0, ts>>>(
-                                                d_jobs, idx_c, cn, T.packed.as<u64>(), Rd.packed.as<u64>(), hs, ck, d_res,
-                                                d_status, w, d_recs, nullptr)));
-        } else {
-          RVN_KLAUNCH_ON(kKNwTraceback, ts, (nw_trace_kernel<false><<<(cn + 63) / 64, 64, 0, ts>>>(
-                                                d_jobs, idx_c, cn, T.packed.as<u64>(), Rd.packed.as<u64>(), hs, ck, d_res,
-                                                d_status, w, d_recs,
-                                                d_strip + static_cast<size_t>(b) * ((e.nw_strip.cap / 32) & ~size_t(63)))));
-        }
-        if (!one_stream) RVN_HIP(hipEventRecord(e.nw_ev[b], ts));
-        if (dbg_sync) {
-          RVN_HIP(hipStreamSynchronize(ts));
-          std::fprintf(stderr, "[raven_hip] nw: trace done, %u jobs\n", cn);
-        }
-        ++st.n_batches;
+      ++st.n_batches;
+      if (sweep_only) continue;
+      // one walk stream per buffer set: the walk of the longest alignments (chunk 0: few waves, tens of milliseconds of
+      // latency) must not hold back the walks of the chunks behind it
+      hipStream_t ts = one_stream ? s : e.nw_streams[b];
+      if (!one_stream) {
+        RVN_HIP(hipEventRecord(e.nw_ev[4], s));
+        RVN_HIP(hipStreamWaitEvent(ts, e.nw_ev[4], 0));
       }
-      if (!one_stream && !sweep_only) {  // everything of this pass done before the results are read
-        bool waited[4] = {false, false, false, false};  // (an event stands for the LAST walk recorded on its set)
-        for (size_t ci = 0; ci < chunks.size(); ++ci) {
-          const int b = set_of(ci);
-          if (!waited[b]) RVN_HIP(hipStreamWaitEvent(s, e.nw_ev[b], 0));
-          waited[b] = true;
-        }
+      if (trace_lds) {
+        RVN_KLAUNCH_ON(kKNwTraceback, ts, (nw_trace_kernel<true><<<(cn + 63) / 64, 64, 0, ts>>>(
+                                              dev.jobs, idx_c, cn, T.packed.as<u64>(), Rd.packed.as<u64>(), hs, ck, dev.res,
+                                              dev.status, w, d_recs, nullptr)));
+      } else {
+        RVN_KLAUNCH_ON(kKNwTraceback, ts, (nw_trace_kernel<false><<<(cn + 63) / 64, 64, 0, ts>>>(
+                                              dev.jobs, idx_c, cn, T.packed.as<u64>(), Rd.packed.as<u64>(), hs, ck, dev.res,
+                                              dev.status, w, d_recs,
+                                              d_strip + static_cast<size_t>(b) * ((e.nw_strip.cap / 32) & ~size_t(63)))));
       }
-      RVN_HIP(hipMemcpyAsync(h_result.data(), d_res, static_cast<size_t>(nj) * 4, hipMemcpyDeviceToHost, s));
-      RVN_HIP(hipMemcpyAsync(h_status.data(), d_status, static_cast<size_t>(nj) * 4, hipMemcpyDeviceToHost, s));
-      RVN_HIP(rvn_stream_sync(s));
-      t_h = clk::now();
-      std::vector<u32> again;
-      for (u32 i : todo) {
+      if (!one_stream) {
+        RVN_HIP(hipEventRecord(e.nw_ev[b], ts));
+        set_used[b] = true;
+      }
+      if (dbg_sync) {
+        RVN_HIP(hipStreamSynchronize(ts));
+        std::fprintf(stderr, "[raven_hip] nw: trace done, %u jobs\n", cn);
+      }
+    }
+    queued.push_back(Queued{std::move(order), dev, sweep_only, {}, {}});
+  };
+  // Waits for everything queued, reads the results; the jobs beyond their thresholds come back in `again` (planned with
+  // twice the band and the variant that holds it).
+  auto collect = [&](std::vector<u32>& again) {
+    again.clear();
+    for (int b = 0; b < 4; ++b) {  // (an event stands for the LAST walk recorded on its set)
+      if (set_used[b]) RVN_HIP(hipStreamWaitEvent(s, e.nw_ev[b], 0));
+      set_used[b] = false;
+    }
+    for (Queued& q : queued) {
+      if (q.dev.compact) {
+        q.res.resize(q.order.size());
+        q.status.resize(q.order.size());
+        RVN_HIP(hipMemcpyAsync(q.res.data(), q.dev.res, q.order.size() * 4, hipMemcpyDeviceToHost, s));
+        RVN_HIP(hipMemcpyAsync(q.status.data(), q.dev.status, q.order.size() * 4, hipMemcpyDeviceToHost, s));
+      }
+    }
+    RVN_HIP(hipMemcpyAsync(h_result.data(), d_res, static_cast<size_t>(nj) * 4, hipMemcpyDeviceToHost, s));
+    RVN_HIP(hipMemcpyAsync(h_status.data(), d_status, static_cast<size_t>(nj) * 4, hipMemcpyDeviceToHost, s));
+    RVN_HIP(rvn_stream_sync(s));
+    auto t_h = clk::now();
+    for (const Queued& q : queued)
+      if (q.dev.compact)
+        for (size_t x = 0; x < q.order.size(); ++x) {
+          h_result[q.order[x]] = q.res[x];
+          h_status[q.order[x]] = q.status[x];
+        }
+    for (size_t qi = 0; qi < queued.size(); ++qi) {
+      const Queued& q = queued[qi];
+      const bool is_early_retry = q.dev.jobs == dev_retry.jobs;
+      for (u32 i : q.order) {
         NwJob& J = jobs[i];
+        if (!is_early_retry && !early.empty() && early[i]) continue;  // its result is the early retry pass's
         if (h_status[i] == 2) {  // distance above the threshold: twice the band (and the variant that holds it)
           ++st.n_retries;
           if (J.k >= static_cast<u64>(J.n) + J.m || !plan(J, static_cast<u64>(J.k) * 2)) ++st.n_unaligned;
@@ -502,16 +569,68 @@ void nw_breakpoints(Engine& e, const ReadsDev& T, const ReadsDev& Rd, std::vecto
         } else if (h_status[i] != 0) {
           throw HipError("[raven_hip] alignment path: the walk left the stored band (internal error)");
         } else {
-          if (!sweep_only) {
+          if (!q.sweep_only) {
             ++st.n_aligned;
             st.sum_distance += h_result[i];
             rates.push_back(static_cast<double>(h_result[i]) / std::max(J.n, J.m));
+          } else {
+            obs.push_back(Obs{static_cast<double>(std::max(J.n, J.m)), static_cast<double>(h_result[i])});
           }
-          obs.push_back(Obs{static_cast<double>(std::max(J.n, J.m)), static_cast<double>(h_result[i])});
         }
       }
+    }
+    early.clear();
+    queued.clear();
+    h_res += since(t_h);
+  };
+  // Whether an alignment is beyond its threshold is known when its SWEEP is done: the states are read once the sweeps of
+  // everything queued are through — the last walks still run on their streams — and the few jobs above their thresholds
+  // (two or three of 295 000 at C4) are planned again and queued at once, as a compact pass on the head's buffer set,
+  // instead of as a pass of their own behind the last walk (~9 ms per round of sweep + lonely walk + host round trips,
+  // profiles/r05_nw_timeline.csv).  A job handed on here is skipped by collect() in the pass that found it.
+  auto retry_early = [&]() {
+    if (one_stream || queued.empty()) return;
+    for (Queued& q : queued)
+      if (q.dev.compact) {
+        q.status.resize(q.order.size());
+        RVN_HIP(hipMemcpyAsync(q.status.data(), q.dev.status, q.order.size() * 4, hipMemcpyDeviceToHost, s));
+      }
+    RVN_HIP(hipMemcpyAsync(h_status.data(), d_status, static_cast<size_t>(nj) * 4, hipMemcpyDeviceToHost, s));
+    RVN_HIP(rvn_stream_sync(s));  // (the sweeps; not the walks)
+    std::vector<u32> todo;
+    for (const Queued& q : queued)
+      for (size_t x = 0; x < q.order.size(); ++x) {
+        const u32 i = q.order[x];
+        if ((q.dev.compact ? q.status[x] : h_status[i]) != 2) continue;
+        if (todo.size() >= kHeadMax) break;  // (a wrong rate estimate: the ordinary repeat pass takes them)
+        NwJob& J = jobs[i];
+        if (J.k >= static_cast<u64>(J.n) + J.m) continue;  // (collect() counts it as unaligned)
+        const NwJob before = J;
+        if (!plan(J, static_cast<u64>(J.k) * 2)) {
+          J = before;
+          continue;
+        }
+        todo.push_back(i);
+      }
+    if (todo.empty()) return;
+    early.assign(nj, 0);
+    for (u32 i : todo) early[i] = 1;
+    st.n_retries += todo.size();
+    std::vector<u32> left;
+    // (set 3 may have to grow for a doubled band, and growing hands the old block back: the walk on it — the head's, queued
+    // long before — must be through)
+    if (set_used[3]) RVN_HIP(hipEventSynchronize(e.nw_ev[3]));
+    enqueue(todo, false, kHeadOnly, dev_retry, e.nw_streams[4], &left);
+    for (u32 i : left) early[i] = 0;  // (beyond the set's share: their doubled plan stands, collect() doubles it once more)
+    st.n_retries -= left.size();
+  };
+  // aligns every job of `todo` (already planned), repeating the ones beyond their threshold with twice the band
+  auto run = [&](std::vector<u32> todo, bool sweep_only) {
+    while (!todo.empty()) {
+      enqueue(todo, sweep_only, kOwnFirst, dev_all, s, nullptr);
+      std::vector<u32> again;
+      collect(again);
       todo.swap(again);
-      h_res += since(t_h);
     }
   };
 
@@ -521,7 +640,7 @@ void nw_breakpoints(Engine& e, const ReadsDev& T, const ReadsDev& Rd, std::vecto
   // spread a few alignments in a million are repeated (a repeat pass ends with lonely, latency-bound walks, so it is
   // worth ~3 % more band to make it rare), against one in ten with a 90th-percentile rule.  The pilot is swept for its
   // distances only and skips the longest quarter of the reads.  Small batches keep the previous call's estimate.
-  std::vector<u32> rest;
+  std::vector<u32> rest, head;
   double mu = -1, va = 0, vb = 0;
   if (valid.size() >= 4096 && !knob("RVN_NW_RATE")) {
     std::vector<u32> lens;
@@ -540,7 +659,23 @@ void nw_breakpoints(Engine& e, const ReadsDev& T, const ReadsDev& Rd, std::vecto
       NwJob& J = jobs[i];
       if (plan(J, static_cast<u64>((rate * 1.25 + 0.02) * std::max(J.n, J.m)) + 16)) ok.push_back(i);
     }
-    run(ok, true);
+    enqueue(ok, true, kOwnFirst, dev_all, s, nullptr);
+    // (while the pilot is swept) the longest alignments: they go first and by themselves, see below
+    if (!one_stream) {
+      const size_t n_head = std::min<size_t>(kHeadMax, rest.size() / 8);
+      auto longer = [&](u32 x, u32 y) {
+        const u32 lx = std::max(jobs[x].n, jobs[x].m), ly = std::max(jobs[y].n, jobs[y].m);
+        return lx != ly ? lx > ly : x < y;
+      };
+      std::nth_element(rest.begin(), rest.begin() + n_head, rest.end(), longer);
+      head.assign(rest.begin(), rest.begin() + n_head);
+      rest.erase(rest.begin(), rest.begin() + n_head);
+    }
+    {
+      std::vector<u32> again;
+      collect(again);
+      run(again, true);
+    }
     if (obs.size() >= 256) {
       double sl = 0, sd = 0;
       for (const Obs& o : obs) {
@@ -584,23 +719,46 @@ void nw_breakpoints(Engine& e, const ReadsDev& T, const ReadsDev& Rd, std::vecto
   }
   {
     auto t_h = clk::now();
-    std::vector<u32> ok;
-    for (u32 i : rest) {
-      NwJob& J = jobs[i];
+    auto threshold = [&](const NwJob& J) -> u64 {
       const double len = std::max(J.n, J.m);
       const double z = 4.5;
-      const u64 k = mu > 0 ? static_cast<u64>(mu * len + z * std::sqrt(va * len + vb * len * len)) + 6 : static_cast<u64>(rate * len) + 16;
-      if (plan(J, k)) ok.push_back(i);
+      return mu > 0 ? static_cast<u64>(mu * len + z * std::sqrt(va * len + vb * len * len)) + 6 : static_cast<u64>(rate * len) + 16;
+    };
+    // The longest alignments are a pass of their own, queued the moment the thresholds exist: planning, ordering and
+    // uploading 300 000 jobs took the host ~20 ms in which the GPU did nothing (profiles/r05_nw_timeline.csv: 6.6 -> 28.7 ms),
+    // every round; now the head's sweeps (~23 ms at C4) run in that time, and its walk — the long pole, one lane per
+    // alignment — starts that much earlier.  (Results do not depend on which pass or chunk a job is in.)
+    std::vector<u32> ok_head, left;
+    for (u32 i : head) {
+      if (plan(jobs[i], threshold(jobs[i]))) ok_head.push_back(i);
       else ++st.n_unaligned;
     }
+    const bool split = !ok_head.empty();
+    if (split) enqueue(ok_head, false, kHeadOnly, dev_head, s, &left);
+    std::vector<u8> planned(rest.size());
+    parallel_for(rest.size(), 16384, [&](size_t x0, size_t x1) {
+      for (size_t x = x0; x < x1; ++x) planned[x] = plan(jobs[rest[x]], threshold(jobs[rest[x]])) ? 1 : 0;
+    });
+    std::vector<u32> ok;
+    ok.reserve(rest.size() + left.size());
+    for (size_t x = 0; x < rest.size(); ++x) {
+      if (planned[x]) ok.push_back(rest[x]);
+      else ++st.n_unaligned;
+    }
+    ok.insert(ok.end(), left.begin(), left.end());
     h_plan += since(t_h);
-    run(ok, false);
-  }
-  if (rates.size() >= 32) {  // rate estimate for the next call (the pilot's first threshold / small batches)
-    std::sort(rates.begin(), rates.end());
-    e.nw_rate = rates[std::min(rates.size() - 1, static_cast<size_t>(rates.size() * 0.9))] * 1.05 + 0.002;
+    enqueue(ok, false, split ? kRotating : kOwnFirst, dev_all, split ? e.nw_streams[4] : s, nullptr);
+    retry_early();
+    std::vector<u32> again;
+    collect(again);
+    run(again, false);
   }
   RVN_HIP(hipEventRecord(e.ev1, s));
+  if (rates.size() >= 32) {  // rate estimate for the next call (the pilot's first threshold / small batches)
+    const size_t at = std::min(rates.size() - 1, static_cast<size_t>(rates.size() * 0.9));
+    std::nth_element(rates.begin(), rates.begin() + at, rates.end());  // (the order statistic a full sort gave: ~15 ms of host time per round)
+    e.nw_rate = rates[at] * 1.05 + 0.002;
+  }
   RVN_HIP(hipEventSynchronize(e.ev1));
   float ms = 0;
   RVN_HIP(hipEventElapsedTime(&ms, e.ev0, e.ev1));

@@ -1,7 +1,9 @@
 """GPU parity of rvn_poa_consensus_batch against the POA oracle (racon Window::GenerateConsensus restatement).
-Tolerance-based where ties can differ (north_star: 'polished consensus within stated edit-distance tolerance'):
-per window ED(gpu, cpu) <= 1 % of the window length, and ED(gpu, truth) <= ED(cpu, truth) + 2; the simple
-cases must be identical."""
+Tolerance-based where ties can differ (north_star: 'polished consensus within stated edit-distance tolerance').  The
+tolerance is the MEASURED level (round 6: 20 000 windows of each shape that is run — unit weights, per-base qualities,
+Phred-10 blocks, HiFi — profiles/r06_poa_parity_*_20000.json: 19 994 - 20 000 identical, no window further than ONE edit,
+every differing window equal to the oracle's statement of the device's tie rules): per window ED(gpu, cpu) <= 2, at most
+one window in 24 different at all, every difference a tie; the simple cases must be identical."""
 import os
 
 import numpy as np
@@ -103,9 +105,13 @@ def test_noisy_windows_within_tolerance(qual, partial):
         assert polished
         d = _ed(c, ref)
         identical += d == 0
-        assert d <= max(2, 0.01 * len(ref)), (d, len(ref))
+        assert d <= 2, (d, len(ref))
         assert _ed(c, t) <= _ed(ref, t) + 2
-    assert identical >= 0.75 * len(wins)
+        if d:  # only a tie between equal scores may fall differently: the oracle under the device's tie rules agrees
+            ref2 = oracle.poa_window(w["layers"], begins=w.get("begins"), ends=w.get("ends"), quals=w.get("quals"),
+                                     device_order=True, end_tie=1)[0]
+            assert np.array_equal(c, ref2), (d, len(ref))
+    assert identical >= len(wins) - 1, identical
 
 
 def test_limits_are_reported_not_hidden():
@@ -155,9 +161,9 @@ def test_band_escalation_matches_full_matrix_kernel():
     assert eng.poa_wide_windows() == int(np.sum((st64 & 0xFF) == 8))
     assert eng.poa_fallback_windows() == int(np.sum((st128 & 0xFF) == 8)) >= 1
     for i, (c, r, w) in enumerate(zip(cons, ref, wins)):
-        assert _ed(c, r) <= 2, i                       # banded and full-matrix kernels agree (ties aside)
+        assert _ed(c, r) <= 1, i                       # banded and full-matrix kernels agree (ties aside)
         o, _ = _oracle(w)
-        assert _ed(c, o) <= max(2, 0.01 * len(o)), i
+        assert _ed(c, o) <= 2, i
 
 
 def test_kernel_modes_agree_on_noisy_windows():
@@ -212,6 +218,22 @@ def test_rows_on_lanes_kernel_equals_one_row_per_iteration_kernel():
     emu, st_emu = hip.poa_banded_emulate(wins[:8])
     for a, b, sa, sb in zip(emu, c9[:8], st_emu, s9[:8]):
         assert (int(sa) & 0xFF) == (int(sb) & 0xFF) and np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("shape", ["qual", "q10", "hifi"])
+def test_consensus_parity_fraction_on_the_other_shapes_that_are_run(shape):
+    """The same measure on the shapes the bench actually runs (round 6): per-base qualities, the
+    Phred-10 block qualities of the metric's configuration, HiFi-like layers.  Measured on 20 000 windows each
+    (profiles/r06_poa_parity_<shape>_20000.json): 19 994 / 19 998 / 20 000 identical, max one edit, none unexplained."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("poa_parity", os.path.join(ROOT, "tools", "poa_parity.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    r = mod.run(1000, threads=os.cpu_count(), mode=0, seed=777, shape=shape)
+    assert r["polished"] == 1000, r
+    assert r["identical_fraction"] >= 0.997, r   # (measured 0.9997 - 1.0: within 10x)
+    assert r["max_ed_between"] <= 2, r
+    assert len(r["not_explained"]) == 0, r
 
 
 def test_consensus_parity_fraction_on_c4_like_windows():

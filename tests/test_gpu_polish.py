@@ -81,6 +81,33 @@ def test_first_call_pilot_and_later_calls_give_the_same_layers():
     assert np.array_equal(eng.polish_layers(), lay1) and np.array_equal(cons3[0], cons1[0])
 
 
+def test_head_pass_and_early_repeats_give_the_oracle_layers():
+    """A batch large enough for the alignment stage's pilot (>= 4096 alignments): the longest alignments are then queued as
+    a pass of their own while the host plans the others (round 6), and alignments beyond their thresholds are repeated
+    as soon as the sweeps have found them, beside the last walks.  Fifty reads get 8 % more errors than the pilot can
+    predict, so the repeat path runs; none of it may show in the result: the layer table equals the oracle's row for row."""
+    truths, drafts, targets, reads, _ = pu2.make_case(genome_len=300_000, coverage=20, read_len=1200, seed=31)
+    rng = np.random.default_rng(2)
+    seqs = [reads.codes(i) for i in range(reads.n)]
+    for i in rng.choice(reads.n, size=50, replace=False):
+        seqs[i] = pu2.mutate(rng, seqs[i], 0.03, 0.025, 0.025)
+    reads = seqio.pack_reads(seqs)
+    eng = hip.Engine(15, 5)
+    td, rd = eng.upload(targets), eng.upload(reads)
+    cons, _, st = eng.polish_round(td, rd)
+    assert st["n_aligned"] >= 4096 and st["n_align_retries"] >= 10, st
+    lay = eng.polish_layers()
+    assert np.array_equal(lay, oracle.polish_layers(targets, reads))
+    assert _ed(cons[0], truths[0]) < 0.25 * _ed(drafts[0], truths[0])
+    # the same from the running estimate (second call) and in many small batches
+    eng.set_option("nw_budget_mb", 64)
+    try:
+        eng.polish_round(td, rd)
+    finally:
+        eng.set_option("nw_budget_mb", 0)
+    assert np.array_equal(eng.polish_layers(), lay)
+
+
 def test_polish_two_rounds_and_low_quality_reads_are_dropped():
     truths, drafts, targets, reads, quals = pu2.make_case(genome_len=16_000, coverage=20, read_len=2000, seed=9,
                                                          with_qual=True)
