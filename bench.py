@@ -61,13 +61,13 @@ _TRAFFIC = None
 
 
 def pmc_traffic_file():
-    """This round's rocprofv3 --pmc result (profiles/r05_pmc_traffic.json, made by tools/pmc_traffic.py from separate
+    """This round's rocprofv3 --pmc result (profiles/r06_pmc_traffic.json, made by tools/pmc_traffic.py from separate
     FETCH_SIZE / WRITE_SIZE passes of this same bench command; tools/profile_round.sh stamps it with the hash of the
     kernel sources it was taken on)."""
     global _TRAFFIC
     if _TRAFFIC is None:
         _TRAFFIC = {}
-        for name in ("r05_pmc_traffic.json",):
+        for name in ("r06_pmc_traffic.json", "r05_pmc_traffic.json"):  # (the newest there is; `stale` says whether it fits the sources)
             try:
                 with open(os.path.join(ROOT, "profiles", name)) as f:
                     _TRAFFIC = json.load(f)
@@ -88,7 +88,7 @@ def pmc_traffic(kernel):
 
 def pmc_traffic_raw(kernel):
     """The same counters as rocprofv3 reports them: FETCH_SIZE KiB + WRITE_SIZE KiB per launch (what a kernel of 4- or
-    16-byte gathers is counted at: 64 B per probe, profiles/r05_pmc_traffic.json "calibration")."""
+    16-byte gathers is counted at: 64 B per probe, profiles/r06_pmc_traffic.json "calibration")."""
     e = pmc_traffic_file().get("kernels", {}).get(kernel)
     return int(e["hbm_bytes_raw_per_launch"]) if e and "hbm_bytes_raw_per_launch" in e else None
 
@@ -554,7 +554,7 @@ def main():
                                     "(poa4.hip: one persistent kernel per polishing round = the launch priced here), what it "
                                     "hands on a 64-column band (poa2.hip: in 'stage').  avg_launch_ms = HIP events around the "
                                     "kernel's launch; rocprofv3's average for poa4_persistent_kernel is in "
-                                    "profiles/r05_kernel_stats.csv."}
+                                    "profiles/r06_kernel_stats.csv."}
             if dom in ("poa_banded", "poa_rows") or legs["poa_ms"] > 0.4 * dt * 1e3:
                 roofline = roofline_poa
             if "nw_forward" in kms and kms["nw_forward"][1] and last.get("polish", {}).get("align_band_cells"):

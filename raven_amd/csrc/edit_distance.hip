@@ -125,7 +125,7 @@ constexpr u32 kEdAbove = 0xFFFFFFFEu;  // bounded mode: the distance exceeds the
 // internal to edit_distance_dev: "beyond the WIDEST lane window" (the wave kernel's business; a pair that overflowed a narrower
 // window gets a second lane pass with the widest one first).  Never leaves this file.
 constexpr u32 kEdOverflowWide = 0xFFFFFFFDu;
-constexpr int kEdLaneWidest = 8;  // blocks of the widest lane window
+constexpr int kEdLaneWidest = 7;  // slots of the widest lane window (threshold 385 for spans of equal length, as the 8 blocks of rounds 1-5)
 
 // One wave per pair.  todo: indices of the pairs to process (null = all).  kmax (nullable): per-pair threshold — a
 // caller that only needs to know whether the distance is <= kmax (the identity filters: score >= identity) gets the
@@ -175,13 +175,127 @@ __global__ __launch_bounds__(256) void ed_banded_kernel(const u64* __restrict__ 
   if (lane_id() == 0) out[p] = res;
 }
 
-// One LANE per pair: banded Myers over a window of B consecutive 64-row blocks that slides down the diagonal, all
-// state in registers.  For pairs whose band is a few blocks wide (HiFi-like spans: distance ~1 % of the length) the
-// wave-per-pair systolic kernel above keeps 1 of 64 lanes busy; here 64 pairs share a wave.  Threshold = the largest
-// one whose band fits B blocks (or the pair's kmax if smaller); result exact if <= threshold, else kEdAbove (kmax
-// reached) or kEdOverflow (the pair needs the wave kernel).  `order`: pairs sorted by text length, so that the lanes of
-// a wave run loops of similar length.
-template <int B>
+// The text of a lane, 32 columns at a time, fetched at the SAME columns by every lane of the wave (column j with
+// (j - 1) % 32 == 0), one group ahead.  TextCursor refills a lane when ITS position crosses a word: with 64 lanes at 64
+// phases some lane crosses in nearly every column, the refill branch — and the wait for its load that the compiler has
+// to put into it — was executed by the whole wave nearly every column: one memory latency per column (round 6: the
+// lane kernel ran 15x below its instruction count).  Here a group is an unaligned 32-base fetch (two words) clipped to
+// the pair's span; the reverse strand is turned round on the way in (bit reversal + complement).
+struct TextGroups {
+  const u64* words;
+  long long first;  // base index of column 1 (forward) / of column 1 in the rc direction
+  long long lo;     // first base of the span
+  u32 m;
+  bool rc;
+  u64 cur, nxt;     // bases of columns 32 g + 1 .. 32 g + 32 (2 bits each, column order) of the current / next group
+  __device__ __forceinline__ u64 fetch(long long j0) const {  // columns j0 .. j0 + 31
+    if (j0 > static_cast<long long>(m)) return 0;
+    const long long span_last32 = m >= 32 ? lo + m - 32 : lo;  // last start whose 32 bases stay inside the span
+    if (!rc) {
+      const long long start = first + (j0 - 1);
+      const long long s = start < span_last32 ? start : span_last32;
+      return load_bases32(words, static_cast<u64>(s)) >> (2 * (start - s));
+    }
+    const long long top = first - (j0 - 1);  // base of column j0; the columns go DOWN from it
+    long long s = top - 31;
+    if (s < lo) s = lo;
+    u64 y = __brevll(load_bases32(words, static_cast<u64>(s)));  // pair at offset o -> pair 31 - o, its two bits swapped
+    y = ((y & 0x5555555555555555ULL) << 1) | ((y >> 1) & 0x5555555555555555ULL);
+    return ~(y >> (2 * (31 - (top - s))));  // column j0 + t = offset (top - s) - t -> pair t; complement = 3 - code
+  }
+  __device__ __forceinline__ void init(const u64* w, u64 b_base, u32 m_, bool rc_) {
+    words = w;
+    rc = rc_;
+    m = m_;
+    lo = static_cast<long long>(b_base);
+    first = rc_ ? lo + m_ - 1 : lo;
+    cur = fetch(1);
+    nxt = fetch(33);
+  }
+  // call once per column, in column order
+  __device__ __forceinline__ unsigned get(int j) {
+    const int x = (j - 1) & 31;
+    if (x == 0 && j > 1) {  // (wave-uniform)
+      cur = nxt;
+      nxt = fetch(j + 32);
+    }
+    return static_cast<unsigned>(cur >> (2 * x)) & 3u;
+  }
+};
+
+// raw words of pattern block b (what load_peq reads), loaded at one column and turned into masks at a later one
+struct PeqRaw {
+  u64 w[4];
+  u32 row0;
+};
+__device__ __forceinline__ void peq_raw_load(const u64* __restrict__ words, u64 a_base, u32 n, u32 b, PeqRaw& r) {
+  r.row0 = b * 64;
+  r.w[0] = r.w[1] = r.w[2] = r.w[3] = 0;
+  if (r.row0 < n) {  // exactly the words load_peq touches
+    const u64 bit = (a_base + r.row0) * 2;
+    const bool off = (bit & 63) != 0, second = r.row0 + 32 < n;
+    r.w[0] = words[bit >> 6];
+    if (off || second) r.w[1] = words[(bit >> 6) + 1];
+    if (off && second) r.w[2] = words[(bit >> 6) + 2];
+  }
+}
+__device__ __forceinline__ void peq_from_raw(const PeqRaw& r, u64 a_base, u32 n, u64 (&peq)[4]) {
+  const unsigned off = static_cast<unsigned>(((a_base + r.row0) * 2) & 63);
+  u64 lo = r.w[0] >> off, hi = r.w[1] >> off;
+  if (off) {
+    lo |= r.w[1] << (64 - off);
+    hi |= r.w[2] << (64 - off);
+  }
+  if (!(r.row0 < n)) lo = 0;
+  if (!(r.row0 + 32 < n)) hi = 0;
+  const u32 valid = n > r.row0 ? (n - r.row0 >= 64 ? 64u : n - r.row0) : 0u;
+  const u64 vmask = valid >= 64 ? ~0ULL : ((1ULL << valid) - 1ULL);
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const u64 rep = 0x5555555555555555ULL * static_cast<u64>(c);
+    const u64 ml = lo ^ rep, mh = hi ^ rep;
+    const u64 el = compress_even(~(ml | (ml >> 1)));
+    const u64 eh = compress_even(~(mh | (mh >> 1)));
+    peq[c] = (el | (eh << 32)) & vmask;
+  }
+}
+
+// One LANE per pair: banded Myers over a window of W consecutive 64-row blocks that moves down the diagonal, all state
+// in registers.  For pairs whose band is a few blocks wide (HiFi-like spans: distance ~1 % of the length) the
+// wave-per-pair systolic kernel above keeps 1 of 64 lanes busy; here 64 pairs share a wave.  Result exact if <= the
+// threshold, else kEdAbove (kmax reached) or an overflow code (kEdOverflow: a wider window may do; kEdOverflowWide from
+// the widest window: the pair needs the wave kernel).  `order`: pairs sorted by text length, so that the lanes of a wave
+// run loops of similar length.
+// Round 6: NOTHING in the column loop happens at a lane's own phase any more.  Rounds 1-5 let every lane slide its
+// window, take in a block and refill its text word when ITS band got there — with 64 lanes at 64 phases each of these
+// happened in nearly every column for somebody, so the whole wave ran the slide (13 register moves per slot), the entry
+// (13 selects per slot), and waited for a load issued one column earlier, nearly every column.  Now the window of every
+// lane moves by one block at the columns 64 c + 1 (it is one block taller than a band needs at any single column, so
+// that it holds the band of a whole 64-column cycle: a band of lo rows above and hi rows below the diagonal needs
+// W >= ceil(lo / 64) + ceil(hi / 64) + 1 slots — FEWER than the per-lane sliding of rounds 1-5, whose accounting kept two
+// spare blocks), the masks of the block that comes in are loaded two cycles ahead and converted one cycle ahead (PeqRaw),
+// the text comes in groups of 32 columns (TextGroups); a block's entry into and exit from the BAND (edlib's rule: the
+// all-(+1) bound below the block above; +1 boundary under a block that left) stay per lane and per column, as
+// predicates of the slot loop: the band, and with it every result and every overflow decision, is the one of rounds 1-5
+// for the same threshold.
+template <int W>
+__device__ __forceinline__ u32 ed_lane_threshold(u32 n, u32 m, u32 km, bool* fits) {
+  const u32 d = n > m ? n - m : m - n;
+  // lo = s + (m > n ? d : 0), hi = s + (n > m ? d : 0); the largest s with ceil(lo / 64) + ceil(hi / 64) <= W - 1:
+  // a units for the side without d, the rest for the side with it
+  int s_max = -1;
+#pragma unroll
+  for (int a = 0; a <= W - 1; ++a) {
+    const int with_d = 64 * (W - 1 - a) - static_cast<int>(d);
+    const int s = 64 * a < with_d ? 64 * a : with_d;
+    s_max = s > s_max ? s : s_max;
+  }
+  *fits = s_max >= 0;
+  const u32 k = d + 2u * static_cast<u32>(s_max > 0 ? s_max : 0) + 1u;
+  return k > km ? km : k;
+}
+
+template <int W>
 __global__ __launch_bounds__(64) void ed_lane_kernel(const u64* __restrict__ packed, const u64* __restrict__ word_off,
                                                     const EdPair* __restrict__ pairs, const u32* __restrict__ order,
                                                     u32 n_order, const u32* __restrict__ kmax, u32* __restrict__ out) {
@@ -200,79 +314,85 @@ __global__ __launch_bounds__(64) void ed_lane_kernel(const u64* __restrict__ pac
     out[p] = kEdAbove;
     return;
   }
-  constexpr u32 room = 64u * (B - 2);  // lo + hi of the widest band B blocks can hold
-  constexpr u32 kOverflow = B >= kEdLaneWidest ? kEdOverflowWide : kEdOverflow;
-  if (d > room) {
+  constexpr u32 kOverflow = W >= kEdLaneWidest ? kEdOverflowWide : kEdOverflow;
+  bool fits;
+  const u32 k = ed_lane_threshold<W>(n, m, km, &fits);
+  if (!fits) {
     out[p] = kOverflow;
     return;
   }
-  u32 k = d + ((room - d) / 2) * 2 + 1;
-  if (k > km) k = km;
-  const int lo = static_cast<int>((k - d) / 2 + (m > n ? d : 0u));
-  const int hi = static_cast<int>((k - d) / 2 + (n > m ? d : 0u));
+  const int lo = static_cast<int>((k - d) / 2 + (m > n ? d : 0u));  // band rows above the diagonal: block t is in the band
+  const int hi = static_cast<int>((k - d) / 2 + (n > m ? d : 0u));  // of column j while 64 t - hi + 1 <= j <= 64 t + 64 + lo
   const int nb = static_cast<int>((n + 63) >> 6);
+  const int sL = (lo + 63) >> 6;  // the window's first block in cycle c (columns 64 c + 1 .. 64 c + 64): max(0, c - sL)
   const u64* aw = packed + word_off[pr.a_idx];
   const u64* bw = packed + word_off[pr.b_idx];
-  u64 Pv[B], Mv[B], peq[B][4];
-  int sc[B];
-  int base = 0;                    // block held by slot 0
-  int top = -1;                    // last block initialised so far
-  TextCursor tc;
-  tc.init(bw, pr.b_begin, m, pr.strand == 0, 1);
+  u64 Pv[W], Mv[W], peq[W][4];
+  int sc[W];
+  int wb = 0;  // block held by slot 0
+#pragma unroll
+  for (int i = 0; i < W; ++i) {
+    Pv[i] = ~0ULL;
+    Mv[i] = 0;
+    sc[i] = 0;
+    load_peq(aw, pr.a_begin, n, static_cast<u32>(i), peq[i]);  // (blocks beyond the pattern: all-zero masks, never in the band)
+  }
+  u64 staged[4];  // match masks of block wb + W (the next to come in)
+  load_peq(aw, pr.a_begin, n, static_cast<u32>(W), staged);
+  PeqRaw raw;     // words of block wb + W + 1 (the one after)
+  peq_raw_load(aw, pr.a_begin, n, static_cast<u32>(W + 1), raw);
+  TextGroups tg;
+  tg.init(bw, pr.b_begin, m, pr.strand == 0);
   u32 result = 0xFFFFFFFFu;
   for (int j = 1; j <= static_cast<int>(m); ++j) {
-    // slide: blocks whose last band column is behind leave at the top
-    while (64 * base + 64 + lo < j) {
+    if (((j - 1) & 63) == 0) {  // wave-uniform: the window moves on
+      const int c = (j - 1) >> 6;
+      if (c - sL > wb) {
 #pragma unroll
-      for (int i = 0; i + 1 < B; ++i) {
-        Pv[i] = Pv[i + 1];
-        Mv[i] = Mv[i + 1];
-        sc[i] = sc[i + 1];
+        for (int i = 0; i + 1 < W; ++i) {
+          Pv[i] = Pv[i + 1];
+          Mv[i] = Mv[i + 1];
+          sc[i] = sc[i + 1];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) peq[i][c] = peq[i + 1][c];
+          for (int x = 0; x < 4; ++x) peq[i][x] = peq[i + 1][x];
+        }
+#pragma unroll
+        for (int x = 0; x < 4; ++x) peq[W - 1][x] = staged[x];
+        ++wb;
+        peq_from_raw(raw, pr.a_begin, n, staged);
+        peq_raw_load(aw, pr.a_begin, n, static_cast<u32>(wb + W + 1), raw);
       }
-      ++base;
     }
-    // enter: blocks whose first band column is j (or earlier, at the start)
-    int bl = (j + hi - 1) >> 6;
-    bl = bl < nb - 1 ? bl : nb - 1;
-    while (top < bl) {
-      ++top;
-      const int slot = top - base;
-      u64 tp[4];
-      load_peq(aw, pr.a_begin, n, static_cast<u32>(top), tp);
-      int above = 0;  // score of the block above at column j-1 (it is always still inside the band when a block enters)
+    const unsigned c = tg.get(j);
+    const bool c0 = c == 0, c1 = c == 1, c2 = c == 2;
+    const int u = j - 64 * wb + hi - 1;   // slot i has entered the band iff u >= 64 i, enters now iff u == 64 i (or j == 1)
+    const int v = j - 64 * wb - lo - 64;  // slot i has left the band iff v > 64 i
+    int hin = 1;        // above the first band block: the matrix border or a block that left the band (+1 boundary)
+    int above_old = 0;  // score of the block above at column j - 1
 #pragma unroll
-      for (int x = 0; x + 1 < B; ++x)
-        if (x + 1 == slot) above = sc[x];
-      // first band column 1: column 0 holds D(i, 0) = i; later: edlib's all-(+1) upper bound below the block above
-      const int first = (64 * top + 1 - hi <= 1) ? 64 * (top + 1) : above + 64;
-#pragma unroll
-      for (int i = 0; i < B; ++i) {
-        if (i == slot) {
+    for (int i = 0; i < W; ++i) {
+      const bool in_band = wb + i < nb && u >= 64 * i && v <= 64 * i;
+      if (in_band) {
+        if (u == 64 * i || j == 1) {  // first band column of the block
           Pv[i] = ~0ULL;
           Mv[i] = 0;
-          sc[i] = first;
-#pragma unroll
-          for (int c = 0; c < 4; ++c) peq[i][c] = tp[c];
+          // band starts at column 1: column 0 holds D(i, 0) = i; later: edlib's all-(+1) upper bound below the block above
+          sc[i] = (64 * (wb + i) + 1 - hi <= 1) ? 64 * (wb + i + 1) : above_old + 64;
         }
-      }
-    }
-    const unsigned c = tc.get(j);
-    int hin = 1;  // above the first band block: the matrix border or a block that left the band (+1 boundary)
-#pragma unroll
-    for (int i = 0; i < B; ++i) {
-      if (base + i <= bl) {
-        const u64 eq = c == 0 ? peq[i][0] : (c == 1 ? peq[i][1] : (c == 2 ? peq[i][2] : peq[i][3]));
+        const int old = sc[i];
+        const u64 eq = c0 ? peq[i][0] : (c1 ? peq[i][1] : (c2 ? peq[i][2] : peq[i][3]));
         const int hout = myers_block(Pv[i], Mv[i], eq, hin);
-        sc[i] += hout;
+        sc[i] = old + hout;
         hin = hout;
+        above_old = old;
+      } else {
+        hin = 1;  // (a block that left: the +1 boundary for the one below; a block not yet in: nothing below it is)
       }
     }
     if (j == static_cast<int>(m)) {
-      const int slot = nb - 1 - base;
+      const int slot = nb - 1 - wb;
 #pragma unroll
-      for (int i = 0; i < B; ++i) {
+      for (int i = 0; i < W; ++i) {
         if (i == slot) {
           const u32 used = n - static_cast<u32>(64 * (nb - 1));
           const u64 padmask = used >= 64 ? 0ULL : ~((1ULL << used) - 1ULL);
@@ -318,8 +438,8 @@ __global__ void ed_sample_kernel(const EdPair* __restrict__ pairs, const u32* __
 // to have is rate x length with the rate of the sample's 90th percentile + 10 % + 16: a class is a contiguous piece of the
 // order.  cnt[kEdBoundsAt + c] = first position whose pair fits the window of class c (windows kEdClassB, narrowest first);
 // a wrong guess costs a second pass with the widest window, never a result.
-constexpr int kEdClasses = 4;                        // narrower windows than the widest one
-__constant__ int kEdClassB[kEdClasses] = {3, 4, 5, 6};
+constexpr int kEdClasses = 2;                        // narrower windows than the widest one
+__constant__ int kEdClassB[kEdClasses] = {3, 5};     // (an even number of slots adds nothing for spans of equal length)
 __global__ void ed_classes_kernel(const u32* __restrict__ sorted_keys, u32 n_main, u32* __restrict__ cnt) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   u32 total = 0;
@@ -336,7 +456,7 @@ __global__ void ed_classes_kernel(const u32* __restrict__ sorted_keys, u32 n_mai
     }
   }
   for (int c = 0; c < kEdClasses; ++c) {
-    const u32 room = 64u * static_cast<u32>(kEdClassB[c] - 2);
+    const u32 room = 64u * static_cast<u32>(kEdClassB[c] - 1);  // (threshold of the window for spans of equal length, - 1)
     // rate = (bin + 1) / 1024, need = 1.1 rate len + 16 <= room  <=>  len <= (room - 16) * 1024 / (1.1 (bin + 1))
     const u32 len_max = total ? static_cast<u32>((static_cast<u64>(room - 16) * 10240ULL) / (11ULL * (bin + 1))) : 0u;
     const u32 key_min = 0xFFFFFFFFu - len_max;  // keys = 0xFFFFFFFF - text length, ascending
@@ -448,7 +568,7 @@ void edit_distance_dev(Engine& e, const ReadsDev& r, const u32* d_pairs_raw, u32
   const u32 done = h_cnt[1];
   bool narrow_used = false;
   if (2 * done >= n_sample && n_main) {
-    // a window as wide as the pair is expected to need (the work of a lane is proportional to the blocks of its window: with
+    // a window as wide as the pair is expected to need (the work of a lane is proportional to the slots of its window: with
     // the widest one for everybody the HiFi identity filter computed 8 blocks per column where 3 to 5 hold the band)
     u32 from = 0;  // positions [from, to) of the order take the window of B blocks; widest (longest pairs) first
     auto piece = [&](u32 to, int B) {
@@ -464,9 +584,7 @@ void edit_distance_dev(Engine& e, const ReadsDev& r, const u32* d_pairs_raw, u32
     break
       switch (B) {
         RVN_ED_LANE(3);
-        RVN_ED_LANE(4);
         RVN_ED_LANE(5);
-        RVN_ED_LANE(6);
         default:
           RVN_KLAUNCH(kKEditLane, ed_lane_kernel<kEdLaneWidest><<<div_up(cn, 64), 64, 0, s>>>(
                                       r.packed.as<u64>(), r.word_off.as<u64>(), d_pairs, ord, cn, d_kmax, d_out));
@@ -474,7 +592,7 @@ void edit_distance_dev(Engine& e, const ReadsDev& r, const u32* d_pairs_raw, u32
 #undef RVN_ED_LANE
       if (B < kEdLaneWidest) narrow_used = true;
     };
-    static const int class_b[kEdClasses] = {3, 4, 5, 6};  // (= kEdClassB on the device)
+    static const int class_b[kEdClasses] = {3, 5};  // (= kEdClassB on the device)
     piece(h_cnt[kEdBoundsAt + kEdClasses - 1], kEdLaneWidest);
     for (int c = kEdClasses - 1; c >= 1; --c) piece(h_cnt[kEdBoundsAt + c - 1], class_b[c]);
     piece(n_main, class_b[0]);

@@ -277,7 +277,6 @@ __device__ void wave_sort_segment(u64* __restrict__ k0, u64* __restrict__ k1, u6
 // One workgroup of NT threads per segment of <= cap keys (payloads beside them when PAY): all LSD passes ping-pong between
 // two LDS buffers, HBM sees one coalesced read and one coalesced write (the global-memory version moved ~20x the data,
 // profiles/r01_g_final_pmc_*).  smem: seg_sort_lds_bytes(cap).
-constexpr u32 kSegLdsCap = 2048;
 template <int NT, bool PAY>
 constexpr size_t seg_sort_lds_bytes(u32 cap) {
   return static_cast<size_t>(cap) * 8 * (PAY ? 4 : 2) + (NT / 64) * 256 * 2 + 32 + (NT / 64) * 16;
@@ -402,27 +401,53 @@ __device__ void block_sort_lds(u64* __restrict__ keys, u64* __restrict__ pays, u
   }
 }
 
-// per-read group sort: one workgroup per read segment of <= kSegLdsCap (key, payload) pairs; larger segments are left to
-// seg_sort_off_kernel
-__global__ __launch_bounds__(256) void seg_sort_lds_kernel(u64* __restrict__ keys, u64* __restrict__ pays,
-                                                          const u64* __restrict__ off, u32 n_seg) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[seg_sort_lds_bytes<256, true>(kSegLdsCap)];
-  const u32 seg = blockIdx.x;
-  if (seg >= n_seg) return;
-  const u64 b = off[seg];
-  const u64 n = off[seg + 1] - b;
-  if (n < 2 || n > kSegLdsCap) return;
-  block_sort_lds<256, true>(keys, pays, b, static_cast<u32>(n), kSegLdsCap, smem);
+// Per-read group sort by size class (round 6; rounds 1-5: one workgroup of 256 threads with LDS for 2048 pairs per read
+// whatever its size — 67 KB, two workgroups per CU — and a wave through global memory beyond that).  A read's segment of
+// <= cap (key, payload) pairs is sorted by one workgroup whose LDS is sized for the class: the typical read of an ONT
+// pass (1 000 - 3 000 matches per launch) gets a workgroup that fits four to eight times per CU.
+constexpr int kSegClasses = 5;
+__constant__ u32 kSegClassCap[kSegClasses] = {256, 512, 1024, 2048, 4096};
+static const u32 kSegClassCapHost[kSegClasses] = {256, 512, 1024, 2048, 4096};
+// lists[c * n_seg ...] <- segments of class c (kSegClasses: beyond the largest: a wave each through global memory)
+__global__ __launch_bounds__(256) void seg_class_list_kernel(const u64* __restrict__ off, u32 n_seg, u32* __restrict__ lists,
+                                                            u32* __restrict__ cnt) {
+  const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+  int cls = -1;
+  if (t < n_seg) {
+    const u64 n = off[t + 1] - off[t];
+    if (n >= 2) {
+      cls = kSegClasses;
+      for (int c = kSegClasses - 1; c >= 0; --c)
+        if (n <= kSegClassCap[c]) cls = c;
+    }
+  }
+  const int lane = lane_id();
+  for (int c = 0; c <= kSegClasses; ++c) {
+    const unsigned long long m = __ballot(cls == c);
+    if (!m) continue;
+    u32 base = 0;
+    if (lane == 0) base = atomicAdd(cnt + c, static_cast<u32>(__popcll(m)));
+    base = __shfl(base, 0, 64);
+    if (cls == c) lists[static_cast<size_t>(c) * n_seg + base + __popcll(m & ((1ULL << lane) - 1ULL))] = t;
+  }
 }
-
-// segments given by off[seg], off[seg+1]
-__global__ __launch_bounds__(256) void seg_sort_off_kernel(u64* k0, u64* k1, u64* p0, u64* p1,
-                                                          const u64* __restrict__ off, u32 n_seg) {
+template <int NT>
+__global__ __launch_bounds__(NT) void seg_sort_group_lds_kernel(u64* __restrict__ keys, u64* __restrict__ pays,
+                                                               const u64* __restrict__ off, const u32* __restrict__ list,
+                                                               u32 n_list, u32 cap) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char seg_smem[];
+  if (blockIdx.x >= n_list) return;
+  const u32 seg = list[blockIdx.x];
+  const u64 b = off[seg];
+  block_sort_lds<NT, true>(keys, pays, b, static_cast<u32>(off[seg + 1] - b), cap, seg_smem);
+}
+__global__ __launch_bounds__(256) void seg_sort_group_big_kernel(u64* k0, u64* k1, u64* p0, u64* p1, const u64* __restrict__ off,
+                                                                const u32* __restrict__ list, u32 n_list) {
   __shared__ u32 hist[4][512];
-  const u32 seg = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (seg >= n_seg) return;
+  const u32 q = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (q >= n_list) return;
+  const u32 seg = list[q];
   const u64 b = off[seg], e = off[seg + 1];
-  if (e - b <= kSegLdsCap) return;  // sorted by seg_sort_lds_kernel
   wave_sort_segment<true>(k0, k1, p0, p1, b, e - b, hist[threadIdx.x >> 6]);
 }
 
@@ -1065,8 +1090,36 @@ void chain_matches(Engine& e, const ReadsDev& r, u32 first, u32 last, u64 H, Map
   u64* p1 = e.m_pos[1].as<u64>();
   {
     StageTimer t(e, StageTimes::kSegSort);
-    RVN_KLAUNCH(kKSegSortGroup, seg_sort_lds_kernel<<<nr, 256, 0, s>>>(g0, p0, seg_off, nr);
-                seg_sort_off_kernel<<<div_up(nr, 4), 256, 0, s>>>(g0, g1, p0, p1, seg_off, nr));
+    u32* lists = e.chain_big.get<u32>(static_cast<size_t>(nr) * (kSegClasses + 1) + 16);
+    u32* d_cnt = lists + static_cast<size_t>(nr) * (kSegClasses + 1);
+    RVN_HIP(hipMemsetAsync(d_cnt, 0, (kSegClasses + 1) * 4, s));
+    seg_class_list_kernel<<<div_up(nr, 256), 256, 0, s>>>(seg_off, nr, lists, d_cnt);
+    RVN_LAUNCH_CHECK();
+    read_back(e, d_cnt, (kSegClasses + 1) * 4);
+    u32 n_cls[kSegClasses + 1];
+    std::memcpy(n_cls, e.h_pin, sizeof(n_cls));
+    static bool attr_set = false;
+    if (!attr_set) {
+      RVN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(seg_sort_group_lds_kernel<256>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  static_cast<int>(seg_sort_lds_bytes<256, true>(kSegClassCapHost[kSegClasses - 1]))));
+      attr_set = true;
+    }
+    // the largest first: their workgroups run longest
+    if (n_cls[kSegClasses])
+      RVN_KLAUNCH(kKSegSortGroup, seg_sort_group_big_kernel<<<div_up(n_cls[kSegClasses], 4), 256, 0, s>>>(
+                                      g0, g1, p0, p1, seg_off, lists + static_cast<size_t>(kSegClasses) * nr, n_cls[kSegClasses]));
+    for (int c = kSegClasses - 1; c >= 0; --c) {
+      if (!n_cls[c]) continue;
+      const u32 cap = kSegClassCapHost[c];
+      const u32* list = lists + static_cast<size_t>(c) * nr;
+      if (cap <= 512)
+        RVN_KLAUNCH(kKSegSortGroup, seg_sort_group_lds_kernel<64><<<n_cls[c], 64, seg_sort_lds_bytes<64, true>(cap), s>>>(
+                                        g0, p0, seg_off, list, n_cls[c], cap));
+      else
+        RVN_KLAUNCH(kKSegSortGroup, seg_sort_group_lds_kernel<256><<<n_cls[c], 256, seg_sort_lds_bytes<256, true>(cap), s>>>(
+                                        g0, p0, seg_off, list, n_cls[c], cap));
+    }
     t.stop();
   }
   u32 NI = 0;

@@ -15,6 +15,7 @@
 // the result is always the exact optimal path, the estimate only decides how much band is computed.  hs + ck of a launch
 // are budgeted (RVN_NW_BUDGET_MB, default: a quarter of the free HBM, at most 64 GB); more jobs than fit go in chunks.
 #include <algorithm>
+#include <mutex>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -559,23 +560,48 @@ void nw_breakpoints(Engine& e, const ReadsDev& T, const ReadsDev& Rd, std::vecto
     for (size_t qi = 0; qi < queued.size(); ++qi) {
       const Queued& q = queued[qi];
       const bool is_early_retry = q.dev.jobs == dev_retry.jobs;
-      for (u32 i : q.order) {
+      // the aligned jobs of a pass (all but a handful) are only counted: on a few threads — the pass order is by length,
+      // i.e. random in the 28 MB of job records, and one thread's cache misses were ~10 ms with the GPU idle
+      std::vector<u32> rest_of;  // everything that is not a plain "aligned"
+      if (q.sweep_only) {
+        rest_of = q.order;
+      } else {
+        std::mutex mu_;
+        parallel_for(q.order.size(), 16384, [&](size_t x0, size_t x1) {
+          u64 n_al = 0, sum_d = 0;
+          std::vector<double> rr;
+          std::vector<u32> other;
+          rr.reserve(x1 - x0);
+          for (size_t x = x0; x < x1; ++x) {
+            const u32 i = q.order[x];
+            if (!is_early_retry && !early.empty() && early[i]) continue;  // its result is the early retry pass's
+            if (h_status[i] != 0) {
+              other.push_back(i);
+              continue;
+            }
+            const NwJob& J = jobs[i];
+            ++n_al;
+            sum_d += h_result[i];
+            rr.push_back(static_cast<double>(h_result[i]) / std::max(J.n, J.m));
+          }
+          std::lock_guard<std::mutex> lk(mu_);
+          st.n_aligned += n_al;
+          st.sum_distance += sum_d;
+          rates.insert(rates.end(), rr.begin(), rr.end());
+          rest_of.insert(rest_of.end(), other.begin(), other.end());
+        });
+        std::sort(rest_of.begin(), rest_of.end());  // (the threads finish in any order)
+      }
+      for (u32 i : rest_of) {
         NwJob& J = jobs[i];
-        if (!is_early_retry && !early.empty() && early[i]) continue;  // its result is the early retry pass's
         if (h_status[i] == 2) {  // distance above the threshold: twice the band (and the variant that holds it)
           ++st.n_retries;
           if (J.k >= static_cast<u64>(J.n) + J.m || !plan(J, static_cast<u64>(J.k) * 2)) ++st.n_unaligned;
           else again.push_back(i);
         } else if (h_status[i] != 0) {
           throw HipError("[raven_hip] alignment path: the walk left the stored band (internal error)");
-        } else {
-          if (!q.sweep_only) {
-            ++st.n_aligned;
-            st.sum_distance += h_result[i];
-            rates.push_back(static_cast<double>(h_result[i]) / std::max(J.n, J.m));
-          } else {
-            obs.push_back(Obs{static_cast<double>(std::max(J.n, J.m)), static_cast<double>(h_result[i])});
-          }
+        } else {  // (a sweep-only pass: the pilot)
+          obs.push_back(Obs{static_cast<double>(std::max(J.n, J.m)), static_cast<double>(h_result[i])});
         }
       }
     }

@@ -1572,18 +1572,23 @@ struct Poa4Ctx {  // what a phase function needs beside the batch description
   u32 quad_delta;  // (group of four windows the wave is working on) - (the wave's own index), modulo 2^32: the wave's records
                    // and scratch slots are its own, the windows are those of the group (0 when the emulator steps the
                    // phases wave by wave in lock step)
+  u32 gw;          // windows per group, 1 .. 4 (0 = 4): a batch that does not fill the machine's wave slots with groups of
+                   // four is dealt out in smaller groups (round 6) — a wave's layer then has fewer graph sides in front of
+                   // its NW, and the latency of a group is what a small batch costs.  The wave's other slots stay empty.
 };
+__host__ __device__ __forceinline__ u32 poa4_group_windows(const Poa4Ctx& C) { return C.gw ? C.gw : static_cast<u32>(P4::G); }
 
 __host__ __device__ __forceinline__ unsigned char* poa4_slot_of(const Poa4Args& A, const Poa4Ctx&, u32 wave, int q) {
   return A.scratch + (static_cast<size_t>(wave) * P4::G + static_cast<size_t>(q)) * A.slot_bytes;
 }
 // the lane's window of this wave: record index, or 0xFFFFFFFF beyond the batch
 __host__ __device__ __forceinline__ u32 poa4_my_record(const Poa4Ctx& C, u32 wave, int q) {
-  const u32 pos = (wave + C.quad_delta) * P4::G + static_cast<u32>(q);  // position within the batch
-  return pos < C.count ? wave * P4::G + static_cast<u32>(q) : 0xFFFFFFFFu;
+  const u32 gw = poa4_group_windows(C);
+  const u32 pos = (wave + C.quad_delta) * gw + static_cast<u32>(q);  // position within the batch
+  return (static_cast<u32>(q) < gw && pos < C.count) ? wave * P4::G + static_cast<u32>(q) : 0xFFFFFFFFu;
 }
 __host__ __device__ __forceinline__ u32 poa4_position(const Poa4Ctx& C, u32 wave, int q) {
-  return C.first + (wave + C.quad_delta) * P4::G + static_cast<u32>(q);
+  return C.first + (wave + C.quad_delta) * poa4_group_windows(C) + static_cast<u32>(q);
 }
 
 // phase 0: graph of the backbone, state record
@@ -2234,7 +2239,7 @@ struct alignas(16) Poa4LdsAll {
 template <class K, int UP, class SC>
 __host__ __device__ inline void poa4_persistent(const Poa4Args& A, const Poa4Ctx& C0, Poa4LdsAll& S, u32 pw) {
   const int lane = sv::lane();
-  const u32 n_quads = (C0.count + P4::G - 1) / P4::G;
+  const u32 n_quads = (C0.count + poa4_group_windows(C0) - 1) / poa4_group_windows(C0);
   for (;;) {
     // (every lane takes part in the fetch — lane 0 adds one, the others nothing: see nwpath.hip on why not `if (lane == 0)`)
     u32 quad = sv::atomic_add(A.next, lane == 0 ? 1u : 0u);
@@ -2309,10 +2314,15 @@ Poa4Args args_of4(const PoaBatchDev& b, unsigned char* scratch, size_t slot_byte
 void poa_v4_launch(Engine& e, const PoaBatchDev& b) {
   if (b.n_windows == 0) return;
   const size_t slot_bytes = poa4_slot_bytes(b.nmax, b.lmax);
-  const u32 n_quads = (b.n_windows + P4::G - 1) / P4::G;
   int dev = 0, cus = 256;
   RVN_HIP(hipGetDevice(&dev));
   RVN_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  // windows per group: four, or two for a batch that leaves more than half of the wave slots empty even then (measured on
+  // tools/small_batch_survey.sh: 2 500 windows 28.3 -> 24.6 ms, 5 000 windows 32.0 -> 29.9 ms; one per group is no better
+  // than two, three no better than four at 10 000)
+  u32 gw = b.n_windows > 2u * static_cast<u32>(cus) * 16u ? static_cast<u32>(P4::G) : 2u;
+  if (const char* ev = knob("RVN_POA_GW")) gw = std::min<u32>(P4::G, std::max(1, std::atoi(ev)));  // (debug builds: A/B)
+  const u32 n_quads = (b.n_windows + gw - 1) / gw;
   size_t free_b = 0, total_b = 0;
   RVN_HIP(hipMemGetInfo(&free_b, &total_b));
   const size_t per_wave = P4::G * (slot_bytes + sizeof(Poa4Win));
@@ -2326,7 +2336,7 @@ void poa_v4_launch(Engine& e, const PoaBatchDev& b) {
   const Poa4Args A = args_of4(b, d_scratch, slot_bytes);
   hipStream_t s = e.stream;
   RVN_HIP(hipMemsetAsync(b.next, 0, 4, s));
-  const Poa4Ctx C{d_st, 0, b.n_windows, 0};
+  const Poa4Ctx C{d_st, 0, b.n_windows, 0, gw};
   // (two sequence positions per lane and turn of the graph update: the kernel's 128 registers hold it without the spills the
   // four-position variant brings — 739 against 829 ms per C4 round)
   if (poa4_racon_scores(A)) {

@@ -27,6 +27,15 @@ namespace rvn {
 
 namespace {
 
+// number of non-zero bytes of flags[0, n) added to *out (n < 2^32)
+__global__ __launch_bounds__(256) void count_flags_kernel(const u8* __restrict__ flags, u64 n, u32* __restrict__ out) {
+  u32 c = 0;
+  for (u64 i = static_cast<u64>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += static_cast<u64>(gridDim.x) * blockDim.x)
+    c += flags[i] ? 1u : 0u;
+  c = wave_sum(c);
+  if (lane_id() == 0 && c) atomicAdd(out, c);
+}
+
 // racon: a layer is used only if the mean Phred of its bases reaches q.  One wave per layer.
 __global__ __launch_bounds__(256) void layer_quality_kernel(const PoaLayer* __restrict__ layers, u32 n_layers,
                                                            const u8* __restrict__ read_quals, u32 qual_shift,
@@ -606,12 +615,11 @@ void polish_round(Engine& e, ReadsDev& T, ReadsDev& R, const u8* h_quals, const 
                                                            q_thr, d_ok);
     RVN_LAUNCH_CHECK();
     src.layer_ok = d_ok;
-    if (q_thr > 0) {  // statistics only: layers that survive
-      std::vector<u8> okh(n_lay);
-      RVN_HIP(hipMemcpyAsync(okh.data(), d_ok, n_lay, hipMemcpyDeviceToHost, s));
-      RVN_HIP(rvn_stream_sync(s));
-      u64 kept = 0;
-      for (u64 i = 0; i < n_lay; ++i) kept += okh[i];
+    if (q_thr > 0) {  // statistics only: layers that survive (counted on the device: the flags of 6 M layers went to the host
+                      // and through a scalar loop with the GPU idle, every round)
+      count_flags_kernel<<<1024, 256, 0, s>>>(d_ok, n_lay, d_misc + 1);
+      RVN_LAUNCH_CHECK();
+      const u64 kept = read_back(e, d_misc + 1, 4);
       stats.n_layers = kept - nw;  // backbones are always flagged ok
     } else {
       stats.n_layers = n_read_layers;

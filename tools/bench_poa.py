@@ -65,9 +65,12 @@ def main():
 def run_mode(eng, mode, wins, truths, n_windows, n_check, cells, label=""):
     eng.poa_set_mode(mode)
     eng.poa_consensus_batch(wins[:64])  # warm-up / allocation
-    t = time.time()
-    cons, status, ms = eng.poa_consensus_batch(wins)
-    wall = time.time() - t
+    ms = None
+    for _ in range(int(os.environ.get("RVN_POA_REPS", "1"))):  # (the first full-size call also grows the per-wave scratch)
+        t = time.time()
+        cons, status, ms1 = eng.poa_consensus_batch(wins)
+        wall = time.time() - t
+        ms = ms1 if ms is None else min(ms, ms1)
     out = {"mode": mode, "run": label, "windows": n_windows, "layers_per_window": 30, "device_ms": ms, "wall_s": wall,
            "windows_per_s": n_windows / ms * 1e3, "approx_gcups": cells / ms / 1e6,
            "status_counts": {int(k): int(v) for k, v in zip(*np.unique(status & 0xFF, return_counts=True))},
