@@ -751,8 +751,15 @@ void poa_run_dev(Engine& e, const PoaWindow* d_wins, const PoaLayer* d_lays, u32
     std::vector<u32> wide, wider, fullm;
     if (v4) {  // a 32-column first attempt: what touched its edge (or is beyond poa4.hip's limits) gets the 64-column band next
       std::vector<u32> narrow;
+      u32 why[16] = {};
       for (u32 w = 0; w < n_windows; ++w)
-        if ((h_status[w] & 0xFF) == kPoaBandHit) narrow.push_back(w);
+        if ((h_status[w] & 0xFF) == kPoaBandHit) {
+          narrow.push_back(w);
+          ++why[(h_status[w] >> 24) & 15u];
+        }
+      if (knob("RVN_POA_STATS") && !narrow.empty())
+        std::fprintf(stderr, "[raven_hip] poa: %zu of %u windows handed on by the first attempt: steps %u, in-degree %u, band step along an in-edge %u, last column outside the bands %u, walk near a band's edge %u, walk met a backpointer it cannot follow %u\n",
+                     narrow.size(), n_windows, why[1], why[3], why[7], why[9], why[10], why[11]);
       if (!narrow.empty()) rerun(narrow, 64);
       e.poa_narrow_windows = static_cast<u32>(narrow.size());
     }
@@ -765,7 +772,7 @@ void poa_run_dev(Engine& e, const PoaWindow* d_wins, const PoaLayer* d_lays, u32
     }
     if (knob("RVN_POA_DEBUG")) {
       for (u32 w : wide)
-        std::fprintf(stderr, "[raven_hip] poa: window %u band hit at layer %u\n", w, h_status[w] >> 8);
+        std::fprintf(stderr, "[raven_hip] poa: window %u band hit at layer %u\n", w, (h_status[w] >> 8) & 0xFFFFu);
       for (u32 w : fullm) std::fprintf(stderr, "[raven_hip] poa: window %u status %u -> full matrix\n", w, h_status[w]);
     }
     if (!wide.empty()) {  // 128 columns

@@ -2052,7 +2052,10 @@ __host__ __device__ inline void poa4_phase_dp(const Poa4Args& A, const Poa4Ctx& 
       // beyond this kernel's limits (in-degree, in-edge length, band step): the 64-column kernel's job
       if ((lane & (K::GS - 1)) == 0) {
         w.phase = kFailed;
-        w.status = kPoaBandHit | (li << 8);
+        // (bits 24-27: why, for the statistics of the debug build — 1..7 a limit of this kernel: 3 in-degree, 7 band step along
+        // an in-edge, 1 steps; 9 the last column in no end node's band; 10 the walk came near a band's edge; 11 the walk met
+        // a backpointer it cannot follow)
+        w.status = kPoaBandHit | (li << 8) | ((w.dflag ? (w.dflag & 7u) : 1u) << 24);
         w.act = 0;
       }
       act = 0;
@@ -2066,7 +2069,7 @@ __host__ __device__ inline void poa4_phase_dp(const Poa4Args& A, const Poa4Ctx& 
     w.best_rho1 = best_rho1;
     if (best_rho1 == 0) {  // the last column is in no end node's band
       w.phase = kFailed;
-      w.status = kPoaBandHit | (li << 8);
+      w.status = kPoaBandHit | (li << 8) | (9u << 24);
       w.act = 0;
     }
   }
@@ -2097,7 +2100,7 @@ __host__ __device__ inline void poa4_phase_tb(const Poa4Args& A, const Poa4Ctx& 
   if (act && (bad || band_hit) && (lane & (K::GS - 1)) == 0) {
     Poa4Win& w = C.st[my_rec];
     w.phase = kFailed;
-    w.status = (bad ? bad : kPoaBandHit) | (li << 8);
+    w.status = (bad ? bad : kPoaBandHit) | (li << 8) | ((bad ? 11u : 10u) << 24);
     w.act = 0;
   }
   if (A.phase_cycles && lane == 0) sv::atomic_add(&A.phase_cycles[2], sv::clock() - t0);

@@ -74,7 +74,7 @@ def run_mode(eng, mode, wins, truths, n_windows, n_check, cells, label=""):
     out = {"mode": mode, "run": label, "windows": n_windows, "layers_per_window": 30, "device_ms": ms, "wall_s": wall,
            "windows_per_s": n_windows / ms * 1e3, "approx_gcups": cells / ms / 1e6,
            "status_counts": {int(k): int(v) for k, v in zip(*np.unique(status & 0xFF, return_counts=True))},
-           "fail_layers": [int(x) >> 8 for x in status[status > 1][:20]], "fail_windows": [int(i) for i in np.nonzero(status > 1)[0][:20]],
+           "fail_layers": [(int(x) >> 8) & 0xFFFF for x in status[status > 1][:20]], "fail_windows": [int(i) for i in np.nonzero(status > 1)[0][:20]],
            "phase_cycles": eng.poa_phase_cycles(), "fallback_windows": eng.poa_fallback_windows(), "wide_windows": eng.poa_wide_windows(),
            "kernel_ms": {k: v for k, v in eng.kernel_ms().items() if k.startswith("poa")} if hasattr(eng, "kernel_ms") else None,
            "read_bases_per_s": sum(sum(len(x) for x in w["layers"][1:]) for w in wins) / ms * 1e3}
