@@ -125,7 +125,7 @@ def algorithmic_bytes(site, c, val_bytes):
         "match_count": rec * Mq + 8.0 * H + 12.0 * Mq,
         "match_emit": 8.0 * Mq + 8.0 * H + 16.0 * H,
         "seg_sort_group": 2.0 * 16.0 * H,
-        "seg_sort_pos": 2.0 * 16.0 * H,
+        "seg_sort_pos": 2.0 * 8.0 * H,  # (keys only since round 6)
         "chain": 16.0 * H + 32.0 * O,
         "minhash_select": val_bytes * Mi + Mi,
     }

@@ -22,8 +22,8 @@ SITES = [  # (regex on the demangled kernel name, bench.py kernel-site name)
     (r"\bpoa_kernel", "poa"), (r"chain_small_kernel", "chain_small"), (r"chain_kernel", "chain"),
     (r"rs_downsweep_kernel", "rs_downsweep"), (r"rs_upsweep_kernel", "rs_upsweep"),
     (r"sketch_kernel<[^>]*false>", "sketch_count"), (r"sketch_kernel<[^>]*true>", "sketch_write"),
-    (r"join_kernel<false>", "join_count"), (r"join_kernel<true>", "join_emit"), (r"seg_sort_off_kernel", "seg_sort_group"),
-    (r"seg_sort_lds_kernel", "seg_sort_group"), (r"seg_sort_be_kernel", "seg_sort_pos"),
+    (r"join_kernel<false>", "join_count"), (r"join_kernel<true>", "join_emit"), (r"seg_sort_group_(lds|big)_kernel", "seg_sort_group"),
+    (r"seg_sort_pos_(lds|big)_kernel", "seg_sort_pos"),
     (r"minhash_select_kernel", "minhash_select"), (r"unique_kernel", "unique"), (r"heads_kernel", "heads"),
     (r"match_count_kernel", "match_count"), (r"match_emit_kernel", "match_emit"), (r"table_kernel", "table"),
     (r"add_layers_kernel", "add_layers"), (r"ed_banded_kernel", "edit_distance"), (r"ed_lane_kernel", "edit_distance_lane"),

@@ -5,11 +5,19 @@ TAG=${1:-r05}
 cd /tmp && export TMPDIR=/tmp
 export RVN_POLISH_SKIP_POA=1
 export RVN_LIB_PATH=$R/raven_amd/lib/libraven_hip_test.so  # (the switch above exists in the debug build only)
-rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/${TAG}_nw_tl -o t -- python $R/bench.py --no-cpu-baseline --no-kernel-timing --steps 1 --warmup 0 > /dev/null 2> $R/gpurun_out/${TAG}_nw_tl.err
+rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/${TAG}_nw_tl -o t -- python $R/bench.py --no-cpu-baseline --no-kernel-timing --load-bases 0 --steps 1 --warmup 1 > /dev/null 2> $R/gpurun_out/${TAG}_nw_tl.err
 F=$(find $R/gpurun_out/${TAG}_nw_tl -name '*kernel_trace.csv' | head -1)
 python - "$F" $R/gpurun_out/${TAG}_nw_timeline.csv <<'PY'
 import csv, sys
 rows = [r for r in csv.DictReader(open(sys.argv[1])) if "nw_" in r["Kernel_Name"]]
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+# the LAST polishing round of the run (a warm one: the first round of a process also grows its buffers): rounds are
+# separated by the other stages, i.e. by gaps of more than 100 ms between two alignment kernels
+last = 0
+for i in range(1, len(rows)):
+    if int(rows[i]["Start_Timestamp"]) - max(int(r["End_Timestamp"]) for r in rows[last:i]) > 100e6:
+        last = i
+rows = rows[last:]
 t0 = min(int(r["Start_Timestamp"]) for r in rows)
 with open(sys.argv[2], "w") as f:
     f.write("kernel,queue,start_ms,end_ms,dur_ms,grid\n")
