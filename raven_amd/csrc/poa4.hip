@@ -56,8 +56,11 @@ struct P4 {
                                       // kept 24; round 6 gave two rows' worth of LDS to the lanes' row descriptors (Poa4Lds::qa ..)
   static constexpr int kRowB = 64;    // bytes per ring row: the 32 cells of the row's band, addressed by the COLUMN (below)
   static constexpr int kMaxD = 8;     // largest band-start difference along an in-edge (a larger one sends the window to poa2)
-  static constexpr int kEdges = 8;    // in-edges a row descriptor holds; a row with more sends the window to poa2 (4-bit backpointers:
-                                      // 8 diagonal + 7 vertical codes + 0 = horizontal or vertical through in-edge 7, see above)
+  static constexpr int kEdges = 8;    // in-edges a row descriptor holds (4-bit backpointers: 8 diagonal + 7 vertical codes + 0 = horizontal
+                                      // or vertical through in-edge 7, see above)
+  static constexpr int kEdgesMax = 15;  // in-edges of a row this kernel follows: a row of 9..15 keeps in-edges 0..6 in its descriptor and
+                                        // in-edges 7..14 in an overflow record (Poa4Slot::ovf) the step's rare path reads; a row with more
+                                        // sends the window to poa2 (the graph itself keeps kPoaMaxIn = 16)
   static constexpr int kU = 8;        // steps between two service points (descriptor prefetch, backpointer store)
 };
 constexpr u32 kNone4 = 0xFFFFu;
@@ -139,19 +142,24 @@ struct Poa4Slot {
   u32* rb;       // per node: rank | backbone coordinate << 16 (kept by the set-up and by poa4_update_graph)
   u32* rbl;      // per node, for the CURRENT layer: rank | band start << 16 (first pass of the descriptor phase)
   u32* v7;       // per row with eight in-edges: bit c = column band start + c took the VERTICAL move through the eighth in-edge —
-                 // the one move the 4-bit codes cannot tell from "horizontal" (both code 0); written by the NW for such rows only
+                 // the one move the 4-bit codes cannot tell from "horizontal" (both code 0); written by the NW for such rows only.
+                 // Per row with 9..15 in-edges: bit c = column band start + c took its move through one of the in-edges 7..14
+                 // (the code's low three bits then count from in-edge 7: 14 - in-edge)
+  uint4* ovf;    // per row with 9..15 in-edges: the ring bytes of in-edges 7..14 (8 x 16 bits; -inf cells for those it does not have)
   uint2* bps;    // backpointer stream: [step / 8][lane of the window] 8 bytes = 8 steps x 2 columns x 4 bits
   u32* seq2g;    // the current layer: [0, 60) 2 bits per base, [64, 96) its band guide as eight segments (set-up kernel ->
                  // descriptor / graph update kernels)
 };
 __host__ __device__ inline u32 poa4_desc_rows(u32 nmax) { return nmax + 64; }
 __host__ __device__ inline u32 poa4_steps(u32 nmax, u32 lmax) { return nmax + nmax / 16 + lmax / 2 + 96; }
+__host__ __device__ inline size_t poa4_v7_bytes(u32 nmax) { return (static_cast<size_t>(poa4_desc_rows(nmax)) * 4 + 255) & ~size_t(255); }
 inline size_t poa4_slot_bytes(u32 nmax, u32 lmax) {
   size_t b = poa2_slot_bytes(nmax, lmax, 0, false);
   b += static_cast<size_t>(poa4_desc_rows(nmax)) * 32;
   b += 2 * ((static_cast<size_t>(nmax) * 4 + 255) & ~size_t(255));
   b += (static_cast<size_t>(poa4_steps(nmax, lmax)) / P4::kU + 2) * 16 * 8;
-  b += (static_cast<size_t>(poa4_desc_rows(nmax)) * 4 + 255) & ~size_t(255);
+  b += poa4_v7_bytes(nmax);
+  b += static_cast<size_t>(poa4_desc_rows(nmax)) * 16;
   b += 512;
   return (b + 255) & ~size_t(255);
 }
@@ -169,7 +177,9 @@ __host__ __device__ inline Poa4Slot poa4_carve(unsigned char* base, u32 nmax, u3
   s.bps = reinterpret_cast<uint2*>(base + o);
   o += (static_cast<size_t>(poa4_steps(nmax, lmax)) / P4::kU + 2) * 16 * 8;
   s.v7 = reinterpret_cast<u32*>(base + o);
-  o += (static_cast<size_t>(poa4_desc_rows(nmax)) * 4 + 255) & ~size_t(255);
+  o += poa4_v7_bytes(nmax);
+  s.ovf = reinterpret_cast<uint4*>(base + o);  // (right behind v7: the NW's rare path derives it from that pointer)
+  o += static_cast<size_t>(poa4_desc_rows(nmax)) * 16;
   s.seq2g = reinterpret_cast<u32*>(base + o);
   return s;
 }
@@ -444,17 +454,23 @@ __host__ __device__ inline void poa4_dp(const Poa4Args A, Poa4Lds& S, unsigned c
   const u32 neg2 = neg_off | (neg_off << 16);
   const u32 negpair = pack16(kNegInf16, kNegInf16);
   // a descriptor as the desc pass left it (2 x 16 bytes) into one of the lane's two slots; `on` = false: a row that never starts
-  auto park = [&](u32 par, uint4 da, uint4 db, bool on) __attribute__((always_inline)) {
+  // (l16 = 16 x lane: the lane's place in a slot.  The loop derives it from its slot pointer where it parks: as three lane-derived
+  // LDS addresses of their own (qa, qm / qc, qe) the compiler kept two in registers across the NW and one in scratch memory, reloaded
+  // — behind a wait for everything outstanding — at every service point)
+  auto park = [&](u32 l16, u32 par, uint4 da, uint4 db, bool on) __attribute__((always_inline)) {
     const u32 s2 = on ? (da.x & 0xFFFFu) : kInactiveS;
     const u32 c1 = on ? da.y : 0u;
     const u32 np = (c1 >> 26) & 15u;
     // bytes of the band's first column pair in a ring row, minus 8 S: the pair of step t is (this + 8 t) & 0x78
     const u32 r0 = (((c1 >> 14) & 0x78u) - 4u * s2) & 0x78u;
     const bool rare = on && s2 != kInactiveS && (np == 0u || np > 4u);
-    S.qa[par][lane] = uint4{on ? da.x : (kInactiveS | (neg_off << 16)), on ? da.w : neg2, on ? db.x : neg2, db.w};
-    S.qm[par][lane] = r0 | ((c1 >> 31) << 8) | (np << 24) | (rare ? 0x80000000u : 0u);
-    S.qe[par][lane] = uint2{on ? db.y : neg2, on ? db.z : neg2};
-    S.qc[par][lane] = c1;
+    unsigned char* const base = reinterpret_cast<unsigned char*>(&S);
+    const u32 a16 = l16 + par * (64u * 16u);
+    *reinterpret_cast<uint4*>(base + offsetof(Poa4Lds, qa) + a16) =
+        uint4{on ? da.x : (kInactiveS | (neg_off << 16)), on ? da.w : neg2, on ? db.x : neg2, db.w};
+    *reinterpret_cast<u32*>(base + offsetof(Poa4Lds, qm) + (a16 >> 2)) = r0 | ((c1 >> 31) << 8) | (np << 24) | (rare ? 0x80000000u : 0u);
+    *reinterpret_cast<uint2*>(base + offsetof(Poa4Lds, qe) + (a16 >> 1)) = uint2{on ? db.y : neg2, on ? db.z : neg2};
+    *reinterpret_cast<u32*>(base + offsetof(Poa4Lds, qc) + (a16 >> 2)) = c1;
   };
   bool sched_bad = false;
   u32 ld_rho = static_cast<u32>(gl) + 16u;  // the last row whose descriptor went to LDS
@@ -462,8 +478,8 @@ __host__ __device__ inline void poa4_dp(const Poa4Args A, Poa4Lds& S, unsigned c
   {
     const uint4 a = sl.desc[2 * static_cast<size_t>(gl)], b = sl.desc[2 * static_cast<size_t>(gl) + 1];
     const uint4 a2 = sl.desc[2 * static_cast<size_t>(gl + 16)], b2 = sl.desc[2 * static_cast<size_t>(gl + 16) + 1];
-    park(0, a, b, act);  // (a group without a layer in this round has no descriptors: it idles on -inf cells)
-    park(1, a2, b2, act);
+    park(static_cast<u32>(lane) * 16u, 0, a, b, act);  // (a group without a layer in this round has no descriptors: it idles on -inf cells)
+    park(static_cast<u32>(lane) * 16u, 1, a2, b2, act);
     const u32 s0 = act ? (a.x & 0xFFFFu) : kInactiveS;
     ld_s2 = act ? (a2.x & 0xFFFFu) : kInactiveS;
     // consecutive rows of a lane start at least 17 steps apart (band starts do not decrease along the order)
@@ -536,7 +552,11 @@ __host__ __device__ inline void poa4_dp(const Poa4Args A, Poa4Lds& S, unsigned c
 #endif
     if (ld_pending) {
       const u32 rho = ld_rho + 16u;
-      park((rho >> 4) & 1u, lA, lB, true);
+      u32 l16 = ptr & (kFlip - 1u);
+#if defined(__HIP_DEVICE_COMPILE__)
+      asm volatile("" : "+v"(l16));  // (from the slot pointer, here: not a value kept since before the loop)
+#endif
+      park(l16, (rho >> 4) & 1u, lA, lB, true);
       const u32 s2 = lA.x & 0xFFFFu;
       if (ld_s2 != kInactiveS && s2 < ld_s2 + 34u) sched_bad = true;  // the row's first step would be over: band starts decreased along the order
       ld_s2 = s2;
@@ -642,9 +662,9 @@ __host__ __device__ inline void poa4_dp(const Poa4Args A, Poa4Lds& S, unsigned c
       // the tags (8 | 7 - e, 7 - e, 0); equal keys are "vertical through the eighth in-edge" and "horizontal": code 0 for both ----
       const u32 cs = cw.w >> (static_cast<u32>(k2) & 31u);
       const i32 m0 = static_cast<i32>(cs << 31) >> 31, m1 = static_cast<i32>(cs << 30) >> 31;  // -1: the row's base matches the column's
-      const i32 M0 = imax3(Am1 + xD + (m0 & dD), A0 + gK, UK + gK);
+      i32 M0 = imax3(Am1 + xD + (m0 & dD), A0 + gK, UK + gK);
       const i32 U0K = M0 & ~0xFF;
-      const i32 M1 = imax3(A0 + xD + (m1 & dD), A1 + gK, U0K + gK);
+      i32 M1 = imax3(A0 + xD + (m1 & dD), A1 + gK, U0K + gK);
       const bool in_band = k2 >= 0;
 #if defined(P4_EXP) && P4_EXP == 4  // (timing experiment: no ring store)
       if (in_band && M0 == 0x12345678) lds_st32(S, add_half<true>(off4, cw.x), clamp_pair(keys_to_pair(M0, M1)));
@@ -659,9 +679,62 @@ __host__ __device__ inline void poa4_dp(const Poa4Args A, Poa4Lds& S, unsigned c
         // 59 ms of a second kernel per C4 round).  The vertical candidate wins a tie with the horizontal one (max3's key
         // order), and a diagonal of the same score would have left a tag >= 8.
         P4_MARK("rare_begin");
-        const bool has8 = ((cm >> 24) & 15u) > 7u;
-        const u32 b0 = (in_band && (M0 & 0xFF) == 0 && M0 == A0 + gK) ? 1u : 0u;
-        const u32 b1 = (in_band && (M1 & 0xFF) == 0 && M1 == A1 + gK) ? 1u : 0u;
+        const u32 npc = (cm >> 24) & 15u;
+        const bool has8 = npc > 7u;
+        u32 b0 = (in_band && (M0 & 0xFF) == 0 && M0 == A0 + gK) ? 1u : 0u;
+        u32 b1 = (in_band && (M1 & 0xFF) == 0 && M1 == A1 + gK) ? 1u : 0u;
+        if (sv::any(npc > 8u)) {
+          // A row of 9..15 in-edges (241 of the 244 windows a C4 round of round 6 still handed to the 64-column kernel had one:
+          // a launch of 38 ms behind the persistent kernel for a thousandth of the windows).  In-edges 7..14 are a second group
+          // with tags of their own (7 - (e - 7)): their cells of this step's pair and of the pair before come out of the ring here
+          // (addresses: the row's overflow record, a global load — on this path only), the group's two cells are folded like the
+          // first group's, and a cell takes the second group's key where that one is better by spoa's order — higher score, then
+          // diagonal before vertical before horizontal; the first group has the earlier in-edges and keeps a tie inside a class.
+          // The row's mask (v7: such a row keeps no eighth in-edge in its descriptor, code 0 is "horizontal") says per column which
+          // group the code counts in.  The cells were stored above with the first group's values: stored again here, same lane,
+          // before any other lane reads them (a step later at the earliest).
+          const bool has9 = npc > 8u;
+          const u32 rho_c = (cw.x & 0xFFFFu) == ld_s2 ? ld_rho : ld_rho - 16u;
+          // (a loop that is NOT unrolled, one in-edge per turn, its ring bytes fetched as the 16 bits they are: this path runs
+          // for one row in ~1 000 windows and must not cost the step's common path a register — unrolled over the record's four
+          // words it pushed the descriptor pointer of the service point into scratch memory: two reloads and two waits for
+          // "everything outstanding" per eight steps, +35 % on the whole NW)
+          const u16* const ovp = reinterpret_cast<const u16*>(reinterpret_cast<const unsigned char*>(sl.v7) + poa4_v7_bytes(A.nmax)) +
+                                 8u * static_cast<size_t>(has9 ? rho_c : 0u);
+          const u32 offp = (off4 - 8u) & 0x78u;
+          i32 B0 = kNegU, B1 = kNegU, Bm1 = kNegU;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1
+#endif
+          for (i32 e = 0; e < 8; ++e) {
+            const u32 rb = has9 ? static_cast<u32>(ovp[e]) : neg_off;
+            const u32 wc = lds_ld32(S, rb + off4), wp = lds_ld32(S, rb + offp);
+            const i32 tag = 7 - e;
+            B0 = imax(B0, sext16(wc) * 256 + tag);
+            B1 = imax(B1, sext16(wc >> 16) * 256 + tag);
+            Bm1 = imax(Bm1, sext16(wp >> 16) * 256 + tag);
+          }
+          // class of a key: 2 diagonal, 1 vertical, 0 horizontal (first group: tag 0 — its vertical tags are 7..1 in such a row)
+          auto better = [](i32 kb, i32 ka) -> bool {
+            const i32 ca = (ka & 8) ? 2 : ((ka & 7) ? 1 : 0), cb = (kb & 8) ? 2 : 1;
+            return ((kb & ~0xFF) | cb) > ((ka & ~0xFF) | ca);
+          };
+          const i32 N0 = imax(Bm1 + xD + (m0 & dD), B0 + gK);
+          const bool t0b = has9 && better(N0, M0);
+          const i32 M0n = t0b ? N0 : M0;
+          const i32 M1a = imax3(A0 + xD + (m1 & dD), A1 + gK, (M0n & ~0xFF) + gK);
+          const i32 N1 = imax(B0 + xD + (m1 & dD), B1 + gK);
+          const bool t1b = has9 && better(N1, M1a);
+          const i32 M1n = t1b ? N1 : M1a;
+          if (has9) {
+            M0 = M0n;
+            M1 = M1n;
+            if (in_band) lds_st32(S, add_half<true>(off4, cw.x), clamp_pair(keys_to_pair(M0, M1)));
+            UK = in_band ? (M1 & ~0xFF) : kNegU;
+            b0 = (in_band && t0b) ? 1u : 0u;
+            b1 = (in_band && t1b) ? 1u : 0u;
+          }
+        }
         v7m = (k2 <= 0 ? 0u : v7m) | ((b0 | (b1 << 1)) << (static_cast<u32>(k2) & 31u));
         if (has8 && k2 == 30) sl.v7[(cw.x & 0xFFFFu) == ld_s2 ? ld_rho : ld_rho - 16u] = v7m;
         P4_MARK("rare_end");
@@ -759,8 +832,18 @@ __host__ __device__ inline void poa4_traceback(const Poa4Args A, Poa4LdsTb& S, u
   const int gl = lane & 15, q = lane >> 4;
   const Poa4Slot sl = poa4_carve(slot_mem, A.nmax, A.lmax);
   const uint4* const dsc = sl.desc;
-  const uint2* const bps = sl.bps;
-  u16* const pos_node = sl.g.pos_node;
+  // (the backpointer stream's address is formed from the descriptors' where the codes are fetched, once per round of 32 rows: as a
+  // pointer of its own it lived — with the descriptors' — in scratch memory across the walk, reloaded at every change of round)
+  const size_t bps_off = static_cast<size_t>(poa4_desc_rows(A.nmax)) * 32 + 2 * ((static_cast<size_t>(A.nmax) * 4 + 255) & ~size_t(255));  // (poa4_carve)
+  // (likewise the position -> node table: a scalar distance from the descriptors, the address formed where a block of sixteen leaves)
+  const i32 pn_off = sv::rfl(static_cast<i32>(reinterpret_cast<const unsigned char*>(sl.g.pos_node) - reinterpret_cast<const unsigned char*>(sl.desc)));
+  auto pos_node_at = [&](u32 idx) __attribute__((always_inline)) -> u16* {
+    i32 po = pn_off;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+s"(po));
+#endif
+    return reinterpret_cast<u16*>(const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(dsc)) + static_cast<ptrdiff_t>(po)) + idx;
+  };
   const u32 w = len + 1;
   bad = 0;
   band_hit = 0;
@@ -791,7 +874,11 @@ __host__ __device__ inline void poa4_traceback(const Poa4Args A, Poa4LdsTb& S, u
     for (int h = 0; h < kTbG; ++h) {
       const u32 s2 = d0[h] & 0xFFFFu;
       const size_t tb = s2 == kInactiveS ? 0u : (s2 >> 1) / K::kU;
-      const v2u* src = reinterpret_cast<const v2u*>(bps + tb * 16 + static_cast<size_t>(gl));
+      size_t bo = bps_off;
+#if defined(__HIP_DEVICE_COMPILE__)
+      asm volatile("" : "+s"(bo));
+#endif
+      const v2u* src = reinterpret_cast<const v2u*>(reinterpret_cast<const unsigned char*>(dsc) + bo) + tb * 16 + static_cast<size_t>(gl);
       a[h] = src[0];
       b[h] = src[16];
       c[h] = src[32];
@@ -876,12 +963,18 @@ __host__ __device__ inline void poa4_traceback(const Poa4Args A, Poa4LdsTb& S, u
       if (sv::any(in_round && np >= 7)) {  // rows of seven or eight in-edges (1 % of the windows have one)
         // code 0 in a row of eight in-edges is "horizontal" or "vertical through the eighth": the NW left the answer in the
         // row's v7 mask; in-edges 6 and 7: their ranks come from the graph
-        if (in_round && !oob && isH && np >= 8u) {
+        // A row of 9..15 in-edges: the mask says which columns took their move through the second group (in-edges 7..14, counted
+        // from 7 by the code's low bits; the descriptor of such a row has no eighth in-edge, code 0 outside the mask is "horizontal")
+        u32 kk = k;
+        if (in_round && !oob && np >= 8u && (isH || np >= 9u)) {
           const u32 m7 = poa4_carve(opaque(slot_mem), A.nmax, A.lmax).v7[i - 1];
-          if ((m7 >> idx) & 1u) isH = false;  // (k = (~0) & 7 = 7: the eighth in-edge; code >> 3 = 0: no column is left)
+          if ((m7 >> idx) & 1u) {
+            isH = false;  // (np = 8: k = (~0) & 7 = 7, the eighth in-edge; code >> 3 = 0: no column is left)
+            if (np >= 9u) kk = k + 7u;
+          }
         }
-        if (in_round && !oob && !isH && k >= 6)
-          ni = poa4_nth_pred_rank(poa4_carve(opaque(slot_mem), A.nmax, A.lmax), node, k, full) - r_lo + 1;
+        if (in_round && !oob && !isH && kk >= 6)
+          ni = poa4_nth_pred_rank(poa4_carve(opaque(slot_mem), A.nmax, A.lmax), node, kk, full) - r_lo + 1;
       }
       // (a diagonal or horizontal code in column 0 — never on a consistent stream — leaves the band in the next step)
       const bool ok = in_round && !oob;
@@ -892,7 +985,7 @@ __host__ __device__ inline void poa4_traceback(const Poa4Args A, Poa4LdsTb& S, u
       const u32 p = static_cast<u32>(j) - 1u;
       if (sv::any(diag && (p >> 4) != pblk)) {
         const bool fl = diag && (p >> 4) != pblk;
-        if (fl && pblk != 0xFFFFFFFFu) pos_node[16u * pblk + static_cast<u32>(gl)] = static_cast<u16>(pbuf);
+        if (fl && pblk != 0xFFFFFFFFu) *pos_node_at(16u * pblk + static_cast<u32>(gl)) = static_cast<u16>(pbuf);
         if (fl) {
           pbuf = kNone4;
           pblk = p >> 4;
@@ -913,7 +1006,7 @@ __host__ __device__ inline void poa4_traceback(const Poa4Args A, Poa4LdsTb& S, u
       P4_MARK("tb_step_end");
     }
   }
-  if (pblk != 0xFFFFFFFFu) pos_node[16u * pblk + static_cast<u32>(gl)] = static_cast<u16>(pbuf);  // the positions of the last block
+  if (pblk != 0xFFFFFFFFu) *pos_node_at(16u * pblk + static_cast<u32>(gl)) = static_cast<u16>(pbuf);  // the positions of the last block
   if (A.phase_cycles && gl == 0 && act) {
     sv::atomic_add(&A.phase_cycles[11], static_cast<unsigned long long>(steps));
     sv::atomic_add(&A.phase_cycles[12], static_cast<unsigned long long>(n_switch));
@@ -1946,7 +2039,7 @@ __host__ __device__ inline void poa4_phase_desc_onewave(const Poa4Args& A, const
       const i32 b = static_cast<i32>(rbv[u] >> 16);
       const u32 rho = r - r_lo;
       u32 ep[4] = {neg2, neg2, neg2, neg2};
-      u32 np = 0, lbw = 0;
+      u32 np = 0, lbw = 0, lbk7 = 0;
       auto edge = [&](u32 rbt, bool inside) {
         if (!inside) return;
         const u32 lbk = r - (rbt & 0xFFFFu);
@@ -1962,6 +2055,22 @@ __host__ __device__ inline void poa4_phase_desc_onewave(const Poa4Args& A, const
 #pragma unroll
           for (u32 i = 0; i < 4; ++i) ep[i] = i == idx ? ((ep[i] & keep) | put) : ep[i];
           if (np < 6) lbw |= lbk << (5 * np);
+          if (np == 7) lbk7 = lbk;
+        } else if (np < static_cast<u32>(K::kEdgesMax)) {
+          // a ninth .. fifteenth in-edge (only the loop over in-edges 8.. below gets here: one row in ~1 000 windows).  The row's
+          // overflow record takes in-edges 7..14 — the eighth moves out of the descriptor, so that code 0 of such a row is
+          // "horizontal" and nothing else — and the NW's rare path reads their cells of the column pair BEFORE the step's as well
+          // (it keeps no "cell left of this step's" for them), a step later than the descriptor's in-edges are read: one step less
+          // of the margin before the ring slot's next owner stores, i.e. in-edges of at most kRing - 2 ranks.
+          const u32 e = poa4_ring_byte(q, ((rho - lbk) % static_cast<u32>(K::kRing)) * static_cast<u32>(kRowW4));
+          u16* const o16 = reinterpret_cast<u16*>(sl.ovf + rho);
+          if (np == static_cast<u32>(K::kEdges)) {
+            sl.ovf[rho] = uint4{(ep[3] >> 16) | (neg_off << 16), neg2, neg2, neg2};
+            ep[3] = (ep[3] & 0xFFFFu) | (neg_off << 16);
+            if (lbk7 > static_cast<u32>(K::kRing - 2)) flag = 7;
+          }
+          o16[np - 7] = static_cast<u16>(e);
+          if (lbk > static_cast<u32>(K::kRing - 2)) flag = 7;
         }
         ++np;
       };
@@ -1972,7 +2081,7 @@ __host__ __device__ inline void poa4_phase_desc_onewave(const Poa4Args& A, const
         const u32 t = g.in_tail[static_cast<size_t>(v) * kPoaMaxIn + k];
         edge(sl.rbl[t], full || g.mark[t] != 0);
       }
-      if (np > static_cast<u32>(K::kEdges)) flag = 3;
+      if (np > static_cast<u32>(K::kEdgesMax)) flag = 3;
       if (ok[u]) {
         // match mask of the row's 32 columns against the layer
         u32 mm = 0;

@@ -221,3 +221,41 @@ def test_what_the_score_ring_holds_beside_a_band_does_not_matter(fill, monkeypat
     if fill == 3:
         assert 0 < polished < base_polished, (polished, base_polished)  # (the case that tells: both outcomes occur)
     print("ring fill", fill, "polished", polished, "of", base_polished)
+
+
+def _fan_in_window(rng, length=160, noise=0.0):
+    """A window whose backbone position P collects more than eight in-edges: deletions of 1..7 bases in front of P (tails
+    P - 2 .. P - 8), every letter and two pairs of letters inserted in front of it (six more tails) — each variant twice, the
+    second time in another order, so that later layers walk the in-edges of both groups the kernel keeps them in."""
+    P = int(rng.integers(40, length - 40))
+    truth = rng.integers(0, 4, size=length, dtype=np.uint8)
+    var = [np.concatenate([truth[:P - d], truth[P:]]) for d in range(1, 8)]
+    var += [np.concatenate([truth[:P], [c], truth[P:]]).astype(np.uint8) for c in range(4)]
+    var += [np.concatenate([truth[:P], [c, 3 - c], truth[P:]]).astype(np.uint8) for c in range(2)]
+    layers = [truth.copy()]
+    for _ in range(2):
+        for i in rng.permutation(len(var)):
+            layers.append(_mutate(rng, var[i], noise, noise / 2, noise / 2) if noise else var[i].copy())
+        for _ in range(3):
+            layers.append(_mutate(rng, truth, noise, noise / 2, noise / 2) if noise else truth.copy())
+    return dict(layers=layers)
+
+
+@pytest.mark.parametrize("fill", [0, 1], ids=["rings_start_low", "off_diagonal_scores"])
+def test_rows_of_nine_to_fifteen_in_edges(fill, monkeypatch):
+    """A graph row with more than eight in-edges used to send its window to the 64-column kernel (241 of the 244 windows a C4
+    round handed on: a second launch behind the persistent one).  Such a row now keeps in-edges 7..14 in an overflow record;
+    the NW's rare path folds them as a second group and a per-row mask tells the traceback which group a code counts in
+    (poa4.hip, P4::kEdgesMax).  The clean windows here have a row of >= 9 in-edges by construction (the kernel before this
+    change flagged them with reason 3) and must be polished, exactly; the noisy ones may still meet another limit."""
+    if fill:
+        monkeypatch.setenv("RVN_POA4_RING_FILL", str(fill))
+    rng = np.random.default_rng(0)
+    wins = [_fan_in_window(rng, noise=0.0 if i < 4 else 0.02) for i in range(8)]
+    cons, status = hip.poa_banded_emulate(wins, variant=VARIANT[0])
+    for i, (w, c, st) in enumerate(zip(wins, cons, status)):
+        if (int(st) & 0xFF) == 1:
+            assert np.array_equal(c, _oracle(w)), i
+        else:
+            assert (int(st) & 0xFF) == 8 and (fill or i >= 4) and ((int(st) >> 24) & 15) != 3, (i, hex(int(st)))
+    assert sum((int(st) & 0xFF) == 1 for st in status) >= (4 if fill else 7)

@@ -91,3 +91,36 @@ def test_the_nw_loop_waits_for_vector_memory_only_where_nothing_recent_is_outsta
             assert not re.match(r"\s*s_waitcnt\s+vmcnt", lines[j]), (j, lines[j])
             j -= 1
         assert first - j < 60, "the backpointer store is the last vector-memory instruction of the service point"
+        # nor a register reloaded from scratch memory anywhere in the service point (round 6, when the rare path of rows with
+        # more than eight in-edges went in: the slot address of the parking had gone to scratch, two reloads each behind a wait
+        # for everything outstanding, +35 % on the NW — same instruction counts in the step, nothing in the source shows it)
+        k, loads = j, 0
+        while k > 0 and loads < 2:
+            k -= 1
+            loads += "global_load_dwordx4" in lines[k]
+        seg = [l.strip() for l in lines[max(0, k - 120):first]]
+        assert not [l for l in seg if l.startswith("scratch_")], [l for l in seg if l.startswith("scratch_")]
+        assert len([l for l in seg if re.match(r"s_waitcnt\s+vmcnt", l)]) <= 2
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="no hipcc")
+def test_the_traceback_walk_reloads_nothing_from_scratch_memory(tmp_path):
+    """The traceback's walk and its change of round (descriptors and codes of the next 32 rows) around the marked step: no
+    register comes back from scratch memory there.  Round 6 measured what it costs when one does: the rare path of rows with
+    more than eight in-edges added one live value to the walk step, the compiler moved the descriptors' and the backpointer
+    stream's addresses to scratch memory, two reloads — each behind a wait for everything outstanding — per change of
+    round: traceback 104.8 -> 120.7 G wave cycles on tools/bench_poa.py (the addresses are now formed from ONE pointer and
+    scalar distances where they are used)."""
+    out = tmp_path / "poa4.s"
+    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-function", "--cuda-device-only", "-S",
+                        os.path.join(ROOT, "raven_amd", "csrc", "poa4.hip"), "-I", os.path.join(ROOT, "include"), "-o", str(out)],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = out.read_text().split("\n")
+    begins = [i for i, l in enumerate(lines) if "P4MARK tb_step_begin" in l]
+    ends = [i for i, l in enumerate(lines) if "P4MARK tb_step_end" in l]
+    assert len(begins) == 2 and len(ends) == 2  # (two instances of the kernel)
+    for b, e in zip(begins, ends):
+        lo, hi = min(b, e) - 400, max(b, e) + 400
+        seg = [l.strip() for l in lines[lo:hi]]
+        assert not [l for l in seg if l.startswith("scratch_")], [l for l in seg if l.startswith("scratch_")]
