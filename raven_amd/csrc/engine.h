@@ -103,7 +103,7 @@ struct PileState;
 struct EngineOptions {
   long long nw_budget_mb = 0;        // alignment-path stage: HBM for the stored band words (default: a quarter of the free memory, <= 64 GB)
   long long poa_rows_min_windows = -1;  // window-consensus stage: smallest batch that starts with the rows-on-lanes kernel (poa4.hip);
-                                        // a smaller one starts with the 64-column kernel (poa2.hip).  < 0: the default, 20 000
+                                        // a smaller one starts with the 64-column kernel (poa2.hip).  < 0: the default, kPoaRowsMinWindowsDefault = 8 192
   long long io_threads = 0;          // rvn_reads_load: inflate threads (default min(32, cores - 2))
   long long io_slab_mb = 0;          // ... page-locked slab size (default 8)
   long long io_ring = 0;             // ... slabs in flight (default 8)

@@ -1868,7 +1868,7 @@ int rvn_engine_set_option(rvn_engine* h, const char* name, int64_t value, int64_
   if (slot == &h->e.opt.io_ring && value == 1)
     return fail(RVN_EINVAL, "[raven_hip] rvn_engine_set_option: io_ring needs at least 2 slabs in flight (0 or -1: the default)");
   std::lock_guard<std::recursive_mutex> lk(h->e.mu);
-  if (previous) *previous = *slot < 0 ? (is_rows ? 20000 : -1) : *slot;  // (the value the default stands for where it has one)
+  if (previous) *previous = *slot < 0 ? (is_rows ? static_cast<int>(kPoaRowsMinWindowsDefault) : -1) : *slot;  // (the value the default stands for where it has one)
   *slot = value == -1 ? ((is_rows || slot == &h->e.opt.polish_sketch_cache_mb) ? -1 : 0) : value;
   return RVN_OK;
 }

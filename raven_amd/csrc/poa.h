@@ -106,7 +106,20 @@ struct PoaBatchDev {  // device-side batch description shared by both launchers
   u32* next;         // work counter (zeroed by the launcher)
   u32 probe;         // diagnostics (RVN_POA_BAND_PROBE): a polished window's status carries, << 16, how far its alignment
                      // paths strayed from the band's centre (0..31 columns) — what a narrower band would have to hold
+  u32* esc;          // poa4.hip only: queue of the windows its 32-column attempt hands on to the 64-column window function
+                     // INSIDE the same launch ([0] pushed, [1] taken, [2] went on to 128 columns, [4 + k] window index; set up by poa_run_dev), or null
+  u32 esc_cap;       // entries of the queue
+  u32 esc_wide;      // != 0: a window the 64 columns cannot hold goes through the 128-column function right there (set by poa_v4_launch)
 };
+// Smallest batch of windows that starts with poa4.hip's rows-on-lanes kernel (engine option poa_rows_min_windows; smaller ones
+// start with poa2.hip's one-window-per-wave kernel).  Round 5: 20 000 — what the first attempt handed on cost a second launch of
+// one window's latency, whatever the count.  Round 6: those windows are done inside the first launch (poa4_esc_*), and what
+// is left of the threshold is the first attempt's own latency on a nearly empty machine: C2's rounds of 10 000 windows 63 ms
+// against 67, 10 000 windows of tools/bench_poa.py (a tenth of them handed on: no band guides) 58.6 against 58.4, 5 000 of
+// those 47 against 33.
+constexpr u32 kPoaRowsMinWindowsDefault = 8192;
+constexpr u32 kPoaTried64 = 0x10000000u;   // status bit of a window the 64-column function already had inside poa4.hip's launch
+constexpr u32 kPoaTried128 = 0x20000000u;  // ... and the 128-column function behind it
 
 // Per-window scratch of the banded kernels (poa2.hip; poa4.hip adds its own arrays behind it): the spoa graph as SoA arrays, the backpointer matrix of
 // the current layer and the traceback's row table, carved out of one allocation per resident window.

@@ -664,10 +664,12 @@ void poa_run_dev(Engine& e, const PoaWindow* d_wins, const PoaLayer* d_lays, u32
   unsigned long long* d_phase = e.q_start.get<unsigned long long>(16);  // [0..7] phases + cells, [8] work counter, [10..15] kernel statistics
   RVN_HIP(hipMemsetAsync(d_phase, 0, 128, s));
   // heaviest windows first: cost ~ number of layers
-  u32* d_sk = e.poa_sched.get<u32>(4 * static_cast<size_t>(n_windows) + 8);
+  const u32 esc_cap = std::min<u32>(n_windows, 1u << 16);
+  u32* d_sk = e.poa_sched.get<u32>(4 * static_cast<size_t>(n_windows) + 8 + esc_cap + 4);
   u32* d_sk1 = d_sk + n_windows + 1;
   u32* d_sv = d_sk1 + n_windows + 1;
   u32* d_sv1 = d_sv + n_windows + 1;
+  u32* d_esc = d_sv1 + n_windows + 1;
   poa_sched_keys_kernel<<<div_up(n_windows, 256), 256, 0, s>>>(d_wins, n_windows, d_sk, d_sv);
   RVN_LAUNCH_CHECK();
   const int which = radix_sort_pairs_u32_u32(d_sk, d_sk1, d_sv, d_sv1, n_windows, 16, e.sort_tmp, e.scan_tmp, s,
@@ -691,13 +693,25 @@ void poa_run_dev(Engine& e, const PoaWindow* d_wins, const PoaLayer* d_lays, u32
   // chip with groups of four windows is faster in poa2's one-window-per-wave kernel (10 000 windows of a configs[2] round:
   // 108 ms in poa4's persistent kernel, 66 ms in poa2's; at 24 576 windows poa4 is ahead): below the threshold the default
   // mode goes straight to poa2 (engine option poa_rows_min_windows).
-  const u32 v4_min_windows = e.opt.poa_rows_min_windows >= 0 ? static_cast<u32>(e.opt.poa_rows_min_windows) : 20000u;
+  const u32 v4_min_windows = e.opt.poa_rows_min_windows >= 0 ? static_cast<u32>(e.opt.poa_rows_min_windows) : kPoaRowsMinWindowsDefault;
   const bool v4 = mode == 9 || (mode == 0 && n_windows >= v4_min_windows);
+  // the windows the 32-column attempt hands on go to the 64-column window function inside the same launch (poa4.hip,
+  // poa4_esc_*) — when the escalation chain is on at all (mode 9 is the first attempt alone)
+  u32 esc_head[4] = {};
+  u32& esc_pushed = esc_head[0];
+  if (v4 && mode == 0 && !knob("RVN_POA_NO_ESC")) {
+    RVN_HIP(hipMemsetAsync(d_esc, 0xFF, (static_cast<size_t>(esc_cap) + 4) * 4, s));
+    RVN_HIP(hipMemsetAsync(d_esc, 0, 16, s));
+    b.esc = d_esc;
+    b.esc_cap = esc_cap;
+  }
   if (mode == 1) poa_v1_launch(e, b);
   else if (v4) poa_v4_launch(e, b);
   else poa_v2_launch(e, b, mode == 3 ? 2 : (mode == 4 ? 4 : 1));
   RVN_HIP(hipMemcpyAsync(h_status.data(), d_status, static_cast<size_t>(n_windows) * 4, hipMemcpyDeviceToHost, s));
+  if (b.esc) RVN_HIP(hipMemcpyAsync(esc_head, d_esc, 16, hipMemcpyDeviceToHost, s));
   RVN_HIP(rvn_stream_sync(s));
+  esc_pushed = std::min(esc_pushed, esc_cap);
   if (b.probe) {  // diagnostics only: histogram of the paths' largest distance from the band centre, first attempt
     unsigned long long hist[33] = {};
     u32 polished = 0;
@@ -718,7 +732,7 @@ void poa_run_dev(Engine& e, const PoaWindow* d_wins, const PoaLayer* d_lays, u32
   }
   e.poa_fallback_windows = 0;
   e.poa_narrow_windows = 0;
-  e.poa_wide_windows = 0;
+  e.poa_wide_windows = esc_head[2];  // (windows that went through the 128-column function inside the first launch)
   e.poa_fullmatrix_windows = 0;
   if (mode == 0) {
     // escalate what the 64-column band could not do: band hits -> 128-column band -> 256 -> full matrix; windows
@@ -753,7 +767,7 @@ void poa_run_dev(Engine& e, const PoaWindow* d_wins, const PoaLayer* d_lays, u32
       std::vector<u32> narrow;
       u32 why[16] = {};
       for (u32 w = 0; w < n_windows; ++w)
-        if ((h_status[w] & 0xFF) == kPoaBandHit) {
+        if ((h_status[w] & 0xFF) == kPoaBandHit && !(h_status[w] & kPoaTried64)) {  // (not queued: no queue, or a full one)
           narrow.push_back(w);
           ++why[(h_status[w] >> 24) & 15u];
         }
@@ -761,13 +775,13 @@ void poa_run_dev(Engine& e, const PoaWindow* d_wins, const PoaLayer* d_lays, u32
         std::fprintf(stderr, "[raven_hip] poa: %zu of %u windows handed on by the first attempt: steps %u, in-degree %u, band step along an in-edge %u, last column outside the bands %u, walk near a band's edge %u, walk met a backpointer it cannot follow %u\n",
                      narrow.size(), n_windows, why[1], why[3], why[7], why[9], why[10], why[11]);
       if (!narrow.empty()) rerun(narrow, 64);
-      e.poa_narrow_windows = static_cast<u32>(narrow.size());
+      e.poa_narrow_windows = static_cast<u32>(narrow.size()) + esc_pushed;
     }
     for (u32 w = 0; w < n_windows; ++w) {
       const u32 st = h_status[w] & 0xFF;
       // 7 = a predecessor row had left the 64-column kernel's LDS ring: the wider kernels keep a score copy in HBM
       // for that case (one window in 400 000 at C4 — not worth a full-matrix launch)
-      if (st == kPoaBandHit || st == 7u) wide.push_back(w);
+      if (st == kPoaBandHit || st == 7u) ((h_status[w] & kPoaTried128) ? wider : wide).push_back(w);  // (128 columns: already tried inside the first launch)
       else if (st >= 2) fullm.push_back(w);
     }
     if (knob("RVN_POA_DEBUG")) {
@@ -777,7 +791,7 @@ void poa_run_dev(Engine& e, const PoaWindow* d_wins, const PoaLayer* d_lays, u32
     }
     if (!wide.empty()) {  // 128 columns
       rerun(wide, 2);
-      e.poa_wide_windows = static_cast<u32>(wide.size());
+      e.poa_wide_windows += static_cast<u32>(wide.size());
       for (u32 w : wide) {
         const u32 st = h_status[w] & 0xFF;
         if (st == kPoaBandHit) wider.push_back(w);

@@ -44,6 +44,7 @@
 #include <vector>
 
 #include "poa.h"
+#include "poa2_window.h"
 
 namespace rvn {
 
@@ -131,6 +132,11 @@ struct Poa4Args {
   unsigned long long* phase_cycles;
   const u32* sched;
   u32* next;
+  u32* esc;      // queue of the windows the 32-column attempt hands on, taken up by the waves of the SAME launch between two groups
+                 // (poa4_esc_*): [0] entries pushed, [1] entries taken, [2] windows that went on to 128 columns, [4 + k] window
+                 // index (0xFFFFFFFF until stored); null: none
+  u32 esc_cap;   // entries the queue holds (a window beyond them keeps its status for the host's escalation, as without a queue)
+  u32 esc_wide;  // != 0: the wave's four slots also hold the 128-column function's one
 };
 
 // Per-window scratch: poa2's graph arrays + the row descriptors of the current layer + its backpointer stream.
@@ -1631,7 +1637,7 @@ __host__ __device__ inline void poa4_consensus(Poa2Slot& g, const u32* rb, u32 n
 // ---- the phases of a window's layer -------------------------------------------------------------------------------------
 // What a window carries from phase to phase lives in an 80-byte record beside its graph (Poa4Win); a phase function reads
 // it, does its part for one window (graph side) or for the wave's four (alignment side) and lane 0 stores the new state.
-enum : u32 { kIdle = 0, kRunning = 1, kLayersDone = 2, kFinal = 3, kFailed = 4 };
+enum : u32 { kIdle = 0, kRunning = 1, kLayersDone = 2, kFinal = 3, kFailed = 4, kHandedOn = 5 };  // (kHandedOn: queued for the 64-column attempt of this launch — whoever runs it writes the window's result)
 
 struct Poa4Win {  // per window in flight (four per resident wave)
   u32 wi;        // window index
@@ -2266,6 +2272,7 @@ __host__ __device__ inline void poa4_phase_final(const Poa4Args& A, const Poa4Ct
     const u32 rec = poa4_my_record(C, wave, q2);
     if (rec == 0xFFFFFFFFu) continue;
     const Poa4Win w = C.st[rec];
+    if (w.phase == kHandedOn) continue;  // (result and status: the wave that takes the window off the queue)
     PoaWindow wq = A.windows[w.wi];
     u32 st = w.status;
     if (w.phase == kFailed || w.phase == kRunning) {  // (still running: the host stopped the rounds early — never)
@@ -2346,13 +2353,120 @@ struct alignas(16) Poa4LdsAll {
     Poa4LdsGraph g;
     Poa4LdsNw n;
     Poa4Lds f;
+    p2::Poa2Lds<1> w64;  // the 64-column window function (poa2_window.h), for a window taken off the queue
+    p2::Poa2Lds<2> w128; // and the 128-column one behind it
   } u;
 };
+static_assert(sizeof(Poa4LdsAll) <= 10240, "sixteen waves per CU");
+
+// ---- the windows the first attempt hands on, inside the same launch (round 6) ------------------------------------------------
+// 3 of 200 000 windows of a C4 round (244 before rows of 9..15 in-edges stayed here) need the 64-column band.  As a launch of
+// their own behind this one they cost one window's latency whatever their number — 30-38 ms per round, and the reason a batch
+// of a few thousand windows did not start here at all.  Now a wave whose window fails with a band hit puts its index into a queue
+// in HBM (agent-scope atomics: the waves sit on eight XCDs whose L2s do not see each other's lines) and goes on with the rest of
+// its group; every wave looks at the queue between two groups and runs what it finds — one window on the whole wave, poa2's window
+// function with its 64-column band, the wave's four scratch slots as that function's one — and again before it leaves.  A window
+// pushed after a wave looked is taken by any wave that comes by later, at the latest by the pusher itself: no wave waits for
+// another.  What the 64 columns cannot do either comes back with bit 28 set in its status (the host goes on with 128 columns).
+constexpr u32 kEscEmpty = 0xFFFFFFFFu;
+__host__ __device__ __forceinline__ u32 poa4_esc_load(const u32* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+  return *p;
+#endif
+}
+// wave-uniform; every lane takes part (lane 0 adds one, the others nothing: see poa4_persistent on why not `if (lane == 0)`)
+__host__ __device__ inline bool poa4_esc_push(const Poa4Args& A, u32 wi) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  u32 k = __hip_atomic_fetch_add(A.esc, sv::lane() == 0 ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  k = static_cast<u32>(sv::rfl(static_cast<int>(k)));
+  if (k >= A.esc_cap) return false;
+  if (sv::lane() == 0) __hip_atomic_store(A.esc + 4 + k, wi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return true;
+#else
+  (void)A;
+  (void)wi;
+  return false;
+#endif
+}
+// the next window of the queue (wave-uniform), kEscEmpty: none right now
+__host__ __device__ inline u32 poa4_esc_pop(const Poa4Args& A) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  for (;;) {
+    u32 p = static_cast<u32>(sv::rfl(static_cast<int>(poa4_esc_load(A.esc))));
+    p = p < A.esc_cap ? p : A.esc_cap;
+    const u32 t = static_cast<u32>(sv::rfl(static_cast<int>(poa4_esc_load(A.esc + 1))));
+    if (t >= p) return kEscEmpty;
+    // (all 64 lanes try the same exchange: one of them gets it, or a lane of another wave did)
+    u32 expected = t;
+    const bool won = __hip_atomic_compare_exchange_strong(A.esc + 1, &expected, t + 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!sv::any(won)) continue;
+    for (;;) {  // (the pusher stores the index right behind its ticket)
+      const u32 e = static_cast<u32>(sv::rfl(static_cast<int>(poa4_esc_load(A.esc + 4 + t))));
+      if (e != kEscEmpty) return e;
+      __builtin_amdgcn_s_sleep(8);
+    }
+  }
+#else
+  (void)A;
+  return kEscEmpty;
+#endif
+}
+// NOT inlined, and not handed the batch description either: as part of the persistent kernel's one function the 64-column code
+// changed the register allocation of the NW and of the traceback (the walk's descriptor pointer went to scratch memory again:
+// tests/test_poa4_isa.py), and a reference to the kernel's arguments passed to a real call moves ALL of them to the stack.  The
+// callee reads the arguments where the launch left them — the kernel-argument segment, scalar loads — and gets five registers.
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __attribute__((noinline)) void poa4_esc_window_far(p2::Poa2Lds<1>* Sp, u32 ka_lo, u32 ka_hi, u32 pw_, u32 wi_) {
+  P4_ASSUME_LDS(Sp);
+  typedef const __attribute__((address_space(4))) Poa4Args* ArgsPtr;
+  // (the address of the kernel-argument segment comes from the kernel: the intrinsic is null in a function that is not one)
+  const unsigned long long ka = (static_cast<unsigned long long>(static_cast<u32>(sv::rfl(static_cast<int>(ka_hi)))) << 32) |
+                                static_cast<u32>(sv::rfl(static_cast<int>(ka_lo)));
+  const Poa4Args A = *(ArgsPtr)ka;  // (the kernel's first parameter)
+  const u32 pw = static_cast<u32>(sv::rfl(static_cast<int>(pw_))), wi = static_cast<u32>(sv::rfl(static_cast<int>(wi_)));
+  const PoaWindow win = A.windows[wi];
+  Poa2Slot g = poa2_carve(A.scratch + static_cast<size_t>(pw) * P4::G * A.slot_bytes, A.nmax, A.lmax, 64);
+  u32 st = p2::poa2_window<1>(win, A.layers, A.src, g, A.nmax, A.lmax, A.m, A.n_, A.gp, A.trim, *Sp, A.out + win.out_off, A.out_len + wi,
+                              A.phase_cycles, 0u);
+  if ((st & 0xFFu) != 1u) st |= kPoaTried64;
+  if (A.esc_wide && ((st & 0xFFu) == kPoaBandHit || (st & 0xFFu) == 7u)) {
+    // the 128-column band right behind it (one window per C4 step: as a launch of its own, 29 ms); its LDS is the same 10 KB
+    Poa2Slot g2 = poa2_carve(A.scratch + static_cast<size_t>(pw) * P4::G * A.slot_bytes, A.nmax, A.lmax, 128);
+    sv::sync();
+    if (sv::lane() == 0) atomicAdd(A.esc + 2, 1u);
+    st = p2::poa2_window<2>(win, A.layers, A.src, g2, A.nmax, A.lmax, A.m, A.n_, A.gp, A.trim, *reinterpret_cast<p2::Poa2Lds<2>*>(Sp), A.out + win.out_off,
+                            A.out_len + wi, A.phase_cycles, 0u);
+    if ((st & 0xFFu) != 1u) st |= kPoaTried64 | kPoaTried128;
+  }
+  if (sv::lane() == 0) A.status[wi] = st;
+  sv::sync();
+}
+#endif
+__host__ __device__ __forceinline__ void poa4_esc_window(Poa4LdsAll& S, u32 pw, u32 wi) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const unsigned long long ka = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+  poa4_esc_window_far(&S.u.w64, static_cast<u32>(ka), static_cast<u32>(ka >> 32), pw, wi);
+#else
+  (void)S;
+  (void)pw;
+  (void)wi;
+#endif
+}
 template <class K, int UP, class SC>
 __host__ __device__ inline void poa4_persistent(const Poa4Args& A, const Poa4Ctx& C0, Poa4LdsAll& S, u32 pw) {
   const int lane = sv::lane();
   const u32 n_quads = (C0.count + poa4_group_windows(C0) - 1) / poa4_group_windows(C0);
   for (;;) {
+    if (A.esc) {  // windows handed on by anybody's first attempt since this wave last looked
+      for (;;) {
+        const u32 wi = poa4_esc_pop(A);
+        if (wi == kEscEmpty) break;
+        poa4_esc_window(S, pw, wi);
+        sv::phase_fence();
+      }
+    }
     // (every lane takes part in the fetch — lane 0 adds one, the others nothing: see nwpath.hip on why not `if (lane == 0)`)
     u32 quad = sv::atomic_add(A.next, lane == 0 ? 1u : 0u);
     quad = static_cast<u32>(sv::rfl(static_cast<int>(quad)));
@@ -2372,6 +2486,12 @@ __host__ __device__ inline void poa4_persistent(const Poa4Args& A, const Poa4Ctx
         if (rec != 0xFFFFFFFFu) {
           const Poa4Win& w = C.st[rec];
           any_layer = any_layer || (w.phase == kRunning && w.act != 0);
+          // a window that just failed with a band hit (or beyond a limit of this kernel that the 64-column function does not have):
+          // into the queue right away, the rest of the group goes on
+          if (A.esc && w.phase == kFailed && (w.status & 0xFFu) == kPoaBandHit) {
+            const bool queued = poa4_esc_push(A, w.wi);
+            if (queued && lane == 0) C.st[rec].phase = kHandedOn;
+          }
         }
       }
       sv::sync();  // (the records are read by every lane before the alignment side rewrites them)
@@ -2416,6 +2536,9 @@ Poa4Args args_of4(const PoaBatchDev& b, unsigned char* scratch, size_t slot_byte
   A.phase_cycles = b.phase_cycles;
   A.sched = b.sched;
   A.next = b.next;
+  A.esc = nullptr;
+  A.esc_cap = 0;
+  A.esc_wide = 0;
   return A;
 }
 
@@ -2445,7 +2568,12 @@ void poa_v4_launch(Engine& e, const PoaBatchDev& b) {
   const size_t slots = static_cast<size_t>(n_waves) * P4::G;
   unsigned char* d_scratch = e.poa2_scratch.get<unsigned char>(slots * (slot_bytes + sizeof(Poa4Win)) + 512);
   Poa4Win* d_st = reinterpret_cast<Poa4Win*>(d_scratch + slots * slot_bytes + 256);
-  const Poa4Args A = args_of4(b, d_scratch, slot_bytes);
+  Poa4Args A = args_of4(b, d_scratch, slot_bytes);
+  if (b.esc && poa2_slot_bytes(b.nmax, b.lmax, 64) <= P4::G * slot_bytes) {  // (the wave's four slots as the 64-column function's one)
+    A.esc = b.esc;
+    A.esc_cap = b.esc_cap;
+    A.esc_wide = poa2_slot_bytes(b.nmax, b.lmax, 128) <= P4::G * slot_bytes ? 1u : 0u;
+  }
   hipStream_t s = e.stream;
   RVN_HIP(hipMemsetAsync(b.next, 0, 4, s));
   const Poa4Ctx C{d_st, 0, b.n_windows, 0, gw};

@@ -164,6 +164,21 @@ def test_band_escalation_matches_full_matrix_kernel():
         assert _ed(c, r) <= 1, i                       # banded and full-matrix kernels agree (ties aside)
         o, _ = _oracle(w)
         assert _ed(c, o) <= 2, i
+    # the same chain behind the rows-on-lanes first attempt (what a batch of >= 8 192 windows gets): the windows its 32 columns
+    # cannot hold go through the 64-column and the 128-column window function INSIDE the first launch (poa4.hip,
+    # poa4_esc_*: a queue in HBM the persistent waves look at between two groups), the 256 columns are the host's launch
+    # as before — same functions, same bytes
+    assert eng.set_option("poa_rows_min_windows", 0) == 8192
+    try:
+        cons4, st4, _ = eng.poa_consensus_batch(wins)
+    finally:
+        eng.set_option("poa_rows_min_windows", -1)
+    assert np.all(st4 == 1)
+    assert eng.poa_narrow_windows() >= int(np.sum((st64 & 0xFF) == 8))   # (what 64 columns cannot hold, 32 cannot)
+    assert eng.poa_wide_windows() == int(np.sum((st64 & 0xFF) == 8))
+    assert eng.poa_fallback_windows() == int(np.sum((st128 & 0xFF) == 8))
+    for a, b in zip(cons4, cons):
+        assert np.array_equal(a, b)
 
 
 def test_kernel_modes_agree_on_noisy_windows():
@@ -205,12 +220,12 @@ def test_rows_on_lanes_kernel_equals_one_row_per_iteration_kernel():
             assert np.array_equal(a, b)
     assert both >= 340, both
     eng.poa_set_mode(0)
-    assert eng.set_option("poa_rows_min_windows", 0) == 20000  # (a batch this small would skip the rows-on-lanes kernel by default)
+    assert eng.set_option("poa_rows_min_windows", 0) == 8192  # (a batch this small would skip the rows-on-lanes kernel by default)
     try:
         c0, s0, _ = eng.poa_consensus_batch(wins)
     finally:
         assert eng.set_option("poa_rows_min_windows", -1) == 0  # (-1: the built-in default, whatever it is)
-        assert eng.set_option("poa_rows_min_windows", -1) == 20000
+        assert eng.set_option("poa_rows_min_windows", -1) == 8192
     assert np.array_equal(s0 & 0xFF, s2 & 0xFF)
     for a, b in zip(c0, c2):
         assert np.array_equal(a, b)

@@ -54,6 +54,8 @@ def main():
             k, v = kv.split("=")
             saved[k] = os.environ.get(k)
             os.environ[k] = v
+        # RVN_POA_MIN=n: the engine option poa_rows_min_windows for this run (0: the first attempt whatever the batch size)
+        eng.set_option("poa_rows_min_windows", int(os.environ.get("RVN_POA_MIN", "-1")))
         run_mode(eng, int(parts[0]), wins, truths, n_windows, n_check, cells, entry)
         for k, v in saved.items():
             if v is None:
