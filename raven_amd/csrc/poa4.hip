@@ -965,7 +965,7 @@ __host__ __device__ inline void poa4_traceback(const Poa4Args A, Poa4LdsTb& S, u
       const bool oob = idx >= static_cast<u32>(K::kBand);  // the path left the stored band
       bool isH = code == 0u;
       const u32 k = (~code) & 7u;
-      u32 ni = np ? i - ((d.z >> (5u * k)) & 31u) : 0u;  // (k >= 6: corrected below)
+      u32 ni = np ? i - ((d.z >> ((5u * k) & 31u)) & 31u) : 0u;  // (k >= 6: corrected below; the shift count as the GPU's shifter takes it)
       if (sv::any(in_round && np >= 7)) {  // rows of seven or eight in-edges (1 % of the windows have one)
         // code 0 in a row of eight in-edges is "horizontal" or "vertical through the eighth": the NW left the answer in the
         // row's v7 mask; in-edges 6 and 7: their ranks come from the graph
