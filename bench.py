@@ -234,6 +234,8 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--engine-option", action="append", default=[], metavar="NAME=VALUE",
                     help="rvn_engine_set_option before the run (tuning experiments; repeatable)")
+    ap.add_argument("--targets-through-host", action="store_true", help="round r + 1's targets = an upload of the sequences "
+                    "round r returned (round 5's way) instead of the consensus the library still holds in HBM")
     ap.add_argument("--no-quality", action="store_true", help="polish FASTA-like reads (no block qualities attached)")
     ap.add_argument("--replicas", action="store_true", help="N > 1: independent shard per GPU (weak scaling, no "
                     "collective) instead of one genome sharded across the ranks")
@@ -370,7 +372,14 @@ def main():
         cur = None
         n_windows = 0
         for rnd in range(args.polish_rounds):
-            targets = peng.upload_codes(drafts if cur is None else cur)
+            # round r + 1 polishes round r's output (raven::Polish, polish.cc:43-74): the library still has it in HBM
+            if cur is None or sharded_mode or args.targets_through_host:
+                targets = peng.upload_codes(drafts if cur is None else cur)
+            else:
+                try:
+                    targets = peng.polish_output_as_reads([len(c) for c in cur])
+                except (ValueError, hip.RavenHipError):  # (the engine gave its scratch back in between: the host's copy)
+                    targets = peng.upload_codes(cur)
             if sharded_mode:
                 cur, ratio = sharded.polish_round_sharded(peng, targets, preads, comm, targets.rs)
                 st = {"n_windows": int(((targets.rs.lengths.astype(np.int64) + 499) // 500).sum())}

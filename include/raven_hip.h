@@ -62,6 +62,13 @@ int rvn_reads_upload(rvn_engine* e, const uint64_t* packed, uint64_t n_words, co
  * (RavenLib/src/polish.cc:50-71 rebuilds biosoup::NucleicAcid objects from the polished strings). */
 int rvn_reads_upload_codes(rvn_engine* e, const uint8_t* codes, const uint64_t* offsets, const uint32_t* ids,
                            uint32_t n_reads, rvn_reads** out);
+
+/* The consensus of the engine's last complete rvn_polish_round (every window: not a _range call over a part) as a read
+ * set, straight from HBM.  Replaces, for rounds after the first, the upload of the targets raven::Polish hands the next
+ * racon::Polisher (RavenLib/src/polish.cc:43-74: the polished sequences of round r are round r + 1's targets); the result
+ * equals rvn_reads_upload_codes of the sequences the round returned, bit for bit.  RVN_EINVAL when no such consensus is
+ * resident (no round yet, a partial round, or the engine released its scratch since). */
+int rvn_polish_output_as_reads(rvn_engine* engine, rvn_reads** out);
 void rvn_reads_destroy(rvn_reads* r);
 /* The input path: raven::CreateParser(path) + Parse(-1) (RavenLib/src/io.cc:7-41, RavenExe/src/main.cc:258-299) straight
  * into HBM.  Format by extension exactly as io.cc (.fasta / .fa / .fastq / .fq, optionally .gz; anything else is

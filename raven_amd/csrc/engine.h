@@ -173,6 +173,10 @@ struct Engine {
   // polishing front end (polish.hip): best overlaps, window records, layer tables, consensus
   DevBuf pl_best, pl_best_t, pl_idmap, pl_recs, pl_keep, pl_win_cnt, pl_win_off, pl_win_fill, pl_win_meta, pl_first_window,
       pl_keys, pl_lays_tmp, pl_lays, pl_wins, pl_out, pl_len, pl_status, pl_ok, pl_cons_off, pl_final, pl_qual_off, pl_misc;
+  // the last COMPLETE polishing round's stitched consensus is still in pl_final: byte offsets of the targets' sequences there
+  // (rvn_polish_output_as_reads: the next round's targets without the way over the host)
+  std::vector<u64> pl_last_off;
+  bool pl_last_valid = false;
   std::vector<u32> polish_target_reads;  // reads used per target in the last polishing round
   // best-overlap table for the NEXT polishing round (rvn_polish_set_best; consumed by that round)
   std::vector<Overlap> polish_given_best;

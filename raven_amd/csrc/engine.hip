@@ -351,6 +351,7 @@ void engine_release_scratch(Engine& e) {
       &e.pl_win_meta, &e.pl_first_window, &e.pl_keys, &e.pl_lays_tmp, &e.pl_lays, &e.pl_wins, &e.pl_out, &e.pl_len,
       &e.pl_status, &e.pl_ok, &e.pl_cons_off, &e.pl_final, &e.pl_qual_off, &e.pl_misc, &e.anc_slot_off, &e.anc_slot_cnt};
   for (DevBuf* b : bufs) b->release();
+  e.pl_last_valid = false;
   e.polish_sketches.clear();  // (the reads' sketch kept between polishing rounds: derived data, recomputed when needed)
   e.polish_sketch_owner = 0;
   e.pl_tval.release();
@@ -525,59 +526,86 @@ int rvn_reads_upload(rvn_engine* h, const uint64_t* packed, uint64_t n_words, co
 
 void rvn_reads_destroy(rvn_reads* r) { delete r; }
 
+namespace {
+// a read set from one-byte codes that are already in HBM (d_codes + boff[i] .. + boff[i + 1]: read i), packed there
+int reads_from_device_codes(Engine& e, const u8* d_codes, const std::vector<u64>& boff, const uint32_t* ids, uint32_t n, rvn_reads** out) {
+  std::vector<u64> woff(static_cast<size_t>(n) + 1, 0);
+  std::vector<u32> lens(n);
+  for (u32 i = 0; i < n; ++i) {
+    if (boff[i + 1] < boff[i] || boff[i + 1] - boff[i] > 0xFFFFFFFFULL)
+      return fail(RVN_EINVAL, "[raven_hip] rvn_reads_upload_codes: bad offsets");
+    lens[i] = static_cast<u32>(boff[i + 1] - boff[i]);
+    woff[i + 1] = woff[i] + (static_cast<u64>(lens[i]) + 31) / 32;
+  }
+  const u64 n_words = woff[n], n_codes = n ? boff[n] - boff[0] : 0;
+  u64* d_boff = e.tmp_b.get<u64>(static_cast<size_t>(n) + 1);
+  u64* d_woff = e.tmp_c.get<u64>(static_cast<size_t>(n) + 1);
+  RVN_HIP(hipMemcpy(d_boff, boff.data(), boff.size() * 8, hipMemcpyHostToDevice));
+  RVN_HIP(hipMemcpy(d_woff, woff.data(), woff.size() * 8, hipMemcpyHostToDevice));
+  std::unique_ptr<rvn_reads> rr(new rvn_reads());
+  ReadsDev& r = rr->r;
+  u64* d_packed = r.packed.get<u64>(n_words + 2);
+  pack_codes_on_device(e, d_codes, d_boff, d_woff, n, n_words, d_packed);
+  RVN_HIP(hipMemsetAsync(d_packed + n_words, 0, 16, e.stream));
+  RVN_HIP(rvn_stream_sync(e.stream));
+  r.n = n;
+  r.h_word_off = woff;
+  r.h_len = lens;
+  r.h_id.resize(n);
+  r.ids_are_indices = true;
+  r.total_bases = n_codes;
+  for (u32 i = 0; i < n; ++i) {
+    r.h_id[i] = ids ? ids[i] : i;
+    if (r.h_id[i] != i || i >= kMaxReadId) r.ids_are_indices = false;
+    if (r.h_id[i] >= kMaxReadId) return fail(RVN_EINVAL, "[raven_hip] read ids must be below 2^30");  // (bit 62 of an origin word is kForeignFlag: ADVICE r05)
+  }
+  r.n_words = n_words;
+  u64* d_wo = r.word_off.get<u64>(static_cast<size_t>(n) + 1);
+  RVN_HIP(hipMemcpy(d_wo, r.h_word_off.data(), (static_cast<size_t>(n) + 1) * 8, hipMemcpyHostToDevice));
+  u32* d_len = r.len.get<u32>(static_cast<size_t>(n) + 1);
+  u32* d_id = r.id.get<u32>(static_cast<size_t>(n) + 1);
+  if (n) {
+    RVN_HIP(hipMemcpy(d_len, r.h_len.data(), static_cast<size_t>(n) * 4, hipMemcpyHostToDevice));
+    RVN_HIP(hipMemcpy(d_id, r.h_id.data(), static_cast<size_t>(n) * 4, hipMemcpyHostToDevice));
+  }
+  reads_build_tiles(e, r);
+  *out = rr.release();
+  return RVN_OK;
+}
+}  // namespace
+
 int rvn_reads_upload_codes(rvn_engine* h, const uint8_t* codes, const uint64_t* offsets, const uint32_t* ids, uint32_t n,
                            rvn_reads** out) {
   return guarded(h ? &h->e : nullptr, [&]() -> int {
     if (!h || !out || (n && (!codes || !offsets))) return fail(RVN_EINVAL, "[raven_hip] rvn_reads_upload_codes: NULL argument");
     Engine& e = h->e;
     RVN_HIP(hipSetDevice(e.device));
-    std::vector<u64> woff(static_cast<size_t>(n) + 1, 0);
-    std::vector<u32> lens(n);
-    for (u32 i = 0; i < n; ++i) {
+    for (u32 i = 0; i < n; ++i)
       if (offsets[i + 1] < offsets[i] || offsets[i + 1] - offsets[i] > 0xFFFFFFFFULL)
         return fail(RVN_EINVAL, "[raven_hip] rvn_reads_upload_codes: bad offsets");
-      lens[i] = static_cast<u32>(offsets[i + 1] - offsets[i]);
-      woff[i + 1] = woff[i] + (static_cast<u64>(lens[i]) + 31) / 32;
-    }
-    const u64 n_words = woff[n], n_codes = n ? offsets[n] - offsets[0] : 0;
+    const u64 n_codes = n ? offsets[n] - offsets[0] : 0;
     // bases to HBM as bytes, packed there (one thread per word)
     u8* d_codes = e.tmp_a.get<u8>(n_codes + 16);
-    u64* d_boff = e.tmp_b.get<u64>(static_cast<size_t>(n) + 1);
-    u64* d_woff = e.tmp_c.get<u64>(static_cast<size_t>(n) + 1);
     if (n_codes) RVN_HIP(hipMemcpy(d_codes, codes + (n ? offsets[0] : 0), n_codes, hipMemcpyHostToDevice));
-    std::vector<u64> boff(static_cast<size_t>(n) + 1);
-    for (u32 i = 0; i <= n; ++i) boff[i] = offsets[i] - offsets[0];
-    RVN_HIP(hipMemcpy(d_boff, boff.data(), boff.size() * 8, hipMemcpyHostToDevice));
-    RVN_HIP(hipMemcpy(d_woff, woff.data(), woff.size() * 8, hipMemcpyHostToDevice));
-    std::unique_ptr<rvn_reads> rr(new rvn_reads());
-    ReadsDev& r = rr->r;
-    u64* d_packed = r.packed.get<u64>(n_words + 2);
-    pack_codes_on_device(e, d_codes, d_boff, d_woff, n, n_words, d_packed);
-    RVN_HIP(hipMemsetAsync(d_packed + n_words, 0, 16, e.stream));
-    RVN_HIP(rvn_stream_sync(e.stream));
-    r.n = n;
-    r.h_word_off = woff;
-    r.h_len = lens;
-    r.h_id.resize(n);
-    r.ids_are_indices = true;
-    r.total_bases = n_codes;
-    for (u32 i = 0; i < n; ++i) {
-      r.h_id[i] = ids ? ids[i] : i;
-      if (r.h_id[i] != i || i >= kMaxReadId) r.ids_are_indices = false;
-      if (r.h_id[i] >= kMaxReadId) return fail(RVN_EINVAL, "[raven_hip] read ids must be below 2^30");  // (bit 62 of an origin word is kForeignFlag: ADVICE r05)
-    }
-    r.n_words = n_words;
-    u64* d_wo = r.word_off.get<u64>(static_cast<size_t>(n) + 1);
-    RVN_HIP(hipMemcpy(d_wo, r.h_word_off.data(), (static_cast<size_t>(n) + 1) * 8, hipMemcpyHostToDevice));
-    u32* d_len = r.len.get<u32>(static_cast<size_t>(n) + 1);
-    u32* d_id = r.id.get<u32>(static_cast<size_t>(n) + 1);
-    if (n) {
-      RVN_HIP(hipMemcpy(d_len, r.h_len.data(), static_cast<size_t>(n) * 4, hipMemcpyHostToDevice));
-      RVN_HIP(hipMemcpy(d_id, r.h_id.data(), static_cast<size_t>(n) * 4, hipMemcpyHostToDevice));
-    }
-    reads_build_tiles(e, r);
-    *out = rr.release();
-    return RVN_OK;
+    std::vector<u64> boff(static_cast<size_t>(n) + 1, 0);
+    for (u32 i = 0; i <= n && n; ++i) boff[i] = offsets[i] - offsets[0];
+    return reads_from_device_codes(e, d_codes, boff, ids, n, out);
+  });
+}
+
+// The consensus of the engine's last COMPLETE polishing round as a read set, straight from HBM: what raven::Polish hands the
+// next round's racon::Polisher as targets (RavenLib/src/polish.cc:43-74: the polished sequences of round r are the targets of
+// round r + 1).  The host has them too (rvn_polish_round returned them); this spares their way back — at C4 100 MB through
+// the host's page cache and PCIe per round, ~40 ms with the GPU idle (profiles/r06_gaps.txt).  Bit-identical to
+// rvn_reads_upload_codes of the sequences the round returned (tests/test_gpu_polish.py).
+int rvn_polish_output_as_reads(rvn_engine* h, rvn_reads** out) {
+  return guarded(h ? &h->e : nullptr, [&]() -> int {
+    if (!h || !out) return fail(RVN_EINVAL, "[raven_hip] rvn_polish_output_as_reads: NULL argument");
+    Engine& e = h->e;
+    if (!e.pl_last_valid) return fail(RVN_EINVAL, "[raven_hip] rvn_polish_output_as_reads: no complete polishing round's consensus is resident");
+    RVN_HIP(hipSetDevice(e.device));
+    const u32 n = static_cast<u32>(e.pl_last_off.size() - 1);
+    return reads_from_device_codes(e, e.pl_final.ptr ? reinterpret_cast<const u8*>(e.pl_final.ptr) : nullptr, e.pl_last_off, nullptr, n, out);
   });
 }
 

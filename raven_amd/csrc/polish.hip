@@ -685,6 +685,18 @@ void polish_round(Engine& e, ReadsDev& T, ReadsDev& R, const u8* h_quals, const 
       for (size_t t = t0; t < t1; ++t)
         if (span[t].second > span[t].first) polished[t].assign(h_final + cons_off[span[t].first], h_final + cons_off[span[t].second]);
     });
+    // (a round over every window leaves the targets' consensus, in target order, in pl_final: rvn_polish_output_as_reads)
+    e.pl_last_valid = false;
+    if (W0 == 0 && W1 == n_windows_all && T.n > 0) {
+      e.pl_last_off.assign(static_cast<size_t>(T.n) + 1, 0);
+      bool all = true;
+      for (u32 t = 0; t < T.n; ++t) {
+        all = all && span[t].second > span[t].first;  // (a target without a window in the range has no consensus here)
+        e.pl_last_off[t] = all ? cons_off[span[t].first] : 0;
+      }
+      e.pl_last_off[T.n] = total;
+      e.pl_last_valid = all && T.n > 0;
+    }
     for (u32 t = 0; t < T.n; ++t) {
       ratio[t] = t_windows[t] ? static_cast<double>(t_polished[t]) / t_windows[t] : 0.0;
       stats.n_polished_windows += t_polished[t];

@@ -53,6 +53,7 @@ SYMBOLS = [
     "rvn_find_overlaps_and_repetitive_regions", "rvn_pass2_num_overlaps", "rvn_pass2_kmer_cells", "rvn_pass2_fetch",
     "rvn_pass2_destroy", "rvn_engine_release_scratch", "rvn_filter_overlaps_by_identity", "rvn_pass1_find_chimeric_regions",
     "rvn_reads_load", "rvn_reads_name", "rvn_reads_info", "rvn_reads_fetch", "rvn_engine_set_option", "rvn_overlap_update_and_type", "rvn_group_polish_round_q", "rvn_group_peer_access", "rvn_shard_sketch_range", "rvn_group_find_overlaps_and_create_piles_batched",
+    "rvn_polish_output_as_reads",
 ]
 
 # TEST INFRASTRUCTURE: what include/raven_hip_test.h declares on top (libraven_hip_test.so only)
@@ -151,6 +152,7 @@ def _declare(L):
     L.rvn_pile_add_kmers_batch.argtypes = [vp, vp, u32, u32, vp, vp, vp, vp]
     L.rvn_reads_attach_quality.argtypes = [vp, vp, vp, vp, i32]
     L.rvn_reads_upload_codes.argtypes = [vp, vp, vp, vp, u32, pp]
+    L.rvn_polish_output_as_reads.argtypes = [vp, pp]
     L.rvn_find_overlaps_and_repetitive_regions.argtypes = [vp, vp, vp, vp, vp, dbl, u32, dbl, u64, pp]
     L.rvn_pass2_num_overlaps.argtypes = [vp]
     L.rvn_pass2_num_overlaps.restype = u64
@@ -253,10 +255,13 @@ class CodeSet:
 
 
 class Reads:
-    def __init__(self, engine: "Engine", rs, codes=None):
+    def __init__(self, engine: "Engine", rs, codes=None, handle=None):
         self.rs = rs
         self.engine = engine
         h = C.c_void_p()
+        if handle is not None:  # a read set the library made on the device (Engine.polish_output_as_reads)
+            self._h = handle
+            return
         if codes is not None:  # one-byte codes, packed on the device
             off = np.zeros(rs.n + 1, dtype=np.uint64)
             np.cumsum(rs.lengths.astype(np.uint64), out=off[1:])
@@ -495,6 +500,14 @@ class Engine:
         lens = [int(len(c)) for c in code_arrays]
         flat = np.concatenate([np.asarray(c, dtype=np.uint8) for c in code_arrays]) if lens else np.zeros(0, np.uint8)
         return Reads(self, CodeSet(lens), codes=flat)
+
+    def polish_output_as_reads(self, lengths) -> Reads:
+        """The consensus of this engine's last complete polish_round as the next round's target set, straight from HBM
+        (rvn_polish_output_as_reads): the same read set upload_codes(<what the round returned>) gives, without the 100 MB
+        of a C4 round going through host memory and PCIe again.  lengths = the lengths of the sequences the round returned."""
+        h = C.c_void_p()
+        _check(lib().rvn_polish_output_as_reads(self._h, C.byref(h)))
+        return Reads(self, CodeSet([int(x) for x in lengths]), handle=h)
 
     # -- ram::MinimizerEngine interface -----------------------------------------------------
     def minimize(self, reads: Reads, first=0, last=None, minhash=False):
@@ -821,7 +834,7 @@ class Engine:
         nt = targets.n
         ooff = np.zeros(nt + 1, dtype=np.uint64)
         np.cumsum(2 * targets.rs.lengths.astype(np.uint64) + 1024, out=ooff[1:])
-        out = np.zeros(int(ooff[-1]) + 1, dtype=np.uint8)
+        out = np.empty(int(ooff[-1]) + 1, dtype=np.uint8)  # (the library writes every byte it reports)
         out_len = np.zeros(nt, dtype=np.uint32)
         ratio = np.zeros(nt, dtype=np.float64)
         stats = np.zeros(16, dtype=np.uint64)
@@ -832,7 +845,8 @@ class Engine:
             qa = np.concatenate([np.asarray(x, dtype=np.uint8) for x in quals])
         _check(lib().rvn_polish_round(self._h, targets._h, reads._h, _p(qa), _p(qo), float(q), float(err), w, int(trim),
                                       m, n, g, _p(out), _p(ooff), _p(out_len), _p(ratio), _p(stats)))
-        cons = [out[int(ooff[i]): int(ooff[i]) + int(out_len[i])].copy() for i in range(nt)]
+        # (views of this call's own buffer — never written again —, not copies: 100 MB at C4)
+        cons = [out[int(ooff[i]): int(ooff[i]) + int(out_len[i])] for i in range(nt)]
         keys = ("n_overlaps", "n_reads_used", "n_layers", "n_windows", "n_polished_windows", "n_failed_windows")
         st = {k2: int(v) for k2, v in zip(keys, stats[:6])}
         for i, k2 in enumerate(("poa_ms", "map_ms", "host_ms", "total_ms")):

@@ -201,3 +201,30 @@ def test_round_is_the_same_with_the_kept_sketch_and_with_the_sorted_mapping():
         assert np.array_equal(ref[0], other[0]) and np.array_equal(ref[2], other[2])
         for a, b in zip(ref[1] + ref[3], other[1] + other[3]):
             assert np.array_equal(a, b)
+
+
+@pytest.mark.gpu
+def test_next_rounds_targets_straight_from_the_device_equal_an_upload_of_what_the_round_returned():
+    """raven::Polish hands round r's polished sequences to round r + 1 as targets (polish.cc:43-74).  The library still
+    holds them in HBM after the round: rvn_polish_output_as_reads makes the target set from there, and it is the read set
+    an upload of the returned sequences gives — packed words, lengths, and the second round's layers and consensus."""
+    truths, drafts, targets, reads, quals = pu2.make_case(genome_len=40_000, coverage=20, seed=71, n_targets=3)
+    eng = hip.Engine(15, 5)
+    rd = eng.upload(reads)
+    td = eng.upload(targets)
+    c1, _, _ = eng.polish_round(td, rd)
+    via_host = eng.upload_codes(c1)
+    resident = eng.polish_output_as_reads([len(c) for c in c1])
+    a, b = via_host.fetch(), resident.fetch()
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    c2h, _, _ = eng.polish_round(via_host, rd)
+    lh = eng.polish_layers()
+    # (the resident set was made BEFORE that round: a read set of its own, not a view of the engine's buffer)
+    c2r, _, _ = eng.polish_round(resident, rd)
+    assert np.array_equal(lh, eng.polish_layers())
+    assert len(c2h) == len(c2r) and all(np.array_equal(x, y) for x, y in zip(c2h, c2r))
+    # a round over a part of the windows leaves no complete consensus behind: the call says so instead of returning one
+    n_win = int(sum((len(c) + 499) // 500 for c in c2r))
+    eng.polish_round_range(resident, rd, 0, max(1, n_win // 2))
+    with pytest.raises((ValueError, hip.RavenHipError)):
+        eng.polish_output_as_reads([len(c) for c in c2r])
