@@ -22,6 +22,7 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "ram/minimizer_engine.hpp"
@@ -57,8 +58,22 @@ class Polisher {
   Sequences Polish(const Sequences& targets, const Sequences& sequences, bool drop_unpolished) {
     Sequences dst;
     if (targets.empty()) return dst;
+    // raven::Polish hands round r's result to round r + 1 as targets (polish.cc:50-52: `unitigs.swap(polished)`), rotated
+    // in place where a unitig is circular (polish.cc:60-65).  The engine still holds the last round's consensus in HBM: when
+    // the targets ARE that result — same number, lengths and 2-bit words of every sequence — the target set is made from
+    // there (rvn_polish_output_as_reads) instead of packing and uploading it again; anything else takes the upload.
     ram::detail::ReadsHandle t;
-    t.Upload(engine_, targets.begin(), targets.end());
+    bool resident = last_out_.size() == targets.size() && !last_out_.empty();
+    for (std::size_t i = 0; resident && i < targets.size(); ++i)
+      resident = last_out_[i] == Fingerprint(*targets[i]);
+    if (!resident || rvn_polish_output_as_reads(engine_, &t.h) != 0) {
+      rvn_reads_destroy(t.h);  // (nothing resident any more — the engine gave its scratch back —: the host's copy)
+      t.h = nullptr;
+      t.Upload(engine_, targets.begin(), targets.end());
+    } else {
+      ++resident_rounds_;
+    }
+    last_out_.clear();
     // raven::Polish calls Polish() once per round with the SAME read set (polish.cc:50-51): upload it (and expand
     // its qualities) only when the container changes
     // (same storage, same size AND same content fingerprint: a caller may refill the vector in place)
@@ -106,10 +121,14 @@ class Polisher {
       const std::string& name = targets[i]->name;
       dst.emplace_back(new biosoup::NucleicAcid(name.substr(0, name.find(' ')) + tags, data));
     }
+    if (dst.size() == n)  // (every target came back: what the engine holds is this result, sequence for sequence)
+      for (const auto& it : dst) last_out_.push_back(Fingerprint(*it));
     return dst;
   }
 
   rvn_engine* handle() const { return engine_; }
+  // rounds whose targets were taken from the consensus the engine held in HBM (diagnostics, tests)
+  std::size_t resident_rounds() const { return resident_rounds_; }
   // forget the device copy of the read set (the next Polish() uploads again)
   void Invalidate() {
     rvn_reads_destroy(reads_.h);
@@ -117,6 +136,15 @@ class Polisher {
   }
 
  private:
+  // length and every 2-bit word of one sequence (FNV-1a)
+  static std::pair<std::uint32_t, std::uint64_t> Fingerprint(const biosoup::NucleicAcid& s) {
+    std::uint64_t h = 1469598103934665603ULL;
+    for (std::uint64_t w : s.deflated_data) {
+      h ^= w;
+      h *= 1099511628211ULL;
+    }
+    return {s.inflated_len, h};
+  }
   // cheap content fingerprint of a read set: ids, lengths and one data word of every read (FNV-1a)
   static std::uint64_t Fingerprint(const Sequences& sequences) {
     std::uint64_t h = 1469598103934665603ULL;
@@ -149,6 +177,9 @@ class Polisher {
   std::size_t reads_n_ = 0;
   std::uint64_t reads_fp_ = 0;
   bool has_q_ = false;
+  // (length, content hash) of every sequence the last Polish() returned — empty when it dropped any
+  std::vector<std::pair<std::uint32_t, std::uint64_t>> last_out_;
+  std::size_t resident_rounds_ = 0;
 };
 
 }  // namespace racon

@@ -49,6 +49,28 @@ int main(int argc, char** argv) {
       for (std::uint32_t i = 0; i < it->inflated_len; ++i) data[i] = "ACGT"[(it->deflated_data[i >> 5] >> ((i << 1) & 63)) & 3];
       std::printf("P %ld %.6f %s\nS %s\n", id, ratio, it->name.c_str(), data.c_str());
     }
+    // a second round the way polish.cc:50-52 runs it: the first round's result as targets (the facade recognises it and
+    // takes the consensus the engine still holds in HBM); then a third one whose first target was rotated in place like a
+    // circular unitig (polish.cc:60-65): not the engine's copy any more, the facade uploads it
+    auto second = polisher->Polish(polished, reads, false);
+    for (const auto& it : second) {
+      std::string data(it->inflated_len, 'A');
+      for (std::uint32_t i = 0; i < it->inflated_len; ++i) data[i] = "ACGT"[(it->deflated_data[i >> 5] >> ((i << 1) & 63)) & 3];
+      std::printf("P2 %s\nS2 %s\n", it->name.c_str(), data.c_str());
+    }
+    {
+      auto s = second[0]->InflateData();
+      const std::size_t b = static_cast<std::size_t>(0.42 * s.size());
+      s = s.substr(b) + s.substr(0, b);
+      second[0]->deflated_data = biosoup::NucleicAcid{"", s}.deflated_data;
+      auto third = polisher->Polish(second, reads, false);
+      for (const auto& it : third) {
+        std::string data(it->inflated_len, 'A');
+        for (std::uint32_t i = 0; i < it->inflated_len; ++i) data[i] = "ACGT"[(it->deflated_data[i >> 5] >> ((i << 1) & 63)) & 3];
+        std::printf("S3 %s\n", data.c_str());
+      }
+    }
+    std::printf("resident_rounds %zu\n", polisher->resident_rounds());
     auto kept = polisher->Polish(targets, std::vector<std::unique_ptr<biosoup::NucleicAcid>>{}, true);
     std::printf("dropped_without_reads %zu\n", targets.size() - kept.size());
   } catch (const std::exception& ex) {

@@ -108,6 +108,17 @@ def test_polisher_facade_matches_c_abi(tmp_path, q):
         assert S[t].encode() == bytes(np.frombuffer(b"ACGT", dtype=np.uint8)[cons[t]])
     used = [int(p[3].split("RC:i:")[1].split()[0]) for p in P]
     assert sum(used) == st["n_reads_used"]
+    # second round = polish.cc:50-52 (the result of the first as targets: the facade takes the engine's resident consensus),
+    # third round with the first target rotated in place like a circular unitig (polish.cc:60-65: the facade uploads)
+    rd = eng.upload(reads)
+    c2, _, _ = eng.polish_round(eng.upload_codes(cons), rd, quals=quals, q=10.0 if q else 0.0)
+    S2 = [ln[3:] for ln in lines if ln.startswith("S2 ")]
+    assert len(S2) == 2 and all(S2[t].encode() == bytes(np.frombuffer(b"ACGT", dtype=np.uint8)[c2[t]]) for t in range(2))
+    b = int(0.42 * len(c2[0]))
+    c3, _, _ = eng.polish_round(eng.upload_codes([np.concatenate([c2[0][b:], c2[0][:b]]), c2[1]]), rd, quals=quals, q=10.0 if q else 0.0)
+    assert "resident_rounds 1" in lines  # (the second round took the engine's copy, the third — rotated — did not)
+    S3 = [ln[3:] for ln in lines if ln.startswith("S3 ")]
+    assert len(S3) == 2 and all(S3[t].encode() == bytes(np.frombuffer(b"ACGT", dtype=np.uint8)[c3[t]]) for t in range(2))
 
 
 def test_edlib_dropin_compiles_and_fails_loudly_without_gpu(tmp_path):
