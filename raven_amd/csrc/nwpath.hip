@@ -38,6 +38,10 @@ namespace {
 // where one block per lane cannot hold the band: variants (2, 8) ... (4, 32) — fewer instructions per block step on
 // paper — were measured and lost (C4 sweep 178 ms with R = 1 wherever possible, 187 ms allowing R = 2, 225 ms allowing
 // R = 4: more registers = fewer waves, a coarser band, costlier ring events).
+constexpr int kNwGroupLanes = 16;           // lanes per alignment of the group walk (four alignments per wave)
+constexpr u32 kNwGroupWalkMaxJobs = 8192;  // a walk launch of at most this many alignments takes the group walk (two rounds of the
+                                           // machine's 4 096 resident groups: beyond that a group's ~3x shorter latency per column loses
+                                           // to the lane walk's sixteen times as many alignments in flight — tools/walk_ab.sh)
 constexpr u32 kLevels = 8;
 const u32 kRs[kLevels] = {1, 1, 1, 1, 1, 2, 4, 8};
 const u32 kGs[kLevels] = {4, 8, 16, 32, 64, 64, 64, 64};
@@ -161,6 +165,42 @@ __global__ __launch_bounds__(64) void nw_trace_kernel(const NwJob* __restrict__ 
   u64* g_pv = scratch + static_cast<u64>(blockIdx.x) * (2 * kNwStripCols * 64);
   const NwStripMem<64> mem{STRIP_LDS ? s_pv : g_pv, STRIP_LDS ? s_mv : g_pv + kNwStripCols * 64, static_cast<int>(threadIdx.x)};
   status[ji] = static_cast<u32>(nw_trace_job<64>(J, geo, t_words, r_words, hs + J.hs, ck + J.ckpt, mem, result[ji], w, recs));
+}
+
+// The group walk (nwtrace.h: NwGroupWalk): GL lanes per alignment, 64 / GL alignments per wave; strips in the same LDS
+// array as nw_trace_kernel's (column = lane), the heads beside it: 36.9 KB per wave, four waves per CU.
+template <int GL>
+__global__ __launch_bounds__(64) void nw_trace_group_kernel(const NwJob* __restrict__ jobs, const u32* __restrict__ idx, u32 n_idx,
+                                                            const u64* __restrict__ t_words, const u64* __restrict__ r_words,
+                                                            const u32* __restrict__ hs, const NwPm* __restrict__ ck,
+                                                            const u32* __restrict__ result, u32* __restrict__ status, u32 w,
+                                                            NwWindowRec* __restrict__ recs) {
+  constexpr int NG = 64 / GL;
+  __shared__ u64 s_pv[kNwStripCols * 64];
+  __shared__ u64 s_mv[kNwStripCols * 64];
+  __shared__ NwStripHead s_heads[64];
+  __builtin_amdgcn_s_setprio(3);
+  const int lane = static_cast<int>(threadIdx.x), grp = lane / GL, t = lane % GL;
+  const u32 q = blockIdx.x * NG + static_cast<u32>(grp);
+  if (q >= n_idx) return;
+  const u32 ji = idx[q];
+  if (status[ji] != 0) return;
+  const NwJob J = jobs[ji];
+  const NwGeo geo = nw_geo(J.n, J.m, J.k, J.R);
+  NwGroupWalk<64, GL> G;
+  G.init(J, t_words, r_words, NwStripMem<64>{s_pv, s_mv, grp * GL}, s_heads + grp * GL, result[ji], w, recs);
+  int bad = 0;
+  while (!G.done()) {
+    G.fill(J, geo, hs + J.hs, ck + J.ckpt, t);
+    __threadfence_block();  // (one wave: the strips and heads of the group's lanes, visible to all of them)
+    __builtin_amdgcn_wave_barrier();
+    bad = G.walk_batch(geo, t == 0);
+    __threadfence_block();  // (the next batch overwrites them)
+    __builtin_amdgcn_wave_barrier();
+    if (bad) break;
+  }
+  const int rcode = bad ? 1 : G.wk.finish(t == 0);
+  if (t == 0) status[ji] = static_cast<u32>(rcode);
 }
 
 template <int R, int G>
@@ -293,6 +333,9 @@ void nw_breakpoints(Engine& e, const ReadsDev& T, const ReadsDev& Rd, std::vecto
     budget = std::max<u64>(budget, 64ULL << 20);
   }
   const bool trace_lds = !(knob("RVN_NW_TRACE_MEM") && std::atoi(knob("RVN_NW_TRACE_MEM")) == 1);
+  // which walk a launch takes (engine option nw_group_walk): 1 the lane per alignment, 2 the group of lanes per alignment,
+  // otherwise by the number of alignments in the launch
+  const int group_walk = static_cast<int>(e.opt.nw_group_walk);
   const bool one_stream = knob("RVN_NW_ONE_STREAM") != nullptr;
   const bool dbg_sync = knob("RVN_NW_DEBUG") && std::atoi(knob("RVN_NW_DEBUG")) >= 2;
   std::vector<double> rates;
@@ -510,7 +553,14 @@ void nw_breakpoints(Engine& e, const ReadsDev& T, const ReadsDev& Rd, std::vecto
         RVN_HIP(hipEventRecord(e.nw_ev[4], s));
         RVN_HIP(hipStreamWaitEvent(ts, e.nw_ev[4], 0));
       }
-      if (trace_lds) {
+      if (group_walk == 2 || (group_walk != 1 && cn <= kNwGroupWalkMaxJobs)) {
+        // few alignments: a group of lanes each (nwtrace.h) — the walk of a few thousand alignments costs its longest one's
+        // latency, and a group walks a column in a fraction of a lane's time
+        constexpr u32 NG = 64 / kNwGroupLanes;
+        RVN_KLAUNCH_ON(kKNwTraceback, ts, (nw_trace_group_kernel<kNwGroupLanes><<<(cn + NG - 1) / NG, 64, 0, ts>>>(
+                                              dev.jobs, idx_c, cn, T.packed.as<u64>(), Rd.packed.as<u64>(), hs, ck, dev.res,
+                                              dev.status, w, d_recs)));
+      } else if (trace_lds) {
         RVN_KLAUNCH_ON(kKNwTraceback, ts, (nw_trace_kernel<true><<<(cn + 63) / 64, 64, 0, ts>>>(
                                               dev.jobs, idx_c, cn, T.packed.as<u64>(), Rd.packed.as<u64>(), hs, ck, dev.res,
                                               dev.status, w, d_recs, nullptr)));
@@ -800,9 +850,11 @@ void nw_breakpoints(Engine& e, const ReadsDev& T, const ReadsDev& Rd, std::vecto
 
 #ifdef RVN_TEST_HOOKS
 // ---- CPU stepper of the same code (test hook rvn_test_nw_breakpoints): 64 emulated lanes, host arrays --------------
+static u64 g_group_batches_store = 0;
+static u64* const g_group_batches = &g_group_batches_store;  // batches of the hook's last group walk (band[3] when a group walk is asked for)
 template <int R>
 static int emulate_job(NwJob J, u32 G, const u64* t_words, const u64* r_words, u32 w, NwWindowRec* recs, u32* distance,
-                       u32* band) {
+                       u32* band, int walk_gl) {
   std::vector<u64> peq(static_cast<size_t>(R) * 4 * 64);
   std::vector<NwSweepLane<R, 64>> lanes(64);
   std::vector<int> xp(64), sp(64);
@@ -857,6 +909,10 @@ static int emulate_job(NwJob J, u32 G, const u64* t_words, const u64* r_words, u
     band[1] = static_cast<u32>(g.L);
     band[2] = R;
   }
+  if (walk_gl == 16) return nw_trace_group_host<16>(J, g, t_words, r_words, hs.data(), ck.data(), res, w, recs, band ? g_group_batches : nullptr);
+  if (walk_gl == 64) return nw_trace_group_host<64>(J, g, t_words, r_words, hs.data(), ck.data(), res, w, recs, band ? g_group_batches : nullptr);
+  if (walk_gl == 4) return nw_trace_group_host<4>(J, g, t_words, r_words, hs.data(), ck.data(), res, w, recs, band ? g_group_batches : nullptr);
+  if (walk_gl != 0) return -2;
   u64 pv[kNwStripCols], mv[kNwStripCols];
   const NwStripMem<1> mem{pv, mv, 0};
   return nw_trace_job<1>(J, g, t_words, r_words, hs.data(), ck.data(), mem, res, w, recs);
@@ -868,6 +924,9 @@ static int emulate_job(NwJob J, u32 G, const u64* t_words, const u64* r_words, u
 int nw_breakpoints_host(const u64* t_words, u32 t_len, const u64* r_words, u32 r_len, u32 t_begin, u32 n, u32 q_begin,
                         u32 m, int rc, u32 w, u32 k, int force_R, NwWindowRec* recs, u32* distance, u32* band) {
   (void)t_len;
+  const int walk_gl = (rc >> 8) & 0xFF;  // bits 8-15 of rc: lanes per alignment of the group walk (0: the lane walk)
+  rc &= 1;
+  g_group_batches_store = 0;
   if (n == 0 || m == 0) return -1;
   NwJob J{};
   J.t_begin = t_begin;
@@ -906,11 +965,12 @@ int nw_breakpoints_host(const u64* t_words, u32 t_len, const u64* r_words, u32 r
     J.kcap = cap;
     int rcode;
     switch (J.R) {
-      case 1: rcode = emulate_job<1>(J, J.G, t_words, r_words, w, recs, distance, band); break;
-      case 2: rcode = emulate_job<2>(J, J.G, t_words, r_words, w, recs, distance, band); break;
-      case 4: rcode = emulate_job<4>(J, J.G, t_words, r_words, w, recs, distance, band); break;
-      default: rcode = emulate_job<8>(J, J.G, t_words, r_words, w, recs, distance, band); break;
+      case 1: rcode = emulate_job<1>(J, J.G, t_words, r_words, w, recs, distance, band, walk_gl); break;
+      case 2: rcode = emulate_job<2>(J, J.G, t_words, r_words, w, recs, distance, band, walk_gl); break;
+      case 4: rcode = emulate_job<4>(J, J.G, t_words, r_words, w, recs, distance, band, walk_gl); break;
+      default: rcode = emulate_job<8>(J, J.G, t_words, r_words, w, recs, distance, band, walk_gl); break;
     }
+    if (walk_gl && band) band[3] = static_cast<u32>(g_group_batches_store);
     if (rcode == -3 && !force_R) {  // the doubled threshold no longer fits this variant's ring
       kk = std::min<u64>(static_cast<u64>(cap) + 1, static_cast<u64>(n) + m);
       continue;

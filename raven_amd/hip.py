@@ -1047,16 +1047,18 @@ NW_REC_DTYPE = np.dtype([("first_t", "<u4"), ("first_q", "<u4"), ("last_t", "<u4
                          ("grid", "<u2", (8,))])
 
 
-def test_nw_breakpoints(t_words, t_len, r_words, r_len, t_begin, n, q_begin, m, rc, w, k=64, force_r=0):
+def test_nw_breakpoints(t_words, t_len, r_words, r_len, t_begin, n, q_begin, m, rc, w, k=64, force_r=0, group_lanes=0):
     """nwpath.h stepped on the CPU (no GPU needed): the forward sweep's lane code for 64 emulated lanes + the
-    traceback.  Returns (records per window, exact distance, (k, lanes, R), status)."""
+    traceback (group_lanes = 4 / 16 / 64: the walk by a group of lanes per alignment, nwtrace.h).  Returns (records per
+    window, exact distance, (k, lanes, R[, batches of the group walk]), status)."""
     t_words = np.ascontiguousarray(t_words, dtype=np.uint64)
     r_words = np.ascontiguousarray(r_words, dtype=np.uint64)
     n_win = (t_begin + n - 1) // w - t_begin // w + 1
     recs = np.zeros(n_win, dtype=NW_REC_DTYPE)
     dist = np.zeros(1, dtype=np.uint32)
-    band = np.zeros(3, dtype=np.uint32)
-    rc_ = test_lib().rvn_test_nw_breakpoints(_p(t_words), t_len, _p(r_words), r_len, t_begin, n, q_begin, m, int(rc), w, k,
+    band = np.zeros(4 if group_lanes else 3, dtype=np.uint32)
+    rc_ = test_lib().rvn_test_nw_breakpoints(_p(t_words), t_len, _p(r_words), r_len, t_begin, n, q_begin, m,
+                                        (1 if rc else 0) | (int(group_lanes) << 8), w, k,
                                         force_r, _p(recs), _p(dist), _p(band))
     if rc_ < 0:
         raise ValueError("rvn_test_nw_breakpoints: %d" % rc_)

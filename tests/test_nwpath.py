@@ -22,12 +22,16 @@ def _oriented(read_codes, rc):
     return (3 - read_codes[::-1]) if rc else read_codes
 
 
-def _check(target, read, t_begin, n, q_begin, m, rc, w, k=64, force_r=0):
+def _check(target, read, t_begin, n, q_begin, m, rc, w, k=64, force_r=0, group_lanes=0):
     """read: codes as stored (original orientation); the alignment uses its reverse complement when rc."""
     tw, rw = _pack(target), _pack(read)
     recs, dist, band, status = hip.test_nw_breakpoints(tw, len(target), rw, len(read), t_begin, n, q_begin, m, rc, w,
-                                                       k=k, force_r=force_r)
+                                                       k=k, force_r=force_r, group_lanes=group_lanes)
     assert status == 0
+    if group_lanes:  # the walk by a group of lanes: the records of the walk by one lane, byte for byte
+        recs1, dist1, _, status1 = hip.test_nw_breakpoints(tw, len(target), rw, len(read), t_begin, n, q_begin, m, rc, w,
+                                                           k=k, force_r=force_r)
+        assert status1 == 0 and dist1 == dist and recs.tobytes() == recs1.tobytes()
     rq = _oriented(np.asarray(read, dtype=np.uint8), rc)
     want, want_dist = oracle.nw_breakpoints(rq[q_begin:q_begin + m], np.asarray(target[t_begin:t_begin + n], np.uint8),
                                             q_begin, t_begin, w)
@@ -251,3 +255,47 @@ def test_window_records_and_grid_samples_equal_an_independent_traceback(w):
                         assert int(r["grid"][g]) == off, (trial, x, g)
                     else:
                         assert int(r["grid"][g]) == 0xFFFF
+
+
+@pytest.mark.parametrize("gl", [4, 16, 64])
+def test_group_walk_equals_the_lane_walk(gl):
+    """nwtrace.h's walk by a group of lanes per alignment (the strips along the predicted path recomputed side by side, one
+    walker stepping through them), its phases stepped lane by lane: the records of the one-lane walk byte for byte and the
+    oracle's breakpoints — where the prediction holds (few batches) and where it cannot (bursts, unrelated sequences,
+    one-sided bands, degenerate spans), on every ring layout of the sweep."""
+    rng = np.random.default_rng(600 + gl)
+    for trial in range(4):  # ONT-like, both strands, embedded at unaligned offsets
+        n = int(rng.integers(900, 3200))
+        t, q = _noisy_pair(rng, n, 0.04, 0.03, 0.03)
+        rc = trial & 1
+        tl, ql = int(rng.integers(0, 700)), int(rng.integers(0, 90))
+        target = np.concatenate([rng.integers(0, 4, tl, dtype=np.uint8), t, rng.integers(0, 4, 77, dtype=np.uint8)])
+        read_o = np.concatenate([rng.integers(0, 4, ql, dtype=np.uint8), q, rng.integers(0, 4, 33, dtype=np.uint8)])
+        dist, band = _check(target, _oriented(read_o, rc), tl, len(t), ql, len(q), rc, 500, group_lanes=gl)
+        # the prediction serves: a batch walks through several strips (a strip is at most 32 columns and 64 rows)
+        strips_at_least = len(q) // 32
+        assert band[3] <= max(2, strips_at_least // min(gl // 2, 4)), (band, len(q))
+    t, q = _noisy_pair(rng, 3000, 0.002, 0.002, 0.002)  # HiFi-like, the narrowest ring
+    _check(t, q, 0, len(t), 0, len(q), 0, 500, k=16, force_r=-4, group_lanes=gl)
+    t, q = _noisy_pair(rng, 2200, 0.04, 0.03, 0.03)
+    for R in (1, 2, 4, 8):  # several blocks per lane: the strips of a super-block share a column phase
+        _check(t, q, 0, len(t), 0, len(q), 0, 500, k=64, force_r=R, group_lanes=gl)
+    for g in (16, 32):
+        rc = 1 if g == 32 else 0
+        _check(t, _oriented(q, rc), 0, len(t), 0, len(q), rc, 500, k=32, force_r=-g, group_lanes=gl)
+    # where the straight line is a bad guess
+    t = rng.integers(0, 4, 2500, dtype=np.uint8)
+    q = np.concatenate([t[:800], rng.integers(0, 4, 300, dtype=np.uint8), t[800:1700], t[1950:]])  # +300 / -250
+    _check(t, q, 0, len(t), 0, len(q), 0, 500, group_lanes=gl)
+    _check(q, t, 0, len(q), 0, len(t), 0, 500, group_lanes=gl)
+    _check(t[:400], np.concatenate([t[:400], rng.integers(0, 4, 900, dtype=np.uint8)]), 0, 400, 0, 1300, 0, 100, group_lanes=gl)
+    _check(np.concatenate([t[:400], rng.integers(0, 4, 900, dtype=np.uint8)]), t[:400], 0, 1300, 0, 400, 0, 100, group_lanes=gl)
+    _check(rng.integers(0, 4, 900, dtype=np.uint8), rng.integers(0, 4, 1000, dtype=np.uint8), 0, 900, 0, 1000, 0, 500, group_lanes=gl)
+    for n, m in [(1, 1), (1, 7), (9, 1), (63, 64), (64, 64), (65, 63), (128, 129), (5, 200), (200, 5)]:
+        _check(rng.integers(0, 4, n, dtype=np.uint8), rng.integers(0, 4, m, dtype=np.uint8), 0, n, 0, m, 0, 50, group_lanes=gl)
+    h = np.zeros(300, dtype=np.uint8)  # homopolymers: the tie rule decides every step
+    _check(h, h[:250], 0, 300, 0, 250, 0, 100, group_lanes=gl)
+    _check(h[:250], h, 0, 250, 0, 300, 0, 100, group_lanes=gl)
+    t, q = _noisy_pair(rng, 1800, 0.03, 0.03, 0.03)
+    for w in (37, 500, 1023):
+        _check(t, q, 0, len(t), 0, len(q), 0, w, group_lanes=gl)

@@ -238,7 +238,11 @@ def main():
     ap.add_argument("--workload", default="c4", choices=["c4", "c2"])
     ap.add_argument("--genome", type=int, default=None)
     ap.add_argument("--rounds", type=int, default=2)
+    ap.add_argument("--engine-option", action="append", default=[], metavar="NAME=VALUE")
+    ap.add_argument("--polish-only", action="store_true", help="the rounds' shares only (tools/trace_share.sh): no overlap pass, no prediction")
     a = ap.parse_args()
+    global ENGINE_OPTIONS
+    ENGINE_OPTIONS = [(kv.split("=")[0], int(kv.split("=")[1])) for kv in a.engine_option]
     args = argparse.Namespace(genome=a.genome or (100_000_000 if a.workload == "c4" else 5_000_000), coverage=30.0,
                               read_len=10000, length_model="lognormal" if a.workload == "c4" else "fixed",
                               errors=(0.04, 0.03, 0.03), polish_rounds=a.rounds, contig=5_000_000)
@@ -247,6 +251,8 @@ def main():
 
     # ---- the single GPU's step on the same data (what bench.py times): pass + rounds, second of two steps ----
     eng = hip.Engine(15, 5)
+    for name, value in ENGINE_OPTIONS:
+        eng.set_option(name, value)
     reads = eng.upload(rs)
     nblk = (rs.lengths.astype(np.int64) + 63) // 64
     qoff = np.zeros(rs.n + 1, dtype=np.uint64)
@@ -278,6 +284,9 @@ def main():
     eng.close()
     import torch
     torch.cuda.empty_cache()
+    if a.polish_only:
+        print(json.dumps({"ranks": world, "polishing_rounds_at_n_ranks": shares, "sharded_rounds_equal_single_gpu_consensus": bool(same)}))
+        return
     ov = overlap_pass_shares(rs, world, 15, 5, 0.001, 32)
 
     t_n = ov["predicted_pass_s"] + sum(r["predicted_round_s"] for r in shares)
