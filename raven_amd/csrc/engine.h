@@ -210,6 +210,8 @@ struct Engine {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   hipStream_t nw_streams[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // alignment-path stage: [0..3] walk streams (beside the sweeps), one per buffer set; [4] uploads of a pass planned while another one sweeps
   hipEvent_t nw_ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // [0..3] the walk of a buffer set is done, [4] sweep -> walk
+  hipStream_t nw_side[3] = {nullptr, nullptr, nullptr};  // ... sweep launches of few waves (the pilot's, the several-blocks-per-lane variants of the longest alignments) beside the main stream's
+  hipEvent_t nw_side_ev[4] = {nullptr, nullptr, nullptr, nullptr};  // [0..2] the side stream's sweeps are done, [3] main -> side
   u64* h_pin = nullptr;  // pinned host scratch for small device->host size read-backs
   PinBuf pin_big;        // pinned staging for bulk read-backs up to 256 MB (polishing: chain anchors)
   HostBuf host_big;      // ... and the unpinned one for larger ones
@@ -337,12 +339,20 @@ void shard_adjacent_diff(Engine& e, const u64* d_seg, u64 n, u64* d_cnt);
 void shard_regroup(Engine& e, u32 world, const u64* const* d_cnt, const u64* const* d_grp, const u64* const* d_pos,
                    const u64* n_src /* host */, u32 n_reads, u64* d_seg, u64* d_grp_out, u64* d_pos_out);
 void shard_lhs_offsets(Engine& e, const Overlap* d_ovl, u64 n, u32 n_reads, u32* d_off);
+// polish_round's consensus straight into the caller's buffer (target t at out + off[t], at most off[t + 1] - off[t] bytes;
+// len[t] = its length) instead of into `polished` (which then stays empty): one pass over the 100 MB of a C4 round less
+struct PolishDirectOut {
+  u8* out;
+  const u64* off;
+  u64* len;
+};
 void polish_map_best(Engine& e, ReadsDev& T, ReadsDev& R, u32 r_first, u32 r_last, double err_thr,
                      std::vector<Overlap>& best, std::vector<u32>& best_t, u64* n_overlaps);
 void polish_round(Engine& e, ReadsDev& T, ReadsDev& R, const u8* h_quals, const u64* h_qual_off, double q_thr,
                   double err_thr, u32 w, bool trim, int m, int n, int g, std::vector<std::vector<u8>>& polished,
                   std::vector<double>& ratio, PolishStats& stats, u64 win_first = 0, u64 win_last = ~0ULL,
-                  std::vector<u32>* win_count = nullptr, std::vector<u32>* win_polished = nullptr);
+                  std::vector<u32>* win_count = nullptr, std::vector<u32>* win_polished = nullptr,
+                  const PolishDirectOut* direct = nullptr);
 
 // Result of the second mapping pass (pass2.hip), resident in HBM
 struct Pass2State {

@@ -471,6 +471,10 @@ void rvn_engine_destroy(rvn_engine* h) {
     if (ev) (void)hipEventDestroy(ev);
   for (hipStream_t st2 : h->e.nw_streams)
     if (st2) (void)hipStreamDestroy(st2);
+  for (hipEvent_t ev : h->e.nw_side_ev)
+    if (ev) (void)hipEventDestroy(ev);
+  for (hipStream_t st2 : h->e.nw_side)
+    if (st2) (void)hipStreamDestroy(st2);
   if (h->e.stream) (void)hipStreamDestroy(h->e.stream);
   if (h->e.h_pin) (void)hipHostFree(h->e.h_pin);
   delete h->e.pile_pool;
@@ -1136,18 +1140,14 @@ int rvn_polish_round_range(rvn_engine* h, rvn_reads* targets, rvn_reads* reads, 
     std::vector<double> rt;
     PolishStats st;
     std::vector<u32> wc, wp;
+    // (the consensus goes from the page-locked read-back buffer straight into the caller's — usually never touched — pages, on a
+    // few threads: 100 MB at C4; a buffer too small for a target fails the call with RVN_EINVAL)
+    std::vector<u64> lens(targets->r.n, 0);
+    const PolishDirectOut direct{out_codes, out_offsets, lens.data()};
     polish_round(h->e, targets->r, reads->r, read_quals, qual_offsets, q, err, w, trim != 0, match, mismatch, gap,
-                 polished, rt, st, window_first, window_last, &wc, &wp);
+                 polished, rt, st, window_first, window_last, &wc, &wp, &direct);
     for (u32 t = 0; t < targets->r.n; ++t) {
-      const u64 cap = out_offsets[t + 1] - out_offsets[t];
-      if (polished[t].size() > cap) return fail(RVN_EINVAL, "[raven_hip] rvn_polish_round_range: output buffer too small");
-    }
-    // (100 MB of consensus at C4 into the caller's — usually never touched — pages: on a few threads)
-    parallel_for(targets->r.n, 1, [&](size_t t0, size_t t1) {
-      for (size_t t = t0; t < t1; ++t) std::memcpy(out_codes + out_offsets[t], polished[t].data(), polished[t].size());
-    });
-    for (u32 t = 0; t < targets->r.n; ++t) {
-      out_len[t] = static_cast<uint32_t>(polished[t].size());
+      out_len[t] = static_cast<uint32_t>(lens[t]);
       if (ratio) ratio[t] = rt[t];
       if (n_windows) n_windows[t] = wc[t];
       if (n_polished) n_polished[t] = wp[t];

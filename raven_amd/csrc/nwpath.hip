@@ -42,6 +42,7 @@ constexpr int kNwGroupLanes = 16;           // lanes per alignment of the group 
 constexpr u32 kNwGroupWalkMaxJobs = 8192;  // a walk launch of at most this many alignments takes the group walk (two rounds of the
                                            // machine's 4 096 resident groups: beyond that a group's ~3x shorter latency per column loses
                                            // to the lane walk's sixteen times as many alignments in flight — tools/walk_ab.sh)
+constexpr u32 kSideSweepMaxWaves = 1024;    // a sweep launch of at most this many waves goes beside the main stream's (enqueue)
 constexpr u32 kLevels = 8;
 const u32 kRs[kLevels] = {1, 1, 1, 1, 1, 2, 4, 8};
 const u32 kGs[kLevels] = {4, 8, 16, 32, 64, 64, 64, 64};
@@ -204,10 +205,9 @@ __global__ __launch_bounds__(64) void nw_trace_group_kernel(const NwJob* __restr
 }
 
 template <int R, int G>
-void launch_sweep(Engine& e, const NwJob* d_jobs, const u32* d_idx, u32 n_idx, const ReadsDev& T, const ReadsDev& Rd,
+void launch_sweep(Engine& e, hipStream_t s, const NwJob* d_jobs, const u32* d_idx, u32 n_idx, const ReadsDev& T, const ReadsDev& Rd,
                   u32* d_hs, NwPm* d_ck, u32* d_result, u32* d_status, u32* d_next) {
   if (n_idx == 0) return;
-  hipStream_t s = e.stream;
   constexpr u32 NG = 64 / G;
   const u32 bundles = (n_idx + NG - 1) / NG;
   // persistent waves: not every slot of the machine — the walks of the previous chunk run beside this sweep on the other
@@ -215,7 +215,7 @@ void launch_sweep(Engine& e, const NwJob* d_jobs, const u32* d_idx, u32 n_idx, c
   const u32 per_simd = static_cast<u32>(sweep_waves_per_simd<R>());
   const u32 waves = std::min<u32>(bundles, 256u * 4u * (per_simd > 4 ? per_simd - 2 : per_simd));
   RVN_HIP(hipMemsetAsync(d_next, 0, 4, s));
-  RVN_KLAUNCH(kKNwForward, (nw_sweep_kernel<R, G><<<(waves + 3) / 4, 256, 0, s>>>(
+  RVN_KLAUNCH_ON(kKNwForward, s, (nw_sweep_kernel<R, G><<<(waves + 3) / 4, 256, 0, s>>>(
                                d_jobs, d_idx, n_idx, T.packed.as<u64>(), Rd.packed.as<u64>(), d_hs, d_ck, d_result,
                                d_status, d_next)));
 }
@@ -263,10 +263,11 @@ void nw_breakpoints(Engine& e, const ReadsDev& T, const ReadsDev& Rd, std::vecto
     RVN_HIP(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
     // created into locals and handed to the engine only when all exist: a creation that throws half-way must not leave
     // nw_streams[0] set with the others null — the next call would skip this block and launch walks on the null stream
-    hipStream_t made[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t made_ev[sizeof(e.nw_ev) / sizeof(e.nw_ev[0])] = {};
+    constexpr int kNwEv = static_cast<int>(sizeof(e.nw_ev) / sizeof(e.nw_ev[0]));
+    hipStream_t made[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // [5..7]: nw_side
+    hipEvent_t made_ev[kNwEv + 4] = {};
     try {
-      for (int b = 0; b < 5; ++b) {
+      for (int b = 0; b < 8; ++b) {
         // ([4], the upload stream, must not share a hardware queue with the engine's stream either: its copies run while a
         // pass queued before is sweeping there)
         if (b >= 3 && prio_greatest != prio_least)
@@ -282,8 +283,10 @@ void nw_breakpoints(Engine& e, const ReadsDev& T, const ReadsDev& Rd, std::vecto
         if (ev) (void)hipEventDestroy(ev);
       throw;
     }
-    for (int b = 0; b < 5; ++b) e.nw_streams[b] = made[b];
-    for (size_t i = 0; i < sizeof(e.nw_ev) / sizeof(e.nw_ev[0]); ++i) e.nw_ev[i] = made_ev[i];
+    for (int b = 0; b < 3; ++b) e.nw_side[b] = made[5 + b];
+    for (int i = 0; i < 4; ++i) e.nw_side_ev[i] = made_ev[kNwEv + i];
+    for (int i = 0; i < kNwEv; ++i) e.nw_ev[i] = made_ev[i];
+    for (int b = 0; b < 5; ++b) e.nw_streams[b] = made[b];  // (last: what the test above looks at)
   }
   // an error in the middle of a pass (a walk that left its band, an allocation that failed) must not leave walks running
   // on the side streams against buffers the next call hands out again
@@ -292,6 +295,8 @@ void nw_breakpoints(Engine& e, const ReadsDev& T, const ReadsDev& Rd, std::vecto
     ~WalkGuard() {
       if (!std::uncaught_exceptions()) return;
       for (hipStream_t st2 : e.nw_streams)
+        if (st2) (void)hipStreamSynchronize(st2);
+      for (hipStream_t st2 : e.nw_side)
         if (st2) (void)hipStreamSynchronize(st2);
       (void)hipStreamSynchronize(e.stream);
     }
@@ -343,7 +348,7 @@ void nw_breakpoints(Engine& e, const ReadsDev& T, const ReadsDev& Rd, std::vecto
   std::vector<u32> h_result(nj), h_status(nj);
   constexpr u32 kHeadMax = 4096;  // jobs of the pass of the longest alignments (below)
   NwJob* d_jobs = e.nw_jobs.get<NwJob>(static_cast<size_t>(nj) + 1 + 2 * kHeadMax);
-  u32* d_res = e.nw_res.get<u32>(3 * static_cast<size_t>(nj) + 16 + 6 * kHeadMax);
+  u32* d_res = e.nw_res.get<u32>(3 * static_cast<size_t>(nj) + 32 + 6 * kHeadMax);
   u32* d_status = d_res + nj + 1;
   u32* d_idx = d_status + nj + 1;
   u32* d_next = d_idx + nj + 1;
@@ -358,6 +363,14 @@ void nw_breakpoints(Engine& e, const ReadsDev& T, const ReadsDev& Rd, std::vecto
   const PassDev dev_head{d_jobs + nj + 1, d_next + 4 + 2 * kHeadMax, d_next + 4, d_next + 4 + kHeadMax, true};
   const PassDev dev_retry{dev_head.jobs + kHeadMax, dev_head.idx + 3 * kHeadMax, dev_head.res + 3 * kHeadMax,
                           dev_head.status + 3 * kHeadMax, true};
+  u32* d_side_next = d_next + 4 + 6 * kHeadMax;  // (behind the compact passes' arrays) job counters of the sweeps launched beside the main stream, one per variant
+  bool side_pending[3] = {false, false, false};   // sweeps on a side stream that the main stream has not waited for yet
+  auto join_side = [&]() {
+    for (int x = 0; x < 3; ++x) {
+      if (side_pending[x]) RVN_HIP(hipStreamWaitEvent(s, e.nw_side_ev[x], 0));
+      side_pending[x] = false;
+    }
+  };
   struct Obs {
     double len, d;
   };
@@ -527,9 +540,53 @@ void nw_breakpoints(Engine& e, const ReadsDev& T, const ReadsDev& Rd, std::vecto
         const u32 next_off = x == 0 ? cn : C.coff[x - 1];
         return next_off - C.coff[x];
       };
+      // one walk stream per buffer set: the walk of the longest alignments (chunk 0: few waves, tens of milliseconds of
+      // latency) must not hold back the walks of the chunks behind it
+      hipStream_t ts = one_stream ? s : e.nw_streams[b];
+      auto launch_walk = [&](hipStream_t wst, const u32* idx_w, u32 n_w) {
+        if (group_walk == 2 || (group_walk != 1 && n_w <= kNwGroupWalkMaxJobs)) {
+          // few alignments: a group of lanes each (nwtrace.h) — the walk of a few thousand alignments costs its longest one's
+          // latency, and a group walks a column in a fraction of a lane's time
+          constexpr u32 NG = 64 / kNwGroupLanes;
+          RVN_KLAUNCH_ON(kKNwTraceback, wst, (nw_trace_group_kernel<kNwGroupLanes><<<(n_w + NG - 1) / NG, 64, 0, wst>>>(
+                                                 dev.jobs, idx_w, n_w, T.packed.as<u64>(), Rd.packed.as<u64>(), hs, ck, dev.res,
+                                                 dev.status, w, d_recs)));
+        } else if (trace_lds) {
+          RVN_KLAUNCH_ON(kKNwTraceback, wst, (nw_trace_kernel<true><<<(n_w + 63) / 64, 64, 0, wst>>>(
+                                                 dev.jobs, idx_w, n_w, T.packed.as<u64>(), Rd.packed.as<u64>(), hs, ck, dev.res,
+                                                 dev.status, w, d_recs, nullptr)));
+        } else {
+          RVN_KLAUNCH_ON(kKNwTraceback, wst, (nw_trace_kernel<false><<<(n_w + 63) / 64, 64, 0, wst>>>(
+                                                 dev.jobs, idx_w, n_w, T.packed.as<u64>(), Rd.packed.as<u64>(), hs, ck, dev.res,
+                                                 dev.status, w, d_recs,
+                                                 d_strip + static_cast<size_t>(b) * ((e.nw_strip.cap / 32) & ~size_t(63)))));
+        }
+      };
+      // A variant's launch of few waves — the pilot's five, the several-blocks-per-lane variants of a round's longest
+      // alignments (a few hundred jobs whose sweep is tens of thousands of dependent steps: 14-18 ms on 60-300 of the
+      // machine's 6 000 wave slots) — runs BESIDE the others on a side stream instead of in front of them; the walk (and
+      // whoever reads the states) waits for all of them, the main stream goes on with the next chunk.
+      bool side[kLevels] = {};
+      bool side_used[3] = {false, false, false};
+      {
+        u32 n_levels = 0;
+        for (u32 x = 0; x < kLevels; ++x) n_levels += count_of(x) ? 1u : 0u;
+        if (n_levels >= 2 && !one_stream && !dbg_sync)
+          for (u32 x = 0; x < kLevels; ++x) {
+            const u32 bundles = (count_of(x) + 64 / kGs[x] - 1) / (64 / kGs[x]);
+            side[x] = count_of(x) && bundles <= kSideSweepMaxWaves;
+            if (side[x]) side_used[x % 3] = true;
+          }
+        if (side_used[0] || side_used[1] || side_used[2]) {
+          RVN_HIP(hipEventRecord(e.nw_side_ev[3], s));
+          for (int y = 0; y < 3; ++y)
+            if (side_used[y]) RVN_HIP(hipStreamWaitEvent(e.nw_side[y], e.nw_side_ev[3], 0));
+        }
+      }
 #define RVN_SWEEP(x, R_, G_)                                                                                         \
   do {                                                                                                               \
-    launch_sweep<R_, G_>(e, dev.jobs, idx_c + C.coff[x], count_of(x), T, Rd, hs, ck, dev.res, dev.status, d_next);     \
+    launch_sweep<R_, G_>(e, side[x] ? e.nw_side[(x) % 3] : s, dev.jobs, idx_c + C.coff[x], count_of(x), T, Rd, hs, ck, \
+                         dev.res, dev.status, side[x] ? d_side_next + (x) : d_next);                                   \
     if (dbg_sync && count_of(x)) {                                                                                   \
       RVN_HIP(hipStreamSynchronize(s));                                                                              \
       std::fprintf(stderr, "[raven_hip] nw: sweep R=%d G=%d done, %u jobs\n", R_, G_, count_of(x));                   \
@@ -544,32 +601,20 @@ void nw_breakpoints(Engine& e, const ReadsDev& T, const ReadsDev& Rd, std::vecto
       RVN_SWEEP(1, 1, 8);
       RVN_SWEEP(0, 1, 4);
 #undef RVN_SWEEP
+      for (int y = 0; y < 3; ++y)
+        if (side_used[y]) {
+          RVN_HIP(hipEventRecord(e.nw_side_ev[y], e.nw_side[y]));
+          side_pending[y] = true;
+        }
       ++st.n_batches;
       if (sweep_only) continue;
-      // one walk stream per buffer set: the walk of the longest alignments (chunk 0: few waves, tens of milliseconds of
-      // latency) must not hold back the walks of the chunks behind it
-      hipStream_t ts = one_stream ? s : e.nw_streams[b];
       if (!one_stream) {
         RVN_HIP(hipEventRecord(e.nw_ev[4], s));
         RVN_HIP(hipStreamWaitEvent(ts, e.nw_ev[4], 0));
+        for (int y = 0; y < 3; ++y)
+          if (side_used[y]) RVN_HIP(hipStreamWaitEvent(ts, e.nw_side_ev[y], 0));
       }
-      if (group_walk == 2 || (group_walk != 1 && cn <= kNwGroupWalkMaxJobs)) {
-        // few alignments: a group of lanes each (nwtrace.h) — the walk of a few thousand alignments costs its longest one's
-        // latency, and a group walks a column in a fraction of a lane's time
-        constexpr u32 NG = 64 / kNwGroupLanes;
-        RVN_KLAUNCH_ON(kKNwTraceback, ts, (nw_trace_group_kernel<kNwGroupLanes><<<(cn + NG - 1) / NG, 64, 0, ts>>>(
-                                              dev.jobs, idx_c, cn, T.packed.as<u64>(), Rd.packed.as<u64>(), hs, ck, dev.res,
-                                              dev.status, w, d_recs)));
-      } else if (trace_lds) {
-        RVN_KLAUNCH_ON(kKNwTraceback, ts, (nw_trace_kernel<true><<<(cn + 63) / 64, 64, 0, ts>>>(
-                                              dev.jobs, idx_c, cn, T.packed.as<u64>(), Rd.packed.as<u64>(), hs, ck, dev.res,
-                                              dev.status, w, d_recs, nullptr)));
-      } else {
-        RVN_KLAUNCH_ON(kKNwTraceback, ts, (nw_trace_kernel<false><<<(cn + 63) / 64, 64, 0, ts>>>(
-                                              dev.jobs, idx_c, cn, T.packed.as<u64>(), Rd.packed.as<u64>(), hs, ck, dev.res,
-                                              dev.status, w, d_recs,
-                                              d_strip + static_cast<size_t>(b) * ((e.nw_strip.cap / 32) & ~size_t(63)))));
-      }
+      launch_walk(ts, idx_c, cn);
       if (!one_stream) {
         RVN_HIP(hipEventRecord(e.nw_ev[b], ts));
         set_used[b] = true;
@@ -585,6 +630,7 @@ void nw_breakpoints(Engine& e, const ReadsDev& T, const ReadsDev& Rd, std::vecto
   // twice the band and the variant that holds it).
   auto collect = [&](std::vector<u32>& again) {
     again.clear();
+    join_side();
     for (int b = 0; b < 4; ++b) {  // (an event stands for the LAST walk recorded on its set)
       if (set_used[b]) RVN_HIP(hipStreamWaitEvent(s, e.nw_ev[b], 0));
       set_used[b] = false;
@@ -666,6 +712,7 @@ void nw_breakpoints(Engine& e, const ReadsDev& T, const ReadsDev& Rd, std::vecto
   // profiles/r05_nw_timeline.csv).  A job handed on here is skipped by collect() in the pass that found it.
   auto retry_early = [&]() {
     if (one_stream || queued.empty()) return;
+    join_side();
     for (Queued& q : queued)
       if (q.dev.compact) {
         q.status.resize(q.order.size());

@@ -14,6 +14,8 @@
 // Everything between the mapping and the final consensus bytes stays in HBM; the host plans the alignment batches
 // from one 36-byte record per read and reads back per-window status words.
 #include <algorithm>
+#include <cstring>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -409,7 +411,7 @@ void polish_map_best(Engine& e, ReadsDev& T, ReadsDev& R, u32 r_first, u32 r_las
 void polish_round(Engine& e, ReadsDev& T, ReadsDev& R, const u8* h_quals, const u64* h_qual_off, double q_thr,
                   double err_thr, u32 w, bool trim, int m, int n, int g, std::vector<std::vector<u8>>& polished,
                   std::vector<double>& ratio, PolishStats& stats, u64 win_first, u64 win_last,
-                  std::vector<u32>* win_count, std::vector<u32>* win_polished) {
+                  std::vector<u32>* win_count, std::vector<u32>* win_polished, const PolishDirectOut* direct) {
   hipStream_t s = e.stream;
   using clk = std::chrono::steady_clock;
   auto ms_since = [](clk::time_point a) { return std::chrono::duration<double, std::milli>(clk::now() - a).count(); };
@@ -681,10 +683,24 @@ void polish_round(Engine& e, ReadsDev& T, ReadsDev& R, const u8* h_quals, const 
         span[t] = {i0, i};
       }
     }
-    parallel_for(T.n, 1, [&](size_t t0, size_t t1) {  // (first touch of 100 MB of host vectors at C4: a few threads)
-      for (size_t t = t0; t < t1; ++t)
-        if (span[t].second > span[t].first) polished[t].assign(h_final + cons_off[span[t].first], h_final + cons_off[span[t].second]);
+    std::atomic<bool> too_small{false};
+    parallel_for(T.n, 1, [&](size_t t0, size_t t1) {  // (first touch of 100 MB of host pages at C4: a few threads)
+      for (size_t t = t0; t < t1; ++t) {
+        if (direct) direct->len[t] = 0;
+        if (span[t].second <= span[t].first) continue;
+        const u8* from = h_final + cons_off[span[t].first];
+        const u64 bytes = cons_off[span[t].second] - cons_off[span[t].first];
+        if (!direct) {
+          polished[t].assign(from, from + bytes);
+        } else if (bytes > direct->off[t + 1] - direct->off[t]) {
+          too_small = true;
+        } else {
+          std::memcpy(direct->out + direct->off[t], from, bytes);
+          direct->len[t] = bytes;
+        }
+      }
     });
+    if (too_small) throw std::invalid_argument("[raven_hip] polishing round: output buffer too small");
     // (a round over every window leaves the targets' consensus, in target order, in pl_final: rvn_polish_output_as_reads)
     e.pl_last_valid = false;
     if (W0 == 0 && W1 == n_windows_all && T.n > 0) {

@@ -117,8 +117,8 @@ def test_head_pass_and_early_repeats_give_the_oracle_layers():
 
 
 @pytest.mark.parametrize("genome_len,coverage,read_len,draft_err", [(40_000, 20, 2500, (0.01, 0.008, 0.008)),
-                                                                    (150_000, 10, 30_000, (0.01, 0.008, 0.008)),
-                                                                    (60_000, 15, 6000, (0.06, 0.05, 0.05))])
+                                                                    (100_000, 8, 16_000, (0.01, 0.008, 0.008)),
+                                                                    (40_000, 12, 5000, (0.06, 0.05, 0.05))])
 def test_walk_by_a_lane_and_by_a_group_of_lanes_give_the_same_layers(genome_len, coverage, read_len, draft_err):
     """The alignment path is walked by one lane per alignment or by a group of sixteen (nwtrace.h: the strips along the
     predicted path side by side, one walker through them; launches of few alignments take the group by default).  Engine
@@ -129,7 +129,7 @@ def test_walk_by_a_lane_and_by_a_group_of_lanes_give_the_same_layers(genome_len,
     td, rd = eng.upload(targets), eng.upload(reads)
     lays, cons = [], []
     try:
-        for mode in (1, 2, 0, 2):  # lane, group, by size, group again (thresholds from the running estimate)
+        for mode in (1, 2, 0):  # lane, group, by size (the later rounds take their thresholds from the running estimate)
             eng.set_option("nw_group_walk", mode)
             c, _, st = eng.polish_round(td, rd)
             assert st["n_aligned"] == st["n_reads_used"] > 0

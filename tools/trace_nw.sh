@@ -22,7 +22,8 @@ t0 = min(int(r["Start_Timestamp"]) for r in rows)
 with open(sys.argv[2], "w") as f:
     f.write("kernel,queue,start_ms,end_ms,dur_ms,grid\n")
     for r in sorted(rows, key=lambda r: int(r["Start_Timestamp"])):
-        n = r["Kernel_Name"].split("rvn::")[-1].split("(")[0][:40]
+        import re
+        n = re.search(r"nw_\w+_kernel(<[^>]*>)?", r["Kernel_Name"]).group(0).replace(",", ";")
         s, e = int(r["Start_Timestamp"]) - t0, int(r["End_Timestamp"]) - t0
         f.write("%s,%s,%.2f,%.2f,%.2f,%s\n" % (n, r.get("Queue_Id", ""), s / 1e6, e / 1e6, (e - s) / 1e6, r.get("Grid_Size", r.get("Grid_Size_X", ""))))
 PY
