@@ -441,7 +441,8 @@ int rvn_overlap_update_and_type(rvn_overlap* overlaps, uint64_t n, const uint32_
  * switches exist only in libraven_hip_test.so (built with -DRVN_DEBUG_KNOBS).  Options:
  *   nw_budget_mb       alignment-path stage: HBM for the stored band words (default: a quarter of the free memory, <= 64 GB)
  *   nw_group_walk      alignment-path stage: which walk a launch takes — 1 a lane per alignment, 2 a group of sixteen lanes per
- *                      alignment, otherwise (default) the group for launches of at most 8 192 alignments; same records either way
+ *                      alignment, 3 a lane per alignment with half-size strips, otherwise (default) the group for launches of at
+ *                      most 8 192 alignments and the half-size strips beyond 65 536; same records either way
  *   poa_rows_min_windows  window-consensus stage: smallest batch that starts with the rows-on-lanes kernel (default 8 192;
  *                      0 means every batch, -1 the default)
  *   io_threads, io_slab_mb, io_ring, io_zlib   rvn_reads_load: inflate threads, page-locked slab size, slabs in flight,

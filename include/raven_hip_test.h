@@ -34,7 +34,8 @@ int rvn_test_low_complexity(const uint8_t* codes, uint32_t k);
  * orientation (rc: the read is reverse-complemented).  k = first band threshold (doubled until exact), force_r = 0
  * or the blocks per lane (1 / 2 / 4 / 8).  recs: one 32-byte record per window of w target bases touched by the span
  * {first_t, first_q, last_t, last_q, u16 grid[8]}; distance = exact edit distance; band = {k, lanes, R} used.
- * Bits 8-15 of rc: 0 = the walk of one lane per alignment; 4 / 16 / 64 = the group walk with that many lanes per alignment
+ * Bits 8-15 of rc: 0 = the walk of one lane per alignment (whole strips), 1 = the same with strips of sixteen kept columns (what
+ * the kernel runs where the strips live in LDS); 4 / 16 / 64 = the group walk with that many lanes per alignment
  * (nwtrace.h: NwGroupWalk, its phases stepped lane by lane) — band then has a fourth entry, the batches the walk took.
  * Returns 0, 1 if the walk did not end at cost 0, < 0 on invalid arguments. */
 int rvn_test_nw_breakpoints(const uint64_t* t_words, uint32_t t_len, const uint64_t* r_words, uint32_t r_len,

@@ -38,6 +38,7 @@ namespace {
 // where one block per lane cannot hold the band: variants (2, 8) ... (4, 32) — fewer instructions per block step on
 // paper — were measured and lost (C4 sweep 178 ms with R = 1 wherever possible, 187 ms allowing R = 2, 225 ms allowing
 // R = 4: more registers = fewer waves, a coarser band, costlier ring events).
+constexpr int kNwLaneStripCols = 16;        // columns a walker's strip keeps in LDS (nw_trace_kernel<true>)
 constexpr int kNwGroupLanes = 16;           // lanes per alignment of the group walk (four alignments per wave)
 constexpr u32 kNwGroupWalkMaxJobs = 8192;  // a walk launch of at most this many alignments takes the group walk (two rounds of the
                                            // machine's 4 096 resident groups: beyond that a group's ~3x shorter latency per column loses
@@ -146,14 +147,17 @@ void nw_sweep_kernel(const NwJob* __restrict__ jobs, const u32* __restrict__ idx
 
 // STRIP_LDS: the walker's strip in LDS (33 KB per wave: four waves per CU) or in a per-wave scratch in HBM / L2
 // ([column][lane], coalesced; occupancy limited by registers only)
-template <bool STRIP_LDS>
+template <bool STRIP_LDS, int SC>
 __global__ __launch_bounds__(64) void nw_trace_kernel(const NwJob* __restrict__ jobs, const u32* __restrict__ idx, u32 n_idx,
                                                       const u64* __restrict__ t_words, const u64* __restrict__ r_words,
                                                       const u32* __restrict__ hs, const NwPm* __restrict__ ck,
                                                       const u32* __restrict__ result, u32* __restrict__ status, u32 w,
                                                       NwWindowRec* __restrict__ recs, u64* __restrict__ scratch) {
-  __shared__ u64 s_pv[STRIP_LDS ? kNwStripCols * 64 : 1];
-  __shared__ u64 s_mv[STRIP_LDS ? kNwStripCols * 64 : 1];
+  // (SC = 16: a strip keeps sixteen columns, 17.4 KB of LDS per wave, nine waves per CU instead of four — nwtrace.h; for
+  // launches of more waves than the machine holds with whole strips.  A walker pays ~15 % for the second visit of a
+  // checkpoint interval, so launches that fit keep whole strips.)
+  __shared__ u64 s_pv[STRIP_LDS ? (SC + 1) * 64 : 1];
+  __shared__ u64 s_mv[STRIP_LDS ? (SC + 1) * 64 : 1];
   // one lane per alignment, a long dependent chain per column: these waves run beside the next chunk's sweep (which keeps
   // the VALUs full) and must not queue behind it for every instruction
   __builtin_amdgcn_s_setprio(3);
@@ -165,7 +169,7 @@ __global__ __launch_bounds__(64) void nw_trace_kernel(const NwJob* __restrict__ 
   const NwGeo geo = nw_geo(J.n, J.m, J.k, J.R);
   u64* g_pv = scratch + static_cast<u64>(blockIdx.x) * (2 * kNwStripCols * 64);
   const NwStripMem<64> mem{STRIP_LDS ? s_pv : g_pv, STRIP_LDS ? s_mv : g_pv + kNwStripCols * 64, static_cast<int>(threadIdx.x)};
-  status[ji] = static_cast<u32>(nw_trace_job<64>(J, geo, t_words, r_words, hs + J.hs, ck + J.ckpt, mem, result[ji], w, recs));
+  status[ji] = static_cast<u32>(nw_trace_job<64, SC>(J, geo, t_words, r_words, hs + J.hs, ck + J.ckpt, mem, result[ji], w, recs));
 }
 
 // The group walk (nwtrace.h: NwGroupWalk): GL lanes per alignment, 64 / GL alignments per wave; strips in the same LDS
@@ -338,8 +342,8 @@ void nw_breakpoints(Engine& e, const ReadsDev& T, const ReadsDev& Rd, std::vecto
     budget = std::max<u64>(budget, 64ULL << 20);
   }
   const bool trace_lds = !(knob("RVN_NW_TRACE_MEM") && std::atoi(knob("RVN_NW_TRACE_MEM")) == 1);
-  // which walk a launch takes (engine option nw_group_walk): 1 the lane per alignment, 2 the group of lanes per alignment,
-  // otherwise by the number of alignments in the launch
+  // which walk a launch takes (engine option nw_group_walk): 1 the lane per alignment with whole strips, 2 the group of lanes
+  // per alignment, 3 the lane per alignment with strips of sixteen kept columns, otherwise by the number of alignments in the launch
   const int group_walk = static_cast<int>(e.opt.nw_group_walk);
   const bool one_stream = knob("RVN_NW_ONE_STREAM") != nullptr;
   const bool dbg_sync = knob("RVN_NW_DEBUG") && std::atoi(knob("RVN_NW_DEBUG")) >= 2;
@@ -551,12 +555,18 @@ void nw_breakpoints(Engine& e, const ReadsDev& T, const ReadsDev& Rd, std::vecto
           RVN_KLAUNCH_ON(kKNwTraceback, wst, (nw_trace_group_kernel<kNwGroupLanes><<<(n_w + NG - 1) / NG, 64, 0, wst>>>(
                                                  dev.jobs, idx_w, n_w, T.packed.as<u64>(), Rd.packed.as<u64>(), hs, ck, dev.res,
                                                  dev.status, w, d_recs)));
+        } else if (trace_lds && (group_walk == 3 || (group_walk != 1 && n_w > 64u * 4u * 256u))) {
+          // more waves than four per CU hold: strips of sixteen kept columns, nine waves per CU (C4: the walk of the last
+          // chunk's 140 000 shortest alignments, alone on the GPU, 18 -> 13 ms; align_ms 185 -> 174)
+          RVN_KLAUNCH_ON(kKNwTraceback, wst, (nw_trace_kernel<true, kNwLaneStripCols><<<(n_w + 63) / 64, 64, 0, wst>>>(
+                                                 dev.jobs, idx_w, n_w, T.packed.as<u64>(), Rd.packed.as<u64>(), hs, ck, dev.res,
+                                                 dev.status, w, d_recs, nullptr)));
         } else if (trace_lds) {
-          RVN_KLAUNCH_ON(kKNwTraceback, wst, (nw_trace_kernel<true><<<(n_w + 63) / 64, 64, 0, wst>>>(
+          RVN_KLAUNCH_ON(kKNwTraceback, wst, (nw_trace_kernel<true, kNwCkSteps><<<(n_w + 63) / 64, 64, 0, wst>>>(
                                                  dev.jobs, idx_w, n_w, T.packed.as<u64>(), Rd.packed.as<u64>(), hs, ck, dev.res,
                                                  dev.status, w, d_recs, nullptr)));
         } else {
-          RVN_KLAUNCH_ON(kKNwTraceback, wst, (nw_trace_kernel<false><<<(n_w + 63) / 64, 64, 0, wst>>>(
+          RVN_KLAUNCH_ON(kKNwTraceback, wst, (nw_trace_kernel<false, kNwCkSteps><<<(n_w + 63) / 64, 64, 0, wst>>>(
                                                  dev.jobs, idx_w, n_w, T.packed.as<u64>(), Rd.packed.as<u64>(), hs, ck, dev.res,
                                                  dev.status, w, d_recs,
                                                  d_strip + static_cast<size_t>(b) * ((e.nw_strip.cap / 32) & ~size_t(63)))));
@@ -959,6 +969,11 @@ static int emulate_job(NwJob J, u32 G, const u64* t_words, const u64* r_words, u
   if (walk_gl == 16) return nw_trace_group_host<16>(J, g, t_words, r_words, hs.data(), ck.data(), res, w, recs, band ? g_group_batches : nullptr);
   if (walk_gl == 64) return nw_trace_group_host<64>(J, g, t_words, r_words, hs.data(), ck.data(), res, w, recs, band ? g_group_batches : nullptr);
   if (walk_gl == 4) return nw_trace_group_host<4>(J, g, t_words, r_words, hs.data(), ck.data(), res, w, recs, band ? g_group_batches : nullptr);
+  if (walk_gl == 1) {  // the lane walk as nw_trace_kernel<true> runs it: strips of sixteen kept columns
+    u64 pv16[kNwLaneStripCols + 1], mv16[kNwLaneStripCols + 1];
+    const NwStripMem<1> mem16{pv16, mv16, 0};
+    return nw_trace_job<1, kNwLaneStripCols>(J, g, t_words, r_words, hs.data(), ck.data(), mem16, res, w, recs);
+  }
   if (walk_gl != 0) return -2;
   u64 pv[kNwStripCols], mv[kNwStripCols];
   const NwStripMem<1> mem{pv, mv, 0};

@@ -90,7 +90,11 @@ __host__ __device__ inline u64 nw_hs_bits(const u32* __restrict__ hs, const NwGe
 }
 
 // The whole walk of one alignment.  hs / ck: the job's regions.  Returns 0 (records written) or 1 (inconsistent).
-template <int LANES>
+// SC = columns of a strip that are KEPT (32: the whole checkpoint interval; 16: only the last sixteen columns up to the walker's
+// — a walker that leaves them to the left comes back for the rest of the interval, which is then at most sixteen columns —:
+// half the strip memory, i.e. twice the resident walkers per CU where the strips live in LDS, for 1.5x the Myers steps, which
+// are not what a wave of 64 diverged walkers is waiting for).
+template <int LANES, int SC = kNwCkSteps>
 __host__ __device__ inline int nw_trace_job(const NwJob& J, const NwGeo& g, const u64* __restrict__ t_words_all,
                                             const u64* __restrict__ r_words_all, const u32* __restrict__ hs,
                                             const NwPm* __restrict__ ck, const NwStripMem<LANES>& mem, u32 distance, u32 w,
@@ -141,21 +145,28 @@ __host__ __device__ inline int nw_trace_job(const NwJob& J, const NwGeo& g, cons
     const BlockPlanes pl = nw_load_planes(tw, J.t_begin, static_cast<u32>(g.n), static_cast<u32>(b));
     u64 text = static_cast<u64>(nw_text16(rw, b_first, rc, j0 + 1));
     if (len > 16) text |= static_cast<u64>(nw_text16(rw, b_first, rc, j0 + 17)) << 32;
-    mem.pv[mem.at(0)] = pv;
-    mem.mv[mem.at(0)] = mv;
-    for (int c = 1; c <= len; ++c) {
+    const int skip = len > SC ? len - SC : 0;  // columns recomputed on the way, not kept
+    int c = 1;
+    for (; c <= skip; ++c) {
       const unsigned sym = static_cast<unsigned>(text >> (2 * (c - 1))) & 3u;
       (void)myers_block2(pv, mv, planes_eq(pl, sym), static_cast<int>(hinw >> (2 * (c - 1))) & 3);
-      mem.pv[mem.at(c)] = pv;
-      mem.mv[mem.at(c)] = mv;
     }
-    wk.cells.j0 = j0;
-    wk.cells.hinw = hinw;
+    mem.pv[mem.at(0)] = pv;
+    mem.mv[mem.at(0)] = mv;
+    for (; c <= len; ++c) {
+      const unsigned sym = static_cast<unsigned>(text >> (2 * (c - 1))) & 3u;
+      (void)myers_block2(pv, mv, planes_eq(pl, sym), static_cast<int>(hinw >> (2 * (c - 1))) & 3);
+      mem.pv[mem.at(c - skip)] = pv;
+      mem.mv[mem.at(c - skip)] = mv;
+    }
+    const u64 text_s = text >> (2 * skip);
+    wk.cells.j0 = j0 + skip;
+    wk.cells.hinw = hinw >> (2 * skip);
     wk.cells.tlo = pl.lo;
     wk.cells.thi = pl.hi;
-    wk.cells.rlo = static_cast<u32>(compress_even(text));
-    wk.cells.rhi = static_cast<u32>(compress_even(text >> 1));
-    wk.seg_j0 = j0;
+    wk.cells.rlo = static_cast<u32>(compress_even(text_s));
+    wk.cells.rhi = static_cast<u32>(compress_even(text_s >> 1));
+    wk.seg_j0 = j0 + skip;
     wk.row_lo = 64 * b;
     wk.walk(true);
   }

@@ -107,7 +107,7 @@ def test_head_pass_and_early_repeats_give_the_oracle_layers():
         eng.set_option("nw_budget_mb", 0)
     assert np.array_equal(eng.polish_layers(), lay)
     # ... and with every walk (head pass, repeats, the rest) by one lane per alignment / by a group of lanes
-    for mode in (1, 2):
+    for mode in (1, 2, 3):
         eng.set_option("nw_group_walk", mode)
         try:
             eng.polish_round(td, rd)
@@ -121,15 +121,16 @@ def test_head_pass_and_early_repeats_give_the_oracle_layers():
                                                                     (40_000, 12, 5000, (0.06, 0.05, 0.05))])
 def test_walk_by_a_lane_and_by_a_group_of_lanes_give_the_same_layers(genome_len, coverage, read_len, draft_err):
     """The alignment path is walked by one lane per alignment or by a group of sixteen (nwtrace.h: the strips along the
-    predicted path side by side, one walker through them; launches of few alignments take the group by default).  Engine
-    option nw_group_walk forces either: the layer table — every breakpoint of every window — is the same, and the oracle's."""
+    predicted path side by side, one walker through them; launches of few alignments take the group by default), the lane's
+    strip whole or — launches of more waves than the machine holds — sixteen columns at a time.  Engine option nw_group_walk
+    forces any of them: the layer table — every breakpoint of every window — is the same, and the oracle's."""
     truths, drafts, targets, reads, _ = pu2.make_case(genome_len=genome_len, coverage=coverage, read_len=read_len,
                                                       draft_err=draft_err, seed=23)
     eng = hip.Engine(15, 5)
     td, rd = eng.upload(targets), eng.upload(reads)
     lays, cons = [], []
     try:
-        for mode in (1, 2, 0):  # lane, group, by size (the later rounds take their thresholds from the running estimate)
+        for mode in (1, 2, 3, 0):  # lane, group, lane with half-size strips, by size (later rounds: thresholds from the running estimate)
             eng.set_option("nw_group_walk", mode)
             c, _, st = eng.polish_round(td, rd)
             assert st["n_aligned"] == st["n_reads_used"] > 0

@@ -257,12 +257,13 @@ def test_window_records_and_grid_samples_equal_an_independent_traceback(w):
                         assert int(r["grid"][g]) == 0xFFFF
 
 
-@pytest.mark.parametrize("gl", [4, 16, 64])
+@pytest.mark.parametrize("gl", [1, 4, 16, 64])
 def test_group_walk_equals_the_lane_walk(gl):
     """nwtrace.h's walk by a group of lanes per alignment (the strips along the predicted path recomputed side by side, one
     walker stepping through them), its phases stepped lane by lane: the records of the one-lane walk byte for byte and the
     oracle's breakpoints — where the prediction holds (few batches) and where it cannot (bursts, unrelated sequences,
-    one-sided bands, degenerate spans), on every ring layout of the sweep."""
+    one-sided bands, degenerate spans), on every ring layout of the sweep.  gl = 1: the one-lane walk with strips of sixteen
+    kept columns (what the kernel runs where the strips live in LDS) against the one with whole strips."""
     rng = np.random.default_rng(600 + gl)
     for trial in range(4):  # ONT-like, both strands, embedded at unaligned offsets
         n = int(rng.integers(900, 3200))
@@ -274,7 +275,7 @@ def test_group_walk_equals_the_lane_walk(gl):
         dist, band = _check(target, _oriented(read_o, rc), tl, len(t), ql, len(q), rc, 500, group_lanes=gl)
         # the prediction serves: a batch walks through several strips (a strip is at most 32 columns and 64 rows)
         strips_at_least = len(q) // 32
-        assert band[3] <= max(2, strips_at_least // min(gl // 2, 4)), (band, len(q))
+        assert gl == 1 or band[3] <= max(2, strips_at_least // min(gl // 2, 4)), (band, len(q))
     t, q = _noisy_pair(rng, 3000, 0.002, 0.002, 0.002)  # HiFi-like, the narrowest ring
     _check(t, q, 0, len(t), 0, len(q), 0, 500, k=16, force_r=-4, group_lanes=gl)
     t, q = _noisy_pair(rng, 2200, 0.04, 0.03, 0.03)
