@@ -43,7 +43,7 @@ constexpr int kNwGroupLanes = 16;           // lanes per alignment of the group 
 constexpr u32 kNwGroupWalkMaxJobs = 8192;  // a walk launch of at most this many alignments takes the group walk (two rounds of the
                                            // machine's 4 096 resident groups: beyond that a group's ~3x shorter latency per column loses
                                            // to the lane walk's sixteen times as many alignments in flight — tools/walk_ab.sh)
-constexpr u32 kSideSweepMaxWaves = 1024;    // a sweep launch of at most this many waves goes beside the main stream's (enqueue)
+constexpr u32 kSideSweepMaxWaves = 2048;    // a sweep launch of at most this many waves goes beside the main stream's (enqueue)
 constexpr u32 kLevels = 8;
 const u32 kRs[kLevels] = {1, 1, 1, 1, 1, 2, 4, 8};
 const u32 kGs[kLevels] = {4, 8, 16, 32, 64, 64, 64, 64};
