@@ -66,6 +66,9 @@ struct Index {
   DevBuf u_val;    // V[u]
   DevBuf u_start;  // u32[u + 1]
   DevBuf table;    // u32[2^table_bits + 1]
+  DevBuf direct;   // u64[4^k]: (count << 32) | first entry of value v's run, 0 = v is not in the index — a probe is ONE
+                   // cache line instead of table -> search in u_val -> u_start (built for 2k <= 30 bits and large indexes only)
+  bool direct_built = false;
   u32 occurrence = 0xFFFFFFFFu;
   bool table_built = false;      // u_val / table are built lazily (only the probe path needs them)
   bool has_query_flags = false;  // origins carry kQueryFlag

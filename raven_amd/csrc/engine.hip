@@ -339,7 +339,7 @@ void engine_release_scratch(Engine& e) {
   e.query_ready = false;
   DevBuf* bufs[] = {
       &e.index.s_val[0], &e.index.s_val[1], &e.index.s_org[0], &e.index.s_org[1], &e.index.u_val, &e.index.u_start,
-      &e.index.table, &e.index_sketch.val, &e.index_sketch.org, &e.index_sketch.read_off, &e.query_sketch.val,
+      &e.index.table, &e.index.direct, &e.index_sketch.val, &e.index_sketch.org, &e.index_sketch.read_off, &e.query_sketch.val,
       &e.query_sketch.org, &e.query_sketch.read_off, &e.raw_sketch.val, &e.raw_sketch.org, &e.raw_sketch.read_off,
       &e.map_out.ovl, &e.map_out.ovl_read_off, &e.map_out.filtered, &e.map_out.anchors, &e.map_out.anchor_off,
       &e.map_out.anchor_cnt, &e.tmp_a, &e.tmp_b, &e.tmp_c, &e.tmp_d, &e.tmp_e, &e.tmp_f, &e.scan_tmp, &e.sort_tmp,
@@ -361,6 +361,7 @@ void engine_release_scratch(Engine& e) {
   e.foreign_org.release();
   e.index.m = e.index.u = 0;
   e.index.table_built = false;
+  e.index.direct_built = false;
   e.map_out.n_query = e.map_out.n_matches = e.map_out.n_intervals = e.map_out.n_overlaps = 0;
   e.map_out.first = e.map_out.last = 0;
   e.map_out.has_anchors = false;

@@ -73,6 +73,16 @@ __global__ __launch_bounds__(256) void table_tail_kernel(const V* __restrict__ u
     table[b] = u;
 }
 
+// direct-address form of the index: direct[v] = (run length << 32) | first entry of v's run in the sorted origins
+template <typename V>
+__global__ __launch_bounds__(256) void direct_fill_kernel(const V* __restrict__ u_val, const u32* __restrict__ u_start, u32 u,
+                                                         u64* __restrict__ direct) {
+  const u32 j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= u) return;
+  const u32 a = u_start[j], b = u_start[j + 1];
+  direct[static_cast<u64>(u_val[j])] = (static_cast<u64>(b - a) << 32) | a;
+}
+
 __global__ void table_empty_kernel(u32* table, u32 B) {
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i <= B) table[i] = 0;
@@ -158,6 +168,8 @@ void index_runs_impl(Engine& e) {
   t.stop();
 }
 
+constexpr u32 kDirectMinKeys = 8u << 20;  // distinct values from which the direct-address table is built
+
 template <typename V>
 void index_table_impl(Engine& e) {
   hipStream_t s = e.stream;
@@ -177,6 +189,19 @@ void index_table_impl(Engine& e) {
   RVN_KLAUNCH(kKTable, table_kernel<V><<<div_up(u, 256), 256, 0, s>>>(u_val, u, ix.shift, table);
               table_tail_kernel<V><<<256, 256, 0, s>>>(u_val, u, ix.shift, B, table));
   ix.table_built = true;
+  // A probe through the bucket table touches four to six cache lines (table, a few entries of u_val, u_start, the origins);
+  // with every possible value addressed directly it is the entry and the origins.  4^k entries of 8 bytes = 8 GB at k = 15:
+  // worth its memset and fill (~6 ms at 100 Mb x 30) where a pass probes hundreds of millions of times, i.e. for large indexes
+  // only (a third to a half of all 15-mers occur among 3 Gbases of reads with 10 % errors: the fill's stores, in ascending
+  // address order, are nearly a stream).
+  ix.direct_built = false;
+  if (sizeof(V) == 4 && 2 * e.k <= 30 && u >= kDirectMinKeys && !knob("RVN_NO_DIRECT_INDEX")) {
+    const size_t n_dir = static_cast<size_t>(1) << (2 * e.k);
+    u64* direct = ix.direct.get<u64>(n_dir);
+    RVN_HIP(hipMemsetAsync(direct, 0, n_dir * 8, s));
+    RVN_KLAUNCH(kKTable, direct_fill_kernel<V><<<div_up(u, 256), 256, 0, s>>>(u_val, ix.u_start.as<u32>(), u, direct));
+    ix.direct_built = true;
+  }
   t.stop();
 }
 
@@ -205,6 +230,7 @@ void index_build_impl(Engine& e, Sketch& sk, bool build_table) {
     ix.u_start.reserve(16);
     RVN_HIP(hipMemsetAsync(ix.u_start.ptr, 0, 8, s));
     ix.table_built = true;
+    ix.direct_built = false;
     return;
   }
   V* v0 = ix.s_val[0].as<V>();
@@ -222,6 +248,7 @@ void index_build_impl(Engine& e, Sketch& sk, bool build_table) {
     t.stop();
   }
   ix.table_built = false;
+  ix.direct_built = false;
   index_runs_impl<V>(e);
   if (build_table) index_table_impl<V>(e);
 }

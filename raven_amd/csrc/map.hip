@@ -47,14 +47,23 @@ __global__ void match_count_kernel(const V* __restrict__ q_val, const u64* __res
                                    const u32* __restrict__ table, int shift, u32 n_keys,
                                    const u64* __restrict__ s_org, u32 occurrence, int avoid_equal,
                                    int avoid_symmetric, u32* __restrict__ q_start, u32* __restrict__ q_n,
-                                   u32* __restrict__ q_cnt, u8* __restrict__ filtered) {
+                                   u32* __restrict__ q_cnt, u8* __restrict__ filtered, const u64* __restrict__ direct) {
   u64 q = static_cast<u64>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (q >= nq) return;
   const V v = q_val[q];
   const u32 qid = origin_id(q_org[q]);
   u32 start = 0, count = 0, cnt = 0;
   u8 filt = 0;
-  if (n_keys && index_find<V>(u_val, u_start, table, shift, v, &start, &count)) {
+  bool found;
+  if (direct) {  // (index.hip: every value addressed directly — the same start / count the search below finds)
+    const u64 ent = direct[static_cast<u64>(v)];
+    count = static_cast<u32>(ent >> 32);
+    found = count != 0;
+    start = found ? static_cast<u32>(ent) : 0u;
+  } else {
+    found = n_keys && index_find<V>(u_val, u_start, table, shift, v, &start, &count);
+  }
+  if (found) {
     if (count > occurrence) {
       filt = 1;
       count = 0;
@@ -1323,7 +1332,7 @@ void map_batch_impl(Engine& e, const ReadsDev& r, u32 first, u32 last, bool avoi
     RVN_KLAUNCH(kKMatchCount, match_count_kernel<V><<<div_up(nq, 256), 256, 0, s>>>(
         qs.val.as<V>(), qs.org.as<u64>(), nq, ix.u_val.as<V>(), ix.u_start.as<u32>(), ix.table.as<u32>(), ix.shift,
         static_cast<u32>(ix.u), ix.s_org[ix.cur].as<u64>(), ix.occurrence, avoid_equal, avoid_symmetric, q_start, q_n,
-        q_cnt, filt));
+        q_cnt, filt, ix.direct_built ? ix.direct.as<u64>() : nullptr));
     exclusive_scan_u32_u64(q_cnt, m_off, nq, e.scan_tmp, s);
     H = read_back(e, m_off + nq, 8);
     out.n_matches = H;
