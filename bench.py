@@ -515,6 +515,7 @@ def main():
         counters = {k: v // steps for k, v in counters_raw.items()}
         val_bytes = 4 if 2 * eng.k < 32 else 8
         kernels, roofline, roofline_hbm, roofline_poa, roofline_nw = {}, None, None, None, None
+        roofline_hbm_all = []  # the four HBM-bound kernels with the largest shares (match_count among them)
         if kms:
             tot = sum(v[0] for v in kms.values())
             for name, (ms, la) in sorted(kms.items(), key=lambda x: -x[1][0]):
@@ -616,7 +617,7 @@ def main():
                     # traffic on the SAME basis as algorithmic_bytes: the PMC file holds bytes per launch
                     per_launch, per_launch_raw = pmc_traffic(name), pmc_traffic_raw(name)
                     scale = launches if basis == "step" else 1.0
-                    roofline_hbm = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                    entry = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                                     "traffic": int(per_launch * scale) if per_launch else None,
                                     "traffic_raw": int(per_launch_raw * scale) if per_launch_raw else None,
@@ -626,7 +627,13 @@ def main():
                                     "kernel_ms_share": round(kms[name][0] / tot, 3) if tot else None,
                                     "note": "traffic, traffic_raw and algorithmic_bytes are all per %s (the PMC file's bytes "
                                             "per launch x %g launches)" % (basis, scale)}
-                    break
+                    if entry["traffic_raw"]:
+                        entry["traffic_raw_over_algorithmic"] = round(entry["traffic_raw"] / b, 2)
+                    if roofline_hbm is None:
+                        roofline_hbm = entry  # the HBM-bound kernel with the largest share of the step
+                    roofline_hbm_all.append(entry)
+                    if len(roofline_hbm_all) >= 4:
+                        break
             if roofline is None:
                 roofline = roofline_hbm
         ovl_s, pol_s = legs["overlap_s"] / steps, legs["polish_s"] / steps
@@ -684,6 +691,7 @@ def main():
             "roofline": roofline,
             "roofline_traffic_source": traffic_provenance(),
             "roofline_hbm": roofline_hbm,
+            "roofline_hbm_kernels": roofline_hbm_all,
             "roofline_poa": roofline_poa if roofline is not roofline_poa else None,
             "roofline_nw": roofline_nw if roofline is not roofline_nw else None,
             "kernels": dict(list(kernels.items())[:16]),
