@@ -1,11 +1,11 @@
 #!/bin/bash
 # kernel timeline of the alignment stage (start / end per dispatch, both streams) -> gpurun_out/<tag>_nw_timeline.csv
 R=${GRAFT_REPO_ROOT:-/root/repo}
-TAG=${1:-r05}
+TAG=${1:-r05}; W=${2:-c4}
 cd /tmp && export TMPDIR=/tmp
 export RVN_POLISH_SKIP_POA=1
 export RVN_LIB_PATH=$R/raven_amd/lib/libraven_hip_test.so  # (the switch above exists in the debug build only)
-rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/${TAG}_nw_tl -o t -- python $R/bench.py --no-cpu-baseline --no-kernel-timing --load-bases 0 --steps 1 --warmup 1 > /dev/null 2> $R/gpurun_out/${TAG}_nw_tl.err
+rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/${TAG}_nw_tl -o t -- python $R/bench.py --workload $W --no-cpu-baseline --no-kernel-timing --load-bases 0 --steps 1 --warmup 1 > /dev/null 2> $R/gpurun_out/${TAG}_nw_tl.err
 F=$(find $R/gpurun_out/${TAG}_nw_tl -name '*kernel_trace.csv' | head -1)
 python - "$F" $R/gpurun_out/${TAG}_nw_timeline.csv <<'PY'
 import csv, sys
