@@ -443,6 +443,8 @@ int rvn_overlap_update_and_type(rvn_overlap* overlaps, uint64_t n, const uint32_
  *   nw_group_walk      alignment-path stage: which walk a launch takes — 1 a lane per alignment, 2 a group of sixteen lanes per
  *                      alignment, 3 a lane per alignment with half-size strips, otherwise (default) the group for launches of at
  *                      most 8 192 alignments and the half-size strips beyond 65 536; same records either way
+ *   index_direct_min_keys  index: distinct values from which all 4^k possible values are addressed directly (an 8-GB table at
+ *                      k = 15, one cache line per probe; default 8 388 608; 1 = every index with k <= 15); same matches either way
  *   poa_rows_min_windows  window-consensus stage: smallest batch that starts with the rows-on-lanes kernel (default 8 192;
  *                      0 means every batch, -1 the default)
  *   io_threads, io_slab_mb, io_ring, io_zlib   rvn_reads_load: inflate threads, page-locked slab size, slabs in flight,

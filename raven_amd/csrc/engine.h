@@ -108,6 +108,8 @@ struct EngineOptions {
   long long nw_group_walk = 0;       // alignment-path stage: 1 = every walk one lane per alignment, 2 = every walk a group of lanes per
                                      // alignment (nwtrace.h), 3 = one lane per alignment with strips of sixteen kept columns, otherwise
                                      // by the number of alignments in the launch.  Same records either way
+  long long index_direct_min_keys = 0;  // index: distinct values from which every possible value is addressed directly (index.hip; default 8 M,
+                                     // 1 = every index with 2k <= 30 bits — the tests of that path on small inputs).  Same matches either way
   long long poa_rows_min_windows = -1;  // window-consensus stage: smallest batch that starts with the rows-on-lanes kernel (poa4.hip);
                                         // a smaller one starts with the 64-column kernel (poa2.hip).  < 0: the default, kPoaRowsMinWindowsDefault = 8 192
   long long io_threads = 0;          // rvn_reads_load: inflate threads (default min(32, cores - 2))

@@ -313,13 +313,14 @@ void stop() {
 }  // namespace devpool
 
 const char* engine_option_names() {
-  return "nw_budget_mb, nw_group_walk, poa_rows_min_windows, io_threads, io_slab_mb, io_ring, io_zlib, arena_mb, arena_margin_mb, "
+  return "nw_budget_mb, nw_group_walk, index_direct_min_keys, poa_rows_min_windows, io_threads, io_slab_mb, io_ring, io_zlib, arena_mb, arena_margin_mb, "
          "no_arena, release_always, polish_join, polish_sketch_cache_mb";
 }
 long long* engine_option(EngineOptions& o, const char* name) {
   const std::string n(name ? name : "");
   if (n == "nw_budget_mb") return &o.nw_budget_mb;
   if (n == "nw_group_walk") return &o.nw_group_walk;
+  if (n == "index_direct_min_keys") return &o.index_direct_min_keys;
   if (n == "poa_rows_min_windows") return &o.poa_rows_min_windows;
   if (n == "io_threads") return &o.io_threads;
   if (n == "io_slab_mb") return &o.io_slab_mb;

@@ -195,7 +195,8 @@ void index_table_impl(Engine& e) {
   // only (a third to a half of all 15-mers occur among 3 Gbases of reads with 10 % errors: the fill's stores, in ascending
   // address order, are nearly a stream).
   ix.direct_built = false;
-  if (sizeof(V) == 4 && 2 * e.k <= 30 && u >= kDirectMinKeys && !knob("RVN_NO_DIRECT_INDEX")) {
+  const u64 direct_min = e.opt.index_direct_min_keys > 0 ? static_cast<u64>(e.opt.index_direct_min_keys) : kDirectMinKeys;
+  if (sizeof(V) == 4 && 2 * e.k <= 30 && u >= direct_min && !knob("RVN_NO_DIRECT_INDEX")) {
     const size_t n_dir = static_cast<size_t>(1) << (2 * e.k);
     u64* direct = ix.direct.get<u64>(n_dir);
     RVN_HIP(hipMemsetAsync(direct, 0, n_dir * 8, s));

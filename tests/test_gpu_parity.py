@@ -103,6 +103,34 @@ def test_pass1_lambda(gpu, lambda_reads, kw):
     assert errs == []
 
 
+def test_pass1_and_map_with_every_value_addressed_directly(gpu, synth_small, lambda_reads):
+    """Large indexes address all 4^k possible values directly (index.hip: one cache line per probe instead of bucket table ->
+    search -> run table); engine option index_direct_min_keys = 1 takes that path on small inputs: per-read Map output and the
+    whole pass — several index batches and query flushes, so the probe path runs, not the self-join — equal the oracle's."""
+    _, rs, _ = synth_small
+    for reads, kw in ((rs, dict(index_batch_bases=rs.total_bases // 2, flush_bases=rs.total_bases // 5 + 1)),
+                      (rs, dict(flush_bases=rs.total_bases // 3 + 1, use_minhash=True)),
+                      (lambda_reads, dict(flush_bases=lambda_reads.total_bases // 4 + 1, kmax=8))):
+        he, oe = _mk()
+        he.set_option("index_direct_min_keys", 1)
+        rd = he.upload(reads)
+        errs, ref = pu.compare_pass1(he, oe, rd, reads, **kw)
+        assert errs == [], kw
+        assert ref["counters"]["matches"] > 0
+    he, oe = _mk()
+    he.set_option("index_direct_min_keys", 1)
+    rd = he.upload(rs)
+    he.minimize(rd, 100, 300, False)  # (index over a sub-range of the reads, queries over another, a filter that bites)
+    oe.minimize(rs, 100, 300, False)
+    he.filter(0.05)
+    oe.filter(0.05)
+    assert he.occurrence == oe.occurrence
+    errs, n_ovl = pu.compare_map(he, oe, rd, rs, 0, 160, False, want_filtered=True)
+    assert errs == [] and n_ovl > 0
+    errs, _ = pu.compare_map(he, oe, rd, rs, 120, 260, True, avoid_equal=False, avoid_symmetric=False)
+    assert errs == []
+
+
 def test_pass1_multibatch(gpu, synth_small):
     """several index batches x several query flushes (construct.cc:32-37, :66-70 with small constants)"""
     _, rs, _ = synth_small
