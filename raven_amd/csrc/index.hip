@@ -198,10 +198,17 @@ void index_table_impl(Engine& e) {
   const u64 direct_min = e.opt.index_direct_min_keys > 0 ? static_cast<u64>(e.opt.index_direct_min_keys) : kDirectMinKeys;
   if (sizeof(V) == 4 && 2 * e.k <= 30 && u >= direct_min && !knob("RVN_NO_DIRECT_INDEX")) {
     const size_t n_dir = static_cast<size_t>(1) << (2 * e.k);
-    u64* direct = ix.direct.get<u64>(n_dir);
-    RVN_HIP(hipMemsetAsync(direct, 0, n_dir * 8, s));
-    RVN_KLAUNCH(kKTable, direct_fill_kernel<V><<<div_up(u, 256), 256, 0, s>>>(u_val, ix.u_start.as<u32>(), u, direct));
-    ix.direct_built = true;
+    u64* direct = nullptr;
+    try {
+      direct = ix.direct.get<u64>(n_dir);
+    } catch (const DeviceOutOfMemory&) {  // (no room for it: the bucket table alone serves every probe, only slower)
+      direct = nullptr;
+    }
+    if (direct) {
+      RVN_HIP(hipMemsetAsync(direct, 0, n_dir * 8, s));
+      RVN_KLAUNCH(kKTable, direct_fill_kernel<V><<<div_up(u, 256), 256, 0, s>>>(u_val, ix.u_start.as<u32>(), u, direct));
+      ix.direct_built = true;
+    }
   }
   t.stop();
 }
